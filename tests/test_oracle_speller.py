@@ -1,0 +1,175 @@
+"""Known-answer and cross-implementation checks of the oracle's speller, losses, metric, optimiser."""
+import math
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from oracle import las_oracle as O
+
+DT = torch.float64
+
+
+def _hp(att='luong', dec_layers=1, bottom_only=True, pass_hidden=True, V=11, H=8, L=2, F_=5, als=None,
+        emb=0):
+    return O.HP(encoder=O.EncoderHP(num_layers=L, num_units=H), num_channels=F_,
+                decoder=O.DecoderHP(num_layers=dec_layers, num_units=H, target_vocab_size=V,
+                                    attention_type=att, bottom_only=bottom_only,
+                                    pass_hidden_state=pass_hidden, attention_layer_size=als,
+                                    embedding_size=emb))
+
+
+def _batch(B=3, T=12, F_=5, V=11, U=6, seed=0):
+    b = O.synthetic_batch(B, T, F_, V, U, ragged=False, seed=seed)
+    b['source_sequence_length'] = torch.tensor([T, T - 5, T - 2][:B])
+    b['target_sequence_length'] = torch.tensor([U, U - 2, U - 1][:B])
+    return b
+
+
+def test_zero_keys_give_uniform_attention_and_ln_v_loss():
+    hp = _hp()
+    p = O.init_params(hp)
+    p['speller/memory_layer/kernel'].zero_()
+    p['speller/projection_layer/kernel'].zero_()
+    b = _batch()
+    (mem, ml), st = O.listener(b['encoder_inputs'], b['source_sequence_length'], p, hp.encoder)
+    logits, sp = O.speller_train(hp, p, mem, ml, st, b['targets_inputs'], b['target_sequence_length'])
+    for bi in range(3):
+        n = int(ml[bi])
+        a = sp.align_hist[0][bi]
+        assert torch.allclose(a[:n], torch.full((n,), 1.0 / n, dtype=DT))
+        assert float(a[n:].abs().sum()) == 0.0
+        # wrapper output = context (attention_layer_size None): mean of valid frames
+        assert torch.allclose(sp.attention[bi], mem[bi, :n].mean(0), atol=1e-12)
+    loss = O.compute_loss_train(logits, b['targets_outputs'], b['target_sequence_length'])
+    assert abs(float(loss) - math.log(11)) < 1e-12
+
+
+def test_sequence_loss_matches_torch_cross_entropy():
+    torch.manual_seed(0)
+    B, U, V = 4, 7, 9
+    logits = torch.randn(B, U, V, dtype=DT)
+    tg = torch.randint(0, V, (B, U))
+    ln = torch.tensor([7, 3, 1, 5])
+    ours = O.compute_loss_train(logits, tg, ln)
+    w = (torch.arange(U)[None] < ln[:, None])
+    ref = F.cross_entropy(logits[w], tg[w], reduction='sum') / w.sum()
+    assert abs(float(ours - ref)) < 1e-12
+
+
+def test_pass_hidden_state_uses_encoder_fw_then_bw():
+    hp = _hp(dec_layers=2)
+    p = O.init_params(hp)
+    b = _batch()
+    (mem, ml), st = O.listener(b['encoder_inputs'], b['source_sequence_length'], p, hp.encoder)
+    sp = O.Speller(hp, p, mem, ml, st)
+    assert torch.equal(sp.cells[0][0], st[0][0]) and torch.equal(sp.cells[1][1], st[1][1])
+    hp2 = _hp(dec_layers=2, bottom_only=False)
+    sp2 = O.Speller(hp2, O.init_params(hp2), mem, ml, st)
+    assert float(sp2.cells[0][0].abs().max()) == 0.0      # silently ignored (las/model.py:260)
+
+
+def test_all_attention_types_run_and_normalise():
+    for att in ('luong', 'bahdanau', 'luong_monotonic', 'bahdanau_monotonic', 'custom'):
+        hp = _hp(att=att, als=6)
+        p = O.init_params(hp)
+        b = _batch()
+        (mem, ml), st = O.listener(b['encoder_inputs'], b['source_sequence_length'], p, hp.encoder)
+        logits, sp = O.speller_train(hp, p, mem, ml, st, b['targets_inputs'], b['target_sequence_length'])
+        assert logits.shape == (3, 6, 11)
+        a = sp.align_hist[-1]
+        for bi in range(3):
+            assert float(a[bi, int(ml[bi]):].abs().sum()) == 0.0
+        if 'monotonic' not in att:
+            assert torch.allclose(a.sum(-1), torch.ones(3, dtype=DT))
+        else:
+            assert bool((a.sum(-1) <= 1 + 1e-9).all())
+
+
+def test_monotonic_parallel_known_answer():
+    # p = 1 everywhere and previous attention one-hot at 0 => stays at 0
+    p = torch.ones(1, 4, dtype=DT)
+    prev = torch.tensor([[1.0, 0, 0, 0]], dtype=DT)
+    a = O.monotonic_attention(p, prev, 'parallel')
+    assert torch.allclose(a, prev)
+    # p = [0, 1, ...]: moves to position 1
+    a = O.monotonic_attention(torch.tensor([[0.0, 1, 1, 1]], dtype=DT), prev, 'parallel')
+    assert torch.allclose(a, torch.tensor([[0.0, 1, 0, 0]], dtype=DT), atol=1e-9)
+    a = O.monotonic_attention(torch.tensor([[0.0, 1, 1, 1]], dtype=DT), prev, 'hard')
+    assert torch.allclose(a, torch.tensor([[0.0, 1, 0, 0]], dtype=DT))
+
+
+def test_greedy_stops_and_lengths():
+    hp = _hp()
+    p = O.init_params(hp)
+    # force EOS at the first step
+    p['speller/projection_layer/bias'][O.EOS_ID] = 50.0
+    b = _batch()
+    (mem, ml), st = O.listener(b['encoder_inputs'], b['source_sequence_length'], p, hp.encoder)
+    logits, ids, fl, _ = O.speller_greedy(hp, p, mem, ml, st)
+    assert logits.shape[1] == 1 and fl.tolist() == [1, 1, 1] and ids[:, 0].tolist() == [2, 2, 2]
+    # never EOS: runs to round(max(len'))
+    p['speller/projection_layer/bias'][O.EOS_ID] = -50.0
+    logits, ids, fl, _ = O.speller_greedy(hp, p, mem, ml, st)
+    assert logits.shape[1] == int(ml.max()) and fl.tolist() == [int(ml.max())] * 3
+
+
+def test_eval_loss_pads_shorter_side():
+    B, V = 2, 5
+    logits = torch.zeros(B, 3, V, dtype=DT)
+    tg = torch.tensor([[3, 4, 2, 2, 2], [3, 2, 2, 2, 2]])
+    l = O.compute_loss_eval(logits, tg, torch.tensor([3, 1]), torch.tensor([5, 2]))
+    assert abs(float(l) - math.log(V)) < 1e-12        # all-zero logits => ln V on every weighted step
+
+
+def test_ctc_matches_torch():
+    torch.manual_seed(3)
+    B, T, C = 3, 9, 6
+    logits = torch.randn(B, T, C, dtype=DT)
+    labels = torch.tensor([[1, 2, 2, 3], [4, 5, 0, 0], [3, 0, 0, 0]])
+    ll = torch.tensor([4, 2, 1])
+    tl = torch.tensor([9, 7, 4])
+    ours = O.ctc_loss_dense(logits, labels, ll, tl, blank=0)
+    ref = F.ctc_loss(torch.log_softmax(logits, -1).transpose(0, 1), labels, tl, ll, blank=0,
+                     reduction='none')
+    assert torch.allclose(ours, ref, atol=1e-9)
+    assert O.ctc_greedy_decode(torch.eye(4, dtype=DT)[[0, 0, 3, 1, 1, 3, 1]][None], torch.tensor([7])) == [[0, 1, 1]]
+
+
+def test_edit_distance_merge_and_trim():
+    # utils/metrics_utils.py:10-23: repeats merged in hyp AND truth, cut at first EOS, -1 dropped
+    assert O.dense_to_sparse_merge([5, 5, 6, 2, 7], 2) == [5, 6]
+    assert O.dense_to_sparse_merge([5, -1, 6, 6], 2) == [5, 6]
+    d = O.edit_distance([[5, 5, 6, 2, 2]], [[5, 7, 6, 2, 2]])
+    assert abs(d[0] - 1.0 / 3.0) < 1e-12
+    assert O.edit_distance([[2, 2]], [[2, 2]]) == [0.0]
+
+
+def test_adam_tf_form_and_per_tensor_clip():
+    p = {'a': torch.tensor([1.0, -2.0], dtype=DT)}
+    m = {'a': torch.zeros(2, dtype=DT)}
+    v = {'a': torch.zeros(2, dtype=DT)}
+    g = {'a': torch.tensor([0.5, -0.25], dtype=DT)}
+    np_, nm, nv = O.adam_apply(p, m, v, g, 1, 1e-3)
+    lr_t = 1e-3 * math.sqrt(1 - 0.999) / (1 - 0.9)
+    exp = p['a'] - lr_t * (0.1 * g['a']) / (torch.sqrt(0.001 * g['a'] ** 2) + 1e-8)
+    assert torch.allclose(np_['a'], exp, atol=1e-15)
+    hp = _hp()
+    params = O.init_params(hp)
+    out = O.train_step(hp, params, None, None, 1, _batch())
+    for k, gc in out['clipped'].items():
+        n = float(out['grads'][k].norm())
+        assert float(gc.norm()) <= 2.0 + 1e-9
+        if n <= 2.0:
+            assert torch.equal(gc, out['grads'][k])
+
+
+def test_param_count_matches_survey_metric_m():
+    # metric-M encoder 4 806 656, decoder 1 705 024
+    hp = O.HP(encoder=O.EncoderHP(num_layers=3, num_units=256), num_channels=40,
+              decoder=O.DecoderHP(num_layers=1, num_units=256, target_vocab_size=64, bottom_only=True,
+                                  pass_hidden_state=True))
+    tab = O.param_table(hp)
+    enc = sum(int(np.prod(s)) for n, s, _ in tab if n.startswith('listener'))
+    dec = sum(int(np.prod(s)) for n, s, _ in tab if n.startswith('speller'))
+    assert enc == 4806656 and dec == 1705024
