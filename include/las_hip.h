@@ -1,0 +1,212 @@
+/*
+ * las_hip.h — C-ABI of liblas_hip.so, the MI355X (gfx950) implementation of the
+ * Listen-Attend-Spell training hot path of sciforce/phones-las.
+ *
+ * The reference has no FFI: the path sits behind Python functions that build a TF-1 graph
+ * (SURVEY.md §8b).  Each entry point below names the reference interface it replaces
+ * (file:line under /root/reference).  The Python host in phones-las_amd/ mirrors those
+ * Python interfaces (las.ops.*, las.model.*, model_helper.las_model_fn) on top of this ABI
+ * through ctypes; INTEGRATION.md shows the binding.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer owned by the caller (torch tensors); nothing is
+ *     allocated or freed inside the library; scratch comes from a caller-provided workspace
+ *     whose size las_workspace_bytes() reports;
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream); calls only enqueue;
+ *   - row-major, batch-major [B,T,C] tensors; weights in TF layout: LSTM kernel [D+H, 4H]
+ *     with gate column order i, j, f, o and bias [4H] (tf.nn.rnn_cell.LSTMCell, forget_bias 1);
+ *   - las_bf16 = raw bfloat16 bits; fp32 master weights / optimiser state / losses;
+ *   - return 0 on success, a negative las_status otherwise; las_last_error() gives the text
+ *     (thread-local).  There is NO CPU fallback: without a HIP device every compute entry
+ *     point fails with LAS_ERR_HIP.
+ */
+#ifndef LAS_HIP_H
+#define LAS_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef uint16_t las_bf16;
+
+enum las_status {
+  LAS_OK = 0,
+  LAS_ERR_ARG = -1,      /* bad shape / alignment / unsupported configuration */
+  LAS_ERR_HIP = -2,      /* a HIP runtime call failed                          */
+  LAS_ERR_WORKSPACE = -3 /* workspace too small                                */
+};
+
+enum las_attention {     /* las/model.py:153-166 --attention_type */
+  LAS_ATT_LUONG = 0,
+  LAS_ATT_BAHDANAU = 1
+};
+
+int las_version(void);
+const char* las_last_error(void);
+
+/* ------------------------------------------------------------------------------------------
+ * Dense products on MFMA (bf16 operands, fp32 accumulate).  These replace the Eigen/cuBLAS
+ * matmuls TF issues for tf.layers.Dense and the LSTM kernels (model_helper.py:349,
+ * las/model.py:168-169,251-257; Appendix A.1 of SURVEY.md).
+ * ---------------------------------------------------------------------------------------- */
+
+/* C[M,N] (=|+=) A[M,K] * B[N,K]^T + bias[N].   A, B bf16 with K contiguous (lda, ldb in
+ * elements, multiples of 8; K multiple of 8).  C is fp32 (out_bf16 = 0) or bf16.
+ * accumulate != 0 adds into C (fp32 only).  batch > 1 runs `batch` independent products with
+ * element strides sa/sb/sc.  split_k > 1 splits K over workgroups with fp32 atomics (C must
+ * then be fp32 and is pre-zeroed by the call unless accumulate). */
+int las_gemm_nt(const las_bf16* A, int64_t lda, const las_bf16* B, int64_t ldb, void* C, int64_t ldc,
+                const float* bias, int M, int N, int K, int out_bf16, int accumulate, int batch,
+                int64_t sa, int64_t sb, int64_t sc, int split_k, void* stream);
+
+/* C[M,N] += sum_k A[k,M] * B[k,N]  (weight gradients X^T dZ; TF autodiff of the matmuls above,
+ * model_helper.py:415).  A [K,M] and B [K,N] bf16 with M resp. N contiguous.  C fp32, always
+ * accumulated with atomics (zero it first).  a_shift/period: row k of A is taken from
+ * k + a_shift when 0 <= (k % period) + a_shift < period and is zero otherwise (the h_{t-1}
+ * operand of dK_h without materialising a shifted copy; period = T).  period = 0 disables. */
+int las_gemm_tn(const las_bf16* A, int64_t lda, const las_bf16* B, int64_t ldb, float* C, int64_t ldc,
+                int M, int N, int K, int a_shift, int period, int batch, int64_t sa, int64_t sb,
+                int64_t sc, int split_k, void* stream);
+
+/* dst_bf16[r, c] = src_f32[r, c] (transpose = 0) or dst[c, r] = src[r, c] (transpose = 1), with the
+ * destination window [dst_rows, dst_cols] (row stride ldd) zero-padded.  `batch` windows at element
+ * strides src_bstride / dst_bstride.  Used to derive the bf16 operand copies of the fp32 master
+ * weights and to cast/pad the (B,T,F) feature batch (utils/dataset_utils.py:254-281 padded_batch). */
+int las_cast_bf16(const float* src, int64_t lds, int rows, int cols, las_bf16* dst, int64_t ldd,
+                  int dst_rows, int dst_cols, int transpose, int batch, int64_t src_bstride,
+                  int64_t dst_bstride, void* stream);
+
+/* out[n] += sum_m X[m, n] for a bf16 [M,N] matrix (bias gradients). */
+int las_colsum_bf16(const las_bf16* X, int64_t ldx, int M, int N, float* out, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Listener: one (Bi)LSTM layer = las/ops.py:23-46 `bilstm` (tf.nn.bidirectional_dynamic_rnn /
+ * dynamic_rnn with sequence_length over LSTMCell of las/ops.py:10-20).
+ * ---------------------------------------------------------------------------------------- */
+
+/* Pack the recurrent half K_h = kernel[D:D+H, :] (fp32, ld 4H) of one direction into the
+ * MFMA-fragment-major bf16 image the forward recurrent kernel streams (size H*4H). */
+int las_lstm_pack_recurrent(const float* kernel_h, int H, las_bf16* packed, void* stream);
+
+/* Forward recurrence.  xproj [B,T,ndir*4H] fp32 holds x_t*K_x + b on entry (las_gemm_nt) and
+ * the activated gates (sigma(i), tanh(j), sigma(f+1), sigma(o)) on exit (saved for backward).
+ * wpacked: ndir images from las_lstm_pack_recurrent.  y [B,T,ndir*H] bf16: outputs, fw in
+ * [0,H) and bw in [H,2H) (the tf.concat of las/ops.py:81), zero for t >= length.  cbuf
+ * [B,T,ndir*H] fp32: cell states (saved).  c_last/h_last [ndir,B,H] fp32: final states
+ * (state carried through t >= length, Appendix A.3).  Direction 1 runs the time-reversed
+ * recurrence of bidirectional_dynamic_rnn (reverse_sequence on the valid prefix). */
+int las_lstm_recurrent_fwd(float* xproj, const las_bf16* wpacked, const int32_t* length, las_bf16* y,
+                           float* cbuf, float* c_last, float* h_last, int B, int T, int H, int ndir,
+                           void* stream);
+
+/* Backward recurrence (reverse-mode AD of the loop above).
+ * gates/cbuf: saved by the forward.  dy [B,T,ndir*H] fp32: gradient w.r.t. y.  dc_last/dh_last
+ * [ndir,B,H] fp32 or NULL.  kh_bf16: ndir natural-layout bf16 copies of K_h [H,4H].
+ * dz [B,T,ndir*4H] bf16 (out): gradient w.r.t. the gate pre-activations, zero for t >= length;
+ * the caller derives dX, dK_x, dK_h, db from it with las_gemm_nt / las_gemm_tn / las_colsum. */
+int las_lstm_recurrent_bwd(const float* gates, const float* cbuf, const float* dy, const float* dc_last,
+                           const float* dh_last, const las_bf16* kh_bf16, const int32_t* length,
+                           las_bf16* dz, int B, int T, int H, int ndir, void* stream);
+
+/* len_out[b] = len[b]/2 + len[b]%2  (las/ops.py:65 pyramidal_stack). */
+int las_pyramid_lengths(const int32_t* len_in, int32_t* len_out, int B, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Speller step kernels: AttentionWrapper(LSTMCell, Luong|Bahdanau) of las/model.py:145-202
+ * driven by BasicDecoder/dynamic_decode (las/model.py:295-296,346-347); SURVEY.md A.5-A.7.
+ * ---------------------------------------------------------------------------------------- */
+
+/* One decoder step for every batch row, after z = [attention_{t-1}, h_{t-1}] * K[E:, :] has been
+ * produced by las_gemm_nt:  adds the input rows K[id] (one-hot / embedding feed) and bias,
+ * applies the LSTM cell, scores h_t against keys (Luong: dot; Bahdanau: v.tanh(keys + W_q h)),
+ * masked softmax over t' < mem_len, context = align * values.  See las_hip.cpp for the buffer
+ * table.  All buffers device pointers. */
+typedef struct las_dec_step {
+  int B, Hd, M, Tm, attention;   /* Tm = padded memory length T' */
+  const float* z;                /* [B,4Hd]  recurrent+attention part of the pre-activations */
+  const float* tok_rows;         /* [E,4Hd] fp32 rows of the cell kernel for the token feed, or NULL */
+  const int32_t* tok_ids;        /* [B] previous token (row into tok_rows) */
+  int64_t tok_stride;            /* elements between consecutive batch entries of tok_ids */
+  const float* bias;             /* [4Hd] */
+  float* c;                      /* [B,Hd] in/out cell state */
+  float* gates_out;              /* [B,4Hd] activated gates (saved) */
+  float* c_out;                  /* [B,Hd]  new c (saved) */
+  las_bf16* h_out;               /* [B,ldh] new h as bf16 (cell output / query), row stride ldh */
+  int64_t ldh;
+  const las_bf16* keys;          /* [B,Tm,Hd] */
+  const las_bf16* values;        /* [B,Tm,M]  (memory, zero beyond mem_len) */
+  const int32_t* mem_len;        /* [B] */
+  const las_bf16* wq;            /* Bahdanau query_layer^T [Hd,Hd] (out,in) bf16 or NULL */
+  const float* att_v;            /* Bahdanau v [Hd] or NULL */
+  float* align_out;              /* [B,Tm] alignments (saved) */
+  float* pq_out;                 /* [B,Hd] processed query (Bahdanau, saved) or NULL */
+  las_bf16* ctx_out;             /* [B,ldc] context as bf16, row stride ldc */
+  int64_t ldc;
+  las_bf16* ctx_out2;            /* optional second copy (next step's cell input), row stride ldc2 */
+  int64_t ldc2;
+} las_dec_step;
+int las_decoder_step_fwd(const las_dec_step* s, void* stream);
+
+/* Backward of one decoder step (Luong/Bahdanau).  Consumes dctx [B,M]
+ * (gradient w.r.t. the context, fp32), dh_rec [B,Hd], dc [B,Hd]; produces dz [B,4Hd] bf16,
+ * ds [B,Tm] (score gradient, bf16) and dc (in place, for step t-1). */
+typedef struct las_dec_step_bwd {
+  int B, Hd, M, Tm, attention;
+  const float* dctx;             /* [B,ldd] fp32 */
+  int64_t ldd;
+  const float* dh_rec;           /* [B,ldr] fp32 gradient into h_t from step t+1 (or zeros) */
+  int64_t ldr;
+  float* dc;                     /* [B,Hd] in: dc_t from step t+1; out: dc_{t-1} */
+  const float* gates;            /* [B,4Hd] saved */
+  const float* c_new;            /* [B,Hd] saved c_t */
+  const float* c_prev;           /* [B,Hd] c_{t-1} */
+  const las_bf16* h;             /* [B,ldh] h_t bf16 */
+  int64_t ldh;
+  const float* align;            /* [B,Tm] saved */
+  const float* pq;               /* [B,Hd] saved processed query (Bahdanau) */
+  const las_bf16* keys;
+  const las_bf16* values;
+  const int32_t* mem_len;
+  const las_bf16* wq_t;          /* Bahdanau query_layer [Hd(in),Hd(out)]^T as needed, or NULL */
+  const float* att_v;
+  las_bf16* dz;                  /* [B,4Hd] out */
+  las_bf16* ds;                  /* [B,Tm] out: Luong d score; Bahdanau unused */
+  las_bf16* dtanh;               /* Bahdanau: [B,Tm,Hd] d(pre-tanh) out (bf16) or NULL */
+  float* dv_acc;                 /* Bahdanau: [Hd] fp32 accumulated d att_v, or NULL */
+  las_bf16* dpq;                 /* Bahdanau: [B,Hd] d processed query out */
+} las_dec_step_bwd;
+int las_decoder_step_bwd(const las_dec_step_bwd* s, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Loss: tf.contrib.seq2seq.sequence_loss as used by compute_loss (model_helper.py:24-30):
+ * loss = sum_{b,t<len_b} CE(logits[b,t], targets[b,t]) / (sum_b len_b + 1e-12).
+ * loss_out[0] += loss contributions (zero it first); dlogits (bf16, [B,U,ldd]) receives
+ * (softmax - onehot) * w / sum(w) * grad_scale, zero for masked steps.
+ * ---------------------------------------------------------------------------------------- */
+int las_seq_ce_loss(const float* logits, int64_t ldl, const int32_t* targets, const int32_t* target_len,
+                    int B, int U, int V, float grad_scale, float* loss_out, las_bf16* dlogits, int64_t ldd,
+                    void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Train op (model_helper.py:403-417): L2 over all variables, per-tensor clip_by_norm(g, 2),
+ * tf.train.AdamOptimizer update.  Parameters, gradients and Adam slots are flat fp32 buffers;
+ * seg_offsets[nseg+1] gives the tensor boundaries (device int64).
+ * ---------------------------------------------------------------------------------------- */
+
+/* grads[i] += l2_scale * params[i]; sumsq[s] = ||grads_s||^2  (sumsq zeroed inside). */
+int las_grad_l2_norms(float* grads, const float* params, const int64_t* seg_offsets, int nseg,
+                      int64_t total, float l2_scale, float* sumsq, void* stream);
+/* grads_s *= clip / max(||grads_s||, clip)  (clip_by_norm, model_helper.py:416). */
+int las_grad_clip(float* grads, const int64_t* seg_offsets, int nseg, int64_t total, const float* sumsq,
+                  float clip, void* stream);
+/* TF-form Adam (epsilon outside the bias correction); step is the 1-based update count. */
+int las_adam_update(float* params, float* m, float* v, const float* grads, int64_t total, float lr,
+                    float beta1, float beta2, float eps, int step, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LAS_HIP_H */

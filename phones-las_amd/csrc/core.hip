@@ -1,0 +1,93 @@
+// Error state, version and the small element-wise / reduction kernels of liblas_hip.
+#include "las_common.h"
+#include <string.h>
+
+static thread_local char g_err[512] = "";
+
+void las_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+int las_check_hip(hipError_t e, const char* what) {
+  if (e == hipSuccess) return LAS_OK;
+  las_set_error("%s: %s", what, hipGetErrorString(e));
+  return LAS_ERR_HIP;
+}
+
+extern "C" int las_version(void) { return 100; }
+extern "C" const char* las_last_error(void) { return g_err; }
+
+namespace {
+
+__global__ void cast_kernel(const float* src, int64_t lds_, int rows, int cols, unsigned short* dst, int64_t ldd,
+                            int dst_rows, int dst_cols, int transpose, int64_t sbs, int64_t dbs) {
+  // one thread per destination element of the [dst_rows, dst_cols] window (row stride ldd)
+  src += (int64_t)blockIdx.y * sbs;
+  dst += (int64_t)blockIdx.y * dbs;
+  const int64_t total = (int64_t)dst_rows * dst_cols;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int dr = (int)(i / dst_cols), dc = (int)(i % dst_cols);
+    const int sr = transpose ? dc : dr;
+    const int sc = transpose ? dr : dc;
+    float v = 0.f;
+    if (sr < rows && sc < cols) v = src[(int64_t)sr * lds_ + sc];
+    dst[(int64_t)dr * ldd + dc] = las_f2bf(v);
+  }
+}
+
+__global__ void colsum_kernel(const unsigned short* X, int64_t ldx, int M, int N, float* out) {
+  // blockDim = (64 columns, 4 row lanes); grid.x over column groups, grid.y over row chunks
+  const int col = blockIdx.x * 64 + threadIdx.x;
+  const int rows_per = (M + gridDim.y - 1) / gridDim.y;
+  const int r0 = blockIdx.y * rows_per;
+  const int r1 = min(M, r0 + rows_per);
+  float s = 0.f;
+  if (col < N)
+    for (int r = r0 + threadIdx.y; r < r1; r += blockDim.y) s += las_bf2f(X[(int64_t)r * ldx + col]);
+  __shared__ float red[4][64];
+  red[threadIdx.y][threadIdx.x] = s;
+  __syncthreads();
+  if (threadIdx.y == 0 && col < N) {
+    atomicAdd(out + col, red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
+  }
+}
+
+__global__ void pyramid_len_kernel(const int32_t* a, int32_t* b, int B) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < B) b[i] = a[i] / 2 + a[i] % 2;
+}
+
+}  // namespace
+
+extern "C" int las_cast_bf16(const float* src, int64_t lds_, int rows, int cols, las_bf16* dst, int64_t ldd,
+                             int dst_rows, int dst_cols, int transpose, int batch, int64_t src_bstride,
+                             int64_t dst_bstride, void* stream) {
+  LAS_REQUIRE(rows >= 0 && cols >= 0 && dst_rows > 0 && dst_cols > 0 && ldd >= dst_cols && batch > 0,
+              "las_cast_bf16: bad shape");
+  const int64_t total = (int64_t)dst_rows * dst_cols;
+  int blocks = (int)((total + 255) / 256);
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(cast_kernel, dim3(blocks, batch), dim3(256), 0, (hipStream_t)stream, src, lds_, rows, cols, dst,
+                     ldd, dst_rows, dst_cols, transpose, src_bstride, dst_bstride);
+  LAS_LAUNCH_CHECK("cast launch");
+  return LAS_OK;
+}
+
+extern "C" int las_colsum_bf16(const las_bf16* X, int64_t ldx, int M, int N, float* out, void* stream) {
+  LAS_REQUIRE(M > 0 && N > 0, "las_colsum_bf16: empty");
+  int chunks = (M + 511) / 512;
+  if (chunks > 256) chunks = 256;
+  hipLaunchKernelGGL(colsum_kernel, dim3((N + 63) / 64, chunks), dim3(64, 4), 0, (hipStream_t)stream, X, ldx, M, N, out);
+  LAS_LAUNCH_CHECK("colsum launch");
+  return LAS_OK;
+}
+
+extern "C" int las_pyramid_lengths(const int32_t* len_in, int32_t* len_out, int B, void* stream) {
+  LAS_REQUIRE(B > 0, "las_pyramid_lengths: B must be positive");
+  hipLaunchKernelGGL(pyramid_len_kernel, dim3((B + 255) / 256), dim3(256), 0, (hipStream_t)stream, len_in, len_out, B);
+  LAS_LAUNCH_CHECK("pyramid launch");
+  return LAS_OK;
+}

@@ -1,0 +1,252 @@
+// bf16 x bf16 -> fp32 MFMA GEMMs for the LAS path (gfx950).
+//
+//   NT : C[M,N] (=|+=) A[M,K] * B[N,K]^T + bias      (forward projections, dX)
+//   TN : C[M,N] += sum_k A[k,M] * B[k,N]             (weight gradients; split-K with fp32 atomics)
+//
+// Both stage BMxBK / BNxBK operand tiles into LDS as [row][k] (k contiguous, row stride BK+8
+// elements = 144 B: the 16 rows one ds_read_b128 lane group touches land on 16 disjoint 4-bank
+// groups) and feed v_mfma_f32_16x16x32_bf16.  256 threads = 4 waves in a 2x2 grid, each wave
+// owns a (BM/2)x(BN/2) block of 16x16 accumulator tiles.  Global->register loads of tile k+1 are
+// issued before the MFMAs of tile k and written to the other LDS buffer after them (one
+// barrier per K-tile).
+#include "las_common.h"
+
+namespace {
+
+constexpr int BK = 64;
+constexpr int LDK = BK + 8;   // LDS row stride in elements
+
+struct GemmArgs {
+  const unsigned short* A;
+  const unsigned short* B;
+  void* C;
+  const float* bias;
+  int64_t lda, ldb, ldc, sa, sb, sc;
+  int M, N, K;
+  int out_bf16, accumulate, atomic, split_k;
+  int a_shift, period;
+};
+
+template <int BM, int BN, bool TN>
+__global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned short* As = reinterpret_cast<unsigned short*>(smem);            // [2][BM][LDK]
+  unsigned short* Bs = As + 2 * BM * LDK;                                  // [2][BN][LDK]
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wr = wave >> 1, wc = wave & 1;
+  const int m0 = blockIdx.y * BM;
+  const int n0 = blockIdx.x * BN;
+  const int batch = blockIdx.z / g.split_k;
+  const int slice = blockIdx.z % g.split_k;
+
+  const unsigned short* A = g.A + (int64_t)batch * g.sa;
+  const unsigned short* B = g.B + (int64_t)batch * g.sb;
+
+  const int nk_total = (g.K + BK - 1) / BK;
+  const int nk_per = (nk_total + g.split_k - 1) / g.split_k;
+  const int kt_begin = slice * nk_per;
+  const int kt_end = min(nk_total, kt_begin + nk_per);
+
+  constexpr int FM = BM / 32, FN = BN / 32;
+  f32x4 acc[FM][FN];
+#pragma unroll
+  for (int i = 0; i < FM; ++i)
+#pragma unroll
+    for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  constexpr int CA = BM * (BK / 8) / 256;   // 16-byte chunks per thread for A
+  constexpr int CB = BN * (BK / 8) / 256;
+  uint4 ra[CA], rb[CB];
+
+  auto load_tiles = [&](int kt) {
+    const int k0 = kt * BK;
+#pragma unroll
+    for (int i = 0; i < CA; ++i) {
+      const int c = tid + i * 256;
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (!TN) {
+        const int row = c / (BK / 8), kc = c % (BK / 8);
+        const int m = m0 + row, k = k0 + kc * 8;
+        if (m < g.M && k < g.K) v = *reinterpret_cast<const uint4*>(A + (int64_t)m * g.lda + k);
+      } else {
+        const int kr = c / (BM / 8), mc = c % (BM / 8);
+        const int m = m0 + mc * 8;
+        int k = k0 + kr;
+        bool ok = (k < g.K) && (m < g.M);
+        if (g.period > 0) {
+          const int t = k % g.period + g.a_shift;
+          ok = ok && (t >= 0) && (t < g.period);
+          k += g.a_shift;
+        }
+        if (ok) v = *reinterpret_cast<const uint4*>(A + (int64_t)k * g.lda + m);
+      }
+      ra[i] = v;
+    }
+#pragma unroll
+    for (int i = 0; i < CB; ++i) {
+      const int c = tid + i * 256;
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (!TN) {
+        const int row = c / (BK / 8), kc = c % (BK / 8);
+        const int n = n0 + row, k = k0 + kc * 8;
+        if (n < g.N && k < g.K) v = *reinterpret_cast<const uint4*>(B + (int64_t)n * g.ldb + k);
+      } else {
+        const int kr = c / (BN / 8), nc = c % (BN / 8);
+        const int n = n0 + nc * 8, k = k0 + kr;
+        if (k < g.K && n < g.N) v = *reinterpret_cast<const uint4*>(B + (int64_t)k * g.ldb + n);
+      }
+      rb[i] = v;
+    }
+  };
+
+  auto store_tiles = [&](int buf) {
+    unsigned short* as = As + buf * BM * LDK;
+    unsigned short* bs = Bs + buf * BN * LDK;
+#pragma unroll
+    for (int i = 0; i < CA; ++i) {
+      const int c = tid + i * 256;
+      if (!TN) {
+        const int row = c / (BK / 8), kc = c % (BK / 8);
+        *reinterpret_cast<uint4*>(as + row * LDK + kc * 8) = ra[i];
+      } else {
+        const int kr = c / (BM / 8), mc = c % (BM / 8);
+        const unsigned short* e = reinterpret_cast<const unsigned short*>(&ra[i]);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) as[(mc * 8 + j) * LDK + kr] = e[j];
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < CB; ++i) {
+      const int c = tid + i * 256;
+      if (!TN) {
+        const int row = c / (BK / 8), kc = c % (BK / 8);
+        *reinterpret_cast<uint4*>(bs + row * LDK + kc * 8) = rb[i];
+      } else {
+        const int kr = c / (BN / 8), nc = c % (BN / 8);
+        const unsigned short* e = reinterpret_cast<const unsigned short*>(&rb[i]);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) bs[(nc * 8 + j) * LDK + kr] = e[j];
+      }
+    }
+  };
+
+  if (kt_begin < kt_end) {
+    load_tiles(kt_begin);
+    store_tiles(0);
+    __syncthreads();
+    int buf = 0;
+    for (int kt = kt_begin; kt < kt_end; ++kt) {
+      const bool more = (kt + 1 < kt_end);
+      if (more) load_tiles(kt + 1);
+      const unsigned short* as = As + buf * BM * LDK + (wr * (BM / 2)) * LDK;
+      const unsigned short* bs = Bs + buf * BN * LDK + (wc * (BN / 2)) * LDK;
+#pragma unroll
+      for (int kk = 0; kk < BK; kk += 32) {
+        bf16x8 af[FM], bfr[FN];
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+          af[i] = *reinterpret_cast<const bf16x8*>(as + (i * 16 + (lane & 15)) * LDK + kk + 8 * (lane >> 4));
+#pragma unroll
+        for (int j = 0; j < FN; ++j)
+          bfr[j] = *reinterpret_cast<const bf16x8*>(bs + (j * 16 + (lane & 15)) * LDK + kk + 8 * (lane >> 4));
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+#pragma unroll
+          for (int j = 0; j < FN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+      }
+      if (more) store_tiles(buf ^ 1);
+      __syncthreads();
+      buf ^= 1;
+    }
+  }
+
+  // epilogue: C/D layout col = lane&15, row = (lane>>4)*4 + reg
+  float* Cf = reinterpret_cast<float*>(g.C) + (int64_t)batch * g.sc;
+  unsigned short* Cb = reinterpret_cast<unsigned short*>(g.C) + (int64_t)batch * g.sc;
+#pragma unroll
+  for (int i = 0; i < FM; ++i) {
+#pragma unroll
+    for (int j = 0; j < FN; ++j) {
+      const int col = n0 + wc * (BN / 2) + j * 16 + (lane & 15);
+      if (col >= g.N) continue;
+      const float bv = (g.bias != nullptr && slice == 0) ? g.bias[col] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = m0 + wr * (BM / 2) + i * 16 + (lane >> 4) * 4 + r;
+        if (row >= g.M) continue;
+        const float v = acc[i][j][r] + bv;
+        const int64_t off = (int64_t)row * g.ldc + col;
+        if (g.out_bf16) {
+          Cb[off] = las_f2bf(v);
+        } else if (g.atomic) {
+          atomicAdd(Cf + off, v);
+        } else if (g.accumulate) {
+          Cf[off] += v;
+        } else {
+          Cf[off] = v;
+        }
+      }
+    }
+  }
+}
+
+template <int BM, int BN, bool TN>
+int launch(const GemmArgs& g, int batch, hipStream_t st) {
+  dim3 grid((g.N + BN - 1) / BN, (g.M + BM - 1) / BM, batch * g.split_k);
+  size_t lds = (size_t)2 * (BM + BN) * LDK * sizeof(unsigned short);
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<BM, BN, TN>),
+                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((gemm_kernel<BM, BN, TN>), grid, dim3(256), lds, st, g);
+  LAS_LAUNCH_CHECK("gemm launch");
+  return LAS_OK;
+}
+
+__global__ void zero_rows_kernel(float* C, int64_t ldc, int M, int N, int64_t sc) {
+  float* c = C + (int64_t)blockIdx.z * sc;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < (int64_t)M * N;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    c[(i / N) * ldc + (i % N)] = 0.f;
+  }
+}
+
+}  // namespace
+
+extern "C" int las_gemm_nt(const las_bf16* A, int64_t lda, const las_bf16* B, int64_t ldb, void* C, int64_t ldc,
+                           const float* bias, int M, int N, int K, int out_bf16, int accumulate, int batch,
+                           int64_t sa, int64_t sb, int64_t sc, int split_k, void* stream) {
+  LAS_REQUIRE(M > 0 && N > 0 && K > 0 && batch > 0, "las_gemm_nt: empty problem M=%d N=%d K=%d batch=%d", M, N, K, batch);
+  LAS_REQUIRE(K % 8 == 0 && lda % 8 == 0 && ldb % 8 == 0, "las_gemm_nt: K, lda, ldb must be multiples of 8 (K=%d lda=%ld ldb=%ld)", K, (long)lda, (long)ldb);
+  LAS_REQUIRE(((uintptr_t)A % 16 == 0) && ((uintptr_t)B % 16 == 0) && sa % 8 == 0 && sb % 8 == 0, "las_gemm_nt: operands must be 16-byte aligned");
+  if (split_k < 1) split_k = 1;
+  LAS_REQUIRE(!(out_bf16 && (accumulate || split_k > 1)), "las_gemm_nt: bf16 output cannot accumulate or split K");
+  hipStream_t st = (hipStream_t)stream;
+  GemmArgs g{A, B, C, bias, lda, ldb, ldc, sa, sb, sc, M, N, K, out_bf16, accumulate, split_k > 1 ? 1 : 0, split_k, 0, 0};
+  if (split_k > 1 && !accumulate) {
+    hipLaunchKernelGGL(zero_rows_kernel, dim3(64, 1, batch), dim3(256), 0, st, (float*)C, ldc, M, N, sc);
+    LAS_LAUNCH_CHECK("gemm zero");
+  }
+  if (M <= 64 || N <= 64) return launch<64, 64, false>(g, batch, st);
+  return launch<128, 128, false>(g, batch, st);
+}
+
+extern "C" int las_gemm_tn(const las_bf16* A, int64_t lda, const las_bf16* B, int64_t ldb, float* C, int64_t ldc,
+                           int M, int N, int K, int a_shift, int period, int batch, int64_t sa, int64_t sb,
+                           int64_t sc, int split_k, void* stream) {
+  LAS_REQUIRE(M > 0 && N > 0 && K > 0 && batch > 0, "las_gemm_tn: empty problem");
+  LAS_REQUIRE(lda % 8 == 0 && ldb % 8 == 0 && lda >= ((M + 7) / 8) * 8 && ldb >= ((N + 7) / 8) * 8,
+              "las_gemm_tn: lda/ldb must be multiples of 8 covering M/N rounded up to 8");
+  LAS_REQUIRE(((uintptr_t)A % 16 == 0) && ((uintptr_t)B % 16 == 0) && sa % 8 == 0 && sb % 8 == 0, "las_gemm_tn: operands must be 16-byte aligned");
+  if (split_k < 1) split_k = 1;
+  hipStream_t st = (hipStream_t)stream;
+  GemmArgs g{A, B, C, nullptr, lda, ldb, ldc, sa, sb, sc, M, N, K, 0, 1, 1, split_k, a_shift, period};
+  if (M <= 64 || N <= 64) return launch<64, 64, true>(g, batch, st);
+  return launch<128, 128, true>(g, batch, st);
+}

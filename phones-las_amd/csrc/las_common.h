@@ -1,0 +1,57 @@
+// Shared device/host helpers for liblas_hip (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+#include "../../include/las_hip.h"
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(8))) unsigned short u16x8;
+typedef __attribute__((ext_vector_type(4))) unsigned short u16x4;
+
+#define LAS_WAVE 64
+
+void las_set_error(const char* fmt, ...);
+int las_check_hip(hipError_t e, const char* what);
+
+#define LAS_REQUIRE(cond, ...)            \
+  do {                                    \
+    if (!(cond)) {                        \
+      las_set_error(__VA_ARGS__);         \
+      return LAS_ERR_ARG;                 \
+    }                                     \
+  } while (0)
+
+#define LAS_LAUNCH_CHECK(what)                                   \
+  do {                                                           \
+    int _rc = las_check_hip(hipGetLastError(), what);            \
+    if (_rc) return _rc;                                         \
+  } while (0)
+
+__device__ __forceinline__ float las_sigmoid(float x) { return 1.0f / (1.0f + __expf(-x)); }
+__device__ __forceinline__ float las_tanh(float x) {
+  // tanh(x) = 1 - 2/(exp(2x)+1); exact limits at +-inf, abs error ~1e-7
+  float e = __expf(2.0f * x);
+  return 1.0f - 2.0f / (e + 1.0f);
+}
+__device__ __forceinline__ unsigned short las_f2bf(float x) {
+  __bf16 b = (__bf16)x;
+  return __builtin_bit_cast(unsigned short, b);
+}
+__device__ __forceinline__ float las_bf2f(unsigned short u) {
+  return __uint_as_float(((unsigned)u) << 16);
+}
+__device__ __forceinline__ float las_wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float las_wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}

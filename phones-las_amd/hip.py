@@ -1,0 +1,123 @@
+"""ctypes binding of liblas_hip.so (include/las_hip.h).  Every wrapper takes torch CUDA tensors,
+checks dtype/contiguity, and enqueues on torch's current stream.  Failures raise LasError with the
+library's message; a missing library raises at import of this module's ``lib()`` — never a fallback."""
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, 'liblas_hip.so')
+_lib = None
+
+
+class LasError(RuntimeError):
+    pass
+
+
+_i32, _i64, _f32, _vp = C.c_int, C.c_int64, C.c_float, C.c_void_p
+
+_SIGS = {
+    'las_version': ([], C.c_int),
+    'las_last_error': ([], C.c_char_p),
+    'las_gemm_nt': ([_vp, _i64, _vp, _i64, _vp, _i64, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i64, _i64, _i64, _i32, _vp], C.c_int),
+    'las_gemm_tn': ([_vp, _i64, _vp, _i64, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _i64, _i64, _i64, _i32, _vp], C.c_int),
+    'las_cast_bf16': ([_vp, _i64, _i32, _i32, _vp, _i64, _i32, _i32, _i32, _i32, _i64, _i64, _vp], C.c_int),
+    'las_colsum_bf16': ([_vp, _i64, _i32, _i32, _vp, _vp], C.c_int),
+    'las_lstm_pack_recurrent': ([_vp, _i32, _vp, _vp], C.c_int),
+    'las_lstm_recurrent_fwd': ([_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp], C.c_int),
+    'las_lstm_recurrent_bwd': ([_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp], C.c_int),
+    'las_pyramid_lengths': ([_vp, _vp, _i32, _vp], C.c_int),
+    'las_decoder_step_fwd': ([_vp, _vp], C.c_int),
+    'las_decoder_step_bwd': ([_vp, _vp], C.c_int),
+    'las_seq_ce_loss': ([_vp, _i64, _vp, _vp, _i32, _i32, _i32, _f32, _vp, _vp, _i64, _vp], C.c_int),
+    'las_grad_l2_norms': ([_vp, _vp, _vp, _i32, _i64, _f32, _vp, _vp], C.c_int),
+    'las_grad_clip': ([_vp, _vp, _i32, _i64, _vp, _f32, _vp], C.c_int),
+    'las_adam_update': ([_vp, _vp, _vp, _vp, _i64, _f32, _f32, _f32, _f32, _i32, _vp], C.c_int),
+}
+
+# entry points declared in include/las_hip.h whose kernels are not written yet (shrinks to empty)
+_PENDING = {'las_decoder_step_fwd', 'las_decoder_step_bwd', 'las_seq_ce_loss', 'las_grad_l2_norms', 'las_grad_clip',
+            'las_adam_update'}
+EXPORTS = tuple(n for n in _SIGS if n not in _PENDING)
+
+
+def lib_path():
+    return _LIB_PATH
+
+
+def lib():
+    """Load liblas_hip.so (built by phones-las_amd/build.py).  Raises if it is missing."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB_PATH):
+            raise LasError('%s not found: run `python phones-las_amd/build.py` (hipcc, gfx950); '
+                           'there is no CPU fallback' % _LIB_PATH)
+        l = C.CDLL(_LIB_PATH)
+        for name, (args, res) in _SIGS.items():
+            if name in _PENDING:
+                continue
+            fn = getattr(l, name)          # AttributeError here = the .so is stale: rebuild
+            fn.argtypes = args
+            fn.restype = res
+        _lib = l
+    return _lib
+
+
+def check(rc):
+    if rc != 0:
+        raise LasError('liblas_hip error %d: %s' % (rc, lib().las_last_error().decode()))
+
+
+def stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def p(t):
+    """Device pointer of a tensor (None -> NULL)."""
+    if t is None:
+        return C.c_void_p(0)
+    if not t.is_cuda:
+        raise LasError('expected a CUDA tensor; the LAS ops have no CPU path')
+    return C.c_void_p(t.data_ptr())
+
+
+def _req(t, dtype, name):
+    if t.dtype != dtype:
+        raise LasError('%s must be %s, got %s' % (name, dtype, t.dtype))
+    if not t.is_contiguous():
+        raise LasError('%s must be contiguous' % name)
+
+
+# ---------------------------------------------------------------------------------------------
+# thin typed wrappers
+# ---------------------------------------------------------------------------------------------
+def gemm_nt(A, B, C_, M, N, K, lda=None, ldb=None, ldc=None, bias=None, out_bf16=False, accumulate=False,
+            batch=1, sa=0, sb=0, sc=0, split_k=1):
+    lda = lda if lda is not None else A.stride(-2)
+    ldb = ldb if ldb is not None else B.stride(-2)
+    ldc = ldc if ldc is not None else C_.stride(-2)
+    check(lib().las_gemm_nt(p(A), lda, p(B), ldb, p(C_), ldc, p(bias), M, N, K, int(out_bf16), int(accumulate),
+                            batch, sa, sb, sc, split_k, stream()))
+
+
+def gemm_tn(A, B, C_, M, N, K, lda=None, ldb=None, ldc=None, a_shift=0, period=0, batch=1, sa=0, sb=0, sc=0,
+            split_k=1):
+    lda = lda if lda is not None else A.stride(-2)
+    ldb = ldb if ldb is not None else B.stride(-2)
+    ldc = ldc if ldc is not None else C_.stride(-2)
+    check(lib().las_gemm_tn(p(A), lda, p(B), ldb, p(C_), ldc, M, N, K, a_shift, period, batch, sa, sb, sc,
+                            split_k, stream()))
+
+
+def cast_bf16(src, rows, cols, dst, dst_rows, dst_cols, ldd=None, transpose=False, lds=None, batch=1, sbs=0, dbs=0):
+    """dst window [dst_rows, dst_cols] (row stride ldd) = bf16(src[rows, cols]) (transposed if asked), zero padded."""
+    lds = lds if lds is not None else (src.stride(-2) if src.dim() >= 2 else cols)
+    ldd = ldd if ldd is not None else (dst.stride(-2) if dst.dim() >= 2 else dst_cols)
+    check(lib().las_cast_bf16(p(src), lds, rows, cols, p(dst), ldd, dst_rows, dst_cols, int(transpose), batch,
+                              sbs, dbs, stream()))
+
+
+def colsum_bf16(X, M, N, out, ldx=None):
+    ldx = ldx if ldx is not None else X.stride(-2)
+    check(lib().las_colsum_bf16(p(X), ldx, M, N, p(out), stream()))

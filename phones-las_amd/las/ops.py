@@ -1,0 +1,172 @@
+"""MI355X host side of the reference's ``las/ops.py`` (lstm_cell, bilstm, pyramidal_bilstm).
+
+Same names and argument meaning as /root/reference/las/ops.py:10-87; the TF graph ops are replaced by
+calls into liblas_hip.so (hand-written HIP, include/las_hip.h).  TF builds variables implicitly inside
+variable scopes; here the caller passes ``variables`` (name -> fp32 CUDA tensor, TF names/layouts) and,
+for training, a ``tape`` list that receives one record per layer for ``*_backward``.
+
+Layout contract: inputs [B,T,D] bf16 with D a multiple of 8 (zero padded), T even wherever a pyramid
+stack follows; outputs [B,T,ndir*H] bf16 with fw in [0,H) and bw in [H,2H) — the tf.concat of
+las/ops.py:81 is free.  pyramidal_stack (las/ops.py:49-65) is then a zero-copy view.
+"""
+import collections
+
+import torch
+
+from .. import hip
+
+__all__ = ['lstm_cell', 'bilstm', 'pyramidal_bilstm', 'pyramidal_stack', 'LSTMStateTuple', 'TRAIN', 'EVAL',
+           'PREDICT']
+
+TRAIN, EVAL, PREDICT = 'train', 'eval', 'infer'      # tf.estimator.ModeKeys values
+LSTMStateTuple = collections.namedtuple('LSTMStateTuple', ['c', 'h'])
+LSTMCellSpec = collections.namedtuple('LSTMCellSpec', ['num_units', 'input_keep_prob'])
+
+
+def lstm_cell(num_units, dropout, mode):
+    """las/ops.py:10-20: LSTMCell(num_units, U(-0.075,0.075)); DropoutWrapper(input_keep_prob) in TRAIN."""
+    dropout = dropout if mode == TRAIN else 0.0
+    if dropout > 0.0:
+        raise NotImplementedError('input dropout > 0 is not implemented on the HIP path yet; use --dropout 0')
+    if num_units not in (64, 128, 256, 512):
+        raise ValueError('num_units must be one of 64, 128, 256, 512 on the HIP path (got %d)' % num_units)
+    return LSTMCellSpec(num_units, 1.0 - dropout)
+
+
+def _dirs(unidirectional):
+    return ['fw'] if unidirectional else ['fw', 'bw']
+
+
+class LayerWeights:
+    """bf16 operand images of one (Bi)LSTM layer's fp32 master weights (rebuilt after each update)."""
+
+    def __init__(self, variables, scope, D, Dp, H, unidirectional, cell_path='/{dir}/lstm_cell'):
+        self.D, self.Dp, self.H = D, Dp, H
+        self.dirs = _dirs(unidirectional)
+        nd = len(self.dirs)
+        dev = 'cuda'
+        self.names = [(scope + cell_path.format(dir=d) + '/kernel', scope + cell_path.format(dir=d) + '/bias')
+                      for d in self.dirs]
+        self.kxT = torch.empty(nd * 4 * H, Dp, dtype=torch.bfloat16, device=dev)       # B^T-form for x*K_x
+        self.kx = torch.empty(max(D, 1), nd * 4 * H, dtype=torch.bfloat16, device=dev)  # B^T-form for dZ*K_x^T
+        self.kh = torch.empty(nd, H, 4 * H, dtype=torch.bfloat16, device=dev)           # natural K_h (bwd)
+        self.khp = torch.empty(nd, H * 4 * H, dtype=torch.bfloat16, device=dev)         # fragment-major (fwd)
+        self.bias = torch.empty(nd * 4 * H, dtype=torch.float32, device=dev)
+        self.refresh(variables)
+
+    def refresh(self, variables):
+        D, Dp, H = self.D, self.Dp, self.H
+        nd = len(self.dirs)
+        for i, (kn, bn) in enumerate(self.names):
+            k, b = variables[kn], variables[bn]
+            assert k.shape == (D + H, 4 * H), (kn, tuple(k.shape), (D + H, 4 * H))
+            hip.cast_bf16(k, D, 4 * H, self.kxT[i * 4 * H:], 4 * H, Dp, ldd=Dp, transpose=True, lds=4 * H)
+            hip.cast_bf16(k, D, 4 * H, self.kx[:, i * 4 * H:], D, 4 * H, ldd=nd * 4 * H, lds=4 * H)
+            hip.cast_bf16(k[D:], H, 4 * H, self.kh[i], H, 4 * H, ldd=4 * H, lds=4 * H)
+            hip.check(hip.lib().las_lstm_pack_recurrent(hip.p(k[D:]), H, hip.p(self.khp[i]), hip.stream()))
+            self.bias[i * 4 * H:(i + 1) * 4 * H].copy_(b)
+
+
+def bilstm(inputs, sequence_length, num_units, dropout, mode, unidirectional=False, *, variables=None,
+           scope='', weights=None, tape=None, in_features=None):
+    """las/ops.py:23-46.  inputs [B,T,Dp] bf16; sequence_length int32 [B] (CUDA).
+    Returns (outputs, state) with the reference's structure: bidirectional -> ((fw, bw), (state_fw,
+    state_bw)); unidirectional -> (fw, state).  fw/bw are views of one [B,T,ndir*H] buffer
+    (use ``concat_outputs`` for the tf.concat of las/ops.py:81)."""
+    lstm_cell(num_units, dropout, mode)
+    B, T, Dp = inputs.shape
+    H = num_units
+    D = in_features if in_features is not None else Dp
+    if weights is None:
+        weights = LayerWeights(variables, scope, D, Dp, H, unidirectional)
+    nd = len(weights.dirs)
+    dev = inputs.device
+    xproj = torch.empty(B, T, nd * 4 * H, dtype=torch.float32, device=dev)
+    hip.gemm_nt(inputs, weights.kxT, xproj, B * T, nd * 4 * H, Dp, lda=Dp, ldb=Dp, ldc=nd * 4 * H,
+                bias=weights.bias)
+    y = torch.empty(B, T, nd * H, dtype=torch.bfloat16, device=dev)
+    cbuf = torch.empty(B, T, nd * H, dtype=torch.float32, device=dev)
+    c_last = torch.empty(nd, B, H, dtype=torch.float32, device=dev)
+    h_last = torch.empty(nd, B, H, dtype=torch.float32, device=dev)
+    hip.check(hip.lib().las_lstm_recurrent_fwd(hip.p(xproj), hip.p(weights.khp), hip.p(sequence_length), hip.p(y),
+                                               hip.p(cbuf), hip.p(c_last), hip.p(h_last), B, T, H, nd,
+                                               hip.stream()))
+    if tape is not None:
+        tape.append(dict(kind='bilstm', inputs=inputs, length=sequence_length, gates=xproj, cbuf=cbuf, y=y,
+                         weights=weights, B=B, T=T, H=H, D=D, Dp=Dp, nd=nd))
+    states = tuple(LSTMStateTuple(c_last[i], h_last[i]) for i in range(nd))
+    if unidirectional:
+        return y, states[0]
+    return (y[..., :H], y[..., H:]), states
+
+
+def concat_outputs(outputs):
+    """tf.concat(outputs, -1) of las/ops.py:81 — free: both halves already live in one buffer."""
+    if isinstance(outputs, tuple):
+        fw, bw = outputs
+        base = fw._base
+        if base is None or bw._base is not base or base.shape[-1] != fw.shape[-1] + bw.shape[-1]:
+            return torch.cat(outputs, -1)
+        return base
+    return outputs
+
+
+def bilstm_backward(rec, dy, d_state, grads, need_dx=True):
+    """Reverse-mode AD of one bilstm() call.  dy [B,T,nd*H] fp32 (gradient of the concatenated outputs),
+    d_state: None or (dc_last, dh_last) each [nd,B,H] fp32.  Accumulates into ``grads`` (name -> fp32
+    tensor, same shapes as the variables) and returns dX [B,T,D'] fp32 (or None)."""
+    B, T, H, D, Dp, nd = rec['B'], rec['T'], rec['H'], rec['D'], rec['Dp'], rec['nd']
+    w = rec['weights']
+    dev = dy.device
+    dz = torch.empty(B, T, nd * 4 * H, dtype=torch.bfloat16, device=dev)
+    dc_last, dh_last = d_state if d_state is not None else (None, None)
+    hip.check(hip.lib().las_lstm_recurrent_bwd(hip.p(rec['gates']), hip.p(rec['cbuf']), hip.p(dy), hip.p(dc_last),
+                                               hip.p(dh_last), hip.p(w.kh), hip.p(rec['length']), hip.p(dz), B, T,
+                                               H, nd, hip.stream()))
+    x, y = rec['inputs'], rec['y']
+    BT = B * T
+    split = max(1, min(32, BT // 2048))
+    for i, (kn, bn) in enumerate(w.names):
+        gk, gb = grads[kn], grads[bn]
+        dzi = dz.view(BT, nd * 4 * H)[:, i * 4 * H:]
+        if D > 0:
+            hip.gemm_tn(x, dzi, gk, D, 4 * H, BT, lda=Dp, ldb=nd * 4 * H, ldc=4 * H, split_k=split)
+        yi = y.view(BT, nd * H)[:, i * H:]
+        hip.gemm_tn(yi, dzi, gk[D:], H, 4 * H, BT, lda=nd * H, ldb=nd * 4 * H, ldc=4 * H,
+                    a_shift=(-1 if i == 0 else 1), period=T, split_k=split)
+        hip.colsum_bf16(dzi, BT, 4 * H, gb, ldx=nd * 4 * H)
+    dx = None
+    if need_dx:
+        dx = torch.empty(B, T, D, dtype=torch.float32, device=dev)
+        hip.gemm_nt(dz, w.kx, dx, BT, D, nd * 4 * H, lda=nd * 4 * H, ldb=nd * 4 * H, ldc=D)
+    return dx
+
+
+def pyramidal_stack(outputs, sequence_length):
+    """las/ops.py:49-65 on the concatenated buffer: [B,T,C] -> [B,T/2,2C] (view), len -> len//2 + len%2."""
+    B, T, C = outputs.shape
+    if T % 2:
+        raise ValueError('time dimension must be padded to an even length before pyramidal_stack')
+    new_len = torch.empty_like(sequence_length)
+    hip.check(hip.lib().las_pyramid_lengths(hip.p(sequence_length), hip.p(new_len), B, hip.stream()))
+    return outputs.view(B, T // 2, 2 * C), new_len
+
+
+def pyramidal_bilstm(inputs, sequence_length, mode, hparams, *, variables=None, weights=None, tape=None,
+                     in_features=None):
+    """las/ops.py:68-87.  ``weights``: optional list of LayerWeights per layer (cached images)."""
+    outputs = inputs
+    state = None
+    D = in_features
+    for layer in range(hparams.num_layers):
+        w = weights[layer] if weights is not None else None
+        out, state = bilstm(outputs, sequence_length, hparams.num_units, hparams.dropout, mode,
+                            hparams.unidirectional, variables=variables,
+                            scope='listener/bilstm_{}'.format(layer), weights=w, tape=tape, in_features=D)
+        outputs = concat_outputs(out)
+        if layer != 0:
+            outputs, sequence_length = pyramidal_stack(outputs, sequence_length)
+            if tape is not None:
+                tape.append(dict(kind='stack'))
+        D = None
+    return (outputs, sequence_length), state

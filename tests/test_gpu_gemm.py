@@ -1,0 +1,137 @@
+"""GPU parity of the MFMA GEMMs (las_gemm_nt / las_gemm_tn, include/las_hip.h) against a float64
+product of the same bf16-rounded operands.  Tolerance: fp32 accumulation of K<=4096 bf16 products,
+|err| <= 2e-3 * sum|a||b| bound in practice -> rtol 1e-3 on the max-abs scale."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _mk(shape, seed):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(shape, generator=g).to(torch.bfloat16)
+
+
+def _close(got, ref, tol=2e-3):
+    scale = ref.abs().max().item() + 1e-6
+    err = (got.double().cpu() - ref).abs().max().item()
+    assert err <= tol * scale, (err, scale)
+
+
+@pytest.mark.parametrize('M,N,K', [(128, 128, 64), (200, 72, 40), (64, 1024, 1280), (3, 5, 8), (257, 129, 328)])
+def test_gemm_nt_matches_fp64(M, N, K):
+    from phones_las_amd import hip
+    A, B = _mk((M, K), 1), _mk((N, K), 2)
+    bias = torch.randn(N)
+    ref = A.double() @ B.double().t() + bias.double()
+    Ad, Bd = A.cuda(), B.cuda()
+    C = torch.empty(M, N, device='cuda')
+    hip.gemm_nt(Ad, Bd, C, M, N, K, bias=bias.cuda())
+    _close(C, ref)
+    # bf16 output, accumulate, split-K
+    Cb = torch.empty(M, N, device='cuda', dtype=torch.bfloat16)
+    hip.gemm_nt(Ad, Bd, Cb, M, N, K, bias=bias.cuda(), out_bf16=True)
+    _close(Cb.float(), ref, 1e-2)
+    C2 = torch.ones(M, N, device='cuda')
+    hip.gemm_nt(Ad, Bd, C2, M, N, K, accumulate=True)
+    _close(C2, ref - bias.double() + 1.0)
+    C3 = torch.full((M, N), 7.0, device='cuda')
+    hip.gemm_nt(Ad, Bd, C3, M, N, K, bias=bias.cuda(), split_k=3)
+    _close(C3, ref)
+
+
+def test_gemm_nt_asymmetric_identity_and_strides():
+    # A = I with an asymmetric B catches a transposed C write (guide §3)
+    from phones_las_amd import hip
+    n = 64
+    A = torch.eye(n).to(torch.bfloat16).cuda()
+    B = (torch.arange(n * n).reshape(n, n) % 251).float().to(torch.bfloat16)
+    C = torch.empty(n, n, device='cuda')
+    hip.gemm_nt(A, B.cuda(), C, n, n, n)
+    assert torch.equal(C.cpu(), B.float().t())
+    # sub-matrix views through lda/ldb/ldc
+    big = _mk((96, 160), 3).cuda()
+    W = _mk((40, 64), 4).cuda()
+    out = torch.zeros(96, 80, device='cuda')
+    hip.gemm_nt(big[:, 32:], W, out[:, 16:], 96, 40, 64, lda=160, ldb=64, ldc=80)
+    ref = big[:, 32:96].double().cpu() @ W.double().cpu().t()
+    _close(out[:, 16:56], ref)
+    assert float(out[:, :16].abs().max()) == 0.0 and float(out[:, 56:].abs().max()) == 0.0
+
+
+def test_gemm_nt_batched():
+    from phones_las_amd import hip
+    nb, M, N, K = 5, 33, 70, 48
+    A, B = _mk((nb, M, K), 5), _mk((nb, N, K), 6)
+    C = torch.empty(nb, M, N, device='cuda')
+    hip.gemm_nt(A.cuda(), B.cuda(), C, M, N, K, lda=K, ldb=K, ldc=N, batch=nb, sa=M * K, sb=N * K, sc=M * N)
+    _close(C, torch.einsum('bmk,bnk->bmn', A.double(), B.double()))
+
+
+@pytest.mark.parametrize('M,N,K,split', [(128, 128, 256, 1), (40, 1024, 1000, 4), (520, 72, 77, 2), (8, 8, 5, 1)])
+def test_gemm_tn_matches_fp64(M, N, K, split):
+    from phones_las_amd import hip
+    lda, ldb = (M + 7) // 8 * 8, (N + 7) // 8 * 8
+    A, B = _mk((K, lda), 7), _mk((K, ldb), 8)
+    ref = A[:, :M].double().t() @ B[:, :N].double()
+    C = torch.zeros(M, N, device='cuda')
+    hip.gemm_tn(A.cuda(), B.cuda(), C, M, N, K, lda=lda, ldb=ldb, split_k=split)
+    _close(C, ref)
+    hip.gemm_tn(A.cuda(), B.cuda(), C, M, N, K, lda=lda, ldb=ldb, split_k=split)   # accumulates
+    _close(C, 2 * ref)
+
+
+@pytest.mark.parametrize('shift', [-1, 1])
+def test_gemm_tn_shifted_rows(shift):
+    # dK_h = sum_t h_{t-1}^T dz_t without a shifted copy: rows cross no utterance boundary
+    from phones_las_amd import hip
+    Bn, T, M, N = 3, 7, 64, 72
+    A, Bm = _mk((Bn * T, M), 9), _mk((Bn * T, N), 10)
+    Ash = torch.zeros(Bn, T, M, dtype=torch.float64)
+    Av = A.double().reshape(Bn, T, M)
+    if shift == -1:
+        Ash[:, 1:] = Av[:, :-1]
+    else:
+        Ash[:, :-1] = Av[:, 1:]
+    ref = Ash.reshape(Bn * T, M).t() @ Bm.double()
+    C = torch.zeros(M, N, device='cuda')
+    hip.gemm_tn(A.cuda(), Bm.cuda(), C, M, N, Bn * T, a_shift=shift, period=T, split_k=2)
+    _close(C, ref)
+
+
+def test_gemm_tn_batched():
+    from phones_las_amd import hip
+    nb, K, M, N = 4, 23, 40, 136
+    A, B = _mk((nb, K, M), 11), _mk((nb, K, N), 12)
+    C = torch.zeros(nb, M, N, device='cuda')
+    hip.gemm_tn(A.cuda(), B.cuda(), C, M, N, K, lda=M, ldb=N, ldc=N, batch=nb, sa=K * M, sb=K * N, sc=M * N)
+    _close(C, torch.einsum('bkm,bkn->bmn', A.double(), B.double()))
+
+
+def test_cast_and_colsum():
+    from phones_las_amd import hip
+    src = torch.randn(37, 50)
+    dst = torch.full((56, 40), 9.0, dtype=torch.bfloat16, device='cuda')
+    hip.cast_bf16(src.cuda(), 37, 50, dst, 56, 40, transpose=True)
+    ref = torch.zeros(56, 40)
+    ref[:50, :37] = src.t()
+    assert torch.equal(dst.cpu().float(), ref.to(torch.bfloat16).float())
+    dst2 = torch.full((37, 56), 9.0, dtype=torch.bfloat16, device='cuda')
+    hip.cast_bf16(src.cuda(), 37, 50, dst2, 37, 56)
+    ref2 = torch.zeros(37, 56)
+    ref2[:, :50] = src
+    assert torch.equal(dst2.cpu().float(), ref2.to(torch.bfloat16).float())
+    X = _mk((1000, 72), 13)
+    out = torch.zeros(72, device='cuda')
+    hip.colsum_bf16(X.cuda(), 1000, 72, out)
+    _close(out, X.double().sum(0), 1e-5)
+
+
+def test_bad_arguments_raise():
+    from phones_las_amd import hip
+    A = torch.zeros(8, 12, dtype=torch.bfloat16, device='cuda')
+    C = torch.zeros(8, 8, device='cuda')
+    with pytest.raises(hip.LasError):
+        hip.gemm_nt(A, A, C, 8, 8, 12)          # K not a multiple of 8
+    with pytest.raises(hip.LasError):
+        hip.gemm_nt(A.cpu(), A, C, 8, 8, 8)     # CPU tensor: no fallback

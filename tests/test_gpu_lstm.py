@@ -1,0 +1,97 @@
+"""GPU parity of the listener kernels (las_lstm_recurrent_fwd/bwd + the GEMMs around them) against the
+oracle's dynamic_rnn in its bf16 storage model (oracle/las_oracle.py, mxu='bf16') on identical inputs.
+
+Tolerances (stated per SURVEY.md §4): forward outputs are bf16 values: |err| <= 2 bf16 ulp of the
+max-abs (1.6e-2 relative) plus fp32-vs-fp64 accumulation; states/gates fp32: 3e-3.  Gradients pass
+through bf16 dz on the device only: 3e-2 of the per-tensor max-abs."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DT = torch.float64
+
+
+def _setup(B, T, D, H, lengths, seed=0, nd=2):
+    from oracle import las_oracle as O
+    rng = np.random.default_rng(seed)
+    x = torch.tensor(rng.standard_normal((B, T, D)), dtype=DT)
+    length = torch.tensor(lengths)
+    for b in range(B):
+        x[b, lengths[b]:] = 0
+    x = O.q_bf16(x)
+    var = {}
+    for d in ['fw', 'bw'][:nd]:
+        var[f'L/{d}/lstm_cell/kernel'] = torch.tensor(rng.uniform(-0.2, 0.2, (D + H, 4 * H)).astype(np.float32), dtype=DT)
+        var[f'L/{d}/lstm_cell/bias'] = torch.tensor(rng.uniform(-0.3, 0.3, (4 * H,)).astype(np.float32), dtype=DT)
+    return x, length, var
+
+
+def _relerr(got, ref):
+    ref = ref.detach()
+    return float((got.double().cpu() - ref).abs().max() / (ref.abs().max() + 1e-12))
+
+
+@pytest.mark.parametrize('B,T,D,H,lengths', [
+    (3, 10, 24, 64, [10, 4, 7]),
+    (17, 12, 40, 128, [12, 1, 5, 12, 3, 9, 2, 11, 6, 8, 10, 4, 12, 7, 1, 12, 5]),
+    (2, 6, 64, 256, [6, 3]),
+])
+def test_bilstm_forward_backward_vs_oracle(B, T, D, H, lengths):
+    from oracle import las_oracle as O
+    from phones_las_amd.las import ops
+    x, length, var = _setup(B, T, D, H, lengths)
+    leaf = {k: v.clone().requires_grad_(True) for k, v in var.items()}
+    xr = x.clone().requires_grad_(True)
+    (fw, bw), (sfw, sbw) = O.bilstm(xr, length, leaf, 'L', O.q_bf16)
+    ref_y = torch.cat([fw, bw], -1)
+
+    dvar = {k: v.float().cuda() for k, v in var.items()}
+    Dp = (D + 7) // 8 * 8
+    xd = torch.zeros(B, T, Dp, dtype=torch.bfloat16, device='cuda')
+    xd[..., :D] = x.to(torch.bfloat16).cuda()
+    ld = length.to(torch.int32).cuda()
+    tape = []
+    (ofw, obw), (dsfw, dsbw) = ops.bilstm(xd, ld, H, 0.0, ops.TRAIN, variables=dvar, scope='L', tape=tape,
+                                          in_features=D)
+    y = ops.concat_outputs((ofw, obw))
+    torch.cuda.synchronize()
+    assert y.shape == (B, T, 2 * H)
+    assert _relerr(y.float(), ref_y) < 1.6e-2
+    for b in range(B):          # outputs beyond the length are exactly zero (Appendix A.3)
+        if lengths[b] < T:
+            assert float(y[b, lengths[b]:].float().abs().max()) == 0.0
+    assert _relerr(dsfw.c, sfw[0]) < 3e-3 and _relerr(dsbw.c, sbw[0]) < 3e-3
+    assert _relerr(dsfw.h, sfw[1]) < 1.6e-2 and _relerr(dsbw.h, sbw[1]) < 1.6e-2
+
+    # backward: random cotangents on outputs and final states
+    rng = np.random.default_rng(5)
+    dy = torch.tensor(rng.standard_normal((B, T, 2 * H)), dtype=DT)
+    dc = torch.tensor(rng.standard_normal((2, B, H)), dtype=DT)
+    dh = torch.tensor(rng.standard_normal((2, B, H)), dtype=DT)
+    obj = (ref_y * dy).sum() + (sfw[0] * dc[0]).sum() + (sbw[0] * dc[1]).sum() + (sfw[1] * dh[0]).sum() + (sbw[1] * dh[1]).sum()
+    obj.backward()
+    grads = {k: torch.zeros_like(v) for k, v in dvar.items()}
+    dx = ops.bilstm_backward(tape[0], dy.float().cuda().contiguous(),
+                             (dc.float().cuda().contiguous(), dh.float().cuda().contiguous()), grads)
+    torch.cuda.synchronize()
+    for k in grads:
+        assert _relerr(grads[k], leaf[k].grad) < 3e-2, k
+    assert _relerr(dx, xr.grad) < 3e-2
+
+
+def test_unidirectional_and_pyramid_view():
+    from oracle import las_oracle as O
+    from phones_las_amd.las import ops
+    B, T, D, H = 4, 8, 16, 64
+    x, length, var = _setup(B, T, D, H, [8, 5, 2, 7], nd=1)
+    fw, (c, h) = O.bilstm(x, length, var, 'L', O.q_bf16, unidirectional=True)
+    dvar = {k: v.float().cuda() for k, v in var.items()}
+    y, st = ops.bilstm(x.to(torch.bfloat16).cuda(), length.to(torch.int32).cuda(), H, 0.0, ops.TRAIN, True,
+                       variables=dvar, scope='L')
+    assert _relerr(y.float(), fw) < 1.6e-2 and _relerr(st.c, c) < 3e-3
+    stacked, l2 = ops.pyramidal_stack(y, length.to(torch.int32).cuda())
+    ref, rl = O.pyramidal_stack(fw, length)
+    assert stacked.shape == (B, T // 2, 2 * H) and l2.cpu().tolist() == rl.tolist()
+    assert stacked.data_ptr() == y.data_ptr()          # zero-copy
+    assert _relerr(stacked.float(), ref) < 1.6e-2
