@@ -120,71 +120,91 @@ int las_pyramid_lengths(const int32_t* len_in, int32_t* len_out, int B, void* st
  * ---------------------------------------------------------------------------------------- */
 
 /* One decoder step for every batch row, after z = [attention_{t-1}, h_{t-1}] * K[E:, :] has been
- * produced by las_gemm_nt:  adds the input rows K[id] (one-hot / embedding feed) and bias,
- * applies the LSTM cell, scores h_t against keys (Luong: dot; Bahdanau: v.tanh(keys + W_q h)),
- * masked softmax over t' < mem_len, context = align * values.  See las_hip.cpp for the buffer
- * table.  All buffers device pointers. */
+ * produced by las_gemm_nt: adds the token rows K[id] (the one-hot feed of las/model.py:246 is a row
+ * gather) and the bias, applies the LSTM cell, scores h_t against the keys (Luong: dot; Bahdanau:
+ * v.tanh(keys + W_q h)), takes the softmax over t' < mem_len and forms context = align * values.
+ * Every per-step tensor is addressed as base + b * row_stride, so the caller can keep all U steps in
+ * [B,U,...] buffers.  `parts` workgroups per utterance split the context columns (speed only). */
 typedef struct las_dec_step {
-  int B, Hd, M, Tm, attention;   /* Tm = padded memory length T' */
-  const float* z;                /* [B,4Hd]  recurrent+attention part of the pre-activations */
-  const float* tok_rows;         /* [E,4Hd] fp32 rows of the cell kernel for the token feed, or NULL */
-  const int32_t* tok_ids;        /* [B] previous token (row into tok_rows) */
-  int64_t tok_stride;            /* elements between consecutive batch entries of tok_ids */
+  int32_t B, Hd, M, Tm, attention, _pad;  /* Tm = padded memory length T'; attention = enum las_attention */
+  const float* z;                /* [B,4Hd] contiguous: recurrent + attention-feed part of the pre-activations */
+  const las_bf16* tok_rows;      /* [E,4Hd] bf16 rows of the cell kernel for the token feed, or NULL */
+  const int32_t* tok_ids;        /* previous token of utterance b at tok_ids[b * tok_stride] */
+  int64_t tok_stride;
   const float* bias;             /* [4Hd] */
-  float* c;                      /* [B,Hd] in/out cell state */
-  float* gates_out;              /* [B,4Hd] activated gates (saved) */
-  float* c_out;                  /* [B,Hd]  new c (saved) */
-  las_bf16* h_out;               /* [B,ldh] new h as bf16 (cell output / query), row stride ldh */
+  const float* c_prev;           /* c_{t-1}, row stride ldcp */
+  int64_t ldcp;
+  float* gates_out;              /* activated gates i,j,f,o (saved), row stride ldg */
+  int64_t ldg;
+  float* c_out;                  /* c_t (saved), row stride ldco */
+  int64_t ldco;
+  las_bf16* h_out;               /* h_t as bf16, row stride ldh */
   int64_t ldh;
+  las_bf16* h_out2;              /* optional second copy (next step's GEMM operand), row stride ldh2 */
+  int64_t ldh2;
   const las_bf16* keys;          /* [B,Tm,Hd] */
   const las_bf16* values;        /* [B,Tm,M]  (memory, zero beyond mem_len) */
   const int32_t* mem_len;        /* [B] */
-  const las_bf16* wq;            /* Bahdanau query_layer^T [Hd,Hd] (out,in) bf16 or NULL */
-  const float* att_v;            /* Bahdanau v [Hd] or NULL */
-  float* align_out;              /* [B,Tm] alignments (saved) */
-  float* pq_out;                 /* [B,Hd] processed query (Bahdanau, saved) or NULL */
-  las_bf16* ctx_out;             /* [B,ldc] context as bf16, row stride ldc */
+  const las_bf16* wq;            /* Bahdanau query_layer kernel [Hd(in),Hd(out)] bf16, or NULL */
+  const float* att_v;            /* Bahdanau attention_v [Hd], or NULL */
+  float* align_out;              /* alignments fp32 (saved), row stride lda */
+  las_bf16* align_bf16;          /* optional bf16 copy (operand of the d(memory) GEMM), row stride lda */
+  int64_t lda;
+  float* pq_out;                 /* Bahdanau processed query (saved), row stride ldpq, or NULL */
+  int64_t ldpq;
+  las_bf16* ctx_out;             /* context as bf16, row stride ldc */
   int64_t ldc;
-  las_bf16* ctx_out2;            /* optional second copy (next step's cell input), row stride ldc2 */
+  las_bf16* ctx_out2;            /* optional second copy (next step's GEMM operand), row stride ldc2 */
   int64_t ldc2;
 } las_dec_step;
-int las_decoder_step_fwd(const las_dec_step* s, void* stream);
+int las_decoder_step_fwd(const las_dec_step* s, int parts, void* stream);
 
-/* Backward of one decoder step (Luong/Bahdanau).  Consumes dctx [B,M]
- * (gradient w.r.t. the context, fp32), dh_rec [B,Hd], dc [B,Hd]; produces dz [B,4Hd] bf16,
- * ds [B,Tm] (score gradient, bf16) and dc (in place, for step t-1). */
+/* Backward of one decoder step.  d(context) = dctx_a + dctx_b; the kernel
+ * back-propagates through context, softmax and score into h_t, adds dh_rec, runs the LSTM cell
+ * backward and emits dz (bf16) for the dense products; dc is updated in place to dc_{t-1}. */
 typedef struct las_dec_step_bwd {
-  int B, Hd, M, Tm, attention;
-  const float* dctx;             /* [B,ldd] fp32 */
-  int64_t ldd;
-  const float* dh_rec;           /* [B,ldr] fp32 gradient into h_t from step t+1 (or zeros) */
+  int32_t B, Hd, M, Tm, attention, _pad;
+  const float* dctx_a;           /* fp32, row stride ldda (e.g. dlogits * W_proj^T), or NULL */
+  int64_t ldda;
+  const float* dctx_b;           /* fp32, row stride lddb (attention-feed gradient from step t+1), or NULL */
+  int64_t lddb;
+  las_bf16* dctx_save;           /* optional bf16 copy of the total (operand of the d(memory) GEMM) */
+  int64_t ldds;
+  const float* dh_rec;           /* gradient into h_t from step t+1 (row stride ldr), or NULL */
   int64_t ldr;
-  float* dc;                     /* [B,Hd] in: dc_t from step t+1; out: dc_{t-1} */
-  const float* gates;            /* [B,4Hd] saved */
-  const float* c_new;            /* [B,Hd] saved c_t */
-  const float* c_prev;           /* [B,Hd] c_{t-1} */
-  const las_bf16* h;             /* [B,ldh] h_t bf16 */
-  int64_t ldh;
-  const float* align;            /* [B,Tm] saved */
-  const float* pq;               /* [B,Hd] saved processed query (Bahdanau) */
+  float* dc;                     /* [B,Hd] contiguous, in: dc_t, out: dc_{t-1} */
+  const float* gates;            /* saved, row stride ldg */
+  int64_t ldg;
+  const float* c_new;            /* c_t, row stride ldcn */
+  int64_t ldcn;
+  const float* c_prev;           /* c_{t-1}, row stride ldcp */
+  int64_t ldcp;
+  const float* align;            /* saved alignments, row stride lda */
+  int64_t lda;
+  const float* pq;               /* Bahdanau saved processed query, row stride ldpq */
+  int64_t ldpq;
   const las_bf16* keys;
   const las_bf16* values;
   const int32_t* mem_len;
-  const las_bf16* wq_t;          /* Bahdanau query_layer [Hd(in),Hd(out)]^T as needed, or NULL */
+  const las_bf16* wq_t;          /* Bahdanau query_layer kernel transposed [Hd(out),Hd(in)] bf16 */
   const float* att_v;
-  las_bf16* dz;                  /* [B,4Hd] out */
-  las_bf16* ds;                  /* [B,Tm] out: Luong d score; Bahdanau unused */
-  las_bf16* dtanh;               /* Bahdanau: [B,Tm,Hd] d(pre-tanh) out (bf16) or NULL */
-  float* dv_acc;                 /* Bahdanau: [Hd] fp32 accumulated d att_v, or NULL */
-  las_bf16* dpq;                 /* Bahdanau: [B,Hd] d processed query out */
+  las_bf16* dz;                  /* out: gate pre-activation gradient, row stride ldz */
+  int64_t ldz;
+  las_bf16* ds_out;              /* out: score gradient bf16 (Luong: operand of the d(keys) GEMM), row stride ldso */
+  int64_t ldso;
+  float* dkeys_acc;              /* Bahdanau: [B,Tm,Hd] fp32 accumulated d(keys) */
+  float* dv_acc;                 /* Bahdanau: [Hd] fp32 accumulated d(attention_v) */
+  las_bf16* dpq_out;             /* Bahdanau: d(processed query) bf16 (operand of d(query_layer)), row stride lddpq */
+  int64_t lddpq;
 } las_dec_step_bwd;
 int las_decoder_step_bwd(const las_dec_step_bwd* s, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Loss: tf.contrib.seq2seq.sequence_loss as used by compute_loss (model_helper.py:24-30):
  * loss = sum_{b,t<len_b} CE(logits[b,t], targets[b,t]) / (sum_b len_b + 1e-12).
- * loss_out[0] += loss contributions (zero it first); dlogits (bf16, [B,U,ldd]) receives
- * (softmax - onehot) * w / sum(w) * grad_scale, zero for masked steps.
+ * logits [B*U rows, row stride ldl] fp32; targets [B,U] contiguous; loss_out[0] += loss (zero it
+ * first); dlogits (bf16, row stride ldd) receives (softmax - onehot) * w / sum(w) * grad_scale, zero
+ * for masked steps.
  * ---------------------------------------------------------------------------------------- */
 int las_seq_ce_loss(const float* logits, int64_t ldl, const int32_t* targets, const int32_t* target_len,
                     int B, int U, int V, float grad_scale, float* loss_out, las_bf16* dlogits, int64_t ldd,
@@ -196,15 +216,20 @@ int las_seq_ce_loss(const float* logits, int64_t ldl, const int32_t* targets, co
  * seg_offsets[nseg+1] gives the tensor boundaries (device int64).
  * ---------------------------------------------------------------------------------------- */
 
+/* out[0] += sum_i x[i]^2 (the L2 regulariser value of model_helper.py:411-413 is scale/2 times this). */
+int las_sumsq(const float* x, int64_t n, float* out, void* stream);
 /* grads[i] += l2_scale * params[i]; sumsq[s] = ||grads_s||^2  (sumsq zeroed inside). */
 int las_grad_l2_norms(float* grads, const float* params, const int64_t* seg_offsets, int nseg,
                       int64_t total, float l2_scale, float* sumsq, void* stream);
 /* grads_s *= clip / max(||grads_s||, clip)  (clip_by_norm, model_helper.py:416). */
 int las_grad_clip(float* grads, const int64_t* seg_offsets, int nseg, int64_t total, const float* sumsq,
                   float clip, void* stream);
-/* TF-form Adam (epsilon outside the bias correction); step is the 1-based update count. */
+/* TF-form Adam (epsilon outside the bias correction).  The 1-based update count t is `step`, or
+ * *step_dev when step_dev != NULL (a device counter: keeps a captured hipGraph replayable). */
 int las_adam_update(float* params, float* m, float* v, const float* grads, int64_t total, float lr,
-                    float beta1, float beta2, float eps, int step, void* stream);
+                    float beta1, float beta2, float eps, int step, const int32_t* step_dev, void* stream);
+/* *counter += delta on the stream (tf.train.get_global_step increment, model_helper.py:417). */
+int las_counter_add(int32_t* counter, int32_t delta, void* stream);
 
 #ifdef __cplusplus
 }

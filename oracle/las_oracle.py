@@ -30,6 +30,13 @@ import torch
 
 DT = torch.float64
 
+
+def set_dtype(dtype):
+    """Switch the arithmetic type of the restatement (float64 for parity checks; float32 to time the
+    reference-shaped fp32 CPU path in bench.py's cpu_baseline leg)."""
+    global DT
+    DT = dtype
+
 UNK_ID, SOS_ID, EOS_ID = 0, 1, 2          # utils/vocab_utils.py:19-21
 GRAD_NORM = 2.0                            # model_helper.py:16
 

@@ -28,18 +28,53 @@ _SIGS = {
     'las_lstm_recurrent_fwd': ([_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp], C.c_int),
     'las_lstm_recurrent_bwd': ([_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp], C.c_int),
     'las_pyramid_lengths': ([_vp, _vp, _i32, _vp], C.c_int),
-    'las_decoder_step_fwd': ([_vp, _vp], C.c_int),
+    'las_decoder_step_fwd': ([_vp, _i32, _vp], C.c_int),
     'las_decoder_step_bwd': ([_vp, _vp], C.c_int),
     'las_seq_ce_loss': ([_vp, _i64, _vp, _vp, _i32, _i32, _i32, _f32, _vp, _vp, _i64, _vp], C.c_int),
     'las_grad_l2_norms': ([_vp, _vp, _vp, _i32, _i64, _f32, _vp, _vp], C.c_int),
     'las_grad_clip': ([_vp, _vp, _i32, _i64, _vp, _f32, _vp], C.c_int),
-    'las_adam_update': ([_vp, _vp, _vp, _vp, _i64, _f32, _f32, _f32, _f32, _i32, _vp], C.c_int),
+    'las_adam_update': ([_vp, _vp, _vp, _vp, _i64, _f32, _f32, _f32, _f32, _i32, _vp, _vp], C.c_int),
+    'las_counter_add': ([_vp, _i32, _vp], C.c_int),
+    'las_sumsq': ([_vp, _i64, _vp, _vp], C.c_int),
 }
 
 # entry points declared in include/las_hip.h whose kernels are not written yet (shrinks to empty)
-_PENDING = {'las_decoder_step_fwd', 'las_decoder_step_bwd', 'las_seq_ce_loss', 'las_grad_l2_norms', 'las_grad_clip',
-            'las_adam_update'}
+_PENDING = set()
 EXPORTS = tuple(n for n in _SIGS if n not in _PENDING)
+
+
+class DecStep(C.Structure):
+    """struct las_dec_step (include/las_hip.h)."""
+    _fields_ = [('B', _i32), ('Hd', _i32), ('M', _i32), ('Tm', _i32), ('attention', _i32), ('_pad', _i32),
+                ('z', _vp), ('tok_rows', _vp), ('tok_ids', _vp), ('tok_stride', _i64), ('bias', _vp),
+                ('c_prev', _vp), ('ldcp', _i64), ('gates_out', _vp), ('ldg', _i64), ('c_out', _vp), ('ldco', _i64),
+                ('h_out', _vp), ('ldh', _i64), ('h_out2', _vp), ('ldh2', _i64), ('keys', _vp), ('values', _vp),
+                ('mem_len', _vp), ('wq', _vp), ('att_v', _vp), ('align_out', _vp), ('align_bf16', _vp),
+                ('lda', _i64), ('pq_out', _vp), ('ldpq', _i64), ('ctx_out', _vp), ('ldc', _i64),
+                ('ctx_out2', _vp), ('ldc2', _i64)]
+
+
+class DecStepBwd(C.Structure):
+    """struct las_dec_step_bwd (include/las_hip.h)."""
+    _fields_ = [('B', _i32), ('Hd', _i32), ('M', _i32), ('Tm', _i32), ('attention', _i32), ('_pad', _i32),
+                ('dctx_a', _vp), ('ldda', _i64), ('dctx_b', _vp), ('lddb', _i64), ('dctx_save', _vp), ('ldds', _i64),
+                ('dh_rec', _vp), ('ldr', _i64), ('dc', _vp), ('gates', _vp), ('ldg', _i64), ('c_new', _vp),
+                ('ldcn', _i64), ('c_prev', _vp), ('ldcp', _i64), ('align', _vp), ('lda', _i64), ('pq', _vp),
+                ('ldpq', _i64), ('keys', _vp), ('values', _vp), ('mem_len', _vp), ('wq_t', _vp), ('att_v', _vp),
+                ('dz', _vp), ('ldz', _i64), ('ds_out', _vp), ('ldso', _i64), ('dkeys_acc', _vp), ('dv_acc', _vp),
+                ('dpq_out', _vp), ('lddpq', _i64)]
+
+
+ATT_LUONG, ATT_BAHDANAU = 0, 1
+
+
+def addr(t, offset_elems=0):
+    """Raw device address (int) of tensor ``t`` advanced by ``offset_elems`` elements; None -> 0."""
+    if t is None:
+        return 0
+    if not t.is_cuda:
+        raise LasError('expected a CUDA tensor; the LAS ops have no CPU path')
+    return t.data_ptr() + offset_elems * t.element_size()
 
 
 def lib_path():

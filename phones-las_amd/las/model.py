@@ -1,0 +1,392 @@
+"""MI355X host side of the reference's ``las/model.py``: ``listener`` (las/model.py:104-142) and
+``speller`` (las/model.py:205-349) with the same argument meaning, built on liblas_hip.so.
+
+TF builds a graph and differentiates it; here each function runs the HIP kernels eagerly and, in TRAIN
+mode, records what the hand-written backward needs (``Listener.backward`` / ``Speller.backward``).
+
+Supported on the HIP path this round (anything else raises ValueError, never a silent fallback):
+  listener: pyramidal (Bi)LSTM stacks (--use_pyramidal), num_units in {64,128,256,512};
+  speller : one decoder layer, attention_type luong | bahdanau, attention_layer_size None,
+            one-hot token feed (embedding_size 0), teacher forcing (sampling_probability 0) and greedy decode.
+"""
+import ctypes as C
+
+import torch
+
+from .. import hip
+from . import ops
+from .ops import TRAIN, EVAL, PREDICT, LSTMStateTuple
+
+__all__ = ['listener', 'speller', 'Listener', 'Speller']
+
+
+def _r8(n):
+    return (n + 7) // 8 * 8
+
+
+# =================================================================================================
+# listener
+# =================================================================================================
+class Listener:
+    """Pyramidal BiLSTM encoder (las/ops.py:68-87) with cached bf16 weight images and a tape."""
+
+    def __init__(self, hparams, variables, num_channels):
+        if not hparams.use_pyramidal:
+            raise ValueError('only --use_pyramidal listeners are implemented on the HIP path')
+        self.hp = hparams
+        self.F = num_channels
+        self.Fp = _r8(num_channels)
+        H = hparams.num_units
+        nd = 1 if hparams.unidirectional else 2
+        self.layers = []
+        D, Dp = num_channels, self.Fp
+        for l in range(hparams.num_layers):
+            self.layers.append(ops.LayerWeights(variables, 'listener/bilstm_{}'.format(l), D, Dp, H,
+                                                hparams.unidirectional))
+            D = nd * H * (1 if l == 0 else 2)
+            Dp = D
+        self.time_multiple = 2 ** max(0, hparams.num_layers - 1)
+        self.tape = None
+
+    def refresh(self, variables):
+        for w in self.layers:
+            w.refresh(variables)
+
+    def pad_features(self, x):
+        """fp32 [B,T,F] -> bf16 [B,Tp,Fp], zero padded (Tp multiple of 2^(L-1), Fp multiple of 8)."""
+        B, T, F = x.shape
+        assert F == self.F, (F, self.F)
+        m = self.time_multiple
+        Tp = (T + m - 1) // m * m
+        out = torch.empty(B, Tp, self.Fp, dtype=torch.bfloat16, device=x.device)
+        hip.cast_bf16(x, T, F, out, Tp, self.Fp, ldd=self.Fp, lds=F, batch=B, sbs=T * F, dbs=Tp * self.Fp)
+        return out
+
+    def forward(self, encoder_inputs, source_sequence_length, mode):
+        x = encoder_inputs
+        if x.dtype != torch.bfloat16:
+            x = self.pad_features(x.contiguous())
+        self.tape = [] if mode == TRAIN else None
+        return ops.pyramidal_bilstm(x, source_sequence_length, mode, self.hp, weights=self.layers,
+                                    tape=self.tape, in_features=self.F)
+
+    def backward(self, d_outputs, d_state, grads):
+        """d_outputs: fp32 gradient w.r.t. the encoder outputs [B,T',M]; d_state: (dc, dh) [nd,B,H] or None."""
+        recs = [r for r in self.tape if r['kind'] == 'bilstm']
+        dy = d_outputs
+        for l in range(len(recs) - 1, -1, -1):
+            r = recs[l]
+            dy = dy.view(r['B'], r['T'], r['nd'] * r['H'])
+            dx = ops.bilstm_backward(r, dy, d_state if l == len(recs) - 1 else None, grads, need_dx=(l > 0))
+            dy = dx
+        self.tape = None
+
+
+def listener(encoder_inputs, source_sequence_length, mode, hparams, *, variables=None, module=None):
+    """las/model.py:104-142.  Returns ((encoder_outputs, source_sequence_length), encoder_state)."""
+    if module is None:
+        module = Listener(hparams, variables, encoder_inputs.shape[-1])
+    return module.forward(encoder_inputs, source_sequence_length, mode)
+
+
+# =================================================================================================
+# speller
+# =================================================================================================
+_ATT = {'luong': hip.ATT_LUONG, 'bahdanau': hip.ATT_BAHDANAU}
+
+
+class Speller:
+    """AttentionWrapper(LSTMCell) decoder + projection layer (las/model.py:145-202,251-257)."""
+
+    def __init__(self, hparams, variables, memory_depth):
+        d = hparams
+        if d.attention_type not in _ATT:
+            raise ValueError('attention_type %r is not implemented on the HIP path (luong, bahdanau)' % d.attention_type)
+        if d.num_layers != 1:
+            raise ValueError('decoder_layers must be 1 on the HIP path this round')
+        if d.attention_layer_size:
+            raise ValueError('attention_layer_size is not implemented on the HIP path this round')
+        if d.embedding_size:
+            raise ValueError('embedding_size > 0 is not implemented on the HIP path this round')
+        if getattr(d, 'binf_projection', False) or getattr(d, 'binary_outputs', False):
+            raise ValueError('binary-feature decoders are not implemented on the HIP path this round')
+        self.hp = d
+        self.att = _ATT[d.attention_type]
+        self.V, self.Vp = d.target_vocab_size, _r8(d.target_vocab_size)
+        self.Hd, self.M = d.num_units, memory_depth
+        if self.Hd % 8 or self.M % 8:
+            raise ValueError('decoder_units and encoder depth must be multiples of 8')
+        V, Vp, Hd, M = self.V, self.Vp, self.Hd, self.M
+        bf, dev = torch.bfloat16, 'cuda'
+        self.wmemT = torch.empty(Hd, M, dtype=bf, device=dev)
+        self.wmem = torch.empty(M, Hd, dtype=bf, device=dev)
+        self.kcT = torch.empty(4 * Hd, M + Hd, dtype=bf, device=dev)
+        self.kc = torch.empty(M + Hd, 4 * Hd, dtype=bf, device=dev)
+        self.tok = torch.empty(V, 4 * Hd, dtype=bf, device=dev)
+        self.wprojT = torch.empty(Vp, M, dtype=bf, device=dev)
+        self.wproj = torch.empty(M, Vp, dtype=bf, device=dev)
+        self.bproj = torch.zeros(Vp, dtype=torch.float32, device=dev)
+        if self.att == hip.ATT_BAHDANAU:
+            self.wq = torch.empty(Hd, Hd, dtype=bf, device=dev)
+            self.wq_t = torch.empty(Hd, Hd, dtype=bf, device=dev)
+        self.refresh(variables)
+        self.saved = None
+
+    # names of the TF variables this module owns
+    K_MEM = 'speller/memory_layer/kernel'
+    K_CELL = 'speller/decoder_cell_0/lstm_cell/kernel'
+    B_CELL = 'speller/decoder_cell_0/lstm_cell/bias'
+    K_PROJ = 'speller/projection_layer/kernel'
+    B_PROJ = 'speller/projection_layer/bias'
+    K_Q = 'speller/query_layer/kernel'
+    V_ATT = 'speller/attention_v'
+
+    def refresh(self, var):
+        V, Vp, Hd, M = self.V, self.Vp, self.Hd, self.M
+        wm, kc, wp = var[self.K_MEM], var[self.K_CELL], var[self.K_PROJ]
+        assert wm.shape == (M, Hd) and kc.shape == (V + M + Hd, 4 * Hd) and wp.shape == (M, V)
+        hip.cast_bf16(wm, M, Hd, self.wmemT, Hd, M, transpose=True)
+        hip.cast_bf16(wm, M, Hd, self.wmem, M, Hd)
+        hip.cast_bf16(kc[V:], M + Hd, 4 * Hd, self.kcT, 4 * Hd, M + Hd, transpose=True, lds=4 * Hd)
+        hip.cast_bf16(kc[V:], M + Hd, 4 * Hd, self.kc, M + Hd, 4 * Hd, lds=4 * Hd)
+        hip.cast_bf16(kc, V, 4 * Hd, self.tok, V, 4 * Hd, lds=4 * Hd)
+        hip.cast_bf16(wp, M, V, self.wprojT, Vp, M, transpose=True)
+        hip.cast_bf16(wp, M, V, self.wproj, M, Vp)
+        self.bproj[:V].copy_(var[self.B_PROJ])
+        self.bias = var[self.B_CELL]
+        if self.att == hip.ATT_BAHDANAU:
+            hip.cast_bf16(var[self.K_Q], Hd, Hd, self.wq, Hd, Hd)
+            hip.cast_bf16(var[self.K_Q], Hd, Hd, self.wq_t, Hd, Hd, transpose=True)
+            self.att_v = var[self.V_ATT]
+
+    # ---------------------------------------------------------------------------------------------
+    def _initial_state(self, encoder_state, B):
+        d = self.hp
+        dev = 'cuda'
+        if d.pass_hidden_state and d.bottom_only:                         # las/model.py:259-268
+            es = encoder_state[0] if isinstance(encoder_state[0], tuple) else encoder_state
+            c0, h0 = es.c, es.h
+            if c0.shape[-1] != self.Hd:
+                raise ValueError('pass_hidden_state needs decoder_units == encoder_units')
+            return c0, h0, True
+        z = torch.zeros(B, self.Hd, dtype=torch.float32, device=dev)
+        return z, z, False
+
+    def _keys(self, memory, B, Tm):
+        keys = torch.empty(B, Tm, self.Hd, dtype=torch.bfloat16, device=memory.device)
+        hip.gemm_nt(memory, self.wmemT, keys, B * Tm, self.Hd, self.M, lda=self.M, ldb=self.M, ldc=self.Hd,
+                    out_bf16=True)
+        return keys
+
+    def _step_struct(self, B, Tm, z, tok_ids, tok_stride, c_prev, ldcp, gates, ldg, c_out, ldco, h_out, ldh, h2, ldh2,
+                     keys, memory, mem_len, align, align_bf, lda, pq, ldpq, ctx, ldc, ctx2, ldc2):
+        s = hip.DecStep()
+        s.B, s.Hd, s.M, s.Tm, s.attention = B, self.Hd, self.M, Tm, self.att
+        s.z, s.tok_rows, s.tok_ids, s.tok_stride = z, hip.addr(self.tok), tok_ids, tok_stride
+        s.bias = hip.addr(self.bias)
+        s.c_prev, s.ldcp, s.gates_out, s.ldg, s.c_out, s.ldco = c_prev, ldcp, gates, ldg, c_out, ldco
+        s.h_out, s.ldh, s.h_out2, s.ldh2 = h_out, ldh, h2, ldh2
+        s.keys, s.values, s.mem_len = hip.addr(keys), hip.addr(memory), hip.addr(mem_len)
+        if self.att == hip.ATT_BAHDANAU:
+            s.wq, s.att_v = hip.addr(self.wq), hip.addr(self.att_v)
+        s.align_out, s.align_bf16, s.lda, s.pq_out, s.ldpq = align, align_bf, lda, pq, ldpq
+        s.ctx_out, s.ldc, s.ctx_out2, s.ldc2 = ctx, ldc, ctx2, ldc2
+        return s
+
+    def forward_train(self, memory, mem_len, encoder_state, targets_inputs, num_steps, parts=4):
+        """TrainingHelper decode (las/model.py:276-296,346-347).  memory [B,T',M] bf16, targets_inputs int32
+        [B,>=num_steps]; num_steps = max(target_sequence_length).  Returns logits fp32 [B,U,Vp] (first V valid)."""
+        B, Tm, M = memory.shape
+        Hd, V, Vp, U = self.Hd, self.V, self.Vp, num_steps
+        dev, bf, f32 = memory.device, torch.bfloat16, torch.float32
+        lib, st = hip.lib(), hip.stream()
+        c0, h0, passed = self._initial_state(encoder_state, B)
+        keys = self._keys(memory, B, Tm)
+        W = M + Hd
+        AH = torch.empty(B, U, W, dtype=bf, device=dev)
+        AH[:, 0, :M].zero_()
+        AH[:, 0, M:].copy_(h0)
+        cs = torch.empty(B, U + 1, Hd, dtype=f32, device=dev)
+        cs[:, 0].copy_(c0)
+        gates = torch.empty(B, U, 4 * Hd, dtype=f32, device=dev)
+        h_all = torch.empty(B, U, Hd, dtype=bf, device=dev)
+        Tmp = _r8(Tm)                      # row stride of per-step [T'] vectors (GEMM operand alignment)
+        align = torch.zeros(B, U, Tmp, dtype=f32, device=dev)
+        align_bf = torch.zeros(B, U, Tmp, dtype=bf, device=dev)
+        ctx_all = torch.empty(B, U, M, dtype=bf, device=dev)
+        pq_all = torch.empty(B, U, Hd, dtype=f32, device=dev) if self.att == hip.ATT_BAHDANAU else None
+        z = torch.empty(B, 4 * Hd, dtype=f32, device=dev)
+        tin = targets_inputs
+        ts = tin.stride(0)
+        for t in range(U):
+            hip.gemm_nt(AH[:, t], self.kcT, z, B, 4 * Hd, W, lda=U * W, ldb=W, ldc=4 * Hd)
+            last = (t + 1 == U)
+            s = self._step_struct(
+                B, Tm, hip.addr(z), hip.addr(tin, t), ts, hip.addr(cs, t * Hd), (U + 1) * Hd,
+                hip.addr(gates, t * 4 * Hd), U * 4 * Hd, hip.addr(cs, (t + 1) * Hd), (U + 1) * Hd,
+                hip.addr(h_all, t * Hd), U * Hd, 0 if last else hip.addr(AH, (t + 1) * W + M), U * W,
+                keys, memory, mem_len, hip.addr(align, t * Tmp), hip.addr(align_bf, t * Tmp), U * Tmp,
+                hip.addr(pq_all, t * Hd) if pq_all is not None else 0, U * Hd,
+                hip.addr(ctx_all, t * M), U * M, 0 if last else hip.addr(AH, (t + 1) * W), U * W)
+            hip.check(lib.las_decoder_step_fwd(C.byref(s), parts, st))
+        logits = torch.empty(B, U, Vp, dtype=f32, device=dev)
+        hip.gemm_nt(ctx_all, self.wprojT, logits, B * U, Vp, M, lda=M, ldb=M, ldc=Vp, bias=self.bproj)
+        self.saved = dict(B=B, Tm=Tm, U=U, memory=memory, mem_len=mem_len, keys=keys, AH=AH, cs=cs, gates=gates,
+                          h_all=h_all, align=align, align_bf=align_bf, ctx_all=ctx_all, pq_all=pq_all,
+                          tin=tin, passed=passed)
+        return logits
+
+    # ---------------------------------------------------------------------------------------------
+    def backward(self, dlogits, grads):
+        """dlogits bf16 [B,U,Vp] (zero in the pad columns).  Accumulates weight gradients into ``grads`` and
+        returns (d_memory fp32 [B,T',M], d_encoder_state or None)."""
+        sv = self.saved
+        B, Tm, U = sv['B'], sv['Tm'], sv['U']
+        Tmp = _r8(Tm)
+        Hd, V, Vp, M = self.Hd, self.V, self.Vp, self.M
+        W = M + Hd
+        dev, bf, f32 = dlogits.device, torch.bfloat16, torch.float32
+        lib, st = hip.lib(), hip.stream()
+        BU = B * U
+        # projection layer
+        hip.gemm_tn(sv['ctx_all'], dlogits, grads[self.K_PROJ], M, V, BU, lda=M, ldb=Vp, ldc=V, split_k=4)
+        hip.colsum_bf16(dlogits, BU, V, grads[self.B_PROJ], ldx=Vp)
+        dattn_proj = torch.empty(B, U, M, dtype=f32, device=dev)
+        hip.gemm_nt(dlogits, self.wproj, dattn_proj, BU, M, Vp, lda=Vp, ldb=Vp, ldc=M)
+        dc = torch.zeros(B, Hd, dtype=f32, device=dev)
+        dfeed = torch.empty(B, W, dtype=f32, device=dev)
+        dz_all = torch.empty(B, U, 4 * Hd, dtype=bf, device=dev)
+        ds_all = torch.zeros(B, U, Tmp, dtype=bf, device=dev)
+        dctx_all = torch.empty(B, U, M, dtype=bf, device=dev)
+        bah = self.att == hip.ATT_BAHDANAU
+        if bah:
+            dkeys = torch.zeros(B, Tm, Hd, dtype=f32, device=dev)
+            dpq_all = torch.empty(B, U, Hd, dtype=bf, device=dev)
+            dv = grads[self.V_ATT]
+        for t in range(U - 1, -1, -1):
+            first = (t == U - 1)
+            s = hip.DecStepBwd()
+            s.B, s.Hd, s.M, s.Tm, s.attention = B, Hd, M, Tm, self.att
+            s.dctx_a, s.ldda = hip.addr(dattn_proj, t * M), U * M
+            s.dctx_b, s.lddb = (0 if first else hip.addr(dfeed)), W
+            s.dctx_save, s.ldds = hip.addr(dctx_all, t * M), U * M
+            s.dh_rec, s.ldr = (0 if first else hip.addr(dfeed, M)), W
+            s.dc = hip.addr(dc)
+            s.gates, s.ldg = hip.addr(sv['gates'], t * 4 * Hd), U * 4 * Hd
+            s.c_new, s.ldcn = hip.addr(sv['cs'], (t + 1) * Hd), (U + 1) * Hd
+            s.c_prev, s.ldcp = hip.addr(sv['cs'], t * Hd), (U + 1) * Hd
+            s.align, s.lda = hip.addr(sv['align'], t * Tmp), U * Tmp
+            s.keys, s.values, s.mem_len = hip.addr(sv['keys']), hip.addr(sv['memory']), hip.addr(sv['mem_len'])
+            s.dz, s.ldz = hip.addr(dz_all, t * 4 * Hd), U * 4 * Hd
+            s.ds_out, s.ldso = hip.addr(ds_all, t * Tmp), U * Tmp
+            if bah:
+                s.pq, s.ldpq = hip.addr(sv['pq_all'], t * Hd), U * Hd
+                s.wq_t, s.att_v = hip.addr(self.wq_t), hip.addr(self.att_v)
+                s.dkeys_acc, s.dv_acc = hip.addr(dkeys), hip.addr(dv)
+                s.dpq_out, s.lddpq = hip.addr(dpq_all, t * Hd), U * Hd
+            hip.check(lib.las_decoder_step_bwd(C.byref(s), st))
+            hip.gemm_nt(dz_all[:, t], self.kc, dfeed, B, W, 4 * Hd, lda=U * 4 * Hd, ldb=4 * Hd, ldc=W)
+        # weight gradients of the cell: rows [V, V+M+Hd) from [attention_{t-1}, h_{t-1}], rows [0,V) from the tokens
+        gk = grads[self.K_CELL]
+        hip.gemm_tn(sv['AH'], dz_all, gk[V:], W, 4 * Hd, BU, lda=W, ldb=4 * Hd, ldc=4 * Hd, split_k=4)
+        onehot = torch.zeros(BU, Vp, dtype=bf, device=dev)
+        onehot.scatter_(1, sv['tin'][:, :U].reshape(BU, 1).long(), 1.0)
+        hip.gemm_tn(onehot, dz_all, gk, V, 4 * Hd, BU, lda=Vp, ldb=4 * Hd, ldc=4 * Hd, split_k=4)
+        hip.colsum_bf16(dz_all, BU, 4 * Hd, grads[self.B_CELL], ldx=4 * Hd)
+        # attention: d(keys), d(memory)
+        if bah:
+            hip.gemm_tn(sv['h_all'], dpq_all, grads[self.K_Q], Hd, Hd, BU, lda=Hd, ldb=Hd, ldc=Hd, split_k=4)
+        else:
+            dkeys = torch.zeros(B, Tm, Hd, dtype=f32, device=dev)
+            hip.gemm_tn(ds_all, sv['h_all'], dkeys, Tm, Hd, U, lda=Tmp, ldb=Hd, ldc=Hd, batch=B, sa=U * Tmp,
+                        sb=U * Hd, sc=Tm * Hd)
+        dmem = torch.zeros(B, Tm, M, dtype=f32, device=dev)
+        hip.gemm_tn(sv['align_bf'], dctx_all, dmem, Tm, M, U, lda=Tmp, ldb=M, ldc=M, batch=B, sa=U * Tmp, sb=U * M,
+                    sc=Tm * M)
+        dkeys_bf = torch.empty(B * Tm, Hd, dtype=bf, device=dev)
+        hip.cast_bf16(dkeys, B * Tm, Hd, dkeys_bf, B * Tm, Hd, ldd=Hd, lds=Hd)
+        hip.gemm_nt(dkeys_bf, self.wmem, dmem, B * Tm, M, Hd, lda=Hd, ldb=Hd, ldc=M, accumulate=True)
+        hip.gemm_tn(sv['memory'], dkeys_bf, grads[self.K_MEM], M, Hd, B * Tm, lda=M, ldb=Hd, ldc=Hd, split_k=8)
+        d_state = None
+        if sv['passed']:
+            d_state = (dc, dfeed[:, M:])
+        self.saved = None
+        return dmem, d_state
+
+    # ---------------------------------------------------------------------------------------------
+    def forward_greedy(self, memory, mem_len, encoder_state, max_iterations, parts=4):
+        """GreedyEmbeddingHelper decode (las/model.py:270-274,337-347).  Returns (logits [B,S,V] fp32, sample_ids
+        [B,S] int32, final_sequence_length [B] int32, alignments [B,S,T'] fp32) with S <= max_iterations."""
+        d = self.hp
+        B, Tm, M = memory.shape
+        Hd, V, Vp = self.Hd, self.V, self.Vp
+        dev, bf, f32 = memory.device, torch.bfloat16, torch.float32
+        lib, st = hip.lib(), hip.stream()
+        c0, h0, _ = self._initial_state(encoder_state, B)
+        keys = self._keys(memory, B, Tm)
+        W = M + Hd
+        S = max_iterations
+        ah = torch.zeros(2, B, W, dtype=bf, device=dev)
+        ah[0, :, M:].copy_(h0)
+        cs = torch.empty(2, B, Hd, dtype=f32, device=dev)
+        cs[0].copy_(c0)
+        gates = torch.empty(B, 4 * Hd, dtype=f32, device=dev)
+        h_t = torch.empty(B, Hd, dtype=bf, device=dev)
+        align = torch.zeros(B, S, Tm, dtype=f32, device=dev)
+        ctx = torch.empty(B, M, dtype=bf, device=dev)
+        pq = torch.empty(B, Hd, dtype=f32, device=dev) if self.att == hip.ATT_BAHDANAU else None
+        z = torch.empty(B, 4 * Hd, dtype=f32, device=dev)
+        logits = torch.zeros(B, S, Vp, dtype=f32, device=dev)
+        ids = torch.full((B,), d.sos_id, dtype=torch.int32, device=dev)
+        samples = torch.full((B, S), d.eos_id, dtype=torch.int32, device=dev)
+        finished = torch.zeros(B, dtype=torch.bool, device=dev)
+        final_len = torch.zeros(B, dtype=torch.int32, device=dev)
+        steps = 0
+        for t in range(S):
+            cur, nxt = t & 1, (t + 1) & 1
+            hip.gemm_nt(ah[cur], self.kcT, z, B, 4 * Hd, W, lda=W, ldb=W, ldc=4 * Hd)
+            s = self._step_struct(
+                B, Tm, hip.addr(z), hip.addr(ids), 1, hip.addr(cs[cur]), Hd, hip.addr(gates), 4 * Hd,
+                hip.addr(cs[nxt]), Hd, hip.addr(h_t), Hd, hip.addr(ah[nxt], M), W, keys, memory, mem_len,
+                hip.addr(align, t * Tm), 0, S * Tm, hip.addr(pq) if pq is not None else 0, Hd,
+                hip.addr(ctx), M, hip.addr(ah[nxt]), W)
+            hip.check(lib.las_decoder_step_fwd(C.byref(s), parts, st))
+            lg = logits[:, t]
+            hip.gemm_nt(ctx, self.wprojT, lg, B, Vp, M, lda=M, ldb=M, ldc=S * Vp, bias=self.bproj)
+            sample = lg[:, :V].argmax(-1).to(torch.int32)
+            samples[:, t] = sample
+            final_len = torch.where(finished, final_len, torch.full_like(final_len, t + 1))
+            finished = finished | (sample == d.eos_id)
+            ids = sample.contiguous()
+            steps = t + 1
+            if bool(finished.all()):
+                break
+        return logits[:, :steps, :V], samples[:, :steps], final_len, align[:, :steps]
+
+
+def speller(encoder_outputs, encoder_state, decoder_inputs, source_sequence_length, target_sequence_length, mode,
+            hparams, binary_outputs=False, binf_embedding=None, transparent_projection=False, *, variables=None,
+            module=None, num_steps=None):
+    """las/model.py:205-349.  Returns (decoder_outputs, final_context_state, final_sequence_length) where
+    decoder_outputs has ``rnn_output`` (logits) and ``sample_id``."""
+    import collections
+    if binary_outputs or binf_embedding is not None or transparent_projection:
+        raise ValueError('binary-feature decoders are not implemented on the HIP path this round')
+    if getattr(hparams, 'beam_width', 0) and mode == PREDICT:
+        raise ValueError('beam search is not implemented on the HIP path this round')
+    if module is None:
+        module = Speller(hparams, variables, encoder_outputs.shape[-1])
+    Out = collections.namedtuple('BasicDecoderOutput', ['rnn_output', 'sample_id'])
+    if mode == TRAIN:
+        if hparams.sampling_probability > 0.0:
+            raise ValueError('sampling_probability > 0 is not implemented on the HIP path this round')
+        U = num_steps if num_steps is not None else int(target_sequence_length.max().item())
+        logits = module.forward_train(encoder_outputs, source_sequence_length, encoder_state, decoder_inputs, U)
+        V = module.V
+        return Out(logits, None), module, target_sequence_length
+    max_len = int(source_sequence_length.max().item())
+    max_it = int(round(max_len * hparams.decoding_length_factor))       # las/model.py:270-274
+    logits, ids, final_len, align = module.forward_greedy(encoder_outputs, source_sequence_length, encoder_state,
+                                                          max_it)
+    module.alignment_history = align
+    return Out(logits, ids), module, final_len

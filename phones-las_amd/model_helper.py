@@ -1,0 +1,305 @@
+"""MI355X host side of the reference's ``model_helper.py``: ``las_model_fn`` (model_helper.py:165-444),
+the losses (model_helper.py:20-78) and the train op (model_helper.py:403-417) over liblas_hip.so.
+
+TF keeps variables in the graph; here ``LasModel`` owns them as ONE flat fp32 buffer (plus flat gradient
+and Adam slot buffers) with per-tensor views named like the TF variables.  The train op is
+L2 -> per-tensor clip_by_norm(2) -> [RCCL all-reduce(sum) when data-parallel] -> TF-form Adam,
+i.e. CrossShardOptimizer's order (model_helper.py:405-417).
+"""
+import collections
+import math
+
+import numpy as np
+import torch
+
+from . import hip
+from .las import model as las_model
+from .las.ops import TRAIN, EVAL, PREDICT
+from .utils import metrics_utils
+
+__all__ = ['las_model_fn', 'LasModel', 'param_table', 'compute_loss', 'EstimatorSpec', 'GRAD_NORM']
+
+GRAD_NORM = 2            # model_helper.py:16
+EstimatorSpec = collections.namedtuple('EstimatorSpec', ['mode', 'loss', 'train_op', 'predictions', 'eval_metric_ops'])
+EstimatorSpec.__new__.__defaults__ = (None, None, None, None)
+
+
+def _enc_depth(e):
+    dirs = 1 if e.unidirectional else 2
+    if e.use_pyramidal:
+        return dirs * e.num_units * (1 if e.num_layers == 1 else 2)
+    return dirs * e.num_units
+
+
+def param_table(params):
+    """Ordered [(tf_variable_name, shape, initializer)] of every trainable variable the model_fn creates."""
+    e, d = params.encoder, params.decoder
+    H = e.num_units
+    dirs = ['fw'] if e.unidirectional else ['fw', 'bw']
+    out = []
+    D = params.num_channels
+    for l in range(e.num_layers):
+        for dr in dirs:
+            base = ('listener/bilstm_%d/%s/lstm_cell' % (l, dr)) if e.use_pyramidal else \
+                ('listener/%s/multi_rnn_cell/cell_%d/lstm_cell' % (dr, l))
+            out.append((base + '/kernel', (D + H, 4 * H), 'lstm'))
+            out.append((base + '/bias', (4 * H,), 'zeros'))
+        D = len(dirs) * H * (1 if l == 0 else 2) if e.use_pyramidal else H
+    M, Hd, V = _enc_depth(e), d.num_units, d.target_vocab_size
+    A = (2 * d.binf_count) if getattr(d, 'binf_projection', False) else (d.attention_layer_size or M)
+    E = d.embedding_size if d.embedding_size else V
+    if d.embedding_size:
+        out.append(('speller/target_embedding', (V, d.embedding_size), 'glorot'))
+    out.append(('speller/memory_layer/kernel', (M, Hd), 'glorot'))
+    if d.attention_type in ('bahdanau', 'bahdanau_monotonic', 'custom'):
+        out.append(('speller/query_layer/kernel', (Hd, Hd), 'glorot'))
+    if d.attention_type in ('bahdanau', 'bahdanau_monotonic'):
+        out.append(('speller/attention_v', (Hd,), 'glorot_v'))
+    if d.attention_type in ('luong_monotonic', 'bahdanau_monotonic'):
+        out.append(('speller/attention_score_bias', (1,), 'zeros'))
+    if d.attention_layer_size or getattr(d, 'binf_projection', False):
+        out.append(('speller/attention_layer/kernel', (Hd + M, A), 'glorot'))
+    for l in range(d.num_layers):
+        if d.bottom_only:
+            din = (E + A) if l == 0 else (Hd + A)
+        else:
+            din = (E + A) if l == 0 else Hd
+        out.append(('speller/decoder_cell_%d/lstm_cell/kernel' % l, (din + Hd, 4 * Hd), 'lstm'))
+        out.append(('speller/decoder_cell_%d/lstm_cell/bias' % l, (4 * Hd,), 'zeros'))
+    out.append(('speller/projection_layer/kernel', (A, V), 'proj'))
+    out.append(('speller/projection_layer/bias', (V,), 'zeros'))
+    if params.ctc_weight > 0:
+        out.append(('ctc_logits/kernel', (M, V + 1), 'glorot'))
+        out.append(('ctc_logits/bias', (V + 1,), 'zeros'))
+    return out
+
+
+def _init_array(shape, init, rng):
+    if init in ('lstm', 'proj'):                       # las/ops.py:12, las/model.py:257
+        return rng.uniform(-0.075, 0.075, size=shape)
+    if init == 'glorot':                               # tf.layers.Dense default kernel initializer
+        lim = math.sqrt(6.0 / (shape[0] + shape[1]))
+        return rng.uniform(-lim, lim, size=shape)
+    if init == 'glorot_v':
+        lim = math.sqrt(6.0 / (shape[0] + 1))
+        return rng.uniform(-lim, lim, size=shape)
+    return np.zeros(shape)
+
+
+class Variables:
+    """Flat fp32 parameter / gradient / Adam-slot buffers with TF-named per-tensor views."""
+
+    def __init__(self, table, device='cuda'):
+        self.table = list(table)
+        offs = [0]
+        for _, shape, _ in self.table:
+            n = int(np.prod(shape))
+            offs.append(offs[-1] + (n + 3) // 4 * 4)          # keep every tensor 16-byte aligned
+        self.offsets = offs
+        self.total = offs[-1]
+        f32 = torch.float32
+        self.flat = torch.zeros(self.total, dtype=f32, device=device)
+        self.grad = torch.zeros(self.total, dtype=f32, device=device)
+        self.m = torch.zeros(self.total, dtype=f32, device=device)
+        self.v = torch.zeros(self.total, dtype=f32, device=device)
+        self.seg = torch.tensor(offs, dtype=torch.int64, device=device)
+        self.sumsq = torch.zeros(len(self.table), dtype=f32, device=device)
+        self.params = self._views(self.flat)
+        self.grads = self._views(self.grad)
+
+    def _views(self, flat):
+        d = collections.OrderedDict()
+        for (name, shape, _), o in zip(self.table, self.offsets):
+            d[name] = flat[o:o + int(np.prod(shape))].view(*shape)
+        return d
+
+    def initialize(self, seed=4321):
+        rng = np.random.default_rng(seed)
+        for name, shape, init in self.table:
+            a = _init_array(shape, init, rng).astype(np.float32)
+            self.params[name].copy_(torch.from_numpy(a))
+
+    def load(self, tensors):
+        for name in self.params:
+            self.params[name].copy_(tensors[name].to(torch.float32))
+
+    def num_parameters(self):
+        return sum(int(np.prod(s)) for _, s, _ in self.table)
+
+
+def compute_loss(logits, targets, final_sequence_length, target_sequence_length, mode, eos_id, grad_scale=1.0,
+                 want_grad=False, vocab=None):
+    """model_helper.py:20-78.  logits fp32 [B,U,ldl] on the device; returns (loss scalar tensor, dlogits or None).
+    TRAIN: weights = sequence_mask(target_len) (model_helper.py:24-30).  EVAL: logits/targets padded to the longer
+    of (target_len, final_len) with zeros / EOS (model_helper.py:54-76)."""
+    B, U, ldl = logits.shape
+    V = vocab if vocab is not None else ldl
+    dev = logits.device
+    if mode != TRAIN:
+        max_ts = int(target_sequence_length.max().item())
+        max_fs = int(final_sequence_length.max().item())
+        L = max(max_ts, max_fs)
+        lg = torch.zeros(B, L, ldl, dtype=torch.float32, device=dev)
+        n = min(max_fs, U)
+        lg[:, :n] = logits[:, :n]
+        tg = torch.full((B, L), eos_id, dtype=torch.int32, device=dev)
+        n = min(L, targets.shape[1])
+        tg[:, :n] = targets[:, :n]
+        lens = torch.maximum(target_sequence_length.to(torch.int32), final_sequence_length.to(torch.int32))
+        logits, targets, target_sequence_length, U = lg, tg, lens, L
+    tg = targets[:, :U].to(torch.int32).contiguous()
+    if tg.shape[1] < U:
+        raise ValueError('targets shorter than the decoded length')
+    loss = torch.zeros(1, dtype=torch.float32, device=dev)
+    dlogits = torch.zeros(B, U, ldl, dtype=torch.bfloat16, device=dev) if want_grad else None
+    hip.check(hip.lib().las_seq_ce_loss(hip.p(logits), ldl, hip.p(tg), hip.p(target_sequence_length.to(torch.int32)),
+                                        B, U, V, float(grad_scale), hip.p(loss), hip.p(dlogits), ldl, hip.stream()))
+    return loss, dlogits
+
+
+class LasModel:
+    """Variables + listener + speller + train op: what tf.estimator.Estimator(model_fn=las_model_fn) holds."""
+
+    def __init__(self, params, seed=4321, world_size=1, process_group=None):
+        if params.ctc_weight > 0:
+            raise ValueError('ctc_weight > 0 is not implemented on the HIP path this round')
+        if params.encoder.dropout > 0 or params.decoder.dropout > 0:
+            raise ValueError('dropout > 0 is not implemented on the HIP path this round (use --dropout 0)')
+        if not torch.cuda.is_available():
+            raise hip.LasError('no HIP device visible: the LAS path has no CPU fallback')
+        hip.lib()
+        self.params = params
+        self.vars = Variables(param_table(params))
+        self.vars.initialize(seed)
+        self.listener = las_model.Listener(params.encoder, self.vars.params, params.num_channels)
+        self.speller = las_model.Speller(params.decoder, self.vars.params, _enc_depth(params.encoder))
+        self.global_step = 0
+        self.step_dev = torch.ones(1, dtype=torch.int32, device='cuda')       # Adam t = global_step + 1
+        self.world_size = world_size
+        self.process_group = process_group
+        self._images_stale = False
+
+    # -- weights --------------------------------------------------------------------------------
+    def load_variables(self, tensors):
+        self.vars.load(tensors)
+        self.refresh_images()
+
+    def refresh_images(self):
+        self.listener.refresh(self.vars.params)
+        self.speller.refresh(self.vars.params)
+        self._images_stale = False
+
+    # -- forward / backward ---------------------------------------------------------------------
+    def forward_train(self, features, labels, num_steps=None):
+        """Forward of las_model_fn in TRAIN mode.  Returns (audio_loss [1], logits [B,U,Vp], dlogits)."""
+        if self._images_stale:
+            self.refresh_images()
+        x = features['encoder_inputs']
+        src_len = features['source_sequence_length']
+        tin, tout, tlen = labels['targets_inputs'], labels['targets_outputs'], labels['target_sequence_length']
+        (mem, mem_len), state = self.listener.forward(x, src_len, TRAIN)
+        U = num_steps if num_steps is not None else int(tlen.max().item())
+        logits = self.speller.forward_train(mem, mem_len, state, tin, U)
+        loss, dlogits = compute_loss(logits, tout, None, tlen, TRAIN, self.params.decoder.eos_id,
+                                     grad_scale=1.0 / self.world_size, want_grad=True, vocab=self.speller.V)
+        return loss, logits, dlogits
+
+    def backward(self, dlogits):
+        g = self.vars.grads
+        dmem, d_state = self.speller.backward(dlogits, g)
+        ds = None
+        if d_state is not None:
+            nd = 1 if self.params.encoder.unidirectional else 2
+            H = self.params.encoder.num_units
+            dc = torch.zeros(nd, dmem.shape[0], H, dtype=torch.float32, device=dmem.device)
+            dh = torch.zeros_like(dc)
+            dc[0].copy_(d_state[0])
+            dh[0].copy_(d_state[1])
+            ds = (dc, dh)
+        self.listener.backward(dmem, ds, g)
+
+    def apply_gradients(self):
+        """model_helper.py:411-417 on the flat buffers (+ the data-parallel sum of model_helper.py:405-406)."""
+        v, p = self.vars, self.params
+        lib, st = hip.lib(), hip.stream()
+        nseg = len(v.table)
+        hip.check(lib.las_grad_l2_norms(hip.p(v.grad), hip.p(v.flat), hip.p(v.seg), nseg, v.total,
+                                        float(p.l2_reg_scale) / self.world_size, hip.p(v.sumsq), st))
+        hip.check(lib.las_grad_clip(hip.p(v.grad), hip.p(v.seg), nseg, v.total, hip.p(v.sumsq), float(GRAD_NORM), st))
+        if self.world_size > 1:
+            torch.distributed.all_reduce(v.grad, op=torch.distributed.ReduceOp.SUM, group=self.process_group)
+        hip.check(lib.las_adam_update(hip.p(v.flat), hip.p(v.m), hip.p(v.v), hip.p(v.grad), v.total,
+                                      float(p.learning_rate), 0.9, 0.999, 1e-8, 0, hip.p(self.step_dev), st))
+        hip.check(lib.las_counter_add(hip.p(self.step_dev), 1, st))
+        self._images_stale = True
+
+    def l2_loss(self):
+        out = torch.zeros(1, dtype=torch.float32, device='cuda')
+        hip.check(hip.lib().las_sumsq(hip.p(self.vars.flat), self.vars.total, hip.p(out), hip.stream()))
+        return out * (0.5 * float(self.params.l2_reg_scale))
+
+    def train_step(self, features, labels, num_steps=None):
+        """One optimiser step; returns the loss (audio loss + L2 term) as a device scalar tensor."""
+        self.vars.grad.zero_()
+        audio_loss, _, dlogits = self.forward_train(features, labels, num_steps)
+        loss = audio_loss + self.l2_loss()
+        self.backward(dlogits)
+        self.apply_gradients()
+        self.refresh_images()
+        self.global_step += 1
+        return loss
+
+    # -- inference ------------------------------------------------------------------------------
+    def predict(self, features):
+        """PREDICT branch of las_model_fn (model_helper.py:253-297) with greedy decoding."""
+        if self._images_stale:
+            self.refresh_images()
+        x, src_len = features['encoder_inputs'], features['source_sequence_length']
+        (mem, mem_len), state = self.listener.forward(x, src_len, PREDICT)
+        max_it = int(round(int(mem_len.max().item()) * self.params.decoder.decoding_length_factor))
+        logits, ids, final_len, align = self.speller.forward_greedy(mem, mem_len, state, max_it)
+        emb_c = torch.cat([s.c for s in state], 1) if isinstance(state[0], tuple) else state.c
+        emb_h = torch.cat([s.h for s in state], 1) if isinstance(state[0], tuple) else state.h
+        return {
+            'encoder_out': mem, 'source_length': mem_len, 'embedding': torch.stack([emb_c, emb_h], 1),
+            'sample_ids': ids, 'alignment': align, 'probs': torch.softmax(logits, -1), 'logits': logits,
+            'final_sequence_length': final_len,
+        }
+
+    def evaluate(self, features, labels):
+        """EVAL branch: free-running greedy decode, padded loss (model_helper.py:54-76), edit distance."""
+        pred = self.predict(features)
+        loss, _ = compute_loss(pred['logits'].contiguous(), labels['targets_outputs'], pred['final_sequence_length'],
+                               labels['target_sequence_length'], EVAL, self.params.decoder.eos_id)
+        ed = metrics_utils.edit_distance(pred['sample_ids'], labels['targets_outputs'], self.params.decoder.eos_id,
+                                         self.params.mapping)
+        return loss, ed, pred
+
+
+def las_model_fn(features, labels, mode, config, params, binf2phone=None, run_name=None,
+                 transparent_projection=False, *, model=None):
+    """model_helper.py:165-444.  ``model`` is the LasModel that holds the variables (an Estimator would own it);
+    when omitted a freshly initialised one is built.  Returns an EstimatorSpec whose ``train_op`` is a callable
+    that applies one optimiser step (TF returns a graph op)."""
+    if binf2phone is not None or transparent_projection:
+        raise ValueError('binary-feature outputs are not implemented on the HIP path this round')
+    if model is None:
+        model = LasModel(params)
+    if mode == PREDICT:
+        return EstimatorSpec(mode, predictions=model.predict(features))
+    if mode == EVAL:
+        loss, ed, pred = model.evaluate(features, labels)
+        return EstimatorSpec(mode, loss=loss, predictions=pred,
+                             eval_metric_ops={'edit_distance': float(np.mean(ed))})
+    model.vars.grad.zero_()
+    audio_loss, logits, dlogits = model.forward_train(features, labels)
+    loss = audio_loss + model.l2_loss()
+    sample_ids = logits[..., :model.speller.V].argmax(-1).to(torch.int32)
+
+    def train_op():
+        model.backward(dlogits)
+        model.apply_gradients()
+        model.refresh_images()
+        model.global_step += 1
+
+    return EstimatorSpec(mode, loss=loss, train_op=train_op, predictions={'sample_ids': sample_ids, 'logits': logits})

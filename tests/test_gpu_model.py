@@ -1,0 +1,137 @@
+"""GPU parity of the whole training path (listener -> speller -> loss -> backward -> clip/Adam) against the
+oracle in its bf16 storage model on identical seeded inputs, through the C-ABI (liblas_hip.so).
+
+Stated tolerances: logits/loss 2e-2 of the max-abs (bf16 operands, fp32 accumulate vs float64);
+gradients 5e-2 of the per-tensor max-abs (the device rounds dz/dlogits/d-context to bf16 before its
+GEMMs, the oracle differentiates exactly); optimiser kernels 1e-5 (pure fp32 arithmetic)."""
+import numpy as np
+import pytest
+import torch
+
+from tests.helpers import make_hparams, make_batch, to_device, relerr
+
+pytestmark = pytest.mark.gpu
+DT = torch.float64
+
+
+def _models(att, **kw):
+    from oracle import las_oracle as O
+    from phones_las_amd import model_helper as mh
+    ohp, params = make_hparams(att=att, **kw)
+    op = O.init_params(ohp, bias_scale=0.1)
+    model = mh.LasModel(params)
+    assert [n for n, _, _ in mh.param_table(params)] == [n for n, _, _ in O.param_table(ohp)]
+    model.load_variables({k: v for k, v in op.items()})
+    return O, ohp, op, model
+
+
+@pytest.mark.parametrize('att', ['luong', 'bahdanau'])
+def test_train_forward_and_gradients_vs_oracle(att):
+    O, ohp, op, model = _models(att)
+    batch = make_batch(src_len=[12, 7, 10], tgt_len=[6, 4, 5])
+    feats, labels = to_device(batch)
+    out = O.train_step(ohp, op, None, None, 1, batch, mxu='bf16')
+    model.vars.grad.zero_()
+    loss, logits, dlogits = model.forward_train(feats, labels)
+    torch.cuda.synchronize()
+    ref_logits = out['aux']['logits']
+    V = ohp.decoder.target_vocab_size
+    for b, n in enumerate([6, 4, 5]):
+        assert relerr(logits[b, :n, :V], ref_logits[b, :n]) < 2e-2
+    assert abs(float(loss) - float(out['aux']['ce'].detach())) < 2e-2 * abs(float(out['aux']['ce'].detach()))
+    total = loss + model.l2_loss()
+    assert abs(float(total) - float(out['loss'])) < 2e-2 * abs(float(out['loss']))
+    # backward (+ L2 term) vs autograd of the oracle
+    model.backward(dlogits)
+    hp = model.params
+    from phones_las_amd import hip
+    v = model.vars
+    hip.check(hip.lib().las_grad_l2_norms(hip.p(v.grad), hip.p(v.flat), hip.p(v.seg), len(v.table), v.total,
+                                          float(hp.l2_reg_scale), hip.p(v.sumsq), hip.stream()))
+    torch.cuda.synchronize()
+    for i, (name, _, _) in enumerate(v.table):
+        g, r = v.grads[name], out['grads'][name]
+        assert relerr(g, r) < 5e-2, name
+        assert abs(float(v.sumsq[i]) - float((r * r).sum())) <= 0.1 * float((r * r).sum()) + 1e-12, name
+
+
+def test_train_step_updates_match_oracle_adam_given_same_grads():
+    O, ohp, op, model = _models('luong')
+    v = model.vars
+    g = torch.Generator().manual_seed(0)
+    grads = {n: torch.randn(tuple(s), generator=g, dtype=DT) * (3.0 if i % 2 else 0.01) for i, (n, s, _) in enumerate(v.table)}
+    for n in grads:
+        v.grads[n].copy_(grads[n].float())
+    # reference: + l2*theta, per-tensor clip to 2, TF Adam
+    full = {n: grads[n].float().double() + ohp.l2_reg_scale * op[n] for n in grads}
+    clipped = {n: full[n] * 2.0 / max(float(full[n].norm()), 2.0) for n in full}
+    zeros = {n: torch.zeros_like(op[n]) for n in op}
+    newp, newm, newv = O.adam_apply(op, zeros, zeros, clipped, 1, ohp.learning_rate)
+    model.apply_gradients()
+    torch.cuda.synchronize()
+    for n in grads:
+        assert relerr(v.grads[n], clipped[n]) < 1e-5, n
+        assert float((v.params[n].double().cpu() - newp[n]).abs().max()) < 2e-6, n
+    assert int(model.step_dev.item()) == 2
+    # second step uses t = 2 from the device counter
+    newp2, _, _ = O.adam_apply(newp, newm, newv, clipped, 2, ohp.learning_rate)
+    for n in grads:
+        v.grads[n].copy_(clipped[n].float() - ohp.l2_reg_scale * v.params[n].cpu().double().float())
+    model.apply_gradients()
+    torch.cuda.synchronize()
+    for n in grads:
+        assert float((v.params[n].double().cpu() - newp2[n]).abs().max()) < 5e-6, n
+
+
+def test_seq_ce_loss_kernel_vs_oracle():
+    from oracle import las_oracle as O
+    from phones_las_amd import model_helper as mh
+    from phones_las_amd.las.ops import TRAIN
+    torch.manual_seed(0)
+    B, U, V, Vp = 5, 7, 11, 16
+    logits = torch.randn(B, U, Vp) * 3
+    tg = torch.randint(0, V, (B, U))
+    ln = torch.tensor([7, 1, 4, 6, 3])
+    lr = logits[..., :V].double().requires_grad_(True)
+    ref = O.compute_loss_train(lr, tg, ln)
+    ref.backward()
+    loss, dl = mh.compute_loss(logits.cuda(), tg.to(torch.int32).cuda(), None, ln.to(torch.int32).cuda(), TRAIN, 2,
+                               grad_scale=0.5, want_grad=True, vocab=V)
+    torch.cuda.synchronize()
+    assert abs(float(loss) - float(ref)) < 1e-5 * abs(float(ref))
+    assert relerr(dl[..., :V].float(), 0.5 * lr.grad) < 1e-2           # bf16 storage of dlogits
+    assert float(dl[..., V:].float().abs().max()) == 0.0
+
+
+def test_model_fn_train_reduces_loss_and_eval_runs():
+    from phones_las_amd import model_helper as mh
+    from phones_las_amd.las.ops import TRAIN, EVAL, PREDICT
+    O, ohp, op, model = _models('luong', lr=1e-2)
+    batch = make_batch(src_len=[12, 7, 10], tgt_len=[6, 4, 5])
+    feats, labels = to_device(batch)
+    losses = []
+    for _ in range(30):
+        spec = mh.las_model_fn(feats, labels, TRAIN, None, model.params, model=model)
+        spec.train_op()
+        losses.append(float(spec.loss))
+    assert losses[-1] < 0.7 * losses[0], losses
+    spec = mh.las_model_fn(feats, labels, EVAL, None, model.params, model=model)
+    assert np.isfinite(float(spec.loss)) and 0.0 <= spec.eval_metric_ops['edit_distance']
+    pred = mh.las_model_fn(feats, None, PREDICT, None, model.params, model=model).predictions
+    assert pred['sample_ids'].shape[0] == 3 and pred['alignment'].shape[-1] == 6
+
+
+def test_greedy_decode_vs_oracle_first_steps():
+    O, ohp, op, model = _models('luong')
+    batch = make_batch(src_len=[12, 7, 10], tgt_len=[6, 4, 5])
+    feats, labels = to_device(batch)
+    (mem, ml), st = O.listener(batch['encoder_inputs'], batch['source_sequence_length'], op, ohp.encoder, 'bf16')
+    rl, rids, rfl, _ = O.speller_greedy(ohp, op, mem, ml, st, 'bf16')
+    pred = model.predict(feats)
+    torch.cuda.synchronize()
+    assert relerr(pred['encoder_out'].float(), mem) < 1.6e-2
+    assert pred['source_length'].cpu().tolist() == ml.tolist()
+    assert relerr(pred['logits'][:, 0], rl[:, 0]) < 2e-2
+    n = min(pred['sample_ids'].shape[1], rids.shape[1])
+    agree = (pred['sample_ids'][:, :n].cpu() == rids[:, :n]).float().mean()
+    assert float(agree) > 0.8
