@@ -218,20 +218,33 @@ class LasModel:
             ds = (dc, dh)
         self.listener.backward(dmem, ds, g)
 
-    def apply_gradients(self):
-        """model_helper.py:411-417 on the flat buffers (+ the data-parallel sum of model_helper.py:405-406)."""
+    def clip_gradients(self):
+        """L2 gradient + per-tensor clip_by_norm(GRAD_NORM) on the flat buffers (model_helper.py:411-416)."""
         v, p = self.vars, self.params
         lib, st = hip.lib(), hip.stream()
         nseg = len(v.table)
         hip.check(lib.las_grad_l2_norms(hip.p(v.grad), hip.p(v.flat), hip.p(v.seg), nseg, v.total,
                                         float(p.l2_reg_scale) / self.world_size, hip.p(v.sumsq), st))
         hip.check(lib.las_grad_clip(hip.p(v.grad), hip.p(v.seg), nseg, v.total, hip.p(v.sumsq), float(GRAD_NORM), st))
+
+    def all_reduce_gradients(self):
+        """CrossShardOptimizer's cross-replica sum (model_helper.py:405-406): one RCCL all-reduce, after the clip."""
         if self.world_size > 1:
-            torch.distributed.all_reduce(v.grad, op=torch.distributed.ReduceOp.SUM, group=self.process_group)
+            torch.distributed.all_reduce(self.vars.grad, op=torch.distributed.ReduceOp.SUM, group=self.process_group)
+
+    def adam_update(self):
+        """tf.train.AdamOptimizer.apply_gradients + global_step increment (model_helper.py:404,417)."""
+        v, p = self.vars, self.params
+        lib, st = hip.lib(), hip.stream()
         hip.check(lib.las_adam_update(hip.p(v.flat), hip.p(v.m), hip.p(v.v), hip.p(v.grad), v.total,
                                       float(p.learning_rate), 0.9, 0.999, 1e-8, 0, hip.p(self.step_dev), st))
         hip.check(lib.las_counter_add(hip.p(self.step_dev), 1, st))
         self._images_stale = True
+
+    def apply_gradients(self):
+        self.clip_gradients()
+        self.all_reduce_gradients()
+        self.adam_update()
 
     def l2_loss(self):
         out = torch.zeros(1, dtype=torch.float32, device='cuda')
