@@ -76,6 +76,7 @@ def time_dominant_kernel(c, reps=5):
     """HIP-event timing of the dominant kernel (the layer-1 forward recurrence: the longest serial chain)
     on its own, on torch's current stream (the stream the library launches on)."""
     from phones_las_amd import hip
+    from phones_las_amd.las import ops
     B, T, H = c['B'], c['T'], c['H']
     dev = 'cuda'
     xproj0 = torch.randn(B, T, 8 * H, device=dev) * 0.5
@@ -85,6 +86,7 @@ def time_dominant_kernel(c, reps=5):
     cbuf = torch.empty(B, T, 2 * H, device=dev)
     cl = torch.empty(2, B, H, device=dev)
     hl = torch.empty(2, B, H, device=dev)
+    ws = ops.lstm_workspace(B, H, 2)
     lib = hip.lib()
     times = []
     for i in range(reps + 1):
@@ -92,11 +94,12 @@ def time_dominant_kernel(c, reps=5):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         hip.check(lib.las_lstm_recurrent_fwd(hip.p(xproj), hip.p(khp), hip.p(length), hip.p(y), hip.p(cbuf), hip.p(cl),
-                                             hip.p(hl), B, T, H, 2, hip.stream()))
+                                             hip.p(hl), hip.p(ws), B, T, H, 2, hip.stream()))
         e1.record()
         e1.synchronize()
         if i:
             times.append(e0.elapsed_time(e1))
+    ops.check_lstm_status(B, H, 2)
     ms = sum(times) / len(times)
     flops = B * T * 2 * 2 * H * 4 * H          # recurrent GEMM h_{t-1} K_h of both directions
     return ms, flops

@@ -99,8 +99,14 @@ int las_lstm_pack_recurrent(const float* kernel_h, int H, las_bf16* packed, void
  * (state carried through t >= length, Appendix A.3).  Direction 1 runs the time-reversed
  * recurrence of bidirectional_dynamic_rnn (reverse_sequence on the valid prefix). */
 int las_lstm_recurrent_fwd(float* xproj, const las_bf16* wpacked, const int32_t* length, las_bf16* y,
-                           float* cbuf, float* c_last, float* h_last, int B, int T, int H, int ndir,
-                           void* stream);
+                           float* cbuf, float* c_last, float* h_last, void* workspace, int B, int T, int H,
+                           int ndir, void* stream);
+
+/* Bytes of device scratch the two recurrent kernels need for (B, H, ndir): a status word plus the
+ * inter-workgroup exchange buffer of the cooperating groups (0 = unsupported num_units).  The calls
+ * zero it themselves (a memset node per launch).  After a launch the first uint32 is 0, or non-zero
+ * if a bounded inter-workgroup wait timed out (results are then invalid). */
+size_t las_lstm_workspace_bytes(int B, int H, int ndir);
 
 /* Backward recurrence (reverse-mode AD of the loop above).
  * gates/cbuf: saved by the forward.  dy [B,T,ndir*H] fp32: gradient w.r.t. y.  dc_last/dh_last
@@ -109,7 +115,7 @@ int las_lstm_recurrent_fwd(float* xproj, const las_bf16* wpacked, const int32_t*
  * the caller derives dX, dK_x, dK_h, db from it with las_gemm_nt / las_gemm_tn / las_colsum. */
 int las_lstm_recurrent_bwd(const float* gates, const float* cbuf, const float* dy, const float* dc_last,
                            const float* dh_last, const las_bf16* kh_bf16, const int32_t* length,
-                           las_bf16* dz, int B, int T, int H, int ndir, void* stream);
+                           las_bf16* dz, void* workspace, int B, int T, int H, int ndir, void* stream);
 
 /* len_out[b] = len[b]/2 + len[b]%2  (las/ops.py:65 pyramidal_stack). */
 int las_pyramid_lengths(const int32_t* len_in, int32_t* len_out, int B, void* stream);

@@ -1,36 +1,59 @@
 // Listener recurrence: tf.nn.(bidirectional_)dynamic_rnn over LSTMCell (las/ops.py:10-46) as two
-// persistent kernels (forward, backward-in-time) on gfx950.
+// persistent, weight-stationary kernels (forward, backward-in-time) on gfx950.
 //
-// Work decomposition: the batch is cut into slices of 16 utterances (the M of
-// v_mfma_f32_16x16x32_bf16); one 256-thread workgroup owns one (slice, direction) chain for the whole
-// sequence, so there is NO inter-workgroup communication.  Wave w owns hidden units
-// [w*H/4, (w+1)*H/4) for all four gates, so i, j, f, o of one (utterance, unit) sit in the same lane's
-// accumulators (C/D layout: col = lane&15 -> unit, row = (lane>>4)*4 + reg -> utterance) and the gate
-// math needs no cross-lane traffic.  h_t crosses waves once per step through a double-buffered 16 x H
-// bf16 LDS tile (one barrier per step) from which every wave reads its A fragments.  K_h is streamed
-// from L2 each step in MFMA-fragment-major order (forward) / natural order (backward).
+// Decomposition.  The batch is cut into slices of 16 utterances (the M of v_mfma_f32_16x16x32_bf16).
+// One (slice, direction) pair is a serial chain of T dependent steps; it is run by a GROUP of G
+// co-resident 256-thread workgroups ("members").  Member m owns hidden units [m*H/G, (m+1)*H/G): each of
+// its 4 waves owns H/(4G) units for all four gates and keeps the matching columns of K_h (forward) /
+// rows of K_h (backward) in REGISTERS for the whole sequence as ready-made MFMA B fragments — the
+// recurrent weights are read from memory once per launch, not once per step.  i, j, f, o of one
+// (utterance, unit) land in the same lane (C/D layout col = lane&15 -> unit, row = (lane>>4)*4+reg ->
+// utterance), so the gate math needs no cross-lane traffic.
+//
+// Per step the members all-gather what the next product needs (h_t: 16 x H bf16 forward; dz_t:
+// 16 x 4H bf16 backward).  Inside a member it goes through a double-buffered LDS tile (one barrier per
+// step); between members through 8-byte {tag, 2 x bf16} granules in a global exchange buffer, stored
+// and polled with agent-scope relaxed atomics (write-through, L1-bypassing): the data is its own flag
+// (cdna_hip_programming.md Guideline 16, form R2), tag = step epoch, buffer zeroed by a memset node at
+// every launch, two parity slots so a fast member cannot overwrite what a slow one still reads.
+// Results never depend on workgroup placement; blockIdx = group + member*ngroups only makes the members
+// of a group share an XCD under round-robin dispatch when ngroups % 8 == 0 (speed).  Every spin is
+// bounded: on timeout the kernel sets a status word and returns.
 #include "las_common.h"
 
 namespace {
 
+typedef unsigned long long u64;
+typedef __attribute__((address_space(1))) u64 gu64;
+
+constexpr unsigned SPIN_LIMIT = 1u << 20;
+
+__device__ __forceinline__ void granule_store(u64* p, unsigned tag, unsigned value) {
+  __hip_atomic_store(p, ((u64)tag << 32) | value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ u64 granule_load(const u64* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// number of cooperating workgroups per chain
+__host__ __device__ constexpr int coop_members(int H) { return H <= 128 ? 1 : H / 64; }
+
 // ------------------------------------------------------------------------------------------------
-// pack K_h [H,4H] fp32 -> fragment-major bf16:
-//   packed[((((w*KC + kc)*4 + g)*UB + ub)*64 + lane)*8 + j] =
-//       K_h[kc*32 + 8*(lane>>4) + j][g*H + w*(H/4) + ub*16 + (lane&15)]
+// pack K_h [H,4H] fp32 -> MFMA-B-fragment-major bf16, grouped by 16-unit block:
+//   packed[(((ublk*KC + kc)*4 + g)*64 + lane)*8 + j] = K_h[kc*32 + 8*(lane>>4) + j][g*H + ublk*16 + (lane&15)]
 // ------------------------------------------------------------------------------------------------
 __global__ void pack_recurrent_kernel(const float* kh, int H, unsigned short* packed) {
-  const int UB = H / 64, KC = H / 32;
+  const int KC = H / 32;
   const int64_t total = (int64_t)H * 4 * H;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
     int64_t r = i;
     const int j = (int)(r % 8); r /= 8;
     const int lane = (int)(r % 64); r /= 64;
-    const int ub = (int)(r % UB); r /= UB;
     const int g = (int)(r % 4); r /= 4;
     const int kc = (int)(r % KC); r /= KC;
-    const int w = (int)r;
+    const int ublk = (int)r;
     const int k = kc * 32 + 8 * (lane >> 4) + j;
-    const int col = g * H + w * (H / 4) + ub * 16 + (lane & 15);
+    const int col = g * H + ublk * 16 + (lane & 15);
     packed[i] = las_f2bf(kh[(int64_t)k * 4 * H + col]);
   }
 }
@@ -42,12 +65,21 @@ template <int H>
 __global__ __launch_bounds__(256, 1) void lstm_fwd_kernel(float* __restrict__ xproj, const unsigned short* __restrict__ wpacked,
                                                           const int32_t* __restrict__ length, unsigned short* __restrict__ y,
                                                           float* __restrict__ cbuf, float* __restrict__ c_last,
-                                                          float* __restrict__ h_last, int B, int T, int ndir) {
-  constexpr int UB = H / 64, KC = H / 32, HS = H + 8;
-  __shared__ __attribute__((aligned(16))) unsigned short hlds[2][16][HS];
+                                                          float* __restrict__ h_last, u64* __restrict__ exch,
+                                                          unsigned* __restrict__ status, int B, int T, int ndir, int ngroups) {
+  constexpr int G = coop_members(H);
+  constexpr int HS = H / G;            // units per member
+  constexpr int UB = HS / 64;          // 16-unit blocks per wave
+  constexpr int KC = H / 32;
+  constexpr int LS = H + 8;            // LDS row stride (elements)
+  constexpr int NGRAN = 8 * HS;        // granules a member publishes per step (2 rows x 1 unit each)
+  __shared__ __attribute__((aligned(16))) unsigned short hlds[2][16][LS];
+  __shared__ int fail_flag;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int slice = blockIdx.x, dir = blockIdx.y;
+  const int group = blockIdx.x % ngroups, member = blockIdx.x / ngroups;
+  const int nslices = ngroups / ndir;
+  const int slice = group % nslices, dir = group / nslices;
   const int l15 = lane & 15, lq = lane >> 4;
 
   int len[4], bidx[4];
@@ -60,19 +92,33 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_kernel(float* __restrict__ xp
   }
   smax = (int)las_wave_max((float)smax);
 
+  // register-resident B fragments of this wave's K_h columns
+  bf16x8 wf[UB][KC][4];
+#pragma unroll
+  for (int ub = 0; ub < UB; ++ub) {
+    const int ublk = (member * 4 + wave) * UB + ub;
+#pragma unroll
+    for (int kc = 0; kc < KC; ++kc)
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+        wf[ub][kc][g] = *reinterpret_cast<const bf16x8*>(wpacked + (int64_t)dir * H * 4 * H +
+                                                          ((int64_t)((ublk * KC + kc) * 4 + g) * 64 + lane) * 8);
+  }
+
   float c[UB][4], h[UB][4];
 #pragma unroll
   for (int ub = 0; ub < UB; ++ub)
 #pragma unroll
     for (int r = 0; r < 4; ++r) { c[ub][r] = 0.f; h[ub][r] = 0.f; }
 
-  for (int i = tid; i < 16 * HS; i += 256) (&hlds[0][0][0])[i] = 0;
+  for (int i = tid; i < 2 * 16 * LS; i += 256) (&hlds[0][0][0])[i] = 0;
+  if (tid == 0) fail_flag = 0;
   __syncthreads();
 
-  const unsigned short* wp = wpacked + (int64_t)dir * H * 4 * H + (int64_t)wave * (KC * 4 * UB * 512) + lane * 8;
-  const int64_t xrow = (int64_t)ndir * 4 * H;   // xproj row stride
+  const int64_t xrow = (int64_t)ndir * 4 * H;
   const int64_t yrow = (int64_t)ndir * H;
-  const int unit0 = wave * (H / 4) + l15;
+  const int unit0 = member * HS + wave * (HS / 4) + l15;      // + ub*16
+  u64* ex_group = exch + (int64_t)group * G * NGRAN;           // + parity*ngroups*G*NGRAN + member*NGRAN
 
   int cur = 0;
   for (int s = 0; s < smax; ++s) {
@@ -84,7 +130,7 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_kernel(float* __restrict__ xp
       const int pos = dir == 0 ? s : len[r] - 1 - s;
       rowoff[r] = act[r] ? ((int64_t)bidx[r] * T + pos) : 0;
     }
-    // x_t K_x + b for this step: issued now, consumed after the MFMA loop
+    // x_t K_x + b of this step: issued now, consumed after the MFMAs
     float xp[4][UB][4];
 #pragma unroll
     for (int g = 0; g < 4; ++g)
@@ -94,27 +140,62 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_kernel(float* __restrict__ xp
         for (int r = 0; r < 4; ++r)
           xp[g][ub][r] = act[r] ? xproj[rowoff[r] * xrow + dir * 4 * H + g * H + unit0 + ub * 16] : 0.f;
 
+    // all-gather h_{s-1}: peers' slices arrive as granules tagged with epoch s
+    if constexpr (G > 1) if (s > 0) {
+      const u64* src = ex_group + (int64_t)((s - 1) & 1) * ngroups * G * NGRAN;
+      constexpr int PER = (G - 1) * NGRAN / 256;     // granules per thread
+      u64 v[PER];
+      unsigned spins = 0;
+      bool ok;
+      do {
+        ok = true;
+#pragma unroll
+        for (int i = 0; i < PER; ++i) {
+          const int q = tid + i * 256;
+          const int pi = q / NGRAN, gi = q % NGRAN;
+          const int peer = pi + (pi >= member ? 1 : 0);
+          v[i] = granule_load(src + (int64_t)peer * NGRAN + gi);
+          ok = ok && ((unsigned)(v[i] >> 32) == (unsigned)s);
+        }
+        if (!ok) {
+          if (++spins > SPIN_LIMIT) { fail_flag = 1; break; }
+          __builtin_amdgcn_s_sleep(1);
+        }
+      } while (!ok);
+#pragma unroll
+      for (int i = 0; i < PER; ++i) {
+        const int q = tid + i * 256;
+        const int pi = q / NGRAN, gi = q % NGRAN;
+        const int peer = pi + (pi >= member ? 1 : 0);
+        const int rp = gi / HS, ul = gi % HS;
+        const unsigned val = (unsigned)v[i];
+        hlds[cur][rp * 2][peer * HS + ul] = (unsigned short)(val & 0xffffu);
+        hlds[cur][rp * 2 + 1][peer * HS + ul] = (unsigned short)(val >> 16);
+      }
+    }
+    __syncthreads();
+    if (fail_flag) break;
+
     f32x4 acc[4][UB];
 #pragma unroll
     for (int g = 0; g < 4; ++g)
 #pragma unroll
       for (int ub = 0; ub < UB; ++ub) acc[g][ub] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-#pragma unroll 2
+#pragma unroll
     for (int kc = 0; kc < KC; ++kc) {
       const bf16x8 a = *reinterpret_cast<const bf16x8*>(&hlds[cur][l15][kc * 32 + 8 * lq]);
 #pragma unroll
-      for (int g = 0; g < 4; ++g)
+      for (int ub = 0; ub < UB; ++ub)
 #pragma unroll
-        for (int ub = 0; ub < UB; ++ub) {
-          const bf16x8 b = *reinterpret_cast<const bf16x8*>(wp + (int64_t)((kc * 4 + g) * UB + ub) * 512);
-          acc[g][ub] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc[g][ub], 0, 0, 0);
-        }
+        for (int g = 0; g < 4; ++g) acc[g][ub] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, wf[ub][kc][g], acc[g][ub], 0, 0, 0);
     }
 
+    u64* dst = ex_group + (int64_t)(s & 1) * ngroups * G * NGRAN + (int64_t)member * NGRAN;
 #pragma unroll
     for (int ub = 0; ub < UB; ++ub) {
       const int unit = unit0 + ub * 16;
+      const int ul = unit - member * HS;
+      unsigned short hb[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const float gi = las_sigmoid(acc[0][ub][r] + xp[0][ub][r]);
@@ -122,22 +203,30 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_kernel(float* __restrict__ xp
         const float gf = las_sigmoid(acc[2][ub][r] + xp[2][ub][r] + 1.0f);
         const float go = las_sigmoid(acc[3][ub][r] + xp[3][ub][r]);
         const float cn = gf * c[ub][r] + gi * gj;
-        const unsigned short hb = las_f2bf(go * las_tanh(cn));
+        const unsigned short hn = las_f2bf(go * las_tanh(cn));
         if (act[r]) {
           float* gp = xproj + rowoff[r] * xrow + dir * 4 * H + unit;
           gp[0] = gi; gp[H] = gj; gp[2 * H] = gf; gp[3 * H] = go;
           cbuf[rowoff[r] * yrow + dir * H + unit] = cn;
-          y[rowoff[r] * yrow + dir * H + unit] = hb;
+          y[rowoff[r] * yrow + dir * H + unit] = hn;
           c[ub][r] = cn;
-          h[ub][r] = las_bf2f(hb);
+          h[ub][r] = las_bf2f(hn);
         }
-        hlds[cur ^ 1][lq * 4 + r][unit] = act[r] ? hb : las_f2bf(h[ub][r]);
+        hb[r] = act[r] ? hn : las_f2bf(h[ub][r]);
+        hlds[cur ^ 1][lq * 4 + r][unit] = hb[r];
+      }
+      if constexpr (G > 1) {
+        granule_store(dst + (lq * 2) * HS + ul, (unsigned)(s + 1), (unsigned)hb[0] | ((unsigned)hb[1] << 16));
+        granule_store(dst + (lq * 2 + 1) * HS + ul, (unsigned)(s + 1), (unsigned)hb[2] | ((unsigned)hb[3] << 16));
       }
     }
-    __syncthreads();
     cur ^= 1;
   }
 
+  if (fail_flag) {
+    if (tid == 0) atomicOr(status, 1u);
+    return;
+  }
 #pragma unroll
   for (int ub = 0; ub < UB; ++ub)
 #pragma unroll
@@ -157,13 +246,22 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_kernel(const float* __restric
                                                           const float* __restrict__ dy, const float* __restrict__ dc_last,
                                                           const float* __restrict__ dh_last, const unsigned short* __restrict__ kh,
                                                           const int32_t* __restrict__ length, unsigned short* __restrict__ dz,
-                                                          int B, int T, int ndir) {
-  constexpr int UB = H / 64, KC = (4 * H) / 32, ZS = 4 * H + 8;
+                                                          u64* __restrict__ exch, unsigned* __restrict__ status,
+                                                          int B, int T, int ndir, int ngroups) {
+  constexpr int G = coop_members(H);
+  constexpr int HS = H / G;
+  constexpr int UB = HS / 64;
+  constexpr int KC = (4 * H) / 32;
+  constexpr int ZS = 4 * H + 8;
+  constexpr int NGRAN = 8 * 4 * HS;    // granules per member per step: 8 row pairs x 4 gates x HS units
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned short* dzl = reinterpret_cast<unsigned short*>(smem);   // [2][16][ZS]
+  int& fail_flag = *reinterpret_cast<int*>(smem + (size_t)2 * 16 * ZS * sizeof(unsigned short));   // keeps the dynamic base 16-B aligned
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int slice = blockIdx.x, dir = blockIdx.y;
+  const int group = blockIdx.x % ngroups, member = blockIdx.x / ngroups;
+  const int nslices = ngroups / ndir;
+  const int slice = group % nslices, dir = group / nslices;
   const int l15 = lane & 15, lq = lane >> 4;
 
   int len[4], bidx[4];
@@ -176,7 +274,16 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_kernel(const float* __restric
   }
   smax = (int)las_wave_max((float)smax);
 
-  const int unit0 = wave * (H / 4) + l15;
+  const int unit0 = member * HS + wave * (HS / 4) + l15;
+  const unsigned short* khd = kh + (int64_t)dir * H * 4 * H;
+  // register-resident B fragments: B[k][n] = K_h[n = unit][k = gate column]  (natural rows of K_h)
+  bf16x8 wf[UB][KC];
+#pragma unroll
+  for (int ub = 0; ub < UB; ++ub)
+#pragma unroll
+    for (int kc = 0; kc < KC; ++kc)
+      wf[ub][kc] = *reinterpret_cast<const bf16x8*>(khd + (int64_t)(unit0 + ub * 16) * 4 * H + kc * 32 + 8 * lq);
+
   float dc[UB][4], dh[UB][4];
 #pragma unroll
   for (int ub = 0; ub < UB; ++ub)
@@ -187,17 +294,24 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_kernel(const float* __restric
       dc[ub][r] = (ok && dc_last) ? dc_last[o] : 0.f;
       dh[ub][r] = (ok && dh_last) ? dh_last[o] : 0.f;
     }
+  if (tid == 0) fail_flag = 0;
+  __syncthreads();
 
   const int64_t grow = (int64_t)ndir * 4 * H;
   const int64_t yrow = (int64_t)ndir * H;
-  const unsigned short* khd = kh + (int64_t)dir * H * 4 * H;
+  u64* ex_group = exch + (int64_t)group * G * NGRAN;
 
   int cur = 0;
+  unsigned epoch = 0;
   for (int s = smax - 1; s >= 0; --s) {
+    ++epoch;
     unsigned short* zl = dzl + cur * 16 * ZS;
+    u64* dst = ex_group + (int64_t)(epoch & 1) * ngroups * G * NGRAN + (int64_t)member * NGRAN;
 #pragma unroll
     for (int ub = 0; ub < UB; ++ub) {
       const int unit = unit0 + ub * 16;
+      const int ul = unit - member * HS;
+      unsigned short zb[4][4];       // [gate][row]
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const bool act = s < len[r];
@@ -224,24 +338,67 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_kernel(const float* __restric
           unsigned short* zp = dz + ro * grow + dir * 4 * H + unit;
           zp[0] = las_f2bf(di); zp[H] = las_f2bf(dj); zp[2 * H] = las_f2bf(df); zp[3 * H] = las_f2bf(dov);
         }
+        zb[0][r] = las_f2bf(di); zb[1][r] = las_f2bf(dj); zb[2][r] = las_f2bf(df); zb[3][r] = las_f2bf(dov);
         unsigned short* zr = zl + (lq * 4 + r) * ZS + unit;
-        zr[0] = las_f2bf(di); zr[H] = las_f2bf(dj); zr[2 * H] = las_f2bf(df); zr[3 * H] = las_f2bf(dov);
+        zr[0] = zb[0][r]; zr[H] = zb[1][r]; zr[2 * H] = zb[2][r]; zr[3 * H] = zb[3][r];
+      }
+      if constexpr (G > 1) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          granule_store(dst + ((lq * 2) * 4 + g) * HS + ul, epoch, (unsigned)zb[g][0] | ((unsigned)zb[g][1] << 16));
+          granule_store(dst + ((lq * 2 + 1) * 4 + g) * HS + ul, epoch, (unsigned)zb[g][2] | ((unsigned)zb[g][3] << 16));
+        }
+      }
+    }
+
+    // all-gather dz_t from the peers
+    if constexpr (G > 1) {
+      const u64* src = ex_group + (int64_t)(epoch & 1) * ngroups * G * NGRAN;
+      constexpr int TOTAL = (G - 1) * NGRAN;
+      constexpr int CH = 8;                          // granules per thread per chunk
+      for (int base = 0; base < TOTAL; base += 256 * CH) {
+        u64 v[CH];
+        unsigned spins = 0;
+        bool ok;
+        do {
+          ok = true;
+#pragma unroll
+          for (int i = 0; i < CH; ++i) {
+            const int q = base + tid + i * 256;
+            const int pi = q / NGRAN, gi = q % NGRAN;
+            const int peer = pi + (pi >= member ? 1 : 0);
+            v[i] = granule_load(src + (int64_t)peer * NGRAN + gi);
+            ok = ok && ((unsigned)(v[i] >> 32) == epoch);
+          }
+          if (!ok) {
+            if (++spins > SPIN_LIMIT) { fail_flag = 1; break; }
+            __builtin_amdgcn_s_sleep(1);
+          }
+        } while (!ok);
+#pragma unroll
+        for (int i = 0; i < CH; ++i) {
+          const int q = base + tid + i * 256;
+          const int pi = q / NGRAN, gi = q % NGRAN;
+          const int peer = pi + (pi >= member ? 1 : 0);
+          const int rp = gi / (4 * HS), g = (gi / HS) % 4, ul = gi % HS;
+          const unsigned val = (unsigned)v[i];
+          zl[(rp * 2) * ZS + g * H + peer * HS + ul] = (unsigned short)(val & 0xffffu);
+          zl[(rp * 2 + 1) * ZS + g * H + peer * HS + ul] = (unsigned short)(val >> 16);
+        }
       }
     }
     __syncthreads();
+    if (fail_flag) break;
 
-    // dh_{t-1} = dz_t * K_h^T : A = dz tile [16, 4H] from LDS, B[k][n] = K_h[n][k] (natural rows)
+    // dh_{t-1}[own units] = dz_t [16,4H] * K_h^T
     f32x4 acc[UB];
 #pragma unroll
     for (int ub = 0; ub < UB; ++ub) acc[ub] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll 4
+#pragma unroll
     for (int kc = 0; kc < KC; ++kc) {
       const bf16x8 a = *reinterpret_cast<const bf16x8*>(zl + l15 * ZS + kc * 32 + 8 * lq);
 #pragma unroll
-      for (int ub = 0; ub < UB; ++ub) {
-        const bf16x8 b = *reinterpret_cast<const bf16x8*>(khd + (int64_t)(unit0 + ub * 16) * 4 * H + kc * 32 + 8 * lq);
-        acc[ub] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc[ub], 0, 0, 0);
-      }
+      for (int ub = 0; ub < UB; ++ub) acc[ub] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, wf[ub][kc], acc[ub], 0, 0, 0);
     }
 #pragma unroll
     for (int ub = 0; ub < UB; ++ub)
@@ -250,73 +407,100 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_kernel(const float* __restric
         if (s < len[r]) dh[ub][r] = acc[ub][r];
     cur ^= 1;
   }
+  if (fail_flag && tid == 0) atomicOr(status, 2u);
+}
+
+struct CoopGeom { int nslices, ngroups, G, blocks; size_t exch_bytes; };
+
+CoopGeom geom(int B, int H, int ndir, bool bwd) {
+  CoopGeom g;
+  g.G = coop_members(H);
+  g.nslices = (B + 15) / 16;
+  g.ngroups = g.nslices * ndir;
+  g.blocks = g.ngroups * g.G;
+  const size_t ngran = (size_t)8 * (H / g.G) * (bwd ? 4 : 1);
+  g.exch_bytes = g.G > 1 ? (size_t)2 * g.ngroups * g.G * ngran * sizeof(u64) : 0;
+  return g;
 }
 
 template <int H>
 int launch_fwd(float* xproj, const las_bf16* wp, const int32_t* length, las_bf16* y, float* cbuf, float* c_last,
-               float* h_last, int B, int T, int ndir, hipStream_t st) {
-  dim3 grid((B + 15) / 16, ndir);
-  hipLaunchKernelGGL((lstm_fwd_kernel<H>), grid, dim3(256), 0, st, xproj, wp, length, y, cbuf, c_last, h_last, B, T, ndir);
+               float* h_last, void* ws, int B, int T, int ndir, hipStream_t st) {
+  const CoopGeom g = geom(B, H, ndir, false);
+  unsigned* status = reinterpret_cast<unsigned*>(ws);
+  u64* exch = reinterpret_cast<u64*>(reinterpret_cast<char*>(ws) + 64);
+  hipLaunchKernelGGL((lstm_fwd_kernel<H>), dim3(g.blocks), dim3(256), 0, st, xproj, wp, length, y, cbuf, c_last, h_last,
+                     exch, status, B, T, ndir, g.ngroups);
   LAS_LAUNCH_CHECK("lstm fwd launch");
   return LAS_OK;
 }
 
 template <int H>
 int launch_bwd(const float* gates, const float* cbuf, const float* dy, const float* dc_last, const float* dh_last,
-               const las_bf16* kh, const int32_t* length, las_bf16* dz, int B, int T, int ndir, hipStream_t st) {
-  dim3 grid((B + 15) / 16, ndir);
-  const size_t lds = (size_t)2 * 16 * (4 * H + 8) * sizeof(unsigned short);
+               const las_bf16* kh, const int32_t* length, las_bf16* dz, void* ws, int B, int T, int ndir, hipStream_t st) {
+  const CoopGeom g = geom(B, H, ndir, true);
+  unsigned* status = reinterpret_cast<unsigned*>(ws);
+  u64* exch = reinterpret_cast<u64*>(reinterpret_cast<char*>(ws) + 64);
+  const size_t lds = (size_t)2 * 16 * (4 * H + 8) * sizeof(unsigned short) + 16;
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&lstm_bwd_kernel<H>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
-  hipLaunchKernelGGL((lstm_bwd_kernel<H>), grid, dim3(256), lds, st, gates, cbuf, dy, dc_last, dh_last, kh, length, dz, B, T, ndir);
+  hipLaunchKernelGGL((lstm_bwd_kernel<H>), dim3(g.blocks), dim3(256), lds, st, gates, cbuf, dy, dc_last, dh_last, kh, length,
+                     dz, exch, status, B, T, ndir, g.ngroups);
   LAS_LAUNCH_CHECK("lstm bwd launch");
   return LAS_OK;
 }
 
+bool supported_units(int H) { return H == 64 || H == 128 || H == 256; }
+
 }  // namespace
 
+extern "C" size_t las_lstm_workspace_bytes(int B, int H, int ndir) {
+  if (!supported_units(H) || B <= 0) return 0;
+  return 64 + geom(B, H, ndir, true).exch_bytes;
+}
+
 extern "C" int las_lstm_pack_recurrent(const float* kernel_h, int H, las_bf16* packed, void* stream) {
-  LAS_REQUIRE(H >= 64 && H % 64 == 0, "las_lstm_pack_recurrent: num_units must be a multiple of 64 (got %d)", H);
+  LAS_REQUIRE(supported_units(H), "las_lstm_pack_recurrent: num_units must be 64, 128 or 256 (got %d)", H);
   hipLaunchKernelGGL(pack_recurrent_kernel, dim3(256), dim3(256), 0, (hipStream_t)stream, kernel_h, H, packed);
   LAS_LAUNCH_CHECK("pack launch");
   return LAS_OK;
 }
 
 extern "C" int las_lstm_recurrent_fwd(float* xproj, const las_bf16* wpacked, const int32_t* length, las_bf16* y,
-                                      float* cbuf, float* c_last, float* h_last, int B, int T, int H, int ndir,
-                                      void* stream) {
+                                      float* cbuf, float* c_last, float* h_last, void* workspace, int B, int T, int H,
+                                      int ndir, void* stream) {
   LAS_REQUIRE(B > 0 && T > 0 && (ndir == 1 || ndir == 2), "las_lstm_recurrent_fwd: bad shape B=%d T=%d ndir=%d", B, T, ndir);
+  LAS_REQUIRE(supported_units(H), "las_lstm_recurrent_fwd: num_units %d not in {64,128,256}", H);
+  LAS_REQUIRE(workspace != nullptr && ((uintptr_t)workspace % 16 == 0), "las_lstm_recurrent_fwd: workspace missing or misaligned");
   hipStream_t st = (hipStream_t)stream;
   int rc = las_check_hip(hipMemsetAsync(y, 0, (size_t)B * T * ndir * H * sizeof(las_bf16), st), "memset y");
   if (rc) return rc;
+  rc = las_check_hip(hipMemsetAsync(workspace, 0, 64 + geom(B, H, ndir, false).exch_bytes, st), "memset workspace");
+  if (rc) return rc;
   switch (H) {
-    case 64: return launch_fwd<64>(xproj, wpacked, length, y, cbuf, c_last, h_last, B, T, ndir, st);
-    case 128: return launch_fwd<128>(xproj, wpacked, length, y, cbuf, c_last, h_last, B, T, ndir, st);
-    case 256: return launch_fwd<256>(xproj, wpacked, length, y, cbuf, c_last, h_last, B, T, ndir, st);
-    case 512: return launch_fwd<512>(xproj, wpacked, length, y, cbuf, c_last, h_last, B, T, ndir, st);
-    default: break;
+    case 64: return launch_fwd<64>(xproj, wpacked, length, y, cbuf, c_last, h_last, workspace, B, T, ndir, st);
+    case 128: return launch_fwd<128>(xproj, wpacked, length, y, cbuf, c_last, h_last, workspace, B, T, ndir, st);
+    default: return launch_fwd<256>(xproj, wpacked, length, y, cbuf, c_last, h_last, workspace, B, T, ndir, st);
   }
-  las_set_error("las_lstm_recurrent_fwd: num_units %d not in {64,128,256,512}", H);
-  return LAS_ERR_ARG;
 }
 
 extern "C" int las_lstm_recurrent_bwd(const float* gates, const float* cbuf, const float* dy, const float* dc_last,
                                       const float* dh_last, const las_bf16* kh_bf16, const int32_t* length,
-                                      las_bf16* dz, int B, int T, int H, int ndir, void* stream) {
+                                      las_bf16* dz, void* workspace, int B, int T, int H, int ndir, void* stream) {
   LAS_REQUIRE(B > 0 && T > 0 && (ndir == 1 || ndir == 2), "las_lstm_recurrent_bwd: bad shape");
+  LAS_REQUIRE(supported_units(H), "las_lstm_recurrent_bwd: num_units %d not in {64,128,256}", H);
+  LAS_REQUIRE(workspace != nullptr && ((uintptr_t)workspace % 16 == 0), "las_lstm_recurrent_bwd: workspace missing or misaligned");
   hipStream_t st = (hipStream_t)stream;
   int rc = las_check_hip(hipMemsetAsync(dz, 0, (size_t)B * T * ndir * 4 * H * sizeof(las_bf16), st), "memset dz");
   if (rc) return rc;
+  rc = las_check_hip(hipMemsetAsync(workspace, 0, 64 + geom(B, H, ndir, true).exch_bytes, st), "memset workspace");
+  if (rc) return rc;
   switch (H) {
-    case 64: return launch_bwd<64>(gates, cbuf, dy, dc_last, dh_last, kh_bf16, length, dz, B, T, ndir, st);
-    case 128: return launch_bwd<128>(gates, cbuf, dy, dc_last, dh_last, kh_bf16, length, dz, B, T, ndir, st);
-    case 256: return launch_bwd<256>(gates, cbuf, dy, dc_last, dh_last, kh_bf16, length, dz, B, T, ndir, st);
-    case 512: return launch_bwd<512>(gates, cbuf, dy, dc_last, dh_last, kh_bf16, length, dz, B, T, ndir, st);
-    default: break;
+    case 64: return launch_bwd<64>(gates, cbuf, dy, dc_last, dh_last, kh_bf16, length, dz, workspace, B, T, ndir, st);
+    case 128: return launch_bwd<128>(gates, cbuf, dy, dc_last, dh_last, kh_bf16, length, dz, workspace, B, T, ndir, st);
+    default: return launch_bwd<256>(gates, cbuf, dy, dc_last, dh_last, kh_bf16, length, dz, workspace, B, T, ndir, st);
   }
-  las_set_error("las_lstm_recurrent_bwd: num_units %d not in {64,128,256,512}", H);
-  return LAS_ERR_ARG;
 }

@@ -28,9 +28,32 @@ def lstm_cell(num_units, dropout, mode):
     dropout = dropout if mode == TRAIN else 0.0
     if dropout > 0.0:
         raise NotImplementedError('input dropout > 0 is not implemented on the HIP path yet; use --dropout 0')
-    if num_units not in (64, 128, 256, 512):
-        raise ValueError('num_units must be one of 64, 128, 256, 512 on the HIP path (got %d)' % num_units)
+    if num_units not in (64, 128, 256):
+        raise ValueError('num_units must be one of 64, 128, 256 on the HIP path (got %d)' % num_units)
     return LSTMCellSpec(num_units, 1.0 - dropout)
+
+
+_WORKSPACES = {}
+
+
+def lstm_workspace(B, H, nd):
+    """Scratch for the cooperative recurrent kernels (status word + exchange buffer), cached per shape."""
+    key = (B, H, nd, torch.cuda.current_device())
+    ws = _WORKSPACES.get(key)
+    if ws is None:
+        n = hip.lib().las_lstm_workspace_bytes(B, H, nd)
+        if n == 0:
+            raise ValueError('num_units %d is not supported by the HIP recurrent kernels' % H)
+        ws = torch.zeros(n, dtype=torch.uint8, device='cuda')
+        _WORKSPACES[key] = ws
+    return ws
+
+
+def check_lstm_status(B, H, nd):
+    """Raise if a bounded inter-workgroup wait of the last recurrent launch timed out (forces a sync)."""
+    st = int(lstm_workspace(B, H, nd)[:4].view(torch.int32).item())
+    if st:
+        raise hip.LasError('recurrent kernel reported an inter-workgroup timeout (status %d)' % st)
 
 
 def _dirs(unidirectional):
@@ -89,8 +112,8 @@ def bilstm(inputs, sequence_length, num_units, dropout, mode, unidirectional=Fal
     c_last = torch.empty(nd, B, H, dtype=torch.float32, device=dev)
     h_last = torch.empty(nd, B, H, dtype=torch.float32, device=dev)
     hip.check(hip.lib().las_lstm_recurrent_fwd(hip.p(xproj), hip.p(weights.khp), hip.p(sequence_length), hip.p(y),
-                                               hip.p(cbuf), hip.p(c_last), hip.p(h_last), B, T, H, nd,
-                                               hip.stream()))
+                                               hip.p(cbuf), hip.p(c_last), hip.p(h_last),
+                                               hip.p(lstm_workspace(B, H, nd)), B, T, H, nd, hip.stream()))
     if tape is not None:
         tape.append(dict(kind='bilstm', inputs=inputs, length=sequence_length, gates=xproj, cbuf=cbuf, y=y,
                          weights=weights, B=B, T=T, H=H, D=D, Dp=Dp, nd=nd))
@@ -121,8 +144,8 @@ def bilstm_backward(rec, dy, d_state, grads, need_dx=True):
     dz = torch.empty(B, T, nd * 4 * H, dtype=torch.bfloat16, device=dev)
     dc_last, dh_last = d_state if d_state is not None else (None, None)
     hip.check(hip.lib().las_lstm_recurrent_bwd(hip.p(rec['gates']), hip.p(rec['cbuf']), hip.p(dy), hip.p(dc_last),
-                                               hip.p(dh_last), hip.p(w.kh), hip.p(rec['length']), hip.p(dz), B, T,
-                                               H, nd, hip.stream()))
+                                               hip.p(dh_last), hip.p(w.kh), hip.p(rec['length']), hip.p(dz),
+                                               hip.p(lstm_workspace(B, H, nd)), B, T, H, nd, hip.stream()))
     x, y = rec['inputs'], rec['y']
     BT = B * T
     split = max(1, min(32, BT // 2048))

@@ -36,6 +36,7 @@ def _relerr(got, ref):
     (3, 10, 24, 64, [10, 4, 7]),
     (17, 12, 40, 128, [12, 1, 5, 12, 3, 9, 2, 11, 6, 8, 10, 4, 12, 7, 1, 12, 5]),
     (2, 6, 64, 256, [6, 3]),
+    (21, 40, 32, 256, [40, 3, 17, 40, 1, 25, 8, 33, 12, 40, 5, 29, 2, 38, 9, 21, 40, 7, 31, 15, 36]),
 ])
 def test_bilstm_forward_backward_vs_oracle(B, T, D, H, lengths):
     from oracle import las_oracle as O
@@ -57,6 +58,7 @@ def test_bilstm_forward_backward_vs_oracle(B, T, D, H, lengths):
     y = ops.concat_outputs((ofw, obw))
     torch.cuda.synchronize()
     assert y.shape == (B, T, 2 * H)
+    ops.check_lstm_status(B, H, 2)
     assert _relerr(y.float(), ref_y) < 1.6e-2
     for b in range(B):          # outputs beyond the length are exactly zero (Appendix A.3)
         if lengths[b] < T:
@@ -75,6 +77,7 @@ def test_bilstm_forward_backward_vs_oracle(B, T, D, H, lengths):
     dx = ops.bilstm_backward(tape[0], dy.float().cuda().contiguous(),
                              (dc.float().cuda().contiguous(), dh.float().cuda().contiguous()), grads)
     torch.cuda.synchronize()
+    ops.check_lstm_status(B, H, 2)
     for k in grads:
         assert _relerr(grads[k], leaf[k].grad) < 3e-2, k
     assert _relerr(dx, xr.grad) < 3e-2
