@@ -82,27 +82,35 @@ __global__ __launch_bounds__(256) void dec_step_fwd_kernel(las_dec_step s) {
     __syncthreads();
   }
 
-  // ---- scores: 16 lanes per memory frame, 16 frames per pass ----
+  // ---- scores: 4 lanes per memory frame (64 frames per pass), each lane Hd/32 independent 16-byte loads ----
   const unsigned short* keys = s.keys + (int64_t)b * Tm * Hd;
-  const int sub = lane & 15, grp = lane >> 4;
-  for (int t0 = 0; t0 < Tm; t0 += 16) {
-    const int t = t0 + wave * 4 + grp;
-    float part_sum = 0.f;
-    if (t < len) {
-      for (int k = sub * 8; k < Hd; k += 128) {
-        const uint4 kv = *reinterpret_cast<const uint4*>(keys + (int64_t)t * Hd + k);
+  {
+    const int sub = lane & 3, fr = lane >> 2;
+    for (int t0 = 0; t0 < Tm; t0 += 64) {
+      const int t = t0 + wave * 16 + fr;
+      float part_sum = 0.f;
+      if (t < len) {
+        const unsigned short* krow = keys + (int64_t)t * Hd;
         if (s.attention == LAS_ATT_LUONG) {
-          part_sum += dot8(kv, hq + k);
+#pragma unroll 8
+          for (int k = sub * 8; k < Hd; k += 32) {
+            const uint4 kv = *reinterpret_cast<const uint4*>(krow + k);
+            part_sum += dot8(kv, hq + k);
+          }
         } else {
-          const unsigned short* e = reinterpret_cast<const unsigned short*>(&kv);
+#pragma unroll 4
+          for (int k = sub * 8; k < Hd; k += 32) {
+            const uint4 kv = *reinterpret_cast<const uint4*>(krow + k);
+            const unsigned short* e = reinterpret_cast<const unsigned short*>(&kv);
 #pragma unroll
-          for (int j = 0; j < 8; ++j) part_sum += s.att_v[k + j] * las_tanh(las_bf2f(e[j]) + pq[k + j]);
+            for (int j = 0; j < 8; ++j) part_sum += s.att_v[k + j] * las_tanh(las_bf2f(e[j]) + pq[k + j]);
+          }
         }
       }
+      part_sum += __shfl_xor(part_sum, 1, 64);
+      part_sum += __shfl_xor(part_sum, 2, 64);
+      if (sub == 0 && t < Tm) sc[t] = (t < len) ? part_sum : -INFINITY;
     }
-#pragma unroll
-    for (int o = 8; o > 0; o >>= 1) part_sum += __shfl_xor(part_sum, o, 64);
-    if (sub == 0 && t < Tm) sc[t] = (t < len) ? part_sum : -INFINITY;
   }
   __syncthreads();
 
@@ -128,25 +136,45 @@ __global__ __launch_bounds__(256) void dec_step_fwd_kernel(las_dec_step s) {
   }
   __syncthreads();
 
-  // ---- context = sum_t' p[t'] * values[b,t',:]  (this workgroup's column range) ----
+  // ---- context = sum_t' p[t'] * values[b,t',:] for this workgroup's column range.  L = cols/8 lanes cover one
+  // frame with 16-byte loads; the 256/L frame phases are reduced through LDS. ----
   const unsigned short* vals = s.values + (int64_t)b * Tm * M;
-  const int cols_per = ((M / 4 + nparts - 1) / nparts) * 4;
+  const int cols_per = ((M / 8 + nparts - 1) / nparts) * 8;
   const int c_begin = part * cols_per, c_end = min(M, c_begin + cols_per);
-  for (int m = c_begin + tid * 4; m < c_end; m += 1024) {
-    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-    for (int t = 0; t < len; ++t) {
-      const uint2 v = *reinterpret_cast<const uint2*>(vals + (int64_t)t * M + m);
-      const float p = sc[t];
-      a0 += p * __uint_as_float(v.x << 16);
-      a1 += p * __uint_as_float(v.x & 0xffff0000u);
-      a2 += p * __uint_as_float(v.y << 16);
-      a3 += p * __uint_as_float(v.y & 0xffff0000u);
+  float* cred = red + 8;     // [256][8] floats
+  for (int cb = c_begin; cb < c_end; cb += 2048) {
+    const int ncols = min(2048, c_end - cb);
+    int L = 1;
+    while (L * 8 < ncols) L <<= 1;           // lanes per frame (power of two <= 256)
+    const int P = 256 / L;                    // frame phases
+    const int phase = tid / L, cl = tid % L;
+    const int col = cb + cl * 8;
+    float a[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) a[j] = 0.f;
+    if (col < c_end) {
+#pragma unroll 4
+      for (int t = phase; t < len; t += P) {
+        const uint4 v = *reinterpret_cast<const uint4*>(vals + (int64_t)t * M + col);
+        const unsigned short* e = reinterpret_cast<const unsigned short*>(&v);
+        const float p = sc[t];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) a[j] += p * las_bf2f(e[j]);
+      }
     }
-    uint2 o;
-    o.x = (unsigned)las_f2bf(a0) | ((unsigned)las_f2bf(a1) << 16);
-    o.y = (unsigned)las_f2bf(a2) | ((unsigned)las_f2bf(a3) << 16);
-    *reinterpret_cast<uint2*>(s.ctx_out + (int64_t)b * s.ldc + m) = o;
-    if (s.ctx_out2) *reinterpret_cast<uint2*>(s.ctx_out2 + (int64_t)b * s.ldc2 + m) = o;
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 8; ++j) cred[tid * 8 + j] = a[j];
+    __syncthreads();
+    // thread j < ncols sums the P phases of column j
+    for (int j = tid; j < ncols; j += 256) {
+      const int cl2 = j >> 3, e = j & 7;
+      float acc = 0.f;
+      for (int ph = 0; ph < P; ++ph) acc += cred[(ph * L + cl2) * 8 + e];
+      const unsigned short o = las_f2bf(acc);
+      s.ctx_out[(int64_t)b * s.ldc + cb + j] = o;
+      if (s.ctx_out2) s.ctx_out2[(int64_t)b * s.ldc2 + cb + j] = o;
+    }
   }
 }
 
@@ -157,8 +185,8 @@ __global__ __launch_bounds__(256) void dec_step_bwd_kernel(las_dec_step_bwd s) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   float* dctx = sm;               // [M]
   float* ds = dctx + s.M;         // [Tm] dalign -> dscore
-  float* dhs = ds + s.Tm;         // [4][Hd] per-wave partial d h (score path) / dpq
-  float* red = dhs + 4 * s.Hd;    // [8]
+  float* dhs = ds + s.Tm;         // [256/L][Hd] = 2048 floats: per-phase partial d h (score path) / dpq
+  float* red = dhs + 2048;        // [8] + [Hd] scratch
 
   const int b = blockIdx.x;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -174,21 +202,33 @@ __global__ __launch_bounds__(256) void dec_step_bwd_kernel(las_dec_step_bwd s) {
   }
   __syncthreads();
 
-  // dalign[t'] = values[b,t',:] . dctx
+  // dalign[t'] = values[b,t',:] . dctx : 16 lanes per frame, two frames per thread in flight
   const unsigned short* vals = s.values + (int64_t)b * Tm * M;
-  const int sub = lane & 15, grp = lane >> 4;
-  for (int t0 = 0; t0 < Tm; t0 += 16) {
-    const int t = t0 + wave * 4 + grp;
-    float acc = 0.f;
-    if (t < len) {
+  {
+    const int sub = lane & 15, grp = lane >> 4;
+    for (int t0 = 0; t0 < Tm; t0 += 32) {
+      const int ta = t0 + wave * 4 + grp, tb = ta + 16;
+      float acc_a = 0.f, acc_b = 0.f;
+      const bool oa = ta < len, ob = tb < len;
+      const unsigned short* ra = vals + (int64_t)(oa ? ta : 0) * M;
+      const unsigned short* rb = vals + (int64_t)(ob ? tb : 0) * M;
+#pragma unroll 4
       for (int k = sub * 8; k < M; k += 128) {
-        const uint4 kv = *reinterpret_cast<const uint4*>(vals + (int64_t)t * M + k);
-        acc += dot8(kv, dctx + k);
+        const uint4 va = *reinterpret_cast<const uint4*>(ra + k);
+        const uint4 vb = *reinterpret_cast<const uint4*>(rb + k);
+        acc_a += dot8(va, dctx + k);
+        acc_b += dot8(vb, dctx + k);
+      }
+#pragma unroll
+      for (int o = 8; o > 0; o >>= 1) {
+        acc_a += __shfl_xor(acc_a, o, 64);
+        acc_b += __shfl_xor(acc_b, o, 64);
+      }
+      if (sub == 0) {
+        if (ta < Tm) ds[ta] = oa ? acc_a : 0.f;
+        if (tb < Tm) ds[tb] = ob ? acc_b : 0.f;
       }
     }
-#pragma unroll
-    for (int o = 8; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
-    if (sub == 0 && t < Tm) ds[t] = (t < len) ? acc : 0.f;
   }
   __syncthreads();
 
@@ -204,48 +244,58 @@ __global__ __launch_bounds__(256) void dec_step_bwd_kernel(las_dec_step_bwd s) {
   }
   __syncthreads();
 
-  // gradient into the query path: wave w takes frames t' = w, w+4, ...; lane takes 4 columns
+  // gradient into the query path: L = Hd/8 lanes cover one frame (16-byte loads), 256/L frame phases
   const unsigned short* keys = s.keys + (int64_t)b * Tm * Hd;
-  for (int u = lane * 4; u < Hd; u += 256) {
-    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  const int L = Hd / 8, P = 256 / L;            // Hd in {64,...,2048} and a power of two
+  {
+    const int phase = tid / L, u = (tid % L) * 8;
+    float a[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) a[j] = 0.f;
     if (s.attention == LAS_ATT_LUONG) {
-      for (int t = wave; t < len; t += 4) {
-        const uint2 v = *reinterpret_cast<const uint2*>(keys + (int64_t)t * Hd + u);
+#pragma unroll 4
+      for (int t = phase; t < len; t += P) {
+        const uint4 v = *reinterpret_cast<const uint4*>(keys + (int64_t)t * Hd + u);
+        const unsigned short* e = reinterpret_cast<const unsigned short*>(&v);
         const float d = ds[t];
-        a0 += d * __uint_as_float(v.x << 16);
-        a1 += d * __uint_as_float(v.x & 0xffff0000u);
-        a2 += d * __uint_as_float(v.y << 16);
-        a3 += d * __uint_as_float(v.y & 0xffff0000u);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) a[j] += d * las_bf2f(e[j]);
       }
     } else {
       // Bahdanau: score = sum_a v[a] tanh(keys[t',a] + pq[a]); d_pre = ds * v * (1 - tanh^2)
-      const float* pq = s.pq + (int64_t)b * s.ldpq;
-      float dv0 = 0.f, dv1 = 0.f, dv2 = 0.f, dv3 = 0.f;
-      const float v0 = s.att_v[u], v1 = s.att_v[u + 1], v2 = s.att_v[u + 2], v3 = s.att_v[u + 3];
-      const float q0 = pq[u], q1 = pq[u + 1], q2 = pq[u + 2], q3 = pq[u + 3];
-      for (int t = wave; t < len; t += 4) {
-        const uint2 v = *reinterpret_cast<const uint2*>(keys + (int64_t)t * Hd + u);
+      const float* pqv = s.pq + (int64_t)b * s.ldpq;
+      float dv[8], vv[8], qq[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { dv[j] = 0.f; vv[j] = s.att_v[u + j]; qq[j] = pqv[u + j]; }
+      for (int t = phase; t < len; t += P) {
+        const uint4 v = *reinterpret_cast<const uint4*>(keys + (int64_t)t * Hd + u);
+        const unsigned short* e = reinterpret_cast<const unsigned short*>(&v);
         const float d = ds[t];
-        const float t0 = las_tanh(__uint_as_float(v.x << 16) + q0);
-        const float t1 = las_tanh(__uint_as_float(v.x & 0xffff0000u) + q1);
-        const float t2 = las_tanh(__uint_as_float(v.y << 16) + q2);
-        const float t3 = las_tanh(__uint_as_float(v.y & 0xffff0000u) + q3);
-        dv0 += d * t0; dv1 += d * t1; dv2 += d * t2; dv3 += d * t3;
-        const float p0 = d * v0 * (1.f - t0 * t0), p1 = d * v1 * (1.f - t1 * t1);
-        const float p2 = d * v2 * (1.f - t2 * t2), p3 = d * v3 * (1.f - t3 * t3);
-        a0 += p0; a1 += p1; a2 += p2; a3 += p3;
-        float* dk = s.dkeys_acc + ((int64_t)b * Tm + t) * Hd + u;   // this workgroup owns utterance b
-        dk[0] += p0; dk[1] += p1; dk[2] += p2; dk[3] += p3;
+        float* dk = s.dkeys_acc + ((int64_t)b * Tm + t) * Hd + u;   // this workgroup owns utterance b; one thread per (t,u)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float th = las_tanh(las_bf2f(e[j]) + qq[j]);
+          dv[j] += d * th;
+          const float p = d * vv[j] * (1.f - th * th);
+          a[j] += p;
+          dk[j] += p;
+        }
       }
-      atomicAdd(s.dv_acc + u, dv0); atomicAdd(s.dv_acc + u + 1, dv1);
-      atomicAdd(s.dv_acc + u + 2, dv2); atomicAdd(s.dv_acc + u + 3, dv3);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) atomicAdd(s.dv_acc + u + j, dv[j]);
     }
-    float* o = dhs + wave * Hd + u;
-    o[0] = a0; o[1] = a1; o[2] = a2; o[3] = a3;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) dhs[phase * Hd + u + j] = a[j];
   }
   __syncthreads();
-  // reduce the 4 per-wave partials
-  for (int u = tid; u < Hd; u += 256) dhs[u] = dhs[u] + dhs[Hd + u] + dhs[2 * Hd + u] + dhs[3 * Hd + u];
+  // reduce the P per-phase partials (dhs is [P][Hd] = 2048 floats)
+  for (int u = tid; u < Hd; u += 256) {
+    float acc = 0.f;
+    for (int ph = 0; ph < P; ++ph) acc += dhs[ph * Hd + u];
+    red[8 + u] = acc;
+  }
+  __syncthreads();
+  for (int u = tid; u < Hd; u += 256) dhs[u] = red[8 + u];
   __syncthreads();
   if (s.attention == LAS_ATT_BAHDANAU) {
     // dhs holds d(processed query); save it (bf16) for d(query_layer) and map back: dh[u] = sum_a dpq[a] Wq[u][a]
@@ -329,7 +379,7 @@ extern "C" int las_decoder_step_fwd(const las_dec_step* s, int parts, void* stre
   LAS_REQUIRE(s->B > 0 && s->Hd % 8 == 0 && s->M % 8 == 0 && s->Tm > 0, "las_decoder_step_fwd: bad shape");
   LAS_REQUIRE(s->attention == LAS_ATT_LUONG || (s->wq && s->att_v), "las_decoder_step_fwd: Bahdanau needs wq and att_v");
   if (parts < 1) parts = 1;
-  const size_t lds = (size_t)(2 * s->Hd + s->Tm + 8) * sizeof(float);
+  const size_t lds = (size_t)(2 * s->Hd + s->Tm + 8 + 8 + 2048) * sizeof(float);
   LAS_REQUIRE(lds <= 64 * 1024, "las_decoder_step_fwd: memory length %d too long for the LDS score buffer", s->Tm);
   hipLaunchKernelGGL(dec_step_fwd_kernel, dim3(s->B, parts), dim3(256), lds, (hipStream_t)stream, *s);
   LAS_LAUNCH_CHECK("decoder step fwd launch");
@@ -337,10 +387,11 @@ extern "C" int las_decoder_step_fwd(const las_dec_step* s, int parts, void* stre
 }
 
 extern "C" int las_decoder_step_bwd(const las_dec_step_bwd* s, void* stream) {
-  LAS_REQUIRE(s->B > 0 && s->Hd % 8 == 0 && s->M % 8 == 0 && s->Tm > 0, "las_decoder_step_bwd: bad shape");
+  LAS_REQUIRE(s->B > 0 && s->Hd >= 64 && s->Hd <= 1024 && (s->Hd & (s->Hd - 1)) == 0 && s->M % 128 == 0 && s->Tm > 0,
+              "las_decoder_step_bwd: decoder_units must be a power of two in [64,1024], memory depth a multiple of 128");
   LAS_REQUIRE(s->attention == LAS_ATT_LUONG || (s->wq_t && s->att_v && s->pq && s->dkeys_acc && s->dv_acc),
               "las_decoder_step_bwd: Bahdanau needs wq_t, att_v, pq, dkeys_acc, dv_acc");
-  const size_t lds = (size_t)(s->M + s->Tm + 4 * s->Hd + 8) * sizeof(float);
+  const size_t lds = (size_t)(s->M + s->Tm + 2048 + 8 + s->Hd) * sizeof(float);
   LAS_REQUIRE(lds <= 64 * 1024, "las_decoder_step_bwd: shapes exceed the LDS budget");
   hipLaunchKernelGGL(dec_step_bwd_kernel, dim3(s->B), dim3(256), lds, (hipStream_t)stream, *s);
   LAS_LAUNCH_CHECK("decoder step bwd launch");

@@ -209,6 +209,63 @@ int launch(const GemmArgs& g, int batch, hipStream_t st) {
   return LAS_OK;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Skinny NT product for the per-step decoder GEMMs (M <= 64 rows = the batch): one workgroup owns a
+// 64 x 16 output block over the WHOLE K; its 4 waves take interleaved 32-deep K chunks, load their MFMA
+// fragments straight from global memory (16 B per lane, no LDS staging, every load independent) and the
+// four partial accumulators meet in LDS.  N/16 workgroups, no split-K atomics, no barrier in the K loop.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gemm_nt_skinny_kernel(GemmArgs g) {
+  __shared__ float part[4][64][17];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l15 = lane & 15, lq = lane >> 4;
+  const int n0 = blockIdx.x * 16;
+  const int nk = (g.K + 31) / 32;
+  f32x4 acc[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int n = n0 + l15;
+  const bool n_ok = n < g.N;
+  const unsigned short* brow = g.B + (int64_t)(n_ok ? n : 0) * g.ldb + 8 * lq;
+  const unsigned short* arow[4];
+  bool a_ok[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int m = i * 16 + l15;
+    a_ok[i] = m < g.M;
+    arow[i] = g.A + (int64_t)(a_ok[i] ? m : 0) * g.lda + 8 * lq;
+  }
+  const uint4 zero = make_uint4(0, 0, 0, 0);
+#pragma unroll 2
+  for (int kc = wave; kc < nk; kc += 4) {
+    const int k = kc * 32;
+    const bool k_ok = (k + 8 * lq) < g.K;
+    uint4 bv = (n_ok && k_ok) ? *reinterpret_cast<const uint4*>(brow + k) : zero;
+    uint4 av[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) av[i] = (a_ok[i] && k_ok) ? *reinterpret_cast<const uint4*>(arow[i] + k) : zero;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, av[i]), __builtin_bit_cast(bf16x8, bv),
+                                                       acc[i], 0, 0, 0);
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) part[wave][i * 16 + lq * 4 + r][l15] = acc[i][r];
+  __syncthreads();
+  float* C = reinterpret_cast<float*>(g.C);
+  for (int e = tid; e < 64 * 16; e += 256) {
+    const int row = e / 16, col = e % 16;
+    if (row < g.M && n0 + col < g.N) {
+      float v = part[0][row][col] + part[1][row][col] + part[2][row][col] + part[3][row][col];
+      if (g.bias) v += g.bias[n0 + col];
+      const int64_t off = (int64_t)row * g.ldc + n0 + col;
+      if (g.accumulate) C[off] += v; else C[off] = v;
+    }
+  }
+}
+
 __global__ void zero_rows_kernel(float* C, int64_t ldc, int M, int N, int64_t sc) {
   float* c = C + (int64_t)blockIdx.z * sc;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < (int64_t)M * N;
@@ -232,6 +289,11 @@ extern "C" int las_gemm_nt(const las_bf16* A, int64_t lda, const las_bf16* B, in
   if (split_k > 1 && !accumulate) {
     hipLaunchKernelGGL(zero_rows_kernel, dim3(64, 1, batch), dim3(256), 0, st, (float*)C, ldc, M, N, sc);
     LAS_LAUNCH_CHECK("gemm zero");
+  }
+  if (M <= 64 && !out_bf16 && batch == 1 && split_k == 1 && K >= 256) {
+    hipLaunchKernelGGL(gemm_nt_skinny_kernel, dim3((N + 15) / 16), dim3(256), 0, st, g);
+    LAS_LAUNCH_CHECK("skinny gemm launch");
+    return LAS_OK;
   }
   if (M <= 64 || N <= 64) return launch<64, 64, false>(g, batch, st);
   return launch<128, 128, false>(g, batch, st);

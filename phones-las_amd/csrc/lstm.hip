@@ -301,8 +301,36 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_kernel(const float* __restric
   const int64_t yrow = (int64_t)ndir * H;
   u64* ex_group = exch + (int64_t)group * G * NGRAN;
 
+  // saved forward values of one step, loaded one step ahead so their latency hides behind the all-gather
+  struct Saved { float gi, gj, gf, go, ct, cp, dyv; };
+  auto load_saved = [&](int s, Saved (&sv)[UB][4]) {
+#pragma unroll
+    for (int ub = 0; ub < UB; ++ub) {
+      const int unit = unit0 + ub * 16;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        Saved v{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (s >= 0 && s < len[r]) {
+          const int pos = dir == 0 ? s : len[r] - 1 - s;
+          const int64_t ro = (int64_t)bidx[r] * T + pos;
+          const float* gp = gates + ro * grow + dir * 4 * H + unit;
+          v.gi = gp[0]; v.gj = gp[H]; v.gf = gp[2 * H]; v.go = gp[3 * H];
+          v.ct = cbuf[ro * yrow + dir * H + unit];
+          if (s > 0) {
+            const int64_t rp = (int64_t)bidx[r] * T + (dir == 0 ? pos - 1 : pos + 1);
+            v.cp = cbuf[rp * yrow + dir * H + unit];
+          }
+          v.dyv = dy[ro * yrow + dir * H + unit];
+        }
+        sv[ub][r] = v;
+      }
+    }
+  };
+
   int cur = 0;
   unsigned epoch = 0;
+  Saved sv[UB][4];
+  load_saved(smax - 1, sv);
   for (int s = smax - 1; s >= 0; --s) {
     ++epoch;
     unsigned short* zl = dzl + cur * 16 * ZS;
@@ -317,24 +345,17 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_kernel(const float* __restric
         const bool act = s < len[r];
         float di = 0.f, dj = 0.f, df = 0.f, dov = 0.f;
         if (act) {
+          const Saved v = sv[ub][r];
           const int pos = dir == 0 ? s : len[r] - 1 - s;
           const int64_t ro = (int64_t)bidx[r] * T + pos;
-          const float* gp = gates + ro * grow + dir * 4 * H + unit;
-          const float gi = gp[0], gj = gp[H], gf = gp[2 * H], go = gp[3 * H];
-          const float ct = cbuf[ro * yrow + dir * H + unit];
-          float cp = 0.f;
-          if (s > 0) {
-            const int64_t rp = (int64_t)bidx[r] * T + (dir == 0 ? pos - 1 : pos + 1);
-            cp = cbuf[rp * yrow + dir * H + unit];
-          }
-          const float dht = dy[ro * yrow + dir * H + unit] + dh[ub][r];
-          const float tc = las_tanh(ct);
-          dov = dht * tc * go * (1.f - go);
-          const float dct = dc[ub][r] + dht * go * (1.f - tc * tc);
-          di = dct * gj * gi * (1.f - gi);
-          dj = dct * gi * (1.f - gj * gj);
-          df = dct * cp * gf * (1.f - gf);
-          dc[ub][r] = dct * gf;
+          const float dht = v.dyv + dh[ub][r];
+          const float tc = las_tanh(v.ct);
+          dov = dht * tc * v.go * (1.f - v.go);
+          const float dct = dc[ub][r] + dht * v.go * (1.f - tc * tc);
+          di = dct * v.gj * v.gi * (1.f - v.gi);
+          dj = dct * v.gi * (1.f - v.gj * v.gj);
+          df = dct * v.cp * v.gf * (1.f - v.gf);
+          dc[ub][r] = dct * v.gf;
           unsigned short* zp = dz + ro * grow + dir * 4 * H + unit;
           zp[0] = las_f2bf(di); zp[H] = las_f2bf(dj); zp[2 * H] = las_f2bf(df); zp[3 * H] = las_f2bf(dov);
         }
@@ -350,12 +371,13 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_kernel(const float* __restric
         }
       }
     }
+    load_saved(s - 1, sv);      // next step's operands: in flight during the all-gather and the MFMAs
 
     // all-gather dz_t from the peers
     if constexpr (G > 1) {
       const u64* src = ex_group + (int64_t)(epoch & 1) * ngroups * G * NGRAN;
       constexpr int TOTAL = (G - 1) * NGRAN;
-      constexpr int CH = 8;                          // granules per thread per chunk
+      constexpr int CH = 12;                         // granules per thread per chunk
       for (int base = 0; base < TOTAL; base += 256 * CH) {
         u64 v[CH];
         unsigned spins = 0;
