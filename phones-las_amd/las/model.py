@@ -70,14 +70,15 @@ class Listener:
         return ops.pyramidal_bilstm(x, source_sequence_length, mode, self.hp, weights=self.layers,
                                     tape=self.tape, in_features=self.F)
 
-    def backward(self, d_outputs, d_state, grads):
+    def backward(self, d_outputs, d_state, grads, overlap=None):
         """d_outputs: fp32 gradient w.r.t. the encoder outputs [B,T',M]; d_state: (dc, dh) [nd,B,H] or None."""
         recs = [r for r in self.tape if r['kind'] == 'bilstm']
         dy = d_outputs
         for l in range(len(recs) - 1, -1, -1):
             r = recs[l]
             dy = dy.view(r['B'], r['T'], r['nd'] * r['H'])
-            dx = ops.bilstm_backward(r, dy, d_state if l == len(recs) - 1 else None, grads, need_dx=(l > 0))
+            dx = ops.bilstm_backward(r, dy, d_state if l == len(recs) - 1 else None, grads, need_dx=(l > 0),
+                                     overlap=overlap)
             dy = dx
         self.tape = None
 
@@ -237,7 +238,7 @@ class Speller:
         return logits
 
     # ---------------------------------------------------------------------------------------------
-    def backward(self, dlogits, grads):
+    def backward(self, dlogits, grads, overlap=None):
         """dlogits bf16 [B,U,Vp] (zero in the pad columns).  Accumulates weight gradients into ``grads`` and
         returns (d_memory fp32 [B,T',M], d_encoder_state or None)."""
         sv = self.saved
@@ -248,9 +249,6 @@ class Speller:
         dev, bf, f32 = dlogits.device, torch.bfloat16, torch.float32
         lib, st = hip.lib(), hip.stream()
         BU = B * U
-        # projection layer
-        hip.gemm_tn(sv['ctx_all'], dlogits, grads[self.K_PROJ], M, V, BU, lda=M, ldb=Vp, ldc=V, split_k=4)
-        hip.colsum_bf16(dlogits, BU, V, grads[self.B_PROJ], ldx=Vp)
         dattn_proj = torch.empty(B, U, M, dtype=f32, device=dev)
         hip.gemm_nt(dlogits, self.wproj, dattn_proj, BU, M, Vp, lda=Vp, ldb=Vp, ldc=M)
         dc = torch.zeros(B, Hd, dtype=f32, device=dev)
@@ -286,17 +284,8 @@ class Speller:
                 s.dpq_out, s.lddpq = hip.addr(dpq_all, t * Hd), U * Hd
             hip.check(lib.las_decoder_step_bwd(C.byref(s), st))
             hip.gemm_nt(dz_all[:, t], self.kc, dfeed, B, W, 4 * Hd, lda=U * 4 * Hd, ldb=4 * Hd, ldc=W)
-        # weight gradients of the cell: rows [V, V+M+Hd) from [attention_{t-1}, h_{t-1}], rows [0,V) from the tokens
-        gk = grads[self.K_CELL]
-        hip.gemm_tn(sv['AH'], dz_all, gk[V:], W, 4 * Hd, BU, lda=W, ldb=4 * Hd, ldc=4 * Hd, split_k=4)
-        onehot = torch.zeros(BU, Vp, dtype=bf, device=dev)
-        onehot.scatter_(1, sv['tin'][:, :U].reshape(BU, 1).long(), 1.0)
-        hip.gemm_tn(onehot, dz_all, gk, V, 4 * Hd, BU, lda=Vp, ldb=4 * Hd, ldc=4 * Hd, split_k=4)
-        hip.colsum_bf16(dz_all, BU, 4 * Hd, grads[self.B_CELL], ldx=4 * Hd)
-        # attention: d(keys), d(memory)
-        if bah:
-            hip.gemm_tn(sv['h_all'], dpq_all, grads[self.K_Q], Hd, Hd, BU, lda=Hd, ldb=Hd, ldc=Hd, split_k=4)
-        else:
+        # critical path: d(keys), d(memory) feed the listener's backward
+        if not bah:
             dkeys = torch.zeros(B, Tm, Hd, dtype=f32, device=dev)
             hip.gemm_tn(ds_all, sv['h_all'], dkeys, Tm, Hd, U, lda=Tmp, ldb=Hd, ldc=Hd, batch=B, sa=U * Tmp,
                         sb=U * Hd, sc=Tm * Hd)
@@ -306,7 +295,23 @@ class Speller:
         dkeys_bf = torch.empty(B * Tm, Hd, dtype=bf, device=dev)
         hip.cast_bf16(dkeys, B * Tm, Hd, dkeys_bf, B * Tm, Hd, ldd=Hd, lds=Hd)
         hip.gemm_nt(dkeys_bf, self.wmem, dmem, B * Tm, M, Hd, lda=Hd, ldb=Hd, ldc=M, accumulate=True)
-        hip.gemm_tn(sv['memory'], dkeys_bf, grads[self.K_MEM], M, Hd, B * Tm, lda=M, ldb=Hd, ldc=Hd, split_k=8)
+        # weight gradients (off the critical path): cell rows [V, V+M+Hd) from [attention_{t-1}, h_{t-1}], rows
+        # [0,V) from the tokens, projection, memory_layer, query_layer
+        onehot = torch.zeros(BU, Vp, dtype=bf, device=dev)
+        onehot.scatter_(1, sv['tin'][:, :U].reshape(BU, 1).long(), 1.0)
+        keep = [sv['AH'], dz_all, onehot, sv['ctx_all'], dlogits, sv['memory'], dkeys_bf, sv['h_all']]
+        if bah:
+            keep.append(dpq_all)
+        with (overlap or ops._NoOverlap()).fork(*keep):
+            gk = grads[self.K_CELL]
+            hip.gemm_tn(sv['AH'], dz_all, gk[V:], W, 4 * Hd, BU, lda=W, ldb=4 * Hd, ldc=4 * Hd, split_k=4)
+            hip.gemm_tn(onehot, dz_all, gk, V, 4 * Hd, BU, lda=Vp, ldb=4 * Hd, ldc=4 * Hd, split_k=4)
+            hip.colsum_bf16(dz_all, BU, 4 * Hd, grads[self.B_CELL], ldx=4 * Hd)
+            hip.gemm_tn(sv['ctx_all'], dlogits, grads[self.K_PROJ], M, V, BU, lda=M, ldb=Vp, ldc=V, split_k=4)
+            hip.colsum_bf16(dlogits, BU, V, grads[self.B_PROJ], ldx=Vp)
+            hip.gemm_tn(sv['memory'], dkeys_bf, grads[self.K_MEM], M, Hd, B * Tm, lda=M, ldb=Hd, ldc=Hd, split_k=8)
+            if bah:
+                hip.gemm_tn(sv['h_all'], dpq_all, grads[self.K_Q], Hd, Hd, BU, lda=Hd, ldb=Hd, ldc=Hd, split_k=4)
         d_state = None
         if sv['passed']:
             d_state = (dc, dfeed[:, M:])

@@ -56,6 +56,37 @@ def check_lstm_status(B, H, nd):
         raise hip.LasError('recurrent kernel reported an inter-workgroup timeout (status %d)' % st)
 
 
+class Overlap:
+    """A second HIP stream for launches that are off the critical path of the backward pass (weight-gradient
+    GEMMs, bias sums): they fill the ~224 CUs the persistent recurrent kernels leave idle.  fork() makes the side
+    stream wait for everything enqueued so far; join() makes the main stream wait for the side stream.  Tensors
+    the side stream reads are kept alive until join()."""
+
+    def __init__(self):
+        self.side = torch.cuda.Stream()
+        self.keep = []
+
+    def fork(self, *tensors):
+        self.side.wait_stream(torch.cuda.current_stream())
+        self.keep.extend(tensors)
+        return torch.cuda.stream(self.side)
+
+    def join(self):
+        torch.cuda.current_stream().wait_stream(self.side)
+        self.keep.clear()
+
+
+class _NoOverlap:
+    """Same interface, everything on the current stream."""
+
+    def fork(self, *tensors):
+        import contextlib
+        return contextlib.nullcontext()
+
+    def join(self):
+        pass
+
+
 def _dirs(unidirectional):
     return ['fw'] if unidirectional else ['fw', 'bw']
 
@@ -134,7 +165,7 @@ def concat_outputs(outputs):
     return outputs
 
 
-def bilstm_backward(rec, dy, d_state, grads, need_dx=True):
+def bilstm_backward(rec, dy, d_state, grads, need_dx=True, overlap=None):
     """Reverse-mode AD of one bilstm() call.  dy [B,T,nd*H] fp32 (gradient of the concatenated outputs),
     d_state: None or (dc_last, dh_last) each [nd,B,H] fp32.  Accumulates into ``grads`` (name -> fp32
     tensor, same shapes as the variables) and returns dX [B,T,D'] fp32 (or None)."""
@@ -148,20 +179,22 @@ def bilstm_backward(rec, dy, d_state, grads, need_dx=True):
                                                hip.p(lstm_workspace(B, H, nd)), B, T, H, nd, hip.stream()))
     x, y = rec['inputs'], rec['y']
     BT = B * T
-    split = max(1, min(32, BT // 2048))
-    for i, (kn, bn) in enumerate(w.names):
-        gk, gb = grads[kn], grads[bn]
-        dzi = dz.view(BT, nd * 4 * H)[:, i * 4 * H:]
-        if D > 0:
-            hip.gemm_tn(x, dzi, gk, D, 4 * H, BT, lda=Dp, ldb=nd * 4 * H, ldc=4 * H, split_k=split)
-        yi = y.view(BT, nd * H)[:, i * H:]
-        hip.gemm_tn(yi, dzi, gk[D:], H, 4 * H, BT, lda=nd * H, ldb=nd * 4 * H, ldc=4 * H,
-                    a_shift=(-1 if i == 0 else 1), period=T, split_k=split)
-        hip.colsum_bf16(dzi, BT, 4 * H, gb, ldx=nd * 4 * H)
+    # critical path first: dX feeds the next (lower) layer's recurrence
     dx = None
     if need_dx:
         dx = torch.empty(B, T, D, dtype=torch.float32, device=dev)
         hip.gemm_nt(dz, w.kx, dx, BT, D, nd * 4 * H, lda=nd * 4 * H, ldb=nd * 4 * H, ldc=D)
+    split = max(1, min(32, BT // 2048))
+    with (overlap or _NoOverlap()).fork(dz, x, y):
+        for i, (kn, bn) in enumerate(w.names):
+            gk, gb = grads[kn], grads[bn]
+            dzi = dz.view(BT, nd * 4 * H)[:, i * 4 * H:]
+            if D > 0:
+                hip.gemm_tn(x, dzi, gk, D, 4 * H, BT, lda=Dp, ldb=nd * 4 * H, ldc=4 * H, split_k=split)
+            yi = y.view(BT, nd * H)[:, i * H:]
+            hip.gemm_tn(yi, dzi, gk[D:], H, 4 * H, BT, lda=nd * H, ldb=nd * 4 * H, ldc=4 * H,
+                        a_shift=(-1 if i == 0 else 1), period=T, split_k=split)
+            hip.colsum_bf16(dzi, BT, 4 * H, gb, ldx=nd * 4 * H)
     return dx
 
 

@@ -178,6 +178,7 @@ class LasModel:
         self.world_size = world_size
         self.process_group = process_group
         self._images_stale = False
+        self.overlap = las_model.ops.Overlap()
 
     # -- weights --------------------------------------------------------------------------------
     def load_variables(self, tensors):
@@ -206,7 +207,7 @@ class LasModel:
 
     def backward(self, dlogits):
         g = self.vars.grads
-        dmem, d_state = self.speller.backward(dlogits, g)
+        dmem, d_state = self.speller.backward(dlogits, g, self.overlap)
         ds = None
         if d_state is not None:
             nd = 1 if self.params.encoder.unidirectional else 2
@@ -216,7 +217,8 @@ class LasModel:
             dc[0].copy_(d_state[0])
             dh[0].copy_(d_state[1])
             ds = (dc, dh)
-        self.listener.backward(dmem, ds, g)
+        self.listener.backward(dmem, ds, g, self.overlap)
+        self.overlap.join()
 
     def clip_gradients(self):
         """L2 gradient + per-tensor clip_by_norm(GRAD_NORM) on the flat buffers (model_helper.py:411-416)."""
