@@ -12,7 +12,7 @@ import math
 import numpy as np
 import torch
 
-from . import hip
+from . import dp, hip
 from .las import model as las_model
 from .las.ops import TRAIN, EVAL, PREDICT
 from .utils import metrics_utils
@@ -103,6 +103,7 @@ class Variables:
         self.m = torch.zeros(self.total, dtype=f32, device=device)
         self.v = torch.zeros(self.total, dtype=f32, device=device)
         self.seg = torch.tensor(offs, dtype=torch.int64, device=device)
+        self.device = device
         self.sumsq = torch.zeros(len(self.table), dtype=f32, device=device)
         self.params = self._views(self.flat)
         self.grads = self._views(self.grad)
@@ -232,7 +233,7 @@ class LasModel:
     def all_reduce_gradients(self):
         """CrossShardOptimizer's cross-replica sum (model_helper.py:405-406): one RCCL all-reduce, after the clip."""
         if self.world_size > 1:
-            torch.distributed.all_reduce(self.vars.grad, op=torch.distributed.ReduceOp.SUM, group=self.process_group)
+            dp.all_reduce_sum_(self.vars.grad, self.process_group)
 
     def adam_update(self):
         """tf.train.AdamOptimizer.apply_gradients + global_step increment (model_helper.py:404,417)."""

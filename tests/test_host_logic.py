@@ -1,0 +1,81 @@
+"""Host-side logic that needs no GPU: hyper-parameter files, vocabulary, edit distance, the variable table and
+the data-parallel helpers."""
+import argparse
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import las_oracle as O
+from tests.helpers import make_hparams
+
+
+def test_param_table_matches_oracle_for_several_models():
+    from phones_las_amd import model_helper as mh
+    for kw in (dict(), dict(att='bahdanau', L=3, H=128), dict(unidirectional=True, L=1), dict(dec_layers=2, bottom_only=False, pass_hidden=False)):
+        ohp, params = make_hparams(**kw)
+        assert mh.param_table(params) == [(n, tuple(s), i) for n, s, i in O.param_table(ohp)]
+
+
+def test_variables_layout_and_init_match_oracle_seed():
+    from phones_las_amd import model_helper as mh
+    ohp, params = make_hparams()
+    v = mh.Variables(mh.param_table(params), device='cpu')
+    v.initialize(4321)
+    ref = O.init_params(ohp, 4321)
+    for n in ref:
+        assert torch.equal(v.params[n].double(), ref[n]), n
+    assert all(o % 4 == 0 for o in v.offsets)
+    assert v.params['listener/bilstm_0/fw/lstm_cell/kernel'].data_ptr() == v.flat.data_ptr()
+    assert v.num_parameters() == sum(int(np.prod(s)) for _, s, _ in O.param_table(ohp))
+
+
+def test_hparams_json_is_double_encoded_and_existing_file_wins(tmp_path):
+    from phones_las_amd.utils import params_utils as pu
+    d = str(tmp_path / 'model')
+    args = argparse.Namespace(model_dir=d, encoder_units=256, learning_rate=1e-3, reset=False)
+    p = pu.create_hparams(args, target_vocab_size=64)
+    assert p.encoder.num_units == 256 and p.decoder.target_vocab_size == 64 and p.learning_rate == 1e-3
+    raw = json.load(open(os.path.join(d, 'hparams.json')))
+    assert isinstance(raw, str) and json.loads(raw)['encoder_units'] == 256          # JSON string holding JSON
+    # rerun with a different learning rate: the saved file wins (reference quirk B6) ...
+    args2 = argparse.Namespace(model_dir=d, encoder_units=128, learning_rate=5e-4, reset=False)
+    p2 = pu.create_hparams(args2)
+    assert p2.encoder.num_units == 256 and p2.learning_rate == 1e-3
+    # ... unless --reset
+    args3 = argparse.Namespace(model_dir=d, encoder_units=128, learning_rate=5e-4, reset=True)
+    p3 = pu.create_hparams(args3, target_vocab_size=64)
+    assert p3.encoder.num_units == 128 and p3.learning_rate == 5e-4
+    with pytest.raises(ValueError):
+        pu.create_hparams(argparse.Namespace(model_dir=str(tmp_path / 'new'), reset=False))
+
+
+def test_vocab_ids_start_after_specials(tmp_path):
+    from phones_las_amd.utils import vocab_utils as vu
+    f = tmp_path / 'vocab.txt'
+    f.write_text('aa\nb\nə\n', encoding='utf-8')
+    assert vu.load_vocab(str(f)) == ['<unk>', '<s>', '</s>', 'aa', 'b', 'ə']
+    t = vu.create_vocab_table(str(f))
+    assert t.lookup(['b', 'zz', '</s>']) == [4, 0, 2]
+
+
+def test_edit_distance_matches_oracle_on_random_rows():
+    from phones_las_amd.utils import metrics_utils as mu
+    rng = np.random.default_rng(0)
+    hyp = rng.integers(-1, 6, size=(50, 9)).tolist()
+    tru = rng.integers(2, 6, size=(50, 7)).tolist()
+    assert mu.edit_distance(hyp, tru, 2) == O.edit_distance(hyp, tru, 2)
+    mapping = [0, 1, 2, 3, 3, 4]
+    hyp = [[max(v, 0) for v in r] for r in hyp]
+    assert mu.edit_distance(hyp, tru, 2, mapping) == O.edit_distance(hyp, tru, 2, mapping)
+
+
+def test_shard_batch_splits_evenly():
+    from phones_las_amd import dp
+    x = {'a': torch.arange(12).reshape(6, 2), 'b': torch.arange(6)}
+    s1 = dp.shard_batch(x, 1, 3)
+    assert s1['a'].tolist() == [[4, 5], [6, 7]] and s1['b'].tolist() == [2, 3]
+    with pytest.raises(ValueError):
+        dp.shard_batch(x, 0, 4)
