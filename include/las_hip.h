@@ -66,21 +66,26 @@ int las_gemm_nt(const las_bf16* A, int64_t lda, const las_bf16* B, int64_t ldb, 
  * model_helper.py:415).  A [K,M] and B [K,N] bf16 with M resp. N contiguous.  C fp32, always
  * accumulated with atomics (zero it first).  a_shift/period: row k of A is taken from
  * k + a_shift when 0 <= (k % period) + a_shift < period and is zero otherwise (the h_{t-1}
- * operand of dK_h without materialising a shifted copy; period = T).  period = 0 disables. */
+ * operand of dK_h without materialising a shifted copy; period = T).  period = 0 disables.
+ * c_perm_h = H > 0: B's columns are gate-interleaved (n = u*4+g, the layout the recurrent kernels
+ * use for gates/dz); C is written in TF order (column g*H+u).  N must be 4H. */
 int las_gemm_tn(const las_bf16* A, int64_t lda, const las_bf16* B, int64_t ldb, float* C, int64_t ldc,
-                int M, int N, int K, int a_shift, int period, int batch, int64_t sa, int64_t sb,
-                int64_t sc, int split_k, void* stream);
+                int M, int N, int K, int a_shift, int period, int c_perm_h, int batch, int64_t sa,
+                int64_t sb, int64_t sc, int split_k, void* stream);
 
 /* dst_bf16[r, c] = src_f32[r, c] (transpose = 0) or dst[c, r] = src[r, c] (transpose = 1), with the
  * destination window [dst_rows, dst_cols] (row stride ldd) zero-padded.  `batch` windows at element
- * strides src_bstride / dst_bstride.  Used to derive the bf16 operand copies of the fp32 master
- * weights and to cast/pad the (B,T,F) feature batch (utils/dataset_utils.py:254-281 padded_batch). */
+ * strides src_bstride / dst_bstride.  src_col_perm_h = H > 0 reads the source's columns through the
+ * gate-interleaving permutation (logical column u*4+g <- TF column g*H+u; cols must be 4H).  Used to
+ * derive the bf16 operand copies of the fp32 master weights and to cast/pad the (B,T,F) feature batch
+ * (utils/dataset_utils.py:254-281 padded_batch). */
 int las_cast_bf16(const float* src, int64_t lds, int rows, int cols, las_bf16* dst, int64_t ldd,
                   int dst_rows, int dst_cols, int transpose, int batch, int64_t src_bstride,
-                  int64_t dst_bstride, void* stream);
+                  int64_t dst_bstride, int src_col_perm_h, void* stream);
 
-/* out[n] += sum_m X[m, n] for a bf16 [M,N] matrix (bias gradients). */
-int las_colsum_bf16(const las_bf16* X, int64_t ldx, int M, int N, float* out, void* stream);
+/* out[n] += sum_m X[m, n] for a bf16 [M,N] matrix (bias gradients).  out_perm_h = H > 0: X's columns are
+ * gate-interleaved (u*4+g) and the sum of column n lands at TF index g*H+u. */
+int las_colsum_bf16(const las_bf16* X, int64_t ldx, int M, int N, float* out, int out_perm_h, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Listener: one (Bi)LSTM layer = las/ops.py:23-46 `bilstm` (tf.nn.bidirectional_dynamic_rnn /
@@ -93,6 +98,9 @@ int las_lstm_pack_recurrent(const float* kernel_h, int H, las_bf16* packed, void
 
 /* Forward recurrence.  xproj [B,T,ndir*4H] fp32 holds x_t*K_x + b on entry (las_gemm_nt) and
  * the activated gates (sigma(i), tanh(j), sigma(f+1), sigma(o)) on exit (saved for backward).
+ * Within a direction the 4H columns are GATE-INTERLEAVED: column u*4+g holds gate g (i,j,f,o) of
+ * unit u, so one lane reads/writes its four gates with a single 16-byte access; build the operands
+ * with las_cast_bf16(..., src_col_perm_h = H).  dz of the backward uses the same column order.
  * wpacked: ndir images from las_lstm_pack_recurrent.  y [B,T,ndir*H] bf16: outputs, fw in
  * [0,H) and bw in [H,2H) (the tf.concat of las/ops.py:81), zero for t >= length.  cbuf
  * [B,T,ndir*H] fp32: cell states (saved).  c_last/h_last [ndir,B,H] fp32: final states

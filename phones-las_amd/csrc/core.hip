@@ -23,7 +23,7 @@ extern "C" const char* las_last_error(void) { return g_err; }
 namespace {
 
 __global__ void cast_kernel(const float* src, int64_t lds_, int rows, int cols, unsigned short* dst, int64_t ldd,
-                            int dst_rows, int dst_cols, int transpose, int64_t sbs, int64_t dbs) {
+                            int dst_rows, int dst_cols, int transpose, int64_t sbs, int64_t dbs, int perm_h) {
   // one thread per destination element of the [dst_rows, dst_cols] window (row stride ldd)
   src += (int64_t)blockIdx.y * sbs;
   dst += (int64_t)blockIdx.y * dbs;
@@ -31,14 +31,17 @@ __global__ void cast_kernel(const float* src, int64_t lds_, int rows, int cols, 
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
     const int dr = (int)(i / dst_cols), dc = (int)(i % dst_cols);
     const int sr = transpose ? dc : dr;
-    const int sc = transpose ? dr : dc;
+    int sc = transpose ? dr : dc;
     float v = 0.f;
-    if (sr < rows && sc < cols) v = src[(int64_t)sr * lds_ + sc];
+    if (sr < rows && sc < cols) {
+      if (perm_h > 0) sc = (sc & 3) * perm_h + (sc >> 2);   // logical gate-interleaved column u*4+g <- TF column g*H+u
+      v = src[(int64_t)sr * lds_ + sc];
+    }
     dst[(int64_t)dr * ldd + dc] = las_f2bf(v);
   }
 }
 
-__global__ void colsum_kernel(const unsigned short* X, int64_t ldx, int M, int N, float* out) {
+__global__ void colsum_kernel(const unsigned short* X, int64_t ldx, int M, int N, float* out, int perm_h) {
   // blockDim = (64 columns, 4 row lanes); grid.x over column groups, grid.y over row chunks
   const int col = blockIdx.x * 64 + threadIdx.x;
   const int rows_per = (M + gridDim.y - 1) / gridDim.y;
@@ -51,7 +54,8 @@ __global__ void colsum_kernel(const unsigned short* X, int64_t ldx, int M, int N
   red[threadIdx.y][threadIdx.x] = s;
   __syncthreads();
   if (threadIdx.y == 0 && col < N) {
-    atomicAdd(out + col, red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
+    const int oc = perm_h > 0 ? (col & 3) * perm_h + (col >> 2) : col;
+    atomicAdd(out + oc, red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
   }
 }
 
@@ -64,23 +68,24 @@ __global__ void pyramid_len_kernel(const int32_t* a, int32_t* b, int B) {
 
 extern "C" int las_cast_bf16(const float* src, int64_t lds_, int rows, int cols, las_bf16* dst, int64_t ldd,
                              int dst_rows, int dst_cols, int transpose, int batch, int64_t src_bstride,
-                             int64_t dst_bstride, void* stream) {
+                             int64_t dst_bstride, int src_col_perm_h, void* stream) {
   LAS_REQUIRE(rows >= 0 && cols >= 0 && dst_rows > 0 && dst_cols > 0 && ldd >= dst_cols && batch > 0,
               "las_cast_bf16: bad shape");
+  LAS_REQUIRE(src_col_perm_h == 0 || cols == 4 * src_col_perm_h, "las_cast_bf16: src_col_perm_h needs cols == 4*H");
   const int64_t total = (int64_t)dst_rows * dst_cols;
   int blocks = (int)((total + 255) / 256);
   if (blocks > 2048) blocks = 2048;
   hipLaunchKernelGGL(cast_kernel, dim3(blocks, batch), dim3(256), 0, (hipStream_t)stream, src, lds_, rows, cols, dst,
-                     ldd, dst_rows, dst_cols, transpose, src_bstride, dst_bstride);
+                     ldd, dst_rows, dst_cols, transpose, src_bstride, dst_bstride, src_col_perm_h);
   LAS_LAUNCH_CHECK("cast launch");
   return LAS_OK;
 }
 
-extern "C" int las_colsum_bf16(const las_bf16* X, int64_t ldx, int M, int N, float* out, void* stream) {
+extern "C" int las_colsum_bf16(const las_bf16* X, int64_t ldx, int M, int N, float* out, int out_perm_h, void* stream) {
   LAS_REQUIRE(M > 0 && N > 0, "las_colsum_bf16: empty");
   int chunks = (M + 511) / 512;
   if (chunks > 256) chunks = 256;
-  hipLaunchKernelGGL(colsum_kernel, dim3((N + 63) / 64, chunks), dim3(64, 4), 0, (hipStream_t)stream, X, ldx, M, N, out);
+  hipLaunchKernelGGL(colsum_kernel, dim3((N + 63) / 64, chunks), dim3(64, 4), 0, (hipStream_t)stream, X, ldx, M, N, out, out_perm_h);
   LAS_LAUNCH_CHECK("colsum launch");
   return LAS_OK;
 }

@@ -25,6 +25,7 @@ struct GemmArgs {
   int M, N, K;
   int out_bf16, accumulate, atomic, split_k;
   int a_shift, period;
+  int c_perm_h;   // > 0: output column n (gate-interleaved index u*4+g) is stored at TF column g*H+u, H = c_perm_h
 };
 
 template <int BM, int BN, bool TN>
@@ -171,8 +172,9 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
   for (int i = 0; i < FM; ++i) {
 #pragma unroll
     for (int j = 0; j < FN; ++j) {
-      const int col = n0 + wc * (BN / 2) + j * 16 + (lane & 15);
-      if (col >= g.N) continue;
+      const int coln = n0 + wc * (BN / 2) + j * 16 + (lane & 15);
+      if (coln >= g.N) continue;
+      const int col = g.c_perm_h > 0 ? (coln & 3) * g.c_perm_h + (coln >> 2) : coln;
       const float bv = (g.bias != nullptr && slice == 0) ? g.bias[col] : 0.f;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
@@ -285,7 +287,7 @@ extern "C" int las_gemm_nt(const las_bf16* A, int64_t lda, const las_bf16* B, in
   if (split_k < 1) split_k = 1;
   LAS_REQUIRE(!(out_bf16 && (accumulate || split_k > 1)), "las_gemm_nt: bf16 output cannot accumulate or split K");
   hipStream_t st = (hipStream_t)stream;
-  GemmArgs g{A, B, C, bias, lda, ldb, ldc, sa, sb, sc, M, N, K, out_bf16, accumulate, split_k > 1 ? 1 : 0, split_k, 0, 0};
+  GemmArgs g{A, B, C, bias, lda, ldb, ldc, sa, sb, sc, M, N, K, out_bf16, accumulate, split_k > 1 ? 1 : 0, split_k, 0, 0, 0};
   if (split_k > 1 && !accumulate) {
     hipLaunchKernelGGL(zero_rows_kernel, dim3(64, 1, batch), dim3(256), 0, st, (float*)C, ldc, M, N, sc);
     LAS_LAUNCH_CHECK("gemm zero");
@@ -300,15 +302,16 @@ extern "C" int las_gemm_nt(const las_bf16* A, int64_t lda, const las_bf16* B, in
 }
 
 extern "C" int las_gemm_tn(const las_bf16* A, int64_t lda, const las_bf16* B, int64_t ldb, float* C, int64_t ldc,
-                           int M, int N, int K, int a_shift, int period, int batch, int64_t sa, int64_t sb,
-                           int64_t sc, int split_k, void* stream) {
+                           int M, int N, int K, int a_shift, int period, int c_perm_h, int batch, int64_t sa,
+                           int64_t sb, int64_t sc, int split_k, void* stream) {
   LAS_REQUIRE(M > 0 && N > 0 && K > 0 && batch > 0, "las_gemm_tn: empty problem");
   LAS_REQUIRE(lda % 8 == 0 && ldb % 8 == 0 && lda >= ((M + 7) / 8) * 8 && ldb >= ((N + 7) / 8) * 8,
               "las_gemm_tn: lda/ldb must be multiples of 8 covering M/N rounded up to 8");
   LAS_REQUIRE(((uintptr_t)A % 16 == 0) && ((uintptr_t)B % 16 == 0) && sa % 8 == 0 && sb % 8 == 0, "las_gemm_tn: operands must be 16-byte aligned");
   if (split_k < 1) split_k = 1;
   hipStream_t st = (hipStream_t)stream;
-  GemmArgs g{A, B, C, nullptr, lda, ldb, ldc, sa, sb, sc, M, N, K, 0, 1, 1, split_k, a_shift, period};
+  LAS_REQUIRE(c_perm_h == 0 || N == 4 * c_perm_h, "las_gemm_tn: c_perm_h needs N == 4*H");
+  GemmArgs g{A, B, C, nullptr, lda, ldb, ldc, sa, sb, sc, M, N, K, 0, 1, 1, split_k, a_shift, period, c_perm_h};
   if (M <= 64 || N <= 64) return launch<64, 64, true>(g, batch, st);
   return launch<128, 128, true>(g, batch, st);
 }

@@ -61,8 +61,15 @@ __global__ void pack_recurrent_kernel(const float* kh, int H, unsigned short* pa
 // ------------------------------------------------------------------------------------------------
 // forward
 // ------------------------------------------------------------------------------------------------
+// Workgroup size: 4 compute waves, plus one PREFETCH wave when the chain is shared by several workgroups.  The
+// prefetch wave only touches (loads and discards) the cache lines the compute waves will need PF_DIST steps
+// later, so their own loads hit L2 instead of HBM: a wave's vmcnt retires in order, so a slow HBM load issued by
+// a compute wave would delay the return of its next inter-workgroup poll.
+__host__ __device__ constexpr int rec_threads(int H) { return coop_members(H) > 1 ? 320 : 256; }
+constexpr int PF_DIST = 3;
+
 template <int H>
-__global__ __launch_bounds__(256, 1) void lstm_fwd_kernel(float* __restrict__ xproj, const unsigned short* __restrict__ wpacked,
+__global__ __launch_bounds__(rec_threads(H)) void lstm_fwd_kernel(float* __restrict__ xproj, const unsigned short* __restrict__ wpacked,
                                                           const int32_t* __restrict__ length, unsigned short* __restrict__ y,
                                                           float* __restrict__ cbuf, float* __restrict__ c_last,
                                                           float* __restrict__ h_last, u64* __restrict__ exch,
@@ -75,6 +82,7 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_kernel(float* __restrict__ xp
   constexpr int NGRAN = 8 * HS;        // granules a member publishes per step (2 rows x 1 unit each)
   __shared__ __attribute__((aligned(16))) unsigned short hlds[2][16][LS];
   __shared__ int fail_flag;
+  __shared__ __attribute__((aligned(16))) float pf_scratch[256];   // 1 KiB sink of the prefetch wave's LDS-DMAs
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int group = blockIdx.x % ngroups, member = blockIdx.x / ngroups;
@@ -94,6 +102,7 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_kernel(float* __restrict__ xp
 
   // register-resident B fragments of this wave's K_h columns
   bf16x8 wf[UB][KC][4];
+  if (wave < 4)
 #pragma unroll
   for (int ub = 0; ub < UB; ++ub) {
     const int ublk = (member * 4 + wave) * UB + ub;
@@ -111,7 +120,7 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_kernel(float* __restrict__ xp
 #pragma unroll
     for (int r = 0; r < 4; ++r) { c[ub][r] = 0.f; h[ub][r] = 0.f; }
 
-  for (int i = tid; i < 2 * 16 * LS; i += 256) (&hlds[0][0][0])[i] = 0;
+  for (int i = tid; i < 2 * 16 * LS; i += rec_threads(H)) (&hlds[0][0][0])[i] = 0;
   if (tid == 0) fail_flag = 0;
   __syncthreads();
 
@@ -119,6 +128,32 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_kernel(float* __restrict__ xp
   const int64_t yrow = (int64_t)ndir * H;
   const int unit0 = member * HS + wave * (HS / 4) + l15;      // + ub*16
   u64* ex_group = exch + (int64_t)group * G * NGRAN;           // + parity*ngroups*G*NGRAN + member*NGRAN
+
+  if constexpr (G > 1) {
+    if (wave == 4) {
+      // prefetch wave: per step and utterance one 1-KiB LDS-DMA (global_load_lds, 16 B per lane) of this member's
+      // gate-interleaved xproj span into a scratch tile nobody reads: no VGPR destination, nothing to wait for.
+      // It uses the raw s_barrier (a __syncthreads() would drain the DMAs first).
+      const int mylen = (slice * 16 + l15 < B) ? min(length[slice * 16 + l15], T) : 0;
+      for (int s = 0; s < smax; ++s) {
+        const int sp = s + PF_DIST;
+#pragma unroll
+        for (int rr = 0; rr < 16; ++rr) {
+          const int ll = __builtin_amdgcn_readlane(mylen, rr);
+          if (sp < ll) {
+            const int pos = dir == 0 ? sp : ll - 1 - sp;
+            const float* src = xproj + ((int64_t)(slice * 16 + rr) * T + pos) * xrow + dir * 4 * H + member * HS * 4 + lane * 4;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src),
+                                             (__attribute__((address_space(3))) void*)(pf_scratch), 16, 0, 0);
+          }
+        }
+        __builtin_amdgcn_s_barrier();
+        if (*reinterpret_cast<volatile int*>(&fail_flag)) break;
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      return;
+    }
+  }
 
   int cur = 0;
   for (int s = 0; s < smax; ++s) {
@@ -133,12 +168,13 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_kernel(float* __restrict__ xp
     // x_t K_x + b of this step: issued now, consumed after the MFMAs
     float xp[4][UB][4];
 #pragma unroll
-    for (int g = 0; g < 4; ++g)
+    for (int ub = 0; ub < UB; ++ub)
 #pragma unroll
-      for (int ub = 0; ub < UB; ++ub)
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-          xp[g][ub][r] = act[r] ? xproj[rowoff[r] * xrow + dir * 4 * H + g * H + unit0 + ub * 16] : 0.f;
+      for (int r = 0; r < 4; ++r) {
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (act[r]) v = *reinterpret_cast<const float4*>(xproj + rowoff[r] * xrow + dir * 4 * H + (unit0 + ub * 16) * 4);
+        xp[0][ub][r] = v.x; xp[1][ub][r] = v.y; xp[2][ub][r] = v.z; xp[3][ub][r] = v.w;
+      }
 
     // all-gather h_{s-1}: peers' slices arrive as granules tagged with epoch s
     if constexpr (G > 1) if (s > 0) {
@@ -205,8 +241,7 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_kernel(float* __restrict__ xp
         const float cn = gf * c[ub][r] + gi * gj;
         const unsigned short hn = las_f2bf(go * las_tanh(cn));
         if (act[r]) {
-          float* gp = xproj + rowoff[r] * xrow + dir * 4 * H + unit;
-          gp[0] = gi; gp[H] = gj; gp[2 * H] = gf; gp[3 * H] = go;
+          *reinterpret_cast<float4*>(xproj + rowoff[r] * xrow + dir * 4 * H + unit * 4) = make_float4(gi, gj, gf, go);
           cbuf[rowoff[r] * yrow + dir * H + unit] = cn;
           y[rowoff[r] * yrow + dir * H + unit] = hn;
           c[ub][r] = cn;
@@ -313,8 +348,8 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_kernel(const float* __restric
         if (s >= 0 && s < len[r]) {
           const int pos = dir == 0 ? s : len[r] - 1 - s;
           const int64_t ro = (int64_t)bidx[r] * T + pos;
-          const float* gp = gates + ro * grow + dir * 4 * H + unit;
-          v.gi = gp[0]; v.gj = gp[H]; v.gf = gp[2 * H]; v.go = gp[3 * H];
+          const float4 gv = *reinterpret_cast<const float4*>(gates + ro * grow + dir * 4 * H + unit * 4);
+          v.gi = gv.x; v.gj = gv.y; v.gf = gv.z; v.go = gv.w;
           v.ct = cbuf[ro * yrow + dir * H + unit];
           if (s > 0) {
             const int64_t rp = (int64_t)bidx[r] * T + (dir == 0 ? pos - 1 : pos + 1);
@@ -356,8 +391,10 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_kernel(const float* __restric
           dj = dct * v.gi * (1.f - v.gj * v.gj);
           df = dct * v.cp * v.gf * (1.f - v.gf);
           dc[ub][r] = dct * v.gf;
-          unsigned short* zp = dz + ro * grow + dir * 4 * H + unit;
-          zp[0] = las_f2bf(di); zp[H] = las_f2bf(dj); zp[2 * H] = las_f2bf(df); zp[3 * H] = las_f2bf(dov);
+          uint2 zv;
+          zv.x = (unsigned)las_f2bf(di) | ((unsigned)las_f2bf(dj) << 16);
+          zv.y = (unsigned)las_f2bf(df) | ((unsigned)las_f2bf(dov) << 16);
+          *reinterpret_cast<uint2*>(dz + ro * grow + dir * 4 * H + unit * 4) = zv;   // gate-interleaved [unit][i,j,f,o]
         }
         zb[0][r] = las_f2bf(di); zb[1][r] = las_f2bf(dj); zb[2][r] = las_f2bf(df); zb[3][r] = las_f2bf(dov);
         unsigned short* zr = zl + (lq * 4 + r) * ZS + unit;
@@ -451,7 +488,7 @@ int launch_fwd(float* xproj, const las_bf16* wp, const int32_t* length, las_bf16
   const CoopGeom g = geom(B, H, ndir, false);
   unsigned* status = reinterpret_cast<unsigned*>(ws);
   u64* exch = reinterpret_cast<u64*>(reinterpret_cast<char*>(ws) + 64);
-  hipLaunchKernelGGL((lstm_fwd_kernel<H>), dim3(g.blocks), dim3(256), 0, st, xproj, wp, length, y, cbuf, c_last, h_last,
+  hipLaunchKernelGGL((lstm_fwd_kernel<H>), dim3(g.blocks), dim3(rec_threads(H)), 0, st, xproj, wp, length, y, cbuf, c_last, h_last,
                      exch, status, B, T, ndir, g.ngroups);
   LAS_LAUNCH_CHECK("lstm fwd launch");
   return LAS_OK;

@@ -21,9 +21,9 @@ _SIGS = {
     'las_version': ([], C.c_int),
     'las_last_error': ([], C.c_char_p),
     'las_gemm_nt': ([_vp, _i64, _vp, _i64, _vp, _i64, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i64, _i64, _i64, _i32, _vp], C.c_int),
-    'las_gemm_tn': ([_vp, _i64, _vp, _i64, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _i64, _i64, _i64, _i32, _vp], C.c_int),
-    'las_cast_bf16': ([_vp, _i64, _i32, _i32, _vp, _i64, _i32, _i32, _i32, _i32, _i64, _i64, _vp], C.c_int),
-    'las_colsum_bf16': ([_vp, _i64, _i32, _i32, _vp, _vp], C.c_int),
+    'las_gemm_tn': ([_vp, _i64, _vp, _i64, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i64, _i64, _i64, _i32, _vp], C.c_int),
+    'las_cast_bf16': ([_vp, _i64, _i32, _i32, _vp, _i64, _i32, _i32, _i32, _i32, _i64, _i64, _i32, _vp], C.c_int),
+    'las_colsum_bf16': ([_vp, _i64, _i32, _i32, _vp, _i32, _vp], C.c_int),
     'las_lstm_pack_recurrent': ([_vp, _i32, _vp, _vp], C.c_int),
     'las_lstm_recurrent_fwd': ([_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp], C.c_int),
     'las_lstm_recurrent_bwd': ([_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp], C.c_int),
@@ -138,22 +138,23 @@ def gemm_nt(A, B, C_, M, N, K, lda=None, ldb=None, ldc=None, bias=None, out_bf16
 
 
 def gemm_tn(A, B, C_, M, N, K, lda=None, ldb=None, ldc=None, a_shift=0, period=0, batch=1, sa=0, sb=0, sc=0,
-            split_k=1):
+            split_k=1, c_perm_h=0):
     lda = lda if lda is not None else A.stride(-2)
     ldb = ldb if ldb is not None else B.stride(-2)
     ldc = ldc if ldc is not None else C_.stride(-2)
-    check(lib().las_gemm_tn(p(A), lda, p(B), ldb, p(C_), ldc, M, N, K, a_shift, period, batch, sa, sb, sc,
+    check(lib().las_gemm_tn(p(A), lda, p(B), ldb, p(C_), ldc, M, N, K, a_shift, period, c_perm_h, batch, sa, sb, sc,
                             split_k, stream()))
 
 
-def cast_bf16(src, rows, cols, dst, dst_rows, dst_cols, ldd=None, transpose=False, lds=None, batch=1, sbs=0, dbs=0):
+def cast_bf16(src, rows, cols, dst, dst_rows, dst_cols, ldd=None, transpose=False, lds=None, batch=1, sbs=0, dbs=0,
+              perm_h=0):
     """dst window [dst_rows, dst_cols] (row stride ldd) = bf16(src[rows, cols]) (transposed if asked), zero padded."""
     lds = lds if lds is not None else (src.stride(-2) if src.dim() >= 2 else cols)
     ldd = ldd if ldd is not None else (dst.stride(-2) if dst.dim() >= 2 else dst_cols)
     check(lib().las_cast_bf16(p(src), lds, rows, cols, p(dst), ldd, dst_rows, dst_cols, int(transpose), batch,
-                              sbs, dbs, stream()))
+                              sbs, dbs, perm_h, stream()))
 
 
-def colsum_bf16(X, M, N, out, ldx=None):
+def colsum_bf16(X, M, N, out, ldx=None, perm_h=0):
     ldx = ldx if ldx is not None else X.stride(-2)
-    check(lib().las_colsum_bf16(p(X), ldx, M, N, p(out), stream()))
+    check(lib().las_colsum_bf16(p(X), ldx, M, N, p(out), perm_h, stream()))

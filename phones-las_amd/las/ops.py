@@ -114,11 +114,12 @@ class LayerWeights:
         for i, (kn, bn) in enumerate(self.names):
             k, b = variables[kn], variables[bn]
             assert k.shape == (D + H, 4 * H), (kn, tuple(k.shape), (D + H, 4 * H))
-            hip.cast_bf16(k, D, 4 * H, self.kxT[i * 4 * H:], 4 * H, Dp, ldd=Dp, transpose=True, lds=4 * H)
-            hip.cast_bf16(k, D, 4 * H, self.kx[:, i * 4 * H:], D, 4 * H, ldd=nd * 4 * H, lds=4 * H)
+            # gate-interleaved column order (u*4+g) for everything the recurrent kernels touch per step
+            hip.cast_bf16(k, D, 4 * H, self.kxT[i * 4 * H:], 4 * H, Dp, ldd=Dp, transpose=True, lds=4 * H, perm_h=H)
+            hip.cast_bf16(k, D, 4 * H, self.kx[:, i * 4 * H:], D, 4 * H, ldd=nd * 4 * H, lds=4 * H, perm_h=H)
             hip.cast_bf16(k[D:], H, 4 * H, self.kh[i], H, 4 * H, ldd=4 * H, lds=4 * H)
             hip.check(hip.lib().las_lstm_pack_recurrent(hip.p(k[D:]), H, hip.p(self.khp[i]), hip.stream()))
-            self.bias[i * 4 * H:(i + 1) * 4 * H].copy_(b)
+            self.bias[i * 4 * H:(i + 1) * 4 * H].view(H, 4).copy_(b.view(4, H).t())
 
 
 def bilstm(inputs, sequence_length, num_units, dropout, mode, unidirectional=False, *, variables=None,
@@ -190,11 +191,11 @@ def bilstm_backward(rec, dy, d_state, grads, need_dx=True, overlap=None):
             gk, gb = grads[kn], grads[bn]
             dzi = dz.view(BT, nd * 4 * H)[:, i * 4 * H:]
             if D > 0:
-                hip.gemm_tn(x, dzi, gk, D, 4 * H, BT, lda=Dp, ldb=nd * 4 * H, ldc=4 * H, split_k=split)
+                hip.gemm_tn(x, dzi, gk, D, 4 * H, BT, lda=Dp, ldb=nd * 4 * H, ldc=4 * H, split_k=split, c_perm_h=H)
             yi = y.view(BT, nd * H)[:, i * H:]
             hip.gemm_tn(yi, dzi, gk[D:], H, 4 * H, BT, lda=nd * H, ldb=nd * 4 * H, ldc=4 * H,
-                        a_shift=(-1 if i == 0 else 1), period=T, split_k=split)
-            hip.colsum_bf16(dzi, BT, 4 * H, gb, ldx=nd * 4 * H)
+                        a_shift=(-1 if i == 0 else 1), period=T, split_k=split, c_perm_h=H)
+            hip.colsum_bf16(dzi, BT, 4 * H, gb, ldx=nd * 4 * H, perm_h=H)
     return dx
 
 
