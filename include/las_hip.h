@@ -245,6 +245,10 @@ int las_adam_update(float* params, float* m, float* v, const float* grads, int64
 /* *counter += delta on the stream (tf.train.get_global_step increment, model_helper.py:417). */
 int las_counter_add(int32_t* counter, int32_t delta, void* stream);
 
+/* Host-side CRC-32C (Castagnoli) of a buffer: the checksum of the TFRecord framing the reference's data
+ * files use (preprocess_all.py:164-167 tf.io.TFRecordWriter; utils/dataset_utils.py:157 TFRecordDataset). */
+uint32_t las_crc32c(const void* data, size_t n);
+
 #ifdef __cplusplus
 }
 #endif

@@ -37,6 +37,7 @@ _SIGS = {
     'las_adam_update': ([_vp, _vp, _vp, _vp, _i64, _f32, _f32, _f32, _f32, _i32, _vp, _vp], C.c_int),
     'las_counter_add': ([_vp, _i32, _vp], C.c_int),
     'las_sumsq': ([_vp, _i64, _vp, _vp], C.c_int),
+    'las_crc32c': ([C.c_char_p, C.c_size_t], C.c_uint32),
 }
 
 # entry points declared in include/las_hip.h whose kernels are not written yet (shrinks to empty)

@@ -1,0 +1,49 @@
+"""End-to-end CLI on the GPU: write a tiny synthetic TFRecord corpus, train.py overfits it, resume works,
+infer.py reads hparams.json + checkpoint and reports a low PER (integration tier of SURVEY.md §4)."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _corpus(d, n=16, F=13, seed=0):
+    from phones_las_amd.utils import tfrecord
+    from phones_las_amd.utils.features_utils import save_normalization
+    rng = np.random.default_rng(seed)
+    phones = ['p%d' % i for i in range(6)]
+    open(os.path.join(d, 'vocab.txt'), 'w').write('\n'.join(phones) + '\n')
+    protos = rng.standard_normal((len(phones), F)).astype(np.float32) * 2
+    with tfrecord.TFRecordWriter(os.path.join(d, 'train.tfr')) as w:
+        for _ in range(n):
+            ys = [int(v) for v in rng.integers(0, len(phones), size=rng.integers(2, 5))]
+            x = np.concatenate([np.repeat(protos[y][None], 8, 0) for y in ys]) + 0.05 * rng.standard_normal((8 * len(ys), F))
+            w.write(tfrecord.make_example(x.astype(np.float32), [phones[y] for y in ys]))
+    save_normalization(os.path.join(d, 'norm.dmp'), np.zeros(F, np.float32), np.ones(F, np.float32))
+
+
+def test_train_resume_infer(tmp_path, capsys):
+    import train, infer
+    d = str(tmp_path)
+    _corpus(d)
+    common = ['--train', os.path.join(d, 'train.tfr'), '--model_dir', os.path.join(d, 'model'), '--encoder_layers', '2',
+              '--encoder_units', '64', '--decoder_layers', '1', '--decoder_units', '64', '--use_pyramidal',
+              '--bottom_only', '--pass_hidden_state', '--dropout', '0', '--sampling_probability', '0',
+              '--batch_size', '8', '--num_channels', '13', '--learning_rate', '0.01']
+    train.main(train.parse_args(common + ['--num_epochs', '150']))      # 16 utts / 8 = 2 steps per epoch -> 300 steps
+    out = capsys.readouterr().out
+    assert 'finished at global_step 300' in out
+    first = float(out.split('step 10: loss = ')[1].split()[0])
+    last = float(out.split('step 300: loss = ')[1].split()[0])
+    assert last < 0.3 * first
+    assert os.path.exists(os.path.join(d, 'model', 'hparams.json'))
+    # resume: the checkpoint restores the step counter; hparams.json wins over the (different) CLI value
+    train.main(train.parse_args(common + ['--num_epochs', '5', '--encoder_units', '128']))
+    out = capsys.readouterr().out
+    assert 'restored' in out and 'at global_step 300' in out
+    per = infer.main(infer.parse_args(['--data', os.path.join(d, 'train.tfr'), '--vocab', os.path.join(d, 'vocab.txt'),
+                                       '--norm', os.path.join(d, 'norm.dmp'), '--model_dir', os.path.join(d, 'model'),
+                                       '--num_channels', '13', '--batch_size', '8']))
+    assert per < 20.0
+    assert len(open(os.path.join(d, 'model', 'infer.txt')).read().split('\n')) == 16

@@ -1,0 +1,174 @@
+#!/usr/bin/env python3
+"""Train Listen-Attend-Spell on MI355X with the flag surface of the reference's train.py (train.py:12-109):
+same flag names and defaults, vocab.txt / norm.dmp looked up next to --train (train.py:112-114), hparams.json in
+--model_dir (existing file wins unless --reset), TFRecord input.  The Estimator is replaced by LasModel
+(phones-las_amd/model_helper.py) driving liblas_hip.so; data parallelism = one process per GPU:
+
+    python train.py --train data/train.tfr --model_dir out --use_pyramidal --bottom_only --pass_hidden_state ...
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 train.py ...
+
+TPU / T2T flags are accepted for command-line compatibility and rejected when used."""
+import argparse
+import multiprocessing
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+
+
+def parse_args(argv=None):
+    p = argparse.ArgumentParser(description='Listen, Attend and Spell (LAS) on MI355X (HIP), drop-in for the '
+                                            'TensorFlow reference CLI.')
+    p.add_argument('--train', type=str, required=True, help='training data in TFRecord format')
+    p.add_argument('--valid', type=str, help='validation data in TFRecord format')
+    p.add_argument('--t2t_format', action='store_true')
+    p.add_argument('--t2t_problem_name', type=str)
+    p.add_argument('--mapping', type=str, help='additional mapping when evaluation')
+    p.add_argument('--model_dir', type=str, required=True, help='path of saving model')
+    p.add_argument('--eval_secs', type=int, default=300)
+    p.add_argument('--encoder_units', type=int, default=128)
+    p.add_argument('--encoder_layers', type=int, default=3)
+    p.add_argument('--use_pyramidal', action='store_true')
+    p.add_argument('--unidirectional', action='store_true')
+    p.add_argument('--decoder_units', type=int, default=128)
+    p.add_argument('--decoder_layers', type=int, default=2)
+    p.add_argument('--embedding_size', type=int, default=0)
+    p.add_argument('--sampling_probability', type=float, default=0.1)
+    p.add_argument('--attention_type', type=str, default='luong',
+                   choices=['luong', 'bahdanau', 'custom', 'luong_monotonic', 'bahdanau_monotonic'])
+    p.add_argument('--attention_layer_size', type=int)
+    p.add_argument('--bottom_only', action='store_true')
+    p.add_argument('--pass_hidden_state', action='store_true')
+    p.add_argument('--batch_size', type=int, default=8)
+    p.add_argument('--num_parallel_calls', type=int, default=multiprocessing.cpu_count())
+    p.add_argument('--num_channels', type=int)
+    p.add_argument('--num_epochs', type=int, default=150)
+    p.add_argument('--learning_rate', type=float, default=1e-3)
+    p.add_argument('--dropout', type=float, default=0.2)
+    p.add_argument('--l2_reg_scale', type=float, default=1e-6)
+    p.add_argument('--add_noise', type=int, default=0)
+    p.add_argument('--noise_std', type=float, default=0.1)
+    p.add_argument('--binary_outputs', action='store_true')
+    p.add_argument('--output_ipa', action='store_true')
+    p.add_argument('--binf_map', type=str, default='misc/binf_map.csv')
+    p.add_argument('--ctc_weight', type=float, default=-1.)
+    p.add_argument('--reset', help='Reset HParams.', action='store_true')
+    p.add_argument('--binf_sampling', action='store_true')
+    p.add_argument('--binf_projection', action='store_true')
+    p.add_argument('--binf_projection_reg_weight', type=float, default=1.0)
+    p.add_argument('--binf_trainable', action='store_true')
+    p.add_argument('--multitask', action='store_true')
+    p.add_argument('--tpu_name', type=str, default='')
+    p.add_argument('--max_frames', type=int, default=-1)
+    p.add_argument('--max_symbols', type=int, default=-1)
+    p.add_argument('--tpu_checkpoints_interval', type=int, default=600)
+    p.add_argument('--t2t_features_hparams_override', type=str, default='')
+    return p.parse_args(argv)
+
+
+def to_device(features, labels, dev):
+    f = {k: torch.from_numpy(v).to(dev) for k, v in features.items()}
+    l = {k: torch.from_numpy(v).to(dev) for k, v in labels.items()} if labels is not None else None
+    return f, l
+
+
+def save_checkpoint(model, path):
+    v = model.vars
+    torch.save({'flat': v.flat.cpu(), 'm': v.m.cpu(), 'v': v.v.cpu(), 'global_step': model.global_step,
+                'names': [n for n, _, _ in v.table], 'offsets': v.offsets}, path + '.tmp')
+    os.replace(path + '.tmp', path)
+
+
+def load_checkpoint(model, path):
+    ck = torch.load(path, map_location='cpu')
+    v = model.vars
+    if ck['names'] != [n for n, _, _ in v.table] or ck['offsets'] != v.offsets:
+        raise ValueError('checkpoint %s does not match the model built from hparams.json' % path)
+    v.flat.copy_(ck['flat']); v.m.copy_(ck['m']); v.v.copy_(ck['v'])
+    model.global_step = int(ck['global_step'])
+    model.step_dev.fill_(model.global_step + 1)
+    model.refresh_images()
+
+
+def main(args):
+    if args.t2t_format or args.tpu_name:
+        raise SystemExit('--t2t_format / --tpu_name are TensorFlow-only input/back-end options and are not supported')
+    if args.binary_outputs:
+        raise SystemExit('--binary_outputs is not implemented on the HIP path this round')
+    from phones_las_amd import dp, utils
+    from phones_las_amd import model_helper as mh
+
+    rank, world, local = dp.init_from_env()
+    torch.cuda.set_device(local)
+    dev = torch.device('cuda', local)
+
+    train_dir = os.path.dirname(args.train)
+    vocab_name = os.path.join(train_dir, 'vocab.txt')
+    norm_name = os.path.join(train_dir, 'norm.dmp')
+    vocab_list = utils.load_vocab(vocab_name)
+    if not args.num_channels:
+        first = next(iter(utils.read_dataset(args.train, None)()))
+        args.num_channels = int(first[0].shape[1])
+    hparams = utils.create_hparams(args, len(vocab_list), None, utils.SOS_ID, utils.EOS_ID)
+    model = mh.LasModel(hparams, world_size=world)
+    ckpt = os.path.join(args.model_dir, 'checkpoint.pt')
+    if os.path.exists(ckpt):
+        load_checkpoint(model, ckpt)
+        print('restored %s at global_step %d' % (ckpt, model.global_step))
+    if rank == 0:
+        print('Trainable parameters: %d' % model.vars.num_parameters())
+
+    global_batch = args.batch_size * world
+
+    def make_input(path, epochs, infer=False):
+        return utils.input_fn(path, vocab_name, norm_name, num_channels=hparams.num_channels, batch_size=global_batch,
+                              num_epochs=epochs, num_parallel_calls=args.num_parallel_calls,
+                              max_frames=args.max_frames, max_symbols=args.max_symbols, is_infer=infer, seed=1234)
+
+    max_steps = args.num_epochs * 1000 * args.batch_size          # train.py:189,202 (quirk B2)
+    t_last, last_eval, t0 = time.time(), time.time(), time.time()
+    for features, labels in make_input(args.train, args.num_epochs):
+        if model.global_step >= max_steps:
+            break
+        if world > 1:
+            features, labels = dp.shard_batch(features, rank, world), dp.shard_batch(labels, rank, world)
+        num_steps = int(labels['target_sequence_length'].max())
+        f, l = to_device(features, labels, dev)
+        loss = model.train_step(f, l, num_steps=num_steps)
+        if model.global_step % 10 == 0:                            # LoggingTensorHook(every_n_iter=10)
+            lv = dp.mean_scalar(float(loss))
+            if rank == 0:
+                dt = time.time() - t_last
+                print('step %d: loss = %.5f (%.2f utt/s)' % (model.global_step, lv, 10 * global_batch / max(dt, 1e-9)))
+            t_last = time.time()
+        if rank == 0 and model.global_step % 500 == 0:
+            save_checkpoint(model, ckpt)
+        if args.valid and time.time() - last_eval > args.eval_secs:
+            evaluate(model, make_input(args.valid, 1, True), dev, rank)
+            last_eval = time.time()
+    if rank == 0:
+        save_checkpoint(model, ckpt)
+        print('finished at global_step %d in %.1f s' % (model.global_step, time.time() - t0))
+    if args.valid:
+        evaluate(model, make_input(args.valid, 1, True), dev, rank)
+
+
+def evaluate(model, batches, dev, rank=0):
+    """tf.estimator evaluate: streaming mean of loss and normalised edit distance (model_helper.py:299-309)."""
+    losses, eds = [], []
+    for features, labels in batches:
+        f, l = to_device(features, labels, dev)
+        loss, ed, _ = model.evaluate(f, l)
+        losses.append(float(loss))
+        eds.extend(ed)
+    if rank == 0 and losses:
+        print('eval: loss = %.5f, edit_distance = %.5f' % (float(np.mean(losses)), float(np.mean(eds))))
+    return (float(np.mean(losses)), float(np.mean(eds))) if losses else (None, None)
+
+
+if __name__ == '__main__':
+    main(parse_args())
