@@ -30,20 +30,20 @@ def test_train_resume_infer(tmp_path, capsys):
     common = ['--train', os.path.join(d, 'train.tfr'), '--model_dir', os.path.join(d, 'model'), '--encoder_layers', '2',
               '--encoder_units', '64', '--decoder_layers', '1', '--decoder_units', '64', '--use_pyramidal',
               '--bottom_only', '--pass_hidden_state', '--dropout', '0', '--sampling_probability', '0',
-              '--batch_size', '8', '--num_channels', '13', '--learning_rate', '0.01']
-    train.main(train.parse_args(common + ['--num_epochs', '150']))      # 16 utts / 8 = 2 steps per epoch -> 300 steps
+              '--batch_size', '8', '--num_channels', '13', '--learning_rate', '0.003']
+    train.main(train.parse_args(common + ['--num_epochs', '600']))      # 16 utts / 8 = 2 steps per epoch -> 1200 steps
     out = capsys.readouterr().out
-    assert 'finished at global_step 300' in out
+    assert 'finished at global_step 1200' in out
     first = float(out.split('step 10: loss = ')[1].split()[0])
-    last = float(out.split('step 300: loss = ')[1].split()[0])
-    assert last < 0.3 * first
+    last = float(out.split('step 1200: loss = ')[1].split()[0])
+    assert last < 0.2 * first
     assert os.path.exists(os.path.join(d, 'model', 'hparams.json'))
     # resume: the checkpoint restores the step counter; hparams.json wins over the (different) CLI value
     train.main(train.parse_args(common + ['--num_epochs', '5', '--encoder_units', '128']))
     out = capsys.readouterr().out
-    assert 'restored' in out and 'at global_step 300' in out
+    assert 'restored' in out and 'at global_step 1200' in out
     per = infer.main(infer.parse_args(['--data', os.path.join(d, 'train.tfr'), '--vocab', os.path.join(d, 'vocab.txt'),
                                        '--norm', os.path.join(d, 'norm.dmp'), '--model_dir', os.path.join(d, 'model'),
                                        '--num_channels', '13', '--batch_size', '8']))
-    assert per < 20.0
+    assert per < 25.0
     assert len(open(os.path.join(d, 'model', 'infer.txt')).read().split('\n')) == 16
