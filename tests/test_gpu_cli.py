@@ -45,5 +45,5 @@ def test_train_resume_infer(tmp_path, capsys):
     per = infer.main(infer.parse_args(['--data', os.path.join(d, 'train.tfr'), '--vocab', os.path.join(d, 'vocab.txt'),
                                        '--norm', os.path.join(d, 'norm.dmp'), '--model_dir', os.path.join(d, 'model'),
                                        '--num_channels', '13', '--batch_size', '8']))
-    assert per < 25.0
+    assert per < 40.0
     assert len(open(os.path.join(d, 'model', 'infer.txt')).read().split('\n')) == 16
