@@ -105,7 +105,7 @@ def time_dominant_kernel(c, reps=5):
     return ms, flops
 
 
-def cpu_baseline(c, sample_b=8, threads=None):
+def cpu_baseline(c, sample_b=32, threads=None):
     """The oracle (a CPU port of the reference's per-time-step graph; TF 1.15 itself cannot run here) timed in
     fp32 on the host cores for ONE train step over `sample_b` utterances of the same shape."""
     from oracle import las_oracle as O
@@ -140,7 +140,7 @@ def main():
     ap.add_argument('--config', default='metric-M', choices=sorted(CONFIGS))
     ap.add_argument('--no-graph', action='store_true', help='launch eagerly instead of replaying HIP graphs')
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--cpu-sample', type=int, default=8)
+    ap.add_argument('--cpu-sample', type=int, default=32)
     args = ap.parse_args()
     c = CONFIGS[args.config]
 
@@ -224,6 +224,10 @@ def main():
         utt_s = c['B'] * world * args.steps / dt
         f_in, f_rec = lstm_gemm_flops_per_utt(c)
         kms, kflops = time_dominant_kernel(c)
+        traffic = None
+        pmc = os.path.join(ROOT, 'profiles', 'r01_pmc_traffic.json')
+        if args.config == 'metric-M' and os.path.exists(pmc):
+            traffic = json.load(open(pmc))['traffic_bytes']        # PMC passes of the same kernel (scripts/gpu_pmc.sh)
         achieved = kflops / (kms * 1e-3) / 1e12
         step_tflops = 3 * (f_in + f_rec) * utt_s / world / 1e12
         out = {
@@ -238,7 +242,7 @@ def main():
                        'hip_graph': not args.no_graph, 'final_loss': round(final_loss, 4)},
             'roofline': {'bound': 'mfma', 'kernel': 'lstm_fwd_kernel<%d> (layer-1 shape, both directions)' % c['H'],
                          'achieved': round(achieved, 3), 'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s',
-                         'frac': round(achieved / PEAK_BF16_TFLOPS, 6), 'traffic': None,
+                         'frac': round(achieved / PEAK_BF16_TFLOPS, 6), 'traffic': traffic,
                          'kernel_ms': round(kms, 3),
                          'whole_step_lstm_gemm_tflops_per_gpu': round(step_tflops, 3),
                          'whole_step_frac': round(step_tflops / PEAK_BF16_TFLOPS, 6)},
