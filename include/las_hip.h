@@ -170,6 +170,12 @@ typedef struct las_dec_step {
   int64_t ldc;
   las_bf16* ctx_out2;            /* optional second copy (next step's GEMM operand), row stride ldc2 */
   int64_t ldc2;
+  /* DropoutWrapper(input_keep_prob = drop_keep) on the cell input [token one-hot | attention] (las/ops.py:14-18):
+   * element e of utterance b at step t uses draw (drop_seed, drop_stream, (t*B + b)*feed_width + e).  The token row
+   * is scaled here; ctx_out2 is written already masked for step+1.  drop_keep >= 1 disables. */
+  float drop_keep;
+  uint32_t drop_seed, drop_stream;
+  int32_t step, feed_width;
 } las_dec_step;
 int las_decoder_step_fwd(const las_dec_step* s, int parts, void* stream);
 
@@ -210,8 +216,32 @@ typedef struct las_dec_step_bwd {
   float* dv_acc;                 /* Bahdanau: [Hd] fp32 accumulated d(attention_v) */
   las_bf16* dpq_out;             /* Bahdanau: d(processed query) bf16 (operand of d(query_layer)), row stride lddpq */
   int64_t lddpq;
+  float drop_keep;               /* as in las_dec_step: dctx_b is masked with step+1's attention-feed mask */
+  uint32_t drop_seed, drop_stream;
+  int32_t step, feed_width;
 } las_dec_step_bwd;
 int las_decoder_step_bwd(const las_dec_step_bwd* s, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Stochastic TRAIN-mode pieces (counter-based generator: forward and backward regenerate the same
+ * draws; nothing is stored).  DropoutWrapper(input_keep_prob) of las/ops.py:14-18 and the scheduled
+ * sampling of utils/training_helper.py:48-87.
+ * ---------------------------------------------------------------------------------------- */
+/* y = x * m / keep, m ~ Bernoulli(keep) per element (element index r*cols + c). */
+int las_dropout_bf16(const las_bf16* x, int64_t ldx, las_bf16* y, int64_t ldy, int rows, int cols, float keep,
+                     uint32_t seed, uint32_t stream_id, void* stream);
+/* out = a * mask(stream_a)/keep (+ b * mask(stream_b)/keep when b != NULL); contiguous [rows, cols] fp32. */
+int las_dropout_bwd(const float* a, const float* b, float* out, int rows, int cols, float keep, uint32_t seed,
+                    uint32_t stream_a, uint32_t stream_b, void* stream);
+/* out[i] = mask_i / keep: the realised mask, for replaying a run through the oracle. */
+int las_dropout_mask(float* out, int64_t total, float keep, uint32_t seed, uint32_t stream_id, void* stream);
+/* out[b*U + t, ids[b, t]] = dropout factor of that one-hot entry (1 when keep >= 1); rest 0. */
+int las_onehot_bf16(const int32_t* ids, int64_t id_stride_b, int B, int U, int V, las_bf16* out, int64_t ldo,
+                    float keep, uint32_t seed, uint32_t stream_id, int feed_width, void* stream);
+/* next[b] = token ~ Categorical(logits[b, :V]) with probability prob, else teacher[b] (scheduled sampling). */
+int las_sample_tokens(const float* logits, int64_t ldl, int V, const int32_t* teacher, int64_t teacher_stride,
+                      int32_t* next, int64_t next_stride, int B, float prob, uint32_t seed, uint32_t step,
+                      void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Loss: tf.contrib.seq2seq.sequence_loss as used by compute_loss (model_helper.py:24-30):

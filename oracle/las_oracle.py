@@ -221,7 +221,7 @@ def dynamic_rnn(x, length, kernel, bias, q, reverse=False, in_mask=None):
             pos = torch.full((B,), s, dtype=torch.long)
         xt = x[ar, pos]
         if in_mask is not None:
-            xt = xt * in_mask[ar, pos]
+            xt = q(xt * in_mask[ar, pos])             # the device stores the dropped input in bf16
         c2, h2 = lstm_step(xt, c, h, kq, bias)
         h2 = q(h2)                                  # device stores h_t in bf16
         m = active.unsqueeze(1).to(DT)
@@ -238,14 +238,16 @@ def dynamic_rnn(x, length, kernel, bias, q, reverse=False, in_mask=None):
     return out, (c, h)
 
 
-def bilstm(x, length, params, prefix, q, unidirectional=False):
-    """las/ops.py:23-46."""
+def bilstm(x, length, params, prefix, q, unidirectional=False, in_masks=None):
+    """las/ops.py:23-46.  in_masks: optional (mask_fw, mask_bw) realised DropoutWrapper masks [B,T,D] (already
+    divided by keep_prob; the fw and bw cells have independent wrappers, las/ops.py:30-34)."""
+    mf, mb = in_masks if in_masks is not None else (None, None)
     fw, sfw = dynamic_rnn(x, length, params[prefix + '/fw/lstm_cell/kernel'],
-                          params[prefix + '/fw/lstm_cell/bias'], q)
+                          params[prefix + '/fw/lstm_cell/bias'], q, in_mask=mf)
     if unidirectional:
         return fw, sfw
     bw, sbw = dynamic_rnn(x, length, params[prefix + '/bw/lstm_cell/kernel'],
-                          params[prefix + '/bw/lstm_cell/bias'], q, reverse=True)
+                          params[prefix + '/bw/lstm_cell/bias'], q, reverse=True, in_mask=mb)
     return (fw, bw), (sfw, sbw)
 
 
@@ -257,24 +259,26 @@ def pyramidal_stack(outputs, length):
     return outputs.reshape(B, -1, 2 * C), length // 2 + length % 2
 
 
-def pyramidal_bilstm(x, length, params, e: EncoderHP, q):
-    """las/ops.py:68-87.  Returns ((outputs, lengths), state_of_last_layer)."""
+def pyramidal_bilstm(x, length, params, e: EncoderHP, q, in_masks=None):
+    """las/ops.py:68-87.  Returns ((outputs, lengths), state_of_last_layer).  in_masks: per-layer list of
+    (mask_fw, mask_bw) or None."""
     out = x
     state = None
     for l in range(e.num_layers):
-        o, state = bilstm(out, length, params, f'listener/bilstm_{l}', q, e.unidirectional)
+        o, state = bilstm(out, length, params, f'listener/bilstm_{l}', q, e.unidirectional,
+                          in_masks[l] if in_masks is not None else None)
         out = o if e.unidirectional else torch.cat(o, -1)          # las/ops.py:81
         if l != 0:
             out, length = pyramidal_stack(out, length)             # las/ops.py:83-85
     return (out, length), state
 
 
-def listener(x, length, params, e: EncoderHP, mxu='f64'):
+def listener(x, length, params, e: EncoderHP, mxu='f64', in_masks=None):
     """las/model.py:104-142."""
     q = make_q(mxu)
     x = q(x.to(DT))
     if e.use_pyramidal:
-        return pyramidal_bilstm(x, length, params, e, q)
+        return pyramidal_bilstm(x, length, params, e, q, in_masks)
     dirs = ['fw'] if e.unidirectional else ['fw', 'bw']
     outs, states = [], []
     for dr in dirs:                                                 # MultiRNNCell per direction
@@ -409,11 +413,14 @@ class Speller:
         c2, h2 = lstm_step(x, state[0], state[1], k, b)
         return c2, self.q(h2)
 
-    def step(self, inputs):
-        """One AttentionWrapper step (Appendix A.5); returns logits [B,V]."""
+    def step(self, inputs, in_mask=None):
+        """One AttentionWrapper step (Appendix A.5); returns logits [B,V].  in_mask [B, E+A]: realised input
+        dropout mask of the (bottom) cell, already divided by keep_prob (A.2)."""
         d, p, q = self.d, self.p, self.q
         old_att = self.attention
         x = torch.cat([inputs, old_att], 1)
+        if in_mask is not None:
+            x = q(x * in_mask)
         new_cells = []
         if d.bottom_only:
             c, h = self._cell(0, x, self.cells[0])
@@ -452,7 +459,7 @@ class Speller:
 
 
 def speller_train(hp: HP, params, memory, mem_len, enc_state, targets_inputs, target_len,
-                  mxu='f64', sample_select=None, sample_ids=None, noise=None):
+                  mxu='f64', sample_select=None, sample_ids=None, noise=None, in_masks=None):
     """las/model.py:276-296,346-347 with TrainingHelper; optional scheduled sampling with externally
     supplied draws (utils/training_helper.py:48-87): sample_select[t,b] bool, sample_ids[t,b]."""
     sp = Speller(hp, params, memory, mem_len, enc_state, mxu, True, noise)
@@ -460,7 +467,7 @@ def speller_train(hp: HP, params, memory, mem_len, enc_state, targets_inputs, ta
     inp = sp.embed(targets_inputs[:, 0])
     outs = []
     for t in range(U):
-        logits = sp.step(inp)
+        logits = sp.step(inp, in_masks[t] if in_masks is not None else None)
         outs.append(logits)
         if t + 1 < targets_inputs.shape[1]:
             nxt = sp.embed(targets_inputs[:, t + 1])
@@ -629,14 +636,17 @@ def edit_distance(hyp, truth, eos_id=EOS_ID, mapping=None):
 # --------------------------------------------------------------------------------------
 # whole model + train op  (model_helper.py:165-444)
 # --------------------------------------------------------------------------------------
-def model_loss(hp: HP, params, batch, mxu='f64'):
+def model_loss(hp: HP, params, batch, mxu='f64', stochastic=None):
     """Forward of las_model_fn in TRAIN mode (model_helper.py:205-227,319-357).  batch keys:
     encoder_inputs [B,T,F], source_sequence_length, targets_inputs, targets_outputs,
     target_sequence_length.  Returns (audio_loss, aux dict)."""
     x = batch['encoder_inputs']
-    (mem, mem_len), state = listener(x, batch['source_sequence_length'], params, hp.encoder, mxu)
+    st = stochastic or {}
+    (mem, mem_len), state = listener(x, batch['source_sequence_length'], params, hp.encoder, mxu,
+                                     st.get('enc_masks'))
     logits, sp = speller_train(hp, params, mem, mem_len, state, batch['targets_inputs'],
-                               batch['target_sequence_length'], mxu)
+                               batch['target_sequence_length'], mxu, sample_select=st.get('sample_select'),
+                               sample_ids=st.get('sample_ids'), in_masks=st.get('dec_masks'))
     loss = compute_loss_train(logits, batch['targets_outputs'], batch['target_sequence_length'])
     aux = {'logits': logits, 'memory': mem, 'memory_len': mem_len, 'state': state, 'ce': loss}
     if hp.ctc_weight > 0:
@@ -655,12 +665,12 @@ def l2_term(params, scale):
 
 
 def train_step(hp: HP, params, adam_m, adam_v, step, batch, mxu='f64', n_replicas=1,
-               beta1=0.9, beta2=0.999, eps=1e-8):
+               beta1=0.9, beta2=0.999, eps=1e-8, stochastic=None):
     """model_helper.py:403-417 (+405-406 for n_replicas>1 on ONE replica's shard): loss(+L2) ->
     grads -> clip_by_norm(g,2) per tensor -> Adam (TF form).  Returns dict with new params/m/v,
     loss, raw and clipped grads.  ``step`` is the 1-based Adam step t."""
     leaf = {k: v.clone().requires_grad_(True) for k, v in params.items()}
-    audio, aux = model_loss(hp, leaf, batch, mxu)
+    audio, aux = model_loss(hp, leaf, batch, mxu, stochastic)
     loss = audio + l2_term(leaf, hp.l2_reg_scale)
     (loss / n_replicas).backward()
     grads = {k: (v.grad if v.grad is not None else torch.zeros_like(v)) for k, v in leaf.items()}

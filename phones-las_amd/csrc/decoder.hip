@@ -50,12 +50,17 @@ __global__ __launch_bounds__(256) void dec_step_fwd_kernel(las_dec_step s) {
 
   // ---- LSTM cell (Appendix A.1) ----
   const int tok = s.tok_rows ? s.tok_ids[(int64_t)b * s.tok_stride] : 0;
+  // DropoutWrapper on the cell input: the one-hot feed keeps/loses its single non-zero entry
+  float tok_scale = 1.0f;
+  if (s.drop_keep < 1.0f)
+    tok_scale = las_uniform(s.drop_seed, s.drop_stream, ((unsigned long long)s.step * s.B + b) * s.feed_width + tok) < s.drop_keep
+                    ? 1.0f / s.drop_keep : 0.f;
   for (int u = tid; u < Hd; u += 256) {
     float z[4];
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
       z[g] = s.z[(int64_t)b * 4 * Hd + g * Hd + u] + s.bias[g * Hd + u];
-      if (s.tok_rows) z[g] += las_bf2f(s.tok_rows[(int64_t)tok * 4 * Hd + g * Hd + u]);
+      if (s.tok_rows) z[g] += tok_scale * las_bf2f(s.tok_rows[(int64_t)tok * 4 * Hd + g * Hd + u]);
     }
     const float gi = las_sigmoid(z[0]), gj = las_tanh(z[1]), gf = las_sigmoid(z[2] + 1.0f), go = las_sigmoid(z[3]);
     const float cn = gf * s.c_prev[(int64_t)b * s.ldcp + u] + gi * gj;
@@ -173,7 +178,14 @@ __global__ __launch_bounds__(256) void dec_step_fwd_kernel(las_dec_step s) {
       for (int ph = 0; ph < P; ++ph) acc += cred[(ph * L + cl2) * 8 + e];
       const unsigned short o = las_f2bf(acc);
       s.ctx_out[(int64_t)b * s.ldc + cb + j] = o;
-      if (s.ctx_out2) s.ctx_out2[(int64_t)b * s.ldc2 + cb + j] = o;
+      if (s.ctx_out2) {
+        unsigned short o2 = o;
+        if (s.drop_keep < 1.0f) {   // the copy that feeds step t+1's cell goes through that step's input dropout
+          const unsigned long long idx = ((unsigned long long)(s.step + 1) * s.B + b) * s.feed_width + (s.feed_width - M) + cb + j;
+          o2 = las_uniform(s.drop_seed, s.drop_stream, idx) < s.drop_keep ? las_f2bf(las_bf2f(o) / s.drop_keep) : (unsigned short)0;
+        }
+        s.ctx_out2[(int64_t)b * s.ldc2 + cb + j] = o2;
+      }
     }
   }
 }
@@ -196,7 +208,14 @@ __global__ __launch_bounds__(256) void dec_step_bwd_kernel(las_dec_step_bwd s) {
   // total gradient w.r.t. the context of this step; keep a bf16 copy for the d(memory) batched GEMM
   for (int m = tid; m < M; m += 256) {
     float v = s.dctx_a ? s.dctx_a[(int64_t)b * s.ldda + m] : 0.f;
-    if (s.dctx_b) v += s.dctx_b[(int64_t)b * s.lddb + m];
+    if (s.dctx_b) {
+      float fb = s.dctx_b[(int64_t)b * s.lddb + m];
+      if (s.drop_keep < 1.0f) {     // gradient through step t+1's input dropout of the attention feed
+        const unsigned long long idx = ((unsigned long long)(s.step + 1) * s.B + b) * s.feed_width + (s.feed_width - M) + m;
+        fb = las_uniform(s.drop_seed, s.drop_stream, idx) < s.drop_keep ? fb / s.drop_keep : 0.f;
+      }
+      v += fb;
+    }
     dctx[m] = v;
     if (s.dctx_save) s.dctx_save[(int64_t)b * s.ldds + m] = las_f2bf(v);
   }

@@ -55,3 +55,17 @@ __device__ __forceinline__ float las_wave_max(float v) {
   for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
   return v;
 }
+
+// counter-based uniform generator shared by the dropout / sampling kernels (rng.hip, decoder.hip)
+__device__ __forceinline__ unsigned las_mix32(unsigned x) {
+  x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+  return x;
+}
+// uniform in [0,1) from (seed, stream, 64-bit element index)
+__device__ __forceinline__ float las_uniform(unsigned seed, unsigned stream, unsigned long long idx) {
+  unsigned h = las_mix32(seed ^ (stream * 0x9E3779B9u));
+  h = las_mix32(h ^ (unsigned)idx);
+  h = las_mix32(h + (unsigned)(idx >> 32) * 0x85EBCA6Bu + 0x632BE5ABu);
+  return (float)(h >> 8) * (1.0f / 16777216.0f);
+}
+

@@ -1,0 +1,138 @@
+// Stochastic pieces of the TRAIN graph, driven by a counter-based generator so that forward and backward
+// regenerate the same draws without storing masks:
+//   - DropoutWrapper(input_keep_prob) on LSTM cell inputs (las/ops.py:14-18): inverted dropout,
+//     an independent Bernoulli(keep) per (utterance, time step, input element);
+//   - scheduled sampling of TPUScheduledEmbeddingTrainingHelper (utils/training_helper.py:48-87):
+//     per (utterance, step) with probability p the next decoder input is a token drawn from Categorical(logits).
+// The draws cannot match TensorFlow's Philox streams; parity tests export the realised masks / tokens and replay
+// them through the oracle.
+#include "las_common.h"
+
+namespace {
+
+__global__ void dropout_bf16_kernel(const unsigned short* x, int64_t ldx, unsigned short* y, int64_t ldy, int rows, int cols,
+                                    float keep, unsigned seed, unsigned stream) {
+  const float inv = 1.0f / keep;
+  const int64_t total = (int64_t)rows * cols;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int r = (int)(i / cols), c = (int)(i % cols);
+    const float m = las_uniform(seed, stream, (unsigned long long)i) < keep ? inv : 0.f;
+    y[(int64_t)r * ldy + c] = las_f2bf(las_bf2f(x[(int64_t)r * ldx + c]) * m);
+  }
+}
+
+// out = a * mask_a (+ b * mask_b): gradient through the input dropout of the fw (and bw) cell
+__global__ void dropout_bwd_kernel(const float* a, const float* b, float* out, int rows, int cols, float keep, unsigned seed,
+                                   unsigned stream_a, unsigned stream_b) {
+  const float inv = 1.0f / keep;
+  const int64_t total = (int64_t)rows * cols;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    float v = a[i] * (las_uniform(seed, stream_a, (unsigned long long)i) < keep ? inv : 0.f);
+    if (b) v += b[i] * (las_uniform(seed, stream_b, (unsigned long long)i) < keep ? inv : 0.f);
+    out[i] = v;
+  }
+}
+
+__global__ void dropout_mask_kernel(float* out, int64_t total, float keep, unsigned seed, unsigned stream) {
+  const float inv = 1.0f / keep;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x)
+    out[i] = las_uniform(seed, stream, (unsigned long long)i) < keep ? inv : 0.f;
+}
+
+// onehot[row, ids[row]] = scale(row) for the token-row gradient GEMM; scale = dropout factor of that one-hot entry
+__global__ void onehot_kernel(const int32_t* ids, int64_t id_stride_b, int B, int U, int V, unsigned short* out, int64_t ldo,
+                              float keep, unsigned seed, unsigned stream, int feed_width) {
+  const int row = blockIdx.x * blockDim.x + threadIdx.x;     // row = b*U + t
+  if (row >= B * U) return;
+  const int b = row / U, t = row % U;
+  const int id = ids[(int64_t)b * id_stride_b + t];
+  float sc = 1.0f;
+  if (keep < 1.0f) {
+    const unsigned long long idx = ((unsigned long long)t * B + b) * feed_width + id;
+    sc = las_uniform(seed, stream, idx) < keep ? 1.0f / keep : 0.f;
+  }
+  if (id >= 0 && id < V) out[(int64_t)row * ldo + id] = las_f2bf(sc);
+}
+
+// scheduled sampling: one wave per utterance.  next[b] = Categorical(logits[b,:V]) with probability p, else teacher[b]
+__global__ void sample_kernel(const float* logits, int64_t ldl, int V, const int32_t* teacher, int64_t teacher_stride,
+                              int32_t* next, int64_t next_stride, int B, float prob, unsigned seed, unsigned step) {
+  const int b = blockIdx.x * (blockDim.x / 64) + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (b >= B) return;
+  const bool select = las_uniform(seed, 0x5e1ec7u, (unsigned long long)step * B + b) < prob;
+  int out = teacher ? teacher[(int64_t)b * teacher_stride] : 0;
+  if (select) {
+    // Gumbel-max: argmax_v logits[v] - log(-log(u_v))
+    float best = -INFINITY;
+    int arg = 0;
+    for (int v = lane; v < V; v += 64) {
+      const float u = fmaxf(las_uniform(seed, 0x9a3b1eu, ((unsigned long long)step * B + b) * V + v), 1e-12f);
+      const float g = logits[(int64_t)b * ldl + v] - __logf(-__logf(u));
+      if (g > best) { best = g; arg = v; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const float ob = __shfl_xor(best, o, 64);
+      const int oa = __shfl_xor(arg, o, 64);
+      if (ob > best || (ob == best && oa < arg)) { best = ob; arg = oa; }
+    }
+    out = arg;
+  }
+  if (lane == 0) next[(int64_t)b * next_stride] = out;
+}
+
+int blocks_for(int64_t n) {
+  int64_t b = (n + 255) / 256;
+  return (int)(b > 2048 ? 2048 : b);
+}
+
+}  // namespace
+
+extern "C" int las_dropout_bf16(const las_bf16* x, int64_t ldx, las_bf16* y, int64_t ldy, int rows, int cols, float keep,
+                                uint32_t seed, uint32_t stream_id, void* stream) {
+  LAS_REQUIRE(rows > 0 && cols > 0 && keep > 0.f && keep <= 1.f, "las_dropout_bf16: bad arguments");
+  hipLaunchKernelGGL(dropout_bf16_kernel, dim3(blocks_for((int64_t)rows * cols)), dim3(256), 0, (hipStream_t)stream, x, ldx, y,
+                     ldy, rows, cols, keep, seed, stream_id);
+  LAS_LAUNCH_CHECK("dropout launch");
+  return LAS_OK;
+}
+
+extern "C" int las_dropout_bwd(const float* a, const float* b, float* out, int rows, int cols, float keep, uint32_t seed,
+                               uint32_t stream_a, uint32_t stream_b, void* stream) {
+  LAS_REQUIRE(rows > 0 && cols > 0 && keep > 0.f && keep <= 1.f, "las_dropout_bwd: bad arguments");
+  hipLaunchKernelGGL(dropout_bwd_kernel, dim3(blocks_for((int64_t)rows * cols)), dim3(256), 0, (hipStream_t)stream, a, b, out,
+                     rows, cols, keep, seed, stream_a, stream_b);
+  LAS_LAUNCH_CHECK("dropout bwd launch");
+  return LAS_OK;
+}
+
+extern "C" int las_dropout_mask(float* out, int64_t total, float keep, uint32_t seed, uint32_t stream_id, void* stream) {
+  LAS_REQUIRE(total > 0 && keep > 0.f && keep <= 1.f, "las_dropout_mask: bad arguments");
+  hipLaunchKernelGGL(dropout_mask_kernel, dim3(blocks_for(total)), dim3(256), 0, (hipStream_t)stream, out, total, keep, seed,
+                     stream_id);
+  LAS_LAUNCH_CHECK("dropout mask launch");
+  return LAS_OK;
+}
+
+extern "C" int las_onehot_bf16(const int32_t* ids, int64_t id_stride_b, int B, int U, int V, las_bf16* out, int64_t ldo,
+                               float keep, uint32_t seed, uint32_t stream_id, int feed_width, void* stream) {
+  LAS_REQUIRE(B > 0 && U > 0 && V > 0 && ldo >= V, "las_onehot_bf16: bad arguments");
+  hipStream_t st = (hipStream_t)stream;
+  int rc = las_check_hip(hipMemsetAsync(out, 0, (size_t)B * U * ldo * sizeof(las_bf16), st), "memset onehot");
+  if (rc) return rc;
+  hipLaunchKernelGGL(onehot_kernel, dim3((B * U + 255) / 256), dim3(256), 0, st, ids, id_stride_b, B, U, V, out, ldo, keep,
+                     seed, stream_id, feed_width);
+  LAS_LAUNCH_CHECK("onehot launch");
+  return LAS_OK;
+}
+
+extern "C" int las_sample_tokens(const float* logits, int64_t ldl, int V, const int32_t* teacher, int64_t teacher_stride,
+                                 int32_t* next, int64_t next_stride, int B, float prob, uint32_t seed, uint32_t step,
+                                 void* stream) {
+  LAS_REQUIRE(B > 0 && V > 0 && prob >= 0.f && prob <= 1.f, "las_sample_tokens: bad arguments");
+  hipLaunchKernelGGL(sample_kernel, dim3((B + 3) / 4), dim3(256), 0, (hipStream_t)stream, logits, ldl, V, teacher, teacher_stride,
+                     next, next_stride, B, prob, seed, step);
+  LAS_LAUNCH_CHECK("sample launch");
+  return LAS_OK;
+}

@@ -38,6 +38,11 @@ _SIGS = {
     'las_counter_add': ([_vp, _i32, _vp], C.c_int),
     'las_sumsq': ([_vp, _i64, _vp, _vp], C.c_int),
     'las_crc32c': ([C.c_char_p, C.c_size_t], C.c_uint32),
+    'las_dropout_bf16': ([_vp, _i64, _vp, _i64, _i32, _i32, _f32, C.c_uint32, C.c_uint32, _vp], C.c_int),
+    'las_dropout_bwd': ([_vp, _vp, _vp, _i32, _i32, _f32, C.c_uint32, C.c_uint32, C.c_uint32, _vp], C.c_int),
+    'las_dropout_mask': ([_vp, _i64, _f32, C.c_uint32, C.c_uint32, _vp], C.c_int),
+    'las_onehot_bf16': ([_vp, _i64, _i32, _i32, _i32, _vp, _i64, _f32, C.c_uint32, C.c_uint32, _i32, _vp], C.c_int),
+    'las_sample_tokens': ([_vp, _i64, _i32, _vp, _i64, _vp, _i64, _i32, _f32, C.c_uint32, C.c_uint32, _vp], C.c_int),
 }
 
 # entry points declared in include/las_hip.h whose kernels are not written yet (shrinks to empty)
@@ -53,7 +58,8 @@ class DecStep(C.Structure):
                 ('h_out', _vp), ('ldh', _i64), ('h_out2', _vp), ('ldh2', _i64), ('keys', _vp), ('values', _vp),
                 ('mem_len', _vp), ('wq', _vp), ('att_v', _vp), ('align_out', _vp), ('align_bf16', _vp),
                 ('lda', _i64), ('pq_out', _vp), ('ldpq', _i64), ('ctx_out', _vp), ('ldc', _i64),
-                ('ctx_out2', _vp), ('ldc2', _i64)]
+                ('ctx_out2', _vp), ('ldc2', _i64), ('drop_keep', _f32), ('drop_seed', C.c_uint32),
+                ('drop_stream', C.c_uint32), ('step', _i32), ('feed_width', _i32)]
 
 
 class DecStepBwd(C.Structure):
@@ -64,7 +70,8 @@ class DecStepBwd(C.Structure):
                 ('ldcn', _i64), ('c_prev', _vp), ('ldcp', _i64), ('align', _vp), ('lda', _i64), ('pq', _vp),
                 ('ldpq', _i64), ('keys', _vp), ('values', _vp), ('mem_len', _vp), ('wq_t', _vp), ('att_v', _vp),
                 ('dz', _vp), ('ldz', _i64), ('ds_out', _vp), ('ldso', _i64), ('dkeys_acc', _vp), ('dv_acc', _vp),
-                ('dpq_out', _vp), ('lddpq', _i64)]
+                ('dpq_out', _vp), ('lddpq', _i64), ('drop_keep', _f32), ('drop_seed', C.c_uint32),
+                ('drop_stream', C.c_uint32), ('step', _i32), ('feed_width', _i32)]
 
 
 ATT_LUONG, ATT_BAHDANAU = 0, 1

@@ -62,13 +62,13 @@ class Listener:
         hip.cast_bf16(x, T, F, out, Tp, self.Fp, ldd=self.Fp, lds=F, batch=B, sbs=T * F, dbs=Tp * self.Fp)
         return out
 
-    def forward(self, encoder_inputs, source_sequence_length, mode):
+    def forward(self, encoder_inputs, source_sequence_length, mode, seed=0):
         x = encoder_inputs
         if x.dtype != torch.bfloat16:
             x = self.pad_features(x.contiguous())
         self.tape = [] if mode == TRAIN else None
         return ops.pyramidal_bilstm(x, source_sequence_length, mode, self.hp, weights=self.layers,
-                                    tape=self.tape, in_features=self.F)
+                                    tape=self.tape, in_features=self.F, seed=seed)
 
     def backward(self, d_outputs, d_state, grads, overlap=None):
         """d_outputs: fp32 gradient w.r.t. the encoder outputs [B,T',M]; d_state: (dc, dh) [nd,B,H] or None."""
@@ -179,6 +179,8 @@ class Speller:
                     out_bf16=True)
         return keys
 
+    DEC_STREAM = 1      # generator stream of the decoder cell's input dropout
+
     def _step_struct(self, B, Tm, z, tok_ids, tok_stride, c_prev, ldcp, gates, ldg, c_out, ldco, h_out, ldh, h2, ldh2,
                      keys, memory, mem_len, align, align_bf, lda, pq, ldpq, ctx, ldc, ctx2, ldc2):
         s = hip.DecStep()
@@ -192,9 +194,10 @@ class Speller:
             s.wq, s.att_v = hip.addr(self.wq), hip.addr(self.att_v)
         s.align_out, s.align_bf16, s.lda, s.pq_out, s.ldpq = align, align_bf, lda, pq, ldpq
         s.ctx_out, s.ldc, s.ctx_out2, s.ldc2 = ctx, ldc, ctx2, ldc2
+        s.drop_keep, s.feed_width = 1.0, self.V + self.M
         return s
 
-    def forward_train(self, memory, mem_len, encoder_state, targets_inputs, num_steps, parts=4):
+    def forward_train(self, memory, mem_len, encoder_state, targets_inputs, num_steps, parts=4, seed=0):
         """TrainingHelper decode (las/model.py:276-296,346-347).  memory [B,T',M] bf16, targets_inputs int32
         [B,>=num_steps]; num_steps = max(target_sequence_length).  Returns logits fp32 [B,U,Vp] (first V valid)."""
         B, Tm, M = memory.shape
@@ -217,22 +220,40 @@ class Speller:
         ctx_all = torch.empty(B, U, M, dtype=bf, device=dev)
         pq_all = torch.empty(B, U, Hd, dtype=f32, device=dev) if self.att == hip.ATT_BAHDANAU else None
         z = torch.empty(B, 4 * Hd, dtype=f32, device=dev)
+        d = self.hp
+        keep = 1.0 - (d.dropout if d.dropout else 0.0)
+        sampling = float(d.sampling_probability or 0.0)
         tin = targets_inputs
-        ts = tin.stride(0)
+        fed = tin
+        logits = None
+        if sampling > 0.0:
+            # scheduled sampling (utils/training_helper.py:48-87): fed[:, t+1] = sampled token or the teacher's
+            fed = tin[:, :U].contiguous().clone()
+            logits = torch.empty(B, U, Vp, dtype=f32, device=dev)
+        ts = fed.stride(0)
         for t in range(U):
             hip.gemm_nt(AH[:, t], self.kcT, z, B, 4 * Hd, W, lda=U * W, ldb=W, ldc=4 * Hd)
             last = (t + 1 == U)
             s = self._step_struct(
-                B, Tm, hip.addr(z), hip.addr(tin, t), ts, hip.addr(cs, t * Hd), (U + 1) * Hd,
+                B, Tm, hip.addr(z), hip.addr(fed, t), ts, hip.addr(cs, t * Hd), (U + 1) * Hd,
                 hip.addr(gates, t * 4 * Hd), U * 4 * Hd, hip.addr(cs, (t + 1) * Hd), (U + 1) * Hd,
                 hip.addr(h_all, t * Hd), U * Hd, 0 if last else hip.addr(AH, (t + 1) * W + M), U * W,
                 keys, memory, mem_len, hip.addr(align, t * Tmp), hip.addr(align_bf, t * Tmp), U * Tmp,
                 hip.addr(pq_all, t * Hd) if pq_all is not None else 0, U * Hd,
                 hip.addr(ctx_all, t * M), U * M, 0 if last else hip.addr(AH, (t + 1) * W), U * W)
+            if keep < 1.0:
+                s.drop_keep, s.drop_seed, s.drop_stream, s.step = keep, seed, self.DEC_STREAM, t
             hip.check(lib.las_decoder_step_fwd(C.byref(s), parts, st))
-        logits = torch.empty(B, U, Vp, dtype=f32, device=dev)
-        hip.gemm_nt(ctx_all, self.wprojT, logits, B * U, Vp, M, lda=M, ldb=M, ldc=Vp, bias=self.bproj)
-        self.saved = dict(B=B, Tm=Tm, U=U, memory=memory, mem_len=mem_len, keys=keys, AH=AH, cs=cs, gates=gates,
+            if sampling > 0.0:
+                hip.gemm_nt(ctx_all[:, t], self.wprojT, logits[:, t], B, Vp, M, lda=U * M, ldb=M, ldc=U * Vp,
+                            bias=self.bproj)
+                if not last:
+                    hip.check(lib.las_sample_tokens(hip.addr(logits, t * Vp), U * Vp, V, hip.addr(tin, t + 1),
+                                                    tin.stride(0), hip.addr(fed, t + 1), ts, B, sampling, seed, t, st))
+        if logits is None:
+            logits = torch.empty(B, U, Vp, dtype=f32, device=dev)
+            hip.gemm_nt(ctx_all, self.wprojT, logits, B * U, Vp, M, lda=M, ldb=M, ldc=Vp, bias=self.bproj)
+        self.saved = dict(keep=keep, seed=seed, fed=fed, B=B, Tm=Tm, U=U, memory=memory, mem_len=mem_len, keys=keys, AH=AH, cs=cs, gates=gates,
                           h_all=h_all, align=align, align_bf=align_bf, ctx_all=ctx_all, pq_all=pq_all,
                           tin=tin, passed=passed)
         return logits
@@ -277,6 +298,9 @@ class Speller:
             s.keys, s.values, s.mem_len = hip.addr(sv['keys']), hip.addr(sv['memory']), hip.addr(sv['mem_len'])
             s.dz, s.ldz = hip.addr(dz_all, t * 4 * Hd), U * 4 * Hd
             s.ds_out, s.ldso = hip.addr(ds_all, t * Tmp), U * Tmp
+            s.drop_keep, s.feed_width = 1.0, V + M
+            if sv['keep'] < 1.0:
+                s.drop_keep, s.drop_seed, s.drop_stream, s.step = sv['keep'], sv['seed'], self.DEC_STREAM, t
             if bah:
                 s.pq, s.ldpq = hip.addr(sv['pq_all'], t * Hd), U * Hd
                 s.wq_t, s.att_v = hip.addr(self.wq_t), hip.addr(self.att_v)
@@ -297,8 +321,10 @@ class Speller:
         hip.gemm_nt(dkeys_bf, self.wmem, dmem, B * Tm, M, Hd, lda=Hd, ldb=Hd, ldc=M, accumulate=True)
         # weight gradients (off the critical path): cell rows [V, V+M+Hd) from [attention_{t-1}, h_{t-1}], rows
         # [0,V) from the tokens, projection, memory_layer, query_layer
-        onehot = torch.zeros(BU, Vp, dtype=bf, device=dev)
-        onehot.scatter_(1, sv['tin'][:, :U].reshape(BU, 1).long(), 1.0)
+        onehot = torch.empty(BU, Vp, dtype=bf, device=dev)
+        fed = sv['fed']
+        hip.check(lib.las_onehot_bf16(hip.p(fed), fed.stride(0), B, U, V, hip.p(onehot), Vp, sv['keep'], sv['seed'],
+                                      self.DEC_STREAM, V + M, st))
         keep = [sv['AH'], dz_all, onehot, sv['ctx_all'], dlogits, sv['memory'], dkeys_bf, sv['h_all']]
         if bah:
             keep.append(dpq_all)
@@ -383,8 +409,6 @@ def speller(encoder_outputs, encoder_state, decoder_inputs, source_sequence_leng
         module = Speller(hparams, variables, encoder_outputs.shape[-1])
     Out = collections.namedtuple('BasicDecoderOutput', ['rnn_output', 'sample_id'])
     if mode == TRAIN:
-        if hparams.sampling_probability > 0.0:
-            raise ValueError('sampling_probability > 0 is not implemented on the HIP path this round')
         U = num_steps if num_steps is not None else int(target_sequence_length.max().item())
         logits = module.forward_train(encoder_outputs, source_sequence_length, encoder_state, decoder_inputs, U)
         V = module.V

@@ -26,8 +26,8 @@ LSTMCellSpec = collections.namedtuple('LSTMCellSpec', ['num_units', 'input_keep_
 def lstm_cell(num_units, dropout, mode):
     """las/ops.py:10-20: LSTMCell(num_units, U(-0.075,0.075)); DropoutWrapper(input_keep_prob) in TRAIN."""
     dropout = dropout if mode == TRAIN else 0.0
-    if dropout > 0.0:
-        raise NotImplementedError('input dropout > 0 is not implemented on the HIP path yet; use --dropout 0')
+    if not 0.0 <= dropout < 1.0:
+        raise ValueError('dropout must be in [0, 1)')
     if num_units not in (64, 128, 256):
         raise ValueError('num_units must be one of 64, 128, 256 on the HIP path (got %d)' % num_units)
     return LSTMCellSpec(num_units, 1.0 - dropout)
@@ -123,12 +123,13 @@ class LayerWeights:
 
 
 def bilstm(inputs, sequence_length, num_units, dropout, mode, unidirectional=False, *, variables=None,
-           scope='', weights=None, tape=None, in_features=None):
+           scope='', weights=None, tape=None, in_features=None, rng=None):
     """las/ops.py:23-46.  inputs [B,T,Dp] bf16; sequence_length int32 [B] (CUDA).
     Returns (outputs, state) with the reference's structure: bidirectional -> ((fw, bw), (state_fw,
     state_bw)); unidirectional -> (fw, state).  fw/bw are views of one [B,T,ndir*H] buffer
     (use ``concat_outputs`` for the tf.concat of las/ops.py:81)."""
-    lstm_cell(num_units, dropout, mode)
+    cell = lstm_cell(num_units, dropout, mode)
+    keep = cell.input_keep_prob
     B, T, Dp = inputs.shape
     H = num_units
     D = in_features if in_features is not None else Dp
@@ -137,8 +138,24 @@ def bilstm(inputs, sequence_length, num_units, dropout, mode, unidirectional=Fal
     nd = len(weights.dirs)
     dev = inputs.device
     xproj = torch.empty(B, T, nd * 4 * H, dtype=torch.float32, device=dev)
-    hip.gemm_nt(inputs, weights.kxT, xproj, B * T, nd * 4 * H, Dp, lda=Dp, ldb=Dp, ldc=nd * 4 * H,
-                bias=weights.bias)
+    dropped = None
+    if keep < 1.0:
+        # DropoutWrapper(input_keep_prob) on each cell's input (las/ops.py:14-18): the fw and bw cells draw
+        # independent masks, fresh per time step -> one dropped copy of the layer input per direction
+        if rng is None:
+            raise ValueError('dropout needs rng=(seed, first_stream_id)')
+        seed, stream0 = rng
+        dropped = []
+        for i in range(nd):
+            xd = torch.empty_like(inputs)
+            hip.check(hip.lib().las_dropout_bf16(hip.p(inputs), Dp, hip.p(xd), Dp, B * T, Dp, keep, seed, stream0 + i,
+                                                 hip.stream()))
+            hip.gemm_nt(xd, weights.kxT[i * 4 * H:], xproj[..., i * 4 * H:], B * T, 4 * H, Dp, lda=Dp, ldb=Dp,
+                        ldc=nd * 4 * H, bias=weights.bias[i * 4 * H:])
+            dropped.append(xd)
+    else:
+        hip.gemm_nt(inputs, weights.kxT, xproj, B * T, nd * 4 * H, Dp, lda=Dp, ldb=Dp, ldc=nd * 4 * H,
+                    bias=weights.bias)
     y = torch.empty(B, T, nd * H, dtype=torch.bfloat16, device=dev)
     cbuf = torch.empty(B, T, nd * H, dtype=torch.float32, device=dev)
     c_last = torch.empty(nd, B, H, dtype=torch.float32, device=dev)
@@ -148,7 +165,7 @@ def bilstm(inputs, sequence_length, num_units, dropout, mode, unidirectional=Fal
                                                hip.p(lstm_workspace(B, H, nd)), B, T, H, nd, hip.stream()))
     if tape is not None:
         tape.append(dict(kind='bilstm', inputs=inputs, length=sequence_length, gates=xproj, cbuf=cbuf, y=y,
-                         weights=weights, B=B, T=T, H=H, D=D, Dp=Dp, nd=nd))
+                         weights=weights, B=B, T=T, H=H, D=D, Dp=Dp, nd=nd, dropped=dropped, keep=keep, rng=rng))
     states = tuple(LSTMStateTuple(c_last[i], h_last[i]) for i in range(nd))
     if unidirectional:
         return y, states[0]
@@ -182,14 +199,30 @@ def bilstm_backward(rec, dy, d_state, grads, need_dx=True, overlap=None):
     BT = B * T
     # critical path first: dX feeds the next (lower) layer's recurrence
     dx = None
+    dropped, keep = rec.get('dropped'), rec.get('keep', 1.0)
     if need_dx:
         dx = torch.empty(B, T, D, dtype=torch.float32, device=dev)
-        hip.gemm_nt(dz, w.kx, dx, BT, D, nd * 4 * H, lda=nd * 4 * H, ldb=nd * 4 * H, ldc=D)
+        if dropped is None:
+            hip.gemm_nt(dz, w.kx, dx, BT, D, nd * 4 * H, lda=nd * 4 * H, ldb=nd * 4 * H, ldc=D)
+        else:
+            # dX = sum_dir (dZ_dir K_x,dir^T) * mask_dir: masks regenerated from the counter-based generator
+            parts = []
+            for i in range(nd):
+                pi = torch.empty(B, T, D, dtype=torch.float32, device=dev)
+                hip.gemm_nt(dz[..., i * 4 * H:], w.kx[:, i * 4 * H:], pi, BT, D, 4 * H, lda=nd * 4 * H, ldb=nd * 4 * H,
+                            ldc=D)
+                parts.append(pi)
+            seed, stream0 = rec['rng']
+            hip.check(hip.lib().las_dropout_bwd(hip.p(parts[0]), hip.p(parts[1]) if nd > 1 else None, hip.p(dx), BT, D,
+                                                keep, seed, stream0, stream0 + 1, hip.stream()))
     split = max(1, min(32, BT // 2048))
-    with (overlap or _NoOverlap()).fork(dz, x, y):
+    keepalive = [dz, x, y] + (dropped or [])
+    with (overlap or _NoOverlap()).fork(*keepalive):
         for i, (kn, bn) in enumerate(w.names):
             gk, gb = grads[kn], grads[bn]
             dzi = dz.view(BT, nd * 4 * H)[:, i * 4 * H:]
+            if dropped is not None:
+                x = dropped[i]
             if D > 0:
                 hip.gemm_tn(x, dzi, gk, D, 4 * H, BT, lda=Dp, ldb=nd * 4 * H, ldc=4 * H, split_k=split, c_perm_h=H)
             yi = y.view(BT, nd * H)[:, i * H:]
@@ -210,7 +243,7 @@ def pyramidal_stack(outputs, sequence_length):
 
 
 def pyramidal_bilstm(inputs, sequence_length, mode, hparams, *, variables=None, weights=None, tape=None,
-                     in_features=None):
+                     in_features=None, seed=0):
     """las/ops.py:68-87.  ``weights``: optional list of LayerWeights per layer (cached images)."""
     outputs = inputs
     state = None
@@ -219,7 +252,8 @@ def pyramidal_bilstm(inputs, sequence_length, mode, hparams, *, variables=None, 
         w = weights[layer] if weights is not None else None
         out, state = bilstm(outputs, sequence_length, hparams.num_units, hparams.dropout, mode,
                             hparams.unidirectional, variables=variables,
-                            scope='listener/bilstm_{}'.format(layer), weights=w, tape=tape, in_features=D)
+                            scope='listener/bilstm_{}'.format(layer), weights=w, tape=tape, in_features=D,
+                            rng=(seed, 16 + 2 * layer))
         outputs = concat_outputs(out)
         if layer != 0:
             outputs, sequence_length = pyramidal_stack(outputs, sequence_length)

@@ -164,8 +164,6 @@ class LasModel:
     def __init__(self, params, seed=4321, world_size=1, process_group=None):
         if params.ctc_weight > 0:
             raise ValueError('ctc_weight > 0 is not implemented on the HIP path this round')
-        if params.encoder.dropout > 0 or params.decoder.dropout > 0:
-            raise ValueError('dropout > 0 is not implemented on the HIP path this round (use --dropout 0)')
         if not torch.cuda.is_available():
             raise hip.LasError('no HIP device visible: the LAS path has no CPU fallback')
         hip.lib()
@@ -175,6 +173,7 @@ class LasModel:
         self.listener = las_model.Listener(params.encoder, self.vars.params, params.num_channels)
         self.speller = las_model.Speller(params.decoder, self.vars.params, _enc_depth(params.encoder))
         self.global_step = 0
+        self.rng_seed = (seed * 2654435761 + 12345) & 0x7fffffff      # base of the dropout / sampling draws
         self.step_dev = torch.ones(1, dtype=torch.int32, device='cuda')       # Adam t = global_step + 1
         self.world_size = world_size
         self.process_group = process_group
@@ -199,9 +198,11 @@ class LasModel:
         x = features['encoder_inputs']
         src_len = features['source_sequence_length']
         tin, tout, tlen = labels['targets_inputs'], labels['targets_outputs'], labels['target_sequence_length']
-        (mem, mem_len), state = self.listener.forward(x, src_len, TRAIN)
+        step_seed = (self.rng_seed + 7919 * self.global_step) & 0x7fffffff   # fresh draws every optimiser step
+        self.last_seed = step_seed
+        (mem, mem_len), state = self.listener.forward(x, src_len, TRAIN, seed=step_seed)
         U = num_steps if num_steps is not None else int(tlen.max().item())
-        logits = self.speller.forward_train(mem, mem_len, state, tin, U)
+        logits = self.speller.forward_train(mem, mem_len, state, tin, U, seed=step_seed)
         loss, dlogits = compute_loss(logits, tout, None, tlen, TRAIN, self.params.decoder.eos_id,
                                      grad_scale=1.0 / self.world_size, want_grad=True, vocab=self.speller.V)
         return loss, logits, dlogits

@@ -1,0 +1,116 @@
+"""TRAIN-mode stochastic pieces on the GPU: input dropout (las/ops.py:14-18) and scheduled sampling
+(utils/training_helper.py:48-87).  TensorFlow's random streams cannot be reproduced, so the realised masks /
+sampled tokens of the device run are exported and replayed through the oracle (same tolerances as
+test_gpu_model.py)."""
+import numpy as np
+import pytest
+import torch
+
+from tests.helpers import make_batch, to_device, relerr
+
+pytestmark = pytest.mark.gpu
+DT = torch.float64
+
+
+def _build(dropout=0.0, sampling=0.0, att='luong'):
+    from oracle import las_oracle as O
+    from phones_las_amd import model_helper as mh
+    from phones_las_amd.utils import params_utils as pu
+    F, L, H, V = 13, 2, 64, 11
+    ohp = O.HP(encoder=O.EncoderHP(num_layers=L, num_units=H), num_channels=F,
+               decoder=O.DecoderHP(num_layers=1, num_units=H, target_vocab_size=V, attention_type=att, bottom_only=True,
+                                   pass_hidden_state=True))
+    hp = pu.get_default_hparams()
+    for k, v in dict(num_channels=F, encoder_layers=L, encoder_units=H, use_pyramidal=True, decoder_layers=1,
+                     decoder_units=H, target_vocab_size=V, attention_type=att, bottom_only=True, pass_hidden_state=True,
+                     dropout=dropout, sampling_probability=sampling).items():
+        hp.set_hparam(k, v)
+    params = pu.get_encoder_decoder_hparams(hp)
+    op = O.init_params(ohp, bias_scale=0.1)
+    model = mh.LasModel(params)
+    model.load_variables(op)
+    return O, ohp, op, model
+
+
+def _mask(total, keep, seed, stream):
+    from phones_las_amd import hip
+    out = torch.empty(total, device='cuda')
+    hip.check(hip.lib().las_dropout_mask(hip.p(out), total, keep, seed, stream, hip.stream()))
+    return out.cpu().double()
+
+
+def test_dropout_forward_backward_replayed_through_oracle():
+    keep = 0.7
+    O, ohp, op, model = _build(dropout=1 - keep)
+    batch = make_batch(src_len=[12, 7, 10], tgt_len=[6, 4, 5])
+    feats, labels = to_device(batch)
+    model.vars.grad.zero_()
+    loss, logits, dlogits = model.forward_train(feats, labels)
+    model.backward(dlogits)
+    torch.cuda.synchronize()
+    seed = model.last_seed
+    B, T, F, H, V, M, U = 3, 12, 13, 64, 11, 256, 6
+    Fp = 16
+    enc_masks = []
+    for l, (Tl, Dp, D) in enumerate([(12, Fp, F), (12, 2 * H, 2 * H)]):
+        pair = tuple(_mask(B * Tl * Dp, keep, seed, 16 + 2 * l + d).reshape(B, Tl, Dp)[..., :D] for d in range(2))
+        enc_masks.append(pair)
+    assert 0.6 < float((enc_masks[1][0] > 0).double().mean()) < 0.8          # Bernoulli(keep)
+    assert not torch.equal(enc_masks[0][0], enc_masks[0][1])                 # fw and bw cells draw independently
+    dm = _mask(U * B * (V + M), keep, seed, 1).reshape(U, B, V + M)
+    stoch = {'enc_masks': enc_masks, 'dec_masks': [dm[t] for t in range(U)]}
+    out = O.train_step(ohp, op, None, None, 1, batch, mxu='bf16', stochastic=stoch)
+    for b, n in enumerate([6, 4, 5]):
+        assert relerr(logits[b, :n, :V], out['aux']['logits'][b, :n]) < 3e-2
+    assert abs(float(loss) - float(out['aux']['ce'].detach())) < 2e-2 * float(out['aux']['ce'].detach())
+    from phones_las_amd import hip
+    v = model.vars
+    hip.check(hip.lib().las_grad_l2_norms(hip.p(v.grad), hip.p(v.flat), hip.p(v.seg), len(v.table), v.total,
+                                          float(model.params.l2_reg_scale), hip.p(v.sumsq), hip.stream()))
+    torch.cuda.synchronize()
+    for name, _, _ in v.table:
+        assert relerr(v.grads[name], out['grads'][name]) < 6e-2, name
+    # a different optimiser step draws different masks
+    model.global_step += 1
+    loss2, _, _ = model.forward_train(feats, labels)
+    assert abs(float(loss2) - float(loss)) > 1e-6
+
+
+def test_scheduled_sampling_replayed_through_oracle():
+    O, ohp, op, model = _build(sampling=0.5)
+    batch = make_batch(src_len=[12, 7, 10], tgt_len=[6, 4, 5])
+    feats, labels = to_device(batch)
+    loss, logits, dlogits = model.forward_train(feats, labels)
+    fed = model.speller.saved['fed'].cpu().long()
+    model.vars.grad.zero_()
+    model.backward(dlogits)
+    torch.cuda.synchronize()
+    tin = batch['targets_inputs']
+    U, V = 6, 11
+    assert torch.equal(fed[:, 0], tin[:, 0])
+    changed = (fed[:, 1:U] != tin[:, 1:U])
+    assert 2 <= int(changed.sum()) <= 14                       # ~ half of the 15 (b, t) slots, minus coincidences
+    assert int(fed.min()) >= 0 and int(fed.max()) < V
+    sel = [changed[:, t] for t in range(U - 1)] + [torch.zeros(3, dtype=torch.bool)]
+    ids = [fed[:, t + 1] for t in range(U - 1)] + [torch.zeros(3, dtype=torch.long)]
+    out = O.train_step(ohp, op, None, None, 1, batch, mxu='bf16',
+                       stochastic={'sample_select': sel, 'sample_ids': ids})
+    for b, n in enumerate([6, 4, 5]):
+        assert relerr(logits[b, :n, :V], out['aux']['logits'][b, :n]) < 2e-2
+    k = 'speller/decoder_cell_0/lstm_cell/kernel'
+    assert relerr(model.vars.grads[k], out['grads'][k] - ohp.l2_reg_scale * op[k]) < 6e-2
+
+
+def test_sampled_tokens_follow_the_logits():
+    from phones_las_amd import hip
+    B, V = 4096, 8
+    logits = torch.zeros(B, V, device='cuda')
+    logits[:, 3] = 2.0                                           # p(3) = e^2 / (e^2 + 7) = 0.5135
+    teacher = torch.full((B,), 7, dtype=torch.int32, device='cuda')
+    nxt = torch.empty(B, dtype=torch.int32, device='cuda')
+    hip.check(hip.lib().las_sample_tokens(hip.p(logits), V, V, hip.p(teacher), 1, hip.p(nxt), 1, B, 1.0, 123, 5, hip.stream()))
+    frac3 = float((nxt == 3).float().mean())
+    assert abs(frac3 - 0.5135) < 0.04
+    hip.check(hip.lib().las_sample_tokens(hip.p(logits), V, V, hip.p(teacher), 1, hip.p(nxt), 1, B, 0.25, 123, 5, hip.stream()))
+    kept = float((nxt == 7).float().mean())                      # teacher kept w.p. 0.75 (+ sampled 7s: 0.25 * 0.0695)
+    assert abs(kept - (0.75 + 0.25 * 0.0695)) < 0.04
