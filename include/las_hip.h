@@ -243,6 +243,9 @@ int las_sample_tokens(const float* logits, int64_t ldl, int V, const int32_t* te
                       int32_t* next, int64_t next_stride, int B, float prob, uint32_t seed, uint32_t step,
                       void* stream);
 
+/* p[i] += std * N(0,1): the periodic Gaussian weight noise on `*kernel` variables (model_helper.py:418-432). */
+int las_add_noise(float* p, int64_t n, float std, uint32_t seed, uint32_t stream_id, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * Loss: tf.contrib.seq2seq.sequence_loss as used by compute_loss (model_helper.py:24-30):
  * loss = sum_{b,t<len_b} CE(logits[b,t], targets[b,t]) / (sum_b len_b + 1e-12).

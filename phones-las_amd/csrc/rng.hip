@@ -82,6 +82,15 @@ __global__ void sample_kernel(const float* logits, int64_t ldl, int V, const int
   if (lane == 0) next[(int64_t)b * next_stride] = out;
 }
 
+// p[i] += std * N(0,1)  (Box-Muller on two counter-based uniforms): weight noise of model_helper.py:418-432
+__global__ void add_noise_kernel(float* p, int64_t n, float std, unsigned seed, unsigned stream) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const float u1 = fmaxf(las_uniform(seed, stream, (unsigned long long)i * 2), 1e-12f);
+    const float u2 = las_uniform(seed, stream, (unsigned long long)i * 2 + 1);
+    p[i] += std * sqrtf(-2.0f * __logf(u1)) * __cosf(6.2831853f * u2);
+  }
+}
+
 int blocks_for(int64_t n) {
   int64_t b = (n + 255) / 256;
   return (int)(b > 2048 ? 2048 : b);
@@ -134,5 +143,12 @@ extern "C" int las_sample_tokens(const float* logits, int64_t ldl, int V, const 
   hipLaunchKernelGGL(sample_kernel, dim3((B + 3) / 4), dim3(256), 0, (hipStream_t)stream, logits, ldl, V, teacher, teacher_stride,
                      next, next_stride, B, prob, seed, step);
   LAS_LAUNCH_CHECK("sample launch");
+  return LAS_OK;
+}
+
+extern "C" int las_add_noise(float* p, int64_t n, float std, uint32_t seed, uint32_t stream_id, void* stream) {
+  LAS_REQUIRE(n > 0 && std >= 0.f, "las_add_noise: bad arguments");
+  hipLaunchKernelGGL(add_noise_kernel, dim3(blocks_for(n)), dim3(256), 0, (hipStream_t)stream, p, n, std, seed, stream_id);
+  LAS_LAUNCH_CHECK("add noise launch");
   return LAS_OK;
 }

@@ -31,8 +31,6 @@ class Listener:
     """Pyramidal BiLSTM encoder (las/ops.py:68-87) with cached bf16 weight images and a tape."""
 
     def __init__(self, hparams, variables, num_channels):
-        if not hparams.use_pyramidal:
-            raise ValueError('only --use_pyramidal listeners are implemented on the HIP path')
         self.hp = hparams
         self.F = num_channels
         self.Fp = _r8(num_channels)
@@ -41,11 +39,16 @@ class Listener:
         self.layers = []
         D, Dp = num_channels, self.Fp
         for l in range(hparams.num_layers):
-            self.layers.append(ops.LayerWeights(variables, 'listener/bilstm_{}'.format(l), D, Dp, H,
-                                                hparams.unidirectional))
-            D = nd * H * (1 if l == 0 else 2)
+            if hparams.use_pyramidal:
+                self.layers.append(ops.LayerWeights(variables, 'listener/bilstm_{}'.format(l), D, Dp, H,
+                                                    hparams.unidirectional))
+                D = nd * H * (1 if l == 0 else 2)
+            else:       # one MultiRNNCell stack per direction (las/model.py:111-133): layer l reads H columns
+                self.layers.append(ops.LayerWeights(variables, 'listener', D, Dp, H, hparams.unidirectional,
+                                                    cell_path='/{dir}/multi_rnn_cell/cell_%d/lstm_cell' % l))
+                D = H
             Dp = D
-        self.time_multiple = 2 ** max(0, hparams.num_layers - 1)
+        self.time_multiple = 2 ** max(0, hparams.num_layers - 1) if hparams.use_pyramidal else 1
         self.tape = None
 
     def refresh(self, variables):
@@ -67,6 +70,9 @@ class Listener:
         if x.dtype != torch.bfloat16:
             x = self.pad_features(x.contiguous())
         self.tape = [] if mode == TRAIN else None
+        if not self.hp.use_pyramidal:
+            return ops.stacked_bilstm(x, source_sequence_length, mode, self.hp, weights=self.layers, tape=self.tape,
+                                      in_features=self.F, seed=seed)
         return ops.pyramidal_bilstm(x, source_sequence_length, mode, self.hp, weights=self.layers,
                                     tape=self.tape, in_features=self.F, seed=seed)
 
@@ -76,7 +82,7 @@ class Listener:
         dy = d_outputs
         for l in range(len(recs) - 1, -1, -1):
             r = recs[l]
-            dy = dy.view(r['B'], r['T'], r['nd'] * r['H'])
+            dy = dy.contiguous().view(r['B'], r['T'], r['nd'] * r['H'])
             dx = ops.bilstm_backward(r, dy, d_state if l == len(recs) - 1 else None, grads, need_dx=(l > 0),
                                      overlap=overlap)
             dy = dx
@@ -166,6 +172,9 @@ class Speller:
         dev = 'cuda'
         if d.pass_hidden_state and d.bottom_only:                         # las/model.py:259-268
             es = encoder_state[0] if isinstance(encoder_state[0], tuple) else encoder_state
+            if not hasattr(es, 'c'):
+                raise ValueError('pass_hidden_state needs the pyramidal listener (its state is one LSTMStateTuple per '
+                                 'direction; the stacked listener returns one per layer, which TF cannot zip either)')
             c0, h0 = es.c, es.h
             if c0.shape[-1] != self.Hd:
                 raise ValueError('pass_hidden_state needs decoder_units == encoder_units')

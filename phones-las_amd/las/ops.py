@@ -123,15 +123,19 @@ class LayerWeights:
 
 
 def bilstm(inputs, sequence_length, num_units, dropout, mode, unidirectional=False, *, variables=None,
-           scope='', weights=None, tape=None, in_features=None, rng=None):
+           scope='', weights=None, tape=None, in_features=None, rng=None, split_inputs=False):
     """las/ops.py:23-46.  inputs [B,T,Dp] bf16; sequence_length int32 [B] (CUDA).
     Returns (outputs, state) with the reference's structure: bidirectional -> ((fw, bw), (state_fw,
     state_bw)); unidirectional -> (fw, state).  fw/bw are views of one [B,T,ndir*H] buffer
-    (use ``concat_outputs`` for the tf.concat of las/ops.py:81)."""
+    (use ``concat_outputs`` for the tf.concat of las/ops.py:81).
+    split_inputs: direction i reads only columns [i*D, (i+1)*D) of ``inputs`` (the per-direction MultiRNNCell
+    stacks of the non-pyramidal listener, las/model.py:111-133)."""
     cell = lstm_cell(num_units, dropout, mode)
     keep = cell.input_keep_prob
-    B, T, Dp = inputs.shape
+    B, T, Dfull = inputs.shape
     H = num_units
+    nd_in = 1 if unidirectional else 2
+    Dp = Dfull // nd_in if split_inputs else Dfull
     D = in_features if in_features is not None else Dp
     if weights is None:
         weights = LayerWeights(variables, scope, D, Dp, H, unidirectional)
@@ -139,20 +143,25 @@ def bilstm(inputs, sequence_length, num_units, dropout, mode, unidirectional=Fal
     dev = inputs.device
     xproj = torch.empty(B, T, nd * 4 * H, dtype=torch.float32, device=dev)
     dropped = None
-    if keep < 1.0:
-        # DropoutWrapper(input_keep_prob) on each cell's input (las/ops.py:14-18): the fw and bw cells draw
-        # independent masks, fresh per time step -> one dropped copy of the layer input per direction
-        if rng is None:
+    if keep < 1.0 or split_inputs:
+        # one A operand per direction: DropoutWrapper(input_keep_prob) draws independent masks for the fw and bw
+        # cells, fresh per time step (las/ops.py:14-18); split_inputs gives each direction its own columns
+        if keep < 1.0 and rng is None:
             raise ValueError('dropout needs rng=(seed, first_stream_id)')
-        seed, stream0 = rng
         dropped = []
         for i in range(nd):
-            xd = torch.empty_like(inputs)
-            hip.check(hip.lib().las_dropout_bf16(hip.p(inputs), Dp, hip.p(xd), Dp, B * T, Dp, keep, seed, stream0 + i,
-                                                 hip.stream()))
-            hip.gemm_nt(xd, weights.kxT[i * 4 * H:], xproj[..., i * 4 * H:], B * T, 4 * H, Dp, lda=Dp, ldb=Dp,
+            src = inputs[..., i * Dp:(i + 1) * Dp] if split_inputs else inputs
+            if keep < 1.0:
+                seed, stream0 = rng
+                xd = torch.empty(B, T, Dp, dtype=torch.bfloat16, device=dev)
+                hip.check(hip.lib().las_dropout_bf16(hip.p(src), Dfull, hip.p(xd), Dp, B * T, Dp, keep, seed,
+                                                     stream0 + i, hip.stream()))
+                a, lda = xd, Dp
+            else:
+                a, lda = src, Dfull
+            hip.gemm_nt(a, weights.kxT[i * 4 * H:], xproj[..., i * 4 * H:], B * T, 4 * H, Dp, lda=lda, ldb=Dp,
                         ldc=nd * 4 * H, bias=weights.bias[i * 4 * H:])
-            dropped.append(xd)
+            dropped.append((a, lda))
     else:
         hip.gemm_nt(inputs, weights.kxT, xproj, B * T, nd * 4 * H, Dp, lda=Dp, ldb=Dp, ldc=nd * 4 * H,
                     bias=weights.bias)
@@ -165,7 +174,8 @@ def bilstm(inputs, sequence_length, num_units, dropout, mode, unidirectional=Fal
                                                hip.p(lstm_workspace(B, H, nd)), B, T, H, nd, hip.stream()))
     if tape is not None:
         tape.append(dict(kind='bilstm', inputs=inputs, length=sequence_length, gates=xproj, cbuf=cbuf, y=y,
-                         weights=weights, B=B, T=T, H=H, D=D, Dp=Dp, nd=nd, dropped=dropped, keep=keep, rng=rng))
+                         weights=weights, B=B, T=T, H=H, D=D, Dp=Dp, nd=nd, dropped=dropped, keep=keep, rng=rng,
+                         split=split_inputs, Dfull=Dfull))
     states = tuple(LSTMStateTuple(c_last[i], h_last[i]) for i in range(nd))
     if unidirectional:
         return y, states[0]
@@ -200,36 +210,65 @@ def bilstm_backward(rec, dy, d_state, grads, need_dx=True, overlap=None):
     # critical path first: dX feeds the next (lower) layer's recurrence
     dx = None
     dropped, keep = rec.get('dropped'), rec.get('keep', 1.0)
+    split_in = rec.get('split', False)
     if need_dx:
-        dx = torch.empty(B, T, D, dtype=torch.float32, device=dev)
         if dropped is None:
+            dx = torch.empty(B, T, D, dtype=torch.float32, device=dev)
             hip.gemm_nt(dz, w.kx, dx, BT, D, nd * 4 * H, lda=nd * 4 * H, ldb=nd * 4 * H, ldc=D)
         else:
-            # dX = sum_dir (dZ_dir K_x,dir^T) * mask_dir: masks regenerated from the counter-based generator
+            # per direction dX_i = dZ_i K_x,i^T, then through that direction's input dropout (masks regenerated from
+            # the counter-based generator); summed when both directions read the same input, side by side otherwise
             parts = []
             for i in range(nd):
                 pi = torch.empty(B, T, D, dtype=torch.float32, device=dev)
                 hip.gemm_nt(dz[..., i * 4 * H:], w.kx[:, i * 4 * H:], pi, BT, D, 4 * H, lda=nd * 4 * H, ldb=nd * 4 * H,
                             ldc=D)
                 parts.append(pi)
-            seed, stream0 = rec['rng']
-            hip.check(hip.lib().las_dropout_bwd(hip.p(parts[0]), hip.p(parts[1]) if nd > 1 else None, hip.p(dx), BT, D,
-                                                keep, seed, stream0, stream0 + 1, hip.stream()))
+            lib = hip.lib()
+            if keep < 1.0:
+                seed, stream0 = rec['rng']
+                if split_in or nd == 1:
+                    for i in range(nd):
+                        hip.check(lib.las_dropout_bwd(hip.p(parts[i]), None, hip.p(parts[i]), BT, D, keep, seed,
+                                                      stream0 + i, 0, hip.stream()))
+                else:
+                    dx = torch.empty(B, T, D, dtype=torch.float32, device=dev)
+                    hip.check(lib.las_dropout_bwd(hip.p(parts[0]), hip.p(parts[1]), hip.p(dx), BT, D, keep, seed, stream0,
+                                                  stream0 + 1, hip.stream()))
+            if dx is None:
+                dx = torch.cat(parts, -1) if split_in else (parts[0] if nd == 1 else parts[0] + parts[1])
     split = max(1, min(32, BT // 2048))
-    keepalive = [dz, x, y] + (dropped or [])
+    keepalive = [dz, x, y] + [a for a, _ in (dropped or [])]
     with (overlap or _NoOverlap()).fork(*keepalive):
         for i, (kn, bn) in enumerate(w.names):
             gk, gb = grads[kn], grads[bn]
             dzi = dz.view(BT, nd * 4 * H)[:, i * 4 * H:]
-            if dropped is not None:
-                x = dropped[i]
+            xa, lda = (dropped[i] if dropped is not None else (x, Dp))
             if D > 0:
-                hip.gemm_tn(x, dzi, gk, D, 4 * H, BT, lda=Dp, ldb=nd * 4 * H, ldc=4 * H, split_k=split, c_perm_h=H)
+                hip.gemm_tn(xa, dzi, gk, D, 4 * H, BT, lda=lda, ldb=nd * 4 * H, ldc=4 * H, split_k=split, c_perm_h=H)
             yi = y.view(BT, nd * H)[:, i * H:]
             hip.gemm_tn(yi, dzi, gk[D:], H, 4 * H, BT, lda=nd * H, ldb=nd * 4 * H, ldc=4 * H,
                         a_shift=(-1 if i == 0 else 1), period=T, split_k=split, c_perm_h=H)
             hip.colsum_bf16(dzi, BT, 4 * H, gb, ldx=nd * 4 * H, perm_h=H)
     return dx
+
+
+def stacked_bilstm(inputs, sequence_length, mode, hparams, *, weights, tape=None, in_features=None, seed=0):
+    """The non-pyramidal listener of las/model.py:111-142: one MultiRNNCell stack per direction (layer l of a
+    direction reads that direction's layer l-1 outputs only), outputs = concat(fw_top, bw_top), no time reduction.
+    Returns ((outputs, lengths), state) with state = (fw_layer_states, bw_layer_states) (or one tuple when
+    unidirectional)."""
+    outputs = inputs
+    per_layer = []
+    for layer in range(hparams.num_layers):
+        out, st = bilstm(outputs, sequence_length, hparams.num_units, hparams.dropout, mode, hparams.unidirectional,
+                         weights=weights[layer], tape=tape, in_features=in_features if layer == 0 else None,
+                         rng=(seed, 16 + 2 * layer), split_inputs=(layer > 0))
+        outputs = concat_outputs(out)
+        per_layer.append(st)
+    if hparams.unidirectional:
+        return (outputs, sequence_length), tuple(per_layer)
+    return (outputs, sequence_length), (tuple(s[0] for s in per_layer), tuple(s[1] for s in per_layer))
 
 
 def pyramidal_stack(outputs, sequence_length):

@@ -250,6 +250,21 @@ class LasModel:
         self.all_reduce_gradients()
         self.adam_update()
 
+    def maybe_add_noise(self):
+        """model_helper.py:418-432: every `add_noise` steps (and not at step 0) add N(0, noise_std) to every variable
+        whose name ends in 'kernel'."""
+        p = self.params
+        n = int(getattr(p, 'add_noise', 0) or 0)
+        if n <= 0 or self.global_step == 0 or self.global_step % n:
+            return
+        lib, st = hip.lib(), hip.stream()
+        for i, (name, shape, _) in enumerate(self.vars.table):
+            if name.endswith('kernel'):
+                t = self.vars.params[name]
+                hip.check(lib.las_add_noise(hip.p(t), t.numel(), float(p.noise_std), self.last_seed if hasattr(self, 'last_seed') else self.rng_seed,
+                                            1000 + i, st))
+        self._images_stale = True
+
     def l2_loss(self):
         out = torch.zeros(1, dtype=torch.float32, device='cuda')
         hip.check(hip.lib().las_sumsq(hip.p(self.vars.flat), self.vars.total, hip.p(out), hip.stream()))
@@ -262,6 +277,7 @@ class LasModel:
         loss = audio_loss + self.l2_loss()
         self.backward(dlogits)
         self.apply_gradients()
+        self.maybe_add_noise()
         self.refresh_images()
         self.global_step += 1
         return loss
@@ -316,6 +332,7 @@ def las_model_fn(features, labels, mode, config, params, binf2phone=None, run_na
     def train_op():
         model.backward(dlogits)
         model.apply_gradients()
+        model.maybe_add_noise()
         model.refresh_images()
         model.global_step += 1
 

@@ -135,3 +135,38 @@ def test_greedy_decode_vs_oracle_first_steps():
     n = min(pred['sample_ids'].shape[1], rids.shape[1])
     agree = (pred['sample_ids'][:, :n].cpu() == rids[:, :n]).float().mean()
     assert float(agree) > 0.8
+
+
+def test_stacked_non_pyramidal_listener_vs_oracle():
+    # las/model.py:111-142: per-direction MultiRNNCell stacks, no time reduction, no state passing
+    O, ohp, op, model = _models('luong', pyramidal=False, pass_hidden=False, L=3)
+    batch = make_batch(src_len=[12, 7, 10], tgt_len=[6, 4, 5])
+    feats, labels = to_device(batch)
+    out = O.train_step(ohp, op, None, None, 1, batch, mxu='bf16')
+    model.vars.grad.zero_()
+    loss, logits, dlogits = model.forward_train(feats, labels)
+    model.backward(dlogits)
+    torch.cuda.synchronize()
+    V = ohp.decoder.target_vocab_size
+    assert out['aux']['memory'].shape[1:] == (12, 128)
+    for b, n in enumerate([6, 4, 5]):
+        assert relerr(logits[b, :n, :V], out['aux']['logits'][b, :n]) < 2e-2
+    for name, _, _ in model.vars.table:
+        g = out['grads'][name] - ohp.l2_reg_scale * op[name]
+        assert relerr(model.vars.grads[name], g) < 5e-2, name
+
+
+def test_weight_noise_hits_kernels_only():
+    O, ohp, op, model = _models('luong')
+    model.params.add_hparam('add_noise', 1) if not hasattr(model.params, 'add_noise') else model.params.set_hparam('add_noise', 1)
+    model.params.set_hparam('noise_std', 0.05)
+    before = {n: t.clone() for n, t in model.vars.params.items()}
+    model.global_step = 3
+    model.maybe_add_noise()
+    torch.cuda.synchronize()
+    for n, t in model.vars.params.items():
+        d = (t - before[n]).double().cpu()
+        if n.endswith('kernel'):
+            assert 0.03 < float(d.std()) < 0.07 and abs(float(d.mean())) < 0.01, n
+        else:
+            assert float(d.abs().max()) == 0.0, n
