@@ -258,6 +258,19 @@ int las_seq_ce_loss(const float* logits, int64_t ldl, const int32_t* targets, co
                     void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * CTC head (model_helper.py:347-367): tf.nn.ctc_loss_v2 with dense labels [B,U] (row stride ldlab; blank
+ * index `blank` = 0 in the reference, labels include the trailing </s>), logits [B,T,ldl] fp32 with C
+ * valid classes, per-utterance label_len / logit_len.  loss_out[0] += loss_scale * sum_b nll_b (pass
+ * ctc_weight / B); per_example[b] = nll_b (optional); dlogits (bf16, [B,T,ldl]) = grad_scale *
+ * d nll_b / d logits (pass ctc_weight / B / replicas).  Workspace: las_ctc_workspace_bytes().
+ * ---------------------------------------------------------------------------------------- */
+size_t las_ctc_workspace_bytes(int B, int T, int C_padded, int U);
+int las_ctc_loss(const float* logits, int64_t ldl, const int32_t* labels, int64_t ldlab, const int32_t* label_len,
+                 const int32_t* logit_len, int B, int T, int C, int U, int blank, float loss_scale,
+                 float grad_scale, void* workspace, float* loss_out, float* per_example, las_bf16* dlogits,
+                 void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * Train op (model_helper.py:403-417): L2 over all variables, per-tensor clip_by_norm(g, 2),
  * tf.train.AdamOptimizer update.  Parameters, gradients and Adam slots are flat fp32 buffers;
  * seg_offsets[nseg+1] gives the tensor boundaries (device int64).

@@ -42,6 +42,8 @@ _SIGS = {
     'las_dropout_bwd': ([_vp, _vp, _vp, _i32, _i32, _f32, C.c_uint32, C.c_uint32, C.c_uint32, _vp], C.c_int),
     'las_dropout_mask': ([_vp, _i64, _f32, C.c_uint32, C.c_uint32, _vp], C.c_int),
     'las_onehot_bf16': ([_vp, _i64, _i32, _i32, _i32, _vp, _i64, _f32, C.c_uint32, C.c_uint32, _i32, _vp], C.c_int),
+    'las_ctc_workspace_bytes': ([_i32, _i32, _i32, _i32], C.c_size_t),
+    'las_ctc_loss': ([_vp, _i64, _vp, _i64, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _f32, _f32, _vp, _vp, _vp, _vp, _vp], C.c_int),
     'las_add_noise': ([_vp, _i64, _f32, C.c_uint32, C.c_uint32, _vp], C.c_int),
     'las_sample_tokens': ([_vp, _i64, _i32, _vp, _i64, _vp, _i64, _i32, _f32, C.c_uint32, C.c_uint32, _vp], C.c_int),
 }

@@ -153,17 +153,77 @@ def compute_loss(logits, targets, final_sequence_length, target_sequence_length,
         raise ValueError('targets shorter than the decoded length')
     loss = torch.zeros(1, dtype=torch.float32, device=dev)
     dlogits = torch.zeros(B, U, ldl, dtype=torch.bfloat16, device=dev) if want_grad else None
-    hip.check(hip.lib().las_seq_ce_loss(hip.p(logits), ldl, hip.p(tg), hip.p(target_sequence_length.to(torch.int32)),
+    tlen32 = target_sequence_length.to(torch.int32)     # named: a temporary would be recycled before the launch
+    hip.check(hip.lib().las_seq_ce_loss(hip.p(logits), ldl, hip.p(tg), hip.p(tlen32),
                                         B, U, V, float(grad_scale), hip.p(loss), hip.p(dlogits), ldl, hip.stream()))
     return loss, dlogits
+
+
+class CtcHead:
+    """Dense(M -> V+1) on the encoder outputs + tf.nn.ctc_loss_v2 (model_helper.py:347-358): blank index 0, labels =
+    targets_outputs incl. </s> with label_length = target_sequence_length, logit_length = reduced source length,
+    mean over the batch, times ctc_weight."""
+    K, Bn = 'ctc_logits/kernel', 'ctc_logits/bias'
+
+    def __init__(self, params, variables, M):
+        self.w = float(params.ctc_weight)
+        self.M, self.C = M, params.decoder.target_vocab_size + 1
+        self.Cp = (self.C + 7) // 8 * 8
+        bf = torch.bfloat16
+        self.wT = torch.empty(self.Cp, M, dtype=bf, device='cuda')
+        self.wn = torch.empty(M, self.Cp, dtype=bf, device='cuda')
+        self.bias = torch.zeros(self.Cp, dtype=torch.float32, device='cuda')
+        self.refresh(variables)
+
+    def refresh(self, var):
+        hip.cast_bf16(var[self.K], self.M, self.C, self.wT, self.Cp, self.M, transpose=True)
+        hip.cast_bf16(var[self.K], self.M, self.C, self.wn, self.M, self.Cp)
+        self.bias[:self.C].copy_(var[self.Bn])
+
+    def forward(self, memory, mem_len, targets, target_len, loss_out, grad_scale):
+        B, Tm, M = memory.shape
+        dev = memory.device
+        lib = hip.lib()
+        self.logits = torch.empty(B, Tm, self.Cp, dtype=torch.float32, device=dev)
+        hip.gemm_nt(memory, self.wT, self.logits, B * Tm, self.Cp, M, lda=M, ldb=M, ldc=self.Cp, bias=self.bias)
+        U = targets.shape[1]
+        ws = torch.empty(lib.las_ctc_workspace_bytes(B, Tm, self.Cp, U), dtype=torch.uint8, device=dev)
+        self.dlogits = torch.empty(B, Tm, self.Cp, dtype=torch.bfloat16, device=dev)
+        self.per_example = torch.empty(B, dtype=torch.float32, device=dev)
+        tg = targets.to(torch.int32).contiguous()
+        tl = target_len.to(torch.int32)                 # named: a temporary would be recycled before the launch
+        hip.check(lib.las_ctc_loss(hip.p(self.logits), self.Cp, hip.p(tg), U, hip.p(tl),
+                                   hip.p(mem_len), B, Tm, self.C, U, 0, self.w / B, self.w / B * grad_scale, hip.p(ws),
+                                   hip.p(loss_out), hip.p(self.per_example), hip.p(self.dlogits), hip.stream()))
+        self.memory = memory
+
+    def backward(self, dmem, grads):
+        B, Tm, M = self.memory.shape
+        hip.gemm_nt(self.dlogits, self.wn, dmem, B * Tm, M, self.Cp, lda=self.Cp, ldb=self.Cp, ldc=M, accumulate=True)
+        hip.gemm_tn(self.memory, self.dlogits, grads[self.K], M, self.C, B * Tm, lda=M, ldb=self.Cp, ldc=self.C, split_k=4)
+        hip.colsum_bf16(self.dlogits, B * Tm, self.C, grads[self.Bn], ldx=self.Cp)
+
+
+def ctc_greedy_decode(logits, logit_len):
+    """tf.nn.ctc_greedy_decoder (model_helper.py:351-353): blank = LAST class, merge repeated; host-side metric."""
+    best = logits.argmax(-1).cpu().tolist()
+    C = logits.shape[-1]
+    out = []
+    for b, row in enumerate(best):
+        prev, seq = -1, []
+        for t in range(int(logit_len[b])):
+            k = row[t]
+            if k != prev and k != C - 1:
+                seq.append(k)
+            prev = k
+        out.append(seq)
+    return out
 
 
 class LasModel:
     """Variables + listener + speller + train op: what tf.estimator.Estimator(model_fn=las_model_fn) holds."""
 
     def __init__(self, params, seed=4321, world_size=1, process_group=None):
-        if params.ctc_weight > 0:
-            raise ValueError('ctc_weight > 0 is not implemented on the HIP path this round')
         if not torch.cuda.is_available():
             raise hip.LasError('no HIP device visible: the LAS path has no CPU fallback')
         hip.lib()
@@ -172,6 +232,7 @@ class LasModel:
         self.vars.initialize(seed)
         self.listener = las_model.Listener(params.encoder, self.vars.params, params.num_channels)
         self.speller = las_model.Speller(params.decoder, self.vars.params, _enc_depth(params.encoder))
+        self.ctc = CtcHead(params, self.vars.params, _enc_depth(params.encoder)) if params.ctc_weight > 0 else None
         self.global_step = 0
         self.rng_seed = (seed * 2654435761 + 12345) & 0x7fffffff      # base of the dropout / sampling draws
         self.step_dev = torch.ones(1, dtype=torch.int32, device='cuda')       # Adam t = global_step + 1
@@ -188,6 +249,8 @@ class LasModel:
     def refresh_images(self):
         self.listener.refresh(self.vars.params)
         self.speller.refresh(self.vars.params)
+        if self.ctc is not None:
+            self.ctc.refresh(self.vars.params)
         self._images_stale = False
 
     # -- forward / backward ---------------------------------------------------------------------
@@ -205,11 +268,15 @@ class LasModel:
         logits = self.speller.forward_train(mem, mem_len, state, tin, U, seed=step_seed)
         loss, dlogits = compute_loss(logits, tout, None, tlen, TRAIN, self.params.decoder.eos_id,
                                      grad_scale=1.0 / self.world_size, want_grad=True, vocab=self.speller.V)
+        if self.ctc is not None:        # audio_loss += ctc_loss * ctc_weight (model_helper.py:347-358)
+            self.ctc.forward(mem, mem_len, tout, tlen, loss, 1.0 / self.world_size)
         return loss, logits, dlogits
 
     def backward(self, dlogits):
         g = self.vars.grads
         dmem, d_state = self.speller.backward(dlogits, g, self.overlap)
+        if self.ctc is not None:
+            self.ctc.backward(dmem, g)
         ds = None
         if d_state is not None:
             nd = 1 if self.params.encoder.unidirectional else 2

@@ -170,3 +170,47 @@ def test_weight_noise_hits_kernels_only():
             assert 0.03 < float(d.std()) < 0.07 and abs(float(d.mean())) < 0.01, n
         else:
             assert float(d.abs().max()) == 0.0, n
+
+
+def test_ctc_kernel_matches_torch_ctc_loss():
+    from phones_las_amd import hip
+    import torch.nn.functional as F
+    torch.manual_seed(0)
+    B, T, C, Cp, U = 5, 17, 9, 16, 6
+    logits = torch.randn(B, T, Cp) * 2
+    labels = torch.randint(1, C, (B, U))
+    labels[0, 2] = labels[0, 1]                       # a repeated label (needs the blank between)
+    ll = torch.tensor([6, 3, 1, 5, 2])
+    tl = torch.tensor([17, 9, 4, 16, 17])
+    lr = logits[..., :C].double().requires_grad_(True)
+    ref = F.ctc_loss(torch.log_softmax(lr, -1).transpose(0, 1), labels, tl, ll, blank=0, reduction='none')
+    ref.sum().backward()
+    lib = hip.lib()
+    ws = torch.empty(lib.las_ctc_workspace_bytes(B, T, Cp, U), dtype=torch.uint8, device='cuda')
+    loss = torch.zeros(1, device='cuda'); per = torch.empty(B, device='cuda')
+    dl = torch.empty(B, T, Cp, dtype=torch.bfloat16, device='cuda')
+    d_logits, d_labels = logits.cuda(), labels.to(torch.int32).cuda()       # keep the device tensors alive
+    d_ll, d_tl = ll.to(torch.int32).cuda(), tl.to(torch.int32).cuda()
+    hip.check(lib.las_ctc_loss(hip.p(d_logits), Cp, hip.p(d_labels), U, hip.p(d_ll), hip.p(d_tl), B, T, C, U, 0, 0.5, 1.0,
+                               hip.p(ws), hip.p(loss), hip.p(per), hip.p(dl), hip.stream()))
+    torch.cuda.synchronize()
+    assert torch.allclose(per.cpu().double(), ref.detach(), rtol=1e-4, atol=1e-4)
+    assert abs(float(loss) - 0.5 * float(ref.sum())) < 1e-3
+    assert relerr(dl[..., :C].float(), lr.grad) < 1e-2
+    assert float(dl[..., C:].float().abs().max()) == 0.0
+
+
+def test_ctc_multitask_train_step_vs_oracle():
+    O, ohp, op, model = _models('luong', ctc=0.3)
+    batch = make_batch(src_len=[12, 7, 10], tgt_len=[3, 2, 3], U=3)
+    feats, labels = to_device(batch)
+    out = O.train_step(ohp, op, None, None, 1, batch, mxu='bf16')
+    model.vars.grad.zero_()
+    loss, logits, dlogits = model.forward_train(feats, labels)
+    model.backward(dlogits)
+    torch.cuda.synchronize()
+    ref_audio = float(out['audio_loss'])
+    assert abs(float(loss) - ref_audio) < 2e-2 * abs(ref_audio)
+    for name, _, _ in model.vars.table:
+        g = out['grads'][name] - ohp.l2_reg_scale * op[name]
+        assert relerr(model.vars.grads[name], g) < 6e-2, name
