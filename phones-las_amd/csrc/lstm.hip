@@ -36,7 +36,10 @@ __device__ __forceinline__ u64 granule_load(const u64* p) {
 }
 
 // number of cooperating workgroups per chain
-__host__ __device__ constexpr int coop_members(int H) { return H <= 128 ? 1 : H / 64; }
+// H <= 128: one workgroup; H = 256: 4 x 64 units; H = 512: 16 x 32 units with the K dimension split over wave pairs
+// (a wave's register-resident weight block is 16 units x 4 gates x K/KS: 128 VGPRs in every case)
+__host__ __device__ constexpr int coop_members(int H) { return H <= 128 ? 1 : (H == 256 ? 4 : H / 32); }
+__host__ __device__ constexpr int k_split(int H) { return H > 256 ? 2 : 1; }
 
 // ------------------------------------------------------------------------------------------------
 // pack K_h [H,4H] fp32 -> MFMA-B-fragment-major bf16, grouped by 16-unit block:
@@ -76,13 +79,17 @@ __global__ __launch_bounds__(rec_threads(H)) void lstm_fwd_kernel(float* __restr
                                                           unsigned* __restrict__ status, int B, int T, int ndir, int ngroups) {
   constexpr int G = coop_members(H);
   constexpr int HS = H / G;            // units per member
-  constexpr int UB = HS / 64;          // 16-unit blocks per wave
+  constexpr int KS = k_split(H);       // ways the K dimension is split over waves
+  constexpr int NUB = HS / 16;         // 16-unit blocks of this member
+  constexpr int UB = (NUB * KS) / 4 > 0 ? (NUB * KS) / 4 : 1;   // blocks per wave (4 compute waves)
   constexpr int KC = H / 32;
+  constexpr int KCW = KC / KS;         // k-chunks a wave owns
   constexpr int LS = H + 8;            // LDS row stride (elements)
   constexpr int NGRAN = 8 * HS;        // granules a member publishes per step (2 rows x 1 unit each)
   __shared__ __attribute__((aligned(16))) unsigned short hlds[2][16][LS];
   __shared__ int fail_flag;
   __shared__ __attribute__((aligned(16))) float pf_scratch[256];   // 1 KiB sink of the prefetch wave's LDS-DMAs
+  __shared__ __attribute__((aligned(16))) float red[KS > 1 ? 2 * 4 * 64 * 4 : 4];   // partial sums of the upper K half
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int group = blockIdx.x % ngroups, member = blockIdx.x / ngroups;
@@ -101,17 +108,21 @@ __global__ __launch_bounds__(rec_threads(H)) void lstm_fwd_kernel(float* __restr
   smax = (int)las_wave_max((float)smax);
 
   // register-resident B fragments of this wave's K_h columns
-  bf16x8 wf[UB][KC][4];
+  // wave -> (first unit block, K half): KS = 1: 4 waves x UB blocks, all of K; KS = 2: wave&1 = block, wave>>1 = K half
+  const int wblk = KS > 1 ? (wave & 1) : wave * UB;
+  const int kh = KS > 1 ? (wave >> 1) & 1 : 0;
+  const bool lead = (kh == 0);          // the wave that finishes the step for its units
+  bf16x8 wf[UB][KCW][4];
   if (wave < 4)
 #pragma unroll
   for (int ub = 0; ub < UB; ++ub) {
-    const int ublk = (member * 4 + wave) * UB + ub;
+    const int ublk = member * NUB + wblk + ub;
 #pragma unroll
-    for (int kc = 0; kc < KC; ++kc)
+    for (int kc = 0; kc < KCW; ++kc)
 #pragma unroll
       for (int g = 0; g < 4; ++g)
         wf[ub][kc][g] = *reinterpret_cast<const bf16x8*>(wpacked + (int64_t)dir * H * 4 * H +
-                                                          ((int64_t)((ublk * KC + kc) * 4 + g) * 64 + lane) * 8);
+                                                          ((int64_t)((ublk * KC + kh * KCW + kc) * 4 + g) * 64 + lane) * 8);
   }
 
   float c[UB][4], h[UB][4];
@@ -126,7 +137,7 @@ __global__ __launch_bounds__(rec_threads(H)) void lstm_fwd_kernel(float* __restr
 
   const int64_t xrow = (int64_t)ndir * 4 * H;
   const int64_t yrow = (int64_t)ndir * H;
-  const int unit0 = member * HS + wave * (HS / 4) + l15;      // + ub*16
+  const int unit0 = member * HS + wblk * 16 + l15;            // + ub*16
   u64* ex_group = exch + (int64_t)group * G * NGRAN;           // + parity*ngroups*G*NGRAN + member*NGRAN
 
   if constexpr (G > 1) {
@@ -142,13 +153,15 @@ __global__ __launch_bounds__(rec_threads(H)) void lstm_fwd_kernel(float* __restr
           const int ll = __builtin_amdgcn_readlane(mylen, rr);
           if (sp < ll) {
             const int pos = dir == 0 ? sp : ll - 1 - sp;
-            const float* src = xproj + ((int64_t)(slice * 16 + rr) * T + pos) * xrow + dir * 4 * H + member * HS * 4 + lane * 4;
+            const float* src = xproj + ((int64_t)(slice * 16 + rr) * T + pos) * xrow + dir * 4 * H + member * HS * 4 +
+                               (lane % (HS > 64 ? 64 : HS)) * 4;
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src),
                                              (__attribute__((address_space(3))) void*)(pf_scratch), 16, 0, 0);
           }
         }
         __builtin_amdgcn_s_barrier();
         if (*reinterpret_cast<volatile int*>(&fail_flag)) break;
+        if constexpr (KS > 1) __builtin_amdgcn_s_barrier();      // the compute waves' partial-sum hand-off barrier
       }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       return;
@@ -172,7 +185,7 @@ __global__ __launch_bounds__(rec_threads(H)) void lstm_fwd_kernel(float* __restr
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (act[r]) v = *reinterpret_cast<const float4*>(xproj + rowoff[r] * xrow + dir * 4 * H + (unit0 + ub * 16) * 4);
+        if (act[r] && lead) v = *reinterpret_cast<const float4*>(xproj + rowoff[r] * xrow + dir * 4 * H + (unit0 + ub * 16) * 4);
         xp[0][ub][r] = v.x; xp[1][ub][r] = v.y; xp[2][ub][r] = v.z; xp[3][ub][r] = v.w;
       }
 
@@ -180,33 +193,37 @@ __global__ __launch_bounds__(rec_threads(H)) void lstm_fwd_kernel(float* __restr
     if constexpr (G > 1) if (s > 0) {
       const u64* src = ex_group + (int64_t)((s - 1) & 1) * ngroups * G * NGRAN;
       constexpr int PER = (G - 1) * NGRAN / 256;     // granules per thread
-      u64 v[PER];
-      unsigned spins = 0;
-      bool ok;
-      do {
-        ok = true;
+      constexpr int CH = PER > 6 ? 5 : PER;          // per polling round (bounds the registers held)
+      static_assert(PER % CH == 0, "sweep chunking");
+      for (int c0 = 0; c0 < PER; c0 += CH) {
+        u64 v[CH];
+        unsigned spins = 0;
+        bool ok;
+        do {
+          ok = true;
 #pragma unroll
-        for (int i = 0; i < PER; ++i) {
-          const int q = tid + i * 256;
+          for (int i = 0; i < CH; ++i) {
+            const int q = tid + (c0 + i) * 256;
+            const int pi = q / NGRAN, gi = q % NGRAN;
+            const int peer = pi + (pi >= member ? 1 : 0);
+            v[i] = granule_load(src + (int64_t)peer * NGRAN + gi);
+            ok = ok && ((unsigned)(v[i] >> 32) == (unsigned)s);
+          }
+          if (!ok) {
+            if (++spins > SPIN_LIMIT) { fail_flag = 1; break; }
+            __builtin_amdgcn_s_sleep(1);
+          }
+        } while (!ok);
+#pragma unroll
+        for (int i = 0; i < CH; ++i) {
+          const int q = tid + (c0 + i) * 256;
           const int pi = q / NGRAN, gi = q % NGRAN;
           const int peer = pi + (pi >= member ? 1 : 0);
-          v[i] = granule_load(src + (int64_t)peer * NGRAN + gi);
-          ok = ok && ((unsigned)(v[i] >> 32) == (unsigned)s);
+          const int rp = gi / HS, ul = gi % HS;
+          const unsigned val = (unsigned)v[i];
+          hlds[cur][rp * 2][peer * HS + ul] = (unsigned short)(val & 0xffffu);
+          hlds[cur][rp * 2 + 1][peer * HS + ul] = (unsigned short)(val >> 16);
         }
-        if (!ok) {
-          if (++spins > SPIN_LIMIT) { fail_flag = 1; break; }
-          __builtin_amdgcn_s_sleep(1);
-        }
-      } while (!ok);
-#pragma unroll
-      for (int i = 0; i < PER; ++i) {
-        const int q = tid + i * 256;
-        const int pi = q / NGRAN, gi = q % NGRAN;
-        const int peer = pi + (pi >= member ? 1 : 0);
-        const int rp = gi / HS, ul = gi % HS;
-        const unsigned val = (unsigned)v[i];
-        hlds[cur][rp * 2][peer * HS + ul] = (unsigned short)(val & 0xffffu);
-        hlds[cur][rp * 2 + 1][peer * HS + ul] = (unsigned short)(val >> 16);
       }
     }
     __syncthreads();
@@ -218,13 +235,27 @@ __global__ __launch_bounds__(rec_threads(H)) void lstm_fwd_kernel(float* __restr
 #pragma unroll
       for (int ub = 0; ub < UB; ++ub) acc[g][ub] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int kc = 0; kc < KC; ++kc) {
-      const bf16x8 a = *reinterpret_cast<const bf16x8*>(&hlds[cur][l15][kc * 32 + 8 * lq]);
+    for (int kc = 0; kc < KCW; ++kc) {
+      const bf16x8 a = *reinterpret_cast<const bf16x8*>(&hlds[cur][l15][(kh * KCW + kc) * 32 + 8 * lq]);
 #pragma unroll
       for (int ub = 0; ub < UB; ++ub)
 #pragma unroll
         for (int g = 0; g < 4; ++g) acc[g][ub] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, wf[ub][kc][g], acc[g][ub], 0, 0, 0);
     }
+    if constexpr (KS > 1) {
+      // the upper-K wave hands its partial sums to the lead wave of the same unit block through LDS
+      f32x4* rbuf = reinterpret_cast<f32x4*>(red);
+      if (!lead) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) rbuf[((wave & 1) * 4 + g) * 64 + lane] = acc[g][0];
+      }
+      __syncthreads();
+      if (lead) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) acc[g][0] += rbuf[((wave & 1) * 4 + g) * 64 + lane];
+      }
+    }
+    if (lead) {
 
     u64* dst = ex_group + (int64_t)(s & 1) * ngroups * G * NGRAN + (int64_t)member * NGRAN;
 #pragma unroll
@@ -255,6 +286,7 @@ __global__ __launch_bounds__(rec_threads(H)) void lstm_fwd_kernel(float* __restr
         granule_store(dst + (lq * 2 + 1) * HS + ul, (unsigned)(s + 1), (unsigned)hb[2] | ((unsigned)hb[3] << 16));
       }
     }
+    }   // lead
     cur ^= 1;
   }
 
@@ -266,7 +298,7 @@ __global__ __launch_bounds__(rec_threads(H)) void lstm_fwd_kernel(float* __restr
   for (int ub = 0; ub < UB; ++ub)
 #pragma unroll
     for (int r = 0; r < 4; ++r)
-      if (bidx[r] < B) {
+      if (bidx[r] < B && lead) {
         const int64_t o = ((int64_t)dir * B + bidx[r]) * H + unit0 + ub * 16;
         c_last[o] = c[ub][r];
         h_last[o] = h[ub][r];
@@ -285,13 +317,17 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_kernel(const float* __restric
                                                           int B, int T, int ndir, int ngroups) {
   constexpr int G = coop_members(H);
   constexpr int HS = H / G;
-  constexpr int UB = HS / 64;
+  constexpr int KS = k_split(H);
+  constexpr int NUB = HS / 16;
+  constexpr int UB = (NUB * KS) / 4 > 0 ? (NUB * KS) / 4 : 1;
   constexpr int KC = (4 * H) / 32;
+  constexpr int KCW = KC / KS;
   constexpr int ZS = 4 * H + 8;
   constexpr int NGRAN = 8 * 4 * HS;    // granules per member per step: 8 row pairs x 4 gates x HS units
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned short* dzl = reinterpret_cast<unsigned short*>(smem);   // [2][16][ZS]
   int& fail_flag = *reinterpret_cast<int*>(smem + (size_t)2 * 16 * ZS * sizeof(unsigned short));   // keeps the dynamic base 16-B aligned
+  f32x4* rbuf = reinterpret_cast<f32x4*>(smem + (size_t)2 * 16 * ZS * sizeof(unsigned short) + 16);   // [2][64] (KS > 1)
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int group = blockIdx.x % ngroups, member = blockIdx.x / ngroups;
@@ -309,22 +345,25 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_kernel(const float* __restric
   }
   smax = (int)las_wave_max((float)smax);
 
-  const int unit0 = member * HS + wave * (HS / 4) + l15;
+  const int wblk = KS > 1 ? (wave & 1) : wave * UB;
+  const int khalf = KS > 1 ? (wave >> 1) & 1 : 0;
+  const bool lead = (khalf == 0);
+  const int unit0 = member * HS + wblk * 16 + l15;
   const unsigned short* khd = kh + (int64_t)dir * H * 4 * H;
   // register-resident B fragments: B[k][n] = K_h[n = unit][k = gate column]  (natural rows of K_h)
-  bf16x8 wf[UB][KC];
+  bf16x8 wf[UB][KCW];
 #pragma unroll
   for (int ub = 0; ub < UB; ++ub)
 #pragma unroll
-    for (int kc = 0; kc < KC; ++kc)
-      wf[ub][kc] = *reinterpret_cast<const bf16x8*>(khd + (int64_t)(unit0 + ub * 16) * 4 * H + kc * 32 + 8 * lq);
+    for (int kc = 0; kc < KCW; ++kc)
+      wf[ub][kc] = *reinterpret_cast<const bf16x8*>(khd + (int64_t)(unit0 + ub * 16) * 4 * H + (khalf * KCW + kc) * 32 + 8 * lq);
 
   float dc[UB][4], dh[UB][4];
 #pragma unroll
   for (int ub = 0; ub < UB; ++ub)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const bool ok = bidx[r] < B;
+      const bool ok = bidx[r] < B && lead;
       const int64_t o = ((int64_t)dir * B + (ok ? bidx[r] : 0)) * H + unit0 + ub * 16;
       dc[ub][r] = (ok && dc_last) ? dc_last[o] : 0.f;
       dh[ub][r] = (ok && dh_last) ? dh_last[o] : 0.f;
@@ -345,7 +384,7 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_kernel(const float* __restric
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         Saved v{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        if (s >= 0 && s < len[r]) {
+        if (s >= 0 && s < len[r] && lead) {
           const int pos = dir == 0 ? s : len[r] - 1 - s;
           const int64_t ro = (int64_t)bidx[r] * T + pos;
           const float4 gv = *reinterpret_cast<const float4*>(gates + ro * grow + dir * 4 * H + unit * 4);
@@ -370,6 +409,7 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_kernel(const float* __restric
     ++epoch;
     unsigned short* zl = dzl + cur * 16 * ZS;
     u64* dst = ex_group + (int64_t)(epoch & 1) * ngroups * G * NGRAN + (int64_t)member * NGRAN;
+    if (lead)
 #pragma unroll
     for (int ub = 0; ub < UB; ++ub) {
       const int unit = unit0 + ub * 16;
@@ -454,16 +494,21 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_kernel(const float* __restric
 #pragma unroll
     for (int ub = 0; ub < UB; ++ub) acc[ub] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int kc = 0; kc < KC; ++kc) {
-      const bf16x8 a = *reinterpret_cast<const bf16x8*>(zl + l15 * ZS + kc * 32 + 8 * lq);
+    for (int kc = 0; kc < KCW; ++kc) {
+      const bf16x8 a = *reinterpret_cast<const bf16x8*>(zl + l15 * ZS + (khalf * KCW + kc) * 32 + 8 * lq);
 #pragma unroll
       for (int ub = 0; ub < UB; ++ub) acc[ub] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, wf[ub][kc], acc[ub], 0, 0, 0);
+    }
+    if constexpr (KS > 1) {
+      if (!lead) rbuf[(wave & 1) * 64 + lane] = acc[0];
+      __syncthreads();
+      if (lead) acc[0] += rbuf[(wave & 1) * 64 + lane];
     }
 #pragma unroll
     for (int ub = 0; ub < UB; ++ub)
 #pragma unroll
       for (int r = 0; r < 4; ++r)
-        if (s < len[r]) dh[ub][r] = acc[ub][r];
+        if (s < len[r] && lead) dh[ub][r] = acc[ub][r];
     cur ^= 1;
   }
   if (fail_flag && tid == 0) atomicOr(status, 2u);
@@ -500,7 +545,7 @@ int launch_bwd(const float* gates, const float* cbuf, const float* dy, const flo
   const CoopGeom g = geom(B, H, ndir, true);
   unsigned* status = reinterpret_cast<unsigned*>(ws);
   u64* exch = reinterpret_cast<u64*>(reinterpret_cast<char*>(ws) + 64);
-  const size_t lds = (size_t)2 * 16 * (4 * H + 8) * sizeof(unsigned short) + 16;
+  const size_t lds = (size_t)2 * 16 * (4 * H + 8) * sizeof(unsigned short) + 16 + 2 * 64 * 16;
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&lstm_bwd_kernel<H>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -512,7 +557,7 @@ int launch_bwd(const float* gates, const float* cbuf, const float* dy, const flo
   return LAS_OK;
 }
 
-bool supported_units(int H) { return H == 64 || H == 128 || H == 256; }
+bool supported_units(int H) { return H == 64 || H == 128 || H == 256 || H == 512; }
 
 }  // namespace
 
@@ -522,7 +567,7 @@ extern "C" size_t las_lstm_workspace_bytes(int B, int H, int ndir) {
 }
 
 extern "C" int las_lstm_pack_recurrent(const float* kernel_h, int H, las_bf16* packed, void* stream) {
-  LAS_REQUIRE(supported_units(H), "las_lstm_pack_recurrent: num_units must be 64, 128 or 256 (got %d)", H);
+  LAS_REQUIRE(supported_units(H), "las_lstm_pack_recurrent: num_units must be 64, 128, 256 or 512 (got %d)", H);
   hipLaunchKernelGGL(pack_recurrent_kernel, dim3(256), dim3(256), 0, (hipStream_t)stream, kernel_h, H, packed);
   LAS_LAUNCH_CHECK("pack launch");
   return LAS_OK;
@@ -532,7 +577,7 @@ extern "C" int las_lstm_recurrent_fwd(float* xproj, const las_bf16* wpacked, con
                                       float* cbuf, float* c_last, float* h_last, void* workspace, int B, int T, int H,
                                       int ndir, void* stream) {
   LAS_REQUIRE(B > 0 && T > 0 && (ndir == 1 || ndir == 2), "las_lstm_recurrent_fwd: bad shape B=%d T=%d ndir=%d", B, T, ndir);
-  LAS_REQUIRE(supported_units(H), "las_lstm_recurrent_fwd: num_units %d not in {64,128,256}", H);
+  LAS_REQUIRE(supported_units(H), "las_lstm_recurrent_fwd: num_units %d not in {64,128,256,512}", H);
   LAS_REQUIRE(workspace != nullptr && ((uintptr_t)workspace % 16 == 0), "las_lstm_recurrent_fwd: workspace missing or misaligned");
   hipStream_t st = (hipStream_t)stream;
   int rc = las_check_hip(hipMemsetAsync(y, 0, (size_t)B * T * ndir * H * sizeof(las_bf16), st), "memset y");
@@ -542,6 +587,7 @@ extern "C" int las_lstm_recurrent_fwd(float* xproj, const las_bf16* wpacked, con
   switch (H) {
     case 64: return launch_fwd<64>(xproj, wpacked, length, y, cbuf, c_last, h_last, workspace, B, T, ndir, st);
     case 128: return launch_fwd<128>(xproj, wpacked, length, y, cbuf, c_last, h_last, workspace, B, T, ndir, st);
+    case 512: return launch_fwd<512>(xproj, wpacked, length, y, cbuf, c_last, h_last, workspace, B, T, ndir, st);
     default: return launch_fwd<256>(xproj, wpacked, length, y, cbuf, c_last, h_last, workspace, B, T, ndir, st);
   }
 }
@@ -550,7 +596,7 @@ extern "C" int las_lstm_recurrent_bwd(const float* gates, const float* cbuf, con
                                       const float* dh_last, const las_bf16* kh_bf16, const int32_t* length,
                                       las_bf16* dz, void* workspace, int B, int T, int H, int ndir, void* stream) {
   LAS_REQUIRE(B > 0 && T > 0 && (ndir == 1 || ndir == 2), "las_lstm_recurrent_bwd: bad shape");
-  LAS_REQUIRE(supported_units(H), "las_lstm_recurrent_bwd: num_units %d not in {64,128,256}", H);
+  LAS_REQUIRE(supported_units(H), "las_lstm_recurrent_bwd: num_units %d not in {64,128,256,512}", H);
   LAS_REQUIRE(workspace != nullptr && ((uintptr_t)workspace % 16 == 0), "las_lstm_recurrent_bwd: workspace missing or misaligned");
   hipStream_t st = (hipStream_t)stream;
   int rc = las_check_hip(hipMemsetAsync(dz, 0, (size_t)B * T * ndir * 4 * H * sizeof(las_bf16), st), "memset dz");
@@ -560,6 +606,7 @@ extern "C" int las_lstm_recurrent_bwd(const float* gates, const float* cbuf, con
   switch (H) {
     case 64: return launch_bwd<64>(gates, cbuf, dy, dc_last, dh_last, kh_bf16, length, dz, workspace, B, T, ndir, st);
     case 128: return launch_bwd<128>(gates, cbuf, dy, dc_last, dh_last, kh_bf16, length, dz, workspace, B, T, ndir, st);
+    case 512: return launch_bwd<512>(gates, cbuf, dy, dc_last, dh_last, kh_bf16, length, dz, workspace, B, T, ndir, st);
     default: return launch_bwd<256>(gates, cbuf, dy, dc_last, dh_last, kh_bf16, length, dz, workspace, B, T, ndir, st);
   }
 }

@@ -28,8 +28,8 @@ def lstm_cell(num_units, dropout, mode):
     dropout = dropout if mode == TRAIN else 0.0
     if not 0.0 <= dropout < 1.0:
         raise ValueError('dropout must be in [0, 1)')
-    if num_units not in (64, 128, 256):
-        raise ValueError('num_units must be one of 64, 128, 256 on the HIP path (got %d)' % num_units)
+    if num_units not in (64, 128, 256, 512):
+        raise ValueError('num_units must be one of 64, 128, 256, 512 on the HIP path (got %d)' % num_units)
     return LSTMCellSpec(num_units, 1.0 - dropout)
 
 

@@ -37,6 +37,7 @@ def _relerr(got, ref):
     (17, 12, 40, 128, [12, 1, 5, 12, 3, 9, 2, 11, 6, 8, 10, 4, 12, 7, 1, 12, 5]),
     (2, 6, 64, 256, [6, 3]),
     (21, 40, 32, 256, [40, 3, 17, 40, 1, 25, 8, 33, 12, 40, 5, 29, 2, 38, 9, 21, 40, 7, 31, 15, 36]),
+    (19, 14, 24, 512, [14, 3, 9, 14, 1, 7, 12, 5, 14, 2, 11, 6, 13, 4, 10, 8, 14, 1, 9]),
 ])
 def test_bilstm_forward_backward_vs_oracle(B, T, D, H, lengths):
     from oracle import las_oracle as O

@@ -214,3 +214,25 @@ def test_ctc_multitask_train_step_vs_oracle():
     for name, _, _ in model.vars.table:
         g = out['grads'][name] - ohp.l2_reg_scale * op[name]
         assert relerr(model.vars.grads[name], g) < 6e-2, name
+
+
+def test_cfg3_like_512_units_bahdanau_ctc_vs_oracle():
+    # BASELINE configs[2]/[3] in miniature: 512-unit pyramidal listener (16 cooperating workgroups per chain,
+    # K split over wave pairs), Bahdanau attention, CTC multitask head
+    O, ohp, op, model = _models('bahdanau', H=512, L=2, F=16, ctc=0.2)
+    batch = make_batch(F=16, src_len=[12, 7, 10], tgt_len=[3, 2, 3], U=3)
+    feats, labels = to_device(batch)
+    out = O.train_step(ohp, op, None, None, 1, batch, mxu='bf16')
+    model.vars.grad.zero_()
+    loss, logits, dlogits = model.forward_train(feats, labels)
+    model.backward(dlogits)
+    torch.cuda.synchronize()
+    from phones_las_amd.las import ops
+    ops.check_lstm_status(3, 512, 2)
+    V = ohp.decoder.target_vocab_size
+    for b, n in enumerate([3, 2, 3]):
+        assert relerr(logits[b, :n, :V], out['aux']['logits'][b, :n]) < 2e-2
+    assert abs(float(loss) - float(out['audio_loss'])) < 2e-2 * float(out['audio_loss'])
+    for name, _, _ in model.vars.table:
+        g = out['grads'][name] - ohp.l2_reg_scale * op[name]
+        assert relerr(model.vars.grads[name], g) < 6e-2, name
