@@ -291,6 +291,29 @@ int las_adam_update(float* params, float* m, float* v, const float* grads, int64
 /* *counter += delta on the stream (tf.train.get_global_step increment, model_helper.py:417). */
 int las_counter_add(int32_t* counter, int32_t delta, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Acoustic front-end (fp32, table driven): preprocess_all.py:69-130 (librosa) and
+ * utils/features_utils.py:5-20 (tf.contrib.signal).  Tables (window, DFT twiddles [n_fft,bins], filterbank /
+ * DCT matrices [K,N], Savitzky-Golay taps and edge matrices) are built on the host.
+ * ---------------------------------------------------------------------------------------- */
+/* out[f,k] = |sum_n window[n] x[f*hop + n - pad]  e^{-2 pi i k n / n_fft}|^power, pad = n_fft/2 reflect if center. */
+int las_fe_stft(const float* wave, int num_samples, int n_fft, int hop, int center, int power, const float* window,
+                const float* costab, const float* sintab, int bins, float* out, int64_t ldo, int frames,
+                void* stream);
+/* C[M,N] = epilogue(A[M,K] W[K,N]); epilogue 0: none, 1: log(x + eps), 2: 10 log10(max(x, eps)). */
+int las_fe_matmul(const float* A, int64_t lda, const float* W, int64_t ldw, float* C, int64_t ldc, int M, int N,
+                  int K, int epilogue, float eps, void* stream);
+/* x = max(x, max(x) - top_db) over the whole [rows, cols] window (librosa power_to_db top_db); scratch: 1 float. */
+int las_fe_top_db(float* x, int64_t ldx, int rows, int cols, float top_db, float* scratch, void* stream);
+/* out[f*ldo] = sqrt(mean(frame_f^2)) with centred reflect-padded frames (librosa.feature.rms). */
+int las_fe_rms(const float* wave, int num_samples, int frame_length, int hop, float* out, int64_t ldo, int frames,
+               void* stream);
+/* out[t, c*out_stride + out_offset] = Savitzky-Golay derivative of x[:, c] along t (mode 'interp'); taps == NULL
+ * copies x instead (used to interleave [c, dc, ddc] as preprocess_all.py:127-129 does). */
+int las_fe_delta(const float* x, int64_t ldx, int T, int F, const float* taps, const float* edge_lo,
+                 const float* edge_hi, int width, float* out, int64_t ldo, int out_stride, int out_offset,
+                 void* stream);
+
 /* Host-side CRC-32C (Castagnoli) of a buffer: the checksum of the TFRecord framing the reference's data
  * files use (preprocess_all.py:164-167 tf.io.TFRecordWriter; utils/dataset_utils.py:157 TFRecordDataset). */
 uint32_t las_crc32c(const void* data, size_t n);

@@ -1,0 +1,186 @@
+// Acoustic front-end kernels (fp32): framing + window + DFT, filterbank / DCT products, dB compression, RMS energy
+// and Savitzky-Golay deltas — the device side of preprocess_all.py:69-130 (librosa semantics) and of
+// utils/features_utils.py:5-20 (tf.contrib.signal semantics).  The transforms are table driven (window, DFT
+// twiddles, mel basis, DCT basis, Savitzky-Golay taps are built on the host in float64 and passed as fp32), so one
+// set of kernels serves both pipelines.  This is offline, HBM-light work: one workgroup per frame / row, coalesced
+// table reads, no attempt to reach MFMA (log-mel needs more than bf16 operands).
+#include "las_common.h"
+
+namespace {
+
+// out[f, k] = | sum_n w[n] x[f*hop + n - pad] e^{-2 pi i k n / n_fft} | ^ power      (power = 1 or 2)
+__global__ __launch_bounds__(256) void stft_kernel(const float* __restrict__ wave, int N, int n_fft, int hop, int pad,
+                                                   const float* __restrict__ window, const float* __restrict__ costab,
+                                                   const float* __restrict__ sintab, int bins, int power,
+                                                   float* __restrict__ out, int64_t ldo) {
+  extern __shared__ float fr[];
+  const int f = blockIdx.x;
+  for (int n = threadIdx.x; n < n_fft; n += 256) {
+    int i = f * hop + n - pad;
+    if (pad > 0) {                       // np.pad(mode='reflect')
+      if (i < 0) i = -i;
+      if (i >= N) i = 2 * (N - 1) - i;
+    }
+    fr[n] = (i >= 0 && i < N) ? wave[i] * window[n] : 0.f;
+  }
+  __syncthreads();
+  for (int k = threadIdx.x; k < bins; k += 256) {
+    float re = 0.f, im = 0.f;
+    for (int n = 0; n < n_fft; ++n) {
+      const float v = fr[n];
+      re += v * costab[(int64_t)n * bins + k];
+      im += v * sintab[(int64_t)n * bins + k];
+    }
+    const float p2 = re * re + im * im;
+    out[(int64_t)f * ldo + k] = power == 2 ? p2 : sqrtf(p2);
+  }
+}
+
+// C[m, n] = epi(sum_k A[m, k] W[k, n]);  epi 0: id, 1: log(x + eps), 2: 10 log10(max(x, eps))
+__global__ __launch_bounds__(256) void matmul_kernel(const float* __restrict__ A, int64_t lda, const float* __restrict__ W,
+                                                     int64_t ldw, float* __restrict__ C, int64_t ldc, int M, int N, int K,
+                                                     int epi, float eps) {
+  extern __shared__ float row[];
+  const int m = blockIdx.x;
+  for (int k = threadIdx.x; k < K; k += 256) row[k] = A[(int64_t)m * lda + k];
+  __syncthreads();
+  for (int n = threadIdx.x; n < N; n += 256) {
+    float acc = 0.f;
+    for (int k = 0; k < K; ++k) acc += row[k] * W[(int64_t)k * ldw + n];
+    if (epi == 1) acc = logf(acc + eps);
+    else if (epi == 2) acc = 10.0f * log10f(fmaxf(acc, eps));
+    C[(int64_t)m * ldc + n] = acc;
+  }
+}
+
+__device__ __forceinline__ void atomic_max_float(float* addr, float v) {
+  // order-preserving integer trick (works for mixed signs)
+  if (v >= 0.f) atomicMax(reinterpret_cast<int*>(addr), __float_as_int(v));
+  else atomicMin(reinterpret_cast<unsigned*>(addr), __float_as_uint(v));
+}
+
+__global__ void max_kernel(const float* x, int64_t ldx, int rows, int cols, float* out) {
+  float m = -INFINITY;
+  const int64_t total = (int64_t)rows * cols;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x)
+    m = fmaxf(m, x[(i / cols) * ldx + (i % cols)]);
+  m = las_wave_max(m);
+  if ((threadIdx.x & 63) == 0) atomic_max_float(out, m);
+}
+
+__global__ void floor_kernel(float* x, int64_t ldx, int rows, int cols, const float* mx, float top_db) {
+  const float lo = *mx - top_db;
+  const int64_t total = (int64_t)rows * cols;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    float* p = x + (i / cols) * ldx + (i % cols);
+    *p = fmaxf(*p, lo);
+  }
+}
+
+// librosa.feature.rms(center=True): sqrt(mean(frame^2)), reflect padded
+__global__ __launch_bounds__(256) void rms_kernel(const float* wave, int N, int frame_length, int hop, int pad, float* out,
+                                                  int64_t ldo) {
+  __shared__ float red[4];
+  const int f = blockIdx.x;
+  float acc = 0.f;
+  for (int n = threadIdx.x; n < frame_length; n += 256) {
+    int i = f * hop + n - pad;
+    if (i < 0) i = -i;
+    if (i >= N) i = 2 * (N - 1) - i;
+    const float v = (i >= 0 && i < N) ? wave[i] : 0.f;
+    acc += v * v;
+  }
+  acc = las_wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) out[(int64_t)f * ldo] = sqrtf((red[0] + red[1] + red[2] + red[3]) / frame_length);
+}
+
+// Savitzky-Golay derivative along time (scipy.signal.savgol_filter(mode='interp')): interior = correlation with
+// `taps[width]`; the first/last `half` rows use the edge matrices [half, width] applied to the first/last window.
+__global__ void delta_kernel(const float* x, int64_t ldx, int T, int F, const float* taps, const float* edge_lo,
+                             const float* edge_hi, int width, float* out, int64_t ldo, int out_stride, int out_offset) {
+  const int half = width / 2;
+  const int64_t total = (int64_t)T * F;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int t = (int)(i / F), c = (int)(i % F);
+    float acc = 0.f;
+    if (t < half) {
+      for (int j = 0; j < width; ++j) acc += edge_lo[t * width + j] * x[(int64_t)j * ldx + c];
+    } else if (t >= T - half) {
+      const int r = t - (T - half);
+      for (int j = 0; j < width; ++j) acc += edge_hi[r * width + j] * x[(int64_t)(T - width + j) * ldx + c];
+    } else {
+      for (int j = 0; j < width; ++j) acc += taps[j] * x[(int64_t)(t - half + j) * ldx + c];
+    }
+    out[(int64_t)t * ldo + c * out_stride + out_offset] = acc;
+  }
+}
+
+__global__ void copy_strided_kernel(const float* x, int64_t ldx, int T, int F, float* out, int64_t ldo, int out_stride,
+                                    int out_offset) {
+  const int64_t total = (int64_t)T * F;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x)
+    out[(i / F) * ldo + (i % F) * out_stride + out_offset] = x[(i / F) * ldx + (i % F)];
+}
+
+int nblocks(int64_t n) { int64_t b = (n + 255) / 256; return (int)(b > 1024 ? 1024 : (b < 1 ? 1 : b)); }
+
+}  // namespace
+
+extern "C" int las_fe_stft(const float* wave, int num_samples, int n_fft, int hop, int center, int power,
+                           const float* window, const float* costab, const float* sintab, int bins, float* out, int64_t ldo,
+                           int frames, void* stream) {
+  LAS_REQUIRE(num_samples > 0 && n_fft > 0 && hop > 0 && frames > 0 && bins > 0 && (power == 1 || power == 2) && n_fft <= 8192,
+              "las_fe_stft: bad arguments");
+  hipLaunchKernelGGL(stft_kernel, dim3(frames), dim3(256), n_fft * sizeof(float), (hipStream_t)stream, wave, num_samples, n_fft,
+                     hop, center ? n_fft / 2 : 0, window, costab, sintab, bins, power, out, ldo);
+  LAS_LAUNCH_CHECK("stft launch");
+  return LAS_OK;
+}
+
+extern "C" int las_fe_matmul(const float* A, int64_t lda, const float* W, int64_t ldw, float* C, int64_t ldc, int M, int N,
+                             int K, int epilogue, float eps, void* stream) {
+  LAS_REQUIRE(M > 0 && N > 0 && K > 0 && K <= 8192, "las_fe_matmul: bad shape");
+  hipLaunchKernelGGL(matmul_kernel, dim3(M), dim3(256), K * sizeof(float), (hipStream_t)stream, A, lda, W, ldw, C, ldc, M, N, K,
+                     epilogue, eps);
+  LAS_LAUNCH_CHECK("fe matmul launch");
+  return LAS_OK;
+}
+
+extern "C" int las_fe_top_db(float* x, int64_t ldx, int rows, int cols, float top_db, float* scratch, void* stream) {
+  LAS_REQUIRE(rows > 0 && cols > 0, "las_fe_top_db: bad shape");
+  hipStream_t st = (hipStream_t)stream;
+  const float ninf = -INFINITY;
+  int rc = las_check_hip(hipMemcpyAsync(scratch, &ninf, sizeof(float), hipMemcpyHostToDevice, st), "init max");
+  if (rc) return rc;
+  hipLaunchKernelGGL(max_kernel, dim3(nblocks((int64_t)rows * cols)), dim3(256), 0, st, x, ldx, rows, cols, scratch);
+  hipLaunchKernelGGL(floor_kernel, dim3(nblocks((int64_t)rows * cols)), dim3(256), 0, st, x, ldx, rows, cols, scratch, top_db);
+  LAS_LAUNCH_CHECK("top_db launch");
+  return LAS_OK;
+}
+
+extern "C" int las_fe_rms(const float* wave, int num_samples, int frame_length, int hop, float* out, int64_t ldo, int frames,
+                          void* stream) {
+  LAS_REQUIRE(num_samples > 0 && frame_length > 0 && hop > 0 && frames > 0, "las_fe_rms: bad arguments");
+  hipLaunchKernelGGL(rms_kernel, dim3(frames), dim3(256), 0, (hipStream_t)stream, wave, num_samples, frame_length, hop,
+                     frame_length / 2, out, ldo);
+  LAS_LAUNCH_CHECK("rms launch");
+  return LAS_OK;
+}
+
+extern "C" int las_fe_delta(const float* x, int64_t ldx, int T, int F, const float* taps, const float* edge_lo,
+                            const float* edge_hi, int width, float* out, int64_t ldo, int out_stride, int out_offset,
+                            void* stream) {
+  LAS_REQUIRE(T >= width && F > 0 && width > 0 && (width & 1), "las_fe_delta: need T >= width (odd)");
+  hipStream_t st = (hipStream_t)stream;
+  if (taps) {
+    hipLaunchKernelGGL(delta_kernel, dim3(nblocks((int64_t)T * F)), dim3(256), 0, st, x, ldx, T, F, taps, edge_lo, edge_hi, width,
+                       out, ldo, out_stride, out_offset);
+  } else {
+    hipLaunchKernelGGL(copy_strided_kernel, dim3(nblocks((int64_t)T * F)), dim3(256), 0, st, x, ldx, T, F, out, ldo, out_stride,
+                       out_offset);
+  }
+  LAS_LAUNCH_CHECK("delta launch");
+  return LAS_OK;
+}

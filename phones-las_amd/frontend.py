@@ -1,0 +1,191 @@
+"""Acoustic front-end on the GPU, mirroring the reference's two entry points:
+
+  * ``calculate_acoustic_features(args, waveform)`` — preprocess_all.py:69-130 with ``--backend librosa``
+    (feature_type mfcc | mfe, --n_mfcc, --n_mels, --window, --step, --energy, --deltas);
+  * ``calculate_mfcc_op(sample_rate, coeffs, window, step, mels)`` — utils/features_utils.py:5-20.
+
+The signal-processing tables (periodic Hann window, DFT twiddles, Slaney / HTK mel bases, DCT-II basis,
+Savitzky-Golay taps) are built here in float64 and handed to the table-driven kernels of csrc/frontend.hip.
+The speechpy backend, the lyon cochlear model and audio decoding are out of scope."""
+import functools
+
+import numpy as np
+import torch
+
+from . import hip
+
+SAMPLE_RATE = 16000
+__all__ = ['calculate_acoustic_features', 'calculate_mfcc_op', 'SAMPLE_RATE']
+
+
+# ---- tables (float64 on the host) -------------------------------------------------------------------------------------
+def _hann_periodic(n):
+    return 0.5 - 0.5 * np.cos(2.0 * np.pi * np.arange(n) / n)
+
+
+def _twiddles(n_fft):
+    bins = n_fft // 2 + 1
+    ang = 2.0 * np.pi * np.outer(np.arange(n_fft), np.arange(bins)) / n_fft
+    return np.cos(ang), -np.sin(ang)
+
+
+def _slaney_hz_to_mel(f):
+    f = np.asarray(f, dtype=np.float64)
+    f_sp, brk, step = 200.0 / 3, 1000.0, np.log(6.4) / 27.0
+    return np.where(f >= brk, brk / f_sp + np.log(np.maximum(f, 1e-10) / brk) / step, f / f_sp)
+
+
+def _slaney_mel_to_hz(m):
+    m = np.asarray(m, dtype=np.float64)
+    f_sp, brk, step = 200.0 / 3, 1000.0, np.log(6.4) / 27.0
+    return np.where(m >= brk / f_sp, brk * np.exp(step * (m - brk / f_sp)), f_sp * m)
+
+
+def _mel_basis_slaney(n_mels, n_fft, sr):
+    """librosa.filters.mel defaults (Slaney scale, fmin 0, fmax sr/2, area normalised), returned as [bins, n_mels]."""
+    freqs = np.linspace(0, sr / 2.0, 1 + n_fft // 2)
+    pts = _slaney_mel_to_hz(np.linspace(_slaney_hz_to_mel(0.0), _slaney_hz_to_mel(sr / 2.0), n_mels + 2))
+    w = np.zeros((1 + n_fft // 2, n_mels))
+    for i in range(n_mels):
+        up = (freqs - pts[i]) / (pts[i + 1] - pts[i])
+        down = (pts[i + 2] - freqs) / (pts[i + 2] - pts[i + 1])
+        w[:, i] = np.maximum(0.0, np.minimum(up, down)) * (2.0 / (pts[i + 2] - pts[i]))
+    return w
+
+
+def _mel_basis_htk(n_mels, bins, sr, lo, hi):
+    """tf.contrib.signal.linear_to_mel_weight_matrix: [bins, n_mels], DC row zero, no normalisation."""
+    mel = lambda f: 1127.0 * np.log1p(np.asarray(f, dtype=np.float64) / 700.0)
+    spec = mel(np.linspace(0.0, sr / 2.0, bins)[1:])[:, None]
+    e = np.linspace(mel(lo), mel(hi), n_mels + 2)
+    w = np.maximum(0.0, np.minimum((spec - e[:-2][None]) / (e[1:-1] - e[:-2])[None], (e[2:][None] - spec) / (e[2:] - e[1:-1])[None]))
+    return np.vstack([np.zeros((1, n_mels)), w])
+
+
+def _dct_basis(n_out, n_in, ortho):
+    k, n = np.arange(n_out)[None, :], np.arange(n_in)[:, None]
+    m = 2.0 * np.cos(np.pi * k * (2 * n + 1) / (2.0 * n_in))          # [n_in, n_out]
+    m = m * np.sqrt(1.0 / (2.0 * n_in))
+    if ortho:
+        m[:, 0] *= np.sqrt(0.5)
+    return m
+
+
+def _savgol(width, order):
+    """Interior taps and the two edge matrices of scipy.signal.savgol_filter(deriv=order, polyorder=order, 'interp')."""
+    half = width // 2
+    fact = float(np.prod(np.arange(1, order + 1)))
+    xs = np.arange(-half, half + 1, dtype=np.float64)
+    taps = np.linalg.pinv(np.vander(xs, order + 1, increasing=True))[order] * fact
+    pinv = np.linalg.pinv(np.vander(np.arange(width, dtype=np.float64), order + 1, increasing=True))
+
+    def rows(positions):
+        out = []
+        for p in positions:
+            d = np.zeros(order + 1)
+            for j in range(order, order + 1):
+                d[j] = fact * (p ** (j - order))
+            out.append(d @ pinv)
+        return np.array(out)
+    return taps, rows(range(half)), rows(range(width - half, width))
+
+
+@functools.lru_cache(maxsize=16)
+def _tables(kind, n_fft, n_mels, n_out, sr):
+    dev = 'cuda'
+    t = lambda a: torch.tensor(np.ascontiguousarray(a), dtype=torch.float32, device=dev)
+    cos, sin = _twiddles(n_fft)
+    d = {'window': t(_hann_periodic(n_fft)), 'cos': t(cos), 'sin': t(sin)}
+    if kind == 'librosa':
+        d['mel'] = t(_mel_basis_slaney(n_mels, n_fft, sr))
+        d['dct'] = t(_dct_basis(n_out, n_mels, ortho=True))
+    else:
+        d['mel'] = t(_mel_basis_htk(n_mels, n_fft // 2 + 1, sr, 80.0, 7600.0))
+        d['dct'] = t(_dct_basis(n_mels, n_mels, ortho=False))
+    for order in (1, 2):
+        taps, lo, hi = _savgol(9, order)
+        d['sg%d' % order] = (t(taps), t(lo), t(hi))
+    return d
+
+
+def _as_wave(waveform):
+    w = torch.as_tensor(waveform, dtype=torch.float32)
+    return w.cuda().contiguous() if not w.is_cuda else w.contiguous()
+
+
+def calculate_acoustic_features(args, waveform):
+    """preprocess_all.py:69-130 (librosa backend).  ``args`` needs feature_type, n_mfcc, n_mels, window, step, energy,
+    deltas (backend must be 'librosa').  Returns a CUDA fp32 tensor [T, F]."""
+    if getattr(args, 'backend', 'librosa') != 'librosa':
+        raise ValueError('only --backend librosa is implemented on the HIP path')
+    if args.feature_type not in ('mfcc', 'mfe'):
+        raise ValueError('Unexpected features type.' if args.feature_type != 'lyon' else 'lyon features are out of scope')
+    lib, st = hip.lib(), hip.stream()
+    n_fft = int(args.window * SAMPLE_RATE / 1000.0)
+    hop = int(args.step * SAMPLE_RATE / 1000.0)
+    wave = _as_wave(waveform)
+    N = wave.numel()
+    frames = 1 + N // hop                                  # center=True
+    bins = n_fft // 2 + 1
+    tb = _tables('librosa', n_fft, args.n_mels, args.n_mfcc, SAMPLE_RATE)
+    dev = wave.device
+    spec = torch.empty(frames, bins, device=dev)
+    hip.check(lib.las_fe_stft(hip.p(wave), N, n_fft, hop, 1, 2, hip.p(tb['window']), hip.p(tb['cos']), hip.p(tb['sin']), bins,
+                              hip.p(spec), bins, frames, st))
+    scratch = torch.empty(1, device=dev)
+    mel_db = torch.empty(frames, args.n_mels, device=dev)
+    if args.feature_type == 'mfcc':
+        # power_to_db(S, amin=1e-10, top_db=80) then ortho DCT-II, first n_mfcc
+        hip.check(lib.las_fe_matmul(hip.p(spec), bins, hip.p(tb['mel']), args.n_mels, hip.p(mel_db), args.n_mels, frames,
+                                    args.n_mels, bins, 2, 1e-10, st))
+        hip.check(lib.las_fe_top_db(hip.p(mel_db), args.n_mels, frames, args.n_mels, 80.0, hip.p(scratch), st))
+        base = torch.empty(frames, args.n_mfcc, device=dev)
+        hip.check(lib.las_fe_matmul(hip.p(mel_db), args.n_mels, hip.p(tb['dct']), args.n_mfcc, hip.p(base), args.n_mfcc, frames,
+                                    args.n_mfcc, args.n_mels, 0, 0.0, st))
+    else:
+        # amplitude_to_db applied to the POWER mel spectrogram (the reference's quirk): 20 log10(max(S, 1e-5)), top_db 80
+        hip.check(lib.las_fe_matmul(hip.p(spec), bins, hip.p(tb['mel']), args.n_mels, hip.p(mel_db), args.n_mels, frames,
+                                    args.n_mels, bins, 2, 1e-5, st))
+        mel_db.mul_(2.0)
+        hip.check(lib.las_fe_top_db(hip.p(mel_db), args.n_mels, frames, args.n_mels, 80.0, hip.p(scratch), st))
+        base = mel_db
+    F = base.shape[1]
+    if args.energy:
+        feats = torch.empty(frames, F + 1, device=dev)
+        feats[:, :F] = base
+        hip.check(lib.las_fe_rms(hip.p(wave), N, n_fft, hop, hip.addr(feats, F), F + 1, frames, st))
+        F += 1
+    else:
+        feats = base
+    if args.deltas:
+        out = torch.empty(frames, 3 * F, device=dev)
+        hip.check(lib.las_fe_delta(hip.p(feats), F, frames, F, None, None, None, 9, hip.p(out), 3 * F, 3, 0, st))
+        for order in (1, 2):
+            taps, lo, hi = tb['sg%d' % order]
+            hip.check(lib.las_fe_delta(hip.p(feats), F, frames, F, hip.p(taps), hip.p(lo), hip.p(hi), 9, hip.p(out), 3 * F, 3,
+                                       order, st))
+        feats = out
+    return feats
+
+
+def calculate_mfcc_op(sample_rate, coeffs, window, step, mels):
+    """utils/features_utils.py:5-20: returns ``_mfcc_op(waveform)`` -> CUDA fp32 [frames, coeffs]."""
+    def _mfcc_op(input_tensor):
+        lib, st = hip.lib(), hip.stream()
+        wave = _as_wave(input_tensor)
+        N = wave.numel()
+        frames = 1 + (N - window) // step                  # no centering / padding
+        if frames <= 0:
+            raise ValueError('signal shorter than one window')
+        bins = window // 2 + 1
+        tb = _tables('tf', window, mels, mels, sample_rate)
+        dev = wave.device
+        spec = torch.empty(frames, bins, device=dev)
+        hip.check(lib.las_fe_stft(hip.p(wave), N, window, step, 0, 1, hip.p(tb['window']), hip.p(tb['cos']), hip.p(tb['sin']),
+                                  bins, hip.p(spec), bins, frames, st))
+        logmel = torch.empty(frames, mels, device=dev)
+        hip.check(lib.las_fe_matmul(hip.p(spec), bins, hip.p(tb['mel']), mels, hip.p(logmel), mels, frames, mels, bins, 1, 1e-6, st))
+        out = torch.empty(frames, mels, device=dev)
+        hip.check(lib.las_fe_matmul(hip.p(logmel), mels, hip.p(tb['dct']), mels, hip.p(out), mels, frames, mels, mels, 0, 0.0, st))
+        return out[..., :coeffs]
+    return _mfcc_op

@@ -44,6 +44,11 @@ _SIGS = {
     'las_onehot_bf16': ([_vp, _i64, _i32, _i32, _i32, _vp, _i64, _f32, C.c_uint32, C.c_uint32, _i32, _vp], C.c_int),
     'las_ctc_workspace_bytes': ([_i32, _i32, _i32, _i32], C.c_size_t),
     'las_ctc_loss': ([_vp, _i64, _vp, _i64, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _f32, _f32, _vp, _vp, _vp, _vp, _vp], C.c_int),
+    'las_fe_stft': ([_vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _i32, _vp, _i64, _i32, _vp], C.c_int),
+    'las_fe_matmul': ([_vp, _i64, _vp, _i64, _vp, _i64, _i32, _i32, _i32, _i32, _f32, _vp], C.c_int),
+    'las_fe_top_db': ([_vp, _i64, _i32, _i32, _f32, _vp, _vp], C.c_int),
+    'las_fe_rms': ([_vp, _i32, _i32, _i32, _vp, _i64, _i32, _vp], C.c_int),
+    'las_fe_delta': ([_vp, _i64, _i32, _i32, _vp, _vp, _vp, _i32, _vp, _i64, _i32, _i32, _vp], C.c_int),
     'las_add_noise': ([_vp, _i64, _f32, C.c_uint32, C.c_uint32, _vp], C.c_int),
     'las_sample_tokens': ([_vp, _i64, _i32, _vp, _i64, _vp, _i64, _i32, _f32, C.c_uint32, C.c_uint32, _vp], C.c_int),
 }
