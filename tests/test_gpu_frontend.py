@@ -47,3 +47,29 @@ def test_short_signal_and_unsupported_backend():
         frontend.calculate_mfcc_op(16000, 13, 320, 160, 40)(np.zeros(100, np.float32))
     with pytest.raises(ValueError):
         frontend.calculate_acoustic_features(argparse.Namespace(feature_type='mfcc', backend='speechpy'), np.zeros(4000))
+
+
+def test_preprocess_all_cli_end_to_end(tmp_path):
+    import wave
+    import preprocess_all
+    from phones_las_amd.utils import tfrecord, load_vocab, load_normalization
+    d = str(tmp_path)
+    lines = []
+    for i in range(3):
+        y = (_audio(8000 + 1600 * i, i) * 32767 * 0.5).astype('<i2')
+        p = '%s/a%d.wav' % (d, i)
+        with wave.open(p, 'wb') as w:
+            w.setnchannels(1); w.setsampwidth(2); w.setframerate(16000); w.writeframes(y.tobytes())
+        lines.append('%s,arpabet,%s' % (p, ['hh ah l ow', 'w er l d', 'ah ah'][i]))
+    lines.append('%s/missing.wav,arpabet,x y' % d)                      # skipped like the reference does
+    open(d + '/list.csv', 'w').write('\n'.join(lines) + '\n')
+    n = preprocess_all.main(preprocess_all.parse_args(['--input_file', d + '/list.csv', '--output_file', d + '/train.tfr',
+                                                       '--targets', 'phones', '--deltas', '--energy', '--save_norm',
+                                                       '--save_vocab']))
+    assert n == 3
+    recs = [tfrecord.parse_sequence_example(r, 42) for r in tfrecord.tf_record_iterator(d + '/train.tfr', verify=True)]
+    assert [x.shape for x, _ in recs] == [(51, 42), (61, 42), (71, 42)]
+    assert recs[0][1] == ['hh', 'ah', 'l', 'ow']
+    assert load_vocab(d + '/vocab.txt')[3] == 'ah'                      # most common first
+    m, s = load_normalization(d + '/norm.dmp')
+    assert m.shape == (42,) and np.allclose(m, np.mean([x.mean(0) for x, _ in recs], 0), atol=1e-4)   # quirk B5
