@@ -39,6 +39,12 @@ enum las_status {
   LAS_ERR_WORKSPACE = -3 /* workspace too small                                */
 };
 
+enum las_dec_mode {      /* which halves of a decoder step a las_decoder_step_* call runs */
+  LAS_DEC_FUSED = 0,          /* LSTM cell, then attention queried by its output (AttentionWrapper around one cell) */
+  LAS_DEC_CELL_ONLY = 1,      /* one LSTM cell of a MultiRNNCell / AttentionMultiCell stack (las/model.py:20-69,194-196) */
+  LAS_DEC_ATTENTION_ONLY = 2  /* attention queried by `query` (the top cell's output) */
+};
+
 enum las_attention {     /* las/model.py:153-166 --attention_type */
   LAS_ATT_LUONG = 0,
   LAS_ATT_BAHDANAU = 1
@@ -140,7 +146,7 @@ int las_pyramid_lengths(const int32_t* len_in, int32_t* len_out, int B, void* st
  * Every per-step tensor is addressed as base + b * row_stride, so the caller can keep all U steps in
  * [B,U,...] buffers.  `parts` workgroups per utterance split the context columns (speed only). */
 typedef struct las_dec_step {
-  int32_t B, Hd, M, Tm, attention, _pad;  /* Tm = padded memory length T'; attention = enum las_attention */
+  int32_t B, Hd, M, Tm, attention, mode;  /* Tm = padded memory length T'; enum las_attention; enum las_dec_mode */
   const float* z;                /* [B,4Hd] contiguous: recurrent + attention-feed part of the pre-activations */
   const las_bf16* tok_rows;      /* [E,4Hd] bf16 rows of the cell kernel for the token feed, or NULL */
   const int32_t* tok_ids;        /* previous token of utterance b at tok_ids[b * tok_stride] */
@@ -176,6 +182,8 @@ typedef struct las_dec_step {
   float drop_keep;
   uint32_t drop_seed, drop_stream;
   int32_t step, feed_width;
+  const las_bf16* query;         /* LAS_DEC_ATTENTION_ONLY: the query [B,Hd] bf16, row stride ldq */
+  int64_t ldq;
 } las_dec_step;
 int las_decoder_step_fwd(const las_dec_step* s, int parts, void* stream);
 
@@ -183,7 +191,7 @@ int las_decoder_step_fwd(const las_dec_step* s, int parts, void* stream);
  * back-propagates through context, softmax and score into h_t, adds dh_rec, runs the LSTM cell
  * backward and emits dz (bf16) for the dense products; dc is updated in place to dc_{t-1}. */
 typedef struct las_dec_step_bwd {
-  int32_t B, Hd, M, Tm, attention, _pad;
+  int32_t B, Hd, M, Tm, attention, mode;
   const float* dctx_a;           /* fp32, row stride ldda (e.g. dlogits * W_proj^T), or NULL */
   int64_t ldda;
   const float* dctx_b;           /* fp32, row stride lddb (attention-feed gradient from step t+1), or NULL */
@@ -219,6 +227,12 @@ typedef struct las_dec_step_bwd {
   float drop_keep;               /* as in las_dec_step: dctx_b is masked with step+1's attention-feed mask */
   uint32_t drop_seed, drop_stream;
   int32_t step, feed_width;
+  float* dq_out;                 /* LAS_DEC_ATTENTION_ONLY: d(query) fp32 out, row stride lddq */
+  int64_t lddq;
+  const float* dh_b;             /* further gradient sources into h_t (fp32), or NULL */
+  int64_t ldhb;
+  const float* dh_c;
+  int64_t ldhc;
 } las_dec_step_bwd;
 int las_decoder_step_bwd(const las_dec_step_bwd* s, void* stream);
 
@@ -242,6 +256,11 @@ int las_onehot_bf16(const int32_t* ids, int64_t id_stride_b, int B, int U, int V
 int las_sample_tokens(const float* logits, int64_t ldl, int V, const int32_t* teacher, int64_t teacher_stride,
                       int32_t* next, int64_t next_stride, int B, float prob, uint32_t seed, uint32_t step,
                       void* stream);
+
+/* out[r, c] = a[r, c] + b[r, c] * mask / keep, mask drawn at index idx_base + r * idx_ld + c of (seed, stream_id);
+ * keep >= 1: plain sum; a == NULL: treated as zero.  (Gradient through the decoder cell's input dropout.) */
+int las_add_masked(const float* a, int64_t lda, const float* b, int64_t ldb, float* out, int64_t ldo, int rows, int cols,
+                   float keep, uint32_t seed, uint32_t stream_id, uint64_t idx_base, int64_t idx_ld, void* stream);
 
 /* p[i] += std * N(0,1): the periodic Gaussian weight noise on `*kernel` variables (model_helper.py:418-432). */
 int las_add_noise(float* p, int64_t n, float std, uint32_t seed, uint32_t stream_id, void* stream);

@@ -154,13 +154,16 @@ def param_table(hp: HP) -> List[Tuple[str, Tuple[int, ...], str]]:
         # Dense(A, no bias) on concat([cell_out, context])  (Appendix A.5)
         out.append(('speller/attention_layer/kernel', (Hd + M, A), 'glorot'))
     for l in range(d.num_layers):
-        if d.bottom_only:
-            din = (E + A) if l == 0 else (Hd + A)                   # las/model.py:36-69
+        if d.bottom_only:                                            # las/model.py:36-69: cell_1 reads [attention_t, attention_{t-1}]
+            din = (E + A) if l == 0 else ((A + A) if l == 1 else (Hd + A))
         else:
             din = (E + A) if l == 0 else Hd                         # MultiRNNCell inside the wrapper
         out.append((f'speller/decoder_cell_{l}/lstm_cell/kernel', (din + Hd, 4 * Hd), 'lstm'))
         out.append((f'speller/decoder_cell_{l}/lstm_cell/bias', (4 * Hd,), 'zeros'))
-    out.append(('speller/projection_layer/kernel', (A, V), 'proj'))
+    # the projection sees the decoder cell's output: attention (A wide), or h of the top cell for an
+    # AttentionMultiCell with upper layers (las/model.py:36-69 returns cur_inp of the last cell)
+    P = Hd if (d.bottom_only and d.num_layers > 1) else A
+    out.append(('speller/projection_layer/kernel', (P, V), 'proj'))
     out.append(('speller/projection_layer/bias', (V,), 'zeros'))
     if hp.ctc_weight > 0:
         out.append(('ctc_logits/kernel', (M, V + 1), 'glorot'))

@@ -45,9 +45,13 @@ __global__ __launch_bounds__(256) void dec_step_fwd_kernel(las_dec_step s) {
   const int part = blockIdx.y, nparts = gridDim.y;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int Hd = s.Hd, M = s.M, Tm = s.Tm;
-  const int len = min(s.mem_len[b], Tm);
+  const int len = (s.mode == LAS_DEC_CELL_ONLY) ? 0 : min(s.mem_len[b], Tm);
   const bool writer = (part == 0);
 
+  if (s.mode == LAS_DEC_ATTENTION_ONLY) {
+    // the query comes from another cell (top of a MultiRNNCell stack, las/model.py:194-200)
+    for (int u = tid; u < Hd; u += 256) hq[u] = las_bf2f(s.query[(int64_t)b * s.ldq + u]);
+  } else {
   // ---- LSTM cell (Appendix A.1) ----
   const int tok = s.tok_rows ? s.tok_ids[(int64_t)b * s.tok_stride] : 0;
   // DropoutWrapper on the cell input: the one-hot feed keeps/loses its single non-zero entry
@@ -74,6 +78,8 @@ __global__ __launch_bounds__(256) void dec_step_fwd_kernel(las_dec_step s) {
       if (s.h_out2) s.h_out2[(int64_t)b * s.ldh2 + u] = hb;
     }
   }
+  }
+  if (s.mode == LAS_DEC_CELL_ONLY) return;
   __syncthreads();
 
   // ---- processed query (Bahdanau): pq[a] = sum_u Wq[u][a] h[u]  (TF Dense kernel layout [in,out]) ----
@@ -203,6 +209,10 @@ __global__ __launch_bounds__(256) void dec_step_bwd_kernel(las_dec_step_bwd s) {
   const int b = blockIdx.x;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int Hd = s.Hd, M = s.M, Tm = s.Tm;
+  if (s.mode == LAS_DEC_CELL_ONLY) {
+    for (int u = tid; u < Hd; u += 256) dhs[u] = 0.f;
+    __syncthreads();
+  } else {
   const int len = min(s.mem_len[b], Tm);
 
   // total gradient w.r.t. the context of this step; keep a bf16 copy for the d(memory) batched GEMM
@@ -330,6 +340,11 @@ __global__ __launch_bounds__(256) void dec_step_bwd_kernel(las_dec_step_bwd s) {
     __syncthreads();
   }
 
+  if (s.mode == LAS_DEC_ATTENTION_ONLY) {      // hand d(query) to the caller; the query's cell is differentiated elsewhere
+    for (int u = tid; u < Hd; u += 256) s.dq_out[(int64_t)b * s.lddq + u] = dhs[u];
+    return;
+  }
+  }
   // ---- LSTM cell backward (Appendix F) ----
   for (int u = tid; u < Hd; u += 256) {
     const float* gp = s.gates + (int64_t)b * s.ldg + u;
@@ -338,6 +353,8 @@ __global__ __launch_bounds__(256) void dec_step_bwd_kernel(las_dec_step_bwd s) {
     const float cp = s.c_prev[(int64_t)b * s.ldcp + u];
     float dht = dhs[u];
     if (s.dh_rec) dht += s.dh_rec[(int64_t)b * s.ldr + u];
+    if (s.dh_b) dht += s.dh_b[(int64_t)b * s.ldhb + u];
+    if (s.dh_c) dht += s.dh_c[(int64_t)b * s.ldhc + u];
     const float tc = las_tanh(ct);
     const float dov = dht * tc * go * (1.f - go);
     const float dct = s.dc[(int64_t)b * Hd + u] + dht * go * (1.f - tc * tc);
@@ -396,7 +413,10 @@ __global__ __launch_bounds__(256) void seq_ce_kernel(const float* logits, int64_
 
 extern "C" int las_decoder_step_fwd(const las_dec_step* s, int parts, void* stream) {
   LAS_REQUIRE(s->B > 0 && s->Hd % 8 == 0 && s->M % 8 == 0 && s->Tm > 0, "las_decoder_step_fwd: bad shape");
-  LAS_REQUIRE(s->attention == LAS_ATT_LUONG || (s->wq && s->att_v), "las_decoder_step_fwd: Bahdanau needs wq and att_v");
+  LAS_REQUIRE(s->mode == LAS_DEC_CELL_ONLY || s->attention == LAS_ATT_LUONG || (s->wq && s->att_v),
+              "las_decoder_step_fwd: Bahdanau needs wq and att_v");
+  LAS_REQUIRE(s->mode != LAS_DEC_ATTENTION_ONLY || s->query, "las_decoder_step_fwd: attention-only mode needs a query");
+  if (s->mode == LAS_DEC_CELL_ONLY) parts = 1;
   if (parts < 1) parts = 1;
   const size_t lds = (size_t)(2 * s->Hd + s->Tm + 8 + 8 + 2048) * sizeof(float);
   LAS_REQUIRE(lds <= 64 * 1024, "las_decoder_step_fwd: memory length %d too long for the LDS score buffer", s->Tm);
@@ -408,8 +428,10 @@ extern "C" int las_decoder_step_fwd(const las_dec_step* s, int parts, void* stre
 extern "C" int las_decoder_step_bwd(const las_dec_step_bwd* s, void* stream) {
   LAS_REQUIRE(s->B > 0 && s->Hd >= 64 && s->Hd <= 1024 && (s->Hd & (s->Hd - 1)) == 0 && s->M % 128 == 0 && s->Tm > 0,
               "las_decoder_step_bwd: decoder_units must be a power of two in [64,1024], memory depth a multiple of 128");
-  LAS_REQUIRE(s->attention == LAS_ATT_LUONG || (s->wq_t && s->att_v && s->pq && s->dkeys_acc && s->dv_acc),
+  LAS_REQUIRE(s->mode == LAS_DEC_CELL_ONLY || s->attention == LAS_ATT_LUONG ||
+                  (s->wq_t && s->att_v && s->pq && s->dkeys_acc && s->dv_acc),
               "las_decoder_step_bwd: Bahdanau needs wq_t, att_v, pq, dkeys_acc, dv_acc");
+  LAS_REQUIRE(s->mode != LAS_DEC_ATTENTION_ONLY || s->dq_out, "las_decoder_step_bwd: attention-only mode needs dq_out");
   const size_t lds = (size_t)(s->M + s->Tm + 2048 + 8 + s->Hd) * sizeof(float);
   LAS_REQUIRE(lds <= 64 * 1024, "las_decoder_step_bwd: shapes exceed the LDS budget");
   hipLaunchKernelGGL(dec_step_bwd_kernel, dim3(s->B), dim3(256), lds, (hipStream_t)stream, *s);

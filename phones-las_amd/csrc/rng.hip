@@ -91,6 +91,18 @@ __global__ void add_noise_kernel(float* p, int64_t n, float std, unsigned seed, 
   }
 }
 
+__global__ void add_masked_kernel(const float* a, int64_t lda, const float* b, int64_t ldb, float* out, int64_t ldo, int rows,
+                                  int cols, float keep, unsigned seed, unsigned stream, unsigned long long idx_base, int64_t idx_ld) {
+  const int64_t total = (int64_t)rows * cols;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int r = (int)(i / cols), c = (int)(i % cols);
+    float v = b[(int64_t)r * ldb + c];
+    if (keep < 1.0f) v = las_uniform(seed, stream, idx_base + (unsigned long long)r * idx_ld + c) < keep ? v / keep : 0.f;
+    if (a) v += a[(int64_t)r * lda + c];
+    out[(int64_t)r * ldo + c] = v;
+  }
+}
+
 int blocks_for(int64_t n) {
   int64_t b = (n + 255) / 256;
   return (int)(b > 2048 ? 2048 : b);
@@ -150,5 +162,15 @@ extern "C" int las_add_noise(float* p, int64_t n, float std, uint32_t seed, uint
   LAS_REQUIRE(n > 0 && std >= 0.f, "las_add_noise: bad arguments");
   hipLaunchKernelGGL(add_noise_kernel, dim3(blocks_for(n)), dim3(256), 0, (hipStream_t)stream, p, n, std, seed, stream_id);
   LAS_LAUNCH_CHECK("add noise launch");
+  return LAS_OK;
+}
+
+extern "C" int las_add_masked(const float* a, int64_t lda, const float* b, int64_t ldb, float* out, int64_t ldo, int rows,
+                              int cols, float keep, uint32_t seed, uint32_t stream_id, uint64_t idx_base, int64_t idx_ld,
+                              void* stream) {
+  LAS_REQUIRE(rows > 0 && cols > 0 && b != nullptr && keep > 0.f, "las_add_masked: bad arguments");
+  hipLaunchKernelGGL(add_masked_kernel, dim3(blocks_for((int64_t)rows * cols)), dim3(256), 0, (hipStream_t)stream, a, lda, b, ldb,
+                     out, ldo, rows, cols, keep, seed, stream_id, (unsigned long long)idx_base, idx_ld);
+  LAS_LAUNCH_CHECK("add masked launch");
   return LAS_OK;
 }

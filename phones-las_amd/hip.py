@@ -49,6 +49,7 @@ _SIGS = {
     'las_fe_top_db': ([_vp, _i64, _i32, _i32, _f32, _vp, _vp], C.c_int),
     'las_fe_rms': ([_vp, _i32, _i32, _i32, _vp, _i64, _i32, _vp], C.c_int),
     'las_fe_delta': ([_vp, _i64, _i32, _i32, _vp, _vp, _vp, _i32, _vp, _i64, _i32, _i32, _vp], C.c_int),
+    'las_add_masked': ([_vp, _i64, _vp, _i64, _vp, _i64, _i32, _i32, _f32, C.c_uint32, C.c_uint32, C.c_uint64, _i64, _vp], C.c_int),
     'las_add_noise': ([_vp, _i64, _f32, C.c_uint32, C.c_uint32, _vp], C.c_int),
     'las_sample_tokens': ([_vp, _i64, _i32, _vp, _i64, _vp, _i64, _i32, _f32, C.c_uint32, C.c_uint32, _vp], C.c_int),
 }
@@ -60,29 +61,31 @@ EXPORTS = tuple(n for n in _SIGS if n not in _PENDING)
 
 class DecStep(C.Structure):
     """struct las_dec_step (include/las_hip.h)."""
-    _fields_ = [('B', _i32), ('Hd', _i32), ('M', _i32), ('Tm', _i32), ('attention', _i32), ('_pad', _i32),
+    _fields_ = [('B', _i32), ('Hd', _i32), ('M', _i32), ('Tm', _i32), ('attention', _i32), ('mode', _i32),
                 ('z', _vp), ('tok_rows', _vp), ('tok_ids', _vp), ('tok_stride', _i64), ('bias', _vp),
                 ('c_prev', _vp), ('ldcp', _i64), ('gates_out', _vp), ('ldg', _i64), ('c_out', _vp), ('ldco', _i64),
                 ('h_out', _vp), ('ldh', _i64), ('h_out2', _vp), ('ldh2', _i64), ('keys', _vp), ('values', _vp),
                 ('mem_len', _vp), ('wq', _vp), ('att_v', _vp), ('align_out', _vp), ('align_bf16', _vp),
                 ('lda', _i64), ('pq_out', _vp), ('ldpq', _i64), ('ctx_out', _vp), ('ldc', _i64),
                 ('ctx_out2', _vp), ('ldc2', _i64), ('drop_keep', _f32), ('drop_seed', C.c_uint32),
-                ('drop_stream', C.c_uint32), ('step', _i32), ('feed_width', _i32)]
+                ('drop_stream', C.c_uint32), ('step', _i32), ('feed_width', _i32), ('query', _vp), ('ldq', _i64)]
 
 
 class DecStepBwd(C.Structure):
     """struct las_dec_step_bwd (include/las_hip.h)."""
-    _fields_ = [('B', _i32), ('Hd', _i32), ('M', _i32), ('Tm', _i32), ('attention', _i32), ('_pad', _i32),
+    _fields_ = [('B', _i32), ('Hd', _i32), ('M', _i32), ('Tm', _i32), ('attention', _i32), ('mode', _i32),
                 ('dctx_a', _vp), ('ldda', _i64), ('dctx_b', _vp), ('lddb', _i64), ('dctx_save', _vp), ('ldds', _i64),
                 ('dh_rec', _vp), ('ldr', _i64), ('dc', _vp), ('gates', _vp), ('ldg', _i64), ('c_new', _vp),
                 ('ldcn', _i64), ('c_prev', _vp), ('ldcp', _i64), ('align', _vp), ('lda', _i64), ('pq', _vp),
                 ('ldpq', _i64), ('keys', _vp), ('values', _vp), ('mem_len', _vp), ('wq_t', _vp), ('att_v', _vp),
                 ('dz', _vp), ('ldz', _i64), ('ds_out', _vp), ('ldso', _i64), ('dkeys_acc', _vp), ('dv_acc', _vp),
                 ('dpq_out', _vp), ('lddpq', _i64), ('drop_keep', _f32), ('drop_seed', C.c_uint32),
-                ('drop_stream', C.c_uint32), ('step', _i32), ('feed_width', _i32)]
+                ('drop_stream', C.c_uint32), ('step', _i32), ('feed_width', _i32), ('dq_out', _vp), ('lddq', _i64),
+                ('dh_b', _vp), ('ldhb', _i64), ('dh_c', _vp), ('ldhc', _i64)]
 
 
 ATT_LUONG, ATT_BAHDANAU = 0, 1
+DEC_FUSED, DEC_CELL_ONLY, DEC_ATTENTION_ONLY = 0, 1, 2
 
 
 def addr(t, offset_elems=0):

@@ -17,7 +17,7 @@ from .. import hip
 from . import ops
 from .ops import TRAIN, EVAL, PREDICT, LSTMStateTuple
 
-__all__ = ['listener', 'speller', 'Listener', 'Speller']
+__all__ = ['listener', 'speller', 'Listener', 'Speller', 'make_speller']
 
 
 def _r8(n):
@@ -102,8 +102,23 @@ def listener(encoder_inputs, source_sequence_length, mode, hparams, *, variables
 _ATT = {'luong': hip.ATT_LUONG, 'bahdanau': hip.ATT_BAHDANAU}
 
 
+def make_speller(hparams, variables, memory_depth):
+    """The decoder for ``hparams``: the fused single-cell path when the configuration allows it, else the general
+    cell stack (speller_general.GeneralSpeller: multi-layer, --bottom_only AttentionMultiCell, attention layer,
+    embedding)."""
+    d = hparams
+    if d.attention_type not in _ATT:
+        raise ValueError('attention_type %r is not implemented on the HIP path (luong, bahdanau)' % d.attention_type)
+    if getattr(d, 'binf_projection', False) or getattr(d, 'binary_outputs', False):
+        raise ValueError('binary-feature decoders are not implemented on the HIP path this round')
+    if d.num_layers == 1 and not d.attention_layer_size and not d.embedding_size:
+        return Speller(hparams, variables, memory_depth)
+    from .speller_general import GeneralSpeller
+    return GeneralSpeller(hparams, variables, memory_depth, _ATT[d.attention_type])
+
+
 class Speller:
-    """AttentionWrapper(LSTMCell) decoder + projection layer (las/model.py:145-202,251-257)."""
+    """AttentionWrapper(LSTMCell) decoder + projection layer (las/model.py:145-202,251-257): the fused fast path."""
 
     def __init__(self, hparams, variables, memory_depth):
         d = hparams
@@ -415,7 +430,7 @@ def speller(encoder_outputs, encoder_state, decoder_inputs, source_sequence_leng
     if getattr(hparams, 'beam_width', 0) and mode == PREDICT:
         raise ValueError('beam search is not implemented on the HIP path this round')
     if module is None:
-        module = Speller(hparams, variables, encoder_outputs.shape[-1])
+        module = make_speller(hparams, variables, encoder_outputs.shape[-1])
     Out = collections.namedtuple('BasicDecoderOutput', ['rnn_output', 'sample_id'])
     if mode == TRAIN:
         U = num_steps if num_steps is not None else int(target_sequence_length.max().item())

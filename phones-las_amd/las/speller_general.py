@@ -1,0 +1,466 @@
+"""General decoder of las/model.py:145-349 on the HIP kernels: any number of LSTM layers, with the attention either
+wrapped around the whole MultiRNNCell stack (default) or around the bottom cell only (``--bottom_only``:
+AttentionMultiCell, las/model.py:20-69), optional ``--attention_layer_size`` (Dense(A, no bias) on
+[cell_output, context]) and ``--embedding_size`` (trainable target embedding instead of one-hot).
+
+The single-layer / no-attention-layer / one-hot configuration has a fused fast path in ``model.Speller``; this module
+composes the same kernels un-fused (LAS_DEC_CELL_ONLY / LAS_DEC_ATTENTION_ONLY) plus skinny GEMMs.  Step t:
+
+  bottom_only:      x0=[emb(y), att_{t-1}] -> cell0 -> h0 -> attention(h0) -> att_t
+                    l>=1: [cur, att_{t-1}] -> cell_l -> h_l (cur = att_t for l=1, h_{l-1} above); output = h_top
+  default:          x0=[emb(y), att_{t-1}] -> cell0 -> ... -> cell_top -> attention(h_top) -> att_t; output = att_t
+  att_t = Dense([query, context]) if attention_layer_size else context.
+
+Input dropout and scheduled sampling are only implemented on the fused fast path (ValueError here)."""
+import ctypes as C
+
+import torch
+
+from .. import hip
+
+__all__ = ['GeneralSpeller']
+
+
+def _r8(n):
+    return (n + 7) // 8 * 8
+
+
+class GeneralSpeller:
+    K_MEM = 'speller/memory_layer/kernel'
+    K_PROJ = 'speller/projection_layer/kernel'
+    B_PROJ = 'speller/projection_layer/bias'
+    K_Q = 'speller/query_layer/kernel'
+    V_ATT = 'speller/attention_v'
+    K_AL = 'speller/attention_layer/kernel'
+    K_EMB = 'speller/target_embedding'
+
+    def __init__(self, hparams, variables, memory_depth, att_code):
+        d = hparams
+        if (d.dropout or 0.0) > 0 or (d.sampling_probability or 0.0) > 0:
+            raise ValueError('dropout / scheduled sampling are only implemented for the single-layer decoder without '
+                             'attention layer or embedding on the HIP path (use --dropout 0 --sampling_probability 0)')
+        self.hp = d
+        self.att = att_code
+        self.NL, self.bottom = d.num_layers, bool(d.bottom_only)
+        self.V, self.Vp = d.target_vocab_size, _r8(d.target_vocab_size)
+        self.Hd, self.M = d.num_units, memory_depth
+        self.A = d.attention_layer_size or self.M
+        self.has_al = bool(d.attention_layer_size)
+        self.emb = bool(d.embedding_size)
+        self.E = d.embedding_size if self.emb else self.V
+        for n, v in (('decoder_units', self.Hd), ('attention depth', self.A), ('embedding_size', self.E if self.emb else 8)):
+            if v % 8:
+                raise ValueError('%s must be a multiple of 8 on the HIP path' % n)
+        self.P = self.Hd if (self.bottom and self.NL > 1) else self.A
+        Hd, A = self.Hd, self.A
+        # GEMM input width of each cell (without the token part of cell 0) and where its pieces sit
+        self.win = []
+        for l in range(self.NL):
+            if l == 0:
+                self.win.append(A)                         # [att_{t-1}]            + h_0
+            elif self.bottom:
+                self.win.append((A if l == 1 else Hd) + A)   # [cur, att_{t-1}]     + h_l
+            else:
+                self.win.append(Hd)                        # [h_{l-1}]              + h_l
+        bf, dev = torch.bfloat16, 'cuda'
+        self.kT = [torch.empty(4 * Hd, w + Hd, dtype=bf, device=dev) for w in self.win]
+        self.kn = [torch.empty(w + Hd, 4 * Hd, dtype=bf, device=dev) for w in self.win]
+        self.tok = torch.empty(self.V, 4 * Hd, dtype=bf, device=dev)
+        self.wmemT = torch.empty(Hd, self.M, dtype=bf, device=dev)
+        self.wmem = torch.empty(self.M, Hd, dtype=bf, device=dev)
+        self.wprojT = torch.empty(self.Vp, self.P, dtype=bf, device=dev)
+        self.wproj = torch.empty(self.P, self.Vp, dtype=bf, device=dev)
+        self.bproj = torch.zeros(self.Vp, dtype=torch.float32, device=dev)
+        if self.has_al:
+            self.walT = torch.empty(A, Hd + self.M, dtype=bf, device=dev)
+            self.waln = torch.empty(Hd + self.M, A, dtype=bf, device=dev)
+        if self.emb:
+            self.emb_bf = torch.empty(self.V, self.E, dtype=bf, device=dev)
+            self.k0tokT = torch.empty(4 * Hd, self.E, dtype=bf, device=dev)
+            self.k0tok = torch.empty(self.E, 4 * Hd, dtype=bf, device=dev)
+        if self.att == hip.ATT_BAHDANAU:
+            self.wq = torch.empty(Hd, Hd, dtype=bf, device=dev)
+            self.wq_t = torch.empty(Hd, Hd, dtype=bf, device=dev)
+        self.refresh(variables)
+        self.saved = None
+
+    @staticmethod
+    def cell_names(l):
+        return ('speller/decoder_cell_%d/lstm_cell/kernel' % l, 'speller/decoder_cell_%d/lstm_cell/bias' % l)
+
+    def refresh(self, var):
+        Hd, M, V, Vp, E, A = self.Hd, self.M, self.V, self.Vp, self.E, self.A
+        hip.cast_bf16(var[self.K_MEM], M, Hd, self.wmemT, Hd, M, transpose=True)
+        hip.cast_bf16(var[self.K_MEM], M, Hd, self.wmem, M, Hd)
+        self.bias = []
+        for l in range(self.NL):
+            k = var[self.cell_names(l)[0]]
+            skip = E if l == 0 else 0
+            rows = self.win[l] + Hd
+            assert k.shape == (skip + rows, 4 * Hd), (l, tuple(k.shape), skip + rows)
+            hip.cast_bf16(k[skip:], rows, 4 * Hd, self.kT[l], 4 * Hd, rows, transpose=True, lds=4 * Hd)
+            hip.cast_bf16(k[skip:], rows, 4 * Hd, self.kn[l], rows, 4 * Hd, lds=4 * Hd)
+            self.bias.append(var[self.cell_names(l)[1]])
+        k0 = var[self.cell_names(0)[0]]
+        if self.emb:
+            hip.cast_bf16(var[self.K_EMB], V, E, self.emb_bf, V, E)
+            hip.cast_bf16(k0, E, 4 * Hd, self.k0tokT, 4 * Hd, E, transpose=True, lds=4 * Hd)
+            hip.cast_bf16(k0, E, 4 * Hd, self.k0tok, E, 4 * Hd, lds=4 * Hd)
+            # rows the cell adds for token v: embedding[v] * K0[:E]  (the embedded feed as a [V,4Hd] table)
+            hip.gemm_nt(self.emb_bf, self.k0tokT, self.tok, V, 4 * Hd, E, lda=E, ldb=E, ldc=4 * Hd, out_bf16=True)
+        else:
+            hip.cast_bf16(k0, V, 4 * Hd, self.tok, V, 4 * Hd, lds=4 * Hd)
+        P = self.P
+        hip.cast_bf16(var[self.K_PROJ], P, V, self.wprojT, Vp, P, transpose=True)
+        hip.cast_bf16(var[self.K_PROJ], P, V, self.wproj, P, Vp)
+        self.bproj[:V].copy_(var[self.B_PROJ])
+        if self.has_al:
+            hip.cast_bf16(var[self.K_AL], Hd + M, A, self.walT, A, Hd + M, transpose=True)
+            hip.cast_bf16(var[self.K_AL], Hd + M, A, self.waln, Hd + M, A)
+        if self.att == hip.ATT_BAHDANAU:
+            hip.cast_bf16(var[self.K_Q], Hd, Hd, self.wq, Hd, Hd)
+            hip.cast_bf16(var[self.K_Q], Hd, Hd, self.wq_t, Hd, Hd, transpose=True)
+            self.att_v = var[self.V_ATT]
+
+    # ------------------------------------------------------------------------------------------------------------------
+    def _init_states(self, encoder_state, B):
+        """zip(zero_state, encoder_state) of las/model.py:259-268: cell 0 <- encoder fw, cell 1 <- encoder bw."""
+        dev = 'cuda'
+        z = torch.zeros(B, self.Hd, dtype=torch.float32, device=dev)
+        init = [(z, z) for _ in range(self.NL)]
+        passed = 0
+        if self.hp.pass_hidden_state and self.bottom:
+            es = list(encoder_state) if isinstance(encoder_state[0], tuple) else [encoder_state]
+            if not hasattr(es[0], 'c'):
+                raise ValueError('pass_hidden_state needs the pyramidal listener')
+            if self.NL > len(es):
+                raise ValueError('pass_hidden_state: decoder_layers (%d) exceeds the encoder states (%d)' % (self.NL, len(es)))
+            for l in range(self.NL):
+                if es[l].c.shape[-1] != self.Hd:
+                    raise ValueError('pass_hidden_state needs decoder_units == encoder_units')
+                init[l] = (es[l].c, es[l].h)
+            passed = self.NL
+        return init, passed
+
+    def _cell_fwd(self, l, t, sv, z, tok_ids, tok_stride):
+        B, Hd, U = sv['B'], self.Hd, sv['U']
+        s = hip.DecStep()
+        s.B, s.Hd, s.M, s.Tm, s.attention, s.mode = B, Hd, self.M, sv['Tm'], self.att, hip.DEC_CELL_ONLY
+        s.z, s.bias = hip.addr(z), hip.addr(self.bias[l])
+        if l == 0:
+            s.tok_rows, s.tok_ids, s.tok_stride = hip.addr(self.tok), tok_ids, tok_stride
+        s.c_prev, s.ldcp = hip.addr(sv['cs'][l], t * Hd), (U + 1) * Hd
+        s.gates_out, s.ldg = hip.addr(sv['gates'][l], t * 4 * Hd), U * 4 * Hd
+        s.c_out, s.ldco = hip.addr(sv['cs'][l], (t + 1) * Hd), (U + 1) * Hd
+        s.h_out, s.ldh = hip.addr(sv['h'][l], t * Hd), U * Hd
+        s.drop_keep, s.feed_width = 1.0, self.E + self.A
+        hip.check(hip.lib().las_decoder_step_fwd(C.byref(s), 1, hip.stream()))
+
+    def _attention_fwd(self, t, sv, query, ldq):
+        B, Hd, U, Tm, M = sv['B'], self.Hd, sv['U'], sv['Tm'], self.M
+        Tmp = _r8(Tm)
+        s = hip.DecStep()
+        s.B, s.Hd, s.M, s.Tm, s.attention, s.mode = B, Hd, M, Tm, self.att, hip.DEC_ATTENTION_ONLY
+        s.query, s.ldq = query, ldq
+        s.keys, s.values, s.mem_len = hip.addr(sv['keys']), hip.addr(sv['memory']), hip.addr(sv['mem_len'])
+        if self.att == hip.ATT_BAHDANAU:
+            s.wq, s.att_v = hip.addr(self.wq), hip.addr(self.att_v)
+            s.pq_out, s.ldpq = hip.addr(sv['pq'], t * Hd), U * Hd
+        s.align_out, s.align_bf16, s.lda = hip.addr(sv['align'], t * Tmp), hip.addr(sv['align_bf'], t * Tmp), U * Tmp
+        s.ctx_out, s.ldc = hip.addr(sv['ctx'], t * M), U * M
+        s.drop_keep, s.feed_width = 1.0, self.E + self.A
+        hip.check(hip.lib().las_decoder_step_fwd(C.byref(s), 4, hip.stream()))
+
+    def forward_train(self, memory, mem_len, encoder_state, targets_inputs, num_steps, parts=4, seed=0):
+        B, Tm, M = memory.shape
+        Hd, V, Vp, U, A, NL = self.Hd, self.V, self.Vp, num_steps, self.A, self.NL
+        dev, bf, f32 = memory.device, torch.bfloat16, torch.float32
+        Tmp = _r8(Tm)
+        init, passed = self._init_states(encoder_state, B)
+        keys = torch.empty(B, Tm, Hd, dtype=bf, device=dev)
+        hip.gemm_nt(memory, self.wmemT, keys, B * Tm, Hd, M, lda=M, ldb=M, ldc=Hd, out_bf16=True)
+        sv = dict(B=B, Tm=Tm, U=U, memory=memory, mem_len=mem_len, keys=keys, passed=passed, tin=targets_inputs)
+        sv['X'] = [torch.zeros(B, U, w + Hd, dtype=bf, device=dev) for w in self.win]
+        sv['gates'] = [torch.empty(B, U, 4 * Hd, dtype=f32, device=dev) for _ in range(NL)]
+        sv['cs'] = [torch.empty(B, U + 1, Hd, dtype=f32, device=dev) for _ in range(NL)]
+        sv['h'] = [torch.empty(B, U, Hd, dtype=bf, device=dev) for _ in range(NL)]
+        sv['align'] = torch.zeros(B, U, Tmp, dtype=f32, device=dev)
+        sv['align_bf'] = torch.zeros(B, U, Tmp, dtype=bf, device=dev)
+        sv['ctx'] = torch.empty(B, U, M, dtype=bf, device=dev)
+        sv['pq'] = torch.empty(B, U, Hd, dtype=f32, device=dev) if self.att == hip.ATT_BAHDANAU else None
+        sv['att'] = torch.empty(B, U, A, dtype=bf, device=dev) if self.has_al else sv['ctx']
+        sv['qc'] = torch.empty(B, U, Hd + M, dtype=bf, device=dev) if self.has_al else None
+        for l in range(NL):
+            sv['cs'][l][:, 0].copy_(init[l][0])
+            sv['X'][l][:, 0, self.win[l]:].copy_(init[l][1])        # h_{l,-1}; attention_{-1} = 0
+        z = torch.empty(B, 4 * Hd, dtype=f32, device=dev)
+        tin = targets_inputs
+        X, h, att = sv['X'], sv['h'], sv['att']
+        qlayer = 0 if self.bottom else NL - 1                       # the cell whose output queries the attention
+        for t in range(U):
+            last = t + 1 == U
+
+            def run_cell(l):
+                Kl = self.win[l] + Hd
+                hip.gemm_nt(X[l][:, t], self.kT[l], z, B, 4 * Hd, Kl, lda=U * Kl, ldb=Kl, ldc=4 * Hd)
+                self._cell_fwd(l, t, sv, z, hip.addr(tin, t), tin.stride(0))
+                if not last:
+                    X[l][:, t + 1, self.win[l]:].copy_(h[l][:, t])     # recurrent input of the next step
+
+            run_cell(0)
+            if not self.bottom:
+                for l in range(1, NL):
+                    X[l][:, t, :Hd].copy_(h[l - 1][:, t])
+                    run_cell(l)
+            self._attention_fwd(t, sv, hip.addr(h[qlayer], t * Hd), U * Hd)
+            if self.has_al:                                           # Dense(A, no bias) on [query, context]
+                sv['qc'][:, t, :Hd].copy_(h[qlayer][:, t])
+                sv['qc'][:, t, Hd:].copy_(sv['ctx'][:, t])
+                hip.gemm_nt(sv['qc'][:, t], self.walT, att[:, t], B, A, Hd + M, lda=U * (Hd + M), ldb=Hd + M, ldc=U * A,
+                            out_bf16=True)
+            if self.bottom:
+                for l in range(1, NL):
+                    wc = A if l == 1 else Hd
+                    X[l][:, t, :wc].copy_(att[:, t] if l == 1 else h[l - 1][:, t])
+                    # X[l][:, t, wc:wc+A] already holds attention_{t-1} (written at the end of step t-1; zero at t=0)
+                    run_cell(l)
+            if not last:
+                X[0][:, t + 1, :A].copy_(att[:, t])
+                if self.bottom:
+                    for l in range(1, NL):
+                        wc = A if l == 1 else Hd
+                        X[l][:, t + 1, wc:wc + A].copy_(att[:, t])
+        out_all = h[NL - 1] if (self.bottom and NL > 1) else att
+        sv['out'] = out_all
+        logits = torch.empty(B, U, Vp, dtype=f32, device=dev)
+        hip.gemm_nt(out_all, self.wprojT, logits, B * U, Vp, self.P, lda=self.P, ldb=self.P, ldc=Vp, bias=self.bproj)
+        self.saved = sv
+        return logits
+
+    # ------------------------------------------------------------------------------------------------------------------
+    def _cell_bwd(self, l, t, sv, dc, sources, dz):
+        B, Hd, U = sv['B'], self.Hd, sv['U']
+        s = hip.DecStepBwd()
+        s.B, s.Hd, s.M, s.Tm, s.attention, s.mode = B, Hd, self.M, sv['Tm'], self.att, hip.DEC_CELL_ONLY
+        s.dc = hip.addr(dc)
+        s.gates, s.ldg = hip.addr(sv['gates'][l], t * 4 * Hd), U * 4 * Hd
+        s.c_new, s.ldcn = hip.addr(sv['cs'][l], (t + 1) * Hd), (U + 1) * Hd
+        s.c_prev, s.ldcp = hip.addr(sv['cs'][l], t * Hd), (U + 1) * Hd
+        s.dz, s.ldz = hip.addr(dz, t * 4 * Hd), U * 4 * Hd
+        srcs = [x for x in sources if x is not None]
+        assert 1 <= len(srcs) <= 3
+        fields = (('dh_rec', 'ldr'), ('dh_b', 'ldhb'), ('dh_c', 'ldhc'))
+        for (pn, ln), (ptr, ld) in zip(fields, srcs):
+            setattr(s, pn, ptr)
+            setattr(s, ln, ld)
+        s.drop_keep, s.feed_width = 1.0, self.E + self.A
+        hip.check(hip.lib().las_decoder_step_bwd(C.byref(s), hip.stream()))
+
+    def backward(self, dlogits, grads, overlap=None):
+        sv = self.saved
+        B, Tm, U = sv['B'], sv['Tm'], sv['U']
+        Hd, V, Vp, M, A, NL, P = self.Hd, self.V, self.Vp, self.M, self.A, self.NL, self.P
+        Tmp = _r8(Tm)
+        dev, bf, f32 = dlogits.device, torch.bfloat16, torch.float32
+        lib, st = hip.lib(), hip.stream()
+        BU = B * U
+        bah = self.att == hip.ATT_BAHDANAU
+        d_out = torch.empty(B, U, P, dtype=f32, device=dev)
+        hip.gemm_nt(dlogits, self.wproj, d_out, BU, P, Vp, lda=Vp, ldb=Vp, ldc=P)
+        dc = [torch.zeros(B, Hd, dtype=f32, device=dev) for _ in range(NL)]
+        dx = [[torch.zeros(B, w + Hd, dtype=f32, device=dev) for _ in range(2)] for w in self.win]
+        dz = [torch.empty(B, U, 4 * Hd, dtype=bf, device=dev) for _ in range(NL)]
+        ds_all = torch.zeros(B, U, Tmp, dtype=bf, device=dev)
+        dctx_all = torch.empty(B, U, M, dtype=bf, device=dev)
+        datt = torch.empty(B, A, dtype=f32, device=dev)
+        datt_bf = torch.empty(B, U, A, dtype=bf, device=dev) if self.has_al else None
+        dqc = torch.empty(B, Hd + M, dtype=f32, device=dev) if self.has_al else None
+        dq = torch.empty(B, Hd, dtype=f32, device=dev)
+        if bah:
+            dkeys = torch.zeros(B, Tm, Hd, dtype=f32, device=dev)
+            dpq_all = torch.empty(B, U, Hd, dtype=bf, device=dev)
+        qlayer = 0 if self.bottom else NL - 1
+        W = [w + Hd for w in self.win]
+
+        def v(buf, off, ld):              # (address, row stride) of a column window of a [B, ld] fp32 buffer
+            return (hip.addr(buf, off), ld)
+
+        for t in range(U - 1, -1, -1):
+            cur, nxt = t & 1, (t + 1) & 1
+            has_next = t + 1 < U
+
+            def cell_and_gemm(l, sources):
+                rec = v(dx[l][nxt], self.win[l], W[l]) if has_next else None
+                self._cell_bwd(l, t, sv, dc[l], list(sources) + [rec], dz[l])
+                hip.gemm_nt(dz[l][:, t], self.kn[l], dx[l][cur], B, W[l], 4 * Hd, lda=U * 4 * Hd, ldb=4 * Hd, ldc=W[l])
+
+            if self.bottom:
+                for l in range(NL - 1, 0, -1):
+                    wc_up = (A if l + 1 == 1 else Hd)
+                    src = v(d_out, t * P, U * P) if l == NL - 1 else v(dx[l + 1][cur], 0, W[l + 1])
+                    cell_and_gemm(l, [src])
+            # gradient w.r.t. attention_t
+            if self.bottom and NL > 1:
+                datt.copy_(dx[1][cur][:, :A])
+            else:
+                datt.copy_(d_out[:, t])
+            if has_next:
+                datt.add_(dx[0][nxt][:, :A])
+                if self.bottom:
+                    for l in range(1, NL):
+                        wc = A if l == 1 else Hd
+                        datt.add_(dx[l][nxt][:, wc:wc + A])
+            if self.has_al:
+                hip.cast_bf16(datt, B, A, datt_bf[:, t], B, A, ldd=U * A, lds=A)
+                hip.gemm_nt(datt_bf[:, t], self.waln, dqc, B, Hd + M, A, lda=U * A, ldb=A, ldc=Hd + M)
+                dctx_ptr, dctx_ld = hip.addr(dqc, Hd), Hd + M
+            else:
+                dctx_ptr, dctx_ld = hip.addr(datt), A
+            s = hip.DecStepBwd()
+            s.B, s.Hd, s.M, s.Tm, s.attention, s.mode = B, Hd, M, Tm, self.att, hip.DEC_ATTENTION_ONLY
+            s.dctx_a, s.ldda = dctx_ptr, dctx_ld
+            s.dctx_save, s.ldds = hip.addr(dctx_all, t * M), U * M
+            s.align, s.lda = hip.addr(sv['align'], t * Tmp), U * Tmp
+            s.keys, s.values, s.mem_len = hip.addr(sv['keys']), hip.addr(sv['memory']), hip.addr(sv['mem_len'])
+            s.ds_out, s.ldso = hip.addr(ds_all, t * Tmp), U * Tmp
+            s.dq_out, s.lddq = hip.addr(dq), Hd
+            s.drop_keep, s.feed_width = 1.0, self.E + A
+            if bah:
+                s.pq, s.ldpq = hip.addr(sv['pq'], t * Hd), U * Hd
+                s.wq_t, s.att_v = hip.addr(self.wq_t), hip.addr(self.att_v)
+                s.dkeys_acc, s.dv_acc = hip.addr(dkeys), hip.addr(grads[self.V_ATT])
+                s.dpq_out, s.lddpq = hip.addr(dpq_all, t * Hd), U * Hd
+            hip.check(lib.las_decoder_step_bwd(C.byref(s), st))
+            qsrc = [v(dq, 0, Hd)] + ([v(dqc, 0, Hd + M)] if self.has_al else [])
+            if self.bottom:
+                cell_and_gemm(0, qsrc)
+            else:
+                cell_and_gemm(NL - 1, qsrc)
+                for l in range(NL - 2, -1, -1):
+                    cell_and_gemm(l, [v(dx[l + 1][cur], 0, W[l + 1])])
+        # ---- after the loop: attention tensors (critical path into the listener) ----
+        if not bah:
+            dkeys = torch.zeros(B, Tm, Hd, dtype=f32, device=dev)
+            hip.gemm_tn(ds_all, sv['h'][qlayer], dkeys, Tm, Hd, U, lda=Tmp, ldb=Hd, ldc=Hd, batch=B, sa=U * Tmp, sb=U * Hd,
+                        sc=Tm * Hd)
+        dmem = torch.zeros(B, Tm, M, dtype=f32, device=dev)
+        hip.gemm_tn(sv['align_bf'], dctx_all, dmem, Tm, M, U, lda=Tmp, ldb=M, ldc=M, batch=B, sa=U * Tmp, sb=U * M, sc=Tm * M)
+        dkeys_bf = torch.empty(B * Tm, Hd, dtype=bf, device=dev)
+        hip.cast_bf16(dkeys, B * Tm, Hd, dkeys_bf, B * Tm, Hd, ldd=Hd, lds=Hd)
+        hip.gemm_nt(dkeys_bf, self.wmem, dmem, B * Tm, M, Hd, lda=Hd, ldb=Hd, ldc=M, accumulate=True)
+        # ---- weight gradients ----
+        hip.gemm_tn(sv['out'], dlogits, grads[self.K_PROJ], P, V, BU, lda=P, ldb=Vp, ldc=V, split_k=4)
+        hip.colsum_bf16(dlogits, BU, V, grads[self.B_PROJ], ldx=Vp)
+        hip.gemm_tn(sv['memory'], dkeys_bf, grads[self.K_MEM], M, Hd, B * Tm, lda=M, ldb=Hd, ldc=Hd, split_k=8)
+        if bah:
+            hip.gemm_tn(sv['h'][qlayer], dpq_all, grads[self.K_Q], Hd, Hd, BU, lda=Hd, ldb=Hd, ldc=Hd, split_k=4)
+        if self.has_al:
+            hip.gemm_tn(sv['qc'], datt_bf, grads[self.K_AL], Hd + M, A, BU, lda=Hd + M, ldb=A, ldc=A, split_k=4)
+        for l in range(NL):
+            kn, bn = self.cell_names(l)
+            skip = self.E if l == 0 else 0
+            hip.gemm_tn(sv['X'][l], dz[l], grads[kn][skip:], W[l], 4 * Hd, BU, lda=W[l], ldb=4 * Hd, ldc=4 * Hd, split_k=4)
+            hip.colsum_bf16(dz[l], BU, 4 * Hd, grads[bn], ldx=4 * Hd)
+        # token part of cell 0: d(rows) = onehot^T dz_0, then through the embedding if there is one
+        onehot = torch.empty(BU, Vp, dtype=bf, device=dev)
+        tin = sv['tin']
+        hip.check(lib.las_onehot_bf16(hip.p(tin), tin.stride(0), B, U, V, hip.p(onehot), Vp, 1.0, 0, 0, self.E + A, st))
+        k0 = grads[self.cell_names(0)[0]]
+        if not self.emb:
+            hip.gemm_tn(onehot, dz[0], k0, V, 4 * Hd, BU, lda=Vp, ldb=4 * Hd, ldc=4 * Hd, split_k=4)
+        else:
+            dtok = torch.zeros(V, 4 * Hd, dtype=f32, device=dev)
+            hip.gemm_tn(onehot, dz[0], dtok, V, 4 * Hd, BU, lda=Vp, ldb=4 * Hd, ldc=4 * Hd, split_k=4)
+            dtok_bf = torch.empty(V, 4 * Hd, dtype=bf, device=dev)
+            hip.cast_bf16(dtok, V, 4 * Hd, dtok_bf, V, 4 * Hd)
+            hip.gemm_tn(self.emb_bf, dtok_bf, k0, self.E, 4 * Hd, V, lda=self.E, ldb=4 * Hd, ldc=4 * Hd)      # emb^T dRows
+            hip.gemm_nt(dtok_bf, self.k0tok, grads[self.K_EMB], V, self.E, 4 * Hd, lda=4 * Hd, ldb=4 * Hd, ldc=self.E,
+                        accumulate=True)                                                                       # dRows K0^T
+        d_state = None
+        if sv['passed']:
+            fin = (0) & 1                      # the buffers written by step t = 0
+            d_state = [(dc[l], dx[l][fin][:, self.win[l]:]) for l in range(sv['passed'])]
+        self.saved = None
+        return dmem, d_state
+
+    # ------------------------------------------------------------------------------------------------------------------
+    def forward_greedy(self, memory, mem_len, encoder_state, max_iterations, parts=4):
+        """GreedyEmbeddingHelper decode (las/model.py:270-274,337-347) with the general cell stack."""
+        d = self.hp
+        B, Tm, M = memory.shape
+        Hd, V, Vp, A, NL, S = self.Hd, self.V, self.Vp, self.A, self.NL, max_iterations
+        dev, bf, f32 = memory.device, torch.bfloat16, torch.float32
+        init, _ = self._init_states(encoder_state, B)
+        ids0 = torch.full((B, 1), d.sos_id, dtype=torch.int32, device=dev)
+        fed = torch.full((B, max(S, 1)), d.eos_id, dtype=torch.int32, device=dev)
+        fed[:, :1] = ids0
+        # reuse the training graph step by step on [B, S] buffers (teacher tokens replaced by the argmax)
+        keys = torch.empty(B, Tm, Hd, dtype=bf, device=dev)
+        hip.gemm_nt(memory, self.wmemT, keys, B * Tm, Hd, M, lda=M, ldb=M, ldc=Hd, out_bf16=True)
+        Tmp = _r8(Tm)
+        U = max(S, 1)
+        sv = dict(B=B, Tm=Tm, U=U, memory=memory, mem_len=mem_len, keys=keys)
+        sv['X'] = [torch.zeros(B, U, w + Hd, dtype=bf, device=dev) for w in self.win]
+        sv['gates'] = [torch.empty(B, U, 4 * Hd, dtype=f32, device=dev) for _ in range(NL)]
+        sv['cs'] = [torch.empty(B, U + 1, Hd, dtype=f32, device=dev) for _ in range(NL)]
+        sv['h'] = [torch.empty(B, U, Hd, dtype=bf, device=dev) for _ in range(NL)]
+        sv['align'] = torch.zeros(B, U, Tmp, dtype=f32, device=dev)
+        sv['align_bf'] = torch.zeros(B, U, Tmp, dtype=bf, device=dev)
+        sv['ctx'] = torch.empty(B, U, M, dtype=bf, device=dev)
+        sv['pq'] = torch.empty(B, U, Hd, dtype=f32, device=dev) if self.att == hip.ATT_BAHDANAU else None
+        att = torch.empty(B, U, A, dtype=bf, device=dev) if self.has_al else sv['ctx']
+        qc = torch.empty(B, U, Hd + M, dtype=bf, device=dev) if self.has_al else None
+        for l in range(NL):
+            sv['cs'][l][:, 0].copy_(init[l][0])
+            sv['X'][l][:, 0, self.win[l]:].copy_(init[l][1])
+        z = torch.empty(B, 4 * Hd, dtype=f32, device=dev)
+        logits = torch.zeros(B, U, Vp, dtype=f32, device=dev)
+        samples = torch.full((B, U), d.eos_id, dtype=torch.int32, device=dev)
+        finished = torch.zeros(B, dtype=torch.bool, device=dev)
+        final_len = torch.zeros(B, dtype=torch.int32, device=dev)
+        X, h = sv['X'], sv['h']
+        qlayer = 0 if self.bottom else NL - 1
+        steps = 0
+        for t in range(S):
+            last = t + 1 == S
+
+            def run_cell(l):
+                Kl = self.win[l] + Hd
+                hip.gemm_nt(X[l][:, t], self.kT[l], z, B, 4 * Hd, Kl, lda=U * Kl, ldb=Kl, ldc=4 * Hd)
+                self._cell_fwd(l, t, sv, z, hip.addr(fed, t), fed.stride(0))
+                if not last:
+                    X[l][:, t + 1, self.win[l]:].copy_(h[l][:, t])
+
+            run_cell(0)
+            if not self.bottom:
+                for l in range(1, NL):
+                    X[l][:, t, :Hd].copy_(h[l - 1][:, t])
+                    run_cell(l)
+            self._attention_fwd(t, sv, hip.addr(h[qlayer], t * Hd), U * Hd)
+            if self.has_al:
+                qc[:, t, :Hd].copy_(h[qlayer][:, t])
+                qc[:, t, Hd:].copy_(sv['ctx'][:, t])
+                hip.gemm_nt(qc[:, t], self.walT, att[:, t], B, A, Hd + M, lda=U * (Hd + M), ldb=Hd + M, ldc=U * A, out_bf16=True)
+            if self.bottom:
+                for l in range(1, NL):
+                    wc = A if l == 1 else Hd
+                    X[l][:, t, :wc].copy_(att[:, t] if l == 1 else h[l - 1][:, t])
+                    run_cell(l)
+            out_t = h[NL - 1][:, t] if (self.bottom and NL > 1) else att[:, t]
+            hip.gemm_nt(out_t, self.wprojT, logits[:, t], B, Vp, self.P, lda=out_t.stride(0), ldb=self.P, ldc=U * Vp,
+                        bias=self.bproj)
+            sample = logits[:, t, :V].argmax(-1).to(torch.int32)
+            samples[:, t] = sample
+            final_len = torch.where(finished, final_len, torch.full_like(final_len, t + 1))
+            finished = finished | (sample == d.eos_id)
+            steps = t + 1
+            if not last:
+                fed[:, t + 1] = sample
+                X[0][:, t + 1, :A].copy_(att[:, t])
+                if self.bottom:
+                    for l in range(1, NL):
+                        wc = A if l == 1 else Hd
+                        X[l][:, t + 1, wc:wc + A].copy_(att[:, t])
+            if bool(finished.all()):
+                break
+        return logits[:, :steps, :V], samples[:, :steps], final_len, sv['align'][:, :steps, :Tm]

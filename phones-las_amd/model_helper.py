@@ -60,13 +60,14 @@ def param_table(params):
     if d.attention_layer_size or getattr(d, 'binf_projection', False):
         out.append(('speller/attention_layer/kernel', (Hd + M, A), 'glorot'))
     for l in range(d.num_layers):
-        if d.bottom_only:
-            din = (E + A) if l == 0 else (Hd + A)
+        if d.bottom_only:       # AttentionMultiCell: cell_1 reads [attention_t, attention_{t-1}], upper cells [h_{l-1}, attention_{t-1}]
+            din = (E + A) if l == 0 else ((A + A) if l == 1 else (Hd + A))
         else:
             din = (E + A) if l == 0 else Hd
         out.append(('speller/decoder_cell_%d/lstm_cell/kernel' % l, (din + Hd, 4 * Hd), 'lstm'))
         out.append(('speller/decoder_cell_%d/lstm_cell/bias' % l, (4 * Hd,), 'zeros'))
-    out.append(('speller/projection_layer/kernel', (A, V), 'proj'))
+    P = Hd if (d.bottom_only and d.num_layers > 1) else A      # AttentionMultiCell with upper layers outputs h_top
+    out.append(('speller/projection_layer/kernel', (P, V), 'proj'))
     out.append(('speller/projection_layer/bias', (V,), 'zeros'))
     if params.ctc_weight > 0:
         out.append(('ctc_logits/kernel', (M, V + 1), 'glorot'))
@@ -231,7 +232,7 @@ class LasModel:
         self.vars = Variables(param_table(params))
         self.vars.initialize(seed)
         self.listener = las_model.Listener(params.encoder, self.vars.params, params.num_channels)
-        self.speller = las_model.Speller(params.decoder, self.vars.params, _enc_depth(params.encoder))
+        self.speller = las_model.make_speller(params.decoder, self.vars.params, _enc_depth(params.encoder))
         self.ctc = CtcHead(params, self.vars.params, _enc_depth(params.encoder)) if params.ctc_weight > 0 else None
         self.global_step = 0
         self.rng_seed = (seed * 2654435761 + 12345) & 0x7fffffff      # base of the dropout / sampling draws
@@ -283,8 +284,10 @@ class LasModel:
             H = self.params.encoder.num_units
             dc = torch.zeros(nd, dmem.shape[0], H, dtype=torch.float32, device=dmem.device)
             dh = torch.zeros_like(dc)
-            dc[0].copy_(d_state[0])
-            dh[0].copy_(d_state[1])
+            per_layer = d_state if isinstance(d_state, list) else [d_state]     # decoder cell l <- encoder direction l
+            for l, (dcl, dhl) in enumerate(per_layer[:nd]):
+                dc[l].copy_(dcl)
+                dh[l].copy_(dhl)
             ds = (dc, dh)
         self.listener.backward(dmem, ds, g, self.overlap)
         self.overlap.join()

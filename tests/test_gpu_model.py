@@ -236,3 +236,34 @@ def test_cfg3_like_512_units_bahdanau_ctc_vs_oracle():
     for name, _, _ in model.vars.table:
         g = out['grads'][name] - ohp.l2_reg_scale * op[name]
         assert relerr(model.vars.grads[name], g) < 6e-2, name
+
+
+@pytest.mark.parametrize('kw', [
+    dict(att='luong', dec_layers=2, bottom_only=True, pass_hidden=True),                   # AttentionMultiCell, fw/bw states
+    dict(att='bahdanau', dec_layers=3, bottom_only=True, pass_hidden=False, als=32),       # + attention layer
+    dict(att='luong', dec_layers=2, bottom_only=False, pass_hidden=False),                 # the reference's default decoder
+    dict(att='bahdanau', dec_layers=1, bottom_only=False, pass_hidden=False, als=24, emb=16),   # embedding + attention layer
+], ids=['multicell2', 'multicell3_al', 'stack2', 'emb_al'])
+def test_general_decoder_configs_vs_oracle(kw):
+    O, ohp, op, model = _models(**kw)
+    from phones_las_amd.las.speller_general import GeneralSpeller
+    assert isinstance(model.speller, GeneralSpeller)
+    batch = make_batch(src_len=[12, 7, 10], tgt_len=[6, 4, 5])
+    feats, labels = to_device(batch)
+    out = O.train_step(ohp, op, None, None, 1, batch, mxu='bf16')
+    model.vars.grad.zero_()
+    loss, logits, dlogits = model.forward_train(feats, labels)
+    model.backward(dlogits)
+    torch.cuda.synchronize()
+    V = ohp.decoder.target_vocab_size
+    for b, n in enumerate([6, 4, 5]):
+        assert relerr(logits[b, :n, :V], out['aux']['logits'][b, :n]) < 2e-2
+    assert abs(float(loss) - float(out['aux']['ce'].detach())) < 2e-2 * float(out['aux']['ce'].detach())
+    for name, _, _ in model.vars.table:
+        g = out['grads'][name] - ohp.l2_reg_scale * op[name]
+        assert relerr(model.vars.grads[name], g) < 6e-2, name
+    # greedy decode runs and agrees with the oracle on the first step
+    (mem, ml), st = O.listener(batch['encoder_inputs'], batch['source_sequence_length'], op, ohp.encoder, 'bf16')
+    rl, rids, rfl, _ = O.speller_greedy(ohp, op, mem, ml, st, 'bf16')
+    pred = model.predict(feats)
+    assert relerr(pred['logits'][:, 0], rl[:, 0]) < 2e-2
