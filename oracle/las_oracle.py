@@ -422,8 +422,13 @@ class Speller:
         d, p, q = self.d, self.p, self.q
         old_att = self.attention
         x = torch.cat([inputs, old_att], 1)
+        lmask = (lambda l: None)
         if in_mask is not None:
-            x = q(x * in_mask)
+            if isinstance(in_mask, (list, tuple)):           # one mask per decoder cell (each has its own wrapper)
+                lmask = (lambda l: in_mask[l])
+                x = q(x * in_mask[0])
+            else:
+                x = q(x * in_mask)
         new_cells = []
         if d.bottom_only:
             c, h = self._cell(0, x, self.cells[0])
@@ -432,6 +437,8 @@ class Speller:
         else:
             cur = x
             for l in range(d.num_layers):
+                if l > 0 and lmask(l) is not None:
+                    cur = q(cur * lmask(l))
                 c, h = self._cell(l, cur, self.cells[l])
                 new_cells.append((c, h))
                 cur = h
@@ -449,6 +456,8 @@ class Speller:
             cur = out
             for l in range(1, d.num_layers):                                     # las/model.py:54-67
                 cur_in = torch.cat([cur, old_att], 1)
+                if lmask(l) is not None:
+                    cur_in = q(cur_in * lmask(l))
                 c, h = self._cell(l, cur_in, self.cells[l])
                 new_cells.append((c, h))
                 cur = h

@@ -11,7 +11,8 @@ composes the same kernels un-fused (LAS_DEC_CELL_ONLY / LAS_DEC_ATTENTION_ONLY) 
   default:          x0=[emb(y), att_{t-1}] -> cell0 -> ... -> cell_top -> attention(h_top) -> att_t; output = att_t
   att_t = Dense([query, context]) if attention_layer_size else context.
 
-Input dropout and scheduled sampling are only implemented on the fused fast path (ValueError here)."""
+Input dropout (DropoutWrapper on every cell's input: the GEMM operand is dropped in place, the one-hot token through
+the kernel's token scale) and scheduled sampling work as on the fused path; dropout + embedding raises."""
 import ctypes as C
 
 import torch
@@ -36,9 +37,9 @@ class GeneralSpeller:
 
     def __init__(self, hparams, variables, memory_depth, att_code):
         d = hparams
-        if (d.dropout or 0.0) > 0 or (d.sampling_probability or 0.0) > 0:
-            raise ValueError('dropout / scheduled sampling are only implemented for the single-layer decoder without '
-                             'attention layer or embedding on the HIP path (use --dropout 0 --sampling_probability 0)')
+        if (d.dropout or 0.0) > 0 and d.embedding_size:
+            raise ValueError('dropout > 0 together with embedding_size > 0 is not implemented on the HIP path '
+                             '(element-wise dropout of the embedded token needs its own product)')
         self.hp = d
         self.att = att_code
         self.NL, self.bottom = d.num_layers, bool(d.bottom_only)
@@ -83,6 +84,13 @@ class GeneralSpeller:
             self.wq_t = torch.empty(Hd, Hd, dtype=bf, device=dev)
         self.refresh(variables)
         self.saved = None
+
+    DEC_STREAM = 1                       # token-scale draws of cell 0 (decoder index scheme of las_dec_step)
+
+    @staticmethod
+    def in_stream(l, t):
+        """generator stream of the input mask of cell l at step t (element index b*win_l + c)."""
+        return 64 + l * 4096 + t
 
     @staticmethod
     def cell_names(l):
@@ -154,6 +162,8 @@ class GeneralSpeller:
         s.c_out, s.ldco = hip.addr(sv['cs'][l], (t + 1) * Hd), (U + 1) * Hd
         s.h_out, s.ldh = hip.addr(sv['h'][l], t * Hd), U * Hd
         s.drop_keep, s.feed_width = 1.0, self.E + self.A
+        if l == 0 and sv['keep'] < 1.0:      # the one-hot token entry survives with probability keep (scaled 1/keep)
+            s.drop_keep, s.drop_seed, s.drop_stream, s.step = sv['keep'], sv['seed'], self.DEC_STREAM, t
         hip.check(hip.lib().las_decoder_step_fwd(C.byref(s), 1, hip.stream()))
 
     def _attention_fwd(self, t, sv, query, ldq):
@@ -179,7 +189,10 @@ class GeneralSpeller:
         init, passed = self._init_states(encoder_state, B)
         keys = torch.empty(B, Tm, Hd, dtype=bf, device=dev)
         hip.gemm_nt(memory, self.wmemT, keys, B * Tm, Hd, M, lda=M, ldb=M, ldc=Hd, out_bf16=True)
-        sv = dict(B=B, Tm=Tm, U=U, memory=memory, mem_len=mem_len, keys=keys, passed=passed, tin=targets_inputs)
+        keep = 1.0 - float(self.hp.dropout or 0.0)
+        sampling = float(self.hp.sampling_probability or 0.0)
+        sv = dict(B=B, Tm=Tm, U=U, memory=memory, mem_len=mem_len, keys=keys, passed=passed, tin=targets_inputs,
+                  keep=keep, seed=seed)
         sv['X'] = [torch.zeros(B, U, w + Hd, dtype=bf, device=dev) for w in self.win]
         sv['gates'] = [torch.empty(B, U, 4 * Hd, dtype=f32, device=dev) for _ in range(NL)]
         sv['cs'] = [torch.empty(B, U + 1, Hd, dtype=f32, device=dev) for _ in range(NL)]
@@ -195,6 +208,13 @@ class GeneralSpeller:
             sv['X'][l][:, 0, self.win[l]:].copy_(init[l][1])        # h_{l,-1}; attention_{-1} = 0
         z = torch.empty(B, 4 * Hd, dtype=f32, device=dev)
         tin = targets_inputs
+        fed = tin
+        logits = None
+        if sampling > 0.0:               # scheduled sampling (utils/training_helper.py:48-87)
+            fed = tin[:, :U].contiguous().clone()
+            logits = torch.empty(B, U, Vp, dtype=f32, device=dev)
+        sv['fed'] = fed
+        lib, st = hip.lib(), hip.stream()
         X, h, att = sv['X'], sv['h'], sv['att']
         qlayer = 0 if self.bottom else NL - 1                       # the cell whose output queries the attention
         for t in range(U):
@@ -202,8 +222,11 @@ class GeneralSpeller:
 
             def run_cell(l):
                 Kl = self.win[l] + Hd
+                if keep < 1.0:            # DropoutWrapper on this cell's input: drop the GEMM operand in place
+                    hip.check(lib.las_dropout_bf16(hip.addr(X[l], t * Kl), U * Kl, hip.addr(X[l], t * Kl), U * Kl, B,
+                                                   self.win[l], keep, seed, self.in_stream(l, t), st))
                 hip.gemm_nt(X[l][:, t], self.kT[l], z, B, 4 * Hd, Kl, lda=U * Kl, ldb=Kl, ldc=4 * Hd)
-                self._cell_fwd(l, t, sv, z, hip.addr(tin, t), tin.stride(0))
+                self._cell_fwd(l, t, sv, z, hip.addr(fed, t), fed.stride(0))
                 if not last:
                     X[l][:, t + 1, self.win[l]:].copy_(h[l][:, t])     # recurrent input of the next step
 
@@ -230,10 +253,18 @@ class GeneralSpeller:
                     for l in range(1, NL):
                         wc = A if l == 1 else Hd
                         X[l][:, t + 1, wc:wc + A].copy_(att[:, t])
+            if sampling > 0.0:
+                out_t = h[NL - 1][:, t] if (self.bottom and NL > 1) else att[:, t]
+                hip.gemm_nt(out_t, self.wprojT, logits[:, t], B, Vp, self.P, lda=out_t.stride(0), ldb=self.P, ldc=U * Vp,
+                            bias=self.bproj)
+                if not last:
+                    hip.check(lib.las_sample_tokens(hip.addr(logits, t * Vp), U * Vp, V, hip.addr(tin, t + 1), tin.stride(0),
+                                                    hip.addr(fed, t + 1), fed.stride(0), B, sampling, seed, t, st))
         out_all = h[NL - 1] if (self.bottom and NL > 1) else att
         sv['out'] = out_all
-        logits = torch.empty(B, U, Vp, dtype=f32, device=dev)
-        hip.gemm_nt(out_all, self.wprojT, logits, B * U, Vp, self.P, lda=self.P, ldb=self.P, ldc=Vp, bias=self.bproj)
+        if logits is None:
+            logits = torch.empty(B, U, Vp, dtype=f32, device=dev)
+            hip.gemm_nt(out_all, self.wprojT, logits, B * U, Vp, self.P, lda=self.P, ldb=self.P, ldc=Vp, bias=self.bproj)
         self.saved = sv
         return logits
 
@@ -293,6 +324,9 @@ class GeneralSpeller:
                 rec = v(dx[l][nxt], self.win[l], W[l]) if has_next else None
                 self._cell_bwd(l, t, sv, dc[l], list(sources) + [rec], dz[l])
                 hip.gemm_nt(dz[l][:, t], self.kn[l], dx[l][cur], B, W[l], 4 * Hd, lda=U * 4 * Hd, ldb=4 * Hd, ldc=W[l])
+                if sv['keep'] < 1.0:      # gradient through this cell's input dropout (mask regenerated), in place
+                    hip.check(lib.las_add_masked(None, 0, hip.p(dx[l][cur]), W[l], hip.p(dx[l][cur]), W[l], B, self.win[l],
+                                                 sv['keep'], sv['seed'], self.in_stream(l, t), 0, self.win[l], st))
 
             if self.bottom:
                 for l in range(NL - 1, 0, -1):
@@ -363,8 +397,9 @@ class GeneralSpeller:
             hip.colsum_bf16(dz[l], BU, 4 * Hd, grads[bn], ldx=4 * Hd)
         # token part of cell 0: d(rows) = onehot^T dz_0, then through the embedding if there is one
         onehot = torch.empty(BU, Vp, dtype=bf, device=dev)
-        tin = sv['tin']
-        hip.check(lib.las_onehot_bf16(hip.p(tin), tin.stride(0), B, U, V, hip.p(onehot), Vp, 1.0, 0, 0, self.E + A, st))
+        fed = sv['fed']
+        hip.check(lib.las_onehot_bf16(hip.p(fed), fed.stride(0), B, U, V, hip.p(onehot), Vp, sv['keep'], sv['seed'],
+                                      self.DEC_STREAM, self.E + A, st))
         k0 = grads[self.cell_names(0)[0]]
         if not self.emb:
             hip.gemm_tn(onehot, dz[0], k0, V, 4 * Hd, BU, lda=Vp, ldb=4 * Hd, ldc=4 * Hd, split_k=4)
@@ -399,7 +434,7 @@ class GeneralSpeller:
         hip.gemm_nt(memory, self.wmemT, keys, B * Tm, Hd, M, lda=M, ldb=M, ldc=Hd, out_bf16=True)
         Tmp = _r8(Tm)
         U = max(S, 1)
-        sv = dict(B=B, Tm=Tm, U=U, memory=memory, mem_len=mem_len, keys=keys)
+        sv = dict(B=B, Tm=Tm, U=U, memory=memory, mem_len=mem_len, keys=keys, keep=1.0, seed=0)
         sv['X'] = [torch.zeros(B, U, w + Hd, dtype=bf, device=dev) for w in self.win]
         sv['gates'] = [torch.empty(B, U, 4 * Hd, dtype=f32, device=dev) for _ in range(NL)]
         sv['cs'] = [torch.empty(B, U + 1, Hd, dtype=f32, device=dev) for _ in range(NL)]

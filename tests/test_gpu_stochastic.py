@@ -12,17 +12,18 @@ pytestmark = pytest.mark.gpu
 DT = torch.float64
 
 
-def _build(dropout=0.0, sampling=0.0, att='luong'):
+def _build(dropout=0.0, sampling=0.0, att='luong', dec_layers=1, bottom_only=True, pass_hidden=True):
     from oracle import las_oracle as O
     from phones_las_amd import model_helper as mh
     from phones_las_amd.utils import params_utils as pu
     F, L, H, V = 13, 2, 64, 11
     ohp = O.HP(encoder=O.EncoderHP(num_layers=L, num_units=H), num_channels=F,
-               decoder=O.DecoderHP(num_layers=1, num_units=H, target_vocab_size=V, attention_type=att, bottom_only=True,
-                                   pass_hidden_state=True))
+               decoder=O.DecoderHP(num_layers=dec_layers, num_units=H, target_vocab_size=V, attention_type=att,
+                                   bottom_only=bottom_only, pass_hidden_state=pass_hidden))
     hp = pu.get_default_hparams()
-    for k, v in dict(num_channels=F, encoder_layers=L, encoder_units=H, use_pyramidal=True, decoder_layers=1,
-                     decoder_units=H, target_vocab_size=V, attention_type=att, bottom_only=True, pass_hidden_state=True,
+    for k, v in dict(num_channels=F, encoder_layers=L, encoder_units=H, use_pyramidal=True, decoder_layers=dec_layers,
+                     decoder_units=H, target_vocab_size=V, attention_type=att, bottom_only=bottom_only,
+                     pass_hidden_state=pass_hidden,
                      dropout=dropout, sampling_probability=sampling).items():
         hp.set_hparam(k, v)
     params = pu.get_encoder_decoder_hparams(hp)
@@ -114,3 +115,43 @@ def test_sampled_tokens_follow_the_logits():
     hip.check(hip.lib().las_sample_tokens(hip.p(logits), V, V, hip.p(teacher), 1, hip.p(nxt), 1, B, 0.25, 123, 5, hip.stream()))
     kept = float((nxt == 7).float().mean())                      # teacher kept w.p. 0.75 (+ sampled 7s: 0.25 * 0.0695)
     assert abs(kept - (0.75 + 0.25 * 0.0695)) < 0.04
+
+
+@pytest.mark.parametrize('bottom', [False, True], ids=['stack2', 'multicell2'])
+def test_general_decoder_dropout_and_sampling_replayed(bottom):
+    # the reference's default decoder shape (2 layers) with its default stochastic training pieces switched on
+    keep = 0.75
+    O, ohp, op, model = _build(dropout=1 - keep, sampling=0.4, dec_layers=2, bottom_only=bottom, pass_hidden=bottom)
+    sp = model.speller
+    batch = make_batch(src_len=[12, 7, 10], tgt_len=[6, 4, 5])
+    feats, labels = to_device(batch)
+    model.vars.grad.zero_()
+    loss, logits, dlogits = model.forward_train(feats, labels)
+    fed = sp.saved['fed'].cpu().long()
+    model.backward(dlogits)
+    torch.cuda.synchronize()
+    seed = model.last_seed
+    B, T, F, H, V, M, U = 3, 12, 13, 64, 11, 256, 6
+    enc_masks = []
+    for l, (Tl, Dp, D) in enumerate([(12, 16, F), (12, 2 * H, 2 * H)]):
+        enc_masks.append(tuple(_mask(B * Tl * Dp, keep, seed, 16 + 2 * l + d).reshape(B, Tl, Dp)[..., :D] for d in range(2)))
+    fw = V + sp.A
+    tokm = _mask(U * B * fw, keep, seed, sp.DEC_STREAM).reshape(U, B, fw)[:, :, :V]
+    dec_masks = []
+    for t in range(U):
+        per_layer = []
+        for l in range(2):
+            m = _mask(B * sp.win[l], keep, seed, sp.in_stream(l, t)).reshape(B, sp.win[l])
+            per_layer.append(torch.cat([tokm[t], m], 1) if l == 0 else m)
+        dec_masks.append(per_layer)
+    tin = batch['targets_inputs']
+    changed = (fed[:, 1:U] != tin[:, 1:U])
+    sel = [changed[:, t] for t in range(U - 1)] + [torch.zeros(3, dtype=torch.bool)]
+    ids = [fed[:, t + 1] for t in range(U - 1)] + [torch.zeros(3, dtype=torch.long)]
+    out = O.train_step(ohp, op, None, None, 1, batch, mxu='bf16',
+                       stochastic={'enc_masks': enc_masks, 'dec_masks': dec_masks, 'sample_select': sel, 'sample_ids': ids})
+    for b, n in enumerate([6, 4, 5]):
+        assert relerr(logits[b, :n, :V], out['aux']['logits'][b, :n]) < 3e-2
+    for name, _, _ in model.vars.table:
+        g = out['grads'][name] - ohp.l2_reg_scale * op[name]
+        assert relerr(model.vars.grads[name], g) < 8e-2, name
