@@ -47,3 +47,18 @@ def test_train_resume_infer(tmp_path, capsys):
                                        '--num_channels', '13', '--batch_size', '8']))
     assert per < 40.0
     assert len(open(os.path.join(d, 'model', 'infer.txt')).read().split('\n')) == 16
+
+
+def test_train_with_the_reference_default_architecture_flags(tmp_path, capsys):
+    # train.py defaults (train.py:34-75): stacked (non-pyramidal) 3x128 BiLSTM listener, 2x128 decoder wrapped by Luong
+    # attention, dropout 0.2, sampling_probability 0.1 -- only the data-dependent flags are given
+    import train
+    d = str(tmp_path)
+    _corpus(d, n=8)
+    train.main(train.parse_args(['--train', os.path.join(d, 'train.tfr'), '--model_dir', os.path.join(d, 'model'),
+                                 '--num_channels', '13', '--batch_size', '8', '--num_epochs', '30']))
+    out = capsys.readouterr().out
+    assert 'finished at global_step 30' in out
+    first = float(out.split('step 10: loss = ')[1].split()[0])
+    last = float(out.split('step 30: loss = ')[1].split()[0])
+    assert np.isfinite(last) and last < first
