@@ -28,11 +28,45 @@ typedef __attribute__((address_space(1))) u64 gu64;
 
 constexpr unsigned SPIN_LIMIT = 1u << 20;
 
-__device__ __forceinline__ void granule_store(u64* p, unsigned tag, unsigned value) {
-  __hip_atomic_store(p, ((u64)tag << 32) | value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+// `local`: every member of the group runs on the SAME XCD (established at kernel start, see xcd_colocated): the
+// XCD's L2 is then the coherence point, so a plain store (line stays in L2) plus the peers' L1-bypassing loads is
+// enough and a poll costs an L2 hit instead of a fabric round trip.  Otherwise the write-through agent-scope store.
+__device__ __forceinline__ void granule_store(u64* p, unsigned tag, unsigned value, bool local) {
+  const u64 x = ((u64)tag << 32) | value;
+  if (local) *p = x;
+  else __hip_atomic_store(p, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 __device__ __forceinline__ u64 granule_load(const u64* p) {
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// Do all G members of this group sit on one XCD?  Each member publishes its XCC id with the placement-independent
+// write-through store, then reads everybody's.  Purely a speed decision: the result only selects the store flavour.
+// Call from all threads; returns the same value in every thread of the workgroup (fail -> false).
+template <int G>
+__device__ bool xcd_colocated(u64* table, int member, int* lds_flag, unsigned* status) {
+  if (G == 1) return false;
+  if (threadIdx.x == 0) {
+    unsigned xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    xcc &= 0xf;
+    __hip_atomic_store(table + member, ((u64)1 << 32) | (xcc + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    bool same = true;
+    for (int m = 0; m < G; ++m) {
+      u64 v = 0;
+      unsigned spins = 0;
+      do {
+        v = __hip_atomic_load(table + m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((v >> 32) == 1) break;
+        __builtin_amdgcn_s_sleep(2);
+      } while (++spins < (1u << 20));
+      same = same && ((v >> 32) == 1) && ((unsigned)v == xcc + 1);
+    }
+    *lds_flag = same ? 1 : 0;
+    atomicAdd(status + (same ? 1 : 2), 1u);      // diagnostics: members that took the local / the fabric flavour
+  }
+  __syncthreads();
+  return *lds_flag != 0;
 }
 
 // number of cooperating workgroups per chain
@@ -92,7 +126,9 @@ __global__ __launch_bounds__(rec_threads(H)) void lstm_fwd_kernel(float* __restr
   __shared__ __attribute__((aligned(16))) float red[KS > 1 ? 2 * 4 * 64 * 4 : 4];   // partial sums of the upper K half
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int group = blockIdx.x % ngroups, member = blockIdx.x / ngroups;
+  const int gstride = (ngroups + 7) & ~7;        // members of a group are 8k blocks apart: one XCD under round-robin
+  const int group = blockIdx.x % gstride, member = blockIdx.x / gstride;
+  if (group >= ngroups) return;
   const int nslices = ngroups / ndir;
   const int slice = group % nslices, dir = group / nslices;
   const int l15 = lane & 15, lq = lane >> 4;
@@ -134,6 +170,8 @@ __global__ __launch_bounds__(rec_threads(H)) void lstm_fwd_kernel(float* __restr
   for (int i = tid; i < 2 * 16 * LS; i += rec_threads(H)) (&hlds[0][0][0])[i] = 0;
   if (tid == 0) fail_flag = 0;
   __syncthreads();
+  __shared__ int colo_flag;
+  const bool local = xcd_colocated<G>(exch + (int64_t)2 * ngroups * G * NGRAN + (int64_t)group * G, member, &colo_flag, status);
 
   const int64_t xrow = (int64_t)ndir * 4 * H;
   const int64_t yrow = (int64_t)ndir * H;
@@ -282,8 +320,8 @@ __global__ __launch_bounds__(rec_threads(H)) void lstm_fwd_kernel(float* __restr
         hlds[cur ^ 1][lq * 4 + r][unit] = hb[r];
       }
       if constexpr (G > 1) {
-        granule_store(dst + (lq * 2) * HS + ul, (unsigned)(s + 1), (unsigned)hb[0] | ((unsigned)hb[1] << 16));
-        granule_store(dst + (lq * 2 + 1) * HS + ul, (unsigned)(s + 1), (unsigned)hb[2] | ((unsigned)hb[3] << 16));
+        granule_store(dst + (lq * 2) * HS + ul, (unsigned)(s + 1), (unsigned)hb[0] | ((unsigned)hb[1] << 16), local);
+        granule_store(dst + (lq * 2 + 1) * HS + ul, (unsigned)(s + 1), (unsigned)hb[2] | ((unsigned)hb[3] << 16), local);
       }
     }
     }   // lead
@@ -330,7 +368,9 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_kernel(const float* __restric
   f32x4* rbuf = reinterpret_cast<f32x4*>(smem + (size_t)2 * 16 * ZS * sizeof(unsigned short) + 16);   // [2][64] (KS > 1)
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int group = blockIdx.x % ngroups, member = blockIdx.x / ngroups;
+  const int gstride = (ngroups + 7) & ~7;
+  const int group = blockIdx.x % gstride, member = blockIdx.x / gstride;
+  if (group >= ngroups) return;
   const int nslices = ngroups / ndir;
   const int slice = group % nslices, dir = group / nslices;
   const int l15 = lane & 15, lq = lane >> 4;
@@ -370,6 +410,8 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_kernel(const float* __restric
     }
   if (tid == 0) fail_flag = 0;
   __syncthreads();
+  int* colo_flag = reinterpret_cast<int*>(smem + (size_t)2 * 16 * ZS * sizeof(unsigned short)) + 1;
+  const bool local = xcd_colocated<G>(exch + (int64_t)2 * ngroups * G * NGRAN + (int64_t)group * G, member, colo_flag, status);
 
   const int64_t grow = (int64_t)ndir * 4 * H;
   const int64_t yrow = (int64_t)ndir * H;
@@ -443,8 +485,8 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_kernel(const float* __restric
       if constexpr (G > 1) {
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-          granule_store(dst + ((lq * 2) * 4 + g) * HS + ul, epoch, (unsigned)zb[g][0] | ((unsigned)zb[g][1] << 16));
-          granule_store(dst + ((lq * 2 + 1) * 4 + g) * HS + ul, epoch, (unsigned)zb[g][2] | ((unsigned)zb[g][3] << 16));
+          granule_store(dst + ((lq * 2) * 4 + g) * HS + ul, epoch, (unsigned)zb[g][0] | ((unsigned)zb[g][1] << 16), local);
+          granule_store(dst + ((lq * 2 + 1) * 4 + g) * HS + ul, epoch, (unsigned)zb[g][2] | ((unsigned)zb[g][3] << 16), local);
         }
       }
     }
@@ -521,9 +563,9 @@ CoopGeom geom(int B, int H, int ndir, bool bwd) {
   g.G = coop_members(H);
   g.nslices = (B + 15) / 16;
   g.ngroups = g.nslices * ndir;
-  g.blocks = g.ngroups * g.G;
+  g.blocks = ((g.ngroups + 7) & ~7) * g.G;        // group stride rounded up to 8 (idle blocks exit at once)
   const size_t ngran = (size_t)8 * (H / g.G) * (bwd ? 4 : 1);
-  g.exch_bytes = g.G > 1 ? (size_t)2 * g.ngroups * g.G * ngran * sizeof(u64) : 0;
+  g.exch_bytes = g.G > 1 ? ((size_t)2 * g.ngroups * g.G * ngran + (size_t)g.ngroups * g.G) * sizeof(u64) : 0;   // + XCC-id table
   return g;
 }
 
