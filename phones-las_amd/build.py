@@ -11,7 +11,9 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
-OUT = os.path.join(HERE, 'liblas_hip.so')
+OUT = os.environ.get('LAS_HIP_LIB') or os.path.join(HERE, 'liblas_hip.so')
+EXTRA = os.environ.get('LAS_CXXFLAGS', '').split()     # e.g. -DLAS_STAMPS for the diagnostics build
+OBJDIR = os.path.join(HERE, 'build' + ('_' + '_'.join(x.strip('-') for x in EXTRA) if EXTRA else ''))
 
 
 def sources():
@@ -32,11 +34,11 @@ def build(force=False, verbose=True):
     hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
     objs = []
     procs = []
-    os.makedirs(os.path.join(HERE, 'build'), exist_ok=True)
+    os.makedirs(OBJDIR, exist_ok=True)
     for src in sources():
-        obj = os.path.join(HERE, 'build', os.path.basename(src) + '.o')
+        obj = os.path.join(OBJDIR, os.path.basename(src) + '.o')
         objs.append(obj)
-        cmd = [hipcc, '-O3', '--offload-arch=gfx950', '-std=c++17', '-fPIC', '-Wno-unused-value', '-c', src, '-o', obj]
+        cmd = [hipcc, '-O3', '--offload-arch=gfx950', '-std=c++17', '-fPIC', '-Wno-unused-value'] + EXTRA + ['-c', src, '-o', obj]
         procs.append((cmd, subprocess.Popen(cmd)))
     for cmd, p in procs:
         if p.wait() != 0:

@@ -32,11 +32,13 @@ int las_check_hip(hipError_t e, const char* what);
     if (_rc) return _rc;                                         \
   } while (0)
 
-__device__ __forceinline__ float las_sigmoid(float x) { return 1.0f / (1.0f + __expf(-x)); }
+// v_exp_f32 + v_rcp_f32 (1 ulp each): an IEEE divide is a ten-instruction sequence, and the gate math sits on the
+// critical path of every recurrent step.  Limits stay exact: rcp(inf) = 0, rcp(1) = 1.
+__device__ __forceinline__ float las_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 __device__ __forceinline__ float las_tanh(float x) {
-  // tanh(x) = 1 - 2/(exp(2x)+1); exact limits at +-inf, abs error ~1e-7
+  // tanh(x) = 1 - 2/(exp(2x)+1); abs error ~2e-7
   float e = __expf(2.0f * x);
-  return 1.0f - 2.0f / (e + 1.0f);
+  return 1.0f - 2.0f * __builtin_amdgcn_rcpf(e + 1.0f);
 }
 __device__ __forceinline__ unsigned short las_f2bf(float x) {
   __bf16 b = (__bf16)x;

@@ -20,6 +20,8 @@
 // of a group share an XCD under round-robin dispatch when ngroups % 8 == 0 (speed).  Every spin is
 // bounded: on timeout the kernel sets a status word and returns.
 #include "las_common.h"
+#include <stdlib.h>
+#include <type_traits>
 
 namespace {
 
@@ -27,6 +29,13 @@ typedef unsigned long long u64;
 typedef __attribute__((address_space(1))) u64 gu64;
 
 constexpr unsigned SPIN_LIMIT = 1u << 20;
+
+// Workgroup barrier that only orders LDS traffic.  __syncthreads() also drains vmcnt, i.e. waits until every global
+// store of the step has been acknowledged, which puts that round trip on the critical path of every step.
+__device__ __forceinline__ void lds_barrier() {
+  __builtin_amdgcn_s_waitcnt(0xC07F);      // lgkmcnt(0) only (vmcnt, expcnt untouched)
+  __builtin_amdgcn_s_barrier();
+}
 
 // `local`: every member of the group runs on the SAME XCD (established at kernel start, see xcd_colocated): the
 // XCD's L2 is then the coherence point, so a plain store (line stays in L2) plus the peers' L1-bypassing loads is
@@ -98,19 +107,17 @@ __global__ void pack_recurrent_kernel(const float* kh, int H, unsigned short* pa
 // ------------------------------------------------------------------------------------------------
 // forward
 // ------------------------------------------------------------------------------------------------
-// Workgroup size: 4 compute waves, plus one PREFETCH wave when the chain is shared by several workgroups.  The
-// prefetch wave only touches (loads and discards) the cache lines the compute waves will need PF_DIST steps
-// later, so their own loads hit L2 instead of HBM: a wave's vmcnt retires in order, so a slow HBM load issued by
-// a compute wave would delay the return of its next inter-workgroup poll.
-__host__ __device__ constexpr int rec_threads(int H) { return coop_members(H) > 1 ? 320 : 256; }
-constexpr int PF_DIST = 3;
+// Workgroup size: 4 compute waves, one per SIMD (512-register budget).  When the chain is shared by several workgroups
+// every compute workgroup has a PREFETCH COMPANION workgroup (see the kernel) that keeps its HBM operands L2-resident.
+__host__ __device__ constexpr int rec_threads(int H) { return 256; }
 
 template <int H>
-__global__ __launch_bounds__(rec_threads(H)) void lstm_fwd_kernel(float* __restrict__ xproj, const unsigned short* __restrict__ wpacked,
-                                                          const int32_t* __restrict__ length, unsigned short* __restrict__ y,
-                                                          float* __restrict__ cbuf, float* __restrict__ c_last,
-                                                          float* __restrict__ h_last, u64* __restrict__ exch,
-                                                          unsigned* __restrict__ status, int B, int T, int ndir, int ngroups) {
+__global__ __launch_bounds__(256) void lstm_fwd_kernel(float* __restrict__ xproj, const unsigned short* __restrict__ wpacked,
+                                                       const int32_t* __restrict__ length, unsigned short* __restrict__ y,
+                                                       float* __restrict__ cbuf, float* __restrict__ c_last,
+                                                       float* __restrict__ h_last, u64* __restrict__ exch,
+                                                       unsigned* __restrict__ status, int B, int T, int ndir, int ngroups,
+                                                       int companions) {
   constexpr int G = coop_members(H);
   constexpr int HS = H / G;            // units per member
   constexpr int KS = k_split(H);       // ways the K dimension is split over waves
@@ -120,28 +127,78 @@ __global__ __launch_bounds__(rec_threads(H)) void lstm_fwd_kernel(float* __restr
   constexpr int KCW = KC / KS;         // k-chunks a wave owns
   constexpr int LS = H + 8;            // LDS row stride (elements)
   constexpr int NGRAN = 8 * HS;        // granules a member publishes per step (2 rows x 1 unit each)
+  constexpr int PER = G > 1 ? (G - 1) * NGRAN / 256 : 1;   // granules a thread polls per step
   __shared__ __attribute__((aligned(16))) unsigned short hlds[2][16][LS];
   __shared__ int fail_flag;
-  __shared__ __attribute__((aligned(16))) float pf_scratch[256];   // 1 KiB sink of the prefetch wave's LDS-DMAs
+  __shared__ int colo_flag;
+  __shared__ __attribute__((aligned(16))) float pf_scratch[256];   // 1 KiB sink of the companion's LDS-DMAs
   __shared__ __attribute__((aligned(16))) float red[KS > 1 ? 2 * 4 * 64 * 4 : 4];   // partial sums of the upper K half
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int gstride = (ngroups + 7) & ~7;        // members of a group are 8k blocks apart: one XCD under round-robin
-  const int group = blockIdx.x % gstride, member = blockIdx.x / gstride;
+  const int nblk = gstride * G;                  // compute workgroups; blocks beyond them are their prefetch companions
+  const bool companion = (int)blockIdx.x >= nblk;
+  const int cblk = companion ? blockIdx.x - nblk : blockIdx.x;
+  const int group = cblk % gstride, member = cblk / gstride;
   if (group >= ngroups) return;
   const int nslices = ngroups / ndir;
   const int slice = group % nslices, dir = group / nslices;
   const int l15 = lane & 15, lq = lane >> 4;
+  const int64_t xrow = (int64_t)ndir * 4 * H;
+  const int64_t yrow = (int64_t)ndir * H;
+  const int64_t par_stride = (int64_t)ngroups * G * NGRAN;     // granules per parity slot
+  u64* ex_group = exch + (int64_t)group * G * NGRAN;           // + parity*par_stride + member*NGRAN
+  u64* done_word = exch + 2 * par_stride + (int64_t)ngroups * G + cblk;
 
   int len[4], bidx[4];
-  int smax = 0;
+  int smax = 0, smin = 0x7fffffff;
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     bidx[r] = slice * 16 + lq * 4 + r;
     len[r] = (bidx[r] < B) ? min(length[bidx[r]], T) : 0;
     smax = max(smax, len[r]);
+    smin = min(smin, len[r]);
   }
   smax = (int)las_wave_max((float)smax);
+  smin = -(int)las_wave_max((float)(-smin));       // steps every utterance of the slice is still running: the lean path
+  if ((int64_t)B * T * xrow * 4 >= ((int64_t)1 << 32)) smin = 0;     // 32-bit byte offsets do not reach: general path only
+
+  if constexpr (G > 1) if (companion) {
+    // PREFETCH COMPANION: a workgroup on another CU of the same XCD (block index = compute block + 8k) pulls the
+    // compute workgroup's xproj lines into the shared L2 PF_AHEAD steps before they are needed (1-KiB LDS-DMAs into a
+    // scratch tile nobody reads), so the compute CU's in-order vector-memory queue only ever sees L2 hits.  It paces
+    // itself on the epoch tags of the compute workgroup's own granules and leaves when the done word is set.
+    constexpr int PF_AHEAD = 6;
+    const int mylen = (slice * 16 + l15 < B) ? min(length[slice * 16 + l15], T) : 0;
+    const u64* tag0 = ex_group + (int64_t)member * NGRAN;
+    int seen = -1;
+    for (int sp = 0; sp < smax; ++sp) {
+      unsigned spins = 0;
+      while (seen < sp - PF_AHEAD) {
+        const u64 v0 = granule_load(tag0), v1 = granule_load(tag0 + par_stride), dn = granule_load(done_word);
+        if (dn != 0) return;                                      // the compute workgroup is done (or failed)
+        seen = (int)max((unsigned)(v0 >> 32), (unsigned)(v1 >> 32)) - 1;
+        if (seen < sp - PF_AHEAD) {
+          if (++spins > SPIN_LIMIT) return;
+          __builtin_amdgcn_s_sleep(8);
+        }
+      }
+#pragma unroll
+      for (int r4 = 0; r4 < 4; ++r4) {
+        const int rr = wave * 4 + r4;
+        const int ll = __builtin_amdgcn_readlane(mylen, rr);
+        if (sp < ll) {
+          const int pos = dir == 0 ? sp : ll - 1 - sp;
+          const float* src = xproj + ((int64_t)(slice * 16 + rr) * T + pos) * xrow + dir * 4 * H + member * HS * 4 +
+                             (lane % (HS > 64 ? 64 : HS)) * 4;
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src),
+                                           (__attribute__((address_space(3))) void*)(pf_scratch), 16, 0, 0);
+        }
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    return;
+  }
 
   // register-resident B fragments of this wave's K_h columns
   // wave -> (first unit block, K half): KS = 1: 4 waves x UB blocks, all of K; KS = 2: wave&1 = block, wave>>1 = K half
@@ -149,7 +206,6 @@ __global__ __launch_bounds__(rec_threads(H)) void lstm_fwd_kernel(float* __restr
   const int kh = KS > 1 ? (wave >> 1) & 1 : 0;
   const bool lead = (kh == 0);          // the wave that finishes the step for its units
   bf16x8 wf[UB][KCW][4];
-  if (wave < 4)
 #pragma unroll
   for (int ub = 0; ub < UB; ++ub) {
     const int ublk = member * NUB + wblk + ub;
@@ -160,6 +216,7 @@ __global__ __launch_bounds__(rec_threads(H)) void lstm_fwd_kernel(float* __restr
         wf[ub][kc][g] = *reinterpret_cast<const bf16x8*>(wpacked + (int64_t)dir * H * 4 * H +
                                                           ((int64_t)((ublk * KC + kh * KCW + kc) * 4 + g) * 64 + lane) * 8);
   }
+  __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0): the weights are in registers before the time loop, not waited for inside it
 
   float c[UB][4], h[UB][4];
 #pragma unroll
@@ -167,105 +224,94 @@ __global__ __launch_bounds__(rec_threads(H)) void lstm_fwd_kernel(float* __restr
 #pragma unroll
     for (int r = 0; r < 4; ++r) { c[ub][r] = 0.f; h[ub][r] = 0.f; }
 
-  for (int i = tid; i < 2 * 16 * LS; i += rec_threads(H)) (&hlds[0][0][0])[i] = 0;
+  for (int i = tid; i < 2 * 16 * LS; i += 256) (&hlds[0][0][0])[i] = 0;
   if (tid == 0) fail_flag = 0;
   __syncthreads();
-  __shared__ int colo_flag;
-  const bool local = xcd_colocated<G>(exch + (int64_t)2 * ngroups * G * NGRAN + (int64_t)group * G, member, &colo_flag, status);
+  const bool local = xcd_colocated<G>(exch + 2 * par_stride + (int64_t)group * G, member, &colo_flag, status);
 
-  const int64_t xrow = (int64_t)ndir * 4 * H;
-  const int64_t yrow = (int64_t)ndir * H;
   const int unit0 = member * HS + wblk * 16 + l15;            // + ub*16
-  u64* ex_group = exch + (int64_t)group * G * NGRAN;           // + parity*ngroups*G*NGRAN + member*NGRAN
 
+  // loop-invariant pieces of the exchange: which granules this thread polls and where their halves go in the LDS tile
+  unsigned poll_off[PER], scat_off[PER];
   if constexpr (G > 1) {
-    if (wave == 4) {
-      // prefetch wave: per step and utterance one 1-KiB LDS-DMA (global_load_lds, 16 B per lane) of this member's
-      // gate-interleaved xproj span into a scratch tile nobody reads: no VGPR destination, nothing to wait for.
-      // It uses the raw s_barrier (a __syncthreads() would drain the DMAs first).
-      const int mylen = (slice * 16 + l15 < B) ? min(length[slice * 16 + l15], T) : 0;
-      for (int s = 0; s < smax; ++s) {
-        const int sp = s + PF_DIST;
 #pragma unroll
-        for (int rr = 0; rr < 16; ++rr) {
-          const int ll = __builtin_amdgcn_readlane(mylen, rr);
-          if (sp < ll) {
-            const int pos = dir == 0 ? sp : ll - 1 - sp;
-            const float* src = xproj + ((int64_t)(slice * 16 + rr) * T + pos) * xrow + dir * 4 * H + member * HS * 4 +
-                               (lane % (HS > 64 ? 64 : HS)) * 4;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src),
-                                             (__attribute__((address_space(3))) void*)(pf_scratch), 16, 0, 0);
-          }
-        }
-        __builtin_amdgcn_s_barrier();
-        if (*reinterpret_cast<volatile int*>(&fail_flag)) break;
-        if constexpr (KS > 1) __builtin_amdgcn_s_barrier();      // the compute waves' partial-sum hand-off barrier
-      }
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      return;
+    for (int i = 0; i < PER; ++i) {
+      const int q = tid + i * 256;
+      const int pi = q / NGRAN, gi = q % NGRAN;
+      const int peer = pi + (pi >= member ? 1 : 0);
+      poll_off[i] = (unsigned)(peer * NGRAN + gi) * 8u;                              // bytes inside the group's parity slot
+      scat_off[i] = (unsigned)((gi / HS) * 2 * LS + peer * HS + gi % HS);           // element of row pair (rp*2, rp*2+1)
     }
   }
+  // lean path: byte offsets of this lane's four rows at the current step (xproj; cbuf = /4, y = /8: same row index)
+  unsigned xoff[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int pos = dir == 0 ? 0 : len[r] - 1;
+    xoff[r] = (unsigned)((((int64_t)bidx[r] * T + pos) * xrow + dir * 4 * H + unit0 * 4) * 4);
+  }
+  const int xstep = (dir == 0 ? 1 : -1) * (int)(xrow * 4);
+  char* const xbase = reinterpret_cast<char*>(xproj);
+  char* const cbase = reinterpret_cast<char*>(cbuf);
+  char* const ybase = reinterpret_cast<char*>(y);
 
   int cur = 0;
-  for (int s = 0; s < smax; ++s) {
+  auto step = [&](int s, auto lean_tag) {
+    constexpr bool LEAN = decltype(lean_tag)::value;
     bool act[4];
     int64_t rowoff[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      act[r] = s < len[r];
-      const int pos = dir == 0 ? s : len[r] - 1 - s;
-      rowoff[r] = act[r] ? ((int64_t)bidx[r] * T + pos) : 0;
+      act[r] = LEAN || s < len[r];
+      if constexpr (!LEAN) {
+        const int pos = dir == 0 ? s : len[r] - 1 - s;
+        rowoff[r] = act[r] ? ((int64_t)bidx[r] * T + pos) : 0;
+      }
     }
     // x_t K_x + b of this step: issued now, consumed after the MFMAs
-    float xp[4][UB][4];
+    float4 xp[UB][4];
 #pragma unroll
     for (int ub = 0; ub < UB; ++ub)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (act[r] && lead) v = *reinterpret_cast<const float4*>(xproj + rowoff[r] * xrow + dir * 4 * H + (unit0 + ub * 16) * 4);
-        xp[0][ub][r] = v.x; xp[1][ub][r] = v.y; xp[2][ub][r] = v.z; xp[3][ub][r] = v.w;
+        xp[ub][r] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (lead) {
+          if constexpr (LEAN) xp[ub][r] = *reinterpret_cast<const float4*>(xbase + xoff[r] + ub * 256);
+          else if (act[r]) xp[ub][r] = *reinterpret_cast<const float4*>(xproj + rowoff[r] * xrow + dir * 4 * H + (unit0 + ub * 16) * 4);
+        }
       }
 
     // all-gather h_{s-1}: peers' slices arrive as granules tagged with epoch s
     if constexpr (G > 1) if (s > 0) {
-      const u64* src = ex_group + (int64_t)((s - 1) & 1) * ngroups * G * NGRAN;
-      constexpr int PER = (G - 1) * NGRAN / 256;     // granules per thread
+      const char* src = reinterpret_cast<const char*>(ex_group + (int64_t)((s - 1) & 1) * par_stride);
+      unsigned short* hl = &hlds[cur][0][0];
       constexpr int CH = PER > 6 ? 5 : PER;          // per polling round (bounds the registers held)
       static_assert(PER % CH == 0, "sweep chunking");
+#pragma unroll
       for (int c0 = 0; c0 < PER; c0 += CH) {
         u64 v[CH];
         unsigned spins = 0;
-        bool ok;
-        do {
-          ok = true;
+        for (;;) {                                   // wave-uniform loop: every lane re-polls until the whole wave is served
+          bool ok = true;
 #pragma unroll
           for (int i = 0; i < CH; ++i) {
-            const int q = tid + (c0 + i) * 256;
-            const int pi = q / NGRAN, gi = q % NGRAN;
-            const int peer = pi + (pi >= member ? 1 : 0);
-            v[i] = granule_load(src + (int64_t)peer * NGRAN + gi);
+            v[i] = granule_load(reinterpret_cast<const u64*>(src + poll_off[c0 + i]));
             ok = ok && ((unsigned)(v[i] >> 32) == (unsigned)s);
           }
-          if (!ok) {
-            if (++spins > SPIN_LIMIT) { fail_flag = 1; break; }
-            __builtin_amdgcn_s_sleep(1);
-          }
-        } while (!ok);
+          if (__all(ok)) break;
+          if (++spins > SPIN_LIMIT) { fail_flag = 1; break; }
+          __builtin_amdgcn_s_sleep(1);
+        }
 #pragma unroll
         for (int i = 0; i < CH; ++i) {
-          const int q = tid + (c0 + i) * 256;
-          const int pi = q / NGRAN, gi = q % NGRAN;
-          const int peer = pi + (pi >= member ? 1 : 0);
-          const int rp = gi / HS, ul = gi % HS;
           const unsigned val = (unsigned)v[i];
-          hlds[cur][rp * 2][peer * HS + ul] = (unsigned short)(val & 0xffffu);
-          hlds[cur][rp * 2 + 1][peer * HS + ul] = (unsigned short)(val >> 16);
+          hl[scat_off[c0 + i]] = (unsigned short)(val & 0xffffu);
+          hl[scat_off[c0 + i] + LS] = (unsigned short)(val >> 16);
         }
       }
     }
-    __syncthreads();
-    if (fail_flag) break;
+    lds_barrier();
+    if (fail_flag) return false;
 
     f32x4 acc[4][UB];
 #pragma unroll
@@ -287,48 +333,76 @@ __global__ __launch_bounds__(rec_threads(H)) void lstm_fwd_kernel(float* __restr
 #pragma unroll
         for (int g = 0; g < 4; ++g) rbuf[((wave & 1) * 4 + g) * 64 + lane] = acc[g][0];
       }
-      __syncthreads();
+      lds_barrier();
       if (lead) {
 #pragma unroll
         for (int g = 0; g < 4; ++g) acc[g][0] += rbuf[((wave & 1) * 4 + g) * 64 + lane];
       }
     }
     if (lead) {
-
-    u64* dst = ex_group + (int64_t)(s & 1) * ngroups * G * NGRAN + (int64_t)member * NGRAN;
+      u64* dst = ex_group + (int64_t)(s & 1) * par_stride + (int64_t)member * NGRAN;
+      float4 gsave[UB][4];
+      float csave[UB][4];
 #pragma unroll
-    for (int ub = 0; ub < UB; ++ub) {
-      const int unit = unit0 + ub * 16;
-      const int ul = unit - member * HS;
-      unsigned short hb[4];
+      for (int ub = 0; ub < UB; ++ub) {
+        const int unit = unit0 + ub * 16;
+        const int ul = unit - member * HS;
+        unsigned short hb[4];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float gi = las_sigmoid(acc[0][ub][r] + xp[0][ub][r]);
-        const float gj = las_tanh(acc[1][ub][r] + xp[1][ub][r]);
-        const float gf = las_sigmoid(acc[2][ub][r] + xp[2][ub][r] + 1.0f);
-        const float go = las_sigmoid(acc[3][ub][r] + xp[3][ub][r]);
-        const float cn = gf * c[ub][r] + gi * gj;
-        const unsigned short hn = las_f2bf(go * las_tanh(cn));
-        if (act[r]) {
-          *reinterpret_cast<float4*>(xproj + rowoff[r] * xrow + dir * 4 * H + unit * 4) = make_float4(gi, gj, gf, go);
-          cbuf[rowoff[r] * yrow + dir * H + unit] = cn;
-          y[rowoff[r] * yrow + dir * H + unit] = hn;
-          c[ub][r] = cn;
-          h[ub][r] = las_bf2f(hn);
+        for (int r = 0; r < 4; ++r) {
+          const float gi = las_sigmoid(acc[0][ub][r] + xp[ub][r].x);
+          const float gj = las_tanh(acc[1][ub][r] + xp[ub][r].y);
+          const float gf = las_sigmoid(acc[2][ub][r] + xp[ub][r].z + 1.0f);
+          const float go = las_sigmoid(acc[3][ub][r] + xp[ub][r].w);
+          const float cn = gf * c[ub][r] + gi * gj;
+          const unsigned short hn = las_f2bf(go * las_tanh(cn));
+          gsave[ub][r] = make_float4(gi, gj, gf, go);
+          csave[ub][r] = cn;
+          if (act[r]) {
+            c[ub][r] = cn;
+            h[ub][r] = las_bf2f(hn);
+          }
+          hb[r] = act[r] ? hn : las_f2bf(h[ub][r]);
+          hlds[cur ^ 1][lq * 4 + r][unit] = hb[r];
         }
-        hb[r] = act[r] ? hn : las_f2bf(h[ub][r]);
-        hlds[cur ^ 1][lq * 4 + r][unit] = hb[r];
+        // the peers wait for these: they go out before the step's own HBM stores
+        if constexpr (G > 1) {
+          granule_store(dst + (lq * 2) * HS + ul, (unsigned)(s + 1), (unsigned)hb[0] | ((unsigned)hb[1] << 16), local);
+          granule_store(dst + (lq * 2 + 1) * HS + ul, (unsigned)(s + 1), (unsigned)hb[2] | ((unsigned)hb[3] << 16), local);
+        }
       }
-      if constexpr (G > 1) {
-        granule_store(dst + (lq * 2) * HS + ul, (unsigned)(s + 1), (unsigned)hb[0] | ((unsigned)hb[1] << 16), local);
-        granule_store(dst + (lq * 2 + 1) * HS + ul, (unsigned)(s + 1), (unsigned)hb[2] | ((unsigned)hb[3] << 16), local);
+#pragma unroll
+      for (int ub = 0; ub < UB; ++ub) {
+        const int unit = unit0 + ub * 16;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          if constexpr (LEAN) {
+            *reinterpret_cast<float4*>(xbase + xoff[r] + ub * 256) = gsave[ub][r];
+            *reinterpret_cast<float*>(cbase + (xoff[r] >> 2) + ub * 64) = csave[ub][r];
+            *reinterpret_cast<unsigned short*>(ybase + (xoff[r] >> 3) + ub * 32) = las_f2bf(h[ub][r]);
+          } else if (act[r]) {
+            *reinterpret_cast<float4*>(xproj + rowoff[r] * xrow + dir * 4 * H + unit * 4) = gsave[ub][r];
+            cbuf[rowoff[r] * yrow + dir * H + unit] = csave[ub][r];
+            y[rowoff[r] * yrow + dir * H + unit] = las_f2bf(h[ub][r]);
+          }
+        }
       }
     }
-    }   // lead
+    if constexpr (LEAN) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) xoff[r] += (unsigned)xstep;
+    }
     cur ^= 1;
-  }
+    return true;
+  };
 
-  if (fail_flag) {
+  bool ok = true;
+  int s = 0;
+  for (; s < smin && ok; ++s) ok = step(s, std::true_type{});
+  for (; s < smax && ok; ++s) ok = step(s, std::false_type{});
+
+  if (G > 1 && tid == 0) __hip_atomic_store(done_word, (u64)1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // releases the companion
+  if (!ok) {
     if (tid == 0) atomicOr(status, 1u);
     return;
   }
@@ -408,6 +482,7 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_kernel(const float* __restric
       dc[ub][r] = (ok && dc_last) ? dc_last[o] : 0.f;
       dh[ub][r] = (ok && dh_last) ? dh_last[o] : 0.f;
     }
+  __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0): weights and initial state are in registers before the time loop
   if (tid == 0) fail_flag = 0;
   __syncthreads();
   int* colo_flag = reinterpret_cast<int*>(smem + (size_t)2 * 16 * ZS * sizeof(unsigned short)) + 1;
@@ -463,8 +538,6 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_kernel(const float* __restric
         float di = 0.f, dj = 0.f, df = 0.f, dov = 0.f;
         if (act) {
           const Saved v = sv[ub][r];
-          const int pos = dir == 0 ? s : len[r] - 1 - s;
-          const int64_t ro = (int64_t)bidx[r] * T + pos;
           const float dht = v.dyv + dh[ub][r];
           const float tc = las_tanh(v.ct);
           dov = dht * tc * v.go * (1.f - v.go);
@@ -473,10 +546,6 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_kernel(const float* __restric
           dj = dct * v.gi * (1.f - v.gj * v.gj);
           df = dct * v.cp * v.gf * (1.f - v.gf);
           dc[ub][r] = dct * v.gf;
-          uint2 zv;
-          zv.x = (unsigned)las_f2bf(di) | ((unsigned)las_f2bf(dj) << 16);
-          zv.y = (unsigned)las_f2bf(df) | ((unsigned)las_f2bf(dov) << 16);
-          *reinterpret_cast<uint2*>(dz + ro * grow + dir * 4 * H + unit * 4) = zv;   // gate-interleaved [unit][i,j,f,o]
         }
         zb[0][r] = las_f2bf(di); zb[1][r] = las_f2bf(dj); zb[2][r] = las_f2bf(df); zb[3][r] = las_f2bf(dov);
         unsigned short* zr = zl + (lq * 4 + r) * ZS + unit;
@@ -489,6 +558,17 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_kernel(const float* __restric
           granule_store(dst + ((lq * 2 + 1) * 4 + g) * HS + ul, epoch, (unsigned)zb[g][2] | ((unsigned)zb[g][3] << 16), local);
         }
       }
+      // the step's own HBM store goes out after the granules the peers wait for
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (s < len[r]) {
+          const int pos = dir == 0 ? s : len[r] - 1 - s;
+          const int64_t ro = (int64_t)bidx[r] * T + pos;
+          uint2 zv;
+          zv.x = (unsigned)zb[0][r] | ((unsigned)zb[1][r] << 16);
+          zv.y = (unsigned)zb[2][r] | ((unsigned)zb[3][r] << 16);
+          *reinterpret_cast<uint2*>(dz + ro * grow + dir * 4 * H + unit * 4) = zv;   // gate-interleaved [unit][i,j,f,o]
+        }
     }
     load_saved(s - 1, sv);      // next step's operands: in flight during the all-gather and the MFMAs
 
@@ -500,9 +580,8 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_kernel(const float* __restric
       for (int base = 0; base < TOTAL; base += 256 * CH) {
         u64 v[CH];
         unsigned spins = 0;
-        bool ok;
-        do {
-          ok = true;
+        for (;;) {                                   // wave-uniform loop: every lane re-polls until the whole wave is served
+          bool ok = true;
 #pragma unroll
           for (int i = 0; i < CH; ++i) {
             const int q = base + tid + i * 256;
@@ -511,11 +590,10 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_kernel(const float* __restric
             v[i] = granule_load(src + (int64_t)peer * NGRAN + gi);
             ok = ok && ((unsigned)(v[i] >> 32) == epoch);
           }
-          if (!ok) {
-            if (++spins > SPIN_LIMIT) { fail_flag = 1; break; }
-            __builtin_amdgcn_s_sleep(1);
-          }
-        } while (!ok);
+          if (__all(ok)) break;
+          if (++spins > SPIN_LIMIT) { fail_flag = 1; break; }
+          __builtin_amdgcn_s_sleep(1);
+        }
 #pragma unroll
         for (int i = 0; i < CH; ++i) {
           const int q = base + tid + i * 256;
@@ -528,7 +606,7 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_kernel(const float* __restric
         }
       }
     }
-    __syncthreads();
+    lds_barrier();
     if (fail_flag) break;
 
     // dh_{t-1}[own units] = dz_t [16,4H] * K_h^T
@@ -543,7 +621,7 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_kernel(const float* __restric
     }
     if constexpr (KS > 1) {
       if (!lead) rbuf[(wave & 1) * 64 + lane] = acc[0];
-      __syncthreads();
+      lds_barrier();
       if (lead) acc[0] += rbuf[(wave & 1) * 64 + lane];
     }
 #pragma unroll
@@ -565,8 +643,18 @@ CoopGeom geom(int B, int H, int ndir, bool bwd) {
   g.ngroups = g.nslices * ndir;
   g.blocks = ((g.ngroups + 7) & ~7) * g.G;        // group stride rounded up to 8 (idle blocks exit at once)
   const size_t ngran = (size_t)8 * (H / g.G) * (bwd ? 4 : 1);
-  g.exch_bytes = g.G > 1 ? ((size_t)2 * g.ngroups * g.G * ngran + (size_t)g.ngroups * g.G) * sizeof(u64) : 0;   // + XCC-id table
+  g.exch_bytes = g.G > 1 ? ((size_t)2 * g.ngroups * g.G * ngran + (size_t)g.ngroups * g.G + g.blocks) * sizeof(u64) : 0;   // + XCC-id table + step counters
   return g;
+}
+
+// LAS_LSTM_PREFETCH=0 launches the recurrent kernels without their prefetch companions (diagnostics)
+int prefetch_mode() {
+  static int mode = -1;
+  if (mode < 0) {
+    const char* e = getenv("LAS_LSTM_PREFETCH");
+    mode = (e && atoi(e) == 0) ? 0 : 1;
+  }
+  return mode;
 }
 
 template <int H>
@@ -575,8 +663,9 @@ int launch_fwd(float* xproj, const las_bf16* wp, const int32_t* length, las_bf16
   const CoopGeom g = geom(B, H, ndir, false);
   unsigned* status = reinterpret_cast<unsigned*>(ws);
   u64* exch = reinterpret_cast<u64*>(reinterpret_cast<char*>(ws) + 64);
-  hipLaunchKernelGGL((lstm_fwd_kernel<H>), dim3(g.blocks), dim3(rec_threads(H)), 0, st, xproj, wp, length, y, cbuf, c_last, h_last,
-                     exch, status, B, T, ndir, g.ngroups);
+  const int pf = g.G > 1 ? prefetch_mode() : 0;
+  hipLaunchKernelGGL((lstm_fwd_kernel<H>), dim3(pf ? 2 * g.blocks : g.blocks), dim3(256), 0, st, xproj, wp, length, y,
+                     cbuf, c_last, h_last, exch, status, B, T, ndir, g.ngroups, pf);
   LAS_LAUNCH_CHECK("lstm fwd launch");
   return LAS_OK;
 }

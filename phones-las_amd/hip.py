@@ -7,7 +7,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.path.join(_HERE, 'liblas_hip.so')
+_LIB_PATH = os.environ.get('LAS_HIP_LIB') or os.path.join(_HERE, 'liblas_hip.so')   # LAS_HIP_LIB: diagnostics builds
 _lib = None
 
 
