@@ -124,7 +124,8 @@ size_t las_lstm_workspace_bytes(int B, int H, int ndir);
 
 /* Backward recurrence (reverse-mode AD of the loop above).
  * gates/cbuf: saved by the forward.  dy [B,T,ndir*H] fp32: gradient w.r.t. y.  dc_last/dh_last
- * [ndir,B,H] fp32 or NULL.  kh_bf16: ndir natural-layout bf16 copies of K_h [H,4H].
+ * [ndir,B,H] fp32 or NULL.  kh_bf16: ndir bf16 copies of K_h [H,4H] with GATE-INTERLEAVED columns (u*4+g,
+ * las_cast_bf16(..., src_col_perm_h = H)): the gate columns of a block of units are contiguous.
  * dz [B,T,ndir*4H] bf16 (out): gradient w.r.t. the gate pre-activations, zero for t >= length;
  * the caller derives dX, dK_x, dK_h, db from it with las_gemm_nt / las_gemm_tn / las_colsum. */
 int las_lstm_recurrent_bwd(const float* gates, const float* cbuf, const float* dy, const float* dc_last,

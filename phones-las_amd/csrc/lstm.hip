@@ -419,93 +419,183 @@ __global__ __launch_bounds__(256) void lstm_fwd_kernel(float* __restrict__ xproj
 
 // ------------------------------------------------------------------------------------------------
 // backward in time
+//
+// Member m owns hidden units [m*HS, (m+1)*HS) and therefore the gate columns dz_t[:, own units x 4 gates]: it
+// computes them from the saved gates (one step ahead in registers), keeps them in a small LDS tile and multiplies
+// that tile with ITS rows of K_h^T: a partial dh_{t-1} for ALL H units (K = 4*HS).  The partial sums are
+// reduce-scattered: the 16-unit tiles that belong to other members travel as fp32 granules {epoch, value} to the
+// lane that will use them (same wave, same lane of the owner), own tiles stay in registers.  Per lane and step that
+// is 4 x (G-1) granules each way, against 8 x 4 x (G-1) for an all-gather of dz_t.
+// kh is K_h [H, 4H] in bf16 with GATE-INTERLEAVED columns (u*4+g): a member's K range is contiguous.
 // ------------------------------------------------------------------------------------------------
 template <int H>
-__global__ __launch_bounds__(256, 1) void lstm_bwd_kernel(const float* __restrict__ gates, const float* __restrict__ cbuf,
-                                                          const float* __restrict__ dy, const float* __restrict__ dc_last,
-                                                          const float* __restrict__ dh_last, const unsigned short* __restrict__ kh,
-                                                          const int32_t* __restrict__ length, unsigned short* __restrict__ dz,
-                                                          u64* __restrict__ exch, unsigned* __restrict__ status,
-                                                          int B, int T, int ndir, int ngroups) {
+__global__ __launch_bounds__(256) void lstm_bwd_kernel(const float* __restrict__ gates, const float* __restrict__ cbuf,
+                                                       const float* __restrict__ dy, const float* __restrict__ dc_last,
+                                                       const float* __restrict__ dh_last, const unsigned short* __restrict__ kh,
+                                                       const int32_t* __restrict__ length, unsigned short* __restrict__ dz,
+                                                       u64* __restrict__ exch, unsigned* __restrict__ status,
+                                                       int B, int T, int ndir, int ngroups) {
   constexpr int G = coop_members(H);
   constexpr int HS = H / G;
-  constexpr int KS = k_split(H);
-  constexpr int NUB = HS / 16;
-  constexpr int UB = (NUB * KS) / 4 > 0 ? (NUB * KS) / 4 : 1;
-  constexpr int KC = (4 * H) / 32;
-  constexpr int KCW = KC / KS;
-  constexpr int ZS = 4 * H + 8;
-  constexpr int NGRAN = 8 * 4 * HS;    // granules per member per step: 8 row pairs x 4 gates x HS units
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  unsigned short* dzl = reinterpret_cast<unsigned short*>(smem);   // [2][16][ZS]
-  int& fail_flag = *reinterpret_cast<int*>(smem + (size_t)2 * 16 * ZS * sizeof(unsigned short));   // keeps the dynamic base 16-B aligned
-  f32x4* rbuf = reinterpret_cast<f32x4*>(smem + (size_t)2 * 16 * ZS * sizeof(unsigned short) + 16);   // [2][64] (KS > 1)
+  constexpr int NUB = HS / 16;                    // 16-unit blocks of a member
+  constexpr bool SPLIT = NUB < 4;                 // H = 512: two waves share a unit block, two rows of every quad each
+  static_assert(!SPLIT || NUB == 2, "row split is written for two unit blocks per member");
+  constexpr int UBW = SPLIT ? 1 : NUB / 4;        // unit blocks a wave owns
+  constexpr int RPL = SPLIT ? 2 : 4;              // rows of its quad a lane owns
+  constexpr int KCW = HS / 8;                     // k-chunks of the member's 4*HS gate columns
+  constexpr int NT = SPLIT ? G / 2 : G * UBW;     // 16-unit output tiles a wave computes
+  constexpr int OWN = SPLIT ? 0 : UBW;            // ... of which stay in registers (own units)
+  constexpr int ZS = 4 * HS + 8;                  // LDS row stride of the dz tile (elements)
+  constexpr int PAIR = NUB * 256;                 // granules per (destination, sender) pair: [block][row][lane]
+  constexpr int PER = G > 1 ? (SPLIT ? G * RPL : (G - 1) * UBW * 4) : 1;   // granules a lane polls per step
+  __shared__ __attribute__((aligned(16))) unsigned short ztile[2][16][ZS];
+  __shared__ int fail_flag;
+  __shared__ int colo_flag;
+  __shared__ __attribute__((aligned(16))) float pf_scratch[256];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int gstride = (ngroups + 7) & ~7;
-  const int group = blockIdx.x % gstride, member = blockIdx.x / gstride;
+  const int nblk = gstride * G;
+  const bool companion = (int)blockIdx.x >= nblk;
+  const int cblk = companion ? blockIdx.x - nblk : blockIdx.x;
+  const int group = cblk % gstride, member = cblk / gstride;
   if (group >= ngroups) return;
   const int nslices = ngroups / ndir;
   const int slice = group % nslices, dir = group / nslices;
   const int l15 = lane & 15, lq = lane >> 4;
+  const int64_t grow = (int64_t)ndir * 4 * H;
+  const int64_t yrow = (int64_t)ndir * H;
+  const int64_t grp_gran = (int64_t)G * G * PAIR;               // granules of one group in one parity slot
+  const int64_t par_stride = (int64_t)ngroups * grp_gran;
+  u64* ex_group = exch + (int64_t)group * grp_gran;             // + parity*par_stride + (dest*G + sender)*PAIR + ...
+  u64* done_word = exch + 2 * par_stride + (int64_t)ngroups * G + cblk;
 
-  int len[4], bidx[4];
-  int smax = 0;
+  const int blk = SPLIT ? (wave & 1) : wave * UBW;              // first unit block of this wave
+  const int hh = SPLIT ? (wave >> 1) : 0;                       // which row pair of every quad (SPLIT)
+  int len[RPL], bidx[RPL];
+  int smax = 0, smin = 0x7fffffff;
 #pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    bidx[r] = slice * 16 + lq * 4 + r;
+  for (int r = 0; r < RPL; ++r) {
+    bidx[r] = slice * 16 + lq * 4 + hh * 2 + r;
     len[r] = (bidx[r] < B) ? min(length[bidx[r]], T) : 0;
-    smax = max(smax, len[r]);
   }
-  smax = (int)las_wave_max((float)smax);
+  {
+    const int ll = (slice * 16 + l15 < B) ? min(length[slice * 16 + l15], T) : 0;     // all 16 rows of the slice
+    smax = (int)las_wave_max((float)ll);
+    smin = -(int)las_wave_max((float)(-ll));
+  }
+  if ((int64_t)B * T * grow * 4 >= ((int64_t)1 << 32)) smin = 0;     // 32-bit byte offsets do not reach: general path only
 
-  const int wblk = KS > 1 ? (wave & 1) : wave * UB;
-  const int khalf = KS > 1 ? (wave >> 1) & 1 : 0;
-  const bool lead = (khalf == 0);
-  const int unit0 = member * HS + wblk * 16 + l15;
-  const unsigned short* khd = kh + (int64_t)dir * H * 4 * H;
-  // register-resident B fragments: B[k][n] = K_h[n = unit][k = gate column]  (natural rows of K_h)
-  bf16x8 wf[UB][KCW];
+  if constexpr (G > 1) if (companion) {
+    // PREFETCH COMPANION (see lstm_fwd_kernel): gates, c and dy lines of the compute workgroup, PF_AHEAD steps ahead.
+    constexpr int PF_AHEAD = 6;
+    const int mylen = (slice * 16 + l15 < B) ? min(length[slice * 16 + l15], T) : 0;
+    const int watch_dest = member == 0 ? 1 : 0;                 // any slot the compute workgroup writes every step
+    const u64* tag0 = ex_group + (int64_t)(watch_dest * G + member) * PAIR;
+    int seen = -1;
+    for (int it = 0; it < smax; ++it) {
+      const int sp = smax - 1 - it;
+      unsigned spins = 0;
+      while (seen < it - PF_AHEAD) {
+        const u64 v0 = granule_load(tag0), v1 = granule_load(tag0 + par_stride), dn = granule_load(done_word);
+        if (dn != 0) return;
+        seen = (int)max((unsigned)(v0 >> 32), (unsigned)(v1 >> 32)) - 1;
+        if (seen < it - PF_AHEAD) {
+          if (++spins > SPIN_LIMIT) return;
+          __builtin_amdgcn_s_sleep(8);
+        }
+      }
 #pragma unroll
-  for (int ub = 0; ub < UB; ++ub)
+      for (int r4 = 0; r4 < 4; ++r4) {
+        const int rr = wave * 4 + r4;
+        const int ll = __builtin_amdgcn_readlane(mylen, rr);
+        if (sp < ll) {
+          const int pos = dir == 0 ? sp : ll - 1 - sp;
+          const int64_t R = (int64_t)(slice * 16 + rr) * T + pos;
+          const float* src = gates + R * grow + dir * 4 * H + member * HS * 4 + (lane % (HS > 64 ? 64 : HS)) * 4;
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src),
+                                           (__attribute__((address_space(3))) void*)(pf_scratch), 16, 0, 0);
+          const float* src2 = ((lane & 32) ? dy : cbuf) + R * yrow + dir * H + member * HS + ((lane & 31) % (HS / 4)) * 4;
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src2),
+                                           (__attribute__((address_space(3))) void*)(pf_scratch), 16, 0, 0);
+        }
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    return;
+  }
+
+  // register-resident B fragments: B[k][n] = K_h[n][member's gate columns k]: rows of K_h, contiguous 16-byte pieces
+  const unsigned short* khd = kh + (int64_t)dir * H * 4 * H;
+  int tile_dest[NT];
+  bf16x8 wf[NT][KCW];
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    const int dest = SPLIT ? hh * (G / 2) + j : (member + j / UBW) % G;      // own tiles first (not SPLIT)
+    const int ublk = SPLIT ? blk : blk + j % UBW;
+    tile_dest[j] = dest;
+    const int n = dest * HS + ublk * 16 + l15;
 #pragma unroll
     for (int kc = 0; kc < KCW; ++kc)
-      wf[ub][kc] = *reinterpret_cast<const bf16x8*>(khd + (int64_t)(unit0 + ub * 16) * 4 * H + (khalf * KCW + kc) * 32 + 8 * lq);
+      wf[j][kc] = *reinterpret_cast<const bf16x8*>(khd + (int64_t)n * 4 * H + member * 4 * HS + kc * 32 + 8 * lq);
+  }
 
-  float dc[UB][4], dh[UB][4];
+  const int unit0 = member * HS + blk * 16 + l15;                // + ub*16
+  float dc[UBW][RPL], dh[UBW][RPL], part[UBW][RPL];
 #pragma unroll
-  for (int ub = 0; ub < UB; ++ub)
+  for (int ub = 0; ub < UBW; ++ub)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const bool ok = bidx[r] < B && lead;
+    for (int r = 0; r < RPL; ++r) {
+      const bool ok = bidx[r] < B;
       const int64_t o = ((int64_t)dir * B + (ok ? bidx[r] : 0)) * H + unit0 + ub * 16;
       dc[ub][r] = (ok && dc_last) ? dc_last[o] : 0.f;
       dh[ub][r] = (ok && dh_last) ? dh_last[o] : 0.f;
+      part[ub][r] = 0.f;
     }
   __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0): weights and initial state are in registers before the time loop
   if (tid == 0) fail_flag = 0;
   __syncthreads();
-  int* colo_flag = reinterpret_cast<int*>(smem + (size_t)2 * 16 * ZS * sizeof(unsigned short)) + 1;
-  const bool local = xcd_colocated<G>(exch + (int64_t)2 * ngroups * G * NGRAN + (int64_t)group * G, member, colo_flag, status);
+  const bool local = xcd_colocated<G>(exch + 2 * par_stride + (int64_t)group * G, member, &colo_flag, status);
 
-  const int64_t grow = (int64_t)ndir * 4 * H;
-  const int64_t yrow = (int64_t)ndir * H;
-  u64* ex_group = exch + (int64_t)group * G * NGRAN;
-
-  // saved forward values of one step, loaded one step ahead so their latency hides behind the all-gather
-  struct Saved { float gi, gj, gf, go, ct, cp, dyv; };
-  auto load_saved = [&](int s, Saved (&sv)[UB][4]) {
+  // loop-invariant pieces of the exchange (byte offsets inside the group's parity slot)
+  unsigned poll_off[PER], send_off[NT > OWN ? NT - OWN : 1];
+  if constexpr (G > 1) {
 #pragma unroll
-    for (int ub = 0; ub < UB; ++ub) {
+    for (int e = 0; e < PER; ++e) {
+      int sender, ub, r;
+      if constexpr (SPLIT) { sender = e / RPL; ub = 0; r = hh * 2 + e % RPL; }
+      else { sender = (member + 1 + e / (UBW * 4)) % G; ub = (e / 4) % UBW; r = e % 4; }
+      poll_off[e] = (unsigned)((((member * G + sender) * NUB + blk + ub) * 4 + r) * 64 + lane) * 8u;
+    }
+#pragma unroll
+    for (int j = OWN; j < NT; ++j) {
+      const int ublk = SPLIT ? blk : blk + j % UBW;
+      send_off[j - OWN] = (unsigned)((((tile_dest[j] * G + member) * NUB + ublk) * 4) * 64 + lane) * 8u;   // + r*512
+    }
+  }
+
+  // lean path: byte offset of this lane's rows into gates (cbuf, dy = /4; dz = /2: same element index)
+  unsigned goff[RPL];
+  const int gstep = (dir == 0 ? 1 : -1) * (int)(grow * 4);
+  const char* const gbase = reinterpret_cast<const char*>(gates);
+  const char* const cbase = reinterpret_cast<const char*>(cbuf);
+  const char* const dbase = reinterpret_cast<const char*>(dy);
+  char* const zbase = reinterpret_cast<char*>(dz);
+
+  struct Saved { float4 g; float ct, cp, dyv; };
+  Saved sv[UBW][RPL];
+  // general loader (any row may be finished); also used for the first lean step, which needs c_t from memory
+  auto load_general = [&](int s) {
+#pragma unroll
+    for (int ub = 0; ub < UBW; ++ub) {
       const int unit = unit0 + ub * 16;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        Saved v{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        if (s >= 0 && s < len[r] && lead) {
+      for (int r = 0; r < RPL; ++r) {
+        Saved v{make_float4(0.f, 0.f, 0.f, 0.f), 0.f, 0.f, 0.f};
+        if (s >= 0 && s < len[r]) {
           const int pos = dir == 0 ? s : len[r] - 1 - s;
           const int64_t ro = (int64_t)bidx[r] * T + pos;
-          const float4 gv = *reinterpret_cast<const float4*>(gates + ro * grow + dir * 4 * H + unit * 4);
-          v.gi = gv.x; v.gj = gv.y; v.gf = gv.z; v.go = gv.w;
+          v.g = *reinterpret_cast<const float4*>(gates + ro * grow + dir * 4 * H + unit * 4);
           v.ct = cbuf[ro * yrow + dir * H + unit];
           if (s > 0) {
             const int64_t rp = (int64_t)bidx[r] * T + (dir == 0 ? pos - 1 : pos + 1);
@@ -517,121 +607,147 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_kernel(const float* __restric
       }
     }
   };
+  // lean loader for step s <= smin-2: every row is running, c_t is the c_{t-1} of the step before
+  auto load_lean = [&](int s) {
+#pragma unroll
+    for (int ub = 0; ub < UBW; ++ub)
+#pragma unroll
+      for (int r = 0; r < RPL; ++r) {
+        Saved v;
+        v.g = *reinterpret_cast<const float4*>(gbase + goff[r] + ub * 256);
+        v.ct = sv[ub][r].cp;
+        v.cp = 0.f;
+        if (s > 0) v.cp = *reinterpret_cast<const float*>(cbase + ((goff[r] - (unsigned)gstep) >> 2) + ub * 64);
+        v.dyv = *reinterpret_cast<const float*>(dbase + (goff[r] >> 2) + ub * 64);
+        sv[ub][r] = v;
+      }
+  };
+  auto set_goff = [&](int s) {       // offsets of step s (valid while every row is running)
+#pragma unroll
+    for (int r = 0; r < RPL; ++r) {
+      const int pos = dir == 0 ? s : len[r] - 1 - s;
+      goff[r] = (unsigned)((((int64_t)bidx[r] * T + pos) * grow + dir * 4 * H + unit0 * 4) * 4);
+    }
+  };
 
   int cur = 0;
-  unsigned epoch = 0;
-  Saved sv[UB][4];
-  load_saved(smax - 1, sv);
-  for (int s = smax - 1; s >= 0; --s) {
-    ++epoch;
-    unsigned short* zl = dzl + cur * 16 * ZS;
-    u64* dst = ex_group + (int64_t)(epoch & 1) * ngroups * G * NGRAN + (int64_t)member * NGRAN;
-    if (lead)
+  unsigned epoch = 0;          // = iterations done; partial sums sent in iteration i carry tag i+1 in parity slot i&1
+  bool ok = true;
+  set_goff(smin > 0 ? smin - 1 : 0);
+  load_general(smax - 1);
+  for (int s = smax - 1; s >= 0 && ok; --s) {
+    const bool lean = s < smin;              // every row of the slice is running at step s
+    // ---- dh_s: own partial + the peers' (sent in the previous iteration, i.e. for time step s) ----
+    if (epoch > 0) {
+      float cand[UBW][RPL];
 #pragma unroll
-    for (int ub = 0; ub < UB; ++ub) {
+      for (int ub = 0; ub < UBW; ++ub)
+#pragma unroll
+        for (int r = 0; r < RPL; ++r) cand[ub][r] = part[ub][r];
+      if constexpr (G > 1) {
+        const char* src = reinterpret_cast<const char*>(ex_group + (int64_t)((epoch - 1) & 1) * par_stride);
+        constexpr int CH = PER > 12 ? 8 : PER;
+        static_assert(PER % CH == 0, "sweep chunking");
+#pragma unroll
+        for (int c0 = 0; c0 < PER; c0 += CH) {
+          u64 v[CH];
+          unsigned spins = 0;
+          for (;;) {                                   // wave-uniform: every lane re-polls until the whole wave is served
+            bool got = true;
+#pragma unroll
+            for (int i = 0; i < CH; ++i) {
+              v[i] = granule_load(reinterpret_cast<const u64*>(src + poll_off[c0 + i]));
+              got = got && ((unsigned)(v[i] >> 32) == epoch);
+            }
+            if (__all(got)) break;
+            if (++spins > SPIN_LIMIT) { fail_flag = 1; ok = false; break; }
+            __builtin_amdgcn_s_sleep(1);
+          }
+#pragma unroll
+          for (int i = 0; i < CH; ++i) {
+            const int e = c0 + i;
+            const int ub = SPLIT ? 0 : (e / 4) % UBW, r = SPLIT ? e % RPL : e % 4;
+            cand[ub][r] += __uint_as_float((unsigned)v[i]);
+          }
+        }
+      }
+#pragma unroll
+      for (int ub = 0; ub < UBW; ++ub)
+#pragma unroll
+        for (int r = 0; r < RPL; ++r)
+          if (s + 1 < len[r]) dh[ub][r] = cand[ub][r];        // rows that were running at step s+1
+    }
+
+    // ---- gate derivatives of step s -> dz (LDS tile for the product, HBM for the weight-gradient GEMMs) ----
+    unsigned short* zl = &ztile[cur][0][0];
+#pragma unroll
+    for (int ub = 0; ub < UBW; ++ub) {
       const int unit = unit0 + ub * 16;
-      const int ul = unit - member * HS;
-      unsigned short zb[4][4];       // [gate][row]
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const bool act = s < len[r];
-        float di = 0.f, dj = 0.f, df = 0.f, dov = 0.f;
+      for (int r = 0; r < RPL; ++r) {
+        const bool act = lean || s < len[r];
+        uint2 zv = make_uint2(0u, 0u);
         if (act) {
           const Saved v = sv[ub][r];
           const float dht = v.dyv + dh[ub][r];
           const float tc = las_tanh(v.ct);
-          dov = dht * tc * v.go * (1.f - v.go);
-          const float dct = dc[ub][r] + dht * v.go * (1.f - tc * tc);
-          di = dct * v.gj * v.gi * (1.f - v.gi);
-          dj = dct * v.gi * (1.f - v.gj * v.gj);
-          df = dct * v.cp * v.gf * (1.f - v.gf);
-          dc[ub][r] = dct * v.gf;
-        }
-        zb[0][r] = las_f2bf(di); zb[1][r] = las_f2bf(dj); zb[2][r] = las_f2bf(df); zb[3][r] = las_f2bf(dov);
-        unsigned short* zr = zl + (lq * 4 + r) * ZS + unit;
-        zr[0] = zb[0][r]; zr[H] = zb[1][r]; zr[2 * H] = zb[2][r]; zr[3 * H] = zb[3][r];
-      }
-      if constexpr (G > 1) {
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          granule_store(dst + ((lq * 2) * 4 + g) * HS + ul, epoch, (unsigned)zb[g][0] | ((unsigned)zb[g][1] << 16), local);
-          granule_store(dst + ((lq * 2 + 1) * 4 + g) * HS + ul, epoch, (unsigned)zb[g][2] | ((unsigned)zb[g][3] << 16), local);
-        }
-      }
-      // the step's own HBM store goes out after the granules the peers wait for
-#pragma unroll
-      for (int r = 0; r < 4; ++r)
-        if (s < len[r]) {
-          const int pos = dir == 0 ? s : len[r] - 1 - s;
-          const int64_t ro = (int64_t)bidx[r] * T + pos;
-          uint2 zv;
-          zv.x = (unsigned)zb[0][r] | ((unsigned)zb[1][r] << 16);
-          zv.y = (unsigned)zb[2][r] | ((unsigned)zb[3][r] << 16);
-          *reinterpret_cast<uint2*>(dz + ro * grow + dir * 4 * H + unit * 4) = zv;   // gate-interleaved [unit][i,j,f,o]
-        }
-    }
-    load_saved(s - 1, sv);      // next step's operands: in flight during the all-gather and the MFMAs
-
-    // all-gather dz_t from the peers
-    if constexpr (G > 1) {
-      const u64* src = ex_group + (int64_t)(epoch & 1) * ngroups * G * NGRAN;
-      constexpr int TOTAL = (G - 1) * NGRAN;
-      constexpr int CH = 12;                         // granules per thread per chunk
-      for (int base = 0; base < TOTAL; base += 256 * CH) {
-        u64 v[CH];
-        unsigned spins = 0;
-        for (;;) {                                   // wave-uniform loop: every lane re-polls until the whole wave is served
-          bool ok = true;
-#pragma unroll
-          for (int i = 0; i < CH; ++i) {
-            const int q = base + tid + i * 256;
-            const int pi = q / NGRAN, gi = q % NGRAN;
-            const int peer = pi + (pi >= member ? 1 : 0);
-            v[i] = granule_load(src + (int64_t)peer * NGRAN + gi);
-            ok = ok && ((unsigned)(v[i] >> 32) == epoch);
+          const float dov = dht * tc * v.g.w * (1.f - v.g.w);
+          const float dct = dc[ub][r] + dht * v.g.w * (1.f - tc * tc);
+          const float di = dct * v.g.y * v.g.x * (1.f - v.g.x);
+          const float dj = dct * v.g.x * (1.f - v.g.y * v.g.y);
+          const float df = dct * v.cp * v.g.z * (1.f - v.g.z);
+          dc[ub][r] = dct * v.g.z;
+          zv.x = (unsigned)las_f2bf(di) | ((unsigned)las_f2bf(dj) << 16);
+          zv.y = (unsigned)las_f2bf(df) | ((unsigned)las_f2bf(dov) << 16);
+          if (lean) *reinterpret_cast<uint2*>(zbase + (goff[r] >> 1) + ub * 128) = zv;
+          else {
+            const int pos = dir == 0 ? s : len[r] - 1 - s;
+            *reinterpret_cast<uint2*>(dz + ((int64_t)bidx[r] * T + pos) * grow + dir * 4 * H + unit * 4) = zv;
           }
-          if (__all(ok)) break;
-          if (++spins > SPIN_LIMIT) { fail_flag = 1; break; }
-          __builtin_amdgcn_s_sleep(1);
         }
-#pragma unroll
-        for (int i = 0; i < CH; ++i) {
-          const int q = base + tid + i * 256;
-          const int pi = q / NGRAN, gi = q % NGRAN;
-          const int peer = pi + (pi >= member ? 1 : 0);
-          const int rp = gi / (4 * HS), g = (gi / HS) % 4, ul = gi % HS;
-          const unsigned val = (unsigned)v[i];
-          zl[(rp * 2) * ZS + g * H + peer * HS + ul] = (unsigned short)(val & 0xffffu);
-          zl[(rp * 2 + 1) * ZS + g * H + peer * HS + ul] = (unsigned short)(val >> 16);
-        }
+        *reinterpret_cast<uint2*>(zl + (lq * 4 + hh * 2 + r) * ZS + (unit - member * HS) * 4) = zv;   // [row][u*4+g]
       }
+    }
+    // next step's operands: in flight during the product and the exchange
+    if (s > 0) {
+      if (lean) {
+#pragma unroll
+        for (int r = 0; r < RPL; ++r) goff[r] -= (unsigned)gstep;
+      }
+      if (s - 1 < smin - 1) load_lean(s - 1);
+      else load_general(s - 1);
     }
     lds_barrier();
-    if (fail_flag) break;
+    if (fail_flag) { ok = false; break; }
+    if (s == 0) break;                       // dh_{-1} is not needed
 
-    // dh_{t-1}[own units] = dz_t [16,4H] * K_h^T
-    f32x4 acc[UB];
+    // ---- partial dh_{s-1}[all units] = dz_s[16, own 4*HS] * K_h^T ----
+    f32x4 acc[NT];
 #pragma unroll
-    for (int ub = 0; ub < UB; ++ub) acc[ub] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < NT; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int kc = 0; kc < KCW; ++kc) {
-      const bf16x8 a = *reinterpret_cast<const bf16x8*>(zl + l15 * ZS + (khalf * KCW + kc) * 32 + 8 * lq);
+      const bf16x8 a = *reinterpret_cast<const bf16x8*>(zl + l15 * ZS + kc * 32 + 8 * lq);
 #pragma unroll
-      for (int ub = 0; ub < UB; ++ub) acc[ub] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, wf[ub][kc], acc[ub], 0, 0, 0);
+      for (int j = 0; j < NT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, wf[j][kc], acc[j], 0, 0, 0);
     }
-    if constexpr (KS > 1) {
-      if (!lead) rbuf[(wave & 1) * 64 + lane] = acc[0];
-      lds_barrier();
-      if (lead) acc[0] += rbuf[(wave & 1) * 64 + lane];
+    if constexpr (G > 1) {
+      char* dst = reinterpret_cast<char*>(ex_group + (int64_t)(epoch & 1) * par_stride);
+#pragma unroll
+      for (int j = OWN; j < NT; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          granule_store(reinterpret_cast<u64*>(dst + send_off[j - OWN] + r * 512), epoch + 1, __float_as_uint(acc[j][r]), local);
     }
 #pragma unroll
-    for (int ub = 0; ub < UB; ++ub)
+    for (int ub = 0; ub < OWN; ++ub)
 #pragma unroll
-      for (int r = 0; r < 4; ++r)
-        if (s < len[r] && lead) dh[ub][r] = acc[ub][r];
+      for (int r = 0; r < RPL; ++r) part[ub][r] = acc[ub][r];
+    ++epoch;
     cur ^= 1;
   }
-  if (fail_flag && tid == 0) atomicOr(status, 2u);
+  if (G > 1 && tid == 0) __hip_atomic_store(done_word, (u64)1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (!ok && tid == 0) atomicOr(status, 2u);
 }
 
 struct CoopGeom { int nslices, ngroups, G, blocks; size_t exch_bytes; };
@@ -642,8 +758,11 @@ CoopGeom geom(int B, int H, int ndir, bool bwd) {
   g.nslices = (B + 15) / 16;
   g.ngroups = g.nslices * ndir;
   g.blocks = ((g.ngroups + 7) & ~7) * g.G;        // group stride rounded up to 8 (idle blocks exit at once)
-  const size_t ngran = (size_t)8 * (H / g.G) * (bwd ? 4 : 1);
-  g.exch_bytes = g.G > 1 ? ((size_t)2 * g.ngroups * g.G * ngran + (size_t)g.ngroups * g.G + g.blocks) * sizeof(u64) : 0;   // + XCC-id table + step counters
+  // granules per parity slot: forward all-gather of h_t: ngroups x G members x 8*HS; backward reduce-scatter of the
+  // partial dh: ngroups x G x G (destination, sender) pairs x NUB*256
+  const size_t HS = H / g.G;
+  const size_t per_parity = bwd ? (size_t)g.ngroups * g.G * g.G * (HS / 16) * 256 : (size_t)g.ngroups * g.G * 8 * HS;
+  g.exch_bytes = g.G > 1 ? (2 * per_parity + (size_t)g.ngroups * g.G + g.blocks) * sizeof(u64) : 0;   // + XCC-id table + done words
   return g;
 }
 
@@ -676,14 +795,9 @@ int launch_bwd(const float* gates, const float* cbuf, const float* dy, const flo
   const CoopGeom g = geom(B, H, ndir, true);
   unsigned* status = reinterpret_cast<unsigned*>(ws);
   u64* exch = reinterpret_cast<u64*>(reinterpret_cast<char*>(ws) + 64);
-  const size_t lds = (size_t)2 * 16 * (4 * H + 8) * sizeof(unsigned short) + 16 + 2 * 64 * 16;
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&lstm_bwd_kernel<H>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_set = true;
-  }
-  hipLaunchKernelGGL((lstm_bwd_kernel<H>), dim3(g.blocks), dim3(256), lds, st, gates, cbuf, dy, dc_last, dh_last, kh, length,
-                     dz, exch, status, B, T, ndir, g.ngroups);
+  const int pf = g.G > 1 ? prefetch_mode() : 0;
+  hipLaunchKernelGGL((lstm_bwd_kernel<H>), dim3(pf ? 2 * g.blocks : g.blocks), dim3(256), 0, st, gates, cbuf, dy, dc_last, dh_last, kh,
+                     length, dz, exch, status, B, T, ndir, g.ngroups);
   LAS_LAUNCH_CHECK("lstm bwd launch");
   return LAS_OK;
 }

@@ -103,7 +103,7 @@ class LayerWeights:
                       for d in self.dirs]
         self.kxT = torch.empty(nd * 4 * H, Dp, dtype=torch.bfloat16, device=dev)       # B^T-form for x*K_x
         self.kx = torch.empty(max(D, 1), nd * 4 * H, dtype=torch.bfloat16, device=dev)  # B^T-form for dZ*K_x^T
-        self.kh = torch.empty(nd, H, 4 * H, dtype=torch.bfloat16, device=dev)           # natural K_h (bwd)
+        self.kh = torch.empty(nd, H, 4 * H, dtype=torch.bfloat16, device=dev)           # K_h, interleaved columns (bwd)
         self.khp = torch.empty(nd, H * 4 * H, dtype=torch.bfloat16, device=dev)         # fragment-major (fwd)
         self.bias = torch.empty(nd * 4 * H, dtype=torch.float32, device=dev)
         self.refresh(variables)
@@ -117,7 +117,7 @@ class LayerWeights:
             # gate-interleaved column order (u*4+g) for everything the recurrent kernels touch per step
             hip.cast_bf16(k, D, 4 * H, self.kxT[i * 4 * H:], 4 * H, Dp, ldd=Dp, transpose=True, lds=4 * H, perm_h=H)
             hip.cast_bf16(k, D, 4 * H, self.kx[:, i * 4 * H:], D, 4 * H, ldd=nd * 4 * H, lds=4 * H, perm_h=H)
-            hip.cast_bf16(k[D:], H, 4 * H, self.kh[i], H, 4 * H, ldd=4 * H, lds=4 * H)
+            hip.cast_bf16(k[D:], H, 4 * H, self.kh[i], H, 4 * H, ldd=4 * H, lds=4 * H, perm_h=H)
             hip.check(hip.lib().las_lstm_pack_recurrent(hip.p(k[D:]), H, hip.p(self.khp[i]), hip.stream()))
             self.bias[i * 4 * H:(i + 1) * 4 * H].view(H, 4).copy_(b.view(4, H).t())
 
