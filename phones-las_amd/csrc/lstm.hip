@@ -200,6 +200,10 @@ __global__ __launch_bounds__(256) void lstm_fwd_kernel(float* __restrict__ xproj
     return;
   }
 
+  // The chain is latency-bound: when other kernels (weight-gradient GEMMs on the side stream) share this CU, these
+  // waves go first in the issue arbitration.
+  __builtin_amdgcn_s_setprio(3);
+
   // register-resident B fragments of this wave's K_h columns
   // wave -> (first unit block, K half): KS = 1: 4 waves x UB blocks, all of K; KS = 2: wave&1 = block, wave>>1 = K half
   const int wblk = KS > 1 ? (wave & 1) : wave * UB;
@@ -524,6 +528,8 @@ __global__ __launch_bounds__(256) void lstm_bwd_kernel(const float* __restrict__
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     return;
   }
+
+  __builtin_amdgcn_s_setprio(3);           // latency-bound chain: ahead of co-resident GEMM waves in the issue arbitration
 
   // register-resident B fragments: B[k][n] = K_h[n][member's gate columns k]: rows of K_h, contiguous 16-byte pieces
   const unsigned short* khd = kh + (int64_t)dir * H * 4 * H;

@@ -13,7 +13,7 @@ for T in (800, 400, 200):
     wp = torch.empty(nd * H * 4 * H, dtype=torch.bfloat16, device='cuda')
     for d in range(nd):
         hip.check(lib.las_lstm_pack_recurrent(hip.p(kh[d]), H, hip.p(wp[d * H * 4 * H:]), hip.stream()))
-    khb = kh.to(torch.bfloat16).contiguous()
+    khb = kh.view(nd, H, 4, H).transpose(2, 3).reshape(nd, H, 4 * H).to(torch.bfloat16).contiguous()   # columns u*4+g
     length = torch.full((B,), T, dtype=torch.int32, device='cuda')
     y = torch.empty(B, T, nd * H, dtype=torch.bfloat16, device='cuda')
     cbuf = torch.empty(B, T, nd * H, device='cuda')
