@@ -3,22 +3,24 @@
 //
 // Decomposition.  The batch is cut into slices of 16 utterances (the M of v_mfma_f32_16x16x32_bf16).
 // One (slice, direction) pair is a serial chain of T dependent steps; it is run by a GROUP of G
-// co-resident 256-thread workgroups ("members").  Member m owns hidden units [m*H/G, (m+1)*H/G): each of
-// its 4 waves owns H/(4G) units for all four gates and keeps the matching columns of K_h (forward) /
-// rows of K_h (backward) in REGISTERS for the whole sequence as ready-made MFMA B fragments — the
-// recurrent weights are read from memory once per launch, not once per step.  i, j, f, o of one
-// (utterance, unit) land in the same lane (C/D layout col = lane&15 -> unit, row = (lane>>4)*4+reg ->
+// co-resident 256-thread workgroups ("members", one wave per SIMD).  Member m owns hidden units
+// [m*H/G, (m+1)*H/G) and keeps its part of K_h in REGISTERS for the whole sequence as ready-made MFMA B
+// fragments - the recurrent weights are read from memory once per launch, not once per step.  i, j, f, o of
+// one (utterance, unit) land in the same lane (C/D layout col = lane&15 -> unit, row = (lane>>4)*4+reg ->
 // utterance), so the gate math needs no cross-lane traffic.
 //
-// Per step the members all-gather what the next product needs (h_t: 16 x H bf16 forward; dz_t:
-// 16 x 4H bf16 backward).  Inside a member it goes through a double-buffered LDS tile (one barrier per
-// step); between members through 8-byte {tag, 2 x bf16} granules in a global exchange buffer, stored
-// and polled with agent-scope relaxed atomics (write-through, L1-bypassing): the data is its own flag
+// Exchange.  Forward: the members all-gather h_t (16 x H bf16).  Backward: each member multiplies ITS dz
+// columns with its rows of K_h^T and the partial dh tiles are reduce-scattered to their owners.  Inside a
+// member data goes through a double-buffered LDS tile (one LDS-only barrier per step); between members
+// through 8-byte {tag, payload} granules in a global exchange buffer: the data is its own flag
 // (cdna_hip_programming.md Guideline 16, form R2), tag = step epoch, buffer zeroed by a memset node at
-// every launch, two parity slots so a fast member cannot overwrite what a slow one still reads.
-// Results never depend on workgroup placement; blockIdx = group + member*ngroups only makes the members
-// of a group share an XCD under round-robin dispatch when ngroups % 8 == 0 (speed).  Every spin is
-// bounded: on timeout the kernel sets a status word and returns.
+// every launch, two parity slots so a fast member cannot overwrite what a slow one still reads.  Loads are
+// agent-scope relaxed atomics (L1-bypassing); stores are write-through agent-scope atomics, or plain stores
+// once the members have established that they share an XCD (then its L2 is the coherence point).
+// Results never depend on workgroup placement; blockIdx = group + 8k*member only makes the members of a
+// group share an XCD under round-robin dispatch (speed).  Every spin is bounded: on timeout the kernel sets
+// a status word and returns.  Each compute workgroup has a PREFETCH COMPANION workgroup on another CU of the
+// same XCD that pulls its HBM operands into the shared L2 a few steps ahead.
 #include "las_common.h"
 #include <stdlib.h>
 #include <type_traits>
