@@ -45,9 +45,18 @@ enum las_dec_mode {      /* which halves of a decoder step a las_decoder_step_* 
   LAS_DEC_ATTENTION_ONLY = 2  /* attention queried by `query` (the top cell's output) */
 };
 
-enum las_attention {     /* las/model.py:153-166 --attention_type */
-  LAS_ATT_LUONG = 0,
-  LAS_ATT_BAHDANAU = 1
+enum las_attention {     /* las/model.py:153-166 --attention_type: how a score is formed */
+  LAS_ATT_LUONG = 0,              /* h . keys                                  (LuongAttention) */
+  LAS_ATT_BAHDANAU = 1,           /* v . tanh(keys + Wq h)                     (BahdanauAttention) */
+  LAS_ATT_CUSTOM = 2,             /* relu(Wq h) . keys, keys = relu(memory Wm) (CustomAttention, las/model.py:72-101) */
+  LAS_ATT_LUONG_MONOTONIC = 3,    /* h . keys + score_bias                     (LuongMonotonicAttention) */
+  LAS_ATT_BAHDANAU_MONOTONIC = 4  /* v . tanh(keys + Wq h) + score_bias        (BahdanauMonotonicAttention) */
+};
+
+enum las_att_norm {      /* how scores become alignments */
+  LAS_NORM_SOFTMAX = 0,
+  LAS_NORM_MONOTONIC_PARALLEL = 1, /* tf.contrib.seq2seq.monotonic_attention(sigmoid(score [+ noise]), prev, 'parallel') */
+  LAS_NORM_MONOTONIC_HARD = 2      /* ... (score > 0, prev, 'hard'): inference only, no backward */
 };
 
 int las_version(void);
@@ -185,6 +194,15 @@ typedef struct las_dec_step {
   int32_t step, feed_width;
   const las_bf16* query;         /* LAS_DEC_ATTENTION_ONLY: the query [B,Hd] bf16, row stride ldq */
   int64_t ldq;
+  /* monotonic attention (enum las_att_norm != 0); all NULL/0 otherwise */
+  int32_t norm;
+  const float* score_bias;       /* device scalar `attention_score_bias` added to every score */
+  const float* prev_align;       /* alignments of step t-1, row stride ldpa; NULL = the initial dirac at frame 0 */
+  int64_t ldpa;
+  float* p_out;                  /* p_choose (saved for backward), row stride ldp, or NULL */
+  int64_t ldp;
+  float noise_scale;             /* sigmoid_noise: score += noise_scale * N(0,1), draw (step*B + b)*Tm + t; 0 = none */
+  uint32_t noise_seed, noise_stream;
 } las_dec_step;
 int las_decoder_step_fwd(const las_dec_step* s, int parts, void* stream);
 
@@ -234,6 +252,16 @@ typedef struct las_dec_step_bwd {
   int64_t ldhb;
   const float* dh_c;
   int64_t ldhc;
+  /* monotonic attention (LAS_NORM_MONOTONIC_PARALLEL); NULL/0 otherwise */
+  int32_t norm;
+  const float* p;                /* saved p_choose, row stride ldp */
+  int64_t ldp;
+  const float* prev_align;       /* alignments of step t-1 (row stride ldpa); NULL = the dirac at frame 0 */
+  int64_t ldpa;
+  float* dalign_carry;           /* [B,Tm] fp32 (row stride ldcarry): in: gradient into align_t from step t+1's
+                                  * normaliser (zero at the last step); out: the same for align_{t-1} */
+  int64_t ldcarry;
+  float* dbias_acc;              /* accumulated d(attention_score_bias) (one float) */
 } las_dec_step_bwd;
 int las_decoder_step_bwd(const las_dec_step_bwd* s, void* stream);
 
@@ -262,6 +290,13 @@ int las_sample_tokens(const float* logits, int64_t ldl, int V, const int32_t* te
  * keep >= 1: plain sum; a == NULL: treated as zero.  (Gradient through the decoder cell's input dropout.) */
 int las_add_masked(const float* a, int64_t lda, const float* b, int64_t ldb, float* out, int64_t ldo, int rows, int cols,
                    float keep, uint32_t seed, uint32_t stream_id, uint64_t idx_base, int64_t idx_ld, void* stream);
+
+/* out[i] = N(0,1) draw i of (seed, stream_id): the realised monotonic-attention score noise, for replaying a run
+ * through the oracle. */
+int las_normal_fill(float* out, int64_t n, uint32_t seed, uint32_t stream_id, void* stream);
+/* y = max(x, 0) on bf16 (CustomAttention keys); dx = dy * (y > 0) on fp32 with the bf16 forward output as mask. */
+int las_relu_bf16(las_bf16* x, int64_t n, void* stream);
+int las_relu_bwd(float* d, const las_bf16* y, int64_t n, void* stream);
 
 /* p[i] += std * N(0,1): the periodic Gaussian weight noise on `*kernel` variables (model_helper.py:418-432). */
 int las_add_noise(float* p, int64_t n, float std, uint32_t seed, uint32_t stream_id, void* stream);

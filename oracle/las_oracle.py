@@ -658,7 +658,7 @@ def model_loss(hp: HP, params, batch, mxu='f64', stochastic=None):
                                      st.get('enc_masks'))
     logits, sp = speller_train(hp, params, mem, mem_len, state, batch['targets_inputs'],
                                batch['target_sequence_length'], mxu, sample_select=st.get('sample_select'),
-                               sample_ids=st.get('sample_ids'), in_masks=st.get('dec_masks'))
+                               sample_ids=st.get('sample_ids'), noise=st.get('att_noise'), in_masks=st.get('dec_masks'))
     loss = compute_loss_train(logits, batch['targets_outputs'], batch['target_sequence_length'])
     aux = {'logits': logits, 'memory': mem, 'memory_len': mem_len, 'state': state, 'ce': loss}
     if hp.ctc_weight > 0:

@@ -23,6 +23,41 @@ __device__ __forceinline__ float block_reduce(float v, float* red, bool is_max) 
   return r;
 }
 
+__device__ __forceinline__ bool att_additive(int a) { return a == LAS_ATT_BAHDANAU || a == LAS_ATT_BAHDANAU_MONOTONIC; }
+__device__ __forceinline__ bool att_uses_wq(int a) { return att_additive(a) || a == LAS_ATT_CUSTOM; }
+
+// In-place scan of arr[0..n) (LDS) by the 256 threads of the workgroup: sum or product, inclusive or exclusive,
+// left-to-right or right-to-left.  Thread i owns a contiguous chunk; chunk totals are scanned through `tmp` (256 floats).
+template <bool MUL>
+__device__ void block_scan(float* arr, int n, float* tmp, bool exclusive, bool reverse) {
+  const int tid = threadIdx.x;
+  const int ch = (n + 255) / 256;
+  const int lo = tid * ch, hi = min(n, lo + ch);
+  const float ident = MUL ? 1.f : 0.f;
+  float tot = ident;
+  for (int i = lo; i < hi; ++i) {
+    const float v = arr[reverse ? n - 1 - i : i];
+    tot = MUL ? tot * v : tot + v;
+  }
+  __syncthreads();
+  tmp[tid] = tot;
+  __syncthreads();
+  if (tid == 0) {                       // 256 chunk totals: a serial pass is cheap next to the memory phases around it
+    float run = ident;
+    for (int i = 0; i < 256; ++i) { const float v = tmp[i]; tmp[i] = run; run = MUL ? run * v : run + v; }
+  }
+  __syncthreads();
+  float run = tmp[tid];
+  for (int i = lo; i < hi; ++i) {
+    const int j = reverse ? n - 1 - i : i;
+    const float v = arr[j];
+    const float inc = MUL ? run * v : run + v;
+    arr[j] = exclusive ? run : inc;
+    run = inc;
+  }
+  __syncthreads();
+}
+
 __device__ __forceinline__ float dot8(const uint4& k, const float* q) {
   const unsigned short* e = reinterpret_cast<const unsigned short*>(&k);
   float s = 0.f;
@@ -41,6 +76,7 @@ __global__ __launch_bounds__(256) void dec_step_fwd_kernel(las_dec_step s) {
   float* sc = pq + s.Hd;          // [Tm] scores -> probabilities
   float* red = sc + s.Tm;         // [8]
 
+  float* cred = red + 8;          // [256][8] floats (context phases); monotonic work arrays follow it
   const int b = blockIdx.x;
   const int part = blockIdx.y, nparts = gridDim.y;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -82,11 +118,13 @@ __global__ __launch_bounds__(256) void dec_step_fwd_kernel(las_dec_step s) {
   if (s.mode == LAS_DEC_CELL_ONLY) return;
   __syncthreads();
 
-  // ---- processed query (Bahdanau): pq[a] = sum_u Wq[u][a] h[u]  (TF Dense kernel layout [in,out]) ----
-  if (s.attention == LAS_ATT_BAHDANAU) {
+  // ---- processed query (Bahdanau, Custom): pq[a] = sum_u Wq[u][a] h[u]  (TF Dense kernel layout [in,out]);
+  //      CustomAttention applies relu and, like every AttentionWrapper query, it is a GEMM operand: bf16-rounded ----
+  if (att_uses_wq(s.attention)) {
     for (int a = tid; a < Hd; a += 256) {
       float acc = 0.f;
       for (int u = 0; u < Hd; ++u) acc += las_bf2f(s.wq[(int64_t)u * Hd + a]) * hq[u];
+      if (s.attention == LAS_ATT_CUSTOM) acc = las_bf2f(las_f2bf(fmaxf(acc, 0.f)));
       pq[a] = acc;
       if (writer && s.pq_out) s.pq_out[(int64_t)b * s.ldpq + a] = acc;
     }
@@ -102,11 +140,12 @@ __global__ __launch_bounds__(256) void dec_step_fwd_kernel(las_dec_step s) {
       float part_sum = 0.f;
       if (t < len) {
         const unsigned short* krow = keys + (int64_t)t * Hd;
-        if (s.attention == LAS_ATT_LUONG) {
+        if (!att_additive(s.attention)) {
+          const float* qv = s.attention == LAS_ATT_CUSTOM ? pq : hq;
 #pragma unroll 8
           for (int k = sub * 8; k < Hd; k += 32) {
             const uint4 kv = *reinterpret_cast<const uint4*>(krow + k);
-            part_sum += dot8(kv, hq + k);
+            part_sum += dot8(kv, qv + k);
           }
         } else {
 #pragma unroll 4
@@ -125,6 +164,53 @@ __global__ __launch_bounds__(256) void dec_step_fwd_kernel(las_dec_step s) {
   }
   __syncthreads();
 
+  if (s.norm != LAS_NORM_SOFTMAX) {
+    // ---- monotonic attention (tf.contrib.seq2seq.monotonic_attention) ----
+    float* wa = cred + 2048;          // [Tm]
+    float* wb = wa + Tm;              // [Tm]
+    float* tmp = cred;                // 256 floats of scan scratch (cred is free until the context phase)
+    const float bias = s.score_bias ? *s.score_bias : 0.f;
+    const float* prev = s.prev_align ? s.prev_align + (int64_t)b * s.ldpa : nullptr;
+    for (int t = tid; t < Tm; t += 256) {
+      float p = 0.f;
+      if (t < len) {
+        float sv = sc[t] + bias;
+        if (s.noise_scale > 0.f)
+          sv += s.noise_scale * las_normal(s.noise_seed, s.noise_stream, ((unsigned long long)s.step * s.B + b) * Tm + t);
+        p = s.norm == LAS_NORM_MONOTONIC_HARD ? (sv > 0.f ? 1.f : 0.f) : las_sigmoid(sv);
+      }
+      sc[t] = p;
+      wb[t] = prev ? prev[t] : (t == 0 ? 1.f : 0.f);
+      if (writer && s.p_out) s.p_out[(int64_t)b * s.ldp + t] = p;
+    }
+    __syncthreads();
+    if (s.norm == LAS_NORM_MONOTONIC_PARALLEL) {
+      // a = p * c * cumsum(prev / clip(c, 1e-10, 1)),  c = exclusive cumprod(1 - p) in log space (safe_cumprod)
+      for (int t = tid; t < Tm; t += 256) wa[t] = __logf(fminf(fmaxf(1.f - sc[t], 1.17549435e-38f), 1.f));
+      block_scan<false>(wa, Tm, tmp, true, false);
+      for (int t = tid; t < Tm; t += 256) {
+        const float c = __expf(wa[t]);
+        wa[t] = c;
+        wb[t] = wb[t] / fminf(fmaxf(c, 1e-10f), 1.f);
+      }
+      block_scan<false>(wb, Tm, tmp, false, false);
+      for (int t = tid; t < Tm; t += 256) sc[t] = sc[t] * wa[t] * wb[t];
+    } else {
+      // hard: p *= cumsum(prev); a = p * exclusive cumprod(1 - p)
+      block_scan<false>(wb, Tm, tmp, false, false);
+      for (int t = tid; t < Tm; t += 256) { sc[t] *= wb[t]; wa[t] = 1.f - sc[t]; }
+      block_scan<true>(wa, Tm, tmp, true, false);
+      for (int t = tid; t < Tm; t += 256) sc[t] *= wa[t];
+    }
+    __syncthreads();
+    for (int t = tid; t < Tm; t += 256) {
+      if (writer) {
+        s.align_out[(int64_t)b * s.lda + t] = sc[t];
+        if (s.align_bf16) s.align_bf16[(int64_t)b * s.lda + t] = las_f2bf(sc[t]);
+      }
+    }
+    __syncthreads();
+  } else {
   // ---- masked softmax over t' ----
   float mx = -INFINITY;
   for (int t = tid; t < Tm; t += 256) mx = fmaxf(mx, sc[t]);
@@ -146,13 +232,13 @@ __global__ __launch_bounds__(256) void dec_step_fwd_kernel(las_dec_step s) {
     }
   }
   __syncthreads();
+  }
 
   // ---- context = sum_t' p[t'] * values[b,t',:] for this workgroup's column range.  L = cols/8 lanes cover one
   // frame with 16-byte loads; the 256/L frame phases are reduced through LDS. ----
   const unsigned short* vals = s.values + (int64_t)b * Tm * M;
   const int cols_per = ((M / 8 + nparts - 1) / nparts) * 8;
   const int c_begin = part * cols_per, c_end = min(M, c_begin + cols_per);
-  float* cred = red + 8;     // [256][8] floats
   for (int cb = c_begin; cb < c_end; cb += 2048) {
     const int ncols = min(2048, c_end - cb);
     int L = 1;
@@ -261,6 +347,62 @@ __global__ __launch_bounds__(256) void dec_step_bwd_kernel(las_dec_step_bwd s) {
   }
   __syncthreads();
 
+  if (s.norm == LAS_NORM_MONOTONIC_PARALLEL) {
+    // backward of a = p * c * S,  c = exp(excl-cumsum(log clip(1-p, tiny, 1))),  S = cumsum(prev / clip(c, 1e-10, 1));
+    // the gradient also flows into prev = align_{t-1} (dalign_carry) and comes back from step t+1 the same way
+    float* wp = red + 8 + Hd;       // [Tm] p
+    float* wc = wp + Tm;            // [Tm] c
+    float* wS = wc + Tm;            // [Tm] S, later dS -> du
+    float* wd = wS + Tm;            // [Tm] dc -> dcs -> dlx
+    float* wprev = wd + Tm;         // [Tm] prev
+    float* tmp = dhs;               // scan scratch (dhs is free until the query-path phase)
+    const float* pv = s.p + (int64_t)b * s.ldp;
+    const float* prev = s.prev_align ? s.prev_align + (int64_t)b * s.ldpa : nullptr;
+    float* carry = s.dalign_carry + (int64_t)b * s.ldcarry;
+    for (int t = tid; t < Tm; t += 256) {
+      const float p = (t < len) ? pv[t] : 0.f;
+      wp[t] = p;
+      wc[t] = __logf(fminf(fmaxf(1.f - p, 1.17549435e-38f), 1.f));
+      wprev[t] = prev ? prev[t] : (t == 0 ? 1.f : 0.f);
+      ds[t] += carry[t];                                    // d(align_t) from step t+1's normaliser
+    }
+    __syncthreads();
+    block_scan<false>(wc, Tm, tmp, true, false);
+    for (int t = tid; t < Tm; t += 256) {
+      const float c = __expf(wc[t]);
+      wc[t] = c;
+      wS[t] = wprev[t] / fminf(fmaxf(c, 1e-10f), 1.f);
+    }
+    block_scan<false>(wS, Tm, tmp, false, false);
+    for (int t = tid; t < Tm; t += 256) {
+      const float da = ds[t], p = wp[t], c = wc[t], S = wS[t];
+      ds[t] = da * c * S;            // dp (direct part)
+      wd[t] = da * p * S;            // dc (direct part)
+      wS[t] = da * p * c;            // dS
+    }
+    block_scan<false>(wS, Tm, tmp, false, true);            // du[t] = sum_{i >= t} dS[i]
+    for (int t = tid; t < Tm; t += 256) {
+      const float c = wc[t], cc = fminf(fmaxf(c, 1e-10f), 1.f), du = wS[t];
+      carry[t] = du / cc;                                   // d(align_{t-1})
+      float dc = wd[t];
+      if (c >= 1e-10f && c <= 1.f) dc -= du * wprev[t] / (cc * cc);
+      wd[t] = dc * c;                                       // d(cs)
+    }
+    block_scan<false>(wd, Tm, tmp, true, true);             // dlx[k] = sum_{j > k} dcs[j]
+    float dbias = 0.f;
+    for (int t = tid; t < Tm; t += 256) {
+      const float p = wp[t], x = 1.f - p;
+      float dp = ds[t];
+      if (x >= 1.17549435e-38f && x <= 1.f) dp -= wd[t] / x;
+      const float v = (t < len) ? dp * p * (1.f - p) : 0.f;
+      ds[t] = v;
+      dbias += v;
+      if (s.ds_out) s.ds_out[(int64_t)b * s.ldso + t] = las_f2bf(v);
+    }
+    dbias = block_reduce(dbias, red, false);
+    if (tid == 0 && s.dbias_acc) atomicAdd(s.dbias_acc, dbias);
+    __syncthreads();
+  } else {
   // softmax backward: ds = p * (dalign - sum p*dalign)
   const float* align = s.align + (int64_t)b * s.lda;
   float dot = 0.f;
@@ -272,6 +414,7 @@ __global__ __launch_bounds__(256) void dec_step_bwd_kernel(las_dec_step_bwd s) {
     if (s.ds_out) s.ds_out[(int64_t)b * s.ldso + t] = las_f2bf(v);
   }
   __syncthreads();
+  }
 
   // gradient into the query path: L = Hd/8 lanes cover one frame (16-byte loads), 256/L frame phases
   const unsigned short* keys = s.keys + (int64_t)b * Tm * Hd;
@@ -281,7 +424,7 @@ __global__ __launch_bounds__(256) void dec_step_bwd_kernel(las_dec_step_bwd s) {
     float a[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) a[j] = 0.f;
-    if (s.attention == LAS_ATT_LUONG) {
+    if (!att_additive(s.attention)) {
 #pragma unroll 4
       for (int t = phase; t < len; t += P) {
         const uint4 v = *reinterpret_cast<const uint4*>(keys + (int64_t)t * Hd + u);
@@ -326,9 +469,14 @@ __global__ __launch_bounds__(256) void dec_step_bwd_kernel(las_dec_step_bwd s) {
   __syncthreads();
   for (int u = tid; u < Hd; u += 256) dhs[u] = red[8 + u];
   __syncthreads();
-  if (s.attention == LAS_ATT_BAHDANAU) {
+  if (att_uses_wq(s.attention)) {
     // dhs holds d(processed query); save it (bf16) for d(query_layer) and map back: dh[u] = sum_a dpq[a] Wq[u][a]
     float* tmp = dhs + Hd;
+    if (s.attention == LAS_ATT_CUSTOM) {          // through relu: the saved processed query is the relu output
+      const float* pqv = s.pq + (int64_t)b * s.ldpq;
+      for (int u = tid; u < Hd; u += 256) if (!(pqv[u] > 0.f)) dhs[u] = 0.f;
+      __syncthreads();
+    }
     for (int u = tid; u < Hd; u += 256) {
       if (s.dpq_out) s.dpq_out[(int64_t)b * s.lddpq + u] = las_f2bf(dhs[u]);
       float acc = 0.f;
@@ -413,12 +561,17 @@ __global__ __launch_bounds__(256) void seq_ce_kernel(const float* logits, int64_
 
 extern "C" int las_decoder_step_fwd(const las_dec_step* s, int parts, void* stream) {
   LAS_REQUIRE(s->B > 0 && s->Hd % 8 == 0 && s->M % 8 == 0 && s->Tm > 0, "las_decoder_step_fwd: bad shape");
-  LAS_REQUIRE(s->mode == LAS_DEC_CELL_ONLY || s->attention == LAS_ATT_LUONG || (s->wq && s->att_v),
-              "las_decoder_step_fwd: Bahdanau needs wq and att_v");
+  const int att = s->attention;
+  const bool additive = att == LAS_ATT_BAHDANAU || att == LAS_ATT_BAHDANAU_MONOTONIC;
+  LAS_REQUIRE(att >= LAS_ATT_LUONG && att <= LAS_ATT_BAHDANAU_MONOTONIC, "las_decoder_step_fwd: unknown attention %d", att);
+  LAS_REQUIRE(s->mode == LAS_DEC_CELL_ONLY || !(additive || att == LAS_ATT_CUSTOM) || s->wq,
+              "las_decoder_step_fwd: this attention type needs the query_layer kernel wq");
+  LAS_REQUIRE(s->mode == LAS_DEC_CELL_ONLY || !additive || s->att_v, "las_decoder_step_fwd: Bahdanau scores need att_v");
+  LAS_REQUIRE(s->norm >= LAS_NORM_SOFTMAX && s->norm <= LAS_NORM_MONOTONIC_HARD, "las_decoder_step_fwd: unknown normaliser %d", s->norm);
   LAS_REQUIRE(s->mode != LAS_DEC_ATTENTION_ONLY || s->query, "las_decoder_step_fwd: attention-only mode needs a query");
   if (s->mode == LAS_DEC_CELL_ONLY) parts = 1;
   if (parts < 1) parts = 1;
-  const size_t lds = (size_t)(2 * s->Hd + s->Tm + 8 + 8 + 2048) * sizeof(float);
+  const size_t lds = (size_t)(2 * s->Hd + s->Tm + 8 + 8 + 2048 + (s->norm != LAS_NORM_SOFTMAX ? 2 * s->Tm : 0)) * sizeof(float);
   LAS_REQUIRE(lds <= 64 * 1024, "las_decoder_step_fwd: memory length %d too long for the LDS score buffer", s->Tm);
   hipLaunchKernelGGL(dec_step_fwd_kernel, dim3(s->B, parts), dim3(256), lds, (hipStream_t)stream, *s);
   LAS_LAUNCH_CHECK("decoder step fwd launch");
@@ -428,11 +581,19 @@ extern "C" int las_decoder_step_fwd(const las_dec_step* s, int parts, void* stre
 extern "C" int las_decoder_step_bwd(const las_dec_step_bwd* s, void* stream) {
   LAS_REQUIRE(s->B > 0 && s->Hd >= 64 && s->Hd <= 1024 && (s->Hd & (s->Hd - 1)) == 0 && s->M % 128 == 0 && s->Tm > 0,
               "las_decoder_step_bwd: decoder_units must be a power of two in [64,1024], memory depth a multiple of 128");
-  LAS_REQUIRE(s->mode == LAS_DEC_CELL_ONLY || s->attention == LAS_ATT_LUONG ||
-                  (s->wq_t && s->att_v && s->pq && s->dkeys_acc && s->dv_acc),
-              "las_decoder_step_bwd: Bahdanau needs wq_t, att_v, pq, dkeys_acc, dv_acc");
+  const int att = s->attention;
+  const bool additive = att == LAS_ATT_BAHDANAU || att == LAS_ATT_BAHDANAU_MONOTONIC;
+  LAS_REQUIRE(att >= LAS_ATT_LUONG && att <= LAS_ATT_BAHDANAU_MONOTONIC, "las_decoder_step_bwd: unknown attention %d", att);
+  LAS_REQUIRE(s->mode == LAS_DEC_CELL_ONLY || !additive || (s->wq_t && s->att_v && s->pq && s->dkeys_acc && s->dv_acc),
+              "las_decoder_step_bwd: Bahdanau scores need wq_t, att_v, pq, dkeys_acc, dv_acc");
+  LAS_REQUIRE(s->mode == LAS_DEC_CELL_ONLY || att != LAS_ATT_CUSTOM || (s->wq_t && s->pq),
+              "las_decoder_step_bwd: CustomAttention needs wq_t and the saved processed query");
+  LAS_REQUIRE(s->norm == LAS_NORM_SOFTMAX || s->norm == LAS_NORM_MONOTONIC_PARALLEL,
+              "las_decoder_step_bwd: normaliser %d has no backward ('hard' monotonic attention is inference only)", s->norm);
+  LAS_REQUIRE(s->mode == LAS_DEC_CELL_ONLY || s->norm == LAS_NORM_SOFTMAX || (s->p && s->dalign_carry),
+              "las_decoder_step_bwd: monotonic attention needs the saved p_choose and the dalign_carry buffer");
   LAS_REQUIRE(s->mode != LAS_DEC_ATTENTION_ONLY || s->dq_out, "las_decoder_step_bwd: attention-only mode needs dq_out");
-  const size_t lds = (size_t)(s->M + s->Tm + 2048 + 8 + s->Hd) * sizeof(float);
+  const size_t lds = (size_t)(s->M + s->Tm + 2048 + 8 + s->Hd + (s->norm != LAS_NORM_SOFTMAX ? 5 * s->Tm : 0)) * sizeof(float);
   LAS_REQUIRE(lds <= 64 * 1024, "las_decoder_step_bwd: shapes exceed the LDS budget");
   hipLaunchKernelGGL(dec_step_bwd_kernel, dim3(s->B), dim3(256), lds, (hipStream_t)stream, *s);
   LAS_LAUNCH_CHECK("decoder step bwd launch");

@@ -70,4 +70,9 @@ __device__ __forceinline__ float las_uniform(unsigned seed, unsigned stream, uns
   h = las_mix32(h + (unsigned)(idx >> 32) * 0x85EBCA6Bu + 0x632BE5ABu);
   return (float)(h >> 8) * (1.0f / 16777216.0f);
 }
-
+// N(0,1) draw i of (seed, stream): Box-Muller on the uniforms 2i and 2i+1
+__device__ __forceinline__ float las_normal(unsigned seed, unsigned stream, unsigned long long i) {
+  const float u1 = fmaxf(las_uniform(seed, stream, i * 2), 1e-12f);
+  const float u2 = las_uniform(seed, stream, i * 2 + 1);
+  return sqrtf(-2.0f * __logf(u1)) * __cosf(6.2831853f * u2);
+}

@@ -85,10 +85,23 @@ __global__ void sample_kernel(const float* logits, int64_t ldl, int V, const int
 // p[i] += std * N(0,1)  (Box-Muller on two counter-based uniforms): weight noise of model_helper.py:418-432
 __global__ void add_noise_kernel(float* p, int64_t n, float std, unsigned seed, unsigned stream) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-    const float u1 = fmaxf(las_uniform(seed, stream, (unsigned long long)i * 2), 1e-12f);
-    const float u2 = las_uniform(seed, stream, (unsigned long long)i * 2 + 1);
-    p[i] += std * sqrtf(-2.0f * __logf(u1)) * __cosf(6.2831853f * u2);
+    p[i] += std * las_normal(seed, stream, (unsigned long long)i);
   }
+}
+
+__global__ void normal_fill_kernel(float* out, int64_t n, unsigned seed, unsigned stream) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    out[i] = las_normal(seed, stream, (unsigned long long)i);
+}
+
+__global__ void relu_bf16_kernel(unsigned short* x, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    if (x[i] & 0x8000u) x[i] = 0;          // negative (or -0): clamp to +0
+}
+
+__global__ void relu_bwd_kernel(float* d, const unsigned short* y, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    if (!(las_bf2f(y[i]) > 0.f)) d[i] = 0.f;
 }
 
 __global__ void add_masked_kernel(const float* a, int64_t lda, const float* b, int64_t ldb, float* out, int64_t ldo, int rows,
@@ -155,6 +168,27 @@ extern "C" int las_sample_tokens(const float* logits, int64_t ldl, int V, const 
   hipLaunchKernelGGL(sample_kernel, dim3((B + 3) / 4), dim3(256), 0, (hipStream_t)stream, logits, ldl, V, teacher, teacher_stride,
                      next, next_stride, B, prob, seed, step);
   LAS_LAUNCH_CHECK("sample launch");
+  return LAS_OK;
+}
+
+extern "C" int las_normal_fill(float* out, int64_t n, uint32_t seed, uint32_t stream_id, void* stream) {
+  LAS_REQUIRE(n > 0 && out, "las_normal_fill: bad arguments");
+  hipLaunchKernelGGL(normal_fill_kernel, dim3(blocks_for(n)), dim3(256), 0, (hipStream_t)stream, out, n, seed, stream_id);
+  LAS_LAUNCH_CHECK("normal fill launch");
+  return LAS_OK;
+}
+
+extern "C" int las_relu_bf16(las_bf16* x, int64_t n, void* stream) {
+  LAS_REQUIRE(n > 0 && x, "las_relu_bf16: bad arguments");
+  hipLaunchKernelGGL(relu_bf16_kernel, dim3(blocks_for(n)), dim3(256), 0, (hipStream_t)stream, x, n);
+  LAS_LAUNCH_CHECK("relu launch");
+  return LAS_OK;
+}
+
+extern "C" int las_relu_bwd(float* d, const las_bf16* y, int64_t n, void* stream) {
+  LAS_REQUIRE(n > 0 && d && y, "las_relu_bwd: bad arguments");
+  hipLaunchKernelGGL(relu_bwd_kernel, dim3(blocks_for(n)), dim3(256), 0, (hipStream_t)stream, d, y, n);
+  LAS_LAUNCH_CHECK("relu bwd launch");
   return LAS_OK;
 }
 

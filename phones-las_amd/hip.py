@@ -51,6 +51,9 @@ _SIGS = {
     'las_fe_delta': ([_vp, _i64, _i32, _i32, _vp, _vp, _vp, _i32, _vp, _i64, _i32, _i32, _vp], C.c_int),
     'las_add_masked': ([_vp, _i64, _vp, _i64, _vp, _i64, _i32, _i32, _f32, C.c_uint32, C.c_uint32, C.c_uint64, _i64, _vp], C.c_int),
     'las_add_noise': ([_vp, _i64, _f32, C.c_uint32, C.c_uint32, _vp], C.c_int),
+    'las_normal_fill': ([_vp, _i64, C.c_uint32, C.c_uint32, _vp], C.c_int),
+    'las_relu_bf16': ([_vp, _i64, _vp], C.c_int),
+    'las_relu_bwd': ([_vp, _vp, _i64, _vp], C.c_int),
     'las_sample_tokens': ([_vp, _i64, _i32, _vp, _i64, _vp, _i64, _i32, _f32, C.c_uint32, C.c_uint32, _vp], C.c_int),
 }
 
@@ -68,7 +71,9 @@ class DecStep(C.Structure):
                 ('mem_len', _vp), ('wq', _vp), ('att_v', _vp), ('align_out', _vp), ('align_bf16', _vp),
                 ('lda', _i64), ('pq_out', _vp), ('ldpq', _i64), ('ctx_out', _vp), ('ldc', _i64),
                 ('ctx_out2', _vp), ('ldc2', _i64), ('drop_keep', _f32), ('drop_seed', C.c_uint32),
-                ('drop_stream', C.c_uint32), ('step', _i32), ('feed_width', _i32), ('query', _vp), ('ldq', _i64)]
+                ('drop_stream', C.c_uint32), ('step', _i32), ('feed_width', _i32), ('query', _vp), ('ldq', _i64),
+                ('norm', _i32), ('score_bias', _vp), ('prev_align', _vp), ('ldpa', _i64), ('p_out', _vp), ('ldp', _i64),
+                ('noise_scale', _f32), ('noise_seed', C.c_uint32), ('noise_stream', C.c_uint32)]
 
 
 class DecStepBwd(C.Structure):
@@ -81,10 +86,16 @@ class DecStepBwd(C.Structure):
                 ('dz', _vp), ('ldz', _i64), ('ds_out', _vp), ('ldso', _i64), ('dkeys_acc', _vp), ('dv_acc', _vp),
                 ('dpq_out', _vp), ('lddpq', _i64), ('drop_keep', _f32), ('drop_seed', C.c_uint32),
                 ('drop_stream', C.c_uint32), ('step', _i32), ('feed_width', _i32), ('dq_out', _vp), ('lddq', _i64),
-                ('dh_b', _vp), ('ldhb', _i64), ('dh_c', _vp), ('ldhc', _i64)]
+                ('dh_b', _vp), ('ldhb', _i64), ('dh_c', _vp), ('ldhc', _i64),
+                ('norm', _i32), ('p', _vp), ('ldp', _i64), ('prev_align', _vp), ('ldpa', _i64), ('dalign_carry', _vp),
+                ('ldcarry', _i64), ('dbias_acc', _vp)]
 
 
-ATT_LUONG, ATT_BAHDANAU = 0, 1
+ATT_LUONG, ATT_BAHDANAU, ATT_CUSTOM, ATT_LUONG_MONOTONIC, ATT_BAHDANAU_MONOTONIC = 0, 1, 2, 3, 4
+NORM_SOFTMAX, NORM_MONOTONIC_PARALLEL, NORM_MONOTONIC_HARD = 0, 1, 2
+ATT_ADDITIVE = (ATT_BAHDANAU, ATT_BAHDANAU_MONOTONIC)
+ATT_USES_WQ = (ATT_BAHDANAU, ATT_BAHDANAU_MONOTONIC, ATT_CUSTOM)
+ATT_MONOTONIC = (ATT_LUONG_MONOTONIC, ATT_BAHDANAU_MONOTONIC)
 DEC_FUSED, DEC_CELL_ONLY, DEC_ATTENTION_ONLY = 0, 1, 2
 
 

@@ -99,7 +99,9 @@ def listener(encoder_inputs, source_sequence_length, mode, hparams, *, variables
 # =================================================================================================
 # speller
 # =================================================================================================
-_ATT = {'luong': hip.ATT_LUONG, 'bahdanau': hip.ATT_BAHDANAU}
+_ATT = {'luong': hip.ATT_LUONG, 'bahdanau': hip.ATT_BAHDANAU, 'custom': hip.ATT_CUSTOM,
+        'luong_monotonic': hip.ATT_LUONG_MONOTONIC, 'bahdanau_monotonic': hip.ATT_BAHDANAU_MONOTONIC}
+_ATT_FUSED = ('luong', 'bahdanau')            # mechanisms of the fused single-cell fast path
 
 
 def make_speller(hparams, variables, memory_depth):
@@ -108,10 +110,10 @@ def make_speller(hparams, variables, memory_depth):
     embedding)."""
     d = hparams
     if d.attention_type not in _ATT:
-        raise ValueError('attention_type %r is not implemented on the HIP path (luong, bahdanau)' % d.attention_type)
+        raise ValueError('attention_type %r is not one of %s' % (d.attention_type, sorted(_ATT)))
     if getattr(d, 'binf_projection', False) or getattr(d, 'binary_outputs', False):
         raise ValueError('binary-feature decoders are not implemented on the HIP path this round')
-    if d.num_layers == 1 and not d.attention_layer_size and not d.embedding_size:
+    if d.num_layers == 1 and not d.attention_layer_size and not d.embedding_size and d.attention_type in _ATT_FUSED:
         return Speller(hparams, variables, memory_depth)
     from .speller_general import GeneralSpeller
     return GeneralSpeller(hparams, variables, memory_depth, _ATT[d.attention_type])
@@ -122,8 +124,8 @@ class Speller:
 
     def __init__(self, hparams, variables, memory_depth):
         d = hparams
-        if d.attention_type not in _ATT:
-            raise ValueError('attention_type %r is not implemented on the HIP path (luong, bahdanau)' % d.attention_type)
+        if d.attention_type not in _ATT_FUSED:
+            raise ValueError('attention_type %r is not on the fused path (use make_speller)' % d.attention_type)
         if d.num_layers != 1:
             raise ValueError('decoder_layers must be 1 on the HIP path this round')
         if d.attention_layer_size:

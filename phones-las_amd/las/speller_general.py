@@ -34,6 +34,8 @@ class GeneralSpeller:
     V_ATT = 'speller/attention_v'
     K_AL = 'speller/attention_layer/kernel'
     K_EMB = 'speller/target_embedding'
+    B_SCORE = 'speller/attention_score_bias'
+    NOISE_STREAM = 3                     # generator stream of the monotonic-attention score noise (draw (t*B + b)*Tm + t')
 
     def __init__(self, hparams, variables, memory_depth, att_code):
         d = hparams
@@ -42,6 +44,10 @@ class GeneralSpeller:
                              '(element-wise dropout of the embedded token needs its own product)')
         self.hp = d
         self.att = att_code
+        self.additive = att_code in hip.ATT_ADDITIVE          # v . tanh(keys + Wq h) scores
+        self.uses_wq = att_code in hip.ATT_USES_WQ            # query_layer in front of the score
+        self.mono = att_code in hip.ATT_MONOTONIC
+        self.custom = att_code == hip.ATT_CUSTOM
         self.NL, self.bottom = d.num_layers, bool(d.bottom_only)
         self.V, self.Vp = d.target_vocab_size, _r8(d.target_vocab_size)
         self.Hd, self.M = d.num_units, memory_depth
@@ -79,7 +85,7 @@ class GeneralSpeller:
             self.emb_bf = torch.empty(self.V, self.E, dtype=bf, device=dev)
             self.k0tokT = torch.empty(4 * Hd, self.E, dtype=bf, device=dev)
             self.k0tok = torch.empty(self.E, 4 * Hd, dtype=bf, device=dev)
-        if self.att == hip.ATT_BAHDANAU:
+        if self.uses_wq:
             self.wq = torch.empty(Hd, Hd, dtype=bf, device=dev)
             self.wq_t = torch.empty(Hd, Hd, dtype=bf, device=dev)
         self.refresh(variables)
@@ -125,10 +131,13 @@ class GeneralSpeller:
         if self.has_al:
             hip.cast_bf16(var[self.K_AL], Hd + M, A, self.walT, A, Hd + M, transpose=True)
             hip.cast_bf16(var[self.K_AL], Hd + M, A, self.waln, Hd + M, A)
-        if self.att == hip.ATT_BAHDANAU:
+        if self.uses_wq:
             hip.cast_bf16(var[self.K_Q], Hd, Hd, self.wq, Hd, Hd)
             hip.cast_bf16(var[self.K_Q], Hd, Hd, self.wq_t, Hd, Hd, transpose=True)
+        if self.additive:
             self.att_v = var[self.V_ATT]
+        if self.mono:
+            self.score_bias = var[self.B_SCORE]
 
     # ------------------------------------------------------------------------------------------------------------------
     def _init_states(self, encoder_state, B):
@@ -149,6 +158,23 @@ class GeneralSpeller:
                 init[l] = (es[l].c, es[l].h)
             passed = self.NL
         return init, passed
+
+    def _keys(self, memory):
+        """keys = memory_layer(memory) (Dense, no bias; las/model.py:168-169), relu'd for CustomAttention (:97)."""
+        B, Tm, M = memory.shape
+        keys = torch.empty(B, Tm, self.Hd, dtype=torch.bfloat16, device=memory.device)
+        hip.gemm_nt(memory, self.wmemT, keys, B * Tm, self.Hd, M, lda=M, ldb=M, ldc=self.Hd, out_bf16=True)
+        if self.custom:
+            hip.check(hip.lib().las_relu_bf16(hip.p(keys), keys.numel(), hip.stream()))
+        return keys
+
+    def _norm(self, train):
+        """alignment normaliser: softmax, or monotonic 'parallel' / 'hard' as las/model.py:157-164 selects them."""
+        if not self.mono:
+            return hip.NORM_SOFTMAX
+        if self.att == hip.ATT_BAHDANAU_MONOTONIC and not train:
+            return hip.NORM_MONOTONIC_HARD
+        return hip.NORM_MONOTONIC_PARALLEL
 
     def _cell_fwd(self, l, t, sv, z, tok_ids, tok_stride):
         B, Hd, U = sv['B'], self.Hd, sv['U']
@@ -173,12 +199,22 @@ class GeneralSpeller:
         s.B, s.Hd, s.M, s.Tm, s.attention, s.mode = B, Hd, M, Tm, self.att, hip.DEC_ATTENTION_ONLY
         s.query, s.ldq = query, ldq
         s.keys, s.values, s.mem_len = hip.addr(sv['keys']), hip.addr(sv['memory']), hip.addr(sv['mem_len'])
-        if self.att == hip.ATT_BAHDANAU:
-            s.wq, s.att_v = hip.addr(self.wq), hip.addr(self.att_v)
+        if self.uses_wq:
+            s.wq = hip.addr(self.wq)
             s.pq_out, s.ldpq = hip.addr(sv['pq'], t * Hd), U * Hd
+        if self.additive:
+            s.att_v = hip.addr(self.att_v)
         s.align_out, s.align_bf16, s.lda = hip.addr(sv['align'], t * Tmp), hip.addr(sv['align_bf'], t * Tmp), U * Tmp
         s.ctx_out, s.ldc = hip.addr(sv['ctx'], t * M), U * M
-        s.drop_keep, s.feed_width = 1.0, self.E + self.A
+        s.drop_keep, s.feed_width, s.step = 1.0, self.E + self.A, t
+        s.norm = sv.get('norm', hip.NORM_SOFTMAX)
+        if self.mono:
+            s.score_bias = hip.addr(self.score_bias)
+            if t > 0:
+                s.prev_align, s.ldpa = hip.addr(sv['align'], (t - 1) * Tmp), U * Tmp
+            if sv.get('p') is not None:
+                s.p_out, s.ldp = hip.addr(sv['p'], t * Tmp), U * Tmp
+            s.noise_scale, s.noise_seed, s.noise_stream = sv.get('noise_scale', 0.0), sv.get('seed', 0), self.NOISE_STREAM
         hip.check(hip.lib().las_decoder_step_fwd(C.byref(s), 4, hip.stream()))
 
     def forward_train(self, memory, mem_len, encoder_state, targets_inputs, num_steps, parts=4, seed=0):
@@ -187,8 +223,7 @@ class GeneralSpeller:
         dev, bf, f32 = memory.device, torch.bfloat16, torch.float32
         Tmp = _r8(Tm)
         init, passed = self._init_states(encoder_state, B)
-        keys = torch.empty(B, Tm, Hd, dtype=bf, device=dev)
-        hip.gemm_nt(memory, self.wmemT, keys, B * Tm, Hd, M, lda=M, ldb=M, ldc=Hd, out_bf16=True)
+        keys = self._keys(memory)
         keep = 1.0 - float(self.hp.dropout or 0.0)
         sampling = float(self.hp.sampling_probability or 0.0)
         sv = dict(B=B, Tm=Tm, U=U, memory=memory, mem_len=mem_len, keys=keys, passed=passed, tin=targets_inputs,
@@ -200,7 +235,11 @@ class GeneralSpeller:
         sv['align'] = torch.zeros(B, U, Tmp, dtype=f32, device=dev)
         sv['align_bf'] = torch.zeros(B, U, Tmp, dtype=bf, device=dev)
         sv['ctx'] = torch.empty(B, U, M, dtype=bf, device=dev)
-        sv['pq'] = torch.empty(B, U, Hd, dtype=f32, device=dev) if self.att == hip.ATT_BAHDANAU else None
+        sv['pq'] = torch.empty(B, U, Hd, dtype=f32, device=dev) if self.uses_wq else None
+        sv['norm'] = self._norm(True)
+        if self.mono:                    # p_choose of every step (backward), sigmoid_noise = 1 for bahdanau_monotonic TRAIN
+            sv['p'] = torch.zeros(B, U, Tmp, dtype=f32, device=dev)
+            sv['noise_scale'] = 1.0 if self.att == hip.ATT_BAHDANAU_MONOTONIC else 0.0
         sv['att'] = torch.empty(B, U, A, dtype=bf, device=dev) if self.has_al else sv['ctx']
         sv['qc'] = torch.empty(B, U, Hd + M, dtype=bf, device=dev) if self.has_al else None
         for l in range(NL):
@@ -266,6 +305,7 @@ class GeneralSpeller:
             logits = torch.empty(B, U, Vp, dtype=f32, device=dev)
             hip.gemm_nt(out_all, self.wprojT, logits, B * U, Vp, self.P, lda=self.P, ldb=self.P, ldc=Vp, bias=self.bproj)
         self.saved = sv
+        self.last_Tm = Tm            # memory length of the last forward (tests replay the score noise)
         return logits
 
     # ------------------------------------------------------------------------------------------------------------------
@@ -295,7 +335,7 @@ class GeneralSpeller:
         dev, bf, f32 = dlogits.device, torch.bfloat16, torch.float32
         lib, st = hip.lib(), hip.stream()
         BU = B * U
-        bah = self.att == hip.ATT_BAHDANAU
+        bah = self.additive
         d_out = torch.empty(B, U, P, dtype=f32, device=dev)
         hip.gemm_nt(dlogits, self.wproj, d_out, BU, P, Vp, lda=Vp, ldb=Vp, ldc=P)
         dc = [torch.zeros(B, Hd, dtype=f32, device=dev) for _ in range(NL)]
@@ -309,7 +349,10 @@ class GeneralSpeller:
         dq = torch.empty(B, Hd, dtype=f32, device=dev)
         if bah:
             dkeys = torch.zeros(B, Tm, Hd, dtype=f32, device=dev)
+        if self.uses_wq:
             dpq_all = torch.empty(B, U, Hd, dtype=bf, device=dev)
+        if self.mono:                    # gradient into align_{t-1} through step t's normaliser
+            carry = torch.zeros(B, Tmp, dtype=f32, device=dev)
         qlayer = 0 if self.bottom else NL - 1
         W = [w + Hd for w in self.win]
 
@@ -359,11 +402,20 @@ class GeneralSpeller:
             s.ds_out, s.ldso = hip.addr(ds_all, t * Tmp), U * Tmp
             s.dq_out, s.lddq = hip.addr(dq), Hd
             s.drop_keep, s.feed_width = 1.0, self.E + A
-            if bah:
+            if self.uses_wq:
                 s.pq, s.ldpq = hip.addr(sv['pq'], t * Hd), U * Hd
-                s.wq_t, s.att_v = hip.addr(self.wq_t), hip.addr(self.att_v)
-                s.dkeys_acc, s.dv_acc = hip.addr(dkeys), hip.addr(grads[self.V_ATT])
+                s.wq_t = hip.addr(self.wq_t)
                 s.dpq_out, s.lddpq = hip.addr(dpq_all, t * Hd), U * Hd
+            if bah:
+                s.att_v = hip.addr(self.att_v)
+                s.dkeys_acc, s.dv_acc = hip.addr(dkeys), hip.addr(grads[self.V_ATT])
+            s.norm = sv['norm']
+            if self.mono:
+                s.p, s.ldp = hip.addr(sv['p'], t * Tmp), U * Tmp
+                if t > 0:
+                    s.prev_align, s.ldpa = hip.addr(sv['align'], (t - 1) * Tmp), U * Tmp
+                s.dalign_carry, s.ldcarry = hip.addr(carry), Tmp
+                s.dbias_acc = hip.addr(grads[self.B_SCORE])
             hip.check(lib.las_decoder_step_bwd(C.byref(s), st))
             qsrc = [v(dq, 0, Hd)] + ([v(dqc, 0, Hd + M)] if self.has_al else [])
             if self.bottom:
@@ -374,9 +426,15 @@ class GeneralSpeller:
                     cell_and_gemm(l, [v(dx[l + 1][cur], 0, W[l + 1])])
         # ---- after the loop: attention tensors (critical path into the listener) ----
         if not bah:
+            # dot-product scores: d(keys)[b] = dScore[b]^T Q[b], Q = the queries (relu(Wq h) for CustomAttention)
+            qmat = sv['h'][qlayer]
+            if self.custom:
+                qmat = torch.empty(B, U, Hd, dtype=bf, device=dev)
+                hip.cast_bf16(sv['pq'], BU, Hd, qmat, BU, Hd, ldd=Hd, lds=Hd)
             dkeys = torch.zeros(B, Tm, Hd, dtype=f32, device=dev)
-            hip.gemm_tn(ds_all, sv['h'][qlayer], dkeys, Tm, Hd, U, lda=Tmp, ldb=Hd, ldc=Hd, batch=B, sa=U * Tmp, sb=U * Hd,
-                        sc=Tm * Hd)
+            hip.gemm_tn(ds_all, qmat, dkeys, Tm, Hd, U, lda=Tmp, ldb=Hd, ldc=Hd, batch=B, sa=U * Tmp, sb=U * Hd, sc=Tm * Hd)
+            if self.custom:              # keys = relu(memory_layer(memory))
+                hip.check(lib.las_relu_bwd(hip.p(dkeys), hip.p(sv['keys']), dkeys.numel(), st))
         dmem = torch.zeros(B, Tm, M, dtype=f32, device=dev)
         hip.gemm_tn(sv['align_bf'], dctx_all, dmem, Tm, M, U, lda=Tmp, ldb=M, ldc=M, batch=B, sa=U * Tmp, sb=U * M, sc=Tm * M)
         dkeys_bf = torch.empty(B * Tm, Hd, dtype=bf, device=dev)
@@ -386,7 +444,7 @@ class GeneralSpeller:
         hip.gemm_tn(sv['out'], dlogits, grads[self.K_PROJ], P, V, BU, lda=P, ldb=Vp, ldc=V, split_k=4)
         hip.colsum_bf16(dlogits, BU, V, grads[self.B_PROJ], ldx=Vp)
         hip.gemm_tn(sv['memory'], dkeys_bf, grads[self.K_MEM], M, Hd, B * Tm, lda=M, ldb=Hd, ldc=Hd, split_k=8)
-        if bah:
+        if self.uses_wq:
             hip.gemm_tn(sv['h'][qlayer], dpq_all, grads[self.K_Q], Hd, Hd, BU, lda=Hd, ldb=Hd, ldc=Hd, split_k=4)
         if self.has_al:
             hip.gemm_tn(sv['qc'], datt_bf, grads[self.K_AL], Hd + M, A, BU, lda=Hd + M, ldb=A, ldc=A, split_k=4)
@@ -430,11 +488,10 @@ class GeneralSpeller:
         fed = torch.full((B, max(S, 1)), d.eos_id, dtype=torch.int32, device=dev)
         fed[:, :1] = ids0
         # reuse the training graph step by step on [B, S] buffers (teacher tokens replaced by the argmax)
-        keys = torch.empty(B, Tm, Hd, dtype=bf, device=dev)
-        hip.gemm_nt(memory, self.wmemT, keys, B * Tm, Hd, M, lda=M, ldb=M, ldc=Hd, out_bf16=True)
+        keys = self._keys(memory)
         Tmp = _r8(Tm)
         U = max(S, 1)
-        sv = dict(B=B, Tm=Tm, U=U, memory=memory, mem_len=mem_len, keys=keys, keep=1.0, seed=0)
+        sv = dict(B=B, Tm=Tm, U=U, memory=memory, mem_len=mem_len, keys=keys, keep=1.0, seed=0, norm=self._norm(False))
         sv['X'] = [torch.zeros(B, U, w + Hd, dtype=bf, device=dev) for w in self.win]
         sv['gates'] = [torch.empty(B, U, 4 * Hd, dtype=f32, device=dev) for _ in range(NL)]
         sv['cs'] = [torch.empty(B, U + 1, Hd, dtype=f32, device=dev) for _ in range(NL)]
@@ -442,7 +499,7 @@ class GeneralSpeller:
         sv['align'] = torch.zeros(B, U, Tmp, dtype=f32, device=dev)
         sv['align_bf'] = torch.zeros(B, U, Tmp, dtype=bf, device=dev)
         sv['ctx'] = torch.empty(B, U, M, dtype=bf, device=dev)
-        sv['pq'] = torch.empty(B, U, Hd, dtype=f32, device=dev) if self.att == hip.ATT_BAHDANAU else None
+        sv['pq'] = torch.empty(B, U, Hd, dtype=f32, device=dev) if self.uses_wq else None
         att = torch.empty(B, U, A, dtype=bf, device=dev) if self.has_al else sv['ctx']
         qc = torch.empty(B, U, Hd + M, dtype=bf, device=dev) if self.has_al else None
         for l in range(NL):

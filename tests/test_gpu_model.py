@@ -267,3 +267,48 @@ def test_general_decoder_configs_vs_oracle(kw):
     rl, rids, rfl, _ = O.speller_greedy(ohp, op, mem, ml, st, 'bf16')
     pred = model.predict(feats)
     assert relerr(pred['logits'][:, 0], rl[:, 0]) < 2e-2
+
+
+@pytest.mark.parametrize('kw', [
+    dict(att='custom', dec_layers=1, bottom_only=True, pass_hidden=True),                 # CustomAttention (las/model.py:72-101)
+    dict(att='luong_monotonic', dec_layers=1, bottom_only=True, pass_hidden=True),        # 'parallel' mode, no noise
+    dict(att='bahdanau_monotonic', dec_layers=2, bottom_only=True, pass_hidden=True, als=16),   # + sigmoid_noise 1 in TRAIN
+], ids=['custom', 'luong_monotonic', 'bahdanau_monotonic'])
+def test_custom_and_monotonic_attention_vs_oracle(kw):
+    """the remaining attention mechanisms.  The Gaussian score noise of
+    BahdanauMonotonicAttention in TRAIN mode is exported from the device generator and replayed through the oracle;
+    score_bias gets a non-zero value so that its gradient path is exercised.  Same tolerances as above."""
+    from phones_las_amd import hip
+    O, ohp, op, model = _models(**kw)
+    from phones_las_amd.las.speller_general import GeneralSpeller
+    assert isinstance(model.speller, GeneralSpeller)
+    if 'speller/attention_score_bias' in op:
+        op['speller/attention_score_bias'] = op['speller/attention_score_bias'] + 0.3
+        model.load_variables({k: v for k, v in op.items()})
+    src_len, tgt_len = [12, 7, 10], [6, 4, 5]
+    batch = make_batch(src_len=src_len, tgt_len=tgt_len)
+    feats, labels = to_device(batch)
+    model.vars.grad.zero_()
+    loss, logits, dlogits = model.forward_train(feats, labels)
+    model.backward(dlogits)
+    torch.cuda.synchronize()
+    stochastic = None
+    if kw['att'] == 'bahdanau_monotonic':
+        B, U = 3, max(tgt_len)
+        Tm = model.speller.last_Tm
+        noise = torch.empty(U * B * Tm, dtype=torch.float32, device='cuda')
+        hip.check(hip.lib().las_normal_fill(hip.p(noise), noise.numel(), model.last_seed, GeneralSpeller.NOISE_STREAM, hip.stream()))
+        stochastic = {'att_noise': noise.view(U, B, Tm).cpu().to(DT)}
+    out = O.train_step(ohp, op, None, None, 1, batch, mxu='bf16', stochastic=stochastic)
+    V = ohp.decoder.target_vocab_size
+    for b, n in enumerate(tgt_len):
+        assert relerr(logits[b, :n, :V], out['aux']['logits'][b, :n]) < 2e-2
+    assert abs(float(loss) - float(out['aux']['ce'].detach())) < 2e-2 * float(out['aux']['ce'].detach())
+    for name, _, _ in model.vars.table:
+        g = out['grads'][name] - ohp.l2_reg_scale * op[name]
+        assert relerr(model.vars.grads[name], g) < 6e-2, name
+    # inference: bahdanau_monotonic switches to the 'hard' normaliser (las/model.py:163-164)
+    (mem, ml), st = O.listener(batch['encoder_inputs'], batch['source_sequence_length'], op, ohp.encoder, 'bf16')
+    rl, rids, rfl, _ = O.speller_greedy(ohp, op, mem, ml, st, 'bf16')
+    pred = model.predict(feats)
+    assert relerr(pred['logits'][:, 0], rl[:, 0]) < 2e-2
