@@ -312,6 +312,12 @@ int las_seq_ce_loss(const float* logits, int64_t ldl, const int32_t* targets, co
                     int B, int U, int V, float grad_scale, float* loss_out, las_bf16* dlogits, int64_t ldd,
                     void* stream);
 
+/* compute_log_probs_loss of the binf_projection decoder (model_helper.py:132-146, :327-331): x [rows, 2*nf] bf16 holds
+ * [log p(f=1) | log p(f=0)] per decoder step (ALL rows count, padded steps too).  loss_out += weight * mean(|e^a + e^b
+ * - 1| + relu(a) + relu(b)); dx (fp32, row stride ldd, may be NULL) = grad_scale * weight * d(mean)/dx. */
+int las_log_probs_loss(const las_bf16* x, int64_t ldx, int rows, int nf, float weight, float grad_scale,
+                       float* loss_out, float* dx, int64_t ldd, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * CTC head (model_helper.py:347-367): tf.nn.ctc_loss_v2 with dense labels [B,U] (row stride ldlab; blank
  * index `blank` = 0 in the reference, labels include the trailing </s>), logits [B,T,ldl] fp32 with C

@@ -58,7 +58,14 @@ def main(args):
     hparams.decoder.set_hparam('beam_width', args.beam_width)
     dev = torch.device('cuda', 0)
     torch.cuda.set_device(0)
-    model = mh.LasModel(hparams)
+    binf2phone_np = None
+    if hparams.decoder.binary_outputs:       # infer.py:203-210 of the reference
+        if args.mapping is not None:
+            vocab_list, mapping_list = utils.get_mapping(args.mapping, args.vocab)
+            hparams.del_hparam('mapping')
+            hparams.add_hparam('mapping', mapping_list)
+        binf2phone_np = utils.load_binf2phone(args.binf_map, vocab_list).values
+    model = mh.LasModel(hparams, binf2phone=binf2phone_np)
     load_checkpoint(model, os.path.join(args.model_dir, 'checkpoint.pt'))
 
     mapping = hparams.mapping

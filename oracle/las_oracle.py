@@ -87,6 +87,8 @@ class DecoderHP:
     dropout: float = 0.0
     binf_projection: bool = False
     binf_count: int = 0
+    binf_projection_reg_weight: float = 1.0
+    binf_map: Optional[object] = None        # [binf_count, V] 0/1 matrix (utils.load_binf2phone); not a trainable variable
     max_symbols: int = -1
 
 
@@ -141,6 +143,8 @@ def param_table(hp: HP) -> List[Tuple[str, Tuple[int, ...], str]]:
     A = attention_depth(hp)
     V = d.target_vocab_size
     E = d.embedding_size if d.embedding_size else V
+    if d.binf_projection and not d.embedding_size:
+        E = d.binf_count                                             # embedding_fn = rows of binf_map^T (las/model.py:242-243)
     if d.embedding_size:
         out.append(('speller/target_embedding', (V, d.embedding_size), 'glorot'))
     out.append(('speller/memory_layer/kernel', (M, Hd), 'glorot'))
@@ -388,6 +392,7 @@ class Speller:
         self.att = Attention(hp, params, memory, mem_len, self.q, train, noise)
         self.B = memory.shape[0]
         self.A = attention_depth(hp)
+        self.train = train
         d = self.d
         Hd = d.num_units
         z = lambda n: torch.zeros(self.B, n, dtype=DT)
@@ -408,7 +413,23 @@ class Speller:
         d = self.d
         if d.embedding_size:
             return self.q(self.p['speller/target_embedding'])[ids]
+        if d.binf_projection:                                                    # las/model.py:242-243
+            return torch.as_tensor(d.binf_map, dtype=DT).t()[ids]
         return torch.nn.functional.one_hot(ids, d.target_vocab_size).to(DT)
+
+    def project(self, out):
+        """projection_layer of las/model.py:251-257 (DenseBinfDecoder, utils/training_helper.py:122-153)."""
+        d, p, q = self.d, self.p, self.q
+        if not d.binf_projection:
+            return out @ q(p['speller/projection_layer/kernel']) + p['speller/projection_layer/bias']
+        # inner_projection_layer=False: the cell output IS [log p(feature=1) | log p(feature=0)]; the Dense kernel and
+        # bias exist as variables but are not applied.  transform_binf_to_phones (:17-27); TRAIN concatenates the input.
+        Mb = torch.as_tensor(d.binf_map, dtype=DT)
+        nf = Mb.shape[0]
+        if out.shape[1] != 2 * nf:
+            raise ValueError('binf_projection needs the decoder output to be the 2*binf_count attention vector')
+        logits = out[:, :nf] @ Mb + out[:, nf:2 * nf] @ (1 - Mb)
+        return torch.cat([logits, out], 1) if self.train else logits
 
     def _cell(self, l, x, state):
         k = self.q(self.p[f'speller/decoder_cell_{l}/lstm_cell/kernel'])
@@ -466,8 +487,7 @@ class Speller:
         self.attention = attention
         self.align = align
         self.align_hist.append(align)
-        logits = out @ q(p['speller/projection_layer/kernel']) + p['speller/projection_layer/bias']
-        return logits
+        return self.project(out)
 
 
 def speller_train(hp: HP, params, memory, mem_len, enc_state, targets_inputs, target_len,
@@ -659,8 +679,16 @@ def model_loss(hp: HP, params, batch, mxu='f64', stochastic=None):
     logits, sp = speller_train(hp, params, mem, mem_len, state, batch['targets_inputs'],
                                batch['target_sequence_length'], mxu, sample_select=st.get('sample_select'),
                                sample_ids=st.get('sample_ids'), noise=st.get('att_noise'), in_masks=st.get('dec_masks'))
+    raw = None
+    if hp.decoder.binf_projection:                                               # model_helper.py:251-253
+        V = hp.decoder.target_vocab_size
+        raw, logits = logits[..., V:], logits[..., :V]
     loss = compute_loss_train(logits, batch['targets_outputs'], batch['target_sequence_length'])
     aux = {'logits': logits, 'memory': mem, 'memory_len': mem_len, 'state': state, 'ce': loss}
+    if raw is not None:                                                          # model_helper.py:327-331
+        reg = compute_log_probs_loss(raw)
+        aux['log_probs_loss'] = reg
+        loss = loss + reg * hp.decoder.binf_projection_reg_weight
     if hp.ctc_weight > 0:
         q = make_q(mxu)
         cl = mem @ q(params['ctc_logits/kernel']) + params['ctc_logits/bias']
@@ -669,6 +697,17 @@ def model_loss(hp: HP, params, batch, mxu='f64', stochastic=None):
         aux['ctc_logits'] = cl
         loss = loss + ctc * hp.ctc_weight
     return loss, aux
+
+
+def compute_log_probs_loss(outputs):
+    """model_helper.py:132-146: pushes [lp1 | lp0] towards normalised log-probabilities; mean over EVERY element
+    (padded steps included); the stabilising constant carries no gradient."""
+    nf = outputs.shape[-1] // 2
+    a, b = outputs[..., :nf], outputs[..., nf:2 * nf]
+    c = (-(a + b) / 2).detach()
+    loss = torch.abs((torch.exp(a + c) + torch.exp(b + c)) / torch.exp(c) - 1)
+    loss = loss + torch.relu(a) + torch.relu(b)
+    return loss.mean()
 
 
 def l2_term(params, scale):

@@ -557,7 +557,45 @@ __global__ __launch_bounds__(256) void seq_ce_kernel(const float* logits, int64_
   if (lane == 0 && local_loss != 0.f) atomicAdd(loss_out, local_loss);
 }
 
+// ------------------------------------------------------------------------------------------------
+// compute_log_probs_loss (model_helper.py:132-146): mean over all rows x nf of
+//   |e^a + e^b - 1| + relu(a) + relu(b),  a = x[:, f] (log p(feature = 1)), b = x[:, nf + f]
+// (the reference multiplies and divides by a gradient-free constant for stability; e^a + e^b is the same value)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void log_probs_loss_kernel(const unsigned short* x, int64_t ldx, int rows, int nf, float weight,
+                                                             float grad_scale, float* loss_out, float* dx, int64_t ldd) {
+  const int64_t total = (int64_t)rows * nf;
+  const float inv = 1.0f / (float)total;
+  float local = 0.f;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int r = (int)(i / nf), f = (int)(i % nf);
+    const float a = las_bf2f(x[(int64_t)r * ldx + f]), b = las_bf2f(x[(int64_t)r * ldx + nf + f]);
+    const float ea = __expf(a), eb = __expf(b);
+    const float v = ea + eb - 1.f;
+    local += (fabsf(v) + fmaxf(a, 0.f) + fmaxf(b, 0.f)) * inv;
+    if (dx) {
+      const float sg = v > 0.f ? 1.f : (v < 0.f ? -1.f : 0.f);
+      const float k = weight * grad_scale * inv;
+      dx[(int64_t)r * ldd + f] = k * (sg * ea + (a > 0.f ? 1.f : 0.f));
+      dx[(int64_t)r * ldd + nf + f] = k * (sg * eb + (b > 0.f ? 1.f : 0.f));
+    }
+  }
+  local = las_wave_sum(local);
+  if ((threadIdx.x & 63) == 0 && local != 0.f) atomicAdd(loss_out, local * weight);
+}
+
 }  // namespace
+
+extern "C" int las_log_probs_loss(const las_bf16* x, int64_t ldx, int rows, int nf, float weight, float grad_scale,
+                                  float* loss_out, float* dx, int64_t ldd, void* stream) {
+  LAS_REQUIRE(x && loss_out && rows > 0 && nf > 0, "las_log_probs_loss: bad arguments");
+  int blocks = (int)(((int64_t)rows * nf + 255) / 256);
+  if (blocks > 1024) blocks = 1024;
+  hipLaunchKernelGGL(log_probs_loss_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, ldx, rows, nf, weight, grad_scale,
+                     loss_out, dx, ldd);
+  LAS_LAUNCH_CHECK("log-probs loss launch");
+  return LAS_OK;
+}
 
 extern "C" int las_decoder_step_fwd(const las_dec_step* s, int parts, void* stream) {
   LAS_REQUIRE(s->B > 0 && s->Hd % 8 == 0 && s->M % 8 == 0 && s->Tm > 0, "las_decoder_step_fwd: bad shape");

@@ -104,19 +104,21 @@ _ATT = {'luong': hip.ATT_LUONG, 'bahdanau': hip.ATT_BAHDANAU, 'custom': hip.ATT_
 _ATT_FUSED = ('luong', 'bahdanau')            # mechanisms of the fused single-cell fast path
 
 
-def make_speller(hparams, variables, memory_depth):
+def make_speller(hparams, variables, memory_depth, binf2phone=None):
     """The decoder for ``hparams``: the fused single-cell path when the configuration allows it, else the general
     cell stack (speller_general.GeneralSpeller: multi-layer, --bottom_only AttentionMultiCell, attention layer,
     embedding)."""
     d = hparams
     if d.attention_type not in _ATT:
         raise ValueError('attention_type %r is not one of %s' % (d.attention_type, sorted(_ATT)))
-    if getattr(d, 'binf_projection', False) or getattr(d, 'binary_outputs', False):
-        raise ValueError('binary-feature decoders are not implemented on the HIP path this round')
-    if d.num_layers == 1 and not d.attention_layer_size and not d.embedding_size and d.attention_type in _ATT_FUSED:
+    binf = bool(getattr(d, 'binf_projection', False))
+    if getattr(d, 'binary_outputs', False) and not binf:
+        raise ValueError('--binary_outputs without --binf_projection is not implemented on the HIP path')
+    if (d.num_layers == 1 and not d.attention_layer_size and not d.embedding_size and d.attention_type in _ATT_FUSED
+            and not binf):
         return Speller(hparams, variables, memory_depth)
     from .speller_general import GeneralSpeller
-    return GeneralSpeller(hparams, variables, memory_depth, _ATT[d.attention_type])
+    return GeneralSpeller(hparams, variables, memory_depth, _ATT[d.attention_type], binf2phone=binf2phone if binf else None)
 
 
 class Speller:

@@ -37,11 +37,23 @@ class GeneralSpeller:
     B_SCORE = 'speller/attention_score_bias'
     NOISE_STREAM = 3                     # generator stream of the monotonic-attention score noise (draw (t*B + b)*Tm + t')
 
-    def __init__(self, hparams, variables, memory_depth, att_code):
+    def __init__(self, hparams, variables, memory_depth, att_code, binf2phone=None):
+        """binf2phone [binf_count, V] (0/1, constant): the --binf_projection decoder (las/model.py:179-183,242-257,
+        utils/training_helper.py:17-27,122-153): tokens are fed as their binary-feature vectors, the attention layer
+        emits A = 2*binf_count values [log p(f=1) | log p(f=0)] and the 'projection' is the fixed map
+        logits = lp1 * Mb + lp0 * (1 - Mb); the Dense kernel/bias of projection_layer exist as variables but are not
+        applied (inner_projection_layer=False)."""
         d = hparams
-        if (d.dropout or 0.0) > 0 and d.embedding_size:
-            raise ValueError('dropout > 0 together with embedding_size > 0 is not implemented on the HIP path '
-                             '(element-wise dropout of the embedded token needs its own product)')
+        self.binf = binf2phone
+        if (d.dropout or 0.0) > 0 and (d.embedding_size or binf2phone is not None):
+            raise ValueError('dropout > 0 together with a dense token feed (embedding_size > 0 or binf_projection) is not '
+                             'implemented on the HIP path (element-wise dropout of the embedded token needs its own product)')
+        if binf2phone is not None and d.bottom_only and d.num_layers > 1:
+            raise ValueError('binf_projection needs the decoder output to be the 2*binf_count attention vector: '
+                             'use decoder_layers 1 or drop --bottom_only')
+        if binf2phone is not None and d.embedding_size:
+            raise ValueError('binf_projection with embedding_size > 0: the reference embeds with target_embedding and '
+                             'ignores the feature vectors; not implemented on the HIP path')
         self.hp = d
         self.att = att_code
         self.additive = att_code in hip.ATT_ADDITIVE          # v . tanh(keys + Wq h) scores
@@ -55,7 +67,11 @@ class GeneralSpeller:
         self.has_al = bool(d.attention_layer_size)
         self.emb = bool(d.embedding_size)
         self.E = d.embedding_size if self.emb else self.V
-        for n, v in (('decoder_units', self.Hd), ('attention depth', self.A), ('embedding_size', self.E if self.emb else 8)):
+        if self.binf is not None:
+            self.nf = int(self.binf.shape[0])
+            self.A, self.has_al = 2 * self.nf, True
+            self.emb, self.E = True, self.nf          # a constant embedding table: rows of Mb^T
+        for n, v in (('decoder_units', self.Hd), ('attention depth', self.A)):      # the token width is zero-padded
             if v % 8:
                 raise ValueError('%s must be a multiple of 8 on the HIP path' % n)
         self.P = self.Hd if (self.bottom and self.NL > 1) else self.A
@@ -81,10 +97,19 @@ class GeneralSpeller:
         if self.has_al:
             self.walT = torch.empty(A, Hd + self.M, dtype=bf, device=dev)
             self.waln = torch.empty(Hd + self.M, A, dtype=bf, device=dev)
+        self.Ep = _r8(self.E)                 # GEMM width of the embedded token (zero padded)
         if self.emb:
-            self.emb_bf = torch.empty(self.V, self.E, dtype=bf, device=dev)
-            self.k0tokT = torch.empty(4 * Hd, self.E, dtype=bf, device=dev)
-            self.k0tok = torch.empty(self.E, 4 * Hd, dtype=bf, device=dev)
+            self.emb_bf = torch.zeros(self.V, self.Ep, dtype=bf, device=dev)
+            self.k0tokT = torch.zeros(4 * Hd, self.Ep, dtype=bf, device=dev)
+            self.k0tok = torch.zeros(self.Ep, 4 * Hd, dtype=bf, device=dev)
+        if self.binf is not None:
+            Mb = self.binf.to(device=dev, dtype=torch.float32)
+            self.emb_bf[:, :self.nf].copy_(Mb.t())
+            wb = torch.cat([Mb, 1.0 - Mb], 0)                         # [2nf, V]: logits = [lp1 | lp0] Wb
+            self.wproj.zero_()
+            self.wprojT.zero_()
+            self.wproj[:, :self.V].copy_(wb)
+            self.wprojT[:self.V].copy_(wb.t())
         if self.uses_wq:
             self.wq = torch.empty(Hd, Hd, dtype=bf, device=dev)
             self.wq_t = torch.empty(Hd, Hd, dtype=bf, device=dev)
@@ -116,18 +141,21 @@ class GeneralSpeller:
             hip.cast_bf16(k[skip:], rows, 4 * Hd, self.kn[l], rows, 4 * Hd, lds=4 * Hd)
             self.bias.append(var[self.cell_names(l)[1]])
         k0 = var[self.cell_names(0)[0]]
+        Ep = self.Ep
         if self.emb:
-            hip.cast_bf16(var[self.K_EMB], V, E, self.emb_bf, V, E)
-            hip.cast_bf16(k0, E, 4 * Hd, self.k0tokT, 4 * Hd, E, transpose=True, lds=4 * Hd)
-            hip.cast_bf16(k0, E, 4 * Hd, self.k0tok, E, 4 * Hd, lds=4 * Hd)
+            if self.binf is None:
+                hip.cast_bf16(var[self.K_EMB], V, E, self.emb_bf, V, Ep)
+            hip.cast_bf16(k0, E, 4 * Hd, self.k0tokT, 4 * Hd, Ep, transpose=True, lds=4 * Hd)
+            hip.cast_bf16(k0, E, 4 * Hd, self.k0tok, Ep, 4 * Hd, lds=4 * Hd)
             # rows the cell adds for token v: embedding[v] * K0[:E]  (the embedded feed as a [V,4Hd] table)
-            hip.gemm_nt(self.emb_bf, self.k0tokT, self.tok, V, 4 * Hd, E, lda=E, ldb=E, ldc=4 * Hd, out_bf16=True)
+            hip.gemm_nt(self.emb_bf, self.k0tokT, self.tok, V, 4 * Hd, Ep, lda=Ep, ldb=Ep, ldc=4 * Hd, out_bf16=True)
         else:
             hip.cast_bf16(k0, V, 4 * Hd, self.tok, V, 4 * Hd, lds=4 * Hd)
         P = self.P
-        hip.cast_bf16(var[self.K_PROJ], P, V, self.wprojT, Vp, P, transpose=True)
-        hip.cast_bf16(var[self.K_PROJ], P, V, self.wproj, P, Vp)
-        self.bproj[:V].copy_(var[self.B_PROJ])
+        if self.binf is None:            # binf_projection: the fixed map set up in __init__; kernel/bias are not applied
+            hip.cast_bf16(var[self.K_PROJ], P, V, self.wprojT, Vp, P, transpose=True)
+            hip.cast_bf16(var[self.K_PROJ], P, V, self.wproj, P, Vp)
+            self.bproj[:V].copy_(var[self.B_PROJ])
         if self.has_al:
             hip.cast_bf16(var[self.K_AL], Hd + M, A, self.walT, A, Hd + M, transpose=True)
             hip.cast_bf16(var[self.K_AL], Hd + M, A, self.waln, Hd + M, A)
@@ -308,6 +336,15 @@ class GeneralSpeller:
         self.last_Tm = Tm            # memory length of the last forward (tests replay the score noise)
         return logits
 
+    def log_probs_loss(self, loss, weight, grad_scale):
+        """loss += weight * compute_log_probs_loss(raw outputs) (model_helper.py:132-146,327-331) on the attention vectors
+        of the last forward_train; its gradient joins d(outputs) in backward()."""
+        sv = self.saved
+        B, U, A = sv['B'], sv['U'], self.A
+        sv['dreg'] = torch.empty(B, U, A, dtype=torch.float32, device=loss.device)
+        hip.check(hip.lib().las_log_probs_loss(hip.p(sv['att']), A, B * U, self.nf, weight, grad_scale, hip.p(loss),
+                                               hip.p(sv['dreg']), A, hip.stream()))
+
     # ------------------------------------------------------------------------------------------------------------------
     def _cell_bwd(self, l, t, sv, dc, sources, dz):
         B, Hd, U = sv['B'], self.Hd, sv['U']
@@ -338,6 +375,8 @@ class GeneralSpeller:
         bah = self.additive
         d_out = torch.empty(B, U, P, dtype=f32, device=dev)
         hip.gemm_nt(dlogits, self.wproj, d_out, BU, P, Vp, lda=Vp, ldb=Vp, ldc=P)
+        if sv.get('dreg') is not None:       # gradient of compute_log_probs_loss w.r.t. the raw outputs (binf_projection)
+            d_out.add_(sv['dreg'])
         dc = [torch.zeros(B, Hd, dtype=f32, device=dev) for _ in range(NL)]
         dx = [[torch.zeros(B, w + Hd, dtype=f32, device=dev) for _ in range(2)] for w in self.win]
         dz = [torch.empty(B, U, 4 * Hd, dtype=bf, device=dev) for _ in range(NL)]
@@ -441,8 +480,9 @@ class GeneralSpeller:
         hip.cast_bf16(dkeys, B * Tm, Hd, dkeys_bf, B * Tm, Hd, ldd=Hd, lds=Hd)
         hip.gemm_nt(dkeys_bf, self.wmem, dmem, B * Tm, M, Hd, lda=Hd, ldb=Hd, ldc=M, accumulate=True)
         # ---- weight gradients ----
-        hip.gemm_tn(sv['out'], dlogits, grads[self.K_PROJ], P, V, BU, lda=P, ldb=Vp, ldc=V, split_k=4)
-        hip.colsum_bf16(dlogits, BU, V, grads[self.B_PROJ], ldx=Vp)
+        if self.binf is None:
+            hip.gemm_tn(sv['out'], dlogits, grads[self.K_PROJ], P, V, BU, lda=P, ldb=Vp, ldc=V, split_k=4)
+            hip.colsum_bf16(dlogits, BU, V, grads[self.B_PROJ], ldx=Vp)
         hip.gemm_tn(sv['memory'], dkeys_bf, grads[self.K_MEM], M, Hd, B * Tm, lda=M, ldb=Hd, ldc=Hd, split_k=8)
         if self.uses_wq:
             hip.gemm_tn(sv['h'][qlayer], dpq_all, grads[self.K_Q], Hd, Hd, BU, lda=Hd, ldb=Hd, ldc=Hd, split_k=4)
@@ -466,9 +506,13 @@ class GeneralSpeller:
             hip.gemm_tn(onehot, dz[0], dtok, V, 4 * Hd, BU, lda=Vp, ldb=4 * Hd, ldc=4 * Hd, split_k=4)
             dtok_bf = torch.empty(V, 4 * Hd, dtype=bf, device=dev)
             hip.cast_bf16(dtok, V, 4 * Hd, dtok_bf, V, 4 * Hd)
-            hip.gemm_tn(self.emb_bf, dtok_bf, k0, self.E, 4 * Hd, V, lda=self.E, ldb=4 * Hd, ldc=4 * Hd)      # emb^T dRows
-            hip.gemm_nt(dtok_bf, self.k0tok, grads[self.K_EMB], V, self.E, 4 * Hd, lda=4 * Hd, ldb=4 * Hd, ldc=self.E,
-                        accumulate=True)                                                                       # dRows K0^T
+            hip.gemm_tn(self.emb_bf, dtok_bf, k0, self.E, 4 * Hd, V, lda=self.Ep, ldb=4 * Hd, ldc=4 * Hd)     # emb^T dRows
+            if self.binf is None:
+                dE = torch.zeros(V, self.Ep, dtype=f32, device=dev) if self.Ep != self.E else grads[self.K_EMB]
+                hip.gemm_nt(dtok_bf, self.k0tok, dE, V, self.Ep, 4 * Hd, lda=4 * Hd, ldb=4 * Hd, ldc=self.Ep,
+                            accumulate=True)                                                                   # dRows K0^T
+                if dE is not grads[self.K_EMB]:
+                    grads[self.K_EMB].add_(dE[:, :self.E])
         d_state = None
         if sv['passed']:
             fin = (0) & 1                      # the buffers written by step t = 0

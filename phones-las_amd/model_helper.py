@@ -48,6 +48,8 @@ def param_table(params):
     M, Hd, V = _enc_depth(e), d.num_units, d.target_vocab_size
     A = (2 * d.binf_count) if getattr(d, 'binf_projection', False) else (d.attention_layer_size or M)
     E = d.embedding_size if d.embedding_size else V
+    if getattr(d, 'binf_projection', False) and not d.embedding_size:
+        E = d.binf_count            # embedding_fn = rows of binf2phone^T (las/model.py:242-243)
     if d.embedding_size:
         out.append(('speller/target_embedding', (V, d.embedding_size), 'glorot'))
     out.append(('speller/memory_layer/kernel', (M, Hd), 'glorot'))
@@ -224,15 +226,32 @@ def ctc_greedy_decode(logits, logit_len):
 class LasModel:
     """Variables + listener + speller + train op: what tf.estimator.Estimator(model_fn=las_model_fn) holds."""
 
-    def __init__(self, params, seed=4321, world_size=1, process_group=None):
+    def __init__(self, params, seed=4321, world_size=1, process_group=None, binf2phone=None):
+        """binf2phone: the [binf_count, V] 0/1 matrix of utils.load_binf2phone for the binary-feature decoders
+        (model_helper.py:181-187: a constant unless --binf_trainable)."""
         if not torch.cuda.is_available():
             raise hip.LasError('no HIP device visible: the LAS path has no CPU fallback')
         hip.lib()
         self.params = params
+        d = params.decoder
+        self.binf_projection = bool(getattr(d, 'binf_projection', False))
+        if getattr(d, 'binary_outputs', False) and not self.binf_projection:
+            raise ValueError('--binary_outputs without --binf_projection (sigmoid decoders, utils/training_helper.py:30-45,'
+                             '89-119) is not implemented on the HIP path')
+        if self.binf_projection:
+            if binf2phone is None:
+                raise ValueError('binf_projection needs the binf2phone matrix (--binf_map)')
+            if getattr(d, 'binf_trainable', False) or getattr(d, 'multitask', False) or getattr(d, 'binf_sampling', False):
+                raise ValueError('binf_trainable / multitask / binf_sampling are not implemented on the HIP path')
+            binf2phone = torch.as_tensor(np.asarray(binf2phone), dtype=torch.float32)
+            if tuple(binf2phone.shape) != (d.binf_count, d.target_vocab_size):
+                raise ValueError('binf2phone must be [binf_count=%d, target_vocab_size=%d], got %s'
+                                 % (d.binf_count, d.target_vocab_size, tuple(binf2phone.shape)))
         self.vars = Variables(param_table(params))
         self.vars.initialize(seed)
         self.listener = las_model.Listener(params.encoder, self.vars.params, params.num_channels)
-        self.speller = las_model.make_speller(params.decoder, self.vars.params, _enc_depth(params.encoder))
+        self.speller = las_model.make_speller(params.decoder, self.vars.params, _enc_depth(params.encoder),
+                                              binf2phone=binf2phone if self.binf_projection else None)
         self.ctc = CtcHead(params, self.vars.params, _enc_depth(params.encoder)) if params.ctc_weight > 0 else None
         self.global_step = 0
         self.rng_seed = (seed * 2654435761 + 12345) & 0x7fffffff      # base of the dropout / sampling draws
@@ -269,6 +288,8 @@ class LasModel:
         logits = self.speller.forward_train(mem, mem_len, state, tin, U, seed=step_seed)
         loss, dlogits = compute_loss(logits, tout, None, tlen, TRAIN, self.params.decoder.eos_id,
                                      grad_scale=1.0 / self.world_size, want_grad=True, vocab=self.speller.V)
+        if self.binf_projection:        # + compute_log_probs_loss(raw outputs) * reg weight (model_helper.py:327-331)
+            self.speller.log_probs_loss(loss, float(self.params.decoder.binf_projection_reg_weight), 1.0 / self.world_size)
         if self.ctc is not None:        # audio_loss += ctc_loss * ctc_weight (model_helper.py:347-358)
             self.ctc.forward(mem, mem_len, tout, tlen, loss, 1.0 / self.world_size)
         return loss, logits, dlogits
@@ -384,10 +405,10 @@ def las_model_fn(features, labels, mode, config, params, binf2phone=None, run_na
     """model_helper.py:165-444.  ``model`` is the LasModel that holds the variables (an Estimator would own it);
     when omitted a freshly initialised one is built.  Returns an EstimatorSpec whose ``train_op`` is a callable
     that applies one optimiser step (TF returns a graph op)."""
-    if binf2phone is not None or transparent_projection:
-        raise ValueError('binary-feature outputs are not implemented on the HIP path this round')
+    if transparent_projection:
+        raise ValueError('transparent_projection (BasicTransparentProjectionDecoder) is not implemented on the HIP path')
     if model is None:
-        model = LasModel(params)
+        model = LasModel(params, binf2phone=binf2phone)
     if mode == PREDICT:
         return EstimatorSpec(mode, predictions=model.predict(features))
     if mode == EVAL:

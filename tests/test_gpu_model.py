@@ -19,7 +19,7 @@ def _models(att, **kw):
     from phones_las_amd import model_helper as mh
     ohp, params = make_hparams(att=att, **kw)
     op = O.init_params(ohp, bias_scale=0.1)
-    model = mh.LasModel(params)
+    model = mh.LasModel(params, binf2phone=kw.get('binf'))
     assert [n for n, _, _ in mh.param_table(params)] == [n for n, _, _ in O.param_table(ohp)]
     model.load_variables({k: v for k, v in op.items()})
     return O, ohp, op, model
@@ -308,6 +308,61 @@ def test_custom_and_monotonic_attention_vs_oracle(kw):
         g = out['grads'][name] - ohp.l2_reg_scale * op[name]
         assert relerr(model.vars.grads[name], g) < 6e-2, name
     # inference: bahdanau_monotonic switches to the 'hard' normaliser (las/model.py:163-164)
+    (mem, ml), st = O.listener(batch['encoder_inputs'], batch['source_sequence_length'], op, ohp.encoder, 'bf16')
+    rl, rids, rfl, _ = O.speller_greedy(ohp, op, mem, ml, st, 'bf16')
+    pred = model.predict(feats)
+    assert relerr(pred['logits'][:, 0], rl[:, 0]) < 2e-2
+
+
+def _toy_binf(nf, V, seed=5):
+    """a 0/1 feature-by-phone matrix with the structure of utils.load_binf2phone (ipa_utils.py:313-328): <unk> column
+    all ones, <s>/</s> one-hot on the last two rows."""
+    rng = np.random.default_rng(seed)
+    m = (rng.random((nf, V)) < 0.4).astype(np.float32)
+    m[:, 0] = 1.0
+    m[:, 1:3] = 0.0
+    m[nf - 2:, :] = 0.0
+    m[nf - 2, 1] = 1.0
+    m[nf - 1, 2] = 1.0
+    return m
+
+
+@pytest.mark.parametrize('kw', [
+    dict(att='luong', dec_layers=1, bottom_only=True, pass_hidden=True, nf=8),
+    dict(att='bahdanau_monotonic', dec_layers=2, bottom_only=False, pass_hidden=False, nf=12),     # cfg5's attention type
+], ids=['binf_luong', 'binf_bahdanau_monotonic'])
+def test_binf_projection_decoder_vs_oracle(kw):
+    """SURVEY.md 8(a) rows a11 + a14 (cfg5: --binary_outputs --binf_projection): binary-feature token feed, attention
+    layer of 2*binf_count outputs, DenseBinfDecoder's fixed map to phone logits, CE + compute_log_probs_loss."""
+    from phones_las_amd import hip
+    kw = dict(kw)
+    nf = kw.pop('nf')
+    binf = _toy_binf(nf, 11)
+    O, ohp, op, model = _models(binf=binf, binf_reg=0.7, **kw)
+    from phones_las_amd.las.speller_general import GeneralSpeller
+    assert isinstance(model.speller, GeneralSpeller) and model.speller.A == 2 * nf
+    src_len, tgt_len = [12, 7, 10], [6, 4, 5]
+    batch = make_batch(src_len=src_len, tgt_len=tgt_len)
+    feats, labels = to_device(batch)
+    model.vars.grad.zero_()
+    loss, logits, dlogits = model.forward_train(feats, labels)
+    model.backward(dlogits)
+    torch.cuda.synchronize()
+    stochastic = None
+    if kw['att'] == 'bahdanau_monotonic':
+        U, Tm = max(tgt_len), model.speller.last_Tm
+        noise = torch.empty(U * 3 * Tm, dtype=torch.float32, device='cuda')
+        hip.check(hip.lib().las_normal_fill(hip.p(noise), noise.numel(), model.last_seed, GeneralSpeller.NOISE_STREAM, hip.stream()))
+        stochastic = {'att_noise': noise.view(U, 3, Tm).cpu().to(DT)}
+    out = O.train_step(ohp, op, None, None, 1, batch, mxu='bf16', stochastic=stochastic)
+    V = ohp.decoder.target_vocab_size
+    for b, n in enumerate(tgt_len):
+        assert relerr(logits[b, :n, :V], out['aux']['logits'][b, :n]) < 2e-2
+    ref_audio = float((out['aux']['ce'] + 0.7 * out['aux']['log_probs_loss']).detach())
+    assert abs(float(loss) - ref_audio) < 2e-2 * abs(ref_audio)
+    for name, _, _ in model.vars.table:
+        g = out['grads'][name] - ohp.l2_reg_scale * op[name]
+        assert relerr(model.vars.grads[name], g) < 6e-2, name
     (mem, ml), st = O.listener(batch['encoder_inputs'], batch['source_sequence_length'], op, ohp.encoder, 'bf16')
     rl, rids, rfl, _ = O.speller_greedy(ohp, op, mem, ml, st, 'bf16')
     pred = model.predict(feats)

@@ -97,8 +97,9 @@ def load_checkpoint(model, path):
 def main(args):
     if args.t2t_format or args.tpu_name:
         raise SystemExit('--t2t_format / --tpu_name are TensorFlow-only input/back-end options and are not supported')
-    if args.binary_outputs:
-        raise SystemExit('--binary_outputs is not implemented on the HIP path this round')
+    if args.binary_outputs and not (args.binf_projection and args.output_ipa):
+        raise SystemExit('--binary_outputs is implemented with --binf_projection --output_ipa (the DenseBinfDecoder path); '
+                         'the sigmoid-output decoders are not on the HIP path')
     from phones_las_amd import dp, utils
     from phones_las_amd import model_helper as mh
 
@@ -110,11 +111,23 @@ def main(args):
     vocab_name = os.path.join(train_dir, 'vocab.txt')
     norm_name = os.path.join(train_dir, 'norm.dmp')
     vocab_list = utils.load_vocab(vocab_name)
+    binf2phone_np, mapping, binf_count = None, None, None
+    if args.binary_outputs:               # train.py:117-126 of the reference
+        if args.mapping is not None:
+            vocab_list, mapping = utils.get_mapping(args.mapping, vocab_name)
+            args.mapping = None
+        binf2phone = utils.load_binf2phone(args.binf_map, vocab_list)
+        binf_count = len(binf2phone.index)
+        if args.output_ipa:
+            binf2phone_np = binf2phone.values
     if not args.num_channels:
         first = next(iter(utils.read_dataset(args.train, None)()))
         args.num_channels = int(first[0].shape[1])
-    hparams = utils.create_hparams(args, len(vocab_list), None, utils.SOS_ID, utils.EOS_ID)
-    model = mh.LasModel(hparams, world_size=world)
+    hparams = utils.create_hparams(args, len(vocab_list), binf_count, utils.SOS_ID, utils.EOS_ID)
+    if mapping is not None:
+        hparams.del_hparam('mapping')
+        hparams.add_hparam('mapping', mapping)
+    model = mh.LasModel(hparams, world_size=world, binf2phone=binf2phone_np)
     ckpt = os.path.join(args.model_dir, 'checkpoint.pt')
     if os.path.exists(ckpt):
         load_checkpoint(model, ckpt)
