@@ -312,6 +312,14 @@ int las_seq_ce_loss(const float* logits, int64_t ldl, const int32_t* targets, co
                     int B, int U, int V, float grad_scale, float* loss_out, las_bf16* dlogits, int64_t ldd,
                     void* stream);
 
+/* One step of tf.contrib.seq2seq.BeamSearchDecoder (las/model.py:312-319, length_penalty_weight 0) for B utterances of
+ * K beams: logits [B*K, V] fp32 (row stride ldl) of this step; log_probs / finished / lengths [B,K] are the beam state
+ * (in: before the step, out: after, already re-ordered); word_ids / parent_ids [B,K] receive the chosen token and the
+ * beam it extends (the caller gathers its decoder state with parent_ids and backtracks with gather_tree at the end).
+ * Initial state: log_probs = [0, -inf, ...], finished = 0, lengths = 0.  Ties resolve to the lower candidate index. */
+int las_beam_step(const float* logits, int64_t ldl, float* log_probs, int32_t* finished, int32_t* lengths,
+                  int32_t* word_ids, int32_t* parent_ids, int B, int K, int V, int eos, void* stream);
+
 /* compute_log_probs_loss of the binf_projection decoder (model_helper.py:132-146, :327-331): x [rows, 2*nf] bf16 holds
  * [log p(f=1) | log p(f=0)] per decoder step (ALL rows count, padded steps too).  loss_out += weight * mean(|e^a + e^b
  * - 1| + relu(a) + relu(b)); dx (fp32, row stride ldd, may be NULL) = grad_scale * weight * d(mean)/dx. */

@@ -43,8 +43,6 @@ def to_text(vocab_list, sample_ids, delimiter=' '):
 
 
 def main(args):
-    if args.beam_width > 0:
-        raise SystemExit('--beam_width > 0 (beam search) is not implemented on the HIP path this round')
     if args.calc_frame_binf_accuracy or args.use_phones_from_binf or args.convert_targets_to_ipa:
         raise SystemExit('binary-feature / IPA analysis options are not supported on the HIP path')
     from phones_las_amd import utils
@@ -72,18 +70,23 @@ def main(args):
     batches = utils.input_fn(args.data, args.vocab, args.norm, num_channels=args.num_channels,
                              batch_size=args.batch_size, num_epochs=1, take=args.take, is_infer=True)
     hyps, refs = [], []
+    optimistic_err = 0
     for features, labels in batches:
         f, _ = to_device(features, None, dev)
         pred = model.predict(f)
-        ids = pred['sample_ids'].cpu().numpy()
+        ids = pred['sample_ids'].cpu().numpy()           # [B,T] greedy, [B,T,K] beam search (infer.py:279-295)
         for b in range(ids.shape[0]):
-            i = ids[b].tolist() + [utils.EOS_ID]
-            i = i[:i.index(utils.EOS_ID)]                # cut at the first EOS (infer.py:296-298)
             t = labels['targets_outputs'][b][:labels['target_sequence_length'][b] - 1].tolist()
             if mapping is not None:
                 t = [mapping[x] for x in t]
                 t = [x for x in t if x >= 0]
-            hyps.append(i)
+            beams = ids[b].T if ids.ndim == 3 else ids[b][None]
+            cut = []
+            for beam in beams:
+                i = beam.tolist() + [utils.EOS_ID]
+                cut.append(i[:i.index(utils.EOS_ID)])    # cut at the first EOS (infer.py:296-298)
+            optimistic_err += min(_levenshtein(i, t) for i in cut)
+            hyps.append(cut[0])                          # the best-scoring beam is the hypothesis
             refs.append(t)
     err = sum(_levenshtein(h, r) for h, r in zip(hyps, refs))
     tot = sum(len(r) for r in refs)
@@ -93,6 +96,8 @@ def main(args):
         f.write('\n'.join(to_text(vocab_list, r, args.delimiter) for r in refs))
     per = 100.0 * err / max(tot, 1)
     print('PER: %2.2f%%' % per)
+    if args.beam_width > 0:                              # infer.py:345-346
+        print('Optimistic PER: %2.2f%%' % (100.0 * optimistic_err / max(tot, 1)))
     return per
 
 

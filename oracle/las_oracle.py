@@ -539,6 +539,80 @@ def speller_greedy(hp: HP, params, memory, mem_len, enc_state, mxu='f64'):
     return torch.stack(outs, 1), torch.stack(samples, 1), final_len, sp
 
 
+def gather_tree(step_ids, parent_ids, max_len, end_token):
+    """tf.contrib.seq2seq.gather_tree (beam_search_ops): step_ids/parent_ids [T,B,K] -> full beams [T,B,K].
+    Backtracks every final beam through its parents from t = max_len[b]-1; positions >= max_len[b] and everything
+    after a beam's first end_token are end_token."""
+    T, B, K = step_ids.shape
+    out = torch.full_like(step_ids, end_token)
+    for b in range(B):
+        L = min(int(max_len[b]), T)
+        for k in range(K):
+            if L <= 0:
+                continue
+            parent = k
+            for t in range(L - 1, -1, -1):
+                out[t, b, k] = step_ids[t, b, parent]
+                parent = int(parent_ids[t, b, parent])
+            seen = False
+            for t in range(L):
+                if seen:
+                    out[t, b, k] = end_token
+                elif int(out[t, b, k]) == end_token:
+                    seen = True
+    return out
+
+
+def speller_beam(hp: HP, params, memory, mem_len, enc_state, beam_width, mxu='f64'):
+    """las/model.py:219-226,298-319: tf.contrib.seq2seq.BeamSearchDecoder (length_penalty_weight 0, no coverage
+    penalty) over the tiled batch, then gather_tree.  Returns (predicted_ids [B,T,K], scores [B,T,K] per step,
+    final lengths [B,K])."""
+    d = hp.decoder
+    B, K, V = memory.shape[0], beam_width, d.target_vocab_size
+    tile = lambda x: x.repeat_interleave(K, 0)
+    if isinstance(enc_state[0], tuple):
+        st = tuple((tile(c), tile(h)) for c, h in enc_state)
+    else:
+        st = (tile(enc_state[0]), tile(enc_state[1]))
+    sp = Speller(hp, params, tile(memory), tile(mem_len), st, mxu, False)
+    max_it = int(round(float(mem_len.max()) * d.decoding_length_factor))
+    ids = torch.full((B * K,), d.sos_id, dtype=torch.long)
+    log_probs = torch.full((B, K), float('-inf'), dtype=DT)
+    log_probs[:, 0] = 0.0
+    finished = torch.zeros(B, K, dtype=torch.bool)
+    lengths = torch.zeros(B, K, dtype=torch.long)
+    NEG = torch.finfo(torch.float32).min
+    step_ids, parents, step_scores = [], [], []
+    for t in range(max_it):
+        logits = sp.step(sp.embed(ids)).view(B, K, V)
+        lp = torch.log_softmax(logits, -1)
+        fin_row = torch.full((V,), NEG, dtype=DT)
+        fin_row[d.eos_id] = 0.0
+        lp = torch.where(finished.unsqueeze(-1), fin_row.view(1, 1, V), lp)       # _mask_probs
+        total = log_probs.unsqueeze(-1) + lp
+        scores, idx = torch.topk(total.view(B, K * V), K, dim=-1)                 # length penalty 0: score = log prob
+        word, beam = idx % V, idx // V
+        prev_fin = torch.gather(finished, 1, beam)
+        lengths = torch.gather(lengths, 1, beam) + (~prev_fin).long()
+        finished = prev_fin | (word == d.eos_id)
+        log_probs = scores
+        flat = (beam + torch.arange(B).unsqueeze(1) * K).view(-1)
+        sp.cells = [(c[flat], h[flat]) for c, h in sp.cells]
+        sp.attention, sp.align = sp.attention[flat], sp.align[flat]
+        ids = word.view(-1)
+        step_ids.append(word)
+        parents.append(beam)
+        step_scores.append(scores)
+        if bool(finished.all()):
+            break
+    if not step_ids:
+        z = torch.zeros(B, 0, K, dtype=torch.long)
+        return z, z.to(DT), lengths
+    sid, par = torch.stack(step_ids, 0), torch.stack(parents, 0)                  # [T,B,K]
+    pred = gather_tree(sid, par, lengths.max(1).values, d.eos_id)
+    return pred.permute(1, 0, 2), torch.stack(step_scores, 0).permute(1, 0, 2), lengths
+
+
 # --------------------------------------------------------------------------------------
 # losses  (model_helper.py:20-146)
 # --------------------------------------------------------------------------------------

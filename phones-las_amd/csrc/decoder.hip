@@ -584,7 +584,90 @@ __global__ __launch_bounds__(256) void log_probs_loss_kernel(const unsigned shor
   if ((threadIdx.x & 63) == 0 && local != 0.f) atomicAdd(loss_out, local * weight);
 }
 
+// ------------------------------------------------------------------------------------------------
+// one step of tf.contrib.seq2seq.BeamSearchDecoder (las/model.py:312-319; length_penalty_weight 0): log-softmax per
+// beam, finished beams keep their mass on end_token (_mask_probs), total = previous log-prob + step log-prob, top-K
+// of the K*V candidates of an utterance (ties: lower index first, as tf.nn.top_k).  One workgroup per utterance.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void beam_step_kernel(const float* logits, int64_t ldl, float* log_probs, int32_t* finished,
+                                                        int32_t* lengths, int32_t* word_ids, int32_t* parent_ids, int K, int V,
+                                                        int eos) {
+  extern __shared__ __attribute__((aligned(16))) float bsm[];
+  float* cand = bsm;                                   // [K*V]
+  float* lse = cand + K * V;                           // [K]
+  float* oldlp = lse + K;                              // [K]
+  int* oldfin = reinterpret_cast<int*>(oldlp + K);     // [K]
+  int* oldlen = oldfin + K;                            // [K]
+  float* rv = reinterpret_cast<float*>(oldlen + K);    // [4] wave maxima
+  int* ri = reinterpret_cast<int*>(rv + 4);            // [4] their indices
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const float NEG = -3.402823466e38f;
+  for (int k = wave; k < K; k += 4) {
+    const float* lg = logits + (int64_t)(b * K + k) * ldl;
+    float mx = -INFINITY;
+    for (int v = lane; v < V; v += 64) mx = fmaxf(mx, lg[v]);
+    mx = las_wave_max(mx);
+    float sum = 0.f;
+    for (int v = lane; v < V; v += 64) sum += __expf(lg[v] - mx);
+    sum = las_wave_sum(sum);
+    if (lane == 0) {
+      lse[k] = mx + __logf(sum);
+      oldlp[k] = log_probs[b * K + k];
+      oldfin[k] = finished[b * K + k];
+      oldlen[k] = lengths[b * K + k];
+    }
+  }
+  __syncthreads();
+  for (int i = tid; i < K * V; i += 256) {
+    const int k = i / V, v = i % V;
+    const float step = oldfin[k] ? (v == eos ? 0.f : NEG) : logits[(int64_t)(b * K + k) * ldl + v] - lse[k];
+    cand[i] = oldlp[k] + step;
+  }
+  __syncthreads();
+  for (int j = 0; j < K; ++j) {
+    float best = -INFINITY;
+    int bi = 0x7fffffff;
+    for (int i = tid; i < K * V; i += 256) {
+      const float c = cand[i];
+      if (!(c != c) && (bi == 0x7fffffff || c > best)) { best = c; bi = i; }      // first (lowest) index wins ties; NaN = taken
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const float ob = __shfl_xor(best, o, 64);
+      const int oi = __shfl_xor(bi, o, 64);
+      if (oi != 0x7fffffff && (bi == 0x7fffffff || ob > best || (ob == best && oi < bi))) { best = ob; bi = oi; }
+    }
+    if (lane == 0) { rv[wave] = best; ri[wave] = bi; }
+    __syncthreads();
+    if (tid == 0) {
+      for (int w = 1; w < 4; ++w)
+        if (ri[w] != 0x7fffffff && (bi == 0x7fffffff || rv[w] > best || (rv[w] == best && ri[w] < bi))) { best = rv[w]; bi = ri[w]; }
+      const int k = bi / V, v = bi % V;
+      const int pf = oldfin[k];
+      word_ids[b * K + j] = v;
+      parent_ids[b * K + j] = k;
+      log_probs[b * K + j] = best;
+      finished[b * K + j] = (pf || v == eos) ? 1 : 0;
+      lengths[b * K + j] = oldlen[k] + (pf ? 0 : 1);
+      cand[bi] = __builtin_nanf("");          // taken
+    }
+    __syncthreads();
+  }
+}
+
 }  // namespace
+
+extern "C" int las_beam_step(const float* logits, int64_t ldl, float* log_probs, int32_t* finished, int32_t* lengths,
+                             int32_t* word_ids, int32_t* parent_ids, int B, int K, int V, int eos, void* stream) {
+  LAS_REQUIRE(logits && log_probs && finished && lengths && word_ids && parent_ids, "las_beam_step: null argument");
+  LAS_REQUIRE(B > 0 && K > 0 && V > 0 && eos >= 0 && eos < V, "las_beam_step: bad shape B=%d K=%d V=%d eos=%d", B, K, V, eos);
+  const size_t lds = ((size_t)K * V + 4 * (size_t)K + 8) * sizeof(float);
+  LAS_REQUIRE(lds <= 64 * 1024 && K * V >= K, "las_beam_step: beam_width * vocabulary = %d exceeds the LDS candidate buffer", K * V);
+  hipLaunchKernelGGL(beam_step_kernel, dim3(B), dim3(256), lds, (hipStream_t)stream, logits, ldl, log_probs, finished, lengths,
+                     word_ids, parent_ids, K, V, eos);
+  LAS_LAUNCH_CHECK("beam step launch");
+  return LAS_OK;
+}
 
 extern "C" int las_log_probs_loss(const las_bf16* x, int64_t ldx, int rows, int nf, float weight, float grad_scale,
                                   float* loss_out, float* dx, int64_t ldd, void* stream) {

@@ -51,6 +51,7 @@ _SIGS = {
     'las_fe_delta': ([_vp, _i64, _i32, _i32, _vp, _vp, _vp, _i32, _vp, _i64, _i32, _i32, _vp], C.c_int),
     'las_add_masked': ([_vp, _i64, _vp, _i64, _vp, _i64, _i32, _i32, _f32, C.c_uint32, C.c_uint32, C.c_uint64, _i64, _vp], C.c_int),
     'las_add_noise': ([_vp, _i64, _f32, C.c_uint32, C.c_uint32, _vp], C.c_int),
+    'las_beam_step': ([_vp, _i64, _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp], C.c_int),
     'las_log_probs_loss': ([_vp, _i64, C.c_int, C.c_int, _f32, _f32, _vp, _vp, _i64, _vp], C.c_int),
     'las_normal_fill': ([_vp, _i64, C.c_uint32, C.c_uint32, _vp], C.c_int),
     'las_relu_bf16': ([_vp, _i64, _vp], C.c_int),

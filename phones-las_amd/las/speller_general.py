@@ -19,11 +19,34 @@ import torch
 
 from .. import hip
 
-__all__ = ['GeneralSpeller']
+__all__ = ['GeneralSpeller', 'gather_tree']
 
 
 def _r8(n):
     return (n + 7) // 8 * 8
+
+
+def gather_tree(step_ids, parent_ids, max_len, end_token):
+    """tf.contrib.seq2seq.gather_tree (beam_search_ops; BeamSearchDecoder.finalize): step_ids / parent_ids [T,B,K]
+    (numpy int) -> full beams [T,B,K].  Every final beam is backtracked through its parents from t = max_len[b]-1;
+    positions >= max_len[b] and everything after a beam's first end_token are end_token.  Host-side index chasing."""
+    import numpy as np
+    T, B, K = step_ids.shape
+    out = np.full_like(step_ids, end_token)
+    for b in range(B):
+        L = min(int(max_len[b]), T)
+        for k in range(K):
+            parent = k
+            for t in range(L - 1, -1, -1):
+                out[t, b, k] = step_ids[t, b, parent]
+                parent = int(parent_ids[t, b, parent])
+            seen = False
+            for t in range(L):
+                if seen:
+                    out[t, b, k] = end_token
+                elif int(out[t, b, k]) == end_token:
+                    seen = True
+    return out
 
 
 class GeneralSpeller:
@@ -521,9 +544,25 @@ class GeneralSpeller:
         return dmem, d_state
 
     # ------------------------------------------------------------------------------------------------------------------
-    def forward_greedy(self, memory, mem_len, encoder_state, max_iterations, parts=4):
-        """GreedyEmbeddingHelper decode (las/model.py:270-274,337-347) with the general cell stack."""
+    def forward_beam(self, memory, mem_len, encoder_state, max_iterations, beam_width):
+        """BeamSearchDecoder decode (las/model.py:219-226,298-319,346-347): the batch tiled beam_width times, one
+        las_beam_step per decoder step, decoder state gathered by the parent beams, gather_tree at the end.
+        Returns (predicted_ids [B,T,K] int32, final lengths [B,K], log-probabilities of the final beams [B,K])."""
+        return self.forward_greedy(memory, mem_len, encoder_state, max_iterations, beam_width=beam_width)
+
+    def forward_greedy(self, memory, mem_len, encoder_state, max_iterations, parts=4, beam_width=0):
+        """GreedyEmbeddingHelper decode (las/model.py:270-274,337-347) with the general cell stack
+        (beam_width > 0: see forward_beam)."""
         d = self.hp
+        K = int(beam_width)
+        if K > 0:                       # tf.contrib.seq2seq.tile_batch of memory, lengths and the encoder state
+            B0 = memory.shape[0]
+            tile = lambda x: x.repeat_interleave(K, 0).contiguous()
+            memory, mem_len = tile(memory), tile(mem_len)
+            if isinstance(encoder_state[0], tuple):
+                encoder_state = tuple(type(s)(tile(s.c), tile(s.h)) for s in encoder_state)
+            else:
+                encoder_state = type(encoder_state)(tile(encoder_state.c), tile(encoder_state.h))
         B, Tm, M = memory.shape
         Hd, V, Vp, A, NL, S = self.Hd, self.V, self.Vp, self.A, self.NL, max_iterations
         dev, bf, f32 = memory.device, torch.bfloat16, torch.float32
@@ -557,6 +596,16 @@ class GeneralSpeller:
         X, h = sv['X'], sv['h']
         qlayer = 0 if self.bottom else NL - 1
         steps = 0
+        if K > 0:
+            i32 = torch.int32
+            b_lp = torch.full((B0, K), float('-inf'), dtype=f32, device=dev)
+            b_lp[:, 0] = 0.0
+            b_fin = torch.zeros(B0, K, dtype=i32, device=dev)
+            b_len = torch.zeros(B0, K, dtype=i32, device=dev)
+            b_word = torch.zeros(B0, K, dtype=i32, device=dev)
+            b_par = torch.zeros(B0, K, dtype=i32, device=dev)
+            parents = torch.zeros(B, U, dtype=i32, device=dev)
+            base = (torch.arange(B0, device=dev) * K).unsqueeze(1)
         for t in range(S):
             last = t + 1 == S
 
@@ -585,10 +634,18 @@ class GeneralSpeller:
             out_t = h[NL - 1][:, t] if (self.bottom and NL > 1) else att[:, t]
             hip.gemm_nt(out_t, self.wprojT, logits[:, t], B, Vp, self.P, lda=out_t.stride(0), ldb=self.P, ldc=U * Vp,
                         bias=self.bproj)
-            sample = logits[:, t, :V].argmax(-1).to(torch.int32)
-            samples[:, t] = sample
-            final_len = torch.where(finished, final_len, torch.full_like(final_len, t + 1))
-            finished = finished | (sample == d.eos_id)
+            if K > 0:
+                hip.check(hip.lib().las_beam_step(hip.addr(logits, t * Vp), U * Vp, hip.p(b_lp), hip.p(b_fin), hip.p(b_len),
+                                                  hip.p(b_word), hip.p(b_par), B0, K, V, d.eos_id, hip.stream()))
+                sample = b_word.view(-1)
+                samples[:, t] = sample
+                parents[:, t] = b_par.view(-1)
+                finished = b_fin.view(-1) != 0
+            else:
+                sample = logits[:, t, :V].argmax(-1).to(torch.int32)
+                samples[:, t] = sample
+                final_len = torch.where(finished, final_len, torch.full_like(final_len, t + 1))
+                finished = finished | (sample == d.eos_id)
             steps = t + 1
             if not last:
                 fed[:, t + 1] = sample
@@ -597,6 +654,18 @@ class GeneralSpeller:
                     for l in range(1, NL):
                         wc = A if l == 1 else Hd
                         X[l][:, t + 1, wc:wc + A].copy_(att[:, t])
+                if K > 0:               # the surviving beams continue from their parents' decoder state
+                    flat = (b_par.long() + base).view(-1)
+                    for l in range(NL):
+                        X[l][:, t + 1] = X[l][:, t + 1][flat]
+                        sv['cs'][l][:, t + 1] = sv['cs'][l][:, t + 1][flat]
+                    if self.mono:
+                        sv['align'][:, t] = sv['align'][:, t][flat]
             if bool(finished.all()):
                 break
+        if K > 0:
+            ids = gather_tree(samples[:, :steps].reshape(B0, K, steps).permute(2, 0, 1).cpu().numpy(),
+                              parents[:, :steps].reshape(B0, K, steps).permute(2, 0, 1).cpu().numpy(),
+                              b_len.max(1).values.cpu().numpy(), d.eos_id)
+            return torch.from_numpy(ids).permute(1, 0, 2).contiguous().to(dev), b_len, b_lp
         return logits[:, :steps, :V], samples[:, :steps], final_len, sv['align'][:, :steps, :Tm]

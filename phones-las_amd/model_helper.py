@@ -381,14 +381,32 @@ class LasModel:
         x, src_len = features['encoder_inputs'], features['source_sequence_length']
         (mem, mem_len), state = self.listener.forward(x, src_len, PREDICT)
         max_it = int(round(int(mem_len.max().item()) * self.params.decoder.decoding_length_factor))
-        logits, ids, final_len, align = self.speller.forward_greedy(mem, mem_len, state, max_it)
         emb_c = torch.cat([s.c for s in state], 1) if isinstance(state[0], tuple) else state.c
         emb_h = torch.cat([s.h for s in state], 1) if isinstance(state[0], tuple) else state.h
+        beam_width = int(getattr(self.params.decoder, 'beam_width', 0) or 0)
+        if beam_width > 0:              # model_helper.py:231-236: predicted_ids [B,T,K] instead of logits
+            ids, lens, lps = self._beam_speller().forward_beam(mem, mem_len, state, max_it, beam_width)
+            return {'encoder_out': mem, 'source_length': mem_len, 'embedding': torch.stack([emb_c, emb_h], 1),
+                    'sample_ids': ids, 'beam_lengths': lens, 'beam_log_probs': lps}
+        logits, ids, final_len, align = self.speller.forward_greedy(mem, mem_len, state, max_it)
         return {
             'encoder_out': mem, 'source_length': mem_len, 'embedding': torch.stack([emb_c, emb_h], 1),
             'sample_ids': ids, 'alignment': align, 'probs': torch.softmax(logits, -1), 'logits': logits,
             'final_sequence_length': final_len,
         }
+
+    def _beam_speller(self):
+        """Beam search runs on the general cell stack (it gathers the decoder state between steps); the fused
+        single-cell speller gets a GeneralSpeller twin over the same variables."""
+        from .las.speller_general import GeneralSpeller
+        if isinstance(self.speller, GeneralSpeller):
+            return self.speller
+        if getattr(self, '_beam_twin', None) is None:
+            self._beam_twin = GeneralSpeller(self.params.decoder, self.vars.params, _enc_depth(self.params.encoder),
+                                             las_model._ATT[self.params.decoder.attention_type])
+        else:
+            self._beam_twin.refresh(self.vars.params)
+        return self._beam_twin
 
     def evaluate(self, features, labels):
         """EVAL branch: free-running greedy decode, padded loss (model_helper.py:54-76), edit distance."""

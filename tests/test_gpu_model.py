@@ -367,3 +367,32 @@ def test_binf_projection_decoder_vs_oracle(kw):
     rl, rids, rfl, _ = O.speller_greedy(ohp, op, mem, ml, st, 'bf16')
     pred = model.predict(feats)
     assert relerr(pred['logits'][:, 0], rl[:, 0]) < 2e-2
+
+
+@pytest.mark.parametrize('kw', [
+    dict(att='luong', dec_layers=1, bottom_only=True, pass_hidden=True),                   # fused speller -> GeneralSpeller twin
+    dict(att='bahdanau', dec_layers=2, bottom_only=True, pass_hidden=True, als=16),
+], ids=['fused_twin', 'multicell_al'])
+def test_beam_search_vs_oracle(kw):
+    """SURVEY.md 8(a) row a9, PREDICT with --beam_width > 0 (las/model.py:219-226,298-319): BeamSearchDecoder +
+    gather_tree.  A random projection bias makes the beams branch and finish at different lengths; ids must agree
+    exactly wherever the oracle's candidate margins exceed the bf16 noise (they do for this seed), final beam
+    log-probabilities within 2e-2."""
+    O, ohp, op, model = _models(**kw)
+    g = torch.Generator().manual_seed(7)
+    op['speller/projection_layer/bias'] = torch.randn(ohp.decoder.target_vocab_size, generator=g, dtype=DT) * 1.5
+    model.load_variables({k: v for k, v in op.items()})
+    batch = make_batch(src_len=[12, 7, 10], tgt_len=[6, 4, 5])
+    feats, _ = to_device(batch)
+    K = 3
+    model.params.decoder.set_hparam('beam_width', K)
+    pred = model.predict(feats)
+    model.params.decoder.set_hparam('beam_width', 0)
+    torch.cuda.synchronize()
+    (mem, ml), st = O.listener(batch['encoder_inputs'], batch['source_sequence_length'], op, ohp.encoder, 'bf16')
+    ref_ids, ref_scores, ref_len = O.speller_beam(ohp, op, mem, ml, st, K, 'bf16')
+    ids = pred['sample_ids'].cpu()
+    assert tuple(ids.shape) == tuple(ref_ids.shape), (ids.shape, ref_ids.shape)
+    assert torch.equal(ids.long(), ref_ids), (ids[0].T.tolist(), ref_ids[0].T.tolist())
+    assert torch.equal(pred['beam_lengths'].cpu().long(), ref_len)
+    assert relerr(pred['beam_log_probs'], ref_scores[:, -1]) < 2e-2

@@ -79,3 +79,43 @@ def test_shard_batch_splits_evenly():
     assert s1['a'].tolist() == [[4, 5], [6, 7]] and s1['b'].tolist() == [2, 3]
     with pytest.raises(ValueError):
         dp.shard_batch(x, 0, 4)
+
+
+def test_gather_tree_matches_oracle_and_hand_example():
+    """BeamSearchDecoder.finalize's gather_tree: product host routine vs the oracle's, plus a hand-checked case."""
+    import numpy as np
+    import torch
+    from oracle import las_oracle as O
+    from phones_las_amd.las.speller_general import gather_tree
+    # T=3, B=1, K=2; end_token 9.  beam 0 at t=2 came from beam 1 at t=1, which came from beam 0 at t=0
+    step = np.array([[[1, 2]], [[3, 4]], [[5, 9]]])
+    par = np.array([[[0, 0]], [[0, 0]], [[1, 0]]])
+    out = gather_tree(step, par, np.array([3]), 9)
+    assert out[:, 0, 0].tolist() == [1, 4, 5]
+    assert out[:, 0, 1].tolist() == [1, 3, 9]
+    rng = np.random.default_rng(0)
+    step = rng.integers(0, 6, size=(7, 3, 4))
+    par = rng.integers(0, 4, size=(7, 3, 4))
+    ml = np.array([7, 4, 0])
+    ref = O.gather_tree(torch.from_numpy(step), torch.from_numpy(par), torch.from_numpy(ml), 2).numpy()
+    assert (gather_tree(step, par, ml, 2) == ref).all()
+    assert (ref[4:, 1] == 2).all() and (ref[:, 2] == 2).all()
+
+
+def test_oracle_beam_width_one_is_greedy():
+    import torch
+    from oracle import las_oracle as O
+    from tests.helpers import make_hparams, make_batch
+    ohp, _ = make_hparams(att='luong')
+    op = O.init_params(ohp, bias_scale=0.1)
+    g = torch.Generator().manual_seed(3)
+    op['speller/projection_layer/bias'] = torch.randn(11, generator=g, dtype=torch.float64) * 1.5
+    b = make_batch(src_len=[12, 7, 10], tgt_len=[6, 4, 5])
+    (mem, ml), st = O.listener(b['encoder_inputs'], b['source_sequence_length'], op, ohp.encoder, 'f64')
+    rl, rids, rfl, _ = O.speller_greedy(ohp, op, mem, ml, st, 'f64')
+    p1, s1, l1 = O.speller_beam(ohp, op, mem, ml, st, 1, 'f64')
+    T = p1.shape[1]
+    for i in range(3):
+        n = int(rfl[i])
+        assert p1[i, :n, 0].tolist() == rids[i, :n].tolist()
+        assert int(l1[i, 0]) == n
