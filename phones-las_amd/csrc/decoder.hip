@@ -7,6 +7,7 @@
 // sum_t' align * values.  keys/values rows are read as 16-byte bf16x8 pieces (16 lanes per memory frame
 // for scores, 4 columns per lane for the context).
 #include "las_common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -131,35 +132,68 @@ __global__ __launch_bounds__(256) void dec_step_fwd_kernel(las_dec_step s) {
     __syncthreads();
   }
 
-  // ---- scores: 4 lanes per memory frame (64 frames per pass), each lane Hd/32 independent 16-byte loads ----
+  // ---- scores: 4 lanes per memory frame, 64 frames per pass; the 16-byte key loads of SC_PASSES passes are all issued
+  //      before the first is used (every launch starts with cold L2s: each dependent round trip goes to Infinity Cache) ----
   const unsigned short* keys = s.keys + (int64_t)b * Tm * Hd;
   {
+    constexpr int SC_PASSES = 4, KMAX = 8;            // KMAX x 16 B per lane and frame: Hd <= 256 in one go
     const int sub = lane & 3, fr = lane >> 2;
-    for (int t0 = 0; t0 < Tm; t0 += 64) {
-      const int t = t0 + wave * 16 + fr;
-      float part_sum = 0.f;
-      if (t < len) {
-        const unsigned short* krow = keys + (int64_t)t * Hd;
-        if (!att_additive(s.attention)) {
-          const float* qv = s.attention == LAS_ATT_CUSTOM ? pq : hq;
-#pragma unroll 8
-          for (int k = sub * 8; k < Hd; k += 32) {
-            const uint4 kv = *reinterpret_cast<const uint4*>(krow + k);
-            part_sum += dot8(kv, qv + k);
-          }
-        } else {
-#pragma unroll 4
-          for (int k = sub * 8; k < Hd; k += 32) {
-            const uint4 kv = *reinterpret_cast<const uint4*>(krow + k);
-            const unsigned short* e = reinterpret_cast<const unsigned short*>(&kv);
+    const bool additive = att_additive(s.attention);
+    const float* qv = s.attention == LAS_ATT_CUSTOM ? pq : hq;
+    if (Hd <= 32 * KMAX) {
+      const int nk = Hd / 32;                          // loads per lane and frame
+      for (int t0 = 0; t0 < Tm; t0 += 64 * SC_PASSES) {
+        uint4 kv[SC_PASSES][KMAX];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) part_sum += s.att_v[k + j] * las_tanh(las_bf2f(e[j]) + pq[k + j]);
+        for (int p = 0; p < SC_PASSES; ++p) {
+          const int t = t0 + p * 64 + wave * 16 + fr;
+          const unsigned short* krow = keys + (int64_t)min(t, Tm - 1) * Hd;
+#pragma unroll
+          for (int j = 0; j < KMAX; ++j)
+            if (j < nk && t < len) kv[p][j] = *reinterpret_cast<const uint4*>(krow + sub * 8 + j * 32);
+        }
+#pragma unroll
+        for (int p = 0; p < SC_PASSES; ++p) {
+          const int t = t0 + p * 64 + wave * 16 + fr;
+          float part_sum = 0.f;
+          if (t < len) {
+#pragma unroll
+            for (int j = 0; j < KMAX; ++j)
+              if (j < nk) {
+                const int k = sub * 8 + j * 32;
+                if (!additive) part_sum += dot8(kv[p][j], qv + k);
+                else {
+                  const unsigned short* e = reinterpret_cast<const unsigned short*>(&kv[p][j]);
+#pragma unroll
+                  for (int i = 0; i < 8; ++i) part_sum += s.att_v[k + i] * las_tanh(las_bf2f(e[i]) + pq[k + i]);
+                }
+              }
           }
+          part_sum += __shfl_xor(part_sum, 1, 64);
+          part_sum += __shfl_xor(part_sum, 2, 64);
+          if (sub == 0 && t < Tm) sc[t] = (t < len) ? part_sum : -INFINITY;
         }
       }
-      part_sum += __shfl_xor(part_sum, 1, 64);
-      part_sum += __shfl_xor(part_sum, 2, 64);
-      if (sub == 0 && t < Tm) sc[t] = (t < len) ? part_sum : -INFINITY;
+    } else {
+      for (int t0 = 0; t0 < Tm; t0 += 64) {
+        const int t = t0 + wave * 16 + fr;
+        float part_sum = 0.f;
+        if (t < len) {
+          const unsigned short* krow = keys + (int64_t)t * Hd;
+          for (int k = sub * 8; k < Hd; k += 32) {
+            const uint4 kvv = *reinterpret_cast<const uint4*>(krow + k);
+            if (!additive) part_sum += dot8(kvv, qv + k);
+            else {
+              const unsigned short* e = reinterpret_cast<const unsigned short*>(&kvv);
+#pragma unroll
+              for (int i = 0; i < 8; ++i) part_sum += s.att_v[k + i] * las_tanh(las_bf2f(e[i]) + pq[k + i]);
+            }
+          }
+        }
+        part_sum += __shfl_xor(part_sum, 1, 64);
+        part_sum += __shfl_xor(part_sum, 2, 64);
+        if (sub == 0 && t < Tm) sc[t] = (t < len) ? part_sum : -INFINITY;
+      }
     }
   }
   __syncthreads();
@@ -250,13 +284,24 @@ __global__ __launch_bounds__(256) void dec_step_fwd_kernel(las_dec_step s) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) a[j] = 0.f;
     if (col < c_end) {
-#pragma unroll 4
-      for (int t = phase; t < len; t += P) {
-        const uint4 v = *reinterpret_cast<const uint4*>(vals + (int64_t)t * M + col);
-        const unsigned short* e = reinterpret_cast<const unsigned short*>(&v);
-        const float p = sc[t];
+      constexpr int VB = 16;                 // value loads in flight per thread (one round trip to Infinity Cache)
+      for (int tb = phase; tb < len; tb += P * VB) {
+        uint4 vv[VB];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) a[j] += p * las_bf2f(e[j]);
+        for (int i = 0; i < VB; ++i) {
+          const int t = tb + i * P;
+          if (t < len) vv[i] = *reinterpret_cast<const uint4*>(vals + (int64_t)t * M + col);
+        }
+#pragma unroll
+        for (int i = 0; i < VB; ++i) {
+          const int t = tb + i * P;
+          if (t < len) {
+            const unsigned short* e = reinterpret_cast<const unsigned short*>(&vv[i]);
+            const float p = sc[t];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) a[j] += p * las_bf2f(e[j]);
+          }
+        }
       }
     }
     __syncthreads();
@@ -281,6 +326,7 @@ __global__ __launch_bounds__(256) void dec_step_fwd_kernel(las_dec_step s) {
     }
   }
 }
+
 
 // ------------------------------------------------------------------------------------------------
 // backward
@@ -317,31 +363,61 @@ __global__ __launch_bounds__(256) void dec_step_bwd_kernel(las_dec_step_bwd s) {
   }
   __syncthreads();
 
-  // dalign[t'] = values[b,t',:] . dctx : 16 lanes per frame, two frames per thread in flight
+  // dalign[t'] = values[b,t',:] . dctx : 16 lanes per frame (4 frames per wave instruction); the loads of DB frames per
+  // lane are all in flight together (cold L2 at every launch: each dependent round trip goes to Infinity Cache)
   const unsigned short* vals = s.values + (int64_t)b * Tm * M;
   {
+    constexpr int DB = 8, NVMAX = 4;               // frames in flight per lane; 16-byte pieces per lane and frame (M <= 512)
     const int sub = lane & 15, grp = lane >> 4;
-    for (int t0 = 0; t0 < Tm; t0 += 32) {
-      const int ta = t0 + wave * 4 + grp, tb = ta + 16;
-      float acc_a = 0.f, acc_b = 0.f;
-      const bool oa = ta < len, ob = tb < len;
-      const unsigned short* ra = vals + (int64_t)(oa ? ta : 0) * M;
-      const unsigned short* rb = vals + (int64_t)(ob ? tb : 0) * M;
-#pragma unroll 4
-      for (int k = sub * 8; k < M; k += 128) {
-        const uint4 va = *reinterpret_cast<const uint4*>(ra + k);
-        const uint4 vb = *reinterpret_cast<const uint4*>(rb + k);
-        acc_a += dot8(va, dctx + k);
-        acc_b += dot8(vb, dctx + k);
-      }
+    const int nv = M / 128;
+    if (nv <= NVMAX) {
+      for (int t0 = 0; t0 < Tm; t0 += 16 * DB) {
+        uint4 vv[DB][NVMAX];
 #pragma unroll
-      for (int o = 8; o > 0; o >>= 1) {
-        acc_a += __shfl_xor(acc_a, o, 64);
-        acc_b += __shfl_xor(acc_b, o, 64);
+        for (int f = 0; f < DB; ++f) {
+          const int t = t0 + f * 16 + wave * 4 + grp;
+          const unsigned short* r = vals + (int64_t)min(t, Tm - 1) * M;
+#pragma unroll
+          for (int j = 0; j < NVMAX; ++j)
+            if (j < nv && t < len) vv[f][j] = *reinterpret_cast<const uint4*>(r + sub * 8 + j * 128);
+        }
+#pragma unroll
+        for (int f = 0; f < DB; ++f) {
+          const int t = t0 + f * 16 + wave * 4 + grp;
+          float acc = 0.f;
+          if (t < len) {
+#pragma unroll
+            for (int j = 0; j < NVMAX; ++j)
+              if (j < nv) acc += dot8(vv[f][j], dctx + sub * 8 + j * 128);
+          }
+#pragma unroll
+          for (int o = 8; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+          if (sub == 0 && t < Tm) ds[t] = (t < len) ? acc : 0.f;
+        }
       }
-      if (sub == 0) {
-        if (ta < Tm) ds[ta] = oa ? acc_a : 0.f;
-        if (tb < Tm) ds[tb] = ob ? acc_b : 0.f;
+    } else {
+      for (int t0 = 0; t0 < Tm; t0 += 32) {
+        const int ta = t0 + wave * 4 + grp, tb = ta + 16;
+        float acc_a = 0.f, acc_b = 0.f;
+        const bool oa = ta < len, ob = tb < len;
+        const unsigned short* ra = vals + (int64_t)(oa ? ta : 0) * M;
+        const unsigned short* rb = vals + (int64_t)(ob ? tb : 0) * M;
+#pragma unroll 4
+        for (int k = sub * 8; k < M; k += 128) {
+          const uint4 va = *reinterpret_cast<const uint4*>(ra + k);
+          const uint4 vb = *reinterpret_cast<const uint4*>(rb + k);
+          acc_a += dot8(va, dctx + k);
+          acc_b += dot8(vb, dctx + k);
+        }
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) {
+          acc_a += __shfl_xor(acc_a, o, 64);
+          acc_b += __shfl_xor(acc_b, o, 64);
+        }
+        if (sub == 0) {
+          if (ta < Tm) ds[ta] = oa ? acc_a : 0.f;
+          if (tb < Tm) ds[tb] = ob ? acc_b : 0.f;
+        }
       }
     }
   }
@@ -425,13 +501,24 @@ __global__ __launch_bounds__(256) void dec_step_bwd_kernel(las_dec_step_bwd s) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) a[j] = 0.f;
     if (!att_additive(s.attention)) {
-#pragma unroll 4
-      for (int t = phase; t < len; t += P) {
-        const uint4 v = *reinterpret_cast<const uint4*>(keys + (int64_t)t * Hd + u);
-        const unsigned short* e = reinterpret_cast<const unsigned short*>(&v);
-        const float d = ds[t];
+      constexpr int KB = 16;                 // key loads in flight per thread
+      for (int tb = phase; tb < len; tb += P * KB) {
+        uint4 kk[KB];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) a[j] += d * las_bf2f(e[j]);
+        for (int i = 0; i < KB; ++i) {
+          const int t = tb + i * P;
+          if (t < len) kk[i] = *reinterpret_cast<const uint4*>(keys + (int64_t)t * Hd + u);
+        }
+#pragma unroll
+        for (int i = 0; i < KB; ++i) {
+          const int t = tb + i * P;
+          if (t < len) {
+            const unsigned short* e = reinterpret_cast<const unsigned short*>(&kk[i]);
+            const float d = ds[t];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) a[j] += d * las_bf2f(e[j]);
+          }
+        }
       }
     } else {
       // Bahdanau: score = sum_a v[a] tanh(keys[t',a] + pq[a]); d_pre = ds * v * (1 - tanh^2)
