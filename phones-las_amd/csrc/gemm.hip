@@ -196,6 +196,141 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// TN product with hardware-transposed LDS reads (gfx950 ds_read_b64_tr_b16, cdna_hip_programming.md T10).
+// The operand tiles are staged exactly as they lie in memory, [k][m] and [k][n] with 256-byte rows (16-byte
+// vector stores, no transposition on the way in), in the XOR image of T10 (b):
+//     off(row, chunk) = 256*row + 16*(chunk ^ (((row & 3) << 2) | ((row >> 2) & 3)))
+// and every MFMA fragment (8 consecutive k of one m or n) is two transposed reads of a 4-row x 16-column block:
+// lane 4q+p of a 16-lane group supplies row q, columns 4p..4p+3; lane i receives column i of the four rows.
+// 128 x 128 output tile, BK = 64, 4 waves in a 2 x 2 grid, register-staged double buffering.
+// ------------------------------------------------------------------------------------------------
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(8))) short s16x8;
+
+__device__ __forceinline__ int tr_off(int row, int chunk) { return 256 * row + 16 * (chunk ^ (((row & 3) << 2) | ((row >> 2) & 3))); }
+
+__global__ __launch_bounds__(256) void gemm_tn_tr_kernel(GemmArgs g) {
+  constexpr int BM = 128, BN = 128;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* As = smem;                       // [2][BK][256 B]
+  unsigned char* Bs = smem + 2 * BK * 256;        // [2][BK][256 B]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 1, wc = wave & 1;
+  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+  const int batch = blockIdx.z / g.split_k, slice = blockIdx.z % g.split_k;
+  const unsigned short* A = g.A + (int64_t)batch * g.sa;
+  const unsigned short* B = g.B + (int64_t)batch * g.sb;
+  const int nk_total = (g.K + BK - 1) / BK;
+  const int nk_per = (nk_total + g.split_k - 1) / g.split_k;
+  const int kt_begin = slice * nk_per;
+  const int kt_end = min(nk_total, kt_begin + nk_per);
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  constexpr int CH = BK * 16 / 256;          // 16-byte chunks per thread and operand (4)
+  uint4 ra[CH], rb[CH];
+  auto load_tiles = [&](int kt) {
+    const int k0 = kt * BK;
+#pragma unroll
+    for (int i = 0; i < CH; ++i) {
+      const int c = tid + i * 256;
+      const int kr = c >> 4, ch = c & 15;
+      uint4 va = make_uint4(0, 0, 0, 0), vb = make_uint4(0, 0, 0, 0);
+      {
+        const int m = m0 + ch * 8;
+        int k = k0 + kr;
+        bool ok = (k < g.K) && (m < g.M);
+        if (g.period > 0) {
+          const int t = k % g.period + g.a_shift;
+          ok = ok && (t >= 0) && (t < g.period);
+          k += g.a_shift;
+        }
+        if (ok) va = *reinterpret_cast<const uint4*>(A + (int64_t)k * g.lda + m);
+      }
+      {
+        const int n = n0 + ch * 8, k = k0 + kr;
+        if (k < g.K && n < g.N) vb = *reinterpret_cast<const uint4*>(B + (int64_t)k * g.ldb + n);
+      }
+      ra[i] = va;
+      rb[i] = vb;
+    }
+  };
+  auto store_tiles = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < CH; ++i) {
+      const int c = tid + i * 256;
+      const int off = tr_off(c >> 4, c & 15);
+      *reinterpret_cast<uint4*>(As + buf * BK * 256 + off) = ra[i];
+      *reinterpret_cast<uint4*>(Bs + buf * BK * 256 + off) = rb[i];
+    }
+  };
+  // transposed-read addressing of this lane: group kg = lane>>4 takes k rows 8kg..8kg+7 of each 32-deep step
+  const int kg = lane >> 4, q = (lane & 15) >> 2, p = lane & 3;
+  auto frag = [&](const unsigned char* tile, int kk, int c0) -> bf16x8 {
+    const int r = kk + 8 * kg + q;
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+        (__attribute__((address_space(3))) s16x4*)(tile + tr_off(r, c0 + (p >> 1)) + 8 * (p & 1)));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+        (__attribute__((address_space(3))) s16x4*)(tile + tr_off(r + 4, c0 + (p >> 1)) + 8 * (p & 1)));
+    const s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    return __builtin_bit_cast(bf16x8, v);
+  };
+
+  if (kt_begin < kt_end) {
+    load_tiles(kt_begin);
+    store_tiles(0);
+    __syncthreads();
+    int buf = 0;
+    for (int kt = kt_begin; kt < kt_end; ++kt) {
+      const bool more = (kt + 1 < kt_end);
+      if (more) load_tiles(kt + 1);
+      const unsigned char* as = As + buf * BK * 256;
+      const unsigned char* bs = Bs + buf * BK * 256;
+#pragma unroll
+      for (int kk = 0; kk < BK; kk += 32) {
+        bf16x8 af[4], bfr[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) af[i] = frag(as, kk, wr * 8 + 2 * i);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bfr[j] = frag(bs, kk, wc * 8 + 2 * j);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+      }
+      if (more) store_tiles(buf ^ 1);
+      __syncthreads();
+      buf ^= 1;
+    }
+  }
+
+  float* Cf = reinterpret_cast<float*>(g.C) + (int64_t)batch * g.sc;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int coln = n0 + wc * 64 + j * 16 + (lane & 15);
+      if (coln >= g.N) continue;
+      const int col = g.c_perm_h > 0 ? (coln & 3) * g.c_perm_h + (coln >> 2) : coln;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = m0 + wr * 64 + i * 16 + (lane >> 4) * 4 + r;
+        if (row >= g.M) continue;
+        const int64_t off = (int64_t)row * g.ldc + col;
+        if (g.atomic) atomicAdd(Cf + off, acc[i][j][r]);
+        else Cf[off] += acc[i][j][r];
+      }
+    }
+  }
+}
+
 template <int BM, int BN, bool TN>
 int launch(const GemmArgs& g, int batch, hipStream_t st) {
   dim3 grid((g.N + BN - 1) / BN, (g.M + BM - 1) / BM, batch * g.split_k);
@@ -313,5 +448,16 @@ extern "C" int las_gemm_tn(const las_bf16* A, int64_t lda, const las_bf16* B, in
   LAS_REQUIRE(c_perm_h == 0 || N == 4 * c_perm_h, "las_gemm_tn: c_perm_h needs N == 4*H");
   GemmArgs g{A, B, C, nullptr, lda, ldb, ldc, sa, sb, sc, M, N, K, 0, 1, 1, split_k, a_shift, period, c_perm_h};
   if (M <= 64 || N <= 64) return launch<64, 64, true>(g, batch, st);
-  return launch<128, 128, true>(g, batch, st);
+  {
+    dim3 grid((N + 127) / 128, (M + 127) / 128, batch * split_k);
+    const size_t lds = (size_t)4 * BK * 256;
+    static bool attr_set = false;
+    if (!attr_set) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_tr_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      attr_set = true;
+    }
+    hipLaunchKernelGGL(gemm_tn_tr_kernel, grid, dim3(256), lds, st, g);
+    LAS_LAUNCH_CHECK("gemm tn launch");
+    return LAS_OK;
+  }
 }
