@@ -638,11 +638,35 @@ __global__ __launch_bounds__(256) void lstm_bwd_kernel(const float* __restrict__
     }
   };
 
+  // gate-derivative coefficients of a step: dz = f(dh) is then seven multiply-adds once dh arrives
+  //   do = dht*ao, dct = dc + dht*bc, di = dct*ci, dj = dct*cj, df = dct*cf, dc' = dct*gf   (dht = dy + dh)
+  struct Coef { float ao, bc, ci, cj, cf, gf, dyv; };
+  Coef cf[UBW][RPL];
+  auto prepare = [&]() {               // from sv (waits for its loads): runs while the partial sums are in flight
+#pragma unroll
+    for (int ub = 0; ub < UBW; ++ub)
+#pragma unroll
+      for (int r = 0; r < RPL; ++r) {
+        const Saved v = sv[ub][r];
+        const float tc = las_tanh(v.ct);
+        Coef k;
+        k.ao = tc * v.g.w * (1.f - v.g.w);
+        k.bc = v.g.w * (1.f - tc * tc);
+        k.ci = v.g.y * v.g.x * (1.f - v.g.x);
+        k.cj = v.g.x * (1.f - v.g.y * v.g.y);
+        k.cf = v.cp * v.g.z * (1.f - v.g.z);
+        k.gf = v.g.z;
+        k.dyv = v.dyv;
+        cf[ub][r] = k;
+      }
+  };
+
   int cur = 0;
   unsigned epoch = 0;          // = iterations done; partial sums sent in iteration i carry tag i+1 in parity slot i&1
   bool ok = true;
   set_goff(smin > 0 ? smin - 1 : 0);
   load_general(smax - 1);
+  prepare();
   for (int s = smax - 1; s >= 0 && ok; --s) {
     const bool lean = s < smin;              // every row of the slice is running at step s
     // ---- dh_s: own partial + the peers' (sent in the previous iteration, i.e. for time step s) ----
@@ -696,15 +720,14 @@ __global__ __launch_bounds__(256) void lstm_bwd_kernel(const float* __restrict__
         const bool act = lean || s < len[r];
         uint2 zv = make_uint2(0u, 0u);
         if (act) {
-          const Saved v = sv[ub][r];
-          const float dht = v.dyv + dh[ub][r];
-          const float tc = las_tanh(v.ct);
-          const float dov = dht * tc * v.g.w * (1.f - v.g.w);
-          const float dct = dc[ub][r] + dht * v.g.w * (1.f - tc * tc);
-          const float di = dct * v.g.y * v.g.x * (1.f - v.g.x);
-          const float dj = dct * v.g.x * (1.f - v.g.y * v.g.y);
-          const float df = dct * v.cp * v.g.z * (1.f - v.g.z);
-          dc[ub][r] = dct * v.g.z;
+          const Coef k = cf[ub][r];              // everything that does not depend on dh was folded one step ahead
+          const float dht = k.dyv + dh[ub][r];
+          const float dov = dht * k.ao;
+          const float dct = dc[ub][r] + dht * k.bc;
+          const float di = dct * k.ci;
+          const float dj = dct * k.cj;
+          const float df = dct * k.cf;
+          dc[ub][r] = dct * k.gf;
           zv.x = (unsigned)las_f2bf(di) | ((unsigned)las_f2bf(dj) << 16);
           zv.y = (unsigned)las_f2bf(df) | ((unsigned)las_f2bf(dov) << 16);
           if (lean) *reinterpret_cast<uint2*>(zbase + (goff[r] >> 1) + ub * 128) = zv;
@@ -751,6 +774,7 @@ __global__ __launch_bounds__(256) void lstm_bwd_kernel(const float* __restrict__
     for (int ub = 0; ub < OWN; ++ub)
 #pragma unroll
       for (int r = 0; r < RPL; ++r) part[ub][r] = acc[ub][r];
+    prepare();                               // coefficients of step s-1 (its operands were loaded above)
     ++epoch;
     cur ^= 1;
   }
