@@ -68,9 +68,6 @@ class GeneralSpeller:
         applied (inner_projection_layer=False)."""
         d = hparams
         self.binf = binf2phone
-        if (d.dropout or 0.0) > 0 and (d.embedding_size or binf2phone is not None):
-            raise ValueError('dropout > 0 together with a dense token feed (embedding_size > 0 or binf_projection) is not '
-                             'implemented on the HIP path (element-wise dropout of the embedded token needs its own product)')
         if binf2phone is not None and d.bottom_only and d.num_layers > 1:
             raise ValueError('binf_projection needs the decoder output to be the 2*binf_count attention vector: '
                              'use decoder_layers 1 or drop --bottom_only')
@@ -98,12 +95,17 @@ class GeneralSpeller:
             if v % 8:
                 raise ValueError('%s must be a multiple of 8 on the HIP path' % n)
         self.P = self.Hd if (self.bottom and self.NL > 1) else self.A
+        # Dense token feed (embedding / binary features) under input dropout: the DropoutWrapper mask is element-wise on
+        # the embedded token, so it cannot be folded into a per-token row table; the (zero-padded) token vector then
+        # travels as the first T0 columns of cell 0's GEMM operand: X_0 = [emb(y) | attention_{t-1} | h_{t-1}].
+        self.tokx = self.emb and (d.dropout or 0.0) > 0
+        self.T0 = _r8(self.E) if self.tokx else 0
         Hd, A = self.Hd, self.A
         # GEMM input width of each cell (without the token part of cell 0) and where its pieces sit
         self.win = []
         for l in range(self.NL):
             if l == 0:
-                self.win.append(A)                         # [att_{t-1}]            + h_0
+                self.win.append(self.T0 + A)               # [(token) att_{t-1}]    + h_0
             elif self.bottom:
                 self.win.append((A if l == 1 else Hd) + A)   # [cur, att_{t-1}]     + h_l
             else:
@@ -158,10 +160,19 @@ class GeneralSpeller:
         for l in range(self.NL):
             k = var[self.cell_names(l)[0]]
             skip = E if l == 0 else 0
-            rows = self.win[l] + Hd
+            rows = self.win[l] + Hd - (self.T0 if l == 0 else 0)
             assert k.shape == (skip + rows, 4 * Hd), (l, tuple(k.shape), skip + rows)
-            hip.cast_bf16(k[skip:], rows, 4 * Hd, self.kT[l], 4 * Hd, rows, transpose=True, lds=4 * Hd)
-            hip.cast_bf16(k[skip:], rows, 4 * Hd, self.kn[l], rows, 4 * Hd, lds=4 * Hd)
+            if l == 0 and self.tokx:     # rows [0,E) token, zero pad to T0, then attention feed and h
+                T0, W0 = self.T0, self.win[0] + Hd
+                self.kT[0].zero_()
+                self.kn[0].zero_()
+                hip.cast_bf16(k, E, 4 * Hd, self.kT[0], 4 * Hd, E, ldd=W0, transpose=True, lds=4 * Hd)
+                hip.cast_bf16(k[E:], rows, 4 * Hd, self.kT[0][:, T0:], 4 * Hd, rows, ldd=W0, transpose=True, lds=4 * Hd)
+                hip.cast_bf16(k, E, 4 * Hd, self.kn[0], E, 4 * Hd, lds=4 * Hd)
+                hip.cast_bf16(k[E:], rows, 4 * Hd, self.kn[0][T0:], rows, 4 * Hd, lds=4 * Hd)
+            else:
+                hip.cast_bf16(k[skip:], rows, 4 * Hd, self.kT[l], 4 * Hd, rows, transpose=True, lds=4 * Hd)
+                hip.cast_bf16(k[skip:], rows, 4 * Hd, self.kn[l], rows, 4 * Hd, lds=4 * Hd)
             self.bias.append(var[self.cell_names(l)[1]])
         k0 = var[self.cell_names(0)[0]]
         Ep = self.Ep
@@ -232,14 +243,14 @@ class GeneralSpeller:
         s = hip.DecStep()
         s.B, s.Hd, s.M, s.Tm, s.attention, s.mode = B, Hd, self.M, sv['Tm'], self.att, hip.DEC_CELL_ONLY
         s.z, s.bias = hip.addr(z), hip.addr(self.bias[l])
-        if l == 0:
+        if l == 0 and not self.tokx:
             s.tok_rows, s.tok_ids, s.tok_stride = hip.addr(self.tok), tok_ids, tok_stride
         s.c_prev, s.ldcp = hip.addr(sv['cs'][l], t * Hd), (U + 1) * Hd
         s.gates_out, s.ldg = hip.addr(sv['gates'][l], t * 4 * Hd), U * 4 * Hd
         s.c_out, s.ldco = hip.addr(sv['cs'][l], (t + 1) * Hd), (U + 1) * Hd
         s.h_out, s.ldh = hip.addr(sv['h'][l], t * Hd), U * Hd
         s.drop_keep, s.feed_width = 1.0, self.E + self.A
-        if l == 0 and sv['keep'] < 1.0:      # the one-hot token entry survives with probability keep (scaled 1/keep)
+        if l == 0 and sv['keep'] < 1.0 and not self.tokx:   # the one-hot token entry survives with probability keep (scaled 1/keep)
             s.drop_keep, s.drop_seed, s.drop_stream, s.step = sv['keep'], sv['seed'], self.DEC_STREAM, t
         hip.check(hip.lib().las_decoder_step_fwd(C.byref(s), 1, hip.stream()))
 
@@ -310,6 +321,9 @@ class GeneralSpeller:
         for t in range(U):
             last = t + 1 == U
 
+            if self.tokx:                 # embedded token of this step into the operand (dropped with the rest below)
+                X[0][:, t, :self.Ep] = self.emb_bf[fed[:, t].long()]
+
             def run_cell(l):
                 Kl = self.win[l] + Hd
                 if keep < 1.0:            # DropoutWrapper on this cell's input: drop the GEMM operand in place
@@ -338,7 +352,7 @@ class GeneralSpeller:
                     # X[l][:, t, wc:wc+A] already holds attention_{t-1} (written at the end of step t-1; zero at t=0)
                     run_cell(l)
             if not last:
-                X[0][:, t + 1, :A].copy_(att[:, t])
+                X[0][:, t + 1, self.T0:self.T0 + A].copy_(att[:, t])
                 if self.bottom:
                     for l in range(1, NL):
                         wc = A if l == 1 else Hd
@@ -417,6 +431,7 @@ class GeneralSpeller:
             carry = torch.zeros(B, Tmp, dtype=f32, device=dev)
         qlayer = 0 if self.bottom else NL - 1
         W = [w + Hd for w in self.win]
+        dtokx = torch.empty(B, U, self.Ep, dtype=bf, device=dev) if (self.tokx and self.binf is None) else None
 
         def v(buf, off, ld):              # (address, row stride) of a column window of a [B, ld] fp32 buffer
             return (hip.addr(buf, off), ld)
@@ -444,7 +459,7 @@ class GeneralSpeller:
             else:
                 datt.copy_(d_out[:, t])
             if has_next:
-                datt.add_(dx[0][nxt][:, :A])
+                datt.add_(dx[0][nxt][:, self.T0:self.T0 + A])
                 if self.bottom:
                     for l in range(1, NL):
                         wc = A if l == 1 else Hd
@@ -486,6 +501,8 @@ class GeneralSpeller:
                 cell_and_gemm(NL - 1, qsrc)
                 for l in range(NL - 2, -1, -1):
                     cell_and_gemm(l, [v(dx[l + 1][cur], 0, W[l + 1])])
+            if dtokx is not None:         # gradient w.r.t. the embedded token of this step (after its dropout mask)
+                hip.cast_bf16(dx[0][cur], B, self.Ep, dtokx[:, t], B, self.Ep, ldd=U * self.Ep, lds=W[0])
         # ---- after the loop: attention tensors (critical path into the listener) ----
         if not bah:
             # dot-product scores: d(keys)[b] = dScore[b]^T Q[b], Q = the queries (relu(Wq h) for CustomAttention)
@@ -514,8 +531,27 @@ class GeneralSpeller:
         for l in range(NL):
             kn, bn = self.cell_names(l)
             skip = self.E if l == 0 else 0
-            hip.gemm_tn(sv['X'][l], dz[l], grads[kn][skip:], W[l], 4 * Hd, BU, lda=W[l], ldb=4 * Hd, ldc=4 * Hd, split_k=4)
+            if l == 0 and self.tokx:     # operand columns [0,E) are the token rows of the kernel, [T0, ...) the rest
+                X0 = sv['X'][0]
+                hip.gemm_tn(X0, dz[0], grads[kn], self.E, 4 * Hd, BU, lda=W[0], ldb=4 * Hd, ldc=4 * Hd, split_k=4)
+                hip.gemm_tn(X0.view(BU, W[0])[:, self.T0:], dz[0], grads[kn][skip:], W[0] - self.T0, 4 * Hd, BU, lda=W[0],
+                            ldb=4 * Hd, ldc=4 * Hd, split_k=4)
+            else:
+                hip.gemm_tn(sv['X'][l], dz[l], grads[kn][skip:], W[l], 4 * Hd, BU, lda=W[l], ldb=4 * Hd, ldc=4 * Hd, split_k=4)
             hip.colsum_bf16(dz[l], BU, 4 * Hd, grads[bn], ldx=4 * Hd)
+        if self.tokx:
+            if dtokx is not None:        # d(embedding) = onehot^T d(embedded tokens)
+                onehot = torch.empty(BU, Vp, dtype=bf, device=dev)
+                fed = sv['fed']
+                hip.check(lib.las_onehot_bf16(hip.p(fed), fed.stride(0), B, U, V, hip.p(onehot), Vp, 1.0, 0, 0, 1, st))
+                dE = torch.zeros(V, self.Ep, dtype=f32, device=dev)
+                hip.gemm_tn(onehot, dtokx, dE, V, self.Ep, BU, lda=Vp, ldb=self.Ep, ldc=self.Ep, split_k=4)
+                grads[self.K_EMB].add_(dE[:, :self.E])
+            d_state = None
+            if sv['passed']:
+                d_state = [(dc[l], dx[l][0][:, self.win[l]:]) for l in range(sv['passed'])]
+            self.saved = None
+            return dmem, d_state
         # token part of cell 0: d(rows) = onehot^T dz_0, then through the embedding if there is one
         onehot = torch.empty(BU, Vp, dtype=bf, device=dev)
         fed = sv['fed']
@@ -609,6 +645,9 @@ class GeneralSpeller:
         for t in range(S):
             last = t + 1 == S
 
+            if self.tokx:
+                X[0][:, t, :self.Ep] = self.emb_bf[fed[:, t].long()]
+
             def run_cell(l):
                 Kl = self.win[l] + Hd
                 hip.gemm_nt(X[l][:, t], self.kT[l], z, B, 4 * Hd, Kl, lda=U * Kl, ldb=Kl, ldc=4 * Hd)
@@ -649,7 +688,7 @@ class GeneralSpeller:
             steps = t + 1
             if not last:
                 fed[:, t + 1] = sample
-                X[0][:, t + 1, :A].copy_(att[:, t])
+                X[0][:, t + 1, self.T0:self.T0 + A].copy_(att[:, t])
                 if self.bottom:
                     for l in range(1, NL):
                         wc = A if l == 1 else Hd

@@ -12,18 +12,18 @@ pytestmark = pytest.mark.gpu
 DT = torch.float64
 
 
-def _build(dropout=0.0, sampling=0.0, att='luong', dec_layers=1, bottom_only=True, pass_hidden=True):
+def _build(dropout=0.0, sampling=0.0, att='luong', dec_layers=1, bottom_only=True, pass_hidden=True, emb=0):
     from oracle import las_oracle as O
     from phones_las_amd import model_helper as mh
     from phones_las_amd.utils import params_utils as pu
     F, L, H, V = 13, 2, 64, 11
     ohp = O.HP(encoder=O.EncoderHP(num_layers=L, num_units=H), num_channels=F,
                decoder=O.DecoderHP(num_layers=dec_layers, num_units=H, target_vocab_size=V, attention_type=att,
-                                   bottom_only=bottom_only, pass_hidden_state=pass_hidden))
+                                   bottom_only=bottom_only, pass_hidden_state=pass_hidden, embedding_size=emb))
     hp = pu.get_default_hparams()
     for k, v in dict(num_channels=F, encoder_layers=L, encoder_units=H, use_pyramidal=True, decoder_layers=dec_layers,
                      decoder_units=H, target_vocab_size=V, attention_type=att, bottom_only=bottom_only,
-                     pass_hidden_state=pass_hidden,
+                     pass_hidden_state=pass_hidden, embedding_size=emb,
                      dropout=dropout, sampling_probability=sampling).items():
         hp.set_hparam(k, v)
     params = pu.get_encoder_decoder_hparams(hp)
@@ -150,6 +150,41 @@ def test_general_decoder_dropout_and_sampling_replayed(bottom):
     ids = [fed[:, t + 1] for t in range(U - 1)] + [torch.zeros(3, dtype=torch.long)]
     out = O.train_step(ohp, op, None, None, 1, batch, mxu='bf16',
                        stochastic={'enc_masks': enc_masks, 'dec_masks': dec_masks, 'sample_select': sel, 'sample_ids': ids})
+    for b, n in enumerate([6, 4, 5]):
+        assert relerr(logits[b, :n, :V], out['aux']['logits'][b, :n]) < 3e-2
+    for name, _, _ in model.vars.table:
+        g = out['grads'][name] - ohp.l2_reg_scale * op[name]
+        assert relerr(model.vars.grads[name], g) < 8e-2, name
+
+
+def test_embedding_with_dropout_replayed():
+    """Dense token feed under DropoutWrapper: the element-wise mask on the embedded token (the token vector travels in
+    cell 0's GEMM operand instead of a per-token row table); embedding gradient through the mask."""
+    keep = 0.75
+    O, ohp, op, model = _build(dropout=1 - keep, sampling=0.0, dec_layers=2, bottom_only=False, pass_hidden=False, emb=12)
+    sp = model.speller
+    assert sp.tokx and sp.T0 == 16
+    batch = make_batch(src_len=[12, 7, 10], tgt_len=[6, 4, 5])
+    feats, labels = to_device(batch)
+    model.vars.grad.zero_()
+    loss, logits, dlogits = model.forward_train(feats, labels)
+    model.backward(dlogits)
+    torch.cuda.synchronize()
+    seed = model.last_seed
+    B, F, H, V, U, E = 3, 13, 64, 11, 6, 12
+    enc_masks = []
+    for l, (Tl, Dp, D) in enumerate([(12, 16, F), (12, 2 * H, 2 * H)]):
+        enc_masks.append(tuple(_mask(B * Tl * Dp, keep, seed, 16 + 2 * l + d).reshape(B, Tl, Dp)[..., :D] for d in range(2)))
+    dec_masks = []
+    for t in range(U):
+        per_layer = []
+        for l in range(2):
+            m = _mask(B * sp.win[l], keep, seed, sp.in_stream(l, t)).reshape(B, sp.win[l])
+            if l == 0:                   # drop the zero-padding columns [E, T0) of the token part
+                m = torch.cat([m[:, :E], m[:, sp.T0:]], 1)
+            per_layer.append(m)
+        dec_masks.append(per_layer)
+    out = O.train_step(ohp, op, None, None, 1, batch, mxu='bf16', stochastic={'enc_masks': enc_masks, 'dec_masks': dec_masks})
     for b, n in enumerate([6, 4, 5]):
         assert relerr(logits[b, :n, :V], out['aux']['logits'][b, :n]) < 3e-2
     for name, _, _ in model.vars.table:
