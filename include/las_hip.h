@@ -206,6 +206,28 @@ typedef struct las_dec_step {
 } las_dec_step;
 int las_decoder_step_fwd(const las_dec_step* s, int parts, void* stream);
 
+/* All U steps of the fused decoder (las_dec_mode FUSED, softmax attentions) in ONE launch: a persistent kernel whose
+ * workgroups alternate between the per-step product z_t = x_t K (x_t = row t of the operand buffer: [attention_{t-1},
+ * h_{t-1}], written by step t-1 through h_out2 / ctx_out2) and the step itself, meeting at flag barriers; keys and
+ * values stay L2-resident for the whole sequence.  `s` describes step 0; the inc_* fields are the element increments of
+ * its per-step pointers (h_out2 / ctx_out2 are not written by the last step).  Replaces the U x (las_gemm_nt +
+ * las_decoder_step_fwd) loop of las/model.py:276-296 when scheduled sampling is off.  The call zeroes `workspace`
+ * (las_decoder_persist_workspace_bytes); its first uint32 is non-zero afterwards if a bounded wait timed out. */
+typedef struct las_dec_persist {
+  las_dec_step s;
+  int32_t U, K_in;               /* steps; columns of the operand rows / of kT (multiple of 32) */
+  int64_t inc_tok, inc_cprev, inc_gates, inc_cout, inc_h, inc_h2, inc_align, inc_pq, inc_ctx, inc_ctx2;
+  const las_bf16* x;             /* operand rows: utterance b, step t at x + b*ldx + t*inc_x */
+  int64_t ldx, inc_x;
+  const las_bf16* kT;            /* [4Hd, K_in] bf16, row n = output column n, row stride ldk */
+  int64_t ldk;
+  float* z_all;                  /* [U, B, 4Hd] fp32 scratch (every z_t keeps its own rows) */
+  void* workspace;
+} las_dec_persist;
+int las_decoder_persist_supported(int Hd, int M, int K_in, int attention, int norm);   /* 1 if the shapes fit */
+size_t las_decoder_persist_workspace_bytes(int B);
+int las_decoder_persist_fwd(const las_dec_persist* p, void* stream);
+
 /* Backward of one decoder step.  d(context) = dctx_a + dctx_b; the kernel
  * back-propagates through context, softmax and score into h_t, adds dh_rec, runs the LSTM cell
  * backward and emits dz (bf16) for the dense products; dc is updated in place to dc_{t-1}. */

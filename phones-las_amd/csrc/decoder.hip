@@ -70,16 +70,13 @@ __device__ __forceinline__ float dot8(const uint4& k, const float* q) {
 // ------------------------------------------------------------------------------------------------
 // forward
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void dec_step_fwd_kernel(las_dec_step s) {
-  extern __shared__ __attribute__((aligned(16))) float sm[];
+__device__ void dec_step_fwd_body(const las_dec_step& s, const int b, const int part, const int nparts, float* sm) {
   float* hq = sm;                 // [Hd] h_t (bf16-rounded) as float
   float* pq = hq + s.Hd;          // [Hd] processed query (Bahdanau)
   float* sc = pq + s.Hd;          // [Tm] scores -> probabilities
   float* red = sc + s.Tm;         // [8]
 
   float* cred = red + 8;          // [256][8] floats (context phases); monotonic work arrays follow it
-  const int b = blockIdx.x;
-  const int part = blockIdx.y, nparts = gridDim.y;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int Hd = s.Hd, M = s.M, Tm = s.Tm;
   const int len = (s.mode == LAS_DEC_CELL_ONLY) ? 0 : min(s.mem_len[b], Tm);
@@ -327,6 +324,171 @@ __global__ __launch_bounds__(256) void dec_step_fwd_kernel(las_dec_step s) {
   }
 }
 
+
+__global__ __launch_bounds__(256) void dec_step_fwd_kernel(las_dec_step s) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  dec_step_fwd_body(s, blockIdx.x, blockIdx.y, gridDim.y, sm);
+}
+
+// ------------------------------------------------------------------------------------------------
+// PERSISTENT forward decoder: all U steps of the fused AttentionWrapper(LSTMCell) decoder in ONE launch.
+// Why: every kernel launch starts with cold per-XCD L2s, so a per-step kernel pays an Infinity-Cache round trip for
+// each dependent phase and re-fetches all keys/values (~20 MB) every step; here they stay in the XCD's L2.
+// Decomposition: utterances are cut into groups of 8; a group is served by 32 co-resident workgroups that the
+// block index places on ONE XCD (block = group + 8k*member).  Per step each member plays two roles:
+//   G: columns [member*4Hd/32, ...) of z_t = [attention_{t-1}, h_{t-1}] K for the group's 8 utterances (its slice of
+//      K stays in registers as MFMA B fragments for all steps; M = 16 rows, 8 used);
+//   S: the step kernel's body for utterance member/4, context-column part member%4.
+// Between the roles the 32 members meet at a flag barrier in global memory (each writes its own epoch word, wave 0
+// polls all 32); the exchanged tensors (z_t, c_t, the next operand row) are written once and read later at distinct
+// addresses, so no stale L1 line can exist, and with the group on one XCD its L2 is the coherence point: plain
+// stores, no fences.  If the members find themselves on different XCDs (XCC_ID handshake) they add agent-scope
+// release/acquire fences around the barrier instead: slower, same results.  Every spin is bounded (status word).
+// ------------------------------------------------------------------------------------------------
+typedef unsigned long long pu64;
+constexpr unsigned P_SPIN_LIMIT = 1u << 22;
+constexpr int P_MEMBERS = 32;
+
+__device__ bool persist_barrier(pu64* flags, int member, unsigned epoch, bool local, int* lds_fail) {
+  __builtin_amdgcn_s_waitcnt(0x0070);                      // vmcnt(0) lgkmcnt(0): this wave's stores are acknowledged
+  if (!local) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    if (local) flags[member] = epoch;
+    else __hip_atomic_store(flags + member, (pu64)epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  if (threadIdx.x < 64) {
+    const int lane = threadIdx.x;
+    unsigned spins = 0;
+    for (;;) {
+      const pu64 v = lane < P_MEMBERS ? __hip_atomic_load(flags + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : (pu64)epoch;
+      if (__all(v >= epoch)) break;
+      if (++spins > P_SPIN_LIMIT) { if (lane == 0) *lds_fail = 1; break; }
+      __builtin_amdgcn_s_sleep(1);
+    }
+  }
+  __syncthreads();
+  if (!local) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  return *lds_fail == 0;
+}
+
+__global__ __launch_bounds__(256) void dec_persist_fwd_kernel(las_dec_persist p) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  constexpr int NTL_MAX = 2, KCW_MAX = 12;
+  const las_dec_step& s0 = p.s;
+  const int B = s0.B, Hd = s0.Hd, M = s0.M, Tm = s0.Tm;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, lq = lane >> 4;
+  const int groups = (B + 7) / 8, gstride = (groups + 7) & ~7;
+  const int group = blockIdx.x % gstride, member = blockIdx.x / gstride;
+  if (group >= groups) return;
+  unsigned* status = reinterpret_cast<unsigned*>(p.workspace);
+  pu64* flags = reinterpret_cast<pu64*>(reinterpret_cast<char*>(p.workspace) + 64) + (size_t)group * 2 * P_MEMBERS;
+  pu64* xcc_tab = flags + P_MEMBERS;
+  float* red = sm + (2 * Hd + Tm + 16 + 2048);             // [4 waves][16][CPM+1] partial z tiles
+  int* fail = reinterpret_cast<int*>(red + 4 * 16 * 33);
+  int* colo = fail + 1;
+  if (tid == 0) { *fail = 0; *colo = 0; }
+  __syncthreads();
+
+  // are the 32 members on one XCD?  (same handshake as the recurrent kernels; decides fences only)
+  if (tid == 0) {
+    unsigned xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    xcc &= 0xf;
+    __hip_atomic_store(xcc_tab + member, ((pu64)1 << 32) | (xcc + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    bool same = true;
+    for (int m = 0; m < P_MEMBERS; ++m) {
+      pu64 v = 0;
+      unsigned spins = 0;
+      do {
+        v = __hip_atomic_load(xcc_tab + m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((v >> 32) == 1) break;
+        __builtin_amdgcn_s_sleep(2);
+      } while (++spins < P_SPIN_LIMIT);
+      same = same && ((v >> 32) == 1) && ((unsigned)v == xcc + 1);
+    }
+    *colo = same ? 1 : 0;
+  }
+  __syncthreads();
+  const bool local = *colo != 0;
+
+  // G role: this member's columns of z and its register-resident slice of K ([4Hd, K_in] bf16, row = output column)
+  const int CPM = 4 * Hd / P_MEMBERS, NTL = CPM / 16;      // columns per member, 16-column tiles
+  const int KC = p.K_in / 32, KCW = (KC + 3) / 4;          // 32-deep K chunks; wave w takes chunks w, w+4, ...
+  bf16x8 wf[NTL_MAX][KCW_MAX];
+#pragma unroll
+  for (int nt = 0; nt < NTL_MAX; ++nt)
+#pragma unroll
+    for (int i = 0; i < KCW_MAX; ++i) {
+      const int kc = wave + 4 * i;
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (nt < NTL && kc < KC) v = *reinterpret_cast<const uint4*>(p.kT + (int64_t)(member * CPM + nt * 16 + l15) * p.ldk + kc * 32 + 8 * lq);
+      wf[nt][i] = __builtin_bit_cast(bf16x8, v);
+    }
+  const int bg = group * 8 + (l15 & 7);                    // utterance of A-fragment row l15 (rows 8..15 repeat 0..7)
+  const int bs = group * 8 + member / 4, part = member & 3;  // S role
+  unsigned epoch = 0;
+
+  for (int t = 0; t < p.U; ++t) {
+    // ---- G: z_t[group's utterances, my columns] ----
+    float* zt = p.z_all + (int64_t)t * B * 4 * Hd;
+    {
+      f32x4 acc[NTL_MAX];
+#pragma unroll
+      for (int nt = 0; nt < NTL_MAX; ++nt) acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+      const unsigned short* arow = p.x + (int64_t)min(bg, B - 1) * p.ldx + (int64_t)t * p.inc_x + 8 * lq;
+      uint4 av[KCW_MAX];
+#pragma unroll
+      for (int i = 0; i < KCW_MAX; ++i) {
+        const int kc = wave + 4 * i;
+        av[i] = make_uint4(0, 0, 0, 0);
+        if (kc < KC && bg < B) av[i] = *reinterpret_cast<const uint4*>(arow + kc * 32);
+      }
+#pragma unroll
+      for (int i = 0; i < KCW_MAX; ++i)
+#pragma unroll
+        for (int nt = 0; nt < NTL_MAX; ++nt)
+          if (nt < NTL && wave + 4 * i < KC)
+            acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, av[i]), wf[nt][i], acc[nt], 0, 0, 0);
+#pragma unroll
+      for (int nt = 0; nt < NTL_MAX; ++nt)
+        if (nt < NTL)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) red[(wave * 16 + lq * 4 + r) * 33 + nt * 16 + l15] = acc[nt][r];
+      __syncthreads();
+      for (int e = tid; e < 8 * CPM; e += 256) {
+        const int row = e / CPM, col = e % CPM;
+        const int b = group * 8 + row;
+        if (b < B)
+          zt[(int64_t)b * 4 * Hd + member * CPM + col] =
+              red[(0 * 16 + row) * 33 + col] + red[(1 * 16 + row) * 33 + col] + red[(2 * 16 + row) * 33 + col] + red[(3 * 16 + row) * 33 + col];
+      }
+    }
+    if (!persist_barrier(flags, member, ++epoch, local, fail)) break;
+
+    // ---- S: cell + attention of utterance bs, context columns of `part` ----
+    if (bs < B) {
+      las_dec_step st = s0;
+      const bool last = (t + 1 == p.U);
+      st.z = zt;
+      st.tok_ids = s0.tok_ids + t * p.inc_tok;
+      st.c_prev = s0.c_prev + t * p.inc_cprev;
+      st.gates_out = s0.gates_out + t * p.inc_gates;
+      st.c_out = s0.c_out + t * p.inc_cout;
+      st.h_out = s0.h_out + t * p.inc_h;
+      st.h_out2 = last ? nullptr : s0.h_out2 + t * p.inc_h2;
+      st.align_out = s0.align_out + t * p.inc_align;
+      st.align_bf16 = s0.align_bf16 ? s0.align_bf16 + t * p.inc_align : nullptr;
+      st.pq_out = s0.pq_out ? s0.pq_out + t * p.inc_pq : nullptr;
+      st.ctx_out = s0.ctx_out + t * p.inc_ctx;
+      st.ctx_out2 = last ? nullptr : s0.ctx_out2 + t * p.inc_ctx2;
+      st.step = t;
+      dec_step_fwd_body(st, bs, part, 4, sm);
+    }
+    if (!persist_barrier(flags, member, ++epoch, local, fail)) break;
+  }
+  if (*fail && tid == 0) atomicOr(status, 8u);
+}
 
 // ------------------------------------------------------------------------------------------------
 // backward
@@ -783,6 +945,37 @@ extern "C" int las_decoder_step_fwd(const las_dec_step* s, int parts, void* stre
   LAS_REQUIRE(lds <= 64 * 1024, "las_decoder_step_fwd: memory length %d too long for the LDS score buffer", s->Tm);
   hipLaunchKernelGGL(dec_step_fwd_kernel, dim3(s->B, parts), dim3(256), lds, (hipStream_t)stream, *s);
   LAS_LAUNCH_CHECK("decoder step fwd launch");
+  return LAS_OK;
+}
+
+extern "C" int las_decoder_persist_supported(int Hd, int M, int K_in, int attention, int norm) {
+  if (norm != LAS_NORM_SOFTMAX) return 0;
+  if (attention != LAS_ATT_LUONG && attention != LAS_ATT_BAHDANAU && attention != LAS_ATT_CUSTOM) return 0;
+  if (Hd != 128 && Hd != 256) return 0;                   // 4Hd/32 columns per member: 16 or 32
+  if (K_in % 32 != 0 || K_in / 32 > 48) return 0;          // register-resident K slice: <= 12 chunks per wave
+  if (M % 32 != 0) return 0;
+  return 1;
+}
+
+extern "C" size_t las_decoder_persist_workspace_bytes(int B) {
+  return 64 + (size_t)((B + 7) / 8) * 2 * P_MEMBERS * sizeof(pu64);
+}
+
+extern "C" int las_decoder_persist_fwd(const las_dec_persist* p, void* stream) {
+  const las_dec_step* s = &p->s;
+  LAS_REQUIRE(s->B > 0 && p->U > 0 && s->mode == LAS_DEC_FUSED, "las_decoder_persist_fwd: bad shape / mode");
+  LAS_REQUIRE(las_decoder_persist_supported(s->Hd, s->M, p->K_in, s->attention, s->norm),
+              "las_decoder_persist_fwd: configuration not supported (Hd=%d M=%d K_in=%d attention=%d norm=%d)", s->Hd, s->M, p->K_in,
+              s->attention, s->norm);
+  LAS_REQUIRE(p->x && p->kT && p->z_all && p->workspace, "las_decoder_persist_fwd: null argument");
+  hipStream_t st = (hipStream_t)stream;
+  const int groups = (s->B + 7) / 8;
+  int rc = las_check_hip(hipMemsetAsync(p->workspace, 0, las_decoder_persist_workspace_bytes(s->B), st), "memset workspace");
+  if (rc) return rc;
+  const size_t lds = (size_t)(2 * s->Hd + s->Tm + 16 + 2048 + 4 * 16 * 33 + 8) * sizeof(float);
+  LAS_REQUIRE(lds <= 64 * 1024, "las_decoder_persist_fwd: memory length %d too long for the LDS score buffer", s->Tm);
+  hipLaunchKernelGGL(dec_persist_fwd_kernel, dim3(((groups + 7) & ~7) * P_MEMBERS), dim3(256), lds, st, *p);
+  LAS_LAUNCH_CHECK("persistent decoder fwd launch");
   return LAS_OK;
 }
 

@@ -51,6 +51,9 @@ _SIGS = {
     'las_fe_delta': ([_vp, _i64, _i32, _i32, _vp, _vp, _vp, _i32, _vp, _i64, _i32, _i32, _vp], C.c_int),
     'las_add_masked': ([_vp, _i64, _vp, _i64, _vp, _i64, _i32, _i32, _f32, C.c_uint32, C.c_uint32, C.c_uint64, _i64, _vp], C.c_int),
     'las_add_noise': ([_vp, _i64, _f32, C.c_uint32, C.c_uint32, _vp], C.c_int),
+    'las_decoder_persist_supported': ([C.c_int] * 5, C.c_int),
+    'las_decoder_persist_workspace_bytes': ([C.c_int], C.c_size_t),
+    'las_decoder_persist_fwd': ([_vp, _vp], C.c_int),
     'las_beam_step': ([_vp, _i64, _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp], C.c_int),
     'las_log_probs_loss': ([_vp, _i64, C.c_int, C.c_int, _f32, _f32, _vp, _vp, _i64, _vp], C.c_int),
     'las_normal_fill': ([_vp, _i64, C.c_uint32, C.c_uint32, _vp], C.c_int),
@@ -76,6 +79,13 @@ class DecStep(C.Structure):
                 ('drop_stream', C.c_uint32), ('step', _i32), ('feed_width', _i32), ('query', _vp), ('ldq', _i64),
                 ('norm', _i32), ('score_bias', _vp), ('prev_align', _vp), ('ldpa', _i64), ('p_out', _vp), ('ldp', _i64),
                 ('noise_scale', _f32), ('noise_seed', C.c_uint32), ('noise_stream', C.c_uint32)]
+
+
+class DecPersist(C.Structure):
+    """struct las_dec_persist (include/las_hip.h)."""
+    _fields_ = [('s', DecStep), ('U', _i32), ('K_in', _i32)] + [(n, _i64) for n in (
+        'inc_tok', 'inc_cprev', 'inc_gates', 'inc_cout', 'inc_h', 'inc_h2', 'inc_align', 'inc_pq', 'inc_ctx', 'inc_ctx2')] + [
+        ('x', _vp), ('ldx', _i64), ('inc_x', _i64), ('kT', _vp), ('ldk', _i64), ('z_all', _vp), ('workspace', _vp)]
 
 
 class DecStepBwd(C.Structure):

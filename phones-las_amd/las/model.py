@@ -10,6 +10,7 @@ Supported on the HIP path this round (anything else raises ValueError, never a s
             one-hot token feed (embedding_size 0), teacher forcing (sampling_probability 0) and greedy decode.
 """
 import ctypes as C
+import os
 
 import torch
 
@@ -259,7 +260,30 @@ class Speller:
             fed = tin[:, :U].contiguous().clone()
             logits = torch.empty(B, U, Vp, dtype=f32, device=dev)
         ts = fed.stride(0)
-        for t in range(U):
+        persist = (sampling == 0.0 and B <= 256 and os.environ.get('LAS_DEC_PERSIST', '1') != '0' and      # B: co-residency
+                   lib.las_decoder_persist_supported(Hd, M, W, self.att, hip.NORM_SOFTMAX) == 1)
+        if persist:
+            # all U steps in one persistent launch (keys/values stay L2-resident; see las_dec_persist in las_hip.h)
+            p = hip.DecPersist()
+            p.s = self._step_struct(
+                B, Tm, 0, hip.addr(fed), ts, hip.addr(cs), (U + 1) * Hd, hip.addr(gates), U * 4 * Hd,
+                hip.addr(cs, Hd), (U + 1) * Hd, hip.addr(h_all), U * Hd, hip.addr(AH, W + M) if U > 1 else 0, U * W,
+                keys, memory, mem_len, hip.addr(align), hip.addr(align_bf), U * Tmp,
+                hip.addr(pq_all) if pq_all is not None else 0, U * Hd, hip.addr(ctx_all), U * M,
+                hip.addr(AH, W) if U > 1 else 0, U * W)
+            if keep < 1.0:
+                p.s.drop_keep, p.s.drop_seed, p.s.drop_stream = keep, seed, self.DEC_STREAM
+            p.U, p.K_in = U, W
+            p.inc_tok, p.inc_cprev, p.inc_gates, p.inc_cout, p.inc_h, p.inc_h2 = 1, Hd, 4 * Hd, Hd, Hd, W
+            p.inc_align, p.inc_pq, p.inc_ctx, p.inc_ctx2 = Tmp, Hd, M, W
+            p.x, p.ldx, p.inc_x = hip.addr(AH), U * W, W
+            p.kT, p.ldk = hip.addr(self.kcT), W
+            z_all = torch.empty(U, B, 4 * Hd, dtype=f32, device=dev)
+            ws = torch.empty(lib.las_decoder_persist_workspace_bytes(B), dtype=torch.uint8, device=dev)
+            p.z_all, p.workspace = hip.addr(z_all), hip.addr(ws)
+            hip.check(lib.las_decoder_persist_fwd(C.byref(p), st))
+            self._persist_ws = ws
+        for t in range(0 if not persist else U, U):
             hip.gemm_nt(AH[:, t], self.kcT, z, B, 4 * Hd, W, lda=U * W, ldb=W, ldc=4 * Hd)
             last = (t + 1 == U)
             s = self._step_struct(

@@ -396,3 +396,33 @@ def test_beam_search_vs_oracle(kw):
     assert torch.equal(ids.long(), ref_ids), (ids[0].T.tolist(), ref_ids[0].T.tolist())
     assert torch.equal(pred['beam_lengths'].cpu().long(), ref_len)
     assert relerr(pred['beam_log_probs'], ref_scores[:, -1]) < 2e-2
+
+
+@pytest.mark.parametrize('att', ['luong', 'bahdanau'])
+def test_persistent_decoder_vs_per_step_and_oracle(att, monkeypatch):
+    """The one-launch persistent forward decoder (las_decoder_persist_fwd: decoder_units 128/256) against the per-step
+    launches (LAS_DEC_PERSIST=0) and the oracle; ragged memory and target lengths, B not a multiple of 8."""
+    from phones_las_amd import hip
+    O, ohp, op, model = _models(att, H=128, F=13, L=2)
+    assert hip.lib().las_decoder_persist_supported(128, 512, 640, model.speller.att, 0) == 1
+    src_len, tgt_len = [12, 7, 10, 12, 3, 9, 11, 12, 5, 8, 12], [6, 4, 5, 6, 2, 3, 6, 5, 4, 6, 1]
+    batch = make_batch(B=11, src_len=src_len, tgt_len=tgt_len)
+    feats, labels = to_device(batch)
+    outs = {}
+    for flag in ('1', '0'):
+        monkeypatch.setenv('LAS_DEC_PERSIST', flag)
+        model.vars.grad.zero_()
+        loss, logits, dlogits = model.forward_train(feats, labels)
+        model.backward(dlogits)
+        torch.cuda.synchronize()
+        if flag == '1':
+            assert int(model.speller._persist_ws[:4].view(torch.int32).item()) == 0      # no barrier timed out
+        outs[flag] = (float(loss), logits.clone(), {n: g.clone() for n, g in model.vars.grads.items()})
+    assert relerr(outs['1'][1], outs['0'][1].cpu()) < 1e-3
+    out = O.train_step(ohp, op, None, None, 1, batch, mxu='bf16')
+    V = ohp.decoder.target_vocab_size
+    for b, n in enumerate(tgt_len):
+        assert relerr(outs['1'][1][b, :n, :V], out['aux']['logits'][b, :n]) < 2e-2
+    for name, _, _ in model.vars.table:
+        g = out['grads'][name] - ohp.l2_reg_scale * op[name]
+        assert relerr(outs['1'][2][name], g) < 6e-2, name
