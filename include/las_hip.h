@@ -222,6 +222,8 @@ typedef struct las_dec_persist {
   const las_bf16* kT;            /* [4Hd, K_in] bf16, row n = output column n, row stride ldk */
   int64_t ldk;
   float* z_all;                  /* [U, B, 4Hd] fp32 scratch (every z_t keeps its own rows) */
+  float* sc_all;                 /* [U, B, ld_sc] fp32 scratch: raw attention scores (the parts of an utterance split the frames) */
+  int64_t ld_sc;                 /* >= Tm */
   void* workspace;
 } las_dec_persist;
 int las_decoder_persist_supported(int Hd, int M, int K_in, int attention, int norm);   /* 1 if the shapes fit */

@@ -70,7 +70,23 @@ __device__ __forceinline__ float dot8(const uint4& k, const float* q) {
 // ------------------------------------------------------------------------------------------------
 // forward
 // ------------------------------------------------------------------------------------------------
-__device__ void dec_step_fwd_body(const las_dec_step& s, const int b, const int part, const int nparts, float* sm) {
+// Set inside the persistent decoder only: the context-column parts of an utterance then SPLIT THE FRAMES of the score
+// phase (each part reads a quarter of the keys instead of all of them), publish their raw scores in a per-step row of
+// global scratch and meet at the group's flag barrier before the softmax.
+typedef unsigned long long pu64;
+struct PersistHook {
+  float* scores;        // [B][ld] raw scores of this step
+  int64_t ld;
+  pu64* flags;
+  int member;
+  unsigned* epoch;
+  bool local;
+  int* fail;
+};
+__device__ bool persist_barrier(pu64* flags, int member, unsigned epoch, bool local, int* lds_fail);
+
+__device__ void dec_step_fwd_body(const las_dec_step& s, const int b, const int part, const int nparts, float* sm,
+                                  const PersistHook* ph = nullptr) {
   float* hq = sm;                 // [Hd] h_t (bf16-rounded) as float
   float* pq = hq + s.Hd;          // [Hd] processed query (Bahdanau)
   float* sc = pq + s.Hd;          // [Tm] scores -> probabilities
@@ -137,9 +153,14 @@ __device__ void dec_step_fwd_body(const las_dec_step& s, const int b, const int 
     const int sub = lane & 3, fr = lane >> 2;
     const bool additive = att_additive(s.attention);
     const float* qv = s.attention == LAS_ATT_CUSTOM ? pq : hq;
+    // frames this workgroup scores: all of them, or its share when the parts exchange scores (persistent decoder)
+    const int fq = (Tm + nparts - 1) / nparts;
+    const int f0 = ph ? part * fq : 0, f1 = ph ? min(Tm, f0 + fq) : Tm;
+    const int flen = min(len, f1);
+    float* scw = ph ? ph->scores + (int64_t)b * ph->ld : sc;       // where raw scores go
     if (Hd <= 32 * KMAX) {
       const int nk = Hd / 32;                          // loads per lane and frame
-      for (int t0 = 0; t0 < Tm; t0 += 64 * SC_PASSES) {
+      for (int t0 = f0; t0 < f1; t0 += 64 * SC_PASSES) {
         uint4 kv[SC_PASSES][KMAX];
 #pragma unroll
         for (int p = 0; p < SC_PASSES; ++p) {
@@ -147,13 +168,13 @@ __device__ void dec_step_fwd_body(const las_dec_step& s, const int b, const int 
           const unsigned short* krow = keys + (int64_t)min(t, Tm - 1) * Hd;
 #pragma unroll
           for (int j = 0; j < KMAX; ++j)
-            if (j < nk && t < len) kv[p][j] = *reinterpret_cast<const uint4*>(krow + sub * 8 + j * 32);
+            if (j < nk && t < flen) kv[p][j] = *reinterpret_cast<const uint4*>(krow + sub * 8 + j * 32);
         }
 #pragma unroll
         for (int p = 0; p < SC_PASSES; ++p) {
           const int t = t0 + p * 64 + wave * 16 + fr;
           float part_sum = 0.f;
-          if (t < len) {
+          if (t < flen) {
 #pragma unroll
             for (int j = 0; j < KMAX; ++j)
               if (j < nk) {
@@ -168,14 +189,14 @@ __device__ void dec_step_fwd_body(const las_dec_step& s, const int b, const int 
           }
           part_sum += __shfl_xor(part_sum, 1, 64);
           part_sum += __shfl_xor(part_sum, 2, 64);
-          if (sub == 0 && t < Tm) sc[t] = (t < len) ? part_sum : -INFINITY;
+          if (sub == 0 && t < f1) scw[t] = (t < len) ? part_sum : -INFINITY;
         }
       }
     } else {
-      for (int t0 = 0; t0 < Tm; t0 += 64) {
+      for (int t0 = f0; t0 < f1; t0 += 64) {
         const int t = t0 + wave * 16 + fr;
         float part_sum = 0.f;
-        if (t < len) {
+        if (t < flen) {
           const unsigned short* krow = keys + (int64_t)t * Hd;
           for (int k = sub * 8; k < Hd; k += 32) {
             const uint4 kvv = *reinterpret_cast<const uint4*>(krow + k);
@@ -189,8 +210,12 @@ __device__ void dec_step_fwd_body(const las_dec_step& s, const int b, const int 
         }
         part_sum += __shfl_xor(part_sum, 1, 64);
         part_sum += __shfl_xor(part_sum, 2, 64);
-        if (sub == 0 && t < Tm) sc[t] = (t < len) ? part_sum : -INFINITY;
+        if (sub == 0 && t < f1) scw[t] = (t < len) ? part_sum : -INFINITY;
       }
+    }
+    if (ph) {            // every part has published its frames: gather the whole score row
+      if (!persist_barrier(ph->flags, ph->member, ++*ph->epoch, ph->local, ph->fail)) return;
+      for (int t = tid; t < Tm; t += 256) sc[t] = scw[t];
     }
   }
   __syncthreads();
@@ -345,7 +370,6 @@ __global__ __launch_bounds__(256) void dec_step_fwd_kernel(las_dec_step s) {
 // stores, no fences.  If the members find themselves on different XCDs (XCC_ID handshake) they add agent-scope
 // release/acquire fences around the barrier instead: slower, same results.  Every spin is bounded (status word).
 // ------------------------------------------------------------------------------------------------
-typedef unsigned long long pu64;
 constexpr unsigned P_SPIN_LIMIT = 1u << 22;
 constexpr int P_MEMBERS = 32;
 
@@ -483,7 +507,11 @@ __global__ __launch_bounds__(256) void dec_persist_fwd_kernel(las_dec_persist p)
       st.ctx_out = s0.ctx_out + t * p.inc_ctx;
       st.ctx_out2 = last ? nullptr : s0.ctx_out2 + t * p.inc_ctx2;
       st.step = t;
-      dec_step_fwd_body(st, bs, part, 4, sm);
+      PersistHook hook{p.sc_all + (int64_t)t * B * p.ld_sc, p.ld_sc, flags, member, &epoch, local, fail};
+      dec_step_fwd_body(st, bs, part, 4, sm, &hook);
+      if (*fail) break;
+    } else {
+      if (!persist_barrier(flags, member, ++epoch, local, fail)) break;     // the score exchange of the busy members
     }
     if (!persist_barrier(flags, member, ++epoch, local, fail)) break;
   }
@@ -967,7 +995,7 @@ extern "C" int las_decoder_persist_fwd(const las_dec_persist* p, void* stream) {
   LAS_REQUIRE(las_decoder_persist_supported(s->Hd, s->M, p->K_in, s->attention, s->norm),
               "las_decoder_persist_fwd: configuration not supported (Hd=%d M=%d K_in=%d attention=%d norm=%d)", s->Hd, s->M, p->K_in,
               s->attention, s->norm);
-  LAS_REQUIRE(p->x && p->kT && p->z_all && p->workspace, "las_decoder_persist_fwd: null argument");
+  LAS_REQUIRE(p->x && p->kT && p->z_all && p->sc_all && p->workspace && p->ld_sc >= s->Tm, "las_decoder_persist_fwd: null argument");
   hipStream_t st = (hipStream_t)stream;
   const int groups = (s->B + 7) / 8;
   int rc = las_check_hip(hipMemsetAsync(p->workspace, 0, las_decoder_persist_workspace_bytes(s->B), st), "memset workspace");

@@ -280,7 +280,8 @@ class Speller:
             p.kT, p.ldk = hip.addr(self.kcT), W
             z_all = torch.empty(U, B, 4 * Hd, dtype=f32, device=dev)
             ws = torch.empty(lib.las_decoder_persist_workspace_bytes(B), dtype=torch.uint8, device=dev)
-            p.z_all, p.workspace = hip.addr(z_all), hip.addr(ws)
+            sc_all = torch.empty(U, B, Tmp, dtype=f32, device=dev)
+            p.z_all, p.sc_all, p.ld_sc, p.workspace = hip.addr(z_all), hip.addr(sc_all), Tmp, hip.addr(ws)
             hip.check(lib.las_decoder_persist_fwd(C.byref(p), st))
             self._persist_ws = ws
         for t in range(0 if not persist else U, U):
