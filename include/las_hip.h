@@ -289,6 +289,25 @@ typedef struct las_dec_step_bwd {
 } las_dec_step_bwd;
 int las_decoder_step_bwd(const las_dec_step_bwd* s, void* stream);
 
+/* The backward counterpart of las_decoder_persist_fwd (Luong / softmax): all U steps, last to first, in one launch,
+ * replacing the U x (las_decoder_step_bwd + las_gemm_nt) loop.  `s` describes step 0 (dctx_b / dh_rec are ignored:
+ * the feed gradient of step t+1 is read from dfeed_all); per-step pointers advance by the inc_* element counts.
+ * dfeed_all[t] = dz_t K^T ([B, W] fp32: d attention_{t-1} in columns [0,M), d h_{t-1} in [M,W)); dfeed_all[0] is the
+ * gradient into the initial state.  s.dc is updated in place to dc_{-1}. */
+typedef struct las_dec_persist_bwd {
+  las_dec_step_bwd s;
+  int32_t U, W;                  /* steps; W = M + Hd */
+  int64_t inc_a, inc_save, inc_gates, inc_c, inc_align, inc_dz, inc_ds;
+  const las_bf16* kc;            /* [W, 4Hd] bf16: row n = row n of the cell kernel below the token rows, stride ldk */
+  int64_t ldk;
+  float* dfeed_all;              /* [U, B, W] fp32 */
+  float* dot_all;                /* [U, B, 4] fp32 scratch */
+  float* dhp_all;                /* [U, B, 4, Hd] fp32 scratch */
+  void* workspace;               /* las_decoder_persist_workspace_bytes(B) */
+} las_dec_persist_bwd;
+int las_decoder_persist_bwd_supported(int Hd, int M, int W, int attention, int norm);
+int las_decoder_persist_bwd(const las_dec_persist_bwd* p, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * Stochastic TRAIN-mode pieces (counter-based generator: forward and backward regenerate the same
  * draws; nothing is stored).  DropoutWrapper(input_keep_prob) of las/ops.py:14-18 and the scheduled

@@ -793,6 +793,228 @@ __global__ __launch_bounds__(256) void dec_step_bwd_kernel(las_dec_step_bwd s) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// PERSISTENT backward decoder (Luong / softmax): all U steps, last to first, in one launch.  Same grouping as the
+// forward (8 utterances per group of 32 workgroups on one XCD); the four workgroups of an utterance split its FRAMES:
+//   S1  d(context) total; dalign over own frames (their quarter of the values); partial sum p.dalign      | barrier
+//   S2  softmax backward on own frames (ds, saved as bf16 for the d(keys) GEMM); partial dh = sum ds*keys  | barrier
+//   S3  part 0: dh total (+ recurrent gradient), LSTM cell backward -> dz_t, dc_{t-1}                      | barrier
+//   G   d[attention_{t-1}, h_{t-1}] = dz_t K^T for the group's 8 utterances, member j owns the 16-column
+//       tiles j, j+32, j+64 (its rows of K register-resident as MFMA B fragments)                          | barrier
+// Every exchanged tensor has its own rows per step (no address is re-read after being rewritten).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void dec_persist_bwd_kernel(las_dec_persist_bwd p) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  constexpr int NT_MAX = 3, KCW_MAX = 8;
+  const las_dec_step_bwd& s0 = p.s;
+  const int B = s0.B, Hd = s0.Hd, M = s0.M, Tm = s0.Tm, W = p.W;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, lq = lane >> 4;
+  const int groups = (B + 7) / 8, gstride = (groups + 7) & ~7;
+  const int group = blockIdx.x % gstride, member = blockIdx.x / gstride;
+  if (group >= groups) return;
+  float* dctx = sm;                       // [M]
+  float* dal = dctx + M;                  // [Tm] dalign -> ds (own frames)
+  float* alg = dal + Tm;                  // [Tm] alignments (own frames)
+  float* dhs = alg + Tm;                  // [2048] per-phase partial dh
+  float* red = dhs + 2048;                // [16 + Hd]
+  float* red2 = red + 16 + Hd;            // [4 waves][16][49] partial output tiles of the G role
+  int* fail = reinterpret_cast<int*>(red2 + 4 * 16 * 49);
+  int* colo = fail + 1;
+  unsigned* status = reinterpret_cast<unsigned*>(p.workspace);
+  pu64* flags = reinterpret_cast<pu64*>(reinterpret_cast<char*>(p.workspace) + 64) + (size_t)group * 2 * P_MEMBERS;
+  pu64* xcc_tab = flags + P_MEMBERS;
+  if (tid == 0) { *fail = 0; *colo = 0; }
+  __syncthreads();
+  if (tid == 0) {
+    unsigned xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    xcc &= 0xf;
+    __hip_atomic_store(xcc_tab + member, ((pu64)1 << 32) | (xcc + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    bool same = true;
+    for (int m = 0; m < P_MEMBERS; ++m) {
+      pu64 v = 0;
+      unsigned spins = 0;
+      do {
+        v = __hip_atomic_load(xcc_tab + m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((v >> 32) == 1) break;
+        __builtin_amdgcn_s_sleep(2);
+      } while (++spins < P_SPIN_LIMIT);
+      same = same && ((v >> 32) == 1) && ((unsigned)v == xcc + 1);
+    }
+    *colo = same ? 1 : 0;
+  }
+  __syncthreads();
+  const bool local = *colo != 0;
+
+  // G role: rows of kc ([W, 4Hd] bf16: row n = output column n) for this member's tiles, register-resident
+  const int NTW = W / 16, KC = 4 * Hd / 32;
+  bf16x8 wf[NT_MAX][KCW_MAX];
+#pragma unroll
+  for (int j = 0; j < NT_MAX; ++j)
+#pragma unroll
+    for (int i = 0; i < KCW_MAX; ++i) {
+      const int tile = member + 32 * j, kc = wave + 4 * i;
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (tile < NTW && kc < KC) v = *reinterpret_cast<const uint4*>(p.kc + (int64_t)(tile * 16 + l15) * p.ldk + kc * 32 + 8 * lq);
+      wf[j][i] = __builtin_bit_cast(bf16x8, v);
+    }
+  const int bg = group * 8 + (l15 & 7);
+  const int b = group * 8 + member / 4, part = member & 3;
+  const bool active = b < B;
+  const int len = active ? min(s0.mem_len[b], Tm) : 0;
+  const int fq = (Tm + 3) / 4, f0 = part * fq, f1 = min(Tm, f0 + fq), flen = min(len, f1);
+  const unsigned short* vals = s0.values + (int64_t)(active ? b : 0) * Tm * M;
+  const unsigned short* keys = s0.keys + (int64_t)(active ? b : 0) * Tm * Hd;
+  unsigned epoch = 0;
+
+  for (int t = p.U - 1; t >= 0; --t) {
+    const bool first = (t == p.U - 1);
+    const float* dfeed_next = first ? nullptr : p.dfeed_all + (int64_t)(t + 1) * B * W;      // written by step t+1
+    float* dot_t = p.dot_all + ((int64_t)t * B + (active ? b : 0)) * 4;
+    float* dhp_t = p.dhp_all + ((int64_t)t * B + (active ? b : 0)) * 4 * Hd;
+    // ---- S1 ----
+    if (active) {
+      for (int m = tid; m < M; m += 256) {
+        float v = s0.dctx_a[(int64_t)b * s0.ldda + (int64_t)t * p.inc_a + m];
+        if (dfeed_next) {
+          float fb = dfeed_next[(int64_t)b * W + m];
+          if (s0.drop_keep < 1.0f) {     // gradient through step t+1's input dropout of the attention feed
+            const unsigned long long idx = ((unsigned long long)(t + 1) * B + b) * s0.feed_width + (s0.feed_width - M) + m;
+            fb = las_uniform(s0.drop_seed, s0.drop_stream, idx) < s0.drop_keep ? fb / s0.drop_keep : 0.f;
+          }
+          v += fb;
+        }
+        dctx[m] = v;
+        if (part == 0 && s0.dctx_save) s0.dctx_save[(int64_t)b * s0.ldds + (int64_t)t * p.inc_save + m] = las_f2bf(v);
+      }
+      const float* arow = s0.align + (int64_t)b * s0.lda + (int64_t)t * p.inc_align;
+      for (int tt = f0 + tid; tt < f1; tt += 256) alg[tt] = tt < len ? arow[tt] : 0.f;
+      __syncthreads();
+      {
+        const int sub = lane & 15, grp = lane >> 4;
+        for (int t0 = f0; t0 < f1; t0 += 32) {
+          const int ta = t0 + wave * 4 + grp, tb = ta + 16;
+          float acc_a = 0.f, acc_b = 0.f;
+          const bool oa = ta < flen, ob = tb < flen;
+          const unsigned short* ra = vals + (int64_t)(oa ? ta : 0) * M;
+          const unsigned short* rb = vals + (int64_t)(ob ? tb : 0) * M;
+#pragma unroll 4
+          for (int k = sub * 8; k < M; k += 128) {
+            const uint4 va = *reinterpret_cast<const uint4*>(ra + k);
+            const uint4 vb = *reinterpret_cast<const uint4*>(rb + k);
+            acc_a += dot8(va, dctx + k);
+            acc_b += dot8(vb, dctx + k);
+          }
+#pragma unroll
+          for (int o = 8; o > 0; o >>= 1) {
+            acc_a += __shfl_xor(acc_a, o, 64);
+            acc_b += __shfl_xor(acc_b, o, 64);
+          }
+          if (sub == 0) {
+            if (ta < f1) dal[ta] = oa ? acc_a : 0.f;
+            if (tb < f1) dal[tb] = ob ? acc_b : 0.f;
+          }
+        }
+      }
+      __syncthreads();
+      float dot = 0.f;
+      for (int tt = f0 + tid; tt < flen; tt += 256) dot += alg[tt] * dal[tt];
+      dot = block_reduce(dot, red, false);
+      if (tid == 0) dot_t[part] = dot;
+    }
+    if (!persist_barrier(flags, member, ++epoch, local, fail)) break;
+    // ---- S2 ----
+    if (active) {
+      const float dot = dot_t[0] + dot_t[1] + dot_t[2] + dot_t[3];
+      unsigned short* dso = s0.ds_out + (int64_t)b * s0.ldso + (int64_t)t * p.inc_ds;
+      for (int tt = f0 + tid; tt < f1; tt += 256) {
+        const float v = (tt < len) ? alg[tt] * (dal[tt] - dot) : 0.f;
+        dal[tt] = v;
+        dso[tt] = las_f2bf(v);
+      }
+      __syncthreads();
+      const int L = Hd / 8, P = 256 / L;
+      const int phase = tid / L, u = (tid % L) * 8;
+      float a[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) a[j] = 0.f;
+#pragma unroll 4
+      for (int tt = f0 + phase; tt < flen; tt += P) {
+        const uint4 v = *reinterpret_cast<const uint4*>(keys + (int64_t)tt * Hd + u);
+        const unsigned short* e = reinterpret_cast<const unsigned short*>(&v);
+        const float d = dal[tt];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) a[j] += d * las_bf2f(e[j]);
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) dhs[phase * Hd + u + j] = a[j];
+      __syncthreads();
+      for (int uu = tid; uu < Hd; uu += 256) {
+        float acc = 0.f;
+        for (int ph = 0; ph < P; ++ph) acc += dhs[ph * Hd + uu];
+        dhp_t[part * Hd + uu] = acc;
+      }
+    }
+    if (!persist_barrier(flags, member, ++epoch, local, fail)) break;
+    // ---- S3: LSTM cell backward (Appendix F), one workgroup per utterance ----
+    if (active && part == 0) {
+      for (int u = tid; u < Hd; u += 256) {
+        const float* gp = s0.gates + (int64_t)b * s0.ldg + (int64_t)t * p.inc_gates + u;
+        const float gi = gp[0], gj = gp[Hd], gf = gp[2 * Hd], go = gp[3 * Hd];
+        const float ct = s0.c_new[(int64_t)b * s0.ldcn + (int64_t)t * p.inc_c + u];
+        const float cp = s0.c_prev[(int64_t)b * s0.ldcp + (int64_t)t * p.inc_c + u];
+        float dht = dhp_t[u] + dhp_t[Hd + u] + dhp_t[2 * Hd + u] + dhp_t[3 * Hd + u];
+        if (dfeed_next) dht += dfeed_next[(int64_t)b * W + M + u];
+        const float tc = las_tanh(ct);
+        const float dov = dht * tc * go * (1.f - go);
+        const float dct = s0.dc[(int64_t)b * Hd + u] + dht * go * (1.f - tc * tc);
+        const float di = dct * gj * gi * (1.f - gi);
+        const float dj = dct * gi * (1.f - gj * gj);
+        const float df = dct * cp * gf * (1.f - gf);
+        s0.dc[(int64_t)b * Hd + u] = dct * gf;
+        unsigned short* zp = s0.dz + (int64_t)b * s0.ldz + (int64_t)t * p.inc_dz + u;
+        zp[0] = las_f2bf(di); zp[Hd] = las_f2bf(dj); zp[2 * Hd] = las_f2bf(df); zp[3 * Hd] = las_f2bf(dov);
+      }
+    }
+    if (!persist_barrier(flags, member, ++epoch, local, fail)) break;
+    // ---- G: dfeed_t[group's utterances, my column tiles] = dz_t K^T ----
+    {
+      f32x4 acc[NT_MAX];
+#pragma unroll
+      for (int j = 0; j < NT_MAX; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+      const unsigned short* zrow = s0.dz + (int64_t)min(bg, B - 1) * s0.ldz + (int64_t)t * p.inc_dz + 8 * lq;
+      uint4 av[KCW_MAX];
+#pragma unroll
+      for (int i = 0; i < KCW_MAX; ++i) {
+        const int kc = wave + 4 * i;
+        av[i] = make_uint4(0, 0, 0, 0);
+        if (kc < KC && bg < B) av[i] = *reinterpret_cast<const uint4*>(zrow + kc * 32);
+      }
+#pragma unroll
+      for (int i = 0; i < KCW_MAX; ++i)
+#pragma unroll
+        for (int j = 0; j < NT_MAX; ++j)
+          if (member + 32 * j < NTW && wave + 4 * i < KC)
+            acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, av[i]), wf[j][i], acc[j], 0, 0, 0);
+#pragma unroll
+      for (int j = 0; j < NT_MAX; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) red2[(wave * 16 + lq * 4 + r) * 49 + j * 16 + l15] = acc[j][r];
+      __syncthreads();
+      float* df = p.dfeed_all + (int64_t)t * B * W;
+      for (int e = tid; e < 8 * 48; e += 256) {
+        const int row = e / 48, c = e % 48, j = c / 16, col = c % 16;
+        const int tile = member + 32 * j, bb = group * 8 + row;
+        if (tile < NTW && bb < B)
+          df[(int64_t)bb * W + tile * 16 + col] = red2[(0 * 16 + row) * 49 + c] + red2[(1 * 16 + row) * 49 + c] +
+                                                 red2[(2 * 16 + row) * 49 + c] + red2[(3 * 16 + row) * 49 + c];
+      }
+    }
+    if (!persist_barrier(flags, member, ++epoch, local, fail)) break;
+  }
+  if (*fail && tid == 0) atomicOr(status, 16u);
+}
+
+// ------------------------------------------------------------------------------------------------
 // sequence cross-entropy (model_helper.py:24-30 -> tf.contrib.seq2seq.sequence_loss)
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void seq_ce_kernel(const float* logits, int64_t ldl, const int32_t* targets,
@@ -1004,6 +1226,33 @@ extern "C" int las_decoder_persist_fwd(const las_dec_persist* p, void* stream) {
   LAS_REQUIRE(lds <= 64 * 1024, "las_decoder_persist_fwd: memory length %d too long for the LDS score buffer", s->Tm);
   hipLaunchKernelGGL(dec_persist_fwd_kernel, dim3(((groups + 7) & ~7) * P_MEMBERS), dim3(256), lds, st, *p);
   LAS_LAUNCH_CHECK("persistent decoder fwd launch");
+  return LAS_OK;
+}
+
+extern "C" int las_decoder_persist_bwd_supported(int Hd, int M, int W, int attention, int norm) {
+  if (norm != LAS_NORM_SOFTMAX || attention != LAS_ATT_LUONG) return 0;
+  if (Hd != 128 && Hd != 256) return 0;                   // 4Hd/32 K chunks: <= 8 per wave
+  if (W % 16 != 0 || W / 16 > 96 || M % 128 != 0) return 0;   // <= 3 column tiles per member
+  return 1;
+}
+
+extern "C" int las_decoder_persist_bwd(const las_dec_persist_bwd* p, void* stream) {
+  const las_dec_step_bwd* s = &p->s;
+  LAS_REQUIRE(s->B > 0 && p->U > 0, "las_decoder_persist_bwd: bad shape");
+  LAS_REQUIRE(las_decoder_persist_bwd_supported(s->Hd, s->M, p->W, s->attention, s->norm),
+              "las_decoder_persist_bwd: configuration not supported (Hd=%d M=%d W=%d attention=%d norm=%d)", s->Hd, s->M, p->W,
+              s->attention, s->norm);
+  LAS_REQUIRE(p->kc && p->dfeed_all && p->dot_all && p->dhp_all && p->workspace && s->dctx_a && s->dc && s->dz && s->ds_out &&
+                  s->align && s->gates && s->c_new && s->c_prev && s->keys && s->values && s->mem_len,
+              "las_decoder_persist_bwd: null argument");
+  hipStream_t st = (hipStream_t)stream;
+  const int groups = (s->B + 7) / 8;
+  int rc = las_check_hip(hipMemsetAsync(p->workspace, 0, las_decoder_persist_workspace_bytes(s->B), st), "memset workspace");
+  if (rc) return rc;
+  const size_t lds = (size_t)(s->M + 2 * s->Tm + 2048 + 16 + s->Hd + 4 * 16 * 49 + 8) * sizeof(float);
+  LAS_REQUIRE(lds <= 64 * 1024, "las_decoder_persist_bwd: shapes exceed the LDS budget");
+  hipLaunchKernelGGL(dec_persist_bwd_kernel, dim3(((groups + 7) & ~7) * P_MEMBERS), dim3(256), lds, st, *p);
+  LAS_LAUNCH_CHECK("persistent decoder bwd launch");
   return LAS_OK;
 }
 

@@ -54,6 +54,8 @@ _SIGS = {
     'las_decoder_persist_supported': ([C.c_int] * 5, C.c_int),
     'las_decoder_persist_workspace_bytes': ([C.c_int], C.c_size_t),
     'las_decoder_persist_fwd': ([_vp, _vp], C.c_int),
+    'las_decoder_persist_bwd_supported': ([C.c_int] * 5, C.c_int),
+    'las_decoder_persist_bwd': ([_vp, _vp], C.c_int),
     'las_beam_step': ([_vp, _i64, _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp], C.c_int),
     'las_log_probs_loss': ([_vp, _i64, C.c_int, C.c_int, _f32, _f32, _vp, _vp, _i64, _vp], C.c_int),
     'las_normal_fill': ([_vp, _i64, C.c_uint32, C.c_uint32, _vp], C.c_int),
@@ -101,6 +103,13 @@ class DecStepBwd(C.Structure):
                 ('dh_b', _vp), ('ldhb', _i64), ('dh_c', _vp), ('ldhc', _i64),
                 ('norm', _i32), ('p', _vp), ('ldp', _i64), ('prev_align', _vp), ('ldpa', _i64), ('dalign_carry', _vp),
                 ('ldcarry', _i64), ('dbias_acc', _vp)]
+
+
+class DecPersistBwd(C.Structure):
+    """struct las_dec_persist_bwd (include/las_hip.h)."""
+    _fields_ = [('s', DecStepBwd), ('U', _i32), ('W', _i32)] + [(n, _i64) for n in (
+        'inc_a', 'inc_save', 'inc_gates', 'inc_c', 'inc_align', 'inc_dz', 'inc_ds')] + [
+        ('kc', _vp), ('ldk', _i64), ('dfeed_all', _vp), ('dot_all', _vp), ('dhp_all', _vp), ('workspace', _vp)]
 
 
 ATT_LUONG, ATT_BAHDANAU, ATT_CUSTOM, ATT_LUONG_MONOTONIC, ATT_BAHDANAU_MONOTONIC = 0, 1, 2, 3, 4

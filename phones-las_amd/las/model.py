@@ -335,7 +335,38 @@ class Speller:
             dkeys = torch.zeros(B, Tm, Hd, dtype=f32, device=dev)
             dpq_all = torch.empty(B, U, Hd, dtype=bf, device=dev)
             dv = grads[self.V_ATT]
-        for t in range(U - 1, -1, -1):
+        persist = (B <= 256 and os.environ.get('LAS_DEC_PERSIST', '1') != '0' and
+                   lib.las_decoder_persist_bwd_supported(Hd, M, W, self.att, hip.NORM_SOFTMAX) == 1)
+        if persist:
+            # all U steps in one persistent launch (las_dec_persist_bwd in las_hip.h)
+            p = hip.DecPersistBwd()
+            s = p.s
+            s.B, s.Hd, s.M, s.Tm, s.attention = B, Hd, M, Tm, self.att
+            s.dctx_a, s.ldda = hip.addr(dattn_proj), U * M
+            s.dctx_save, s.ldds = hip.addr(dctx_all), U * M
+            s.dc = hip.addr(dc)
+            s.gates, s.ldg = hip.addr(sv['gates']), U * 4 * Hd
+            s.c_new, s.ldcn = hip.addr(sv['cs'], Hd), (U + 1) * Hd
+            s.c_prev, s.ldcp = hip.addr(sv['cs']), (U + 1) * Hd
+            s.align, s.lda = hip.addr(sv['align']), U * Tmp
+            s.keys, s.values, s.mem_len = hip.addr(sv['keys']), hip.addr(sv['memory']), hip.addr(sv['mem_len'])
+            s.dz, s.ldz = hip.addr(dz_all), U * 4 * Hd
+            s.ds_out, s.ldso = hip.addr(ds_all), U * Tmp
+            s.drop_keep, s.feed_width = 1.0, V + M
+            if sv['keep'] < 1.0:
+                s.drop_keep, s.drop_seed, s.drop_stream = sv['keep'], sv['seed'], self.DEC_STREAM
+            p.U, p.W = U, W
+            p.inc_a, p.inc_save, p.inc_gates, p.inc_c, p.inc_align, p.inc_dz, p.inc_ds = M, M, 4 * Hd, Hd, Tmp, 4 * Hd, Tmp
+            p.kc, p.ldk = hip.addr(self.kc), 4 * Hd
+            dfeed_all = torch.empty(U, B, W, dtype=f32, device=dev)
+            dot_all = torch.empty(U, B, 4, dtype=f32, device=dev)
+            dhp_all = torch.empty(U, B, 4, Hd, dtype=f32, device=dev)
+            ws = torch.empty(lib.las_decoder_persist_workspace_bytes(B), dtype=torch.uint8, device=dev)
+            p.dfeed_all, p.dot_all, p.dhp_all, p.workspace = hip.addr(dfeed_all), hip.addr(dot_all), hip.addr(dhp_all), hip.addr(ws)
+            hip.check(lib.las_decoder_persist_bwd(C.byref(p), st))
+            self._persist_ws_bwd = ws
+            dfeed = dfeed_all[0]
+        for t in range(U - 1 if not persist else -1, -1, -1):
             first = (t == U - 1)
             s = hip.DecStepBwd()
             s.B, s.Hd, s.M, s.Tm, s.attention = B, Hd, M, Tm, self.att

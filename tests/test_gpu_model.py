@@ -417,8 +417,12 @@ def test_persistent_decoder_vs_per_step_and_oracle(att, monkeypatch):
         torch.cuda.synchronize()
         if flag == '1':
             assert int(model.speller._persist_ws[:4].view(torch.int32).item()) == 0      # no barrier timed out
+            if att == 'luong':
+                assert int(model.speller._persist_ws_bwd[:4].view(torch.int32).item()) == 0
         outs[flag] = (float(loss), logits.clone(), {n: g.clone() for n, g in model.vars.grads.items()})
     assert relerr(outs['1'][1], outs['0'][1].cpu()) < 1e-3
+    for name in outs['1'][2]:                      # persistent backward vs the per-step launches
+        assert relerr(outs['1'][2][name], outs['0'][2][name].cpu()) < 2e-3, name
     out = O.train_step(ohp, op, None, None, 1, batch, mxu='bf16')
     V = ohp.decoder.target_vocab_size
     for b, n in enumerate(tgt_len):
