@@ -168,6 +168,59 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
   // epilogue: C/D layout col = lane&15, row = (lane>>4)*4 + reg
   float* Cf = reinterpret_cast<float*>(g.C) + (int64_t)batch * g.sc;
   unsigned short* Cb = reinterpret_cast<unsigned short*>(g.C) + (int64_t)batch * g.sc;
+  if (!TN && !g.atomic && g.c_perm_h == 0) {
+    // Row-contiguous stores: each wave parks its (BM/2) x (BN/2) tile in LDS (the operand buffers are free now) and
+    // writes it back 16 bytes per lane, 16 lanes per row.  The products of this path are output-bound (fp32 xproj:
+    // 419 MB per layer), and four-byte stores scattered over four rows per instruction waste most of the write path.
+    constexpr int WM = BM / 2, WN = BN / 2, LDC = WN + 4;
+    __syncthreads();
+    float* cs = reinterpret_cast<float*>(smem) + wave * WM * LDC;
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+      for (int j = 0; j < FN; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) cs[(i * 16 + (lane >> 4) * 4 + r) * LDC + j * 16 + (lane & 15)] = acc[i][j][r];
+    __builtin_amdgcn_s_waitcnt(0xC07F);       // lgkmcnt(0): a wave only reads back what it wrote itself
+    constexpr int LPR = WN / 4;                // lanes per row
+    constexpr int RPI = 64 / LPR;              // rows per instruction
+    const int cl = (lane % LPR) * 4, rl = lane / LPR;
+    const int col = n0 + wc * WN + cl;
+    float bv[4] = {0.f, 0.f, 0.f, 0.f};
+    if (g.bias != nullptr && slice == 0)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) if (col + e < g.N) bv[e] = g.bias[col + e];
+#pragma unroll 4
+    for (int r0 = 0; r0 < WM; r0 += RPI) {
+      const int row = m0 + wr * WM + r0 + rl;
+      if (row >= g.M || col >= g.N) continue;
+      const float4 v4 = *reinterpret_cast<const float4*>(cs + (r0 + rl) * LDC + cl);
+      float v[4] = {v4.x + bv[0], v4.y + bv[1], v4.z + bv[2], v4.w + bv[3]};
+      const int64_t off = (int64_t)row * g.ldc + col;
+      const bool full = (col + 3 < g.N);
+      if (g.out_bf16) {
+        if (full && ((off & 3) == 0)) {
+          uint2 pk;
+          pk.x = (unsigned)las_f2bf(v[0]) | ((unsigned)las_f2bf(v[1]) << 16);
+          pk.y = (unsigned)las_f2bf(v[2]) | ((unsigned)las_f2bf(v[3]) << 16);
+          *reinterpret_cast<uint2*>(Cb + off) = pk;
+        } else {
+          for (int e = 0; e < 4; ++e) if (col + e < g.N) Cb[off + e] = las_f2bf(v[e]);
+        }
+      } else if (full && ((off & 3) == 0)) {
+        float4 o = make_float4(v[0], v[1], v[2], v[3]);
+        if (g.accumulate) {
+          const float4 c = *reinterpret_cast<const float4*>(Cf + off);
+          o.x += c.x; o.y += c.y; o.z += c.z; o.w += c.w;
+        }
+        *reinterpret_cast<float4*>(Cf + off) = o;
+      } else {
+        for (int e = 0; e < 4; ++e)
+          if (col + e < g.N) { if (g.accumulate) Cf[off + e] += v[e]; else Cf[off + e] = v[e]; }
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int i = 0; i < FM; ++i) {
 #pragma unroll
