@@ -88,6 +88,17 @@ int las_gemm_tn(const las_bf16* A, int64_t lda, const las_bf16* B, int64_t ldb, 
                 int M, int N, int K, int a_shift, int period, int c_perm_h, int batch, int64_t sa,
                 int64_t sb, int64_t sc, int split_k, void* stream);
 
+/* All weight gradients of one LSTM direction in ONE product (dz is read once instead of three times):
+ *   kernel_grad[0:D, :]   += x^T dz              (input half of the [D+H, 4H] TF kernel)
+ *   kernel_grad[D:D+H, :] += shift(y)^T dz       (recurrent half: row k of y pairs with dz row k - a_shift inside a
+ *                                                 `period` of rows, i.e. h_{t-1} of the direction's own time order)
+ *   bias_grad[:]          += column sums of dz
+ * x [K, D] bf16 (row stride ldx), y [K, H] bf16 (ldy), dz [K, 4H] bf16 with GATE-INTERLEAVED columns (ldz); outputs
+ * fp32 in TF column order (g*H+u), accumulated with atomics (split_k slices of K). */
+int las_gemm_tn_lstm(const las_bf16* x, int64_t ldx, int D, const las_bf16* y, int64_t ldy, int H, int a_shift,
+                     int period, const las_bf16* dz, int64_t ldz, float* kernel_grad, float* bias_grad, int K,
+                     int split_k, void* stream);
+
 /* dst_bf16[r, c] = src_f32[r, c] (transpose = 0) or dst[c, r] = src[r, c] (transpose = 1), with the
  * destination window [dst_rows, dst_cols] (row stride ldd) zero-padded.  `batch` windows at element
  * strides src_bstride / dst_bstride.  src_col_perm_h = H > 0 reads the source's columns through the

@@ -26,6 +26,13 @@ struct GemmArgs {
   int out_bf16, accumulate, atomic, split_k;
   int a_shift, period;
   int c_perm_h;   // > 0: output column n (gate-interleaved index u*4+g) is stored at TF column g*H+u, H = c_perm_h
+  // fused LSTM weight gradient (gemm_tn_tr_kernel only): rows [0,M1) of the A^T side come from A (no shift), rows
+  // [M1, M1+M2) from A2 (shifted by a_shift inside `period`), row M1+M2 is all ones when bias_row != nullptr (its
+  // output row, the column sums of B, goes to bias_row).  M = M1 + M2 (+1).
+  const unsigned short* A2 = nullptr;
+  int64_t lda2 = 0;
+  int M1 = -1, M2 = 0;
+  float* bias_row = nullptr;
 };
 
 template <int BM, int BN, bool TN>
@@ -298,13 +305,23 @@ __global__ __launch_bounds__(256) void gemm_tn_tr_kernel(GemmArgs g) {
       {
         const int m = m0 + ch * 8;
         int k = k0 + kr;
-        bool ok = (k < g.K) && (m < g.M);
-        if (g.period > 0) {
-          const int t = k % g.period + g.a_shift;
-          ok = ok && (t >= 0) && (t < g.period);
-          k += g.a_shift;
+        if (g.M1 >= 0) {              // fused LSTM weight gradient: [x | y shifted | ones]
+          if (k < g.K) {
+            if (m < g.M1) va = *reinterpret_cast<const uint4*>(A + (int64_t)k * g.lda + m);
+            else if (m < g.M1 + g.M2) {
+              const int t = k % g.period + g.a_shift;
+              if (t >= 0 && t < g.period) va = *reinterpret_cast<const uint4*>(g.A2 + (int64_t)(k + g.a_shift) * g.lda2 + (m - g.M1));
+            } else if (m == g.M1 + g.M2 && g.bias_row) va.x = 0x3F80u;      // bf16 1.0 in the first of the eight rows
+          }
+        } else {
+          bool ok = (k < g.K) && (m < g.M);
+          if (g.period > 0) {
+            const int t = k % g.period + g.a_shift;
+            ok = ok && (t >= 0) && (t < g.period);
+            k += g.a_shift;
+          }
+          if (ok) va = *reinterpret_cast<const uint4*>(A + (int64_t)k * g.lda + m);
         }
-        if (ok) va = *reinterpret_cast<const uint4*>(A + (int64_t)k * g.lda + m);
       }
       {
         const int n = n0 + ch * 8, k = k0 + kr;
@@ -376,6 +393,7 @@ __global__ __launch_bounds__(256) void gemm_tn_tr_kernel(GemmArgs g) {
       for (int r = 0; r < 4; ++r) {
         const int row = m0 + wr * 64 + i * 16 + (lane >> 4) * 4 + r;
         if (row >= g.M) continue;
+        if (g.bias_row && row == g.M - 1) { atomicAdd(g.bias_row + col, acc[i][j][r]); continue; }
         const int64_t off = (int64_t)row * g.ldc + col;
         if (g.atomic) atomicAdd(Cf + off, acc[i][j][r]);
         else Cf[off] += acc[i][j][r];
@@ -513,4 +531,30 @@ extern "C" int las_gemm_tn(const las_bf16* A, int64_t lda, const las_bf16* B, in
     LAS_LAUNCH_CHECK("gemm tn launch");
     return LAS_OK;
   }
+}
+
+extern "C" int las_gemm_tn_lstm(const las_bf16* x, int64_t ldx, int D, const las_bf16* y, int64_t ldy, int H, int a_shift,
+                                int period, const las_bf16* dz, int64_t ldz, float* kernel_grad, float* bias_grad, int K,
+                                int split_k, void* stream) {
+  LAS_REQUIRE(D >= 0 && H > 0 && K > 0 && period > 0 && D % 8 == 0 && H % 8 == 0, "las_gemm_tn_lstm: bad shape D=%d H=%d K=%d", D, H, K);
+  LAS_REQUIRE((D == 0 || (x && ldx % 8 == 0 && ((uintptr_t)x % 16 == 0))) && y && dz && kernel_grad && bias_grad && ldy % 8 == 0 &&
+                  ldz % 8 == 0 && ((uintptr_t)y % 16 == 0) && ((uintptr_t)dz % 16 == 0),
+              "las_gemm_tn_lstm: operands must be 16-byte aligned with strides that are multiples of 8");
+  if (split_k < 1) split_k = 1;
+  GemmArgs g{x, dz, kernel_grad, nullptr, ldx, ldz, 4 * (int64_t)H, 0, 0, 0, D + H + 1, 4 * H, K, 0, 1, 1, split_k, a_shift, period, H};
+  g.A2 = y;
+  g.lda2 = ldy;
+  g.M1 = D;
+  g.M2 = H;
+  g.bias_row = bias_grad;
+  dim3 grid((g.N + 127) / 128, (g.M + 127) / 128, split_k);
+  const size_t lds = (size_t)4 * BK * 256;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_tr_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(gemm_tn_tr_kernel, grid, dim3(256), lds, (hipStream_t)stream, g);
+  LAS_LAUNCH_CHECK("lstm weight-gradient gemm launch");
+  return LAS_OK;
 }

@@ -244,9 +244,15 @@ def bilstm_backward(rec, dy, d_state, grads, need_dx=True, overlap=None):
             gk, gb = grads[kn], grads[bn]
             dzi = dz.view(BT, nd * 4 * H)[:, i * 4 * H:]
             xa, lda = (dropped[i] if dropped is not None else (x, Dp))
+            yi = y.view(BT, nd * H)[:, i * H:]
+            if D % 8 == 0:
+                # dK_x, dK_h and db of this direction in one product (dz read once)
+                hip.check(hip.lib().las_gemm_tn_lstm(hip.p(xa) if D > 0 else None, lda, D, hip.p(yi), nd * H, H,
+                                                     (-1 if i == 0 else 1), T, hip.p(dzi), nd * 4 * H, hip.p(gk), hip.p(gb),
+                                                     BT, split, hip.stream()))
+                continue
             if D > 0:
                 hip.gemm_tn(xa, dzi, gk, D, 4 * H, BT, lda=lda, ldb=nd * 4 * H, ldc=4 * H, split_k=split, c_perm_h=H)
-            yi = y.view(BT, nd * H)[:, i * H:]
             hip.gemm_tn(yi, dzi, gk[D:], H, 4 * H, BT, lda=nd * H, ldb=nd * 4 * H, ldc=4 * H,
                         a_shift=(-1 if i == 0 else 1), period=T, split_k=split, c_perm_h=H)
             hip.colsum_bf16(dzi, BT, 4 * H, gb, ldx=nd * 4 * H, perm_h=H)

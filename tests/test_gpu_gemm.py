@@ -135,3 +135,31 @@ def test_bad_arguments_raise():
         hip.gemm_nt(A, A, C, 8, 8, 12)          # K not a multiple of 8
     with pytest.raises(hip.LasError):
         hip.gemm_nt(A.cpu(), A, C, 8, 8, 8)     # CPU tensor: no fallback
+
+
+@pytest.mark.parametrize('D,H,B,T,shift', [(40, 64, 3, 20, -1), (128, 64, 2, 37, 1), (0, 128, 2, 16, -1)])
+def test_gemm_tn_lstm_fused_weight_gradients(D, H, B, T, shift):
+    """las_gemm_tn_lstm: dK_x, dK_h (row-shifted h) and db of one LSTM direction in one product, against float64.
+    dz arrives with gate-interleaved columns (u*4+g); outputs are in TF column order (g*H+u)."""
+    from phones_las_amd import hip
+    K = B * T
+    Dp = max(D, 8)
+    x, y, dz = _mk((K, Dp), 3), _mk((K, 2 * H), 4), _mk((K, 8 * H), 5)      # y / dz hold two directions side by side
+    yi, dzi = y[:, H:], dz[:, 4 * H:]                                         # the second direction's columns
+    # reference in TF column order
+    dz_tf = dzi.double().view(K, H, 4).permute(0, 2, 1).reshape(K, 4 * H)
+    ysh = torch.zeros(K, H, dtype=torch.float64)
+    for k in range(K):
+        t = k % T + shift
+        if 0 <= t < T:
+            ysh[k] = yi[k + shift].double()
+    ref_k = torch.cat([x[:, :D].double().t() @ dz_tf, ysh.t() @ dz_tf], 0)
+    ref_b = dz_tf.sum(0)
+    gk = torch.zeros(D + H, 4 * H, device='cuda')
+    gb = torch.zeros(4 * H, device='cuda')
+    xd, yd, dzd = x.cuda(), y.cuda(), dz.cuda()
+    hip.check(hip.lib().las_gemm_tn_lstm(hip.p(xd) if D else None, Dp, D, hip.addr(yd, H), 2 * H, H, shift, T,
+                                         hip.addr(dzd, 4 * H), 8 * H, hip.p(gk), hip.p(gb), K, 3, hip.stream()))
+    torch.cuda.synchronize()
+    _close(gk, ref_k)
+    _close(gb, ref_b)
