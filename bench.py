@@ -28,6 +28,9 @@ CONFIGS = {
     'metric-M': dict(F=40, L=3, H=256, Hd=256, V=64, att='luong', T=800, U=80, B=64),
     'metric-L': dict(F=40, L=4, H=512, Hd=512, V=64, att='bahdanau', T=800, U=80, B=64),
     'tiny': dict(F=40, L=2, H=64, Hd=64, V=64, att='luong', T=64, U=8, B=16),
+    # the same model at the reference's default stochastic settings (train.py:48,71); scheduled sampling
+    # keeps the decoder on the per-step path (the next input depends on this step's logits)
+    'metric-M-stochastic': dict(F=40, L=3, H=256, Hd=256, V=64, att='luong', T=800, U=80, B=64, dropout=0.2, sampling=0.1),
 }
 
 
@@ -50,8 +53,8 @@ def build_params(c, lr=1e-3, l2=1e-6):
     hp = pu.get_default_hparams()
     for k, v in dict(num_channels=c['F'], encoder_layers=c['L'], encoder_units=c['H'], use_pyramidal=True,
                      unidirectional=False, decoder_layers=1, decoder_units=c['Hd'], target_vocab_size=c['V'],
-                     attention_type=c['att'], bottom_only=True, pass_hidden_state=True, dropout=0.0,
-                     sampling_probability=0.0, learning_rate=lr, l2_reg_scale=l2).items():
+                     attention_type=c['att'], bottom_only=True, pass_hidden_state=True, dropout=c.get('dropout', 0.0),
+                     sampling_probability=c.get('sampling', 0.0), learning_rate=lr, l2_reg_scale=l2).items():
         hp.set_hparam(k, v)
     return pu.get_encoder_decoder_hparams(hp)
 
