@@ -172,6 +172,18 @@ __global__ __launch_bounds__(256) void lstm_fwd_kernel(float* __restrict__ xproj
     // itself on the epoch tags of the compute workgroup's own granules and leaves when the done word is set.
     constexpr int PF_AHEAD = 6;
     const int mylen = (slice * 16 + l15 < B) ? min(length[slice * 16 + l15], T) : 0;
+    // rows t >= length of the outputs are zero (dynamic_rnn): the companion clears this member's columns of them, so a
+    // dense batch needs no memset of y at all (the compute workgroups write every row they own)
+    for (int rr = wave * 4; rr < wave * 4 + 4; ++rr) {
+      const int bb = slice * 16 + rr;
+      if (bb >= B) continue;
+      const int ll = __builtin_amdgcn_readlane(mylen, rr);
+      constexpr int LPR = HS * 2 / 16;                            // 16-byte pieces of the member's span in a row
+      for (int e = ll * LPR + lane; e < T * LPR; e += 64) {
+        const int t = e / LPR, c = e % LPR;
+        *reinterpret_cast<uint4*>(y + ((int64_t)bb * T + t) * yrow + dir * H + member * HS + c * 8) = make_uint4(0, 0, 0, 0);
+      }
+    }
     const u64* tag0 = ex_group + (int64_t)member * NGRAN;
     int seen = -1;
     for (int sp = 0; sp < smax; ++sp) {
@@ -496,6 +508,17 @@ __global__ __launch_bounds__(256) void lstm_bwd_kernel(const float* __restrict__
     // PREFETCH COMPANION (see lstm_fwd_kernel): gates, c and dy lines of the compute workgroup, PF_AHEAD steps ahead.
     constexpr int PF_AHEAD = 6;
     const int mylen = (slice * 16 + l15 < B) ? min(length[slice * 16 + l15], T) : 0;
+    // dz rows t >= length are zero: cleared here (this member's gate columns), so dense batches need no memset of dz
+    for (int rr = wave * 4; rr < wave * 4 + 4; ++rr) {
+      const int bb = slice * 16 + rr;
+      if (bb >= B) continue;
+      const int ll = __builtin_amdgcn_readlane(mylen, rr);
+      constexpr int LPR = 4 * HS * 2 / 16;
+      for (int e = ll * LPR + lane; e < T * LPR; e += 64) {
+        const int t = e / LPR, c = e % LPR;
+        *reinterpret_cast<uint4*>(dz + ((int64_t)bb * T + t) * grow + dir * 4 * H + member * 4 * HS + c * 8) = make_uint4(0, 0, 0, 0);
+      }
+    }
     const int watch_dest = member == 0 ? 1 : 0;                 // any slot the compute workgroup writes every step
     const u64* tag0 = ex_group + (int64_t)(watch_dest * G + member) * PAIR;
     int seen = -1;
@@ -857,8 +880,11 @@ extern "C" int las_lstm_recurrent_fwd(float* xproj, const las_bf16* wpacked, con
   LAS_REQUIRE(supported_units(H), "las_lstm_recurrent_fwd: num_units %d not in {64,128,256,512}", H);
   LAS_REQUIRE(workspace != nullptr && ((uintptr_t)workspace % 16 == 0), "las_lstm_recurrent_fwd: workspace missing or misaligned");
   hipStream_t st = (hipStream_t)stream;
-  int rc = las_check_hip(hipMemsetAsync(y, 0, (size_t)B * T * ndir * H * sizeof(las_bf16), st), "memset y");
-  if (rc) return rc;
+  int rc = 0;
+  if (!(coop_members(H) > 1 && prefetch_mode())) {       // otherwise the companions clear the rows beyond each length
+    rc = las_check_hip(hipMemsetAsync(y, 0, (size_t)B * T * ndir * H * sizeof(las_bf16), st), "memset y");
+    if (rc) return rc;
+  }
   rc = las_check_hip(hipMemsetAsync(workspace, 0, 64 + geom(B, H, ndir, false).exch_bytes, st), "memset workspace");
   if (rc) return rc;
   switch (H) {
@@ -876,8 +902,11 @@ extern "C" int las_lstm_recurrent_bwd(const float* gates, const float* cbuf, con
   LAS_REQUIRE(supported_units(H), "las_lstm_recurrent_bwd: num_units %d not in {64,128,256,512}", H);
   LAS_REQUIRE(workspace != nullptr && ((uintptr_t)workspace % 16 == 0), "las_lstm_recurrent_bwd: workspace missing or misaligned");
   hipStream_t st = (hipStream_t)stream;
-  int rc = las_check_hip(hipMemsetAsync(dz, 0, (size_t)B * T * ndir * 4 * H * sizeof(las_bf16), st), "memset dz");
-  if (rc) return rc;
+  int rc = 0;
+  if (!(coop_members(H) > 1 && prefetch_mode())) {
+    rc = las_check_hip(hipMemsetAsync(dz, 0, (size_t)B * T * ndir * 4 * H * sizeof(las_bf16), st), "memset dz");
+    if (rc) return rc;
+  }
   rc = las_check_hip(hipMemsetAsync(workspace, 0, 64 + geom(B, H, ndir, true).exch_bytes, st), "memset workspace");
   if (rc) return rc;
   switch (H) {
