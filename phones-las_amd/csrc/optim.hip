@@ -23,31 +23,38 @@ __global__ __launch_bounds__(256) void l2_norm_kernel(float* g, const float* p, 
                                                       float l2, float* sumsq) {
   __shared__ float red[4];
   for (int64_t base = (int64_t)blockIdx.x * CHUNK; base < total; base += (int64_t)gridDim.x * CHUNK) {
-    // a chunk may straddle tensor boundaries: accumulate per run of equal segment
-    int seg = -1;
-    float acc = 0.f;
-    for (int64_t i = base + threadIdx.x; i < min(total, base + CHUNK); i += 256) {
-      const int sgi = find_seg(off, nseg, i);
-      const float v = g[i] + l2 * p[i];
-      g[i] = v;
-      if (sgi != seg) {
-        if (seg >= 0) atomicAdd(sumsq + seg, acc);
-        seg = sgi;
-        acc = 0.f;
-      }
-      acc += v * v;
-    }
-    // most chunks lie inside one tensor: reduce across the workgroup when every thread agrees
+    const int64_t end = min(total, base + CHUNK);
     const int seg0 = find_seg(off, nseg, base);
-    const int seg1 = find_seg(off, nseg, min(total, base + CHUNK) - 1);
+    const int seg1 = find_seg(off, nseg, end - 1);
     if (seg0 == seg1) {
-      float v = las_wave_sum(seg >= 0 ? acc : 0.f);
+      // the common case: the whole chunk lies inside one tensor (no per-element search)
+      float acc = 0.f;
+      for (int64_t i = base + threadIdx.x; i < end; i += 256) {
+        const float v = g[i] + l2 * p[i];
+        g[i] = v;
+        acc += v * v;
+      }
+      const float v = las_wave_sum(acc);
       __syncthreads();
       if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
       __syncthreads();
       if (threadIdx.x == 0) atomicAdd(sumsq + seg0, red[0] + red[1] + red[2] + red[3]);
-    } else if (seg >= 0) {
-      atomicAdd(sumsq + seg, acc);
+    } else {
+      // the chunk straddles tensor boundaries: accumulate per run of equal segment
+      int seg = -1;
+      float acc = 0.f;
+      for (int64_t i = base + threadIdx.x; i < end; i += 256) {
+        const int sgi = find_seg(off, nseg, i);
+        const float v = g[i] + l2 * p[i];
+        g[i] = v;
+        if (sgi != seg) {
+          if (seg >= 0) atomicAdd(sumsq + seg, acc);
+          seg = sgi;
+          acc = 0.f;
+        }
+        acc += v * v;
+      }
+      if (seg >= 0) atomicAdd(sumsq + seg, acc);
     }
   }
 }
