@@ -851,7 +851,16 @@ int launch_bwd(const float* gates, const float* cbuf, const float* dy, const flo
   unsigned* status = reinterpret_cast<unsigned*>(ws);
   u64* exch = reinterpret_cast<u64*>(reinterpret_cast<char*>(ws) + 64);
   const int pf = g.G > 1 ? prefetch_mode() : 0;
-  hipLaunchKernelGGL((lstm_bwd_kernel<H>), dim3(pf ? 2 * g.blocks : g.blocks), dim3(256), 0, st, gates, cbuf, dy, dc_last, dh_last, kh,
+  // The weight-gradient GEMMs of the layer above run beside this kernel on the second stream.  Asking for LDS the
+  // kernel does not use keeps their workgroups (64 KiB of LDS each) off the CUs of the chain's workgroups.
+  static int hog_kb = -1;
+  if (hog_kb < 0) {
+    const char* e = getenv("LAS_LSTM_BWD_LDS_KB");
+    hog_kb = e ? atoi(e) : 120;
+    if (hog_kb > 0)
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&lstm_bwd_kernel<H>), hipFuncAttributeMaxDynamicSharedMemorySize, hog_kb * 1024);
+  }
+  hipLaunchKernelGGL((lstm_bwd_kernel<H>), dim3(pf ? 2 * g.blocks : g.blocks), dim3(256), (size_t)hog_kb * 1024, st, gates, cbuf, dy, dc_last, dh_last, kh,
                      length, dz, exch, status, B, T, ndir, g.ngroups);
   LAS_LAUNCH_CHECK("lstm bwd launch");
   return LAS_OK;
