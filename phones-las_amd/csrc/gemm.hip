@@ -45,8 +45,21 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
   const int lane = tid & 63;
   const int wave = tid >> 6;
   const int wr = wave >> 1, wc = wave & 1;
-  const int m0 = blockIdx.y * BM;
-  const int n0 = blockIdx.x * BN;
+  // XCD-aware tile order: workgroups are dealt round-robin to the 8 XCDs (non-coherent L2s), so the N tiles that share
+  // one block of A rows should be 8 linear ids apart: id = x + gx*y  ->  row block (id / (8 gx))*8 + id % 8, column
+  // tile (id / 8) % gx.  Each XCD then fetches an A block once instead of every XCD fetching every A block.
+  int bx = blockIdx.x, by = blockIdx.y;
+  {
+    const int gx = gridDim.x, gy = gridDim.y;
+    const int id = bx + gx * by;
+    const int full = (gy / 8) * 8 * gx;            // ids covered by complete groups of 8 row blocks
+    if (id < full) {
+      by = (id / (8 * gx)) * 8 + (id & 7);
+      bx = (id >> 3) % gx;
+    }
+  }
+  const int m0 = by * BM;
+  const int n0 = bx * BN;
   const int batch = blockIdx.z / g.split_k;
   const int slice = blockIdx.z % g.split_k;
 
