@@ -430,3 +430,31 @@ def test_persistent_decoder_vs_per_step_and_oracle(att, monkeypatch):
     for name, _, _ in model.vars.table:
         g = out['grads'][name] - ohp.l2_reg_scale * op[name]
         assert relerr(outs['1'][2][name], g) < 6e-2, name
+
+
+@pytest.mark.parametrize('B,T,U,src_len,tgt_len', [
+    (1, 8, 1, [8], [1]),                                   # one utterance, one decoder step
+    (2, 8, 3, [2, 8], [3, 1]),                             # memory shorter than the four frame shares
+    (9, 20, 4, [20, 1, 7, 13, 20, 4, 9, 16, 3], [4, 1, 2, 3, 4, 4, 1, 2, 3]),     # two groups, the second with one utterance
+    (17, 12, 2, [12] * 17, [2] * 17),                      # three groups
+], ids=['b1_u1', 'short_memory', 'two_groups', 'three_groups'])
+def test_persistent_decoder_edge_shapes_match_per_step_path(B, T, U, src_len, tgt_len, monkeypatch):
+    """Edge shapes of the one-launch decoder (partial groups, empty frame shares, a single step) against the per-step
+    launches: logits and every gradient agree to fp32 summation-order noise."""
+    O, ohp, op, model = _models('luong', H=128, F=13, L=2)
+    batch = make_batch(B=B, T=T, U=U, src_len=src_len, tgt_len=tgt_len)
+    feats, labels = to_device(batch)
+    outs = {}
+    for flag in ('1', '0'):
+        monkeypatch.setenv('LAS_DEC_PERSIST', flag)
+        model.vars.grad.zero_()
+        loss, logits, dlogits = model.forward_train(feats, labels)
+        model.backward(dlogits)
+        torch.cuda.synchronize()
+        if flag == '1':
+            assert int(model.speller._persist_ws[:4].view(torch.int32).item()) == 0
+            assert int(model.speller._persist_ws_bwd[:4].view(torch.int32).item()) == 0
+        outs[flag] = (logits.clone(), {n: g.clone() for n, g in model.vars.grads.items()})
+    assert relerr(outs['1'][0], outs['0'][0].cpu()) < 1e-3
+    for name in outs['1'][1]:
+        assert relerr(outs['1'][1][name], outs['0'][1][name].cpu()) < 3e-3, name
