@@ -28,8 +28,7 @@ CONFIGS = {
     'metric-M': dict(F=40, L=3, H=256, Hd=256, V=64, att='luong', T=800, U=80, B=64),
     'metric-L': dict(F=40, L=4, H=512, Hd=512, V=64, att='bahdanau', T=800, U=80, B=64),
     'tiny': dict(F=40, L=2, H=64, Hd=64, V=64, att='luong', T=64, U=8, B=16),
-    # the same model at the reference's default stochastic settings (train.py:48,71); scheduled sampling
-    # keeps the decoder on the per-step path (the next input depends on this step's logits)
+    # the same model at the reference's default stochastic settings (train.py:48,71)
     'metric-M-stochastic': dict(F=40, L=3, H=256, Hd=256, V=64, att='luong', T=800, U=80, B=64, dropout=0.2, sampling=0.1),
 }
 

@@ -236,6 +236,21 @@ typedef struct las_dec_persist {
   float* sc_all;                 /* [U, B, ld_sc] fp32 scratch: raw attention scores (the parts of an utterance split the frames) */
   int64_t ld_sc;                 /* >= Tm */
   void* workspace;
+  /* scheduled sampling (utils/training_helper.py:48-87), sampling_prob > 0: after step t the kernel forms
+   * logits_t = context_t W_proj + b, stores them (logits + b*ld_logits + t*Vp) and writes the token fed at step t+1 into
+   * the tok_ids row (s.tok_ids[b*tok_stride + t+1]): a draw from Categorical(logits_t) with probability sampling_prob,
+   * else teacher[b*teacher_stride + t+1].  Same generator streams as las_sample_tokens(step = t). */
+  float sampling_prob;
+  uint32_t seed;
+  const int32_t* teacher;
+  int64_t teacher_stride;
+  const las_bf16* wprojT;        /* [V, M] bf16, row stride ldw */
+  int64_t ldw;
+  const float* bproj;            /* [Vp] */
+  float* logits;                 /* fp32, utterance stride ld_logits, Vp per step */
+  int64_t ld_logits;
+  float* plog;                   /* [U, B, 4, Vp] fp32 scratch */
+  int32_t V, Vp;
 } las_dec_persist;
 int las_decoder_persist_supported(int Hd, int M, int K_in, int attention, int norm);   /* 1 if the shapes fit */
 size_t las_decoder_persist_workspace_bytes(int B);

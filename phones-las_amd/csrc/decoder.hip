@@ -103,7 +103,11 @@ __device__ void dec_step_fwd_body(const las_dec_step& s, const int b, const int 
     for (int u = tid; u < Hd; u += 256) hq[u] = las_bf2f(s.query[(int64_t)b * s.ldq + u]);
   } else {
   // ---- LSTM cell (Appendix A.1) ----
-  const int tok = s.tok_rows ? s.tok_ids[(int64_t)b * s.tok_stride] : 0;
+  // (persistent decoder with scheduled sampling: the id was written by another workgroup during this launch and shares
+  // a cache line with ids read earlier: bypass L1)
+  const int tok = !s.tok_rows ? 0
+                  : (ph ? __hip_atomic_load(s.tok_ids + (int64_t)b * s.tok_stride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                        : s.tok_ids[(int64_t)b * s.tok_stride]);
   // DropoutWrapper on the cell input: the one-hot feed keeps/loses its single non-zero entry
   float tok_scale = 1.0f;
   if (s.drop_keep < 1.0f)
@@ -512,6 +516,67 @@ __global__ __launch_bounds__(256) void dec_persist_fwd_kernel(las_dec_persist p)
       if (*fail) break;
     } else {
       if (!persist_barrier(flags, member, ++epoch, local, fail)) break;     // the score exchange of the busy members
+    }
+    if (p.sampling_prob > 0.f) {
+      // ---- scheduled sampling (utils/training_helper.py:48-87): logits_t = context_t W_proj + b from the four parts'
+      //      partial products, then the next fed token = Categorical(logits_t) with probability p, else the teacher's ----
+      const int V = p.V, Vp = p.Vp;
+      float* plog_t = p.plog + ((int64_t)t * B + (bs < B ? bs : 0)) * 4 * Vp;
+      if (bs < B) {
+        const int cols = M / 4, c0 = part * cols;
+        float* cx = sm;                                   // [cols] my context columns as floats
+        __builtin_amdgcn_s_waitcnt(0x0070);               // my context stores are done
+        __syncthreads();
+        const unsigned short* crow = s0.ctx_out + (int64_t)bs * s0.ldc + (int64_t)t * p.inc_ctx + c0;
+        for (int c = tid; c < cols; c += 256)
+          cx[c] = las_bf2f(__builtin_bit_cast(unsigned short, (unsigned short)__hip_atomic_load(
+                      reinterpret_cast<const unsigned short*>(crow) + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)));
+        __syncthreads();
+        for (int v = tid; v < Vp; v += 256) {
+          float acc = 0.f;
+          if (v < V) {
+            const unsigned short* wrow = p.wprojT + (int64_t)v * p.ldw + c0;
+            for (int c = 0; c < cols; c += 8) {
+              const uint4 w = *reinterpret_cast<const uint4*>(wrow + c);
+              acc += dot8(w, cx + c);
+            }
+          }
+          plog_t[part * Vp + v] = acc;
+        }
+      }
+      if (!persist_barrier(flags, member, ++epoch, local, fail)) break;
+      if (bs < B && part == 0) {
+        float* lrow = p.logits + (int64_t)bs * p.ld_logits + (int64_t)t * Vp;
+        float* lg = sm;                                   // [Vp]
+        for (int v = tid; v < Vp; v += 256) {
+          const float x = v < V ? plog_t[v] + plog_t[Vp + v] + plog_t[2 * Vp + v] + plog_t[3 * Vp + v] + p.bproj[v] : p.bproj[v];
+          lg[v] = x;
+          lrow[v] = x;
+        }
+        __syncthreads();
+        if (t + 1 < p.U && tid < 64) {
+          const unsigned long long sidx = (unsigned long long)t * B + bs;
+          const bool select = las_uniform(p.seed, 0x5e1ec7u, sidx) < p.sampling_prob;
+          int out = p.teacher[(int64_t)bs * p.teacher_stride + t + 1];
+          if (select) {
+            float best = -INFINITY;
+            int arg = 0;
+            for (int v = lane; v < V; v += 64) {
+              const float u = fmaxf(las_uniform(p.seed, 0x9a3b1eu, sidx * V + v), 1e-12f);
+              const float gmb = lg[v] - __logf(-__logf(u));
+              if (gmb > best) { best = gmb; arg = v; }
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+              const float ob = __shfl_xor(best, o, 64);
+              const int oa = __shfl_xor(arg, o, 64);
+              if (ob > best || (ob == best && oa < arg)) { best = ob; arg = oa; }
+            }
+            out = arg;
+          }
+          if (lane == 0) const_cast<int32_t*>(s0.tok_ids)[(int64_t)bs * s0.tok_stride + t + 1] = out;
+        }
+      }
     }
     if (!persist_barrier(flags, member, ++epoch, local, fail)) break;
   }
@@ -1218,6 +1283,9 @@ extern "C" int las_decoder_persist_fwd(const las_dec_persist* p, void* stream) {
               "las_decoder_persist_fwd: configuration not supported (Hd=%d M=%d K_in=%d attention=%d norm=%d)", s->Hd, s->M, p->K_in,
               s->attention, s->norm);
   LAS_REQUIRE(p->x && p->kT && p->z_all && p->sc_all && p->workspace && p->ld_sc >= s->Tm, "las_decoder_persist_fwd: null argument");
+  LAS_REQUIRE(p->sampling_prob <= 0.f || (p->wprojT && p->bproj && p->logits && p->plog && p->teacher && p->V > 0 && p->Vp >= p->V &&
+                                          p->Vp <= 1024 && s->M % 32 == 0 && p->inc_tok == 1),
+              "las_decoder_persist_fwd: scheduled sampling needs wprojT, bproj, logits, plog, teacher (and fed ids with unit step)");
   hipStream_t st = (hipStream_t)stream;
   const int groups = (s->B + 7) / 8;
   int rc = las_check_hip(hipMemsetAsync(p->workspace, 0, las_decoder_persist_workspace_bytes(s->B), st), "memset workspace");

@@ -88,7 +88,9 @@ class DecPersist(C.Structure):
     """struct las_dec_persist (include/las_hip.h)."""
     _fields_ = [('s', DecStep), ('U', _i32), ('K_in', _i32)] + [(n, _i64) for n in (
         'inc_tok', 'inc_cprev', 'inc_gates', 'inc_cout', 'inc_h', 'inc_h2', 'inc_align', 'inc_pq', 'inc_ctx', 'inc_ctx2')] + [
-        ('x', _vp), ('ldx', _i64), ('inc_x', _i64), ('kT', _vp), ('ldk', _i64), ('z_all', _vp), ('sc_all', _vp), ('ld_sc', _i64), ('workspace', _vp)]
+        ('x', _vp), ('ldx', _i64), ('inc_x', _i64), ('kT', _vp), ('ldk', _i64), ('z_all', _vp), ('sc_all', _vp), ('ld_sc', _i64), ('workspace', _vp),
+        ('sampling_prob', _f32), ('seed', C.c_uint32), ('teacher', _vp), ('teacher_stride', _i64), ('wprojT', _vp), ('ldw', _i64),
+        ('bproj', _vp), ('logits', _vp), ('ld_logits', _i64), ('plog', _vp), ('V', _i32), ('Vp', _i32)]
 
 
 class DecStepBwd(C.Structure):

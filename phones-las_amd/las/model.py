@@ -260,7 +260,7 @@ class Speller:
             fed = tin[:, :U].contiguous().clone()
             logits = torch.empty(B, U, Vp, dtype=f32, device=dev)
         ts = fed.stride(0)
-        persist = (sampling == 0.0 and B <= 256 and os.environ.get('LAS_DEC_PERSIST', '1') != '0' and      # B: co-residency
+        persist = (B <= 256 and Vp <= 1024 and os.environ.get('LAS_DEC_PERSIST', '1') != '0' and      # B: co-residency
                    lib.las_decoder_persist_supported(Hd, M, W, self.att, hip.NORM_SOFTMAX) == 1)
         if persist:
             # all U steps in one persistent launch (keys/values stay L2-resident; see las_dec_persist in las_hip.h)
@@ -282,6 +282,12 @@ class Speller:
             ws = torch.empty(lib.las_decoder_persist_workspace_bytes(B), dtype=torch.uint8, device=dev)
             sc_all = torch.empty(U, B, Tmp, dtype=f32, device=dev)
             p.z_all, p.sc_all, p.ld_sc, p.workspace = hip.addr(z_all), hip.addr(sc_all), Tmp, hip.addr(ws)
+            if sampling > 0.0:           # logits and the sampled feed are produced inside the launch
+                plog = torch.empty(U, B, 4, Vp, dtype=f32, device=dev)
+                p.sampling_prob, p.seed = sampling, seed
+                p.teacher, p.teacher_stride = hip.addr(tin), tin.stride(0)
+                p.wprojT, p.ldw, p.bproj = hip.addr(self.wprojT), M, hip.addr(self.bproj)
+                p.logits, p.ld_logits, p.plog, p.V, p.Vp = hip.addr(logits), U * Vp, hip.addr(plog), V, Vp
             hip.check(lib.las_decoder_persist_fwd(C.byref(p), st))
             self._persist_ws = ws
         for t in range(0 if not persist else U, U):

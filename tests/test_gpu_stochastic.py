@@ -12,11 +12,11 @@ pytestmark = pytest.mark.gpu
 DT = torch.float64
 
 
-def _build(dropout=0.0, sampling=0.0, att='luong', dec_layers=1, bottom_only=True, pass_hidden=True, emb=0):
+def _build(dropout=0.0, sampling=0.0, att='luong', dec_layers=1, bottom_only=True, pass_hidden=True, emb=0, H=64):
     from oracle import las_oracle as O
     from phones_las_amd import model_helper as mh
     from phones_las_amd.utils import params_utils as pu
-    F, L, H, V = 13, 2, 64, 11
+    F, L, V = 13, 2, 11
     ohp = O.HP(encoder=O.EncoderHP(num_layers=L, num_units=H), num_channels=F,
                decoder=O.DecoderHP(num_layers=dec_layers, num_units=H, target_vocab_size=V, attention_type=att,
                                    bottom_only=bottom_only, pass_hidden_state=pass_hidden, embedding_size=emb))
@@ -190,3 +190,47 @@ def test_embedding_with_dropout_replayed():
     for name, _, _ in model.vars.table:
         g = out['grads'][name] - ohp.l2_reg_scale * op[name]
         assert relerr(model.vars.grads[name], g) < 8e-2, name
+
+
+def test_persistent_decoder_with_sampling_and_dropout_replayed(monkeypatch):
+    """Scheduled sampling and input dropout INSIDE the one-launch decoder (decoder_units 128): same sampled feed as the
+    per-step launches (same generator streams), and the replay through the oracle."""
+    keep = 0.8
+    O, ohp, op, model = _build(dropout=1 - keep, sampling=0.5, H=128)
+    from phones_las_amd.las.model import Speller
+    sp = model.speller
+    assert isinstance(sp, Speller)
+    batch = make_batch(src_len=[12, 7, 10], tgt_len=[6, 4, 5])
+    feats, labels = to_device(batch)
+    res = {}
+    for flag in ('1', '0'):
+        monkeypatch.setenv('LAS_DEC_PERSIST', flag)
+        model.vars.grad.zero_()
+        loss, logits, dlogits = model.forward_train(feats, labels)
+        fed = sp.saved['fed'].cpu().long().clone()
+        model.backward(dlogits)
+        torch.cuda.synchronize()
+        res[flag] = (fed, logits.clone(), {n: g.clone() for n, g in model.vars.grads.items()})
+    assert int(sp._persist_ws[:4].view(torch.int32).item()) == 0
+    assert torch.equal(res['1'][0], res['0'][0])                      # the same tokens were sampled
+    assert bool((res['1'][0][:, 1:6] != batch['targets_inputs'][:, 1:6]).any())      # and some were sampled at all
+    assert relerr(res['1'][1], res['0'][1].cpu()) < 1e-2      # bf16 roundings of h / context may flip between the two orders
+    fed, logits, grads = res['1']
+    seed = model.last_seed
+    B, T, F, H, V, U = 3, 12, 13, 128, 11, 6
+    enc_masks = []
+    for l, (Tl, Dp, D) in enumerate([(12, 16, F), (12, 2 * H, 2 * H)]):
+        enc_masks.append(tuple(_mask(B * Tl * Dp, keep, seed, 16 + 2 * l + d).reshape(B, Tl, Dp)[..., :D] for d in range(2)))
+    fw = V + sp.M
+    dec_masks = [m for m in _mask(U * B * fw, keep, seed, sp.DEC_STREAM).reshape(U, B, fw)]
+    tin = batch['targets_inputs']
+    changed = (fed[:, 1:U] != tin[:, 1:U])
+    sel = [changed[:, t] for t in range(U - 1)] + [torch.zeros(3, dtype=torch.bool)]
+    ids = [fed[:, t + 1] for t in range(U - 1)] + [torch.zeros(3, dtype=torch.long)]
+    out = O.train_step(ohp, op, None, None, 1, batch, mxu='bf16',
+                       stochastic={'enc_masks': enc_masks, 'dec_masks': dec_masks, 'sample_select': sel, 'sample_ids': ids})
+    for b, n in enumerate([6, 4, 5]):
+        assert relerr(logits[b, :n, :V], out['aux']['logits'][b, :n]) < 3e-2
+    for name, _, _ in model.vars.table:
+        g = out['grads'][name] - ohp.l2_reg_scale * op[name]
+        assert relerr(grads[name], g) < 8e-2, name
