@@ -315,7 +315,7 @@ typedef struct las_dec_step_bwd {
 } las_dec_step_bwd;
 int las_decoder_step_bwd(const las_dec_step_bwd* s, void* stream);
 
-/* The backward counterpart of las_decoder_persist_fwd (Luong / softmax): all U steps, last to first, in one launch,
+/* The backward counterpart of las_decoder_persist_fwd (softmax attentions): all U steps, last to first, in one launch,
  * replacing the U x (las_decoder_step_bwd + las_gemm_nt) loop.  `s` describes step 0 (dctx_b / dh_rec are ignored:
  * the feed gradient of step t+1 is read from dfeed_all); per-step pointers advance by the inc_* element counts.
  * dfeed_all[t] = dz_t K^T ([B, W] fp32: d attention_{t-1} in columns [0,M), d h_{t-1} in [M,W)); dfeed_all[0] is the
@@ -323,7 +323,7 @@ int las_decoder_step_bwd(const las_dec_step_bwd* s, void* stream);
 typedef struct las_dec_persist_bwd {
   las_dec_step_bwd s;
   int32_t U, W;                  /* steps; W = M + Hd */
-  int64_t inc_a, inc_save, inc_gates, inc_c, inc_align, inc_dz, inc_ds;
+  int64_t inc_a, inc_save, inc_gates, inc_c, inc_align, inc_dz, inc_ds, inc_pq;
   const las_bf16* kc;            /* [W, 4Hd] bf16: row n = row n of the cell kernel below the token rows, stride ldk */
   int64_t ldk;
   float* dfeed_all;              /* [U, B, W] fp32 */

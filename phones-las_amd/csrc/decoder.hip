@@ -858,7 +858,7 @@ __global__ __launch_bounds__(256) void dec_step_bwd_kernel(las_dec_step_bwd s) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// PERSISTENT backward decoder (Luong / softmax): all U steps, last to first, in one launch.  Same grouping as the
+// PERSISTENT backward decoder (softmax attentions): all U steps, last to first, in one launch.  Same grouping as the
 // forward (8 utterances per group of 32 workgroups on one XCD); the four workgroups of an utterance split its FRAMES:
 //   S1  d(context) total; dalign over own frames (their quarter of the values); partial sum p.dalign      | barrier
 //   S2  softmax backward on own frames (ds, saved as bf16 for the d(keys) GEMM); partial dh = sum ds*keys  | barrier
@@ -1002,13 +1002,38 @@ __global__ __launch_bounds__(256) void dec_persist_bwd_kernel(las_dec_persist_bw
       float a[8];
 #pragma unroll
       for (int j = 0; j < 8; ++j) a[j] = 0.f;
+      if (!att_additive(s0.attention)) {
 #pragma unroll 4
-      for (int tt = f0 + phase; tt < flen; tt += P) {
-        const uint4 v = *reinterpret_cast<const uint4*>(keys + (int64_t)tt * Hd + u);
-        const unsigned short* e = reinterpret_cast<const unsigned short*>(&v);
-        const float d = dal[tt];
+        for (int tt = f0 + phase; tt < flen; tt += P) {
+          const uint4 v = *reinterpret_cast<const uint4*>(keys + (int64_t)tt * Hd + u);
+          const unsigned short* e = reinterpret_cast<const unsigned short*>(&v);
+          const float d = dal[tt];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) a[j] += d * las_bf2f(e[j]);
+          for (int j = 0; j < 8; ++j) a[j] += d * las_bf2f(e[j]);
+        }
+      } else {
+        // Bahdanau: score = sum_a v[a] tanh(keys[t',a] + pq[a]); d_pre = ds * v * (1 - tanh^2).  This workgroup owns its
+        // frames of the utterance: d(keys) is accumulated in place, d(attention_v) with atomics.
+        const float* pqv = s0.pq + (int64_t)b * s0.ldpq + (int64_t)t * p.inc_pq;
+        float dv[8], vv[8], qq[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { dv[j] = 0.f; vv[j] = s0.att_v[u + j]; qq[j] = pqv[u + j]; }
+        for (int tt = f0 + phase; tt < flen; tt += P) {
+          const uint4 v = *reinterpret_cast<const uint4*>(keys + (int64_t)tt * Hd + u);
+          const unsigned short* e = reinterpret_cast<const unsigned short*>(&v);
+          const float d = dal[tt];
+          float* dk = s0.dkeys_acc + ((int64_t)b * Tm + tt) * Hd + u;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const float th = las_tanh(las_bf2f(e[j]) + qq[j]);
+            dv[j] += d * th;
+            const float pp = d * vv[j] * (1.f - th * th);
+            a[j] += pp;
+            dk[j] += pp;
+          }
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) atomicAdd(s0.dv_acc + u + j, dv[j]);
       }
 #pragma unroll
       for (int j = 0; j < 8; ++j) dhs[phase * Hd + u + j] = a[j];
@@ -1022,12 +1047,32 @@ __global__ __launch_bounds__(256) void dec_persist_bwd_kernel(las_dec_persist_bw
     if (!persist_barrier(flags, member, ++epoch, local, fail)) break;
     // ---- S3: LSTM cell backward (Appendix F), one workgroup per utterance ----
     if (active && part == 0) {
+      for (int u = tid; u < Hd; u += 256) dhs[u] = dhp_t[u] + dhp_t[Hd + u] + dhp_t[2 * Hd + u] + dhp_t[3 * Hd + u];
+      __syncthreads();
+      if (att_uses_wq(s0.attention)) {
+        // dhs holds d(processed query): save it (bf16) for d(query_layer), map back: dh[u] = sum_a dpq[a] Wq[u][a]
+        float* tmp = dhs + Hd;
+        if (s0.attention == LAS_ATT_CUSTOM) {
+          const float* pqv = s0.pq + (int64_t)b * s0.ldpq + (int64_t)t * p.inc_pq;
+          for (int u = tid; u < Hd; u += 256) if (!(pqv[u] > 0.f)) dhs[u] = 0.f;
+          __syncthreads();
+        }
+        for (int u = tid; u < Hd; u += 256) {
+          if (s0.dpq_out) s0.dpq_out[(int64_t)b * s0.lddpq + (int64_t)t * p.inc_pq + u] = las_f2bf(dhs[u]);
+          float acc = 0.f;
+          for (int a = 0; a < Hd; ++a) acc += las_bf2f(s0.wq_t[(int64_t)a * Hd + u]) * dhs[a];
+          tmp[u] = acc;
+        }
+        __syncthreads();
+        for (int u = tid; u < Hd; u += 256) dhs[u] = tmp[u];
+        __syncthreads();
+      }
       for (int u = tid; u < Hd; u += 256) {
         const float* gp = s0.gates + (int64_t)b * s0.ldg + (int64_t)t * p.inc_gates + u;
         const float gi = gp[0], gj = gp[Hd], gf = gp[2 * Hd], go = gp[3 * Hd];
         const float ct = s0.c_new[(int64_t)b * s0.ldcn + (int64_t)t * p.inc_c + u];
         const float cp = s0.c_prev[(int64_t)b * s0.ldcp + (int64_t)t * p.inc_c + u];
-        float dht = dhp_t[u] + dhp_t[Hd + u] + dhp_t[2 * Hd + u] + dhp_t[3 * Hd + u];
+        float dht = dhs[u];
         if (dfeed_next) dht += dfeed_next[(int64_t)b * W + M + u];
         const float tc = las_tanh(ct);
         const float dov = dht * tc * go * (1.f - go);
@@ -1298,7 +1343,8 @@ extern "C" int las_decoder_persist_fwd(const las_dec_persist* p, void* stream) {
 }
 
 extern "C" int las_decoder_persist_bwd_supported(int Hd, int M, int W, int attention, int norm) {
-  if (norm != LAS_NORM_SOFTMAX || attention != LAS_ATT_LUONG) return 0;
+  if (norm != LAS_NORM_SOFTMAX) return 0;
+  if (attention != LAS_ATT_LUONG && attention != LAS_ATT_BAHDANAU && attention != LAS_ATT_CUSTOM) return 0;
   if (Hd != 128 && Hd != 256) return 0;                   // 4Hd/32 K chunks: <= 8 per wave
   if (W % 16 != 0 || W / 16 > 96 || M % 128 != 0) return 0;   // <= 3 column tiles per member
   return 1;
@@ -1313,6 +1359,9 @@ extern "C" int las_decoder_persist_bwd(const las_dec_persist_bwd* p, void* strea
   LAS_REQUIRE(p->kc && p->dfeed_all && p->dot_all && p->dhp_all && p->workspace && s->dctx_a && s->dc && s->dz && s->ds_out &&
                   s->align && s->gates && s->c_new && s->c_prev && s->keys && s->values && s->mem_len,
               "las_decoder_persist_bwd: null argument");
+  LAS_REQUIRE(s->attention == LAS_ATT_LUONG || (s->pq && s->wq_t), "las_decoder_persist_bwd: this attention needs pq and wq_t");
+  LAS_REQUIRE(s->attention != LAS_ATT_BAHDANAU || (s->att_v && s->dkeys_acc && s->dv_acc),
+              "las_decoder_persist_bwd: Bahdanau scores need att_v, dkeys_acc, dv_acc");
   hipStream_t st = (hipStream_t)stream;
   const int groups = (s->B + 7) / 8;
   int rc = las_check_hip(hipMemsetAsync(p->workspace, 0, las_decoder_persist_workspace_bytes(s->B), st), "memset workspace");

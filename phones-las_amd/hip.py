@@ -111,7 +111,7 @@ class DecStepBwd(C.Structure):
 class DecPersistBwd(C.Structure):
     """struct las_dec_persist_bwd (include/las_hip.h)."""
     _fields_ = [('s', DecStepBwd), ('U', _i32), ('W', _i32)] + [(n, _i64) for n in (
-        'inc_a', 'inc_save', 'inc_gates', 'inc_c', 'inc_align', 'inc_dz', 'inc_ds')] + [
+        'inc_a', 'inc_save', 'inc_gates', 'inc_c', 'inc_align', 'inc_dz', 'inc_ds', 'inc_pq')] + [
         ('kc', _vp), ('ldk', _i64), ('dfeed_all', _vp), ('dot_all', _vp), ('dhp_all', _vp), ('workspace', _vp)]
 
 

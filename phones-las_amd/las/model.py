@@ -361,8 +361,14 @@ class Speller:
             s.drop_keep, s.feed_width = 1.0, V + M
             if sv['keep'] < 1.0:
                 s.drop_keep, s.drop_seed, s.drop_stream = sv['keep'], sv['seed'], self.DEC_STREAM
+            if bah:
+                s.pq, s.ldpq = hip.addr(sv['pq_all']), U * Hd
+                s.wq_t, s.att_v = hip.addr(self.wq_t), hip.addr(self.att_v)
+                s.dkeys_acc, s.dv_acc = hip.addr(dkeys), hip.addr(dv)
+                s.dpq_out, s.lddpq = hip.addr(dpq_all), U * Hd
             p.U, p.W = U, W
             p.inc_a, p.inc_save, p.inc_gates, p.inc_c, p.inc_align, p.inc_dz, p.inc_ds = M, M, 4 * Hd, Hd, Tmp, 4 * Hd, Tmp
+            p.inc_pq = Hd
             p.kc, p.ldk = hip.addr(self.kc), 4 * Hd
             dfeed_all = torch.empty(U, B, W, dtype=f32, device=dev)
             dot_all = torch.empty(U, B, 4, dtype=f32, device=dev)

@@ -417,8 +417,7 @@ def test_persistent_decoder_vs_per_step_and_oracle(att, monkeypatch):
         torch.cuda.synchronize()
         if flag == '1':
             assert int(model.speller._persist_ws[:4].view(torch.int32).item()) == 0      # no barrier timed out
-            if att == 'luong':
-                assert int(model.speller._persist_ws_bwd[:4].view(torch.int32).item()) == 0
+            assert int(model.speller._persist_ws_bwd[:4].view(torch.int32).item()) == 0
         outs[flag] = (float(loss), logits.clone(), {n: g.clone() for n, g in model.vars.grads.items()})
     assert relerr(outs['1'][1], outs['0'][1].cpu()) < 1e-3
     for name in outs['1'][2]:                      # persistent backward vs the per-step launches
