@@ -221,6 +221,7 @@ def main():
         dt = float(t.item())
     final_loss = float(loss_buf.item())
 
+    model.check_device_status()        # a bounded inter-workgroup wait that timed out would invalidate the numbers
     if rank == 0:
         ms = dt / args.steps * 1e3
         utt_s = c['B'] * world * args.steps / dt

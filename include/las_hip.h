@@ -234,7 +234,7 @@ typedef struct las_dec_persist {
   int64_t ldk;
   float* z_all;                  /* [U, B, 4Hd] fp32 scratch (every z_t keeps its own rows) */
   float* sc_all;                 /* [U, B, ld_sc] fp32 scratch: raw attention scores (the parts of an utterance split the frames) */
-  int64_t ld_sc;                 /* >= Tm */
+  int64_t ld_sc;                 /* >= Tm, multiple of 32 (whole cache lines per row) */
   void* workspace;
   /* scheduled sampling (utils/training_helper.py:48-87), sampling_prob > 0: after step t the kernel forms
    * logits_t = context_t W_proj + b, stores them (logits + b*ld_logits + t*Vp) and writes the token fed at step t+1 into
@@ -327,7 +327,7 @@ typedef struct las_dec_persist_bwd {
   const las_bf16* kc;            /* [W, 4Hd] bf16: row n = row n of the cell kernel below the token rows, stride ldk */
   int64_t ldk;
   float* dfeed_all;              /* [U, B, W] fp32 */
-  float* dot_all;                /* [U, B, 4] fp32 scratch */
+  float* dot_all;                /* [U, B, 32] fp32 scratch (4 used: one cache line per row) */
   float* dhp_all;                /* [U, B, 4, Hd] fp32 scratch */
   void* workspace;               /* las_decoder_persist_workspace_bytes(B) */
 } las_dec_persist_bwd;

@@ -84,6 +84,10 @@ struct PersistHook {
   int* fail;
 };
 __device__ bool persist_barrier(pu64* flags, int member, unsigned epoch, bool local, int* lds_fail);
+// Exchange discipline of the persistent decoder: every (utterance, step) row of an exchanged tensor occupies WHOLE
+// 128-byte cache lines and is read only after it is complete, so a workgroup never holds a line in its L1 that somebody
+// else is still going to write (a row sharing a line with the next step's row would be served stale from L1 later; the
+// host pads the small rows - raw scores, partial dots - to 32 floats).
 
 __device__ void dec_step_fwd_body(const las_dec_step& s, const int b, const int part, const int nparts, float* sm,
                                   const PersistHook* ph = nullptr) {
@@ -400,6 +404,7 @@ __device__ bool persist_barrier(pu64* flags, int member, unsigned epoch, bool lo
   return *lds_fail == 0;
 }
 
+template <bool SAMPLING>
 __global__ __launch_bounds__(256) void dec_persist_fwd_kernel(las_dec_persist p) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   constexpr int NTL_MAX = 2, KCW_MAX = 12;
@@ -517,7 +522,7 @@ __global__ __launch_bounds__(256) void dec_persist_fwd_kernel(las_dec_persist p)
     } else {
       if (!persist_barrier(flags, member, ++epoch, local, fail)) break;     // the score exchange of the busy members
     }
-    if (p.sampling_prob > 0.f) {
+    if constexpr (SAMPLING) {
       // ---- scheduled sampling (utils/training_helper.py:48-87): logits_t = context_t W_proj + b from the four parts'
       //      partial products, then the next fed token = Categorical(logits_t) with probability p, else the teacher's ----
       const int V = p.V, Vp = p.Vp;
@@ -867,6 +872,7 @@ __global__ __launch_bounds__(256) void dec_step_bwd_kernel(las_dec_step_bwd s) {
 //       tiles j, j+32, j+64 (its rows of K register-resident as MFMA B fragments)                          | barrier
 // Every exchanged tensor has its own rows per step (no address is re-read after being rewritten).
 // ------------------------------------------------------------------------------------------------
+template <bool WQ>
 __global__ __launch_bounds__(256) void dec_persist_bwd_kernel(las_dec_persist_bwd p) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   constexpr int NT_MAX = 3, KCW_MAX = 8;
@@ -934,7 +940,7 @@ __global__ __launch_bounds__(256) void dec_persist_bwd_kernel(las_dec_persist_bw
   for (int t = p.U - 1; t >= 0; --t) {
     const bool first = (t == p.U - 1);
     const float* dfeed_next = first ? nullptr : p.dfeed_all + (int64_t)(t + 1) * B * W;      // written by step t+1
-    float* dot_t = p.dot_all + ((int64_t)t * B + (active ? b : 0)) * 4;
+    float* dot_t = p.dot_all + ((int64_t)t * B + (active ? b : 0)) * 32;      // one cache line per (step, utterance)
     float* dhp_t = p.dhp_all + ((int64_t)t * B + (active ? b : 0)) * 4 * Hd;
     // ---- S1 ----
     if (active) {
@@ -1002,7 +1008,7 @@ __global__ __launch_bounds__(256) void dec_persist_bwd_kernel(las_dec_persist_bw
       float a[8];
 #pragma unroll
       for (int j = 0; j < 8; ++j) a[j] = 0.f;
-      if (!att_additive(s0.attention)) {
+      if (!WQ || !att_additive(s0.attention)) {
 #pragma unroll 4
         for (int tt = f0 + phase; tt < flen; tt += P) {
           const uint4 v = *reinterpret_cast<const uint4*>(keys + (int64_t)tt * Hd + u);
@@ -1049,7 +1055,7 @@ __global__ __launch_bounds__(256) void dec_persist_bwd_kernel(las_dec_persist_bw
     if (active && part == 0) {
       for (int u = tid; u < Hd; u += 256) dhs[u] = dhp_t[u] + dhp_t[Hd + u] + dhp_t[2 * Hd + u] + dhp_t[3 * Hd + u];
       __syncthreads();
-      if (att_uses_wq(s0.attention)) {
+      if (WQ && att_uses_wq(s0.attention)) {
         // dhs holds d(processed query): save it (bf16) for d(query_layer), map back: dh[u] = sum_a dpq[a] Wq[u][a]
         float* tmp = dhs + Hd;
         if (s0.attention == LAS_ATT_CUSTOM) {
@@ -1312,7 +1318,8 @@ extern "C" int las_decoder_persist_supported(int Hd, int M, int K_in, int attent
   if (norm != LAS_NORM_SOFTMAX) return 0;
   if (attention != LAS_ATT_LUONG && attention != LAS_ATT_BAHDANAU && attention != LAS_ATT_CUSTOM) return 0;
   if (Hd != 128 && Hd != 256) return 0;                   // 4Hd/32 columns per member: 16 or 32
-  if (K_in % 32 != 0 || K_in / 32 > 48) return 0;          // register-resident K slice: <= 12 chunks per wave
+  if (K_in % 64 != 0 || K_in / 32 > 48) return 0;          // register-resident K slice (<= 12 chunks per wave); operand
+                                                           // rows of whole 128-byte lines (no line shared by two steps)
   if (M % 32 != 0) return 0;
   return 1;
 }
@@ -1327,7 +1334,9 @@ extern "C" int las_decoder_persist_fwd(const las_dec_persist* p, void* stream) {
   LAS_REQUIRE(las_decoder_persist_supported(s->Hd, s->M, p->K_in, s->attention, s->norm),
               "las_decoder_persist_fwd: configuration not supported (Hd=%d M=%d K_in=%d attention=%d norm=%d)", s->Hd, s->M, p->K_in,
               s->attention, s->norm);
-  LAS_REQUIRE(p->x && p->kT && p->z_all && p->sc_all && p->workspace && p->ld_sc >= s->Tm, "las_decoder_persist_fwd: null argument");
+  LAS_REQUIRE(p->x && p->kT && p->z_all && p->sc_all && p->workspace && p->ld_sc >= s->Tm && p->ld_sc % 32 == 0 &&
+                  ((uintptr_t)p->sc_all % 128 == 0) && ((uintptr_t)p->z_all % 128 == 0) && ((uintptr_t)p->x % 128 == 0),
+              "las_decoder_persist_fwd: null argument, or exchanged rows that are not whole 128-byte lines");
   LAS_REQUIRE(p->sampling_prob <= 0.f || (p->wprojT && p->bproj && p->logits && p->plog && p->teacher && p->V > 0 && p->Vp >= p->V &&
                                           p->Vp <= 1024 && s->M % 32 == 0 && p->inc_tok == 1),
               "las_decoder_persist_fwd: scheduled sampling needs wprojT, bproj, logits, plog, teacher (and fed ids with unit step)");
@@ -1337,7 +1346,11 @@ extern "C" int las_decoder_persist_fwd(const las_dec_persist* p, void* stream) {
   if (rc) return rc;
   const size_t lds = (size_t)(2 * s->Hd + s->Tm + 16 + 2048 + 4 * 16 * 33 + 8) * sizeof(float);
   LAS_REQUIRE(lds <= 64 * 1024, "las_decoder_persist_fwd: memory length %d too long for the LDS score buffer", s->Tm);
-  hipLaunchKernelGGL(dec_persist_fwd_kernel, dim3(((groups + 7) & ~7) * P_MEMBERS), dim3(256), lds, st, *p);
+  // two instantiations: the scheduled-sampling phase costs registers the plain teacher-forcing loop should not pay for
+  if (p->sampling_prob > 0.f)
+    hipLaunchKernelGGL(dec_persist_fwd_kernel<true>, dim3(((groups + 7) & ~7) * P_MEMBERS), dim3(256), lds, st, *p);
+  else
+    hipLaunchKernelGGL(dec_persist_fwd_kernel<false>, dim3(((groups + 7) & ~7) * P_MEMBERS), dim3(256), lds, st, *p);
   LAS_LAUNCH_CHECK("persistent decoder fwd launch");
   return LAS_OK;
 }
@@ -1346,7 +1359,7 @@ extern "C" int las_decoder_persist_bwd_supported(int Hd, int M, int W, int atten
   if (norm != LAS_NORM_SOFTMAX) return 0;
   if (attention != LAS_ATT_LUONG && attention != LAS_ATT_BAHDANAU && attention != LAS_ATT_CUSTOM) return 0;
   if (Hd != 128 && Hd != 256) return 0;                   // 4Hd/32 K chunks: <= 8 per wave
-  if (W % 16 != 0 || W / 16 > 96 || M % 128 != 0) return 0;   // <= 3 column tiles per member
+  if (W % 32 != 0 || W / 16 > 96 || M % 128 != 0) return 0;   // <= 3 column tiles per member; dfeed rows of whole lines
   return 1;
 }
 
@@ -1368,7 +1381,10 @@ extern "C" int las_decoder_persist_bwd(const las_dec_persist_bwd* p, void* strea
   if (rc) return rc;
   const size_t lds = (size_t)(s->M + 2 * s->Tm + 2048 + 16 + s->Hd + 4 * 16 * 49 + 8) * sizeof(float);
   LAS_REQUIRE(lds <= 64 * 1024, "las_decoder_persist_bwd: shapes exceed the LDS budget");
-  hipLaunchKernelGGL(dec_persist_bwd_kernel, dim3(((groups + 7) & ~7) * P_MEMBERS), dim3(256), lds, st, *p);
+  if (s->attention == LAS_ATT_LUONG)
+    hipLaunchKernelGGL(dec_persist_bwd_kernel<false>, dim3(((groups + 7) & ~7) * P_MEMBERS), dim3(256), lds, st, *p);
+  else
+    hipLaunchKernelGGL(dec_persist_bwd_kernel<true>, dim3(((groups + 7) & ~7) * P_MEMBERS), dim3(256), lds, st, *p);
   LAS_LAUNCH_CHECK("persistent decoder bwd launch");
   return LAS_OK;
 }

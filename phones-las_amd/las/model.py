@@ -280,8 +280,9 @@ class Speller:
             p.kT, p.ldk = hip.addr(self.kcT), W
             z_all = torch.empty(U, B, 4 * Hd, dtype=f32, device=dev)
             ws = torch.empty(lib.las_decoder_persist_workspace_bytes(B), dtype=torch.uint8, device=dev)
-            sc_all = torch.empty(U, B, Tmp, dtype=f32, device=dev)
-            p.z_all, p.sc_all, p.ld_sc, p.workspace = hip.addr(z_all), hip.addr(sc_all), Tmp, hip.addr(ws)
+            ld_sc = (Tm + 31) // 32 * 32          # whole cache lines per (step, utterance) row
+            sc_all = torch.empty(U, B, ld_sc, dtype=f32, device=dev)
+            p.z_all, p.sc_all, p.ld_sc, p.workspace = hip.addr(z_all), hip.addr(sc_all), ld_sc, hip.addr(ws)
             if sampling > 0.0:           # logits and the sampled feed are produced inside the launch
                 plog = torch.empty(U, B, 4, Vp, dtype=f32, device=dev)
                 p.sampling_prob, p.seed = sampling, seed
@@ -371,7 +372,7 @@ class Speller:
             p.inc_pq = Hd
             p.kc, p.ldk = hip.addr(self.kc), 4 * Hd
             dfeed_all = torch.empty(U, B, W, dtype=f32, device=dev)
-            dot_all = torch.empty(U, B, 4, dtype=f32, device=dev)
+            dot_all = torch.empty(U, B, 32, dtype=f32, device=dev)
             dhp_all = torch.empty(U, B, 4, Hd, dtype=f32, device=dev)
             ws = torch.empty(lib.las_decoder_persist_workspace_bytes(B), dtype=torch.uint8, device=dev)
             p.dfeed_all, p.dot_all, p.dhp_all, p.workspace = hip.addr(dfeed_all), hip.addr(dot_all), hip.addr(dhp_all), hip.addr(ws)

@@ -56,6 +56,14 @@ def check_lstm_status(B, H, nd):
         raise hip.LasError('recurrent kernel reported an inter-workgroup timeout (status %d)' % st)
 
 
+def check_all_lstm_status():
+    """Raise if any recurrent launch since the last check reported an inter-workgroup timeout (forces a sync)."""
+    for (B, H, nd, dev), ws in _WORKSPACES.items():
+        st = int(ws[:4].view(torch.int32).item())
+        if st:
+            raise hip.LasError('recurrent kernel (B=%d, H=%d) reported an inter-workgroup timeout (status %d)' % (B, H, st))
+
+
 class Overlap:
     """A second HIP stream for launches that are off the critical path of the backward pass (weight-gradient
     GEMMs, bias sums): they fill the ~224 CUs the persistent recurrent kernels leave idle.  fork() makes the side

@@ -395,6 +395,18 @@ class LasModel:
             'final_sequence_length': final_len,
         }
 
+    def check_device_status(self):
+        """The persistent kernels (recurrent layers, one-launch decoder) bound every inter-workgroup wait and flag a
+        timeout in their workspace instead of hanging; results are then invalid.  Call at logging points (it
+        synchronises): raises LasError if any launch since the last check timed out."""
+        las_model.ops.check_all_lstm_status()
+        for name in ('_persist_ws', '_persist_ws_bwd'):
+            ws = getattr(self.speller, name, None)
+            if ws is not None:
+                st = int(ws[:4].view(torch.int32).item())
+                if st:
+                    raise hip.LasError('persistent decoder reported a barrier timeout (status %d)' % st)
+
     def _beam_speller(self):
         """Beam search runs on the general cell stack (it gathers the decoder state between steps); the fused
         single-cell speller gets a GeneralSpeller twin over the same variables."""

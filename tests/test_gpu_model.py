@@ -419,7 +419,10 @@ def test_persistent_decoder_vs_per_step_and_oracle(att, monkeypatch):
             assert int(model.speller._persist_ws[:4].view(torch.int32).item()) == 0      # no barrier timed out
             assert int(model.speller._persist_ws_bwd[:4].view(torch.int32).item()) == 0
         outs[flag] = (float(loss), logits.clone(), {n: g.clone() for n, g in model.vars.grads.items()})
-    assert relerr(outs['1'][1], outs['0'][1].cpu()) < 1e-3
+    # same arithmetic in the same order: the two paths agree to fp32 rounding (a stale-cache race once hid behind a
+    # looser bound); in the backward the partial sums of the four frame shares are added in another order and the
+    # bf16 roundings of dz / d(query) can flip, weight gradients are summed with atomics in the split-K GEMMs
+    assert relerr(outs['1'][1], outs['0'][1].cpu()) < 1e-5
     for name in outs['1'][2]:                      # persistent backward vs the per-step launches
         assert relerr(outs['1'][2][name], outs['0'][2][name].cpu()) < 2e-3, name
     out = O.train_step(ohp, op, None, None, 1, batch, mxu='bf16')
@@ -454,6 +457,6 @@ def test_persistent_decoder_edge_shapes_match_per_step_path(B, T, U, src_len, tg
             assert int(model.speller._persist_ws[:4].view(torch.int32).item()) == 0
             assert int(model.speller._persist_ws_bwd[:4].view(torch.int32).item()) == 0
         outs[flag] = (logits.clone(), {n: g.clone() for n, g in model.vars.grads.items()})
-    assert relerr(outs['1'][0], outs['0'][0].cpu()) < 1e-3
+    assert relerr(outs['1'][0], outs['0'][0].cpu()) < 1e-5
     for name in outs['1'][1]:
-        assert relerr(outs['1'][1][name], outs['0'][1][name].cpu()) < 3e-3, name
+        assert relerr(outs['1'][1][name], outs['0'][1][name].cpu()) < 2e-3, name

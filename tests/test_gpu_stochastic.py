@@ -205,6 +205,8 @@ def test_persistent_decoder_with_sampling_and_dropout_replayed(monkeypatch):
     res = {}
     for flag in ('1', '0'):
         monkeypatch.setenv('LAS_DEC_PERSIST', flag)
+        junk = torch.randn(16 << 20, device='cuda')      # dirty the allocator's free blocks: nothing may depend on them
+        del junk
         model.vars.grad.zero_()
         loss, logits, dlogits = model.forward_train(feats, labels)
         fed = sp.saved['fed'].cpu().long().clone()
@@ -214,7 +216,7 @@ def test_persistent_decoder_with_sampling_and_dropout_replayed(monkeypatch):
     assert int(sp._persist_ws[:4].view(torch.int32).item()) == 0
     assert torch.equal(res['1'][0], res['0'][0])                      # the same tokens were sampled
     assert bool((res['1'][0][:, 1:6] != batch['targets_inputs'][:, 1:6]).any())      # and some were sampled at all
-    assert relerr(res['1'][1], res['0'][1].cpu()) < 1e-2      # bf16 roundings of h / context may flip between the two orders
+    assert relerr(res['1'][1], res['0'][1].cpu()) < 1e-5      # same arithmetic, same order (only the projection sums differ)
     fed, logits, grads = res['1']
     seed = model.last_seed
     B, T, F, H, V, U = 3, 12, 13, 128, 11, 6

@@ -154,6 +154,7 @@ def main(args):
         loss = model.train_step(f, l, num_steps=num_steps)
         if model.global_step % 10 == 0:                            # LoggingTensorHook(every_n_iter=10)
             lv = dp.mean_scalar(float(loss))
+            model.check_device_status()          # bounded waits of the persistent kernels: fail loudly, never silently
             if rank == 0:
                 dt = time.time() - t_last
                 print('step %d: loss = %.5f (%.2f utt/s)' % (model.global_step, lv, 10 * global_batch / max(dt, 1e-9)))
