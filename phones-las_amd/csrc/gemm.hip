@@ -457,7 +457,6 @@ __global__ __launch_bounds__(256) void gemm_nt_skinny_kernel(GemmArgs g) {
     arow[i] = g.A + (int64_t)(a_ok[i] ? m : 0) * g.lda + 8 * lq;
   }
   const uint4 zero = make_uint4(0, 0, 0, 0);
-#pragma unroll 2
   for (int kc = wave; kc < nk; kc += 4) {
     const int k = kc * 32;
     const bool k_ok = (k + 8 * lq) < g.K;
