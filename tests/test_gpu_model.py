@@ -460,3 +460,29 @@ def test_persistent_decoder_edge_shapes_match_per_step_path(B, T, U, src_len, tg
     assert relerr(outs['1'][0], outs['0'][0].cpu()) < 1e-5
     for name in outs['1'][1]:
         assert relerr(outs['1'][1][name], outs['0'][1][name].cpu()) < 2e-3, name
+
+
+def test_training_with_the_persistent_kernels_learns_and_reports_no_timeout():
+    """End to end on the kernels the benchmark runs: cooperative recurrent kernels with companions (256 units) and the
+    one-launch decoder (256 units, dropout + scheduled sampling on): 40 optimiser steps on one ragged batch must bring
+    the loss down, and no bounded inter-workgroup wait may have timed out (check_device_status)."""
+    from phones_las_amd import model_helper as mh
+    from phones_las_amd.utils import params_utils as pu
+    from phones_las_amd.las.model import Speller
+    hp = pu.get_default_hparams()
+    for k, v in dict(num_channels=13, encoder_layers=2, encoder_units=256, use_pyramidal=True, decoder_layers=1,
+                     decoder_units=256, target_vocab_size=11, attention_type='luong', bottom_only=True,
+                     pass_hidden_state=True, dropout=0.1, sampling_probability=0.1, learning_rate=3e-3).items():
+        hp.set_hparam(k, v)
+    model = mh.LasModel(pu.get_encoder_decoder_hparams(hp))
+    assert isinstance(model.speller, Speller)
+    src_len = [24, 7, 16, 24, 3, 19, 11, 24, 5, 8, 22, 24, 13, 24, 2, 17, 9]
+    tgt_len = [6, 4, 5, 6, 2, 3, 6, 5, 4, 6, 1, 6, 3, 6, 2, 4, 5]
+    batch = make_batch(B=17, T=24, U=6, src_len=src_len, tgt_len=tgt_len)
+    feats, labels = to_device(batch)
+    losses = []
+    for _ in range(40):
+        losses.append(float(model.train_step(feats, labels)))
+    model.check_device_status()
+    assert getattr(model.speller, '_persist_ws', None) is not None and getattr(model.speller, '_persist_ws_bwd', None) is not None
+    assert np.isfinite(losses).all() and losses[-1] < 0.6 * losses[0], losses
