@@ -47,6 +47,16 @@ def test_train_resume_infer(tmp_path, capsys):
                                        '--num_channels', '13', '--batch_size', '8']))
     assert per < 40.0
     assert len(open(os.path.join(d, 'model', 'infer.txt')).read().split('\n')) == 16
+    # beam search over the same checkpoint (infer.py --beam_width) and the stand-alone evaluation (eval.py)
+    per_beam = infer.main(infer.parse_args(['--data', os.path.join(d, 'train.tfr'), '--vocab', os.path.join(d, 'vocab.txt'),
+                                            '--norm', os.path.join(d, 'norm.dmp'), '--model_dir', os.path.join(d, 'model'),
+                                            '--num_channels', '13', '--batch_size', '8', '--beam_width', '3']))
+    assert per_beam < 40.0 and 'Optimistic PER' in capsys.readouterr().out
+    import eval as eval_cli
+    loss, ed = eval_cli.main(eval_cli.parse_args(['--data', os.path.join(d, 'train.tfr'), '--vocab', os.path.join(d, 'vocab.txt'),
+                                                  '--norm', os.path.join(d, 'norm.dmp'), '--model_dir', os.path.join(d, 'model'),
+                                                  '--num_channels', '13', '--batch_size', '8']))
+    assert np.isfinite(loss) and 0.0 <= ed < 0.4
 
 
 def test_train_with_the_reference_default_architecture_flags(tmp_path, capsys):
