@@ -94,10 +94,14 @@ int las_gemm_tn(const las_bf16* A, int64_t lda, const las_bf16* B, int64_t ldb, 
  *                                                 `period` of rows, i.e. h_{t-1} of the direction's own time order)
  *   bias_grad[:]          += column sums of dz
  * x [K, D] bf16 (row stride ldx), y [K, H] bf16 (ldy), dz [K, 4H] bf16 with GATE-INTERLEAVED columns (ldz); outputs
- * fp32 in TF column order (g*H+u), accumulated with atomics (split_k slices of K). */
+ * fp32 in TF column order (g*H+u).  K is cut into split_k slices; with `workspace`
+ * (las_gemm_tn_lstm_workspace_bytes, caller-owned, reusable once the stream has passed this call) every slice stores
+ * its partial product and a second kernel sums them into the outputs; workspace NULL accumulates with fp32 atomics
+ * instead (several times slower at training shapes). */
+size_t las_gemm_tn_lstm_workspace_bytes(int D, int H, int split_k);
 int las_gemm_tn_lstm(const las_bf16* x, int64_t ldx, int D, const las_bf16* y, int64_t ldy, int H, int a_shift,
                      int period, const las_bf16* dz, int64_t ldz, float* kernel_grad, float* bias_grad, int K,
-                     int split_k, void* stream);
+                     int split_k, float* workspace, void* stream);
 
 /* dst_bf16[r, c] = src_f32[r, c] (transpose = 0) or dst[c, r] = src[r, c] (transpose = 1), with the
  * destination window [dst_rows, dst_cols] (row stride ldd) zero-padded.  `batch` windows at element

@@ -6,6 +6,13 @@
 // against the keys, the length-masked softmax (wave-shuffle + LDS reductions) and the context
 // sum_t' align * values.  keys/values rows are read as 16-byte bf16x8 pieces (16 lanes per memory frame
 // for scores, 4 columns per lane for the context).
+//
+// For the fused Speller (single cell, Hd 128/256, B <= 256) the whole decode loop runs in ONE launch per direction
+// (dec_persist_fwd_kernel / dec_persist_bwd_kernel below): groups of 32 workgroups on one XCD own 8 utterances,
+// keep their slice of the cell kernel in registers as MFMA fragments, and trade the per-step vectors through L2
+// behind flag barriers.  The step kernels above remain the general path (stacked cells, wider shapes, greedy and
+// beam decoding).  The file also holds the masked sequence loss, the log-probs loss of the binary-feature decoder
+// and the beam-search step.
 #include "las_common.h"
 #include <stdlib.h>
 

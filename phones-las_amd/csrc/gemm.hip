@@ -33,6 +33,10 @@ struct GemmArgs {
   int64_t lda2 = 0;
   int M1 = -1, M2 = 0;
   float* bias_row = nullptr;
+  // split-K without atomics (gemm_tn_tr_kernel): slice z stores its fp32 tile at partial + z * partial_stride
+  // ([M][N], plain column order); tn_reduce_kernel folds the slices into C / bias_row afterwards.
+  float* partial = nullptr;
+  int64_t partial_stride = 0;
 };
 
 template <int BM, int BN, bool TN>
@@ -278,6 +282,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
 // lane 4q+p of a 16-lane group supplies row q, columns 4p..4p+3; lane i receives column i of the four rows.
 // 128 x 128 output tile, BK = 64, 4 waves in a 2 x 2 grid, register-staged double buffering.
 // ------------------------------------------------------------------------------------------------
+constexpr int TBK = 32;     // K depth of one staged tile of the TN kernel
 typedef __attribute__((ext_vector_type(4))) short s16x4;
 typedef __attribute__((ext_vector_type(8))) short s16x8;
 
@@ -286,16 +291,31 @@ __device__ __forceinline__ int tr_off(int row, int chunk) { return 256 * row + 1
 __global__ __launch_bounds__(256) void gemm_tn_tr_kernel(GemmArgs g) {
   constexpr int BM = 128, BN = 128;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  unsigned char* As = smem;                       // [2][BK][256 B]
-  unsigned char* Bs = smem + 2 * BK * 256;        // [2][BK][256 B]
+  unsigned char* As = smem;                       // [2][TBK][256 B]
+  unsigned char* Bs = smem + 2 * TBK * 256;        // [2][TBK][256 B]
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wr = wave >> 1, wc = wave & 1;
-  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
-  const int batch = blockIdx.z / g.split_k, slice = blockIdx.z % g.split_k;
+  // XCD-aware order: workgroups are dealt round-robin to the 8 XCDs, and all output tiles of one K slice read the same
+  // A and B rows.  Linear id -> (XCD = id % 8, j = id / 8); the j-th workgroup of an XCD takes tile j % P of slice
+  // (j / P) * 8 + XCD, so a slice's operands are pulled into ONE L2 once and shared by its P tiles (instead of every XCD
+  // fetching every slice).  The last gz % 8 slices keep the plain order.
+  int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+  {
+    const int gx = gridDim.x, gy = gridDim.y, P = gx * gy;
+    const int id = bx + gx * (by + gy * bz);
+    if (id < (int)(gridDim.z / 8) * 8 * P) {
+      const int j = id >> 3, t = j % P;
+      bz = (j / P) * 8 + (id & 7);
+      by = t / gx;
+      bx = t - by * gx;
+    }
+  }
+  const int m0 = by * BM, n0 = bx * BN;
+  const int batch = bz / g.split_k, slice = bz % g.split_k;
   const unsigned short* A = g.A + (int64_t)batch * g.sa;
   const unsigned short* B = g.B + (int64_t)batch * g.sb;
-  const int nk_total = (g.K + BK - 1) / BK;
+  const int nk_total = (g.K + TBK - 1) / TBK;
   const int nk_per = (nk_total + g.split_k - 1) / g.split_k;
   const int kt_begin = slice * nk_per;
   const int kt_end = min(nk_total, kt_begin + nk_per);
@@ -306,42 +326,60 @@ __global__ __launch_bounds__(256) void gemm_tn_tr_kernel(GemmArgs g) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  constexpr int CH = BK * 16 / 256;          // 16-byte chunks per thread and operand (4)
+  constexpr int CH = TBK * 16 / 256;          // 16-byte chunks per thread and operand
   uint4 ra[CH], rb[CH];
-  auto load_tiles = [&](int kt) {
-    const int k0 = kt * BK;
+  // A thread always stages the same 8-column chunk (256 % 16 == 0), rows kr0 + 16 i of every tile: which source its A
+  // columns come from, the row pointers and the position inside the period are loop-carried instead of being
+  // recomputed (the integer work per tile was costing more issue slots than the MFMAs).
+  const int ch = tid & 15, kr0 = tid >> 4;
+  int kindA = 0;                  // 0: zero, 1: rows as they lie, 2: rows shifted inside the period, 3: the ones row
+  const unsigned short* pa = A;
+  int64_t lda_e = 0;
+  int shift = 0;
+  {
+    const int m = m0 + ch * 8;
+    if (g.M1 >= 0) {              // fused LSTM weight gradient: [x | y shifted | ones]
+      if (m < g.M1) { kindA = 1; pa = A + m; lda_e = g.lda; }
+      else if (m < g.M1 + g.M2) { kindA = 2; pa = g.A2 + (m - g.M1); lda_e = g.lda2; shift = g.a_shift; }
+      else if (m == g.M1 + g.M2 && g.bias_row) kindA = 3;
+    } else if (m < g.M) {
+      kindA = g.period > 0 ? 2 : 1;
+      pa = A + m;
+      lda_e = g.lda;
+      shift = g.period > 0 ? g.a_shift : 0;
+    }
+  }
+  const bool n_ok = (n0 + ch * 8) < g.N;
+  int kcur = kt_begin * TBK + kr0;                       // row of chunk 0 in the tile staged next
+  int t0 = g.period > 0 ? kcur % g.period : 0;
+  const unsigned short* paK = pa + ((int64_t)kcur + shift) * lda_e;
+  const unsigned short* pbK = B + (int64_t)kcur * g.ldb + (n0 + ch * 8);
+  auto load_tiles = [&]() {
 #pragma unroll
     for (int i = 0; i < CH; ++i) {
-      const int c = tid + i * 256;
-      const int kr = c >> 4, ch = c & 15;
       uint4 va = make_uint4(0, 0, 0, 0), vb = make_uint4(0, 0, 0, 0);
-      {
-        const int m = m0 + ch * 8;
-        int k = k0 + kr;
-        if (g.M1 >= 0) {              // fused LSTM weight gradient: [x | y shifted | ones]
-          if (k < g.K) {
-            if (m < g.M1) va = *reinterpret_cast<const uint4*>(A + (int64_t)k * g.lda + m);
-            else if (m < g.M1 + g.M2) {
-              const int t = k % g.period + g.a_shift;
-              if (t >= 0 && t < g.period) va = *reinterpret_cast<const uint4*>(g.A2 + (int64_t)(k + g.a_shift) * g.lda2 + (m - g.M1));
-            } else if (m == g.M1 + g.M2 && g.bias_row) va.x = 0x3F80u;      // bf16 1.0 in the first of the eight rows
-          }
-        } else {
-          bool ok = (k < g.K) && (m < g.M);
-          if (g.period > 0) {
-            const int t = k % g.period + g.a_shift;
-            ok = ok && (t >= 0) && (t < g.period);
-            k += g.a_shift;
-          }
-          if (ok) va = *reinterpret_cast<const uint4*>(A + (int64_t)k * g.lda + m);
+      if (kcur + 16 * i < g.K) {
+        if (kindA == 1) {
+          va = *reinterpret_cast<const uint4*>(paK + (int64_t)(16 * i) * lda_e);
+        } else if (kindA == 2) {
+          int t = t0 + 16 * i;
+          while (t >= g.period) t -= g.period;
+          t += shift;
+          if (t >= 0 && t < g.period) va = *reinterpret_cast<const uint4*>(paK + (int64_t)(16 * i) * lda_e);
+        } else if (kindA == 3) {
+          va.x = 0x3F80u;                                 // bf16 1.0 in the first of the eight rows
         }
-      }
-      {
-        const int n = n0 + ch * 8, k = k0 + kr;
-        if (k < g.K && n < g.N) vb = *reinterpret_cast<const uint4*>(B + (int64_t)k * g.ldb + n);
+        if (n_ok) vb = *reinterpret_cast<const uint4*>(pbK + (int64_t)(16 * i) * g.ldb);
       }
       ra[i] = va;
       rb[i] = vb;
+    }
+    kcur += TBK;
+    paK += (int64_t)TBK * lda_e;
+    pbK += (int64_t)TBK * g.ldb;
+    if (g.period > 0) {
+      t0 += TBK;
+      while (t0 >= g.period) t0 -= g.period;
     }
   };
   auto store_tiles = [&](int buf) {
@@ -349,8 +387,8 @@ __global__ __launch_bounds__(256) void gemm_tn_tr_kernel(GemmArgs g) {
     for (int i = 0; i < CH; ++i) {
       const int c = tid + i * 256;
       const int off = tr_off(c >> 4, c & 15);
-      *reinterpret_cast<uint4*>(As + buf * BK * 256 + off) = ra[i];
-      *reinterpret_cast<uint4*>(Bs + buf * BK * 256 + off) = rb[i];
+      *reinterpret_cast<uint4*>(As + buf * TBK * 256 + off) = ra[i];
+      *reinterpret_cast<uint4*>(Bs + buf * TBK * 256 + off) = rb[i];
     }
   };
   // transposed-read addressing of this lane: group kg = lane>>4 takes k rows 8kg..8kg+7 of each 32-deep step
@@ -366,17 +404,17 @@ __global__ __launch_bounds__(256) void gemm_tn_tr_kernel(GemmArgs g) {
   };
 
   if (kt_begin < kt_end) {
-    load_tiles(kt_begin);
+    load_tiles();
     store_tiles(0);
     __syncthreads();
     int buf = 0;
     for (int kt = kt_begin; kt < kt_end; ++kt) {
       const bool more = (kt + 1 < kt_end);
-      if (more) load_tiles(kt + 1);
-      const unsigned char* as = As + buf * BK * 256;
-      const unsigned char* bs = Bs + buf * BK * 256;
+      if (more) load_tiles();
+      const unsigned char* as = As + buf * TBK * 256;
+      const unsigned char* bs = Bs + buf * TBK * 256;
 #pragma unroll
-      for (int kk = 0; kk < BK; kk += 32) {
+      for (int kk = 0; kk < TBK; kk += 32) {
         bf16x8 af[4], bfr[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) af[i] = frag(as, kk, wr * 8 + 2 * i);
@@ -394,6 +432,24 @@ __global__ __launch_bounds__(256) void gemm_tn_tr_kernel(GemmArgs g) {
     }
   }
 
+  if (g.partial) {
+    // memory-side fp32 atomics cost far more than the product itself at these shapes (~16k per workgroup): every
+    // slice stores its tile plainly (empty slices store zeros) and tn_reduce_kernel sums them
+    float* P = g.partial + (int64_t)bz * g.partial_stride;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int coln = n0 + wc * 64 + j * 16 + (lane & 15);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = m0 + wr * 64 + i * 16 + (lane >> 4) * 4 + r;
+          if (row < g.M && coln < g.N) P[(int64_t)row * g.N + coln] = acc[i][j][r];
+        }
+      }
+    }
+    return;
+  }
   float* Cf = reinterpret_cast<float*>(g.C) + (int64_t)batch * g.sc;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
@@ -412,6 +468,29 @@ __global__ __launch_bounds__(256) void gemm_tn_tr_kernel(GemmArgs g) {
         else Cf[off] += acc[i][j][r];
       }
     }
+  }
+}
+
+// C[row, perm(col)] += sum over slices of partial[slice][row][col] (last row -> bias_row when given); N % 4 == 0.
+__global__ __launch_bounds__(256) void tn_reduce_kernel(const float* __restrict__ P, int64_t stride, int nsl, float* C, int64_t ldc,
+                                                        float* bias_row, int M, int N, int perm_h) {
+  const int n4 = N >> 2;
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (int64_t)M * n4) return;
+  const int row = (int)(idx / n4), c4 = (int)(idx - (int64_t)row * n4);
+  const float* src = P + (int64_t)row * N + 4 * c4;
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 4
+  for (int sl = 0; sl < nsl; ++sl) {
+    const float4 v = *reinterpret_cast<const float4*>(src + (int64_t)sl * stride);
+    s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+  }
+  const float e[4] = {s.x, s.y, s.z, s.w};
+  float* dst = (bias_row && row == M - 1) ? bias_row : C + (int64_t)row * ldc;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int coln = 4 * c4 + i;
+    dst[perm_h > 0 ? (coln & 3) * perm_h + (coln >> 2) : coln] += e[i];
   }
 }
 
@@ -533,7 +612,7 @@ extern "C" int las_gemm_tn(const las_bf16* A, int64_t lda, const las_bf16* B, in
   if (M <= 64 || N <= 64) return launch<64, 64, true>(g, batch, st);
   {
     dim3 grid((N + 127) / 128, (M + 127) / 128, batch * split_k);
-    const size_t lds = (size_t)4 * BK * 256;
+    const size_t lds = (size_t)4 * TBK * 256;
     static bool attr_set = false;
     if (!attr_set) {
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_tr_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -545,9 +624,13 @@ extern "C" int las_gemm_tn(const las_bf16* A, int64_t lda, const las_bf16* B, in
   }
 }
 
+extern "C" size_t las_gemm_tn_lstm_workspace_bytes(int D, int H, int split_k) {
+  return split_k > 1 ? sizeof(float) * (size_t)split_k * (size_t)(D + H + 1) * (size_t)(4 * H) : 0;
+}
+
 extern "C" int las_gemm_tn_lstm(const las_bf16* x, int64_t ldx, int D, const las_bf16* y, int64_t ldy, int H, int a_shift,
                                 int period, const las_bf16* dz, int64_t ldz, float* kernel_grad, float* bias_grad, int K,
-                                int split_k, void* stream) {
+                                int split_k, float* workspace, void* stream) {
   LAS_REQUIRE(D >= 0 && H > 0 && K > 0 && period > 0 && D % 8 == 0 && H % 8 == 0, "las_gemm_tn_lstm: bad shape D=%d H=%d K=%d", D, H, K);
   LAS_REQUIRE((D == 0 || (x && ldx % 8 == 0 && ((uintptr_t)x % 16 == 0))) && y && dz && kernel_grad && bias_grad && ldy % 8 == 0 &&
                   ldz % 8 == 0 && ((uintptr_t)y % 16 == 0) && ((uintptr_t)dz % 16 == 0),
@@ -559,8 +642,12 @@ extern "C" int las_gemm_tn_lstm(const las_bf16* x, int64_t ldx, int D, const las
   g.M1 = D;
   g.M2 = H;
   g.bias_row = bias_grad;
+  if (workspace && split_k > 1) {
+    g.partial = workspace;
+    g.partial_stride = (int64_t)g.M * g.N;
+  }
   dim3 grid((g.N + 127) / 128, (g.M + 127) / 128, split_k);
-  const size_t lds = (size_t)4 * BK * 256;
+  const size_t lds = (size_t)4 * TBK * 256;
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_tr_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -568,5 +655,11 @@ extern "C" int las_gemm_tn_lstm(const las_bf16* x, int64_t ldx, int D, const las
   }
   hipLaunchKernelGGL(gemm_tn_tr_kernel, grid, dim3(256), lds, (hipStream_t)stream, g);
   LAS_LAUNCH_CHECK("lstm weight-gradient gemm launch");
+  if (g.partial) {
+    const int64_t n = (int64_t)g.M * (g.N / 4);
+    hipLaunchKernelGGL(tn_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, g.partial,
+                       g.partial_stride, split_k, kernel_grad, g.ldc, bias_grad, g.M, g.N, H);
+    LAS_LAUNCH_CHECK("lstm weight-gradient reduce launch");
+  }
   return LAS_OK;
 }

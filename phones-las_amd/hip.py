@@ -51,7 +51,8 @@ _SIGS = {
     'las_fe_delta': ([_vp, _i64, _i32, _i32, _vp, _vp, _vp, _i32, _vp, _i64, _i32, _i32, _vp], C.c_int),
     'las_add_masked': ([_vp, _i64, _vp, _i64, _vp, _i64, _i32, _i32, _f32, C.c_uint32, C.c_uint32, C.c_uint64, _i64, _vp], C.c_int),
     'las_add_noise': ([_vp, _i64, _f32, C.c_uint32, C.c_uint32, _vp], C.c_int),
-    'las_gemm_tn_lstm': ([_vp, _i64, C.c_int, _vp, _i64, C.c_int, C.c_int, C.c_int, _vp, _i64, _vp, _vp, C.c_int, C.c_int, _vp], C.c_int),
+    'las_gemm_tn_lstm_workspace_bytes': ([C.c_int, C.c_int, C.c_int], C.c_size_t),
+    'las_gemm_tn_lstm': ([_vp, _i64, C.c_int, _vp, _i64, C.c_int, C.c_int, C.c_int, _vp, _i64, _vp, _vp, C.c_int, C.c_int, _vp, _vp], C.c_int),
     'las_decoder_persist_supported': ([C.c_int] * 5, C.c_int),
     'las_decoder_persist_workspace_bytes': ([C.c_int], C.c_size_t),
     'las_decoder_persist_fwd': ([_vp, _vp], C.c_int),

@@ -246,6 +246,10 @@ def bilstm_backward(rec, dy, d_state, grads, need_dx=True, overlap=None):
             if dx is None:
                 dx = torch.cat(parts, -1) if split_in else (parts[0] if nd == 1 else parts[0] + parts[1])
     split = max(1, min(32, BT // 2048))
+    if D % 8 == 0:
+        # fused product: about 700 workgroups in flight measured best on MI355X (128 x 128 output tiles, K cut in slices)
+        tiles = -(-(D + H + 1) // 128) * -(-(4 * H) // 128)
+        split = max(1, min(32, BT // 512, round(704 / tiles)))
     keepalive = [dz, x, y] + [a for a, _ in (dropped or [])]
     with (overlap or _NoOverlap()).fork(*keepalive):
         for i, (kn, bn) in enumerate(w.names):
@@ -254,10 +258,15 @@ def bilstm_backward(rec, dy, d_state, grads, need_dx=True, overlap=None):
             xa, lda = (dropped[i] if dropped is not None else (x, Dp))
             yi = y.view(BT, nd * H)[:, i * H:]
             if D % 8 == 0:
-                # dK_x, dK_h and db of this direction in one product (dz read once)
+                # dK_x, dK_h and db of this direction in one product (dz read once); the K slices meet in a workspace
+                # owned by this layer (its products run one after the other on one stream)
+                need = hip.lib().las_gemm_tn_lstm_workspace_bytes(D, H, split)
+                ws = getattr(w, '_tn_ws', None)
+                if ws is None or ws.numel() * 4 < need:
+                    ws = w._tn_ws = torch.empty(max(1, need // 4), dtype=torch.float32, device=dev)
                 hip.check(hip.lib().las_gemm_tn_lstm(hip.p(xa) if D > 0 else None, lda, D, hip.p(yi), nd * H, H,
                                                      (-1 if i == 0 else 1), T, hip.p(dzi), nd * 4 * H, hip.p(gk), hip.p(gb),
-                                                     BT, split, hip.stream()))
+                                                     BT, split, hip.p(ws), hip.stream()))
                 continue
             if D > 0:
                 hip.gemm_tn(xa, dzi, gk, D, 4 * H, BT, lda=lda, ldb=nd * 4 * H, ldc=4 * H, split_k=split, c_perm_h=H)

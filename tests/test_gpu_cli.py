@@ -30,7 +30,9 @@ def test_train_resume_infer(tmp_path, capsys):
     common = ['--train', os.path.join(d, 'train.tfr'), '--model_dir', os.path.join(d, 'model'), '--encoder_layers', '2',
               '--encoder_units', '64', '--decoder_layers', '1', '--decoder_units', '64', '--use_pyramidal',
               '--bottom_only', '--pass_hidden_state', '--dropout', '0', '--sampling_probability', '0',
-              '--batch_size', '8', '--num_channels', '13', '--learning_rate', '0.003']
+              '--batch_size', '8', '--num_channels', '13', '--learning_rate', '0.001']
+    # (0.001 = the reference default; at 0.003 Adam turns unstable once the loss is ~0 and the outcome of 1200 steps then
+    #  depends on fp32 summation order -- scripts/gpu_cli_flaky.py)
     train.main(train.parse_args(common + ['--num_epochs', '600']))      # 16 utts / 8 = 2 steps per epoch -> 1200 steps
     out = capsys.readouterr().out
     assert 'finished at global_step 1200' in out
@@ -45,18 +47,18 @@ def test_train_resume_infer(tmp_path, capsys):
     per = infer.main(infer.parse_args(['--data', os.path.join(d, 'train.tfr'), '--vocab', os.path.join(d, 'vocab.txt'),
                                        '--norm', os.path.join(d, 'norm.dmp'), '--model_dir', os.path.join(d, 'model'),
                                        '--num_channels', '13', '--batch_size', '8']))
-    assert per < 40.0
+    assert per < 10.0
     assert len(open(os.path.join(d, 'model', 'infer.txt')).read().split('\n')) == 16
     # beam search over the same checkpoint (infer.py --beam_width) and the stand-alone evaluation (eval.py)
     per_beam = infer.main(infer.parse_args(['--data', os.path.join(d, 'train.tfr'), '--vocab', os.path.join(d, 'vocab.txt'),
                                             '--norm', os.path.join(d, 'norm.dmp'), '--model_dir', os.path.join(d, 'model'),
                                             '--num_channels', '13', '--batch_size', '8', '--beam_width', '3']))
-    assert per_beam < 40.0 and 'Optimistic PER' in capsys.readouterr().out
+    assert per_beam < 10.0 and 'Optimistic PER' in capsys.readouterr().out
     import eval as eval_cli
     loss, ed = eval_cli.main(eval_cli.parse_args(['--data', os.path.join(d, 'train.tfr'), '--vocab', os.path.join(d, 'vocab.txt'),
                                                   '--norm', os.path.join(d, 'norm.dmp'), '--model_dir', os.path.join(d, 'model'),
                                                   '--num_channels', '13', '--batch_size', '8']))
-    assert np.isfinite(loss) and 0.0 <= ed < 0.4
+    assert np.isfinite(loss) and 0.0 <= ed < 0.1
 
 
 def test_train_with_the_reference_default_architecture_flags(tmp_path, capsys):

@@ -137,8 +137,9 @@ def test_bad_arguments_raise():
         hip.gemm_nt(A.cpu(), A, C, 8, 8, 8)     # CPU tensor: no fallback
 
 
-@pytest.mark.parametrize('D,H,B,T,shift', [(40, 64, 3, 20, -1), (128, 64, 2, 37, 1), (0, 128, 2, 16, -1)])
-def test_gemm_tn_lstm_fused_weight_gradients(D, H, B, T, shift):
+@pytest.mark.parametrize('use_ws', [True, False])
+@pytest.mark.parametrize('D,H,B,T,shift', [(40, 64, 3, 20, -1), (128, 64, 2, 37, 1), (0, 128, 2, 16, -1), (40, 256, 8, 100, 1)])
+def test_gemm_tn_lstm_fused_weight_gradients(D, H, B, T, shift, use_ws):
     """las_gemm_tn_lstm: dK_x, dK_h (row-shifted h) and db of one LSTM direction in one product, against float64.
     dz arrives with gate-interleaved columns (u*4+g); outputs are in TF column order (g*H+u)."""
     from phones_las_amd import hip
@@ -155,11 +156,18 @@ def test_gemm_tn_lstm_fused_weight_gradients(D, H, B, T, shift):
             ysh[k] = yi[k + shift].double()
     ref_k = torch.cat([x[:, :D].double().t() @ dz_tf, ysh.t() @ dz_tf], 0)
     ref_b = dz_tf.sum(0)
-    gk = torch.zeros(D + H, 4 * H, device='cuda')
-    gb = torch.zeros(4 * H, device='cuda')
+    # outputs ACCUMULATE: start from a known non-zero state; split 11 leaves empty K slices on the small shapes
+    gk = torch.full((D + H, 4 * H), 0.5, device='cuda')
+    gb = torch.full((4 * H,), -0.25, device='cuda')
     xd, yd, dzd = x.cuda(), y.cuda(), dz.cuda()
+    split = 11
+    ws = None
+    if use_ws:
+        need = hip.lib().las_gemm_tn_lstm_workspace_bytes(D, H, split)
+        assert need == 4 * split * (D + H + 1) * 4 * H
+        ws = torch.full((need // 4,), float('nan'), device='cuda')           # every word must be overwritten before use
     hip.check(hip.lib().las_gemm_tn_lstm(hip.p(xd) if D else None, Dp, D, hip.addr(yd, H), 2 * H, H, shift, T,
-                                         hip.addr(dzd, 4 * H), 8 * H, hip.p(gk), hip.p(gb), K, 3, hip.stream()))
+                                         hip.addr(dzd, 4 * H), 8 * H, hip.p(gk), hip.p(gb), K, split, hip.p(ws), hip.stream()))
     torch.cuda.synchronize()
-    _close(gk, ref_k)
-    _close(gb, ref_b)
+    _close(gk - 0.5, ref_k)
+    _close(gb + 0.25, ref_b)
