@@ -166,15 +166,21 @@ def main():
     U = c['U']
     loss_buf = torch.zeros(1, device=dev)
 
-    def part_a():     # zero grads, forward, loss, backward, L2 + per-tensor clip
+    def part_a():     # zero grads, forward, loss, backward, L2 term + per-tensor norms (+ clip before the all-reduce)
         model.vars.grad.zero_()
         audio, _, dlogits = model.forward_train(feats, labels, num_steps=U)
-        loss_buf.copy_(audio + model.l2_loss())
         model.backward(dlogits)
-        model.clip_gradients()
+        if world > 1:
+            model.clip_gradients()
+        else:
+            model.gradient_norms()
+        loss_buf.copy_(audio + model.l2_loss(from_norms=True))
 
-    def part_b():     # Adam + refresh of the bf16 weight images
-        model.adam_update()
+    def part_b():     # (clip +) Adam + refresh of the bf16 weight images
+        if world > 1:
+            model.adam_update()
+        else:
+            model.clip_adam_update()
         model.refresh_images()
 
     def reduce():

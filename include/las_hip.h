@@ -420,9 +420,10 @@ int las_ctc_loss(const float* logits, int64_t ldl, const int32_t* labels, int64_
 
 /* out[0] += sum_i x[i]^2 (the L2 regulariser value of model_helper.py:411-413 is scale/2 times this). */
 int las_sumsq(const float* x, int64_t n, float* out, void* stream);
-/* grads[i] += l2_scale * params[i]; sumsq[s] = ||grads_s||^2  (sumsq zeroed inside). */
+/* grads[i] += l2_scale * params[i]; sumsq[s] = ||grads_s||^2  (sumsq zeroed inside).  param_sumsq (nullable):
+ * *param_sumsq = sum_i params[i]^2 from the same pass (the value las_sumsq(params) would give). */
 int las_grad_l2_norms(float* grads, const float* params, const int64_t* seg_offsets, int nseg,
-                      int64_t total, float l2_scale, float* sumsq, void* stream);
+                      int64_t total, float l2_scale, float* sumsq, float* param_sumsq, void* stream);
 /* grads_s *= clip / max(||grads_s||, clip)  (clip_by_norm, model_helper.py:416). */
 int las_grad_clip(float* grads, const int64_t* seg_offsets, int nseg, int64_t total, const float* sumsq,
                   float clip, void* stream);
@@ -430,6 +431,11 @@ int las_grad_clip(float* grads, const int64_t* seg_offsets, int nseg, int64_t to
  * *step_dev when step_dev != NULL (a device counter: keeps a captured hipGraph replayable). */
 int las_adam_update(float* params, float* m, float* v, const float* grads, int64_t total, float lr,
                     float beta1, float beta2, float eps, int step, const int32_t* step_dev, void* stream);
+/* las_grad_clip followed by las_adam_update in one pass over the buffers (single replica: nothing happens between
+ * the two); grads holds the clipped gradient afterwards, exactly as after las_grad_clip. */
+int las_clip_adam_update(float* params, float* m, float* v, float* grads, const int64_t* seg_offsets, int nseg,
+                         int64_t total, const float* sumsq, float clip, float lr, float beta1, float beta2, float eps,
+                         int step, const int32_t* step_dev, void* stream);
 /* *counter += delta on the stream (tf.train.get_global_step increment, model_helper.py:417). */
 int las_counter_add(int32_t* counter, int32_t delta, void* stream);
 

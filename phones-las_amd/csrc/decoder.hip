@@ -1176,7 +1176,14 @@ __global__ __launch_bounds__(256) void seq_ce_kernel(const float* logits, int64_
       }
     }
   }
-  if (lane == 0 && local_loss != 0.f) atomicAdd(loss_out, local_loss);
+  // one atomic per workgroup: thousands of same-address atomics cost more than the rows themselves
+  __shared__ float wl[4];
+  if (lane == 0) wl[wave] = local_loss;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const float v = wl[0] + wl[1] + wl[2] + wl[3];
+    if (v != 0.f) atomicAdd(loss_out, v);
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1423,7 +1430,7 @@ extern "C" int las_seq_ce_loss(const float* logits, int64_t ldl, const int32_t* 
                                void* stream) {
   LAS_REQUIRE(B > 0 && U > 0 && V > 0, "las_seq_ce_loss: bad shape");
   int blocks = (B * U + 3) / 4;
-  if (blocks > 1024) blocks = 1024;
+  if (blocks > 256) blocks = 256;
   hipLaunchKernelGGL(seq_ce_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, logits, ldl, targets, target_len, B,
                      U, V, grad_scale, loss_out, dlogits, ldd);
   LAS_LAUNCH_CHECK("seq ce launch");

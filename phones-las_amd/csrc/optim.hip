@@ -8,7 +8,7 @@
 
 namespace {
 
-constexpr int CHUNK = 4096;   // elements per workgroup pass
+constexpr int SPAN = 16384;   // elements per workgroup (a contiguous range: one segment search per workgroup)
 
 __device__ __forceinline__ int find_seg(const int64_t* off, int nseg, int64_t i) {
   int lo = 0, hi = nseg - 1;
@@ -19,68 +19,145 @@ __device__ __forceinline__ int find_seg(const int64_t* off, int nseg, int64_t i)
   return lo;
 }
 
-__global__ __launch_bounds__(256) void l2_norm_kernel(float* g, const float* p, const int64_t* off, int nseg, int64_t total,
-                                                      float l2, float* sumsq) {
-  __shared__ float red[4];
-  for (int64_t base = (int64_t)blockIdx.x * CHUNK; base < total; base += (int64_t)gridDim.x * CHUNK) {
-    const int64_t end = min(total, base + CHUNK);
-    const int seg0 = find_seg(off, nseg, base);
-    const int seg1 = find_seg(off, nseg, end - 1);
-    if (seg0 == seg1) {
-      // the common case: the whole chunk lies inside one tensor (no per-element search)
-      float acc = 0.f;
-      for (int64_t i = base + threadIdx.x; i < end; i += 256) {
-        const float v = g[i] + l2 * p[i];
-        g[i] = v;
-        acc += v * v;
-      }
-      const float v = las_wave_sum(acc);
-      __syncthreads();
-      if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
-      __syncthreads();
-      if (threadIdx.x == 0) atomicAdd(sumsq + seg0, red[0] + red[1] + red[2] + red[3]);
+__device__ __forceinline__ float block_sum(float v, float* red) {
+  v = las_wave_sum(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return red[0] + red[1] + red[2] + red[3];
+}
+
+// Walks the pieces [cur, stop) of this workgroup's range that lie inside one tensor and calls body(i, n) for runs of
+// n = 4 (16-byte aligned) or n = 1 elements; `flush(seg)` runs after every piece.  Same-address atomics are the cost
+// to avoid here: one per (workgroup, tensor piece) instead of one per 4096 elements.
+template <typename Body, typename Flush>
+__device__ __forceinline__ void for_each_piece(const int64_t* off, int nseg, int64_t total, Body body, Flush flush) {
+  const int64_t start = (int64_t)blockIdx.x * SPAN;
+  const int64_t end = min(total, start + SPAN);
+  if (start >= end) return;
+  int seg = find_seg(off, nseg, start);
+  int64_t cur = start;
+  while (cur < end) {
+    const int64_t stop = (seg + 1 < nseg) ? min(end, off[seg + 1]) : end;
+    if ((cur & 3) == 0) {
+      const int64_t n4 = (stop - cur) >> 2;
+      for (int64_t q = threadIdx.x; q < n4; q += 256) body(cur + 4 * q, 4, seg);
+      for (int64_t i = cur + 4 * n4 + threadIdx.x; i < stop; i += 256) body(i, 1, seg);
     } else {
-      // the chunk straddles tensor boundaries: accumulate per run of equal segment
-      int seg = -1;
-      float acc = 0.f;
-      for (int64_t i = base + threadIdx.x; i < end; i += 256) {
-        const int sgi = find_seg(off, nseg, i);
-        const float v = g[i] + l2 * p[i];
-        g[i] = v;
-        if (sgi != seg) {
-          if (seg >= 0) atomicAdd(sumsq + seg, acc);
-          seg = sgi;
-          acc = 0.f;
-        }
-        acc += v * v;
-      }
-      if (seg >= 0) atomicAdd(sumsq + seg, acc);
+      for (int64_t i = cur + threadIdx.x; i < stop; i += 256) body(i, 1, seg);
     }
+    flush(seg);
+    cur = stop;
+    ++seg;
+  }
+}
+
+__global__ __launch_bounds__(256) void l2_norm_kernel(float* g, const float* p, const int64_t* off, int nseg, int64_t total,
+                                                      float l2, float* sumsq, float* param_sumsq) {
+  __shared__ float red[4];
+  float acc = 0.f, pacc = 0.f;
+  for_each_piece(off, nseg, total,
+      [&](int64_t i, int n, int) {
+        if (n == 4) {
+          float4 gv = *reinterpret_cast<const float4*>(g + i);
+          const float4 pv = *reinterpret_cast<const float4*>(p + i);
+          gv.x += l2 * pv.x; gv.y += l2 * pv.y; gv.z += l2 * pv.z; gv.w += l2 * pv.w;
+          *reinterpret_cast<float4*>(g + i) = gv;
+          acc += gv.x * gv.x + gv.y * gv.y + gv.z * gv.z + gv.w * gv.w;
+          pacc += pv.x * pv.x + pv.y * pv.y + pv.z * pv.z + pv.w * pv.w;
+        } else {
+          const float pv = p[i], v = g[i] + l2 * pv;
+          g[i] = v;
+          acc += v * v;
+          pacc += pv * pv;
+        }
+      },
+      [&](int seg) {
+        const float v = block_sum(acc, red);
+        if (threadIdx.x == 0) atomicAdd(sumsq + seg, v);
+        acc = 0.f;
+      });
+  if (param_sumsq) {
+    const float v = block_sum(pacc, red);
+    if (threadIdx.x == 0) atomicAdd(param_sumsq, v);
   }
 }
 
 __global__ __launch_bounds__(256) void clip_kernel(float* g, const int64_t* off, int nseg, int64_t total, const float* sumsq,
                                                    float clip) {
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-    const int sgi = find_seg(off, nseg, i);
-    const float n = sqrtf(sumsq[sgi]);
-    g[i] = g[i] * (clip / fmaxf(n, clip));
-  }
+  for_each_piece(off, nseg, total,
+      [&](int64_t i, int n, int seg) {
+        const float sc = clip / fmaxf(sqrtf(sumsq[seg]), clip);
+        if (n == 4) {
+          float4 gv = *reinterpret_cast<const float4*>(g + i);
+          gv.x *= sc; gv.y *= sc; gv.z *= sc; gv.w *= sc;
+          *reinterpret_cast<float4*>(g + i) = gv;
+        } else {
+          g[i] *= sc;
+        }
+      },
+      [](int) {});
+}
+
+// lr_t = lr * sqrt(1 - b2^t) / (1 - b1^t); t read from device memory when given (graph replay)
+__device__ __forceinline__ float adam_lr_t(float lr, float b1, float b2, int step, const int32_t* step_dev) {
+  const double t = (double)(step_dev ? *step_dev : step);
+  return (float)((double)lr * sqrt(1.0 - pow((double)b2, t)) / (1.0 - pow((double)b1, t)));
+}
+
+__device__ __forceinline__ void adam_one(float& p, float& m, float& v, float gi, float lr_t, float b1, float b2, float eps) {
+  m = b1 * m + (1.f - b1) * gi;
+  v = b2 * v + (1.f - b2) * gi * gi;
+  p = p - lr_t * m / (sqrtf(v) + eps);
 }
 
 __global__ __launch_bounds__(256) void adam_kernel(float* p, float* m, float* v, const float* g, int64_t total, float lr,
                                                    float b1, float b2, float eps, int step, const int32_t* step_dev) {
-  // lr_t = lr * sqrt(1 - b2^t) / (1 - b1^t); t read from device memory when given (graph replay)
-  const double t = (double)(step_dev ? *step_dev : step);
-  const float lr_t = (float)((double)lr * sqrt(1.0 - pow((double)b2, t)) / (1.0 - pow((double)b1, t)));
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-    const float gi = g[i];
-    const float mi = b1 * m[i] + (1.f - b1) * gi;
-    const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
-    m[i] = mi;
-    v[i] = vi;
-    p[i] = p[i] - lr_t * mi / (sqrtf(vi) + eps);
+  const float lr_t = adam_lr_t(lr, b1, b2, step, step_dev);
+  const int64_t n4 = total >> 2;
+  for (int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x; q < n4; q += (int64_t)gridDim.x * 256) {
+    const float4 gv = reinterpret_cast<const float4*>(g)[q];
+    float4 pv = reinterpret_cast<float4*>(p)[q], mv = reinterpret_cast<float4*>(m)[q], vv = reinterpret_cast<float4*>(v)[q];
+    adam_one(pv.x, mv.x, vv.x, gv.x, lr_t, b1, b2, eps);
+    adam_one(pv.y, mv.y, vv.y, gv.y, lr_t, b1, b2, eps);
+    adam_one(pv.z, mv.z, vv.z, gv.z, lr_t, b1, b2, eps);
+    adam_one(pv.w, mv.w, vv.w, gv.w, lr_t, b1, b2, eps);
+    reinterpret_cast<float4*>(p)[q] = pv;
+    reinterpret_cast<float4*>(m)[q] = mv;
+    reinterpret_cast<float4*>(v)[q] = vv;
   }
+  for (int64_t i = 4 * n4 + (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256)
+    adam_one(p[i], m[i], v[i], g[i], lr_t, b1, b2, eps);
+}
+
+// clip_by_norm and the Adam update in one pass (single replica: nothing happens between them); the clipped gradient is
+// written back so that the gradient buffer reads the same as after las_grad_clip.
+__global__ __launch_bounds__(256) void clip_adam_kernel(float* p, float* m, float* v, float* g, const int64_t* off, int nseg,
+                                                        int64_t total, const float* sumsq, float clip, float lr, float b1,
+                                                        float b2, float eps, int step, const int32_t* step_dev) {
+  const float lr_t = adam_lr_t(lr, b1, b2, step, step_dev);
+  for_each_piece(off, nseg, total,
+      [&](int64_t i, int n, int seg) {
+        const float sc = clip / fmaxf(sqrtf(sumsq[seg]), clip);
+        if (n == 4) {
+          float4 gv = *reinterpret_cast<const float4*>(g + i);
+          float4 pv = *reinterpret_cast<float4*>(p + i), mv = *reinterpret_cast<float4*>(m + i), vv = *reinterpret_cast<float4*>(v + i);
+          gv.x *= sc; gv.y *= sc; gv.z *= sc; gv.w *= sc;
+          adam_one(pv.x, mv.x, vv.x, gv.x, lr_t, b1, b2, eps);
+          adam_one(pv.y, mv.y, vv.y, gv.y, lr_t, b1, b2, eps);
+          adam_one(pv.z, mv.z, vv.z, gv.z, lr_t, b1, b2, eps);
+          adam_one(pv.w, mv.w, vv.w, gv.w, lr_t, b1, b2, eps);
+          *reinterpret_cast<float4*>(g + i) = gv;
+          *reinterpret_cast<float4*>(p + i) = pv;
+          *reinterpret_cast<float4*>(m + i) = mv;
+          *reinterpret_cast<float4*>(v + i) = vv;
+        } else {
+          const float gi = g[i] * sc;
+          g[i] = gi;
+          adam_one(p[i], m[i], v[i], gi, lr_t, b1, b2, eps);
+        }
+      },
+      [](int) {});
 }
 
 __global__ __launch_bounds__(256) void sumsq_kernel(const float* x, int64_t n, float* out) {
@@ -113,14 +190,18 @@ extern "C" int las_sumsq(const float* x, int64_t n, float* out, void* stream) {
 }
 
 extern "C" int las_grad_l2_norms(float* grads, const float* params, const int64_t* seg_offsets, int nseg, int64_t total,
-                                 float l2_scale, float* sumsq, void* stream) {
+                                 float l2_scale, float* sumsq, float* param_sumsq, void* stream) {
   LAS_REQUIRE(nseg > 0 && total > 0, "las_grad_l2_norms: empty");
+  LAS_REQUIRE(((uintptr_t)grads % 16 == 0) && ((uintptr_t)params % 16 == 0), "las_grad_l2_norms: buffers must be 16-byte aligned");
   hipStream_t st = (hipStream_t)stream;
   int rc = las_check_hip(hipMemsetAsync(sumsq, 0, sizeof(float) * nseg, st), "memset sumsq");
   if (rc) return rc;
-  int blocks = (int)((total + CHUNK - 1) / CHUNK);
-  if (blocks > 2048) blocks = 2048;
-  hipLaunchKernelGGL(l2_norm_kernel, dim3(blocks), dim3(256), 0, st, grads, params, seg_offsets, nseg, total, l2_scale, sumsq);
+  if (param_sumsq) {
+    rc = las_check_hip(hipMemsetAsync(param_sumsq, 0, sizeof(float), st), "memset param_sumsq");
+    if (rc) return rc;
+  }
+  hipLaunchKernelGGL(l2_norm_kernel, dim3((unsigned)((total + SPAN - 1) / SPAN)), dim3(256), 0, st, grads, params, seg_offsets, nseg,
+                     total, l2_scale, sumsq, param_sumsq);
   LAS_LAUNCH_CHECK("l2 norm launch");
   return LAS_OK;
 }
@@ -128,9 +209,9 @@ extern "C" int las_grad_l2_norms(float* grads, const float* params, const int64_
 extern "C" int las_grad_clip(float* grads, const int64_t* seg_offsets, int nseg, int64_t total, const float* sumsq,
                              float clip, void* stream) {
   LAS_REQUIRE(nseg > 0 && total > 0 && clip > 0.f, "las_grad_clip: bad arguments");
-  int blocks = (int)((total + 1023) / 1024);
-  if (blocks > 2048) blocks = 2048;
-  hipLaunchKernelGGL(clip_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, grads, seg_offsets, nseg, total, sumsq, clip);
+  LAS_REQUIRE((uintptr_t)grads % 16 == 0, "las_grad_clip: buffer must be 16-byte aligned");
+  hipLaunchKernelGGL(clip_kernel, dim3((unsigned)((total + SPAN - 1) / SPAN)), dim3(256), 0, (hipStream_t)stream, grads, seg_offsets,
+                     nseg, total, sumsq, clip);
   LAS_LAUNCH_CHECK("clip launch");
   return LAS_OK;
 }
@@ -138,10 +219,22 @@ extern "C" int las_grad_clip(float* grads, const int64_t* seg_offsets, int nseg,
 extern "C" int las_adam_update(float* params, float* m, float* v, const float* grads, int64_t total, float lr,
                                float beta1, float beta2, float eps, int step, const int32_t* step_dev, void* stream) {
   LAS_REQUIRE(total > 0 && (step >= 1 || step_dev), "las_adam_update: bad arguments");
-  int blocks = (int)((total + 1023) / 1024);
+  LAS_REQUIRE((((uintptr_t)params | (uintptr_t)m | (uintptr_t)v | (uintptr_t)grads) % 16) == 0, "las_adam_update: buffers must be 16-byte aligned");
+  int blocks = (int)((total + 4095) / 4096);
   if (blocks > 2048) blocks = 2048;
   hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, params, m, v, grads, total, lr,
                      beta1, beta2, eps, step, step_dev);
   LAS_LAUNCH_CHECK("adam launch");
+  return LAS_OK;
+}
+
+extern "C" int las_clip_adam_update(float* params, float* m, float* v, float* grads, const int64_t* seg_offsets, int nseg,
+                                    int64_t total, const float* sumsq, float clip, float lr, float beta1, float beta2,
+                                    float eps, int step, const int32_t* step_dev, void* stream) {
+  LAS_REQUIRE(nseg > 0 && total > 0 && clip > 0.f && (step >= 1 || step_dev), "las_clip_adam_update: bad arguments");
+  LAS_REQUIRE((((uintptr_t)params | (uintptr_t)m | (uintptr_t)v | (uintptr_t)grads) % 16) == 0, "las_clip_adam_update: buffers must be 16-byte aligned");
+  hipLaunchKernelGGL(clip_adam_kernel, dim3((unsigned)((total + SPAN - 1) / SPAN)), dim3(256), 0, (hipStream_t)stream, params, m, v,
+                     grads, seg_offsets, nseg, total, sumsq, clip, lr, beta1, beta2, eps, step, step_dev);
+  LAS_LAUNCH_CHECK("clip + adam launch");
   return LAS_OK;
 }

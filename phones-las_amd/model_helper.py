@@ -108,6 +108,7 @@ class Variables:
         self.seg = torch.tensor(offs, dtype=torch.int64, device=device)
         self.device = device
         self.sumsq = torch.zeros(len(self.table), dtype=f32, device=device)
+        self.param_sumsq = torch.zeros(1, dtype=f32, device=device)      # sum theta^2, by-product of the norms pass
         self.params = self._views(self.flat)
         self.grads = self._views(self.grad)
 
@@ -313,14 +314,20 @@ class LasModel:
         self.listener.backward(dmem, ds, g, self.overlap)
         self.overlap.join()
 
+    def gradient_norms(self):
+        """grad += l2 * theta (gradient of the L2 term, model_helper.py:411-413) and per-tensor ||grad||^2; the same pass
+        leaves sum theta^2 (the value of the L2 term) in vars.param_sumsq."""
+        v, p = self.vars, self.params
+        hip.check(hip.lib().las_grad_l2_norms(hip.p(v.grad), hip.p(v.flat), hip.p(v.seg), len(v.table), v.total,
+                                              float(p.l2_reg_scale) / self.world_size, hip.p(v.sumsq), hip.p(v.param_sumsq),
+                                              hip.stream()))
+
     def clip_gradients(self):
         """L2 gradient + per-tensor clip_by_norm(GRAD_NORM) on the flat buffers (model_helper.py:411-416)."""
-        v, p = self.vars, self.params
-        lib, st = hip.lib(), hip.stream()
-        nseg = len(v.table)
-        hip.check(lib.las_grad_l2_norms(hip.p(v.grad), hip.p(v.flat), hip.p(v.seg), nseg, v.total,
-                                        float(p.l2_reg_scale) / self.world_size, hip.p(v.sumsq), st))
-        hip.check(lib.las_grad_clip(hip.p(v.grad), hip.p(v.seg), nseg, v.total, hip.p(v.sumsq), float(GRAD_NORM), st))
+        v = self.vars
+        self.gradient_norms()
+        hip.check(hip.lib().las_grad_clip(hip.p(v.grad), hip.p(v.seg), len(v.table), v.total, hip.p(v.sumsq), float(GRAD_NORM),
+                                          hip.stream()))
 
     def all_reduce_gradients(self):
         """CrossShardOptimizer's cross-replica sum (model_helper.py:405-406): one RCCL all-reduce, after the clip."""
@@ -336,10 +343,24 @@ class LasModel:
         hip.check(lib.las_counter_add(hip.p(self.step_dev), 1, st))
         self._images_stale = True
 
+    def clip_adam_update(self):
+        """Single replica: the clip and the Adam update in one pass over the buffers (after gradient_norms)."""
+        v, p = self.vars, self.params
+        lib, st = hip.lib(), hip.stream()
+        hip.check(lib.las_clip_adam_update(hip.p(v.flat), hip.p(v.m), hip.p(v.v), hip.p(v.grad), hip.p(v.seg), len(v.table),
+                                           v.total, hip.p(v.sumsq), float(GRAD_NORM), float(p.learning_rate), 0.9, 0.999, 1e-8,
+                                           0, hip.p(self.step_dev), st))
+        hip.check(lib.las_counter_add(hip.p(self.step_dev), 1, st))
+        self._images_stale = True
+
     def apply_gradients(self):
-        self.clip_gradients()
-        self.all_reduce_gradients()
-        self.adam_update()
+        if self.world_size == 1:
+            self.gradient_norms()
+            self.clip_adam_update()
+        else:
+            self.clip_gradients()
+            self.all_reduce_gradients()
+            self.adam_update()
 
     def maybe_add_noise(self):
         """model_helper.py:418-432: every `add_noise` steps (and not at step 0) add N(0, noise_std) to every variable
@@ -356,7 +377,11 @@ class LasModel:
                                             1000 + i, st))
         self._images_stale = True
 
-    def l2_loss(self):
+    def l2_loss(self, from_norms=False):
+        """scale * sum(theta^2) / 2 (model_helper.py:411-413).  from_norms: take sum theta^2 from the last gradient_norms()
+        pass (the parameters of this step, before the update) instead of another pass over the parameters."""
+        if from_norms:
+            return self.vars.param_sumsq * (0.5 * float(self.params.l2_reg_scale))
         out = torch.zeros(1, dtype=torch.float32, device='cuda')
         hip.check(hip.lib().las_sumsq(hip.p(self.vars.flat), self.vars.total, hip.p(out), hip.stream()))
         return out * (0.5 * float(self.params.l2_reg_scale))
@@ -365,9 +390,9 @@ class LasModel:
         """One optimiser step; returns the loss (audio loss + L2 term) as a device scalar tensor."""
         self.vars.grad.zero_()
         audio_loss, _, dlogits = self.forward_train(features, labels, num_steps)
-        loss = audio_loss + self.l2_loss()
         self.backward(dlogits)
         self.apply_gradients()
+        loss = audio_loss + self.l2_loss(from_norms=True)
         self.maybe_add_noise()
         self.refresh_images()
         self.global_step += 1

@@ -47,7 +47,7 @@ def test_train_forward_and_gradients_vs_oracle(att):
     from phones_las_amd import hip
     v = model.vars
     hip.check(hip.lib().las_grad_l2_norms(hip.p(v.grad), hip.p(v.flat), hip.p(v.seg), len(v.table), v.total,
-                                          float(hp.l2_reg_scale), hip.p(v.sumsq), hip.stream()))
+                                          float(hp.l2_reg_scale), hip.p(v.sumsq), None, hip.stream()))
     torch.cuda.synchronize()
     for i, (name, _, _) in enumerate(v.table):
         g, r = v.grads[name], out['grads'][name]
@@ -81,6 +81,61 @@ def test_train_step_updates_match_oracle_adam_given_same_grads():
     torch.cuda.synchronize()
     for n in grads:
         assert float((v.params[n].double().cpu() - newp2[n]).abs().max()) < 5e-6, n
+
+
+def test_train_op_kernels_on_unaligned_tensor_boundaries():
+    """las_grad_l2_norms / las_grad_clip / las_adam_update / las_clip_adam_update on flat buffers whose tensor
+    boundaries are NOT multiples of 4 and span several workgroup ranges: against float64 torch, and the fused
+    clip + Adam pass against the two separate kernels."""
+    from phones_las_amd import hip
+    lib = hip.lib()
+    sizes = [5, 1, 40003, 7, 16384, 3, 50001, 2]
+    offs = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+    total, nseg = int(offs[-1]), len(sizes)
+    gen = torch.Generator().manual_seed(3)
+    g0 = torch.randn(total, generator=gen) * torch.repeat_interleave(torch.tensor([3.0, 0.01] * 4), torch.tensor(sizes))
+    p0, m0, v0 = torch.randn(total, generator=gen), torch.randn(total, generator=gen) * 0.1, torch.rand(total, generator=gen) * 0.01
+    seg = torch.from_numpy(offs).cuda()
+    l2, clip, lr, t = 1e-3, 2.0, 1e-3, 3
+    step_dev = torch.tensor([t], dtype=torch.int32, device='cuda')
+    # float64 reference
+    full = g0.double() + l2 * p0.double()
+    clipped = full.clone()
+    norms = []
+    for i in range(nseg):
+        sl = slice(int(offs[i]), int(offs[i + 1]))
+        n = float(full[sl].norm())
+        norms.append(n * n)
+        clipped[sl] = full[sl] * clip / max(n, clip)
+    m1 = 0.9 * m0.double() + 0.1 * clipped
+    v1 = 0.999 * v0.double() + 0.001 * clipped * clipped
+    lr_t = lr * np.sqrt(1 - 0.999 ** t) / (1 - 0.9 ** t)
+    p1 = p0.double() - lr_t * m1 / (v1.sqrt() + 1e-8)
+
+    def run(fused):
+        g, p, m, v = g0.cuda(), p0.cuda(), m0.cuda(), v0.cuda()
+        sumsq = torch.full((nseg,), float('nan'), device='cuda')
+        psq = torch.full((1,), float('nan'), device='cuda')
+        hip.check(lib.las_grad_l2_norms(hip.p(g), hip.p(p), hip.p(seg), nseg, total, l2, hip.p(sumsq), hip.p(psq), hip.stream()))
+        if fused:
+            hip.check(lib.las_clip_adam_update(hip.p(p), hip.p(m), hip.p(v), hip.p(g), hip.p(seg), nseg, total, hip.p(sumsq), clip,
+                                               lr, 0.9, 0.999, 1e-8, 0, hip.p(step_dev), hip.stream()))
+        else:
+            hip.check(lib.las_grad_clip(hip.p(g), hip.p(seg), nseg, total, hip.p(sumsq), clip, hip.stream()))
+            hip.check(lib.las_adam_update(hip.p(p), hip.p(m), hip.p(v), hip.p(g), total, lr, 0.9, 0.999, 1e-8, 0, hip.p(step_dev),
+                                          hip.stream()))
+        torch.cuda.synchronize()
+        return [x.cpu() for x in (g, p, m, v, sumsq, psq)]
+
+    sep, fus = run(False), run(True)
+    for a, b in zip(sep[:4], fus[:4]):        # same arithmetic; only the compiler's choice of fused multiply-adds may differ
+        assert float((a - b).abs().max()) <= 1e-6 * float(a.abs().max())
+    g, p, m, v, sumsq, psq = fus
+    assert np.allclose(sumsq.double().numpy(), norms, rtol=1e-4)
+    assert abs(float(psq) - float((p0.double() ** 2).sum())) < 1e-4 * float((p0.double() ** 2).sum())
+    assert float((g.double() - clipped).abs().max()) < 1e-5 * float(clipped.abs().max())
+    assert float((m.double() - m1).abs().max()) < 1e-6 and float((v.double() - v1).abs().max()) < 1e-6
+    assert float((p.double() - p1).abs().max()) < 1e-5
 
 
 def test_seq_ce_loss_kernel_vs_oracle():
