@@ -113,6 +113,22 @@ int las_cast_bf16(const float* src, int64_t lds, int rows, int cols, las_bf16* d
                   int dst_rows, int dst_cols, int transpose, int batch, int64_t src_bstride,
                   int64_t dst_bstride, int src_col_perm_h, void* stream);
 
+/* The image rebuilds of a whole model in one launch (after every optimiser step the bf16 operand copies of the fp32
+ * master weights are rebuilt; one launch per image is launch-bound).  `jobs_dev` is a DEVICE array of njobs entries:
+ *   LAS_IMAGE_CAST            the las_cast_bf16 window (batch 1) with the same field meanings;
+ *   LAS_IMAGE_PACK_RECURRENT  las_lstm_pack_recurrent: src = K_h (ld 4H), rows = H, dst = packed image;
+ *   LAS_IMAGE_BIAS_INTERLEAVE fp32 dst[u*4+g] = src[g*H+u], rows = H (the LSTM bias in the recurrent kernels' order);
+ *   LAS_IMAGE_COPY_F32        fp32 dst[0:cols] = src[0:cols]. */
+enum las_image_kind { LAS_IMAGE_CAST = 0, LAS_IMAGE_PACK_RECURRENT = 1, LAS_IMAGE_BIAS_INTERLEAVE = 2, LAS_IMAGE_COPY_F32 = 3 };
+typedef struct las_image_job {
+  const float* src;
+  void* dst;
+  int64_t lds, ldd;
+  int32_t rows, cols, dst_rows, dst_cols;
+  int32_t transpose, perm_h, kind, reserved;
+} las_image_job;
+int las_refresh_images(const las_image_job* jobs_dev, int njobs, void* stream);
+
 /* out[n] += sum_m X[m, n] for a bf16 [M,N] matrix (bias gradients).  out_perm_h = H > 0: X's columns are
  * gate-interleaved (u*4+g) and the sum of column n lands at TF index g*H+u. */
 int las_colsum_bf16(const las_bf16* X, int64_t ldx, int M, int N, float* out, int out_perm_h, void* stream);

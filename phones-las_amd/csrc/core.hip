@@ -41,6 +41,41 @@ __global__ void cast_kernel(const float* src, int64_t lds_, int rows, int cols, 
   }
 }
 
+// All bf16 / re-ordered images of the fp32 master weights in ONE launch (they are rebuilt after every optimiser step:
+// ~40 tiny launches otherwise).  blockIdx.y selects the job; the job table lives in device memory.
+__global__ __launch_bounds__(256) void refresh_images_kernel(const las_image_job* jobs) {
+  const las_image_job jb = jobs[blockIdx.y];
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  const int64_t first = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (jb.kind == LAS_IMAGE_CAST) {
+    unsigned short* dst = static_cast<unsigned short*>(jb.dst);
+    const int64_t total = (int64_t)jb.dst_rows * jb.dst_cols;
+    for (int64_t i = first; i < total; i += stride) {
+      const int dr = (int)(i / jb.dst_cols), dc = (int)(i % jb.dst_cols);
+      const int sr = jb.transpose ? dc : dr;
+      int sc = jb.transpose ? dr : dc;
+      float v = 0.f;
+      if (sr < jb.rows && sc < jb.cols) {
+        if (jb.perm_h > 0) sc = (sc & 3) * jb.perm_h + (sc >> 2);
+        v = jb.src[(int64_t)sr * jb.lds + sc];
+      }
+      dst[(int64_t)dr * jb.ldd + dc] = las_f2bf(v);
+    }
+  } else if (jb.kind == LAS_IMAGE_PACK_RECURRENT) {
+    unsigned short* dst = static_cast<unsigned short*>(jb.dst);
+    const int H = jb.rows;
+    const int64_t total = (int64_t)H * 4 * H;
+    for (int64_t i = first; i < total; i += stride) dst[i] = las_f2bf(jb.src[las_pack_recurrent_src(i, H)]);
+  } else if (jb.kind == LAS_IMAGE_BIAS_INTERLEAVE) {
+    float* dst = static_cast<float*>(jb.dst);
+    const int H = jb.rows;
+    for (int64_t i = first; i < 4 * (int64_t)H; i += stride) dst[i] = jb.src[(i & 3) * H + (i >> 2)];     // [u*4+g] <- [g*H+u]
+  } else {                                                  // LAS_IMAGE_COPY_F32
+    float* dst = static_cast<float*>(jb.dst);
+    for (int64_t i = first; i < jb.cols; i += stride) dst[i] = jb.src[i];
+  }
+}
+
 __global__ void colsum_kernel(const unsigned short* X, int64_t ldx, int M, int N, float* out, int perm_h) {
   // blockDim = (64 columns, 4 row lanes); grid.x over column groups, grid.y over row chunks
   const int col = blockIdx.x * 64 + threadIdx.x;
@@ -78,6 +113,13 @@ extern "C" int las_cast_bf16(const float* src, int64_t lds_, int rows, int cols,
   hipLaunchKernelGGL(cast_kernel, dim3(blocks, batch), dim3(256), 0, (hipStream_t)stream, src, lds_, rows, cols, dst,
                      ldd, dst_rows, dst_cols, transpose, src_bstride, dst_bstride, src_col_perm_h);
   LAS_LAUNCH_CHECK("cast launch");
+  return LAS_OK;
+}
+
+extern "C" int las_refresh_images(const las_image_job* jobs_dev, int njobs, void* stream) {
+  LAS_REQUIRE(jobs_dev != nullptr && njobs > 0 && njobs <= 65535, "las_refresh_images: bad job table (njobs=%d)", njobs);
+  hipLaunchKernelGGL(refresh_images_kernel, dim3(96, njobs), dim3(256), 0, (hipStream_t)stream, jobs_dev);
+  LAS_LAUNCH_CHECK("refresh images launch");
   return LAS_OK;
 }
 

@@ -76,3 +76,18 @@ __device__ __forceinline__ float las_normal(unsigned seed, unsigned stream, unsi
   const float u2 = las_uniform(seed, stream, i * 2 + 1);
   return sqrtf(-2.0f * __logf(u1)) * __cosf(6.2831853f * u2);
 }
+
+// Fragment-major image of K_h [H, 4H] (las_lstm_pack_recurrent): element i of the packed image comes from
+//   K_h[kc*32 + 8*(lane>>4) + j][g*H + ublk*16 + (lane&15)],  i = (((ublk*KC + kc)*4 + g)*64 + lane)*8 + j,  KC = H/32.
+__device__ __forceinline__ int64_t las_pack_recurrent_src(int64_t i, int H) {
+  const int KC = H / 32;
+  int64_t r = i;
+  const int j = (int)(r % 8); r /= 8;
+  const int lane = (int)(r % 64); r /= 64;
+  const int g = (int)(r % 4); r /= 4;
+  const int kc = (int)(r % KC); r /= KC;
+  const int ublk = (int)r;
+  const int k = kc * 32 + 8 * (lane >> 4) + j;
+  const int col = g * H + ublk * 16 + (lane & 15);
+  return (int64_t)k * 4 * H + col;
+}

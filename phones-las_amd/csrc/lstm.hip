@@ -91,19 +91,9 @@ __host__ __device__ constexpr int k_split(int H) { return H > 256 ? 2 : 1; }
 //   packed[(((ublk*KC + kc)*4 + g)*64 + lane)*8 + j] = K_h[kc*32 + 8*(lane>>4) + j][g*H + ublk*16 + (lane&15)]
 // ------------------------------------------------------------------------------------------------
 __global__ void pack_recurrent_kernel(const float* kh, int H, unsigned short* packed) {
-  const int KC = H / 32;
   const int64_t total = (int64_t)H * 4 * H;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-    int64_t r = i;
-    const int j = (int)(r % 8); r /= 8;
-    const int lane = (int)(r % 64); r /= 64;
-    const int g = (int)(r % 4); r /= 4;
-    const int kc = (int)(r % KC); r /= KC;
-    const int ublk = (int)r;
-    const int k = kc * 32 + 8 * (lane >> 4) + j;
-    const int col = g * H + ublk * 16 + (lane & 15);
-    packed[i] = las_f2bf(kh[(int64_t)k * 4 * H + col]);
-  }
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x)
+    packed[i] = las_f2bf(kh[las_pack_recurrent_src(i, H)]);
 }
 
 // ------------------------------------------------------------------------------------------------

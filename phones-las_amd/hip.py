@@ -23,6 +23,7 @@ _SIGS = {
     'las_gemm_nt': ([_vp, _i64, _vp, _i64, _vp, _i64, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i64, _i64, _i64, _i32, _vp], C.c_int),
     'las_gemm_tn': ([_vp, _i64, _vp, _i64, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i64, _i64, _i64, _i32, _vp], C.c_int),
     'las_cast_bf16': ([_vp, _i64, _i32, _i32, _vp, _i64, _i32, _i32, _i32, _i32, _i64, _i64, _i32, _vp], C.c_int),
+    'las_refresh_images': ([_vp, C.c_int, _vp], C.c_int),
     'las_colsum_bf16': ([_vp, _i64, _i32, _i32, _vp, _i32, _vp], C.c_int),
     'las_lstm_pack_recurrent': ([_vp, _i32, _vp, _vp], C.c_int),
     'las_lstm_recurrent_fwd': ([_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp], C.c_int),
@@ -202,13 +203,93 @@ def gemm_tn(A, B, C_, M, N, K, lda=None, ldb=None, ldc=None, a_shift=0, period=0
                             split_k, stream()))
 
 
+class ImageJob(C.Structure):
+    """las_image_job of include/las_hip.h."""
+    _fields_ = [('src', C.c_void_p), ('dst', C.c_void_p), ('lds', C.c_int64), ('ldd', C.c_int64),
+                ('rows', C.c_int32), ('cols', C.c_int32), ('dst_rows', C.c_int32), ('dst_cols', C.c_int32),
+                ('transpose', C.c_int32), ('perm_h', C.c_int32), ('kind', C.c_int32), ('reserved', C.c_int32)]
+
+
+IMAGE_CAST, IMAGE_PACK_RECURRENT, IMAGE_BIAS_INTERLEAVE, IMAGE_COPY_F32 = 0, 1, 2, 3
+_image_batch = None
+_image_tables = {}        # bytes of a job table -> its device copy (tables repeat every step: uploaded once)
+
+
+class image_batch:
+    """Collects the image rebuilds issued inside the block (cast_bf16 with batch 1, pack_recurrent, bias_interleave,
+    copy_f32) and runs them as ONE las_refresh_images launch at exit.  The jobs must be independent of each other and of
+    anything else enqueued inside the block.  A table seen before is not uploaded again, so a block whose jobs repeat
+    (same tensors every step) can be captured into a HIP graph after one eager run."""
+
+    def __enter__(self):
+        global _image_batch
+        self.outer, _image_batch = _image_batch, self
+        self.jobs = []
+        return self
+
+    def __exit__(self, exc_type, exc, tb):
+        global _image_batch
+        _image_batch = self.outer
+        if exc_type is None and self.jobs:
+            if self.outer is not None:
+                self.outer.jobs.extend(self.jobs)
+            else:
+                _run_image_jobs(self.jobs)
+        return False
+
+
+def _run_image_jobs(jobs):
+    arr = (ImageJob * len(jobs))(*jobs)
+    key = bytes(arr)
+    table = _image_tables.get(key)
+    if table is None:
+        if torch.cuda.is_current_stream_capturing():
+            raise LasError('image_batch: new job table during graph capture (run the block once eagerly first)')
+        table = torch.frombuffer(bytearray(key), dtype=torch.uint8).cuda()
+        if len(_image_tables) > 256:
+            _image_tables.clear()
+        _image_tables[key] = table
+    check(lib().las_refresh_images(p(table), len(jobs), stream()))
+
+
+def _image_job(kind, src, dst, lds=0, ldd=0, rows=0, cols=0, dst_rows=0, dst_cols=0, transpose=0, perm_h=0):
+    if not (src.is_cuda and dst.is_cuda):
+        raise LasError('expected CUDA tensors; the LAS ops have no CPU path')
+    job = ImageJob(src.data_ptr(), dst.data_ptr(), lds, ldd, rows, cols, dst_rows, dst_cols, int(transpose), perm_h, kind, 0)
+    if _image_batch is not None:
+        _image_batch.jobs.append(job)
+    else:
+        _run_image_jobs([job])
+
+
 def cast_bf16(src, rows, cols, dst, dst_rows, dst_cols, ldd=None, transpose=False, lds=None, batch=1, sbs=0, dbs=0,
               perm_h=0):
     """dst window [dst_rows, dst_cols] (row stride ldd) = bf16(src[rows, cols]) (transposed if asked), zero padded."""
     lds = lds if lds is not None else (src.stride(-2) if src.dim() >= 2 else cols)
     ldd = ldd if ldd is not None else (dst.stride(-2) if dst.dim() >= 2 else dst_cols)
+    if _image_batch is not None and batch == 1:
+        _image_job(IMAGE_CAST, src, dst, lds, ldd, rows, cols, dst_rows, dst_cols, transpose, perm_h)
+        return
     check(lib().las_cast_bf16(p(src), lds, rows, cols, p(dst), ldd, dst_rows, dst_cols, int(transpose), batch,
                               sbs, dbs, perm_h, stream()))
+
+
+def pack_recurrent(kernel_h, H, packed):
+    """las_lstm_pack_recurrent (joins an open image_batch)."""
+    if _image_batch is not None:
+        _image_job(IMAGE_PACK_RECURRENT, kernel_h, packed, rows=H)
+        return
+    check(lib().las_lstm_pack_recurrent(p(kernel_h), H, p(packed), stream()))
+
+
+def bias_interleave(bias, H, dst):
+    """fp32 dst[u*4+g] = bias[g*H+u]: the LSTM bias in the gate-interleaved column order of the recurrent kernels."""
+    _image_job(IMAGE_BIAS_INTERLEAVE, bias, dst, rows=H)
+
+
+def copy_f32(src, n, dst):
+    """fp32 dst[0:n] = src[0:n] (joins an open image_batch)."""
+    _image_job(IMAGE_COPY_F32, src, dst, cols=n)
 
 
 def colsum_bf16(X, M, N, out, ldx=None, perm_h=0):

@@ -53,8 +53,9 @@ class Listener:
         self.tape = None
 
     def refresh(self, variables):
-        for w in self.layers:
-            w.refresh(variables)
+        with hip.image_batch():                 # every image of every layer in one launch
+            for w in self.layers:
+                w.refresh(variables)
 
     def pad_features(self, x):
         """fp32 [B,T,F] -> bf16 [B,Tp,Fp], zero padded (Tp multiple of 2^(L-1), Fp multiple of 8)."""
@@ -172,18 +173,20 @@ class Speller:
         V, Vp, Hd, M = self.V, self.Vp, self.Hd, self.M
         wm, kc, wp = var[self.K_MEM], var[self.K_CELL], var[self.K_PROJ]
         assert wm.shape == (M, Hd) and kc.shape == (V + M + Hd, 4 * Hd) and wp.shape == (M, V)
-        hip.cast_bf16(wm, M, Hd, self.wmemT, Hd, M, transpose=True)
-        hip.cast_bf16(wm, M, Hd, self.wmem, M, Hd)
-        hip.cast_bf16(kc[V:], M + Hd, 4 * Hd, self.kcT, 4 * Hd, M + Hd, transpose=True, lds=4 * Hd)
-        hip.cast_bf16(kc[V:], M + Hd, 4 * Hd, self.kc, M + Hd, 4 * Hd, lds=4 * Hd)
-        hip.cast_bf16(kc, V, 4 * Hd, self.tok, V, 4 * Hd, lds=4 * Hd)
-        hip.cast_bf16(wp, M, V, self.wprojT, Vp, M, transpose=True)
-        hip.cast_bf16(wp, M, V, self.wproj, M, Vp)
-        self.bproj[:V].copy_(var[self.B_PROJ])
+        with hip.image_batch():                 # independent images: one launch
+            hip.cast_bf16(wm, M, Hd, self.wmemT, Hd, M, transpose=True)
+            hip.cast_bf16(wm, M, Hd, self.wmem, M, Hd)
+            hip.cast_bf16(kc[V:], M + Hd, 4 * Hd, self.kcT, 4 * Hd, M + Hd, transpose=True, lds=4 * Hd)
+            hip.cast_bf16(kc[V:], M + Hd, 4 * Hd, self.kc, M + Hd, 4 * Hd, lds=4 * Hd)
+            hip.cast_bf16(kc, V, 4 * Hd, self.tok, V, 4 * Hd, lds=4 * Hd)
+            hip.cast_bf16(wp, M, V, self.wprojT, Vp, M, transpose=True)
+            hip.cast_bf16(wp, M, V, self.wproj, M, Vp)
+            hip.copy_f32(var[self.B_PROJ], V, self.bproj)
+            if self.att == hip.ATT_BAHDANAU:
+                hip.cast_bf16(var[self.K_Q], Hd, Hd, self.wq, Hd, Hd)
+                hip.cast_bf16(var[self.K_Q], Hd, Hd, self.wq_t, Hd, Hd, transpose=True)
         self.bias = var[self.B_CELL]
         if self.att == hip.ATT_BAHDANAU:
-            hip.cast_bf16(var[self.K_Q], Hd, Hd, self.wq, Hd, Hd)
-            hip.cast_bf16(var[self.K_Q], Hd, Hd, self.wq_t, Hd, Hd, transpose=True)
             self.att_v = var[self.V_ATT]
 
     # ---------------------------------------------------------------------------------------------

@@ -126,8 +126,8 @@ class LayerWeights:
             hip.cast_bf16(k, D, 4 * H, self.kxT[i * 4 * H:], 4 * H, Dp, ldd=Dp, transpose=True, lds=4 * H, perm_h=H)
             hip.cast_bf16(k, D, 4 * H, self.kx[:, i * 4 * H:], D, 4 * H, ldd=nd * 4 * H, lds=4 * H, perm_h=H)
             hip.cast_bf16(k[D:], H, 4 * H, self.kh[i], H, 4 * H, ldd=4 * H, lds=4 * H, perm_h=H)
-            hip.check(hip.lib().las_lstm_pack_recurrent(hip.p(k[D:]), H, hip.p(self.khp[i]), hip.stream()))
-            self.bias[i * 4 * H:(i + 1) * 4 * H].view(H, 4).copy_(b.view(4, H).t())
+            hip.pack_recurrent(k[D:], H, self.khp[i])
+            hip.bias_interleave(b, H, self.bias[i * 4 * H:(i + 1) * 4 * H])
 
 
 def bilstm(inputs, sequence_length, num_units, dropout, mode, unidirectional=False, *, variables=None,

@@ -18,7 +18,8 @@ def _close(got, ref, tol=2e-3):
     assert err <= tol * scale, (err, scale)
 
 
-@pytest.mark.parametrize('M,N,K', [(128, 128, 64), (200, 72, 40), (64, 1024, 1280), (3, 5, 8), (257, 129, 328)])
+@pytest.mark.parametrize('M,N,K', [(128, 128, 64), (200, 72, 40), (64, 1024, 1280), (3, 5, 8), (257, 129, 328),
+                                   (1024, 256, 128), (1100, 300, 136), (2304, 512, 328)])
 def test_gemm_nt_matches_fp64(M, N, K):
     from phones_las_amd import hip
     A, B = _mk((M, K), 1), _mk((N, K), 2)

@@ -138,6 +138,44 @@ def test_train_op_kernels_on_unaligned_tensor_boundaries():
     assert float((p.double() - p1).abs().max()) < 1e-5
 
 
+def test_image_batch_matches_the_single_launches():
+    """hip.image_batch (one las_refresh_images launch over a device job table) against the per-image entry points
+    las_cast_bf16 / las_lstm_pack_recurrent and torch for the fp32 jobs; the repeated block reuses the cached table."""
+    from phones_las_amd import hip
+    torch.manual_seed(0)
+    D, H, V = 24, 64, 11
+    k = torch.randn(D + H, 4 * H, device='cuda')
+    b = torch.randn(4 * H, device='cuda')
+    pb = torch.randn(V, device='cuda')
+
+    def images():
+        return dict(kxT=torch.full((4 * H, 32), 7.0, dtype=torch.bfloat16, device='cuda'),
+                    kx=torch.full((D, 8 * H), 7.0, dtype=torch.bfloat16, device='cuda'),
+                    kh=torch.full((H, 4 * H), 7.0, dtype=torch.bfloat16, device='cuda'),
+                    khp=torch.full((H * 4 * H,), 7.0, dtype=torch.bfloat16, device='cuda'),
+                    bias=torch.full((8 * H,), 7.0, device='cuda'), bproj=torch.full((16,), 7.0, device='cuda'))
+
+    def build(im):
+        hip.cast_bf16(k, D, 4 * H, im['kxT'], 4 * H, 32, ldd=32, transpose=True, lds=4 * H, perm_h=H)
+        hip.cast_bf16(k, D, 4 * H, im['kx'][:, 4 * H:], D, 4 * H, ldd=8 * H, lds=4 * H, perm_h=H)
+        hip.cast_bf16(k[D:], H, 4 * H, im['kh'], H, 4 * H, ldd=4 * H, lds=4 * H, perm_h=H)
+        hip.pack_recurrent(k[D:], H, im['khp'])
+
+    ref, got = images(), images()
+    build(ref)                                   # single launches
+    for _ in range(2):                           # second pass: cached job table
+        with hip.image_batch():
+            build(got)
+            hip.bias_interleave(b, H, got['bias'][4 * H:])
+            hip.copy_f32(pb, V, got['bproj'])
+    torch.cuda.synchronize()
+    for name in ('kxT', 'kx', 'kh', 'khp'):
+        assert torch.equal(ref[name], got[name]), name
+    assert torch.equal(got['bias'][4 * H:].view(H, 4), b.view(4, H).t()) and bool((got['bias'][:4 * H] == 7.0).all())
+    assert torch.equal(got['bproj'][:V], pb) and bool((got['bproj'][V:] == 7.0).all())
+    assert len(hip._image_tables) >= 1
+
+
 def test_seq_ce_loss_kernel_vs_oracle():
     from oracle import las_oracle as O
     from phones_las_amd import model_helper as mh
