@@ -563,9 +563,12 @@ def gather_tree(step_ids, parent_ids, max_len, end_token):
     return out
 
 
-def speller_beam(hp: HP, params, memory, mem_len, enc_state, beam_width, mxu='f64'):
+def speller_beam(hp: HP, params, memory, mem_len, enc_state, beam_width, mxu='f64', partial_targets=None):
     """las/model.py:219-226,298-319: tf.contrib.seq2seq.BeamSearchDecoder (length_penalty_weight 0, no coverage
-    penalty) over the tiled batch, then gather_tree.  Returns (predicted_ids [B,T,K], scores [B,T,K] per step,
+    penalty) over the tiled batch, then gather_tree.  partial_targets [B,L] (features['partial_targets'],
+    model_helper.py:203): get_partial_targets_state (las/model.py:299-307,351-361) first runs the decoder
+    teacher-forced over the tiled tokens (TrainingHelper, full length for every row) and the search starts from that
+    final state with start_tokens = partial_targets[:, 0].  Returns (predicted_ids [B,T,K], scores [B,T,K] per step,
     final lengths [B,K])."""
     d = hp.decoder
     B, K, V = memory.shape[0], beam_width, d.target_vocab_size
@@ -577,6 +580,11 @@ def speller_beam(hp: HP, params, memory, mem_len, enc_state, beam_width, mxu='f6
     sp = Speller(hp, params, tile(memory), tile(mem_len), st, mxu, False)
     max_it = int(round(float(mem_len.max()) * d.decoding_length_factor))
     ids = torch.full((B * K,), d.sos_id, dtype=torch.long)
+    if partial_targets is not None:
+        prefix = tile(partial_targets.long())
+        for t in range(prefix.shape[1]):
+            sp.step(sp.embed(prefix[:, t]))           # outputs dropped: only final_context_state is kept
+        ids = prefix[:, 0]
     log_probs = torch.full((B, K), float('-inf'), dtype=DT)
     log_probs[:, 0] = 0.0
     finished = torch.zeros(B, K, dtype=torch.bool)

@@ -580,17 +580,23 @@ class GeneralSpeller:
         return dmem, d_state
 
     # ------------------------------------------------------------------------------------------------------------------
-    def forward_beam(self, memory, mem_len, encoder_state, max_iterations, beam_width):
+    def forward_beam(self, memory, mem_len, encoder_state, max_iterations, beam_width, partial_targets=None):
         """BeamSearchDecoder decode (las/model.py:219-226,298-319,346-347): the batch tiled beam_width times, one
         las_beam_step per decoder step, decoder state gathered by the parent beams, gather_tree at the end.
+        partial_targets [B,L] int (features['partial_targets'], model_helper.py:203): the decoder is first run
+        teacher-forced over these tokens (get_partial_targets_state, las/model.py:299-307,351-361) and the search
+        starts from that state with start_tokens = partial_targets[:, 0], as the reference does.
         Returns (predicted_ids [B,T,K] int32, final lengths [B,K], log-probabilities of the final beams [B,K])."""
-        return self.forward_greedy(memory, mem_len, encoder_state, max_iterations, beam_width=beam_width)
+        return self.forward_greedy(memory, mem_len, encoder_state, max_iterations, beam_width=beam_width,
+                                   partial_targets=partial_targets)
 
-    def forward_greedy(self, memory, mem_len, encoder_state, max_iterations, parts=4, beam_width=0):
+    def forward_greedy(self, memory, mem_len, encoder_state, max_iterations, parts=4, beam_width=0, partial_targets=None):
         """GreedyEmbeddingHelper decode (las/model.py:270-274,337-347) with the general cell stack
         (beam_width > 0: see forward_beam)."""
         d = self.hp
         K = int(beam_width)
+        if partial_targets is not None and K <= 0:
+            raise ValueError('partial_targets is a beam-search option (las/model.py:298-307)')
         if K > 0:                       # tf.contrib.seq2seq.tile_batch of memory, lengths and the encoder state
             B0 = memory.shape[0]
             tile = lambda x: x.repeat_interleave(K, 0).contiguous()
@@ -600,12 +606,20 @@ class GeneralSpeller:
             else:
                 encoder_state = type(encoder_state)(tile(encoder_state.c), tile(encoder_state.h))
         B, Tm, M = memory.shape
-        Hd, V, Vp, A, NL, S = self.Hd, self.V, self.Vp, self.A, self.NL, max_iterations
+        Hd, V, Vp, A, NL = self.Hd, self.V, self.Vp, self.A, self.NL
         dev, bf, f32 = memory.device, torch.bfloat16, torch.float32
+        # steps [0, L) run teacher-forced over the partial targets (no projection, no search), the search follows
+        L = 0
+        if partial_targets is not None:
+            prefix = partial_targets.to(device=dev, dtype=torch.int32).repeat_interleave(K, 0).contiguous()
+            L = int(prefix.shape[1])
+        S = max_iterations + L
         init, _ = self._init_states(encoder_state, B)
         ids0 = torch.full((B, 1), d.sos_id, dtype=torch.int32, device=dev)
         fed = torch.full((B, max(S, 1)), d.eos_id, dtype=torch.int32, device=dev)
         fed[:, :1] = ids0
+        if L > 0:
+            fed[:, :L] = prefix
         # reuse the training graph step by step on [B, S] buffers (teacher tokens replaced by the argmax)
         keys = self._keys(memory)
         Tmp = _r8(Tm)
@@ -670,6 +684,17 @@ class GeneralSpeller:
                     wc = A if l == 1 else Hd
                     X[l][:, t, :wc].copy_(att[:, t] if l == 1 else h[l - 1][:, t])
                     run_cell(l)
+            if t < L:                   # prefix step: only the state moves on
+                steps = t + 1
+                if not last:
+                    X[0][:, t + 1, self.T0:self.T0 + A].copy_(att[:, t])
+                    if self.bottom:
+                        for l in range(1, NL):
+                            wc = A if l == 1 else Hd
+                            X[l][:, t + 1, wc:wc + A].copy_(att[:, t])
+                    if t + 1 == L:
+                        fed[:, L] = prefix[:, 0]
+                continue
             out_t = h[NL - 1][:, t] if (self.bottom and NL > 1) else att[:, t]
             hip.gemm_nt(out_t, self.wprojT, logits[:, t], B, Vp, self.P, lda=out_t.stride(0), ldb=self.P, ldc=U * Vp,
                         bias=self.bproj)
@@ -703,8 +728,9 @@ class GeneralSpeller:
             if bool(finished.all()):
                 break
         if K > 0:
-            ids = gather_tree(samples[:, :steps].reshape(B0, K, steps).permute(2, 0, 1).cpu().numpy(),
-                              parents[:, :steps].reshape(B0, K, steps).permute(2, 0, 1).cpu().numpy(),
+            n = steps - L
+            ids = gather_tree(samples[:, L:steps].reshape(B0, K, n).permute(2, 0, 1).cpu().numpy(),
+                              parents[:, L:steps].reshape(B0, K, n).permute(2, 0, 1).cpu().numpy(),
                               b_len.max(1).values.cpu().numpy(), d.eos_id)
             return torch.from_numpy(ids).permute(1, 0, 2).contiguous().to(dev), b_len, b_lp
         return logits[:, :steps, :V], samples[:, :steps], final_len, sv['align'][:, :steps, :Tm]

@@ -410,7 +410,8 @@ class LasModel:
         emb_h = torch.cat([s.h for s in state], 1) if isinstance(state[0], tuple) else state.h
         beam_width = int(getattr(self.params.decoder, 'beam_width', 0) or 0)
         if beam_width > 0:              # model_helper.py:231-236: predicted_ids [B,T,K] instead of logits
-            ids, lens, lps = self._beam_speller().forward_beam(mem, mem_len, state, max_it, beam_width)
+            ids, lens, lps = self._beam_speller().forward_beam(mem, mem_len, state, max_it, beam_width,
+                                                               partial_targets=features.get('partial_targets'))
             return {'encoder_out': mem, 'source_length': mem_len, 'embedding': torch.stack([emb_c, emb_h], 1),
                     'sample_ids': ids, 'beam_lengths': lens, 'beam_log_probs': lps}
         logits, ids, final_len, align = self.speller.forward_greedy(mem, mem_len, state, max_it)

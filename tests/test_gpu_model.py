@@ -491,6 +491,39 @@ def test_beam_search_vs_oracle(kw):
     assert relerr(pred['beam_log_probs'], ref_scores[:, -1]) < 2e-2
 
 
+@pytest.mark.parametrize('kw', [
+    dict(att='luong', dec_layers=1, bottom_only=True, pass_hidden=True),
+    dict(att='luong_monotonic', dec_layers=2, bottom_only=True, pass_hidden=True, als=16),
+], ids=['fused_twin', 'multicell_monotonic'])
+def test_beam_search_from_partial_targets_vs_oracle(kw):
+    """features['partial_targets'] (model_helper.py:203, las/model.py:299-307,351-361): the decoder runs teacher-forced over
+    the given tokens, the beam search continues from that state with start_tokens = partial_targets[:, 0].  Ids exact
+    against the oracle, and different from the search without the prefix."""
+    O, ohp, op, model = _models(**kw)
+    g = torch.Generator().manual_seed(11)
+    op['speller/projection_layer/bias'] = torch.randn(ohp.decoder.target_vocab_size, generator=g, dtype=DT) * 1.5
+    model.load_variables({k: v for k, v in op.items()})
+    batch = make_batch(src_len=[12, 7, 10], tgt_len=[6, 4, 5])
+    feats, _ = to_device(batch)
+    partial = torch.tensor([[O.SOS_ID, 5, 7], [O.SOS_ID, 3, 3], [O.SOS_ID, 9, 4]], dtype=torch.int32)
+    K = 3
+    model.params.decoder.set_hparam('beam_width', K)
+    plain = model.predict(feats)
+    pred = model.predict(dict(feats, partial_targets=partial.cuda()))
+    model.params.decoder.set_hparam('beam_width', 0)
+    torch.cuda.synchronize()
+    (mem, ml), st = O.listener(batch['encoder_inputs'], batch['source_sequence_length'], op, ohp.encoder, 'bf16')
+    ref_ids, ref_scores, ref_len = O.speller_beam(ohp, op, mem, ml, st, K, 'bf16', partial_targets=partial)
+    ids = pred['sample_ids'].cpu()
+    assert tuple(ids.shape) == tuple(ref_ids.shape), (ids.shape, ref_ids.shape)
+    assert torch.equal(ids.long(), ref_ids), (ids[0].T.tolist(), ref_ids[0].T.tolist())
+    assert torch.equal(pred['beam_lengths'].cpu().long(), ref_len)
+    assert relerr(pred['beam_log_probs'], ref_scores[:, -1]) < 2e-2
+    if kw['att'] == 'luong':          # (hard monotonic attention on random weights decodes the same dull sequence either way)
+        p0 = plain['sample_ids'].cpu()
+        assert p0.shape != ids.shape or not torch.equal(p0, ids)
+
+
 @pytest.mark.parametrize('att', ['luong', 'bahdanau'])
 def test_persistent_decoder_vs_per_step_and_oracle(att, monkeypatch):
     """The one-launch persistent forward decoder (las_decoder_persist_fwd: decoder_units 128/256) against the per-step

@@ -119,3 +119,30 @@ def test_oracle_beam_width_one_is_greedy():
         n = int(rfl[i])
         assert p1[i, :n, 0].tolist() == rids[i, :n].tolist()
         assert int(l1[i, 0]) == n
+
+
+def test_oracle_beam_from_partial_targets_continues_the_teacher_forced_state():
+    """speller_beam(partial_targets=...) (las/model.py:299-307,351-361): with beam width 1 the search is greedy decoding
+    from the state a teacher-forced pass over the prefix leaves behind, fed partial_targets[:, 0] first."""
+    import torch
+    from oracle import las_oracle as O
+    from tests.helpers import make_hparams, make_batch
+    ohp, _ = make_hparams(att='luong')
+    op = O.init_params(ohp, bias_scale=0.1)
+    g = torch.Generator().manual_seed(5)
+    op['speller/projection_layer/bias'] = torch.randn(11, generator=g, dtype=torch.float64) * 1.5
+    b = make_batch(src_len=[12, 7, 10], tgt_len=[6, 4, 5])
+    (mem, ml), st = O.listener(b['encoder_inputs'], b['source_sequence_length'], op, ohp.encoder, 'f64')
+    partial = torch.tensor([[1, 5, 7], [1, 3, 3], [1, 9, 4]])
+    p1, _, l1 = O.speller_beam(ohp, op, mem, ml, st, 1, 'f64', partial_targets=partial)
+    sp = O.Speller(ohp, op, mem, ml, st, 'f64', False)
+    for t in range(partial.shape[1]):
+        sp.step(sp.embed(partial[:, t]))
+    ids = partial[:, 0]
+    done = torch.zeros(3, dtype=torch.bool)
+    for t in range(p1.shape[1]):
+        ids = sp.step(sp.embed(ids)).argmax(-1)
+        for i in range(3):
+            if not done[i]:
+                assert int(p1[i, t, 0]) == int(ids[i]), (i, t)
+        done |= ids == ohp.decoder.eos_id
