@@ -142,6 +142,9 @@ def main():
     ap.add_argument('--config', default='metric-M', choices=sorted(CONFIGS))
     ap.add_argument('--no-graph', action='store_true', help='launch eagerly instead of replaying HIP graphs')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--dp-overlap', action='store_true',
+                    help='exchange the gradients in two buckets, the first one beside the lower layers\' backward '
+                         '(with --gpus 1 the all-reduces run on a 1-rank RCCL group: plumbing check)')
     ap.add_argument('--cpu-sample', type=int, default=32)
     args = ap.parse_args()
     c = CONFIGS[args.config]
@@ -149,6 +152,8 @@ def main():
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
+    if rank != 0:
+        os.dup2(2, 1)          # only rank 0 owns stdout (one JSON line, last); library banners of the others go to stderr
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit('bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d'
@@ -160,7 +165,14 @@ def main():
         torch.distributed.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
 
     from phones_las_amd import model_helper as mh
-    model = mh.LasModel(build_params(c), world_size=world)
+    group = None
+    if args.dp_overlap and world == 1:          # plumbing check on one GPU: the exchange runs on a 1-rank RCCL group
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29517')
+        torch.distributed.init_process_group('nccl', rank=0, world_size=1, device_id=dev)
+        group = torch.distributed.group.WORLD
+    model = mh.LasModel(build_params(c), world_size=world, process_group=group)
+    overlap_exchange = bool(args.dp_overlap) and len(model.enable_exchange_overlap()) == 2
     feats, labels = synthetic_batch(c, 1234 + rank, dev)
     feats['encoder_inputs'] = model.listener.pad_features(feats['encoder_inputs'])   # resident bf16 [B,T,F'] batch
     U = c['U']
@@ -184,8 +196,24 @@ def main():
         model.refresh_images()
 
     def reduce():
-        if world > 1:
+        if world > 1 or group is not None:
             torch.distributed.all_reduce(model.vars.grad)
+
+    # --dp-overlap: the exchange in two buckets, the first one (top listener layer + speller) handed to RCCL while the
+    # lower layers' backward is still running: three graphs with the asynchronous all-reduces between them
+    def part_a1():
+        model.vars.grad.zero_()
+        audio, _, dlogits = model.forward_train(feats, labels, num_steps=U)
+        audio_buf.copy_(audio)
+        model.backward_exchange_begin(dlogits, exchange=False)
+
+    def part_a2():
+        model.backward_exchange_end([], exchange=False)
+        loss_buf.copy_(audio_buf + model.l2_loss(from_norms=True))
+
+    def part_b_dp():
+        model.adam_update()
+        model.refresh_images()
 
     # eager warm-up on a side stream (also what graph capture needs)
     s = torch.cuda.Stream()
@@ -195,7 +223,34 @@ def main():
     torch.cuda.current_stream().wait_stream(s)
     torch.cuda.synchronize()
 
-    if args.no_graph:
+    audio_buf = torch.zeros(1, device=dev)
+    if overlap_exchange:
+        b0, b1 = model.vars.buckets
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):              # eager run of the three parts (allocations, job tables) before capture
+            part_a1(); part_a2(); part_b_dp()
+        torch.cuda.current_stream().wait_stream(s)
+        torch.cuda.synchronize()
+        if args.no_graph:
+            run_a1, run_a2, run_b = part_a1, part_a2, part_b_dp
+        else:
+            g1, g2, g3 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g1):
+                part_a1()
+            with torch.cuda.graph(g2, pool=g1.pool()):
+                part_a2()
+            with torch.cuda.graph(g3, pool=g1.pool()):
+                part_b_dp()
+            run_a1, run_a2, run_b = g1.replay, g2.replay, g3.replay
+
+        def step():
+            run_a1()
+            w0 = model.all_reduce_gradients(b0, async_op=True)
+            run_a2()
+            w1 = model.all_reduce_gradients(b1, async_op=True)
+            w0.wait(); w1.wait()
+            run_b()
+    elif args.no_graph:
         def step():
             part_a(); reduce(); part_b()
     else:
@@ -248,7 +303,8 @@ def main():
                                    'T=%d, F=%d, full train step' % (args.config, c['L'], c['H'], c['att'], c['Hd'],
                                                                     c['V'], c['U'], c['T'], c['F']),
                        'global_batch': c['B'] * world, 'parallelism': 'dp%d' % world,
-                       'hip_graph': not args.no_graph, 'final_loss': round(final_loss, 4)},
+                       'hip_graph': not args.no_graph, 'exchange': 'two buckets, overlapped' if overlap_exchange else 'one all-reduce',
+                       'final_loss': round(final_loss, 4)},
             'roofline': {'bound': 'mfma', 'kernel': 'lstm_fwd_kernel<%d> (layer-1 shape, both directions)' % c['H'],
                          'achieved': round(achieved, 3), 'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s',
                          'frac': round(achieved / PEAK_BF16_TFLOPS, 6), 'traffic': traffic,
@@ -258,9 +314,16 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(c, args.cpu_sample)
-        print(json.dumps(out), flush=True)
-    if world > 1:
+    if world > 1 or group is not None:
+        torch.cuda.synchronize()
         torch.distributed.destroy_process_group()
+    if rank == 0:
+        # the JSON line must be the LAST line on stdout: RCCL writes its NCCL_DEBUG=VERSION banner to the C stdout
+        # buffer, which would otherwise be flushed after this print at process exit
+        import ctypes
+        sys.stdout.flush()
+        ctypes.CDLL(None).fflush(None)
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == '__main__':

@@ -80,15 +80,43 @@ class Listener:
 
     def backward(self, d_outputs, d_state, grads, overlap=None):
         """d_outputs: fp32 gradient w.r.t. the encoder outputs [B,T',M]; d_state: (dc, dh) [nd,B,H] or None."""
+        self.backward_begin(d_outputs, d_state)
+        self.backward_layers(len(self._bwd['recs']), grads, overlap)
+
+    def backward_begin(self, d_outputs, d_state):
+        """Start a backward pass that backward_layers() walks top-down in pieces (the data-parallel step exchanges the
+        gradients of the layers that are done while the lower layers are still running)."""
         recs = [r for r in self.tape if r['kind'] == 'bilstm']
-        dy = d_outputs
-        for l in range(len(recs) - 1, -1, -1):
+        self._bwd = dict(recs=recs, dy=d_outputs, d_state=d_state, next=len(recs) - 1)
+
+    def backward_layers(self, n, grads, overlap=None, defer_last=False):
+        """Backward of the next n layers (from the top).  Returns the number of layers still to do.  defer_last: the
+        weight-gradient products of the last of these layers are not launched yet -- the next call launches them first
+        (so that a HIP graph can end here with nothing pending on the second stream)."""
+        st = self._bwd
+        recs = st['recs']
+        pending = st.pop('deferred', None)
+        if pending is not None:
+            pending()
+        for i in range(n):
+            l = st['next']
+            if l < 0:
+                break
             r = recs[l]
-            dy = dy.contiguous().view(r['B'], r['T'], r['nd'] * r['H'])
-            dx = ops.bilstm_backward(r, dy, d_state if l == len(recs) - 1 else None, grads, need_dx=(l > 0),
-                                     overlap=overlap)
-            dy = dx
-        self.tape = None
+            dy = st['dy'].contiguous().view(r['B'], r['T'], r['nd'] * r['H'])
+            defer = defer_last and (i == n - 1) and l > 0
+            res = ops.bilstm_backward(r, dy, st['d_state'] if l == len(recs) - 1 else None, grads, need_dx=(l > 0),
+                                      overlap=overlap, defer_weight_grads=defer)
+            if defer:
+                st['dy'], st['deferred'] = res
+            else:
+                st['dy'] = res
+            st['next'] = l - 1
+        left = st['next'] + 1
+        if left == 0:
+            self.tape = None
+            self._bwd = None
+        return left
 
 
 def listener(encoder_inputs, source_sequence_length, mode, hparams, *, variables=None, module=None):

@@ -79,6 +79,12 @@ class Overlap:
         self.keep.extend(tensors)
         return torch.cuda.stream(self.side)
 
+    def mark(self):
+        """An event after everything forked so far (the main stream can wait for exactly that much of the side stream)."""
+        ev = torch.cuda.Event()
+        ev.record(self.side)
+        return ev
+
     def join(self):
         torch.cuda.current_stream().wait_stream(self.side)
         self.keep.clear()
@@ -90,6 +96,9 @@ class _NoOverlap:
     def fork(self, *tensors):
         import contextlib
         return contextlib.nullcontext()
+
+    def mark(self):
+        return None
 
     def join(self):
         pass
@@ -201,10 +210,11 @@ def concat_outputs(outputs):
     return outputs
 
 
-def bilstm_backward(rec, dy, d_state, grads, need_dx=True, overlap=None):
+def bilstm_backward(rec, dy, d_state, grads, need_dx=True, overlap=None, defer_weight_grads=False):
     """Reverse-mode AD of one bilstm() call.  dy [B,T,nd*H] fp32 (gradient of the concatenated outputs),
     d_state: None or (dc_last, dh_last) each [nd,B,H] fp32.  Accumulates into ``grads`` (name -> fp32
-    tensor, same shapes as the variables) and returns dX [B,T,D'] fp32 (or None)."""
+    tensor, same shapes as the variables) and returns dX [B,T,D'] fp32 (or None).  defer_weight_grads: returns
+    (dX, launch) instead and leaves the weight-gradient products to launch() (the caller forks them later)."""
     B, T, H, D, Dp, nd = rec['B'], rec['T'], rec['H'], rec['D'], rec['Dp'], rec['nd']
     w = rec['weights']
     dev = dy.device
@@ -251,28 +261,34 @@ def bilstm_backward(rec, dy, d_state, grads, need_dx=True, overlap=None):
         tiles = -(-(D + H + 1) // 128) * -(-(4 * H) // 128)
         split = max(1, min(32, BT // 512, round(704 / tiles)))
     keepalive = [dz, x, y] + [a for a, _ in (dropped or [])]
-    with (overlap or _NoOverlap()).fork(*keepalive):
-        for i, (kn, bn) in enumerate(w.names):
-            gk, gb = grads[kn], grads[bn]
-            dzi = dz.view(BT, nd * 4 * H)[:, i * 4 * H:]
-            xa, lda = (dropped[i] if dropped is not None else (x, Dp))
-            yi = y.view(BT, nd * H)[:, i * H:]
-            if D % 8 == 0:
-                # dK_x, dK_h and db of this direction in one product (dz read once); the K slices meet in a workspace
-                # owned by this layer (its products run one after the other on one stream)
-                need = hip.lib().las_gemm_tn_lstm_workspace_bytes(D, H, split)
-                ws = getattr(w, '_tn_ws', None)
-                if ws is None or ws.numel() * 4 < need:
-                    ws = w._tn_ws = torch.empty(max(1, need // 4), dtype=torch.float32, device=dev)
-                hip.check(hip.lib().las_gemm_tn_lstm(hip.p(xa) if D > 0 else None, lda, D, hip.p(yi), nd * H, H,
-                                                     (-1 if i == 0 else 1), T, hip.p(dzi), nd * 4 * H, hip.p(gk), hip.p(gb),
-                                                     BT, split, hip.p(ws), hip.stream()))
-                continue
-            if D > 0:
-                hip.gemm_tn(xa, dzi, gk, D, 4 * H, BT, lda=lda, ldb=nd * 4 * H, ldc=4 * H, split_k=split, c_perm_h=H)
-            hip.gemm_tn(yi, dzi, gk[D:], H, 4 * H, BT, lda=nd * H, ldb=nd * 4 * H, ldc=4 * H,
-                        a_shift=(-1 if i == 0 else 1), period=T, split_k=split, c_perm_h=H)
-            hip.colsum_bf16(dzi, BT, 4 * H, gb, ldx=nd * 4 * H, perm_h=H)
+
+    def weight_grads():
+        with (overlap or _NoOverlap()).fork(*keepalive):
+            for i, (kn, bn) in enumerate(w.names):
+                gk, gb = grads[kn], grads[bn]
+                dzi = dz.view(BT, nd * 4 * H)[:, i * 4 * H:]
+                xa, lda = (dropped[i] if dropped is not None else (x, Dp))
+                yi = y.view(BT, nd * H)[:, i * H:]
+                if D % 8 == 0:
+                    # dK_x, dK_h and db of this direction in one product (dz read once); the K slices meet in a workspace
+                    # owned by this layer (its products run one after the other on one stream)
+                    need = hip.lib().las_gemm_tn_lstm_workspace_bytes(D, H, split)
+                    ws = getattr(w, '_tn_ws', None)
+                    if ws is None or ws.numel() * 4 < need:
+                        ws = w._tn_ws = torch.empty(max(1, need // 4), dtype=torch.float32, device=dev)
+                    hip.check(hip.lib().las_gemm_tn_lstm(hip.p(xa) if D > 0 else None, lda, D, hip.p(yi), nd * H, H,
+                                                         (-1 if i == 0 else 1), T, hip.p(dzi), nd * 4 * H, hip.p(gk), hip.p(gb),
+                                                         BT, split, hip.p(ws), hip.stream()))
+                    continue
+                if D > 0:
+                    hip.gemm_tn(xa, dzi, gk, D, 4 * H, BT, lda=lda, ldb=nd * 4 * H, ldc=4 * H, split_k=split, c_perm_h=H)
+                hip.gemm_tn(yi, dzi, gk[D:], H, 4 * H, BT, lda=nd * H, ldb=nd * 4 * H, ldc=4 * H,
+                            a_shift=(-1 if i == 0 else 1), period=T, split_k=split, c_perm_h=H)
+                hip.colsum_bf16(dzi, BT, 4 * H, gb, ldx=nd * 4 * H, perm_h=H)
+
+    if defer_weight_grads:
+        return dx, weight_grads
+    weight_grads()
     return dx
 
 

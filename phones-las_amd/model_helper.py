@@ -108,9 +108,24 @@ class Variables:
         self.seg = torch.tensor(offs, dtype=torch.int64, device=device)
         self.device = device
         self.sumsq = torch.zeros(len(self.table), dtype=f32, device=device)
-        self.param_sumsq = torch.zeros(1, dtype=f32, device=device)      # sum theta^2, by-product of the norms pass
+        self.param_sumsq = torch.zeros(2, dtype=f32, device=device)      # sum theta^2 per bucket, by-product of the norms pass
+        self.buckets = [self._bucket(0, len(self.table), 0)]             # one exchange bucket = everything
         self.params = self._views(self.flat)
         self.grads = self._views(self.grad)
+
+    def _bucket(self, lo, hi, slot):
+        """Tensors lo..hi-1 as a contiguous piece of the flat buffers: element range, boundaries relative to its start."""
+        o = self.offsets
+        rel = torch.tensor([x - o[lo] for x in o[lo:hi + 1]], dtype=torch.int64, device=self.device)
+        return dict(lo=lo, hi=hi, begin=o[lo], end=o[hi], seg=rel, slot=slot)
+
+    def split_buckets(self, first_of_last):
+        """Two exchange buckets in the order the backward pass completes them: tensors [first_of_last, end) first (top
+        listener layer, speller, CTC head), then [0, first_of_last).  At most two (param_sumsq has two slots)."""
+        n = len(self.table)
+        if 0 < first_of_last < n:
+            self.buckets = [self._bucket(first_of_last, n, 0), self._bucket(0, first_of_last, 1)]
+        return self.buckets
 
     def _views(self, flat):
         d = collections.OrderedDict()
@@ -296,6 +311,11 @@ class LasModel:
         return loss, logits, dlogits
 
     def backward(self, dlogits):
+        self.backward_top(dlogits, layers=None)
+
+    def backward_top(self, dlogits, layers=None):
+        """Backward of the speller (+ CTC head) and of the top `layers` listener layers (None: all of them).
+        Returns the number of listener layers still to do (backward_rest)."""
         g = self.vars.grads
         dmem, d_state = self.speller.backward(dlogits, g, self.overlap)
         if self.ctc is not None:
@@ -311,28 +331,47 @@ class LasModel:
                 dc[l].copy_(dcl)
                 dh[l].copy_(dhl)
             ds = (dc, dh)
-        self.listener.backward(dmem, ds, g, self.overlap)
-        self.overlap.join()
+        self.listener.backward_begin(dmem, ds)
+        return self.backward_rest(layers)
 
-    def gradient_norms(self):
+    def backward_rest(self, layers=None, defer_last=False):
+        n = self.params.encoder.num_layers if layers is None else layers
+        left = self.listener.backward_layers(n, self.vars.grads, self.overlap, defer_last=defer_last)
+        if left == 0:
+            self.overlap.join()
+        return left
+
+    def gradient_norms(self, bucket=None):
         """grad += l2 * theta (gradient of the L2 term, model_helper.py:411-413) and per-tensor ||grad||^2; the same pass
-        leaves sum theta^2 (the value of the L2 term) in vars.param_sumsq."""
+        leaves sum theta^2 (the value of the L2 term) in vars.param_sumsq.  bucket: one of vars.buckets (default: all)."""
         v, p = self.vars, self.params
-        hip.check(hip.lib().las_grad_l2_norms(hip.p(v.grad), hip.p(v.flat), hip.p(v.seg), len(v.table), v.total,
-                                              float(p.l2_reg_scale) / self.world_size, hip.p(v.sumsq), hip.p(v.param_sumsq),
-                                              hip.stream()))
+        for b in (v.buckets if bucket is None else [bucket]):
+            hip.check(hip.lib().las_grad_l2_norms(hip.addr(v.grad, b['begin']), hip.addr(v.flat, b['begin']), hip.p(b['seg']),
+                                                  b['hi'] - b['lo'], b['end'] - b['begin'],
+                                                  float(p.l2_reg_scale) / self.world_size, hip.addr(v.sumsq, b['lo']),
+                                                  hip.addr(v.param_sumsq, b['slot']), hip.stream()))
 
-    def clip_gradients(self):
+    def clip_gradients(self, bucket=None, norms=True):
         """L2 gradient + per-tensor clip_by_norm(GRAD_NORM) on the flat buffers (model_helper.py:411-416)."""
         v = self.vars
-        self.gradient_norms()
-        hip.check(hip.lib().las_grad_clip(hip.p(v.grad), hip.p(v.seg), len(v.table), v.total, hip.p(v.sumsq), float(GRAD_NORM),
-                                          hip.stream()))
+        if norms:
+            self.gradient_norms(bucket)
+        for b in (v.buckets if bucket is None else [bucket]):
+            hip.check(hip.lib().las_grad_clip(hip.addr(v.grad, b['begin']), hip.p(b['seg']), b['hi'] - b['lo'],
+                                              b['end'] - b['begin'], hip.addr(v.sumsq, b['lo']), float(GRAD_NORM), hip.stream()))
 
-    def all_reduce_gradients(self):
-        """CrossShardOptimizer's cross-replica sum (model_helper.py:405-406): one RCCL all-reduce, after the clip."""
-        if self.world_size > 1:
-            dp.all_reduce_sum_(self.vars.grad, self.process_group)
+    def all_reduce_gradients(self, bucket=None, async_op=False):
+        """CrossShardOptimizer's cross-replica sum (model_helper.py:405-406): RCCL all-reduce of the clipped gradients,
+        the whole flat buffer or one bucket of it.  async_op: returns the work handle (RCCL's own stream; the caller
+        waits on it before the Adam update), so that the rest of the backward pass runs beside the exchange."""
+        if self.world_size <= 1 and self.process_group is None:
+            return None
+        v = self.vars
+        flat = v.grad if bucket is None else v.grad[bucket['begin']:bucket['end']]
+        if async_op:
+            return torch.distributed.all_reduce(flat, group=self.process_group, async_op=True)
+        dp.all_reduce_sum_(flat, self.process_group)
+        return None
 
     def adam_update(self):
         """tf.train.AdamOptimizer.apply_gradients + global_step increment (model_helper.py:404,417)."""
@@ -354,13 +393,54 @@ class LasModel:
         self._images_stale = True
 
     def apply_gradients(self):
-        if self.world_size == 1:
+        if self.world_size == 1 and self.process_group is None:
             self.gradient_norms()
             self.clip_adam_update()
         else:
             self.clip_gradients()
             self.all_reduce_gradients()
             self.adam_update()
+
+    # -- data-parallel step with the exchange overlapped with the backward pass ----------------------------------
+    def enable_exchange_overlap(self):
+        """Two exchange buckets: [top listener layer, speller, CTC head] and [the lower listener layers].  The first is
+        clipped and handed to RCCL while the lower layers' backward is still running (backward_and_exchange)."""
+        e = self.params.encoder
+        per_layer = 2 * (1 if e.unidirectional else 2)
+        self.exchange_overlap = True
+        return self.vars.split_buckets((e.num_layers - 1) * per_layer)
+
+    def backward_exchange_begin(self, dlogits, exchange=True):
+        """First half of the overlapped step: speller backward, the top listener layer and the RECURRENCE of the next
+        one (the top layer's weight-gradient products run beside it), then norms + clip + all-reduce of bucket 0.
+        Returns the pending work handles.  exchange=False: only the compute part (bench.py captures it in a HIP graph and
+        issues the all-reduce itself between the graphs)."""
+        v = self.vars
+        if len(v.buckets) < 2:
+            self.backward(dlogits)
+            self.clip_gradients()
+            return [self.all_reduce_gradients(async_op=True)] if exchange else []
+        left = self.backward_top(dlogits, layers=1)
+        if left > 0:
+            # recurrence and dX of the next layer; its own weight-gradient products wait for backward_exchange_end
+            left = self.backward_rest(layers=1, defer_last=True)
+        if left > 0:
+            self.overlap.join()                         # = the top layer's (and the speller's) weight gradients
+        self.clip_gradients(v.buckets[0])
+        return [self.all_reduce_gradients(v.buckets[0], async_op=True)] if exchange else []
+
+    def backward_exchange_end(self, pending, exchange=True):
+        """Second half: the remaining layers, bucket 1, then wait for both exchanges."""
+        v = self.vars
+        if len(v.buckets) >= 2:
+            if self.listener._bwd is not None:
+                self.backward_rest()
+            self.clip_gradients(v.buckets[1])
+            if exchange:
+                pending = list(pending) + [self.all_reduce_gradients(v.buckets[1], async_op=True)]
+        for w in pending:
+            if w is not None:
+                w.wait()
 
     def maybe_add_noise(self):
         """model_helper.py:418-432: every `add_noise` steps (and not at step 0) add N(0, noise_std) to every variable
@@ -381,7 +461,7 @@ class LasModel:
         """scale * sum(theta^2) / 2 (model_helper.py:411-413).  from_norms: take sum theta^2 from the last gradient_norms()
         pass (the parameters of this step, before the update) instead of another pass over the parameters."""
         if from_norms:
-            return self.vars.param_sumsq * (0.5 * float(self.params.l2_reg_scale))
+            return self.vars.param_sumsq.sum(0, keepdim=True) * (0.5 * float(self.params.l2_reg_scale))
         out = torch.zeros(1, dtype=torch.float32, device='cuda')
         hip.check(hip.lib().las_sumsq(hip.p(self.vars.flat), self.vars.total, hip.p(out), hip.stream()))
         return out * (0.5 * float(self.params.l2_reg_scale))
@@ -390,8 +470,12 @@ class LasModel:
         """One optimiser step; returns the loss (audio loss + L2 term) as a device scalar tensor."""
         self.vars.grad.zero_()
         audio_loss, _, dlogits = self.forward_train(features, labels, num_steps)
-        self.backward(dlogits)
-        self.apply_gradients()
+        if getattr(self, 'exchange_overlap', False):
+            self.backward_exchange_end(self.backward_exchange_begin(dlogits))
+            self.adam_update()
+        else:
+            self.backward(dlogits)
+            self.apply_gradients()
         loss = audio_loss + self.l2_loss(from_norms=True)
         self.maybe_add_noise()
         self.refresh_images()

@@ -176,6 +176,44 @@ def test_image_batch_matches_the_single_launches():
     assert len(hip._image_tables) >= 1
 
 
+@pytest.mark.parametrize('L', [2, 3])
+def test_overlapped_gradient_exchange_matches_the_plain_step(L):
+    """The data-parallel step that exchanges the gradients in two buckets beside the backward pass
+    (LasModel.enable_exchange_overlap: top listener layer + speller first, lower layers second; per-bucket norms and
+    clip on pieces of the flat buffers; deferred weight-gradient products) on a 1-rank RCCL group against the plain
+    single-replica step: same parameters after two optimiser steps."""
+    import socket
+    import torch.distributed as dist
+    from phones_las_amd import model_helper as mh
+    sock = socket.socket()
+    sock.bind(('127.0.0.1', 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    dist.init_process_group('nccl', init_method='tcp://127.0.0.1:%d' % port, rank=0, world_size=1,
+                            device_id=torch.device('cuda', 0))
+    try:
+        _, params = make_hparams(att='luong', L=L, H=64)
+        batch = make_batch(B=5, src_len=[12, 7, 10, 12, 4], tgt_len=[6, 4, 5, 6, 2])
+        feats, labels = to_device(batch)
+        plain = mh.LasModel(params)
+        over = mh.LasModel(params, process_group=dist.group.WORLD)
+        over.load_variables({k: v.clone() for k, v in plain.vars.params.items()})
+        assert len(over.enable_exchange_overlap()) == 2
+        b0, b1 = over.vars.buckets
+        assert b0['end'] == over.vars.total and b1['begin'] == 0 and b1['end'] == b0['begin']
+        for _ in range(2):
+            lp = plain.train_step(feats, labels)
+            lo = over.train_step(feats, labels)
+        torch.cuda.synchronize()
+        assert abs(float(lp) - float(lo)) < 1e-5 * abs(float(lp))
+        for name in plain.vars.params:
+            a, b = plain.vars.params[name], over.vars.params[name]
+            assert float((a - b).abs().max()) <= 2e-6 + 1e-5 * float(a.abs().max()), name
+        assert over.listener._bwd is None and over.listener.tape is None
+    finally:
+        dist.destroy_process_group()
+
+
 def test_seq_ce_loss_kernel_vs_oracle():
     from oracle import las_oracle as O
     from phones_las_amd import model_helper as mh
