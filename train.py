@@ -52,6 +52,8 @@ def parse_args(argv=None):
     p.add_argument('--l2_reg_scale', type=float, default=1e-6)
     p.add_argument('--add_noise', type=int, default=0)
     p.add_argument('--noise_std', type=float, default=0.1)
+    p.add_argument('--dp_overlap', action='store_true',
+                   help='multi-GPU (torch.distributed.run): exchange the gradients in two buckets beside the backward pass')
     p.add_argument('--binary_outputs', action='store_true')
     p.add_argument('--output_ipa', action='store_true')
     p.add_argument('--binf_map', type=str, default='misc/binf_map.csv')
@@ -128,6 +130,8 @@ def main(args):
         hparams.del_hparam('mapping')
         hparams.add_hparam('mapping', mapping)
     model = mh.LasModel(hparams, world_size=world, binf2phone=binf2phone_np)
+    if world > 1 and getattr(args, 'dp_overlap', False):
+        model.enable_exchange_overlap()
     ckpt = os.path.join(args.model_dir, 'checkpoint.pt')
     if os.path.exists(ckpt):
         load_checkpoint(model, ckpt)
