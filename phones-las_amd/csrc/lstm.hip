@@ -103,7 +103,10 @@ __global__ void pack_recurrent_kernel(const float* kh, int H, unsigned short* pa
 // every compute workgroup has a PREFETCH COMPANION workgroup (see the kernel) that keeps its HBM operands L2-resident.
 __host__ __device__ constexpr int rec_threads(int H) { return 256; }
 
-template <int H>
+// ROWS = utterances per slice: 16 fills the MFMA tile; 8 (rows 0,1 of every quad; the other two stay zero) halves the
+// element-wise work, the exchange and the HBM accesses of every lane at the same MFMA cost -- the per-step latency is
+// mostly that work, so small batches run twice as many (half-filled) chains on otherwise idle CUs.
+template <int H, int ROWS>
 __global__ __launch_bounds__(256) void lstm_fwd_kernel(float* __restrict__ xproj, const unsigned short* __restrict__ wpacked,
                                                        const int32_t* __restrict__ length, unsigned short* __restrict__ y,
                                                        float* __restrict__ cbuf, float* __restrict__ c_last,
@@ -118,8 +121,11 @@ __global__ __launch_bounds__(256) void lstm_fwd_kernel(float* __restrict__ xproj
   constexpr int KC = H / 32;
   constexpr int KCW = KC / KS;         // k-chunks a wave owns
   constexpr int LS = H + 8;            // LDS row stride (elements)
-  constexpr int NGRAN = 8 * HS;        // granules a member publishes per step (2 rows x 1 unit each)
+  constexpr int RL = ROWS / 4;         // utterances per lane (rows lq*4 .. lq*4+RL-1 of the MFMA tile)
+  static_assert(ROWS == 16 || (ROWS == 8 && KS == 1), "8-row slices: only without the K split");
+  constexpr int NGRAN = (ROWS / 2) * HS;   // granules a member publishes per step (2 rows x 1 unit each)
   constexpr int PER = G > 1 ? (G - 1) * NGRAN / 256 : 1;   // granules a thread polls per step
+  static_assert(G == 1 || ((G - 1) * NGRAN) % 256 == 0, "granules must divide over the threads");
   __shared__ __attribute__((aligned(16))) unsigned short hlds[2][16][LS];
   __shared__ int fail_flag;
   __shared__ int colo_flag;
@@ -142,11 +148,11 @@ __global__ __launch_bounds__(256) void lstm_fwd_kernel(float* __restrict__ xproj
   u64* ex_group = exch + (int64_t)group * G * NGRAN;           // + parity*par_stride + member*NGRAN
   u64* done_word = exch + 2 * par_stride + (int64_t)ngroups * G + cblk;
 
-  int len[4], bidx[4];
+  int len[RL], bidx[RL];
   int smax = 0, smin = 0x7fffffff;
 #pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    bidx[r] = slice * 16 + lq * 4 + r;
+  for (int r = 0; r < RL; ++r) {
+    bidx[r] = slice * ROWS + lq * RL + r;
     len[r] = (bidx[r] < B) ? min(length[bidx[r]], T) : 0;
     smax = max(smax, len[r]);
     smin = min(smin, len[r]);
@@ -161,11 +167,11 @@ __global__ __launch_bounds__(256) void lstm_fwd_kernel(float* __restrict__ xproj
     // scratch tile nobody reads), so the compute CU's in-order vector-memory queue only ever sees L2 hits.  It paces
     // itself on the epoch tags of the compute workgroup's own granules and leaves when the done word is set.
     constexpr int PF_AHEAD = 6;
-    const int mylen = (slice * 16 + l15 < B) ? min(length[slice * 16 + l15], T) : 0;
+    const int mylen = (l15 < ROWS && slice * ROWS + l15 < B) ? min(length[slice * ROWS + l15], T) : 0;   // lane = row of the slice
     // rows t >= length of the outputs are zero (dynamic_rnn): the companion clears this member's columns of them, so a
     // dense batch needs no memset of y at all (the compute workgroups write every row they own)
-    for (int rr = wave * 4; rr < wave * 4 + 4; ++rr) {
-      const int bb = slice * 16 + rr;
+    for (int rr = wave * RL; rr < wave * RL + RL; ++rr) {
+      const int bb = slice * ROWS + rr;
       if (bb >= B) continue;
       const int ll = __builtin_amdgcn_readlane(mylen, rr);
       constexpr int LPR = HS * 2 / 16;                            // 16-byte pieces of the member's span in a row
@@ -188,12 +194,12 @@ __global__ __launch_bounds__(256) void lstm_fwd_kernel(float* __restrict__ xproj
         }
       }
 #pragma unroll
-      for (int r4 = 0; r4 < 4; ++r4) {
-        const int rr = wave * 4 + r4;
+      for (int r4 = 0; r4 < RL; ++r4) {
+        const int rr = wave * RL + r4;
         const int ll = __builtin_amdgcn_readlane(mylen, rr);
         if (sp < ll) {
           const int pos = dir == 0 ? sp : ll - 1 - sp;
-          const float* src = xproj + ((int64_t)(slice * 16 + rr) * T + pos) * xrow + dir * 4 * H + member * HS * 4 +
+          const float* src = xproj + ((int64_t)(slice * ROWS + rr) * T + pos) * xrow + dir * 4 * H + member * HS * 4 +
                              (lane % (HS > 64 ? 64 : HS)) * 4;
           __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src),
                                            (__attribute__((address_space(3))) void*)(pf_scratch), 16, 0, 0);
@@ -226,11 +232,11 @@ __global__ __launch_bounds__(256) void lstm_fwd_kernel(float* __restrict__ xproj
   }
   __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0): the weights are in registers before the time loop, not waited for inside it
 
-  float c[UB][4], h[UB][4];
+  float c[UB][RL], h[UB][RL];
 #pragma unroll
   for (int ub = 0; ub < UB; ++ub)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) { c[ub][r] = 0.f; h[ub][r] = 0.f; }
+    for (int r = 0; r < RL; ++r) { c[ub][r] = 0.f; h[ub][r] = 0.f; }
 
   for (int i = tid; i < 2 * 16 * LS; i += 256) (&hlds[0][0][0])[i] = 0;
   if (tid == 0) fail_flag = 0;
@@ -248,13 +254,13 @@ __global__ __launch_bounds__(256) void lstm_fwd_kernel(float* __restrict__ xproj
       const int pi = q / NGRAN, gi = q % NGRAN;
       const int peer = pi + (pi >= member ? 1 : 0);
       poll_off[i] = (unsigned)(peer * NGRAN + gi) * 8u;                              // bytes inside the group's parity slot
-      scat_off[i] = (unsigned)((gi / HS) * 2 * LS + peer * HS + gi % HS);           // element of row pair (rp*2, rp*2+1)
+      scat_off[i] = (unsigned)((gi / HS) * (ROWS == 16 ? 2 : 4) * LS + peer * HS + gi % HS);   // first row of the pair in the tile
     }
   }
   // lean path: byte offsets of this lane's four rows at the current step (xproj; cbuf = /4, y = /8: same row index)
-  unsigned xoff[4];
+  unsigned xoff[RL];
 #pragma unroll
-  for (int r = 0; r < 4; ++r) {
+  for (int r = 0; r < RL; ++r) {
     const int pos = dir == 0 ? 0 : len[r] - 1;
     xoff[r] = (unsigned)((((int64_t)bidx[r] * T + pos) * xrow + dir * 4 * H + unit0 * 4) * 4);
   }
@@ -266,10 +272,10 @@ __global__ __launch_bounds__(256) void lstm_fwd_kernel(float* __restrict__ xproj
   int cur = 0;
   auto step = [&](int s, auto lean_tag) {
     constexpr bool LEAN = decltype(lean_tag)::value;
-    bool act[4];
-    int64_t rowoff[4];
+    bool act[RL];
+    int64_t rowoff[RL];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
+    for (int r = 0; r < RL; ++r) {
       act[r] = LEAN || s < len[r];
       if constexpr (!LEAN) {
         const int pos = dir == 0 ? s : len[r] - 1 - s;
@@ -277,11 +283,11 @@ __global__ __launch_bounds__(256) void lstm_fwd_kernel(float* __restrict__ xproj
       }
     }
     // x_t K_x + b of this step: issued now, consumed after the MFMAs
-    float4 xp[UB][4];
+    float4 xp[UB][RL];
 #pragma unroll
     for (int ub = 0; ub < UB; ++ub)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
+      for (int r = 0; r < RL; ++r) {
         xp[ub][r] = make_float4(0.f, 0.f, 0.f, 0.f);
         if (lead) {
           if constexpr (LEAN) xp[ub][r] = *reinterpret_cast<const float4*>(xbase + xoff[r] + ub * 256);
@@ -349,15 +355,15 @@ __global__ __launch_bounds__(256) void lstm_fwd_kernel(float* __restrict__ xproj
     }
     if (lead) {
       u64* dst = ex_group + (int64_t)(s & 1) * par_stride + (int64_t)member * NGRAN;
-      float4 gsave[UB][4];
-      float csave[UB][4];
+      float4 gsave[UB][RL];
+      float csave[UB][RL];
 #pragma unroll
       for (int ub = 0; ub < UB; ++ub) {
         const int unit = unit0 + ub * 16;
         const int ul = unit - member * HS;
-        unsigned short hb[4];
+        unsigned short hb[RL];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
+        for (int r = 0; r < RL; ++r) {
           const float gi = las_sigmoid(acc[0][ub][r] + xp[ub][r].x);
           const float gj = las_tanh(acc[1][ub][r] + xp[ub][r].y);
           const float gf = las_sigmoid(acc[2][ub][r] + xp[ub][r].z + 1.0f);
@@ -375,15 +381,17 @@ __global__ __launch_bounds__(256) void lstm_fwd_kernel(float* __restrict__ xproj
         }
         // the peers wait for these: they go out before the step's own HBM stores
         if constexpr (G > 1) {
-          granule_store(dst + (lq * 2) * HS + ul, (unsigned)(s + 1), (unsigned)hb[0] | ((unsigned)hb[1] << 16), local);
-          granule_store(dst + (lq * 2 + 1) * HS + ul, (unsigned)(s + 1), (unsigned)hb[2] | ((unsigned)hb[3] << 16), local);
+#pragma unroll
+          for (int rp = 0; rp < RL / 2; ++rp)
+            granule_store(dst + (lq * (RL / 2) + rp) * HS + ul, (unsigned)(s + 1),
+                          (unsigned)hb[2 * rp] | ((unsigned)hb[2 * rp + 1] << 16), local);
         }
       }
 #pragma unroll
       for (int ub = 0; ub < UB; ++ub) {
         const int unit = unit0 + ub * 16;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
+        for (int r = 0; r < RL; ++r) {
           if constexpr (LEAN) {
             *reinterpret_cast<float4*>(xbase + xoff[r] + ub * 256) = gsave[ub][r];
             *reinterpret_cast<float*>(cbase + (xoff[r] >> 2) + ub * 64) = csave[ub][r];
@@ -398,7 +406,7 @@ __global__ __launch_bounds__(256) void lstm_fwd_kernel(float* __restrict__ xproj
     }
     if constexpr (LEAN) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) xoff[r] += (unsigned)xstep;
+      for (int r = 0; r < RL; ++r) xoff[r] += (unsigned)xstep;
     }
     cur ^= 1;
     return true;
@@ -417,7 +425,7 @@ __global__ __launch_bounds__(256) void lstm_fwd_kernel(float* __restrict__ xproj
 #pragma unroll
   for (int ub = 0; ub < UB; ++ub)
 #pragma unroll
-    for (int r = 0; r < 4; ++r)
+    for (int r = 0; r < RL; ++r)
       if (bidx[r] < B && lead) {
         const int64_t o = ((int64_t)dir * B + bidx[r]) * H + unit0 + ub * 16;
         c_last[o] = c[ub][r];
@@ -797,18 +805,32 @@ __global__ __launch_bounds__(256) void lstm_bwd_kernel(const float* __restrict__
 
 struct CoopGeom { int nslices, ngroups, G, blocks; size_t exch_bytes; };
 
-CoopGeom geom(int B, int H, int ndir, bool bwd) {
+CoopGeom geom(int B, int H, int ndir, bool bwd, int rows = 16) {
   CoopGeom g;
   g.G = coop_members(H);
-  g.nslices = (B + 15) / 16;
+  g.nslices = (B + rows - 1) / rows;
   g.ngroups = g.nslices * ndir;
   g.blocks = ((g.ngroups + 7) & ~7) * g.G;        // group stride rounded up to 8 (idle blocks exit at once)
-  // granules per parity slot: forward all-gather of h_t: ngroups x G members x 8*HS; backward reduce-scatter of the
-  // partial dh: ngroups x G x G (destination, sender) pairs x NUB*256
+  // granules per parity slot: forward all-gather of h_t: ngroups x G members x (rows/2)*HS; backward reduce-scatter of
+  // the partial dh: ngroups x G x G (destination, sender) pairs x NUB*256
   const size_t HS = H / g.G;
-  const size_t per_parity = bwd ? (size_t)g.ngroups * g.G * g.G * (HS / 16) * 256 : (size_t)g.ngroups * g.G * 8 * HS;
+  const size_t per_parity = bwd ? (size_t)g.ngroups * g.G * g.G * (HS / 16) * 256 : (size_t)g.ngroups * g.G * (rows / 2) * HS;
   g.exch_bytes = g.G > 1 ? (2 * per_parity + (size_t)g.ngroups * g.G + g.blocks) * sizeof(u64) : 0;   // + XCC-id table + done words
   return g;
+}
+
+// Utterances per slice.  8-row slices (see lstm_fwd_kernel) when the chains they make, with their companions, still
+// find a CU each (256 on MI355X); LAS_LSTM_ROWS=16 / 8 forces one (diagnostics; 8 needs a kernel that supports it).
+int slice_rows(int B, int H, int ndir) {
+  static int forced = -1;
+  if (forced < 0) {
+    const char* e = getenv("LAS_LSTM_ROWS");
+    forced = e ? atoi(e) : 0;
+  }
+  if (H != 256) return 16;
+  if (forced == 16 || forced == 8) return forced;
+  const CoopGeom g8 = geom(B, H, ndir, false, 8);
+  return 2 * g8.blocks <= 256 ? 8 : 16;
 }
 
 // LAS_LSTM_PREFETCH=0 launches the recurrent kernels without their prefetch companions (diagnostics)
@@ -824,11 +846,20 @@ int prefetch_mode() {
 template <int H>
 int launch_fwd(float* xproj, const las_bf16* wp, const int32_t* length, las_bf16* y, float* cbuf, float* c_last,
                float* h_last, void* ws, int B, int T, int ndir, hipStream_t st) {
-  const CoopGeom g = geom(B, H, ndir, false);
+  const int rows = slice_rows(B, H, ndir);
+  const CoopGeom g = geom(B, H, ndir, false, rows);
   unsigned* status = reinterpret_cast<unsigned*>(ws);
   u64* exch = reinterpret_cast<u64*>(reinterpret_cast<char*>(ws) + 64);
   const int pf = g.G > 1 ? prefetch_mode() : 0;
-  hipLaunchKernelGGL((lstm_fwd_kernel<H>), dim3(pf ? 2 * g.blocks : g.blocks), dim3(256), 0, st, xproj, wp, length, y,
+  if constexpr (H == 256) {
+    if (rows == 8) {
+      hipLaunchKernelGGL((lstm_fwd_kernel<H, 8>), dim3(pf ? 2 * g.blocks : g.blocks), dim3(256), 0, st, xproj, wp, length, y,
+                         cbuf, c_last, h_last, exch, status, B, T, ndir, g.ngroups, pf);
+      LAS_LAUNCH_CHECK("lstm fwd launch");
+      return LAS_OK;
+    }
+  }
+  hipLaunchKernelGGL((lstm_fwd_kernel<H, 16>), dim3(pf ? 2 * g.blocks : g.blocks), dim3(256), 0, st, xproj, wp, length, y,
                      cbuf, c_last, h_last, exch, status, B, T, ndir, g.ngroups, pf);
   LAS_LAUNCH_CHECK("lstm fwd launch");
   return LAS_OK;
@@ -862,7 +893,13 @@ bool supported_units(int H) { return H == 64 || H == 128 || H == 256 || H == 512
 
 extern "C" size_t las_lstm_workspace_bytes(int B, int H, int ndir) {
   if (!supported_units(H) || B <= 0) return 0;
-  return 64 + geom(B, H, ndir, true).exch_bytes;
+  size_t n = 0;
+  for (int rows = 8; rows <= 16; rows += 8)
+    for (int bwd = 0; bwd < 2; ++bwd) {
+      const size_t e = geom(B, H, ndir, bwd != 0, rows).exch_bytes;
+      if (e > n) n = e;
+    }
+  return 64 + n;
 }
 
 extern "C" int las_lstm_pack_recurrent(const float* kernel_h, int H, las_bf16* packed, void* stream) {
@@ -884,7 +921,7 @@ extern "C" int las_lstm_recurrent_fwd(float* xproj, const las_bf16* wpacked, con
     rc = las_check_hip(hipMemsetAsync(y, 0, (size_t)B * T * ndir * H * sizeof(las_bf16), st), "memset y");
     if (rc) return rc;
   }
-  rc = las_check_hip(hipMemsetAsync(workspace, 0, 64 + geom(B, H, ndir, false).exch_bytes, st), "memset workspace");
+  rc = las_check_hip(hipMemsetAsync(workspace, 0, 64 + geom(B, H, ndir, false, slice_rows(B, H, ndir)).exch_bytes, st), "memset workspace");
   if (rc) return rc;
   switch (H) {
     case 64: return launch_fwd<64>(xproj, wpacked, length, y, cbuf, c_last, h_last, workspace, B, T, ndir, st);
