@@ -444,7 +444,7 @@ __global__ __launch_bounds__(256) void lstm_fwd_kernel(float* __restrict__ xproj
 // is 4 x (G-1) granules each way, against 8 x 4 x (G-1) for an all-gather of dz_t.
 // kh is K_h [H, 4H] in bf16 with GATE-INTERLEAVED columns (u*4+g): a member's K range is contiguous.
 // ------------------------------------------------------------------------------------------------
-template <int H>
+template <int H, int ROWS>            // ROWS: utterances per slice, as in lstm_fwd_kernel
 __global__ __launch_bounds__(256) void lstm_bwd_kernel(const float* __restrict__ gates, const float* __restrict__ cbuf,
                                                        const float* __restrict__ dy, const float* __restrict__ dc_last,
                                                        const float* __restrict__ dh_last, const unsigned short* __restrict__ kh,
@@ -457,13 +457,14 @@ __global__ __launch_bounds__(256) void lstm_bwd_kernel(const float* __restrict__
   constexpr bool SPLIT = NUB < 4;                 // H = 512: two waves share a unit block, two rows of every quad each
   static_assert(!SPLIT || NUB == 2, "row split is written for two unit blocks per member");
   constexpr int UBW = SPLIT ? 1 : NUB / 4;        // unit blocks a wave owns
-  constexpr int RPL = SPLIT ? 2 : 4;              // rows of its quad a lane owns
+  static_assert(ROWS == 16 || (ROWS == 8 && !SPLIT), "8-row slices: only without the row split");
+  constexpr int RPL = SPLIT ? 2 : ROWS / 4;       // rows of its quad a lane owns (8-row slices: rows 0,1 of every quad)
   constexpr int KCW = HS / 8;                     // k-chunks of the member's 4*HS gate columns
   constexpr int NT = SPLIT ? G / 2 : G * UBW;     // 16-unit output tiles a wave computes
   constexpr int OWN = SPLIT ? 0 : UBW;            // ... of which stay in registers (own units)
   constexpr int ZS = 4 * HS + 8;                  // LDS row stride of the dz tile (elements)
   constexpr int PAIR = NUB * 256;                 // granules per (destination, sender) pair: [block][row][lane]
-  constexpr int PER = G > 1 ? (SPLIT ? G * RPL : (G - 1) * UBW * 4) : 1;   // granules a lane polls per step
+  constexpr int PER = G > 1 ? (SPLIT ? G * RPL : (G - 1) * UBW * RPL) : 1;   // granules a lane polls per step
   __shared__ __attribute__((aligned(16))) unsigned short ztile[2][16][ZS];
   __shared__ int fail_flag;
   __shared__ int colo_flag;
@@ -492,11 +493,11 @@ __global__ __launch_bounds__(256) void lstm_bwd_kernel(const float* __restrict__
   int smax = 0, smin = 0x7fffffff;
 #pragma unroll
   for (int r = 0; r < RPL; ++r) {
-    bidx[r] = slice * 16 + lq * 4 + hh * 2 + r;
+    bidx[r] = ROWS == 16 ? slice * 16 + lq * 4 + hh * 2 + r : slice * ROWS + lq * RPL + r;
     len[r] = (bidx[r] < B) ? min(length[bidx[r]], T) : 0;
   }
   {
-    const int ll = (slice * 16 + l15 < B) ? min(length[slice * 16 + l15], T) : 0;     // all 16 rows of the slice
+    const int ll = (l15 < ROWS && slice * ROWS + l15 < B) ? min(length[slice * ROWS + l15], T) : 0;     // all rows of the slice
     smax = (int)las_wave_max((float)ll);
     smin = -(int)las_wave_max((float)(-ll));
   }
@@ -505,10 +506,10 @@ __global__ __launch_bounds__(256) void lstm_bwd_kernel(const float* __restrict__
   if constexpr (G > 1) if (companion) {
     // PREFETCH COMPANION (see lstm_fwd_kernel): gates, c and dy lines of the compute workgroup, PF_AHEAD steps ahead.
     constexpr int PF_AHEAD = 6;
-    const int mylen = (slice * 16 + l15 < B) ? min(length[slice * 16 + l15], T) : 0;
+    const int mylen = (l15 < ROWS && slice * ROWS + l15 < B) ? min(length[slice * ROWS + l15], T) : 0;
     // dz rows t >= length are zero: cleared here (this member's gate columns), so dense batches need no memset of dz
-    for (int rr = wave * 4; rr < wave * 4 + 4; ++rr) {
-      const int bb = slice * 16 + rr;
+    for (int rr = wave * (ROWS / 4); rr < (wave + 1) * (ROWS / 4); ++rr) {
+      const int bb = slice * ROWS + rr;
       if (bb >= B) continue;
       const int ll = __builtin_amdgcn_readlane(mylen, rr);
       constexpr int LPR = 4 * HS * 2 / 16;
@@ -533,12 +534,12 @@ __global__ __launch_bounds__(256) void lstm_bwd_kernel(const float* __restrict__
         }
       }
 #pragma unroll
-      for (int r4 = 0; r4 < 4; ++r4) {
-        const int rr = wave * 4 + r4;
+      for (int r4 = 0; r4 < ROWS / 4; ++r4) {
+        const int rr = wave * (ROWS / 4) + r4;
         const int ll = __builtin_amdgcn_readlane(mylen, rr);
         if (sp < ll) {
           const int pos = dir == 0 ? sp : ll - 1 - sp;
-          const int64_t R = (int64_t)(slice * 16 + rr) * T + pos;
+          const int64_t R = (int64_t)(slice * ROWS + rr) * T + pos;
           const float* src = gates + R * grow + dir * 4 * H + member * HS * 4 + (lane % (HS > 64 ? 64 : HS)) * 4;
           __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src),
                                            (__attribute__((address_space(3))) void*)(pf_scratch), 16, 0, 0);
@@ -593,7 +594,7 @@ __global__ __launch_bounds__(256) void lstm_bwd_kernel(const float* __restrict__
     for (int e = 0; e < PER; ++e) {
       int sender, ub, r;
       if constexpr (SPLIT) { sender = e / RPL; ub = 0; r = hh * 2 + e % RPL; }
-      else { sender = (member + 1 + e / (UBW * 4)) % G; ub = (e / 4) % UBW; r = e % 4; }
+      else { sender = (member + 1 + e / (UBW * RPL)) % G; ub = (e / RPL) % UBW; r = e % RPL; }
       poll_off[e] = (unsigned)((((member * G + sender) * NUB + blk + ub) * 4 + r) * 64 + lane) * 8u;
     }
 #pragma unroll
@@ -719,7 +720,7 @@ __global__ __launch_bounds__(256) void lstm_bwd_kernel(const float* __restrict__
 #pragma unroll
           for (int i = 0; i < CH; ++i) {
             const int e = c0 + i;
-            const int ub = SPLIT ? 0 : (e / 4) % UBW, r = SPLIT ? e % RPL : e % 4;
+            const int ub = SPLIT ? 0 : (e / RPL) % UBW, r = e % RPL;
             cand[ub][r] += __uint_as_float((unsigned)v[i]);
           }
         }
@@ -788,7 +789,7 @@ __global__ __launch_bounds__(256) void lstm_bwd_kernel(const float* __restrict__
 #pragma unroll
       for (int j = OWN; j < NT; ++j)
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
+        for (int r = 0; r < (SPLIT ? 4 : RPL); ++r)       // 8-row slices: rows 2, 3 of every quad carry nothing
           granule_store(reinterpret_cast<u64*>(dst + send_off[j - OWN] + r * 512), epoch + 1, __float_as_uint(acc[j][r]), local);
     }
 #pragma unroll
@@ -822,11 +823,8 @@ CoopGeom geom(int B, int H, int ndir, bool bwd, int rows = 16) {
 // Utterances per slice.  8-row slices (see lstm_fwd_kernel) when the chains they make, with their companions, still
 // find a CU each (256 on MI355X); LAS_LSTM_ROWS=16 / 8 forces one (diagnostics; 8 needs a kernel that supports it).
 int slice_rows(int B, int H, int ndir) {
-  static int forced = -1;
-  if (forced < 0) {
-    const char* e = getenv("LAS_LSTM_ROWS");
-    forced = e ? atoi(e) : 0;
-  }
+  const char* e = getenv("LAS_LSTM_ROWS");          // read at every launch: the tests switch it
+  const int forced = e ? atoi(e) : 0;
   if (H != 256) return 16;
   if (forced == 16 || forced == 8) return forced;
   const CoopGeom g8 = geom(B, H, ndir, false, 8);
@@ -868,7 +866,8 @@ int launch_fwd(float* xproj, const las_bf16* wp, const int32_t* length, las_bf16
 template <int H>
 int launch_bwd(const float* gates, const float* cbuf, const float* dy, const float* dc_last, const float* dh_last,
                const las_bf16* kh, const int32_t* length, las_bf16* dz, void* ws, int B, int T, int ndir, hipStream_t st) {
-  const CoopGeom g = geom(B, H, ndir, true);
+  const int rows = slice_rows(B, H, ndir);
+  const CoopGeom g = geom(B, H, ndir, true, rows);
   unsigned* status = reinterpret_cast<unsigned*>(ws);
   u64* exch = reinterpret_cast<u64*>(reinterpret_cast<char*>(ws) + 64);
   const int pf = g.G > 1 ? prefetch_mode() : 0;
@@ -878,10 +877,21 @@ int launch_bwd(const float* gates, const float* cbuf, const float* dy, const flo
   if (hog_kb < 0) {
     const char* e = getenv("LAS_LSTM_BWD_LDS_KB");
     hog_kb = e ? atoi(e) : 120;
-    if (hog_kb > 0)
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&lstm_bwd_kernel<H>), hipFuncAttributeMaxDynamicSharedMemorySize, hog_kb * 1024);
+    if (hog_kb > 0) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&lstm_bwd_kernel<H, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, hog_kb * 1024);
+      if constexpr (H == 256)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&lstm_bwd_kernel<H, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, hog_kb * 1024);
+    }
   }
-  hipLaunchKernelGGL((lstm_bwd_kernel<H>), dim3(pf ? 2 * g.blocks : g.blocks), dim3(256), (size_t)hog_kb * 1024, st, gates, cbuf, dy, dc_last, dh_last, kh,
+  if constexpr (H == 256) {
+    if (rows == 8) {
+      hipLaunchKernelGGL((lstm_bwd_kernel<H, 8>), dim3(pf ? 2 * g.blocks : g.blocks), dim3(256), (size_t)hog_kb * 1024, st, gates, cbuf, dy,
+                         dc_last, dh_last, kh, length, dz, exch, status, B, T, ndir, g.ngroups);
+      LAS_LAUNCH_CHECK("lstm bwd launch");
+      return LAS_OK;
+    }
+  }
+  hipLaunchKernelGGL((lstm_bwd_kernel<H, 16>), dim3(pf ? 2 * g.blocks : g.blocks), dim3(256), (size_t)hog_kb * 1024, st, gates, cbuf, dy, dc_last, dh_last, kh,
                      length, dz, exch, status, B, T, ndir, g.ngroups);
   LAS_LAUNCH_CHECK("lstm bwd launch");
   return LAS_OK;
@@ -943,7 +953,7 @@ extern "C" int las_lstm_recurrent_bwd(const float* gates, const float* cbuf, con
     rc = las_check_hip(hipMemsetAsync(dz, 0, (size_t)B * T * ndir * 4 * H * sizeof(las_bf16), st), "memset dz");
     if (rc) return rc;
   }
-  rc = las_check_hip(hipMemsetAsync(workspace, 0, 64 + geom(B, H, ndir, true).exch_bytes, st), "memset workspace");
+  rc = las_check_hip(hipMemsetAsync(workspace, 0, 64 + geom(B, H, ndir, true, slice_rows(B, H, ndir)).exch_bytes, st), "memset workspace");
   if (rc) return rc;
   switch (H) {
     case 64: return launch_bwd<64>(gates, cbuf, dy, dc_last, dh_last, kh_bf16, length, dz, workspace, B, T, ndir, st);
