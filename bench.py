@@ -305,7 +305,8 @@ def main():
                        'global_batch': c['B'] * world, 'parallelism': 'dp%d' % world,
                        'hip_graph': not args.no_graph, 'exchange': 'two buckets, overlapped' if overlap_exchange else 'one all-reduce',
                        'final_loss': round(final_loss, 4)},
-            'roofline': {'bound': 'mfma', 'kernel': 'lstm_fwd_kernel<%d> (layer-1 shape, both directions)' % c['H'],
+            'roofline': {'bound': 'mfma', 'kernel': 'lstm_fwd_kernel<%d, %d> (layer-1 shape, both directions)' % (
+                             c['H'], __import__('phones_las_amd.hip', fromlist=['lib']).lib().las_lstm_slice_rows(c['B'], c['H'], 2)),
                          'achieved': round(achieved, 3), 'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s',
                          'frac': round(achieved / PEAK_BF16_TFLOPS, 6), 'traffic': traffic,
                          'kernel_ms': round(kms, 3),

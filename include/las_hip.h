@@ -161,6 +161,10 @@ int las_lstm_recurrent_fwd(float* xproj, const las_bf16* wpacked, const int32_t*
  * zero it themselves (a memset node per launch).  After a launch the first uint32 is 0, or non-zero
  * if a bounded inter-workgroup wait timed out (results are then invalid). */
 size_t las_lstm_workspace_bytes(int B, int H, int ndir);
+/* Utterances per slice the recurrent kernels will use for this shape (16 = full MFMA tiles; 8 = half-filled tiles on
+ * twice as many chains, chosen for 256 units while every chain and its prefetch companion still find a CU each: the
+ * per-step latency is mostly element-wise work per lane).  LAS_LSTM_ROWS=16|8 in the environment overrides (tests). */
+int las_lstm_slice_rows(int B, int H, int ndir);
 
 /* Backward recurrence (reverse-mode AD of the loop above).
  * gates/cbuf: saved by the forward.  dy [B,T,ndir*H] fp32: gradient w.r.t. y.  dc_last/dh_last

@@ -901,6 +901,11 @@ bool supported_units(int H) { return H == 64 || H == 128 || H == 256 || H == 512
 
 }  // namespace
 
+extern "C" int las_lstm_slice_rows(int B, int H, int ndir) {
+  if (!supported_units(H) || B <= 0) return 0;
+  return slice_rows(B, H, ndir);
+}
+
 extern "C" size_t las_lstm_workspace_bytes(int B, int H, int ndir) {
   if (!supported_units(H) || B <= 0) return 0;
   size_t n = 0;
