@@ -122,8 +122,9 @@ __global__ __launch_bounds__(256) void lstm_fwd_kernel(float* __restrict__ xproj
   constexpr int KCW = KC / KS;         // k-chunks a wave owns
   constexpr int LS = H + 8;            // LDS row stride (elements)
   constexpr int RL = ROWS / 4;         // utterances per lane (rows lq*4 .. lq*4+RL-1 of the MFMA tile)
-  static_assert(ROWS == 16 || (ROWS == 8 && KS == 1), "8-row slices: only without the K split");
-  constexpr int NGRAN = (ROWS / 2) * HS;   // granules a member publishes per step (2 rows x 1 unit each)
+  static_assert(ROWS == 16 || ((ROWS == 8 || ROWS == 4) && KS == 1), "short slices: only without the K split");
+  constexpr int GV = RL >= 2 ? 2 : 1;      // bf16 values per granule: a row pair of one unit, or a single value (4-row slices)
+  constexpr int NGRAN = ROWS * HS / GV;    // granules a member publishes per step
   constexpr int PER = G > 1 ? (G - 1) * NGRAN / 256 : 1;   // granules a thread polls per step
   static_assert(G == 1 || ((G - 1) * NGRAN) % 256 == 0, "granules must divide over the threads");
   __shared__ __attribute__((aligned(16))) unsigned short hlds[2][16][LS];
@@ -254,7 +255,7 @@ __global__ __launch_bounds__(256) void lstm_fwd_kernel(float* __restrict__ xproj
       const int pi = q / NGRAN, gi = q % NGRAN;
       const int peer = pi + (pi >= member ? 1 : 0);
       poll_off[i] = (unsigned)(peer * NGRAN + gi) * 8u;                              // bytes inside the group's parity slot
-      scat_off[i] = (unsigned)((gi / HS) * (ROWS == 16 ? 2 : 4) * LS + peer * HS + gi % HS);   // first row of the pair in the tile
+      scat_off[i] = (unsigned)((gi / HS) * (ROWS == 16 ? 2 : 4) * LS + peer * HS + gi % HS);   // (first) row of the granule in the tile
     }
   }
   // lean path: byte offsets of this lane's four rows at the current step (xproj; cbuf = /4, y = /8: same row index)
@@ -320,7 +321,7 @@ __global__ __launch_bounds__(256) void lstm_fwd_kernel(float* __restrict__ xproj
         for (int i = 0; i < CH; ++i) {
           const unsigned val = (unsigned)v[i];
           hl[scat_off[c0 + i]] = (unsigned short)(val & 0xffffu);
-          hl[scat_off[c0 + i] + LS] = (unsigned short)(val >> 16);
+          if constexpr (GV == 2) hl[scat_off[c0 + i] + LS] = (unsigned short)(val >> 16);
         }
       }
     }
@@ -382,9 +383,9 @@ __global__ __launch_bounds__(256) void lstm_fwd_kernel(float* __restrict__ xproj
         // the peers wait for these: they go out before the step's own HBM stores
         if constexpr (G > 1) {
 #pragma unroll
-          for (int rp = 0; rp < RL / 2; ++rp)
-            granule_store(dst + (lq * (RL / 2) + rp) * HS + ul, (unsigned)(s + 1),
-                          (unsigned)hb[2 * rp] | ((unsigned)hb[2 * rp + 1] << 16), local);
+          for (int rp = 0; rp < (RL + 1) / 2; ++rp)
+            granule_store(dst + (lq * ((RL + 1) / 2) + rp) * HS + ul, (unsigned)(s + 1),
+                          (unsigned)hb[2 * rp] | (GV == 2 ? (unsigned)hb[(2 * rp + 1) % RL] << 16 : 0u), local);
         }
       }
 #pragma unroll
@@ -457,7 +458,7 @@ __global__ __launch_bounds__(256) void lstm_bwd_kernel(const float* __restrict__
   constexpr bool SPLIT = NUB < 4;                 // H = 512: two waves share a unit block, two rows of every quad each
   static_assert(!SPLIT || NUB == 2, "row split is written for two unit blocks per member");
   constexpr int UBW = SPLIT ? 1 : NUB / 4;        // unit blocks a wave owns
-  static_assert(ROWS == 16 || (ROWS == 8 && !SPLIT), "8-row slices: only without the row split");
+  static_assert(ROWS == 16 || ((ROWS == 8 || ROWS == 4) && !SPLIT), "short slices: only without the row split");
   constexpr int RPL = SPLIT ? 2 : ROWS / 4;       // rows of its quad a lane owns (8-row slices: rows 0,1 of every quad)
   constexpr int KCW = HS / 8;                     // k-chunks of the member's 4*HS gate columns
   constexpr int NT = SPLIT ? G / 2 : G * UBW;     // 16-unit output tiles a wave computes
@@ -815,20 +816,20 @@ CoopGeom geom(int B, int H, int ndir, bool bwd, int rows = 16) {
   // granules per parity slot: forward all-gather of h_t: ngroups x G members x (rows/2)*HS; backward reduce-scatter of
   // the partial dh: ngroups x G x G (destination, sender) pairs x NUB*256
   const size_t HS = H / g.G;
-  const size_t per_parity = bwd ? (size_t)g.ngroups * g.G * g.G * (HS / 16) * 256 : (size_t)g.ngroups * g.G * (rows / 2) * HS;
+  const size_t per_parity = bwd ? (size_t)g.ngroups * g.G * g.G * (HS / 16) * 256 : (size_t)g.ngroups * g.G * (rows >= 8 ? rows / 2 : rows) * HS;
   g.exch_bytes = g.G > 1 ? (2 * per_parity + (size_t)g.ngroups * g.G + g.blocks) * sizeof(u64) : 0;   // + XCC-id table + done words
   return g;
 }
 
 // Utterances per slice.  8-row slices (see lstm_fwd_kernel) when the chains they make, with their companions, still
 // find a CU each (256 on MI355X); LAS_LSTM_ROWS=16 / 8 forces one (diagnostics; 8 needs a kernel that supports it).
-int slice_rows(int B, int H, int ndir) {
+int slice_rows(int B, int H, int ndir, bool bwd) {
   const char* e = getenv("LAS_LSTM_ROWS");          // read at every launch: the tests switch it
   const int forced = e ? atoi(e) : 0;
   if (H != 256) return 16;
-  if (forced == 16 || forced == 8) return forced;
-  const CoopGeom g8 = geom(B, H, ndir, false, 8);
-  return 2 * g8.blocks <= 256 ? 8 : 16;
+  if (forced == 16 || forced == 8 || forced == 4) return forced;
+  if (!bwd && 2 * geom(B, H, ndir, false, 4).blocks <= 256) return 4;      // forward only: one (utterance, unit) per lane
+  return 2 * geom(B, H, ndir, false, 8).blocks <= 256 ? 8 : 16;
 }
 
 // LAS_LSTM_PREFETCH=0 launches the recurrent kernels without their prefetch companions (diagnostics)
@@ -844,7 +845,7 @@ int prefetch_mode() {
 template <int H>
 int launch_fwd(float* xproj, const las_bf16* wp, const int32_t* length, las_bf16* y, float* cbuf, float* c_last,
                float* h_last, void* ws, int B, int T, int ndir, hipStream_t st) {
-  const int rows = slice_rows(B, H, ndir);
+  const int rows = slice_rows(B, H, ndir, false);
   const CoopGeom g = geom(B, H, ndir, false, rows);
   unsigned* status = reinterpret_cast<unsigned*>(ws);
   u64* exch = reinterpret_cast<u64*>(reinterpret_cast<char*>(ws) + 64);
@@ -852,6 +853,12 @@ int launch_fwd(float* xproj, const las_bf16* wp, const int32_t* length, las_bf16
   if constexpr (H == 256) {
     if (rows == 8) {
       hipLaunchKernelGGL((lstm_fwd_kernel<H, 8>), dim3(pf ? 2 * g.blocks : g.blocks), dim3(256), 0, st, xproj, wp, length, y,
+                         cbuf, c_last, h_last, exch, status, B, T, ndir, g.ngroups, pf);
+      LAS_LAUNCH_CHECK("lstm fwd launch");
+      return LAS_OK;
+    }
+    if (rows == 4) {
+      hipLaunchKernelGGL((lstm_fwd_kernel<H, 4>), dim3(pf ? 2 * g.blocks : g.blocks), dim3(256), 0, st, xproj, wp, length, y,
                          cbuf, c_last, h_last, exch, status, B, T, ndir, g.ngroups, pf);
       LAS_LAUNCH_CHECK("lstm fwd launch");
       return LAS_OK;
@@ -866,7 +873,7 @@ int launch_fwd(float* xproj, const las_bf16* wp, const int32_t* length, las_bf16
 template <int H>
 int launch_bwd(const float* gates, const float* cbuf, const float* dy, const float* dc_last, const float* dh_last,
                const las_bf16* kh, const int32_t* length, las_bf16* dz, void* ws, int B, int T, int ndir, hipStream_t st) {
-  const int rows = slice_rows(B, H, ndir);
+  const int rows = slice_rows(B, H, ndir, true);
   const CoopGeom g = geom(B, H, ndir, true, rows);
   unsigned* status = reinterpret_cast<unsigned*>(ws);
   u64* exch = reinterpret_cast<u64*>(reinterpret_cast<char*>(ws) + 64);
@@ -890,6 +897,12 @@ int launch_bwd(const float* gates, const float* cbuf, const float* dy, const flo
       LAS_LAUNCH_CHECK("lstm bwd launch");
       return LAS_OK;
     }
+    if (rows == 4) {        // every CU holds a chain or a companion: no LDS request beyond what the kernel uses
+      hipLaunchKernelGGL((lstm_bwd_kernel<H, 4>), dim3(pf ? 2 * g.blocks : g.blocks), dim3(256), 0, st, gates, cbuf, dy,
+                         dc_last, dh_last, kh, length, dz, exch, status, B, T, ndir, g.ngroups);
+      LAS_LAUNCH_CHECK("lstm bwd launch");
+      return LAS_OK;
+    }
   }
   hipLaunchKernelGGL((lstm_bwd_kernel<H, 16>), dim3(pf ? 2 * g.blocks : g.blocks), dim3(256), (size_t)hog_kb * 1024, st, gates, cbuf, dy, dc_last, dh_last, kh,
                      length, dz, exch, status, B, T, ndir, g.ngroups);
@@ -903,13 +916,13 @@ bool supported_units(int H) { return H == 64 || H == 128 || H == 256 || H == 512
 
 extern "C" int las_lstm_slice_rows(int B, int H, int ndir) {
   if (!supported_units(H) || B <= 0) return 0;
-  return slice_rows(B, H, ndir);
+  return slice_rows(B, H, ndir, false);
 }
 
 extern "C" size_t las_lstm_workspace_bytes(int B, int H, int ndir) {
   if (!supported_units(H) || B <= 0) return 0;
   size_t n = 0;
-  for (int rows = 8; rows <= 16; rows += 8)
+  for (int rows = 4; rows <= 16; rows *= 2)
     for (int bwd = 0; bwd < 2; ++bwd) {
       const size_t e = geom(B, H, ndir, bwd != 0, rows).exch_bytes;
       if (e > n) n = e;
@@ -936,7 +949,7 @@ extern "C" int las_lstm_recurrent_fwd(float* xproj, const las_bf16* wpacked, con
     rc = las_check_hip(hipMemsetAsync(y, 0, (size_t)B * T * ndir * H * sizeof(las_bf16), st), "memset y");
     if (rc) return rc;
   }
-  rc = las_check_hip(hipMemsetAsync(workspace, 0, 64 + geom(B, H, ndir, false, slice_rows(B, H, ndir)).exch_bytes, st), "memset workspace");
+  rc = las_check_hip(hipMemsetAsync(workspace, 0, 64 + geom(B, H, ndir, false, slice_rows(B, H, ndir, false)).exch_bytes, st), "memset workspace");
   if (rc) return rc;
   switch (H) {
     case 64: return launch_fwd<64>(xproj, wpacked, length, y, cbuf, c_last, h_last, workspace, B, T, ndir, st);
@@ -958,7 +971,7 @@ extern "C" int las_lstm_recurrent_bwd(const float* gates, const float* cbuf, con
     rc = las_check_hip(hipMemsetAsync(dz, 0, (size_t)B * T * ndir * 4 * H * sizeof(las_bf16), st), "memset dz");
     if (rc) return rc;
   }
-  rc = las_check_hip(hipMemsetAsync(workspace, 0, 64 + geom(B, H, ndir, true, slice_rows(B, H, ndir)).exch_bytes, st), "memset workspace");
+  rc = las_check_hip(hipMemsetAsync(workspace, 0, 64 + geom(B, H, ndir, true, slice_rows(B, H, ndir, true)).exch_bytes, st), "memset workspace");
   if (rc) return rc;
   switch (H) {
     case 64: return launch_bwd<64>(gates, cbuf, dy, dc_last, dh_last, kh_bf16, length, dz, workspace, B, T, ndir, st);
