@@ -85,6 +85,8 @@ __device__ bool xcd_colocated(u64* table, int member, int* lds_flag, unsigned* s
 // (a wave's register-resident weight block is 16 units x 4 gates x K/KS: 128 VGPRs in every case)
 __host__ __device__ constexpr int coop_members(int H) { return H <= 128 ? 1 : (H == 256 ? 4 : H / 32); }
 __host__ __device__ constexpr int k_split(int H) { return H > 256 ? 2 : 1; }
+// prefetch companions per group: one serves four members' columns
+__host__ __device__ constexpr int group_companions(int H) { return coop_members(H) >= 4 ? coop_members(H) / 4 : 1; }
 
 // ------------------------------------------------------------------------------------------------
 // pack K_h [H,4H] fp32 -> MFMA-B-fragment-major bf16, grouped by 16-unit block:
@@ -135,10 +137,12 @@ __global__ __launch_bounds__(256) void lstm_fwd_kernel(float* __restrict__ xproj
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int gstride = (ngroups + 7) & ~7;        // members of a group are 8k blocks apart: one XCD under round-robin
-  const int nblk = gstride * G;                  // compute workgroups; blocks beyond them are their prefetch companions
+  const int nblk = gstride * G;                  // compute workgroups; the blocks beyond them: CPG prefetch companions per group
+  constexpr int CPG = group_companions(H);
   const bool companion = (int)blockIdx.x >= nblk;
   const int cblk = companion ? blockIdx.x - nblk : blockIdx.x;
-  const int group = cblk % gstride, member = cblk / gstride;
+  const int group = cblk % gstride, member = companion ? 0 : cblk / gstride;
+  const int cm = companion ? cblk / gstride : 0;       // which quarter (1/CPG) of the direction's columns a companion serves
   if (group >= ngroups) return;
   const int nslices = ngroups / ndir;
   const int slice = group % nslices, dir = group / nslices;
@@ -147,7 +151,7 @@ __global__ __launch_bounds__(256) void lstm_fwd_kernel(float* __restrict__ xproj
   const int64_t yrow = (int64_t)ndir * H;
   const int64_t par_stride = (int64_t)ngroups * G * NGRAN;     // granules per parity slot
   u64* ex_group = exch + (int64_t)group * G * NGRAN;           // + parity*par_stride + member*NGRAN
-  u64* done_word = exch + 2 * par_stride + (int64_t)ngroups * G + cblk;
+  u64* done_word = exch + 2 * par_stride + (int64_t)ngroups * G + (companion ? group : cblk);   // companions watch member 0's
 
   int len[RL], bidx[RL];
   int smax = 0, smin = 0x7fffffff;
@@ -163,31 +167,32 @@ __global__ __launch_bounds__(256) void lstm_fwd_kernel(float* __restrict__ xproj
   if ((int64_t)B * T * xrow * 4 >= ((int64_t)1 << 32)) smin = 0;     // 32-bit byte offsets do not reach: general path only
 
   if constexpr (G > 1) if (companion) {
-    // PREFETCH COMPANION: a workgroup on another CU of the same XCD (block index = compute block + 8k) pulls the
-    // compute workgroup's xproj lines into the shared L2 PF_AHEAD steps before they are needed (1-KiB LDS-DMAs into a
-    // scratch tile nobody reads), so the compute CU's in-order vector-memory queue only ever sees L2 hits.  It paces
-    // itself on the epoch tags of the compute workgroup's own granules and leaves when the done word is set.
+    // PREFETCH COMPANION: one workgroup per group on another CU of the same XCD (block index = nblk + group, and nblk is
+    // a multiple of 8) pulls the xproj lines of ALL members of the group into the shared L2 PF_AHEAD steps before they
+    // are needed (1-KiB LDS-DMAs into a scratch tile nobody reads), so the compute CUs' in-order vector-memory queues
+    // only ever see L2 hits.  It paces itself on the epoch tags of member 0's granules and leaves when member 0's done
+    // word is set.
     constexpr int PF_AHEAD = 6;
     const int mylen = (l15 < ROWS && slice * ROWS + l15 < B) ? min(length[slice * ROWS + l15], T) : 0;   // lane = row of the slice
-    // rows t >= length of the outputs are zero (dynamic_rnn): the companion clears this member's columns of them, so a
+    // rows t >= length of the outputs are zero (dynamic_rnn): the companion clears the direction's columns of them, so a
     // dense batch needs no memset of y at all (the compute workgroups write every row they own)
     for (int rr = wave * RL; rr < wave * RL + RL; ++rr) {
       const int bb = slice * ROWS + rr;
       if (bb >= B) continue;
       const int ll = __builtin_amdgcn_readlane(mylen, rr);
-      constexpr int LPR = HS * 2 / 16;                            // 16-byte pieces of the member's span in a row
+      constexpr int LPR = H * 2 / 16 / CPG;                       // 16-byte pieces of this companion's share of a row
       for (int e = ll * LPR + lane; e < T * LPR; e += 64) {
-        const int t = e / LPR, c = e % LPR;
-        *reinterpret_cast<uint4*>(y + ((int64_t)bb * T + t) * yrow + dir * H + member * HS + c * 8) = make_uint4(0, 0, 0, 0);
+        const int t = e / LPR, c = cm * LPR + e % LPR;
+        *reinterpret_cast<uint4*>(y + ((int64_t)bb * T + t) * yrow + dir * H + c * 8) = make_uint4(0, 0, 0, 0);
       }
     }
-    const u64* tag0 = ex_group + (int64_t)member * NGRAN;
+    const u64* tag0 = ex_group;                                   // member 0 publishes here every step
     int seen = -1;
     for (int sp = 0; sp < smax; ++sp) {
       unsigned spins = 0;
       while (seen < sp - PF_AHEAD) {
         const u64 v0 = granule_load(tag0), v1 = granule_load(tag0 + par_stride), dn = granule_load(done_word);
-        if (dn != 0) return;                                      // the compute workgroup is done (or failed)
+        if (dn != 0) return;                                      // the compute workgroups are done (or failed)
         seen = (int)max((unsigned)(v0 >> 32), (unsigned)(v1 >> 32)) - 1;
         if (seen < sp - PF_AHEAD) {
           if (++spins > SPIN_LIMIT) return;
@@ -200,10 +205,11 @@ __global__ __launch_bounds__(256) void lstm_fwd_kernel(float* __restrict__ xproj
         const int ll = __builtin_amdgcn_readlane(mylen, rr);
         if (sp < ll) {
           const int pos = dir == 0 ? sp : ll - 1 - sp;
-          const float* src = xproj + ((int64_t)(slice * ROWS + rr) * T + pos) * xrow + dir * 4 * H + member * HS * 4 +
-                             (lane % (HS > 64 ? 64 : HS)) * 4;
-          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src),
-                                           (__attribute__((address_space(3))) void*)(pf_scratch), 16, 0, 0);
+          const float* src = xproj + ((int64_t)(slice * ROWS + rr) * T + pos) * xrow + dir * 4 * H + cm * (4 * H / CPG) + lane * 4;
+#pragma unroll
+          for (int c4 = 0; c4 < H / 64 / CPG; ++c4)               // this companion's share of the 4H floats in 1-KiB pieces
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + c4 * 256),
+                                             (__attribute__((address_space(3))) void*)(pf_scratch), 16, 0, 0);
         }
       }
     }
@@ -474,9 +480,11 @@ __global__ __launch_bounds__(256) void lstm_bwd_kernel(const float* __restrict__
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int gstride = (ngroups + 7) & ~7;
   const int nblk = gstride * G;
-  const bool companion = (int)blockIdx.x >= nblk;
+  constexpr int CPG = group_companions(H);
+  const bool companion = (int)blockIdx.x >= nblk;                // CPG per group (see lstm_fwd_kernel)
   const int cblk = companion ? blockIdx.x - nblk : blockIdx.x;
-  const int group = cblk % gstride, member = cblk / gstride;
+  const int group = cblk % gstride, member = companion ? 0 : cblk / gstride;
+  const int cm = companion ? cblk / gstride : 0;
   if (group >= ngroups) return;
   const int nslices = ngroups / ndir;
   const int slice = group % nslices, dir = group / nslices;
@@ -486,7 +494,7 @@ __global__ __launch_bounds__(256) void lstm_bwd_kernel(const float* __restrict__
   const int64_t grp_gran = (int64_t)G * G * PAIR;               // granules of one group in one parity slot
   const int64_t par_stride = (int64_t)ngroups * grp_gran;
   u64* ex_group = exch + (int64_t)group * grp_gran;             // + parity*par_stride + (dest*G + sender)*PAIR + ...
-  u64* done_word = exch + 2 * par_stride + (int64_t)ngroups * G + cblk;
+  u64* done_word = exch + 2 * par_stride + (int64_t)ngroups * G + (companion ? group : cblk);
 
   const int blk = SPLIT ? (wave & 1) : wave * UBW;              // first unit block of this wave
   const int hh = SPLIT ? (wave >> 1) : 0;                       // which row pair of every quad (SPLIT)
@@ -505,22 +513,21 @@ __global__ __launch_bounds__(256) void lstm_bwd_kernel(const float* __restrict__
   if ((int64_t)B * T * grow * 4 >= ((int64_t)1 << 32)) smin = 0;     // 32-bit byte offsets do not reach: general path only
 
   if constexpr (G > 1) if (companion) {
-    // PREFETCH COMPANION (see lstm_fwd_kernel): gates, c and dy lines of the compute workgroup, PF_AHEAD steps ahead.
+    // PREFETCH COMPANION (see lstm_fwd_kernel): gates, c and dy lines of the whole group, PF_AHEAD steps ahead.
     constexpr int PF_AHEAD = 6;
     const int mylen = (l15 < ROWS && slice * ROWS + l15 < B) ? min(length[slice * ROWS + l15], T) : 0;
-    // dz rows t >= length are zero: cleared here (this member's gate columns), so dense batches need no memset of dz
+    // dz rows t >= length are zero: cleared here (the direction's gate columns), so dense batches need no memset of dz
     for (int rr = wave * (ROWS / 4); rr < (wave + 1) * (ROWS / 4); ++rr) {
       const int bb = slice * ROWS + rr;
       if (bb >= B) continue;
       const int ll = __builtin_amdgcn_readlane(mylen, rr);
-      constexpr int LPR = 4 * HS * 2 / 16;
+      constexpr int LPR = 4 * H * 2 / 16 / CPG;
       for (int e = ll * LPR + lane; e < T * LPR; e += 64) {
-        const int t = e / LPR, c = e % LPR;
-        *reinterpret_cast<uint4*>(dz + ((int64_t)bb * T + t) * grow + dir * 4 * H + member * 4 * HS + c * 8) = make_uint4(0, 0, 0, 0);
+        const int t = e / LPR, c = cm * LPR + e % LPR;
+        *reinterpret_cast<uint4*>(dz + ((int64_t)bb * T + t) * grow + dir * 4 * H + c * 8) = make_uint4(0, 0, 0, 0);
       }
     }
-    const int watch_dest = member == 0 ? 1 : 0;                 // any slot the compute workgroup writes every step
-    const u64* tag0 = ex_group + (int64_t)(watch_dest * G + member) * PAIR;
+    const u64* tag0 = ex_group + (int64_t)(1 * G + 0) * PAIR;   // (destination 1, sender 0): member 0 writes it every step
     int seen = -1;
     for (int it = 0; it < smax; ++it) {
       const int sp = smax - 1 - it;
@@ -541,12 +548,20 @@ __global__ __launch_bounds__(256) void lstm_bwd_kernel(const float* __restrict__
         if (sp < ll) {
           const int pos = dir == 0 ? sp : ll - 1 - sp;
           const int64_t R = (int64_t)(slice * ROWS + rr) * T + pos;
-          const float* src = gates + R * grow + dir * 4 * H + member * HS * 4 + (lane % (HS > 64 ? 64 : HS)) * 4;
-          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src),
-                                           (__attribute__((address_space(3))) void*)(pf_scratch), 16, 0, 0);
-          const float* src2 = ((lane & 32) ? dy : cbuf) + R * yrow + dir * H + member * HS + ((lane & 31) % (HS / 4)) * 4;
-          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src2),
-                                           (__attribute__((address_space(3))) void*)(pf_scratch), 16, 0, 0);
+          const float* src = gates + R * grow + dir * 4 * H + cm * (4 * H / CPG) + lane * 4;
+#pragma unroll
+          for (int c4 = 0; c4 < H / 64 / CPG; ++c4)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + c4 * 256),
+                                             (__attribute__((address_space(3))) void*)(pf_scratch), 16, 0, 0);
+          constexpr int CW = H / CPG;                              // c and dy: this companion's H/CPG floats of each
+#pragma unroll
+          for (int c4 = 0; c4 < (CW + 255) / 256; ++c4) {
+            const int col = cm * CW + (c4 * 256 + lane * 4) % CW;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(cbuf + R * yrow + dir * H + col),
+                                             (__attribute__((address_space(3))) void*)(pf_scratch), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(dy + R * yrow + dir * H + col),
+                                             (__attribute__((address_space(3))) void*)(pf_scratch), 16, 0, 0);
+          }
         }
       }
     }
@@ -805,7 +820,7 @@ __global__ __launch_bounds__(256) void lstm_bwd_kernel(const float* __restrict__
   if (!ok && tid == 0) atomicOr(status, 2u);
 }
 
-struct CoopGeom { int nslices, ngroups, G, blocks; size_t exch_bytes; };
+struct CoopGeom { int nslices, ngroups, G, blocks, companions; size_t exch_bytes; };
 
 CoopGeom geom(int B, int H, int ndir, bool bwd, int rows = 16) {
   CoopGeom g;
@@ -818,6 +833,7 @@ CoopGeom geom(int B, int H, int ndir, bool bwd, int rows = 16) {
   const size_t HS = H / g.G;
   const size_t per_parity = bwd ? (size_t)g.ngroups * g.G * g.G * (HS / 16) * 256 : (size_t)g.ngroups * g.G * (rows >= 8 ? rows / 2 : rows) * HS;
   g.exch_bytes = g.G > 1 ? (2 * per_parity + (size_t)g.ngroups * g.G + g.blocks) * sizeof(u64) : 0;   // + XCC-id table + done words
+  g.companions = g.G > 1 ? ((g.ngroups + 7) & ~7) * group_companions(H) : 0;   // prefetch companions (blocks nblk ...)
   return g;
 }
 
@@ -828,8 +844,14 @@ int slice_rows(int B, int H, int ndir, bool bwd) {
   const int forced = e ? atoi(e) : 0;
   if (H != 256) return 16;
   if (forced == 16 || forced == 8 || forced == 4) return forced;
-  if (!bwd && 2 * geom(B, H, ndir, false, 4).blocks <= 256) return 4;      // forward only: one (utterance, unit) per lane
-  return 2 * geom(B, H, ndir, false, 8).blocks <= 256 ? 8 : 16;
+  // every chain workgroup and every companion should find a CU of its own (256 on MI355X); the backward leaves at
+  // least 96 CUs to the weight-gradient products that run beside it
+  const int budget = bwd ? 160 : 256;
+  for (int rows = 4; rows <= 8; rows *= 2) {
+    const CoopGeom g = geom(B, H, ndir, bwd, rows);
+    if (g.blocks + g.companions <= budget) return rows;
+  }
+  return 16;
 }
 
 // LAS_LSTM_PREFETCH=0 launches the recurrent kernels without their prefetch companions (diagnostics)
@@ -852,19 +874,19 @@ int launch_fwd(float* xproj, const las_bf16* wp, const int32_t* length, las_bf16
   const int pf = g.G > 1 ? prefetch_mode() : 0;
   if constexpr (H == 256) {
     if (rows == 8) {
-      hipLaunchKernelGGL((lstm_fwd_kernel<H, 8>), dim3(pf ? 2 * g.blocks : g.blocks), dim3(256), 0, st, xproj, wp, length, y,
+      hipLaunchKernelGGL((lstm_fwd_kernel<H, 8>), dim3(pf ? g.blocks + g.companions : g.blocks), dim3(256), 0, st, xproj, wp, length, y,
                          cbuf, c_last, h_last, exch, status, B, T, ndir, g.ngroups, pf);
       LAS_LAUNCH_CHECK("lstm fwd launch");
       return LAS_OK;
     }
     if (rows == 4) {
-      hipLaunchKernelGGL((lstm_fwd_kernel<H, 4>), dim3(pf ? 2 * g.blocks : g.blocks), dim3(256), 0, st, xproj, wp, length, y,
+      hipLaunchKernelGGL((lstm_fwd_kernel<H, 4>), dim3(pf ? g.blocks + g.companions : g.blocks), dim3(256), 0, st, xproj, wp, length, y,
                          cbuf, c_last, h_last, exch, status, B, T, ndir, g.ngroups, pf);
       LAS_LAUNCH_CHECK("lstm fwd launch");
       return LAS_OK;
     }
   }
-  hipLaunchKernelGGL((lstm_fwd_kernel<H, 16>), dim3(pf ? 2 * g.blocks : g.blocks), dim3(256), 0, st, xproj, wp, length, y,
+  hipLaunchKernelGGL((lstm_fwd_kernel<H, 16>), dim3(pf ? g.blocks + g.companions : g.blocks), dim3(256), 0, st, xproj, wp, length, y,
                      cbuf, c_last, h_last, exch, status, B, T, ndir, g.ngroups, pf);
   LAS_LAUNCH_CHECK("lstm fwd launch");
   return LAS_OK;
@@ -888,23 +910,25 @@ int launch_bwd(const float* gates, const float* cbuf, const float* dy, const flo
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&lstm_bwd_kernel<H, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, hog_kb * 1024);
       if constexpr (H == 256)
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&lstm_bwd_kernel<H, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, hog_kb * 1024);
+      if constexpr (H == 256)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&lstm_bwd_kernel<H, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, hog_kb * 1024);
     }
   }
   if constexpr (H == 256) {
     if (rows == 8) {
-      hipLaunchKernelGGL((lstm_bwd_kernel<H, 8>), dim3(pf ? 2 * g.blocks : g.blocks), dim3(256), (size_t)hog_kb * 1024, st, gates, cbuf, dy,
+      hipLaunchKernelGGL((lstm_bwd_kernel<H, 8>), dim3(pf ? g.blocks + g.companions : g.blocks), dim3(256), (size_t)hog_kb * 1024, st, gates, cbuf, dy,
                          dc_last, dh_last, kh, length, dz, exch, status, B, T, ndir, g.ngroups);
       LAS_LAUNCH_CHECK("lstm bwd launch");
       return LAS_OK;
     }
-    if (rows == 4) {        // every CU holds a chain or a companion: no LDS request beyond what the kernel uses
-      hipLaunchKernelGGL((lstm_bwd_kernel<H, 4>), dim3(pf ? 2 * g.blocks : g.blocks), dim3(256), 0, st, gates, cbuf, dy,
+    if (rows == 4) {
+      hipLaunchKernelGGL((lstm_bwd_kernel<H, 4>), dim3(pf ? g.blocks + g.companions : g.blocks), dim3(256), (size_t)hog_kb * 1024, st, gates, cbuf, dy,
                          dc_last, dh_last, kh, length, dz, exch, status, B, T, ndir, g.ngroups);
       LAS_LAUNCH_CHECK("lstm bwd launch");
       return LAS_OK;
     }
   }
-  hipLaunchKernelGGL((lstm_bwd_kernel<H, 16>), dim3(pf ? 2 * g.blocks : g.blocks), dim3(256), (size_t)hog_kb * 1024, st, gates, cbuf, dy, dc_last, dh_last, kh,
+  hipLaunchKernelGGL((lstm_bwd_kernel<H, 16>), dim3(pf ? g.blocks + g.companions : g.blocks), dim3(256), (size_t)hog_kb * 1024, st, gates, cbuf, dy, dc_last, dh_last, kh,
                      length, dz, exch, status, B, T, ndir, g.ngroups);
   LAS_LAUNCH_CHECK("lstm bwd launch");
   return LAS_OK;
