@@ -1,7 +1,7 @@
 // bf16 x bf16 -> fp32 MFMA GEMMs for the LAS path (gfx950).
 //
 //   NT : C[M,N] (=|+=) A[M,K] * B[N,K]^T + bias      (forward projections, dX)
-//   TN : C[M,N] += sum_k A[k,M] * B[k,N]             (weight gradients; split-K with fp32 atomics)
+//   TN : C[M,N] += sum_k A[k,M] * B[k,N]             (weight gradients; K slices through a workspace or fp32 atomics)
 //
 // Both stage BMxBK / BNxBK operand tiles into LDS as [row][k] (k contiguous, row stride BK+8
 // elements = 144 B: the 16 rows one ds_read_b128 lane group touches land on 16 disjoint 4-bank
@@ -13,8 +13,7 @@
 
 namespace {
 
-constexpr int BK = 64;
-constexpr int LDK = BK + 8;   // LDS row stride in elements
+constexpr int BK = 64;        // K depth of a staged tile (gemm_kernel: template parameter KB)
 
 struct GemmArgs {
   const unsigned short* A;
@@ -39,8 +38,11 @@ struct GemmArgs {
   int64_t partial_stride = 0;
 };
 
-template <int BM, int BN, bool TN>
+// KB = depth of a staged K tile: 64, or 32 for the large NT products (half the LDS, so three workgroups share a CU
+// instead of two: these products wait on memory most of the time, and the epilogue of one overlaps the others' loops)
+template <int BM, int BN, bool TN, int KB = 64>
 __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
+  constexpr int BK = KB, LDK = KB + 8;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned short* As = reinterpret_cast<unsigned short*>(smem);            // [2][BM][LDK]
   unsigned short* Bs = As + 2 * BM * LDK;                                  // [2][BN][LDK]
@@ -197,14 +199,18 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
     // writes it back 16 bytes per lane, 16 lanes per row.  The products of this path are output-bound (fp32 xproj:
     // 419 MB per layer), and four-byte stores scattered over four rows per instruction waste most of the write path.
     constexpr int WM = BM / 2, WN = BN / 2, LDC = WN + 4;
+    constexpr int EH = (KB < 64 && FM >= 2) ? 2 : 1;      // row halves of the wave's tile staged at a time (LDS budget)
+    constexpr int HM = WM / EH;
     __syncthreads();
-    float* cs = reinterpret_cast<float*>(smem) + wave * WM * LDC;
+    float* cs = reinterpret_cast<float*>(smem) + wave * HM * LDC;
 #pragma unroll
-    for (int i = 0; i < FM; ++i)
+    for (int eh = 0; eh < EH; ++eh) {
+#pragma unroll
+    for (int i = 0; i < FM / EH; ++i)
 #pragma unroll
       for (int j = 0; j < FN; ++j)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) cs[(i * 16 + (lane >> 4) * 4 + r) * LDC + j * 16 + (lane & 15)] = acc[i][j][r];
+        for (int r = 0; r < 4; ++r) cs[(i * 16 + (lane >> 4) * 4 + r) * LDC + j * 16 + (lane & 15)] = acc[eh * (FM / EH) + i][j][r];
     __builtin_amdgcn_s_waitcnt(0xC07F);       // lgkmcnt(0): a wave only reads back what it wrote itself
     constexpr int LPR = WN / 4;                // lanes per row
     constexpr int RPI = 64 / LPR;              // rows per instruction
@@ -215,8 +221,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) if (col + e < g.N) bv[e] = g.bias[col + e];
 #pragma unroll 4
-    for (int r0 = 0; r0 < WM; r0 += RPI) {
-      const int row = m0 + wr * WM + r0 + rl;
+    for (int r0 = 0; r0 < HM; r0 += RPI) {
+      const int row = m0 + wr * WM + eh * HM + r0 + rl;
       if (row >= g.M || col >= g.N) continue;
       const float4 v4 = *reinterpret_cast<const float4*>(cs + (r0 + rl) * LDC + cl);
       float v[4] = {v4.x + bv[0], v4.y + bv[1], v4.z + bv[2], v4.w + bv[3]};
@@ -242,6 +248,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
         for (int e = 0; e < 4; ++e)
           if (col + e < g.N) { if (g.accumulate) Cf[off + e] += v[e]; else Cf[off + e] = v[e]; }
       }
+    }
+    __builtin_amdgcn_s_waitcnt(0xC07F);       // the staging rows are rewritten by the next half
     }
     return;
   }
@@ -494,17 +502,19 @@ __global__ __launch_bounds__(256) void tn_reduce_kernel(const float* __restrict_
   }
 }
 
-template <int BM, int BN, bool TN>
+template <int BM, int BN, bool TN, int KB = 64>
 int launch(const GemmArgs& g, int batch, hipStream_t st) {
   dim3 grid((g.N + BN - 1) / BN, (g.M + BM - 1) / BM, batch * g.split_k);
-  size_t lds = (size_t)2 * (BM + BN) * LDK * sizeof(unsigned short);
+  size_t lds = (size_t)2 * (BM + BN) * (KB + 8) * sizeof(unsigned short);
+  const size_t stage = (size_t)4 * (BM / 2 / (KB < 64 && BM >= 64 ? 2 : 1)) * (BN / 2 + 4) * sizeof(float);   // epilogue staging
+  if (!TN && stage > lds) lds = stage;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<BM, BN, TN>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<BM, BN, TN, KB>),
                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
-  hipLaunchKernelGGL((gemm_kernel<BM, BN, TN>), grid, dim3(256), lds, st, g);
+  hipLaunchKernelGGL((gemm_kernel<BM, BN, TN, KB>), grid, dim3(256), lds, st, g);
   LAS_LAUNCH_CHECK("gemm launch");
   return LAS_OK;
 }
@@ -595,6 +605,7 @@ extern "C" int las_gemm_nt(const las_bf16* A, int64_t lda, const las_bf16* B, in
     return LAS_OK;
   }
   if (M <= 64 || N <= 64) return launch<64, 64, false>(g, batch, st);
+  if (M >= 4096) return launch<128, 128, false, 32>(g, batch, st);      // the bulk products: three workgroups per CU
   return launch<128, 128, false>(g, batch, st);
 }
 
