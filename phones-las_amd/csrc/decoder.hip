@@ -387,6 +387,17 @@ __global__ __launch_bounds__(256) void dec_step_fwd_kernel(las_dec_step s) {
 // ------------------------------------------------------------------------------------------------
 constexpr unsigned P_SPIN_LIMIT = 1u << 22;
 constexpr int P_MEMBERS = 32;
+// LDS of the persistent backward kernel: its scratch, and -- when it fits the CU's 160 KiB -- this workgroup's quarter
+// of the utterance's memory frames (values [fq, M] and keys [fq, Hd], bf16), which every step reads again.
+__host__ __device__ inline size_t persist_bwd_scratch_floats(int M, int Hd, int Tm) {
+  return ((size_t)M + 2 * (size_t)Tm + 2048 + 16 + Hd + 4 * 16 * 49 + 8 + 3) & ~(size_t)3;
+}
+__host__ __device__ inline size_t persist_bwd_resident_bytes(int M, int Hd, int Tm) {
+  return (size_t)((Tm + 3) / 4) * (size_t)(M + Hd) * 2;
+}
+__host__ __device__ inline bool persist_bwd_resident(int M, int Hd, int Tm) {
+  return persist_bwd_scratch_floats(M, Hd, Tm) * 4 + persist_bwd_resident_bytes(M, Hd, Tm) <= 160 * 1024;
+}
 
 __device__ bool persist_barrier(pu64* flags, int member, unsigned epoch, bool local, int* lds_fail) {
   __builtin_amdgcn_s_waitcnt(0x0070);                      // vmcnt(0) lgkmcnt(0): this wave's stores are acknowledged
@@ -942,6 +953,23 @@ __global__ __launch_bounds__(256) void dec_persist_bwd_kernel(las_dec_persist_bw
   const int fq = (Tm + 3) / 4, f0 = part * fq, f1 = min(Tm, f0 + fq), flen = min(len, f1);
   const unsigned short* vals = s0.values + (int64_t)(active ? b : 0) * Tm * M;
   const unsigned short* keys = s0.keys + (int64_t)(active ? b : 0) * Tm * Hd;
+  // the frames of this workgroup do not change over the U steps: keep them in LDS when they fit (every step would
+  // otherwise stream them from L2 / Infinity Cache again, four dependent round trips in S1 alone)
+  const bool resident = persist_bwd_resident(M, Hd, Tm);
+  unsigned short* lvals = reinterpret_cast<unsigned short*>(sm + persist_bwd_scratch_floats(M, Hd, Tm));   // [fq][M]
+  unsigned short* lkeys = lvals + (size_t)fq * M;                                                            // [fq][Hd]
+  if (resident && active) {
+    const int nrow = max(f1 - f0, 0);
+    for (int e = tid; e < nrow * (M / 8); e += 256) {
+      const int r = e / (M / 8), c = e % (M / 8);
+      *reinterpret_cast<uint4*>(lvals + (size_t)r * M + c * 8) = *reinterpret_cast<const uint4*>(vals + (int64_t)(f0 + r) * M + c * 8);
+    }
+    for (int e = tid; e < nrow * (Hd / 8); e += 256) {
+      const int r = e / (Hd / 8), c = e % (Hd / 8);
+      *reinterpret_cast<uint4*>(lkeys + (size_t)r * Hd + c * 8) = *reinterpret_cast<const uint4*>(keys + (int64_t)(f0 + r) * Hd + c * 8);
+    }
+    __syncthreads();
+  }
   unsigned epoch = 0;
 
   for (int t = p.U - 1; t >= 0; --t) {
@@ -969,29 +997,34 @@ __global__ __launch_bounds__(256) void dec_persist_bwd_kernel(las_dec_persist_bw
       __syncthreads();
       {
         const int sub = lane & 15, grp = lane >> 4;
-        for (int t0 = f0; t0 < f1; t0 += 32) {
-          const int ta = t0 + wave * 4 + grp, tb = ta + 16;
-          float acc_a = 0.f, acc_b = 0.f;
-          const bool oa = ta < flen, ob = tb < flen;
-          const unsigned short* ra = vals + (int64_t)(oa ? ta : 0) * M;
-          const unsigned short* rb = vals + (int64_t)(ob ? tb : 0) * M;
+        // rows: the frames' value rows, from LDS (row 0 = frame f0) or from memory (row 0 = frame 0)
+        auto dalign_pass = [&](const unsigned short* rows, int row0) {
+          for (int t0 = f0; t0 < f1; t0 += 32) {
+            const int ta = t0 + wave * 4 + grp, tb = ta + 16;
+            float acc_a = 0.f, acc_b = 0.f;
+            const bool oa = ta < flen, ob = tb < flen;
+            const unsigned short* ra = rows + (int64_t)(oa ? ta - row0 : 0) * M;
+            const unsigned short* rb = rows + (int64_t)(ob ? tb - row0 : 0) * M;
 #pragma unroll 4
-          for (int k = sub * 8; k < M; k += 128) {
-            const uint4 va = *reinterpret_cast<const uint4*>(ra + k);
-            const uint4 vb = *reinterpret_cast<const uint4*>(rb + k);
-            acc_a += dot8(va, dctx + k);
-            acc_b += dot8(vb, dctx + k);
-          }
+            for (int k = sub * 8; k < M; k += 128) {
+              const uint4 va = *reinterpret_cast<const uint4*>(ra + k);
+              const uint4 vb = *reinterpret_cast<const uint4*>(rb + k);
+              acc_a += dot8(va, dctx + k);
+              acc_b += dot8(vb, dctx + k);
+            }
 #pragma unroll
-          for (int o = 8; o > 0; o >>= 1) {
-            acc_a += __shfl_xor(acc_a, o, 64);
-            acc_b += __shfl_xor(acc_b, o, 64);
+            for (int o = 8; o > 0; o >>= 1) {
+              acc_a += __shfl_xor(acc_a, o, 64);
+              acc_b += __shfl_xor(acc_b, o, 64);
+            }
+            if (sub == 0) {
+              if (ta < f1) dal[ta] = oa ? acc_a : 0.f;
+              if (tb < f1) dal[tb] = ob ? acc_b : 0.f;
+            }
           }
-          if (sub == 0) {
-            if (ta < f1) dal[ta] = oa ? acc_a : 0.f;
-            if (tb < f1) dal[tb] = ob ? acc_b : 0.f;
-          }
-        }
+        };
+        if (resident) dalign_pass(lvals, f0);
+        else dalign_pass(vals, 0);
       }
       __syncthreads();
       float dot = 0.f;
@@ -1016,14 +1049,18 @@ __global__ __launch_bounds__(256) void dec_persist_bwd_kernel(las_dec_persist_bw
 #pragma unroll
       for (int j = 0; j < 8; ++j) a[j] = 0.f;
       if (!WQ || !att_additive(s0.attention)) {
+        auto dh_pass = [&](const unsigned short* rows, int row0) {
 #pragma unroll 4
-        for (int tt = f0 + phase; tt < flen; tt += P) {
-          const uint4 v = *reinterpret_cast<const uint4*>(keys + (int64_t)tt * Hd + u);
-          const unsigned short* e = reinterpret_cast<const unsigned short*>(&v);
-          const float d = dal[tt];
+          for (int tt = f0 + phase; tt < flen; tt += P) {
+            const uint4 v = *reinterpret_cast<const uint4*>(rows + (int64_t)(tt - row0) * Hd + u);
+            const unsigned short* e = reinterpret_cast<const unsigned short*>(&v);
+            const float d = dal[tt];
 #pragma unroll
-          for (int j = 0; j < 8; ++j) a[j] += d * las_bf2f(e[j]);
-        }
+            for (int j = 0; j < 8; ++j) a[j] += d * las_bf2f(e[j]);
+          }
+        };
+        if (resident) dh_pass(lkeys, f0);
+        else dh_pass(keys, 0);
       } else {
         // Bahdanau: score = sum_a v[a] tanh(keys[t',a] + pq[a]); d_pre = ds * v * (1 - tanh^2).  This workgroup owns its
         // frames of the utterance: d(keys) is accumulated in place, d(attention_v) with atomics.
@@ -1032,7 +1069,8 @@ __global__ __launch_bounds__(256) void dec_persist_bwd_kernel(las_dec_persist_bw
 #pragma unroll
         for (int j = 0; j < 8; ++j) { dv[j] = 0.f; vv[j] = s0.att_v[u + j]; qq[j] = pqv[u + j]; }
         for (int tt = f0 + phase; tt < flen; tt += P) {
-          const uint4 v = *reinterpret_cast<const uint4*>(keys + (int64_t)tt * Hd + u);
+          const uint4 v = resident ? *reinterpret_cast<const uint4*>(lkeys + (size_t)(tt - f0) * Hd + u)
+                                   : *reinterpret_cast<const uint4*>(keys + (int64_t)tt * Hd + u);
           const unsigned short* e = reinterpret_cast<const unsigned short*>(&v);
           const float d = dal[tt];
           float* dk = s0.dkeys_acc + ((int64_t)b * Tm + tt) * Hd + u;
@@ -1393,8 +1431,15 @@ extern "C" int las_decoder_persist_bwd(const las_dec_persist_bwd* p, void* strea
   const int groups = (s->B + 7) / 8;
   int rc = las_check_hip(hipMemsetAsync(p->workspace, 0, las_decoder_persist_workspace_bytes(s->B), st), "memset workspace");
   if (rc) return rc;
-  const size_t lds = (size_t)(s->M + 2 * s->Tm + 2048 + 16 + s->Hd + 4 * 16 * 49 + 8) * sizeof(float);
+  size_t lds = persist_bwd_scratch_floats(s->M, s->Hd, s->Tm) * sizeof(float);
   LAS_REQUIRE(lds <= 64 * 1024, "las_decoder_persist_bwd: shapes exceed the LDS budget");
+  if (persist_bwd_resident(s->M, s->Hd, s->Tm)) lds += persist_bwd_resident_bytes(s->M, s->Hd, s->Tm);
+  static size_t lds_attr = 64 * 1024;
+  if (lds > lds_attr) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dec_persist_bwd_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dec_persist_bwd_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    lds_attr = 160 * 1024;
+  }
   if (s->attention == LAS_ATT_LUONG)
     hipLaunchKernelGGL(dec_persist_bwd_kernel<false>, dim3(((groups + 7) & ~7) * P_MEMBERS), dim3(256), lds, st, *p);
   else
