@@ -81,6 +81,16 @@ __device__ __forceinline__ float dot8(const uint4& k, const float* q) {
 // phase (each part reads a quarter of the keys instead of all of them), publish their raw scores in a per-step row of
 // global scratch and meet at the group's flag barrier before the softmax.
 typedef unsigned long long pu64;
+// 16-byte loads from global memory or, through an address-space-qualified pointer, from LDS (a pointer that travelled
+// through a struct is otherwise a FLAT access: slower than either)
+typedef const __attribute__((address_space(3))) unsigned short* lds_cu16;
+__device__ __forceinline__ uint4 ld16(const unsigned short* p) { return *reinterpret_cast<const uint4*>(p); }
+typedef __attribute__((ext_vector_type(4))) unsigned int las_u32x4;
+__device__ __forceinline__ uint4 ld16(lds_cu16 p) {
+  const las_u32x4 v = *(const __attribute__((address_space(3))) las_u32x4*)p;
+  return make_uint4(v.x, v.y, v.z, v.w);
+}
+
 struct PersistHook {
   float* scores;        // [B][ld] raw scores of this step
   int64_t ld;
@@ -89,6 +99,9 @@ struct PersistHook {
   unsigned* epoch;
   bool local;
   int* fail;
+  // LDS copies of what this workgroup reads from the memory at every step (nullptr: read from global memory):
+  const unsigned short* lkeys;   // keys of its score frames [fq][Hd], row 0 = frame part*fq
+  const unsigned short* lvals;   // its context columns of every frame [Tm][cols_per]
 };
 __device__ bool persist_barrier(pu64* flags, int member, unsigned epoch, bool local, int* lds_fail);
 // Exchange discipline of the persistent decoder: every (utterance, step) row of an exchanged tensor occupies WHOLE
@@ -96,6 +109,8 @@ __device__ bool persist_barrier(pu64* flags, int member, unsigned epoch, bool lo
 // else is still going to write (a row sharing a line with the next step's row would be served stale from L1 later; the
 // host pads the small rows - raw scores, partial dots - to 32 floats).
 
+// RES: the persistent kernel's LDS copies of keys / values are in use (compile-time: one load flavour per instantiation)
+template <bool RES = false>
 __device__ void dec_step_fwd_body(const las_dec_step& s, const int b, const int part, const int nparts, float* sm,
                                   const PersistHook* ph = nullptr) {
   float* hq = sm;                 // [Hd] h_t (bf16-rounded) as float
@@ -175,15 +190,17 @@ __device__ void dec_step_fwd_body(const las_dec_step& s, const int b, const int 
     float* scw = ph ? ph->scores + (int64_t)b * ph->ld : sc;       // where raw scores go
     if (Hd <= 32 * KMAX) {
       const int nk = Hd / 32;                          // loads per lane and frame
+      // krows: key rows from memory (row 0 = frame 0) or from the workgroup's LDS copy (row 0 = frame f0)
+      auto score_pass = [&](auto krows, int row0) {
       for (int t0 = f0; t0 < f1; t0 += 64 * SC_PASSES) {
         uint4 kv[SC_PASSES][KMAX];
 #pragma unroll
         for (int p = 0; p < SC_PASSES; ++p) {
           const int t = t0 + p * 64 + wave * 16 + fr;
-          const unsigned short* krow = keys + (int64_t)min(t, Tm - 1) * Hd;
+          const auto krow = krows + (int64_t)(min(t, f1 - 1) - row0) * Hd;
 #pragma unroll
           for (int j = 0; j < KMAX; ++j)
-            if (j < nk && t < flen) kv[p][j] = *reinterpret_cast<const uint4*>(krow + sub * 8 + j * 32);
+            if (j < nk && t < flen) kv[p][j] = ld16(krow + sub * 8 + j * 32);
         }
 #pragma unroll
         for (int p = 0; p < SC_PASSES; ++p) {
@@ -207,6 +224,9 @@ __device__ void dec_step_fwd_body(const las_dec_step& s, const int b, const int 
           if (sub == 0 && t < f1) scw[t] = (t < len) ? part_sum : -INFINITY;
         }
       }
+      };
+      if constexpr (RES) score_pass((lds_cu16)ph->lkeys, f0);
+      else score_pass(keys, 0);
     } else {
       for (int t0 = f0; t0 < f1; t0 += 64) {
         const int t = t0 + wave * 16 + fr;
@@ -322,24 +342,29 @@ __device__ void dec_step_fwd_body(const las_dec_step& s, const int b, const int 
     for (int j = 0; j < 8; ++j) a[j] = 0.f;
     if (col < c_end) {
       constexpr int VB = 16;                 // value loads in flight per thread (one round trip to Infinity Cache)
-      for (int tb = phase; tb < len; tb += P * VB) {
-        uint4 vv[VB];
+      // vrows + t * vstride: this thread's 8 columns of frame t (memory, or the workgroup's LDS copy of its columns)
+      auto context_pass = [&](auto vrows, int64_t vstride) {
+        for (int tb = phase; tb < len; tb += P * VB) {
+          uint4 vv[VB];
 #pragma unroll
-        for (int i = 0; i < VB; ++i) {
-          const int t = tb + i * P;
-          if (t < len) vv[i] = *reinterpret_cast<const uint4*>(vals + (int64_t)t * M + col);
-        }
+          for (int i = 0; i < VB; ++i) {
+            const int t = tb + i * P;
+            if (t < len) vv[i] = ld16(vrows + (int64_t)t * vstride);
+          }
 #pragma unroll
-        for (int i = 0; i < VB; ++i) {
-          const int t = tb + i * P;
-          if (t < len) {
-            const unsigned short* e = reinterpret_cast<const unsigned short*>(&vv[i]);
-            const float p = sc[t];
+          for (int i = 0; i < VB; ++i) {
+            const int t = tb + i * P;
+            if (t < len) {
+              const unsigned short* e = reinterpret_cast<const unsigned short*>(&vv[i]);
+              const float p = sc[t];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) a[j] += p * las_bf2f(e[j]);
+              for (int j = 0; j < 8; ++j) a[j] += p * las_bf2f(e[j]);
+            }
           }
         }
-      }
+      };
+      if constexpr (RES) context_pass((lds_cu16)ph->lvals + (col - c_begin), cols_per);
+      else context_pass(vals + col, M);
     }
     __syncthreads();
 #pragma unroll
@@ -389,6 +414,17 @@ constexpr unsigned P_SPIN_LIMIT = 1u << 22;
 constexpr int P_MEMBERS = 32;
 // LDS of the persistent backward kernel: its scratch, and -- when it fits the CU's 160 KiB -- this workgroup's quarter
 // of the utterance's memory frames (values [fq, M] and keys [fq, Hd], bf16), which every step reads again.
+// forward: scratch, and this workgroup's score frames of the keys [fq, Hd] + its context columns of the values [Tm, M/4]
+__host__ __device__ inline size_t persist_fwd_scratch_floats(int Hd, int Tm) {
+  return ((size_t)2 * Hd + Tm + 16 + 2048 + 4 * 16 * 33 + 8 + 3) & ~(size_t)3;
+}
+__host__ __device__ inline int persist_cols_per(int M) { return ((M / 8 + 3) / 4) * 8; }
+__host__ __device__ inline size_t persist_fwd_resident_bytes(int M, int Hd, int Tm) {
+  return ((size_t)((Tm + 3) / 4) * Hd + (size_t)Tm * persist_cols_per(M)) * 2;
+}
+__host__ __device__ inline bool persist_fwd_resident(int M, int Hd, int Tm) {
+  return persist_fwd_scratch_floats(Hd, Tm) * 4 + persist_fwd_resident_bytes(M, Hd, Tm) <= 160 * 1024;
+}
 __host__ __device__ inline size_t persist_bwd_scratch_floats(int M, int Hd, int Tm) {
   return ((size_t)M + 2 * (size_t)Tm + 2048 + 16 + Hd + 4 * 16 * 49 + 8 + 3) & ~(size_t)3;
 }
@@ -422,7 +458,7 @@ __device__ bool persist_barrier(pu64* flags, int member, unsigned epoch, bool lo
   return *lds_fail == 0;
 }
 
-template <bool SAMPLING>
+template <bool SAMPLING, bool RES>
 __global__ __launch_bounds__(256) void dec_persist_fwd_kernel(las_dec_persist p) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   constexpr int NTL_MAX = 2, KCW_MAX = 12;
@@ -478,6 +514,28 @@ __global__ __launch_bounds__(256) void dec_persist_fwd_kernel(las_dec_persist p)
     }
   const int bg = group * 8 + (l15 & 7);                    // utterance of A-fragment row l15 (rows 8..15 repeat 0..7)
   const int bs = group * 8 + member / 4, part = member & 3;  // S role
+  // what the S role reads from the encoder memory never changes over the U steps: keep it in LDS when it fits
+  const unsigned short* lkeys = nullptr;
+  const unsigned short* lvals = nullptr;
+  if (RES && bs < B) {
+    unsigned short* lk = reinterpret_cast<unsigned short*>(sm + persist_fwd_scratch_floats(Hd, Tm));
+    const int fq = (Tm + 3) / 4, f0 = part * fq, f1 = min(Tm, f0 + fq);
+    unsigned short* lv = lk + (size_t)fq * Hd;
+    const int cols_per = persist_cols_per(M), c0 = part * cols_per, cn = max(0, min(M, c0 + cols_per) - c0);
+    const unsigned short* gk = s0.keys + (int64_t)bs * Tm * Hd;
+    const unsigned short* gv = s0.values + (int64_t)bs * Tm * M;
+    for (int e = tid; e < max(f1 - f0, 0) * (Hd / 8); e += 256) {
+      const int r = e / (Hd / 8), c = e % (Hd / 8);
+      *reinterpret_cast<uint4*>(lk + (size_t)r * Hd + c * 8) = *reinterpret_cast<const uint4*>(gk + (int64_t)(f0 + r) * Hd + c * 8);
+    }
+    for (int e = tid; e < Tm * (cn / 8); e += 256) {
+      const int r = e / (cn / 8), c = e % (cn / 8);
+      *reinterpret_cast<uint4*>(lv + (size_t)r * cols_per + c * 8) = *reinterpret_cast<const uint4*>(gv + (int64_t)r * M + c0 + c * 8);
+    }
+    lkeys = lk;
+    lvals = lv;
+  }
+  __syncthreads();
   unsigned epoch = 0;
 
   for (int t = 0; t < p.U; ++t) {
@@ -534,8 +592,8 @@ __global__ __launch_bounds__(256) void dec_persist_fwd_kernel(las_dec_persist p)
       st.ctx_out = s0.ctx_out + t * p.inc_ctx;
       st.ctx_out2 = last ? nullptr : s0.ctx_out2 + t * p.inc_ctx2;
       st.step = t;
-      PersistHook hook{p.sc_all + (int64_t)t * B * p.ld_sc, p.ld_sc, flags, member, &epoch, local, fail};
-      dec_step_fwd_body(st, bs, part, 4, sm, &hook);
+      PersistHook hook{p.sc_all + (int64_t)t * B * p.ld_sc, p.ld_sc, flags, member, &epoch, local, fail, lkeys, lvals};
+      dec_step_fwd_body<RES>(st, bs, part, 4, sm, &hook);
       if (*fail) break;
     } else {
       if (!persist_barrier(flags, member, ++epoch, local, fail)) break;     // the score exchange of the busy members
@@ -1396,13 +1454,24 @@ extern "C" int las_decoder_persist_fwd(const las_dec_persist* p, void* stream) {
   const int groups = (s->B + 7) / 8;
   int rc = las_check_hip(hipMemsetAsync(p->workspace, 0, las_decoder_persist_workspace_bytes(s->B), st), "memset workspace");
   if (rc) return rc;
-  const size_t lds = (size_t)(2 * s->Hd + s->Tm + 16 + 2048 + 4 * 16 * 33 + 8) * sizeof(float);
+  size_t lds = persist_fwd_scratch_floats(s->Hd, s->Tm) * sizeof(float);
   LAS_REQUIRE(lds <= 64 * 1024, "las_decoder_persist_fwd: memory length %d too long for the LDS score buffer", s->Tm);
-  // two instantiations: the scheduled-sampling phase costs registers the plain teacher-forcing loop should not pay for
-  if (p->sampling_prob > 0.f)
-    hipLaunchKernelGGL(dec_persist_fwd_kernel<true>, dim3(((groups + 7) & ~7) * P_MEMBERS), dim3(256), lds, st, *p);
-  else
-    hipLaunchKernelGGL(dec_persist_fwd_kernel<false>, dim3(((groups + 7) & ~7) * P_MEMBERS), dim3(256), lds, st, *p);
+  const bool res = persist_fwd_resident(s->M, s->Hd, s->Tm);
+  const dim3 grid(((groups + 7) & ~7) * P_MEMBERS);
+  if (res) {
+    lds += persist_fwd_resident_bytes(s->M, s->Hd, s->Tm);
+    static bool attr_set = false;
+    if (!attr_set) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dec_persist_fwd_kernel<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dec_persist_fwd_kernel<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      attr_set = true;
+    }
+    if (p->sampling_prob > 0.f) hipLaunchKernelGGL((dec_persist_fwd_kernel<true, true>), grid, dim3(256), lds, st, *p);
+    else hipLaunchKernelGGL((dec_persist_fwd_kernel<false, true>), grid, dim3(256), lds, st, *p);
+  } else {
+    if (p->sampling_prob > 0.f) hipLaunchKernelGGL((dec_persist_fwd_kernel<true, false>), grid, dim3(256), lds, st, *p);
+    else hipLaunchKernelGGL((dec_persist_fwd_kernel<false, false>), grid, dim3(256), lds, st, *p);
+  }
   LAS_LAUNCH_CHECK("persistent decoder fwd launch");
   return LAS_OK;
 }
