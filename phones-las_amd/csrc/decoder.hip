@@ -102,6 +102,11 @@ struct PersistHook {
   // LDS copies of what this workgroup reads from the memory at every step (nullptr: read from global memory):
   const unsigned short* lkeys;   // keys of its score frames [fq][Hd], row 0 = frame part*fq
   const unsigned short* lvals;   // its context columns of every frame [Tm][cols_per]
+  // operands of the cell that do not depend on this step's product, fetched while the product was running
+  // (unit = threadIdx.x; Hd <= 256): token id, its row of the cell kernel, c_{t-1}; the bias once per launch
+  bool pre;
+  int tok;
+  float tok4[4], bias4[4], cprev;
 };
 __device__ bool persist_barrier(pu64* flags, int member, unsigned epoch, bool local, int* lds_fail);
 // Exchange discipline of the persistent decoder: every (utterance, step) row of an exchanged tensor occupies WHOLE
@@ -131,9 +136,11 @@ __device__ void dec_step_fwd_body(const las_dec_step& s, const int b, const int 
   // ---- LSTM cell (Appendix A.1) ----
   // (persistent decoder with scheduled sampling: the id was written by another workgroup during this launch and shares
   // a cache line with ids read earlier: bypass L1)
+  const bool pre = ph && ph->pre;
   const int tok = !s.tok_rows ? 0
-                  : (ph ? __hip_atomic_load(s.tok_ids + (int64_t)b * s.tok_stride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
-                        : s.tok_ids[(int64_t)b * s.tok_stride]);
+                  : (pre ? ph->tok
+                         : (ph ? __hip_atomic_load(s.tok_ids + (int64_t)b * s.tok_stride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                               : s.tok_ids[(int64_t)b * s.tok_stride]));
   // DropoutWrapper on the cell input: the one-hot feed keeps/loses its single non-zero entry
   float tok_scale = 1.0f;
   if (s.drop_keep < 1.0f)
@@ -143,11 +150,15 @@ __device__ void dec_step_fwd_body(const las_dec_step& s, const int b, const int 
     float z[4];
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
-      z[g] = s.z[(int64_t)b * 4 * Hd + g * Hd + u] + s.bias[g * Hd + u];
-      if (s.tok_rows) z[g] += tok_scale * las_bf2f(s.tok_rows[(int64_t)tok * 4 * Hd + g * Hd + u]);
+      if (pre) {
+        z[g] = s.z[(int64_t)b * 4 * Hd + g * Hd + u] + ph->bias4[g] + tok_scale * ph->tok4[g];
+      } else {
+        z[g] = s.z[(int64_t)b * 4 * Hd + g * Hd + u] + s.bias[g * Hd + u];
+        if (s.tok_rows) z[g] += tok_scale * las_bf2f(s.tok_rows[(int64_t)tok * 4 * Hd + g * Hd + u]);
+      }
     }
     const float gi = las_sigmoid(z[0]), gj = las_tanh(z[1]), gf = las_sigmoid(z[2] + 1.0f), go = las_sigmoid(z[3]);
-    const float cn = gf * s.c_prev[(int64_t)b * s.ldcp + u] + gi * gj;
+    const float cn = gf * (pre ? ph->cprev : s.c_prev[(int64_t)b * s.ldcp + u]) + gi * gj;
     const unsigned short hb = las_f2bf(go * las_tanh(cn));
     hq[u] = las_bf2f(hb);
     if (writer) {
@@ -538,7 +549,24 @@ __global__ __launch_bounds__(256) void dec_persist_fwd_kernel(las_dec_persist p)
   __syncthreads();
   unsigned epoch = 0;
 
+  // cell bias of this thread's unit: the same at every step
+  float bias4[4] = {0.f, 0.f, 0.f, 0.f};
+  const bool pre_ok = s0.tok_rows != nullptr && tid < Hd;
+  if (pre_ok)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) bias4[g] = s0.bias[g * Hd + tid];
+
   for (int t = 0; t < p.U; ++t) {
+    // the S role's cell operands that are already final (token id of this step -- teacher's, or drawn before the last
+    // barrier --, its kernel row, c_{t-1}): requested now, used after the product and its barrier
+    int tok_pre = 0;
+    float tok4[4] = {0.f, 0.f, 0.f, 0.f}, cprev_pre = 0.f;
+    if (pre_ok && bs < B) {
+      tok_pre = __hip_atomic_load(s0.tok_ids + (int64_t)bs * s0.tok_stride + t * p.inc_tok, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+      for (int g = 0; g < 4; ++g) tok4[g] = las_bf2f(s0.tok_rows[(int64_t)tok_pre * 4 * Hd + g * Hd + tid]);
+      cprev_pre = (s0.c_prev + t * p.inc_cprev)[(int64_t)bs * s0.ldcp + tid];
+    }
     // ---- G: z_t[group's utterances, my columns] ----
     float* zt = p.z_all + (int64_t)t * B * 4 * Hd;
     {
@@ -592,7 +620,8 @@ __global__ __launch_bounds__(256) void dec_persist_fwd_kernel(las_dec_persist p)
       st.ctx_out = s0.ctx_out + t * p.inc_ctx;
       st.ctx_out2 = last ? nullptr : s0.ctx_out2 + t * p.inc_ctx2;
       st.step = t;
-      PersistHook hook{p.sc_all + (int64_t)t * B * p.ld_sc, p.ld_sc, flags, member, &epoch, local, fail, lkeys, lvals};
+      PersistHook hook{p.sc_all + (int64_t)t * B * p.ld_sc, p.ld_sc, flags, member, &epoch, local, fail, lkeys, lvals,
+                       pre_ok, tok_pre, {tok4[0], tok4[1], tok4[2], tok4[3]}, {bias4[0], bias4[1], bias4[2], bias4[3]}, cprev_pre};
       dec_step_fwd_body<RES>(st, bs, part, 4, sm, &hook);
       if (*fail) break;
     } else {
