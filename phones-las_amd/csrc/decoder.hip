@@ -1058,10 +1058,22 @@ __global__ __launch_bounds__(256) void dec_persist_bwd_kernel(las_dec_persist_bw
     __syncthreads();
   }
   unsigned epoch = 0;
+  // S3 runs on part 0 with unit = threadIdx.x (Hd <= 256): d(c) stays in a register over the steps, and the saved
+  // values of a step are requested at its top, two barriers before the cell backward uses them
+  const bool cellw = active && part == 0 && tid < Hd;
+  float dcr = cellw ? s0.dc[(int64_t)b * Hd + tid] : 0.f;
 
   for (int t = p.U - 1; t >= 0; --t) {
     const bool first = (t == p.U - 1);
     const float* dfeed_next = first ? nullptr : p.dfeed_all + (int64_t)(t + 1) * B * W;      // written by step t+1
+    float sg[4] = {0.f, 0.f, 0.f, 0.f}, sct = 0.f, scp = 0.f, sdf = 0.f;
+    if (cellw) {
+      const float* gp = s0.gates + (int64_t)b * s0.ldg + (int64_t)t * p.inc_gates + tid;
+      sg[0] = gp[0]; sg[1] = gp[Hd]; sg[2] = gp[2 * Hd]; sg[3] = gp[3 * Hd];
+      sct = s0.c_new[(int64_t)b * s0.ldcn + (int64_t)t * p.inc_c + tid];
+      scp = s0.c_prev[(int64_t)b * s0.ldcp + (int64_t)t * p.inc_c + tid];
+      if (dfeed_next) sdf = dfeed_next[(int64_t)b * W + M + tid];
+    }
     float* dot_t = p.dot_all + ((int64_t)t * B + (active ? b : 0)) * 32;      // one cache line per (step, utterance)
     float* dhp_t = p.dhp_all + ((int64_t)t * B + (active ? b : 0)) * 4 * Hd;
     // ---- S1 ----
@@ -1205,20 +1217,17 @@ __global__ __launch_bounds__(256) void dec_persist_bwd_kernel(las_dec_persist_bw
         for (int u = tid; u < Hd; u += 256) dhs[u] = tmp[u];
         __syncthreads();
       }
-      for (int u = tid; u < Hd; u += 256) {
-        const float* gp = s0.gates + (int64_t)b * s0.ldg + (int64_t)t * p.inc_gates + u;
-        const float gi = gp[0], gj = gp[Hd], gf = gp[2 * Hd], go = gp[3 * Hd];
-        const float ct = s0.c_new[(int64_t)b * s0.ldcn + (int64_t)t * p.inc_c + u];
-        const float cp = s0.c_prev[(int64_t)b * s0.ldcp + (int64_t)t * p.inc_c + u];
-        float dht = dhs[u];
-        if (dfeed_next) dht += dfeed_next[(int64_t)b * W + M + u];
+      if (cellw) {
+        const int u = tid;
+        const float gi = sg[0], gj = sg[1], gf = sg[2], go = sg[3], ct = sct, cp = scp;
+        const float dht = dhs[u] + sdf;
         const float tc = las_tanh(ct);
         const float dov = dht * tc * go * (1.f - go);
-        const float dct = s0.dc[(int64_t)b * Hd + u] + dht * go * (1.f - tc * tc);
+        const float dct = dcr + dht * go * (1.f - tc * tc);
         const float di = dct * gj * gi * (1.f - gi);
         const float dj = dct * gi * (1.f - gj * gj);
         const float df = dct * cp * gf * (1.f - gf);
-        s0.dc[(int64_t)b * Hd + u] = dct * gf;
+        dcr = dct * gf;
         unsigned short* zp = s0.dz + (int64_t)b * s0.ldz + (int64_t)t * p.inc_dz + u;
         zp[0] = las_f2bf(di); zp[Hd] = las_f2bf(dj); zp[2 * Hd] = las_f2bf(df); zp[3 * Hd] = las_f2bf(dov);
       }
@@ -1259,6 +1268,7 @@ __global__ __launch_bounds__(256) void dec_persist_bwd_kernel(las_dec_persist_bw
     }
     if (!persist_barrier(flags, member, ++epoch, local, fail)) break;
   }
+  if (cellw) s0.dc[(int64_t)b * Hd + tid] = dcr;          // d(c) before the first step: the caller's d(initial state)
   if (*fail && tid == 0) atomicOr(status, 16u);
 }
 
