@@ -1062,6 +1062,20 @@ __global__ __launch_bounds__(256) void dec_persist_bwd_kernel(las_dec_persist_bw
   // values of a step are requested at its top, two barriers before the cell backward uses them
   const bool cellw = active && part == 0 && tid < Hd;
   float dcr = cellw ? s0.dc[(int64_t)b * Hd + tid] : 0.f;
+  // likewise the step's row of d(context) from the projection layer and its alignments: step t-1's are requested
+  // at the top of step t (PD values per thread cover M <= 256 * PD)
+  constexpr int PD = 6;
+  float cur_dc[PD], cur_al = 0.f;
+  auto fetch_step = [&](int tt_, float (&dcv)[PD], float& alv) {
+#pragma unroll
+    for (int i = 0; i < PD; ++i) {
+      const int m = tid + i * 256;
+      dcv[i] = (active && m < M) ? s0.dctx_a[(int64_t)b * s0.ldda + (int64_t)tt_ * p.inc_a + m] : 0.f;
+    }
+    const int fr = f0 + tid;
+    alv = (active && fr < f1 && fr < len) ? (s0.align + (int64_t)b * s0.lda + (int64_t)tt_ * p.inc_align)[fr] : 0.f;
+  };
+  fetch_step(p.U - 1, cur_dc, cur_al);
 
   for (int t = p.U - 1; t >= 0; --t) {
     const bool first = (t == p.U - 1);
@@ -1074,12 +1088,17 @@ __global__ __launch_bounds__(256) void dec_persist_bwd_kernel(las_dec_persist_bw
       scp = s0.c_prev[(int64_t)b * s0.ldcp + (int64_t)t * p.inc_c + tid];
       if (dfeed_next) sdf = dfeed_next[(int64_t)b * W + M + tid];
     }
+    float nxt_dc[PD], nxt_al = 0.f;
+    if (t > 0) fetch_step(t - 1, nxt_dc, nxt_al);
     float* dot_t = p.dot_all + ((int64_t)t * B + (active ? b : 0)) * 32;      // one cache line per (step, utterance)
     float* dhp_t = p.dhp_all + ((int64_t)t * B + (active ? b : 0)) * 4 * Hd;
     // ---- S1 ----
     if (active) {
-      for (int m = tid; m < M; m += 256) {
-        float v = s0.dctx_a[(int64_t)b * s0.ldda + (int64_t)t * p.inc_a + m];
+#pragma unroll
+      for (int i = 0; i < PD; ++i) {
+        const int m = tid + i * 256;
+        if (m >= M) break;
+        float v = cur_dc[i];
         if (dfeed_next) {
           float fb = dfeed_next[(int64_t)b * W + m];
           if (s0.drop_keep < 1.0f) {     // gradient through step t+1's input dropout of the attention feed
@@ -1091,8 +1110,11 @@ __global__ __launch_bounds__(256) void dec_persist_bwd_kernel(las_dec_persist_bw
         dctx[m] = v;
         if (part == 0 && s0.dctx_save) s0.dctx_save[(int64_t)b * s0.ldds + (int64_t)t * p.inc_save + m] = las_f2bf(v);
       }
-      const float* arow = s0.align + (int64_t)b * s0.lda + (int64_t)t * p.inc_align;
-      for (int tt = f0 + tid; tt < f1; tt += 256) alg[tt] = tt < len ? arow[tt] : 0.f;
+      if (f0 + tid < f1) alg[f0 + tid] = cur_al;
+      {                                                      // frame shares beyond 256 frames (Tm > 1024): the rest from memory
+        const float* arow = s0.align + (int64_t)b * s0.lda + (int64_t)t * p.inc_align;
+        for (int tt = f0 + 256 + tid; tt < f1; tt += 256) alg[tt] = tt < len ? arow[tt] : 0.f;
+      }
       __syncthreads();
       {
         const int sub = lane & 15, grp = lane >> 4;
@@ -1267,6 +1289,9 @@ __global__ __launch_bounds__(256) void dec_persist_bwd_kernel(las_dec_persist_bw
       }
     }
     if (!persist_barrier(flags, member, ++epoch, local, fail)) break;
+#pragma unroll
+    for (int i = 0; i < PD; ++i) cur_dc[i] = nxt_dc[i];
+    cur_al = nxt_al;
   }
   if (cellw) s0.dc[(int64_t)b * Hd + tid] = dcr;          // d(c) before the first step: the caller's d(initial state)
   if (*fail && tid == 0) atomicOr(status, 16u);

@@ -604,7 +604,8 @@ def test_persistent_decoder_vs_per_step_and_oracle(att, monkeypatch):
     (9, 20, 4, [20, 1, 7, 13, 20, 4, 9, 16, 3], [4, 1, 2, 3, 4, 4, 1, 2, 3]),     # two groups, the second with one utterance
     (17, 12, 2, [12] * 17, [2] * 17),                      # three groups
     (2, 1200, 2, [1200, 700], [2, 1]),                     # 600 memory frames: the LDS copies of keys / values do not fit
-], ids=['b1_u1', 'short_memory', 'two_groups', 'three_groups', 'long_memory_not_resident'])
+    (1, 2400, 2, [2400], [2]),                             # 1200 memory frames: a frame share longer than the 256 threads
+], ids=['b1_u1', 'short_memory', 'two_groups', 'three_groups', 'long_memory_not_resident', 'very_long_memory'])
 def test_persistent_decoder_edge_shapes_match_per_step_path(B, T, U, src_len, tgt_len, monkeypatch):
     """Edge shapes of the one-launch decoder (partial groups, empty frame shares, a single step) against the per-step
     launches: logits and every gradient agree to fp32 summation-order noise."""
