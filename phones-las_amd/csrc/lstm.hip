@@ -1,7 +1,9 @@
 // Listener recurrence: tf.nn.(bidirectional_)dynamic_rnn over LSTMCell (las/ops.py:10-46) as two
 // persistent, weight-stationary kernels (forward, backward-in-time) on gfx950.
 //
-// Decomposition.  The batch is cut into slices of 16 utterances (the M of v_mfma_f32_16x16x32_bf16).
+// Decomposition.  The batch is cut into slices of 16 utterances (the M of v_mfma_f32_16x16x32_bf16) -- or of 8 / 4
+// (rows 0..1 / row 0 of every lane's quad; the rest of the tile stays zero) while every chain still finds CUs of its
+// own: a step costs what one lane has to do in it, and shorter slices give every lane fewer (utterance, unit) pairs.
 // One (slice, direction) pair is a serial chain of T dependent steps; it is run by a GROUP of G
 // co-resident 256-thread workgroups ("members", one wave per SIMD).  Member m owns hidden units
 // [m*H/G, (m+1)*H/G) and keeps its part of K_h in REGISTERS for the whole sequence as ready-made MFMA B
@@ -19,8 +21,8 @@
 // once the members have established that they share an XCD (then its L2 is the coherence point).
 // Results never depend on workgroup placement; blockIdx = group + 8k*member only makes the members of a
 // group share an XCD under round-robin dispatch (speed).  Every spin is bounded: on timeout the kernel sets
-// a status word and returns.  Each compute workgroup has a PREFETCH COMPANION workgroup on another CU of the
-// same XCD that pulls its HBM operands into the shared L2 a few steps ahead.
+// a status word and returns.  Each group has a PREFETCH COMPANION workgroup per four members on another CU of the
+// same XCD that pulls their HBM operands into the shared L2 a few steps ahead.
 #include "las_common.h"
 #include <stdlib.h>
 #include <type_traits>
@@ -102,7 +104,7 @@ __global__ void pack_recurrent_kernel(const float* kh, int H, unsigned short* pa
 // forward
 // ------------------------------------------------------------------------------------------------
 // Workgroup size: 4 compute waves, one per SIMD (512-register budget).  When the chain is shared by several workgroups
-// every compute workgroup has a PREFETCH COMPANION workgroup (see the kernel) that keeps its HBM operands L2-resident.
+// the group has PREFETCH COMPANION workgroups (see the kernel) that keep its HBM operands L2-resident.
 __host__ __device__ constexpr int rec_threads(int H) { return 256; }
 
 // ROWS = utterances per slice: 16 fills the MFMA tile; 8 (rows 0,1 of every quad; the other two stay zero) halves the
@@ -837,8 +839,8 @@ CoopGeom geom(int B, int H, int ndir, bool bwd, int rows = 16) {
   return g;
 }
 
-// Utterances per slice.  8-row slices (see lstm_fwd_kernel) when the chains they make, with their companions, still
-// find a CU each (256 on MI355X); LAS_LSTM_ROWS=16 / 8 forces one (diagnostics; 8 needs a kernel that supports it).
+// Utterances per slice: the shortest (4, 8, 16; see lstm_fwd_kernel) whose chains, with their companions, still find
+// a CU each (256 on MI355X); LAS_LSTM_ROWS=16 / 8 / 4 forces one (tests, diagnostics).
 int slice_rows(int B, int H, int ndir, bool bwd) {
   const char* e = getenv("LAS_LSTM_ROWS");          // read at every launch: the tests switch it
   const int forced = e ? atoi(e) : 0;
