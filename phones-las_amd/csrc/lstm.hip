@@ -844,7 +844,7 @@ CoopGeom geom(int B, int H, int ndir, bool bwd, int rows = 16) {
 int slice_rows(int B, int H, int ndir, bool bwd) {
   const char* e = getenv("LAS_LSTM_ROWS");          // read at every launch: the tests switch it
   const int forced = e ? atoi(e) : 0;
-  if (H != 256) return 16;
+  if (H > 256) return 16;               // the 512-unit kernels (K split, row split) assume full tiles
   if (forced == 16 || forced == 8 || forced == 4) return forced;
   // every chain workgroup and every companion should find a CU of its own (256 on MI355X); the backward leaves at
   // least 96 CUs to the weight-gradient products that run beside it
@@ -874,7 +874,7 @@ int launch_fwd(float* xproj, const las_bf16* wp, const int32_t* length, las_bf16
   unsigned* status = reinterpret_cast<unsigned*>(ws);
   u64* exch = reinterpret_cast<u64*>(reinterpret_cast<char*>(ws) + 64);
   const int pf = g.G > 1 ? prefetch_mode() : 0;
-  if constexpr (H == 256) {
+  if constexpr (H <= 256) {
     if (rows == 8) {
       hipLaunchKernelGGL((lstm_fwd_kernel<H, 8>), dim3(pf ? g.blocks + g.companions : g.blocks), dim3(256), 0, st, xproj, wp, length, y,
                          cbuf, c_last, h_last, exch, status, B, T, ndir, g.ngroups, pf);
@@ -910,13 +910,13 @@ int launch_bwd(const float* gates, const float* cbuf, const float* dy, const flo
     hog_kb = e ? atoi(e) : 120;
     if (hog_kb > 0) {
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&lstm_bwd_kernel<H, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, hog_kb * 1024);
-      if constexpr (H == 256)
+      if constexpr (H <= 256)
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&lstm_bwd_kernel<H, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, hog_kb * 1024);
-      if constexpr (H == 256)
+      if constexpr (H <= 256)
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&lstm_bwd_kernel<H, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, hog_kb * 1024);
     }
   }
-  if constexpr (H == 256) {
+  if constexpr (H <= 256) {
     if (rows == 8) {
       hipLaunchKernelGGL((lstm_bwd_kernel<H, 8>), dim3(pf ? g.blocks + g.companions : g.blocks), dim3(256), (size_t)hog_kb * 1024, st, gates, cbuf, dy,
                          dc_last, dh_last, kh, length, dz, exch, status, B, T, ndir, g.ngroups);
