@@ -47,3 +47,26 @@ def test_ops_refuse_cpu_tensors():
     a = torch.zeros(8, 8, dtype=torch.bfloat16)
     with pytest.raises(hip.LasError):
         hip.gemm_nt(a, a, torch.zeros(8, 8), 8, 8, 8)
+
+
+def test_slice_height_policy_and_workspace_sizes(monkeypatch):
+    """Host-side queries of the recurrent kernels (no GPU work): utterances per slice as a function of the batch
+    (every chain workgroup and companion keeps a CU of its own out of 256), the override, and a workspace that covers
+    every layout."""
+    from phones_las_amd import hip
+    l = hip.lib()
+    monkeypatch.delenv('LAS_LSTM_ROWS', raising=False)
+    assert l.las_lstm_slice_rows(64, 256, 2) == 4            # 32 chains x 4 workgroups + 32 companions = 160
+    assert l.las_lstm_slice_rows(96, 256, 2) == 4            # 48 x 4 + 48 = 240
+    assert l.las_lstm_slice_rows(128, 256, 2) == 8           # 4-row slices would need 320 workgroups
+    assert l.las_lstm_slice_rows(512, 256, 2) == 16
+    assert l.las_lstm_slice_rows(64, 512, 2) == 16           # the 512-unit kernels run on full tiles
+    assert l.las_lstm_slice_rows(8, 128, 2) == 4
+    assert l.las_lstm_slice_rows(0, 256, 2) == 0 and l.las_lstm_slice_rows(8, 100, 2) == 0
+    monkeypatch.setenv('LAS_LSTM_ROWS', '16')
+    assert l.las_lstm_slice_rows(64, 256, 2) == 16
+    monkeypatch.delenv('LAS_LSTM_ROWS')
+    # the workspace covers the forward and the backward exchange of every slice height
+    w = l.las_lstm_workspace_bytes(64, 256, 2)
+    assert w >= 64 + 2 * 32 * 4 * 4 * 4 * 256 * 8            # backward, 4-row slices: 32 groups x 4 x 4 pairs x NUB*256 granules x 2 slots
+    assert l.las_lstm_workspace_bytes(64, 128, 2) == 64      # one workgroup per chain: no exchange buffer
