@@ -260,10 +260,13 @@ typedef struct las_dec_persist {
   float* sc_all;                 /* [U, B, ld_sc] fp32 scratch: raw attention scores (the parts of an utterance split the frames) */
   int64_t ld_sc;                 /* >= Tm, multiple of 32 (whole cache lines per row) */
   void* workspace;
-  /* scheduled sampling (utils/training_helper.py:48-87), sampling_prob > 0: after step t the kernel forms
-   * logits_t = context_t W_proj + b, stores them (logits + b*ld_logits + t*Vp) and writes the token fed at step t+1 into
-   * the tok_ids row (s.tok_ids[b*tok_stride + t+1]): a draw from Categorical(logits_t) with probability sampling_prob,
-   * else teacher[b*teacher_stride + t+1].  Same generator streams as las_sample_tokens(step = t). */
+  /* scheduled sampling (utils/training_helper.py:48-87), sampling_prob > 0: after step t the kernel replaces the token
+   * fed at step t+1 (s.tok_ids[b*tok_stride + t+1], which must hold the teacher's token on entry) by a draw from
+   * Categorical(logits_t), logits_t = context_t W_proj + b, for the utterances selected with probability sampling_prob.
+   * The draws are counter-based (same generator streams as las_sample_tokens(step = t)), so a group of utterances
+   * without a selection at step t skips the phase; logits are formed for the selected utterances only and are NOT an
+   * output (the caller computes all logits with one las_gemm_nt after the loop; `logits` / `ld_logits` / `teacher` are
+   * unused and may be NULL / 0). */
   float sampling_prob;
   uint32_t seed;
   const int32_t* teacher;

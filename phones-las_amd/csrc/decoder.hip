@@ -630,9 +630,24 @@ __global__ __launch_bounds__(256) void dec_persist_fwd_kernel(las_dec_persist p)
     if constexpr (SAMPLING) {
       // ---- scheduled sampling (utils/training_helper.py:48-87): logits_t = context_t W_proj + b from the four parts'
       //      partial products, then the next fed token = Categorical(logits_t) with probability p, else the teacher's ----
+      // The draws are counter-based, so every member knows which utterances of its group are selected at this step:
+      // a group without a selection skips the phase and both of its barriers (57 % of the steps at p = 0.1), and only
+      // the selected utterances' workgroups compute logits.  (The logits the model returns come from one GEMM after
+      // the loop, as without sampling.)
       const int V = p.V, Vp = p.Vp;
+      bool any_sel = false, my_sel = false;
+      if (t + 1 < p.U) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int bj = group * 8 + j;
+          const bool sel = bj < B && las_uniform(p.seed, 0x5e1ec7u, (unsigned long long)t * B + bj) < p.sampling_prob;
+          any_sel = any_sel || sel;
+          if (bj == bs) my_sel = sel;
+        }
+      }
+      if (any_sel) {
       float* plog_t = p.plog + ((int64_t)t * B + (bs < B ? bs : 0)) * 4 * Vp;
-      if (bs < B) {
+      if (my_sel) {
         const int cols = M / 4, c0 = part * cols;
         float* cx = sm;                                   // [cols] my context columns as floats
         __builtin_amdgcn_s_waitcnt(0x0070);               // my context stores are done
@@ -655,20 +670,15 @@ __global__ __launch_bounds__(256) void dec_persist_fwd_kernel(las_dec_persist p)
         }
       }
       if (!persist_barrier(flags, member, ++epoch, local, fail)) break;
-      if (bs < B && part == 0) {
-        float* lrow = p.logits + (int64_t)bs * p.ld_logits + (int64_t)t * Vp;
+      if (my_sel && part == 0) {
         float* lg = sm;                                   // [Vp]
-        for (int v = tid; v < Vp; v += 256) {
-          const float x = v < V ? plog_t[v] + plog_t[Vp + v] + plog_t[2 * Vp + v] + plog_t[3 * Vp + v] + p.bproj[v] : p.bproj[v];
-          lg[v] = x;
-          lrow[v] = x;
-        }
+        for (int v = tid; v < Vp; v += 256)
+          lg[v] = v < V ? plog_t[v] + plog_t[Vp + v] + plog_t[2 * Vp + v] + plog_t[3 * Vp + v] + p.bproj[v] : p.bproj[v];
         __syncthreads();
-        if (t + 1 < p.U && tid < 64) {
+        if (tid < 64) {
           const unsigned long long sidx = (unsigned long long)t * B + bs;
-          const bool select = las_uniform(p.seed, 0x5e1ec7u, sidx) < p.sampling_prob;
-          int out = p.teacher[(int64_t)bs * p.teacher_stride + t + 1];
-          if (select) {
+          int out;
+          {
             float best = -INFINITY;
             int arg = 0;
             for (int v = lane; v < V; v += 64) {
@@ -684,8 +694,9 @@ __global__ __launch_bounds__(256) void dec_persist_fwd_kernel(las_dec_persist p)
             }
             out = arg;
           }
-          if (lane == 0) const_cast<int32_t*>(s0.tok_ids)[(int64_t)bs * s0.tok_stride + t + 1] = out;
+          if (lane == 0) const_cast<int32_t*>(s0.tok_ids)[(int64_t)bs * s0.tok_stride + t + 1] = out;   // else: the teacher's, already there
         }
+      }
       }
     }
     if (!persist_barrier(flags, member, ++epoch, local, fail)) break;
@@ -1511,9 +1522,9 @@ extern "C" int las_decoder_persist_fwd(const las_dec_persist* p, void* stream) {
   LAS_REQUIRE(p->x && p->kT && p->z_all && p->sc_all && p->workspace && p->ld_sc >= s->Tm && p->ld_sc % 32 == 0 &&
                   ((uintptr_t)p->sc_all % 128 == 0) && ((uintptr_t)p->z_all % 128 == 0) && ((uintptr_t)p->x % 128 == 0),
               "las_decoder_persist_fwd: null argument, or exchanged rows that are not whole 128-byte lines");
-  LAS_REQUIRE(p->sampling_prob <= 0.f || (p->wprojT && p->bproj && p->logits && p->plog && p->teacher && p->V > 0 && p->Vp >= p->V &&
+  LAS_REQUIRE(p->sampling_prob <= 0.f || (p->wprojT && p->bproj && p->plog && p->V > 0 && p->Vp >= p->V &&
                                           p->Vp <= 1024 && s->M % 32 == 0 && p->inc_tok == 1),
-              "las_decoder_persist_fwd: scheduled sampling needs wprojT, bproj, logits, plog, teacher (and fed ids with unit step)");
+              "las_decoder_persist_fwd: scheduled sampling needs wprojT, bproj, plog (and fed ids with unit step)");
   hipStream_t st = (hipStream_t)stream;
   const int groups = (s->B + 7) / 8;
   int rc = las_check_hip(hipMemsetAsync(p->workspace, 0, las_decoder_persist_workspace_bytes(s->B), st), "memset workspace");

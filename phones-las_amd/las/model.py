@@ -319,9 +319,10 @@ class Speller:
                 p.sampling_prob, p.seed = sampling, seed
                 p.teacher, p.teacher_stride = hip.addr(tin), tin.stride(0)
                 p.wprojT, p.ldw, p.bproj = hip.addr(self.wprojT), M, hip.addr(self.bproj)
-                p.logits, p.ld_logits, p.plog, p.V, p.Vp = hip.addr(logits), U * Vp, hip.addr(plog), V, Vp
+                p.logits, p.ld_logits, p.plog, p.V, p.Vp = 0, U * Vp, hip.addr(plog), V, Vp
             hip.check(lib.las_decoder_persist_fwd(C.byref(p), st))
             self._persist_ws = ws
+            logits = None                # the launch only forms the logits it samples from; all of them come from one GEMM below
         for t in range(0 if not persist else U, U):
             hip.gemm_nt(AH[:, t], self.kcT, z, B, 4 * Hd, W, lda=U * W, ldb=W, ldc=4 * Hd)
             last = (t + 1 == U)
