@@ -425,6 +425,25 @@ constexpr unsigned P_SPIN_LIMIT = 1u << 22;
 constexpr int P_MEMBERS = 32;
 // LDS of the persistent backward kernel: its scratch, and -- when it fits the CU's 160 KiB -- this workgroup's quarter
 // of the utterance's memory frames (values [fq, M] and keys [fq, Hd], bf16), which every step reads again.
+// Workspace of a persistent launch: [64 B status][group flags and XCC table: groups * 2 * 32 words][exchange granules].
+// The four workgroups of an UTTERANCE hand small results to each other as 8-byte {tag, fp32} granules (the data is its
+// own flag, as in the recurrent kernels; two parity slots, tag = step count) instead of meeting all 32 workgroups of
+// the group at a flag barrier: forward the raw scores [2][B][ld] (ld = frames rounded up to 32), backward the partial
+// dots [2][B][4] and the partial dh [2][B][3][Hd].
+__host__ __device__ inline size_t persist_flag_words(int B) { return (size_t)((B + 7) / 8) * 2 * P_MEMBERS; }
+__host__ __device__ inline size_t persist_exchange_words(int B, int Tm, int Hd) {
+  const size_t ld = (size_t)((Tm + 31) / 32) * 32;
+  const size_t fwd = 2 * (size_t)B * ld, bwd = 2 * (size_t)B * (4 + 3 * (size_t)Hd);
+  return fwd > bwd ? fwd : bwd;
+}
+__device__ __forceinline__ void pgranule_store(pu64* p, unsigned tag, float value, bool local) {
+  const pu64 x = ((pu64)tag << 32) | __float_as_uint(value);
+  if (local) *p = x;
+  else __hip_atomic_store(p, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ pu64 pgranule_load(const pu64* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 // forward: scratch, and this workgroup's score frames of the keys [fq, Hd] + its context columns of the values [Tm, M/4]
 __host__ __device__ inline size_t persist_fwd_scratch_floats(int Hd, int Tm) {
   return ((size_t)2 * Hd + Tm + 16 + 2048 + 4 * 16 * 33 + 8 + 3) & ~(size_t)3;
@@ -1009,6 +1028,8 @@ __global__ __launch_bounds__(256) void dec_persist_bwd_kernel(las_dec_persist_bw
   unsigned* status = reinterpret_cast<unsigned*>(p.workspace);
   pu64* flags = reinterpret_cast<pu64*>(reinterpret_cast<char*>(p.workspace) + 64) + (size_t)group * 2 * P_MEMBERS;
   pu64* xcc_tab = flags + P_MEMBERS;
+  pu64* xdot = reinterpret_cast<pu64*>(reinterpret_cast<char*>(p.workspace) + 64) + persist_flag_words(B);   // [2][B][4]
+  pu64* xdh = xdot + 2 * (size_t)B * 4;                                                                        // [2][B][3][Hd]
   if (tid == 0) { *fail = 0; *colo = 0; }
   __syncthreads();
   if (tid == 0) {
@@ -1101,8 +1122,7 @@ __global__ __launch_bounds__(256) void dec_persist_bwd_kernel(las_dec_persist_bw
     }
     float nxt_dc[PD], nxt_al = 0.f;
     if (t > 0) fetch_step(t - 1, nxt_dc, nxt_al);
-    float* dot_t = p.dot_all + ((int64_t)t * B + (active ? b : 0)) * 32;      // one cache line per (step, utterance)
-    float* dhp_t = p.dhp_all + ((int64_t)t * B + (active ? b : 0)) * 4 * Hd;
+    const unsigned xtag = (unsigned)(p.U - t);       // 1, 2, ...: tag of this step's granules, parity slot xtag & 1
     // ---- S1 ----
     if (active) {
 #pragma unroll
@@ -1162,12 +1182,25 @@ __global__ __launch_bounds__(256) void dec_persist_bwd_kernel(las_dec_persist_bw
       float dot = 0.f;
       for (int tt = f0 + tid; tt < flen; tt += 256) dot += alg[tt] * dal[tt];
       dot = block_reduce(dot, red, false);
-      if (tid == 0) dot_t[part] = dot;
+      if (tid == 0) pgranule_store(xdot + ((size_t)(xtag & 1) * B + b) * 4 + part, xtag, dot, local);
     }
-    if (!persist_barrier(flags, member, ++epoch, local, fail)) break;
-    // ---- S2 ----
+    // ---- S2 ----  (the four partial dots meet as granules: no group barrier)
     if (active) {
-      const float dot = dot_t[0] + dot_t[1] + dot_t[2] + dot_t[3];
+      if (tid < 64) {
+        const pu64* xd = xdot + ((size_t)(xtag & 1) * B + b) * 4;
+        float v = 0.f;
+        unsigned spins = 0;
+        for (;;) {
+          const pu64 gq = lane < 4 ? pgranule_load(xd + lane) : ((pu64)xtag << 32);
+          if (__all((unsigned)(gq >> 32) == xtag)) { v = __uint_as_float((unsigned)gq); break; }
+          if (++spins > P_SPIN_LIMIT) { if (lane == 0) *fail = 1; break; }
+          __builtin_amdgcn_s_sleep(1);
+        }
+        const float d0 = __shfl(v, 0, 64), d1 = __shfl(v, 1, 64), d2 = __shfl(v, 2, 64), d3 = __shfl(v, 3, 64);
+        if (lane == 0) red[0] = d0 + d1 + d2 + d3;
+      }
+      __syncthreads();
+      const float dot = red[0];
       unsigned short* dso = s0.ds_out + (int64_t)b * s0.ldso + (int64_t)t * p.inc_ds;
       for (int tt = f0 + tid; tt < f1; tt += 256) {
         const float v = (tt < len) ? alg[tt] * (dal[tt] - dot) : 0.f;
@@ -1221,16 +1254,38 @@ __global__ __launch_bounds__(256) void dec_persist_bwd_kernel(las_dec_persist_bw
 #pragma unroll
       for (int j = 0; j < 8; ++j) dhs[phase * Hd + u + j] = a[j];
       __syncthreads();
-      for (int uu = tid; uu < Hd; uu += 256) {
-        float acc = 0.f;
-        for (int ph = 0; ph < P; ++ph) acc += dhs[ph * Hd + uu];
-        dhp_t[part * Hd + uu] = acc;
+      // partial dh of this workgroup's frames (unit = threadIdx.x; Hd <= 256): parts 1..3 send theirs to part 0 as granules
+      float dh_own = 0.f;
+      if (tid < Hd)
+        for (int ph = 0; ph < P; ++ph) dh_own += dhs[ph * Hd + tid];
+      pu64* xh = xdh + ((size_t)(xtag & 1) * B + b) * 3 * Hd;
+      if (part != 0) {
+        if (tid < Hd) pgranule_store(xh + (size_t)(part - 1) * Hd + tid, xtag, dh_own, local);
+      } else {
+        // ---- S3 on part 0: total dh, then the LSTM cell backward (Appendix F) ----
+        float tot = dh_own;
+        unsigned spins = 0;
+        for (;;) {                                  // wave-uniform polling, bounded
+          bool got = true;
+          pu64 g3[3];
+#pragma unroll
+          for (int q = 0; q < 3; ++q) {
+            g3[q] = tid < Hd ? pgranule_load(xh + (size_t)q * Hd + tid) : ((pu64)xtag << 32);
+            got = got && ((unsigned)(g3[q] >> 32) == xtag);
+          }
+          if (__all(got)) {
+#pragma unroll
+            for (int q = 0; q < 3; ++q) tot += __uint_as_float((unsigned)g3[q]);
+            break;
+          }
+          if (++spins > P_SPIN_LIMIT) { if (lane == 0) *fail = 1; break; }
+          __builtin_amdgcn_s_sleep(1);
+        }
+        __syncthreads();                            // dhs (the per-phase partials) has been read by everybody
+        if (tid < Hd) dhs[tid] = tot;
       }
     }
-    if (!persist_barrier(flags, member, ++epoch, local, fail)) break;
-    // ---- S3: LSTM cell backward (Appendix F), one workgroup per utterance ----
     if (active && part == 0) {
-      for (int u = tid; u < Hd; u += 256) dhs[u] = dhp_t[u] + dhp_t[Hd + u] + dhp_t[2 * Hd + u] + dhp_t[3 * Hd + u];
       __syncthreads();
       if (WQ && att_uses_wq(s0.attention)) {
         // dhs holds d(processed query): save it (bf16) for d(query_layer), map back: dh[u] = sum_a dpq[a] Wq[u][a]
@@ -1509,8 +1564,8 @@ extern "C" int las_decoder_persist_supported(int Hd, int M, int K_in, int attent
   return 1;
 }
 
-extern "C" size_t las_decoder_persist_workspace_bytes(int B) {
-  return 64 + (size_t)((B + 7) / 8) * 2 * P_MEMBERS * sizeof(pu64);
+extern "C" size_t las_decoder_persist_workspace_bytes(int B, int Tm, int Hd) {
+  return 64 + (persist_flag_words(B) + persist_exchange_words(B, Tm, Hd)) * sizeof(pu64);
 }
 
 extern "C" int las_decoder_persist_fwd(const las_dec_persist* p, void* stream) {
@@ -1527,7 +1582,7 @@ extern "C" int las_decoder_persist_fwd(const las_dec_persist* p, void* stream) {
               "las_decoder_persist_fwd: scheduled sampling needs wprojT, bproj, plog (and fed ids with unit step)");
   hipStream_t st = (hipStream_t)stream;
   const int groups = (s->B + 7) / 8;
-  int rc = las_check_hip(hipMemsetAsync(p->workspace, 0, las_decoder_persist_workspace_bytes(s->B), st), "memset workspace");
+  int rc = las_check_hip(hipMemsetAsync(p->workspace, 0, las_decoder_persist_workspace_bytes(s->B, s->Tm, s->Hd), st), "memset workspace");
   if (rc) return rc;
   size_t lds = persist_fwd_scratch_floats(s->Hd, s->Tm) * sizeof(float);
   LAS_REQUIRE(lds <= 64 * 1024, "las_decoder_persist_fwd: memory length %d too long for the LDS score buffer", s->Tm);
@@ -1573,7 +1628,7 @@ extern "C" int las_decoder_persist_bwd(const las_dec_persist_bwd* p, void* strea
               "las_decoder_persist_bwd: Bahdanau scores need att_v, dkeys_acc, dv_acc");
   hipStream_t st = (hipStream_t)stream;
   const int groups = (s->B + 7) / 8;
-  int rc = las_check_hip(hipMemsetAsync(p->workspace, 0, las_decoder_persist_workspace_bytes(s->B), st), "memset workspace");
+  int rc = las_check_hip(hipMemsetAsync(p->workspace, 0, las_decoder_persist_workspace_bytes(s->B, s->Tm, s->Hd), st), "memset workspace");
   if (rc) return rc;
   size_t lds = persist_bwd_scratch_floats(s->M, s->Hd, s->Tm) * sizeof(float);
   LAS_REQUIRE(lds <= 64 * 1024, "las_decoder_persist_bwd: shapes exceed the LDS budget");
