@@ -81,6 +81,15 @@ __device__ __forceinline__ float dot8(const uint4& k, const float* q) {
 // phase (each part reads a quarter of the keys instead of all of them), publish their raw scores in a per-step row of
 // global scratch and meet at the group's flag barrier before the softmax.
 typedef unsigned long long pu64;
+// 8-byte {tag, fp32} granule of the persistent decoder's utterance-local exchanges (see persist_exchange_words)
+__device__ __forceinline__ void pgranule_store(pu64* p, unsigned tag, float value, bool local) {
+  const pu64 x = ((pu64)tag << 32) | __float_as_uint(value);
+  if (local) *p = x;
+  else __hip_atomic_store(p, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ pu64 pgranule_load(const pu64* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 // 16-byte loads from global memory or, through an address-space-qualified pointer, from LDS (a pointer that travelled
 // through a struct is otherwise a FLAT access: slower than either)
 typedef const __attribute__((address_space(3))) unsigned short* lds_cu16;
@@ -92,8 +101,8 @@ __device__ __forceinline__ uint4 ld16(lds_cu16 p) {
 }
 
 struct PersistHook {
-  float* scores;        // [B][ld] raw scores of this step
-  int64_t ld;
+  pu64* xsc;            // raw-score granules of this utterance and step parity: [ld] {tag, fp32}
+  unsigned xtag;        // tag of this step (1, 2, ...)
   pu64* flags;
   int member;
   unsigned* epoch;
@@ -198,7 +207,6 @@ __device__ void dec_step_fwd_body(const las_dec_step& s, const int b, const int 
     const int fq = (Tm + nparts - 1) / nparts;
     const int f0 = ph ? part * fq : 0, f1 = ph ? min(Tm, f0 + fq) : Tm;
     const int flen = min(len, f1);
-    float* scw = ph ? ph->scores + (int64_t)b * ph->ld : sc;       // where raw scores go
     if (Hd <= 32 * KMAX) {
       const int nk = Hd / 32;                          // loads per lane and frame
       // krows: key rows from memory (row 0 = frame 0) or from the workgroup's LDS copy (row 0 = frame f0)
@@ -232,7 +240,11 @@ __device__ void dec_step_fwd_body(const las_dec_step& s, const int b, const int 
           }
           part_sum += __shfl_xor(part_sum, 1, 64);
           part_sum += __shfl_xor(part_sum, 2, 64);
-          if (sub == 0 && t < f1) scw[t] = (t < len) ? part_sum : -INFINITY;
+          if (sub == 0 && t < f1) {
+            const float sv = (t < len) ? part_sum : -INFINITY;
+            if (ph) pgranule_store(ph->xsc + t, ph->xtag, sv, ph->local);      // the other three parts are waiting for it
+            else sc[t] = sv;
+          }
         }
       }
       };
@@ -256,12 +268,27 @@ __device__ void dec_step_fwd_body(const las_dec_step& s, const int b, const int 
         }
         part_sum += __shfl_xor(part_sum, 1, 64);
         part_sum += __shfl_xor(part_sum, 2, 64);
-        if (sub == 0 && t < f1) scw[t] = (t < len) ? part_sum : -INFINITY;
+        if (sub == 0 && t < f1) {
+            const float sv = (t < len) ? part_sum : -INFINITY;
+            if (ph) pgranule_store(ph->xsc + t, ph->xtag, sv, ph->local);      // the other three parts are waiting for it
+            else sc[t] = sv;
+          }
       }
     }
-    if (ph) {            // every part has published its frames: gather the whole score row
-      if (!persist_barrier(ph->flags, ph->member, ++*ph->epoch, ph->local, ph->fail)) return;
-      for (int t = tid; t < Tm; t += 256) sc[t] = scw[t];
+    if (ph) {            // gather the whole score row: the data is its own flag (no group barrier)
+      for (int t0 = 0; t0 < Tm; t0 += 256) {
+        const int t = t0 + tid;
+        unsigned spins = 0;
+        for (;;) {                                      // wave-uniform, bounded
+          const pu64 gq = t < Tm ? pgranule_load(ph->xsc + t) : ((pu64)ph->xtag << 32);
+          if (__all((unsigned)(gq >> 32) == ph->xtag)) {
+            if (t < Tm) sc[t] = __uint_as_float((unsigned)gq);
+            break;
+          }
+          if (++spins > (1u << 22)) { *ph->fail = 1; break; }
+          __builtin_amdgcn_s_sleep(1);
+        }
+      }
     }
   }
   __syncthreads();
@@ -435,14 +462,6 @@ __host__ __device__ inline size_t persist_exchange_words(int B, int Tm, int Hd) 
   const size_t ld = (size_t)((Tm + 31) / 32) * 32;
   const size_t fwd = 2 * (size_t)B * ld, bwd = 2 * (size_t)B * (4 + 3 * (size_t)Hd);
   return fwd > bwd ? fwd : bwd;
-}
-__device__ __forceinline__ void pgranule_store(pu64* p, unsigned tag, float value, bool local) {
-  const pu64 x = ((pu64)tag << 32) | __float_as_uint(value);
-  if (local) *p = x;
-  else __hip_atomic_store(p, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ pu64 pgranule_load(const pu64* p) {
-  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 // forward: scratch, and this workgroup's score frames of the keys [fq, Hd] + its context columns of the values [Tm, M/4]
 __host__ __device__ inline size_t persist_fwd_scratch_floats(int Hd, int Tm) {
@@ -639,12 +658,13 @@ __global__ __launch_bounds__(256) void dec_persist_fwd_kernel(las_dec_persist p)
       st.ctx_out = s0.ctx_out + t * p.inc_ctx;
       st.ctx_out2 = last ? nullptr : s0.ctx_out2 + t * p.inc_ctx2;
       st.step = t;
-      PersistHook hook{p.sc_all + (int64_t)t * B * p.ld_sc, p.ld_sc, flags, member, &epoch, local, fail, lkeys, lvals,
+      const unsigned xtag = (unsigned)(t + 1);
+      pu64* xsc = reinterpret_cast<pu64*>(reinterpret_cast<char*>(p.workspace) + 64) + persist_flag_words(B) +
+                  ((size_t)(xtag & 1) * B + bs) * (size_t)((Tm + 31) / 32 * 32);
+      PersistHook hook{xsc, xtag, flags, member, &epoch, local, fail, lkeys, lvals,
                        pre_ok, tok_pre, {tok4[0], tok4[1], tok4[2], tok4[3]}, {bias4[0], bias4[1], bias4[2], bias4[3]}, cprev_pre};
       dec_step_fwd_body<RES>(st, bs, part, 4, sm, &hook);
       if (*fail) break;
-    } else {
-      if (!persist_barrier(flags, member, ++epoch, local, fail)) break;     // the score exchange of the busy members
     }
     if constexpr (SAMPLING) {
       // ---- scheduled sampling (utils/training_helper.py:48-87): logits_t = context_t W_proj + b from the four parts'
