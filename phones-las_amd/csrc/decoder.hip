@@ -102,6 +102,7 @@ __device__ __forceinline__ uint4 ld16(lds_cu16 p) {
 
 struct PersistHook {
   pu64* xsc;            // raw-score granules of this utterance and step parity: [ld] {tag, fp32}
+  pu64* xz;             // z_t granules of this utterance and step parity: [4Hd] {tag, fp32}
   unsigned xtag;        // tag of this step (1, 2, ...)
   pu64* flags;
   int member;
@@ -157,12 +158,36 @@ __device__ void dec_step_fwd_body(const las_dec_step& s, const int b, const int 
                     ? 1.0f / s.drop_keep : 0.f;
   for (int u = tid; u < Hd; u += 256) {
     float z[4];
+    if (ph) {
+      // persistent decoder: the product slices arrive as granules from the 32 workgroups of the group (whole waves
+      // are in this loop: Hd is a multiple of 64); wave-uniform, bounded polling
+      unsigned spins = 0;
+      for (;;) {
+        pu64 gq[4];
+        bool got = true;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          gq[g] = pgranule_load(ph->xz + g * Hd + u);
+          got = got && ((unsigned)(gq[g] >> 32) == ph->xtag);
+        }
+        if (__all(got)) {
+#pragma unroll
+          for (int g = 0; g < 4; ++g) z[g] = __uint_as_float((unsigned)gq[g]);
+          break;
+        }
+        if (++spins > (1u << 22)) { *ph->fail = 1; z[0] = z[1] = z[2] = z[3] = 0.f; break; }
+        __builtin_amdgcn_s_sleep(1);
+      }
+    } else {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) z[g] = s.z[(int64_t)b * 4 * Hd + g * Hd + u];
+    }
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
       if (pre) {
-        z[g] = s.z[(int64_t)b * 4 * Hd + g * Hd + u] + ph->bias4[g] + tok_scale * ph->tok4[g];
+        z[g] += ph->bias4[g] + tok_scale * ph->tok4[g];
       } else {
-        z[g] = s.z[(int64_t)b * 4 * Hd + g * Hd + u] + s.bias[g * Hd + u];
+        z[g] += s.bias[g * Hd + u];
         if (s.tok_rows) z[g] += tok_scale * las_bf2f(s.tok_rows[(int64_t)tok * 4 * Hd + g * Hd + u]);
       }
     }
@@ -455,12 +480,13 @@ constexpr int P_MEMBERS = 32;
 // Workspace of a persistent launch: [64 B status][group flags and XCC table: groups * 2 * 32 words][exchange granules].
 // The four workgroups of an UTTERANCE hand small results to each other as 8-byte {tag, fp32} granules (the data is its
 // own flag, as in the recurrent kernels; two parity slots, tag = step count) instead of meeting all 32 workgroups of
-// the group at a flag barrier: forward the raw scores [2][B][ld] (ld = frames rounded up to 32), backward the partial
+// the group at a flag barrier: forward the raw scores [2][B][ld] (ld = frames rounded up to 32) and the gate
+// pre-activations z_t [2][B][4Hd] (from the 32 product slices to the utterance's workgroups), backward the partial
 // dots [2][B][4] and the partial dh [2][B][3][Hd].
 __host__ __device__ inline size_t persist_flag_words(int B) { return (size_t)((B + 7) / 8) * 2 * P_MEMBERS; }
 __host__ __device__ inline size_t persist_exchange_words(int B, int Tm, int Hd) {
   const size_t ld = (size_t)((Tm + 31) / 32) * 32;
-  const size_t fwd = 2 * (size_t)B * ld, bwd = 2 * (size_t)B * (4 + 3 * (size_t)Hd);
+  const size_t fwd = 2 * (size_t)B * (ld + 4 * (size_t)Hd), bwd = 2 * (size_t)B * (4 + 3 * (size_t)Hd);
   return fwd > bwd ? fwd : bwd;
 }
 // forward: scratch, and this workgroup's score frames of the keys [fq, Hd] + its context columns of the values [Tm, M/4]
@@ -606,7 +632,10 @@ __global__ __launch_bounds__(256) void dec_persist_fwd_kernel(las_dec_persist p)
       cprev_pre = (s0.c_prev + t * p.inc_cprev)[(int64_t)bs * s0.ldcp + tid];
     }
     // ---- G: z_t[group's utterances, my columns] ----
-    float* zt = p.z_all + (int64_t)t * B * 4 * Hd;
+    const unsigned xtag = (unsigned)(t + 1);
+    pu64* const xbase = reinterpret_cast<pu64*>(reinterpret_cast<char*>(p.workspace) + 64) + persist_flag_words(B);
+    const size_t ldsc = (size_t)((Tm + 31) / 32 * 32);
+    pu64* const xzb = xbase + 2 * (size_t)B * ldsc;           // [2][B][4Hd] after the score granules [2][B][ldsc]
     {
       f32x4 acc[NTL_MAX];
 #pragma unroll
@@ -635,17 +664,17 @@ __global__ __launch_bounds__(256) void dec_persist_fwd_kernel(las_dec_persist p)
         const int row = e / CPM, col = e % CPM;
         const int b = group * 8 + row;
         if (b < B)
-          zt[(int64_t)b * 4 * Hd + member * CPM + col] =
-              red[(0 * 16 + row) * 33 + col] + red[(1 * 16 + row) * 33 + col] + red[(2 * 16 + row) * 33 + col] + red[(3 * 16 + row) * 33 + col];
+          pgranule_store(xzb + ((size_t)(xtag & 1) * B + b) * 4 * Hd + member * CPM + col, xtag,
+                         red[(0 * 16 + row) * 33 + col] + red[(1 * 16 + row) * 33 + col] + red[(2 * 16 + row) * 33 + col] + red[(3 * 16 + row) * 33 + col],
+                         local);
       }
     }
-    if (!persist_barrier(flags, member, ++epoch, local, fail)) break;
+    // (no group barrier here: the S role polls the granules of its utterance)
 
     // ---- S: cell + attention of utterance bs, context columns of `part` ----
     if (bs < B) {
       las_dec_step st = s0;
       const bool last = (t + 1 == p.U);
-      st.z = zt;
       st.tok_ids = s0.tok_ids + t * p.inc_tok;
       st.c_prev = s0.c_prev + t * p.inc_cprev;
       st.gates_out = s0.gates_out + t * p.inc_gates;
@@ -658,10 +687,9 @@ __global__ __launch_bounds__(256) void dec_persist_fwd_kernel(las_dec_persist p)
       st.ctx_out = s0.ctx_out + t * p.inc_ctx;
       st.ctx_out2 = last ? nullptr : s0.ctx_out2 + t * p.inc_ctx2;
       st.step = t;
-      const unsigned xtag = (unsigned)(t + 1);
-      pu64* xsc = reinterpret_cast<pu64*>(reinterpret_cast<char*>(p.workspace) + 64) + persist_flag_words(B) +
-                  ((size_t)(xtag & 1) * B + bs) * (size_t)((Tm + 31) / 32 * 32);
-      PersistHook hook{xsc, xtag, flags, member, &epoch, local, fail, lkeys, lvals,
+      pu64* xsc = xbase + ((size_t)(xtag & 1) * B + bs) * ldsc;
+      pu64* xz = xzb + ((size_t)(xtag & 1) * B + bs) * 4 * Hd;
+      PersistHook hook{xsc, xz, xtag, flags, member, &epoch, local, fail, lkeys, lvals,
                        pre_ok, tok_pre, {tok4[0], tok4[1], tok4[2], tok4[3]}, {bias4[0], bias4[1], bias4[2], bias4[3]}, cprev_pre};
       dec_step_fwd_body<RES>(st, bs, part, 4, sm, &hook);
       if (*fail) break;
