@@ -280,7 +280,7 @@ typedef struct las_dec_persist {
   int32_t V, Vp;
 } las_dec_persist;
 int las_decoder_persist_supported(int Hd, int M, int K_in, int attention, int norm);   /* 1 if the shapes fit */
-size_t las_decoder_persist_workspace_bytes(int B, int Tm, int Hd);   /* status, group flags, exchange granules */
+size_t las_decoder_persist_workspace_bytes(int B, int Tm, int Hd, int M);   /* status, group flags, exchange granules */
 int las_decoder_persist_fwd(const las_dec_persist* p, void* stream);
 
 /* Backward of one decoder step.  d(context) = dctx_a + dctx_b; the kernel
@@ -356,7 +356,7 @@ typedef struct las_dec_persist_bwd {
   float* dfeed_all;              /* [U, B, W] fp32 */
   float* dot_all;                /* [U, B, 32] fp32 scratch (4 used: one cache line per row) */
   float* dhp_all;                /* [U, B, 4, Hd] fp32 scratch */
-  void* workspace;               /* las_decoder_persist_workspace_bytes(B, Tm, Hd) */
+  void* workspace;               /* las_decoder_persist_workspace_bytes(B, Tm, Hd, M) */
 } las_dec_persist_bwd;
 int las_decoder_persist_bwd_supported(int Hd, int M, int W, int attention, int norm);
 int las_decoder_persist_bwd(const las_dec_persist_bwd* p, void* stream);

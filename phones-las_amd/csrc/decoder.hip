@@ -482,11 +482,12 @@ constexpr int P_MEMBERS = 32;
 // own flag, as in the recurrent kernels; two parity slots, tag = step count) instead of meeting all 32 workgroups of
 // the group at a flag barrier: forward the raw scores [2][B][ld] (ld = frames rounded up to 32) and the gate
 // pre-activations z_t [2][B][4Hd] (from the 32 product slices to the utterance's workgroups), backward the partial
-// dots [2][B][4] and the partial dh [2][B][3][Hd].
+// dots [2][B][4], the partial dh [2][B][3][Hd] and the feed gradients d[attention, h]_t [2][B][M+Hd] (from the 32 product
+// slices to the utterance's workgroups of the step before).
 __host__ __device__ inline size_t persist_flag_words(int B) { return (size_t)((B + 7) / 8) * 2 * P_MEMBERS; }
-__host__ __device__ inline size_t persist_exchange_words(int B, int Tm, int Hd) {
+__host__ __device__ inline size_t persist_exchange_words(int B, int Tm, int Hd, int M) {
   const size_t ld = (size_t)((Tm + 31) / 32) * 32;
-  const size_t fwd = 2 * (size_t)B * (ld + 4 * (size_t)Hd), bwd = 2 * (size_t)B * (4 + 3 * (size_t)Hd);
+  const size_t fwd = 2 * (size_t)B * (ld + 4 * (size_t)Hd), bwd = 2 * (size_t)B * (4 + 3 * (size_t)Hd + (size_t)(M + Hd));
   return fwd > bwd ? fwd : bwd;
 }
 // forward: scratch, and this workgroup's score frames of the keys [fq, Hd] + its context columns of the values [Tm, M/4]
@@ -1078,6 +1079,7 @@ __global__ __launch_bounds__(256) void dec_persist_bwd_kernel(las_dec_persist_bw
   pu64* xcc_tab = flags + P_MEMBERS;
   pu64* xdot = reinterpret_cast<pu64*>(reinterpret_cast<char*>(p.workspace) + 64) + persist_flag_words(B);   // [2][B][4]
   pu64* xdh = xdot + 2 * (size_t)B * 4;                                                                        // [2][B][3][Hd]
+  pu64* xdf = xdh + 2 * (size_t)B * 3 * Hd;                                                                    // [2][B][W]
   if (tid == 0) { *fail = 0; *colo = 0; }
   __syncthreads();
   if (tid == 0) {
@@ -1166,20 +1168,48 @@ __global__ __launch_bounds__(256) void dec_persist_bwd_kernel(las_dec_persist_bw
       sg[0] = gp[0]; sg[1] = gp[Hd]; sg[2] = gp[2 * Hd]; sg[3] = gp[3 * Hd];
       sct = s0.c_new[(int64_t)b * s0.ldcn + (int64_t)t * p.inc_c + tid];
       scp = s0.c_prev[(int64_t)b * s0.ldcp + (int64_t)t * p.inc_c + tid];
-      if (dfeed_next) sdf = dfeed_next[(int64_t)b * W + M + tid];
     }
     float nxt_dc[PD], nxt_al = 0.f;
     if (t > 0) fetch_step(t - 1, nxt_dc, nxt_al);
     const unsigned xtag = (unsigned)(p.U - t);       // 1, 2, ...: tag of this step's granules, parity slot xtag & 1
     // ---- S1 ----
     if (active) {
+      // the feed gradient of step t+1 arrives as granules from that step's 32 product slices (tag xtag - 1): this
+      // thread's columns of the attention part, and on part 0 its unit of the h part (wave-uniform, bounded polling)
+      float fbv[PD];
+#pragma unroll
+      for (int i = 0; i < PD; ++i) fbv[i] = 0.f;
+      if (!first) {
+        const pu64* xf = xdf + ((size_t)((xtag - 1) & 1) * B + b) * W;
+        unsigned spins = 0;
+        for (;;) {
+          bool got = true;
+          pu64 gq[PD + 1];
+#pragma unroll
+          for (int i = 0; i < PD; ++i) {
+            const int m = tid + i * 256;
+            gq[i] = m < M ? pgranule_load(xf + m) : ((pu64)(xtag - 1) << 32);
+            got = got && ((unsigned)(gq[i] >> 32) == xtag - 1);
+          }
+          gq[PD] = cellw ? pgranule_load(xf + M + tid) : ((pu64)(xtag - 1) << 32);
+          got = got && ((unsigned)(gq[PD] >> 32) == xtag - 1);
+          if (__all(got)) {
+#pragma unroll
+            for (int i = 0; i < PD; ++i) fbv[i] = __uint_as_float((unsigned)gq[i]);
+            if (cellw) sdf = __uint_as_float((unsigned)gq[PD]);
+            break;
+          }
+          if (++spins > P_SPIN_LIMIT) { if (lane == 0) *fail = 1; break; }
+          __builtin_amdgcn_s_sleep(1);
+        }
+      }
 #pragma unroll
       for (int i = 0; i < PD; ++i) {
         const int m = tid + i * 256;
         if (m >= M) break;
         float v = cur_dc[i];
-        if (dfeed_next) {
-          float fb = dfeed_next[(int64_t)b * W + m];
+        if (!first) {
+          float fb = fbv[i];
           if (s0.drop_keep < 1.0f) {     // gradient through step t+1's input dropout of the attention feed
             const unsigned long long idx = ((unsigned long long)(t + 1) * B + b) * s0.feed_width + (s0.feed_width - M) + m;
             fb = las_uniform(s0.drop_seed, s0.drop_stream, idx) < s0.drop_keep ? fb / s0.drop_keep : 0.f;
@@ -1397,12 +1427,15 @@ __global__ __launch_bounds__(256) void dec_persist_bwd_kernel(las_dec_persist_bw
       for (int e = tid; e < 8 * 48; e += 256) {
         const int row = e / 48, c = e % 48, j = c / 16, col = c % 16;
         const int tile = member + 32 * j, bb = group * 8 + row;
-        if (tile < NTW && bb < B)
-          df[(int64_t)bb * W + tile * 16 + col] = red2[(0 * 16 + row) * 49 + c] + red2[(1 * 16 + row) * 49 + c] +
-                                                 red2[(2 * 16 + row) * 49 + c] + red2[(3 * 16 + row) * 49 + c];
+        if (tile < NTW && bb < B) {
+          const float v = red2[(0 * 16 + row) * 49 + c] + red2[(1 * 16 + row) * 49 + c] +
+                          red2[(2 * 16 + row) * 49 + c] + red2[(3 * 16 + row) * 49 + c];
+          if (t == 0) df[(int64_t)bb * W + tile * 16 + col] = v;        // the caller's d(initial attention, h)
+          else pgranule_store(xdf + ((size_t)(xtag & 1) * B + bb) * W + tile * 16 + col, xtag, v, local);
+        }
       }
     }
-    if (!persist_barrier(flags, member, ++epoch, local, fail)) break;
+    // (no group barrier: step t-1 polls the granules of its utterance)
 #pragma unroll
     for (int i = 0; i < PD; ++i) cur_dc[i] = nxt_dc[i];
     cur_al = nxt_al;
@@ -1612,8 +1645,8 @@ extern "C" int las_decoder_persist_supported(int Hd, int M, int K_in, int attent
   return 1;
 }
 
-extern "C" size_t las_decoder_persist_workspace_bytes(int B, int Tm, int Hd) {
-  return 64 + (persist_flag_words(B) + persist_exchange_words(B, Tm, Hd)) * sizeof(pu64);
+extern "C" size_t las_decoder_persist_workspace_bytes(int B, int Tm, int Hd, int M) {
+  return 64 + (persist_flag_words(B) + persist_exchange_words(B, Tm, Hd, M)) * sizeof(pu64);
 }
 
 extern "C" int las_decoder_persist_fwd(const las_dec_persist* p, void* stream) {
@@ -1630,7 +1663,7 @@ extern "C" int las_decoder_persist_fwd(const las_dec_persist* p, void* stream) {
               "las_decoder_persist_fwd: scheduled sampling needs wprojT, bproj, plog (and fed ids with unit step)");
   hipStream_t st = (hipStream_t)stream;
   const int groups = (s->B + 7) / 8;
-  int rc = las_check_hip(hipMemsetAsync(p->workspace, 0, las_decoder_persist_workspace_bytes(s->B, s->Tm, s->Hd), st), "memset workspace");
+  int rc = las_check_hip(hipMemsetAsync(p->workspace, 0, las_decoder_persist_workspace_bytes(s->B, s->Tm, s->Hd, s->M), st), "memset workspace");
   if (rc) return rc;
   size_t lds = persist_fwd_scratch_floats(s->Hd, s->Tm) * sizeof(float);
   LAS_REQUIRE(lds <= 64 * 1024, "las_decoder_persist_fwd: memory length %d too long for the LDS score buffer", s->Tm);
@@ -1676,7 +1709,7 @@ extern "C" int las_decoder_persist_bwd(const las_dec_persist_bwd* p, void* strea
               "las_decoder_persist_bwd: Bahdanau scores need att_v, dkeys_acc, dv_acc");
   hipStream_t st = (hipStream_t)stream;
   const int groups = (s->B + 7) / 8;
-  int rc = las_check_hip(hipMemsetAsync(p->workspace, 0, las_decoder_persist_workspace_bytes(s->B, s->Tm, s->Hd), st), "memset workspace");
+  int rc = las_check_hip(hipMemsetAsync(p->workspace, 0, las_decoder_persist_workspace_bytes(s->B, s->Tm, s->Hd, s->M), st), "memset workspace");
   if (rc) return rc;
   size_t lds = persist_bwd_scratch_floats(s->M, s->Hd, s->Tm) * sizeof(float);
   LAS_REQUIRE(lds <= 64 * 1024, "las_decoder_persist_bwd: shapes exceed the LDS budget");

@@ -310,7 +310,7 @@ class Speller:
             p.x, p.ldx, p.inc_x = hip.addr(AH), U * W, W
             p.kT, p.ldk = hip.addr(self.kcT), W
             z_all = torch.empty(U, B, 4 * Hd, dtype=f32, device=dev)
-            ws = torch.empty(lib.las_decoder_persist_workspace_bytes(B, Tm, Hd), dtype=torch.uint8, device=dev)
+            ws = torch.empty(lib.las_decoder_persist_workspace_bytes(B, Tm, Hd, M), dtype=torch.uint8, device=dev)
             ld_sc = (Tm + 31) // 32 * 32          # whole cache lines per (step, utterance) row
             sc_all = torch.empty(U, B, ld_sc, dtype=f32, device=dev)
             p.z_all, p.sc_all, p.ld_sc, p.workspace = hip.addr(z_all), hip.addr(sc_all), ld_sc, hip.addr(ws)
@@ -406,7 +406,7 @@ class Speller:
             dfeed_all = torch.empty(U, B, W, dtype=f32, device=dev)
             dot_all = torch.empty(U, B, 32, dtype=f32, device=dev)
             dhp_all = torch.empty(U, B, 4, Hd, dtype=f32, device=dev)
-            ws = torch.empty(lib.las_decoder_persist_workspace_bytes(B, Tm, Hd), dtype=torch.uint8, device=dev)
+            ws = torch.empty(lib.las_decoder_persist_workspace_bytes(B, Tm, Hd, M), dtype=torch.uint8, device=dev)
             p.dfeed_all, p.dot_all, p.dhp_all, p.workspace = hip.addr(dfeed_all), hip.addr(dot_all), hip.addr(dhp_all), hip.addr(ws)
             hip.check(lib.las_decoder_persist_bwd(C.byref(p), st))
             self._persist_ws_bwd = ws
