@@ -256,8 +256,8 @@ typedef struct las_dec_persist {
   int64_t ldx, inc_x;
   const las_bf16* kT;            /* [4Hd, K_in] bf16, row n = output column n, row stride ldk */
   int64_t ldk;
-  float* z_all;                  /* [U, B, 4Hd] fp32 scratch (every z_t keeps its own rows) */
-  float* sc_all;                 /* [U, B, ld_sc] fp32 scratch: raw attention scores (the parts of an utterance split the frames) */
+  float* z_all;                  /* unused (z_t travels through the workspace); may be NULL */
+  float* sc_all;                 /* unused (the raw scores travel through the workspace); may be NULL */
   int64_t ld_sc;                 /* >= Tm, multiple of 32 (whole cache lines per row) */
   void* workspace;
   /* scheduled sampling (utils/training_helper.py:48-87), sampling_prob > 0: after step t the kernel replaces the token
@@ -344,9 +344,9 @@ int las_decoder_step_bwd(const las_dec_step_bwd* s, void* stream);
 
 /* The backward counterpart of las_decoder_persist_fwd (softmax attentions): all U steps, last to first, in one launch,
  * replacing the U x (las_decoder_step_bwd + las_gemm_nt) loop.  `s` describes step 0 (dctx_b / dh_rec are ignored:
- * the feed gradient of step t+1 is read from dfeed_all); per-step pointers advance by the inc_* element counts.
- * dfeed_all[t] = dz_t K^T ([B, W] fp32: d attention_{t-1} in columns [0,M), d h_{t-1} in [M,W)); dfeed_all[0] is the
- * gradient into the initial state.  s.dc is updated in place to dc_{-1}. */
+ * the feed gradient dz_t K^T of step t+1 -- [B, W] fp32: d attention_{t-1} in columns [0,M), d h_{t-1} in [M,W) -- travels
+ * inside the launch through the workspace); per-step pointers advance by the inc_* element counts.  dfeed_all receives
+ * ONE row block [B, W]: step 0's, the gradient into the initial feed / state.  s.dc is updated in place to dc_{-1}. */
 typedef struct las_dec_persist_bwd {
   las_dec_step_bwd s;
   int32_t U, W;                  /* steps; W = M + Hd */
@@ -354,8 +354,8 @@ typedef struct las_dec_persist_bwd {
   const las_bf16* kc;            /* [W, 4Hd] bf16: row n = row n of the cell kernel below the token rows, stride ldk */
   int64_t ldk;
   float* dfeed_all;              /* [U, B, W] fp32 */
-  float* dot_all;                /* [U, B, 32] fp32 scratch (4 used: one cache line per row) */
-  float* dhp_all;                /* [U, B, 4, Hd] fp32 scratch */
+  float* dot_all;                /* unused (the partial dots travel through the workspace); may be NULL */
+  float* dhp_all;                /* unused (the partial dh travel through the workspace); may be NULL */
   void* workspace;               /* las_decoder_persist_workspace_bytes(B, Tm, Hd, M) */
 } las_dec_persist_bwd;
 int las_decoder_persist_bwd_supported(int Hd, int M, int W, int attention, int norm);

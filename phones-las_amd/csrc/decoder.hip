@@ -467,11 +467,14 @@ __global__ __launch_bounds__(256) void dec_step_fwd_kernel(las_dec_step s) {
 //   G: columns [member*4Hd/32, ...) of z_t = [attention_{t-1}, h_{t-1}] K for the group's 8 utterances (its slice of
 //      K stays in registers as MFMA B fragments for all steps; M = 16 rows, 8 used);
 //   S: the step kernel's body for utterance member/4, context-column part member%4.
-// Between the roles the 32 members meet at a flag barrier in global memory (each writes its own epoch word, wave 0
-// polls all 32); the exchanged tensors (z_t, c_t, the next operand row) are written once and read later at distinct
+// Once per step (after S) the 32 members meet at a flag barrier in global memory (each writes its own epoch word,
+// wave 0 polls all 32): what crosses it (c_t, the next operand row) is written once and read later at distinct
 // addresses, so no stale L1 line can exist, and with the group on one XCD its L2 is the coherence point: plain
 // stores, no fences.  If the members find themselves on different XCDs (XCC_ID handshake) they add agent-scope
-// release/acquire fences around the barrier instead: slower, same results.  Every spin is bounded (status word).
+// release/acquire fences around the barrier instead: slower, same results.  Everything else that travels inside a
+// step -- z_t from the 32 product slices to the utterance's workgroups, the raw scores among the four workgroups of an
+// utterance -- goes as 8-byte {step tag, fp32} granules that the consumer polls (two parity slots in the workspace):
+// the data is its own flag, one L2 round trip instead of store + barrier + load.  Every spin is bounded (status word).
 // ------------------------------------------------------------------------------------------------
 constexpr unsigned P_SPIN_LIMIT = 1u << 22;
 constexpr int P_MEMBERS = 32;
@@ -1655,8 +1658,7 @@ extern "C" int las_decoder_persist_fwd(const las_dec_persist* p, void* stream) {
   LAS_REQUIRE(las_decoder_persist_supported(s->Hd, s->M, p->K_in, s->attention, s->norm),
               "las_decoder_persist_fwd: configuration not supported (Hd=%d M=%d K_in=%d attention=%d norm=%d)", s->Hd, s->M, p->K_in,
               s->attention, s->norm);
-  LAS_REQUIRE(p->x && p->kT && p->z_all && p->sc_all && p->workspace && p->ld_sc >= s->Tm && p->ld_sc % 32 == 0 &&
-                  ((uintptr_t)p->sc_all % 128 == 0) && ((uintptr_t)p->z_all % 128 == 0) && ((uintptr_t)p->x % 128 == 0),
+  LAS_REQUIRE(p->x && p->kT && p->workspace && ((uintptr_t)p->workspace % 128 == 0) && ((uintptr_t)p->x % 128 == 0),
               "las_decoder_persist_fwd: null argument, or exchanged rows that are not whole 128-byte lines");
   LAS_REQUIRE(p->sampling_prob <= 0.f || (p->wprojT && p->bproj && p->plog && p->V > 0 && p->Vp >= p->V &&
                                           p->Vp <= 1024 && s->M % 32 == 0 && p->inc_tok == 1),
@@ -1701,7 +1703,7 @@ extern "C" int las_decoder_persist_bwd(const las_dec_persist_bwd* p, void* strea
   LAS_REQUIRE(las_decoder_persist_bwd_supported(s->Hd, s->M, p->W, s->attention, s->norm),
               "las_decoder_persist_bwd: configuration not supported (Hd=%d M=%d W=%d attention=%d norm=%d)", s->Hd, s->M, p->W,
               s->attention, s->norm);
-  LAS_REQUIRE(p->kc && p->dfeed_all && p->dot_all && p->dhp_all && p->workspace && s->dctx_a && s->dc && s->dz && s->ds_out &&
+  LAS_REQUIRE(p->kc && p->dfeed_all && p->workspace && ((uintptr_t)p->workspace % 128 == 0) && s->dctx_a && s->dc && s->dz && s->ds_out &&
                   s->align && s->gates && s->c_new && s->c_prev && s->keys && s->values && s->mem_len,
               "las_decoder_persist_bwd: null argument");
   LAS_REQUIRE(s->attention == LAS_ATT_LUONG || (s->pq && s->wq_t), "las_decoder_persist_bwd: this attention needs pq and wq_t");

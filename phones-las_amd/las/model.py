@@ -309,11 +309,8 @@ class Speller:
             p.inc_align, p.inc_pq, p.inc_ctx, p.inc_ctx2 = Tmp, Hd, M, W
             p.x, p.ldx, p.inc_x = hip.addr(AH), U * W, W
             p.kT, p.ldk = hip.addr(self.kcT), W
-            z_all = torch.empty(U, B, 4 * Hd, dtype=f32, device=dev)
             ws = torch.empty(lib.las_decoder_persist_workspace_bytes(B, Tm, Hd, M), dtype=torch.uint8, device=dev)
-            ld_sc = (Tm + 31) // 32 * 32          # whole cache lines per (step, utterance) row
-            sc_all = torch.empty(U, B, ld_sc, dtype=f32, device=dev)
-            p.z_all, p.sc_all, p.ld_sc, p.workspace = hip.addr(z_all), hip.addr(sc_all), ld_sc, hip.addr(ws)
+            p.workspace = hip.addr(ws)       # status, group flags and the exchange granules (z_t, raw scores)
             if sampling > 0.0:           # logits and the sampled feed are produced inside the launch
                 plog = torch.empty(U, B, 4, Vp, dtype=f32, device=dev)
                 p.sampling_prob, p.seed = sampling, seed
@@ -403,11 +400,9 @@ class Speller:
             p.inc_a, p.inc_save, p.inc_gates, p.inc_c, p.inc_align, p.inc_dz, p.inc_ds = M, M, 4 * Hd, Hd, Tmp, 4 * Hd, Tmp
             p.inc_pq = Hd
             p.kc, p.ldk = hip.addr(self.kc), 4 * Hd
-            dfeed_all = torch.empty(U, B, W, dtype=f32, device=dev)
-            dot_all = torch.empty(U, B, 32, dtype=f32, device=dev)
-            dhp_all = torch.empty(U, B, 4, Hd, dtype=f32, device=dev)
+            dfeed_all = torch.empty(1, B, W, dtype=f32, device=dev)      # only step 0's row leaves the launch: d(initial feed)
             ws = torch.empty(lib.las_decoder_persist_workspace_bytes(B, Tm, Hd, M), dtype=torch.uint8, device=dev)
-            p.dfeed_all, p.dot_all, p.dhp_all, p.workspace = hip.addr(dfeed_all), hip.addr(dot_all), hip.addr(dhp_all), hip.addr(ws)
+            p.dfeed_all, p.workspace = hip.addr(dfeed_all), hip.addr(ws)
             hip.check(lib.las_decoder_persist_bwd(C.byref(p), st))
             self._persist_ws_bwd = ws
             dfeed = dfeed_all[0]

@@ -490,20 +490,30 @@ class LasModel:
         x, src_len = features['encoder_inputs'], features['source_sequence_length']
         (mem, mem_len), state = self.listener.forward(x, src_len, PREDICT)
         max_it = int(round(int(mem_len.max().item()) * self.params.decoder.decoding_length_factor))
-        emb_c = torch.cat([s.c for s in state], 1) if isinstance(state[0], tuple) else state.c
-        emb_h = torch.cat([s.h for s in state], 1) if isinstance(state[0], tuple) else state.h
+        # model_helper.py:259-268: concat of the directions' states; a bare LSTMStateTuple as it is; anything else
+        # (the per-layer tuples of the stacked listener) leaves 'embedding' out of the predictions
+        emb = None
+        if hasattr(state, 'c') and hasattr(state, 'h') and torch.is_tensor(state.c):
+            emb = torch.stack([state.c, state.h], 1)
+        elif all(hasattr(s, 'c') and torch.is_tensor(s.c) for s in state):
+            emb = torch.stack([torch.cat([s.c for s in state], 1), torch.cat([s.h for s in state], 1)], 1)
         beam_width = int(getattr(self.params.decoder, 'beam_width', 0) or 0)
         if beam_width > 0:              # model_helper.py:231-236: predicted_ids [B,T,K] instead of logits
             ids, lens, lps = self._beam_speller().forward_beam(mem, mem_len, state, max_it, beam_width,
                                                                partial_targets=features.get('partial_targets'))
-            return {'encoder_out': mem, 'source_length': mem_len, 'embedding': torch.stack([emb_c, emb_h], 1),
-                    'sample_ids': ids, 'beam_lengths': lens, 'beam_log_probs': lps}
+            out = {'encoder_out': mem, 'source_length': mem_len, 'sample_ids': ids, 'beam_lengths': lens, 'beam_log_probs': lps}
+            if emb is not None:
+                out['embedding'] = emb
+            return out
         logits, ids, final_len, align = self.speller.forward_greedy(mem, mem_len, state, max_it)
-        return {
-            'encoder_out': mem, 'source_length': mem_len, 'embedding': torch.stack([emb_c, emb_h], 1),
+        out = {
+            'encoder_out': mem, 'source_length': mem_len,
             'sample_ids': ids, 'alignment': align, 'probs': torch.softmax(logits, -1), 'logits': logits,
             'final_sequence_length': final_len,
         }
+        if emb is not None:
+            out['embedding'] = emb
+        return out
 
     def check_device_status(self):
         """The persistent kernels (recurrent layers, one-launch decoder) bound every inter-workgroup wait and flag a

@@ -36,8 +36,19 @@ for name in os.environ.get('CONFIGS', 'cli,h256,stacked').split(','):
         if ref is None:
             ref = (logits, g)
             continue
-        worst_l = max(worst_l, float((logits - ref[0]).abs().max() / ref[0].abs().max()))
-        worst_g = max(worst_g, float((g - ref[1]).abs().max() / ref[1].abs().max()))
+        dl = float((logits - ref[0]).abs().max() / ref[0].abs().max())
+        dg = float((g - ref[1]).abs().max() / ref[1].abs().max())
+        if max(dl, dg) > float(os.environ.get('REPORT', '1e-4')):          # name the tensors that moved
+            names = []
+            for (nm, shape, _), o in zip(model.vars.table, model.vars.offsets):
+                n = 1
+                for d_ in shape: n *= d_
+                a, b_ = g[o:o + n], ref[1][o:o + n]
+                dev = float((a - b_).abs().max() / (b_.abs().max() + 1e-30))
+                if dev > 1e-4: names.append('%s %.1e' % (nm.split('/', 1)[-1], dev))
+            print('  rep %d: logits dev %.1e grad dev %.1e: %s' % (it, dl, dg, '; '.join(names[:12])), flush=True)
+        worst_l = max(worst_l, dl)
+        worst_g = max(worst_g, dg)
         # scribble over freed blocks so that reads of uninitialised memory show up
         junk = torch.full((1 << 22,), float('nan'), device='cuda'); del junk
     model.check_device_status()
