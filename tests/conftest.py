@@ -21,3 +21,12 @@ def pytest_collection_modifyitems(config, items):
     for it in items:
         if 'gpu' in it.keywords:
             it.add_marker(skip)
+
+
+def pytest_sessionstart(session):
+    # LAS_NANFILL=1: torch.empty() hands out NaN / max-int filled memory, so a kernel that reads what nobody wrote
+    # turns results into NaN instead of into "plausible" numbers (debugging aid for allocator-dependent flakiness)
+    if os.environ.get('LAS_NANFILL'):
+        import torch
+        torch.use_deterministic_algorithms(True, warn_only=True)
+        torch.utils.deterministic.fill_uninitialized_memory = True
