@@ -175,7 +175,7 @@ __device__ void dec_step_fwd_body(const las_dec_step& s, const int b, const int 
           for (int g = 0; g < 4; ++g) z[g] = __uint_as_float((unsigned)gq[g]);
           break;
         }
-        if (++spins > (1u << 22)) { *ph->fail = 1; z[0] = z[1] = z[2] = z[3] = 0.f; break; }
+        if (++spins > (1u << 22) || *ph->fail) { *ph->fail = 1; z[0] = z[1] = z[2] = z[3] = 0.f; break; }
         __builtin_amdgcn_s_sleep(1);
       }
     } else {
@@ -310,7 +310,7 @@ __device__ void dec_step_fwd_body(const las_dec_step& s, const int b, const int 
             if (t < Tm) sc[t] = __uint_as_float((unsigned)gq);
             break;
           }
-          if (++spins > (1u << 22)) { *ph->fail = 1; break; }
+          if (++spins > (1u << 22) || *ph->fail) { *ph->fail = 1; break; }
           __builtin_amdgcn_s_sleep(1);
         }
       }
@@ -695,8 +695,7 @@ __global__ __launch_bounds__(256) void dec_persist_fwd_kernel(las_dec_persist p)
       pu64* xz = xzb + ((size_t)(xtag & 1) * B + bs) * 4 * Hd;
       PersistHook hook{xsc, xz, xtag, flags, member, &epoch, local, fail, lkeys, lvals,
                        pre_ok, tok_pre, {tok4[0], tok4[1], tok4[2], tok4[3]}, {bias4[0], bias4[1], bias4[2], bias4[3]}, cprev_pre};
-      dec_step_fwd_body<RES>(st, bs, part, 4, sm, &hook);
-      if (*fail) break;
+      dec_step_fwd_body<RES>(st, bs, part, 4, sm, &hook);     // (a timed-out poll leaves through the barrier below)
     }
     if constexpr (SAMPLING) {
       // ---- scheduled sampling (utils/training_helper.py:48-87): logits_t = context_t W_proj + b from the four parts'
@@ -1202,7 +1201,7 @@ __global__ __launch_bounds__(256) void dec_persist_bwd_kernel(las_dec_persist_bw
             if (cellw) sdf = __uint_as_float((unsigned)gq[PD]);
             break;
           }
-          if (++spins > P_SPIN_LIMIT) { if (lane == 0) *fail = 1; break; }
+          if (++spins > P_SPIN_LIMIT || *fail) { if (lane == 0) *fail = 1; break; }
           __builtin_amdgcn_s_sleep(1);
         }
       }
@@ -1274,7 +1273,7 @@ __global__ __launch_bounds__(256) void dec_persist_bwd_kernel(las_dec_persist_bw
         for (;;) {
           const pu64 gq = lane < 4 ? pgranule_load(xd + lane) : ((pu64)xtag << 32);
           if (__all((unsigned)(gq >> 32) == xtag)) { v = __uint_as_float((unsigned)gq); break; }
-          if (++spins > P_SPIN_LIMIT) { if (lane == 0) *fail = 1; break; }
+          if (++spins > P_SPIN_LIMIT || *fail) { if (lane == 0) *fail = 1; break; }
           __builtin_amdgcn_s_sleep(1);
         }
         const float d0 = __shfl(v, 0, 64), d1 = __shfl(v, 1, 64), d2 = __shfl(v, 2, 64), d3 = __shfl(v, 3, 64);
@@ -1359,7 +1358,7 @@ __global__ __launch_bounds__(256) void dec_persist_bwd_kernel(las_dec_persist_bw
             for (int q = 0; q < 3; ++q) tot += __uint_as_float((unsigned)g3[q]);
             break;
           }
-          if (++spins > P_SPIN_LIMIT) { if (lane == 0) *fail = 1; break; }
+          if (++spins > P_SPIN_LIMIT || *fail) { if (lane == 0) *fail = 1; break; }
           __builtin_amdgcn_s_sleep(1);
         }
         __syncthreads();                            // dhs (the per-phase partials) has been read by everybody
