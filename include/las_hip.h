@@ -243,8 +243,9 @@ int las_decoder_step_fwd(const las_dec_step* s, int parts, void* stream);
 
 /* All U steps of the fused decoder (las_dec_mode FUSED, softmax attentions) in ONE launch: a persistent kernel whose
  * workgroups alternate between the per-step product z_t = x_t K (x_t = row t of the operand buffer: [attention_{t-1},
- * h_{t-1}], written by step t-1 through h_out2 / ctx_out2) and the step itself, meeting at flag barriers; keys and
- * values stay L2-resident for the whole sequence.  `s` describes step 0; the inc_* fields are the element increments of
+ * h_{t-1}], written by step t-1 through h_out2 / ctx_out2) and the step itself; inside a step they hand results to
+ * each other as tagged 8-byte granules through the workspace and meet at one flag barrier; the keys / values a
+ * workgroup needs stay in its LDS for the whole sequence when they fit (else they are read from L2 every step).  `s` describes step 0; the inc_* fields are the element increments of
  * its per-step pointers (h_out2 / ctx_out2 are not written by the last step).  Replaces the U x (las_gemm_nt +
  * las_decoder_step_fwd) loop of las/model.py:276-296 when scheduled sampling is off.  The call zeroes `workspace`
  * (las_decoder_persist_workspace_bytes); its first uint32 is non-zero afterwards if a bounded wait timed out. */

@@ -294,7 +294,7 @@ class Speller:
         persist = (B <= 256 and Vp <= 1024 and os.environ.get('LAS_DEC_PERSIST', '1') != '0' and      # B: co-residency
                    lib.las_decoder_persist_supported(Hd, M, W, self.att, hip.NORM_SOFTMAX) == 1)
         if persist:
-            # all U steps in one persistent launch (keys/values stay L2-resident; see las_dec_persist in las_hip.h)
+            # all U steps in one persistent launch (see las_dec_persist in las_hip.h)
             p = hip.DecPersist()
             p.s = self._step_struct(
                 B, Tm, 0, hip.addr(fed), ts, hip.addr(cs), (U + 1) * Hd, hip.addr(gates), U * 4 * Hd,
