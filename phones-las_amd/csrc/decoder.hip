@@ -502,7 +502,7 @@ __host__ __device__ inline size_t persist_fwd_resident_bytes(int M, int Hd, int 
   return ((size_t)((Tm + 3) / 4) * Hd + (size_t)Tm * persist_cols_per(M)) * 2;
 }
 __host__ __device__ inline bool persist_fwd_resident(int M, int Hd, int Tm) {
-  return persist_fwd_scratch_floats(Hd, Tm) * 4 + persist_fwd_resident_bytes(M, Hd, Tm) <= 160 * 1024;
+  return persist_fwd_scratch_floats(Hd, Tm) * 4 + persist_fwd_resident_bytes(M, Hd, Tm) <= 158 * 1024;   // (2 KiB of margin below the CU's 160 KiB)
 }
 __host__ __device__ inline size_t persist_bwd_scratch_floats(int M, int Hd, int Tm) {
   return ((size_t)M + 2 * (size_t)Tm + 2048 + 16 + Hd + 4 * 16 * 49 + 8 + 3) & ~(size_t)3;
@@ -511,7 +511,7 @@ __host__ __device__ inline size_t persist_bwd_resident_bytes(int M, int Hd, int 
   return (size_t)((Tm + 3) / 4) * (size_t)(M + Hd) * 2;
 }
 __host__ __device__ inline bool persist_bwd_resident(int M, int Hd, int Tm) {
-  return persist_bwd_scratch_floats(M, Hd, Tm) * 4 + persist_bwd_resident_bytes(M, Hd, Tm) <= 160 * 1024;
+  return persist_bwd_scratch_floats(M, Hd, Tm) * 4 + persist_bwd_resident_bytes(M, Hd, Tm) <= 158 * 1024;
 }
 
 __device__ bool persist_barrier(pu64* flags, int member, unsigned epoch, bool local, int* lds_fail) {
