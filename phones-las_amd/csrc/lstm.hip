@@ -846,9 +846,16 @@ int slice_rows(int B, int H, int ndir, bool bwd) {
   const int forced = e ? atoi(e) : 0;
   if (H > 256) return 16;               // the 512-unit kernels (K split, row split) assume full tiles
   if (forced == 16 || forced == 8 || forced == 4) return forced;
-  // every chain workgroup and every companion should find a CU of its own (256 on MI355X); the backward leaves at
-  // least 96 CUs to the weight-gradient products that run beside it
-  const int budget = bwd ? 160 : 256;
+  // every chain workgroup and every companion should find a CU of its own (256 on MI355X; fewer in a partitioned
+  // mode); the backward leaves three eighths of them to the weight-gradient products that run beside it
+  static int cus = 0;
+  if (cus == 0) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+              ? prop.multiProcessorCount : 256;
+  }
+  const int budget = bwd ? cus * 5 / 8 : cus;
   for (int rows = 4; rows <= 8; rows *= 2) {
     const CoopGeom g = geom(B, H, ndir, bwd, rows);
     if (g.blocks + g.companions <= budget) return rows;
