@@ -146,3 +146,23 @@ def test_oracle_beam_from_partial_targets_continues_the_teacher_forced_state():
             if not done[i]:
                 assert int(p1[i, t, 0]) == int(ids[i]), (i, t)
         done |= ids == ohp.decoder.eos_id
+
+
+def test_exchange_buckets_partition_the_flat_buffer():
+    """Variables.split_buckets (the two exchange buckets of the overlapped data-parallel step): contiguous pieces of the
+    flat buffers in the order the backward pass completes them, boundaries relative to each piece, 16-byte aligned."""
+    from phones_las_amd import model_helper as mh
+    table = [('a', (5, 3), 'zeros'), ('b', (7,), 'zeros'), ('c', (4, 4), 'zeros'), ('d', (1,), 'zeros'), ('e', (9, 2), 'zeros')]
+    v = mh.Variables(table, device='cpu')
+    assert len(v.buckets) == 1 and v.buckets[0]['begin'] == 0 and v.buckets[0]['end'] == v.total
+    b0, b1 = v.split_buckets(3)
+    assert (b0['lo'], b0['hi'], b1['lo'], b1['hi']) == (3, 5, 0, 3)
+    assert b1['begin'] == 0 and b1['end'] == b0['begin'] and b0['end'] == v.total
+    assert b0['begin'] % 4 == 0 and (b0['slot'], b1['slot']) == (0, 1)
+    assert b0['seg'].tolist() == [0, v.offsets[4] - v.offsets[3], v.total - v.offsets[3]]
+    assert b1['seg'].tolist() == [0, v.offsets[1], v.offsets[2], v.offsets[3]]
+    # the views of the tensors tile the pieces exactly
+    assert v.grads['d'].data_ptr() == v.grad.data_ptr() + 4 * v.offsets[3]
+    # a split at either end keeps the single bucket
+    w = mh.Variables(table, device='cpu')
+    assert len(w.split_buckets(0)) == 1 and len(w.split_buckets(5)) == 1
