@@ -910,11 +910,17 @@ int launch_bwd(const float* gates, const float* cbuf, const float* dy, const flo
   u64* exch = reinterpret_cast<u64*>(reinterpret_cast<char*>(ws) + 64);
   const int pf = g.G > 1 ? prefetch_mode() : 0;
   // The weight-gradient GEMMs of the layer above run beside this kernel on the second stream.  Asking for LDS the
-  // kernel does not use keeps their workgroups (64 KiB of LDS each) off the CUs of the chain's workgroups.
+  // kernel does not use keeps their workgroups (32 KiB of LDS each) off the CUs of the chain's workgroups: measured
+  // 7.96 ms per metric-M step with them kept off, 8.5 ms when one fits beside a chain workgroup.  The request is what
+  // the CU's 160 KiB leave after the kernel's own static LDS (dz tile 2 x 16 x (4*HS + 8) bf16, DMA scratch), minus a
+  // margin smaller than any GEMM workgroup's need.
   static int hog_kb = -1;
   if (hog_kb < 0) {
     const char* e = getenv("LAS_LSTM_BWD_LDS_KB");
-    hog_kb = e ? atoi(e) : 120;
+    constexpr int HS_ = H / coop_members(H);
+    constexpr int static_kb = (2 * 16 * (4 * HS_ + 8) * 2 + 1024 + 1023) / 1024 + 1;
+    hog_kb = e ? atoi(e) : 160 - static_kb - 6;
+    if (hog_kb > 160 - static_kb - 2) hog_kb = 160 - static_kb - 2;
     if (hog_kb > 0) {
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&lstm_bwd_kernel<H, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, hog_kb * 1024);
       if constexpr (H <= 256)
