@@ -41,3 +41,16 @@ for li, (name, T, D) in enumerate((('layer0', 800, 40), ('layer1', 800, 512), ('
         e1.record(); torch.cuda.synchronize()
         ts.append(e0.elapsed_time(e1))
     print('%s NT M=%d N=%d K=%d: %.1f us  %.0f TFLOP/s' % (name, BT, 8 * H, Dk, min(ts) * 1e3, 2.0 * BT * 8 * H * Dk / min(ts) / 1e9))
+
+for name, M, N, K in (('dX layer2->1', 25600, 1024, 2048), ('dX layer1->0', 51200, 512, 2048), ('proj layer1 fp32', 51200, 2048, 512)):
+    a = (torch.randn(M, K, device='cuda') * 0.1).to(torch.bfloat16)
+    b = (torch.randn(N, K, device='cuda') * 0.1).to(torch.bfloat16)
+    out = torch.empty(M, N, device='cuda')
+    ts = []
+    for it in range(6):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        hip.gemm_nt(a, b, out, M, N, K, lda=K, ldb=K, ldc=N)
+        e1.record(); torch.cuda.synchronize()
+        ts.append(e0.elapsed_time(e1))
+    print('%s NT M=%d N=%d K=%d fp32 out: %.1f us  %.0f TFLOP/s' % (name, M, N, K, min(ts) * 1e3, 2.0 * M * N * K / min(ts) / 1e9))
