@@ -282,6 +282,9 @@ typedef struct las_dec_persist {
 } las_dec_persist;
 int las_decoder_persist_supported(int Hd, int M, int K_in, int attention, int norm);   /* 1 if the shapes fit */
 size_t las_decoder_persist_workspace_bytes(int B, int Tm, int Hd, int M);   /* status, group flags, exchange granules */
+/* Largest batch of one persistent launch: all its workgroups (32 per 8 utterances, one per CU) must be resident at once:
+ * 64 on a 256-CU MI355X.  Larger batches take the per-step launches (or several launches over slices of the batch). */
+int las_decoder_persist_max_batch(void);
 int las_decoder_persist_fwd(const las_dec_persist* p, void* stream);
 
 /* Backward of one decoder step.  d(context) = dctx_a + dctx_b; the kernel

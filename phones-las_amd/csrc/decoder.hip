@@ -1647,6 +1647,21 @@ extern "C" int las_decoder_persist_supported(int Hd, int M, int K_in, int attent
   return 1;
 }
 
+// Every workgroup of a persistent launch needs a CU of its own (its registers and LDS fill one) and all of them must be
+// resident at once: groups of 8 utterances x 32 workgroups, the group stride rounded up to 8 -> at most 8 utterances per
+// 32 CUs (64 on a 256-CU MI355X).
+static int persist_max_batch() {
+  static int cus = 0;
+  if (cus == 0) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+              ? prop.multiProcessorCount : 256;
+  }
+  return (cus / (8 * P_MEMBERS)) * 8 * 8;
+}
+extern "C" int las_decoder_persist_max_batch(void) { return persist_max_batch(); }
+
 extern "C" size_t las_decoder_persist_workspace_bytes(int B, int Tm, int Hd, int M) {
   return 64 + (persist_flag_words(B) + persist_exchange_words(B, Tm, Hd, M)) * sizeof(pu64);
 }
@@ -1654,6 +1669,7 @@ extern "C" size_t las_decoder_persist_workspace_bytes(int B, int Tm, int Hd, int
 extern "C" int las_decoder_persist_fwd(const las_dec_persist* p, void* stream) {
   const las_dec_step* s = &p->s;
   LAS_REQUIRE(s->B > 0 && p->U > 0 && s->mode == LAS_DEC_FUSED, "las_decoder_persist_fwd: bad shape / mode");
+  LAS_REQUIRE(s->B <= persist_max_batch(), "las_decoder_persist_fwd: %d utterances need more co-resident workgroups than the device has CUs (at most %d per launch)", s->B, persist_max_batch());
   LAS_REQUIRE(las_decoder_persist_supported(s->Hd, s->M, p->K_in, s->attention, s->norm),
               "las_decoder_persist_fwd: configuration not supported (Hd=%d M=%d K_in=%d attention=%d norm=%d)", s->Hd, s->M, p->K_in,
               s->attention, s->norm);
@@ -1699,6 +1715,7 @@ extern "C" int las_decoder_persist_bwd_supported(int Hd, int M, int W, int atten
 extern "C" int las_decoder_persist_bwd(const las_dec_persist_bwd* p, void* stream) {
   const las_dec_step_bwd* s = &p->s;
   LAS_REQUIRE(s->B > 0 && p->U > 0, "las_decoder_persist_bwd: bad shape");
+  LAS_REQUIRE(s->B <= persist_max_batch(), "las_decoder_persist_bwd: %d utterances need more co-resident workgroups than the device has CUs (at most %d per launch)", s->B, persist_max_batch());
   LAS_REQUIRE(las_decoder_persist_bwd_supported(s->Hd, s->M, p->W, s->attention, s->norm),
               "las_decoder_persist_bwd: configuration not supported (Hd=%d M=%d W=%d attention=%d norm=%d)", s->Hd, s->M, p->W,
               s->attention, s->norm);

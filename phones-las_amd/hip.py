@@ -58,6 +58,7 @@ _SIGS = {
     'las_gemm_tn_lstm': ([_vp, _i64, C.c_int, _vp, _i64, C.c_int, C.c_int, C.c_int, _vp, _i64, _vp, _vp, C.c_int, C.c_int, _vp, _vp], C.c_int),
     'las_decoder_persist_supported': ([C.c_int] * 5, C.c_int),
     'las_decoder_persist_workspace_bytes': ([C.c_int, C.c_int, C.c_int, C.c_int], C.c_size_t),
+    'las_decoder_persist_max_batch': ([], C.c_int),
     'las_decoder_persist_fwd': ([_vp, _vp], C.c_int),
     'las_decoder_persist_bwd_supported': ([C.c_int] * 5, C.c_int),
     'las_decoder_persist_bwd': ([_vp, _vp], C.c_int),

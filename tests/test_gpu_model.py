@@ -628,6 +628,32 @@ def test_persistent_decoder_edge_shapes_match_per_step_path(B, T, U, src_len, tg
         assert relerr(outs['1'][1][name], outs['0'][1][name].cpu()) < 2e-3, name
 
 
+def test_batches_beyond_the_co_resident_limit_take_the_per_step_decoder():
+    """A persistent decoder launch needs all its workgroups resident at once (32 per 8 utterances, one per CU: 64
+    utterances on 256 CUs, las_decoder_persist_max_batch).  A larger batch must not be sent there (it would wait for
+    workgroups that can never be scheduled): it runs on the per-step launches and still matches the oracle."""
+    from phones_las_amd import hip
+    limit = hip.lib().las_decoder_persist_max_batch()
+    assert limit >= 8 and limit % 8 == 0
+    O, ohp, op, model = _models('luong', H=128, F=13, L=2)
+    B = limit + 8
+    src_len = [12 - (i % 5) for i in range(B)]
+    tgt_len = [6 - (i % 4) for i in range(B)]
+    batch = make_batch(B=B, src_len=src_len, tgt_len=tgt_len)
+    feats, labels = to_device(batch)
+    model.vars.grad.zero_()
+    loss, logits, dlogits = model.forward_train(feats, labels)
+    model.backward(dlogits)
+    torch.cuda.synchronize()
+    model.check_device_status()
+    assert getattr(model.speller, '_persist_ws', None) is None and getattr(model.speller, '_persist_ws_bwd', None) is None
+    out = O.train_step(ohp, op, None, None, 1, batch, mxu='bf16')
+    V = ohp.decoder.target_vocab_size
+    for b in (0, B // 2, B - 1):
+        assert relerr(logits[b, :tgt_len[b], :V], out['aux']['logits'][b, :tgt_len[b]]) < 2e-2
+    assert abs(float(loss) - float(out['aux']['ce'].detach())) < 2e-2 * abs(float(out['aux']['ce'].detach()))
+
+
 def test_training_with_the_persistent_kernels_learns_and_reports_no_timeout():
     """End to end on the kernels the benchmark runs: cooperative recurrent kernels with companions (256 units) and the
     one-launch decoder (256 units, dropout + scheduled sampling on): 40 optimiser steps on one ragged batch must bring
