@@ -19,7 +19,7 @@
 // every launch, two parity slots so a fast member cannot overwrite what a slow one still reads.  Loads are
 // agent-scope relaxed atomics (L1-bypassing); stores are write-through agent-scope atomics, or plain stores
 // once the members have established that they share an XCD (then its L2 is the coherence point).
-// Results never depend on workgroup placement; blockIdx = group + 8k*member only makes the members of a
+// Results never depend on workgroup placement; blocks in chunks of 8 groups (block = chunk*8G + member*8 + group%8) only make the members of a
 // group share an XCD under round-robin dispatch (speed).  Every spin is bounded: on timeout the kernel sets
 // a status word and returns.  Each group has a PREFETCH COMPANION workgroup per four members on another CU of the
 // same XCD that pulls their HBM operands into the shared L2 a few steps ahead.
@@ -143,8 +143,13 @@ __global__ __launch_bounds__(256) void lstm_fwd_kernel(float* __restrict__ xproj
   constexpr int CPG = group_companions(H);
   const bool companion = (int)blockIdx.x >= nblk;
   const int cblk = companion ? blockIdx.x - nblk : blockIdx.x;
-  const int group = cblk % gstride, member = companion ? 0 : cblk / gstride;
-  const int cm = companion ? cblk / gstride : 0;       // which quarter (1/CPG) of the direction's columns a companion serves
+  // Blocks are laid out in chunks of 8 groups: block = chunk * 8 * G + member * 8 + group % 8.  The members of a group are
+  // 8 blocks apart (one XCD under round-robin dispatch), and the dispatcher, which hands out blocks in order, completes
+  // the groups of one chunk before it starts the next: when there are more workgroups than the device can hold at once,
+  // the resident groups are whole and the others wait their turn (a member-major order would leave every group partial).
+  const int per = 8 * (companion ? CPG : G), chunk = cblk / per, within = cblk % per;
+  const int group = chunk * 8 + (within & 7), member = companion ? 0 : within >> 3;
+  const int cm = companion ? within >> 3 : 0;          // which quarter (1/CPG) of the direction's columns a companion serves
   if (group >= ngroups) return;
   const int nslices = ngroups / ndir;
   const int slice = group % nslices, dir = group / nslices;
@@ -153,7 +158,7 @@ __global__ __launch_bounds__(256) void lstm_fwd_kernel(float* __restrict__ xproj
   const int64_t yrow = (int64_t)ndir * H;
   const int64_t par_stride = (int64_t)ngroups * G * NGRAN;     // granules per parity slot
   u64* ex_group = exch + (int64_t)group * G * NGRAN;           // + parity*par_stride + member*NGRAN
-  u64* done_word = exch + 2 * par_stride + (int64_t)ngroups * G + (companion ? group : cblk);   // companions watch member 0's
+  u64* done_word = exch + 2 * par_stride + (int64_t)ngroups * G + (int64_t)group * G + member;   // companions watch member 0's
 
   int len[RL], bidx[RL];
   int smax = 0, smin = 0x7fffffff;
@@ -485,8 +490,9 @@ __global__ __launch_bounds__(256) void lstm_bwd_kernel(const float* __restrict__
   constexpr int CPG = group_companions(H);
   const bool companion = (int)blockIdx.x >= nblk;                // CPG per group (see lstm_fwd_kernel)
   const int cblk = companion ? blockIdx.x - nblk : blockIdx.x;
-  const int group = cblk % gstride, member = companion ? 0 : cblk / gstride;
-  const int cm = companion ? cblk / gstride : 0;
+  const int per = 8 * (companion ? CPG : G), chunk = cblk / per, within = cblk % per;     // chunks of 8 groups (lstm_fwd_kernel)
+  const int group = chunk * 8 + (within & 7), member = companion ? 0 : within >> 3;
+  const int cm = companion ? within >> 3 : 0;
   if (group >= ngroups) return;
   const int nslices = ngroups / ndir;
   const int slice = group % nslices, dir = group / nslices;
@@ -496,7 +502,7 @@ __global__ __launch_bounds__(256) void lstm_bwd_kernel(const float* __restrict__
   const int64_t grp_gran = (int64_t)G * G * PAIR;               // granules of one group in one parity slot
   const int64_t par_stride = (int64_t)ngroups * grp_gran;
   u64* ex_group = exch + (int64_t)group * grp_gran;             // + parity*par_stride + (dest*G + sender)*PAIR + ...
-  u64* done_word = exch + 2 * par_stride + (int64_t)ngroups * G + (companion ? group : cblk);
+  u64* done_word = exch + 2 * par_stride + (int64_t)ngroups * G + (int64_t)group * G + member;
 
   const int blk = SPLIT ? (wave & 1) : wave * UBW;              // first unit block of this wave
   const int hh = SPLIT ? (wave >> 1) : 0;                       // which row pair of every quad (SPLIT)

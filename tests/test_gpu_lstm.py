@@ -39,6 +39,7 @@ def _relerr(got, ref):
     (21, 40, 32, 256, [40, 3, 17, 40, 1, 25, 8, 33, 12, 40, 5, 29, 2, 38, 9, 21, 40, 7, 31, 15, 36]),
     (19, 14, 24, 512, [14, 3, 9, 14, 1, 7, 12, 5, 14, 2, 11, 6, 13, 4, 10, 8, 14, 1, 9]),
     (140, 6, 16, 256, [6 - (i * 7) % 6 for i in range(140)]),      # the policy's own choice here: 8-row slices forward, 16 backward
+    (600, 5, 16, 256, [5 - (i * 3) % 5 for i in range(600)]),      # 76 chains x 4 workgroups (+ companions): more than the device holds at once
 ])
 @pytest.mark.parametrize('rows', [0, 8, 16])
 def test_bilstm_forward_backward_vs_oracle(B, T, D, H, lengths, rows, monkeypatch):
