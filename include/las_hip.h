@@ -282,8 +282,9 @@ typedef struct las_dec_persist {
 } las_dec_persist;
 int las_decoder_persist_supported(int Hd, int M, int K_in, int attention, int norm);   /* 1 if the shapes fit */
 size_t las_decoder_persist_workspace_bytes(int B, int Tm, int Hd, int M);   /* status, group flags, exchange granules */
-/* Largest batch of one persistent launch: all its workgroups (32 per 8 utterances, one per CU) must be resident at once:
- * 64 on a 256-CU MI355X.  Larger batches take the per-step launches (or several launches over slices of the batch). */
+/* Utterances a persistent launch works on at once: the 32 workgroups of every group of 8 utterances need a CU each and
+ * must be resident together: 64 on a 256-CU MI355X.  A launch accepts up to four times as many (its blocks are laid out
+ * in chunks of 8 groups that the dispatcher completes one after the other). */
 int las_decoder_persist_max_batch(void);
 int las_decoder_persist_fwd(const las_dec_persist* p, void* stream);
 

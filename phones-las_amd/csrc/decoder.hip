@@ -544,8 +544,11 @@ __global__ __launch_bounds__(256) void dec_persist_fwd_kernel(las_dec_persist p)
   const las_dec_step& s0 = p.s;
   const int B = s0.B, Hd = s0.Hd, M = s0.M, Tm = s0.Tm;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, lq = lane >> 4;
-  const int groups = (B + 7) / 8, gstride = (groups + 7) & ~7;
-  const int group = blockIdx.x % gstride, member = blockIdx.x / gstride;
+  // blocks in chunks of 8 groups (block = chunk * 256 + member * 8 + group % 8): a group's 32 members are 8 blocks apart (one
+  // XCD under round-robin dispatch), and the in-order dispatcher completes the 8 groups of a chunk -- one workgroup per CU of
+  // a 256-CU device -- before it starts the next chunk: a batch of more than 64 utterances runs chunk after chunk
+  const int groups = (B + 7) / 8;
+  const int group = (blockIdx.x / (8 * P_MEMBERS)) * 8 + (blockIdx.x & 7), member = (blockIdx.x % (8 * P_MEMBERS)) >> 3;
   if (group >= groups) return;
   unsigned* status = reinterpret_cast<unsigned*>(p.workspace);
   pu64* flags = reinterpret_cast<pu64*>(reinterpret_cast<char*>(p.workspace) + 64) + (size_t)group * 2 * P_MEMBERS;
@@ -1065,8 +1068,11 @@ __global__ __launch_bounds__(256) void dec_persist_bwd_kernel(las_dec_persist_bw
   const las_dec_step_bwd& s0 = p.s;
   const int B = s0.B, Hd = s0.Hd, M = s0.M, Tm = s0.Tm, W = p.W;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, lq = lane >> 4;
-  const int groups = (B + 7) / 8, gstride = (groups + 7) & ~7;
-  const int group = blockIdx.x % gstride, member = blockIdx.x / gstride;
+  // blocks in chunks of 8 groups (block = chunk * 256 + member * 8 + group % 8): a group's 32 members are 8 blocks apart (one
+  // XCD under round-robin dispatch), and the in-order dispatcher completes the 8 groups of a chunk -- one workgroup per CU of
+  // a 256-CU device -- before it starts the next chunk: a batch of more than 64 utterances runs chunk after chunk
+  const int groups = (B + 7) / 8;
+  const int group = (blockIdx.x / (8 * P_MEMBERS)) * 8 + (blockIdx.x & 7), member = (blockIdx.x % (8 * P_MEMBERS)) >> 3;
   if (group >= groups) return;
   float* dctx = sm;                       // [M]
   float* dal = dctx + M;                  // [Tm] dalign -> ds (own frames)
@@ -1647,9 +1653,9 @@ extern "C" int las_decoder_persist_supported(int Hd, int M, int K_in, int attent
   return 1;
 }
 
-// Every workgroup of a persistent launch needs a CU of its own (its registers and LDS fill one) and all of them must be
-// resident at once: groups of 8 utterances x 32 workgroups, the group stride rounded up to 8 -> at most 8 utterances per
-// 32 CUs (64 on a 256-CU MI355X).
+// Every workgroup of a persistent launch needs a CU of its own (its registers and LDS fill one) and the 32 of a group must
+// be resident together: 8 utterances per 32 CUs, 64 at once on a 256-CU MI355X.  Blocks are laid out in chunks of 8 groups,
+// so a larger batch (up to four chunks per launch) runs chunk after chunk as CUs become free.
 static int persist_max_batch() {
   static int cus = 0;
   if (cus == 0) {
@@ -1669,7 +1675,7 @@ extern "C" size_t las_decoder_persist_workspace_bytes(int B, int Tm, int Hd, int
 extern "C" int las_decoder_persist_fwd(const las_dec_persist* p, void* stream) {
   const las_dec_step* s = &p->s;
   LAS_REQUIRE(s->B > 0 && p->U > 0 && s->mode == LAS_DEC_FUSED, "las_decoder_persist_fwd: bad shape / mode");
-  LAS_REQUIRE(s->B <= persist_max_batch(), "las_decoder_persist_fwd: %d utterances need more co-resident workgroups than the device has CUs (at most %d per launch)", s->B, persist_max_batch());
+  LAS_REQUIRE(s->B <= 4 * persist_max_batch(), "las_decoder_persist_fwd: at most %d utterances per launch (got %d)", 4 * persist_max_batch(), s->B);
   LAS_REQUIRE(las_decoder_persist_supported(s->Hd, s->M, p->K_in, s->attention, s->norm),
               "las_decoder_persist_fwd: configuration not supported (Hd=%d M=%d K_in=%d attention=%d norm=%d)", s->Hd, s->M, p->K_in,
               s->attention, s->norm);
@@ -1715,7 +1721,7 @@ extern "C" int las_decoder_persist_bwd_supported(int Hd, int M, int W, int atten
 extern "C" int las_decoder_persist_bwd(const las_dec_persist_bwd* p, void* stream) {
   const las_dec_step_bwd* s = &p->s;
   LAS_REQUIRE(s->B > 0 && p->U > 0, "las_decoder_persist_bwd: bad shape");
-  LAS_REQUIRE(s->B <= persist_max_batch(), "las_decoder_persist_bwd: %d utterances need more co-resident workgroups than the device has CUs (at most %d per launch)", s->B, persist_max_batch());
+  LAS_REQUIRE(s->B <= 4 * persist_max_batch(), "las_decoder_persist_bwd: at most %d utterances per launch (got %d)", 4 * persist_max_batch(), s->B);
   LAS_REQUIRE(las_decoder_persist_bwd_supported(s->Hd, s->M, p->W, s->attention, s->norm),
               "las_decoder_persist_bwd: configuration not supported (Hd=%d M=%d W=%d attention=%d norm=%d)", s->Hd, s->M, p->W,
               s->attention, s->norm);

@@ -291,7 +291,7 @@ class Speller:
             fed = tin[:, :U].contiguous().clone()
             logits = torch.empty(B, U, Vp, dtype=f32, device=dev)
         ts = fed.stride(0)
-        persist = (B <= lib.las_decoder_persist_max_batch() and Vp <= 1024 and os.environ.get('LAS_DEC_PERSIST', '1') != '0' and      # B: co-residency
+        persist = (B <= 4 * lib.las_decoder_persist_max_batch() and Vp <= 1024 and os.environ.get('LAS_DEC_PERSIST', '1') != '0' and      # B: co-residency
                    lib.las_decoder_persist_supported(Hd, M, W, self.att, hip.NORM_SOFTMAX) == 1)
         if persist:
             # all U steps in one persistent launch (see las_dec_persist in las_hip.h)
@@ -371,7 +371,7 @@ class Speller:
             dkeys = torch.zeros(B, Tm, Hd, dtype=f32, device=dev)
             dpq_all = torch.empty(B, U, Hd, dtype=bf, device=dev)
             dv = grads[self.V_ATT]
-        persist = (B <= lib.las_decoder_persist_max_batch() and os.environ.get('LAS_DEC_PERSIST', '1') != '0' and
+        persist = (B <= 4 * lib.las_decoder_persist_max_batch() and os.environ.get('LAS_DEC_PERSIST', '1') != '0' and
                    lib.las_decoder_persist_bwd_supported(Hd, M, W, self.att, hip.NORM_SOFTMAX) == 1)
         if persist:
             # all U steps in one persistent launch (las_dec_persist_bwd in las_hip.h)
