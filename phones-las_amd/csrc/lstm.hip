@@ -802,20 +802,26 @@ __global__ __launch_bounds__(256) void lstm_bwd_kernel(const float* __restrict__
     f32x4 acc[NT];
 #pragma unroll
     for (int j = 0; j < NT; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // the tiles the peers are waiting for first (each sent as soon as it is complete), this member's own tiles last: their
+    // MFMAs run while the granules are on their way
+    bf16x8 afr[KCW];
 #pragma unroll
-    for (int kc = 0; kc < KCW; ++kc) {
-      const bf16x8 a = *reinterpret_cast<const bf16x8*>(zl + l15 * ZS + kc * 32 + 8 * lq);
-#pragma unroll
-      for (int j = 0; j < NT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, wf[j][kc], acc[j], 0, 0, 0);
-    }
+    for (int kc = 0; kc < KCW; ++kc) afr[kc] = *reinterpret_cast<const bf16x8*>(zl + l15 * ZS + kc * 32 + 8 * lq);
     if constexpr (G > 1) {
       char* dst = reinterpret_cast<char*>(ex_group + (int64_t)(epoch & 1) * par_stride);
 #pragma unroll
-      for (int j = OWN; j < NT; ++j)
+      for (int j = OWN; j < NT; ++j) {
+#pragma unroll
+        for (int kc = 0; kc < KCW; ++kc) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afr[kc], wf[j][kc], acc[j], 0, 0, 0);
 #pragma unroll
         for (int r = 0; r < (SPLIT ? 4 : RPL); ++r)       // 8-row slices: rows 2, 3 of every quad carry nothing
           granule_store(reinterpret_cast<u64*>(dst + send_off[j - OWN] + r * 512), epoch + 1, __float_as_uint(acc[j][r]), local);
+      }
     }
+#pragma unroll
+    for (int j = 0; j < (G > 1 ? OWN : NT); ++j)
+#pragma unroll
+      for (int kc = 0; kc < KCW; ++kc) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afr[kc], wf[j][kc], acc[j], 0, 0, 0);
 #pragma unroll
     for (int ub = 0; ub < OWN; ++ub)
 #pragma unroll
