@@ -787,6 +787,19 @@ __global__ __launch_bounds__(256) void lstm_bwd_kernel(const float* __restrict__
           if (s + 1 < len[r]) dh[ub][r] = cand[ub][r];        // rows that were running at step s+1
     }
 
+    // next step's operands first: in flight during the gate math, the product and the exchange, and ahead of this
+    // step's dz stores in the in-order vector-memory queue
+    unsigned zoff[RPL];
+#pragma unroll
+    for (int r = 0; r < RPL; ++r) zoff[r] = goff[r];
+    if (s > 0) {
+      if (lean) {
+#pragma unroll
+        for (int r = 0; r < RPL; ++r) goff[r] -= (unsigned)gstep;
+      }
+      if (s - 1 < smin - 1) load_lean(s - 1);
+      else load_general(s - 1);
+    }
     // ---- gate derivatives of step s -> dz (LDS tile for the product, HBM for the weight-gradient GEMMs) ----
     unsigned short* zl = &ztile[cur][0][0];
 #pragma unroll
@@ -807,7 +820,7 @@ __global__ __launch_bounds__(256) void lstm_bwd_kernel(const float* __restrict__
           dc[ub][r] = dct * k.gf;
           zv.x = (unsigned)las_f2bf(di) | ((unsigned)las_f2bf(dj) << 16);
           zv.y = (unsigned)las_f2bf(df) | ((unsigned)las_f2bf(dov) << 16);
-          if (lean) *reinterpret_cast<uint2*>(zbase + (goff[r] >> 1) + ub * 128) = zv;
+          if (lean) *reinterpret_cast<uint2*>(zbase + (zoff[r] >> 1) + ub * 128) = zv;
           else {
             const int pos = dir == 0 ? s : len[r] - 1 - s;
             *reinterpret_cast<uint2*>(dz + ((int64_t)bidx[r] * T + pos) * grow + dir * 4 * H + unit * 4) = zv;
@@ -815,15 +828,6 @@ __global__ __launch_bounds__(256) void lstm_bwd_kernel(const float* __restrict__
         }
         *reinterpret_cast<uint2*>(zl + (lq * 4 + hh * 2 + r) * ZS + (unit - member * HS) * 4) = zv;   // [row][u*4+g]
       }
-    }
-    // next step's operands: in flight during the product and the exchange
-    if (s > 0) {
-      if (lean) {
-#pragma unroll
-        for (int r = 0; r < RPL; ++r) goff[r] -= (unsigned)gstep;
-      }
-      if (s - 1 < smin - 1) load_lean(s - 1);
-      else load_general(s - 1);
     }
     lds_barrier();
     if (fail_flag) { ok = false; break; }
