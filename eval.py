@@ -43,7 +43,9 @@ def main(args):
     load_checkpoint(model, os.path.join(args.model_dir, 'checkpoint.pt'))
     eval_name = str(os.path.basename(args.data).split('.')[0])
     print('Evaluating on {}'.format(eval_name))
-    batches = utils.input_fn(args.data, args.vocab, args.norm, num_channels=args.num_channels, batch_size=args.batch_size)
+    # is_infer=True: file order, last partial batch kept (same metrics as train.py's in-loop evaluation and infer.py)
+    batches = utils.input_fn(args.data, args.vocab, args.norm, num_channels=args.num_channels, batch_size=args.batch_size,
+                             is_infer=True)
     return evaluate(model, batches, dev)
 
 

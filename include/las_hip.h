@@ -157,9 +157,11 @@ int las_lstm_recurrent_fwd(float* xproj, const las_bf16* wpacked, const int32_t*
                            int ndir, void* stream);
 
 /* Bytes of device scratch the two recurrent kernels need for (B, H, ndir): a status word plus the
- * inter-workgroup exchange buffer of the cooperating groups (0 = unsupported num_units).  The calls
- * zero it themselves (a memset node per launch).  After a launch the first uint32 is 0, or non-zero
- * if a bounded inter-workgroup wait timed out (results are then invalid). */
+ * inter-workgroup exchange buffer of the cooperating groups (0 = unsupported num_units).  The caller
+ * hands it over zeroed once; each call zeroes the exchange part itself (a memset node per launch) and leaves the
+ * 64-byte status header alone: its first uint32 is STICKY -- a launch ORs a bit into it when a bounded
+ * inter-workgroup wait timed out (results of that launch are invalid), and only the host clears it after reading
+ * it (one workspace serves every layer, forward and backward: see las_status_collect). */
 size_t las_lstm_workspace_bytes(int B, int H, int ndir);
 /* Utterances per slice the recurrent kernels will use for this shape (16 = full MFMA tiles; 8 = half-filled tiles on
  * twice as many chains, chosen for 256 units while every chain and its prefetch companion still find a CU each: the
@@ -247,8 +249,9 @@ int las_decoder_step_fwd(const las_dec_step* s, int parts, void* stream);
  * each other as tagged 8-byte granules through the workspace and meet at one flag barrier; the keys / values a
  * workgroup needs stay in its LDS for the whole sequence when they fit (else they are read from L2 every step).  `s` describes step 0; the inc_* fields are the element increments of
  * its per-step pointers (h_out2 / ctx_out2 are not written by the last step).  Replaces the U x (las_gemm_nt +
- * las_decoder_step_fwd) loop of las/model.py:276-296 when scheduled sampling is off.  The call zeroes `workspace`
- * (las_decoder_persist_workspace_bytes); its first uint32 is non-zero afterwards if a bounded wait timed out. */
+ * las_decoder_step_fwd) loop of las/model.py:276-296 when scheduled sampling is off.  `workspace`
+ * (las_decoder_persist_workspace_bytes) is handed over zeroed once; the call zeroes everything behind its 64-byte status
+ * header; the header's first uint32 is sticky: a bit is ORed in when a bounded wait timed out, the host clears it. */
 typedef struct las_dec_persist {
   las_dec_step s;
   int32_t U, K_in;               /* steps; columns of the operand rows / of kT (multiple of 32) */
@@ -456,14 +459,23 @@ int las_grad_l2_norms(float* grads, const float* params, const int64_t* seg_offs
 int las_grad_clip(float* grads, const int64_t* seg_offsets, int nseg, int64_t total, const float* sumsq,
                   float clip, void* stream);
 /* TF-form Adam (epsilon outside the bias correction).  The 1-based update count t is `step`, or
- * *step_dev when step_dev != NULL (a device counter: keeps a captured hipGraph replayable). */
+ * *step_dev when step_dev != NULL (a device counter: keeps a captured hipGraph replayable).
+ * skip_flag (nullable, device): when *skip_flag != 0 the launch changes nothing (las_status_collect: a persistent
+ * kernel of this step reported a timeout, on this replica or -- the flag travels with the all-reduced gradients --
+ * on another one; the reference has no such state: tf.train.AdamOptimizer, model_helper.py:404,417). */
 int las_adam_update(float* params, float* m, float* v, const float* grads, int64_t total, float lr,
-                    float beta1, float beta2, float eps, int step, const int32_t* step_dev, void* stream);
+                    float beta1, float beta2, float eps, int step, const int32_t* step_dev, const float* skip_flag,
+                    void* stream);
+/* *flag = 1.0f when any of the n status words is non-zero, else 0.0f.  status_words: device array of n device
+ * pointers, each to the first 32-bit word of a persistent kernel's workspace (las_lstm_recurrent_fwd/bwd,
+ * las_decoder_persist_fwd/bwd: bit set = a bounded inter-workgroup wait timed out; the launches never clear it,
+ * the host does after reading it). */
+int las_status_collect(const uint32_t* const* status_words, int n, float* flag, void* stream);
 /* las_grad_clip followed by las_adam_update in one pass over the buffers (single replica: nothing happens between
  * the two); grads holds the clipped gradient afterwards, exactly as after las_grad_clip. */
 int las_clip_adam_update(float* params, float* m, float* v, float* grads, const int64_t* seg_offsets, int nseg,
                          int64_t total, const float* sumsq, float clip, float lr, float beta1, float beta2, float eps,
-                         int step, const int32_t* step_dev, void* stream);
+                         int step, const int32_t* step_dev, const float* skip_flag, void* stream);
 /* *counter += delta on the stream (tf.train.get_global_step increment, model_helper.py:417). */
 int las_counter_add(int32_t* counter, int32_t delta, void* stream);
 

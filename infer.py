@@ -88,6 +88,7 @@ def main(args):
             optimistic_err += min(_levenshtein(i, t) for i in cut)
             hyps.append(cut[0])                          # the best-scoring beam is the hypothesis
             refs.append(t)
+    model.check_device_status()          # a timed-out persistent kernel would have produced invalid hypotheses
     err = sum(_levenshtein(h, r) for h, r in zip(hyps, refs))
     tot = sum(len(r) for r in refs)
     with open(os.path.join(args.model_dir, 'infer.txt'), 'w') as f:

@@ -50,12 +50,91 @@ def q_bf16(x: torch.Tensor) -> torch.Tensor:
     return x + (r - x.detach())
 
 
+class _RoundGrad(torch.autograd.Function):
+    """Identity whose BACKWARD rounds the incoming gradient to bfloat16: the device stores dz (every LSTM cell),
+    dlogits, d(keys) and the CTC dlogits in bf16 before they enter its backward GEMMs."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.to(torch.float32).to(torch.bfloat16).to(g.dtype)
+
+
+def _r(x):
+    return x.to(torch.float32).to(torch.bfloat16).to(x.dtype)
+
+
+class _ContextFn(torch.autograd.Function):
+    """context = align . values.  Device backward (decoder.hip dec_step_bwd_kernel): d(align) from the fp32 d(context);
+    d(values) = bf16(align)^T bf16(d context) (one batched GEMM after the loop)."""
+
+    @staticmethod
+    def forward(ctx, align, values):
+        ctx.save_for_backward(align, values)
+        return torch.einsum('bt,btm->bm', align, values)
+
+    @staticmethod
+    def backward(ctx, g):
+        align, values = ctx.saved_tensors
+        return torch.einsum('bm,btm->bt', g, values), torch.einsum('bt,bm->btm', _r(align), _r(g))
+
+
+class _DotScoreFn(torch.autograd.Function):
+    """Luong score = query . keys.  Device backward: d(query) from the fp32 d(score); d(keys) = bf16(d score)^T query
+    (one batched GEMM after the loop; the query is the cell output, already bf16)."""
+
+    @staticmethod
+    def forward(ctx, query, keys):
+        ctx.save_for_backward(query, keys)
+        return torch.einsum('bh,bth->bt', query, keys)
+
+    @staticmethod
+    def backward(ctx, g):
+        query, keys = ctx.saved_tensors
+        return torch.einsum('bt,bth->bh', g, keys), torch.einsum('bt,bh->bth', _r(g), query)
+
+
+class _QueryLayerFn(torch.autograd.Function):
+    """processed query = query @ Wq.  Device backward: d(query) from the fp32 d(pq); d(Wq) = query^T bf16(d pq)."""
+
+    @staticmethod
+    def forward(ctx, query, wq):
+        ctx.save_for_backward(query, wq)
+        return query @ wq
+
+    @staticmethod
+    def backward(ctx, g):
+        query, wq = ctx.saved_tensors
+        return g @ wq.t(), query.t() @ _r(g)
+
+
+def _identity(x):
+    return x
+
+
+# q_bf16 carries the device's BACKWARD storage model as attributes: .g rounds a gradient on its way back,
+# .bwd selects the device forms of the three attention products above
+q_bf16.g = _RoundGrad.apply
+q_bf16.bwd = True
+
+
 def make_q(mxu: str):
     if mxu == 'f64':
-        return lambda x: x
+        return _identity
     if mxu == 'bf16':
         return q_bf16
     raise ValueError('mxu must be f64 or bf16')
+
+
+def _g(q):
+    return getattr(q, 'g', _identity)
+
+
+def _bwd(q):
+    return getattr(q, 'bwd', False)
 
 
 # --------------------------------------------------------------------------------------
@@ -198,10 +277,10 @@ def init_params(hp: HP, seed: int = 4321, bias_scale: float = 0.0) -> Dict[str, 
 # --------------------------------------------------------------------------------------
 # listener  (las/ops.py, las/model.py:104-142)
 # --------------------------------------------------------------------------------------
-def lstm_step(x, c, h, kernel, bias):
+def lstm_step(x, c, h, kernel, bias, gq=_identity):
     """tf.nn.rnn_cell.LSTMCell as built by las/ops.py:10-12 (Appendix A.1): gate order i,j,f,o,
-    forget_bias 1.0, no peepholes/projection."""
-    z = torch.cat([x, h], 1) @ kernel + bias
+    forget_bias 1.0, no peepholes/projection.  gq: the device keeps d(z) in bf16 (storage model of the backward)."""
+    z = gq(torch.cat([x, h], 1) @ kernel + bias)
     i, j, f, o = z.chunk(4, dim=1)
     c2 = torch.sigmoid(f + 1.0) * c + torch.sigmoid(i) * torch.tanh(j)
     h2 = torch.sigmoid(o) * torch.tanh(c2)
@@ -229,7 +308,7 @@ def dynamic_rnn(x, length, kernel, bias, q, reverse=False, in_mask=None):
         xt = x[ar, pos]
         if in_mask is not None:
             xt = q(xt * in_mask[ar, pos])             # the device stores the dropped input in bf16
-        c2, h2 = lstm_step(xt, c, h, kq, bias)
+        c2, h2 = lstm_step(xt, c, h, kq, bias, _g(q))
         h2 = q(h2)                                  # device stores h_t in bf16
         m = active.unsqueeze(1).to(DT)
         c = m * c2 + (1 - m) * c
@@ -336,7 +415,7 @@ class Attention:
         B, Tm, _ = memory.shape
         self.mask = (torch.arange(Tm).unsqueeze(0) < mem_len.unsqueeze(1))       # [B,T']
         self.values = memory * self.mask.unsqueeze(-1).to(DT)
-        self.keys = q(self.values @ q(params['speller/memory_layer/kernel']))
+        self.keys = _g(q)(q(self.values @ q(params['speller/memory_layer/kernel'])))   # d(keys): summed over the steps in fp32, one bf16 rounding
         if self.kind == 'custom':
             self.keys = torch.relu(self.keys)                                    # las/model.py:97
         self.train = train
@@ -355,10 +434,12 @@ class Attention:
         if kind in ('luong', 'luong_monotonic', 'custom'):
             qq = query
             if kind == 'custom':
-                qq = q(torch.relu(query @ q(p['speller/query_layer/kernel'])))   # las/model.py:99
-            score = torch.einsum('bh,bth->bt', qq, self.keys)
+                wq = q(p['speller/query_layer/kernel'])
+                qq = q(torch.relu(_QueryLayerFn.apply(query, wq) if _bwd(q) else query @ wq))   # las/model.py:99
+            score = _DotScoreFn.apply(qq, self.keys) if _bwd(q) else torch.einsum('bh,bth->bt', qq, self.keys)
         else:
-            pq = query @ q(p['speller/query_layer/kernel'])
+            wq = q(p['speller/query_layer/kernel'])
+            pq = _QueryLayerFn.apply(query, wq) if _bwd(q) else query @ wq
             score = torch.einsum('h,bth->bt', p['speller/attention_v'],
                                  torch.tanh(self.keys + pq.unsqueeze(1)))
         if 'monotonic' in kind:
@@ -434,7 +515,7 @@ class Speller:
     def _cell(self, l, x, state):
         k = self.q(self.p[f'speller/decoder_cell_{l}/lstm_cell/kernel'])
         b = self.p[f'speller/decoder_cell_{l}/lstm_cell/bias']
-        c2, h2 = lstm_step(x, state[0], state[1], k, b)
+        c2, h2 = lstm_step(x, state[0], state[1], k, b, _g(self.q))
         return c2, self.q(h2)
 
     def step(self, inputs, in_mask=None):
@@ -465,7 +546,7 @@ class Speller:
                 cur = h
             cell_out = cur
         align = self.att(cell_out, self.align)
-        ctx = torch.einsum('bt,btm->bm', align, self.att.values)
+        ctx = _ContextFn.apply(align, self.att.values) if _bwd(q) else torch.einsum('bt,btm->bm', align, self.att.values)
         if d.attention_layer_size or d.binf_projection:
             ctx = q(ctx)
             attention = torch.cat([cell_out, ctx], 1) @ q(p['speller/attention_layer/kernel'])
@@ -761,7 +842,10 @@ def model_loss(hp: HP, params, batch, mxu='f64', stochastic=None):
     logits, sp = speller_train(hp, params, mem, mem_len, state, batch['targets_inputs'],
                                batch['target_sequence_length'], mxu, sample_select=st.get('sample_select'),
                                sample_ids=st.get('sample_ids'), noise=st.get('att_noise'), in_masks=st.get('dec_masks'))
+    gq = _g(make_q(mxu))
     raw = None
+    if not hp.decoder.binf_projection:
+        logits = gq(logits)                          # the loss kernel writes d(logits) in bf16
     if hp.decoder.binf_projection:                                               # model_helper.py:251-253
         V = hp.decoder.target_vocab_size
         raw, logits = logits[..., V:], logits[..., :V]
@@ -773,7 +857,7 @@ def model_loss(hp: HP, params, batch, mxu='f64', stochastic=None):
         loss = loss + reg * hp.decoder.binf_projection_reg_weight
     if hp.ctc_weight > 0:
         q = make_q(mxu)
-        cl = mem @ q(params['ctc_logits/kernel']) + params['ctc_logits/bias']
+        cl = gq(mem @ q(params['ctc_logits/kernel']) + params['ctc_logits/bias'])    # CTC d(logits) in bf16
         ctc = ctc_loss_dense(cl, batch['targets_outputs'], batch['target_sequence_length'], mem_len).mean()
         aux['ctc'] = ctc
         aux['ctc_logits'] = cl

@@ -1686,7 +1686,9 @@ extern "C" int las_decoder_persist_fwd(const las_dec_persist* p, void* stream) {
               "las_decoder_persist_fwd: scheduled sampling needs wprojT, bproj, plog (and fed ids with unit step)");
   hipStream_t st = (hipStream_t)stream;
   const int groups = (s->B + 7) / 8;
-  int rc = las_check_hip(hipMemsetAsync(p->workspace, 0, las_decoder_persist_workspace_bytes(s->B, s->Tm, s->Hd, s->M), st), "memset workspace");
+  // flags and granules start from zero; the 64-byte status header is sticky (cleared by the host after it has read it)
+  int rc = las_check_hip(hipMemsetAsync(reinterpret_cast<char*>(p->workspace) + 64, 0,
+                                        las_decoder_persist_workspace_bytes(s->B, s->Tm, s->Hd, s->M) - 64, st), "memset workspace");
   if (rc) return rc;
   size_t lds = persist_fwd_scratch_floats(s->Hd, s->Tm) * sizeof(float);
   LAS_REQUIRE(lds <= 64 * 1024, "las_decoder_persist_fwd: memory length %d too long for the LDS score buffer", s->Tm);
@@ -1733,7 +1735,9 @@ extern "C" int las_decoder_persist_bwd(const las_dec_persist_bwd* p, void* strea
               "las_decoder_persist_bwd: Bahdanau scores need att_v, dkeys_acc, dv_acc");
   hipStream_t st = (hipStream_t)stream;
   const int groups = (s->B + 7) / 8;
-  int rc = las_check_hip(hipMemsetAsync(p->workspace, 0, las_decoder_persist_workspace_bytes(s->B, s->Tm, s->Hd, s->M), st), "memset workspace");
+  // flags and granules start from zero; the 64-byte status header is sticky (cleared by the host after it has read it)
+  int rc = las_check_hip(hipMemsetAsync(reinterpret_cast<char*>(p->workspace) + 64, 0,
+                                        las_decoder_persist_workspace_bytes(s->B, s->Tm, s->Hd, s->M) - 64, st), "memset workspace");
   if (rc) return rc;
   size_t lds = persist_bwd_scratch_floats(s->M, s->Hd, s->Tm) * sizeof(float);
   LAS_REQUIRE(lds <= 64 * 1024, "las_decoder_persist_bwd: shapes exceed the LDS budget");

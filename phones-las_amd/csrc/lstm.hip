@@ -1035,8 +1035,12 @@ extern "C" int las_lstm_recurrent_fwd(float* xproj, const las_bf16* wpacked, con
     rc = las_check_hip(hipMemsetAsync(y, 0, (size_t)B * T * ndir * H * sizeof(las_bf16), st), "memset y");
     if (rc) return rc;
   }
-  rc = las_check_hip(hipMemsetAsync(workspace, 0, 64 + geom(B, H, ndir, false, slice_rows(B, H, ndir, false)).exch_bytes, st), "memset workspace");
-  if (rc) return rc;
+  // the exchange granules start from zero tags at every launch; the 64-byte status header is STICKY (a timeout bit
+  // survives until the host reads and clears it: the workspace is shared by every layer and by forward and backward)
+  if (const size_t eb = geom(B, H, ndir, false, slice_rows(B, H, ndir, false)).exch_bytes) {
+    rc = las_check_hip(hipMemsetAsync(reinterpret_cast<char*>(workspace) + 64, 0, eb, st), "memset workspace");
+    if (rc) return rc;
+  }
   switch (H) {
     case 64: return launch_fwd<64>(xproj, wpacked, length, y, cbuf, c_last, h_last, workspace, B, T, ndir, st);
     case 128: return launch_fwd<128>(xproj, wpacked, length, y, cbuf, c_last, h_last, workspace, B, T, ndir, st);
@@ -1057,8 +1061,10 @@ extern "C" int las_lstm_recurrent_bwd(const float* gates, const float* cbuf, con
     rc = las_check_hip(hipMemsetAsync(dz, 0, (size_t)B * T * ndir * 4 * H * sizeof(las_bf16), st), "memset dz");
     if (rc) return rc;
   }
-  rc = las_check_hip(hipMemsetAsync(workspace, 0, 64 + geom(B, H, ndir, true, slice_rows(B, H, ndir, true)).exch_bytes, st), "memset workspace");
-  if (rc) return rc;
+  if (const size_t eb = geom(B, H, ndir, true, slice_rows(B, H, ndir, true)).exch_bytes) {      // status header: sticky (see forward)
+    rc = las_check_hip(hipMemsetAsync(reinterpret_cast<char*>(workspace) + 64, 0, eb, st), "memset workspace");
+    if (rc) return rc;
+  }
   switch (H) {
     case 64: return launch_bwd<64>(gates, cbuf, dy, dc_last, dh_last, kh_bf16, length, dz, workspace, B, T, ndir, st);
     case 128: return launch_bwd<128>(gates, cbuf, dy, dc_last, dh_last, kh_bf16, length, dz, workspace, B, T, ndir, st);

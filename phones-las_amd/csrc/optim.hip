@@ -112,7 +112,9 @@ __device__ __forceinline__ void adam_one(float& p, float& m, float& v, float gi,
 }
 
 __global__ __launch_bounds__(256) void adam_kernel(float* p, float* m, float* v, const float* g, int64_t total, float lr,
-                                                   float b1, float b2, float eps, int step, const int32_t* step_dev) {
+                                                   float b1, float b2, float eps, int step, const int32_t* step_dev,
+                                                   const float* skip) {
+  if (skip && *skip != 0.f) return;        // a persistent kernel of this step (on any replica) reported a timeout: no update
   const float lr_t = adam_lr_t(lr, b1, b2, step, step_dev);
   const int64_t n4 = total >> 2;
   for (int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x; q < n4; q += (int64_t)gridDim.x * 256) {
@@ -134,7 +136,9 @@ __global__ __launch_bounds__(256) void adam_kernel(float* p, float* m, float* v,
 // written back so that the gradient buffer reads the same as after las_grad_clip.
 __global__ __launch_bounds__(256) void clip_adam_kernel(float* p, float* m, float* v, float* g, const int64_t* off, int nseg,
                                                         int64_t total, const float* sumsq, float clip, float lr, float b1,
-                                                        float b2, float eps, int step, const int32_t* step_dev) {
+                                                        float b2, float eps, int step, const int32_t* step_dev,
+                                                        const float* skip) {
+  if (skip && *skip != 0.f) return;
   const float lr_t = adam_lr_t(lr, b1, b2, step, step_dev);
   for_each_piece(off, nseg, total,
       [&](int64_t i, int n, int seg) {
@@ -172,7 +176,23 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float* x, int64_t n, f
 
 __global__ void counter_add_kernel(int32_t* c, int32_t d) { if (threadIdx.x == 0 && blockIdx.x == 0) *c += d; }
 
+// flag = 1.0 when any of the n status words (first word of a persistent kernel's workspace) is non-zero, else 0.0
+__global__ void status_collect_kernel(const unsigned* const* words, int n, float* flag) {
+  unsigned any = 0;
+  for (int i = threadIdx.x; i < n; i += 64) any |= __hip_atomic_load(words[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) any |= __shfl_xor(any, o, 64);
+  if (threadIdx.x == 0) *flag = any ? 1.f : 0.f;
+}
+
 }  // namespace
+
+extern "C" int las_status_collect(const uint32_t* const* status_words, int n, float* flag, void* stream) {
+  LAS_REQUIRE(n >= 0 && flag != nullptr && (n == 0 || status_words != nullptr), "las_status_collect: bad arguments");
+  hipLaunchKernelGGL(status_collect_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, status_words, n, flag);
+  LAS_LAUNCH_CHECK("status collect launch");
+  return LAS_OK;
+}
 
 extern "C" int las_counter_add(int32_t* counter, int32_t delta, void* stream) {
   hipLaunchKernelGGL(counter_add_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, counter, delta);
@@ -217,24 +237,25 @@ extern "C" int las_grad_clip(float* grads, const int64_t* seg_offsets, int nseg,
 }
 
 extern "C" int las_adam_update(float* params, float* m, float* v, const float* grads, int64_t total, float lr,
-                               float beta1, float beta2, float eps, int step, const int32_t* step_dev, void* stream) {
+                               float beta1, float beta2, float eps, int step, const int32_t* step_dev, const float* skip_flag,
+                               void* stream) {
   LAS_REQUIRE(total > 0 && (step >= 1 || step_dev), "las_adam_update: bad arguments");
   LAS_REQUIRE((((uintptr_t)params | (uintptr_t)m | (uintptr_t)v | (uintptr_t)grads) % 16) == 0, "las_adam_update: buffers must be 16-byte aligned");
   int blocks = (int)((total + 4095) / 4096);
   if (blocks > 2048) blocks = 2048;
   hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, params, m, v, grads, total, lr,
-                     beta1, beta2, eps, step, step_dev);
+                     beta1, beta2, eps, step, step_dev, skip_flag);
   LAS_LAUNCH_CHECK("adam launch");
   return LAS_OK;
 }
 
 extern "C" int las_clip_adam_update(float* params, float* m, float* v, float* grads, const int64_t* seg_offsets, int nseg,
                                     int64_t total, const float* sumsq, float clip, float lr, float beta1, float beta2,
-                                    float eps, int step, const int32_t* step_dev, void* stream) {
+                                    float eps, int step, const int32_t* step_dev, const float* skip_flag, void* stream) {
   LAS_REQUIRE(nseg > 0 && total > 0 && clip > 0.f && (step >= 1 || step_dev), "las_clip_adam_update: bad arguments");
   LAS_REQUIRE((((uintptr_t)params | (uintptr_t)m | (uintptr_t)v | (uintptr_t)grads) % 16) == 0, "las_clip_adam_update: buffers must be 16-byte aligned");
   hipLaunchKernelGGL(clip_adam_kernel, dim3((unsigned)((total + SPAN - 1) / SPAN)), dim3(256), 0, (hipStream_t)stream, params, m, v,
-                     grads, seg_offsets, nseg, total, sumsq, clip, lr, beta1, beta2, eps, step, step_dev);
+                     grads, seg_offsets, nseg, total, sumsq, clip, lr, beta1, beta2, eps, step, step_dev, skip_flag);
   LAS_LAUNCH_CHECK("clip + adam launch");
   return LAS_OK;
 }

@@ -9,7 +9,8 @@ import os
 import torch
 import torch.distributed as dist
 
-__all__ = ['init_from_env', 'shard_batch', 'all_reduce_sum_', 'mean_scalar', 'world_size', 'rank']
+__all__ = ['init_from_env', 'shard_batch', 'all_reduce_sum_', 'mean_scalar', 'world_size', 'rank', 'barrier',
+           'broadcast_int', 'sum_floats']
 
 
 def init_from_env(backend=None, device=None):
@@ -69,3 +70,30 @@ def mean_scalar(value, group=None):
         dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
         t = t / dist.get_world_size(group)
     return float(t)
+
+
+def _dev_of(group=None):
+    return 'cuda' if dist.get_backend(group) == 'nccl' else 'cpu'
+
+
+def barrier(group=None):
+    if dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.barrier(group=group)
+
+
+def broadcast_int(value, src=0, group=None):
+    """Every replica returns rank `src`'s integer (decisions taken by one clock: when to evaluate, when to stop)."""
+    if not (dist.is_initialized() and dist.get_world_size(group) > 1):
+        return int(value)
+    t = torch.tensor([int(value)], dtype=torch.int64, device=_dev_of(group))
+    dist.broadcast(t, src=src, group=group)
+    return int(t.item())
+
+
+def sum_floats(values, group=None):
+    """Element-wise sum of a short list of python floats over the replicas (evaluation metrics of sharded batches)."""
+    t = torch.tensor([float(v) for v in values], dtype=torch.float64)
+    if dist.is_initialized() and dist.get_world_size(group) > 1:
+        t = t.to(_dev_of(group))
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    return [float(x) for x in t.cpu()]

@@ -35,9 +35,10 @@ _SIGS = {
     'las_decoder_step_bwd': ([_vp, _vp], C.c_int),
     'las_seq_ce_loss': ([_vp, _i64, _vp, _vp, _i32, _i32, _i32, _f32, _vp, _vp, _i64, _vp], C.c_int),
     'las_grad_l2_norms': ([_vp, _vp, _vp, _i32, _i64, _f32, _vp, _vp, _vp], C.c_int),
-    'las_clip_adam_update': ([_vp, _vp, _vp, _vp, _vp, _i32, _i64, _vp, _f32, _f32, _f32, _f32, _f32, _i32, _vp, _vp], C.c_int),
+    'las_clip_adam_update': ([_vp, _vp, _vp, _vp, _vp, _i32, _i64, _vp, _f32, _f32, _f32, _f32, _f32, _i32, _vp, _vp, _vp], C.c_int),
     'las_grad_clip': ([_vp, _vp, _i32, _i64, _vp, _f32, _vp], C.c_int),
-    'las_adam_update': ([_vp, _vp, _vp, _vp, _i64, _f32, _f32, _f32, _f32, _i32, _vp, _vp], C.c_int),
+    'las_adam_update': ([_vp, _vp, _vp, _vp, _i64, _f32, _f32, _f32, _f32, _i32, _vp, _vp, _vp], C.c_int),
+    'las_status_collect': ([_vp, _i32, _vp, _vp], C.c_int),
     'las_counter_add': ([_vp, _i32, _vp], C.c_int),
     'las_sumsq': ([_vp, _i64, _vp, _vp], C.c_int),
     'las_crc32c': ([C.c_char_p, C.c_size_t], C.c_uint32),

@@ -241,6 +241,17 @@ class Speller:
 
     DEC_STREAM = 1      # generator stream of the decoder cell's input dropout
 
+    def _persist_workspace(self, which, nbytes):
+        """Workspace of the one-launch decoder ('fwd' / 'bwd'), kept across steps: the launches zero everything behind
+        its 64-byte status header themselves; the header is sticky (LasModel.check_device_status reads and clears it)."""
+        cache = self.__dict__.setdefault('_persist_cache', {})
+        ws = cache.get(which)
+        if ws is None or ws.numel() < nbytes:
+            if ws is not None and int(ws[:4].view(torch.int32).item()):
+                raise hip.LasError('persistent decoder reported a barrier timeout')
+            ws = cache[which] = torch.zeros(nbytes, dtype=torch.uint8, device='cuda')
+        return ws
+
     def _step_struct(self, B, Tm, z, tok_ids, tok_stride, c_prev, ldcp, gates, ldg, c_out, ldco, h_out, ldh, h2, ldh2,
                      keys, memory, mem_len, align, align_bf, lda, pq, ldpq, ctx, ldc, ctx2, ldc2):
         s = hip.DecStep()
@@ -309,7 +320,7 @@ class Speller:
             p.inc_align, p.inc_pq, p.inc_ctx, p.inc_ctx2 = Tmp, Hd, M, W
             p.x, p.ldx, p.inc_x = hip.addr(AH), U * W, W
             p.kT, p.ldk = hip.addr(self.kcT), W
-            ws = torch.empty(lib.las_decoder_persist_workspace_bytes(B, Tm, Hd, M), dtype=torch.uint8, device=dev)
+            ws = self._persist_workspace('fwd', lib.las_decoder_persist_workspace_bytes(B, Tm, Hd, M))
             p.workspace = hip.addr(ws)       # status, group flags and the exchange granules (z_t, raw scores)
             if sampling > 0.0:           # logits and the sampled feed are produced inside the launch
                 plog = torch.empty(U, B, 4, Vp, dtype=f32, device=dev)
@@ -401,7 +412,7 @@ class Speller:
             p.inc_pq = Hd
             p.kc, p.ldk = hip.addr(self.kc), 4 * Hd
             dfeed_all = torch.empty(1, B, W, dtype=f32, device=dev)      # only step 0's row leaves the launch: d(initial feed)
-            ws = torch.empty(lib.las_decoder_persist_workspace_bytes(B, Tm, Hd, M), dtype=torch.uint8, device=dev)
+            ws = self._persist_workspace('bwd', lib.las_decoder_persist_workspace_bytes(B, Tm, Hd, M))
             p.dfeed_all, p.workspace = hip.addr(dfeed_all), hip.addr(ws)
             hip.check(lib.las_decoder_persist_bwd(C.byref(p), st))
             self._persist_ws_bwd = ws

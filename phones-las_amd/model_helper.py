@@ -102,7 +102,12 @@ class Variables:
         self.total = offs[-1]
         f32 = torch.float32
         self.flat = torch.zeros(self.total, dtype=f32, device=device)
-        self.grad = torch.zeros(self.total, dtype=f32, device=device)
+        # gradient buffer with a 4-float head: grad_store[0] is the step's "a persistent kernel timed out" flag
+        # (las_status_collect).  It is all-reduced together with the gradients, so every replica skips the Adam update
+        # when any of them saw a timeout (las_adam_update's skip_flag).
+        self.grad_store = torch.zeros(self.total + 4, dtype=f32, device=device)
+        self.grad = self.grad_store[4:]
+        self.skip_flag = self.grad_store[:1]
         self.m = torch.zeros(self.total, dtype=f32, device=device)
         self.v = torch.zeros(self.total, dtype=f32, device=device)
         self.seg = torch.tensor(offs, dtype=torch.int64, device=device)
@@ -242,9 +247,11 @@ def ctc_greedy_decode(logits, logit_len):
 class LasModel:
     """Variables + listener + speller + train op: what tf.estimator.Estimator(model_fn=las_model_fn) holds."""
 
-    def __init__(self, params, seed=4321, world_size=1, process_group=None, binf2phone=None):
+    def __init__(self, params, seed=4321, world_size=1, process_group=None, binf2phone=None, rank=0):
         """binf2phone: the [binf_count, V] 0/1 matrix of utils.load_binf2phone for the binary-feature decoders
-        (model_helper.py:181-187: a constant unless --binf_trainable)."""
+        (model_helper.py:181-187: a constant unless --binf_trainable).  rank: this replica's index in a data-parallel
+        job; it enters the seed of the dropout / sampling draws (replicas draw independently, as CrossShardOptimizer's
+        do) but not the weight-noise seed (the weights stay identical)."""
         if not torch.cuda.is_available():
             raise hip.LasError('no HIP device visible: the LAS path has no CPU fallback')
         hip.lib()
@@ -271,6 +278,8 @@ class LasModel:
         self.ctc = CtcHead(params, self.vars.params, _enc_depth(params.encoder)) if params.ctc_weight > 0 else None
         self.global_step = 0
         self.rng_seed = (seed * 2654435761 + 12345) & 0x7fffffff      # base of the dropout / sampling draws
+        self.noise_seed = self.rng_seed                               # weight noise: the same on every replica
+        self.rng_seed = (self.rng_seed ^ ((rank * 0x9E3779B9) & 0x7fffffff)) & 0x7fffffff
         self.step_dev = torch.ones(1, dtype=torch.int32, device='cuda')       # Adam t = global_step + 1
         self.world_size = world_size
         self.process_group = process_group
@@ -367,7 +376,13 @@ class LasModel:
         if self.world_size <= 1 and self.process_group is None:
             return None
         v = self.vars
-        flat = v.grad if bucket is None else v.grad[bucket['begin']:bucket['end']]
+        # the flag in front of the buffer travels with the piece that starts at element 0 (the last one to leave)
+        if bucket is None:
+            flat = v.grad_store
+        elif bucket['begin'] == 0:
+            flat = v.grad_store[:4 + bucket['end']]
+        else:
+            flat = v.grad[bucket['begin']:bucket['end']]
         if async_op:
             return torch.distributed.all_reduce(flat, group=self.process_group, async_op=True)
         dp.all_reduce_sum_(flat, self.process_group)
@@ -378,7 +393,7 @@ class LasModel:
         v, p = self.vars, self.params
         lib, st = hip.lib(), hip.stream()
         hip.check(lib.las_adam_update(hip.p(v.flat), hip.p(v.m), hip.p(v.v), hip.p(v.grad), v.total,
-                                      float(p.learning_rate), 0.9, 0.999, 1e-8, 0, hip.p(self.step_dev), st))
+                                      float(p.learning_rate), 0.9, 0.999, 1e-8, 0, hip.p(self.step_dev), hip.p(v.skip_flag), st))
         hip.check(lib.las_counter_add(hip.p(self.step_dev), 1, st))
         self._images_stale = True
 
@@ -388,11 +403,12 @@ class LasModel:
         lib, st = hip.lib(), hip.stream()
         hip.check(lib.las_clip_adam_update(hip.p(v.flat), hip.p(v.m), hip.p(v.v), hip.p(v.grad), hip.p(v.seg), len(v.table),
                                            v.total, hip.p(v.sumsq), float(GRAD_NORM), float(p.learning_rate), 0.9, 0.999, 1e-8,
-                                           0, hip.p(self.step_dev), st))
+                                           0, hip.p(self.step_dev), hip.p(v.skip_flag), st))
         hip.check(lib.las_counter_add(hip.p(self.step_dev), 1, st))
         self._images_stale = True
 
     def apply_gradients(self):
+        self.collect_status()
         if self.world_size == 1 and self.process_group is None:
             self.gradient_norms()
             self.clip_adam_update()
@@ -400,6 +416,29 @@ class LasModel:
             self.clip_gradients()
             self.all_reduce_gradients()
             self.adam_update()
+
+    # -- timeouts of the persistent kernels -----------------------------------------------------------------------
+    def _status_tensors(self):
+        """Workspaces whose first word is a sticky timeout status: the recurrent kernels' (one per batch shape) and the
+        one-launch decoder's."""
+        dev = torch.cuda.current_device()
+        out = [ws for (B, H, nd, d), ws in las_model.ops._WORKSPACES.items() if d == dev]
+        out += [ws for ws in getattr(self.speller, '_persist_cache', {}).values()]
+        return out
+
+    def collect_status(self):
+        """vars.skip_flag = 1 if any persistent kernel launched so far reported a timeout (the status words are sticky),
+        else 0: enqueued once per step after the backward pass, before the gradients are exchanged.  The Adam kernels do
+        nothing when the (all-reduced) flag is set, so parameters never see the invalid gradients of such a step; the
+        host raises at its next check_device_status()."""
+        ws = self._status_tensors()
+        key = tuple(t.data_ptr() for t in ws)
+        if getattr(self, '_status_key', None) != key:
+            if torch.cuda.is_current_stream_capturing():
+                raise hip.LasError('collect_status: new workspace during graph capture (run the step once eagerly first)')
+            self._status_ptrs = torch.tensor(list(key) or [0], dtype=torch.int64).cuda()
+            self._status_key = key
+        hip.check(hip.lib().las_status_collect(hip.p(self._status_ptrs), len(key), hip.p(self.vars.skip_flag), hip.stream()))
 
     # -- data-parallel step with the exchange overlapped with the backward pass ----------------------------------
     def enable_exchange_overlap(self):
@@ -418,6 +457,7 @@ class LasModel:
         v = self.vars
         if len(v.buckets) < 2:
             self.backward(dlogits)
+            self.collect_status()
             self.clip_gradients()
             return [self.all_reduce_gradients(async_op=True)] if exchange else []
         left = self.backward_top(dlogits, layers=1)
@@ -435,6 +475,7 @@ class LasModel:
         if len(v.buckets) >= 2:
             if self.listener._bwd is not None:
                 self.backward_rest()
+            self.collect_status()                       # the flag leaves with bucket 1 (it starts at element 0)
             self.clip_gradients(v.buckets[1])
             if exchange:
                 pending = list(pending) + [self.all_reduce_gradients(v.buckets[1], async_op=True)]
@@ -453,8 +494,8 @@ class LasModel:
         for i, (name, shape, _) in enumerate(self.vars.table):
             if name.endswith('kernel'):
                 t = self.vars.params[name]
-                hip.check(lib.las_add_noise(hip.p(t), t.numel(), float(p.noise_std), self.last_seed if hasattr(self, 'last_seed') else self.rng_seed,
-                                            1000 + i, st))
+                hip.check(lib.las_add_noise(hip.p(t), t.numel(), float(p.noise_std),
+                                            (self.noise_seed + 7919 * self.global_step) & 0x7fffffff, 1000 + i, st))
         self._images_stale = True
 
     def l2_loss(self, from_norms=False):
@@ -517,15 +558,19 @@ class LasModel:
 
     def check_device_status(self):
         """The persistent kernels (recurrent layers, one-launch decoder) bound every inter-workgroup wait and flag a
-        timeout in their workspace instead of hanging; results are then invalid.  Call at logging points (it
-        synchronises): raises LasError if any launch since the last check timed out."""
-        las_model.ops.check_all_lstm_status()
-        for name in ('_persist_ws', '_persist_ws_bwd'):
-            ws = getattr(self.speller, name, None)
-            if ws is not None:
+        timeout in their workspace instead of hanging; results are then invalid.  The status words are sticky (no launch
+        clears them), so this reports ANY launch since the last check.  Call at logging points, before a checkpoint
+        is written and at the end of inference (it synchronises): raises LasError and clears the words."""
+        try:
+            las_model.ops.check_all_lstm_status()
+            for ws in getattr(self.speller, '_persist_cache', {}).values():
                 st = int(ws[:4].view(torch.int32).item())
                 if st:
                     raise hip.LasError('persistent decoder reported a barrier timeout (status %d)' % st)
+        except hip.LasError:
+            for ws in self._status_tensors():        # read: the sticky words start over
+                ws[:4].zero_()
+            raise
 
     def _beam_speller(self):
         """Beam search runs on the general cell stack (it gathers the decoder state between steps); the fused

@@ -45,8 +45,10 @@ class HParams(object):
         return json.dumps(self.values(), sort_keys=True)
 
     def save_to_file(self, filename):
-        with open(filename, 'w') as f:
+        tmp = '%s.tmp.%d' % (filename, os.getpid())
+        with open(tmp, 'w') as f:
             json.dump(self.to_json(), f)          # double encoding, as the reference does
+        os.replace(tmp, filename)                 # readers never see a truncated file
 
     def __repr__(self):
         return 'HParams(%s)' % ', '.join('%s=%r' % (k, getattr(self, k)) for k in self._names)
@@ -65,8 +67,9 @@ def get_default_hparams():
         binf_trainable=False, multitask=False, mapping=None)
 
 
-def create_hparams(args, target_vocab_size=None, binf_count=None, sos_id=1, eos_id=2):
-    """utils/params_utils.py:80-116."""
+def create_hparams(args, target_vocab_size=None, binf_count=None, sos_id=1, eos_id=2, write=True):
+    """utils/params_utils.py:80-116.  write=False: read / merge only (the replicas of a multi-GPU job other than rank 0:
+    one writer per model_dir)."""
     hparams = get_default_hparams()
     hparams_file = os.path.join(args.model_dir, 'hparams.json')
     is_reset = getattr(args, 'reset', False)
@@ -93,9 +96,9 @@ def create_hparams(args, target_vocab_size=None, binf_count=None, sos_id=1, eos_
                 hparams.add_hparam(name, value)
             else:
                 hparams.set_hparam(name, value)
-    if not os.path.exists(args.model_dir):
-        os.makedirs(args.model_dir)
-    hparams.save_to_file(hparams_file)
+    if write:
+        os.makedirs(args.model_dir, exist_ok=True)
+        hparams.save_to_file(hparams_file)
     return get_encoder_decoder_hparams(hparams)
 
 

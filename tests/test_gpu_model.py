@@ -119,11 +119,11 @@ def test_train_op_kernels_on_unaligned_tensor_boundaries():
         hip.check(lib.las_grad_l2_norms(hip.p(g), hip.p(p), hip.p(seg), nseg, total, l2, hip.p(sumsq), hip.p(psq), hip.stream()))
         if fused:
             hip.check(lib.las_clip_adam_update(hip.p(p), hip.p(m), hip.p(v), hip.p(g), hip.p(seg), nseg, total, hip.p(sumsq), clip,
-                                               lr, 0.9, 0.999, 1e-8, 0, hip.p(step_dev), hip.stream()))
+                                               lr, 0.9, 0.999, 1e-8, 0, hip.p(step_dev), None, hip.stream()))
         else:
             hip.check(lib.las_grad_clip(hip.p(g), hip.p(seg), nseg, total, hip.p(sumsq), clip, hip.stream()))
             hip.check(lib.las_adam_update(hip.p(p), hip.p(m), hip.p(v), hip.p(g), total, lr, 0.9, 0.999, 1e-8, 0, hip.p(step_dev),
-                                          hip.stream()))
+                                          None, hip.stream()))
         torch.cuda.synchronize()
         return [x.cpu() for x in (g, p, m, v, sumsq, psq)]
 
@@ -686,3 +686,40 @@ def test_training_with_the_persistent_kernels_learns_and_reports_no_timeout():
     model.check_device_status()
     assert getattr(model.speller, '_persist_ws', None) is not None and getattr(model.speller, '_persist_ws_bwd', None) is not None
     assert np.isfinite(losses).all() and losses[-1] < 0.75 * losses[0], losses     # typically 0.55-0.6 (stochastic: dropout, sampling)
+
+
+def test_timeout_status_is_sticky_and_blocks_the_update():
+    """a timeout bit in a persistent kernel's workspace survives later launches (only the exchange part of the
+    workspace is zeroed per launch), reaches vars.skip_flag through las_status_collect, makes the Adam kernels a no-op
+    (parameters never see the invalid gradients) and is raised -- then cleared -- by check_device_status()."""
+    from phones_las_amd import hip
+    from phones_las_amd.las import ops
+    O, ohp, op, model = _models('luong', H=128, F=13, L=2)
+    batch = make_batch(B=5, src_len=[12, 7, 10, 12, 4], tgt_len=[6, 4, 5, 6, 2])
+    feats, labels = to_device(batch)
+    model.train_step(feats, labels)
+    torch.cuda.synchronize()
+    model.check_device_status()
+    assert float(model.vars.skip_flag) == 0.0
+    before = model.vars.flat.clone()
+    ws = ops.lstm_workspace(5, 128, 2)
+    ws[:4].view(torch.int32).fill_(1)                  # what a timed-out recurrent launch leaves behind
+    model.train_step(feats, labels)                    # several more launches on the same workspace: the bit must survive
+    torch.cuda.synchronize()
+    assert int(ws[:4].view(torch.int32).item()) == 1
+    assert float(model.vars.skip_flag) == 1.0
+    assert torch.equal(model.vars.flat, before)        # the update was skipped
+    with pytest.raises(hip.LasError):
+        model.check_device_status()
+    model.check_device_status()                        # read = cleared
+    model.train_step(feats, labels)
+    torch.cuda.synchronize()
+    assert float(model.vars.skip_flag) == 0.0 and not torch.equal(model.vars.flat, before)
+    # the decoder's workspace the same way
+    dws = model.speller._persist_cache['bwd']
+    dws[:4].view(torch.int32).fill_(16)
+    model.train_step(feats, labels)
+    torch.cuda.synchronize()
+    assert float(model.vars.skip_flag) == 1.0
+    with pytest.raises(hip.LasError):
+        model.check_device_status()

@@ -110,3 +110,19 @@ def test_bf16_quantiser_is_rne_and_straight_through():
     assert r[1].item() == 1.0 + 2 ** -7            # 1.0059 -> tie to even mantissa
     r.sum().backward()
     assert torch.equal(v.grad, torch.ones(3, dtype=DT))
+
+
+def test_fused_cpu_stand_in_matches_the_step_wise_oracle():
+    """oracle/fused_cpu.py (bench.py's stronger cpu_baseline: torch.nn.LSTM's fused kernel for the listener) computes the
+    same train step as the step-wise restatement: TF gate order i,j,f,o and forget_bias 1 mapped to torch's i,f,g,o."""
+    from oracle import las_oracle as O, fused_cpu
+    hp = O.HP(encoder=O.EncoderHP(num_layers=3, num_units=16), num_channels=8,
+              decoder=O.DecoderHP(num_layers=1, num_units=16, target_vocab_size=11, attention_type='luong',
+                                  bottom_only=True, pass_hidden_state=True))
+    p = O.init_params(hp, bias_scale=0.1)
+    b = O.synthetic_batch(3, 16, 8, 11, 5)
+    r1 = O.train_step(hp, p, None, None, 1, b)
+    r2 = fused_cpu.train_step_fused(hp, p, b)
+    assert abs(float(r1['loss']) - float(r2['loss'])) < 1e-12
+    assert max(float((r1['grads'][k] - r2['grads'][k]).abs().max()) for k in p) < 1e-12
+    assert max(float((r1['clipped'][k] - r2['clipped'][k]).abs().max()) for k in p) < 1e-12

@@ -125,11 +125,16 @@ def main(args):
     if not args.num_channels:
         first = next(iter(utils.read_dataset(args.train, None)()))
         args.num_channels = int(first[0].shape[1])
-    hparams = utils.create_hparams(args, len(vocab_list), binf_count, utils.SOS_ID, utils.EOS_ID)
+    # one writer per model_dir: rank 0 creates / merges hparams.json (atomic replace), the others read it afterwards
+    if rank == 0:
+        hparams = utils.create_hparams(args, len(vocab_list), binf_count, utils.SOS_ID, utils.EOS_ID)
+    dp.barrier()
+    if rank != 0:
+        hparams = utils.create_hparams(args, len(vocab_list), binf_count, utils.SOS_ID, utils.EOS_ID, write=False)
     if mapping is not None:
         hparams.del_hparam('mapping')
         hparams.add_hparam('mapping', mapping)
-    model = mh.LasModel(hparams, world_size=world, binf2phone=binf2phone_np)
+    model = mh.LasModel(hparams, world_size=world, binf2phone=binf2phone_np, rank=rank)
     if world > 1 and getattr(args, 'dp_overlap', False):
         model.enable_exchange_overlap()
     ckpt = os.path.join(args.model_dir, 'checkpoint.pt')
@@ -163,29 +168,46 @@ def main(args):
                 dt = time.time() - t_last
                 print('step %d: loss = %.5f (%.2f utt/s)' % (model.global_step, lv, 10 * global_batch / max(dt, 1e-9)))
             t_last = time.time()
-        if rank == 0 and model.global_step % 500 == 0:
-            save_checkpoint(model, ckpt)
-        if args.valid and time.time() - last_eval > args.eval_secs:
-            evaluate(model, make_input(args.valid, 1, True), dev, rank)
-            last_eval = time.time()
+            # rank 0's clock decides when to evaluate (every replica must enter the evaluation at the same step)
+            if args.valid and dp.broadcast_int(time.time() - last_eval > args.eval_secs):
+                evaluate(model, make_input(args.valid, 1, True), dev, rank, world)
+                last_eval = time.time()
+        if model.global_step % 500 == 0:
+            model.check_device_status()          # never checkpoint parameters of a step whose kernels timed out
+            if rank == 0:
+                save_checkpoint(model, ckpt)
+    model.check_device_status()
     if rank == 0:
         save_checkpoint(model, ckpt)
         print('finished at global_step %d in %.1f s' % (model.global_step, time.time() - t0))
     if args.valid:
-        evaluate(model, make_input(args.valid, 1, True), dev, rank)
+        evaluate(model, make_input(args.valid, 1, True), dev, rank, world)
 
 
-def evaluate(model, batches, dev, rank=0):
-    """tf.estimator evaluate: streaming mean of loss and normalised edit distance (model_helper.py:299-309)."""
-    losses, eds = [], []
-    for features, labels in batches:
+def evaluate(model, batches, dev, rank=0, world=1):
+    """tf.estimator evaluate: streaming mean of loss and normalised edit distance (model_helper.py:299-309).  With several
+    replicas every batch is dealt round-robin to them (every replica walks the same batches) and the sums are
+    all-reduced at the end, so all replicas leave the evaluation together."""
+    from phones_las_amd import dp
+    loss_sum, n_batches, ed_sum, n_utt = 0.0, 0, 0.0, 0
+    for i, (features, labels) in enumerate(batches):
+        if world > 1 and i % world != rank:
+            continue
         f, l = to_device(features, labels, dev)
         loss, ed, _ = model.evaluate(f, l)
-        losses.append(float(loss))
-        eds.extend(ed)
-    if rank == 0 and losses:
-        print('eval: loss = %.5f, edit_distance = %.5f' % (float(np.mean(losses)), float(np.mean(eds))))
-    return (float(np.mean(losses)), float(np.mean(eds))) if losses else (None, None)
+        loss_sum += float(loss)
+        n_batches += 1
+        ed_sum += float(np.sum(ed))
+        n_utt += len(ed)
+    model.check_device_status()
+    if world > 1:
+        loss_sum, n_batches, ed_sum, n_utt = dp.sum_floats([loss_sum, n_batches, ed_sum, n_utt])
+    if not n_batches:
+        return None, None
+    res = (loss_sum / n_batches, ed_sum / max(n_utt, 1))
+    if rank == 0:
+        print('eval: loss = %.5f, edit_distance = %.5f' % res)
+    return res
 
 
 if __name__ == '__main__':
