@@ -8,8 +8,10 @@ SURVEY.md §8(d) "metric-M": 3-layer pBiLSTM-256 + Luong + 1x256 decoder, V=64, 
 
 One process per GPU; weak scaling (each rank trains its own B=64 shard; gradients are summed with one
 all-reduce between the local per-tensor clip and Adam, the CrossShardOptimizer order of model_helper.py:405-417).
-Rank 0 prints ONE JSON line.  The step is captured once into HIP graphs (torch.cuda.CUDAGraph) and replayed:
-the same kernels, no host launch overhead.
+`python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment starts the N ranks itself (a child
+`python -m torch.distributed.run`; this parent never touches a GPU) and relays rank 0's JSON line as its last
+line of stdout.  Rank 0 prints ONE JSON line.  The step is captured once into HIP graphs (torch.cuda.CUDAGraph)
+and replayed, or launched eagerly, whichever an untimed probe finds faster.
 """
 import argparse
 import json
@@ -74,45 +76,56 @@ def synthetic_batch(c, seed, device):
     return feats, labels
 
 
-def time_dominant_kernel(c, reps=5):
-    """HIP-event timing of the dominant kernel (the layer-1 forward recurrence: the longest serial chain)
-    on its own, on torch's current stream (the stream the library launches on)."""
+KERNEL_NAMES = {        # family (phones_las_amd.hip.KernelTimer) -> kernel symbol(s) in a rocprofv3 trace
+    'lstm_fwd': 'lstm_fwd_kernel<%(H)d, %(rows)d>', 'lstm_bwd': 'lstm_bwd_kernel<%(H)d, %(rows)d>',
+    'dec_persist_fwd': 'dec_persist_fwd_kernel', 'dec_persist_bwd': 'dec_persist_bwd_kernel',
+    'gemm_nt': 'gemm_kernel<..., false, ...> (x K_x, dX, keys, logits)', 'gemm_tn': 'gemm_kernel<..., true, ...> (speller weight gradients)',
+    'gemm_tn_lstm': 'gemm_tn_tr_kernel + tn_reduce_kernel (dK_x, dK_h, db of a direction)',
+}
+
+
+def kernel_table(step_fn, c, steps=3):
+    """Per-kernel-family time of `steps` eagerly launched train steps, HIP events around every launch on the stream it is
+    launched on (weight-gradient products: the second stream).  Returns a list of dicts sorted by ms per step."""
     from phones_las_amd import hip
-    from phones_las_amd.las import ops
-    B, T, H = c['B'], c['T'], c['H']
-    dev = 'cuda'
-    xproj0 = torch.randn(B, T, 8 * H, device=dev) * 0.5
-    khp = (torch.randn(2, H * 4 * H, device=dev) * 0.05).to(torch.bfloat16)
-    length = torch.full((B,), T, dtype=torch.int32, device=dev)
-    y = torch.empty(B, T, 2 * H, dtype=torch.bfloat16, device=dev)
-    cbuf = torch.empty(B, T, 2 * H, device=dev)
-    cl = torch.empty(2, B, H, device=dev)
-    hl = torch.empty(2, B, H, device=dev)
-    ws = ops.lstm_workspace(B, H, 2)
-    lib = hip.lib()
-    times = []
-    for i in range(reps + 1):
-        xproj = xproj0.clone()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        hip.check(lib.las_lstm_recurrent_fwd(hip.p(xproj), hip.p(khp), hip.p(length), hip.p(y), hip.p(cbuf), hip.p(cl),
-                                             hip.p(hl), hip.p(ws), B, T, H, 2, hip.stream()))
-        e1.record()
-        e1.synchronize()
-        if i:
-            times.append(e0.elapsed_time(e1))
-    ops.check_lstm_status(B, H, 2)
-    ms = sum(times) / len(times)
-    flops = B * T * 2 * 2 * H * 4 * H          # recurrent GEMM h_{t-1} K_h of both directions
-    return ms, flops
+    step_fn()
+    torch.cuda.synchronize()
+    with hip.KernelTimer() as kt:
+        for _ in range(steps):
+            step_fn()
+    rows = hip.lib().las_lstm_slice_rows(c['B'], c['H'], 2)
+    out = []
+    for fam, (n, ms, flops) in kt.table().items():
+        ms_step = ms / steps
+        name = KERNEL_NAMES.get(fam, fam)
+        out.append({'name': name % dict(H=c['H'], rows=rows) if '%(' in name else name, 'family': fam, 'launches_per_step': n // steps, 'ms_per_step': round(ms_step, 4),
+                    'algorithmic_flops': flops / steps,
+                    'tflops': round(flops / steps / (ms_step * 1e-3) / 1e12, 2) if ms_step > 0 else None,
+                    'frac': round(flops / steps / (ms_step * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 5) if ms_step > 0 else None})
+    out.sort(key=lambda r: -r['ms_per_step'])
+    return out
 
 
-def cpu_baseline(c, sample_b=32, threads=None):
-    """The oracle (a CPU port of the reference's per-time-step graph; TF 1.15 itself cannot run here) timed in
-    fp32 on the host cores for ONE train step over `sample_b` utterances of the same shape."""
-    from oracle import las_oracle as O
-    # the per-time-step ops are small: more threads than ~16 only add synchronisation cost
-    threads = threads or min(os.cpu_count(), 16)
+def pmc_traffic(family):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (scripts/gpu_pmc.sh ->
+    profiles/r02_pmc_traffic.json; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950).  Counters cannot be
+    read from inside this process: null when no committed pass names this kernel family."""
+    path = os.path.join(ROOT, 'profiles', 'r02_pmc_traffic.json')
+    if not os.path.exists(path):
+        return None, None
+    d = json.load(open(path))
+    k = d.get('kernels', {}).get(family)
+    return (k['traffic_bytes_per_launch'], os.path.relpath(path, ROOT)) if k else (None, None)
+
+
+def cpu_baseline(c, sample_b=16, fused_b=64, threads=None):
+    """The reference's CPU path timed on this host next to the GPU number.  TensorFlow 1.15 cannot run here, so two
+    stated stand-ins, both one full fp32 train step (fwd + autograd bwd + clip + Adam) on a
+    bounded sample of the same workload: (i) the oracle's step-wise restatement (one matmul + element-wise ops per time
+    step, the structure of dynamic_rnn / dynamic_decode) and (ii) the same step with the listener on torch.nn.LSTM's
+    fused kernel (oracle/fused_cpu.py).  The faster one is quoted as `value`."""
+    from oracle import las_oracle as O, fused_cpu
+    threads = threads or min(os.cpu_count(), 16)      # per-time-step ops are small: more threads only add synchronisation
     torch.set_num_threads(threads)
     O.set_dtype(torch.float32)
     try:
@@ -120,18 +133,61 @@ def cpu_baseline(c, sample_b=32, threads=None):
                   decoder=O.DecoderHP(num_layers=1, num_units=c['Hd'], target_vocab_size=c['V'],
                                       attention_type=c['att'], bottom_only=True, pass_hidden_state=True))
         params = {k: v.float() for k, v in O.init_params(hp).items()}
-        batch = O.synthetic_batch(sample_b, c['T'], c['F'], c['V'], c['U'])
-        batch['encoder_inputs'] = batch['encoder_inputs'].float()
-        t0 = time.time()
-        out = O.train_step(hp, params, None, None, 1, batch)
         zeros = {k: torch.zeros_like(v) for k, v in params.items()}
-        O.adam_apply(params, zeros, zeros, out['clipped'], 1, 1e-3)
-        dt = time.time() - t0
+
+        def run(fn, b):
+            batch = O.synthetic_batch(b, c['T'], c['F'], c['V'], c['U'])
+            batch['encoder_inputs'] = batch['encoder_inputs'].float()
+            t0 = time.time()
+            out = fn(batch)
+            O.adam_apply(params, zeros, zeros, out['clipped'], 1, 1e-3)
+            return time.time() - t0
+
+        dt_i = run(lambda b: O.train_step(hp, params, None, None, 1, b), sample_b)
+        run(lambda b: fused_cpu.train_step_fused(hp, params, b), min(8, fused_b))       # primitive creation, untimed
+        dt_ii = run(lambda b: fused_cpu.train_step_fused(hp, params, b), fused_b)
     finally:
         O.set_dtype(torch.float64)
-    return {'value': round(sample_b / dt, 4), 'unit': 'utterances/s', 'cores': threads, 'kind': 'port',
-            'sample': '1 full train step (fwd+bwd+clip+Adam) on %d utterances of T=%d, fp32 torch-CPU oracle, %.1f s'
-                      % (sample_b, c['T'], dt)}
+    v_i, v_ii = sample_b / dt_i, fused_b / dt_ii
+    return {'value': round(max(v_i, v_ii), 4), 'unit': 'utterances/s', 'cores': threads, 'kind': 'port',
+            'step_wise_utt_s': round(v_i, 4), 'fused_lstm_utt_s': round(v_ii, 4),
+            'sample': 'one full fp32 train step (fwd+bwd+clip+Adam) of the same model on T=%d utterances, torch-CPU stand-ins '
+                      'for TF 1.15: (i) step-wise oracle on %d utterances %.1f s, (ii) fused torch.nn.LSTM listener on %d '
+                      'utterances %.1f s; value = the faster' % (c['T'], sample_b, dt_i, fused_b, dt_ii)}
+
+
+def launcher_command(argv, gpus, port):
+    """The command `bench.py --gpus N` runs when it has to start its own ranks (no WORLD_SIZE in the environment)."""
+    return [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(gpus),
+            '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + list(argv)
+
+
+def free_port():
+    import socket
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        return sk.getsockname()[1]
+
+
+def self_launch(argv, gpus):
+    """Start the ranks as a child torch.distributed.run and relay its stdout; rank 0's JSON line is printed last.  This
+    process never initialises a GPU (the children own them); a failing child makes the exit code non-zero."""
+    import subprocess
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')          # dmabuf IPC: what RCCL needs on this host driver
+    proc = subprocess.Popen(launcher_command(argv, gpus, free_port()), stdout=subprocess.PIPE, env=env, text=True)
+    last_json = None
+    for line in proc.stdout:
+        t = line.strip()
+        if t.startswith('{') and '"metric"' in t:
+            last_json = t                       # held back: printed as the very last line
+        else:
+            sys.stdout.write(line)
+    rc = proc.wait()
+    sys.stdout.flush()
+    if last_json is not None:
+        print(last_json, flush=True)
+    return rc if rc else (0 if last_json is not None else 1)
 
 
 def main():
@@ -144,12 +200,19 @@ def main():
     ap.add_argument('--launch', default='auto', choices=['auto', 'graph'],
                     help="auto: an untimed probe picks graph replay or eager launches, whichever is faster; graph: always replay")
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--dp-overlap', action='store_true',
-                    help='exchange the gradients in two buckets, the first one beside the lower layers\' backward '
-                         '(with --gpus 1 the all-reduces run on a 1-rank RCCL group: plumbing check)')
-    ap.add_argument('--cpu-sample', type=int, default=32)
+    ap.add_argument('--dp-overlap', nargs='?', const='on', default='auto', choices=['auto', 'on', 'off'],
+                    help="gradient exchange in two buckets, the first one beside the lower layers' backward.  auto (default): "
+                         "with more than one rank an untimed probe picks the faster of the overlapped and the plain exchange; "
+                         "off with one rank.  on with --gpus 1: the all-reduces run on a 1-rank RCCL group (plumbing check)")
+    ap.add_argument('--dp-test-group', action='store_true',
+                    help='--gpus 1 only: run the multi-rank code path (clip, all-reduce, Adam; the overlap probe) on a 1-rank RCCL group')
+    ap.add_argument('--cpu-sample', type=int, default=16)
     args = ap.parse_args()
     c = CONFIGS[args.config]
+
+    if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
+        # started bare (`python bench.py --gpus N`): become the launcher.  Nothing in this process has touched a GPU.
+        raise SystemExit(self_launch(sys.argv[1:], args.gpus))
 
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
@@ -157,24 +220,25 @@ def main():
     if rank != 0:
         os.dup2(2, 1)          # only rank 0 owns stdout (one JSON line, last); library banners of the others go to stderr
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit('bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d'
-                             % (args.gpus, args.gpus))
+        raise SystemExit('bench.py --gpus %d inside a job of WORLD_SIZE %d' % (args.gpus, world))
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
+    group = None
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         torch.distributed.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
-
-    from phones_las_amd import model_helper as mh
-    group = None
-    if args.dp_overlap and world == 1:          # plumbing check on one GPU: the exchange runs on a 1-rank RCCL group
+    elif args.dp_overlap == 'on' or args.dp_test_group:     # plumbing check on one GPU: a 1-rank RCCL group
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        os.environ.setdefault('MASTER_PORT', '29517')
+        os.environ.setdefault('MASTER_PORT', str(free_port()))
         torch.distributed.init_process_group('nccl', rank=0, world_size=1, device_id=dev)
         group = torch.distributed.group.WORLD
-    model = mh.LasModel(build_params(c), world_size=world, process_group=group)
-    overlap_exchange = bool(args.dp_overlap) and len(model.enable_exchange_overlap()) == 2
+    multi = world > 1 or args.dp_test_group       # the data-parallel form of the step: clip, exchange, Adam
+    rccl_ranks = torch.distributed.get_world_size() if torch.distributed.is_initialized() else 1
+
+    from phones_las_amd import model_helper as mh
+    model = mh.LasModel(build_params(c), world_size=world, process_group=group, rank=rank)
+    want_overlap = args.dp_overlap == 'on' or (args.dp_overlap == 'auto' and multi)
+    overlap_exchange = want_overlap and len(model.enable_exchange_overlap()) == 2
     feats, labels = synthetic_batch(c, 1234 + rank, dev)
     feats['encoder_inputs'] = model.listener.pad_features(feats['encoder_inputs'])   # resident bf16 [B,T,F'] batch
     U = c['U']
@@ -184,22 +248,24 @@ def main():
         model.vars.grad.zero_()
         audio, _, dlogits = model.forward_train(feats, labels, num_steps=U)
         model.backward(dlogits)
-        if world > 1:
+        model.collect_status()        # timeout flag of the persistent kernels: travels with the gradients, gates Adam
+        if multi:
             model.clip_gradients()
         else:
             model.gradient_norms()
         loss_buf.copy_(audio + model.l2_loss(from_norms=True))
 
     def part_b():     # (clip +) Adam + refresh of the bf16 weight images
-        if world > 1:
+        if multi:
             model.adam_update()
         else:
             model.clip_adam_update()
         model.refresh_images()
+        model.global_step += 1        # eager steps draw fresh dropout / sampling streams; a captured graph keeps its seed
 
     def reduce():
-        if world > 1 or group is not None:
-            torch.distributed.all_reduce(model.vars.grad)
+        if multi:
+            model.all_reduce_gradients()
 
     # --dp-overlap: the exchange in two buckets, the first one (top listener layer + speller) handed to RCCL while the
     # lower layers' backward is still running: three graphs with the asynchronous all-reduces between them
@@ -216,6 +282,7 @@ def main():
     def part_b_dp():
         model.adam_update()
         model.refresh_images()
+        model.global_step += 1
 
     # eager warm-up on a side stream (also what graph capture needs)
     s = torch.cuda.Stream()
@@ -225,7 +292,29 @@ def main():
     torch.cuda.current_stream().wait_stream(s)
     torch.cuda.synchronize()
 
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    def probe(fn, n=8):
+        """Untimed (not part of `value`) wall time of n steps; every rank gets the slowest rank's time, so all agree."""
+        fn(); barrier()
+        t_ = time.perf_counter()
+        for _ in range(n):
+            fn()
+        barrier()
+        t_ = time.perf_counter() - t_
+        if world > 1:
+            tt = torch.tensor([t_], device=dev, dtype=torch.float64)
+            torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
+            t_ = float(tt[0])
+        return t_
+
     audio_buf = torch.zeros(1, device=dev)
+    candidates = {}          # name -> (step function, uses graphs, overlapped exchange)
+    want_graph = not args.no_graph
+    want_eager = args.no_graph or args.launch == 'auto'
     if overlap_exchange:
         b0, b1 = model.vars.buckets
         s.wait_stream(torch.cuda.current_stream())
@@ -233,9 +322,19 @@ def main():
             part_a1(); part_a2(); part_b_dp()
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
-        if args.no_graph:
-            run_a1, run_a2, run_b = part_a1, part_a2, part_b_dp
-        else:
+
+        def overlapped(run_a1, run_a2, run_b):
+            def step():
+                run_a1()
+                w0 = model.all_reduce_gradients(b0, async_op=True)
+                run_a2()
+                w1 = model.all_reduce_gradients(b1, async_op=True)
+                w0.wait(); w1.wait()
+                run_b()
+            return step
+        if want_eager:
+            candidates['overlap_eager'] = (overlapped(part_a1, part_a2, part_b_dp), False, True)
+        if want_graph:
             g1, g2, g3 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
             with torch.cuda.graph(g1):
                 part_a1()
@@ -243,57 +342,37 @@ def main():
                 part_a2()
             with torch.cuda.graph(g3, pool=g1.pool()):
                 part_b_dp()
-            run_a1, run_a2, run_b = g1.replay, g2.replay, g3.replay
-
-        def step():
-            run_a1()
-            w0 = model.all_reduce_gradients(b0, async_op=True)
-            run_a2()
-            w1 = model.all_reduce_gradients(b1, async_op=True)
-            w0.wait(); w1.wait()
-            run_b()
-    elif args.no_graph:
-        def step():
-            part_a(); reduce(); part_b()
-    else:
-        ga, gb = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-        with torch.cuda.graph(ga):
-            part_a()
-        with torch.cuda.graph(gb):
-            part_b()
-
-        def step_graph():
-            ga.replay(); reduce(); gb.replay()
-
+            candidates['overlap_graph'] = (overlapped(g1.replay, g2.replay, g3.replay), True, True)
+    if not overlap_exchange or args.dp_overlap == 'auto':
+        # the plain step: one all-reduce of the flat gradient buffer between the backward pass and Adam
         def step_eager():
             part_a(); reduce(); part_b()
+        if want_eager:
+            candidates['plain_eager'] = (step_eager, False, False)
+        if want_graph:
+            ga, gb = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+            with torch.cuda.graph(ga):
+                part_a()
+            with torch.cuda.graph(gb):
+                part_b()
 
-        step = step_graph
+            def step_graph():
+                ga.replay(); reduce(); gb.replay()
+            candidates['plain_graph'] = (step_graph, True, False)
 
-    def barrier():
-        if world > 1:
-            torch.distributed.barrier()
-        torch.cuda.synchronize()
-
-    used_graph = not args.no_graph
-    if not args.no_graph and not overlap_exchange and args.launch == 'auto':
-        # The step has about 130 launches.  Replaying them as HIP graphs takes the host out of the picture; launching them
-        # eagerly lets the host run ahead of the GPU, which is a little faster when the host is quick and idle (graph
-        # nodes carry a fixed cost).  Untimed probe of both, the faster one runs the timed steps; ranks agree on it.
-        def probe(fn, n=8):
-            fn(); barrier()
-            t_ = time.perf_counter()
-            for _ in range(n):
-                fn()
-            barrier()
-            return time.perf_counter() - t_
-        tg, te = probe(step_graph), probe(step_eager)
-        if world > 1:
-            tt = torch.tensor([tg, te], device=dev, dtype=torch.float64)
-            torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
-            tg, te = float(tt[0]), float(tt[1])
-        if te < 0.995 * tg:
-            step, used_graph = step_eager, False
+    # The step has about 130 launches.  Replaying them as HIP graphs takes the host out of the picture; launching them
+    # eagerly lets the host run ahead of the GPU, which is a little faster when the host is quick and idle (graph nodes
+    # carry a fixed cost).  With several ranks the exchange beside the backward pass may or may not pay (RCCL's kernels
+    # share the chip with the persistent recurrent kernels).  An untimed probe of every candidate form picks the fastest
+    # for the timed steps; the ranks agree on it (max over ranks).
+    probed = {}
+    if len(candidates) > 1:
+        for name in sorted(candidates):
+            probed[name] = probe(candidates[name][0])
+        chosen = min(sorted(probed), key=lambda n: probed[n])
+    else:
+        chosen = next(iter(candidates))
+    step, used_graph, used_overlap = candidates[chosen]
 
     for _ in range(args.warmup):
         step()
@@ -314,12 +393,14 @@ def main():
         ms = dt / args.steps * 1e3
         utt_s = c['B'] * world * args.steps / dt
         f_in, f_rec = lstm_gemm_flops_per_utt(c)
-        kms, kflops = time_dominant_kernel(c)
-        traffic = None
-        pmc = os.path.join(ROOT, 'profiles', 'r01_pmc_traffic.json')
-        if args.config == 'metric-M' and os.path.exists(pmc):
-            traffic = json.load(open(pmc))['traffic_bytes']        # PMC passes of the same kernel (scripts/gpu_pmc.sh)
-        achieved = kflops / (kms * 1e-3) / 1e12
+        # per-kernel times of the same step, launched eagerly with HIP events around every launch (after the timed region,
+        # so `value` is not perturbed); the dominant kernel = the family with the largest time per step
+        eager = candidates.get('overlap_eager' if used_overlap else 'plain_eager')
+        if eager is None:
+            eager = (overlapped(part_a1, part_a2, part_b_dp) if used_overlap else (lambda: (part_a(), reduce(), part_b())), False, used_overlap)
+        kernels = kernel_table(eager[0], c)
+        dom = kernels[0]
+        traffic, traffic_src = pmc_traffic(dom['family'])
         step_tflops = 3 * (f_in + f_rec) * utt_s / world / 1e12
         out = {
             'metric': 'utterances/s LAS train step (B=64 per GPU, T=800, F=40)', 'value': round(utt_s, 2),
@@ -329,20 +410,24 @@ def main():
             'config': {'workload': '%s: %d-layer pBiLSTM-%d + %s attention + 1x%d LSTM decoder, V=%d, U=%d, dense '
                                    'T=%d, F=%d, full train step' % (args.config, c['L'], c['H'], c['att'], c['Hd'],
                                                                     c['V'], c['U'], c['T'], c['F']),
-                       'global_batch': c['B'] * world, 'parallelism': 'dp%d' % world,
-                       'hip_graph': used_graph, 'exchange': 'two buckets, overlapped' if overlap_exchange else 'one all-reduce',
+                       'global_batch': c['B'] * world, 'parallelism': 'dp%d' % world, 'rccl_ranks': rccl_ranks,
+                       'hip_graph': used_graph, 'exchange': 'two buckets, overlapped' if used_overlap else 'one all-reduce',
+                       'step_form': chosen, 'probe_s': {k: round(v, 4) for k, v in probed.items()},
+                       'stochastic_draws': 'fresh every step' if not (c.get('dropout') or c.get('sampling')) or not used_graph
+                                           else 'frozen at capture (graph replay)',
                        'final_loss': round(final_loss, 4)},
-            'roofline': {'bound': 'mfma', 'kernel': 'lstm_fwd_kernel<%d, %d> (layer-1 shape, both directions)' % (
-                             c['H'], __import__('phones_las_amd.hip', fromlist=['lib']).lib().las_lstm_slice_rows(c['B'], c['H'], 2)),
-                         'achieved': round(achieved, 3), 'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s',
-                         'frac': round(achieved / PEAK_BF16_TFLOPS, 6), 'traffic': traffic,
-                         'kernel_ms': round(kms, 3),
+            'roofline': {'bound': 'mfma', 'kernel': dom['name'],
+                         'achieved': dom['tflops'], 'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s',
+                         'frac': dom['frac'], 'traffic': traffic, 'traffic_source': traffic_src,
+                         'kernel_ms_per_step': dom['ms_per_step'], 'launches_per_step': dom['launches_per_step'],
+                         'algorithmic_flops_per_step': dom['algorithmic_flops'],
+                         'kernels': kernels,
                          'whole_step_lstm_gemm_tflops_per_gpu': round(step_tflops, 3),
                          'whole_step_frac': round(step_tflops / PEAK_BF16_TFLOPS, 6)},
         }
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(c, args.cpu_sample)
-    if world > 1 or group is not None:
+    if torch.distributed.is_initialized():
         torch.cuda.synchronize()
         torch.distributed.destroy_process_group()
     if rank == 0:

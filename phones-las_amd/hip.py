@@ -129,6 +129,52 @@ ATT_MONOTONIC = (ATT_LUONG_MONOTONIC, ATT_BAHDANAU_MONOTONIC)
 DEC_FUSED, DEC_CELL_ONLY, DEC_ATTENTION_ONLY = 0, 1, 2
 
 
+# ---------------------------------------------------------------------------------------------
+# optional per-kernel timing with HIP events on the launching stream (bench.py's roofline table)
+# ---------------------------------------------------------------------------------------------
+_prof = None
+
+
+class KernelTimer:
+    """with KernelTimer() as kt: ... enqueue steps ...; kt.table() -> {family: (launches, ms, flops)} after a device
+    synchronise.  Each timed launch is bracketed by two events on the stream it is launched on (torch's current stream
+    at the call), so launches on the second stream are timed on that stream."""
+
+    def __enter__(self):
+        global _prof
+        self.records = []
+        self.outer, _prof = _prof, self
+        return self
+
+    def __exit__(self, *exc):
+        global _prof
+        _prof = self.outer
+        return False
+
+    def table(self):
+        torch.cuda.synchronize()
+        out = {}
+        for name, flops, e0, e1 in self.records:
+            n, ms, fl = out.get(name, (0, 0.0, 0.0))
+            out[name] = (n + 1, ms + e0.elapsed_time(e1), fl + flops)
+        return out
+
+
+def prof_begin(name, flops):
+    if _prof is None:
+        return None
+    e0 = torch.cuda.Event(enable_timing=True)
+    e0.record()
+    return (name, float(flops), e0)
+
+
+def prof_end(tok):
+    if tok is not None:
+        e1 = torch.cuda.Event(enable_timing=True)
+        e1.record()
+        _prof.records.append(tok + (e1,))
+
+
 def addr(t, offset_elems=0):
     """Raw device address (int) of tensor ``t`` advanced by ``offset_elems`` elements; None -> 0."""
     if t is None:
@@ -193,8 +239,10 @@ def gemm_nt(A, B, C_, M, N, K, lda=None, ldb=None, ldc=None, bias=None, out_bf16
     lda = lda if lda is not None else A.stride(-2)
     ldb = ldb if ldb is not None else B.stride(-2)
     ldc = ldc if ldc is not None else C_.stride(-2)
+    tok = prof_begin('gemm_nt', 2.0 * M * N * K * batch)
     check(lib().las_gemm_nt(p(A), lda, p(B), ldb, p(C_), ldc, p(bias), M, N, K, int(out_bf16), int(accumulate),
                             batch, sa, sb, sc, split_k, stream()))
+    prof_end(tok)
 
 
 def gemm_tn(A, B, C_, M, N, K, lda=None, ldb=None, ldc=None, a_shift=0, period=0, batch=1, sa=0, sb=0, sc=0,
@@ -202,8 +250,10 @@ def gemm_tn(A, B, C_, M, N, K, lda=None, ldb=None, ldc=None, a_shift=0, period=0
     lda = lda if lda is not None else A.stride(-2)
     ldb = ldb if ldb is not None else B.stride(-2)
     ldc = ldc if ldc is not None else C_.stride(-2)
+    tok = prof_begin('gemm_tn', 2.0 * M * N * K * batch)
     check(lib().las_gemm_tn(p(A), lda, p(B), ldb, p(C_), ldc, M, N, K, a_shift, period, c_perm_h, batch, sa, sb, sc,
                             split_k, stream()))
+    prof_end(tok)
 
 
 class ImageJob(C.Structure):

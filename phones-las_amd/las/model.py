@@ -328,7 +328,10 @@ class Speller:
                 p.teacher, p.teacher_stride = hip.addr(tin), tin.stride(0)
                 p.wprojT, p.ldw, p.bproj = hip.addr(self.wprojT), M, hip.addr(self.bproj)
                 p.logits, p.ld_logits, p.plog, p.V, p.Vp = 0, U * Vp, hip.addr(plog), V, Vp
+            # per step and utterance: the cell product [attention, h] K, the scores and the context
+            tok = hip.prof_begin('dec_persist_fwd', 2.0 * U * B * (W * 4 * Hd + Tm * Hd + Tm * M))
             hip.check(lib.las_decoder_persist_fwd(C.byref(p), st))
+            hip.prof_end(tok)
             self._persist_ws = ws
             logits = None                # the launch only forms the logits it samples from; all of them come from one GEMM below
         for t in range(0 if not persist else U, U):
@@ -414,7 +417,10 @@ class Speller:
             dfeed_all = torch.empty(1, B, W, dtype=f32, device=dev)      # only step 0's row leaves the launch: d(initial feed)
             ws = self._persist_workspace('bwd', lib.las_decoder_persist_workspace_bytes(B, Tm, Hd, M))
             p.dfeed_all, p.workspace = hip.addr(dfeed_all), hip.addr(ws)
+            # per step and utterance: dz K^T, d(align) = values . d(context), the d(query) sum over the keys
+            tok = hip.prof_begin('dec_persist_bwd', 2.0 * U * B * (W * 4 * Hd + Tm * Hd + Tm * M))
             hip.check(lib.las_decoder_persist_bwd(C.byref(p), st))
+            hip.prof_end(tok)
             self._persist_ws_bwd = ws
             dfeed = dfeed_all[0]
         for t in range(U - 1 if not persist else -1, -1, -1):

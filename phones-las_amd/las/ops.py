@@ -186,9 +186,11 @@ def bilstm(inputs, sequence_length, num_units, dropout, mode, unidirectional=Fal
     cbuf = torch.empty(B, T, nd * H, dtype=torch.float32, device=dev)
     c_last = torch.empty(nd, B, H, dtype=torch.float32, device=dev)
     h_last = torch.empty(nd, B, H, dtype=torch.float32, device=dev)
+    tok = hip.prof_begin('lstm_fwd', 2.0 * B * T * nd * H * 4 * H)       # the recurrent product h_{t-1} K_h of every step
     hip.check(hip.lib().las_lstm_recurrent_fwd(hip.p(xproj), hip.p(weights.khp), hip.p(sequence_length), hip.p(y),
                                                hip.p(cbuf), hip.p(c_last), hip.p(h_last),
                                                hip.p(lstm_workspace(B, H, nd)), B, T, H, nd, hip.stream()))
+    hip.prof_end(tok)
     if tape is not None:
         tape.append(dict(kind='bilstm', inputs=inputs, length=sequence_length, gates=xproj, cbuf=cbuf, y=y,
                          weights=weights, B=B, T=T, H=H, D=D, Dp=Dp, nd=nd, dropped=dropped, keep=keep, rng=rng,
@@ -220,9 +222,11 @@ def bilstm_backward(rec, dy, d_state, grads, need_dx=True, overlap=None, defer_w
     dev = dy.device
     dz = torch.empty(B, T, nd * 4 * H, dtype=torch.bfloat16, device=dev)
     dc_last, dh_last = d_state if d_state is not None else (None, None)
+    tok = hip.prof_begin('lstm_bwd', 2.0 * B * T * nd * H * 4 * H)       # dh_{t-1} = dz_t K_h^T of every step
     hip.check(hip.lib().las_lstm_recurrent_bwd(hip.p(rec['gates']), hip.p(rec['cbuf']), hip.p(dy), hip.p(dc_last),
                                                hip.p(dh_last), hip.p(w.kh), hip.p(rec['length']), hip.p(dz),
                                                hip.p(lstm_workspace(B, H, nd)), B, T, H, nd, hip.stream()))
+    hip.prof_end(tok)
     x, y = rec['inputs'], rec['y']
     BT = B * T
     # critical path first: dX feeds the next (lower) layer's recurrence
@@ -276,9 +280,11 @@ def bilstm_backward(rec, dy, d_state, grads, need_dx=True, overlap=None, defer_w
                     ws = getattr(w, '_tn_ws', None)
                     if ws is None or ws.numel() * 4 < need:
                         ws = w._tn_ws = torch.empty(max(1, need // 4), dtype=torch.float32, device=dev)
+                    tok = hip.prof_begin('gemm_tn_lstm', 2.0 * (D + H + 1) * 4 * H * BT)
                     hip.check(hip.lib().las_gemm_tn_lstm(hip.p(xa) if D > 0 else None, lda, D, hip.p(yi), nd * H, H,
                                                          (-1 if i == 0 else 1), T, hip.p(dzi), nd * 4 * H, hip.p(gk), hip.p(gb),
                                                          BT, split, hip.p(ws), hip.stream()))
+                    hip.prof_end(tok)
                     continue
                 if D > 0:
                     hip.gemm_tn(xa, dzi, gk, D, 4 * H, BT, lda=lda, ldb=nd * 4 * H, ldc=4 * H, split_k=split, c_perm_h=H)

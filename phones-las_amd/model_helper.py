@@ -132,6 +132,16 @@ class Variables:
             self.buckets = [self._bucket(first_of_last, n, 0), self._bucket(0, first_of_last, 1)]
         return self.buckets
 
+    def exchange_view(self, bucket=None):
+        """The piece of the gradient storage that is all-reduced for `bucket` (None: everything).  The timeout flag in
+        front of the gradients travels with the piece that starts at element 0 -- of two buckets the LAST to leave, so
+        the flag covers every kernel of the step."""
+        if bucket is None:
+            return self.grad_store
+        if bucket['begin'] == 0:
+            return self.grad_store[:4 + bucket['end']]
+        return self.grad[bucket['begin']:bucket['end']]
+
     def _views(self, flat):
         d = collections.OrderedDict()
         for (name, shape, _), o in zip(self.table, self.offsets):
@@ -375,14 +385,7 @@ class LasModel:
         waits on it before the Adam update), so that the rest of the backward pass runs beside the exchange."""
         if self.world_size <= 1 and self.process_group is None:
             return None
-        v = self.vars
-        # the flag in front of the buffer travels with the piece that starts at element 0 (the last one to leave)
-        if bucket is None:
-            flat = v.grad_store
-        elif bucket['begin'] == 0:
-            flat = v.grad_store[:4 + bucket['end']]
-        else:
-            flat = v.grad[bucket['begin']:bucket['end']]
+        flat = self.vars.exchange_view(bucket)
         if async_op:
             return torch.distributed.all_reduce(flat, group=self.process_group, async_op=True)
         dp.all_reduce_sum_(flat, self.process_group)

@@ -82,3 +82,51 @@ def test_single_process_is_a_no_op():
     assert dp.world_size() == 1 and dp.rank() == 0
     assert torch.equal(dp.all_reduce_sum_(x.clone()), x)
     assert dp.mean_scalar(3.0) == 3.0
+
+
+def _bucket_worker(rank, world, port, ret):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    torch.set_num_threads(1)
+    from phones_las_amd import dp, model_helper as mh
+    dp.init_from_env(backend='gloo')
+    _, params = make_hparams(F=5, L=3, H=8, V=9)
+    table = mh.param_table(params)
+    res = {}
+    for split in (False, True):
+        v = mh.Variables(table, device='cpu')
+        if split:
+            buckets = v.split_buckets(2 * 4)          # [top listener layer + speller] first, [layers 0..1] second
+            assert len(buckets) == 2 and buckets[1]['begin'] == 0 and buckets[0]['end'] == v.total
+        g = torch.Generator().manual_seed(100 + rank)
+        v.grad.copy_(torch.randn(v.total, generator=g))
+        mine = v.grad.clone()
+        v.skip_flag.fill_(1.0 if rank == 1 else 0.0)          # replica 1's persistent kernels "timed out"
+        for b in (v.buckets if split else [None]):            # bucket order = the order the backward pass completes them
+            dp.all_reduce_sum_(v.exchange_view(b))
+        other = torch.Generator().manual_seed(100 + (1 - rank))
+        want = mine + torch.randn(v.total, generator=other)
+        res[split] = (float((v.grad - want).abs().max()), float(v.skip_flag))
+        # per-tensor views still address the summed values
+        name = table[-1][0]
+        assert torch.equal(v.grads[name].reshape(-1), v.grad[v.offsets[-2]:v.offsets[-2] + v.grads[name].numel()])
+    ret[rank] = res
+    dp.barrier()
+    assert dp.broadcast_int(7 if rank == 0 else 99) == 7
+    assert dp.sum_floats([1.0, rank]) == [2.0, 1.0]
+    dist.destroy_process_group()
+
+
+def test_two_replica_bucket_exchange_carries_the_timeout_flag():
+    """LasModel's exchange pieces (Variables.exchange_view / split_buckets) on two gloo ranks: the whole buffer and the
+    two-bucket form both sum the gradients, and the timeout flag set on ONE replica reaches BOTH (flag > 0 makes every
+    replica's Adam kernel skip the update)."""
+    world = 2
+    port = _free_port()
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_bucket_worker, args=(world, port, ret), nprocs=world, join=True)
+    for r in range(world):
+        for split in (False, True):
+            err, flag = ret[r][split]
+            assert err < 1e-6 and flag == 1.0, (r, split, err, flag)
