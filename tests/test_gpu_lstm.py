@@ -3,7 +3,7 @@ oracle's dynamic_rnn in its bf16 storage model (oracle/las_oracle.py, mxu='bf16'
 
 Tolerances (stated per SURVEY.md §4): forward outputs are bf16 values: |err| <= 2 bf16 ulp of the
 max-abs (1.6e-2 relative) plus fp32-vs-fp64 accumulation; states/gates fp32: 3e-3.  Gradients pass
-through bf16 dz on the device only: 3e-2 of the per-tensor max-abs."""
+through bf16 dz on the device and in the oracle's 'bf16' model alike: 1e-2 of the per-tensor max-abs."""
 import numpy as np
 import pytest
 import torch
@@ -89,8 +89,8 @@ def test_bilstm_forward_backward_vs_oracle(B, T, D, H, lengths, rows, monkeypatc
     torch.cuda.synchronize()
     ops.check_lstm_status(B, H, 2)
     for k in grads:
-        assert _relerr(grads[k], leaf[k].grad) < 3e-2, k
-    assert _relerr(dx, xr.grad) < 3e-2
+        assert _relerr(grads[k], leaf[k].grad) < 1e-2, k
+    assert _relerr(dx, xr.grad) < 1e-2
 
 
 def test_unidirectional_and_pyramid_view():

@@ -2,8 +2,8 @@
 oracle in its bf16 storage model on identical seeded inputs, through the C-ABI (liblas_hip.so).
 
 Stated tolerances: logits/loss 2e-2 of the max-abs (bf16 operands, fp32 accumulate vs float64);
-gradients 5e-2 of the per-tensor max-abs (the device rounds dz/dlogits/d-context to bf16 before its
-GEMMs, the oracle differentiates exactly); optimiser kernels 1e-5 (pure fp32 arithmetic)."""
+gradients 1e-2 of the per-tensor max-abs and 2 % of the squared norm (the oracle's 'bf16' model rounds dz, dlogits,
+d-context, d-score and d-keys to bf16 where the device does); optimiser kernels 1e-5 (pure fp32 arithmetic)."""
 import numpy as np
 import pytest
 import torch
@@ -12,6 +12,7 @@ from tests.helpers import make_hparams, make_batch, to_device, relerr
 
 pytestmark = pytest.mark.gpu
 DT = torch.float64
+GRAD_TOL = 1e-2          # of the per-tensor max-abs, against the oracle with the device's bf16 storage points (fwd + bwd)
 
 
 def _models(att, **kw):
@@ -51,8 +52,8 @@ def test_train_forward_and_gradients_vs_oracle(att):
     torch.cuda.synchronize()
     for i, (name, _, _) in enumerate(v.table):
         g, r = v.grads[name], out['grads'][name]
-        assert relerr(g, r) < 5e-2, name
-        assert abs(float(v.sumsq[i]) - float((r * r).sum())) <= 0.1 * float((r * r).sum()) + 1e-12, name
+        assert relerr(g, r) < 1e-2, name
+        assert abs(float(v.sumsq[i]) - float((r * r).sum())) <= 0.02 * float((r * r).sum()) + 1e-12, name
 
 
 def test_train_step_updates_match_oracle_adam_given_same_grads():
@@ -284,7 +285,7 @@ def test_stacked_non_pyramidal_listener_vs_oracle():
         assert relerr(logits[b, :n, :V], out['aux']['logits'][b, :n]) < 2e-2
     for name, _, _ in model.vars.table:
         g = out['grads'][name] - ohp.l2_reg_scale * op[name]
-        assert relerr(model.vars.grads[name], g) < 5e-2, name
+        assert relerr(model.vars.grads[name], g) < GRAD_TOL, name
 
 
 def test_weight_noise_hits_kernels_only():
@@ -344,7 +345,7 @@ def test_ctc_multitask_train_step_vs_oracle():
     assert abs(float(loss) - ref_audio) < 2e-2 * abs(ref_audio)
     for name, _, _ in model.vars.table:
         g = out['grads'][name] - ohp.l2_reg_scale * op[name]
-        assert relerr(model.vars.grads[name], g) < 6e-2, name
+        assert relerr(model.vars.grads[name], g) < GRAD_TOL, name
 
 
 def test_cfg3_like_512_units_bahdanau_ctc_vs_oracle():
@@ -366,7 +367,7 @@ def test_cfg3_like_512_units_bahdanau_ctc_vs_oracle():
     assert abs(float(loss) - float(out['audio_loss'])) < 2e-2 * float(out['audio_loss'])
     for name, _, _ in model.vars.table:
         g = out['grads'][name] - ohp.l2_reg_scale * op[name]
-        assert relerr(model.vars.grads[name], g) < 6e-2, name
+        assert relerr(model.vars.grads[name], g) < GRAD_TOL, name
 
 
 @pytest.mark.parametrize('kw', [
@@ -392,7 +393,9 @@ def test_general_decoder_configs_vs_oracle(kw):
     assert abs(float(loss) - float(out['aux']['ce'].detach())) < 2e-2 * float(out['aux']['ce'].detach())
     for name, _, _ in model.vars.table:
         g = out['grads'][name] - ohp.l2_reg_scale * op[name]
-        assert relerr(model.vars.grads[name], g) < 6e-2, name
+        # (the general decoder also keeps d(attention) / d(attention-layer input) in bf16 for its weight-gradient products:
+        # not in the oracle's backward model; measured up to 1.3e-2)
+        assert relerr(model.vars.grads[name], g) < 2 * GRAD_TOL, name
     # greedy decode runs and agrees with the oracle on the first step
     (mem, ml), st = O.listener(batch['encoder_inputs'], batch['source_sequence_length'], op, ohp.encoder, 'bf16')
     rl, rids, rfl, _ = O.speller_greedy(ohp, op, mem, ml, st, 'bf16')
@@ -437,7 +440,7 @@ def test_custom_and_monotonic_attention_vs_oracle(kw):
     assert abs(float(loss) - float(out['aux']['ce'].detach())) < 2e-2 * float(out['aux']['ce'].detach())
     for name, _, _ in model.vars.table:
         g = out['grads'][name] - ohp.l2_reg_scale * op[name]
-        assert relerr(model.vars.grads[name], g) < 6e-2, name
+        assert relerr(model.vars.grads[name], g) < GRAD_TOL, name
     # inference: bahdanau_monotonic switches to the 'hard' normaliser (las/model.py:163-164)
     (mem, ml), st = O.listener(batch['encoder_inputs'], batch['source_sequence_length'], op, ohp.encoder, 'bf16')
     rl, rids, rfl, _ = O.speller_greedy(ohp, op, mem, ml, st, 'bf16')
@@ -493,7 +496,7 @@ def test_binf_projection_decoder_vs_oracle(kw):
     assert abs(float(loss) - ref_audio) < 2e-2 * abs(ref_audio)
     for name, _, _ in model.vars.table:
         g = out['grads'][name] - ohp.l2_reg_scale * op[name]
-        assert relerr(model.vars.grads[name], g) < 6e-2, name
+        assert relerr(model.vars.grads[name], g) < GRAD_TOL, name
     (mem, ml), st = O.listener(batch['encoder_inputs'], batch['source_sequence_length'], op, ohp.encoder, 'bf16')
     rl, rids, rfl, _ = O.speller_greedy(ohp, op, mem, ml, st, 'bf16')
     pred = model.predict(feats)
@@ -595,7 +598,7 @@ def test_persistent_decoder_vs_per_step_and_oracle(att, monkeypatch):
         assert relerr(outs['1'][1][b, :n, :V], out['aux']['logits'][b, :n]) < 2e-2
     for name, _, _ in model.vars.table:
         g = out['grads'][name] - ohp.l2_reg_scale * op[name]
-        assert relerr(outs['1'][2][name], g) < 6e-2, name
+        assert relerr(outs['1'][2][name], g) < GRAD_TOL, name
 
 
 @pytest.mark.parametrize('B,T,U,src_len,tgt_len', [
@@ -723,3 +726,58 @@ def test_timeout_status_is_sticky_and_blocks_the_update():
     assert float(model.vars.skip_flag) == 1.0
     with pytest.raises(hip.LasError):
         model.check_device_status()
+
+
+@pytest.mark.parametrize('att', ['luong', 'bahdanau'])
+def test_full_greedy_decode_and_eval_loss_vs_oracle_on_trained_weights(att):
+    """PREDICT / EVAL parity beyond the first step (las/model.py:337-347, model_helper.py:54-76): the model is first
+    trained on the device for 150 steps on one batch (random-initialised weights decode one dull token with argmax margins
+    below the bf16 noise), the trained weights go to the oracle, and the FREE-RUNNING greedy decode is compared step by
+    step: sample ids exactly, final_sequence_length exactly, alignments and logits within 2e-2, and the EVAL loss with its
+    pad-to-the-longer rule against O.compute_loss_eval.  A step whose oracle margin (top-1 minus top-2 logit) is below 0.05
+    ends the comparison of that utterance (a flip there changes every later input); at least 60 % of all steps and two whole
+    utterances must be compared (measured: 78 % / 3 of 5 with the margin at 0.1)."""
+    O, ohp, op, model = _models(att, lr=1e-2)
+    src_len, tgt_len = [24, 9, 17, 24, 12], [6, 4, 5, 6, 3]
+    batch = make_batch(B=5, T=24, src_len=src_len, tgt_len=tgt_len)
+    feats, labels = to_device(batch)
+    first = last = None
+    for i in range(150):
+        last = float(model.train_step(feats, labels))
+        first = last if first is None else first
+    assert last < 0.5 * first, (first, last)
+    model.check_device_status()
+    trained = {n: t.detach().double().cpu() for n, t in model.vars.params.items()}
+    (mem, ml), st = O.listener(batch['encoder_inputs'], batch['source_sequence_length'], trained, ohp.encoder, 'bf16')
+    rl, rids, rfl, sp = O.speller_greedy(ohp, trained, mem, ml, st, 'bf16')
+    ralign = torch.stack(sp.align_hist, 1)
+    loss, ed, pred = model.evaluate(feats, labels)
+    torch.cuda.synchronize()
+    ids, fl = pred['sample_ids'].cpu().long(), pred['final_sequence_length'].cpu().long()
+    lg, al = pred['logits'].double().cpu(), pred['alignment'].double().cpu()
+    top2 = rl.topk(2, -1).values
+    margin = top2[..., 0] - top2[..., 1]
+    compared = total = whole = 0
+    scale = float(rl.abs().max())
+    for b in range(5):
+        n = int(rfl[b])
+        total += n
+        ok = True
+        for t in range(n):
+            if float(margin[b, t]) < 0.05:
+                ok = False
+                break
+            assert t < ids.shape[1] and int(ids[b, t]) == int(rids[b, t]), (b, t, ids[b].tolist(), rids[b].tolist())
+            assert float((lg[b, t] - rl[b, t]).abs().max()) < 2e-2 * scale, (b, t)
+            assert float((al[b, t, :ralign.shape[-1]] - ralign[b, t]).abs().max()) < 2e-2, (b, t)
+            compared += 1
+        if ok:
+            whole += 1
+            assert int(fl[b]) == n, (b, int(fl[b]), n)
+    assert compared >= 0.6 * total and whole >= 2, (compared, total, whole)
+    assert len({tuple(r) for r in rids.tolist()}) >= 3           # the trained model decodes different sequences
+    if whole == 5 and ids.shape[1] == rids.shape[1]:
+        ref_loss = O.compute_loss_eval(rl, batch['targets_outputs'], rfl, batch['target_sequence_length'])
+        assert abs(float(loss) - float(ref_loss)) < 2e-2 * abs(float(ref_loss)), (float(loss), float(ref_loss))
+        red = O.edit_distance(rids.tolist(), batch['targets_outputs'].tolist())
+        assert np.allclose(ed, red)

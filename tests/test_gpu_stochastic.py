@@ -62,7 +62,7 @@ def test_dropout_forward_backward_replayed_through_oracle():
     stoch = {'enc_masks': enc_masks, 'dec_masks': [dm[t] for t in range(U)]}
     out = O.train_step(ohp, op, None, None, 1, batch, mxu='bf16', stochastic=stoch)
     for b, n in enumerate([6, 4, 5]):
-        assert relerr(logits[b, :n, :V], out['aux']['logits'][b, :n]) < 3e-2
+        assert relerr(logits[b, :n, :V], out['aux']['logits'][b, :n]) < 2e-2
     assert abs(float(loss) - float(out['aux']['ce'].detach())) < 2e-2 * float(out['aux']['ce'].detach())
     from phones_las_amd import hip
     v = model.vars
@@ -70,7 +70,7 @@ def test_dropout_forward_backward_replayed_through_oracle():
                                           float(model.params.l2_reg_scale), hip.p(v.sumsq), None, hip.stream()))
     torch.cuda.synchronize()
     for name, _, _ in v.table:
-        assert relerr(v.grads[name], out['grads'][name]) < 6e-2, name
+        assert relerr(v.grads[name], out['grads'][name]) < 2e-2, name
     # a different optimiser step draws different masks
     model.global_step += 1
     loss2, _, _ = model.forward_train(feats, labels)
@@ -99,7 +99,7 @@ def test_scheduled_sampling_replayed_through_oracle():
     for b, n in enumerate([6, 4, 5]):
         assert relerr(logits[b, :n, :V], out['aux']['logits'][b, :n]) < 2e-2
     k = 'speller/decoder_cell_0/lstm_cell/kernel'
-    assert relerr(model.vars.grads[k], out['grads'][k] - ohp.l2_reg_scale * op[k]) < 6e-2
+    assert relerr(model.vars.grads[k], out['grads'][k] - ohp.l2_reg_scale * op[k]) < 2e-2
 
 
 def test_sampled_tokens_follow_the_logits():
@@ -151,10 +151,10 @@ def test_general_decoder_dropout_and_sampling_replayed(bottom):
     out = O.train_step(ohp, op, None, None, 1, batch, mxu='bf16',
                        stochastic={'enc_masks': enc_masks, 'dec_masks': dec_masks, 'sample_select': sel, 'sample_ids': ids})
     for b, n in enumerate([6, 4, 5]):
-        assert relerr(logits[b, :n, :V], out['aux']['logits'][b, :n]) < 3e-2
+        assert relerr(logits[b, :n, :V], out['aux']['logits'][b, :n]) < 2e-2
     for name, _, _ in model.vars.table:
         g = out['grads'][name] - ohp.l2_reg_scale * op[name]
-        assert relerr(model.vars.grads[name], g) < 8e-2, name
+        assert relerr(model.vars.grads[name], g) < 2e-2, name
 
 
 def test_embedding_with_dropout_replayed():
@@ -186,10 +186,10 @@ def test_embedding_with_dropout_replayed():
         dec_masks.append(per_layer)
     out = O.train_step(ohp, op, None, None, 1, batch, mxu='bf16', stochastic={'enc_masks': enc_masks, 'dec_masks': dec_masks})
     for b, n in enumerate([6, 4, 5]):
-        assert relerr(logits[b, :n, :V], out['aux']['logits'][b, :n]) < 3e-2
+        assert relerr(logits[b, :n, :V], out['aux']['logits'][b, :n]) < 2e-2
     for name, _, _ in model.vars.table:
         g = out['grads'][name] - ohp.l2_reg_scale * op[name]
-        assert relerr(model.vars.grads[name], g) < 8e-2, name
+        assert relerr(model.vars.grads[name], g) < 2e-2, name
 
 
 def test_persistent_decoder_with_sampling_and_dropout_replayed(monkeypatch):
@@ -232,7 +232,7 @@ def test_persistent_decoder_with_sampling_and_dropout_replayed(monkeypatch):
     out = O.train_step(ohp, op, None, None, 1, batch, mxu='bf16',
                        stochastic={'enc_masks': enc_masks, 'dec_masks': dec_masks, 'sample_select': sel, 'sample_ids': ids})
     for b, n in enumerate([6, 4, 5]):
-        assert relerr(logits[b, :n, :V], out['aux']['logits'][b, :n]) < 3e-2
+        assert relerr(logits[b, :n, :V], out['aux']['logits'][b, :n]) < 2e-2
     for name, _, _ in model.vars.table:
         g = out['grads'][name] - ohp.l2_reg_scale * op[name]
-        assert relerr(grads[name], g) < 8e-2, name
+        assert relerr(grads[name], g) < 2e-2, name
