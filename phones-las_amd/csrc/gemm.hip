@@ -502,6 +502,222 @@ __global__ __launch_bounds__(256) void tn_reduce_kernel(const float* __restrict_
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// NT product for the bulk shapes (x K_x of layers >= 1, dX, keys; K a multiple of 64): 256 x 128 output tile,
+// 512 threads = 8 waves in a 4 x 2 grid, each wave a 64 x 64 block as 2 x 2 tiles of v_mfma_f32_32x32x16_bf16 (half the
+// LDS fragment bytes per flop of the 16x16x32 form: 16 KB of fragments per wave and 64-deep K tile against 1024 MFMA
+// cycles per SIMD, so the LDS read path runs at about half its peak instead of at it).
+// Operand tiles travel global -> LDS by LDS-DMA (global_load_lds_dwordx4, 1 KiB per wave instruction, no registers) into
+// a ring of three 48-KiB stages; a wave waits only for ITS six loads of the tile it is about to read (counted vmcnt: the
+// six of the next tile stay in flight across the raw s_barrier) and issues the loads of tile kt+2 right after the
+// barrier that proves every wave has left tile kt-1 (whose stage they overwrite): one barrier per K tile.
+// The LDS image of a tile is lane-linear per load ([row][8 chunks of 16 B], 128-B rows, eight rows per KiB); bank
+// conflicts are avoided by permuting the SOURCE chunk a lane fetches: LDS slot s of row r holds chunk s ^ ((r >> 1) & 7),
+// so the 32 rows one ds_read_b128 lane group touches fall on 16 distinct (row parity, slot) = 4-bank groups.
+// ------------------------------------------------------------------------------------------------
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+__device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+
+// BM x BN output tile, BK-deep stages, STAGES of them; 8 waves as WGM x (8 / WGM)
+template <int BM, int BN, int BK, int STAGES, int WGM>
+__global__ __launch_bounds__(512) void gemm_nt_ring_kernel(GemmArgs g) {
+  constexpr int WGN = 8 / WGM;
+  constexpr int TM = BM / WGM / 32, TN = BN / WGN / 32;          // 32 x 32 tiles per wave
+  constexpr int ROWB = BK * 2;                                   // bytes per tile row
+  constexpr int CPR = BK / 8;                                    // 16-byte chunks per row
+  constexpr int RPC = 1024 / ROWB;                               // rows per 1-KiB load
+  constexpr int NA = BM / RPC / 8, NB = BN / RPC / 8;            // loads per wave and stage
+  constexpr int NL = NA + NB;
+  constexpr int STAGE_BYTES = (BM + BN) * ROWB;
+  constexpr int KS = BK / 16;                                    // MFMA k-steps per stage
+  extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+  typedef __attribute__((address_space(3))) unsigned char lds_u8;
+  lds_u8* lds = (lds_u8*)smem;
+  const unsigned lds_base = (unsigned)__builtin_amdgcn_readfirstlane((int)(size_t)lds);
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WGN, wn = wave % WGN;
+  // XCD-aware tile order (workgroups are dealt round-robin to the 8 XCDs): the column tiles that share a block of A rows
+  // are 8 linear ids apart, so an A block enters ONE L2 once
+  int bx = blockIdx.x, by = blockIdx.y;
+  {
+    const int gx = gridDim.x, gy = gridDim.y;
+    const int id = bx + gx * by;
+    const int full = (gy / 8) * 8 * gx;
+    if (id < full) {
+      by = (id / (8 * gx)) * 8 + (id & 7);
+      bx = (id >> 3) % gx;
+    }
+  }
+  const int m0 = by * BM, n0 = bx * BN;
+  const int batch = blockIdx.z;
+  const unsigned short* A = g.A + (int64_t)batch * g.sa;
+  const unsigned short* B = g.B + (int64_t)batch * g.sb;
+  const int nk = g.K / BK;
+
+  // row swizzle: LDS slot s of row r holds source chunk s ^ f(r); f spreads the rows one ds_read_b128 lane group touches
+  // ({0-3, 12-15, 20-27} / {4-11, 16-19, 28-31} of a 32-row fragment) over distinct 4-bank groups of the 256-byte bank row
+  auto fswz = [](int r) { return CPR == 8 ? ((r >> 1) & 7) : ((r >> 2) & 3); };
+  // this lane's source rows: chunk q = wave + 8 i covers rows RPC q .. RPC q + RPC - 1; rows past the edge re-read the last row
+  const unsigned short* src[NL];
+#pragma unroll
+  for (int i = 0; i < NL; ++i) {
+    const bool isA = i < NA;
+    const int q = wave + 8 * (isA ? i : i - NA);
+    const int row = RPC * q + lane / CPR;
+    const int ch = (lane % CPR) ^ fswz(row);
+    if (isA) src[i] = A + (int64_t)min(m0 + row, g.M - 1) * g.lda + 8 * ch;
+    else src[i] = B + (int64_t)min(n0 + row, g.N - 1) * g.ldb + 8 * ch;
+  }
+  auto issue = [&](int stage) {
+    const unsigned base = lds_base + stage * STAGE_BYTES;
+#pragma unroll
+    for (int i = 0; i < NL; ++i) {
+      const int q = wave + 8 * (i < NA ? i : i - NA);
+      glds16(src[i], base + (i < NA ? 0 : BM * ROWB) + q * 1024);
+      src[i] += BK;
+    }
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // fragment addresses: lane reads (row = l & 31, chunk 2 ks + (l >> 5)) at slot chunk ^ f(row)
+  const int l31 = lane & 31, hk = lane >> 5, swz = fswz(l31);
+  const int a_row = (wm * (BM / WGM) + l31) * ROWB, b_row = BM * ROWB + (wn * (BN / WGN) + l31) * ROWB;
+  int koff[KS];
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) koff[ks] = ((2 * ks + hk) ^ swz) << 4;
+
+  if (nk > 0) {
+#pragma unroll
+    for (int p = 0; p < STAGES - 1; ++p)
+      if (p < nk) issue(p);
+    int stage = 0;
+    for (int kt = 0; kt < nk; ++kt) {
+      // own loads of tile kt have landed: at most the STAGES - 2 younger tiles stay in flight (the tail drains fully)
+      if (kt + STAGES - 2 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(NL * (STAGES - 2)) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();                        // everybody's have landed; everybody has left tile kt - 1
+      asm volatile("" ::: "memory");
+#ifndef RING_NO_GLDS
+      if (kt + STAGES - 1 < nk) issue(stage == 0 ? STAGES - 1 : stage - 1);        // = (kt + STAGES - 1) % STAGES
+#endif
+      const lds_u8* st = lds + stage * STAGE_BYTES;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        bf16x8 af[TM], bfr[TN];
+#ifndef RING_NO_DSREAD
+#pragma unroll
+        for (int i = 0; i < TM; ++i) af[i] = *(const __attribute__((address_space(3))) bf16x8*)(st + a_row + i * 32 * ROWB + koff[ks]);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) bfr[j] = *(const __attribute__((address_space(3))) bf16x8*)(st + b_row + j * 32 * ROWB + koff[ks]);
+#else
+#pragma unroll
+        for (int i = 0; i < TM; ++i) { af[i] = __builtin_bit_cast(bf16x8, make_uint4(kt + i, lane, ks, 3)); asm volatile("" : "+v"(af[i])); }
+#pragma unroll
+        for (int j = 0; j < TN; ++j) { bfr[j] = __builtin_bit_cast(bf16x8, make_uint4(kt + j, lane, ks, 5)); asm volatile("" : "+v"(bfr[j])); }
+#endif
+#ifndef RING_NO_MFMA
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+#else
+#pragma unroll
+        for (int i = 0; i < TM; ++i) asm volatile("" :: "v"(af[i]));
+#pragma unroll
+        for (int j = 0; j < TN; ++j) asm volatile("" :: "v"(bfr[j]));
+#endif
+      }
+      stage = (stage + 1 == STAGES) ? 0 : stage + 1;
+    }
+  }
+
+  // epilogue: each wave parks 32 rows x (32 TN) columns of its tile at a time in LDS (row stride 32 TN + 4 floats) and
+  // writes the rows back 16 bytes per lane: row-contiguous stores (these products are bound by their fp32 output)
+  __builtin_amdgcn_s_barrier();              // every wave has finished reading the last stage
+  asm volatile("" ::: "memory");
+  constexpr int WN_ = 32 * TN, LDC = WN_ + 4;
+  static_assert(8 * 32 * LDC * 4 <= STAGES * STAGE_BYTES, "epilogue staging must fit in the ring");
+  float* cs = reinterpret_cast<float*>(smem) + wave * 32 * LDC;
+  float* Cf = reinterpret_cast<float*>(g.C) + (int64_t)batch * g.sc;
+  unsigned short* Cb = reinterpret_cast<unsigned short*>(g.C) + (int64_t)batch * g.sc;
+  constexpr int LPR = WN_ / 4, RPI = 64 / LPR;        // lanes per row, rows per store instruction
+  const int cl = (lane % LPR) * 4, rl = lane / LPR;
+  const int col = n0 + wn * WN_ + cl;
+  float bv[4] = {0.f, 0.f, 0.f, 0.f};
+  if (g.bias != nullptr)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) if (col + e < g.N) bv[e] = g.bias[col + e];
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        cs[((r & 3) + 8 * (r >> 2) + 4 * hk) * LDC + j * 32 + l31] = acc[i][j][r];
+    __builtin_amdgcn_s_waitcnt(0xC07F);        // lgkmcnt(0): a wave reads back only what it wrote itself
+#pragma unroll 4
+    for (int r0 = 0; r0 < 32; r0 += RPI) {
+      const int row = m0 + wm * (BM / WGM) + i * 32 + r0 + rl;
+      if (row >= g.M || col >= g.N) continue;
+      const float4 v4 = *reinterpret_cast<const float4*>(cs + (r0 + rl) * LDC + cl);
+      float v[4] = {v4.x + bv[0], v4.y + bv[1], v4.z + bv[2], v4.w + bv[3]};
+      const int64_t off = (int64_t)row * g.ldc + col;
+      const bool full = (col + 3 < g.N);
+      if (g.out_bf16) {
+        if (full && ((off & 3) == 0)) {
+          uint2 pk;
+          pk.x = (unsigned)las_f2bf(v[0]) | ((unsigned)las_f2bf(v[1]) << 16);
+          pk.y = (unsigned)las_f2bf(v[2]) | ((unsigned)las_f2bf(v[3]) << 16);
+          *reinterpret_cast<uint2*>(Cb + off) = pk;
+        } else {
+          for (int e = 0; e < 4; ++e) if (col + e < g.N) Cb[off + e] = las_f2bf(v[e]);
+        }
+      } else if (full && ((off & 3) == 0)) {
+        float4 o = make_float4(v[0], v[1], v[2], v[3]);
+        if (g.accumulate) {
+          const float4 c = *reinterpret_cast<const float4*>(Cf + off);
+          o.x += c.x; o.y += c.y; o.z += c.z; o.w += c.w;
+        }
+        *reinterpret_cast<float4*>(Cf + off) = o;
+      } else {
+        for (int e = 0; e < 4; ++e)
+          if (col + e < g.N) { if (g.accumulate) Cf[off + e] += v[e]; else Cf[off + e] = v[e]; }
+      }
+    }
+    __builtin_amdgcn_s_waitcnt(0xC07F);        // the staging rows are rewritten by the next 32 rows
+  }
+}
+
+template <int BM, int BN, int BK, int STAGES, int WGM>
+int launch_ring(const GemmArgs& g, int batch, hipStream_t st) {
+  dim3 grid((g.N + BN - 1) / BN, (g.M + BM - 1) / BM, batch);
+  const size_t lds = (size_t)STAGES * (BM + BN) * BK * 2;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_ring_kernel<BM, BN, BK, STAGES, WGM>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((gemm_nt_ring_kernel<BM, BN, BK, STAGES, WGM>), grid, dim3(512), lds, st, g);
+  LAS_LAUNCH_CHECK("ring gemm launch");
+  return LAS_OK;
+}
+
 template <int BM, int BN, bool TN, int KB = 64>
 int launch(const GemmArgs& g, int batch, hipStream_t st) {
   dim3 grid((g.N + BN - 1) / BN, (g.M + BM - 1) / BM, batch * g.split_k);
@@ -605,6 +821,23 @@ extern "C" int las_gemm_nt(const las_bf16* A, int64_t lda, const las_bf16* B, in
     return LAS_OK;
   }
   if (M <= 64 || N <= 64) return launch<64, 64, false>(g, batch, st);
+  {
+    // The bulk products run on the LDS-DMA ring kernel.  Measured on the metric-M shapes (scripts/gpu_nt_ab.py, us):
+    //   K = 2048 (dX): 256 x 256 tiles, 32-deep x 4 stages (one workgroup per CU)      140 / 154  (register-staged: 188 / 203)
+    //   K <= 1024 (x K_x with its fp32 output, keys): 256 x 128 tiles, 32-deep x 3 stages = 72 KiB, two workgroups
+    //   per CU, so one's epilogue runs beside the other's K loop                          215 / 155 / 27  (251 / 199 / 30)
+    // LAS_GEMM_RING=0: register-staged kernels everywhere; 1: 256x128x64 (3 stages); 2: 256x256 wherever N allows; 4: the
+    // two-per-CU form everywhere (diagnostics, A/B timing)
+    static int ring = -1;
+    if (ring < 0) { const char* e = getenv("LAS_GEMM_RING"); ring = e ? atoi(e) : 5; }
+    if (ring && split_k == 1 && K % 64 == 0 && K >= 128 && M >= 1024 && N >= 128 && (ldc % 4 == 0 || out_bf16)) {
+      const bool wide = N >= 256 && N % 256 != 128;
+      if (ring == 1) return launch_ring<256, 128, 64, 3, 4>(g, batch, st);
+      if (ring == 4 || (ring == 5 && !(wide && K > 1024))) return launch_ring<256, 128, 32, 3, 4>(g, batch, st);
+      if (wide) return launch_ring<256, 256, 32, 4, 2>(g, batch, st);
+      return launch_ring<256, 128, 64, 3, 4>(g, batch, st);
+    }
+  }
   if (M >= 4096) return launch<128, 128, false, 32>(g, batch, st);      // the bulk products: three workgroups per CU
   return launch<128, 128, false>(g, batch, st);
 }

@@ -19,7 +19,9 @@ def _close(got, ref, tol=2e-3):
 
 
 @pytest.mark.parametrize('M,N,K', [(128, 128, 64), (200, 72, 40), (64, 1024, 1280), (3, 5, 8), (257, 129, 328),
-                                   (1024, 256, 128), (1100, 300, 136), (2304, 512, 328)])
+                                   (1024, 256, 128), (1100, 300, 136), (2304, 512, 328),
+                                   # the LDS-DMA ring kernel (K % 64 == 0, M >= 1024, N >= 128): one and many K tiles, ragged M / N edges
+                                   (1024, 128, 128), (1300, 200, 192), (2500, 1000, 512), (4096, 512, 2048), (1025, 129, 64 * 7)])
 def test_gemm_nt_matches_fp64(M, N, K):
     from phones_las_amd import hip
     A, B = _mk((M, K), 1), _mk((N, K), 2)
@@ -172,3 +174,29 @@ def test_gemm_tn_lstm_fused_weight_gradients(D, H, B, T, shift, use_ws):
     torch.cuda.synchronize()
     _close(gk - 0.5, ref_k)
     _close(gb + 0.25, ref_b)
+
+
+def test_gemm_nt_ring_asymmetric_identity_strides_and_batch():
+    """The LDS-DMA ring kernel (gemm_nt_ring_kernel: 256 x 128 tiles of v_mfma_f32_32x32x16_bf16): A = I against an
+    asymmetric B catches a transposed or permuted C write and a wrong source-chunk swizzle exactly (integer data);
+    sub-matrix views through lda / ldb / ldc; a batch of two; and the same product through the register-staged kernel
+    (LAS_GEMM_RING is read once per process, so the reference here is the float64 product)."""
+    from phones_las_amd import hip
+    n = 1024
+    A = torch.eye(n).to(torch.bfloat16).cuda()
+    B = ((torch.arange(256 * n).reshape(256, n) * 7) % 253).float().to(torch.bfloat16)
+    C = torch.empty(n, 256, device='cuda')
+    hip.gemm_nt(A, B.cuda(), C, n, 256, n)
+    assert torch.equal(C.cpu(), B.float().t())
+    big = _mk((1500, 400), 3).cuda()
+    W = _mk((200, 256), 4).cuda()
+    out = torch.zeros(1500, 260, device='cuda')
+    hip.gemm_nt(big[:, 64:], W[:, :192], out[:, 20:], 1500, 200, 192, lda=400, ldb=256, ldc=260)
+    ref = big[:, 64:256].double().cpu() @ W[:, :192].double().cpu().t()
+    _close(out[:, 20:220], ref)
+    assert float(out[:, :20].abs().max()) == 0.0 and float(out[:, 220:].abs().max()) == 0.0
+    nb, M, N, K = 2, 1100, 136, 128
+    Ab, Bb = _mk((nb, M, K), 5), _mk((nb, N, K), 6)
+    Cb = torch.empty(nb, M, N, device='cuda')
+    hip.gemm_nt(Ab.cuda(), Bb.cuda(), Cb, M, N, K, lda=K, ldb=K, ldc=N, batch=nb, sa=M * K, sb=N * K, sc=M * N)
+    _close(Cb, torch.einsum('bmk,bnk->bmn', Ab.double(), Bb.double()))
