@@ -424,6 +424,21 @@ int las_seq_ce_loss(const float* logits, int64_t ldl, const int32_t* targets, co
 int las_beam_step(const float* logits, int64_t ldl, float* log_probs, int32_t* finished, int32_t* lengths,
                   int32_t* word_ids, int32_t* parent_ids, int B, int K, int V, int eos, void* stream);
 
+/* sequence_loss_sigmoid / compute_loss_sigmoid of the sigmoid-output decoder (--binary_outputs without
+ * --binf_projection; model_helper.py:81-95,98-130): logits [B*U rows, row stride ldl] fp32 over nf binary features,
+ * targets bf16 0/1 rows (row stride ldt), seq_len [B] = the weights' sequence_mask lengths (TRAIN: target lengths; EVAL:
+ * max(target, decoded) lengths after the caller padded both to the longer).  loss_out[0] += sum_{b,t<len_b}
+ * mean_f BCE(logits, targets) / (sum_b len_b + 1e-12); dlogits (bf16, row stride ldd, may be NULL) its gradient times
+ * grad_scale, zero for masked steps. */
+int las_seq_sigmoid_loss(const float* logits, int64_t ldl, const las_bf16* targets, int64_t ldt, const int32_t* seq_len,
+                         int B, int U, int nf, float grad_scale, float* loss_out, las_bf16* dlogits, int64_t ldd,
+                         void* stream);
+/* ScheduledSigmoidHelper.sample + next_inputs (utils/training_helper.py:89-119 with binf_to_ipa None, :57-74): utterance
+ * b feeds next[b, 0:nf] = Bernoulli(sigmoid(logits[b, f])) draws with probability prob (one draw per utterance and step),
+ * else teacher[b, 0:nf] (bf16 0/1 rows; NULL = zeros).  Draws come from the counter-based generator (seed, step). */
+int las_sample_features(const float* logits, int64_t ldl, int nf, const las_bf16* teacher, int64_t ldt, las_bf16* next,
+                        int64_t ldn, int B, float prob, uint32_t seed, uint32_t step, void* stream);
+
 /* compute_log_probs_loss of the binf_projection decoder (model_helper.py:132-146, :327-331): x [rows, 2*nf] bf16 holds
  * [log p(f=1) | log p(f=0)] per decoder step (ALL rows count, padded steps too).  loss_out += weight * mean(|e^a + e^b
  * - 1| + relu(a) + relu(b)); dx (fp32, row stride ldd, may be NULL) = grad_scale * weight * d(mean)/dx. */

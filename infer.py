@@ -43,8 +43,8 @@ def to_text(vocab_list, sample_ids, delimiter=' '):
 
 
 def main(args):
-    if args.calc_frame_binf_accuracy or args.use_phones_from_binf or args.convert_targets_to_ipa:
-        raise SystemExit('binary-feature / IPA analysis options are not supported on the HIP path')
+    if args.calc_frame_binf_accuracy or args.convert_targets_to_ipa:
+        raise SystemExit('--calc_frame_binf_accuracy / --convert_targets_to_ipa (TIMIT markup and IPA analysis) are not on the HIP path')
     from phones_las_amd import utils
     from phones_las_amd import model_helper as mh
     from phones_las_amd.utils.metrics_utils import _levenshtein
@@ -73,8 +73,9 @@ def main(args):
     optimistic_err = 0
     for features, labels in batches:
         f, _ = to_device(features, None, dev)
-        pred = model.predict(f)
-        ids = pred['sample_ids'].cpu().numpy()           # [B,T] greedy, [B,T,K] beam search (infer.py:279-295)
+        pred = model.predict(f, transparent_projection=bool(args.use_phones_from_binf))   # transcribe_audio_file.py:90 couples the two
+        # infer.py:223: the phones decoded from the binary-feature decoder, or the phone decoder's
+        ids = pred['sample_ids_phones_binf' if args.use_phones_from_binf else 'sample_ids'].cpu().numpy()   # [B,T] / [B,T,K]
         for b in range(ids.shape[0]):
             t = labels['targets_outputs'][b][:labels['target_sequence_length'][b] - 1].tolist()
             if mapping is not None:

@@ -164,6 +164,8 @@ class DecoderHP:
     attention_type: str = 'luong'
     attention_layer_size: Optional[int] = None
     dropout: float = 0.0
+    binary_outputs: bool = False             # with binf_projection False: the sigmoid-output decoder (feature logits)
+    multitask: bool = False                  # --multitask: phone decoder ('speller') + binary decoder ('speller_binf')
     binf_projection: bool = False
     binf_count: int = 0
     binf_projection_reg_weight: float = 1.0
@@ -198,6 +200,52 @@ def attention_depth(hp: HP) -> int:
     return d.attention_layer_size or encoder_out_depth(hp.encoder)
 
 
+def speller_plan(d: DecoderHP):
+    """[(scope, kind)] of the decoders las_model_fn builds (model_helper.py:211-227); kind: 'phones', 'binf_projection'
+    or 'sigmoid' (binary_outputs without binf_projection).  A single decoder is scoped 'speller' here whatever its kind
+    (the reference says 'speller_binf' for a binary one), the second decoder of --multitask 'speller_binf'."""
+    binary = d.binary_outputs or d.binf_projection
+    kind = 'binf_projection' if d.binf_projection else 'sigmoid'
+    if not binary:
+        return [('speller', 'phones')]
+    if d.multitask:
+        return [('speller', 'phones'), ('speller_binf', kind)]
+    return [('speller', kind)]
+
+
+def _speller_table(hp: HP, scope: str, kind: str):
+    e, d = hp.encoder, hp.decoder
+    M, Hd, V = encoder_out_depth(e), d.num_units, d.target_vocab_size
+    A = 2 * d.binf_count if kind == 'binf_projection' else (d.attention_layer_size or M)
+    E = d.embedding_size if d.embedding_size else V
+    if kind != 'phones' and not d.embedding_size:
+        E = d.binf_count                                             # las/model.py:237-243
+    Vo = d.binf_count if kind == 'sigmoid' else V                    # DenseBinfDecoder(binf_count) (las/model.py:251-252)
+    out = []
+    if d.embedding_size:
+        out.append((f'{scope}/target_embedding', (V, d.embedding_size), 'glorot'))
+    out.append((f'{scope}/memory_layer/kernel', (M, Hd), 'glorot'))
+    if d.attention_type in ('bahdanau', 'bahdanau_monotonic', 'custom'):
+        out.append((f'{scope}/query_layer/kernel', (Hd, Hd), 'glorot'))
+    if d.attention_type in ('bahdanau', 'bahdanau_monotonic'):
+        out.append((f'{scope}/attention_v', (Hd,), 'glorot_v'))
+    if d.attention_type in ('luong_monotonic', 'bahdanau_monotonic'):
+        out.append((f'{scope}/attention_score_bias', (1,), 'zeros'))
+    if d.attention_layer_size or kind == 'binf_projection':
+        out.append((f'{scope}/attention_layer/kernel', (Hd + M, A), 'glorot'))
+    for l in range(d.num_layers):
+        if d.bottom_only:                                            # las/model.py:36-69: cell_1 reads [attention_t, attention_{t-1}]
+            din = (E + A) if l == 0 else ((A + A) if l == 1 else (Hd + A))
+        else:
+            din = (E + A) if l == 0 else Hd                         # MultiRNNCell inside the wrapper
+        out.append((f'{scope}/decoder_cell_{l}/lstm_cell/kernel', (din + Hd, 4 * Hd), 'lstm'))
+        out.append((f'{scope}/decoder_cell_{l}/lstm_cell/bias', (4 * Hd,), 'zeros'))
+    P = Hd if (d.bottom_only and d.num_layers > 1) else A
+    out.append((f'{scope}/projection_layer/kernel', (P, Vo), 'proj'))
+    out.append((f'{scope}/projection_layer/bias', (Vo,), 'zeros'))
+    return out
+
+
 def param_table(hp: HP) -> List[Tuple[str, Tuple[int, ...], str]]:
     """Ordered (name, shape, init) list.  init in {lstm, zeros, glorot, proj, emb}."""
     e, d = hp.encoder, hp.decoder
@@ -218,36 +266,9 @@ def param_table(hp: HP) -> List[Tuple[str, Tuple[int, ...], str]]:
         else:
             D = H
     M = encoder_out_depth(e)
-    Hd = d.num_units
-    A = attention_depth(hp)
     V = d.target_vocab_size
-    E = d.embedding_size if d.embedding_size else V
-    if d.binf_projection and not d.embedding_size:
-        E = d.binf_count                                             # embedding_fn = rows of binf_map^T (las/model.py:242-243)
-    if d.embedding_size:
-        out.append(('speller/target_embedding', (V, d.embedding_size), 'glorot'))
-    out.append(('speller/memory_layer/kernel', (M, Hd), 'glorot'))
-    if d.attention_type in ('bahdanau', 'bahdanau_monotonic', 'custom'):
-        out.append(('speller/query_layer/kernel', (Hd, Hd), 'glorot'))
-    if d.attention_type in ('bahdanau', 'bahdanau_monotonic'):
-        out.append(('speller/attention_v', (Hd,), 'glorot_v'))
-    if d.attention_type in ('luong_monotonic', 'bahdanau_monotonic'):
-        out.append(('speller/attention_score_bias', (1,), 'zeros'))
-    if d.attention_layer_size or d.binf_projection:
-        # Dense(A, no bias) on concat([cell_out, context])  (Appendix A.5)
-        out.append(('speller/attention_layer/kernel', (Hd + M, A), 'glorot'))
-    for l in range(d.num_layers):
-        if d.bottom_only:                                            # las/model.py:36-69: cell_1 reads [attention_t, attention_{t-1}]
-            din = (E + A) if l == 0 else ((A + A) if l == 1 else (Hd + A))
-        else:
-            din = (E + A) if l == 0 else Hd                         # MultiRNNCell inside the wrapper
-        out.append((f'speller/decoder_cell_{l}/lstm_cell/kernel', (din + Hd, 4 * Hd), 'lstm'))
-        out.append((f'speller/decoder_cell_{l}/lstm_cell/bias', (4 * Hd,), 'zeros'))
-    # the projection sees the decoder cell's output: attention (A wide), or h of the top cell for an
-    # AttentionMultiCell with upper layers (las/model.py:36-69 returns cur_inp of the last cell)
-    P = Hd if (d.bottom_only and d.num_layers > 1) else A
-    out.append(('speller/projection_layer/kernel', (P, V), 'proj'))
-    out.append(('speller/projection_layer/bias', (V,), 'zeros'))
+    for scope, kind in speller_plan(d):
+        out.extend(_speller_table(hp, scope, kind))
     if hp.ctc_weight > 0:
         out.append(('ctc_logits/kernel', (M, V + 1), 'glorot'))
         out.append(('ctc_logits/bias', (V + 1,), 'zeros'))
@@ -408,10 +429,13 @@ def monotonic_attention(p, prev, mode):
 class Attention:
     """One of the mechanisms selected in las/model.py:153-169 over ``memory`` [B,T',M]."""
 
-    def __init__(self, hp: HP, params, memory, mem_len, q, train=True, noise=None):
+    def __init__(self, hp: HP, params, memory, mem_len, q, train=True, noise=None, scope='speller'):
         self.kind = hp.decoder.attention_type
         self.q = q
-        self.p = params
+        # this decoder's variables under the plain 'speller/...' names the methods below use
+        self.p = params if scope == 'speller' else {'speller/' + k[len(scope) + 1:]: v for k, v in params.items()
+                                                    if k.startswith(scope + '/')}
+        params = self.p
         B, Tm, _ = memory.shape
         self.mask = (torch.arange(Tm).unsqueeze(0) < mem_len.unsqueeze(1))       # [B,T']
         self.values = memory * self.mask.unsqueeze(-1).to(DT)
@@ -467,12 +491,18 @@ class Speller:
     projection layer (las/model.py:251-257) and embedding_fn (las/model.py:228-246)."""
 
     def __init__(self, hp: HP, params, memory, mem_len, enc_state, mxu='f64', train=True,
-                 noise=None):
-        self.hp, self.d, self.p = hp, hp.decoder, params
+                 noise=None, scope='speller', kind=None):
+        """kind: 'phones' | 'binf_projection' | 'sigmoid' (default: the first decoder of speller_plan); scope: prefix of
+        this decoder's variables ('speller_binf' for the binary decoder of a --multitask model)."""
+        self.hp, self.d = hp, hp.decoder
+        self.kind = kind or speller_plan(hp.decoder)[0][1]
         self.q = make_q(mxu)
-        self.att = Attention(hp, params, memory, mem_len, self.q, train, noise)
+        self.att = Attention(hp, params, memory, mem_len, self.q, train, noise, scope)
+        self.p = self.att.p
+        params = self.p
         self.B = memory.shape[0]
-        self.A = attention_depth(hp)
+        self.A = (2 * hp.decoder.binf_count) if self.kind == 'binf_projection' else \
+            (hp.decoder.attention_layer_size or encoder_out_depth(hp.encoder))
         self.train = train
         d = self.d
         Hd = d.num_units
@@ -494,14 +524,15 @@ class Speller:
         d = self.d
         if d.embedding_size:
             return self.q(self.p['speller/target_embedding'])[ids]
-        if d.binf_projection:                                                    # las/model.py:242-243
+        if self.kind in ('binf_projection', 'sigmoid'):                          # las/model.py:237-243
             return torch.as_tensor(d.binf_map, dtype=DT).t()[ids]
         return torch.nn.functional.one_hot(ids, d.target_vocab_size).to(DT)
 
     def project(self, out):
-        """projection_layer of las/model.py:251-257 (DenseBinfDecoder, utils/training_helper.py:122-153)."""
+        """projection_layer of las/model.py:251-257 (DenseBinfDecoder, utils/training_helper.py:122-153); for the
+        sigmoid-output decoder a Dense(binf_count) whose outputs are feature logits (binf_to_ipa None in TRAIN)."""
         d, p, q = self.d, self.p, self.q
-        if not d.binf_projection:
+        if self.kind != 'binf_projection':
             return out @ q(p['speller/projection_layer/kernel']) + p['speller/projection_layer/bias']
         # inner_projection_layer=False: the cell output IS [log p(feature=1) | log p(feature=0)]; the Dense kernel and
         # bias exist as variables but are not applied.  transform_binf_to_phones (:17-27); TRAIN concatenates the input.
@@ -547,7 +578,7 @@ class Speller:
             cell_out = cur
         align = self.att(cell_out, self.align)
         ctx = _ContextFn.apply(align, self.att.values) if _bwd(q) else torch.einsum('bt,btm->bm', align, self.att.values)
-        if d.attention_layer_size or d.binf_projection:
+        if d.attention_layer_size or self.kind == 'binf_projection':
             ctx = q(ctx)
             attention = torch.cat([cell_out, ctx], 1) @ q(p['speller/attention_layer/kernel'])
         else:
@@ -572,10 +603,12 @@ class Speller:
 
 
 def speller_train(hp: HP, params, memory, mem_len, enc_state, targets_inputs, target_len,
-                  mxu='f64', sample_select=None, sample_ids=None, noise=None, in_masks=None):
-    """las/model.py:276-296,346-347 with TrainingHelper; optional scheduled sampling with externally
-    supplied draws (utils/training_helper.py:48-87): sample_select[t,b] bool, sample_ids[t,b]."""
-    sp = Speller(hp, params, memory, mem_len, enc_state, mxu, True, noise)
+                  mxu='f64', sample_select=None, sample_ids=None, noise=None, in_masks=None, scope='speller', kind=None,
+                  sample_vecs=None):
+    """las/model.py:276-296,346-347 with TrainingHelper / TrainingSigmoidHelper; optional scheduled sampling with
+    externally supplied draws (utils/training_helper.py:48-87): sample_select[t,b] bool, sample_ids[t,b]; for the
+    sigmoid-output decoder (ScheduledSigmoidHelper, :89-119) sample_vecs[t,b,nf] holds the Bernoulli feature draws."""
+    sp = Speller(hp, params, memory, mem_len, enc_state, mxu, True, noise, scope, kind)
     U = int(target_len.max())
     inp = sp.embed(targets_inputs[:, 0])
     outs = []
@@ -588,16 +621,43 @@ def speller_train(hp: HP, params, memory, mem_len, enc_state, targets_inputs, ta
             nxt = torch.zeros_like(inp)
         if sample_select is not None:
             sel = sample_select[t].unsqueeze(1).to(DT)
-            nxt = sel * sp.embed(sample_ids[t]) + (1 - sel) * nxt
+            samp = sample_vecs[t].to(DT) if sample_vecs is not None else sp.embed(sample_ids[t])
+            nxt = sel * samp + (1 - sel) * nxt
         inp = nxt
     return torch.stack(outs, 1), sp
 
 
-def speller_greedy(hp: HP, params, memory, mem_len, enc_state, mxu='f64'):
+def speller_greedy_binary(hp: HP, params, memory, mem_len, enc_state, mxu='f64', scope='speller'):
+    """las/model.py:320-336: the sigmoid-output decoder under InferenceHelper -- start_inputs = [0, ..., 0, 1, 0] (the
+    features of <s>), sample = round(sigmoid(outputs)) fed back as the next input, finished when the last feature (the
+    one of </s>) exceeds 0.5.  Returns (feature logits [B,steps,nf], samples [B,steps,nf], final lengths, speller)."""
+    d = hp.decoder
+    sp = Speller(hp, params, memory, mem_len, enc_state, mxu, False, None, scope, 'sigmoid')
+    B, nf = memory.shape[0], d.binf_count
+    max_it = int(round(float(mem_len.max()) * d.decoding_length_factor))
+    inp = torch.zeros(B, nf, dtype=DT)
+    inp[:, nf - 2] = 1.0
+    finished = torch.zeros(B, dtype=torch.bool)
+    final_len = torch.zeros(B, dtype=torch.long)
+    outs, samples = [], []
+    for t in range(max_it):
+        logits = sp.step(inp)
+        sample = (logits > 0).to(DT)                           # tf.round(tf.sigmoid(x)): 1 iff x > 0
+        outs.append(logits)
+        samples.append(sample)
+        final_len = torch.where(finished, final_len, torch.full_like(final_len, t + 1))
+        finished = finished | (sample[:, -1] > 0.5)
+        inp = sample
+        if bool(finished.all()):
+            break
+    return torch.stack(outs, 1), torch.stack(samples, 1), final_len, sp
+
+
+def speller_greedy(hp: HP, params, memory, mem_len, enc_state, mxu='f64', scope='speller', kind=None):
     """las/model.py:270-274,337-347: GreedyEmbeddingHelper, maximum_iterations =
     round(max(len') * decoding_length_factor); returns logits [B,steps,V], ids, final lengths, speller."""
     d = hp.decoder
-    sp = Speller(hp, params, memory, mem_len, enc_state, mxu, False)
+    sp = Speller(hp, params, memory, mem_len, enc_state, mxu, False, None, scope, kind)
     B = memory.shape[0]
     max_it = int(round(float(mem_len.max()) * d.decoding_length_factor))
     ids = torch.full((B,), d.sos_id, dtype=torch.long)
@@ -737,6 +797,36 @@ def compute_loss_eval(logits, targets, final_len, target_len, eos_id=EOS_ID):
     return sequence_loss(logits[:, :L], targets[:, :L], w)
 
 
+def sequence_loss_sigmoid(logits, targets, weights):
+    """model_helper.py:81-95: mean over the features of sigmoid_cross_entropy_with_logits, weighted over the steps,
+    divided by (sum of the weights + 1e-12)."""
+    ce = torch.nn.functional.binary_cross_entropy_with_logits(logits, targets.to(logits.dtype), reduction='none').mean(-1)
+    return (ce * weights).sum() / (weights.sum() + 1e-12)
+
+
+def compute_loss_sigmoid_train(logits, targets_binf, target_len):
+    """model_helper.py:102-105."""
+    U = logits.shape[1]
+    w = (torch.arange(U).unsqueeze(0) < target_len.unsqueeze(1)).to(DT)
+    return sequence_loss_sigmoid(logits, targets_binf[:, :U], w)
+
+
+def compute_loss_sigmoid_eval(logits, targets_binf, final_len, target_len):
+    """model_helper.py:106-128 with the targets' FEATURE vectors (the reference passes the integer ids at :336-337, which
+    its own reshape cannot take): cut the logits at the longest decoded length, zero-pad both to the longer, weigh
+    max(target_len, final_len) steps per utterance."""
+    B, _, nf = logits.shape
+    max_ts, max_fs = int(target_len.max()), int(final_len.max())
+    L = max(max_ts, max_fs)
+    logits = logits[:, :max_fs]
+    if targets_binf.shape[1] < L:
+        targets_binf = torch.cat([targets_binf, torch.zeros(B, L - targets_binf.shape[1], nf, dtype=targets_binf.dtype)], 1)
+    if logits.shape[1] < L:
+        logits = torch.cat([logits, torch.zeros(B, L - logits.shape[1], nf, dtype=DT)], 1)
+    w = (torch.arange(L).unsqueeze(0) < torch.maximum(target_len, final_len).unsqueeze(1)).to(DT)
+    return sequence_loss_sigmoid(logits[:, :L], targets_binf[:, :L], w)
+
+
 def ctc_loss_dense(logits, labels, label_len, logit_len, blank=0):
     """tf.nn.ctc_loss_v2 with dense labels, blank index 0 (model_helper.py:355-357; Appendix A.8).
     Log-space alpha recursion; returns per-example negative log likelihood [B]."""
@@ -839,25 +929,37 @@ def model_loss(hp: HP, params, batch, mxu='f64', stochastic=None):
     st = stochastic or {}
     (mem, mem_len), state = listener(x, batch['source_sequence_length'], params, hp.encoder, mxu,
                                      st.get('enc_masks'))
-    logits, sp = speller_train(hp, params, mem, mem_len, state, batch['targets_inputs'],
-                               batch['target_sequence_length'], mxu, sample_select=st.get('sample_select'),
-                               sample_ids=st.get('sample_ids'), noise=st.get('att_noise'), in_masks=st.get('dec_masks'))
     gq = _g(make_q(mxu))
-    raw = None
-    if not hp.decoder.binf_projection:
-        logits = gq(logits)                          # the loss kernel writes d(logits) in bf16
-    if hp.decoder.binf_projection:                                               # model_helper.py:251-253
-        V = hp.decoder.target_vocab_size
-        raw, logits = logits[..., V:], logits[..., :V]
-    loss = compute_loss_train(logits, batch['targets_outputs'], batch['target_sequence_length'])
-    aux = {'logits': logits, 'memory': mem, 'memory_len': mem_len, 'state': state, 'ce': loss}
-    if raw is not None:                                                          # model_helper.py:327-331
-        reg = compute_log_probs_loss(raw)
-        aux['log_probs_loss'] = reg
-        loss = loss + reg * hp.decoder.binf_projection_reg_weight
+    loss, aux = None, {'memory': mem, 'memory_len': mem_len, 'state': state}
+    for scope, kind in speller_plan(hp.decoder):                                 # model_helper.py:211-227,319-342
+        logits, sp = speller_train(hp, params, mem, mem_len, state, batch['targets_inputs'],
+                                   batch['target_sequence_length'], mxu, sample_select=st.get('sample_select'),
+                                   sample_ids=st.get('sample_ids'), noise=st.get('att_noise'), in_masks=st.get('dec_masks'),
+                                   scope=scope, kind=kind, sample_vecs=st.get('sample_vecs'))
+        if kind == 'sigmoid':
+            logits = gq(logits)
+            tb = torch.as_tensor(hp.decoder.binf_map, dtype=DT).t()[batch['targets_outputs']]
+            l_ = compute_loss_sigmoid_train(logits, tb, batch['target_sequence_length'])
+            aux.setdefault('logits_binf', logits)
+        elif kind == 'binf_projection':                                          # model_helper.py:251-253
+            V = hp.decoder.target_vocab_size
+            raw, logits = logits[..., V:], logits[..., :V]
+            l_ = compute_loss_train(logits, batch['targets_outputs'], batch['target_sequence_length'])
+            aux['ce_binf'] = l_
+            reg = compute_log_probs_loss(raw)                                    # model_helper.py:327-331
+            aux['log_probs_loss'] = reg
+            l_ = l_ + reg * hp.decoder.binf_projection_reg_weight
+            aux.setdefault('logits_binf', logits)
+        else:
+            logits = gq(logits)                          # the loss kernel writes d(logits) in bf16
+            l_ = compute_loss_train(logits, batch['targets_outputs'], batch['target_sequence_length'])
+        if loss is None:
+            aux['logits'], aux['ce'] = logits, (aux['ce_binf'] if kind == 'binf_projection' else l_)
+        loss = l_ if loss is None else loss + l_
+    gq_ = gq
     if hp.ctc_weight > 0:
         q = make_q(mxu)
-        cl = gq(mem @ q(params['ctc_logits/kernel']) + params['ctc_logits/bias'])    # CTC d(logits) in bf16
+        cl = gq_(mem @ q(params['ctc_logits/kernel']) + params['ctc_logits/bias'])    # CTC d(logits) in bf16
         ctc = ctc_loss_dense(cl, batch['targets_outputs'], batch['target_sequence_length'], mem_len).mean()
         aux['ctc'] = ctc
         aux['ctc_logits'] = cl

@@ -1502,6 +1502,64 @@ __global__ __launch_bounds__(256) void seq_ce_kernel(const float* logits, int64_
 }
 
 // ------------------------------------------------------------------------------------------------
+// sequence_loss_sigmoid (model_helper.py:81-95) as compute_loss_sigmoid uses it (:98-130): per decoder step the MEAN over
+// the nf features of sigmoid_cross_entropy_with_logits(labels, logits) = max(x, 0) - x z + log(1 + exp(-|x|)), weighted
+// by the sequence mask, divided by (sum of the weights + 1e-12).  targets: bf16 0/1 rows [B*U, ldt].
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void seq_sigmoid_kernel(const float* logits, int64_t ldl, const unsigned short* targets,
+                                                          int64_t ldt, const int32_t* seq_len, int B, int U, int nf,
+                                                          float grad_scale, float* loss_out, unsigned short* dlogits, int64_t ldd) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float total = 0.f;
+  for (int i = lane; i < B; i += 64) total += (float)min(seq_len[i], U);
+  total = las_wave_sum(total) + 1e-12f;
+  const float inv_total = 1.0f / total, inv_nf = 1.0f / (float)nf;
+  float local_loss = 0.f;
+  for (int row = blockIdx.x * 4 + wave; row < B * U; row += gridDim.x * 4) {
+    const int b = row / U, t = row % U;
+    const bool on = t < seq_len[b];
+    const float* lg = logits + (int64_t)row * ldl;
+    unsigned short* dl = dlogits ? dlogits + (int64_t)row * ldd : nullptr;
+    if (!on) {
+      if (dl) for (int f = lane; f < nf; f += 64) dl[f] = 0;
+      continue;
+    }
+    const unsigned short* tg = targets + (int64_t)row * ldt;
+    float ce = 0.f;
+    for (int f = lane; f < nf; f += 64) {
+      const float x = lg[f], z = las_bf2f(tg[f]);
+      ce += fmaxf(x, 0.f) - x * z + log1pf(__expf(-fabsf(x)));
+      if (dl) dl[f] = las_f2bf((las_sigmoid(x) - z) * inv_nf * inv_total * grad_scale);
+    }
+    ce = las_wave_sum(ce);
+    if (lane == 0) local_loss += ce * inv_nf * inv_total;
+  }
+  __shared__ float wl[4];
+  if (lane == 0) wl[wave] = local_loss;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const float v = wl[0] + wl[1] + wl[2] + wl[3];
+    if (v != 0.f) atomicAdd(loss_out, v);
+  }
+}
+
+// ScheduledSigmoidHelper (utils/training_helper.py:89-119, binf_to_ipa None): with probability prob per utterance the next
+// decoder input is a Bernoulli(sigmoid(logits)) draw per feature, else the teacher's feature vector.  One thread per (b, f).
+__global__ void sample_features_kernel(const float* logits, int64_t ldl, int nf, const unsigned short* teacher, int64_t ldt,
+                                       unsigned short* next, int64_t ldn, int B, float prob, unsigned seed, unsigned step) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * nf) return;
+  const int b = i / nf, f = i % nf;
+  const bool select = las_uniform(seed, 0x5e1ec7u, (unsigned long long)step * B + b) < prob;
+  unsigned short out = teacher ? teacher[(int64_t)b * ldt + f] : 0;
+  if (select) {
+    const float u = las_uniform(seed, 0xb17f00du, ((unsigned long long)step * B + b) * nf + f);
+    out = u < las_sigmoid(logits[(int64_t)b * ldl + f]) ? 0x3F80u : 0u;       // bf16 1.0 / 0.0
+  }
+  next[(int64_t)b * ldn + f] = out;
+}
+
+// ------------------------------------------------------------------------------------------------
 // compute_log_probs_loss (model_helper.py:132-146): mean over all rows x nf of
 //   |e^a + e^b - 1| + relu(a) + relu(b),  a = x[:, f] (log p(feature = 1)), b = x[:, nf + f]
 // (the reference multiplies and divides by a gradient-free constant for stability; e^a + e^b is the same value)
@@ -1775,6 +1833,27 @@ extern "C" int las_decoder_step_bwd(const las_dec_step_bwd* s, void* stream) {
   LAS_REQUIRE(lds <= 64 * 1024, "las_decoder_step_bwd: shapes exceed the LDS budget");
   hipLaunchKernelGGL(dec_step_bwd_kernel, dim3(s->B), dim3(256), lds, (hipStream_t)stream, *s);
   LAS_LAUNCH_CHECK("decoder step bwd launch");
+  return LAS_OK;
+}
+
+extern "C" int las_seq_sigmoid_loss(const float* logits, int64_t ldl, const las_bf16* targets, int64_t ldt,
+                                    const int32_t* seq_len, int B, int U, int nf, float grad_scale, float* loss_out,
+                                    las_bf16* dlogits, int64_t ldd, void* stream) {
+  LAS_REQUIRE(B > 0 && U > 0 && nf > 0 && logits && targets && seq_len && loss_out, "las_seq_sigmoid_loss: bad arguments");
+  int blocks = (B * U + 3) / 4;
+  if (blocks > 256) blocks = 256;
+  hipLaunchKernelGGL(seq_sigmoid_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, logits, ldl, targets, ldt, seq_len, B,
+                     U, nf, grad_scale, loss_out, dlogits, ldd);
+  LAS_LAUNCH_CHECK("seq sigmoid launch");
+  return LAS_OK;
+}
+
+extern "C" int las_sample_features(const float* logits, int64_t ldl, int nf, const las_bf16* teacher, int64_t ldt,
+                                   las_bf16* next, int64_t ldn, int B, float prob, uint32_t seed, uint32_t step, void* stream) {
+  LAS_REQUIRE(B > 0 && nf > 0 && logits && next && prob >= 0.f && prob <= 1.f, "las_sample_features: bad arguments");
+  hipLaunchKernelGGL(sample_features_kernel, dim3((B * nf + 255) / 256), dim3(256), 0, (hipStream_t)stream, logits, ldl, nf,
+                     teacher, ldt, next, ldn, B, prob, seed, step);
+  LAS_LAUNCH_CHECK("sample features launch");
   return LAS_OK;
 }
 

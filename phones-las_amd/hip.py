@@ -34,6 +34,8 @@ _SIGS = {
     'las_decoder_step_fwd': ([_vp, _i32, _vp], C.c_int),
     'las_decoder_step_bwd': ([_vp, _vp], C.c_int),
     'las_seq_ce_loss': ([_vp, _i64, _vp, _vp, _i32, _i32, _i32, _f32, _vp, _vp, _i64, _vp], C.c_int),
+    'las_seq_sigmoid_loss': ([_vp, _i64, _vp, _i64, _vp, _i32, _i32, _i32, _f32, _vp, _vp, _i64, _vp], C.c_int),
+    'las_sample_features': ([_vp, _i64, _i32, _vp, _i64, _vp, _i64, _i32, _f32, C.c_uint32, C.c_uint32, _vp], C.c_int),
     'las_grad_l2_norms': ([_vp, _vp, _vp, _i32, _i64, _f32, _vp, _vp, _vp], C.c_int),
     'las_clip_adam_update': ([_vp, _vp, _vp, _vp, _vp, _i32, _i64, _vp, _f32, _f32, _f32, _f32, _f32, _i32, _vp, _vp, _vp], C.c_int),
     'las_grad_clip': ([_vp, _vp, _i32, _i64, _vp, _f32, _vp], C.c_int),

@@ -4,10 +4,8 @@
 TF builds a graph and differentiates it; here each function runs the HIP kernels eagerly and, in TRAIN
 mode, records what the hand-written backward needs (``Listener.backward`` / ``Speller.backward``).
 
-Supported on the HIP path this round (anything else raises ValueError, never a silent fallback):
-  listener: pyramidal (Bi)LSTM stacks (--use_pyramidal), num_units in {64,128,256,512};
-  speller : one decoder layer, attention_type luong | bahdanau, attention_layer_size None,
-            one-hot token feed (embedding_size 0), teacher forcing (sampling_probability 0) and greedy decode.
+``Speller`` below is the fused fast path (one decoder layer, luong | bahdanau, no attention layer, one-hot token feed);
+``make_speller`` routes every other configuration -- and the binary-feature decoders -- to speller_general.GeneralSpeller.
 """
 import ctypes as C
 import os
@@ -134,21 +132,23 @@ _ATT = {'luong': hip.ATT_LUONG, 'bahdanau': hip.ATT_BAHDANAU, 'custom': hip.ATT_
 _ATT_FUSED = ('luong', 'bahdanau')            # mechanisms of the fused single-cell fast path
 
 
-def make_speller(hparams, variables, memory_depth, binf2phone=None):
+def make_speller(hparams, variables, memory_depth, binf2phone=None, scope='speller', phones_only=False):
     """The decoder for ``hparams``: the fused single-cell path when the configuration allows it, else the general
     cell stack (speller_general.GeneralSpeller: multi-layer, --bottom_only AttentionMultiCell, attention layer,
-    embedding)."""
+    embedding, the two binary-feature decoders).  phones_only: the plain phone decoder of a --multitask model (the
+    first las.model.speller call of model_helper.py:211-217, binary_outputs=False); scope: variable-name prefix."""
     d = hparams
     if d.attention_type not in _ATT:
         raise ValueError('attention_type %r is not one of %s' % (d.attention_type, sorted(_ATT)))
     binf = bool(getattr(d, 'binf_projection', False))
-    if getattr(d, 'binary_outputs', False) and not binf:
-        raise ValueError('--binary_outputs without --binf_projection is not implemented on the HIP path')
+    sigmoid = bool(getattr(d, 'binary_outputs', False)) and not binf and not phones_only
+    binf = binf and not phones_only
     if (d.num_layers == 1 and not d.attention_layer_size and not d.embedding_size and d.attention_type in _ATT_FUSED
-            and not binf):
+            and not binf and not sigmoid and scope == 'speller'):
         return Speller(hparams, variables, memory_depth)
     from .speller_general import GeneralSpeller
-    return GeneralSpeller(hparams, variables, memory_depth, _ATT[d.attention_type], binf2phone=binf2phone if binf else None)
+    return GeneralSpeller(hparams, variables, memory_depth, _ATT[d.attention_type],
+                          binf2phone=binf2phone if (binf or sigmoid) else None, sigmoid=sigmoid, scope=scope)
 
 
 class Speller:
@@ -164,8 +164,6 @@ class Speller:
             raise ValueError('attention_layer_size is not implemented on the HIP path this round')
         if d.embedding_size:
             raise ValueError('embedding_size > 0 is not implemented on the HIP path this round')
-        if getattr(d, 'binf_projection', False) or getattr(d, 'binary_outputs', False):
-            raise ValueError('binary-feature decoders are not implemented on the HIP path this round')
         self.hp = d
         self.att = _ATT[d.attention_type]
         self.V, self.Vp = d.target_vocab_size, _r8(d.target_vocab_size)

@@ -50,24 +50,28 @@ def gather_tree(step_ids, parent_ids, max_len, end_token):
 
 
 class GeneralSpeller:
-    K_MEM = 'speller/memory_layer/kernel'
-    K_PROJ = 'speller/projection_layer/kernel'
-    B_PROJ = 'speller/projection_layer/bias'
-    K_Q = 'speller/query_layer/kernel'
-    V_ATT = 'speller/attention_v'
-    K_AL = 'speller/attention_layer/kernel'
-    K_EMB = 'speller/target_embedding'
-    B_SCORE = 'speller/attention_score_bias'
     NOISE_STREAM = 3                     # generator stream of the monotonic-attention score noise (draw (t*B + b)*Tm + t')
 
-    def __init__(self, hparams, variables, memory_depth, att_code, binf2phone=None):
+    def __init__(self, hparams, variables, memory_depth, att_code, binf2phone=None, sigmoid=False, scope='speller'):
         """binf2phone [binf_count, V] (0/1, constant): the --binf_projection decoder (las/model.py:179-183,242-257,
         utils/training_helper.py:17-27,122-153): tokens are fed as their binary-feature vectors, the attention layer
         emits A = 2*binf_count values [log p(f=1) | log p(f=0)] and the 'projection' is the fixed map
         logits = lp1 * Mb + lp0 * (1 - Mb); the Dense kernel/bias of projection_layer exist as variables but are not
-        applied (inner_projection_layer=False)."""
+        applied (inner_projection_layer=False).
+        sigmoid: the sigmoid-output decoder (--binary_outputs without --binf_projection; las/model.py:237-241,251-257,
+        283-291,320-336): the decoder input of a step is a binary-feature VECTOR (TRAIN: the features of the teacher's
+        token, rows of binf2phone^T; inference: the rounded sigmoid of the previous output), the projection is a plain
+        Dense(binf_count) and its outputs are feature logits.  binf2phone may then be None (inference without a map).
+        scope: variable-name prefix ('speller'; the second decoder of --multitask lives under 'speller_binf',
+        model_helper.py:219-227)."""
         d = hparams
-        self.binf = binf2phone
+        self.scope = scope
+        self.K_MEM, self.K_PROJ, self.B_PROJ = scope + '/memory_layer/kernel', scope + '/projection_layer/kernel', scope + '/projection_layer/bias'
+        self.K_Q, self.V_ATT, self.K_AL = scope + '/query_layer/kernel', scope + '/attention_v', scope + '/attention_layer/kernel'
+        self.K_EMB, self.B_SCORE = scope + '/target_embedding', scope + '/attention_score_bias'
+        self.sigmoid = bool(sigmoid)
+        self.binf = binf2phone if not sigmoid else None      # the binf_projection machinery (fixed output map, A = 2 nf)
+        self.feat = binf2phone                               # feature table of the token feed (both binary decoders)
         if binf2phone is not None and d.bottom_only and d.num_layers > 1:
             raise ValueError('binf_projection needs the decoder output to be the 2*binf_count attention vector: '
                              'use decoder_layers 1 or drop --bottom_only')
@@ -91,6 +95,16 @@ class GeneralSpeller:
             self.nf = int(self.binf.shape[0])
             self.A, self.has_al = 2 * self.nf, True
             self.emb, self.E = True, self.nf          # a constant embedding table: rows of Mb^T
+        if self.sigmoid:
+            if d.embedding_size:
+                raise ValueError('the sigmoid-output decoder with embedding_size > 0 is not implemented on the HIP path')
+            self.nf = int(d.binf_count)
+            if self.feat is not None and int(self.feat.shape[0]) != self.nf:
+                raise ValueError('binf2phone has %d rows, binf_count is %d' % (int(self.feat.shape[0]), self.nf))
+            self.emb, self.E = True, self.nf          # the feature vector itself is the decoder input
+        # width of the projection layer's output: phones, or binary features for the sigmoid-output decoder
+        self.Vo = self.nf if self.sigmoid else self.V
+        self.Vop = _r8(self.Vo)
         for n, v in (('decoder_units', self.Hd), ('attention depth', self.A)):      # the token width is zero-padded
             if v % 8:
                 raise ValueError('%s must be a multiple of 8 on the HIP path' % n)
@@ -98,7 +112,7 @@ class GeneralSpeller:
         # Dense token feed (embedding / binary features) under input dropout: the DropoutWrapper mask is element-wise on
         # the embedded token, so it cannot be folded into a per-token row table; the (zero-padded) token vector then
         # travels as the first T0 columns of cell 0's GEMM operand: X_0 = [emb(y) | attention_{t-1} | h_{t-1}].
-        self.tokx = self.emb and (d.dropout or 0.0) > 0
+        self.tokx = self.emb and ((d.dropout or 0.0) > 0 or self.sigmoid)     # (sigmoid: inference feeds arbitrary vectors)
         self.T0 = _r8(self.E) if self.tokx else 0
         Hd, A = self.Hd, self.A
         # GEMM input width of each cell (without the token part of cell 0) and where its pieces sit
@@ -116,9 +130,9 @@ class GeneralSpeller:
         self.tok = torch.empty(self.V, 4 * Hd, dtype=bf, device=dev)
         self.wmemT = torch.empty(Hd, self.M, dtype=bf, device=dev)
         self.wmem = torch.empty(self.M, Hd, dtype=bf, device=dev)
-        self.wprojT = torch.empty(self.Vp, self.P, dtype=bf, device=dev)
-        self.wproj = torch.empty(self.P, self.Vp, dtype=bf, device=dev)
-        self.bproj = torch.zeros(self.Vp, dtype=torch.float32, device=dev)
+        self.wprojT = torch.empty(self.Vop, self.P, dtype=bf, device=dev)
+        self.wproj = torch.empty(self.P, self.Vop, dtype=bf, device=dev)
+        self.bproj = torch.zeros(self.Vop, dtype=torch.float32, device=dev)
         if self.has_al:
             self.walT = torch.empty(A, Hd + self.M, dtype=bf, device=dev)
             self.waln = torch.empty(Hd + self.M, A, dtype=bf, device=dev)
@@ -127,9 +141,10 @@ class GeneralSpeller:
             self.emb_bf = torch.zeros(self.V, self.Ep, dtype=bf, device=dev)
             self.k0tokT = torch.zeros(4 * Hd, self.Ep, dtype=bf, device=dev)
             self.k0tok = torch.zeros(self.Ep, 4 * Hd, dtype=bf, device=dev)
+        if self.feat is not None:
+            self.emb_bf[:, :self.nf].copy_(self.feat.to(device=dev, dtype=torch.float32).t())
         if self.binf is not None:
             Mb = self.binf.to(device=dev, dtype=torch.float32)
-            self.emb_bf[:, :self.nf].copy_(Mb.t())
             wb = torch.cat([Mb, 1.0 - Mb], 0)                         # [2nf, V]: logits = [lp1 | lp0] Wb
             self.wproj.zero_()
             self.wprojT.zero_()
@@ -148,12 +163,12 @@ class GeneralSpeller:
         """generator stream of the input mask of cell l at step t (element index b*win_l + c)."""
         return 64 + l * 4096 + t
 
-    @staticmethod
-    def cell_names(l):
-        return ('speller/decoder_cell_%d/lstm_cell/kernel' % l, 'speller/decoder_cell_%d/lstm_cell/bias' % l)
+    def cell_names(self, l):
+        return ('%s/decoder_cell_%d/lstm_cell/kernel' % (self.scope, l), '%s/decoder_cell_%d/lstm_cell/bias' % (self.scope, l))
 
     def refresh(self, var):
         Hd, M, V, Vp, E, A = self.Hd, self.M, self.V, self.Vp, self.E, self.A
+        Vo, Vop = self.Vo, self.Vop
         hip.cast_bf16(var[self.K_MEM], M, Hd, self.wmemT, Hd, M, transpose=True)
         hip.cast_bf16(var[self.K_MEM], M, Hd, self.wmem, M, Hd)
         self.bias = []
@@ -177,7 +192,7 @@ class GeneralSpeller:
         k0 = var[self.cell_names(0)[0]]
         Ep = self.Ep
         if self.emb:
-            if self.binf is None:
+            if self.feat is None and not self.sigmoid:
                 hip.cast_bf16(var[self.K_EMB], V, E, self.emb_bf, V, Ep)
             hip.cast_bf16(k0, E, 4 * Hd, self.k0tokT, 4 * Hd, Ep, transpose=True, lds=4 * Hd)
             hip.cast_bf16(k0, E, 4 * Hd, self.k0tok, Ep, 4 * Hd, lds=4 * Hd)
@@ -187,9 +202,9 @@ class GeneralSpeller:
             hip.cast_bf16(k0, V, 4 * Hd, self.tok, V, 4 * Hd, lds=4 * Hd)
         P = self.P
         if self.binf is None:            # binf_projection: the fixed map set up in __init__; kernel/bias are not applied
-            hip.cast_bf16(var[self.K_PROJ], P, V, self.wprojT, Vp, P, transpose=True)
-            hip.cast_bf16(var[self.K_PROJ], P, V, self.wproj, P, Vp)
-            self.bproj[:V].copy_(var[self.B_PROJ])
+            hip.cast_bf16(var[self.K_PROJ], P, Vo, self.wprojT, Vop, P, transpose=True)
+            hip.cast_bf16(var[self.K_PROJ], P, Vo, self.wproj, P, Vop)
+            self.bproj[:Vo].copy_(var[self.B_PROJ])
         if self.has_al:
             hip.cast_bf16(var[self.K_AL], Hd + M, A, self.walT, A, Hd + M, transpose=True)
             hip.cast_bf16(var[self.K_AL], Hd + M, A, self.waln, Hd + M, A)
@@ -281,9 +296,12 @@ class GeneralSpeller:
 
     def forward_train(self, memory, mem_len, encoder_state, targets_inputs, num_steps, parts=4, seed=0):
         B, Tm, M = memory.shape
-        Hd, V, Vp, U, A, NL = self.Hd, self.V, self.Vp, num_steps, self.A, self.NL
+        Hd, V, Vp, U, A, NL = self.Hd, self.V, self.Vop, num_steps, self.A, self.NL      # Vp: padded projection width
         dev, bf, f32 = memory.device, torch.bfloat16, torch.float32
         Tmp = _r8(Tm)
+        if self.sigmoid and self.feat is None:
+            raise ValueError('training the sigmoid-output decoder needs the binf2phone map (the targets\' feature vectors, '
+                             'model_helper.py:199-200)')
         init, passed = self._init_states(encoder_state, B)
         keys = self._keys(memory)
         keep = 1.0 - float(self.hp.dropout or 0.0)
@@ -321,7 +339,9 @@ class GeneralSpeller:
         for t in range(U):
             last = t + 1 == U
 
-            if self.tokx:                 # embedded token of this step into the operand (dropped with the rest below)
+            if self.tokx and not (self.sigmoid and sampling > 0.0 and t > 0):
+                # embedded token of this step into the operand (dropped with the rest below); the sigmoid-output decoder
+                # under scheduled sampling got its input vector from las_sample_features at the end of step t-1
                 X[0][:, t, :self.Ep] = self.emb_bf[fed[:, t].long()]
 
             def run_cell(l):
@@ -361,7 +381,13 @@ class GeneralSpeller:
                 out_t = h[NL - 1][:, t] if (self.bottom and NL > 1) else att[:, t]
                 hip.gemm_nt(out_t, self.wprojT, logits[:, t], B, Vp, self.P, lda=out_t.stride(0), ldb=self.P, ldc=U * Vp,
                             bias=self.bproj)
-                if not last:
+                if not last and self.sigmoid:
+                    # ScheduledSigmoidHelper: Bernoulli(sigmoid(logits)) feature draws or the teacher's feature vector
+                    teach = self.emb_bf[tin[:, t + 1].long()]
+                    hip.check(lib.las_sample_features(hip.addr(logits, t * Vp), U * Vp, self.nf, hip.p(teach), self.Ep,
+                                                      hip.addr(X[0], (t + 1) * (self.win[0] + Hd)), U * (self.win[0] + Hd), B,
+                                                      sampling, seed, t, st))
+                elif not last:
                     hip.check(lib.las_sample_tokens(hip.addr(logits, t * Vp), U * Vp, V, hip.addr(tin, t + 1), tin.stride(0),
                                                     hip.addr(fed, t + 1), fed.stride(0), B, sampling, seed, t, st))
         out_all = h[NL - 1] if (self.bottom and NL > 1) else att
@@ -405,13 +431,14 @@ class GeneralSpeller:
         sv = self.saved
         B, Tm, U = sv['B'], sv['Tm'], sv['U']
         Hd, V, Vp, M, A, NL, P = self.Hd, self.V, self.Vp, self.M, self.A, self.NL, self.P
+        Vo, Vop = self.Vo, self.Vop
         Tmp = _r8(Tm)
         dev, bf, f32 = dlogits.device, torch.bfloat16, torch.float32
         lib, st = hip.lib(), hip.stream()
         BU = B * U
         bah = self.additive
         d_out = torch.empty(B, U, P, dtype=f32, device=dev)
-        hip.gemm_nt(dlogits, self.wproj, d_out, BU, P, Vp, lda=Vp, ldb=Vp, ldc=P)
+        hip.gemm_nt(dlogits, self.wproj, d_out, BU, P, Vop, lda=Vop, ldb=Vop, ldc=P)
         if sv.get('dreg') is not None:       # gradient of compute_log_probs_loss w.r.t. the raw outputs (binf_projection)
             d_out.add_(sv['dreg'])
         dc = [torch.zeros(B, Hd, dtype=f32, device=dev) for _ in range(NL)]
@@ -431,7 +458,7 @@ class GeneralSpeller:
             carry = torch.zeros(B, Tmp, dtype=f32, device=dev)
         qlayer = 0 if self.bottom else NL - 1
         W = [w + Hd for w in self.win]
-        dtokx = torch.empty(B, U, self.Ep, dtype=bf, device=dev) if (self.tokx and self.binf is None) else None
+        dtokx = torch.empty(B, U, self.Ep, dtype=bf, device=dev) if (self.tokx and self.feat is None and not self.sigmoid) else None
 
         def v(buf, off, ld):              # (address, row stride) of a column window of a [B, ld] fp32 buffer
             return (hip.addr(buf, off), ld)
@@ -521,8 +548,8 @@ class GeneralSpeller:
         hip.gemm_nt(dkeys_bf, self.wmem, dmem, B * Tm, M, Hd, lda=Hd, ldb=Hd, ldc=M, accumulate=True)
         # ---- weight gradients ----
         if self.binf is None:
-            hip.gemm_tn(sv['out'], dlogits, grads[self.K_PROJ], P, V, BU, lda=P, ldb=Vp, ldc=V, split_k=4)
-            hip.colsum_bf16(dlogits, BU, V, grads[self.B_PROJ], ldx=Vp)
+            hip.gemm_tn(sv['out'], dlogits, grads[self.K_PROJ], P, Vo, BU, lda=P, ldb=Vop, ldc=Vo, split_k=4)
+            hip.colsum_bf16(dlogits, BU, Vo, grads[self.B_PROJ], ldx=Vop)
         hip.gemm_tn(sv['memory'], dkeys_bf, grads[self.K_MEM], M, Hd, B * Tm, lda=M, ldb=Hd, ldc=Hd, split_k=8)
         if self.uses_wq:
             hip.gemm_tn(sv['h'][qlayer], dpq_all, grads[self.K_Q], Hd, Hd, BU, lda=Hd, ldb=Hd, ldc=Hd, split_k=4)
@@ -597,6 +624,14 @@ class GeneralSpeller:
         K = int(beam_width)
         if partial_targets is not None and K <= 0:
             raise ValueError('partial_targets is a beam-search option (las/model.py:298-307)')
+        # the sigmoid-output decoder decodes with the InferenceHelper of las/model.py:320-336: the first input is the
+        # feature vector of <s> (zeros, 1, 0), a step's sample is round(sigmoid(logits)), fed back as it is, and an utterance
+        # ends when its last feature (the one of </s>) is set
+        binary = self.sigmoid
+        if binary and K > 0:
+            raise ValueError('beam search over the sigmoid-output decoder: the reference\'s BeamSearchDecoder needs the phone '
+                             'scores of transform_binf_to_phones, which are undefined for binf_count-wide outputs '
+                             '(utils/training_helper.py:17-27)')
         if K > 0:                       # tf.contrib.seq2seq.tile_batch of memory, lengths and the encoder state
             B0 = memory.shape[0]
             tile = lambda x: x.repeat_interleave(K, 0).contiguous()
@@ -606,7 +641,7 @@ class GeneralSpeller:
             else:
                 encoder_state = type(encoder_state)(tile(encoder_state.c), tile(encoder_state.h))
         B, Tm, M = memory.shape
-        Hd, V, Vp, A, NL = self.Hd, self.V, self.Vp, self.A, self.NL
+        Hd, V, Vp, A, NL = self.Hd, self.Vo, self.Vop, self.A, self.NL       # V / Vp: width of the projection output
         dev, bf, f32 = memory.device, torch.bfloat16, torch.float32
         # steps [0, L) run teacher-forced over the partial targets (no projection, no search), the search follows
         L = 0
@@ -641,6 +676,9 @@ class GeneralSpeller:
         z = torch.empty(B, 4 * Hd, dtype=f32, device=dev)
         logits = torch.zeros(B, U, Vp, dtype=f32, device=dev)
         samples = torch.full((B, U), d.eos_id, dtype=torch.int32, device=dev)
+        if binary:
+            samples = torch.zeros(B, U, self.nf, dtype=f32, device=dev)
+            sv['X'][0][:, 0, self.nf - 2] = 1.0                       # start_inputs = [0, ..., 0, 1, 0]
         finished = torch.zeros(B, dtype=torch.bool, device=dev)
         final_len = torch.zeros(B, dtype=torch.int32, device=dev)
         X, h = sv['X'], sv['h']
@@ -659,7 +697,7 @@ class GeneralSpeller:
         for t in range(S):
             last = t + 1 == S
 
-            if self.tokx:
+            if self.tokx and not binary:
                 X[0][:, t, :self.Ep] = self.emb_bf[fed[:, t].long()]
 
             def run_cell(l):
@@ -705,14 +743,22 @@ class GeneralSpeller:
                 samples[:, t] = sample
                 parents[:, t] = b_par.view(-1)
                 finished = b_fin.view(-1) != 0
+            elif binary:
+                sample = (logits[:, t, :V] > 0).to(f32)                # round(sigmoid(x)): 1 iff x > 0
+                samples[:, t] = sample
+                final_len = torch.where(finished, final_len, torch.full_like(final_len, t + 1))
+                finished = finished | (sample[:, V - 1] > 0.5)          # end_fn: the </s> feature
             else:
                 sample = logits[:, t, :V].argmax(-1).to(torch.int32)
                 samples[:, t] = sample
                 final_len = torch.where(finished, final_len, torch.full_like(final_len, t + 1))
                 finished = finished | (sample == d.eos_id)
             steps = t + 1
+            if not last and binary:
+                X[0][:, t + 1, :V] = sample.to(bf)
             if not last:
-                fed[:, t + 1] = sample
+                if not binary:
+                    fed[:, t + 1] = sample
                 X[0][:, t + 1, self.T0:self.T0 + A].copy_(att[:, t])
                 if self.bottom:
                     for l in range(1, NL):
@@ -733,4 +779,6 @@ class GeneralSpeller:
                               parents[:, L:steps].reshape(B0, K, n).permute(2, 0, 1).cpu().numpy(),
                               b_len.max(1).values.cpu().numpy(), d.eos_id)
             return torch.from_numpy(ids).permute(1, 0, 2).contiguous().to(dev), b_len, b_lp
+        # raw cell outputs of the decode: what BasicTransparentProjectionDecoder returns as rnn_output (training_helper.py:156-178)
+        self.last_raw_outputs = (h[NL - 1] if (self.bottom and NL > 1) else att)[:, :steps]
         return logits[:, :steps, :V], samples[:, :steps], final_len, sv['align'][:, :steps, :Tm]

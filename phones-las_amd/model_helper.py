@@ -17,7 +17,7 @@ from .las import model as las_model
 from .las.ops import TRAIN, EVAL, PREDICT
 from .utils import metrics_utils
 
-__all__ = ['las_model_fn', 'LasModel', 'param_table', 'compute_loss', 'EstimatorSpec', 'GRAD_NORM']
+__all__ = ['las_model_fn', 'LasModel', 'param_table', 'compute_loss', 'compute_loss_sigmoid', 'EstimatorSpec', 'GRAD_NORM']
 
 GRAD_NORM = 2            # model_helper.py:16
 EstimatorSpec = collections.namedtuple('EstimatorSpec', ['mode', 'loss', 'train_op', 'predictions', 'eval_metric_ops'])
@@ -45,35 +45,60 @@ def param_table(params):
             out.append((base + '/kernel', (D + H, 4 * H), 'lstm'))
             out.append((base + '/bias', (4 * H,), 'zeros'))
         D = len(dirs) * H * (1 if l == 0 else 2) if e.use_pyramidal else H
-    M, Hd, V = _enc_depth(e), d.num_units, d.target_vocab_size
-    A = (2 * d.binf_count) if getattr(d, 'binf_projection', False) else (d.attention_layer_size or M)
+    M, V = _enc_depth(e), d.target_vocab_size
+    for scope, kind in speller_plan(d):
+        out.extend(_speller_table(d, M, scope, kind))
+    if params.ctc_weight > 0:
+        out.append(('ctc_logits/kernel', (M, V + 1), 'glorot'))
+        out.append(('ctc_logits/bias', (V + 1,), 'zeros'))
+    return out
+
+
+def speller_plan(d):
+    """[(variable scope, kind)] of the decoders las_model_fn builds (model_helper.py:211-227): kind 'phones' (softmax over
+    the vocabulary), 'binf_projection' (--binary_outputs --binf_projection: DenseBinfDecoder's fixed feature-to-phone map)
+    or 'sigmoid' (--binary_outputs alone: feature logits).  A binary model has ONE decoder unless --multitask adds the
+    phone decoder in front of it.  Scopes: the reference names the binary decoder 'speller_binf' in every case; here a
+    single decoder always lives under 'speller' (TF checkpoints cannot be loaded either way) and only the second decoder
+    of a multitask model under 'speller_binf'."""
+    binary = bool(getattr(d, 'binary_outputs', False))
+    kind = 'binf_projection' if getattr(d, 'binf_projection', False) else 'sigmoid'
+    if not binary:
+        return [('speller', 'phones')]
+    if getattr(d, 'multitask', False):
+        return [('speller', 'phones'), ('speller_binf', kind)]
+    return [('speller', kind)]
+
+
+def _speller_table(d, M, scope, kind):
+    Hd, V = d.num_units, d.target_vocab_size
+    out = []
+    A = (2 * d.binf_count) if kind == 'binf_projection' else (d.attention_layer_size or M)
     E = d.embedding_size if d.embedding_size else V
-    if getattr(d, 'binf_projection', False) and not d.embedding_size:
-        E = d.binf_count            # embedding_fn = rows of binf2phone^T (las/model.py:242-243)
+    if kind != 'phones' and not d.embedding_size:
+        E = d.binf_count            # embedding_fn = rows of binf2phone^T / the feature vector itself (las/model.py:237-243)
+    Vo = d.binf_count if kind == 'sigmoid' else V          # DenseBinfDecoder(binf_count units) (las/model.py:251-252)
     if d.embedding_size:
-        out.append(('speller/target_embedding', (V, d.embedding_size), 'glorot'))
-    out.append(('speller/memory_layer/kernel', (M, Hd), 'glorot'))
+        out.append((scope + '/target_embedding', (V, d.embedding_size), 'glorot'))
+    out.append((scope + '/memory_layer/kernel', (M, Hd), 'glorot'))
     if d.attention_type in ('bahdanau', 'bahdanau_monotonic', 'custom'):
-        out.append(('speller/query_layer/kernel', (Hd, Hd), 'glorot'))
+        out.append((scope + '/query_layer/kernel', (Hd, Hd), 'glorot'))
     if d.attention_type in ('bahdanau', 'bahdanau_monotonic'):
-        out.append(('speller/attention_v', (Hd,), 'glorot_v'))
+        out.append((scope + '/attention_v', (Hd,), 'glorot_v'))
     if d.attention_type in ('luong_monotonic', 'bahdanau_monotonic'):
-        out.append(('speller/attention_score_bias', (1,), 'zeros'))
-    if d.attention_layer_size or getattr(d, 'binf_projection', False):
-        out.append(('speller/attention_layer/kernel', (Hd + M, A), 'glorot'))
+        out.append((scope + '/attention_score_bias', (1,), 'zeros'))
+    if d.attention_layer_size or kind == 'binf_projection':
+        out.append((scope + '/attention_layer/kernel', (Hd + M, A), 'glorot'))
     for l in range(d.num_layers):
         if d.bottom_only:       # AttentionMultiCell: cell_1 reads [attention_t, attention_{t-1}], upper cells [h_{l-1}, attention_{t-1}]
             din = (E + A) if l == 0 else ((A + A) if l == 1 else (Hd + A))
         else:
             din = (E + A) if l == 0 else Hd
-        out.append(('speller/decoder_cell_%d/lstm_cell/kernel' % l, (din + Hd, 4 * Hd), 'lstm'))
-        out.append(('speller/decoder_cell_%d/lstm_cell/bias' % l, (4 * Hd,), 'zeros'))
+        out.append((scope + '/decoder_cell_%d/lstm_cell/kernel' % l, (din + Hd, 4 * Hd), 'lstm'))
+        out.append((scope + '/decoder_cell_%d/lstm_cell/bias' % l, (4 * Hd,), 'zeros'))
     P = Hd if (d.bottom_only and d.num_layers > 1) else A      # AttentionMultiCell with upper layers outputs h_top
-    out.append(('speller/projection_layer/kernel', (P, V), 'proj'))
-    out.append(('speller/projection_layer/bias', (V,), 'zeros'))
-    if params.ctc_weight > 0:
-        out.append(('ctc_logits/kernel', (M, V + 1), 'glorot'))
-        out.append(('ctc_logits/bias', (V + 1,), 'zeros'))
+    out.append((scope + '/projection_layer/kernel', (P, Vo), 'proj'))
+    out.append((scope + '/projection_layer/bias', (Vo,), 'zeros'))
     return out
 
 
@@ -193,6 +218,37 @@ def compute_loss(logits, targets, final_sequence_length, target_sequence_length,
     return loss, dlogits
 
 
+def compute_loss_sigmoid(logits, targets_binf, final_sequence_length, target_sequence_length, mode, nf, grad_scale=1.0,
+                         want_grad=False):
+    """model_helper.py:98-130 over sequence_loss_sigmoid (:81-95).  logits fp32 [B,U,ldl] (first nf columns: feature
+    logits), targets_binf bf16 0/1 [B,Ut,ldt].  TRAIN: weights = sequence_mask(target_len).  EVAL: logits cut at the
+    longest decoded length, both padded with zeros to the longer of (targets, decoded), weights over max(target_len,
+    final_len) per utterance.  Returns (loss [1], dlogits bf16 or None)."""
+    B, U, ldl = logits.shape
+    dev = logits.device
+    if mode != TRAIN:
+        max_ts = int(target_sequence_length.max().item())
+        max_fs = int(final_sequence_length.max().item())
+        L = max(max_ts, max_fs)
+        lg = torch.zeros(B, L, ldl, dtype=torch.float32, device=dev)
+        n = min(max_fs, U)
+        lg[:, :n] = logits[:, :n]
+        tg = torch.zeros(B, L, targets_binf.shape[-1], dtype=torch.bfloat16, device=dev)
+        n = min(L, targets_binf.shape[1])
+        tg[:, :n] = targets_binf[:, :n]
+        lens = torch.maximum(target_sequence_length.to(torch.int32), final_sequence_length.to(torch.int32))
+        logits, targets_binf, target_sequence_length, U = lg, tg, lens, L
+    tg = targets_binf[:, :U].contiguous()
+    if tg.shape[1] < U:
+        raise ValueError('targets shorter than the decoded length')
+    loss = torch.zeros(1, dtype=torch.float32, device=dev)
+    dlogits = torch.zeros(B, U, ldl, dtype=torch.bfloat16, device=dev) if want_grad else None
+    tlen32 = target_sequence_length.to(torch.int32)     # named: a temporary would be recycled before the launch
+    hip.check(hip.lib().las_seq_sigmoid_loss(hip.p(logits), ldl, hip.p(tg), tg.shape[-1], hip.p(tlen32), B, U, nf,
+                                             float(grad_scale), hip.p(loss), hip.p(dlogits), ldl, hip.stream()))
+    return loss, dlogits
+
+
 class CtcHead:
     """Dense(M -> V+1) on the encoder outputs + tf.nn.ctc_loss_v2 (model_helper.py:347-358): blank index 0, labels =
     targets_outputs incl. </s> with label_length = target_sequence_length, logit_length = reduced source length,
@@ -267,24 +323,32 @@ class LasModel:
         hip.lib()
         self.params = params
         d = params.decoder
-        self.binf_projection = bool(getattr(d, 'binf_projection', False))
-        if getattr(d, 'binary_outputs', False) and not self.binf_projection:
-            raise ValueError('--binary_outputs without --binf_projection (sigmoid decoders, utils/training_helper.py:30-45,'
-                             '89-119) is not implemented on the HIP path')
-        if self.binf_projection:
-            if binf2phone is None:
+        binary = bool(getattr(d, 'binary_outputs', False))
+        self.binf_projection = binary and bool(getattr(d, 'binf_projection', False))
+        self.sigmoid = binary and not self.binf_projection       # feature-logit outputs (a12 / a14 of SURVEY.md 8a)
+        if binary:
+            if getattr(d, 'binf_trainable', False) or getattr(d, 'binf_sampling', False):
+                raise ValueError('binf_trainable / binf_sampling are not implemented on the HIP path')
+            if self.binf_projection and binf2phone is None:
                 raise ValueError('binf_projection needs the binf2phone matrix (--binf_map)')
-            if getattr(d, 'binf_trainable', False) or getattr(d, 'multitask', False) or getattr(d, 'binf_sampling', False):
-                raise ValueError('binf_trainable / multitask / binf_sampling are not implemented on the HIP path')
-            binf2phone = torch.as_tensor(np.asarray(binf2phone), dtype=torch.float32)
-            if tuple(binf2phone.shape) != (d.binf_count, d.target_vocab_size):
-                raise ValueError('binf2phone must be [binf_count=%d, target_vocab_size=%d], got %s'
-                                 % (d.binf_count, d.target_vocab_size, tuple(binf2phone.shape)))
+            if binf2phone is not None:
+                binf2phone = torch.as_tensor(np.asarray(binf2phone), dtype=torch.float32)
+                if tuple(binf2phone.shape) != (d.binf_count, d.target_vocab_size):
+                    raise ValueError('binf2phone must be [binf_count=%d, target_vocab_size=%d], got %s'
+                                     % (d.binf_count, d.target_vocab_size, tuple(binf2phone.shape)))
         self.vars = Variables(param_table(params))
         self.vars.initialize(seed)
         self.listener = las_model.Listener(params.encoder, self.vars.params, params.num_channels)
-        self.speller = las_model.make_speller(params.decoder, self.vars.params, _enc_depth(params.encoder),
-                                              binf2phone=binf2phone if self.binf_projection else None)
+        # the decoders of model_helper.py:211-227: [(module, kind)]; self.speller is the first one (the only one unless
+        # --multitask), self.speller_binf the binary decoder of a multitask model
+        self.spellers = []
+        for scope, kind in speller_plan(d):
+            mod = las_model.make_speller(d, self.vars.params, _enc_depth(params.encoder),
+                                         binf2phone=binf2phone if kind != 'phones' else None, scope=scope,
+                                         phones_only=(kind == 'phones'))
+            self.spellers.append((mod, kind))
+        self.speller = self.spellers[0][0]
+        self.speller_binf = self.spellers[1][0] if len(self.spellers) > 1 else None
         self.ctc = CtcHead(params, self.vars.params, _enc_depth(params.encoder)) if params.ctc_weight > 0 else None
         self.global_step = 0
         self.rng_seed = (seed * 2654435761 + 12345) & 0x7fffffff      # base of the dropout / sampling draws
@@ -303,7 +367,8 @@ class LasModel:
 
     def refresh_images(self):
         self.listener.refresh(self.vars.params)
-        self.speller.refresh(self.vars.params)
+        for mod, _ in self.spellers:
+            mod.refresh(self.vars.params)
         if self.ctc is not None:
             self.ctc.refresh(self.vars.params)
         self._images_stale = False
@@ -320,11 +385,22 @@ class LasModel:
         self.last_seed = step_seed
         (mem, mem_len), state = self.listener.forward(x, src_len, TRAIN, seed=step_seed)
         U = num_steps if num_steps is not None else int(tlen.max().item())
-        logits = self.speller.forward_train(mem, mem_len, state, tin, U, seed=step_seed)
-        loss, dlogits = compute_loss(logits, tout, None, tlen, TRAIN, self.params.decoder.eos_id,
-                                     grad_scale=1.0 / self.world_size, want_grad=True, vocab=self.speller.V)
-        if self.binf_projection:        # + compute_log_probs_loss(raw outputs) * reg weight (model_helper.py:327-331)
-            self.speller.log_probs_loss(loss, float(self.params.decoder.binf_projection_reg_weight), 1.0 / self.world_size)
+        loss, logits, dlogits = None, None, []
+        for mod, kind in self.spellers:          # audio_loss = sum of the decoders' losses (model_helper.py:337-342)
+            lg = mod.forward_train(mem, mem_len, state, tin, U, seed=step_seed)
+            if kind == 'sigmoid':
+                # compute_loss_sigmoid against the feature vectors of the targets (model_helper.py:199,333-335)
+                l_, dl = compute_loss_sigmoid(lg, mod.emb_bf[tout[:, :U].long()], None, tlen, TRAIN, nf=mod.nf,
+                                              grad_scale=1.0 / self.world_size, want_grad=True)
+            else:
+                l_, dl = compute_loss(lg, tout, None, tlen, TRAIN, self.params.decoder.eos_id,
+                                      grad_scale=1.0 / self.world_size, want_grad=True, vocab=mod.V)
+            if kind == 'binf_projection':   # + compute_log_probs_loss(raw outputs) * reg weight (model_helper.py:327-331)
+                mod.log_probs_loss(l_, float(self.params.decoder.binf_projection_reg_weight), 1.0 / self.world_size)
+            loss = l_ if loss is None else loss + l_
+            logits = lg if logits is None else logits
+            dlogits.append(dl)
+        dlogits = dlogits[0] if len(dlogits) == 1 else dlogits
         if self.ctc is not None:        # audio_loss += ctc_loss * ctc_weight (model_helper.py:347-358)
             self.ctc.forward(mem, mem_len, tout, tlen, loss, 1.0 / self.world_size)
         return loss, logits, dlogits
@@ -336,7 +412,16 @@ class LasModel:
         """Backward of the speller (+ CTC head) and of the top `layers` listener layers (None: all of them).
         Returns the number of listener layers still to do (backward_rest)."""
         g = self.vars.grads
-        dmem, d_state = self.speller.backward(dlogits, g, self.overlap)
+        if isinstance(dlogits, (list, tuple)):      # --multitask: both decoders read the same memory and encoder state
+            dmem, d_state = None, None
+            for (mod, _), dl in zip(self.spellers, dlogits):
+                dm, ds_ = mod.backward(dl, g, self.overlap)
+                dmem = dm if dmem is None else dmem.add_(dm)
+                if ds_ is not None:
+                    ds_ = ds_ if isinstance(ds_, list) else [ds_]
+                    d_state = ds_ if d_state is None else [(a[0] + b[0], a[1] + b[1]) for a, b in zip(d_state, ds_)]
+        else:
+            dmem, d_state = self.speller.backward(dlogits, g, self.overlap)
         if self.ctc is not None:
             self.ctc.backward(dmem, g)
         ds = None
@@ -527,10 +612,22 @@ class LasModel:
         return loss
 
     # -- inference ------------------------------------------------------------------------------
-    def predict(self, features):
-        """PREDICT branch of las_model_fn (model_helper.py:253-297) with greedy decoding."""
+    def predict(self, features, transparent_projection=False):
+        """PREDICT branch of las_model_fn (model_helper.py:253-297), greedy or beam search.  Keys follow the reference:
+        a phone decoder gives 'sample_ids', 'alignment'; a binary decoder 'logits_binf', 'sample_ids_phones_binf',
+        'alignment_binf' (a --multitask model both sets); 'probs' as model_helper.py:281-295 chooses it.  On top of
+        those: 'logits' and 'final_sequence_length' of the decoder that defines 'probs' (EVAL uses them), and -- for a
+        single binary decoder -- 'sample_ids' / 'alignment' aliases of its phone ids and alignments, so that infer.py
+        works without --use_phones_from_binf.
+        transparent_projection (BasicTransparentProjectionDecoder, utils/training_helper.py:156-178, binf_projection
+        decoders): 'logits_binf' holds the RAW cell outputs [log p(f=1) | log p(f=0)], the phone ids come from
+        transform_binf_to_phones of them (the same ids: the projection is that map) and 'probs' is the normalised
+        per-feature probability p1 / (p1 + p0) (model_helper.py:287-293)."""
         if self._images_stale:
             self.refresh_images()
+        if transparent_projection and not self.binf_projection:
+            raise ValueError('transparent_projection needs a --binf_projection decoder: model_helper.py:247-248 applies '
+                             'transform_binf_to_phones to its raw 2*binf_count-wide outputs')
         x, src_len = features['encoder_inputs'], features['source_sequence_length']
         (mem, mem_len), state = self.listener.forward(x, src_len, PREDICT)
         max_it = int(round(int(mem_len.max().item()) * self.params.decoder.decoding_length_factor))
@@ -541,23 +638,76 @@ class LasModel:
             emb = torch.stack([state.c, state.h], 1)
         elif all(hasattr(s, 'c') and torch.is_tensor(s.c) for s in state):
             emb = torch.stack([torch.cat([s.c for s in state], 1), torch.cat([s.h for s in state], 1)], 1)
-        beam_width = int(getattr(self.params.decoder, 'beam_width', 0) or 0)
-        if beam_width > 0:              # model_helper.py:231-236: predicted_ids [B,T,K] instead of logits
-            ids, lens, lps = self._beam_speller().forward_beam(mem, mem_len, state, max_it, beam_width,
-                                                               partial_targets=features.get('partial_targets'))
-            out = {'encoder_out': mem, 'source_length': mem_len, 'sample_ids': ids, 'beam_lengths': lens, 'beam_log_probs': lps}
-            if emb is not None:
-                out['embedding'] = emb
-            return out
-        logits, ids, final_len, align = self.speller.forward_greedy(mem, mem_len, state, max_it)
-        out = {
-            'encoder_out': mem, 'source_length': mem_len,
-            'sample_ids': ids, 'alignment': align, 'probs': torch.softmax(logits, -1), 'logits': logits,
-            'final_sequence_length': final_len,
-        }
+        out = {'encoder_out': mem, 'source_length': mem_len}
         if emb is not None:
             out['embedding'] = emb
+        beam_width = int(getattr(self.params.decoder, 'beam_width', 0) or 0)
+        if beam_width > 0:              # model_helper.py:231-236: predicted_ids [B,T,K] instead of logits
+            for mod, kind in self.spellers:
+                bs = self._beam_speller() if mod is self.speller and kind == 'phones' else mod
+                ids, lens, lps = bs.forward_beam(mem, mem_len, state, max_it, beam_width,
+                                                 partial_targets=features.get('partial_targets'))
+                key = 'sample_ids' if kind == 'phones' else 'sample_ids_phones_binf'
+                out[key] = ids
+                if key not in ('sample_ids',) and 'sample_ids' not in out and len(self.spellers) == 1:
+                    out['sample_ids'] = ids
+                if 'beam_lengths' not in out:
+                    out['beam_lengths'], out['beam_log_probs'] = lens, lps
+            return out
+        primary = None
+        out['_decoders'] = []                # (kind, logits, final_sequence_length) per decoder, for evaluate()
+        for mod, kind in self.spellers:
+            logits, ids, final_len, align = mod.forward_greedy(mem, mem_len, state, max_it)
+            out['_decoders'].append((kind, logits, final_len))
+            if kind == 'phones':
+                out['sample_ids'], out['alignment'] = ids, align
+                out['probs'] = torch.softmax(logits, -1)                             # model_helper.py:284-285
+                primary = (logits, final_len)
+                continue
+            out['alignment_binf'] = align
+            if kind == 'sigmoid':            # feature logits; ids = argmax over them as model_helper.py:251 writes it
+                out['logits_binf'] = logits
+                out['sample_ids_phones_binf'] = logits.argmax(-1).to(torch.int32)
+                out['sample_features_binf'] = ids                                    # the decoded 0/1 vectors [B,S,nf]
+                probs = torch.sigmoid(logits)                                        # model_helper.py:282-283
+            elif transparent_projection:
+                raw = mod.last_raw_outputs.float()                                   # [B,S,2 nf]
+                out['logits_binf'] = raw
+                out['sample_ids_phones_binf'] = ids                                  # argmax(transform_binf_to_phones(raw))
+                e = torch.exp(raw - raw.max(-1, keepdim=True).values)
+                nf = raw.shape[-1] // 2
+                probs = e[..., :nf] / (e[..., :nf] + e[..., nf:2 * nf])              # model_helper.py:287-293
+            else:
+                out['logits_binf'] = logits
+                out['sample_ids_phones_binf'] = ids
+                probs = torch.softmax(logits, -1)                                    # model_helper.py:294-295
+            if primary is None:
+                out['probs'] = probs
+                primary = (logits, final_len)
+            if len(self.spellers) == 1:
+                out['sample_ids'], out['alignment'] = out['sample_ids_phones_binf'], align
+        out['logits'], out['final_sequence_length'] = primary
         return out
+
+    def evaluate(self, features, labels):
+        """EVAL branch: free-running greedy decode, the padded losses of every decoder (model_helper.py:54-76,98-130,
+        319-342) and the edit distance of the first decoder's phone ids (:299-309)."""
+        pred = self.predict(features)
+        tout, tlen = labels['targets_outputs'], labels['target_sequence_length']
+        eos = self.params.decoder.eos_id
+        loss = None
+        for (mod, kind), (_, logits, final_len) in zip(self.spellers, pred['_decoders']):
+            if kind == 'sigmoid':
+                if mod.feat is None:
+                    raise ValueError('evaluating the sigmoid-output decoder needs the binf2phone map (target feature vectors)')
+                # (the reference passes the integer targets here, model_helper.py:336-337, which its reshape to
+                # [-1, binf_count] cannot take; the evident intent -- the targets' feature vectors, as in TRAIN -- is used)
+                l_, _ = compute_loss_sigmoid(logits.contiguous(), mod.emb_bf[tout.long()], final_len, tlen, EVAL, nf=mod.nf)
+            else:
+                l_, _ = compute_loss(logits.contiguous(), tout, final_len, tlen, EVAL, eos)
+            loss = l_ if loss is None else loss + l_
+        ed = metrics_utils.edit_distance(pred['sample_ids'], tout, eos, self.params.mapping)
+        return loss, ed, pred
 
     def check_device_status(self):
         """The persistent kernels (recurrent layers, one-launch decoder) bound every inter-workgroup wait and flag a
@@ -588,27 +738,16 @@ class LasModel:
             self._beam_twin.refresh(self.vars.params)
         return self._beam_twin
 
-    def evaluate(self, features, labels):
-        """EVAL branch: free-running greedy decode, padded loss (model_helper.py:54-76), edit distance."""
-        pred = self.predict(features)
-        loss, _ = compute_loss(pred['logits'].contiguous(), labels['targets_outputs'], pred['final_sequence_length'],
-                               labels['target_sequence_length'], EVAL, self.params.decoder.eos_id)
-        ed = metrics_utils.edit_distance(pred['sample_ids'], labels['targets_outputs'], self.params.decoder.eos_id,
-                                         self.params.mapping)
-        return loss, ed, pred
-
 
 def las_model_fn(features, labels, mode, config, params, binf2phone=None, run_name=None,
                  transparent_projection=False, *, model=None):
     """model_helper.py:165-444.  ``model`` is the LasModel that holds the variables (an Estimator would own it);
     when omitted a freshly initialised one is built.  Returns an EstimatorSpec whose ``train_op`` is a callable
     that applies one optimiser step (TF returns a graph op)."""
-    if transparent_projection:
-        raise ValueError('transparent_projection (BasicTransparentProjectionDecoder) is not implemented on the HIP path')
     if model is None:
         model = LasModel(params, binf2phone=binf2phone)
     if mode == PREDICT:
-        return EstimatorSpec(mode, predictions=model.predict(features))
+        return EstimatorSpec(mode, predictions=model.predict(features, transparent_projection=transparent_projection))
     if mode == EVAL:
         loss, ed, pred = model.evaluate(features, labels)
         return EstimatorSpec(mode, loss=loss, predictions=pred,
@@ -616,7 +755,7 @@ def las_model_fn(features, labels, mode, config, params, binf2phone=None, run_na
     model.vars.grad.zero_()
     audio_loss, logits, dlogits = model.forward_train(features, labels)
     loss = audio_loss + model.l2_loss()
-    sample_ids = logits[..., :model.speller.V].argmax(-1).to(torch.int32)
+    sample_ids = logits[..., :getattr(model.speller, 'Vo', model.speller.V)].argmax(-1).to(torch.int32)
 
     def train_op():
         model.backward(dlogits)

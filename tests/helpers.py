@@ -7,28 +7,31 @@ from oracle import las_oracle as O
 
 def make_hparams(F=13, L=2, H=64, Hd=None, V=11, att='luong', dec_layers=1, bottom_only=True, pass_hidden=True,
                  unidirectional=False, lr=1e-3, l2=1e-6, pyramidal=True, ctc=-1.0, als=None, emb=0, binf=None,
-                 binf_reg=1.0):
-    """Returns (oracle HP, product params) describing the same model."""
+                 binf_reg=1.0, sigmoid=False, multitask=False, sampling=0.0):
+    """Returns (oracle HP, product params) describing the same model.  binf: the [nf, V] feature map of a binary decoder:
+    --binf_projection unless sigmoid=True (--binary_outputs alone: feature-logit outputs); multitask adds the phone
+    decoder in front of it."""
     Hd = Hd or H
     ohp = O.HP(encoder=O.EncoderHP(num_layers=L, num_units=H, unidirectional=unidirectional, use_pyramidal=pyramidal),
                num_channels=F,
                decoder=O.DecoderHP(num_layers=dec_layers, num_units=Hd, target_vocab_size=V, attention_type=att,
                                    bottom_only=bottom_only, pass_hidden_state=pass_hidden, attention_layer_size=als,
-                                   embedding_size=emb, binf_projection=binf is not None,
+                                   embedding_size=emb, binf_projection=binf is not None and not sigmoid,
+                                   binary_outputs=binf is not None, multitask=multitask,
                                    binf_count=0 if binf is None else int(binf.shape[0]), binf_map=binf,
-                                   binf_projection_reg_weight=binf_reg),
+                                   binf_projection_reg_weight=binf_reg, sampling_probability=sampling),
                learning_rate=lr, l2_reg_scale=l2, ctc_weight=ctc)
     from phones_las_amd.utils import params_utils as pu
     hp = pu.get_default_hparams()
     for k, v in dict(num_channels=F, encoder_layers=L, encoder_units=H, use_pyramidal=pyramidal,
                      unidirectional=unidirectional, decoder_layers=dec_layers, decoder_units=Hd,
                      target_vocab_size=V, attention_type=att, bottom_only=bottom_only, pass_hidden_state=pass_hidden,
-                     dropout=0.0, sampling_probability=0.0, learning_rate=lr, l2_reg_scale=l2, ctc_weight=ctc,
+                     dropout=0.0, sampling_probability=sampling, learning_rate=lr, l2_reg_scale=l2, ctc_weight=ctc,
                      attention_layer_size=als, embedding_size=emb).items():
         hp.set_hparam(k, v)
     if binf is not None:             # --binary_outputs --binf_projection --binf_map (cfg5)
-        for k, v in dict(binary_outputs=True, binf_projection=True, binf_count=int(binf.shape[0]),
-                         binf_projection_reg_weight=binf_reg).items():
+        for k, v in dict(binary_outputs=True, binf_projection=not sigmoid, binf_count=int(binf.shape[0]),
+                         binf_projection_reg_weight=binf_reg, multitask=multitask).items():
             hp.set_hparam(k, v)
     return ohp, pu.get_encoder_decoder_hparams(hp)
 

@@ -1,0 +1,239 @@
+"""GPU parity of the binary-feature decoder variants against the oracle:
+  * the sigmoid-output decoder (--binary_outputs without --binf_projection): TrainingSigmoidHelper's teacher-forced TRAIN
+    path with compute_loss_sigmoid, ScheduledSigmoidHelper's Bernoulli feature draws (replayed through the oracle), the
+    InferenceHelper greedy decode of las/model.py:320-336 and the EVAL loss;
+  * --multitask: phone decoder ('speller') + binary decoder ('speller_binf') on one listener, losses summed;
+  * the prediction keys of model_helper.py:253-297 and BasicTransparentProjectionDecoder's raw outputs / normalised probs.
+Tolerances as in test_gpu_model.py (logits / loss 2e-2, gradients 2e-2 of the per-tensor max-abs: general decoder path)."""
+import numpy as np
+import pytest
+import torch
+
+from tests.helpers import make_hparams, make_batch, to_device, relerr
+from tests import golden_cases as G
+
+pytestmark = pytest.mark.gpu
+DT = torch.float64
+
+
+def _toy_binf(nf, V, seed=5):
+    rng = np.random.default_rng(seed)
+    m = (rng.random((nf, V)) < 0.4).astype(np.float32)
+    m[:, 0] = 1.0
+    m[:, 1:3] = 0.0
+    m[nf - 2:, :] = 0.0
+    m[nf - 2, 1] = 1.0          # <s>: one-hot on the last-but-one feature
+    m[nf - 1, 2] = 1.0          # </s>: one-hot on the last feature
+    return m
+
+
+def _models(**kw):
+    from oracle import las_oracle as O
+    from phones_las_amd import model_helper as mh
+    ohp, params = make_hparams(**kw)
+    op = O.init_params(ohp, bias_scale=0.1)
+    model = mh.LasModel(params, binf2phone=kw.get('binf'))
+    assert [n for n, _, _ in mh.param_table(params)] == [n for n, _, _ in O.param_table(ohp)]
+    model.load_variables({k: v for k, v in op.items()})
+    return O, ohp, op, model
+
+
+@pytest.mark.parametrize('kw', [
+    dict(att='luong', dec_layers=1, bottom_only=True, pass_hidden=True),
+    dict(att='bahdanau', dec_layers=2, bottom_only=False, pass_hidden=False, als=16),
+], ids=['luong_1', 'bahdanau_stack2_al'])
+def test_sigmoid_decoder_train_step_vs_oracle(kw):
+    binf = _toy_binf(8, 11)
+    O, ohp, op, model = _models(binf=binf, sigmoid=True, **kw)
+    assert model.sigmoid and model.speller.sigmoid and model.speller.Vo == 8
+    src_len, tgt_len = [12, 7, 10], [6, 4, 5]
+    batch = make_batch(src_len=src_len, tgt_len=tgt_len)
+    feats, labels = to_device(batch)
+    out = O.train_step(ohp, op, None, None, 1, batch, mxu='bf16')
+    model.vars.grad.zero_()
+    loss, logits, dlogits = model.forward_train(feats, labels)
+    model.backward(dlogits)
+    torch.cuda.synchronize()
+    for b, n in enumerate(tgt_len):
+        assert relerr(logits[b, :n, :8], out['aux']['logits'][b, :n]) < 2e-2
+    assert abs(float(loss) - float(out['audio_loss'])) < 2e-2 * abs(float(out['audio_loss']))
+    for name, _, _ in model.vars.table:
+        g = out['grads'][name] - ohp.l2_reg_scale * op[name]
+        assert relerr(model.vars.grads[name], g) < 2e-2, name
+
+
+def test_sigmoid_loss_kernel_train_and_eval_vs_oracle():
+    from oracle import las_oracle as O
+    from phones_las_amd import model_helper as mh
+    from phones_las_amd.las.ops import TRAIN, EVAL
+    torch.manual_seed(0)
+    B, U, nf, ld = 5, 7, 6, 8
+    logits = torch.randn(B, U, ld) * 3
+    tg = (torch.rand(B, U, ld) < 0.4).float()
+    ln = torch.tensor([7, 1, 4, 6, 3])
+    lr = logits[..., :nf].double().requires_grad_(True)
+    ref = O.compute_loss_sigmoid_train(lr, tg[..., :nf].double(), ln)
+    ref.backward()
+    loss, dl = mh.compute_loss_sigmoid(logits.cuda(), tg.to(torch.bfloat16).cuda(), None, ln.to(torch.int32).cuda(), TRAIN, nf=nf,
+                                       grad_scale=0.5, want_grad=True)
+    torch.cuda.synchronize()
+    assert abs(float(loss) - float(ref)) < 1e-5 * abs(float(ref))
+    assert relerr(dl[..., :nf].float(), 0.5 * lr.grad) < 1e-2 and float(dl[..., nf:].float().abs().max()) == 0.0
+    fl = torch.tensor([3, 5, 1, 2, 5])
+    ev = O.compute_loss_sigmoid_eval(logits[:, :5, :nf].double(), tg[..., :nf].double(), fl, ln)
+    loss, _ = mh.compute_loss_sigmoid(logits[:, :5].contiguous().cuda(), tg.to(torch.bfloat16).cuda(), fl.to(torch.int32).cuda(),
+                                      ln.to(torch.int32).cuda(), EVAL, nf=nf)
+    assert abs(float(loss) - float(ev)) < 1e-5 * abs(float(ev))
+
+
+def test_scheduled_sigmoid_sampling_replayed_through_oracle():
+    """ScheduledSigmoidHelper (utils/training_helper.py:89-119, binf_to_ipa None): per utterance and step, with probability
+    p, the next input is a Bernoulli(sigmoid(logits)) draw per feature.  The select draws are the device generator's
+    (restated in numpy); the feature draws are read back from the operand buffer and replayed through the oracle."""
+    binf = _toy_binf(8, 11)
+    O, ohp, op, model = _models(binf=binf, sigmoid=True, sampling=0.5, att='luong')
+    tgt_len = [6, 4, 5]
+    batch = make_batch(src_len=[12, 7, 10], tgt_len=tgt_len)
+    feats, labels = to_device(batch)
+    model.vars.grad.zero_()
+    loss, logits, dlogits = model.forward_train(feats, labels)
+    sp = model.speller
+    X0 = sp.saved['X'][0].float().cpu()                  # [B, U, T0 + A + Hd]: columns [0, nf) = the fed feature vector
+    model.backward(dlogits)
+    torch.cuda.synchronize()
+    B, U, nf = 3, 6, 8
+    sel = np.zeros((U, B), dtype=bool)
+    for t in range(U - 1):
+        sel[t] = G.device_uniform(model.last_seed, 0x5e1ec7, t * B + np.arange(B)) < 0.5
+    assert sel.any() and not sel[:U - 1].all()
+    vecs = torch.zeros(U, B, nf, dtype=DT)
+    for t in range(U - 1):
+        vecs[t] = X0[:, t + 1, :nf].double()                 # what step t+1 was fed
+    teacher = torch.as_tensor(binf, dtype=DT).t()[batch['targets_inputs']]
+    for t in range(U - 1):
+        for b in range(B):
+            if not sel[t, b]:
+                assert torch.equal(vecs[t, b], teacher[b, t + 1]), (t, b)       # unselected rows feed the teacher's features
+    st = {'sample_select': torch.from_numpy(sel), 'sample_vecs': vecs}
+    out = O.train_step(ohp, op, None, None, 1, batch, mxu='bf16', stochastic=st)
+    for b, n in enumerate(tgt_len):
+        assert relerr(logits[b, :n, :nf], out['aux']['logits'][b, :n]) < 2e-2
+    assert abs(float(loss) - float(out['audio_loss'])) < 2e-2 * abs(float(out['audio_loss']))
+    for name, _, _ in model.vars.table:
+        g = out['grads'][name] - ohp.l2_reg_scale * op[name]
+        assert relerr(model.vars.grads[name], g) < 2e-2, name
+
+
+def test_sigmoid_decoder_binary_greedy_and_prediction_keys_vs_oracle():
+    """InferenceHelper decode of las/model.py:320-336 on trained weights (a fresh model's feature logits sit at the bias):
+    the decoded 0/1 vectors, lengths, alignments and the EVAL loss; prediction keys of model_helper.py:253-297."""
+    binf = _toy_binf(8, 11)
+    O, ohp, op, model = _models(binf=binf, sigmoid=True, att='luong', lr=1e-2)
+    src_len, tgt_len = [24, 9, 17, 24, 12], [6, 4, 5, 6, 3]
+    batch = make_batch(B=5, T=24, src_len=src_len, tgt_len=tgt_len)
+    feats, labels = to_device(batch)
+    first = last = None
+    for _ in range(150):
+        last = float(model.train_step(feats, labels))
+        first = last if first is None else first
+    assert last < 0.5 * first, (first, last)
+    trained = {n: t.detach().double().cpu() for n, t in model.vars.params.items()}
+    (mem, ml), st = O.listener(batch['encoder_inputs'], batch['source_sequence_length'], trained, ohp.encoder, 'bf16')
+    rl, rs, rfl, sp = O.speller_greedy_binary(ohp, trained, mem, ml, st, 'bf16')
+    loss, ed, pred = model.evaluate(feats, labels)
+    torch.cuda.synchronize()
+    for k in ('logits_binf', 'sample_ids_phones_binf', 'alignment_binf', 'probs', 'sample_features_binf', 'encoder_out', 'embedding'):
+        assert k in pred, k
+    lg, smp, fl = pred['logits_binf'].double().cpu(), pred['sample_features_binf'].double().cpu(), pred['final_sequence_length'].cpu().long()
+    assert torch.equal(pred['sample_ids_phones_binf'].cpu().long(), pred['logits_binf'].argmax(-1).cpu())
+    assert float((pred['probs'] - torch.sigmoid(pred['logits_binf'])).abs().max()) == 0.0
+    ralign = torch.stack(sp.align_hist, 1)
+    compared = total = whole = 0
+    scale = float(rl.abs().max())
+    for b in range(5):
+        n = int(rfl[b])
+        total += n
+        ok = True
+        for t in range(n):
+            if float(rl[b, t].abs().min()) < 0.05:         # a feature logit near the rounding threshold: later inputs may differ
+                ok = False
+                break
+            assert torch.equal(smp[b, t], rs[b, t]), (b, t)
+            assert float((lg[b, t] - rl[b, t]).abs().max()) < 2e-2 * scale
+            assert float((pred['alignment_binf'][b, t, :ralign.shape[-1]].double().cpu() - ralign[b, t]).abs().max()) < 2e-2
+            compared += 1
+        if ok:
+            whole += 1
+            assert int(fl[b]) == n
+    assert compared >= 0.5 * total and whole >= 2, (compared, total, whole)
+    if whole == 5 and lg.shape[1] == rl.shape[1]:
+        tb = torch.as_tensor(binf, dtype=DT).t()[batch['targets_outputs']]
+        ref = O.compute_loss_sigmoid_eval(rl, tb, rfl, batch['target_sequence_length'])
+        assert abs(float(loss) - float(ref)) < 2e-2 * abs(float(ref))
+    # inference without a map (binf2phone None): same decode from the same weights
+    from phones_las_amd import model_helper as mh
+    nomap = mh.LasModel(model.params, binf2phone=None)
+    nomap.load_variables(model.vars.params)
+    p2 = nomap.predict(feats)
+    assert torch.equal(p2['sample_features_binf'], pred['sample_features_binf'])
+    with pytest.raises(ValueError):
+        nomap.forward_train(feats, labels)
+
+
+@pytest.mark.parametrize('kind', ['sigmoid', 'binf_projection'])
+def test_multitask_two_decoders_vs_oracle(kind):
+    """--multitask (model_helper.py:211-227,337-342): the phone decoder and the binary decoder read the same encoder memory
+    and state; the audio loss is the sum of theirs; gradients of both reach the listener."""
+    binf = _toy_binf(8, 11)
+    O, ohp, op, model = _models(binf=binf, sigmoid=(kind == 'sigmoid'), multitask=True, att='luong', binf_reg=0.7)
+    assert len(model.spellers) == 2 and model.speller_binf is not None
+    assert any(n.startswith('speller_binf/') for n, _, _ in model.vars.table)
+    src_len, tgt_len = [12, 7, 10], [6, 4, 5]
+    batch = make_batch(src_len=src_len, tgt_len=tgt_len)
+    feats, labels = to_device(batch)
+    out = O.train_step(ohp, op, None, None, 1, batch, mxu='bf16')
+    model.vars.grad.zero_()
+    loss, logits, dlogits = model.forward_train(feats, labels)
+    assert isinstance(dlogits, list) and len(dlogits) == 2
+    model.backward(dlogits)
+    torch.cuda.synchronize()
+    for b, n in enumerate(tgt_len):
+        assert relerr(logits[b, :n, :11], out['aux']['logits'][b, :n]) < 2e-2
+    assert abs(float(loss) - float(out['audio_loss'])) < 2e-2 * abs(float(out['audio_loss']))
+    for name, _, _ in model.vars.table:
+        g = out['grads'][name] - ohp.l2_reg_scale * op[name]
+        assert relerr(model.vars.grads[name], g) < 2e-2, name
+    pred = model.predict(feats)
+    for k in ('sample_ids', 'alignment', 'logits_binf', 'sample_ids_phones_binf', 'alignment_binf', 'probs'):
+        assert k in pred, k
+    assert float((pred['probs'] - torch.softmax(pred['logits'], -1)).abs().max()) == 0.0      # the phone decoder's (model_helper.py:284)
+    loss_e, ed, _ = model.evaluate(feats, labels)
+    assert np.isfinite(float(loss_e)) and len(ed) == 3
+
+
+def test_binf_projection_prediction_keys_and_transparent_projection():
+    """model_helper.py:247-295 for a --binf_projection decoder: plain PREDICT gives phone logits under 'logits_binf' and
+    softmax probs; transparent_projection (BasicTransparentProjectionDecoder) gives the raw [lp1 | lp0] outputs, the same
+    phone ids through transform_binf_to_phones, and probs = p1 / (p1 + p0) per feature."""
+    binf = _toy_binf(8, 11)
+    O, ohp, op, model = _models(binf=binf, att='luong')
+    batch = make_batch(src_len=[12, 7, 10], tgt_len=[6, 4, 5])
+    feats, _ = to_device(batch)
+    plain = model.predict(feats)
+    assert plain['logits_binf'].shape[-1] == 11 and torch.equal(plain['sample_ids_phones_binf'], plain['sample_ids'])
+    assert float((plain['probs'] - torch.softmax(plain['logits_binf'], -1)).abs().max()) == 0.0
+    tr = model.predict(feats, transparent_projection=True)
+    raw = tr['logits_binf']
+    assert raw.shape[-1] == 16 and torch.equal(tr['sample_ids_phones_binf'], plain['sample_ids_phones_binf'])
+    Mb = torch.as_tensor(binf, device='cuda')
+    phones = raw[..., :8] @ Mb + raw[..., 8:] @ (1 - Mb)                      # transform_binf_to_phones
+    assert relerr(phones, plain['logits_binf'].double().cpu()) < 1e-2          # (bf16 operands of the device's map product)
+    e = torch.exp(raw - raw.max(-1, keepdim=True).values)
+    assert float((tr['probs'] - e[..., :8] / (e[..., :8] + e[..., 8:])).abs().max()) < 1e-6
+    (mem, ml), st = O.listener(batch['encoder_inputs'], batch['source_sequence_length'], op, ohp.encoder, 'bf16')
+    rl, rids, rfl, sp = O.speller_greedy(ohp, op, mem, ml, st, 'bf16')
+    assert relerr(plain['logits_binf'][:, 0], rl[:, 0]) < 2e-2
+    with pytest.raises(ValueError):
+        from phones_las_amd import model_helper as mh
+        _, p2 = make_hparams(att='luong')
+        mh.LasModel(p2).predict(feats, transparent_projection=True)

@@ -173,3 +173,54 @@ def test_param_count_matches_survey_metric_m():
     enc = sum(int(np.prod(s)) for n, s, _ in tab if n.startswith('listener'))
     dec = sum(int(np.prod(s)) for n, s, _ in tab if n.startswith('speller'))
     assert enc == 4806656 and dec == 1705024
+
+
+def test_sigmoid_losses_known_answers():
+    """sequence_loss_sigmoid / compute_loss_sigmoid (model_helper.py:81-130): zero logits give ln 2 whatever the targets;
+    masked steps do not count; the EVAL form pads the shorter of (decoded, targets) with zeros and weighs the longer."""
+    import math
+    from oracle import las_oracle as O
+    B, U, nf = 3, 5, 6
+    g = torch.Generator().manual_seed(0)
+    tg = (torch.rand(B, U, nf, generator=g) < 0.4).double()
+    ln = torch.tensor([5, 2, 4])
+    z = torch.zeros(B, U, nf, dtype=torch.float64)
+    assert abs(float(O.compute_loss_sigmoid_train(z, tg, ln)) - math.log(2.0)) < 1e-12
+    lg = torch.randn(B, U, nf, generator=g, dtype=torch.float64)
+    ref = 0.0
+    for b in range(B):
+        for t in range(int(ln[b])):
+            x, y = lg[b, t], tg[b, t]
+            ref += float((torch.clamp(x, min=0) - x * y + torch.log1p(torch.exp(-x.abs()))).mean())
+    assert abs(float(O.compute_loss_sigmoid_train(lg, tg, ln)) - ref / float(ln.sum())) < 1e-12
+    lg2 = lg.clone(); lg2[1, 2:] = 99.0                                # beyond the length: ignored
+    assert abs(float(O.compute_loss_sigmoid_train(lg2, tg, ln)) - ref / float(ln.sum())) < 1e-12
+    # EVAL: decoded 3 steps, targets up to 5: logits zero-padded, weights over max(len) = target lengths here
+    fl = torch.tensor([3, 3, 1])
+    ev = O.compute_loss_sigmoid_eval(lg[:, :3], tg, fl, ln)
+    lgp = torch.cat([lg[:, :3], torch.zeros(B, 2, nf, dtype=torch.float64)], 1)
+    w = (torch.arange(5).unsqueeze(0) < torch.maximum(ln, fl).unsqueeze(1)).double()
+    assert abs(float(ev) - float(O.sequence_loss_sigmoid(lgp, tg, w))) < 1e-12
+
+
+def test_binary_greedy_decode_known_answers():
+    """las/model.py:320-336 (InferenceHelper): with a zero projection kernel the sample is the sign of the bias; the decode
+    stops at the first step when the bias of the last (</s>) feature is positive, and runs to maximum_iterations when it is
+    negative; the first input is the <s> feature vector."""
+    from oracle import las_oracle as O
+    nf, V = 6, 9
+    binf = (torch.rand(nf, V, generator=torch.Generator().manual_seed(1)) < 0.5).float().numpy()
+    hp = O.HP(encoder=O.EncoderHP(num_layers=2, num_units=8), num_channels=5,
+              decoder=O.DecoderHP(num_layers=1, num_units=8, target_vocab_size=V, bottom_only=True, pass_hidden_state=True,
+                                  binary_outputs=True, binf_count=nf, binf_map=binf))
+    p = O.init_params(hp)
+    assert p['speller/projection_layer/kernel'].shape == (32, nf) and p['speller/decoder_cell_0/lstm_cell/kernel'].shape[0] == nf + 32 + 8
+    p['speller/projection_layer/kernel'] = torch.zeros_like(p['speller/projection_layer/kernel'])
+    b = O.synthetic_batch(2, 8, 5, V, 4)
+    (mem, ml), st = O.listener(b['encoder_inputs'], b['source_sequence_length'], p, hp.encoder)
+    p['speller/projection_layer/bias'] = torch.tensor([1., -1., 1., -1., 1., 2.], dtype=torch.float64)
+    lg, smp, fl, _ = O.speller_greedy_binary(hp, p, mem, ml, st)
+    assert lg.shape == (2, 1, nf) and fl.tolist() == [1, 1] and smp[0, 0].tolist() == [1, 0, 1, 0, 1, 1]
+    p['speller/projection_layer/bias'] = torch.tensor([1., -1., 1., -1., 1., -2.], dtype=torch.float64)
+    lg, smp, fl, _ = O.speller_greedy_binary(hp, p, mem, ml, st)
+    assert lg.shape[1] == int(ml.max()) and fl.tolist() == [int(ml.max())] * 2

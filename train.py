@@ -99,9 +99,9 @@ def load_checkpoint(model, path):
 def main(args):
     if args.t2t_format or args.tpu_name:
         raise SystemExit('--t2t_format / --tpu_name are TensorFlow-only input/back-end options and are not supported')
-    if args.binary_outputs and not (args.binf_projection and args.output_ipa):
-        raise SystemExit('--binary_outputs is implemented with --binf_projection --output_ipa (the DenseBinfDecoder path); '
-                         'the sigmoid-output decoders are not on the HIP path')
+    if args.binary_outputs and not args.output_ipa:
+        raise SystemExit('--binary_outputs needs --output_ipa: without it the reference hands no binf2phone map to the model '
+                         '(train.py:125-127) and its TRAIN graph has no decoder inputs (model_helper.py:199-200)')
     from phones_las_amd import dp, utils
     from phones_las_amd import model_helper as mh
 
