@@ -517,6 +517,38 @@ int las_fe_delta(const float* x, int64_t ldx, int T, int F, const float* taps, c
                  const float* edge_hi, int width, float* out, int64_t ldo, int out_stride, int out_offset,
                  void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Input path (utils/dataset_utils.py:138-283 of the reference: tf.data.TFRecordDataset ->
+ * tf.parse_single_sequence_example -> (x - mean) / std -> padded_batch).  Host functions; `data` is the image of a
+ * TFRecord file (e.g. an mmap), nothing is copied that the caller does not ask for.
+ * ---------------------------------------------------------------------------------------- */
+/* Walk the TFRecord framing (uint64 length | masked crc32c | payload | masked crc32c; preprocess_all.py:164-167 writes it
+ * with tf.io.TFRecordWriter).  For the first max_records records: payload offset / length and, when the arrays are
+ * given, the number of frames ('inputs' float lists), of labels and of label token bytes of the SequenceExample
+ * (-1 if the payload is not one).  verify_crc != 0 checks both checksums of every record (as TFRecordDataset does).
+ * Returns the number of records in the file (may exceed max_records), or a negative las_status. */
+int64_t las_tfrecord_index(const uint8_t* data, size_t nbytes, int verify_crc, int64_t max_records, int64_t* offsets,
+                           int64_t* lengths, int32_t* n_frames, int32_t* n_labels, int64_t* label_bytes);
+/* Parse n SequenceExamples {'inputs': FixedLenSequenceFeature([num_channels], float32), 'labels':
+ * FixedLenSequenceFeature([], string)} (utils/dataset_utils.py:141-153) given by their payload offsets / lengths:
+ * frames -> packed rows [sum T, num_channels] with frame_row_offsets [n+1]; labels -> their token bytes back to back
+ * with token_offsets [total tokens + 1] and label_counts [n].  A frame of another width is an error, as in TF. */
+int las_tfrecord_parse_batch(const uint8_t* data, const int64_t* offsets, const int64_t* lengths, int n, int num_channels,
+                             float* frames, int64_t frame_rows_capacity, int64_t* frame_row_offsets, uint8_t* label_bytes,
+                             int64_t label_bytes_capacity, int32_t* token_offsets, int64_t token_capacity,
+                             int32_t* label_counts);
+/* The same for ONE serialized SequenceExample (token_offsets [n_labels + 1]). */
+int las_tfrecord_parse(const uint8_t* record, int64_t length, int num_channels, float* frames, int64_t frame_rows_capacity,
+                       int32_t* n_frames, uint8_t* label_bytes, int64_t label_bytes_capacity, int32_t* token_offsets,
+                       int64_t token_capacity, int32_t* n_labels);
+/* Device: out[b, t, f] = bf16((frames[row_b + t, f] - mean[f]) / std[f]) for t < T_b, f < num_channels, else 0 -- the
+ * normalisation of utils/dataset_utils.py:217-220 (in double, as numpy does with the float64 norm.dmp arrays; mean/std
+ * NULL: no normalisation), the bf16 cast and the zero padding to [B, T_padded, F_padded] in one pass over the packed
+ * frames of a batch; lengths_out[b] (nullable) = min(T_b, T_padded). */
+int las_normalize_pad_bf16(const float* frames, const int64_t* frame_row_offsets, const double* mean, const double* stdv,
+                           int num_channels, las_bf16* out, int B, int T_padded, int F_padded, int32_t* lengths_out,
+                           void* stream);
+
 /* Host-side CRC-32C (Castagnoli) of a buffer: the checksum of the TFRecord framing the reference's data
  * files use (preprocess_all.py:164-167 tf.io.TFRecordWriter; utils/dataset_utils.py:157 TFRecordDataset). */
 uint32_t las_crc32c(const void* data, size_t n);

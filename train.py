@@ -52,6 +52,9 @@ def parse_args(argv=None):
     p.add_argument('--l2_reg_scale', type=float, default=1e-6)
     p.add_argument('--add_noise', type=int, default=0)
     p.add_argument('--noise_std', type=float, default=0.1)
+    p.add_argument('--slow_input', action='store_true',
+                   help='read the training TFRecords with the pure-Python parser on the step loop\'s thread instead of the '
+                        'C parser + prefetch thread (same batches for the same seed)')
     p.add_argument('--dp_overlap', action='store_true',
                    help='multi-GPU (torch.distributed.run): exchange the gradients in two buckets beside the backward pass')
     p.add_argument('--binary_outputs', action='store_true')
@@ -151,16 +154,36 @@ def main(args):
                               num_epochs=epochs, num_parallel_calls=args.num_parallel_calls,
                               max_frames=args.max_frames, max_symbols=args.max_symbols, is_infer=infer, seed=1234)
 
+    def make_train_input():
+        """The training stream: same pipeline semantics, parsed in C by a prefetch thread, normalised / cast / padded on the
+        device (phones-las_amd/utils/fast_input.py); --slow_input keeps the pure-Python reader."""
+        if args.slow_input:
+            return make_input(args.train, args.num_epochs)
+        from phones_las_amd.utils.fast_input import fast_input_fn
+        return fast_input_fn(args.train, vocab_name, norm_name, num_channels=hparams.num_channels, batch_size=global_batch,
+                             num_epochs=args.num_epochs, max_frames=args.max_frames, max_symbols=args.max_symbols, seed=1234,
+                             time_multiple=model.listener.time_multiple)
+
     max_steps = args.num_epochs * 1000 * args.batch_size          # train.py:189,202 (quirk B2)
     t_last, last_eval, t0 = time.time(), time.time(), time.time()
-    for features, labels in make_input(args.train, args.num_epochs):
+    n_utt, t_log = 0, time.time()
+    for features, labels in make_train_input():
         if model.global_step >= max_steps:
             break
+        # decoder steps of this batch = the longest target: a host number on both input paths (no device round trip)
+        num_steps = labels.pop('max_target_length', None)
         if world > 1:
             features, labels = dp.shard_batch(features, rank, world), dp.shard_batch(labels, rank, world)
-        num_steps = int(labels['target_sequence_length'].max())
-        f, l = to_device(features, labels, dev)
+        if num_steps is None:
+            num_steps = int(labels['target_sequence_length'].max())
+        elif world > 1:
+            num_steps = min(num_steps, labels['targets_inputs'].shape[1])
+        if torch.is_tensor(features['encoder_inputs']):
+            f, l = features, labels
+        else:
+            f, l = to_device(features, labels, dev)
         loss = model.train_step(f, l, num_steps=num_steps)
+        n_utt += global_batch
         if model.global_step % 10 == 0:                            # LoggingTensorHook(every_n_iter=10)
             lv = dp.mean_scalar(float(loss))
             model.check_device_status()          # bounded waits of the persistent kernels: fail loudly, never silently
@@ -168,6 +191,8 @@ def main(args):
                 dt = time.time() - t_last
                 print('step %d: loss = %.5f (%.2f utt/s)' % (model.global_step, lv, 10 * global_batch / max(dt, 1e-9)))
             t_last = time.time()
+            if model.global_step == 10:          # throughput of the run without its first steps (allocations, indexing)
+                n_utt, t_log = 0, time.time()
             # rank 0's clock decides when to evaluate (every replica must enter the evaluation at the same step)
             if args.valid and dp.broadcast_int(time.time() - last_eval > args.eval_secs):
                 evaluate(model, make_input(args.valid, 1, True), dev, rank, world)
@@ -177,9 +202,12 @@ def main(args):
             if rank == 0:
                 save_checkpoint(model, ckpt)
     model.check_device_status()
+    torch.cuda.synchronize()
     if rank == 0:
         save_checkpoint(model, ckpt)
         print('finished at global_step %d in %.1f s' % (model.global_step, time.time() - t0))
+        if model.global_step > 10 and n_utt:
+            print('throughput after step 10: %.1f utterances/s' % (n_utt / max(time.time() - t_log, 1e-9)))
     if args.valid:
         evaluate(model, make_input(args.valid, 1, True), dev, rank, world)
 
