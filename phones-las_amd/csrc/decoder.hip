@@ -74,6 +74,63 @@ __device__ __forceinline__ float dot8(const uint4& k, const float* q) {
   return s;
 }
 
+__device__ __forceinline__ uint4 ld16(const unsigned short* p);
+// out[c] = sum_r W[r][c] * x[r] for a square bf16 matrix W [n, n] (row-major) by the 256 threads of the workgroup; x, out and
+// scratch (2048 floats) in LDS.  The query layer of the Bahdanau / Custom attentions: forward pq = h Wq (W = Wq), backward
+// dh = dpq Wq^T (W = the transposed copy).  Thread (column group of 8, row phase) walks its rows with 16-byte loads, eight
+// in flight, and the row phases meet in scratch.  (A column at a time with 2-byte loads -- n dependent L2 round trips per
+// thread -- made this product the longest phase of a decoder step at 512 units: 75 of 100 us.)
+__device__ void square_matvec_bf16(const unsigned short* __restrict__ W, const float* x, float* out, float* scratch, int n) {
+  const int tid = threadIdx.x;
+  const int AG = n / 8;
+  if (AG > 256 || (n & 7)) {            // wider than 2048: a column per thread
+    for (int c = tid; c < n; c += 256) {
+      float acc = 0.f;
+      for (int r = 0; r < n; ++r) acc += las_bf2f(W[(int64_t)r * n + c]) * x[r];
+      out[c] = acc;
+    }
+    __syncthreads();
+    return;
+  }
+  const int UG = 256 / AG;
+  const int ag = tid % AG, ug = tid / AG;
+  if (ug < UG) {
+    float acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+    const unsigned short* wp = W + ag * 8;
+    int r = ug;
+    for (; r + 7 * UG < n; r += 8 * UG) {
+      uint4 w[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) w[i] = ld16(wp + (int64_t)(r + i * UG) * n);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const unsigned short* e = reinterpret_cast<const unsigned short*>(&w[i]);
+        const float xv = x[r + i * UG];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] += xv * las_bf2f(e[j]);
+      }
+    }
+    for (; r < n; r += UG) {
+      const uint4 w = ld16(wp + (int64_t)r * n);
+      const unsigned short* e = reinterpret_cast<const unsigned short*>(&w);
+      const float xv = x[r];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[j] += xv * las_bf2f(e[j]);
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) scratch[(ug * AG + ag) * 8 + j] = acc[j];
+  }
+  __syncthreads();
+  for (int c = tid; c < n; c += 256) {
+    float t = 0.f;
+    for (int g = 0; g < UG; ++g) t += scratch[(g * AG + (c >> 3)) * 8 + (c & 7)];
+    out[c] = t;
+  }
+  __syncthreads();
+}
+
 // ------------------------------------------------------------------------------------------------
 // forward
 // ------------------------------------------------------------------------------------------------
@@ -210,9 +267,9 @@ __device__ void dec_step_fwd_body(const las_dec_step& s, const int b, const int 
   // ---- processed query (Bahdanau, Custom): pq[a] = sum_u Wq[u][a] h[u]  (TF Dense kernel layout [in,out]);
   //      CustomAttention applies relu and, like every AttentionWrapper query, it is a GEMM operand: bf16-rounded ----
   if (att_uses_wq(s.attention)) {
+    square_matvec_bf16(s.wq, hq, pq, cred, Hd);            // (cred: free until the context phase)
     for (int a = tid; a < Hd; a += 256) {
-      float acc = 0.f;
-      for (int u = 0; u < Hd; ++u) acc += las_bf2f(s.wq[(int64_t)u * Hd + a]) * hq[u];
+      float acc = pq[a];
       if (s.attention == LAS_ATT_CUSTOM) acc = las_bf2f(las_f2bf(fmaxf(acc, 0.f)));
       pq[a] = acc;
       if (writer && s.pq_out) s.pq_out[(int64_t)b * s.ldpq + a] = acc;
@@ -494,8 +551,10 @@ __host__ __device__ inline size_t persist_exchange_words(int B, int Tm, int Hd, 
   return fwd > bwd ? fwd : bwd;
 }
 // forward: scratch, and this workgroup's score frames of the keys [fq, Hd] + its context columns of the values [Tm, M/4]
+// (red: [4 waves][16 rows][columns per member + 1] partial z tiles; 4 Hd / 32 columns per member, at least 32)
+__host__ __device__ inline int persist_red_stride(int Hd) { return (Hd / 8 > 32 ? Hd / 8 : 32) + 1; }
 __host__ __device__ inline size_t persist_fwd_scratch_floats(int Hd, int Tm) {
-  return ((size_t)2 * Hd + Tm + 16 + 2048 + 4 * 16 * 33 + 8 + 3) & ~(size_t)3;
+  return ((size_t)2 * Hd + Tm + 16 + 2048 + 4 * 16 * persist_red_stride(Hd) + 8 + 3) & ~(size_t)3;
 }
 __host__ __device__ inline int persist_cols_per(int M) { return ((M / 8 + 3) / 4) * 8; }
 __host__ __device__ inline size_t persist_fwd_resident_bytes(int M, int Hd, int Tm) {
@@ -537,10 +596,14 @@ __device__ bool persist_barrier(pu64* flags, int member, unsigned epoch, bool lo
   return *lds_fail == 0;
 }
 
-template <bool SAMPLING, bool RES>
+// NTL_MAX 16-column tiles of z per member (4 Hd / 32 / 16) and KCW_MAX 32-deep K chunks per wave (K_in / 32 / 4) stay in
+// registers as MFMA B fragments: <2, 12> for decoder_units <= 256 (96 VGPRs), <4, 20, 8> for 512 units with a 2048-deep
+// memory
+// KRES: K chunks per wave that stay in registers; the chunks beyond are re-read from L2 / Infinity Cache at every step
+// (512 units: 8 of 20 resident = 128 VGPRs; all 20 would need 320 of the 512 next to the step body's ~270).
+template <bool SAMPLING, bool RES, int NTL_MAX = 2, int KCW_MAX = 12, int KRES = KCW_MAX>
 __global__ __launch_bounds__(256) void dec_persist_fwd_kernel(las_dec_persist p) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
-  constexpr int NTL_MAX = 2, KCW_MAX = 12;
   const las_dec_step& s0 = p.s;
   const int B = s0.B, Hd = s0.Hd, M = s0.M, Tm = s0.Tm;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, lq = lane >> 4;
@@ -554,7 +617,8 @@ __global__ __launch_bounds__(256) void dec_persist_fwd_kernel(las_dec_persist p)
   pu64* flags = reinterpret_cast<pu64*>(reinterpret_cast<char*>(p.workspace) + 64) + (size_t)group * 2 * P_MEMBERS;
   pu64* xcc_tab = flags + P_MEMBERS;
   float* red = sm + (2 * Hd + Tm + 16 + 2048);             // [4 waves][16][CPM+1] partial z tiles
-  int* fail = reinterpret_cast<int*>(red + 4 * 16 * 33);
+  const int RS = persist_red_stride(Hd);
+  int* fail = reinterpret_cast<int*>(red + 4 * 16 * RS);
   int* colo = fail + 1;
   if (tid == 0) { *fail = 0; *colo = 0; }
   __syncthreads();
@@ -584,16 +648,19 @@ __global__ __launch_bounds__(256) void dec_persist_fwd_kernel(las_dec_persist p)
   // G role: this member's columns of z and its register-resident slice of K ([4Hd, K_in] bf16, row = output column)
   const int CPM = 4 * Hd / P_MEMBERS, NTL = CPM / 16;      // columns per member, 16-column tiles
   const int KC = p.K_in / 32, KCW = (KC + 3) / 4;          // 32-deep K chunks; wave w takes chunks w, w+4, ...
-  bf16x8 wf[NTL_MAX][KCW_MAX];
+  bf16x8 wf[NTL_MAX][KRES];
+  const unsigned short* wrow[NTL_MAX];          // this lane's row of kT per column tile (the streamed chunks' source)
 #pragma unroll
-  for (int nt = 0; nt < NTL_MAX; ++nt)
+  for (int nt = 0; nt < NTL_MAX; ++nt) {
+    wrow[nt] = p.kT + (int64_t)(member * CPM + min(nt, NTL - 1) * 16 + l15) * p.ldk + 8 * lq;
 #pragma unroll
-    for (int i = 0; i < KCW_MAX; ++i) {
+    for (int i = 0; i < KRES; ++i) {
       const int kc = wave + 4 * i;
       uint4 v = make_uint4(0, 0, 0, 0);
-      if (nt < NTL && kc < KC) v = *reinterpret_cast<const uint4*>(p.kT + (int64_t)(member * CPM + nt * 16 + l15) * p.ldk + kc * 32 + 8 * lq);
+      if (nt < NTL && kc < KC) v = *reinterpret_cast<const uint4*>(wrow[nt] + kc * 32);
       wf[nt][i] = __builtin_bit_cast(bf16x8, v);
     }
+  }
   const int bg = group * 8 + (l15 & 7);                    // utterance of A-fragment row l15 (rows 8..15 repeat 0..7)
   const int bs = group * 8 + member / 4, part = member & 3;  // S role
   // what the S role reads from the encoder memory never changes over the U steps: keep it in LDS when it fits
@@ -622,7 +689,7 @@ __global__ __launch_bounds__(256) void dec_persist_fwd_kernel(las_dec_persist p)
 
   // cell bias of this thread's unit: the same at every step
   float bias4[4] = {0.f, 0.f, 0.f, 0.f};
-  const bool pre_ok = s0.tok_rows != nullptr && tid < Hd;
+  const bool pre_ok = s0.tok_rows != nullptr && tid < Hd && Hd <= 256;     // (one unit per thread; wider cells load in the body)
   if (pre_ok)
 #pragma unroll
     for (int g = 0; g < 4; ++g) bias4[g] = s0.bias[g * Hd + tid];
@@ -648,31 +715,49 @@ __global__ __launch_bounds__(256) void dec_persist_fwd_kernel(las_dec_persist p)
 #pragma unroll
       for (int nt = 0; nt < NTL_MAX; ++nt) acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
       const unsigned short* arow = p.x + (int64_t)min(bg, B - 1) * p.ldx + (int64_t)t * p.inc_x + 8 * lq;
-      uint4 av[KCW_MAX];
+      uint4 av[KRES];
 #pragma unroll
-      for (int i = 0; i < KCW_MAX; ++i) {
+      for (int i = 0; i < KRES; ++i) {
         const int kc = wave + 4 * i;
         av[i] = make_uint4(0, 0, 0, 0);
         if (kc < KC && bg < B) av[i] = *reinterpret_cast<const uint4*>(arow + kc * 32);
       }
 #pragma unroll
-      for (int i = 0; i < KCW_MAX; ++i)
+      for (int i = 0; i < KRES; ++i)
 #pragma unroll
         for (int nt = 0; nt < NTL_MAX; ++nt)
           if (nt < NTL && wave + 4 * i < KC)
             acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, av[i]), wf[nt][i], acc[nt], 0, 0, 0);
+#ifndef DEC_SKIP_STREAM
+      if constexpr (KRES < KCW_MAX) {
+        // the chunks that do not fit the register file: operand and weight fragments of two chunks in flight
+#pragma unroll 2
+        for (int i = KRES; i < KCW_MAX; ++i) {
+          const int kc = wave + 4 * i;
+          if (kc >= KC) break;
+          const uint4 a = bg < B ? *reinterpret_cast<const uint4*>(arow + kc * 32) : make_uint4(0, 0, 0, 0);
+          uint4 w[NTL_MAX];
+#pragma unroll
+          for (int nt = 0; nt < NTL_MAX; ++nt) w[nt] = *reinterpret_cast<const uint4*>(wrow[nt] + kc * 32);
+#pragma unroll
+          for (int nt = 0; nt < NTL_MAX; ++nt)
+            if (nt < NTL)
+              acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, w[nt]), acc[nt], 0, 0, 0);
+        }
+      }
+#endif
 #pragma unroll
       for (int nt = 0; nt < NTL_MAX; ++nt)
         if (nt < NTL)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) red[(wave * 16 + lq * 4 + r) * 33 + nt * 16 + l15] = acc[nt][r];
+          for (int r = 0; r < 4; ++r) red[(wave * 16 + lq * 4 + r) * RS + nt * 16 + l15] = acc[nt][r];
       __syncthreads();
       for (int e = tid; e < 8 * CPM; e += 256) {
         const int row = e / CPM, col = e % CPM;
         const int b = group * 8 + row;
         if (b < B)
           pgranule_store(xzb + ((size_t)(xtag & 1) * B + b) * 4 * Hd + member * CPM + col, xtag,
-                         red[(0 * 16 + row) * 33 + col] + red[(1 * 16 + row) * 33 + col] + red[(2 * 16 + row) * 33 + col] + red[(3 * 16 + row) * 33 + col],
+                         red[(0 * 16 + row) * RS + col] + red[(1 * 16 + row) * RS + col] + red[(2 * 16 + row) * RS + col] + red[(3 * 16 + row) * RS + col],
                          local);
       }
     }
@@ -975,18 +1060,41 @@ __global__ __launch_bounds__(256) void dec_step_bwd_kernel(las_dec_step_bwd s) {
       float dv[8], vv[8], qq[8];
 #pragma unroll
       for (int j = 0; j < 8; ++j) { dv[j] = 0.f; vv[j] = s.att_v[u + j]; qq[j] = pqv[u + j]; }
-      for (int t = phase; t < len; t += P) {
-        const uint4 v = *reinterpret_cast<const uint4*>(keys + (int64_t)t * Hd + u);
-        const unsigned short* e = reinterpret_cast<const unsigned short*>(&v);
+      // FB frames per thread at a time: their key rows and their d(keys) rows (read-modify-write, 2 x 16 bytes) are all
+      // requested before the first is used (one frame at a time made every frame a dependent L2 round trip: 25 per thread
+      // and step at 512 units)
+      constexpr int FB = 4;
+      for (int tb = phase; tb < len; tb += P * FB) {
+        uint4 kv[FB];
+        float4 d0[FB], d1[FB];
+#pragma unroll
+        for (int i = 0; i < FB; ++i) {
+          const int t = tb + i * P;
+          if (t < len) {
+            kv[i] = *reinterpret_cast<const uint4*>(keys + (int64_t)t * Hd + u);
+            const float4* dk = reinterpret_cast<const float4*>(s.dkeys_acc + ((int64_t)b * Tm + t) * Hd + u);
+            d0[i] = dk[0];
+            d1[i] = dk[1];
+          }
+        }
+#pragma unroll
+        for (int i = 0; i < FB; ++i) {
+        const int t = tb + i * P;
+        if (t >= len) continue;
+        const unsigned short* e = reinterpret_cast<const unsigned short*>(&kv[i]);
         const float d = ds[t];
-        float* dk = s.dkeys_acc + ((int64_t)b * Tm + t) * Hd + u;   // this workgroup owns utterance b; one thread per (t,u)
+        float dkv[8] = {d0[i].x, d0[i].y, d0[i].z, d0[i].w, d1[i].x, d1[i].y, d1[i].z, d1[i].w};
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
           const float th = las_tanh(las_bf2f(e[j]) + qq[j]);
           dv[j] += d * th;
           const float p = d * vv[j] * (1.f - th * th);
           a[j] += p;
-          dk[j] += p;
+          dkv[j] += p;
+        }
+        float4* dk = reinterpret_cast<float4*>(s.dkeys_acc + ((int64_t)b * Tm + t) * Hd + u);   // this workgroup owns utterance b
+        dk[0] = make_float4(dkv[0], dkv[1], dkv[2], dkv[3]);
+        dk[1] = make_float4(dkv[4], dkv[5], dkv[6], dkv[7]);
         }
       }
 #pragma unroll
@@ -1013,13 +1121,10 @@ __global__ __launch_bounds__(256) void dec_step_bwd_kernel(las_dec_step_bwd s) {
       for (int u = tid; u < Hd; u += 256) if (!(pqv[u] > 0.f)) dhs[u] = 0.f;
       __syncthreads();
     }
-    for (int u = tid; u < Hd; u += 256) {
+    for (int u = tid; u < Hd; u += 256)
       if (s.dpq_out) s.dpq_out[(int64_t)b * s.lddpq + u] = las_f2bf(dhs[u]);
-      float acc = 0.f;
-      for (int a = 0; a < Hd; ++a) acc += las_bf2f(s.wq_t[(int64_t)a * Hd + u]) * dhs[a];
-      tmp[u] = acc;
-    }
-    __syncthreads();
+    // (scratch: 2048 floats behind everything else of this kernel's LDS, see las_decoder_step_bwd)
+    square_matvec_bf16(s.wq_t, dhs, tmp, red + 8 + Hd + (s.norm != LAS_NORM_SOFTMAX ? 5 * Tm : 0), Hd);
     for (int u = tid; u < Hd; u += 256) dhs[u] = tmp[u];
     __syncthreads();
   }
@@ -1704,9 +1809,9 @@ extern "C" int las_decoder_step_fwd(const las_dec_step* s, int parts, void* stre
 extern "C" int las_decoder_persist_supported(int Hd, int M, int K_in, int attention, int norm) {
   if (norm != LAS_NORM_SOFTMAX) return 0;
   if (attention != LAS_ATT_LUONG && attention != LAS_ATT_BAHDANAU && attention != LAS_ATT_CUSTOM) return 0;
-  if (Hd != 128 && Hd != 256) return 0;                   // 4Hd/32 columns per member: 16 or 32
-  if (K_in % 64 != 0 || K_in / 32 > 48) return 0;          // register-resident K slice (<= 12 chunks per wave); operand
-                                                           // rows of whole 128-byte lines (no line shared by two steps)
+  if (Hd != 128 && Hd != 256 && Hd != 512) return 0;      // 4Hd/32 columns per member: 16, 32 or 64
+  if (K_in % 64 != 0 || K_in / 32 > (Hd == 512 ? 80 : 48)) return 0;   // register-resident K slice (<= 12 / 20 chunks per wave);
+                                                           // operand rows of whole 128-byte lines (no line shared by two steps)
   if (M % 32 != 0) return 0;
   return 1;
 }
@@ -1752,6 +1857,23 @@ extern "C" int las_decoder_persist_fwd(const las_dec_persist* p, void* stream) {
   LAS_REQUIRE(lds <= 64 * 1024, "las_decoder_persist_fwd: memory length %d too long for the LDS score buffer", s->Tm);
   const bool res = persist_fwd_resident(s->M, s->Hd, s->Tm);
   const dim3 grid(((groups + 7) & ~7) * P_MEMBERS);
+  if (s->Hd == 512) {          // the wide flavour: 4 column tiles x 20 K chunks of the cell kernel per wave in registers
+    LAS_REQUIRE(p->sampling_prob <= 0.f, "las_decoder_persist_fwd: scheduled sampling inside the launch is built for decoder_units <= 256");
+    static bool attr512 = false;
+    if (!attr512) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dec_persist_fwd_kernel<false, true, 4, 20, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dec_persist_fwd_kernel<false, false, 4, 20, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      attr512 = true;
+    }
+    if (res) {
+      lds += persist_fwd_resident_bytes(s->M, s->Hd, s->Tm);
+      hipLaunchKernelGGL((dec_persist_fwd_kernel<false, true, 4, 20, 8>), grid, dim3(256), lds, st, *p);
+    } else {
+      hipLaunchKernelGGL((dec_persist_fwd_kernel<false, false, 4, 20, 8>), grid, dim3(256), lds, st, *p);
+    }
+    LAS_LAUNCH_CHECK("persistent decoder fwd launch");
+    return LAS_OK;
+  }
   if (res) {
     lds += persist_fwd_resident_bytes(s->M, s->Hd, s->Tm);
     static bool attr_set = false;
@@ -1829,7 +1951,7 @@ extern "C" int las_decoder_step_bwd(const las_dec_step_bwd* s, void* stream) {
   LAS_REQUIRE(s->mode == LAS_DEC_CELL_ONLY || s->norm == LAS_NORM_SOFTMAX || (s->p && s->dalign_carry),
               "las_decoder_step_bwd: monotonic attention needs the saved p_choose and the dalign_carry buffer");
   LAS_REQUIRE(s->mode != LAS_DEC_ATTENTION_ONLY || s->dq_out, "las_decoder_step_bwd: attention-only mode needs dq_out");
-  const size_t lds = (size_t)(s->M + s->Tm + 2048 + 8 + s->Hd + (s->norm != LAS_NORM_SOFTMAX ? 5 * s->Tm : 0)) * sizeof(float);
+  const size_t lds = (size_t)(s->M + s->Tm + 2048 + 8 + s->Hd + (s->norm != LAS_NORM_SOFTMAX ? 5 * s->Tm : 0) + 2048) * sizeof(float);
   LAS_REQUIRE(lds <= 64 * 1024, "las_decoder_step_bwd: shapes exceed the LDS budget");
   hipLaunchKernelGGL(dec_step_bwd_kernel, dim3(s->B), dim3(256), lds, (hipStream_t)stream, *s);
   LAS_LAUNCH_CHECK("decoder step bwd launch");

@@ -301,7 +301,8 @@ class Speller:
             logits = torch.empty(B, U, Vp, dtype=f32, device=dev)
         ts = fed.stride(0)
         persist = (B <= 4 * lib.las_decoder_persist_max_batch() and Vp <= 1024 and os.environ.get('LAS_DEC_PERSIST', '1') != '0' and      # B: co-residency
-                   lib.las_decoder_persist_supported(Hd, M, W, self.att, hip.NORM_SOFTMAX) == 1)
+                   lib.las_decoder_persist_supported(Hd, M, W, self.att, hip.NORM_SOFTMAX) == 1 and
+                   (Hd <= 256 or sampling == 0.0))          # (the in-launch sampling phase is built for decoder_units <= 256)
         if persist:
             # all U steps in one persistent launch (see las_dec_persist in las_hip.h)
             p = hip.DecPersist()
