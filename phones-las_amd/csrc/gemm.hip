@@ -38,6 +38,16 @@ struct GemmArgs {
   int64_t partial_stride = 0;
 };
 
+// LDS-DMA: 16 bytes per lane from a per-lane global address to (wave-uniform LDS base in M0) + lane * 16; invisible to the
+// compiler's vmcnt bookkeeping (the ring kernels count their loads themselves)
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+__device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+
 // KB = depth of a staged K tile: 64, or 32 for the large NT products (half the LDS, so three workgroups share a CU
 // instead of two: these products wait on memory most of the time, and the epilogue of one overlaps the others' loops)
 template <int BM, int BN, bool TN, int KB = 64>
@@ -479,6 +489,155 @@ __global__ __launch_bounds__(256) void gemm_tn_tr_kernel(GemmArgs g) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// The fused LSTM weight-gradient product on the LDS-DMA ring (same structure as gemm_nt_ring_kernel): 128 x 256 output
+// tile, 8 waves as 2 x 4 with a 64 x 64 block = 2 x 2 tiles of v_mfma_f32_32x32x16_bf16 each, 32-deep stages of
+// [k][128 m] (A) and two [k][128 n] sub-images (B) as they lie in memory -- 256-byte rows in the XOR image tr_off() -- filled
+// by global_load_lds_dwordx4 with the chunk permutation on the SOURCE address, read back with ds_read_b64_tr_b16.  Rows
+// that must read as zero (outside the period of the shifted y rows, beyond K, the padding columns) and the ones row fetch
+// from a 32-byte constant block instead.  Slices store their tiles into the caller's workspace (tn_reduce_kernel sums them).
+// ------------------------------------------------------------------------------------------------
+__device__ __attribute__((aligned(32))) unsigned short las_const_rows[16] = {0x3F80, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+constexpr int TR_STAGES = 4, TR_BK = 32, TR_STAGE_BYTES = TR_BK * 256 * 3;      // A 8 KiB + B 2 x 8 KiB
+
+__global__ __launch_bounds__(512) void gemm_tn_ring_kernel(GemmArgs g) {
+  constexpr int BM = 128, BN = 256;
+  extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+  typedef __attribute__((address_space(3))) unsigned char lds_u8;
+  lds_u8* lds = (lds_u8*)smem;
+  const unsigned lds_base = (unsigned)__builtin_amdgcn_readfirstlane((int)(size_t)lds);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+  // XCD-aware order as in gemm_tn_tr_kernel: the tiles of one K slice go to one XCD
+  int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+  {
+    const int gx = gridDim.x, gy = gridDim.y, P = gx * gy;
+    const int id = bx + gx * (by + gy * bz);
+    if (id < (int)(gridDim.z / 8) * 8 * P) {
+      const int j = id >> 3, t = j % P;
+      bz = (j / P) * 8 + (id & 7);
+      by = t / gx;
+      bx = t - by * gx;
+    }
+  }
+  const int m0 = by * BM, n0 = bx * BN;
+  const int slice = bz;
+  const int nk_total = (g.K + TR_BK - 1) / TR_BK;
+  const int nk_per = (nk_total + g.split_k - 1) / g.split_k;
+  const int kt_begin = slice * nk_per;
+  const int nk = max(0, min(nk_total, kt_begin + nk_per) - kt_begin);
+
+  // this lane's three loads per stage: rows 4 wave + (lane >> 4) of the A image and of the two B sub-images; LDS slot
+  // (lane & 15) of a row holds source chunk slot ^ swz(row)
+  const int srow = 4 * wave + (lane >> 4);
+  const int chunk = (lane & 15) ^ (((srow & 3) << 2) | ((srow >> 2) & 3));
+  const unsigned short* zeros = las_const_rows + 8;
+  int kindA = 0;
+  const unsigned short* pa = zeros;
+  int64_t lda_e = 0;
+  int shift = 0;
+  {
+    const int m = m0 + chunk * 8;
+    if (m < g.M1) { kindA = 1; pa = g.A + m; lda_e = g.lda; }
+    else if (m < g.M1 + g.M2) { kindA = 2; pa = g.A2 + (m - g.M1); lda_e = g.lda2; shift = g.a_shift; }
+    else if (m == g.M1 + g.M2 && g.bias_row) kindA = 3;
+  }
+  int kcur = kt_begin * TR_BK + srow;
+  int t0 = kcur % g.period;
+  const unsigned short* paK = pa + ((int64_t)kcur + shift) * lda_e;
+  const unsigned short* pbK[2];
+  bool b_ok[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int n = n0 + j * 128 + chunk * 8;
+    b_ok[j] = n < g.N;
+    pbK[j] = g.B + (int64_t)kcur * g.ldb + (b_ok[j] ? n : 0);
+  }
+  auto issue = [&](int stage) {
+    const unsigned base = lds_base + stage * TR_STAGE_BYTES + wave * 1024;
+    const bool k_ok = kcur < g.K;
+    const unsigned short* sa = zeros;
+    if (k_ok) {
+      if (kindA == 1) sa = paK;
+      else if (kindA == 2) { const int t = t0 + shift; if (t >= 0 && t < g.period) sa = paK; }
+      else if (kindA == 3) sa = las_const_rows;
+    }
+    glds16(sa, base);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) glds16((k_ok && b_ok[j]) ? pbK[j] : zeros, base + (1 + j) * TR_BK * 256);
+    kcur += TR_BK;
+    paK += (int64_t)TR_BK * lda_e;
+    pbK[0] += (int64_t)TR_BK * g.ldb;
+    pbK[1] += (int64_t)TR_BK * g.ldb;
+    t0 += TR_BK;
+    while (t0 >= g.period) t0 -= g.period;
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // transposed fragment reads: lane group (lane >> 4): k half = lane >> 5, 16-column block = (lane >> 4) & 1 of the 32 rows /
+  // columns of an MFMA tile; inside a group lane 4 q + p reads row q, columns 4 p .. 4 p + 3 and receives column (lane & 15)
+  const int kh = lane >> 5, blk = (lane >> 4) & 1, q = (lane & 15) >> 2, p = lane & 3;
+  auto frag = [&](const lds_u8* img, int kk, int c32) -> bf16x8 {        // c32: 32-column tile index inside the 128-column image
+    const int r = kk + 8 * kh + q;
+    const int c0 = c32 * 4 + blk * 2 + (p >> 1);
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(img + tr_off(r, c0) + 8 * (p & 1)));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(img + tr_off(r + 4, c0) + 8 * (p & 1)));
+    return __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+  };
+
+  if (nk > 0) {
+#pragma unroll
+    for (int s0 = 0; s0 < TR_STAGES - 1; ++s0)
+      if (s0 < nk) issue(s0);
+    int stage = 0;
+    for (int kt = 0; kt < nk; ++kt) {
+      if (kt + TR_STAGES - 2 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(3 * (TR_STAGES - 2)) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      if (kt + TR_STAGES - 1 < nk) issue(stage == 0 ? TR_STAGES - 1 : stage - 1);
+      const lds_u8* as = lds + stage * TR_STAGE_BYTES;
+      const lds_u8* bs = as + TR_BK * 256 + (wn >> 1) * TR_BK * 256;       // the 128-column sub-image of this wave's columns
+#pragma unroll
+      for (int kk = 0; kk < TR_BK; kk += 16) {
+        bf16x8 af[2], bfr[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) af[i] = frag(as, kk, wm * 2 + i);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) bfr[j] = frag(bs, kk, (wn & 1) * 2 + j);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+      }
+      stage = (stage + 1 == TR_STAGES) ? 0 : stage + 1;
+    }
+  }
+  // every slice stores its tile (empty slices: zeros); C/D layout: column = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
+  float* P = g.partial + (int64_t)bz * g.partial_stride;
+  const int l31 = lane & 31;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int coln = n0 + wn * 64 + j * 32 + l31;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+        if (row < g.M && coln < g.N) P[(int64_t)row * g.N + coln] = acc[i][j][r];
+      }
+    }
+}
+
 // C[row, perm(col)] += sum over slices of partial[slice][row][col] (last row -> bias_row when given); N % 4 == 0.
 __global__ __launch_bounds__(256) void tn_reduce_kernel(const float* __restrict__ P, int64_t stride, int nsl, float* C, int64_t ldc,
                                                         float* bias_row, int M, int N, int perm_h) {
@@ -515,14 +674,6 @@ __global__ __launch_bounds__(256) void tn_reduce_kernel(const float* __restrict_
 // conflicts are avoided by permuting the SOURCE chunk a lane fetches: LDS slot s of row r holds chunk s ^ ((r >> 1) & 7),
 // so the 32 rows one ds_read_b128 lane group touches fall on 16 distinct (row parity, slot) = 4-bank groups.
 // ------------------------------------------------------------------------------------------------
-typedef __attribute__((ext_vector_type(16))) float f32x16;
-
-__device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst) {
-  unsigned keep;
-  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-               : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
-}
-
 // BM x BN output tile, BK-deep stages, STAGES of them; 8 waves as WGM x (8 / WGM)
 template <int BM, int BN, int BK, int STAGES, int WGM>
 __global__ __launch_bounds__(512) void gemm_nt_ring_kernel(GemmArgs g) {
@@ -890,6 +1041,18 @@ extern "C" int las_gemm_tn_lstm(const las_bf16* x, int64_t ldx, int D, const las
     g.partial = workspace;
     g.partial_stride = (int64_t)g.M * g.N;
   }
+  static int ring = -1;            // LAS_TN_RING=0: the register-staged 128 x 128 kernel (diagnostics, A/B timing)
+  if (ring < 0) { const char* e = getenv("LAS_TN_RING"); ring = (e && atoi(e) == 0) ? 0 : 1; }
+  if (ring && g.partial) {
+    dim3 grid((g.N + 255) / 256, (g.M + 127) / 128, split_k);
+    const size_t lds = (size_t)TR_STAGES * TR_STAGE_BYTES;
+    static bool attr_ring = false;
+    if (!attr_ring) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_ring_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      attr_ring = true;
+    }
+    hipLaunchKernelGGL(gemm_tn_ring_kernel, grid, dim3(512), lds, (hipStream_t)stream, g);
+  } else {
   dim3 grid((g.N + 127) / 128, (g.M + 127) / 128, split_k);
   const size_t lds = (size_t)4 * TBK * 256;
   static bool attr_set = false;
@@ -898,6 +1061,7 @@ extern "C" int las_gemm_tn_lstm(const las_bf16* x, int64_t ldx, int D, const las
     attr_set = true;
   }
   hipLaunchKernelGGL(gemm_tn_tr_kernel, grid, dim3(256), lds, (hipStream_t)stream, g);
+  }
   LAS_LAUNCH_CHECK("lstm weight-gradient gemm launch");
   if (g.partial) {
     const int64_t n = (int64_t)g.M * (g.N / 4);
