@@ -90,3 +90,53 @@ def test_train_with_the_reference_default_architecture_flags(tmp_path, capsys):
                                        '--norm', os.path.join(d, 'norm.dmp'), '--model_dir', os.path.join(d, 'model'),
                                        '--num_channels', '13', '--batch_size', '8']))
     assert np.isfinite(per)
+
+
+def _binf_csv(path, phones, nf=6, seed=3):
+    """A binary-feature map in the reference's CSV layout (misc/binf_map*.csv: a header row of phones, one row per feature)."""
+    rng = np.random.default_rng(seed)
+    with open(path, 'w') as f:
+        f.write(',' + ','.join(phones) + '\n')
+        codes = set()
+        cols = []
+        while len(cols) < len(phones):                     # distinct feature vectors per phone
+            c = tuple(int(v) for v in rng.integers(0, 2, nf))
+            if c not in codes and any(c):
+                codes.add(c)
+                cols.append(c)
+        for k in range(nf):
+            f.write('f%d,' % k + ','.join(str(c[k]) for c in cols) + '\n')
+
+
+@pytest.mark.parametrize('mode', ['binf_projection', 'sigmoid', 'multitask'])
+def test_binary_feature_cli_modes_train_and_infer(tmp_path, capsys, mode):
+    """The reference's --binary_outputs flag family through train.py / infer.py (train.py:117-127, infer.py:203-223):
+    --binf_projection (DenseBinfDecoder), --binary_outputs alone (sigmoid-output decoder: feature logits, InferenceHelper
+    decode), --multitask (phone + binary decoders); infer.py --use_phones_from_binf reads sample_ids_phones_binf."""
+    import train, infer
+    d = str(tmp_path)
+    _corpus(d)
+    phones = ['p%d' % i for i in range(6)]
+    binf = os.path.join(d, 'binf_map.csv')
+    _binf_csv(binf, phones)
+    flags = ['--binary_outputs', '--output_ipa', '--binf_map', binf]
+    if mode in ('binf_projection', 'multitask'):
+        flags += ['--binf_projection']
+    if mode == 'multitask':
+        flags += ['--multitask']
+    train.main(train.parse_args(['--train', os.path.join(d, 'train.tfr'), '--model_dir', os.path.join(d, 'model'), '--encoder_layers', '2',
+                                 '--encoder_units', '64', '--decoder_layers', '1', '--decoder_units', '64', '--use_pyramidal',
+                                 '--bottom_only', '--pass_hidden_state', '--dropout', '0', '--sampling_probability', '0',
+                                 '--batch_size', '16', '--num_channels', '13', '--learning_rate', '0.002', '--num_epochs', '300'] + flags))
+    out = capsys.readouterr().out
+    assert 'finished at global_step 300' in out
+    first = float(out.split('step 10: loss = ')[1].split()[0])
+    last = float(out.split('step 300: loss = ')[1].split()[0])
+    assert np.isfinite(last) and last < 0.6 * first, (first, last)
+    base = ['--data', os.path.join(d, 'train.tfr'), '--vocab', os.path.join(d, 'vocab.txt'), '--norm', os.path.join(d, 'norm.dmp'),
+            '--model_dir', os.path.join(d, 'model'), '--num_channels', '13', '--batch_size', '8', '--binf_map', binf]
+    per = infer.main(infer.parse_args(base))
+    assert np.isfinite(per)
+    if mode != 'sigmoid':                                  # phone ids decoded from the binary-feature decoder
+        per_b = infer.main(infer.parse_args(base + ['--use_phones_from_binf']))
+        assert np.isfinite(per_b) and per_b < 60.0, per_b
