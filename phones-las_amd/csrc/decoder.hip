@@ -1097,13 +1097,24 @@ __global__ __launch_bounds__(256) void dec_step_bwd_kernel(las_dec_step_bwd s) {
         dk[1] = make_float4(dkv[4], dkv[5], dkv[6], dkv[7]);
         }
       }
+      // d(attention_v): the P frame phases of a column meet in LDS first (the scratch behind the kernel's other arrays),
+      // so a workgroup sends one atomic per column instead of P -- all 64 workgroups of a step add into the same Hd words
+      float* dvs = red + 8 + Hd + (s.norm != LAS_NORM_SOFTMAX ? 5 * Tm : 0);
 #pragma unroll
-      for (int j = 0; j < 8; ++j) atomicAdd(s.dv_acc + u + j, dv[j]);
+      for (int j = 0; j < 8; ++j) dvs[phase * Hd + u + j] = dv[j];
     }
 #pragma unroll
     for (int j = 0; j < 8; ++j) dhs[phase * Hd + u + j] = a[j];
   }
   __syncthreads();
+  if (att_additive(s.attention)) {
+    const float* dvs = red + 8 + Hd + (s.norm != LAS_NORM_SOFTMAX ? 5 * Tm : 0);
+    for (int u = tid; u < Hd; u += 256) {
+      float acc = 0.f;
+      for (int ph = 0; ph < P; ++ph) acc += dvs[ph * Hd + u];
+      atomicAdd(s.dv_acc + u, acc);
+    }
+  }
   // reduce the P per-phase partials (dhs is [P][Hd] = 2048 floats)
   for (int u = tid; u < Hd; u += 256) {
     float acc = 0.f;
@@ -1272,6 +1283,9 @@ __global__ __launch_bounds__(256) void dec_persist_bwd_kernel(las_dec_persist_bw
   };
   fetch_step(p.U - 1, cur_dc, cur_al);
 
+  // d(attention_v) of this thread's 8 columns over ALL steps (Bahdanau): one round of atomics at the end of the launch
+  // instead of 2 048 per workgroup and step into the same Hd words (that contention was most of the Bahdanau backward)
+  float dv_tot[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   for (int t = p.U - 1; t >= 0; --t) {
     const bool first = (t == p.U - 1);
     const float* dfeed_next = first ? nullptr : p.dfeed_all + (int64_t)(t + 1) * B * W;      // written by step t+1
@@ -1424,23 +1438,43 @@ __global__ __launch_bounds__(256) void dec_persist_bwd_kernel(las_dec_persist_bw
         float dv[8], vv[8], qq[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) { dv[j] = 0.f; vv[j] = s0.att_v[u + j]; qq[j] = pqv[u + j]; }
-        for (int tt = f0 + phase; tt < flen; tt += P) {
-          const uint4 v = resident ? *reinterpret_cast<const uint4*>(lkeys + (size_t)(tt - f0) * Hd + u)
-                                   : *reinterpret_cast<const uint4*>(keys + (int64_t)tt * Hd + u);
-          const unsigned short* e = reinterpret_cast<const unsigned short*>(&v);
-          const float d = dal[tt];
-          float* dk = s0.dkeys_acc + ((int64_t)b * Tm + tt) * Hd + u;
+        // four frames per thread at a time: their d(keys) rows (read-modify-write, 2 x 16 bytes) are requested together
+        constexpr int FB = 4;
+        for (int tb = f0 + phase; tb < flen; tb += P * FB) {
+          float4 d0[FB], d1[FB];
 #pragma unroll
-          for (int j = 0; j < 8; ++j) {
-            const float th = las_tanh(las_bf2f(e[j]) + qq[j]);
-            dv[j] += d * th;
-            const float pp = d * vv[j] * (1.f - th * th);
-            a[j] += pp;
-            dk[j] += pp;
+          for (int i = 0; i < FB; ++i) {
+            const int tt = tb + i * P;
+            if (tt < flen) {
+              const float4* dk = reinterpret_cast<const float4*>(s0.dkeys_acc + ((int64_t)b * Tm + tt) * Hd + u);
+              d0[i] = dk[0];
+              d1[i] = dk[1];
+            }
+          }
+#pragma unroll
+          for (int i = 0; i < FB; ++i) {
+            const int tt = tb + i * P;
+            if (tt >= flen) continue;
+            const uint4 v = resident ? *reinterpret_cast<const uint4*>(lkeys + (size_t)(tt - f0) * Hd + u)
+                                     : *reinterpret_cast<const uint4*>(keys + (int64_t)tt * Hd + u);
+            const unsigned short* e = reinterpret_cast<const unsigned short*>(&v);
+            const float d = dal[tt];
+            float dkv[8] = {d0[i].x, d0[i].y, d0[i].z, d0[i].w, d1[i].x, d1[i].y, d1[i].z, d1[i].w};
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+              const float th = las_tanh(las_bf2f(e[j]) + qq[j]);
+              dv[j] += d * th;
+              const float pp = d * vv[j] * (1.f - th * th);
+              a[j] += pp;
+              dkv[j] += pp;
+            }
+            float4* dk = reinterpret_cast<float4*>(s0.dkeys_acc + ((int64_t)b * Tm + tt) * Hd + u);
+            dk[0] = make_float4(dkv[0], dkv[1], dkv[2], dkv[3]);
+            dk[1] = make_float4(dkv[4], dkv[5], dkv[6], dkv[7]);
           }
         }
 #pragma unroll
-        for (int j = 0; j < 8; ++j) atomicAdd(s0.dv_acc + u + j, dv[j]);
+        for (int j = 0; j < 8; ++j) dv_tot[j] += dv[j];
       }
 #pragma unroll
       for (int j = 0; j < 8; ++j) dhs[phase * Hd + u + j] = a[j];
@@ -1486,13 +1520,10 @@ __global__ __launch_bounds__(256) void dec_persist_bwd_kernel(las_dec_persist_bw
           for (int u = tid; u < Hd; u += 256) if (!(pqv[u] > 0.f)) dhs[u] = 0.f;
           __syncthreads();
         }
-        for (int u = tid; u < Hd; u += 256) {
+        for (int u = tid; u < Hd; u += 256)
           if (s0.dpq_out) s0.dpq_out[(int64_t)b * s0.lddpq + (int64_t)t * p.inc_pq + u] = las_f2bf(dhs[u]);
-          float acc = 0.f;
-          for (int a = 0; a < Hd; ++a) acc += las_bf2f(s0.wq_t[(int64_t)a * Hd + u]) * dhs[a];
-          tmp[u] = acc;
-        }
-        __syncthreads();
+        // (scratch: the G role's partial-tile area, idle between two products: 4 x 16 x 49 >= 2048 floats)
+        square_matvec_bf16(s0.wq_t, dhs, tmp, red2, Hd);
         for (int u = tid; u < Hd; u += 256) dhs[u] = tmp[u];
         __syncthreads();
       }
@@ -1554,6 +1585,11 @@ __global__ __launch_bounds__(256) void dec_persist_bwd_kernel(las_dec_persist_bw
     cur_al = nxt_al;
   }
   if (cellw) s0.dc[(int64_t)b * Hd + tid] = dcr;          // d(c) before the first step: the caller's d(initial state)
+  if (WQ && att_additive(s0.attention) && active) {
+    const int u = (tid % (Hd / 8)) * 8;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) atomicAdd(s0.dv_acc + u + j, dv_tot[j]);
+  }
   if (*fail && tid == 0) atomicOr(status, 16u);
 }
 
