@@ -30,6 +30,10 @@ CONFIGS = {
     'metric-M': dict(F=40, L=3, H=256, Hd=256, V=64, att='luong', T=800, U=80, B=64),
     'metric-L': dict(F=40, L=4, H=512, Hd=512, V=64, att='bahdanau', T=800, U=80, B=64),
     'tiny': dict(F=40, L=2, H=64, Hd=64, V=64, att='luong', T=64, U=8, B=16),
+    # the other BASELINE.json configs at their stated shapes (parity-test cases; timed here for DESIGN.md, not bench lines)
+    'cfg1': dict(F=39, L=2, H=128, Hd=128, V=64, att='luong', T=300, U=40, B=4),
+    'cfg4': dict(F=80, L=4, H=512, Hd=512, V=64, att='bahdanau', T=800, U=80, B=64, ctc=0.3),
+    'cfg5': dict(F=39, L=3, H=256, Hd=256, V=197, att='bahdanau_monotonic', T=800, U=80, B=64, binf='binf_map.csv'),
     # the same model at the reference's default stochastic settings (train.py:48,71)
     'metric-M-stochastic': dict(F=40, L=3, H=256, Hd=256, V=64, att='luong', T=800, U=80, B=64, dropout=0.2, sampling=0.1),
 }
@@ -55,9 +59,20 @@ def build_params(c, lr=1e-3, l2=1e-6):
     for k, v in dict(num_channels=c['F'], encoder_layers=c['L'], encoder_units=c['H'], use_pyramidal=True,
                      unidirectional=False, decoder_layers=1, decoder_units=c['Hd'], target_vocab_size=c['V'],
                      attention_type=c['att'], bottom_only=True, pass_hidden_state=True, dropout=c.get('dropout', 0.0),
-                     sampling_probability=c.get('sampling', 0.0), learning_rate=lr, l2_reg_scale=l2).items():
+                     sampling_probability=c.get('sampling', 0.0), learning_rate=lr, l2_reg_scale=l2,
+                     ctc_weight=c.get('ctc', -1.0)).items():
         hp.set_hparam(k, v)
+    if c.get('binf'):           # cfg5: --binary_outputs --output_ipa --binf_projection with the reference's misc/binf_map.csv
+        for k, v in dict(binary_outputs=True, binf_projection=True, binf_count=binf_matrix(c['binf']).shape[0]).items():
+            hp.set_hparam(k, v)
     return pu.get_encoder_decoder_hparams(hp)
+
+
+def binf_matrix(name):
+    """[nf, V] map as the reference's load_binf2phone returned it for misc/<name> (data fixture tests/golden/binf_maps.json)."""
+    import numpy as np
+    m = json.load(open(os.path.join(ROOT, 'tests', 'golden', 'binf_maps.json')))['maps'][name]
+    return np.array([[int(ch) for ch in row] for row in m['rows']], dtype=np.float32)
 
 
 def synthetic_batch(c, seed, device):
@@ -236,7 +251,8 @@ def main():
     rccl_ranks = torch.distributed.get_world_size() if torch.distributed.is_initialized() else 1
 
     from phones_las_amd import model_helper as mh
-    model = mh.LasModel(build_params(c), world_size=world, process_group=group, rank=rank)
+    model = mh.LasModel(build_params(c), world_size=world, process_group=group, rank=rank,
+                        binf2phone=binf_matrix(c['binf']) if c.get('binf') else None)
     want_overlap = args.dp_overlap == 'on' or (args.dp_overlap == 'auto' and multi)
     overlap_exchange = want_overlap and len(model.enable_exchange_overlap()) == 2
     feats, labels = synthetic_batch(c, 1234 + rank, dev)
