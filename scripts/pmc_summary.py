@@ -5,7 +5,7 @@
 import csv, glob, json, sys
 rnd = sys.argv[1] if len(sys.argv) > 1 else 'r02'
 FAMILIES = {'lstm_fwd': 'lstm_fwd_kernel', 'lstm_bwd': 'lstm_bwd_kernel', 'dec_persist_fwd': 'dec_persist_fwd_kernel',
-            'dec_persist_bwd': 'dec_persist_bwd_kernel', 'gemm_nt': 'gemm_nt_ring_kernel', 'gemm_tn_lstm': 'gemm_tn_tr_kernel'}
+            'dec_persist_bwd': 'dec_persist_bwd_kernel', 'gemm_nt': 'gemm_nt_ring_kernel', 'gemm_tn_lstm': 'gemm_tn_ring_kernel', 'gemm_tn': 'gemm_tn_tr_kernel'}
 B, T, H = 64, 800, 256
 ALGO = {   # bytes per launch at the layer-1 shape (B=64, T=800, both directions)
     'lstm_fwd': B * T * 2 * (4 * H * 4 + 4 * H * 4 + H * 4 + H * 2),       # xproj read, gates written, c written, y (bf16) written
@@ -17,7 +17,9 @@ for c in ('FETCH_SIZE', 'WRITE_SIZE', 'SQ_VALU_MFMA_BUSY_CYCLES', 'GRBM_GUI_ACTI
     if not fs:
         print(c, 'no counter file')
         continue
-    for r in csv.DictReader(open(fs[0])):
+    import os
+    fs.sort(key=os.path.getmtime)          # several runs may have been merged into the directory: the newest one
+    for r in csv.DictReader(open(fs[-1])):
         name = r['Kernel_Name']
         for fam, pat in FAMILIES.items():
             if pat in name:
