@@ -29,7 +29,8 @@ def lstm_cell(num_units, dropout, mode):
     if not 0.0 <= dropout < 1.0:
         raise ValueError('dropout must be in [0, 1)')
     if num_units not in (64, 128, 256, 512):
-        raise ValueError('num_units must be one of 64, 128, 256, 512 on the HIP path (got %d)' % num_units)
+        raise ValueError('the recurrent kernels are built for 64, 128, 256 and 512 units (got %d): LasModel runs other '
+                         'widths zero-padded to the next of these (model_helper.physical_params)' % num_units)
     return LSTMCellSpec(num_units, 1.0 - dropout)
 
 

@@ -7,6 +7,7 @@ L2 -> per-tensor clip_by_norm(2) -> [RCCL all-reduce(sum) when data-parallel] ->
 i.e. CrossShardOptimizer's order (model_helper.py:405-417).
 """
 import collections
+import copy
 import math
 
 import numpy as np
@@ -31,27 +32,93 @@ def _enc_depth(e):
     return dirs * e.num_units
 
 
-def param_table(params):
-    """Ordered [(tf_variable_name, shape, initializer)] of every trainable variable the model_fn creates."""
+SUPPORTED_UNITS = (64, 128, 256, 512)      # what the recurrent / decoder kernels are built for (las/ops.py lstm_cell)
+
+
+def physical_units(n):
+    """The width the kernels run a `n`-unit LSTM at: the next supported size.  The extra units have all-zero weights and
+    biases, which keeps them at c = h = 0 for ever and their gradients at exactly 0 (see physical_params)."""
+    for s in SUPPORTED_UNITS:
+        if n <= s:
+            return s
+    raise ValueError('num_units %d: the HIP kernels go up to %d units' % (n, SUPPORTED_UNITS[-1]))
+
+
+def physical_params(params):
+    """The hparams the kernels run at.  The reference takes any --encoder_units / --decoder_units (las/ops.py:10-12); the
+    kernels are built for SUPPORTED_UNITS, so other widths run zero-padded to the next one: a unit whose kernel columns,
+    kernel rows and bias are zero has i = o = 1/2, j = 0, so c_t = f c_{t-1} = 0 and h_t = 0 from a zero state, every
+    product it enters contributes 0.0 exactly, and its dz (hence every gradient element that touches it) is 0.0 exactly;
+    L2, the per-tensor norms, the clip and Adam (m = v = 0) leave the padding at zero.  Returns `params` itself when
+    nothing needs padding."""
+    He, Hd = params.encoder.num_units, params.decoder.num_units
+    if physical_units(He) == He and physical_units(Hd) == Hd:
+        return params
+    phys = copy.deepcopy(params)
+    phys.encoder.set_hparam('num_units', physical_units(He))
+    phys.decoder.set_hparam('num_units', physical_units(Hd))
+    return phys
+
+
+def _mem_atoms(e):
+    """The listener's output depth as encoder-unit blocks: [fw | bw] per frame, two frames when pyramid-stacked."""
+    dirs = 1 if e.unidirectional else 2
+    if e.use_pyramidal:
+        return ['H'] * (dirs * (1 if e.num_layers == 1 else 2))
+    return ['H'] * dirs
+
+
+def param_layout(params):
+    """Ordered [(tf_variable_name, axes, initializer)]: every axis is a list of atoms, an int (a fixed extent) or 'H' /
+    'D' (one block of encoder / decoder units).  param_table() turns the atoms into a shape for given unit counts; the
+    same walk at the logical and the physical unit counts gives the index map of a zero-padded model."""
     e, d = params.encoder, params.decoder
-    H = e.num_units
     dirs = ['fw'] if e.unidirectional else ['fw', 'bw']
     out = []
-    D = params.num_channels
+    D = [params.num_channels]
     for l in range(e.num_layers):
         for dr in dirs:
             base = ('listener/bilstm_%d/%s/lstm_cell' % (l, dr)) if e.use_pyramidal else \
                 ('listener/%s/multi_rnn_cell/cell_%d/lstm_cell' % (dr, l))
-            out.append((base + '/kernel', (D + H, 4 * H), 'lstm'))
-            out.append((base + '/bias', (4 * H,), 'zeros'))
-        D = len(dirs) * H * (1 if l == 0 else 2) if e.use_pyramidal else H
-    M, V = _enc_depth(e), d.target_vocab_size
+            out.append((base + '/kernel', (D + ['H'], ['H'] * 4), 'lstm'))
+            out.append((base + '/bias', (['H'] * 4,), 'zeros'))
+        D = ['H'] * (len(dirs) * (1 if l == 0 else 2)) if e.use_pyramidal else ['H']
+    M, V = _mem_atoms(e), d.target_vocab_size
     for scope, kind in speller_plan(d):
-        out.extend(_speller_table(d, M, scope, kind))
+        out.extend(_speller_layout(d, M, scope, kind))
     if params.ctc_weight > 0:
-        out.append(('ctc_logits/kernel', (M, V + 1), 'glorot'))
-        out.append(('ctc_logits/bias', (V + 1,), 'zeros'))
+        out.append(('ctc_logits/kernel', (M, [V + 1]), 'glorot'))
+        out.append(('ctc_logits/bias', ([V + 1],), 'zeros'))
     return out
+
+
+def _extent(axis, H, Hd):
+    return sum(H if a == 'H' else Hd if a == 'D' else int(a) for a in axis)
+
+
+def param_table(params):
+    """Ordered [(tf_variable_name, shape, initializer)] of every trainable variable the model_fn creates."""
+    H, Hd = params.encoder.num_units, params.decoder.num_units
+    return [(name, tuple(_extent(a, H, Hd) for a in axes), init) for name, axes, init in param_layout(params)]
+
+
+def pad_index_maps(logical, physical):
+    """{name: [per axis: int64 array, logical index -> physical index]} between the same model at its logical unit counts
+    and at the widths the kernels run (physical_params)."""
+    Hl, Dl = logical.encoder.num_units, logical.decoder.num_units
+    Hp, Dp = physical.encoder.num_units, physical.decoder.num_units
+    maps = {}
+    for name, axes, _ in param_layout(logical):
+        per_axis = []
+        for axis in axes:
+            idx, o = [], 0
+            for a in axis:
+                nl, npad = (Hl, Hp) if a == 'H' else (Dl, Dp) if a == 'D' else (int(a), int(a))
+                idx.append(np.arange(o, o + nl, dtype=np.int64))
+                o += npad
+            per_axis.append(np.concatenate(idx))
+        maps[name] = per_axis
+    return maps
 
 
 def speller_plan(d):
@@ -70,36 +137,43 @@ def speller_plan(d):
     return [('speller', kind)]
 
 
-def _speller_table(d, M, scope, kind):
-    Hd, V = d.num_units, d.target_vocab_size
+def _speller_layout(d, M, scope, kind):
+    """param_layout's rows of one decoder; M: the memory depth as atoms (_mem_atoms)."""
+    V = d.target_vocab_size
     out = []
-    A = (2 * d.binf_count) if kind == 'binf_projection' else (d.attention_layer_size or M)
+    A = [2 * d.binf_count] if kind == 'binf_projection' else ([d.attention_layer_size] if d.attention_layer_size else list(M))
     E = d.embedding_size if d.embedding_size else V
     if kind != 'phones' and not d.embedding_size:
         E = d.binf_count            # embedding_fn = rows of binf2phone^T / the feature vector itself (las/model.py:237-243)
     Vo = d.binf_count if kind == 'sigmoid' else V          # DenseBinfDecoder(binf_count units) (las/model.py:251-252)
     if d.embedding_size:
-        out.append((scope + '/target_embedding', (V, d.embedding_size), 'glorot'))
-    out.append((scope + '/memory_layer/kernel', (M, Hd), 'glorot'))
+        out.append((scope + '/target_embedding', ([V], [d.embedding_size]), 'glorot'))
+    out.append((scope + '/memory_layer/kernel', (list(M), ['D']), 'glorot'))
     if d.attention_type in ('bahdanau', 'bahdanau_monotonic', 'custom'):
-        out.append((scope + '/query_layer/kernel', (Hd, Hd), 'glorot'))
+        out.append((scope + '/query_layer/kernel', (['D'], ['D']), 'glorot'))
     if d.attention_type in ('bahdanau', 'bahdanau_monotonic'):
-        out.append((scope + '/attention_v', (Hd,), 'glorot_v'))
+        out.append((scope + '/attention_v', (['D'],), 'glorot_v'))
     if d.attention_type in ('luong_monotonic', 'bahdanau_monotonic'):
-        out.append((scope + '/attention_score_bias', (1,), 'zeros'))
+        out.append((scope + '/attention_score_bias', ([1],), 'zeros'))
     if d.attention_layer_size or kind == 'binf_projection':
-        out.append((scope + '/attention_layer/kernel', (Hd + M, A), 'glorot'))
+        out.append((scope + '/attention_layer/kernel', (['D'] + list(M), A), 'glorot'))
     for l in range(d.num_layers):
         if d.bottom_only:       # AttentionMultiCell: cell_1 reads [attention_t, attention_{t-1}], upper cells [h_{l-1}, attention_{t-1}]
-            din = (E + A) if l == 0 else ((A + A) if l == 1 else (Hd + A))
+            din = ([E] + A) if l == 0 else ((A + A) if l == 1 else (['D'] + A))
         else:
-            din = (E + A) if l == 0 else Hd
-        out.append((scope + '/decoder_cell_%d/lstm_cell/kernel' % l, (din + Hd, 4 * Hd), 'lstm'))
-        out.append((scope + '/decoder_cell_%d/lstm_cell/bias' % l, (4 * Hd,), 'zeros'))
-    P = Hd if (d.bottom_only and d.num_layers > 1) else A      # AttentionMultiCell with upper layers outputs h_top
-    out.append((scope + '/projection_layer/kernel', (P, Vo), 'proj'))
-    out.append((scope + '/projection_layer/bias', (Vo,), 'zeros'))
+            din = ([E] + A) if l == 0 else ['D']
+        out.append((scope + '/decoder_cell_%d/lstm_cell/kernel' % l, (din + ['D'], ['D'] * 4), 'lstm'))
+        out.append((scope + '/decoder_cell_%d/lstm_cell/bias' % l, (['D'] * 4,), 'zeros'))
+    P = ['D'] if (d.bottom_only and d.num_layers > 1) else A      # AttentionMultiCell with upper layers outputs h_top
+    out.append((scope + '/projection_layer/kernel', (P, [Vo]), 'proj'))
+    out.append((scope + '/projection_layer/bias', ([Vo],), 'zeros'))
     return out
+
+
+def _speller_table(d, M, scope, kind):
+    """[(name, shape, init)] of one decoder on a memory of depth M (an int)."""
+    Hd = d.num_units
+    return [(n, tuple(_extent(a, M, Hd) for a in axes), i) for n, axes, i in _speller_layout(d, ['H'], scope, kind)]
 
 
 def _init_array(shape, init, rng):
@@ -117,8 +191,12 @@ def _init_array(shape, init, rng):
 class Variables:
     """Flat fp32 parameter / gradient / Adam-slot buffers with TF-named per-tensor views."""
 
-    def __init__(self, table, device='cuda'):
+    def __init__(self, table, device='cuda', logical_table=None, index_maps=None):
+        """table: the tensors as the kernels see them.  logical_table / index_maps (pad_index_maps): set when the model
+        runs zero-padded to wider LSTMs than its hparams say; initialize / load / logical() then speak the logical shapes."""
         self.table = list(table)
+        self.logical_table = list(logical_table) if logical_table is not None else None
+        self.index_maps = index_maps
         offs = [0]
         for _, shape, _ in self.table:
             n = int(np.prod(shape))
@@ -142,6 +220,12 @@ class Variables:
         self.buckets = [self._bucket(0, len(self.table), 0)]             # one exchange bucket = everything
         self.params = self._views(self.flat)
         self.grads = self._views(self.grad)
+        self.mask = None
+        if self.index_maps is not None:
+            # 1.0 where a logical element lives, 0.0 on the padding (weight noise must not wake the padded units up)
+            self.mask = torch.zeros(self.total, dtype=f32, device=device)
+            for name, view in self._views(self.mask).items():
+                self._scatter(view, name, torch.ones(1, dtype=f32, device=device).expand(*self._logical_shape(name)))
 
     def _bucket(self, lo, hi, slot):
         """Tensors lo..hi-1 as a contiguous piece of the flat buffers: element range, boundaries relative to its start."""
@@ -173,18 +257,62 @@ class Variables:
             d[name] = flat[o:o + int(np.prod(shape))].view(*shape)
         return d
 
+    def _logical_shape(self, name):
+        return tuple(len(i) for i in self.index_maps[name])
+
+    def _index(self, name):
+        """Broadcastable index tensors of the logical elements inside the physical tensor."""
+        maps = self.index_maps[name]
+        n = len(maps)
+        return tuple(torch.as_tensor(m, device=self.device).view(*[(-1 if k == a else 1) for k in range(n)])
+                     for a, m in enumerate(maps))
+
+    def _scatter(self, view, name, value):
+        view.zero_()
+        view[self._index(name)] = value.to(device=view.device, dtype=view.dtype)
+
     def initialize(self, seed=4321):
+        """The initial values are drawn at the LOGICAL shapes (a zero-padded model starts from the same weights as an
+        un-padded one of its hparams would)."""
         rng = np.random.default_rng(seed)
-        for name, shape, init in self.table:
-            a = _init_array(shape, init, rng).astype(np.float32)
-            self.params[name].copy_(torch.from_numpy(a))
+        for name, shape, init in (self.logical_table or self.table):
+            a = torch.from_numpy(_init_array(shape, init, rng).astype(np.float32))
+            if self.index_maps is None:
+                self.params[name].copy_(a)
+            else:
+                self._scatter(self.params[name], name, a)
 
     def load(self, tensors):
+        """tensors: {name: array} at the logical shapes (or, for a padded model, at the physical ones)."""
         for name in self.params:
-            self.params[name].copy_(tensors[name].to(torch.float32))
+            t = torch.as_tensor(tensors[name]).to(torch.float32)
+            if tuple(t.shape) == tuple(self.params[name].shape):
+                self.params[name].copy_(t)
+            elif self.index_maps is not None and tuple(t.shape) == self._logical_shape(name):
+                self._scatter(self.params[name], name, t)
+            else:
+                raise ValueError('%s: got shape %s, the model holds %s' % (name, tuple(t.shape), tuple(self.params[name].shape)))
+
+    def logical(self, which='params'):
+        """{name: tensor} of `which` ('params' | 'grads' | 'm' | 'v') at the logical shapes (copies for a padded model)."""
+        views = {'params': self.params, 'grads': self.grads}.get(which)
+        if views is None:
+            views = self._views(getattr(self, which))
+        if self.index_maps is None:
+            return views
+        return collections.OrderedDict((n, t[self._index(n)]) for n, t in views.items())
+
+    def padding_is_zero(self, which='params'):
+        """True when every padded element of `which` is exactly 0.0 (always True for an un-padded model)."""
+        if self.mask is None:
+            return True
+        flat = {'params': self.flat, 'grads': self.grad}.get(which)
+        if flat is None:
+            flat = getattr(self, which)
+        return bool((flat * (1.0 - self.mask)).abs().max().item() == 0.0)
 
     def num_parameters(self):
-        return sum(int(np.prod(s)) for _, s, _ in self.table)
+        return sum(int(np.prod(s)) for _, s, _ in (self.logical_table or self.table))
 
 
 def compute_loss(logits, targets, final_sequence_length, target_sequence_length, mode, eos_id, grad_scale=1.0,
@@ -321,7 +449,12 @@ class LasModel:
         if not torch.cuda.is_available():
             raise hip.LasError('no HIP device visible: the LAS path has no CPU fallback')
         hip.lib()
+        # any --encoder_units / --decoder_units: widths the kernels are not built for run zero-padded to the next one that
+        # is (physical_params); self.params is what the modules run at, self.hparams what the caller asked for
+        self.hparams = params
+        params = physical_params(params)
         self.params = params
+        self.padded = params is not self.hparams
         d = params.decoder
         binary = bool(getattr(d, 'binary_outputs', False))
         self.binf_projection = binary and bool(getattr(d, 'binf_projection', False))
@@ -336,7 +469,11 @@ class LasModel:
                 if tuple(binf2phone.shape) != (d.binf_count, d.target_vocab_size):
                     raise ValueError('binf2phone must be [binf_count=%d, target_vocab_size=%d], got %s'
                                      % (d.binf_count, d.target_vocab_size, tuple(binf2phone.shape)))
-        self.vars = Variables(param_table(params))
+        if self.padded:
+            self.vars = Variables(param_table(params), logical_table=param_table(self.hparams),
+                                  index_maps=pad_index_maps(self.hparams, params))
+        else:
+            self.vars = Variables(param_table(params))
         self.vars.initialize(seed)
         self.listener = las_model.Listener(params.encoder, self.vars.params, params.num_channels)
         # the decoders of model_helper.py:211-227: [(module, kind)]; self.speller is the first one (the only one unless
@@ -584,6 +721,8 @@ class LasModel:
                 t = self.vars.params[name]
                 hip.check(lib.las_add_noise(hip.p(t), t.numel(), float(p.noise_std),
                                             (self.noise_seed + 7919 * self.global_step) & 0x7fffffff, 1000 + i, st))
+        if self.vars.mask is not None:
+            self.vars.flat.mul_(self.vars.mask)        # the padded units of a zero-padded model stay at zero
         self._images_stale = True
 
     def l2_loss(self, from_norms=False):
@@ -638,7 +777,11 @@ class LasModel:
             emb = torch.stack([state.c, state.h], 1)
         elif all(hasattr(s, 'c') and torch.is_tensor(s.c) for s in state):
             emb = torch.stack([torch.cat([s.c for s in state], 1), torch.cat([s.h for s in state], 1)], 1)
-        out = {'encoder_out': mem, 'source_length': mem_len}
+        enc_out = mem
+        if self.padded and self.params.encoder.num_units != self.hparams.encoder.num_units:
+            cols = self.vars.index_maps[speller_plan(self.params.decoder)[0][0] + '/memory_layer/kernel'][0]
+            enc_out = mem[..., torch.as_tensor(cols, device=mem.device)]        # the logical units of the zero-padded listener
+        out = {'encoder_out': enc_out, 'source_length': mem_len}
         if emb is not None:
             out['embedding'] = emb
         beam_width = int(getattr(self.params.decoder, 'beam_width', 0) or 0)

@@ -92,6 +92,34 @@ def test_train_with_the_reference_default_architecture_flags(tmp_path, capsys):
     assert np.isfinite(per)
 
 
+def test_train_resume_infer_with_unit_counts_the_kernels_are_not_built_for(tmp_path, capsys):
+    # las/ops.py:10-12 takes any --encoder_units / --decoder_units; 96 / 72 run zero-padded at 128 / 128 (model_helper.
+    # physical_params).  hparams.json keeps the numbers the user gave, the checkpoint restores, infer.py decodes.
+    import json
+    import train, infer
+    d = str(tmp_path)
+    _corpus(d, n=8)
+    common = ['--train', os.path.join(d, 'train.tfr'), '--model_dir', os.path.join(d, 'model'), '--encoder_layers', '2',
+              '--encoder_units', '96', '--decoder_layers', '1', '--decoder_units', '72', '--use_pyramidal', '--bottom_only',
+              '--dropout', '0', '--sampling_probability', '0', '--batch_size', '8', '--num_channels', '13']
+    train.main(train.parse_args(common + ['--num_epochs', '200']))
+    out = capsys.readouterr().out
+    assert 'finished at global_step 200' in out
+    first = float(out.split('step 10: loss = ')[1].split()[0])
+    last = float(out.split('step 200: loss = ')[1].split()[0])
+    assert last < 0.5 * first
+    hp = json.load(open(os.path.join(d, 'model', 'hparams.json')))
+    hp = json.loads(hp) if isinstance(hp, str) else hp
+    assert hp['encoder_units'] == 96 and hp['decoder_units'] == 72
+    train.main(train.parse_args(common + ['--num_epochs', '5']))
+    out = capsys.readouterr().out
+    assert 'restored' in out and 'at global_step 200' in out
+    per = infer.main(infer.parse_args(['--data', os.path.join(d, 'train.tfr'), '--vocab', os.path.join(d, 'vocab.txt'),
+                                       '--norm', os.path.join(d, 'norm.dmp'), '--model_dir', os.path.join(d, 'model'),
+                                       '--num_channels', '13', '--batch_size', '8']))
+    assert np.isfinite(per) and per < 60.0
+
+
 def _binf_csv(path, phones, nf=6, seed=3):
     """A binary-feature map in the reference's CSV layout (misc/binf_map*.csv: a header row of phones, one row per feature)."""
     rng = np.random.default_rng(seed)
