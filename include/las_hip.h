@@ -129,6 +129,27 @@ typedef struct las_image_job {
 } las_image_job;
 int las_refresh_images(const las_image_job* jobs_dev, int njobs, void* stream);
 
+/* A one-wave kernel that keeps `stream` busy for about `microseconds` (0..1000): put in front of side-stream work that
+ * becomes runnable at the same moment as a persistent recurrent launch on the main stream and should not take CUs before
+ * that launch's workgroups are resident (a chain that finds some of its CUs taken starts late as a whole). */
+int las_stream_delay(int microseconds, void* stream);
+
+/* Several small fills / copies in ONE launch (the decoder's per-step scratch: zeroed accumulators, the initial state
+ * rows).  The job table travels as a kernel argument: no device-side table, nothing to upload.  Every job is a 2-D window
+ * [rows, cols] of ELEMENTS with row strides ldd / lds (elements):
+ *   LAS_FILL_ZERO32   dst (4-byte elements) = 0;             LAS_FILL_ZERO16   dst (2-byte elements) = 0;
+ *   LAS_FILL_COPY_F32 dst fp32 = src fp32;                   LAS_FILL_CAST_BF16 dst bf16 = round(src fp32).
+ * src == NULL in a copy / cast job writes zeros.  njobs <= LAS_FILL_MAX_JOBS. */
+enum las_fill_kind { LAS_FILL_ZERO32 = 0, LAS_FILL_ZERO16 = 1, LAS_FILL_COPY_F32 = 2, LAS_FILL_CAST_BF16 = 3 };
+enum { LAS_FILL_MAX_JOBS = 12 };
+typedef struct las_fill_job {
+  void* dst;
+  const void* src;
+  int64_t rows, cols, ldd, lds;
+  int32_t kind, reserved;
+} las_fill_job;
+int las_fill_many(const las_fill_job* jobs_host, int njobs, void* stream);
+
 /* out[n] += sum_m X[m, n] for a bf16 [M,N] matrix (bias gradients).  out_perm_h = H > 0: X's columns are
  * gate-interleaved (u*4+g) and the sum of column n lands at TF index g*H+u. */
 int las_colsum_bf16(const las_bf16* X, int64_t ldx, int M, int N, float* out, int out_perm_h, void* stream);
@@ -470,6 +491,17 @@ int las_sumsq(const float* x, int64_t n, float* out, void* stream);
  * *param_sumsq = sum_i params[i]^2 from the same pass (the value las_sumsq(params) would give). */
 int las_grad_l2_norms(float* grads, const float* params, const int64_t* seg_offsets, int nseg,
                       int64_t total, float l2_scale, float* sumsq, float* param_sumsq, void* stream);
+/* The same pass ADDING into sumsq / param_sumsq (nothing is zeroed): after las_train_op_begin, which clears them once per
+ * step, the passes over several gradient buckets (and their param_sumsq slots) need no memsets of their own. */
+int las_grad_l2_norms_acc(float* grads, const float* params, const int64_t* seg_offsets, int nseg,
+                          int64_t total, float l2_scale, float* sumsq, float* param_sumsq, void* stream);
+/* First launch of the train op: las_status_collect (flag nullable: n = 0) and sumsq[0..nseg) = 0, param_sumsq[0..npsq) = 0. */
+int las_train_op_begin(const uint32_t* const* status_words, int n, float* flag, float* sumsq, int nseg,
+                       float* param_sumsq, int npsq, void* stream);
+/* *out = *audio_loss + half_l2_scale * sum(param_sumsq[0..npsq)): the loss train.py logs (audio loss + L2 term,
+ * model_helper.py:411-413) from the sums the norms pass left behind.  audio_loss nullable (0). */
+int las_total_loss(const float* audio_loss, const float* param_sumsq, int npsq, float half_l2_scale, float* out,
+                   void* stream);
 /* grads_s *= clip / max(||grads_s||, clip)  (clip_by_norm, model_helper.py:416). */
 int las_grad_clip(float* grads, const int64_t* seg_offsets, int nseg, int64_t total, const float* sumsq,
                   float clip, void* stream);

@@ -76,6 +76,31 @@ __global__ __launch_bounds__(256) void refresh_images_kernel(const las_image_job
   }
 }
 
+// holds its stream for about `ticks` cycles of the 100 MHz wall clock (las_stream_delay)
+__global__ void delay_kernel(long long ticks) {
+  const long long t0 = wall_clock64();
+  while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(16);
+}
+
+struct FillTable { las_fill_job job[LAS_FILL_MAX_JOBS]; };
+
+// blockIdx.y = job; the table is a kernel argument (see las_fill_many)
+__global__ __launch_bounds__(256) void fill_many_kernel(FillTable t) {
+  const las_fill_job jb = t.job[blockIdx.y];
+  const int64_t total = jb.rows * jb.cols;
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += stride) {
+    const int64_t r = i / jb.cols, c = i - r * jb.cols;
+    if (jb.kind == LAS_FILL_ZERO32) static_cast<uint32_t*>(jb.dst)[r * jb.ldd + c] = 0u;
+    else if (jb.kind == LAS_FILL_ZERO16) static_cast<unsigned short*>(jb.dst)[r * jb.ldd + c] = 0;
+    else {
+      const float v = jb.src ? static_cast<const float*>(jb.src)[r * jb.lds + c] : 0.f;
+      if (jb.kind == LAS_FILL_COPY_F32) static_cast<float*>(jb.dst)[r * jb.ldd + c] = v;
+      else static_cast<unsigned short*>(jb.dst)[r * jb.ldd + c] = las_f2bf(v);
+    }
+  }
+}
+
 __global__ void colsum_kernel(const unsigned short* X, int64_t ldx, int M, int N, float* out, int perm_h) {
   // blockDim = (64 columns, 4 row lanes); grid.x over column groups, grid.y over row chunks
   const int col = blockIdx.x * 64 + threadIdx.x;
@@ -120,6 +145,34 @@ extern "C" int las_refresh_images(const las_image_job* jobs_dev, int njobs, void
   LAS_REQUIRE(jobs_dev != nullptr && njobs > 0 && njobs <= 65535, "las_refresh_images: bad job table (njobs=%d)", njobs);
   hipLaunchKernelGGL(refresh_images_kernel, dim3(96, njobs), dim3(256), 0, (hipStream_t)stream, jobs_dev);
   LAS_LAUNCH_CHECK("refresh images launch");
+  return LAS_OK;
+}
+
+extern "C" int las_stream_delay(int microseconds, void* stream) {
+  LAS_REQUIRE(microseconds >= 0 && microseconds <= 1000, "las_stream_delay: 0..1000 us (got %d)", microseconds);
+  if (microseconds == 0) return LAS_OK;
+  hipLaunchKernelGGL(delay_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (long long)microseconds * 100);
+  LAS_LAUNCH_CHECK("delay launch");
+  return LAS_OK;
+}
+
+extern "C" int las_fill_many(const las_fill_job* jobs_host, int njobs, void* stream) {
+  LAS_REQUIRE(jobs_host != nullptr && njobs > 0 && njobs <= LAS_FILL_MAX_JOBS, "las_fill_many: 1..%d jobs (got %d)", (int)LAS_FILL_MAX_JOBS, njobs);
+  FillTable t;
+  int64_t most = 0;
+  for (int i = 0; i < njobs; ++i) {
+    const las_fill_job& j = jobs_host[i];
+    LAS_REQUIRE(j.dst != nullptr && j.rows >= 0 && j.cols >= 0 && j.kind >= LAS_FILL_ZERO32 && j.kind <= LAS_FILL_CAST_BF16,
+                "las_fill_many: bad job %d", i);
+    t.job[i] = j;
+    if (j.cols == 0) t.job[i].cols = 1, t.job[i].rows = 0;
+    if (j.rows * j.cols > most) most = j.rows * j.cols;
+  }
+  if (most == 0) return LAS_OK;
+  int blocks = (int)((most + 1023) / 1024);          // about four elements per thread
+  if (blocks > 1024) blocks = 1024;
+  hipLaunchKernelGGL(fill_many_kernel, dim3(blocks, njobs), dim3(256), 0, (hipStream_t)stream, t);
+  LAS_LAUNCH_CHECK("fill launch");
   return LAS_OK;
 }
 

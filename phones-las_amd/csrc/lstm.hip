@@ -126,11 +126,12 @@ __global__ __launch_bounds__(256) void lstm_fwd_kernel(float* __restrict__ xproj
   constexpr int KCW = KC / KS;         // k-chunks a wave owns
   constexpr int LS = H + 8;            // LDS row stride (elements)
   constexpr int RL = ROWS / 4;         // utterances per lane (rows lq*4 .. lq*4+RL-1 of the MFMA tile)
-  static_assert(ROWS == 16 || ((ROWS == 8 || ROWS == 4) && KS == 1), "short slices: only without the K split");
+  static_assert(ROWS == 16 || ROWS == 8 || (ROWS == 4 && KS == 1), "4-row slices: only without the K split");
   constexpr int GV = RL >= 2 ? 2 : 1;      // bf16 values per granule: a row pair of one unit, or a single value (4-row slices)
   constexpr int NGRAN = ROWS * HS / GV;    // granules a member publishes per step
-  constexpr int PER = G > 1 ? (G - 1) * NGRAN / 256 : 1;   // granules a thread polls per step
-  static_assert(G == 1 || ((G - 1) * NGRAN) % 256 == 0, "granules must divide over the threads");
+  constexpr int NPOLL = (G - 1) * NGRAN;   // granules a member collects per step
+  constexpr int PER = G > 1 ? (NPOLL + 255) / 256 : 1;     // granules a thread polls per step (512 units, 8 rows: 7.5 ->
+                                                           // 8, the threads past the end poll a granule a second time)
   __shared__ __attribute__((aligned(16))) unsigned short hlds[2][16][LS];
   __shared__ int fail_flag;
   __shared__ int colo_flag;
@@ -264,7 +265,7 @@ __global__ __launch_bounds__(256) void lstm_fwd_kernel(float* __restrict__ xproj
   if constexpr (G > 1) {
 #pragma unroll
     for (int i = 0; i < PER; ++i) {
-      const int q = tid + i * 256;
+      const int q = (tid + i * 256) % NPOLL;
       const int pi = q / NGRAN, gi = q % NGRAN;
       const int peer = pi + (pi >= member ? 1 : 0);
       poll_off[i] = (unsigned)(peer * NGRAN + gi) * 8u;                              // bytes inside the group's parity slot
@@ -336,7 +337,7 @@ __global__ __launch_bounds__(256) void lstm_fwd_kernel(float* __restrict__ xproj
     if constexpr (G > 1) if (s > 0) {
       const char* src = reinterpret_cast<const char*>(ex_group + (int64_t)((s - 1) & 1) * par_stride);
       unsigned short* hl = &hlds[cur][0][0];
-      constexpr int CH = PER > 6 ? 5 : PER;          // per polling round (bounds the registers held)
+      constexpr int CH = PER > 8 ? 5 : PER;          // per polling round (bounds the registers held)
       static_assert(PER % CH == 0, "sweep chunking");
 #pragma unroll
       for (int c0 = 0; c0 < PER; c0 += CH) {
@@ -502,8 +503,9 @@ __global__ __launch_bounds__(256) void lstm_bwd_kernel(const float* __restrict__
   constexpr bool SPLIT = NUB < 4;                 // H = 512: two waves share a unit block, two rows of every quad each
   static_assert(!SPLIT || NUB == 2, "row split is written for two unit blocks per member");
   constexpr int UBW = SPLIT ? 1 : NUB / 4;        // unit blocks a wave owns
-  static_assert(ROWS == 16 || ((ROWS == 8 || ROWS == 4) && !SPLIT), "short slices: only without the row split");
-  constexpr int RPL = SPLIT ? 2 : ROWS / 4;       // rows of its quad a lane owns (8-row slices: rows 0,1 of every quad)
+  static_assert(ROWS == 16 || ROWS == 8 || (ROWS == 4 && !SPLIT), "4-row slices: only without the row split");
+  constexpr int RPL = SPLIT ? ROWS / 8 : ROWS / 4;   // rows of its quad a lane owns (8-row slices: rows 0,1 of every quad; SPLIT:
+                                                     // the two waves of a unit block take half of them each)
   constexpr int KCW = HS / 8;                     // k-chunks of the member's 4*HS gate columns
   constexpr int NT = SPLIT ? G / 2 : G * UBW;     // 16-unit output tiles a wave computes
   constexpr int OWN = SPLIT ? 0 : UBW;            // ... of which stay in registers (own units)
@@ -541,7 +543,7 @@ __global__ __launch_bounds__(256) void lstm_bwd_kernel(const float* __restrict__
   int smax = 0, smin = 0x7fffffff;
 #pragma unroll
   for (int r = 0; r < RPL; ++r) {
-    bidx[r] = ROWS == 16 ? slice * 16 + lq * 4 + hh * 2 + r : slice * ROWS + lq * RPL + r;
+    bidx[r] = slice * ROWS + lq * (ROWS / 4) + hh * RPL + r;
     len[r] = (bidx[r] < B) ? min(length[bidx[r]], T) : 0;
   }
   {
@@ -648,7 +650,7 @@ __global__ __launch_bounds__(256) void lstm_bwd_kernel(const float* __restrict__
 #pragma unroll
     for (int e = 0; e < PER; ++e) {
       int sender, ub, r;
-      if constexpr (SPLIT) { sender = e / RPL; ub = 0; r = hh * 2 + e % RPL; }
+      if constexpr (SPLIT) { sender = e / RPL; ub = 0; r = hh * RPL + e % RPL; }
       else { sender = (member + 1 + e / (UBW * RPL)) % G; ub = (e / RPL) % UBW; r = e % RPL; }
       poll_off[e] = (unsigned)((((member * G + sender) * NUB + blk + ub) * 4 + r) * 64 + lane) * 8u;
     }
@@ -826,7 +828,7 @@ __global__ __launch_bounds__(256) void lstm_bwd_kernel(const float* __restrict__
             *reinterpret_cast<uint2*>(dz + ((int64_t)bidx[r] * T + pos) * grow + dir * 4 * H + unit * 4) = zv;
           }
         }
-        *reinterpret_cast<uint2*>(zl + (lq * 4 + hh * 2 + r) * ZS + (unit - member * HS) * 4) = zv;   // [row][u*4+g]
+        *reinterpret_cast<uint2*>(zl + (lq * 4 + hh * RPL + r) * ZS + (unit - member * HS) * 4) = zv;   // [row][u*4+g]
       }
     }
     lds_barrier();
@@ -849,7 +851,7 @@ __global__ __launch_bounds__(256) void lstm_bwd_kernel(const float* __restrict__
 #pragma unroll
         for (int kc = 0; kc < KCW; ++kc) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afr[kc], wf[j][kc], acc[j], 0, 0, 0);
 #pragma unroll
-        for (int r = 0; r < (SPLIT ? 4 : RPL); ++r)       // 8-row slices: rows 2, 3 of every quad carry nothing
+        for (int r = 0; r < (SPLIT ? ROWS / 4 : RPL); ++r)       // 8-row slices: rows 2, 3 of every quad carry nothing
           granule_store(reinterpret_cast<u64*>(dst + send_off[j - OWN] + r * 512), epoch + 1, __float_as_uint(acc[j][r]), local);
       }
     }
@@ -891,7 +893,16 @@ CoopGeom geom(int B, int H, int ndir, bool bwd, int rows = 16) {
 int slice_rows(int B, int H, int ndir, bool bwd) {
   const char* e = getenv("LAS_LSTM_ROWS");          // read at every launch: the tests switch it
   const int forced = e ? atoi(e) : 0;
-  if (H > 256) return 16;               // the 512-unit kernels (K split, row split) assume full tiles
+  if (H > 256) {                        // the 512-unit kernels (K split, row split): 16 or 8 rows
+    static int r512 = -1;               // LAS_LSTM_ROWS512=16 / 8: the default for both directions (diagnostics)
+    if (r512 < 0) {
+      const char* e5 = getenv("LAS_LSTM_ROWS512");
+      r512 = e5 ? atoi(e5) : 0;
+    }
+    if (forced == 16 || forced == 8) return forced;
+    if (r512 == 16 || r512 == 8) return r512;
+    return 16;
+  }
   if (forced == 16 || forced == 8 || forced == 4) return forced;
   // every chain workgroup and every companion should find a CU of its own (256 on MI355X; fewer in a partitioned
   // mode); the backward leaves three eighths of them to the weight-gradient products that run beside it
@@ -928,13 +939,13 @@ int launch_fwd(float* xproj, const las_bf16* wp, const int32_t* length, las_bf16
   unsigned* status = reinterpret_cast<unsigned*>(ws);
   u64* exch = reinterpret_cast<u64*>(reinterpret_cast<char*>(ws) + 64);
   const int pf = g.G > 1 ? prefetch_mode() : 0;
+  if (rows == 8) {
+    hipLaunchKernelGGL((lstm_fwd_kernel<H, 8>), dim3(pf ? g.blocks + g.companions : g.blocks), dim3(256), 0, st, xproj, wp, length, y,
+                       cbuf, c_last, h_last, exch, status, B, T, ndir, g.ngroups, pf);
+    LAS_LAUNCH_CHECK("lstm fwd launch");
+    return LAS_OK;
+  }
   if constexpr (H <= 256) {
-    if (rows == 8) {
-      hipLaunchKernelGGL((lstm_fwd_kernel<H, 8>), dim3(pf ? g.blocks + g.companions : g.blocks), dim3(256), 0, st, xproj, wp, length, y,
-                         cbuf, c_last, h_last, exch, status, B, T, ndir, g.ngroups, pf);
-      LAS_LAUNCH_CHECK("lstm fwd launch");
-      return LAS_OK;
-    }
     if (rows == 4) {
       hipLaunchKernelGGL((lstm_fwd_kernel<H, 4>), dim3(pf ? g.blocks + g.companions : g.blocks), dim3(256), 0, st, xproj, wp, length, y,
                          cbuf, c_last, h_last, exch, status, B, T, ndir, g.ngroups, pf);
@@ -970,19 +981,18 @@ int launch_bwd(const float* gates, const float* cbuf, const float* dy, const flo
     if (hog_kb > 160 - static_kb - 2) hog_kb = 160 - static_kb - 2;
     if (hog_kb > 0) {
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&lstm_bwd_kernel<H, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, hog_kb * 1024);
-      if constexpr (H <= 256)
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&lstm_bwd_kernel<H, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, hog_kb * 1024);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&lstm_bwd_kernel<H, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, hog_kb * 1024);
       if constexpr (H <= 256)
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&lstm_bwd_kernel<H, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, hog_kb * 1024);
     }
   }
+  if (rows == 8) {
+    hipLaunchKernelGGL((lstm_bwd_kernel<H, 8>), dim3(pf ? g.blocks + g.companions : g.blocks), dim3(256), (size_t)hog_kb * 1024, st, gates, cbuf, dy,
+                       dc_last, dh_last, kh, length, dz, exch, status, B, T, ndir, g.ngroups);
+    LAS_LAUNCH_CHECK("lstm bwd launch");
+    return LAS_OK;
+  }
   if constexpr (H <= 256) {
-    if (rows == 8) {
-      hipLaunchKernelGGL((lstm_bwd_kernel<H, 8>), dim3(pf ? g.blocks + g.companions : g.blocks), dim3(256), (size_t)hog_kb * 1024, st, gates, cbuf, dy,
-                         dc_last, dh_last, kh, length, dz, exch, status, B, T, ndir, g.ngroups);
-      LAS_LAUNCH_CHECK("lstm bwd launch");
-      return LAS_OK;
-    }
     if (rows == 4) {
       hipLaunchKernelGGL((lstm_bwd_kernel<H, 4>), dim3(pf ? g.blocks + g.companions : g.blocks), dim3(256), (size_t)hog_kb * 1024, st, gates, cbuf, dy,
                          dc_last, dh_last, kh, length, dz, exch, status, B, T, ndir, g.ngroups);

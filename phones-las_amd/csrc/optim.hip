@@ -185,7 +185,43 @@ __global__ void status_collect_kernel(const unsigned* const* words, int n, float
   if (threadIdx.x == 0) *flag = any ? 1.f : 0.f;
 }
 
+// status_collect_kernel + the zeroing of the norm accumulators the gradient passes of this step add into
+__global__ void train_op_begin_kernel(const unsigned* const* words, int n, float* flag, float* sumsq, int nseg, float* psq, int npsq) {
+  for (int i = threadIdx.x; i < nseg; i += 64) sumsq[i] = 0.f;
+  for (int i = threadIdx.x; i < npsq; i += 64) psq[i] = 0.f;
+  unsigned any = 0;
+  for (int i = threadIdx.x; i < n; i += 64) any |= __hip_atomic_load(words[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) any |= __shfl_xor(any, o, 64);
+  if (threadIdx.x == 0 && flag) *flag = any ? 1.f : 0.f;
+}
+
+// out = audio + half_l2 * sum(psq[0..npsq))
+__global__ void total_loss_kernel(const float* audio, const float* psq, int npsq, float half_l2, float* out) {
+  if (threadIdx.x == 0) {
+    float s = 0.f;
+    for (int i = 0; i < npsq; ++i) s += psq[i];
+    *out = (audio ? *audio : 0.f) + half_l2 * s;
+  }
+}
+
 }  // namespace
+
+extern "C" int las_train_op_begin(const uint32_t* const* status_words, int n, float* flag, float* sumsq, int nseg,
+                                  float* param_sumsq, int npsq, void* stream) {
+  LAS_REQUIRE(n >= 0 && nseg >= 0 && npsq >= 0 && (n == 0 || status_words != nullptr) && (nseg == 0 || sumsq != nullptr) &&
+              (npsq == 0 || param_sumsq != nullptr), "las_train_op_begin: bad arguments");
+  hipLaunchKernelGGL(train_op_begin_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, status_words, n, flag, sumsq, nseg, param_sumsq, npsq);
+  LAS_LAUNCH_CHECK("train op begin launch");
+  return LAS_OK;
+}
+
+extern "C" int las_total_loss(const float* audio_loss, const float* param_sumsq, int npsq, float half_l2_scale, float* out, void* stream) {
+  LAS_REQUIRE(out != nullptr && npsq >= 0 && (npsq == 0 || param_sumsq != nullptr), "las_total_loss: bad arguments");
+  hipLaunchKernelGGL(total_loss_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, audio_loss, param_sumsq, npsq, half_l2_scale, out);
+  LAS_LAUNCH_CHECK("total loss launch");
+  return LAS_OK;
+}
 
 extern "C" int las_status_collect(const uint32_t* const* status_words, int n, float* flag, void* stream) {
   LAS_REQUIRE(n >= 0 && flag != nullptr && (n == 0 || status_words != nullptr), "las_status_collect: bad arguments");
@@ -209,21 +245,33 @@ extern "C" int las_sumsq(const float* x, int64_t n, float* out, void* stream) {
   return LAS_OK;
 }
 
-extern "C" int las_grad_l2_norms(float* grads, const float* params, const int64_t* seg_offsets, int nseg, int64_t total,
-                                 float l2_scale, float* sumsq, float* param_sumsq, void* stream) {
+static int grad_l2_norms(float* grads, const float* params, const int64_t* seg_offsets, int nseg, int64_t total,
+                         float l2_scale, float* sumsq, float* param_sumsq, bool zero_first, void* stream) {
   LAS_REQUIRE(nseg > 0 && total > 0, "las_grad_l2_norms: empty");
   LAS_REQUIRE(((uintptr_t)grads % 16 == 0) && ((uintptr_t)params % 16 == 0), "las_grad_l2_norms: buffers must be 16-byte aligned");
   hipStream_t st = (hipStream_t)stream;
-  int rc = las_check_hip(hipMemsetAsync(sumsq, 0, sizeof(float) * nseg, st), "memset sumsq");
-  if (rc) return rc;
-  if (param_sumsq) {
-    rc = las_check_hip(hipMemsetAsync(param_sumsq, 0, sizeof(float), st), "memset param_sumsq");
+  if (zero_first) {
+    int rc = las_check_hip(hipMemsetAsync(sumsq, 0, sizeof(float) * nseg, st), "memset sumsq");
     if (rc) return rc;
+    if (param_sumsq) {
+      rc = las_check_hip(hipMemsetAsync(param_sumsq, 0, sizeof(float), st), "memset param_sumsq");
+      if (rc) return rc;
+    }
   }
   hipLaunchKernelGGL(l2_norm_kernel, dim3((unsigned)((total + SPAN - 1) / SPAN)), dim3(256), 0, st, grads, params, seg_offsets, nseg,
                      total, l2_scale, sumsq, param_sumsq);
   LAS_LAUNCH_CHECK("l2 norm launch");
   return LAS_OK;
+}
+
+extern "C" int las_grad_l2_norms(float* grads, const float* params, const int64_t* seg_offsets, int nseg, int64_t total,
+                                 float l2_scale, float* sumsq, float* param_sumsq, void* stream) {
+  return grad_l2_norms(grads, params, seg_offsets, nseg, total, l2_scale, sumsq, param_sumsq, true, stream);
+}
+
+extern "C" int las_grad_l2_norms_acc(float* grads, const float* params, const int64_t* seg_offsets, int nseg, int64_t total,
+                                     float l2_scale, float* sumsq, float* param_sumsq, void* stream) {
+  return grad_l2_norms(grads, params, seg_offsets, nseg, total, l2_scale, sumsq, param_sumsq, false, stream);
 }
 
 extern "C" int las_grad_clip(float* grads, const int64_t* seg_offsets, int nseg, int64_t total, const float* sumsq,

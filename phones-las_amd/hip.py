@@ -24,6 +24,8 @@ _SIGS = {
     'las_gemm_tn': ([_vp, _i64, _vp, _i64, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i64, _i64, _i64, _i32, _vp], C.c_int),
     'las_cast_bf16': ([_vp, _i64, _i32, _i32, _vp, _i64, _i32, _i32, _i32, _i32, _i64, _i64, _i32, _vp], C.c_int),
     'las_refresh_images': ([_vp, C.c_int, _vp], C.c_int),
+    'las_fill_many': ([_vp, C.c_int, _vp], C.c_int),
+    'las_stream_delay': ([C.c_int, _vp], C.c_int),
     'las_colsum_bf16': ([_vp, _i64, _i32, _i32, _vp, _i32, _vp], C.c_int),
     'las_lstm_pack_recurrent': ([_vp, _i32, _vp, _vp], C.c_int),
     'las_lstm_recurrent_fwd': ([_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp], C.c_int),
@@ -41,6 +43,9 @@ _SIGS = {
     'las_grad_clip': ([_vp, _vp, _i32, _i64, _vp, _f32, _vp], C.c_int),
     'las_adam_update': ([_vp, _vp, _vp, _vp, _i64, _f32, _f32, _f32, _f32, _i32, _vp, _vp, _vp], C.c_int),
     'las_status_collect': ([_vp, _i32, _vp, _vp], C.c_int),
+    'las_grad_l2_norms_acc': ([_vp, _vp, _vp, _i32, _i64, _f32, _vp, _vp, _vp], C.c_int),
+    'las_train_op_begin': ([_vp, _i32, _vp, _vp, _i32, _vp, _i32, _vp], C.c_int),
+    'las_total_loss': ([_vp, _vp, _i32, _f32, _vp, _vp], C.c_int),
     'las_counter_add': ([_vp, _i32, _vp], C.c_int),
     'las_sumsq': ([_vp, _i64, _vp, _vp], C.c_int),
     'las_crc32c': ([C.c_char_p, C.c_size_t], C.c_uint32),
@@ -267,6 +272,62 @@ class ImageJob(C.Structure):
     _fields_ = [('src', C.c_void_p), ('dst', C.c_void_p), ('lds', C.c_int64), ('ldd', C.c_int64),
                 ('rows', C.c_int32), ('cols', C.c_int32), ('dst_rows', C.c_int32), ('dst_cols', C.c_int32),
                 ('transpose', C.c_int32), ('perm_h', C.c_int32), ('kind', C.c_int32), ('reserved', C.c_int32)]
+
+
+class FillJob(C.Structure):
+    """las_fill_job of include/las_hip.h."""
+    _fields_ = [('dst', C.c_void_p), ('src', C.c_void_p), ('rows', C.c_int64), ('cols', C.c_int64), ('ldd', C.c_int64),
+                ('lds', C.c_int64), ('kind', C.c_int32), ('reserved', C.c_int32)]
+
+
+FILL_MAX_JOBS = 12
+
+
+def _window(t):
+    """(rows, cols, row stride in elements) of a 1-D / 2-D tensor view with unit inner stride (or any contiguous tensor)."""
+    if t.is_contiguous():
+        return 1, t.numel(), t.numel()
+    if t.dim() == 2 and t.stride(1) == 1:
+        return t.shape[0], t.shape[1], t.stride(0)
+    raise LasError('fill_many: expected a contiguous tensor or a 2-D view with unit inner stride, got shape %s stride %s'
+                   % (tuple(t.shape), tuple(t.stride())))
+
+
+def fill_many(zero=(), copy=()):
+    """One launch (las_fill_many) instead of a torch kernel per tensor: `zero` -- tensors / 2-D views (2- or 4-byte
+    elements) to clear; `copy` -- (dst, src) pairs, src fp32 (or None = zeros), dst fp32 or bf16, same shape."""
+    jobs = []
+    for t in zero:
+        if t.numel() == 0:
+            continue
+        if not t.is_cuda or t.element_size() not in (2, 4):
+            raise LasError('fill_many: CUDA tensors of 2- or 4-byte elements only')
+        r, c, ld = _window(t)
+        jobs.append(FillJob(t.data_ptr(), None, r, c, ld, 0, 0 if t.element_size() == 4 else 1, 0))
+    for dst, src in copy:
+        if dst.numel() == 0:
+            continue
+        if src is not None and (src.dtype != torch.float32 or tuple(src.shape) != tuple(dst.shape)):
+            raise LasError('fill_many: copy sources are fp32 tensors of the destination\'s shape')
+        if dst.dtype not in (torch.float32, torch.bfloat16):
+            raise LasError('fill_many: copy destinations are fp32 or bf16')
+        r, c, ld = _window(dst)
+        lds = 0
+        if src is not None:
+            rs, cs, lds = _window(src)
+            if (rs, cs) != (r, c):
+                if src.is_contiguous() and r * c == rs * cs:      # a contiguous source read through the destination's window
+                    lds = c
+                elif dst.is_contiguous() and r * c == rs * cs:    # a contiguous destination written through the source's
+                    r, c, ld = rs, cs, cs
+                else:
+                    raise LasError('fill_many: source and destination windows differ')
+        jobs.append(FillJob(dst.data_ptr(), src.data_ptr() if src is not None else None, r, c, ld, lds,
+                            2 if dst.dtype == torch.float32 else 3, 0))
+    for i in range(0, len(jobs), FILL_MAX_JOBS):
+        part = jobs[i:i + FILL_MAX_JOBS]
+        arr = (FillJob * len(part))(*part)
+        check(lib().las_fill_many(arr, len(part), stream()))
 
 
 IMAGE_CAST, IMAGE_PACK_RECURRENT, IMAGE_BIAS_INTERLEAVE, IMAGE_COPY_F32 = 0, 1, 2, 3

@@ -50,10 +50,12 @@ class Listener:
         self.time_multiple = 2 ** max(0, hparams.num_layers - 1) if hparams.use_pyramidal else 1
         self.tape = None
 
-    def refresh(self, variables):
-        with hip.image_batch():                 # every image of every layer in one launch
-            for w in self.layers:
-                w.refresh(variables)
+    def refresh(self, variables, layers=None):
+        """layers: which layers' images (default: all)."""
+        with hip.image_batch():                 # every image of these layers in one launch
+            for l, w in enumerate(self.layers):
+                if layers is None or l in layers:
+                    w.refresh(variables)
 
     def pad_features(self, x):
         """fp32 [B,T,F] -> bf16 [B,Tp,Fp], zero padded (Tp multiple of 2^(L-1), Fp multiple of 8)."""
@@ -65,16 +67,19 @@ class Listener:
         hip.cast_bf16(x, T, F, out, Tp, self.Fp, ldd=self.Fp, lds=F, batch=B, sbs=T * F, dbs=Tp * self.Fp)
         return out
 
-    def forward(self, encoder_inputs, source_sequence_length, mode, seed=0):
+    def forward(self, encoder_inputs, source_sequence_length, mode, seed=0, after_first_layer=None):
+        """after_first_layer: (f, g) -- f() is called between layer 0's input projection and its recurrence, g() once layer 0
+        is enqueued (LasModel.refresh_images: f starts the rebuild of the upper layers' weight images on the second stream,
+        beside layer 0's recurrence; g makes this stream wait for them)."""
         x = encoder_inputs
         if x.dtype != torch.bfloat16:
             x = self.pad_features(x.contiguous())
         self.tape = [] if mode == TRAIN else None
         if not self.hp.use_pyramidal:
             return ops.stacked_bilstm(x, source_sequence_length, mode, self.hp, weights=self.layers, tape=self.tape,
-                                      in_features=self.F, seed=seed)
+                                      in_features=self.F, seed=seed, after_first_layer=after_first_layer)
         return ops.pyramidal_bilstm(x, source_sequence_length, mode, self.hp, weights=self.layers,
-                                    tape=self.tape, in_features=self.F, seed=seed)
+                                    tape=self.tape, in_features=self.F, seed=seed, after_first_layer=after_first_layer)
 
     def backward(self, d_outputs, d_state, grads, overlap=None):
         """d_outputs: fp32 gradient w.r.t. the encoder outputs [B,T',M]; d_state: (dc, dh) [nd,B,H] or None."""
@@ -104,7 +109,7 @@ class Listener:
             dy = st['dy'].contiguous().view(r['B'], r['T'], r['nd'] * r['H'])
             defer = defer_last and (i == n - 1) and l > 0
             res = ops.bilstm_backward(r, dy, st['d_state'] if l == len(recs) - 1 else None, grads, need_dx=(l > 0),
-                                      overlap=overlap, defer_weight_grads=defer)
+                                      overlap=overlap, defer_weight_grads=defer, exposed=(l == 0 and overlap is not None and os.environ.get('LAS_TN_EXPOSED', '1') != '0'))
             if defer:
                 st['dy'], st['deferred'] = res
             else:
@@ -216,7 +221,7 @@ class Speller:
             self.att_v = var[self.V_ATT]
 
     # ---------------------------------------------------------------------------------------------
-    def _initial_state(self, encoder_state, B):
+    def _initial_state(self, encoder_state, B, want_zeros=True):
         d = self.hp
         dev = 'cuda'
         if d.pass_hidden_state and d.bottom_only:                         # las/model.py:259-268
@@ -228,6 +233,8 @@ class Speller:
             if c0.shape[-1] != self.Hd:
                 raise ValueError('pass_hidden_state needs decoder_units == encoder_units')
             return c0, h0, True
+        if not want_zeros:
+            return None, None, False
         z = torch.zeros(B, self.Hd, dtype=torch.float32, device=dev)
         return z, z, False
 
@@ -273,19 +280,19 @@ class Speller:
         Hd, V, Vp, U = self.Hd, self.V, self.Vp, num_steps
         dev, bf, f32 = memory.device, torch.bfloat16, torch.float32
         lib, st = hip.lib(), hip.stream()
-        c0, h0, passed = self._initial_state(encoder_state, B)
+        c0, h0, passed = self._initial_state(encoder_state, B, want_zeros=False)
         keys = self._keys(memory, B, Tm)
         W = M + Hd
         AH = torch.empty(B, U, W, dtype=bf, device=dev)
-        AH[:, 0, :M].zero_()
-        AH[:, 0, M:].copy_(h0)
         cs = torch.empty(B, U + 1, Hd, dtype=f32, device=dev)
-        cs[:, 0].copy_(c0)
         gates = torch.empty(B, U, 4 * Hd, dtype=f32, device=dev)
         h_all = torch.empty(B, U, Hd, dtype=bf, device=dev)
         Tmp = _r8(Tm)                      # row stride of per-step [T'] vectors (GEMM operand alignment)
-        align = torch.zeros(B, U, Tmp, dtype=f32, device=dev)
-        align_bf = torch.zeros(B, U, Tmp, dtype=bf, device=dev)
+        align = torch.empty(B, U, Tmp, dtype=f32, device=dev)
+        align_bf = torch.empty(B, U, Tmp, dtype=bf, device=dev)
+        # one launch: the first operand row [attention_{-1} = 0 | h_0], c_0, and the alignment buffers' zero padding
+        hip.fill_many(zero=[AH[:, 0, :M], align, align_bf],
+                      copy=[(AH[:, 0, M:], h0.float() if passed else None), (cs[:, 0], c0.float() if passed else None)])
         ctx_all = torch.empty(B, U, M, dtype=bf, device=dev)
         pq_all = torch.empty(B, U, Hd, dtype=f32, device=dev) if self.att == hip.ATT_BAHDANAU else None
         z = torch.empty(B, 4 * Hd, dtype=f32, device=dev)
@@ -374,10 +381,11 @@ class Speller:
         BU = B * U
         dattn_proj = torch.empty(B, U, M, dtype=f32, device=dev)
         hip.gemm_nt(dlogits, self.wproj, dattn_proj, BU, M, Vp, lda=Vp, ldb=Vp, ldc=M)
-        dc = torch.zeros(B, Hd, dtype=f32, device=dev)
+        dc = torch.empty(B, Hd, dtype=f32, device=dev)
         dfeed = torch.empty(B, W, dtype=f32, device=dev)
         dz_all = torch.empty(B, U, 4 * Hd, dtype=bf, device=dev)
-        ds_all = torch.zeros(B, U, Tmp, dtype=bf, device=dev)
+        ds_all = torch.empty(B, U, Tmp, dtype=bf, device=dev)
+        hip.fill_many(zero=[dc, ds_all])
         dctx_all = torch.empty(B, U, M, dtype=bf, device=dev)
         bah = self.att == hip.ATT_BAHDANAU
         if bah:
@@ -468,7 +476,7 @@ class Speller:
         keep = [sv['AH'], dz_all, onehot, sv['ctx_all'], dlogits, sv['memory'], dkeys_bf, sv['h_all']]
         if bah:
             keep.append(dpq_all)
-        with (overlap or ops._NoOverlap()).fork(*keep):
+        with (overlap or ops._NoOverlap()).fork(*keep, beside_chain=True):     # (beside the top listener layer's recurrence)
             gk = grads[self.K_CELL]
             hip.gemm_tn(sv['AH'], dz_all, gk[V:], W, 4 * Hd, BU, lda=W, ldb=4 * Hd, ldc=4 * Hd, split_k=4)
             hip.gemm_tn(onehot, dz_all, gk, V, 4 * Hd, BU, lda=Vp, ldb=4 * Hd, ldc=4 * Hd, split_k=4)

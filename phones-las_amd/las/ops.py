@@ -10,6 +10,7 @@ stack follows; outputs [B,T,ndir*H] bf16 with fw in [0,H) and bw in [H,2H) — t
 las/ops.py:81 is free.  pyramidal_stack (las/ops.py:49-65) is then a zero-copy view.
 """
 import collections
+import os
 
 import torch
 
@@ -73,12 +74,27 @@ class Overlap:
 
     def __init__(self):
         self.side = torch.cuda.Stream()
+        self.side2 = None           # a third stream, created on first use (fork(..., lane=1))
         self.keep = []
 
-    def fork(self, *tensors):
-        self.side.wait_stream(torch.cuda.current_stream())
+    # how long side work that is going to run BESIDE a recurrent launch is held back (see fork)
+    BESIDE_US = int(os.environ.get('LAS_SIDE_DELAY_US', '12'))
+
+    def fork(self, *tensors, lane=0, beside_chain=False):
+        """lane 1: another side stream, for two pieces of side work that should run at the same time (the two directions'
+        weight-gradient products of the bottom listener layer, which nothing hides).
+        beside_chain: the next launch on the main stream is a persistent recurrent kernel and this side work becomes
+        runnable at the same moment: it is held back a few microseconds (las_stream_delay) so that the chain's workgroups
+        are resident first -- a chain that finds CUs taken by a GEMM workgroup starts late as a whole (measured: 1.03-1.07
+        instead of 0.96-1.00 ms for an 800-step backward launch when the product beside it was dispatched first)."""
+        if lane and self.side2 is None:
+            self.side2 = torch.cuda.Stream()
+        side = self.side2 if lane else self.side
+        side.wait_stream(torch.cuda.current_stream())
         self.keep.extend(tensors)
-        return torch.cuda.stream(self.side)
+        if beside_chain and self.BESIDE_US > 0:
+            hip.check(hip.lib().las_stream_delay(self.BESIDE_US, side.cuda_stream))
+        return torch.cuda.stream(side)
 
     def mark(self):
         """An event after everything forked so far (the main stream can wait for exactly that much of the side stream)."""
@@ -88,13 +104,15 @@ class Overlap:
 
     def join(self):
         torch.cuda.current_stream().wait_stream(self.side)
+        if self.side2 is not None:
+            torch.cuda.current_stream().wait_stream(self.side2)
         self.keep.clear()
 
 
 class _NoOverlap:
     """Same interface, everything on the current stream."""
 
-    def fork(self, *tensors):
+    def fork(self, *tensors, lane=0, beside_chain=False):
         import contextlib
         return contextlib.nullcontext()
 
@@ -141,7 +159,7 @@ class LayerWeights:
 
 
 def bilstm(inputs, sequence_length, num_units, dropout, mode, unidirectional=False, *, variables=None,
-           scope='', weights=None, tape=None, in_features=None, rng=None, split_inputs=False):
+           scope='', weights=None, tape=None, in_features=None, rng=None, split_inputs=False, after_projection=None):
     """las/ops.py:23-46.  inputs [B,T,Dp] bf16; sequence_length int32 [B] (CUDA).
     Returns (outputs, state) with the reference's structure: bidirectional -> ((fw, bw), (state_fw,
     state_bw)); unidirectional -> (fw, state).  fw/bw are views of one [B,T,ndir*H] buffer
@@ -183,6 +201,8 @@ def bilstm(inputs, sequence_length, num_units, dropout, mode, unidirectional=Fal
     else:
         hip.gemm_nt(inputs, weights.kxT, xproj, B * T, nd * 4 * H, Dp, lda=Dp, ldb=Dp, ldc=nd * 4 * H,
                     bias=weights.bias)
+    if after_projection is not None:
+        after_projection()          # (LasModel: side-stream work that should run beside this layer's recurrence starts here)
     y = torch.empty(B, T, nd * H, dtype=torch.bfloat16, device=dev)
     cbuf = torch.empty(B, T, nd * H, dtype=torch.float32, device=dev)
     c_last = torch.empty(nd, B, H, dtype=torch.float32, device=dev)
@@ -213,11 +233,13 @@ def concat_outputs(outputs):
     return outputs
 
 
-def bilstm_backward(rec, dy, d_state, grads, need_dx=True, overlap=None, defer_weight_grads=False):
+def bilstm_backward(rec, dy, d_state, grads, need_dx=True, overlap=None, defer_weight_grads=False, exposed=False):
     """Reverse-mode AD of one bilstm() call.  dy [B,T,nd*H] fp32 (gradient of the concatenated outputs),
     d_state: None or (dc_last, dh_last) each [nd,B,H] fp32.  Accumulates into ``grads`` (name -> fp32
     tensor, same shapes as the variables) and returns dX [B,T,D'] fp32 (or None).  defer_weight_grads: returns
-    (dX, launch) instead and leaves the weight-gradient products to launch() (the caller forks them later)."""
+    (dX, launch) instead and leaves the weight-gradient products to launch() (the caller forks them later).
+    exposed: no recurrence follows that would hide the weight-gradient products (the bottom layer): the two directions'
+    products then run on two streams at once instead of one after the other."""
     B, T, H, D, Dp, nd = rec['B'], rec['T'], rec['H'], rec['D'], rec['Dp'], rec['nd']
     w = rec['weights']
     dev = dy.device
@@ -268,8 +290,8 @@ def bilstm_backward(rec, dy, d_state, grads, need_dx=True, overlap=None, defer_w
     keepalive = [dz, x, y] + [a for a, _ in (dropped or [])]
 
     def weight_grads():
-        with (overlap or _NoOverlap()).fork(*keepalive):
-            for i, (kn, bn) in enumerate(w.names):
+        for i, (kn, bn) in enumerate(w.names):
+            with (overlap or _NoOverlap()).fork(*keepalive, lane=(i % 2 if exposed else 0), beside_chain=(i == 0 and not exposed)):
                 gk, gb = grads[kn], grads[bn]
                 dzi = dz.view(BT, nd * 4 * H)[:, i * 4 * H:]
                 xa, lda = (dropped[i] if dropped is not None else (x, Dp))
@@ -277,10 +299,12 @@ def bilstm_backward(rec, dy, d_state, grads, need_dx=True, overlap=None, defer_w
                 if D % 8 == 0:
                     # dK_x, dK_h and db of this direction in one product (dz read once); the K slices meet in a workspace
                     # owned by this layer (its products run one after the other on one stream)
+                    # (one workspace per stream the products may run on)
                     need = hip.lib().las_gemm_tn_lstm_workspace_bytes(D, H, split)
-                    ws = getattr(w, '_tn_ws', None)
+                    wss = w.__dict__.setdefault('_tn_ws', {})
+                    ws = wss.get(i % 2 if exposed else 0)
                     if ws is None or ws.numel() * 4 < need:
-                        ws = w._tn_ws = torch.empty(max(1, need // 4), dtype=torch.float32, device=dev)
+                        ws = wss[i % 2 if exposed else 0] = torch.empty(max(1, need // 4), dtype=torch.float32, device=dev)
                     tok = hip.prof_begin('gemm_tn_lstm', 2.0 * (D + H + 1) * 4 * H * BT)
                     hip.check(hip.lib().las_gemm_tn_lstm(hip.p(xa) if D > 0 else None, lda, D, hip.p(yi), nd * H, H,
                                                          (-1 if i == 0 else 1), T, hip.p(dzi), nd * 4 * H, hip.p(gk), hip.p(gb),
@@ -299,7 +323,8 @@ def bilstm_backward(rec, dy, d_state, grads, need_dx=True, overlap=None, defer_w
     return dx
 
 
-def stacked_bilstm(inputs, sequence_length, mode, hparams, *, weights, tape=None, in_features=None, seed=0):
+def stacked_bilstm(inputs, sequence_length, mode, hparams, *, weights, tape=None, in_features=None, seed=0,
+                   after_first_layer=None):
     """The non-pyramidal listener of las/model.py:111-142: one MultiRNNCell stack per direction (layer l of a
     direction reads that direction's layer l-1 outputs only), outputs = concat(fw_top, bw_top), no time reduction.
     Returns ((outputs, lengths), state) with state = (fw_layer_states, bw_layer_states) (or one tuple when
@@ -307,11 +332,14 @@ def stacked_bilstm(inputs, sequence_length, mode, hparams, *, weights, tape=None
     outputs = inputs
     per_layer = []
     for layer in range(hparams.num_layers):
+        hooks = after_first_layer if (layer == 0 and after_first_layer is not None) else (None, None)
         out, st = bilstm(outputs, sequence_length, hparams.num_units, hparams.dropout, mode, hparams.unidirectional,
                          weights=weights[layer], tape=tape, in_features=in_features if layer == 0 else None,
-                         rng=(seed, 16 + 2 * layer), split_inputs=(layer > 0))
+                         rng=(seed, 16 + 2 * layer), split_inputs=(layer > 0), after_projection=hooks[0])
         outputs = concat_outputs(out)
         per_layer.append(st)
+        if hooks[1] is not None:
+            hooks[1]()
     if hparams.unidirectional:
         return (outputs, sequence_length), tuple(per_layer)
     return (outputs, sequence_length), (tuple(s[0] for s in per_layer), tuple(s[1] for s in per_layer))
@@ -328,18 +356,21 @@ def pyramidal_stack(outputs, sequence_length):
 
 
 def pyramidal_bilstm(inputs, sequence_length, mode, hparams, *, variables=None, weights=None, tape=None,
-                     in_features=None, seed=0):
+                     in_features=None, seed=0, after_first_layer=None):
     """las/ops.py:68-87.  ``weights``: optional list of LayerWeights per layer (cached images)."""
     outputs = inputs
     state = None
     D = in_features
     for layer in range(hparams.num_layers):
         w = weights[layer] if weights is not None else None
+        hooks = after_first_layer if (layer == 0 and after_first_layer is not None) else (None, None)
         out, state = bilstm(outputs, sequence_length, hparams.num_units, hparams.dropout, mode,
                             hparams.unidirectional, variables=variables,
                             scope='listener/bilstm_{}'.format(layer), weights=w, tape=tape, in_features=D,
-                            rng=(seed, 16 + 2 * layer))
+                            rng=(seed, 16 + 2 * layer), after_projection=hooks[0])
         outputs = concat_outputs(out)
+        if hooks[1] is not None:
+            hooks[1]()
         if layer != 0:
             outputs, sequence_length = pyramidal_stack(outputs, sequence_length)
             if tape is not None:

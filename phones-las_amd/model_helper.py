@@ -9,6 +9,7 @@ i.e. CrossShardOptimizer's order (model_helper.py:405-417).
 import collections
 import copy
 import math
+import os
 
 import numpy as np
 import torch
@@ -338,8 +339,9 @@ def compute_loss(logits, targets, final_sequence_length, target_sequence_length,
     tg = targets[:, :U].to(torch.int32).contiguous()
     if tg.shape[1] < U:
         raise ValueError('targets shorter than the decoded length')
-    loss = torch.zeros(1, dtype=torch.float32, device=dev)
-    dlogits = torch.zeros(B, U, ldl, dtype=torch.bfloat16, device=dev) if want_grad else None
+    loss = torch.empty(1, dtype=torch.float32, device=dev)
+    dlogits = torch.empty(B, U, ldl, dtype=torch.bfloat16, device=dev) if want_grad else None
+    hip.fill_many(zero=[loss] + ([dlogits] if want_grad else []))
     tlen32 = target_sequence_length.to(torch.int32)     # named: a temporary would be recycled before the launch
     hip.check(hip.lib().las_seq_ce_loss(hip.p(logits), ldl, hip.p(tg), hip.p(tlen32),
                                         B, U, V, float(grad_scale), hip.p(loss), hip.p(dlogits), ldl, hip.stream()))
@@ -502,25 +504,46 @@ class LasModel:
         self.vars.load(tensors)
         self.refresh_images()
 
-    def refresh_images(self):
-        self.listener.refresh(self.vars.params)
-        for mod, _ in self.spellers:
-            mod.refresh(self.vars.params)
-        if self.ctc is not None:
-            self.ctc.refresh(self.vars.params)
+    def refresh_images(self, beside_first_layer=False):
+        """Rebuild the bf16 operand images from the fp32 master weights.  beside_first_layer: only the bottom listener
+        layer's images now; returns (start, wait) for Listener.forward: start() -- called between that layer's input
+        projection and its recurrence -- enqueues everything else on the second stream, where it runs beside the
+        recurrence (which leaves a third of the CUs idle); wait() makes the current stream wait for it in front of the
+        second layer.  Otherwise everything on the current stream; returns None."""
+        hooks = None
+        if beside_first_layer and len(self.listener.layers) > 1 and os.environ.get('LAS_REFRESH_BESIDE', '1') != '0':
+            self.listener.refresh(self.vars.params, layers=[0])
+            done = []
+
+            def start():
+                with self.overlap.fork(beside_chain=True):
+                    self.listener.refresh(self.vars.params, layers=range(1, len(self.listener.layers)))
+                    for mod, _ in self.spellers:
+                        mod.refresh(self.vars.params)
+                    if self.ctc is not None:
+                        self.ctc.refresh(self.vars.params)
+                    done.append(self.overlap.mark())
+
+            hooks = (start, lambda: torch.cuda.current_stream().wait_event(done[0]))
+        else:
+            self.listener.refresh(self.vars.params)
+            for mod, _ in self.spellers:
+                mod.refresh(self.vars.params)
+            if self.ctc is not None:
+                self.ctc.refresh(self.vars.params)
         self._images_stale = False
+        return hooks
 
     # -- forward / backward ---------------------------------------------------------------------
     def forward_train(self, features, labels, num_steps=None):
         """Forward of las_model_fn in TRAIN mode.  Returns (audio_loss [1], logits [B,U,Vp], dlogits)."""
-        if self._images_stale:
-            self.refresh_images()
+        images_ready = self.refresh_images(beside_first_layer=True) if self._images_stale else None
         x = features['encoder_inputs']
         src_len = features['source_sequence_length']
         tin, tout, tlen = labels['targets_inputs'], labels['targets_outputs'], labels['target_sequence_length']
         step_seed = (self.rng_seed + 7919 * self.global_step) & 0x7fffffff   # fresh draws every optimiser step
         self.last_seed = step_seed
-        (mem, mem_len), state = self.listener.forward(x, src_len, TRAIN, seed=step_seed)
+        (mem, mem_len), state = self.listener.forward(x, src_len, TRAIN, seed=step_seed, after_first_layer=images_ready)
         U = num_steps if num_steps is not None else int(tlen.max().item())
         loss, logits, dlogits = None, None, []
         for mod, kind in self.spellers:          # audio_loss = sum of the decoders' losses (model_helper.py:337-342)
@@ -565,12 +588,14 @@ class LasModel:
         if d_state is not None:
             nd = 1 if self.params.encoder.unidirectional else 2
             H = self.params.encoder.num_units
-            dc = torch.zeros(nd, dmem.shape[0], H, dtype=torch.float32, device=dmem.device)
-            dh = torch.zeros_like(dc)
+            dc = torch.empty(nd, dmem.shape[0], H, dtype=torch.float32, device=dmem.device)
+            dh = torch.empty_like(dc)
             per_layer = d_state if isinstance(d_state, list) else [d_state]     # decoder cell l <- encoder direction l
-            for l, (dcl, dhl) in enumerate(per_layer[:nd]):
-                dc[l].copy_(dcl)
-                dh[l].copy_(dhl)
+            pairs = []
+            for l in range(nd):                      # directions without a decoder cell on top get zeros
+                dcl, dhl = per_layer[l] if l < len(per_layer) else (None, None)
+                pairs += [(dc[l], dcl.float() if dcl is not None else None), (dh[l], dhl.float() if dhl is not None else None)]
+            hip.fill_many(copy=pairs)
             ds = (dc, dh)
         self.listener.backward_begin(dmem, ds)
         return self.backward_rest(layers)
@@ -586,11 +611,14 @@ class LasModel:
         """grad += l2 * theta (gradient of the L2 term, model_helper.py:411-413) and per-tensor ||grad||^2; the same pass
         leaves sum theta^2 (the value of the L2 term) in vars.param_sumsq.  bucket: one of vars.buckets (default: all)."""
         v, p = self.vars, self.params
+        lib = hip.lib()
+        # (after collect_status(zero_norms=True) the accumulators are already clear: the pass that only adds)
+        fn = lib.las_grad_l2_norms_acc if self.__dict__.pop('_norms_zeroed', False) else lib.las_grad_l2_norms
         for b in (v.buckets if bucket is None else [bucket]):
-            hip.check(hip.lib().las_grad_l2_norms(hip.addr(v.grad, b['begin']), hip.addr(v.flat, b['begin']), hip.p(b['seg']),
-                                                  b['hi'] - b['lo'], b['end'] - b['begin'],
-                                                  float(p.l2_reg_scale) / self.world_size, hip.addr(v.sumsq, b['lo']),
-                                                  hip.addr(v.param_sumsq, b['slot']), hip.stream()))
+            hip.check(fn(hip.addr(v.grad, b['begin']), hip.addr(v.flat, b['begin']), hip.p(b['seg']),
+                         b['hi'] - b['lo'], b['end'] - b['begin'],
+                         float(p.l2_reg_scale) / self.world_size, hip.addr(v.sumsq, b['lo']),
+                         hip.addr(v.param_sumsq, b['slot']), hip.stream()))
 
     def clip_gradients(self, bucket=None, norms=True):
         """L2 gradient + per-tensor clip_by_norm(GRAD_NORM) on the flat buffers (model_helper.py:411-416)."""
@@ -633,7 +661,7 @@ class LasModel:
         self._images_stale = True
 
     def apply_gradients(self):
-        self.collect_status()
+        self.collect_status(zero_norms=True)
         if self.world_size == 1 and self.process_group is None:
             self.gradient_norms()
             self.clip_adam_update()
@@ -651,11 +679,13 @@ class LasModel:
         out += [ws for ws in getattr(self.speller, '_persist_cache', {}).values()]
         return out
 
-    def collect_status(self):
+    def collect_status(self, zero_norms=False):
         """vars.skip_flag = 1 if any persistent kernel launched so far reported a timeout (the status words are sticky),
         else 0: enqueued once per step after the backward pass, before the gradients are exchanged.  The Adam kernels do
         nothing when the (all-reduced) flag is set, so parameters never see the invalid gradients of such a step; the
-        host raises at its next check_device_status()."""
+        host raises at its next check_device_status().  zero_norms: the same launch clears the per-tensor ||g||^2 and
+        sum(theta^2) accumulators, and the NEXT gradient_norms() call only adds into them (no memsets of its own): for the
+        flows that take all norms after this point (not the two-bucket exchange, whose first bucket is clipped earlier)."""
         ws = self._status_tensors()
         key = tuple(t.data_ptr() for t in ws)
         if getattr(self, '_status_key', None) != key:
@@ -663,6 +693,12 @@ class LasModel:
                 raise hip.LasError('collect_status: new workspace during graph capture (run the step once eagerly first)')
             self._status_ptrs = torch.tensor(list(key) or [0], dtype=torch.int64).cuda()
             self._status_key = key
+        if zero_norms:
+            v = self.vars
+            hip.check(hip.lib().las_train_op_begin(hip.p(self._status_ptrs), len(key), hip.p(v.skip_flag), hip.p(v.sumsq),
+                                                   v.sumsq.numel(), hip.p(v.param_sumsq), v.param_sumsq.numel(), hip.stream()))
+            self._norms_zeroed = True
+            return
         hip.check(hip.lib().las_status_collect(hip.p(self._status_ptrs), len(key), hip.p(self.vars.skip_flag), hip.stream()))
 
     # -- data-parallel step with the exchange overlapped with the backward pass ----------------------------------
@@ -734,6 +770,15 @@ class LasModel:
         hip.check(hip.lib().las_sumsq(hip.p(self.vars.flat), self.vars.total, hip.p(out), hip.stream()))
         return out * (0.5 * float(self.params.l2_reg_scale))
 
+    def total_loss(self, audio_loss, out=None):
+        """audio loss + L2 term (from the sums of the last gradient_norms() pass) in one launch; out: a [1] fp32 tensor."""
+        if out is None:
+            out = torch.empty(1, dtype=torch.float32, device='cuda')
+        v = self.vars
+        hip.check(hip.lib().las_total_loss(hip.p(audio_loss), hip.p(v.param_sumsq), v.param_sumsq.numel(),
+                                           0.5 * float(self.params.l2_reg_scale), hip.p(out), hip.stream()))
+        return out
+
     def train_step(self, features, labels, num_steps=None):
         """One optimiser step; returns the loss (audio loss + L2 term) as a device scalar tensor."""
         self.vars.grad.zero_()
@@ -744,10 +789,9 @@ class LasModel:
         else:
             self.backward(dlogits)
             self.apply_gradients()
-        loss = audio_loss + self.l2_loss(from_norms=True)
+        loss = self.total_loss(audio_loss)
         self.maybe_add_noise()
-        self.refresh_images()
-        self.global_step += 1
+        self.global_step += 1         # (the weight images are stale now: the next forward rebuilds them, see refresh_images)
         return loss
 
     # -- inference ------------------------------------------------------------------------------

@@ -44,12 +44,11 @@ def _relerr(got, ref):
 @pytest.mark.parametrize('rows', [0, 8, 16])
 def test_bilstm_forward_backward_vs_oracle(B, T, D, H, lengths, rows, monkeypatch):
     """rows: 0 = the library's choice of utterances per slice (4-row slices at these batch sizes),
-    8 / 16 = forced through LAS_LSTM_ROWS -- all three layouts of the 64/128/256-unit kernels are covered."""
+    8 / 16 = forced through LAS_LSTM_ROWS -- all three layouts of the 64/128/256-unit kernels and both (16, 8) of the 512-unit
+    kernels (K split forward, row split backward) are covered."""
     from oracle import las_oracle as O
     from phones_las_amd.las import ops
     if rows:
-        if H > 256:
-            pytest.skip('the 512-unit kernels run on full 16-row tiles only')
         monkeypatch.setenv('LAS_LSTM_ROWS', str(rows))
     x, length, var = _setup(B, T, D, H, lengths)
     leaf = {k: v.clone().requires_grad_(True) for k, v in var.items()}
