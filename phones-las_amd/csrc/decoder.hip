@@ -157,6 +157,14 @@ __device__ __forceinline__ uint4 ld16(lds_cu16 p) {
   return make_uint4(v.x, v.y, v.z, v.w);
 }
 
+#ifdef LAS_STAMPS
+// diagnostics build (LAS_CXXFLAGS=-DLAS_STAMPS): wall-clock (100 MHz) stamps of the phases of every step of workgroup 0
+__device__ unsigned long long las_stamps[256 * 16];
+#define LAS_STAMP(step, k) do { if (blockIdx.x == 0 && threadIdx.x == 0 && (step) < 256) las_stamps[(step) * 16 + (k)] = wall_clock64(); } while (0)
+#else
+#define LAS_STAMP(step, k) do { } while (0)
+#endif
+
 struct PersistHook {
   pu64* xsc;            // raw-score granules of this utterance and step parity: [ld] {tag, fp32}
   pu64* xz;             // z_t granules of this utterance and step parity: [4Hd] {tag, fp32}
@@ -262,7 +270,9 @@ __device__ void dec_step_fwd_body(const las_dec_step& s, const int b, const int 
   }
   }
   if (s.mode == LAS_DEC_CELL_ONLY) return;
+  if (ph) LAS_STAMP(s.step, 3);
   __syncthreads();
+  if (ph) LAS_STAMP(s.step, 4);
 
   // ---- processed query (Bahdanau, Custom): pq[a] = sum_u Wq[u][a] h[u]  (TF Dense kernel layout [in,out]);
   //      CustomAttention applies relu and, like every AttentionWrapper query, it is a GEMM operand: bf16-rounded ----
@@ -357,6 +367,7 @@ __device__ void dec_step_fwd_body(const las_dec_step& s, const int b, const int 
           }
       }
     }
+    if (ph) LAS_STAMP(s.step, 5);
     if (ph) {            // gather the whole score row: the data is its own flag (no group barrier)
       for (int t0 = 0; t0 < Tm; t0 += 256) {
         const int t = t0 + tid;
@@ -374,6 +385,7 @@ __device__ void dec_step_fwd_body(const las_dec_step& s, const int b, const int 
     }
   }
   __syncthreads();
+  if (ph) LAS_STAMP(s.step, 6);
 
   if (s.norm != LAS_NORM_SOFTMAX) {
     // ---- monotonic attention (tf.contrib.seq2seq.monotonic_attention) ----
@@ -445,6 +457,7 @@ __device__ void dec_step_fwd_body(const las_dec_step& s, const int b, const int 
   __syncthreads();
   }
 
+  if (ph) LAS_STAMP(s.step, 7);
   // ---- context = sum_t' p[t'] * values[b,t',:] for this workgroup's column range.  L = cols/8 lanes cover one
   // frame with 16-byte loads; the 256/L frame phases are reduced through LDS. ----
   const unsigned short* vals = s.values + (int64_t)b * Tm * M;
@@ -486,6 +499,7 @@ __device__ void dec_step_fwd_body(const las_dec_step& s, const int b, const int 
       if constexpr (RES) context_pass((lds_cu16)ph->lvals + (col - c_begin), cols_per);
       else context_pass(vals + col, M);
     }
+    if (ph) LAS_STAMP(s.step, 8);
     __syncthreads();
 #pragma unroll
     for (int j = 0; j < 8; ++j) cred[tid * 8 + j] = a[j];
@@ -507,6 +521,7 @@ __device__ void dec_step_fwd_body(const las_dec_step& s, const int b, const int 
       }
     }
   }
+  if (ph) LAS_STAMP(s.step, 9);
 }
 
 
@@ -705,6 +720,7 @@ __global__ __launch_bounds__(256) void dec_persist_fwd_kernel(las_dec_persist p)
       for (int g = 0; g < 4; ++g) tok4[g] = las_bf2f(s0.tok_rows[(int64_t)tok_pre * 4 * Hd + g * Hd + tid]);
       cprev_pre = (s0.c_prev + t * p.inc_cprev)[(int64_t)bs * s0.ldcp + tid];
     }
+    LAS_STAMP(t, 0);
     // ---- G: z_t[group's utterances, my columns] ----
     const unsigned xtag = (unsigned)(t + 1);
     pu64* const xbase = reinterpret_cast<pu64*>(reinterpret_cast<char*>(p.workspace) + 64) + persist_flag_words(B);
@@ -751,6 +767,7 @@ __global__ __launch_bounds__(256) void dec_persist_fwd_kernel(las_dec_persist p)
         if (nt < NTL)
 #pragma unroll
           for (int r = 0; r < 4; ++r) red[(wave * 16 + lq * 4 + r) * RS + nt * 16 + l15] = acc[nt][r];
+      LAS_STAMP(t, 1);
       __syncthreads();
       for (int e = tid; e < 8 * CPM; e += 256) {
         const int row = e / CPM, col = e % CPM;
@@ -762,6 +779,7 @@ __global__ __launch_bounds__(256) void dec_persist_fwd_kernel(las_dec_persist p)
       }
     }
     // (no group barrier here: the S role polls the granules of its utterance)
+    LAS_STAMP(t, 2);
 
     // ---- S: cell + attention of utterance bs, context columns of `part` ----
     if (bs < B) {
@@ -858,6 +876,418 @@ __global__ __launch_bounds__(256) void dec_persist_fwd_kernel(las_dec_persist p)
       }
     }
     if (!persist_barrier(flags, member, ++epoch, local, fail)) break;
+    LAS_STAMP(t, 10);
+  }
+  if (*fail && tid == 0) atomicOr(status, 8u);
+}
+
+// ------------------------------------------------------------------------------------------------
+// The same launch with the S role WRITTEN OUT for the case the train step runs (teacher forcing without scheduled sampling,
+// softmax attention Luong or Bahdanau, decoder_units <= 256, keys / values resident in LDS): dec_step_fwd_body serves every
+// mode of the step kernels and, inlined into the persistent loop, cost 6 600 instructions for the score phase alone, 420
+// spilled scalar registers and a full vmcnt(0) drain in front of most phases (phase stamps of the diagnostics build,
+// scripts/gpu_dec_stamps.py: 13.9 us per step, of which scores 2.9, context 2.7, operands + product 3.0, softmax 1.4).
+// Differences from the general body, none of them visible in the results' layout:
+//   * the attention type is a template parameter; the Luong score is v_dot2c_f32_bf16 on (key, h) bf16 pairs (h_t is
+//     bf16-rounded before it is a query in every path, so the products are the same numbers);
+//   * c_t stays in a register (all four workgroups of an utterance compute the same cell), the token's kernel row and id
+//     of step t+1 are requested during step t (the ids are the teacher's: known up front);
+//   * the saved tensors are written by four workgroups instead of one: part p writes gate p, parts 0 / 1 / 2 write
+//     c_t / h_t / the operand copy of h_t, part 3 the processed query, and every part its own frames of the alignments;
+//   * the product's operand loads are issued before anything else in the step; LDS key rows are padded against bank
+//     conflicts (4 lanes per frame, 16 frames per wave).
+// ------------------------------------------------------------------------------------------------
+constexpr int LEAN_KPAD = 32;                       // bf16 elements of padding per LDS key row (row stride = 64 mod 128 bytes)
+struct LeanLayout { size_t hq, pq, vq, sc, red, cred, zred, flags, hqb, keys, vals, total_bytes; int fq, kst, cols_per; };
+__host__ __device__ inline LeanLayout lean_layout(int Hd, int Tm, int M) {
+  LeanLayout l;
+  size_t o = 0;                                     // in floats
+  l.hq = o; o += Hd;
+  l.pq = o; o += Hd;
+  l.vq = o; o += Hd;
+  l.sc = o; o += (size_t)((Tm + 3) & ~3);
+  l.red = o; o += 16;
+  l.cred = o; o += 2048;
+  l.zred = o; o += (size_t)4 * 16 * persist_red_stride(Hd);
+  l.flags = o; o += 8;
+  l.hqb = o; o += Hd / 2;
+  o = (o + 3) & ~(size_t)3;
+  l.fq = (Tm + 3) / 4;
+  l.kst = Hd + LEAN_KPAD;
+  l.cols_per = persist_cols_per(M);
+  l.keys = o; o += ((size_t)l.fq * l.kst + 1) / 2;
+  o = (o + 3) & ~(size_t)3;
+  l.vals = o; o += ((size_t)Tm * l.cols_per + 1) / 2;
+  l.total_bytes = ((o + 3) & ~(size_t)3) * sizeof(float);
+  return l;
+}
+__host__ __device__ inline bool persist_fwd_lean_ok(int Hd, int M, int Tm, int att, int norm) {
+  return (att == LAS_ATT_LUONG || att == LAS_ATT_BAHDANAU) && norm == LAS_NORM_SOFTMAX && Hd <= 256 && Hd % 64 == 0 && M % 32 == 0 &&
+         lean_layout(Hd, Tm, M).total_bytes <= 158 * 1024;
+}
+
+typedef __attribute__((ext_vector_type(2))) __bf16 las_bf16x2;
+__device__ __forceinline__ float dot2_bf16(unsigned a, unsigned b, float acc) {
+  return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(las_bf16x2, a), __builtin_bit_cast(las_bf16x2, b), acc, false);
+}
+
+template <int ATT>
+__global__ __launch_bounds__(256) void dec_persist_fwd_lean_kernel(las_dec_persist p) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  constexpr int NTL_MAX = 2, KRES = 12;
+  const int B = p.s.B, Hd = p.s.Hd, M = p.s.M, Tm = p.s.Tm, U = p.U;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, lq = lane >> 4;
+  const int groups = (B + 7) / 8;
+  const int group = (blockIdx.x / (8 * P_MEMBERS)) * 8 + (blockIdx.x & 7), member = (blockIdx.x % (8 * P_MEMBERS)) >> 3;
+  if (group >= groups) return;
+  unsigned* status = reinterpret_cast<unsigned*>(p.workspace);
+  pu64* flags = reinterpret_cast<pu64*>(reinterpret_cast<char*>(p.workspace) + 64) + (size_t)group * 2 * P_MEMBERS;
+  pu64* xcc_tab = flags + P_MEMBERS;
+  const LeanLayout L = lean_layout(Hd, Tm, M);
+  float* hq = sm + L.hq;
+  float* pq = sm + L.pq;
+  float* vq = sm + L.vq;
+  float* sc = sm + L.sc;
+  float* red = sm + L.red;
+  float* cred = sm + L.cred;
+  float* zred = sm + L.zred;
+  int* fail = reinterpret_cast<int*>(sm + L.flags);
+  int* colo = fail + 1;
+  unsigned short* hqb = reinterpret_cast<unsigned short*>(sm + L.hqb);
+  unsigned short* lk = reinterpret_cast<unsigned short*>(sm + L.keys);
+  unsigned short* lv = reinterpret_cast<unsigned short*>(sm + L.vals);
+  const int RS = persist_red_stride(Hd);
+  if (tid == 0) { *fail = 0; *colo = 0; }
+  __syncthreads();
+  if (tid == 0) {                                          // are the 32 members on one XCD?  (decides fences only)
+    unsigned xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    xcc &= 0xf;
+    __hip_atomic_store(xcc_tab + member, ((pu64)1 << 32) | (xcc + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    bool same = true;
+    for (int m = 0; m < P_MEMBERS; ++m) {
+      pu64 v = 0;
+      unsigned spins = 0;
+      do {
+        v = __hip_atomic_load(xcc_tab + m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((v >> 32) == 1) break;
+        __builtin_amdgcn_s_sleep(2);
+      } while (++spins < P_SPIN_LIMIT);
+      same = same && ((v >> 32) == 1) && ((unsigned)v == xcc + 1);
+    }
+    *colo = same ? 1 : 0;
+  }
+  __syncthreads();
+  const bool local = *colo != 0;
+
+  // G role: this member's columns of z and its register-resident slice of K ([4Hd, K_in] bf16, row = output column)
+  const int CPM = 4 * Hd / P_MEMBERS, NTL = CPM / 16;
+  const int KC = p.K_in / 32;
+  bf16x8 wf[NTL_MAX][KRES];
+#pragma unroll
+  for (int nt = 0; nt < NTL_MAX; ++nt) {
+    const unsigned short* wrow = p.kT + (int64_t)(member * CPM + min(nt, NTL - 1) * 16 + l15) * p.ldk + 8 * lq;
+#pragma unroll
+    for (int i = 0; i < KRES; ++i) {
+      const int kc = wave + 4 * i;
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (nt < NTL && kc < KC) v = *reinterpret_cast<const uint4*>(wrow + kc * 32);
+      wf[nt][i] = __builtin_bit_cast(bf16x8, v);
+    }
+  }
+  const int bg = group * 8 + (l15 & 7);                    // utterance of A-fragment row l15 (rows 8..15 repeat 0..7)
+  const int bs = group * 8 + member / 4, part = member & 3;  // S role: utterance, part
+  const bool have = bs < B;
+  const int bsc = have ? bs : 0;
+  // S role constants
+  const int fq = L.fq, f0 = part * fq, f1 = min(Tm, f0 + fq), KST = L.kst;
+  const int cols_per = L.cols_per, c_begin = part * cols_per, ncols = max(0, min(M, c_begin + cols_per) - c_begin);
+  const int len = have ? min(p.s.mem_len[bsc], Tm) : 0;
+  const int flen = min(len, f1);
+  if (have) {                                              // this workgroup's share of the encoder memory: resident for all steps
+    const unsigned short* gk = p.s.keys + (int64_t)bs * Tm * Hd;
+    const unsigned short* gv = p.s.values + (int64_t)bs * Tm * M;
+    for (int e = tid; e < max(f1 - f0, 0) * (Hd / 8); e += 256) {
+      const int r = e / (Hd / 8), c = e % (Hd / 8);
+      *reinterpret_cast<uint4*>(lk + (size_t)r * KST + c * 8) = *reinterpret_cast<const uint4*>(gk + (int64_t)(f0 + r) * Hd + c * 8);
+    }
+    for (int e = tid; e < Tm * (ncols / 8); e += 256) {
+      const int r = e / (ncols / 8), c = e % (ncols / 8);
+      *reinterpret_cast<uint4*>(lv + (size_t)r * cols_per + c * 8) = *reinterpret_cast<const uint4*>(gv + (int64_t)r * M + c_begin + c * 8);
+    }
+    if (ATT == LAS_ATT_BAHDANAU)
+      for (int u = tid; u < Hd; u += 256) vq[u] = p.s.att_v[u];
+  }
+  unsigned epoch = 0;
+  const bool unit = tid < Hd && have;                      // this thread owns hidden unit `tid` of utterance bs
+  float bias4[4] = {0.f, 0.f, 0.f, 0.f};
+  float c_reg = 0.f;
+  int tok_cur = 0;
+  if (unit) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) bias4[g] = p.s.bias[g * Hd + tid];
+    c_reg = p.s.c_prev[(int64_t)bs * p.s.ldcp + tid];
+    tok_cur = p.s.tok_ids[(int64_t)bs * p.s.tok_stride];
+  }
+  const float keep = p.s.drop_keep;
+  const int sub = lane & 3, fr = lane >> 2;                // score phase: 4 lanes per frame, 16 frames per wave
+  const int nk = Hd / 32;
+  int Lc = 1;
+  while (Lc * 8 < ncols) Lc <<= 1;                         // context phase: lanes per frame (power of two), frame phases
+  const int Pc = 256 / Lc, cphase = tid / Lc, ccl = tid % Lc;
+  pu64* const xbase = reinterpret_cast<pu64*>(reinterpret_cast<char*>(p.workspace) + 64) + persist_flag_words(B);
+  const size_t ldsc = (size_t)((Tm + 31) / 32 * 32);
+  pu64* const xzb = xbase + 2 * (size_t)B * ldsc;           // [2][B][4Hd] after the score granules [2][B][ldsc]
+  __syncthreads();
+
+  for (int t = 0; t < U; ++t) {
+    LAS_STAMP(t, 0);
+    const bool last = (t + 1 == U);
+    const unsigned xtag = (unsigned)(t + 1);
+    // ---- G: z_t[group's utterances, my columns]; its operand row first, everything else of the step behind it ----
+    const unsigned short* arow = p.x + (int64_t)min(bg, B - 1) * p.ldx + (int64_t)t * p.inc_x + 8 * lq;
+    uint4 av[KRES];
+#pragma unroll
+    for (int i = 0; i < KRES; ++i) {
+      const int kc = wave + 4 * i;
+      av[i] = make_uint4(0, 0, 0, 0);
+      if (kc < KC && bg < B) av[i] = *reinterpret_cast<const uint4*>(arow + kc * 32);
+    }
+    // the token's row of the cell kernel (its id was requested a step ago), and the next step's id
+    float tok4[4] = {0.f, 0.f, 0.f, 0.f};
+    int tok_next = 0;
+    if (unit) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) tok4[g] = las_bf2f(p.s.tok_rows[(int64_t)tok_cur * 4 * Hd + g * Hd + tid]);
+      if (!last) tok_next = p.s.tok_ids[(int64_t)bs * p.s.tok_stride + (int64_t)(t + 1) * p.inc_tok];
+    }
+    {
+      f32x4 acc[NTL_MAX];
+#pragma unroll
+      for (int nt = 0; nt < NTL_MAX; ++nt) acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int i = 0; i < KRES; ++i)
+#pragma unroll
+        for (int nt = 0; nt < NTL_MAX; ++nt)
+          if (nt < NTL && wave + 4 * i < KC)
+            acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, av[i]), wf[nt][i], acc[nt], 0, 0, 0);
+#pragma unroll
+      for (int nt = 0; nt < NTL_MAX; ++nt)
+        if (nt < NTL)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) zred[(wave * 16 + lq * 4 + r) * RS + nt * 16 + l15] = acc[nt][r];
+      LAS_STAMP(t, 1);
+      __syncthreads();
+      for (int e = tid; e < 8 * CPM; e += 256) {
+        const int row = e / CPM, col = e % CPM;
+        const int b = group * 8 + row;
+        if (b < B)
+          pgranule_store(xzb + ((size_t)(xtag & 1) * B + b) * 4 * Hd + member * CPM + col, xtag,
+                         zred[(0 * 16 + row) * RS + col] + zred[(1 * 16 + row) * RS + col] + zred[(2 * 16 + row) * RS + col] + zred[(3 * 16 + row) * RS + col],
+                         local);
+      }
+    }
+    LAS_STAMP(t, 2);
+
+    // ---- S: cell + attention of utterance bs, frames / context columns of `part` ----
+    if (have) {
+      pu64* const xsc = xbase + ((size_t)(xtag & 1) * B + bs) * ldsc;
+      const pu64* const xz = xzb + ((size_t)(xtag & 1) * B + bs) * 4 * Hd;
+      if (tid < Hd) {                                      // whole waves: Hd is a multiple of 64
+        float z[4];
+        unsigned spins = 0;
+        for (;;) {                                         // the 32 product slices arrive as granules: wave-uniform, bounded
+          pu64 gq[4];
+          bool got = true;
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            gq[g] = pgranule_load(xz + g * Hd + tid);
+            got = got && ((unsigned)(gq[g] >> 32) == xtag);
+          }
+          if (__all(got)) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) z[g] = __uint_as_float((unsigned)gq[g]);
+            break;
+          }
+          if (++spins > P_SPIN_LIMIT || *fail) { *fail = 1; z[0] = z[1] = z[2] = z[3] = 0.f; break; }
+          __builtin_amdgcn_s_sleep(1);
+        }
+        float tok_scale = 1.0f;                            // DropoutWrapper on the one-hot feed: its single entry is kept or lost
+        if (keep < 1.0f)
+          tok_scale = las_uniform(p.s.drop_seed, p.s.drop_stream, ((unsigned long long)t * B + bs) * p.s.feed_width + tok_cur) < keep
+                          ? 1.0f / keep : 0.f;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) z[g] += bias4[g] + tok_scale * tok4[g];
+        const float gi = las_sigmoid(z[0]), gj = las_tanh(z[1]), gf = las_sigmoid(z[2] + 1.0f), go = las_sigmoid(z[3]);
+        const float cn = gf * c_reg + gi * gj;
+        c_reg = cn;
+        const unsigned short hb = las_f2bf(go * las_tanh(cn));
+        hq[tid] = las_bf2f(hb);
+        hqb[tid] = hb;
+        // saved for the backward pass: one quarter per workgroup of the utterance
+        const float gsel = part == 0 ? gi : (part == 1 ? gj : (part == 2 ? gf : go));
+        p.s.gates_out[(int64_t)bs * p.s.ldg + (int64_t)t * p.inc_gates + part * Hd + tid] = gsel;
+        if (part == 0) p.s.c_out[(int64_t)bs * p.s.ldco + (int64_t)t * p.inc_cout + tid] = cn;
+        else if (part == 1) p.s.h_out[(int64_t)bs * p.s.ldh + (int64_t)t * p.inc_h + tid] = hb;
+        else if (part == 2 && !last) p.s.h_out2[(int64_t)bs * p.s.ldh2 + (int64_t)t * p.inc_h2 + tid] = hb;
+      }
+      LAS_STAMP(t, 3);
+      __syncthreads();
+      LAS_STAMP(t, 4);
+      if (ATT == LAS_ATT_BAHDANAU) {                       // processed query pq = h Wq
+        square_matvec_bf16(p.s.wq, hq, pq, cred, Hd);
+        if (part == 3 && p.s.pq_out)
+          for (int a = tid; a < Hd; a += 256) p.s.pq_out[(int64_t)bs * p.s.ldpq + (int64_t)t * p.inc_pq + a] = pq[a];
+        __syncthreads();
+      }
+      // ---- raw scores of my frames ----
+      {
+        uint4 qreg[8];
+        if (ATT == LAS_ATT_LUONG) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j)
+            if (j < nk) qreg[j] = ld16((lds_cu16)hqb + sub * 8 + j * 32);
+        }
+        for (int fl0 = 0; fl0 < fq; fl0 += 64) {
+          const int fl = fl0 + wave * 16 + fr, tf = f0 + fl;
+          float acc = 0.f;
+          if (tf < flen) {
+            const lds_cu16 krow = (lds_cu16)lk + (size_t)fl * KST + sub * 8;
+            uint4 kv[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+              if (j < nk) kv[j] = ld16(krow + j * 32);
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+              if (j < nk) {
+                if (ATT == LAS_ATT_LUONG) {
+                  acc = dot2_bf16(kv[j].x, qreg[j].x, acc);
+                  acc = dot2_bf16(kv[j].y, qreg[j].y, acc);
+                  acc = dot2_bf16(kv[j].z, qreg[j].z, acc);
+                  acc = dot2_bf16(kv[j].w, qreg[j].w, acc);
+                } else {
+                  const unsigned short* e = reinterpret_cast<const unsigned short*>(&kv[j]);
+                  const int k = sub * 8 + j * 32;
+#pragma unroll
+                  for (int i = 0; i < 8; ++i) acc += vq[k + i] * las_tanh(las_bf2f(e[i]) + pq[k + i]);
+                }
+              }
+          }
+          acc += __shfl_xor(acc, 1, 64);
+          acc += __shfl_xor(acc, 2, 64);
+          if (sub == 0 && fl < fq && tf < f1) {
+            const float sv = (tf < len) ? acc : -INFINITY;
+            pgranule_store(xsc + tf, xtag, sv, local);     // the other three parts are waiting for it
+            sc[tf] = sv;
+          }
+        }
+      }
+      LAS_STAMP(t, 5);
+      // ---- the other parts' scores: the data is its own flag ----
+      for (int t0 = 0; t0 < Tm; t0 += 256) {
+        const int tf = t0 + tid;
+        const bool need = tf < Tm && (tf < f0 || tf >= f1);
+        unsigned spins = 0;
+        for (;;) {                                          // wave-uniform, bounded
+          const pu64 gq = need ? pgranule_load(xsc + tf) : ((pu64)xtag << 32);
+          if (__all((unsigned)(gq >> 32) == xtag)) {
+            if (need) sc[tf] = __uint_as_float((unsigned)gq);
+            break;
+          }
+          if (++spins > P_SPIN_LIMIT || *fail) { *fail = 1; break; }
+          __builtin_amdgcn_s_sleep(1);
+        }
+      }
+      __syncthreads();
+      LAS_STAMP(t, 6);
+      // ---- masked softmax over the frames ----
+      {
+        float mx = -INFINITY;
+        for (int tf = tid; tf < Tm; tf += 256) mx = fmaxf(mx, sc[tf]);
+        mx = las_wave_max(mx);
+        if (lane == 0) red[wave] = mx;
+        __syncthreads();
+        mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+        float sum = 0.f;
+        for (int tf = tid; tf < Tm; tf += 256) {
+          const float e = (tf < len) ? __expf(sc[tf] - mx) : 0.f;
+          sc[tf] = e;
+          sum += e;
+        }
+        sum = las_wave_sum(sum);
+        if (lane == 0) red[4 + wave] = sum;
+        __syncthreads();
+        sum = red[4] + red[5] + red[6] + red[7];
+        const float inv = len > 0 ? 1.0f / sum : 0.f;
+        float* const arow_out = p.s.align_out + (int64_t)bs * p.s.lda + (int64_t)t * p.inc_align;
+        unsigned short* const abf = p.s.align_bf16 ? p.s.align_bf16 + (int64_t)bs * p.s.lda + (int64_t)t * p.inc_align : nullptr;
+        for (int tf = tid; tf < Tm; tf += 256) {
+          const float pr = sc[tf] * inv;
+          sc[tf] = pr;
+          if (tf >= f0 && tf < f1) {                       // every part saves its own frames
+            arow_out[tf] = pr;
+            if (abf) abf[tf] = las_f2bf(pr);
+          }
+        }
+        __syncthreads();
+      }
+      LAS_STAMP(t, 7);
+      // ---- context columns [c_begin, c_begin + ncols): Lc lanes cover a frame with 16-byte LDS reads, Pc frame phases ----
+      {
+        float a[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) a[j] = 0.f;
+        if (ccl * 8 < ncols) {
+          const lds_cu16 vcol = (lds_cu16)lv + ccl * 8;
+          int tf = cphase;
+          for (; tf + 3 * Pc < len; tf += 4 * Pc) {
+            uint4 vv[4];
+            float pr[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              vv[i] = ld16(vcol + (size_t)(tf + i * Pc) * cols_per);
+              pr[i] = sc[tf + i * Pc];
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              const unsigned short* e = reinterpret_cast<const unsigned short*>(&vv[i]);
+#pragma unroll
+              for (int j = 0; j < 8; ++j) a[j] += pr[i] * las_bf2f(e[j]);
+            }
+          }
+          for (; tf < len; tf += Pc) {
+            const uint4 vv = ld16(vcol + (size_t)tf * cols_per);
+            const float pr = sc[tf];
+            const unsigned short* e = reinterpret_cast<const unsigned short*>(&vv);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) a[j] += pr * las_bf2f(e[j]);
+          }
+        }
+        LAS_STAMP(t, 8);
+        *reinterpret_cast<float4*>(cred + tid * 8) = make_float4(a[0], a[1], a[2], a[3]);
+        *reinterpret_cast<float4*>(cred + tid * 8 + 4) = make_float4(a[4], a[5], a[6], a[7]);
+        __syncthreads();
+        for (int j = tid; j < ncols; j += 256) {
+          const int cl2 = j >> 3, e = j & 7;
+          float acc = 0.f;
+          for (int ph = 0; ph < Pc; ++ph) acc += cred[(ph * Lc + cl2) * 8 + e];
+          const unsigned short o = las_f2bf(acc);
+          p.s.ctx_out[(int64_t)bs * p.s.ldc + (int64_t)t * p.inc_ctx + c_begin + j] = o;
+          if (!last) {
+            unsigned short o2 = o;
+            if (keep < 1.0f) {   // the copy that feeds step t+1's cell goes through that step's input dropout
+              const unsigned long long idx = ((unsigned long long)(t + 1) * B + bs) * p.s.feed_width + (p.s.feed_width - M) + c_begin + j;
+              o2 = las_uniform(p.s.drop_seed, p.s.drop_stream, idx) < keep ? las_f2bf(las_bf2f(o) / keep) : (unsigned short)0;
+            }
+            p.s.ctx_out2[(int64_t)bs * p.s.ldc2 + (int64_t)t * p.inc_ctx2 + c_begin + j] = o2;
+          }
+        }
+      }
+      LAS_STAMP(t, 9);
+    }
+    tok_cur = tok_next;
+    if (!persist_barrier(flags, member, ++epoch, local, fail)) break;
+    LAS_STAMP(t, 10);
   }
   if (*fail && tid == 0) atomicOr(status, 8u);
 }
@@ -1910,6 +2340,25 @@ extern "C" int las_decoder_persist_fwd(const las_dec_persist* p, void* stream) {
     LAS_LAUNCH_CHECK("persistent decoder fwd launch");
     return LAS_OK;
   }
+  static int lean_mode = -1;                 // LAS_DEC_LEAN=0: the general body also where the written-out one applies (diagnostics)
+  if (lean_mode < 0) {
+    const char* e = getenv("LAS_DEC_LEAN");
+    lean_mode = (e && atoi(e) == 0) ? 0 : 1;
+  }
+  if (lean_mode && p->sampling_prob <= 0.f && s->tok_rows && persist_fwd_lean_ok(s->Hd, s->M, s->Tm, s->attention, s->norm) &&
+      p->K_in / 32 <= 48) {
+    static bool lean_attr = false;
+    if (!lean_attr) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dec_persist_fwd_lean_kernel<LAS_ATT_LUONG>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dec_persist_fwd_lean_kernel<LAS_ATT_BAHDANAU>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      lean_attr = true;
+    }
+    const size_t lbytes = lean_layout(s->Hd, s->Tm, s->M).total_bytes;
+    if (s->attention == LAS_ATT_LUONG) hipLaunchKernelGGL((dec_persist_fwd_lean_kernel<LAS_ATT_LUONG>), grid, dim3(256), lbytes, st, *p);
+    else hipLaunchKernelGGL((dec_persist_fwd_lean_kernel<LAS_ATT_BAHDANAU>), grid, dim3(256), lbytes, st, *p);
+    LAS_LAUNCH_CHECK("persistent decoder fwd launch");
+    return LAS_OK;
+  }
   if (res) {
     lds += persist_fwd_resident_bytes(s->M, s->Hd, s->Tm);
     static bool attr_set = false;
@@ -2026,3 +2475,9 @@ extern "C" int las_seq_ce_loss(const float* logits, int64_t ldl, const int32_t* 
   LAS_LAUNCH_CHECK("seq ce launch");
   return LAS_OK;
 }
+
+#ifdef LAS_STAMPS
+extern "C" int las_debug_read_stamps(unsigned long long* out_host, int n) {
+  return las_check_hip(hipMemcpyFromSymbol(out_host, HIP_SYMBOL(las_stamps), sizeof(unsigned long long) * (size_t)n), "read stamps");
+}
+#endif

@@ -1,0 +1,27 @@
+# Phase times of the one-launch decoder (workgroup 0: group 0, member 0 = utterance 0, part 0) from the diagnostics build:
+#   LAS_CXXFLAGS=-DLAS_STAMPS LAS_HIP_LIB=$PWD/phones-las_amd/liblas_hip_stamps.so python phones-las_amd/build.py --force
+#   LAS_HIP_LIB=$PWD/phones-las_amd/liblas_hip_stamps.so python scripts/gpu_dec_stamps.py
+import ctypes as C, os, sys
+import numpy as np, torch
+sys.path.insert(0, '.')
+import bench
+from phones_las_amd import hip, model_helper as mh
+c = bench.CONFIGS[os.environ.get('CFG', 'metric-M')]
+model = mh.LasModel(bench.build_params(c))
+feats, labels = bench.synthetic_batch(c, 1234, 'cuda')
+feats['encoder_inputs'] = model.listener.pad_features(feats['encoder_inputs'])
+for _ in range(3):
+    model.train_step(feats, labels, num_steps=c['U'])
+torch.cuda.synchronize()
+lib = hip.lib()
+lib.las_debug_read_stamps.argtypes = [C.c_void_p, C.c_int]
+buf = np.zeros(256 * 16, np.uint64)
+hip.check(lib.las_debug_read_stamps(buf.ctypes.data, buf.size))
+U = c['U']
+st = buf.reshape(256, 16)[:U].astype(np.int64)
+names = os.environ.get('NAMES', 'G:operands+MFMA,G:LDS reduce+z granules,S:wait for z+cell,S:sync,S:own scores,S:gather scores,S:softmax,'
+                       'S:context partial,S:reduce+stores,barrier').split(',')
+d = np.diff(st[:, :len(names) + 1], axis=1) / 100.0          # 100 MHz ticks -> us
+print('step time (stamp 0 to stamp 0): %.2f us' % (np.diff(st[:, 0]).mean() / 100.0))
+for k, n in enumerate(names):
+    print('  %-28s %6.2f us  (min %5.2f max %5.2f)' % (n, d[5:, k].mean(), d[5:, k].min(), d[5:, k].max()))
