@@ -922,7 +922,7 @@ __host__ __device__ inline LeanLayout lean_layout(int Hd, int Tm, int M) {
   return l;
 }
 __host__ __device__ inline bool persist_fwd_lean_ok(int Hd, int M, int Tm, int att, int norm) {
-  return (att == LAS_ATT_LUONG || att == LAS_ATT_BAHDANAU) && norm == LAS_NORM_SOFTMAX && Hd <= 256 && Hd % 64 == 0 && M % 32 == 0 &&
+  return (att == LAS_ATT_LUONG || att == LAS_ATT_BAHDANAU) && norm == LAS_NORM_SOFTMAX && (Hd == 128 || Hd == 256) && M % 32 == 0 &&
          lean_layout(Hd, Tm, M).total_bytes <= 158 * 1024;
 }
 
@@ -931,10 +931,10 @@ __device__ __forceinline__ float dot2_bf16(unsigned a, unsigned b, float acc) {
   return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(las_bf16x2, a), __builtin_bit_cast(las_bf16x2, b), acc, false);
 }
 
-template <int ATT>
+template <int ATT, int NTL>             // NTL: 16-column tiles of z per member (decoder_units / 128)
 __global__ __launch_bounds__(256) void dec_persist_fwd_lean_kernel(las_dec_persist p) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
-  constexpr int NTL_MAX = 2, KRES = 12;
+  constexpr int KRES = 12;
   const int B = p.s.B, Hd = p.s.Hd, M = p.s.M, Tm = p.s.Tm, U = p.U;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, lq = lane >> 4;
   const int groups = (B + 7) / 8;
@@ -981,17 +981,17 @@ __global__ __launch_bounds__(256) void dec_persist_fwd_lean_kernel(las_dec_persi
   const bool local = *colo != 0;
 
   // G role: this member's columns of z and its register-resident slice of K ([4Hd, K_in] bf16, row = output column)
-  const int CPM = 4 * Hd / P_MEMBERS, NTL = CPM / 16;
+  constexpr int CPM = NTL * 16;
   const int KC = p.K_in / 32;
-  bf16x8 wf[NTL_MAX][KRES];
+  bf16x8 wf[NTL][KRES];                                    // chunks past the end of K: zero weights (their products add nothing)
 #pragma unroll
-  for (int nt = 0; nt < NTL_MAX; ++nt) {
-    const unsigned short* wrow = p.kT + (int64_t)(member * CPM + min(nt, NTL - 1) * 16 + l15) * p.ldk + 8 * lq;
+  for (int nt = 0; nt < NTL; ++nt) {
+    const unsigned short* wrow = p.kT + (int64_t)(member * CPM + nt * 16 + l15) * p.ldk + 8 * lq;
 #pragma unroll
     for (int i = 0; i < KRES; ++i) {
       const int kc = wave + 4 * i;
       uint4 v = make_uint4(0, 0, 0, 0);
-      if (nt < NTL && kc < KC) v = *reinterpret_cast<const uint4*>(wrow + kc * 32);
+      if (kc < KC) v = *reinterpret_cast<const uint4*>(wrow + kc * 32);
       wf[nt][i] = __builtin_bit_cast(bf16x8, v);
     }
   }
@@ -1022,12 +1022,11 @@ __global__ __launch_bounds__(256) void dec_persist_fwd_lean_kernel(las_dec_persi
   const bool unit = tid < Hd && have;                      // this thread owns hidden unit `tid` of utterance bs
   float bias4[4] = {0.f, 0.f, 0.f, 0.f};
   float c_reg = 0.f;
-  int tok_cur = 0;
+  int tok_cur = p.s.tok_ids[(int64_t)bsc * p.s.tok_stride];          // (every thread: the loads of the loop are unconditional)
   if (unit) {
 #pragma unroll
     for (int g = 0; g < 4; ++g) bias4[g] = p.s.bias[g * Hd + tid];
     c_reg = p.s.c_prev[(int64_t)bs * p.s.ldcp + tid];
-    tok_cur = p.s.tok_ids[(int64_t)bs * p.s.tok_stride];
   }
   const float keep = p.s.drop_keep;
   const int sub = lane & 3, fr = lane >> 2;                // score phase: 4 lanes per frame, 16 frames per wave
@@ -1045,37 +1044,38 @@ __global__ __launch_bounds__(256) void dec_persist_fwd_lean_kernel(las_dec_persi
     const bool last = (t + 1 == U);
     const unsigned xtag = (unsigned)(t + 1);
     // ---- G: z_t[group's utterances, my columns]; its operand row first, everything else of the step behind it ----
-    const unsigned short* arow = p.x + (int64_t)min(bg, B - 1) * p.ldx + (int64_t)t * p.inc_x + 8 * lq;
+    // (no branches around the loads: chunks past the end of K re-read the last one against zero weights, rows of absent
+    //  utterances re-read the last utterance's and are dropped below; a branch would cost a vmcnt(0) at its join)
+    // Rows 8..15 of the 16-row MFMA tile carry nothing (8 utterances per group; their outputs are never read): those
+    // lanes all read one 16-byte piece instead of a second copy of the operand rows.
+    const unsigned short* arow = (l15 < 8) ? p.x + (int64_t)min(bg, B - 1) * p.ldx + (int64_t)t * p.inc_x + 8 * lq : p.x;
+    const int astep = (l15 < 8) ? 32 : 0;
     uint4 av[KRES];
 #pragma unroll
-    for (int i = 0; i < KRES; ++i) {
-      const int kc = wave + 4 * i;
-      av[i] = make_uint4(0, 0, 0, 0);
-      if (kc < KC && bg < B) av[i] = *reinterpret_cast<const uint4*>(arow + kc * 32);
-    }
-    // the token's row of the cell kernel (its id was requested a step ago), and the next step's id
-    float tok4[4] = {0.f, 0.f, 0.f, 0.f};
-    int tok_next = 0;
-    if (unit) {
-#pragma unroll
-      for (int g = 0; g < 4; ++g) tok4[g] = las_bf2f(p.s.tok_rows[(int64_t)tok_cur * 4 * Hd + g * Hd + tid]);
-      if (!last) tok_next = p.s.tok_ids[(int64_t)bs * p.s.tok_stride + (int64_t)(t + 1) * p.inc_tok];
-    }
+    for (int i = 0; i < KRES; ++i) av[i] = *reinterpret_cast<const uint4*>(arow + min(wave + 4 * i, KC - 1) * astep);
+    // the token's row of the cell kernel (its id was requested a step ago; used in the cell phase), and the next step's id
+    unsigned short tokraw[4];
     {
-      f32x4 acc[NTL_MAX];
+      const unsigned short* trow = p.s.tok_rows + (int64_t)tok_cur * 4 * Hd + min(tid, Hd - 1);
 #pragma unroll
-      for (int nt = 0; nt < NTL_MAX; ++nt) acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int g = 0; g < 4; ++g) tokraw[g] = trow[g * Hd];
+    }
+    // every load of the step's head is in flight before the first product instruction (left to itself the scheduler
+    // re-used four registers for the twelve operand pieces: three dependent round trips to L2 instead of one)
+    __builtin_amdgcn_sched_barrier(0);
+    {
+      f32x4 acc[NTL];
+#pragma unroll
+      for (int nt = 0; nt < NTL; ++nt) acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int i = 0; i < KRES; ++i)
 #pragma unroll
-        for (int nt = 0; nt < NTL_MAX; ++nt)
-          if (nt < NTL && wave + 4 * i < KC)
-            acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, av[i]), wf[nt][i], acc[nt], 0, 0, 0);
+        for (int nt = 0; nt < NTL; ++nt)
+          acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, av[i]), wf[nt][i], acc[nt], 0, 0, 0);
 #pragma unroll
-      for (int nt = 0; nt < NTL_MAX; ++nt)
-        if (nt < NTL)
+      for (int nt = 0; nt < NTL; ++nt)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) zred[(wave * 16 + lq * 4 + r) * RS + nt * 16 + l15] = acc[nt][r];
+        for (int r = 0; r < 4; ++r) zred[(wave * 16 + lq * 4 + r) * RS + nt * 16 + l15] = acc[nt][r];
       LAS_STAMP(t, 1);
       __syncthreads();
       for (int e = tid; e < 8 * CPM; e += 256) {
@@ -1088,6 +1088,9 @@ __global__ __launch_bounds__(256) void dec_persist_fwd_lean_kernel(las_dec_persi
       }
     }
     LAS_STAMP(t, 2);
+    // the next step's token id (workgroup-uniform: the compiler moves it to a scalar register, i.e. waits for it at its
+    // first use -- the top of the next step, a whole step away; requested next to the operand loads it stalled them)
+    const int tok_next = p.s.tok_ids[(int64_t)bsc * p.s.tok_stride + (int64_t)min(t + 1, U - 1) * p.inc_tok];
 
     // ---- S: cell + attention of utterance bs, frames / context columns of `part` ----
     if (have) {
@@ -1117,7 +1120,7 @@ __global__ __launch_bounds__(256) void dec_persist_fwd_lean_kernel(las_dec_persi
           tok_scale = las_uniform(p.s.drop_seed, p.s.drop_stream, ((unsigned long long)t * B + bs) * p.s.feed_width + tok_cur) < keep
                           ? 1.0f / keep : 0.f;
 #pragma unroll
-        for (int g = 0; g < 4; ++g) z[g] += bias4[g] + tok_scale * tok4[g];
+        for (int g = 0; g < 4; ++g) z[g] += bias4[g] + tok_scale * las_bf2f(tokraw[g]);
         const float gi = las_sigmoid(z[0]), gj = las_tanh(z[1]), gf = las_sigmoid(z[2] + 1.0f), go = las_sigmoid(z[3]);
         const float cn = gf * c_reg + gi * gj;
         c_reg = cn;
@@ -2349,13 +2352,21 @@ extern "C" int las_decoder_persist_fwd(const las_dec_persist* p, void* stream) {
       p->K_in / 32 <= 48) {
     static bool lean_attr = false;
     if (!lean_attr) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dec_persist_fwd_lean_kernel<LAS_ATT_LUONG>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dec_persist_fwd_lean_kernel<LAS_ATT_BAHDANAU>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dec_persist_fwd_lean_kernel<LAS_ATT_LUONG, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dec_persist_fwd_lean_kernel<LAS_ATT_LUONG, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dec_persist_fwd_lean_kernel<LAS_ATT_BAHDANAU, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dec_persist_fwd_lean_kernel<LAS_ATT_BAHDANAU, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
       lean_attr = true;
     }
     const size_t lbytes = lean_layout(s->Hd, s->Tm, s->M).total_bytes;
-    if (s->attention == LAS_ATT_LUONG) hipLaunchKernelGGL((dec_persist_fwd_lean_kernel<LAS_ATT_LUONG>), grid, dim3(256), lbytes, st, *p);
-    else hipLaunchKernelGGL((dec_persist_fwd_lean_kernel<LAS_ATT_BAHDANAU>), grid, dim3(256), lbytes, st, *p);
+    const bool two = s->Hd == 256;           // 4 Hd / 32 columns per member = one or two 16-column tiles
+    if (s->attention == LAS_ATT_LUONG) {
+      if (two) hipLaunchKernelGGL((dec_persist_fwd_lean_kernel<LAS_ATT_LUONG, 2>), grid, dim3(256), lbytes, st, *p);
+      else hipLaunchKernelGGL((dec_persist_fwd_lean_kernel<LAS_ATT_LUONG, 1>), grid, dim3(256), lbytes, st, *p);
+    } else {
+      if (two) hipLaunchKernelGGL((dec_persist_fwd_lean_kernel<LAS_ATT_BAHDANAU, 2>), grid, dim3(256), lbytes, st, *p);
+      else hipLaunchKernelGGL((dec_persist_fwd_lean_kernel<LAS_ATT_BAHDANAU, 1>), grid, dim3(256), lbytes, st, *p);
+    }
     LAS_LAUNCH_CHECK("persistent decoder fwd launch");
     return LAS_OK;
   }
