@@ -1176,8 +1176,7 @@ __global__ __launch_bounds__(256) void dec_persist_fwd_lean_kernel(las_dec_persi
                 }
               }
           }
-          acc += __shfl_xor(acc, 1, 64);
-          acc += __shfl_xor(acc, 2, 64);
+          acc = las_quad_sum(acc);
           if (sub == 0 && fl < fq && tf < f1) {
             const float sv = (tf < len) ? acc : -INFINITY;
             pgranule_store(xsc + tf, xtag, sv, local);     // the other three parts are waiting for it
@@ -1203,29 +1202,30 @@ __global__ __launch_bounds__(256) void dec_persist_fwd_lean_kernel(las_dec_persi
       }
       __syncthreads();
       LAS_STAMP(t, 6);
-      // ---- masked softmax over the frames ----
+      // ---- masked softmax over the frames: every wave reduces its own elements (max, then the sum relative to that
+      //      max); the four (max, sum) pairs meet in LDS behind ONE barrier and every thread rescales ----
       {
-        float mx = -INFINITY;
-        for (int tf = tid; tf < Tm; tf += 256) mx = fmaxf(mx, sc[tf]);
-        mx = las_wave_max(mx);
-        if (lane == 0) red[wave] = mx;
-        __syncthreads();
-        mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
-        float sum = 0.f;
+        float mw = -INFINITY;
+        for (int tf = tid; tf < Tm; tf += 256) mw = fmaxf(mw, sc[tf]);
+        mw = las_wave_max_dpp(mw);
+        float sw = 0.f;
         for (int tf = tid; tf < Tm; tf += 256) {
-          const float e = (tf < len) ? __expf(sc[tf] - mx) : 0.f;
+          const float e = (tf < len) ? __expf(sc[tf] - mw) : 0.f;
           sc[tf] = e;
-          sum += e;
+          sw += e;
         }
-        sum = las_wave_sum(sum);
-        if (lane == 0) red[4 + wave] = sum;
+        sw = las_wave_sum_dpp(sw);
+        if (lane == 0) { red[wave] = mw; red[4 + wave] = sw; }
         __syncthreads();
-        sum = red[4] + red[5] + red[6] + red[7];
-        const float inv = len > 0 ? 1.0f / sum : 0.f;
+        const float mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+        float sum = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) sum += red[4 + w] > 0.f ? red[4 + w] * __expf(red[w] - mx) : 0.f;
+        const float scale = (len > 0 && sw > 0.f) ? __expf(mw - mx) / sum : 0.f;
         float* const arow_out = p.s.align_out + (int64_t)bs * p.s.lda + (int64_t)t * p.inc_align;
         unsigned short* const abf = p.s.align_bf16 ? p.s.align_bf16 + (int64_t)bs * p.s.lda + (int64_t)t * p.inc_align : nullptr;
         for (int tf = tid; tf < Tm; tf += 256) {
-          const float pr = sc[tf] * inv;
+          const float pr = sc[tf] * scale;
           sc[tf] = pr;
           if (tf >= f0 && tf < f1) {                       // every part saves its own frames
             arow_out[tf] = pr;
@@ -1243,16 +1243,16 @@ __global__ __launch_bounds__(256) void dec_persist_fwd_lean_kernel(las_dec_persi
         if (ccl * 8 < ncols) {
           const lds_cu16 vcol = (lds_cu16)lv + ccl * 8;
           int tf = cphase;
-          for (; tf + 3 * Pc < len; tf += 4 * Pc) {
-            uint4 vv[4];
-            float pr[4];
+          for (; tf + 7 * Pc < len; tf += 8 * Pc) {
+            uint4 vv[8];
+            float pr[8];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
+            for (int i = 0; i < 8; ++i) {
               vv[i] = ld16(vcol + (size_t)(tf + i * Pc) * cols_per);
               pr[i] = sc[tf + i * Pc];
             }
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
+            for (int i = 0; i < 8; ++i) {
               const unsigned short* e = reinterpret_cast<const unsigned short*>(&vv[i]);
 #pragma unroll
               for (int j = 0; j < 8; ++j) a[j] += pr[i] * las_bf2f(e[j]);

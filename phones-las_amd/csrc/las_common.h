@@ -58,6 +58,38 @@ __device__ __forceinline__ float las_wave_max(float v) {
   return v;
 }
 
+// The same reductions on the DPP path (no LDS permutes: a shuffle is a ds_bpermute round trip of ~100 cycles, a DPP operand
+// costs nothing): two quad_perm steps, row_half_mirror, row_mirror give every lane its 16-lane row's result, the four rows
+// meet through readlane.  Sums add in a different order than las_wave_sum.
+template <int CTRL>
+__device__ __forceinline__ float las_dpp(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float las_quad_sum(float v) {       // every lane: the sum over its quad (lanes 4k .. 4k+3)
+  v += las_dpp<0xB1>(v);      // quad_perm:[1,0,3,2]
+  v += las_dpp<0x4E>(v);      // quad_perm:[2,3,0,1]
+  return v;
+}
+__device__ __forceinline__ float las_wave_sum_dpp(float v) {
+  v = las_quad_sum(v);
+  v += las_dpp<0x141>(v);     // row_half_mirror
+  v += las_dpp<0x140>(v);     // row_mirror
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 0)) +
+         __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 16)) +
+         __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 32)) +
+         __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 48));
+}
+__device__ __forceinline__ float las_wave_max_dpp(float v) {
+  v = fmaxf(v, las_dpp<0xB1>(v));
+  v = fmaxf(v, las_dpp<0x4E>(v));
+  v = fmaxf(v, las_dpp<0x141>(v));
+  v = fmaxf(v, las_dpp<0x140>(v));
+  return fmaxf(fmaxf(__builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 0)),
+                     __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 16))),
+               fmaxf(__builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 32)),
+                     __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 48))));
+}
+
 // counter-based uniform generator shared by the dropout / sampling kernels (rng.hip, decoder.hip)
 __device__ __forceinline__ unsigned las_mix32(unsigned x) {
   x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;

@@ -177,8 +177,9 @@ def test_persistent_decoder_matches_per_step_launches_at_the_benchmarked_shape(m
     times) against the per-step launches on the same inputs, and against itself.
       * two persistent runs are BIT-identical (logits and every gradient whose reduction order is fixed): no exchange
         of the launch depends on timing;
-      * step 0 agrees with the per-step path to fp32 rounding (same arithmetic; the four frame shares add their softmax
-        sums in another order);
+      * step 0 agrees with the per-step path to rounding: the one-launch kernel writes the step out with its own
+        arithmetic (v_dot2c scores, per-wave softmax partials, DPP sums), so fp32 values differ in the last bits and a
+        context element may round to the neighbouring bf16 (one such flip is ~1e-4 of the largest logit);
       * later steps: a 1-ulp fp32 difference flips a bf16 rounding of h_t / context now and then, and the flip feeds the
         next step -- over 80 steps the two paths drift apart by a few 1e-4 of the largest logit (measured 4.7e-4), both
         inside the 2e-2 tolerance against the fixture."""
@@ -205,7 +206,7 @@ def test_persistent_decoder_matches_per_step_launches_at_the_benchmarked_shape(m
     print(json.dumps({'persist_run_to_run_grad': run_to_run, 'persist_vs_per_step_logits_step0': d_step0,
                       'persist_vs_per_step_logits': d_logits, 'persist_vs_per_step_grad_worst': list(worst)}))
     assert run_to_run < 1e-5          # (split-K atomics of the speller's weight-gradient products: fp32 summation order)
-    assert d_step0 < 1e-5
+    assert d_step0 < 5e-4
     assert d_logits < 2e-3
     assert worst[0] < 5e-3, worst
     V, tl, ref = 64, nb['target_sequence_length'], g['bf16_logits']
