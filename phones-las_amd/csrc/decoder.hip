@@ -159,10 +159,12 @@ __device__ __forceinline__ uint4 ld16(lds_cu16 p) {
 
 #ifdef LAS_STAMPS
 // diagnostics build (LAS_CXXFLAGS=-DLAS_STAMPS): wall-clock (100 MHz) stamps of the phases of every step of workgroup 0
-__device__ unsigned long long las_stamps[256 * 16];
+__device__ unsigned long long las_stamps[2 * 256 * 16];        // forward launch, then backward launch
 #define LAS_STAMP(step, k) do { if (blockIdx.x == 0 && threadIdx.x == 0 && (step) < 256) las_stamps[(step) * 16 + (k)] = wall_clock64(); } while (0)
+#define LAS_STAMPB(step, k) do { if (blockIdx.x == 0 && threadIdx.x == 0 && (step) < 256) las_stamps[4096 + (step) * 16 + (k)] = wall_clock64(); } while (0)
 #else
 #define LAS_STAMP(step, k) do { } while (0)
+#define LAS_STAMPB(step, k) do { } while (0)
 #endif
 
 struct PersistHook {
@@ -1047,8 +1049,10 @@ __global__ __launch_bounds__(256) void dec_persist_fwd_lean_kernel(las_dec_persi
     // (no branches around the loads: chunks past the end of K re-read the last one against zero weights, rows of absent
     //  utterances re-read the last utterance's and are dropped below; a branch would cost a vmcnt(0) at its join)
     // Rows 8..15 of the 16-row MFMA tile carry nothing (8 utterances per group; their outputs are never read): those
-    // lanes all read one 16-byte piece instead of a second copy of the operand rows.
-    const unsigned short* arow = (l15 < 8) ? p.x + (int64_t)min(bg, B - 1) * p.ldx + (int64_t)t * p.inc_x + 8 * lq : p.x;
+    // lanes all read one 16-byte piece of zeros (workspace header, words 4..7: never written) instead of a second copy of
+    // the operand rows.
+    const unsigned short* arow = (l15 < 8) ? p.x + (int64_t)min(bg, B - 1) * p.ldx + (int64_t)t * p.inc_x + 8 * lq
+                                           : reinterpret_cast<const unsigned short*>(reinterpret_cast<const char*>(p.workspace) + 16);
     const int astep = (l15 < 8) ? 32 : 0;
     uint4 av[KRES];
 #pragma unroll
@@ -1610,7 +1614,7 @@ __global__ __launch_bounds__(256) void dec_step_bwd_kernel(las_dec_step_bwd s) {
 //       tiles j, j+32, j+64 (its rows of K register-resident as MFMA B fragments)                          | barrier
 // Every exchanged tensor has its own rows per step (no address is re-read after being rewritten).
 // ------------------------------------------------------------------------------------------------
-template <bool WQ>
+template <bool WQ, int NPQ = 0>       // NPQ = M / 128 when the written-out d(alignments) pass applies (LDS-resident frames, M = 512 or 1024), else 0
 __global__ __launch_bounds__(256) void dec_persist_bwd_kernel(las_dec_persist_bwd p) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   constexpr int NT_MAX = 3, KCW_MAX = 8;
@@ -1721,6 +1725,7 @@ __global__ __launch_bounds__(256) void dec_persist_bwd_kernel(las_dec_persist_bw
   float dv_tot[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   for (int t = p.U - 1; t >= 0; --t) {
     const bool first = (t == p.U - 1);
+    LAS_STAMPB(p.U - 1 - t, 0);
     const float* dfeed_next = first ? nullptr : p.dfeed_all + (int64_t)(t + 1) * B * W;      // written by step t+1
     float sg[4] = {0.f, 0.f, 0.f, 0.f}, sct = 0.f, scp = 0.f, sdf = 0.f;
     if (cellw) {
@@ -1763,6 +1768,7 @@ __global__ __launch_bounds__(256) void dec_persist_bwd_kernel(las_dec_persist_bw
           __builtin_amdgcn_s_sleep(1);
         }
       }
+      LAS_STAMPB(p.U - 1 - t, 1);
 #pragma unroll
       for (int i = 0; i < PD; ++i) {
         const int m = tid + i * 256;
@@ -1785,9 +1791,48 @@ __global__ __launch_bounds__(256) void dec_persist_bwd_kernel(las_dec_persist_bw
         for (int tt = f0 + 256 + tid; tt < f1; tt += 256) alg[tt] = tt < len ? arow[tt] : 0.f;
       }
       __syncthreads();
+      LAS_STAMPB(p.U - 1 - t, 2);
       {
         const int sub = lane & 15, grp = lane >> 4;
         // rows: the frames' value rows, from LDS (row 0 = frame f0) or from memory (row 0 = frame 0)
+        // the fast form (M = 128 * NP, NP <= 8): this lane's pieces of d(context) are the same for every frame -- they
+        // are read from LDS once, not once per frame (halves the LDS traffic of the pass) -- and the 16 lanes of a frame
+        // meet through DPP instead of four LDS permutes
+        constexpr int NP = NPQ > 0 ? NPQ : 1;
+        constexpr bool fast = NPQ > 0;
+        if constexpr (fast) {
+          float dcr8[NP][8];
+          constexpr int np = NP;
+#pragma unroll
+          for (int q = 0; q < NP; ++q)
+            if (q < np) {
+              const float4 x0 = *reinterpret_cast<const float4*>(dctx + sub * 8 + q * 128);
+              const float4 x1 = *reinterpret_cast<const float4*>(dctx + sub * 8 + q * 128 + 4);
+              dcr8[q][0] = x0.x; dcr8[q][1] = x0.y; dcr8[q][2] = x0.z; dcr8[q][3] = x0.w;
+              dcr8[q][4] = x1.x; dcr8[q][5] = x1.y; dcr8[q][6] = x1.z; dcr8[q][7] = x1.w;
+            }
+          for (int t0 = f0; t0 < f1; t0 += 16) {
+            const int ta = t0 + wave * 4 + grp;
+            const bool oa = ta < flen;
+            const lds_cu16 ra = (lds_cu16)lvals + (size_t)(oa ? ta - f0 : 0) * M + sub * 8;
+            uint4 va[NP];
+#pragma unroll
+            for (int q = 0; q < NP; ++q)
+              if (q < np) va[q] = ld16(ra + q * 128);
+            float acc_a = 0.f;
+#pragma unroll
+            for (int q = 0; q < NP; ++q)
+              if (q < np) {
+                const unsigned short* e = reinterpret_cast<const unsigned short*>(&va[q]);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc_a += las_bf2f(e[j]) * dcr8[q][j];
+              }
+            acc_a = las_quad_sum(acc_a);
+            acc_a += las_dpp<0x141>(acc_a);       // row_half_mirror
+            acc_a += las_dpp<0x140>(acc_a);       // row_mirror: every lane of the 16-lane row holds the frame's sum
+            if (sub == 0 && ta < f1) dal[ta] = oa ? acc_a : 0.f;
+          }
+        }
         auto dalign_pass = [&](const unsigned short* rows, int row0) {
           for (int t0 = f0; t0 < f1; t0 += 32) {
             const int ta = t0 + wave * 4 + grp, tb = ta + 16;
@@ -1813,15 +1858,18 @@ __global__ __launch_bounds__(256) void dec_persist_bwd_kernel(las_dec_persist_bw
             }
           }
         };
-        if (resident) dalign_pass(lvals, f0);
+        if constexpr (fast) { }
+        else if (resident) dalign_pass(lvals, f0);
         else dalign_pass(vals, 0);
       }
       __syncthreads();
+      LAS_STAMPB(p.U - 1 - t, 3);
       float dot = 0.f;
       for (int tt = f0 + tid; tt < flen; tt += 256) dot += alg[tt] * dal[tt];
       dot = block_reduce(dot, red, false);
       if (tid == 0) pgranule_store(xdot + ((size_t)(xtag & 1) * B + b) * 4 + part, xtag, dot, local);
     }
+    LAS_STAMPB(p.U - 1 - t, 4);
     // ---- S2 ----  (the four partial dots meet as granules: no group barrier)
     if (active) {
       if (tid < 64) {
@@ -1838,6 +1886,7 @@ __global__ __launch_bounds__(256) void dec_persist_bwd_kernel(las_dec_persist_bw
         if (lane == 0) red[0] = d0 + d1 + d2 + d3;
       }
       __syncthreads();
+      LAS_STAMPB(p.U - 1 - t, 5);
       const float dot = red[0];
       unsigned short* dso = s0.ds_out + (int64_t)b * s0.ldso + (int64_t)t * p.inc_ds;
       for (int tt = f0 + tid; tt < f1; tt += 256) {
@@ -1846,6 +1895,7 @@ __global__ __launch_bounds__(256) void dec_persist_bwd_kernel(las_dec_persist_bw
         dso[tt] = las_f2bf(v);
       }
       __syncthreads();
+      LAS_STAMPB(p.U - 1 - t, 6);
       const int L = Hd / 8, P = 256 / L;
       const int phase = tid / L, u = (tid % L) * 8;
       float a[8];
@@ -1912,6 +1962,7 @@ __global__ __launch_bounds__(256) void dec_persist_bwd_kernel(las_dec_persist_bw
 #pragma unroll
       for (int j = 0; j < 8; ++j) dhs[phase * Hd + u + j] = a[j];
       __syncthreads();
+      LAS_STAMPB(p.U - 1 - t, 7);
       // partial dh of this workgroup's frames (unit = threadIdx.x; Hd <= 256): parts 1..3 send theirs to part 0 as granules
       float dh_own = 0.f;
       if (tid < Hd)
@@ -1975,30 +2026,37 @@ __global__ __launch_bounds__(256) void dec_persist_bwd_kernel(las_dec_persist_bw
         zp[0] = las_f2bf(di); zp[Hd] = las_f2bf(dj); zp[2 * Hd] = las_f2bf(df); zp[3 * Hd] = las_f2bf(dov);
       }
     }
+    LAS_STAMPB(p.U - 1 - t, 8);
     if (!persist_barrier(flags, member, ++epoch, local, fail)) break;
+    LAS_STAMPB(p.U - 1 - t, 9);
     // ---- G: dfeed_t[group's utterances, my column tiles] = dz_t K^T ----
     {
       f32x4 acc[NT_MAX];
 #pragma unroll
       for (int j = 0; j < NT_MAX; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-      const unsigned short* zrow = s0.dz + (int64_t)min(bg, B - 1) * s0.ldz + (int64_t)t * p.inc_dz + 8 * lq;
+      // no branches around the loads or the products (a branch costs a vmcnt(0) at its join and the scheduler then
+      // re-uses a few registers for the operand pieces: dependent round trips to L2): chunks past the end of K re-read the
+      // last one against zero weights, absent tiles multiply zero weights, absent utterances' rows are dropped below,
+      // and rows 8..15 of the MFMA tile (never read) all load one piece
+      // (those lanes read 16 zero bytes of the workspace header: words 4..7 are never written.  Zeros, not "anything":
+      //  with uninitialised memory there -- NaN / Inf patterns -- the gradients came out wrong in the full test run)
+      const unsigned short* zrow = (l15 < 8) ? s0.dz + (int64_t)min(bg, B - 1) * s0.ldz + (int64_t)t * p.inc_dz + 8 * lq
+                                             : reinterpret_cast<const unsigned short*>(reinterpret_cast<const char*>(p.workspace) + 16);
+      const int zstep = (l15 < 8) ? 32 : 0;
       uint4 av[KCW_MAX];
 #pragma unroll
-      for (int i = 0; i < KCW_MAX; ++i) {
-        const int kc = wave + 4 * i;
-        av[i] = make_uint4(0, 0, 0, 0);
-        if (kc < KC && bg < B) av[i] = *reinterpret_cast<const uint4*>(zrow + kc * 32);
-      }
+      for (int i = 0; i < KCW_MAX; ++i) av[i] = *reinterpret_cast<const uint4*>(zrow + min(wave + 4 * i, KC - 1) * zstep);
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int i = 0; i < KCW_MAX; ++i)
 #pragma unroll
         for (int j = 0; j < NT_MAX; ++j)
-          if (member + 32 * j < NTW && wave + 4 * i < KC)
-            acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, av[i]), wf[j][i], acc[j], 0, 0, 0);
+          acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, av[i]), wf[j][i], acc[j], 0, 0, 0);
 #pragma unroll
       for (int j = 0; j < NT_MAX; ++j)
 #pragma unroll
         for (int r = 0; r < 4; ++r) red2[(wave * 16 + lq * 4 + r) * 49 + j * 16 + l15] = acc[j][r];
+      LAS_STAMPB(p.U - 1 - t, 10);
       __syncthreads();
       float* df = p.dfeed_all + (int64_t)t * B * W;
       for (int e = tid; e < 8 * 48; e += 256) {
@@ -2418,16 +2476,30 @@ extern "C" int las_decoder_persist_bwd(const las_dec_persist_bwd* p, void* strea
   size_t lds = persist_bwd_scratch_floats(s->M, s->Hd, s->Tm) * sizeof(float);
   LAS_REQUIRE(lds <= 64 * 1024, "las_decoder_persist_bwd: shapes exceed the LDS budget");
   if (persist_bwd_resident(s->M, s->Hd, s->Tm)) lds += persist_bwd_resident_bytes(s->M, s->Hd, s->Tm);
-  static size_t lds_attr = 64 * 1024;
-  if (lds > lds_attr) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dec_persist_bwd_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dec_persist_bwd_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    lds_attr = 160 * 1024;
+  const bool res = persist_bwd_resident(s->M, s->Hd, s->Tm);
+  const int npq = (res && (s->M == 512 || s->M == 1024)) ? s->M / 128 : 0;
+  const dim3 grid(((groups + 7) & ~7) * P_MEMBERS);
+  const bool wq = s->attention != LAS_ATT_LUONG;
+#define LAS_BWD_LAUNCH(WQ_, NPQ_)                                                                                               \
+  do {                                                                                                                          \
+    static bool attr = false;                                                                                                   \
+    if (!attr) {                                                                                                                \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dec_persist_bwd_kernel<WQ_, NPQ_>),                              \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                                        \
+      attr = true;                                                                                                              \
+    }                                                                                                                           \
+    hipLaunchKernelGGL((dec_persist_bwd_kernel<WQ_, NPQ_>), grid, dim3(256), lds, st, *p);                                      \
+  } while (0)
+  if (wq) {
+    if (npq == 8) LAS_BWD_LAUNCH(true, 8);
+    else if (npq == 4) LAS_BWD_LAUNCH(true, 4);
+    else LAS_BWD_LAUNCH(true, 0);
+  } else {
+    if (npq == 8) LAS_BWD_LAUNCH(false, 8);
+    else if (npq == 4) LAS_BWD_LAUNCH(false, 4);
+    else LAS_BWD_LAUNCH(false, 0);
   }
-  if (s->attention == LAS_ATT_LUONG)
-    hipLaunchKernelGGL(dec_persist_bwd_kernel<false>, dim3(((groups + 7) & ~7) * P_MEMBERS), dim3(256), lds, st, *p);
-  else
-    hipLaunchKernelGGL(dec_persist_bwd_kernel<true>, dim3(((groups + 7) & ~7) * P_MEMBERS), dim3(256), lds, st, *p);
+#undef LAS_BWD_LAUNCH
   LAS_LAUNCH_CHECK("persistent decoder bwd launch");
   return LAS_OK;
 }

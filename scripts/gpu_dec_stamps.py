@@ -15,13 +15,17 @@ for _ in range(3):
 torch.cuda.synchronize()
 lib = hip.lib()
 lib.las_debug_read_stamps.argtypes = [C.c_void_p, C.c_int]
-buf = np.zeros(256 * 16, np.uint64)
+buf = np.zeros(2 * 256 * 16, np.uint64)
 hip.check(lib.las_debug_read_stamps(buf.ctypes.data, buf.size))
 U = c['U']
-st = buf.reshape(256, 16)[:U].astype(np.int64)
-names = os.environ.get('NAMES', 'G:operands+MFMA,G:LDS reduce+z granules,S:wait for z+cell,S:sync,S:own scores,S:gather scores,S:softmax,'
-                       'S:context partial,S:reduce+stores,barrier').split(',')
-d = np.diff(st[:, :len(names) + 1], axis=1) / 100.0          # 100 MHz ticks -> us
-print('step time (stamp 0 to stamp 0): %.2f us' % (np.diff(st[:, 0]).mean() / 100.0))
-for k, n in enumerate(names):
-    print('  %-28s %6.2f us  (min %5.2f max %5.2f)' % (n, d[5:, k].mean(), d[5:, k].min(), d[5:, k].max()))
+NAMES = {'forward': 'G:operands+MFMA,G:LDS reduce+z granules,S:wait for z+cell,S:sync,S:own scores,S:gather scores,S:softmax,'
+                    'S:context partial,S:reduce+stores,barrier',
+         'backward': 'top: saved-value requests + wait for d(feed),S1:d(context) row,S1:d(align) over own frames,S1:dot reduce + granule,'
+                     'S2:wait for the dots,S2:ds,S2:dh over own keys,S3:partials + cell (part 0),barrier,G:operands+MFMA,G:granules'}
+for which, off in (('forward', 0), ('backward', 256)):
+    st = buf.reshape(512, 16)[off:off + U].astype(np.int64)
+    names = NAMES[which].split(',')
+    d = np.diff(st[:, :len(names) + 1], axis=1) / 100.0          # 100 MHz ticks -> us
+    print('%s: step time (stamp 0 to stamp 0): %.2f us' % (which, np.diff(st[:, 0]).mean() / 100.0))
+    for k, n in enumerate(names[:d.shape[1]]):
+        print('  %-44s %6.2f us  (min %5.2f max %5.2f)' % (n, d[5:-1, k].mean(), d[5:-1, k].min(), d[5:-1, k].max()))
