@@ -34,6 +34,15 @@ typedef __attribute__((address_space(1))) u64 gu64;
 
 constexpr unsigned SPIN_LIMIT = 1u << 20;
 
+#ifdef LAS_STAMPS
+// diagnostics build (LAS_CXXFLAGS=-DLAS_STAMPS): wall-clock (100 MHz) stamps of the phases of the first 256 steps of workgroup 0
+// (forward launch: [0, 2048), backward launch: [2048, 4096)); scripts/gpu_lstm_stamps.py
+__device__ unsigned long long las_lstm_stamps[2 * 256 * 8];
+#define LSTM_STAMP(off, step, k) do { if (blockIdx.x == 0 && threadIdx.x == 0 && (step) < 256) las_lstm_stamps[(off) + (step) * 8 + (k)] = wall_clock64(); } while (0)
+#else
+#define LSTM_STAMP(off, step, k) do { } while (0)
+#endif
+
 // Workgroup barrier that only orders LDS traffic.  __syncthreads() also drains vmcnt, i.e. waits until every global
 // store of the step has been acknowledged, which puts that round trip on the critical path of every step.
 __device__ __forceinline__ void lds_barrier() {
@@ -320,6 +329,7 @@ __global__ __launch_bounds__(256) void lstm_fwd_kernel(float* __restrict__ xproj
         rowoff[r] = act[r] ? ((int64_t)bidx[r] * T + pos) : 0;
       }
     }
+    LSTM_STAMP(0, s, 0);
     // x_t K_x + b of this step: issued now, consumed after the MFMAs
     float4 xp[UB][RL];
 #pragma unroll
@@ -362,8 +372,10 @@ __global__ __launch_bounds__(256) void lstm_fwd_kernel(float* __restrict__ xproj
         }
       }
     }
+    LSTM_STAMP(0, s, 1);
     flush_pending();                          // the previous step's stores, now that this step's polls are served
     lds_barrier();
+    LSTM_STAMP(0, s, 2);
     if (fail_flag) return false;
 
     f32x4 acc[4][UB];
@@ -392,6 +404,7 @@ __global__ __launch_bounds__(256) void lstm_fwd_kernel(float* __restrict__ xproj
         for (int g = 0; g < 4; ++g) acc[g][0] += rbuf[((wave & 1) * 4 + g) * 64 + lane];
       }
     }
+    LSTM_STAMP(0, s, 3);
     if (lead) {
       u64* dst = ex_group + (int64_t)(s & 1) * par_stride + (int64_t)member * NGRAN;
       float4 gsave[UB][RL];
@@ -426,6 +439,7 @@ __global__ __launch_bounds__(256) void lstm_fwd_kernel(float* __restrict__ xproj
                           (unsigned)hb[2 * rp] | (GV == 2 ? (unsigned)hb[(2 * rp + 1) % RL] << 16 : 0u), local);
         }
       }
+      LSTM_STAMP(0, s, 4);
 #pragma unroll
       for (int ub = 0; ub < UB; ++ub) {
         const int unit = unit0 + ub * 16;
@@ -454,6 +468,7 @@ __global__ __launch_bounds__(256) void lstm_fwd_kernel(float* __restrict__ xproj
       for (int r = 0; r < RL; ++r) xoff[r] += (unsigned)xstep;
     }
     cur ^= 1;
+    LSTM_STAMP(0, s, 5);
     return true;
   };
 
@@ -748,6 +763,7 @@ __global__ __launch_bounds__(256) void lstm_bwd_kernel(const float* __restrict__
   prepare();
   for (int s = smax - 1; s >= 0 && ok; --s) {
     const bool lean = s < smin;              // every row of the slice is running at step s
+    LSTM_STAMP(2048, smax - 1 - s, 0);
     // ---- dh_s: own partial + the peers' (sent in the previous iteration, i.e. for time step s) ----
     if (epoch > 0) {
       float cand[UBW][RPL];
@@ -789,6 +805,7 @@ __global__ __launch_bounds__(256) void lstm_bwd_kernel(const float* __restrict__
           if (s + 1 < len[r]) dh[ub][r] = cand[ub][r];        // rows that were running at step s+1
     }
 
+    LSTM_STAMP(2048, smax - 1 - s, 1);
     // next step's operands first: in flight during the gate math, the product and the exchange, and ahead of this
     // step's dz stores in the in-order vector-memory queue
     unsigned zoff[RPL];
@@ -802,6 +819,7 @@ __global__ __launch_bounds__(256) void lstm_bwd_kernel(const float* __restrict__
       if (s - 1 < smin - 1) load_lean(s - 1);
       else load_general(s - 1);
     }
+    LSTM_STAMP(2048, smax - 1 - s, 2);
     // ---- gate derivatives of step s -> dz (LDS tile for the product, HBM for the weight-gradient GEMMs) ----
     unsigned short* zl = &ztile[cur][0][0];
 #pragma unroll
@@ -831,7 +849,9 @@ __global__ __launch_bounds__(256) void lstm_bwd_kernel(const float* __restrict__
         *reinterpret_cast<uint2*>(zl + (lq * 4 + hh * RPL + r) * ZS + (unit - member * HS) * 4) = zv;   // [row][u*4+g]
       }
     }
+    LSTM_STAMP(2048, smax - 1 - s, 3);
     lds_barrier();
+    LSTM_STAMP(2048, smax - 1 - s, 4);
     if (fail_flag) { ok = false; break; }
     if (s == 0) break;                       // dh_{-1} is not needed
 
@@ -859,11 +879,13 @@ __global__ __launch_bounds__(256) void lstm_bwd_kernel(const float* __restrict__
     for (int j = 0; j < (G > 1 ? OWN : NT); ++j)
 #pragma unroll
       for (int kc = 0; kc < KCW; ++kc) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afr[kc], wf[j][kc], acc[j], 0, 0, 0);
+    LSTM_STAMP(2048, smax - 1 - s, 5);
 #pragma unroll
     for (int ub = 0; ub < OWN; ++ub)
 #pragma unroll
       for (int r = 0; r < RPL; ++r) part[ub][r] = acc[ub][r];
     prepare();                               // coefficients of step s-1 (its operands were loaded above)
+    LSTM_STAMP(2048, smax - 1 - s, 6);
     ++epoch;
     cur ^= 1;
   }
@@ -1082,3 +1104,9 @@ extern "C" int las_lstm_recurrent_bwd(const float* gates, const float* cbuf, con
     default: return launch_bwd<256>(gates, cbuf, dy, dc_last, dh_last, kh_bf16, length, dz, workspace, B, T, ndir, st);
   }
 }
+
+#ifdef LAS_STAMPS
+extern "C" int las_debug_read_lstm_stamps(unsigned long long* out_host, int n) {
+  return las_check_hip(hipMemcpyFromSymbol(out_host, HIP_SYMBOL(las_lstm_stamps), sizeof(unsigned long long) * (size_t)n), "read stamps");
+}
+#endif
