@@ -564,7 +564,7 @@ constexpr int P_MEMBERS = 32;
 __host__ __device__ inline size_t persist_flag_words(int B) { return (size_t)((B + 7) / 8) * 2 * P_MEMBERS; }
 __host__ __device__ inline size_t persist_exchange_words(int B, int Tm, int Hd, int M) {
   const size_t ld = (size_t)((Tm + 31) / 32) * 32;
-  const size_t fwd = 2 * (size_t)B * (ld + 4 * (size_t)Hd), bwd = 2 * (size_t)B * (4 + 3 * (size_t)Hd + (size_t)(M + Hd));
+  const size_t fwd = 2 * (size_t)B * (ld + 5 * (size_t)Hd), bwd = 2 * (size_t)B * (4 + 3 * (size_t)Hd + (size_t)(M + Hd));
   return fwd > bwd ? fwd : bwd;
 }
 // forward: scratch, and this workgroup's score frames of the keys [fq, Hd] + its context columns of the values [Tm, M/4]
@@ -910,7 +910,7 @@ __host__ __device__ inline LeanLayout lean_layout(int Hd, int Tm, int M) {
   l.sc = o; o += (size_t)((Tm + 3) & ~3);
   l.red = o; o += 16;
   l.cred = o; o += 2048;
-  l.zred = o; o += (size_t)4 * 16 * persist_red_stride(Hd);
+  l.zred = o; o += (size_t)4 * 8 * persist_red_stride(Hd);      // [4 waves][8 utterances][columns per member + 1]
   l.flags = o; o += 8;
   l.hqb = o; o += Hd / 2;
   o = (o + 3) & ~(size_t)3;
@@ -924,7 +924,7 @@ __host__ __device__ inline LeanLayout lean_layout(int Hd, int Tm, int M) {
   return l;
 }
 __host__ __device__ inline bool persist_fwd_lean_ok(int Hd, int M, int Tm, int att, int norm) {
-  return (att == LAS_ATT_LUONG || att == LAS_ATT_BAHDANAU) && norm == LAS_NORM_SOFTMAX && (Hd == 128 || Hd == 256) && M % 32 == 0 &&
+  return (att == LAS_ATT_LUONG || att == LAS_ATT_BAHDANAU) && norm == LAS_NORM_SOFTMAX && (Hd == 128 || Hd == 256 || Hd == 512) && M % 32 == 0 &&
          lean_layout(Hd, Tm, M).total_bytes <= 158 * 1024;
 }
 
@@ -933,10 +933,13 @@ __device__ __forceinline__ float dot2_bf16(unsigned a, unsigned b, float acc) {
   return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(las_bf16x2, a), __builtin_bit_cast(las_bf16x2, b), acc, false);
 }
 
-template <int ATT, int NTL>             // NTL: 16-column tiles of z per member (decoder_units / 128)
+// NTL: 16-column tiles of z per member (decoder_units / 128: 1, 2 or 4).  KRES of the KCWM 32-deep K chunks a wave owns stay in
+// registers as MFMA B fragments; the chunks beyond (512 units: 12 of 20) are streamed from L2 at every step, three in flight.
+template <int ATT, int NTL, int KRES = 12, int KCWM = 12>
 __global__ __launch_bounds__(256) void dec_persist_fwd_lean_kernel(las_dec_persist p) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
-  constexpr int KRES = 12;
+  constexpr int UPT = NTL == 4 ? 2 : 1;                    // hidden units per thread (512 units: tid and tid + 256)
+  constexpr int NK = NTL * 4;                              // 16-byte key pieces per lane and frame (4 lanes per frame)
   const int B = p.s.B, Hd = p.s.Hd, M = p.s.M, Tm = p.s.Tm, U = p.U;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, lq = lane >> 4;
   const int groups = (B + 7) / 8;
@@ -986,14 +989,15 @@ __global__ __launch_bounds__(256) void dec_persist_fwd_lean_kernel(las_dec_persi
   constexpr int CPM = NTL * 16;
   const int KC = p.K_in / 32;
   bf16x8 wf[NTL][KRES];                                    // chunks past the end of K: zero weights (their products add nothing)
+  const unsigned short* wrow[NTL];                         // this lane's row of kT per column tile (the streamed chunks' source)
 #pragma unroll
   for (int nt = 0; nt < NTL; ++nt) {
-    const unsigned short* wrow = p.kT + (int64_t)(member * CPM + nt * 16 + l15) * p.ldk + 8 * lq;
+    wrow[nt] = p.kT + (int64_t)(member * CPM + nt * 16 + l15) * p.ldk + 8 * lq;
 #pragma unroll
     for (int i = 0; i < KRES; ++i) {
       const int kc = wave + 4 * i;
       uint4 v = make_uint4(0, 0, 0, 0);
-      if (kc < KC) v = *reinterpret_cast<const uint4*>(wrow + kc * 32);
+      if (kc < KC) v = *reinterpret_cast<const uint4*>(wrow[nt] + kc * 32);
       wf[nt][i] = __builtin_bit_cast(bf16x8, v);
     }
   }
@@ -1021,24 +1025,29 @@ __global__ __launch_bounds__(256) void dec_persist_fwd_lean_kernel(las_dec_persi
       for (int u = tid; u < Hd; u += 256) vq[u] = p.s.att_v[u];
   }
   unsigned epoch = 0;
-  const bool unit = tid < Hd && have;                      // this thread owns hidden unit `tid` of utterance bs
-  float bias4[4] = {0.f, 0.f, 0.f, 0.f};
-  float c_reg = 0.f;
+  const bool unit = tid < Hd && have;                      // this thread owns hidden units tid (+ 256) of utterance bs
+  float bias4[UPT][4], c_reg[UPT];
   int tok_cur = p.s.tok_ids[(int64_t)bsc * p.s.tok_stride];          // (every thread: the loads of the loop are unconditional)
-  if (unit) {
 #pragma unroll
-    for (int g = 0; g < 4; ++g) bias4[g] = p.s.bias[g * Hd + tid];
-    c_reg = p.s.c_prev[(int64_t)bs * p.s.ldcp + tid];
+  for (int q = 0; q < UPT; ++q) {
+    c_reg[q] = 0.f;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) bias4[q][g] = 0.f;
+    if (unit) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) bias4[q][g] = p.s.bias[g * Hd + tid + q * 256];
+      c_reg[q] = p.s.c_prev[(int64_t)bs * p.s.ldcp + tid + q * 256];
+    }
   }
   const float keep = p.s.drop_keep;
   const int sub = lane & 3, fr = lane >> 2;                // score phase: 4 lanes per frame, 16 frames per wave
-  const int nk = Hd / 32;
   int Lc = 1;
   while (Lc * 8 < ncols) Lc <<= 1;                         // context phase: lanes per frame (power of two), frame phases
   const int Pc = 256 / Lc, cphase = tid / Lc, ccl = tid % Lc;
   pu64* const xbase = reinterpret_cast<pu64*>(reinterpret_cast<char*>(p.workspace) + 64) + persist_flag_words(B);
   const size_t ldsc = (size_t)((Tm + 31) / 32 * 32);
   pu64* const xzb = xbase + 2 * (size_t)B * ldsc;           // [2][B][4Hd] after the score granules [2][B][ldsc]
+  pu64* const xpqb = xzb + 2 * (size_t)B * 4 * Hd;          // [2][B][Hd]: the four quarters of the processed query (Bahdanau)
   __syncthreads();
 
   for (int t = 0; t < U; ++t) {
@@ -1057,12 +1066,26 @@ __global__ __launch_bounds__(256) void dec_persist_fwd_lean_kernel(las_dec_persi
     uint4 av[KRES];
 #pragma unroll
     for (int i = 0; i < KRES; ++i) av[i] = *reinterpret_cast<const uint4*>(arow + min(wave + 4 * i, KC - 1) * astep);
-    // the token's row of the cell kernel (its id was requested a step ago; used in the cell phase), and the next step's id
-    unsigned short tokraw[4];
-    {
-      const unsigned short* trow = p.s.tok_rows + (int64_t)tok_cur * 4 * Hd + min(tid, Hd - 1);
+    // the streamed chunks: operand piece and NTL weight pieces each, SD of them in flight
+    constexpr int NS = KCWM - KRES, SD = 3;
+    uint4 sa[NS > 0 ? SD : 1], sw[NS > 0 ? SD : 1][NTL];
+    auto stream_issue = [&](int slot, int i) {              // i: chunk index of this wave (KRES ...)
+      const int kcc = min(wave + 4 * i, KC - 1);
+      sa[slot] = *reinterpret_cast<const uint4*>(arow + kcc * astep);
 #pragma unroll
-      for (int g = 0; g < 4; ++g) tokraw[g] = trow[g * Hd];
+      for (int nt = 0; nt < NTL; ++nt) sw[slot][nt] = *reinterpret_cast<const uint4*>(wrow[nt] + kcc * 32);
+    };
+    if constexpr (NS > 0) {
+#pragma unroll
+      for (int q = 0; q < SD; ++q) stream_issue(q, KRES + q);
+    }
+    // the token's row of the cell kernel (its id was requested a step ago; used in the cell phase), and the next step's id
+    unsigned short tokraw[UPT][4];
+#pragma unroll
+    for (int q = 0; q < UPT; ++q) {
+      const unsigned short* trow = p.s.tok_rows + (int64_t)tok_cur * 4 * Hd + min(tid + q * 256, Hd - 1);
+#pragma unroll
+      for (int g = 0; g < 4; ++g) tokraw[q][g] = trow[g * Hd];
     }
     // every load of the step's head is in flight before the first product instruction (left to itself the scheduler
     // re-used four registers for the twelve operand pieces: three dependent round trips to L2 instead of one)
@@ -1076,10 +1099,24 @@ __global__ __launch_bounds__(256) void dec_persist_fwd_lean_kernel(las_dec_persi
 #pragma unroll
         for (int nt = 0; nt < NTL; ++nt)
           acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, av[i]), wf[nt][i], acc[nt], 0, 0, 0);
+      if constexpr (NS > 0) {
 #pragma unroll
-      for (int nt = 0; nt < NTL; ++nt)
+        for (int i = 0; i < NS; ++i) {
+          const int slot = i % SD;
+          const bool in = wave + 4 * (KRES + i) < KC;                         // past the end of K: nothing to add
+          const uint4 a4 = in ? sa[slot] : make_uint4(0, 0, 0, 0);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) zred[(wave * 16 + lq * 4 + r) * RS + nt * 16 + l15] = acc[nt][r];
+          for (int nt = 0; nt < NTL; ++nt)
+            acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a4), __builtin_bit_cast(bf16x8, sw[slot][nt]), acc[nt], 0, 0, 0);
+          if (i + SD < NS) stream_issue(slot, KRES + i + SD);
+        }
+      }
+      if (lq < 2) {                                        // rows 0..7 of the tile: the group's 8 utterances
+#pragma unroll
+        for (int nt = 0; nt < NTL; ++nt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) zred[(wave * 8 + lq * 4 + r) * RS + nt * 16 + l15] = acc[nt][r];
+      }
       LAS_STAMP(t, 1);
       __syncthreads();
       for (int e = tid; e < 8 * CPM; e += 256) {
@@ -1087,7 +1124,7 @@ __global__ __launch_bounds__(256) void dec_persist_fwd_lean_kernel(las_dec_persi
         const int b = group * 8 + row;
         if (b < B)
           pgranule_store(xzb + ((size_t)(xtag & 1) * B + b) * 4 * Hd + member * CPM + col, xtag,
-                         zred[(0 * 16 + row) * RS + col] + zred[(1 * 16 + row) * RS + col] + zred[(2 * 16 + row) * RS + col] + zred[(3 * 16 + row) * RS + col],
+                         zred[(0 * 8 + row) * RS + col] + zred[(1 * 8 + row) * RS + col] + zred[(2 * 8 + row) * RS + col] + zred[(3 * 8 + row) * RS + col],
                          local);
       }
     }
@@ -1101,72 +1138,128 @@ __global__ __launch_bounds__(256) void dec_persist_fwd_lean_kernel(las_dec_persi
       pu64* const xsc = xbase + ((size_t)(xtag & 1) * B + bs) * ldsc;
       const pu64* const xz = xzb + ((size_t)(xtag & 1) * B + bs) * 4 * Hd;
       if (tid < Hd) {                                      // whole waves: Hd is a multiple of 64
-        float z[4];
-        unsigned spins = 0;
-        for (;;) {                                         // the 32 product slices arrive as granules: wave-uniform, bounded
-          pu64 gq[4];
-          bool got = true;
-#pragma unroll
-          for (int g = 0; g < 4; ++g) {
-            gq[g] = pgranule_load(xz + g * Hd + tid);
-            got = got && ((unsigned)(gq[g] >> 32) == xtag);
-          }
-          if (__all(got)) {
-#pragma unroll
-            for (int g = 0; g < 4; ++g) z[g] = __uint_as_float((unsigned)gq[g]);
-            break;
-          }
-          if (++spins > P_SPIN_LIMIT || *fail) { *fail = 1; z[0] = z[1] = z[2] = z[3] = 0.f; break; }
-          __builtin_amdgcn_s_sleep(1);
-        }
         float tok_scale = 1.0f;                            // DropoutWrapper on the one-hot feed: its single entry is kept or lost
         if (keep < 1.0f)
           tok_scale = las_uniform(p.s.drop_seed, p.s.drop_stream, ((unsigned long long)t * B + bs) * p.s.feed_width + tok_cur) < keep
                           ? 1.0f / keep : 0.f;
 #pragma unroll
-        for (int g = 0; g < 4; ++g) z[g] += bias4[g] + tok_scale * las_bf2f(tokraw[g]);
-        const float gi = las_sigmoid(z[0]), gj = las_tanh(z[1]), gf = las_sigmoid(z[2] + 1.0f), go = las_sigmoid(z[3]);
-        const float cn = gf * c_reg + gi * gj;
-        c_reg = cn;
-        const unsigned short hb = las_f2bf(go * las_tanh(cn));
-        hq[tid] = las_bf2f(hb);
-        hqb[tid] = hb;
-        // saved for the backward pass: one quarter per workgroup of the utterance
-        const float gsel = part == 0 ? gi : (part == 1 ? gj : (part == 2 ? gf : go));
-        p.s.gates_out[(int64_t)bs * p.s.ldg + (int64_t)t * p.inc_gates + part * Hd + tid] = gsel;
-        if (part == 0) p.s.c_out[(int64_t)bs * p.s.ldco + (int64_t)t * p.inc_cout + tid] = cn;
-        else if (part == 1) p.s.h_out[(int64_t)bs * p.s.ldh + (int64_t)t * p.inc_h + tid] = hb;
-        else if (part == 2 && !last) p.s.h_out2[(int64_t)bs * p.s.ldh2 + (int64_t)t * p.inc_h2 + tid] = hb;
+        for (int q = 0; q < UPT; ++q) {
+          const int u = tid + q * 256;
+          float z[4];
+          unsigned spins = 0;
+          for (;;) {                                       // the 32 product slices arrive as granules: wave-uniform, bounded
+            pu64 gq[4];
+            bool got = true;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+              gq[g] = pgranule_load(xz + g * Hd + u);
+              got = got && ((unsigned)(gq[g] >> 32) == xtag);
+            }
+            if (__all(got)) {
+#pragma unroll
+              for (int g = 0; g < 4; ++g) z[g] = __uint_as_float((unsigned)gq[g]);
+              break;
+            }
+            if (++spins > P_SPIN_LIMIT || *fail) { *fail = 1; z[0] = z[1] = z[2] = z[3] = 0.f; break; }
+            __builtin_amdgcn_s_sleep(1);
+          }
+#pragma unroll
+          for (int g = 0; g < 4; ++g) z[g] += bias4[q][g] + tok_scale * las_bf2f(tokraw[q][g]);
+          const float gi = las_sigmoid(z[0]), gj = las_tanh(z[1]), gf = las_sigmoid(z[2] + 1.0f), go = las_sigmoid(z[3]);
+          const float cn = gf * c_reg[q] + gi * gj;
+          c_reg[q] = cn;
+          const unsigned short hb = las_f2bf(go * las_tanh(cn));
+          hq[u] = las_bf2f(hb);
+          hqb[u] = hb;
+          // saved for the backward pass: one quarter per workgroup of the utterance
+          const float gsel = part == 0 ? gi : (part == 1 ? gj : (part == 2 ? gf : go));
+          p.s.gates_out[(int64_t)bs * p.s.ldg + (int64_t)t * p.inc_gates + part * Hd + u] = gsel;
+          if (part == 0) p.s.c_out[(int64_t)bs * p.s.ldco + (int64_t)t * p.inc_cout + u] = cn;
+          else if (part == 1) p.s.h_out[(int64_t)bs * p.s.ldh + (int64_t)t * p.inc_h + u] = hb;
+          else if (part == 2 && !last) p.s.h_out2[(int64_t)bs * p.s.ldh2 + (int64_t)t * p.inc_h2 + u] = hb;
+        }
       }
       LAS_STAMP(t, 3);
       __syncthreads();
       LAS_STAMP(t, 4);
-      if (ATT == LAS_ATT_BAHDANAU) {                       // processed query pq = h Wq
-        square_matvec_bf16(p.s.wq, hq, pq, cred, Hd);
-        if (part == 3 && p.s.pq_out)
-          for (int a = tid; a < Hd; a += 256) p.s.pq_out[(int64_t)bs * p.s.ldpq + (int64_t)t * p.inc_pq + a] = pq[a];
+      if (ATT == LAS_ATT_BAHDANAU) {
+        // processed query pq = h Wq: every part forms ITS quarter of the columns (a quarter of Wq from L2 instead of all of
+        // it -- at 512 units the full product in each of the four workgroups was 22 of the step's 49 us) and hands it to
+        // the other three as granules
+        const int qc = Hd / 4, c0 = part * qc;
+        pu64* const xpq = xpqb + ((size_t)(xtag & 1) * B + bs) * Hd;
+        const int AG = qc / 8, UG = 256 / AG;               // column groups of 8, row phases
+        {
+          const int ag = tid % AG, ug = tid / AG;
+          float acc[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+          const unsigned short* wp = p.s.wq + c0 + ag * 8;
+          int r = ug;
+          for (; r + 7 * UG < Hd; r += 8 * UG) {
+            uint4 w[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) w[i] = ld16(wp + (int64_t)(r + i * UG) * Hd);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+              const unsigned short* e = reinterpret_cast<const unsigned short*>(&w[i]);
+              const float xv = hq[r + i * UG];
+#pragma unroll
+              for (int j = 0; j < 8; ++j) acc[j] += xv * las_bf2f(e[j]);
+            }
+          }
+          for (; r < Hd; r += UG) {
+            const uint4 w = ld16(wp + (int64_t)r * Hd);
+            const unsigned short* e = reinterpret_cast<const unsigned short*>(&w);
+            const float xv = hq[r];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[j] += xv * las_bf2f(e[j]);
+          }
+#pragma unroll
+          for (int j = 0; j < 8; ++j) cred[(ug * AG + ag) * 8 + j] = acc[j];
+        }
+        __syncthreads();
+        for (int c = tid; c < qc; c += 256) {
+          float v = 0.f;
+          for (int g = 0; g < UG; ++g) v += cred[(g * AG + (c >> 3)) * 8 + (c & 7)];
+          pq[c0 + c] = v;
+          pgranule_store(xpq + c0 + c, xtag, v, local);
+          if (p.s.pq_out) p.s.pq_out[(int64_t)bs * p.s.ldpq + (int64_t)t * p.inc_pq + c0 + c] = v;
+        }
+        for (int a0 = 0; a0 < Hd; a0 += 256) {             // the other parts' quarters
+          const int a = a0 + tid;
+          const bool need = a < Hd && (a < c0 || a >= c0 + qc);
+          unsigned spins = 0;
+          for (;;) {
+            const pu64 gq = need ? pgranule_load(xpq + a) : ((pu64)xtag << 32);
+            if (__all((unsigned)(gq >> 32) == xtag)) {
+              if (need) pq[a] = __uint_as_float((unsigned)gq);
+              break;
+            }
+            if (++spins > P_SPIN_LIMIT || *fail) { *fail = 1; break; }
+            __builtin_amdgcn_s_sleep(1);
+          }
+        }
         __syncthreads();
       }
       // ---- raw scores of my frames ----
       {
-        uint4 qreg[8];
+        uint4 qreg[ATT == LAS_ATT_LUONG ? NK : 1];
         if (ATT == LAS_ATT_LUONG) {
 #pragma unroll
-          for (int j = 0; j < 8; ++j)
-            if (j < nk) qreg[j] = ld16((lds_cu16)hqb + sub * 8 + j * 32);
+          for (int j = 0; j < NK; ++j) qreg[j] = ld16((lds_cu16)hqb + sub * 8 + j * 32);
         }
         for (int fl0 = 0; fl0 < fq; fl0 += 64) {
           const int fl = fl0 + wave * 16 + fr, tf = f0 + fl;
           float acc = 0.f;
           if (tf < flen) {
             const lds_cu16 krow = (lds_cu16)lk + (size_t)fl * KST + sub * 8;
-            uint4 kv[8];
+            uint4 kv[NK];
 #pragma unroll
-            for (int j = 0; j < 8; ++j)
-              if (j < nk) kv[j] = ld16(krow + j * 32);
+            for (int j = 0; j < NK; ++j) kv[j] = ld16(krow + j * 32);
 #pragma unroll
-            for (int j = 0; j < 8; ++j)
-              if (j < nk) {
+            for (int j = 0; j < NK; ++j)
+              {
                 if (ATT == LAS_ATT_LUONG) {
                   acc = dot2_bf16(kv[j].x, qreg[j].x, acc);
                   acc = dot2_bf16(kv[j].y, qreg[j].y, acc);
@@ -2384,6 +2477,38 @@ extern "C" int las_decoder_persist_fwd(const las_dec_persist* p, void* stream) {
   LAS_REQUIRE(lds <= 64 * 1024, "las_decoder_persist_fwd: memory length %d too long for the LDS score buffer", s->Tm);
   const bool res = persist_fwd_resident(s->M, s->Hd, s->Tm);
   const dim3 grid(((groups + 7) & ~7) * P_MEMBERS);
+  static int lean_mode = -1;                 // LAS_DEC_LEAN=0: the general body also where the written-out one applies (diagnostics)
+  if (lean_mode < 0) {
+    const char* e = getenv("LAS_DEC_LEAN");
+    lean_mode = (e && atoi(e) == 0) ? 0 : 1;
+  }
+  if (lean_mode && p->sampling_prob <= 0.f && s->tok_rows && persist_fwd_lean_ok(s->Hd, s->M, s->Tm, s->attention, s->norm) &&
+      p->K_in / 32 <= (s->Hd == 512 ? 80 : 48)) {
+    const size_t lbytes = lean_layout(s->Hd, s->Tm, s->M).total_bytes;
+#define LAS_LEAN_LAUNCH(...)                                                                                                    \
+  do {                                                                                                                          \
+    static bool attr = false;                                                                                                   \
+    if (!attr) {                                                                                                                \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dec_persist_fwd_lean_kernel<__VA_ARGS__>),                       \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                                        \
+      attr = true;                                                                                                              \
+    }                                                                                                                           \
+    hipLaunchKernelGGL((dec_persist_fwd_lean_kernel<__VA_ARGS__>), grid, dim3(256), lbytes, st, *p);                            \
+  } while (0)
+    // 4 Hd / 32 columns per member = one, two or four 16-column tiles; 512 units: 8 of the 20 K chunks per wave resident
+    if (s->attention == LAS_ATT_LUONG) {
+      if (s->Hd == 512) LAS_LEAN_LAUNCH(LAS_ATT_LUONG, 4, 8, 20);
+      else if (s->Hd == 256) LAS_LEAN_LAUNCH(LAS_ATT_LUONG, 2);
+      else LAS_LEAN_LAUNCH(LAS_ATT_LUONG, 1);
+    } else {
+      if (s->Hd == 512) LAS_LEAN_LAUNCH(LAS_ATT_BAHDANAU, 4, 8, 20);
+      else if (s->Hd == 256) LAS_LEAN_LAUNCH(LAS_ATT_BAHDANAU, 2);
+      else LAS_LEAN_LAUNCH(LAS_ATT_BAHDANAU, 1);
+    }
+#undef LAS_LEAN_LAUNCH
+    LAS_LAUNCH_CHECK("persistent decoder fwd launch");
+    return LAS_OK;
+  }
   if (s->Hd == 512) {          // the wide flavour: 4 column tiles x 20 K chunks of the cell kernel per wave in registers
     LAS_REQUIRE(p->sampling_prob <= 0.f, "las_decoder_persist_fwd: scheduled sampling inside the launch is built for decoder_units <= 256");
     static bool attr512 = false;
@@ -2397,33 +2522,6 @@ extern "C" int las_decoder_persist_fwd(const las_dec_persist* p, void* stream) {
       hipLaunchKernelGGL((dec_persist_fwd_kernel<false, true, 4, 20, 8>), grid, dim3(256), lds, st, *p);
     } else {
       hipLaunchKernelGGL((dec_persist_fwd_kernel<false, false, 4, 20, 8>), grid, dim3(256), lds, st, *p);
-    }
-    LAS_LAUNCH_CHECK("persistent decoder fwd launch");
-    return LAS_OK;
-  }
-  static int lean_mode = -1;                 // LAS_DEC_LEAN=0: the general body also where the written-out one applies (diagnostics)
-  if (lean_mode < 0) {
-    const char* e = getenv("LAS_DEC_LEAN");
-    lean_mode = (e && atoi(e) == 0) ? 0 : 1;
-  }
-  if (lean_mode && p->sampling_prob <= 0.f && s->tok_rows && persist_fwd_lean_ok(s->Hd, s->M, s->Tm, s->attention, s->norm) &&
-      p->K_in / 32 <= 48) {
-    static bool lean_attr = false;
-    if (!lean_attr) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dec_persist_fwd_lean_kernel<LAS_ATT_LUONG, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dec_persist_fwd_lean_kernel<LAS_ATT_LUONG, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dec_persist_fwd_lean_kernel<LAS_ATT_BAHDANAU, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dec_persist_fwd_lean_kernel<LAS_ATT_BAHDANAU, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      lean_attr = true;
-    }
-    const size_t lbytes = lean_layout(s->Hd, s->Tm, s->M).total_bytes;
-    const bool two = s->Hd == 256;           // 4 Hd / 32 columns per member = one or two 16-column tiles
-    if (s->attention == LAS_ATT_LUONG) {
-      if (two) hipLaunchKernelGGL((dec_persist_fwd_lean_kernel<LAS_ATT_LUONG, 2>), grid, dim3(256), lbytes, st, *p);
-      else hipLaunchKernelGGL((dec_persist_fwd_lean_kernel<LAS_ATT_LUONG, 1>), grid, dim3(256), lbytes, st, *p);
-    } else {
-      if (two) hipLaunchKernelGGL((dec_persist_fwd_lean_kernel<LAS_ATT_BAHDANAU, 2>), grid, dim3(256), lbytes, st, *p);
-      else hipLaunchKernelGGL((dec_persist_fwd_lean_kernel<LAS_ATT_BAHDANAU, 1>), grid, dim3(256), lbytes, st, *p);
     }
     LAS_LAUNCH_CHECK("persistent decoder fwd launch");
     return LAS_OK;
