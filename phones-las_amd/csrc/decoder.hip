@@ -580,8 +580,15 @@ __host__ __device__ inline size_t persist_fwd_resident_bytes(int M, int Hd, int 
 __host__ __device__ inline bool persist_fwd_resident(int M, int Hd, int Tm) {
   return persist_fwd_scratch_floats(Hd, Tm) * 4 + persist_fwd_resident_bytes(M, Hd, Tm) <= 158 * 1024;   // (2 KiB of margin below the CU's 160 KiB)
 }
+// G role's partial tiles: [4 waves][8 utterances][16-column tiles per member * 16 + 1] (W / 16 tiles over 32 members: <= 3, or 5)
+__host__ __device__ inline size_t persist_bwd_red2_floats(int W) {
+  const int nt = (W / 16 + 31) / 32;
+  return (size_t)4 * 8 * ((nt <= 3 ? 3 : 5) * 16 + 1);
+}
 __host__ __device__ inline size_t persist_bwd_scratch_floats(int M, int Hd, int Tm) {
-  return ((size_t)M + 2 * (size_t)Tm + 2048 + 16 + Hd + 4 * 16 * 49 + 8 + 3) & ~(size_t)3;
+  // (the Bahdanau query-layer product borrows the partial-tile area as 2048 floats of scratch)
+  const size_t r2 = persist_bwd_red2_floats(M + Hd);
+  return ((size_t)M + 2 * (size_t)Tm + 2048 + 16 + Hd + (r2 > 2048 ? r2 : 2048) + 8 + 3) & ~(size_t)3;
 }
 __host__ __device__ inline size_t persist_bwd_resident_bytes(int M, int Hd, int Tm) {
   return (size_t)((Tm + 3) / 4) * (size_t)(M + Hd) * 2;
@@ -1707,10 +1714,14 @@ __global__ __launch_bounds__(256) void dec_step_bwd_kernel(las_dec_step_bwd s) {
 //       tiles j, j+32, j+64 (its rows of K register-resident as MFMA B fragments)                          | barrier
 // Every exchanged tensor has its own rows per step (no address is re-read after being rewritten).
 // ------------------------------------------------------------------------------------------------
-template <bool WQ, int NPQ = 0>       // NPQ = M / 128 when the written-out d(alignments) pass applies (LDS-resident frames, M = 512 or 1024), else 0
+// NPQ = M / 128 when the written-out d(alignments) pass applies (LDS-resident frames, M = 512, 1024 or 2048), else 0.
+// NT_MAX 16-column tiles of d[attention, h] per member (W / 16 / 32), KCW_MAX 32-deep chunks of the 4 Hd gate columns per wave
+// of which KRES stay in registers (512 units: 5 tiles x 6 of 16 chunks resident, the rest streamed from L2 every step, three in
+// flight); PD d(context) columns per thread (M <= 256 PD); UPT hidden units per thread in the cell backward (512 units: 2).
+template <bool WQ, int NPQ = 0, int NT_MAX = 3, int KRES = 8, int KCW_MAX = 8, int PD = 6, int UPT = 1>
 __global__ __launch_bounds__(256) void dec_persist_bwd_kernel(las_dec_persist_bwd p) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
-  constexpr int NT_MAX = 3, KCW_MAX = 8;
+  constexpr int RS2 = NT_MAX * 16 + 1;              // row stride of the G role's partial tiles
   const las_dec_step_bwd& s0 = p.s;
   const int B = s0.B, Hd = s0.Hd, M = s0.M, Tm = s0.Tm, W = p.W;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, lq = lane >> 4;
@@ -1725,8 +1736,8 @@ __global__ __launch_bounds__(256) void dec_persist_bwd_kernel(las_dec_persist_bw
   float* alg = dal + Tm;                  // [Tm] alignments (own frames)
   float* dhs = alg + Tm;                  // [2048] per-phase partial dh
   float* red = dhs + 2048;                // [16 + Hd]
-  float* red2 = red + 16 + Hd;            // [4 waves][16][49] partial output tiles of the G role
-  int* fail = reinterpret_cast<int*>(red2 + 4 * 16 * 49);
+  float* red2 = red + 16 + Hd;            // [4 waves][8 utterances][RS2] partial output tiles of the G role
+  int* fail = reinterpret_cast<int*>(red2 + (persist_bwd_red2_floats(M + Hd) > 2048 ? persist_bwd_red2_floats(M + Hd) : 2048));
   int* colo = fail + 1;
   unsigned* status = reinterpret_cast<unsigned*>(p.workspace);
   pu64* flags = reinterpret_cast<pu64*>(reinterpret_cast<char*>(p.workspace) + 64) + (size_t)group * 2 * P_MEMBERS;
@@ -1759,16 +1770,20 @@ __global__ __launch_bounds__(256) void dec_persist_bwd_kernel(las_dec_persist_bw
 
   // G role: rows of kc ([W, 4Hd] bf16: row n = output column n) for this member's tiles, register-resident
   const int NTW = W / 16, KC = 4 * Hd / 32;
-  bf16x8 wf[NT_MAX][KCW_MAX];
+  bf16x8 wf[NT_MAX][KRES];
+  const unsigned short* wrow[NT_MAX];          // this lane's row of kc per tile (absent tiles: the last one's, results dropped)
 #pragma unroll
-  for (int j = 0; j < NT_MAX; ++j)
+  for (int j = 0; j < NT_MAX; ++j) {
+    const int tile = member + 32 * j;
+    wrow[j] = p.kc + (int64_t)(min(tile, NTW - 1) * 16 + l15) * p.ldk + 8 * lq;
 #pragma unroll
-    for (int i = 0; i < KCW_MAX; ++i) {
-      const int tile = member + 32 * j, kc = wave + 4 * i;
+    for (int i = 0; i < KRES; ++i) {
+      const int kc = wave + 4 * i;
       uint4 v = make_uint4(0, 0, 0, 0);
-      if (tile < NTW && kc < KC) v = *reinterpret_cast<const uint4*>(p.kc + (int64_t)(tile * 16 + l15) * p.ldk + kc * 32 + 8 * lq);
+      if (tile < NTW && kc < KC) v = *reinterpret_cast<const uint4*>(wrow[j] + kc * 32);
       wf[j][i] = __builtin_bit_cast(bf16x8, v);
     }
+  }
   const int bg = group * 8 + (l15 & 7);
   const int b = group * 8 + member / 4, part = member & 3;
   const bool active = b < B;
@@ -1797,10 +1812,11 @@ __global__ __launch_bounds__(256) void dec_persist_bwd_kernel(las_dec_persist_bw
   // S3 runs on part 0 with unit = threadIdx.x (Hd <= 256): d(c) stays in a register over the steps, and the saved
   // values of a step are requested at its top, two barriers before the cell backward uses them
   const bool cellw = active && part == 0 && tid < Hd;
-  float dcr = cellw ? s0.dc[(int64_t)b * Hd + tid] : 0.f;
+  float dcr[UPT];
+#pragma unroll
+  for (int q = 0; q < UPT; ++q) dcr[q] = cellw ? s0.dc[(int64_t)b * Hd + tid + q * 256] : 0.f;
   // likewise the step's row of d(context) from the projection layer and its alignments: step t-1's are requested
   // at the top of step t (PD values per thread cover M <= 256 * PD)
-  constexpr int PD = 6;
   float cur_dc[PD], cur_al = 0.f;
   auto fetch_step = [&](int tt_, float (&dcv)[PD], float& alv) {
 #pragma unroll
@@ -1820,12 +1836,17 @@ __global__ __launch_bounds__(256) void dec_persist_bwd_kernel(las_dec_persist_bw
     const bool first = (t == p.U - 1);
     LAS_STAMPB(p.U - 1 - t, 0);
     const float* dfeed_next = first ? nullptr : p.dfeed_all + (int64_t)(t + 1) * B * W;      // written by step t+1
-    float sg[4] = {0.f, 0.f, 0.f, 0.f}, sct = 0.f, scp = 0.f, sdf = 0.f;
-    if (cellw) {
-      const float* gp = s0.gates + (int64_t)b * s0.ldg + (int64_t)t * p.inc_gates + tid;
-      sg[0] = gp[0]; sg[1] = gp[Hd]; sg[2] = gp[2 * Hd]; sg[3] = gp[3 * Hd];
-      sct = s0.c_new[(int64_t)b * s0.ldcn + (int64_t)t * p.inc_c + tid];
-      scp = s0.c_prev[(int64_t)b * s0.ldcp + (int64_t)t * p.inc_c + tid];
+    float sg[UPT][4], sct[UPT], scp[UPT], sdf[UPT];
+#pragma unroll
+    for (int q = 0; q < UPT; ++q) {
+      sg[q][0] = sg[q][1] = sg[q][2] = sg[q][3] = 0.f;
+      sct[q] = scp[q] = sdf[q] = 0.f;
+      if (cellw) {
+        const float* gp = s0.gates + (int64_t)b * s0.ldg + (int64_t)t * p.inc_gates + tid + q * 256;
+        sg[q][0] = gp[0]; sg[q][1] = gp[Hd]; sg[q][2] = gp[2 * Hd]; sg[q][3] = gp[3 * Hd];
+        sct[q] = s0.c_new[(int64_t)b * s0.ldcn + (int64_t)t * p.inc_c + tid + q * 256];
+        scp[q] = s0.c_prev[(int64_t)b * s0.ldcp + (int64_t)t * p.inc_c + tid + q * 256];
+      }
     }
     float nxt_dc[PD], nxt_al = 0.f;
     if (t > 0) fetch_step(t - 1, nxt_dc, nxt_al);
@@ -1842,19 +1863,24 @@ __global__ __launch_bounds__(256) void dec_persist_bwd_kernel(las_dec_persist_bw
         unsigned spins = 0;
         for (;;) {
           bool got = true;
-          pu64 gq[PD + 1];
+          pu64 gq[PD + UPT];
 #pragma unroll
           for (int i = 0; i < PD; ++i) {
             const int m = tid + i * 256;
             gq[i] = m < M ? pgranule_load(xf + m) : ((pu64)(xtag - 1) << 32);
             got = got && ((unsigned)(gq[i] >> 32) == xtag - 1);
           }
-          gq[PD] = cellw ? pgranule_load(xf + M + tid) : ((pu64)(xtag - 1) << 32);
-          got = got && ((unsigned)(gq[PD] >> 32) == xtag - 1);
+#pragma unroll
+          for (int q = 0; q < UPT; ++q) {
+            gq[PD + q] = cellw ? pgranule_load(xf + M + tid + q * 256) : ((pu64)(xtag - 1) << 32);
+            got = got && ((unsigned)(gq[PD + q] >> 32) == xtag - 1);
+          }
           if (__all(got)) {
 #pragma unroll
             for (int i = 0; i < PD; ++i) fbv[i] = __uint_as_float((unsigned)gq[i]);
-            if (cellw) sdf = __uint_as_float((unsigned)gq[PD]);
+#pragma unroll
+            for (int q = 0; q < UPT; ++q)
+              if (cellw) sdf[q] = __uint_as_float((unsigned)gq[PD + q]);
             break;
           }
           if (++spins > P_SPIN_LIMIT || *fail) { if (lane == 0) *fail = 1; break; }
@@ -1891,39 +1917,40 @@ __global__ __launch_bounds__(256) void dec_persist_bwd_kernel(las_dec_persist_bw
         // the fast form (M = 128 * NP, NP <= 8): this lane's pieces of d(context) are the same for every frame -- they
         // are read from LDS once, not once per frame (halves the LDS traffic of the pass) -- and the 16 lanes of a frame
         // meet through DPP instead of four LDS permutes
-        constexpr int NP = NPQ > 0 ? NPQ : 1;
+        constexpr int NP = NPQ > 8 ? 8 : (NPQ > 0 ? NPQ : 1);       // pieces per lane and pass (M = 2048: two passes of 8)
+        constexpr int NPASS = NPQ > 8 ? NPQ / 8 : 1;
         constexpr bool fast = NPQ > 0;
         if constexpr (fast) {
-          float dcr8[NP][8];
-          constexpr int np = NP;
+#pragma unroll 1
+          for (int pass = 0; pass < NPASS; ++pass) {
+            float dcr8[NP][8];
+            const int koff = pass * NP * 128 + sub * 8;
 #pragma unroll
-          for (int q = 0; q < NP; ++q)
-            if (q < np) {
-              const float4 x0 = *reinterpret_cast<const float4*>(dctx + sub * 8 + q * 128);
-              const float4 x1 = *reinterpret_cast<const float4*>(dctx + sub * 8 + q * 128 + 4);
+            for (int q = 0; q < NP; ++q) {
+              const float4 x0 = *reinterpret_cast<const float4*>(dctx + koff + q * 128);
+              const float4 x1 = *reinterpret_cast<const float4*>(dctx + koff + q * 128 + 4);
               dcr8[q][0] = x0.x; dcr8[q][1] = x0.y; dcr8[q][2] = x0.z; dcr8[q][3] = x0.w;
               dcr8[q][4] = x1.x; dcr8[q][5] = x1.y; dcr8[q][6] = x1.z; dcr8[q][7] = x1.w;
             }
-          for (int t0 = f0; t0 < f1; t0 += 16) {
-            const int ta = t0 + wave * 4 + grp;
-            const bool oa = ta < flen;
-            const lds_cu16 ra = (lds_cu16)lvals + (size_t)(oa ? ta - f0 : 0) * M + sub * 8;
-            uint4 va[NP];
+            for (int t0 = f0; t0 < f1; t0 += 16) {
+              const int ta = t0 + wave * 4 + grp;
+              const bool oa = ta < flen;
+              const lds_cu16 ra = (lds_cu16)lvals + (size_t)(oa ? ta - f0 : 0) * M + koff;
+              uint4 va[NP];
 #pragma unroll
-            for (int q = 0; q < NP; ++q)
-              if (q < np) va[q] = ld16(ra + q * 128);
-            float acc_a = 0.f;
+              for (int q = 0; q < NP; ++q) va[q] = ld16(ra + q * 128);
+              float acc_a = 0.f;
 #pragma unroll
-            for (int q = 0; q < NP; ++q)
-              if (q < np) {
+              for (int q = 0; q < NP; ++q) {
                 const unsigned short* e = reinterpret_cast<const unsigned short*>(&va[q]);
 #pragma unroll
                 for (int j = 0; j < 8; ++j) acc_a += las_bf2f(e[j]) * dcr8[q][j];
               }
-            acc_a = las_quad_sum(acc_a);
-            acc_a += las_dpp<0x141>(acc_a);       // row_half_mirror
-            acc_a += las_dpp<0x140>(acc_a);       // row_mirror: every lane of the 16-lane row holds the frame's sum
-            if (sub == 0 && ta < f1) dal[ta] = oa ? acc_a : 0.f;
+              acc_a = las_quad_sum(acc_a);
+              acc_a += las_dpp<0x141>(acc_a);       // row_half_mirror
+              acc_a += las_dpp<0x140>(acc_a);       // row_mirror: every lane of the 16-lane row holds the frame's sum
+              if (sub == 0 && ta < f1) dal[ta] = (pass == 0 ? 0.f : dal[ta]) + (oa ? acc_a : 0.f);
+            }
           }
         }
         auto dalign_pass = [&](const unsigned short* rows, int row0) {
@@ -2057,34 +2084,48 @@ __global__ __launch_bounds__(256) void dec_persist_bwd_kernel(las_dec_persist_bw
       __syncthreads();
       LAS_STAMPB(p.U - 1 - t, 7);
       // partial dh of this workgroup's frames (unit = threadIdx.x; Hd <= 256): parts 1..3 send theirs to part 0 as granules
-      float dh_own = 0.f;
-      if (tid < Hd)
-        for (int ph = 0; ph < P; ++ph) dh_own += dhs[ph * Hd + tid];
+      float dh_own[UPT];
+#pragma unroll
+      for (int q = 0; q < UPT; ++q) {
+        dh_own[q] = 0.f;
+        if (tid < Hd)
+          for (int ph = 0; ph < P; ++ph) dh_own[q] += dhs[ph * Hd + tid + q * 256];
+      }
       pu64* xh = xdh + ((size_t)(xtag & 1) * B + b) * 3 * Hd;
       if (part != 0) {
-        if (tid < Hd) pgranule_store(xh + (size_t)(part - 1) * Hd + tid, xtag, dh_own, local);
+#pragma unroll
+        for (int q = 0; q < UPT; ++q)
+          if (tid < Hd) pgranule_store(xh + (size_t)(part - 1) * Hd + tid + q * 256, xtag, dh_own[q], local);
       } else {
         // ---- S3 on part 0: total dh, then the LSTM cell backward (Appendix F) ----
-        float tot = dh_own;
+        float tot[UPT];
+#pragma unroll
+        for (int q = 0; q < UPT; ++q) tot[q] = dh_own[q];
         unsigned spins = 0;
         for (;;) {                                  // wave-uniform polling, bounded
           bool got = true;
-          pu64 g3[3];
+          pu64 g3[UPT][3];
 #pragma unroll
-          for (int q = 0; q < 3; ++q) {
-            g3[q] = tid < Hd ? pgranule_load(xh + (size_t)q * Hd + tid) : ((pu64)xtag << 32);
-            got = got && ((unsigned)(g3[q] >> 32) == xtag);
-          }
+          for (int q = 0; q < UPT; ++q)
+#pragma unroll
+            for (int w = 0; w < 3; ++w) {
+              g3[q][w] = tid < Hd ? pgranule_load(xh + (size_t)w * Hd + tid + q * 256) : ((pu64)xtag << 32);
+              got = got && ((unsigned)(g3[q][w] >> 32) == xtag);
+            }
           if (__all(got)) {
 #pragma unroll
-            for (int q = 0; q < 3; ++q) tot += __uint_as_float((unsigned)g3[q]);
+            for (int q = 0; q < UPT; ++q)
+#pragma unroll
+              for (int w = 0; w < 3; ++w) tot[q] += __uint_as_float((unsigned)g3[q][w]);
             break;
           }
           if (++spins > P_SPIN_LIMIT || *fail) { if (lane == 0) *fail = 1; break; }
           __builtin_amdgcn_s_sleep(1);
         }
         __syncthreads();                            // dhs (the per-phase partials) has been read by everybody
-        if (tid < Hd) dhs[tid] = tot;
+#pragma unroll
+        for (int q = 0; q < UPT; ++q)
+          if (tid < Hd) dhs[tid + q * 256] = tot[q];
       }
     }
     if (active && part == 0) {
@@ -2105,18 +2146,21 @@ __global__ __launch_bounds__(256) void dec_persist_bwd_kernel(las_dec_persist_bw
         __syncthreads();
       }
       if (cellw) {
-        const int u = tid;
-        const float gi = sg[0], gj = sg[1], gf = sg[2], go = sg[3], ct = sct, cp = scp;
-        const float dht = dhs[u] + sdf;
-        const float tc = las_tanh(ct);
-        const float dov = dht * tc * go * (1.f - go);
-        const float dct = dcr + dht * go * (1.f - tc * tc);
-        const float di = dct * gj * gi * (1.f - gi);
-        const float dj = dct * gi * (1.f - gj * gj);
-        const float df = dct * cp * gf * (1.f - gf);
-        dcr = dct * gf;
-        unsigned short* zp = s0.dz + (int64_t)b * s0.ldz + (int64_t)t * p.inc_dz + u;
-        zp[0] = las_f2bf(di); zp[Hd] = las_f2bf(dj); zp[2 * Hd] = las_f2bf(df); zp[3 * Hd] = las_f2bf(dov);
+#pragma unroll
+        for (int q = 0; q < UPT; ++q) {
+          const int u = tid + q * 256;
+          const float gi = sg[q][0], gj = sg[q][1], gf = sg[q][2], go = sg[q][3], ct = sct[q], cp = scp[q];
+          const float dht = dhs[u] + sdf[q];
+          const float tc = las_tanh(ct);
+          const float dov = dht * tc * go * (1.f - go);
+          const float dct = dcr[q] + dht * go * (1.f - tc * tc);
+          const float di = dct * gj * gi * (1.f - gi);
+          const float dj = dct * gi * (1.f - gj * gj);
+          const float df = dct * cp * gf * (1.f - gf);
+          dcr[q] = dct * gf;
+          unsigned short* zp = s0.dz + (int64_t)b * s0.ldz + (int64_t)t * p.inc_dz + u;
+          zp[0] = las_f2bf(di); zp[Hd] = las_f2bf(dj); zp[2 * Hd] = las_f2bf(df); zp[3 * Hd] = las_f2bf(dov);
+        }
       }
     }
     LAS_STAMPB(p.U - 1 - t, 8);
@@ -2136,28 +2180,54 @@ __global__ __launch_bounds__(256) void dec_persist_bwd_kernel(las_dec_persist_bw
       const unsigned short* zrow = (l15 < 8) ? s0.dz + (int64_t)min(bg, B - 1) * s0.ldz + (int64_t)t * p.inc_dz + 8 * lq
                                              : reinterpret_cast<const unsigned short*>(reinterpret_cast<const char*>(p.workspace) + 16);
       const int zstep = (l15 < 8) ? 32 : 0;
-      uint4 av[KCW_MAX];
+      uint4 av[KRES];
 #pragma unroll
-      for (int i = 0; i < KCW_MAX; ++i) av[i] = *reinterpret_cast<const uint4*>(zrow + min(wave + 4 * i, KC - 1) * zstep);
+      for (int i = 0; i < KRES; ++i) av[i] = *reinterpret_cast<const uint4*>(zrow + min(wave + 4 * i, KC - 1) * zstep);
+      constexpr int NS = KCW_MAX - KRES, SD = 3;           // streamed chunks: operand piece and NT_MAX weight pieces each
+      uint4 sa[NS > 0 ? SD : 1], sw[NS > 0 ? SD : 1][NT_MAX];
+      auto stream_issue = [&](int slot, int i) {
+        const int kcc = min(wave + 4 * i, KC - 1);
+        sa[slot] = *reinterpret_cast<const uint4*>(zrow + kcc * zstep);
+#pragma unroll
+        for (int j = 0; j < NT_MAX; ++j) sw[slot][j] = *reinterpret_cast<const uint4*>(wrow[j] + kcc * 32);
+      };
+      if constexpr (NS > 0) {
+#pragma unroll
+        for (int q = 0; q < SD; ++q) stream_issue(q, KRES + q);
+      }
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int i = 0; i < KCW_MAX; ++i)
+      for (int i = 0; i < KRES; ++i)
 #pragma unroll
         for (int j = 0; j < NT_MAX; ++j)
           acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, av[i]), wf[j][i], acc[j], 0, 0, 0);
+      if constexpr (NS > 0) {
 #pragma unroll
-      for (int j = 0; j < NT_MAX; ++j)
+        for (int i = 0; i < NS; ++i) {
+          const int slot = i % SD;
+          const bool in = wave + 4 * (KRES + i) < KC;
+          const uint4 a4 = in ? sa[slot] : make_uint4(0, 0, 0, 0);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) red2[(wave * 16 + lq * 4 + r) * 49 + j * 16 + l15] = acc[j][r];
+          for (int j = 0; j < NT_MAX; ++j)
+            acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a4), __builtin_bit_cast(bf16x8, sw[slot][j]), acc[j], 0, 0, 0);
+          if (i + SD < NS) stream_issue(slot, KRES + i + SD);
+        }
+      }
+      if (lq < 2) {
+#pragma unroll
+        for (int j = 0; j < NT_MAX; ++j)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) red2[(wave * 8 + lq * 4 + r) * RS2 + j * 16 + l15] = acc[j][r];
+      }
       LAS_STAMPB(p.U - 1 - t, 10);
       __syncthreads();
       float* df = p.dfeed_all + (int64_t)t * B * W;
-      for (int e = tid; e < 8 * 48; e += 256) {
-        const int row = e / 48, c = e % 48, j = c / 16, col = c % 16;
+      for (int e = tid; e < 8 * NT_MAX * 16; e += 256) {
+        const int row = e / (NT_MAX * 16), c = e % (NT_MAX * 16), j = c / 16, col = c % 16;
         const int tile = member + 32 * j, bb = group * 8 + row;
         if (tile < NTW && bb < B) {
-          const float v = red2[(0 * 16 + row) * 49 + c] + red2[(1 * 16 + row) * 49 + c] +
-                          red2[(2 * 16 + row) * 49 + c] + red2[(3 * 16 + row) * 49 + c];
+          const float v = red2[(0 * 8 + row) * RS2 + c] + red2[(1 * 8 + row) * RS2 + c] +
+                          red2[(2 * 8 + row) * RS2 + c] + red2[(3 * 8 + row) * RS2 + c];
           if (t == 0) df[(int64_t)bb * W + tile * 16 + col] = v;        // the caller's d(initial attention, h)
           else pgranule_store(xdf + ((size_t)(xtag & 1) * B + bb) * W + tile * 16 + col, xtag, v, local);
         }
@@ -2168,7 +2238,9 @@ __global__ __launch_bounds__(256) void dec_persist_bwd_kernel(las_dec_persist_bw
     for (int i = 0; i < PD; ++i) cur_dc[i] = nxt_dc[i];
     cur_al = nxt_al;
   }
-  if (cellw) s0.dc[(int64_t)b * Hd + tid] = dcr;          // d(c) before the first step: the caller's d(initial state)
+#pragma unroll
+  for (int q = 0; q < UPT; ++q)
+    if (cellw) s0.dc[(int64_t)b * Hd + tid + q * 256] = dcr[q];          // d(c) before the first step: the caller's d(initial state)
   if (WQ && att_additive(s0.attention) && active) {
     const int u = (tid % (Hd / 8)) * 8;
 #pragma unroll
@@ -2547,8 +2619,10 @@ extern "C" int las_decoder_persist_fwd(const las_dec_persist* p, void* stream) {
 extern "C" int las_decoder_persist_bwd_supported(int Hd, int M, int W, int attention, int norm) {
   if (norm != LAS_NORM_SOFTMAX) return 0;
   if (attention != LAS_ATT_LUONG && attention != LAS_ATT_BAHDANAU && attention != LAS_ATT_CUSTOM) return 0;
-  if (Hd != 128 && Hd != 256) return 0;                   // 4Hd/32 K chunks: <= 8 per wave
-  if (W % 32 != 0 || W / 16 > 96 || M % 128 != 0) return 0;   // <= 3 column tiles per member; dfeed rows of whole lines
+  if (Hd != 128 && Hd != 256 && Hd != 512) return 0;       // 4Hd/32 K chunks: <= 8 per wave (512 units: 16, ten of them streamed)
+  if (W % 32 != 0 || M % 128 != 0) return 0;               // dfeed rows of whole lines
+  if (Hd == 512) return (W / 16 <= 160 && M <= 2048) ? 1 : 0;   // <= 5 column tiles per member, 8 d(context) columns per thread
+  if (W / 16 > 96 || M > 1536) return 0;                   // <= 3 column tiles per member, 6 d(context) columns per thread
   return 1;
 }
 
@@ -2575,20 +2649,28 @@ extern "C" int las_decoder_persist_bwd(const las_dec_persist_bwd* p, void* strea
   LAS_REQUIRE(lds <= 64 * 1024, "las_decoder_persist_bwd: shapes exceed the LDS budget");
   if (persist_bwd_resident(s->M, s->Hd, s->Tm)) lds += persist_bwd_resident_bytes(s->M, s->Hd, s->Tm);
   const bool res = persist_bwd_resident(s->M, s->Hd, s->Tm);
-  const int npq = (res && (s->M == 512 || s->M == 1024)) ? s->M / 128 : 0;
+  const int npq = (res && (s->M == 512 || s->M == 1024 || (s->M == 2048 && s->Hd == 512))) ? s->M / 128 : 0;
   const dim3 grid(((groups + 7) & ~7) * P_MEMBERS);
   const bool wq = s->attention != LAS_ATT_LUONG;
-#define LAS_BWD_LAUNCH(WQ_, NPQ_)                                                                                               \
+#define LAS_BWD_LAUNCH(...)                                                                                                     \
   do {                                                                                                                          \
     static bool attr = false;                                                                                                   \
     if (!attr) {                                                                                                                \
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dec_persist_bwd_kernel<WQ_, NPQ_>),                              \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dec_persist_bwd_kernel<__VA_ARGS__>),                            \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                                        \
       attr = true;                                                                                                              \
     }                                                                                                                           \
-    hipLaunchKernelGGL((dec_persist_bwd_kernel<WQ_, NPQ_>), grid, dim3(256), lds, st, *p);                                      \
+    hipLaunchKernelGGL((dec_persist_bwd_kernel<__VA_ARGS__>), grid, dim3(256), lds, st, *p);                                    \
   } while (0)
-  if (wq) {
+  if (s->Hd == 512) {            // 5 column tiles per member, 6 of 16 K chunks per wave resident, 8 d(context) columns and 2 units per thread
+    if (wq) {
+      if (npq == 16) LAS_BWD_LAUNCH(true, 16, 5, 5, 16, 8, 2);      // (one resident chunk fewer: the query-layer part's registers)
+      else LAS_BWD_LAUNCH(true, 0, 5, 5, 16, 8, 2);
+    } else {
+      if (npq == 16) LAS_BWD_LAUNCH(false, 16, 5, 6, 16, 8, 2);
+      else LAS_BWD_LAUNCH(false, 0, 5, 6, 16, 8, 2);
+    }
+  } else if (wq) {
     if (npq == 8) LAS_BWD_LAUNCH(true, 8);
     else if (npq == 4) LAS_BWD_LAUNCH(true, 4);
     else LAS_BWD_LAUNCH(true, 0);
