@@ -347,7 +347,7 @@ __global__ __launch_bounds__(256) void lstm_fwd_kernel(float* __restrict__ xproj
     if constexpr (G > 1) if (s > 0) {
       const char* src = reinterpret_cast<const char*>(ex_group + (int64_t)((s - 1) & 1) * par_stride);
       unsigned short* hl = &hlds[cur][0][0];
-      constexpr int CH = PER > 8 ? 5 : PER;          // per polling round (bounds the registers held)
+      constexpr int CH = PER;                        // all of them in one polling round (512 units: 15 granules, 30 registers)
       static_assert(PER % CH == 0, "sweep chunking");
 #pragma unroll
       for (int c0 = 0; c0 < PER; c0 += CH) {
@@ -773,7 +773,7 @@ __global__ __launch_bounds__(256) void lstm_bwd_kernel(const float* __restrict__
         for (int r = 0; r < RPL; ++r) cand[ub][r] = part[ub][r];
       if constexpr (G > 1) {
         const char* src = reinterpret_cast<const char*>(ex_group + (int64_t)((epoch - 1) & 1) * par_stride);
-        constexpr int CH = PER > 12 ? 8 : PER;
+        constexpr int CH = PER > 16 ? 16 : PER;
         static_assert(PER % CH == 0, "sweep chunking");
 #pragma unroll
         for (int c0 = 0; c0 < PER; c0 += CH) {
