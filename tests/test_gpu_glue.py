@@ -1,0 +1,107 @@
+"""The step-glue entry points of include/las_hip.h (las_fill_many, las_train_op_begin, las_grad_l2_norms_acc, las_total_loss,
+las_stream_delay) against plain torch, through the C-ABI."""
+import ctypes as C
+import time
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def test_fill_many_windows_and_casts():
+    from phones_las_amd import hip
+    dev = 'cuda'
+    a = torch.full((5, 7, 12), 3.0, dtype=torch.bfloat16, device=dev)           # zero a strided 2-D window of 2-byte elements
+    b = torch.full((33,), 5.0, dtype=torch.float32, device=dev)                  # a contiguous fp32 tensor
+    c = torch.full((4, 3, 10), 9.0, dtype=torch.float32, device=dev)            # copy fp32 -> fp32 into a strided window
+    d = torch.full((4, 6, 16), 9.0, dtype=torch.bfloat16, device=dev)           # cast fp32 -> bf16 into a strided window
+    e = torch.full((2, 8), 1.0, dtype=torch.float32, device=dev)                 # copy with src = None: zeros
+    src_c = torch.randn(4, 10, device=dev)
+    src_d = torch.randn(4, 5, device=dev)
+    src_strided = torch.randn(4, 9, device=dev)[:, 2:7]                          # a strided SOURCE into a contiguous destination
+    f = torch.empty(4, 5, dtype=torch.float32, device=dev)
+    hip.fill_many(zero=[a[:, 2, :5], b], copy=[(c[:, 1], src_c), (d[:, 3, 4:9], src_d), (e[1], None), (f, src_strided)])
+    torch.cuda.synchronize()
+    ref = torch.full((5, 7, 12), 3.0, dtype=torch.bfloat16, device=dev)
+    ref[:, 2, :5] = 0
+    assert torch.equal(a, ref)
+    assert float(b.abs().max()) == 0.0
+    assert torch.equal(c[:, 1], src_c) and float((c[:, 0] - 9).abs().max()) == 0.0 and float((c[:, 2] - 9).abs().max()) == 0.0
+    assert torch.equal(d[:, 3, 4:9], src_d.to(torch.bfloat16)) and float((d[:, 3, :4].float() - 9).abs().max()) == 0.0
+    assert float(e[1].abs().max()) == 0.0 and float((e[0] - 1).abs().max()) == 0.0
+    assert torch.equal(f, src_strided)
+    # more jobs than one launch takes; shapes that cannot be expressed raise
+    many = [torch.ones(3, device=dev) for _ in range(2 * hip.FILL_MAX_JOBS + 1)]
+    hip.fill_many(zero=many)
+    torch.cuda.synchronize()
+    assert all(float(t.abs().max()) == 0.0 for t in many)
+    with pytest.raises(hip.LasError):
+        hip.fill_many(zero=[torch.ones(4, 4, 4, device=dev)[:, :, 1]])
+
+
+def test_train_op_begin_norms_acc_and_total_loss():
+    from phones_las_amd import hip
+    lib = hip.lib()
+    dev = 'cuda'
+    sizes = [5, 1, 40003, 7]
+    offs = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+    total, nseg = int(offs[-1]), len(sizes)
+    gen = torch.Generator().manual_seed(1)
+    g0, p0 = torch.randn(total, generator=gen).to(dev), torch.randn(total, generator=gen).to(dev)
+    seg = torch.from_numpy(offs).to(dev)
+    l2 = 1e-3
+    # status words: two clean workspaces and one with a bit set
+    ws = [torch.zeros(16, dtype=torch.int32, device=dev) for _ in range(3)]
+    ptrs = torch.tensor([w.data_ptr() for w in ws], dtype=torch.int64, device=dev)
+    flag = torch.full((1,), 7.0, device=dev)
+    sumsq = torch.full((nseg,), float('nan'), device=dev)
+    psq = torch.full((2,), float('nan'), device=dev)
+    hip.check(lib.las_train_op_begin(hip.p(ptrs), 3, hip.p(flag), hip.p(sumsq), nseg, hip.p(psq), 2, hip.stream()))
+    torch.cuda.synchronize()
+    assert float(flag) == 0.0 and float(sumsq.abs().max()) == 0.0 and float(psq.abs().max()) == 0.0
+    ws[1][0] = 8
+    hip.check(lib.las_train_op_begin(hip.p(ptrs), 3, hip.p(flag), hip.p(sumsq), nseg, hip.p(psq), 2, hip.stream()))
+    torch.cuda.synchronize()
+    assert float(flag) == 1.0
+    # the accumulating norms pass twice = twice the sums of the zeroing one (same gradients, L2 already added once)
+    ga, gb = g0.clone(), g0.clone()
+    s1, q1 = torch.empty(nseg, device=dev), torch.empty(1, device=dev)
+    hip.check(lib.las_grad_l2_norms(hip.p(ga), hip.p(p0), hip.p(seg), nseg, total, l2, hip.p(s1), hip.p(q1), hip.stream()))
+    hip.check(lib.las_grad_l2_norms_acc(hip.p(gb), hip.p(p0), hip.p(seg), nseg, total, l2, hip.p(sumsq), hip.p(psq), hip.stream()))
+    torch.cuda.synchronize()
+    assert torch.allclose(sumsq, s1, rtol=1e-6) and abs(float(psq[0]) - float(q1)) <= 1e-6 * float(q1) and float(psq[1]) == 0.0
+    assert torch.equal(ga, gb)
+    ref = [float(((g0 + l2 * p0)[offs[i]:offs[i + 1]].double() ** 2).sum()) for i in range(nseg)]
+    assert np.allclose(s1.cpu().double().numpy(), ref, rtol=1e-4)
+    # total loss = audio + half_l2 * (psq[0] + psq[1])
+    audio = torch.tensor([2.5], device=dev)
+    psq[1] = 3.0
+    out = torch.empty(1, device=dev)
+    hip.check(lib.las_total_loss(hip.p(audio), hip.p(psq), 2, 0.5 * l2, hip.p(out), hip.stream()))
+    hip.check(lib.las_total_loss(None, hip.p(psq), 1, 0.5 * l2, hip.p(flag), hip.stream()))
+    torch.cuda.synchronize()
+    assert abs(float(out) - (2.5 + 0.5 * l2 * (float(psq[0]) + 3.0))) < 1e-5
+    assert abs(float(flag) - 0.5 * l2 * float(psq[0])) < 1e-6
+
+
+def test_stream_delay_holds_its_stream_only():
+    from phones_las_amd import hip
+    lib = hip.lib()
+    side = torch.cuda.Stream()
+    x = torch.zeros(1, device='cuda')
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    with torch.cuda.stream(side):
+        e0.record()
+        hip.check(lib.las_stream_delay(500, side.cuda_stream))
+        e1.record()
+    t0 = time.perf_counter()
+    x.add_(1.0)                                     # the main stream is not held
+    torch.cuda.current_stream().synchronize()
+    side.synchronize()
+    assert 0.3 < e0.elapsed_time(e1) < 5.0          # about 0.5 ms on the side stream
+    assert float(x) == 1.0
+    assert lib.las_stream_delay(5000, side.cuda_stream) != 0       # out of range: refused
+    assert lib.las_stream_delay(0, side.cuda_stream) == 0
