@@ -1986,8 +1986,10 @@ __global__ __launch_bounds__(256) void dec_persist_bwd_kernel(las_dec_persist_bw
       LAS_STAMPB(p.U - 1 - t, 3);
       float dot = 0.f;
       for (int tt = f0 + tid; tt < flen; tt += 256) dot += alg[tt] * dal[tt];
-      dot = block_reduce(dot, red, false);
-      if (tid == 0) pgranule_store(xdot + ((size_t)(xtag & 1) * B + b) * 4 + part, xtag, dot, local);
+      dot = las_wave_sum_dpp(dot);                          // (DPP row sums + one barrier instead of 12 LDS permutes + two)
+      if (lane == 0) red[8 + wave] = dot;
+      __syncthreads();
+      if (tid == 0) pgranule_store(xdot + ((size_t)(xtag & 1) * B + b) * 4 + part, xtag, red[8] + red[9] + red[10] + red[11], local);
     }
     LAS_STAMPB(p.U - 1 - t, 4);
     // ---- S2 ----  (the four partial dots meet as granules: no group barrier)
@@ -2079,8 +2081,13 @@ __global__ __launch_bounds__(256) void dec_persist_bwd_kernel(las_dec_persist_bw
 #pragma unroll
         for (int j = 0; j < 8; ++j) dv_tot[j] += dv[j];
       }
+      if ((Tm & 1) == 0) {                       // (dhs sits 2 Tm floats behind a 16-byte boundary)
+        *reinterpret_cast<float4*>(dhs + phase * Hd + u) = make_float4(a[0], a[1], a[2], a[3]);
+        *reinterpret_cast<float4*>(dhs + phase * Hd + u + 4) = make_float4(a[4], a[5], a[6], a[7]);
+      } else {
 #pragma unroll
-      for (int j = 0; j < 8; ++j) dhs[phase * Hd + u + j] = a[j];
+        for (int j = 0; j < 8; ++j) dhs[phase * Hd + u + j] = a[j];
+      }
       __syncthreads();
       LAS_STAMPB(p.U - 1 - t, 7);
       // partial dh of this workgroup's frames (unit = threadIdx.x; Hd <= 256): parts 1..3 send theirs to part 0 as granules
