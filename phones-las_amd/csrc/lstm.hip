@@ -709,19 +709,20 @@ __global__ __launch_bounds__(256) void lstm_bwd_kernel(const float* __restrict__
       }
     }
   };
-  // lean loader for step s <= smin-2: every row is running, c_t is the c_{t-1} of the step before
+  // lean loader for step s <= smin-2: every row is running, c_t is the c_{t-1} of the step before.  No branch in it: a
+  // conditional load is a branch, the compiler put a vmcnt wait at its join and copied the loaded c_{t-1} into its home
+  // register at once -- 0.25 us of stall per step, on the chain's critical path (phase stamps).  Step 0 reads c_0 in place
+  // of the c_{-1} that does not exist; prepare() replaces it by 0.
   auto load_lean = [&](int s) {
+    const unsigned cback = s > 0 ? (unsigned)gstep : 0u;
 #pragma unroll
     for (int ub = 0; ub < UBW; ++ub)
 #pragma unroll
       for (int r = 0; r < RPL; ++r) {
-        Saved v;
-        v.g = *reinterpret_cast<const float4*>(gbase + goff[r] + ub * 256);
-        v.ct = sv[ub][r].cp;
-        v.cp = 0.f;
-        if (s > 0) v.cp = *reinterpret_cast<const float*>(cbase + ((goff[r] - (unsigned)gstep) >> 2) + ub * 64);
-        v.dyv = *reinterpret_cast<const float*>(dbase + (goff[r] >> 2) + ub * 64);
-        sv[ub][r] = v;
+        sv[ub][r].ct = sv[ub][r].cp;
+        sv[ub][r].g = *reinterpret_cast<const float4*>(gbase + goff[r] + ub * 256);
+        sv[ub][r].cp = *reinterpret_cast<const float*>(cbase + ((goff[r] - cback) >> 2) + ub * 64);
+        sv[ub][r].dyv = *reinterpret_cast<const float*>(dbase + (goff[r] >> 2) + ub * 64);
       }
   };
   auto set_goff = [&](int s) {       // offsets of step s (valid while every row is running)
@@ -736,8 +737,8 @@ __global__ __launch_bounds__(256) void lstm_bwd_kernel(const float* __restrict__
   //   do = dht*ao, dct = dc + dht*bc, di = dct*ci, dj = dct*cj, df = dct*cf, dc' = dct*gf   (dht = dy + dh)
   struct Coef { float ao, bc, ci, cj, cf, gf, dyv; };
   Coef cf[UBW][RPL];
-  auto prepare = [&]() {               // from sv (waits for its loads): runs while the partial sums are in flight
-#pragma unroll
+  auto prepare = [&](bool first_step = false) {   // from sv (waits for its loads): runs while the partial sums are in flight
+#pragma unroll                                     // first_step: the coefficients of time step 0 (c_{-1} = 0)
     for (int ub = 0; ub < UBW; ++ub)
 #pragma unroll
       for (int r = 0; r < RPL; ++r) {
@@ -748,7 +749,7 @@ __global__ __launch_bounds__(256) void lstm_bwd_kernel(const float* __restrict__
         k.bc = v.g.w * (1.f - tc * tc);
         k.ci = v.g.y * v.g.x * (1.f - v.g.x);
         k.cj = v.g.x * (1.f - v.g.y * v.g.y);
-        k.cf = v.cp * v.g.z * (1.f - v.g.z);
+        k.cf = (first_step ? 0.f : v.cp) * v.g.z * (1.f - v.g.z);
         k.gf = v.g.z;
         k.dyv = v.dyv;
         cf[ub][r] = k;
@@ -761,8 +762,11 @@ __global__ __launch_bounds__(256) void lstm_bwd_kernel(const float* __restrict__
   set_goff(smin > 0 ? smin - 1 : 0);
   load_general(smax - 1);
   prepare();
-  for (int s = smax - 1; s >= 0 && ok; --s) {
-    const bool lean = s < smin;              // every row of the slice is running at step s
+  // one time step; LEAN (compile time): every row of the slice is running at step s (and at s - 1: the lean loader).
+  // Two instantiations instead of a run-time flag: with both loaders in one body the values they load met in phi copies,
+  // i.e. in waits for loads that are not needed before the end of the step.  Returns false when the chain is over.
+  auto iter = [&](const int s, auto lean_tag) -> bool {
+    constexpr bool lean = decltype(lean_tag)::value;
     LSTM_STAMP(2048, smax - 1 - s, 0);
     // ---- dh_s: own partial + the peers' (sent in the previous iteration, i.e. for time step s) ----
     if (epoch > 0) {
@@ -816,7 +820,7 @@ __global__ __launch_bounds__(256) void lstm_bwd_kernel(const float* __restrict__
 #pragma unroll
         for (int r = 0; r < RPL; ++r) goff[r] -= (unsigned)gstep;
       }
-      if (s - 1 < smin - 1) load_lean(s - 1);
+      if constexpr (lean) load_lean(s - 1);
       else load_general(s - 1);
     }
     LSTM_STAMP(2048, smax - 1 - s, 2);
@@ -852,8 +856,8 @@ __global__ __launch_bounds__(256) void lstm_bwd_kernel(const float* __restrict__
     LSTM_STAMP(2048, smax - 1 - s, 3);
     lds_barrier();
     LSTM_STAMP(2048, smax - 1 - s, 4);
-    if (fail_flag) { ok = false; break; }
-    if (s == 0) break;                       // dh_{-1} is not needed
+    if (fail_flag) { ok = false; return false; }
+    if (s == 0) return false;                // dh_{-1} is not needed
 
     // ---- partial dh_{s-1}[all units] = dz_s[16, own 4*HS] * K_h^T ----
     f32x4 acc[NT];
@@ -884,10 +888,17 @@ __global__ __launch_bounds__(256) void lstm_bwd_kernel(const float* __restrict__
     for (int ub = 0; ub < OWN; ++ub)
 #pragma unroll
       for (int r = 0; r < RPL; ++r) part[ub][r] = acc[ub][r];
-    prepare();                               // coefficients of step s-1 (its operands were loaded above)
+    prepare(lean && s == 1);                 // coefficients of step s-1 (its operands were loaded above)
     LSTM_STAMP(2048, smax - 1 - s, 6);
     ++epoch;
     cur ^= 1;
+    return ok;
+  };
+  {
+    int s = smax - 1;
+    bool go = true;
+    for (; s >= smin && go; --s) go = iter(s, std::false_type{});
+    for (; s >= 0 && go; --s) go = iter(s, std::true_type{});
   }
   if (G > 1 && tid == 0) __hip_atomic_store(done_word, (u64)1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   if (!ok && tid == 0) atomicOr(status, 2u);
