@@ -383,13 +383,18 @@ __global__ __launch_bounds__(256) void lstm_fwd_kernel(float* __restrict__ xproj
     for (int g = 0; g < 4; ++g)
 #pragma unroll
       for (int ub = 0; ub < UB; ++ub) acc[g][ub] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // all of the step's A fragments are requested before the first product (left to itself the compiler kept two in
+    // flight and waited for the next pair right behind the products of the last: the LDS latency three more times per step)
+    bf16x8 afr[KCW];
+#pragma unroll
+    for (int kc = 0; kc < KCW; ++kc) afr[kc] = *reinterpret_cast<const bf16x8*>(&hlds[cur][l15][(kh * KCW + kc) * 32 + 8 * lq]);
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int kc = 0; kc < KCW; ++kc) {
-      const bf16x8 a = *reinterpret_cast<const bf16x8*>(&hlds[cur][l15][(kh * KCW + kc) * 32 + 8 * lq]);
 #pragma unroll
       for (int ub = 0; ub < UB; ++ub)
 #pragma unroll
-        for (int g = 0; g < 4; ++g) acc[g][ub] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, wf[ub][kc][g], acc[g][ub], 0, 0, 0);
+        for (int g = 0; g < 4; ++g) acc[g][ub] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afr[kc], wf[ub][kc][g], acc[g][ub], 0, 0, 0);
     }
     if constexpr (KS > 1) {
       // the upper-K wave hands its partial sums to the lead wave of the same unit block through LDS
