@@ -820,13 +820,15 @@ __global__ __launch_bounds__(256) void lstm_bwd_kernel(const float* __restrict__
     unsigned zoff[RPL];
 #pragma unroll
     for (int r = 0; r < RPL; ++r) zoff[r] = goff[r];
-    if (s > 0) {
-      if (lean) {
+    if constexpr (lean) {
+      // unconditional (a block under `if (s > 0)` gave the loaded values a home register to be copied into, behind a wait for
+      // the load: 0.2 us per step): the last step re-reads its own row, nobody uses what it gets
+      const unsigned dec = s > 0 ? (unsigned)gstep : 0u;
 #pragma unroll
-        for (int r = 0; r < RPL; ++r) goff[r] -= (unsigned)gstep;
-      }
-      if constexpr (lean) load_lean(s - 1);
-      else load_general(s - 1);
+      for (int r = 0; r < RPL; ++r) goff[r] -= dec;
+      load_lean(s > 0 ? s - 1 : 0);
+    } else {
+      if (s > 0) load_general(s - 1);
     }
     LSTM_STAMP(2048, smax - 1 - s, 2);
     // ---- gate derivatives of step s -> dz (LDS tile for the product, HBM for the weight-gradient GEMMs) ----
@@ -884,10 +886,13 @@ __global__ __launch_bounds__(256) void lstm_bwd_kernel(const float* __restrict__
           granule_store(reinterpret_cast<u64*>(dst + send_off[j - OWN] + r * 512), epoch + 1, __float_as_uint(acc[j][r]), local);
       }
     }
+    // own tiles: nobody waits for one of them in particular, so they advance together -- K chunk by K chunk -- instead of one
+    // after the other (a tile alone is a chain of KCW dependent MFMAs: 128 units, single-workgroup chains, 16 in a row)
 #pragma unroll
-    for (int j = 0; j < (G > 1 ? OWN : NT); ++j)
+    for (int kc = 0; kc < KCW; ++kc)
 #pragma unroll
-      for (int kc = 0; kc < KCW; ++kc) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afr[kc], wf[j][kc], acc[j], 0, 0, 0);
+      for (int j = 0; j < (G > 1 ? OWN : NT); ++j)
+        acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afr[kc], wf[j][kc], acc[j], 0, 0, 0);
     LSTM_STAMP(2048, smax - 1 - s, 5);
 #pragma unroll
     for (int ub = 0; ub < OWN; ++ub)
