@@ -289,6 +289,26 @@ extern "C" int las_tfrecord_parse_batch(const uint8_t* data, const int64_t* offs
   return LAS_OK;
 }
 
+extern "C" int las_vocab_lookup(const uint8_t* label_bytes, const int32_t* token_offsets, int64_t n_tokens, const uint64_t* keys,
+                                const int32_t* vals, int64_t table_size, int32_t default_id, int32_t* ids) {
+  LAS_REQUIRE(n_tokens >= 0 && table_size > 0 && (table_size & (table_size - 1)) == 0 && keys && vals && ids &&
+                  (n_tokens == 0 || (label_bytes && token_offsets)),
+              "las_vocab_lookup: bad arguments (table_size must be a power of two)");
+  const uint64_t mask = (uint64_t)table_size - 1;
+  for (int64_t k = 0; k < n_tokens; ++k) {
+    uint64_t h = 1469598103934665603ull;                       // FNV-1a
+    for (int32_t i = token_offsets[k]; i < token_offsets[k + 1]; ++i) h = (h ^ label_bytes[i]) * 1099511628211ull;
+    if (h == 0) h = 1;
+    int32_t id = default_id;
+    for (uint64_t slot = h & mask, probes = 0; probes < (uint64_t)table_size; slot = (slot + 1) & mask, ++probes) {
+      if (keys[slot] == h) { id = vals[slot]; break; }
+      if (keys[slot] == 0) break;
+    }
+    ids[k] = id;
+  }
+  return LAS_OK;
+}
+
 extern "C" int las_tfrecord_parse(const uint8_t* record, int64_t length, int num_channels, float* frames, int64_t frame_rows_capacity,
                                   int32_t* n_frames, uint8_t* label_bytes, int64_t label_bytes_capacity, int32_t* token_offsets,
                                   int64_t token_capacity, int32_t* n_labels) {

@@ -51,6 +51,7 @@ _SIGS = {
     'las_crc32c': ([C.c_char_p, C.c_size_t], C.c_uint32),
     'las_tfrecord_index': ([_vp, C.c_size_t, _i32, _i64, _vp, _vp, _vp, _vp, _vp], C.c_int64),
     'las_tfrecord_parse_batch': ([_vp, _vp, _vp, _i32, _i32, _vp, _i64, _vp, _vp, _i64, _vp, _i64, _vp], C.c_int),
+    'las_vocab_lookup': ([_vp, _vp, _i64, _vp, _vp, _i64, _i32, _vp], C.c_int),
     'las_tfrecord_parse': ([_vp, _i64, _i32, _vp, _i64, _vp, _vp, _i64, _vp, _i64, _vp], C.c_int),
     'las_normalize_pad_bf16': ([_vp, _vp, _vp, _vp, _i32, _vp, _i32, _i32, _i32, _vp, _vp], C.c_int),
     'las_dropout_bf16': ([_vp, _i64, _vp, _i64, _i32, _i32, _f32, C.c_uint32, C.c_uint32, _vp], C.c_int),

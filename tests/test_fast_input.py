@@ -99,6 +99,40 @@ def test_c_index_detects_corruption_and_truncation(tmp_path):
     assert len(rec) == 7 and rec.n_frames.tolist() == [x.shape[0] for x, _ in ex + ex2]
 
 
+def test_c_vocab_lookup_matches_the_vocab_table(tmp_path):
+    """las_vocab_lookup (FNV-1a open-addressing table built by fast_input) against vocab_utils.create_vocab_table: known
+    tokens (multi-byte utf-8 among them), an unknown token -> <unk>, the empty token, a token repeated in the vocab file
+    (first index wins)."""
+    from phones_las_amd import hip
+    from phones_las_amd.utils import vocab_utils
+    from phones_las_amd.utils.fast_input import _fnv1a
+    vocab = str(tmp_path / 'vocab.txt')
+    words = ['aa', 'b', 'sil', 'zh', 'æ', 'b', 'ʃ'] + ['w%d' % i for i in range(300)]
+    open(vocab, 'w', encoding='utf-8').write('\n'.join(words) + '\n')
+    table = vocab_utils.create_vocab_table(vocab)
+    size = 16
+    while size < 4 * len(table):
+        size *= 2
+    keys, vals = np.zeros(size, np.uint64), np.zeros(size, np.int32)
+    for tok, idx in table.items():
+        h = _fnv1a(tok.encode('utf-8'))
+        slot = h & (size - 1)
+        while keys[slot] != 0 and int(keys[slot]) != h:
+            slot = (slot + 1) & (size - 1)
+        if keys[slot] == 0:
+            keys[slot], vals[slot] = h, idx
+    toks = ['zh', 'æ', 'nope', '', 'b', 'w299', 'ʃ', '</s>', 'w0', 'aa ']
+    blob = b''.join(t.encode('utf-8') for t in toks)
+    offs = np.concatenate([[0], np.cumsum([len(t.encode('utf-8')) for t in toks])]).astype(np.int32)
+    lab = np.frombuffer(blob, np.uint8).copy()
+    out = np.full(len(toks), -7, np.int32)
+    hip.check(hip.lib().las_vocab_lookup(lab.ctypes.data, offs.ctypes.data, len(toks), keys.ctypes.data, vals.ctypes.data, size,
+                                         vocab_utils.UNK_ID, out.ctypes.data))
+    assert out.tolist() == table.lookup(toks)
+    assert out[2] == vocab_utils.UNK_ID and out[3] == vocab_utils.UNK_ID and out[4] == 3 + 1      # 'b': its first line
+    assert hip.lib().las_vocab_lookup(lab.ctypes.data, offs.ctypes.data, 1, keys.ctypes.data, vals.ctypes.data, size - 1, 0, out.ctypes.data) != 0
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize('infer,max_frames', [(False, -1), (True, -1), (False, 6)])
 def test_fast_input_batches_equal_the_python_pipeline(tmp_path, infer, max_frames):
