@@ -183,7 +183,7 @@ __global__ __launch_bounds__(256) void lstm_fwd_kernel(float* __restrict__ xproj
   smin = -(int)las_wave_max((float)(-smin));       // steps every utterance of the slice is still running: the lean path
   if ((int64_t)B * T * xrow * 4 >= ((int64_t)1 << 32)) smin = 0;     // 32-bit byte offsets do not reach: general path only
 
-  if constexpr (G > 1) if (companion) {
+  if (companion) {
     // PREFETCH COMPANION: one workgroup per group on another CU of the same XCD (block index = nblk + group, and nblk is
     // a multiple of 8) pulls the xproj lines of ALL members of the group into the shared L2 PF_AHEAD steps before they
     // are needed (1-KiB LDS-DMAs into a scratch tile nobody reads), so the compute CUs' in-order vector-memory queues
@@ -472,6 +472,11 @@ __global__ __launch_bounds__(256) void lstm_fwd_kernel(float* __restrict__ xproj
 #pragma unroll
       for (int r = 0; r < RL; ++r) xoff[r] += (unsigned)xstep;
     }
+    if constexpr (G == 1) {
+      // single-workgroup chains exchange nothing: one granule per step tells the companion how far the chain is
+      // (every fourth step: the write-through store sits in the in-order memory queue of the wave that also loads)
+      if (companions && tid == 0 && (s & 3) == 3) granule_store(ex_group + (int64_t)(s & 1) * par_stride, (unsigned)(s + 1), 0u, false);
+    }
     cur ^= 1;
     LSTM_STAMP(0, s, 5);
     return true;
@@ -483,7 +488,7 @@ __global__ __launch_bounds__(256) void lstm_fwd_kernel(float* __restrict__ xproj
   for (; s < smax && ok; ++s) ok = step(s, std::false_type{});
   flush_pending();
 
-  if (G > 1 && tid == 0) __hip_atomic_store(done_word, (u64)1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // releases the companion
+  if (tid == 0) __hip_atomic_store(done_word, (u64)1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // releases the companion
   if (!ok) {
     if (tid == 0) atomicOr(status, 1u);
     return;
@@ -573,7 +578,7 @@ __global__ __launch_bounds__(256) void lstm_bwd_kernel(const float* __restrict__
   }
   if ((int64_t)B * T * grow * 4 >= ((int64_t)1 << 32)) smin = 0;     // 32-bit byte offsets do not reach: general path only
 
-  if constexpr (G > 1) if (companion) {
+  if (companion) {
     // PREFETCH COMPANION (see lstm_fwd_kernel): gates, c and dy lines of the whole group, PF_AHEAD steps ahead.
     constexpr int PF_AHEAD = 6;
     const int mylen = (l15 < ROWS && slice * ROWS + l15 < B) ? min(length[slice * ROWS + l15], T) : 0;
@@ -588,7 +593,7 @@ __global__ __launch_bounds__(256) void lstm_bwd_kernel(const float* __restrict__
         *reinterpret_cast<uint4*>(dz + ((int64_t)bb * T + t) * grow + dir * 4 * H + c * 8) = make_uint4(0, 0, 0, 0);
       }
     }
-    const u64* tag0 = ex_group + (int64_t)(1 * G + 0) * PAIR;   // (destination 1, sender 0): member 0 writes it every step
+    const u64* tag0 = ex_group + (G > 1 ? (int64_t)(1 * G + 0) * PAIR : 0);   // (destination 1, sender 0): member 0 writes it every step (G = 1: a progress granule)
     int seen = -1;
     for (int it = 0; it < smax; ++it) {
       const int sp = smax - 1 - it;
@@ -900,6 +905,9 @@ __global__ __launch_bounds__(256) void lstm_bwd_kernel(const float* __restrict__
       for (int r = 0; r < RPL; ++r) part[ub][r] = acc[ub][r];
     prepare(lean && s == 1);                 // coefficients of step s-1 (its operands were loaded above)
     LSTM_STAMP(2048, smax - 1 - s, 6);
+    if constexpr (G == 1) {                  // (see lstm_fwd_kernel: the companion's pace)
+      if (tid == 0 && (epoch & 3) == 3) granule_store(ex_group + (int64_t)(epoch & 1) * par_stride, epoch + 1, 0u, false);
+    }
     ++epoch;
     cur ^= 1;
     return ok;
@@ -910,7 +918,7 @@ __global__ __launch_bounds__(256) void lstm_bwd_kernel(const float* __restrict__
     for (; s >= smin && go; --s) go = iter(s, std::false_type{});
     for (; s >= 0 && go; --s) go = iter(s, std::true_type{});
   }
-  if (G > 1 && tid == 0) __hip_atomic_store(done_word, (u64)1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (tid == 0) __hip_atomic_store(done_word, (u64)1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   if (!ok && tid == 0) atomicOr(status, 2u);
 }
 
@@ -926,8 +934,8 @@ CoopGeom geom(int B, int H, int ndir, bool bwd, int rows = 16) {
   // the partial dh: ngroups x G x G (destination, sender) pairs x NUB*256
   const size_t HS = H / g.G;
   const size_t per_parity = bwd ? (size_t)g.ngroups * g.G * g.G * (HS / 16) * 256 : (size_t)g.ngroups * g.G * (rows >= 8 ? rows / 2 : rows) * HS;
-  g.exch_bytes = g.G > 1 ? (2 * per_parity + (size_t)g.ngroups * g.G + g.blocks) * sizeof(u64) : 0;   // + XCC-id table + done words
-  g.companions = g.G > 1 ? ((g.ngroups + 7) & ~7) * group_companions(H) : 0;   // prefetch companions (blocks nblk ...)
+  g.exch_bytes = (2 * per_parity + (size_t)g.ngroups * g.G + g.blocks) * sizeof(u64);   // + XCC-id table + done words (G = 1: progress granules + done words)
+  g.companions = ((g.ngroups + 7) & ~7) * group_companions(H);   // prefetch companions (blocks nblk ...)
   return g;
 }
 
@@ -981,7 +989,7 @@ int launch_fwd(float* xproj, const las_bf16* wp, const int32_t* length, las_bf16
   const CoopGeom g = geom(B, H, ndir, false, rows);
   unsigned* status = reinterpret_cast<unsigned*>(ws);
   u64* exch = reinterpret_cast<u64*>(reinterpret_cast<char*>(ws) + 64);
-  const int pf = g.G > 1 ? prefetch_mode() : 0;
+  const int pf = prefetch_mode();
   if (rows == 8) {
     hipLaunchKernelGGL((lstm_fwd_kernel<H, 8>), dim3(pf ? g.blocks + g.companions : g.blocks), dim3(256), 0, st, xproj, wp, length, y,
                        cbuf, c_last, h_last, exch, status, B, T, ndir, g.ngroups, pf);
@@ -1009,7 +1017,7 @@ int launch_bwd(const float* gates, const float* cbuf, const float* dy, const flo
   const CoopGeom g = geom(B, H, ndir, true, rows);
   unsigned* status = reinterpret_cast<unsigned*>(ws);
   u64* exch = reinterpret_cast<u64*>(reinterpret_cast<char*>(ws) + 64);
-  const int pf = g.G > 1 ? prefetch_mode() : 0;
+  const int pf = prefetch_mode();
   // The weight-gradient GEMMs of the layer above run beside this kernel on the second stream.  Asking for LDS the
   // kernel does not use keeps their workgroups (32 KiB of LDS each) off the CUs of the chain's workgroups: measured
   // 7.96 ms per metric-M step with them kept off, 8.5 ms when one fits beside a chain workgroup.  The request is what
@@ -1084,7 +1092,7 @@ extern "C" int las_lstm_recurrent_fwd(float* xproj, const las_bf16* wpacked, con
   LAS_REQUIRE(workspace != nullptr && ((uintptr_t)workspace % 16 == 0), "las_lstm_recurrent_fwd: workspace missing or misaligned");
   hipStream_t st = (hipStream_t)stream;
   int rc = 0;
-  if (!(coop_members(H) > 1 && prefetch_mode())) {       // otherwise the companions clear the rows beyond each length
+  if (!prefetch_mode()) {       // otherwise the companions clear the rows beyond each length
     rc = las_check_hip(hipMemsetAsync(y, 0, (size_t)B * T * ndir * H * sizeof(las_bf16), st), "memset y");
     if (rc) return rc;
   }
@@ -1110,7 +1118,7 @@ extern "C" int las_lstm_recurrent_bwd(const float* gates, const float* cbuf, con
   LAS_REQUIRE(workspace != nullptr && ((uintptr_t)workspace % 16 == 0), "las_lstm_recurrent_bwd: workspace missing or misaligned");
   hipStream_t st = (hipStream_t)stream;
   int rc = 0;
-  if (!(coop_members(H) > 1 && prefetch_mode())) {
+  if (!prefetch_mode()) {
     rc = las_check_hip(hipMemsetAsync(dz, 0, (size_t)B * T * ndir * 4 * H * sizeof(las_bf16), st), "memset dz");
     if (rc) return rc;
   }

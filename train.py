@@ -203,11 +203,12 @@ def main(args):
                 save_checkpoint(model, ckpt)
     model.check_device_status()
     torch.cuda.synchronize()
+    t_end = time.time()                          # (the steps' clock stops before the final checkpoint is written)
     if rank == 0:
         save_checkpoint(model, ckpt)
         print('finished at global_step %d in %.1f s' % (model.global_step, time.time() - t0))
         if model.global_step > 10 and n_utt:
-            print('throughput after step 10: %.1f utterances/s' % (n_utt / max(time.time() - t_log, 1e-9)))
+            print('throughput after step 10: %.1f utterances/s' % (n_utt / max(t_end - t_log, 1e-9)))
     if args.valid:
         evaluate(model, make_input(args.valid, 1, True), dev, rank, world)
 
