@@ -907,8 +907,8 @@ __global__ __launch_bounds__(256) void dec_persist_fwd_kernel(las_dec_persist p)
 //     conflicts (4 lanes per frame, 16 frames per wave).
 // ------------------------------------------------------------------------------------------------
 constexpr int LEAN_KPAD = 32;                       // bf16 elements of padding per LDS key row (row stride = 64 mod 128 bytes)
-struct LeanLayout { size_t hq, pq, vq, sc, red, cred, zred, flags, hqb, keys, vals, total_bytes; int fq, kst, cols_per; };
-__host__ __device__ inline LeanLayout lean_layout(int Hd, int Tm, int M) {
+struct LeanLayout { size_t hq, pq, vq, sc, red, cred, zred, flags, hqb, tok, keys, vals, total_bytes; int fq, kst, cols_per; };
+__host__ __device__ inline LeanLayout lean_layout(int Hd, int Tm, int M, int U) {
   LeanLayout l;
   size_t o = 0;                                     // in floats
   l.hq = o; o += Hd;
@@ -920,6 +920,7 @@ __host__ __device__ inline LeanLayout lean_layout(int Hd, int Tm, int M) {
   l.zred = o; o += (size_t)4 * 8 * persist_red_stride(Hd);      // [4 waves][8 utterances][columns per member + 1]
   l.flags = o; o += 8;
   l.hqb = o; o += Hd / 2;
+  l.tok = o; o += (size_t)((U + 3) & ~3);            // the utterance's fed token ids, all steps
   o = (o + 3) & ~(size_t)3;
   l.fq = (Tm + 3) / 4;
   l.kst = Hd + LEAN_KPAD;
@@ -930,9 +931,9 @@ __host__ __device__ inline LeanLayout lean_layout(int Hd, int Tm, int M) {
   l.total_bytes = ((o + 3) & ~(size_t)3) * sizeof(float);
   return l;
 }
-__host__ __device__ inline bool persist_fwd_lean_ok(int Hd, int M, int Tm, int att, int norm) {
+__host__ __device__ inline bool persist_fwd_lean_ok(int Hd, int M, int Tm, int U, int att, int norm) {
   return (att == LAS_ATT_LUONG || att == LAS_ATT_BAHDANAU) && norm == LAS_NORM_SOFTMAX && (Hd == 128 || Hd == 256 || Hd == 512) && M % 32 == 0 &&
-         lean_layout(Hd, Tm, M).total_bytes <= 158 * 1024;
+         lean_layout(Hd, Tm, M, U).total_bytes <= 158 * 1024;
 }
 
 typedef __attribute__((ext_vector_type(2))) __bf16 las_bf16x2;
@@ -955,7 +956,7 @@ __global__ __launch_bounds__(256) void dec_persist_fwd_lean_kernel(las_dec_persi
   unsigned* status = reinterpret_cast<unsigned*>(p.workspace);
   pu64* flags = reinterpret_cast<pu64*>(reinterpret_cast<char*>(p.workspace) + 64) + (size_t)group * 2 * P_MEMBERS;
   pu64* xcc_tab = flags + P_MEMBERS;
-  const LeanLayout L = lean_layout(Hd, Tm, M);
+  const LeanLayout L = lean_layout(Hd, Tm, M, U);
   float* hq = sm + L.hq;
   float* pq = sm + L.pq;
   float* vq = sm + L.vq;
@@ -966,6 +967,7 @@ __global__ __launch_bounds__(256) void dec_persist_fwd_lean_kernel(las_dec_persi
   int* fail = reinterpret_cast<int*>(sm + L.flags);
   int* colo = fail + 1;
   unsigned short* hqb = reinterpret_cast<unsigned short*>(sm + L.hqb);
+  int* ltok = reinterpret_cast<int*>(sm + L.tok);
   unsigned short* lk = reinterpret_cast<unsigned short*>(sm + L.keys);
   unsigned short* lv = reinterpret_cast<unsigned short*>(sm + L.vals);
   const int RS = persist_red_stride(Hd);
@@ -1031,6 +1033,9 @@ __global__ __launch_bounds__(256) void dec_persist_fwd_lean_kernel(las_dec_persi
     if (ATT == LAS_ATT_BAHDANAU)
       for (int u = tid; u < Hd; u += 256) vq[u] = p.s.att_v[u];
   }
+  // the fed token ids of all steps (the teacher's: known up front).  From LDS the next step's id costs an LDS read; as a global
+  // load it was waited for at once (a workgroup-uniform value goes to a scalar register): an L2 round trip in every step
+  for (int i = tid; i < U; i += 256) ltok[i] = p.s.tok_ids[(int64_t)bsc * p.s.tok_stride + (int64_t)i * p.inc_tok];
   unsigned epoch = 0;
   const bool unit = tid < Hd && have;                      // this thread owns hidden units tid (+ 256) of utterance bs
   float bias4[UPT][4], c_reg[UPT];
@@ -1136,9 +1141,7 @@ __global__ __launch_bounds__(256) void dec_persist_fwd_lean_kernel(las_dec_persi
       }
     }
     LAS_STAMP(t, 2);
-    // the next step's token id (workgroup-uniform: the compiler moves it to a scalar register, i.e. waits for it at its
-    // first use -- the top of the next step, a whole step away; requested next to the operand loads it stalled them)
-    const int tok_next = p.s.tok_ids[(int64_t)bsc * p.s.tok_stride + (int64_t)min(t + 1, U - 1) * p.inc_tok];
+    const int tok_next = ltok[min(t + 1, U - 1)];            // the next step's token id
 
     // ---- S: cell + attention of utterance bs, frames / context columns of `part` ----
     if (have) {
@@ -2561,9 +2564,9 @@ extern "C" int las_decoder_persist_fwd(const las_dec_persist* p, void* stream) {
     const char* e = getenv("LAS_DEC_LEAN");
     lean_mode = (e && atoi(e) == 0) ? 0 : 1;
   }
-  if (lean_mode && p->sampling_prob <= 0.f && s->tok_rows && persist_fwd_lean_ok(s->Hd, s->M, s->Tm, s->attention, s->norm) &&
+  if (lean_mode && p->sampling_prob <= 0.f && s->tok_rows && persist_fwd_lean_ok(s->Hd, s->M, s->Tm, p->U, s->attention, s->norm) &&
       p->K_in / 32 <= (s->Hd == 512 ? 80 : 48)) {
-    const size_t lbytes = lean_layout(s->Hd, s->Tm, s->M).total_bytes;
+    const size_t lbytes = lean_layout(s->Hd, s->Tm, s->M, p->U).total_bytes;
 #define LAS_LEAN_LAUNCH(...)                                                                                                    \
   do {                                                                                                                          \
     static bool attr = false;                                                                                                   \
