@@ -4,7 +4,7 @@
 # both in KiB), MFMA-busy cycles and GUI-active cycles, next to the algorithmic bytes of the metric-M shapes.
 import csv, glob, json, sys
 rnd = sys.argv[1] if len(sys.argv) > 1 else 'r02'
-FAMILIES = {'lstm_fwd': 'lstm_fwd_kernel', 'lstm_bwd': 'lstm_bwd_kernel', 'dec_persist_fwd': 'dec_persist_fwd_kernel',
+FAMILIES = {'lstm_fwd': 'lstm_fwd_kernel', 'lstm_bwd': 'lstm_bwd_kernel', 'dec_persist_fwd': 'dec_persist_fwd_',
             'dec_persist_bwd': 'dec_persist_bwd_kernel', 'gemm_nt': 'gemm_nt_ring_kernel', 'gemm_tn_lstm': 'gemm_tn_ring_kernel', 'gemm_tn': 'gemm_tn_tr_kernel'}
 B, T, H = 64, 800, 256
 ALGO = {   # bytes per launch at the layer-1 shape (B=64, T=800, both directions)
