@@ -564,7 +564,7 @@ constexpr int P_MEMBERS = 32;
 __host__ __device__ inline size_t persist_flag_words(int B) { return (size_t)((B + 7) / 8) * 2 * P_MEMBERS; }
 __host__ __device__ inline size_t persist_exchange_words(int B, int Tm, int Hd, int M) {
   const size_t ld = (size_t)((Tm + 31) / 32) * 32;
-  const size_t fwd = 2 * (size_t)B * (ld + 5 * (size_t)Hd), bwd = 2 * (size_t)B * (4 + 3 * (size_t)Hd + (size_t)(M + Hd));
+  const size_t fwd = 2 * (size_t)B * (ld + 5 * (size_t)Hd), bwd = 2 * (size_t)B * (4 + 5 * (size_t)Hd + (size_t)(M + Hd));
   return fwd > bwd ? fwd : bwd;
 }
 // forward: scratch, and this workgroup's score frames of the keys [fq, Hd] + its context columns of the values [Tm, M/4]
@@ -1746,8 +1746,9 @@ __global__ __launch_bounds__(256) void dec_persist_bwd_kernel(las_dec_persist_bw
   pu64* flags = reinterpret_cast<pu64*>(reinterpret_cast<char*>(p.workspace) + 64) + (size_t)group * 2 * P_MEMBERS;
   pu64* xcc_tab = flags + P_MEMBERS;
   pu64* xdot = reinterpret_cast<pu64*>(reinterpret_cast<char*>(p.workspace) + 64) + persist_flag_words(B);   // [2][B][4]
-  pu64* xdh = xdot + 2 * (size_t)B * 4;                                                                        // [2][B][3][Hd]
-  pu64* xdf = xdh + 2 * (size_t)B * 3 * Hd;                                                                    // [2][B][W]
+  pu64* xdh = xdot + 2 * (size_t)B * 4;                                                                        // [2][B][4][Hd]
+  pu64* xdq = xdh + 2 * (size_t)B * 4 * Hd;                                                                    // [2][B][Hd]
+  pu64* xdf = xdq + 2 * (size_t)B * Hd;                                                                        // [2][B][W]
   if (tid == 0) { *fail = 0; *colo = 0; }
   __syncthreads();
   if (tid == 0) {
@@ -2101,13 +2102,17 @@ __global__ __launch_bounds__(256) void dec_persist_bwd_kernel(las_dec_persist_bw
         if (tid < Hd)
           for (int ph = 0; ph < P; ++ph) dh_own[q] += dhs[ph * Hd + tid + q * 256];
       }
-      pu64* xh = xdh + ((size_t)(xtag & 1) * B + b) * 3 * Hd;
-      if (part != 0) {
+      pu64* xh = xdh + ((size_t)(xtag & 1) * B + b) * 4 * Hd;
+      constexpr bool SPLITQ = WQ;            // query-layer attentions: the dh = d(pq) Wq^T product is split over the four parts
+      const bool splitq = SPLITQ && att_uses_wq(s0.attention);
+      // parts 1..3 send their partial sums to part 0 (slots 0..2); with the split product every part sends to every other
+      if (part != 0 || splitq) {
 #pragma unroll
         for (int q = 0; q < UPT; ++q)
-          if (tid < Hd) pgranule_store(xh + (size_t)(part - 1) * Hd + tid + q * 256, xtag, dh_own[q], local);
-      } else {
-        // ---- S3 on part 0: total dh, then the LSTM cell backward (Appendix F) ----
+          if (tid < Hd) pgranule_store(xh + (size_t)(splitq ? part : part - 1) * Hd + tid + q * 256, xtag, dh_own[q], local);
+      }
+      if (part == 0 || splitq) {
+        // ---- S3: total dh (part 0; every part when the product is split) ----
         float tot[UPT];
 #pragma unroll
         for (int q = 0; q < UPT; ++q) tot[q] = dh_own[q];
@@ -2119,7 +2124,8 @@ __global__ __launch_bounds__(256) void dec_persist_bwd_kernel(las_dec_persist_bw
           for (int q = 0; q < UPT; ++q)
 #pragma unroll
             for (int w = 0; w < 3; ++w) {
-              g3[q][w] = tid < Hd ? pgranule_load(xh + (size_t)w * Hd + tid + q * 256) : ((pu64)xtag << 32);
+              const int slot = splitq ? (w + (w >= part ? 1 : 0)) : w;          // the other three parts
+              g3[q][w] = tid < Hd ? pgranule_load(xh + (size_t)slot * Hd + tid + q * 256) : ((pu64)xtag << 32);
               got = got && ((unsigned)(g3[q][w] >> 32) == xtag);
             }
           if (__all(got)) {
@@ -2137,24 +2143,83 @@ __global__ __launch_bounds__(256) void dec_persist_bwd_kernel(las_dec_persist_bw
         for (int q = 0; q < UPT; ++q)
           if (tid < Hd) dhs[tid + q * 256] = tot[q];
       }
-    }
-    if (active && part == 0) {
-      __syncthreads();
-      if (WQ && att_uses_wq(s0.attention)) {
-        // dhs holds d(processed query): save it (bf16) for d(query_layer), map back: dh[u] = sum_a dpq[a] Wq[u][a]
-        float* tmp = dhs + Hd;
+      if constexpr (SPLITQ) if (splitq) {
+        // dhs holds d(processed query) in every part.  Part 0 saves it (bf16) for d(query_layer); each part maps ITS
+        // quarter of the units back -- dh[u] = sum_a dpq[a] Wq[u][a] over a quarter of Wq^T's columns (a quarter of the
+        // matrix from L2 instead of all of it on one workgroup: 11 of the 32 us of a 512-unit step) -- and parts 1..3 hand
+        // their quarters to part 0 as granules
+        __syncthreads();
         if (s0.attention == LAS_ATT_CUSTOM) {
           const float* pqv = s0.pq + (int64_t)b * s0.ldpq + (int64_t)t * p.inc_pq;
           for (int u = tid; u < Hd; u += 256) if (!(pqv[u] > 0.f)) dhs[u] = 0.f;
           __syncthreads();
         }
-        for (int u = tid; u < Hd; u += 256)
-          if (s0.dpq_out) s0.dpq_out[(int64_t)b * s0.lddpq + (int64_t)t * p.inc_pq + u] = las_f2bf(dhs[u]);
-        // (scratch: the G role's partial-tile area, idle between two products: 4 x 16 x 49 >= 2048 floats)
-        square_matvec_bf16(s0.wq_t, dhs, tmp, red2, Hd);
-        for (int u = tid; u < Hd; u += 256) dhs[u] = tmp[u];
+        if (part == 0)
+          for (int u = tid; u < Hd; u += 256)
+            if (s0.dpq_out) s0.dpq_out[(int64_t)b * s0.lddpq + (int64_t)t * p.inc_pq + u] = las_f2bf(dhs[u]);
+        const int qc = Hd / 4, c0 = part * qc;
+        const int AG = qc / 8, UG = 256 / AG;
+        {
+          const int ag = tid % AG, ug = tid / AG;
+          float acc[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+          const unsigned short* wp = s0.wq_t + c0 + ag * 8;
+          int r = ug;
+          for (; r + 7 * UG < Hd; r += 8 * UG) {
+            uint4 w[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) w[i] = ld16(wp + (int64_t)(r + i * UG) * Hd);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+              const unsigned short* e = reinterpret_cast<const unsigned short*>(&w[i]);
+              const float xv = dhs[r + i * UG];
+#pragma unroll
+              for (int j = 0; j < 8; ++j) acc[j] += xv * las_bf2f(e[j]);
+            }
+          }
+          for (; r < Hd; r += UG) {
+            const uint4 w = ld16(wp + (int64_t)r * Hd);
+            const unsigned short* e = reinterpret_cast<const unsigned short*>(&w);
+            const float xv = dhs[r];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[j] += xv * las_bf2f(e[j]);
+          }
+          // (scratch: the G role's partial-tile area, idle between two products: at least 2048 floats)
+#pragma unroll
+          for (int j = 0; j < 8; ++j) red2[(ug * AG + ag) * 8 + j] = acc[j];
+        }
         __syncthreads();
+        pu64* xq = xdq + ((size_t)(xtag & 1) * B + b) * Hd;
+        float* tmp = dhs + Hd;                      // (dhs: 2048 floats, Hd <= 512)
+        for (int c = tid; c < qc; c += 256) {
+          float v = 0.f;
+          for (int g = 0; g < UG; ++g) v += red2[(g * AG + (c >> 3)) * 8 + (c & 7)];
+          if (part == 0) tmp[c0 + c] = v;
+          else pgranule_store(xq + c0 + c, xtag, v, local);
+        }
+        if (part == 0) {
+          for (int a0 = 0; a0 < Hd; a0 += 256) {
+            const int aa = a0 + tid;
+            const bool need = aa < Hd && aa >= qc;
+            unsigned spins = 0;
+            for (;;) {
+              const pu64 gq = need ? pgranule_load(xq + aa) : ((pu64)xtag << 32);
+              if (__all((unsigned)(gq >> 32) == xtag)) {
+                if (need) tmp[aa] = __uint_as_float((unsigned)gq);
+                break;
+              }
+              if (++spins > P_SPIN_LIMIT || *fail) { if (lane == 0) *fail = 1; break; }
+              __builtin_amdgcn_s_sleep(1);
+            }
+          }
+          __syncthreads();
+          for (int u = tid; u < Hd; u += 256) dhs[u] = tmp[u];
+        }
       }
+    }
+    if (active && part == 0) {
+      __syncthreads();
       if (cellw) {
 #pragma unroll
         for (int q = 0; q < UPT; ++q) {
