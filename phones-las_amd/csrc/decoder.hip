@@ -138,6 +138,14 @@ __device__ void square_matvec_bf16(const unsigned short* __restrict__ W, const f
 // phase (each part reads a quarter of the keys instead of all of them), publish their raw scores in a per-step row of
 // global scratch and meet at the group's flag barrier before the softmax.
 typedef unsigned long long pu64;
+// Workgroup barrier that orders LDS traffic only (what the workgroups exchange through global memory is ordered by the granule
+// tags and by persist_barrier's own vmcnt(0); threads of one workgroup exchange through LDS only).  Used inside the one-launch
+// decoder's step loops; measured: no difference to __syncthreads() there (hipcc's barrier does not drain vmcnt on gfx950
+// either -- the vmcnt(0) waits of the phases come from the compiler's own tracking of loads carried across iterations).
+__device__ __forceinline__ void lds_barrier() {
+  __builtin_amdgcn_s_waitcnt(0xC07F);      // lgkmcnt(0) only (vmcnt, expcnt untouched)
+  __builtin_amdgcn_s_barrier();
+}
 // 8-byte {tag, fp32} granule of the persistent decoder's utterance-local exchanges (see persist_exchange_words)
 __device__ __forceinline__ void pgranule_store(pu64* p, unsigned tag, float value, bool local) {
   const pu64 x = ((pu64)tag << 32) | __float_as_uint(value);
@@ -1130,7 +1138,7 @@ __global__ __launch_bounds__(256) void dec_persist_fwd_lean_kernel(las_dec_persi
           for (int r = 0; r < 4; ++r) zred[(wave * 8 + lq * 4 + r) * RS + nt * 16 + l15] = acc[nt][r];
       }
       LAS_STAMP(t, 1);
-      __syncthreads();
+      lds_barrier();
       for (int e = tid; e < 8 * CPM; e += 256) {
         const int row = e / CPM, col = e % CPM;
         const int b = group * 8 + row;
@@ -1190,7 +1198,7 @@ __global__ __launch_bounds__(256) void dec_persist_fwd_lean_kernel(las_dec_persi
         }
       }
       LAS_STAMP(t, 3);
-      __syncthreads();
+      lds_barrier();
       LAS_STAMP(t, 4);
       if (ATT == LAS_ATT_BAHDANAU) {
         // processed query pq = h Wq: every part forms ITS quarter of the columns (a quarter of Wq from L2 instead of all of
@@ -1228,7 +1236,7 @@ __global__ __launch_bounds__(256) void dec_persist_fwd_lean_kernel(las_dec_persi
 #pragma unroll
           for (int j = 0; j < 8; ++j) cred[(ug * AG + ag) * 8 + j] = acc[j];
         }
-        __syncthreads();
+        lds_barrier();
         for (int c = tid; c < qc; c += 256) {
           float v = 0.f;
           for (int g = 0; g < UG; ++g) v += cred[(g * AG + (c >> 3)) * 8 + (c & 7)];
@@ -1250,7 +1258,7 @@ __global__ __launch_bounds__(256) void dec_persist_fwd_lean_kernel(las_dec_persi
             __builtin_amdgcn_s_sleep(1);
           }
         }
-        __syncthreads();
+        lds_barrier();
       }
       // ---- raw scores of my frames ----
       {
@@ -1307,7 +1315,7 @@ __global__ __launch_bounds__(256) void dec_persist_fwd_lean_kernel(las_dec_persi
           __builtin_amdgcn_s_sleep(1);
         }
       }
-      __syncthreads();
+      lds_barrier();
       LAS_STAMP(t, 6);
       // ---- masked softmax over the frames: every wave reduces its own elements (max, then the sum relative to that
       //      max); the four (max, sum) pairs meet in LDS behind ONE barrier and every thread rescales ----
@@ -1323,7 +1331,7 @@ __global__ __launch_bounds__(256) void dec_persist_fwd_lean_kernel(las_dec_persi
         }
         sw = las_wave_sum_dpp(sw);
         if (lane == 0) { red[wave] = mw; red[4 + wave] = sw; }
-        __syncthreads();
+        lds_barrier();
         const float mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
         float sum = 0.f;
 #pragma unroll
@@ -1339,7 +1347,7 @@ __global__ __launch_bounds__(256) void dec_persist_fwd_lean_kernel(las_dec_persi
             if (abf) abf[tf] = las_f2bf(pr);
           }
         }
-        __syncthreads();
+        lds_barrier();
       }
       LAS_STAMP(t, 7);
       // ---- context columns [c_begin, c_begin + ncols): Lc lanes cover a frame with 16-byte LDS reads, Pc frame phases ----
@@ -1376,7 +1384,7 @@ __global__ __launch_bounds__(256) void dec_persist_fwd_lean_kernel(las_dec_persi
         LAS_STAMP(t, 8);
         *reinterpret_cast<float4*>(cred + tid * 8) = make_float4(a[0], a[1], a[2], a[3]);
         *reinterpret_cast<float4*>(cred + tid * 8 + 4) = make_float4(a[4], a[5], a[6], a[7]);
-        __syncthreads();
+        lds_barrier();
         for (int j = tid; j < ncols; j += 256) {
           const int cl2 = j >> 3, e = j & 7;
           float acc = 0.f;
@@ -1913,7 +1921,7 @@ __global__ __launch_bounds__(256) void dec_persist_bwd_kernel(las_dec_persist_bw
         const float* arow = s0.align + (int64_t)b * s0.lda + (int64_t)t * p.inc_align;
         for (int tt = f0 + 256 + tid; tt < f1; tt += 256) alg[tt] = tt < len ? arow[tt] : 0.f;
       }
-      __syncthreads();
+      lds_barrier();
       LAS_STAMPB(p.U - 1 - t, 2);
       {
         const int sub = lane & 15, grp = lane >> 4;
@@ -1986,13 +1994,13 @@ __global__ __launch_bounds__(256) void dec_persist_bwd_kernel(las_dec_persist_bw
         else if (resident) dalign_pass(lvals, f0);
         else dalign_pass(vals, 0);
       }
-      __syncthreads();
+      lds_barrier();
       LAS_STAMPB(p.U - 1 - t, 3);
       float dot = 0.f;
       for (int tt = f0 + tid; tt < flen; tt += 256) dot += alg[tt] * dal[tt];
       dot = las_wave_sum_dpp(dot);                          // (DPP row sums + one barrier instead of 12 LDS permutes + two)
       if (lane == 0) red[8 + wave] = dot;
-      __syncthreads();
+      lds_barrier();
       if (tid == 0) pgranule_store(xdot + ((size_t)(xtag & 1) * B + b) * 4 + part, xtag, red[8] + red[9] + red[10] + red[11], local);
     }
     LAS_STAMPB(p.U - 1 - t, 4);
@@ -2011,7 +2019,7 @@ __global__ __launch_bounds__(256) void dec_persist_bwd_kernel(las_dec_persist_bw
         const float d0 = __shfl(v, 0, 64), d1 = __shfl(v, 1, 64), d2 = __shfl(v, 2, 64), d3 = __shfl(v, 3, 64);
         if (lane == 0) red[0] = d0 + d1 + d2 + d3;
       }
-      __syncthreads();
+      lds_barrier();
       LAS_STAMPB(p.U - 1 - t, 5);
       const float dot = red[0];
       unsigned short* dso = s0.ds_out + (int64_t)b * s0.ldso + (int64_t)t * p.inc_ds;
@@ -2020,7 +2028,7 @@ __global__ __launch_bounds__(256) void dec_persist_bwd_kernel(las_dec_persist_bw
         dal[tt] = v;
         dso[tt] = las_f2bf(v);
       }
-      __syncthreads();
+      lds_barrier();
       LAS_STAMPB(p.U - 1 - t, 6);
       const int L = Hd / 8, P = 256 / L;
       const int phase = tid / L, u = (tid % L) * 8;
@@ -2092,7 +2100,7 @@ __global__ __launch_bounds__(256) void dec_persist_bwd_kernel(las_dec_persist_bw
 #pragma unroll
         for (int j = 0; j < 8; ++j) dhs[phase * Hd + u + j] = a[j];
       }
-      __syncthreads();
+      lds_barrier();
       LAS_STAMPB(p.U - 1 - t, 7);
       // partial dh of this workgroup's frames (unit = threadIdx.x; Hd <= 256): parts 1..3 send theirs to part 0 as granules
       float dh_own[UPT];
@@ -2138,7 +2146,7 @@ __global__ __launch_bounds__(256) void dec_persist_bwd_kernel(las_dec_persist_bw
           if (++spins > P_SPIN_LIMIT || *fail) { if (lane == 0) *fail = 1; break; }
           __builtin_amdgcn_s_sleep(1);
         }
-        __syncthreads();                            // dhs (the per-phase partials) has been read by everybody
+        lds_barrier();                            // dhs (the per-phase partials) has been read by everybody
 #pragma unroll
         for (int q = 0; q < UPT; ++q)
           if (tid < Hd) dhs[tid + q * 256] = tot[q];
@@ -2148,11 +2156,11 @@ __global__ __launch_bounds__(256) void dec_persist_bwd_kernel(las_dec_persist_bw
         // quarter of the units back -- dh[u] = sum_a dpq[a] Wq[u][a] over a quarter of Wq^T's columns (a quarter of the
         // matrix from L2 instead of all of it on one workgroup: 11 of the 32 us of a 512-unit step) -- and parts 1..3 hand
         // their quarters to part 0 as granules
-        __syncthreads();
+        lds_barrier();
         if (s0.attention == LAS_ATT_CUSTOM) {
           const float* pqv = s0.pq + (int64_t)b * s0.ldpq + (int64_t)t * p.inc_pq;
           for (int u = tid; u < Hd; u += 256) if (!(pqv[u] > 0.f)) dhs[u] = 0.f;
-          __syncthreads();
+          lds_barrier();
         }
         if (part == 0)
           for (int u = tid; u < Hd; u += 256)
@@ -2189,7 +2197,7 @@ __global__ __launch_bounds__(256) void dec_persist_bwd_kernel(las_dec_persist_bw
 #pragma unroll
           for (int j = 0; j < 8; ++j) red2[(ug * AG + ag) * 8 + j] = acc[j];
         }
-        __syncthreads();
+        lds_barrier();
         pu64* xq = xdq + ((size_t)(xtag & 1) * B + b) * Hd;
         float* tmp = dhs + Hd;                      // (dhs: 2048 floats, Hd <= 512)
         for (int c = tid; c < qc; c += 256) {
@@ -2213,13 +2221,13 @@ __global__ __launch_bounds__(256) void dec_persist_bwd_kernel(las_dec_persist_bw
               __builtin_amdgcn_s_sleep(1);
             }
           }
-          __syncthreads();
+          lds_barrier();
           for (int u = tid; u < Hd; u += 256) dhs[u] = tmp[u];
         }
       }
     }
     if (active && part == 0) {
-      __syncthreads();
+      lds_barrier();
       if (cellw) {
 #pragma unroll
         for (int q = 0; q < UPT; ++q) {
@@ -2295,7 +2303,7 @@ __global__ __launch_bounds__(256) void dec_persist_bwd_kernel(las_dec_persist_bw
           for (int r = 0; r < 4; ++r) red2[(wave * 8 + lq * 4 + r) * RS2 + j * 16 + l15] = acc[j][r];
       }
       LAS_STAMPB(p.U - 1 - t, 10);
-      __syncthreads();
+      lds_barrier();
       float* df = p.dfeed_all + (int64_t)t * B * W;
       for (int e = tid; e < 8 * NT_MAX * 16; e += 256) {
         const int row = e / (NT_MAX * 16), c = e % (NT_MAX * 16), j = c / 16, col = c % 16;
