@@ -129,6 +129,12 @@ typedef struct las_image_job {
 } las_image_job;
 int las_refresh_images(const las_image_job* jobs_dev, int njobs, void* stream);
 
+/* out[r, c] = bf16(a[r, c] + b[r, c]) over a [rows, cols] window (row strides in elements), b nullable: the general decoder's
+ * d(attention_t) = d(output projection)_t + d(feed into step t+1) as the attention layer's bf16 GEMM operand, in one launch
+ * instead of a copy, an add and a cast. */
+int las_add_cast_bf16(const float* a, int64_t lda, const float* b, int64_t ldb, las_bf16* out, int64_t ldo, int rows, int cols,
+                      void* stream);
+
 /* A one-wave kernel that keeps `stream` busy for about `microseconds` (0..1000): put in front of side-stream work that
  * becomes runnable at the same moment as a persistent recurrent launch on the main stream and should not take CUs before
  * that launch's workgroups are resident (a chain that finds some of its CUs taken starts late as a whole). */
@@ -228,7 +234,8 @@ typedef struct las_dec_step {
   int64_t ldco;
   las_bf16* h_out;               /* h_t as bf16, row stride ldh */
   int64_t ldh;
-  las_bf16* h_out2;              /* optional second copy (next step's GEMM operand), row stride ldh2 */
+  las_bf16* h_out2;              /* optional second copy (next step's GEMM operand), row stride ldh2; LAS_DEC_ATTENTION_ONLY:
+                                  * optional copy of the QUERY (the attention layer's operand [query | context]) */
   int64_t ldh2;
   const las_bf16* keys;          /* [B,Tm,Hd] */
   const las_bf16* values;        /* [B,Tm,M]  (memory, zero beyond mem_len) */

@@ -82,6 +82,17 @@ __global__ void delay_kernel(long long ticks) {
   while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(16);
 }
 
+// out = bf16(a + b), b nullable (las_add_cast_bf16)
+__global__ void add_cast_kernel(const float* a, int64_t lda, const float* b, int64_t ldb, unsigned short* out, int64_t ldo, int rows, int cols) {
+  const int64_t total = (int64_t)rows * cols;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int r = (int)(i / cols), c = (int)(i % cols);
+    float v = a[(int64_t)r * lda + c];
+    if (b) v += b[(int64_t)r * ldb + c];
+    out[(int64_t)r * ldo + c] = las_f2bf(v);
+  }
+}
+
 struct FillTable { las_fill_job job[LAS_FILL_MAX_JOBS]; };
 
 // blockIdx.y = job; the table is a kernel argument (see las_fill_many)
@@ -145,6 +156,16 @@ extern "C" int las_refresh_images(const las_image_job* jobs_dev, int njobs, void
   LAS_REQUIRE(jobs_dev != nullptr && njobs > 0 && njobs <= 65535, "las_refresh_images: bad job table (njobs=%d)", njobs);
   hipLaunchKernelGGL(refresh_images_kernel, dim3(96, njobs), dim3(256), 0, (hipStream_t)stream, jobs_dev);
   LAS_LAUNCH_CHECK("refresh images launch");
+  return LAS_OK;
+}
+
+extern "C" int las_add_cast_bf16(const float* a, int64_t lda, const float* b, int64_t ldb, las_bf16* out, int64_t ldo, int rows, int cols,
+                                 void* stream) {
+  LAS_REQUIRE(a != nullptr && out != nullptr && rows > 0 && cols > 0, "las_add_cast_bf16: bad arguments");
+  int blocks = (int)(((int64_t)rows * cols + 255) / 256);
+  if (blocks > 1024) blocks = 1024;
+  hipLaunchKernelGGL(add_cast_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a, lda, b, ldb, out, ldo, rows, cols);
+  LAS_LAUNCH_CHECK("add cast launch");
   return LAS_OK;
 }
 

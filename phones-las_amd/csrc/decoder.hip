@@ -216,7 +216,11 @@ __device__ void dec_step_fwd_body(const las_dec_step& s, const int b, const int 
 
   if (s.mode == LAS_DEC_ATTENTION_ONLY) {
     // the query comes from another cell (top of a MultiRNNCell stack, las/model.py:194-200)
-    for (int u = tid; u < Hd; u += 256) hq[u] = las_bf2f(s.query[(int64_t)b * s.ldq + u]);
+    for (int u = tid; u < Hd; u += 256) {
+      const unsigned short qv = s.query[(int64_t)b * s.ldq + u];
+      hq[u] = las_bf2f(qv);
+      if (writer && s.h_out2) s.h_out2[(int64_t)b * s.ldh2 + u] = qv;      // the query next to the context: [query | context]
+    }
   } else {
   // ---- LSTM cell (Appendix A.1) ----
   // (persistent decoder with scheduled sampling: the id was written by another workgroup during this launch and shares

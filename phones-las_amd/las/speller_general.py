@@ -253,7 +253,8 @@ class GeneralSpeller:
             return hip.NORM_MONOTONIC_HARD
         return hip.NORM_MONOTONIC_PARALLEL
 
-    def _cell_fwd(self, l, t, sv, z, tok_ids, tok_stride):
+    def _cell_fwd(self, l, t, sv, z, tok_ids, tok_stride, h2=None):
+        """h2: (address, row stride) of a second place for h_t (the next step's operand row): written by the kernel, not by a copy."""
         B, Hd, U = sv['B'], self.Hd, sv['U']
         s = hip.DecStep()
         s.B, s.Hd, s.M, s.Tm, s.attention, s.mode = B, Hd, self.M, sv['Tm'], self.att, hip.DEC_CELL_ONLY
@@ -264,12 +265,16 @@ class GeneralSpeller:
         s.gates_out, s.ldg = hip.addr(sv['gates'][l], t * 4 * Hd), U * 4 * Hd
         s.c_out, s.ldco = hip.addr(sv['cs'][l], (t + 1) * Hd), (U + 1) * Hd
         s.h_out, s.ldh = hip.addr(sv['h'][l], t * Hd), U * Hd
+        if h2 is not None:
+            s.h_out2, s.ldh2 = h2
         s.drop_keep, s.feed_width = 1.0, self.E + self.A
         if l == 0 and sv['keep'] < 1.0 and not self.tokx:   # the one-hot token entry survives with probability keep (scaled 1/keep)
             s.drop_keep, s.drop_seed, s.drop_stream, s.step = sv['keep'], sv['seed'], self.DEC_STREAM, t
         hip.check(hip.lib().las_decoder_step_fwd(C.byref(s), 1, hip.stream()))
 
-    def _attention_fwd(self, t, sv, query, ldq):
+    def _attention_fwd(self, t, sv, query, ldq, qc=None):
+        """qc: (address, row stride) of this step's [query | context] operand row of the attention layer: the kernel writes both
+        halves itself."""
         B, Hd, U, Tm, M = sv['B'], self.Hd, sv['U'], sv['Tm'], self.M
         Tmp = _r8(Tm)
         s = hip.DecStep()
@@ -283,6 +288,9 @@ class GeneralSpeller:
             s.att_v = hip.addr(self.att_v)
         s.align_out, s.align_bf16, s.lda = hip.addr(sv['align'], t * Tmp), hip.addr(sv['align_bf'], t * Tmp), U * Tmp
         s.ctx_out, s.ldc = hip.addr(sv['ctx'], t * M), U * M
+        if qc is not None:
+            s.h_out2, s.ldh2 = qc[0], qc[1]
+            s.ctx_out2, s.ldc2 = qc[0] + 2 * Hd, qc[1]
         s.drop_keep, s.feed_width, s.step = 1.0, self.E + self.A, t
         s.norm = sv.get('norm', hip.NORM_SOFTMAX)
         if self.mono:
@@ -350,28 +358,37 @@ class GeneralSpeller:
                     hip.check(lib.las_dropout_bf16(hip.addr(X[l], t * Kl), U * Kl, hip.addr(X[l], t * Kl), U * Kl, B,
                                                    self.win[l], keep, seed, self.in_stream(l, t), st))
                 hip.gemm_nt(X[l][:, t], self.kT[l], z, B, 4 * Hd, Kl, lda=U * Kl, ldb=Kl, ldc=4 * Hd)
-                self._cell_fwd(l, t, sv, z, hip.addr(fed, t), fed.stride(0))
-                if not last:
-                    X[l][:, t + 1, self.win[l]:].copy_(h[l][:, t])     # recurrent input of the next step
+                # (h_t also lands in the next step's operand row: the recurrent input, written by the cell kernel)
+                self._cell_fwd(l, t, sv, z, hip.addr(fed, t), fed.stride(0),
+                               h2=None if last else (hip.addr(X[l], (t + 1) * Kl + self.win[l]), U * Kl))
 
             run_cell(0)
             if not self.bottom:
                 for l in range(1, NL):
                     X[l][:, t, :Hd].copy_(h[l - 1][:, t])
                     run_cell(l)
-            self._attention_fwd(t, sv, hip.addr(h[qlayer], t * Hd), U * Hd)
+            # (the attention kernel leaves [query | context] in the attention layer's operand row itself: no copies)
+            self._attention_fwd(t, sv, hip.addr(h[qlayer], t * Hd), U * Hd,
+                                qc=(hip.addr(sv['qc'], t * (Hd + M)), U * (Hd + M)) if self.has_al else None)
+            # Dense(A, no bias) on [query, context].  Where nothing else needs attention_t at once -- one cell, no input dropout
+            # (which is applied to the operand row in place), no scheduled sampling -- the product writes it straight into the
+            # next step's operand row and `att` is gathered from there once after the loop
+            direct = self.has_al and NL == 1 and keep >= 1.0 and sampling == 0.0 and not last
             if self.has_al:                                           # Dense(A, no bias) on [query, context]
-                sv['qc'][:, t, :Hd].copy_(h[qlayer][:, t])
-                sv['qc'][:, t, Hd:].copy_(sv['ctx'][:, t])
-                hip.gemm_nt(sv['qc'][:, t], self.walT, att[:, t], B, A, Hd + M, lda=U * (Hd + M), ldb=Hd + M, ldc=U * A,
-                            out_bf16=True)
+                if direct:
+                    K0 = self.win[0] + Hd
+                    hip.gemm_nt(sv['qc'][:, t], self.walT, X[0][:, t + 1, self.T0:], B, A, Hd + M, lda=U * (Hd + M), ldb=Hd + M,
+                                ldc=U * K0, out_bf16=True)
+                else:
+                    hip.gemm_nt(sv['qc'][:, t], self.walT, att[:, t], B, A, Hd + M, lda=U * (Hd + M), ldb=Hd + M, ldc=U * A,
+                                out_bf16=True)
             if self.bottom:
                 for l in range(1, NL):
                     wc = A if l == 1 else Hd
                     X[l][:, t, :wc].copy_(att[:, t] if l == 1 else h[l - 1][:, t])
                     # X[l][:, t, wc:wc+A] already holds attention_{t-1} (written at the end of step t-1; zero at t=0)
                     run_cell(l)
-            if not last:
+            if not last and not direct:
                 X[0][:, t + 1, self.T0:self.T0 + A].copy_(att[:, t])
                 if self.bottom:
                     for l in range(1, NL):
@@ -390,6 +407,8 @@ class GeneralSpeller:
                 elif not last:
                     hip.check(lib.las_sample_tokens(hip.addr(logits, t * Vp), U * Vp, V, hip.addr(tin, t + 1), tin.stride(0),
                                                     hip.addr(fed, t + 1), fed.stride(0), B, sampling, seed, t, st))
+        if self.has_al and NL == 1 and keep >= 1.0 and sampling == 0.0 and U > 1:
+            att[:, :U - 1].copy_(X[0][:, 1:, self.T0:self.T0 + A])       # the steps that wrote into the operand rows (see above)
         out_all = h[NL - 1] if (self.bottom and NL > 1) else att
         sv['out'] = out_all
         if logits is None:
@@ -481,18 +500,24 @@ class GeneralSpeller:
                     src = v(d_out, t * P, U * P) if l == NL - 1 else v(dx[l + 1][cur], 0, W[l + 1])
                     cell_and_gemm(l, [src])
             # gradient w.r.t. attention_t
-            if self.bottom and NL > 1:
-                datt.copy_(dx[1][cur][:, :A])
+            if self.has_al and NL == 1:
+                # d(attention_t) = d(output projection)_t + d(feed into step t+1), as the attention layer's bf16 operand: one launch
+                hip.check(lib.las_add_cast_bf16(hip.addr(d_out, t * P), U * P, hip.addr(dx[0][nxt], self.T0) if has_next else None,
+                                                W[0], hip.addr(datt_bf, t * A), U * A, B, A, st))
             else:
-                datt.copy_(d_out[:, t])
-            if has_next:
-                datt.add_(dx[0][nxt][:, self.T0:self.T0 + A])
-                if self.bottom:
-                    for l in range(1, NL):
-                        wc = A if l == 1 else Hd
-                        datt.add_(dx[l][nxt][:, wc:wc + A])
+                if self.bottom and NL > 1:
+                    datt.copy_(dx[1][cur][:, :A])
+                else:
+                    datt.copy_(d_out[:, t])
+                if has_next:
+                    datt.add_(dx[0][nxt][:, self.T0:self.T0 + A])
+                    if self.bottom:
+                        for l in range(1, NL):
+                            wc = A if l == 1 else Hd
+                            datt.add_(dx[l][nxt][:, wc:wc + A])
+                if self.has_al:
+                    hip.cast_bf16(datt, B, A, datt_bf[:, t], B, A, ldd=U * A, lds=A)
             if self.has_al:
-                hip.cast_bf16(datt, B, A, datt_bf[:, t], B, A, ldd=U * A, lds=A)
                 hip.gemm_nt(datt_bf[:, t], self.waln, dqc, B, Hd + M, A, lda=U * A, ldb=A, ldc=Hd + M)
                 dctx_ptr, dctx_ld = hip.addr(dqc, Hd), Hd + M
             else:
