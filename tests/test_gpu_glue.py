@@ -105,3 +105,22 @@ def test_stream_delay_holds_its_stream_only():
     assert float(x) == 1.0
     assert lib.las_stream_delay(5000, side.cuda_stream) != 0       # out of range: refused
     assert lib.las_stream_delay(0, side.cuda_stream) == 0
+
+
+def test_add_cast_bf16_windows():
+    from phones_las_amd import hip
+    lib = hip.lib()
+    dev = 'cuda'
+    a = torch.randn(5, 3, 40, device=dev)          # row r = a[r, 1, 8:28]: strided window
+    b = torch.randn(5, 64, device=dev)
+    out = torch.full((5, 7, 24), 9.0, dtype=torch.bfloat16, device=dev)
+    hip.check(lib.las_add_cast_bf16(hip.addr(a, 1 * 40 + 8), 3 * 40, hip.addr(b, 16), 64, hip.addr(out, 2 * 24 + 2), 7 * 24, 5, 20, hip.stream()))
+    torch.cuda.synchronize()
+    ref = (a[:, 1, 8:28] + b[:, 16:36]).to(torch.bfloat16)
+    assert torch.equal(out[:, 2, 2:22], ref)
+    assert float((out[:, 2, :2].float() - 9).abs().max()) == 0.0 and float((out[:, 2, 22:].float() - 9).abs().max()) == 0.0
+    assert float((out[:, 1].float() - 9).abs().max()) == 0.0
+    hip.check(lib.las_add_cast_bf16(hip.addr(a, 1 * 40 + 8), 3 * 40, None, 0, hip.addr(out, 2 * 24 + 2), 7 * 24, 5, 20, hip.stream()))
+    torch.cuda.synchronize()
+    assert torch.equal(out[:, 2, 2:22], a[:, 1, 8:28].to(torch.bfloat16))
+    assert lib.las_add_cast_bf16(None, 0, None, 0, hip.addr(out), 24, 5, 20, hip.stream()) != 0
