@@ -66,6 +66,10 @@ def check_all_lstm_status():
             raise hip.LasError('recurrent kernel (B=%d, H=%d) reported an inter-workgroup timeout (status %d)' % (B, H, st))
 
 
+# workgroups the fused weight-gradient product of a direction aims for (K slices x output tiles); LAS_TN_WGS overrides
+TN_WORKGROUPS = int(os.environ.get('LAS_TN_WGS', '704'))
+
+
 class Overlap:
     """A second HIP stream for launches that are off the critical path of the backward pass (weight-gradient
     GEMMs, bias sums): they fill the ~224 CUs the persistent recurrent kernels leave idle.  fork() makes the side
@@ -286,7 +290,7 @@ def bilstm_backward(rec, dy, d_state, grads, need_dx=True, overlap=None, defer_w
     if D % 8 == 0:
         # fused product: about 700 workgroups in flight measured best on MI355X (128 x 128 output tiles, K cut in slices)
         tiles = -(-(D + H + 1) // 128) * -(-(4 * H) // 128)
-        split = max(1, min(32, BT // 512, round(704 / tiles)))
+        split = max(1, min(32, BT // 512, round(TN_WORKGROUPS / tiles)))
     keepalive = [dz, x, y] + [a for a, _ in (dropped or [])]
 
     def weight_grads():
