@@ -600,10 +600,14 @@ __host__ __device__ inline size_t persist_bwd_red2_floats(int W) {
 __host__ __device__ inline size_t persist_bwd_scratch_floats(int M, int Hd, int Tm) {
   // (the Bahdanau query-layer product borrows the partial-tile area as 2048 floats of scratch)
   const size_t r2 = persist_bwd_red2_floats(M + Hd);
-  return ((size_t)M + 2 * (size_t)Tm + 2048 + 16 + Hd + (r2 > 2048 ? r2 : 2048) + 8 + 3) & ~(size_t)3;
+  // (d(context): M floats, or two bf16 rows of M -- high and low halves -- for the matrix-core d(alignments) pass; + 16 B of zeros)
+  return ((size_t)M + 4 + 2 * (size_t)Tm + 2048 + 16 + Hd + (r2 > 2048 ? r2 : 2048) + 8 + 3) & ~(size_t)3;
 }
+// rows of the LDS-resident values are P_VPAD elements apart from a multiple of 64 banks: the 16 frames of a matrix-core
+// fragment read 16 different rows at the same column
+#define P_VPAD 8
 __host__ __device__ inline size_t persist_bwd_resident_bytes(int M, int Hd, int Tm) {
-  return (size_t)((Tm + 3) / 4) * (size_t)(M + Hd) * 2;
+  return (size_t)((Tm + 3) / 4) * (size_t)(M + P_VPAD + Hd) * 2;
 }
 __host__ __device__ inline bool persist_bwd_resident(int M, int Hd, int Tm) {
   return persist_bwd_scratch_floats(M, Hd, Tm) * 4 + persist_bwd_resident_bytes(M, Hd, Tm) <= 158 * 1024;
@@ -1747,7 +1751,8 @@ __global__ __launch_bounds__(256) void dec_persist_bwd_kernel(las_dec_persist_bw
   const int group = (blockIdx.x / (8 * P_MEMBERS)) * 8 + (blockIdx.x & 7), member = (blockIdx.x % (8 * P_MEMBERS)) >> 3;
   if (group >= groups) return;
   float* dctx = sm;                       // [M]
-  float* dal = dctx + M;                  // [Tm] dalign -> ds (own frames)
+  unsigned short* dcb = reinterpret_cast<unsigned short*>(dctx);       // NPQ > 0: [2][M] bf16 instead, d(context) = high + low; then 16 B of zeros
+  float* dal = dctx + M + 4;              // [Tm] dalign -> ds (own frames)
   float* alg = dal + Tm;                  // [Tm] alignments (own frames)
   float* dhs = alg + Tm;                  // [2048] per-phase partial dh
   float* red = dhs + 2048;                // [16 + Hd]
@@ -1810,13 +1815,15 @@ __global__ __launch_bounds__(256) void dec_persist_bwd_kernel(las_dec_persist_bw
   // the frames of this workgroup do not change over the U steps: keep them in LDS when they fit (every step would
   // otherwise stream them from L2 / Infinity Cache again, four dependent round trips in S1 alone)
   const bool resident = persist_bwd_resident(M, Hd, Tm);
-  unsigned short* lvals = reinterpret_cast<unsigned short*>(sm + persist_bwd_scratch_floats(M, Hd, Tm));   // [fq][M]
-  unsigned short* lkeys = lvals + (size_t)fq * M;                                                            // [fq][Hd]
+  const int MS = M + P_VPAD;
+  unsigned short* lvals = reinterpret_cast<unsigned short*>(sm + persist_bwd_scratch_floats(M, Hd, Tm));   // [fq][MS]
+  unsigned short* lkeys = lvals + (size_t)fq * MS;                                                           // [fq][Hd]
+  if (tid < 8) dcb[2 * M + tid] = 0;
   if (resident && active) {
     const int nrow = max(f1 - f0, 0);
     for (int e = tid; e < nrow * (M / 8); e += 256) {
       const int r = e / (M / 8), c = e % (M / 8);
-      *reinterpret_cast<uint4*>(lvals + (size_t)r * M + c * 8) = *reinterpret_cast<const uint4*>(vals + (int64_t)(f0 + r) * M + c * 8);
+      *reinterpret_cast<uint4*>(lvals + (size_t)r * MS + c * 8) = *reinterpret_cast<const uint4*>(vals + (int64_t)(f0 + r) * M + c * 8);
     }
     for (int e = tid; e < nrow * (Hd / 8); e += 256) {
       const int r = e / (Hd / 8), c = e % (Hd / 8);
@@ -1917,7 +1924,13 @@ __global__ __launch_bounds__(256) void dec_persist_bwd_kernel(las_dec_persist_bw
           }
           v += fb;
         }
-        dctx[m] = v;
+        if constexpr (NPQ > 0) {
+          const unsigned short hi = las_f2bf(v);
+          dcb[m] = hi;
+          dcb[M + m] = las_f2bf(v - las_bf2f(hi));
+        } else {
+          dctx[m] = v;
+        }
         if (part == 0 && s0.dctx_save) s0.dctx_save[(int64_t)b * s0.ldds + (int64_t)t * p.inc_save + m] = las_f2bf(v);
       }
       if (f0 + tid < f1) alg[f0 + tid] = cur_al;
@@ -1930,52 +1943,62 @@ __global__ __launch_bounds__(256) void dec_persist_bwd_kernel(las_dec_persist_bw
       {
         const int sub = lane & 15, grp = lane >> 4;
         // rows: the frames' value rows, from LDS (row 0 = frame f0) or from memory (row 0 = frame 0)
-        // the fast form (M = 128 * NP, NP <= 8): this lane's pieces of d(context) are the same for every frame -- they
-        // are read from LDS once, not once per frame (halves the LDS traffic of the pass) -- and the 16 lanes of a frame
-        // meet through DPP instead of four LDS permutes
-        constexpr int NP = NPQ > 8 ? 8 : (NPQ > 0 ? NPQ : 1);       // pieces per lane and pass (M = 2048: two passes of 8)
-        constexpr int NPASS = NPQ > 8 ? NPQ / 8 : 1;
+        // the fast form (LDS-resident frames, M a multiple of 128): on the matrix cores.  One 16x16x32 product per 16
+        // frames and 32 columns: A = the frames' value rows as they lie in LDS (bf16, no conversion), B = d(context) as
+        // two bf16 columns (high half, low half -- together 16 mantissa bits) and 14 zero columns.  Wave w takes the
+        // frame tiles w, w+4, ...
         constexpr bool fast = NPQ > 0;
         if constexpr (fast) {
-#pragma unroll 1
-          for (int pass = 0; pass < NPASS; ++pass) {
-            float dcr8[NP][8];
-            const int koff = pass * NP * 128 + sub * 8;
+          const lds_cu16 bsrc = (lds_cu16)dcb + (sub < 2 ? sub * M + grp * 8 : 2 * M);
+          const int bstep = sub < 2 ? 32 : 0;
+          for (int t0 = f0 + wave * 16; t0 < f1; t0 += 64) {
+            const int ta = t0 + sub;
+            const lds_cu16 ra = (lds_cu16)lvals + (size_t)(ta < flen ? ta - f0 : 0) * MS + grp * 8;
+            // (M / 32 = 4 NPQ chunks, written out four at a time: the next four chunks' fragments are requested before
+            // this four's products, so that the LDS latency is paid once, not per chunk)
+            constexpr int KC = 4 * NPQ, CH = NPQ > 8 ? 2 : 4;
+            f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+            uint4 av[2][CH], bv[2][CH];
+            auto request = [&](int buf, int c) {
 #pragma unroll
-            for (int q = 0; q < NP; ++q) {
-              const float4 x0 = *reinterpret_cast<const float4*>(dctx + koff + q * 128);
-              const float4 x1 = *reinterpret_cast<const float4*>(dctx + koff + q * 128 + 4);
-              dcr8[q][0] = x0.x; dcr8[q][1] = x0.y; dcr8[q][2] = x0.z; dcr8[q][3] = x0.w;
-              dcr8[q][4] = x1.x; dcr8[q][5] = x1.y; dcr8[q][6] = x1.z; dcr8[q][7] = x1.w;
-            }
-            for (int t0 = f0; t0 < f1; t0 += 16) {
-              const int ta = t0 + wave * 4 + grp;
-              const bool oa = ta < flen;
-              const lds_cu16 ra = (lds_cu16)lvals + (size_t)(oa ? ta - f0 : 0) * M + koff;
-              uint4 va[NP];
+              for (int j = 0; j < CH; ++j) { av[buf][j] = ld16(ra + (c * CH + j) * 32); bv[buf][j] = ld16(bsrc + (c * CH + j) * bstep); }
+            };
+            auto products = [&](int buf) {
 #pragma unroll
-              for (int q = 0; q < NP; ++q) va[q] = ld16(ra + q * 128);
-              float acc_a = 0.f;
-#pragma unroll
-              for (int q = 0; q < NP; ++q) {
-                const unsigned short* e = reinterpret_cast<const unsigned short*>(&va[q]);
-#pragma unroll
-                for (int j = 0; j < 8; ++j) acc_a += las_bf2f(e[j]) * dcr8[q][j];
+              for (int j = 0; j < CH; j += 2) {
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, av[buf][j]), __builtin_bit_cast(bf16x8, bv[buf][j]), acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, av[buf][j + 1]), __builtin_bit_cast(bf16x8, bv[buf][j + 1]), acc1, 0, 0, 0);
               }
-              acc_a = las_quad_sum(acc_a);
-              acc_a += las_dpp<0x141>(acc_a);       // row_half_mirror
-              acc_a += las_dpp<0x140>(acc_a);       // row_mirror: every lane of the 16-lane row holds the frame's sum
-              if (sub == 0 && ta < f1) dal[ta] = (pass == 0 ? 0.f : dal[ta]) + (oa ? acc_a : 0.f);
+            };
+            request(0, 0);
+            // (the 512-unit variants have no registers to spare: their loop stays rolled, two chunks of four per turn)
+#pragma unroll(NPQ > 8 ? 1 : KC / CH / 2)
+            for (int c = 0; c < KC / CH; c += 2) {
+              request(1, c + 1);
+              __builtin_amdgcn_sched_barrier(0);
+              products(0);
+              __builtin_amdgcn_sched_barrier(0);
+              if (c + 2 < KC / CH) request(0, c + 2);
+              __builtin_amdgcn_sched_barrier(0);
+              products(1);
+              __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              float v = acc0[r] + acc1[r];
+              v += las_dpp<0xB1>(v);                       // column 0 (high half) + column 1 (low half)
+              const int tr = t0 + grp * 4 + r;
+              if (sub == 0 && tr < f1) dal[tr] = tr < flen ? v : 0.f;
             }
           }
         }
-        auto dalign_pass = [&](const unsigned short* rows, int row0) {
+        auto dalign_pass = [&](const unsigned short* rows, int row0, int stride) {
           for (int t0 = f0; t0 < f1; t0 += 32) {
             const int ta = t0 + wave * 4 + grp, tb = ta + 16;
             float acc_a = 0.f, acc_b = 0.f;
             const bool oa = ta < flen, ob = tb < flen;
-            const unsigned short* ra = rows + (int64_t)(oa ? ta - row0 : 0) * M;
-            const unsigned short* rb = rows + (int64_t)(ob ? tb - row0 : 0) * M;
+            const unsigned short* ra = rows + (int64_t)(oa ? ta - row0 : 0) * stride;
+            const unsigned short* rb = rows + (int64_t)(ob ? tb - row0 : 0) * stride;
 #pragma unroll 4
             for (int k = sub * 8; k < M; k += 128) {
               const uint4 va = *reinterpret_cast<const uint4*>(ra + k);
@@ -1995,8 +2018,8 @@ __global__ __launch_bounds__(256) void dec_persist_bwd_kernel(las_dec_persist_bw
           }
         };
         if constexpr (fast) { }
-        else if (resident) dalign_pass(lvals, f0);
-        else dalign_pass(vals, 0);
+        else if (resident) dalign_pass(lvals, f0, MS);
+        else dalign_pass(vals, 0, M);
       }
       lds_barrier();
       LAS_STAMPB(p.U - 1 - t, 3);
