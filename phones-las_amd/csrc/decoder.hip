@@ -597,20 +597,31 @@ __host__ __device__ inline size_t persist_bwd_red2_floats(int W) {
   const int nt = (W / 16 + 31) / 32;
   return (size_t)4 * 8 * ((nt <= 3 ? 3 : 5) * 16 + 1);
 }
+__host__ __device__ inline int persist_bwd_ds_pad(int Tm) { return (((Tm + 3) / 4 + 31) / 32) * 32; }
+// Luong scores with the matrix-core passes: the keys lie TRANSPOSED in LDS, [Hd][FS] (a unit's frames are contiguous,
+// as a B fragment reads them); FS = the frame share rounded up to an odd number of 16-byte pieces, so that the 16 units
+// of a fragment fall on 16 different bank groups
+__host__ __device__ inline int persist_bwd_kt_stride(int Tm) {
+  int r = ((Tm + 3) / 4 + 7) & ~7;
+  if (((r / 8) & 1) == 0) r += 8;
+  return r;
+}
 __host__ __device__ inline size_t persist_bwd_scratch_floats(int M, int Hd, int Tm) {
   // (the Bahdanau query-layer product borrows the partial-tile area as 2048 floats of scratch)
   const size_t r2 = persist_bwd_red2_floats(M + Hd);
   // (d(context): M floats, or two bf16 rows of M -- high and low halves -- for the matrix-core d(alignments) pass; + 16 B of zeros)
-  return ((size_t)M + 4 + 2 * (size_t)Tm + 2048 + 16 + Hd + (r2 > 2048 ? r2 : 2048) + 8 + 3) & ~(size_t)3;
+  // (+ ds of the own frames as two bf16 rows, high and low halves, padded to whole 32-frame chunks with zeros)
+  return ((size_t)M + 4 + 2 * (size_t)Tm + 2048 + 16 + Hd + (r2 > 2048 ? r2 : 2048) + 8 + persist_bwd_ds_pad(Tm) + 3) & ~(size_t)3;
 }
 // rows of the LDS-resident values are P_VPAD elements apart from a multiple of 64 banks: the 16 frames of a matrix-core
 // fragment read 16 different rows at the same column
 #define P_VPAD 8
-__host__ __device__ inline size_t persist_bwd_resident_bytes(int M, int Hd, int Tm) {
-  return (size_t)((Tm + 3) / 4) * (size_t)(M + P_VPAD + Hd) * 2;
+__host__ __device__ inline size_t persist_bwd_resident_bytes(int M, int Hd, int Tm, bool keys_t) {
+  const size_t fq = (Tm + 3) / 4;
+  return (fq * (size_t)(M + P_VPAD) + (keys_t ? (size_t)Hd * persist_bwd_kt_stride(Tm) : fq * (size_t)Hd)) * 2;
 }
-__host__ __device__ inline bool persist_bwd_resident(int M, int Hd, int Tm) {
-  return persist_bwd_scratch_floats(M, Hd, Tm) * 4 + persist_bwd_resident_bytes(M, Hd, Tm) <= 158 * 1024;
+__host__ __device__ inline bool persist_bwd_resident(int M, int Hd, int Tm, bool keys_t) {
+  return persist_bwd_scratch_floats(M, Hd, Tm) * 4 + persist_bwd_resident_bytes(M, Hd, Tm, keys_t) <= 158 * 1024;
 }
 
 __device__ bool persist_barrier(pu64* flags, int member, unsigned epoch, bool local, int* lds_fail) {
@@ -1752,7 +1763,8 @@ __global__ __launch_bounds__(256) void dec_persist_bwd_kernel(las_dec_persist_bw
   if (group >= groups) return;
   float* dctx = sm;                       // [M]
   unsigned short* dcb = reinterpret_cast<unsigned short*>(dctx);       // NPQ > 0: [2][M] bf16 instead, d(context) = high + low; then 16 B of zeros
-  float* dal = dctx + M + 4;              // [Tm] dalign -> ds (own frames)
+  unsigned short* dsb = reinterpret_cast<unsigned short*>(dctx + M + 4);    // [2][ds_pad] bf16: ds of the own frames = high + low
+  float* dal = dctx + M + 4 + persist_bwd_ds_pad(Tm);   // [Tm] dalign -> ds (own frames)
   float* alg = dal + Tm;                  // [Tm] alignments (own frames)
   float* dhs = alg + Tm;                  // [2048] per-phase partial dh
   float* red = dhs + 2048;                // [16 + Hd]
@@ -1814,20 +1826,32 @@ __global__ __launch_bounds__(256) void dec_persist_bwd_kernel(las_dec_persist_bw
   const unsigned short* keys = s0.keys + (int64_t)(active ? b : 0) * Tm * Hd;
   // the frames of this workgroup do not change over the U steps: keep them in LDS when they fit (every step would
   // otherwise stream them from L2 / Infinity Cache again, four dependent round trips in S1 alone)
-  const bool resident = persist_bwd_resident(M, Hd, Tm);
-  const int MS = M + P_VPAD;
+  constexpr bool KT = !WQ && NPQ > 0;     // Luong with the matrix-core passes: the resident keys are transposed
+  const bool resident = persist_bwd_resident(M, Hd, Tm, KT);
+  const int MS = M + P_VPAD, FS = persist_bwd_kt_stride(Tm), DSP = persist_bwd_ds_pad(Tm);
   unsigned short* lvals = reinterpret_cast<unsigned short*>(sm + persist_bwd_scratch_floats(M, Hd, Tm));   // [fq][MS]
   unsigned short* lkeys = lvals + (size_t)fq * MS;                                                           // [fq][Hd]
   if (tid < 8) dcb[2 * M + tid] = 0;
+  for (int e = tid; e < 2 * DSP; e += 256) dsb[e] = 0;
   if (resident && active) {
     const int nrow = max(f1 - f0, 0);
     for (int e = tid; e < nrow * (M / 8); e += 256) {
       const int r = e / (M / 8), c = e % (M / 8);
       *reinterpret_cast<uint4*>(lvals + (size_t)r * MS + c * 8) = *reinterpret_cast<const uint4*>(vals + (int64_t)(f0 + r) * M + c * 8);
     }
-    for (int e = tid; e < nrow * (Hd / 8); e += 256) {
-      const int r = e / (Hd / 8), c = e % (Hd / 8);
-      *reinterpret_cast<uint4*>(lkeys + (size_t)r * Hd + c * 8) = *reinterpret_cast<const uint4*>(keys + (int64_t)(f0 + r) * Hd + c * 8);
+    if constexpr (KT) {
+      for (int e = tid; e < FS * (Hd / 8); e += 256) {
+        const int r = e / (Hd / 8), c = e % (Hd / 8);
+        const uint4 v = r < nrow ? *reinterpret_cast<const uint4*>(keys + (int64_t)(f0 + r) * Hd + c * 8) : make_uint4(0, 0, 0, 0);
+        const unsigned short* e8 = reinterpret_cast<const unsigned short*>(&v);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) lkeys[(size_t)(c * 8 + j) * FS + r] = e8[j];
+      }
+    } else {
+      for (int e = tid; e < nrow * (Hd / 8); e += 256) {
+        const int r = e / (Hd / 8), c = e % (Hd / 8);
+        *reinterpret_cast<uint4*>(lkeys + (size_t)r * Hd + c * 8) = *reinterpret_cast<const uint4*>(keys + (int64_t)(f0 + r) * Hd + c * 8);
+      }
     }
     __syncthreads();
   }
@@ -2052,12 +2076,51 @@ __global__ __launch_bounds__(256) void dec_persist_bwd_kernel(las_dec_persist_bw
       unsigned short* dso = s0.ds_out + (int64_t)b * s0.ldso + (int64_t)t * p.inc_ds;
       for (int tt = f0 + tid; tt < f1; tt += 256) {
         const float v = (tt < len) ? alg[tt] * (dal[tt] - dot) : 0.f;
+        const unsigned short hi = las_f2bf(v);
         dal[tt] = v;
-        dso[tt] = las_f2bf(v);
+        dso[tt] = hi;
+        if constexpr (KT) { dsb[tt - f0] = hi; dsb[DSP + tt - f0] = las_f2bf(v - las_bf2f(hi)); }
       }
       lds_barrier();
       LAS_STAMPB(p.U - 1 - t, 6);
+      float dh_own[UPT];
       const int L = Hd / 8, P = 256 / L;
+      if constexpr (KT) {
+        // dh[u] = sum over the own frames of ds[t'] keys[t'][u] on the matrix cores: A = ds (rows 0, 4, 8, 12 the high
+        // halves, rows 1, 5, 9, 13 the low halves, the rest zeros), B = the transposed keys of 16 units.  Every quarter
+        // of the wave ends up with the tile's sums, so lane l of wave w keeps unit 64 w + l (+ 256 q): the per-phase
+        // partial sums in LDS, their barrier and their 8 reads per unit are gone
+        const int sub = lane & 15, grp = lane >> 4;
+        const lds_cu16 asrc = (lds_cu16)((sub & 3) < 2 ? dsb + (sub & 3) * DSP + grp * 8 : dcb + 2 * M);
+        const int astep = (sub & 3) < 2 ? 32 : 0;
+        f32x4 acc[UPT][4];
+#pragma unroll
+        for (int q = 0; q < UPT; ++q)
+#pragma unroll
+          for (int g = 0; g < 4; ++g) acc[q][g] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int kc = 0; kc * 32 < f1 - f0; ++kc) {
+          const int kk = kc * 32 + grp * 8;
+          const uint4 av = ld16(asrc + kc * astep);
+          uint4 bv[UPT][4];
+#pragma unroll
+          for (int q = 0; q < UPT; ++q)
+#pragma unroll
+            for (int g = 0; g < 4; ++g)          // (waves beyond Hd / 64 reread wave 0's units: their sums are not used)
+              bv[q][g] = ld16((lds_cu16)lkeys + (size_t)((q * 256 + wave * 64) % Hd + g * 16 + sub) * FS + (kk < FS ? kk : 0));
+#pragma unroll
+          for (int q = 0; q < UPT; ++q)
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+              acc[q][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, av), __builtin_bit_cast(bf16x8, bv[q][g]), acc[q][g], 0, 0, 0);
+        }
+#pragma unroll
+        for (int q = 0; q < UPT; ++q) {
+          const float r0 = acc[q][0][0] + acc[q][0][1], r1 = acc[q][1][0] + acc[q][1][1];
+          const float r2 = acc[q][2][0] + acc[q][2][1], r3 = acc[q][3][0] + acc[q][3][1];
+          dh_own[q] = grp == 0 ? r0 : (grp == 1 ? r1 : (grp == 2 ? r2 : r3));
+        }
+        LAS_STAMPB(p.U - 1 - t, 7);
+      } else {
       const int phase = tid / L, u = (tid % L) * 8;
       float a[8];
 #pragma unroll
@@ -2130,12 +2193,12 @@ __global__ __launch_bounds__(256) void dec_persist_bwd_kernel(las_dec_persist_bw
       lds_barrier();
       LAS_STAMPB(p.U - 1 - t, 7);
       // partial dh of this workgroup's frames (unit = threadIdx.x; Hd <= 256): parts 1..3 send theirs to part 0 as granules
-      float dh_own[UPT];
 #pragma unroll
       for (int q = 0; q < UPT; ++q) {
         dh_own[q] = 0.f;
         if (tid < Hd)
           for (int ph = 0; ph < P; ++ph) dh_own[q] += dhs[ph * Hd + tid + q * 256];
+      }
       }
       pu64* xh = xdh + ((size_t)(xtag & 1) * B + b) * 4 * Hd;
       constexpr bool SPLITQ = WQ;            // query-layer attentions: the dh = d(pq) Wq^T product is split over the four parts
@@ -2757,9 +2820,12 @@ extern "C" int las_decoder_persist_bwd(const las_dec_persist_bwd* p, void* strea
   if (rc) return rc;
   size_t lds = persist_bwd_scratch_floats(s->M, s->Hd, s->Tm) * sizeof(float);
   LAS_REQUIRE(lds <= 64 * 1024, "las_decoder_persist_bwd: shapes exceed the LDS budget");
-  if (persist_bwd_resident(s->M, s->Hd, s->Tm)) lds += persist_bwd_resident_bytes(s->M, s->Hd, s->Tm);
-  const bool res = persist_bwd_resident(s->M, s->Hd, s->Tm);
-  const int npq = (res && (s->M == 512 || s->M == 1024 || (s->M == 2048 && s->Hd == 512))) ? s->M / 128 : 0;
+  // the matrix-core passes need the frames in LDS and M = 512, 1024 or 2048; with Luong scores they keep the keys transposed
+  const bool mshape = s->M == 512 || s->M == 1024 || (s->M == 2048 && s->Hd == 512);
+  const bool keys_t = s->attention == LAS_ATT_LUONG && mshape && persist_bwd_resident(s->M, s->Hd, s->Tm, true);
+  const bool res = persist_bwd_resident(s->M, s->Hd, s->Tm, keys_t);
+  if (res) lds += persist_bwd_resident_bytes(s->M, s->Hd, s->Tm, keys_t);
+  const int npq = (res && mshape && (keys_t || s->attention != LAS_ATT_LUONG)) ? s->M / 128 : 0;
   const dim3 grid(((groups + 7) & ~7) * P_MEMBERS);
   const bool wq = s->attention != LAS_ATT_LUONG;
 #define LAS_BWD_LAUNCH(...)                                                                                                     \
