@@ -934,7 +934,7 @@ __global__ __launch_bounds__(256) void dec_persist_fwd_kernel(las_dec_persist p)
 //     conflicts (4 lanes per frame, 16 frames per wave).
 // ------------------------------------------------------------------------------------------------
 constexpr int LEAN_KPAD = 32;                       // bf16 elements of padding per LDS key row (row stride = 64 mod 128 bytes)
-struct LeanLayout { size_t hq, pq, vq, sc, red, cred, zred, flags, hqb, tok, keys, vals, total_bytes; int fq, kst, cols_per; };
+struct LeanLayout { size_t hq, pq, vq, sc, red, cred, zred, flags, hqb, tok, psb, zero, keys, vals, total_bytes; int fq, kst, cols_per, kp, ts, cp; };
 __host__ __device__ inline LeanLayout lean_layout(int Hd, int Tm, int M, int U) {
   LeanLayout l;
   size_t o = 0;                                     // in floats
@@ -949,12 +949,23 @@ __host__ __device__ inline LeanLayout lean_layout(int Hd, int Tm, int M, int U) 
   l.hqb = o; o += Hd / 2;
   l.tok = o; o += (size_t)((U + 3) & ~3);            // the utterance's fed token ids, all steps
   o = (o + 3) & ~(size_t)3;
+  // the alignments as two bf16 rows (high and low halves; zeros up to a whole number of 32-frame chunks) and 16 B of zeros:
+  // the A operand of the context product on the matrix cores
+  l.kp = (Tm + 31) / 32 * 32;
+  l.psb = o; o += (size_t)l.kp;
+  l.zero = o; o += 4;
   l.fq = (Tm + 3) / 4;
   l.kst = Hd + LEAN_KPAD;
   l.cols_per = persist_cols_per(M);
   l.keys = o; o += ((size_t)l.fq * l.kst + 1) / 2;
   o = (o + 3) & ~(size_t)3;
-  l.vals = o; o += ((size_t)Tm * l.cols_per + 1) / 2;
+  // the values TRANSPOSED, [cp columns][ts frames]: a column's frames are contiguous, as a B fragment reads them (ts: the
+  // frames rounded up to an odd number of 16-byte pieces -- the 16 columns of a fragment on 16 different bank groups;
+  // cp: whole 64-column shares of the four waves)
+  l.ts = (Tm + 7) & ~7;
+  if (((l.ts / 8) & 1) == 0) l.ts += 8;
+  l.cp = (l.cols_per + 63) & ~63;
+  l.vals = o; o += ((size_t)l.cp * l.ts + 1) / 2;
   l.total_bytes = ((o + 3) & ~(size_t)3) * sizeof(float);
   return l;
 }
@@ -997,7 +1008,9 @@ __global__ __launch_bounds__(256) void dec_persist_fwd_lean_kernel(las_dec_persi
   int* ltok = reinterpret_cast<int*>(sm + L.tok);
   unsigned short* lk = reinterpret_cast<unsigned short*>(sm + L.keys);
   unsigned short* lv = reinterpret_cast<unsigned short*>(sm + L.vals);
+  unsigned short* psb = reinterpret_cast<unsigned short*>(sm + L.psb);
   const int RS = persist_red_stride(Hd);
+  for (int i = tid; i < 2 * L.kp + 8; i += 256) psb[i] = 0;            // (the 16 zero bytes lie right behind)
   if (tid == 0) { *fail = 0; *colo = 0; }
   __syncthreads();
   if (tid == 0) {                                          // are the 32 members on one XCD?  (decides fences only)
@@ -1044,6 +1057,7 @@ __global__ __launch_bounds__(256) void dec_persist_fwd_lean_kernel(las_dec_persi
   // S role constants
   const int fq = L.fq, f0 = part * fq, f1 = min(Tm, f0 + fq), KST = L.kst;
   const int cols_per = L.cols_per, c_begin = part * cols_per, ncols = max(0, min(M, c_begin + cols_per) - c_begin);
+  const int KP = L.kp, TS = L.ts, CP = L.cp;
   const int len = have ? min(p.s.mem_len[bsc], Tm) : 0;
   const int flen = min(len, f1);
   if (have) {                                              // this workgroup's share of the encoder memory: resident for all steps
@@ -1053,9 +1067,15 @@ __global__ __launch_bounds__(256) void dec_persist_fwd_lean_kernel(las_dec_persi
       const int r = e / (Hd / 8), c = e % (Hd / 8);
       *reinterpret_cast<uint4*>(lk + (size_t)r * KST + c * 8) = *reinterpret_cast<const uint4*>(gk + (int64_t)(f0 + r) * Hd + c * 8);
     }
-    for (int e = tid; e < Tm * (ncols / 8); e += 256) {
-      const int r = e / (ncols / 8), c = e % (ncols / 8);
-      *reinterpret_cast<uint4*>(lv + (size_t)r * cols_per + c * 8) = *reinterpret_cast<const uint4*>(gv + (int64_t)r * M + c_begin + c * 8);
+    // (consecutive lanes take consecutive frames of the same 8 columns: the 2-byte LDS stores of a wave fall on 32 banks;
+    // frames past the utterance and columns past its share are zeros -- their products must add nothing)
+    for (int e = tid; e < TS * (CP / 8); e += 256) {
+      const int r = e % TS, c = e / TS;
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (r < len && c * 8 < ncols) v = *reinterpret_cast<const uint4*>(gv + (int64_t)r * M + c_begin + c * 8);
+      const unsigned short* e8 = reinterpret_cast<const unsigned short*>(&v);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) lv[(size_t)(c * 8 + j) * TS + r] = e8[j];
     }
     if (ATT == LAS_ATT_BAHDANAU)
       for (int u = tid; u < Hd; u += 256) vq[u] = p.s.att_v[u];
@@ -1080,9 +1100,6 @@ __global__ __launch_bounds__(256) void dec_persist_fwd_lean_kernel(las_dec_persi
   }
   const float keep = p.s.drop_keep;
   const int sub = lane & 3, fr = lane >> 2;                // score phase: 4 lanes per frame, 16 frames per wave
-  int Lc = 1;
-  while (Lc * 8 < ncols) Lc <<= 1;                         // context phase: lanes per frame (power of two), frame phases
-  const int Pc = 256 / Lc, cphase = tid / Lc, ccl = tid % Lc;
   pu64* const xbase = reinterpret_cast<pu64*>(reinterpret_cast<char*>(p.workspace) + 64) + persist_flag_words(B);
   const size_t ldsc = (size_t)((Tm + 31) / 32 * 32);
   pu64* const xzb = xbase + 2 * (size_t)B * ldsc;           // [2][B][4Hd] after the score granules [2][B][ldsc]
@@ -1360,7 +1377,9 @@ __global__ __launch_bounds__(256) void dec_persist_fwd_lean_kernel(las_dec_persi
         unsigned short* const abf = p.s.align_bf16 ? p.s.align_bf16 + (int64_t)bs * p.s.lda + (int64_t)t * p.inc_align : nullptr;
         for (int tf = tid; tf < Tm; tf += 256) {
           const float pr = sc[tf] * scale;
-          sc[tf] = pr;
+          const unsigned short hi = las_f2bf(pr);
+          psb[tf] = hi;
+          psb[KP + tf] = las_f2bf(pr - las_bf2f(hi));
           if (tf >= f0 && tf < f1) {                       // every part saves its own frames
             arow_out[tf] = pr;
             if (abf) abf[tf] = las_f2bf(pr);
@@ -1369,54 +1388,62 @@ __global__ __launch_bounds__(256) void dec_persist_fwd_lean_kernel(las_dec_persi
         lds_barrier();
       }
       LAS_STAMP(t, 7);
-      // ---- context columns [c_begin, c_begin + ncols): Lc lanes cover a frame with 16-byte LDS reads, Pc frame phases ----
+      // ---- context columns [c_begin, c_begin + ncols) on the matrix cores: ctx[c] = sum_t' p[t'] values[t'][c] as 16x16x32
+      //      products, A = the alignments (rows 0, 4, 8, 12 their high halves, rows 1, 5, 9, 13 the low halves, the other
+      //      rows zeros), B = 16 columns x 32 frames of the transposed values.  Every quarter of the wave ends up with a
+      //      tile's sums, so lane l of wave w keeps column 64 w + l of each pass of 256: no partial sums through LDS.
+      //      Chunks past the utterance's length are not visited ----
       {
-        float a[8];
+        const int kcn = (len + 31) / 32;
+        const lds_cu16 zslot = (lds_cu16)psb + 2 * KP;
+        const lds_cu16 abase = (l15 & 3) < 2 ? (lds_cu16)psb + (l15 & 3) * KP + lq * 8 : zslot;
+        const int astep = (l15 & 3) < 2 ? 32 : 0;
+        for (int c0 = wave * 64; c0 < CP; c0 += 256) {
+          const lds_cu16 brow = (lds_cu16)lv + (size_t)(c0 + l15) * TS;
+          f32x4 acc[4];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) a[j] = 0.f;
-        if (ccl * 8 < ncols) {
-          const lds_cu16 vcol = (lds_cu16)lv + ccl * 8;
-          int tf = cphase;
-          for (; tf + 7 * Pc < len; tf += 8 * Pc) {
-            uint4 vv[8];
-            float pr[8];
+          for (int g = 0; g < 4; ++g) acc[g] = f32x4{0.f, 0.f, 0.f, 0.f};
+          uint4 av[2], bv[2][4];
+          auto request = [&](int buf, int kc) {            // (branch-free: a chunk past the end multiplies zeros)
+            const bool in = kc < kcn;
+            const int kk = kc * 32 + lq * 8;
+            av[buf] = ld16(in ? abase + kc * astep : zslot);
+            const lds_cu16 bp = brow + ((in && kk < TS) ? kk : 0);
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-              vv[i] = ld16(vcol + (size_t)(tf + i * Pc) * cols_per);
-              pr[i] = sc[tf + i * Pc];
-            }
+            for (int g = 0; g < 4; ++g) bv[buf][g] = ld16(bp + (size_t)g * 16 * TS);
+          };
+          auto products = [&](int buf) {
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-              const unsigned short* e = reinterpret_cast<const unsigned short*>(&vv[i]);
-#pragma unroll
-              for (int j = 0; j < 8; ++j) a[j] += pr[i] * las_bf2f(e[j]);
-            }
+            for (int g = 0; g < 4; ++g)
+              acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, av[buf]), __builtin_bit_cast(bf16x8, bv[buf][g]), acc[g], 0, 0, 0);
+          };
+          request(0, 0);
+#pragma unroll 1
+          for (int kc = 0; kc < kcn; kc += 2) {
+            request(1, kc + 1);
+            __builtin_amdgcn_sched_barrier(0);
+            products(0);
+            __builtin_amdgcn_sched_barrier(0);
+            request(0, kc + 2);
+            __builtin_amdgcn_sched_barrier(0);
+            products(1);
+            __builtin_amdgcn_sched_barrier(0);
           }
-          for (; tf < len; tf += Pc) {
-            const uint4 vv = ld16(vcol + (size_t)tf * cols_per);
-            const float pr = sc[tf];
-            const unsigned short* e = reinterpret_cast<const unsigned short*>(&vv);
-#pragma unroll
-            for (int j = 0; j < 8; ++j) a[j] += pr * las_bf2f(e[j]);
-          }
-        }
-        LAS_STAMP(t, 8);
-        *reinterpret_cast<float4*>(cred + tid * 8) = make_float4(a[0], a[1], a[2], a[3]);
-        *reinterpret_cast<float4*>(cred + tid * 8 + 4) = make_float4(a[4], a[5], a[6], a[7]);
-        lds_barrier();
-        for (int j = tid; j < ncols; j += 256) {
-          const int cl2 = j >> 3, e = j & 7;
-          float acc = 0.f;
-          for (int ph = 0; ph < Pc; ++ph) acc += cred[(ph * Lc + cl2) * 8 + e];
-          const unsigned short o = las_f2bf(acc);
-          p.s.ctx_out[(int64_t)bs * p.s.ldc + (int64_t)t * p.inc_ctx + c_begin + j] = o;
-          if (!last) {
-            unsigned short o2 = o;
-            if (keep < 1.0f) {   // the copy that feeds step t+1's cell goes through that step's input dropout
-              const unsigned long long idx = ((unsigned long long)(t + 1) * B + bs) * p.s.feed_width + (p.s.feed_width - M) + c_begin + j;
-              o2 = las_uniform(p.s.drop_seed, p.s.drop_stream, idx) < keep ? las_f2bf(las_bf2f(o) / keep) : (unsigned short)0;
+          const float r0 = acc[0][0] + acc[0][1], r1 = acc[1][0] + acc[1][1], r2 = acc[2][0] + acc[2][1], r3 = acc[3][0] + acc[3][1];
+          const float cv = lq == 0 ? r0 : (lq == 1 ? r1 : (lq == 2 ? r2 : r3));
+          const int j = c0 + lane;                          // = c0 - 64 wave + tid
+          if (c0 == wave * 64) LAS_STAMP(t, 8);
+          if (j < ncols) {
+            const unsigned short o = las_f2bf(cv);
+            p.s.ctx_out[(int64_t)bs * p.s.ldc + (int64_t)t * p.inc_ctx + c_begin + j] = o;
+            if (!last) {
+              unsigned short o2 = o;
+              if (keep < 1.0f) {   // the copy that feeds step t+1's cell goes through that step's input dropout
+                const unsigned long long idx = ((unsigned long long)(t + 1) * B + bs) * p.s.feed_width + (p.s.feed_width - M) + c_begin + j;
+                o2 = las_uniform(p.s.drop_seed, p.s.drop_stream, idx) < keep ? las_f2bf(las_bf2f(o) / keep) : (unsigned short)0;
+              }
+              p.s.ctx_out2[(int64_t)bs * p.s.ldc2 + (int64_t)t * p.inc_ctx2 + c_begin + j] = o2;
             }
-            p.s.ctx_out2[(int64_t)bs * p.s.ldc2 + (int64_t)t * p.inc_ctx2 + c_begin + j] = o2;
           }
         }
       }
@@ -1840,9 +1867,11 @@ __global__ __launch_bounds__(256) void dec_persist_bwd_kernel(las_dec_persist_bw
       *reinterpret_cast<uint4*>(lvals + (size_t)r * MS + c * 8) = *reinterpret_cast<const uint4*>(vals + (int64_t)(f0 + r) * M + c * 8);
     }
     if constexpr (KT) {
+      // (consecutive lanes take consecutive frames of the same 8 units: the 2-byte LDS stores of a wave fall on 32 banks;
+      // frames past the utterance are zeros)
       for (int e = tid; e < FS * (Hd / 8); e += 256) {
-        const int r = e / (Hd / 8), c = e % (Hd / 8);
-        const uint4 v = r < nrow ? *reinterpret_cast<const uint4*>(keys + (int64_t)(f0 + r) * Hd + c * 8) : make_uint4(0, 0, 0, 0);
+        const int r = e % FS, c = e / FS;
+        const uint4 v = f0 + r < flen ? *reinterpret_cast<const uint4*>(keys + (int64_t)(f0 + r) * Hd + c * 8) : make_uint4(0, 0, 0, 0);
         const unsigned short* e8 = reinterpret_cast<const unsigned short*>(&v);
 #pragma unroll
         for (int j = 0; j < 8; ++j) lkeys[(size_t)(c * 8 + j) * FS + r] = e8[j];

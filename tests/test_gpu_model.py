@@ -614,7 +614,7 @@ def test_persistent_decoder_vs_per_step_and_oracle(att, monkeypatch):
 ], ids=['b1_u1', 'short_memory', 'two_groups', 'three_groups', 'long_memory_not_resident', 'very_long_memory'])
 def test_persistent_decoder_edge_shapes_match_per_step_path(B, T, U, src_len, tgt_len, monkeypatch):
     """Edge shapes of the one-launch decoder (partial groups, empty frame shares, a single step) against the per-step
-    launches: logits and every gradient agree to fp32 summation-order noise."""
+    launches: logits and every gradient agree to summation-order and bf16-rounding noise."""
     O, ohp, op, model = _models('luong', H=128, F=13, L=2)
     batch = make_batch(B=B, T=T, U=U, src_len=src_len, tgt_len=tgt_len)
     feats, labels = to_device(batch)
@@ -629,7 +629,9 @@ def test_persistent_decoder_edge_shapes_match_per_step_path(B, T, U, src_len, tg
             assert int(model.speller._persist_ws[:4].view(torch.int32).item()) == 0
             assert int(model.speller._persist_ws_bwd[:4].view(torch.int32).item()) == 0
         outs[flag] = (logits.clone(), {n: g.clone() for n, g in model.vars.grads.items()})
-    assert relerr(outs['1'][0], outs['0'][0].cpu()) < 1e-5
+    # (the one-launch kernels sum the context on the matrix cores, the alignments as a high + low bf16 pair: a context
+    # element that rounds to the other bf16 neighbour moves the logits by ~1e-4)
+    assert relerr(outs['1'][0], outs['0'][0].cpu()) < 1e-3
     for name in outs['1'][1]:
         assert relerr(outs['1'][1][name], outs['0'][1][name].cpu()) < 2e-3, name
 
