@@ -457,13 +457,14 @@ class Speller:
             hip.check(lib.las_decoder_step_bwd(C.byref(s), st))
             hip.gemm_nt(dz_all[:, t], self.kc, dfeed, B, W, 4 * Hd, lda=U * 4 * Hd, ldb=4 * Hd, ldc=W)
         # critical path: d(keys), d(memory) feed the listener's backward
+        # (stored, not accumulated: no zero fills in front of them, no atomics -- K is only the U steps)
         if not bah:
-            dkeys = torch.zeros(B, Tm, Hd, dtype=f32, device=dev)
+            dkeys = torch.empty(B, Tm, Hd, dtype=f32, device=dev)
             hip.gemm_tn(ds_all, sv['h_all'], dkeys, Tm, Hd, U, lda=Tmp, ldb=Hd, ldc=Hd, batch=B, sa=U * Tmp,
-                        sb=U * Hd, sc=Tm * Hd)
-        dmem = torch.zeros(B, Tm, M, dtype=f32, device=dev)
+                        sb=U * Hd, sc=Tm * Hd, store=True)
+        dmem = torch.empty(B, Tm, M, dtype=f32, device=dev)
         hip.gemm_tn(sv['align_bf'], dctx_all, dmem, Tm, M, U, lda=Tmp, ldb=M, ldc=M, batch=B, sa=U * Tmp, sb=U * M,
-                    sc=Tm * M)
+                    sc=Tm * M, store=True)
         dkeys_bf = torch.empty(B * Tm, Hd, dtype=bf, device=dev)
         hip.cast_bf16(dkeys, B * Tm, Hd, dkeys_bf, B * Tm, Hd, ldd=Hd, lds=Hd)
         hip.gemm_nt(dkeys_bf, self.wmem, dmem, B * Tm, M, Hd, lda=Hd, ldb=Hd, ldc=M, accumulate=True)

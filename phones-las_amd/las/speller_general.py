@@ -562,12 +562,14 @@ class GeneralSpeller:
             if self.custom:
                 qmat = torch.empty(B, U, Hd, dtype=bf, device=dev)
                 hip.cast_bf16(sv['pq'], BU, Hd, qmat, BU, Hd, ldd=Hd, lds=Hd)
-            dkeys = torch.zeros(B, Tm, Hd, dtype=f32, device=dev)
-            hip.gemm_tn(ds_all, qmat, dkeys, Tm, Hd, U, lda=Tmp, ldb=Hd, ldc=Hd, batch=B, sa=U * Tmp, sb=U * Hd, sc=Tm * Hd)
+            dkeys = torch.empty(B, Tm, Hd, dtype=f32, device=dev)          # (stored: no zero fill, no atomics)
+            hip.gemm_tn(ds_all, qmat, dkeys, Tm, Hd, U, lda=Tmp, ldb=Hd, ldc=Hd, batch=B, sa=U * Tmp, sb=U * Hd, sc=Tm * Hd,
+                        store=True)
             if self.custom:              # keys = relu(memory_layer(memory))
                 hip.check(lib.las_relu_bwd(hip.p(dkeys), hip.p(sv['keys']), dkeys.numel(), st))
-        dmem = torch.zeros(B, Tm, M, dtype=f32, device=dev)
-        hip.gemm_tn(sv['align_bf'], dctx_all, dmem, Tm, M, U, lda=Tmp, ldb=M, ldc=M, batch=B, sa=U * Tmp, sb=U * M, sc=Tm * M)
+        dmem = torch.empty(B, Tm, M, dtype=f32, device=dev)
+        hip.gemm_tn(sv['align_bf'], dctx_all, dmem, Tm, M, U, lda=Tmp, ldb=M, ldc=M, batch=B, sa=U * Tmp, sb=U * M, sc=Tm * M,
+                    store=True)
         dkeys_bf = torch.empty(B * Tm, Hd, dtype=bf, device=dev)
         hip.cast_bf16(dkeys, B * Tm, Hd, dkeys_bf, B * Tm, Hd, ldd=Hd, lds=Hd)
         hip.gemm_nt(dkeys_bf, self.wmem, dmem, B * Tm, M, Hd, lda=Hd, ldb=Hd, ldc=M, accumulate=True)

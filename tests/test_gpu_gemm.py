@@ -84,6 +84,21 @@ def test_gemm_tn_matches_fp64(M, N, K, split):
     _close(C, 2 * ref)
 
 
+@pytest.mark.parametrize('nb,M,N,K', [(3, 200, 1024, 80), (5, 50, 256, 80), (2, 7, 40, 3), (1, 130, 136, 33)])
+def test_gemm_tn_store_overwrites(nb, M, N, K):
+    """las_gemm_tn_store: C = A^T B into a buffer full of junk (NaN included), batched -- the speller's d(keys) and
+    d(memory) products, whose K is the U decoder steps."""
+    from phones_las_amd import hip
+    lda, ldb = (M + 7) // 8 * 8, (N + 7) // 8 * 8
+    A, B = _mk((nb, K, lda), 17), _mk((nb, K, ldb), 18)
+    ref = torch.einsum('bkm,bkn->bmn', A[..., :M].double(), B[..., :N].double())
+    C = torch.full((nb, M, N), float('nan'), device='cuda')
+    hip.gemm_tn(A.cuda(), B.cuda(), C, M, N, K, lda=lda, ldb=ldb, ldc=N, batch=nb, sa=K * lda, sb=K * ldb, sc=M * N, store=True)
+    _close(C, ref)
+    with pytest.raises(hip.LasError):
+        hip.check(hip.lib().las_gemm_tn_store(None, lda, None, ldb, None, N, M, N, 0, 0, 0, 0, 1, 0, 0, 0, hip.stream()))
+
+
 @pytest.mark.parametrize('shift', [-1, 1])
 def test_gemm_tn_shifted_rows(shift):
     # dK_h = sum_t h_{t-1}^T dz_t without a shifted copy: rows cross no utterance boundary
