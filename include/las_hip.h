@@ -89,10 +89,11 @@ int las_gemm_tn(const las_bf16* A, int64_t lda, const las_bf16* B, int64_t ldb, 
                 int64_t sb, int64_t sc, int split_k, void* stream);
 /* C = A^T B: the same product storing its result (no zeroing of C beforehand, no atomics, K not split): the batched
  * d(keys) = ds^T h and d(memory) = alignments^T d(context) of the speller's backward, whose K is only the U decoder steps
- * (TF autodiff of the attention mechanism's matmuls, model_helper.py:415). */
-int las_gemm_tn_store(const las_bf16* A, int64_t lda, const las_bf16* B, int64_t ldb, float* C, int64_t ldc,
+ * (TF autodiff of the attention mechanism's matmuls, model_helper.py:415).  C fp32, or bf16 with out_bf16 != 0 (d(keys)
+ * is only ever an operand of further products). */
+int las_gemm_tn_store(const las_bf16* A, int64_t lda, const las_bf16* B, int64_t ldb, void* C, int64_t ldc,
                       int M, int N, int K, int a_shift, int period, int c_perm_h, int batch, int64_t sa,
-                      int64_t sb, int64_t sc, void* stream);
+                      int64_t sb, int64_t sc, int out_bf16, void* stream);
 
 /* All weight gradients of one LSTM direction in ONE product (dz is read once instead of three times):
  *   kernel_grad[0:D, :]   += x^T dz              (input half of the [D+H, 4H] TF kernel)

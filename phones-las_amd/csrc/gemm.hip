@@ -484,6 +484,7 @@ __global__ __launch_bounds__(256) void gemm_tn_tr_kernel(GemmArgs g) {
         const int64_t off = (int64_t)row * g.ldc + col;
         if (g.atomic) atomicAdd(Cf + off, acc[i][j][r]);
         else if (g.accumulate) Cf[off] += acc[i][j][r];
+        else if (g.out_bf16) (reinterpret_cast<unsigned short*>(g.C) + (int64_t)batch * g.sc)[off] = las_f2bf(acc[i][j][r]);
         else Cf[off] = acc[i][j][r];
       }
     }
@@ -994,9 +995,9 @@ extern "C" int las_gemm_nt(const las_bf16* A, int64_t lda, const las_bf16* B, in
   return launch<128, 128, false>(g, batch, st);
 }
 
-static int gemm_tn(const las_bf16* A, int64_t lda, const las_bf16* B, int64_t ldb, float* C, int64_t ldc,
+static int gemm_tn(const las_bf16* A, int64_t lda, const las_bf16* B, int64_t ldb, void* C, int64_t ldc,
                    int M, int N, int K, int a_shift, int period, int c_perm_h, int batch, int64_t sa,
-                   int64_t sb, int64_t sc, int split_k, bool store, void* stream) {
+                   int64_t sb, int64_t sc, int split_k, bool store, bool out_bf16, void* stream) {
   LAS_REQUIRE(M > 0 && N > 0 && K > 0 && batch > 0, "las_gemm_tn: empty problem");
   LAS_REQUIRE(!store || split_k <= 1, "las_gemm_tn_store: K cannot be split");
   LAS_REQUIRE(lda % 8 == 0 && ldb % 8 == 0 && lda >= ((M + 7) / 8) * 8 && ldb >= ((N + 7) / 8) * 8,
@@ -1005,7 +1006,7 @@ static int gemm_tn(const las_bf16* A, int64_t lda, const las_bf16* B, int64_t ld
   if (split_k < 1) split_k = 1;
   hipStream_t st = (hipStream_t)stream;
   LAS_REQUIRE(c_perm_h == 0 || N == 4 * c_perm_h, "las_gemm_tn: c_perm_h needs N == 4*H");
-  GemmArgs g{A, B, C, nullptr, lda, ldb, ldc, sa, sb, sc, M, N, K, 0, store ? 0 : 1, store ? 0 : 1, split_k, a_shift, period, c_perm_h};
+  GemmArgs g{A, B, C, nullptr, lda, ldb, ldc, sa, sb, sc, M, N, K, out_bf16 ? 1 : 0, store ? 0 : 1, store ? 0 : 1, split_k, a_shift, period, c_perm_h};
   if (M <= 64 || N <= 64) return launch<64, 64, true>(g, batch, st);
   {
     dim3 grid((N + 127) / 128, (M + 127) / 128, batch * split_k);
@@ -1024,13 +1025,14 @@ static int gemm_tn(const las_bf16* A, int64_t lda, const las_bf16* B, int64_t ld
 extern "C" int las_gemm_tn(const las_bf16* A, int64_t lda, const las_bf16* B, int64_t ldb, float* C, int64_t ldc,
                            int M, int N, int K, int a_shift, int period, int c_perm_h, int batch, int64_t sa,
                            int64_t sb, int64_t sc, int split_k, void* stream) {
-  return gemm_tn(A, lda, B, ldb, C, ldc, M, N, K, a_shift, period, c_perm_h, batch, sa, sb, sc, split_k, false, stream);
+  return gemm_tn(A, lda, B, ldb, C, ldc, M, N, K, a_shift, period, c_perm_h, batch, sa, sb, sc, split_k, false, false, stream);
 }
 
-extern "C" int las_gemm_tn_store(const las_bf16* A, int64_t lda, const las_bf16* B, int64_t ldb, float* C, int64_t ldc,
+extern "C" int las_gemm_tn_store(const las_bf16* A, int64_t lda, const las_bf16* B, int64_t ldb, void* C, int64_t ldc,
                                  int M, int N, int K, int a_shift, int period, int c_perm_h, int batch, int64_t sa,
-                                 int64_t sb, int64_t sc, void* stream) {
-  return gemm_tn(A, lda, B, ldb, C, ldc, M, N, K, a_shift, period, c_perm_h, batch, sa, sb, sc, 1, true, stream);
+                                 int64_t sb, int64_t sc, int out_bf16, void* stream) {
+  LAS_REQUIRE(!(out_bf16 && c_perm_h), "las_gemm_tn_store: no column permutation with bf16 output");
+  return gemm_tn(A, lda, B, ldb, C, ldc, M, N, K, a_shift, period, c_perm_h, batch, sa, sb, sc, 1, true, out_bf16 != 0, stream);
 }
 
 extern "C" size_t las_gemm_tn_lstm_workspace_bytes(int D, int H, int split_k) {

@@ -22,7 +22,7 @@ _SIGS = {
     'las_last_error': ([], C.c_char_p),
     'las_gemm_nt': ([_vp, _i64, _vp, _i64, _vp, _i64, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i64, _i64, _i64, _i32, _vp], C.c_int),
     'las_gemm_tn': ([_vp, _i64, _vp, _i64, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i64, _i64, _i64, _i32, _vp], C.c_int),
-    'las_gemm_tn_store': ([_vp, _i64, _vp, _i64, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i64, _i64, _i64, _vp], C.c_int),
+    'las_gemm_tn_store': ([_vp, _i64, _vp, _i64, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i64, _i64, _i64, _i32, _vp], C.c_int),
     'las_cast_bf16': ([_vp, _i64, _i32, _i32, _vp, _i64, _i32, _i32, _i32, _i32, _i64, _i64, _i32, _vp], C.c_int),
     'las_refresh_images': ([_vp, C.c_int, _vp], C.c_int),
     'las_fill_many': ([_vp, C.c_int, _vp], C.c_int),
@@ -261,14 +261,14 @@ def gemm_nt(A, B, C_, M, N, K, lda=None, ldb=None, ldc=None, bias=None, out_bf16
 
 def gemm_tn(A, B, C_, M, N, K, lda=None, ldb=None, ldc=None, a_shift=0, period=0, batch=1, sa=0, sb=0, sc=0,
             split_k=1, c_perm_h=0, store=False):
-    """C += A^T B (atomics: zero C first), or with store=True C = A^T B (no zeroing, K not split)."""
+    """C += A^T B (atomics: zero C first), or with store=True C = A^T B (no zeroing, K not split; C fp32 or bf16)."""
     lda = lda if lda is not None else A.stride(-2)
     ldb = ldb if ldb is not None else B.stride(-2)
     ldc = ldc if ldc is not None else C_.stride(-2)
     tok = prof_begin('gemm_tn', 2.0 * M * N * K * batch)
     if store:
         check(lib().las_gemm_tn_store(p(A), lda, p(B), ldb, p(C_), ldc, M, N, K, a_shift, period, c_perm_h, batch, sa, sb,
-                                      sc, stream()))
+                                      sc, int(C_.dtype == torch.bfloat16), stream()))
     else:
         check(lib().las_gemm_tn(p(A), lda, p(B), ldb, p(C_), ldc, M, N, K, a_shift, period, c_perm_h, batch, sa, sb, sc,
                                 split_k, stream()))

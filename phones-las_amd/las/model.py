@@ -457,16 +457,18 @@ class Speller:
             hip.check(lib.las_decoder_step_bwd(C.byref(s), st))
             hip.gemm_nt(dz_all[:, t], self.kc, dfeed, B, W, 4 * Hd, lda=U * 4 * Hd, ldb=4 * Hd, ldc=W)
         # critical path: d(keys), d(memory) feed the listener's backward
-        # (stored, not accumulated: no zero fills in front of them, no atomics -- K is only the U steps)
+        # (stored, not accumulated: no zero fills in front of them, no atomics -- K is only the U steps; d(keys) of the
+        # dot-product scores is only ever an operand of further products: written as bf16 at once)
         if not bah:
-            dkeys = torch.empty(B, Tm, Hd, dtype=f32, device=dev)
-            hip.gemm_tn(ds_all, sv['h_all'], dkeys, Tm, Hd, U, lda=Tmp, ldb=Hd, ldc=Hd, batch=B, sa=U * Tmp,
+            dkeys_bf = torch.empty(B * Tm, Hd, dtype=bf, device=dev)
+            hip.gemm_tn(ds_all, sv['h_all'], dkeys_bf, Tm, Hd, U, lda=Tmp, ldb=Hd, ldc=Hd, batch=B, sa=U * Tmp,
                         sb=U * Hd, sc=Tm * Hd, store=True)
+        else:
+            dkeys_bf = torch.empty(B * Tm, Hd, dtype=bf, device=dev)
+            hip.cast_bf16(dkeys, B * Tm, Hd, dkeys_bf, B * Tm, Hd, ldd=Hd, lds=Hd)
         dmem = torch.empty(B, Tm, M, dtype=f32, device=dev)
         hip.gemm_tn(sv['align_bf'], dctx_all, dmem, Tm, M, U, lda=Tmp, ldb=M, ldc=M, batch=B, sa=U * Tmp, sb=U * M,
                     sc=Tm * M, store=True)
-        dkeys_bf = torch.empty(B * Tm, Hd, dtype=bf, device=dev)
-        hip.cast_bf16(dkeys, B * Tm, Hd, dkeys_bf, B * Tm, Hd, ldd=Hd, lds=Hd)
         hip.gemm_nt(dkeys_bf, self.wmem, dmem, B * Tm, M, Hd, lda=Hd, ldb=Hd, ldc=M, accumulate=True)
         # weight gradients (off the critical path): cell rows [V, V+M+Hd) from [attention_{t-1}, h_{t-1}], rows
         # [0,V) from the tokens, projection, memory_layer, query_layer

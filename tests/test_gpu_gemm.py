@@ -95,8 +95,11 @@ def test_gemm_tn_store_overwrites(nb, M, N, K):
     C = torch.full((nb, M, N), float('nan'), device='cuda')
     hip.gemm_tn(A.cuda(), B.cuda(), C, M, N, K, lda=lda, ldb=ldb, ldc=N, batch=nb, sa=K * lda, sb=K * ldb, sc=M * N, store=True)
     _close(C, ref)
+    Cb = torch.full((nb, M, N), float('nan'), device='cuda', dtype=torch.bfloat16)      # bf16 output: one rounding of the fp32 sums
+    hip.gemm_tn(A.cuda(), B.cuda(), Cb, M, N, K, lda=lda, ldb=ldb, ldc=N, batch=nb, sa=K * lda, sb=K * ldb, sc=M * N, store=True)
+    assert torch.equal(Cb, C.to(torch.bfloat16))
     with pytest.raises(hip.LasError):
-        hip.check(hip.lib().las_gemm_tn_store(None, lda, None, ldb, None, N, M, N, 0, 0, 0, 0, 1, 0, 0, 0, hip.stream()))
+        hip.check(hip.lib().las_gemm_tn_store(None, lda, None, ldb, None, N, M, N, 0, 0, 0, 0, 1, 0, 0, 0, 0, hip.stream()))
 
 
 @pytest.mark.parametrize('shift', [-1, 1])
