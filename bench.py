@@ -388,7 +388,11 @@ def main():
     if len(candidates) > 1:
         for name in sorted(candidates):
             probed[name] = probe(candidates[name][0])
-        chosen = min(sorted(probed), key=lambda n: probed[n])
+        # (sorted: the same tie-break on every rank.  Forms within 1 % of the fastest tie, and a tie goes to eager
+        # launches: eight probe steps of a 6-ms step scatter by that much, and a graph picked on a 0.5 % edge has replayed
+        # slower than eager launches as often as not)
+        best = min(probed.values())
+        chosen = min(sorted(n for n in probed if probed[n] <= 1.01 * best), key=lambda n: (n.endswith('_graph'), probed[n]))
     else:
         chosen = next(iter(candidates))
     step, used_graph, used_overlap = candidates[chosen]
