@@ -604,6 +604,39 @@ def test_persistent_decoder_vs_per_step_and_oracle(att, monkeypatch):
         assert relerr(outs['1'][2][name], g) < GRAD_TOL, name
 
 
+@pytest.mark.parametrize('H,Hd', [(512, 512), (256, 128), (128, 256)])
+def test_persistent_luong_decoder_other_widths_vs_per_step_and_oracle(H, Hd, monkeypatch):
+    """The one-launch Luong decoder at the other instantiations: 512 units (two hidden units per thread, M = 2048: the
+    d(alignments) loop in its rolled form, the transposed keys of 512 units) and listener / decoder widths that differ
+    (M = 4H against Hd) -- against the per-step launches and the oracle."""
+    from phones_las_amd import hip
+    O, ohp, op, model = _models('luong', H=H, Hd=Hd, F=13, L=2, pass_hidden=False)
+    src_len, tgt_len = [16, 7, 10, 16, 3, 9, 11, 16, 5], [6, 4, 5, 6, 2, 3, 6, 5, 4]
+    batch = make_batch(B=9, T=16, src_len=src_len, tgt_len=tgt_len)
+    feats, labels = to_device(batch)
+    outs = {}
+    for flag in ('1', '0'):
+        monkeypatch.setenv('LAS_DEC_PERSIST', flag)
+        model.vars.grad.zero_()
+        loss, logits, dlogits = model.forward_train(feats, labels)
+        model.backward(dlogits)
+        torch.cuda.synchronize()
+        if flag == '1':
+            assert int(model.speller._persist_ws[:4].view(torch.int32).item()) == 0
+            assert int(model.speller._persist_ws_bwd[:4].view(torch.int32).item()) == 0
+        outs[flag] = (logits.clone(), {n: g.clone() for n, g in model.vars.grads.items()})
+    assert relerr(outs['1'][0], outs['0'][0].cpu()) < 1e-3
+    for name in outs['1'][1]:            # (bf16 flips of dz / d(context) elements between the two paths: measured 2.4e-3 at 512 units)
+        assert relerr(outs['1'][1][name], outs['0'][1][name].cpu()) < 4e-3, name
+    out = O.train_step(ohp, op, None, None, 1, batch, mxu='bf16')
+    V = ohp.decoder.target_vocab_size
+    for b, n in enumerate(tgt_len):
+        assert relerr(outs['1'][0][b, :n, :V], out['aux']['logits'][b, :n]) < 2e-2
+    for name, _, _ in model.vars.table:
+        g = out['grads'][name] - ohp.l2_reg_scale * op[name]
+        assert relerr(outs['1'][1][name], g) < GRAD_TOL, name
+
+
 @pytest.mark.parametrize('B,T,U,src_len,tgt_len', [
     (1, 8, 1, [8], [1]),                                   # one utterance, one decoder step
     (2, 8, 3, [2, 8], [3, 1]),                             # memory shorter than the four frame shares
