@@ -698,7 +698,7 @@ __global__ __launch_bounds__(256) void dec_persist_fwd_kernel(las_dec_persist p)
 
   // G role: this member's columns of z and its register-resident slice of K ([4Hd, K_in] bf16, row = output column)
   const int CPM = 4 * Hd / P_MEMBERS, NTL = CPM / 16;      // columns per member, 16-column tiles
-  const int KC = p.K_in / 32, KCW = (KC + 3) / 4;          // 32-deep K chunks; wave w takes chunks w, w+4, ...
+  const int KC = p.K_in / 32;                               // 32-deep K chunks; wave w takes chunks w, w+4, ...
   bf16x8 wf[NTL_MAX][KRES];
   const unsigned short* wrow[NTL_MAX];          // this lane's row of kT per column tile (the streamed chunks' source)
 #pragma unroll
@@ -1911,7 +1911,6 @@ __global__ __launch_bounds__(256) void dec_persist_bwd_kernel(las_dec_persist_bw
   for (int t = p.U - 1; t >= 0; --t) {
     const bool first = (t == p.U - 1);
     LAS_STAMPB(p.U - 1 - t, 0);
-    const float* dfeed_next = first ? nullptr : p.dfeed_all + (int64_t)(t + 1) * B * W;      // written by step t+1
     float sg[UPT][4], sct[UPT], scp[UPT], sdf[UPT];
 #pragma unroll
     for (int q = 0; q < UPT; ++q) {

@@ -13,8 +13,6 @@
 
 namespace {
 
-constexpr int BK = 64;        // K depth of a staged tile (gemm_kernel: template parameter KB)
-
 struct GemmArgs {
   const unsigned short* A;
   const unsigned short* B;

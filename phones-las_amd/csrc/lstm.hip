@@ -114,7 +114,6 @@ __global__ void pack_recurrent_kernel(const float* kh, int H, unsigned short* pa
 // ------------------------------------------------------------------------------------------------
 // Workgroup size: 4 compute waves, one per SIMD (512-register budget).  When the chain is shared by several workgroups
 // the group has PREFETCH COMPANION workgroups (see the kernel) that keep its HBM operands L2-resident.
-__host__ __device__ constexpr int rec_threads(int H) { return 256; }
 
 // ROWS = utterances per slice: 16 fills the MFMA tile; 8 (rows 0,1 of every quad; the other two stay zero) halves the
 // element-wise work, the exchange and the HBM accesses of every lane at the same MFMA cost -- the per-step latency is
