@@ -1250,6 +1250,18 @@ __global__ __launch_bounds__(256) void dec_persist_fwd_lean_kernel(las_dec_persi
           for (int j = 0; j < 8; ++j) acc[j] = 0.f;
           const unsigned short* wp = p.s.wq + c0 + ag * 8;
           int r = ug;
+          for (; r + 15 * UG < Hd; r += 16 * UG) {           // (16 rows in flight: the loop is L2 round trips)
+            uint4 w[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) w[i] = ld16(wp + (int64_t)(r + i * UG) * Hd);
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+              const unsigned short* e = reinterpret_cast<const unsigned short*>(&w[i]);
+              const float xv = hq[r + i * UG];
+#pragma unroll
+              for (int j = 0; j < 8; ++j) acc[j] += xv * las_bf2f(e[j]);
+            }
+          }
           for (; r + 7 * UG < Hd; r += 8 * UG) {
             uint4 w[8];
 #pragma unroll
