@@ -981,7 +981,7 @@ __device__ __forceinline__ float dot2_bf16(unsigned a, unsigned b, float acc) {
 
 // NTL: 16-column tiles of z per member (decoder_units / 128: 1, 2 or 4).  KRES of the KCWM 32-deep K chunks a wave owns stay in
 // registers as MFMA B fragments; the chunks beyond (512 units: 12 of 20) are streamed from L2 at every step, three in flight.
-template <int ATT, int NTL, int KRES = 12, int KCWM = 12>
+template <int ATT, int NTL, int KRES = 12, int KCWM = 12, bool SAMPLING = false>
 __global__ __launch_bounds__(256) void dec_persist_fwd_lean_kernel(las_dec_persist p) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   constexpr int UPT = NTL == 4 ? 2 : 1;                    // hidden units per thread (512 units: tid and tid + 256)
@@ -1462,7 +1462,77 @@ __global__ __launch_bounds__(256) void dec_persist_fwd_lean_kernel(las_dec_persi
       LAS_STAMP(t, 9);
     }
     tok_cur = tok_next;
+    bool resampled = false;
+    if constexpr (SAMPLING) {
+      // ---- scheduled sampling (utils/training_helper.py:48-87), as in dec_persist_fwd_kernel: logits_t = context_t W_proj + b
+      //      from the four parts' partial products, then the token fed at step t+1 = Categorical(logits_t) with probability
+      //      p, else the teacher's.  The draws are counter-based: every member knows which utterances of its group are
+      //      selected at this step; a group without a selection skips the phase and its barrier ----
+      const int V = p.V, Vp = p.Vp;
+      bool any_sel = false, my_sel = false;
+      if (t + 1 < U) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int bj = group * 8 + j;
+          const bool sel = bj < B && las_uniform(p.seed, 0x5e1ec7u, (unsigned long long)t * B + bj) < p.sampling_prob;
+          any_sel = any_sel || sel;
+          if (bj == bs) my_sel = sel;
+        }
+      }
+      if (any_sel) {
+        float* plog_t = p.plog + ((int64_t)t * B + bsc) * 4 * Vp;
+        if (my_sel) {
+          float* cx = cred;                               // [ncols] my context columns as floats (cred: idle since the scores)
+          __builtin_amdgcn_s_waitcnt(0x0070);             // my context stores are done
+          __syncthreads();
+          const unsigned short* crow = p.s.ctx_out + (int64_t)bs * p.s.ldc + (int64_t)t * p.inc_ctx + c_begin;
+          for (int c = tid; c < ncols; c += 256)
+            cx[c] = las_bf2f(__hip_atomic_load(crow + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+          __syncthreads();
+          for (int v = tid; v < Vp; v += 256) {
+            float acc = 0.f;
+            if (v < V) {
+              const unsigned short* wrow = p.wprojT + (int64_t)v * p.ldw + c_begin;
+              for (int c = 0; c < ncols; c += 8) {
+                const uint4 w = *reinterpret_cast<const uint4*>(wrow + c);
+                acc += dot8(w, cx + c);
+              }
+            }
+            plog_t[part * Vp + v] = acc;
+          }
+        }
+        if (!persist_barrier(flags, member, ++epoch, local, fail)) break;
+        if (my_sel && part == 0) {
+          float* lg = cred;                               // [Vp]
+          for (int v = tid; v < Vp; v += 256)
+            lg[v] = v < V ? plog_t[v] + plog_t[Vp + v] + plog_t[2 * Vp + v] + plog_t[3 * Vp + v] + p.bproj[v] : p.bproj[v];
+          __syncthreads();
+          if (tid < 64) {
+            const unsigned long long sidx = (unsigned long long)t * B + bs;
+            float best = -INFINITY;
+            int arg = 0;
+            for (int v = lane; v < V; v += 64) {
+              const float u = fmaxf(las_uniform(p.seed, 0x9a3b1eu, sidx * V + v), 1e-12f);
+              const float gmb = lg[v] - __logf(-__logf(u));
+              if (gmb > best) { best = gmb; arg = v; }
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+              const float ob = __shfl_xor(best, o, 64);
+              const int oa = __shfl_xor(arg, o, 64);
+              if (ob > best || (ob == best && oa < arg)) { best = ob; arg = oa; }
+            }
+            if (lane == 0) const_cast<int32_t*>(p.s.tok_ids)[(int64_t)bs * p.s.tok_stride + t + 1] = arg;   // else: the teacher's, already there
+          }
+        }
+        resampled = my_sel;
+      }
+    }
     if (!persist_barrier(flags, member, ++epoch, local, fail)) break;
+    if constexpr (SAMPLING) {
+      // the token part 0 has just drawn for step t+1 (behind the barrier: every part of the utterance reads it)
+      if (resampled) tok_cur = __hip_atomic_load(p.s.tok_ids + (int64_t)bs * p.s.tok_stride + t + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     LAS_STAMP(t, 10);
   }
   if (*fail && tid == 0) atomicOr(status, 8u);
@@ -2767,8 +2837,8 @@ extern "C" int las_decoder_persist_fwd(const las_dec_persist* p, void* stream) {
     const char* e = getenv("LAS_DEC_LEAN");
     lean_mode = (e && atoi(e) == 0) ? 0 : 1;
   }
-  if (lean_mode && p->sampling_prob <= 0.f && s->tok_rows && persist_fwd_lean_ok(s->Hd, s->M, s->Tm, p->U, s->attention, s->norm) &&
-      p->K_in / 32 <= (s->Hd == 512 ? 80 : 48)) {
+  if (lean_mode && (p->sampling_prob <= 0.f || s->Hd <= 256) && s->tok_rows &&
+      persist_fwd_lean_ok(s->Hd, s->M, s->Tm, p->U, s->attention, s->norm) && p->K_in / 32 <= (s->Hd == 512 ? 80 : 48)) {
     const size_t lbytes = lean_layout(s->Hd, s->Tm, s->M, p->U).total_bytes;
 #define LAS_LEAN_LAUNCH(...)                                                                                                    \
   do {                                                                                                                          \
@@ -2781,7 +2851,15 @@ extern "C" int las_decoder_persist_fwd(const las_dec_persist* p, void* stream) {
     hipLaunchKernelGGL((dec_persist_fwd_lean_kernel<__VA_ARGS__>), grid, dim3(256), lbytes, st, *p);                            \
   } while (0)
     // 4 Hd / 32 columns per member = one, two or four 16-column tiles; 512 units: 8 of the 20 K chunks per wave resident
-    if (s->attention == LAS_ATT_LUONG) {
+    if (p->sampling_prob > 0.f) {           // (scheduled sampling inside the launch: decoder_units <= 256)
+      if (s->attention == LAS_ATT_LUONG) {
+        if (s->Hd == 256) LAS_LEAN_LAUNCH(LAS_ATT_LUONG, 2, 12, 12, true);
+        else LAS_LEAN_LAUNCH(LAS_ATT_LUONG, 1, 12, 12, true);
+      } else {
+        if (s->Hd == 256) LAS_LEAN_LAUNCH(LAS_ATT_BAHDANAU, 2, 12, 12, true);
+        else LAS_LEAN_LAUNCH(LAS_ATT_BAHDANAU, 1, 12, 12, true);
+      }
+    } else if (s->attention == LAS_ATT_LUONG) {
       if (s->Hd == 512) LAS_LEAN_LAUNCH(LAS_ATT_LUONG, 4, 8, 20);
       else if (s->Hd == 256) LAS_LEAN_LAUNCH(LAS_ATT_LUONG, 2);
       else LAS_LEAN_LAUNCH(LAS_ATT_LUONG, 1);

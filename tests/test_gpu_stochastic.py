@@ -216,7 +216,9 @@ def test_persistent_decoder_with_sampling_and_dropout_replayed(monkeypatch):
     assert int(sp._persist_ws[:4].view(torch.int32).item()) == 0
     assert torch.equal(res['1'][0], res['0'][0])                      # the same tokens were sampled
     assert bool((res['1'][0][:, 1:6] != batch['targets_inputs'][:, 1:6]).any())      # and some were sampled at all
-    assert relerr(res['1'][1], res['0'][1].cpu()) < 1e-5      # same arithmetic, same order (only the projection sums differ)
+    # (the one-launch launch now runs the written-out kernel under scheduled sampling too: v_dot2c scores, matrix-core context
+    #  sums -- a bf16 context element that rounds the other way moves the logits by ~1e-4; the sampled tokens are identical)
+    assert relerr(res['1'][1], res['0'][1].cpu()) < 1e-3
     fed, logits, grads = res['1']
     seed = model.last_seed
     B, T, F, H, V, U = 3, 12, 13, 128, 11, 6
