@@ -77,6 +77,13 @@ int las_gemm_nt(const las_bf16* A, int64_t lda, const las_bf16* B, int64_t ldb, 
                 const float* bias, int M, int N, int K, int out_bf16, int accumulate, int batch,
                 int64_t sa, int64_t sb, int64_t sc, int split_k, void* stream);
 
+/* C (=|+=) (A B^T) * mask / keep, mask[row, col] = [las_uniform(seed, stream_id, row * N + col) < keep]: the gradient through a
+ * cell's input dropout (DropoutWrapper(input_keep_prob), las/ops.py:14-18; the mask las_dropout_bf16 drew for that cell in
+ * the forward pass) folded into the epilogue of dX = dZ K_x^T.  One direction stores, the other accumulates: no partial dX
+ * buffers, no las_dropout_bwd pass over them.  C fp32, contiguous (ldc == N); bulk shapes (M, N > 64). */
+int las_gemm_nt_masked(const las_bf16* A, int64_t lda, const las_bf16* B, int64_t ldb, float* C, int64_t ldc,
+                       int M, int N, int K, int accumulate, float keep, uint32_t seed, uint32_t stream_id, void* stream);
+
 /* C[M,N] += sum_k A[k,M] * B[k,N]  (weight gradients X^T dZ; TF autodiff of the matmuls above,
  * model_helper.py:415).  A [K,M] and B [K,N] bf16 with M resp. N contiguous.  C fp32, always
  * accumulated with atomics (zero it first).  a_shift/period: row k of A is taken from

@@ -34,7 +34,14 @@ struct GemmArgs {
   // ([M][N], plain column order); tn_reduce_kernel folds the slices into C / bias_row afterwards.
   float* partial = nullptr;
   int64_t partial_stride = 0;
+  // las_gemm_nt_masked: element (row, col) of the product is multiplied by the input-dropout mask of the cell that read it
+  // (1 / keep where las_uniform(seed, stream, row * N + col) < keep, else 0) before it is stored or accumulated
+  float drop_keep = 1.0f;
+  unsigned drop_seed = 0, drop_stream = 0;
 };
+__device__ __forceinline__ float drop_scale(const GemmArgs& g, int row, int col) {
+  return las_uniform(g.drop_seed, g.drop_stream, (unsigned long long)row * g.N + col) < g.drop_keep ? 1.0f / g.drop_keep : 0.f;
+}
 
 // LDS-DMA: 16 bytes per lane from a per-lane global address to (wave-uniform LDS base in M0) + lane * 16; invisible to the
 // compiler's vmcnt bookkeeping (the ring kernels count their loads themselves)
@@ -234,6 +241,10 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
       if (row >= g.M || col >= g.N) continue;
       const float4 v4 = *reinterpret_cast<const float4*>(cs + (r0 + rl) * LDC + cl);
       float v[4] = {v4.x + bv[0], v4.y + bv[1], v4.z + bv[2], v4.w + bv[3]};
+      if (g.drop_keep < 1.0f) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] *= drop_scale(g, row, col + e);
+      }
       const int64_t off = (int64_t)row * g.ldc + col;
       const bool full = (col + 3 < g.N);
       if (g.out_bf16) {
@@ -273,7 +284,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
       for (int r = 0; r < 4; ++r) {
         const int row = m0 + wr * (BM / 2) + i * 16 + (lane >> 4) * 4 + r;
         if (row >= g.M) continue;
-        const float v = acc[i][j][r] + bv;
+        float v = acc[i][j][r] + bv;
+        if (g.drop_keep < 1.0f) v *= drop_scale(g, row, col);
         const int64_t off = (int64_t)row * g.ldc + col;
         if (g.out_bf16) {
           Cb[off] = las_f2bf(v);
@@ -827,6 +839,10 @@ __global__ __launch_bounds__(512) void gemm_nt_ring_kernel(GemmArgs g) {
       if (row >= g.M || col >= g.N) continue;
       const float4 v4 = *reinterpret_cast<const float4*>(cs + (r0 + rl) * LDC + cl);
       float v[4] = {v4.x + bv[0], v4.y + bv[1], v4.z + bv[2], v4.w + bv[3]};
+      if (g.drop_keep < 1.0f) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] *= drop_scale(g, row, col + e);
+      }
       const int64_t off = (int64_t)row * g.ldc + col;
       const bool full = (col + 3 < g.N);
       if (g.out_bf16) {
@@ -952,9 +968,10 @@ __global__ void zero_rows_kernel(float* C, int64_t ldc, int M, int N, int64_t sc
 
 }  // namespace
 
-extern "C" int las_gemm_nt(const las_bf16* A, int64_t lda, const las_bf16* B, int64_t ldb, void* C, int64_t ldc,
-                           const float* bias, int M, int N, int K, int out_bf16, int accumulate, int batch,
-                           int64_t sa, int64_t sb, int64_t sc, int split_k, void* stream) {
+static int gemm_nt(const las_bf16* A, int64_t lda, const las_bf16* B, int64_t ldb, void* C, int64_t ldc,
+                   const float* bias, int M, int N, int K, int out_bf16, int accumulate, int batch,
+                   int64_t sa, int64_t sb, int64_t sc, int split_k, float drop_keep, unsigned drop_seed, unsigned drop_stream,
+                   void* stream) {
   LAS_REQUIRE(M > 0 && N > 0 && K > 0 && batch > 0, "las_gemm_nt: empty problem M=%d N=%d K=%d batch=%d", M, N, K, batch);
   LAS_REQUIRE(K % 8 == 0 && lda % 8 == 0 && ldb % 8 == 0, "las_gemm_nt: K, lda, ldb must be multiples of 8 (K=%d lda=%ld ldb=%ld)", K, (long)lda, (long)ldb);
   LAS_REQUIRE(((uintptr_t)A % 16 == 0) && ((uintptr_t)B % 16 == 0) && sa % 8 == 0 && sb % 8 == 0, "las_gemm_nt: operands must be 16-byte aligned");
@@ -962,6 +979,11 @@ extern "C" int las_gemm_nt(const las_bf16* A, int64_t lda, const las_bf16* B, in
   LAS_REQUIRE(!(out_bf16 && (accumulate || split_k > 1)), "las_gemm_nt: bf16 output cannot accumulate or split K");
   hipStream_t st = (hipStream_t)stream;
   GemmArgs g{A, B, C, bias, lda, ldb, ldc, sa, sb, sc, M, N, K, out_bf16, accumulate, split_k > 1 ? 1 : 0, split_k, 0, 0, 0};
+  g.drop_keep = drop_keep;
+  g.drop_seed = drop_seed;
+  g.drop_stream = drop_stream;
+  LAS_REQUIRE(drop_keep >= 1.0f || (split_k == 1 && batch == 1 && M > 64 && N > 64 && !out_bf16),
+              "las_gemm_nt_masked: one fp32 product of bulk shape (M, N > 64), K not split");
   if (split_k > 1 && !accumulate) {
     hipLaunchKernelGGL(zero_rows_kernel, dim3(64, 1, batch), dim3(256), 0, st, (float*)C, ldc, M, N, sc);
     LAS_LAUNCH_CHECK("gemm zero");
@@ -1018,6 +1040,19 @@ static int gemm_tn(const las_bf16* A, int64_t lda, const las_bf16* B, int64_t ld
     LAS_LAUNCH_CHECK("gemm tn launch");
     return LAS_OK;
   }
+}
+
+extern "C" int las_gemm_nt(const las_bf16* A, int64_t lda, const las_bf16* B, int64_t ldb, void* C, int64_t ldc,
+                           const float* bias, int M, int N, int K, int out_bf16, int accumulate, int batch,
+                           int64_t sa, int64_t sb, int64_t sc, int split_k, void* stream) {
+  return gemm_nt(A, lda, B, ldb, C, ldc, bias, M, N, K, out_bf16, accumulate, batch, sa, sb, sc, split_k, 1.0f, 0, 0, stream);
+}
+
+extern "C" int las_gemm_nt_masked(const las_bf16* A, int64_t lda, const las_bf16* B, int64_t ldb, float* C, int64_t ldc,
+                                  int M, int N, int K, int accumulate, float keep, uint32_t seed, uint32_t stream_id,
+                                  void* stream) {
+  LAS_REQUIRE(keep > 0.f && keep <= 1.f && ldc == N, "las_gemm_nt_masked: keep in (0, 1], C contiguous (ldc == N: the mask is indexed row * N + col)");
+  return gemm_nt(A, lda, B, ldb, C, ldc, nullptr, M, N, K, 0, accumulate, 1, 0, 0, 0, 1, keep, seed, stream_id, stream);
 }
 
 extern "C" int las_gemm_tn(const las_bf16* A, int64_t lda, const las_bf16* B, int64_t ldb, float* C, int64_t ldc,

@@ -22,6 +22,7 @@ _SIGS = {
     'las_last_error': ([], C.c_char_p),
     'las_gemm_nt': ([_vp, _i64, _vp, _i64, _vp, _i64, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i64, _i64, _i64, _i32, _vp], C.c_int),
     'las_gemm_tn': ([_vp, _i64, _vp, _i64, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i64, _i64, _i64, _i32, _vp], C.c_int),
+    'las_gemm_nt_masked': ([_vp, _i64, _vp, _i64, _vp, _i64, _i32, _i32, _i32, _i32, _f32, C.c_uint32, C.c_uint32, _vp], C.c_int),
     'las_gemm_tn_store': ([_vp, _i64, _vp, _i64, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i64, _i64, _i64, _i32, _vp], C.c_int),
     'las_cast_bf16': ([_vp, _i64, _i32, _i32, _vp, _i64, _i32, _i32, _i32, _i32, _i64, _i64, _i32, _vp], C.c_int),
     'las_refresh_images': ([_vp, C.c_int, _vp], C.c_int),

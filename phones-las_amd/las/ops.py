@@ -237,6 +237,10 @@ def concat_outputs(outputs):
     return outputs
 
 
+# LAS_MASKED_DX=0: the input-dropout backward as its own pass over two partial dX buffers again (diagnostics, A/B timing)
+MASKED_DX = os.environ.get('LAS_MASKED_DX', '1') != '0'
+
+
 def bilstm_backward(rec, dy, d_state, grads, need_dx=True, overlap=None, defer_weight_grads=False, exposed=False):
     """Reverse-mode AD of one bilstm() call.  dy [B,T,nd*H] fp32 (gradient of the concatenated outputs),
     d_state: None or (dc_last, dh_last) each [nd,B,H] fp32.  Accumulates into ``grads`` (name -> fp32
@@ -268,13 +272,23 @@ def bilstm_backward(rec, dy, d_state, grads, need_dx=True, overlap=None, defer_w
             # per direction dX_i = dZ_i K_x,i^T, then through that direction's input dropout (masks regenerated from
             # the counter-based generator); summed when both directions read the same input, side by side otherwise
             parts = []
-            for i in range(nd):
+            lib = hip.lib()
+            if keep < 1.0 and not split_in and nd == 2 and BT > 64 and D > 64 and MASKED_DX:
+                # both directions read the same input through their own masks: dX = sum_d mask_d * (dZ_d K_x,d^T) / keep, the
+                # mask applied in the products' epilogues (the first stores, the second accumulates)
+                seed, stream0 = rec['rng']
+                dx = torch.empty(B, T, D, dtype=torch.float32, device=dev)
+                for i in range(nd):
+                    tok2 = hip.prof_begin('gemm_nt', 2.0 * BT * D * 4 * H)
+                    hip.check(lib.las_gemm_nt_masked(hip.p(dz[..., i * 4 * H:]), nd * 4 * H, hip.p(w.kx[:, i * 4 * H:]), nd * 4 * H,
+                                                     hip.p(dx), D, BT, D, 4 * H, int(i > 0), keep, seed, stream0 + i, hip.stream()))
+                    hip.prof_end(tok2)
+            for i in range(nd if dx is None else 0):
                 pi = torch.empty(B, T, D, dtype=torch.float32, device=dev)
                 hip.gemm_nt(dz[..., i * 4 * H:], w.kx[:, i * 4 * H:], pi, BT, D, 4 * H, lda=nd * 4 * H, ldb=nd * 4 * H,
                             ldc=D)
                 parts.append(pi)
-            lib = hip.lib()
-            if keep < 1.0:
+            if keep < 1.0 and dx is None:
                 seed, stream0 = rec['rng']
                 if split_in or nd == 1:
                     for i in range(nd):

@@ -84,6 +84,29 @@ def test_gemm_tn_matches_fp64(M, N, K, split):
     _close(C, 2 * ref)
 
 
+@pytest.mark.parametrize('M,N,K', [(1536, 1024, 256), (300, 200, 64), (4100, 136, 1024)])
+def test_gemm_nt_masked_is_the_product_through_the_dropout_backward(M, N, K):
+    """las_gemm_nt_masked (the mask of a cell's input dropout in the dX product's epilogue; one direction stores, the other
+    accumulates) against las_gemm_nt into two buffers + las_dropout_bwd over them: the same bits."""
+    from phones_las_amd import hip
+    lib = hip.lib()
+    A0, A1 = _mk((M, K), 21).cuda(), _mk((M, K), 22).cuda()
+    B0, B1 = _mk((N, K), 23).cuda(), _mk((N, K), 24).cuda()
+    keep, seed, st = 0.8, 4242, 16
+    p0, p1 = torch.empty(M, N, device='cuda'), torch.empty(M, N, device='cuda')
+    hip.gemm_nt(A0, B0, p0, M, N, K, lda=K, ldb=K, ldc=N)
+    hip.gemm_nt(A1, B1, p1, M, N, K, lda=K, ldb=K, ldc=N)
+    ref = torch.empty(M, N, device='cuda')
+    hip.check(lib.las_dropout_bwd(hip.p(p0), hip.p(p1), hip.p(ref), M, N, keep, seed, st, st + 1, hip.stream()))
+    out = torch.full((M, N), float('nan'), device='cuda')
+    hip.check(lib.las_gemm_nt_masked(hip.p(A0), K, hip.p(B0), K, hip.p(out), N, M, N, K, 0, keep, seed, st, hip.stream()))
+    hip.check(lib.las_gemm_nt_masked(hip.p(A1), K, hip.p(B1), K, hip.p(out), N, M, N, K, 1, keep, seed, st + 1, hip.stream()))
+    torch.cuda.synchronize()
+    assert float((out == 0).float().mean()) > 0.02              # both masks dropped some elements
+    assert torch.equal(out == 0, ref == 0)
+    assert float((out - ref).abs().max()) <= 1e-6 * float(ref.abs().max())
+
+
 @pytest.mark.parametrize('nb,M,N,K', [(3, 200, 1024, 80), (5, 50, 256, 80), (2, 7, 40, 3), (1, 130, 136, 33)])
 def test_gemm_tn_store_overwrites(nb, M, N, K):
     """las_gemm_tn_store: C = A^T B into a buffer full of junk (NaN included), batched -- the speller's d(keys) and
