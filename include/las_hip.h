@@ -419,6 +419,10 @@ int las_decoder_persist_bwd(const las_dec_persist_bwd* p, void* stream);
 /* y = x * m / keep, m ~ Bernoulli(keep) per element (element index r*cols + c). */
 int las_dropout_bf16(const las_bf16* x, int64_t ldx, las_bf16* y, int64_t ldy, int rows, int cols, float keep,
                      uint32_t seed, uint32_t stream_id, void* stream);
+/* The two directions' copies at once (independent masks for the fw and the bw cell: streams stream0 / stream1, the element
+ * indices of las_dropout_bf16); x is read once.  cols and the row strides in multiples of 8. */
+int las_dropout_bf16_pair(const las_bf16* x, int64_t ldx, las_bf16* y0, las_bf16* y1, int64_t ldy, int rows, int cols,
+                          float keep, uint32_t seed, uint32_t stream0, uint32_t stream1, void* stream);
 /* out = a * mask(stream_a)/keep (+ b * mask(stream_b)/keep when b != NULL); contiguous [rows, cols] fp32. */
 int las_dropout_bwd(const float* a, const float* b, float* out, int rows, int cols, float keep, uint32_t seed,
                     uint32_t stream_a, uint32_t stream_b, void* stream);

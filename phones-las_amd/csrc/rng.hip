@@ -21,6 +21,31 @@ __global__ void dropout_bf16_kernel(const unsigned short* x, int64_t ldx, unsign
   }
 }
 
+// both directions' masked copies of one input in one pass (x is read once): 8 elements per thread when the rows allow
+__global__ void dropout_bf16_pair_kernel(const unsigned short* x, int64_t ldx, unsigned short* y0, unsigned short* y1, int64_t ldy,
+                                         int rows, int cols, float keep, unsigned seed, unsigned stream0, unsigned stream1) {
+  const float inv = 1.0f / keep;
+  const int c8 = cols / 8;
+  const int64_t total = (int64_t)rows * c8;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int r = (int)(i / c8), c = (int)(i % c8) * 8;
+    const uint4 v = *reinterpret_cast<const uint4*>(x + (int64_t)r * ldx + c);
+    const unsigned short* e = reinterpret_cast<const unsigned short*>(&v);
+    uint4 o0, o1;
+    unsigned short* a = reinterpret_cast<unsigned short*>(&o0);
+    unsigned short* b = reinterpret_cast<unsigned short*>(&o1);
+    const unsigned long long base = (unsigned long long)r * cols + c;       // (the element index las_dropout_bf16 uses)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float f = las_bf2f(e[j]);
+      a[j] = las_f2bf(f * (las_uniform(seed, stream0, base + j) < keep ? inv : 0.f));
+      b[j] = las_f2bf(f * (las_uniform(seed, stream1, base + j) < keep ? inv : 0.f));
+    }
+    *reinterpret_cast<uint4*>(y0 + (int64_t)r * ldy + c) = o0;
+    *reinterpret_cast<uint4*>(y1 + (int64_t)r * ldy + c) = o1;
+  }
+}
+
 // out = a * mask_a (+ b * mask_b): gradient through the input dropout of the fw (and bw) cell
 __global__ void dropout_bwd_kernel(const float* a, const float* b, float* out, int rows, int cols, float keep, unsigned seed,
                                    unsigned stream_a, unsigned stream_b) {
@@ -129,6 +154,17 @@ extern "C" int las_dropout_bf16(const las_bf16* x, int64_t ldx, las_bf16* y, int
   hipLaunchKernelGGL(dropout_bf16_kernel, dim3(blocks_for((int64_t)rows * cols)), dim3(256), 0, (hipStream_t)stream, x, ldx, y,
                      ldy, rows, cols, keep, seed, stream_id);
   LAS_LAUNCH_CHECK("dropout launch");
+  return LAS_OK;
+}
+
+extern "C" int las_dropout_bf16_pair(const las_bf16* x, int64_t ldx, las_bf16* y0, las_bf16* y1, int64_t ldy, int rows, int cols,
+                                     float keep, uint32_t seed, uint32_t stream0, uint32_t stream1, void* stream) {
+  LAS_REQUIRE(rows > 0 && cols > 0 && keep > 0.f && keep <= 1.f, "las_dropout_bf16_pair: bad arguments");
+  LAS_REQUIRE(cols % 8 == 0 && ldx % 8 == 0 && ldy % 8 == 0 && ((uintptr_t)x % 16 == 0) && ((uintptr_t)y0 % 16 == 0) && ((uintptr_t)y1 % 16 == 0),
+              "las_dropout_bf16_pair: columns and row strides in multiples of 8, 16-byte aligned buffers");
+  hipLaunchKernelGGL(dropout_bf16_pair_kernel, dim3(blocks_for((int64_t)rows * (cols / 8))), dim3(256), 0, (hipStream_t)stream, x, ldx,
+                     y0, y1, ldy, rows, cols, keep, seed, stream0, stream1);
+  LAS_LAUNCH_CHECK("dropout pair launch");
   return LAS_OK;
 }
 

@@ -58,6 +58,7 @@ _SIGS = {
     'las_tfrecord_parse': ([_vp, _i64, _i32, _vp, _i64, _vp, _vp, _i64, _vp, _i64, _vp], C.c_int),
     'las_normalize_pad_bf16': ([_vp, _vp, _vp, _vp, _i32, _vp, _i32, _i32, _i32, _vp, _vp], C.c_int),
     'las_dropout_bf16': ([_vp, _i64, _vp, _i64, _i32, _i32, _f32, C.c_uint32, C.c_uint32, _vp], C.c_int),
+    'las_dropout_bf16_pair': ([_vp, _i64, _vp, _vp, _i64, _i32, _i32, _f32, C.c_uint32, C.c_uint32, C.c_uint32, _vp], C.c_int),
     'las_dropout_bwd': ([_vp, _vp, _vp, _i32, _i32, _f32, C.c_uint32, C.c_uint32, C.c_uint32, _vp], C.c_int),
     'las_dropout_mask': ([_vp, _i64, _f32, C.c_uint32, C.c_uint32, _vp], C.c_int),
     'las_onehot_bf16': ([_vp, _i64, _i32, _i32, _i32, _vp, _i64, _f32, C.c_uint32, C.c_uint32, _i32, _vp], C.c_int),

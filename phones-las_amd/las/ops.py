@@ -189,9 +189,18 @@ def bilstm(inputs, sequence_length, num_units, dropout, mode, unidirectional=Fal
         if keep < 1.0 and rng is None:
             raise ValueError('dropout needs rng=(seed, first_stream_id)')
         dropped = []
+        pair = None
+        if keep < 1.0 and nd == 2 and not split_inputs and Dp % 8 == 0:
+            # both cells read the same input through their own masks: the two copies in one pass over it
+            seed, stream0 = rng
+            pair = torch.empty(2, B, T, Dp, dtype=torch.bfloat16, device=dev)
+            hip.check(hip.lib().las_dropout_bf16_pair(hip.p(inputs), Dfull, hip.p(pair[0]), hip.p(pair[1]), Dp, B * T, Dp, keep,
+                                                      seed, stream0, stream0 + 1, hip.stream()))
         for i in range(nd):
             src = inputs[..., i * Dp:(i + 1) * Dp] if split_inputs else inputs
-            if keep < 1.0:
+            if pair is not None:
+                a, lda = pair[i], Dp
+            elif keep < 1.0:
                 seed, stream0 = rng
                 xd = torch.empty(B, T, Dp, dtype=torch.bfloat16, device=dev)
                 hip.check(hip.lib().las_dropout_bf16(hip.p(src), Dfull, hip.p(xd), Dp, B * T, Dp, keep, seed,
