@@ -1448,6 +1448,7 @@ __global__ __launch_bounds__(256) void dec_persist_fwd_lean_kernel(las_dec_persi
           if (j < ncols) {
             const unsigned short o = las_f2bf(cv);
             p.s.ctx_out[(int64_t)bs * p.s.ldc + (int64_t)t * p.inc_ctx + c_begin + j] = o;
+            if constexpr (SAMPLING) cred[j] = las_bf2f(o);   // (the sampling phase's operand: the context as the projection sees it)
             if (!last) {
               unsigned short o2 = o;
               if (keep < 1.0f) {   // the copy that feeds step t+1's cell goes through that step's input dropout
@@ -1482,23 +1483,39 @@ __global__ __launch_bounds__(256) void dec_persist_fwd_lean_kernel(las_dec_persi
       if (any_sel) {
         float* plog_t = p.plog + ((int64_t)t * B + bsc) * 4 * Vp;
         if (my_sel) {
-          float* cx = cred;                               // [ncols] my context columns as floats (cred: idle since the scores)
-          __builtin_amdgcn_s_waitcnt(0x0070);             // my context stores are done
+          const float* cx = cred;                         // [ncols] my context columns (bf16 values), left there by the context phase
           __syncthreads();
-          const unsigned short* crow = p.s.ctx_out + (int64_t)bs * p.s.ldc + (int64_t)t * p.inc_ctx + c_begin;
-          for (int c = tid; c < ncols; c += 256)
-            cx[c] = las_bf2f(__hip_atomic_load(crow + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-          __syncthreads();
-          for (int v = tid; v < Vp; v += 256) {
+          if (V <= 64 && (ncols & 31) == 0) {
+            // 64 rows x 4 column quarters: every thread's pieces of W_proj are requested at once (one L2 round trip, not
+            // ncols / 8 of them in 64 threads), the quarters meet in LDS
+            const int v = tid & 63, q = tid >> 6, qn = ncols >> 2;
             float acc = 0.f;
             if (v < V) {
-              const unsigned short* wrow = p.wprojT + (int64_t)v * p.ldw + c_begin;
-              for (int c = 0; c < ncols; c += 8) {
-                const uint4 w = *reinterpret_cast<const uint4*>(wrow + c);
-                acc += dot8(w, cx + c);
+              const unsigned short* wrow = p.wprojT + (int64_t)v * p.ldw + c_begin + q * qn;
+              for (int c0 = 0; c0 < qn; c0 += 64) {
+                uint4 w[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) w[i] = c0 + i * 8 < qn ? *reinterpret_cast<const uint4*>(wrow + c0 + i * 8) : make_uint4(0, 0, 0, 0);
+#pragma unroll
+                for (int i = 0; i < 8; ++i)
+                  if (c0 + i * 8 < qn) acc += dot8(w[i], cx + q * qn + c0 + i * 8);
               }
             }
-            plog_t[part * Vp + v] = acc;
+            cred[1024 + tid] = acc;
+            __syncthreads();
+            if (tid < Vp) plog_t[part * Vp + tid] = tid < V ? (cred[1024 + tid] + cred[1088 + tid]) + (cred[1152 + tid] + cred[1216 + tid]) : 0.f;
+          } else {
+            for (int v = tid; v < Vp; v += 256) {
+              float acc = 0.f;
+              if (v < V) {
+                const unsigned short* wrow = p.wprojT + (int64_t)v * p.ldw + c_begin;
+                for (int c = 0; c < ncols; c += 8) {
+                  const uint4 w = *reinterpret_cast<const uint4*>(wrow + c);
+                  acc += dot8(w, cx + c);
+                }
+              }
+              plog_t[part * Vp + v] = acc;
+            }
           }
         }
         if (!persist_barrier(flags, member, ++epoch, local, fail)) break;
