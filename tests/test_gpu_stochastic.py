@@ -238,3 +238,34 @@ def test_persistent_decoder_with_sampling_and_dropout_replayed(monkeypatch):
     for name, _, _ in model.vars.table:
         g = out['grads'][name] - ohp.l2_reg_scale * op[name]
         assert relerr(grads[name], g) < 2e-2, name
+
+
+@pytest.mark.parametrize('att,H', [('luong', 256), ('bahdanau', 128)])
+def test_sampling_inside_the_written_out_decoder_over_several_groups(att, H, monkeypatch):
+    """Scheduled sampling in the one-launch decoder with 19 utterances (three groups of eight, the last one partial), ragged
+    memory and targets, Luong at 256 units and Bahdanau at 128: the same sampled feed and logits as the per-step launches
+    (which draw from the same generator streams), gradients to bf16-flip noise."""
+    O, ohp, op, model = _build(dropout=0.25, sampling=0.3, att=att, H=H)
+    sp = model.speller
+    B = 19
+    src_len = [12 - (i * 5) % 9 for i in range(B)]
+    tgt_len = [6 - (i * 3) % 5 for i in range(B)]
+    batch = make_batch(B=B, src_len=src_len, tgt_len=tgt_len)
+    feats, labels = to_device(batch)
+    res = {}
+    for flag in ('1', '0'):
+        monkeypatch.setenv('LAS_DEC_PERSIST', flag)
+        model.vars.grad.zero_()
+        loss, logits, dlogits = model.forward_train(feats, labels)
+        fed = sp.saved['fed'].cpu().long().clone()
+        model.backward(dlogits)
+        torch.cuda.synchronize()
+        res[flag] = (fed, logits.clone(), {n: g.clone() for n, g in model.vars.grads.items()})
+    assert int(sp._persist_ws[:4].view(torch.int32).item()) == 0
+    assert torch.equal(res['1'][0], res['0'][0])
+    changed = res['1'][0][:, 1:6] != batch['targets_inputs'][:, 1:6]
+    assert int(changed.sum()) >= 5 and int(changed.any(1).sum()) >= 4          # several utterances, in several groups
+    assert bool(changed[16:].any()) or bool(changed[8:16].any())
+    assert relerr(res['1'][1], res['0'][1].cpu()) < 1e-3
+    for name in res['1'][2]:
+        assert relerr(res['1'][2][name], res['0'][2][name].cpu()) < 4e-3, name
