@@ -1,3 +1,4 @@
+# host enqueue time against total time of 50 back-to-back dX products (is the launch path the limit?)
 import os, sys, time, torch
 sys.path.insert(0, '.')
 from phones_las_amd import hip
