@@ -94,6 +94,16 @@ int las_gemm_nt_masked(const las_bf16* A, int64_t lda, const las_bf16* B, int64_
 int las_gemm_tn(const las_bf16* A, int64_t lda, const las_bf16* B, int64_t ldb, float* C, int64_t ldc,
                 int M, int N, int K, int a_shift, int period, int c_perm_h, int batch, int64_t sa,
                 int64_t sb, int64_t sc, int split_k, void* stream);
+/* C += A^T B with a result that does not depend on scheduling (two runs are bit-identical): the K slices store their
+ * 128 x 128 tiles in `workspace` (las_gemm_tn_ws_bytes(M, N, split_k) bytes, owned by the caller, one per stream that
+ * issues such products) and a second kernel adds them to C in slice order -- no fp32 atomics.  The speller's weight
+ * gradients (TF autodiff of the decoder's matmuls, model_helper.py:415) use this form so that training is reproducible.
+ * Shapes the slice kernel is not built for (M or N <= 64, N % 4 != 0) and calls without a sufficient workspace run
+ * unsplit (one contributor per output element).  Arguments as las_gemm_tn, batch 1. */
+size_t las_gemm_tn_ws_bytes(int M, int N, int split_k);
+int las_gemm_tn_ws(const las_bf16* A, int64_t lda, const las_bf16* B, int64_t ldb, float* C, int64_t ldc,
+                   int M, int N, int K, int a_shift, int period, int c_perm_h, int split_k, float* workspace,
+                   size_t workspace_bytes, void* stream);
 /* C = A^T B: the same product storing its result (no zeroing of C beforehand, no atomics, K not split): the batched
  * d(keys) = ds^T h and d(memory) = alignments^T d(context) of the speller's backward, whose K is only the U decoder steps
  * (TF autodiff of the attention mechanism's matmuls, model_helper.py:415).  C fp32, or bf16 with out_bf16 != 0 (d(keys)
@@ -173,6 +183,13 @@ int las_fill_many(const las_fill_job* jobs_host, int njobs, void* stream);
 /* out[n] += sum_m X[m, n] for a bf16 [M,N] matrix (bias gradients).  out_perm_h = H > 0: X's columns are
  * gate-interleaved (u*4+g) and the sum of column n lands at TF index g*H+u. */
 int las_colsum_bf16(const las_bf16* X, int64_t ldx, int M, int N, float* out, int out_perm_h, void* stream);
+/* The same sums with a result that does not depend on scheduling (no fp32 atomics: the row chunks' partial sums meet in
+ * `workspace` and the last block of a column group adds them in chunk order).  workspace: las_colsum_ws_bytes(M, N) bytes,
+ * 16-byte aligned, owned by the caller, its first 4096 bytes (the per-group counters) ZERO before the first use; launches
+ * leave them zero.  One workspace per stream that issues such sums. */
+size_t las_colsum_ws_bytes(int M, int N);
+int las_colsum_bf16_ws(const las_bf16* X, int64_t ldx, int M, int N, float* out, int out_perm_h, void* workspace,
+                       size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Listener: one (Bi)LSTM layer = las/ops.py:23-46 `bilstm` (tf.nn.bidirectional_dynamic_rnn /
@@ -513,13 +530,19 @@ int las_ctc_loss(const float* logits, int64_t ldl, const int32_t* labels, int64_
 /* out[0] += sum_i x[i]^2 (the L2 regulariser value of model_helper.py:411-413 is scale/2 times this). */
 int las_sumsq(const float* x, int64_t n, float* out, void* stream);
 /* grads[i] += l2_scale * params[i]; sumsq[s] = ||grads_s||^2  (sumsq zeroed inside).  param_sumsq (nullable):
- * *param_sumsq = sum_i params[i]^2 from the same pass (the value las_sumsq(params) would give). */
+ * *param_sumsq = sum_i params[i]^2 from the same pass (the value las_sumsq(params) would give).
+ * workspace (nullable; las_grad_l2_norms_ws_bytes(nseg, total) bytes, 16-byte aligned, its first 64 bytes ZERO before the
+ * first use, left zero by every launch): with it the workgroups' partial sums are added in a fixed order instead of with fp32
+ * atomics, so the norms -- and through the clip factors the whole update -- are bit-identical from run to run. */
+size_t las_grad_l2_norms_ws_bytes(int nseg, int64_t total);
 int las_grad_l2_norms(float* grads, const float* params, const int64_t* seg_offsets, int nseg,
-                      int64_t total, float l2_scale, float* sumsq, float* param_sumsq, void* stream);
+                      int64_t total, float l2_scale, float* sumsq, float* param_sumsq, void* workspace,
+                      size_t workspace_bytes, void* stream);
 /* The same pass ADDING into sumsq / param_sumsq (nothing is zeroed): after las_train_op_begin, which clears them once per
  * step, the passes over several gradient buckets (and their param_sumsq slots) need no memsets of their own. */
 int las_grad_l2_norms_acc(float* grads, const float* params, const int64_t* seg_offsets, int nseg,
-                          int64_t total, float l2_scale, float* sumsq, float* param_sumsq, void* stream);
+                          int64_t total, float l2_scale, float* sumsq, float* param_sumsq, void* workspace,
+                          size_t workspace_bytes, void* stream);
 /* First launch of the train op: las_status_collect (flag nullable: n = 0) and sumsq[0..nseg) = 0, param_sumsq[0..npsq) = 0. */
 int las_train_op_begin(const uint32_t* const* status_words, int n, float* flag, float* sumsq, int nseg,
                        float* param_sumsq, int npsq, void* stream);
@@ -550,6 +573,10 @@ int las_clip_adam_update(float* params, float* m, float* v, float* grads, const 
                          int step, const int32_t* step_dev, const float* skip_flag, void* stream);
 /* *counter += delta on the stream (tf.train.get_global_step increment, model_helper.py:417). */
 int las_counter_add(int32_t* counter, int32_t delta, void* stream);
+/* The same, but nothing happens when *skip_flag != 0 (the flag las_adam_update / las_clip_adam_update honour): the Adam
+ * step count t of a step whose update was withheld (a persistent kernel timed out on some replica) is not consumed, so
+ * the bias corrections of the next applied step are those of an uninterrupted run.  skip_flag may be NULL. */
+int las_counter_add_unless(int32_t* counter, int32_t delta, const float* skip_flag, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Acoustic front-end (fp32, table driven): preprocess_all.py:69-130 (librosa) and

@@ -1,9 +1,19 @@
 #!/usr/bin/env python3
-"""Greedy decoding + PER with the flag surface of the reference's infer.py (infer.py:21-63,192-359): reads
-hparams.json and the checkpoint from --model_dir, decodes --data (TFRecord), writes model_dir/infer.txt and
-infer_targets.txt and prints PER = 100 * sum(edit distance) / sum(len(reference)) (infer.py:270-303,338), with the
-optional 61->39 style --mapping.  Beam search, frame-level binary-feature accuracy and IPA conversion are not on
-the HIP path."""
+"""Decoding with the flag surface and the OUTPUT FILES of the reference's infer.py (infer.py:21-63,192-359): reads
+hparams.json and the checkpoint from --model_dir, decodes --data (TFRecord; no shuffle, the tail batch kept -- SURVEY B1)
+greedily or with --beam_width, and writes, as the reference does (infer.py:345-359):
+
+  model_dir/infer.txt          one line per utterance: to_text(ids) = the symbols up to the first </s>, joined with
+                               --delimiter (infer.py:65-67 cuts at the first EOS SYMBOL; the best beam under --beam_width)
+  model_dir/infer.dmp          joblib.dump([{'transcription': <that line>}, ...])
+  model_dir/infer_targets.txt  the targets, joined with --delimiter (infer.py:269-271)
+
+--plain_targets CSV (infer.py:246-271): rows `sound,lang,phrase` (tab-separated when the line holds a tab); the phrase is
+split on blanks, stripped and lower-cased, zipped with the predictions in file order, and PER / Optimistic PER are the
+text-level edit distances against it (infer.py:277-303,338-339; with --mapping on a binary-outputs model the target symbols
+go through the 61->39 style map, infer.py:300-303).  WITHOUT --plain_targets the reference prints no PER at all; here the
+labels stored in the TFRecord serve as targets (same files, same formulas) -- an addition, not a difference in the files.
+Frame-level binary-feature accuracy (TIMIT markup) and text -> IPA conversion are out of scope."""
 import argparse
 import os
 import sys
@@ -38,8 +48,10 @@ def parse_args(argv=None):
 
 
 def to_text(vocab_list, sample_ids, delimiter=' '):
-    """infer.py:65-67."""
-    return delimiter.join(vocab_list[i] for i in sample_ids)
+    """infer.py:65-67: the symbols of the ids up to (not including) the first </s> SYMBOL, joined with the delimiter."""
+    from phones_las_amd.utils import EOS
+    sym_list = [vocab_list[x] for x in sample_ids] + [EOS]
+    return delimiter.join(sym_list[:sym_list.index(EOS)])
 
 
 def main(args):
@@ -51,15 +63,18 @@ def main(args):
     from train import load_checkpoint, to_device
 
     vocab_list = utils.load_vocab(args.vocab)
+    vocab_list_orig = vocab_list
     args_h = argparse.Namespace(model_dir=args.model_dir, mapping=args.mapping)
     hparams = utils.create_hparams(args_h)              # requires an existing hparams.json (params_utils.py:96-97)
     hparams.decoder.set_hparam('beam_width', args.beam_width)
     dev = torch.device('cuda', 0)
     torch.cuda.set_device(0)
     binf2phone_np = None
+    text_mapping = None                      # the reference's local `mapping` (infer.py:202-207): binary-outputs models only
     if hparams.decoder.binary_outputs:       # infer.py:203-210 of the reference
         if args.mapping is not None:
             vocab_list, mapping_list = utils.get_mapping(args.mapping, args.vocab)
+            text_mapping = mapping_list
             hparams.del_hparam('mapping')
             hparams.add_hparam('mapping', mapping_list)
         binf2phone_np = utils.load_binf2phone(args.binf_map, vocab_list).values
@@ -69,36 +84,54 @@ def main(args):
     mapping = hparams.mapping
     batches = utils.input_fn(args.data, args.vocab, args.norm, num_channels=args.num_channels,
                              batch_size=args.batch_size, num_epochs=1, take=args.take, is_infer=True)
-    hyps, refs = [], []
-    optimistic_err = 0
+    # per utterance: the beams' id lists (greedy: one), uncut; and the TFRecord's own labels
+    beams_all, record_targets = [], []
     for features, labels in batches:
         f, _ = to_device(features, None, dev)
         pred = model.predict(f, transparent_projection=bool(args.use_phones_from_binf))   # transcribe_audio_file.py:90 couples the two
         # infer.py:223: the phones decoded from the binary-feature decoder, or the phone decoder's
         ids = pred['sample_ids_phones_binf' if args.use_phones_from_binf else 'sample_ids'].cpu().numpy()   # [B,T] / [B,T,K]
         for b in range(ids.shape[0]):
+            beams_all.append([beam.tolist() for beam in (ids[b].T if ids.ndim == 3 else ids[b][None])])
             t = labels['targets_outputs'][b][:labels['target_sequence_length'][b] - 1].tolist()
             if mapping is not None:
                 t = [mapping[x] for x in t]
                 t = [x for x in t if x >= 0]
-            beams = ids[b].T if ids.ndim == 3 else ids[b][None]
-            cut = []
-            for beam in beams:
-                i = beam.tolist() + [utils.EOS_ID]
-                cut.append(i[:i.index(utils.EOS_ID)])    # cut at the first EOS (infer.py:296-298)
-            optimistic_err += min(_levenshtein(i, t) for i in cut)
-            hyps.append(cut[0])                          # the best-scoring beam is the hypothesis
-            refs.append(t)
+            record_targets.append([vocab_list[x] for x in t])
     model.check_device_status()          # a timed-out persistent kernel would have produced invalid hypotheses
-    err = sum(_levenshtein(h, r) for h, r in zip(hyps, refs))
-    tot = sum(len(r) for r in refs)
-    with open(os.path.join(args.model_dir, 'infer.txt'), 'w') as f:
-        f.write('\n'.join(to_text(vocab_list, h, args.delimiter) for h in hyps))
+
+    def text_of(ids):                    # infer.py:65-67 (as a symbol list)
+        syms = [vocab_list[x] for x in ids] + [utils.EOS]
+        return syms[:syms.index(utils.EOS)]
+
+    if args.plain_targets:               # infer.py:246-268
+        targets = []
+        for line in open(args.plain_targets, 'r'):
+            if not line.strip():
+                continue
+            cells = line.split('\t' if '\t' in line else ',')
+            targets.append([x.strip().lower() for x in cells[2].split()])
+    else:
+        targets = record_targets
+    err = tot = optimistic_err = 0
+    for beams, t in zip(beams_all, targets):            # zip: the shorter of the two, as the reference's loop (infer.py:276)
+        texts = [text_of(i) for i in beams]
+        if args.plain_targets and text_mapping is not None:
+            # infer.py:300-303: symbols of the original vocabulary through the id map (infer_targets.txt keeps the raw phrase)
+            t = [vocab_list[text_mapping[vocab_list_orig.index(x)]] for x in t]
+        err += _levenshtein(texts[0], t)                # the best-scoring beam is the hypothesis (infer.py:286-288)
+        optimistic_err += min(_levenshtein(x, t) for x in texts)
+        tot += len(t)
     with open(os.path.join(args.model_dir, 'infer_targets.txt'), 'w') as f:
-        f.write('\n'.join(to_text(vocab_list, r, args.delimiter) for r in refs))
+        f.write('\n'.join(args.delimiter.join(t) for t in targets))
+    predictions = [{'transcription': args.delimiter.join(text_of(beams[0]))} for beams in beams_all]      # infer.py:345-353
+    with open(os.path.join(args.model_dir, 'infer.txt'), 'w') as f:
+        f.write('\n'.join(p['transcription'] for p in predictions))
+    from joblib import dump
+    dump(predictions, os.path.join(args.model_dir, 'infer.dmp'))                                           # infer.py:358-359
     per = 100.0 * err / max(tot, 1)
     print('PER: %2.2f%%' % per)
-    if args.beam_width > 0:                              # infer.py:345-346
+    if args.beam_width > 0 or args.plain_targets:        # infer.py:338-339 prints both whenever it prints
         print('Optimistic PER: %2.2f%%' % (100.0 * optimistic_err / max(tot, 1)))
     return per
 

@@ -130,6 +130,43 @@ __global__ void colsum_kernel(const unsigned short* X, int64_t ldx, int M, int N
   }
 }
 
+// The same sums with a result that does not depend on scheduling: every (column group, row chunk) block stores its 64 partial
+// sums in the workspace, and the block that finishes LAST for a column group (a counter per group, reset by that block for the
+// next launch) adds the chunks' partials in chunk order.  Workspace: [1024 counters][chunks][N rounded up to 64] floats.
+__global__ void colsum_ws_kernel(const unsigned short* X, int64_t ldx, int M, int N, float* out, int perm_h, unsigned* counters,
+                                 float* partial) {
+  const int col = blockIdx.x * 64 + threadIdx.x;
+  const int rows_per = (M + gridDim.y - 1) / gridDim.y;
+  const int r0 = blockIdx.y * rows_per;
+  const int r1 = min(M, r0 + rows_per);
+  const int N64 = gridDim.x * 64;
+  float s = 0.f;
+  if (col < N)
+    for (int r = r0 + threadIdx.y; r < r1; r += blockDim.y) s += las_bf2f(X[(int64_t)r * ldx + col]);
+  __shared__ float red[4][64];
+  __shared__ unsigned last;
+  red[threadIdx.y][threadIdx.x] = s;
+  __syncthreads();
+  if (threadIdx.y == 0) {
+    __hip_atomic_store(partial + (int64_t)blockIdx.y * N64 + col, (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]),
+                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  __threadfence();
+  __syncthreads();
+  if (threadIdx.x == 0 && threadIdx.y == 0)
+    last = (__hip_atomic_fetch_add(counters + blockIdx.x, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == gridDim.y - 1) ? 1u : 0u;
+  __syncthreads();
+  if (!last) return;
+  if (threadIdx.y == 0 && col < N) {
+    float t = 0.f;
+    for (unsigned y = 0; y < gridDim.y; ++y)
+      t += __hip_atomic_load(partial + (int64_t)y * N64 + col, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int oc = perm_h > 0 ? (col & 3) * perm_h + (col >> 2) : col;
+    out[oc] += t;
+  }
+  if (threadIdx.x == 0 && threadIdx.y == 0) counters[blockIdx.x] = 0u;
+}
+
 __global__ void pyramid_len_kernel(const int32_t* a, int32_t* b, int B) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < B) b[i] = a[i] / 2 + a[i] % 2;
@@ -197,12 +234,31 @@ extern "C" int las_fill_many(const las_fill_job* jobs_host, int njobs, void* str
   return LAS_OK;
 }
 
+static int colsum_chunks(int M) {
+  int chunks = (M + 511) / 512;
+  return chunks > 256 ? 256 : chunks;
+}
+
 extern "C" int las_colsum_bf16(const las_bf16* X, int64_t ldx, int M, int N, float* out, int out_perm_h, void* stream) {
   LAS_REQUIRE(M > 0 && N > 0, "las_colsum_bf16: empty");
-  int chunks = (M + 511) / 512;
-  if (chunks > 256) chunks = 256;
+  const int chunks = colsum_chunks(M);
   hipLaunchKernelGGL(colsum_kernel, dim3((N + 63) / 64, chunks), dim3(64, 4), 0, (hipStream_t)stream, X, ldx, M, N, out, out_perm_h);
   LAS_LAUNCH_CHECK("colsum launch");
+  return LAS_OK;
+}
+
+extern "C" size_t las_colsum_ws_bytes(int M, int N) {
+  return 4096 + sizeof(float) * (size_t)colsum_chunks(M) * (size_t)((N + 63) / 64 * 64);
+}
+
+extern "C" int las_colsum_bf16_ws(const las_bf16* X, int64_t ldx, int M, int N, float* out, int out_perm_h, void* workspace,
+                                  size_t workspace_bytes, void* stream) {
+  LAS_REQUIRE(M > 0 && N > 0 && N <= 64 * 1024, "las_colsum_bf16_ws: bad shape");
+  LAS_REQUIRE(workspace && workspace_bytes >= las_colsum_ws_bytes(M, N) && ((uintptr_t)workspace % 16 == 0),
+              "las_colsum_bf16_ws: workspace of las_colsum_ws_bytes(M, N) bytes needed (its first 4096 bytes zero before the first use)");
+  hipLaunchKernelGGL(colsum_ws_kernel, dim3((N + 63) / 64, colsum_chunks(M)), dim3(64, 4), 0, (hipStream_t)stream, X, ldx, M, N, out,
+                     out_perm_h, static_cast<unsigned*>(workspace), reinterpret_cast<float*>(static_cast<char*>(workspace) + 4096));
+  LAS_LAUNCH_CHECK("colsum (workspace) launch");
   return LAS_OK;
 }
 

@@ -43,6 +43,10 @@ __device__ void block_scan(float* arr, int n, float* tmp, bool exclusive, bool r
   const int lo = tid * ch, hi = min(n, lo + ch);
   const float ident = MUL ? 1.f : 0.f;
   float tot = ident;
+  // the callers fill arr[t] with thread t % 256; a chunk (or, right-to-left, any element) belongs to another thread as soon
+  // as n exceeds one wave: without this barrier the reverse scans of the monotonic backward read what the previous phase had
+  // left in the array (cfg5 at T' = 200: gradients of 1e36 after ten decoder steps, NaN after twenty)
+  __syncthreads();
   for (int i = lo; i < hi; ++i) {
     const float v = arr[reverse ? n - 1 - i : i];
     tot = MUL ? tot * v : tot + v;

@@ -1061,6 +1061,44 @@ extern "C" int las_gemm_tn(const las_bf16* A, int64_t lda, const las_bf16* B, in
   return gemm_tn(A, lda, B, ldb, C, ldc, M, N, K, a_shift, period, c_perm_h, batch, sa, sb, sc, split_k, false, false, stream);
 }
 
+extern "C" size_t las_gemm_tn_ws_bytes(int M, int N, int split_k) {
+  return (split_k > 1 && M > 64 && N > 64 && N % 4 == 0) ? sizeof(float) * (size_t)split_k * (size_t)M * (size_t)N : 0;
+}
+
+// C += A^T B with a result that does not depend on scheduling (bit-identical from run to run): the K slices store their
+// tiles in the caller's workspace and tn_reduce_kernel adds them to C in slice order -- no fp32 atomics.  Shapes the
+// slice kernel is not built for (M or N <= 64, N not a multiple of 4) or a workspace that is too small run unsplit: one
+// workgroup per output tile, one contributor per element.
+extern "C" int las_gemm_tn_ws(const las_bf16* A, int64_t lda, const las_bf16* B, int64_t ldb, float* C, int64_t ldc,
+                              int M, int N, int K, int a_shift, int period, int c_perm_h, int split_k, float* workspace,
+                              size_t workspace_bytes, void* stream) {
+  const size_t need = las_gemm_tn_ws_bytes(M, N, split_k);
+  if (need == 0 || workspace == nullptr || workspace_bytes < need)
+    return gemm_tn(A, lda, B, ldb, C, ldc, M, N, K, a_shift, period, c_perm_h, 1, 0, 0, 0, 1, false, false, stream);
+  LAS_REQUIRE(M > 0 && N > 0 && K > 0, "las_gemm_tn_ws: empty problem");
+  LAS_REQUIRE(lda % 8 == 0 && ldb % 8 == 0 && lda >= ((M + 7) / 8) * 8 && ldb >= ((N + 7) / 8) * 8,
+              "las_gemm_tn_ws: lda/ldb must be multiples of 8 covering M/N rounded up to 8");
+  LAS_REQUIRE(((uintptr_t)A % 16 == 0) && ((uintptr_t)B % 16 == 0), "las_gemm_tn_ws: operands must be 16-byte aligned");
+  LAS_REQUIRE(c_perm_h == 0 || N == 4 * c_perm_h, "las_gemm_tn_ws: c_perm_h needs N == 4*H");
+  GemmArgs g{A, B, C, nullptr, lda, ldb, ldc, 0, 0, 0, M, N, K, 0, 1, 1, split_k, a_shift, period, c_perm_h};
+  g.partial = workspace;
+  g.partial_stride = (int64_t)M * N;
+  dim3 grid((N + 127) / 128, (M + 127) / 128, split_k);
+  const size_t lds = (size_t)4 * TBK * 256;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_tr_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(gemm_tn_tr_kernel, grid, dim3(256), lds, (hipStream_t)stream, g);
+  LAS_LAUNCH_CHECK("gemm tn (workspace) launch");
+  const int64_t n = (int64_t)M * (N / 4);
+  hipLaunchKernelGGL(tn_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, workspace,
+                     g.partial_stride, split_k, C, ldc, (float*)nullptr, M, N, c_perm_h);
+  LAS_LAUNCH_CHECK("gemm tn (workspace) reduce launch");
+  return LAS_OK;
+}
+
 extern "C" int las_gemm_tn_store(const las_bf16* A, int64_t lda, const las_bf16* B, int64_t ldb, void* C, int64_t ldc,
                                  int M, int N, int K, int a_shift, int period, int c_perm_h, int batch, int64_t sa,
                                  int64_t sb, int64_t sc, int out_bf16, void* stream) {

@@ -52,9 +52,19 @@ __device__ __forceinline__ void for_each_piece(const int64_t* off, int nseg, int
   }
 }
 
+// ws != nullptr: no fp32 atomics -- every workgroup stores its per-tensor partial sums as a dense row [nseg + 1] (last column:
+// sum theta^2) of the workspace, and the workgroup that finishes LAST (a counter in the workspace head, reset by that workgroup
+// for the next launch) adds the rows in workgroup order, one wave per tensor with a fixed lane -> row mapping: the norms, hence
+// the clip factors, hence the whole update are bit-identical from run to run.
 __global__ __launch_bounds__(256) void l2_norm_kernel(float* g, const float* p, const int64_t* off, int nseg, int64_t total,
-                                                      float l2, float* sumsq, float* param_sumsq) {
+                                                      float l2, float* sumsq, float* param_sumsq, unsigned* ws) {
   __shared__ float red[4];
+  __shared__ unsigned last;
+  float* rows = ws ? reinterpret_cast<float*>(ws + 16) : nullptr;      // [gridDim.x][nseg + 1]
+  float* my = rows ? rows + (int64_t)blockIdx.x * (nseg + 1) : nullptr;
+  if (my)
+    for (int i = threadIdx.x; i <= nseg; i += 256) my[i] = 0.f;
+  __syncthreads();
   float acc = 0.f, pacc = 0.f;
   for_each_piece(off, nseg, total,
       [&](int64_t i, int n, int) {
@@ -74,13 +84,40 @@ __global__ __launch_bounds__(256) void l2_norm_kernel(float* g, const float* p, 
       },
       [&](int seg) {
         const float v = block_sum(acc, red);
-        if (threadIdx.x == 0) atomicAdd(sumsq + seg, v);
+        if (threadIdx.x == 0) {
+          if (my) my[seg] = v;
+          else atomicAdd(sumsq + seg, v);
+        }
         acc = 0.f;
       });
   if (param_sumsq) {
     const float v = block_sum(pacc, red);
-    if (threadIdx.x == 0) atomicAdd(param_sumsq, v);
+    if (threadIdx.x == 0) {
+      if (my) my[nseg] = v;
+      else atomicAdd(param_sumsq, v);
+    }
   }
+  if (!ws) return;
+  __threadfence();
+  __syncthreads();
+  if (threadIdx.x == 0)
+    last = (__hip_atomic_fetch_add(ws, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1) ? 1u : 0u;
+  __syncthreads();
+  if (!last) return;
+  __threadfence();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int seg = wave; seg <= nseg; seg += 4) {
+    if (seg == nseg && !param_sumsq) break;
+    float t = 0.f;
+    for (unsigned b = lane; b < gridDim.x; b += 64)
+      t += __hip_atomic_load(rows + (int64_t)b * (nseg + 1) + seg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    t = las_wave_sum(t);
+    if (lane == 0) {
+      if (seg < nseg) sumsq[seg] += t;
+      else *param_sumsq += t;
+    }
+  }
+  if (threadIdx.x == 0) *ws = 0u;
 }
 
 __global__ __launch_bounds__(256) void clip_kernel(float* g, const int64_t* off, int nseg, int64_t total, const float* sumsq,
@@ -174,7 +211,9 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float* x, int64_t n, f
   if (threadIdx.x == 0) atomicAdd(out, red[0] + red[1] + red[2] + red[3]);
 }
 
-__global__ void counter_add_kernel(int32_t* c, int32_t d) { if (threadIdx.x == 0 && blockIdx.x == 0) *c += d; }
+__global__ void counter_add_kernel(int32_t* c, int32_t d, const float* skip) {
+  if (threadIdx.x == 0 && blockIdx.x == 0 && !(skip && *skip != 0.f)) *c += d;
+}
 
 // flag = 1.0 when any of the n status words (first word of a persistent kernel's workspace) is non-zero, else 0.0
 __global__ void status_collect_kernel(const unsigned* const* words, int n, float* flag) {
@@ -231,7 +270,14 @@ extern "C" int las_status_collect(const uint32_t* const* status_words, int n, fl
 }
 
 extern "C" int las_counter_add(int32_t* counter, int32_t delta, void* stream) {
-  hipLaunchKernelGGL(counter_add_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, counter, delta);
+  hipLaunchKernelGGL(counter_add_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, counter, delta, (const float*)nullptr);
+  LAS_LAUNCH_CHECK("counter launch");
+  return LAS_OK;
+}
+
+extern "C" int las_counter_add_unless(int32_t* counter, int32_t delta, const float* skip_flag, void* stream) {
+  LAS_REQUIRE(counter != nullptr, "las_counter_add_unless: null counter");
+  hipLaunchKernelGGL(counter_add_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, counter, delta, skip_flag);
   LAS_LAUNCH_CHECK("counter launch");
   return LAS_OK;
 }
@@ -245,8 +291,11 @@ extern "C" int las_sumsq(const float* x, int64_t n, float* out, void* stream) {
   return LAS_OK;
 }
 
+extern "C" size_t las_grad_l2_norms_ws_bytes(int nseg, int64_t total);
+
 static int grad_l2_norms(float* grads, const float* params, const int64_t* seg_offsets, int nseg, int64_t total,
-                         float l2_scale, float* sumsq, float* param_sumsq, bool zero_first, void* stream) {
+                         float l2_scale, float* sumsq, float* param_sumsq, bool zero_first, void* workspace, size_t workspace_bytes,
+                         void* stream) {
   LAS_REQUIRE(nseg > 0 && total > 0, "las_grad_l2_norms: empty");
   LAS_REQUIRE(((uintptr_t)grads % 16 == 0) && ((uintptr_t)params % 16 == 0), "las_grad_l2_norms: buffers must be 16-byte aligned");
   hipStream_t st = (hipStream_t)stream;
@@ -258,20 +307,28 @@ static int grad_l2_norms(float* grads, const float* params, const int64_t* seg_o
       if (rc) return rc;
     }
   }
+  LAS_REQUIRE(workspace == nullptr || (workspace_bytes >= las_grad_l2_norms_ws_bytes(nseg, total) && (uintptr_t)workspace % 16 == 0),
+              "las_grad_l2_norms: workspace of las_grad_l2_norms_ws_bytes(nseg, total) bytes needed");
   hipLaunchKernelGGL(l2_norm_kernel, dim3((unsigned)((total + SPAN - 1) / SPAN)), dim3(256), 0, st, grads, params, seg_offsets, nseg,
-                     total, l2_scale, sumsq, param_sumsq);
+                     total, l2_scale, sumsq, param_sumsq, static_cast<unsigned*>(workspace));
   LAS_LAUNCH_CHECK("l2 norm launch");
   return LAS_OK;
 }
 
+extern "C" size_t las_grad_l2_norms_ws_bytes(int nseg, int64_t total) {
+  return 64 + sizeof(float) * (size_t)((total + SPAN - 1) / SPAN) * (size_t)(nseg + 1);
+}
+
 extern "C" int las_grad_l2_norms(float* grads, const float* params, const int64_t* seg_offsets, int nseg, int64_t total,
-                                 float l2_scale, float* sumsq, float* param_sumsq, void* stream) {
-  return grad_l2_norms(grads, params, seg_offsets, nseg, total, l2_scale, sumsq, param_sumsq, true, stream);
+                                 float l2_scale, float* sumsq, float* param_sumsq, void* workspace, size_t workspace_bytes,
+                                 void* stream) {
+  return grad_l2_norms(grads, params, seg_offsets, nseg, total, l2_scale, sumsq, param_sumsq, true, workspace, workspace_bytes, stream);
 }
 
 extern "C" int las_grad_l2_norms_acc(float* grads, const float* params, const int64_t* seg_offsets, int nseg, int64_t total,
-                                     float l2_scale, float* sumsq, float* param_sumsq, void* stream) {
-  return grad_l2_norms(grads, params, seg_offsets, nseg, total, l2_scale, sumsq, param_sumsq, false, stream);
+                                     float l2_scale, float* sumsq, float* param_sumsq, void* workspace, size_t workspace_bytes,
+                                     void* stream) {
+  return grad_l2_norms(grads, params, seg_offsets, nseg, total, l2_scale, sumsq, param_sumsq, false, workspace, workspace_bytes, stream);
 }
 
 extern "C" int las_grad_clip(float* grads, const int64_t* seg_offsets, int nseg, int64_t total, const float* sumsq,

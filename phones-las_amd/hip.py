@@ -23,6 +23,8 @@ _SIGS = {
     'las_gemm_nt': ([_vp, _i64, _vp, _i64, _vp, _i64, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i64, _i64, _i64, _i32, _vp], C.c_int),
     'las_gemm_tn': ([_vp, _i64, _vp, _i64, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i64, _i64, _i64, _i32, _vp], C.c_int),
     'las_gemm_nt_masked': ([_vp, _i64, _vp, _i64, _vp, _i64, _i32, _i32, _i32, _i32, _f32, C.c_uint32, C.c_uint32, _vp], C.c_int),
+    'las_gemm_tn_ws_bytes': ([_i32, _i32, _i32], C.c_size_t),
+    'las_gemm_tn_ws': ([_vp, _i64, _vp, _i64, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, C.c_size_t, _vp], C.c_int),
     'las_gemm_tn_store': ([_vp, _i64, _vp, _i64, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i64, _i64, _i64, _i32, _vp], C.c_int),
     'las_cast_bf16': ([_vp, _i64, _i32, _i32, _vp, _i64, _i32, _i32, _i32, _i32, _i64, _i64, _i32, _vp], C.c_int),
     'las_refresh_images': ([_vp, C.c_int, _vp], C.c_int),
@@ -30,6 +32,8 @@ _SIGS = {
     'las_stream_delay': ([C.c_int, _vp], C.c_int),
     'las_add_cast_bf16': ([_vp, _i64, _vp, _i64, _vp, _i64, _i32, _i32, _vp], C.c_int),
     'las_colsum_bf16': ([_vp, _i64, _i32, _i32, _vp, _i32, _vp], C.c_int),
+    'las_colsum_ws_bytes': ([_i32, _i32], C.c_size_t),
+    'las_colsum_bf16_ws': ([_vp, _i64, _i32, _i32, _vp, _i32, _vp, C.c_size_t, _vp], C.c_int),
     'las_lstm_pack_recurrent': ([_vp, _i32, _vp, _vp], C.c_int),
     'las_lstm_recurrent_fwd': ([_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp], C.c_int),
     'las_lstm_recurrent_bwd': ([_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp], C.c_int),
@@ -41,15 +45,17 @@ _SIGS = {
     'las_seq_ce_loss': ([_vp, _i64, _vp, _vp, _i32, _i32, _i32, _f32, _vp, _vp, _i64, _vp], C.c_int),
     'las_seq_sigmoid_loss': ([_vp, _i64, _vp, _i64, _vp, _i32, _i32, _i32, _f32, _vp, _vp, _i64, _vp], C.c_int),
     'las_sample_features': ([_vp, _i64, _i32, _vp, _i64, _vp, _i64, _i32, _f32, C.c_uint32, C.c_uint32, _vp], C.c_int),
-    'las_grad_l2_norms': ([_vp, _vp, _vp, _i32, _i64, _f32, _vp, _vp, _vp], C.c_int),
+    'las_grad_l2_norms_ws_bytes': ([_i32, _i64], C.c_size_t),
+    'las_grad_l2_norms': ([_vp, _vp, _vp, _i32, _i64, _f32, _vp, _vp, _vp, C.c_size_t, _vp], C.c_int),
     'las_clip_adam_update': ([_vp, _vp, _vp, _vp, _vp, _i32, _i64, _vp, _f32, _f32, _f32, _f32, _f32, _i32, _vp, _vp, _vp], C.c_int),
     'las_grad_clip': ([_vp, _vp, _i32, _i64, _vp, _f32, _vp], C.c_int),
     'las_adam_update': ([_vp, _vp, _vp, _vp, _i64, _f32, _f32, _f32, _f32, _i32, _vp, _vp, _vp], C.c_int),
     'las_status_collect': ([_vp, _i32, _vp, _vp], C.c_int),
-    'las_grad_l2_norms_acc': ([_vp, _vp, _vp, _i32, _i64, _f32, _vp, _vp, _vp], C.c_int),
+    'las_grad_l2_norms_acc': ([_vp, _vp, _vp, _i32, _i64, _f32, _vp, _vp, _vp, C.c_size_t, _vp], C.c_int),
     'las_train_op_begin': ([_vp, _i32, _vp, _vp, _i32, _vp, _i32, _vp], C.c_int),
     'las_total_loss': ([_vp, _vp, _i32, _f32, _vp, _vp], C.c_int),
     'las_counter_add': ([_vp, _i32, _vp], C.c_int),
+    'las_counter_add_unless': ([_vp, _i32, _vp, _vp], C.c_int),
     'las_sumsq': ([_vp, _i64, _vp, _vp], C.c_int),
     'las_crc32c': ([C.c_char_p, C.c_size_t], C.c_uint32),
     'las_tfrecord_index': ([_vp, C.c_size_t, _i32, _i64, _vp, _vp, _vp, _vp, _vp], C.c_int64),
@@ -261,9 +267,50 @@ def gemm_nt(A, B, C_, M, N, K, lda=None, ldb=None, ldc=None, bias=None, out_bf16
     prof_end(tok)
 
 
+_TN_ATOMIC = os.environ.get('LAS_TN_ATOMIC', '0') == '1'      # diagnostics / A-B timing: split K with fp32 atomics (round 1-2)
+_TN_WS = {}
+
+
+_ws_lane = 0
+
+
+class ws_lane:
+    """with ws_lane(k): products issued inside take workspace k.  las.ops.Overlap.fork() enters lane 1 / 2 together with its
+    side streams, so that products running at the same time on different streams never share a workspace (a key taken from
+    the stream itself would change under graph capture, which runs on a stream of its own)."""
+
+    def __init__(self, lane):
+        self.lane = lane
+
+    def __enter__(self):
+        global _ws_lane
+        self.prev, _ws_lane = _ws_lane, self.lane
+
+    def __exit__(self, *exc):
+        global _ws_lane
+        _ws_lane = self.prev
+        return False
+
+
+def _tn_workspace(nbytes):
+    """The K-slice workspace of las_gemm_tn_ws for the current lane (ws_lane: 0 = the main stream, 1 / 2 = the side streams
+    of the backward pass; products of one lane run in stream order and share it).  Grows on demand; growing inside a graph
+    capture is refused (run the step once eagerly first, as every captured flow here does)."""
+    if nbytes == 0:
+        return None
+    key = (torch.cuda.current_device(), _ws_lane)
+    ws = _TN_WS.get(key)
+    if ws is None or ws.numel() < nbytes:
+        if torch.cuda.is_current_stream_capturing():
+            raise LasError('gemm_tn: new weight-gradient workspace during graph capture (run the step once eagerly first)')
+        ws = _TN_WS[key] = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device='cuda')
+    return ws
+
+
 def gemm_tn(A, B, C_, M, N, K, lda=None, ldb=None, ldc=None, a_shift=0, period=0, batch=1, sa=0, sb=0, sc=0,
             split_k=1, c_perm_h=0, store=False):
-    """C += A^T B (atomics: zero C first), or with store=True C = A^T B (no zeroing, K not split; C fp32 or bf16)."""
+    """C += A^T B (K slices through a workspace, summed in a fixed order; batched products: fp32 atomics, zero C first), or
+    with store=True C = A^T B (no zeroing, K not split; C fp32 or bf16)."""
     lda = lda if lda is not None else A.stride(-2)
     ldb = ldb if ldb is not None else B.stride(-2)
     ldc = ldc if ldc is not None else C_.stride(-2)
@@ -271,6 +318,11 @@ def gemm_tn(A, B, C_, M, N, K, lda=None, ldb=None, ldc=None, a_shift=0, period=0
     if store:
         check(lib().las_gemm_tn_store(p(A), lda, p(B), ldb, p(C_), ldc, M, N, K, a_shift, period, c_perm_h, batch, sa, sb,
                                       sc, int(C_.dtype == torch.bfloat16), stream()))
+    elif batch == 1 and not _TN_ATOMIC:
+        # split K through a workspace + fixed-order reduce: no fp32 atomics, bit-identical from run to run
+        ws = _tn_workspace(lib().las_gemm_tn_ws_bytes(M, N, split_k))
+        check(lib().las_gemm_tn_ws(p(A), lda, p(B), ldb, p(C_), ldc, M, N, K, a_shift, period, c_perm_h, split_k,
+                                   p(ws), ws.numel() if ws is not None else 0, stream()))
     else:
         check(lib().las_gemm_tn(p(A), lda, p(B), ldb, p(C_), ldc, M, N, K, a_shift, period, c_perm_h, batch, sa, sb, sc,
                                 split_k, stream()))
@@ -422,6 +474,21 @@ def copy_f32(src, n, dst):
     _image_job(IMAGE_COPY_F32, src, dst, cols=n)
 
 
+_CS_WS = {}
+
+
 def colsum_bf16(X, M, N, out, ldx=None, perm_h=0):
+    """out[n] += sum_m X[m, n] (bias gradients), bit-identical from run to run: the row chunks meet in a per-lane workspace
+    (ws_lane) instead of fp32 atomics."""
     ldx = ldx if ldx is not None else X.stride(-2)
-    check(lib().las_colsum_bf16(p(X), ldx, M, N, p(out), perm_h, stream()))
+    if _TN_ATOMIC:
+        check(lib().las_colsum_bf16(p(X), ldx, M, N, p(out), perm_h, stream()))
+        return
+    need = lib().las_colsum_ws_bytes(M, N)
+    key = (torch.cuda.current_device(), _ws_lane)
+    ws = _CS_WS.get(key)
+    if ws is None or ws.numel() < need:
+        if torch.cuda.is_current_stream_capturing():
+            raise LasError('colsum_bf16: new workspace during graph capture (run the step once eagerly first)')
+        ws = _CS_WS[key] = torch.zeros(max(need, 1 << 18), dtype=torch.uint8, device='cuda')
+    check(lib().las_colsum_bf16_ws(p(X), ldx, M, N, p(out), perm_h, p(ws), ws.numel(), stream()))

@@ -98,7 +98,11 @@ class Overlap:
         self.keep.extend(tensors)
         if beside_chain and self.BESIDE_US > 0:
             hip.check(hip.lib().las_stream_delay(self.BESIDE_US, side.cuda_stream))
-        return torch.cuda.stream(side)
+        import contextlib
+        ctx = contextlib.ExitStack()
+        ctx.enter_context(torch.cuda.stream(side))
+        ctx.enter_context(hip.ws_lane(2 if lane else 1))       # the side streams' own product workspaces
+        return ctx
 
     def mark(self):
         """An event after everything forked so far (the main stream can wait for exactly that much of the side stream)."""

@@ -155,6 +155,7 @@ class GeneralSpeller:
             self.wq_t = torch.empty(Hd, Hd, dtype=bf, device=dev)
         self.refresh(variables)
         self.saved = None
+        self.debug_hook = None
 
     DEC_STREAM = 1                       # token-scale draws of cell 0 (decoder index scheme of las_dec_step)
 
@@ -555,6 +556,11 @@ class GeneralSpeller:
                     cell_and_gemm(l, [v(dx[l + 1][cur], 0, W[l + 1])])
             if dtokx is not None:         # gradient w.r.t. the embedded token of this step (after its dropout mask)
                 hip.cast_bf16(dx[0][cur], B, self.Ep, dtokx[:, t], B, self.Ep, ldd=U * self.Ep, lds=W[0])
+            if self.debug_hook is not None:      # diagnostics (scripts/gpu_cfg5_nan.py): look at the step's tensors
+                self.debug_hook(t, dict(d_out=d_out[:, t], datt_bf=datt_bf[:, t] if datt_bf is not None else datt, dqc=dqc, dq=dq,
+                                        ds=ds_all[:, t], dctx=dctx_all[:, t], dz=dz[0][:, t], dx=dx[0][cur], dc=dc[0],
+                                        carry=carry if self.mono else None, dkeys=dkeys if bah else None,
+                                        dpq=dpq_all[:, t] if self.uses_wq else None))
         # ---- after the loop: attention tensors (critical path into the listener) ----
         if not bah:
             # dot-product scores: d(keys)[b] = dScore[b]^T Q[b], Q = the queries (relu(Wq h) for CustomAttention)

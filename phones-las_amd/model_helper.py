@@ -614,11 +614,13 @@ class LasModel:
         lib = hip.lib()
         # (after collect_status(zero_norms=True) the accumulators are already clear: the pass that only adds)
         fn = lib.las_grad_l2_norms_acc if self.__dict__.pop('_norms_zeroed', False) else lib.las_grad_l2_norms
+        if getattr(v, 'norm_ws', None) is None:     # fixed-order sums of the workgroups' partial norms (no fp32 atomics)
+            v.norm_ws = torch.zeros(lib.las_grad_l2_norms_ws_bytes(len(v.table), v.total), dtype=torch.uint8, device=v.flat.device)
         for b in (v.buckets if bucket is None else [bucket]):
             hip.check(fn(hip.addr(v.grad, b['begin']), hip.addr(v.flat, b['begin']), hip.p(b['seg']),
                          b['hi'] - b['lo'], b['end'] - b['begin'],
                          float(p.l2_reg_scale) / self.world_size, hip.addr(v.sumsq, b['lo']),
-                         hip.addr(v.param_sumsq, b['slot']), hip.stream()))
+                         hip.addr(v.param_sumsq, b['slot']), hip.p(v.norm_ws), v.norm_ws.numel(), hip.stream()))
 
     def clip_gradients(self, bucket=None, norms=True):
         """L2 gradient + per-tensor clip_by_norm(GRAD_NORM) on the flat buffers (model_helper.py:411-416)."""
@@ -647,7 +649,7 @@ class LasModel:
         lib, st = hip.lib(), hip.stream()
         hip.check(lib.las_adam_update(hip.p(v.flat), hip.p(v.m), hip.p(v.v), hip.p(v.grad), v.total,
                                       float(p.learning_rate), 0.9, 0.999, 1e-8, 0, hip.p(self.step_dev), hip.p(v.skip_flag), st))
-        hip.check(lib.las_counter_add(hip.p(self.step_dev), 1, st))
+        hip.check(lib.las_counter_add_unless(hip.p(self.step_dev), 1, hip.p(v.skip_flag), st))   # a withheld update does not consume a step
         self._images_stale = True
 
     def clip_adam_update(self):
@@ -657,7 +659,7 @@ class LasModel:
         hip.check(lib.las_clip_adam_update(hip.p(v.flat), hip.p(v.m), hip.p(v.v), hip.p(v.grad), hip.p(v.seg), len(v.table),
                                            v.total, hip.p(v.sumsq), float(GRAD_NORM), float(p.learning_rate), 0.9, 0.999, 1e-8,
                                            0, hip.p(self.step_dev), hip.p(v.skip_flag), st))
-        hip.check(lib.las_counter_add(hip.p(self.step_dev), 1, st))
+        hip.check(lib.las_counter_add_unless(hip.p(self.step_dev), 1, hip.p(v.skip_flag), st))   # a withheld update does not consume a step
         self._images_stale = True
 
     def apply_gradients(self):
@@ -911,6 +913,20 @@ class LasModel:
             for ws in self._status_tensors():        # read: the sticky words start over
                 ws[:4].zero_()
             raise
+
+    def read_and_clear_status(self):
+        """Non-raising form of check_device_status(): synchronises, returns the non-zero status words of the persistent
+        kernels' workspaces (empty list: no timeout since the last read) and clears them.  bench.py calls it after every
+        candidate of its untimed probe, so that a form that timed out there is dropped instead of poisoning the timed run
+        through the sticky words."""
+        torch.cuda.synchronize()
+        bad = []
+        for ws in self._status_tensors():
+            st = int(ws[:4].view(torch.int32).item())
+            if st:
+                bad.append(st)
+                ws[:4].zero_()
+        return bad
 
     def _beam_speller(self):
         """Beam search runs on the general cell stack (it gathers the decoder state between steps); the fused

@@ -13,6 +13,9 @@ Cases (BASELINE.json configs / SURVEY.md 8(d)):
                   bahdanau_monotonic (sigmoid_noise 1 in TRAIN: the score noise comes from the device's counter-based
                   generator, restated in numpy below), 3 x pBiLSTM-256, F=39, T=64, U=12, B=4
   cfg1_timit      cfg1: 2 x pBiLSTM-128 + Luong, F=39, V=64, B=4, T=300 (TIMIT's ~3 s), U=40, ragged
+  cfg5_full       cfg5 at T=800 / U=80 (T'=200), B=4, ragged
+  metricL_full    cfg3/cfg4 at T=800 / U=80, B=16 ragged, CTC head
+  dec512_groups   (and _luong) 512-unit decoders on M=2048, T'=100, U=80, B=16 ragged: two decoder groups
 """
 import json
 import math
@@ -31,6 +34,19 @@ CASES = {
     'cfg5_binf': dict(F=39, L=3, H=256, Hd=256, V=197, att='bahdanau_monotonic', T=64, U=12, B=4, ragged='mixed',
                       binf='binf_map.csv', binf_reg=1.0),
     'cfg1_timit': dict(F=39, L=2, H=128, Hd=128, V=64, att='luong', T=300, U=40, B=4, ragged='mixed'),
+    # round 3: cfg5 AT ITS STATED SIZE (T=800 -> T'=200 frames, U=80: the monotonic 'parallel' chain runs past the point
+    # where the exclusive cumprod drops below its 1e-10 clip, which the T=64 case never reaches)
+    'cfg5_full': dict(F=39, L=3, H=256, Hd=256, V=197, att='bahdanau_monotonic', T=800, U=80, B=4, ragged='mixed',
+                      binf='binf_map.csv', binf_reg=1.0, memory=False),
+    # round 3: the 512-unit one-launch decoders of metric-L / cfg3 / cfg4 over SEVERAL groups at the benchmarked decoder
+    # shape (M=2048, T'=100, U=80; B=16 = two groups of 8); the listener is kept short (2 layers, T=200) so that the oracle
+    # finishes in minutes
+    'dec512_groups': dict(F=40, L=2, H=512, Hd=512, V=64, att='bahdanau', T=200, U=80, B=16, ragged='mixed', memory=False),
+    # round 3: cfg3 / cfg4 at their stated size: 4 x pBiLSTM-512 over T=800 (T'=100), Bahdanau, 1x512 decoder, CTC head,
+    # B=16 ragged (lstm_fwd/bwd_kernel<512> over 800-step chains, two decoder groups)
+    'metricL_full': dict(F=80, L=4, H=512, Hd=512, V=64, att='bahdanau', T=800, U=80, B=16, ragged='mixed', ctc=0.3,
+                         memory=False),
+    'dec512_groups_luong': dict(F=40, L=2, H=512, Hd=512, V=64, att='luong', T=200, U=80, B=16, ragged='mixed', memory=False),
 }
 SEED_PARAMS, SEED_BATCH = 4321, 1234
 

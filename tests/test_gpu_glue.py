@@ -68,11 +68,14 @@ def test_train_op_begin_norms_acc_and_total_loss():
     # the accumulating norms pass twice = twice the sums of the zeroing one (same gradients, L2 already added once)
     ga, gb = g0.clone(), g0.clone()
     s1, q1 = torch.empty(nseg, device=dev), torch.empty(1, device=dev)
-    hip.check(lib.las_grad_l2_norms(hip.p(ga), hip.p(p0), hip.p(seg), nseg, total, l2, hip.p(s1), hip.p(q1), hip.stream()))
-    hip.check(lib.las_grad_l2_norms_acc(hip.p(gb), hip.p(p0), hip.p(seg), nseg, total, l2, hip.p(sumsq), hip.p(psq), hip.stream()))
+    nws = torch.zeros(lib.las_grad_l2_norms_ws_bytes(nseg, total), dtype=torch.uint8, device=dev)     # fixed-order form for one of them
+    hip.check(lib.las_grad_l2_norms(hip.p(ga), hip.p(p0), hip.p(seg), nseg, total, l2, hip.p(s1), hip.p(q1), None, 0, hip.stream()))
+    hip.check(lib.las_grad_l2_norms_acc(hip.p(gb), hip.p(p0), hip.p(seg), nseg, total, l2, hip.p(sumsq), hip.p(psq),
+                                        hip.p(nws), nws.numel(), hip.stream()))
     torch.cuda.synchronize()
     assert torch.allclose(sumsq, s1, rtol=1e-6) and abs(float(psq[0]) - float(q1)) <= 1e-6 * float(q1) and float(psq[1]) == 0.0
     assert torch.equal(ga, gb)
+    assert int(nws[:4].view(torch.int32).item()) == 0          # the arrival counter is back at zero for the next launch
     ref = [float(((g0 + l2 * p0)[offs[i]:offs[i + 1]].double() ** 2).sum()) for i in range(nseg)]
     assert np.allclose(s1.cpu().double().numpy(), ref, rtol=1e-4)
     # total loss = audio + half_l2 * (psq[0] + psq[1])

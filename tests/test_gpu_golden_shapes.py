@@ -75,22 +75,25 @@ def _run_case(case):
         rep['audio_loss_vs_' + mxu] = abs(float(loss) - float(g[mxu + '_audio_loss'])) / abs(float(g[mxu + '_audio_loss']))
     names = [str(n) for n in g['names']]
     assert names == [n for n, _, _ in model.vars.table]
-    worst_g, worst_n = ('', 0.0), ('', 0.0)
+    # gradients against BOTH models: 'bf16' (the oracle with the device's storage points, forward and backward) and 'f64' (the
+    # exact model: nothing in it was fitted to the device -- ADVICE r2)
     per_tensor = {}
-    for i, n in enumerate(names):
-        got = model.vars.grads[n].reshape(-1).cpu().numpy()
-        ref = g['bf16_grad_%02d' % i]
-        e = _rel(got[G.grad_sample(n, got.size)], ref)
-        rn = float(g['bf16_gradnorm'][i])
-        en = abs(float(np.linalg.norm(got.astype(np.float64))) - rn) / (rn if rn > 0 else 1.0)
-        per_tensor[n] = [e, en]
-        if e > worst_g[1]:
-            worst_g = (n, e)
-        if en > worst_n[1]:
-            worst_n = (n, en)
-    rep['grad_worst'] = list(worst_g)
-    rep['gradnorm_worst'] = list(worst_n)
-    rep['grad_per_tensor'] = per_tensor
+    for mxu, tag in (('bf16', ''), ('f64', '_f64')):
+        worst_g, worst_n = ('', 0.0), ('', 0.0)
+        for i, n in enumerate(names):
+            got = model.vars.grads[n].reshape(-1).cpu().numpy()
+            ref = g['%s_grad_%02d' % (mxu, i)]
+            e = _rel(got[G.grad_sample(n, got.size)], ref)
+            rn = float(g[mxu + '_gradnorm'][i])
+            en = abs(float(np.linalg.norm(got.astype(np.float64))) - rn) / (rn if rn > 0 else 1.0)
+            per_tensor.setdefault(n, []).extend([e, en])
+            if e > worst_g[1]:
+                worst_g = (n, e)
+            if en > worst_n[1]:
+                worst_n = (n, en)
+        rep['grad_worst' + tag] = list(worst_g)
+        rep['gradnorm_worst' + tag] = list(worst_n)
+    rep['grad_per_tensor'] = per_tensor          # name -> [element err, norm err] vs bf16 model, then vs f64 model
     return g, model, rep, (loss, logits)
 
 
@@ -109,7 +112,7 @@ def _check(rep):
     assert rep['gradnorm_worst'][1] < TOL['gradnorm'], rep['gradnorm_worst']
 
 
-@pytest.mark.parametrize('case', ['metricM_dense', 'metricM_ragged', 'metricM_bench', 'cfg1_timit', 'metricL_ctc'])
+@pytest.mark.parametrize('case', ['metricM_dense', 'metricM_ragged', 'metricM_bench', 'cfg1_timit', 'metricL_ctc', 'metricL_full'])
 def test_train_step_matches_the_oracle_fixture(case):
     """Forward + backward of one train step at the case's shape: logits, loss and every gradient tensor against the
     fixture.  metricM_*: the persistent decoder and the 4-row recurrent kernels must be the ones that ran."""
@@ -214,3 +217,38 @@ def test_persistent_decoder_matches_per_step_launches_at_the_benchmarked_shape(m
         lg = outs[flag][1][..., :V].float().cpu().numpy()
         err = max(float(np.abs(lg[b, :tl[b]].astype(np.float64) - ref[b, :tl[b]]).max()) for b in range(len(tl)))
         assert err / float(np.abs(ref).max()) < TOL['logits']
+
+
+def test_cfg5_at_its_stated_size_matches_the_fixture():
+    """BASELINE configs[4] at T=800 / U=80 (T'=200 frames): the monotonic 'parallel' chain p * cp * cumsum(prev / clip(cp,
+    1e-10, 1)) runs far past the frame where the exclusive cumprod drops under its clip, the attention mass of late decoder
+    steps shrinks to 1e-8 (as the reference's formula makes it: SURVEY A.6), and the normaliser's backward scans cross
+    waves.  Round 2's only run at this size ended in NaN (a missing barrier in front of the right-to-left scans, invisible
+    at T' <= 64); the T=64 fixture could not see it.  Gradients must be finite and match the oracle."""
+    g, model, rep, _ = _run_case('cfg5_full')
+    _write(rep)
+    for n, t in model.vars.grads.items():
+        assert bool(torch.isfinite(t).all()), n
+    assert rep['logits_vs_bf16'] < TOL['logits'] and rep['logits_vs_f64'] < TOL['logits'], rep
+    assert rep['audio_loss_vs_bf16'] < 2e-3 and rep['audio_loss_vs_f64'] < 2e-3, rep
+    # Gradients are asserted against the EXACT (f64) model here: 3e-2 of the per-tensor max-abs, norms within 3 % (measured
+    # 1.4e-2 / 9.6e-3).  The oracle's bf16 model is reported, not asserted: d/dc of prev / clip(c, 1e-10, 1) is -prev / c^2 (up
+    # to 1e20 prev) just inside the clip and 0 outside, so the gradient of the reference's formula is DISCONTINUOUS where the
+    # exclusive cumprod crosses 1e-10 under attention mass; in this fixture utterance 0 crosses at decoder step 31 and the
+    # bf16 model's forward roundings put it on the other side of that edge than the exact model and the device (its score-path
+    # gradients -- memory_layer, query_layer, attention_v, score_bias -- are 18-20 % larger from that single (utterance, step)
+    # entry; every other step agrees to 1 %: measured with the oracle alone, DESIGN.md 2).
+    assert rep['grad_worst_f64'][1] < 3e-2, rep['grad_worst_f64']
+    assert rep['gradnorm_worst_f64'][1] < 3e-2, rep['gradnorm_worst_f64']
+    assert rep['grad_worst'][1] < 0.4, rep['grad_worst']
+
+
+@pytest.mark.parametrize('case', ['dec512_groups', 'dec512_groups_luong'])
+def test_512_unit_one_launch_decoders_over_several_groups(case):
+    """The written-out 512-unit decoders metric-L / cfg3 / cfg4 time (dec_persist_fwd_lean_kernel<att, 4, 8, 20>,
+    dec_persist_bwd_kernel<wq, 16, ...>: streamed K chunks, column-split h Wq with the granule all-to-all) at the benchmarked
+    decoder shape M=2048, T'=100, U=80 on TWO groups of 8 utterances with ragged lengths, against the oracle fixture."""
+    g, model, rep, _ = _run_case(case)
+    assert getattr(model.speller, '_persist_ws', None) is not None and getattr(model.speller, '_persist_ws_bwd', None) is not None
+    _write(rep)
+    _check(rep)

@@ -67,7 +67,7 @@ def test_dropout_forward_backward_replayed_through_oracle():
     from phones_las_amd import hip
     v = model.vars
     hip.check(hip.lib().las_grad_l2_norms(hip.p(v.grad), hip.p(v.flat), hip.p(v.seg), len(v.table), v.total,
-                                          float(model.params.l2_reg_scale), hip.p(v.sumsq), None, hip.stream()))
+                                          float(model.params.l2_reg_scale), hip.p(v.sumsq), None, None, 0, hip.stream()))
     torch.cuda.synchronize()
     for name, _, _ in v.table:
         assert relerr(v.grads[name], out['grads'][name]) < 2e-2, name
