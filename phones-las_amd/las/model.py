@@ -188,6 +188,7 @@ class Speller:
         if self.att == hip.ATT_BAHDANAU:
             self.wq = torch.empty(Hd, Hd, dtype=bf, device=dev)
             self.wq_t = torch.empty(Hd, Hd, dtype=bf, device=dev)
+        self._variables = variables
         self.refresh(variables)
         self.saved = None
 
@@ -546,27 +547,98 @@ class Speller:
         return logits[:, :steps, :V], samples[:, :steps], final_len, align[:, :steps]
 
 
+BasicDecoderOutput = None
+FinalBeamSearchDecoderOutput = None
+
+
+def _output_types():
+    global BasicDecoderOutput, FinalBeamSearchDecoderOutput
+    if BasicDecoderOutput is None:
+        import collections
+        BasicDecoderOutput = collections.namedtuple('BasicDecoderOutput', ['rnn_output', 'sample_id'])
+        FinalBeamSearchDecoderOutput = collections.namedtuple('FinalBeamSearchDecoderOutput',
+                                                              ['predicted_ids', 'beam_search_decoder_output'])
+    return BasicDecoderOutput, FinalBeamSearchDecoderOutput
+
+
+def speller_kind(hparams, binary_outputs=False, binf_embedding=None):
+    """Which decoder a las.model.speller(...) call builds (las/model.py:228-257): 'sigmoid' when the caller passes
+    binary_outputs (projection = Dense(binf_count), feature-vector inputs), 'binf_projection' when hparams.binf_projection is
+    set and the feature map is handed in (attention layer of 2*binf_count, DenseBinfDecoder's fixed map), else 'phones'."""
+    if binary_outputs:
+        return 'sigmoid'
+    if bool(getattr(hparams, 'binf_projection', False)) and binf_embedding is not None:
+        return 'binf_projection'
+    return 'phones'
+
+
 def speller(encoder_outputs, encoder_state, decoder_inputs, source_sequence_length, target_sequence_length, mode,
             hparams, binary_outputs=False, binf_embedding=None, transparent_projection=False, *, variables=None,
-            module=None, num_steps=None):
-    """las/model.py:205-349.  Returns (decoder_outputs, final_context_state, final_sequence_length) where
-    decoder_outputs has ``rnn_output`` (logits) and ``sample_id``."""
-    import collections
-    if binary_outputs or binf_embedding is not None or transparent_projection:
-        raise ValueError('binary-feature decoders are not implemented on the HIP path this round')
-    if getattr(hparams, 'beam_width', 0) and mode == PREDICT:
-        raise ValueError('beam search is not implemented on the HIP path this round')
+            module=None, num_steps=None, scope='speller'):
+    """las/model.py:205-349, same positional arguments.  Returns (decoder_outputs, final_context_state,
+    final_sequence_length) as the reference's dynamic_decode does:
+
+      TRAIN                          BasicDecoderOutput(rnn_output = logits [B,U,.], sample_id = argmax ids); with
+                                     hparams.binf_projection the rnn_output is [phone logits | raw 2*binf_count outputs]
+                                     (DenseBinfDecoder(concat_cell_outputs=True), las/model.py:251-257); with binary_outputs
+                                     the decoder inputs are the targets' FEATURE VECTORS [B,U,binf_count] (model_helper.py:
+                                     199-200,222) or their token ids, and the outputs feature logits
+      EVAL / PREDICT, beam_width 0   greedy decode (GreedyEmbeddingHelper; the InferenceHelper of :320-336 for binary_outputs
+                                     without a map); transparent_projection: rnn_output = the raw cell outputs
+                                     (BasicTransparentProjectionDecoder, utils/training_helper.py:156-178)
+      PREDICT, beam_width > 0        FinalBeamSearchDecoderOutput(predicted_ids [B,T,K]); decoder_inputs = the partial targets
+                                     the search starts from (las/model.py:298-311) or None
+
+    final_context_state is the decoder module (its ``alignment_history`` [B,S,T'] is what get_alignment_history reads).
+    variables: {tf name: fp32 CUDA tensor} under ``scope`` (model_helper.param_table), or pass a ready ``module``."""
+    Out, BeamOut = _output_types()
+    kind = speller_kind(hparams, binary_outputs, binf_embedding)
+    beam = int(getattr(hparams, 'beam_width', 0) or 0) if mode == PREDICT else 0
+    if kind == 'sigmoid' and binf_embedding is not None and mode != TRAIN:
+        raise ValueError('binary_outputs with a feature map outside TRAIN: the reference samples through '
+                         'transform_binf_to_phones on binf_count-wide outputs, whose [nf:2nf] half is empty '
+                         '(utils/training_helper.py:17-27 from las/model.py:251-257); decode with binf_embedding=None '
+                         '(InferenceHelper) or use --binf_projection')
     if module is None:
-        module = make_speller(hparams, variables, encoder_outputs.shape[-1])
-    Out = collections.namedtuple('BasicDecoderOutput', ['rnn_output', 'sample_id'])
+        from .speller_general import GeneralSpeller
+        if kind == 'phones':
+            module = make_speller(hparams, variables, encoder_outputs.shape[-1], scope=scope, phones_only=True)
+        else:
+            module = GeneralSpeller(hparams, variables, encoder_outputs.shape[-1], _ATT[hparams.attention_type],
+                                    binf2phone=binf_embedding, sigmoid=(kind == 'sigmoid'), scope=scope)
+    if beam > 0 and isinstance(module, Speller):      # the search gathers decoder state between steps: general cell stack
+        from .speller_general import GeneralSpeller
+        module = GeneralSpeller(hparams, variables if variables is not None else module._variables, module.M,
+                                _ATT[hparams.attention_type], scope=scope)
     if mode == TRAIN:
+        vec = None
+        if kind == 'sigmoid' and decoder_inputs.is_floating_point():      # feature vectors, as model_helper.py:222 passes them
+            vec, decoder_inputs = decoder_inputs, None
+        n = vec.shape[1] if vec is not None else None
         U = num_steps if num_steps is not None else int(target_sequence_length.max().item())
-        logits = module.forward_train(encoder_outputs, source_sequence_length, encoder_state, decoder_inputs, U)
-        V = module.V
-        return Out(logits, None), module, target_sequence_length
+        if vec is not None:
+            logits = module.forward_train(encoder_outputs, source_sequence_length, encoder_state, None, U, input_vectors=vec)
+        else:
+            logits = module.forward_train(encoder_outputs, source_sequence_length, encoder_state, decoder_inputs, U)
+        Vo = getattr(module, 'Vo', module.V)
+        out = logits[..., :Vo]
+        ids = out.argmax(-1).to(torch.int32)
+        if kind == 'binf_projection':       # concat_cell_outputs: model_helper.py:245-246 splits them again
+            out = torch.cat([out, module.saved['att'].float()], -1)
+        elif kind == 'sigmoid':             # TrainingSigmoidHelper.sample without a map: round(sigmoid(outputs))
+            ids = (out > 0).to(torch.float32)
+        return Out(out, ids), module, target_sequence_length
     max_len = int(source_sequence_length.max().item())
     max_it = int(round(max_len * hparams.decoding_length_factor))       # las/model.py:270-274
-    logits, ids, final_len, align = module.forward_greedy(encoder_outputs, source_sequence_length, encoder_state,
-                                                          max_it)
+    if beam > 0:
+        ids, lens, lps = module.forward_beam(encoder_outputs, source_sequence_length, encoder_state, max_it, beam,
+                                             partial_targets=decoder_inputs)
+        module.beam_log_probs = lps
+        return BeamOut(ids, None), module, lens
+    logits, ids, final_len, align = module.forward_greedy(encoder_outputs, source_sequence_length, encoder_state, max_it)
     module.alignment_history = align
+    if transparent_projection:
+        if kind != 'binf_projection':
+            raise ValueError('transparent_projection needs the binf_projection decoder (its raw [lp1 | lp0] outputs)')
+        logits = module.last_raw_outputs.float()
     return Out(logits, ids), module, final_len

@@ -153,6 +153,7 @@ class GeneralSpeller:
         if self.uses_wq:
             self.wq = torch.empty(Hd, Hd, dtype=bf, device=dev)
             self.wq_t = torch.empty(Hd, Hd, dtype=bf, device=dev)
+        self._variables = variables
         self.refresh(variables)
         self.saved = None
         self.debug_hook = None
@@ -303,12 +304,19 @@ class GeneralSpeller:
             s.noise_scale, s.noise_seed, s.noise_stream = sv.get('noise_scale', 0.0), sv.get('seed', 0), self.NOISE_STREAM
         hip.check(hip.lib().las_decoder_step_fwd(C.byref(s), 4, hip.stream()))
 
-    def forward_train(self, memory, mem_len, encoder_state, targets_inputs, num_steps, parts=4, seed=0):
+    def forward_train(self, memory, mem_len, encoder_state, targets_inputs, num_steps, parts=4, seed=0, input_vectors=None):
+        """input_vectors [B,>=U,nf] (sigmoid-output decoder only): the decoder inputs as feature VECTORS, the form
+        las_model_fn hands them to las.model.speller (model_helper.py:199-200,222), instead of token ids."""
         B, Tm, M = memory.shape
+        if input_vectors is not None:
+            if not self.sigmoid:
+                raise ValueError('input_vectors: only the sigmoid-output decoder is fed feature vectors')
+            input_vectors = input_vectors.to(torch.bfloat16)
+            targets_inputs = torch.zeros(B, num_steps, dtype=torch.int32, device=memory.device)     # (unused placeholder ids)
         Hd, V, Vp, U, A, NL = self.Hd, self.V, self.Vop, num_steps, self.A, self.NL      # Vp: padded projection width
         dev, bf, f32 = memory.device, torch.bfloat16, torch.float32
         Tmp = _r8(Tm)
-        if self.sigmoid and self.feat is None:
+        if self.sigmoid and self.feat is None and input_vectors is None:
             raise ValueError('training the sigmoid-output decoder needs the binf2phone map (the targets\' feature vectors, '
                              'model_helper.py:199-200)')
         init, passed = self._init_states(encoder_state, B)
@@ -351,7 +359,10 @@ class GeneralSpeller:
             if self.tokx and not (self.sigmoid and sampling > 0.0 and t > 0):
                 # embedded token of this step into the operand (dropped with the rest below); the sigmoid-output decoder
                 # under scheduled sampling got its input vector from las_sample_features at the end of step t-1
-                X[0][:, t, :self.Ep] = self.emb_bf[fed[:, t].long()]
+                if input_vectors is not None:
+                    X[0][:, t, :self.nf] = input_vectors[:, t, :self.nf]
+                else:
+                    X[0][:, t, :self.Ep] = self.emb_bf[fed[:, t].long()]
 
             def run_cell(l):
                 Kl = self.win[l] + Hd
@@ -401,7 +412,11 @@ class GeneralSpeller:
                             bias=self.bproj)
                 if not last and self.sigmoid:
                     # ScheduledSigmoidHelper: Bernoulli(sigmoid(logits)) feature draws or the teacher's feature vector
-                    teach = self.emb_bf[tin[:, t + 1].long()]
+                    if input_vectors is not None:
+                        teach = torch.zeros(B, self.Ep, dtype=bf, device=dev)
+                        teach[:, :self.nf] = input_vectors[:, t + 1, :self.nf]
+                    else:
+                        teach = self.emb_bf[tin[:, t + 1].long()]
                     hip.check(lib.las_sample_features(hip.addr(logits, t * Vp), U * Vp, self.nf, hip.p(teach), self.Ep,
                                                       hip.addr(X[0], (t + 1) * (self.win[0] + Hd)), U * (self.win[0] + Hd), B,
                                                       sampling, seed, t, st))
