@@ -27,7 +27,7 @@ from .dataset_utils import _shuffle
 from .features_utils import load_normalization
 from .vocab_utils import SOS, EOS, create_vocab_table
 
-__all__ = ['IndexedRecords', 'FastInput', 'fast_input_fn']
+__all__ = ['IndexedRecords', 'HostBatcher', 'FastInput', 'fast_input_fn', 'shard_indices']
 
 
 def _fnv1a(data):
@@ -83,19 +83,18 @@ class IndexedRecords(object):
         return len(self.offsets)
 
 
-class FastInput(object):
-    """Iterator of (features, labels) dicts of CUDA tensors, produced ahead of the consumer by a background thread."""
+class HostBatcher(object):
+    """The host half of a batch: padded shapes from the INDEXED counts, then one C call that parses the records into packed
+    frames + token ids.  Separate from FastInput so that the per-rank work of a data-parallel job can be measured and tested
+    without a GPU: `shapes()` looks at the whole global batch (every rank must agree on T', U and the decoder steps), `parse()`
+    only at the records it is given -- a rank hands it ITS slice of the global index batch, so host parse time, pinned memory
+    and H2D bytes per rank stay those of one replica's batch however many replicas there are (round 2
+    parsed and copied the whole global batch on every rank and sliced on the device)."""
 
-    def __init__(self, records, vocab_table, num_channels, batch_size, num_epochs=1, is_infer=False, max_frames=-1,
-                 max_symbols=-1, means=None, stds=None, seed=None, time_multiple=1, depth=3, device=None, take=0):
-        self.rec, self.F, self.B = records, int(num_channels), int(batch_size)
-        self.num_epochs, self.is_infer = num_epochs, is_infer
+    def __init__(self, records, vocab_table, num_channels, max_frames=-1, max_symbols=-1, time_multiple=1):
+        self.rec, self.F = records, int(num_channels)
         self.max_frames, self.max_symbols = max_frames, max_symbols
         self.tm = max(1, int(time_multiple))
-        self.Fp = (self.F + 7) // 8 * 8
-        self.take = take
-        self.dev = torch.device('cuda', torch.cuda.current_device()) if device is None else device
-        self.rng = random.Random(seed)
         # vocab_utils.create_vocab_table semantics on the tokens' utf-8 bytes, looked up in C (las_vocab_lookup): an open
         # addressing table over FNV-1a hashes, built here once (a Python dict lookup per token was 5 of the 7.5 ms a batch took)
         self.sos_id, self.eos_id = vocab_table.lookup([SOS])[0], vocab_table.lookup([EOS])[0]
@@ -111,6 +110,79 @@ class FastInput(object):
                 slot = (slot + 1) & (size - 1)
             if self.vkeys[slot] == 0:                     # (setdefault semantics: the first index of a repeated token)
                 self.vkeys[slot], self.vvals[slot] = h, idx
+
+    def shapes(self, idx):
+        """(T, U, T', decoder steps) of the batch with record indices `idx` -- no record is touched."""
+        nfr, nlb = self.rec.n_frames[idx], self.rec.n_labels[idx]
+        T = self.max_frames if self.max_frames > 0 else int(nfr.max())
+        U = self.max_symbols if self.max_frames > 0 else int(nlb.max()) + 1
+        Tp = (T + self.tm - 1) // self.tm * self.tm
+        return T, U, Tp, min(int(nlb.max()) + 1, U)
+
+    def parse(self, idx, U, pinned=False):
+        """Packed frames [rows, F] fp32, row offsets [B+1], targets_inputs / targets_outputs [B, U] and target lengths [B] of
+        the records `idx` (labels: [<s>] + y / y + [</s>], padded with the EOS id, utils/dataset_utils.py:226-264)."""
+        lib, rec = hip.lib(), self.rec
+        idx = np.asarray(idx, dtype=np.int64)
+        B = len(idx)
+        nfr, nlb = rec.n_frames[idx], rec.n_labels[idx]
+        rows, ntok, nbytes = int(nfr.sum()), int(nlb.sum()), int(rec.label_bytes[idx].sum())
+        frames = torch.empty(max(rows, 1), self.F, dtype=torch.float32, pin_memory=pinned)
+        row_off = torch.empty(B + 1, dtype=torch.int64, pin_memory=pinned)
+        lab = np.empty(max(nbytes, 1), np.uint8)
+        tok_off = np.empty(ntok + 1, np.int32)
+        counts = np.empty(B, np.int32)
+        addr = np.ascontiguousarray(rec.addr[idx])
+        lens = np.ascontiguousarray(rec.lengths[idx])
+        hip.check(lib.las_tfrecord_parse_batch(0, addr.ctypes.data, lens.ctypes.data, B, self.F, frames.data_ptr(), rows,
+                                               row_off.data_ptr(), lab.ctypes.data, nbytes, tok_off.ctypes.data, ntok,
+                                               counts.ctypes.data))
+        all_ids = np.empty(max(ntok, 1), np.int32)
+        hip.check(lib.las_vocab_lookup(lab.ctypes.data, tok_off.ctypes.data, ntok, self.vkeys.ctypes.data, self.vvals.ctypes.data,
+                                       len(self.vkeys), self.unk_id, all_ids.ctypes.data))
+        tin = np.full((B, U), self.eos_id, np.int32)
+        tout = np.full((B, U), self.eos_id, np.int32)
+        tl = np.zeros(B, np.int32)
+        t0 = 0
+        for b in range(B):
+            c = int(counts[b])
+            ids = all_ids[t0:t0 + c]
+            t0 += c
+            n = min(c + 1, U)                    # quirk B4 of the slow path: the padded shape is [max_symbols]
+            tin[b, 0] = self.sos_id
+            tin[b, 1:n] = ids[:n - 1]
+            tout[b, :min(c, n)] = ids[:n]
+            if c < n:
+                tout[b, c] = self.eos_id
+            tl[b] = n
+        return dict(frames=frames, row_off=row_off, tin=tin, tout=tout, tl=tl, rows=rows)
+
+
+def shard_indices(idx, rank, world):
+    """This rank's contiguous slice of a global index batch (dp.shard_batch's split, applied BEFORE anything is parsed)."""
+    if len(idx) % world:
+        raise ValueError('global batch %d is not divisible by %d replicas' % (len(idx), world))
+    n = len(idx) // world
+    return idx[rank * n:(rank + 1) * n]
+
+
+class FastInput(object):
+    """Iterator of (features, labels) dicts of CUDA tensors, produced ahead of the consumer by a background thread."""
+
+    def __init__(self, records, vocab_table, num_channels, batch_size, num_epochs=1, is_infer=False, max_frames=-1,
+                 max_symbols=-1, means=None, stds=None, seed=None, time_multiple=1, depth=3, device=None, take=0, shard=None):
+        """batch_size: the GLOBAL batch.  shard = (rank, world): every rank walks the same index stream (same seed), derives
+        the padded shapes from the whole global batch and parses / copies only its own 1/world of it."""
+        self.rec, self.F, self.B = records, int(num_channels), int(batch_size)
+        self.num_epochs, self.is_infer = num_epochs, is_infer
+        self.max_frames, self.max_symbols = max_frames, max_symbols
+        self.tm = max(1, int(time_multiple))
+        self.Fp = (self.F + 7) // 8 * 8
+        self.take = take
+        self.shard = tuple(shard) if shard is not None and shard[1] > 1 else None
+        self.dev = torch.device('cuda', torch.cuda.current_device()) if device is None else device
+        self.rng = random.Random(seed)
+        self.host = HostBatcher(records, vocab_table, num_channels, max_frames, max_symbols, time_multiple)
         self.mean = self.std = None
         if means is not None and stds is not None:
             self.mean = torch.as_tensor(np.asarray(means, dtype=np.float64)).to(self.dev)
@@ -154,48 +226,18 @@ class FastInput(object):
         try:
             torch.cuda.set_device(self.dev)
             lib = hip.lib()
-            rec = self.rec
             produced = 0
             for idx in self._index_batches():
                 if self.take > 0 and produced >= self.take:
                     break
                 idx = np.asarray(idx, dtype=np.int64)
+                T, U, Tp, max_len = self.host.shapes(idx)          # from the whole global batch: all ranks agree
+                if self.shard is not None:
+                    idx = shard_indices(idx, *self.shard)          # ... and parse / copy only this rank's records
                 B = len(idx)
-                nfr, nlb = rec.n_frames[idx], rec.n_labels[idx]
-                rows, ntok, nbytes = int(nfr.sum()), int(nlb.sum()), int(rec.label_bytes[idx].sum())
-                frames = torch.empty(max(rows, 1), self.F, dtype=torch.float32, pin_memory=True)
-                row_off = torch.empty(B + 1, dtype=torch.int64, pin_memory=True)
-                lab = np.empty(max(nbytes, 1), np.uint8)
-                tok_off = np.empty(ntok + 1, np.int32)
-                counts = np.empty(B, np.int32)
-                addr = np.ascontiguousarray(rec.addr[idx])
-                lens = np.ascontiguousarray(rec.lengths[idx])
-                hip.check(lib.las_tfrecord_parse_batch(0, addr.ctypes.data, lens.ctypes.data, B, self.F, frames.data_ptr(), rows,
-                                                       row_off.data_ptr(), lab.ctypes.data, nbytes, tok_off.ctypes.data, ntok,
-                                                       counts.ctypes.data))
-                T = self.max_frames if self.max_frames > 0 else int(nfr.max())
-                U = self.max_symbols if self.max_frames > 0 else int(nlb.max()) + 1
-                Tp = (T + self.tm - 1) // self.tm * self.tm
-                # labels: [<s>] + y / y + [</s>], padded with the EOS id (utils/dataset_utils.py:226-264)
-                all_ids = np.empty(max(ntok, 1), np.int32)
-                hip.check(lib.las_vocab_lookup(lab.ctypes.data, tok_off.ctypes.data, ntok, self.vkeys.ctypes.data, self.vvals.ctypes.data,
-                                               len(self.vkeys), self.unk_id, all_ids.ctypes.data))
-                tin = np.full((B, U), self.eos_id, np.int32)
-                tout = np.full((B, U), self.eos_id, np.int32)
-                tl = np.zeros(B, np.int32)
-                t0 = 0
-                for b in range(B):
-                    c = int(counts[b])
-                    ids = all_ids[t0:t0 + c]
-                    t0 += c
-                    n = min(c + 1, U)                    # quirk B4 of the slow path: the padded shape is [max_symbols]
-                    tin[b, 0] = self.sos_id
-                    tin[b, 1:n] = ids[:n - 1]
-                    tout[b, :min(c, n)] = ids[:n]
-                    if c < n:
-                        tout[b, c] = self.eos_id
-                    tl[b] = n
-                labels_host = torch.from_numpy(np.concatenate([tin.reshape(-1), tout.reshape(-1), tl])).pin_memory()
+                hb = self.host.parse(idx, U, pinned=True)
+                frames, row_off = hb['frames'], hb['row_off']
+                labels_host = torch.from_numpy(np.concatenate([hb['tin'].reshape(-1), hb['tout'].reshape(-1), hb['tl']])).pin_memory()
                 with torch.cuda.stream(self.copy_stream):
                     d_frames = frames.to(self.dev, non_blocking=True)
                     d_off = row_off.to(self.dev, non_blocking=True)
@@ -211,7 +253,7 @@ class FastInput(object):
                 labels = {'targets_inputs': d_lab[:n1].view(B, U), 'targets_outputs': d_lab[n1:2 * n1].view(B, U),
                           'target_sequence_length': d_lab[2 * n1:]}
                 # the pinned staging buffers stay referenced until the consumer has taken the batch (the copies read them)
-                self.q.put((feats, labels, ev, int(tl.max()), (frames, row_off, labels_host, d_frames, d_off)))
+                self.q.put((feats, labels, ev, max_len, (frames, row_off, labels_host, d_frames, d_off)))
                 produced += 1
         except BaseException as e:          # surfaced in the consumer
             self.err = e
@@ -237,12 +279,13 @@ class FastInput(object):
 
 def fast_input_fn(dataset_filename, vocab_filename, norm_filename=None, num_channels=39, batch_size=8, num_epochs=1,
                   num_parallel_calls=32, max_frames=-1, max_symbols=-1, take=0, is_infer=False, seed=None, time_multiple=1,
-                  verify_crc=True, depth=3):
-    """utils/dataset_utils.py:286-308 (same arguments, plus the listener's time multiple): an iterator of device batches."""
+                  verify_crc=True, depth=3, shard=None):
+    """utils/dataset_utils.py:286-308 (same arguments, plus the listener's time multiple): an iterator of device batches.
+    batch_size is the global batch; shard = (rank, world) makes this process parse and copy only its replica's part."""
     records = IndexedRecords(dataset_filename, verify_crc=verify_crc)
     vocab_table = create_vocab_table(vocab_filename)
     means = stds = None
     if norm_filename is not None and os.path.exists(norm_filename):
         means, stds = load_normalization(norm_filename)
     return FastInput(records, vocab_table, num_channels, batch_size, num_epochs, is_infer, max_frames, max_symbols, means, stds,
-                     seed, time_multiple, depth, take=take)
+                     seed, time_multiple, depth, take=take, shard=shard)

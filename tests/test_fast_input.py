@@ -219,3 +219,98 @@ def test_train_loop_on_tfrecords_sustains_the_resident_batch_rate(tmp_path):
     model.check_device_status()
     print('resident batch %.0f / %.0f utt/s, TFRecord-fed %.0f utt/s (%.1f %%)' % (r_res, r_res2, r_fed, 100 * r_fed / max(r_res, r_res2)))
     assert r_fed >= 0.9 * min(r_res, r_res2), (r_fed, r_res, r_res2)
+
+
+def _big_corpus(tmp_path, n=96, F=40, seed=5):
+    from phones_las_amd.utils import tfrecord as tfr
+    rng = np.random.default_rng(seed)
+    path = str(tmp_path / 'big.tfr')
+    with tfr.TFRecordWriter(path) as w:
+        for i in range(n):
+            T, U = int(rng.integers(150, 400)), int(rng.integers(3, 30))
+            w.write(tfr.make_example(rng.standard_normal((T, F)).astype(np.float32), ['w%d' % int(k) for k in rng.integers(0, 50, U)]))
+    vocab = str(tmp_path / 'vocab.txt')
+    open(vocab, 'w').write('\n'.join('w%d' % i for i in range(50)) + '\n')
+    return path, vocab
+
+
+def _shard_worker(rank, world, port, path, vocab, ret):
+    """One rank of a data-parallel job on the HOST side of the input path (no GPU): walks the same index stream as every
+    other rank, takes the padded shapes from the whole global batch and parses only its slice."""
+    import random
+    import time
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    from phones_las_amd.utils import vocab_utils
+    from phones_las_amd.utils.dataset_utils import _shuffle
+    from phones_las_amd.utils.fast_input import IndexedRecords, HostBatcher, shard_indices
+    rec = IndexedRecords(path)
+    hb = HostBatcher(rec, vocab_utils.create_vocab_table(vocab), 40, time_multiple=4)
+    rng = random.Random(1234)                                   # train.py's seed: the same stream on every rank
+    order = list(_shuffle(iter(range(len(rec))), 32 * 500, rng))
+    out = []
+    t_shard = t_global = 0.0
+    for k in range(0, len(order) - 31, 32):
+        gidx = np.asarray(order[k:k + 32], dtype=np.int64)
+        T, U, Tp, steps = hb.shapes(gidx)
+        mine = shard_indices(gidx, rank, world)
+        t0 = time.perf_counter()
+        part = hb.parse(mine, U)
+        t_shard += time.perf_counter() - t0
+        if rank == 0:                                           # what round 2 did on EVERY rank: the whole global batch
+            t0 = time.perf_counter()
+            whole = hb.parse(gidx, U)
+            t_global += time.perf_counter() - t0
+        else:
+            whole = None
+        out.append((gidx.tolist(), (T, U, Tp, steps), part, whole))
+    ret[rank] = (out, t_shard, t_global)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_host_batches_tile_the_global_batch_gloo(tmp_path):
+    """world_size 2 on CPU: the ranks agree on the index stream and the padded shapes, the UNION of their
+    parsed shards is the batch one rank would have parsed -- frames, row offsets, targets, lengths -- and a rank touches
+    half the records: half the rows (deterministic) and clearly less parse time than the global batch (measured ~0.5x)."""
+    import socket
+    import torch.multiprocessing as mp
+    path, vocab = _big_corpus(tmp_path)
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    ret = mp.Manager().dict()
+    mp.spawn(_shard_worker, args=(2, port, path, vocab, ret), nprocs=2, join=True)
+    (o0, ts0, tg0), (o1, ts1, _) = ret[0], ret[1]
+    assert len(o0) == len(o1) == 3
+    for (g0, shp0, p0, whole), (g1, shp1, p1, _) in zip(o0, o1):
+        assert g0 == g1 and shp0 == shp1                                            # same stream, same padded shapes
+        rows0, rows1 = p0['rows'], p1['rows']
+        assert rows0 + rows1 == whole['rows'] and 0.3 < rows0 / whole['rows'] < 0.7
+        assert torch.equal(torch.cat([p0['frames'][:rows0], p1['frames'][:rows1]]), whole['frames'][:whole['rows']])
+        assert torch.equal(torch.cat([p0['row_off'], p1['row_off'][1:] + rows0]), whole['row_off'])
+        for k in ('tin', 'tout', 'tl'):
+            assert np.array_equal(np.concatenate([p0[k], p1[k]]), whole[k]), k
+        assert p0['tin'].shape == (16, shp0[1]) and shp0[2] % 4 == 0 and shp0[3] == int(whole['tl'].max())
+    assert ts0 < 0.8 * tg0, (ts0, tg0)
+
+
+@pytest.mark.gpu
+def test_fast_input_shards_are_the_slices_of_the_unsharded_batches(tmp_path):
+    """FastInput(shard=(r, 2)) for r = 0, 1 against the unsharded iterator: the same steps, and each rank's device batch is
+    bit-identical to its slice of the global one (features after normalise + bf16 + pad, labels, lengths, decoder steps)."""
+    from phones_las_amd.utils.fast_input import fast_input_fn
+    path, vocab = _big_corpus(tmp_path, n=40)
+    kw = dict(num_channels=40, batch_size=8, num_epochs=2, seed=1234, time_multiple=4)
+    whole = list(fast_input_fn(path, vocab, None, **kw))
+    parts = [list(fast_input_fn(path, vocab, None, shard=(r, 2), **kw)) for r in range(2)]
+    assert len(whole) == len(parts[0]) == len(parts[1]) == 10
+    for (fw, lw), (f0, l0), (f1, l1) in zip(whole, *parts):
+        assert lw.pop('max_target_length') == l0.pop('max_target_length') == l1.pop('max_target_length')
+        for k in fw:
+            assert torch.equal(torch.cat([f0[k], f1[k]]), fw[k]), k
+        for k in lw:
+            assert torch.equal(torch.cat([l0[k], l1[k]]), lw[k]), k

@@ -224,3 +224,72 @@ def test_binary_greedy_decode_known_answers():
     p['speller/projection_layer/bias'] = torch.tensor([1., -1., 1., -1., 1., -2.], dtype=torch.float64)
     lg, smp, fl, _ = O.speller_greedy_binary(hp, p, mem, ml, st)
     assert lg.shape[1] == int(ml.max()) and fl.tolist() == [int(ml.max())] * 2
+
+
+def _simulate_monotonic(p, hard_scores=None):
+    """The stochastic process monotonic attention is the expectation of (Raffel et al. 2017, what
+    tf.contrib.seq2seq.monotonic_attention computes in closed form): at output step i the decoder starts at the memory
+    position it attended at step i-1 (position 0 before the first step) and walks right; at position j it stops and attends
+    with probability p[i, j], else moves on; walking off the end attends nothing, at this and every later step.
+    BRUTE FORCE: every outcome z in {0,1}^(U x T) of the independent stop / move-on draws is enumerated, the walk is
+    simulated for it, and the attended positions are weighted with the outcome's probability.  Returns alpha [U, T]."""
+    U, T = p.shape
+    alpha = np.zeros((U, T))
+    for code in range(1 << (U * T)):
+        z = np.array([(code >> k) & 1 for k in range(U * T)]).reshape(U, T)
+        w = float(np.prod(np.where(z == 1, p, 1.0 - p)))
+        if w == 0.0:
+            continue
+        pos = 0
+        for i in range(U):
+            j = pos
+            while j < T and z[i, j] == 0:
+                j += 1
+            if j >= T:
+                break                      # fell off the end: nothing attended from here on
+            alpha[i, j] += w
+            pos = j
+    return alpha
+
+
+def test_monotonic_attention_parallel_is_the_expectation_of_the_attend_or_skip_process():
+    """Pins oracle.monotonic_attention('parallel') -- p * cumprod_excl(1-p) * cumsum(prev / clip(cumprod_excl(1-p))) chained
+    over decoder steps from the one-hot initial alignment -- on an INDEPENDENT statement of what it means: the marginals of
+    the stop / move-on walk, by enumeration of all 2^(U T) outcomes (U=3 steps, T'=5 frames; and T'=6 with U=2).  Also the
+    'hard' mode: with p in {0,1} the walk is deterministic and the alignment one-hot (or empty)."""
+    rng = np.random.default_rng(11)
+    for U, T in ((3, 5), (2, 6)):
+        p = rng.uniform(0.05, 0.95, size=(U, T))
+        p[0, 1] = 0.0                      # a frame that is never chosen, and one that almost always stops the walk
+        p[U - 1, T - 2] = 0.97
+        want = _simulate_monotonic(p)
+        prev = torch.zeros(1, T, dtype=DT)
+        prev[0, 0] = 1.0
+        for i in range(U):
+            a = O.monotonic_attention(torch.tensor(p[i:i + 1], dtype=DT), prev, 'parallel')
+            assert float((a[0] - torch.tensor(want[i])).abs().max()) < 1e-12, (U, T, i)
+            prev = a
+        assert abs(float(want.sum(1)[-1]) - float(prev.sum())) < 1e-12 and float(prev.sum()) < 1.0      # mass lost off the end
+    # Where the closed form LEAVES the process -- and the reference with it, this is tf.contrib's formula: once the exclusive
+    # cumprod of (1 - p) falls under the 1e-10 clip, prev / clip(cp) no longer cancels cp and the mass of walkers that START
+    # beyond that point is lost (a frame with p = 1 in front of the previous position is enough).  This is the regime cfg5 at
+    # T' = 200 is in from about the 30th decoder step (alignments summing to 1e-8: DESIGN.md 2); the device kernels reproduce
+    # the formula, not the process.
+    p = np.array([[0.5, 0.5, 0.5, 0.5], [0.3, 1.0, 0.4, 0.6]])
+    want = _simulate_monotonic(p)
+    prev = torch.zeros(1, 4, dtype=DT)
+    prev[0, 0] = 1.0
+    a0 = O.monotonic_attention(torch.tensor(p[0:1], dtype=DT), prev, 'parallel')
+    a1 = O.monotonic_attention(torch.tensor(p[1:2], dtype=DT), a0, 'parallel')
+    assert float((a0[0] - torch.tensor(want[0])).abs().max()) < 1e-12
+    assert float((a1[0, :2] - torch.tensor(want[1, :2])).abs().max()) < 1e-12
+    assert want[1, 2] > 0.04 and float(a1[0, 2]) < 1e-20 and want[1, 3] > 0.05 and float(a1[0, 3]) < 1e-20
+    # hard mode = the same walk with deterministic draws
+    z = (rng.uniform(size=(3, 5)) < 0.35).astype(np.float64)
+    want = _simulate_monotonic(z)
+    prev = torch.zeros(1, 5, dtype=DT)
+    prev[0, 0] = 1.0
+    for i in range(3):
+        a = O.monotonic_attention(torch.tensor(z[i:i + 1], dtype=DT), prev, 'hard')
+        assert torch.equal(a[0], torch.tensor(want[i])), i
+        prev = a

@@ -162,7 +162,7 @@ def main(args):
         from phones_las_amd.utils.fast_input import fast_input_fn
         return fast_input_fn(args.train, vocab_name, norm_name, num_channels=hparams.num_channels, batch_size=global_batch,
                              num_epochs=args.num_epochs, max_frames=args.max_frames, max_symbols=args.max_symbols, seed=1234,
-                             time_multiple=model.listener.time_multiple)
+                             time_multiple=model.listener.time_multiple, shard=(rank, world))
 
     max_steps = args.num_epochs * 1000 * args.batch_size          # train.py:189,202 (quirk B2)
     t_last, last_eval, t0 = time.time(), time.time(), time.time()
@@ -172,7 +172,9 @@ def main(args):
             break
         # decoder steps of this batch = the longest target: a host number on both input paths (no device round trip)
         num_steps = labels.pop('max_target_length', None)
-        if world > 1:
+        if world > 1 and args.slow_input:
+            # (the C input path hands every rank ITS shard: it parses and copies 1/world of the global batch; the pure-Python
+            # reader yields the whole global batch on the host and is cut here)
             features, labels = dp.shard_batch(features, rank, world), dp.shard_batch(labels, rank, world)
         if num_steps is None:
             num_steps = int(labels['target_sequence_length'].max())
