@@ -95,9 +95,12 @@ __device__ bool xcd_colocated(u64* table, int member, int* lds_flag, unsigned* s
 // H <= 128: one workgroup; H = 256: 4 x 64 units; H = 512: 16 x 32 units with the K dimension split over wave pairs
 // (a wave's register-resident weight block is 16 units x 4 gates x K/KS: 128 VGPRs in every case)
 __host__ __device__ constexpr int coop_members(int H) { return H <= 128 ? 1 : (H == 256 ? 4 : H / 32); }
-__host__ __device__ constexpr int k_split(int H) { return H > 256 ? 2 : 1; }
+// The kernels take the member count as a template parameter (default: coop_members(H)); H = 512 also runs as 8 members of
+// 64 units (round 3): one 16-unit block per wave over the WHOLE K (256 weight VGPRs of the wave's 512), no K split / row
+// split hand-over inside the workgroup, 7 peers instead of 15 -- the H = 256 code path at twice the K.
+__host__ __device__ constexpr int k_split_g(int H, int G) { return H / G < 64 ? 2 : 1; }
 // prefetch companions per group: one serves four members' columns
-__host__ __device__ constexpr int group_companions(int H) { return coop_members(H) >= 4 ? coop_members(H) / 4 : 1; }
+__host__ __device__ constexpr int group_companions_g(int G) { return G >= 4 ? G / 4 : 1; }
 
 // ------------------------------------------------------------------------------------------------
 // pack K_h [H,4H] fp32 -> MFMA-B-fragment-major bf16, grouped by 16-unit block:
@@ -118,16 +121,15 @@ __global__ void pack_recurrent_kernel(const float* kh, int H, unsigned short* pa
 // ROWS = utterances per slice: 16 fills the MFMA tile; 8 (rows 0,1 of every quad; the other two stay zero) halves the
 // element-wise work, the exchange and the HBM accesses of every lane at the same MFMA cost -- the per-step latency is
 // mostly that work, so small batches run twice as many (half-filled) chains on otherwise idle CUs.
-template <int H, int ROWS>
+template <int H, int ROWS, int G = coop_members(H)>
 __global__ __launch_bounds__(256) void lstm_fwd_kernel(float* __restrict__ xproj, const unsigned short* __restrict__ wpacked,
                                                        const int32_t* __restrict__ length, unsigned short* __restrict__ y,
                                                        float* __restrict__ cbuf, float* __restrict__ c_last,
                                                        float* __restrict__ h_last, u64* __restrict__ exch,
                                                        unsigned* __restrict__ status, int B, int T, int ndir, int ngroups,
                                                        int companions) {
-  constexpr int G = coop_members(H);
   constexpr int HS = H / G;            // units per member
-  constexpr int KS = k_split(H);       // ways the K dimension is split over waves
+  constexpr int KS = k_split_g(H, G);  // ways the K dimension is split over waves
   constexpr int NUB = HS / 16;         // 16-unit blocks of this member
   constexpr int UB = (NUB * KS) / 4 > 0 ? (NUB * KS) / 4 : 1;   // blocks per wave (4 compute waves)
   constexpr int KC = H / 32;
@@ -149,7 +151,7 @@ __global__ __launch_bounds__(256) void lstm_fwd_kernel(float* __restrict__ xproj
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int gstride = (ngroups + 7) & ~7;        // members of a group are 8k blocks apart: one XCD under round-robin
   const int nblk = gstride * G;                  // compute workgroups; the blocks beyond them: CPG prefetch companions per group
-  constexpr int CPG = group_companions(H);
+  constexpr int CPG = group_companions_g(G);
   const bool companion = (int)blockIdx.x >= nblk;
   const int cblk = companion ? blockIdx.x - nblk : blockIdx.x;
   // Blocks are laid out in chunks of 8 groups: block = chunk * 8 * G + member * 8 + group % 8.  The members of a group are
@@ -254,6 +256,18 @@ __global__ __launch_bounds__(256) void lstm_fwd_kernel(float* __restrict__ xproj
                                                           ((int64_t)((ublk * KC + kh * KCW + kc) * 4 + g) * 64 + lane) * 8);
   }
   __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0): the weights are in registers before the time loop, not waited for inside it
+  // More than 128 weight registers (512 units as 8 members: 256) do not fit the 256 architectural VGPRs next to the step's
+  // own values.  Left to itself the allocator keeps such weights in AccVGPRs as SPILLS and copies them back through
+  // v_accvgpr_read before every product that uses them (four VALU instructions per MFMA: the product phase of a step took
+  // twice the MFMAs' own time).  An MFMA reads its B operand from an AccVGPR directly, so the weights are pinned there.
+  if constexpr (UB * KCW * 4 * 4 > 128) {
+#pragma unroll
+    for (int ub = 0; ub < UB; ++ub)
+#pragma unroll
+      for (int kc = 0; kc < KCW; ++kc)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) asm("" : "+a"(wf[ub][kc][g]));
+  }
 
   float c[UB][RL], h[UB][RL];
 #pragma unroll
@@ -514,14 +528,13 @@ __global__ __launch_bounds__(256) void lstm_fwd_kernel(float* __restrict__ xproj
 // is 4 x (G-1) granules each way, against 8 x 4 x (G-1) for an all-gather of dz_t.
 // kh is K_h [H, 4H] in bf16 with GATE-INTERLEAVED columns (u*4+g): a member's K range is contiguous.
 // ------------------------------------------------------------------------------------------------
-template <int H, int ROWS>            // ROWS: utterances per slice, as in lstm_fwd_kernel
+template <int H, int ROWS, int G = coop_members(H)>            // ROWS: utterances per slice, G: members, as in lstm_fwd_kernel
 __global__ __launch_bounds__(256) void lstm_bwd_kernel(const float* __restrict__ gates, const float* __restrict__ cbuf,
                                                        const float* __restrict__ dy, const float* __restrict__ dc_last,
                                                        const float* __restrict__ dh_last, const unsigned short* __restrict__ kh,
                                                        const int32_t* __restrict__ length, unsigned short* __restrict__ dz,
                                                        u64* __restrict__ exch, unsigned* __restrict__ status,
                                                        int B, int T, int ndir, int ngroups) {
-  constexpr int G = coop_members(H);
   constexpr int HS = H / G;
   constexpr int NUB = HS / 16;                    // 16-unit blocks of a member
   constexpr bool SPLIT = NUB < 4;                 // H = 512: two waves share a unit block, two rows of every quad each
@@ -544,7 +557,7 @@ __global__ __launch_bounds__(256) void lstm_bwd_kernel(const float* __restrict__
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int gstride = (ngroups + 7) & ~7;
   const int nblk = gstride * G;
-  constexpr int CPG = group_companions(H);
+  constexpr int CPG = group_companions_g(G);
   const bool companion = (int)blockIdx.x >= nblk;                // CPG per group (see lstm_fwd_kernel)
   const int cblk = companion ? blockIdx.x - nblk : blockIdx.x;
   const int per = 8 * (companion ? CPG : G), chunk = cblk / per, within = cblk % per;     // chunks of 8 groups (lstm_fwd_kernel)
@@ -650,6 +663,7 @@ __global__ __launch_bounds__(256) void lstm_bwd_kernel(const float* __restrict__
     for (int kc = 0; kc < KCW; ++kc)
       wf[j][kc] = *reinterpret_cast<const bf16x8*>(khd + (int64_t)n * 4 * H + member * 4 * HS + kc * 32 + 8 * lq);
   }
+  constexpr bool W_AGPR = NT * KCW * 4 > 128;       // (see lstm_fwd_kernel: weights beyond 128 registers live in AccVGPRs)
 
   const int unit0 = member * HS + blk * 16 + l15;                // + ub*16
   float dc[UBW][RPL], dh[UBW][RPL], part[UBW][RPL];
@@ -664,6 +678,12 @@ __global__ __launch_bounds__(256) void lstm_bwd_kernel(const float* __restrict__
       part[ub][r] = 0.f;
     }
   __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0): weights and initial state are in registers before the time loop
+  if constexpr (W_AGPR) {
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int kc = 0; kc < KCW; ++kc) asm("" : "+a"(wf[j][kc]));
+  }
   if (tid == 0) fail_flag = 0;
   __syncthreads();
   const bool local = xcd_colocated<G>(exch + 2 * par_stride + (int64_t)group * G, member, &colo_flag, status);
@@ -786,7 +806,7 @@ __global__ __launch_bounds__(256) void lstm_bwd_kernel(const float* __restrict__
         for (int r = 0; r < RPL; ++r) cand[ub][r] = part[ub][r];
       if constexpr (G > 1) {
         const char* src = reinterpret_cast<const char*>(ex_group + (int64_t)((epoch - 1) & 1) * par_stride);
-        constexpr int CH = PER > 16 ? 16 : PER;
+        constexpr int CH = PER / ((PER + 15) / 16);      // polling rounds of at most 16 granules in flight (28 -> 2 x 14)
         static_assert(PER % CH == 0, "sweep chunking");
 #pragma unroll
         for (int c0 = 0; c0 < PER; c0 += CH) {
@@ -867,8 +887,17 @@ __global__ __launch_bounds__(256) void lstm_bwd_kernel(const float* __restrict__
     LSTM_STAMP(2048, smax - 1 - s, 3);
     lds_barrier();
     LSTM_STAMP(2048, smax - 1 - s, 4);
-    if (fail_flag) { ok = false; return false; }
-    if (s == 0) return false;                // dh_{-1} is not needed
+    // Exchanging chains read the timeout flag together with the A fragments and test it when those arrive: a read-and-branch
+    // right behind the barrier is an LDS round trip of its own on the critical path of every step (256 units: 1.10 -> 1.05 us
+    // per step, 512 units: 2.60 -> 2.50).  The single-workgroup chains keep the early test (there the late one costs: 128
+    // units 1.26 -> 1.42 us; so does it in the forward kernel, 0.87 -> 0.95: measured, left alone).
+    int failed = 0;
+    if constexpr (G > 1) failed = *reinterpret_cast<volatile int*>(&fail_flag);
+    else if (fail_flag) { ok = false; return false; }
+    if (s == 0) {                            // dh_{-1} is not needed
+      if (failed) ok = false;
+      return false;
+    }
 
     // ---- partial dh_{s-1}[all units] = dz_s[16, own 4*HS] * K_h^T ----
     f32x4 acc[NT];
@@ -879,6 +908,7 @@ __global__ __launch_bounds__(256) void lstm_bwd_kernel(const float* __restrict__
     bf16x8 afr[KCW];
 #pragma unroll
     for (int kc = 0; kc < KCW; ++kc) afr[kc] = *reinterpret_cast<const bf16x8*>(zl + l15 * ZS + kc * 32 + 8 * lq);
+    if (failed) { ok = false; return false; }
     if constexpr (G > 1) {
       char* dst = reinterpret_cast<char*>(ex_group + (int64_t)(epoch & 1) * par_stride);
 #pragma unroll
@@ -923,9 +953,18 @@ __global__ __launch_bounds__(256) void lstm_bwd_kernel(const float* __restrict__
 
 struct CoopGeom { int nslices, ngroups, G, blocks, companions; size_t exch_bytes; };
 
-CoopGeom geom(int B, int H, int ndir, bool bwd, int rows = 16) {
+// members per chain at run time: 512 units run as 8 members of 64 units (default since round 3; LAS_LSTM_G512=16 selects the
+// round-2 form: 16 members of 32 units with the K split / row split inside the workgroup)
+int members(int H) {
+  if (H != 512) return coop_members(H);
+  const char* e = getenv("LAS_LSTM_G512");          // read at every launch: tests and A/B runs switch it
+  const int g = e ? atoi(e) : 8;
+  return g == 16 ? 16 : 8;
+}
+
+CoopGeom geom(int B, int H, int ndir, bool bwd, int rows = 16, int G = 0) {
   CoopGeom g;
-  g.G = coop_members(H);
+  g.G = G > 0 ? G : members(H);
   g.nslices = (B + rows - 1) / rows;
   g.ngroups = g.nslices * ndir;
   g.blocks = ((g.ngroups + 7) & ~7) * g.G;        // group stride rounded up to 8 (idle blocks exit at once)
@@ -934,7 +973,7 @@ CoopGeom geom(int B, int H, int ndir, bool bwd, int rows = 16) {
   const size_t HS = H / g.G;
   const size_t per_parity = bwd ? (size_t)g.ngroups * g.G * g.G * (HS / 16) * 256 : (size_t)g.ngroups * g.G * (rows >= 8 ? rows / 2 : rows) * HS;
   g.exch_bytes = (2 * per_parity + (size_t)g.ngroups * g.G + g.blocks) * sizeof(u64);   // + XCC-id table + done words (G = 1: progress granules + done words)
-  g.companions = ((g.ngroups + 7) & ~7) * group_companions(H);   // prefetch companions (blocks nblk ...)
+  g.companions = ((g.ngroups + 7) & ~7) * group_companions_g(g.G);   // prefetch companions (blocks nblk ...)
   return g;
 }
 
@@ -943,7 +982,7 @@ CoopGeom geom(int B, int H, int ndir, bool bwd, int rows = 16) {
 int slice_rows(int B, int H, int ndir, bool bwd) {
   const char* e = getenv("LAS_LSTM_ROWS");          // read at every launch: the tests switch it
   const int forced = e ? atoi(e) : 0;
-  if (H > 256) {                        // the 512-unit kernels (K split, row split): 16 or 8 rows
+  if (H > 256 && members(H) == 16) {    // the 16-member 512-unit kernels (K split, row split): 16 or 8 rows
     static int r512 = -1;               // LAS_LSTM_ROWS512=16 / 8: the default for both directions (diagnostics)
     if (r512 < 0) {
       const char* e5 = getenv("LAS_LSTM_ROWS512");
@@ -981,39 +1020,44 @@ int prefetch_mode() {
   return mode;
 }
 
-template <int H>
-int launch_fwd(float* xproj, const las_bf16* wp, const int32_t* length, las_bf16* y, float* cbuf, float* c_last,
-               float* h_last, void* ws, int B, int T, int ndir, hipStream_t st) {
-  const int rows = slice_rows(B, H, ndir, false);
-  const CoopGeom g = geom(B, H, ndir, false, rows);
+template <int H, int ROWS, int G>
+int launch_fwd_as(float* xproj, const las_bf16* wp, const int32_t* length, las_bf16* y, float* cbuf, float* c_last, float* h_last,
+                  void* ws, int B, int T, int ndir, hipStream_t st) {
+  const CoopGeom g = geom(B, H, ndir, false, ROWS, G);
   unsigned* status = reinterpret_cast<unsigned*>(ws);
   u64* exch = reinterpret_cast<u64*>(reinterpret_cast<char*>(ws) + 64);
   const int pf = prefetch_mode();
-  if (rows == 8) {
-    hipLaunchKernelGGL((lstm_fwd_kernel<H, 8>), dim3(pf ? g.blocks + g.companions : g.blocks), dim3(256), 0, st, xproj, wp, length, y,
-                       cbuf, c_last, h_last, exch, status, B, T, ndir, g.ngroups, pf);
-    LAS_LAUNCH_CHECK("lstm fwd launch");
-    return LAS_OK;
-  }
-  if constexpr (H <= 256) {
-    if (rows == 4) {
-      hipLaunchKernelGGL((lstm_fwd_kernel<H, 4>), dim3(pf ? g.blocks + g.companions : g.blocks), dim3(256), 0, st, xproj, wp, length, y,
-                         cbuf, c_last, h_last, exch, status, B, T, ndir, g.ngroups, pf);
-      LAS_LAUNCH_CHECK("lstm fwd launch");
-      return LAS_OK;
-    }
-  }
-  hipLaunchKernelGGL((lstm_fwd_kernel<H, 16>), dim3(pf ? g.blocks + g.companions : g.blocks), dim3(256), 0, st, xproj, wp, length, y,
+  hipLaunchKernelGGL((lstm_fwd_kernel<H, ROWS, G>), dim3(pf ? g.blocks + g.companions : g.blocks), dim3(256), 0, st, xproj, wp, length, y,
                      cbuf, c_last, h_last, exch, status, B, T, ndir, g.ngroups, pf);
   LAS_LAUNCH_CHECK("lstm fwd launch");
   return LAS_OK;
 }
 
 template <int H>
-int launch_bwd(const float* gates, const float* cbuf, const float* dy, const float* dc_last, const float* dh_last,
-               const las_bf16* kh, const int32_t* length, las_bf16* dz, void* ws, int B, int T, int ndir, hipStream_t st) {
-  const int rows = slice_rows(B, H, ndir, true);
-  const CoopGeom g = geom(B, H, ndir, true, rows);
+int launch_fwd(float* xproj, const las_bf16* wp, const int32_t* length, las_bf16* y, float* cbuf, float* c_last,
+               float* h_last, void* ws, int B, int T, int ndir, hipStream_t st) {
+  const int rows = slice_rows(B, H, ndir, false);
+#define LAS_FWD(R, GG) return launch_fwd_as<H, R, GG>(xproj, wp, length, y, cbuf, c_last, h_last, ws, B, T, ndir, st)
+  if constexpr (H == 512) {
+    if (members(H) == 8) {
+      if (rows == 4) LAS_FWD(4, 8);
+      if (rows == 8) LAS_FWD(8, 8);
+      LAS_FWD(16, 8);
+    }
+  }
+  constexpr int G0 = coop_members(H);
+  if (rows == 8) LAS_FWD(8, G0);
+  if constexpr (H <= 256) {
+    if (rows == 4) LAS_FWD(4, G0);
+  }
+  LAS_FWD(16, G0);
+#undef LAS_FWD
+}
+
+template <int H, int ROWS, int G>
+int launch_bwd_as(const float* gates, const float* cbuf, const float* dy, const float* dc_last, const float* dh_last,
+                  const las_bf16* kh, const int32_t* length, las_bf16* dz, void* ws, int B, int T, int ndir, hipStream_t st) {
+  const CoopGeom g = geom(B, H, ndir, true, ROWS, G);
   unsigned* status = reinterpret_cast<unsigned*>(ws);
   u64* exch = reinterpret_cast<u64*>(reinterpret_cast<char*>(ws) + 64);
   const int pf = prefetch_mode();
@@ -1025,35 +1069,38 @@ int launch_bwd(const float* gates, const float* cbuf, const float* dy, const flo
   static int hog_kb = -1;
   if (hog_kb < 0) {
     const char* e = getenv("LAS_LSTM_BWD_LDS_KB");
-    constexpr int HS_ = H / coop_members(H);
+    constexpr int HS_ = H / G;
     constexpr int static_kb = (2 * 16 * (4 * HS_ + 8) * 2 + 1024 + 1023) / 1024 + 1;
     hog_kb = e ? atoi(e) : 160 - static_kb - 6;
     if (hog_kb > 160 - static_kb - 2) hog_kb = 160 - static_kb - 2;
-    if (hog_kb > 0) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&lstm_bwd_kernel<H, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, hog_kb * 1024);
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&lstm_bwd_kernel<H, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, hog_kb * 1024);
-      if constexpr (H <= 256)
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&lstm_bwd_kernel<H, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, hog_kb * 1024);
-    }
+    if (hog_kb > 0)
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&lstm_bwd_kernel<H, ROWS, G>), hipFuncAttributeMaxDynamicSharedMemorySize, hog_kb * 1024);
   }
-  if (rows == 8) {
-    hipLaunchKernelGGL((lstm_bwd_kernel<H, 8>), dim3(pf ? g.blocks + g.companions : g.blocks), dim3(256), (size_t)hog_kb * 1024, st, gates, cbuf, dy,
-                       dc_last, dh_last, kh, length, dz, exch, status, B, T, ndir, g.ngroups);
-    LAS_LAUNCH_CHECK("lstm bwd launch");
-    return LAS_OK;
-  }
-  if constexpr (H <= 256) {
-    if (rows == 4) {
-      hipLaunchKernelGGL((lstm_bwd_kernel<H, 4>), dim3(pf ? g.blocks + g.companions : g.blocks), dim3(256), (size_t)hog_kb * 1024, st, gates, cbuf, dy,
-                         dc_last, dh_last, kh, length, dz, exch, status, B, T, ndir, g.ngroups);
-      LAS_LAUNCH_CHECK("lstm bwd launch");
-      return LAS_OK;
-    }
-  }
-  hipLaunchKernelGGL((lstm_bwd_kernel<H, 16>), dim3(pf ? g.blocks + g.companions : g.blocks), dim3(256), (size_t)hog_kb * 1024, st, gates, cbuf, dy, dc_last, dh_last, kh,
-                     length, dz, exch, status, B, T, ndir, g.ngroups);
+  hipLaunchKernelGGL((lstm_bwd_kernel<H, ROWS, G>), dim3(pf ? g.blocks + g.companions : g.blocks), dim3(256), (size_t)(hog_kb > 0 ? hog_kb : 0) * 1024, st,
+                     gates, cbuf, dy, dc_last, dh_last, kh, length, dz, exch, status, B, T, ndir, g.ngroups);
   LAS_LAUNCH_CHECK("lstm bwd launch");
   return LAS_OK;
+}
+
+template <int H>
+int launch_bwd(const float* gates, const float* cbuf, const float* dy, const float* dc_last, const float* dh_last,
+               const las_bf16* kh, const int32_t* length, las_bf16* dz, void* ws, int B, int T, int ndir, hipStream_t st) {
+  const int rows = slice_rows(B, H, ndir, true);
+#define LAS_BWD(R, GG) return launch_bwd_as<H, R, GG>(gates, cbuf, dy, dc_last, dh_last, kh, length, dz, ws, B, T, ndir, st)
+  if constexpr (H == 512) {
+    if (members(H) == 8) {
+      if (rows == 4) LAS_BWD(4, 8);
+      if (rows == 8) LAS_BWD(8, 8);
+      LAS_BWD(16, 8);
+    }
+  }
+  constexpr int G0 = coop_members(H);
+  if (rows == 8) LAS_BWD(8, G0);
+  if constexpr (H <= 256) {
+    if (rows == 4) LAS_BWD(4, G0);
+  }
+  LAS_BWD(16, G0);
+#undef LAS_BWD
 }
 
 bool supported_units(int H) { return H == 64 || H == 128 || H == 256 || H == 512; }
@@ -1068,11 +1115,12 @@ extern "C" int las_lstm_slice_rows(int B, int H, int ndir) {
 extern "C" size_t las_lstm_workspace_bytes(int B, int H, int ndir) {
   if (!supported_units(H) || B <= 0) return 0;
   size_t n = 0;
-  for (int rows = 4; rows <= 16; rows *= 2)
-    for (int bwd = 0; bwd < 2; ++bwd) {
-      const size_t e = geom(B, H, ndir, bwd != 0, rows).exch_bytes;
-      if (e > n) n = e;
-    }
+  for (int G = (H == 512 ? 8 : coop_members(H)); G <= (H == 512 ? 16 : coop_members(H)); G *= 2)      // every member count the launches may take
+    for (int rows = 4; rows <= 16; rows *= 2)
+      for (int bwd = 0; bwd < 2; ++bwd) {
+        const size_t e = geom(B, H, ndir, bwd != 0, rows, G).exch_bytes;
+        if (e > n) n = e;
+      }
   return 64 + n;
 }
 

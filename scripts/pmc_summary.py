@@ -3,7 +3,7 @@
 # (FETCH_SIZE is tallied at half for wide streaming reads on gfx950: doubled, MI355X_MICROARCH.md "HBM"; WRITE_SIZE as read;
 # both in KiB), MFMA-busy cycles and GUI-active cycles, next to the algorithmic bytes of the metric-M shapes.
 import csv, glob, json, sys
-rnd = sys.argv[1] if len(sys.argv) > 1 else 'r02'
+rnd = sys.argv[1] if len(sys.argv) > 1 else 'r03'
 FAMILIES = {'lstm_fwd': 'lstm_fwd_kernel', 'lstm_bwd': 'lstm_bwd_kernel', 'dec_persist_fwd': 'dec_persist_fwd_',
             'dec_persist_bwd': 'dec_persist_bwd_kernel', 'gemm_nt': 'gemm_nt_ring_kernel', 'gemm_tn_lstm': 'gemm_tn_ring_kernel', 'gemm_tn': 'gemm_tn_tr_kernel'}
 B, T, H = 64, 800, 256
@@ -43,4 +43,9 @@ for fam, d in per.items():
             k['mfma_busy_fraction_of_chip'] = round(k['sq_valu_mfma_busy_cycles'] / (k['grbm_gui_active_sum_over_8_xcd'] / 8 * 1024), 4)
     out['kernels'][fam] = k
     print(fam, k)
+# the build these counters belong to: bench.py compares it with the build it times and reports `traffic_stale`
+import sys as _sys
+_sys.path.insert(0, '.')
+import bench as _bench
+out['csrc_digest'] = _bench.csrc_digest()
 json.dump(out, open('gpurun_out/%s_pmc_traffic.json' % rnd, 'w'), indent=1)

@@ -92,6 +92,18 @@ def test_bilstm_forward_backward_vs_oracle(B, T, D, H, lengths, rows, monkeypatc
     assert _relerr(dx, xr.grad) < 1e-2
 
 
+@pytest.mark.parametrize('g512,rows', [(8, 0), (8, 4), (8, 8), (8, 16), (16, 0), (16, 8)])
+@pytest.mark.parametrize('B,T', [(19, 14), (70, 9)])
+def test_512_unit_chains_as_8_or_16_members(g512, rows, B, T, monkeypatch):
+    """The 512-unit recurrences in both member counts (LAS_LSTM_G512): 8 members of 64 units (round 3, the default: one
+    16-unit block per wave over the whole K, no hand-over inside the workgroup, 7 peers; 4-, 8- and 16-row slices) and the
+    round-2 form of 16 members of 32 units (K split forward, row split backward; 8- and 16-row slices).  B=70: several
+    slices per direction with a ragged tail."""
+    monkeypatch.setenv('LAS_LSTM_G512', str(g512))
+    lengths = [T - (i * 5) % T for i in range(B)]
+    test_bilstm_forward_backward_vs_oracle(B, T, 24, 512, lengths, rows, monkeypatch)
+
+
 def test_unidirectional_and_pyramid_view():
     from oracle import las_oracle as O
     from phones_las_amd.las import ops
