@@ -784,7 +784,8 @@ class LasModel:
     def train_step(self, features, labels, num_steps=None):
         """One optimiser step; returns the loss (audio loss + L2 term) as a device scalar tensor."""
         self.vars.grad.zero_()
-        audio_loss, _, dlogits = self.forward_train(features, labels, num_steps)
+        audio_loss, logits, dlogits = self.forward_train(features, labels, num_steps)
+        self.last_train_logits = logits          # (train_edit_distance: the TRAIN-mode metric of model_helper.py:299-317,435-439)
         if getattr(self, 'exchange_overlap', False):
             self.backward_exchange_end(self.backward_exchange_begin(dlogits))
             self.adam_update()
@@ -795,6 +796,21 @@ class LasModel:
         self.maybe_add_noise()
         self.global_step += 1         # (the weight images are stale now: the next forward rebuilds them, see refresh_images)
         return loss
+
+    def train_edit_distance(self, labels):
+        """Mean normalised edit distance of the LAST train step's teacher-forced outputs against its targets: what the
+        reference's LoggingTensorHook prints beside the loss every 10 iterations (model_helper.py:299-317: sample ids =
+        argmax of the first decoder's logits -- phone logits, or for a lone sigmoid-output decoder its feature logits, as
+        model_helper.py:251 writes it -- `utils.edit_distance(..., eos_id, mapping)`; :435-439: the last batch's mean).
+        Synchronises (one argmax + a [B, U] int copy): call it at logging steps only."""
+        logits = getattr(self, 'last_train_logits', None)
+        if logits is None:
+            return None
+        width = getattr(self.speller, 'Vo', self.speller.V)
+        ids = logits[..., :width].argmax(-1).to(torch.int32).cpu().numpy()
+        tout = labels['targets_outputs']
+        tout = (tout.cpu().numpy() if torch.is_tensor(tout) else np.asarray(tout))[:, :ids.shape[1]]
+        return float(np.mean(metrics_utils.edit_distance(ids, tout, self.params.decoder.eos_id, self.params.mapping)))
 
     # -- inference ------------------------------------------------------------------------------
     def predict(self, features, transparent_projection=False):

@@ -41,9 +41,13 @@ def test_train_resume_infer(tmp_path, capsys):
     train.main(train.parse_args(common + ['--num_epochs', '800']))      # 16 utts / 16 = 1 step per epoch -> 800 steps
     out = capsys.readouterr().out
     assert 'finished at global_step 800' in out
-    first = float(out.split('step 10: loss = ')[1].split()[0])
-    last = float(out.split('step 800: loss = ')[1].split()[0])
+    first = float(out.split('step 10: loss = ')[1].split()[0].rstrip(','))
+    last = float(out.split('step 800: loss = ')[1].split()[0].rstrip(','))
     assert last < 0.2 * first
+    # the reference's TRAIN-mode log line carries the last batch's mean edit distance beside the loss (model_helper.py:435-439)
+    ed_first = float(out.split('step 10: loss = ')[1].split('edit_distance = ')[1].split()[0])
+    ed_last = float(out.split('step 800: loss = ')[1].split('edit_distance = ')[1].split()[0])
+    assert ed_first > 0.3 and ed_last < 0.05, (ed_first, ed_last)
     assert os.path.exists(os.path.join(d, 'model', 'hparams.json'))
     # resume: the checkpoint restores the step counter; hparams.json wins over the (different) CLI value
     train.main(train.parse_args(common + ['--num_epochs', '5', '--encoder_units', '128']))
@@ -108,8 +112,8 @@ def test_train_with_the_reference_default_architecture_flags(tmp_path, capsys):
                                  '--num_channels', '13', '--batch_size', '8', '--num_epochs', '30']))
     out = capsys.readouterr().out
     assert 'finished at global_step 30' in out
-    first = float(out.split('step 10: loss = ')[1].split()[0])
-    last = float(out.split('step 30: loss = ')[1].split()[0])
+    first = float(out.split('step 10: loss = ')[1].split()[0].rstrip(','))
+    last = float(out.split('step 30: loss = ')[1].split()[0].rstrip(','))
     assert np.isfinite(last) and last < first
     # the same (stacked, per-layer encoder states: no 'embedding' in the predictions, model_helper.py:259-268) through infer.py
     import infer
@@ -132,8 +136,8 @@ def test_train_resume_infer_with_unit_counts_the_kernels_are_not_built_for(tmp_p
     train.main(train.parse_args(common + ['--num_epochs', '200']))
     out = capsys.readouterr().out
     assert 'finished at global_step 200' in out
-    first = float(out.split('step 10: loss = ')[1].split()[0])
-    last = float(out.split('step 200: loss = ')[1].split()[0])
+    first = float(out.split('step 10: loss = ')[1].split()[0].rstrip(','))
+    last = float(out.split('step 200: loss = ')[1].split()[0].rstrip(','))
     assert last < 0.5 * first
     hp = json.load(open(os.path.join(d, 'model', 'hparams.json')))
     hp = json.loads(hp) if isinstance(hp, str) else hp
@@ -185,8 +189,8 @@ def test_binary_feature_cli_modes_train_and_infer(tmp_path, capsys, mode):
                                  '--batch_size', '16', '--num_channels', '13', '--learning_rate', '0.002', '--num_epochs', '300'] + flags))
     out = capsys.readouterr().out
     assert 'finished at global_step 300' in out
-    first = float(out.split('step 10: loss = ')[1].split()[0])
-    last = float(out.split('step 300: loss = ')[1].split()[0])
+    first = float(out.split('step 10: loss = ')[1].split()[0].rstrip(','))
+    last = float(out.split('step 300: loss = ')[1].split()[0].rstrip(','))
     assert np.isfinite(last) and last < 0.6 * first, (first, last)
     base = ['--data', os.path.join(d, 'train.tfr'), '--vocab', os.path.join(d, 'vocab.txt'), '--norm', os.path.join(d, 'norm.dmp'),
             '--model_dir', os.path.join(d, 'model'), '--num_channels', '13', '--batch_size', '8', '--binf_map', binf]

@@ -189,9 +189,11 @@ def main(args):
         if model.global_step % 10 == 0:                            # LoggingTensorHook(every_n_iter=10)
             lv = dp.mean_scalar(float(loss))
             model.check_device_status()          # bounded waits of the persistent kernels: fail loudly, never silently
+            dt = time.time() - t_last            # (before the metric below: its argmax + copy are not the step loop's time)
+            # the reference's train_log_data (model_helper.py:435-439): loss and the last batch's mean edit distance
+            ed = dp.mean_scalar(model.train_edit_distance(l))
             if rank == 0:
-                dt = time.time() - t_last
-                print('step %d: loss = %.5f (%.2f utt/s)' % (model.global_step, lv, 10 * global_batch / max(dt, 1e-9)))
+                print('step %d: loss = %.5f, edit_distance = %.5f (%.2f utt/s)' % (model.global_step, lv, ed, 10 * global_batch / max(dt, 1e-9)))
             t_last = time.time()
             if model.global_step == 10:          # throughput of the run without its first steps (allocations, indexing)
                 n_utt, t_log = 0, time.time()
