@@ -169,7 +169,8 @@ class DecoderHP:
     binf_projection: bool = False
     binf_count: int = 0
     binf_projection_reg_weight: float = 1.0
-    binf_map: Optional[object] = None        # [binf_count, V] 0/1 matrix (utils.load_binf2phone); not a trainable variable
+    binf_map: Optional[object] = None        # [binf_count, V] 0/1 matrix (utils.load_binf2phone); a constant ...
+    binf_trainable: bool = False             # ... unless --binf_trainable: variable 'binf2phone', U(0,1) init (model_helper.py:182-184)
     max_symbols: int = -1
 
 
@@ -252,6 +253,8 @@ def param_table(hp: HP) -> List[Tuple[str, Tuple[int, ...], str]]:
     H = e.num_units
     dirs = ['fw'] if e.unidirectional else ['fw', 'bw']
     out: List[Tuple[str, Tuple[int, ...], str]] = []
+    if (d.binary_outputs or d.binf_projection) and d.binf_trainable:             # model_helper.py:181-184
+        out.append(('binf2phone', (d.binf_count, d.target_vocab_size), 'uniform01'))
     D = hp.num_channels
     for l in range(e.num_layers):
         for dr in dirs:
@@ -289,6 +292,8 @@ def init_params(hp: HP, seed: int = 4321, bias_scale: float = 0.0) -> Dict[str, 
         elif init == 'glorot_v':
             lim = math.sqrt(6.0 / (shape[0] + 1))
             a = rng.uniform(-lim, lim, size=shape)
+        elif init == 'uniform01':
+            a = rng.uniform(0.0, 1.0, size=shape)
         else:
             a = rng.uniform(-bias_scale, bias_scale, size=shape) if bias_scale > 0 else np.zeros(shape)
         p[name] = torch.tensor(a.astype(np.float32).astype(np.float64), dtype=DT)
@@ -498,6 +503,7 @@ class Speller:
         self.kind = kind or speller_plan(hp.decoder)[0][1]
         self.q = make_q(mxu)
         self.att = Attention(hp, params, memory, mem_len, self.q, train, noise, scope)
+        self.p_all = params                      # (variables outside the decoder's scope: the trainable binf2phone)
         self.p = self.att.p
         params = self.p
         self.B = memory.shape[0]
@@ -525,8 +531,15 @@ class Speller:
         if d.embedding_size:
             return self.q(self.p['speller/target_embedding'])[ids]
         if self.kind in ('binf_projection', 'sigmoid'):                          # las/model.py:237-243
-            return torch.as_tensor(d.binf_map, dtype=DT).t()[ids]
+            return self.binf_map().t()[ids]
         return torch.nn.functional.one_hot(ids, d.target_vocab_size).to(DT)
+
+    def binf_map(self):
+        """binf_embedding of model_helper.py:181-186: the constant map, or the trainable variable (bf16 as a GEMM operand
+        and as the token feed on the device: rounded here too in the bf16 model)."""
+        if self.d.binf_trainable:
+            return self.q(self.p_all['binf2phone'])
+        return torch.as_tensor(self.d.binf_map, dtype=DT)
 
     def project(self, out):
         """projection_layer of las/model.py:251-257 (DenseBinfDecoder, utils/training_helper.py:122-153); for the
@@ -536,7 +549,7 @@ class Speller:
             return out @ q(p['speller/projection_layer/kernel']) + p['speller/projection_layer/bias']
         # inner_projection_layer=False: the cell output IS [log p(feature=1) | log p(feature=0)]; the Dense kernel and
         # bias exist as variables but are not applied.  transform_binf_to_phones (:17-27); TRAIN concatenates the input.
-        Mb = torch.as_tensor(d.binf_map, dtype=DT)
+        Mb = self.binf_map()
         nf = Mb.shape[0]
         if out.shape[1] != 2 * nf:
             raise ValueError('binf_projection needs the decoder output to be the 2*binf_count attention vector')

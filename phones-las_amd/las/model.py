@@ -137,7 +137,7 @@ _ATT = {'luong': hip.ATT_LUONG, 'bahdanau': hip.ATT_BAHDANAU, 'custom': hip.ATT_
 _ATT_FUSED = ('luong', 'bahdanau')            # mechanisms of the fused single-cell fast path
 
 
-def make_speller(hparams, variables, memory_depth, binf2phone=None, scope='speller', phones_only=False):
+def make_speller(hparams, variables, memory_depth, binf2phone=None, scope='speller', phones_only=False, binf_var=None):
     """The decoder for ``hparams``: the fused single-cell path when the configuration allows it, else the general
     cell stack (speller_general.GeneralSpeller: multi-layer, --bottom_only AttentionMultiCell, attention layer,
     embedding, the two binary-feature decoders).  phones_only: the plain phone decoder of a --multitask model (the
@@ -153,7 +153,8 @@ def make_speller(hparams, variables, memory_depth, binf2phone=None, scope='spell
         return Speller(hparams, variables, memory_depth)
     from .speller_general import GeneralSpeller
     return GeneralSpeller(hparams, variables, memory_depth, _ATT[d.attention_type],
-                          binf2phone=binf2phone if (binf or sigmoid) else None, sigmoid=sigmoid, scope=scope)
+                          binf2phone=binf2phone if (binf or sigmoid) else None, sigmoid=sigmoid, scope=scope,
+                          binf_var=binf_var if (binf or sigmoid) else None)
 
 
 class Speller:

@@ -52,7 +52,7 @@ def gather_tree(step_ids, parent_ids, max_len, end_token):
 class GeneralSpeller:
     NOISE_STREAM = 3                     # generator stream of the monotonic-attention score noise (draw (t*B + b)*Tm + t')
 
-    def __init__(self, hparams, variables, memory_depth, att_code, binf2phone=None, sigmoid=False, scope='speller'):
+    def __init__(self, hparams, variables, memory_depth, att_code, binf2phone=None, sigmoid=False, scope='speller', binf_var=None):
         """binf2phone [binf_count, V] (0/1, constant): the --binf_projection decoder (las/model.py:179-183,242-257,
         utils/training_helper.py:17-27,122-153): tokens are fed as their binary-feature vectors, the attention layer
         emits A = 2*binf_count values [log p(f=1) | log p(f=0)] and the 'projection' is the fixed map
@@ -63,8 +63,19 @@ class GeneralSpeller:
         token, rows of binf2phone^T; inference: the rounded sigmoid of the previous output), the projection is a plain
         Dense(binf_count) and its outputs are feature logits.  binf2phone may then be None (inference without a map).
         scope: variable-name prefix ('speller'; the second decoder of --multitask lives under 'speller_binf',
-        model_helper.py:219-227)."""
+        model_helper.py:219-227).
+        binf_var: name of the TRAINABLE feature map among `variables` (--binf_trainable: model_helper.py:182-184 makes
+        binf2phone a variable initialised U(0, 1) instead of a constant; --binf_projection decoders only).  The token feed
+        (rows of Mb^T) and the output map [Mb; 1 - Mb] are then rebuilt from it at every refresh(), and backward() adds its
+        gradient: d(Mb) = (raw^T dlogits)[:nf] - (raw^T dlogits)[nf:] + (d embedded tokens)^T."""
         d = hparams
+        self.binf_var = binf_var
+        if binf_var is not None:
+            if sigmoid:
+                raise ValueError('--binf_trainable with the sigmoid-output decoder: the reference differentiates its sigmoid loss '
+                                 'through the TARGETS too (targets_binf is a lookup in the variable, model_helper.py:199); only '
+                                 '--binf_projection decoders take a trainable map on the HIP path')
+            binf2phone = variables[binf_var]
         self.scope = scope
         self.K_MEM, self.K_PROJ, self.B_PROJ = scope + '/memory_layer/kernel', scope + '/projection_layer/kernel', scope + '/projection_layer/bias'
         self.K_Q, self.V_ATT, self.K_AL = scope + '/query_layer/kernel', scope + '/attention_v', scope + '/attention_layer/kernel'
@@ -171,6 +182,12 @@ class GeneralSpeller:
     def refresh(self, var):
         Hd, M, V, Vp, E, A = self.Hd, self.M, self.V, self.Vp, self.E, self.A
         Vo, Vop = self.Vo, self.Vop
+        if self.binf_var is not None:      # trainable feature map: token feed and output map from the current values
+            Mb = var[self.binf_var]
+            self.emb_bf[:, :self.nf].copy_(Mb.t())
+            wb = torch.cat([Mb, 1.0 - Mb], 0)
+            self.wproj[:, :V].copy_(wb)
+            self.wprojT[:V].copy_(wb.t())
         hip.cast_bf16(var[self.K_MEM], M, Hd, self.wmemT, Hd, M, transpose=True)
         hip.cast_bf16(var[self.K_MEM], M, Hd, self.wmem, M, Hd)
         self.bias = []
@@ -493,7 +510,7 @@ class GeneralSpeller:
             carry = torch.zeros(B, Tmp, dtype=f32, device=dev)
         qlayer = 0 if self.bottom else NL - 1
         W = [w + Hd for w in self.win]
-        dtokx = torch.empty(B, U, self.Ep, dtype=bf, device=dev) if (self.tokx and self.feat is None and not self.sigmoid) else None
+        dtokx = torch.empty(B, U, self.Ep, dtype=bf, device=dev) if (self.tokx and (self.feat is None or self.binf_var is not None) and not self.sigmoid) else None
 
         def v(buf, off, ld):              # (address, row stride) of a column window of a [B, ld] fp32 buffer
             return (hip.addr(buf, off), ld)
@@ -598,6 +615,11 @@ class GeneralSpeller:
         if self.binf is None:
             hip.gemm_tn(sv['out'], dlogits, grads[self.K_PROJ], P, Vo, BU, lda=P, ldb=Vop, ldc=Vo, split_k=4)
             hip.colsum_bf16(dlogits, BU, Vo, grads[self.B_PROJ], ldx=Vop)
+        elif self.binf_var is not None:
+            # logits = raw [Mb; 1 - Mb]:  d(Mb) = (raw^T dlogits)[:nf] - (raw^T dlogits)[nf:]
+            dwb = torch.zeros(2 * self.nf, Vop, dtype=f32, device=dev)
+            hip.gemm_tn(sv['out'], dlogits, dwb, 2 * self.nf, Vop, BU, lda=P, ldb=Vop, ldc=Vop, split_k=4)
+            grads[self.binf_var].add_(dwb[:self.nf, :V] - dwb[self.nf:, :V])
         hip.gemm_tn(sv['memory'], dkeys_bf, grads[self.K_MEM], M, Hd, B * Tm, lda=M, ldb=Hd, ldc=Hd, split_k=8)
         if self.uses_wq:
             hip.gemm_tn(sv['h'][qlayer], dpq_all, grads[self.K_Q], Hd, Hd, BU, lda=Hd, ldb=Hd, ldc=Hd, split_k=4)
@@ -621,7 +643,10 @@ class GeneralSpeller:
                 hip.check(lib.las_onehot_bf16(hip.p(fed), fed.stride(0), B, U, V, hip.p(onehot), Vp, 1.0, 0, 0, 1, st))
                 dE = torch.zeros(V, self.Ep, dtype=f32, device=dev)
                 hip.gemm_tn(onehot, dtokx, dE, V, self.Ep, BU, lda=Vp, ldb=self.Ep, ldc=self.Ep, split_k=4)
-                grads[self.K_EMB].add_(dE[:, :self.E])
+                if self.binf_var is not None:        # the embedding table is Mb^T
+                    grads[self.binf_var].add_(dE[:, :self.nf].t())
+                else:
+                    grads[self.K_EMB].add_(dE[:, :self.E])
             d_state = None
             if sv['passed']:
                 d_state = [(dc[l], dx[l][0][:, self.win[l]:]) for l in range(sv['passed'])]
@@ -647,6 +672,10 @@ class GeneralSpeller:
                             accumulate=True)                                                                   # dRows K0^T
                 if dE is not grads[self.K_EMB]:
                     grads[self.K_EMB].add_(dE[:, :self.E])
+            elif self.binf_var is not None:          # the embedding table is Mb^T: d(Mb) += (dRows K0^T)^T
+                dE = torch.zeros(V, self.Ep, dtype=f32, device=dev)
+                hip.gemm_nt(dtok_bf, self.k0tok, dE, V, self.Ep, 4 * Hd, lda=4 * Hd, ldb=4 * Hd, ldc=self.Ep, accumulate=True)
+                grads[self.binf_var].add_(dE[:, :self.nf].t())
         d_state = None
         if sv['passed']:
             fin = (0) & 1                      # the buffers written by step t = 0

@@ -76,6 +76,9 @@ def param_layout(params):
     e, d = params.encoder, params.decoder
     dirs = ['fw'] if e.unidirectional else ['fw', 'bw']
     out = []
+    if bool(getattr(d, 'binary_outputs', False)) and bool(getattr(d, 'binf_trainable', False)):
+        # --binf_trainable: the feature map is a variable, U(0, 1) initialised, created before the listener (model_helper.py:182-184)
+        out.append(('binf2phone', ([d.binf_count], [d.target_vocab_size]), 'uniform01'))
     D = [params.num_channels]
     for l in range(e.num_layers):
         for dr in dirs:
@@ -186,6 +189,8 @@ def _init_array(shape, init, rng):
     if init == 'glorot_v':
         lim = math.sqrt(6.0 / (shape[0] + 1))
         return rng.uniform(-lim, lim, size=shape)
+    if init == 'uniform01':                            # tf.random_uniform_initializer(0., 1.): the trainable binf2phone map
+        return rng.uniform(0.0, 1.0, size=shape)
     return np.zeros(shape)
 
 
@@ -461,9 +466,19 @@ class LasModel:
         binary = bool(getattr(d, 'binary_outputs', False))
         self.binf_projection = binary and bool(getattr(d, 'binf_projection', False))
         self.sigmoid = binary and not self.binf_projection       # feature-logit outputs (a12 / a14 of SURVEY.md 8a)
+        self.binf_trainable = binary and bool(getattr(d, 'binf_trainable', False))
         if binary:
-            if getattr(d, 'binf_trainable', False) or getattr(d, 'binf_sampling', False):
-                raise ValueError('binf_trainable / binf_sampling are not implemented on the HIP path')
+            if getattr(d, 'binf_sampling', False):
+                # not a gap of this implementation: the flag has no well-formed graph in the reference
+                raise ValueError(
+                    '--binf_sampling: the reference cannot build this graph in any flag combination -- with --binf_projection '
+                    'las.model.speller gets binf_embedding=None and its embedding_fn transposes it (las/model.py:241-243); '
+                    'without, las_model_fn applies transform_binf_to_phones to binf_count-wide logits whose [nf:2nf] half is '
+                    'empty (model_helper.py:247-249, utils/training_helper.py:17-27).  Drop the flag.')
+            if self.binf_trainable and not self.binf_projection:
+                raise ValueError('--binf_trainable needs --binf_projection on the HIP path: for the sigmoid-output decoder the '
+                                 'reference differentiates the loss through its TARGETS as well (targets_binf is a lookup in the '
+                                 'variable, model_helper.py:199)')
             if self.binf_projection and binf2phone is None:
                 raise ValueError('binf_projection needs the binf2phone matrix (--binf_map)')
             if binf2phone is not None:
@@ -484,7 +499,8 @@ class LasModel:
         for scope, kind in speller_plan(d):
             mod = las_model.make_speller(d, self.vars.params, _enc_depth(params.encoder),
                                          binf2phone=binf2phone if kind != 'phones' else None, scope=scope,
-                                         phones_only=(kind == 'phones'))
+                                         phones_only=(kind == 'phones'),
+                                         binf_var='binf2phone' if (self.binf_trainable and kind != 'phones') else None)
             self.spellers.append((mod, kind))
         self.speller = self.spellers[0][0]
         self.speller_binf = self.spellers[1][0] if len(self.spellers) > 1 else None
@@ -710,7 +726,8 @@ class LasModel:
         e = self.params.encoder
         per_layer = 2 * (1 if e.unidirectional else 2)
         self.exchange_overlap = True
-        return self.vars.split_buckets((e.num_layers - 1) * per_layer)
+        lead = next(i for i, (n, _, _) in enumerate(self.vars.table) if n.startswith('listener/'))   # (a trainable binf2phone comes first)
+        return self.vars.split_buckets(lead + (e.num_layers - 1) * per_layer)
 
     def backward_exchange_begin(self, dlogits, exchange=True):
         """First half of the overlapped step: speller backward, the top listener layer and the RECURRENCE of the next

@@ -7,7 +7,7 @@ from oracle import las_oracle as O
 
 def make_hparams(F=13, L=2, H=64, Hd=None, V=11, att='luong', dec_layers=1, bottom_only=True, pass_hidden=True,
                  unidirectional=False, lr=1e-3, l2=1e-6, pyramidal=True, ctc=-1.0, als=None, emb=0, binf=None,
-                 binf_reg=1.0, sigmoid=False, multitask=False, sampling=0.0):
+                 binf_reg=1.0, sigmoid=False, multitask=False, sampling=0.0, binf_trainable=False):
     """Returns (oracle HP, product params) describing the same model.  binf: the [nf, V] feature map of a binary decoder:
     --binf_projection unless sigmoid=True (--binary_outputs alone: feature-logit outputs); multitask adds the phone
     decoder in front of it."""
@@ -19,7 +19,8 @@ def make_hparams(F=13, L=2, H=64, Hd=None, V=11, att='luong', dec_layers=1, bott
                                    embedding_size=emb, binf_projection=binf is not None and not sigmoid,
                                    binary_outputs=binf is not None, multitask=multitask,
                                    binf_count=0 if binf is None else int(binf.shape[0]), binf_map=binf,
-                                   binf_projection_reg_weight=binf_reg, sampling_probability=sampling),
+                                   binf_projection_reg_weight=binf_reg, sampling_probability=sampling,
+                                   binf_trainable=binf_trainable),
                learning_rate=lr, l2_reg_scale=l2, ctc_weight=ctc)
     from phones_las_amd.utils import params_utils as pu
     hp = pu.get_default_hparams()
@@ -31,7 +32,7 @@ def make_hparams(F=13, L=2, H=64, Hd=None, V=11, att='luong', dec_layers=1, bott
         hp.set_hparam(k, v)
     if binf is not None:             # --binary_outputs --binf_projection --binf_map (cfg5)
         for k, v in dict(binary_outputs=True, binf_projection=not sigmoid, binf_count=int(binf.shape[0]),
-                         binf_projection_reg_weight=binf_reg, multitask=multitask).items():
+                         binf_projection_reg_weight=binf_reg, multitask=multitask, binf_trainable=binf_trainable).items():
             hp.set_hparam(k, v)
     return ohp, pu.get_encoder_decoder_hparams(hp)
 

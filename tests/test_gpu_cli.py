@@ -167,7 +167,7 @@ def _binf_csv(path, phones, nf=6, seed=3):
             f.write('f%d,' % k + ','.join(str(c[k]) for c in cols) + '\n')
 
 
-@pytest.mark.parametrize('mode', ['binf_projection', 'sigmoid', 'multitask'])
+@pytest.mark.parametrize('mode', ['binf_projection', 'sigmoid', 'multitask', 'binf_trainable'])
 def test_binary_feature_cli_modes_train_and_infer(tmp_path, capsys, mode):
     """The reference's --binary_outputs flag family through train.py / infer.py (train.py:117-127, infer.py:203-223):
     --binf_projection (DenseBinfDecoder), --binary_outputs alone (sigmoid-output decoder: feature logits, InferenceHelper
@@ -179,8 +179,10 @@ def test_binary_feature_cli_modes_train_and_infer(tmp_path, capsys, mode):
     binf = os.path.join(d, 'binf_map.csv')
     _binf_csv(binf, phones)
     flags = ['--binary_outputs', '--output_ipa', '--binf_map', binf]
-    if mode in ('binf_projection', 'multitask'):
+    if mode in ('binf_projection', 'multitask', 'binf_trainable'):
         flags += ['--binf_projection']
+    if mode == 'binf_trainable':                           # the feature map as a variable (model_helper.py:181-186), checkpointed
+        flags += ['--binf_trainable']
     if mode == 'multitask':
         flags += ['--multitask']
     train.main(train.parse_args(['--train', os.path.join(d, 'train.tfr'), '--model_dir', os.path.join(d, 'model'), '--encoder_layers', '2',
