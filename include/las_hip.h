@@ -601,6 +601,30 @@ int las_fe_delta(const float* x, int64_t ldx, int T, int F, const float* taps, c
                  const float* edge_hi, int width, float* out, int64_t ldo, int out_stride, int out_offset,
                  void* stream);
 
+/* The same pipeline over a BATCH of utterances in three launches (preprocess_all.py:69-130 loops over files; the kernels
+ * loop over the frames of all of them): `waves` holds the signals back to back, wave_off[n_utt + 1] (device int64) their
+ * first samples, frame_off[n_utt + 1] (device int32) the first output frame of each; outputs are [total_frames, .] with the
+ * utterances' frames back to back.  Reflect padding, the top_db floor (under the utterance's OWN maximum) and the
+ * Savitzky-Golay edge windows are per utterance; a frame's arithmetic is that of the per-utterance entry points above, in the
+ * same order (bit-identical results).
+ *   las_fe_batch_melspec: frame -> window -> DFT -> |.|^power -> filterbank mel [bins, n_mels] -> epilogue (0: id, 1:
+ *     log(x + eps), 2: 10 log10(max(x, eps))) * scale -> out [total_frames, n_mels]; utt_max [n_utt] (nullable) receives
+ *     every utterance's maximum.
+ *   las_fe_batch_finish: max(row, utt_max[u] - top_db) (utt_max NULL: as it is) -> DCT dct [n_mels, n_out] (NULL: the first
+ *     n_out columns) -> out[f, 0..n_out); energy != 0: out[f, n_out] = RMS of the frame (librosa.feature.rms, center=True).
+ *   las_fe_batch_delta: out[f, 3c..3c+2] = x[f, c] and its first / second Savitzky-Golay derivatives along the utterance's
+ *     time axis (taps / edge matrices of both orders; every utterance needs >= width frames). */
+int las_fe_batch_melspec(const float* waves, const int64_t* wave_off, const int32_t* frame_off, int n_utt, int total_frames,
+                         int n_fft, int hop, int center, int power, const float* window, const float* costab,
+                         const float* sintab, int bins, const float* mel, int n_mels, int epilogue, float eps, float scale,
+                         float* out, float* utt_max, void* stream);
+int las_fe_batch_finish(const float* mel_db, int n_mels, const int32_t* frame_off, int n_utt, int total_frames,
+                        const float* utt_max, float top_db, const float* dct, int n_out, const float* waves,
+                        const int64_t* wave_off, int frame_length, int hop, int energy, float* out, int64_t ldo, void* stream);
+int las_fe_batch_delta(const float* x, int64_t ldx, const int32_t* frame_off, int n_utt, int total_frames, int F,
+                       const float* taps1, const float* lo1, const float* hi1, const float* taps2, const float* lo2,
+                       const float* hi2, int width, float* out, int64_t ldo, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * Input path (utils/dataset_utils.py:138-283 of the reference: tf.data.TFRecordDataset ->
  * tf.parse_single_sequence_example -> (x - mean) / std -> padded_batch).  Host functions; `data` is the image of a

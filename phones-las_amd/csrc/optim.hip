@@ -104,18 +104,30 @@ __global__ __launch_bounds__(256) void l2_norm_kernel(float* g, const float* p, 
     last = (__hip_atomic_fetch_add(ws, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1) ? 1u : 0u;
   __syncthreads();
   if (!last) return;
-  __threadfence();
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  for (int seg = wave; seg <= nseg; seg += 4) {
-    if (seg == nseg && !param_sumsq) break;
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");       // the other workgroups' rows (this CU never held a line of them)
+  // 32 tensors at a time: thread (tensor sl, stripe pt) adds the rows pt, pt + 8, ... (plain loads, eight in flight: one
+  // lane walking all rows with dependent loads made this tail 60 us of an 84-us kernel), the eight stripes meet in LDS
+  // in stripe order -- a fixed assignment, so the sums do not depend on scheduling
+  __shared__ float stripe[8][32];
+  const int sl = threadIdx.x & 31, pt = threadIdx.x >> 5;
+  for (int s0 = 0; s0 <= nseg; s0 += 32) {
+    const int seg = s0 + sl;
     float t = 0.f;
-    for (unsigned b = lane; b < gridDim.x; b += 64)
-      t += __hip_atomic_load(rows + (int64_t)b * (nseg + 1) + seg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    t = las_wave_sum(t);
-    if (lane == 0) {
-      if (seg < nseg) sumsq[seg] += t;
-      else *param_sumsq += t;
+    if (seg <= nseg) {
+      const float* src = rows + seg;
+#pragma unroll 8
+      for (unsigned b = pt; b < gridDim.x; b += 8) t += src[(int64_t)b * (nseg + 1)];
     }
+    stripe[pt][sl] = t;
+    __syncthreads();
+    if (pt == 0 && seg <= nseg && (seg < nseg || param_sumsq)) {
+      float tot = 0.f;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) tot += stripe[k][sl];
+      if (seg < nseg) sumsq[seg] += tot;
+      else *param_sumsq += tot;
+    }
+    __syncthreads();
   }
   if (threadIdx.x == 0) *ws = 0u;
 }

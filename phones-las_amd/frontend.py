@@ -15,7 +15,7 @@ import torch
 from . import hip
 
 SAMPLE_RATE = 16000
-__all__ = ['calculate_acoustic_features', 'calculate_mfcc_op', 'SAMPLE_RATE']
+__all__ = ['calculate_acoustic_features', 'calculate_acoustic_features_batch', 'calculate_mfcc_op', 'SAMPLE_RATE']
 
 
 # ---- tables (float64 on the host) -------------------------------------------------------------------------------------
@@ -166,6 +166,62 @@ def calculate_acoustic_features(args, waveform):
                                        order, st))
         feats = out
     return feats
+
+
+def calculate_acoustic_features_batch(args, waveforms):
+    """calculate_acoustic_features over a LIST of waveforms in three launches (las_fe_batch_melspec / _finish / _delta over the
+    frames of all utterances; a fourth of two small kernels when --energy / --deltas are off is not needed).  The per-frame
+    arithmetic is that of the per-utterance kernels in the same order: the result is bit-identical to calling
+    calculate_acoustic_features on every waveform.  Returns a list of CUDA fp32 tensors [T_u, F] (views of one buffer).
+    preprocess_all.py:69-130 of the reference runs this chain file by file on the host (librosa); here the utterances of
+    a batch share every launch."""
+    if getattr(args, 'backend', 'librosa') != 'librosa':
+        raise ValueError('only --backend librosa is implemented on the HIP path')
+    if args.feature_type not in ('mfcc', 'mfe'):
+        raise ValueError('Unexpected features type.' if args.feature_type != 'lyon' else 'lyon features are out of scope')
+    if not len(waveforms):
+        return []
+    lib, st = hip.lib(), hip.stream()
+    n_fft = int(args.window * SAMPLE_RATE / 1000.0)
+    hop = int(args.step * SAMPLE_RATE / 1000.0)
+    bins = n_fft // 2 + 1
+    waves = [torch.as_tensor(w, dtype=torch.float32).reshape(-1) for w in waveforms]
+    lens = [int(w.numel()) for w in waves]
+    frames = [1 + n // hop for n in lens]                      # center=True
+    if args.deltas and min(frames) < 9:
+        raise ValueError('deltas need at least 9 frames per utterance (Savitzky-Golay window)')
+    if min(lens) < n_fft // 2 + 1:
+        raise ValueError('signal shorter than half a window (reflect padding)')
+    dev = 'cuda'
+    wave_off = torch.tensor(np.concatenate([[0], np.cumsum(lens)]), dtype=torch.int64)
+    frame_off = torch.tensor(np.concatenate([[0], np.cumsum(frames)]), dtype=torch.int32)
+    total = int(frame_off[-1])
+    flat = torch.cat([w.cpu() if w.is_cuda else w for w in waves]).pin_memory().to(dev, non_blocking=True) \
+        if not all(w.is_cuda for w in waves) else torch.cat(waves)
+    d_woff, d_foff = wave_off.to(dev), frame_off.to(dev)
+    n_utt = len(waves)
+    tb = _tables('librosa', n_fft, args.n_mels, args.n_mfcc, SAMPLE_RATE)
+    mel_db = torch.empty(total, args.n_mels, device=dev)
+    umax = torch.empty(n_utt, device=dev)
+    mfcc = args.feature_type == 'mfcc'
+    # mfcc: power_to_db(S, amin=1e-10); mfe: amplitude_to_db of the POWER mel spectrogram (the reference's quirk) = 2 * 10 log10(max(S, 1e-5))
+    hip.check(lib.las_fe_batch_melspec(hip.p(flat), hip.p(d_woff), hip.p(d_foff), n_utt, total, n_fft, hop, 1, 2, hip.p(tb['window']),
+                                       hip.p(tb['cos']), hip.p(tb['sin']), bins, hip.p(tb['mel']), args.n_mels, 2,
+                                       1e-10 if mfcc else 1e-5, 1.0 if mfcc else 2.0, hip.p(mel_db), hip.p(umax), st))
+    n_out = args.n_mfcc if mfcc else args.n_mels
+    F = n_out + (1 if args.energy else 0)
+    feats = torch.empty(total, F, device=dev)
+    hip.check(lib.las_fe_batch_finish(hip.p(mel_db), args.n_mels, hip.p(d_foff), n_utt, total, hip.p(umax), 80.0,
+                                      hip.p(tb['dct']) if mfcc else None, n_out, hip.p(flat), hip.p(d_woff), n_fft, hop,
+                                      1 if args.energy else 0, hip.p(feats), F, st))
+    if args.deltas:
+        out = torch.empty(total, 3 * F, device=dev)
+        (t1, l1, h1), (t2, l2, h2) = tb['sg1'], tb['sg2']
+        hip.check(lib.las_fe_batch_delta(hip.p(feats), F, hip.p(d_foff), n_utt, total, F, hip.p(t1), hip.p(l1), hip.p(h1),
+                                         hip.p(t2), hip.p(l2), hip.p(h2), 9, hip.p(out), 3 * F, st))
+        feats = out
+    fo = frame_off.tolist()
+    return [feats[fo[u]:fo[u + 1]] for u in range(n_utt)]
 
 
 def calculate_mfcc_op(sample_rate, coeffs, window, step, mels):

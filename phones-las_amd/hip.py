@@ -75,6 +75,9 @@ _SIGS = {
     'las_fe_top_db': ([_vp, _i64, _i32, _i32, _f32, _vp, _vp], C.c_int),
     'las_fe_rms': ([_vp, _i32, _i32, _i32, _vp, _i64, _i32, _vp], C.c_int),
     'las_fe_delta': ([_vp, _i64, _i32, _i32, _vp, _vp, _vp, _i32, _vp, _i64, _i32, _i32, _vp], C.c_int),
+    'las_fe_batch_melspec': ([_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _i32, _vp, _i32, _i32, _f32, _f32, _vp, _vp, _vp], C.c_int),
+    'las_fe_batch_finish': ([_vp, _i32, _vp, _i32, _i32, _vp, _f32, _vp, _i32, _vp, _vp, _i32, _i32, _i32, _vp, _i64, _vp], C.c_int),
+    'las_fe_batch_delta': ([_vp, _i64, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _i64, _vp], C.c_int),
     'las_add_masked': ([_vp, _i64, _vp, _i64, _vp, _i64, _i32, _i32, _f32, C.c_uint32, C.c_uint32, C.c_uint64, _i64, _vp], C.c_int),
     'las_add_noise': ([_vp, _i64, _f32, C.c_uint32, C.c_uint32, _vp], C.c_int),
     'las_gemm_tn_lstm_workspace_bytes': ([C.c_int, C.c_int, C.c_int], C.c_size_t),

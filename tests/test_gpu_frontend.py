@@ -73,3 +73,22 @@ def test_preprocess_all_cli_end_to_end(tmp_path):
     assert load_vocab(d + '/vocab.txt')[3] == 'ah'                      # most common first
     m, s = load_normalization(d + '/norm.dmp')
     assert m.shape == (42,) and np.allclose(m, np.mean([x.mean(0) for x, _ in recs], 0), atol=1e-4)   # quirk B5
+
+
+@pytest.mark.parametrize('feature_type,energy,deltas', [('mfcc', True, True), ('mfcc', False, False), ('mfe', True, True), ('mfe', False, True)])
+def test_batched_front_end_is_bit_identical_to_the_per_utterance_path(feature_type, energy, deltas):
+    """calculate_acoustic_features_batch (three launches over the frames of ALL utterances: las_fe_batch_melspec / _finish /
+    _delta) against calculate_acoustic_features utterance by utterance: reflect padding at every signal's own ends, the
+    top_db floor under every utterance's own maximum and the Savitzky-Golay edge windows are per utterance, and a frame's
+    arithmetic runs in the same order -- torch.equal, not a tolerance.  Ragged lengths, one utterance much louder than the
+    others (its maximum must not floor its neighbours)."""
+    from phones_las_amd import frontend
+    args = argparse.Namespace(feature_type=feature_type, backend='librosa', n_mfcc=13, n_mels=40, window=20, step=10,
+                              energy=energy, deltas=deltas)
+    waves = [_audio(16000, 0), 30.0 * _audio(4321, 1), 1e-3 * _audio(9999, 2), _audio(1600, 3), _audio(24000, 4)]
+    got = frontend.calculate_acoustic_features_batch(args, waves)
+    assert len(got) == 5
+    for w, g in zip(waves, got):
+        ref = frontend.calculate_acoustic_features(args, w)
+        assert g.shape == ref.shape and torch.equal(g, ref)
+    assert frontend.calculate_acoustic_features_batch(args, []) == []
