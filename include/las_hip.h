@@ -341,8 +341,22 @@ typedef struct las_dec_persist {
   int64_t ld_logits;
   float* plog;                   /* [U, B, 4, Vp] fp32 scratch */
   int32_t V, Vp;
+  /* Attention layer (attention_layer_size, or 2 * binf_count under --binf_projection: las/model.py:179-200), walT != NULL:
+   * attention_t = [h_t | context_t] W_al (tf.layers.Dense, no bias) is the decoder's output and the feed of step t+1: the
+   * launch writes it (bf16) to att_out[b*ld_att + t*A ..] and into columns [x_att_off, x_att_off + A) of the operand row of
+   * step t+1; s.ctx_out2 must then be NULL (the context is not fed).  A: a multiple of 16, at most 512; (Hd + M) / 32 <= 40.
+   * Monotonic normalisers (s.norm = LAS_NORM_MONOTONIC_PARALLEL with the monotonic attentions): s.p_out receives p_choose of
+   * every step (step increment inc_p, the alignments' increment for the rows of s.align_out it chains through). */
+  const las_bf16* walT;          /* [A, Hd + M] bf16, row n = output column n, row stride ld_wal */
+  int64_t ld_wal;
+  int32_t A, x_att_off;
+  las_bf16* att_out;
+  int64_t ld_att;
+  int64_t inc_p;
 } las_dec_persist;
 int las_decoder_persist_supported(int Hd, int M, int K_in, int attention, int norm);   /* 1 if the shapes fit */
+/* ... with an attention layer of A outputs (A = 0: none) and / or a monotonic normaliser (decoder_units 128 / 256) */
+int las_decoder_persist_al_supported(int Hd, int M, int K_in, int A, int attention, int norm);
 size_t las_decoder_persist_workspace_bytes(int B, int Tm, int Hd, int M);   /* status, group flags, exchange granules */
 /* Utterances a persistent launch works on at once: the 32 workgroups of every group of 8 utterances need a CU each and
  * must be resident together: 64 on a 256-CU MI355X.  A launch accepts up to four times as many (its blocks are laid out

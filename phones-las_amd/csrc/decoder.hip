@@ -421,7 +421,9 @@ __device__ void dec_step_fwd_body(const las_dec_step& s, const int b, const int 
         p = s.norm == LAS_NORM_MONOTONIC_HARD ? (sv > 0.f ? 1.f : 0.f) : las_sigmoid(sv);
       }
       sc[t] = p;
-      wb[t] = prev ? prev[t] : (t == 0 ? 1.f : 0.f);
+      // (one-launch decoder: the previous step's alignments were written by ANOTHER workgroup of this launch and their rows
+      //  share cache lines with rows read earlier: bypass L1)
+      wb[t] = prev ? (ph ? __hip_atomic_load(prev + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : prev[t]) : (t == 0 ? 1.f : 0.f);
       if (writer && s.p_out) s.p_out[(int64_t)b * s.ldp + t] = p;
     }
     __syncthreads();
@@ -656,7 +658,12 @@ __device__ bool persist_barrier(pu64* flags, int member, unsigned epoch, bool lo
 // memory
 // KRES: K chunks per wave that stay in registers; the chunks beyond are re-read from L2 / Infinity Cache at every step
 // (512 units: 8 of 20 resident = 128 VGPRs; all 20 would need 320 of the 512 next to the step body's ~270).
-template <bool SAMPLING, bool RES, int NTL_MAX = 2, int KCW_MAX = 12, int KRES = KCW_MAX>
+// AL: the decoder has an attention layer (attention_layer_size / --binf_projection, las/model.py:179-200): attention_t =
+// [h_t | context_t] W_al is its output and the next step's feed.  After the S role a group barrier, then members 0 .. A/16-1
+// form one 16-column tile of attention_t each for the group's 8 utterances (K = Hd + M over the four waves, W_al slice in
+// registers: KAL_MAX chunks per wave) and write it to `att_out` and into the next operand row.  The monotonic normalisers
+// (las/model.py:157-164) run inside the shared step body; here they only get their per-step pointers.
+template <bool SAMPLING, bool RES, int NTL_MAX = 2, int KCW_MAX = 12, int KRES = KCW_MAX, bool AL = false, int KAL_MAX = 10>
 __global__ __launch_bounds__(256) void dec_persist_fwd_kernel(las_dec_persist p) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   const las_dec_step& s0 = p.s;
@@ -717,6 +724,18 @@ __global__ __launch_bounds__(256) void dec_persist_fwd_kernel(las_dec_persist p)
     }
   }
   const int bg = group * 8 + (l15 & 7);                    // utterance of A-fragment row l15 (rows 8..15 repeat 0..7)
+  // A role (AL): this member's 16 columns of W_al^T [A, Hd + M], K chunks wave, wave + 4, ...
+  bf16x8 wal[AL ? KAL_MAX : 1];
+  const int KA = (Hd + M) / 32, NA = AL ? p.A / 16 : 0;
+  if constexpr (AL) {
+#pragma unroll
+    for (int i = 0; i < KAL_MAX; ++i) {
+      const int kc = wave + 4 * i;
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (member < NA && kc < KA) v = *reinterpret_cast<const uint4*>(p.walT + (int64_t)(member * 16 + l15) * p.ld_wal + kc * 32 + 8 * lq);
+      wal[i] = __builtin_bit_cast(bf16x8, v);
+    }
+  }
   const int bs = group * 8 + member / 4, part = member & 3;  // S role
   // what the S role reads from the encoder memory never changes over the U steps: keep it in LDS when it fits
   const unsigned short* lkeys = nullptr;
@@ -835,8 +854,13 @@ __global__ __launch_bounds__(256) void dec_persist_fwd_kernel(las_dec_persist p)
       st.align_bf16 = s0.align_bf16 ? s0.align_bf16 + t * p.inc_align : nullptr;
       st.pq_out = s0.pq_out ? s0.pq_out + t * p.inc_pq : nullptr;
       st.ctx_out = s0.ctx_out + t * p.inc_ctx;
-      st.ctx_out2 = last ? nullptr : s0.ctx_out2 + t * p.inc_ctx2;
+      st.ctx_out2 = (last || !s0.ctx_out2) ? nullptr : s0.ctx_out2 + t * p.inc_ctx2;
       st.step = t;
+      if (s0.norm != LAS_NORM_SOFTMAX) {      // monotonic normalisers: alignments of the step before, p_choose for the backward
+        st.prev_align = t > 0 ? s0.align_out + (t - 1) * p.inc_align : nullptr;
+        st.ldpa = s0.lda;
+        st.p_out = s0.p_out ? s0.p_out + t * p.inc_p : nullptr;
+      }
       pu64* xsc = xbase + ((size_t)(xtag & 1) * B + bs) * ldsc;
       pu64* xz = xzb + ((size_t)(xtag & 1) * B + bs) * 4 * Hd;
       PersistHook hook{xsc, xz, xtag, flags, member, &epoch, local, fail, lkeys, lvals,
@@ -913,6 +937,41 @@ __global__ __launch_bounds__(256) void dec_persist_fwd_kernel(las_dec_persist p)
           if (lane == 0) const_cast<int32_t*>(s0.tok_ids)[(int64_t)bs * s0.tok_stride + t + 1] = out;   // else: the teacher's, already there
         }
       }
+      }
+    }
+    if constexpr (AL) {
+      // ---- A: attention_t = [h_t | context_t] W_al for the group's utterances (every part's context columns and h_t are
+      //      in memory behind this barrier; their lines were never read by this workgroup before) ----
+      if (!persist_barrier(flags, member, ++epoch, local, fail)) break;
+      if (member < NA) {
+        f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+        const int64_t bgc = min(bg, B - 1);
+        const unsigned short* hrow = s0.h_out + bgc * s0.ldh + (int64_t)t * p.inc_h + 8 * lq;
+        const unsigned short* crow = s0.ctx_out + bgc * s0.ldc + (int64_t)t * p.inc_ctx + 8 * lq;
+        uint4 av[KAL_MAX];
+#pragma unroll
+        for (int i = 0; i < KAL_MAX; ++i) {
+          const int kc = wave + 4 * i;
+          av[i] = make_uint4(0, 0, 0, 0);
+          if (kc < KA && bg < B) av[i] = *reinterpret_cast<const uint4*>(kc < Hd / 32 ? hrow + kc * 32 : crow + (kc - Hd / 32) * 32);
+        }
+#pragma unroll
+        for (int i = 0; i < KAL_MAX; ++i)
+          if (wave + 4 * i < KA) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, av[i]), wal[i], acc, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) red[(wave * 16 + lq * 4 + r) * RS + l15] = acc[r];
+        __syncthreads();
+        if (tid < 8 * 16) {
+          const int row = tid >> 4, col = tid & 15;
+          const int b = group * 8 + row;
+          if (b < B) {
+            const unsigned short v = las_f2bf(red[(0 * 16 + row) * RS + col] + red[(1 * 16 + row) * RS + col] + red[(2 * 16 + row) * RS + col] +
+                                              red[(3 * 16 + row) * RS + col]);
+            p.att_out[(int64_t)b * p.ld_att + (int64_t)t * p.A + member * 16 + col] = v;
+            if (t + 1 < p.U)
+              const_cast<unsigned short*>(p.x)[(int64_t)b * p.ldx + (int64_t)(t + 1) * p.inc_x + p.x_att_off + member * 16 + col] = v;
+          }
+        }
       }
     }
     if (!persist_barrier(flags, member, ++epoch, local, fail)) break;
@@ -2799,6 +2858,17 @@ extern "C" int las_decoder_step_fwd(const las_dec_step* s, int parts, void* stre
   return LAS_OK;
 }
 
+extern "C" int las_decoder_persist_al_supported(int Hd, int M, int K_in, int A, int attention, int norm) {
+  // the one-launch forward with an attention layer and / or a monotonic normaliser ('parallel' mode: TRAIN): general body
+  if (norm != LAS_NORM_SOFTMAX && norm != LAS_NORM_MONOTONIC_PARALLEL) return 0;
+  if (attention < LAS_ATT_LUONG || attention > LAS_ATT_BAHDANAU_MONOTONIC) return 0;
+  if ((norm == LAS_NORM_SOFTMAX) != (attention == LAS_ATT_LUONG || attention == LAS_ATT_BAHDANAU || attention == LAS_ATT_CUSTOM)) return 0;
+  if (Hd != 128 && Hd != 256) return 0;
+  if (K_in % 64 != 0 || K_in / 32 > 48 || M % 32 != 0) return 0;
+  if (A < 0 || A % 16 != 0 || A / 16 > P_MEMBERS || (A > 0 && (Hd + M) / 32 > 40)) return 0;      // <= 10 K chunks of W_al per wave
+  return 1;
+}
+
 extern "C" int las_decoder_persist_supported(int Hd, int M, int K_in, int attention, int norm) {
   if (norm != LAS_NORM_SOFTMAX) return 0;
   if (attention != LAS_ATT_LUONG && attention != LAS_ATT_BAHDANAU && attention != LAS_ATT_CUSTOM) return 0;
@@ -2832,9 +2902,17 @@ extern "C" int las_decoder_persist_fwd(const las_dec_persist* p, void* stream) {
   const las_dec_step* s = &p->s;
   LAS_REQUIRE(s->B > 0 && p->U > 0 && s->mode == LAS_DEC_FUSED, "las_decoder_persist_fwd: bad shape / mode");
   LAS_REQUIRE(s->B <= 4 * persist_max_batch(), "las_decoder_persist_fwd: at most %d utterances per launch (got %d)", 4 * persist_max_batch(), s->B);
-  LAS_REQUIRE(las_decoder_persist_supported(s->Hd, s->M, p->K_in, s->attention, s->norm),
+  const bool al_path = p->walT != nullptr || s->norm != LAS_NORM_SOFTMAX;
+  LAS_REQUIRE(al_path ? las_decoder_persist_al_supported(s->Hd, s->M, p->K_in, p->walT ? p->A : 0, s->attention, s->norm)
+                      : las_decoder_persist_supported(s->Hd, s->M, p->K_in, s->attention, s->norm),
               "las_decoder_persist_fwd: configuration not supported (Hd=%d M=%d K_in=%d attention=%d norm=%d)", s->Hd, s->M, p->K_in,
               s->attention, s->norm);
+  LAS_REQUIRE(!al_path || (p->sampling_prob <= 0.f && s->drop_keep >= 1.0f), "las_decoder_persist_fwd: attention layer / monotonic "
+              "normalisers inside the launch: without scheduled sampling and input dropout");
+  LAS_REQUIRE(!p->walT || (p->att_out && p->ld_wal >= s->Hd + s->M && p->x_att_off >= 0 && p->x_att_off + p->A <= p->K_in && !s->ctx_out2),
+              "las_decoder_persist_fwd: attention layer needs att_out, a W_al^T of Hd + M columns, a place in the operand row (and no "
+              "context copy there)");
+  LAS_REQUIRE(s->norm == LAS_NORM_SOFTMAX || (s->p_out && s->align_out), "las_decoder_persist_fwd: monotonic normalisers save p_choose");
   LAS_REQUIRE(p->x && p->kT && p->workspace && ((uintptr_t)p->workspace % 128 == 0) && ((uintptr_t)p->x % 128 == 0),
               "las_decoder_persist_fwd: null argument, or exchanged rows that are not whole 128-byte lines");
   LAS_REQUIRE(p->sampling_prob <= 0.f || (p->wprojT && p->bproj && p->plog && p->V > 0 && p->Vp >= p->V &&
@@ -2850,6 +2928,30 @@ extern "C" int las_decoder_persist_fwd(const las_dec_persist* p, void* stream) {
   LAS_REQUIRE(lds <= 64 * 1024, "las_decoder_persist_fwd: memory length %d too long for the LDS score buffer", s->Tm);
   const bool res = persist_fwd_resident(s->M, s->Hd, s->Tm);
   const dim3 grid(((groups + 7) & ~7) * P_MEMBERS);
+  if (al_path) {
+    // attention layer and / or monotonic normaliser: the general body with the A role (AL) or without
+    const size_t lds_al = lds + (res ? persist_fwd_resident_bytes(s->M, s->Hd, s->Tm) : 0);
+#define LAS_AL_LAUNCH(...)                                                                                                      \
+  do {                                                                                                                          \
+    static bool attr = false;                                                                                                   \
+    if (!attr) {                                                                                                                \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dec_persist_fwd_kernel<__VA_ARGS__>),                            \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                                        \
+      attr = true;                                                                                                              \
+    }                                                                                                                           \
+    hipLaunchKernelGGL((dec_persist_fwd_kernel<__VA_ARGS__>), grid, dim3(256), lds_al, st, *p);                                 \
+  } while (0)
+    if (p->walT) {
+      if (res) LAS_AL_LAUNCH(false, true, 2, 12, 12, true, 10);
+      else LAS_AL_LAUNCH(false, false, 2, 12, 12, true, 10);
+    } else {
+      if (res) LAS_AL_LAUNCH(false, true, 2, 12, 12, false, 1);
+      else LAS_AL_LAUNCH(false, false, 2, 12, 12, false, 1);
+    }
+#undef LAS_AL_LAUNCH
+    LAS_LAUNCH_CHECK("persistent decoder fwd (attention layer / monotonic) launch");
+    return LAS_OK;
+  }
   static int lean_mode = -1;                 // LAS_DEC_LEAN=0: the general body also where the written-out one applies (diagnostics)
   if (lean_mode < 0) {
     const char* e = getenv("LAS_DEC_LEAN");

@@ -83,6 +83,7 @@ _SIGS = {
     'las_gemm_tn_lstm_workspace_bytes': ([C.c_int, C.c_int, C.c_int], C.c_size_t),
     'las_gemm_tn_lstm': ([_vp, _i64, C.c_int, _vp, _i64, C.c_int, C.c_int, C.c_int, _vp, _i64, _vp, _vp, C.c_int, C.c_int, _vp, _vp], C.c_int),
     'las_decoder_persist_supported': ([C.c_int] * 5, C.c_int),
+    'las_decoder_persist_al_supported': ([_i32, _i32, _i32, _i32, _i32, _i32], C.c_int),
     'las_decoder_persist_workspace_bytes': ([C.c_int, C.c_int, C.c_int, C.c_int], C.c_size_t),
     'las_decoder_persist_max_batch': ([], C.c_int),
     'las_decoder_persist_fwd': ([_vp, _vp], C.c_int),
@@ -121,7 +122,8 @@ class DecPersist(C.Structure):
         'inc_tok', 'inc_cprev', 'inc_gates', 'inc_cout', 'inc_h', 'inc_h2', 'inc_align', 'inc_pq', 'inc_ctx', 'inc_ctx2')] + [
         ('x', _vp), ('ldx', _i64), ('inc_x', _i64), ('kT', _vp), ('ldk', _i64), ('z_all', _vp), ('sc_all', _vp), ('ld_sc', _i64), ('workspace', _vp),
         ('sampling_prob', _f32), ('seed', C.c_uint32), ('teacher', _vp), ('teacher_stride', _i64), ('wprojT', _vp), ('ldw', _i64),
-        ('bproj', _vp), ('logits', _vp), ('ld_logits', _i64), ('plog', _vp), ('V', _i32), ('Vp', _i32)]
+        ('bproj', _vp), ('logits', _vp), ('ld_logits', _i64), ('plog', _vp), ('V', _i32), ('Vp', _i32),
+        ('walT', _vp), ('ld_wal', _i64), ('A', _i32), ('x_att_off', _i32), ('att_out', _vp), ('ld_att', _i64), ('inc_p', _i64)]
 
 
 class DecStepBwd(C.Structure):

@@ -363,6 +363,8 @@ class GeneralSpeller:
         tin = targets_inputs
         fed = tin
         logits = None
+        if self._persist_ok(B, Tm, keep, sampling, input_vectors):
+            return self._forward_train_persist(sv, init, targets_inputs)
         if sampling > 0.0:               # scheduled sampling (utils/training_helper.py:48-87)
             fed = tin[:, :U].contiguous().clone()
             logits = torch.empty(B, U, Vp, dtype=f32, device=dev)
@@ -449,6 +451,102 @@ class GeneralSpeller:
             hip.gemm_nt(out_all, self.wprojT, logits, B * U, Vp, self.P, lda=self.P, ldb=self.P, ldc=Vp, bias=self.bproj)
         self.saved = sv
         self.last_Tm = Tm            # memory length of the last forward (tests replay the score noise)
+        return logits
+
+    # ------------------------------------------------------------------------------------------------------------------
+    # one-launch forward (round 3): single cell + attention layer and / or monotonic normaliser (cfg5: --binf_projection with
+    # bahdanau_monotonic; --attention_layer_size models).  All U steps in ONE las_decoder_persist_fwd launch; the backward
+    # still runs step by step on what this leaves behind.
+    def _persist_workspace(self, which, nbytes):
+        cache = self.__dict__.setdefault('_persist_cache', {})
+        ws = cache.get(which)
+        if ws is None or ws.numel() < nbytes:
+            if ws is not None and int(ws[:4].view(torch.int32).item()):
+                raise hip.LasError('persistent decoder reported a barrier timeout')
+            ws = cache[which] = torch.zeros(nbytes, dtype=torch.uint8, device='cuda')
+        return ws
+
+    def _persist_ok(self, B, Tm, keep, sampling, input_vectors):
+        import os
+        if os.environ.get('LAS_DEC_PERSIST', '1') == '0' or os.environ.get('LAS_DEC_PERSIST_AL', '1') == '0':
+            return False
+        if self.NL != 1 or self.tokx or self.sigmoid or keep < 1.0 or sampling > 0.0 or input_vectors is not None:
+            return False
+        if not (self.has_al or self.mono):
+            return False
+        lib = hip.lib()
+        Kp = (self.win[0] + self.Hd + 63) // 64 * 64
+        return (B <= 4 * lib.las_decoder_persist_max_batch() and
+                lib.las_decoder_persist_al_supported(self.Hd, self.M, Kp, self.A if self.has_al else 0, self.att, self._norm(True)) == 1)
+
+    def _forward_train_persist(self, sv, init, targets_inputs):
+        B, Tm, U, M = sv['B'], sv['Tm'], sv['U'], self.M
+        Hd, A, Vp = self.Hd, self.A, self.Vop
+        dev, bf, f32 = sv['memory'].device, torch.bfloat16, torch.float32
+        lib, st = hip.lib(), hip.stream()
+        Tmp = _r8(Tm)
+        W0 = self.win[0] + Hd                                  # [attention_{t-1} | h_{t-1}]: the cell kernel's rows behind the token rows
+        Kp = (W0 + 63) // 64 * 64                              # operand rows of whole 128-byte lines
+        feed = A if self.has_al else M                         # what is fed back: attention_t, or the context itself
+        Xp = torch.zeros(B, U, Kp, dtype=bf, device=dev)
+        Xp[:, 0, feed:feed + Hd].copy_(init[0][1])
+        sv['cs'][0][:, 0].copy_(init[0][0])
+        if getattr(self, '_kTp', None) is None or self._kTp.shape[1] != Kp:
+            self._kTp = torch.zeros(4 * Hd, Kp, dtype=bf, device=dev)
+        self._kTp[:, :W0].copy_(self.kT[0])                    # (the image follows the weights: refreshed every step anyway)
+        fed = targets_inputs[:, :U].to(torch.int32).contiguous()
+        sv['fed'] = fed
+        p = hip.DecPersist()
+        s = p.s
+        s.B, s.Hd, s.M, s.Tm, s.attention, s.mode = B, Hd, M, Tm, self.att, 0
+        s.tok_rows, s.tok_ids, s.tok_stride = hip.addr(self.tok), hip.addr(fed), fed.stride(0)
+        s.bias = hip.addr(self.bias[0])
+        s.c_prev, s.ldcp = hip.addr(sv['cs'][0]), (U + 1) * Hd
+        s.gates_out, s.ldg = hip.addr(sv['gates'][0]), U * 4 * Hd
+        s.c_out, s.ldco = hip.addr(sv['cs'][0], Hd), (U + 1) * Hd
+        s.h_out, s.ldh = hip.addr(sv['h'][0]), U * Hd
+        s.h_out2, s.ldh2 = (hip.addr(Xp, Kp + feed) if U > 1 else 0), U * Kp
+        s.keys, s.values, s.mem_len = hip.addr(sv['keys']), hip.addr(sv['memory']), hip.addr(sv['mem_len'])
+        if self.uses_wq:
+            s.wq = hip.addr(self.wq)
+            s.pq_out, s.ldpq = hip.addr(sv['pq']), U * Hd
+        if self.additive:
+            s.att_v = hip.addr(self.att_v)
+        s.align_out, s.align_bf16, s.lda = hip.addr(sv['align']), hip.addr(sv['align_bf']), U * Tmp
+        s.ctx_out, s.ldc = hip.addr(sv['ctx']), U * M
+        if not self.has_al:                                    # the context is the feed: straight into the next operand row
+            s.ctx_out2, s.ldc2 = (hip.addr(Xp, Kp) if U > 1 else 0), U * Kp
+        s.drop_keep, s.feed_width = 1.0, self.E + A
+        s.norm = sv['norm']
+        if self.mono:
+            s.score_bias = hip.addr(self.score_bias)
+            s.p_out, s.ldp = hip.addr(sv['p']), U * Tmp
+            s.noise_scale, s.noise_seed, s.noise_stream = sv.get('noise_scale', 0.0), sv.get('seed', 0), self.NOISE_STREAM
+        p.U, p.K_in = U, Kp
+        p.inc_tok, p.inc_cprev, p.inc_gates, p.inc_cout, p.inc_h, p.inc_h2 = 1, Hd, 4 * Hd, Hd, Hd, Kp
+        p.inc_align, p.inc_pq, p.inc_ctx, p.inc_ctx2, p.inc_p = Tmp, Hd, M, Kp, Tmp
+        p.x, p.ldx, p.inc_x = hip.addr(Xp), U * Kp, Kp
+        p.kT, p.ldk = hip.addr(self._kTp), Kp
+        if self.has_al:
+            p.walT, p.ld_wal, p.A, p.x_att_off = hip.addr(self.walT), Hd + M, A, 0
+            p.att_out, p.ld_att = hip.addr(sv['att']), U * A
+        ws = self._persist_workspace('fwd', lib.las_decoder_persist_workspace_bytes(B, Tm, Hd, M))
+        p.workspace = hip.addr(ws)
+        tok = hip.prof_begin('dec_persist_fwd', 2.0 * U * B * (Kp * 4 * Hd + Tm * Hd + Tm * M + (Hd + M) * (A if self.has_al else 0)))
+        hip.check(lib.las_decoder_persist_fwd(C.byref(p), st))
+        hip.prof_end(tok)
+        self._persist_ws = ws
+        # what the step-by-step backward reads: the compact operand rows and the attention layer's [query | context] rows
+        sv['X'][0] = Xp[:, :, :W0].contiguous()
+        if self.has_al:
+            sv['qc'][:, :, :Hd].copy_(sv['h'][0])
+            sv['qc'][:, :, Hd:].copy_(sv['ctx'])
+        out_all = sv['att']
+        sv['out'] = out_all
+        logits = torch.empty(B, U, Vp, dtype=f32, device=dev)
+        hip.gemm_nt(out_all, self.wprojT, logits, B * U, Vp, self.P, lda=self.P, ldb=self.P, ldc=Vp, bias=self.bproj)
+        self.saved = sv
+        self.last_Tm = Tm
         return logits
 
     def log_probs_loss(self, loss, weight, grad_scale):

@@ -694,7 +694,8 @@ class LasModel:
         one-launch decoder's."""
         dev = torch.cuda.current_device()
         out = [ws for (B, H, nd, d), ws in las_model.ops._WORKSPACES.items() if d == dev]
-        out += [ws for ws in getattr(self.speller, '_persist_cache', {}).values()]
+        for mod, _ in self.spellers:               # every decoder's one-launch workspaces
+            out += [ws for ws in getattr(mod, '_persist_cache', {}).values()]
         return out
 
     def collect_status(self, zero_norms=False):
@@ -938,10 +939,11 @@ class LasModel:
         is written and at the end of inference (it synchronises): raises LasError and clears the words."""
         try:
             las_model.ops.check_all_lstm_status()
-            for ws in getattr(self.speller, '_persist_cache', {}).values():
-                st = int(ws[:4].view(torch.int32).item())
-                if st:
-                    raise hip.LasError('persistent decoder reported a barrier timeout (status %d)' % st)
+            for mod, _ in self.spellers:
+                for ws in getattr(mod, '_persist_cache', {}).values():
+                    st = int(ws[:4].view(torch.int32).item())
+                    if st:
+                        raise hip.LasError('persistent decoder reported a barrier timeout (status %d)' % st)
         except hip.LasError:
             for ws in self._status_tensors():        # read: the sticky words start over
                 ws[:4].zero_()

@@ -258,3 +258,37 @@ def test_512_unit_one_launch_decoders_over_several_groups(case):
     assert getattr(model.speller, '_persist_ws', None) is not None and getattr(model.speller, '_persist_ws_bwd', None) is not None
     _write(rep)
     _check(rep)
+
+
+@pytest.mark.parametrize('case', ['cfg5_binf', 'cfg5_full'])
+def test_one_launch_forward_with_attention_layer_and_monotonic_normaliser_matches_the_step_launches(case, monkeypatch):
+    """cfg5's decoder (attention layer of 2 * binf_count outputs + bahdanau_monotonic) forward in ONE launch
+    (dec_persist_fwd_kernel<..., AL>: the monotonic chain inside the shared step body, the attention layer as a 16-column-tile
+    product on the group's members behind one more group barrier) against the same model on the per-step launches
+    (LAS_DEC_PERSIST_AL=0): same noise stream, so the same numbers up to bf16 flips of h / context / attention (the frame
+    split of the score phase changes the fp32 summation order of nothing, but the attention layer's K chunks are summed per
+    wave): logits within 2e-3 of the largest, saved p_choose / alignments within 1e-3, gradients within 1e-2 of each tensor's
+    largest.  And both against the fixture (the case's own test)."""
+    outs = {}
+    for flag in ('1', '0'):
+        monkeypatch.setenv('LAS_DEC_PERSIST_AL', flag)
+        model, feats, labels, nb = _model(case)
+        model.vars.grad.zero_()
+        loss, logits, dlogits = model.forward_train(feats, labels)
+        took = getattr(model.speller, '_persist_ws', None) is not None
+        assert took == (flag == '1')
+        sv = model.speller.saved
+        keep = {k: sv[k].clone() for k in ('align', 'p', 'att')}
+        model.backward(dlogits)
+        torch.cuda.synchronize()
+        model.check_device_status()
+        outs[flag] = (float(loss), logits.clone(), keep, {n: t.clone() for n, t in model.vars.grads.items()})
+    scale = float(outs['0'][1].abs().max())
+    d_logits = float((outs['1'][1] - outs['0'][1]).abs().max()) / scale
+    d_align = float((outs['1'][2]['align'] - outs['0'][2]['align']).abs().max())
+    d_p = float((outs['1'][2]['p'] - outs['0'][2]['p']).abs().max())
+    worst = max((float((outs['1'][3][n] - outs['0'][3][n]).abs().max() / (outs['0'][3][n].abs().max() + 1e-30)), n) for n in outs['1'][3])
+    print(json.dumps({'case': case, 'one_launch_vs_steps_logits': d_logits, 'align': d_align, 'p_choose': d_p, 'grad_worst': list(worst),
+                      'loss': [outs['1'][0], outs['0'][0]]}))
+    assert d_logits < 2e-3 and d_align < 1e-3 and d_p < 1e-3, (d_logits, d_align, d_p)
+    assert worst[0] < 1e-2, worst

@@ -851,3 +851,49 @@ def test_training_is_bit_reproducible(cfg):
     for a, b in zip(*runs):
         assert torch.equal(a, b)
     assert float((runs[0][0] - mh.LasModel(params, seed=77).vars.flat).abs().max()) > 0       # ... and they did move
+
+
+@pytest.mark.parametrize('kw', [
+    dict(att='luong', H=128, als=32),                        # attention_layer_size on dot-product scores
+    dict(att='bahdanau', H=128, Hd=256, als=16, pass_hidden=False),
+    dict(att='custom', H=128, als=48),                       # CustomAttention + attention layer
+    dict(att='luong_monotonic', H=128),                      # monotonic normaliser, the context itself is fed back
+    dict(att='bahdanau_monotonic', H=128, als=32),           # + TRAIN-mode score noise (replayed through the oracle)
+], ids=['luong_al', 'bahdanau_al_256', 'custom_al', 'luong_monotonic', 'bahdanau_monotonic_al'])
+def test_one_launch_forward_with_attention_layer_or_monotonic_normaliser_vs_oracle(kw):
+    """The single-cell decoders with an attention layer (--attention_layer_size, or --binf_projection: test_gpu_golden_shapes)
+    and / or a monotonic normaliser take their forward pass in ONE launch since round 3 (las_decoder_persist_fwd with walT /
+    norm = monotonic 'parallel'; the backward still steps).  Ragged lengths, two groups of utterances (B = 11), against the
+    oracle with the tolerances of the general decoder path."""
+    from phones_las_amd import hip
+    from phones_las_amd.las.speller_general import GeneralSpeller
+    O, ohp, op, model = _models(**kw)
+    assert isinstance(model.speller, GeneralSpeller)
+    if 'speller/attention_score_bias' in op:
+        op['speller/attention_score_bias'] = op['speller/attention_score_bias'] + 0.3
+        model.load_variables({k: v for k, v in op.items()})
+    B = 11
+    src_len = [24, 9, 17, 24, 12, 21, 5, 24, 16, 3, 20]
+    tgt_len = [6, 4, 5, 6, 3, 6, 2, 5, 4, 1, 6]
+    batch = make_batch(B=B, T=24, src_len=src_len, tgt_len=tgt_len)
+    feats, labels = to_device(batch)
+    model.vars.grad.zero_()
+    loss, logits, dlogits = model.forward_train(feats, labels)
+    assert getattr(model.speller, '_persist_ws', None) is not None          # the one-launch forward ran
+    model.backward(dlogits)
+    torch.cuda.synchronize()
+    model.check_device_status()
+    stochastic = None
+    if kw['att'] == 'bahdanau_monotonic':
+        U, Tm = max(tgt_len), model.speller.last_Tm
+        noise = torch.empty(U * B * Tm, dtype=torch.float32, device='cuda')
+        hip.check(hip.lib().las_normal_fill(hip.p(noise), noise.numel(), model.last_seed, GeneralSpeller.NOISE_STREAM, hip.stream()))
+        stochastic = {'att_noise': noise.view(U, B, Tm).cpu().to(DT)}
+    out = O.train_step(ohp, op, None, None, 1, batch, mxu='bf16', stochastic=stochastic)
+    V = ohp.decoder.target_vocab_size
+    for b, n in enumerate(tgt_len):
+        assert relerr(logits[b, :n, :V], out['aux']['logits'][b, :n]) < 2e-2, b
+    assert abs(float(loss) - float(out['aux']['ce'].detach())) < 2e-2 * float(out['aux']['ce'].detach())
+    for name, _, _ in model.vars.table:
+        g = out['grads'][name] - ohp.l2_reg_scale * op[name]
+        assert relerr(model.vars.grads[name], g) < 2 * GRAD_TOL, name
