@@ -98,8 +98,8 @@ int las_gemm_tn(const las_bf16* A, int64_t lda, const las_bf16* B, int64_t ldb, 
  * 128 x 128 tiles in `workspace` (las_gemm_tn_ws_bytes(M, N, split_k) bytes, owned by the caller, one per stream that
  * issues such products) and a second kernel adds them to C in slice order -- no fp32 atomics.  The speller's weight
  * gradients (TF autodiff of the decoder's matmuls, model_helper.py:415) use this form so that training is reproducible.
- * Shapes the slice kernel is not built for (M or N <= 64, N % 4 != 0) and calls without a sufficient workspace run
- * unsplit (one contributor per output element).  Arguments as las_gemm_tn, batch 1. */
+ * Shapes the slice kernel is not built for (N % 4 != 0) and calls without a sufficient workspace run unsplit (one contributor
+ * per output element).  Arguments as las_gemm_tn, batch 1. */
 size_t las_gemm_tn_ws_bytes(int M, int N, int split_k);
 int las_gemm_tn_ws(const las_bf16* A, int64_t lda, const las_bf16* B, int64_t ldb, float* C, int64_t ldc,
                    int M, int N, int K, int a_shift, int period, int c_perm_h, int split_k, float* workspace,
@@ -441,6 +441,33 @@ typedef struct las_dec_persist_bwd {
 } las_dec_persist_bwd;
 int las_decoder_persist_bwd_supported(int Hd, int M, int W, int attention, int norm);
 int las_decoder_persist_bwd(const las_dec_persist_bwd* p, void* stream);
+
+/* All U backward steps of a single-cell decoder with an attention layer (attention_layer_size / --binf_projection,
+ * las/model.py:179-200) and / or a monotonic normaliser in ONE launch: one workgroup per utterance walks its chain from the
+ * last step to the first, no exchange between workgroups (TF autodiff of dynamic_decode, model_helper.py:415).  `s` is the
+ * step struct of las_decoder_step_bwd for step 0 (fused mode; its dctx_* / dh_* fields are set by the launch), per-step
+ * pointers advance by the inc_* element counts; s.p / s.align serve the monotonic chain (prev_align = the row before).
+ *   A > 0: attention layer of A outputs: d(attention_t) = d_out[b, t, :A] + d(feed)_{t+1}[:A] (saved as bf16 in datt_out
+ *          [B, U, A] for d(W_al)), d[query | context] = d(attention_t) waln^T with waln [Hd + M, A] bf16 (row stride ld_waln);
+ *   A = 0: the context is output and feed: d(context_t) = d_out[b, t, :M] + d(feed)_{t+1}[:M].
+ * d(feed)_t = dz_t kn^T, kn [W0, 4 Hd] bf16 (row n = row n of the cell kernel below the token rows), W0 = (A or M) + Hd.
+ * dfeed_out (nullable) [B, W0] fp32: step 0's, the gradient into the initial feed / state; s.dc ends as dc_{-1}. */
+typedef struct las_dec_seq_bwd {
+  las_dec_step_bwd s;
+  int32_t U, A, W0, reserved;
+  int64_t inc_gates, inc_c, inc_align, inc_dz, inc_ds, inc_save, inc_pq;
+  const float* d_out;            /* fp32 [B, U, .]: utterance stride ld_dout, step stride inc_dout */
+  int64_t ld_dout, inc_dout;
+  las_bf16* datt_out;            /* bf16, utterance stride ld_datt, A per step (A > 0) */
+  int64_t ld_datt;
+  const las_bf16* waln;
+  int64_t ld_waln;
+  const las_bf16* kn;
+  int64_t ld_kn;
+  float* dfeed_out;
+} las_dec_seq_bwd;
+int las_decoder_seq_bwd_supported(int Hd, int M, int A, int W0, int Tm, int attention, int norm);
+int las_decoder_seq_bwd(const las_dec_seq_bwd* p, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Stochastic TRAIN-mode pieces (counter-based generator: forward and backward regenerate the same

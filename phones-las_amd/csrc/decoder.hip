@@ -38,7 +38,7 @@ __device__ __forceinline__ bool att_uses_wq(int a) { return att_additive(a) || a
 // left-to-right or right-to-left.  Thread i owns a contiguous chunk; chunk totals are scanned through `tmp` (256 floats).
 template <bool MUL>
 __device__ void block_scan(float* arr, int n, float* tmp, bool exclusive, bool reverse) {
-  const int tid = threadIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int ch = (n + 255) / 256;
   const int lo = tid * ch, hi = min(n, lo + ch);
   const float ident = MUL ? 1.f : 0.f;
@@ -51,21 +51,26 @@ __device__ void block_scan(float* arr, int n, float* tmp, bool exclusive, bool r
     const float v = arr[reverse ? n - 1 - i : i];
     tot = MUL ? tot * v : tot + v;
   }
-  __syncthreads();
-  tmp[tid] = tot;
-  __syncthreads();
-  if (tid == 0) {                       // 256 chunk totals: a serial pass is cheap next to the memory phases around it
-    float run = ident;
-    for (int i = 0; i < 256; ++i) { const float v = tmp[i]; tmp[i] = run; run = MUL ? run * v : run + v; }
+  // exclusive scan of the 256 chunk totals: shuffles inside a wave, the four wave totals through `tmp` (a serial pass of
+  // thread 0 over 256 LDS words was 6 us per scan: two of them per forward step of the monotonic normaliser, four per
+  // backward step)
+  float inc = tot;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const float nb = __shfl_up(inc, o, 64);
+    if (lane >= o) inc = MUL ? inc * nb : inc + nb;
   }
+  if (lane == 63) tmp[wave] = inc;
+  float run = __shfl_up(inc, 1, 64);
+  if (lane == 0) run = ident;
   __syncthreads();
-  float run = tmp[tid];
+  for (int w = 0; w < wave; ++w) run = MUL ? tmp[w] * run : tmp[w] + run;
   for (int i = lo; i < hi; ++i) {
     const int j = reverse ? n - 1 - i : i;
     const float v = arr[j];
-    const float inc = MUL ? run * v : run + v;
-    arr[j] = exclusive ? run : inc;
-    run = inc;
+    const float nxt = MUL ? run * v : run + v;
+    arr[j] = exclusive ? run : nxt;
+    run = nxt;
   }
   __syncthreads();
 }
@@ -1618,14 +1623,20 @@ __global__ __launch_bounds__(256) void dec_persist_fwd_lean_kernel(las_dec_persi
 // ------------------------------------------------------------------------------------------------
 // backward
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void dec_step_bwd_kernel(las_dec_step_bwd s) {
-  extern __shared__ __attribute__((aligned(16))) float sm[];
+// LDS floats of one backward step (dec_step_bwd_body): d(context), dalign -> dscore, per-phase partials, scratch, the
+// monotonic normaliser's five arrays, the query-layer scratch
+__host__ __device__ inline size_t dec_step_bwd_floats(int M, int Tm, int Hd, int norm) {
+  return (size_t)M + Tm + 2048 + 8 + Hd + (norm != LAS_NORM_SOFTMAX ? 5 * (size_t)Tm : 0) + 2048;
+}
+
+// One backward step of utterance b by the 256 threads of a workgroup (dec_step_bwd_kernel: one launch per step; dec_seq_bwd_kernel:
+// all steps of an utterance in one launch, the struct's pointers advanced by the caller; a pointer may then address LDS).
+__device__ void dec_step_bwd_body(const las_dec_step_bwd& s, const int b, float* sm) {
   float* dctx = sm;               // [M]
   float* ds = dctx + s.M;         // [Tm] dalign -> dscore
   float* dhs = ds + s.Tm;         // [256/L][Hd] = 2048 floats: per-phase partial d h (score path) / dpq
   float* red = dhs + 2048;        // [8] + [Hd] scratch
 
-  const int b = blockIdx.x;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int Hd = s.Hd, M = s.M, Tm = s.Tm;
   if (s.mode == LAS_DEC_CELL_ONLY) {
@@ -1918,6 +1929,156 @@ __global__ __launch_bounds__(256) void dec_step_bwd_kernel(las_dec_step_bwd s) {
     unsigned short* zp = s.dz + (int64_t)b * s.ldz + u;
     zp[0] = las_f2bf(di); zp[Hd] = las_f2bf(dj); zp[2 * Hd] = las_f2bf(df); zp[3 * Hd] = las_f2bf(dov);
   }
+}
+
+__global__ __launch_bounds__(256) void dec_step_bwd_kernel(las_dec_step_bwd s) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  dec_step_bwd_body(s, blockIdx.x, sm);
+}
+
+// ------------------------------------------------------------------------------------------------
+// SEQUENTIAL backward decoder (round 3): all U steps of the single-cell decoders that the grouped one-launch kernel below does
+// not cover -- an attention layer (attention_layer_size / --binf_projection) and / or a monotonic normaliser -- in ONE launch,
+// one workgroup per utterance, NO exchange between workgroups: an utterance's backward chain only ever needs the shared
+// weights.  Per step, last to first:
+//   d(attention_t) = d(outputs)_t + d(feed)_{t+1}[:A]  (bf16, as the attention layer's products see it; saved for d(W_al))
+//   d[query | context] = d(attention_t) W_al^T          (A x (Hd + M) from L2: 205 KB at cfg5)
+//   the step body: d(context) -> d(alignments) -> normaliser backward -> d(scores) -> d(keys), d(query); LSTM cell backward
+//   d(feed)_t = dz_t K^T                                 (4 Hd x (A + Hd) from L2: 688 KB at cfg5; a wave per output row)
+// The per-step launches this replaces made five launches per step (818 per train step at cfg5, each a cold-L2 start); here the
+// weights and the utterance's keys / values stay warm in the XCD's L2.  Results: the per-step path's, bit for bit (same body,
+// same operand roundings, same summation order of the two products' K loops is NOT guaranteed -- compared at 1e-3).
+// LDS: the step body's floats, then d(attention) [A], d[query | context] [Hd + M], d(feed) [W0].
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void dec_seq_bwd_kernel(las_dec_seq_bwd p) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const las_dec_step_bwd& s0 = p.s;
+  const int b = blockIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int Hd = s0.Hd, M = s0.M, A = p.A, W0 = p.W0, feed = p.A > 0 ? p.A : M;
+  float* datt = sm + dec_step_bwd_floats(M, s0.Tm, Hd, s0.norm);      // [A] (bf16-rounded values)
+  float* dqc = datt + (A > 0 ? A : 0);                                 // [Hd + M]
+  float* dfeed = dqc + (A > 0 ? Hd + M : 0);                           // [W0] d[feed | h]_{t} from step t+1
+  for (int n = tid; n < W0; n += 256) dfeed[n] = 0.f;
+  __syncthreads();
+  for (int t = p.U - 1; t >= 0; --t) {
+    const bool has_next = t + 1 < p.U;
+    las_dec_step_bwd st = s0;
+    st.mode = 0;
+    st.gates = s0.gates + (int64_t)t * p.inc_gates;
+    st.c_new = s0.c_new + (int64_t)t * p.inc_c;
+    st.c_prev = s0.c_prev + (int64_t)t * p.inc_c;
+    st.align = s0.align + (int64_t)t * p.inc_align;
+    st.dz = s0.dz + (int64_t)t * p.inc_dz;
+    st.ds_out = s0.ds_out + (int64_t)t * p.inc_ds;
+    st.dctx_save = s0.dctx_save + (int64_t)t * p.inc_save;
+    if (s0.pq) st.pq = s0.pq + (int64_t)t * p.inc_pq;
+    if (s0.dpq_out) st.dpq_out = s0.dpq_out + (int64_t)t * p.inc_pq;
+    if (s0.norm != LAS_NORM_SOFTMAX) {
+      st.p = s0.p + (int64_t)t * p.inc_align;
+      st.prev_align = t > 0 ? s0.align + (int64_t)(t - 1) * p.inc_align : nullptr;
+      st.ldpa = s0.lda;
+    }
+    st.step = t;
+    const float* dout = p.d_out + (int64_t)b * p.ld_dout + (int64_t)t * p.inc_dout;
+    if (A > 0) {
+      // d(attention_t), rounded to bf16 once (the operand of both of the attention layer's backward products)
+      for (int a = tid; a < A; a += 256) {
+        const unsigned short v = las_f2bf(dout[a] + (has_next ? dfeed[a] : 0.f));
+        datt[a] = las_bf2f(v);
+        p.datt_out[(int64_t)b * p.ld_datt + (int64_t)t * A + a] = v;
+      }
+      __syncthreads();
+      // d[query | context][n] = sum_a d(attention)[a] W_al[n][a]   (waln: [Hd + M, A] bf16, row n contiguous)
+      // (ten 16-byte pieces of two rows in flight per thread: left rolled, every piece was a dependent L2 round trip)
+      for (int n = tid; n < Hd + M; n += 512) {
+        const int n2 = n + 256;
+        const unsigned short* w0 = p.waln + (int64_t)n * p.ld_waln;
+        const unsigned short* w1 = p.waln + (int64_t)(n2 < Hd + M ? n2 : n) * p.ld_waln;
+        float acc0 = 0.f, acc1 = 0.f;
+        for (int a = 0; a < A; a += 40) {
+          uint4 v0[5], v1[5];
+#pragma unroll
+          for (int i = 0; i < 5; ++i) {
+            const int aa = a + 8 * i < A ? a + 8 * i : 0;
+            v0[i] = ld16(w0 + aa);
+            v1[i] = ld16(w1 + aa);
+          }
+#pragma unroll
+          for (int i = 0; i < 5; ++i)
+            if (a + 8 * i < A) {
+              acc0 += dot8(v0[i], datt + a + 8 * i);
+              acc1 += dot8(v1[i], datt + a + 8 * i);
+            }
+        }
+        dqc[n] = acc0;
+        if (n2 < Hd + M) dqc[n2] = acc1;
+      }
+      __syncthreads();
+      st.dctx_a = dqc + Hd;  st.ldda = 0;          // (LDS: the row stride is not used)
+      st.dctx_b = nullptr;
+      st.dh_b = dqc;         st.ldhb = 0;          // the attention layer's query input
+      st.dh_c = nullptr;
+      st.dh_rec = has_next ? dfeed + feed : nullptr;   st.ldr = 0;
+    } else {
+      // no attention layer: the context is the output and the feed
+      st.dctx_a = dout - (int64_t)b * p.ld_dout;   st.ldda = p.ld_dout;       // (the body adds b * ldda back)
+      st.dctx_b = has_next ? dfeed : nullptr;      st.lddb = 0;
+      st.dh_b = st.dh_c = nullptr;
+      st.dh_rec = has_next ? dfeed + feed : nullptr;   st.ldr = 0;
+    }
+    dec_step_bwd_body(st, b, sm);
+    __syncthreads();                               // dz_t of this utterance is in memory (same workgroup: visible behind the barrier)
+    if (t > 0 || p.dfeed_out) {
+      // d[feed | h]_t[n] = sum_k dz_t[k] K[n][k]   (kn: [W0, 4 Hd] bf16, row n contiguous); a wave per output row, every lane
+      // keeps its 16-byte pieces of dz_t in registers for all rows
+      const unsigned short* dzr = st.dz + (int64_t)b * st.ldz;
+      const int K4 = 4 * Hd, NP = K4 / 512;        // 16-byte pieces per lane (Hd = 128: 1, 256: 2)
+      float dzf[2][8];
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+        if (i < NP) {
+          const uint4 v = ld16(dzr + (i * 64 + lane) * 8);
+          const unsigned short* e = reinterpret_cast<const unsigned short*>(&v);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) dzf[i][j] = las_bf2f(e[j]);
+        }
+      // eight rows per wave at a time, all of their pieces requested before the first is used (a row at a time was one L2
+      // round trip per row: 84 per wave and step -- the launch took longer than the 400 step launches it replaces)
+      constexpr int RB = 8;
+      for (int n0 = wave * RB; n0 < W0; n0 += 4 * RB) {
+        uint4 kv[RB][2];
+#pragma unroll
+        for (int r = 0; r < RB; ++r) {
+          const unsigned short* krow = p.kn + (int64_t)min(n0 + r, W0 - 1) * p.ld_kn;
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+            if (i < NP) kv[r][i] = ld16(krow + (i * 64 + lane) * 8);
+        }
+        float acc[RB];
+#pragma unroll
+        for (int r = 0; r < RB; ++r) {
+          acc[r] = 0.f;
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+            if (i < NP) acc[r] += dot8(kv[r][i], dzf[i]);
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1)
+#pragma unroll
+          for (int r = 0; r < RB; ++r) acc[r] += __shfl_xor(acc[r], o, 64);
+        if (lane < RB && n0 + lane < W0) {
+          float v = acc[0];
+#pragma unroll
+          for (int r = 1; r < RB; ++r) v = lane == r ? acc[r] : v;
+          dfeed[n0 + lane] = v;
+        }
+      }
+    }
+    __syncthreads();
+  }
+  if (p.dfeed_out)
+    for (int n = tid; n < W0; n += 256) p.dfeed_out[(int64_t)b * W0 + n] = dfeed[n];
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -3095,6 +3256,34 @@ extern "C" int las_decoder_persist_bwd(const las_dec_persist_bwd* p, void* strea
   }
 #undef LAS_BWD_LAUNCH
   LAS_LAUNCH_CHECK("persistent decoder bwd launch");
+  return LAS_OK;
+}
+
+extern "C" int las_decoder_seq_bwd_supported(int Hd, int M, int A, int W0, int Tm, int attention, int norm) {
+  if (Hd != 128 && Hd != 256) return 0;                       // dz_t as one or two 16-byte pieces per lane
+  if (M % 128 != 0 || A < 0 || A % 8 != 0 || W0 <= 0) return 0;
+  if (attention < LAS_ATT_LUONG || attention > LAS_ATT_BAHDANAU_MONOTONIC) return 0;
+  if (norm != LAS_NORM_SOFTMAX && norm != LAS_NORM_MONOTONIC_PARALLEL) return 0;
+  const size_t lds = (dec_step_bwd_floats(M, Tm, Hd, norm) + (size_t)(A > 0 ? A + Hd + M : 0) + W0) * sizeof(float);
+  return lds <= 64 * 1024 ? 1 : 0;
+}
+
+extern "C" int las_decoder_seq_bwd(const las_dec_seq_bwd* p, void* stream) {
+  const las_dec_step_bwd* s = &p->s;
+  LAS_REQUIRE(s->B > 0 && p->U > 0 && las_decoder_seq_bwd_supported(s->Hd, s->M, p->A, p->W0, s->Tm, s->attention, s->norm),
+              "las_decoder_seq_bwd: configuration not supported (Hd=%d M=%d A=%d W0=%d Tm=%d attention=%d norm=%d)", s->Hd, s->M, p->A,
+              p->W0, s->Tm, s->attention, s->norm);
+  const bool additive = s->attention == LAS_ATT_BAHDANAU || s->attention == LAS_ATT_BAHDANAU_MONOTONIC;
+  LAS_REQUIRE(p->d_out && p->kn && s->dc && s->dz && s->ds_out && s->dctx_save && s->align && s->gates && s->c_new && s->c_prev && s->keys &&
+                  s->values && s->mem_len && (p->A == 0 || (p->waln && p->datt_out && p->ld_waln >= p->A)) && p->W0 == (p->A > 0 ? p->A : s->M) + s->Hd,
+              "las_decoder_seq_bwd: null argument or inconsistent widths");
+  LAS_REQUIRE(!additive || (s->wq_t && s->att_v && s->pq && s->dkeys_acc && s->dv_acc), "las_decoder_seq_bwd: Bahdanau scores need wq_t, att_v, pq, dkeys_acc, dv_acc");
+  LAS_REQUIRE(s->attention != LAS_ATT_CUSTOM || (s->wq_t && s->pq), "las_decoder_seq_bwd: CustomAttention needs wq_t and the saved processed query");
+  LAS_REQUIRE(s->norm == LAS_NORM_SOFTMAX || (s->p && s->dalign_carry), "las_decoder_seq_bwd: monotonic attention needs p_choose and the carry buffer");
+  LAS_REQUIRE(s->drop_keep >= 1.0f, "las_decoder_seq_bwd: without input dropout");
+  const size_t lds = (dec_step_bwd_floats(s->M, s->Tm, s->Hd, s->norm) + (size_t)(p->A > 0 ? p->A + s->Hd + s->M : 0) + p->W0) * sizeof(float);
+  hipLaunchKernelGGL(dec_seq_bwd_kernel, dim3(s->B), dim3(256), lds, (hipStream_t)stream, *p);
+  LAS_LAUNCH_CHECK("sequential decoder bwd launch");
   return LAS_OK;
 }
 

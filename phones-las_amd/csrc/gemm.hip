@@ -1062,13 +1062,15 @@ extern "C" int las_gemm_tn(const las_bf16* A, int64_t lda, const las_bf16* B, in
 }
 
 extern "C" size_t las_gemm_tn_ws_bytes(int M, int N, int split_k) {
-  return (split_k > 1 && M > 64 && N > 64 && N % 4 == 0) ? sizeof(float) * (size_t)split_k * (size_t)M * (size_t)N : 0;
+  return (split_k > 1 && M > 0 && N > 0 && N % 4 == 0) ? sizeof(float) * (size_t)split_k * (size_t)M * (size_t)N : 0;
 }
 
 // C += A^T B with a result that does not depend on scheduling (bit-identical from run to run): the K slices store their
 // tiles in the caller's workspace and tn_reduce_kernel adds them to C in slice order -- no fp32 atomics.  Shapes the
-// slice kernel is not built for (M or N <= 64, N not a multiple of 4) or a workspace that is too small run unsplit: one
-// workgroup per output tile, one contributor per element.
+// slice kernel is not built for (N not a multiple of 4) or a workspace that is too small run unsplit: one workgroup per output
+// tile, one contributor per element.  (Narrow products -- M or N <= 64: the token rows of the cell kernel, the projection
+// layer -- take the 128 x 128 slice kernel too when their caller splits K: unsplit on the 64-row kernel they ran 16
+// workgroups over K = B*U and took 140 us.)
 extern "C" int las_gemm_tn_ws(const las_bf16* A, int64_t lda, const las_bf16* B, int64_t ldb, float* C, int64_t ldc,
                               int M, int N, int K, int a_shift, int period, int c_perm_h, int split_k, float* workspace,
                               size_t workspace_bytes, void* stream) {

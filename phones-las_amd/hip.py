@@ -42,6 +42,8 @@ _SIGS = {
     'las_pyramid_lengths': ([_vp, _vp, _i32, _vp], C.c_int),
     'las_decoder_step_fwd': ([_vp, _i32, _vp], C.c_int),
     'las_decoder_step_bwd': ([_vp, _vp], C.c_int),
+    'las_decoder_seq_bwd_supported': ([_i32] * 7, C.c_int),
+    'las_decoder_seq_bwd': ([_vp, _vp], C.c_int),
     'las_seq_ce_loss': ([_vp, _i64, _vp, _vp, _i32, _i32, _i32, _f32, _vp, _vp, _i64, _vp], C.c_int),
     'las_seq_sigmoid_loss': ([_vp, _i64, _vp, _i64, _vp, _i32, _i32, _i32, _f32, _vp, _vp, _i64, _vp], C.c_int),
     'las_sample_features': ([_vp, _i64, _i32, _vp, _i64, _vp, _i64, _i32, _f32, C.c_uint32, C.c_uint32, _vp], C.c_int),
@@ -139,6 +141,14 @@ class DecStepBwd(C.Structure):
                 ('dh_b', _vp), ('ldhb', _i64), ('dh_c', _vp), ('ldhc', _i64),
                 ('norm', _i32), ('p', _vp), ('ldp', _i64), ('prev_align', _vp), ('ldpa', _i64), ('dalign_carry', _vp),
                 ('ldcarry', _i64), ('dbias_acc', _vp)]
+
+
+class DecSeqBwd(C.Structure):
+    """struct las_dec_seq_bwd (include/las_hip.h)."""
+    _fields_ = [('s', DecStepBwd), ('U', _i32), ('A', _i32), ('W0', _i32), ('reserved', _i32)] + [(n, _i64) for n in (
+        'inc_gates', 'inc_c', 'inc_align', 'inc_dz', 'inc_ds', 'inc_save', 'inc_pq')] + [
+        ('d_out', _vp), ('ld_dout', _i64), ('inc_dout', _i64), ('datt_out', _vp), ('ld_datt', _i64), ('waln', _vp), ('ld_waln', _i64),
+        ('kn', _vp), ('ld_kn', _i64), ('dfeed_out', _vp)]
 
 
 class DecPersistBwd(C.Structure):

@@ -314,9 +314,14 @@ def bilstm_backward(rec, dy, d_state, grads, need_dx=True, overlap=None, defer_w
             if dx is None:
                 dx = torch.cat(parts, -1) if split_in else (parts[0] if nd == 1 else parts[0] + parts[1])
     split = max(1, min(32, BT // 2048))
-    if D % 8 == 0:
+    # The fused product takes an input width that is a multiple of 8.  A feature count that is not (39-dim MFCCs: cfg1, cfg5)
+    # runs it at the PADDED width -- the zero pad columns of x give zero gradient rows -- into a scratch kernel gradient whose
+    # rows are then added where they belong.  (The separate products this replaces went through the 64-row kernel unsplit once
+    # the K slices stopped meeting in atomics: 2 x 1.26 ms exposed behind the last recurrence of a cfg5 step.)
+    Df = D if D % 8 == 0 else (Dp if (Dp % 8 == 0 and all(a.shape[-1] == Dp for a, _ in (dropped or [(x, 0)]))) else -1)
+    if Df >= 0:
         # fused product: about 700 workgroups in flight measured best on MI355X (128 x 128 output tiles, K cut in slices)
-        tiles = -(-(D + H + 1) // 128) * -(-(4 * H) // 128)
+        tiles = -(-(Df + H + 1) // 128) * -(-(4 * H) // 128)
         split = max(1, min(32, BT // 512, round(TN_WORKGROUPS / tiles)))
     keepalive = [dz, x, y] + [a for a, _ in (dropped or [])]
 
@@ -327,20 +332,30 @@ def bilstm_backward(rec, dy, d_state, grads, need_dx=True, overlap=None, defer_w
                 dzi = dz.view(BT, nd * 4 * H)[:, i * 4 * H:]
                 xa, lda = (dropped[i] if dropped is not None else (x, Dp))
                 yi = y.view(BT, nd * H)[:, i * H:]
-                if D % 8 == 0:
+                if Df >= 0:
                     # dK_x, dK_h and db of this direction in one product (dz read once); the K slices meet in a workspace
                     # owned by this layer (its products run one after the other on one stream)
                     # (one workspace per stream the products may run on)
-                    need = hip.lib().las_gemm_tn_lstm_workspace_bytes(D, H, split)
+                    need = hip.lib().las_gemm_tn_lstm_workspace_bytes(Df, H, split)
                     wss = w.__dict__.setdefault('_tn_ws', {})
                     ws = wss.get(i % 2 if exposed else 0)
                     if ws is None or ws.numel() * 4 < need:
                         ws = wss[i % 2 if exposed else 0] = torch.empty(max(1, need // 4), dtype=torch.float32, device=dev)
-                    tok = hip.prof_begin('gemm_tn_lstm', 2.0 * (D + H + 1) * 4 * H * BT)
-                    hip.check(hip.lib().las_gemm_tn_lstm(hip.p(xa) if D > 0 else None, lda, D, hip.p(yi), nd * H, H,
-                                                         (-1 if i == 0 else 1), T, hip.p(dzi), nd * 4 * H, hip.p(gk), hip.p(gb),
+                    gdst = gk
+                    if Df != D:                 # padded input width: the kernel gradient at [Df + H, 4H], folded back below
+                        pads = w.__dict__.setdefault('_gk_pad', {})
+                        gdst = pads.get(i)
+                        if gdst is None:
+                            gdst = pads[i] = torch.empty(Df + H, 4 * H, dtype=torch.float32, device=dev)
+                        gdst.zero_()
+                    tok = hip.prof_begin('gemm_tn_lstm', 2.0 * (Df + H + 1) * 4 * H * BT)
+                    hip.check(hip.lib().las_gemm_tn_lstm(hip.p(xa) if Df > 0 else None, lda, Df, hip.p(yi), nd * H, H,
+                                                         (-1 if i == 0 else 1), T, hip.p(dzi), nd * 4 * H, hip.p(gdst), hip.p(gb),
                                                          BT, split, hip.p(ws), hip.stream()))
                     hip.prof_end(tok)
+                    if Df != D:
+                        gk[:D].add_(gdst[:D])
+                        gk[D:].add_(gdst[Df:])
                     continue
                 if D > 0:
                     hip.gemm_tn(xa, dzi, gk, D, 4 * H, BT, lda=lda, ldb=nd * 4 * H, ldc=4 * H, split_k=split, c_perm_h=H)

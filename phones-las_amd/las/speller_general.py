@@ -549,6 +549,17 @@ class GeneralSpeller:
         self.last_Tm = Tm
         return logits
 
+    def _seq_bwd_ok(self, sv):
+        import os
+        if os.environ.get('LAS_DEC_PERSIST', '1') == '0' or os.environ.get('LAS_DEC_SEQ_BWD', '1') == '0':
+            return False
+        if self.NL != 1 or self.tokx or self.sigmoid or sv['keep'] < 1.0 or self.debug_hook is not None:
+            return False
+        if not (self.has_al or self.mono):
+            return False
+        return hip.lib().las_decoder_seq_bwd_supported(self.Hd, self.M, self.A if self.has_al else 0, self.win[0] + self.Hd, sv['Tm'],
+                                                       self.att, sv['norm']) == 1
+
     def log_probs_loss(self, loss, weight, grad_scale):
         """loss += weight * compute_log_probs_loss(raw outputs) (model_helper.py:132-146,327-331) on the attention vectors
         of the last forward_train; its gradient joins d(outputs) in backward()."""
@@ -613,7 +624,48 @@ class GeneralSpeller:
         def v(buf, off, ld):              # (address, row stride) of a column window of a [B, ld] fp32 buffer
             return (hip.addr(buf, off), ld)
 
-        for t in range(U - 1, -1, -1):
+        seq = self._seq_bwd_ok(sv)
+        if seq:
+            # all U steps in ONE launch, one workgroup per utterance (las_decoder_seq_bwd): what the loop below does step by step
+            q = hip.DecSeqBwd()
+            s = q.s
+            s.B, s.Hd, s.M, s.Tm, s.attention, s.mode = B, Hd, M, Tm, self.att, 0
+            s.dctx_save, s.ldds = hip.addr(dctx_all), U * M
+            s.dc = hip.addr(dc[0])
+            s.gates, s.ldg = hip.addr(sv['gates'][0]), U * 4 * Hd
+            s.c_new, s.ldcn = hip.addr(sv['cs'][0], Hd), (U + 1) * Hd
+            s.c_prev, s.ldcp = hip.addr(sv['cs'][0]), (U + 1) * Hd
+            s.align, s.lda = hip.addr(sv['align']), U * Tmp
+            s.keys, s.values, s.mem_len = hip.addr(sv['keys']), hip.addr(sv['memory']), hip.addr(sv['mem_len'])
+            s.dz, s.ldz = hip.addr(dz[0]), U * 4 * Hd
+            s.ds_out, s.ldso = hip.addr(ds_all), U * Tmp
+            s.drop_keep, s.feed_width = 1.0, self.E + A
+            if self.uses_wq:
+                s.pq, s.ldpq = hip.addr(sv['pq']), U * Hd
+                s.wq_t = hip.addr(self.wq_t)
+                s.dpq_out, s.lddpq = hip.addr(dpq_all), U * Hd
+            if bah:
+                s.att_v = hip.addr(self.att_v)
+                s.dkeys_acc, s.dv_acc = hip.addr(dkeys), hip.addr(grads[self.V_ATT])
+            s.norm = sv['norm']
+            if self.mono:
+                s.p, s.ldp = hip.addr(sv['p']), U * Tmp
+                s.dalign_carry, s.ldcarry = hip.addr(carry), Tmp
+                s.dbias_acc = hip.addr(grads[self.B_SCORE])
+            q.U, q.A, q.W0 = U, (A if self.has_al else 0), W[0]
+            q.inc_gates, q.inc_c, q.inc_align, q.inc_dz, q.inc_ds, q.inc_save, q.inc_pq = 4 * Hd, Hd, Tmp, 4 * Hd, Tmp, M, Hd
+            q.d_out, q.ld_dout, q.inc_dout = hip.addr(d_out), U * P, P
+            if self.has_al:
+                q.datt_out, q.ld_datt = hip.addr(datt_bf), U * A
+                q.waln, q.ld_waln = hip.addr(self.waln), A
+            q.kn, q.ld_kn = hip.addr(self.kn[0]), 4 * Hd
+            dfeed0 = torch.empty(B, W[0], dtype=f32, device=dev)
+            q.dfeed_out = hip.addr(dfeed0)
+            tok = hip.prof_begin('dec_seq_bwd', 2.0 * U * B * (W[0] * 4 * Hd + 2 * Tm * Hd + 2 * Tm * M + (Hd + M) * (A if self.has_al else 0)))
+            hip.check(lib.las_decoder_seq_bwd(C.byref(q), st))
+            hip.prof_end(tok)
+            dx[0][0] = dfeed0                          # step 0's d[feed | h]: the gradient into the initial state
+        for t in (range(U - 1, -1, -1) if not seq else ()):
             cur, nxt = t & 1, (t + 1) & 1
             has_next = t + 1 < U
 

@@ -261,7 +261,7 @@ def test_512_unit_one_launch_decoders_over_several_groups(case):
 
 
 @pytest.mark.parametrize('case', ['cfg5_binf', 'cfg5_full'])
-def test_one_launch_forward_with_attention_layer_and_monotonic_normaliser_matches_the_step_launches(case, monkeypatch):
+def test_one_launch_decoder_with_attention_layer_and_monotonic_normaliser_matches_the_step_launches(case, monkeypatch):
     """cfg5's decoder (attention layer of 2 * binf_count outputs + bahdanau_monotonic) forward in ONE launch
     (dec_persist_fwd_kernel<..., AL>: the monotonic chain inside the shared step body, the attention layer as a 16-column-tile
     product on the group's members behind one more group barrier) against the same model on the per-step launches
@@ -272,6 +272,7 @@ def test_one_launch_forward_with_attention_layer_and_monotonic_normaliser_matche
     outs = {}
     for flag in ('1', '0'):
         monkeypatch.setenv('LAS_DEC_PERSIST_AL', flag)
+        monkeypatch.setenv('LAS_DEC_SEQ_BWD', flag)         # ... and the backward: one launch (one workgroup per utterance) or step by step
         model, feats, labels, nb = _model(case)
         model.vars.grad.zero_()
         loss, logits, dlogits = model.forward_train(feats, labels)
