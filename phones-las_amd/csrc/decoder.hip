@@ -1660,6 +1660,7 @@ __device__ void dec_step_bwd_body(const las_dec_step_bwd& s, const int b, float*
     if (s.dctx_save) s.dctx_save[(int64_t)b * s.ldds + m] = las_f2bf(v);
   }
   __syncthreads();
+  LAS_STAMPB(s.step, 2);
 
   // dalign[t'] = values[b,t',:] . dctx : 16 lanes per frame (4 frames per wave instruction); the loads of DB frames per
   // lane are all in flight together (cold L2 at every launch: each dependent round trip goes to Infinity Cache)
@@ -1686,6 +1687,35 @@ __device__ void dec_step_bwd_body(const las_dec_step_bwd& s, const int b, float*
           if (t < len) {
 #pragma unroll
             for (int j = 0; j < NVMAX; ++j)
+              if (j < nv) acc += dot8(vv[f][j], dctx + sub * 8 + j * 128);
+          }
+#pragma unroll
+          for (int o = 8; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+          if (sub == 0 && t < Tm) ds[t] = (t < len) ? acc : 0.f;
+        }
+      }
+    } else if (nv <= 8) {
+      // M <= 1024 (the usual pyramid output, 4 x 256): four frames per lane at a time with ALL of their pieces in flight (32
+      // loads of 16 bytes).  The rolled loop below kept eight in flight and made seven dependent rounds of them per step:
+      // 23 us of the sequential backward's 78 us per step at cfg5 (phase stamps).
+      constexpr int FR = 4, NV8 = 8;
+      for (int t0 = 0; t0 < Tm; t0 += 16 * FR) {
+        uint4 vv[FR][NV8];
+#pragma unroll
+        for (int f = 0; f < FR; ++f) {
+          const int t = t0 + f * 16 + wave * 4 + grp;
+          const unsigned short* r = vals + (int64_t)min(t, Tm - 1) * M;
+#pragma unroll
+          for (int j = 0; j < NV8; ++j)
+            if (j < nv && t < len) vv[f][j] = *reinterpret_cast<const uint4*>(r + sub * 8 + j * 128);
+        }
+#pragma unroll
+        for (int f = 0; f < FR; ++f) {
+          const int t = t0 + f * 16 + wave * 4 + grp;
+          float acc = 0.f;
+          if (t < len) {
+#pragma unroll
+            for (int j = 0; j < NV8; ++j)
               if (j < nv) acc += dot8(vv[f][j], dctx + sub * 8 + j * 128);
           }
 #pragma unroll
@@ -1721,6 +1751,7 @@ __device__ void dec_step_bwd_body(const las_dec_step_bwd& s, const int b, float*
   }
   __syncthreads();
 
+  LAS_STAMPB(s.step, 3);
   if (s.norm == LAS_NORM_MONOTONIC_PARALLEL) {
     // backward of a = p * c * S,  c = exp(excl-cumsum(log clip(1-p, tiny, 1))),  S = cumsum(prev / clip(c, 1e-10, 1));
     // the gradient also flows into prev = align_{t-1} (dalign_carry) and comes back from step t+1 the same way
@@ -1790,6 +1821,7 @@ __device__ void dec_step_bwd_body(const las_dec_step_bwd& s, const int b, float*
   __syncthreads();
   }
 
+  LAS_STAMPB(s.step, 4);
   // gradient into the query path: L = Hd/8 lanes cover one frame (16-byte loads), 256/L frame phases
   const unsigned short* keys = s.keys + (int64_t)b * Tm * Hd;
   const int L = Hd / 8, P = 256 / L;            // Hd in {64,...,2048} and a power of two
@@ -1879,6 +1911,7 @@ __device__ void dec_step_bwd_body(const las_dec_step_bwd& s, const int b, float*
       atomicAdd(s.dv_acc + u, acc);
     }
   }
+  LAS_STAMPB(s.step, 5);
   // reduce the P per-phase partials (dhs is [P][Hd] = 2048 floats)
   for (int u = tid; u < Hd; u += 256) {
     float acc = 0.f;
@@ -1909,6 +1942,7 @@ __device__ void dec_step_bwd_body(const las_dec_step_bwd& s, const int b, float*
     return;
   }
   }
+  LAS_STAMPB(s.step, 6);
   // ---- LSTM cell backward (Appendix F) ----
   for (int u = tid; u < Hd; u += 256) {
     const float* gp = s.gates + (int64_t)b * s.ldg + u;
@@ -1981,6 +2015,7 @@ __global__ __launch_bounds__(256) void dec_seq_bwd_kernel(las_dec_seq_bwd p) {
     }
     st.step = t;
     const float* dout = p.d_out + (int64_t)b * p.ld_dout + (int64_t)t * p.inc_dout;
+    LAS_STAMPB(t, 0);
     if (A > 0) {
       // d(attention_t), rounded to bf16 once (the operand of both of the attention layer's backward products)
       for (int a = tid; a < A; a += 256) {
@@ -2015,6 +2050,7 @@ __global__ __launch_bounds__(256) void dec_seq_bwd_kernel(las_dec_seq_bwd p) {
         if (n2 < Hd + M) dqc[n2] = acc1;
       }
       __syncthreads();
+      LAS_STAMPB(t, 1);
       st.dctx_a = dqc + Hd;  st.ldda = 0;          // (LDS: the row stride is not used)
       st.dctx_b = nullptr;
       st.dh_b = dqc;         st.ldhb = 0;          // the attention layer's query input
@@ -2029,6 +2065,7 @@ __global__ __launch_bounds__(256) void dec_seq_bwd_kernel(las_dec_seq_bwd p) {
     }
     dec_step_bwd_body(st, b, sm);
     __syncthreads();                               // dz_t of this utterance is in memory (same workgroup: visible behind the barrier)
+    LAS_STAMPB(t, 8);
     if (t > 0 || p.dfeed_out) {
       // d[feed | h]_t[n] = sum_k dz_t[k] K[n][k]   (kn: [W0, 4 Hd] bf16, row n contiguous); a wave per output row, every lane
       // keeps its 16-byte pieces of dz_t in registers for all rows
@@ -2043,9 +2080,9 @@ __global__ __launch_bounds__(256) void dec_seq_bwd_kernel(las_dec_seq_bwd p) {
 #pragma unroll
           for (int j = 0; j < 8; ++j) dzf[i][j] = las_bf2f(e[j]);
         }
-      // eight rows per wave at a time, all of their pieces requested before the first is used (a row at a time was one L2
+      // sixteen rows per wave at a time, all of their pieces requested before the first is used (a row at a time was one L2
       // round trip per row: 84 per wave and step -- the launch took longer than the 400 step launches it replaces)
-      constexpr int RB = 8;
+      constexpr int RB = 16;
       for (int n0 = wave * RB; n0 < W0; n0 += 4 * RB) {
         uint4 kv[RB][2];
 #pragma unroll
@@ -2076,6 +2113,7 @@ __global__ __launch_bounds__(256) void dec_seq_bwd_kernel(las_dec_seq_bwd p) {
       }
     }
     __syncthreads();
+    LAS_STAMPB(t, 9);
   }
   if (p.dfeed_out)
     for (int n = tid; n < W0; n += 256) p.dfeed_out[(int64_t)b * W0 + n] = dfeed[n];
