@@ -151,10 +151,10 @@ __global__ void colsum_ws_kernel(const unsigned short* X, int64_t ldx, int M, in
     __hip_atomic_store(partial + (int64_t)blockIdx.y * N64 + col, (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]),
                        __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
-  __threadfence();
-  __syncthreads();
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this thread's write-through partial is acknowledged (no agent-scope fence:
+  __syncthreads();                                       // it would write back the XCD's dirty L2 lines)
   if (threadIdx.x == 0 && threadIdx.y == 0)
-    last = (__hip_atomic_fetch_add(counters + blockIdx.x, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == gridDim.y - 1) ? 1u : 0u;
+    last = (__hip_atomic_fetch_add(counters + blockIdx.x, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.y - 1) ? 1u : 0u;
   __syncthreads();
   if (!last) return;
   if (threadIdx.y == 0 && col < N) {
@@ -210,10 +210,10 @@ __global__ __launch_bounds__(256) void colsum_ws8_kernel(const unsigned short* X
     for (int k = 0; k < 8; ++k) t += red[k][c];
     __hip_atomic_store(partial + (int64_t)blockIdx.y * N256 + blockIdx.x * 256 + c, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
-  __threadfence();
-  __syncthreads();
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this thread's write-through partial is acknowledged (no agent-scope fence:
+  __syncthreads();                                       // it would write back the XCD's dirty L2 lines)
   if (threadIdx.x == 0)
-    last = (__hip_atomic_fetch_add(counters + blockIdx.x, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == gridDim.y - 1) ? 1u : 0u;
+    last = (__hip_atomic_fetch_add(counters + blockIdx.x, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.y - 1) ? 1u : 0u;
   __syncthreads();
   if (!last) return;
   const int c = blockIdx.x * 256 + threadIdx.x;
