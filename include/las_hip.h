@@ -142,8 +142,13 @@ int las_cast_bf16(const float* src, int64_t lds, int rows, int cols, las_bf16* d
  *   LAS_IMAGE_CAST            the las_cast_bf16 window (batch 1) with the same field meanings;
  *   LAS_IMAGE_PACK_RECURRENT  las_lstm_pack_recurrent: src = K_h (ld 4H), rows = H, dst = packed image;
  *   LAS_IMAGE_BIAS_INTERLEAVE fp32 dst[u*4+g] = src[g*H+u], rows = H (the LSTM bias in the recurrent kernels' order);
- *   LAS_IMAGE_COPY_F32        fp32 dst[0:cols] = src[0:cols]. */
-enum las_image_kind { LAS_IMAGE_CAST = 0, LAS_IMAGE_PACK_RECURRENT = 1, LAS_IMAGE_BIAS_INTERLEAVE = 2, LAS_IMAGE_COPY_F32 = 3 };
+ *   LAS_IMAGE_COPY_F32        fp32 dst[0:cols] = src[0:cols];
+ *   LAS_IMAGE_PACK_MFMA_B     bf16 image of src [rows, cols] (row stride lds) in matrix-core B-fragment order, zero padded to
+ *                             dst_rows (multiple of 16) x dst_cols (multiple of 32): [dst_rows / 16][dst_cols / 32][64 lanes][8]
+ *                             with lane l = row tile * 16 + (l & 15), columns chunk * 32 + (l >> 4) * 8 + 0..7 -- every
+ *                             fragment one contiguous KB (rows 2^k bytes apart all land on one L2 channel otherwise). */
+enum las_image_kind { LAS_IMAGE_CAST = 0, LAS_IMAGE_PACK_RECURRENT = 1, LAS_IMAGE_BIAS_INTERLEAVE = 2, LAS_IMAGE_COPY_F32 = 3,
+                      LAS_IMAGE_PACK_MFMA_B = 4 };
 typedef struct las_image_job {
   const float* src;
   void* dst;
@@ -450,7 +455,8 @@ int las_decoder_persist_bwd(const las_dec_persist_bwd* p, void* stream);
  *   A > 0: attention layer of A outputs: d(attention_t) = d_out[b, t, :A] + d(feed)_{t+1}[:A] (saved as bf16 in datt_out
  *          [B, U, A] for d(W_al)), d[query | context] = d(attention_t) waln^T with waln [Hd + M, A] bf16 (row stride ld_waln);
  *   A = 0: the context is output and feed: d(context_t) = d_out[b, t, :M] + d(feed)_{t+1}[:M].
- * d(feed)_t = dz_t kn^T, kn [W0, 4 Hd] bf16 (row n = row n of the cell kernel below the token rows), W0 = (A or M) + Hd.
+ * d(feed)_t = dz_t kn^T, kn [W0, 4 Hd] (row n = row n of the cell kernel below the token rows), W0 = (A or M) + Hd, handed in
+ * as its LAS_IMAGE_PACK_MFMA_B image kn_packed (dst_rows = W0 rounded up to 16, dst_cols = 4 Hd).
  * dfeed_out (nullable) [B, W0] fp32: step 0's, the gradient into the initial feed / state; s.dc ends as dc_{-1}. */
 typedef struct las_dec_seq_bwd {
   las_dec_step_bwd s;
@@ -462,9 +468,14 @@ typedef struct las_dec_seq_bwd {
   int64_t ld_datt;
   const las_bf16* waln;
   int64_t ld_waln;
-  const las_bf16* kn;
-  int64_t ld_kn;
+  const las_bf16* kn_packed;
+  int64_t reserved2;
   float* dfeed_out;
+  /* A > 0, optional: VW = values W_c [B, T', A] fp32 (W_c: rows [Hd, Hd + M) of the attention layer's kernel; utterance stride
+   * ld_vw), formed by the caller once per train step.  With it d(alignments)_t = VW d(attention_t) (T' x A multiply-adds from
+   * an LDS copy) instead of values . d(context_t) (a pass over the utterance's T' x M values at every step). */
+  const float* vw;
+  int64_t ld_vw;
 } las_dec_seq_bwd;
 int las_decoder_seq_bwd_supported(int Hd, int M, int A, int W0, int Tm, int attention, int norm);
 int las_decoder_seq_bwd(const las_dec_seq_bwd* p, void* stream);

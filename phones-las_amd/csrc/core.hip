@@ -70,6 +70,18 @@ __global__ __launch_bounds__(256) void refresh_images_kernel(const las_image_job
     float* dst = static_cast<float*>(jb.dst);
     const int H = jb.rows;
     for (int64_t i = first; i < 4 * (int64_t)H; i += stride) dst[i] = jb.src[(i & 3) * H + (i >> 2)];     // [u*4+g] <- [g*H+u]
+  } else if (jb.kind == LAS_IMAGE_PACK_MFMA_B) {
+    // [dst_rows / 16 column tiles][dst_cols / 32 K chunks][64 lanes][8]: lane l of a fragment holds row tile * 16 + (l & 15),
+    // columns chunk * 32 + (l >> 4) * 8 + 0..7 of the source -- the B operand of v_mfma_f32_16x16x32_bf16 as one contiguous KB
+    unsigned short* dst = static_cast<unsigned short*>(jb.dst);
+    const int KC = jb.dst_cols / 32;
+    const int64_t total = (int64_t)jb.dst_rows * jb.dst_cols;
+    for (int64_t i = first; i < total; i += stride) {
+      const int e = (int)(i & 7), lane = (int)(i >> 3) & 63;
+      const int64_t frag = i >> 9;
+      const int n = (int)(frag / KC) * 16 + (lane & 15), k = (int)(frag % KC) * 32 + (lane >> 4) * 8 + e;
+      dst[i] = las_f2bf(n < jb.rows && k < jb.cols ? jb.src[(int64_t)n * jb.lds + k] : 0.f);
+    }
   } else {                                                  // LAS_IMAGE_COPY_F32
     float* dst = static_cast<float*>(jb.dst);
     for (int64_t i = first; i < jb.cols; i += stride) dst[i] = jb.src[i];

@@ -1631,7 +1631,18 @@ __host__ __device__ inline size_t dec_step_bwd_floats(int M, int Tm, int Hd, int
 
 // One backward step of utterance b by the 256 threads of a workgroup (dec_step_bwd_kernel: one launch per step; dec_seq_bwd_kernel:
 // all steps of an utterance in one launch, the struct's pointers advanced by the caller; a pointer may then address LDS).
-__device__ void dec_step_bwd_body(const las_dec_step_bwd& s, const int b, float* sm) {
+// vw / datt / A (dec_seq_bwd_kernel with an attention layer): d(alignments) without touching the values.  d(context) is
+// d(attention) W_c^T there (W_c: the context rows of the attention layer's kernel), so d(alignments)[t'] = values[t'] . d(context)
+// = sum_a d(attention)[a] (values W_c)[t'][a]: VW = values W_c [T', A] does not depend on the decoder step -- one product per
+// train step, resident in LDS (row stride A + 1) -- and a step's pass over the utterance's values (400 KB from beyond L2: 21 of
+// the sequential backward's 75 us per step at cfg5) becomes T' x A multiply-adds.
+// NPK > 0 (dec_seq_bwd_kernel, Bahdanau scores): the utterance's fp32 d(keys) lives in REGISTERS across the steps -- dkr[i][j]
+// is frame phase + i P, column u + j of the thread's fixed (phase, u) -- instead of being read and written in memory at
+// every step (NPK frame passes x 8 columns; the caller adds them into dkeys_acc once, after the last step).
+constexpr int SEQ_NPK = 25;
+template <int NPK = 0>
+__device__ __forceinline__ void dec_step_bwd_body(const las_dec_step_bwd& s, const int b, float* sm, const float* vw = nullptr,
+                                                  const float* datt = nullptr, const int A = 0, float (*dkr)[8] = nullptr) {
   float* dctx = sm;               // [M]
   float* ds = dctx + s.M;         // [Tm] dalign -> dscore
   float* dhs = ds + s.Tm;         // [256/L][Hd] = 2048 floats: per-phase partial d h (score path) / dpq
@@ -1665,7 +1676,16 @@ __device__ void dec_step_bwd_body(const las_dec_step_bwd& s, const int b, float*
   // dalign[t'] = values[b,t',:] . dctx : 16 lanes per frame (4 frames per wave instruction); the loads of DB frames per
   // lane are all in flight together (cold L2 at every launch: each dependent round trip goes to Infinity Cache)
   const unsigned short* vals = s.values + (int64_t)b * Tm * M;
-  {
+  if (NPK > 0 || vw) {                                 // (the register-d(keys) kernel is only launched with VW)
+    for (int t = tid; t < Tm; t += 256) {
+      float acc = 0.f;
+      if (t < len) {
+        const float* row = vw + (int64_t)t * (A + 1);
+        for (int a = 0; a < A; ++a) acc += row[a] * datt[a];
+      }
+      ds[t] = acc;
+    }
+  } else {
     constexpr int DB = 8, NVMAX = 4;               // frames in flight per lane; 16-byte pieces per lane and frame (M <= 512)
     const int sub = lane & 15, grp = lane >> 4;
     const int nv = M / 128;
@@ -1830,7 +1850,7 @@ __device__ void dec_step_bwd_body(const las_dec_step_bwd& s, const int b, float*
     float a[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) a[j] = 0.f;
-    if (!att_additive(s.attention)) {
+    if (NPK == 0 && !att_additive(s.attention)) {      // (NPK > 0: launched for Bahdanau scores only)
       constexpr int KB = 16;                 // key loads in flight per thread
       for (int tb = phase; tb < len; tb += P * KB) {
         uint4 kk[KB];
@@ -1860,6 +1880,34 @@ __device__ void dec_step_bwd_body(const las_dec_step_bwd& s, const int b, float*
       // requested before the first is used (one frame at a time made every frame a dependent L2 round trip: 25 per thread
       // and step at 512 units)
       constexpr int FB = 4;
+      if constexpr (NPK > 0) {
+#pragma unroll
+        for (int i0 = 0; i0 < NPK; i0 += FB) {
+          uint4 kv[FB];
+#pragma unroll
+          for (int i = 0; i < FB; ++i) {
+            const int t = phase + (i0 + i) * P;
+            if (i0 + i < NPK && t < len) kv[i] = *reinterpret_cast<const uint4*>(keys + (int64_t)t * Hd + u);
+          }
+#pragma unroll
+          for (int i = 0; i < FB; ++i) {
+            const int t = phase + (i0 + i) * P;
+            if (i0 + i < NPK && t < len) {
+              const unsigned short* e = reinterpret_cast<const unsigned short*>(&kv[i]);
+              const float d = ds[t];
+#pragma unroll
+              for (int j = 0; j < 8; ++j) {
+                const float th = las_tanh(las_bf2f(e[j]) + qq[j]);
+                dv[j] += d * th;
+                const float p = d * vv[j] * (1.f - th * th);
+                a[j] += p;
+                dkr[i0 + i < NPK ? i0 + i : 0][j] += p;
+              }
+            }
+          }
+          __builtin_amdgcn_sched_barrier(0);         // keep the next passes' key loads from being hoisted over this one (registers)
+        }
+      } else
       for (int tb = phase; tb < len; tb += P * FB) {
         uint4 kv[FB];
         float4 d0[FB], d1[FB];
@@ -1888,6 +1936,8 @@ __device__ void dec_step_bwd_body(const las_dec_step_bwd& s, const int b, float*
           a[j] += p;
           dkv[j] += p;
         }
+        // (streaming hints on this read-modify-write were tried -- the 8 utterances of an XCD move 3.2 MB of fp32 d(keys) through
+        //  its 4 MB L2 at every step -- and made the phase slower, 11.5 -> 17.3 us, without helping anything else)
         float4* dk = reinterpret_cast<float4*>(s.dkeys_acc + ((int64_t)b * Tm + t) * Hd + u);   // this workgroup owns utterance b
         dk[0] = make_float4(dkv[0], dkv[1], dkv[2], dkv[3]);
         dk[1] = make_float4(dkv[4], dkv[5], dkv[6], dkv[7]);
@@ -1984,6 +2034,7 @@ __global__ __launch_bounds__(256) void dec_step_bwd_kernel(las_dec_step_bwd s) {
 // same operand roundings, same summation order of the two products' K loops is NOT guaranteed -- compared at 1e-3).
 // LDS: the step body's floats, then d(attention) [A], d[query | context] [Hd + M], d(feed) [W0].
 // ------------------------------------------------------------------------------------------------
+template <int NPK, int KC>                      // KC = 4 Hd / 32: the 32-deep chunks of the gate columns (Hd 128: 16, 256: 32)
 __global__ __launch_bounds__(256) void dec_seq_bwd_kernel(las_dec_seq_bwd p) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   const las_dec_step_bwd& s0 = p.s;
@@ -1993,7 +2044,20 @@ __global__ __launch_bounds__(256) void dec_seq_bwd_kernel(las_dec_seq_bwd p) {
   float* datt = sm + dec_step_bwd_floats(M, s0.Tm, Hd, s0.norm);      // [A] (bf16-rounded values)
   float* dqc = datt + (A > 0 ? A : 0);                                 // [Hd + M]
   float* dfeed = dqc + (A > 0 ? Hd + M : 0);                           // [W0] d[feed | h]_{t} from step t+1
+  // [4 Hd] bf16 dz_t and 8 zeros behind it, on a 16-byte boundary (sm is): the A operand of the d(feed) product
+  unsigned short* dzl = reinterpret_cast<unsigned short*>(sm + (((dfeed + W0 - sm) + 3) & ~(ptrdiff_t)3));
+  float* vwl = dfeed + W0 + 2 * Hd + 8;                                // [Tm][A + 1]: values W_c of this utterance (p.vw given)
   for (int n = tid; n < W0; n += 256) dfeed[n] = 0.f;
+  float dkr[NPK > 0 ? NPK : 1][8];                                    // d(keys) of this utterance (Bahdanau scores; see the body)
+#pragma unroll
+  for (int i = 0; i < (NPK > 0 ? NPK : 1); ++i)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) dkr[i][j] = 0.f;
+  const bool use_vw = A > 0 && p.vw != nullptr;
+  if (use_vw) {
+    const float* src = p.vw + (int64_t)b * p.ld_vw;
+    for (int e = tid; e < s0.Tm * A; e += 256) vwl[(e / A) * (A + 1) + e % A] = src[e];
+  }
   __syncthreads();
   for (int t = p.U - 1; t >= 0; --t) {
     const bool has_next = t + 1 < p.U;
@@ -2063,60 +2127,66 @@ __global__ __launch_bounds__(256) void dec_seq_bwd_kernel(las_dec_seq_bwd p) {
       st.dh_b = st.dh_c = nullptr;
       st.dh_rec = has_next ? dfeed + feed : nullptr;   st.ldr = 0;
     }
-    dec_step_bwd_body(st, b, sm);
+    dec_step_bwd_body<NPK>(st, b, sm, use_vw ? vwl : nullptr, datt, A, dkr);
     __syncthreads();                               // dz_t of this utterance is in memory (same workgroup: visible behind the barrier)
     LAS_STAMPB(t, 8);
     if (t > 0 || p.dfeed_out) {
-      // d[feed | h]_t[n] = sum_k dz_t[k] K[n][k]   (kn: [W0, 4 Hd] bf16, row n contiguous); a wave per output row, every lane
-      // keeps its 16-byte pieces of dz_t in registers for all rows
+      // d[feed | h]_t[n] = sum_k dz_t[k] K[n][k]   (kn: [W0, 4 Hd] bf16, row n contiguous) on the matrix cores: dz_t is row 0 of
+      // the A tile (the other 15 rows zero), a wave takes the 16-column tiles wave, wave + 4, ... and reads its B fragments
+      // straight from kn (16 bytes per lane: 8 consecutive k of row n).  As multiply-adds on bf16 -> fp32 conversions (a wave
+      // per output row, all pieces in flight) this product was ALU-bound: 23 of the 55 us of a step.
+      // dz_t goes through LDS (2 KB): the A fragments are read from there at every product -- held in registers across the
+      // tiles they cost 128 VGPRs, which the register-resident d(keys) needs.  Lanes of rows 1..15 read the zeros behind it.
       const unsigned short* dzr = st.dz + (int64_t)b * st.ldz;
-      const int K4 = 4 * Hd, NP = K4 / 512;        // 16-byte pieces per lane (Hd = 128: 1, 256: 2)
-      float dzf[2][8];
+      const int l15 = lane & 15, lq = lane >> 4;
+      if (tid < Hd / 2) *reinterpret_cast<uint4*>(dzl + tid * 8) = ld16(dzr + tid * 8);
+      if (tid == 255) *reinterpret_cast<uint4*>(dzl + 4 * Hd) = make_uint4(0, 0, 0, 0);
+      __syncthreads();
+      const unsigned short* azp = l15 == 0 ? dzl + 8 * lq : dzl + 4 * Hd;
+      const int azs = l15 == 0 ? 32 : 0;
+      LAS_STAMPB(t, 10);
+      const int NTL = (W0 + 15) / 16;
+      for (int nt = wave; nt < NTL; nt += 4) {
+        const unsigned short* kfr = p.kn_packed + ((int64_t)nt * KC * 64 + lane) * 8;     // fragment (nt, kc): + kc * 512
+        f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
-        if (i < NP) {
-          const uint4 v = ld16(dzr + (i * 64 + lane) * 8);
-          const unsigned short* e = reinterpret_cast<const unsigned short*>(&v);
+        for (int k0 = 0; k0 < KC; k0 += 16) {
+          uint4 bv[16];
 #pragma unroll
-          for (int j = 0; j < 8; ++j) dzf[i][j] = las_bf2f(e[j]);
+          for (int i = 0; i < 16; ++i) bv[i] = ld16(kfr + (k0 + i) * 512);
+          uint4 av[16];                              // (the LDS reads overlap the loads' round trip)
+#pragma unroll
+          for (int i = 0; i < 16; ++i) av[i] = *reinterpret_cast<const uint4*>(azp + (k0 + i) * azs);
+#pragma unroll
+          for (int i = 0; i < 16; ++i)
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, av[i]), __builtin_bit_cast(bf16x8, bv[i]), acc, 0, 0, 0);
         }
-      // sixteen rows per wave at a time, all of their pieces requested before the first is used (a row at a time was one L2
-      // round trip per row: 84 per wave and step -- the launch took longer than the 400 step launches it replaces)
-      constexpr int RB = 16;
-      for (int n0 = wave * RB; n0 < W0; n0 += 4 * RB) {
-        uint4 kv[RB][2];
-#pragma unroll
-        for (int r = 0; r < RB; ++r) {
-          const unsigned short* krow = p.kn + (int64_t)min(n0 + r, W0 - 1) * p.ld_kn;
-#pragma unroll
-          for (int i = 0; i < 2; ++i)
-            if (i < NP) kv[r][i] = ld16(krow + (i * 64 + lane) * 8);
-        }
-        float acc[RB];
-#pragma unroll
-        for (int r = 0; r < RB; ++r) {
-          acc[r] = 0.f;
-#pragma unroll
-          for (int i = 0; i < 2; ++i)
-            if (i < NP) acc[r] += dot8(kv[r][i], dzf[i]);
-        }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1)
-#pragma unroll
-          for (int r = 0; r < RB; ++r) acc[r] += __shfl_xor(acc[r], o, 64);
-        if (lane < RB && n0 + lane < W0) {
-          float v = acc[0];
-#pragma unroll
-          for (int r = 1; r < RB; ++r) v = lane == r ? acc[r] : v;
-          dfeed[n0 + lane] = v;
-        }
+        if (lq == 0 && nt * 16 + l15 < W0) dfeed[nt * 16 + l15] = acc[0];
+        if (nt == wave) LAS_STAMPB(t, 11);
       }
+      LAS_STAMPB(t, 12);
     }
     __syncthreads();
     LAS_STAMPB(t, 9);
   }
   if (p.dfeed_out)
     for (int n = tid; n < W0; n += 256) p.dfeed_out[(int64_t)b * W0 + n] = dfeed[n];
+  if constexpr (NPK > 0) {
+    // the register-resident d(keys) joins the accumulator once (same thread layout as the body's query path)
+    const int L = Hd / 8, P = 256 / L, phase = tid / L, u = (tid % L) * 8;
+#pragma unroll
+    for (int i = 0; i < NPK; ++i) {
+      const int tt = phase + i * P;
+      if (tt < s0.Tm) {
+        float4* dk = reinterpret_cast<float4*>(s0.dkeys_acc + ((int64_t)b * s0.Tm + tt) * Hd + u);
+        float4 a0 = dk[0], a1 = dk[1];
+        a0.x += dkr[i][0]; a0.y += dkr[i][1]; a0.z += dkr[i][2]; a0.w += dkr[i][3];
+        a1.x += dkr[i][4]; a1.y += dkr[i][5]; a1.z += dkr[i][6]; a1.w += dkr[i][7];
+        dk[0] = a0;
+        dk[1] = a1;
+      }
+    }
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -3302,8 +3372,8 @@ extern "C" int las_decoder_seq_bwd_supported(int Hd, int M, int A, int W0, int T
   if (M % 128 != 0 || A < 0 || A % 8 != 0 || W0 <= 0) return 0;
   if (attention < LAS_ATT_LUONG || attention > LAS_ATT_BAHDANAU_MONOTONIC) return 0;
   if (norm != LAS_NORM_SOFTMAX && norm != LAS_NORM_MONOTONIC_PARALLEL) return 0;
-  const size_t lds = (dec_step_bwd_floats(M, Tm, Hd, norm) + (size_t)(A > 0 ? A + Hd + M : 0) + W0) * sizeof(float);
-  return lds <= 64 * 1024 ? 1 : 0;
+  const size_t lds = (dec_step_bwd_floats(M, Tm, Hd, norm) + (size_t)(A > 0 ? A + Hd + M : 0) + W0 + 2 * Hd + 8) * sizeof(float);
+  return lds <= 64 * 1024 ? 1 : 0;      // (+ Tm * (A + 1) floats when the caller hands in VW: checked at the launch against 160 KiB)
 }
 
 extern "C" int las_decoder_seq_bwd(const las_dec_seq_bwd* p, void* stream) {
@@ -3312,15 +3382,37 @@ extern "C" int las_decoder_seq_bwd(const las_dec_seq_bwd* p, void* stream) {
               "las_decoder_seq_bwd: configuration not supported (Hd=%d M=%d A=%d W0=%d Tm=%d attention=%d norm=%d)", s->Hd, s->M, p->A,
               p->W0, s->Tm, s->attention, s->norm);
   const bool additive = s->attention == LAS_ATT_BAHDANAU || s->attention == LAS_ATT_BAHDANAU_MONOTONIC;
-  LAS_REQUIRE(p->d_out && p->kn && s->dc && s->dz && s->ds_out && s->dctx_save && s->align && s->gates && s->c_new && s->c_prev && s->keys &&
+  LAS_REQUIRE(p->d_out && p->kn_packed && s->dc && s->dz && s->ds_out && s->dctx_save && s->align && s->gates && s->c_new && s->c_prev && s->keys &&
                   s->values && s->mem_len && (p->A == 0 || (p->waln && p->datt_out && p->ld_waln >= p->A)) && p->W0 == (p->A > 0 ? p->A : s->M) + s->Hd,
               "las_decoder_seq_bwd: null argument or inconsistent widths");
   LAS_REQUIRE(!additive || (s->wq_t && s->att_v && s->pq && s->dkeys_acc && s->dv_acc), "las_decoder_seq_bwd: Bahdanau scores need wq_t, att_v, pq, dkeys_acc, dv_acc");
   LAS_REQUIRE(s->attention != LAS_ATT_CUSTOM || (s->wq_t && s->pq), "las_decoder_seq_bwd: CustomAttention needs wq_t and the saved processed query");
   LAS_REQUIRE(s->norm == LAS_NORM_SOFTMAX || (s->p && s->dalign_carry), "las_decoder_seq_bwd: monotonic attention needs p_choose and the carry buffer");
   LAS_REQUIRE(s->drop_keep >= 1.0f, "las_decoder_seq_bwd: without input dropout");
-  const size_t lds = (dec_step_bwd_floats(s->M, s->Tm, s->Hd, s->norm) + (size_t)(p->A > 0 ? p->A + s->Hd + s->M : 0) + p->W0) * sizeof(float);
-  hipLaunchKernelGGL(dec_seq_bwd_kernel, dim3(s->B), dim3(256), lds, (hipStream_t)stream, *p);
+  size_t lds = (dec_step_bwd_floats(s->M, s->Tm, s->Hd, s->norm) + (size_t)(p->A > 0 ? p->A + s->Hd + s->M : 0) + p->W0 + 2 * s->Hd + 8) * sizeof(float);
+  las_dec_seq_bwd q = *p;
+  if (q.A > 0 && q.vw) {
+    const size_t with_vw = lds + (size_t)s->Tm * (q.A + 1) * sizeof(float);
+    if (with_vw <= 158 * 1024) lds = with_vw;
+    else q.vw = nullptr;                             // does not fit the CU's LDS: d(alignments) from the values, as without VW
+  }
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dec_seq_bwd_kernel<0, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dec_seq_bwd_kernel<0, 32>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dec_seq_bwd_kernel<SEQ_NPK, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dec_seq_bwd_kernel<SEQ_NPK, 32>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr = true;
+  }
+  // Bahdanau scores: d(keys) in registers when the utterance's frames fit SEQ_NPK passes of the 256 / (Hd / 8) frame phases
+  // (Tm <= 200 at 256 units, 400 at 128); LAS_DEC_SEQ_REGK=0 keeps the read-modify-write in memory (A/B measurements)
+  static const bool regk_on = [] { const char* e = getenv("LAS_DEC_SEQ_REGK"); return !(e && e[0] == '0'); }();
+  const int P = 256 / (s->Hd / 8);
+  const bool regk = additive && regk_on && q.A > 0 && q.vw && (s->Tm + P - 1) / P <= SEQ_NPK;
+#define LAS_SEQ_LAUNCH(NPK_, KC_) hipLaunchKernelGGL((dec_seq_bwd_kernel<NPK_, KC_>), dim3(s->B), dim3(256), lds, (hipStream_t)stream, q)
+  if (s->Hd == 128) { if (regk) LAS_SEQ_LAUNCH(SEQ_NPK, 16); else LAS_SEQ_LAUNCH(0, 16); }
+  else              { if (regk) LAS_SEQ_LAUNCH(SEQ_NPK, 32); else LAS_SEQ_LAUNCH(0, 32); }
+#undef LAS_SEQ_LAUNCH
   LAS_LAUNCH_CHECK("sequential decoder bwd launch");
   return LAS_OK;
 }

@@ -148,7 +148,7 @@ class DecSeqBwd(C.Structure):
     _fields_ = [('s', DecStepBwd), ('U', _i32), ('A', _i32), ('W0', _i32), ('reserved', _i32)] + [(n, _i64) for n in (
         'inc_gates', 'inc_c', 'inc_align', 'inc_dz', 'inc_ds', 'inc_save', 'inc_pq')] + [
         ('d_out', _vp), ('ld_dout', _i64), ('inc_dout', _i64), ('datt_out', _vp), ('ld_datt', _i64), ('waln', _vp), ('ld_waln', _i64),
-        ('kn', _vp), ('ld_kn', _i64), ('dfeed_out', _vp)]
+        ('kn_packed', _vp), ('reserved2', _i64), ('dfeed_out', _vp), ('vw', _vp), ('ld_vw', _i64)]
 
 
 class DecPersistBwd(C.Structure):
@@ -407,7 +407,7 @@ def fill_many(zero=(), copy=()):
         check(lib().las_fill_many(arr, len(part), stream()))
 
 
-IMAGE_CAST, IMAGE_PACK_RECURRENT, IMAGE_BIAS_INTERLEAVE, IMAGE_COPY_F32 = 0, 1, 2, 3
+IMAGE_CAST, IMAGE_PACK_RECURRENT, IMAGE_BIAS_INTERLEAVE, IMAGE_COPY_F32, IMAGE_PACK_MFMA_B = 0, 1, 2, 3, 4
 _image_batch = None
 _image_tables = {}        # bytes of a job table -> its device copy (tables repeat every step: uploaded once)
 
@@ -477,6 +477,15 @@ def pack_recurrent(kernel_h, H, packed):
         _image_job(IMAGE_PACK_RECURRENT, kernel_h, packed, rows=H)
         return
     check(lib().las_lstm_pack_recurrent(p(kernel_h), H, p(packed), stream()))
+
+
+def pack_mfma_b(src, rows, cols, dst, lds=None):
+    """dst = the LAS_IMAGE_PACK_MFMA_B image of fp32 src[rows, cols] (joins an open image_batch): dst holds
+    ceil(rows / 16) * 16 x ceil(cols / 32) * 32 bf16 elements in B-fragment order."""
+    dr, dc = -(-rows // 16) * 16, -(-cols // 32) * 32
+    if dst.numel() != dr * dc:
+        raise LasError('pack_mfma_b: destination of %d elements, expected %d' % (dst.numel(), dr * dc))
+    _image_job(IMAGE_PACK_MFMA_B, src, dst, lds=lds if lds is not None else src.stride(-2), rows=rows, cols=cols, dst_rows=dr, dst_cols=dc)
 
 
 def bias_interleave(bias, H, dst):

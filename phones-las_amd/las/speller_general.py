@@ -14,6 +14,7 @@ composes the same kernels un-fused (LAS_DEC_CELL_ONLY / LAS_DEC_ATTENTION_ONLY) 
 Input dropout (DropoutWrapper on every cell's input: the GEMM operand is dropped in place, the one-hot token through
 the kernel's token scale) and scheduled sampling work as on the fused path; dropout + embedding raises."""
 import ctypes as C
+import os
 
 import torch
 
@@ -138,6 +139,9 @@ class GeneralSpeller:
         bf, dev = torch.bfloat16, 'cuda'
         self.kT = [torch.empty(4 * Hd, w + Hd, dtype=bf, device=dev) for w in self.win]
         self.kn = [torch.empty(w + Hd, 4 * Hd, dtype=bf, device=dev) for w in self.win]
+        # cell 0's rows below the token rows in matrix-core B-fragment order: d(feed)_t = dz_t K^T of the one-launch backward
+        self.kn_pk = (torch.empty(-(-(self.win[0] + Hd) // 16) * 16 * 4 * Hd, dtype=bf, device=dev)
+                      if self.NL == 1 and not self.tokx else None)
         self.tok = torch.empty(self.V, 4 * Hd, dtype=bf, device=dev)
         self.wmemT = torch.empty(Hd, self.M, dtype=bf, device=dev)
         self.wmem = torch.empty(self.M, Hd, dtype=bf, device=dev)
@@ -207,6 +211,8 @@ class GeneralSpeller:
             else:
                 hip.cast_bf16(k[skip:], rows, 4 * Hd, self.kT[l], 4 * Hd, rows, transpose=True, lds=4 * Hd)
                 hip.cast_bf16(k[skip:], rows, 4 * Hd, self.kn[l], rows, 4 * Hd, lds=4 * Hd)
+                if l == 0 and self.kn_pk is not None:
+                    hip.pack_mfma_b(k[skip:], rows, 4 * Hd, self.kn_pk, lds=4 * Hd)
             self.bias.append(var[self.cell_names(l)[1]])
         k0 = var[self.cell_names(0)[0]]
         Ep = self.Ep
@@ -658,7 +664,12 @@ class GeneralSpeller:
             if self.has_al:
                 q.datt_out, q.ld_datt = hip.addr(datt_bf), U * A
                 q.waln, q.ld_waln = hip.addr(self.waln), A
-            q.kn, q.ld_kn = hip.addr(self.kn[0]), 4 * Hd
+                if os.environ.get('LAS_DEC_SEQ_VW', '1') != '0':
+                    # VW = values W_c [B, T', A]: d(alignments)_t = VW d(attention_t) inside the launch (no pass over the values)
+                    vw = torch.empty(B, Tm, A, dtype=f32, device=dev)
+                    hip.gemm_nt(sv['memory'], self.walT[:, Hd:], vw, B * Tm, A, M, lda=M, ldb=Hd + M, ldc=A)
+                    q.vw, q.ld_vw = hip.addr(vw), Tm * A
+            q.kn_packed = hip.addr(self.kn_pk)
             dfeed0 = torch.empty(B, W[0], dtype=f32, device=dev)
             q.dfeed_out = hip.addr(dfeed0)
             tok = hip.prof_begin('dec_seq_bwd', 2.0 * U * B * (W[0] * 4 * Hd + 2 * Tm * Hd + 2 * Tm * M + (Hd + M) * (A if self.has_al else 0)))

@@ -20,11 +20,16 @@ lib.las_debug_read_stamps.argtypes = [C.c_void_p, C.c_int]
 buf = np.zeros(2 * 256 * 16, np.uint64)
 hip.check(lib.las_debug_read_stamps(buf.ctypes.data, buf.size))
 st = buf.reshape(512, 16)[256:256 + c['U']].astype(np.int64)
-names = ['d(attention)', 'd[query|context] = datt W_al^T', 'body: d(context) total', 'body: d(alignments) over the values',
-         'body: normaliser backward', 'body: query path (keys, d(keys))', 'body: reduce + Wq^T', 'body: cell backward', 'd(feed) = dz K^T']
+# stamp k -> k+1 intervals of one step (stamp 7 is unused in the fused body)
+names = ['d(attention) + d[query|context] = datt W_al^T', 'body: d(context) total', 'body: d(alignments) (values W_c resident in LDS)',
+         'body: normaliser backward', 'body: query path (keys, d(keys))', 'body: reduce + Wq^T', 'body: cell backward',
+         'd(feed) = dz K^T (MFMA)']
 order = [0, 1, 2, 3, 4, 5, 6, 8, 9]
 rows = st[5:c['U'] - 5]
 print('step time %.2f us' % (np.diff(st[5:c['U'] - 5, 0]).mean() / -100.0))
 for k in range(len(order) - 1):
     d = (rows[:, order[k + 1]] - rows[:, order[k]]) / 100.0
-    print('  %-40s %7.2f us' % (names[k] if k < 7 else names[k + 1] if k == 7 else '', d.mean()))
+    print('  %-52s %7.2f us' % (names[k], d.mean()))
+for a, b, what in ((8, 10, 'd(feed): dz_t into LDS'), (10, 11, 'd(feed): first tile of wave 0'), (11, 12, 'd(feed): its other tiles'),
+                   (12, 9, 'd(feed): wait for the other waves')):
+    print('    %-50s %7.2f us' % (what, ((rows[:, b] - rows[:, a]) / 100.0).mean()))

@@ -295,7 +295,7 @@ def test_sharded_host_batches_tile_the_global_batch_gloo(tmp_path):
         for k in ('tin', 'tout', 'tl'):
             assert np.array_equal(np.concatenate([p0[k], p1[k]]), whole[k]), k
         assert p0['tin'].shape == (16, shp0[1]) and shp0[2] % 4 == 0 and shp0[3] == int(whole['tl'].max())
-    assert ts0 < 0.8 * tg0, (ts0, tg0)
+    assert ts0 < 0.9 * tg0, (ts0, tg0)             # (half the rows; measured 0.5x -- the bound leaves room for a loaded host)
 
 
 @pytest.mark.gpu
