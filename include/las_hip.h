@@ -453,7 +453,8 @@ int las_decoder_persist_bwd(const las_dec_persist_bwd* p, void* stream);
  * step struct of las_decoder_step_bwd for step 0 (fused mode; its dctx_* / dh_* fields are set by the launch), per-step
  * pointers advance by the inc_* element counts; s.p / s.align serve the monotonic chain (prev_align = the row before).
  *   A > 0: attention layer of A outputs: d(attention_t) = d_out[b, t, :A] + d(feed)_{t+1}[:A] (saved as bf16 in datt_out
- *          [B, U, A] for d(W_al)), d[query | context] = d(attention_t) waln^T with waln [Hd + M, A] bf16 (row stride ld_waln);
+ *          [B, U, A] for d(W_al)), d[query | context] = d(attention_t) W_al^T with the attention layer's kernel [Hd + M, A]
+ *          handed in as its LAS_IMAGE_PACK_MFMA_B image waln_packed (dst_rows = Hd + M, dst_cols = A rounded up to 32);
  *   A = 0: the context is output and feed: d(context_t) = d_out[b, t, :M] + d(feed)_{t+1}[:M].
  * d(feed)_t = dz_t kn^T, kn [W0, 4 Hd] (row n = row n of the cell kernel below the token rows), W0 = (A or M) + Hd, handed in
  * as its LAS_IMAGE_PACK_MFMA_B image kn_packed (dst_rows = W0 rounded up to 16, dst_cols = 4 Hd).
@@ -466,8 +467,8 @@ typedef struct las_dec_seq_bwd {
   int64_t ld_dout, inc_dout;
   las_bf16* datt_out;            /* bf16, utterance stride ld_datt, A per step (A > 0) */
   int64_t ld_datt;
-  const las_bf16* waln;
-  int64_t ld_waln;
+  const las_bf16* waln_packed;
+  int64_t reserved1;
   const las_bf16* kn_packed;
   int64_t reserved2;
   float* dfeed_out;

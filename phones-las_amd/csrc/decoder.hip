@@ -1642,13 +1642,15 @@ __host__ __device__ inline size_t dec_step_bwd_floats(int M, int Tm, int Hd, int
 constexpr int SEQ_NPK = 25;
 template <int NPK = 0>
 __device__ __forceinline__ void dec_step_bwd_body(const las_dec_step_bwd& s, const int b, float* sm, const float* vw = nullptr,
-                                                  const float* datt = nullptr, const int A = 0, float (*dkr)[8] = nullptr) {
+                                                  const float* datt = nullptr, const int A = 0, float (*dkr)[8] = nullptr,
+                                                  const int tid_in = -1) {
   float* dctx = sm;               // [M]
   float* ds = dctx + s.M;         // [Tm] dalign -> dscore
   float* dhs = ds + s.Tm;         // [256/L][Hd] = 2048 floats: per-phase partial d h (score path) / dpq
   float* red = dhs + 2048;        // [8] + [Hd] scratch
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // (tid_in: the caller's opaque copy of threadIdx.x -- see dec_seq_bwd_kernel)
+  const int tid = tid_in >= 0 ? tid_in : (int)threadIdx.x, lane = tid & 63, wave = tid_in >= 0 ? __builtin_amdgcn_readfirstlane(tid >> 6) : tid >> 6;
   const int Hd = s.Hd, M = s.M, Tm = s.Tm;
   if (s.mode == LAS_DEC_CELL_ONLY) {
     for (int u = tid; u < Hd; u += 256) dhs[u] = 0.f;
@@ -1881,19 +1883,28 @@ __device__ __forceinline__ void dec_step_bwd_body(const las_dec_step_bwd& s, con
       // and step at 512 units)
       constexpr int FB = 4;
       if constexpr (NPK > 0) {
+        // the key rows of the NEXT FB passes are requested before this group's tanh work (two register buffers)
+        constexpr int NG = (NPK + FB - 1) / FB;
+        uint4 kv[2][FB];
 #pragma unroll
-        for (int i0 = 0; i0 < NPK; i0 += FB) {
-          uint4 kv[FB];
+        for (int i = 0; i < FB; ++i) {
+          const int t = phase + i * P;
+          if (i < NPK && t < len) kv[0][i] = *reinterpret_cast<const uint4*>(keys + (int64_t)t * Hd + u);
+        }
 #pragma unroll
-          for (int i = 0; i < FB; ++i) {
-            const int t = phase + (i0 + i) * P;
-            if (i0 + i < NPK && t < len) kv[i] = *reinterpret_cast<const uint4*>(keys + (int64_t)t * Hd + u);
+        for (int g = 0; g < NG; ++g) {
+          if (g + 1 < NG) {
+#pragma unroll
+            for (int i = 0; i < FB; ++i) {
+              const int t = phase + ((g + 1) * FB + i) * P;
+              if ((g + 1) * FB + i < NPK && t < len) kv[(g + 1) & 1][i] = *reinterpret_cast<const uint4*>(keys + (int64_t)t * Hd + u);
+            }
           }
 #pragma unroll
           for (int i = 0; i < FB; ++i) {
-            const int t = phase + (i0 + i) * P;
-            if (i0 + i < NPK && t < len) {
-              const unsigned short* e = reinterpret_cast<const unsigned short*>(&kv[i]);
+            const int t = phase + (g * FB + i) * P;
+            if (g * FB + i < NPK && t < len) {
+              const unsigned short* e = reinterpret_cast<const unsigned short*>(&kv[g & 1][i]);
               const float d = ds[t];
 #pragma unroll
               for (int j = 0; j < 8; ++j) {
@@ -1901,11 +1912,11 @@ __device__ __forceinline__ void dec_step_bwd_body(const las_dec_step_bwd& s, con
                 dv[j] += d * th;
                 const float p = d * vv[j] * (1.f - th * th);
                 a[j] += p;
-                dkr[i0 + i < NPK ? i0 + i : 0][j] += p;
+                dkr[g * FB + i < NPK ? g * FB + i : 0][j] += p;
               }
             }
           }
-          __builtin_amdgcn_sched_barrier(0);         // keep the next passes' key loads from being hoisted over this one (registers)
+          __builtin_amdgcn_sched_barrier(0);         // keep later groups' loads from being hoisted over this one (registers)
         }
       } else
       for (int tb = phase; tb < len; tb += P * FB) {
@@ -2039,7 +2050,7 @@ __global__ __launch_bounds__(256) void dec_seq_bwd_kernel(las_dec_seq_bwd p) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   const las_dec_step_bwd& s0 = p.s;
   const int b = blockIdx.x;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid0 = threadIdx.x;
   const int Hd = s0.Hd, M = s0.M, A = p.A, W0 = p.W0, feed = p.A > 0 ? p.A : M;
   float* datt = sm + dec_step_bwd_floats(M, s0.Tm, Hd, s0.norm);      // [A] (bf16-rounded values)
   float* dqc = datt + (A > 0 ? A : 0);                                 // [Hd + M]
@@ -2047,7 +2058,8 @@ __global__ __launch_bounds__(256) void dec_seq_bwd_kernel(las_dec_seq_bwd p) {
   // [4 Hd] bf16 dz_t and 8 zeros behind it, on a 16-byte boundary (sm is): the A operand of the d(feed) product
   unsigned short* dzl = reinterpret_cast<unsigned short*>(sm + (((dfeed + W0 - sm) + 3) & ~(ptrdiff_t)3));
   float* vwl = dfeed + W0 + 2 * Hd + 8;                                // [Tm][A + 1]: values W_c of this utterance (p.vw given)
-  for (int n = tid; n < W0; n += 256) dfeed[n] = 0.f;
+  for (int n = tid0; n < W0; n += 256) dfeed[n] = 0.f;
+  if (tid0 < 4) reinterpret_cast<unsigned*>(dzl + 4 * Hd)[tid0] = 0u;       // the zeros behind the A operands' row 0
   float dkr[NPK > 0 ? NPK : 1][8];                                    // d(keys) of this utterance (Bahdanau scores; see the body)
 #pragma unroll
   for (int i = 0; i < (NPK > 0 ? NPK : 1); ++i)
@@ -2056,10 +2068,16 @@ __global__ __launch_bounds__(256) void dec_seq_bwd_kernel(las_dec_seq_bwd p) {
   const bool use_vw = A > 0 && p.vw != nullptr;
   if (use_vw) {
     const float* src = p.vw + (int64_t)b * p.ld_vw;
-    for (int e = tid; e < s0.Tm * A; e += 256) vwl[(e / A) * (A + 1) + e % A] = src[e];
+    for (int e = tid0; e < s0.Tm * A; e += 256) vwl[(e / A) * (A + 1) + e % A] = src[e];
   }
   __syncthreads();
   for (int t = p.U - 1; t >= 0; --t) {
+    // The thread index is made opaque to the compiler once per step: everything that depends on it alone (row addresses of
+    // the weights' fragments, of the keys' frames, bounds tests ...) is invariant across the steps and was hoisted out of
+    // this loop -- some 200 registers held for the whole launch, more than the loop's own working set.
+    int tid = tid0;
+    asm volatile("" : "+v"(tid));
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const bool has_next = t + 1 < p.U;
     las_dec_step_bwd st = s0;
     st.mode = 0;
@@ -2085,33 +2103,56 @@ __global__ __launch_bounds__(256) void dec_seq_bwd_kernel(las_dec_seq_bwd p) {
       for (int a = tid; a < A; a += 256) {
         const unsigned short v = las_f2bf(dout[a] + (has_next ? dfeed[a] : 0.f));
         datt[a] = las_bf2f(v);
+        dzl[a] = v;
         p.datt_out[(int64_t)b * p.ld_datt + (int64_t)t * A + a] = v;
       }
+      for (int a = A + tid; a < ((A + 31) & ~31); a += 256) dzl[a] = 0;
       __syncthreads();
-      // d[query | context][n] = sum_a d(attention)[a] W_al[n][a]   (waln: [Hd + M, A] bf16, row n contiguous)
-      // (ten 16-byte pieces of two rows in flight per thread: left rolled, every piece was a dependent L2 round trip)
-      for (int n = tid; n < Hd + M; n += 512) {
-        const int n2 = n + 256;
-        const unsigned short* w0 = p.waln + (int64_t)n * p.ld_waln;
-        const unsigned short* w1 = p.waln + (int64_t)(n2 < Hd + M ? n2 : n) * p.ld_waln;
-        float acc0 = 0.f, acc1 = 0.f;
-        for (int a = 0; a < A; a += 40) {
-          uint4 v0[5], v1[5];
+      // d[query | context][n] = sum_a d(attention)[a] W_al[n][a] on the matrix cores: d(attention) is row 0 of the A tile (bf16
+      // in LDS, zero padded to the 32-deep chunks), W_al's B-fragment image gives every 16-column tile of a chunk as one KB.
+      // A wave owns the tiles wave, wave + 4, ...; TB of them per pass, one pass and chunk = TB loads in flight, the next
+      // (pass, chunk)'s requested before this one's products.
+      {
+        constexpr int TB = 10;
+        const int KCa = (A + 31) / 32, NTQ = (Hd + M) / 16;
+        const int l15 = lane & 15, lq = lane >> 4;
+        const unsigned short* azp = l15 == 0 ? dzl + 8 * lq : dzl + 4 * Hd;
+        const int azs = l15 == 0 ? 32 : 0;
+        const int NB = ((NTQ - wave + 3) / 4 + TB - 1) / TB, Q = NB * KCa;
+        uint4 cur[TB], nxt[TB];
+        f32x4 acc[TB];
+        auto frag = [&](int q, int i) {
+          const int bi = q / KCa, kc = q - bi * KCa;
+          const int nt = min(wave + 4 * (bi * TB + i), NTQ - 1);
+          return p.waln_packed + (((int64_t)nt * KCa + kc) * 64 + lane) * 8;
+        };
 #pragma unroll
-          for (int i = 0; i < 5; ++i) {
-            const int aa = a + 8 * i < A ? a + 8 * i : 0;
-            v0[i] = ld16(w0 + aa);
-            v1[i] = ld16(w1 + aa);
+        for (int i = 0; i < TB; ++i) cur[i] = ld16(frag(0, i));
+#pragma unroll 1
+        for (int q = 0; q < Q; ++q) {
+          const int bi = q / KCa, kc = q - bi * KCa;
+          if (q + 1 < Q) {
+#pragma unroll
+            for (int i = 0; i < TB; ++i) nxt[i] = ld16(frag(q + 1, i));
+          }
+          const uint4 av = *reinterpret_cast<const uint4*>(azp + kc * azs);
+          if (kc == 0) {
+#pragma unroll
+            for (int i = 0; i < TB; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
           }
 #pragma unroll
-          for (int i = 0; i < 5; ++i)
-            if (a + 8 * i < A) {
-              acc0 += dot8(v0[i], datt + a + 8 * i);
-              acc1 += dot8(v1[i], datt + a + 8 * i);
+          for (int i = 0; i < TB; ++i)
+            acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, av), __builtin_bit_cast(bf16x8, cur[i]), acc[i], 0, 0, 0);
+          if (kc == KCa - 1) {
+#pragma unroll
+            for (int i = 0; i < TB; ++i) {
+              const int nt = wave + 4 * (bi * TB + i);
+              if (lq == 0 && nt < NTQ) dqc[nt * 16 + l15] = acc[i][0];
             }
+          }
+#pragma unroll
+          for (int i = 0; i < TB; ++i) cur[i] = nxt[i];
         }
-        dqc[n] = acc0;
-        if (n2 < Hd + M) dqc[n2] = acc1;
       }
       __syncthreads();
       LAS_STAMPB(t, 1);
@@ -2127,7 +2168,7 @@ __global__ __launch_bounds__(256) void dec_seq_bwd_kernel(las_dec_seq_bwd p) {
       st.dh_b = st.dh_c = nullptr;
       st.dh_rec = has_next ? dfeed + feed : nullptr;   st.ldr = 0;
     }
-    dec_step_bwd_body<NPK>(st, b, sm, use_vw ? vwl : nullptr, datt, A, dkr);
+    dec_step_bwd_body<NPK>(st, b, sm, use_vw ? vwl : nullptr, datt, A, dkr, tid);
     __syncthreads();                               // dz_t of this utterance is in memory (same workgroup: visible behind the barrier)
     LAS_STAMPB(t, 8);
     if (t > 0 || p.dfeed_out) {
@@ -2140,7 +2181,6 @@ __global__ __launch_bounds__(256) void dec_seq_bwd_kernel(las_dec_seq_bwd p) {
       const unsigned short* dzr = st.dz + (int64_t)b * st.ldz;
       const int l15 = lane & 15, lq = lane >> 4;
       if (tid < Hd / 2) *reinterpret_cast<uint4*>(dzl + tid * 8) = ld16(dzr + tid * 8);
-      if (tid == 255) *reinterpret_cast<uint4*>(dzl + 4 * Hd) = make_uint4(0, 0, 0, 0);
       __syncthreads();
       const unsigned short* azp = l15 == 0 ? dzl + 8 * lq : dzl + 4 * Hd;
       const int azs = l15 == 0 ? 32 : 0;
@@ -2170,10 +2210,10 @@ __global__ __launch_bounds__(256) void dec_seq_bwd_kernel(las_dec_seq_bwd p) {
     LAS_STAMPB(t, 9);
   }
   if (p.dfeed_out)
-    for (int n = tid; n < W0; n += 256) p.dfeed_out[(int64_t)b * W0 + n] = dfeed[n];
+    for (int n = tid0; n < W0; n += 256) p.dfeed_out[(int64_t)b * W0 + n] = dfeed[n];
   if constexpr (NPK > 0) {
     // the register-resident d(keys) joins the accumulator once (same thread layout as the body's query path)
-    const int L = Hd / 8, P = 256 / L, phase = tid / L, u = (tid % L) * 8;
+    const int L = Hd / 8, P = 256 / L, phase = tid0 / L, u = (tid0 % L) * 8;
 #pragma unroll
     for (int i = 0; i < NPK; ++i) {
       const int tt = phase + i * P;
@@ -3383,7 +3423,7 @@ extern "C" int las_decoder_seq_bwd(const las_dec_seq_bwd* p, void* stream) {
               p->W0, s->Tm, s->attention, s->norm);
   const bool additive = s->attention == LAS_ATT_BAHDANAU || s->attention == LAS_ATT_BAHDANAU_MONOTONIC;
   LAS_REQUIRE(p->d_out && p->kn_packed && s->dc && s->dz && s->ds_out && s->dctx_save && s->align && s->gates && s->c_new && s->c_prev && s->keys &&
-                  s->values && s->mem_len && (p->A == 0 || (p->waln && p->datt_out && p->ld_waln >= p->A)) && p->W0 == (p->A > 0 ? p->A : s->M) + s->Hd,
+                  s->values && s->mem_len && (p->A == 0 || (p->waln_packed && p->datt_out)) && p->W0 == (p->A > 0 ? p->A : s->M) + s->Hd,
               "las_decoder_seq_bwd: null argument or inconsistent widths");
   LAS_REQUIRE(!additive || (s->wq_t && s->att_v && s->pq && s->dkeys_acc && s->dv_acc), "las_decoder_seq_bwd: Bahdanau scores need wq_t, att_v, pq, dkeys_acc, dv_acc");
   LAS_REQUIRE(s->attention != LAS_ATT_CUSTOM || (s->wq_t && s->pq), "las_decoder_seq_bwd: CustomAttention needs wq_t and the saved processed query");

@@ -151,6 +151,7 @@ class GeneralSpeller:
         if self.has_al:
             self.walT = torch.empty(A, Hd + self.M, dtype=bf, device=dev)
             self.waln = torch.empty(Hd + self.M, A, dtype=bf, device=dev)
+            self.waln_pk = torch.empty((Hd + self.M) * (-(-A // 32) * 32), dtype=bf, device=dev)   # B-fragment image (one-launch backward)
         self.Ep = _r8(self.E)                 # GEMM width of the embedded token (zero padded)
         if self.emb:
             self.emb_bf = torch.zeros(self.V, self.Ep, dtype=bf, device=dev)
@@ -233,6 +234,7 @@ class GeneralSpeller:
         if self.has_al:
             hip.cast_bf16(var[self.K_AL], Hd + M, A, self.walT, A, Hd + M, transpose=True)
             hip.cast_bf16(var[self.K_AL], Hd + M, A, self.waln, Hd + M, A)
+            hip.pack_mfma_b(var[self.K_AL], Hd + M, A, self.waln_pk)
         if self.uses_wq:
             hip.cast_bf16(var[self.K_Q], Hd, Hd, self.wq, Hd, Hd)
             hip.cast_bf16(var[self.K_Q], Hd, Hd, self.wq_t, Hd, Hd, transpose=True)
@@ -663,7 +665,7 @@ class GeneralSpeller:
             q.d_out, q.ld_dout, q.inc_dout = hip.addr(d_out), U * P, P
             if self.has_al:
                 q.datt_out, q.ld_datt = hip.addr(datt_bf), U * A
-                q.waln, q.ld_waln = hip.addr(self.waln), A
+                q.waln_packed = hip.addr(self.waln_pk)
                 if os.environ.get('LAS_DEC_SEQ_VW', '1') != '0':
                     # VW = values W_c [B, T', A]: d(alignments)_t = VW d(attention_t) inside the launch (no pass over the values)
                     vw = torch.empty(B, Tm, A, dtype=f32, device=dev)
