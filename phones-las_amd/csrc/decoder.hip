@@ -208,9 +208,46 @@ __device__ bool persist_barrier(pu64* flags, int member, unsigned epoch, bool lo
 // else is still going to write (a row sharing a line with the next step's row would be served stale from L1 later; the
 // host pads the small rows - raw scores, partial dots - to 32 floats).
 
+// Bahdanau scores of the persistent decoders' own frames at a compile-time width (NK = Hd / 32 sixteen-byte pieces per lane and
+// frame; 4 lanes per frame, 64 frames per pass): score[t] = sum_a v[a] tanh(keys[t, a] + pq[a]).  pq and v come from LDS as
+// 16-byte reads, every piece has its own partial sum, nothing in the pass is conditional but the final store.  (The general
+// loop below read pq two floats and v four floats at a time, each read waited for before its two tanh, one running sum:
+// 7.5 us per step at cfg5 for 64 tanh per lane.)
+template <int NK, typename KR>
+__device__ __forceinline__ void score_additive_rows(KR krows, const int row0, const int Hd, const int f0, const int f1, const int len,
+                                                    const float* pql, const float* vl, const int lane, const int wave,
+                                                    const PersistHook* ph) {
+  const int sub = lane & 3, fr = lane >> 2;
+  for (int t0 = f0; t0 < f1; t0 += 64) {
+    const int t = t0 + wave * 16 + fr;
+    const auto krow = krows + (int64_t)(min(t, f1 - 1) - row0) * Hd + sub * 8;
+    uint4 kv[NK];
+#pragma unroll
+    for (int j = 0; j < NK; ++j) kv[j] = ld16(krow + j * 32);
+    float pe = 0.f, po = 0.f;                       // even and odd pieces: two independent chains
+#pragma unroll
+    for (int j = 0; j < NK; ++j) {
+      const int k = sub * 8 + j * 32;
+      const float4 q0 = *reinterpret_cast<const float4*>(pql + k), q1 = *reinterpret_cast<const float4*>(pql + k + 4);
+      const float4 v0 = *reinterpret_cast<const float4*>(vl + k), v1 = *reinterpret_cast<const float4*>(vl + k + 4);
+      const uint4 kk = kv[j];
+      const float a0 = v0.x * las_tanh(__uint_as_float(kk.x << 16) + q0.x) + v0.y * las_tanh(__uint_as_float(kk.x & 0xffff0000u) + q0.y);
+      const float a1 = v0.z * las_tanh(__uint_as_float(kk.y << 16) + q0.z) + v0.w * las_tanh(__uint_as_float(kk.y & 0xffff0000u) + q0.w);
+      const float a2 = v1.x * las_tanh(__uint_as_float(kk.z << 16) + q1.x) + v1.y * las_tanh(__uint_as_float(kk.z & 0xffff0000u) + q1.y);
+      const float a3 = v1.z * las_tanh(__uint_as_float(kk.w << 16) + q1.z) + v1.w * las_tanh(__uint_as_float(kk.w & 0xffff0000u) + q1.w);
+      if (j & 1) po += (a0 + a1) + (a2 + a3);
+      else pe += (a0 + a1) + (a2 + a3);
+    }
+    float part_sum = pe + po;
+    part_sum += __shfl_xor(part_sum, 1, 64);
+    part_sum += __shfl_xor(part_sum, 2, 64);
+    if (sub == 0 && t < f1) pgranule_store(ph->xsc + t, ph->xtag, (t < len) ? part_sum : -INFINITY, ph->local);
+  }
+}
+
 // RES: the persistent kernel's LDS copies of keys / values are in use (compile-time: one load flavour per instantiation)
 template <bool RES = false>
-__device__ void dec_step_fwd_body(const las_dec_step& s, const int b, const int part, const int nparts, float* sm,
+__device__ __forceinline__ void dec_step_fwd_body(const las_dec_step& s, const int b, const int part, const int nparts, float* sm,
                                   const PersistHook* ph = nullptr) {
   float* hq = sm;                 // [Hd] h_t (bf16-rounded) as float
   float* pq = hq + s.Hd;          // [Hd] processed query (Bahdanau)
@@ -307,6 +344,9 @@ __device__ void dec_step_fwd_body(const las_dec_step& s, const int b, const int 
       pq[a] = acc;
       if (writer && s.pq_out) s.pq_out[(int64_t)b * s.ldpq + a] = acc;
     }
+    // (persistent decoders, Bahdanau scores: attention_v next to it in LDS -- cred is free until the context phase)
+    if (ph && att_additive(s.attention))
+      for (int a = tid; a < Hd; a += 256) (sm + ((2 * Hd + Tm + 8 + 3) & ~3))[a] = s.att_v[a];
     __syncthreads();
   }
 
@@ -322,7 +362,15 @@ __device__ void dec_step_fwd_body(const las_dec_step& s, const int b, const int 
     const int fq = (Tm + nparts - 1) / nparts;
     const int f0 = ph ? part * fq : 0, f1 = ph ? min(Tm, f0 + fq) : Tm;
     const int flen = min(len, f1);
-    if (Hd <= 32 * KMAX) {
+    if (ph && additive && (Hd == 256 || Hd == 128)) {
+      const float* vl = sm + ((2 * Hd + Tm + 8 + 3) & ~3);
+      auto run = [&](auto krows, int row0) {
+        if (Hd == 256) score_additive_rows<8>(krows, row0, Hd, f0, f1, len, pq, vl, lane, wave, ph);
+        else score_additive_rows<4>(krows, row0, Hd, f0, f1, len, pq, vl, lane, wave, ph);
+      };
+      if constexpr (RES) run((lds_cu16)ph->lkeys, f0);
+      else run(keys, 0);
+    } else if (Hd <= 32 * KMAX) {
       const int nk = Hd / 32;                          // loads per lane and frame
       // krows: key rows from memory (row 0 = frame 0) or from the workgroup's LDS copy (row 0 = frame f0)
       auto score_pass = [&](auto krows, int row0) {

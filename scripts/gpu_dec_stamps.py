@@ -7,7 +7,7 @@ sys.path.insert(0, '.')
 import bench
 from phones_las_amd import hip, model_helper as mh
 c = bench.CONFIGS[os.environ.get('CFG', 'metric-M')]
-model = mh.LasModel(bench.build_params(c))
+model = mh.LasModel(bench.build_params(c), binf2phone=bench.binf_matrix(c['binf']) if c.get('binf') else None)
 feats, labels = bench.synthetic_batch(c, 1234, 'cuda')
 feats['encoder_inputs'] = model.listener.pad_features(feats['encoder_inputs'])
 for _ in range(3):

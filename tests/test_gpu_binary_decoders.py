@@ -133,10 +133,13 @@ def test_sigmoid_decoder_binary_greedy_and_prediction_keys_vs_oracle():
     batch = make_batch(B=5, T=24, src_len=src_len, tgt_len=tgt_len)
     feats, labels = to_device(batch)
     first = last = None
-    for _ in range(200):
+    for _ in range(100):
         last = float(model.train_step(feats, labels))
         first = last if first is None else first
-    assert last < 0.5 * first, (first, last)          # (150 steps ended at 0.49-0.51 of the first loss, depending on the summation order of the weight-gradient products)
+    # (lr 1e-2 on five utterances: 0.70 -> 0.085 in 100 steps, 0.074 by step 120; near step 190 Adam's step-size spike takes
+    #  the loss back to 0.6 for a while -- scripts/gpu_sigmoid_traj.py prints the trajectory and checks the gradients against
+    #  the oracle at the trained weights -- so the run stops well before it)
+    assert last < 0.5 * first, (first, last)
     trained = {n: t.detach().double().cpu() for n, t in model.vars.params.items()}
     (mem, ml), st = O.listener(batch['encoder_inputs'], batch['source_sequence_length'], trained, ohp.encoder, 'bf16')
     rl, rs, rfl, sp = O.speller_greedy_binary(ohp, trained, mem, ml, st, 'bf16')
