@@ -75,6 +75,28 @@ __device__ void block_scan(float* arr, int n, float* tmp, bool exclusive, bool r
   __syncthreads();
 }
 
+// The same scans for n <= 256 with element t in a REGISTER of thread t (v = the identity for t >= n): a wave-shuffle scan, the four
+// wave totals through tmp4 (4 floats; the caller alternates between two such buffers from one scan to the next, so a buffer is
+// rewritten only behind the barrier of the scan in between) and ONE barrier.  block_scan keeps its array in LDS and needs three;
+// the monotonic normaliser runs two scans per forward and four per backward step.  Forward scans add in block_scan's order.
+template <bool MUL, bool REVERSE, bool EXCLUSIVE>
+__device__ __forceinline__ float scan256(const float v, float* tmp4, const int lane, const int wave) {
+  const float ident = MUL ? 1.f : 0.f;
+  float inc = v;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const float nb = REVERSE ? __shfl_down(inc, o, 64) : __shfl_up(inc, o, 64);
+    if (REVERSE ? (lane + o < 64) : (lane >= o)) inc = MUL ? inc * nb : inc + nb;
+  }
+  if (lane == (REVERSE ? 0 : 63)) tmp4[wave] = inc;
+  float run = REVERSE ? __shfl_down(inc, 1, 64) : __shfl_up(inc, 1, 64);
+  if (lane == (REVERSE ? 63 : 0)) run = ident;
+  __syncthreads();
+  if (REVERSE) { for (int w = 3; w > wave; --w) run = MUL ? tmp4[w] * run : tmp4[w] + run; }
+  else { for (int w = 0; w < wave; ++w) run = MUL ? tmp4[w] * run : tmp4[w] + run; }
+  return EXCLUSIVE ? run : (MUL ? run * v : run + v);
+}
+
 __device__ __forceinline__ float dot8(const uint4& k, const float* q) {
   const unsigned short* e = reinterpret_cast<const unsigned short*>(&k);
   float s = 0.f;
@@ -465,6 +487,33 @@ __device__ __forceinline__ void dec_step_fwd_body(const las_dec_step& s, const i
     float* tmp = cred;                // 256 floats of scan scratch (cred is free until the context phase)
     const float bias = s.score_bias ? *s.score_bias : 0.f;
     const float* prev = s.prev_align ? s.prev_align + (int64_t)b * s.ldpa : nullptr;
+    if (Tm <= 256 && s.norm == LAS_NORM_MONOTONIC_PARALLEL) {
+      // frame t in the registers of thread t from the score to the alignment: two scans, two barriers (see scan256)
+      const int t = tid;
+      float p = 0.f, pr = 0.f;
+      if (t < Tm) {
+        if (t < len) {
+          float sv = sc[t] + bias;
+          if (s.noise_scale > 0.f)
+            sv += s.noise_scale * las_normal(s.noise_seed, s.noise_stream, ((unsigned long long)s.step * s.B + b) * Tm + t);
+          p = las_sigmoid(sv);
+        }
+        pr = prev ? (ph ? __hip_atomic_load(prev + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : prev[t]) : (t == 0 ? 1.f : 0.f);
+        if (writer && s.p_out) s.p_out[(int64_t)b * s.ldp + t] = p;
+      }
+      const float lc = t < Tm ? __logf(fminf(fmaxf(1.f - p, 1.17549435e-38f), 1.f)) : 0.f;
+      const float c = __expf(scan256<false, false, true>(lc, tmp, lane, wave));
+      const float S = scan256<false, false, false>(t < Tm ? pr / fminf(fmaxf(c, 1e-10f), 1.f) : 0.f, tmp + 4, lane, wave);
+      if (t < Tm) {
+        const float a = p * c * S;
+        sc[t] = a;
+        if (writer) {
+          s.align_out[(int64_t)b * s.lda + t] = a;
+          if (s.align_bf16) s.align_bf16[(int64_t)b * s.lda + t] = las_f2bf(a);
+        }
+      }
+      __syncthreads();
+    } else {
     for (int t = tid; t < Tm; t += 256) {
       float p = 0.f;
       if (t < len) {
@@ -506,6 +555,7 @@ __device__ __forceinline__ void dec_step_fwd_body(const las_dec_step& s, const i
       }
     }
     __syncthreads();
+    }
   } else {
   // ---- masked softmax over t' ----
   float mx = -INFINITY;
@@ -1834,6 +1884,34 @@ __device__ __forceinline__ void dec_step_bwd_body(const las_dec_step_bwd& s, con
     const float* pv = s.p + (int64_t)b * s.ldp;
     const float* prev = s.prev_align ? s.prev_align + (int64_t)b * s.ldpa : nullptr;
     float* carry = s.dalign_carry + (int64_t)b * s.ldcarry;
+    if (Tm <= 256) {
+      // frame t in the registers of thread t through the whole chain: four scans, four barriers (see scan256)
+      const int t = tid;
+      const bool in = t < Tm;
+      const float p = (in && t < len) ? pv[t] : 0.f;
+      const float pr = in ? (prev ? prev[t] : (t == 0 ? 1.f : 0.f)) : 0.f;
+      const float da = in ? ds[t] + carry[t] : 0.f;           // d(align_t): this step's + step t+1's normaliser's
+      const float c = __expf(scan256<false, false, true>(in ? __logf(fminf(fmaxf(1.f - p, 1.17549435e-38f), 1.f)) : 0.f, tmp, lane, wave));
+      const float cc = fminf(fmaxf(c, 1e-10f), 1.f);
+      const float S = scan256<false, false, false>(in ? pr / cc : 0.f, tmp + 4, lane, wave);
+      const float du = scan256<false, true, false>(in ? da * p * c : 0.f, tmp, lane, wave);      // sum_{i >= t} dS[i]
+      float dc = da * p * S;
+      if (c >= 1e-10f && c <= 1.f) dc -= du * pr / (cc * cc);
+      const float dlx = scan256<false, true, true>(in ? dc * c : 0.f, tmp + 4, lane, wave);         // sum_{j > t} dcs[j]
+      float v = 0.f;
+      if (in) {
+        carry[t] = du / cc;                                   // d(align_{t-1})
+        const float x = 1.f - p;
+        float dp = da * c * S;
+        if (x >= 1.17549435e-38f && x <= 1.f) dp -= dlx / x;
+        v = (t < len) ? dp * p * (1.f - p) : 0.f;
+        ds[t] = v;
+        if (s.ds_out) s.ds_out[(int64_t)b * s.ldso + t] = las_f2bf(v);
+      }
+      const float dbias = block_reduce(v, red, false);
+      if (tid == 0 && s.dbias_acc) atomicAdd(s.dbias_acc, dbias);
+      __syncthreads();
+    } else {
     for (int t = tid; t < Tm; t += 256) {
       const float p = (t < len) ? pv[t] : 0.f;
       wp[t] = p;
@@ -1877,6 +1955,7 @@ __device__ __forceinline__ void dec_step_bwd_body(const las_dec_step_bwd& s, con
     dbias = block_reduce(dbias, red, false);
     if (tid == 0 && s.dbias_acc) atomicAdd(s.dbias_acc, dbias);
     __syncthreads();
+    }
   } else {
   // softmax backward: ds = p * (dalign - sum p*dalign)
   const float* align = s.align + (int64_t)b * s.lda;
