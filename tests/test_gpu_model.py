@@ -865,6 +865,21 @@ def test_one_launch_forward_with_attention_layer_or_monotonic_normaliser_vs_orac
     and / or a monotonic normaliser take their forward pass in ONE launch since round 3 (las_decoder_persist_fwd with walT /
     norm = monotonic 'parallel'; the backward still steps).  Ragged lengths, two groups of utterances (B = 11), against the
     oracle with the tolerances of the general decoder path."""
+    _one_launch_vs_oracle(kw, 24, [24, 9, 17, 24, 12, 21, 5, 24, 16, 3, 20], [6, 4, 5, 6, 3, 6, 2, 5, 4, 1, 6])
+
+
+@pytest.mark.parametrize('kw', [
+    dict(att='bahdanau_monotonic', H=128, als=32, pyramidal=False, pass_hidden=False),
+    dict(att='bahdanau_monotonic', H=128, Hd=256, als=16, pyramidal=False, pass_hidden=False),
+], ids=['128_units', '256_units'])
+def test_one_launch_decoders_over_a_long_memory(kw):
+    """T' = 280 frames (stacked, non-pyramidal listener): past the 256 frames that the register-resident monotonic chain
+    (scan256) covers -- the LDS scans take over -- and, at 256 units, past the 200 frames whose d(keys) fits the registers of
+    the one-launch backward (35 frame passes > SEQ_NPK: the read-modify-write variant); at 128 units 18 passes fit."""
+    _one_launch_vs_oracle(kw, 280, [280, 131, 277, 64, 201], [6, 4, 5, 6, 3])
+
+
+def _one_launch_vs_oracle(kw, T, src_len, tgt_len):
     from phones_las_amd import hip
     from phones_las_amd.las.speller_general import GeneralSpeller
     O, ohp, op, model = _models(**kw)
@@ -872,10 +887,8 @@ def test_one_launch_forward_with_attention_layer_or_monotonic_normaliser_vs_orac
     if 'speller/attention_score_bias' in op:
         op['speller/attention_score_bias'] = op['speller/attention_score_bias'] + 0.3
         model.load_variables({k: v for k, v in op.items()})
-    B = 11
-    src_len = [24, 9, 17, 24, 12, 21, 5, 24, 16, 3, 20]
-    tgt_len = [6, 4, 5, 6, 3, 6, 2, 5, 4, 1, 6]
-    batch = make_batch(B=B, T=24, src_len=src_len, tgt_len=tgt_len)
+    B = len(src_len)
+    batch = make_batch(B=B, T=T, src_len=src_len, tgt_len=tgt_len)
     feats, labels = to_device(batch)
     model.vars.grad.zero_()
     loss, logits, dlogits = model.forward_train(feats, labels)
