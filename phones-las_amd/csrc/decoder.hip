@@ -903,27 +903,37 @@ __global__ __launch_bounds__(256) void dec_persist_fwd_kernel(las_dec_persist p)
 #pragma unroll
       for (int i = 0; i < KRES; ++i)
 #pragma unroll
-        for (int nt = 0; nt < NTL_MAX; ++nt)
-          if (nt < NTL && wave + 4 * i < KC)
-            acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, av[i]), wf[nt][i], acc[nt], 0, 0, 0);
+        for (int nt = 0; nt < NTL_MAX; ++nt)      // (absent tiles / chunks hold zero weights: no guard -- 32 branches otherwise)
+          acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, av[i]), wf[nt][i], acc[nt], 0, 0, 0);
+      LAS_STAMP(t, 11);
 #ifndef DEC_SKIP_STREAM
       if constexpr (KRES < KCW_MAX) {
-        // the chunks that do not fit the register file: operand and weight fragments of two chunks in flight
-#pragma unroll 2
-        for (int i = KRES; i < KCW_MAX; ++i) {
-          const int kc = wave + 4 * i;
-          if (kc >= KC) break;
-          const uint4 a = bg < B ? *reinterpret_cast<const uint4*>(arow + kc * 32) : make_uint4(0, 0, 0, 0);
-          uint4 w[NTL_MAX];
+        // the chunks that do not fit the register file, SB at a time: their operand and weight fragments (SB (1 + NTL_MAX)
+        // loads) are all requested before the first product.  (One chunk at a time under `#pragma unroll 2` the compiler,
+        // short of VGPRs, had made every weight fragment its own load -> wait -> product: ~18 dependent L2 round trips, 6 of
+        // the 8 us of this phase at 512 units.)  Chunks past the end of K: clamped address, zero operand.
+        constexpr int SB = 4;
+#pragma unroll 1
+        for (int i0 = KRES; i0 < KCW_MAX; i0 += SB) {
+          if (wave + 4 * i0 >= KC) break;
+          uint4 a[SB], w[SB][NTL_MAX];
 #pragma unroll
-          for (int nt = 0; nt < NTL_MAX; ++nt) w[nt] = *reinterpret_cast<const uint4*>(wrow[nt] + kc * 32);
+          for (int j = 0; j < SB; ++j) {
+            const int kc = wave + 4 * (i0 + j), kcc = min(kc, KC - 1);
+            a[j] = *reinterpret_cast<const uint4*>(arow + kcc * 32);
+            if (kc >= KC || bg >= B) a[j] = make_uint4(0, 0, 0, 0);
 #pragma unroll
-          for (int nt = 0; nt < NTL_MAX; ++nt)
-            if (nt < NTL)
-              acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, w[nt]), acc[nt], 0, 0, 0);
+            for (int nt = 0; nt < NTL_MAX; ++nt) w[j][nt] = *reinterpret_cast<const uint4*>(wrow[nt] + kcc * 32);
+          }
+#pragma unroll
+          for (int j = 0; j < SB; ++j)
+#pragma unroll
+            for (int nt = 0; nt < NTL_MAX; ++nt)  // (an absent tile repeats the last one's weights; its sums are never stored)
+              acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a[j]), __builtin_bit_cast(bf16x8, w[j][nt]), acc[nt], 0, 0, 0);
         }
       }
 #endif
+      LAS_STAMP(t, 12);
 #pragma unroll
       for (int nt = 0; nt < NTL_MAX; ++nt)
         if (nt < NTL)
@@ -1289,7 +1299,7 @@ __global__ __launch_bounds__(256) void dec_persist_fwd_lean_kernel(las_dec_persi
 #pragma unroll
     for (int i = 0; i < KRES; ++i) av[i] = *reinterpret_cast<const uint4*>(arow + min(wave + 4 * i, KC - 1) * astep);
     // the streamed chunks: operand piece and NTL weight pieces each, SD of them in flight
-    constexpr int NS = KCWM - KRES, SD = 3;
+    constexpr int NS = KCWM - KRES, SD = 4;
     uint4 sa[NS > 0 ? SD : 1], sw[NS > 0 ? SD : 1][NTL];
     auto stream_issue = [&](int slot, int i) {              // i: chunk index of this wave (KRES ...)
       const int kcc = min(wave + 4 * i, KC - 1);
@@ -1321,7 +1331,21 @@ __global__ __launch_bounds__(256) void dec_persist_fwd_lean_kernel(las_dec_persi
 #pragma unroll
         for (int nt = 0; nt < NTL; ++nt)
           acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, av[i]), wf[nt][i], acc[nt], 0, 0, 0);
+      LAS_STAMP(t, 11);
       if constexpr (NS > 0) {
+        // KCWM is the instantiation's bound, not the model's K: at metric-L (K = 1536) 4 of the 12 streamable chunks of a wave
+        // exist, and walking all 12 three at a time was 4 L2 round trips of clamped loads (5 of the 8 us of this phase).  When
+        // the chunks that exist were all requested above, their products are all that is left (scalar branch).
+        const int nreal = __builtin_amdgcn_readfirstlane((KC - (tid >> 6) + 3) / 4) - KRES;
+        if (nreal <= SD) {
+#pragma unroll
+          for (int q = 0; q < SD; ++q) {
+            const uint4 a4 = q < nreal ? sa[q] : make_uint4(0, 0, 0, 0);
+#pragma unroll
+            for (int nt = 0; nt < NTL; ++nt)
+              acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a4), __builtin_bit_cast(bf16x8, sw[q][nt]), acc[nt], 0, 0, 0);
+          }
+        } else
 #pragma unroll
         for (int i = 0; i < NS; ++i) {
           const int slot = i % SD;
@@ -1333,6 +1357,7 @@ __global__ __launch_bounds__(256) void dec_persist_fwd_lean_kernel(las_dec_persi
           if (i + SD < NS) stream_issue(slot, KRES + i + SD);
         }
       }
+      LAS_STAMP(t, 12);
       if (lq < 2) {                                        // rows 0..7 of the tile: the group's 8 utterances
 #pragma unroll
         for (int nt = 0; nt < NTL; ++nt)

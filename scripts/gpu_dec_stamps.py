@@ -29,3 +29,7 @@ for which, off in (('forward', 0), ('backward', 256)):
     print('%s: step time (stamp 0 to stamp 0): %.2f us' % (which, np.diff(st[:, 0]).mean() / 100.0))
     for k, n in enumerate(names[:d.shape[1]]):
         print('  %-44s %6.2f us  (min %5.2f max %5.2f)' % (n, d[5:-1, k].mean(), d[5:-1, k].min(), d[5:-1, k].max()))
+st = buf.reshape(512, 16)[0:U].astype(np.int64)
+if st[5:, 11].any():
+    print('forward G role: operands + resident products %.2f us, streamed chunks %.2f us, partial sums to LDS %.2f us' % (
+        ((st[5:-1, 11] - st[5:-1, 0]) / 100.0).mean(), ((st[5:-1, 12] - st[5:-1, 11]) / 100.0).mean(), ((st[5:-1, 1] - st[5:-1, 12]) / 100.0).mean()))
