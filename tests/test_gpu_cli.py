@@ -38,21 +38,21 @@ def test_train_resume_infer(tmp_path, capsys):
     #  near zero -- Adam with vanishing gradients -- and fp32 sums through atomics make two runs agree to rounding only,
     #  so about 3 % of the runs were evaluated right after a spike and ended at 24 % PER.  With all 16 utterances in
     #  every step the loss falls monotonically; scripts/gpu_cli_flaky.py and gpu_golden_then_cli.py are the probes.)
-    train.main(train.parse_args(common + ['--num_epochs', '800']))      # 16 utts / 16 = 1 step per epoch -> 800 steps
+    train.main(train.parse_args(common + ['--num_epochs', '1200']))     # 16 utts / 16 = 1 step per epoch -> 1200 steps
     out = capsys.readouterr().out
-    assert 'finished at global_step 800' in out
+    assert 'finished at global_step 1200' in out
     first = float(out.split('step 10: loss = ')[1].split()[0].rstrip(','))
-    last = float(out.split('step 800: loss = ')[1].split()[0].rstrip(','))
+    last = float(out.split('step 1200: loss = ')[1].split()[0].rstrip(','))
     assert last < 0.2 * first
     # the reference's TRAIN-mode log line carries the last batch's mean edit distance beside the loss (model_helper.py:435-439)
     ed_first = float(out.split('step 10: loss = ')[1].split('edit_distance = ')[1].split()[0])
-    ed_last = float(out.split('step 800: loss = ')[1].split('edit_distance = ')[1].split()[0])
+    ed_last = float(out.split('step 1200: loss = ')[1].split('edit_distance = ')[1].split()[0])
     assert ed_first > 0.3 and ed_last < 0.05, (ed_first, ed_last)
     assert os.path.exists(os.path.join(d, 'model', 'hparams.json'))
     # resume: the checkpoint restores the step counter; hparams.json wins over the (different) CLI value
     train.main(train.parse_args(common + ['--num_epochs', '5', '--encoder_units', '128']))
     out = capsys.readouterr().out
-    assert 'restored' in out and 'at global_step 800' in out
+    assert 'restored' in out and 'at global_step 1200' in out
     per = infer.main(infer.parse_args(['--data', os.path.join(d, 'train.tfr'), '--vocab', os.path.join(d, 'vocab.txt'),
                                        '--norm', os.path.join(d, 'norm.dmp'), '--model_dir', os.path.join(d, 'model'),
                                        '--num_channels', '13', '--batch_size', '8']))
@@ -64,11 +64,12 @@ def test_train_resume_infer(tmp_path, capsys):
     # Training is bit-reproducible since round 3 (the weight-gradient K slices, bias sums and norms are added in a fixed order:
     # test_training_is_bit_reproducible), so this run has ONE trajectory, not a distribution: round 2's retries and its
     # `per < 55` bound (for the one run in seven that ended on a plateau) are gone.
-    # (ONE trajectory per build: a kernel change that moves a rounding moves it.  Most builds of this round end with 16 of 16
-    #  sentences right (PER 0); one ended with 15 right and the greedy decode of the 16th never emitting </s> -- 12 inserted
-    #  symbols, PER 24 % -- although its TRAIN-mode edit distance above is < 0.05.  The criterion is therefore the sentences:
-    #  at most one wrong, and the PER bound is what one runaway hypothesis of the maximum length can cost.)
-    assert sentences_right() >= 15 and per < 30.0, (sentences_right(), per)
+    # (ONE trajectory per build, and Adam on a loss near zero spikes now and then: this build's trajectory has the loss at 0.022
+    #  at step 800 -- thirty times its neighbours -- where one greedy hypothesis never emits </s> (15 of 16 right, PER 24 %);
+    #  at step 1200 it is at 0.0005 like every perturbed run.  scripts/gpu_cli_robust.py samples the trajectories a kernel change
+    #  draws from (speller weight-gradient slices through atomics): 12 of 12 runs end with 16 sentences right and PER 0 at
+    #  800 and at 1200 steps, with and without the resume.  The criterion stays the strict one.)
+    assert sentences_right() == 16 and per < 10.0, (sentences_right(), per)
     assert len(open(os.path.join(d, 'model', 'infer.txt')).read().split('\n')) == 16
     # the three output files, as the reference writes them (infer.py:269-271,345-359): infer.txt = to_text of the ids (cut at
     # the first </s> symbol), infer.dmp = joblib list of {'transcription': line}, infer_targets.txt = the targets
@@ -99,7 +100,7 @@ def test_train_resume_infer(tmp_path, capsys):
     per_beam = infer.main(infer.parse_args(['--data', os.path.join(d, 'train.tfr'), '--vocab', os.path.join(d, 'vocab.txt'),
                                             '--norm', os.path.join(d, 'norm.dmp'), '--model_dir', os.path.join(d, 'model'),
                                             '--num_channels', '13', '--batch_size', '8', '--beam_width', '3']))
-    assert per_beam < 30.0 and sentences_right() >= 15 and 'Optimistic PER' in capsys.readouterr().out
+    assert per_beam < 10.0 and sentences_right() == 16 and 'Optimistic PER' in capsys.readouterr().out
     import eval as eval_cli
     loss, ed = eval_cli.main(eval_cli.parse_args(['--data', os.path.join(d, 'train.tfr'), '--vocab', os.path.join(d, 'vocab.txt'),
                                                   '--norm', os.path.join(d, 'norm.dmp'), '--model_dir', os.path.join(d, 'model'),
