@@ -440,7 +440,9 @@ typedef struct las_dec_persist_bwd {
   const las_bf16* kc;            /* [W, 4Hd] bf16: row n = row n of the cell kernel below the token rows, stride ldk */
   int64_t ldk;
   float* dfeed_all;              /* [U, B, W] fp32 */
-  float* dot_all;                /* unused (the partial dots travel through the workspace); may be NULL */
+  void* sum_workspace;           /* optional, Bahdanau: las_decoder_sum_workspace_bytes(blocks, Hd) bytes with blocks = 32 * (ceil(B / 8) rounded up to 8: the launch's grid), first word zero
+                                  * before the first use (the launch leaves it zero): d(attention_v) is then summed over the
+                                  * workgroups in a fixed order instead of with fp32 atomics (bit-reproducible training) */
   float* dhp_all;                /* unused (the partial dh travel through the workspace); may be NULL */
   void* workspace;               /* las_decoder_persist_workspace_bytes(B, Tm, Hd, M) */
 } las_dec_persist_bwd;
@@ -477,7 +479,13 @@ typedef struct las_dec_seq_bwd {
    * an LDS copy) instead of values . d(context_t) (a pass over the utterance's T' x M values at every step). */
   const float* vw;
   int64_t ld_vw;
+  /* optional: las_decoder_sum_workspace_bytes(B, Hd + 1) bytes, first word zero before the first use (the launch leaves it
+   * zero): d(attention_v) [Hd] and d(attention_score_bias) are summed over the steps in the utterance's workgroup and over the
+   * utterances in a fixed order, instead of one fp32 atomic per step and utterance */
+  void* sum_workspace;
 } las_dec_seq_bwd;
+/* bytes of the fixed-order sum workspace of the one-launch backward decoders: a counter line + `blocks` rows of n floats */
+size_t las_decoder_sum_workspace_bytes(int blocks, int n);
 int las_decoder_seq_bwd_supported(int Hd, int M, int A, int W0, int Tm, int attention, int norm);
 int las_decoder_seq_bwd(const las_dec_seq_bwd* p, void* stream);
 

@@ -1746,6 +1746,32 @@ __global__ __launch_bounds__(256) void dec_persist_fwd_lean_kernel(las_dec_persi
 // ------------------------------------------------------------------------------------------------
 // backward
 // ------------------------------------------------------------------------------------------------
+// Sum over the workgroups of a launch in a FIXED order (d(attention_v), d(attention_score_bias) of the one-launch backward
+// decoders: fp32 atomics would add the workgroups' shares in the order they happen to finish, and two runs would differ in
+// the last bits).  Every workgroup hands in n values `mine` (LDS); ws = {counter word, 15 pad words, nblk rows of n floats}.  The
+// rows are written with write-through stores and acknowledged before the counter moves (no release fence: see l2_norm_kernel);
+// the LAST workgroup to arrive adds the rows up in workgroup order with L2-bypassing loads, adds the sums into dst_a[0..na) and
+// dst_b[0..n-na) and clears the counter for the next launch.  All 256 threads of every workgroup call it.
+__device__ void ordered_accumulate(unsigned* ws, const int blk, const int nblk, const int n, const float* mine, float* dst_a, const int na,
+                                   float* dst_b, int* lds_word) {
+  const int tid = threadIdx.x;
+  float* rows = reinterpret_cast<float*>(ws + 16);
+  for (int u = tid; u < n; u += 256) __hip_atomic_store(rows + (int64_t)blk * n + u, mine[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (tid == 0) *lds_word = (__hip_atomic_fetch_add(ws, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)(nblk - 1)) ? 1 : 0;
+  __syncthreads();
+  if (!*lds_word) return;
+  for (int u = tid; u < n; u += 256) {
+    float t = 0.f;
+#pragma unroll 8
+    for (int b = 0; b < nblk; ++b) t += __hip_atomic_load(rows + (int64_t)b * n + u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (u < na) { if (dst_a) dst_a[u] += t; }
+    else if (dst_b) dst_b[u - na] += t;
+  }
+  if (tid == 0) __hip_atomic_store(ws, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 // LDS floats of one backward step (dec_step_bwd_body): d(context), dalign -> dscore, per-phase partials, scratch, the
 // monotonic normaliser's five arrays, the query-layer scratch
 __host__ __device__ inline size_t dec_step_bwd_floats(int M, int Tm, int Hd, int norm) {
@@ -1766,7 +1792,7 @@ constexpr int SEQ_NPK = 25;
 template <int NPK = 0>
 __device__ __forceinline__ void dec_step_bwd_body(const las_dec_step_bwd& s, const int b, float* sm, const float* vw = nullptr,
                                                   const float* datt = nullptr, const int A = 0, float (*dkr)[8] = nullptr,
-                                                  const int tid_in = -1) {
+                                                  const int tid_in = -1, float* acc_run = nullptr) {
   float* dctx = sm;               // [M]
   float* ds = dctx + s.M;         // [Tm] dalign -> dscore
   float* dhs = ds + s.Tm;         // [256/L][Hd] = 2048 floats: per-phase partial d h (score path) / dpq
@@ -1934,7 +1960,7 @@ __device__ __forceinline__ void dec_step_bwd_body(const las_dec_step_bwd& s, con
         if (s.ds_out) s.ds_out[(int64_t)b * s.ldso + t] = las_f2bf(v);
       }
       const float dbias = block_reduce(v, red, false);
-      if (tid == 0 && s.dbias_acc) atomicAdd(s.dbias_acc, dbias);
+      if (tid == 0 && s.dbias_acc) { if (acc_run) acc_run[Hd] += dbias; else atomicAdd(s.dbias_acc, dbias); }   // (acc_run: see dec_seq_bwd_kernel)
       __syncthreads();
     } else {
     for (int t = tid; t < Tm; t += 256) {
@@ -1978,7 +2004,7 @@ __device__ __forceinline__ void dec_step_bwd_body(const las_dec_step_bwd& s, con
       if (s.ds_out) s.ds_out[(int64_t)b * s.ldso + t] = las_f2bf(v);
     }
     dbias = block_reduce(dbias, red, false);
-    if (tid == 0 && s.dbias_acc) atomicAdd(s.dbias_acc, dbias);
+    if (tid == 0 && s.dbias_acc) { if (acc_run) acc_run[Hd] += dbias; else atomicAdd(s.dbias_acc, dbias); }
     __syncthreads();
     }
   } else {
@@ -2121,7 +2147,8 @@ __device__ __forceinline__ void dec_step_bwd_body(const las_dec_step_bwd& s, con
     for (int u = tid; u < Hd; u += 256) {
       float acc = 0.f;
       for (int ph = 0; ph < P; ++ph) acc += dvs[ph * Hd + u];
-      atomicAdd(s.dv_acc + u, acc);
+      if (acc_run) acc_run[u] += acc;          // (the launch's running sum of this utterance: thread u owns column u)
+      else atomicAdd(s.dv_acc + u, acc);
     }
   }
   LAS_STAMPB(s.step, 5);
@@ -2209,8 +2236,10 @@ __global__ __launch_bounds__(256) void dec_seq_bwd_kernel(las_dec_seq_bwd p) {
   float* dfeed = dqc + (A > 0 ? Hd + M : 0);                           // [W0] d[feed | h]_{t} from step t+1
   // [4 Hd] bf16 dz_t and 8 zeros behind it, on a 16-byte boundary (sm is): the A operand of the d(feed) product
   unsigned short* dzl = reinterpret_cast<unsigned short*>(sm + (((dfeed + W0 - sm) + 3) & ~(ptrdiff_t)3));
-  float* vwl = dfeed + W0 + 2 * Hd + 8;                                // [Tm][A + 1]: values W_c of this utterance (p.vw given)
+  float* acc_run = dfeed + W0 + 2 * Hd + 8;                            // [Hd + 1]: this utterance's d(attention_v), d(score_bias) over the steps
+  float* vwl = acc_run + Hd + 8;                                       // [Tm][A + 1]: values W_c of this utterance (p.vw given)
   for (int n = tid0; n < W0; n += 256) dfeed[n] = 0.f;
+  for (int n = tid0; n < Hd + 8; n += 256) acc_run[n] = 0.f;
   if (tid0 < 4) reinterpret_cast<unsigned*>(dzl + 4 * Hd)[tid0] = 0u;       // the zeros behind the A operands' row 0
   float dkr[NPK > 0 ? NPK : 1][8];                                    // d(keys) of this utterance (Bahdanau scores; see the body)
 #pragma unroll
@@ -2320,7 +2349,7 @@ __global__ __launch_bounds__(256) void dec_seq_bwd_kernel(las_dec_seq_bwd p) {
       st.dh_b = st.dh_c = nullptr;
       st.dh_rec = has_next ? dfeed + feed : nullptr;   st.ldr = 0;
     }
-    dec_step_bwd_body<NPK>(st, b, sm, use_vw ? vwl : nullptr, datt, A, dkr, tid);
+    dec_step_bwd_body<NPK>(st, b, sm, use_vw ? vwl : nullptr, datt, A, dkr, tid, p.sum_workspace ? acc_run : nullptr);
     __syncthreads();                               // dz_t of this utterance is in memory (same workgroup: visible behind the barrier)
     LAS_STAMPB(t, 8);
     if (t > 0 || p.dfeed_out) {
@@ -2363,6 +2392,12 @@ __global__ __launch_bounds__(256) void dec_seq_bwd_kernel(las_dec_seq_bwd p) {
   }
   if (p.dfeed_out)
     for (int n = tid0; n < W0; n += 256) p.dfeed_out[(int64_t)b * W0 + n] = dfeed[n];
+  if (p.sum_workspace && (s0.dv_acc || s0.dbias_acc)) {
+    // d(attention_v) / d(score_bias): the utterances' sums over the steps meet in utterance order (ordered_accumulate)
+    __syncthreads();
+    ordered_accumulate(static_cast<unsigned*>(p.sum_workspace), b, gridDim.x, Hd + 1, acc_run, s0.dv_acc, Hd, s0.dbias_acc,
+                       reinterpret_cast<int*>(acc_run + Hd + 4));
+  }
   if constexpr (NPK > 0) {
     // the register-resident d(keys) joins the accumulator once (same thread layout as the body's query path)
     const int L = Hd / 8, P = 256 / L, phase = tid0 / L, u = (tid0 % L) * 8;
@@ -2407,7 +2442,15 @@ __global__ __launch_bounds__(256) void dec_persist_bwd_kernel(las_dec_persist_bw
   // a 256-CU device -- before it starts the next chunk: a batch of more than 64 utterances runs chunk after chunk
   const int groups = (B + 7) / 8;
   const int group = (blockIdx.x / (8 * P_MEMBERS)) * 8 + (blockIdx.x & 7), member = (blockIdx.x % (8 * P_MEMBERS)) >> 3;
-  if (group >= groups) return;
+  if (group >= groups) {
+    // (a workgroup without utterances still takes its place in the fixed-order sum of d(attention_v): a row of zeros)
+    if (WQ && att_additive(s0.attention) && p.sum_workspace) {
+      for (int c = tid; c < Hd; c += 256) sm[c] = 0.f;
+      __syncthreads();
+      ordered_accumulate(static_cast<unsigned*>(p.sum_workspace), blockIdx.x, gridDim.x, Hd, sm, s0.dv_acc, Hd, nullptr, reinterpret_cast<int*>(sm + Hd));
+    }
+    return;
+  }
   float* dctx = sm;                       // [M]
   unsigned short* dcb = reinterpret_cast<unsigned short*>(dctx);       // NPQ > 0: [2][M] bf16 instead, d(context) = high + low; then 16 B of zeros
   unsigned short* dsb = reinterpret_cast<unsigned short*>(dctx + M + 4);    // [2][ds_pad] bf16: ds of the own frames = high + low
@@ -3062,10 +3105,27 @@ __global__ __launch_bounds__(256) void dec_persist_bwd_kernel(las_dec_persist_bw
 #pragma unroll
   for (int q = 0; q < UPT; ++q)
     if (cellw) s0.dc[(int64_t)b * Hd + tid + q * 256] = dcr[q];          // d(c) before the first step: the caller's d(initial state)
-  if (WQ && att_additive(s0.attention) && active) {
-    const int u = (tid % (Hd / 8)) * 8;
+  if (WQ && att_additive(s0.attention)) {
+    const int L8 = Hd / 8, P8 = 256 / L8, u = (tid % L8) * 8, phs = tid / L8;
+    if (p.sum_workspace) {
+      // the frame phases of a column meet in LDS, the workgroups in workgroup order (ordered_accumulate); absent utterances add zeros
+      __syncthreads();
+      float* scr = sm;                                   // [P8][Hd] + [Hd] + a flag word: the step arrays are free now
 #pragma unroll
-    for (int j = 0; j < 8; ++j) atomicAdd(s0.dv_acc + u + j, dv_tot[j]);
+      for (int j = 0; j < 8; ++j) scr[phs * Hd + u + j] = active ? dv_tot[j] : 0.f;
+      __syncthreads();
+      for (int c = tid; c < Hd; c += 256) {
+        float a = 0.f;
+        for (int ph = 0; ph < P8; ++ph) a += scr[ph * Hd + c];
+        scr[P8 * Hd + c] = a;
+      }
+      __syncthreads();
+      ordered_accumulate(static_cast<unsigned*>(p.sum_workspace), blockIdx.x, gridDim.x, Hd, scr + P8 * Hd, s0.dv_acc, Hd, nullptr,
+                         reinterpret_cast<int*>(scr + P8 * Hd + Hd));
+    } else if (active) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) atomicAdd(s0.dv_acc + u + j, dv_tot[j]);
+    }
   }
   if (*fail && tid == 0) atomicOr(status, 16u);
 }
@@ -3559,12 +3619,16 @@ extern "C" int las_decoder_persist_bwd(const las_dec_persist_bwd* p, void* strea
   return LAS_OK;
 }
 
+extern "C" size_t las_decoder_sum_workspace_bytes(int blocks, int n) {
+  return blocks > 0 && n > 0 ? 64 + (size_t)blocks * n * sizeof(float) : 0;
+}
+
 extern "C" int las_decoder_seq_bwd_supported(int Hd, int M, int A, int W0, int Tm, int attention, int norm) {
   if (Hd != 128 && Hd != 256) return 0;                       // dz_t as one or two 16-byte pieces per lane
   if (M % 128 != 0 || A < 0 || A % 8 != 0 || W0 <= 0) return 0;
   if (attention < LAS_ATT_LUONG || attention > LAS_ATT_BAHDANAU_MONOTONIC) return 0;
   if (norm != LAS_NORM_SOFTMAX && norm != LAS_NORM_MONOTONIC_PARALLEL) return 0;
-  const size_t lds = (dec_step_bwd_floats(M, Tm, Hd, norm) + (size_t)(A > 0 ? A + Hd + M : 0) + W0 + 2 * Hd + 8) * sizeof(float);
+  const size_t lds = (dec_step_bwd_floats(M, Tm, Hd, norm) + (size_t)(A > 0 ? A + Hd + M : 0) + W0 + 2 * Hd + 8 + Hd + 8) * sizeof(float);
   return lds <= 64 * 1024 ? 1 : 0;      // (+ Tm * (A + 1) floats when the caller hands in VW: checked at the launch against 160 KiB)
 }
 
@@ -3581,7 +3645,7 @@ extern "C" int las_decoder_seq_bwd(const las_dec_seq_bwd* p, void* stream) {
   LAS_REQUIRE(s->attention != LAS_ATT_CUSTOM || (s->wq_t && s->pq), "las_decoder_seq_bwd: CustomAttention needs wq_t and the saved processed query");
   LAS_REQUIRE(s->norm == LAS_NORM_SOFTMAX || (s->p && s->dalign_carry), "las_decoder_seq_bwd: monotonic attention needs p_choose and the carry buffer");
   LAS_REQUIRE(s->drop_keep >= 1.0f, "las_decoder_seq_bwd: without input dropout");
-  size_t lds = (dec_step_bwd_floats(s->M, s->Tm, s->Hd, s->norm) + (size_t)(p->A > 0 ? p->A + s->Hd + s->M : 0) + p->W0 + 2 * s->Hd + 8) * sizeof(float);
+  size_t lds = (dec_step_bwd_floats(s->M, s->Tm, s->Hd, s->norm) + (size_t)(p->A > 0 ? p->A + s->Hd + s->M : 0) + p->W0 + 2 * s->Hd + 8 + s->Hd + 8) * sizeof(float);
   las_dec_seq_bwd q = *p;
   if (q.A > 0 && q.vw) {
     const size_t with_vw = lds + (size_t)s->Tm * (q.A + 1) * sizeof(float);

@@ -43,6 +43,7 @@ _SIGS = {
     'las_decoder_step_fwd': ([_vp, _i32, _vp], C.c_int),
     'las_decoder_step_bwd': ([_vp, _vp], C.c_int),
     'las_decoder_seq_bwd_supported': ([_i32] * 7, C.c_int),
+    'las_decoder_sum_workspace_bytes': ([_i32, _i32], C.c_size_t),
     'las_decoder_seq_bwd': ([_vp, _vp], C.c_int),
     'las_seq_ce_loss': ([_vp, _i64, _vp, _vp, _i32, _i32, _i32, _f32, _vp, _vp, _i64, _vp], C.c_int),
     'las_seq_sigmoid_loss': ([_vp, _i64, _vp, _i64, _vp, _i32, _i32, _i32, _f32, _vp, _vp, _i64, _vp], C.c_int),
@@ -148,14 +149,14 @@ class DecSeqBwd(C.Structure):
     _fields_ = [('s', DecStepBwd), ('U', _i32), ('A', _i32), ('W0', _i32), ('reserved', _i32)] + [(n, _i64) for n in (
         'inc_gates', 'inc_c', 'inc_align', 'inc_dz', 'inc_ds', 'inc_save', 'inc_pq')] + [
         ('d_out', _vp), ('ld_dout', _i64), ('inc_dout', _i64), ('datt_out', _vp), ('ld_datt', _i64), ('waln_packed', _vp), ('reserved1', _i64),
-        ('kn_packed', _vp), ('reserved2', _i64), ('dfeed_out', _vp), ('vw', _vp), ('ld_vw', _i64)]
+        ('kn_packed', _vp), ('reserved2', _i64), ('dfeed_out', _vp), ('vw', _vp), ('ld_vw', _i64), ('sum_workspace', _vp)]
 
 
 class DecPersistBwd(C.Structure):
     """struct las_dec_persist_bwd (include/las_hip.h)."""
     _fields_ = [('s', DecStepBwd), ('U', _i32), ('W', _i32)] + [(n, _i64) for n in (
         'inc_a', 'inc_save', 'inc_gates', 'inc_c', 'inc_align', 'inc_dz', 'inc_ds', 'inc_pq')] + [
-        ('kc', _vp), ('ldk', _i64), ('dfeed_all', _vp), ('dot_all', _vp), ('dhp_all', _vp), ('workspace', _vp)]
+        ('kc', _vp), ('ldk', _i64), ('dfeed_all', _vp), ('sum_workspace', _vp), ('dhp_all', _vp), ('workspace', _vp)]
 
 
 ATT_LUONG, ATT_BAHDANAU, ATT_CUSTOM, ATT_LUONG_MONOTONIC, ATT_BAHDANAU_MONOTONIC = 0, 1, 2, 3, 4

@@ -426,6 +426,8 @@ class Speller:
             dfeed_all = torch.empty(1, B, W, dtype=f32, device=dev)      # only step 0's row leaves the launch: d(initial feed)
             ws = self._persist_workspace('bwd', lib.las_decoder_persist_workspace_bytes(B, Tm, Hd, M))
             p.dfeed_all, p.workspace = hip.addr(dfeed_all), hip.addr(ws)
+            if self.att == hip.ATT_BAHDANAU:        # d(attention_v) summed over the workgroups in a fixed order (no atomics)
+                p.sum_workspace = hip.addr(self._persist_workspace('sum', lib.las_decoder_sum_workspace_bytes(32 * (((B + 7) // 8 + 7) // 8 * 8), Hd)))
             # per step and utterance: dz K^T, d(align) = values . d(context), the d(query) sum over the keys
             tok = hip.prof_begin('dec_persist_bwd', 2.0 * U * B * (W * 4 * Hd + Tm * Hd + Tm * M))
             hip.check(lib.las_decoder_persist_bwd(C.byref(p), st))

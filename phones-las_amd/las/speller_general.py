@@ -672,6 +672,8 @@ class GeneralSpeller:
                     hip.gemm_nt(sv['memory'], self.walT[:, Hd:], vw, B * Tm, A, M, lda=M, ldb=Hd + M, ldc=A)
                     q.vw, q.ld_vw = hip.addr(vw), Tm * A
             q.kn_packed = hip.addr(self.kn_pk)
+            if bah or self.mono:                    # d(attention_v) / d(score_bias): fixed-order sums instead of atomics
+                q.sum_workspace = hip.addr(self._persist_workspace('sum', lib.las_decoder_sum_workspace_bytes(B, Hd + 1)))
             dfeed0 = torch.empty(B, W[0], dtype=f32, device=dev)
             q.dfeed_out = hip.addr(dfeed0)
             tok = hip.prof_begin('dec_seq_bwd', 2.0 * U * B * (W[0] * 4 * Hd + 2 * Tm * Hd + 2 * Tm * M + (Hd + M) * (A if self.has_al else 0)))

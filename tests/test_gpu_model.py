@@ -829,16 +829,22 @@ def test_full_greedy_decode_and_eval_loss_vs_oracle_on_trained_weights(att):
         assert np.allclose(ed, red)
 
 
-@pytest.mark.parametrize('cfg', [dict(att='luong', H=128, L=2), dict(att='luong', H=256, L=3, ctc=0.3)], ids=['luong128', 'luong256_ctc'])
+@pytest.mark.parametrize('cfg', [dict(att='luong', H=128, L=2), dict(att='luong', H=256, L=3, ctc=0.3),
+                                 dict(att='bahdanau', H=128, L=2), dict(att='bahdanau', H=256, L=2),
+                                 dict(att='bahdanau_monotonic', H=128, L=2, als=32), dict(att='luong_monotonic', H=128, L=2)],
+                         ids=['luong128', 'luong256_ctc', 'bahdanau128', 'bahdanau256', 'bahdanau_monotonic_al', 'luong_monotonic'])
 def test_training_is_bit_reproducible(cfg):
     """Two models from the same seed, the same batches, eight optimiser steps each: parameters, Adam slots and gradients must
     be BIT-identical.  Round 2 summed the K slices of the speller's weight-gradient products, the bias
     column sums and the per-tensor norms with fp32 atomics, so every run had its own trajectory; they now meet in workspaces
-    and are added in a fixed order (las_gemm_tn_ws, las_colsum_bf16_ws, las_grad_l2_norms with a workspace).  Dot-product
-    attentions only: the Bahdanau d(attention_v) / monotonic d(score_bias) sums still use atomics."""
+    and are added in a fixed order (las_gemm_tn_ws, las_colsum_bf16_ws, las_grad_l2_norms with a workspace).  The Bahdanau
+    d(attention_v) and the monotonic d(score_bias) sums of the one-launch backward decoders meet in workgroup order too
+    (ordered_accumulate in decoder.hip: `sum_workspace` of las_dec_persist_bwd / las_dec_seq_bwd); the per-step launches of the
+    other decoder shapes (several cells, input dropout, sigmoid outputs) still add them with atomics."""
     from phones_las_amd import model_helper as mh
     ohp, params = make_hparams(F=13, V=11, **cfg)
-    batches = [to_device(make_batch(B=5, T=24, src_len=[24, 17, 20, 24, 9], tgt_len=[6, 4, 5, 6, 2], seed=s)) for s in (0, 1)]
+    src_len, tgt_len = [24, 17, 20, 24, 9, 12, 24, 21, 7, 24, 15], [6, 4, 5, 6, 2, 3, 6, 5, 1, 6, 4]       # two groups of utterances
+    batches = [to_device(make_batch(B=11, T=24, src_len=src_len, tgt_len=tgt_len, seed=s)) for s in (0, 1)]
     runs = []
     for _ in range(2):
         model = mh.LasModel(params, seed=77)
