@@ -1785,14 +1785,84 @@ __host__ __device__ inline size_t dec_step_bwd_floats(int M, int Tm, int Hd, int
 // = sum_a d(attention)[a] (values W_c)[t'][a]: VW = values W_c [T', A] does not depend on the decoder step -- one product per
 // train step, resident in LDS (row stride A + 1) -- and a step's pass over the utterance's values (400 KB from beyond L2: 21 of
 // the sequential backward's 75 us per step at cfg5) becomes T' x A multiply-adds.
+// dec_seq_bwd_kernel with FOUR workgroups per utterance (PARTS = 4): part 0 walks the chain as before, parts 1..3 take three
+// quarters of the memory frames of the Bahdanau query path off it -- 200 tanh per thread and step on one CU otherwise.
+// Per step part 0 publishes d(scores) of the frames it does not own (xds, {tag, fp32} granules), every part runs the query path
+// over its own frames (d(keys) of those frames in ITS registers, d(attention_v) in its own running sum) and parts 1..3 send
+// their partial d(processed query) back (xdq); part 0 adds them in part order.  tag = U - t (1, 2, ...: the workspace is zeroed
+// at every launch); every wait is bounded (the sticky status word of the workspace reports a timeout).
+struct SeqXchg {
+  pu64* xds;            // [Tm] d(scores) of this utterance and step
+  pu64* xdq;            // [3][Hd] partial d(processed query) of parts 1..3
+  unsigned tag;
+  int* fail;            // LDS
+  int f0, f1;           // this workgroup's frames
+};
+constexpr unsigned SEQ_SPIN_LIMIT = 1u << 22;
+
+// Wave-uniform bounded wait for granule p[i] (threads with have = false ride along); returns its value (0 after a timeout).
+__device__ __forceinline__ float seq_wait(const pu64* p, const bool have, const unsigned tag, int* fail) {
+  unsigned spins = 0;
+  for (;;) {
+    const pu64 g = have ? pgranule_load(p) : ((pu64)tag << 32);
+    if (__all((unsigned)(g >> 32) == tag)) return __uint_as_float((unsigned)g);
+    if (++spins > SEQ_SPIN_LIMIT || *fail) { *fail = 1; return 0.f; }
+    __builtin_amdgcn_s_sleep(1);
+  }
+}
+
+// Bahdanau query path over the frames [f0, flen) of an utterance with d(keys) in registers (see dec_step_bwd_body, NPK > 0):
+// thread (phase, u) takes frames f0 + phase + i P, columns u .. u + 7; the key rows of the NEXT FB passes are requested before
+// this group's tanh work (two register buffers).  a: d(processed query) partial, dv: d(attention_v) partial.
+template <int NPK>
+__device__ __forceinline__ void query_path_regk(const unsigned short* keys, const int Hd, const int f0, const int flen, const float* ds,
+                                                const float* qq, const float* vv, const int phase, const int P, const int u,
+                                                float (&a)[8], float (&dv)[8], float (*dkr)[8]) {
+  constexpr int FB = 4, NG = (NPK + FB - 1) / FB;
+  uint4 kv[2][FB];
+#pragma unroll
+  for (int i = 0; i < FB; ++i) {
+    const int t = f0 + phase + i * P;
+    if (i < NPK && t < flen) kv[0][i] = *reinterpret_cast<const uint4*>(keys + (int64_t)t * Hd + u);
+  }
+#pragma unroll
+  for (int g = 0; g < NG; ++g) {
+    if (g + 1 < NG) {
+#pragma unroll
+      for (int i = 0; i < FB; ++i) {
+        const int t = f0 + phase + ((g + 1) * FB + i) * P;
+        if ((g + 1) * FB + i < NPK && t < flen) kv[(g + 1) & 1][i] = *reinterpret_cast<const uint4*>(keys + (int64_t)t * Hd + u);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < FB; ++i) {
+      const int t = f0 + phase + (g * FB + i) * P;
+      if (g * FB + i < NPK && t < flen) {
+        const unsigned short* e = reinterpret_cast<const unsigned short*>(&kv[g & 1][i]);
+        const float d = ds[t];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float th = las_tanh(las_bf2f(e[j]) + qq[j]);
+          dv[j] += d * th;
+          const float p = d * vv[j] * (1.f - th * th);
+          a[j] += p;
+          dkr[g * FB + i < NPK ? g * FB + i : 0][j] += p;
+        }
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);         // keep later groups' loads from being hoisted over this one (registers)
+  }
+}
+
 // NPK > 0 (dec_seq_bwd_kernel, Bahdanau scores): the utterance's fp32 d(keys) lives in REGISTERS across the steps -- dkr[i][j]
 // is frame phase + i P, column u + j of the thread's fixed (phase, u) -- instead of being read and written in memory at
 // every step (NPK frame passes x 8 columns; the caller adds them into dkeys_acc once, after the last step).
 constexpr int SEQ_NPK = 25;
+constexpr int SEQ_NPK4 = 7;        // ... of a quarter of the frames (four workgroups per utterance)
 template <int NPK = 0>
 __device__ __forceinline__ void dec_step_bwd_body(const las_dec_step_bwd& s, const int b, float* sm, const float* vw = nullptr,
                                                   const float* datt = nullptr, const int A = 0, float (*dkr)[8] = nullptr,
-                                                  const int tid_in = -1, float* acc_run = nullptr) {
+                                                  const int tid_in = -1, float* acc_run = nullptr, const SeqXchg* xc = nullptr) {
   float* dctx = sm;               // [M]
   float* ds = dctx + s.M;         // [Tm] dalign -> dscore
   float* dhs = ds + s.Tm;         // [256/L][Hd] = 2048 floats: per-phase partial d h (score path) / dpq
@@ -1958,6 +2028,7 @@ __device__ __forceinline__ void dec_step_bwd_body(const las_dec_step_bwd& s, con
         v = (t < len) ? dp * p * (1.f - p) : 0.f;
         ds[t] = v;
         if (s.ds_out) s.ds_out[(int64_t)b * s.ldso + t] = las_f2bf(v);
+        if (xc && (t < xc->f0 || t >= xc->f1)) pgranule_store(xc->xds + t, xc->tag, v, false);     // the other parts' frames
       }
       const float dbias = block_reduce(v, red, false);
       if (tid == 0 && s.dbias_acc) { if (acc_run) acc_run[Hd] += dbias; else atomicAdd(s.dbias_acc, dbias); }   // (acc_run: see dec_seq_bwd_kernel)
@@ -2002,6 +2073,7 @@ __device__ __forceinline__ void dec_step_bwd_body(const las_dec_step_bwd& s, con
       ds[t] = v;
       dbias += v;
       if (s.ds_out) s.ds_out[(int64_t)b * s.ldso + t] = las_f2bf(v);
+      if (xc && (t < xc->f0 || t >= xc->f1)) pgranule_store(xc->xds + t, xc->tag, v, false);
     }
     dbias = block_reduce(dbias, red, false);
     if (tid == 0 && s.dbias_acc) { if (acc_run) acc_run[Hd] += dbias; else atomicAdd(s.dbias_acc, dbias); }
@@ -2017,6 +2089,7 @@ __device__ __forceinline__ void dec_step_bwd_body(const las_dec_step_bwd& s, con
     const float v = (t < len) ? align[t] * (ds[t] - dot) : 0.f;
     ds[t] = v;
     if (s.ds_out) s.ds_out[(int64_t)b * s.ldso + t] = las_f2bf(v);
+    if (xc && (t < xc->f0 || t >= xc->f1)) pgranule_store(xc->xds + t, xc->tag, v, false);
   }
   __syncthreads();
   }
@@ -2061,41 +2134,9 @@ __device__ __forceinline__ void dec_step_bwd_body(const las_dec_step_bwd& s, con
       // and step at 512 units)
       constexpr int FB = 4;
       if constexpr (NPK > 0) {
-        // the key rows of the NEXT FB passes are requested before this group's tanh work (two register buffers)
-        constexpr int NG = (NPK + FB - 1) / FB;
-        uint4 kv[2][FB];
-#pragma unroll
-        for (int i = 0; i < FB; ++i) {
-          const int t = phase + i * P;
-          if (i < NPK && t < len) kv[0][i] = *reinterpret_cast<const uint4*>(keys + (int64_t)t * Hd + u);
-        }
-#pragma unroll
-        for (int g = 0; g < NG; ++g) {
-          if (g + 1 < NG) {
-#pragma unroll
-            for (int i = 0; i < FB; ++i) {
-              const int t = phase + ((g + 1) * FB + i) * P;
-              if ((g + 1) * FB + i < NPK && t < len) kv[(g + 1) & 1][i] = *reinterpret_cast<const uint4*>(keys + (int64_t)t * Hd + u);
-            }
-          }
-#pragma unroll
-          for (int i = 0; i < FB; ++i) {
-            const int t = phase + (g * FB + i) * P;
-            if (g * FB + i < NPK && t < len) {
-              const unsigned short* e = reinterpret_cast<const unsigned short*>(&kv[g & 1][i]);
-              const float d = ds[t];
-#pragma unroll
-              for (int j = 0; j < 8; ++j) {
-                const float th = las_tanh(las_bf2f(e[j]) + qq[j]);
-                dv[j] += d * th;
-                const float p = d * vv[j] * (1.f - th * th);
-                a[j] += p;
-                dkr[g * FB + i < NPK ? g * FB + i : 0][j] += p;
-              }
-            }
-          }
-          __builtin_amdgcn_sched_barrier(0);         // keep later groups' loads from being hoisted over this one (registers)
-        }
+        // (with four workgroups per utterance -- xc -- this one's frames only)
+        const int qf0 = xc ? xc->f0 : 0, qflen = xc ? min(len, xc->f1) : len;
+        query_path_regk<NPK>(keys, Hd, qf0, qflen, ds, qq, vv, phase, P, u, a, dv, dkr);
       } else
       for (int tb = phase; tb < len; tb += P * FB) {
         uint4 kv[FB];
@@ -2153,10 +2194,14 @@ __device__ __forceinline__ void dec_step_bwd_body(const las_dec_step_bwd& s, con
   }
   LAS_STAMPB(s.step, 5);
   // reduce the P per-phase partials (dhs is [P][Hd] = 2048 floats)
-  for (int u = tid; u < Hd; u += 256) {
+  for (int u0 = 0; u0 < Hd; u0 += 256) {                // (whole waves: Hd is a multiple of 64)
+    const int u = u0 + tid;
     float acc = 0.f;
-    for (int ph = 0; ph < P; ++ph) acc += dhs[ph * Hd + u];
-    red[8 + u] = acc;
+    if (u < Hd)
+      for (int ph = 0; ph < P; ++ph) acc += dhs[ph * Hd + u];
+    if (xc)                                              // + the other three parts' frames, in part order
+      for (int q = 0; q < 3; ++q) acc += seq_wait(xc->xdq + q * Hd + min(u, Hd - 1), u < Hd, xc->tag, xc->fail);
+    if (u < Hd) red[8 + u] = acc;
   }
   __syncthreads();
   for (int u = tid; u < Hd; u += 256) dhs[u] = red[8 + u];
@@ -2224,13 +2269,93 @@ __global__ __launch_bounds__(256) void dec_step_bwd_kernel(las_dec_step_bwd s) {
 // same operand roundings, same summation order of the two products' K loops is NOT guaranteed -- compared at 1e-3).
 // LDS: the step body's floats, then d(attention) [A], d[query | context] [Hd + M], d(feed) [W0].
 // ------------------------------------------------------------------------------------------------
-template <int NPK, int KC>                      // KC = 4 Hd / 32: the 32-deep chunks of the gate columns (Hd 128: 16, 256: 32)
+// KC = 4 Hd / 32: the 32-deep chunks of the gate columns (Hd 128: 16, 256: 32).  PARTS = 4 (Bahdanau scores, NPK > 0): four
+// workgroups per utterance, blocks in chunks of 8 utterances (block = chunk * 32 + part * 8 + utterance % 8: the four parts of
+// an utterance are 8 blocks apart, i.e. on one XCD under round-robin dispatch); see SeqXchg.
+template <int NPK, int KC, int PARTS = 1>
 __global__ __launch_bounds__(256) void dec_seq_bwd_kernel(las_dec_seq_bwd p) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   const las_dec_step_bwd& s0 = p.s;
-  const int b = blockIdx.x;
+  const int b = PARTS == 1 ? (int)blockIdx.x : (int)(blockIdx.x / 32) * 8 + (int)(blockIdx.x & 7);
+  const int part = PARTS == 1 ? 0 : (int)(blockIdx.x % 32) / 8;
   const int tid0 = threadIdx.x;
   const int Hd = s0.Hd, M = s0.M, A = p.A, W0 = p.W0, feed = p.A > 0 ? p.A : M;
+  // frames of this part, exchange granules of this utterance (PARTS = 4)
+  const int fq = (s0.Tm + PARTS - 1) / PARTS, pf0 = part * fq, pf1 = min(s0.Tm, pf0 + fq);
+  const int ldx = (s0.Tm + 3 * Hd + 15) & ~15;
+  pu64* const xbase = PARTS > 1 ? reinterpret_cast<pu64*>(static_cast<char*>(p.xchg_workspace) + 64) + (int64_t)min(b, s0.B - 1) * ldx : nullptr;
+  if constexpr (PARTS > 1) {
+    if (b >= s0.B || part > 0) {
+      // ---- an absent utterance's workgroups only take their place in the fixed-order sums; parts 1..3 run the query path of
+      //      their frames: wait for d(scores), tanh work with d(keys) in registers, partial d(processed query) back ----
+      float* ds_l = sm;                                   // [Tm] (indexed by frame)
+      float* dhs = sm + ((s0.Tm + 3) & ~3);               // [P][Hd] partial d(processed query), then [P][Hd] partial d(attention_v)
+      float* run = dhs + 4096;                            // [Hd + 8]: running d(attention_v) of this part; [Hd + 4]: flag word
+      int* fail = reinterpret_cast<int*>(run + Hd + 5);
+      for (int n = tid0; n < Hd + 8; n += 256) run[n] = 0.f;
+      __syncthreads();
+      if (b < s0.B) {
+        float dkr[NPK > 0 ? NPK : 1][8];
+#pragma unroll
+        for (int i = 0; i < (NPK > 0 ? NPK : 1); ++i)
+#pragma unroll
+          for (int j = 0; j < 8; ++j) dkr[i][j] = 0.f;
+        const int L = Hd / 8, P = 256 / L, phase = tid0 / L, u = (tid0 % L) * 8;
+        const int len = min(s0.mem_len[b], s0.Tm), flen = min(len, pf1);
+        const unsigned short* keys = s0.keys + (int64_t)b * s0.Tm * Hd;
+        float vv[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) vv[j] = s0.att_v[u + j];
+        for (int t = p.U - 1; t >= 0; --t) {
+          const unsigned tag = (unsigned)(p.U - t);
+          const float* pqv = s0.pq + (int64_t)b * s0.ldpq + (int64_t)t * p.inc_pq;
+          float qq[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) qq[j] = pqv[u + j];
+          for (int f = pf0; f < pf1; f += 256) {
+            const float v = seq_wait(xbase + min(f + tid0, pf1 - 1), f + tid0 < pf1, tag, fail);
+            if (f + tid0 < pf1) ds_l[f + tid0] = v;
+          }
+          __syncthreads();
+          float a[8], dv[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) a[j] = dv[j] = 0.f;
+          if constexpr (NPK > 0) query_path_regk<NPK>(keys, Hd, pf0, flen, ds_l, qq, vv, phase, P, u, a, dv, dkr);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) { dhs[phase * Hd + u + j] = a[j]; dhs[2048 + phase * Hd + u + j] = dv[j]; }
+          __syncthreads();
+          for (int c = tid0; c < Hd; c += 256) {
+            float sa = 0.f, sv = 0.f;
+            for (int ph = 0; ph < P; ++ph) { sa += dhs[ph * Hd + c]; sv += dhs[2048 + ph * Hd + c]; }
+            pgranule_store(xbase + s0.Tm + (part - 1) * Hd + c, tag, sa, false);
+            run[c] += sv;
+          }
+          __syncthreads();
+        }
+        if constexpr (NPK > 0) {
+#pragma unroll
+          for (int i = 0; i < NPK; ++i) {
+            const int tt = pf0 + phase + i * P;
+            if (tt < pf1) {
+              float4* dk = reinterpret_cast<float4*>(s0.dkeys_acc + ((int64_t)b * s0.Tm + tt) * Hd + u);
+              float4 a0 = dk[0], a1 = dk[1];
+              a0.x += dkr[i][0]; a0.y += dkr[i][1]; a0.z += dkr[i][2]; a0.w += dkr[i][3];
+              a1.x += dkr[i][4]; a1.y += dkr[i][5]; a1.z += dkr[i][6]; a1.w += dkr[i][7];
+              dk[0] = a0;
+              dk[1] = a1;
+            }
+          }
+        }
+        if (*fail && tid0 == 0) atomicOr(static_cast<unsigned*>(p.xchg_workspace), 32u);
+      }
+      if (p.sum_workspace && (s0.dv_acc || s0.dbias_acc)) {
+        __syncthreads();
+        ordered_accumulate(static_cast<unsigned*>(p.sum_workspace), blockIdx.x, gridDim.x, Hd + 1, run, s0.dv_acc, Hd, s0.dbias_acc,
+                           reinterpret_cast<int*>(run + Hd + 4));
+      }
+      return;
+    }
+  }
   float* datt = sm + dec_step_bwd_floats(M, s0.Tm, Hd, s0.norm);      // [A] (bf16-rounded values)
   float* dqc = datt + (A > 0 ? A : 0);                                 // [Hd + M]
   float* dfeed = dqc + (A > 0 ? Hd + M : 0);                           // [W0] d[feed | h]_{t} from step t+1
@@ -2349,7 +2474,12 @@ __global__ __launch_bounds__(256) void dec_seq_bwd_kernel(las_dec_seq_bwd p) {
       st.dh_b = st.dh_c = nullptr;
       st.dh_rec = has_next ? dfeed + feed : nullptr;   st.ldr = 0;
     }
-    dec_step_bwd_body<NPK>(st, b, sm, use_vw ? vwl : nullptr, datt, A, dkr, tid, p.sum_workspace ? acc_run : nullptr);
+    if constexpr (PARTS > 1) {
+      const SeqXchg xc{xbase, xbase + s0.Tm, (unsigned)(p.U - t), reinterpret_cast<int*>(acc_run + Hd + 5), pf0, pf1};
+      dec_step_bwd_body<NPK>(st, b, sm, use_vw ? vwl : nullptr, datt, A, dkr, tid, p.sum_workspace ? acc_run : nullptr, &xc);
+    } else {
+      dec_step_bwd_body<NPK>(st, b, sm, use_vw ? vwl : nullptr, datt, A, dkr, tid, p.sum_workspace ? acc_run : nullptr);
+    }
     __syncthreads();                               // dz_t of this utterance is in memory (same workgroup: visible behind the barrier)
     LAS_STAMPB(t, 8);
     if (t > 0 || p.dfeed_out) {
@@ -2395,16 +2525,17 @@ __global__ __launch_bounds__(256) void dec_seq_bwd_kernel(las_dec_seq_bwd p) {
   if (p.sum_workspace && (s0.dv_acc || s0.dbias_acc)) {
     // d(attention_v) / d(score_bias): the utterances' sums over the steps meet in utterance order (ordered_accumulate)
     __syncthreads();
-    ordered_accumulate(static_cast<unsigned*>(p.sum_workspace), b, gridDim.x, Hd + 1, acc_run, s0.dv_acc, Hd, s0.dbias_acc,
+    ordered_accumulate(static_cast<unsigned*>(p.sum_workspace), blockIdx.x, gridDim.x, Hd + 1, acc_run, s0.dv_acc, Hd, s0.dbias_acc,
                        reinterpret_cast<int*>(acc_run + Hd + 4));
   }
+  if (PARTS > 1 && tid0 == 0 && *reinterpret_cast<int*>(acc_run + Hd + 5)) atomicOr(static_cast<unsigned*>(p.xchg_workspace), 32u);
   if constexpr (NPK > 0) {
     // the register-resident d(keys) joins the accumulator once (same thread layout as the body's query path)
     const int L = Hd / 8, P = 256 / L, phase = tid0 / L, u = (tid0 % L) * 8;
 #pragma unroll
     for (int i = 0; i < NPK; ++i) {
-      const int tt = phase + i * P;
-      if (tt < s0.Tm) {
+      const int tt = pf0 + phase + i * P;
+      if (tt < pf1) {
         float4* dk = reinterpret_cast<float4*>(s0.dkeys_acc + ((int64_t)b * s0.Tm + tt) * Hd + u);
         float4 a0 = dk[0], a1 = dk[1];
         a0.x += dkr[i][0]; a0.y += dkr[i][1]; a0.z += dkr[i][2]; a0.w += dkr[i][3];
@@ -3619,6 +3750,10 @@ extern "C" int las_decoder_persist_bwd(const las_dec_persist_bwd* p, void* strea
   return LAS_OK;
 }
 
+extern "C" size_t las_decoder_seq_xchg_bytes(int B, int Tm, int Hd) {
+  return B > 0 && Tm > 0 && Hd > 0 ? 64 + (size_t)B * ((Tm + 3 * Hd + 15) & ~15) * sizeof(pu64) : 0;
+}
+
 extern "C" size_t las_decoder_sum_workspace_bytes(int blocks, int n) {
   return blocks > 0 && n > 0 ? 64 + (size_t)blocks * n * sizeof(float) : 0;
 }
@@ -3658,6 +3793,8 @@ extern "C" int las_decoder_seq_bwd(const las_dec_seq_bwd* p, void* stream) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dec_seq_bwd_kernel<0, 32>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dec_seq_bwd_kernel<SEQ_NPK, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dec_seq_bwd_kernel<SEQ_NPK, 32>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dec_seq_bwd_kernel<SEQ_NPK4, 16, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dec_seq_bwd_kernel<SEQ_NPK4, 32, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr = true;
   }
   // Bahdanau scores: d(keys) in registers when the utterance's frames fit SEQ_NPK passes of the 256 / (Hd / 8) frame phases
@@ -3665,10 +3802,25 @@ extern "C" int las_decoder_seq_bwd(const las_dec_seq_bwd* p, void* stream) {
   static const bool regk_on = [] { const char* e = getenv("LAS_DEC_SEQ_REGK"); return !(e && e[0] == '0'); }();
   const int P = 256 / (s->Hd / 8);
   const bool regk = additive && regk_on && q.A > 0 && q.vw && (s->Tm + P - 1) / P <= SEQ_NPK;
+  // ... and four workgroups per utterance (the caller hands in the exchange workspace) when every one of them finds a CU of its
+  // own -- they wait for one another -- and a quarter of the frames fits SEQ_NPK4 passes
+  static const int cus = [] { int dev = 0, n = 0; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return n; }();
+  const int blocks4 = (s->B + 7) / 8 * 32, fq = (s->Tm + 3) / 4;
+  const bool parts4 = regk && q.xchg_workspace && blocks4 <= cus && (fq + P - 1) / P <= SEQ_NPK4 && s->dv_acc && q.sum_workspace;
 #define LAS_SEQ_LAUNCH(NPK_, KC_) hipLaunchKernelGGL((dec_seq_bwd_kernel<NPK_, KC_>), dim3(s->B), dim3(256), lds, (hipStream_t)stream, q)
-  if (s->Hd == 128) { if (regk) LAS_SEQ_LAUNCH(SEQ_NPK, 16); else LAS_SEQ_LAUNCH(0, 16); }
-  else              { if (regk) LAS_SEQ_LAUNCH(SEQ_NPK, 32); else LAS_SEQ_LAUNCH(0, 32); }
+#define LAS_SEQ_LAUNCH4(KC_) hipLaunchKernelGGL((dec_seq_bwd_kernel<SEQ_NPK4, KC_, 4>), dim3(blocks4), dim3(256), lds, (hipStream_t)stream, q)
+  if (parts4) {
+    int rc = las_check_hip(hipMemsetAsync(static_cast<char*>(q.xchg_workspace) + 64, 0, las_decoder_seq_xchg_bytes(s->B, s->Tm, s->Hd) - 64, (hipStream_t)stream),
+                           "memset exchange workspace");
+    if (rc) return rc;
+    if (s->Hd == 128) LAS_SEQ_LAUNCH4(16); else LAS_SEQ_LAUNCH4(32);
+  } else {
+    q.xchg_workspace = nullptr;
+    if (s->Hd == 128) { if (regk) LAS_SEQ_LAUNCH(SEQ_NPK, 16); else LAS_SEQ_LAUNCH(0, 16); }
+    else              { if (regk) LAS_SEQ_LAUNCH(SEQ_NPK, 32); else LAS_SEQ_LAUNCH(0, 32); }
+  }
 #undef LAS_SEQ_LAUNCH
+#undef LAS_SEQ_LAUNCH4
   LAS_LAUNCH_CHECK("sequential decoder bwd launch");
   return LAS_OK;
 }

@@ -44,6 +44,7 @@ _SIGS = {
     'las_decoder_step_bwd': ([_vp, _vp], C.c_int),
     'las_decoder_seq_bwd_supported': ([_i32] * 7, C.c_int),
     'las_decoder_sum_workspace_bytes': ([_i32, _i32], C.c_size_t),
+    'las_decoder_seq_xchg_bytes': ([_i32, _i32, _i32], C.c_size_t),
     'las_decoder_seq_bwd': ([_vp, _vp], C.c_int),
     'las_seq_ce_loss': ([_vp, _i64, _vp, _vp, _i32, _i32, _i32, _f32, _vp, _vp, _i64, _vp], C.c_int),
     'las_seq_sigmoid_loss': ([_vp, _i64, _vp, _i64, _vp, _i32, _i32, _i32, _f32, _vp, _vp, _i64, _vp], C.c_int),
@@ -149,7 +150,7 @@ class DecSeqBwd(C.Structure):
     _fields_ = [('s', DecStepBwd), ('U', _i32), ('A', _i32), ('W0', _i32), ('reserved', _i32)] + [(n, _i64) for n in (
         'inc_gates', 'inc_c', 'inc_align', 'inc_dz', 'inc_ds', 'inc_save', 'inc_pq')] + [
         ('d_out', _vp), ('ld_dout', _i64), ('inc_dout', _i64), ('datt_out', _vp), ('ld_datt', _i64), ('waln_packed', _vp), ('reserved1', _i64),
-        ('kn_packed', _vp), ('reserved2', _i64), ('dfeed_out', _vp), ('vw', _vp), ('ld_vw', _i64), ('sum_workspace', _vp)]
+        ('kn_packed', _vp), ('reserved2', _i64), ('dfeed_out', _vp), ('vw', _vp), ('ld_vw', _i64), ('sum_workspace', _vp), ('xchg_workspace', _vp)]
 
 
 class DecPersistBwd(C.Structure):
