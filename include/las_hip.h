@@ -483,14 +483,14 @@ typedef struct las_dec_seq_bwd {
    * zero): d(attention_v) [Hd] and d(attention_score_bias) are summed over the steps in the utterance's workgroup and over the
    * utterances in a fixed order, instead of one fp32 atomic per step and utterance */
   void* sum_workspace;
-  /* optional (Bahdanau scores, with vw and sum_workspace): las_decoder_seq_xchg_bytes(B, Tm, Hd) bytes, zero before the first
+  /* optional (Bahdanau scores, with vw and sum_workspace): las_decoder_seq_xchg_bytes(B, Tm, Hd, M, W0) bytes, zero before the first
    * use.  The launch then runs FOUR workgroups per utterance when 32 * ceil(B / 8) of them find a CU each: three take three
-   * quarters of the frames of the query path (tanh recompute, d(keys)) off the one that walks the chain, exchanging d(scores)
-   * and partial d(processed query) through this workspace at every step; sum_workspace must then hold 32 * ceil(B / 8) rows.  Its
+   * quarters of the frames of the query path (tanh recompute, d(keys)) and of the tiles of the two matrix-vector products off
+   * the one that walks the chain, exchanging their operands and results through this workspace at every step (A <= 128); sum_workspace must then hold 32 * ceil(B / 8) rows.  Its
    * first 64 bytes are a STICKY status word (bit 5: a bounded wait timed out, results invalid) like the other one-launch kernels'. */
   void* xchg_workspace;
 } las_dec_seq_bwd;
-size_t las_decoder_seq_xchg_bytes(int B, int Tm, int Hd);
+size_t las_decoder_seq_xchg_bytes(int B, int Tm, int Hd, int M, int W0);
 /* bytes of the fixed-order sum workspace of the one-launch backward decoders: a counter line + `blocks` rows of n floats */
 size_t las_decoder_sum_workspace_bytes(int blocks, int n);
 int las_decoder_seq_bwd_supported(int Hd, int M, int A, int W0, int Tm, int attention, int norm);

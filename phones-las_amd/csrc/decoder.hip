@@ -1797,6 +1797,7 @@ struct SeqXchg {
   unsigned tag;
   int* fail;            // LDS
   int f0, f1;           // this workgroup's frames
+  bool local;           // the four parts share an XCD (its L2 is the point of coherence: plain stores)
 };
 constexpr unsigned SEQ_SPIN_LIMIT = 1u << 22;
 
@@ -1901,8 +1902,18 @@ __device__ __forceinline__ void dec_step_bwd_body(const las_dec_step_bwd& s, con
     for (int t = tid; t < Tm; t += 256) {
       float acc = 0.f;
       if (t < len) {
+        // (A is a multiple of 8; eight LDS reads of the row in flight and two running sums: the rolled loop waited for every
+        //  pair of reads -- 3.6 us per step for 80 multiply-adds per thread)
         const float* row = vw + (int64_t)t * (A + 1);
-        for (int a = 0; a < A; ++a) acc += row[a] * datt[a];
+        float acc1 = 0.f;
+        for (int a = 0; a < A; a += 8) {
+          float r[8], d[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) { r[j] = row[a + j]; d[j] = datt[a + j]; }
+          acc += r[0] * d[0] + r[2] * d[2] + r[4] * d[4] + r[6] * d[6];
+          acc1 += r[1] * d[1] + r[3] * d[3] + r[5] * d[5] + r[7] * d[7];
+        }
+        acc += acc1;
       }
       ds[t] = acc;
     }
@@ -2028,7 +2039,7 @@ __device__ __forceinline__ void dec_step_bwd_body(const las_dec_step_bwd& s, con
         v = (t < len) ? dp * p * (1.f - p) : 0.f;
         ds[t] = v;
         if (s.ds_out) s.ds_out[(int64_t)b * s.ldso + t] = las_f2bf(v);
-        if (xc && (t < xc->f0 || t >= xc->f1)) pgranule_store(xc->xds + t, xc->tag, v, false);     // the other parts' frames
+        if (xc && (t < xc->f0 || t >= xc->f1)) pgranule_store(xc->xds + t, xc->tag, v, xc->local);     // the other parts' frames
       }
       const float dbias = block_reduce(v, red, false);
       if (tid == 0 && s.dbias_acc) { if (acc_run) acc_run[Hd] += dbias; else atomicAdd(s.dbias_acc, dbias); }   // (acc_run: see dec_seq_bwd_kernel)
@@ -2073,7 +2084,7 @@ __device__ __forceinline__ void dec_step_bwd_body(const las_dec_step_bwd& s, con
       ds[t] = v;
       dbias += v;
       if (s.ds_out) s.ds_out[(int64_t)b * s.ldso + t] = las_f2bf(v);
-      if (xc && (t < xc->f0 || t >= xc->f1)) pgranule_store(xc->xds + t, xc->tag, v, false);
+      if (xc && (t < xc->f0 || t >= xc->f1)) pgranule_store(xc->xds + t, xc->tag, v, xc->local);
     }
     dbias = block_reduce(dbias, red, false);
     if (tid == 0 && s.dbias_acc) { if (acc_run) acc_run[Hd] += dbias; else atomicAdd(s.dbias_acc, dbias); }
@@ -2089,7 +2100,7 @@ __device__ __forceinline__ void dec_step_bwd_body(const las_dec_step_bwd& s, con
     const float v = (t < len) ? align[t] * (ds[t] - dot) : 0.f;
     ds[t] = v;
     if (s.ds_out) s.ds_out[(int64_t)b * s.ldso + t] = las_f2bf(v);
-    if (xc && (t < xc->f0 || t >= xc->f1)) pgranule_store(xc->xds + t, xc->tag, v, false);
+    if (xc && (t < xc->f0 || t >= xc->f1)) pgranule_store(xc->xds + t, xc->tag, v, xc->local);
   }
   __syncthreads();
   }
@@ -2269,6 +2280,100 @@ __global__ __launch_bounds__(256) void dec_step_bwd_kernel(las_dec_step_bwd s) {
 // same operand roundings, same summation order of the two products' K loops is NOT guaranteed -- compared at 1e-3).
 // LDS: the step body's floats, then d(attention) [A], d[query | context] [Hd + M], d(feed) [W0].
 // ------------------------------------------------------------------------------------------------
+// Exchange rows of one utterance (PARTS = 4), in granules: d(scores) [Tm], partial d(processed query) [3][Hd], d(attention_t) as
+// bf16 pairs [64], d[query | context] [Hd + M], dz_t as bf16 pairs [2 Hd], d[feed | h] [W0], XCC ids [4]
+struct SeqXLayout { int xdq, xda, xqc, xdz, xdf, xcc, total; };
+__host__ __device__ inline SeqXLayout seq_xlayout(int Tm, int Hd, int M, int W0) {
+  SeqXLayout L;
+  L.xdq = Tm;
+  L.xda = L.xdq + 3 * Hd;
+  L.xqc = L.xda + 64;
+  L.xdz = L.xqc + Hd + M;
+  L.xdf = L.xdz + 2 * Hd;
+  L.xcc = L.xdf + ((W0 + 15) & ~15);                   // [4] {1, XCC id + 1} of the four parts (are they on one XCD?)
+  L.total = (L.xcc + 4 + 15) & ~15;
+  return L;
+}
+
+// out(n, value) for the columns n of the 16-column tiles vwave, vwave + nvw, ... of y = a W^T, W as a LAS_IMAGE_PACK_MFMA_B image
+// with KCa 32-deep chunks, a (bf16, row 0 of the A tile) in LDS at a_lds with 8 zeros at zeros: TB tiles per pass, one pass and
+// chunk = TB loads in flight, the next (pass, chunk)'s requested before this one's products.  (d[query | context] = d(attention) W_al^T)
+template <typename OUT>
+__device__ __forceinline__ void seq_matvec_few_chunks(const unsigned short* packed, const int KCa, const int NT, const unsigned short* a_lds,
+                                                      const unsigned short* zeros, const int lane, const int vwave, const int nvw, OUT out) {
+  constexpr int TB = 10;
+  const int l15 = lane & 15, lq = lane >> 4;
+  const unsigned short* azp = l15 == 0 ? a_lds + 8 * lq : zeros;
+  const int azs = l15 == 0 ? 32 : 0;
+  const int mine = vwave < NT ? (NT - vwave + nvw - 1) / nvw : 0;       // tiles of this (virtual) wave
+  const int NB = (mine + TB - 1) / TB, Q = NB * KCa;
+  if (Q == 0) return;
+  uint4 cur[TB], nxt[TB];
+  f32x4 acc[TB];
+  auto frag = [&](int q, int i) {
+    const int bi = q / KCa, kc = q - bi * KCa;
+    const int nt = min(vwave + nvw * (bi * TB + i), NT - 1);
+    return packed + (((int64_t)nt * KCa + kc) * 64 + lane) * 8;
+  };
+#pragma unroll
+  for (int i = 0; i < TB; ++i) cur[i] = ld16(frag(0, i));
+#pragma unroll 1
+  for (int q = 0; q < Q; ++q) {
+    const int bi = q / KCa, kc = q - bi * KCa;
+    if (q + 1 < Q) {
+#pragma unroll
+      for (int i = 0; i < TB; ++i) nxt[i] = ld16(frag(q + 1, i));
+    }
+    const uint4 av = *reinterpret_cast<const uint4*>(azp + kc * azs);
+    if (kc == 0) {
+#pragma unroll
+      for (int i = 0; i < TB; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int i = 0; i < TB; ++i)
+      acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, av), __builtin_bit_cast(bf16x8, cur[i]), acc[i], 0, 0, 0);
+    if (kc == KCa - 1) {
+#pragma unroll
+      for (int i = 0; i < TB; ++i) {
+        const int nt = vwave + nvw * (bi * TB + i);
+        if (lq == 0 && nt < NT) out(nt * 16 + l15, acc[i][0]);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < TB; ++i) cur[i] = nxt[i];
+  }
+}
+
+// The same for a deep product (KC chunks, compile-time): a tile's 16 fragments of half its chunks in flight at once, the A
+// fragments read from LDS beside them.  (d[feed | h]_t = dz_t K^T)
+template <int KC, typename OUT>
+__device__ __forceinline__ void seq_matvec_deep(const unsigned short* packed, const int NT, const unsigned short* a_lds, const unsigned short* zeros,
+                                                const int lane, const int vwave, const int nvw, OUT out) {
+  const int l15 = lane & 15, lq = lane >> 4;
+  const unsigned short* azp = l15 == 0 ? a_lds + 8 * lq : zeros;
+  const int azs = l15 == 0 ? 32 : 0;
+  for (int nt = vwave; nt < NT; nt += nvw) {
+    const unsigned short* kfr = packed + ((int64_t)nt * KC * 64 + lane) * 8;     // fragment (nt, kc): + kc * 512
+    f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k0 = 0; k0 < KC; k0 += 16) {
+      uint4 bv[16];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) bv[i] = ld16(kfr + (k0 + i) * 512);
+      uint4 av[16];                              // (the LDS reads overlap the loads' round trip)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) av[i] = *reinterpret_cast<const uint4*>(azp + (k0 + i) * azs);
+#pragma unroll
+      for (int i = 0; i < 16; ++i)
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, av[i]), __builtin_bit_cast(bf16x8, bv[i]), acc, 0, 0, 0);
+    }
+    if (lq == 0) out(nt * 16 + l15, acc[0]);
+  }
+}
+
+// part that owns column n of such a product split over 4 x 4 virtual waves (tile n / 16 belongs to virtual wave (n / 16) % 16)
+__device__ __forceinline__ int seq_owner(int n) { return ((n >> 4) & 15) >> 2; }
+
 // KC = 4 Hd / 32: the 32-deep chunks of the gate columns (Hd 128: 16, 256: 32).  PARTS = 4 (Bahdanau scores, NPK > 0): four
 // workgroups per utterance, blocks in chunks of 8 utterances (block = chunk * 32 + part * 8 + utterance % 8: the four parts of
 // an utterance are 8 blocks apart, i.e. on one XCD under round-robin dispatch); see SeqXchg.
@@ -2282,9 +2387,35 @@ __global__ __launch_bounds__(256) void dec_seq_bwd_kernel(las_dec_seq_bwd p) {
   const int Hd = s0.Hd, M = s0.M, A = p.A, W0 = p.W0, feed = p.A > 0 ? p.A : M;
   // frames of this part, exchange granules of this utterance (PARTS = 4)
   const int fq = (s0.Tm + PARTS - 1) / PARTS, pf0 = part * fq, pf1 = min(s0.Tm, pf0 + fq);
-  const int ldx = (s0.Tm + 3 * Hd + 15) & ~15;
-  pu64* const xbase = PARTS > 1 ? reinterpret_cast<pu64*>(static_cast<char*>(p.xchg_workspace) + 64) + (int64_t)min(b, s0.B - 1) * ldx : nullptr;
+  const SeqXLayout XL = seq_xlayout(s0.Tm, Hd, M, W0);
+  pu64* const xbase = PARTS > 1 ? reinterpret_cast<pu64*>(static_cast<char*>(p.xchg_workspace) + 64) + (int64_t)min(b, s0.B - 1) * XL.total : nullptr;
+  bool xlocal = false;
   if constexpr (PARTS > 1) {
+    if (b < s0.B) {
+      // are the four parts on one XCD?  (decides the flavour of the granule stores only)
+      int* lw = reinterpret_cast<int*>(sm);
+      if (tid0 == 0) {
+        unsigned xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        xcc &= 0xf;
+        __hip_atomic_store(xbase + XL.xcc + part, ((pu64)1 << 32) | (xcc + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        bool same = true;
+        for (int m = 0; m < 4; ++m) {
+          pu64 v = 0;
+          unsigned spins = 0;
+          do {
+            v = __hip_atomic_load(xbase + XL.xcc + m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if ((v >> 32) == 1) break;
+            __builtin_amdgcn_s_sleep(2);
+          } while (++spins < SEQ_SPIN_LIMIT);
+          same = same && ((v >> 32) == 1) && ((unsigned)v == xcc + 1);
+        }
+        *lw = same ? 1 : 0;
+      }
+      __syncthreads();
+      xlocal = *lw != 0;
+      __syncthreads();
+    }
     if (b >= s0.B || part > 0) {
       // ---- an absent utterance's workgroups only take their place in the fixed-order sums; parts 1..3 run the query path of
       //      their frames: wait for d(scores), tanh work with d(keys) in registers, partial d(processed query) back ----
@@ -2292,7 +2423,9 @@ __global__ __launch_bounds__(256) void dec_seq_bwd_kernel(las_dec_seq_bwd p) {
       float* dhs = sm + ((s0.Tm + 3) & ~3);               // [P][Hd] partial d(processed query), then [P][Hd] partial d(attention_v)
       float* run = dhs + 4096;                            // [Hd + 8]: running d(attention_v) of this part; [Hd + 4]: flag word
       int* fail = reinterpret_cast<int*>(run + Hd + 5);
+      unsigned short* opl = reinterpret_cast<unsigned short*>(run + Hd + 8);      // [4 Hd] bf16 operand row (d(attention_t), then dz_t) + 8 zeros
       for (int n = tid0; n < Hd + 8; n += 256) run[n] = 0.f;
+      if (tid0 < 4) reinterpret_cast<unsigned*>(opl + 4 * Hd)[tid0] = 0u;
       __syncthreads();
       if (b < s0.B) {
         float dkr[NPK > 0 ? NPK : 1][8];
@@ -2306,8 +2439,18 @@ __global__ __launch_bounds__(256) void dec_seq_bwd_kernel(las_dec_seq_bwd p) {
         float vv[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) vv[j] = s0.att_v[u + j];
+        const int hl = tid0 & 63, hvw = part * 4 + __builtin_amdgcn_readfirstlane(tid0 >> 6);      // lane, virtual wave of the products
         for (int t = p.U - 1; t >= 0; --t) {
           const unsigned tag = (unsigned)(p.U - t);
+          {
+            // this part's quarter of d[query | context] = d(attention_t) W_al^T
+            const float v = seq_wait(xbase + XL.xda + min(tid0, A / 2 - 1), tid0 < A / 2, tag, fail);
+            if (tid0 < A / 2) reinterpret_cast<unsigned*>(opl)[tid0] = __float_as_uint(v);
+            for (int a = A + tid0; a < ((A + 31) & ~31); a += 256) opl[a] = 0;
+            __syncthreads();
+            seq_matvec_few_chunks(p.waln_packed, (A + 31) / 32, (Hd + M) / 16, opl, opl + 4 * Hd, hl, hvw, 16,
+                                  [&](int n, float v2) { pgranule_store(xbase + XL.xqc + n, tag, v2, xlocal); });
+          }
           const float* pqv = s0.pq + (int64_t)b * s0.ldpq + (int64_t)t * p.inc_pq;
           float qq[8];
 #pragma unroll
@@ -2327,10 +2470,19 @@ __global__ __launch_bounds__(256) void dec_seq_bwd_kernel(las_dec_seq_bwd p) {
           for (int c = tid0; c < Hd; c += 256) {
             float sa = 0.f, sv = 0.f;
             for (int ph = 0; ph < P; ++ph) { sa += dhs[ph * Hd + c]; sv += dhs[2048 + ph * Hd + c]; }
-            pgranule_store(xbase + s0.Tm + (part - 1) * Hd + c, tag, sa, false);
+            pgranule_store(xbase + XL.xdq + (part - 1) * Hd + c, tag, sa, xlocal);
             run[c] += sv;
           }
           __syncthreads();
+          if (t > 0 || p.dfeed_out) {
+            // this part's quarter of d[feed | h]_t = dz_t K^T
+            for (int i = tid0; i < 2 * Hd; i += 256)
+              reinterpret_cast<unsigned*>(opl)[i] = __float_as_uint(seq_wait(xbase + XL.xdz + i, true, tag, fail));
+            __syncthreads();
+            seq_matvec_deep<KC>(p.kn_packed, (W0 + 15) / 16, opl, opl + 4 * Hd, hl, hvw, 16,
+                                [&](int n, float v2) { if (n < W0) pgranule_store(xbase + XL.xdf + n, tag, v2, xlocal); });
+            __syncthreads();
+          }
         }
         if constexpr (NPK > 0) {
 #pragma unroll
@@ -2414,50 +2566,21 @@ __global__ __launch_bounds__(256) void dec_seq_bwd_kernel(las_dec_seq_bwd p) {
       }
       for (int a = A + tid; a < ((A + 31) & ~31); a += 256) dzl[a] = 0;
       __syncthreads();
-      // d[query | context][n] = sum_a d(attention)[a] W_al[n][a] on the matrix cores: d(attention) is row 0 of the A tile (bf16
-      // in LDS, zero padded to the 32-deep chunks), W_al's B-fragment image gives every 16-column tile of a chunk as one KB.
-      // A wave owns the tiles wave, wave + 4, ...; TB of them per pass, one pass and chunk = TB loads in flight, the next
-      // (pass, chunk)'s requested before this one's products.
-      {
-        constexpr int TB = 10;
-        const int KCa = (A + 31) / 32, NTQ = (Hd + M) / 16;
-        const int l15 = lane & 15, lq = lane >> 4;
-        const unsigned short* azp = l15 == 0 ? dzl + 8 * lq : dzl + 4 * Hd;
-        const int azs = l15 == 0 ? 32 : 0;
-        const int NB = ((NTQ - wave + 3) / 4 + TB - 1) / TB, Q = NB * KCa;
-        uint4 cur[TB], nxt[TB];
-        f32x4 acc[TB];
-        auto frag = [&](int q, int i) {
-          const int bi = q / KCa, kc = q - bi * KCa;
-          const int nt = min(wave + 4 * (bi * TB + i), NTQ - 1);
-          return p.waln_packed + (((int64_t)nt * KCa + kc) * 64 + lane) * 8;
-        };
-#pragma unroll
-        for (int i = 0; i < TB; ++i) cur[i] = ld16(frag(0, i));
-#pragma unroll 1
-        for (int q = 0; q < Q; ++q) {
-          const int bi = q / KCa, kc = q - bi * KCa;
-          if (q + 1 < Q) {
-#pragma unroll
-            for (int i = 0; i < TB; ++i) nxt[i] = ld16(frag(q + 1, i));
-          }
-          const uint4 av = *reinterpret_cast<const uint4*>(azp + kc * azs);
-          if (kc == 0) {
-#pragma unroll
-            for (int i = 0; i < TB; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-          }
-#pragma unroll
-          for (int i = 0; i < TB; ++i)
-            acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, av), __builtin_bit_cast(bf16x8, cur[i]), acc[i], 0, 0, 0);
-          if (kc == KCa - 1) {
-#pragma unroll
-            for (int i = 0; i < TB; ++i) {
-              const int nt = wave + 4 * (bi * TB + i);
-              if (lq == 0 && nt < NTQ) dqc[nt * 16 + l15] = acc[i][0];
-            }
-          }
-#pragma unroll
-          for (int i = 0; i < TB; ++i) cur[i] = nxt[i];
+      // d[query | context][n] = sum_a d(attention)[a] W_al[n][a] on the matrix cores (seq_matvec_few_chunks); with four workgroups
+      // per utterance d(attention_t) goes out to the other three first, this one takes the tiles of virtual waves 0..3 and
+      // collects the rest
+      if constexpr (PARTS > 1) {
+        if (tid < A / 2) pgranule_store(xbase + XL.xda + tid, (unsigned)(p.U - t), __uint_as_float(reinterpret_cast<const unsigned*>(dzl)[tid]), xlocal);
+      }
+      seq_matvec_few_chunks(p.waln_packed, (A + 31) / 32, (Hd + M) / 16, dzl, dzl + 4 * Hd, lane, wave, 4 * PARTS,
+                            [&](int n, float v) { dqc[n] = v; });
+      if constexpr (PARTS > 1) {
+        int* fl = reinterpret_cast<int*>(acc_run + Hd + 5);
+        for (int n0 = 0; n0 < Hd + M; n0 += 256) {
+          const int n = n0 + tid;
+          const bool have = n < Hd + M && seq_owner(n) != 0;
+          const float v = seq_wait(xbase + XL.xqc + min(n, Hd + M - 1), have, (unsigned)(p.U - t), fl);
+          if (have) dqc[n] = v;
         }
       }
       __syncthreads();
@@ -2475,7 +2598,7 @@ __global__ __launch_bounds__(256) void dec_seq_bwd_kernel(las_dec_seq_bwd p) {
       st.dh_rec = has_next ? dfeed + feed : nullptr;   st.ldr = 0;
     }
     if constexpr (PARTS > 1) {
-      const SeqXchg xc{xbase, xbase + s0.Tm, (unsigned)(p.U - t), reinterpret_cast<int*>(acc_run + Hd + 5), pf0, pf1};
+      const SeqXchg xc{xbase, xbase + XL.xdq, (unsigned)(p.U - t), reinterpret_cast<int*>(acc_run + Hd + 5), pf0, pf1, xlocal};
       dec_step_bwd_body<NPK>(st, b, sm, use_vw ? vwl : nullptr, datt, A, dkr, tid, p.sum_workspace ? acc_run : nullptr, &xc);
     } else {
       dec_step_bwd_body<NPK>(st, b, sm, use_vw ? vwl : nullptr, datt, A, dkr, tid, p.sum_workspace ? acc_run : nullptr);
@@ -2490,32 +2613,24 @@ __global__ __launch_bounds__(256) void dec_seq_bwd_kernel(las_dec_seq_bwd p) {
       // dz_t goes through LDS (2 KB): the A fragments are read from there at every product -- held in registers across the
       // tiles they cost 128 VGPRs, which the register-resident d(keys) needs.  Lanes of rows 1..15 read the zeros behind it.
       const unsigned short* dzr = st.dz + (int64_t)b * st.ldz;
-      const int l15 = lane & 15, lq = lane >> 4;
       if (tid < Hd / 2) *reinterpret_cast<uint4*>(dzl + tid * 8) = ld16(dzr + tid * 8);
       __syncthreads();
-      const unsigned short* azp = l15 == 0 ? dzl + 8 * lq : dzl + 4 * Hd;
-      const int azs = l15 == 0 ? 32 : 0;
       LAS_STAMPB(t, 10);
-      const int NTL = (W0 + 15) / 16;
-      for (int nt = wave; nt < NTL; nt += 4) {
-        const unsigned short* kfr = p.kn_packed + ((int64_t)nt * KC * 64 + lane) * 8;     // fragment (nt, kc): + kc * 512
-        f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int k0 = 0; k0 < KC; k0 += 16) {
-          uint4 bv[16];
-#pragma unroll
-          for (int i = 0; i < 16; ++i) bv[i] = ld16(kfr + (k0 + i) * 512);
-          uint4 av[16];                              // (the LDS reads overlap the loads' round trip)
-#pragma unroll
-          for (int i = 0; i < 16; ++i) av[i] = *reinterpret_cast<const uint4*>(azp + (k0 + i) * azs);
-#pragma unroll
-          for (int i = 0; i < 16; ++i)
-            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, av[i]), __builtin_bit_cast(bf16x8, bv[i]), acc, 0, 0, 0);
-        }
-        if (lq == 0 && nt * 16 + l15 < W0) dfeed[nt * 16 + l15] = acc[0];
-        if (nt == wave) LAS_STAMPB(t, 11);
+      if constexpr (PARTS > 1) {
+        for (int i = tid; i < 2 * Hd; i += 256)
+          pgranule_store(xbase + XL.xdz + i, (unsigned)(p.U - t), __uint_as_float(reinterpret_cast<const unsigned*>(dzl)[i]), xlocal);
       }
-      LAS_STAMPB(t, 12);
+      const int NTL = (W0 + 15) / 16;
+      seq_matvec_deep<KC>(p.kn_packed, NTL, dzl, dzl + 4 * Hd, lane, wave, 4 * PARTS, [&](int n, float v) { if (n < W0) dfeed[n] = v; });
+      if constexpr (PARTS > 1) {
+        int* fl = reinterpret_cast<int*>(acc_run + Hd + 5);
+        for (int n0 = 0; n0 < NTL * 16; n0 += 256) {
+          const int n = n0 + tid;
+          const bool have = n < W0 && seq_owner(n) != 0;
+          const float v = seq_wait(xbase + XL.xdf + min(n, W0 - 1), have, (unsigned)(p.U - t), fl);
+          if (have) dfeed[n] = v;
+        }
+      }
     }
     __syncthreads();
     LAS_STAMPB(t, 9);
@@ -3750,8 +3865,8 @@ extern "C" int las_decoder_persist_bwd(const las_dec_persist_bwd* p, void* strea
   return LAS_OK;
 }
 
-extern "C" size_t las_decoder_seq_xchg_bytes(int B, int Tm, int Hd) {
-  return B > 0 && Tm > 0 && Hd > 0 ? 64 + (size_t)B * ((Tm + 3 * Hd + 15) & ~15) * sizeof(pu64) : 0;
+extern "C" size_t las_decoder_seq_xchg_bytes(int B, int Tm, int Hd, int M, int W0) {
+  return B > 0 && Tm > 0 && Hd > 0 && M > 0 && W0 > 0 ? 64 + (size_t)B * seq_xlayout(Tm, Hd, M, W0).total * sizeof(pu64) : 0;
 }
 
 extern "C" size_t las_decoder_sum_workspace_bytes(int blocks, int n) {
@@ -3806,11 +3921,11 @@ extern "C" int las_decoder_seq_bwd(const las_dec_seq_bwd* p, void* stream) {
   // own -- they wait for one another -- and a quarter of the frames fits SEQ_NPK4 passes
   static const int cus = [] { int dev = 0, n = 0; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return n; }();
   const int blocks4 = (s->B + 7) / 8 * 32, fq = (s->Tm + 3) / 4;
-  const bool parts4 = regk && q.xchg_workspace && blocks4 <= cus && (fq + P - 1) / P <= SEQ_NPK4 && s->dv_acc && q.sum_workspace;
+  const bool parts4 = regk && q.xchg_workspace && blocks4 <= cus && (fq + P - 1) / P <= SEQ_NPK4 && s->dv_acc && q.sum_workspace && q.A <= 128;
 #define LAS_SEQ_LAUNCH(NPK_, KC_) hipLaunchKernelGGL((dec_seq_bwd_kernel<NPK_, KC_>), dim3(s->B), dim3(256), lds, (hipStream_t)stream, q)
 #define LAS_SEQ_LAUNCH4(KC_) hipLaunchKernelGGL((dec_seq_bwd_kernel<SEQ_NPK4, KC_, 4>), dim3(blocks4), dim3(256), lds, (hipStream_t)stream, q)
   if (parts4) {
-    int rc = las_check_hip(hipMemsetAsync(static_cast<char*>(q.xchg_workspace) + 64, 0, las_decoder_seq_xchg_bytes(s->B, s->Tm, s->Hd) - 64, (hipStream_t)stream),
+    int rc = las_check_hip(hipMemsetAsync(static_cast<char*>(q.xchg_workspace) + 64, 0, las_decoder_seq_xchg_bytes(s->B, s->Tm, s->Hd, s->M, q.W0) - 64, (hipStream_t)stream),
                            "memset exchange workspace");
     if (rc) return rc;
     if (s->Hd == 128) LAS_SEQ_LAUNCH4(16); else LAS_SEQ_LAUNCH4(32);

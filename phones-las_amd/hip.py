@@ -44,7 +44,7 @@ _SIGS = {
     'las_decoder_step_bwd': ([_vp, _vp], C.c_int),
     'las_decoder_seq_bwd_supported': ([_i32] * 7, C.c_int),
     'las_decoder_sum_workspace_bytes': ([_i32, _i32], C.c_size_t),
-    'las_decoder_seq_xchg_bytes': ([_i32, _i32, _i32], C.c_size_t),
+    'las_decoder_seq_xchg_bytes': ([_i32] * 5, C.c_size_t),
     'las_decoder_seq_bwd': ([_vp, _vp], C.c_int),
     'las_seq_ce_loss': ([_vp, _i64, _vp, _vp, _i32, _i32, _i32, _f32, _vp, _vp, _i64, _vp], C.c_int),
     'las_seq_sigmoid_loss': ([_vp, _i64, _vp, _i64, _vp, _i32, _i32, _i32, _f32, _vp, _vp, _i64, _vp], C.c_int),

@@ -675,7 +675,7 @@ class GeneralSpeller:
             if bah or self.mono:                    # d(attention_v) / d(score_bias): fixed-order sums instead of atomics
                 q.sum_workspace = hip.addr(self._persist_workspace('sum', lib.las_decoder_sum_workspace_bytes(32 * ((B + 7) // 8), Hd + 1)))
                 if bah and os.environ.get('LAS_DEC_SEQ_PARTS', '4') != '1':       # four workgroups per utterance (see las_dec_seq_bwd)
-                    q.xchg_workspace = hip.addr(self._persist_workspace('seqx', lib.las_decoder_seq_xchg_bytes(B, Tm, Hd)))
+                    q.xchg_workspace = hip.addr(self._persist_workspace('seqx', lib.las_decoder_seq_xchg_bytes(B, Tm, Hd, M, W[0])))
             dfeed0 = torch.empty(B, W[0], dtype=f32, device=dev)
             q.dfeed_out = hip.addr(dfeed0)
             tok = hip.prof_begin('dec_seq_bwd', 2.0 * U * B * (W[0] * 4 * Hd + 2 * Tm * Hd + 2 * Tm * M + (Hd + M) * (A if self.has_al else 0)))

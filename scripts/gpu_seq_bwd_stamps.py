@@ -30,6 +30,3 @@ print('step time %.2f us' % (np.diff(st[5:c['U'] - 5, 0]).mean() / -100.0))
 for k in range(len(order) - 1):
     d = (rows[:, order[k + 1]] - rows[:, order[k]]) / 100.0
     print('  %-52s %7.2f us' % (names[k], d.mean()))
-for a, b, what in ((8, 10, 'd(feed): dz_t into LDS'), (10, 11, 'd(feed): first tile of wave 0'), (11, 12, 'd(feed): its other tiles'),
-                   (12, 9, 'd(feed): wait for the other waves')):
-    print('    %-50s %7.2f us' % (what, ((rows[:, b] - rows[:, a]) / 100.0).mean()))
