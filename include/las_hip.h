@@ -489,6 +489,9 @@ typedef struct las_dec_seq_bwd {
    * the one that walks the chain, exchanging their operands and results through this workspace at every step (A <= 128); sum_workspace must then hold 32 * ceil(B / 8) rows.  Its
    * first 64 bytes are a STICKY status word (bit 5: a bounded wait timed out, results invalid) like the other one-launch kernels'. */
   void* xchg_workspace;
+  /* optional, with xchg_workspace: the LAS_IMAGE_PACK_MFMA_B image of the query layer's kernel [Hd(in), Hd(out)] (dh = d(processed
+   * query) Wq^T on the matrix cores; without it the product runs from s.wq_t as in the other kernels) */
+  const las_bf16* wq_packed;
 } las_dec_seq_bwd;
 size_t las_decoder_seq_xchg_bytes(int B, int Tm, int Hd, int M, int W0);
 /* bytes of the fixed-order sum workspace of the one-launch backward decoders: a counter line + `blocks` rows of n floats */

@@ -1785,6 +1785,126 @@ __host__ __device__ inline size_t dec_step_bwd_floats(int M, int Tm, int Hd, int
 // = sum_a d(attention)[a] (values W_c)[t'][a]: VW = values W_c [T', A] does not depend on the decoder step -- one product per
 // train step, resident in LDS (row stride A + 1) -- and a step's pass over the utterance's values (400 KB from beyond L2: 21 of
 // the sequential backward's 75 us per step at cfg5) becomes T' x A multiply-adds.
+// Exchange rows of one utterance (PARTS = 4), in granules: d(scores) [Tm], partial d(processed query) [3][Hd], d(attention_t) as
+// bf16 pairs [64], d[query | context] [Hd + M], dz_t as bf16 pairs [2 Hd], d[feed | h] [W0], XCC ids [4]
+struct SeqXLayout { int xdq, xda, xqc, xdz, xdf, xcc, total; };
+__host__ __device__ inline SeqXLayout seq_xlayout(int Tm, int Hd, int M, int W0) {
+  SeqXLayout L;
+  L.xdq = Tm;
+  L.xda = L.xdq + 3 * Hd;
+  L.xqc = L.xda + 64;
+  L.xdz = L.xqc + Hd + M;
+  L.xdf = L.xdz + 2 * Hd;
+  L.xcc = L.xdf + ((W0 + 15) & ~15);                   // [4] {1, XCC id + 1} of the four parts (are they on one XCD?)
+  L.total = (L.xcc + 4 + 15) & ~15;
+  return L;
+}
+
+// out(n, value) for the columns n of the 16-column tiles vwave, vwave + nvw, ... of y = a W^T, W as a LAS_IMAGE_PACK_MFMA_B image
+// with KCa 32-deep chunks, a (bf16, row 0 of the A tile) in LDS at a_lds with 8 zeros at zeros: TB tiles per pass, one pass and
+// chunk = TB loads in flight, the next (pass, chunk)'s requested before this one's products.  (d[query | context] = d(attention) W_al^T)
+template <typename OUT>
+__device__ __forceinline__ void seq_matvec_few_chunks(const unsigned short* packed, const int KCa, const int NT, const unsigned short* a_lds,
+                                                      const unsigned short* zeros, const int lane, const int vwave, const int nvw, OUT out) {
+  constexpr int TB = 10;
+  const int l15 = lane & 15, lq = lane >> 4;
+  const unsigned short* azp = l15 == 0 ? a_lds + 8 * lq : zeros;
+  const int azs = l15 == 0 ? 32 : 0;
+  const int mine = vwave < NT ? (NT - vwave + nvw - 1) / nvw : 0;       // tiles of this (virtual) wave
+  const int NB = (mine + TB - 1) / TB, Q = NB * KCa;
+  if (Q == 0) return;
+  uint4 cur[TB], nxt[TB];
+  f32x4 acc[TB];
+  auto frag = [&](int q, int i) {
+    const int bi = q / KCa, kc = q - bi * KCa;
+    const int nt = min(vwave + nvw * (bi * TB + i), NT - 1);
+    return packed + (((int64_t)nt * KCa + kc) * 64 + lane) * 8;
+  };
+#pragma unroll
+  for (int i = 0; i < TB; ++i) cur[i] = ld16(frag(0, i));
+#pragma unroll 1
+  for (int q = 0; q < Q; ++q) {
+    const int bi = q / KCa, kc = q - bi * KCa;
+    if (q + 1 < Q) {
+#pragma unroll
+      for (int i = 0; i < TB; ++i) nxt[i] = ld16(frag(q + 1, i));
+    }
+    const uint4 av = *reinterpret_cast<const uint4*>(azp + kc * azs);
+    if (kc == 0) {
+#pragma unroll
+      for (int i = 0; i < TB; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int i = 0; i < TB; ++i)
+      acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, av), __builtin_bit_cast(bf16x8, cur[i]), acc[i], 0, 0, 0);
+    if (kc == KCa - 1) {
+#pragma unroll
+      for (int i = 0; i < TB; ++i) {
+        const int nt = vwave + nvw * (bi * TB + i);
+        if (lq == 0 && nt < NT) out(nt * 16 + l15, acc[i][0]);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < TB; ++i) cur[i] = nxt[i];
+  }
+}
+
+// The same for a deep product (KC chunks, compile-time): a tile's 16 fragments of half its chunks in flight at once, the A
+// fragments read from LDS beside them.  (d[feed | h]_t = dz_t K^T)
+template <int KC, typename OUT>
+__device__ __forceinline__ void seq_matvec_deep(const unsigned short* packed, const int NT, const unsigned short* a_lds, const unsigned short* zeros,
+                                                const int lane, const int vwave, const int nvw, OUT out) {
+  const int l15 = lane & 15, lq = lane >> 4;
+  const unsigned short* azp = l15 == 0 ? a_lds + 8 * lq : zeros;
+  const int azs = l15 == 0 ? 32 : 0;
+  for (int nt = vwave; nt < NT; nt += nvw) {
+    const unsigned short* kfr = packed + ((int64_t)nt * KC * 64 + lane) * 8;     // fragment (nt, kc): + kc * 512
+    f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k0 = 0; k0 < KC; k0 += 16) {
+      uint4 bv[16];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) bv[i] = ld16(kfr + (k0 + i) * 512);
+      uint4 av[16];                              // (the LDS reads overlap the loads' round trip)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) av[i] = *reinterpret_cast<const uint4*>(azp + (k0 + i) * azs);
+#pragma unroll
+      for (int i = 0; i < 16; ++i)
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, av[i]), __builtin_bit_cast(bf16x8, bv[i]), acc, 0, 0, 0);
+    }
+    if (lq == 0) out(nt * 16 + l15, acc[0]);
+  }
+}
+
+// part that owns column n of such a product split over 4 x 4 virtual waves (tile n / 16 belongs to virtual wave (n / 16) % 16)
+__device__ __forceinline__ int seq_owner(int n) { return ((n >> 4) & 15) >> 2; }
+
+// ... and for a square product with ALL of a wave's fragments in flight (KC^2 / 2 of them: 32 at 256 units): y = a W^T with
+// 2 KC tiles, wave w takes the tiles w, w + 4, ...  (dh = d(processed query) Wq^T of the Bahdanau / Custom query layer)
+template <int KC, typename OUT>
+__device__ __forceinline__ void seq_matvec_square(const unsigned short* packed, const unsigned short* a_lds, const unsigned short* zeros,
+                                                  const int lane, const int wave, OUT out) {
+  constexpr int TPW = KC / 2;
+  const int l15 = lane & 15, lq = lane >> 4;
+  const unsigned short* azp = l15 == 0 ? a_lds + 8 * lq : zeros;
+  const int azs = l15 == 0 ? 32 : 0;
+  uint4 bv[TPW][KC], av[KC];
+#pragma unroll
+  for (int i = 0; i < TPW; ++i)
+#pragma unroll
+    for (int kc = 0; kc < KC; ++kc) bv[i][kc] = ld16(packed + (((int64_t)(wave + 4 * i) * KC + kc) * 64 + lane) * 8);
+#pragma unroll
+  for (int kc = 0; kc < KC; ++kc) av[kc] = *reinterpret_cast<const uint4*>(azp + kc * azs);
+#pragma unroll
+  for (int i = 0; i < TPW; ++i) {
+    f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kc = 0; kc < KC; ++kc)
+      acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, av[kc]), __builtin_bit_cast(bf16x8, bv[i][kc]), acc, 0, 0, 0);
+    if (lq == 0) out((wave + 4 * i) * 16 + l15, acc[0]);
+  }
+}
+
 // dec_seq_bwd_kernel with FOUR workgroups per utterance (PARTS = 4): part 0 walks the chain as before, parts 1..3 take three
 // quarters of the memory frames of the Bahdanau query path off it -- 200 tanh per thread and step on one CU otherwise.
 // Per step part 0 publishes d(scores) of the frames it does not own (xds, {tag, fp32} granules), every part runs the query path
@@ -1863,7 +1983,8 @@ constexpr int SEQ_NPK4 = 7;        // ... of a quarter of the frames (four workg
 template <int NPK = 0>
 __device__ __forceinline__ void dec_step_bwd_body(const las_dec_step_bwd& s, const int b, float* sm, const float* vw = nullptr,
                                                   const float* datt = nullptr, const int A = 0, float (*dkr)[8] = nullptr,
-                                                  const int tid_in = -1, float* acc_run = nullptr, const SeqXchg* xc = nullptr) {
+                                                  const int tid_in = -1, float* acc_run = nullptr, const SeqXchg* xc = nullptr,
+                                                  const unsigned short* wq_pk = nullptr) {
   float* dctx = sm;               // [M]
   float* ds = dctx + s.M;         // [Tm] dalign -> dscore
   float* dhs = ds + s.Tm;         // [256/L][Hd] = 2048 floats: per-phase partial d h (score path) / dpq
@@ -1877,6 +1998,14 @@ __device__ __forceinline__ void dec_step_bwd_body(const las_dec_step_bwd& s, con
     __syncthreads();
   } else {
   const int len = min(s.mem_len[b], Tm);
+  // the register-resident monotonic chain's inputs (saved p_choose, the previous alignments, the carry of step t+1's
+  // normaliser -- written by this very thread) are requested now and used two phases later
+  float pre_p = 0.f, pre_pr = 0.f, pre_carry = 0.f;
+  if (s.norm == LAS_NORM_MONOTONIC_PARALLEL && Tm <= 256 && tid < Tm) {
+    if (tid < len) pre_p = s.p[(int64_t)b * s.ldp + tid];
+    pre_pr = s.prev_align ? s.prev_align[(int64_t)b * s.ldpa + tid] : (tid == 0 ? 1.f : 0.f);
+    pre_carry = s.dalign_carry[(int64_t)b * s.ldcarry + tid];
+  }
 
   // total gradient w.r.t. the context of this step; keep a bf16 copy for the d(memory) batched GEMM
   for (int m = tid; m < M; m += 256) {
@@ -2020,9 +2149,8 @@ __device__ __forceinline__ void dec_step_bwd_body(const las_dec_step_bwd& s, con
       // frame t in the registers of thread t through the whole chain: four scans, four barriers (see scan256)
       const int t = tid;
       const bool in = t < Tm;
-      const float p = (in && t < len) ? pv[t] : 0.f;
-      const float pr = in ? (prev ? prev[t] : (t == 0 ? 1.f : 0.f)) : 0.f;
-      const float da = in ? ds[t] + carry[t] : 0.f;           // d(align_t): this step's + step t+1's normaliser's
+      const float p = pre_p, pr = pre_pr;
+      const float da = in ? ds[t] + pre_carry : 0.f;          // d(align_t): this step's + step t+1's normaliser's
       const float c = __expf(scan256<false, false, true>(in ? __logf(fminf(fmaxf(1.f - p, 1.17549435e-38f), 1.f)) : 0.f, tmp, lane, wave));
       const float cc = fminf(fmaxf(c, 1e-10f), 1.f);
       const float S = scan256<false, false, false>(in ? pr / cc : 0.f, tmp + 4, lane, wave);
@@ -2227,10 +2355,27 @@ __device__ __forceinline__ void dec_step_bwd_body(const las_dec_step_bwd& s, con
     }
     for (int u = tid; u < Hd; u += 256)
       if (s.dpq_out) s.dpq_out[(int64_t)b * s.lddpq + u] = las_f2bf(dhs[u]);
-    // (scratch: 2048 floats behind everything else of this kernel's LDS, see las_decoder_step_bwd)
-    square_matvec_bf16(s.wq_t, dhs, tmp, red + 8 + Hd + (s.norm != LAS_NORM_SOFTMAX ? 5 * Tm : 0), Hd);
-    for (int u = tid; u < Hd; u += 256) dhs[u] = tmp[u];
-    __syncthreads();
+    bool done = false;
+    if constexpr (NPK == SEQ_NPK4) {
+      // (the four-workgroup kernel has the registers: the product on the matrix cores from Wq's B-fragment image, d(processed
+      //  query) rounded to bf16 -- the operand the d(query_layer) product sees too -- as row 0 of the A tile)
+      if (wq_pk && (Hd == 256 || Hd == 128)) {
+        unsigned short* opq = reinterpret_cast<unsigned short*>(tmp);
+        for (int u = tid; u < Hd; u += 256) opq[u] = las_f2bf(dhs[u]);
+        if (tid < 4) reinterpret_cast<unsigned*>(opq + Hd)[tid] = 0u;
+        __syncthreads();
+        if (Hd == 256) seq_matvec_square<8>(wq_pk, opq, opq + Hd, lane, wave, [&](int n, float v) { dhs[n] = v; });
+        else seq_matvec_square<4>(wq_pk, opq, opq + Hd, lane, wave, [&](int n, float v) { dhs[n] = v; });
+        __syncthreads();
+        done = true;
+      }
+    }
+    if (!done) {
+      // (scratch: 2048 floats behind everything else of this kernel's LDS, see las_decoder_step_bwd)
+      square_matvec_bf16(s.wq_t, dhs, tmp, red + 8 + Hd + (s.norm != LAS_NORM_SOFTMAX ? 5 * Tm : 0), Hd);
+      for (int u = tid; u < Hd; u += 256) dhs[u] = tmp[u];
+      __syncthreads();
+    }
   }
 
   if (s.mode == LAS_DEC_ATTENTION_ONLY) {      // hand d(query) to the caller; the query's cell is differentiated elsewhere
@@ -2280,100 +2425,6 @@ __global__ __launch_bounds__(256) void dec_step_bwd_kernel(las_dec_step_bwd s) {
 // same operand roundings, same summation order of the two products' K loops is NOT guaranteed -- compared at 1e-3).
 // LDS: the step body's floats, then d(attention) [A], d[query | context] [Hd + M], d(feed) [W0].
 // ------------------------------------------------------------------------------------------------
-// Exchange rows of one utterance (PARTS = 4), in granules: d(scores) [Tm], partial d(processed query) [3][Hd], d(attention_t) as
-// bf16 pairs [64], d[query | context] [Hd + M], dz_t as bf16 pairs [2 Hd], d[feed | h] [W0], XCC ids [4]
-struct SeqXLayout { int xdq, xda, xqc, xdz, xdf, xcc, total; };
-__host__ __device__ inline SeqXLayout seq_xlayout(int Tm, int Hd, int M, int W0) {
-  SeqXLayout L;
-  L.xdq = Tm;
-  L.xda = L.xdq + 3 * Hd;
-  L.xqc = L.xda + 64;
-  L.xdz = L.xqc + Hd + M;
-  L.xdf = L.xdz + 2 * Hd;
-  L.xcc = L.xdf + ((W0 + 15) & ~15);                   // [4] {1, XCC id + 1} of the four parts (are they on one XCD?)
-  L.total = (L.xcc + 4 + 15) & ~15;
-  return L;
-}
-
-// out(n, value) for the columns n of the 16-column tiles vwave, vwave + nvw, ... of y = a W^T, W as a LAS_IMAGE_PACK_MFMA_B image
-// with KCa 32-deep chunks, a (bf16, row 0 of the A tile) in LDS at a_lds with 8 zeros at zeros: TB tiles per pass, one pass and
-// chunk = TB loads in flight, the next (pass, chunk)'s requested before this one's products.  (d[query | context] = d(attention) W_al^T)
-template <typename OUT>
-__device__ __forceinline__ void seq_matvec_few_chunks(const unsigned short* packed, const int KCa, const int NT, const unsigned short* a_lds,
-                                                      const unsigned short* zeros, const int lane, const int vwave, const int nvw, OUT out) {
-  constexpr int TB = 10;
-  const int l15 = lane & 15, lq = lane >> 4;
-  const unsigned short* azp = l15 == 0 ? a_lds + 8 * lq : zeros;
-  const int azs = l15 == 0 ? 32 : 0;
-  const int mine = vwave < NT ? (NT - vwave + nvw - 1) / nvw : 0;       // tiles of this (virtual) wave
-  const int NB = (mine + TB - 1) / TB, Q = NB * KCa;
-  if (Q == 0) return;
-  uint4 cur[TB], nxt[TB];
-  f32x4 acc[TB];
-  auto frag = [&](int q, int i) {
-    const int bi = q / KCa, kc = q - bi * KCa;
-    const int nt = min(vwave + nvw * (bi * TB + i), NT - 1);
-    return packed + (((int64_t)nt * KCa + kc) * 64 + lane) * 8;
-  };
-#pragma unroll
-  for (int i = 0; i < TB; ++i) cur[i] = ld16(frag(0, i));
-#pragma unroll 1
-  for (int q = 0; q < Q; ++q) {
-    const int bi = q / KCa, kc = q - bi * KCa;
-    if (q + 1 < Q) {
-#pragma unroll
-      for (int i = 0; i < TB; ++i) nxt[i] = ld16(frag(q + 1, i));
-    }
-    const uint4 av = *reinterpret_cast<const uint4*>(azp + kc * azs);
-    if (kc == 0) {
-#pragma unroll
-      for (int i = 0; i < TB; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-    }
-#pragma unroll
-    for (int i = 0; i < TB; ++i)
-      acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, av), __builtin_bit_cast(bf16x8, cur[i]), acc[i], 0, 0, 0);
-    if (kc == KCa - 1) {
-#pragma unroll
-      for (int i = 0; i < TB; ++i) {
-        const int nt = vwave + nvw * (bi * TB + i);
-        if (lq == 0 && nt < NT) out(nt * 16 + l15, acc[i][0]);
-      }
-    }
-#pragma unroll
-    for (int i = 0; i < TB; ++i) cur[i] = nxt[i];
-  }
-}
-
-// The same for a deep product (KC chunks, compile-time): a tile's 16 fragments of half its chunks in flight at once, the A
-// fragments read from LDS beside them.  (d[feed | h]_t = dz_t K^T)
-template <int KC, typename OUT>
-__device__ __forceinline__ void seq_matvec_deep(const unsigned short* packed, const int NT, const unsigned short* a_lds, const unsigned short* zeros,
-                                                const int lane, const int vwave, const int nvw, OUT out) {
-  const int l15 = lane & 15, lq = lane >> 4;
-  const unsigned short* azp = l15 == 0 ? a_lds + 8 * lq : zeros;
-  const int azs = l15 == 0 ? 32 : 0;
-  for (int nt = vwave; nt < NT; nt += nvw) {
-    const unsigned short* kfr = packed + ((int64_t)nt * KC * 64 + lane) * 8;     // fragment (nt, kc): + kc * 512
-    f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int k0 = 0; k0 < KC; k0 += 16) {
-      uint4 bv[16];
-#pragma unroll
-      for (int i = 0; i < 16; ++i) bv[i] = ld16(kfr + (k0 + i) * 512);
-      uint4 av[16];                              // (the LDS reads overlap the loads' round trip)
-#pragma unroll
-      for (int i = 0; i < 16; ++i) av[i] = *reinterpret_cast<const uint4*>(azp + (k0 + i) * azs);
-#pragma unroll
-      for (int i = 0; i < 16; ++i)
-        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, av[i]), __builtin_bit_cast(bf16x8, bv[i]), acc, 0, 0, 0);
-    }
-    if (lq == 0) out(nt * 16 + l15, acc[0]);
-  }
-}
-
-// part that owns column n of such a product split over 4 x 4 virtual waves (tile n / 16 belongs to virtual wave (n / 16) % 16)
-__device__ __forceinline__ int seq_owner(int n) { return ((n >> 4) & 15) >> 2; }
-
 // KC = 4 Hd / 32: the 32-deep chunks of the gate columns (Hd 128: 16, 256: 32).  PARTS = 4 (Bahdanau scores, NPK > 0): four
 // workgroups per utterance, blocks in chunks of 8 utterances (block = chunk * 32 + part * 8 + utterance % 8: the four parts of
 // an utterance are 8 blocks apart, i.e. on one XCD under round-robin dispatch); see SeqXchg.
@@ -2529,6 +2580,7 @@ __global__ __launch_bounds__(256) void dec_seq_bwd_kernel(las_dec_seq_bwd p) {
     for (int e = tid0; e < s0.Tm * A; e += 256) vwl[(e / A) * (A + 1) + e % A] = src[e];
   }
   __syncthreads();
+  float dout_pre = (A > 0 && tid0 < A) ? (p.d_out + (int64_t)b * p.ld_dout + (int64_t)(p.U - 1) * p.inc_dout)[tid0] : 0.f;
   for (int t = p.U - 1; t >= 0; --t) {
     // The thread index is made opaque to the compiler once per step: everything that depends on it alone (row addresses of
     // the weights' fragments, of the keys' frames, bounds tests ...) is invariant across the steps and was hoisted out of
@@ -2555,11 +2607,14 @@ __global__ __launch_bounds__(256) void dec_seq_bwd_kernel(las_dec_seq_bwd p) {
     }
     st.step = t;
     const float* dout = p.d_out + (int64_t)b * p.ld_dout + (int64_t)t * p.inc_dout;
+    // d(outputs)_t[tid] was requested a step ago; the next step's goes out now (an input: no dependence on the chain)
+    const float dout_cur = dout_pre;
+    if (t > 0 && tid0 < A) dout_pre = (dout - p.inc_dout)[tid0];
     LAS_STAMPB(t, 0);
     if (A > 0) {
       // d(attention_t), rounded to bf16 once (the operand of both of the attention layer's backward products)
       for (int a = tid; a < A; a += 256) {
-        const unsigned short v = las_f2bf(dout[a] + (has_next ? dfeed[a] : 0.f));
+        const unsigned short v = las_f2bf((a < 256 ? dout_cur : dout[a]) + (has_next ? dfeed[a] : 0.f));
         datt[a] = las_bf2f(v);
         dzl[a] = v;
         p.datt_out[(int64_t)b * p.ld_datt + (int64_t)t * A + a] = v;
@@ -2599,7 +2654,7 @@ __global__ __launch_bounds__(256) void dec_seq_bwd_kernel(las_dec_seq_bwd p) {
     }
     if constexpr (PARTS > 1) {
       const SeqXchg xc{xbase, xbase + XL.xdq, (unsigned)(p.U - t), reinterpret_cast<int*>(acc_run + Hd + 5), pf0, pf1, xlocal};
-      dec_step_bwd_body<NPK>(st, b, sm, use_vw ? vwl : nullptr, datt, A, dkr, tid, p.sum_workspace ? acc_run : nullptr, &xc);
+      dec_step_bwd_body<NPK>(st, b, sm, use_vw ? vwl : nullptr, datt, A, dkr, tid, p.sum_workspace ? acc_run : nullptr, &xc, p.wq_packed);
     } else {
       dec_step_bwd_body<NPK>(st, b, sm, use_vw ? vwl : nullptr, datt, A, dkr, tid, p.sum_workspace ? acc_run : nullptr);
     }

@@ -150,7 +150,7 @@ class DecSeqBwd(C.Structure):
     _fields_ = [('s', DecStepBwd), ('U', _i32), ('A', _i32), ('W0', _i32), ('reserved', _i32)] + [(n, _i64) for n in (
         'inc_gates', 'inc_c', 'inc_align', 'inc_dz', 'inc_ds', 'inc_save', 'inc_pq')] + [
         ('d_out', _vp), ('ld_dout', _i64), ('inc_dout', _i64), ('datt_out', _vp), ('ld_datt', _i64), ('waln_packed', _vp), ('reserved1', _i64),
-        ('kn_packed', _vp), ('reserved2', _i64), ('dfeed_out', _vp), ('vw', _vp), ('ld_vw', _i64), ('sum_workspace', _vp), ('xchg_workspace', _vp)]
+        ('kn_packed', _vp), ('reserved2', _i64), ('dfeed_out', _vp), ('vw', _vp), ('ld_vw', _i64), ('sum_workspace', _vp), ('xchg_workspace', _vp), ('wq_packed', _vp)]
 
 
 class DecPersistBwd(C.Structure):

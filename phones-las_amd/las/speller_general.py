@@ -169,6 +169,7 @@ class GeneralSpeller:
         if self.uses_wq:
             self.wq = torch.empty(Hd, Hd, dtype=bf, device=dev)
             self.wq_t = torch.empty(Hd, Hd, dtype=bf, device=dev)
+            self.wq_pk = torch.empty(Hd * Hd, dtype=bf, device=dev) if Hd % 32 == 0 else None      # B-fragment image (one-launch backward)
         self._variables = variables
         self.refresh(variables)
         self.saved = None
@@ -238,6 +239,8 @@ class GeneralSpeller:
         if self.uses_wq:
             hip.cast_bf16(var[self.K_Q], Hd, Hd, self.wq, Hd, Hd)
             hip.cast_bf16(var[self.K_Q], Hd, Hd, self.wq_t, Hd, Hd, transpose=True)
+            if self.wq_pk is not None:
+                hip.pack_mfma_b(var[self.K_Q], Hd, Hd, self.wq_pk)
         if self.additive:
             self.att_v = var[self.V_ATT]
         if self.mono:
@@ -676,6 +679,8 @@ class GeneralSpeller:
                 q.sum_workspace = hip.addr(self._persist_workspace('sum', lib.las_decoder_sum_workspace_bytes(32 * ((B + 7) // 8), Hd + 1)))
                 if bah and os.environ.get('LAS_DEC_SEQ_PARTS', '4') != '1':       # four workgroups per utterance (see las_dec_seq_bwd)
                     q.xchg_workspace = hip.addr(self._persist_workspace('seqx', lib.las_decoder_seq_xchg_bytes(B, Tm, Hd, M, W[0])))
+                    if self.uses_wq and self.wq_pk is not None:
+                        q.wq_packed = hip.addr(self.wq_pk)
             dfeed0 = torch.empty(B, W[0], dtype=f32, device=dev)
             q.dfeed_out = hip.addr(dfeed0)
             tok = hip.prof_begin('dec_seq_bwd', 2.0 * U * B * (W[0] * 4 * Hd + 2 * Tm * Hd + 2 * Tm * M + (Hd + M) * (A if self.has_al else 0)))
