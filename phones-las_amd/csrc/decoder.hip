@@ -600,22 +600,26 @@ __device__ __forceinline__ void dec_step_fwd_body(const las_dec_step& s, const i
       constexpr int VB = 16;                 // value loads in flight per thread (one round trip to Infinity Cache)
       // vrows + t * vstride: this thread's 8 columns of frame t (memory, or the workgroup's LDS copy of its columns)
       auto context_pass = [&](auto vrows, int64_t vstride) {
+        // (no branches in the pass: frames past the utterance re-read its last frame with weight 0 -- guarded loads were 16
+        //  branches per pass, each on a per-lane condition)
+        const int last = max(len - 1, 0);
         for (int tb = phase; tb < len; tb += P * VB) {
           uint4 vv[VB];
+          float pw[VB];
 #pragma unroll
           for (int i = 0; i < VB; ++i) {
             const int t = tb + i * P;
-            if (t < len) vv[i] = ld16(vrows + (int64_t)t * vstride);
+            vv[i] = ld16(vrows + (int64_t)min(t, last) * vstride);
+            pw[i] = t < len ? sc[min(t, last)] : 0.f;
           }
 #pragma unroll
           for (int i = 0; i < VB; ++i) {
-            const int t = tb + i * P;
-            if (t < len) {
-              const unsigned short* e = reinterpret_cast<const unsigned short*>(&vv[i]);
-              const float p = sc[t];
-#pragma unroll
-              for (int j = 0; j < 8; ++j) a[j] += p * las_bf2f(e[j]);
-            }
+            const uint4 q = vv[i];
+            const float p = pw[i];
+            a[0] += p * __uint_as_float(q.x << 16); a[1] += p * __uint_as_float(q.x & 0xffff0000u);
+            a[2] += p * __uint_as_float(q.y << 16); a[3] += p * __uint_as_float(q.y & 0xffff0000u);
+            a[4] += p * __uint_as_float(q.z << 16); a[5] += p * __uint_as_float(q.z & 0xffff0000u);
+            a[6] += p * __uint_as_float(q.w << 16); a[7] += p * __uint_as_float(q.w & 0xffff0000u);
           }
         }
       };
