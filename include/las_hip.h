@@ -146,7 +146,8 @@ int las_cast_bf16(const float* src, int64_t lds, int rows, int cols, las_bf16* d
  *   LAS_IMAGE_PACK_MFMA_B     bf16 image of src [rows, cols] (row stride lds) in matrix-core B-fragment order, zero padded to
  *                             dst_rows (multiple of 16) x dst_cols (multiple of 32): [dst_rows / 16][dst_cols / 32][64 lanes][8]
  *                             with lane l = row tile * 16 + (l & 15), columns chunk * 32 + (l >> 4) * 8 + 0..7 -- every
- *                             fragment one contiguous KB (rows 2^k bytes apart all land on one L2 channel otherwise). */
+ *                             fragment one contiguous KB (rows 2^k bytes apart all land on one L2 channel otherwise);
+ *                             transpose = 1: the image of src^T (src is [cols, rows], row stride lds). */
 enum las_image_kind { LAS_IMAGE_CAST = 0, LAS_IMAGE_PACK_RECURRENT = 1, LAS_IMAGE_BIAS_INTERLEAVE = 2, LAS_IMAGE_COPY_F32 = 3,
                       LAS_IMAGE_PACK_MFMA_B = 4 };
 typedef struct las_image_job {
@@ -324,7 +325,8 @@ typedef struct las_dec_persist {
   int64_t ldx, inc_x;
   const las_bf16* kT;            /* [4Hd, K_in] bf16, row n = output column n, row stride ldk */
   int64_t ldk;
-  float* z_all;                  /* unused (z_t travels through the workspace); may be NULL */
+  const las_bf16* wq_packed;     /* optional (Bahdanau / Custom, Hd 128 or 256): the LAS_IMAGE_PACK_MFMA_B image of the query layer's
+                                  * kernel TRANSPOSED (rows = outputs): the processed query h_t Wq on the matrix cores */
   float* sc_all;                 /* unused (the raw scores travel through the workspace); may be NULL */
   int64_t ld_sc;                 /* >= Tm, multiple of 32 (whole cache lines per row) */
   void* workspace;

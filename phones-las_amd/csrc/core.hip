@@ -80,7 +80,8 @@ __global__ __launch_bounds__(256) void refresh_images_kernel(const las_image_job
       const int e = (int)(i & 7), lane = (int)(i >> 3) & 63;
       const int64_t frag = i >> 9;
       const int n = (int)(frag / KC) * 16 + (lane & 15), k = (int)(frag % KC) * 32 + (lane >> 4) * 8 + e;
-      dst[i] = las_f2bf(n < jb.rows && k < jb.cols ? jb.src[(int64_t)n * jb.lds + k] : 0.f);
+      // (transpose: the image of the source's transpose -- row n of the product's B operand is COLUMN n of src [cols, rows])
+      dst[i] = las_f2bf(n < jb.rows && k < jb.cols ? (jb.transpose ? jb.src[(int64_t)k * jb.lds + n] : jb.src[(int64_t)n * jb.lds + k]) : 0.f);
     }
   } else {                                                  // LAS_IMAGE_COPY_F32
     float* dst = static_cast<float*>(jb.dst);

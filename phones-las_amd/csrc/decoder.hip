@@ -196,6 +196,41 @@ __device__ __forceinline__ uint4 ld16(lds_cu16 p) {
   return make_uint4(v.x, v.y, v.z, v.w);
 }
 
+typedef __attribute__((ext_vector_type(8))) __bf16 sq_bf16x8;
+typedef __attribute__((ext_vector_type(4))) float sq_f32x4;
+// out[n] = sum_k a[k] W[n][k] for a square matrix of 32 KC rows handed in as its LAS_IMAGE_PACK_MFMA_B image (2 KC tiles of 16
+// rows x KC chunks of 32), a (bf16) in LDS with 8 zeros at `zeros`: a is row 0 of the MFMA A tile, wave w takes the tiles w,
+// w + 4, ..., TPB of them -- TPB KC fragments, one contiguous KB each -- in flight at a time.  The query layer of the Bahdanau /
+// Custom attentions in the one-launch decoders (square_matvec_bf16 walks the row-major matrix with eight 16-byte loads in
+// flight: 2.5 us per step at 256 units).
+template <int KC, int TPB>
+__device__ __forceinline__ void square_matvec_mfma(const unsigned short* packed, const unsigned short* a_lds, const unsigned short* zeros,
+                                                   float* out, const int lane, const int wave) {
+  constexpr int TPW = KC / 2;
+  const int l15 = lane & 15, lq = lane >> 4;
+  const unsigned short* azp = l15 == 0 ? a_lds + 8 * lq : zeros;
+  const int azs = l15 == 0 ? 32 : 0;
+  uint4 av[KC];
+#pragma unroll
+  for (int kc = 0; kc < KC; ++kc) av[kc] = *reinterpret_cast<const uint4*>(azp + kc * azs);
+#pragma unroll
+  for (int i0 = 0; i0 < TPW; i0 += TPB) {
+    uint4 bv[TPB][KC];
+#pragma unroll
+    for (int i = 0; i < TPB; ++i)
+#pragma unroll
+      for (int kc = 0; kc < KC; ++kc) bv[i][kc] = ld16(packed + (((int64_t)(wave + 4 * (i0 + i)) * KC + kc) * 64 + lane) * 8);
+#pragma unroll
+    for (int i = 0; i < TPB; ++i) {
+      sq_f32x4 acc = sq_f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int kc = 0; kc < KC; ++kc)
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(sq_bf16x8, av[kc]), __builtin_bit_cast(sq_bf16x8, bv[i][kc]), acc, 0, 0, 0);
+      if (lq == 0) out[(wave + 4 * (i0 + i)) * 16 + l15] = acc[0];
+    }
+  }
+}
+
 #ifdef LAS_STAMPS
 // diagnostics build (LAS_CXXFLAGS=-DLAS_STAMPS): wall-clock (100 MHz) stamps of the phases of every step of workgroup 0
 __device__ unsigned long long las_stamps[2 * 256 * 16];        // forward launch, then backward launch
@@ -216,6 +251,7 @@ struct PersistHook {
   bool local;
   int* fail;
   // LDS copies of what this workgroup reads from the memory at every step (nullptr: read from global memory):
+  const unsigned short* wq_pk;   // B-fragment image of the query layer's kernel transposed (nullable): pq = h Wq on MFMA
   const unsigned short* lkeys;   // keys of its score frames [fq][Hd], row 0 = frame part*fq
   const unsigned short* lvals;   // its context columns of every frame [Tm][cols_per]
   // operands of the cell that do not depend on this step's product, fetched while the product was running
@@ -359,6 +395,16 @@ __device__ __forceinline__ void dec_step_fwd_body(const las_dec_step& s, const i
   // ---- processed query (Bahdanau, Custom): pq[a] = sum_u Wq[u][a] h[u]  (TF Dense kernel layout [in,out]);
   //      CustomAttention applies relu and, like every AttentionWrapper query, it is a GEMM operand: bf16-rounded ----
   if (att_uses_wq(s.attention)) {
+    if (ph && ph->wq_pk && (Hd == 256 || Hd == 128)) {
+      // on the matrix cores: h_t (bf16, exactly what hq holds) as row 0 of the A tile
+      unsigned short* hb = reinterpret_cast<unsigned short*>(cred);
+      for (int u = tid; u < Hd; u += 256) hb[u] = (unsigned short)(__float_as_uint(hq[u]) >> 16);
+      if (tid < 4) reinterpret_cast<unsigned*>(hb + Hd)[tid] = 0u;
+      __syncthreads();
+      if (Hd == 256) square_matvec_mfma<8, 2>(ph->wq_pk, hb, hb + Hd, pq, lane, wave);
+      else square_matvec_mfma<4, 2>(ph->wq_pk, hb, hb + Hd, pq, lane, wave);
+      __syncthreads();
+    } else
     square_matvec_bf16(s.wq, hq, pq, cred, Hd);            // (cred: free until the context phase)
     for (int a = tid; a < Hd; a += 256) {
       float acc = pq[a];
@@ -980,7 +1026,7 @@ __global__ __launch_bounds__(256) void dec_persist_fwd_kernel(las_dec_persist p)
       }
       pu64* xsc = xbase + ((size_t)(xtag & 1) * B + bs) * ldsc;
       pu64* xz = xzb + ((size_t)(xtag & 1) * B + bs) * 4 * Hd;
-      PersistHook hook{xsc, xz, xtag, flags, member, &epoch, local, fail, lkeys, lvals,
+      PersistHook hook{xsc, xz, xtag, flags, member, &epoch, local, fail, p.wq_packed, lkeys, lvals,
                        pre_ok, tok_pre, {tok4[0], tok4[1], tok4[2], tok4[3]}, {bias4[0], bias4[1], bias4[2], bias4[3]}, cprev_pre};
       dec_step_fwd_body<RES>(st, bs, part, 4, sm, &hook);     // (a timed-out poll leaves through the barrier below)
     }

@@ -124,7 +124,7 @@ class DecPersist(C.Structure):
     """struct las_dec_persist (include/las_hip.h)."""
     _fields_ = [('s', DecStep), ('U', _i32), ('K_in', _i32)] + [(n, _i64) for n in (
         'inc_tok', 'inc_cprev', 'inc_gates', 'inc_cout', 'inc_h', 'inc_h2', 'inc_align', 'inc_pq', 'inc_ctx', 'inc_ctx2')] + [
-        ('x', _vp), ('ldx', _i64), ('inc_x', _i64), ('kT', _vp), ('ldk', _i64), ('z_all', _vp), ('sc_all', _vp), ('ld_sc', _i64), ('workspace', _vp),
+        ('x', _vp), ('ldx', _i64), ('inc_x', _i64), ('kT', _vp), ('ldk', _i64), ('wq_packed', _vp), ('sc_all', _vp), ('ld_sc', _i64), ('workspace', _vp),
         ('sampling_prob', _f32), ('seed', C.c_uint32), ('teacher', _vp), ('teacher_stride', _i64), ('wprojT', _vp), ('ldw', _i64),
         ('bproj', _vp), ('logits', _vp), ('ld_logits', _i64), ('plog', _vp), ('V', _i32), ('Vp', _i32),
         ('walT', _vp), ('ld_wal', _i64), ('A', _i32), ('x_att_off', _i32), ('att_out', _vp), ('ld_att', _i64), ('inc_p', _i64)]
@@ -481,13 +481,14 @@ def pack_recurrent(kernel_h, H, packed):
     check(lib().las_lstm_pack_recurrent(p(kernel_h), H, p(packed), stream()))
 
 
-def pack_mfma_b(src, rows, cols, dst, lds=None):
+def pack_mfma_b(src, rows, cols, dst, lds=None, transpose=False):
     """dst = the LAS_IMAGE_PACK_MFMA_B image of fp32 src[rows, cols] (joins an open image_batch): dst holds
     ceil(rows / 16) * 16 x ceil(cols / 32) * 32 bf16 elements in B-fragment order."""
     dr, dc = -(-rows // 16) * 16, -(-cols // 32) * 32
     if dst.numel() != dr * dc:
         raise LasError('pack_mfma_b: destination of %d elements, expected %d' % (dst.numel(), dr * dc))
-    _image_job(IMAGE_PACK_MFMA_B, src, dst, lds=lds if lds is not None else src.stride(-2), rows=rows, cols=cols, dst_rows=dr, dst_cols=dc)
+    _image_job(IMAGE_PACK_MFMA_B, src, dst, lds=lds if lds is not None else src.stride(-2), rows=rows, cols=cols, dst_rows=dr, dst_cols=dc,
+               transpose=int(transpose))
 
 
 def bias_interleave(bias, H, dst):

@@ -170,6 +170,7 @@ class GeneralSpeller:
             self.wq = torch.empty(Hd, Hd, dtype=bf, device=dev)
             self.wq_t = torch.empty(Hd, Hd, dtype=bf, device=dev)
             self.wq_pk = torch.empty(Hd * Hd, dtype=bf, device=dev) if Hd % 32 == 0 else None      # B-fragment image (one-launch backward)
+            self.wq_pkT = torch.empty(Hd * Hd, dtype=bf, device=dev) if Hd % 32 == 0 else None     # ... of the transpose (one-launch forward)
         self._variables = variables
         self.refresh(variables)
         self.saved = None
@@ -241,6 +242,7 @@ class GeneralSpeller:
             hip.cast_bf16(var[self.K_Q], Hd, Hd, self.wq_t, Hd, Hd, transpose=True)
             if self.wq_pk is not None:
                 hip.pack_mfma_b(var[self.K_Q], Hd, Hd, self.wq_pk)
+                hip.pack_mfma_b(var[self.K_Q], Hd, Hd, self.wq_pkT, transpose=True)
         if self.additive:
             self.att_v = var[self.V_ATT]
         if self.mono:
@@ -534,6 +536,8 @@ class GeneralSpeller:
             s.p_out, s.ldp = hip.addr(sv['p']), U * Tmp
             s.noise_scale, s.noise_seed, s.noise_stream = sv.get('noise_scale', 0.0), sv.get('seed', 0), self.NOISE_STREAM
         p.U, p.K_in = U, Kp
+        if self.uses_wq and self.wq_pkT is not None and Hd in (128, 256) and os.environ.get('LAS_DEC_PQ_MFMA', '1') != '0':
+            p.wq_packed = hip.addr(self.wq_pkT)
         p.inc_tok, p.inc_cprev, p.inc_gates, p.inc_cout, p.inc_h, p.inc_h2 = 1, Hd, 4 * Hd, Hd, Hd, Kp
         p.inc_align, p.inc_pq, p.inc_ctx, p.inc_ctx2, p.inc_p = Tmp, Hd, M, Kp, Tmp
         p.x, p.ldx, p.inc_x = hip.addr(Xp), U * Kp, Kp
