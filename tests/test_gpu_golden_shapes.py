@@ -260,8 +260,9 @@ def test_512_unit_one_launch_decoders_over_several_groups(case):
     _check(rep)
 
 
+@pytest.mark.parametrize('parts', ['4', '1'], ids=['four_workgroups', 'one_workgroup'])
 @pytest.mark.parametrize('case', ['cfg5_binf', 'cfg5_full'])
-def test_one_launch_decoder_with_attention_layer_and_monotonic_normaliser_matches_the_step_launches(case, monkeypatch):
+def test_one_launch_decoder_with_attention_layer_and_monotonic_normaliser_matches_the_step_launches(case, parts, monkeypatch):
     """cfg5's decoder (attention layer of 2 * binf_count outputs + bahdanau_monotonic) forward in ONE launch
     (dec_persist_fwd_kernel<..., AL>: the monotonic chain inside the shared step body, the attention layer as a 16-column-tile
     product on the group's members behind one more group barrier) against the same model on the per-step launches
@@ -269,6 +270,10 @@ def test_one_launch_decoder_with_attention_layer_and_monotonic_normaliser_matche
     split of the score phase changes the fp32 summation order of nothing, but the attention layer's K chunks are summed per
     wave): logits within 2e-3 of the largest, saved p_choose / alignments within 1e-3, gradients within 1e-2 of each tensor's
     largest.  And both against the fixture (the case's own test)."""
+    # parts: the one-launch backward with four workgroups per utterance (three take quarters of the query path and of the two
+    # products off the one that walks the chain; the default where it fits) or with one (LAS_DEC_SEQ_PARTS=1: d(keys) of all
+    # frames in one workgroup's registers)
+    monkeypatch.setenv('LAS_DEC_SEQ_PARTS', parts)
     outs = {}
     for flag in ('1', '0'):
         monkeypatch.setenv('LAS_DEC_PERSIST_AL', flag)
