@@ -355,18 +355,19 @@ class GeneralSpeller:
         sampling = float(self.hp.sampling_probability or 0.0)
         sv = dict(B=B, Tm=Tm, U=U, memory=memory, mem_len=mem_len, keys=keys, passed=passed, tin=targets_inputs,
                   keep=keep, seed=seed)
-        sv['X'] = [torch.zeros(B, U, w + Hd, dtype=bf, device=dev) for w in self.win]
+        sv['X'] = [torch.empty(B, U, w + Hd, dtype=bf, device=dev) for w in self.win]
         sv['gates'] = [torch.empty(B, U, 4 * Hd, dtype=f32, device=dev) for _ in range(NL)]
         sv['cs'] = [torch.empty(B, U + 1, Hd, dtype=f32, device=dev) for _ in range(NL)]
         sv['h'] = [torch.empty(B, U, Hd, dtype=bf, device=dev) for _ in range(NL)]
-        sv['align'] = torch.zeros(B, U, Tmp, dtype=f32, device=dev)
-        sv['align_bf'] = torch.zeros(B, U, Tmp, dtype=bf, device=dev)
+        sv['align'] = torch.empty(B, U, Tmp, dtype=f32, device=dev)
+        sv['align_bf'] = torch.empty(B, U, Tmp, dtype=bf, device=dev)
         sv['ctx'] = torch.empty(B, U, M, dtype=bf, device=dev)
         sv['pq'] = torch.empty(B, U, Hd, dtype=f32, device=dev) if self.uses_wq else None
         sv['norm'] = self._norm(True)
         if self.mono:                    # p_choose of every step (backward), sigmoid_noise = 1 for bahdanau_monotonic TRAIN
-            sv['p'] = torch.zeros(B, U, Tmp, dtype=f32, device=dev)
+            sv['p'] = torch.empty(B, U, Tmp, dtype=f32, device=dev)
             sv['noise_scale'] = 1.0 if self.att == hip.ATT_BAHDANAU_MONOTONIC else 0.0
+        hip.fill_many(zero=sv['X'] + [sv['align'], sv['align_bf']] + ([sv['p']] if self.mono else []))    # one launch, not one per buffer
         sv['att'] = torch.empty(B, U, A, dtype=bf, device=dev) if self.has_al else sv['ctx']
         sv['qc'] = torch.empty(B, U, Hd + M, dtype=bf, device=dev) if self.has_al else None
         for l in range(NL):
@@ -617,21 +618,22 @@ class GeneralSpeller:
         hip.gemm_nt(dlogits, self.wproj, d_out, BU, P, Vop, lda=Vop, ldb=Vop, ldc=P)
         if sv.get('dreg') is not None:       # gradient of compute_log_probs_loss w.r.t. the raw outputs (binf_projection)
             d_out.add_(sv['dreg'])
-        dc = [torch.zeros(B, Hd, dtype=f32, device=dev) for _ in range(NL)]
-        dx = [[torch.zeros(B, w + Hd, dtype=f32, device=dev) for _ in range(2)] for w in self.win]
+        dc = [torch.empty(B, Hd, dtype=f32, device=dev) for _ in range(NL)]
+        dx = [[torch.empty(B, w + Hd, dtype=f32, device=dev) for _ in range(2)] for w in self.win]
         dz = [torch.empty(B, U, 4 * Hd, dtype=bf, device=dev) for _ in range(NL)]
-        ds_all = torch.zeros(B, U, Tmp, dtype=bf, device=dev)
+        ds_all = torch.empty(B, U, Tmp, dtype=bf, device=dev)
         dctx_all = torch.empty(B, U, M, dtype=bf, device=dev)
         datt = torch.empty(B, A, dtype=f32, device=dev)
         datt_bf = torch.empty(B, U, A, dtype=bf, device=dev) if self.has_al else None
         dqc = torch.empty(B, Hd + M, dtype=f32, device=dev) if self.has_al else None
         dq = torch.empty(B, Hd, dtype=f32, device=dev)
         if bah:
-            dkeys = torch.zeros(B, Tm, Hd, dtype=f32, device=dev)
+            dkeys = torch.empty(B, Tm, Hd, dtype=f32, device=dev)
         if self.uses_wq:
             dpq_all = torch.empty(B, U, Hd, dtype=bf, device=dev)
         if self.mono:                    # gradient into align_{t-1} through step t's normaliser
-            carry = torch.zeros(B, Tmp, dtype=f32, device=dev)
+            carry = torch.empty(B, Tmp, dtype=f32, device=dev)
+        hip.fill_many(zero=dc + [x for pair in dx for x in pair] + [ds_all] + ([dkeys] if bah else []) + ([carry] if self.mono else []))
         qlayer = 0 if self.bottom else NL - 1
         W = [w + Hd for w in self.win]
         dtokx = torch.empty(B, U, self.Ep, dtype=bf, device=dev) if (self.tokx and (self.feat is None or self.binf_var is not None) and not self.sigmoid) else None
