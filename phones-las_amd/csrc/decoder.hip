@@ -1550,6 +1550,43 @@ __global__ __launch_bounds__(256) void dec_persist_fwd_lean_kernel(las_dec_persi
         lds_barrier();
       }
       // ---- raw scores of my frames ----
+      if constexpr (ATT == LAS_ATT_BAHDANAU && NTL == 4) {
+        // 512 units: SIXTEEN lanes per frame (4 frames per wave, 16 per pass).  With four, the 25 own frames of a T' = 100
+        // utterance kept 100 lanes busy with 128 tanh each -- 4.7 of the 7 us of this phase; now 64 tanh on every lane.
+        constexpr int LPF = 16, NKL = NK * 4 / LPF;
+        const int sub16 = lane & (LPF - 1), fr16 = lane / LPF;
+        for (int fl0 = 0; fl0 < fq; fl0 += 4 * (64 / LPF)) {
+          const int fl = fl0 + wave * (64 / LPF) + fr16, tf = f0 + fl;
+          float acc = 0.f, acc1 = 0.f;
+          if (tf < flen) {
+            const lds_cu16 krow = (lds_cu16)lk + (size_t)fl * KST + sub16 * 8;
+            uint4 kv[NKL];
+#pragma unroll
+            for (int j = 0; j < NKL; ++j) kv[j] = ld16(krow + j * 8 * LPF);
+#pragma unroll
+            for (int j = 0; j < NKL; ++j) {
+              const uint4 kk = kv[j];
+              const int k = sub16 * 8 + j * 8 * LPF;
+              const float4 q0 = *reinterpret_cast<const float4*>(pq + k), q1 = *reinterpret_cast<const float4*>(pq + k + 4);
+              const float4 v0 = *reinterpret_cast<const float4*>(vq + k), v1 = *reinterpret_cast<const float4*>(vq + k + 4);
+              const float a0 = v0.x * las_tanh(__uint_as_float(kk.x << 16) + q0.x) + v0.y * las_tanh(__uint_as_float(kk.x & 0xffff0000u) + q0.y);
+              const float a1 = v0.z * las_tanh(__uint_as_float(kk.y << 16) + q0.z) + v0.w * las_tanh(__uint_as_float(kk.y & 0xffff0000u) + q0.w);
+              const float a2 = v1.x * las_tanh(__uint_as_float(kk.z << 16) + q1.x) + v1.y * las_tanh(__uint_as_float(kk.z & 0xffff0000u) + q1.y);
+              const float a3 = v1.z * las_tanh(__uint_as_float(kk.w << 16) + q1.z) + v1.w * las_tanh(__uint_as_float(kk.w & 0xffff0000u) + q1.w);
+              if (j & 1) acc1 += (a0 + a1) + (a2 + a3);
+              else acc += (a0 + a1) + (a2 + a3);
+            }
+          }
+          acc += acc1;
+#pragma unroll
+          for (int o = 1; o < LPF; o <<= 1) acc += __shfl_xor(acc, o, 64);
+          if (sub16 == 0 && fl < fq && tf < f1) {
+            const float sv = (tf < len) ? acc : -INFINITY;
+            pgranule_store(xsc + tf, xtag, sv, local);     // the other three parts are waiting for it
+            sc[tf] = sv;
+          }
+        }
+      } else
       {
         uint4 qreg[ATT == LAS_ATT_LUONG ? NK : 1];
         if (ATT == LAS_ATT_LUONG) {
@@ -1558,7 +1595,7 @@ __global__ __launch_bounds__(256) void dec_persist_fwd_lean_kernel(las_dec_persi
         }
         for (int fl0 = 0; fl0 < fq; fl0 += 64) {
           const int fl = fl0 + wave * 16 + fr, tf = f0 + fl;
-          float acc = 0.f;
+          float acc = 0.f, acc1 = 0.f;
           if (tf < flen) {
             const lds_cu16 krow = (lds_cu16)lk + (size_t)fl * KST + sub * 8;
             uint4 kv[NK];
@@ -1573,14 +1610,22 @@ __global__ __launch_bounds__(256) void dec_persist_fwd_lean_kernel(las_dec_persi
                   acc = dot2_bf16(kv[j].z, qreg[j].z, acc);
                   acc = dot2_bf16(kv[j].w, qreg[j].w, acc);
                 } else {
-                  const unsigned short* e = reinterpret_cast<const unsigned short*>(&kv[j]);
+                  // (pq and attention_v as 16-byte LDS reads, the pieces on two running sums: as scalar reads each pair was
+                  //  waited for before its two tanh -- see score_additive_rows)
+                  const uint4 kk = kv[j];
                   const int k = sub * 8 + j * 32;
-#pragma unroll
-                  for (int i = 0; i < 8; ++i) acc += vq[k + i] * las_tanh(las_bf2f(e[i]) + pq[k + i]);
+                  const float4 q0 = *reinterpret_cast<const float4*>(pq + k), q1 = *reinterpret_cast<const float4*>(pq + k + 4);
+                  const float4 v0 = *reinterpret_cast<const float4*>(vq + k), v1 = *reinterpret_cast<const float4*>(vq + k + 4);
+                  const float a0 = v0.x * las_tanh(__uint_as_float(kk.x << 16) + q0.x) + v0.y * las_tanh(__uint_as_float(kk.x & 0xffff0000u) + q0.y);
+                  const float a1 = v0.z * las_tanh(__uint_as_float(kk.y << 16) + q0.z) + v0.w * las_tanh(__uint_as_float(kk.y & 0xffff0000u) + q0.w);
+                  const float a2 = v1.x * las_tanh(__uint_as_float(kk.z << 16) + q1.x) + v1.y * las_tanh(__uint_as_float(kk.z & 0xffff0000u) + q1.y);
+                  const float a3 = v1.z * las_tanh(__uint_as_float(kk.w << 16) + q1.z) + v1.w * las_tanh(__uint_as_float(kk.w & 0xffff0000u) + q1.w);
+                  if (j & 1) acc1 += (a0 + a1) + (a2 + a3);
+                  else acc += (a0 + a1) + (a2 + a3);
                 }
               }
           }
-          acc = las_quad_sum(acc);
+          acc = las_quad_sum(acc + acc1);
           if (sub == 0 && fl < fq && tf < f1) {
             const float sv = (tf < len) ? acc : -INFINITY;
             pgranule_store(xsc + tf, xtag, sv, local);     // the other three parts are waiting for it
