@@ -1259,6 +1259,9 @@ __global__ __launch_bounds__(256) void dec_persist_fwd_lean_kernel(las_dec_persi
   }
   __syncthreads();
   const bool local = *colo != 0;
+#ifdef LAS_STAMPS
+  if (tid == 0 && (blockIdx.x % 37) == 0) atomicAdd(&las_stamps[255 * 16 + (local ? 15 : 14)], 1ull);   // diagnostics: groups on one XCD / not
+#endif
 
   // G role: this member's columns of z and its register-resident slice of K ([4Hd, K_in] bf16, row = output column)
   constexpr int CPM = NTL * 16;
@@ -1352,7 +1355,11 @@ __global__ __launch_bounds__(256) void dec_persist_fwd_lean_kernel(las_dec_persi
     constexpr int NS = KCWM - KRES, SD = 4;
     uint4 sa[NS > 0 ? SD : 1], sw[NS > 0 ? SD : 1][NTL];
     auto stream_issue = [&](int slot, int i) {              // i: chunk index of this wave (KRES ...)
+#ifdef LEAN_STREAM_SAME                                      // (diagnostics: every streamed chunk re-reads the first one -- wrong results, L1 hits)
+      const int kcc = min(wave + 4 * KRES, KC - 1) + 0 * i;
+#else
       const int kcc = min(wave + 4 * i, KC - 1);
+#endif
       sa[slot] = *reinterpret_cast<const uint4*>(arow + kcc * astep);
 #pragma unroll
       for (int nt = 0; nt < NTL; ++nt) sw[slot][nt] = *reinterpret_cast<const uint4*>(wrow[nt] + kcc * 32);

@@ -33,3 +33,5 @@ st = buf.reshape(512, 16)[0:U].astype(np.int64)
 if st[5:, 11].any():
     print('forward G role: operands + resident products %.2f us, streamed chunks %.2f us, partial sums to LDS %.2f us' % (
         ((st[5:-1, 11] - st[5:-1, 0]) / 100.0).mean(), ((st[5:-1, 12] - st[5:-1, 11]) / 100.0).mean(), ((st[5:-1, 1] - st[5:-1, 12]) / 100.0).mean()))
+loc = buf.reshape(512, 16)[255]
+print('lean forward kernel, sampled workgroups whose group sits on one XCD: %d, spread over XCDs: %d (counts over all launches)' % (int(loc[15]), int(loc[14])))
