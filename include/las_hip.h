@@ -143,13 +143,14 @@ int las_cast_bf16(const float* src, int64_t lds, int rows, int cols, las_bf16* d
  *   LAS_IMAGE_PACK_RECURRENT  las_lstm_pack_recurrent: src = K_h (ld 4H), rows = H, dst = packed image;
  *   LAS_IMAGE_BIAS_INTERLEAVE fp32 dst[u*4+g] = src[g*H+u], rows = H (the LSTM bias in the recurrent kernels' order);
  *   LAS_IMAGE_COPY_F32        fp32 dst[0:cols] = src[0:cols];
+ *   LAS_IMAGE_PACK_INPUT      las_lstm_pack_input: src = kernel (ld 4H), rows = D, cols = H, dst_rows = chunks, dst = packed image;
  *   LAS_IMAGE_PACK_MFMA_B     bf16 image of src [rows, cols] (row stride lds) in matrix-core B-fragment order, zero padded to
  *                             dst_rows (multiple of 16) x dst_cols (multiple of 32): [dst_rows / 16][dst_cols / 32][64 lanes][8]
  *                             with lane l = row tile * 16 + (l & 15), columns chunk * 32 + (l >> 4) * 8 + 0..7 -- every
  *                             fragment one contiguous KB (rows 2^k bytes apart all land on one L2 channel otherwise);
  *                             transpose = 1: the image of src^T (src is [cols, rows], row stride lds). */
 enum las_image_kind { LAS_IMAGE_CAST = 0, LAS_IMAGE_PACK_RECURRENT = 1, LAS_IMAGE_BIAS_INTERLEAVE = 2, LAS_IMAGE_COPY_F32 = 3,
-                      LAS_IMAGE_PACK_MFMA_B = 4 };
+                      LAS_IMAGE_PACK_MFMA_B = 4, LAS_IMAGE_PACK_INPUT = 5 };
 typedef struct las_image_job {
   const float* src;
   void* dst;
@@ -220,12 +221,30 @@ int las_lstm_recurrent_fwd(float* xproj, const las_bf16* wpacked, const int32_t*
                            float* cbuf, float* c_last, float* h_last, void* workspace, int B, int T, int H,
                            int ndir, void* stream);
 
-/* Bytes of device scratch the two recurrent kernels need for (B, H, ndir): a status word plus the
+/* The forward recurrence WITH the input projection (round 4; the bottom listener layer, las/ops.py:35-46 over the features):
+ * x [B,T,ldx] bf16 (direction d reads x + d * x_dir_stride elements: 0 when both directions read the same input, the copy
+ * stride when each has its own input-dropout mask), Dp = its valid width (multiple of 8, the columns from the layer's D on
+ * zero), kx_packed = ndir images of las_lstm_pack_input, bias [ndir*4H] fp32 gate-interleaved.  z_t = x_t K_x + b + h_{t-1} K_h
+ * is formed inside the step (the x products are issued while the step waits for its peers' h), so no las_gemm_nt and no
+ * [B,T,ndir*4H] fp32 round trip precede the launch; `gates` is output only.  Supported when las_lstm_fused_input_chunks(H, Dp)
+ * > 0 (H in {128, 256, 512}, Dp <= 96); everything else as las_lstm_recurrent_fwd. */
+int las_lstm_fused_input_chunks(int H, int Dp);
+/* K_x = kernel[0:D, :] (fp32, ld 4H) of one direction -> the fragment-major bf16 image over `chunks` (=
+ * las_lstm_fused_input_chunks) 32-deep K chunks, (H/16) * chunks * 4 * 512 elements, zero from row D on. */
+int las_lstm_pack_input(const float* kernel, int D, int H, int chunks, las_bf16* packed, void* stream);
+int las_lstm_recurrent_fwd_x(const las_bf16* x, int64_t ldx, int64_t x_dir_stride, int Dp, const las_bf16* kx_packed,
+                             const float* bias, float* gates, const las_bf16* wpacked, const int32_t* length,
+                             las_bf16* y, float* cbuf, float* c_last, float* h_last, void* workspace, int B, int T,
+                             int H, int ndir, void* stream);
+
+/* Bytes of device scratch the two recurrent kernels need for (B, H, ndir): a 64-byte header plus the
  * inter-workgroup exchange buffer of the cooperating groups (0 = unsupported num_units).  The caller
- * hands it over zeroed once; each call zeroes the exchange part itself (a memset node per launch) and leaves the
- * 64-byte status header alone: its first uint32 is STICKY -- a launch ORs a bit into it when a bounded
- * inter-workgroup wait timed out (results of that launch are invalid), and only the host clears it after reading
- * it (one workspace serves every layer, forward and backward: see las_status_collect). */
+ * hands it over ZEROED ONCE, when it allocates it, and otherwise leaves it alone; the launches keep it consistent
+ * themselves (round 4: no memset node per launch -- every tag in the exchange buffer is offset by a launch base kept in
+ * header word 4, which the last workgroup of a launch moves past all tags of that launch, so what earlier launches left
+ * behind can never satisfy a wait; one launch at a time per workspace).  The header's first uint32 is STICKY -- a launch
+ * ORs a bit into it when a bounded inter-workgroup wait timed out (results of that launch are invalid), and only the host
+ * clears it after reading it (one workspace serves every layer, forward and backward: see las_status_collect). */
 size_t las_lstm_workspace_bytes(int B, int H, int ndir);
 /* Utterances per slice the recurrent kernels will use for this shape (16 = full MFMA tiles; 8 = half-filled tiles on
  * twice as many chains, chosen for 256 units while every chain and its prefetch companion still find a CU each: the
@@ -244,6 +263,9 @@ int las_lstm_recurrent_bwd(const float* gates, const float* cbuf, const float* d
 
 /* len_out[b] = len[b]/2 + len[b]%2  (las/ops.py:65 pyramidal_stack). */
 int las_pyramid_lengths(const int32_t* len_in, int32_t* len_out, int B, void* stream);
+/* The lengths after 1, 2, ..., levels stackings in one launch: len_out [levels, B] (the listener asks for all of them before
+ * its first layer, so that no tiny launch sits between a layer's recurrence and the next layer's input product). */
+int las_pyramid_lengths_multi(const int32_t* len_in, int32_t* len_out, int B, int levels, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Speller step kernels: AttentionWrapper(LSTMCell, Luong|Bahdanau) of las/model.py:145-202

@@ -83,6 +83,14 @@ __global__ __launch_bounds__(256) void refresh_images_kernel(const las_image_job
       // (transpose: the image of the source's transpose -- row n of the product's B operand is COLUMN n of src [cols, rows])
       dst[i] = las_f2bf(n < jb.rows && k < jb.cols ? (jb.transpose ? jb.src[(int64_t)k * jb.lds + n] : jb.src[(int64_t)n * jb.lds + k]) : 0.f);
     }
+  } else if (jb.kind == LAS_IMAGE_PACK_INPUT) {
+    unsigned short* dst = static_cast<unsigned short*>(jb.dst);
+    const int D = jb.rows, H = jb.cols, chunks = jb.dst_rows;
+    const int64_t total = (int64_t)(H / 16) * chunks * 4 * 512;
+    for (int64_t i = first; i < total; i += stride) {
+      const int64_t src = las_pack_input_src(i, D, H, chunks);
+      dst[i] = las_f2bf(src >= 0 ? jb.src[src] : 0.f);
+    }
   } else {                                                  // LAS_IMAGE_COPY_F32
     float* dst = static_cast<float*>(jb.dst);
     for (int64_t i = first; i < jb.cols; i += stride) dst[i] = jb.src[i];
@@ -239,9 +247,14 @@ __global__ __launch_bounds__(256) void colsum_ws8_kernel(const unsigned short* X
   if (threadIdx.x == 0) counters[blockIdx.x] = 0u;
 }
 
-__global__ void pyramid_len_kernel(const int32_t* a, int32_t* b, int B) {
+__global__ void pyramid_len_kernel(const int32_t* a, int32_t* b, int B, int levels) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < B) b[i] = a[i] / 2 + a[i] % 2;
+  if (i >= B) return;
+  int v = a[i];
+  for (int l = 0; l < levels; ++l) {          // level l: l + 1 stackings
+    v = v / 2 + v % 2;
+    b[(int64_t)l * B + i] = v;
+  }
 }
 
 }  // namespace
@@ -343,7 +356,14 @@ extern "C" int las_colsum_bf16_ws(const las_bf16* X, int64_t ldx, int M, int N, 
 
 extern "C" int las_pyramid_lengths(const int32_t* len_in, int32_t* len_out, int B, void* stream) {
   LAS_REQUIRE(B > 0, "las_pyramid_lengths: B must be positive");
-  hipLaunchKernelGGL(pyramid_len_kernel, dim3((B + 255) / 256), dim3(256), 0, (hipStream_t)stream, len_in, len_out, B);
+  hipLaunchKernelGGL(pyramid_len_kernel, dim3((B + 255) / 256), dim3(256), 0, (hipStream_t)stream, len_in, len_out, B, 1);
+  LAS_LAUNCH_CHECK("pyramid launch");
+  return LAS_OK;
+}
+
+extern "C" int las_pyramid_lengths_multi(const int32_t* len_in, int32_t* len_out, int B, int levels, void* stream) {
+  LAS_REQUIRE(B > 0 && levels > 0 && levels <= 16, "las_pyramid_lengths_multi: B > 0, 1..16 levels");
+  hipLaunchKernelGGL(pyramid_len_kernel, dim3((B + 255) / 256), dim3(256), 0, (hipStream_t)stream, len_in, len_out, B, levels);
   LAS_LAUNCH_CHECK("pyramid launch");
   return LAS_OK;
 }

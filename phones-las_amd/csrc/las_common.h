@@ -123,3 +123,17 @@ __device__ __forceinline__ int64_t las_pack_recurrent_src(int64_t i, int H) {
   const int col = g * H + ublk * 16 + (lane & 15);
   return (int64_t)k * 4 * H + col;
 }
+
+// Fragment-major image of K_x = kernel[0:D, :] over `chunks` 32-deep K chunks (las_lstm_pack_input): element i comes from
+//   K_x[k][g*H + ublk*16 + (lane&15)],  k = kc*32 + 8*(lane>>4) + j,  i = (((ublk*chunks + kc)*4 + g)*64 + lane)*8 + j,
+// and is zero for k >= D.  Returns the source index, or -1 for the zero padding.
+__device__ __forceinline__ int64_t las_pack_input_src(int64_t i, int D, int H, int chunks) {
+  int64_t r = i;
+  const int j = (int)(r % 8); r /= 8;
+  const int lane = (int)(r % 64); r /= 64;
+  const int g = (int)(r % 4); r /= 4;
+  const int kc = (int)(r % chunks); r /= chunks;
+  const int ublk = (int)r;
+  const int k = kc * 32 + 8 * (lane >> 4) + j;
+  return k < D ? (int64_t)k * 4 * H + g * H + ublk * 16 + (lane & 15) : -1;
+}

@@ -15,8 +15,11 @@
 // columns with its rows of K_h^T and the partial dh tiles are reduce-scattered to their owners.  Inside a
 // member data goes through a double-buffered LDS tile (one LDS-only barrier per step); between members
 // through 8-byte {tag, payload} granules in a global exchange buffer: the data is its own flag
-// (cdna_hip_programming.md Guideline 16, form R2), tag = step epoch, buffer zeroed by a memset node at
-// every launch, two parity slots so a fast member cannot overwrite what a slow one still reads.  Loads are
+// (cdna_hip_programming.md Guideline 16, form R2), tag = LAUNCH BASE + step epoch, two parity slots so a fast member
+// cannot overwrite what a slow one still reads.  The launch base lives in the workspace header and is advanced past every
+// tag of the launch by the LAST workgroup to leave (launch_arrive below): whatever earlier launches left in the buffer
+// carries smaller tags and can never satisfy a poll, so the buffer is zeroed once, by the caller, when it is allocated --
+// not by a memset node in front of every launch (round 4: six nodes and their launch gaps per train step).  Loads are
 // agent-scope relaxed atomics (L1-bypassing); stores are write-through agent-scope atomics, or plain stores
 // once the members have established that they share an XCD (then its L2 is the coherence point).
 // Results never depend on workgroup placement; blocks in chunks of 8 groups (block = chunk*8G + member*8 + group%8) only make the members of a
@@ -62,27 +65,58 @@ __device__ __forceinline__ u64 granule_load(const u64* p) {
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// Launch epochs (round 4).  Workspace header (the 64 bytes in front of the exchange buffer), as 32-bit words: [0] sticky
+// timeout status, [1], [2] diagnostics counters, [4] EPOCH BASE of the next launch, [5] arrival counter.  Every tag a
+// launch writes is base + k with 1 <= k <= T + 1; every workgroup of the grid -- members, companions, the idle blocks of a
+// rounded-up grid -- calls launch_arrive() on its way out, and the last one moves the base past this launch's tags.  All of
+// them have read the base by then (they read it first and only arrive when they are done), so the members of a group
+// always agree on it.  Before the 32-bit tags could wrap, the last workgroup clears the exchange buffer and starts the base
+// over from zero (once in about two million launches).
+constexpr int HDR_BASE = 4, HDR_ARRIVE = 5;
+__device__ __forceinline__ unsigned launch_base(const unsigned* status) {
+  return __hip_atomic_load(status + HDR_BASE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void launch_arrive(unsigned* status, unsigned base, int T, u64* exch, long long exch_words) {
+  __shared__ int last_one;
+  __syncthreads();                                   // every thread of this workgroup is done with the exchange
+  if (threadIdx.x == 0) {
+    const unsigned n = atomicAdd(status + HDR_ARRIVE, 1u);
+    last_one = (n == gridDim.x - 1) ? 1 : 0;
+  }
+  __syncthreads();
+  if (!last_one) return;
+  const unsigned next = base + (unsigned)T + 2u;
+  const bool wrap = next >= 0x7ff00000u;
+  if (wrap)
+    for (long long i = threadIdx.x; i < exch_words; i += blockDim.x) exch[i] = 0;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __hip_atomic_store(status + HDR_ARRIVE, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(status + HDR_BASE, wrap ? 0u : next, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
 // Do all G members of this group sit on one XCD?  Each member publishes its XCC id with the placement-independent
 // write-through store, then reads everybody's.  Purely a speed decision: the result only selects the store flavour.
 // Call from all threads; returns the same value in every thread of the workgroup (fail -> false).
 template <int G>
-__device__ bool xcd_colocated(u64* table, int member, int* lds_flag, unsigned* status) {
+__device__ bool xcd_colocated(u64* table, int member, int* lds_flag, unsigned* status, unsigned base) {
   if (G == 1) return false;
   if (threadIdx.x == 0) {
     unsigned xcc;
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
     xcc &= 0xf;
-    __hip_atomic_store(table + member, ((u64)1 << 32) | (xcc + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(table + member, ((u64)(base + 1u) << 32) | (xcc + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     bool same = true;
     for (int m = 0; m < G; ++m) {
       u64 v = 0;
       unsigned spins = 0;
       do {
         v = __hip_atomic_load(table + m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if ((v >> 32) == 1) break;
+        if ((unsigned)(v >> 32) == base + 1u) break;
         __builtin_amdgcn_s_sleep(2);
       } while (++spins < (1u << 20));
-      same = same && ((v >> 32) == 1) && ((unsigned)v == xcc + 1);
+      same = same && ((unsigned)(v >> 32) == base + 1u) && ((unsigned)v == xcc + 1);
     }
     *lds_flag = same ? 1 : 0;
     atomicAdd(status + (same ? 1 : 2), 1u);      // diagnostics: members that took the local / the fabric flavour
@@ -112,6 +146,16 @@ __global__ void pack_recurrent_kernel(const float* kh, int H, unsigned short* pa
     packed[i] = las_f2bf(kh[las_pack_recurrent_src(i, H)]);
 }
 
+// K_x = kernel[0:D, :] (fp32, ld 4H) -> the same fragment-major image over `chunks` 32-deep K chunks, zero from row D on:
+//   packed[(((ublk*chunks + kc)*4 + g)*64 + lane)*8 + j] = K_x[kc*32 + 8*(lane>>4) + j][g*H + ublk*16 + (lane&15)]
+__global__ void pack_input_kernel(const float* kx, int D, int H, int chunks, unsigned short* packed) {
+  const int64_t total = (int64_t)(H / 16) * chunks * 4 * 512;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t src = las_pack_input_src(i, D, H, chunks);
+    packed[i] = las_f2bf(src >= 0 ? kx[src] : 0.f);
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 // forward
 // ------------------------------------------------------------------------------------------------
@@ -121,13 +165,26 @@ __global__ void pack_recurrent_kernel(const float* kh, int H, unsigned short* pa
 // ROWS = utterances per slice: 16 fills the MFMA tile; 8 (rows 0,1 of every quad; the other two stay zero) halves the
 // element-wise work, the exchange and the HBM accesses of every lane at the same MFMA cost -- the per-step latency is
 // mostly that work, so small batches run twice as many (half-filled) chains on otherwise idle CUs.
-template <int H, int ROWS, int G = coop_members(H)>
-__global__ __launch_bounds__(256) void lstm_fwd_kernel(float* __restrict__ xproj, const unsigned short* __restrict__ wpacked,
-                                                       const int32_t* __restrict__ length, unsigned short* __restrict__ y,
-                                                       float* __restrict__ cbuf, float* __restrict__ c_last,
-                                                       float* __restrict__ h_last, u64* __restrict__ exch,
-                                                       unsigned* __restrict__ status, int B, int T, int ndir, int ngroups,
-                                                       int companions) {
+// KX > 0 (round 4): the INPUT projection x_t K_x + b is formed inside the step as well -- KX 32-deep chunks of the input width,
+// K_x register-resident as B fragments (las_lstm_pack_input), x_t as A fragments straight from the [B, T, Dp] bf16 features
+// (loaded one step ahead; the companion keeps the rows L2-resident).  These products do not depend on h_{t-1}: they are issued
+// at the top of the step and run while the peers' granules are on their way, so the bottom listener layer needs no x K_x GEMM,
+// no 419 MB fp32 round trip of its result, and the chain no xproj load.  `xproj` is then only the saved-gates OUTPUT.
+struct FusedInput {
+  const unsigned short* x;       // [B, T, ldx] bf16 (per direction: + dir * xdir elements)
+  int64_t ldx, xdir;
+  const unsigned short* kxp;     // ndir images of las_lstm_pack_input
+  const float* bias;             // [ndir * 4H] gate-interleaved
+  int Dp;                        // valid input columns (multiple of 8, <= 32 * KX)
+};
+
+template <int H, int ROWS, int G, int KX>
+__device__ __forceinline__ void lstm_fwd_body(float* __restrict__ xproj, const unsigned short* __restrict__ wpacked,
+                                              const int32_t* __restrict__ length, unsigned short* __restrict__ y,
+                                              float* __restrict__ cbuf, float* __restrict__ c_last,
+                                              float* __restrict__ h_last, u64* __restrict__ exch,
+                                              unsigned* __restrict__ status, int B, int T, int ndir, int ngroups,
+                                              int companions, const FusedInput fi, const unsigned base) {
   constexpr int HS = H / G;            // units per member
   constexpr int KS = k_split_g(H, G);  // ways the K dimension is split over waves
   constexpr int NUB = HS / 16;         // 16-unit blocks of this member
@@ -210,8 +267,8 @@ __global__ __launch_bounds__(256) void lstm_fwd_kernel(float* __restrict__ xproj
       unsigned spins = 0;
       while (seen < sp - PF_AHEAD) {
         const u64 v0 = granule_load(tag0), v1 = granule_load(tag0 + par_stride), dn = granule_load(done_word);
-        if (dn != 0) return;                                      // the compute workgroups are done (or failed)
-        seen = (int)max((unsigned)(v0 >> 32), (unsigned)(v1 >> 32)) - 1;
+        if ((unsigned)(dn >> 32) == base + 1u) return;            // the compute workgroups are done (or failed)
+        seen = max(max((int)((unsigned)(v0 >> 32) - base), (int)((unsigned)(v1 >> 32) - base)), 0) - 1;   // (older launches' tags: <= base)
         if (seen < sp - PF_AHEAD) {
           if (++spins > SPIN_LIMIT) return;
           __builtin_amdgcn_s_sleep(8);
@@ -223,11 +280,19 @@ __global__ __launch_bounds__(256) void lstm_fwd_kernel(float* __restrict__ xproj
         const int ll = __builtin_amdgcn_readlane(mylen, rr);
         if (sp < ll) {
           const int pos = dir == 0 ? sp : ll - 1 - sp;
-          const float* src = xproj + ((int64_t)(slice * ROWS + rr) * T + pos) * xrow + dir * 4 * H + cm * (4 * H / CPG) + lane * 4;
+          if constexpr (KX > 0) {
+            // fused input projection: the step reads the feature row itself (Dp bf16: one dword per lane)
+            const unsigned short* src = fi.x + dir * fi.xdir + ((int64_t)(slice * ROWS + rr) * T + pos) * fi.ldx + lane * 2;
+            if (cm == 0 && lane * 2 < fi.Dp)
+              __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src),
+                                               (__attribute__((address_space(3))) void*)(pf_scratch), 4, 0, 0);
+          } else {
+            const float* src = xproj + ((int64_t)(slice * ROWS + rr) * T + pos) * xrow + dir * 4 * H + cm * (4 * H / CPG) + lane * 4;
 #pragma unroll
-          for (int c4 = 0; c4 < H / 64 / CPG; ++c4)               // this companion's share of the 4H floats in 1-KiB pieces
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + c4 * 256),
-                                             (__attribute__((address_space(3))) void*)(pf_scratch), 16, 0, 0);
+            for (int c4 = 0; c4 < H / 64 / CPG; ++c4)               // this companion's share of the 4H floats in 1-KiB pieces
+              __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + c4 * 256),
+                                               (__attribute__((address_space(3))) void*)(pf_scratch), 16, 0, 0);
+          }
         }
       }
     }
@@ -255,6 +320,24 @@ __global__ __launch_bounds__(256) void lstm_fwd_kernel(float* __restrict__ xproj
         wf[ub][kc][g] = *reinterpret_cast<const bf16x8*>(wpacked + (int64_t)dir * H * 4 * H +
                                                           ((int64_t)((ublk * KC + kh * KCW + kc) * 4 + g) * 64 + lane) * 8);
   }
+  // fused input projection: this wave's K_x columns as B fragments, the bias of this lane's unit(s)
+  constexpr int KXA = KX > 0 ? KX : 1;
+  bf16x8 wx[UB][KXA][4];
+  float4 bz[UB];
+  if constexpr (KX > 0) {
+    static_assert(KS == 1, "fused input projection: not with the K split");
+#pragma unroll
+    for (int ub = 0; ub < UB; ++ub) {
+      const int ublk = member * NUB + wblk + ub;
+#pragma unroll
+      for (int kc = 0; kc < KX; ++kc)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+          wx[ub][kc][g] = *reinterpret_cast<const bf16x8*>(fi.kxp + (int64_t)dir * (H / 16) * KX * 4 * 512 +
+                                                            ((int64_t)((ublk * KX + kc) * 4 + g) * 64 + lane) * 8);
+      bz[ub] = *reinterpret_cast<const float4*>(fi.bias + dir * 4 * H + (member * HS + (wblk + ub) * 16 + l15) * 4);
+    }
+  }
   __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0): the weights are in registers before the time loop, not waited for inside it
   // More than 128 weight registers (512 units as 8 members: 256) do not fit the 256 architectural VGPRs next to the step's
   // own values.  Left to itself the allocator keeps such weights in AccVGPRs as SPILLS and copies them back through
@@ -278,7 +361,7 @@ __global__ __launch_bounds__(256) void lstm_fwd_kernel(float* __restrict__ xproj
   for (int i = tid; i < 2 * 16 * LS; i += 256) (&hlds[0][0][0])[i] = 0;
   if (tid == 0) fail_flag = 0;
   __syncthreads();
-  const bool local = xcd_colocated<G>(exch + 2 * par_stride + (int64_t)group * G, member, &colo_flag, status);
+  const bool local = xcd_colocated<G>(exch + 2 * par_stride + (int64_t)group * G, member, &colo_flag, status, base);
 
   const int unit0 = member * HS + wblk * 16 + l15;            // + ub*16
 
@@ -302,6 +385,29 @@ __global__ __launch_bounds__(256) void lstm_fwd_kernel(float* __restrict__ xproj
     xoff[r] = (unsigned)((((int64_t)bidx[r] * T + pos) * xrow + dir * 4 * H + unit0 * 4) * 4);
   }
   const int xstep = (dir == 0 ? 1 : -1) * (int)(xrow * 4);
+  // fused input projection: A fragments of x_t.  A row a of the tile = C row a = utterance (a >> 2) * RL + (a & 3) of the slice
+  // (rows with (a & 3) >= RL are padding: they read utterance 0 of the slice, their products are never looked at); lane
+  // (l15 = a, lq) holds columns kc * 32 + 8 * lq .. + 8 -- clamped into the row: K_x's image is zero from row D on.
+  bf16x8 xa[KXA];
+  int xa_len = 0, xa_b = 0;
+  unsigned xa_col[KXA];
+  const char* xa_base = nullptr;
+  int xa_step = 0;
+  unsigned xa_off = 0;
+  if constexpr (KX > 0) {
+    const bool valid = (l15 & 3) < RL && slice * ROWS + (l15 >> 2) * RL + (l15 & 3) < B;
+    xa_b = valid ? slice * ROWS + (l15 >> 2) * RL + (l15 & 3) : slice * ROWS;
+    xa_len = valid ? min(length[xa_b], T) : 0;
+#pragma unroll
+    for (int kc = 0; kc < KX; ++kc) xa_col[kc] = (unsigned)min(kc * 32 + 8 * lq, fi.Dp - 8) * 2u;
+    xa_base = reinterpret_cast<const char*>(fi.x + dir * fi.xdir);
+    xa_step = (dir == 0 ? 1 : -1) * (int)(fi.ldx * 2);
+    const int pos0 = (dir == 0 || xa_len == 0) ? 0 : xa_len - 1;
+    xa_off = (unsigned)((((int64_t)xa_b * T + pos0) * fi.ldx) * 2);
+    if ((int64_t)B * T * fi.ldx * 2 >= ((int64_t)1 << 32)) smin = 0;
+#pragma unroll
+    for (int kc = 0; kc < KX; ++kc) xa[kc] = *reinterpret_cast<const bf16x8*>(xa_base + xa_off + xa_col[kc]);
+  }
   char* const xbase = reinterpret_cast<char*>(xproj);
   char* const cbase = reinterpret_cast<char*>(cbuf);
   char* const ybase = reinterpret_cast<char*>(y);
@@ -345,16 +451,47 @@ __global__ __launch_bounds__(256) void lstm_fwd_kernel(float* __restrict__ xproj
     LSTM_STAMP(0, s, 0);
     // x_t K_x + b of this step: issued now, consumed after the MFMAs
     float4 xp[UB][RL];
+    f32x4 acc[4][UB];
 #pragma unroll
-    for (int ub = 0; ub < UB; ++ub)
+    for (int g = 0; g < 4; ++g)
 #pragma unroll
-      for (int r = 0; r < RL; ++r) {
-        xp[ub][r] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (lead) {
-          if constexpr (LEAN) xp[ub][r] = *reinterpret_cast<const float4*>(xbase + xoff[r] + ub * 256);
-          else if (act[r]) xp[ub][r] = *reinterpret_cast<const float4*>(xproj + rowoff[r] * xrow + dir * 4 * H + (unit0 + ub * 16) * 4);
-        }
+      for (int ub = 0; ub < UB; ++ub) acc[g][ub] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if constexpr (KX > 0) {
+      // the input products of this step (x_t arrived during the previous one), then x_{t+1} is requested: both ahead of the
+      // polls, i.e. in the shadow of the exchange
+#pragma unroll
+      for (int kc = 0; kc < KX; ++kc)
+#pragma unroll
+        for (int ub = 0; ub < UB; ++ub)
+#pragma unroll
+          for (int g = 0; g < 4; ++g) acc[g][ub] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xa[kc], wx[ub][kc][g], acc[g][ub], 0, 0, 0);
+      if constexpr (LEAN) {
+        if (s + 1 < xa_len) xa_off += (unsigned)xa_step;      // (a row that ends here re-reads its last frame: never used)
+#pragma unroll
+        for (int kc = 0; kc < KX; ++kc) xa[kc] = *reinterpret_cast<const bf16x8*>(xa_base + xa_off + xa_col[kc]);
+      } else {
+        const int sn = s + 1;
+        const int posn = sn < xa_len ? (dir == 0 ? sn : xa_len - 1 - sn) : 0;
+        const int64_t o = (((int64_t)xa_b * T + posn) * fi.ldx) * 2;
+#pragma unroll
+        for (int kc = 0; kc < KX; ++kc) xa[kc] = *reinterpret_cast<const bf16x8*>(xa_base + o + xa_col[kc]);
       }
+#pragma unroll
+      for (int ub = 0; ub < UB; ++ub)
+#pragma unroll
+        for (int r = 0; r < RL; ++r) xp[ub][r] = bz[ub];
+    } else {
+#pragma unroll
+      for (int ub = 0; ub < UB; ++ub)
+#pragma unroll
+        for (int r = 0; r < RL; ++r) {
+          xp[ub][r] = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (lead) {
+            if constexpr (LEAN) xp[ub][r] = *reinterpret_cast<const float4*>(xbase + xoff[r] + ub * 256);
+            else if (act[r]) xp[ub][r] = *reinterpret_cast<const float4*>(xproj + rowoff[r] * xrow + dir * 4 * H + (unit0 + ub * 16) * 4);
+          }
+        }
+    }
 
     // all-gather h_{s-1}: peers' slices arrive as granules tagged with epoch s
     if constexpr (G > 1) if (s > 0) {
@@ -371,7 +508,7 @@ __global__ __launch_bounds__(256) void lstm_fwd_kernel(float* __restrict__ xproj
 #pragma unroll
           for (int i = 0; i < CH; ++i) {
             v[i] = granule_load(reinterpret_cast<const u64*>(src + poll_off[c0 + i]));
-            ok = ok && ((unsigned)(v[i] >> 32) == (unsigned)s);
+            ok = ok && ((unsigned)(v[i] >> 32) == base + (unsigned)s);
           }
           if (__all(ok)) break;
           if (++spins > SPIN_LIMIT) { fail_flag = 1; break; }
@@ -391,11 +528,6 @@ __global__ __launch_bounds__(256) void lstm_fwd_kernel(float* __restrict__ xproj
     LSTM_STAMP(0, s, 2);
     if (fail_flag) return false;
 
-    f32x4 acc[4][UB];
-#pragma unroll
-    for (int g = 0; g < 4; ++g)
-#pragma unroll
-      for (int ub = 0; ub < UB; ++ub) acc[g][ub] = f32x4{0.f, 0.f, 0.f, 0.f};
     // all of the step's A fragments are requested before the first product (left to itself the compiler kept two in
     // flight and waited for the next pair right behind the products of the last: the LDS latency three more times per step)
     bf16x8 afr[KCW];
@@ -453,7 +585,7 @@ __global__ __launch_bounds__(256) void lstm_fwd_kernel(float* __restrict__ xproj
         if constexpr (G > 1) {
 #pragma unroll
           for (int rp = 0; rp < (RL + 1) / 2; ++rp)
-            granule_store(dst + (lq * ((RL + 1) / 2) + rp) * HS + ul, (unsigned)(s + 1),
+            granule_store(dst + (lq * ((RL + 1) / 2) + rp) * HS + ul, base + (unsigned)(s + 1),
                           (unsigned)hb[2 * rp] | (GV == 2 ? (unsigned)hb[(2 * rp + 1) % RL] << 16 : 0u), local);
         }
       }
@@ -488,7 +620,7 @@ __global__ __launch_bounds__(256) void lstm_fwd_kernel(float* __restrict__ xproj
     if constexpr (G == 1) {
       // single-workgroup chains exchange nothing: one granule per step tells the companion how far the chain is
       // (every fourth step: the write-through store sits in the in-order memory queue of the wave that also loads)
-      if (companions && tid == 0 && (s & 3) == 3) granule_store(ex_group + (int64_t)(s & 1) * par_stride, (unsigned)(s + 1), 0u, false);
+      if (companions && tid == 0 && (s & 3) == 3) granule_store(ex_group + (int64_t)(s & 1) * par_stride, base + (unsigned)(s + 1), 0u, false);
     }
     cur ^= 1;
     LSTM_STAMP(0, s, 5);
@@ -501,7 +633,7 @@ __global__ __launch_bounds__(256) void lstm_fwd_kernel(float* __restrict__ xproj
   for (; s < smax && ok; ++s) ok = step(s, std::false_type{});
   flush_pending();
 
-  if (tid == 0) __hip_atomic_store(done_word, (u64)1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // releases the companion
+  if (tid == 0) __hip_atomic_store(done_word, ((u64)(base + 1u) << 32) | 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // releases the companion
   if (!ok) {
     if (tid == 0) atomicOr(status, 1u);
     return;
@@ -517,6 +649,18 @@ __global__ __launch_bounds__(256) void lstm_fwd_kernel(float* __restrict__ xproj
       }
 }
 
+template <int H, int ROWS, int G = coop_members(H), int KX = 0>
+__global__ __launch_bounds__(256) void lstm_fwd_kernel(float* __restrict__ xproj, const unsigned short* __restrict__ wpacked,
+                                                       const int32_t* __restrict__ length, unsigned short* __restrict__ y,
+                                                       float* __restrict__ cbuf, float* __restrict__ c_last,
+                                                       float* __restrict__ h_last, u64* __restrict__ exch,
+                                                       unsigned* __restrict__ status, int B, int T, int ndir, int ngroups,
+                                                       int companions, long long exch_words, const FusedInput fi) {
+  const unsigned base = launch_base(status);
+  lstm_fwd_body<H, ROWS, G, KX>(xproj, wpacked, length, y, cbuf, c_last, h_last, exch, status, B, T, ndir, ngroups, companions, fi, base);
+  launch_arrive(status, base, T, exch, exch_words);
+}
+
 // ------------------------------------------------------------------------------------------------
 // backward in time
 //
@@ -528,13 +672,13 @@ __global__ __launch_bounds__(256) void lstm_fwd_kernel(float* __restrict__ xproj
 // is 4 x (G-1) granules each way, against 8 x 4 x (G-1) for an all-gather of dz_t.
 // kh is K_h [H, 4H] in bf16 with GATE-INTERLEAVED columns (u*4+g): a member's K range is contiguous.
 // ------------------------------------------------------------------------------------------------
-template <int H, int ROWS, int G = coop_members(H)>            // ROWS: utterances per slice, G: members, as in lstm_fwd_kernel
-__global__ __launch_bounds__(256) void lstm_bwd_kernel(const float* __restrict__ gates, const float* __restrict__ cbuf,
-                                                       const float* __restrict__ dy, const float* __restrict__ dc_last,
-                                                       const float* __restrict__ dh_last, const unsigned short* __restrict__ kh,
-                                                       const int32_t* __restrict__ length, unsigned short* __restrict__ dz,
-                                                       u64* __restrict__ exch, unsigned* __restrict__ status,
-                                                       int B, int T, int ndir, int ngroups) {
+template <int H, int ROWS, int G>            // ROWS: utterances per slice, G: members, as in lstm_fwd_kernel
+__device__ __forceinline__ void lstm_bwd_body(const float* __restrict__ gates, const float* __restrict__ cbuf,
+                                              const float* __restrict__ dy, const float* __restrict__ dc_last,
+                                              const float* __restrict__ dh_last, const unsigned short* __restrict__ kh,
+                                              const int32_t* __restrict__ length, unsigned short* __restrict__ dz,
+                                              u64* __restrict__ exch, unsigned* __restrict__ status,
+                                              int B, int T, int ndir, int ngroups, const unsigned base) {
   constexpr int HS = H / G;
   constexpr int NUB = HS / 16;                    // 16-unit blocks of a member
   constexpr bool SPLIT = NUB < 4;                 // H = 512: two waves share a unit block, two rows of every quad each
@@ -612,8 +756,8 @@ __global__ __launch_bounds__(256) void lstm_bwd_kernel(const float* __restrict__
       unsigned spins = 0;
       while (seen < it - PF_AHEAD) {
         const u64 v0 = granule_load(tag0), v1 = granule_load(tag0 + par_stride), dn = granule_load(done_word);
-        if (dn != 0) return;
-        seen = (int)max((unsigned)(v0 >> 32), (unsigned)(v1 >> 32)) - 1;
+        if ((unsigned)(dn >> 32) == base + 1u) return;
+        seen = max(max((int)((unsigned)(v0 >> 32) - base), (int)((unsigned)(v1 >> 32) - base)), 0) - 1;
         if (seen < it - PF_AHEAD) {
           if (++spins > SPIN_LIMIT) return;
           __builtin_amdgcn_s_sleep(8);
@@ -686,7 +830,7 @@ __global__ __launch_bounds__(256) void lstm_bwd_kernel(const float* __restrict__
   }
   if (tid == 0) fail_flag = 0;
   __syncthreads();
-  const bool local = xcd_colocated<G>(exch + 2 * par_stride + (int64_t)group * G, member, &colo_flag, status);
+  const bool local = xcd_colocated<G>(exch + 2 * par_stride + (int64_t)group * G, member, &colo_flag, status, base);
 
   // loop-invariant pieces of the exchange (byte offsets inside the group's parity slot)
   unsigned poll_off[PER], send_off[NT > OWN ? NT - OWN : 1];
@@ -817,7 +961,7 @@ __global__ __launch_bounds__(256) void lstm_bwd_kernel(const float* __restrict__
 #pragma unroll
             for (int i = 0; i < CH; ++i) {
               v[i] = granule_load(reinterpret_cast<const u64*>(src + poll_off[c0 + i]));
-              got = got && ((unsigned)(v[i] >> 32) == epoch);
+              got = got && ((unsigned)(v[i] >> 32) == base + epoch);
             }
             if (__all(got)) break;
             if (++spins > SPIN_LIMIT) { fail_flag = 1; ok = false; break; }
@@ -917,7 +1061,7 @@ __global__ __launch_bounds__(256) void lstm_bwd_kernel(const float* __restrict__
         for (int kc = 0; kc < KCW; ++kc) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afr[kc], wf[j][kc], acc[j], 0, 0, 0);
 #pragma unroll
         for (int r = 0; r < (SPLIT ? ROWS / 4 : RPL); ++r)       // 8-row slices: rows 2, 3 of every quad carry nothing
-          granule_store(reinterpret_cast<u64*>(dst + send_off[j - OWN] + r * 512), epoch + 1, __float_as_uint(acc[j][r]), local);
+          granule_store(reinterpret_cast<u64*>(dst + send_off[j - OWN] + r * 512), base + epoch + 1, __float_as_uint(acc[j][r]), local);
       }
     }
     // own tiles: nobody waits for one of them in particular, so they advance together -- K chunk by K chunk -- instead of one
@@ -935,7 +1079,7 @@ __global__ __launch_bounds__(256) void lstm_bwd_kernel(const float* __restrict__
     prepare(lean && s == 1);                 // coefficients of step s-1 (its operands were loaded above)
     LSTM_STAMP(2048, smax - 1 - s, 6);
     if constexpr (G == 1) {                  // (see lstm_fwd_kernel: the companion's pace)
-      if (tid == 0 && (epoch & 3) == 3) granule_store(ex_group + (int64_t)(epoch & 1) * par_stride, epoch + 1, 0u, false);
+      if (tid == 0 && (epoch & 3) == 3) granule_store(ex_group + (int64_t)(epoch & 1) * par_stride, base + epoch + 1, 0u, false);
     }
     ++epoch;
     cur ^= 1;
@@ -947,8 +1091,20 @@ __global__ __launch_bounds__(256) void lstm_bwd_kernel(const float* __restrict__
     for (; s >= smin && go; --s) go = iter(s, std::false_type{});
     for (; s >= 0 && go; --s) go = iter(s, std::true_type{});
   }
-  if (tid == 0) __hip_atomic_store(done_word, (u64)1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (tid == 0) __hip_atomic_store(done_word, ((u64)(base + 1u) << 32) | 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   if (!ok && tid == 0) atomicOr(status, 2u);
+}
+
+template <int H, int ROWS, int G = coop_members(H)>
+__global__ __launch_bounds__(256) void lstm_bwd_kernel(const float* __restrict__ gates, const float* __restrict__ cbuf,
+                                                       const float* __restrict__ dy, const float* __restrict__ dc_last,
+                                                       const float* __restrict__ dh_last, const unsigned short* __restrict__ kh,
+                                                       const int32_t* __restrict__ length, unsigned short* __restrict__ dz,
+                                                       u64* __restrict__ exch, unsigned* __restrict__ status,
+                                                       int B, int T, int ndir, int ngroups, long long exch_words) {
+  const unsigned base = launch_base(status);
+  lstm_bwd_body<H, ROWS, G>(gates, cbuf, dy, dc_last, dh_last, kh, length, dz, exch, status, B, T, ndir, ngroups, base);
+  launch_arrive(status, base, T, exch, exch_words);
 }
 
 struct CoopGeom { int nslices, ngroups, G, blocks, companions; size_t exch_bytes; };
@@ -1020,24 +1176,45 @@ int prefetch_mode() {
   return mode;
 }
 
-template <int H, int ROWS, int G>
+// 64-bit words of the workspace behind its header: what the last workgroup clears before the launch tags would wrap (the
+// whole exchange area of las_lstm_workspace_bytes, not only this launch's layout: forward and backward launches of every layer
+// share it)
+long long exch_words(int B, int H, int ndir) { return (long long)((las_lstm_workspace_bytes(B, H, ndir) - 64) / sizeof(u64)); }
+
+template <int H, int ROWS, int G, int KX = 0>
 int launch_fwd_as(float* xproj, const las_bf16* wp, const int32_t* length, las_bf16* y, float* cbuf, float* c_last, float* h_last,
-                  void* ws, int B, int T, int ndir, hipStream_t st) {
+                  void* ws, int B, int T, int ndir, hipStream_t st, const FusedInput& fi) {
   const CoopGeom g = geom(B, H, ndir, false, ROWS, G);
   unsigned* status = reinterpret_cast<unsigned*>(ws);
   u64* exch = reinterpret_cast<u64*>(reinterpret_cast<char*>(ws) + 64);
   const int pf = prefetch_mode();
-  hipLaunchKernelGGL((lstm_fwd_kernel<H, ROWS, G>), dim3(pf ? g.blocks + g.companions : g.blocks), dim3(256), 0, st, xproj, wp, length, y,
-                     cbuf, c_last, h_last, exch, status, B, T, ndir, g.ngroups, pf);
+  hipLaunchKernelGGL((lstm_fwd_kernel<H, ROWS, G, KX>), dim3(pf ? g.blocks + g.companions : g.blocks), dim3(256), 0, st, xproj, wp, length, y,
+                     cbuf, c_last, h_last, exch, status, B, T, ndir, g.ngroups, pf, exch_words(B, H, ndir), fi);
   LAS_LAUNCH_CHECK("lstm fwd launch");
   return LAS_OK;
 }
 
+// widths the fused input projection is built for: 32-deep chunks of the (padded) feature count
+constexpr bool fused_input_units(int H) { return H == 128 || H == 256 || H == 512; }
+int fused_input_chunks(int H, int Dp) {
+  if (!fused_input_units(H) || Dp < 8 || Dp % 8 || Dp > 96) return 0;
+  if (H == 512 && members(H) != 8) return 0;       // (the 16-member form splits K over wave pairs)
+  return Dp <= 64 ? 2 : 3;
+}
+
 template <int H>
 int launch_fwd(float* xproj, const las_bf16* wp, const int32_t* length, las_bf16* y, float* cbuf, float* c_last,
-               float* h_last, void* ws, int B, int T, int ndir, hipStream_t st) {
+               float* h_last, void* ws, int B, int T, int ndir, hipStream_t st, const FusedInput& fi) {
   const int rows = slice_rows(B, H, ndir, false);
-#define LAS_FWD(R, GG) return launch_fwd_as<H, R, GG>(xproj, wp, length, y, cbuf, c_last, h_last, ws, B, T, ndir, st)
+  const int kx = fi.x ? fused_input_chunks(H, fi.Dp) : 0;
+#define LAS_FWD(R, GG) do {                                                                                                   \
+    if constexpr (fused_input_units(H)) {                                                                                      \
+      if (kx == 2) return launch_fwd_as<H, R, GG, 2>(xproj, wp, length, y, cbuf, c_last, h_last, ws, B, T, ndir, st, fi);      \
+      if (kx == 3) return launch_fwd_as<H, R, GG, 3>(xproj, wp, length, y, cbuf, c_last, h_last, ws, B, T, ndir, st, fi);      \
+    }                                                                                                                          \
+    return launch_fwd_as<H, R, GG, 0>(xproj, wp, length, y, cbuf, c_last, h_last, ws, B, T, ndir, st, fi);                     \
+  } while (0)
+#define LAS_FWD0(R, GG) return launch_fwd_as<H, R, GG, 0>(xproj, wp, length, y, cbuf, c_last, h_last, ws, B, T, ndir, st, fi)
   if constexpr (H == 512) {
     if (members(H) == 8) {
       if (rows == 4) LAS_FWD(4, 8);
@@ -1046,12 +1223,18 @@ int launch_fwd(float* xproj, const las_bf16* wp, const int32_t* length, las_bf16
     }
   }
   constexpr int G0 = coop_members(H);
-  if (rows == 8) LAS_FWD(8, G0);
-  if constexpr (H <= 256) {
-    if (rows == 4) LAS_FWD(4, G0);
+  if constexpr (H == 512) {
+    if (rows == 8) LAS_FWD0(8, G0);
+    LAS_FWD0(16, G0);
+  } else {
+    if (rows == 8) LAS_FWD(8, G0);
+    if constexpr (H <= 256) {
+      if (rows == 4) LAS_FWD(4, G0);
+    }
+    LAS_FWD(16, G0);
   }
-  LAS_FWD(16, G0);
 #undef LAS_FWD
+#undef LAS_FWD0
 }
 
 template <int H, int ROWS, int G>
@@ -1077,7 +1260,7 @@ int launch_bwd_as(const float* gates, const float* cbuf, const float* dy, const 
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&lstm_bwd_kernel<H, ROWS, G>), hipFuncAttributeMaxDynamicSharedMemorySize, hog_kb * 1024);
   }
   hipLaunchKernelGGL((lstm_bwd_kernel<H, ROWS, G>), dim3(pf ? g.blocks + g.companions : g.blocks), dim3(256), (size_t)(hog_kb > 0 ? hog_kb : 0) * 1024, st,
-                     gates, cbuf, dy, dc_last, dh_last, kh, length, dz, exch, status, B, T, ndir, g.ngroups);
+                     gates, cbuf, dy, dc_last, dh_last, kh, length, dz, exch, status, B, T, ndir, g.ngroups, exch_words(B, H, ndir));
   LAS_LAUNCH_CHECK("lstm bwd launch");
   return LAS_OK;
 }
@@ -1131,9 +1314,9 @@ extern "C" int las_lstm_pack_recurrent(const float* kernel_h, int H, las_bf16* p
   return LAS_OK;
 }
 
-extern "C" int las_lstm_recurrent_fwd(float* xproj, const las_bf16* wpacked, const int32_t* length, las_bf16* y,
-                                      float* cbuf, float* c_last, float* h_last, void* workspace, int B, int T, int H,
-                                      int ndir, void* stream) {
+namespace {
+int recurrent_fwd(float* xproj, const las_bf16* wpacked, const int32_t* length, las_bf16* y, float* cbuf, float* c_last,
+                  float* h_last, void* workspace, int B, int T, int H, int ndir, void* stream, const FusedInput& fi) {
   LAS_REQUIRE(B > 0 && T > 0 && (ndir == 1 || ndir == 2), "las_lstm_recurrent_fwd: bad shape B=%d T=%d ndir=%d", B, T, ndir);
   LAS_REQUIRE(supported_units(H), "las_lstm_recurrent_fwd: num_units %d not in {64,128,256,512}", H);
   LAS_REQUIRE(workspace != nullptr && ((uintptr_t)workspace % 16 == 0), "las_lstm_recurrent_fwd: workspace missing or misaligned");
@@ -1143,18 +1326,45 @@ extern "C" int las_lstm_recurrent_fwd(float* xproj, const las_bf16* wpacked, con
     rc = las_check_hip(hipMemsetAsync(y, 0, (size_t)B * T * ndir * H * sizeof(las_bf16), st), "memset y");
     if (rc) return rc;
   }
-  // the exchange granules start from zero tags at every launch; the 64-byte status header is STICKY (a timeout bit
-  // survives until the host reads and clears it: the workspace is shared by every layer and by forward and backward)
-  if (const size_t eb = geom(B, H, ndir, false, slice_rows(B, H, ndir, false)).exch_bytes) {
-    rc = las_check_hip(hipMemsetAsync(reinterpret_cast<char*>(workspace) + 64, 0, eb, st), "memset workspace");
-    if (rc) return rc;
-  }
+  // No memset of the exchange buffer: the tags of a launch start from the launch base in the workspace header (see
+  // launch_arrive); the caller zeroes the workspace ONCE, when it allocates it.  The first word of the header is the STICKY
+  // timeout status (it survives until the host reads and clears it: one workspace serves every layer, forward and backward).
   switch (H) {
-    case 64: return launch_fwd<64>(xproj, wpacked, length, y, cbuf, c_last, h_last, workspace, B, T, ndir, st);
-    case 128: return launch_fwd<128>(xproj, wpacked, length, y, cbuf, c_last, h_last, workspace, B, T, ndir, st);
-    case 512: return launch_fwd<512>(xproj, wpacked, length, y, cbuf, c_last, h_last, workspace, B, T, ndir, st);
-    default: return launch_fwd<256>(xproj, wpacked, length, y, cbuf, c_last, h_last, workspace, B, T, ndir, st);
+    case 64: return launch_fwd<64>(xproj, wpacked, length, y, cbuf, c_last, h_last, workspace, B, T, ndir, st, fi);
+    case 128: return launch_fwd<128>(xproj, wpacked, length, y, cbuf, c_last, h_last, workspace, B, T, ndir, st, fi);
+    case 512: return launch_fwd<512>(xproj, wpacked, length, y, cbuf, c_last, h_last, workspace, B, T, ndir, st, fi);
+    default: return launch_fwd<256>(xproj, wpacked, length, y, cbuf, c_last, h_last, workspace, B, T, ndir, st, fi);
   }
+}
+}  // namespace
+
+extern "C" int las_lstm_recurrent_fwd(float* xproj, const las_bf16* wpacked, const int32_t* length, las_bf16* y,
+                                      float* cbuf, float* c_last, float* h_last, void* workspace, int B, int T, int H,
+                                      int ndir, void* stream) {
+  return recurrent_fwd(xproj, wpacked, length, y, cbuf, c_last, h_last, workspace, B, T, H, ndir, stream, FusedInput{});
+}
+
+extern "C" int las_lstm_fused_input_chunks(int H, int Dp) { return supported_units(H) ? fused_input_chunks(H, Dp) : 0; }
+
+extern "C" int las_lstm_pack_input(const float* kernel, int D, int H, int chunks, las_bf16* packed, void* stream) {
+  LAS_REQUIRE(supported_units(H) && D > 0 && chunks > 0 && D <= 32 * chunks, "las_lstm_pack_input: bad shape D=%d H=%d chunks=%d", D, H, chunks);
+  hipLaunchKernelGGL(pack_input_kernel, dim3(64), dim3(256), 0, (hipStream_t)stream, kernel, D, H, chunks, packed);
+  LAS_LAUNCH_CHECK("pack input launch");
+  return LAS_OK;
+}
+
+extern "C" int las_lstm_recurrent_fwd_x(const las_bf16* x, int64_t ldx, int64_t x_dir_stride, int Dp, const las_bf16* kx_packed,
+                                        const float* bias, float* gates, const las_bf16* wpacked, const int32_t* length,
+                                        las_bf16* y, float* cbuf, float* c_last, float* h_last, void* workspace, int B, int T,
+                                        int H, int ndir, void* stream) {
+  LAS_REQUIRE(x != nullptr && kx_packed != nullptr && bias != nullptr, "las_lstm_recurrent_fwd_x: x, kx_packed and bias are required");
+  LAS_REQUIRE(supported_units(H) && fused_input_chunks(H, Dp) > 0, "las_lstm_recurrent_fwd_x: no fused input projection for H=%d, Dp=%d "
+              "(las_lstm_fused_input_chunks)", H, Dp);
+  LAS_REQUIRE(ldx >= Dp && ldx % 8 == 0 && ((uintptr_t)x % 16 == 0), "las_lstm_recurrent_fwd_x: x rows must be 16-byte aligned (ldx %% 8 == 0)");
+  FusedInput fi;
+  fi.x = reinterpret_cast<const unsigned short*>(x); fi.ldx = ldx; fi.xdir = x_dir_stride;
+  fi.kxp = reinterpret_cast<const unsigned short*>(kx_packed); fi.bias = bias; fi.Dp = Dp;
+  return recurrent_fwd(gates, wpacked, length, y, cbuf, c_last, h_last, workspace, B, T, H, ndir, stream, fi);
 }
 
 extern "C" int las_lstm_recurrent_bwd(const float* gates, const float* cbuf, const float* dy, const float* dc_last,
@@ -1169,10 +1379,7 @@ extern "C" int las_lstm_recurrent_bwd(const float* gates, const float* cbuf, con
     rc = las_check_hip(hipMemsetAsync(dz, 0, (size_t)B * T * ndir * 4 * H * sizeof(las_bf16), st), "memset dz");
     if (rc) return rc;
   }
-  if (const size_t eb = geom(B, H, ndir, true, slice_rows(B, H, ndir, true)).exch_bytes) {      // status header: sticky (see forward)
-    rc = las_check_hip(hipMemsetAsync(reinterpret_cast<char*>(workspace) + 64, 0, eb, st), "memset workspace");
-    if (rc) return rc;
-  }
+  // (no memset of the exchange buffer: launch epochs, see las_lstm_recurrent_fwd)
   switch (H) {
     case 64: return launch_bwd<64>(gates, cbuf, dy, dc_last, dh_last, kh_bf16, length, dz, workspace, B, T, ndir, st);
     case 128: return launch_bwd<128>(gates, cbuf, dy, dc_last, dh_last, kh_bf16, length, dz, workspace, B, T, ndir, st);

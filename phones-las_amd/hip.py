@@ -37,9 +37,13 @@ _SIGS = {
     'las_lstm_pack_recurrent': ([_vp, _i32, _vp, _vp], C.c_int),
     'las_lstm_recurrent_fwd': ([_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp], C.c_int),
     'las_lstm_recurrent_bwd': ([_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp], C.c_int),
+    'las_lstm_fused_input_chunks': ([_i32, _i32], C.c_int),
+    'las_lstm_pack_input': ([_vp, _i32, _i32, _i32, _vp, _vp], C.c_int),
+    'las_lstm_recurrent_fwd_x': ([_vp, _i64, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp], C.c_int),
     'las_lstm_workspace_bytes': ([_i32, _i32, _i32], C.c_size_t),
     'las_lstm_slice_rows': ([_i32, _i32, _i32], C.c_int),
     'las_pyramid_lengths': ([_vp, _vp, _i32, _vp], C.c_int),
+    'las_pyramid_lengths_multi': ([_vp, _vp, _i32, _i32, _vp], C.c_int),
     'las_decoder_step_fwd': ([_vp, _i32, _vp], C.c_int),
     'las_decoder_step_bwd': ([_vp, _vp], C.c_int),
     'las_decoder_seq_bwd_supported': ([_i32] * 7, C.c_int),
@@ -409,7 +413,7 @@ def fill_many(zero=(), copy=()):
         check(lib().las_fill_many(arr, len(part), stream()))
 
 
-IMAGE_CAST, IMAGE_PACK_RECURRENT, IMAGE_BIAS_INTERLEAVE, IMAGE_COPY_F32, IMAGE_PACK_MFMA_B = 0, 1, 2, 3, 4
+IMAGE_CAST, IMAGE_PACK_RECURRENT, IMAGE_BIAS_INTERLEAVE, IMAGE_COPY_F32, IMAGE_PACK_MFMA_B, IMAGE_PACK_INPUT = 0, 1, 2, 3, 4, 5
 _image_batch = None
 _image_tables = {}        # bytes of a job table -> its device copy (tables repeat every step: uploaded once)
 
@@ -479,6 +483,16 @@ def pack_recurrent(kernel_h, H, packed):
         _image_job(IMAGE_PACK_RECURRENT, kernel_h, packed, rows=H)
         return
     check(lib().las_lstm_pack_recurrent(p(kernel_h), H, p(packed), stream()))
+
+
+def pack_input(kernel, D, H, chunks, packed):
+    """las_lstm_pack_input (joins an open image_batch): the K_x image of the fused input projection."""
+    if packed.numel() != (H // 16) * chunks * 4 * 512:
+        raise LasError('pack_input: destination of %d elements, expected %d' % (packed.numel(), (H // 16) * chunks * 4 * 512))
+    if _image_batch is not None:
+        _image_job(IMAGE_PACK_INPUT, kernel, packed, rows=D, cols=H, dst_rows=chunks)
+        return
+    check(lib().las_lstm_pack_input(p(kernel), D, H, chunks, p(packed), stream()))
 
 
 def pack_mfma_b(src, rows, cols, dst, lds=None, transpose=False):

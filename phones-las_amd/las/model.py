@@ -49,6 +49,7 @@ class Listener:
             Dp = D
         self.time_multiple = 2 ** max(0, hparams.num_layers - 1) if hparams.use_pyramidal else 1
         self.tape = None
+        self.before_bottom_grads = None
 
     def refresh(self, variables, layers=None):
         """layers: which layers' images (default: all)."""
@@ -108,6 +109,10 @@ class Listener:
             r = recs[l]
             dy = st['dy'].contiguous().view(r['B'], r['T'], r['nd'] * r['H'])
             defer = defer_last and (i == n - 1) and l > 0
+            if l == 0 and overlap is not None:
+                # everything the side stream holds before the bottom layer's weight-gradient products: LasModel's train op
+                # starts on the other tensors while those products (which nothing else hides) are still running
+                self.before_bottom_grads = overlap.mark()
             res = ops.bilstm_backward(r, dy, st['d_state'] if l == len(recs) - 1 else None, grads, need_dx=(l > 0),
                                       overlap=overlap, defer_weight_grads=defer, exposed=(l == 0 and overlap is not None and os.environ.get('LAS_TN_EXPOSED', '1') != '0'))
             if defer:
@@ -275,7 +280,7 @@ class Speller:
         s.drop_keep, s.feed_width = 1.0, self.V + self.M
         return s
 
-    def forward_train(self, memory, mem_len, encoder_state, targets_inputs, num_steps, parts=4, seed=0):
+    def forward_train(self, memory, mem_len, encoder_state, targets_inputs, num_steps, parts=4, seed=0, overlap=None):
         """TrainingHelper decode (las/model.py:276-296,346-347).  memory [B,T',M] bf16, targets_inputs int32
         [B,>=num_steps]; num_steps = max(target_sequence_length).  Returns logits fp32 [B,U,Vp] (first V valid)."""
         B, Tm, M = memory.shape
@@ -290,10 +295,19 @@ class Speller:
         gates = torch.empty(B, U, 4 * Hd, dtype=f32, device=dev)
         h_all = torch.empty(B, U, Hd, dtype=bf, device=dev)
         Tmp = _r8(Tm)                      # row stride of per-step [T'] vectors (GEMM operand alignment)
-        align = torch.empty(B, U, Tmp, dtype=f32, device=dev)
-        align_bf = torch.empty(B, U, Tmp, dtype=bf, device=dev)
+        # Dot-product scores (round 4): d(memory)[b] = align[b]^T d(context)[b] + d(scores)[b]^T (h[b] W_mem^T) is ONE batched
+        # product over K = 2U when the two left operands and the two right operands sit behind each other per utterance:
+        # rows [0, U) of `al2` are the alignments (this pass), rows [U, 2U) d(scores) (the backward pass); rows [0, U) of `cw2`
+        # d(context) (the backward pass), rows [U, 2U) hW = h_t W_mem^T (formed beside the loss, off the critical path).  The
+        # fp32 alignments share the row stride (struct las_dec_step has one lda for both).
+        merged = (self.att == hip.ATT_LUONG and os.environ.get('LAS_DMEM_MERGED', '1') != '0')
+        R = 2 if merged else 1
+        align = torch.empty(B, R * U, Tmp, dtype=f32, device=dev)
+        al2 = torch.empty(B, R * U, Tmp, dtype=bf, device=dev)
+        align_bf = al2[:, :U]
+        dc_bwd = torch.empty(B, Hd, dtype=f32, device=dev)          # the backward pass's running d(c): cleared here, in the same launch
         # one launch: the first operand row [attention_{-1} = 0 | h_0], c_0, and the alignment buffers' zero padding
-        hip.fill_many(zero=[AH[:, 0, :M], align, align_bf],
+        hip.fill_many(zero=[AH[:, 0, :M], align.view(B, -1)[:, :U * Tmp], al2, dc_bwd],
                       copy=[(AH[:, 0, M:], h0.float() if passed else None), (cs[:, 0], c0.float() if passed else None)])
         ctx_all = torch.empty(B, U, M, dtype=bf, device=dev)
         pq_all = torch.empty(B, U, Hd, dtype=f32, device=dev) if self.att == hip.ATT_BAHDANAU else None
@@ -318,7 +332,7 @@ class Speller:
             p.s = self._step_struct(
                 B, Tm, 0, hip.addr(fed), ts, hip.addr(cs), (U + 1) * Hd, hip.addr(gates), U * 4 * Hd,
                 hip.addr(cs, Hd), (U + 1) * Hd, hip.addr(h_all), U * Hd, hip.addr(AH, W + M) if U > 1 else 0, U * W,
-                keys, memory, mem_len, hip.addr(align), hip.addr(align_bf), U * Tmp,
+                keys, memory, mem_len, hip.addr(align), hip.addr(align_bf), R * U * Tmp,
                 hip.addr(pq_all) if pq_all is not None else 0, U * Hd, hip.addr(ctx_all), U * M,
                 hip.addr(AH, W) if U > 1 else 0, U * W)
             if keep < 1.0:
@@ -349,7 +363,7 @@ class Speller:
                 B, Tm, hip.addr(z), hip.addr(fed, t), ts, hip.addr(cs, t * Hd), (U + 1) * Hd,
                 hip.addr(gates, t * 4 * Hd), U * 4 * Hd, hip.addr(cs, (t + 1) * Hd), (U + 1) * Hd,
                 hip.addr(h_all, t * Hd), U * Hd, 0 if last else hip.addr(AH, (t + 1) * W + M), U * W,
-                keys, memory, mem_len, hip.addr(align, t * Tmp), hip.addr(align_bf, t * Tmp), U * Tmp,
+                keys, memory, mem_len, hip.addr(align, t * Tmp), hip.addr(al2, t * Tmp), R * U * Tmp,
                 hip.addr(pq_all, t * Hd) if pq_all is not None else 0, U * Hd,
                 hip.addr(ctx_all, t * M), U * M, 0 if last else hip.addr(AH, (t + 1) * W), U * W)
             if keep < 1.0:
@@ -361,12 +375,20 @@ class Speller:
                 if not last:
                     hip.check(lib.las_sample_tokens(hip.addr(logits, t * Vp), U * Vp, V, hip.addr(tin, t + 1),
                                                     tin.stride(0), hip.addr(fed, t + 1), ts, B, sampling, seed, t, st))
+        cw2 = None
+        if merged:
+            # hW[b, u] = h_t W_mem^T into rows [U, 2U) of cw2, on the second stream: beside the projection, the loss and the
+            # decoder's backward launch; the d(memory) product after that launch is the first to read it
+            cw2 = torch.empty(B, 2 * U, M, dtype=bf, device=dev)
+            with (overlap or ops._NoOverlap()).fork(h_all, cw2):
+                hip.gemm_nt(h_all, self.wmem, cw2[:, U:], U, M, Hd, lda=Hd, ldb=Hd, ldc=M, out_bf16=True, batch=B,
+                            sa=U * Hd, sb=0, sc=2 * U * M)
         if logits is None:
             logits = torch.empty(B, U, Vp, dtype=f32, device=dev)
             hip.gemm_nt(ctx_all, self.wprojT, logits, B * U, Vp, M, lda=M, ldb=M, ldc=Vp, bias=self.bproj)
         self.saved = dict(keep=keep, seed=seed, fed=fed, B=B, Tm=Tm, U=U, memory=memory, mem_len=mem_len, keys=keys, AH=AH, cs=cs, gates=gates,
                           h_all=h_all, align=align, align_bf=align_bf, ctx_all=ctx_all, pq_all=pq_all,
-                          tin=tin, passed=passed)
+                          tin=tin, passed=passed, al2=al2, cw2=cw2, R=R, dc=dc_bwd)
         return logits
 
     # ---------------------------------------------------------------------------------------------
@@ -383,12 +405,18 @@ class Speller:
         BU = B * U
         dattn_proj = torch.empty(B, U, M, dtype=f32, device=dev)
         hip.gemm_nt(dlogits, self.wproj, dattn_proj, BU, M, Vp, lda=Vp, ldb=Vp, ldc=M)
-        dc = torch.empty(B, Hd, dtype=f32, device=dev)
+        R, merged = sv['R'], sv['cw2'] is not None
+        dc = sv['dc']                       # cleared in the forward pass's fill launch
         dfeed = torch.empty(B, W, dtype=f32, device=dev)
         dz_all = torch.empty(B, U, 4 * Hd, dtype=bf, device=dev)
-        ds_all = torch.empty(B, U, Tmp, dtype=bf, device=dev)
-        hip.fill_many(zero=[dc, ds_all])
-        dctx_all = torch.empty(B, U, M, dtype=bf, device=dev)
+        if merged:
+            # d(scores) behind the alignments, d(context) in front of hW (forward_train): both already zero / in place
+            ds_all, ldso = sv['al2'][:, U:], 2 * U * Tmp
+            dctx_all, ldds = sv['cw2'][:, :U], 2 * U * M
+        else:
+            ds_all, ldso = torch.empty(B, U, Tmp, dtype=bf, device=dev), U * Tmp
+            hip.fill_many(zero=[ds_all])
+            dctx_all, ldds = torch.empty(B, U, M, dtype=bf, device=dev), U * M
         bah = self.att == hip.ATT_BAHDANAU
         if bah:
             dkeys = torch.zeros(B, Tm, Hd, dtype=f32, device=dev)
@@ -402,15 +430,15 @@ class Speller:
             s = p.s
             s.B, s.Hd, s.M, s.Tm, s.attention = B, Hd, M, Tm, self.att
             s.dctx_a, s.ldda = hip.addr(dattn_proj), U * M
-            s.dctx_save, s.ldds = hip.addr(dctx_all), U * M
+            s.dctx_save, s.ldds = hip.addr(dctx_all), ldds
             s.dc = hip.addr(dc)
             s.gates, s.ldg = hip.addr(sv['gates']), U * 4 * Hd
             s.c_new, s.ldcn = hip.addr(sv['cs'], Hd), (U + 1) * Hd
             s.c_prev, s.ldcp = hip.addr(sv['cs']), (U + 1) * Hd
-            s.align, s.lda = hip.addr(sv['align']), U * Tmp
+            s.align, s.lda = hip.addr(sv['align']), R * U * Tmp
             s.keys, s.values, s.mem_len = hip.addr(sv['keys']), hip.addr(sv['memory']), hip.addr(sv['mem_len'])
             s.dz, s.ldz = hip.addr(dz_all), U * 4 * Hd
-            s.ds_out, s.ldso = hip.addr(ds_all), U * Tmp
+            s.ds_out, s.ldso = hip.addr(ds_all), ldso
             s.drop_keep, s.feed_width = 1.0, V + M
             if sv['keep'] < 1.0:
                 s.drop_keep, s.drop_seed, s.drop_stream = sv['keep'], sv['seed'], self.DEC_STREAM
@@ -440,16 +468,16 @@ class Speller:
             s.B, s.Hd, s.M, s.Tm, s.attention = B, Hd, M, Tm, self.att
             s.dctx_a, s.ldda = hip.addr(dattn_proj, t * M), U * M
             s.dctx_b, s.lddb = (0 if first else hip.addr(dfeed)), W
-            s.dctx_save, s.ldds = hip.addr(dctx_all, t * M), U * M
+            s.dctx_save, s.ldds = hip.addr(dctx_all, t * M), ldds
             s.dh_rec, s.ldr = (0 if first else hip.addr(dfeed, M)), W
             s.dc = hip.addr(dc)
             s.gates, s.ldg = hip.addr(sv['gates'], t * 4 * Hd), U * 4 * Hd
             s.c_new, s.ldcn = hip.addr(sv['cs'], (t + 1) * Hd), (U + 1) * Hd
             s.c_prev, s.ldcp = hip.addr(sv['cs'], t * Hd), (U + 1) * Hd
-            s.align, s.lda = hip.addr(sv['align'], t * Tmp), U * Tmp
+            s.align, s.lda = hip.addr(sv['align'], t * Tmp), R * U * Tmp
             s.keys, s.values, s.mem_len = hip.addr(sv['keys']), hip.addr(sv['memory']), hip.addr(sv['mem_len'])
             s.dz, s.ldz = hip.addr(dz_all, t * 4 * Hd), U * 4 * Hd
-            s.ds_out, s.ldso = hip.addr(ds_all, t * Tmp), U * Tmp
+            s.ds_out, s.ldso = hip.addr(ds_all, t * Tmp), ldso
             s.drop_keep, s.feed_width = 1.0, V + M
             if sv['keep'] < 1.0:
                 s.drop_keep, s.drop_seed, s.drop_stream, s.step = sv['keep'], sv['seed'], self.DEC_STREAM, t
@@ -463,27 +491,40 @@ class Speller:
         # critical path: d(keys), d(memory) feed the listener's backward
         # (stored, not accumulated: no zero fills in front of them, no atomics -- K is only the U steps; d(keys) of the
         # dot-product scores is only ever an operand of further products: written as bf16 at once)
-        if not bah:
-            dkeys_bf = torch.empty(B * Tm, Hd, dtype=bf, device=dev)
-            hip.gemm_tn(ds_all, sv['h_all'], dkeys_bf, Tm, Hd, U, lda=Tmp, ldb=Hd, ldc=Hd, batch=B, sa=U * Tmp,
-                        sb=U * Hd, sc=Tm * Hd, store=True)
-        else:
-            dkeys_bf = torch.empty(B * Tm, Hd, dtype=bf, device=dev)
-            hip.cast_bf16(dkeys, B * Tm, Hd, dkeys_bf, B * Tm, Hd, ldd=Hd, lds=Hd)
+        dkeys_bf = torch.empty(B * Tm, Hd, dtype=bf, device=dev)
         dmem = torch.empty(B, Tm, M, dtype=f32, device=dev)
-        hip.gemm_tn(sv['align_bf'], dctx_all, dmem, Tm, M, U, lda=Tmp, ldb=M, ldc=M, batch=B, sa=U * Tmp, sb=U * M,
-                    sc=Tm * M, store=True)
-        hip.gemm_nt(dkeys_bf, self.wmem, dmem, B * Tm, M, Hd, lda=Hd, ldb=Hd, ldc=M, accumulate=True)
+
+        def dkeys_from_scores():            # d(keys)[b] = d(scores)[b]^T h[b] (bf16: only ever an operand of further products)
+            hip.gemm_tn(ds_all, sv['h_all'], dkeys_bf, Tm, Hd, U, lda=Tmp, ldb=Hd, ldc=Hd, batch=B, sa=ldso,
+                        sb=U * Hd, sc=Tm * Hd, store=True)
+        if merged:
+            # one batched product over K = 2U: [align | d(scores)]^T [d(context) ; h W_mem^T]; d(keys) itself is only needed
+            # for the memory layer's weight gradient and moves to the second stream
+            if overlap is not None:
+                overlap.join_side()          # hW
+            hip.gemm_tn(sv['al2'], sv['cw2'], dmem, Tm, M, 2 * U, lda=Tmp, ldb=M, ldc=M, batch=B, sa=2 * U * Tmp,
+                        sb=2 * U * M, sc=Tm * M, store=True)
+        else:
+            if not bah:
+                dkeys_from_scores()
+            else:
+                hip.cast_bf16(dkeys, B * Tm, Hd, dkeys_bf, B * Tm, Hd, ldd=Hd, lds=Hd)
+            hip.gemm_tn(sv['align_bf'], dctx_all, dmem, Tm, M, U, lda=Tmp, ldb=M, ldc=M, batch=B, sa=ldso, sb=ldds,
+                        sc=Tm * M, store=True)
+            hip.gemm_nt(dkeys_bf, self.wmem, dmem, B * Tm, M, Hd, lda=Hd, ldb=Hd, ldc=M, accumulate=True)
         # weight gradients (off the critical path): cell rows [V, V+M+Hd) from [attention_{t-1}, h_{t-1}], rows
         # [0,V) from the tokens, projection, memory_layer, query_layer
         onehot = torch.empty(BU, Vp, dtype=bf, device=dev)
         fed = sv['fed']
-        hip.check(lib.las_onehot_bf16(hip.p(fed), fed.stride(0), B, U, V, hip.p(onehot), Vp, sv['keep'], sv['seed'],
-                                      self.DEC_STREAM, V + M, st))
-        keep = [sv['AH'], dz_all, onehot, sv['ctx_all'], dlogits, sv['memory'], dkeys_bf, sv['h_all']]
+        keep = [sv['AH'], dz_all, onehot, sv['ctx_all'], dlogits, sv['memory'], dkeys_bf, sv['h_all'], sv['al2'], sv['cw2']]
         if bah:
             keep.append(dpq_all)
         with (overlap or ops._NoOverlap()).fork(*keep, beside_chain=True):     # (beside the top listener layer's recurrence)
+            if merged:
+                dkeys_from_scores()
+            # (the one-hot rows of the fed tokens are an operand of the weight gradients only: built on this stream)
+            hip.check(lib.las_onehot_bf16(hip.p(fed), fed.stride(0), B, U, V, hip.p(onehot), Vp, sv['keep'], sv['seed'],
+                                          self.DEC_STREAM, V + M, hip.stream()))
             gk = grads[self.K_CELL]
             hip.gemm_tn(sv['AH'], dz_all, gk[V:], W, 4 * Hd, BU, lda=W, ldb=4 * Hd, ldc=4 * Hd, split_k=4)
             hip.gemm_tn(onehot, dz_all, gk, V, 4 * Hd, BU, lda=Vp, ldb=4 * Hd, ldc=4 * Hd, split_k=4)

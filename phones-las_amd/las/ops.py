@@ -116,6 +116,10 @@ class Overlap:
             torch.cuda.current_stream().wait_stream(self.side2)
         self.keep.clear()
 
+    def join_side(self):
+        """The main stream waits for what the first side stream holds so far (nothing is released: join() does that)."""
+        torch.cuda.current_stream().wait_stream(self.side)
+
 
 class _NoOverlap:
     """Same interface, everything on the current stream."""
@@ -129,6 +133,13 @@ class _NoOverlap:
 
     def join(self):
         pass
+
+    def join_side(self):
+        pass
+
+
+# LAS_LSTM_FUSED_X=0: the bottom layer's input projection as a separate product again (diagnostics, A/B timing)
+FUSED_X = os.environ.get('LAS_LSTM_FUSED_X', '1') != '0'
 
 
 def _dirs(unidirectional):
@@ -150,6 +161,11 @@ class LayerWeights:
         self.kh = torch.empty(nd, H, 4 * H, dtype=torch.bfloat16, device=dev)           # K_h, interleaved columns (bwd)
         self.khp = torch.empty(nd, H * 4 * H, dtype=torch.bfloat16, device=dev)         # fragment-major (fwd)
         self.bias = torch.empty(nd * 4 * H, dtype=torch.float32, device=dev)
+        # fused input projection (las_lstm_recurrent_fwd_x): narrow inputs -- the bottom layer's features -- enter the recurrent
+        # kernel itself; K_x as register-resident fragment images.  LAS_LSTM_FUSED_X=0 keeps the separate x K_x product.
+        self.kx_chunks = hip.lib().las_lstm_fused_input_chunks(H, Dp) if (FUSED_X and D > 0) else 0
+        self.kxp = (torch.empty(nd, (H // 16) * self.kx_chunks * 4 * 512, dtype=torch.bfloat16, device=dev)
+                    if self.kx_chunks else None)
         self.refresh(variables)
 
     def refresh(self, variables):
@@ -163,6 +179,8 @@ class LayerWeights:
             hip.cast_bf16(k, D, 4 * H, self.kx[:, i * 4 * H:], D, 4 * H, ldd=nd * 4 * H, lds=4 * H, perm_h=H)
             hip.cast_bf16(k[D:], H, 4 * H, self.kh[i], H, 4 * H, ldd=4 * H, lds=4 * H, perm_h=H)
             hip.pack_recurrent(k[D:], H, self.khp[i])
+            if self.kx_chunks:
+                hip.pack_input(k, D, H, self.kx_chunks, self.kxp[i])
             hip.bias_interleave(b, H, self.bias[i * 4 * H:(i + 1) * 4 * H])
 
 
@@ -187,7 +205,13 @@ def bilstm(inputs, sequence_length, num_units, dropout, mode, unidirectional=Fal
     dev = inputs.device
     xproj = torch.empty(B, T, nd * 4 * H, dtype=torch.float32, device=dev)
     dropped = None
-    if keep < 1.0 or split_inputs:
+    # narrow inputs (the features): x_t K_x + b is formed inside the recurrent kernel -- no product, no fp32 round trip
+    fused = (weights.kx_chunks > 0 and not split_inputs and Dp == weights.Dp and
+             (keep == 1.0 or nd == 1 or (nd == 2 and Dp % 8 == 0)))
+    fused_x = None                    # (x, ldx, stride between the directions' copies)
+    if fused and keep == 1.0:
+        fused_x = (inputs, Dfull, 0)
+    elif keep < 1.0 or split_inputs:
         # one A operand per direction: DropoutWrapper(input_keep_prob) draws independent masks for the fw and bw
         # cells, fresh per time step (las/ops.py:14-18); split_inputs gives each direction its own columns
         if keep < 1.0 and rng is None:
@@ -212,9 +236,12 @@ def bilstm(inputs, sequence_length, num_units, dropout, mode, unidirectional=Fal
                 a, lda = xd, Dp
             else:
                 a, lda = src, Dfull
-            hip.gemm_nt(a, weights.kxT[i * 4 * H:], xproj[..., i * 4 * H:], B * T, 4 * H, Dp, lda=lda, ldb=Dp,
-                        ldc=nd * 4 * H, bias=weights.bias[i * 4 * H:])
+            if not fused:
+                hip.gemm_nt(a, weights.kxT[i * 4 * H:], xproj[..., i * 4 * H:], B * T, 4 * H, Dp, lda=lda, ldb=Dp,
+                            ldc=nd * 4 * H, bias=weights.bias[i * 4 * H:])
             dropped.append((a, lda))
+        if fused:
+            fused_x = (dropped[0][0], Dp, B * T * Dp if nd == 2 else 0)
     else:
         hip.gemm_nt(inputs, weights.kxT, xproj, B * T, nd * 4 * H, Dp, lda=Dp, ldb=Dp, ldc=nd * 4 * H,
                     bias=weights.bias)
@@ -224,10 +251,18 @@ def bilstm(inputs, sequence_length, num_units, dropout, mode, unidirectional=Fal
     cbuf = torch.empty(B, T, nd * H, dtype=torch.float32, device=dev)
     c_last = torch.empty(nd, B, H, dtype=torch.float32, device=dev)
     h_last = torch.empty(nd, B, H, dtype=torch.float32, device=dev)
-    tok = hip.prof_begin('lstm_fwd', 2.0 * B * T * nd * H * 4 * H)       # the recurrent product h_{t-1} K_h of every step
-    hip.check(hip.lib().las_lstm_recurrent_fwd(hip.p(xproj), hip.p(weights.khp), hip.p(sequence_length), hip.p(y),
-                                               hip.p(cbuf), hip.p(c_last), hip.p(h_last),
-                                               hip.p(lstm_workspace(B, H, nd)), B, T, H, nd, hip.stream()))
+    if fused_x is not None:
+        xa, ldx, xdir = fused_x
+        tok = hip.prof_begin('lstm_fwd', 2.0 * B * T * nd * (H + Dp) * 4 * H)       # h_{t-1} K_h and x_t K_x of every step
+        hip.check(hip.lib().las_lstm_recurrent_fwd_x(hip.p(xa), ldx, xdir, Dp, hip.p(weights.kxp), hip.p(weights.bias), hip.p(xproj),
+                                                     hip.p(weights.khp), hip.p(sequence_length), hip.p(y), hip.p(cbuf),
+                                                     hip.p(c_last), hip.p(h_last), hip.p(lstm_workspace(B, H, nd)),
+                                                     B, T, H, nd, hip.stream()))
+    else:
+        tok = hip.prof_begin('lstm_fwd', 2.0 * B * T * nd * H * 4 * H)       # the recurrent product h_{t-1} K_h of every step
+        hip.check(hip.lib().las_lstm_recurrent_fwd(hip.p(xproj), hip.p(weights.khp), hip.p(sequence_length), hip.p(y),
+                                                   hip.p(cbuf), hip.p(c_last), hip.p(h_last),
+                                                   hip.p(lstm_workspace(B, H, nd)), B, T, H, nd, hip.stream()))
     hip.prof_end(tok)
     if tape is not None:
         tape.append(dict(kind='bilstm', inputs=inputs, length=sequence_length, gates=xproj, cbuf=cbuf, y=y,
@@ -391,13 +426,15 @@ def stacked_bilstm(inputs, sequence_length, mode, hparams, *, weights, tape=None
     return (outputs, sequence_length), (tuple(s[0] for s in per_layer), tuple(s[1] for s in per_layer))
 
 
-def pyramidal_stack(outputs, sequence_length):
-    """las/ops.py:49-65 on the concatenated buffer: [B,T,C] -> [B,T/2,2C] (view), len -> len//2 + len%2."""
+def pyramidal_stack(outputs, sequence_length, new_len=None):
+    """las/ops.py:49-65 on the concatenated buffer: [B,T,C] -> [B,T/2,2C] (view), len -> len//2 + len%2.
+    new_len: the stacked lengths when the caller already has them (pyramidal_bilstm forms all levels in one launch)."""
     B, T, C = outputs.shape
     if T % 2:
         raise ValueError('time dimension must be padded to an even length before pyramidal_stack')
-    new_len = torch.empty_like(sequence_length)
-    hip.check(hip.lib().las_pyramid_lengths(hip.p(sequence_length), hip.p(new_len), B, hip.stream()))
+    if new_len is None:
+        new_len = torch.empty_like(sequence_length)
+        hip.check(hip.lib().las_pyramid_lengths(hip.p(sequence_length), hip.p(new_len), B, hip.stream()))
     return outputs.view(B, T // 2, 2 * C), new_len
 
 
@@ -407,6 +444,11 @@ def pyramidal_bilstm(inputs, sequence_length, mode, hparams, *, variables=None, 
     outputs = inputs
     state = None
     D = in_features
+    levels = None
+    if hparams.num_layers > 1:          # the stacked lengths of every level, before the first layer starts
+        levels = torch.empty(hparams.num_layers - 1, sequence_length.shape[0], dtype=torch.int32, device=sequence_length.device)
+        hip.check(hip.lib().las_pyramid_lengths_multi(hip.p(sequence_length), hip.p(levels), sequence_length.shape[0],
+                                                      hparams.num_layers - 1, hip.stream()))
     for layer in range(hparams.num_layers):
         w = weights[layer] if weights is not None else None
         hooks = after_first_layer if (layer == 0 and after_first_layer is not None) else (None, None)
@@ -418,7 +460,7 @@ def pyramidal_bilstm(inputs, sequence_length, mode, hparams, *, variables=None, 
         if hooks[1] is not None:
             hooks[1]()
         if layer != 0:
-            outputs, sequence_length = pyramidal_stack(outputs, sequence_length)
+            outputs, sequence_length = pyramidal_stack(outputs, sequence_length, new_len=levels[layer - 1])
             if tape is not None:
                 tape.append(dict(kind='stack'))
         D = None

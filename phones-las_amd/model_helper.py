@@ -514,6 +514,23 @@ class LasModel:
         self.process_group = process_group
         self._images_stale = False
         self.overlap = las_model.ops.Overlap()
+        self.tail_buckets = self._tail_buckets()
+
+    def _tail_buckets(self):
+        """Single replica, pyramidal listener: [everything above the bottom listener layer] and [the bottom layer (and
+        whatever the table holds in front of it)] as two pieces of the flat buffers.  The bottom layer's weight-gradient
+        products are the last thing a backward pass computes and nothing hides them; apply_gradients() runs norms + clip +
+        Adam of the first piece beside them and only the second piece after them.  LAS_TAIL_OVERLAP=0: one pass, as before."""
+        e = self.params.encoder
+        if (self.world_size != 1 or self.process_group is not None or not e.use_pyramidal
+                or os.environ.get('LAS_TAIL_OVERLAP', '1') == '0'):
+            return None
+        names = [n for n, _, _ in self.vars.table]
+        lead = next(i for i, n in enumerate(names) if n.startswith('listener/'))
+        k = lead + 2 * (1 if e.unidirectional else 2)
+        if not all(n.startswith('listener/bilstm_0/') for n in names[lead:k]) or k >= len(names):
+            return None
+        return [self.vars._bucket(k, len(names), 0), self.vars._bucket(0, k, 1)]
 
     # -- weights --------------------------------------------------------------------------------
     def load_variables(self, tensors):
@@ -563,7 +580,8 @@ class LasModel:
         U = num_steps if num_steps is not None else int(tlen.max().item())
         loss, logits, dlogits = None, None, []
         for mod, kind in self.spellers:          # audio_loss = sum of the decoders' losses (model_helper.py:337-342)
-            lg = mod.forward_train(mem, mem_len, state, tin, U, seed=step_seed)
+            extra = {'overlap': self.overlap} if isinstance(mod, las_model.Speller) else {}
+            lg = mod.forward_train(mem, mem_len, state, tin, U, seed=step_seed, **extra)
             if kind == 'sigmoid':
                 # compute_loss_sigmoid against the feature vectors of the targets (model_helper.py:199,333-335)
                 l_, dl = compute_loss_sigmoid(lg, mod.emb_bf[tout[:, :U].long()], None, tlen, TRAIN, nf=mod.nf,
@@ -581,10 +599,12 @@ class LasModel:
             self.ctc.forward(mem, mem_len, tout, tlen, loss, 1.0 / self.world_size)
         return loss, logits, dlogits
 
-    def backward(self, dlogits):
-        self.backward_top(dlogits, layers=None)
+    def backward(self, dlogits, join=True):
+        """join=False: the side streams are left running (the bottom layer's weight-gradient products); the caller joins --
+        apply_gradients(joined=False) does, after it has updated the tensors that are already final."""
+        self.backward_top(dlogits, layers=None, join=join)
 
-    def backward_top(self, dlogits, layers=None):
+    def backward_top(self, dlogits, layers=None, join=True):
         """Backward of the speller (+ CTC head) and of the top `layers` listener layers (None: all of them).
         Returns the number of listener layers still to do (backward_rest)."""
         g = self.vars.grads
@@ -614,22 +634,24 @@ class LasModel:
             hip.fill_many(copy=pairs)
             ds = (dc, dh)
         self.listener.backward_begin(dmem, ds)
-        return self.backward_rest(layers)
+        return self.backward_rest(layers, join=join)
 
-    def backward_rest(self, layers=None, defer_last=False):
+    def backward_rest(self, layers=None, defer_last=False, join=True):
         n = self.params.encoder.num_layers if layers is None else layers
         left = self.listener.backward_layers(n, self.vars.grads, self.overlap, defer_last=defer_last)
-        if left == 0:
+        if left == 0 and join:
             self.overlap.join()
         return left
 
-    def gradient_norms(self, bucket=None):
+    def gradient_norms(self, bucket=None, acc=None):
         """grad += l2 * theta (gradient of the L2 term, model_helper.py:411-413) and per-tensor ||grad||^2; the same pass
-        leaves sum theta^2 (the value of the L2 term) in vars.param_sumsq.  bucket: one of vars.buckets (default: all)."""
+        leaves sum theta^2 (the value of the L2 term) in vars.param_sumsq.  bucket: one of vars.buckets (default: all).
+        acc=True: the accumulators are already clear (collect_status(zero_norms=True)): the pass that only adds."""
         v, p = self.vars, self.params
         lib = hip.lib()
         # (after collect_status(zero_norms=True) the accumulators are already clear: the pass that only adds)
-        fn = lib.las_grad_l2_norms_acc if self.__dict__.pop('_norms_zeroed', False) else lib.las_grad_l2_norms
+        zeroed = self.__dict__.pop('_norms_zeroed', False)
+        fn = lib.las_grad_l2_norms_acc if (zeroed if acc is None else acc) else lib.las_grad_l2_norms
         if getattr(v, 'norm_ws', None) is None:     # fixed-order sums of the workgroups' partial norms (no fp32 atomics)
             v.norm_ws = torch.zeros(lib.las_grad_l2_norms_ws_bytes(len(v.table), v.total), dtype=torch.uint8, device=v.flat.device)
         for b in (v.buckets if bucket is None else [bucket]):
@@ -668,25 +690,67 @@ class LasModel:
         hip.check(lib.las_counter_add_unless(hip.p(self.step_dev), 1, hip.p(v.skip_flag), st))   # a withheld update does not consume a step
         self._images_stale = True
 
-    def clip_adam_update(self):
-        """Single replica: the clip and the Adam update in one pass over the buffers (after gradient_norms)."""
+    def clip_adam_update(self, bucket=None, count=True):
+        """Single replica: the clip and the Adam update in one pass over the buffers (after gradient_norms).  bucket: one
+        piece of the flat buffers (tail_buckets); count=False: the step counter stays (another piece of this step follows)."""
         v, p = self.vars, self.params
         lib, st = hip.lib(), hip.stream()
-        hip.check(lib.las_clip_adam_update(hip.p(v.flat), hip.p(v.m), hip.p(v.v), hip.p(v.grad), hip.p(v.seg), len(v.table),
-                                           v.total, hip.p(v.sumsq), float(GRAD_NORM), float(p.learning_rate), 0.9, 0.999, 1e-8,
-                                           0, hip.p(self.step_dev), hip.p(v.skip_flag), st))
-        hip.check(lib.las_counter_add_unless(hip.p(self.step_dev), 1, hip.p(v.skip_flag), st))   # a withheld update does not consume a step
+        if bucket is None:
+            hip.check(lib.las_clip_adam_update(hip.p(v.flat), hip.p(v.m), hip.p(v.v), hip.p(v.grad), hip.p(v.seg), len(v.table),
+                                               v.total, hip.p(v.sumsq), float(GRAD_NORM), float(p.learning_rate), 0.9, 0.999, 1e-8,
+                                               0, hip.p(self.step_dev), hip.p(v.skip_flag), st))
+        else:
+            b = bucket
+            hip.check(lib.las_clip_adam_update(hip.addr(v.flat, b['begin']), hip.addr(v.m, b['begin']), hip.addr(v.v, b['begin']),
+                                               hip.addr(v.grad, b['begin']), hip.p(b['seg']), b['hi'] - b['lo'], b['end'] - b['begin'],
+                                               hip.addr(v.sumsq, b['lo']), float(GRAD_NORM), float(p.learning_rate), 0.9, 0.999,
+                                               1e-8, 0, hip.p(self.step_dev), hip.p(v.skip_flag), st))
+        if count:
+            hip.check(lib.las_counter_add_unless(hip.p(self.step_dev), 1, hip.p(v.skip_flag), st))   # a withheld update does not consume a step
         self._images_stale = True
 
-    def apply_gradients(self):
-        self.collect_status(zero_norms=True)
+    def apply_gradients(self, joined=True, update_tail=True):
+        """The train op after the backward pass.  joined=False (after backward(join=False), single replica with
+        tail_buckets): norms + clip + Adam of everything above the bottom listener layer run while that layer's
+        weight-gradient products are still in flight on the side streams; then the join and the same for the bottom layer.
+        update_tail=False leaves that last clip + Adam launch to the caller (apply_tail(): bench.py's second graph)."""
         if self.world_size == 1 and self.process_group is None:
-            self.gradient_norms()
-            self.clip_adam_update()
+            tb = self.tail_buckets
+            ev = self.listener.before_bottom_grads
+            if not joined and (tb is None or ev is None):
+                self.overlap.join()
+                joined = True
+            self._tail_split = not (joined or tb is None)
+            if not self._tail_split:
+                self.collect_status(zero_norms=True)
+                self.gradient_norms()
+                if update_tail:
+                    self.clip_adam_update()
+                return
+            # the bottom layer's recurrence has been enqueued on this stream; the side streams hold its products
+            torch.cuda.current_stream().wait_event(ev)          # ... and, before them, every other weight gradient
+            self.collect_status(zero_norms=True)
+            self.__dict__.pop('_norms_zeroed', None)
+            self.gradient_norms(tb[0], acc=True)
+            self.clip_adam_update(tb[0], count=False)
+            self.overlap.join()
+            self.gradient_norms(tb[1], acc=True)
+            if update_tail:
+                self.clip_adam_update(tb[1])
         else:
+            if not joined:
+                self.overlap.join()
+            self.collect_status(zero_norms=True)
             self.clip_gradients()
             self.all_reduce_gradients()
             self.adam_update()
+
+    def apply_tail(self):
+        """The launch apply_gradients(update_tail=False) left out."""
+        if getattr(self, '_tail_split', False):
+            self.clip_adam_update(self.tail_buckets[1])
+        else:
+            self.clip_adam_update()
 
     # -- timeouts of the persistent kernels -----------------------------------------------------------------------
     def _status_tensors(self):
@@ -808,8 +872,9 @@ class LasModel:
             self.backward_exchange_end(self.backward_exchange_begin(dlogits))
             self.adam_update()
         else:
-            self.backward(dlogits)
-            self.apply_gradients()
+            tail = self.tail_buckets is not None
+            self.backward(dlogits, join=not tail)
+            self.apply_gradients(joined=not tail)
         loss = self.total_loss(audio_loss)
         self.maybe_add_noise()
         self.global_step += 1         # (the weight images are stale now: the next forward rebuilds them, see refresh_images)

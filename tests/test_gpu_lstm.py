@@ -38,6 +38,9 @@ def _relerr(got, ref):
     (2, 6, 64, 256, [6, 3]),
     (21, 40, 32, 256, [40, 3, 17, 40, 1, 25, 8, 33, 12, 40, 5, 29, 2, 38, 9, 21, 40, 7, 31, 15, 36]),
     (19, 14, 24, 512, [14, 3, 9, 14, 1, 7, 12, 5, 14, 2, 11, 6, 13, 4, 10, 8, 14, 1, 9]),
+    (9, 11, 80, 256, [11, 2, 7, 11, 5, 1, 9, 3, 11]),              # three 32-deep chunks of the fused input projection (F = 80)
+    (5, 9, 72, 128, [9, 4, 1, 9, 6]),
+    (6, 7, 104, 256, [7, 3, 7, 1, 5, 2]),                          # wider than the fused projection takes: the separate product
     (140, 6, 16, 256, [6 - (i * 7) % 6 for i in range(140)]),      # the policy's own choice here: 8-row slices forward, 16 backward
     (600, 5, 16, 256, [5 - (i * 3) % 5 for i in range(600)]),      # 76 chains x 4 workgroups (+ companions): more than the device holds at once
 ])
@@ -119,3 +122,75 @@ def test_unidirectional_and_pyramid_view():
     assert stacked.shape == (B, T // 2, 2 * H) and l2.cpu().tolist() == rl.tolist()
     assert stacked.data_ptr() == y.data_ptr()          # zero-copy
     assert _relerr(stacked.float(), ref) < 1.6e-2
+
+
+@pytest.mark.parametrize('B,T,D,H', [(13, 23, 40, 256), (5, 17, 39, 128), (10, 12, 80, 512), (70, 9, 24, 256)])
+def test_fused_input_projection_matches_the_separate_product(B, T, D, H, monkeypatch):
+    """Round 4: for narrow inputs (the features) x_t K_x + b is formed inside the recurrent kernel (las_lstm_recurrent_fwd_x).
+    Same inputs through both forms: the saved gates agree to fp32 rounding of one more accumulation order, y to a bf16 ulp."""
+    from phones_las_amd.las import ops
+    lengths = [T - (i * 5) % T for i in range(B)]
+    x, length, var = _setup(B, T, D, H, lengths)
+    dvar = {k: v.float().cuda() for k, v in var.items()}
+    Dp = (D + 7) // 8 * 8
+    xd = torch.zeros(B, T, Dp, dtype=torch.bfloat16, device='cuda')
+    xd[..., :D] = x.to(torch.bfloat16).cuda()
+    ld = length.to(torch.int32).cuda()
+    out = {}
+    for fused in (True, False):
+        monkeypatch.setattr(ops, 'FUSED_X', fused)
+        tape = []
+        (ofw, obw), st = ops.bilstm(xd, ld, H, 0.0, ops.TRAIN, variables=dvar, scope='L', tape=tape, in_features=D)
+        torch.cuda.synchronize()
+        ops.check_lstm_status(B, H, 2)
+        assert (tape[0]['weights'].kx_chunks > 0) == fused
+        out[fused] = (ops.concat_outputs((ofw, obw)).float().clone(), tape[0]['gates'].clone(), tape[0]['cbuf'].clone(), st)
+    (ya, ga, ca, sa), (yb, gb, cb, sb) = out[True], out[False]
+    mask = (torch.arange(T, device='cuda')[None, :] < ld[:, None])[..., None]
+    assert float(((ga - gb) * mask).abs().max()) < 2e-2 * 1.0          # gates are in (-1, 1); bf16 h feeds back into them
+    assert float((ya - yb).abs().max()) <= 2 ** -6                        # a couple of bf16 ulps of |h| < 1
+    assert float(((ca - cb) * mask).abs().max()) < 3e-2
+    for d in range(2):
+        assert _relerr(sa[d].c, sb[d].c.double().cpu()) < 1e-2
+
+
+def test_exchange_tags_need_no_memset_between_launches():
+    """Round 4: the exchange buffer is zeroed once, at allocation; every launch offsets its tags by a base kept in the
+    workspace header and moves the base past them when its last workgroup leaves.  Forward and backward launches of two
+    layer shapes share one workspace here, interleaved, many times over: results stay bit-identical, the base grows, and a
+    base about to wrap is started over (the last workgroup clears the buffer)."""
+    from phones_las_amd.las import ops
+    B, H = 21, 256
+    ws = ops.lstm_workspace(B, H, 2)
+    hdr = ws[:64].view(torch.int32)
+
+    def run(T, D, seed):
+        lengths = [T - (i * 5) % T for i in range(B)]
+        x, length, var = _setup(B, T, D, H, lengths, seed=seed)
+        dvar = {k: v.float().cuda() for k, v in var.items()}
+        xd = x.to(torch.bfloat16).cuda()
+        ld = length.to(torch.int32).cuda()
+        tape = []
+        (ofw, obw), _ = ops.bilstm(xd, ld, H, 0.0, ops.TRAIN, variables=dvar, scope='L', tape=tape, in_features=D)
+        y = ops.concat_outputs((ofw, obw)).clone()
+        dy = torch.ones(B, T, 2 * H, dtype=torch.float32, device='cuda')
+        grads = {k: torch.zeros_like(v) for k, v in dvar.items()}
+        dx = ops.bilstm_backward(tape[0], dy, None, grads)
+        torch.cuda.synchronize()
+        ops.check_lstm_status(B, H, 2)
+        return y, dx.clone(), {k: v.clone() for k, v in grads.items()}
+
+    ref = {(T, D): run(T, D, 3) for (T, D) in [(40, 32), (13, 512)]}
+    base0 = int(hdr[4])
+    assert base0 > 0 and int(hdr[5]) == 0                     # the arrival counter is back at zero after every launch
+    for it in range(6):
+        if it == 3:
+            hdr[4] = 0x7ff00000 - 50                          # a base about to wrap: the next launches start it over
+            torch.cuda.synchronize()
+        for key in ref:
+            y, dx, g = run(key[0], key[1], 3)
+            assert torch.equal(y, ref[key][0]) and torch.equal(dx, ref[key][1])
+            for k in g:
+                assert torch.equal(g[k], ref[key][2][k]), k
+        assert int(hdr[5]) == 0
+    assert 0 < int(hdr[4]) < 10000                            # started over from zero
