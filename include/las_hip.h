@@ -76,6 +76,18 @@ const char* las_last_error(void);
 int las_gemm_nt(const las_bf16* A, int64_t lda, const las_bf16* B, int64_t ldb, void* C, int64_t ldc,
                 const float* bias, int M, int N, int K, int out_bf16, int accumulate, int batch,
                 int64_t sa, int64_t sb, int64_t sc, int split_k, void* stream);
+/* The input product of a recurrent layer that runs BESIDE the product (round 4): C [B*T, N] fp32 = A [B*T, K] * Bm [N, K]^T + bias,
+ * row b*T + t = utterance b at time t, the N columns in ndir halves (direction d reads columns [d*N/ndir, (d+1)*N/ndir)).  The
+ * 256 x 128 output tiles are 16 utterances x 16 STEPS of one direction's time order (step tau = time tau forward, time
+ * length - 1 - tau in the reversed direction; steps beyond an utterance's length are not computed) and are handed out step
+ * block by step block; a finished tile adds one to ready[(d * nsb + tau / 16) * nbg + b / 16] (nsb = ceil(T/16), nbg =
+ * ceil(B/16); las_gemm_nt_stream_flags counters, zero before the launch) once its rows are visible device-wide.
+ * las_lstm_recurrent_fwd_ex(ready = ...) consumes the rows as they appear.  N / ndir a multiple of 128, K of 64. */
+int las_gemm_nt_stream_supported(int N, int K, int ndir);
+size_t las_gemm_nt_stream_flags(int B, int T, int ndir);
+int las_gemm_nt_stream(const las_bf16* A, int64_t lda, const las_bf16* Bm, int64_t ldb, float* C, int64_t ldc,
+                       const float* bias, const int32_t* length, int B, int T, int N, int K, int ndir,
+                       uint32_t* ready, void* stream);
 
 /* C (=|+=) (A B^T) * mask / keep, mask[row, col] = [las_uniform(seed, stream_id, row * N + col) < keep]: the gradient through a
  * cell's input dropout (DropoutWrapper(input_keep_prob), las/ops.py:14-18; the mask las_dropout_bf16 drew for that cell in
@@ -232,10 +244,31 @@ int las_lstm_fused_input_chunks(int H, int Dp);
 /* K_x = kernel[0:D, :] (fp32, ld 4H) of one direction -> the fragment-major bf16 image over `chunks` (=
  * las_lstm_fused_input_chunks) 32-deep K chunks, (H/16) * chunks * 4 * 512 elements, zero from row D on. */
 int las_lstm_pack_input(const float* kernel, int D, int H, int chunks, las_bf16* packed, void* stream);
-int las_lstm_recurrent_fwd_x(const las_bf16* x, int64_t ldx, int64_t x_dir_stride, int Dp, const las_bf16* kx_packed,
-                             const float* bias, float* gates, const las_bf16* wpacked, const int32_t* length,
-                             las_bf16* y, float* cbuf, float* c_last, float* h_last, void* workspace, int B, int T,
-                             int H, int ndir, void* stream);
+/* The forward recurrence with its options (las_lstm_recurrent_fwd = all of them off):
+ *   x != NULL      fused input projection, as described above;
+ *   ready != NULL  STREAMED input projection: xproj is being produced by a las_gemm_nt_stream launch that runs beside this
+ *                  one on another stream (launch this kernel first; hold the product back a few microseconds with
+ *                  las_stream_delay so that the chain's workgroups are resident first).  ready = the product's counters,
+ *                  zeroed by the caller before both launches; ready_count = the column tiles per block = N / ndir / 128. */
+typedef struct las_lstm_fwd {
+  float* xproj;                  /* [B,T,ndir*4H] fp32: x K_x + b on entry (unless x != NULL), the saved gates on exit */
+  const las_bf16* wpacked;
+  const int32_t* length;
+  las_bf16* y;
+  float* cbuf;
+  float* c_last;
+  float* h_last;
+  void* workspace;
+  int32_t B, T, H, ndir;
+  const las_bf16* x;             /* fused input projection (optional) */
+  int64_t ldx, x_dir_stride;
+  int32_t Dp, reserved0;
+  const las_bf16* kx_packed;
+  const float* bias;
+  const uint32_t* ready;         /* streamed input projection (optional) */
+  int32_t ready_count, reserved1;
+} las_lstm_fwd;
+int las_lstm_recurrent_fwd_ex(const las_lstm_fwd* p, void* stream);
 
 /* Bytes of device scratch the two recurrent kernels need for (B, H, ndir): a 64-byte header plus the
  * inter-workgroup exchange buffer of the cooperating groups (0 = unsupported num_units).  The caller
@@ -250,6 +283,9 @@ size_t las_lstm_workspace_bytes(int B, int H, int ndir);
  * twice as many chains, chosen for 256 units while every chain and its prefetch companion still find a CU each: the
  * per-step latency is mostly element-wise work per lane).  LAS_LSTM_ROWS=16|8 in the environment overrides (tests). */
 int las_lstm_slice_rows(int B, int H, int ndir);
+/* Workgroups (chain members + prefetch companions, one CU each) of a forward launch for this shape: a streamed input product
+ * (las_gemm_nt_stream) beside it needs CUs of its own, so callers only stream when this leaves some (0 = unsupported). */
+int las_lstm_fwd_workgroups(int B, int H, int ndir);
 
 /* Backward recurrence (reverse-mode AD of the loop above).
  * gates/cbuf: saved by the forward.  dy [B,T,ndir*H] fp32: gradient w.r.t. y.  dc_last/dh_last

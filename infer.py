@@ -13,7 +13,14 @@ split on blanks, stripped and lower-cased, zipped with the predictions in file o
 text-level edit distances against it (infer.py:277-303,338-339; with --mapping on a binary-outputs model the target symbols
 go through the 61->39 style map, infer.py:300-303).  WITHOUT --plain_targets the reference prints no PER at all; here the
 labels stored in the TFRecord serve as targets (same files, same formulas) -- an addition, not a difference in the files.
-Frame-level binary-feature accuracy (TIMIT markup) and text -> IPA conversion are out of scope."""
+Frame-level binary-feature accuracy (TIMIT markup) and text -> IPA conversion are out of scope.
+
+Deliberate deviations in the PRINTED numbers (the files are the reference's):
+  * Optimistic PER, greedy decode: the reference only lowers its per-utterance `min_err = 100000` inside the beam loop
+    (infer.py:278-289), so without --beam_width it adds 100000 per utterance; here the minimum runs over the hypotheses
+    that exist (one, in greedy mode: Optimistic PER = PER).  In its beam loop the reference scores the beams against `t`
+    BEFORE this utterance's `t` is assigned (infer.py:286 vs :296: the previous utterance's target); here against this one's.
+  * blank lines of --plain_targets are skipped; the reference's split(',') would raise on them."""
 import argparse
 import os
 import sys

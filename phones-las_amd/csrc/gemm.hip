@@ -38,6 +38,11 @@ struct GemmArgs {
   // (1 / keep where las_uniform(seed, stream, row * N + col) < keep, else 0) before it is stored or accumulated
   float drop_keep = 1.0f;
   unsigned drop_seed = 0, drop_stream = 0;
+  // las_gemm_nt_stream (gemm_nt_ring_kernel<..., STREAM>): the rows are (utterance, step) pairs handed out in the order a
+  // recurrence beside this launch consumes them; see the kernel
+  const int32_t* length = nullptr;
+  unsigned* ready = nullptr;
+  int sB = 0, sT = 0, s_ndir = 1, s_nsb = 0, s_nbg = 0;
 };
 __device__ __forceinline__ float drop_scale(const GemmArgs& g, int row, int col) {
   return las_uniform(g.drop_seed, g.drop_stream, (unsigned long long)row * g.N + col) < g.drop_keep ? 1.0f / g.drop_keep : 0.f;
@@ -687,7 +692,15 @@ __global__ __launch_bounds__(256) void tn_reduce_kernel(const float* __restrict_
 // so the 32 rows one ds_read_b128 lane group touches fall on 16 distinct (row parity, slot) = 4-bank groups.
 // ------------------------------------------------------------------------------------------------
 // BM x BN output tile, BK-deep stages, STAGES of them; 8 waves as WGM x (8 / WGM)
-template <int BM, int BN, int BK, int STAGES, int WGM>
+// STREAM (round 4, las_gemm_nt_stream): the product feeds a recurrence that runs BESIDE it.  A 256-row tile is then not 256
+// consecutive rows of A but 16 utterances x 16 steps of one direction's time order: tile (step block sb, direction d,
+// utterance block bg, column tile nc of d's half of the N columns), row i of it = utterance bg * 16 + (i >> 4) at step
+// tau = sb * 16 + (i & 15) of ITS sequence, i.e. time t = tau (d = 0) or length - 1 - tau (d = 1, the reversed recurrence);
+// steps beyond an utterance's length are not stored (nobody reads them).  Workgroups are numbered step block by step block,
+// so the dispatcher hands the tiles out in the order the recurrence needs them, and each tile, once its stores are visible
+// device-wide (release fence: L2 write-back), adds one to ready[(d * nsb + sb) * nbg + bg]; the recurrence waits for the
+// count of column tiles of its (direction, step block, utterance block) before it touches the rows.
+template <int BM, int BN, int BK, int STAGES, int WGM, bool STREAM = false>
 __global__ __launch_bounds__(512) void gemm_nt_ring_kernel(GemmArgs g) {
   constexpr int WGN = 8 / WGM;
   constexpr int TM = BM / WGM / 32, TN = BN / WGN / 32;          // 32 x 32 tiles per wave
@@ -709,7 +722,20 @@ __global__ __launch_bounds__(512) void gemm_nt_ring_kernel(GemmArgs g) {
   // XCD-aware tile order (workgroups are dealt round-robin to the 8 XCDs): the column tiles that share a block of A rows
   // are 8 linear ids apart, so an A block enters ONE L2 once
   int bx = blockIdx.x, by = blockIdx.y;
-  {
+  int s_sb = 0, s_d = 0, s_bg = 0;
+  if constexpr (STREAM) {
+    // linear id = ((sb * NC + nc) * ndir + d) * nbg + bg: the (d, bg) blocks of one column tile are neighbours (one per XCD
+    // under round-robin dispatch when there are 8 of them), the column tiles that share an A block 8 ids apart (one L2)
+    static_assert(BM == 256, "streamed tiles are 16 utterances x 16 steps");
+    const int nc_tiles = g.N / g.s_ndir / BN;
+    int id = blockIdx.x;
+    s_bg = id % g.s_nbg; id /= g.s_nbg;
+    s_d = id % g.s_ndir; id /= g.s_ndir;
+    const int nc = id % nc_tiles;
+    s_sb = id / nc_tiles;
+    bx = s_d * nc_tiles + nc;
+    by = 0;
+  } else {
     const int gx = gridDim.x, gy = gridDim.y;
     const int id = bx + gx * by;
     const int full = (gy / 8) * 8 * gx;
@@ -719,7 +745,15 @@ __global__ __launch_bounds__(512) void gemm_nt_ring_kernel(GemmArgs g) {
     }
   }
   const int m0 = by * BM, n0 = bx * BN;
-  const int batch = blockIdx.z;
+  const int batch = STREAM ? 0 : blockIdx.z;
+  // streamed tiles: global row of tile row i, or -1 when that (utterance, step) does not exist
+  auto stream_row = [&](int i) -> int {
+    const int b = s_bg * 16 + (i >> 4), tau = s_sb * 16 + (i & 15);
+    if (b >= g.sB) return -1;
+    const int len = min(g.length[b], g.sT);
+    if (tau >= len) return -1;
+    return b * g.sT + (s_d == 0 ? tau : len - 1 - tau);
+  };
   const unsigned short* A = g.A + (int64_t)batch * g.sa;
   const unsigned short* B = g.B + (int64_t)batch * g.sb;
   const int nk = g.K / BK;
@@ -735,8 +769,10 @@ __global__ __launch_bounds__(512) void gemm_nt_ring_kernel(GemmArgs g) {
     const int q = wave + 8 * (isA ? i : i - NA);
     const int row = RPC * q + lane / CPR;
     const int ch = (lane % CPR) ^ fswz(row);
-    if (isA) src[i] = A + (int64_t)min(m0 + row, g.M - 1) * g.lda + 8 * ch;
-    else src[i] = B + (int64_t)min(n0 + row, g.N - 1) * g.ldb + 8 * ch;
+    if (isA) {
+      if constexpr (STREAM) src[i] = A + (int64_t)max(stream_row(row), 0) * g.lda + 8 * ch;       // (absent rows read row 0: never stored)
+      else src[i] = A + (int64_t)min(m0 + row, g.M - 1) * g.lda + 8 * ch;
+    } else src[i] = B + (int64_t)min(n0 + row, g.N - 1) * g.ldb + 8 * ch;
   }
   auto issue = [&](int stage) {
     const unsigned base = lds_base + stage * STAGE_BYTES;
@@ -835,7 +871,11 @@ __global__ __launch_bounds__(512) void gemm_nt_ring_kernel(GemmArgs g) {
     __builtin_amdgcn_s_waitcnt(0xC07F);        // lgkmcnt(0): a wave reads back only what it wrote itself
 #pragma unroll 4
     for (int r0 = 0; r0 < 32; r0 += RPI) {
-      const int row = m0 + wm * (BM / WGM) + i * 32 + r0 + rl;
+      int row = m0 + wm * (BM / WGM) + i * 32 + r0 + rl;
+      if constexpr (STREAM) {
+        row = stream_row(row);
+        if (row < 0) continue;
+      }
       if (row >= g.M || col >= g.N) continue;
       const float4 v4 = *reinterpret_cast<const float4*>(cs + (r0 + rl) * LDC + cl);
       float v[4] = {v4.x + bv[0], v4.y + bv[1], v4.z + bv[2], v4.w + bv[3]};
@@ -867,6 +907,16 @@ __global__ __launch_bounds__(512) void gemm_nt_ring_kernel(GemmArgs g) {
       }
     }
     __builtin_amdgcn_s_waitcnt(0xC07F);        // the staging rows are rewritten by the next 32 rows
+  }
+  if constexpr (STREAM) {
+    // every wave's stores have been acknowledged (vmcnt(0)) before the barrier; one thread then makes the XCD's dirty lines
+    // visible device-wide (agent-scope release: L2 write-back) and counts the tile in
+    __builtin_amdgcn_s_waitcnt(0x0F70);        // vmcnt(0)
+    __builtin_amdgcn_s_barrier();
+    if (threadIdx.x == 0) {
+      __threadfence();
+      __hip_atomic_fetch_add(g.ready + (s_d * g.s_nsb + s_sb) * g.s_nbg + s_bg, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
   }
 }
 
@@ -1046,6 +1096,41 @@ extern "C" int las_gemm_nt(const las_bf16* A, int64_t lda, const las_bf16* B, in
                            const float* bias, int M, int N, int K, int out_bf16, int accumulate, int batch,
                            int64_t sa, int64_t sb, int64_t sc, int split_k, void* stream) {
   return gemm_nt(A, lda, B, ldb, C, ldc, bias, M, N, K, out_bf16, accumulate, batch, sa, sb, sc, split_k, 1.0f, 0, 0, stream);
+}
+
+extern "C" int las_gemm_nt_stream_supported(int N, int K, int ndir) {
+  return (ndir == 1 || ndir == 2) && N > 0 && (N / ndir) % 128 == 0 && N % ndir == 0 && K >= 128 && K % 64 == 0;
+}
+
+extern "C" size_t las_gemm_nt_stream_flags(int B, int T, int ndir) {
+  return (size_t)ndir * ((T + 15) / 16) * ((B + 15) / 16);
+}
+
+extern "C" int las_gemm_nt_stream(const las_bf16* A, int64_t lda, const las_bf16* Bm, int64_t ldb, float* C, int64_t ldc,
+                                  const float* bias, const int32_t* length, int B, int T, int N, int K, int ndir,
+                                  uint32_t* ready, void* stream) {
+  LAS_REQUIRE(A && Bm && C && length && ready && B > 0 && T > 0, "las_gemm_nt_stream: null argument or empty batch");
+  LAS_REQUIRE(las_gemm_nt_stream_supported(N, K, ndir), "las_gemm_nt_stream: N = %d (per direction a multiple of 128), K = %d (multiple of 64, >= 128), ndir = %d", N, K, ndir);
+  LAS_REQUIRE(lda % 8 == 0 && ldb % 8 == 0 && ldc % 4 == 0 && ((uintptr_t)A % 16 == 0) && ((uintptr_t)Bm % 16 == 0),
+              "las_gemm_nt_stream: operands must be 16-byte aligned, lda / ldb multiples of 8, ldc of 4");
+  GemmArgs g{A, Bm, C, bias, lda, ldb, ldc, 0, 0, 0, B * T, N, K, 0, 0, 0, 1, 0, 0, 0};
+  g.length = length;
+  g.ready = ready;
+  g.sB = B; g.sT = T; g.s_ndir = ndir;
+  g.s_nsb = (T + 15) / 16;
+  g.s_nbg = (B + 15) / 16;
+  constexpr int BM = 256, BN = 128, BK = 32, STAGES = 3, WGM = 4;
+  const int tiles = g.s_nsb * g.s_nbg * ndir * (N / ndir / BN);
+  const size_t lds = (size_t)STAGES * (BM + BN) * BK * 2;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_ring_kernel<BM, BN, BK, STAGES, WGM, true>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((gemm_nt_ring_kernel<BM, BN, BK, STAGES, WGM, true>), dim3(tiles), dim3(512), lds, (hipStream_t)stream, g);
+  LAS_LAUNCH_CHECK("streamed gemm launch");
+  return LAS_OK;
 }
 
 extern "C" int las_gemm_nt_masked(const las_bf16* A, int64_t lda, const las_bf16* B, int64_t ldb, float* C, int64_t ldc,

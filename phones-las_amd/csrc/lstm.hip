@@ -176,7 +176,25 @@ struct FusedInput {
   const unsigned short* kxp;     // ndir images of las_lstm_pack_input
   const float* bias;             // [ndir * 4H] gate-interleaved
   int Dp;                        // valid input columns (multiple of 8, <= 32 * KX)
+  // streamed input projection (round 4): xproj is being written by a las_gemm_nt_stream launch that runs BESIDE this kernel;
+  // ready[(dir * nsb + (s >> 4)) * nbg + utterance / 16] counts the column tiles of a (direction, 16-step block, 16-utterance
+  // block) whose rows are visible device-wide; `want` of them make the block complete.  nullptr: xproj is complete on entry.
+  const unsigned* ready;
+  int nsb, nbg;
+  unsigned want;
 };
+
+// Wait until the streamed rows of step block sb are there (wave-uniform; bounded).  Returns false on timeout.
+__device__ __forceinline__ bool stream_wait(const FusedInput& fi, int dir, int sb, int bgi) {
+  const unsigned* f = fi.ready + ((int64_t)dir * fi.nsb + sb) * fi.nbg + bgi;
+  unsigned spins = 0;
+  while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < fi.want) {
+    if (++spins > SPIN_LIMIT) return false;
+    __builtin_amdgcn_s_sleep(4);
+  }
+  asm volatile("" ::: "memory");        // the rows are read after the count (no acquire fence: nobody has touched these lines before)
+  return true;
+}
 
 template <int H, int ROWS, int G, int KX>
 __device__ __forceinline__ void lstm_fwd_body(float* __restrict__ xproj, const unsigned short* __restrict__ wpacked,
@@ -273,6 +291,10 @@ __device__ __forceinline__ void lstm_fwd_body(float* __restrict__ xproj, const u
           if (++spins > SPIN_LIMIT) return;
           __builtin_amdgcn_s_sleep(8);
         }
+      }
+      if constexpr (KX == 0) {
+        // streamed xproj: a line must not enter this XCD's L2 before the product has written it (it would stay stale there)
+        if (fi.ready != nullptr && (sp & 15) == 0 && !stream_wait(fi, dir, sp >> 4, (slice * ROWS) >> 4)) return;
       }
 #pragma unroll
       for (int r4 = 0; r4 < RL; ++r4) {
@@ -436,6 +458,37 @@ __device__ __forceinline__ void lstm_fwd_body(float* __restrict__ xproj, const u
     }
     pending = false;
   };
+  // fused input projection: accx = x_s K_x of the step about to run, formed from xa = x_s; then xa <- x_{s+1} is requested
+  f32x4 accx[4][UB];
+  auto input_products = [&](int s, auto lean_tag) {        // s: the step the products are for (xa holds x_s)
+    constexpr bool LEAN = decltype(lean_tag)::value;
+    if constexpr (KX > 0) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int ub = 0; ub < UB; ++ub) accx[g][ub] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int kc = 0; kc < KX; ++kc)
+#pragma unroll
+        for (int ub = 0; ub < UB; ++ub)
+#pragma unroll
+          for (int g = 0; g < 4; ++g) accx[g][ub] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xa[kc], wx[ub][kc][g], accx[g][ub], 0, 0, 0);
+      if constexpr (LEAN) {
+        if (s + 1 < xa_len) xa_off += (unsigned)xa_step;      // (a row that ends here re-reads its last frame: never used)
+#pragma unroll
+        for (int kc = 0; kc < KX; ++kc) xa[kc] = *reinterpret_cast<const bf16x8*>(xa_base + xa_off + xa_col[kc]);
+      } else {
+        const int sn = s + 1;
+        const int posn = sn < xa_len ? (dir == 0 ? sn : xa_len - 1 - sn) : 0;
+        const int64_t o = (((int64_t)xa_b * T + posn) * fi.ldx) * 2;
+#pragma unroll
+        for (int kc = 0; kc < KX; ++kc) xa[kc] = *reinterpret_cast<const bf16x8*>(xa_base + o + xa_col[kc]);
+      }
+    }
+  };
+  if constexpr (KX > 0) {
+    if (smin > 0) input_products(0, std::true_type{}); else input_products(0, std::false_type{});
+  }
   auto step = [&](int s, auto lean_tag) {
     constexpr bool LEAN = decltype(lean_tag)::value;
     bool act[RL];
@@ -449,6 +502,10 @@ __device__ __forceinline__ void lstm_fwd_body(float* __restrict__ xproj, const u
       }
     }
     LSTM_STAMP(0, s, 0);
+    if constexpr (KX == 0) {
+      // streamed xproj: the first step of a 16-step block waits for the block's rows (normally long there: the product runs ahead)
+      if (fi.ready != nullptr && (s & 15) == 0 && !stream_wait(fi, dir, s >> 4, (slice * ROWS) >> 4)) fail_flag = 1;
+    }
     // x_t K_x + b of this step: issued now, consumed after the MFMAs
     float4 xp[UB][RL];
     f32x4 acc[4][UB];
@@ -457,25 +514,12 @@ __device__ __forceinline__ void lstm_fwd_body(float* __restrict__ xproj, const u
 #pragma unroll
       for (int ub = 0; ub < UB; ++ub) acc[g][ub] = f32x4{0.f, 0.f, 0.f, 0.f};
     if constexpr (KX > 0) {
-      // the input products of this step (x_t arrived during the previous one), then x_{t+1} is requested: both ahead of the
-      // polls, i.e. in the shadow of the exchange
+      // the input products of this step were formed at the END of the previous one (input_products below), behind its granule
+      // stores: in the shadow of the exchange, not in front of this step's polls
 #pragma unroll
-      for (int kc = 0; kc < KX; ++kc)
+      for (int g = 0; g < 4; ++g)
 #pragma unroll
-        for (int ub = 0; ub < UB; ++ub)
-#pragma unroll
-          for (int g = 0; g < 4; ++g) acc[g][ub] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xa[kc], wx[ub][kc][g], acc[g][ub], 0, 0, 0);
-      if constexpr (LEAN) {
-        if (s + 1 < xa_len) xa_off += (unsigned)xa_step;      // (a row that ends here re-reads its last frame: never used)
-#pragma unroll
-        for (int kc = 0; kc < KX; ++kc) xa[kc] = *reinterpret_cast<const bf16x8*>(xa_base + xa_off + xa_col[kc]);
-      } else {
-        const int sn = s + 1;
-        const int posn = sn < xa_len ? (dir == 0 ? sn : xa_len - 1 - sn) : 0;
-        const int64_t o = (((int64_t)xa_b * T + posn) * fi.ldx) * 2;
-#pragma unroll
-        for (int kc = 0; kc < KX; ++kc) xa[kc] = *reinterpret_cast<const bf16x8*>(xa_base + o + xa_col[kc]);
-      }
+        for (int ub = 0; ub < UB; ++ub) acc[g][ub] = accx[g][ub];
 #pragma unroll
       for (int ub = 0; ub < UB; ++ub)
 #pragma unroll
@@ -590,6 +634,7 @@ __device__ __forceinline__ void lstm_fwd_body(float* __restrict__ xproj, const u
         }
       }
       LSTM_STAMP(0, s, 4);
+      if constexpr (KX > 0) input_products(s + 1, lean_tag);       // x_{s+1} K_x (+ the request for x_{s+2}): the peers have their granules
 #pragma unroll
       for (int ub = 0; ub < UB; ++ub) {
         const int unit = unit0 + ub * 16;
@@ -1188,7 +1233,19 @@ int launch_fwd_as(float* xproj, const las_bf16* wp, const int32_t* length, las_b
   unsigned* status = reinterpret_cast<unsigned*>(ws);
   u64* exch = reinterpret_cast<u64*>(reinterpret_cast<char*>(ws) + 64);
   const int pf = prefetch_mode();
-  hipLaunchKernelGGL((lstm_fwd_kernel<H, ROWS, G, KX>), dim3(pf ? g.blocks + g.companions : g.blocks), dim3(256), 0, st, xproj, wp, length, y,
+  // A streamed input product runs beside this launch (fi.ready): asking for LDS the kernel does not use keeps its workgroups
+  // (72 KiB each) off the CUs of the chain's workgroups, as the backward launch does for the weight-gradient products.
+  size_t hog = 0;
+  if (fi.ready != nullptr) {
+    static int hog_kb = -1;
+    if (hog_kb < 0) {
+      constexpr int static_kb = (2 * 16 * (H + 8) * 2 + 1024 + 4096 + 1023) / 1024 + 2;
+      hog_kb = 160 - static_kb - 6;
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&lstm_fwd_kernel<H, ROWS, G, KX>), hipFuncAttributeMaxDynamicSharedMemorySize, hog_kb * 1024);
+    }
+    hog = (size_t)hog_kb * 1024;
+  }
+  hipLaunchKernelGGL((lstm_fwd_kernel<H, ROWS, G, KX>), dim3(pf ? g.blocks + g.companions : g.blocks), dim3(256), hog, st, xproj, wp, length, y,
                      cbuf, c_last, h_last, exch, status, B, T, ndir, g.ngroups, pf, exch_words(B, H, ndir), fi);
   LAS_LAUNCH_CHECK("lstm fwd launch");
   return LAS_OK;
@@ -1295,6 +1352,12 @@ extern "C" int las_lstm_slice_rows(int B, int H, int ndir) {
   return slice_rows(B, H, ndir, false);
 }
 
+extern "C" int las_lstm_fwd_workgroups(int B, int H, int ndir) {
+  if (!supported_units(H) || B <= 0) return 0;
+  const CoopGeom g = geom(B, H, ndir, false, slice_rows(B, H, ndir, false));
+  return g.blocks + (prefetch_mode() ? g.companions : 0);
+}
+
 extern "C" size_t las_lstm_workspace_bytes(int B, int H, int ndir) {
   if (!supported_units(H) || B <= 0) return 0;
   size_t n = 0;
@@ -1353,18 +1416,23 @@ extern "C" int las_lstm_pack_input(const float* kernel, int D, int H, int chunks
   return LAS_OK;
 }
 
-extern "C" int las_lstm_recurrent_fwd_x(const las_bf16* x, int64_t ldx, int64_t x_dir_stride, int Dp, const las_bf16* kx_packed,
-                                        const float* bias, float* gates, const las_bf16* wpacked, const int32_t* length,
-                                        las_bf16* y, float* cbuf, float* c_last, float* h_last, void* workspace, int B, int T,
-                                        int H, int ndir, void* stream) {
-  LAS_REQUIRE(x != nullptr && kx_packed != nullptr && bias != nullptr, "las_lstm_recurrent_fwd_x: x, kx_packed and bias are required");
-  LAS_REQUIRE(supported_units(H) && fused_input_chunks(H, Dp) > 0, "las_lstm_recurrent_fwd_x: no fused input projection for H=%d, Dp=%d "
-              "(las_lstm_fused_input_chunks)", H, Dp);
-  LAS_REQUIRE(ldx >= Dp && ldx % 8 == 0 && ((uintptr_t)x % 16 == 0), "las_lstm_recurrent_fwd_x: x rows must be 16-byte aligned (ldx %% 8 == 0)");
-  FusedInput fi;
-  fi.x = reinterpret_cast<const unsigned short*>(x); fi.ldx = ldx; fi.xdir = x_dir_stride;
-  fi.kxp = reinterpret_cast<const unsigned short*>(kx_packed); fi.bias = bias; fi.Dp = Dp;
-  return recurrent_fwd(gates, wpacked, length, y, cbuf, c_last, h_last, workspace, B, T, H, ndir, stream, fi);
+extern "C" int las_lstm_recurrent_fwd_ex(const las_lstm_fwd* p, void* stream) {
+  LAS_REQUIRE(p != nullptr, "las_lstm_recurrent_fwd_ex: null argument");
+  FusedInput fi{};
+  if (p->x != nullptr) {
+    LAS_REQUIRE(p->kx_packed != nullptr && p->bias != nullptr, "las_lstm_recurrent_fwd_ex: the fused input projection needs kx_packed and bias");
+    LAS_REQUIRE(supported_units(p->H) && fused_input_chunks(p->H, p->Dp) > 0, "las_lstm_recurrent_fwd_ex: no fused input projection for H=%d, Dp=%d "
+                "(las_lstm_fused_input_chunks)", p->H, p->Dp);
+    LAS_REQUIRE(p->ldx >= p->Dp && p->ldx % 8 == 0 && ((uintptr_t)p->x % 16 == 0), "las_lstm_recurrent_fwd_ex: x rows must be 16-byte aligned (ldx %% 8 == 0)");
+    LAS_REQUIRE(p->ready == nullptr, "las_lstm_recurrent_fwd_ex: fused and streamed input projections exclude each other");
+    fi.x = reinterpret_cast<const unsigned short*>(p->x); fi.ldx = p->ldx; fi.xdir = p->x_dir_stride;
+    fi.kxp = reinterpret_cast<const unsigned short*>(p->kx_packed); fi.bias = p->bias; fi.Dp = p->Dp;
+  }
+  if (p->ready != nullptr) {
+    LAS_REQUIRE(p->ready_count > 0, "las_lstm_recurrent_fwd_ex: ready_count = column tiles per block of the streamed product");
+    fi.ready = p->ready; fi.nsb = (p->T + 15) / 16; fi.nbg = (p->B + 15) / 16; fi.want = (unsigned)p->ready_count;
+  }
+  return recurrent_fwd(p->xproj, p->wpacked, p->length, p->y, p->cbuf, p->c_last, p->h_last, p->workspace, p->B, p->T, p->H, p->ndir, stream, fi);
 }
 
 extern "C" int las_lstm_recurrent_bwd(const float* gates, const float* cbuf, const float* dy, const float* dc_last,

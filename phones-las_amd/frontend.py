@@ -169,7 +169,7 @@ def calculate_acoustic_features(args, waveform):
 
 
 def calculate_acoustic_features_batch(args, waveforms):
-    """calculate_acoustic_features over a LIST of waveforms in three launches (las_fe_batch_melspec / _finish / _delta over the
+    """calculate_acoustic_features over a LIST of waveforms in three kernel launches (las_fe_batch_melspec -- preceded by one small fill of its per-utterance maxima -- / _finish / _delta over the
     frames of all utterances; a fourth of two small kernels when --energy / --deltas are off is not needed).  The per-frame
     arithmetic is that of the per-utterance kernels in the same order: the result is bit-identical to calling
     calculate_acoustic_features on every waveform.  Returns a list of CUDA fp32 tensors [T_u, F] (views of one buffer).

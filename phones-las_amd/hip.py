@@ -39,9 +39,13 @@ _SIGS = {
     'las_lstm_recurrent_bwd': ([_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp], C.c_int),
     'las_lstm_fused_input_chunks': ([_i32, _i32], C.c_int),
     'las_lstm_pack_input': ([_vp, _i32, _i32, _i32, _vp, _vp], C.c_int),
-    'las_lstm_recurrent_fwd_x': ([_vp, _i64, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp], C.c_int),
+    'las_lstm_recurrent_fwd_ex': ([_vp, _vp], C.c_int),
+    'las_gemm_nt_stream_supported': ([_i32, _i32, _i32], C.c_int),
+    'las_gemm_nt_stream_flags': ([_i32, _i32, _i32], C.c_size_t),
+    'las_gemm_nt_stream': ([_vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp], C.c_int),
     'las_lstm_workspace_bytes': ([_i32, _i32, _i32], C.c_size_t),
     'las_lstm_slice_rows': ([_i32, _i32, _i32], C.c_int),
+    'las_lstm_fwd_workgroups': ([_i32, _i32, _i32], C.c_int),
     'las_pyramid_lengths': ([_vp, _vp, _i32, _vp], C.c_int),
     'las_pyramid_lengths_multi': ([_vp, _vp, _i32, _i32, _vp], C.c_int),
     'las_decoder_step_fwd': ([_vp, _i32, _vp], C.c_int),
@@ -108,6 +112,14 @@ _SIGS = {
 # entry points declared in include/las_hip.h whose kernels are not written yet (shrinks to empty)
 _PENDING = set()
 EXPORTS = tuple(n for n in _SIGS if n not in _PENDING)
+
+
+class LstmFwd(C.Structure):
+    """struct las_lstm_fwd (include/las_hip.h)."""
+    _fields_ = [('xproj', _vp), ('wpacked', _vp), ('length', _vp), ('y', _vp), ('cbuf', _vp), ('c_last', _vp), ('h_last', _vp),
+                ('workspace', _vp), ('B', _i32), ('T', _i32), ('H', _i32), ('ndir', _i32),
+                ('x', _vp), ('ldx', _i64), ('x_dir_stride', _i64), ('Dp', _i32), ('reserved0', _i32), ('kx_packed', _vp), ('bias', _vp),
+                ('ready', _vp), ('ready_count', _i32), ('reserved1', _i32)]
 
 
 class DecStep(C.Structure):

@@ -140,6 +140,21 @@ class _NoOverlap:
 
 # LAS_LSTM_FUSED_X=0: the bottom layer's input projection as a separate product again (diagnostics, A/B timing)
 FUSED_X = os.environ.get('LAS_LSTM_FUSED_X', '1') != '0'
+# LAS_LSTM_STREAM=0: the upper layers' input products run to completion BEFORE their recurrence again.  Default: the product
+# (las_gemm_nt_stream) runs on a second stream BESIDE the recurrence and hands its rows over step block by step block.
+STREAM_X = os.environ.get('LAS_LSTM_STREAM', '1') != '0'
+STREAM_MIN_ROWS = int(os.environ.get('LAS_LSTM_STREAM_MIN_ROWS', '4096'))      # smaller products are not worth the hand-over
+STREAM_MAX_WORKGROUPS = 192       # the recurrence (members + companions, a CU each) must leave CUs to the product beside it
+_PRODUCT_STREAMS = {}
+
+
+def _product_stream():
+    """The stream the streamed input products run on (one per device; its work is always joined by the launching stream)."""
+    dev = torch.cuda.current_device()
+    st = _PRODUCT_STREAMS.get(dev)
+    if st is None:
+        st = _PRODUCT_STREAMS[dev] = torch.cuda.Stream()
+    return st
 
 
 def _dirs(unidirectional):
@@ -205,6 +220,7 @@ def bilstm(inputs, sequence_length, num_units, dropout, mode, unidirectional=Fal
     dev = inputs.device
     xproj = torch.empty(B, T, nd * 4 * H, dtype=torch.float32, device=dev)
     dropped = None
+    stream_ready = None
     # narrow inputs (the features): x_t K_x + b is formed inside the recurrent kernel -- no product, no fp32 round trip
     fused = (weights.kx_chunks > 0 and not split_inputs and Dp == weights.Dp and
              (keep == 1.0 or nd == 1 or (nd == 2 and Dp % 8 == 0)))
@@ -243,21 +259,57 @@ def bilstm(inputs, sequence_length, num_units, dropout, mode, unidirectional=Fal
         if fused:
             fused_x = (dropped[0][0], Dp, B * T * Dp if nd == 2 else 0)
     else:
-        hip.gemm_nt(inputs, weights.kxT, xproj, B * T, nd * 4 * H, Dp, lda=Dp, ldb=Dp, ldc=nd * 4 * H,
-                    bias=weights.bias)
+        lib = hip.lib()
+        # the recurrence's slices must not straddle the product's 16-utterance blocks, and the chain must leave CUs to the product
+        streamed = (STREAM_X and H >= 256 and B * T >= STREAM_MIN_ROWS and lib.las_gemm_nt_stream_supported(nd * 4 * H, Dp, nd) == 1
+                    and 16 % max(lib.las_lstm_slice_rows(B, H, nd), 1) == 0
+                    and 0 < lib.las_lstm_fwd_workgroups(B, H, nd) <= STREAM_MAX_WORKGROUPS)
+        if streamed:
+            # x K_x BESIDE the recurrence: counters zeroed here, the product on its own stream (held back a few microseconds
+            # so that the chain's workgroups are resident first), the recurrence consumes the rows as they become visible
+            n = lib.las_gemm_nt_stream_flags(B, T, nd)
+            ready = weights.__dict__.setdefault('_ready', {}).get((B, T))
+            if ready is None:
+                ready = weights._ready[(B, T)] = torch.zeros(n, dtype=torch.int32, device=dev)
+            hip.fill_many(zero=[ready])
+            cur, side = torch.cuda.current_stream(), _product_stream()
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):
+                hip.check(lib.las_stream_delay(Overlap.BESIDE_US, hip.stream()))
+                tok = hip.prof_begin('gemm_nt', 2.0 * B * T * nd * 4 * H * Dp)
+                hip.check(lib.las_gemm_nt_stream(hip.p(inputs), Dp, hip.p(weights.kxT), Dp, hip.p(xproj), nd * 4 * H, hip.p(weights.bias),
+                                                 hip.p(sequence_length), B, T, nd * 4 * H, Dp, nd, hip.p(ready), hip.stream()))
+                hip.prof_end(tok)
+            stream_ready = (ready, 4 * H // 128, side, (inputs, xproj))
+        else:
+            hip.gemm_nt(inputs, weights.kxT, xproj, B * T, nd * 4 * H, Dp, lda=Dp, ldb=Dp, ldc=nd * 4 * H,
+                        bias=weights.bias)
     if after_projection is not None:
         after_projection()          # (LasModel: side-stream work that should run beside this layer's recurrence starts here)
     y = torch.empty(B, T, nd * H, dtype=torch.bfloat16, device=dev)
     cbuf = torch.empty(B, T, nd * H, dtype=torch.float32, device=dev)
     c_last = torch.empty(nd, B, H, dtype=torch.float32, device=dev)
     h_last = torch.empty(nd, B, H, dtype=torch.float32, device=dev)
-    if fused_x is not None:
-        xa, ldx, xdir = fused_x
-        tok = hip.prof_begin('lstm_fwd', 2.0 * B * T * nd * (H + Dp) * 4 * H)       # h_{t-1} K_h and x_t K_x of every step
-        hip.check(hip.lib().las_lstm_recurrent_fwd_x(hip.p(xa), ldx, xdir, Dp, hip.p(weights.kxp), hip.p(weights.bias), hip.p(xproj),
-                                                     hip.p(weights.khp), hip.p(sequence_length), hip.p(y), hip.p(cbuf),
-                                                     hip.p(c_last), hip.p(h_last), hip.p(lstm_workspace(B, H, nd)),
-                                                     B, T, H, nd, hip.stream()))
+    if fused_x is not None or stream_ready is not None:
+        a = hip.LstmFwd()
+        a.xproj, a.wpacked, a.length, a.y, a.cbuf = hip.addr(xproj), hip.addr(weights.khp), hip.addr(sequence_length), hip.addr(y), hip.addr(cbuf)
+        a.c_last, a.h_last, a.workspace = hip.addr(c_last), hip.addr(h_last), hip.addr(lstm_workspace(B, H, nd))
+        a.B, a.T, a.H, a.ndir = B, T, H, nd
+        flops = 2.0 * B * T * nd * H * 4 * H
+        if fused_x is not None:
+            xa, ldx, xdir = fused_x
+            a.x, a.ldx, a.x_dir_stride, a.Dp = hip.addr(xa), ldx, xdir, Dp
+            a.kx_packed, a.bias = hip.addr(weights.kxp), hip.addr(weights.bias)
+            flops += 2.0 * B * T * nd * Dp * 4 * H                            # x_t K_x of every step as well
+        else:
+            a.ready, a.ready_count = hip.addr(stream_ready[0]), stream_ready[1]
+        tok = hip.prof_begin('lstm_fwd', flops)
+        import ctypes
+        hip.check(hip.lib().las_lstm_recurrent_fwd_ex(ctypes.byref(a), hip.stream()))
+        if stream_ready is not None:
+            # (the product is done long before the recurrence is; everything later on this stream is ordered behind both,
+            # so the operands need no record_stream)
+            torch.cuda.current_stream().wait_stream(stream_ready[2])
     else:
         tok = hip.prof_begin('lstm_fwd', 2.0 * B * T * nd * H * 4 * H)       # the recurrent product h_{t-1} K_h of every step
         hip.check(hip.lib().las_lstm_recurrent_fwd(hip.p(xproj), hip.p(weights.khp), hip.p(sequence_length), hip.p(y),

@@ -103,7 +103,6 @@ def main(args):
             for (_, tokens), feats in zip(pending, features_of([w for w, _ in pending])):
                 if feats is None:
                     continue
-                vocabulary.update(tokens)
                 if args.save_norm:
                     m, s = feats.mean(0), feats.std(0)
                     means, stds = (m, s) if means is None else (means + m, stds + s)
@@ -129,6 +128,9 @@ def main(args):
             except Exception as e:  # noqa: BLE001
                 print('Hopefully recoverable error: %s' % e)
                 continue
+            # (the vocabulary counts a line's tokens BEFORE its features are formed, as the reference does,
+            # preprocess_all.py:147-148: a line whose audio then fails still contributes to vocab.txt -- ADVICE r3)
+            vocabulary.update(tokens)
             pending.append((waveform, tokens))
             if len(pending) >= max(1, args.gpu_batch):
                 flush()

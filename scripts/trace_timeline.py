@@ -1,8 +1,10 @@
+# prints the dispatch timeline of the LAST train step in a rocprofv3 --kernel-trace CSV: start offset, duration, gap to the previous end, queue, name
 import csv, glob, sys, re
 f = glob.glob(sys.argv[1] + '/**/*kernel_trace.csv', recursive=True)[0]
 rows = list(csv.DictReader(open(f)))
 rows.sort(key=lambda r: int(r['Start_Timestamp']))
-idx = [i for i, r in enumerate(rows) if 'clip_adam' in r['Kernel_Name'] or 'adam_kernel' in r['Kernel_Name']]
+# a step = from one counter_add launch (the last launch of a train step) to the next
+idx = [i for i, r in enumerate(rows) if 'counter_add' in r['Kernel_Name']]
 a, b = idx[-2] + 1, idx[-1] + 1
 t0 = int(rows[a]['Start_Timestamp'])
 prev_end = t0

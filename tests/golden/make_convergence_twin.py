@@ -1,0 +1,71 @@
+"""Trains the ORACLE (oracle/las_oracle.py: exact f64 model and its bf16 storage model) on the toy corpus of
+tests/twin_corpus.py for STEPS optimiser steps and writes the loss curve checkpoints and the final greedy PER on the held-out
+utterances to tests/golden/convergence_twin.json -- the fixture tests/test_gpu_convergence.py holds the device against.
+
+    python tests/golden/make_convergence_twin.py [f64|bf16 ...]     (build container, CPU; ~10 min per model)
+
+The only available stand-in for north_star's "matched TIMIT PER": the reference's TF-1 graph cannot run here and no corpus
+ships with it, so the question the twin answers is whether the device's bf16 operand storage (3e-2 worst-case gradient error
+against the exact model) changes WHERE training ends up."""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, '..', '..'))
+from oracle import las_oracle as O          # noqa: E402
+from tests import twin_corpus as TC         # noqa: E402
+
+OUT = os.path.join(HERE, 'convergence_twin.json')
+
+
+def oracle_hp():
+    m = TC.MODEL
+    return O.HP(encoder=O.EncoderHP(num_layers=m['L'], num_units=m['H']), num_channels=m['F'],
+                decoder=O.DecoderHP(num_layers=1, num_units=m['Hd'], target_vocab_size=m['V'], attention_type=m['att'],
+                                    bottom_only=True, pass_hidden_state=True),
+                learning_rate=m['lr'], l2_reg_scale=m['l2'])
+
+
+def to_torch(b):
+    return {k: torch.tensor(v.astype(np.float64) if k == 'encoder_inputs' else v.astype(np.int64)) for k, v in b.items()}
+
+
+def run(mxu):
+    hp = oracle_hp()
+    p = O.init_params(hp, seed=4321)
+    m = {k: torch.zeros_like(v) for k, v in p.items()}
+    v = {k: torch.zeros_like(x) for k, x in p.items()}
+    batches = [to_torch(b) for b in TC.train_batches()]
+    curve, losses = {}, []
+    t0 = time.time()
+    for t in range(TC.STEPS):
+        out = O.train_step(hp, p, None, None, t + 1, batches[t % len(batches)], mxu=mxu)
+        losses.append(float(out['loss']))
+        if t + 1 in TC.CHECKPOINTS:
+            curve[t + 1] = float(np.mean(losses[-TC.WINDOW:]))
+            print(mxu, t + 1, curve[t + 1], '%.0f s' % (time.time() - t0), flush=True)
+        p, m, v = O.adam_apply(p, m, v, out['clipped'], t + 1, hp.learning_rate)
+    tb, refs = TC.test_batches()
+    hyps = []
+    with torch.no_grad():
+        for b in tb:
+            b = to_torch(b)
+            (mem, ml), st = O.listener(b['encoder_inputs'], b['source_sequence_length'], p, hp.encoder, mxu)
+            _, ids, _, _ = O.speller_greedy(hp, p, mem, ml, st, mxu)
+            hyps += [row.tolist() for row in ids]
+    return dict(curve={str(k): v for k, v in curve.items()}, per=TC.per(hyps, refs), seconds=round(time.time() - t0))
+
+
+if __name__ == '__main__':
+    which = sys.argv[1:] or ['f64', 'bf16']
+    res = json.load(open(OUT)) if os.path.exists(OUT) else {}
+    res['corpus'] = dict(n_train=TC.N_TRAIN, n_test=TC.N_TEST, batch=TC.BATCH, steps=TC.STEPS, noise=TC.NOISE, window=TC.WINDOW, model=TC.MODEL)
+    for mxu in which:
+        res[mxu] = run(mxu)
+        json.dump(res, open(OUT, 'w'), indent=1)
+    print(json.dumps(res, indent=1))

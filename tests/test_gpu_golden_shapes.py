@@ -244,9 +244,16 @@ def test_cfg5_at_its_stated_size_matches_the_fixture():
     # bf16 model's forward roundings put it on the other side of that edge than the exact model and the device (its score-path
     # gradients -- memory_layer, query_layer, attention_v, score_bias -- are 18-20 % larger from that single (utterance, step)
     # entry; every other step agrees to 1 %: measured with the oracle alone).
-    assert rep['grad_worst_f64'][1] < 3e-2, rep['grad_worst_f64']
-    assert rep['gradnorm_worst_f64'][1] < 3e-2, rep['gradnorm_worst_f64']
-    assert rep['grad_worst'][1] < 0.4, rep['grad_worst']
+    # Round 4: which side of that edge the DEVICE lands on depends on its own forward roundings -- with the bottom layer's
+    # input projection accumulated inside the recurrence (one more change of summation order) it moved from the exact model's
+    # side (1.4e-2 / 9.6e-3 against f64) to the bf16 model's (9.4e-3 / 6.0e-3 against bf16; 0.27 against f64 on the
+    # score-path tensors).  Both are restatements of the same formula, so the assertion is: EVERY tensor agrees with one of the
+    # two models within that model's tolerance (bf16 model: 1e-2 / 2 %; exact model: 3e-2 / 3 %), and all tensors with the SAME
+    # one (the device cannot be on both sides of the edge at once).
+    per = rep['grad_per_tensor']
+    fits_bf16 = all(v[0] < TOL['grad'] and v[1] < TOL['gradnorm'] for v in per.values())
+    fits_f64 = all(v[2] < 3e-2 and v[3] < 3e-2 for v in per.values())
+    assert fits_bf16 or fits_f64, (rep['grad_worst'], rep['gradnorm_worst'], rep['grad_worst_f64'], rep['gradnorm_worst_f64'])
 
 
 @pytest.mark.parametrize('case', ['dec512_groups', 'dec512_groups_luong'])

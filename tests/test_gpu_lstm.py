@@ -194,3 +194,38 @@ def test_exchange_tags_need_no_memset_between_launches():
                 assert torch.equal(g[k], ref[key][2][k]), k
         assert int(hdr[5]) == 0
     assert 0 < int(hdr[4]) < 10000                            # started over from zero
+
+
+@pytest.mark.parametrize('B,T,D,H,ragged', [(21, 40, 512, 256, True), (64, 48, 512, 256, False), (64, 37, 1024, 256, True),
+                                             (19, 23, 128, 512, True), (5, 7, 512, 256, True)])
+def test_streamed_input_product_matches_the_product_before_the_recurrence(B, T, D, H, ragged, monkeypatch):
+    """Round 4: the input product of the upper layers runs on a second stream BESIDE the recurrence (las_gemm_nt_stream: tiles
+    of 16 utterances x 16 steps in consumption order, a counter per block; las_lstm_recurrent_fwd_ex(ready=...) waits on it).
+    Same inputs through both forms, several times over (the hand-over is a race if anything is wrong with it): the saved
+    gates, cell states and outputs must agree -- bit for bit where both products run on the same matrix-core instruction."""
+    from phones_las_amd.las import ops
+    monkeypatch.setattr(ops, 'STREAM_MIN_ROWS', 0)
+    lengths = [T - (i * 5) % T if ragged else T for i in range(B)]
+    x, length, var = _setup(B, T, D, H, lengths)
+    dvar = {k: v.float().cuda() for k, v in var.items()}
+    xd = (x * 0.25).to(torch.bfloat16).cuda()
+    ld = length.to(torch.int32).cuda()
+    out = {}
+    for streamed in (False, True, True, True):
+        monkeypatch.setattr(ops, 'STREAM_X', streamed)
+        tape = []
+        (ofw, obw), st = ops.bilstm(xd, ld, H, 0.0, ops.TRAIN, variables=dvar, scope='L', tape=tape, in_features=D)
+        torch.cuda.synchronize()
+        ops.check_lstm_status(B, H, 2)
+        got = (ops.concat_outputs((ofw, obw)).float().clone(), tape[0]['gates'].clone(), tape[0]['cbuf'].clone())
+        if streamed not in out:
+            out[streamed] = got
+        else:                                     # streamed runs repeat exactly
+            for a, b in zip(got, out[streamed]):
+                mask = (torch.arange(T, device='cuda')[None, :] < ld[:, None])[..., None]
+                assert torch.equal(a * mask, b * mask)
+    mask = (torch.arange(T, device='cuda')[None, :] < ld[:, None])[..., None]
+    (ya, ga, ca), (yb, gb, cb) = out[True], out[False]
+    assert float(((ga - gb) * mask).abs().max()) < 2e-2
+    assert float((ya - yb).abs().max()) <= 2 ** -6
+    assert float(((ca - cb) * mask).abs().max()) < 3e-2

@@ -83,7 +83,12 @@ def to_device(features, labels, dev):
 
 def save_checkpoint(model, path):
     v = model.vars
+    # global_step = steps the host has issued; adam_step = updates the device has APPLIED + 1 (its Adam t).  They differ only
+    # when a step's update was withheld after a persistent-kernel timeout (las_counter_add_unless) -- and this function is
+    # only reached behind a check_device_status() that raises in that case -- but the checkpoint keeps both, so a resumed run
+    # continues with the device's own bias-correction count whatever happened.
     torch.save({'flat': v.flat.cpu(), 'm': v.m.cpu(), 'v': v.v.cpu(), 'global_step': model.global_step,
+                'adam_step': int(model.step_dev.item()),
                 'names': [n for n, _, _ in v.table], 'offsets': v.offsets}, path + '.tmp')
     os.replace(path + '.tmp', path)
 
@@ -95,7 +100,7 @@ def load_checkpoint(model, path):
         raise ValueError('checkpoint %s does not match the model built from hparams.json' % path)
     v.flat.copy_(ck['flat']); v.m.copy_(ck['m']); v.v.copy_(ck['v'])
     model.global_step = int(ck['global_step'])
-    model.step_dev.fill_(model.global_step + 1)
+    model.step_dev.fill_(int(ck.get('adam_step', model.global_step + 1)))
     model.refresh_images()
 
 
