@@ -42,6 +42,7 @@ struct GemmArgs {
   // recurrence beside this launch consumes them; see the kernel
   const int32_t* length = nullptr;
   unsigned* ready = nullptr;
+  int stream_fence = 0;
   int sB = 0, sT = 0, s_ndir = 1, s_nsb = 0, s_nbg = 0;
 };
 __device__ __forceinline__ float drop_scale(const GemmArgs& g, int row, int col) {
@@ -900,6 +901,13 @@ __global__ __launch_bounds__(512) void gemm_nt_ring_kernel(GemmArgs g) {
           const float4 c = *reinterpret_cast<const float4*>(Cf + off);
           o.x += c.x; o.y += c.y; o.z += c.z; o.w += c.w;
         }
+        if constexpr (STREAM) {
+          // write-through (agent scope): the rows are visible device-wide once the store is acknowledged -- no L2 write-back
+          // fence at the end of the tile (a buffer_wbl2 walks the whole L2 of the XCD, 3 200 times per launch, beside a
+          // recurrence whose exchange lives in that L2)
+          const f32x4 ov = {o.x, o.y, o.z, o.w};
+          asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(Cf + off), "v"(ov) : "memory");
+        } else
         *reinterpret_cast<float4*>(Cf + off) = o;
       } else {
         for (int e = 0; e < 4; ++e)
@@ -914,7 +922,7 @@ __global__ __launch_bounds__(512) void gemm_nt_ring_kernel(GemmArgs g) {
     __builtin_amdgcn_s_waitcnt(0x0F70);        // vmcnt(0)
     __builtin_amdgcn_s_barrier();
     if (threadIdx.x == 0) {
-      __threadfence();
+      if (g.stream_fence) __threadfence();       // (diagnostics: plain stores would need it; the write-through stores do not)
       __hip_atomic_fetch_add(g.ready + (s_d * g.s_nsb + s_sb) * g.s_nbg + s_bg, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
@@ -1119,6 +1127,7 @@ extern "C" int las_gemm_nt_stream(const las_bf16* A, int64_t lda, const las_bf16
   g.sB = B; g.sT = T; g.s_ndir = ndir;
   g.s_nsb = (T + 15) / 16;
   g.s_nbg = (B + 15) / 16;
+  { const char* e = getenv("LAS_STREAM_FENCE"); g.stream_fence = (e && atoi(e) == 1) ? 1 : 0; }
   constexpr int BM = 256, BN = 128, BK = 32, STAGES = 3, WGM = 4;
   const int tiles = g.s_nsb * g.s_nbg * ndir * (N / ndir / BN);
   const size_t lds = (size_t)STAGES * (BM + BN) * BK * 2;

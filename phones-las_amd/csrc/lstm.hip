@@ -1240,10 +1240,12 @@ int launch_fwd_as(float* xproj, const las_bf16* wp, const int32_t* length, las_b
     static int hog_kb = -1;
     if (hog_kb < 0) {
       constexpr int static_kb = (2 * 16 * (H + 8) * 2 + 1024 + 4096 + 1023) / 1024 + 2;
-      hog_kb = 160 - static_kb - 6;
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&lstm_fwd_kernel<H, ROWS, G, KX>), hipFuncAttributeMaxDynamicSharedMemorySize, hog_kb * 1024);
+      const char* e = getenv("LAS_STREAM_HOG_KB");          // (diagnostics: 0 lets the product's workgroups share the chain's CUs)
+      hog_kb = e ? atoi(e) : 160 - static_kb - 6;
+      if (hog_kb > 160 - static_kb - 2) hog_kb = 160 - static_kb - 2;
+      if (hog_kb > 0) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&lstm_fwd_kernel<H, ROWS, G, KX>), hipFuncAttributeMaxDynamicSharedMemorySize, hog_kb * 1024);
     }
-    hog = (size_t)hog_kb * 1024;
+    hog = (size_t)(hog_kb > 0 ? hog_kb : 0) * 1024;
   }
   hipLaunchKernelGGL((lstm_fwd_kernel<H, ROWS, G, KX>), dim3(pf ? g.blocks + g.companions : g.blocks), dim3(256), hog, st, xproj, wp, length, y,
                      cbuf, c_last, h_last, exch, status, B, T, ndir, g.ngroups, pf, exch_words(B, H, ndir), fi);

@@ -20,7 +20,7 @@ sys.path.insert(0, os.path.join(HERE, '..', '..'))
 from oracle import las_oracle as O          # noqa: E402
 from tests import twin_corpus as TC         # noqa: E402
 
-OUT = os.path.join(HERE, 'convergence_twin.json')
+OUT = os.environ.get('TWIN_OUT') or os.path.join(HERE, 'convergence_twin.json')
 
 
 def oracle_hp():

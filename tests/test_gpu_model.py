@@ -668,8 +668,11 @@ def test_persistent_decoder_edge_shapes_match_per_step_path(B, T, U, src_len, tg
     # (the one-launch kernels sum the context on the matrix cores, the alignments as a high + low bf16 pair: a context
     # element that rounds to the other bf16 neighbour moves the logits by ~1e-4)
     assert relerr(outs['1'][0], outs['0'][0].cpu()) < 1e-3
+    # (gradients: 2e-3, except with a single decoder step and a single utterance, where one d(score) element that rounds to the
+    # other bf16 neighbour in one of the two paths IS the whole d(memory) = d(scores)^T (h W_mem^T): one bf16 ulp, 2^-8 = 3.9e-3)
+    tol = 4.5e-3 if B * U == 1 else 2e-3
     for name in outs['1'][1]:
-        assert relerr(outs['1'][1][name], outs['0'][1][name].cpu()) < 2e-3, name
+        assert relerr(outs['1'][1][name], outs['0'][1][name].cpu()) < tol, name
 
 
 def test_persistent_decoder_beyond_one_chunk_of_groups(monkeypatch):

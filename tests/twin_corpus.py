@@ -9,11 +9,11 @@ F, NPHONES = 13, 10
 V = NPHONES + 3                      # <unk>, <s>, </s> + phones (ids 3 ..): utils/vocab_utils.py:24-28
 SOS, EOS = 1, 2
 N_TRAIN, N_TEST, BATCH = 512, 128, 16
-STEPS = 1200
-CHECKPOINTS = [10, 50, 100, 200, 400, 600, 800, 1000, 1200]
-WINDOW = 10                          # a checkpoint is the MEAN loss of the WINDOW steps that end there (single steps spike)
+STEPS = 2400
+CHECKPOINTS = [10, 50, 100, 200, 400, 800, 1200, 1600, 2000, 2400]
+WINDOW = 32                          # a checkpoint is the MEAN loss of the WINDOW steps that end there (single steps spike)
 NOISE = 0.9
-MODEL = dict(F=F, L=2, H=64, Hd=64, V=V, att='luong', lr=2e-3, l2=1e-6)
+MODEL = dict(F=F, L=2, H=64, Hd=64, V=V, att='luong', lr=1e-3, l2=1e-6)
 
 
 def utterances(n, seed):
