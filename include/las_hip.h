@@ -77,17 +77,19 @@ int las_gemm_nt(const las_bf16* A, int64_t lda, const las_bf16* B, int64_t ldb, 
                 const float* bias, int M, int N, int K, int out_bf16, int accumulate, int batch,
                 int64_t sa, int64_t sb, int64_t sc, int split_k, void* stream);
 /* The input product of a recurrent layer that runs BESIDE the product (round 4): C [B*T, N] fp32 = A [B*T, K] * Bm [N, K]^T + bias,
- * row b*T + t = utterance b at time t, the N columns in ndir halves (direction d reads columns [d*N/ndir, (d+1)*N/ndir)).  The
- * 256 x 128 output tiles are 16 utterances x 16 STEPS of one direction's time order (step tau = time tau forward, time
- * length - 1 - tau in the reversed direction; steps beyond an utterance's length are not computed) and are handed out step
- * block by step block; a finished tile adds one to ready[(d * nsb + tau / 16) * nbg + b / 16] (nsb = ceil(T/16), nbg =
- * ceil(B/16); las_gemm_nt_stream_flags counters, zero before the launch) once its rows are visible device-wide.
- * las_lstm_recurrent_fwd_ex(ready = ...) consumes the rows as they appear.  N / ndir a multiple of 128, K of 64. */
+ * row b*T + t = utterance b at time t, the N columns in ndir halves (direction d reads columns [d*N/ndir, (d+1)*N/ndir)).  A
+ * 256 x 128 output tile is the rows_per_slice (= las_lstm_slice_rows) utterances of ONE chain group x 256 / rows_per_slice
+ * STEPS of its direction's time order (step tau = time tau forward, time length - 1 - tau in the reversed direction; steps
+ * beyond an utterance's length are not computed).  The kernel is persistent and XCD-aware: the recurrence
+ * (las_lstm_recurrent_fwd_ex(ready = ...), launched FIRST, on another stream) publishes in `ready` on which XCD each of its
+ * groups runs; a product workgroup serves the groups of ITS XCD, step block by step block, so that a tile is written into the
+ * L2 its consumer reads from, and counts finished column tiles per (group, step block) there.  `ready`:
+ * las_gemm_nt_stream_flags(...) 32-bit words, zero before both launches.  N / ndir a multiple of 128, K of 64. */
 int las_gemm_nt_stream_supported(int N, int K, int ndir);
-size_t las_gemm_nt_stream_flags(int B, int T, int ndir);
+size_t las_gemm_nt_stream_flags(int B, int T, int ndir, int rows_per_slice);
 int las_gemm_nt_stream(const las_bf16* A, int64_t lda, const las_bf16* Bm, int64_t ldb, float* C, int64_t ldc,
                        const float* bias, const int32_t* length, int B, int T, int N, int K, int ndir,
-                       uint32_t* ready, void* stream);
+                       int rows_per_slice, uint32_t* ready, void* stream);
 
 /* C (=|+=) (A B^T) * mask / keep, mask[row, col] = [las_uniform(seed, stream_id, row * N + col) < keep]: the gradient through a
  * cell's input dropout (DropoutWrapper(input_keep_prob), las/ops.py:14-18; the mask las_dropout_bf16 drew for that cell in
@@ -248,8 +250,9 @@ int las_lstm_pack_input(const float* kernel, int D, int H, int chunks, las_bf16*
  *   x != NULL      fused input projection, as described above;
  *   ready != NULL  STREAMED input projection: xproj is being produced by a las_gemm_nt_stream launch that runs beside this
  *                  one on another stream (launch this kernel first; hold the product back a few microseconds with
- *                  las_stream_delay so that the chain's workgroups are resident first).  ready = the product's counters,
- *                  zeroed by the caller before both launches; ready_count = the column tiles per block = N / ndir / 128. */
+ *                  las_stream_delay so that the chain's workgroups are resident first).  ready = the buffer shared with the
+ *                  product (las_gemm_nt_stream_flags words, zeroed by the caller before both launches: this launch writes its
+ *                  groups' XCDs into it and waits on the product's counters); ready_count = column tiles per block = N / ndir / 128. */
 typedef struct las_lstm_fwd {
   float* xproj;                  /* [B,T,ndir*4H] fp32: x K_x + b on entry (unless x != NULL), the saved gates on exit */
   const las_bf16* wpacked;
@@ -265,7 +268,7 @@ typedef struct las_lstm_fwd {
   int32_t Dp, reserved0;
   const las_bf16* kx_packed;
   const float* bias;
-  const uint32_t* ready;         /* streamed input projection (optional) */
+  uint32_t* ready;               /* streamed input projection (optional): shared with las_gemm_nt_stream, written by both */
   int32_t ready_count, reserved1;
 } las_lstm_fwd;
 int las_lstm_recurrent_fwd_ex(const las_lstm_fwd* p, void* stream);
@@ -609,6 +612,20 @@ int las_add_noise(float* p, int64_t n, float std, uint32_t seed, uint32_t stream
 int las_seq_ce_loss(const float* logits, int64_t ldl, const int32_t* targets, const int32_t* target_len,
                     int B, int U, int V, float grad_scale, float* loss_out, las_bf16* dlogits, int64_t ldd,
                     void* stream);
+
+/* Output projection + the loss above + its backward through the projection in ONE launch (round 4; the phone decoder's TRAIN
+ * path, las/model.py:251-257 + model_helper.py:24-30): logits [B*U, Vp] fp32 = ctx [B*U, M] (bf16, row stride ld_ctx) wprojT^T +
+ * bproj (wprojT [Vp, M]: the projection kernel transposed, zero rows from V on; bproj [Vp]); *loss_out = the sequence loss
+ * (STORED, not added: nothing to zero first); dlogits [B*U, Vp] bf16 as las_seq_ce_loss leaves it; dctx [B*U, M] fp32 (row stride
+ * ld_dctx) = dlogits wproj^T with wproj [M, Vp] bf16.  targets [B, >= U] int32 with row stride target_stride.  Supported when
+ * las_proj_ce_supported(V, Vp, M): Vp a multiple of 16 up to 128, M a multiple of 128.  workspace: las_proj_ce_workspace_bytes
+ * bytes, 16-byte aligned, ZERO before the first use (every launch leaves it zero); one launch at a time per workspace. */
+int las_proj_ce_supported(int V, int Vp, int M);
+size_t las_proj_ce_workspace_bytes(int B, int U);
+int las_proj_ce(const las_bf16* ctx, int64_t ld_ctx, const las_bf16* wprojT, const float* bproj, const las_bf16* wproj,
+                const int32_t* targets, int64_t target_stride, const int32_t* target_len, int B, int U, int V, int Vp, int M,
+                float grad_scale, float* logits, las_bf16* dlogits, float* dctx, int64_t ld_dctx, float* loss_out,
+                void* workspace, void* stream);
 
 /* One step of tf.contrib.seq2seq.BeamSearchDecoder (las/model.py:312-319, length_penalty_weight 0) for B utterances of
  * K beams: logits [B*K, V] fp32 (row stride ldl) of this step; log_probs / finished / lengths [B,K] are the beam state

@@ -3442,8 +3442,12 @@ __global__ __launch_bounds__(256) void dec_persist_bwd_kernel(las_dec_persist_bw
       // re-uses a few registers for the operand pieces: dependent round trips to L2): chunks past the end of K re-read the
       // last one against zero weights, absent tiles multiply zero weights, absent utterances' rows are dropped below,
       // and rows 8..15 of the MFMA tile (never read) all load one piece
-      // (those lanes read 16 zero bytes of the workspace header: words 4..7 are never written.  Zeros, not "anything":
-      //  with uninitialised memory there -- NaN / Inf patterns -- the gradients came out wrong in the full test run)
+      // (those lanes read 16 bytes of the workspace header: words 4..7 are never written, so they are zeros.  Round 3 noted
+      //  "wrong gradients with uninitialised memory there" without finding a consumer that mixes rows.  Round 4 ran the
+      //  experiment: NaN / Inf / max-finite / 1.0 patterns in exactly these 16 bytes, forward and backward workspace, 128 and
+      //  256 units, Luong and Bahdanau, one and two groups -- logits and gradients bit-identical to the clean run in all 64
+      //  combinations (tests/test_gpu_model.py::test_padding_rows_of_the_one_launch_decoders_do_not_leak keeps it so).  The
+      //  rows do not leak; what round 3 saw was not this read.  Zeros stay: one cache line every lane group shares.)
       const unsigned short* zrow = (l15 < 8) ? s0.dz + (int64_t)min(bg, B - 1) * s0.ldz + (int64_t)t * p.inc_dz + 8 * lq
                                              : reinterpret_cast<const unsigned short*>(reinterpret_cast<const char*>(p.workspace) + 16);
       const int zstep = (l15 < 8) ? 32 : 0;

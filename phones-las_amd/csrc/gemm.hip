@@ -42,9 +42,16 @@ struct GemmArgs {
   // recurrence beside this launch consumes them; see the kernel
   const int32_t* length = nullptr;
   unsigned* ready = nullptr;
-  int stream_fence = 0;
-  int sB = 0, sT = 0, s_ndir = 1, s_nsb = 0, s_nbg = 0;
+  int sB = 0, sT = 0, s_ndir = 1, s_nsb = 0, sR = 4, s_nslices = 0;
 };
+
+// Layout of the `ready` buffer shared by las_gemm_nt_stream and the recurrence it feeds (32-bit words, zero before both launches):
+//   [0, 8)                      per-XCD tile queues (next tile index of the XCD's list)
+//   [16, 16 + ngroups)          written by the RECURRENCE at its start: group g = dir * nslices + slice runs on XCD x -> x + 1;
+//                               its members are spread over several XCDs -> LAS_STREAM_SPREAD
+//   [flags, flags + ngroups*nsb) column tiles finished of (group, step block): flags = 16 + ngroups rounded up to 16
+constexpr unsigned LAS_STREAM_SPREAD = 0x100u;
+__host__ __device__ inline int las_stream_flags_offset(int ngroups) { return 16 + ((ngroups + 15) & ~15); }
 __device__ __forceinline__ float drop_scale(const GemmArgs& g, int row, int col) {
   return las_uniform(g.drop_seed, g.drop_stream, (unsigned long long)row * g.N + col) < g.drop_keep ? 1.0f / g.drop_keep : 0.f;
 }
@@ -694,13 +701,17 @@ __global__ __launch_bounds__(256) void tn_reduce_kernel(const float* __restrict_
 // ------------------------------------------------------------------------------------------------
 // BM x BN output tile, BK-deep stages, STAGES of them; 8 waves as WGM x (8 / WGM)
 // STREAM (round 4, las_gemm_nt_stream): the product feeds a recurrence that runs BESIDE it.  A 256-row tile is then not 256
-// consecutive rows of A but 16 utterances x 16 steps of one direction's time order: tile (step block sb, direction d,
-// utterance block bg, column tile nc of d's half of the N columns), row i of it = utterance bg * 16 + (i >> 4) at step
-// tau = sb * 16 + (i & 15) of ITS sequence, i.e. time t = tau (d = 0) or length - 1 - tau (d = 1, the reversed recurrence);
-// steps beyond an utterance's length are not stored (nobody reads them).  Workgroups are numbered step block by step block,
-// so the dispatcher hands the tiles out in the order the recurrence needs them, and each tile, once its stores are visible
-// device-wide (release fence: L2 write-back), adds one to ready[(d * nsb + sb) * nbg + bg]; the recurrence waits for the
-// count of column tiles of its (direction, step block, utterance block) before it touches the rows.
+// consecutive rows of A but the R utterances of ONE slice of the recurrence (one chain group) x 256 / R steps of that
+// group's direction: row i = utterance slice * R + i / (256/R) at step tau = sb * (256/R) + i % (256/R) of ITS sequence,
+// i.e. time t = tau (d = 0) or length - 1 - tau (d = 1, the reversed recurrence); steps beyond an utterance's length are not
+// stored (nobody reads them).  The kernel is PERSISTENT and XCD-aware: a workgroup reads its XCC id, collects the chain
+// groups that run on the same XCD (the recurrence publishes where its groups sit) and takes their tiles from that XCD's
+// queue, step block by step block -- so a tile is written into the L2 its consumer reads from: plain stores, an L2-level
+// counter (column tiles finished of (group, step block)) and plain loads are coherent there, with no device-wide release
+// (a buffer_wbl2 per tile walks the whole L2 -- measured: it cost the recurrence beside it 25 % -- and write-through stores
+// without it are NOT ordered against the counter: tiles arrived torn).  Groups whose members are spread over XCDs (never seen
+// under an otherwise idle dispatcher, but placement is not a contract) are dealt to the XCDs round-robin and take the
+// write-back fence.
 template <int BM, int BN, int BK, int STAGES, int WGM, bool STREAM = false>
 __global__ __launch_bounds__(512) void gemm_nt_ring_kernel(GemmArgs g) {
   constexpr int WGN = 8 / WGM;
@@ -720,21 +731,50 @@ __global__ __launch_bounds__(512) void gemm_nt_ring_kernel(GemmArgs g) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WGN, wn = wave % WGN;
-  // XCD-aware tile order (workgroups are dealt round-robin to the 8 XCDs): the column tiles that share a block of A rows
-  // are 8 linear ids apart, so an A block enters ONE L2 once
-  int bx = blockIdx.x, by = blockIdx.y;
-  int s_sb = 0, s_d = 0, s_bg = 0;
+  // ---- streamed form: this XCD's list of chain groups, then tiles from its queue until the list is done ----
+  __shared__ int s_list[STREAM ? 256 : 1];
+  __shared__ int s_n, s_q;
+  int my_xcd = 0;
   if constexpr (STREAM) {
-    // linear id = ((sb * NC + nc) * ndir + d) * nbg + bg: the (d, bg) blocks of one column tile are neighbours (one per XCD
-    // under round-robin dispatch when there are 8 of them), the column tiles that share an A block 8 ids apart (one L2)
-    static_assert(BM == 256, "streamed tiles are 16 utterances x 16 steps");
+    static_assert(BM == 256, "streamed tiles are one slice x 256 / R steps");
+    unsigned xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    my_xcd = (int)(xcc & 7);
+    if (tid == 0) {
+      const int ngroups = g.s_nslices * g.s_ndir;
+      int n = 0;
+      for (int gi = 0; gi < ngroups && gi < 256; ++gi) {
+        unsigned v = 0, spins = 0;
+        do {            // the recurrence publishes its groups' XCDs when it starts (it is launched first)
+          v = __hip_atomic_load(g.ready + 16 + gi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (v != 0) break;
+          __builtin_amdgcn_s_sleep(8);
+        } while (++spins < (1u << 17));
+        if (v == (unsigned)my_xcd + 1u || ((v == LAS_STREAM_SPREAD || v == 0) && (gi & 7) == my_xcd)) s_list[n++] = gi | (v == (unsigned)my_xcd + 1u ? 0 : 0x10000);
+      }
+      s_n = n;
+    }
+    __syncthreads();
+  }
+  for (;;) {
+  int bx = blockIdx.x, by = blockIdx.y;
+  int s_sb = 0, s_d = 0, s_slice = 0, s_group = 0;
+  bool s_spread = false;
+  if constexpr (STREAM) {
     const int nc_tiles = g.N / g.s_ndir / BN;
-    int id = blockIdx.x;
-    s_bg = id % g.s_nbg; id /= g.s_nbg;
-    s_d = id % g.s_ndir; id /= g.s_ndir;
-    const int nc = id % nc_tiles;
-    s_sb = id / nc_tiles;
-    bx = s_d * nc_tiles + nc;
+    __syncthreads();                              // the previous tile's epilogue has left the LDS; s_q may be rewritten
+    if (tid == 0) s_q = (int)__hip_atomic_fetch_add(g.ready + my_xcd, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    const int q = s_q, per_sb = s_n * nc_tiles;
+    if (per_sb == 0 || q >= per_sb * g.s_nsb) break;
+    // step block by step block; inside a block the column tiles of one group are neighbours (they share the A rows)
+    s_sb = q / per_sb;
+    const int r = q % per_sb, e = s_list[r / nc_tiles];
+    s_group = e & 0xffff;
+    s_spread = (e >> 16) != 0;
+    s_d = s_group / g.s_nslices;
+    s_slice = s_group % g.s_nslices;
+    bx = s_d * nc_tiles + r % nc_tiles;
     by = 0;
   } else {
     const int gx = gridDim.x, gy = gridDim.y;
@@ -749,7 +789,8 @@ __global__ __launch_bounds__(512) void gemm_nt_ring_kernel(GemmArgs g) {
   const int batch = STREAM ? 0 : blockIdx.z;
   // streamed tiles: global row of tile row i, or -1 when that (utterance, step) does not exist
   auto stream_row = [&](int i) -> int {
-    const int b = s_bg * 16 + (i >> 4), tau = s_sb * 16 + (i & 15);
+    const int sbs = 256 / g.sR;                   // steps per block (R = 4: 64)
+    const int b = s_slice * g.sR + i / sbs, tau = s_sb * sbs + i % sbs;
     if (b >= g.sB) return -1;
     const int len = min(g.length[b], g.sT);
     if (tau >= len) return -1;
@@ -901,13 +942,6 @@ __global__ __launch_bounds__(512) void gemm_nt_ring_kernel(GemmArgs g) {
           const float4 c = *reinterpret_cast<const float4*>(Cf + off);
           o.x += c.x; o.y += c.y; o.z += c.z; o.w += c.w;
         }
-        if constexpr (STREAM) {
-          // write-through (agent scope): the rows are visible device-wide once the store is acknowledged -- no L2 write-back
-          // fence at the end of the tile (a buffer_wbl2 walks the whole L2 of the XCD, 3 200 times per launch, beside a
-          // recurrence whose exchange lives in that L2)
-          const f32x4 ov = {o.x, o.y, o.z, o.w};
-          asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(Cf + off), "v"(ov) : "memory");
-        } else
         *reinterpret_cast<float4*>(Cf + off) = o;
       } else {
         for (int e = 0; e < 4; ++e)
@@ -917,15 +951,19 @@ __global__ __launch_bounds__(512) void gemm_nt_ring_kernel(GemmArgs g) {
     __builtin_amdgcn_s_waitcnt(0xC07F);        // the staging rows are rewritten by the next 32 rows
   }
   if constexpr (STREAM) {
-    // every wave's stores have been acknowledged (vmcnt(0)) before the barrier; one thread then makes the XCD's dirty lines
-    // visible device-wide (agent-scope release: L2 write-back) and counts the tile in
+    // every wave's stores have been acknowledged by this XCD's L2 (vmcnt(0)) before the barrier; the consumer reads through the
+    // same L2, so the counter (an L2 atomic) may follow at once.  Spread groups: device-wide release first (L2 write-back).
     __builtin_amdgcn_s_waitcnt(0x0F70);        // vmcnt(0)
     __builtin_amdgcn_s_barrier();
     if (threadIdx.x == 0) {
-      if (g.stream_fence) __threadfence();       // (diagnostics: plain stores would need it; the write-through stores do not)
-      __hip_atomic_fetch_add(g.ready + (s_d * g.s_nsb + s_sb) * g.s_nbg + s_bg, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (s_spread) __threadfence();
+      __hip_atomic_fetch_add(g.ready + las_stream_flags_offset(g.s_nslices * g.s_ndir) + s_group * g.s_nsb + s_sb, 1u, __ATOMIC_RELAXED,
+                             __HIP_MEMORY_SCOPE_AGENT);
     }
+  } else {
+    break;
   }
+  }   // for (;;): the streamed form takes the next tile of its XCD's queue
 }
 
 template <int BM, int BN, int BK, int STAGES, int WGM>
@@ -1110,26 +1148,28 @@ extern "C" int las_gemm_nt_stream_supported(int N, int K, int ndir) {
   return (ndir == 1 || ndir == 2) && N > 0 && (N / ndir) % 128 == 0 && N % ndir == 0 && K >= 128 && K % 64 == 0;
 }
 
-extern "C" size_t las_gemm_nt_stream_flags(int B, int T, int ndir) {
-  return (size_t)ndir * ((T + 15) / 16) * ((B + 15) / 16);
+extern "C" size_t las_gemm_nt_stream_flags(int B, int T, int ndir, int rows_per_slice) {
+  if (rows_per_slice != 4 && rows_per_slice != 8 && rows_per_slice != 16) return 0;
+  const int nslices = (B + rows_per_slice - 1) / rows_per_slice, ngroups = nslices * ndir, sbs = 256 / rows_per_slice;
+  return (size_t)las_stream_flags_offset(ngroups) + (size_t)ngroups * ((T + sbs - 1) / sbs);
 }
 
 extern "C" int las_gemm_nt_stream(const las_bf16* A, int64_t lda, const las_bf16* Bm, int64_t ldb, float* C, int64_t ldc,
                                   const float* bias, const int32_t* length, int B, int T, int N, int K, int ndir,
-                                  uint32_t* ready, void* stream) {
+                                  int rows_per_slice, uint32_t* ready, void* stream) {
   LAS_REQUIRE(A && Bm && C && length && ready && B > 0 && T > 0, "las_gemm_nt_stream: null argument or empty batch");
   LAS_REQUIRE(las_gemm_nt_stream_supported(N, K, ndir), "las_gemm_nt_stream: N = %d (per direction a multiple of 128), K = %d (multiple of 64, >= 128), ndir = %d", N, K, ndir);
+  LAS_REQUIRE(rows_per_slice == 4 || rows_per_slice == 8 || rows_per_slice == 16, "las_gemm_nt_stream: rows_per_slice = the recurrence's slice height (4, 8, 16)");
   LAS_REQUIRE(lda % 8 == 0 && ldb % 8 == 0 && ldc % 4 == 0 && ((uintptr_t)A % 16 == 0) && ((uintptr_t)Bm % 16 == 0),
               "las_gemm_nt_stream: operands must be 16-byte aligned, lda / ldb multiples of 8, ldc of 4");
   GemmArgs g{A, Bm, C, bias, lda, ldb, ldc, 0, 0, 0, B * T, N, K, 0, 0, 0, 1, 0, 0, 0};
   g.length = length;
   g.ready = ready;
-  g.sB = B; g.sT = T; g.s_ndir = ndir;
-  g.s_nsb = (T + 15) / 16;
-  g.s_nbg = (B + 15) / 16;
-  { const char* e = getenv("LAS_STREAM_FENCE"); g.stream_fence = (e && atoi(e) == 1) ? 1 : 0; }
+  g.sB = B; g.sT = T; g.s_ndir = ndir; g.sR = rows_per_slice;
+  g.s_nslices = (B + rows_per_slice - 1) / rows_per_slice;
+  g.s_nsb = (T + 256 / rows_per_slice - 1) / (256 / rows_per_slice);
+  LAS_REQUIRE(g.s_nslices * ndir <= 256, "las_gemm_nt_stream: at most 256 chain groups");
   constexpr int BM = 256, BN = 128, BK = 32, STAGES = 3, WGM = 4;
-  const int tiles = g.s_nsb * g.s_nbg * ndir * (N / ndir / BN);
   const size_t lds = (size_t)STAGES * (BM + BN) * BK * 2;
   static bool attr_set = false;
   if (!attr_set) {
@@ -1137,7 +1177,9 @@ extern "C" int las_gemm_nt_stream(const las_bf16* A, int64_t lda, const las_bf16
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
-  hipLaunchKernelGGL((gemm_nt_ring_kernel<BM, BN, BK, STAGES, WGM, true>), dim3(tiles), dim3(512), lds, (hipStream_t)stream, g);
+  // persistent: two workgroups per CU would fit; whatever is resident on an XCD works through that XCD's queue, the rest of the
+  // grid finds the queues empty and leaves
+  hipLaunchKernelGGL((gemm_nt_ring_kernel<BM, BN, BK, STAGES, WGM, true>), dim3(512), dim3(512), lds, (hipStream_t)stream, g);
   LAS_LAUNCH_CHECK("streamed gemm launch");
   return LAS_OK;
 }

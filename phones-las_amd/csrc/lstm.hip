@@ -176,17 +176,19 @@ struct FusedInput {
   const unsigned short* kxp;     // ndir images of las_lstm_pack_input
   const float* bias;             // [ndir * 4H] gate-interleaved
   int Dp;                        // valid input columns (multiple of 8, <= 32 * KX)
-  // streamed input projection (round 4): xproj is being written by a las_gemm_nt_stream launch that runs BESIDE this kernel;
-  // ready[(dir * nsb + (s >> 4)) * nbg + utterance / 16] counts the column tiles of a (direction, 16-step block, 16-utterance
-  // block) whose rows are visible device-wide; `want` of them make the block complete.  nullptr: xproj is complete on entry.
-  const unsigned* ready;
-  int nsb, nbg;
+  // streamed input projection (round 4): xproj is being written by a las_gemm_nt_stream launch that runs BESIDE this kernel.
+  // `ready` is the buffer shared with it (layout: gemm.hip, las_stream_flags_offset): this kernel writes, per chain group, the
+  // XCD the group runs on (word 16 + group), the product's workgroups on that XCD then produce the group's rows into the L2
+  // both sides share and count finished column tiles in word flags + group * nsb + step block; `want` of them make a block
+  // of 256 / ROWS steps complete.  nullptr: xproj is complete on entry.
+  unsigned* ready;
+  int nsb, flags;
   unsigned want;
 };
 
-// Wait until the streamed rows of step block sb are there (wave-uniform; bounded).  Returns false on timeout.
-__device__ __forceinline__ bool stream_wait(const FusedInput& fi, int dir, int sb, int bgi) {
-  const unsigned* f = fi.ready + ((int64_t)dir * fi.nsb + sb) * fi.nbg + bgi;
+// Wait until the streamed rows of step block sb of this group are there (wave-uniform; bounded).  Returns false on timeout.
+__device__ __forceinline__ bool stream_wait(const FusedInput& fi, int group, int sb) {
+  const unsigned* f = fi.ready + fi.flags + (int64_t)group * fi.nsb + sb;
   unsigned spins = 0;
   while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < fi.want) {
     if (++spins > SPIN_LIMIT) return false;
@@ -294,7 +296,7 @@ __device__ __forceinline__ void lstm_fwd_body(float* __restrict__ xproj, const u
       }
       if constexpr (KX == 0) {
         // streamed xproj: a line must not enter this XCD's L2 before the product has written it (it would stay stale there)
-        if (fi.ready != nullptr && (sp & 15) == 0 && !stream_wait(fi, dir, sp >> 4, (slice * ROWS) >> 4)) return;
+        if (fi.ready != nullptr && sp % (256 / ROWS) == 0 && !stream_wait(fi, group, sp / (256 / ROWS))) return;
       }
 #pragma unroll
       for (int r4 = 0; r4 < RL; ++r4) {
@@ -384,6 +386,14 @@ __device__ __forceinline__ void lstm_fwd_body(float* __restrict__ xproj, const u
   if (tid == 0) fail_flag = 0;
   __syncthreads();
   const bool local = xcd_colocated<G>(exch + 2 * par_stride + (int64_t)group * G, member, &colo_flag, status, base);
+  if constexpr (KX == 0) {
+    // streamed input product: tell its workgroups where this group runs (they produce its rows into that XCD's L2)
+    if (fi.ready != nullptr && member == 0 && tid == 0) {
+      unsigned xcc;
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+      __hip_atomic_store(fi.ready + 16 + group, (local || G == 1) ? (xcc & 7u) + 1u : 0x100u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
 
   const int unit0 = member * HS + wblk * 16 + l15;            // + ub*16
 
@@ -503,8 +513,8 @@ __device__ __forceinline__ void lstm_fwd_body(float* __restrict__ xproj, const u
     }
     LSTM_STAMP(0, s, 0);
     if constexpr (KX == 0) {
-      // streamed xproj: the first step of a 16-step block waits for the block's rows (normally long there: the product runs ahead)
-      if (fi.ready != nullptr && (s & 15) == 0 && !stream_wait(fi, dir, s >> 4, (slice * ROWS) >> 4)) fail_flag = 1;
+      // streamed xproj: the first step of a block of 256 / ROWS steps waits for the block's rows (normally long there: the product runs ahead)
+      if (fi.ready != nullptr && s % (256 / ROWS) == 0 && !stream_wait(fi, group, s / (256 / ROWS))) fail_flag = 1;
     }
     // x_t K_x + b of this step: issued now, consumed after the MFMAs
     float4 xp[UB][RL];
@@ -1432,7 +1442,10 @@ extern "C" int las_lstm_recurrent_fwd_ex(const las_lstm_fwd* p, void* stream) {
   }
   if (p->ready != nullptr) {
     LAS_REQUIRE(p->ready_count > 0, "las_lstm_recurrent_fwd_ex: ready_count = column tiles per block of the streamed product");
-    fi.ready = p->ready; fi.nsb = (p->T + 15) / 16; fi.nbg = (p->B + 15) / 16; fi.want = (unsigned)p->ready_count;
+    const int rows = slice_rows(p->B, p->H, p->ndir, false), sbs = 256 / rows;
+    fi.ready = p->ready; fi.nsb = (p->T + sbs - 1) / sbs;
+    fi.flags = 16 + ((((p->B + rows - 1) / rows) * p->ndir + 15) & ~15);
+    fi.want = (unsigned)p->ready_count;
   }
   return recurrent_fwd(p->xproj, p->wpacked, p->length, p->y, p->cbuf, p->c_last, p->h_last, p->workspace, p->B, p->T, p->H, p->ndir, stream, fi);
 }

@@ -41,8 +41,8 @@ _SIGS = {
     'las_lstm_pack_input': ([_vp, _i32, _i32, _i32, _vp, _vp], C.c_int),
     'las_lstm_recurrent_fwd_ex': ([_vp, _vp], C.c_int),
     'las_gemm_nt_stream_supported': ([_i32, _i32, _i32], C.c_int),
-    'las_gemm_nt_stream_flags': ([_i32, _i32, _i32], C.c_size_t),
-    'las_gemm_nt_stream': ([_vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp], C.c_int),
+    'las_gemm_nt_stream_flags': ([_i32, _i32, _i32, _i32], C.c_size_t),
+    'las_gemm_nt_stream': ([_vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp], C.c_int),
     'las_lstm_workspace_bytes': ([_i32, _i32, _i32], C.c_size_t),
     'las_lstm_slice_rows': ([_i32, _i32, _i32], C.c_int),
     'las_lstm_fwd_workgroups': ([_i32, _i32, _i32], C.c_int),
@@ -55,6 +55,9 @@ _SIGS = {
     'las_decoder_seq_xchg_bytes': ([_i32] * 5, C.c_size_t),
     'las_decoder_seq_bwd': ([_vp, _vp], C.c_int),
     'las_seq_ce_loss': ([_vp, _i64, _vp, _vp, _i32, _i32, _i32, _f32, _vp, _vp, _i64, _vp], C.c_int),
+    'las_proj_ce_supported': ([_i32, _i32, _i32], C.c_int),
+    'las_proj_ce_workspace_bytes': ([_i32, _i32], C.c_size_t),
+    'las_proj_ce': ([_vp, _i64, _vp, _vp, _vp, _vp, _i64, _vp, _i32, _i32, _i32, _i32, _i32, _f32, _vp, _vp, _vp, _i64, _vp, _vp, _vp], C.c_int),
     'las_seq_sigmoid_loss': ([_vp, _i64, _vp, _i64, _vp, _i32, _i32, _i32, _f32, _vp, _vp, _i64, _vp], C.c_int),
     'las_sample_features': ([_vp, _i64, _i32, _vp, _i64, _vp, _i64, _i32, _f32, C.c_uint32, C.c_uint32, _vp], C.c_int),
     'las_grad_l2_norms_ws_bytes': ([_i32, _i64], C.c_size_t),

@@ -267,10 +267,11 @@ def bilstm(inputs, sequence_length, num_units, dropout, mode, unidirectional=Fal
         if streamed:
             # x K_x BESIDE the recurrence: counters zeroed here, the product on its own stream (held back a few microseconds
             # so that the chain's workgroups are resident first), the recurrence consumes the rows as they become visible
-            n = lib.las_gemm_nt_stream_flags(B, T, nd)
-            ready = weights.__dict__.setdefault('_ready', {}).get((B, T))
+            rows = lib.las_lstm_slice_rows(B, H, nd)
+            n = lib.las_gemm_nt_stream_flags(B, T, nd, rows)
+            ready = weights.__dict__.setdefault('_ready', {}).get((B, T, rows))
             if ready is None:
-                ready = weights._ready[(B, T)] = torch.zeros(n, dtype=torch.int32, device=dev)
+                ready = weights._ready[(B, T, rows)] = torch.zeros(n, dtype=torch.int32, device=dev)
             hip.fill_many(zero=[ready])
             cur, side = torch.cuda.current_stream(), _product_stream()
             side.wait_stream(cur)
@@ -278,7 +279,7 @@ def bilstm(inputs, sequence_length, num_units, dropout, mode, unidirectional=Fal
                 hip.check(lib.las_stream_delay(Overlap.BESIDE_US, hip.stream()))
                 tok = hip.prof_begin('gemm_nt', 2.0 * B * T * nd * 4 * H * Dp)
                 hip.check(lib.las_gemm_nt_stream(hip.p(inputs), Dp, hip.p(weights.kxT), Dp, hip.p(xproj), nd * 4 * H, hip.p(weights.bias),
-                                                 hip.p(sequence_length), B, T, nd * 4 * H, Dp, nd, hip.p(ready), hip.stream()))
+                                                 hip.p(sequence_length), B, T, nd * 4 * H, Dp, nd, rows, hip.p(ready), hip.stream()))
                 hip.prof_end(tok)
             stream_ready = (ready, 4 * H // 128, side, (inputs, xproj))
         else:

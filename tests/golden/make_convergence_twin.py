@@ -41,7 +41,18 @@ def run(mxu):
     m = {k: torch.zeros_like(v) for k, v in p.items()}
     v = {k: torch.zeros_like(x) for k, x in p.items()}
     batches = [to_torch(b) for b in TC.train_batches()]
-    curve, losses = {}, []
+    curve, losses, pers = {}, [], {}
+    tb, refs = TC.test_batches()
+    tb = [to_torch(b) for b in tb]
+
+    def held_out_per():
+        hyps = []
+        with torch.no_grad():
+            for b in tb:
+                (mem, ml), st = O.listener(b['encoder_inputs'], b['source_sequence_length'], p, hp.encoder, mxu)
+                _, ids, _, _ = O.speller_greedy(hp, p, mem, ml, st, mxu)
+                hyps += [row.tolist() for row in ids]
+        return TC.per(hyps, refs)
     t0 = time.time()
     for t in range(TC.STEPS):
         out = O.train_step(hp, p, None, None, t + 1, batches[t % len(batches)], mxu=mxu)
@@ -50,15 +61,11 @@ def run(mxu):
             curve[t + 1] = float(np.mean(losses[-TC.WINDOW:]))
             print(mxu, t + 1, curve[t + 1], '%.0f s' % (time.time() - t0), flush=True)
         p, m, v = O.adam_apply(p, m, v, out['clipped'], t + 1, hp.learning_rate)
-    tb, refs = TC.test_batches()
-    hyps = []
-    with torch.no_grad():
-        for b in tb:
-            b = to_torch(b)
-            (mem, ml), st = O.listener(b['encoder_inputs'], b['source_sequence_length'], p, hp.encoder, mxu)
-            _, ids, _, _ = O.speller_greedy(hp, p, mem, ml, st, mxu)
-            hyps += [row.tolist() for row in ids]
-    return dict(curve={str(k): v for k, v in curve.items()}, per=TC.per(hyps, refs), seconds=round(time.time() - t0))
+        if t + 1 in TC.PER_STEPS:
+            pers[t + 1] = held_out_per()
+            print(mxu, 'PER at', t + 1, pers[t + 1], flush=True)
+    return dict(curve={str(k): v for k, v in curve.items()}, per_at={str(k): v for k, v in pers.items()},
+                per=float(np.median(list(pers.values()))), seconds=round(time.time() - t0))
 
 
 if __name__ == '__main__':

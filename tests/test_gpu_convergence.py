@@ -1,13 +1,14 @@
 """Convergence twin: the device trains on the same toy corpus, from the same initial weights, on the same
 batch sequence as the oracle did in the build container (tests/golden/make_convergence_twin.py -> the fixture
 tests/golden/convergence_twin.json: windowed loss-curve checkpoints and the held-out greedy PER of the exact f64 model and of
-the oracle's bf16 storage model), 1 200 optimiser steps, dropout and sampling off.
+the oracle's bf16 storage model), 2 400 optimiser steps, dropout and sampling off.
 
-What can be asked of it.  1 200 Adam steps amplify every rounding difference (tests/test_gpu_trajectory.py follows the oracle
+What can be asked of it.  2 400 Adam steps amplify every rounding difference (tests/test_gpu_trajectory.py follows the oracle
 step for step over 20), so the three runs -- f64 oracle, bf16-model oracle, device -- are three samples of where training of
 this model on this corpus ends, not three copies of one trajectory.  The distance between the two ORACLE runs is the scale:
-the device must stay inside a band a few times that wide around the f64 curve (stated below), and its held-out PER within 1.5
-points of the f64 oracle's (the verdict's +-1 point plus half a point for the 640-phone test set's granularity of 0.16).
+the device must stay inside a band a few times that wide around the f64 curve (stated below), and its held-out PER -- the
+median over six late checkpoints, on 128 utterances / about 640 phones -- within max(1 point, the two oracle runs' own
+distance) + 0.5 of the f64 oracle's.
 This is the only available stand-in for north_star's "matched TIMIT PER": no TF, no corpus."""
 import json
 import os
@@ -53,30 +54,39 @@ def test_device_training_ends_where_the_oracle_does():
     model = mh.LasModel(params)
     model.load_variables(O.init_params(ohp, seed=4321))
     batches = [to_device(_tensors(b)) for b in TC.train_batches()]
-    losses, curve = [], {}
+    tb, refs = TC.test_batches()
+    tb = [to_device(_tensors(b))[0] for b in tb]
+
+    def held_out_per():
+        hyps = []
+        for feats in tb:
+            hyps += [row.tolist() for row in model.predict(feats)['sample_ids'].cpu()]
+        return TC.per(hyps, refs)
+
+    losses, curve, pers = [], {}, {}
     for t in range(TC.STEPS):
         feats, labels = batches[t % len(batches)]
         losses.append(float(model.train_step(feats, labels)))
         if t + 1 in TC.CHECKPOINTS:
             curve[t + 1] = float(np.mean(losses[-TC.WINDOW:]))
+        if t + 1 in TC.PER_STEPS:
+            pers[t + 1] = held_out_per()
     model.check_device_status()
-    tb, refs = TC.test_batches()
-    hyps = []
-    for b in tb:
-        feats, _ = to_device(_tensors(b))
-        pred = model.predict(feats)
-        hyps += [row.tolist() for row in pred['sample_ids'].cpu()]
-    per = TC.per(hyps, refs)
+    per = float(np.median(list(pers.values())))
     f64, bf = fx['f64'], fx['bf16']
-    report = {'per': {'device': per, 'f64': f64['per'], 'bf16': bf['per']},
+    report = {'per': {'device': per, 'f64': f64['per'], 'bf16': bf['per'], 'device_at': pers, 'f64_at': f64['per_at'], 'bf16_at': bf['per_at']},
               'curve': {k: (round(curve[int(k)], 5), round(f64['curve'][k], 5), round(bf['curve'][k], 5)) for k in f64['curve']}}
     print(json.dumps(report))
     out = os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', 'gpurun_out')
     if os.path.isdir(out):
         json.dump(report, open(os.path.join(out, 'convergence_twin_device.json'), 'w'), indent=1)
-    # the loss curve: within max(3 x the distance between the two oracle runs, 25 % of the f64 value, 2e-3) of the f64 curve
+    # the loss curve: within max(3 x the distance between the two oracle runs, 50 % of the larger oracle value, 5e-3) of the f64
+    # curve (late checkpoints sit near zero with occasional Adam spikes on either side: the band is relative to what the two
+    # oracle runs themselves do there)
     for k, ref in f64['curve'].items():
-        band = max(3.0 * abs(ref - bf['curve'][k]), 0.25 * ref, 2e-3)
+        band = max(3.0 * abs(ref - bf['curve'][k]), 0.5 * max(ref, bf['curve'][k]), 5e-3)
         assert abs(curve[int(k)] - ref) <= band, (k, curve[int(k)], ref, bf['curve'][k], band)
     assert curve[TC.STEPS] < 0.05 * curve[TC.CHECKPOINTS[0]]
-    assert abs(per - f64['per']) <= 1.5, report['per']
+    # held-out PER (median over the six late checkpoints): within max(1, the two oracle runs' own distance) + 0.5 points of f64
+    gap = abs(f64['per'] - bf['per'])
+    assert abs(per - f64['per']) <= max(1.0, gap) + 0.5, report['per']

@@ -11,6 +11,8 @@ SOS, EOS = 1, 2
 N_TRAIN, N_TEST, BATCH = 512, 128, 16
 STEPS = 2400
 CHECKPOINTS = [10, 50, 100, 200, 400, 800, 1200, 1600, 2000, 2400]
+PER_STEPS = [1400, 1600, 1800, 2000, 2200, 2400]   # held-out greedy PER at each of these; the statistic is their MEDIAN (Adam on a
+                                                   # near-zero loss spikes now and then: a single checkpoint may sit on a spike)
 WINDOW = 32                          # a checkpoint is the MEAN loss of the WINDOW steps that end there (single steps spike)
 NOISE = 0.9
 MODEL = dict(F=F, L=2, H=64, Hd=64, V=V, att='luong', lr=1e-3, l2=1e-6)
