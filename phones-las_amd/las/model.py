@@ -197,6 +197,7 @@ class Speller:
         self._variables = variables
         self.refresh(variables)
         self.saved = None
+        self.fused_loss = None          # (loss, dlogits) of the last forward_train when it formed the loss itself (las_proj_ce)
 
     # names of the TF variables this module owns
     K_MEM = 'speller/memory_layer/kernel'
@@ -280,7 +281,8 @@ class Speller:
         s.drop_keep, s.feed_width = 1.0, self.V + self.M
         return s
 
-    def forward_train(self, memory, mem_len, encoder_state, targets_inputs, num_steps, parts=4, seed=0, overlap=None):
+    def forward_train(self, memory, mem_len, encoder_state, targets_inputs, num_steps, parts=4, seed=0, overlap=None,
+                      loss_targets=None):
         """TrainingHelper decode (las/model.py:276-296,346-347).  memory [B,T',M] bf16, targets_inputs int32
         [B,>=num_steps]; num_steps = max(target_sequence_length).  Returns logits fp32 [B,U,Vp] (first V valid)."""
         B, Tm, M = memory.shape
@@ -383,10 +385,30 @@ class Speller:
             with (overlap or ops._NoOverlap()).fork(h_all, cw2):
                 hip.gemm_nt(h_all, self.wmem, cw2[:, U:], U, M, Hd, lda=Hd, ldb=Hd, ldc=M, out_bf16=True, batch=B,
                             sa=U * Hd, sb=0, sc=2 * U * M)
+        self.fused_loss, dattn_proj = None, None
+        if (logits is None and loss_targets is not None and os.environ.get('LAS_PROJ_CE', '1') != '0'
+                and lib.las_proj_ce_supported(V, Vp, M) == 1):
+            # projection + sequence loss + the product back through the projection in one launch (las_proj_ce): what used to be
+            # five small launches between the decoder's forward and backward launches.  loss_targets = (targets_outputs int32
+            # [B, >= U], target_sequence_length int32 [B], grad_scale): compute_loss(TRAIN)'s arguments (model_helper.py:24-30).
+            tout, tlen, gscale = loss_targets
+            if tout.dtype != torch.int32 or tout.stride(1) != 1:
+                tout = tout.to(torch.int32).contiguous()
+            tlen = tlen.to(torch.int32)
+            logits = torch.empty(B, U, Vp, dtype=f32, device=dev)
+            dlog = torch.empty(B, U, Vp, dtype=bf, device=dev)
+            dattn_proj = torch.empty(B, U, M, dtype=f32, device=dev)
+            loss = torch.empty(1, dtype=f32, device=dev)
+            if getattr(self, '_projce_ws', None) is None:
+                self._projce_ws = torch.zeros(lib.las_proj_ce_workspace_bytes(B, U), dtype=torch.uint8, device=dev)
+            hip.check(lib.las_proj_ce(hip.p(ctx_all), M, hip.p(self.wprojT), hip.p(self.bproj), hip.p(self.wproj), hip.p(tout),
+                                      tout.stride(0), hip.p(tlen), B, U, V, Vp, M, float(gscale), hip.p(logits), hip.p(dlog),
+                                      hip.p(dattn_proj), M, hip.p(loss), hip.p(self._projce_ws), st))
+            self.fused_loss = (loss, dlog)
         if logits is None:
             logits = torch.empty(B, U, Vp, dtype=f32, device=dev)
             hip.gemm_nt(ctx_all, self.wprojT, logits, B * U, Vp, M, lda=M, ldb=M, ldc=Vp, bias=self.bproj)
-        self.saved = dict(keep=keep, seed=seed, fed=fed, B=B, Tm=Tm, U=U, memory=memory, mem_len=mem_len, keys=keys, AH=AH, cs=cs, gates=gates,
+        self.saved = dict(dattn_proj=dattn_proj, keep=keep, seed=seed, fed=fed, B=B, Tm=Tm, U=U, memory=memory, mem_len=mem_len, keys=keys, AH=AH, cs=cs, gates=gates,
                           h_all=h_all, align=align, align_bf=align_bf, ctx_all=ctx_all, pq_all=pq_all,
                           tin=tin, passed=passed, al2=al2, cw2=cw2, R=R, dc=dc_bwd)
         return logits
@@ -403,8 +425,11 @@ class Speller:
         dev, bf, f32 = dlogits.device, torch.bfloat16, torch.float32
         lib, st = hip.lib(), hip.stream()
         BU = B * U
-        dattn_proj = torch.empty(B, U, M, dtype=f32, device=dev)
-        hip.gemm_nt(dlogits, self.wproj, dattn_proj, BU, M, Vp, lda=Vp, ldb=Vp, ldc=M)
+        # d(decoder outputs) through the projection: already formed with the loss when the gradient handed in IS that loss's
+        dattn_proj = sv.get('dattn_proj') if (self.fused_loss is not None and dlogits is self.fused_loss[1]) else None
+        if dattn_proj is None:
+            dattn_proj = torch.empty(B, U, M, dtype=f32, device=dev)
+            hip.gemm_nt(dlogits, self.wproj, dattn_proj, BU, M, Vp, lda=Vp, ldb=Vp, ldc=M)
         R, merged = sv['R'], sv['cw2'] is not None
         dc = sv['dc']                       # cleared in the forward pass's fill launch
         dfeed = torch.empty(B, W, dtype=f32, device=dev)

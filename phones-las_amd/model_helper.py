@@ -581,8 +581,13 @@ class LasModel:
         loss, logits, dlogits = None, None, []
         for mod, kind in self.spellers:          # audio_loss = sum of the decoders' losses (model_helper.py:337-342)
             extra = {'overlap': self.overlap} if isinstance(mod, las_model.Speller) else {}
+            if extra and kind == 'phones':
+                # the fused speller forms the loss itself when it can (las_proj_ce: projection + loss + product back in one launch)
+                extra['loss_targets'] = (tout, tlen, 1.0 / self.world_size)
             lg = mod.forward_train(mem, mem_len, state, tin, U, seed=step_seed, **extra)
-            if kind == 'sigmoid':
+            if extra and getattr(mod, 'fused_loss', None) is not None:
+                l_, dl = mod.fused_loss
+            elif kind == 'sigmoid':
                 # compute_loss_sigmoid against the feature vectors of the targets (model_helper.py:199,333-335)
                 l_, dl = compute_loss_sigmoid(lg, mod.emb_bf[tout[:, :U].long()], None, tlen, TRAIN, nf=mod.nf,
                                               grad_scale=1.0 / self.world_size, want_grad=True)

@@ -959,3 +959,35 @@ def test_padding_rows_of_the_one_launch_decoders_do_not_leak(att, H, B):
             assert torch.equal(got[0], clean[0]), (which, hex(pattern))
             assert torch.equal(got[1], clean[1]), (which, hex(pattern))
     model.check_device_status()
+
+
+@pytest.mark.parametrize('V,H,B,tgt_len', [(11, 128, 5, [6, 4, 5, 6, 3]), (64, 256, 9, [7, 1, 3, 7, 7, 2, 5, 6, 4]), (42, 128, 3, [4, 4, 2]),
+                                           (100, 128, 4, [5, 3, 5, 1])])
+def test_fused_projection_loss_launch_matches_the_separate_launches(V, H, B, tgt_len, monkeypatch):
+    """Round 4: las_proj_ce forms the logits, the sequence loss (model_helper.py:24-30), d(logits) and the product back through the
+    projection in one launch.  Against the separate launches (LAS_PROJ_CE=0: projection product, las_seq_ce_loss, product back):
+    logits to fp32 summation order, the loss to 1e-5, d(logits) to a bf16 ulp, and every gradient of a full backward pass to the
+    usual 2e-3 of its max-abs.  V = 42 pads to 48 columns (three 16-column tiles, the last K chunk of the product back half
+    empty), V = 100 to 112 (two values per lane)."""
+    O, ohp, op, model = _models('luong', H=H, F=13, L=2, V=V)
+    U = max(tgt_len)
+    feats, labels = to_device(make_batch(B=B, T=24, V=V, U=U, src_len=[24 - (i * 5) % 11 for i in range(B)], tgt_len=tgt_len))
+    outs = {}
+    for flag in ('1', '0'):
+        monkeypatch.setenv('LAS_PROJ_CE', flag)
+        model.vars.grad.zero_()
+        loss, logits, dlogits = model.forward_train(feats, labels)
+        assert (model.speller.fused_loss is not None) == (flag == '1')
+        model.backward(dlogits)
+        torch.cuda.synchronize()
+        outs[flag] = (float(loss), logits.clone(), dlogits.float().clone(), {n: g.clone() for n, g in model.vars.grads.items()})
+    model.check_device_status()
+    (la, lga, dla, ga), (lb, lgb, dlb, gb) = outs['1'], outs['0']
+    assert abs(la - lb) < 1e-5 * abs(lb), (la, lb)
+    assert relerr(lga, lgb.cpu()) < 1e-5
+    assert float((dla - dlb).abs().max()) <= 2 ** -7 * float(dlb.abs().max())
+    for name in ga:
+        assert relerr(ga[name], gb[name].cpu()) < 2e-3, name
+    # ... and against the oracle
+    ref = O.train_step(ohp, op, None, None, 1, {k: v for k, v in make_batch(B=B, T=24, V=V, U=U, src_len=[24 - (i * 5) % 11 for i in range(B)], tgt_len=tgt_len).items()}, mxu='bf16')
+    assert abs(la - float(ref['aux']['ce'])) < 2e-2 * abs(float(ref['aux']['ce']))
