@@ -261,6 +261,33 @@ def cpu_baseline(c, sample_b=16, fused_b=64, threads=None):
                       '40-s wall-clock cap; `all_core_run` = the leg on every host thread); value = the fastest run that finished' % (c['T'], sample_b, fused_b, base_th)}
 
 
+def choose_step_form(candidates, probe, read_and_clear_status, any_rank, rank=0):
+    """The untimed probe of bench.py: times every candidate form of the step (name -> (step function, uses graphs, overlapped
+    exchange)) with `probe` (which returns the SLOWEST rank's time on every rank), reads AND CLEARS the persistent kernels'
+    status words after each one on every rank, drops a form that timed out on ANY rank (`any_rank`), and picks the fastest of the
+    rest -- forms within 1 % of the fastest tie, and a tie goes to eager launches (eight probe steps of a 6-ms step scatter by that
+    much, and a graph picked on a 0.5 % edge has replayed slower than eager launches as often as not); candidates are walked in
+    sorted order so that every rank takes the same decisions.  With every form dropped the plain eager form is the fall-back.
+    Returns (chosen name, {name: seconds}, {name: why it was dropped})."""
+    probed, dropped = {}, {}
+    if len(candidates) > 1:
+        for name in sorted(candidates):
+            t_ = probe(candidates[name][0])
+            bad = read_and_clear_status()
+            if any_rank(bool(bad)):
+                dropped[name] = 'persistent-kernel timeout in the probe (status %s on rank %d)' % (bad, rank)
+            else:
+                probed[name] = t_
+        if probed:
+            best = min(probed.values())
+            chosen = min(sorted(n for n in probed if probed[n] <= 1.01 * best), key=lambda n: (n.endswith('_graph'), probed[n]))
+        else:
+            chosen = 'plain_eager' if 'plain_eager' in candidates else sorted(candidates)[0]
+    else:
+        chosen = next(iter(candidates))
+    return chosen, probed, dropped
+
+
 def launcher_command(argv, gpus, port):
     """The command `bench.py --gpus N` runs when it has to start its own ranks (no WORLD_SIZE in the environment)."""
     return [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(gpus),
@@ -487,25 +514,7 @@ def main():
     # RCCL's kernels share the chip with groups that need co-residency) must not poison the run: the status words are
     # sticky and gate Adam, so they are read AND CLEARED after every candidate, on every rank, and a form that timed out on
     # any rank is dropped.  The plain eager form is the fall-back.
-    probed, dropped = {}, {}
-    if len(candidates) > 1:
-        for name in sorted(candidates):
-            t_ = probe(candidates[name][0])
-            bad = model.read_and_clear_status()
-            if any_rank(bool(bad)):
-                dropped[name] = 'persistent-kernel timeout in the probe (status %s on rank %d)' % (bad, rank)
-            else:
-                probed[name] = t_
-        # (sorted: the same tie-break on every rank.  Forms within 1 % of the fastest tie, and a tie goes to eager
-        # launches: eight probe steps of a 6-ms step scatter by that much, and a graph picked on a 0.5 % edge has replayed
-        # slower than eager launches as often as not)
-        if probed:
-            best = min(probed.values())
-            chosen = min(sorted(n for n in probed if probed[n] <= 1.01 * best), key=lambda n: (n.endswith('_graph'), probed[n]))
-        else:
-            chosen = 'plain_eager' if 'plain_eager' in candidates else sorted(candidates)[0]
-    else:
-        chosen = next(iter(candidates))
+    chosen, probed, dropped = choose_step_form(candidates, probe, model.read_and_clear_status, any_rank, rank)
     step, used_graph, used_overlap = candidates[chosen]
 
     for _ in range(args.warmup):

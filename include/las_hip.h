@@ -815,6 +815,25 @@ int las_normalize_pad_bf16(const float* frames, const int64_t* frame_row_offsets
  * files use (preprocess_all.py:164-167 tf.io.TFRecordWriter; utils/dataset_utils.py:157 TFRecordDataset). */
 uint32_t las_crc32c(const void* data, size_t n);
 
+/* ------------------------------------------------------------------------------------------
+ * Data parallelism: the cross-replica gradient SUM of tf.tpu.CrossShardOptimizer (model_helper.py:405-406; train.py:129-140,
+ * 157-160) as RCCL all-reduces over xGMI, for hosts that bind this library without torch (the Python host's default transport
+ * is torch.distributed, backend "nccl" = the same RCCL).  One process per GPU.  RCCL is resolved at run time (a copy the process
+ * already holds is reused; LAS_RCCL_LIB names another): las_dp_available() = 1 when it was found.
+ *   rank 0: las_dp_unique_id(id)  -> 128 bytes, handed to every rank by the host's own means (file, socket, environment);
+ *   all:    las_dp_init(id, rank, nranks, &comm)   with the rank's HIP device current;
+ *   step:   las_dp_allreduce_bucket(comm, grads + begin, count, stream)   in place, fp32, SUM, asynchronous on `stream` -- one call
+ *           per exchange bucket, in the same order on every rank (the reference order: each replica scales its loss by 1/N,
+ *           clips ITS per-tensor gradients, then the clipped gradients are summed; las_grad_clip before, las_adam_update after);
+ *   end:    las_dp_finalize(comm).
+ * ---------------------------------------------------------------------------------------- */
+typedef struct las_dp_comm las_dp_comm;
+int las_dp_available(void);
+int las_dp_unique_id(void* id_out_128_bytes);
+int las_dp_init(const void* id_128_bytes, int rank, int nranks, las_dp_comm** comm_out);
+int las_dp_allreduce_bucket(las_dp_comm* comm, float* grads, int64_t count, void* stream);
+int las_dp_finalize(las_dp_comm* comm);
+
 #ifdef __cplusplus
 }
 #endif

@@ -73,6 +73,11 @@ _SIGS = {
     'las_counter_add_unless': ([_vp, _i32, _vp, _vp], C.c_int),
     'las_sumsq': ([_vp, _i64, _vp, _vp], C.c_int),
     'las_crc32c': ([C.c_char_p, C.c_size_t], C.c_uint32),
+    'las_dp_available': ([], C.c_int),
+    'las_dp_unique_id': ([_vp], C.c_int),
+    'las_dp_init': ([_vp, _i32, _i32, _vp], C.c_int),
+    'las_dp_allreduce_bucket': ([_vp, _vp, _i64, _vp], C.c_int),
+    'las_dp_finalize': ([_vp], C.c_int),
     'las_tfrecord_index': ([_vp, C.c_size_t, _i32, _i64, _vp, _vp, _vp, _vp, _vp], C.c_int64),
     'las_tfrecord_parse_batch': ([_vp, _vp, _vp, _i32, _i32, _vp, _i64, _vp, _vp, _i64, _vp, _i64, _vp], C.c_int),
     'las_vocab_lookup': ([_vp, _vp, _i64, _vp, _vp, _i64, _i32, _vp], C.c_int),

@@ -111,3 +111,91 @@ def test_epilogue_runs_the_timing_pass_on_every_rank_and_reports_errors_in_the_j
     assert 'not finite' in out0['error'] and out0['value'] == round(64 * 2 * 10 / 0.0626, 2)
     assert out0['n_gpus'] == 2 and out0['roofline']['kernel'].startswith('lstm_bwd') and 'traffic_stale' in out0['roofline']
     json.dumps(out0)                                           # the record serialises (NaN loss is kept as a string)
+
+
+def _probe_worker(rank, world, port, ret):
+    """bench.choose_step_form under gloo with two ranks and the four candidate forms of a multi-rank run (plain / overlapped
+    exchange x eager / graph): every form's step contains a collective, the probe's time is the SLOWEST rank's, one form
+    reports a persistent-kernel timeout on ONE rank only (it must be dropped on both), and the status words are read -- and
+    cleared -- after every candidate on every rank."""
+    import time
+    import torch
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    bench = _bench()
+    cost = {'plain_eager': 0.004, 'plain_graph': 0.00398, 'overlap_eager': 0.002, 'overlap_graph': 0.0035}   # seconds per step on rank 0
+    state = {'current': None, 'status_reads': 0, 'steps': {k: 0 for k in cost}}
+
+    def make(name):
+        def step():
+            state['current'] = name
+            state['steps'][name] += 1
+            time.sleep(cost[name] * (1.5 if rank == 1 else 1.0))         # rank 1 is the slower one
+            t = torch.ones(2)
+            dist.all_reduce(t)                                           # the gradient exchange every form contains
+        return step
+
+    def barrier():
+        dist.barrier()
+
+    def probe(fn, n=4):
+        fn(); barrier()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            fn()
+        barrier()
+        tt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        return float(tt[0])
+
+    def read_and_clear_status():
+        state['status_reads'] += 1
+        # the overlapped eager form times out on rank 1 only (RCCL kernels beside the persistent groups, say)
+        return [1] if (state['current'] == 'overlap_eager' and rank == 1) else []
+
+    def any_rank(flag):
+        t = torch.tensor([1.0 if flag else 0.0])
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return bool(t.item() > 0)
+
+    candidates = {k: (make(k), k.endswith('_graph'), k.startswith('overlap')) for k in cost}
+    chosen, probed, dropped = bench.choose_step_form(candidates, probe, read_and_clear_status, any_rank, rank)
+    # every form dropped: the plain eager form is the fall-back
+    all_bad = bench.choose_step_form(candidates, probe, lambda: [2], any_rank, rank)
+    ret[rank] = (chosen, probed, dropped, state['status_reads'], dict(state['steps']), all_bad[0], sorted(all_bad[2]))
+    dist.destroy_process_group()
+
+
+def test_probe_picks_one_form_on_every_rank_and_drops_a_form_that_timed_out_anywhere():
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    ret = mp.Manager().dict()
+    mp.spawn(_probe_worker, args=(2, port, ret), nprocs=2, join=True)
+    (c0, p0, d0, reads0, steps0, fb0, fbd0), (c1, p1, d1, reads1, steps1, fb1, fbd1) = ret[0], ret[1]
+    assert c0 == c1 == 'overlap_graph'                                  # the fastest of the forms that survived, on both ranks
+    assert sorted(d0) == sorted(d1) == ['overlap_eager']               # the timeout on rank 1 dropped the form on rank 0 too
+    assert sorted(p0) == sorted(p1) == ['overlap_graph', 'plain_eager', 'plain_graph']
+    for k in p0:
+        assert abs(p0[k] - p1[k]) < 1e-9                                # the slowest rank's time, identical on both
+    assert p0['plain_eager'] > 4 * 0.004 * 1.4                          # ... i.e. rank 1's (1.5 x slower)
+    assert reads0 == reads1 == 4 and steps0 == steps1                   # status read after every candidate, same steps everywhere
+    assert fb0 == fb1 == 'plain_eager' and fbd0 == fbd1 == sorted(['overlap_eager', 'overlap_graph', 'plain_eager', 'plain_graph'])
+
+
+def test_probe_prefers_eager_launches_within_one_percent():
+    bench = _bench()
+    times = {'plain_eager': 1.004, 'plain_graph': 1.0}
+    cands = {k: ((lambda: None), k.endswith('_graph'), False) for k in times}
+    order = []
+    chosen, probed, dropped = bench.choose_step_form(cands, lambda fn: times[order.append(1) or sorted(times)[len(order) - 1]],
+                                                     lambda: [], lambda f: f)
+    assert chosen == 'plain_eager' and not dropped
+    times['plain_eager'] = 1.02
+    order.clear()
+    assert bench.choose_step_form(cands, lambda fn: times[order.append(1) or sorted(times)[len(order) - 1]], lambda: [], lambda f: f)[0] == 'plain_graph'
+    assert bench.choose_step_form({'plain_eager': cands['plain_eager']}, None, None, None)[0] == 'plain_eager'      # one candidate: no probe

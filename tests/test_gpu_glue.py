@@ -127,3 +127,28 @@ def test_add_cast_bf16_windows():
     torch.cuda.synchronize()
     assert torch.equal(out[:, 2, 2:22], a[:, 1, 8:28].to(torch.bfloat16))
     assert lib.las_add_cast_bf16(None, 0, None, 0, hip.addr(out), 24, 5, 20, hip.stream()) != 0
+
+
+def test_rccl_behind_the_c_abi_one_rank():
+    """SURVEY 8(b) / VERDICT r3 #7b: las_dp_unique_id / las_dp_init / las_dp_allreduce_bucket / las_dp_finalize over RCCL, resolved
+    at run time (the copy torch has loaded is reused).  One GPU: a 1-rank communicator, the in-place SUM over a gradient bucket
+    on a side stream is the identity, asynchronous on that stream, and the flat-buffer offset form (grads + begin) works."""
+    import ctypes as C
+    from phones_las_amd import hip
+    lib = hip.lib()
+    assert lib.las_dp_available() == 1
+    uid = (C.c_char * 128)()
+    hip.check(lib.las_dp_unique_id(uid))
+    assert any(bytes(uid))
+    comm = C.c_void_p()
+    hip.check(lib.las_dp_init(uid, 0, 1, C.byref(comm)))
+    assert comm.value
+    g = torch.randn(1 << 20, device='cuda')
+    ref = g.clone()
+    st = torch.cuda.Stream()
+    st.wait_stream(torch.cuda.current_stream())
+    hip.check(lib.las_dp_allreduce_bucket(comm, C.c_void_p(g.data_ptr() + 4 * 1000), g.numel() - 1000, C.c_void_p(st.cuda_stream)))
+    st.synchronize()
+    assert torch.equal(g, ref)
+    assert lib.las_dp_init(uid, 3, 2, C.byref(C.c_void_p())) != 0          # rank out of range: an error code, no crash
+    hip.check(lib.las_dp_finalize(comm))
