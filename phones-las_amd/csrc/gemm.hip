@@ -749,7 +749,7 @@ __global__ __launch_bounds__(512) void gemm_nt_ring_kernel(GemmArgs g) {
           v = __hip_atomic_load(g.ready + 16 + gi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           if (v != 0) break;
           __builtin_amdgcn_s_sleep(8);
-        } while (++spins < (1u << 17));
+        } while (++spins < (1u << 14));
         if (v == (unsigned)my_xcd + 1u || ((v == LAS_STREAM_SPREAD || v == 0) && (gi & 7) == my_xcd)) s_list[n++] = gi | (v == (unsigned)my_xcd + 1u ? 0 : 0x10000);
       }
       s_n = n;

@@ -496,9 +496,6 @@ __device__ __forceinline__ void lstm_fwd_body(float* __restrict__ xproj, const u
       }
     }
   };
-  if constexpr (KX > 0) {
-    if (smin > 0) input_products(0, std::true_type{}); else input_products(0, std::false_type{});
-  }
   auto step = [&](int s, auto lean_tag) {
     constexpr bool LEAN = decltype(lean_tag)::value;
     bool act[RL];
@@ -523,13 +520,11 @@ __device__ __forceinline__ void lstm_fwd_body(float* __restrict__ xproj, const u
     for (int g = 0; g < 4; ++g)
 #pragma unroll
       for (int ub = 0; ub < UB; ++ub) acc[g][ub] = f32x4{0.f, 0.f, 0.f, 0.f};
+    bool did_x = (KX == 0);
     if constexpr (KX > 0) {
-      // the input products of this step were formed at the END of the previous one (input_products below), behind its granule
-      // stores: in the shadow of the exchange, not in front of this step's polls
-#pragma unroll
-      for (int g = 0; g < 4; ++g)
-#pragma unroll
-        for (int ub = 0; ub < UB; ++ub) acc[g][ub] = accx[g][ub];
+      // the input products of this step are issued inside the poll below, the first time a polling round comes back empty (the
+      // wave would only sleep): eight MFMAs in front of the polls cost their issue time on every step (0.78 against 0.70 ms per
+      // 800-step launch), behind the previous step's granule stores likewise
 #pragma unroll
       for (int ub = 0; ub < UB; ++ub)
 #pragma unroll
@@ -565,6 +560,9 @@ __device__ __forceinline__ void lstm_fwd_body(float* __restrict__ xproj, const u
             ok = ok && ((unsigned)(v[i] >> 32) == base + (unsigned)s);
           }
           if (__all(ok)) break;
+          if constexpr (KX > 0) {
+            if (!did_x) { input_products(s, lean_tag); did_x = true; continue; }      // use the wait: x_s K_x, then the request for x_{s+1}
+          }
           if (++spins > SPIN_LIMIT) { fail_flag = 1; break; }
           __builtin_amdgcn_s_sleep(1);
         }
@@ -575,6 +573,13 @@ __device__ __forceinline__ void lstm_fwd_body(float* __restrict__ xproj, const u
           if constexpr (GV == 2) hl[scat_off[c0 + i] + LS] = (unsigned short)(val >> 16);
         }
       }
+    }
+    if constexpr (KX > 0) {
+      if (!did_x) input_products(s, lean_tag);          // (the granules were there at once, the first step, single-workgroup chains)
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int ub = 0; ub < UB; ++ub) acc[g][ub] = accx[g][ub];
     }
     LSTM_STAMP(0, s, 1);
     flush_pending();                          // the previous step's stores, now that this step's polls are served
@@ -644,7 +649,6 @@ __device__ __forceinline__ void lstm_fwd_body(float* __restrict__ xproj, const u
         }
       }
       LSTM_STAMP(0, s, 4);
-      if constexpr (KX > 0) input_products(s + 1, lean_tag);       // x_{s+1} K_x (+ the request for x_{s+2}): the peers have their granules
 #pragma unroll
       for (int ub = 0; ub < UB; ++ub) {
         const int unit = unit0 + ub * 16;

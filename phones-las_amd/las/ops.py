@@ -140,7 +140,8 @@ class _NoOverlap:
 
 # LAS_LSTM_FUSED_X=0: the bottom layer's input projection as a separate product again (diagnostics, A/B timing)
 FUSED_X = os.environ.get('LAS_LSTM_FUSED_X', '1') != '0'
-# LAS_LSTM_STREAM=0: the upper layers' input products run to completion BEFORE their recurrence again.  Default: the product
+# LAS_LSTM_STREAM=0: the upper layers' input products run to completion BEFORE their recurrence again.  Default (256-unit
+# layers; at 512 units the product beside the chain cost more than it hid: metric-L 17.83 against 17.69 ms): the product
 # (las_gemm_nt_stream) runs on a second stream BESIDE the recurrence and hands its rows over step block by step block.
 STREAM_X = os.environ.get('LAS_LSTM_STREAM', '1') != '0'
 STREAM_MIN_ROWS = int(os.environ.get('LAS_LSTM_STREAM_MIN_ROWS', '4096'))      # smaller products are not worth the hand-over
@@ -261,7 +262,7 @@ def bilstm(inputs, sequence_length, num_units, dropout, mode, unidirectional=Fal
     else:
         lib = hip.lib()
         # the recurrence's slices must not straddle the product's 16-utterance blocks, and the chain must leave CUs to the product
-        streamed = (STREAM_X and H >= 256 and B * T >= STREAM_MIN_ROWS and lib.las_gemm_nt_stream_supported(nd * 4 * H, Dp, nd) == 1
+        streamed = (STREAM_X and H == 256 and B * T >= STREAM_MIN_ROWS and lib.las_gemm_nt_stream_supported(nd * 4 * H, Dp, nd) == 1
                     and 16 % max(lib.las_lstm_slice_rows(B, H, nd), 1) == 0
                     and 0 < lib.las_lstm_fwd_workgroups(B, H, nd) <= STREAM_MAX_WORKGROUPS)
         if streamed:
@@ -273,15 +274,22 @@ def bilstm(inputs, sequence_length, num_units, dropout, mode, unidirectional=Fal
             if ready is None:
                 ready = weights._ready[(B, T, rows)] = torch.zeros(n, dtype=torch.int32, device=dev)
             hip.fill_many(zero=[ready])
-            cur, side = torch.cuda.current_stream(), _product_stream()
-            side.wait_stream(cur)
-            with torch.cuda.stream(side):
-                hip.check(lib.las_stream_delay(Overlap.BESIDE_US, hip.stream()))
-                tok = hip.prof_begin('gemm_nt', 2.0 * B * T * nd * 4 * H * Dp)
-                hip.check(lib.las_gemm_nt_stream(hip.p(inputs), Dp, hip.p(weights.kxT), Dp, hip.p(xproj), nd * 4 * H, hip.p(weights.bias),
-                                                 hip.p(sequence_length), B, T, nd * 4 * H, Dp, nd, rows, hip.p(ready), hip.stream()))
-                hip.prof_end(tok)
-            stream_ready = (ready, 4 * H // 128, side, (inputs, xproj))
+            cleared = torch.cuda.Event()
+            cleared.record()
+
+            def launch_product():
+                # (called once the recurrence has been ENQUEUED: an idle GPU must not start the product first -- its persistent
+                # workgroups would hold every CU while they wait for the recurrence to say where its groups run)
+                side = _product_stream()
+                side.wait_event(cleared)
+                with torch.cuda.stream(side):
+                    hip.check(lib.las_stream_delay(Overlap.BESIDE_US, hip.stream()))
+                    tok = hip.prof_begin('gemm_nt', 2.0 * B * T * nd * 4 * H * Dp)
+                    hip.check(lib.las_gemm_nt_stream(hip.p(inputs), Dp, hip.p(weights.kxT), Dp, hip.p(xproj), nd * 4 * H, hip.p(weights.bias),
+                                                     hip.p(sequence_length), B, T, nd * 4 * H, Dp, nd, rows, hip.p(ready), hip.stream()))
+                    hip.prof_end(tok)
+                return side
+            stream_ready = (ready, 4 * H // 128, launch_product)
         else:
             hip.gemm_nt(inputs, weights.kxT, xproj, B * T, nd * 4 * H, Dp, lda=Dp, ldb=Dp, ldc=nd * 4 * H,
                         bias=weights.bias)
@@ -310,7 +318,7 @@ def bilstm(inputs, sequence_length, num_units, dropout, mode, unidirectional=Fal
         if stream_ready is not None:
             # (the product is done long before the recurrence is; everything later on this stream is ordered behind both,
             # so the operands need no record_stream)
-            torch.cuda.current_stream().wait_stream(stream_ready[2])
+            torch.cuda.current_stream().wait_stream(stream_ready[2]())
     else:
         tok = hip.prof_begin('lstm_fwd', 2.0 * B * T * nd * H * 4 * H)       # the recurrent product h_{t-1} K_h of every step
         hip.check(hip.lib().las_lstm_recurrent_fwd(hip.p(xproj), hip.p(weights.khp), hip.p(sequence_length), hip.p(y),

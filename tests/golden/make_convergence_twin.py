@@ -2,7 +2,8 @@
 tests/twin_corpus.py for STEPS optimiser steps and writes the loss curve checkpoints and the final greedy PER on the held-out
 utterances to tests/golden/convergence_twin.json -- the fixture tests/test_gpu_convergence.py holds the device against.
 
-    python tests/golden/make_convergence_twin.py [f64|bf16 ...]     (build container, CPU; ~10 min per model)
+    TWIN_OUT=part.json python tests/golden/make_convergence_twin.py <f64|bf16> <init seed> [...]    (build container, CPU; ~5 min per run)
+    python tests/golden/make_convergence_twin.py merge part*.json                                 -> tests/golden/convergence_twin.json
 
 The only available stand-in for north_star's "matched TIMIT PER": the reference's TF-1 graph cannot run here and no corpus
 ships with it, so the question the twin answers is whether the device's bf16 operand storage (3e-2 worst-case gradient error
@@ -35,9 +36,9 @@ def to_torch(b):
     return {k: torch.tensor(v.astype(np.float64) if k == 'encoder_inputs' else v.astype(np.int64)) for k, v in b.items()}
 
 
-def run(mxu):
+def run(mxu, seed):
     hp = oracle_hp()
-    p = O.init_params(hp, seed=4321)
+    p = O.init_params(hp, seed=seed)
     m = {k: torch.zeros_like(v) for k, v in p.items()}
     v = {k: torch.zeros_like(x) for k, x in p.items()}
     batches = [to_torch(b) for b in TC.train_batches()]
@@ -69,10 +70,20 @@ def run(mxu):
 
 
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['f64', 'bf16']
-    res = json.load(open(OUT)) if os.path.exists(OUT) else {}
-    res['corpus'] = dict(n_train=TC.N_TRAIN, n_test=TC.N_TEST, batch=TC.BATCH, steps=TC.STEPS, noise=TC.NOISE, window=TC.WINDOW, model=TC.MODEL)
-    for mxu in which:
-        res[mxu] = run(mxu)
+    # usage: make_convergence_twin.py <f64|bf16> <seed> [<seed> ...]   (one json per invocation when TWIN_OUT is set; merge below)
+    if sys.argv[1] == 'merge':
+        res = {'corpus': dict(n_train=TC.N_TRAIN, n_test=TC.N_TEST, batch=TC.BATCH, steps=TC.STEPS, noise=TC.NOISE, window=TC.WINDOW,
+                              per_steps=TC.PER_STEPS, model=TC.MODEL), 'f64': {}, 'bf16': {}}
+        for path in sys.argv[2:]:
+            part = json.load(open(path))
+            for mxu in ('f64', 'bf16'):
+                res[mxu].update(part.get(mxu, {}))
         json.dump(res, open(OUT, 'w'), indent=1)
-    print(json.dumps(res, indent=1))
+        print({m: {s: round(v['per'], 2) for s, v in res[m].items()} for m in ('f64', 'bf16')})
+        sys.exit(0)
+    mxu, seeds = sys.argv[1], [int(a) for a in sys.argv[2:]]
+    res = json.load(open(OUT)) if os.path.exists(OUT) else {}
+    res.setdefault(mxu, {})
+    for seed in seeds:
+        res[mxu][str(seed)] = run(mxu, seed)
+        json.dump(res, open(OUT, 'w'), indent=1)

@@ -6,6 +6,7 @@ oracle's expected outputs travel as fixtures (tests/golden/shape_<case>.npz).
 Cases (BASELINE.json configs / SURVEY.md 8(d)):
   metricM_dense   cfg2 = the headline config: 3 x pBiLSTM-256 + Luong + 1x256 decoder, F=40, V=64, T=800, U=80, B=4
   metricM_ragged  the same model, B=8, SURVEY 8(d)'s ragged lengths (800-8*(i%26), 80-(i%17))
+  metricM_ragged64  the same ragged lengths at bench.py's `metric-M-ragged` shape, B=64 (round 4)
   metricM_bench   the same model at bench.py's exact shape: B=64 dense (16 slices of 4 utterances per direction, 8 decoder
                   groups); the fixture keeps logits, losses, states and gradients, not the encoder memory
   metricL_ctc     cfg3/cfg4: 4 x pBiLSTM-512 + Bahdanau + CTC head (ctc_weight 0.3), F=80, T=384 (T'=48 >= U for CTC), U=24, B=4, ragged
@@ -30,6 +31,9 @@ CASES = {
     'metricM_dense': dict(F=40, L=3, H=256, Hd=256, V=64, att='luong', T=800, U=80, B=4, ragged='dense'),
     'metricM_ragged': dict(F=40, L=3, H=256, Hd=256, V=64, att='luong', T=800, U=80, B=8, ragged='survey'),
     'metricM_bench': dict(F=40, L=3, H=256, Hd=256, V=64, att='luong', T=800, U=80, B=64, ragged='dense', memory=False),
+    # round 4: bench.py's `metric-M-ragged` at its exact shape (SURVEY 8(d)'s ragged lengths over all 64 utterances: every
+    # slice of four utterances mixes lengths, the lean steps end at the slice's shortest and the masked general step takes over)
+    'metricM_ragged64': dict(F=40, L=3, H=256, Hd=256, V=64, att='luong', T=800, U=80, B=64, ragged='survey', memory=False),
     'metricL_ctc': dict(F=80, L=4, H=512, Hd=512, V=64, att='bahdanau', T=384, U=24, B=4, ragged='mixed', ctc=0.3),
     'cfg5_binf': dict(F=39, L=3, H=256, Hd=256, V=197, att='bahdanau_monotonic', T=64, U=12, B=4, ragged='mixed',
                       binf='binf_map.csv', binf_reg=1.0),

@@ -1,14 +1,19 @@
 """Convergence twin: the device trains on the same toy corpus, from the same initial weights, on the same
 batch sequence as the oracle did in the build container (tests/golden/make_convergence_twin.py -> the fixture
-tests/golden/convergence_twin.json: windowed loss-curve checkpoints and the held-out greedy PER of the exact f64 model and of
-the oracle's bf16 storage model), 2 400 optimiser steps, dropout and sampling off.
+tests/golden/convergence_twin.json), 2 400 optimiser steps per run, dropout and sampling off -- SIX runs from six initial
+seeds on either side (the exact f64 model for all six, the oracle's bf16 storage model for two of them).
 
 What can be asked of it.  2 400 Adam steps amplify every rounding difference (tests/test_gpu_trajectory.py follows the oracle
-step for step over 20), so the three runs -- f64 oracle, bf16-model oracle, device -- are three samples of where training of
-this model on this corpus ends, not three copies of one trajectory.  The distance between the two ORACLE runs is the scale:
-the device must stay inside a band a few times that wide around the f64 curve (stated below), and its held-out PER -- the
-median over six late checkpoints, on 128 utterances / about 640 phones -- within max(1 point, the two oracle runs' own
-distance) + 0.5 of the f64 oracle's.
+step for step over 20): the loss curves of the f64 oracle, of the bf16-model oracle and of the device agree to 1e-4 at step 50,
+to 3 % at step 200 and are three different trajectories from step 400 on -- each with its own Adam spikes once the loss is
+near zero (measured: at one and the same checkpoint 0.176 / 0.013 / 0.011, at another 0.009 / 0.160 / 0.006).  So a run is a
+SAMPLE of where training of this model on this corpus ends, and the question "does bf16 operand storage (3e-2 worst-case
+gradient error against the exact model) change where training ends up" is asked of the samples' statistics:
+  * coupled phase (steps <= 100): every device run within 1 % of its own f64 twin's windowed loss;
+  * every run converges: final windowed loss < 5 % of the first checkpoint's;
+  * held-out greedy PER (per run: the MEDIAN over six late checkpoints, 128 utterances / about 640 phones; then the MEAN over
+    the six runs): the device's mean within max(1.0, 2 standard errors of the oracle runs' spread) of the f64 oracle's mean, and
+    no device run worse than the worst oracle run by more than 3 points.
 This is the only available stand-in for north_star's "matched TIMIT PER": no TF, no corpus."""
 import json
 import os
@@ -44,18 +49,11 @@ def test_the_corpus_survives_the_tfrecord_round_trip(tmp_path):
         assert [l.decode() if isinstance(l, bytes) else l for l in by] == ['p%d' % y for y in ys]
 
 
-def test_device_training_ends_where_the_oracle_does():
+def _device_run(seed, ohp, params, batches, tb, refs):
     from oracle import las_oracle as O
     from phones_las_amd import model_helper as mh
-    fx = json.load(open(FIXTURE))
-    assert fx['corpus']['steps'] == TC.STEPS and fx['corpus']['n_train'] == TC.N_TRAIN and fx['corpus']['window'] == TC.WINDOW
-    m = TC.MODEL
-    ohp, params = make_hparams(F=m['F'], L=m['L'], H=m['H'], Hd=m['Hd'], V=m['V'], att=m['att'], lr=m['lr'], l2=m['l2'])
     model = mh.LasModel(params)
-    model.load_variables(O.init_params(ohp, seed=4321))
-    batches = [to_device(_tensors(b)) for b in TC.train_batches()]
-    tb, refs = TC.test_batches()
-    tb = [to_device(_tensors(b))[0] for b in tb]
+    model.load_variables(O.init_params(ohp, seed=seed))
 
     def held_out_per():
         hyps = []
@@ -72,21 +70,40 @@ def test_device_training_ends_where_the_oracle_does():
         if t + 1 in TC.PER_STEPS:
             pers[t + 1] = held_out_per()
     model.check_device_status()
-    per = float(np.median(list(pers.values())))
-    f64, bf = fx['f64'], fx['bf16']
-    report = {'per': {'device': per, 'f64': f64['per'], 'bf16': bf['per'], 'device_at': pers, 'f64_at': f64['per_at'], 'bf16_at': bf['per_at']},
-              'curve': {k: (round(curve[int(k)], 5), round(f64['curve'][k], 5), round(bf['curve'][k], 5)) for k in f64['curve']}}
+    return curve, pers, float(np.median(list(pers.values())))
+
+
+def test_device_training_ends_where_the_oracle_does():
+    fx = json.load(open(FIXTURE))
+    assert fx['corpus']['steps'] == TC.STEPS and fx['corpus']['n_train'] == TC.N_TRAIN and fx['corpus']['window'] == TC.WINDOW
+    assert sorted(int(k) for k in fx['f64']) == sorted(TC.SEEDS)
+    m = TC.MODEL
+    ohp, params = make_hparams(F=m['F'], L=m['L'], H=m['H'], Hd=m['Hd'], V=m['V'], att=m['att'], lr=m['lr'], l2=m['l2'])
+    batches = [to_device(_tensors(b)) for b in TC.train_batches()]
+    tb, refs = TC.test_batches()
+    tb = [to_device(_tensors(b))[0] for b in tb]
+    report = {'runs': {}}
+    dev_per, f64_per = [], []
+    for seed in TC.SEEDS:
+        curve, pers, per = _device_run(seed, ohp, params, batches, tb, refs)
+        f64 = fx['f64'][str(seed)]
+        report['runs'][seed] = {'per': round(per, 2), 'per_f64': round(f64['per'], 2),
+                                'per_bf16': round(fx['bf16'][str(seed)]['per'], 2) if str(seed) in fx['bf16'] else None,
+                                'curve': {k: (round(curve[int(k)], 5), round(f64['curve'][k], 5)) for k in f64['curve']}}
+        dev_per.append(per)
+        f64_per.append(f64['per'])
+        for k, ref in f64['curve'].items():            # the coupled phase
+            if int(k) <= 100:
+                assert abs(curve[int(k)] - ref) <= 1e-2 * ref, (seed, k, curve[int(k)], ref)
+        assert curve[TC.STEPS] < 0.05 * curve[TC.CHECKPOINTS[0]], (seed, curve)
+    spread = float(np.std(f64_per, ddof=1))
+    band = max(1.0, 2.0 * spread * np.sqrt(2.0 / len(TC.SEEDS)))       # two standard errors of a difference of two such means
+    report.update(per_mean_device=round(float(np.mean(dev_per)), 3), per_mean_f64=round(float(np.mean(f64_per)), 3),
+                  per_std_f64=round(spread, 3), per_std_device=round(float(np.std(dev_per, ddof=1)), 3), band=round(float(band), 3),
+                  per_bf16={k: round(v['per'], 2) for k, v in fx['bf16'].items()})
     print(json.dumps(report))
     out = os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', 'gpurun_out')
     if os.path.isdir(out):
         json.dump(report, open(os.path.join(out, 'convergence_twin_device.json'), 'w'), indent=1)
-    # the loss curve: within max(3 x the distance between the two oracle runs, 50 % of the larger oracle value, 5e-3) of the f64
-    # curve (late checkpoints sit near zero with occasional Adam spikes on either side: the band is relative to what the two
-    # oracle runs themselves do there)
-    for k, ref in f64['curve'].items():
-        band = max(3.0 * abs(ref - bf['curve'][k]), 0.5 * max(ref, bf['curve'][k]), 5e-3)
-        assert abs(curve[int(k)] - ref) <= band, (k, curve[int(k)], ref, bf['curve'][k], band)
-    assert curve[TC.STEPS] < 0.05 * curve[TC.CHECKPOINTS[0]]
-    # held-out PER (median over the six late checkpoints): within max(1, the two oracle runs' own distance) + 0.5 points of f64
-    gap = abs(f64['per'] - bf['per'])
-    assert abs(per - f64['per']) <= max(1.0, gap) + 0.5, report['per']
+    assert abs(np.mean(dev_per) - np.mean(f64_per)) <= band, report
+    assert max(dev_per) <= max(f64_per) + 3.0, report

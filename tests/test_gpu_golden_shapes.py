@@ -118,7 +118,7 @@ def _check(rep):
     assert rep['gradnorm_worst_f64'][1] < TOL['gradnorm_f64'], rep['gradnorm_worst_f64']
 
 
-@pytest.mark.parametrize('case', ['metricM_dense', 'metricM_ragged', 'metricM_bench', 'cfg1_timit', 'metricL_ctc', 'metricL_full'])
+@pytest.mark.parametrize('case', ['metricM_dense', 'metricM_ragged', 'metricM_bench', 'metricM_ragged64', 'cfg1_timit', 'metricL_ctc', 'metricL_full'])
 def test_train_step_matches_the_oracle_fixture(case):
     """Forward + backward of one train step at the case's shape: logits, loss and every gradient tensor against the
     fixture.  metricM_*: the persistent decoder and the 4-row recurrent kernels must be the ones that ran."""

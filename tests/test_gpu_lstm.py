@@ -197,7 +197,7 @@ def test_exchange_tags_need_no_memset_between_launches():
 
 
 @pytest.mark.parametrize('B,T,D,H,ragged', [(21, 40, 512, 256, True), (64, 48, 512, 256, False), (64, 37, 1024, 256, True),
-                                             (19, 23, 128, 512, True), (5, 7, 512, 256, True)])
+                                             (19, 23, 128, 256, True), (5, 7, 512, 256, True)])
 def test_streamed_input_product_matches_the_product_before_the_recurrence(B, T, D, H, ragged, monkeypatch):
     """Round 4: the input product of the upper layers runs on a second stream BESIDE the recurrence (las_gemm_nt_stream: tiles
     of 16 utterances x 16 steps in consumption order, a counter per block; las_lstm_recurrent_fwd_ex(ready=...) waits on it).

@@ -962,13 +962,13 @@ def test_padding_rows_of_the_one_launch_decoders_do_not_leak(att, H, B):
 
 
 @pytest.mark.parametrize('V,H,B,tgt_len', [(11, 128, 5, [6, 4, 5, 6, 3]), (64, 256, 9, [7, 1, 3, 7, 7, 2, 5, 6, 4]), (42, 128, 3, [4, 4, 2]),
-                                           (100, 128, 4, [5, 3, 5, 1])])
+                                           (110, 128, 4, [5, 3, 5, 1])])
 def test_fused_projection_loss_launch_matches_the_separate_launches(V, H, B, tgt_len, monkeypatch):
     """Round 4: las_proj_ce forms the logits, the sequence loss (model_helper.py:24-30), d(logits) and the product back through the
     projection in one launch.  Against the separate launches (LAS_PROJ_CE=0: projection product, las_seq_ce_loss, product back):
     logits to fp32 summation order, the loss to 1e-5, d(logits) to a bf16 ulp, and every gradient of a full backward pass to the
     usual 2e-3 of its max-abs.  V = 42 pads to 48 columns (three 16-column tiles, the last K chunk of the product back half
-    empty), V = 100 to 112 (two values per lane)."""
+    empty), V = 110 to 112 (two values per lane)."""
     O, ohp, op, model = _models('luong', H=H, F=13, L=2, V=V)
     U = max(tgt_len)
     feats, labels = to_device(make_batch(B=B, T=24, V=V, U=U, src_len=[24 - (i * 5) % 11 for i in range(B)], tgt_len=tgt_len))

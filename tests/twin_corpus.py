@@ -9,6 +9,8 @@ F, NPHONES = 13, 10
 V = NPHONES + 3                      # <unk>, <s>, </s> + phones (ids 3 ..): utils/vocab_utils.py:24-28
 SOS, EOS = 1, 2
 N_TRAIN, N_TEST, BATCH = 512, 128, 16
+SEEDS = [4321, 4322, 4323, 4324, 4325, 4326]      # initial weights of the runs (same corpus, same batch order)
+BF16_SEEDS = [4321, 4322]                         # ... of which the oracle's bf16 storage model is run too
 STEPS = 2400
 CHECKPOINTS = [10, 50, 100, 200, 400, 800, 1200, 1600, 2000, 2400]
 PER_STEPS = [1400, 1600, 1800, 2000, 2200, 2400]   # held-out greedy PER at each of these; the statistic is their MEDIAN (Adam on a
