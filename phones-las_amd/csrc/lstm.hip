@@ -522,9 +522,9 @@ __device__ __forceinline__ void lstm_fwd_body(float* __restrict__ xproj, const u
       for (int ub = 0; ub < UB; ++ub) acc[g][ub] = f32x4{0.f, 0.f, 0.f, 0.f};
     bool did_x = (KX == 0);
     if constexpr (KX > 0) {
-      // the input products of this step are issued inside the poll below, the first time a polling round comes back empty (the
-      // wave would only sleep): eight MFMAs in front of the polls cost their issue time on every step (0.78 against 0.70 ms per
-      // 800-step launch), behind the previous step's granule stores likewise
+      // the input products of this step are issued inside the poll below, behind the first polling round's loads (eight MFMAs in
+      // FRONT of the polls cost their issue time on every step: 0.78 against 0.70 ms per 800-step launch; behind the previous
+      // step's granule stores likewise)
 #pragma unroll
       for (int ub = 0; ub < UB; ++ub)
 #pragma unroll
@@ -552,19 +552,32 @@ __device__ __forceinline__ void lstm_fwd_body(float* __restrict__ xproj, const u
       for (int c0 = 0; c0 < PER; c0 += CH) {
         u64 v[CH];
         unsigned spins = 0;
-        for (;;) {                                   // wave-uniform loop: every lane re-polls until the whole wave is served
-          bool ok = true;
+        bool ok = true;
+        // the first polling round is issued, THEN the input products of this step (fused input projection) and the request
+        // for x_{s+1}: the MFMAs run while the round is in flight.  One site, unconditional: with the products under the
+        // "round came back empty" branch the compiler merged two copies of them through 16 accumulator moves and a
+        // vmcnt(0) wait for x_{s+1} INSIDE the polling loop (0.80 against 0.70 ms per 800-step launch).
+#pragma unroll
+        for (int i = 0; i < CH; ++i) v[i] = granule_load(reinterpret_cast<const u64*>(src + poll_off[c0 + i]));
+        if constexpr (KX > 0) {
+          if (c0 == 0) {
+            __builtin_amdgcn_sched_barrier(0);
+            input_products(s, lean_tag);
+            did_x = true;
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
+#pragma unroll
+        for (int i = 0; i < CH; ++i) ok = ok && ((unsigned)(v[i] >> 32) == base + (unsigned)s);
+        while (!__all(ok)) {                         // wave-uniform loop: every lane re-polls until the whole wave is served
+          if (++spins > SPIN_LIMIT) { fail_flag = 1; break; }
+          __builtin_amdgcn_s_sleep(1);
+          ok = true;
 #pragma unroll
           for (int i = 0; i < CH; ++i) {
             v[i] = granule_load(reinterpret_cast<const u64*>(src + poll_off[c0 + i]));
             ok = ok && ((unsigned)(v[i] >> 32) == base + (unsigned)s);
           }
-          if (__all(ok)) break;
-          if constexpr (KX > 0) {
-            if (!did_x) { input_products(s, lean_tag); did_x = true; continue; }      // use the wait: x_s K_x, then the request for x_{s+1}
-          }
-          if (++spins > SPIN_LIMIT) { fail_flag = 1; break; }
-          __builtin_amdgcn_s_sleep(1);
         }
 #pragma unroll
         for (int i = 0; i < CH; ++i) {
