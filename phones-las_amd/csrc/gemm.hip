@@ -712,14 +712,19 @@ __global__ __launch_bounds__(256) void tn_reduce_kernel(const float* __restrict_
 // without it are NOT ordered against the counter: tiles arrived torn).  Groups whose members are spread over XCDs (never seen
 // under an otherwise idle dispatcher, but placement is not a contract) are dealt to the XCDs round-robin and take the
 // write-back fence.
-template <int BM, int BN, int BK, int STAGES, int WGM, bool STREAM = false>
-__global__ __launch_bounds__(512) void gemm_nt_ring_kernel(GemmArgs g) {
-  constexpr int WGN = 8 / WGM;
+// NW (round 4): waves per workgroup.  With 8 waves on a 256 x 256 tile (128 x 64 per wave) a 32-deep stage costs every wave 12
+// fragment reads of 1 KiB for 16 MFMAs: 96 KiB of LDS reads + 32 KiB of LDS-DMA writes per stage and CU = 1 024 cycles of the
+// 128 B/clk LDS port against 1 024 cycles of MFMA per SIMD -- the LDS port is as busy as the matrix cores, and the kernel sat
+// at half the clock-derated roof.  NW = 4 gives every wave a 128 x 128 block (256 accumulator registers, one wave per SIMD):
+// 16 reads for 32 MFMAs, 64 + 32 KiB per stage = 768 LDS cycles against the same 1 024 MFMA cycles.
+template <int BM, int BN, int BK, int STAGES, int WGM, bool STREAM = false, int NW = 8>
+__global__ __launch_bounds__(NW * 64) void gemm_nt_ring_kernel(GemmArgs g) {
+  constexpr int WGN = NW / WGM;
   constexpr int TM = BM / WGM / 32, TN = BN / WGN / 32;          // 32 x 32 tiles per wave
   constexpr int ROWB = BK * 2;                                   // bytes per tile row
   constexpr int CPR = BK / 8;                                    // 16-byte chunks per row
   constexpr int RPC = 1024 / ROWB;                               // rows per 1-KiB load
-  constexpr int NA = BM / RPC / 8, NB = BN / RPC / 8;            // loads per wave and stage
+  constexpr int NA = BM / RPC / NW, NB = BN / RPC / NW;          // loads per wave and stage
   constexpr int NL = NA + NB;
   constexpr int STAGE_BYTES = (BM + BN) * ROWB;
   constexpr int KS = BK / 16;                                    // MFMA k-steps per stage
@@ -808,7 +813,7 @@ __global__ __launch_bounds__(512) void gemm_nt_ring_kernel(GemmArgs g) {
 #pragma unroll
   for (int i = 0; i < NL; ++i) {
     const bool isA = i < NA;
-    const int q = wave + 8 * (isA ? i : i - NA);
+    const int q = wave + NW * (isA ? i : i - NA);
     const int row = RPC * q + lane / CPR;
     const int ch = (lane % CPR) ^ fswz(row);
     if (isA) {
@@ -820,7 +825,7 @@ __global__ __launch_bounds__(512) void gemm_nt_ring_kernel(GemmArgs g) {
     const unsigned base = lds_base + stage * STAGE_BYTES;
 #pragma unroll
     for (int i = 0; i < NL; ++i) {
-      const int q = wave + 8 * (i < NA ? i : i - NA);
+      const int q = wave + NW * (i < NA ? i : i - NA);
       glds16(src[i], base + (i < NA ? 0 : BM * ROWB) + q * 1024);
       src[i] += BK;
     }
@@ -892,7 +897,7 @@ __global__ __launch_bounds__(512) void gemm_nt_ring_kernel(GemmArgs g) {
   __builtin_amdgcn_s_barrier();              // every wave has finished reading the last stage
   asm volatile("" ::: "memory");
   constexpr int WN_ = 32 * TN, LDC = WN_ + 4;
-  static_assert(8 * 32 * LDC * 4 <= STAGES * STAGE_BYTES, "epilogue staging must fit in the ring");
+  static_assert(NW * 32 * LDC * 4 <= STAGES * STAGE_BYTES, "epilogue staging must fit in the ring");
   float* cs = reinterpret_cast<float*>(smem) + wave * 32 * LDC;
   float* Cf = reinterpret_cast<float*>(g.C) + (int64_t)batch * g.sc;
   unsigned short* Cb = reinterpret_cast<unsigned short*>(g.C) + (int64_t)batch * g.sc;
@@ -966,17 +971,17 @@ __global__ __launch_bounds__(512) void gemm_nt_ring_kernel(GemmArgs g) {
   }   // for (;;): the streamed form takes the next tile of its XCD's queue
 }
 
-template <int BM, int BN, int BK, int STAGES, int WGM>
+template <int BM, int BN, int BK, int STAGES, int WGM, int NW = 8>
 int launch_ring(const GemmArgs& g, int batch, hipStream_t st) {
   dim3 grid((g.N + BN - 1) / BN, (g.M + BM - 1) / BM, batch);
   const size_t lds = (size_t)STAGES * (BM + BN) * BK * 2;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_ring_kernel<BM, BN, BK, STAGES, WGM>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_ring_kernel<BM, BN, BK, STAGES, WGM, false, NW>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
-  hipLaunchKernelGGL((gemm_nt_ring_kernel<BM, BN, BK, STAGES, WGM>), grid, dim3(512), lds, st, g);
+  hipLaunchKernelGGL((gemm_nt_ring_kernel<BM, BN, BK, STAGES, WGM, false, NW>), grid, dim3(NW * 64), lds, st, g);
   LAS_LAUNCH_CHECK("ring gemm launch");
   return LAS_OK;
 }
@@ -1102,7 +1107,9 @@ static int gemm_nt(const las_bf16* A, int64_t lda, const las_bf16* B, int64_t ld
     if (ring && split_k == 1 && K % 64 == 0 && K >= 128 && M >= 1024 && N >= 128 && (ldc % 4 == 0 || out_bf16)) {
       const bool wide = N >= 256 && N % 256 != 128;
       if (ring == 1) return launch_ring<256, 128, 64, 3, 4>(g, batch, st);
-      if (ring == 4 || (ring == 5 && !(wide && K > 1024))) return launch_ring<256, 128, 32, 3, 4>(g, batch, st);
+      if (ring == 6 && wide) return launch_ring<256, 256, 32, 4, 2, 4>(g, batch, st);
+      if (ring == 4 || (ring >= 5 && !(wide && K > 1024))) return launch_ring<256, 128, 32, 3, 4>(g, batch, st);
+      if (wide && ring == 6) return launch_ring<256, 256, 32, 4, 2, 4>(g, batch, st);      // four waves of 128 x 128
       if (wide) return launch_ring<256, 256, 32, 4, 2>(g, batch, st);
       return launch_ring<256, 128, 64, 3, 4>(g, batch, st);
     }
