@@ -421,8 +421,25 @@ typedef struct las_dec_persist {
   las_bf16* att_out;
   int64_t ld_att;
   int64_t inc_p;
+  /* Second decoder cell (decoder_layers = 2, the reference's default depth; round 4), k1T != NULL; softmax attentions, no
+   * attention layer, teacher forcing without input dropout / scheduled sampling; las_decoder_persist2_supported.
+   *   wiring 0  MultiRNNCell inside the AttentionWrapper (las/model.py:194-200): cell 1 reads [h0_t | h1_{t-1}] (K1_in = 2 Hd), the
+   *             attention is queried with h1_t and its context is the output and the feed of cell 0;
+   *   wiring 1  AttentionMultiCell (--bottom_only, las/model.py:36-69): the attention is queried with h0_t, cell 1 reads
+   *             [attention_t | attention_{t-1} | h1_{t-1}] (K1_in = 2 M + Hd), its h1_t is the output.
+   * k1T [4Hd, K1_in] bf16 (row n = output column n of cell 1's kernel, rows in that order; row stride ldk1), bias1 [4Hd];
+   * c1 [B, U+1, Hd] fp32 and h1 [B, U+1, Hd] bf16: row 0 = the initial state (in), row t+1 = the state after step t (out);
+   * gates1 [B, U, 4Hd] fp32 (out).  The fields of `s` describe cell 0 and the attention as without a second cell. */
+  const las_bf16* k1T;
+  int64_t ldk1;
+  int32_t K1_in, wiring;
+  const float* bias1;
+  float* c1;
+  float* gates1;
+  las_bf16* h1;
 } las_dec_persist;
 int las_decoder_persist_supported(int Hd, int M, int K_in, int attention, int norm);   /* 1 if the shapes fit */
+int las_decoder_persist2_supported(int Hd, int M, int K_in, int K1_in, int attention, int wiring);   /* ... with a second cell */
 /* ... with an attention layer of A outputs (A = 0: none) and / or a monotonic normaliser (decoder_units 128 / 256) */
 int las_decoder_persist_al_supported(int Hd, int M, int K_in, int A, int attention, int norm);
 size_t las_decoder_persist_workspace_bytes(int B, int Tm, int Hd, int M);   /* status, group flags, exchange granules */

@@ -735,7 +735,7 @@ constexpr int P_MEMBERS = 32;
 __host__ __device__ inline size_t persist_flag_words(int B) { return (size_t)((B + 7) / 8) * 2 * P_MEMBERS; }
 __host__ __device__ inline size_t persist_exchange_words(int B, int Tm, int Hd, int M) {
   const size_t ld = (size_t)((Tm + 31) / 32) * 32;
-  const size_t fwd = 2 * (size_t)B * (ld + 5 * (size_t)Hd), bwd = 2 * (size_t)B * (4 + 5 * (size_t)Hd + (size_t)(M + Hd));
+  const size_t fwd = 2 * (size_t)B * (ld + 9 * (size_t)Hd), bwd = 2 * (size_t)B * (4 + 5 * (size_t)Hd + (size_t)(M + Hd));
   return fwd > bwd ? fwd : bwd;
 }
 // forward: scratch, and this workgroup's score frames of the keys [fq, Hd] + its context columns of the values [Tm, M/4]
@@ -816,7 +816,14 @@ __device__ bool persist_barrier(pu64* flags, int member, unsigned epoch, bool lo
 // form one 16-column tile of attention_t each for the group's 8 utterances (K = Hd + M over the four waves, W_al slice in
 // registers: KAL_MAX chunks per wave) and write it to `att_out` and into the next operand row.  The monotonic normalisers
 // (las/model.py:157-164) run inside the shared step body; here they only get their per-step pointers.
-template <bool SAMPLING, bool RES, int NTL_MAX = 2, int KCW_MAX = 12, int KRES = KCW_MAX, bool AL = false, int KAL_MAX = 10>
+// TWO (round 4): a second decoder cell (decoder_layers = 2, the reference's default depth) inside the launch.  p.wiring 0 = a
+// MultiRNNCell inside the AttentionWrapper (las/model.py:194-200): per step G0 -> cell 0 -> barrier -> G1: z1 = [h0_t | h1_{t-1}] K1
+// -> cell 1 + attention queried with h1_t; p.wiring 1 = AttentionMultiCell (--bottom_only, las/model.py:36-69): G0 -> cell 0 +
+// attention queried with h0_t -> barrier -> G1: z1 = [attention_t | attention_{t-1} | h1_{t-1}] K1 -> cell 1.  G1's operand row is
+// gathered chunk by chunk from where its pieces already lie (h0_t in s.h_out, attention_t in s.ctx_out, attention_{t-1} in the
+// operand row of cell 0, h1_{t-1} in p.h1): no copies; K1's chunks are streamed from L2 at every step (at 2M + Hd columns in
+// the --bottom_only wiring they would not fit the registers next to K0's).
+template <bool SAMPLING, bool RES, int NTL_MAX = 2, int KCW_MAX = 12, int KRES = KCW_MAX, bool AL = false, int KAL_MAX = 10, bool TWO = false>
 __global__ __launch_bounds__(256) void dec_persist_fwd_kernel(las_dec_persist p) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   const las_dec_step& s0 = p.s;
@@ -1004,8 +1011,8 @@ __global__ __launch_bounds__(256) void dec_persist_fwd_kernel(las_dec_persist p)
     LAS_STAMP(t, 2);
 
     // ---- S: cell + attention of utterance bs, context columns of `part` ----
-    if (bs < B) {
-      las_dec_step st = s0;
+    las_dec_step st = s0;
+    {
       const bool last = (t + 1 == p.U);
       st.tok_ids = s0.tok_ids + t * p.inc_tok;
       st.c_prev = s0.c_prev + t * p.inc_cprev;
@@ -1024,11 +1031,105 @@ __global__ __launch_bounds__(256) void dec_persist_fwd_kernel(las_dec_persist p)
         st.ldpa = s0.lda;
         st.p_out = s0.p_out ? s0.p_out + t * p.inc_p : nullptr;
       }
-      pu64* xsc = xbase + ((size_t)(xtag & 1) * B + bs) * ldsc;
-      pu64* xz = xzb + ((size_t)(xtag & 1) * B + bs) * 4 * Hd;
-      PersistHook hook{xsc, xz, xtag, flags, member, &epoch, local, fail, p.wq_packed, lkeys, lvals,
-                       pre_ok, tok_pre, {tok4[0], tok4[1], tok4[2], tok4[3]}, {bias4[0], bias4[1], bias4[2], bias4[3]}, cprev_pre};
-      dec_step_fwd_body<RES>(st, bs, part, 4, sm, &hook);     // (a timed-out poll leaves through the barrier below)
+    }
+    pu64* const xsc = xbase + ((size_t)(xtag & 1) * B + (bs < B ? bs : 0)) * ldsc;
+    pu64* const xz = xzb + ((size_t)(xtag & 1) * B + (bs < B ? bs : 0)) * 4 * Hd;
+    if constexpr (!TWO) {
+      if (bs < B) {
+        PersistHook hook{xsc, xz, xtag, flags, member, &epoch, local, fail, p.wq_packed, lkeys, lvals,
+                         pre_ok, tok_pre, {tok4[0], tok4[1], tok4[2], tok4[3]}, {bias4[0], bias4[1], bias4[2], bias4[3]}, cprev_pre};
+        dec_step_fwd_body<RES>(st, bs, part, 4, sm, &hook);     // (a timed-out poll leaves through the barrier below)
+      }
+    } else {
+      // the second cell's step: no token rows, its own bias / state / saved gates; the attention fields are cell 0's (one attention)
+      las_dec_step st1 = st;
+      st1.tok_rows = nullptr;
+      st1.bias = p.bias1;
+      st1.c_prev = p.c1 + (int64_t)t * Hd;            st1.ldcp = (int64_t)(p.U + 1) * Hd;
+      st1.c_out = p.c1 + (int64_t)(t + 1) * Hd;       st1.ldco = (int64_t)(p.U + 1) * Hd;
+      st1.gates_out = p.gates1 + (int64_t)t * 4 * Hd; st1.ldg = (int64_t)p.U * 4 * Hd;
+      st1.h_out = p.h1 + (int64_t)(t + 1) * Hd;       st1.ldh = (int64_t)(p.U + 1) * Hd;
+      st1.h_out2 = nullptr;
+      st1.drop_keep = 1.0f;
+      las_dec_step stA = st;
+      if (p.wiring == 0) {           // cell 0 alone now; the attention runs with cell 1
+        stA.mode = LAS_DEC_CELL_ONLY;
+        stA.ctx_out2 = nullptr;
+        st1.mode = LAS_DEC_FUSED;
+      } else {                       // cell 0 with the attention now; cell 1 alone afterwards
+        stA.mode = LAS_DEC_FUSED;
+        st1.mode = LAS_DEC_CELL_ONLY;
+        st1.ctx_out2 = nullptr;
+      }
+      if (bs < B) {
+        PersistHook hook{xsc, xz, xtag, flags, member, &epoch, local, fail, p.wq_packed, lkeys, lvals,
+                         pre_ok, tok_pre, {tok4[0], tok4[1], tok4[2], tok4[3]}, {bias4[0], bias4[1], bias4[2], bias4[3]}, cprev_pre};
+        dec_step_fwd_body<RES>(stA, bs, part, 4, sm, &hook);
+      }
+      // every piece of G1's operand rows (h0_t, attention_t of all 8 utterances) is in memory behind this barrier
+      if (!persist_barrier(flags, member, ++epoch, local, fail)) break;
+      // ---- G1: z1_t[group's utterances, my columns] = [pieces] K1, all chunks streamed ----
+      pu64* const xz1b = xzb + 2 * (size_t)B * 4 * Hd;
+      {
+        f32x4 acc[NTL_MAX];
+#pragma unroll
+        for (int nt = 0; nt < NTL_MAX; ++nt) acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const int64_t bgc = min(bg, B - 1);
+        const int KC1 = p.K1_in / 32, nH = Hd / 32, nM = M / 32;
+        // this lane's row of each piece (8 lq = its 16 bytes of a 32-deep chunk)
+        const unsigned short* r_h0 = s0.h_out + bgc * s0.ldh + (int64_t)t * p.inc_h + 8 * lq;                    // h0_t
+        const unsigned short* r_h1 = p.h1 + (bgc * (p.U + 1) + t) * Hd + 8 * lq;                                  // h1_{t-1}
+        const unsigned short* r_at = s0.ctx_out + bgc * s0.ldc + (int64_t)t * p.inc_ctx + 8 * lq;                // attention_t
+        const unsigned short* r_ap = p.x + bgc * p.ldx + (int64_t)t * p.inc_x + 8 * lq;                          // attention_{t-1}
+        auto piece = [&](int kc) -> const unsigned short* {
+          if (p.wiring == 0) return kc < nH ? r_h0 + kc * 32 : r_h1 + (kc - nH) * 32;
+          if (kc < nM) return r_at + kc * 32;
+          if (kc < 2 * nM) return r_ap + (kc - nM) * 32;
+          return r_h1 + (kc - 2 * nM) * 32;
+        };
+        const unsigned short* w1row[NTL_MAX];
+#pragma unroll
+        for (int nt = 0; nt < NTL_MAX; ++nt) w1row[nt] = p.k1T + (int64_t)(member * CPM + min(nt, NTL - 1) * 16 + l15) * p.ldk1 + 8 * lq;
+        constexpr int SB = 4;
+#pragma unroll 1
+        for (int i0 = 0; wave + 4 * i0 < KC1; i0 += SB) {
+          uint4 a[SB], w[SB][NTL_MAX];
+#pragma unroll
+          for (int j = 0; j < SB; ++j) {
+            const int kc = wave + 4 * (i0 + j), kcc = min(kc, KC1 - 1);
+            a[j] = *reinterpret_cast<const uint4*>(piece(kcc));
+            if (kc >= KC1 || bg >= B) a[j] = make_uint4(0, 0, 0, 0);
+#pragma unroll
+            for (int nt = 0; nt < NTL_MAX; ++nt) w[j][nt] = *reinterpret_cast<const uint4*>(w1row[nt] + kcc * 32);
+          }
+#pragma unroll
+          for (int j = 0; j < SB; ++j)
+#pragma unroll
+            for (int nt = 0; nt < NTL_MAX; ++nt)
+              acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a[j]), __builtin_bit_cast(bf16x8, w[j][nt]), acc[nt], 0, 0, 0);
+        }
+        __syncthreads();                         // (the S role above is done with the LDS scratch `red` lies behind)
+#pragma unroll
+        for (int nt = 0; nt < NTL_MAX; ++nt)
+          if (nt < NTL)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) red[(wave * 16 + lq * 4 + r) * RS + nt * 16 + l15] = acc[nt][r];
+        __syncthreads();
+        for (int e = tid; e < 8 * CPM; e += 256) {
+          const int row = e / CPM, col = e % CPM;
+          const int b = group * 8 + row;
+          if (b < B)
+            pgranule_store(xz1b + ((size_t)(xtag & 1) * B + b) * 4 * Hd + member * CPM + col, xtag,
+                           red[(0 * 16 + row) * RS + col] + red[(1 * 16 + row) * RS + col] + red[(2 * 16 + row) * RS + col] + red[(3 * 16 + row) * RS + col],
+                           local);
+        }
+      }
+      if (bs < B) {
+        pu64* const xz1 = xz1b + ((size_t)(xtag & 1) * B + bs) * 4 * Hd;
+        PersistHook hook1{xsc, xz1, xtag, flags, member, &epoch, local, fail, p.wq_packed, lkeys, lvals,
+                          false, 0, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, 0.f};
+        dec_step_fwd_body<RES>(st1, bs, part, 4, sm, &hook1);
+      }
     }
     if constexpr (SAMPLING) {
       // ---- scheduled sampling (utils/training_helper.py:48-87): logits_t = context_t W_proj + b from the four parts'
@@ -3797,6 +3898,16 @@ extern "C" int las_decoder_persist_al_supported(int Hd, int M, int K_in, int A, 
   return 1;
 }
 
+extern "C" int las_decoder_persist2_supported(int Hd, int M, int K_in, int K1_in, int attention, int wiring) {
+  // the one-launch forward with a second cell (general body): decoder_units 128 / 256, softmax attentions
+  if (attention != LAS_ATT_LUONG && attention != LAS_ATT_BAHDANAU) return 0;
+  if (Hd != 128 && Hd != 256) return 0;
+  if (K_in % 64 != 0 || K_in / 32 > 48 || M % 32 != 0) return 0;
+  if (wiring == 0) return K1_in == 2 * Hd ? 1 : 0;
+  if (wiring == 1) return K1_in == 2 * M + Hd ? 1 : 0;
+  return 0;
+}
+
 extern "C" int las_decoder_persist_supported(int Hd, int M, int K_in, int attention, int norm) {
   if (norm != LAS_NORM_SOFTMAX) return 0;
   if (attention != LAS_ATT_LUONG && attention != LAS_ATT_BAHDANAU && attention != LAS_ATT_CUSTOM) return 0;
@@ -3830,9 +3941,14 @@ extern "C" int las_decoder_persist_fwd(const las_dec_persist* p, void* stream) {
   const las_dec_step* s = &p->s;
   LAS_REQUIRE(s->B > 0 && p->U > 0 && s->mode == LAS_DEC_FUSED, "las_decoder_persist_fwd: bad shape / mode");
   LAS_REQUIRE(s->B <= 4 * persist_max_batch(), "las_decoder_persist_fwd: at most %d utterances per launch (got %d)", 4 * persist_max_batch(), s->B);
-  const bool al_path = p->walT != nullptr || s->norm != LAS_NORM_SOFTMAX;
-  LAS_REQUIRE(al_path ? las_decoder_persist_al_supported(s->Hd, s->M, p->K_in, p->walT ? p->A : 0, s->attention, s->norm)
-                      : las_decoder_persist_supported(s->Hd, s->M, p->K_in, s->attention, s->norm),
+  const bool two = p->k1T != nullptr;
+  const bool al_path = p->walT != nullptr || s->norm != LAS_NORM_SOFTMAX || two;
+  LAS_REQUIRE(!two || (las_decoder_persist2_supported(s->Hd, s->M, p->K_in, p->K1_in, s->attention, p->wiring) && !p->walT &&
+                       s->norm == LAS_NORM_SOFTMAX && p->bias1 && p->c1 && p->gates1 && p->h1 && p->ldk1 >= p->K1_in && p->ldk1 % 8 == 0),
+              "las_decoder_persist_fwd: second cell: unsupported configuration or missing buffers (Hd=%d M=%d K_in=%d K1_in=%d wiring=%d)",
+              s->Hd, s->M, p->K_in, p->K1_in, p->wiring);
+  LAS_REQUIRE(two || (al_path ? las_decoder_persist_al_supported(s->Hd, s->M, p->K_in, p->walT ? p->A : 0, s->attention, s->norm)
+                              : las_decoder_persist_supported(s->Hd, s->M, p->K_in, s->attention, s->norm)),
               "las_decoder_persist_fwd: configuration not supported (Hd=%d M=%d K_in=%d attention=%d norm=%d)", s->Hd, s->M, p->K_in,
               s->attention, s->norm);
   LAS_REQUIRE(!al_path || (p->sampling_prob <= 0.f && s->drop_keep >= 1.0f), "las_decoder_persist_fwd: attention layer / monotonic "
@@ -3869,7 +3985,10 @@ extern "C" int las_decoder_persist_fwd(const las_dec_persist* p, void* stream) {
     }                                                                                                                           \
     hipLaunchKernelGGL((dec_persist_fwd_kernel<__VA_ARGS__>), grid, dim3(256), lds_al, st, *p);                                 \
   } while (0)
-    if (p->walT) {
+    if (two) {
+      if (res) LAS_AL_LAUNCH(false, true, 2, 12, 12, false, 10, true);
+      else LAS_AL_LAUNCH(false, false, 2, 12, 12, false, 10, true);
+    } else if (p->walT) {
       if (res) LAS_AL_LAUNCH(false, true, 2, 12, 12, true, 10);
       else LAS_AL_LAUNCH(false, false, 2, 12, 12, true, 10);
     } else {

@@ -104,6 +104,7 @@ _SIGS = {
     'las_gemm_tn_lstm': ([_vp, _i64, C.c_int, _vp, _i64, C.c_int, C.c_int, C.c_int, _vp, _i64, _vp, _vp, C.c_int, C.c_int, _vp, _vp], C.c_int),
     'las_decoder_persist_supported': ([C.c_int] * 5, C.c_int),
     'las_decoder_persist_al_supported': ([_i32, _i32, _i32, _i32, _i32, _i32], C.c_int),
+    'las_decoder_persist2_supported': ([_i32, _i32, _i32, _i32, _i32, _i32], C.c_int),
     'las_decoder_persist_workspace_bytes': ([C.c_int, C.c_int, C.c_int, C.c_int], C.c_size_t),
     'las_decoder_persist_max_batch': ([], C.c_int),
     'las_decoder_persist_fwd': ([_vp, _vp], C.c_int),
@@ -151,7 +152,8 @@ class DecPersist(C.Structure):
         ('x', _vp), ('ldx', _i64), ('inc_x', _i64), ('kT', _vp), ('ldk', _i64), ('wq_packed', _vp), ('sc_all', _vp), ('ld_sc', _i64), ('workspace', _vp),
         ('sampling_prob', _f32), ('seed', C.c_uint32), ('teacher', _vp), ('teacher_stride', _i64), ('wprojT', _vp), ('ldw', _i64),
         ('bproj', _vp), ('logits', _vp), ('ld_logits', _i64), ('plog', _vp), ('V', _i32), ('Vp', _i32),
-        ('walT', _vp), ('ld_wal', _i64), ('A', _i32), ('x_att_off', _i32), ('att_out', _vp), ('ld_att', _i64), ('inc_p', _i64)]
+        ('walT', _vp), ('ld_wal', _i64), ('A', _i32), ('x_att_off', _i32), ('att_out', _vp), ('ld_att', _i64), ('inc_p', _i64),
+        ('k1T', _vp), ('ldk1', _i64), ('K1_in', _i32), ('wiring', _i32), ('bias1', _vp), ('c1', _vp), ('gates1', _vp), ('h1', _vp)]
 
 
 class DecStepBwd(C.Structure):

@@ -379,6 +379,8 @@ class GeneralSpeller:
         logits = None
         if self._persist_ok(B, Tm, keep, sampling, input_vectors):
             return self._forward_train_persist(sv, init, targets_inputs)
+        if self._persist2_ok(B, Tm, keep, sampling, input_vectors):
+            return self._forward_train_persist(sv, init, targets_inputs, two=True)
         if sampling > 0.0:               # scheduled sampling (utils/training_helper.py:48-87)
             fed = tin[:, :U].contiguous().clone()
             logits = torch.empty(B, U, Vp, dtype=f32, device=dev)
@@ -493,7 +495,22 @@ class GeneralSpeller:
         return (B <= 4 * lib.las_decoder_persist_max_batch() and
                 lib.las_decoder_persist_al_supported(self.Hd, self.M, Kp, self.A if self.has_al else 0, self.att, self._norm(True)) == 1)
 
-    def _forward_train_persist(self, sv, init, targets_inputs):
+    def _persist2_ok(self, B, Tm, keep, sampling, input_vectors):
+        """Two decoder cells (the reference's default depth) in ONE forward launch (round 4): both wirings, softmax attentions,
+        one-hot tokens, no attention layer, teacher forcing without dropout / sampling.  LAS_DEC_PERSIST2=0: step by step."""
+        import os
+        if os.environ.get('LAS_DEC_PERSIST', '1') == '0' or os.environ.get('LAS_DEC_PERSIST2', '1') == '0':
+            return False
+        if self.NL != 2 or self.tokx or self.emb or self.sigmoid or self.has_al or self.mono or self.custom:
+            return False
+        if keep < 1.0 or sampling > 0.0 or input_vectors is not None:
+            return False
+        lib = hip.lib()
+        Kp = (self.win[0] + self.Hd + 63) // 64 * 64
+        return (B <= 4 * lib.las_decoder_persist_max_batch() and
+                lib.las_decoder_persist2_supported(self.Hd, self.M, Kp, self.win[1] + self.Hd, self.att, 1 if self.bottom else 0) == 1)
+
+    def _forward_train_persist(self, sv, init, targets_inputs, two=False):
         B, Tm, U, M = sv['B'], sv['Tm'], sv['U'], self.M
         Hd, A, Vp = self.Hd, self.A, self.Vop
         dev, bf, f32 = sv['memory'].device, torch.bfloat16, torch.float32
@@ -546,18 +563,36 @@ class GeneralSpeller:
         if self.has_al:
             p.walT, p.ld_wal, p.A, p.x_att_off = hip.addr(self.walT), Hd + M, A, 0
             p.att_out, p.ld_att = hip.addr(sv['att']), U * A
+        if two:
+            # the second cell: its kernel rows in operand order ([h0 | h1] or [attention_t | attention_{t-1} | h1]: self.kT[1] as
+            # it is), its states with the initial row in front
+            K1 = self.win[1] + Hd
+            c1 = torch.empty(B, U + 1, Hd, dtype=f32, device=dev)
+            h1 = torch.empty(B, U + 1, Hd, dtype=bf, device=dev)
+            hip.fill_many(copy=[(c1[:, 0], init[1][0].float()), (h1[:, 0], init[1][1].float())])
+            p.k1T, p.ldk1, p.K1_in, p.wiring = hip.addr(self.kT[1]), K1, K1, 1 if self.bottom else 0
+            p.bias1, p.c1, p.gates1, p.h1 = hip.addr(self.bias[1]), hip.addr(c1), hip.addr(sv['gates'][1]), hip.addr(h1)
         ws = self._persist_workspace('fwd', lib.las_decoder_persist_workspace_bytes(B, Tm, Hd, M))
         p.workspace = hip.addr(ws)
-        tok = hip.prof_begin('dec_persist_fwd', 2.0 * U * B * (Kp * 4 * Hd + Tm * Hd + Tm * M + (Hd + M) * (A if self.has_al else 0)))
+        tok = hip.prof_begin('dec_persist_fwd', 2.0 * U * B * (Kp * 4 * Hd + Tm * Hd + Tm * M + (Hd + M) * (A if self.has_al else 0)
+                                                               + ((self.win[1] + Hd) * 4 * Hd if two else 0)))
         hip.check(lib.las_decoder_persist_fwd(C.byref(p), st))
         hip.prof_end(tok)
         self._persist_ws = ws
         # what the step-by-step backward reads: the compact operand rows and the attention layer's [query | context] rows
         sv['X'][0] = Xp[:, :, :W0].contiguous()
+        if two:
+            # ... and the second cell's: its states in the step-by-step layout, its operand rows gathered from the pieces
+            sv['cs'][1] = c1
+            sv['h'][1] = h1[:, 1:].contiguous()
+            if self.bottom:     # [attention_t | attention_{t-1} | h1_{t-1}]
+                sv['X'][1] = torch.cat([sv['ctx'], Xp[:, :, :M], h1[:, :U]], -1)
+            else:               # [h0_t | h1_{t-1}]
+                sv['X'][1] = torch.cat([sv['h'][0], h1[:, :U]], -1)
         if self.has_al:
             sv['qc'][:, :, :Hd].copy_(sv['h'][0])
             sv['qc'][:, :, Hd:].copy_(sv['ctx'])
-        out_all = sv['att']
+        out_all = sv['h'][1] if (two and self.bottom) else sv['att']
         sv['out'] = out_all
         logits = torch.empty(B, U, Vp, dtype=f32, device=dev)
         hip.gemm_nt(out_all, self.wprojT, logits, B * U, Vp, self.P, lda=self.P, ldb=self.P, ldc=Vp, bias=self.bproj)

@@ -991,3 +991,48 @@ def test_fused_projection_loss_launch_matches_the_separate_launches(V, H, B, tgt
     # ... and against the oracle
     ref = O.train_step(ohp, op, None, None, 1, {k: v for k, v in make_batch(B=B, T=24, V=V, U=U, src_len=[24 - (i * 5) % 11 for i in range(B)], tgt_len=tgt_len).items()}, mxu='bf16')
     assert abs(la - float(ref['aux']['ce'])) < 2e-2 * abs(float(ref['aux']['ce']))
+
+
+@pytest.mark.parametrize('kw', [
+    dict(att='luong', dec_layers=2, bottom_only=False, pass_hidden=False, H=128),      # the reference's default decoder wiring
+    dict(att='luong', dec_layers=2, bottom_only=True, pass_hidden=True, H=128),        # AttentionMultiCell (--bottom_only)
+    dict(att='bahdanau', dec_layers=2, bottom_only=False, pass_hidden=False, H=256),
+    dict(att='bahdanau', dec_layers=2, bottom_only=True, pass_hidden=True, H=256),
+], ids=['stack2_luong128', 'multicell2_luong128', 'stack2_bahdanau256', 'multicell2_bahdanau256'])
+@pytest.mark.parametrize('B', [3, 19])
+def test_two_cell_decoder_forward_in_one_launch(kw, B, monkeypatch):
+    """Round 4 (first half): decoder_layers = 2 -- the reference's DEFAULT depth (train.py:44) -- in ONE forward
+    launch, in both wirings (MultiRNNCell inside the AttentionWrapper, las/model.py:194-200; AttentionMultiCell with the old
+    attention fed to the upper cell, las/model.py:36-69).  Against the oracle (logits, loss, every gradient: the backward still
+    runs step by step on what the launch leaves behind) and against the step-by-step forward (LAS_DEC_PERSIST2=0); B = 19:
+    three groups of utterances, the last one partial."""
+    O, ohp, op, model = _models(L=2, F=13, **kw)
+    from phones_las_amd.las.speller_general import GeneralSpeller
+    assert isinstance(model.speller, GeneralSpeller)
+    src_len = [12 - (i * 5) % 9 for i in range(B)]
+    tgt_len = [6 - (i * 3) % 5 for i in range(B)]
+    batch = make_batch(B=B, src_len=src_len, tgt_len=tgt_len)
+    feats, labels = to_device(batch)
+    out = O.train_step(ohp, op, None, None, 1, batch, mxu='bf16')
+    res = {}
+    for flag in ('1', '0'):
+        monkeypatch.setenv('LAS_DEC_PERSIST2', flag)
+        model.vars.grad.zero_()
+        loss, logits, dlogits = model.forward_train(feats, labels)
+        one_launch = getattr(model.speller, '_persist_ws', None) is not None and flag == '1'
+        model.backward(dlogits)
+        torch.cuda.synchronize()
+        res[flag] = (float(loss), logits.clone(), {n: g.clone() for n, g in model.vars.grads.items()}, one_launch)
+        model.speller._persist_ws = None
+    model.check_device_status()
+    assert res['1'][3] and not res['0'][3]
+    V = ohp.decoder.target_vocab_size
+    for flag in ('1', '0'):
+        loss, logits, grads, _ = res[flag]
+        for b, n in enumerate(tgt_len):
+            assert relerr(logits[b, :n, :V], out['aux']['logits'][b, :n]) < 2e-2, (flag, b)
+        assert abs(loss - float(out['aux']['ce'].detach())) < 2e-2 * float(out['aux']['ce'].detach())
+        for name, _, _ in model.vars.table:
+            g = out['grads'][name] - ohp.l2_reg_scale * op[name]
+            assert relerr(grads[name], g) < 2 * GRAD_TOL, (flag, name)
+    assert relerr(res['1'][1], res['0'][1].cpu()) < 2e-3
