@@ -115,8 +115,8 @@ def synthetic_batch(c, seed, device):
 
 
 KERNEL_NAMES = {        # family (phones_las_amd.hip.KernelTimer) -> kernel symbol(s) in a rocprofv3 trace
-    'lstm_fwd': 'lstm_fwd_kernel<%(H)d, %(rows)d>', 'lstm_bwd': 'lstm_bwd_kernel<%(H)d, %(rows)d>',
-    'dec_persist_fwd': 'dec_persist_fwd_lean_kernel<att, tiles> (dec_persist_fwd_kernel: scheduled sampling, 512 units)',
+    'lstm_fwd': 'lstm_fwd_kernel<%(H)d, %(rows)d, G, KX> (KX > 0: the bottom layer, input projection inside the chain)', 'lstm_bwd': 'lstm_bwd_kernel<%(H)d, %(rows)d, G>',
+    'dec_persist_fwd': 'dec_persist_fwd_lean_kernel<att, tiles> (dec_persist_fwd_kernel: scheduled sampling, 512 units, two cells)',
     'dec_persist_bwd': 'dec_persist_bwd_kernel<wq, M/128>',
     'gemm_nt': 'gemm_nt_ring_kernel<256, 128|256, 32, ...> (+ gemm_kernel<..., false, ...> for the small shapes): x K_x, dX, keys, logits',
     'gemm_tn': 'gemm_tn_tr_kernel / gemm_kernel<..., true, ...> (speller weight gradients)',
