@@ -355,6 +355,7 @@ typedef struct las_dec_step {
   float drop_keep;
   uint32_t drop_seed, drop_stream;
   int32_t step, feed_width;
+  int32_t feed_plain;            /* != 0: ctx_out2 is written unmasked also under drop_keep < 1 (the reader applies the mask) */
   const las_bf16* query;         /* LAS_DEC_ATTENTION_ONLY: the query [B,Hd] bf16, row stride ldq */
   int64_t ldq;
   /* monotonic attention (enum las_att_norm != 0); all NULL/0 otherwise */
@@ -422,7 +423,11 @@ typedef struct las_dec_persist {
   int64_t ld_att;
   int64_t inc_p;
   /* Second decoder cell (decoder_layers = 2, the reference's default depth; round 4), k1T != NULL; softmax attentions, no
-   * attention layer, teacher forcing without input dropout / scheduled sampling; las_decoder_persist2_supported.
+   * attention layer; las_decoder_persist2_supported.  Input dropout (s.drop_keep < 1, the reference's default 0.8): the token row's
+   * scale as in `s`; the masks of the two cells' input rows are applied where the launch reads them -- element (b, c), c < win_l,
+   * of cell l at step t is draw (s.drop_seed, in_stream_l + t, b * win_l + c), the streams of U x las_dropout_bf16 on the
+   * step-by-step path -- and the rows in memory (x, h1, s.ctx_out, s.h_out) stay undropped.  Scheduled sampling as above, on
+   * the output row of the wiring (the context, or h1_t).
    *   wiring 0  MultiRNNCell inside the AttentionWrapper (las/model.py:194-200): cell 1 reads [h0_t | h1_{t-1}] (K1_in = 2 Hd), the
    *             attention is queried with h1_t and its context is the output and the feed of cell 0;
    *   wiring 1  AttentionMultiCell (--bottom_only, las/model.py:36-69): the attention is queried with h0_t, cell 1 reads
@@ -437,6 +442,8 @@ typedef struct las_dec_persist {
   float* c1;
   float* gates1;
   las_bf16* h1;
+  int32_t win0, win1;            /* masked leading columns of cell 0's operand row (the attention feed) and of cell 1's */
+  uint32_t in_stream0, in_stream1;
 } las_dec_persist;
 int las_decoder_persist_supported(int Hd, int M, int K_in, int attention, int norm);   /* 1 if the shapes fit */
 int las_decoder_persist2_supported(int Hd, int M, int K_in, int K1_in, int attention, int wiring);   /* ... with a second cell */
@@ -525,8 +532,34 @@ typedef struct las_dec_persist_bwd {
                                   * workgroups in a fixed order instead of with fp32 atomics (bit-reproducible training) */
   float* dhp_all;                /* unused (the partial dh travel through the workspace); may be NULL */
   void* workspace;               /* las_decoder_persist_workspace_bytes(B, Tm, Hd, M) */
+  /* Second decoder cell (decoder_layers = 2; round 4), k1c != NULL: the backward of las_dec_persist's two wirings in one launch;
+   * decoder_units 128 / 256; las_decoder_persist2_bwd_supported.  `s` describes cell 0 and the attention (s.gates / c_new /
+   * c_prev / dz / dc: cell 0's), the fields here cell 1 with the SAME row strides and step increments (gates1 [B,U,4Hd] like
+   * s.gates, c1 [B,U+1,Hd]: row t = c1_{t-1}, dz1 like s.dz, dc1 [B,Hd] in/out like s.dc).  Replaces the U x (2 cell backward
+   * launches + attention backward + 2 las_gemm_nt + the adds between them) loop of the step-by-step path.
+   *   wiring 0: s.dctx_a = d(outputs) [.., M] (the context is the output); cell 1's product P1_t = dz1_t K1^T is
+   *             [d h0_t | d h1_{t-1}] (W1 = 2 Hd);
+   *   wiring 1: s.dctx_a = NULL, d_out1 = d(outputs) [.., Hd] (h1_t is the output, row stride ld_dout1, step increment
+   *             inc_dout1); P1_t = [d attention_t | d attention_{t-1} | d h1_{t-1}] (W1 = 2 M + Hd).
+   * k1c [W1, 4Hd] bf16: row n = input row n of cell 1's kernel.  dfeed_all [B, W] / dfeed1_all [B, W1] receive step 0's
+   * products (the gradients into the initial feed / states; the masked columns are returned UNMASKED).  Input dropout
+   * (s.drop_keep < 1): element (b, c), c < win_l, of cell l's input row at step t was scaled by draw (s.drop_seed,
+   * in_stream_l + t, b * win_l + c) (las_dec_persist); its gradient is scaled likewise where the products are consumed. */
+  const las_bf16* k1c;
+  int64_t ldk1;
+  int32_t W1, wiring;
+  const float* gates1;
+  const float* c1;
+  las_bf16* dz1;
+  float* dc1;
+  float* dfeed1_all;
+  const float* d_out1;
+  int64_t ld_dout1, inc_dout1;
+  int32_t win0, win1;
+  uint32_t in_stream0, in_stream1;
 } las_dec_persist_bwd;
 int las_decoder_persist_bwd_supported(int Hd, int M, int W, int attention, int norm);
+int las_decoder_persist2_bwd_supported(int Hd, int M, int W, int W1, int attention, int wiring);
 int las_decoder_persist_bwd(const las_dec_persist_bwd* p, void* stream);
 
 /* All U backward steps of a single-cell decoder with an attention layer (attention_layer_size / --binf_projection,
@@ -591,6 +624,12 @@ int las_dropout_bf16(const las_bf16* x, int64_t ldx, las_bf16* y, int64_t ldy, i
  * indices of las_dropout_bf16); x is read once.  cols and the row strides in multiples of 8. */
 int las_dropout_bf16_pair(const las_bf16* x, int64_t ldx, las_bf16* y0, las_bf16* y1, int64_t ldy, int rows, int cols,
                           float keep, uint32_t seed, uint32_t stream0, uint32_t stream1, void* stream);
+/* The input masks of U decoder steps in one pass, in place: element (b, t, c), c < cols, at x[b * ldb + t * ldt + c] is scaled by
+ * draw (seed, stream0 + t, b * cols + c) -- U x las_dropout_bf16(rows = B, stream = stream0 + t).  The two-cell one-launch
+ * decoder leaves its operand rows undropped; the weight-gradient products (las/model.py:194-200 cells under
+ * DropoutWrapper, las/ops.py:14-18) read them dropped.  cols, ldb, ldt: multiples of 8. */
+int las_dropout_bf16_steps(las_bf16* x, int64_t ldb, int64_t ldt, int B, int U, int cols, float keep, uint32_t seed,
+                           uint32_t stream0, void* stream);
 /* out = a * mask(stream_a)/keep (+ b * mask(stream_b)/keep when b != NULL); contiguous [rows, cols] fp32. */
 int las_dropout_bwd(const float* a, const float* b, float* out, int rows, int cols, float keep, uint32_t seed,
                     uint32_t stream_a, uint32_t stream_b, void* stream);

@@ -241,6 +241,15 @@ __device__ unsigned long long las_stamps[2 * 256 * 16];        // forward launch
 #define LAS_STAMPB(step, k) do { } while (0)
 #endif
 
+// DropoutWrapper mask on 8 consecutive elements of a cell's input row (elements idx0 .. idx0 + 7 of generator stream `stream`):
+// exactly what las_dropout_bf16 writes, applied where a product role reads the operand row (two-cell one-launch decoders)
+__device__ __forceinline__ uint4 drop8(uint4 v, unsigned seed, unsigned stream, unsigned long long idx0, float keep, float inv) {
+  unsigned short* e = reinterpret_cast<unsigned short*>(&v);
+#pragma unroll
+  for (int j = 0; j < 8; ++j) e[j] = las_f2bf(las_bf2f(e[j]) * (las_uniform(seed, stream, idx0 + j) < keep ? inv : 0.f));
+  return v;
+}
+
 struct PersistHook {
   pu64* xsc;            // raw-score granules of this utterance and step parity: [ld] {tag, fp32}
   pu64* xz;             // z_t granules of this utterance and step parity: [4Hd] {tag, fp32}
@@ -686,7 +695,7 @@ __device__ __forceinline__ void dec_step_fwd_body(const las_dec_step& s, const i
       s.ctx_out[(int64_t)b * s.ldc + cb + j] = o;
       if (s.ctx_out2) {
         unsigned short o2 = o;
-        if (s.drop_keep < 1.0f) {   // the copy that feeds step t+1's cell goes through that step's input dropout
+        if (s.drop_keep < 1.0f && !s.feed_plain) {   // the copy that feeds step t+1's cell goes through that step's input dropout
           const unsigned long long idx = ((unsigned long long)(s.step + 1) * s.B + b) * s.feed_width + (s.feed_width - M) + cb + j;
           o2 = las_uniform(s.drop_seed, s.drop_stream, idx) < s.drop_keep ? las_f2bf(las_bf2f(o) / s.drop_keep) : (unsigned short)0;
         }
@@ -735,7 +744,8 @@ constexpr int P_MEMBERS = 32;
 __host__ __device__ inline size_t persist_flag_words(int B) { return (size_t)((B + 7) / 8) * 2 * P_MEMBERS; }
 __host__ __device__ inline size_t persist_exchange_words(int B, int Tm, int Hd, int M) {
   const size_t ld = (size_t)((Tm + 31) / 32) * 32;
-  const size_t fwd = 2 * (size_t)B * (ld + 9 * (size_t)Hd), bwd = 2 * (size_t)B * (4 + 5 * (size_t)Hd + (size_t)(M + Hd));
+  // (backward with a second cell: + [2][B][W1] granules of its product, W1 <= 2 M + Hd)
+  const size_t fwd = 2 * (size_t)B * (ld + 9 * (size_t)Hd), bwd = 2 * (size_t)B * (4 + 5 * (size_t)Hd + (size_t)(M + Hd) + (size_t)(2 * M + Hd));
   return fwd > bwd ? fwd : bwd;
 }
 // forward: scratch, and this workgroup's score frames of the keys [fq, Hd] + its context columns of the values [Tm, M/4]
@@ -765,9 +775,15 @@ __host__ __device__ inline int persist_bwd_kt_stride(int Tm) {
   if (((r / 8) & 1) == 0) r += 8;
   return r;
 }
-__host__ __device__ inline size_t persist_bwd_scratch_floats(int M, int Hd, int Tm) {
+// partial-tile area of the product roles: the cell product's tiles, at least 2048 floats; with a second cell its product's
+// [4 waves][8][5 * 16 + 1] (up to 5 column tiles of 2 M + Hd columns per member)
+__host__ __device__ inline size_t persist_bwd_red_area(int M, int Hd, bool two) {
+  const size_t r2 = persist_bwd_red2_floats(M + Hd), lo = two ? (size_t)4 * 8 * (5 * 16 + 1) : 2048;
+  return r2 > lo ? r2 : lo;
+}
+__host__ __device__ inline size_t persist_bwd_scratch_floats(int M, int Hd, int Tm, bool two = false) {
   // (the Bahdanau query-layer product borrows the partial-tile area as 2048 floats of scratch)
-  const size_t r2 = persist_bwd_red2_floats(M + Hd);
+  const size_t r2 = persist_bwd_red_area(M, Hd, two);
   // (d(context): M floats, or two bf16 rows of M -- high and low halves -- for the matrix-core d(alignments) pass; + 16 B of zeros)
   // (+ ds of the own frames as two bf16 rows, high and low halves, padded to whole 32-frame chunks with zeros)
   return ((size_t)M + 4 + 2 * (size_t)Tm + 2048 + 16 + Hd + (r2 > 2048 ? r2 : 2048) + 8 + persist_bwd_ds_pad(Tm) + 3) & ~(size_t)3;
@@ -779,8 +795,8 @@ __host__ __device__ inline size_t persist_bwd_resident_bytes(int M, int Hd, int 
   const size_t fq = (Tm + 3) / 4;
   return (fq * (size_t)(M + P_VPAD) + (keys_t ? (size_t)Hd * persist_bwd_kt_stride(Tm) : fq * (size_t)Hd)) * 2;
 }
-__host__ __device__ inline bool persist_bwd_resident(int M, int Hd, int Tm, bool keys_t) {
-  return persist_bwd_scratch_floats(M, Hd, Tm) * 4 + persist_bwd_resident_bytes(M, Hd, Tm, keys_t) <= 158 * 1024;
+__host__ __device__ inline bool persist_bwd_resident(int M, int Hd, int Tm, bool keys_t, bool two = false) {
+  return persist_bwd_scratch_floats(M, Hd, Tm, two) * 4 + persist_bwd_resident_bytes(M, Hd, Tm, keys_t) <= 158 * 1024;
 }
 
 __device__ bool persist_barrier(pu64* flags, int member, unsigned epoch, bool local, int* lds_fail) {
@@ -956,6 +972,9 @@ __global__ __launch_bounds__(256) void dec_persist_fwd_kernel(las_dec_persist p)
         const int kc = wave + 4 * i;
         av[i] = make_uint4(0, 0, 0, 0);
         if (kc < KC && bg < B) av[i] = *reinterpret_cast<const uint4*>(arow + kc * 32);
+        if constexpr (TWO)       // input dropout of cell 0's attention feed (columns [0, win0)): the rows in memory stay undropped
+          if (s0.drop_keep < 1.0f && kc * 32 + 8 * lq < p.win0 && bg < B)
+            av[i] = drop8(av[i], s0.drop_seed, p.in_stream0 + (unsigned)t, (unsigned long long)bg * p.win0 + kc * 32 + 8 * lq, s0.drop_keep, 1.0f / s0.drop_keep);
       }
 #pragma unroll
       for (int i = 0; i < KRES; ++i)
@@ -979,6 +998,9 @@ __global__ __launch_bounds__(256) void dec_persist_fwd_kernel(las_dec_persist p)
             const int kc = wave + 4 * (i0 + j), kcc = min(kc, KC - 1);
             a[j] = *reinterpret_cast<const uint4*>(arow + kcc * 32);
             if (kc >= KC || bg >= B) a[j] = make_uint4(0, 0, 0, 0);
+            if constexpr (TWO)
+              if (s0.drop_keep < 1.0f && kcc * 32 + 8 * lq < p.win0)
+                a[j] = drop8(a[j], s0.drop_seed, p.in_stream0 + (unsigned)t, (unsigned long long)min(bg, B - 1) * p.win0 + kcc * 32 + 8 * lq, s0.drop_keep, 1.0f / s0.drop_keep);
 #pragma unroll
             for (int nt = 0; nt < NTL_MAX; ++nt) w[j][nt] = *reinterpret_cast<const uint4*>(wrow[nt] + kcc * 32);
           }
@@ -1050,8 +1072,9 @@ __global__ __launch_bounds__(256) void dec_persist_fwd_kernel(las_dec_persist p)
       st1.gates_out = p.gates1 + (int64_t)t * 4 * Hd; st1.ldg = (int64_t)p.U * 4 * Hd;
       st1.h_out = p.h1 + (int64_t)(t + 1) * Hd;       st1.ldh = (int64_t)(p.U + 1) * Hd;
       st1.h_out2 = nullptr;
-      st1.drop_keep = 1.0f;
-      las_dec_step stA = st;
+      st1.drop_keep = 1.0f;                           // (no token rows; its input mask is applied where G1 reads the row)
+      las_dec_step stA = st;                          // (keeps drop_keep: the token row's scale; the feed copy stays plain)
+      stA.feed_plain = 1;
       if (p.wiring == 0) {           // cell 0 alone now; the attention runs with cell 1
         stA.mode = LAS_DEC_CELL_ONLY;
         stA.ctx_out2 = nullptr;
@@ -1099,6 +1122,8 @@ __global__ __launch_bounds__(256) void dec_persist_fwd_kernel(las_dec_persist p)
             const int kc = wave + 4 * (i0 + j), kcc = min(kc, KC1 - 1);
             a[j] = *reinterpret_cast<const uint4*>(piece(kcc));
             if (kc >= KC1 || bg >= B) a[j] = make_uint4(0, 0, 0, 0);
+            if (s0.drop_keep < 1.0f && kcc * 32 + 8 * lq < p.win1)       // input dropout of cell 1 (columns [0, win1) of its row)
+              a[j] = drop8(a[j], s0.drop_seed, p.in_stream1 + (unsigned)t, (unsigned long long)bgc * p.win1 + kcc * 32 + 8 * lq, s0.drop_keep, 1.0f / s0.drop_keep);
 #pragma unroll
             for (int nt = 0; nt < NTL_MAX; ++nt) w[j][nt] = *reinterpret_cast<const uint4*>(w1row[nt] + kcc * 32);
           }
@@ -1152,15 +1177,20 @@ __global__ __launch_bounds__(256) void dec_persist_fwd_kernel(las_dec_persist p)
       if (any_sel) {
       float* plog_t = p.plog + ((int64_t)t * B + (bs < B ? bs : 0)) * 4 * Vp;
       if (my_sel) {
-        const int cols = M / 4, c0 = part * cols;
-        float* cx = sm;                                   // [cols] my context columns as floats
+        // the decoder's output row: the context (this part's columns, as it wrote them), or -- second cell in the --bottom_only
+        // wiring -- h1_t, which every part holds in LDS (hq of the cell it just ran)
+        const bool out_h1 = TWO && p.wiring == 1;
+        const int cols = (out_h1 ? Hd : M) / 4, c0 = part * cols;
+        float* cx = out_h1 ? sm + c0 : sm;                // [cols] my columns of the output as floats
         __builtin_amdgcn_s_waitcnt(0x0070);               // my context stores are done
         __syncthreads();
-        const unsigned short* crow = s0.ctx_out + (int64_t)bs * s0.ldc + (int64_t)t * p.inc_ctx + c0;
-        for (int c = tid; c < cols; c += 256)
-          cx[c] = las_bf2f(__builtin_bit_cast(unsigned short, (unsigned short)__hip_atomic_load(
-                      reinterpret_cast<const unsigned short*>(crow) + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)));
-        __syncthreads();
+        if (!out_h1) {
+          const unsigned short* crow = s0.ctx_out + (int64_t)bs * s0.ldc + (int64_t)t * p.inc_ctx + c0;
+          for (int c = tid; c < cols; c += 256)
+            cx[c] = las_bf2f(__builtin_bit_cast(unsigned short, (unsigned short)__hip_atomic_load(
+                        reinterpret_cast<const unsigned short*>(crow) + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)));
+          __syncthreads();
+        }
         for (int v = tid; v < Vp; v += 256) {
           float acc = 0.f;
           if (v < V) {
@@ -2934,8 +2964,16 @@ __global__ __launch_bounds__(256) void dec_seq_bwd_kernel(las_dec_seq_bwd p) {
 // NT_MAX 16-column tiles of d[attention, h] per member (W / 16 / 32), KCW_MAX 32-deep chunks of the 4 Hd gate columns per wave
 // of which KRES stay in registers (512 units: 5 tiles x 6 of 16 chunks resident, the rest streamed from L2 every step, three in
 // flight); PD d(context) columns per thread (M <= 256 PD); UPT hidden units per thread in the cell backward (512 units: 2).
-template <bool WQ, int NPQ = 0, int NT_MAX = 3, int KRES = 8, int KCW_MAX = 8, int PD = 6, int UPT = 1>
+// TWO (round 4): a second decoder cell (decoder_layers = 2) inside the launch -- `s` describes cell 0 and the attention, the
+// fields behind `workspace` cell 1.  Per step, cell 1 first: (cell backward) -> barrier -> P1 = dz1_t K1^T -> (cell backward) ->
+// barrier -> P0 = dz0_t K0^T; the attention phases S1 / S2 / S3 belong to the cell that queries the attention: cell 1 in
+// wiring 0 (MultiRNNCell inside the AttentionWrapper), cell 0 in wiring 1 (--bottom_only), the other cell's backward is the
+// plain one (part 0 of each utterance, unit = thread).  Both products travel as granules; P1's weights are streamed from L2.
+// Input dropout: the masks of the step-by-step path (draw (seed, in_stream_l + t, b * win_l + c)) where a product's columns
+// are consumed.
+template <bool WQ, int NPQ = 0, int NT_MAX = 3, int KRES = 8, int KCW_MAX = 8, int PD = 6, int UPT = 1, bool TWO = false>
 __global__ __launch_bounds__(256) void dec_persist_bwd_kernel(las_dec_persist_bwd p) {
+  static_assert(!TWO || UPT == 1, "second cell: decoder_units <= 256");
   extern __shared__ __attribute__((aligned(16))) float sm[];
   constexpr int RS2 = NT_MAX * 16 + 1;              // row stride of the G role's partial tiles
   const las_dec_step_bwd& s0 = p.s;
@@ -2963,7 +3001,7 @@ __global__ __launch_bounds__(256) void dec_persist_bwd_kernel(las_dec_persist_bw
   float* dhs = alg + Tm;                  // [2048] per-phase partial dh
   float* red = dhs + 2048;                // [16 + Hd]
   float* red2 = red + 16 + Hd;            // [4 waves][8 utterances][RS2] partial output tiles of the G role
-  int* fail = reinterpret_cast<int*>(red2 + (persist_bwd_red2_floats(M + Hd) > 2048 ? persist_bwd_red2_floats(M + Hd) : 2048));
+  int* fail = reinterpret_cast<int*>(red2 + persist_bwd_red_area(M, Hd, TWO));
   int* colo = fail + 1;
   unsigned* status = reinterpret_cast<unsigned*>(p.workspace);
   pu64* flags = reinterpret_cast<pu64*>(reinterpret_cast<char*>(p.workspace) + 64) + (size_t)group * 2 * P_MEMBERS;
@@ -2972,6 +3010,22 @@ __global__ __launch_bounds__(256) void dec_persist_bwd_kernel(las_dec_persist_bw
   pu64* xdh = xdot + 2 * (size_t)B * 4;                                                                        // [2][B][4][Hd]
   pu64* xdq = xdh + 2 * (size_t)B * 4 * Hd;                                                                    // [2][B][Hd]
   pu64* xdf = xdq + 2 * (size_t)B * Hd;                                                                        // [2][B][W]
+  pu64* xdf1 = xdf + 2 * (size_t)B * W;                                                                        // [2][B][W1] (TWO)
+  const int W1 = TWO ? p.W1 : 0;
+  const bool w1 = TWO && p.wiring == 1;
+  // the cell the attention phases belong to (A) and the plain one (P): saved tensors, d(c), dz rows
+  const bool a_is_1 = TWO && !w1;
+  const float* gatesA = a_is_1 ? p.gates1 : s0.gates;
+  const float* cnewA = a_is_1 ? p.c1 + Hd : s0.c_new;
+  const float* cprevA = a_is_1 ? p.c1 : s0.c_prev;
+  unsigned short* dzA = a_is_1 ? p.dz1 : s0.dz;
+  float* dcA = a_is_1 ? p.dc1 : s0.dc;
+  const float* gatesP = a_is_1 ? s0.gates : p.gates1;
+  const float* cnewP = a_is_1 ? s0.c_new : p.c1 + Hd;
+  const float* cprevP = a_is_1 ? s0.c_prev : p.c1;
+  unsigned short* dzP = a_is_1 ? s0.dz : p.dz1;
+  float* dcP = a_is_1 ? s0.dc : p.dc1;
+  const float keep = s0.drop_keep, inv_keep = 1.0f / s0.drop_keep;
   if (tid == 0) { *fail = 0; *colo = 0; }
   __syncthreads();
   if (tid == 0) {
@@ -3021,9 +3075,9 @@ __global__ __launch_bounds__(256) void dec_persist_bwd_kernel(las_dec_persist_bw
   // the frames of this workgroup do not change over the U steps: keep them in LDS when they fit (every step would
   // otherwise stream them from L2 / Infinity Cache again, four dependent round trips in S1 alone)
   constexpr bool KT = !WQ && NPQ > 0;     // Luong with the matrix-core passes: the resident keys are transposed
-  const bool resident = persist_bwd_resident(M, Hd, Tm, KT);
+  const bool resident = persist_bwd_resident(M, Hd, Tm, KT, TWO);
   const int MS = M + P_VPAD, FS = persist_bwd_kt_stride(Tm), DSP = persist_bwd_ds_pad(Tm);
-  unsigned short* lvals = reinterpret_cast<unsigned short*>(sm + persist_bwd_scratch_floats(M, Hd, Tm));   // [fq][MS]
+  unsigned short* lvals = reinterpret_cast<unsigned short*>(sm + persist_bwd_scratch_floats(M, Hd, Tm, TWO));   // [fq][MS]
   unsigned short* lkeys = lvals + (size_t)fq * MS;                                                           // [fq][Hd]
   if (tid < 8) dcb[2 * M + tid] = 0;
   for (int e = tid; e < 2 * DSP; e += 256) dsb[e] = 0;
@@ -3057,7 +3111,100 @@ __global__ __launch_bounds__(256) void dec_persist_bwd_kernel(las_dec_persist_bw
   const bool cellw = active && part == 0 && tid < Hd;
   float dcr[UPT];
 #pragma unroll
-  for (int q = 0; q < UPT; ++q) dcr[q] = cellw ? s0.dc[(int64_t)b * Hd + tid + q * 256] : 0.f;
+  for (int q = 0; q < UPT; ++q) dcr[q] = cellw ? dcA[(int64_t)b * Hd + tid + q * 256] : 0.f;
+  float dcp = (TWO && cellw) ? dcP[(int64_t)b * Hd + tid] : 0.f;          // d(c) of the plain cell
+  // input-dropout factor of element (b, col) of cell l's input row at step tt (1 without dropout)
+  auto in_mask = [&](int l, int tt, int col) -> float {
+    if (!(keep < 1.0f)) return 1.0f;
+    const int win = l == 0 ? p.win0 : p.win1;
+    return las_uniform(s0.drop_seed, (l == 0 ? p.in_stream0 : p.in_stream1) + (unsigned)tt, (unsigned long long)b * win + col) < keep ? inv_keep : 0.f;
+  };
+  // the plain cell's backward at step t (part 0, unit = thread): dh from the sources the wiring names, dz_t (bf16) out
+  auto plain_cell = [&](int t, unsigned xtag, bool first) {
+    if (!cellw) return;
+    float dht = 0.f;
+    const pu64* xf0 = xdf + ((size_t)((xtag - 1) & 1) * B + b) * W;
+    const pu64* xf1p = xdf1 + ((size_t)((xtag - 1) & 1) * B + b) * W1;
+    const pu64* xf1c = xdf1 + ((size_t)(xtag & 1) * B + b) * W1;
+    unsigned spins = 0;
+    for (;;) {
+      // wiring 0 (cell 0): d(h0_t) = mask . P1_t[tid] + P0_{t+1}[M + tid];  wiring 1 (cell 1): d_out_t[tid] + P1_{t+1}[2 M + tid]
+      const pu64 ga = w1 ? ((pu64)xtag << 32) : pgranule_load(xf1c + tid);
+      const pu64 gb = first ? ((pu64)(xtag - 1) << 32) : pgranule_load(w1 ? xf1p + 2 * M + tid : xf0 + M + tid);
+      if (__all((unsigned)(ga >> 32) == xtag && (unsigned)(gb >> 32) == xtag - 1)) {
+        dht = __uint_as_float((unsigned)gb);
+        if (w1) dht += p.d_out1[(int64_t)b * p.ld_dout1 + (int64_t)t * p.inc_dout1 + tid];
+        else dht += __uint_as_float((unsigned)ga) * in_mask(1, t, tid);
+        break;
+      }
+      if (++spins > P_SPIN_LIMIT || *fail) { if (lane == 0) *fail = 1; break; }
+      __builtin_amdgcn_s_sleep(1);
+    }
+    const float* gp = gatesP + (int64_t)b * s0.ldg + (int64_t)t * p.inc_gates + tid;
+    const float gi = gp[0], gj = gp[Hd], gf = gp[2 * Hd], go = gp[3 * Hd];
+    const float ct = cnewP[(int64_t)b * s0.ldcn + (int64_t)t * p.inc_c + tid], cp = cprevP[(int64_t)b * s0.ldcp + (int64_t)t * p.inc_c + tid];
+    const float tc = las_tanh(ct);
+    const float dov = dht * tc * go * (1.f - go);
+    const float dct = dcp + dht * go * (1.f - tc * tc);
+    const float di = dct * gj * gi * (1.f - gi);
+    const float dj = dct * gi * (1.f - gj * gj);
+    const float df = dct * cp * gf * (1.f - gf);
+    dcp = dct * gf;
+    unsigned short* zp = dzP + (int64_t)b * s0.ldz + (int64_t)t * p.inc_dz + tid;
+    zp[0] = las_f2bf(di); zp[Hd] = las_f2bf(dj); zp[2 * Hd] = las_f2bf(df); zp[3 * Hd] = las_f2bf(dov);
+  };
+  // P1 = dz1_t K1^T for the group's 8 utterances: member j owns the 16-column tiles j, j + 32, ... of its W1 columns; K1's
+  // rows are streamed from L2 (four 32-deep chunks in flight per wave)
+  auto product1 = [&](int t, unsigned xtag) {
+    constexpr int NT1 = TWO ? 5 : 1, RS1 = NT1 * 16 + 1;       // up to 5 column tiles per member (2 M + Hd <= 2560 columns)
+    const int NTW1 = W1 / 16, KC1 = 4 * Hd / 32;
+    f32x4 acc[NT1];
+#pragma unroll
+    for (int j = 0; j < NT1; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int bgc = min(group * 8 + (l15 & 7), B - 1);
+    const unsigned short* zrow = (l15 < 8) ? p.dz1 + (int64_t)bgc * s0.ldz + (int64_t)t * p.inc_dz + 8 * lq
+                                           : reinterpret_cast<const unsigned short*>(reinterpret_cast<const char*>(p.workspace) + 16);
+    const int zstep = (l15 < 8) ? 32 : 0;
+    const unsigned short* w1row[NT1];
+#pragma unroll
+    for (int j = 0; j < NT1; ++j) w1row[j] = p.k1c + (int64_t)(min(member + 32 * j, NTW1 - 1) * 16 + l15) * p.ldk1 + 8 * lq;
+    constexpr int SB = 4;
+#pragma unroll 1
+    for (int i0 = 0; wave + 4 * i0 < KC1; i0 += SB) {
+      uint4 a[SB], w[SB][NT1];
+#pragma unroll
+      for (int q = 0; q < SB; ++q) {
+        const int kc = wave + 4 * (i0 + q), kcc = min(kc, KC1 - 1);
+        a[q] = *reinterpret_cast<const uint4*>(zrow + kcc * zstep);
+        if (kc >= KC1) a[q] = make_uint4(0, 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < NT1; ++j) w[q][j] = *reinterpret_cast<const uint4*>(w1row[j] + kcc * 32);
+      }
+#pragma unroll
+      for (int q = 0; q < SB; ++q)
+#pragma unroll
+        for (int j = 0; j < NT1; ++j)
+          acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a[q]), __builtin_bit_cast(bf16x8, w[q][j]), acc[j], 0, 0, 0);
+    }
+    if (lq < 2) {
+#pragma unroll
+      for (int j = 0; j < NT1; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) red2[(wave * 8 + lq * 4 + r) * RS1 + j * 16 + l15] = acc[j][r];
+    }
+    lds_barrier();
+    for (int e = tid; e < 8 * NT1 * 16; e += 256) {
+      const int row = e / (NT1 * 16), c = e % (NT1 * 16), j = c / 16, col = c % 16;
+      const int tile = member + 32 * j, bb = group * 8 + row;
+      if (tile < NTW1 && bb < B) {
+        const float v = red2[(0 * 8 + row) * RS1 + c] + red2[(1 * 8 + row) * RS1 + c] +
+                        red2[(2 * 8 + row) * RS1 + c] + red2[(3 * 8 + row) * RS1 + c];
+        if (t == 0 && p.dfeed1_all) p.dfeed1_all[(int64_t)bb * W1 + tile * 16 + col] = v;      // the caller's d(initial state of cell 1)
+        pgranule_store(xdf1 + ((size_t)(xtag & 1) * B + bb) * W1 + tile * 16 + col, xtag, v, local);
+      }
+    }
+    lds_barrier();                          // (red2 is written again by the next product)
+  };
   // likewise the step's row of d(context) from the projection layer and its alignments: step t-1's are requested
   // at the top of step t (PD values per thread cover M <= 256 * PD)
   float cur_dc[PD], cur_al = 0.f;
@@ -3065,7 +3212,7 @@ __global__ __launch_bounds__(256) void dec_persist_bwd_kernel(las_dec_persist_bw
 #pragma unroll
     for (int i = 0; i < PD; ++i) {
       const int m = tid + i * 256;
-      dcv[i] = (active && m < M) ? s0.dctx_a[(int64_t)b * s0.ldda + (int64_t)tt_ * p.inc_a + m] : 0.f;
+      dcv[i] = (active && m < M && (!TWO || s0.dctx_a)) ? s0.dctx_a[(int64_t)b * s0.ldda + (int64_t)tt_ * p.inc_a + m] : 0.f;
     }
     const int fr = f0 + tid;
     alv = (active && fr < f1 && fr < len) ? (s0.align + (int64_t)b * s0.lda + (int64_t)tt_ * p.inc_align)[fr] : 0.f;
@@ -3084,15 +3231,23 @@ __global__ __launch_bounds__(256) void dec_persist_bwd_kernel(las_dec_persist_bw
       sg[q][0] = sg[q][1] = sg[q][2] = sg[q][3] = 0.f;
       sct[q] = scp[q] = sdf[q] = 0.f;
       if (cellw) {
-        const float* gp = s0.gates + (int64_t)b * s0.ldg + (int64_t)t * p.inc_gates + tid + q * 256;
+        const float* gp = gatesA + (int64_t)b * s0.ldg + (int64_t)t * p.inc_gates + tid + q * 256;
         sg[q][0] = gp[0]; sg[q][1] = gp[Hd]; sg[q][2] = gp[2 * Hd]; sg[q][3] = gp[3 * Hd];
-        sct[q] = s0.c_new[(int64_t)b * s0.ldcn + (int64_t)t * p.inc_c + tid + q * 256];
-        scp[q] = s0.c_prev[(int64_t)b * s0.ldcp + (int64_t)t * p.inc_c + tid + q * 256];
+        sct[q] = cnewA[(int64_t)b * s0.ldcn + (int64_t)t * p.inc_c + tid + q * 256];
+        scp[q] = cprevA[(int64_t)b * s0.ldcp + (int64_t)t * p.inc_c + tid + q * 256];
       }
     }
     float nxt_dc[PD], nxt_al = 0.f;
     if (t > 0) fetch_step(t - 1, nxt_dc, nxt_al);
     const unsigned xtag = (unsigned)(p.U - t);       // 1, 2, ...: tag of this step's granules, parity slot xtag & 1
+    if constexpr (TWO) {
+      if (w1) {
+        // ---- cell 1 (plain; its h1_t is the decoder's output) -> barrier -> P1_t ----
+        if (active && part == 0) plain_cell(t, xtag, first);
+        if (!persist_barrier(flags, member, ++epoch, local, fail)) break;
+        product1(t, xtag);
+      }
+    }
     // ---- S1 ----
     if (active) {
       // the feed gradient of step t+1 arrives as granules from that step's 32 product slices (tag xtag - 1): this
@@ -3100,7 +3255,42 @@ __global__ __launch_bounds__(256) void dec_persist_bwd_kernel(las_dec_persist_bw
       float fbv[PD];
 #pragma unroll
       for (int i = 0; i < PD; ++i) fbv[i] = 0.f;
-      if (!first) {
+      if constexpr (TWO) {
+        // sources of d(context)_t and of the attention cell's recurrent gradient: step t+1's products (tag xtag - 1; none at
+        // the first step) and, in wiring 1, this step's P1; the masks of the cell inputs they went through
+        const pu64* xf0 = xdf + ((size_t)((xtag - 1) & 1) * B + b) * W;
+        const pu64* xf1p = xdf1 + ((size_t)((xtag - 1) & 1) * B + b) * W1;
+        const pu64* xf1c = xdf1 + ((size_t)(xtag & 1) * B + b) * W1;
+        unsigned spins = 0;
+        for (;;) {
+          bool got = true;
+          pu64 g0[PD], g1[PD], g2[PD];
+#pragma unroll
+          for (int i = 0; i < PD; ++i) {
+            const int m = tid + i * 256;
+            g0[i] = (!first && m < M) ? pgranule_load(xf0 + m) : ((pu64)(xtag - 1) << 32);
+            g1[i] = (w1 && !first && m < M) ? pgranule_load(xf1p + M + m) : ((pu64)(xtag - 1) << 32);
+            g2[i] = (w1 && m < M) ? pgranule_load(xf1c + m) : ((pu64)xtag << 32);
+            got = got && ((unsigned)(g0[i] >> 32) == xtag - 1) && ((unsigned)(g1[i] >> 32) == xtag - 1) && ((unsigned)(g2[i] >> 32) == xtag);
+          }
+          const pu64 gr = (cellw && !first) ? pgranule_load(w1 ? xf0 + M + tid : xf1p + Hd + tid) : ((pu64)(xtag - 1) << 32);
+          got = got && ((unsigned)(gr >> 32) == xtag - 1);
+          if (__all(got)) {
+#pragma unroll
+            for (int i = 0; i < PD; ++i) {
+              const int m = tid + i * 256;
+              if (m < M) {
+                fbv[i] = __uint_as_float((unsigned)g0[i]) * in_mask(0, t + 1, m);
+                if (w1) fbv[i] += __uint_as_float((unsigned)g1[i]) * in_mask(1, t + 1, M + m) + __uint_as_float((unsigned)g2[i]) * in_mask(1, t, m);
+              }
+            }
+            if (cellw) sdf[0] = __uint_as_float((unsigned)gr);
+            break;
+          }
+          if (++spins > P_SPIN_LIMIT || *fail) { if (lane == 0) *fail = 1; break; }
+          __builtin_amdgcn_s_sleep(1);
+        }
+      } else if (!first) {
         const pu64* xf = xdf + ((size_t)((xtag - 1) & 1) * B + b) * W;
         unsigned spins = 0;
         for (;;) {
@@ -3135,7 +3325,9 @@ __global__ __launch_bounds__(256) void dec_persist_bwd_kernel(las_dec_persist_bw
         const int m = tid + i * 256;
         if (m >= M) break;
         float v = cur_dc[i];
-        if (!first) {
+        if constexpr (TWO) {
+          v += fbv[i];                   // (already through the masks)
+        } else if (!first) {
           float fb = fbv[i];
           if (s0.drop_keep < 1.0f) {     // gradient through step t+1's input dropout of the attention feed
             const unsigned long long idx = ((unsigned long long)(t + 1) * B + b) * s0.feed_width + (s0.feed_width - M) + m;
@@ -3526,7 +3718,7 @@ __global__ __launch_bounds__(256) void dec_persist_bwd_kernel(las_dec_persist_bw
           const float dj = dct * gi * (1.f - gj * gj);
           const float df = dct * cp * gf * (1.f - gf);
           dcr[q] = dct * gf;
-          unsigned short* zp = s0.dz + (int64_t)b * s0.ldz + (int64_t)t * p.inc_dz + u;
+          unsigned short* zp = dzA + (int64_t)b * s0.ldz + (int64_t)t * p.inc_dz + u;
           zp[0] = las_f2bf(di); zp[Hd] = las_f2bf(dj); zp[2 * Hd] = las_f2bf(df); zp[3 * Hd] = las_f2bf(dov);
         }
       }
@@ -3534,6 +3726,14 @@ __global__ __launch_bounds__(256) void dec_persist_bwd_kernel(las_dec_persist_bw
     LAS_STAMPB(p.U - 1 - t, 8);
     if (!persist_barrier(flags, member, ++epoch, local, fail)) break;
     LAS_STAMPB(p.U - 1 - t, 9);
+    if constexpr (TWO) {
+      if (!w1) {
+        // ---- wiring 0: P1_t -> cell 0 (plain; polls its columns of P1_t) -> barrier -> P0_t below ----
+        product1(t, xtag);
+        if (active && part == 0) plain_cell(t, xtag, first);
+        if (!persist_barrier(flags, member, ++epoch, local, fail)) break;
+      }
+    }
     // ---- G: dfeed_t[group's utterances, my column tiles] = dz_t K^T ----
     {
       f32x4 acc[NT_MAX];
@@ -3612,7 +3812,8 @@ __global__ __launch_bounds__(256) void dec_persist_bwd_kernel(las_dec_persist_bw
   }
 #pragma unroll
   for (int q = 0; q < UPT; ++q)
-    if (cellw) s0.dc[(int64_t)b * Hd + tid + q * 256] = dcr[q];          // d(c) before the first step: the caller's d(initial state)
+    if (cellw) dcA[(int64_t)b * Hd + tid + q * 256] = dcr[q];            // d(c) before the first step: the caller's d(initial state)
+  if (TWO && cellw) dcP[(int64_t)b * Hd + tid] = dcp;
   if (WQ && att_additive(s0.attention)) {
     const int L8 = Hd / 8, P8 = 256 / L8, u = (tid % L8) * 8, phs = tid / L8;
     if (p.sum_workspace) {
@@ -3951,8 +4152,12 @@ extern "C" int las_decoder_persist_fwd(const las_dec_persist* p, void* stream) {
                               : las_decoder_persist_supported(s->Hd, s->M, p->K_in, s->attention, s->norm)),
               "las_decoder_persist_fwd: configuration not supported (Hd=%d M=%d K_in=%d attention=%d norm=%d)", s->Hd, s->M, p->K_in,
               s->attention, s->norm);
-  LAS_REQUIRE(!al_path || (p->sampling_prob <= 0.f && s->drop_keep >= 1.0f), "las_decoder_persist_fwd: attention layer / monotonic "
+  LAS_REQUIRE(!al_path || two || (p->sampling_prob <= 0.f && s->drop_keep >= 1.0f), "las_decoder_persist_fwd: attention layer / monotonic "
               "normalisers inside the launch: without scheduled sampling and input dropout");
+  LAS_REQUIRE(!two || s->drop_keep >= 1.0f || (p->win0 > 0 && p->win0 % 8 == 0 && p->win0 <= p->K_in && p->win1 > 0 && p->win1 % 8 == 0 && p->win1 <= p->K1_in),
+              "las_decoder_persist_fwd: second cell with input dropout: win0 / win1 (masked columns of the two operand rows, multiples of 8)");
+  LAS_REQUIRE(!two || p->sampling_prob <= 0.f || (p->wiring == 0 ? p->ldw >= s->M : (p->ldw >= s->Hd && s->Hd % 32 == 0)),
+              "las_decoder_persist_fwd: second cell with scheduled sampling: projection rows of the output width");
   LAS_REQUIRE(!p->walT || (p->att_out && p->ld_wal >= s->Hd + s->M && p->x_att_off >= 0 && p->x_att_off + p->A <= p->K_in && !s->ctx_out2),
               "las_decoder_persist_fwd: attention layer needs att_out, a W_al^T of Hd + M columns, a place in the operand row (and no "
               "context copy there)");
@@ -3985,7 +4190,10 @@ extern "C" int las_decoder_persist_fwd(const las_dec_persist* p, void* stream) {
     }                                                                                                                           \
     hipLaunchKernelGGL((dec_persist_fwd_kernel<__VA_ARGS__>), grid, dim3(256), lds_al, st, *p);                                 \
   } while (0)
-    if (two) {
+    if (two && p->sampling_prob > 0.f) {
+      if (res) LAS_AL_LAUNCH(true, true, 2, 12, 12, false, 10, true);
+      else LAS_AL_LAUNCH(true, false, 2, 12, 12, false, 10, true);
+    } else if (two) {
       if (res) LAS_AL_LAUNCH(false, true, 2, 12, 12, false, 10, true);
       else LAS_AL_LAUNCH(false, false, 2, 12, 12, false, 10, true);
     } else if (p->walT) {
@@ -4084,6 +4292,16 @@ extern "C" int las_decoder_persist_bwd_supported(int Hd, int M, int W, int atten
   return 1;
 }
 
+extern "C" int las_decoder_persist2_bwd_supported(int Hd, int M, int W, int W1, int attention, int wiring) {
+  // the one-launch backward with a second cell: decoder_units 128 / 256 (one unit per thread), softmax attentions
+  if (attention != LAS_ATT_LUONG && attention != LAS_ATT_BAHDANAU) return 0;
+  if (Hd != 128 && Hd != 256) return 0;
+  if (!las_decoder_persist_bwd_supported(Hd, M, W, attention, LAS_NORM_SOFTMAX)) return 0;
+  if (wiring == 0) return W1 == 2 * Hd ? 1 : 0;
+  if (wiring == 1) return (W1 == 2 * M + Hd && W1 / 16 <= 160) ? 1 : 0;
+  return 0;
+}
+
 extern "C" int las_decoder_persist_bwd(const las_dec_persist_bwd* p, void* stream) {
   const las_dec_step_bwd* s = &p->s;
   LAS_REQUIRE(s->B > 0 && p->U > 0, "las_decoder_persist_bwd: bad shape");
@@ -4091,7 +4309,15 @@ extern "C" int las_decoder_persist_bwd(const las_dec_persist_bwd* p, void* strea
   LAS_REQUIRE(las_decoder_persist_bwd_supported(s->Hd, s->M, p->W, s->attention, s->norm),
               "las_decoder_persist_bwd: configuration not supported (Hd=%d M=%d W=%d attention=%d norm=%d)", s->Hd, s->M, p->W,
               s->attention, s->norm);
-  LAS_REQUIRE(p->kc && p->dfeed_all && p->workspace && ((uintptr_t)p->workspace % 128 == 0) && s->dctx_a && s->dc && s->dz && s->ds_out &&
+  const bool two = p->k1c != nullptr;
+  LAS_REQUIRE(!two || (las_decoder_persist2_bwd_supported(s->Hd, s->M, p->W, p->W1, s->attention, p->wiring) && p->gates1 && p->c1 && p->dz1 &&
+                       p->dc1 && p->ldk1 >= 4 * s->Hd && p->ldk1 % 8 == 0 && (p->wiring == 0 ? s->dctx_a != nullptr : (p->d_out1 != nullptr && !s->dctx_a))),
+              "las_decoder_persist_bwd: second cell: unsupported configuration or missing buffers (Hd=%d M=%d W=%d W1=%d wiring=%d)", s->Hd, s->M,
+              p->W, p->W1, p->wiring);
+  LAS_REQUIRE(!two || s->drop_keep >= 1.0f || (p->win0 == s->M && p->win1 > 0 && p->win1 <= p->W1),
+              "las_decoder_persist_bwd: second cell with input dropout: win0 (= M) / win1");
+  LAS_REQUIRE(two || s->drop_keep >= 1.0f || s->feed_width >= s->M, "las_decoder_persist_bwd: feed_width");
+  LAS_REQUIRE(p->kc && p->dfeed_all && p->workspace && ((uintptr_t)p->workspace % 128 == 0) && (s->dctx_a || two) && s->dc && s->dz && s->ds_out &&
                   s->align && s->gates && s->c_new && s->c_prev && s->keys && s->values && s->mem_len,
               "las_decoder_persist_bwd: null argument");
   LAS_REQUIRE(s->attention == LAS_ATT_LUONG || (s->pq && s->wq_t), "las_decoder_persist_bwd: this attention needs pq and wq_t");
@@ -4103,12 +4329,12 @@ extern "C" int las_decoder_persist_bwd(const las_dec_persist_bwd* p, void* strea
   int rc = las_check_hip(hipMemsetAsync(reinterpret_cast<char*>(p->workspace) + 64, 0,
                                         las_decoder_persist_workspace_bytes(s->B, s->Tm, s->Hd, s->M) - 64, st), "memset workspace");
   if (rc) return rc;
-  size_t lds = persist_bwd_scratch_floats(s->M, s->Hd, s->Tm) * sizeof(float);
+  size_t lds = persist_bwd_scratch_floats(s->M, s->Hd, s->Tm, two) * sizeof(float);
   LAS_REQUIRE(lds <= 64 * 1024, "las_decoder_persist_bwd: shapes exceed the LDS budget");
   // the matrix-core passes need the frames in LDS and M = 512, 1024 or 2048; with Luong scores they keep the keys transposed
   const bool mshape = s->M == 512 || s->M == 1024 || (s->M == 2048 && s->Hd == 512);
-  const bool keys_t = s->attention == LAS_ATT_LUONG && mshape && persist_bwd_resident(s->M, s->Hd, s->Tm, true);
-  const bool res = persist_bwd_resident(s->M, s->Hd, s->Tm, keys_t);
+  const bool keys_t = s->attention == LAS_ATT_LUONG && mshape && persist_bwd_resident(s->M, s->Hd, s->Tm, true, two);
+  const bool res = persist_bwd_resident(s->M, s->Hd, s->Tm, keys_t, two);
   if (res) lds += persist_bwd_resident_bytes(s->M, s->Hd, s->Tm, keys_t);
   const int npq = (res && mshape && (keys_t || s->attention != LAS_ATT_LUONG)) ? s->M / 128 : 0;
   const dim3 grid(((groups + 7) & ~7) * P_MEMBERS);
@@ -4130,6 +4356,16 @@ extern "C" int las_decoder_persist_bwd(const las_dec_persist_bwd* p, void* strea
     } else {
       if (npq == 16) LAS_BWD_LAUNCH(false, 16, 5, 6, 16, 8, 2);
       else LAS_BWD_LAUNCH(false, 0, 5, 6, 16, 8, 2);
+    }
+  } else if (two) {              // second cell: the same passes, + its plain backward and its streamed product
+    if (wq) {
+      if (npq == 8) LAS_BWD_LAUNCH(true, 8, 3, 8, 8, 6, 1, true);
+      else if (npq == 4) LAS_BWD_LAUNCH(true, 4, 3, 8, 8, 6, 1, true);
+      else LAS_BWD_LAUNCH(true, 0, 3, 8, 8, 6, 1, true);
+    } else {
+      if (npq == 8) LAS_BWD_LAUNCH(false, 8, 3, 8, 8, 6, 1, true);
+      else if (npq == 4) LAS_BWD_LAUNCH(false, 4, 3, 8, 8, 6, 1, true);
+      else LAS_BWD_LAUNCH(false, 0, 3, 8, 8, 6, 1, true);
     }
   } else if (wq) {
     if (npq == 8) LAS_BWD_LAUNCH(true, 8);

@@ -46,6 +46,26 @@ __global__ void dropout_bf16_pair_kernel(const unsigned short* x, int64_t ldx, u
   }
 }
 
+// the input masks of U decoder steps in one pass, in place: element (b, t, c), c < cols, of rows x[b * ldb + t * ldt ..] is
+// draw (seed, stream0 + t, b * cols + c) -- U x las_dropout_bf16 with the streams stream0 + t (the one-launch decoders leave
+// the operand rows undropped; the weight-gradient products read them dropped)
+__global__ void dropout_bf16_steps_kernel(unsigned short* x, int64_t ldb, int64_t ldt, int B, int U, int cols, float keep,
+                                          unsigned seed, unsigned stream0) {
+  const float inv = 1.0f / keep;
+  const int c8 = cols / 8;
+  const int64_t total = (int64_t)B * U * c8;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % c8) * 8, t = (int)((i / c8) % U), b = (int)(i / ((int64_t)c8 * U));
+    unsigned short* row = x + (int64_t)b * ldb + (int64_t)t * ldt + c;
+    uint4 v = *reinterpret_cast<const uint4*>(row);
+    unsigned short* e = reinterpret_cast<unsigned short*>(&v);
+    const unsigned long long base = (unsigned long long)b * cols + c;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) e[j] = las_f2bf(las_bf2f(e[j]) * (las_uniform(seed, stream0 + (unsigned)t, base + j) < keep ? inv : 0.f));
+    *reinterpret_cast<uint4*>(row) = v;
+  }
+}
+
 // out = a * mask_a (+ b * mask_b): gradient through the input dropout of the fw (and bw) cell
 __global__ void dropout_bwd_kernel(const float* a, const float* b, float* out, int rows, int cols, float keep, unsigned seed,
                                    unsigned stream_a, unsigned stream_b) {
@@ -165,6 +185,17 @@ extern "C" int las_dropout_bf16_pair(const las_bf16* x, int64_t ldx, las_bf16* y
   hipLaunchKernelGGL(dropout_bf16_pair_kernel, dim3(blocks_for((int64_t)rows * (cols / 8))), dim3(256), 0, (hipStream_t)stream, x, ldx,
                      y0, y1, ldy, rows, cols, keep, seed, stream0, stream1);
   LAS_LAUNCH_CHECK("dropout pair launch");
+  return LAS_OK;
+}
+
+extern "C" int las_dropout_bf16_steps(las_bf16* x, int64_t ldb, int64_t ldt, int B, int U, int cols, float keep, uint32_t seed,
+                                      uint32_t stream0, void* stream) {
+  LAS_REQUIRE(x && B > 0 && U > 0 && cols > 0 && keep > 0.f && keep <= 1.f, "las_dropout_bf16_steps: bad arguments");
+  LAS_REQUIRE(cols % 8 == 0 && ldb % 8 == 0 && ldt % 8 == 0 && ((uintptr_t)x % 16 == 0),
+              "las_dropout_bf16_steps: columns and strides in multiples of 8, 16-byte aligned rows");
+  hipLaunchKernelGGL(dropout_bf16_steps_kernel, dim3(blocks_for((int64_t)B * U * (cols / 8))), dim3(256), 0, (hipStream_t)stream, x, ldb,
+                     ldt, B, U, cols, keep, seed, stream0);
+  LAS_LAUNCH_CHECK("dropout steps launch");
   return LAS_OK;
 }
 

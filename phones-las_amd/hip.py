@@ -85,6 +85,7 @@ _SIGS = {
     'las_normalize_pad_bf16': ([_vp, _vp, _vp, _vp, _i32, _vp, _i32, _i32, _i32, _vp, _vp], C.c_int),
     'las_dropout_bf16': ([_vp, _i64, _vp, _i64, _i32, _i32, _f32, C.c_uint32, C.c_uint32, _vp], C.c_int),
     'las_dropout_bf16_pair': ([_vp, _i64, _vp, _vp, _i64, _i32, _i32, _f32, C.c_uint32, C.c_uint32, C.c_uint32, _vp], C.c_int),
+    'las_dropout_bf16_steps': ([_vp, _i64, _i64, _i32, _i32, _i32, _f32, C.c_uint32, C.c_uint32, _vp], C.c_int),
     'las_dropout_bwd': ([_vp, _vp, _vp, _i32, _i32, _f32, C.c_uint32, C.c_uint32, C.c_uint32, _vp], C.c_int),
     'las_dropout_mask': ([_vp, _i64, _f32, C.c_uint32, C.c_uint32, _vp], C.c_int),
     'las_onehot_bf16': ([_vp, _i64, _i32, _i32, _i32, _vp, _i64, _f32, C.c_uint32, C.c_uint32, _i32, _vp], C.c_int),
@@ -109,6 +110,7 @@ _SIGS = {
     'las_decoder_persist_max_batch': ([], C.c_int),
     'las_decoder_persist_fwd': ([_vp, _vp], C.c_int),
     'las_decoder_persist_bwd_supported': ([C.c_int] * 5, C.c_int),
+    'las_decoder_persist2_bwd_supported': ([_i32, _i32, _i32, _i32, _i32, _i32], C.c_int),
     'las_decoder_persist_bwd': ([_vp, _vp], C.c_int),
     'las_beam_step': ([_vp, _i64, _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp], C.c_int),
     'las_log_probs_loss': ([_vp, _i64, C.c_int, C.c_int, _f32, _f32, _vp, _vp, _i64, _vp], C.c_int),
@@ -140,7 +142,7 @@ class DecStep(C.Structure):
                 ('mem_len', _vp), ('wq', _vp), ('att_v', _vp), ('align_out', _vp), ('align_bf16', _vp),
                 ('lda', _i64), ('pq_out', _vp), ('ldpq', _i64), ('ctx_out', _vp), ('ldc', _i64),
                 ('ctx_out2', _vp), ('ldc2', _i64), ('drop_keep', _f32), ('drop_seed', C.c_uint32),
-                ('drop_stream', C.c_uint32), ('step', _i32), ('feed_width', _i32), ('query', _vp), ('ldq', _i64),
+                ('drop_stream', C.c_uint32), ('step', _i32), ('feed_width', _i32), ('feed_plain', _i32), ('query', _vp), ('ldq', _i64),
                 ('norm', _i32), ('score_bias', _vp), ('prev_align', _vp), ('ldpa', _i64), ('p_out', _vp), ('ldp', _i64),
                 ('noise_scale', _f32), ('noise_seed', C.c_uint32), ('noise_stream', C.c_uint32)]
 
@@ -153,7 +155,8 @@ class DecPersist(C.Structure):
         ('sampling_prob', _f32), ('seed', C.c_uint32), ('teacher', _vp), ('teacher_stride', _i64), ('wprojT', _vp), ('ldw', _i64),
         ('bproj', _vp), ('logits', _vp), ('ld_logits', _i64), ('plog', _vp), ('V', _i32), ('Vp', _i32),
         ('walT', _vp), ('ld_wal', _i64), ('A', _i32), ('x_att_off', _i32), ('att_out', _vp), ('ld_att', _i64), ('inc_p', _i64),
-        ('k1T', _vp), ('ldk1', _i64), ('K1_in', _i32), ('wiring', _i32), ('bias1', _vp), ('c1', _vp), ('gates1', _vp), ('h1', _vp)]
+        ('k1T', _vp), ('ldk1', _i64), ('K1_in', _i32), ('wiring', _i32), ('bias1', _vp), ('c1', _vp), ('gates1', _vp), ('h1', _vp),
+        ('win0', _i32), ('win1', _i32), ('in_stream0', C.c_uint32), ('in_stream1', C.c_uint32)]
 
 
 class DecStepBwd(C.Structure):
@@ -183,7 +186,10 @@ class DecPersistBwd(C.Structure):
     """struct las_dec_persist_bwd (include/las_hip.h)."""
     _fields_ = [('s', DecStepBwd), ('U', _i32), ('W', _i32)] + [(n, _i64) for n in (
         'inc_a', 'inc_save', 'inc_gates', 'inc_c', 'inc_align', 'inc_dz', 'inc_ds', 'inc_pq')] + [
-        ('kc', _vp), ('ldk', _i64), ('dfeed_all', _vp), ('sum_workspace', _vp), ('dhp_all', _vp), ('workspace', _vp)]
+        ('kc', _vp), ('ldk', _i64), ('dfeed_all', _vp), ('sum_workspace', _vp), ('dhp_all', _vp), ('workspace', _vp),
+        ('k1c', _vp), ('ldk1', _i64), ('W1', _i32), ('wiring', _i32), ('gates1', _vp), ('c1', _vp), ('dz1', _vp), ('dc1', _vp),
+        ('dfeed1_all', _vp), ('d_out1', _vp), ('ld_dout1', _i64), ('inc_dout1', _i64), ('win0', _i32), ('win1', _i32),
+        ('in_stream0', C.c_uint32), ('in_stream1', C.c_uint32)]
 
 
 ATT_LUONG, ATT_BAHDANAU, ATT_CUSTOM, ATT_LUONG_MONOTONIC, ATT_BAHDANAU_MONOTONIC = 0, 1, 2, 3, 4

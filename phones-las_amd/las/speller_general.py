@@ -497,13 +497,14 @@ class GeneralSpeller:
 
     def _persist2_ok(self, B, Tm, keep, sampling, input_vectors):
         """Two decoder cells (the reference's default depth) in ONE forward launch (round 4): both wirings, softmax attentions,
-        one-hot tokens, no attention layer, teacher forcing without dropout / sampling.  LAS_DEC_PERSIST2=0: step by step."""
+        one-hot tokens, no attention layer; input dropout and scheduled sampling (the reference's defaults: dropout 0.2,
+        sampling_probability 0.1) inside the launch.  LAS_DEC_PERSIST2=0: step by step."""
         import os
         if os.environ.get('LAS_DEC_PERSIST', '1') == '0' or os.environ.get('LAS_DEC_PERSIST2', '1') == '0':
             return False
         if self.NL != 2 or self.tokx or self.emb or self.sigmoid or self.has_al or self.mono or self.custom:
             return False
-        if keep < 1.0 or sampling > 0.0 or input_vectors is not None:
+        if input_vectors is not None or self.Vop > 1024 or (keep < 1.0 and (self.win[0] % 8 or self.win[1] % 8)):
             return False
         lib = hip.lib()
         Kp = (self.win[0] + self.Hd + 63) // 64 * 64
@@ -526,6 +527,9 @@ class GeneralSpeller:
             self._kTp = torch.zeros(4 * Hd, Kp, dtype=bf, device=dev)
         self._kTp[:, :W0].copy_(self.kT[0])                    # (the image follows the weights: refreshed every step anyway)
         fed = targets_inputs[:, :U].to(torch.int32).contiguous()
+        keep, sampling = (sv['keep'], float(self.hp.sampling_probability or 0.0)) if two else (1.0, 0.0)
+        if sampling > 0.0 and fed.data_ptr() == targets_inputs.data_ptr():
+            fed = fed.clone()                                  # the launch writes the sampled tokens into the fed ids
         sv['fed'] = fed
         p = hip.DecPersist()
         s = p.s
@@ -548,11 +552,20 @@ class GeneralSpeller:
         if not self.has_al:                                    # the context is the feed: straight into the next operand row
             s.ctx_out2, s.ldc2 = (hip.addr(Xp, Kp) if U > 1 else 0), U * Kp
         s.drop_keep, s.feed_width = 1.0, self.E + A
+        if keep < 1.0:                                         # the token row's scale: cell 0's draws of the step-by-step path
+            s.drop_keep, s.drop_seed, s.drop_stream = keep, sv['seed'], self.DEC_STREAM
+            p.win0, p.win1, p.in_stream0, p.in_stream1 = self.win[0], self.win[1], self.in_stream(0, 0), self.in_stream(1, 0)
         s.norm = sv['norm']
         if self.mono:
             s.score_bias = hip.addr(self.score_bias)
             s.p_out, s.ldp = hip.addr(sv['p']), U * Tmp
             s.noise_scale, s.noise_seed, s.noise_stream = sv.get('noise_scale', 0.0), sv.get('seed', 0), self.NOISE_STREAM
+        if sampling > 0.0:                                     # the sampled feed is produced inside the launch
+            plog = torch.empty(U, B, 4, Vp, dtype=f32, device=dev)
+            p.sampling_prob, p.seed = sampling, sv['seed']
+            p.teacher, p.teacher_stride = hip.addr(targets_inputs), targets_inputs.stride(0)
+            p.wprojT, p.ldw, p.bproj = hip.addr(self.wprojT), self.P, hip.addr(self.bproj)
+            p.logits, p.ld_logits, p.plog, p.V, p.Vp = 0, U * Vp, hip.addr(plog), self.V, Vp
         p.U, p.K_in = U, Kp
         if self.uses_wq and self.wq_pkT is not None and Hd in (128, 256) and os.environ.get('LAS_DEC_PQ_MFMA', '1') != '0':
             p.wq_packed = hip.addr(self.wq_pkT)
@@ -589,6 +602,11 @@ class GeneralSpeller:
                 sv['X'][1] = torch.cat([sv['ctx'], Xp[:, :, :M], h1[:, :U]], -1)
             else:               # [h0_t | h1_{t-1}]
                 sv['X'][1] = torch.cat([sv['h'][0], h1[:, :U]], -1)
+            if keep < 1.0:      # the weight-gradient products read the rows as the cells saw them: dropped
+                for l in range(2):
+                    Kl = self.win[l] + Hd
+                    hip.check(lib.las_dropout_bf16_steps(hip.addr(sv['X'][l]), U * Kl, Kl, B, U, self.win[l], keep, sv['seed'],
+                                                         self.in_stream(l, 0), st))
         if self.has_al:
             sv['qc'][:, :, :Hd].copy_(sv['h'][0])
             sv['qc'][:, :, Hd:].copy_(sv['ctx'])
@@ -610,6 +628,23 @@ class GeneralSpeller:
             return False
         return hip.lib().las_decoder_seq_bwd_supported(self.Hd, self.M, self.A if self.has_al else 0, self.win[0] + self.Hd, sv['Tm'],
                                                        self.att, sv['norm']) == 1
+
+    def _persist2_bwd_ok(self, sv):
+        """Two decoder cells: all U backward steps in ONE las_decoder_persist_bwd launch (round 4) where the forward's one-launch
+        kernel applies.  LAS_DEC_PERSIST2_BWD=0: step by step."""
+        import os
+        if os.environ.get('LAS_DEC_PERSIST', '1') == '0' or os.environ.get('LAS_DEC_PERSIST2', '1') == '0':
+            return False
+        if os.environ.get('LAS_DEC_PERSIST2_BWD', '1') == '0' or self.debug_hook is not None or sv.get('dreg') is not None:
+            return False
+        if self.NL != 2 or self.tokx or self.emb or self.sigmoid or self.has_al or self.mono or self.custom:
+            return False
+        if sv['keep'] < 1.0 and (self.win[0] != self.M or self.win[1] % 8):
+            return False
+        lib = hip.lib()
+        return (sv['B'] <= 4 * lib.las_decoder_persist_max_batch() and
+                lib.las_decoder_persist2_bwd_supported(self.Hd, self.M, self.win[0] + self.Hd, self.win[1] + self.Hd, self.att,
+                                                       1 if self.bottom else 0) == 1)
 
     def log_probs_loss(self, loss, weight, grad_scale):
         """loss += weight * compute_log_probs_loss(raw outputs) (model_helper.py:132-146,327-331) on the attention vectors
@@ -728,7 +763,51 @@ class GeneralSpeller:
             hip.check(lib.las_decoder_seq_bwd(C.byref(q), st))
             hip.prof_end(tok)
             dx[0][0] = dfeed0                          # step 0's d[feed | h]: the gradient into the initial state
-        for t in (range(U - 1, -1, -1) if not seq else ()):
+        two = (not seq) and self._persist2_bwd_ok(sv)
+        if two:
+            # both cells, all U steps in ONE launch (las_dec_persist_bwd with a second cell): what the loop below does step by step
+            q = hip.DecPersistBwd()
+            s = q.s
+            s.B, s.Hd, s.M, s.Tm, s.attention, s.mode = B, Hd, M, Tm, self.att, 0
+            if not self.bottom:                        # the context is the output
+                s.dctx_a, s.ldda = hip.addr(d_out), U * P
+            else:                                      # h1_t is
+                q.d_out1, q.ld_dout1, q.inc_dout1 = hip.addr(d_out), U * P, P
+            s.dctx_save, s.ldds = hip.addr(dctx_all), U * M
+            s.dc = hip.addr(dc[0])
+            s.gates, s.ldg = hip.addr(sv['gates'][0]), U * 4 * Hd
+            s.c_new, s.ldcn = hip.addr(sv['cs'][0], Hd), (U + 1) * Hd
+            s.c_prev, s.ldcp = hip.addr(sv['cs'][0]), (U + 1) * Hd
+            s.align, s.lda = hip.addr(sv['align']), U * Tmp
+            s.keys, s.values, s.mem_len = hip.addr(sv['keys']), hip.addr(sv['memory']), hip.addr(sv['mem_len'])
+            s.dz, s.ldz = hip.addr(dz[0]), U * 4 * Hd
+            s.ds_out, s.ldso = hip.addr(ds_all), U * Tmp
+            s.drop_keep, s.feed_width = 1.0, self.E + A
+            if sv['keep'] < 1.0:
+                s.drop_keep, s.drop_seed, s.drop_stream = sv['keep'], sv['seed'], self.DEC_STREAM
+                q.win0, q.win1, q.in_stream0, q.in_stream1 = self.win[0], self.win[1], self.in_stream(0, 0), self.in_stream(1, 0)
+            if bah:
+                s.pq, s.ldpq = hip.addr(sv['pq']), U * Hd
+                s.wq_t, s.att_v = hip.addr(self.wq_t), hip.addr(self.att_v)
+                s.dkeys_acc, s.dv_acc = hip.addr(dkeys), hip.addr(grads[self.V_ATT])
+                s.dpq_out, s.lddpq = hip.addr(dpq_all), U * Hd
+                q.sum_workspace = hip.addr(self._persist_workspace('sum', lib.las_decoder_sum_workspace_bytes(32 * (((B + 7) // 8 + 7) // 8 * 8), Hd)))
+            q.U, q.W = U, W[0]
+            q.inc_a, q.inc_save, q.inc_gates, q.inc_c, q.inc_align, q.inc_dz, q.inc_ds, q.inc_pq = P, M, 4 * Hd, Hd, Tmp, 4 * Hd, Tmp, Hd
+            q.kc, q.ldk = hip.addr(self.kn[0]), 4 * Hd
+            dfeed0 = torch.empty(B, W[0], dtype=f32, device=dev)
+            dfeed1 = torch.empty(B, W[1], dtype=f32, device=dev)
+            ws = self._persist_workspace('bwd', lib.las_decoder_persist_workspace_bytes(B, Tm, Hd, M))
+            q.dfeed_all, q.workspace = hip.addr(dfeed0), hip.addr(ws)
+            q.k1c, q.ldk1, q.W1, q.wiring = hip.addr(self.kn[1]), 4 * Hd, W[1], 1 if self.bottom else 0
+            q.gates1, q.c1, q.dz1, q.dc1 = hip.addr(sv['gates'][1]), hip.addr(sv['cs'][1]), hip.addr(dz[1]), hip.addr(dc[1])
+            q.dfeed1_all = hip.addr(dfeed1)
+            tok = hip.prof_begin('dec_persist_bwd', 2.0 * U * B * ((W[0] + W[1]) * 4 * Hd + Tm * Hd + Tm * M))
+            hip.check(lib.las_decoder_persist_bwd(C.byref(q), st))
+            hip.prof_end(tok)
+            self._persist_ws_bwd = ws
+            dx[0][0], dx[1][0] = dfeed0, dfeed1       # step 0's products: the gradients into the initial states (their h columns)
+        for t in (range(U - 1, -1, -1) if not (seq or two) else ()):
             cur, nxt = t & 1, (t + 1) & 1
             has_next = t + 1 < U
 

@@ -76,3 +76,31 @@ def test_slice_height_policy_and_workspace_sizes(monkeypatch):
     assert w >= 64 + 2 * 32 * 4 * 4 * 4 * 256 * 8            # backward, 4-row slices: 32 groups x 4 x 4 pairs x NUB*256 granules x 2 slots
     # one workgroup per chain: nothing to exchange, but the chain's progress granules for its prefetch companion live there
     assert 64 < l.las_lstm_workspace_bytes(64, 128, 2) <= 64 + 4 * 1024 * 1024
+
+
+def test_ctypes_structures_have_the_layout_of_the_header(tmp_path):
+    """Every struct the C-ABI takes by pointer: size and the offset of each field of the ctypes mirror against the header as gcc
+    lays it out (a field added on one side only would silently shift everything behind it)."""
+    import subprocess
+    from phones_las_amd import hip
+    pairs = {'las_lstm_fwd': hip.LstmFwd, 'las_dec_step': hip.DecStep, 'las_dec_persist': hip.DecPersist,
+             'las_dec_step_bwd': hip.DecStepBwd, 'las_dec_persist_bwd': hip.DecPersistBwd, 'las_dec_seq_bwd': hip.DecSeqBwd,
+             'las_image_job': hip.ImageJob, 'las_fill_job': hip.FillJob}
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "las_hip.h"', 'int main(void) {']
+    for cname, cls in pairs.items():
+        lines.append('  printf("%s . %%zu\\n", sizeof(%s));' % (cname, cname))
+        for fname, _ in cls._fields_:
+            lines.append('  printf("%s %s %%zu\\n", offsetof(%s, %s));' % (cname, fname, cname, fname))
+    lines += ['  return 0;', '}']
+    src = tmp_path / 'layout.c'
+    src.write_text('\n'.join(lines))
+    exe = tmp_path / 'layout'
+    subprocess.run(['gcc', '-I', os.path.join(ROOT, 'include'), str(src), '-o', str(exe)], check=True)
+    got = {}
+    for line in subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.splitlines():
+        c, f, v = line.split()
+        got[(c, f)] = int(v)
+    for cname, cls in pairs.items():
+        assert got[(cname, '.')] == ctypes.sizeof(cls), cname
+        for fname, _ in cls._fields_:
+            assert got[(cname, fname)] == getattr(cls, fname).offset, (cname, fname)

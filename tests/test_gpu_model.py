@@ -1000,12 +1000,12 @@ def test_fused_projection_loss_launch_matches_the_separate_launches(V, H, B, tgt
     dict(att='bahdanau', dec_layers=2, bottom_only=True, pass_hidden=True, H=256),
 ], ids=['stack2_luong128', 'multicell2_luong128', 'stack2_bahdanau256', 'multicell2_bahdanau256'])
 @pytest.mark.parametrize('B', [3, 19])
-def test_two_cell_decoder_forward_in_one_launch(kw, B, monkeypatch):
-    """Round 4 (first half): decoder_layers = 2 -- the reference's DEFAULT depth (train.py:44) -- in ONE forward
-    launch, in both wirings (MultiRNNCell inside the AttentionWrapper, las/model.py:194-200; AttentionMultiCell with the old
-    attention fed to the upper cell, las/model.py:36-69).  Against the oracle (logits, loss, every gradient: the backward still
-    runs step by step on what the launch leaves behind) and against the step-by-step forward (LAS_DEC_PERSIST2=0); B = 19:
-    three groups of utterances, the last one partial."""
+def test_two_cell_decoder_in_one_launch_each_way(kw, B, monkeypatch):
+    """Round 4: decoder_layers = 2 -- the reference's DEFAULT depth (train.py:44) -- in ONE forward and ONE
+    backward launch, in both wirings (MultiRNNCell inside the AttentionWrapper, las/model.py:194-200; AttentionMultiCell with
+    the old attention fed to the upper cell, las/model.py:36-69).  Against the oracle (logits, loss, every gradient) and against
+    the step-by-step launches (LAS_DEC_PERSIST2=0), and the one-launch forward under the step-by-step backward
+    (LAS_DEC_PERSIST2_BWD=0); B = 19: three groups of utterances, the last one partial."""
     O, ohp, op, model = _models(L=2, F=13, **kw)
     from phones_las_amd.las.speller_general import GeneralSpeller
     assert isinstance(model.speller, GeneralSpeller)
@@ -1015,19 +1015,23 @@ def test_two_cell_decoder_forward_in_one_launch(kw, B, monkeypatch):
     feats, labels = to_device(batch)
     out = O.train_step(ohp, op, None, None, 1, batch, mxu='bf16')
     res = {}
-    for flag in ('1', '0'):
-        monkeypatch.setenv('LAS_DEC_PERSIST2', flag)
+    for flag in ('1', '0', 'fwd'):
+        monkeypatch.setenv('LAS_DEC_PERSIST2', '0' if flag == '0' else '1')
+        monkeypatch.setenv('LAS_DEC_PERSIST2_BWD', '0' if flag == 'fwd' else '1')
         model.vars.grad.zero_()
         loss, logits, dlogits = model.forward_train(feats, labels)
-        one_launch = getattr(model.speller, '_persist_ws', None) is not None and flag == '1'
+        one_launch = getattr(model.speller, '_persist_ws', None) is not None
         model.backward(dlogits)
         torch.cuda.synchronize()
-        res[flag] = (float(loss), logits.clone(), {n: g.clone() for n, g in model.vars.grads.items()}, one_launch)
-        model.speller._persist_ws = None
+        one_launch_bwd = getattr(model.speller, '_persist_ws_bwd', None) is not None
+        res[flag] = (float(loss), logits.clone(), {n: g.clone() for n, g in model.vars.grads.items()}, (one_launch, one_launch_bwd))
+        model.speller._persist_ws = model.speller._persist_ws_bwd = None
     model.check_device_status()
-    assert res['1'][3] and not res['0'][3]
+    assert res['1'][3] == (True, True) and res['0'][3] == (False, False) and res['fwd'][3] == (True, False)
+    for name in res['1'][2]:                     # the two backward paths on the same saved forward: bf16-flip noise only
+        assert relerr(res['1'][2][name], res['fwd'][2][name].cpu()) < 4e-3, name
     V = ohp.decoder.target_vocab_size
-    for flag in ('1', '0'):
+    for flag in ('1', '0', 'fwd'):
         loss, logits, grads, _ = res[flag]
         for b, n in enumerate(tgt_len):
             assert relerr(logits[b, :n, :V], out['aux']['logits'][b, :n]) < 2e-2, (flag, b)

@@ -117,12 +117,15 @@ def test_sampled_tokens_follow_the_logits():
     assert abs(kept - (0.75 + 0.25 * 0.0695)) < 0.04
 
 
+@pytest.mark.parametrize('H', [64, 128], ids=['steps', 'one_launch'])
 @pytest.mark.parametrize('bottom', [False, True], ids=['stack2', 'multicell2'])
-def test_general_decoder_dropout_and_sampling_replayed(bottom):
-    # the reference's default decoder shape (2 layers) with its default stochastic training pieces switched on
+def test_general_decoder_dropout_and_sampling_replayed(bottom, H):
+    # the reference's default decoder shape (2 layers) with its default stochastic training pieces switched on; at 128 units
+    # (the reference's default width) both cells, the input masks and the sampling run inside the one-launch kernels
     keep = 0.75
-    O, ohp, op, model = _build(dropout=1 - keep, sampling=0.4, dec_layers=2, bottom_only=bottom, pass_hidden=bottom)
+    O, ohp, op, model = _build(dropout=1 - keep, sampling=0.4, dec_layers=2, bottom_only=bottom, pass_hidden=bottom, H=H)
     sp = model.speller
+    assert sp._persist2_ok(3, 3, keep, 0.4, None) == (H == 128)
     batch = make_batch(src_len=[12, 7, 10], tgt_len=[6, 4, 5])
     feats, labels = to_device(batch)
     model.vars.grad.zero_()
@@ -131,7 +134,7 @@ def test_general_decoder_dropout_and_sampling_replayed(bottom):
     model.backward(dlogits)
     torch.cuda.synchronize()
     seed = model.last_seed
-    B, T, F, H, V, M, U = 3, 12, 13, 64, 11, 256, 6
+    B, T, F, V, U = 3, 12, 13, 11, 6
     enc_masks = []
     for l, (Tl, Dp, D) in enumerate([(12, 16, F), (12, 2 * H, 2 * H)]):
         enc_masks.append(tuple(_mask(B * Tl * Dp, keep, seed, 16 + 2 * l + d).reshape(B, Tl, Dp)[..., :D] for d in range(2)))
@@ -269,6 +272,36 @@ def test_sampling_inside_the_written_out_decoder_over_several_groups(att, H, mon
     assert relerr(res['1'][1], res['0'][1].cpu()) < 1e-3
     for name in res['1'][2]:
         assert relerr(res['1'][2][name], res['0'][2][name].cpu()) < 4e-3, name
+
+
+@pytest.mark.parametrize('bottom', [False, True], ids=['stack2', 'multicell2'])
+def test_two_cell_one_launch_decoder_draws_what_the_step_by_step_path_draws(bottom, monkeypatch):
+    """decoder_layers = 2 at the reference's default width (128 units) with input dropout and scheduled sampling, 19 ragged
+    utterances (three groups of eight): the one-launch kernels (LAS_DEC_PERSIST2, default) against the step-by-step launches --
+    same generator streams, so the same sampled feed; logits and gradients to bf16-flip noise."""
+    O, ohp, op, model = _build(dropout=0.25, sampling=0.3, dec_layers=2, bottom_only=bottom, pass_hidden=bottom, H=128)
+    sp = model.speller
+    B = 19
+    src_len = [12 - (i * 5) % 9 for i in range(B)]
+    tgt_len = [6 - (i * 3) % 5 for i in range(B)]
+    batch = make_batch(B=B, src_len=src_len, tgt_len=tgt_len)
+    feats, labels = to_device(batch)
+    res = {}
+    for flag in ('1', '0'):
+        monkeypatch.setenv('LAS_DEC_PERSIST2', flag)
+        model.vars.grad.zero_()
+        loss, logits, dlogits = model.forward_train(feats, labels)
+        fed = sp.saved['fed'].cpu().long().clone()
+        model.backward(dlogits)
+        torch.cuda.synchronize()
+        res[flag] = (fed, logits.clone(), {n: g.clone() for n, g in model.vars.grads.items()})
+    assert int(sp._persist_ws[:4].view(torch.int32).item()) == 0
+    assert torch.equal(res['1'][0], res['0'][0])
+    changed = res['1'][0][:, 1:6] != batch['targets_inputs'][:, 1:6]
+    assert int(changed.sum()) >= 5 and int(changed.any(1).sum()) >= 4          # several utterances, in several groups
+    assert relerr(res['1'][1], res['0'][1].cpu()) < 2e-3
+    for name in res['1'][2]:
+        assert relerr(res['1'][2][name], res['0'][2][name].cpu()) < 6e-3, name
 
 
 def test_checkpoint_resume_reproduces_the_stochastic_stream(tmp_path):
