@@ -355,7 +355,8 @@ typedef struct las_dec_step {
   float drop_keep;
   uint32_t drop_seed, drop_stream;
   int32_t step, feed_width;
-  int32_t feed_plain;            /* != 0: ctx_out2 is written unmasked also under drop_keep < 1 (the reader applies the mask) */
+  int32_t feed_plain;            /* ctx_out2 under drop_keep < 1: 0 = masked with the draws above; 1 = written unmasked; 2 = masked with
+                                  * draw (drop_seed, feed_stream0 + step + 1, b * M + column): one generator stream per step */
   const las_bf16* query;         /* LAS_DEC_ATTENTION_ONLY: the query [B,Hd] bf16, row stride ldq */
   int64_t ldq;
   /* monotonic attention (enum las_att_norm != 0); all NULL/0 otherwise */
@@ -367,6 +368,7 @@ typedef struct las_dec_step {
   int64_t ldp;
   float noise_scale;             /* sigmoid_noise: score += noise_scale * N(0,1), draw (step*B + b)*Tm + t; 0 = none */
   uint32_t noise_seed, noise_stream;
+  uint32_t feed_stream0;         /* feed_plain 2 */
 } las_dec_step;
 int las_decoder_step_fwd(const las_dec_step* s, int parts, void* stream);
 
@@ -424,9 +426,10 @@ typedef struct las_dec_persist {
   int64_t inc_p;
   /* Second decoder cell (decoder_layers = 2, the reference's default depth; round 4), k1T != NULL; softmax attentions, no
    * attention layer; las_decoder_persist2_supported.  Input dropout (s.drop_keep < 1, the reference's default 0.8): the token row's
-   * scale as in `s`; the masks of the two cells' input rows are applied where the launch reads them -- element (b, c), c < win_l,
-   * of cell l at step t is draw (s.drop_seed, in_stream_l + t, b * win_l + c), the streams of U x las_dropout_bf16 on the
-   * step-by-step path -- and the rows in memory (x, h1, s.ctx_out, s.h_out) stay undropped.  Scheduled sampling as above, on
+   * scale as in `s`; element (b, c), c < win_l, of cell l's input row at step t is scaled by draw (s.drop_seed, in_stream_l + t,
+   * b * win_l + c) -- the streams of U x las_dropout_bf16 on the step-by-step path; win0 = M.  Cell 0's attention feed is
+   * written masked into its operand rows `x`; cell 1's row is masked where the launch reads its pieces (h1, s.ctx_out, s.h_out
+   * stay undropped).  Scheduled sampling as above, on
    * the output row of the wiring (the context, or h1_t).
    *   wiring 0  MultiRNNCell inside the AttentionWrapper (las/model.py:194-200): cell 1 reads [h0_t | h1_{t-1}] (K1_in = 2 Hd), the
    *             attention is queried with h1_t and its context is the output and the feed of cell 0;

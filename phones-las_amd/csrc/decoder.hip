@@ -243,11 +243,15 @@ __device__ unsigned long long las_stamps[2 * 256 * 16];        // forward launch
 
 // DropoutWrapper mask on 8 consecutive elements of a cell's input row (elements idx0 .. idx0 + 7 of generator stream `stream`):
 // exactly what las_dropout_bf16 writes, applied where a product role reads the operand row (two-cell one-launch decoders)
+__device__ __forceinline__ unsigned drop2(unsigned x, unsigned seed, unsigned stream, unsigned long long idx, float keep, float inv) {
+  const float lo = __uint_as_float(x << 16) * (las_uniform(seed, stream, idx) < keep ? inv : 0.f);
+  const float hi = __uint_as_float(x & 0xffff0000u) * (las_uniform(seed, stream, idx + 1) < keep ? inv : 0.f);
+  return (unsigned)las_f2bf(lo) | ((unsigned)las_f2bf(hi) << 16);
+}
 __device__ __forceinline__ uint4 drop8(uint4 v, unsigned seed, unsigned stream, unsigned long long idx0, float keep, float inv) {
-  unsigned short* e = reinterpret_cast<unsigned short*>(&v);
-#pragma unroll
-  for (int j = 0; j < 8; ++j) e[j] = las_f2bf(las_bf2f(e[j]) * (las_uniform(seed, stream, idx0 + j) < keep ? inv : 0.f));
-  return v;
+  // (register arithmetic only: through a pointer to its halves the vector -- and the array it came from -- went to scratch)
+  return make_uint4(drop2(v.x, seed, stream, idx0, keep, inv), drop2(v.y, seed, stream, idx0 + 2, keep, inv),
+                    drop2(v.z, seed, stream, idx0 + 4, keep, inv), drop2(v.w, seed, stream, idx0 + 6, keep, inv));
 }
 
 struct PersistHook {
@@ -695,9 +699,13 @@ __device__ __forceinline__ void dec_step_fwd_body(const las_dec_step& s, const i
       s.ctx_out[(int64_t)b * s.ldc + cb + j] = o;
       if (s.ctx_out2) {
         unsigned short o2 = o;
-        if (s.drop_keep < 1.0f && !s.feed_plain) {   // the copy that feeds step t+1's cell goes through that step's input dropout
-          const unsigned long long idx = ((unsigned long long)(s.step + 1) * s.B + b) * s.feed_width + (s.feed_width - M) + cb + j;
-          o2 = las_uniform(s.drop_seed, s.drop_stream, idx) < s.drop_keep ? las_f2bf(las_bf2f(o) / s.drop_keep) : (unsigned short)0;
+        if (s.drop_keep < 1.0f && s.feed_plain != 1) {   // the copy that feeds step t+1's cell goes through that step's input dropout
+          // (feed_plain 2: the step-by-step path's draws -- one generator stream per step, element index b * M + column)
+          const unsigned long long idx = s.feed_plain == 2 ? (unsigned long long)b * M + cb + j
+                                         : ((unsigned long long)(s.step + 1) * s.B + b) * s.feed_width + (s.feed_width - M) + cb + j;
+          const unsigned stream = s.feed_plain == 2 ? s.feed_stream0 + (unsigned)(s.step + 1) : s.drop_stream;
+          o2 = s.feed_plain == 2 ? (las_uniform(s.drop_seed, stream, idx) < s.drop_keep ? las_f2bf(las_bf2f(o) * (1.0f / s.drop_keep)) : (unsigned short)0)
+                                 : (las_uniform(s.drop_seed, stream, idx) < s.drop_keep ? las_f2bf(las_bf2f(o) / s.drop_keep) : (unsigned short)0);
         }
         s.ctx_out2[(int64_t)b * s.ldc2 + cb + j] = o2;
       }
@@ -972,9 +980,6 @@ __global__ __launch_bounds__(256) void dec_persist_fwd_kernel(las_dec_persist p)
         const int kc = wave + 4 * i;
         av[i] = make_uint4(0, 0, 0, 0);
         if (kc < KC && bg < B) av[i] = *reinterpret_cast<const uint4*>(arow + kc * 32);
-        if constexpr (TWO)       // input dropout of cell 0's attention feed (columns [0, win0)): the rows in memory stay undropped
-          if (s0.drop_keep < 1.0f && kc * 32 + 8 * lq < p.win0 && bg < B)
-            av[i] = drop8(av[i], s0.drop_seed, p.in_stream0 + (unsigned)t, (unsigned long long)bg * p.win0 + kc * 32 + 8 * lq, s0.drop_keep, 1.0f / s0.drop_keep);
       }
 #pragma unroll
       for (int i = 0; i < KRES; ++i)
@@ -998,9 +1003,6 @@ __global__ __launch_bounds__(256) void dec_persist_fwd_kernel(las_dec_persist p)
             const int kc = wave + 4 * (i0 + j), kcc = min(kc, KC - 1);
             a[j] = *reinterpret_cast<const uint4*>(arow + kcc * 32);
             if (kc >= KC || bg >= B) a[j] = make_uint4(0, 0, 0, 0);
-            if constexpr (TWO)
-              if (s0.drop_keep < 1.0f && kcc * 32 + 8 * lq < p.win0)
-                a[j] = drop8(a[j], s0.drop_seed, p.in_stream0 + (unsigned)t, (unsigned long long)min(bg, B - 1) * p.win0 + kcc * 32 + 8 * lq, s0.drop_keep, 1.0f / s0.drop_keep);
 #pragma unroll
             for (int nt = 0; nt < NTL_MAX; ++nt) w[j][nt] = *reinterpret_cast<const uint4*>(wrow[nt] + kcc * 32);
           }
@@ -1072,9 +1074,11 @@ __global__ __launch_bounds__(256) void dec_persist_fwd_kernel(las_dec_persist p)
       st1.gates_out = p.gates1 + (int64_t)t * 4 * Hd; st1.ldg = (int64_t)p.U * 4 * Hd;
       st1.h_out = p.h1 + (int64_t)(t + 1) * Hd;       st1.ldh = (int64_t)(p.U + 1) * Hd;
       st1.h_out2 = nullptr;
-      st1.drop_keep = 1.0f;                           // (no token rows; its input mask is applied where G1 reads the row)
-      las_dec_step stA = st;                          // (keeps drop_keep: the token row's scale; the feed copy stays plain)
-      stA.feed_plain = 1;
+      // input dropout: cell 0's token row is scaled in its cell (stA keeps drop_keep); its attention feed is written masked
+      // with step t+1's draws by whichever body writes ctx_out2 (feed_plain 2); cell 1's row is masked where G1 reads it
+      las_dec_step stA = st;
+      stA.feed_plain = st1.feed_plain = 2;
+      stA.feed_stream0 = st1.feed_stream0 = p.in_stream0;
       if (p.wiring == 0) {           // cell 0 alone now; the attention runs with cell 1
         stA.mode = LAS_DEC_CELL_ONLY;
         stA.ctx_out2 = nullptr;
@@ -1083,78 +1087,85 @@ __global__ __launch_bounds__(256) void dec_persist_fwd_kernel(las_dec_persist p)
         stA.mode = LAS_DEC_FUSED;
         st1.mode = LAS_DEC_CELL_ONLY;
         st1.ctx_out2 = nullptr;
+        st1.drop_keep = 1.0f;
       }
-      if (bs < B) {
-        PersistHook hook{xsc, xz, xtag, flags, member, &epoch, local, fail, p.wq_packed, lkeys, lvals,
-                         pre_ok, tok_pre, {tok4[0], tok4[1], tok4[2], tok4[3]}, {bias4[0], bias4[1], bias4[2], bias4[3]}, cprev_pre};
-        dec_step_fwd_body<RES>(stA, bs, part, 4, sm, &hook);
-      }
-      // every piece of G1's operand rows (h0_t, attention_t of all 8 utterances) is in memory behind this barrier
-      if (!persist_barrier(flags, member, ++epoch, local, fail)) break;
-      // ---- G1: z1_t[group's utterances, my columns] = [pieces] K1, all chunks streamed ----
-      pu64* const xz1b = xzb + 2 * (size_t)B * 4 * Hd;
-      {
-        f32x4 acc[NTL_MAX];
-#pragma unroll
-        for (int nt = 0; nt < NTL_MAX; ++nt) acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
-        const int64_t bgc = min(bg, B - 1);
-        const int KC1 = p.K1_in / 32, nH = Hd / 32, nM = M / 32;
-        // this lane's row of each piece (8 lq = its 16 bytes of a 32-deep chunk)
-        const unsigned short* r_h0 = s0.h_out + bgc * s0.ldh + (int64_t)t * p.inc_h + 8 * lq;                    // h0_t
-        const unsigned short* r_h1 = p.h1 + (bgc * (p.U + 1) + t) * Hd + 8 * lq;                                  // h1_{t-1}
-        const unsigned short* r_at = s0.ctx_out + bgc * s0.ldc + (int64_t)t * p.inc_ctx + 8 * lq;                // attention_t
-        const unsigned short* r_ap = p.x + bgc * p.ldx + (int64_t)t * p.inc_x + 8 * lq;                          // attention_{t-1}
-        auto piece = [&](int kc) -> const unsigned short* {
-          if (p.wiring == 0) return kc < nH ? r_h0 + kc * 32 : r_h1 + (kc - nH) * 32;
-          if (kc < nM) return r_at + kc * 32;
-          if (kc < 2 * nM) return r_ap + (kc - nM) * 32;
-          return r_h1 + (kc - 2 * nM) * 32;
-        };
-        const unsigned short* w1row[NTL_MAX];
-#pragma unroll
-        for (int nt = 0; nt < NTL_MAX; ++nt) w1row[nt] = p.k1T + (int64_t)(member * CPM + min(nt, NTL - 1) * 16 + l15) * p.ldk1 + 8 * lq;
-        constexpr int SB = 4;
-#pragma unroll 1
-        for (int i0 = 0; wave + 4 * i0 < KC1; i0 += SB) {
-          uint4 a[SB], w[SB][NTL_MAX];
-#pragma unroll
-          for (int j = 0; j < SB; ++j) {
-            const int kc = wave + 4 * (i0 + j), kcc = min(kc, KC1 - 1);
-            a[j] = *reinterpret_cast<const uint4*>(piece(kcc));
-            if (kc >= KC1 || bg >= B) a[j] = make_uint4(0, 0, 0, 0);
-            if (s0.drop_keep < 1.0f && kcc * 32 + 8 * lq < p.win1)       // input dropout of cell 1 (columns [0, win1) of its row)
-              a[j] = drop8(a[j], s0.drop_seed, p.in_stream1 + (unsigned)t, (unsigned long long)bgc * p.win1 + kcc * 32 + 8 * lq, s0.drop_keep, 1.0f / s0.drop_keep);
-#pragma unroll
-            for (int nt = 0; nt < NTL_MAX; ++nt) w[j][nt] = *reinterpret_cast<const uint4*>(w1row[nt] + kcc * 32);
+      // one instance of the step body for both cells (a loop, not two inlined copies: the second copy had pushed the kernel 150
+      // VGPRs over the register file, into scratch)
+      bool dead = false;
+#pragma nounroll
+      for (int cell = 0; cell < 2; ++cell) {
+        if (cell == 1) {
+          // every piece of G1's operand rows (h0_t, attention_t of all 8 utterances) is in memory behind this barrier
+          if (!persist_barrier(flags, member, ++epoch, local, fail)) { dead = true; break; }
+        // ---- G1: z1_t[group's utterances, my columns] = [pieces] K1, all chunks streamed ----
+        pu64* const xz1b = xzb + 2 * (size_t)B * 4 * Hd;
+        {
+          f32x4 acc[NTL_MAX];
+  #pragma unroll
+          for (int nt = 0; nt < NTL_MAX; ++nt) acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+          const int64_t bgc = min(bg, B - 1);
+          const int KC1 = p.K1_in / 32, nH = Hd / 32, nM = M / 32;
+          // this lane's row of each piece (8 lq = its 16 bytes of a 32-deep chunk)
+          const unsigned short* r_h0 = s0.h_out + bgc * s0.ldh + (int64_t)t * p.inc_h + 8 * lq;                    // h0_t
+          const unsigned short* r_h1 = p.h1 + (bgc * (p.U + 1) + t) * Hd + 8 * lq;                                  // h1_{t-1}
+          const unsigned short* r_at = s0.ctx_out + bgc * s0.ldc + (int64_t)t * p.inc_ctx + 8 * lq;                // attention_t
+          const unsigned short* r_ap = s0.ctx_out + bgc * s0.ldc + (int64_t)max(t - 1, 0) * p.inc_ctx + 8 * lq;    // attention_{t-1} (unmasked; zeros at t = 0)
+          auto piece = [&](int kc) -> const unsigned short* {
+            if (p.wiring == 0) return kc < nH ? r_h0 + kc * 32 : r_h1 + (kc - nH) * 32;
+            if (kc < nM) return r_at + kc * 32;
+            if (kc < 2 * nM) return r_ap + (kc - nM) * 32;
+            return r_h1 + (kc - 2 * nM) * 32;
+          };
+          const unsigned short* w1row[NTL_MAX];
+  #pragma unroll
+          for (int nt = 0; nt < NTL_MAX; ++nt) w1row[nt] = p.k1T + (int64_t)(member * CPM + min(nt, NTL - 1) * 16 + l15) * p.ldk1 + 8 * lq;
+          constexpr int SB = 4;
+  #pragma unroll 1
+          for (int i0 = 0; wave + 4 * i0 < KC1; i0 += SB) {
+            uint4 a[SB], w[SB][NTL_MAX];
+  #pragma unroll
+            for (int j = 0; j < SB; ++j) {
+              const int kc = wave + 4 * (i0 + j), kcc = min(kc, KC1 - 1);
+              a[j] = *reinterpret_cast<const uint4*>(piece(kcc));
+              if (kc >= KC1 || bg >= B || (t == 0 && p.wiring == 1 && kc >= nM && kc < 2 * nM)) a[j] = make_uint4(0, 0, 0, 0);
+              if (s0.drop_keep < 1.0f && kcc * 32 + 8 * lq < p.win1)       // input dropout of cell 1 (columns [0, win1) of its row)
+                a[j] = drop8(a[j], s0.drop_seed, p.in_stream1 + (unsigned)t, (unsigned long long)bgc * p.win1 + kcc * 32 + 8 * lq, s0.drop_keep, 1.0f / s0.drop_keep);
+  #pragma unroll
+              for (int nt = 0; nt < NTL_MAX; ++nt) w[j][nt] = *reinterpret_cast<const uint4*>(w1row[nt] + kcc * 32);
+            }
+  #pragma unroll
+            for (int j = 0; j < SB; ++j)
+  #pragma unroll
+              for (int nt = 0; nt < NTL_MAX; ++nt)
+                acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a[j]), __builtin_bit_cast(bf16x8, w[j][nt]), acc[nt], 0, 0, 0);
           }
-#pragma unroll
-          for (int j = 0; j < SB; ++j)
-#pragma unroll
-            for (int nt = 0; nt < NTL_MAX; ++nt)
-              acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a[j]), __builtin_bit_cast(bf16x8, w[j][nt]), acc[nt], 0, 0, 0);
+          __syncthreads();                         // (the S role above is done with the LDS scratch `red` lies behind)
+  #pragma unroll
+          for (int nt = 0; nt < NTL_MAX; ++nt)
+            if (nt < NTL)
+  #pragma unroll
+              for (int r = 0; r < 4; ++r) red[(wave * 16 + lq * 4 + r) * RS + nt * 16 + l15] = acc[nt][r];
+          __syncthreads();
+          for (int e = tid; e < 8 * CPM; e += 256) {
+            const int row = e / CPM, col = e % CPM;
+            const int b = group * 8 + row;
+            if (b < B)
+              pgranule_store(xz1b + ((size_t)(xtag & 1) * B + b) * 4 * Hd + member * CPM + col, xtag,
+                             red[(0 * 16 + row) * RS + col] + red[(1 * 16 + row) * RS + col] + red[(2 * 16 + row) * RS + col] + red[(3 * 16 + row) * RS + col],
+                             local);
+          }
         }
-        __syncthreads();                         // (the S role above is done with the LDS scratch `red` lies behind)
-#pragma unroll
-        for (int nt = 0; nt < NTL_MAX; ++nt)
-          if (nt < NTL)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) red[(wave * 16 + lq * 4 + r) * RS + nt * 16 + l15] = acc[nt][r];
-        __syncthreads();
-        for (int e = tid; e < 8 * CPM; e += 256) {
-          const int row = e / CPM, col = e % CPM;
-          const int b = group * 8 + row;
-          if (b < B)
-            pgranule_store(xz1b + ((size_t)(xtag & 1) * B + b) * 4 * Hd + member * CPM + col, xtag,
-                           red[(0 * 16 + row) * RS + col] + red[(1 * 16 + row) * RS + col] + red[(2 * 16 + row) * RS + col] + red[(3 * 16 + row) * RS + col],
-                           local);
+        }
+        if (bs < B) {
+          const bool c0 = cell == 0;
+          const las_dec_step& stc = c0 ? stA : st1;
+          pu64* const xzc = c0 ? xz : xzb + 2 * (size_t)B * 4 * Hd + ((size_t)(xtag & 1) * B + bs) * 4 * Hd;
+          PersistHook hookc{xsc, xzc, xtag, flags, member, &epoch, local, fail, p.wq_packed, lkeys, lvals,
+                            c0 && pre_ok, c0 ? tok_pre : 0, {tok4[0], tok4[1], tok4[2], tok4[3]}, {bias4[0], bias4[1], bias4[2], bias4[3]}, cprev_pre};
+          dec_step_fwd_body<RES>(stc, bs, part, 4, sm, &hookc);
         }
       }
-      if (bs < B) {
-        pu64* const xz1 = xz1b + ((size_t)(xtag & 1) * B + bs) * 4 * Hd;
-        PersistHook hook1{xsc, xz1, xtag, flags, member, &epoch, local, fail, p.wq_packed, lkeys, lvals,
-                          false, 0, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, 0.f};
-        dec_step_fwd_body<RES>(st1, bs, part, 4, sm, &hook1);
-      }
+      if (dead) break;
     }
     if constexpr (SAMPLING) {
       // ---- scheduled sampling (utils/training_helper.py:48-87): logits_t = context_t W_proj + b from the four parts'
@@ -4154,7 +4165,7 @@ extern "C" int las_decoder_persist_fwd(const las_dec_persist* p, void* stream) {
               s->attention, s->norm);
   LAS_REQUIRE(!al_path || two || (p->sampling_prob <= 0.f && s->drop_keep >= 1.0f), "las_decoder_persist_fwd: attention layer / monotonic "
               "normalisers inside the launch: without scheduled sampling and input dropout");
-  LAS_REQUIRE(!two || s->drop_keep >= 1.0f || (p->win0 > 0 && p->win0 % 8 == 0 && p->win0 <= p->K_in && p->win1 > 0 && p->win1 % 8 == 0 && p->win1 <= p->K1_in),
+  LAS_REQUIRE(!two || s->drop_keep >= 1.0f || (p->win0 == s->M && p->win1 > 0 && p->win1 % 8 == 0 && p->win1 <= p->K1_in),
               "las_decoder_persist_fwd: second cell with input dropout: win0 / win1 (masked columns of the two operand rows, multiples of 8)");
   LAS_REQUIRE(!two || p->sampling_prob <= 0.f || (p->wiring == 0 ? p->ldw >= s->M : (p->ldw >= s->Hd && s->Hd % 32 == 0)),
               "las_decoder_persist_fwd: second cell with scheduled sampling: projection rows of the output width");

@@ -144,7 +144,7 @@ class DecStep(C.Structure):
                 ('ctx_out2', _vp), ('ldc2', _i64), ('drop_keep', _f32), ('drop_seed', C.c_uint32),
                 ('drop_stream', C.c_uint32), ('step', _i32), ('feed_width', _i32), ('feed_plain', _i32), ('query', _vp), ('ldq', _i64),
                 ('norm', _i32), ('score_bias', _vp), ('prev_align', _vp), ('ldpa', _i64), ('p_out', _vp), ('ldp', _i64),
-                ('noise_scale', _f32), ('noise_seed', C.c_uint32), ('noise_stream', C.c_uint32)]
+                ('noise_scale', _f32), ('noise_seed', C.c_uint32), ('noise_stream', C.c_uint32), ('feed_stream0', C.c_uint32)]
 
 
 class DecPersist(C.Structure):

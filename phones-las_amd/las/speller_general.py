@@ -504,7 +504,7 @@ class GeneralSpeller:
             return False
         if self.NL != 2 or self.tokx or self.emb or self.sigmoid or self.has_al or self.mono or self.custom:
             return False
-        if input_vectors is not None or self.Vop > 1024 or (keep < 1.0 and (self.win[0] % 8 or self.win[1] % 8)):
+        if input_vectors is not None or self.Vop > 1024 or (keep < 1.0 and (self.win[0] != self.M or self.win[1] % 8)):
             return False
         lib = hip.lib()
         Kp = (self.win[0] + self.Hd + 63) // 64 * 64
@@ -598,15 +598,15 @@ class GeneralSpeller:
             # ... and the second cell's: its states in the step-by-step layout, its operand rows gathered from the pieces
             sv['cs'][1] = c1
             sv['h'][1] = h1[:, 1:].contiguous()
-            if self.bottom:     # [attention_t | attention_{t-1} | h1_{t-1}]
-                sv['X'][1] = torch.cat([sv['ctx'], Xp[:, :, :M], h1[:, :U]], -1)
+            if self.bottom:     # [attention_t | attention_{t-1} | h1_{t-1}] (the feed in Xp carries cell 0's mask: from the contexts)
+                prev = torch.cat([torch.zeros(B, 1, M, dtype=bf, device=dev), sv['ctx'][:, :U - 1]], 1)
+                sv['X'][1] = torch.cat([sv['ctx'], prev, h1[:, :U]], -1)
             else:               # [h0_t | h1_{t-1}]
                 sv['X'][1] = torch.cat([sv['h'][0], h1[:, :U]], -1)
-            if keep < 1.0:      # the weight-gradient products read the rows as the cells saw them: dropped
-                for l in range(2):
-                    Kl = self.win[l] + Hd
-                    hip.check(lib.las_dropout_bf16_steps(hip.addr(sv['X'][l]), U * Kl, Kl, B, U, self.win[l], keep, sv['seed'],
-                                                         self.in_stream(l, 0), st))
+            if keep < 1.0:      # the weight-gradient products read the rows as the cells saw them: dropped (cell 0's already are)
+                K1 = self.win[1] + Hd
+                hip.check(lib.las_dropout_bf16_steps(hip.addr(sv['X'][1]), U * K1, K1, B, U, self.win[1], keep, sv['seed'],
+                                                     self.in_stream(1, 0), st))
         if self.has_al:
             sv['qc'][:, :, :Hd].copy_(sv['h'][0])
             sv['qc'][:, :, Hd:].copy_(sv['ctx'])
