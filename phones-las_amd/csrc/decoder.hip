@@ -1096,7 +1096,9 @@ __global__ __launch_bounds__(256) void dec_persist_fwd_kernel(las_dec_persist p)
       for (int cell = 0; cell < 2; ++cell) {
         if (cell == 1) {
           // every piece of G1's operand rows (h0_t, attention_t of all 8 utterances) is in memory behind this barrier
+          LAS_STAMP(t, 13);
           if (!persist_barrier(flags, member, ++epoch, local, fail)) { dead = true; break; }
+          LAS_STAMP(t, 14);
         // ---- G1: z1_t[group's utterances, my columns] = [pieces] K1, all chunks streamed ----
         pu64* const xz1b = xzb + 2 * (size_t)B * 4 * Hd;
         {
@@ -1156,6 +1158,7 @@ __global__ __launch_bounds__(256) void dec_persist_fwd_kernel(las_dec_persist p)
           }
         }
         }
+        if (cell == 1) LAS_STAMP(t, 15);
         if (bs < B) {
           const bool c0 = cell == 0;
           const las_dec_step& stc = c0 ? stA : st1;
