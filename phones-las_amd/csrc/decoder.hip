@@ -266,12 +266,13 @@ struct PersistHook {
   // LDS copies of what this workgroup reads from the memory at every step (nullptr: read from global memory):
   const unsigned short* wq_pk;   // B-fragment image of the query layer's kernel transposed (nullable): pq = h Wq on MFMA
   const unsigned short* lkeys;   // keys of its score frames [fq][Hd], row 0 = frame part*fq
-  const unsigned short* lvals;   // its context columns of every frame [Tm][cols_per]
+  const unsigned short* lvals;   // its context columns of the frames [0, vres): [vres][cols_per]
   // operands of the cell that do not depend on this step's product, fetched while the product was running
   // (unit = threadIdx.x; Hd <= 256): token id, its row of the cell kernel, c_{t-1}; the bias once per launch
   bool pre;
   int tok;
   float tok4[4], bias4[4], cprev;
+  int vres = 1 << 30;  // value frames [0, vres) are in LDS (lvals), the rest is read from memory (partial residency: long memories)
 };
 __device__ bool persist_barrier(pu64* flags, int member, unsigned epoch, bool local, int* lds_fail);
 // Exchange discipline of the persistent decoder: every (utterance, step) row of an exchanged tensor occupies WHOLE
@@ -658,18 +659,19 @@ __device__ __forceinline__ void dec_step_fwd_body(const las_dec_step& s, const i
     if (col < c_end) {
       constexpr int VB = 16;                 // value loads in flight per thread (one round trip to Infinity Cache)
       // vrows + t * vstride: this thread's 8 columns of frame t (memory, or the workgroup's LDS copy of its columns)
-      auto context_pass = [&](auto vrows, int64_t vstride) {
+      // frames [ta, te) of the pass; vrows + t * vstride addresses frame t
+      auto context_pass = [&](auto vrows, int64_t vstride, int ta, int te) {
         // (no branches in the pass: frames past the utterance re-read its last frame with weight 0 -- guarded loads were 16
         //  branches per pass, each on a per-lane condition)
-        const int last = max(len - 1, 0);
-        for (int tb = phase; tb < len; tb += P * VB) {
+        const int last = max(te - 1, ta);
+        for (int tb = ta + phase; tb < te; tb += P * VB) {
           uint4 vv[VB];
           float pw[VB];
 #pragma unroll
           for (int i = 0; i < VB; ++i) {
             const int t = tb + i * P;
             vv[i] = ld16(vrows + (int64_t)min(t, last) * vstride);
-            pw[i] = t < len ? sc[min(t, last)] : 0.f;
+            pw[i] = t < te ? sc[min(t, last)] : 0.f;
           }
 #pragma unroll
           for (int i = 0; i < VB; ++i) {
@@ -682,8 +684,10 @@ __device__ __forceinline__ void dec_step_fwd_body(const las_dec_step& s, const i
           }
         }
       };
-      if constexpr (RES) context_pass((lds_cu16)ph->lvals + (col - c_begin), cols_per);
-      else context_pass(vals + col, M);
+      if constexpr (RES) {
+        context_pass((lds_cu16)ph->lvals + (col - c_begin), cols_per, 0, min(len, ph->vres));
+        if (ph->vres < len) context_pass(vals + col, M, ph->vres, len);      // long memories: the frames that did not fit the LDS
+      } else context_pass(vals + col, M, 0, len);
     }
     if (ph) LAS_STAMP(s.step, 8);
     __syncthreads();
@@ -769,6 +773,17 @@ __host__ __device__ inline size_t persist_fwd_resident_bytes(int M, int Hd, int 
 __host__ __device__ inline bool persist_fwd_resident(int M, int Hd, int Tm) {
   return persist_fwd_scratch_floats(Hd, Tm) * 4 + persist_fwd_resident_bytes(M, Hd, Tm) <= 158 * 1024;   // (2 KiB of margin below the CU's 160 KiB)
 }
+// Long memories (general kernel): the workgroup's key frames and the value frames [0, vres) of its columns in LDS, the rest of
+// the values streamed at every step.  Returns vres: Tm (everything fits), a multiple of 16 below it, or 0 (nothing resident).
+__host__ __device__ inline int persist_fwd_resident_frames(int M, int Hd, int Tm) {
+  if (persist_fwd_resident(M, Hd, Tm)) return Tm;
+  const long long room = 158 * 1024 - (long long)persist_fwd_scratch_floats(Hd, Tm) * 4 - (long long)((Tm + 3) / 4) * Hd * 2;
+  const long long fr = room / ((long long)persist_cols_per(M) * 2);
+  return fr >= 64 ? (int)(fr & ~15LL) : 0;
+}
+__host__ __device__ inline size_t persist_fwd_resident_bytes_partial(int M, int Hd, int Tm, int vres) {
+  return ((size_t)((Tm + 3) / 4) * Hd + (size_t)vres * persist_cols_per(M)) * 2;
+}
 // G role's partial tiles: [4 waves][8 utterances][16-column tiles per member * 16 + 1] (W / 16 tiles over 32 members: <= 3, or 5)
 __host__ __device__ inline size_t persist_bwd_red2_floats(int W) {
   const int nt = (W / 16 + 31) / 32;
@@ -805,6 +820,15 @@ __host__ __device__ inline size_t persist_bwd_resident_bytes(int M, int Hd, int 
 }
 __host__ __device__ inline bool persist_bwd_resident(int M, int Hd, int Tm, bool keys_t, bool two = false) {
   return persist_bwd_scratch_floats(M, Hd, Tm, two) * 4 + persist_bwd_resident_bytes(M, Hd, Tm, keys_t) <= 158 * 1024;
+}
+// Long memories: the workgroup's key frames [fq, Hd] (row-major) and the first `rows` of its value frames in LDS, the rest of the
+// values streamed at every step.  Returns fq (everything fits), a multiple of 8 below it, or 0 (nothing resident).
+__host__ __device__ inline int persist_bwd_resident_rows(int M, int Hd, int Tm, bool two) {
+  const int fq = (Tm + 3) / 4;
+  if (persist_bwd_resident(M, Hd, Tm, false, two)) return fq;
+  const long long room = 158 * 1024 - (long long)persist_bwd_scratch_floats(M, Hd, Tm, two) * 4 - (long long)fq * Hd * 2;
+  const long long rows = room / ((long long)(M + P_VPAD) * 2);
+  return rows >= 32 ? (int)(rows & ~7LL) : 0;
 }
 
 __device__ bool persist_barrier(pu64* flags, int member, unsigned epoch, bool local, int* lds_fail) {
@@ -924,6 +948,7 @@ __global__ __launch_bounds__(256) void dec_persist_fwd_kernel(las_dec_persist p)
   // what the S role reads from the encoder memory never changes over the U steps: keep it in LDS when it fits
   const unsigned short* lkeys = nullptr;
   const unsigned short* lvals = nullptr;
+  const int vres = RES ? persist_fwd_resident_frames(M, Hd, Tm) : 0;      // value frames in LDS (Tm unless the memory is long)
   if (RES && bs < B) {
     unsigned short* lk = reinterpret_cast<unsigned short*>(sm + persist_fwd_scratch_floats(Hd, Tm));
     const int fq = (Tm + 3) / 4, f0 = part * fq, f1 = min(Tm, f0 + fq);
@@ -935,7 +960,7 @@ __global__ __launch_bounds__(256) void dec_persist_fwd_kernel(las_dec_persist p)
       const int r = e / (Hd / 8), c = e % (Hd / 8);
       *reinterpret_cast<uint4*>(lk + (size_t)r * Hd + c * 8) = *reinterpret_cast<const uint4*>(gk + (int64_t)(f0 + r) * Hd + c * 8);
     }
-    for (int e = tid; e < Tm * (cn / 8); e += 256) {
+    for (int e = tid; e < vres * (cn / 8); e += 256) {
       const int r = e / (cn / 8), c = e % (cn / 8);
       *reinterpret_cast<uint4*>(lv + (size_t)r * cols_per + c * 8) = *reinterpret_cast<const uint4*>(gv + (int64_t)r * M + c0 + c * 8);
     }
@@ -1062,6 +1087,7 @@ __global__ __launch_bounds__(256) void dec_persist_fwd_kernel(las_dec_persist p)
       if (bs < B) {
         PersistHook hook{xsc, xz, xtag, flags, member, &epoch, local, fail, p.wq_packed, lkeys, lvals,
                          pre_ok, tok_pre, {tok4[0], tok4[1], tok4[2], tok4[3]}, {bias4[0], bias4[1], bias4[2], bias4[3]}, cprev_pre};
+        hook.vres = vres;
         dec_step_fwd_body<RES>(st, bs, part, 4, sm, &hook);     // (a timed-out poll leaves through the barrier below)
       }
     } else {
@@ -1165,6 +1191,7 @@ __global__ __launch_bounds__(256) void dec_persist_fwd_kernel(las_dec_persist p)
           pu64* const xzc = c0 ? xz : xzb + 2 * (size_t)B * 4 * Hd + ((size_t)(xtag & 1) * B + bs) * 4 * Hd;
           PersistHook hookc{xsc, xzc, xtag, flags, member, &epoch, local, fail, p.wq_packed, lkeys, lvals,
                             c0 && pre_ok, c0 ? tok_pre : 0, {tok4[0], tok4[1], tok4[2], tok4[3]}, {bias4[0], bias4[1], bias4[2], bias4[3]}, cprev_pre};
+          hookc.vres = vres;
           dec_step_fwd_body<RES>(stc, bs, part, 4, sm, &hookc);
         }
       }
@@ -3089,15 +3116,17 @@ __global__ __launch_bounds__(256) void dec_persist_bwd_kernel(las_dec_persist_bw
   // the frames of this workgroup do not change over the U steps: keep them in LDS when they fit (every step would
   // otherwise stream them from L2 / Infinity Cache again, four dependent round trips in S1 alone)
   constexpr bool KT = !WQ && NPQ > 0;     // Luong with the matrix-core passes: the resident keys are transposed
-  const bool resident = persist_bwd_resident(M, Hd, Tm, KT, TWO);
+  // value frames [f0, f0 + vfr) of this workgroup are in LDS (vfr = fq unless the memory is long: then the rest is streamed)
+  const int vfr = (KT || NPQ > 0) ? (persist_bwd_resident(M, Hd, Tm, KT, TWO) ? fq : 0) : persist_bwd_resident_rows(M, Hd, Tm, TWO);
+  const bool resident = vfr > 0;
   const int MS = M + P_VPAD, FS = persist_bwd_kt_stride(Tm), DSP = persist_bwd_ds_pad(Tm);
-  unsigned short* lvals = reinterpret_cast<unsigned short*>(sm + persist_bwd_scratch_floats(M, Hd, Tm, TWO));   // [fq][MS]
-  unsigned short* lkeys = lvals + (size_t)fq * MS;                                                           // [fq][Hd]
+  unsigned short* lvals = reinterpret_cast<unsigned short*>(sm + persist_bwd_scratch_floats(M, Hd, Tm, TWO));   // [vfr][MS]
+  unsigned short* lkeys = lvals + (size_t)vfr * MS;                                                          // [fq][Hd]
   if (tid < 8) dcb[2 * M + tid] = 0;
   for (int e = tid; e < 2 * DSP; e += 256) dsb[e] = 0;
   if (resident && active) {
     const int nrow = max(f1 - f0, 0);
-    for (int e = tid; e < nrow * (M / 8); e += 256) {
+    for (int e = tid; e < min(nrow, vfr) * (M / 8); e += 256) {
       const int r = e / (M / 8), c = e % (M / 8);
       *reinterpret_cast<uint4*>(lvals + (size_t)r * MS + c * 8) = *reinterpret_cast<const uint4*>(vals + (int64_t)(f0 + r) * M + c * 8);
     }
@@ -3417,11 +3446,13 @@ __global__ __launch_bounds__(256) void dec_persist_bwd_kernel(las_dec_persist_bw
             }
           }
         }
-        auto dalign_pass = [&](const unsigned short* rows, int row0, int stride) {
-          for (int t0 = f0; t0 < f1; t0 += 32) {
+        // frames [fa, fe) of the own quarter
+        auto dalign_pass = [&](const unsigned short* rows, int row0, int stride, int fa, int fe) {
+          const int fle = min(flen, fe);
+          for (int t0 = fa; t0 < fe; t0 += 32) {
             const int ta = t0 + wave * 4 + grp, tb = ta + 16;
             float acc_a = 0.f, acc_b = 0.f;
-            const bool oa = ta < flen, ob = tb < flen;
+            const bool oa = ta < fle, ob = tb < fle;
             const unsigned short* ra = rows + (int64_t)(oa ? ta - row0 : 0) * stride;
             const unsigned short* rb = rows + (int64_t)(ob ? tb - row0 : 0) * stride;
 #pragma unroll 4
@@ -3437,14 +3468,16 @@ __global__ __launch_bounds__(256) void dec_persist_bwd_kernel(las_dec_persist_bw
               acc_b += __shfl_xor(acc_b, o, 64);
             }
             if (sub == 0) {
-              if (ta < f1) dal[ta] = oa ? acc_a : 0.f;
-              if (tb < f1) dal[tb] = ob ? acc_b : 0.f;
+              if (ta < fe) dal[ta] = oa ? acc_a : 0.f;
+              if (tb < fe) dal[tb] = ob ? acc_b : 0.f;
             }
           }
         };
         if constexpr (fast) { }
-        else if (resident) dalign_pass(lvals, f0, MS);
-        else dalign_pass(vals, 0, M);
+        else if (resident) {
+          dalign_pass(lvals, f0, MS, f0, min(f1, f0 + vfr));
+          if (f0 + vfr < f1) dalign_pass(vals, 0, M, f0 + vfr, f1);        // long memories: the frames that did not fit the LDS
+        } else dalign_pass(vals, 0, M, f0, f1);
       }
       lds_barrier();
       LAS_STAMPB(p.U - 1 - t, 3);
@@ -4193,7 +4226,10 @@ extern "C" int las_decoder_persist_fwd(const las_dec_persist* p, void* stream) {
   const dim3 grid(((groups + 7) & ~7) * P_MEMBERS);
   if (al_path) {
     // attention layer and / or monotonic normaliser: the general body with the A role (AL) or without
-    const size_t lds_al = lds + (res ? persist_fwd_resident_bytes(s->M, s->Hd, s->Tm) : 0);
+    // (long memories: keys + as many value frames as fit stay in LDS, the rest of the values is streamed)
+    const int vres = persist_fwd_resident_frames(s->M, s->Hd, s->Tm);
+    const bool res = vres > 0;
+    const size_t lds_al = lds + (res ? persist_fwd_resident_bytes_partial(s->M, s->Hd, s->Tm, vres) : 0);
 #define LAS_AL_LAUNCH(...)                                                                                                      \
   do {                                                                                                                          \
     static bool attr = false;                                                                                                   \
@@ -4350,6 +4386,10 @@ extern "C" int las_decoder_persist_bwd(const las_dec_persist_bwd* p, void* strea
   const bool keys_t = s->attention == LAS_ATT_LUONG && mshape && persist_bwd_resident(s->M, s->Hd, s->Tm, true, two);
   const bool res = persist_bwd_resident(s->M, s->Hd, s->Tm, keys_t, two);
   if (res) lds += persist_bwd_resident_bytes(s->M, s->Hd, s->Tm, keys_t);
+  else {       // long memories: the key frames and the first rows of the value frames (persist_bwd_resident_rows)
+    const int vfr = persist_bwd_resident_rows(s->M, s->Hd, s->Tm, two);
+    if (vfr > 0) lds += ((size_t)vfr * (s->M + P_VPAD) + (size_t)((s->Tm + 3) / 4) * s->Hd) * 2;
+  }
   const int npq = (res && mshape && (keys_t || s->attention != LAS_ATT_LUONG)) ? s->M / 128 : 0;
   const dim3 grid(((groups + 7) & ~7) * P_MEMBERS);
   const bool wq = s->attention != LAS_ATT_LUONG;
