@@ -1040,3 +1040,40 @@ def test_two_cell_decoder_in_one_launch_each_way(kw, B, monkeypatch):
             g = out['grads'][name] - ohp.l2_reg_scale * op[name]
             assert relerr(grads[name], g) < 2 * GRAD_TOL, (flag, name)
     assert relerr(res['1'][1], res['0'][1].cpu()) < 2e-3
+
+
+@pytest.mark.parametrize('bottom', [False, True], ids=['stack2', 'multicell2'])
+def test_two_cell_decoder_with_a_memory_longer_than_the_lds(bottom, monkeypatch):
+    """T' = 256 frames of 1024 + 256 columns per utterance: 12 % more than the four workgroups of an utterance can keep in LDS next
+    to their scratch, so the one-launch kernels keep the keys and the first 192 (forward) / 48 of 64 (backward) value frames
+    resident and stream the rest at every step (persist_*_resident_frames / _rows in decoder.hip).  Against the oracle and
+    against the step-by-step launches, ragged memory lengths on both sides of the resident / streamed boundary."""
+    O, ohp, op, model = _models(L=2, F=13, att='bahdanau', dec_layers=2, bottom_only=bottom, pass_hidden=bottom, H=256)
+    src_len, tgt_len = [512, 300, 431], [6, 4, 5]
+    batch = make_batch(B=3, T=512, src_len=src_len, tgt_len=tgt_len)
+    feats, labels = to_device(batch)
+    out = O.train_step(ohp, op, None, None, 1, batch, mxu='bf16')
+    res = {}
+    for flag in ('1', '0'):
+        monkeypatch.setenv('LAS_DEC_PERSIST2', flag)
+        model.vars.grad.zero_()
+        loss, logits, dlogits = model.forward_train(feats, labels)
+        model.backward(dlogits)
+        torch.cuda.synchronize()
+        ran = (getattr(model.speller, '_persist_ws', None) is not None, getattr(model.speller, '_persist_ws_bwd', None) is not None)
+        res[flag] = (float(loss), logits.clone(), {n: g.clone() for n, g in model.vars.grads.items()}, ran)
+        model.speller._persist_ws = model.speller._persist_ws_bwd = None
+    model.check_device_status()
+    assert res['1'][3] == (True, True) and res['0'][3] == (False, False)
+    V = ohp.decoder.target_vocab_size
+    for flag in ('1', '0'):
+        loss, logits, grads, _ = res[flag]
+        for b, n in enumerate(tgt_len):
+            assert relerr(logits[b, :n, :V], out['aux']['logits'][b, :n]) < 2e-2, (flag, b)
+        for name, _, _ in model.vars.table:
+            g = out['grads'][name] - ohp.l2_reg_scale * op[name]
+            assert relerr(grads[name], g) < 2 * GRAD_TOL, (flag, name)
+    assert relerr(res['1'][1], res['0'][1].cpu()) < 2e-3
+    for name in res['1'][2]:
+        assert relerr(res['1'][2][name], res['0'][2][name].cpu()) < 6e-3, name
+
