@@ -140,6 +140,14 @@ size_t las_gemm_tn_lstm_workspace_bytes(int D, int H, int split_k);
 int las_gemm_tn_lstm(const las_bf16* x, int64_t ldx, int D, const las_bf16* y, int64_t ldy, int H, int a_shift,
                      int period, const las_bf16* dz, int64_t ldz, float* kernel_grad, float* bias_grad, int K,
                      int split_k, float* workspace, void* stream);
+/* The same product over a TIME WINDOW of every utterance (round 4): K index k = b * win_T + j, j < win_T, is row b * T + tb + j
+ * of x / y / dz, tb = win_lo (win_len NULL) or min(win_len[b], T) - win_lo (a window counted from the end of each utterance:
+ * what a window of las_lstm_recurrent_bwd_window's steps covers in the right-to-left direction); rows outside [0, T) read as
+ * zeros.  The weight gradients of a window can so run beside the next window's recurrence instead of behind the whole layer
+ * (the reference has one tf.gradients call: las/ops.py:68-87, model_helper.py:403-417).  split_k > 1 (workspace). */
+int las_gemm_tn_lstm_window(const las_bf16* x, int64_t ldx, int D, const las_bf16* y, int64_t ldy, int H, int a_shift,
+                            int B, int T, int win_T, int win_lo, const int32_t* win_len, const las_bf16* dz, int64_t ldz,
+                            float* kernel_grad, float* bias_grad, int split_k, float* workspace, void* stream);
 
 /* dst_bf16[r, c] = src_f32[r, c] (transpose = 0) or dst[c, r] = src[r, c] (transpose = 1), with the
  * destination window [dst_rows, dst_cols] (row stride ldd) zero-padded.  `batch` windows at element
@@ -299,6 +307,13 @@ int las_lstm_fwd_workgroups(int B, int H, int ndir);
 int las_lstm_recurrent_bwd(const float* gates, const float* cbuf, const float* dy, const float* dc_last,
                            const float* dh_last, const las_bf16* kh_bf16, const int32_t* length,
                            las_bf16* dz, void* workspace, int B, int T, int H, int ndir, void* stream);
+/* ... over the steps s in [s_lo, s_hi) only (s counts from the start of a direction's forward pass; the backward walks them
+ * downwards): d(c), d(h) enter through dc_last / dh_last and, for s_lo > 0, leave through dc_out / dh_out [ndir, B, H] -- the
+ * next window's dc_last / dh_last.  Windows from the top (s_hi = T) down to s_lo = 0 give the results of one launch. */
+int las_lstm_recurrent_bwd_window(const float* gates, const float* cbuf, const float* dy, const float* dc_last,
+                                  const float* dh_last, const las_bf16* kh_bf16, const int32_t* length, las_bf16* dz,
+                                  void* workspace, int B, int T, int H, int ndir, int s_lo, int s_hi, float* dc_out,
+                                  float* dh_out, void* stream);
 
 /* len_out[b] = len[b]/2 + len[b]%2  (las/ops.py:65 pyramidal_stack). */
 int las_pyramid_lengths(const int32_t* len_in, int32_t* len_out, int B, void* stream);

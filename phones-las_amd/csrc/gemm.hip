@@ -43,6 +43,11 @@ struct GemmArgs {
   const int32_t* length = nullptr;
   unsigned* ready = nullptr;
   int sB = 0, sT = 0, s_ndir = 1, s_nsb = 0, sR = 4, s_nslices = 0;
+  // las_gemm_tn_lstm_window (gemm_tn_ring_kernel): the K rows are a TIME WINDOW of every utterance -- K index k = b * win_T + j
+  // is row b * period + tb + j, tb = win_lo (win_len == nullptr) or win_len[b] - win_lo (windows counted from the END of each
+  // utterance: the right-to-left direction of a BiLSTM); rows with t outside [0, period) read as zeros.  win_T = 0: off.
+  int win_T = 0, win_lo = 0, win_B = 0;
+  const int32_t* win_len = nullptr;
 };
 
 // Layout of the `ready` buffer shared by las_gemm_nt_stream and the recurrence it feeds (32-bit words, zero before both launches):
@@ -570,6 +575,12 @@ __global__ __launch_bounds__(512) void gemm_tn_ring_kernel(GemmArgs g) {
   }
   int kcur = kt_begin * TR_BK + srow;
   int t0 = kcur % g.period;
+  // row window: the utterances' window bases in LDS behind the ring (no global load inside issue(): the ring counts its own)
+  int* wbase = reinterpret_cast<int*>(smem + TR_STAGES * TR_STAGE_BYTES);
+  if (g.win_T) {
+    for (int b = tid; b < g.win_B; b += 512) wbase[b] = g.win_len ? min(g.win_len[b], g.period) - g.win_lo : g.win_lo;
+    __syncthreads();
+  }
   const unsigned short* paK = pa + ((int64_t)kcur + shift) * lda_e;
   const unsigned short* pbK[2];
   bool b_ok[2];
@@ -581,7 +592,25 @@ __global__ __launch_bounds__(512) void gemm_tn_ring_kernel(GemmArgs g) {
   }
   auto issue = [&](int stage) {
     const unsigned base = lds_base + stage * TR_STAGE_BYTES + wave * 1024;
-    const bool k_ok = kcur < g.K;
+    bool k_ok = kcur < g.K;
+    if (g.win_T) {
+      // this lane's row of the stage inside the window of its utterance (see GemmArgs)
+      const int b = min(kcur / g.win_T, g.win_B - 1), t = wbase[b] + (kcur - b * g.win_T);
+      const int64_t row = (int64_t)b * g.period + t;
+      k_ok = k_ok && t >= 0 && t < g.period;
+      const unsigned short* sa = zeros;
+      if (k_ok) {
+        if (kindA == 1) sa = pa + row * lda_e;
+        else if (kindA == 2) { if (t + shift >= 0 && t + shift < g.period) sa = pa + (row + shift) * lda_e; }
+        else if (kindA == 3) sa = las_const_rows;
+      }
+      glds16(sa, base);
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+        glds16((k_ok && b_ok[j]) ? g.B + row * g.ldb + (n0 + j * 128 + chunk * 8) : zeros, base + (1 + j) * TR_BK * 256);
+      kcur += TR_BK;
+      return;
+    }
     const unsigned short* sa = zeros;
     if (k_ok) {
       if (kindA == 1) sa = paK;
@@ -1255,9 +1284,27 @@ extern "C" size_t las_gemm_tn_lstm_workspace_bytes(int D, int H, int split_k) {
   return split_k > 1 ? sizeof(float) * (size_t)split_k * (size_t)(D + H + 1) * (size_t)(4 * H) : 0;
 }
 
+static int gemm_tn_lstm(const las_bf16* x, int64_t ldx, int D, const las_bf16* y, int64_t ldy, int H, int a_shift,
+                        int period, const las_bf16* dz, int64_t ldz, float* kernel_grad, float* bias_grad, int K,
+                        int split_k, float* workspace, void* stream, int win_B, int win_T, int win_lo, const int32_t* win_len);
+
 extern "C" int las_gemm_tn_lstm(const las_bf16* x, int64_t ldx, int D, const las_bf16* y, int64_t ldy, int H, int a_shift,
                                 int period, const las_bf16* dz, int64_t ldz, float* kernel_grad, float* bias_grad, int K,
                                 int split_k, float* workspace, void* stream) {
+  return gemm_tn_lstm(x, ldx, D, y, ldy, H, a_shift, period, dz, ldz, kernel_grad, bias_grad, K, split_k, workspace, stream, 0, 0, 0, nullptr);
+}
+
+extern "C" int las_gemm_tn_lstm_window(const las_bf16* x, int64_t ldx, int D, const las_bf16* y, int64_t ldy, int H, int a_shift,
+                                       int B, int T, int win_T, int win_lo, const int32_t* win_len, const las_bf16* dz, int64_t ldz,
+                                       float* kernel_grad, float* bias_grad, int split_k, float* workspace, void* stream) {
+  LAS_REQUIRE(B > 0 && B <= 4096 && T > 0 && win_T > 0 && win_T <= T && split_k > 1 && workspace,
+              "las_gemm_tn_lstm_window: a window of 1 .. T rows per utterance, split over a workspace (B=%d T=%d win_T=%d split_k=%d)", B, T, win_T, split_k);
+  return gemm_tn_lstm(x, ldx, D, y, ldy, H, a_shift, T, dz, ldz, kernel_grad, bias_grad, B * win_T, split_k, workspace, stream, B, win_T, win_lo, win_len);
+}
+
+static int gemm_tn_lstm(const las_bf16* x, int64_t ldx, int D, const las_bf16* y, int64_t ldy, int H, int a_shift,
+                        int period, const las_bf16* dz, int64_t ldz, float* kernel_grad, float* bias_grad, int K,
+                        int split_k, float* workspace, void* stream, int win_B, int win_T, int win_lo, const int32_t* win_len) {
   LAS_REQUIRE(D >= 0 && H > 0 && K > 0 && period > 0 && D % 8 == 0 && H % 8 == 0, "las_gemm_tn_lstm: bad shape D=%d H=%d K=%d", D, H, K);
   LAS_REQUIRE((D == 0 || (x && ldx % 8 == 0 && ((uintptr_t)x % 16 == 0))) && y && dz && kernel_grad && bias_grad && ldy % 8 == 0 &&
                   ldz % 8 == 0 && ((uintptr_t)y % 16 == 0) && ((uintptr_t)dz % 16 == 0),
@@ -1273,14 +1320,16 @@ extern "C" int las_gemm_tn_lstm(const las_bf16* x, int64_t ldx, int D, const las
     g.partial = workspace;
     g.partial_stride = (int64_t)g.M * g.N;
   }
+  g.win_T = win_T; g.win_lo = win_lo; g.win_B = win_B; g.win_len = win_len;
   static int ring = -1;            // LAS_TN_RING=0: the register-staged 128 x 128 kernel (diagnostics, A/B timing)
   if (ring < 0) { const char* e = getenv("LAS_TN_RING"); ring = (e && atoi(e) == 0) ? 0 : 1; }
-  if (ring && g.partial) {
+  if ((ring || win_T) && g.partial) {
     dim3 grid((g.N + 255) / 256, (g.M + 127) / 128, split_k);
-    const size_t lds = (size_t)TR_STAGES * TR_STAGE_BYTES;
+    const size_t lds = (size_t)TR_STAGES * TR_STAGE_BYTES + (size_t)win_B * sizeof(int);
     static bool attr_ring = false;
     if (!attr_ring) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_ring_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_ring_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)((size_t)TR_STAGES * TR_STAGE_BYTES + 4096 * sizeof(int)));
       attr_ring = true;
     }
     hipLaunchKernelGGL(gemm_tn_ring_kernel, grid, dim3(512), lds, (hipStream_t)stream, g);

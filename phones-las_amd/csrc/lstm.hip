@@ -744,13 +744,19 @@ __global__ __launch_bounds__(256) void lstm_fwd_kernel(float* __restrict__ xproj
 // is 4 x (G-1) granules each way, against 8 x 4 x (G-1) for an all-gather of dz_t.
 // kh is K_h [H, 4H] in bf16 with GATE-INTERLEAVED columns (u*4+g): a member's K range is contiguous.
 // ------------------------------------------------------------------------------------------------
+// TIME WINDOW of a backward launch (round 4): the chain runs its steps s in [s_lo, s_hi) only (s counts from the START of the
+// direction's forward pass: the backward walks s downwards) -- d(h), d(c) enter through dh_last / dc_last and, for s_lo > 0,
+// leave through dh_out / dc_out [ndir, B, H]: the next window's dh_last / dc_last.  The weight-gradient products over a window's
+// rows can then run beside the next window's chain (las_gemm_tn_lstm's row window) instead of behind the whole layer.
+struct BwdWindow { int s_lo, s_hi; float* dc_out; float* dh_out; };
+
 template <int H, int ROWS, int G>            // ROWS: utterances per slice, G: members, as in lstm_fwd_kernel
 __device__ __forceinline__ void lstm_bwd_body(const float* __restrict__ gates, const float* __restrict__ cbuf,
                                               const float* __restrict__ dy, const float* __restrict__ dc_last,
                                               const float* __restrict__ dh_last, const unsigned short* __restrict__ kh,
                                               const int32_t* __restrict__ length, unsigned short* __restrict__ dz,
                                               u64* __restrict__ exch, unsigned* __restrict__ status,
-                                              int B, int T, int ndir, int ngroups, const unsigned base) {
+                                              int B, int T, int ndir, int ngroups, const unsigned base, const BwdWindow win) {
   constexpr int HS = H / G;
   constexpr int NUB = HS / 16;                    // 16-unit blocks of a member
   constexpr bool SPLIT = NUB < 4;                 // H = 512: two waves share a unit block, two rows of every quad each
@@ -805,15 +811,17 @@ __device__ __forceinline__ void lstm_bwd_body(const float* __restrict__ gates, c
     smin = -(int)las_wave_max((float)(-ll));
   }
   if ((int64_t)B * T * grow * 4 >= ((int64_t)1 << 32)) smin = 0;     // 32-bit byte offsets do not reach: general path only
+  const int s_lo = max(win.s_lo, 0), s_start = min(smax, win.s_hi) - 1;     // this launch's steps: s_start down to s_lo
 
   if (companion) {
     // PREFETCH COMPANION (see lstm_fwd_kernel): gates, c and dy lines of the whole group, PF_AHEAD steps ahead.
     constexpr int PF_AHEAD = 6;
     const int mylen = (l15 < ROWS && slice * ROWS + l15 < B) ? min(length[slice * ROWS + l15], T) : 0;
     // dz rows t >= length are zero: cleared here (the direction's gate columns), so dense batches need no memset of dz
+    // (the launch of the window that reaches the end of the sequences does it)
     for (int rr = wave * (ROWS / 4); rr < (wave + 1) * (ROWS / 4); ++rr) {
       const int bb = slice * ROWS + rr;
-      if (bb >= B) continue;
+      if (bb >= B || win.s_hi < T) continue;
       const int ll = __builtin_amdgcn_readlane(mylen, rr);
       constexpr int LPR = 4 * H * 2 / 16 / CPG;
       for (int e = ll * LPR + lane; e < T * LPR; e += 64) {
@@ -823,8 +831,8 @@ __device__ __forceinline__ void lstm_bwd_body(const float* __restrict__ gates, c
     }
     const u64* tag0 = ex_group + (G > 1 ? (int64_t)(1 * G + 0) * PAIR : 0);   // (destination 1, sender 0): member 0 writes it every step (G = 1: a progress granule)
     int seen = -1;
-    for (int it = 0; it < smax; ++it) {
-      const int sp = smax - 1 - it;
+    for (int it = 0; it <= s_start - s_lo; ++it) {
+      const int sp = s_start - it;
       unsigned spins = 0;
       while (seen < it - PF_AHEAD) {
         const u64 v0 = granule_load(tag0), v1 = granule_load(tag0 + par_stride), dn = granule_load(done_word);
@@ -1004,8 +1012,8 @@ __device__ __forceinline__ void lstm_bwd_body(const float* __restrict__ gates, c
   int cur = 0;
   unsigned epoch = 0;          // = iterations done; partial sums sent in iteration i carry tag i+1 in parity slot i&1
   bool ok = true;
-  set_goff(smin > 0 ? smin - 1 : 0);
-  load_general(smax - 1);
+  set_goff(max(min(smin - 1, s_start), 0));
+  load_general(s_start);
   prepare();
   // one time step; LEAN (compile time): every row of the slice is running at step s (and at s - 1: the lean loader).
   // Two instantiations instead of a run-time flag: with both loaders in one body the values they load met in phi copies,
@@ -1158,10 +1166,45 @@ __device__ __forceinline__ void lstm_bwd_body(const float* __restrict__ gates, c
     return ok;
   };
   {
-    int s = smax - 1;
+    int s = s_start;
     bool go = true;
-    for (; s >= smin && go; --s) go = iter(s, std::false_type{});
-    for (; s >= 0 && go; --s) go = iter(s, std::true_type{});
+    for (; s >= smin && s >= s_lo && go; --s) go = iter(s, std::false_type{});
+    for (; s >= s_lo && go; --s) go = iter(s, std::true_type{});
+    if (s_lo > 0) {
+      // ---- end of a time window: complete dh_{s_lo - 1} (the partial sums of the last iteration are on their way) and hand
+      //      d(h), d(c) to the next window's launch (a slice that is over before the window: its initial values).  A copy of
+      //      the poll at the top of iter(): the hot loop stays as it is. ----
+      const bool ran = s_start >= s_lo && go && ok;
+      if constexpr (G > 1) {
+        if (ran) {
+          const char* src = reinterpret_cast<const char*>(ex_group + (int64_t)((epoch - 1) & 1) * par_stride);
+  #pragma unroll
+          for (int e = 0; e < PER; ++e) {
+            u64 v = 0;
+            unsigned spins = 0;
+            for (;;) {
+              v = granule_load(reinterpret_cast<const u64*>(src + poll_off[e]));
+              if (__all((unsigned)(v >> 32) == base + epoch)) break;
+              if (++spins > SPIN_LIMIT) { fail_flag = 1; ok = false; break; }
+              __builtin_amdgcn_s_sleep(1);
+            }
+            const int ub = SPLIT ? 0 : (e / RPL) % UBW, r = e % RPL;
+            part[ub][r] += __uint_as_float((unsigned)v);
+          }
+        }
+      }
+#pragma unroll
+      for (int ub = 0; ub < UBW; ++ub)
+#pragma unroll
+        for (int r = 0; r < RPL; ++r) {
+          if (ran && s_lo < len[r]) dh[ub][r] = part[ub][r];   // rows that were running at step s_lo
+          if (bidx[r] < B && win.dh_out && win.dc_out) {
+            const int64_t o = ((int64_t)dir * B + bidx[r]) * H + unit0 + ub * 16;
+            win.dh_out[o] = dh[ub][r];
+            win.dc_out[o] = dc[ub][r];
+          }
+        }
+    }
   }
   if (tid == 0) __hip_atomic_store(done_word, ((u64)(base + 1u) << 32) | 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   if (!ok && tid == 0) atomicOr(status, 2u);
@@ -1173,9 +1216,9 @@ __global__ __launch_bounds__(256) void lstm_bwd_kernel(const float* __restrict__
                                                        const float* __restrict__ dh_last, const unsigned short* __restrict__ kh,
                                                        const int32_t* __restrict__ length, unsigned short* __restrict__ dz,
                                                        u64* __restrict__ exch, unsigned* __restrict__ status,
-                                                       int B, int T, int ndir, int ngroups, long long exch_words) {
+                                                       int B, int T, int ndir, int ngroups, long long exch_words, const BwdWindow win) {
   const unsigned base = launch_base(status);
-  lstm_bwd_body<H, ROWS, G>(gates, cbuf, dy, dc_last, dh_last, kh, length, dz, exch, status, B, T, ndir, ngroups, base);
+  lstm_bwd_body<H, ROWS, G>(gates, cbuf, dy, dc_last, dh_last, kh, length, dz, exch, status, B, T, ndir, ngroups, base, win);
   launch_arrive(status, base, T, exch, exch_words);
 }
 
@@ -1325,7 +1368,8 @@ int launch_fwd(float* xproj, const las_bf16* wp, const int32_t* length, las_bf16
 
 template <int H, int ROWS, int G>
 int launch_bwd_as(const float* gates, const float* cbuf, const float* dy, const float* dc_last, const float* dh_last,
-                  const las_bf16* kh, const int32_t* length, las_bf16* dz, void* ws, int B, int T, int ndir, hipStream_t st) {
+                  const las_bf16* kh, const int32_t* length, las_bf16* dz, void* ws, int B, int T, int ndir, hipStream_t st,
+                  const BwdWindow win) {
   const CoopGeom g = geom(B, H, ndir, true, ROWS, G);
   unsigned* status = reinterpret_cast<unsigned*>(ws);
   u64* exch = reinterpret_cast<u64*>(reinterpret_cast<char*>(ws) + 64);
@@ -1346,16 +1390,17 @@ int launch_bwd_as(const float* gates, const float* cbuf, const float* dy, const 
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&lstm_bwd_kernel<H, ROWS, G>), hipFuncAttributeMaxDynamicSharedMemorySize, hog_kb * 1024);
   }
   hipLaunchKernelGGL((lstm_bwd_kernel<H, ROWS, G>), dim3(pf ? g.blocks + g.companions : g.blocks), dim3(256), (size_t)(hog_kb > 0 ? hog_kb : 0) * 1024, st,
-                     gates, cbuf, dy, dc_last, dh_last, kh, length, dz, exch, status, B, T, ndir, g.ngroups, exch_words(B, H, ndir));
+                     gates, cbuf, dy, dc_last, dh_last, kh, length, dz, exch, status, B, T, ndir, g.ngroups, exch_words(B, H, ndir), win);
   LAS_LAUNCH_CHECK("lstm bwd launch");
   return LAS_OK;
 }
 
 template <int H>
 int launch_bwd(const float* gates, const float* cbuf, const float* dy, const float* dc_last, const float* dh_last,
-               const las_bf16* kh, const int32_t* length, las_bf16* dz, void* ws, int B, int T, int ndir, hipStream_t st) {
+               const las_bf16* kh, const int32_t* length, las_bf16* dz, void* ws, int B, int T, int ndir, hipStream_t st,
+               const BwdWindow win) {
   const int rows = slice_rows(B, H, ndir, true);
-#define LAS_BWD(R, GG) return launch_bwd_as<H, R, GG>(gates, cbuf, dy, dc_last, dh_last, kh, length, dz, ws, B, T, ndir, st)
+#define LAS_BWD(R, GG) return launch_bwd_as<H, R, GG>(gates, cbuf, dy, dc_last, dh_last, kh, length, dz, ws, B, T, ndir, st, win)
   if constexpr (H == 512) {
     if (members(H) == 8) {
       if (rows == 4) LAS_BWD(4, 8);
@@ -1467,24 +1512,40 @@ extern "C" int las_lstm_recurrent_fwd_ex(const las_lstm_fwd* p, void* stream) {
   return recurrent_fwd(p->xproj, p->wpacked, p->length, p->y, p->cbuf, p->c_last, p->h_last, p->workspace, p->B, p->T, p->H, p->ndir, stream, fi);
 }
 
+extern "C" int las_lstm_recurrent_bwd_window(const float* gates, const float* cbuf, const float* dy, const float* dc_last,
+                                             const float* dh_last, const las_bf16* kh_bf16, const int32_t* length,
+                                             las_bf16* dz, void* workspace, int B, int T, int H, int ndir, int s_lo, int s_hi,
+                                             float* dc_out, float* dh_out, void* stream);
+
 extern "C" int las_lstm_recurrent_bwd(const float* gates, const float* cbuf, const float* dy, const float* dc_last,
                                       const float* dh_last, const las_bf16* kh_bf16, const int32_t* length,
                                       las_bf16* dz, void* workspace, int B, int T, int H, int ndir, void* stream) {
+  return las_lstm_recurrent_bwd_window(gates, cbuf, dy, dc_last, dh_last, kh_bf16, length, dz, workspace, B, T, H, ndir, 0, T, nullptr,
+                                       nullptr, stream);
+}
+
+extern "C" int las_lstm_recurrent_bwd_window(const float* gates, const float* cbuf, const float* dy, const float* dc_last,
+                                             const float* dh_last, const las_bf16* kh_bf16, const int32_t* length,
+                                             las_bf16* dz, void* workspace, int B, int T, int H, int ndir, int s_lo, int s_hi,
+                                             float* dc_out, float* dh_out, void* stream) {
   LAS_REQUIRE(B > 0 && T > 0 && (ndir == 1 || ndir == 2), "las_lstm_recurrent_bwd: bad shape");
+  LAS_REQUIRE(s_lo >= 0 && s_lo < s_hi && s_hi <= T && (s_lo == 0 || (dc_out && dh_out)),
+              "las_lstm_recurrent_bwd_window: steps [%d, %d) of %d; a window that stops above step 0 hands d(c), d(h) on", s_lo, s_hi, T);
+  const BwdWindow win{s_lo, s_hi, dc_out, dh_out};
   LAS_REQUIRE(supported_units(H), "las_lstm_recurrent_bwd: num_units %d not in {64,128,256,512}", H);
   LAS_REQUIRE(workspace != nullptr && ((uintptr_t)workspace % 16 == 0), "las_lstm_recurrent_bwd: workspace missing or misaligned");
   hipStream_t st = (hipStream_t)stream;
   int rc = 0;
-  if (!prefetch_mode()) {
+  if (!prefetch_mode() && s_hi >= T) {
     rc = las_check_hip(hipMemsetAsync(dz, 0, (size_t)B * T * ndir * 4 * H * sizeof(las_bf16), st), "memset dz");
     if (rc) return rc;
   }
   // (no memset of the exchange buffer: launch epochs, see las_lstm_recurrent_fwd)
   switch (H) {
-    case 64: return launch_bwd<64>(gates, cbuf, dy, dc_last, dh_last, kh_bf16, length, dz, workspace, B, T, ndir, st);
-    case 128: return launch_bwd<128>(gates, cbuf, dy, dc_last, dh_last, kh_bf16, length, dz, workspace, B, T, ndir, st);
-    case 512: return launch_bwd<512>(gates, cbuf, dy, dc_last, dh_last, kh_bf16, length, dz, workspace, B, T, ndir, st);
-    default: return launch_bwd<256>(gates, cbuf, dy, dc_last, dh_last, kh_bf16, length, dz, workspace, B, T, ndir, st);
+    case 64: return launch_bwd<64>(gates, cbuf, dy, dc_last, dh_last, kh_bf16, length, dz, workspace, B, T, ndir, st, win);
+    case 128: return launch_bwd<128>(gates, cbuf, dy, dc_last, dh_last, kh_bf16, length, dz, workspace, B, T, ndir, st, win);
+    case 512: return launch_bwd<512>(gates, cbuf, dy, dc_last, dh_last, kh_bf16, length, dz, workspace, B, T, ndir, st, win);
+    default: return launch_bwd<256>(gates, cbuf, dy, dc_last, dh_last, kh_bf16, length, dz, workspace, B, T, ndir, st, win);
   }
 }
 

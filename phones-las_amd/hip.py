@@ -37,6 +37,7 @@ _SIGS = {
     'las_lstm_pack_recurrent': ([_vp, _i32, _vp, _vp], C.c_int),
     'las_lstm_recurrent_fwd': ([_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp], C.c_int),
     'las_lstm_recurrent_bwd': ([_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp], C.c_int),
+    'las_lstm_recurrent_bwd_window': ([_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp], C.c_int),
     'las_lstm_fused_input_chunks': ([_i32, _i32], C.c_int),
     'las_lstm_pack_input': ([_vp, _i32, _i32, _i32, _vp, _vp], C.c_int),
     'las_lstm_recurrent_fwd_ex': ([_vp, _vp], C.c_int),
@@ -103,6 +104,7 @@ _SIGS = {
     'las_add_noise': ([_vp, _i64, _f32, C.c_uint32, C.c_uint32, _vp], C.c_int),
     'las_gemm_tn_lstm_workspace_bytes': ([C.c_int, C.c_int, C.c_int], C.c_size_t),
     'las_gemm_tn_lstm': ([_vp, _i64, C.c_int, _vp, _i64, C.c_int, C.c_int, C.c_int, _vp, _i64, _vp, _vp, C.c_int, C.c_int, _vp, _vp], C.c_int),
+    'las_gemm_tn_lstm_window': ([_vp, _i64, C.c_int, _vp, _i64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp, _i64, _vp, _vp, C.c_int, _vp, _vp], C.c_int),
     'las_decoder_persist_supported': ([C.c_int] * 5, C.c_int),
     'las_decoder_persist_al_supported': ([_i32, _i32, _i32, _i32, _i32, _i32], C.c_int),
     'las_decoder_persist2_supported': ([_i32, _i32, _i32, _i32, _i32, _i32], C.c_int),

@@ -350,6 +350,18 @@ def concat_outputs(outputs):
 MASKED_DX = os.environ.get('LAS_MASKED_DX', '1') != '0'
 
 
+# LAS_BWD_WINDOWS=n: the backward recurrence of the BOTTOM listener layer in n time windows (n launches that hand d(h), d(c) on);
+# the weight-gradient products over a window's rows run beside the next window's chain, so only the last window's are exposed
+# behind the layer (metric-M: ~0.2 ms of products that nothing else hides).  LAS_BWD_WINDOWS_ALL=1: every layer.  1 = off.
+# MEASURED (round 4, one call): metric-M 6.075 ms with 1 window, 6.18 / 6.17 / 6.24 with 2 / 3 / 4; metric-L 17.77 -> 17.99 (bottom
+# layer) -> 18.59 (every layer).  The side stream beside the bottom layer's chain is already ~80 % busy with the layer above's
+# products, the extra launches each restart the chain (weights, handshake, first general step) and more product workgroups beside
+# the chain slow it: the windows cost more than the ~0.15 ms they can hide.  Off by default; the kernels and their tests stay.
+BWD_WINDOWS = int(os.environ.get('LAS_BWD_WINDOWS', '1'))
+BWD_WINDOWS_ALL = os.environ.get('LAS_BWD_WINDOWS_ALL', '0') != '0'
+BWD_WINDOW_MIN_STEPS = 64
+
+
 def bilstm_backward(rec, dy, d_state, grads, need_dx=True, overlap=None, defer_weight_grads=False, exposed=False):
     """Reverse-mode AD of one bilstm() call.  dy [B,T,nd*H] fp32 (gradient of the concatenated outputs),
     d_state: None or (dc_last, dh_last) each [nd,B,H] fp32.  Accumulates into ``grads`` (name -> fp32
@@ -362,17 +374,107 @@ def bilstm_backward(rec, dy, d_state, grads, need_dx=True, overlap=None, defer_w
     dev = dy.device
     dz = torch.empty(B, T, nd * 4 * H, dtype=torch.bfloat16, device=dev)
     dc_last, dh_last = d_state if d_state is not None else (None, None)
-    tok = hip.prof_begin('lstm_bwd', 2.0 * B * T * nd * H * 4 * H)       # dh_{t-1} = dz_t K_h^T of every step
-    hip.check(hip.lib().las_lstm_recurrent_bwd(hip.p(rec['gates']), hip.p(rec['cbuf']), hip.p(dy), hip.p(dc_last),
-                                               hip.p(dh_last), hip.p(w.kh), hip.p(rec['length']), hip.p(dz),
-                                               hip.p(lstm_workspace(B, H, nd)), B, T, H, nd, hip.stream()))
-    hip.prof_end(tok)
     x, y = rec['inputs'], rec['y']
     BT = B * T
-    # critical path first: dX feeds the next (lower) layer's recurrence
+    Df_w = D if D % 8 == 0 else (Dp if (Dp % 8 == 0 and all(a.shape[-1] == Dp for a, _ in (rec.get('dropped') or [(x, 0)]))) else -1)
     dx = None
     dropped, keep = rec.get('dropped'), rec.get('keep', 1.0)
     split_in = rec.get('split', False)
+    split = max(1, min(32, BT // 2048))
+    # The fused product takes an input width that is a multiple of 8.  A feature count that is not (39-dim MFCCs: cfg1, cfg5)
+    # runs it at the PADDED width -- the zero pad columns of x give zero gradient rows -- into a scratch kernel gradient whose
+    # rows are then added where they belong.  (The separate products this replaces went through the 64-row kernel unsplit once
+    # the K slices stopped meeting in atomics: 2 x 1.26 ms exposed behind the last recurrence of a cfg5 step.)
+    Df = D if D % 8 == 0 else (Dp if (Dp % 8 == 0 and all(a.shape[-1] == Dp for a, _ in (dropped or [(x, 0)]))) else -1)
+    if Df >= 0:
+        # fused product: about 700 workgroups in flight measured best on MI355X (128 x 128 output tiles, K cut in slices)
+        tiles = -(-(Df + H + 1) // 128) * -(-(4 * H) // 128)
+        split = max(1, min(32, BT // 512, round(TN_WORKGROUPS / tiles)))
+    keepalive = [dz, x, y] + [a for a, _ in (dropped or [])]
+
+    def weight_grads(win=None, beside=False):
+        """win = (s_lo, s_hi): the products over the rows of that window of recurrence steps only (positions [s_lo, s_hi) of the
+        left-to-right direction, [len - s_hi, len - s_lo) of the right-to-left one); beside: a chain launch follows on the main stream."""
+        for i, (kn, bn) in enumerate(w.names):
+            with (overlap or _NoOverlap()).fork(*keepalive, lane=(i % 2 if exposed else 0), beside_chain=((i == 0 and not exposed) or beside)):
+                gk, gb = grads[kn], grads[bn]
+                dzi = dz.view(BT, nd * 4 * H)[:, i * 4 * H:]
+                xa, lda = (dropped[i] if dropped is not None else (x, Dp))
+                yi = y.view(BT, nd * H)[:, i * H:]
+                if Df >= 0:
+                    # dK_x, dK_h and db of this direction in one product (dz read once); the K slices meet in a workspace
+                    # owned by this layer (its products run one after the other on one stream)
+                    # (one workspace per stream the products may run on)
+                    need = hip.lib().las_gemm_tn_lstm_workspace_bytes(Df, H, max(split, 2))
+                    wss = w.__dict__.setdefault('_tn_ws', {})
+                    ws = wss.get(i % 2 if exposed else 0)
+                    if ws is None or ws.numel() * 4 < need:
+                        ws = wss[i % 2 if exposed else 0] = torch.empty(max(1, need // 4), dtype=torch.float32, device=dev)
+                    gdst = gk
+                    if Df != D:                 # padded input width: the kernel gradient at [Df + H, 4H], folded back below
+                        pads = w.__dict__.setdefault('_gk_pad', {})
+                        gdst = pads.get(i)
+                        if gdst is None:
+                            gdst = pads[i] = torch.empty(Df + H, 4 * H, dtype=torch.float32, device=dev)
+                        gdst.zero_()
+                    if win is None:
+                        tok = hip.prof_begin('gemm_tn_lstm', 2.0 * (Df + H + 1) * 4 * H * BT)
+                        hip.check(hip.lib().las_gemm_tn_lstm(hip.p(xa) if Df > 0 else None, lda, Df, hip.p(yi), nd * H, H,
+                                                             (-1 if i == 0 else 1), T, hip.p(dzi), nd * 4 * H, hip.p(gdst), hip.p(gb),
+                                                             BT, split, hip.p(ws), hip.stream()))
+                    else:
+                        s_lo, s_hi = win
+                        wsplit = max(2, min(split, B * (s_hi - s_lo) // 512))
+                        tok = hip.prof_begin('gemm_tn_lstm', 2.0 * (Df + H + 1) * 4 * H * B * (s_hi - s_lo))
+                        hip.check(hip.lib().las_gemm_tn_lstm_window(
+                            hip.p(xa) if Df > 0 else None, lda, Df, hip.p(yi), nd * H, H, (-1 if i == 0 else 1), B, T, s_hi - s_lo,
+                            (s_lo if i == 0 else s_hi), (None if i == 0 else hip.p(rec['length'])), hip.p(dzi), nd * 4 * H,
+                            hip.p(gdst), hip.p(gb), wsplit, hip.p(ws), hip.stream()))
+                    hip.prof_end(tok)
+                    if Df != D:
+                        gk[:D].add_(gdst[:D])
+                        gk[D:].add_(gdst[Df:])
+                    continue
+                if D > 0:
+                    hip.gemm_tn(xa, dzi, gk, D, 4 * H, BT, lda=lda, ldb=nd * 4 * H, ldc=4 * H, split_k=split, c_perm_h=H)
+                hip.gemm_tn(yi, dzi, gk[D:], H, 4 * H, BT, lda=nd * H, ldb=nd * 4 * H, ldc=4 * H,
+                            a_shift=(-1 if i == 0 else 1), period=T, split_k=split, c_perm_h=H)
+                hip.colsum_bf16(dzi, BT, 4 * H, gb, ldx=nd * 4 * H, perm_h=H)
+
+    nwin = 1
+    if (overlap is not None and not defer_weight_grads and (exposed or BWD_WINDOWS_ALL) and Df_w >= 0 and nd == 2
+            and T >= 2 * BWD_WINDOW_MIN_STEPS and BT >= 8192):
+        nwin = max(1, min(BWD_WINDOWS, T // BWD_WINDOW_MIN_STEPS))
+    bounds = [round(k * T / nwin) for k in range(nwin + 1)]
+    window_grads = []                       # (s_lo, s_hi) of the windows whose weight gradients are still to be launched
+    if nwin == 1:
+        tok = hip.prof_begin('lstm_bwd', 2.0 * B * T * nd * H * 4 * H)       # dh_{t-1} = dz_t K_h^T of every step
+        hip.check(hip.lib().las_lstm_recurrent_bwd(hip.p(rec['gates']), hip.p(rec['cbuf']), hip.p(dy), hip.p(dc_last),
+                                                   hip.p(dh_last), hip.p(w.kh), hip.p(rec['length']), hip.p(dz),
+                                                   hip.p(lstm_workspace(B, H, nd)), B, T, H, nd, hip.stream()))
+        hip.prof_end(tok)
+    else:
+        # time windows, last steps first: each launch hands d(h), d(c) to the next; the weight gradients of a window's rows are
+        # forked as soon as its launch is enqueued, i.e. they run beside the next window's chain
+        lib = hip.lib()
+        carry = [(torch.empty(nd, B, H, dtype=torch.float32, device=dev), torch.empty(nd, B, H, dtype=torch.float32, device=dev))
+                 for _ in range(2)]
+        keepalive.extend(t for pair in carry for t in pair)
+        dc_in, dh_in = dc_last, dh_last
+        for k in range(nwin - 1, -1, -1):
+            s_lo, s_hi = bounds[k], bounds[k + 1]
+            dc_out, dh_out = carry[k % 2] if s_lo > 0 else (None, None)
+            tok = hip.prof_begin('lstm_bwd', 2.0 * B * (s_hi - s_lo) * nd * H * 4 * H)
+            hip.check(lib.las_lstm_recurrent_bwd_window(hip.p(rec['gates']), hip.p(rec['cbuf']), hip.p(dy), hip.p(dc_in), hip.p(dh_in),
+                                                        hip.p(w.kh), hip.p(rec['length']), hip.p(dz), hip.p(lstm_workspace(B, H, nd)),
+                                                        B, T, H, nd, s_lo, s_hi, hip.p(dc_out), hip.p(dh_out), hip.stream()))
+            hip.prof_end(tok)
+            dc_in, dh_in = dc_out, dh_out
+            if k > 0 or not need_dx:
+                weight_grads((s_lo, s_hi), beside=(k > 0))
+            else:
+                window_grads.append((s_lo, s_hi))       # behind dX (critical path first), as without windows
+    # critical path first: dX feeds the next (lower) layer's recurrence
     if need_dx:
         if dropped is None:
             dx = torch.empty(B, T, D, dtype=torch.float32, device=dev)
@@ -409,56 +511,10 @@ def bilstm_backward(rec, dy, d_state, grads, need_dx=True, overlap=None, defer_w
                                                   stream0 + 1, hip.stream()))
             if dx is None:
                 dx = torch.cat(parts, -1) if split_in else (parts[0] if nd == 1 else parts[0] + parts[1])
-    split = max(1, min(32, BT // 2048))
-    # The fused product takes an input width that is a multiple of 8.  A feature count that is not (39-dim MFCCs: cfg1, cfg5)
-    # runs it at the PADDED width -- the zero pad columns of x give zero gradient rows -- into a scratch kernel gradient whose
-    # rows are then added where they belong.  (The separate products this replaces went through the 64-row kernel unsplit once
-    # the K slices stopped meeting in atomics: 2 x 1.26 ms exposed behind the last recurrence of a cfg5 step.)
-    Df = D if D % 8 == 0 else (Dp if (Dp % 8 == 0 and all(a.shape[-1] == Dp for a, _ in (dropped or [(x, 0)]))) else -1)
-    if Df >= 0:
-        # fused product: about 700 workgroups in flight measured best on MI355X (128 x 128 output tiles, K cut in slices)
-        tiles = -(-(Df + H + 1) // 128) * -(-(4 * H) // 128)
-        split = max(1, min(32, BT // 512, round(TN_WORKGROUPS / tiles)))
-    keepalive = [dz, x, y] + [a for a, _ in (dropped or [])]
-
-    def weight_grads():
-        for i, (kn, bn) in enumerate(w.names):
-            with (overlap or _NoOverlap()).fork(*keepalive, lane=(i % 2 if exposed else 0), beside_chain=(i == 0 and not exposed)):
-                gk, gb = grads[kn], grads[bn]
-                dzi = dz.view(BT, nd * 4 * H)[:, i * 4 * H:]
-                xa, lda = (dropped[i] if dropped is not None else (x, Dp))
-                yi = y.view(BT, nd * H)[:, i * H:]
-                if Df >= 0:
-                    # dK_x, dK_h and db of this direction in one product (dz read once); the K slices meet in a workspace
-                    # owned by this layer (its products run one after the other on one stream)
-                    # (one workspace per stream the products may run on)
-                    need = hip.lib().las_gemm_tn_lstm_workspace_bytes(Df, H, split)
-                    wss = w.__dict__.setdefault('_tn_ws', {})
-                    ws = wss.get(i % 2 if exposed else 0)
-                    if ws is None or ws.numel() * 4 < need:
-                        ws = wss[i % 2 if exposed else 0] = torch.empty(max(1, need // 4), dtype=torch.float32, device=dev)
-                    gdst = gk
-                    if Df != D:                 # padded input width: the kernel gradient at [Df + H, 4H], folded back below
-                        pads = w.__dict__.setdefault('_gk_pad', {})
-                        gdst = pads.get(i)
-                        if gdst is None:
-                            gdst = pads[i] = torch.empty(Df + H, 4 * H, dtype=torch.float32, device=dev)
-                        gdst.zero_()
-                    tok = hip.prof_begin('gemm_tn_lstm', 2.0 * (Df + H + 1) * 4 * H * BT)
-                    hip.check(hip.lib().las_gemm_tn_lstm(hip.p(xa) if Df > 0 else None, lda, Df, hip.p(yi), nd * H, H,
-                                                         (-1 if i == 0 else 1), T, hip.p(dzi), nd * 4 * H, hip.p(gdst), hip.p(gb),
-                                                         BT, split, hip.p(ws), hip.stream()))
-                    hip.prof_end(tok)
-                    if Df != D:
-                        gk[:D].add_(gdst[:D])
-                        gk[D:].add_(gdst[Df:])
-                    continue
-                if D > 0:
-                    hip.gemm_tn(xa, dzi, gk, D, 4 * H, BT, lda=lda, ldb=nd * 4 * H, ldc=4 * H, split_k=split, c_perm_h=H)
-                hip.gemm_tn(yi, dzi, gk[D:], H, 4 * H, BT, lda=nd * H, ldb=nd * 4 * H, ldc=4 * H,
-                            a_shift=(-1 if i == 0 else 1), period=T, split_k=split, c_perm_h=H)
-                hip.colsum_bf16(dzi, BT, 4 * H, gb, ldx=nd * 4 * H, perm_h=H)
-
+    if nwin > 1:
+        for wn in window_grads:
+            weight_grads(wn)
+        return dx
     if defer_weight_grads:
         return dx, weight_grads
     weight_grads()
