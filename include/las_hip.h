@@ -90,6 +90,13 @@ size_t las_gemm_nt_stream_flags(int B, int T, int ndir, int rows_per_slice);
 int las_gemm_nt_stream(const las_bf16* A, int64_t lda, const las_bf16* Bm, int64_t ldb, float* C, int64_t ldc,
                        const float* bias, const int32_t* length, int B, int T, int N, int K, int ndir,
                        int rows_per_slice, uint32_t* ready, void* stream);
+/* ... with one A operand per direction: the columns of direction d are formed from A + d * a_dir_stride (elements).  Under
+ * DropoutWrapper(input_keep_prob) the fw and bw cells of a layer read the same input through independent masks
+ * (las/ops.py:14-18): the two masked copies lie a_dir_stride apart; a MultiRNNCell stack per direction (las/model.py:111-142)
+ * reads its own column range of the layer below: a_dir_stride = that range's width. */
+int las_gemm_nt_stream_dirs(const las_bf16* A, int64_t lda, int64_t a_dir_stride, const las_bf16* Bm, int64_t ldb, float* C,
+                            int64_t ldc, const float* bias, const int32_t* length, int B, int T, int N, int K, int ndir,
+                            int rows_per_slice, uint32_t* ready, void* stream);
 
 /* C (=|+=) (A B^T) * mask / keep, mask[row, col] = [las_uniform(seed, stream_id, row * N + col) < keep]: the gradient through a
  * cell's input dropout (DropoutWrapper(input_keep_prob), las/ops.py:14-18; the mask las_dropout_bf16 drew for that cell in

@@ -43,6 +43,7 @@ struct GemmArgs {
   const int32_t* length = nullptr;
   unsigned* ready = nullptr;
   int sB = 0, sT = 0, s_ndir = 1, s_nsb = 0, sR = 4, s_nslices = 0;
+  int64_t s_astride = 0;      // direction d reads A + d * s_astride (each direction's cell behind its own input-dropout mask)
   // las_gemm_tn_lstm_window (gemm_tn_ring_kernel): the K rows are a TIME WINDOW of every utterance -- K index k = b * win_T + j
   // is row b * period + tb + j, tb = win_lo (win_len == nullptr) or win_len[b] - win_lo (windows counted from the END of each
   // utterance: the right-to-left direction of a BiLSTM); rows with t outside [0, period) read as zeros.  win_T = 0: off.
@@ -830,7 +831,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_nt_ring_kernel(GemmArgs g) {
     if (tau >= len) return -1;
     return b * g.sT + (s_d == 0 ? tau : len - 1 - tau);
   };
-  const unsigned short* A = g.A + (int64_t)batch * g.sa;
+  const unsigned short* A = g.A + (int64_t)batch * g.sa + (STREAM ? (int64_t)s_d * g.s_astride : 0);
   const unsigned short* B = g.B + (int64_t)batch * g.sb;
   const int nk = g.K / BK;
 
@@ -1190,9 +1191,20 @@ extern "C" size_t las_gemm_nt_stream_flags(int B, int T, int ndir, int rows_per_
   return (size_t)las_stream_flags_offset(ngroups) + (size_t)ngroups * ((T + sbs - 1) / sbs);
 }
 
+extern "C" int las_gemm_nt_stream_dirs(const las_bf16* A, int64_t lda, int64_t a_dir_stride, const las_bf16* Bm, int64_t ldb, float* C,
+                                       int64_t ldc, const float* bias, const int32_t* length, int B, int T, int N, int K, int ndir,
+                                       int rows_per_slice, uint32_t* ready, void* stream);
+
 extern "C" int las_gemm_nt_stream(const las_bf16* A, int64_t lda, const las_bf16* Bm, int64_t ldb, float* C, int64_t ldc,
                                   const float* bias, const int32_t* length, int B, int T, int N, int K, int ndir,
                                   int rows_per_slice, uint32_t* ready, void* stream) {
+  return las_gemm_nt_stream_dirs(A, lda, 0, Bm, ldb, C, ldc, bias, length, B, T, N, K, ndir, rows_per_slice, ready, stream);
+}
+
+extern "C" int las_gemm_nt_stream_dirs(const las_bf16* A, int64_t lda, int64_t a_dir_stride, const las_bf16* Bm, int64_t ldb, float* C,
+                                       int64_t ldc, const float* bias, const int32_t* length, int B, int T, int N, int K, int ndir,
+                                       int rows_per_slice, uint32_t* ready, void* stream) {
+  LAS_REQUIRE(a_dir_stride % 8 == 0, "las_gemm_nt_stream_dirs: the directions' operands 16-byte aligned (a_dir_stride a multiple of 8)");
   LAS_REQUIRE(A && Bm && C && length && ready && B > 0 && T > 0, "las_gemm_nt_stream: null argument or empty batch");
   LAS_REQUIRE(las_gemm_nt_stream_supported(N, K, ndir), "las_gemm_nt_stream: N = %d (per direction a multiple of 128), K = %d (multiple of 64, >= 128), ndir = %d", N, K, ndir);
   LAS_REQUIRE(rows_per_slice == 4 || rows_per_slice == 8 || rows_per_slice == 16, "las_gemm_nt_stream: rows_per_slice = the recurrence's slice height (4, 8, 16)");
@@ -1202,6 +1214,7 @@ extern "C" int las_gemm_nt_stream(const las_bf16* A, int64_t lda, const las_bf16
   g.length = length;
   g.ready = ready;
   g.sB = B; g.sT = T; g.s_ndir = ndir; g.sR = rows_per_slice;
+  g.s_astride = a_dir_stride;
   g.s_nslices = (B + rows_per_slice - 1) / rows_per_slice;
   g.s_nsb = (T + 256 / rows_per_slice - 1) / (256 / rows_per_slice);
   LAS_REQUIRE(g.s_nslices * ndir <= 256, "las_gemm_nt_stream: at most 256 chain groups");

@@ -44,6 +44,7 @@ _SIGS = {
     'las_gemm_nt_stream_supported': ([_i32, _i32, _i32], C.c_int),
     'las_gemm_nt_stream_flags': ([_i32, _i32, _i32, _i32], C.c_size_t),
     'las_gemm_nt_stream': ([_vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp], C.c_int),
+    'las_gemm_nt_stream_dirs': ([_vp, _i64, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp], C.c_int),
     'las_lstm_workspace_bytes': ([_i32, _i32, _i32], C.c_size_t),
     'las_lstm_slice_rows': ([_i32, _i32, _i32], C.c_int),
     'las_lstm_fwd_workgroups': ([_i32, _i32, _i32], C.c_int),

@@ -200,6 +200,43 @@ class LayerWeights:
             hip.bias_interleave(b, H, self.bias[i * 4 * H:(i + 1) * 4 * H])
 
 
+def _stream_setup(a, lda, a_dir_stride, weights, xproj, sequence_length, B, T, H, Dp, nd, dev):
+    """x K_x BESIDE the recurrence (las_gemm_nt_stream[_dirs]) when the shapes allow: returns (ready flags, column tiles per
+    direction, launch_product) or None.  a_dir_stride: 0 = both directions read `a`; else direction d reads a + d * stride."""
+    lib = hip.lib()
+    # the recurrence's slices must not straddle the product's 16-utterance blocks, and the chain must leave CUs to the product
+    streamed = (STREAM_X and H == 256 and B * T >= STREAM_MIN_ROWS and lib.las_gemm_nt_stream_supported(nd * 4 * H, Dp, nd) == 1
+                and 16 % max(lib.las_lstm_slice_rows(B, H, nd), 1) == 0
+                and 0 < lib.las_lstm_fwd_workgroups(B, H, nd) <= STREAM_MAX_WORKGROUPS)
+    if not streamed:
+        return None
+    # counters zeroed here, the product on its own stream (held back a few microseconds so that the chain's workgroups are
+    # resident first), the recurrence consumes the rows as they become visible
+    rows = lib.las_lstm_slice_rows(B, H, nd)
+    n = lib.las_gemm_nt_stream_flags(B, T, nd, rows)
+    ready = weights.__dict__.setdefault('_ready', {}).get((B, T, rows))
+    if ready is None:
+        ready = weights._ready[(B, T, rows)] = torch.zeros(n, dtype=torch.int32, device=dev)
+    hip.fill_many(zero=[ready])
+    cleared = torch.cuda.Event()
+    cleared.record()
+
+    def launch_product():
+        # (called once the recurrence has been ENQUEUED: an idle GPU must not start the product first -- its persistent
+        # workgroups would hold every CU while they wait for the recurrence to say where its groups run)
+        side = _product_stream()
+        side.wait_event(cleared)
+        with torch.cuda.stream(side):
+            hip.check(lib.las_stream_delay(Overlap.BESIDE_US, hip.stream()))
+            tok = hip.prof_begin('gemm_nt', 2.0 * B * T * nd * 4 * H * Dp)
+            hip.check(lib.las_gemm_nt_stream_dirs(hip.p(a), lda, a_dir_stride, hip.p(weights.kxT), Dp, hip.p(xproj), nd * 4 * H,
+                                                  hip.p(weights.bias), hip.p(sequence_length), B, T, nd * 4 * H, Dp, nd, rows,
+                                                  hip.p(ready), hip.stream()))
+            hip.prof_end(tok)
+        return side
+    return (ready, 4 * H // 128, launch_product)
+
+
 def bilstm(inputs, sequence_length, num_units, dropout, mode, unidirectional=False, *, variables=None,
            scope='', weights=None, tape=None, in_features=None, rng=None, split_inputs=False, after_projection=None):
     """las/ops.py:23-46.  inputs [B,T,Dp] bf16; sequence_length int32 [B] (CUDA).
@@ -241,6 +278,13 @@ def bilstm(inputs, sequence_length, num_units, dropout, mode, unidirectional=Fal
             pair = torch.empty(2, B, T, Dp, dtype=torch.bfloat16, device=dev)
             hip.check(hip.lib().las_dropout_bf16_pair(hip.p(inputs), Dfull, hip.p(pair[0]), hip.p(pair[1]), Dp, B * T, Dp, keep,
                                                       seed, stream0, stream0 + 1, hip.stream()))
+        # one streamed product for both directions where their operands lie a fixed stride apart: the two masked copies
+        # (pair), or the directions' own column ranges of the layer below (split_inputs without dropout)
+        if not fused:
+            if pair is not None:
+                stream_ready = _stream_setup(pair, Dp, B * T * Dp, weights, xproj, sequence_length, B, T, H, Dp, nd, dev)
+            elif split_inputs and keep == 1.0 and nd == 2:
+                stream_ready = _stream_setup(inputs, Dfull, Dp, weights, xproj, sequence_length, B, T, H, Dp, nd, dev)
         for i in range(nd):
             src = inputs[..., i * Dp:(i + 1) * Dp] if split_inputs else inputs
             if pair is not None:
@@ -253,44 +297,15 @@ def bilstm(inputs, sequence_length, num_units, dropout, mode, unidirectional=Fal
                 a, lda = xd, Dp
             else:
                 a, lda = src, Dfull
-            if not fused:
+            if not fused and stream_ready is None:
                 hip.gemm_nt(a, weights.kxT[i * 4 * H:], xproj[..., i * 4 * H:], B * T, 4 * H, Dp, lda=lda, ldb=Dp,
                             ldc=nd * 4 * H, bias=weights.bias[i * 4 * H:])
             dropped.append((a, lda))
         if fused:
             fused_x = (dropped[0][0], Dp, B * T * Dp if nd == 2 else 0)
     else:
-        lib = hip.lib()
-        # the recurrence's slices must not straddle the product's 16-utterance blocks, and the chain must leave CUs to the product
-        streamed = (STREAM_X and H == 256 and B * T >= STREAM_MIN_ROWS and lib.las_gemm_nt_stream_supported(nd * 4 * H, Dp, nd) == 1
-                    and 16 % max(lib.las_lstm_slice_rows(B, H, nd), 1) == 0
-                    and 0 < lib.las_lstm_fwd_workgroups(B, H, nd) <= STREAM_MAX_WORKGROUPS)
-        if streamed:
-            # x K_x BESIDE the recurrence: counters zeroed here, the product on its own stream (held back a few microseconds
-            # so that the chain's workgroups are resident first), the recurrence consumes the rows as they become visible
-            rows = lib.las_lstm_slice_rows(B, H, nd)
-            n = lib.las_gemm_nt_stream_flags(B, T, nd, rows)
-            ready = weights.__dict__.setdefault('_ready', {}).get((B, T, rows))
-            if ready is None:
-                ready = weights._ready[(B, T, rows)] = torch.zeros(n, dtype=torch.int32, device=dev)
-            hip.fill_many(zero=[ready])
-            cleared = torch.cuda.Event()
-            cleared.record()
-
-            def launch_product():
-                # (called once the recurrence has been ENQUEUED: an idle GPU must not start the product first -- its persistent
-                # workgroups would hold every CU while they wait for the recurrence to say where its groups run)
-                side = _product_stream()
-                side.wait_event(cleared)
-                with torch.cuda.stream(side):
-                    hip.check(lib.las_stream_delay(Overlap.BESIDE_US, hip.stream()))
-                    tok = hip.prof_begin('gemm_nt', 2.0 * B * T * nd * 4 * H * Dp)
-                    hip.check(lib.las_gemm_nt_stream(hip.p(inputs), Dp, hip.p(weights.kxT), Dp, hip.p(xproj), nd * 4 * H, hip.p(weights.bias),
-                                                     hip.p(sequence_length), B, T, nd * 4 * H, Dp, nd, rows, hip.p(ready), hip.stream()))
-                    hip.prof_end(tok)
-                return side
-            stream_ready = (ready, 4 * H // 128, launch_product)
-        else:
+        stream_ready = _stream_setup(inputs, Dp, 0, weights, xproj, sequence_length, B, T, H, Dp, nd, dev)
+        if stream_ready is None:
             hip.gemm_nt(inputs, weights.kxT, xproj, B * T, nd * 4 * H, Dp, lda=Dp, ldb=Dp, ldc=nd * 4 * H,
                         bias=weights.bias)
     if after_projection is not None:

@@ -231,6 +231,43 @@ def test_streamed_input_product_matches_the_product_before_the_recurrence(B, T, 
     assert float(((ca - cb) * mask).abs().max()) < 3e-2
 
 
+@pytest.mark.parametrize('mode', ['dropout', 'split'])
+def test_streamed_input_product_with_one_operand_per_direction(mode, monkeypatch):
+    """las_gemm_nt_stream_dirs: the streamed product when the two directions read DIFFERENT operands -- the two masked copies of
+    the input under DropoutWrapper (independent masks for the fw and bw cells), or each direction's own column range of the
+    layer below (the stacked listener's split inputs).  Against the products before the recurrence, repeated (race check)."""
+    from phones_las_amd.las import ops
+    monkeypatch.setattr(ops, 'STREAM_MIN_ROWS', 0)
+    B, T, D, H = 19, 23, 128, 256
+    lengths = [T - (i * 5) % T for i in range(B)]
+    x, length, var = _setup(B, T, D, H, lengths)
+    dvar = {k: v.float().cuda() for k, v in var.items()}
+    xd = (x * 0.25).to(torch.bfloat16).cuda()
+    if mode == 'split':
+        xd = torch.cat([xd, torch.flip(xd, dims=[2])], -1).contiguous()          # [B, T, 2 D]: the directions' own columns
+    ld = length.to(torch.int32).cuda()
+    kw = dict(rng=(77, 40)) if mode == 'dropout' else dict(split_inputs=True)
+    out = {}
+    for streamed in (False, True, True):
+        monkeypatch.setattr(ops, 'STREAM_X', streamed)
+        tape = []
+        (ofw, obw), st = ops.bilstm(xd, ld, H, 0.25 if mode == 'dropout' else 0.0, ops.TRAIN, variables=dvar, scope='L', tape=tape, **kw)
+        torch.cuda.synchronize()
+        ops.check_lstm_status(B, H, 2)
+        got = (ops.concat_outputs((ofw, obw)).float().clone(), tape[0]['gates'].clone(), tape[0]['cbuf'].clone())
+        mask = (torch.arange(T, device='cuda')[None, :] < ld[:, None])[..., None]
+        if streamed not in out:
+            out[streamed] = got
+        else:
+            for a, b in zip(got, out[streamed]):
+                assert torch.equal(a * mask, b * mask)
+    (ya, ga, ca), (yb, gb, cb) = out[True], out[False]
+    assert float(((ga - gb) * mask).abs().max()) < 2e-2
+    assert float((ya - yb).abs().max()) <= 2 ** -6
+    assert float(((ca - cb) * mask).abs().max()) < 3e-2
+    assert float(ga.abs().max()) > 0.1
+
+
 @pytest.mark.parametrize('B,T,H,ragged', [(6, 96, 64, True), (9, 130, 256, True), (64, 128, 256, False), (10, 80, 512, True), (5, 70, 128, True)])
 def test_backward_recurrence_in_time_windows_is_the_one_launch_bit_for_bit(B, T, H, ragged):
     """las_lstm_recurrent_bwd_window: the backward chain over the steps [s_lo, s_hi) only, d(h) / d(c) handed from launch to
