@@ -6,6 +6,14 @@
 #include <stdarg.h>
 #include "../../include/las_hip.h"
 
+// One target, stated to the compiler: the fence-free "last workgroup adds up" reductions (optim.hip, decoder.hip)
+// order their relaxed stores with s_waitcnt vmcnt(0) because gfx950 acknowledges sc1 write-through stores at the coherence
+// point, and the XCD-local exchanges rely on one L2 per XCD; neither is a property of the HIP memory model.  Another target
+// must not compile this code silently.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
+#error "liblas_hip is written for gfx950 (MI355X) only"
+#endif
+
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
 typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
