@@ -144,6 +144,7 @@ FUSED_X = os.environ.get('LAS_LSTM_FUSED_X', '1') != '0'
 # layers; at 512 units the product beside the chain cost more than it hid: metric-L 17.83 against 17.69 ms): the product
 # (las_gemm_nt_stream) runs on a second stream BESIDE the recurrence and hands its rows over step block by step block.
 STREAM_X = os.environ.get('LAS_LSTM_STREAM', '1') != '0'
+STREAM_512 = os.environ.get('LAS_LSTM_STREAM_512', '0') != '0'      # (diagnostics: stream at 512 units too)
 STREAM_MIN_ROWS = int(os.environ.get('LAS_LSTM_STREAM_MIN_ROWS', '4096'))      # smaller products are not worth the hand-over
 STREAM_MAX_WORKGROUPS = 192       # the recurrence (members + companions, a CU each) must leave CUs to the product beside it
 _PRODUCT_STREAMS = {}
@@ -205,7 +206,7 @@ def _stream_setup(a, lda, a_dir_stride, weights, xproj, sequence_length, B, T, H
     direction, launch_product) or None.  a_dir_stride: 0 = both directions read `a`; else direction d reads a + d * stride."""
     lib = hip.lib()
     # the recurrence's slices must not straddle the product's 16-utterance blocks, and the chain must leave CUs to the product
-    streamed = (STREAM_X and H == 256 and B * T >= STREAM_MIN_ROWS and lib.las_gemm_nt_stream_supported(nd * 4 * H, Dp, nd) == 1
+    streamed = (STREAM_X and (H == 256 or (H == 512 and STREAM_512)) and B * T >= STREAM_MIN_ROWS and lib.las_gemm_nt_stream_supported(nd * 4 * H, Dp, nd) == 1
                 and 16 % max(lib.las_lstm_slice_rows(B, H, nd), 1) == 0
                 and 0 < lib.las_lstm_fwd_workgroups(B, H, nd) <= STREAM_MAX_WORKGROUPS)
     if not streamed:
