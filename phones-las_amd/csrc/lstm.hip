@@ -750,7 +750,9 @@ __global__ __launch_bounds__(256) void lstm_fwd_kernel(float* __restrict__ xproj
 // rows can then run beside the next window's chain (las_gemm_tn_lstm's row window) instead of behind the whole layer.
 struct BwdWindow { int s_lo, s_hi; float* dc_out; float* dh_out; };
 
-template <int H, int ROWS, int G>            // ROWS: utterances per slice, G: members, as in lstm_fwd_kernel
+// WIN (compile time): the windowed form.  The one-launch form is its own instantiation -- with the window's bounds as run-time
+// values in the loop conditions the 128-unit chains ran 17-23 % slower (cfg1, default-arch: measured), the 256 / 512-unit ones 1 %.
+template <int H, int ROWS, int G, bool WIN = false>     // ROWS: utterances per slice, G: members, as in lstm_fwd_kernel
 __device__ __forceinline__ void lstm_bwd_body(const float* __restrict__ gates, const float* __restrict__ cbuf,
                                               const float* __restrict__ dy, const float* __restrict__ dc_last,
                                               const float* __restrict__ dh_last, const unsigned short* __restrict__ kh,
@@ -811,7 +813,7 @@ __device__ __forceinline__ void lstm_bwd_body(const float* __restrict__ gates, c
     smin = -(int)las_wave_max((float)(-ll));
   }
   if ((int64_t)B * T * grow * 4 >= ((int64_t)1 << 32)) smin = 0;     // 32-bit byte offsets do not reach: general path only
-  const int s_lo = max(win.s_lo, 0), s_start = min(smax, win.s_hi) - 1;     // this launch's steps: s_start down to s_lo
+  const int s_lo = WIN ? max(win.s_lo, 0) : 0, s_start = (WIN ? min(smax, win.s_hi) : smax) - 1;     // this launch's steps: s_start down to s_lo
 
   if (companion) {
     // PREFETCH COMPANION (see lstm_fwd_kernel): gates, c and dy lines of the whole group, PF_AHEAD steps ahead.
@@ -821,7 +823,7 @@ __device__ __forceinline__ void lstm_bwd_body(const float* __restrict__ gates, c
     // (the launch of the window that reaches the end of the sequences does it)
     for (int rr = wave * (ROWS / 4); rr < (wave + 1) * (ROWS / 4); ++rr) {
       const int bb = slice * ROWS + rr;
-      if (bb >= B || win.s_hi < T) continue;
+      if (bb >= B || (WIN && win.s_hi < T)) continue;
       const int ll = __builtin_amdgcn_readlane(mylen, rr);
       constexpr int LPR = 4 * H * 2 / 16 / CPG;
       for (int e = ll * LPR + lane; e < T * LPR; e += 64) {
@@ -1012,7 +1014,7 @@ __device__ __forceinline__ void lstm_bwd_body(const float* __restrict__ gates, c
   int cur = 0;
   unsigned epoch = 0;          // = iterations done; partial sums sent in iteration i carry tag i+1 in parity slot i&1
   bool ok = true;
-  set_goff(max(min(smin - 1, s_start), 0));
+  set_goff(WIN ? max(min(smin - 1, s_start), 0) : (smin > 0 ? smin - 1 : 0));
   load_general(s_start);
   prepare();
   // one time step; LEAN (compile time): every row of the slice is running at step s (and at s - 1: the lean loader).
@@ -1168,9 +1170,14 @@ __device__ __forceinline__ void lstm_bwd_body(const float* __restrict__ gates, c
   {
     int s = s_start;
     bool go = true;
-    for (; s >= smin && s >= s_lo && go; --s) go = iter(s, std::false_type{});
-    for (; s >= s_lo && go; --s) go = iter(s, std::true_type{});
-    if (s_lo > 0) {
+    if constexpr (WIN) {
+      for (; s >= smin && s >= s_lo && go; --s) go = iter(s, std::false_type{});
+      for (; s >= s_lo && go; --s) go = iter(s, std::true_type{});
+    } else {
+      for (; s >= smin && go; --s) go = iter(s, std::false_type{});
+      for (; s >= 0 && go; --s) go = iter(s, std::true_type{});
+    }
+    if (WIN && s_lo > 0) {
       // ---- end of a time window: complete dh_{s_lo - 1} (the partial sums of the last iteration are on their way) and hand
       //      d(h), d(c) to the next window's launch (a slice that is over before the window: its initial values).  A copy of
       //      the poll at the top of iter(): the hot loop stays as it is. ----
@@ -1210,7 +1217,7 @@ __device__ __forceinline__ void lstm_bwd_body(const float* __restrict__ gates, c
   if (!ok && tid == 0) atomicOr(status, 2u);
 }
 
-template <int H, int ROWS, int G = coop_members(H)>
+template <int H, int ROWS, int G = coop_members(H), bool WIN = false>
 __global__ __launch_bounds__(256) void lstm_bwd_kernel(const float* __restrict__ gates, const float* __restrict__ cbuf,
                                                        const float* __restrict__ dy, const float* __restrict__ dc_last,
                                                        const float* __restrict__ dh_last, const unsigned short* __restrict__ kh,
@@ -1218,7 +1225,7 @@ __global__ __launch_bounds__(256) void lstm_bwd_kernel(const float* __restrict__
                                                        u64* __restrict__ exch, unsigned* __restrict__ status,
                                                        int B, int T, int ndir, int ngroups, long long exch_words, const BwdWindow win) {
   const unsigned base = launch_base(status);
-  lstm_bwd_body<H, ROWS, G>(gates, cbuf, dy, dc_last, dh_last, kh, length, dz, exch, status, B, T, ndir, ngroups, base, win);
+  lstm_bwd_body<H, ROWS, G, WIN>(gates, cbuf, dy, dc_last, dh_last, kh, length, dz, exch, status, B, T, ndir, ngroups, base, win);
   launch_arrive(status, base, T, exch, exch_words);
 }
 
@@ -1386,11 +1393,17 @@ int launch_bwd_as(const float* gates, const float* cbuf, const float* dy, const 
     constexpr int static_kb = (2 * 16 * (4 * HS_ + 8) * 2 + 1024 + 1023) / 1024 + 1;
     hog_kb = e ? atoi(e) : 160 - static_kb - 6;
     if (hog_kb > 160 - static_kb - 2) hog_kb = 160 - static_kb - 2;
-    if (hog_kb > 0)
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&lstm_bwd_kernel<H, ROWS, G>), hipFuncAttributeMaxDynamicSharedMemorySize, hog_kb * 1024);
+    if (hog_kb > 0) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&lstm_bwd_kernel<H, ROWS, G, false>), hipFuncAttributeMaxDynamicSharedMemorySize, hog_kb * 1024);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&lstm_bwd_kernel<H, ROWS, G, true>), hipFuncAttributeMaxDynamicSharedMemorySize, hog_kb * 1024);
+    }
   }
-  hipLaunchKernelGGL((lstm_bwd_kernel<H, ROWS, G>), dim3(pf ? g.blocks + g.companions : g.blocks), dim3(256), (size_t)(hog_kb > 0 ? hog_kb : 0) * 1024, st,
-                     gates, cbuf, dy, dc_last, dh_last, kh, length, dz, exch, status, B, T, ndir, g.ngroups, exch_words(B, H, ndir), win);
+  if (win.s_lo > 0 || win.s_hi < T)
+    hipLaunchKernelGGL((lstm_bwd_kernel<H, ROWS, G, true>), dim3(pf ? g.blocks + g.companions : g.blocks), dim3(256), (size_t)(hog_kb > 0 ? hog_kb : 0) * 1024, st,
+                       gates, cbuf, dy, dc_last, dh_last, kh, length, dz, exch, status, B, T, ndir, g.ngroups, exch_words(B, H, ndir), win);
+  else
+    hipLaunchKernelGGL((lstm_bwd_kernel<H, ROWS, G, false>), dim3(pf ? g.blocks + g.companions : g.blocks), dim3(256), (size_t)(hog_kb > 0 ? hog_kb : 0) * 1024, st,
+                       gates, cbuf, dy, dc_last, dh_last, kh, length, dz, exch, status, B, T, ndir, g.ngroups, exch_words(B, H, ndir), win);
   LAS_LAUNCH_CHECK("lstm bwd launch");
   return LAS_OK;
 }
