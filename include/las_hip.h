@@ -469,6 +469,13 @@ typedef struct las_dec_persist {
   las_bf16* h1;
   int32_t win0, win1;            /* masked leading columns of cell 0's operand row (the attention feed) and of cell 1's */
   uint32_t in_stream0, in_stream1;
+  /* Dense token feed (embedding_size > 0 under input dropout, las/model.py:230-237; s.tok_rows NULL): the operand rows carry the
+   * (masked) embedded token in their first T0 columns, filled by the caller for the teacher's tokens; win0 = T0 + M,
+   * s.feed_width = win0.  Under scheduled sampling the launch rewrites those columns of row t+1 for a sampled token from
+   * emb [V, >= T0] bf16 (row stride ld_emb, zero beyond the embedding width). */
+  const las_bf16* emb;
+  int64_t ld_emb;
+  int32_t T0, reserved_t0;
 } las_dec_persist;
 int las_decoder_persist_supported(int Hd, int M, int K_in, int attention, int norm);   /* 1 if the shapes fit */
 int las_decoder_persist2_supported(int Hd, int M, int K_in, int K1_in, int attention, int wiring);   /* ... with a second cell */
@@ -650,11 +657,12 @@ int las_dropout_bf16(const las_bf16* x, int64_t ldx, las_bf16* y, int64_t ldy, i
 int las_dropout_bf16_pair(const las_bf16* x, int64_t ldx, las_bf16* y0, las_bf16* y1, int64_t ldy, int rows, int cols,
                           float keep, uint32_t seed, uint32_t stream0, uint32_t stream1, void* stream);
 /* The input masks of U decoder steps in one pass, in place: element (b, t, c), c < cols, at x[b * ldb + t * ldt + c] is scaled by
- * draw (seed, stream0 + t, b * cols + c) -- U x las_dropout_bf16(rows = B, stream = stream0 + t).  The two-cell one-launch
+ * draw (seed, stream0 + t, b * idx_cols + c) (idx_cols >= cols: the width of the masked window these columns lead; 0 = cols)
+ * -- U x las_dropout_bf16(rows = B, stream = stream0 + t).  The two-cell one-launch
  * decoder leaves its operand rows undropped; the weight-gradient products (las/model.py:194-200 cells under
  * DropoutWrapper, las/ops.py:14-18) read them dropped.  cols, ldb, ldt: multiples of 8. */
-int las_dropout_bf16_steps(las_bf16* x, int64_t ldb, int64_t ldt, int B, int U, int cols, float keep, uint32_t seed,
-                           uint32_t stream0, void* stream);
+int las_dropout_bf16_steps(las_bf16* x, int64_t ldb, int64_t ldt, int B, int U, int cols, int idx_cols, float keep,
+                           uint32_t seed, uint32_t stream0, void* stream);
 /* out = a * mask(stream_a)/keep (+ b * mask(stream_b)/keep when b != NULL); contiguous [rows, cols] fp32. */
 int las_dropout_bwd(const float* a, const float* b, float* out, int rows, int cols, float keep, uint32_t seed,
                     uint32_t stream_a, uint32_t stream_b, void* stream);

@@ -705,7 +705,9 @@ __device__ __forceinline__ void dec_step_fwd_body(const las_dec_step& s, const i
         unsigned short o2 = o;
         if (s.drop_keep < 1.0f && s.feed_plain != 1) {   // the copy that feeds step t+1's cell goes through that step's input dropout
           // (feed_plain 2: the step-by-step path's draws -- one generator stream per step, element index b * M + column)
-          const unsigned long long idx = s.feed_plain == 2 ? (unsigned long long)b * M + cb + j
+          // (feed_plain 2 without token rows -- a dense token vector in front of the feed --: the masked window is feed_width wide)
+          const int W2 = s.tok_rows ? M : max(s.feed_width, M);
+          const unsigned long long idx = s.feed_plain == 2 ? (unsigned long long)b * W2 + (W2 - M) + cb + j
                                          : ((unsigned long long)(s.step + 1) * s.B + b) * s.feed_width + (s.feed_width - M) + cb + j;
           const unsigned stream = s.feed_plain == 2 ? s.feed_stream0 + (unsigned)(s.step + 1) : s.drop_stream;
           o2 = s.feed_plain == 2 ? (las_uniform(s.drop_seed, stream, idx) < s.drop_keep ? las_f2bf(las_bf2f(o) * (1.0f / s.drop_keep)) : (unsigned short)0)
@@ -1270,6 +1272,19 @@ __global__ __launch_bounds__(256) void dec_persist_fwd_kernel(las_dec_persist p)
             out = arg;
           }
           if (lane == 0) const_cast<int32_t*>(s0.tok_ids)[(int64_t)bs * s0.tok_stride + t + 1] = out;   // else: the teacher's, already there
+          if constexpr (TWO) {
+            if (p.emb) {
+              // dense token feed (embedding_size > 0 under input dropout): the host filled the operand rows with the teacher's
+              // embedded tokens; a sampled token replaces the next row's token columns (through that step's input mask)
+              const float kp = s0.drop_keep;
+              for (int c = lane; c < p.T0; c += 64) {
+                float v = las_bf2f(p.emb[(int64_t)out * p.ld_emb + c]);
+                if (kp < 1.0f)
+                  v = las_uniform(s0.drop_seed, p.in_stream0 + (unsigned)(t + 1), (unsigned long long)bs * p.win0 + c) < kp ? v * (1.0f / kp) : 0.f;
+                const_cast<unsigned short*>(p.x)[(int64_t)bs * p.ldx + (int64_t)(t + 1) * p.inc_x + c] = las_f2bf(v);
+              }
+            }
+          }
         }
       }
       }
@@ -3160,6 +3175,7 @@ __global__ __launch_bounds__(256) void dec_persist_bwd_kernel(las_dec_persist_bw
   auto in_mask = [&](int l, int tt, int col) -> float {
     if (!(keep < 1.0f)) return 1.0f;
     const int win = l == 0 ? p.win0 : p.win1;
+    if (l == 0) col += p.win0 - M;       // (a dense token vector in front of cell 0's attention feed)
     return las_uniform(s0.drop_seed, (l == 0 ? p.in_stream0 : p.in_stream1) + (unsigned)tt, (unsigned long long)b * win + col) < keep ? inv_keep : 0.f;
   };
   // the plain cell's backward at step t (part 0, unit = thread): dh from the sources the wiring names, dz_t (bf16) out
@@ -4201,7 +4217,7 @@ extern "C" int las_decoder_persist_fwd(const las_dec_persist* p, void* stream) {
               s->attention, s->norm);
   LAS_REQUIRE(!al_path || two || (p->sampling_prob <= 0.f && s->drop_keep >= 1.0f), "las_decoder_persist_fwd: attention layer / monotonic "
               "normalisers inside the launch: without scheduled sampling and input dropout");
-  LAS_REQUIRE(!two || s->drop_keep >= 1.0f || (p->win0 == s->M && p->win1 > 0 && p->win1 % 8 == 0 && p->win1 <= p->K1_in),
+  LAS_REQUIRE(!two || s->drop_keep >= 1.0f || (p->win0 >= s->M && p->win0 % 8 == 0 && p->win0 <= p->K_in && p->win1 > 0 && p->win1 % 8 == 0 && p->win1 <= p->K1_in),
               "las_decoder_persist_fwd: second cell with input dropout: win0 / win1 (masked columns of the two operand rows, multiples of 8)");
   LAS_REQUIRE(!two || p->sampling_prob <= 0.f || (p->wiring == 0 ? p->ldw >= s->M : (p->ldw >= s->Hd && s->Hd % 32 == 0)),
               "las_decoder_persist_fwd: second cell with scheduled sampling: projection rows of the output width");
@@ -4364,8 +4380,8 @@ extern "C" int las_decoder_persist_bwd(const las_dec_persist_bwd* p, void* strea
                        p->dc1 && p->ldk1 >= 4 * s->Hd && p->ldk1 % 8 == 0 && (p->wiring == 0 ? s->dctx_a != nullptr : (p->d_out1 != nullptr && !s->dctx_a))),
               "las_decoder_persist_bwd: second cell: unsupported configuration or missing buffers (Hd=%d M=%d W=%d W1=%d wiring=%d)", s->Hd, s->M,
               p->W, p->W1, p->wiring);
-  LAS_REQUIRE(!two || s->drop_keep >= 1.0f || (p->win0 == s->M && p->win1 > 0 && p->win1 <= p->W1),
-              "las_decoder_persist_bwd: second cell with input dropout: win0 (= M) / win1");
+  LAS_REQUIRE(!two || s->drop_keep >= 1.0f || (p->win0 >= s->M && p->win1 > 0 && p->win1 <= p->W1),
+              "las_decoder_persist_bwd: second cell with input dropout: win0 (>= M) / win1");
   LAS_REQUIRE(two || s->drop_keep >= 1.0f || s->feed_width >= s->M, "las_decoder_persist_bwd: feed_width");
   LAS_REQUIRE(p->kc && p->dfeed_all && p->workspace && ((uintptr_t)p->workspace % 128 == 0) && (s->dctx_a || two) && s->dc && s->dz && s->ds_out &&
                   s->align && s->gates && s->c_new && s->c_prev && s->keys && s->values && s->mem_len,

@@ -49,7 +49,7 @@ __global__ void dropout_bf16_pair_kernel(const unsigned short* x, int64_t ldx, u
 // the input masks of U decoder steps in one pass, in place: element (b, t, c), c < cols, of rows x[b * ldb + t * ldt ..] is
 // draw (seed, stream0 + t, b * cols + c) -- U x las_dropout_bf16 with the streams stream0 + t (the one-launch decoders leave
 // the operand rows undropped; the weight-gradient products read them dropped)
-__global__ void dropout_bf16_steps_kernel(unsigned short* x, int64_t ldb, int64_t ldt, int B, int U, int cols, float keep,
+__global__ void dropout_bf16_steps_kernel(unsigned short* x, int64_t ldb, int64_t ldt, int B, int U, int cols, int idx_cols, float keep,
                                           unsigned seed, unsigned stream0) {
   const float inv = 1.0f / keep;
   const int c8 = cols / 8;
@@ -59,7 +59,7 @@ __global__ void dropout_bf16_steps_kernel(unsigned short* x, int64_t ldb, int64_
     unsigned short* row = x + (int64_t)b * ldb + (int64_t)t * ldt + c;
     uint4 v = *reinterpret_cast<const uint4*>(row);
     unsigned short* e = reinterpret_cast<unsigned short*>(&v);
-    const unsigned long long base = (unsigned long long)b * cols + c;
+    const unsigned long long base = (unsigned long long)b * idx_cols + c;
 #pragma unroll
     for (int j = 0; j < 8; ++j) e[j] = las_f2bf(las_bf2f(e[j]) * (las_uniform(seed, stream0 + (unsigned)t, base + j) < keep ? inv : 0.f));
     *reinterpret_cast<uint4*>(row) = v;
@@ -188,13 +188,14 @@ extern "C" int las_dropout_bf16_pair(const las_bf16* x, int64_t ldx, las_bf16* y
   return LAS_OK;
 }
 
-extern "C" int las_dropout_bf16_steps(las_bf16* x, int64_t ldb, int64_t ldt, int B, int U, int cols, float keep, uint32_t seed,
-                                      uint32_t stream0, void* stream) {
-  LAS_REQUIRE(x && B > 0 && U > 0 && cols > 0 && keep > 0.f && keep <= 1.f, "las_dropout_bf16_steps: bad arguments");
+extern "C" int las_dropout_bf16_steps(las_bf16* x, int64_t ldb, int64_t ldt, int B, int U, int cols, int idx_cols, float keep,
+                                      uint32_t seed, uint32_t stream0, void* stream) {
+  if (idx_cols <= 0) idx_cols = cols;
+  LAS_REQUIRE(x && B > 0 && U > 0 && cols > 0 && idx_cols >= cols && keep > 0.f && keep <= 1.f, "las_dropout_bf16_steps: bad arguments");
   LAS_REQUIRE(cols % 8 == 0 && ldb % 8 == 0 && ldt % 8 == 0 && ((uintptr_t)x % 16 == 0),
               "las_dropout_bf16_steps: columns and strides in multiples of 8, 16-byte aligned rows");
   hipLaunchKernelGGL(dropout_bf16_steps_kernel, dim3(blocks_for((int64_t)B * U * (cols / 8))), dim3(256), 0, (hipStream_t)stream, x, ldb,
-                     ldt, B, U, cols, keep, seed, stream0);
+                     ldt, B, U, cols, idx_cols, keep, seed, stream0);
   LAS_LAUNCH_CHECK("dropout steps launch");
   return LAS_OK;
 }

@@ -87,7 +87,7 @@ _SIGS = {
     'las_normalize_pad_bf16': ([_vp, _vp, _vp, _vp, _i32, _vp, _i32, _i32, _i32, _vp, _vp], C.c_int),
     'las_dropout_bf16': ([_vp, _i64, _vp, _i64, _i32, _i32, _f32, C.c_uint32, C.c_uint32, _vp], C.c_int),
     'las_dropout_bf16_pair': ([_vp, _i64, _vp, _vp, _i64, _i32, _i32, _f32, C.c_uint32, C.c_uint32, C.c_uint32, _vp], C.c_int),
-    'las_dropout_bf16_steps': ([_vp, _i64, _i64, _i32, _i32, _i32, _f32, C.c_uint32, C.c_uint32, _vp], C.c_int),
+    'las_dropout_bf16_steps': ([_vp, _i64, _i64, _i32, _i32, _i32, _i32, _f32, C.c_uint32, C.c_uint32, _vp], C.c_int),
     'las_dropout_bwd': ([_vp, _vp, _vp, _i32, _i32, _f32, C.c_uint32, C.c_uint32, C.c_uint32, _vp], C.c_int),
     'las_dropout_mask': ([_vp, _i64, _f32, C.c_uint32, C.c_uint32, _vp], C.c_int),
     'las_onehot_bf16': ([_vp, _i64, _i32, _i32, _i32, _vp, _i64, _f32, C.c_uint32, C.c_uint32, _i32, _vp], C.c_int),
@@ -159,7 +159,8 @@ class DecPersist(C.Structure):
         ('bproj', _vp), ('logits', _vp), ('ld_logits', _i64), ('plog', _vp), ('V', _i32), ('Vp', _i32),
         ('walT', _vp), ('ld_wal', _i64), ('A', _i32), ('x_att_off', _i32), ('att_out', _vp), ('ld_att', _i64), ('inc_p', _i64),
         ('k1T', _vp), ('ldk1', _i64), ('K1_in', _i32), ('wiring', _i32), ('bias1', _vp), ('c1', _vp), ('gates1', _vp), ('h1', _vp),
-        ('win0', _i32), ('win1', _i32), ('in_stream0', C.c_uint32), ('in_stream1', C.c_uint32)]
+        ('win0', _i32), ('win1', _i32), ('in_stream0', C.c_uint32), ('in_stream1', C.c_uint32),
+        ('emb', _vp), ('ld_emb', _i64), ('T0', _i32), ('reserved_t0', _i32)]
 
 
 class DecStepBwd(C.Structure):

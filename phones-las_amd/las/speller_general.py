@@ -497,14 +497,15 @@ class GeneralSpeller:
 
     def _persist2_ok(self, B, Tm, keep, sampling, input_vectors):
         """Two decoder cells (the reference's default depth) in ONE forward launch (round 4): both wirings, softmax attentions,
-        one-hot tokens, no attention layer; input dropout and scheduled sampling (the reference's defaults: dropout 0.2,
+        one-hot or embedded tokens (embedding_size > 0: a row table without dropout, the dense token vector in the operand
+        row with it), no attention layer; input dropout and scheduled sampling (the reference's defaults: dropout 0.2,
         sampling_probability 0.1) inside the launch.  LAS_DEC_PERSIST2=0: step by step."""
         import os
         if os.environ.get('LAS_DEC_PERSIST', '1') == '0' or os.environ.get('LAS_DEC_PERSIST2', '1') == '0':
             return False
-        if self.NL != 2 or self.tokx or self.emb or self.sigmoid or self.has_al or self.mono or self.custom:
+        if self.NL != 2 or self.sigmoid or self.has_al or self.mono or self.custom or self.binf is not None:
             return False
-        if input_vectors is not None or self.Vop > 1024 or (keep < 1.0 and (self.win[0] != self.M or self.win[1] % 8)):
+        if input_vectors is not None or self.Vop > 1024 or (keep < 1.0 and (self.win[0] != self.T0 + self.M or self.win[1] % 8)):
             return False
         lib = hip.lib()
         Kp = (self.win[0] + self.Hd + 63) // 64 * 64
@@ -517,9 +518,10 @@ class GeneralSpeller:
         dev, bf, f32 = sv['memory'].device, torch.bfloat16, torch.float32
         lib, st = hip.lib(), hip.stream()
         Tmp = _r8(Tm)
-        W0 = self.win[0] + Hd                                  # [attention_{t-1} | h_{t-1}]: the cell kernel's rows behind the token rows
+        W0 = self.win[0] + Hd                                  # [(token) | attention_{t-1} | h_{t-1}]: the cell kernel's rows behind the token rows
         Kp = (W0 + 63) // 64 * 64                              # operand rows of whole 128-byte lines
-        feed = A if self.has_al else M                         # what is fed back: attention_t, or the context itself
+        T0 = self.T0 if two else 0                             # dense token vector in front (embedding_size > 0 under dropout)
+        feed = T0 + (A if self.has_al else M)                  # column of h: behind what is fed back (attention_t, or the context itself)
         Xp = torch.zeros(B, U, Kp, dtype=bf, device=dev)
         Xp[:, 0, feed:feed + Hd].copy_(init[0][1])
         sv['cs'][0][:, 0].copy_(init[0][0])
@@ -534,7 +536,7 @@ class GeneralSpeller:
         p = hip.DecPersist()
         s = p.s
         s.B, s.Hd, s.M, s.Tm, s.attention, s.mode = B, Hd, M, Tm, self.att, 0
-        s.tok_rows, s.tok_ids, s.tok_stride = hip.addr(self.tok), hip.addr(fed), fed.stride(0)
+        s.tok_rows, s.tok_ids, s.tok_stride = (0 if T0 else hip.addr(self.tok)), hip.addr(fed), fed.stride(0)
         s.bias = hip.addr(self.bias[0])
         s.c_prev, s.ldcp = hip.addr(sv['cs'][0]), (U + 1) * Hd
         s.gates_out, s.ldg = hip.addr(sv['gates'][0]), U * 4 * Hd
@@ -550,11 +552,20 @@ class GeneralSpeller:
         s.align_out, s.align_bf16, s.lda = hip.addr(sv['align']), hip.addr(sv['align_bf']), U * Tmp
         s.ctx_out, s.ldc = hip.addr(sv['ctx']), U * M
         if not self.has_al:                                    # the context is the feed: straight into the next operand row
-            s.ctx_out2, s.ldc2 = (hip.addr(Xp, Kp) if U > 1 else 0), U * Kp
+            s.ctx_out2, s.ldc2 = (hip.addr(Xp, Kp + T0) if U > 1 else 0), U * Kp
         s.drop_keep, s.feed_width = 1.0, self.E + A
         if keep < 1.0:                                         # the token row's scale: cell 0's draws of the step-by-step path
             s.drop_keep, s.drop_seed, s.drop_stream = keep, sv['seed'], self.DEC_STREAM
             p.win0, p.win1, p.in_stream0, p.in_stream1 = self.win[0], self.win[1], self.in_stream(0, 0), self.in_stream(1, 0)
+        if T0:
+            # dense token feed: the teacher's embedded tokens into the first T0 columns of every operand row, through the steps'
+            # input masks (the launch rewrites a row whose token it samples); the feed's mask window is win0 wide
+            Xp[:, :, :self.Ep].copy_(self.emb_bf[fed.long()])
+            if keep < 1.0:
+                hip.check(lib.las_dropout_bf16_steps(hip.addr(Xp), U * Kp, Kp, B, U, T0, self.win[0], keep, sv['seed'],
+                                                     self.in_stream(0, 0), st))
+            s.feed_width = self.win[0]
+            p.emb, p.ld_emb, p.T0 = hip.addr(self.emb_bf), self.Ep, T0
         s.norm = sv['norm']
         if self.mono:
             s.score_bias = hip.addr(self.score_bias)
@@ -605,7 +616,7 @@ class GeneralSpeller:
                 sv['X'][1] = torch.cat([sv['h'][0], h1[:, :U]], -1)
             if keep < 1.0:      # the weight-gradient products read the rows as the cells saw them: dropped (cell 0's already are)
                 K1 = self.win[1] + Hd
-                hip.check(lib.las_dropout_bf16_steps(hip.addr(sv['X'][1]), U * K1, K1, B, U, self.win[1], keep, sv['seed'],
+                hip.check(lib.las_dropout_bf16_steps(hip.addr(sv['X'][1]), U * K1, K1, B, U, self.win[1], 0, keep, sv['seed'],
                                                      self.in_stream(1, 0), st))
         if self.has_al:
             sv['qc'][:, :, :Hd].copy_(sv['h'][0])
@@ -637,13 +648,13 @@ class GeneralSpeller:
             return False
         if os.environ.get('LAS_DEC_PERSIST2_BWD', '1') == '0' or self.debug_hook is not None or sv.get('dreg') is not None:
             return False
-        if self.NL != 2 or self.tokx or self.emb or self.sigmoid or self.has_al or self.mono or self.custom:
+        if self.NL != 2 or self.sigmoid or self.has_al or self.mono or self.custom or self.binf is not None:
             return False
-        if sv['keep'] < 1.0 and (self.win[0] != self.M or self.win[1] % 8):
+        if sv['keep'] < 1.0 and (self.win[0] != self.T0 + self.M or self.win[1] % 8):
             return False
         lib = hip.lib()
         return (sv['B'] <= 4 * lib.las_decoder_persist_max_batch() and
-                lib.las_decoder_persist2_bwd_supported(self.Hd, self.M, self.win[0] + self.Hd, self.win[1] + self.Hd, self.att,
+                lib.las_decoder_persist2_bwd_supported(self.Hd, self.M, self.M + self.Hd, self.win[1] + self.Hd, self.att,
                                                        1 if self.bottom else 0) == 1)
 
     def log_probs_loss(self, loss, weight, grad_scale):
@@ -792,10 +803,11 @@ class GeneralSpeller:
                 s.dkeys_acc, s.dv_acc = hip.addr(dkeys), hip.addr(grads[self.V_ATT])
                 s.dpq_out, s.lddpq = hip.addr(dpq_all), U * Hd
                 q.sum_workspace = hip.addr(self._persist_workspace('sum', lib.las_decoder_sum_workspace_bytes(32 * (((B + 7) // 8 + 7) // 8 * 8), Hd)))
-            q.U, q.W = U, W[0]
+            T0 = self.T0                               # (dense token vector in front of cell 0's rows: its gradient is one product below)
+            q.U, q.W = U, W[0] - T0
             q.inc_a, q.inc_save, q.inc_gates, q.inc_c, q.inc_align, q.inc_dz, q.inc_ds, q.inc_pq = P, M, 4 * Hd, Hd, Tmp, 4 * Hd, Tmp, Hd
-            q.kc, q.ldk = hip.addr(self.kn[0]), 4 * Hd
-            dfeed0 = torch.empty(B, W[0], dtype=f32, device=dev)
+            q.kc, q.ldk = hip.addr(self.kn[0], T0 * 4 * Hd), 4 * Hd
+            dfeed0 = torch.empty(B, W[0] - T0, dtype=f32, device=dev)
             dfeed1 = torch.empty(B, W[1], dtype=f32, device=dev)
             ws = self._persist_workspace('bwd', lib.las_decoder_persist_workspace_bytes(B, Tm, Hd, M))
             q.dfeed_all, q.workspace = hip.addr(dfeed0), hip.addr(ws)
@@ -806,6 +818,16 @@ class GeneralSpeller:
             hip.check(lib.las_decoder_persist_bwd(C.byref(q), st))
             hip.prof_end(tok)
             self._persist_ws_bwd = ws
+            if T0:
+                dfeed0 = torch.cat([torch.zeros(B, T0, dtype=f32, device=dev), dfeed0], 1)
+                if dtokx is not None:
+                    # gradient w.r.t. the embedded tokens of all steps: dz_0 K_0[token rows]^T, then through the steps' input masks
+                    dtok = torch.empty(B, U, self.Ep, dtype=f32, device=dev)
+                    hip.gemm_nt(dz[0], self.kn[0], dtok, BU, self.Ep, 4 * Hd, lda=4 * Hd, ldb=4 * Hd, ldc=self.Ep)
+                    hip.cast_bf16(dtok, BU, self.Ep, dtokx, BU, self.Ep, ldd=self.Ep, lds=self.Ep)
+                    if sv['keep'] < 1.0:
+                        hip.check(lib.las_dropout_bf16_steps(hip.addr(dtokx), U * self.Ep, self.Ep, B, U, self.Ep, self.win[0], sv['keep'],
+                                                             sv['seed'], self.in_stream(0, 0), st))
             dx[0][0], dx[1][0] = dfeed0, dfeed1       # step 0's products: the gradients into the initial states (their h columns)
         for t in (range(U - 1, -1, -1) if not (seq or two) else ()):
             cur, nxt = t & 1, (t + 1) & 1

@@ -160,13 +160,16 @@ def test_general_decoder_dropout_and_sampling_replayed(bottom, H):
         assert relerr(model.vars.grads[name], g) < 2e-2, name
 
 
-def test_embedding_with_dropout_replayed():
+@pytest.mark.parametrize('H', [64, 128], ids=['steps', 'one_launch'])
+def test_embedding_with_dropout_replayed(H):
     """Dense token feed under DropoutWrapper: the element-wise mask on the embedded token (the token vector travels in
-    cell 0's GEMM operand instead of a per-token row table); embedding gradient through the mask."""
+    cell 0's GEMM operand instead of a per-token row table); embedding gradient through the mask.  At 128 units the two cells
+    run in the one-launch kernels (the operand rows are filled with the masked embedded tokens before the launch)."""
     keep = 0.75
-    O, ohp, op, model = _build(dropout=1 - keep, sampling=0.0, dec_layers=2, bottom_only=False, pass_hidden=False, emb=12)
+    O, ohp, op, model = _build(dropout=1 - keep, sampling=0.0, dec_layers=2, bottom_only=False, pass_hidden=False, emb=12, H=H)
     sp = model.speller
     assert sp.tokx and sp.T0 == 16
+    assert sp._persist2_ok(3, 3, keep, 0.0, None) == (H == 128)
     batch = make_batch(src_len=[12, 7, 10], tgt_len=[6, 4, 5])
     feats, labels = to_device(batch)
     model.vars.grad.zero_()
@@ -174,7 +177,7 @@ def test_embedding_with_dropout_replayed():
     model.backward(dlogits)
     torch.cuda.synchronize()
     seed = model.last_seed
-    B, F, H, V, U, E = 3, 13, 64, 11, 6, 12
+    B, F, V, U, E = 3, 13, 11, 6, 12
     enc_masks = []
     for l, (Tl, Dp, D) in enumerate([(12, 16, F), (12, 2 * H, 2 * H)]):
         enc_masks.append(tuple(_mask(B * Tl * Dp, keep, seed, 16 + 2 * l + d).reshape(B, Tl, Dp)[..., :D] for d in range(2)))
@@ -274,13 +277,15 @@ def test_sampling_inside_the_written_out_decoder_over_several_groups(att, H, mon
         assert relerr(res['1'][2][name], res['0'][2][name].cpu()) < 4e-3, name
 
 
+@pytest.mark.parametrize('emb', [0, 12], ids=['onehot', 'embedding'])
 @pytest.mark.parametrize('bottom', [False, True], ids=['stack2', 'multicell2'])
-def test_two_cell_one_launch_decoder_draws_what_the_step_by_step_path_draws(bottom, monkeypatch):
+def test_two_cell_one_launch_decoder_draws_what_the_step_by_step_path_draws(bottom, emb, monkeypatch):
     """decoder_layers = 2 at the reference's default width (128 units) with input dropout and scheduled sampling, 19 ragged
     utterances (three groups of eight): the one-launch kernels (LAS_DEC_PERSIST2, default) against the step-by-step launches --
     same generator streams, so the same sampled feed; logits and gradients to bf16-flip noise."""
-    O, ohp, op, model = _build(dropout=0.25, sampling=0.3, dec_layers=2, bottom_only=bottom, pass_hidden=bottom, H=128)
+    O, ohp, op, model = _build(dropout=0.25, sampling=0.3, dec_layers=2, bottom_only=bottom, pass_hidden=bottom, H=128, emb=emb)
     sp = model.speller
+    assert sp._persist2_ok(3, 3, 0.75, 0.3, None)
     B = 19
     src_len = [12 - (i * 5) % 9 for i in range(B)]
     tgt_len = [6 - (i * 3) % 5 for i in range(B)]
