@@ -1107,6 +1107,8 @@ __global__ __launch_bounds__(256) void dec_persist_fwd_kernel(las_dec_persist p)
       las_dec_step stA = st;
       stA.feed_plain = st1.feed_plain = 2;
       stA.feed_stream0 = st1.feed_stream0 = p.in_stream0;
+      st1.feed_width = p.win0;       // (cell 1 has no token rows: the body takes the feed's mask window from here; cell 0 keeps
+                                     //  the width its token-row draws are indexed with)
       if (p.wiring == 0) {           // cell 0 alone now; the attention runs with cell 1
         stA.mode = LAS_DEC_CELL_ONLY;
         stA.ctx_out2 = nullptr;
