@@ -28,10 +28,10 @@ __global__ __launch_bounds__(256) void stft_kernel(const float* __restrict__ wav
     float re = 0.f, im = 0.f;
     for (int n = 0; n < n_fft; ++n) {
       const float v = fr[n];
-      re += v * costab[(int64_t)n * bins + k];
-      im += v * sintab[(int64_t)n * bins + k];
+      re = __builtin_fmaf(v, costab[(int64_t)n * bins + k], re);
+      im = __builtin_fmaf(v, sintab[(int64_t)n * bins + k], im);
     }
-    const float p2 = re * re + im * im;
+    const float p2 = __builtin_fmaf(im, im, re * re);      // (spelled out: the kernels of this file must round alike)
     out[(int64_t)f * ldo + k] = power == 2 ? p2 : sqrtf(p2);
   }
 }
@@ -46,7 +46,7 @@ __global__ __launch_bounds__(256) void matmul_kernel(const float* __restrict__ A
   __syncthreads();
   for (int n = threadIdx.x; n < N; n += 256) {
     float acc = 0.f;
-    for (int k = 0; k < K; ++k) acc += row[k] * W[(int64_t)k * ldw + n];
+    for (int k = 0; k < K; ++k) acc = __builtin_fmaf(row[k], W[(int64_t)k * ldw + n], acc);
     if (epi == 1) acc = logf(acc + eps);
     else if (epi == 2) acc = 10.0f * log10f(fmaxf(acc, eps));
     C[(int64_t)m * ldc + n] = acc;
@@ -180,17 +180,17 @@ __global__ __launch_bounds__(256) void batch_melspec_kernel(const float* __restr
     float re = 0.f, im = 0.f;
     for (int n = 0; n < n_fft; ++n) {
       const float v = fr[n];
-      re += v * costab[(int64_t)n * bins + k];
-      im += v * sintab[(int64_t)n * bins + k];
+      re = __builtin_fmaf(v, costab[(int64_t)n * bins + k], re);
+      im = __builtin_fmaf(v, sintab[(int64_t)n * bins + k], im);
     }
-    const float p2 = re * re + im * im;
+    const float p2 = __builtin_fmaf(im, im, re * re);      // (spelled out: the kernels of this file must round alike)
     spec[k] = power == 2 ? p2 : sqrtf(p2);
   }
   __syncthreads();
   float m = -INFINITY;
   for (int n = threadIdx.x; n < n_mels; n += 256) {
     float acc = 0.f;
-    for (int k = 0; k < bins; ++k) acc += spec[k] * mel[(int64_t)k * n_mels + n];
+    for (int k = 0; k < bins; ++k) acc = __builtin_fmaf(spec[k], mel[(int64_t)k * n_mels + n], acc);
     if (epi == 1) acc = logf(acc + eps);
     else if (epi == 2) acc = 10.0f * log10f(fmaxf(acc, eps));
     acc *= scale;
@@ -200,6 +200,86 @@ __global__ __launch_bounds__(256) void batch_melspec_kernel(const float* __restr
   if (utt_max) {
     m = las_wave_max(m);
     if ((threadIdx.x & 63) == 0 && m > -INFINITY) atomic_max_float(utt_max + u, m);
+  }
+}
+
+// The same stage with FB frames per workgroup (round 4): the DFT tables (2 x n_fft x bins floats = 412 KB at 20-ms windows) were
+// read from L2 once per FRAME -- 84 GB of L2 traffic for 256 utterances of 8 s, the whole 4 ms of the stage; here a table element
+// is loaded once and used for FB frames held in LDS (frame-minor layout: the FB samples of one n are two 16-byte reads).  Every
+// (frame, bin) sum runs over n in the same order with the same fused multiply-adds as above, and every mel sum over k likewise:
+// the results are bit-identical to the one-frame kernels (tests/test_gpu_frontend.py compares with torch.equal).
+// LDS: FB * (n_fft + bins) floats + FB maxima.
+template <int FB>
+__global__ __launch_bounds__(256) void batch_melspec_blocked_kernel(const float* __restrict__ waves, const int64_t* __restrict__ wave_off,
+                                                                    const int32_t* __restrict__ frame_off, int n_utt, int total_frames,
+                                                                    int n_fft, int hop, int pad, int power, const float* __restrict__ window,
+                                                                    const float* __restrict__ costab, const float* __restrict__ sintab,
+                                                                    int bins, const float* __restrict__ mel, int n_mels, int epi, float eps,
+                                                                    float scale, float* __restrict__ out, float* __restrict__ utt_max) {
+  static_assert(FB == 8, "two 16-byte LDS reads per sample index");
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  float* frT = sm;                         // [n_fft][FB]
+  float* spec = sm + (size_t)FB * n_fft;   // [FB][bins]
+  __shared__ int s_utt[FB];
+  __shared__ float s_max[FB];
+  const int tid = threadIdx.x, f0 = blockIdx.x * FB;
+  if (tid < FB) {
+    s_utt[tid] = f0 + tid < total_frames ? find_utt(frame_off, n_utt, f0 + tid) : -1;
+    s_max[tid] = -INFINITY;
+  }
+  __syncthreads();
+  for (int e = tid; e < FB * n_fft; e += 256) {
+    const int j = e / n_fft, n = e - j * n_fft, u = s_utt[j];
+    float v = 0.f;
+    if (u >= 0) {
+      const float* wave = waves + wave_off[u];
+      const int N = (int)(wave_off[u + 1] - wave_off[u]);
+      int i = (f0 + j - frame_off[u]) * hop + n - pad;
+      if (pad > 0) {
+        if (i < 0) i = -i;
+        if (i >= N) i = 2 * (N - 1) - i;
+      }
+      v = (i >= 0 && i < N) ? wave[i] * window[n] : 0.f;
+    }
+    frT[n * FB + j] = v;
+  }
+  __syncthreads();
+  for (int k = tid; k < bins; k += 256) {
+    float re[FB], im[FB];
+#pragma unroll
+    for (int j = 0; j < FB; ++j) re[j] = im[j] = 0.f;
+    for (int n = 0; n < n_fft; ++n) {
+      const float c = costab[(int64_t)n * bins + k], sn = sintab[(int64_t)n * bins + k];
+      const float4 a = *reinterpret_cast<const float4*>(frT + n * FB), b = *reinterpret_cast<const float4*>(frT + n * FB + 4);
+      const float v[FB] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+#pragma unroll
+      for (int j = 0; j < FB; ++j) {
+        re[j] = __builtin_fmaf(v[j], c, re[j]);
+        im[j] = __builtin_fmaf(v[j], sn, im[j]);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < FB; ++j) {
+      const float p2 = __builtin_fmaf(im[j], im[j], re[j] * re[j]);
+      spec[j * bins + k] = power == 2 ? p2 : sqrtf(p2);
+    }
+  }
+  __syncthreads();
+  for (int e = tid; e < FB * n_mels; e += 256) {
+    const int j = e / n_mels, n = e - j * n_mels;
+    if (s_utt[j] < 0) continue;
+    const float* sp = spec + j * bins;
+    float acc = 0.f;
+    for (int k = 0; k < bins; ++k) acc = __builtin_fmaf(sp[k], mel[(int64_t)k * n_mels + n], acc);
+    if (epi == 1) acc = logf(acc + eps);
+    else if (epi == 2) acc = 10.0f * log10f(fmaxf(acc, eps));
+    acc *= scale;
+    out[(int64_t)(f0 + j) * n_mels + n] = acc;
+    if (utt_max) atomic_max_float(&s_max[j], acc);            // (LDS; the order of a maximum does not matter)
+  }
+  if (utt_max) {
+    __syncthreads();
+    if (tid < FB && s_utt[tid] >= 0 && s_max[tid] > -INFINITY) atomic_max_float(utt_max + s_utt[tid], s_max[tid]);
   }
 }
 
@@ -226,7 +306,7 @@ __global__ __launch_bounds__(256) void batch_finish_kernel(const float* __restri
     float acc;
     if (dct) {
       acc = 0.f;
-      for (int k = 0; k < n_mels; ++k) acc += row[k] * dct[(int64_t)k * n_out + n];
+      for (int k = 0; k < n_mels; ++k) acc = __builtin_fmaf(row[k], dct[(int64_t)k * n_out + n], acc);
     } else {
       acc = row[n];
     }
@@ -350,6 +430,14 @@ extern "C" int las_fe_batch_melspec(const float* waves, const int64_t* wave_off,
     hipLaunchKernelGGL(fill_f32_kernel, dim3((n_utt + 255) / 256), dim3(256), 0, st, utt_max, n_utt, -INFINITY);
     LAS_LAUNCH_CHECK("fe batch max init");
   }
+  static int blocked = -1;          // LAS_FE_BLOCKED=0: one frame per workgroup again (diagnostics, A/B timing)
+  if (blocked < 0) { const char* e = getenv("LAS_FE_BLOCKED"); blocked = (e && atoi(e) == 0) ? 0 : 1; }
+  constexpr int FB = 8;
+  if (blocked && (size_t)FB * (n_fft + bins) * sizeof(float) <= 60 * 1024 && total_frames >= 4 * FB)
+    hipLaunchKernelGGL(batch_melspec_blocked_kernel<FB>, dim3((total_frames + FB - 1) / FB), dim3(256),
+                       (size_t)FB * (n_fft + bins) * sizeof(float), st, waves, wave_off, frame_off, n_utt, total_frames, n_fft, hop,
+                       center ? n_fft / 2 : 0, power, window, costab, sintab, bins, mel, n_mels, epilogue, eps, scale, out, utt_max);
+  else
   hipLaunchKernelGGL(batch_melspec_kernel, dim3(total_frames), dim3(256), (size_t)(n_fft + bins) * sizeof(float), st, waves, wave_off,
                      frame_off, n_utt, n_fft, hop, center ? n_fft / 2 : 0, power, window, costab, sintab, bins, mel, n_mels, epilogue,
                      eps, scale, out, utt_max);

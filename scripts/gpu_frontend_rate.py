@@ -44,3 +44,7 @@ print('batched : %.1f ms for %d x %.0f s = %.0f audio-seconds/s (%.0f x real tim
 print('per utt : %.1f ms (extrapolated from 32)  = %.0f audio-seconds/s; batched is %.1f x faster' % (t_single * 1e3, audio / t_single, t_single / t_batch))
 print('needed HBM traffic %.1f MB in %.2f ms = %.1f GB/s = %.4f of the 8 TB/s roof (the stages are L2 / VALU work: a %d-point direct '
       'DFT per frame from a 412 KB twiddle table that lives in L2)' % (need / 1e6, t_batch * 1e3, need / t_batch / 1e9, need / t_batch / 8e12, 320))
+# the arithmetic the stages need: the 320-point direct DFT (re and im: 4 flops per sample and bin) + the mel filterbank, fp32
+flops = frames * (320 * 161 * 4 + 161 * 40 * 2)
+print('arithmetic %.1f GF in %.2f ms (all three launches) >= %.1f TFLOP/s = %.3f of the 157 TFLOP/s fp32 (vector = matrix) roof; '
+      'round 3 (one frame per workgroup, tables re-read per frame: LAS_FE_BLOCKED=0): 4.8 ms' % (flops / 1e9, t_batch * 1e3, flops / t_batch / 1e12, flops / t_batch / 157e12))
