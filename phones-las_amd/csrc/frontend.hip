@@ -216,7 +216,7 @@ __global__ __launch_bounds__(256) void batch_melspec_blocked_kernel(const float*
                                                                     const float* __restrict__ costab, const float* __restrict__ sintab,
                                                                     int bins, const float* __restrict__ mel, int n_mels, int epi, float eps,
                                                                     float scale, float* __restrict__ out, float* __restrict__ utt_max) {
-  static_assert(FB == 8, "two 16-byte LDS reads per sample index");
+  static_assert(FB % 4 == 0, "16-byte LDS reads of the frames' samples");
   extern __shared__ __attribute__((aligned(16))) float sm[];
   float* frT = sm;                         // [n_fft][FB]
   float* spec = sm + (size_t)FB * n_fft;   // [FB][bins]
@@ -250,8 +250,12 @@ __global__ __launch_bounds__(256) void batch_melspec_blocked_kernel(const float*
     for (int j = 0; j < FB; ++j) re[j] = im[j] = 0.f;
     for (int n = 0; n < n_fft; ++n) {
       const float c = costab[(int64_t)n * bins + k], sn = sintab[(int64_t)n * bins + k];
-      const float4 a = *reinterpret_cast<const float4*>(frT + n * FB), b = *reinterpret_cast<const float4*>(frT + n * FB + 4);
-      const float v[FB] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+      float v[FB];
+#pragma unroll
+      for (int q = 0; q < FB / 4; ++q) {
+        const float4 a = *reinterpret_cast<const float4*>(frT + n * FB + 4 * q);
+        v[4 * q] = a.x; v[4 * q + 1] = a.y; v[4 * q + 2] = a.z; v[4 * q + 3] = a.w;
+      }
 #pragma unroll
       for (int j = 0; j < FB; ++j) {
         re[j] = __builtin_fmaf(v[j], c, re[j]);
@@ -432,8 +436,14 @@ extern "C" int las_fe_batch_melspec(const float* waves, const int64_t* wave_off,
   }
   static int blocked = -1;          // LAS_FE_BLOCKED=0: one frame per workgroup again (diagnostics, A/B timing)
   if (blocked < 0) { const char* e = getenv("LAS_FE_BLOCKED"); blocked = (e && atoi(e) == 0) ? 0 : 1; }
+  static int fb16 = -1;             // LAS_FE_FB=16: sixteen frames per workgroup (A/B)
+  if (fb16 < 0) { const char* e = getenv("LAS_FE_FB"); fb16 = (e && atoi(e) == 16) ? 1 : 0; }
   constexpr int FB = 8;
-  if (blocked && (size_t)FB * (n_fft + bins) * sizeof(float) <= 60 * 1024 && total_frames >= 4 * FB)
+  if (blocked && fb16 && (size_t)16 * (n_fft + bins) * sizeof(float) <= 60 * 1024 && total_frames >= 64)
+    hipLaunchKernelGGL(batch_melspec_blocked_kernel<16>, dim3((total_frames + 15) / 16), dim3(256),
+                       (size_t)16 * (n_fft + bins) * sizeof(float), st, waves, wave_off, frame_off, n_utt, total_frames, n_fft, hop,
+                       center ? n_fft / 2 : 0, power, window, costab, sintab, bins, mel, n_mels, epilogue, eps, scale, out, utt_max);
+  else if (blocked && (size_t)FB * (n_fft + bins) * sizeof(float) <= 60 * 1024 && total_frames >= 4 * FB)
     hipLaunchKernelGGL(batch_melspec_blocked_kernel<FB>, dim3((total_frames + FB - 1) / FB), dim3(256),
                        (size_t)FB * (n_fft + bins) * sizeof(float), st, waves, wave_off, frame_off, n_utt, total_frames, n_fft, hop,
                        center ? n_fft / 2 : 0, power, window, costab, sintab, bins, mel, n_mels, epilogue, eps, scale, out, utt_max);
