@@ -199,6 +199,13 @@ int las_add_cast_bf16(const float* a, int64_t lda, const float* b, int64_t ldb, 
  * becomes runnable at the same moment as a persistent recurrent launch on the main stream and should not take CUs before
  * that launch's workgroups are resident (a chain that finds some of its CUs taken starts late as a whole). */
 int las_stream_delay(int microseconds, void* stream);
+/* Can a kernel on `setter_stream` run while an EARLIER-enqueued kernel on `waiter_stream` is still running?  A process that
+ * has created many streams gets them mapped onto a handful of hardware queues; two streams that share one run their kernels
+ * in submission order.  The streamed input products (las_gemm_nt_stream beside las_lstm_recurrent_fwd_ex) need the answer to be
+ * yes for their pair of streams.  Enqueues a one-thread kernel on waiter_stream that waits up to wait_us for a word that a
+ * one-thread kernel enqueued AFTERWARDS on setter_stream writes; once both streams are synchronised, words[1] == 1: concurrent,
+ * 2: the setter never ran beside the waiter.  words: two int32 in device memory. */
+int las_stream_concurrency_probe(void* waiter_stream, void* setter_stream, int32_t* words, int wait_us);
 
 /* Several small fills / copies in ONE launch (the decoder's per-step scratch: zeroed accumulators, the initial state
  * rows).  The job table travels as a kernel argument: no device-side table, nothing to upload.  Every job is a 2-D window

@@ -103,6 +103,18 @@ __global__ void delay_kernel(long long ticks) {
   while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(16);
 }
 
+// las_stream_concurrency_probe: the waiter spins (bounded by the wall clock) until the setter's word arrives
+__global__ void probe_wait_kernel(int* words, long long ticks) {
+  const long long t0 = wall_clock64();
+  int seen = 0;
+  while (wall_clock64() - t0 < ticks) {
+    if (__hip_atomic_load(words, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) { seen = 1; break; }
+    __builtin_amdgcn_s_sleep(16);
+  }
+  words[1] = seen ? 1 : 2;
+}
+__global__ void probe_set_kernel(int* words) { __hip_atomic_store(words, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
 // out = bf16(a + b), b nullable (las_add_cast_bf16)
 __global__ void add_cast_kernel(const float* a, int64_t lda, const float* b, int64_t ldb, unsigned short* out, int64_t ldo, int rows, int cols) {
   const int64_t total = (int64_t)rows * cols;
@@ -296,6 +308,24 @@ extern "C" int las_stream_delay(int microseconds, void* stream) {
   if (microseconds == 0) return LAS_OK;
   hipLaunchKernelGGL(delay_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (long long)microseconds * 100);
   LAS_LAUNCH_CHECK("delay launch");
+  return LAS_OK;
+}
+
+extern "C" int las_stream_concurrency_probe(void* waiter_stream, void* setter_stream, int32_t* words, int wait_us) {
+  LAS_REQUIRE(words != nullptr && wait_us > 0 && wait_us <= 100000, "las_stream_concurrency_probe: two device words, a wait of 1 .. 100000 us");
+  int rc = las_check_hip(hipMemsetAsync(words, 0, 2 * sizeof(int32_t), (hipStream_t)waiter_stream), "probe memset");
+  if (rc) return rc;
+  hipEvent_t ev;
+  rc = las_check_hip(hipEventCreateWithFlags(&ev, hipEventDisableTiming), "probe event");
+  if (rc) return rc;
+  rc = las_check_hip(hipEventRecord(ev, (hipStream_t)waiter_stream), "probe event record");
+  if (!rc) rc = las_check_hip(hipStreamWaitEvent((hipStream_t)setter_stream, ev, 0), "probe stream wait");
+  (void)hipEventDestroy(ev);
+  if (rc) return rc;
+  hipLaunchKernelGGL(probe_wait_kernel, dim3(1), dim3(1), 0, (hipStream_t)waiter_stream, words, (long long)wait_us * 100);
+  LAS_LAUNCH_CHECK("probe waiter launch");
+  hipLaunchKernelGGL(probe_set_kernel, dim3(1), dim3(1), 0, (hipStream_t)setter_stream, words);
+  LAS_LAUNCH_CHECK("probe setter launch");
   return LAS_OK;
 }
 

@@ -30,6 +30,7 @@ _SIGS = {
     'las_refresh_images': ([_vp, C.c_int, _vp], C.c_int),
     'las_fill_many': ([_vp, C.c_int, _vp], C.c_int),
     'las_stream_delay': ([C.c_int, _vp], C.c_int),
+    'las_stream_concurrency_probe': ([_vp, _vp, _vp, C.c_int], C.c_int),
     'las_add_cast_bf16': ([_vp, _i64, _vp, _i64, _vp, _i64, _i32, _i32, _vp], C.c_int),
     'las_colsum_bf16': ([_vp, _i64, _i32, _i32, _vp, _i32, _vp], C.c_int),
     'las_colsum_ws_bytes': ([_i32, _i32], C.c_size_t),

@@ -51,10 +51,23 @@ def lstm_workspace(B, H, nd):
     return ws
 
 
+def _note_timeout(st):
+    """A forward launch that timed out while its input products were being streamed beside it: the hand-over needs the two
+    kernels to run concurrently; if this process cannot give them that (see _product_stream), the steps that follow fall
+    back to the product before the recurrence instead of failing one after the other."""
+    global STREAM_X
+    if (st & 1) and STREAM_X and _PRODUCT_STREAMS:
+        STREAM_X = False
+        import sys
+        print('phones_las_amd: a recurrent forward launch timed out beside its streamed input product; streaming is off for the '
+              'rest of this process (LAS_LSTM_STREAM=0 has the same effect)', file=sys.stderr)
+
+
 def check_lstm_status(B, H, nd):
     """Raise if a bounded inter-workgroup wait of the last recurrent launch timed out (forces a sync)."""
     st = int(lstm_workspace(B, H, nd)[:4].view(torch.int32).item())
     if st:
+        _note_timeout(st)
         raise hip.LasError('recurrent kernel reported an inter-workgroup timeout (status %d)' % st)
 
 
@@ -63,6 +76,7 @@ def check_all_lstm_status():
     for (B, H, nd, dev), ws in _WORKSPACES.items():
         st = int(ws[:4].view(torch.int32).item())
         if st:
+            _note_timeout(st)
             raise hip.LasError('recurrent kernel (B=%d, H=%d) reported an inter-workgroup timeout (status %d)' % (B, H, st))
 
 
@@ -148,15 +162,44 @@ STREAM_512 = os.environ.get('LAS_LSTM_STREAM_512', '0') != '0'      # (diagnosti
 STREAM_MIN_ROWS = int(os.environ.get('LAS_LSTM_STREAM_MIN_ROWS', '4096'))      # smaller products are not worth the hand-over
 STREAM_MAX_WORKGROUPS = 192       # the recurrence (members + companions, a CU each) must leave CUs to the product beside it
 _PRODUCT_STREAMS = {}
+_ALIASED_STREAMS = []
 
 
 def _product_stream():
-    """The stream the streamed input products run on (one per device; its work is always joined by the launching stream)."""
+    """The stream the streamed input products run on (one per device; its work is always joined by the launching stream).
+    The recurrence waits INSIDE its kernel for tiles this stream's kernel produces, so the two must never share a hardware queue
+    -- a process that has created many streams gets them mapped onto a handful of queues, and a product queued behind the
+    recurrence that waits for it is a (bounded) deadlock: every streamed launch timed out in a test session that had created
+    ~100 streams before this one.  (A high-priority stream has queues of its own but its workgroups are placed before the
+    recurrence's: measured, 41 ms per step.)  So the stream is PROBED when it is created (_concurrent_stream)."""
     dev = torch.cuda.current_device()
     st = _PRODUCT_STREAMS.get(dev)
     if st is None:
-        st = _PRODUCT_STREAMS[dev] = torch.cuda.Stream()
+        st = _PRODUCT_STREAMS[dev] = _concurrent_stream()
     return st
+
+
+def _concurrent_stream(tries=8):
+    """A stream whose kernels run BESIDE kernels enqueued earlier on the current stream (las_stream_concurrency_probe), or None.
+    A new stream takes the next hardware queue in turn, so a few tries find one that is not the current stream's; the streams
+    that failed are kept (dropping them would hand their queue to the next try)."""
+    global STREAM_X
+    if torch.cuda.is_current_stream_capturing():
+        return torch.cuda.Stream()               # (cannot probe inside a capture: callers create the stream in an eager step first)
+    main = torch.cuda.current_stream()
+    words = torch.zeros(2, dtype=torch.int32, device='cuda')
+    for _ in range(tries):
+        cand = torch.cuda.Stream()
+        hip.check(hip.lib().las_stream_concurrency_probe(main.cuda_stream, cand.cuda_stream, hip.p(words), 2000))
+        main.wait_stream(cand)
+        if int(words[1].item()) == 1:
+            return cand
+        _ALIASED_STREAMS.append(cand)
+    import sys
+    print('phones_las_amd: no stream found that runs beside the current one (%d tried): input products are not streamed in this '
+          'process' % tries, file=sys.stderr)
+    STREAM_X = False
+    return torch.cuda.Stream()
 
 
 def _dirs(unidirectional):
@@ -210,6 +253,9 @@ def _stream_setup(a, lda, a_dir_stride, weights, xproj, sequence_length, B, T, H
                 and 16 % max(lib.las_lstm_slice_rows(B, H, nd), 1) == 0
                 and 0 < lib.las_lstm_fwd_workgroups(B, H, nd) <= STREAM_MAX_WORKGROUPS)
     if not streamed:
+        return None
+    _product_stream()                 # (created -- and probed against the current stream -- before the first streamed launch)
+    if not STREAM_X:
         return None
     # counters zeroed here, the product on its own stream (held back a few microseconds so that the chain's workgroups are
     # resident first), the recurrence consumes the rows as they become visible

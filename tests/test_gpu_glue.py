@@ -152,3 +152,27 @@ def test_rccl_behind_the_c_abi_one_rank():
     assert torch.equal(g, ref)
     assert lib.las_dp_init(uid, 3, 2, C.byref(C.c_void_p())) != 0          # rank out of range: an error code, no crash
     hip.check(lib.las_dp_finalize(comm))
+
+
+def test_stream_concurrency_probe_and_the_product_stream():
+    """The streamed input products need a stream whose kernels run BESIDE an earlier kernel of the launching stream.  After a
+    process has created many streams they share hardware queues: las_stream_concurrency_probe tells (a stream against itself: the
+    setter can never run beside the waiter), and ops._concurrent_stream() hands out a stream that passes the probe."""
+    from phones_las_amd import hip
+    from phones_las_amd.las import ops
+    lib = hip.lib()
+    crowd = [torch.cuda.Stream() for _ in range(48)]          # what a long test session / a process with many models has created
+    for st in crowd:
+        with torch.cuda.stream(st):
+            torch.zeros(1, device='cuda')
+    main = torch.cuda.current_stream()
+    words = torch.zeros(2, dtype=torch.int32, device='cuda')
+    hip.check(lib.las_stream_concurrency_probe(main.cuda_stream, main.cuda_stream, hip.p(words), 500))
+    torch.cuda.synchronize()
+    assert int(words[1].item()) == 2                          # same queue: in submission order, the waiter gives up
+    side = ops._concurrent_stream()
+    assert ops.STREAM_X                                       # a stream was found
+    hip.check(lib.las_stream_concurrency_probe(main.cuda_stream, side.cuda_stream, hip.p(words), 2000))
+    torch.cuda.synchronize()
+    assert int(words[1].item()) == 1
+
