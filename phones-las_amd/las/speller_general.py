@@ -177,6 +177,10 @@ class GeneralSpeller:
         self.debug_hook = None
 
     DEC_STREAM = 1                       # token-scale draws of cell 0 (decoder index scheme of las_dec_step)
+    # the sequential backward decoder runs four co-operating workgroups per utterance while that has never timed out in this
+    # process (the four parts need CUs of their own at the same time; LasModel.check_device_status clears this when a
+    # launch reported status bit 32, and the launches after it take one workgroup per utterance)
+    SEQ_FOUR_PARTS = True
 
     @staticmethod
     def in_stream(l, t):
@@ -764,7 +768,7 @@ class GeneralSpeller:
             q.kn_packed = hip.addr(self.kn_pk)
             if bah or self.mono:                    # d(attention_v) / d(score_bias): fixed-order sums instead of atomics
                 q.sum_workspace = hip.addr(self._persist_workspace('sum', lib.las_decoder_sum_workspace_bytes(32 * ((B + 7) // 8), Hd + 1)))
-                if bah and os.environ.get('LAS_DEC_SEQ_PARTS', '4') != '1':       # four workgroups per utterance (see las_dec_seq_bwd)
+                if bah and os.environ.get('LAS_DEC_SEQ_PARTS', '4') != '1' and GeneralSpeller.SEQ_FOUR_PARTS:       # four workgroups per utterance (see las_dec_seq_bwd)
                     q.xchg_workspace = hip.addr(self._persist_workspace('seqx', lib.las_decoder_seq_xchg_bytes(B, Tm, Hd, M, W[0])))
                     if self.uses_wq and self.wq_pk is not None:
                         q.wq_packed = hip.addr(self.wq_pk)

@@ -1013,6 +1013,13 @@ class LasModel:
                 for ws in getattr(mod, '_persist_cache', {}).values():
                     st = int(ws[:4].view(torch.int32).item())
                     if st:
+                        if st & 32:          # the four-parts sequential backward: one workgroup per utterance from here on
+                            from .las.speller_general import GeneralSpeller
+                            if GeneralSpeller.SEQ_FOUR_PARTS:
+                                GeneralSpeller.SEQ_FOUR_PARTS = False
+                                import sys
+                                print('phones_las_amd: the four-parts backward decoder timed out; it runs one workgroup per utterance '
+                                      'for the rest of this process (LAS_DEC_SEQ_PARTS=1 has the same effect)', file=sys.stderr)
                         raise hip.LasError('persistent decoder reported a barrier timeout (status %d)' % st)
         except hip.LasError:
             for ws in self._status_tensors():        # read: the sticky words start over
