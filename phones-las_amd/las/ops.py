@@ -82,6 +82,9 @@ def check_all_lstm_status():
 
 # workgroups the fused weight-gradient product of a direction aims for (K slices x output tiles); LAS_TN_WGS overrides
 TN_WORKGROUPS = int(os.environ.get('LAS_TN_WGS', '704'))
+# ... of the bottom layer, whose two directions' products run ALONE on the chip (nothing hides them), at the same time on two
+# streams; a 512-thread workgroup with 96 KiB of LDS takes a CU
+TN_WORKGROUPS_EXPOSED = int(os.environ.get('LAS_TN_WGS_EXPOSED', '704'))
 
 
 class Overlap:
@@ -451,7 +454,7 @@ def bilstm_backward(rec, dy, d_state, grads, need_dx=True, overlap=None, defer_w
     if Df >= 0:
         # fused product: about 700 workgroups in flight measured best on MI355X (128 x 128 output tiles, K cut in slices)
         tiles = -(-(Df + H + 1) // 128) * -(-(4 * H) // 128)
-        split = max(1, min(32, BT // 512, round(TN_WORKGROUPS / tiles)))
+        split = max(1, min(32, BT // 512, round((TN_WORKGROUPS_EXPOSED if exposed else TN_WORKGROUPS) / tiles)))
     keepalive = [dz, x, y] + [a for a, _ in (dropped or [])]
 
     def weight_grads(win=None, beside=False):
