@@ -1,10 +1,12 @@
 # forward / backward time of the fused decoder at the metric-L shape (Hd=512, M=2048, T'=100, U=80, B=64):
-# LAS_DEC_PERSIST=1|0 (one launch / per-step launches), ATT=bahdanau|luong, CFG=metric-L|metric-M (256 units, T'=200)
+# LAS_DEC_PERSIST=1|0 (one launch / per-step launches), ATT=bahdanau|luong, CFG=metric-L|metric-M (256 units, T'=200), B=utterances
 import os, sys, time, torch
 sys.path.insert(0, '.')
 import bench
 from phones_las_amd import model_helper as mh
 c = dict(bench.CONFIGS[os.environ.get('CFG', 'metric-L')], att=os.environ.get('ATT', 'bahdanau'))
+if os.environ.get('B'):
+    c['B'] = int(os.environ['B'])          # fewer utterances = fewer groups streaming their weight slices at once
 model = mh.LasModel(bench.build_params(c))
 feats, labels = bench.synthetic_batch(c, 1234, torch.device('cuda', 0))
 feats['encoder_inputs'] = model.listener.pad_features(feats['encoder_inputs'])
