@@ -61,6 +61,9 @@ enum las_att_norm {      /* how scores become alignments (SURVEY.md Appendix A.6
 
 int las_version(void);
 const char* las_last_error(void);
+/* The library's diagnostics / A-B switches are integer environment variables (LAS_*: slice heights, member counts, kernel
+ * families; see README) that it reads ONCE, at their first use.  las_set_knob overrides one afterwards (the tests' hook). */
+int las_set_knob(const char* name, int value);
 
 /* ------------------------------------------------------------------------------------------
  * Dense products on MFMA (bf16 operands, fp32 accumulate).  These replace the Eigen/cuBLAS
@@ -97,6 +100,35 @@ int las_gemm_nt_stream(const las_bf16* A, int64_t lda, const las_bf16* Bm, int64
 int las_gemm_nt_stream_dirs(const las_bf16* A, int64_t lda, int64_t a_dir_stride, const las_bf16* Bm, int64_t ldb, float* C,
                             int64_t ldc, const float* bias, const int32_t* length, int B, int T, int N, int K, int ndir,
                             int rows_per_slice, uint32_t* ready, void* stream);
+
+/* FOLLOWER product (round 5): C [B*T_out, N] fp32 = A(view) B^T (+ bias) over the OUTPUT rows of a recurrent launch that runs beside
+ * it -- the next layer's input projection behind a forward launch (kind 0: A = y, las/ops.py:75-87), dX = dz K_x^T behind a
+ * backward launch (kind 1: A = dz) -- formed in two halves, one per direction of the recurrence: direction d contributes the K
+ * columns [d * a_dir + i * a_seg, + seg_len), i < nseg, of A (the same with b_dir / b_seg of Bw [N, ldb]), and each half is
+ * produced as soon as ITS chain has passed the tile's rows; the half that comes first stores, the second adds (and adds the
+ * bias): (P + Q) + b in either order, so results do not depend on timing.  Row (b, t) of A = A + (b * T_out + t) * lda; one row
+ * covers `stack` steps of the chain (2: pyramidal_stack's view of the layer below), T_chain = T_out * stack; `length` = the
+ * chain's lengths.  rows_per_slice = las_lstm_slice_rows of the recurrence.
+ * Protocol: zero `words` (las_gemm_nt_follow_words of them); launch the recurrence with follow = words; launch this with cleanup
+ * = 0 and `workgroups` persistent workgroups on ANOTHER stream (one that runs beside the first: las_stream_concurrency_probe);
+ * then, ordered behind BOTH, launch it again with cleanup = 1: that pass forms whatever the follower did not (the tiles of
+ * the chain's last steps; every tile if the two did not overlap).  las_gemm_nt_follow_supported: rows_per_slice in {4, 8, 16},
+ * two directions need ceil(B / rows_per_slice) % 8 == 0 (both chains of a slice on one XCD), seg_len a multiple of 32. */
+typedef struct las_follow {
+  const las_bf16* A;
+  const las_bf16* Bw;
+  float* C;
+  const float* bias;             /* [N] or NULL */
+  int64_t lda, ldb, ldc;
+  int32_t a_dir, a_seg, b_dir, b_seg, nseg, seg_len;
+  int32_t N, B, T_out, T_chain, stack, rows_per_slice, ndir, kind;
+  const int32_t* length;
+  uint32_t* words;
+  int32_t workgroups, reserved;
+} las_follow;
+int las_gemm_nt_follow_supported(int B, int N, int seg_len, int rows_per_slice, int ndir);
+size_t las_gemm_nt_follow_words(int B, int T_out, int N, int rows_per_slice, int ndir);
+int las_gemm_nt_follow(const las_follow* p, int cleanup, void* stream);
 
 /* C (=|+=) (A B^T) * mask / keep, mask[row, col] = [las_uniform(seed, stream_id, row * N + col) < keep]: the gradient through a
  * cell's input dropout (DropoutWrapper(input_keep_prob), las/ops.py:14-18; the mask las_dropout_bf16 drew for that cell in
@@ -147,15 +179,6 @@ size_t las_gemm_tn_lstm_workspace_bytes(int D, int H, int split_k);
 int las_gemm_tn_lstm(const las_bf16* x, int64_t ldx, int D, const las_bf16* y, int64_t ldy, int H, int a_shift,
                      int period, const las_bf16* dz, int64_t ldz, float* kernel_grad, float* bias_grad, int K,
                      int split_k, float* workspace, void* stream);
-/* The same product over a TIME WINDOW of every utterance (round 4): K index k = b * win_T + j, j < win_T, is row b * T + tb + j
- * of x / y / dz, tb = win_lo (win_len NULL) or min(win_len[b], T) - win_lo (a window counted from the end of each utterance:
- * what a window of las_lstm_recurrent_bwd_window's steps covers in the right-to-left direction); rows outside [0, T) read as
- * zeros.  The weight gradients of a window can so run beside the next window's recurrence instead of behind the whole layer
- * (the reference has one tf.gradients call: las/ops.py:68-87, model_helper.py:403-417).  split_k > 1 (workspace). */
-int las_gemm_tn_lstm_window(const las_bf16* x, int64_t ldx, int D, const las_bf16* y, int64_t ldy, int H, int a_shift,
-                            int B, int T, int win_T, int win_lo, const int32_t* win_len, const las_bf16* dz, int64_t ldz,
-                            float* kernel_grad, float* bias_grad, int split_k, float* workspace, void* stream);
-
 /* dst_bf16[r, c] = src_f32[r, c] (transpose = 0) or dst[c, r] = src[r, c] (transpose = 1), with the
  * destination window [dst_rows, dst_cols] (row stride ldd) zero-padded.  `batch` windows at element
  * strides src_bstride / dst_bstride.  src_col_perm_h = H > 0 reads the source's columns through the
@@ -274,7 +297,10 @@ int las_lstm_pack_input(const float* kernel, int D, int H, int chunks, las_bf16*
  *                  one on another stream (launch this kernel first; hold the product back a few microseconds with
  *                  las_stream_delay so that the chain's workgroups are resident first).  ready = the buffer shared with the
  *                  product (las_gemm_nt_stream_flags words, zeroed by the caller before both launches: this launch writes its
- *                  groups' XCDs into it and waits on the product's counters); ready_count = column tiles per block = N / ndir / 128. */
+ *                  groups' XCDs into it and waits on the product's counters); ready_count = column tiles per block = N / ndir / 128.
+ *   follow != NULL a FOLLOWER product (las_gemm_nt_follow: the next layer's input projection) consumes y behind this launch: the
+ *                  chains publish where they run and how far they are in these words (las_gemm_nt_follow_words of them, zeroed
+ *                  by the caller before both launches). */
 typedef struct las_lstm_fwd {
   float* xproj;                  /* [B,T,ndir*4H] fp32: x K_x + b on entry (unless x != NULL), the saved gates on exit */
   const las_bf16* wpacked;
@@ -292,6 +318,7 @@ typedef struct las_lstm_fwd {
   const float* bias;
   uint32_t* ready;               /* streamed input projection (optional): shared with las_gemm_nt_stream, written by both */
   int32_t ready_count, reserved1;
+  uint32_t* follow;              /* a follower product consumes y behind this launch (optional): the words shared with las_gemm_nt_follow */
 } las_lstm_fwd;
 int las_lstm_recurrent_fwd_ex(const las_lstm_fwd* p, void* stream);
 
@@ -320,14 +347,8 @@ int las_lstm_fwd_workgroups(int B, int H, int ndir);
  * the caller derives dX, dK_x, dK_h, db from it with las_gemm_nt / las_gemm_tn / las_colsum. */
 int las_lstm_recurrent_bwd(const float* gates, const float* cbuf, const float* dy, const float* dc_last,
                            const float* dh_last, const las_bf16* kh_bf16, const int32_t* length,
-                           las_bf16* dz, void* workspace, int B, int T, int H, int ndir, void* stream);
-/* ... over the steps s in [s_lo, s_hi) only (s counts from the start of a direction's forward pass; the backward walks them
- * downwards): d(c), d(h) enter through dc_last / dh_last and, for s_lo > 0, leave through dc_out / dh_out [ndir, B, H] -- the
- * next window's dc_last / dh_last.  Windows from the top (s_hi = T) down to s_lo = 0 give the results of one launch. */
-int las_lstm_recurrent_bwd_window(const float* gates, const float* cbuf, const float* dy, const float* dc_last,
-                                  const float* dh_last, const las_bf16* kh_bf16, const int32_t* length, las_bf16* dz,
-                                  void* workspace, int B, int T, int H, int ndir, int s_lo, int s_hi, float* dc_out,
-                                  float* dh_out, void* stream);
+                           las_bf16* dz, void* workspace, int B, int T, int H, int ndir, uint32_t* follow, void* stream);
+/* follow: NULL, or the words shared with a follower product (las_gemm_nt_follow, kind 1: dX = dz K_x^T behind the chains). */
 
 /* len_out[b] = len[b]/2 + len[b]%2  (las/ops.py:65 pyramidal_stack). */
 int las_pyramid_lengths(const int32_t* len_in, int32_t* len_out, int B, void* stream);
@@ -715,7 +736,8 @@ int las_seq_ce_loss(const float* logits, int64_t ldl, const int32_t* targets, co
  * (STORED, not added: nothing to zero first); dlogits [B*U, Vp] bf16 as las_seq_ce_loss leaves it; dctx [B*U, M] fp32 (row stride
  * ld_dctx) = dlogits wproj^T with wproj [M, Vp] bf16.  targets [B, >= U] int32 with row stride target_stride.  Supported when
  * las_proj_ce_supported(V, Vp, M): Vp a multiple of 16 up to 128, M a multiple of 128.  workspace: las_proj_ce_workspace_bytes
- * bytes, 16-byte aligned, ZERO before the first use (every launch leaves it zero); one launch at a time per workspace. */
+ * bytes, 16-byte aligned, ZERO before the first use (every launch leaves its counter zero); one launch at a time per workspace.
+ * The workgroups' partial losses meet in slots of the workspace and are added in a fixed order: *loss_out is bit-reproducible. */
 int las_proj_ce_supported(int V, int Vp, int M);
 size_t las_proj_ce_workspace_bytes(int B, int U);
 int las_proj_ce(const las_bf16* ctx, int64_t ld_ctx, const las_bf16* wprojT, const float* bproj, const las_bf16* wproj,

@@ -17,6 +17,32 @@ int las_check_hip(hipError_t e, const char* what) {
   return LAS_ERR_HIP;
 }
 
+// ---- knobs: name -> value, read from the environment once (first use), overridable through las_set_knob ----
+#include <map>
+#include <mutex>
+#include <string>
+#include <stdlib.h>
+static std::mutex g_knob_mutex;
+static std::map<std::string, int>& knob_table() { static std::map<std::string, int> t; return t; }
+
+int las_knob(const char* name, int default_value) {
+  std::lock_guard<std::mutex> lock(g_knob_mutex);
+  auto& t = knob_table();
+  auto it = t.find(name);
+  if (it != t.end()) return it->second;
+  const char* e = getenv(name);
+  const int v = (e && *e) ? atoi(e) : default_value;
+  t[name] = v;
+  return v;
+}
+
+extern "C" int las_set_knob(const char* name, int value) {
+  LAS_REQUIRE(name != nullptr && name[0] == 'L' && name[1] == 'A' && name[2] == 'S' && name[3] == '_', "las_set_knob: knob names start with LAS_");
+  std::lock_guard<std::mutex> lock(g_knob_mutex);
+  knob_table()[name] = value;
+  return LAS_OK;
+}
+
 extern "C" int las_version(void) { return 100; }
 extern "C" const char* las_last_error(void) { return g_err; }
 

@@ -4275,11 +4275,7 @@ extern "C" int las_decoder_persist_fwd(const las_dec_persist* p, void* stream) {
     LAS_LAUNCH_CHECK("persistent decoder fwd (attention layer / monotonic) launch");
     return LAS_OK;
   }
-  static int lean_mode = -1;                 // LAS_DEC_LEAN=0: the general body also where the written-out one applies (diagnostics)
-  if (lean_mode < 0) {
-    const char* e = getenv("LAS_DEC_LEAN");
-    lean_mode = (e && atoi(e) == 0) ? 0 : 1;
-  }
+  const int lean_mode = las_knob("LAS_DEC_LEAN", 1);     // 0: the general body also where the written-out one applies (diagnostics)
   if (lean_mode && (p->sampling_prob <= 0.f || s->Hd <= 256) && s->tok_rows &&
       persist_fwd_lean_ok(s->Hd, s->M, s->Tm, p->U, s->attention, s->norm) && p->K_in / 32 <= (s->Hd == 512 ? 80 : 48)) {
     const size_t lbytes = lean_layout(s->Hd, s->Tm, s->M, p->U).total_bytes;
@@ -4502,7 +4498,7 @@ extern "C" int las_decoder_seq_bwd(const las_dec_seq_bwd* p, void* stream) {
   }
   // Bahdanau scores: d(keys) in registers when the utterance's frames fit SEQ_NPK passes of the 256 / (Hd / 8) frame phases
   // (Tm <= 200 at 256 units, 400 at 128); LAS_DEC_SEQ_REGK=0 keeps the read-modify-write in memory (A/B measurements)
-  static const bool regk_on = [] { const char* e = getenv("LAS_DEC_SEQ_REGK"); return !(e && e[0] == '0'); }();
+  const bool regk_on = las_knob("LAS_DEC_SEQ_REGK", 1) != 0;
   const int P = 256 / (s->Hd / 8);
   const bool regk = additive && regk_on && q.A > 0 && q.vw && (s->Tm + P - 1) / P <= SEQ_NPK;
   // ... and four workgroups per utterance (the caller hands in the exchange workspace) when every one of them finds a CU of its

@@ -434,10 +434,8 @@ extern "C" int las_fe_batch_melspec(const float* waves, const int64_t* wave_off,
     hipLaunchKernelGGL(fill_f32_kernel, dim3((n_utt + 255) / 256), dim3(256), 0, st, utt_max, n_utt, -INFINITY);
     LAS_LAUNCH_CHECK("fe batch max init");
   }
-  static int blocked = -1;          // LAS_FE_BLOCKED=0: one frame per workgroup again (diagnostics, A/B timing)
-  if (blocked < 0) { const char* e = getenv("LAS_FE_BLOCKED"); blocked = (e && atoi(e) == 0) ? 0 : 1; }
-  static int fb16 = -1;             // LAS_FE_FB=16: sixteen frames per workgroup (A/B)
-  if (fb16 < 0) { const char* e = getenv("LAS_FE_FB"); fb16 = (e && atoi(e) == 16) ? 1 : 0; }
+  const int blocked = las_knob("LAS_FE_BLOCKED", 1);          // 0: one frame per workgroup again (diagnostics, A/B timing)
+  const int fb16 = las_knob("LAS_FE_FB", 8) == 16 ? 1 : 0;     // 16: sixteen frames per workgroup (A/B)
   constexpr int FB = 8;
   if (blocked && fb16 && (size_t)16 * (n_fft + bins) * sizeof(float) <= 60 * 1024 && total_frames >= 64)
     hipLaunchKernelGGL(batch_melspec_blocked_kernel<16>, dim3((total_frames + 15) / 16), dim3(256),

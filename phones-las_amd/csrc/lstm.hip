@@ -170,6 +170,20 @@ __global__ void pack_input_kernel(const float* kx, int D, int H, int chunks, uns
 // (loaded one step ahead; the companion keeps the rows L2-resident).  These products do not depend on h_{t-1}: they are issued
 // at the top of the step and run while the peers' granules are on their way, so the bottom listener layer needs no x K_x GEMM,
 // no 419 MB fp32 round trip of its result, and the chain no xproj load.  `xproj` is then only the saved-gates OUTPUT.
+// Progress of a chain for a FOLLOWER product (round 5; gemm.hip, las_gemm_nt_follow): a product over this launch's OUTPUT rows
+// (y: the next layer's input projection; dz: the gradient w.r.t. the layer's input) runs BESIDE the launch on the CUs the chain
+// leaves idle and consumes the rows behind the chain, direction by direction.  `words` is the buffer shared with it (layout:
+// las_follow_layout in las_common.h; zero before both launches).  The chain writes
+//   words[16 + group]   at its start: XCC id + 1 of the group (0xff: members spread over XCDs) | waves per group << 8 |
+//                       companions per group << 16 -- the follower's workgroups on that XCD read the rows through the L2 the
+//                       chain's plain stores land in;
+//   words[z0 + group]   += 1 per companion workgroup once the rows beyond every utterance's length are zero-filled;
+//   words[p0 + group]   += 1 per wave for every block of LAS_FOLLOW_STEPS steps whose stores have been acknowledged by the L2
+//                       (vmcnt(0) once per block, at a point of the step where the wave's memory queue is all but empty), and at
+//                       the end what is missing to ceil(T / LAS_FOLLOW_STEPS): waves * n says "all rows of the first n blocks
+//                       of steps are there".
+struct FollowPub { unsigned* words; int p0, z0; };
+
 struct FusedInput {
   const unsigned short* x;       // [B, T, ldx] bf16 (per direction: + dir * xdir elements)
   int64_t ldx, xdir;
@@ -184,7 +198,19 @@ struct FusedInput {
   unsigned* ready;
   int nsb, flags;
   unsigned want;
+  FollowPub pub;                 // a follower product consumes y behind this launch (words == nullptr: none)
 };
+
+__device__ __forceinline__ void follow_publish(const FollowPub& pub, int group, unsigned n) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's stores of every finished step are in the L2
+  if ((threadIdx.x & 63) == 0) atomicAdd(pub.words + pub.p0 + group, n);
+}
+__device__ __forceinline__ void follow_placement(const FollowPub& pub, int group, bool one_xcd, int waves, int companions) {
+  unsigned xcc;
+  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+  __hip_atomic_store(pub.words + 16 + group, (one_xcd ? (xcc & 7u) + 1u : 0xffu) | ((unsigned)waves << 8) | ((unsigned)companions << 16),
+                     __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 
 // Wait until the streamed rows of step block sb of this group are there (wave-uniform; bounded).  Returns false on timeout.
 __device__ __forceinline__ bool stream_wait(const FusedInput& fi, int group, int sb) {
@@ -280,6 +306,11 @@ __device__ __forceinline__ void lstm_fwd_body(float* __restrict__ xproj, const u
         const int t = e / LPR, c = cm * LPR + e % LPR;
         *reinterpret_cast<uint4*>(y + ((int64_t)bb * T + t) * yrow + dir * H + c * 8) = make_uint4(0, 0, 0, 0);
       }
+    }
+    if (fi.pub.words != nullptr) {                                // a follower product reads those rows: they are in the L2 now
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (tid == 0) atomicAdd(fi.pub.words + fi.pub.z0 + group, 1u);
     }
     const u64* tag0 = ex_group;                                   // member 0 publishes here every step
     int seen = -1;
@@ -394,6 +425,9 @@ __device__ __forceinline__ void lstm_fwd_body(float* __restrict__ xproj, const u
       __hip_atomic_store(fi.ready + 16 + group, (local || G == 1) ? (xcc & 7u) + 1u : 0x100u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
+
+  if (fi.pub.words != nullptr && member == 0 && tid == 0) follow_placement(fi.pub, group, local || G == 1, 4 * G, companions ? CPG : 0);
+  int pub_blocks = 0;                                         // blocks of LAS_FOLLOW_STEPS steps this wave has published
 
   const int unit0 = member * HS + wblk * 16 + l15;            // + ub*16
 
@@ -596,6 +630,10 @@ __device__ __forceinline__ void lstm_fwd_body(float* __restrict__ xproj, const u
     }
     LSTM_STAMP(0, s, 1);
     flush_pending();                          // the previous step's stores, now that this step's polls are served
+    if (fi.pub.words != nullptr && s > 0 && (s & (LAS_FOLLOW_STEPS - 1)) == 0) {      // (wave-uniform)
+      follow_publish(fi.pub, group, 1u);      // steps < s: what is still in flight here is this step's own operand load
+      ++pub_blocks;
+    }
     lds_barrier();
     LSTM_STAMP(0, s, 2);
     if (fail_flag) return false;
@@ -704,6 +742,7 @@ __device__ __forceinline__ void lstm_fwd_body(float* __restrict__ xproj, const u
   for (; s < smin && ok; ++s) ok = step(s, std::true_type{});
   for (; s < smax && ok; ++s) ok = step(s, std::false_type{});
   flush_pending();
+  if (fi.pub.words != nullptr) follow_publish(fi.pub, group, (unsigned)((T + LAS_FOLLOW_STEPS - 1) / LAS_FOLLOW_STEPS - pub_blocks));
 
   if (tid == 0) __hip_atomic_store(done_word, ((u64)(base + 1u) << 32) | 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // releases the companion
   if (!ok) {
@@ -744,21 +783,14 @@ __global__ __launch_bounds__(256) void lstm_fwd_kernel(float* __restrict__ xproj
 // is 4 x (G-1) granules each way, against 8 x 4 x (G-1) for an all-gather of dz_t.
 // kh is K_h [H, 4H] in bf16 with GATE-INTERLEAVED columns (u*4+g): a member's K range is contiguous.
 // ------------------------------------------------------------------------------------------------
-// TIME WINDOW of a backward launch (round 4): the chain runs its steps s in [s_lo, s_hi) only (s counts from the START of the
-// direction's forward pass: the backward walks s downwards) -- d(h), d(c) enter through dh_last / dc_last and, for s_lo > 0,
-// leave through dh_out / dc_out [ndir, B, H]: the next window's dh_last / dc_last.  The weight-gradient products over a window's
-// rows can then run beside the next window's chain (las_gemm_tn_lstm's row window) instead of behind the whole layer.
-struct BwdWindow { int s_lo, s_hi; float* dc_out; float* dh_out; };
-
-// WIN (compile time): the windowed form.  The one-launch form is its own instantiation -- with the window's bounds as run-time
-// values in the loop conditions the 128-unit chains ran 17-23 % slower (cfg1, default-arch: measured), the 256 / 512-unit ones 1 %.
-template <int H, int ROWS, int G, bool WIN = false>     // ROWS: utterances per slice, G: members, as in lstm_fwd_kernel
+// `pub`: a follower product (dX = dz K_x^T, gemm.hip las_gemm_nt_follow) consumes dz behind this launch, see FollowPub.
+template <int H, int ROWS, int G>     // ROWS: utterances per slice, G: members, as in lstm_fwd_kernel
 __device__ __forceinline__ void lstm_bwd_body(const float* __restrict__ gates, const float* __restrict__ cbuf,
                                               const float* __restrict__ dy, const float* __restrict__ dc_last,
                                               const float* __restrict__ dh_last, const unsigned short* __restrict__ kh,
                                               const int32_t* __restrict__ length, unsigned short* __restrict__ dz,
                                               u64* __restrict__ exch, unsigned* __restrict__ status,
-                                              int B, int T, int ndir, int ngroups, const unsigned base, const BwdWindow win) {
+                                              int B, int T, int ndir, int ngroups, const unsigned base, const FollowPub pub, const int companions) {
   constexpr int HS = H / G;
   constexpr int NUB = HS / 16;                    // 16-unit blocks of a member
   constexpr bool SPLIT = NUB < 4;                 // H = 512: two waves share a unit block, two rows of every quad each
@@ -813,17 +845,16 @@ __device__ __forceinline__ void lstm_bwd_body(const float* __restrict__ gates, c
     smin = -(int)las_wave_max((float)(-ll));
   }
   if ((int64_t)B * T * grow * 4 >= ((int64_t)1 << 32)) smin = 0;     // 32-bit byte offsets do not reach: general path only
-  const int s_lo = WIN ? max(win.s_lo, 0) : 0, s_start = (WIN ? min(smax, win.s_hi) : smax) - 1;     // this launch's steps: s_start down to s_lo
+  const int s_start = smax - 1;                  // this launch's steps: s_start down to 0
 
   if (companion) {
     // PREFETCH COMPANION (see lstm_fwd_kernel): gates, c and dy lines of the whole group, PF_AHEAD steps ahead.
     constexpr int PF_AHEAD = 6;
     const int mylen = (l15 < ROWS && slice * ROWS + l15 < B) ? min(length[slice * ROWS + l15], T) : 0;
     // dz rows t >= length are zero: cleared here (the direction's gate columns), so dense batches need no memset of dz
-    // (the launch of the window that reaches the end of the sequences does it)
     for (int rr = wave * (ROWS / 4); rr < (wave + 1) * (ROWS / 4); ++rr) {
       const int bb = slice * ROWS + rr;
-      if (bb >= B || (WIN && win.s_hi < T)) continue;
+      if (bb >= B) continue;
       const int ll = __builtin_amdgcn_readlane(mylen, rr);
       constexpr int LPR = 4 * H * 2 / 16 / CPG;
       for (int e = ll * LPR + lane; e < T * LPR; e += 64) {
@@ -831,9 +862,14 @@ __device__ __forceinline__ void lstm_bwd_body(const float* __restrict__ gates, c
         *reinterpret_cast<uint4*>(dz + ((int64_t)bb * T + t) * grow + dir * 4 * H + c * 8) = make_uint4(0, 0, 0, 0);
       }
     }
+    if (pub.words != nullptr) {                                   // a follower product reads those rows: they are in the L2 now
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (tid == 0) atomicAdd(pub.words + pub.z0 + group, 1u);
+    }
     const u64* tag0 = ex_group + (G > 1 ? (int64_t)(1 * G + 0) * PAIR : 0);   // (destination 1, sender 0): member 0 writes it every step (G = 1: a progress granule)
     int seen = -1;
-    for (int it = 0; it <= s_start - s_lo; ++it) {
+    for (int it = 0; it <= s_start; ++it) {
       const int sp = s_start - it;
       unsigned spins = 0;
       while (seen < it - PF_AHEAD) {
@@ -913,6 +949,8 @@ __device__ __forceinline__ void lstm_bwd_body(const float* __restrict__ gates, c
   if (tid == 0) fail_flag = 0;
   __syncthreads();
   const bool local = xcd_colocated<G>(exch + 2 * par_stride + (int64_t)group * G, member, &colo_flag, status, base);
+  if (pub.words != nullptr && member == 0 && tid == 0) follow_placement(pub, group, local || G == 1, 4 * G, companions ? CPG : 0);
+  int pub_blocks = 0;
 
   // loop-invariant pieces of the exchange (byte offsets inside the group's parity slot)
   unsigned poll_off[PER], send_off[NT > OWN ? NT - OWN : 1];
@@ -1014,7 +1052,7 @@ __device__ __forceinline__ void lstm_bwd_body(const float* __restrict__ gates, c
   int cur = 0;
   unsigned epoch = 0;          // = iterations done; partial sums sent in iteration i carry tag i+1 in parity slot i&1
   bool ok = true;
-  set_goff(WIN ? max(min(smin - 1, s_start), 0) : (smin > 0 ? smin - 1 : 0));
+  set_goff(smin > 0 ? smin - 1 : 0);
   load_general(s_start);
   prepare();
   // one time step; LEAN (compile time): every row of the slice is running at step s (and at s - 1: the lean loader).
@@ -1065,6 +1103,10 @@ __device__ __forceinline__ void lstm_bwd_body(const float* __restrict__ gates, c
     }
 
     LSTM_STAMP(2048, smax - 1 - s, 1);
+    if (pub.words != nullptr && epoch > 0 && (epoch & (LAS_FOLLOW_STEPS - 1)) == 0) {     // (wave-uniform)
+      follow_publish(pub, group, 1u);          // the dz rows of the first `epoch` iterations; in flight here: the last one's stores
+      ++pub_blocks;
+    }
     // next step's operands first: in flight during the gate math, the product and the exchange, and ahead of this
     // step's dz stores in the in-order vector-memory queue
     unsigned zoff[RPL];
@@ -1170,62 +1212,23 @@ __device__ __forceinline__ void lstm_bwd_body(const float* __restrict__ gates, c
   {
     int s = s_start;
     bool go = true;
-    if constexpr (WIN) {
-      for (; s >= smin && s >= s_lo && go; --s) go = iter(s, std::false_type{});
-      for (; s >= s_lo && go; --s) go = iter(s, std::true_type{});
-    } else {
-      for (; s >= smin && go; --s) go = iter(s, std::false_type{});
-      for (; s >= 0 && go; --s) go = iter(s, std::true_type{});
-    }
-    if (WIN && s_lo > 0) {
-      // ---- end of a time window: complete dh_{s_lo - 1} (the partial sums of the last iteration are on their way) and hand
-      //      d(h), d(c) to the next window's launch (a slice that is over before the window: its initial values).  A copy of
-      //      the poll at the top of iter(): the hot loop stays as it is. ----
-      const bool ran = s_start >= s_lo && go && ok;
-      if constexpr (G > 1) {
-        if (ran) {
-          const char* src = reinterpret_cast<const char*>(ex_group + (int64_t)((epoch - 1) & 1) * par_stride);
-  #pragma unroll
-          for (int e = 0; e < PER; ++e) {
-            u64 v = 0;
-            unsigned spins = 0;
-            for (;;) {
-              v = granule_load(reinterpret_cast<const u64*>(src + poll_off[e]));
-              if (__all((unsigned)(v >> 32) == base + epoch)) break;
-              if (++spins > SPIN_LIMIT) { fail_flag = 1; ok = false; break; }
-              __builtin_amdgcn_s_sleep(1);
-            }
-            const int ub = SPLIT ? 0 : (e / RPL) % UBW, r = e % RPL;
-            part[ub][r] += __uint_as_float((unsigned)v);
-          }
-        }
-      }
-#pragma unroll
-      for (int ub = 0; ub < UBW; ++ub)
-#pragma unroll
-        for (int r = 0; r < RPL; ++r) {
-          if (ran && s_lo < len[r]) dh[ub][r] = part[ub][r];   // rows that were running at step s_lo
-          if (bidx[r] < B && win.dh_out && win.dc_out) {
-            const int64_t o = ((int64_t)dir * B + bidx[r]) * H + unit0 + ub * 16;
-            win.dh_out[o] = dh[ub][r];
-            win.dc_out[o] = dc[ub][r];
-          }
-        }
-    }
+    for (; s >= smin && go; --s) go = iter(s, std::false_type{});
+    for (; s >= 0 && go; --s) go = iter(s, std::true_type{});
   }
+  if (pub.words != nullptr) follow_publish(pub, group, (unsigned)((T + LAS_FOLLOW_STEPS - 1) / LAS_FOLLOW_STEPS - pub_blocks));
   if (tid == 0) __hip_atomic_store(done_word, ((u64)(base + 1u) << 32) | 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   if (!ok && tid == 0) atomicOr(status, 2u);
 }
 
-template <int H, int ROWS, int G = coop_members(H), bool WIN = false>
+template <int H, int ROWS, int G = coop_members(H)>
 __global__ __launch_bounds__(256) void lstm_bwd_kernel(const float* __restrict__ gates, const float* __restrict__ cbuf,
                                                        const float* __restrict__ dy, const float* __restrict__ dc_last,
                                                        const float* __restrict__ dh_last, const unsigned short* __restrict__ kh,
                                                        const int32_t* __restrict__ length, unsigned short* __restrict__ dz,
                                                        u64* __restrict__ exch, unsigned* __restrict__ status,
-                                                       int B, int T, int ndir, int ngroups, long long exch_words, const BwdWindow win) {
+                                                       int B, int T, int ndir, int ngroups, long long exch_words, const FollowPub pub, int companions) {
   const unsigned base = launch_base(status);
-  lstm_bwd_body<H, ROWS, G, WIN>(gates, cbuf, dy, dc_last, dh_last, kh, length, dz, exch, status, B, T, ndir, ngroups, base, win);
+  lstm_bwd_body<H, ROWS, G>(gates, cbuf, dy, dc_last, dh_last, kh, length, dz, exch, status, B, T, ndir, ngroups, base, pub, companions);
   launch_arrive(status, base, T, exch, exch_words);
 }
 
@@ -1235,9 +1238,7 @@ struct CoopGeom { int nslices, ngroups, G, blocks, companions; size_t exch_bytes
 // round-2 form: 16 members of 32 units with the K split / row split inside the workgroup)
 int members(int H) {
   if (H != 512) return coop_members(H);
-  const char* e = getenv("LAS_LSTM_G512");          // read at every launch: tests and A/B runs switch it
-  const int g = e ? atoi(e) : 8;
-  return g == 16 ? 16 : 8;
+  return las_knob("LAS_LSTM_G512", 8) == 16 ? 16 : 8;
 }
 
 CoopGeom geom(int B, int H, int ndir, bool bwd, int rows = 16, int G = 0) {
@@ -1258,16 +1259,9 @@ CoopGeom geom(int B, int H, int ndir, bool bwd, int rows = 16, int G = 0) {
 // Utterances per slice: the shortest (4, 8, 16; see lstm_fwd_kernel) whose chains, with their companions, still find
 // a CU each (256 on MI355X); LAS_LSTM_ROWS=16 / 8 / 4 forces one (tests, diagnostics).
 int slice_rows(int B, int H, int ndir, bool bwd) {
-  const char* e = getenv("LAS_LSTM_ROWS");          // read at every launch: the tests switch it
-  const int forced = e ? atoi(e) : 0;
+  const int forced = las_knob("LAS_LSTM_ROWS", 0);
   if (H > 256 && members(H) == 16) {    // the 16-member 512-unit kernels (K split, row split): 16 or 8 rows
-    static int r512 = -1;               // LAS_LSTM_ROWS512=16 / 8: the default for both directions (diagnostics)
-    if (r512 < 0) {
-      const char* e5 = getenv("LAS_LSTM_ROWS512");
-      r512 = e5 ? atoi(e5) : 0;
-    }
     if (forced == 16 || forced == 8) return forced;
-    if (r512 == 16 || r512 == 8) return r512;
     return 16;
   }
   if (forced == 16 || forced == 8 || forced == 4) return forced;
@@ -1289,14 +1283,7 @@ int slice_rows(int B, int H, int ndir, bool bwd) {
 }
 
 // LAS_LSTM_PREFETCH=0 launches the recurrent kernels without their prefetch companions (diagnostics)
-int prefetch_mode() {
-  static int mode = -1;
-  if (mode < 0) {
-    const char* e = getenv("LAS_LSTM_PREFETCH");
-    mode = (e && atoi(e) == 0) ? 0 : 1;
-  }
-  return mode;
-}
+int prefetch_mode() { return las_knob("LAS_LSTM_PREFETCH", 1) != 0; }
 
 // 64-bit words of the workspace behind its header: what the last workgroup clears before the launch tags would wrap (the
 // whole exchange area of las_lstm_workspace_bytes, not only this launch's layout: forward and backward launches of every layer
@@ -1317,8 +1304,7 @@ int launch_fwd_as(float* xproj, const las_bf16* wp, const int32_t* length, las_b
     static int hog_kb = -1;
     if (hog_kb < 0) {
       constexpr int static_kb = (2 * 16 * (H + 8) * 2 + 1024 + 4096 + 1023) / 1024 + 2;
-      const char* e = getenv("LAS_STREAM_HOG_KB");          // (diagnostics: 0 lets the product's workgroups share the chain's CUs)
-      hog_kb = e ? atoi(e) : 160 - static_kb - 6;
+      hog_kb = las_knob("LAS_STREAM_HOG_KB", 160 - static_kb - 6);     // (diagnostics: 0 lets the product's workgroups share the chain's CUs)
       if (hog_kb > 160 - static_kb - 2) hog_kb = 160 - static_kb - 2;
       if (hog_kb > 0) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&lstm_fwd_kernel<H, ROWS, G, KX>), hipFuncAttributeMaxDynamicSharedMemorySize, hog_kb * 1024);
     }
@@ -1376,7 +1362,7 @@ int launch_fwd(float* xproj, const las_bf16* wp, const int32_t* length, las_bf16
 template <int H, int ROWS, int G>
 int launch_bwd_as(const float* gates, const float* cbuf, const float* dy, const float* dc_last, const float* dh_last,
                   const las_bf16* kh, const int32_t* length, las_bf16* dz, void* ws, int B, int T, int ndir, hipStream_t st,
-                  const BwdWindow win) {
+                  const FollowPub pub) {
   const CoopGeom g = geom(B, H, ndir, true, ROWS, G);
   unsigned* status = reinterpret_cast<unsigned*>(ws);
   u64* exch = reinterpret_cast<u64*>(reinterpret_cast<char*>(ws) + 64);
@@ -1388,22 +1374,15 @@ int launch_bwd_as(const float* gates, const float* cbuf, const float* dy, const 
   // margin smaller than any GEMM workgroup's need.
   static int hog_kb = -1;
   if (hog_kb < 0) {
-    const char* e = getenv("LAS_LSTM_BWD_LDS_KB");
     constexpr int HS_ = H / G;
     constexpr int static_kb = (2 * 16 * (4 * HS_ + 8) * 2 + 1024 + 1023) / 1024 + 1;
-    hog_kb = e ? atoi(e) : 160 - static_kb - 6;
+    hog_kb = las_knob("LAS_LSTM_BWD_LDS_KB", 160 - static_kb - 6);
     if (hog_kb > 160 - static_kb - 2) hog_kb = 160 - static_kb - 2;
-    if (hog_kb > 0) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&lstm_bwd_kernel<H, ROWS, G, false>), hipFuncAttributeMaxDynamicSharedMemorySize, hog_kb * 1024);
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&lstm_bwd_kernel<H, ROWS, G, true>), hipFuncAttributeMaxDynamicSharedMemorySize, hog_kb * 1024);
-    }
+    if (hog_kb > 0)
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&lstm_bwd_kernel<H, ROWS, G>), hipFuncAttributeMaxDynamicSharedMemorySize, hog_kb * 1024);
   }
-  if (win.s_lo > 0 || win.s_hi < T)
-    hipLaunchKernelGGL((lstm_bwd_kernel<H, ROWS, G, true>), dim3(pf ? g.blocks + g.companions : g.blocks), dim3(256), (size_t)(hog_kb > 0 ? hog_kb : 0) * 1024, st,
-                       gates, cbuf, dy, dc_last, dh_last, kh, length, dz, exch, status, B, T, ndir, g.ngroups, exch_words(B, H, ndir), win);
-  else
-    hipLaunchKernelGGL((lstm_bwd_kernel<H, ROWS, G, false>), dim3(pf ? g.blocks + g.companions : g.blocks), dim3(256), (size_t)(hog_kb > 0 ? hog_kb : 0) * 1024, st,
-                       gates, cbuf, dy, dc_last, dh_last, kh, length, dz, exch, status, B, T, ndir, g.ngroups, exch_words(B, H, ndir), win);
+  hipLaunchKernelGGL((lstm_bwd_kernel<H, ROWS, G>), dim3(pf ? g.blocks + g.companions : g.blocks), dim3(256), (size_t)(hog_kb > 0 ? hog_kb : 0) * 1024, st,
+                     gates, cbuf, dy, dc_last, dh_last, kh, length, dz, exch, status, B, T, ndir, g.ngroups, exch_words(B, H, ndir), pub, pf);
   LAS_LAUNCH_CHECK("lstm bwd launch");
   return LAS_OK;
 }
@@ -1411,9 +1390,9 @@ int launch_bwd_as(const float* gates, const float* cbuf, const float* dy, const 
 template <int H>
 int launch_bwd(const float* gates, const float* cbuf, const float* dy, const float* dc_last, const float* dh_last,
                const las_bf16* kh, const int32_t* length, las_bf16* dz, void* ws, int B, int T, int ndir, hipStream_t st,
-               const BwdWindow win) {
+               const FollowPub pub) {
   const int rows = slice_rows(B, H, ndir, true);
-#define LAS_BWD(R, GG) return launch_bwd_as<H, R, GG>(gates, cbuf, dy, dc_last, dh_last, kh, length, dz, ws, B, T, ndir, st, win)
+#define LAS_BWD(R, GG) return launch_bwd_as<H, R, GG>(gates, cbuf, dy, dc_last, dh_last, kh, length, dz, ws, B, T, ndir, st, pub)
   if constexpr (H == 512) {
     if (members(H) == 8) {
       if (rows == 4) LAS_BWD(4, 8);
@@ -1431,6 +1410,14 @@ int launch_bwd(const float* gates, const float* cbuf, const float* dy, const flo
 }
 
 bool supported_units(int H) { return H == 64 || H == 128 || H == 256 || H == 512; }
+
+// the follower's shared words as a chain launch sees them (las_follow_layout_of: the same arithmetic as in gemm.hip)
+FollowPub follow_pub(uint32_t* words, int B, int H, int ndir, bool bwd) {
+  if (words == nullptr) return FollowPub{nullptr, 0, 0};
+  const int rows = slice_rows(B, H, ndir, bwd);
+  const las_follow_layout L = las_follow_layout_of(((B + rows - 1) / rows) * ndir, 0);
+  return FollowPub{words, L.p0, L.z0};
+}
 
 }  // namespace
 
@@ -1522,44 +1509,38 @@ extern "C" int las_lstm_recurrent_fwd_ex(const las_lstm_fwd* p, void* stream) {
     fi.flags = 16 + ((((p->B + rows - 1) / rows) * p->ndir + 15) & ~15);
     fi.want = (unsigned)p->ready_count;
   }
+  fi.pub = follow_pub(p->follow, p->B, p->H, p->ndir, false);
   return recurrent_fwd(p->xproj, p->wpacked, p->length, p->y, p->cbuf, p->c_last, p->h_last, p->workspace, p->B, p->T, p->H, p->ndir, stream, fi);
 }
 
-extern "C" int las_lstm_recurrent_bwd_window(const float* gates, const float* cbuf, const float* dy, const float* dc_last,
-                                             const float* dh_last, const las_bf16* kh_bf16, const int32_t* length,
-                                             las_bf16* dz, void* workspace, int B, int T, int H, int ndir, int s_lo, int s_hi,
-                                             float* dc_out, float* dh_out, void* stream);
-
-extern "C" int las_lstm_recurrent_bwd(const float* gates, const float* cbuf, const float* dy, const float* dc_last,
-                                      const float* dh_last, const las_bf16* kh_bf16, const int32_t* length,
-                                      las_bf16* dz, void* workspace, int B, int T, int H, int ndir, void* stream) {
-  return las_lstm_recurrent_bwd_window(gates, cbuf, dy, dc_last, dh_last, kh_bf16, length, dz, workspace, B, T, H, ndir, 0, T, nullptr,
-                                       nullptr, stream);
-}
-
-extern "C" int las_lstm_recurrent_bwd_window(const float* gates, const float* cbuf, const float* dy, const float* dc_last,
-                                             const float* dh_last, const las_bf16* kh_bf16, const int32_t* length,
-                                             las_bf16* dz, void* workspace, int B, int T, int H, int ndir, int s_lo, int s_hi,
-                                             float* dc_out, float* dh_out, void* stream) {
+namespace {
+int recurrent_bwd(const float* gates, const float* cbuf, const float* dy, const float* dc_last, const float* dh_last,
+                  const las_bf16* kh_bf16, const int32_t* length, las_bf16* dz, void* workspace, int B, int T, int H, int ndir,
+                  void* stream, const FollowPub pub) {
   LAS_REQUIRE(B > 0 && T > 0 && (ndir == 1 || ndir == 2), "las_lstm_recurrent_bwd: bad shape");
-  LAS_REQUIRE(s_lo >= 0 && s_lo < s_hi && s_hi <= T && (s_lo == 0 || (dc_out && dh_out)),
-              "las_lstm_recurrent_bwd_window: steps [%d, %d) of %d; a window that stops above step 0 hands d(c), d(h) on", s_lo, s_hi, T);
-  const BwdWindow win{s_lo, s_hi, dc_out, dh_out};
   LAS_REQUIRE(supported_units(H), "las_lstm_recurrent_bwd: num_units %d not in {64,128,256,512}", H);
   LAS_REQUIRE(workspace != nullptr && ((uintptr_t)workspace % 16 == 0), "las_lstm_recurrent_bwd: workspace missing or misaligned");
   hipStream_t st = (hipStream_t)stream;
   int rc = 0;
-  if (!prefetch_mode() && s_hi >= T) {
+  if (!prefetch_mode()) {
     rc = las_check_hip(hipMemsetAsync(dz, 0, (size_t)B * T * ndir * 4 * H * sizeof(las_bf16), st), "memset dz");
     if (rc) return rc;
   }
   // (no memset of the exchange buffer: launch epochs, see las_lstm_recurrent_fwd)
   switch (H) {
-    case 64: return launch_bwd<64>(gates, cbuf, dy, dc_last, dh_last, kh_bf16, length, dz, workspace, B, T, ndir, st, win);
-    case 128: return launch_bwd<128>(gates, cbuf, dy, dc_last, dh_last, kh_bf16, length, dz, workspace, B, T, ndir, st, win);
-    case 512: return launch_bwd<512>(gates, cbuf, dy, dc_last, dh_last, kh_bf16, length, dz, workspace, B, T, ndir, st, win);
-    default: return launch_bwd<256>(gates, cbuf, dy, dc_last, dh_last, kh_bf16, length, dz, workspace, B, T, ndir, st, win);
+    case 64: return launch_bwd<64>(gates, cbuf, dy, dc_last, dh_last, kh_bf16, length, dz, workspace, B, T, ndir, st, pub);
+    case 128: return launch_bwd<128>(gates, cbuf, dy, dc_last, dh_last, kh_bf16, length, dz, workspace, B, T, ndir, st, pub);
+    case 512: return launch_bwd<512>(gates, cbuf, dy, dc_last, dh_last, kh_bf16, length, dz, workspace, B, T, ndir, st, pub);
+    default: return launch_bwd<256>(gates, cbuf, dy, dc_last, dh_last, kh_bf16, length, dz, workspace, B, T, ndir, st, pub);
   }
+}
+}  // namespace
+
+extern "C" int las_lstm_recurrent_bwd(const float* gates, const float* cbuf, const float* dy, const float* dc_last,
+                                      const float* dh_last, const las_bf16* kh_bf16, const int32_t* length,
+                                      las_bf16* dz, void* workspace, int B, int T, int H, int ndir, uint32_t* follow, void* stream) {
+  return recurrent_bwd(gates, cbuf, dy, dc_last, dh_last, kh_bf16, length, dz, workspace, B, T, H, ndir, stream,
+                       follow_pub(follow, B, H, ndir, true));
 }
 
 #ifdef LAS_STAMPS

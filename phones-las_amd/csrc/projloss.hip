@@ -9,8 +9,8 @@
 // its four waves (operand pieces straight from global memory: W_proj is 128 KB and L2-resident), the partial tiles meet in LDS,
 // every wave then normalises four rows (wave reductions), and the 16 x Vp tile of dlogits is the A operand -- from LDS -- of the
 // product back through W_proj, 16 column tiles of 16 per wave.  The loss needs no zeroed output in front of the launch: the
-// workgroups add their partial sums into an accumulator of a small persistent workspace and the LAST one to arrive (a counter
-// it resets) hands the total over and clears the accumulator.
+// workgroups leave their partial sums in slots of a small persistent workspace and the LAST one to arrive (a counter it resets)
+// adds them in a fixed order (no fp32 atomics: the loss is bit-reproducible).
 #include "las_common.h"
 
 namespace {
@@ -143,17 +143,25 @@ __global__ __launch_bounds__(256) void proj_ce_kernel(const unsigned short* __re
     }
   }
 
-  // ---- the loss: one returning atomic per workgroup into an accumulator of the workspace, then the arrival counter; the last
-  // workgroup to arrive hands the sum over and clears both (returning atomics are performed when they return, and all of them
-  // meet at one coherence point: no zeroed output, no fill launch in front of the kernel) ----
+  // ---- the loss: every workgroup leaves its partial sum in ITS slot of the workspace (write-through) and arrives at a counter;
+  // the LAST one to arrive adds the slots in a fixed order (lane i: slots i, i + 64, ...; then the wave butterfly) -- the reported
+  // loss is the same bits from run to run, as every other sum of the train op -- and resets the counter.  No zeroed output, no
+  // fill launch in front of the kernel. ----
+  __shared__ int last_one;
   if (tid == 0) {
     const float mine = wl[0] + wl[1] + wl[2] + wl[3];
-    const float before = __hip_atomic_fetch_add(partial, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    asm volatile("s_waitcnt vmcnt(0)" :: "v"(before) : "memory");       // the add has been performed (its old value is back)
+    __hip_atomic_store(partial + blockIdx.x, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                    // the slot is at the coherence point before the arrival
     const unsigned n = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (n == gridDim.x - 1) {
-      const float total_loss = __hip_atomic_exchange(partial, 0.f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      *loss_out = total_loss;
+    last_one = (n == gridDim.x - 1) ? 1 : 0;
+  }
+  __syncthreads();
+  if (last_one && wave == 0) {
+    float sum = 0.f;
+    for (int i = lane; i < (int)gridDim.x; i += 64) sum += __hip_atomic_load(partial + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    sum = las_wave_sum(sum);
+    if (lane == 0) {
+      *loss_out = sum;
       __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
@@ -166,8 +174,8 @@ extern "C" int las_proj_ce_supported(int V, int Vp, int M) {
 }
 
 extern "C" size_t las_proj_ce_workspace_bytes(int B, int U) {
-  (void)B; (void)U;
-  return 128;            // arrival counter + accumulator (zero before the first use; every launch leaves them zero)
+  // arrival counter (zero before the first use; every launch leaves it zero) + one partial-sum slot per workgroup
+  return 64 + sizeof(float) * (size_t)(((size_t)B * U + PL_ROWS - 1) / PL_ROWS);
 }
 
 extern "C" int las_proj_ce(const las_bf16* ctx, int64_t ld_ctx, const las_bf16* wprojT, const float* bproj, const las_bf16* wproj,

@@ -37,8 +37,11 @@ _SIGS = {
     'las_colsum_bf16_ws': ([_vp, _i64, _i32, _i32, _vp, _i32, _vp, C.c_size_t, _vp], C.c_int),
     'las_lstm_pack_recurrent': ([_vp, _i32, _vp, _vp], C.c_int),
     'las_lstm_recurrent_fwd': ([_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp], C.c_int),
-    'las_lstm_recurrent_bwd': ([_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp], C.c_int),
-    'las_lstm_recurrent_bwd_window': ([_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp], C.c_int),
+    'las_lstm_recurrent_bwd': ([_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp], C.c_int),
+    'las_set_knob': ([C.c_char_p, _i32], C.c_int),
+    'las_gemm_nt_follow_supported': ([_i32, _i32, _i32, _i32, _i32], C.c_int),
+    'las_gemm_nt_follow_words': ([_i32, _i32, _i32, _i32, _i32], C.c_size_t),
+    'las_gemm_nt_follow': ([_vp, _i32, _vp], C.c_int),
     'las_lstm_fused_input_chunks': ([_i32, _i32], C.c_int),
     'las_lstm_pack_input': ([_vp, _i32, _i32, _i32, _vp, _vp], C.c_int),
     'las_lstm_recurrent_fwd_ex': ([_vp, _vp], C.c_int),
@@ -106,7 +109,6 @@ _SIGS = {
     'las_add_noise': ([_vp, _i64, _f32, C.c_uint32, C.c_uint32, _vp], C.c_int),
     'las_gemm_tn_lstm_workspace_bytes': ([C.c_int, C.c_int, C.c_int], C.c_size_t),
     'las_gemm_tn_lstm': ([_vp, _i64, C.c_int, _vp, _i64, C.c_int, C.c_int, C.c_int, _vp, _i64, _vp, _vp, C.c_int, C.c_int, _vp, _vp], C.c_int),
-    'las_gemm_tn_lstm_window': ([_vp, _i64, C.c_int, _vp, _i64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp, _i64, _vp, _vp, C.c_int, _vp, _vp], C.c_int),
     'las_decoder_persist_supported': ([C.c_int] * 5, C.c_int),
     'las_decoder_persist_al_supported': ([_i32, _i32, _i32, _i32, _i32, _i32], C.c_int),
     'las_decoder_persist2_supported': ([_i32, _i32, _i32, _i32, _i32, _i32], C.c_int),
@@ -134,7 +136,15 @@ class LstmFwd(C.Structure):
     _fields_ = [('xproj', _vp), ('wpacked', _vp), ('length', _vp), ('y', _vp), ('cbuf', _vp), ('c_last', _vp), ('h_last', _vp),
                 ('workspace', _vp), ('B', _i32), ('T', _i32), ('H', _i32), ('ndir', _i32),
                 ('x', _vp), ('ldx', _i64), ('x_dir_stride', _i64), ('Dp', _i32), ('reserved0', _i32), ('kx_packed', _vp), ('bias', _vp),
-                ('ready', _vp), ('ready_count', _i32), ('reserved1', _i32)]
+                ('ready', _vp), ('ready_count', _i32), ('reserved1', _i32), ('follow', _vp)]
+
+
+class Follow(C.Structure):
+    """struct las_follow (include/las_hip.h)."""
+    _fields_ = [('A', _vp), ('Bw', _vp), ('C', _vp), ('bias', _vp), ('lda', _i64), ('ldb', _i64), ('ldc', _i64),
+                ('a_dir', _i32), ('a_seg', _i32), ('b_dir', _i32), ('b_seg', _i32), ('nseg', _i32), ('seg_len', _i32),
+                ('N', _i32), ('B', _i32), ('T_out', _i32), ('T_chain', _i32), ('stack', _i32), ('rows_per_slice', _i32), ('ndir', _i32),
+                ('kind', _i32), ('length', _vp), ('words', _vp), ('workgroups', _i32), ('reserved', _i32)]
 
 
 class DecStep(C.Structure):
@@ -280,6 +290,11 @@ def lib():
             fn.restype = res
         _lib = l
     return _lib
+
+
+def set_knob(name, value):
+    """Override one of the library's LAS_* integer switches (it reads the environment only once): the tests' hook."""
+    check(lib().las_set_knob(name.encode(), int(value)))
 
 
 def check(rc):

@@ -289,6 +289,10 @@ class Speller:
         Hd, V, Vp, U = self.Hd, self.V, self.Vp, num_steps
         dev, bf, f32 = memory.device, torch.bfloat16, torch.float32
         lib, st = hip.lib(), hip.stream()
+        if self.saved is not None and overlap is not None:
+            # a forward_train that no backward() followed left its h W_mem^T product on the side stream: joined and released here
+            overlap.join()
+        self.saved = None
         c0, h0, passed = self._initial_state(encoder_state, B, want_zeros=False)
         keys = self._keys(memory, B, Tm)
         W = M + Hd
@@ -399,8 +403,11 @@ class Speller:
             dlog = torch.empty(B, U, Vp, dtype=bf, device=dev)
             dattn_proj = torch.empty(B, U, M, dtype=f32, device=dev)
             loss = torch.empty(1, dtype=f32, device=dev)
-            if getattr(self, '_projce_ws', None) is None:
-                self._projce_ws = torch.zeros(lib.las_proj_ce_workspace_bytes(B, U), dtype=torch.uint8, device=dev)
+            need = lib.las_proj_ce_workspace_bytes(B, U)
+            if getattr(self, '_projce_ws', None) is None or self._projce_ws.numel() < need:
+                if torch.cuda.is_current_stream_capturing():
+                    raise hip.LasError('las_proj_ce: new workspace during graph capture (run the step once eagerly first)')
+                self._projce_ws = torch.zeros(need, dtype=torch.uint8, device=dev)
             hip.check(lib.las_proj_ce(hip.p(ctx_all), M, hip.p(self.wprojT), hip.p(self.bproj), hip.p(self.wproj), hip.p(tout),
                                       tout.stride(0), hip.p(tlen), B, U, V, Vp, M, float(gscale), hip.p(logits), hip.p(dlog),
                                       hip.p(dattn_proj), M, hip.p(loss), hip.p(self._projce_ws), st))
@@ -418,6 +425,10 @@ class Speller:
         """dlogits bf16 [B,U,Vp] (zero in the pad columns).  Accumulates weight gradients into ``grads`` and
         returns (d_memory fp32 [B,T',M], d_encoder_state or None)."""
         sv = self.saved
+        if sv is None:
+            # (the running d(c) and the d(scores) rows are cleared by forward_train's fill launch only: a second pass over the
+            # same saved forward would start from the first one's leftovers)
+            raise hip.LasError('Speller.backward: no saved forward pass (every forward_train is consumed by ONE backward)')
         B, Tm, U = sv['B'], sv['Tm'], sv['U']
         Tmp = _r8(Tm)
         Hd, V, Vp, M = self.Hd, self.V, self.Vp, self.M

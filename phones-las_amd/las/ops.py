@@ -96,6 +96,7 @@ class Overlap:
     def __init__(self):
         self.side = torch.cuda.Stream()
         self.side2 = None           # a third stream, created on first use (fork(..., lane=1))
+        self.side2_busy = False     # something was forked onto side2 since the last join()
         self.keep = []
 
     # how long side work that is going to run BESIDE a recurrent launch is held back (see fork)
@@ -111,6 +112,8 @@ class Overlap:
         if lane and self.side2 is None:
             self.side2 = torch.cuda.Stream()
         side = self.side2 if lane else self.side
+        if lane:
+            self.side2_busy = True
         side.wait_stream(torch.cuda.current_stream())
         self.keep.extend(tensors)
         if beside_chain and self.BESIDE_US > 0:
@@ -122,20 +125,30 @@ class Overlap:
         return ctx
 
     def mark(self):
-        """An event after everything forked so far (the main stream can wait for exactly that much of the side stream)."""
-        ev = torch.cuda.Event()
-        ev.record(self.side)
-        return ev
+        """Events after everything forked so far, on every side stream in use; .wait() makes the current stream wait for exactly
+        that much of them."""
+        streams = [self.side] + ([self.side2] if self.side2_busy else [])     # (an idle side2 holds nothing to wait for -- and
+        return _Marks([s.record_event() for s in streams])                    #  may not be part of a graph capture yet)
 
     def join(self):
         torch.cuda.current_stream().wait_stream(self.side)
         if self.side2 is not None:
             torch.cuda.current_stream().wait_stream(self.side2)
+        self.side2_busy = False
         self.keep.clear()
 
     def join_side(self):
         """The main stream waits for what the first side stream holds so far (nothing is released: join() does that)."""
         torch.cuda.current_stream().wait_stream(self.side)
+
+
+class _Marks:
+    def __init__(self, events):
+        self.events = events
+
+    def wait(self):
+        for ev in self.events:
+            torch.cuda.current_stream().wait_event(ev)
 
 
 class _NoOverlap:
@@ -287,14 +300,101 @@ def _stream_setup(a, lda, a_dir_stride, weights, xproj, sequence_length, B, T, H
     return (ready, 4 * H // 128, launch_product)
 
 
+# LAS_FOLLOW=0: no follower products (round 5) -- the next layer's input projection / the gradient w.r.t. a layer's input are
+# formed behind the recurrence again (or streamed beside the consumer, STREAM_X) instead of behind the chains that produce
+# their operands.  LAS_FOLLOW_WGS: persistent workgroups of a follower (the recurrence keeps a CU per workgroup of its own).
+FOLLOW = os.environ.get('LAS_FOLLOW', '1') != '0'
+FOLLOW_BWD = os.environ.get('LAS_FOLLOW_BWD', '1') != '0'
+FOLLOW_WGS = int(os.environ.get('LAS_FOLLOW_WGS', '96'))
+FOLLOW_MIN_ROWS = 4096
+
+
+def _follow_words(owner, key, n, dev):
+    """The words a chain launch and its follower share (cached per layer and shape; zeroed before every use)."""
+    cache = owner.__dict__.setdefault('_follow', {})
+    words = cache.get(key)
+    if words is None or words.numel() < n:
+        if torch.cuda.is_current_stream_capturing():
+            raise hip.LasError('follower product: new shape during graph capture (run the step once eagerly first)')
+        words = cache[key] = torch.zeros(n, dtype=torch.int32, device=dev)
+    return words
+
+
+def _follow_plan(B, T_out, N, seg_len, H, nd, bwd):
+    """(rows per slice, persistent workgroups) of a follower product beside a recurrent launch of (B, H, nd), or None."""
+    lib = hip.lib()
+    if not FOLLOW or (bwd and not FOLLOW_BWD) or B * T_out < FOLLOW_MIN_ROWS:
+        return None
+    rows = lib.las_lstm_slice_rows(B, H, nd)
+    if lib.las_gemm_nt_follow_supported(B, N, seg_len, rows, nd) != 1:
+        return None
+    chain = lib.las_lstm_fwd_workgroups(B, H, nd)
+    wgs = min(FOLLOW_WGS, 256 - chain)
+    if chain <= 0 or (wgs < 16 and FOLLOW_WGS > 0):
+        return None
+    _product_stream()                 # (created -- and probed against the current stream -- before the first launch that needs it)
+    if not STREAM_X:                  # no stream of this process runs beside the current one
+        return None
+    return rows, wgs
+
+
+class _Follower:
+    """One follower product: zero the shared words, hand them to the recurrent launch (`.words`), then launch(): the persistent
+    follower on the product stream (held back a few microseconds so that the chain's workgroups are resident first), the
+    join, and the clean-up pass on the launching stream behind the recurrence."""
+
+    def __init__(self, owner, key, desc, plan, keep):
+        self.rows, self.wgs = plan
+        self.desc = desc
+        n = hip.lib().las_gemm_nt_follow_words(desc['B'], desc['T_out'], desc['N'], self.rows, desc['ndir'])
+        self.words = _follow_words(owner, key, n, desc['C'].device)
+        hip.fill_many(zero=[self.words])
+        self.cleared = torch.cuda.Event()
+        self.cleared.record()
+        self.keep = keep
+
+    def _struct(self, workgroups):
+        d = self.desc
+        f = hip.Follow()
+        f.A, f.Bw, f.C, f.bias = hip.addr(d['A']), hip.addr(d['Bw']), hip.addr(d['C']), hip.addr(d.get('bias'))
+        f.lda, f.ldb, f.ldc = d['lda'], d['ldb'], d['ldc']
+        f.a_dir, f.a_seg, f.b_dir, f.b_seg, f.nseg, f.seg_len = d['a_dir'], d['a_seg'], d['b_dir'], d['b_seg'], d['nseg'], d['seg_len']
+        f.N, f.B, f.T_out, f.T_chain, f.stack, f.rows_per_slice, f.ndir, f.kind = (d['N'], d['B'], d['T_out'], d['T_out'] * d['stack'],
+                                                                                   d['stack'], self.rows, d['ndir'], d['kind'])
+        f.length, f.words, f.workgroups = hip.addr(d['length']), hip.addr(self.words), workgroups
+        return f
+
+    def launch(self):
+        import ctypes
+        lib, d = hip.lib(), self.desc
+        flops = 2.0 * d['B'] * d['T_out'] * d['N'] * d['nseg'] * d['seg_len'] * d['ndir']
+        side = _product_stream()
+        side.wait_event(self.cleared)
+        if self.wgs > 0:              # (FOLLOW_WGS = 0: the clean-up pass does all of the work -- tests)
+            with torch.cuda.stream(side):
+                hip.check(lib.las_stream_delay(Overlap.BESIDE_US, hip.stream()))
+                tok = hip.prof_begin('gemm_nt_follow', flops)
+                hip.check(lib.las_gemm_nt_follow(ctypes.byref(self._struct(self.wgs)), 0, hip.stream()))
+                hip.prof_end(tok)
+            torch.cuda.current_stream().wait_stream(side)
+        tok = hip.prof_begin('gemm_nt_follow_cleanup', 0.0)
+        hip.check(lib.las_gemm_nt_follow(ctypes.byref(self._struct(0)), 1, hip.stream()))
+        hip.prof_end(tok)
+
+
 def bilstm(inputs, sequence_length, num_units, dropout, mode, unidirectional=False, *, variables=None,
-           scope='', weights=None, tape=None, in_features=None, rng=None, split_inputs=False, after_projection=None):
+           scope='', weights=None, tape=None, in_features=None, rng=None, split_inputs=False, after_projection=None,
+           xproj_ready=None, follow_next=None):
     """las/ops.py:23-46.  inputs [B,T,Dp] bf16; sequence_length int32 [B] (CUDA).
     Returns (outputs, state) with the reference's structure: bidirectional -> ((fw, bw), (state_fw,
     state_bw)); unidirectional -> (fw, state).  fw/bw are views of one [B,T,ndir*H] buffer
     (use ``concat_outputs`` for the tf.concat of las/ops.py:81).
     split_inputs: direction i reads only columns [i*D, (i+1)*D) of ``inputs`` (the per-direction MultiRNNCell
-    stacks of the non-pyramidal listener, las/model.py:111-133)."""
+    stacks of the non-pyramidal listener, las/model.py:111-133).
+    xproj_ready: this layer's x K_x + b [B,T,nd*4H] fp32, already formed (by the follower of the layer below).
+    follow_next = (weights of the layer above, stack): that layer's input projection over this layer's outputs (viewed
+    [B, T/stack, stack*nd*H]) is formed by a FOLLOWER product behind this layer's chains; the return value gets a third
+    element: the projection (or None when the shapes do not allow it)."""
     cell = lstm_cell(num_units, dropout, mode)
     keep = cell.input_keep_prob
     B, T, Dfull = inputs.shape
@@ -306,14 +406,16 @@ def bilstm(inputs, sequence_length, num_units, dropout, mode, unidirectional=Fal
         weights = LayerWeights(variables, scope, D, Dp, H, unidirectional)
     nd = len(weights.dirs)
     dev = inputs.device
-    xproj = torch.empty(B, T, nd * 4 * H, dtype=torch.float32, device=dev)
+    xproj = xproj_ready if xproj_ready is not None else torch.empty(B, T, nd * 4 * H, dtype=torch.float32, device=dev)
     dropped = None
     stream_ready = None
     # narrow inputs (the features): x_t K_x + b is formed inside the recurrent kernel -- no product, no fp32 round trip
-    fused = (weights.kx_chunks > 0 and not split_inputs and Dp == weights.Dp and
+    fused = (weights.kx_chunks > 0 and not split_inputs and Dp == weights.Dp and xproj_ready is None and
              (keep == 1.0 or nd == 1 or (nd == 2 and Dp % 8 == 0)))
     fused_x = None                    # (x, ldx, stride between the directions' copies)
-    if fused and keep == 1.0:
+    if xproj_ready is not None:
+        assert keep == 1.0 and not split_inputs and tuple(xproj.shape) == (B, T, nd * 4 * H)
+    elif fused and keep == 1.0:
         fused_x = (inputs, Dfull, 0)
     elif keep < 1.0 or split_inputs:
         # one A operand per direction: DropoutWrapper(input_keep_prob) draws independent masks for the fw and bw
@@ -360,44 +462,54 @@ def bilstm(inputs, sequence_length, num_units, dropout, mode, unidirectional=Fal
                         bias=weights.bias)
     if after_projection is not None:
         after_projection()          # (LasModel: side-stream work that should run beside this layer's recurrence starts here)
-    y = torch.empty(B, T, nd * H, dtype=torch.bfloat16, device=dev)
+    # the layer above's input projection behind THIS layer's chains (follower product)
+    follower, xproj_next = None, None
+    if follow_next is not None and nd == len(follow_next[0].dirs):
+        w2, stack = follow_next
+        H2, T2 = w2.H, T // stack
+        plan = _follow_plan(B, T2, nd * 4 * H2, H, H, nd, False) if (T % stack == 0 and w2.Dp == stack * nd * H) else None
+        if plan is not None:
+            xproj_next = torch.empty(B, T2, nd * 4 * H2, dtype=torch.float32, device=dev)
+            # A = y viewed [B, T/stack, stack * nd * H]: direction d's columns are [d * H + i * nd * H, + H), i < stack
+            follower = _Follower(weights, ('fwd', B, T, stack), dict(
+                A=torch.empty(B, T, nd * H, dtype=torch.bfloat16, device=dev), Bw=w2.kxT, C=xproj_next, bias=w2.bias, lda=stack * nd * H, ldb=w2.Dp, ldc=nd * 4 * H2,
+                a_dir=H, a_seg=nd * H, b_dir=H, b_seg=nd * H, nseg=stack, seg_len=H, N=nd * 4 * H2, B=B, T_out=T2, stack=stack,
+                ndir=nd, kind=0, length=sequence_length), plan, keep=[])
+    y = follower.desc['A'] if follower is not None else torch.empty(B, T, nd * H, dtype=torch.bfloat16, device=dev)
     cbuf = torch.empty(B, T, nd * H, dtype=torch.float32, device=dev)
     c_last = torch.empty(nd, B, H, dtype=torch.float32, device=dev)
     h_last = torch.empty(nd, B, H, dtype=torch.float32, device=dev)
-    if fused_x is not None or stream_ready is not None:
-        a = hip.LstmFwd()
-        a.xproj, a.wpacked, a.length, a.y, a.cbuf = hip.addr(xproj), hip.addr(weights.khp), hip.addr(sequence_length), hip.addr(y), hip.addr(cbuf)
-        a.c_last, a.h_last, a.workspace = hip.addr(c_last), hip.addr(h_last), hip.addr(lstm_workspace(B, H, nd))
-        a.B, a.T, a.H, a.ndir = B, T, H, nd
-        flops = 2.0 * B * T * nd * H * 4 * H
-        if fused_x is not None:
-            xa, ldx, xdir = fused_x
-            a.x, a.ldx, a.x_dir_stride, a.Dp = hip.addr(xa), ldx, xdir, Dp
-            a.kx_packed, a.bias = hip.addr(weights.kxp), hip.addr(weights.bias)
-            flops += 2.0 * B * T * nd * Dp * 4 * H                            # x_t K_x of every step as well
-        else:
-            a.ready, a.ready_count = hip.addr(stream_ready[0]), stream_ready[1]
-        tok = hip.prof_begin('lstm_fwd', flops)
-        import ctypes
-        hip.check(hip.lib().las_lstm_recurrent_fwd_ex(ctypes.byref(a), hip.stream()))
-        if stream_ready is not None:
-            # (the product is done long before the recurrence is; everything later on this stream is ordered behind both,
-            # so the operands need no record_stream)
-            torch.cuda.current_stream().wait_stream(stream_ready[2]())
-    else:
-        tok = hip.prof_begin('lstm_fwd', 2.0 * B * T * nd * H * 4 * H)       # the recurrent product h_{t-1} K_h of every step
-        hip.check(hip.lib().las_lstm_recurrent_fwd(hip.p(xproj), hip.p(weights.khp), hip.p(sequence_length), hip.p(y),
-                                                   hip.p(cbuf), hip.p(c_last), hip.p(h_last),
-                                                   hip.p(lstm_workspace(B, H, nd)), B, T, H, nd, hip.stream()))
+    a = hip.LstmFwd()
+    a.xproj, a.wpacked, a.length, a.y, a.cbuf = hip.addr(xproj), hip.addr(weights.khp), hip.addr(sequence_length), hip.addr(y), hip.addr(cbuf)
+    a.c_last, a.h_last, a.workspace = hip.addr(c_last), hip.addr(h_last), hip.addr(lstm_workspace(B, H, nd))
+    a.B, a.T, a.H, a.ndir = B, T, H, nd
+    flops = 2.0 * B * T * nd * H * 4 * H                                   # the recurrent product h_{t-1} K_h of every step
+    if fused_x is not None:
+        xa, ldx, xdir = fused_x
+        a.x, a.ldx, a.x_dir_stride, a.Dp = hip.addr(xa), ldx, xdir, Dp
+        a.kx_packed, a.bias = hip.addr(weights.kxp), hip.addr(weights.bias)
+        flops += 2.0 * B * T * nd * Dp * 4 * H                            # x_t K_x of every step as well
+    elif stream_ready is not None:
+        a.ready, a.ready_count = hip.addr(stream_ready[0]), stream_ready[1]
+    if follower is not None:
+        a.follow = hip.addr(follower.words)
+    tok = hip.prof_begin('lstm_fwd', flops)
+    import ctypes
+    hip.check(hip.lib().las_lstm_recurrent_fwd_ex(ctypes.byref(a), hip.stream()))
     hip.prof_end(tok)
+    if stream_ready is not None:
+        # (the product is done long before the recurrence is; everything later on this stream is ordered behind both,
+        # so the operands need no record_stream)
+        torch.cuda.current_stream().wait_stream(stream_ready[2]())
+    if follower is not None:
+        follower.launch()
     if tape is not None:
         tape.append(dict(kind='bilstm', inputs=inputs, length=sequence_length, gates=xproj, cbuf=cbuf, y=y,
                          weights=weights, B=B, T=T, H=H, D=D, Dp=Dp, nd=nd, dropped=dropped, keep=keep, rng=rng,
                          split=split_inputs, Dfull=Dfull))
     states = tuple(LSTMStateTuple(c_last[i], h_last[i]) for i in range(nd))
-    if unidirectional:
-        return y, states[0]
-    return (y[..., :H], y[..., H:]), states
+    out = (y, states[0]) if unidirectional else ((y[..., :H], y[..., H:]), states)
+    return out + (xproj_next,) if follow_next is not None else out
 
 
 def concat_outputs(outputs):
@@ -413,18 +525,6 @@ def concat_outputs(outputs):
 
 # LAS_MASKED_DX=0: the input-dropout backward as its own pass over two partial dX buffers again (diagnostics, A/B timing)
 MASKED_DX = os.environ.get('LAS_MASKED_DX', '1') != '0'
-
-
-# LAS_BWD_WINDOWS=n: the backward recurrence of the BOTTOM listener layer in n time windows (n launches that hand d(h), d(c) on);
-# the weight-gradient products over a window's rows run beside the next window's chain, so only the last window's are exposed
-# behind the layer (metric-M: ~0.2 ms of products that nothing else hides).  LAS_BWD_WINDOWS_ALL=1: every layer.  1 = off.
-# MEASURED (round 4, one call): metric-M 6.075 ms with 1 window, 6.18 / 6.17 / 6.24 with 2 / 3 / 4; metric-L 17.77 -> 17.99 (bottom
-# layer) -> 18.59 (every layer).  The side stream beside the bottom layer's chain is already ~80 % busy with the layer above's
-# products, the extra launches each restart the chain (weights, handshake, first general step) and more product workgroups beside
-# the chain slow it: the windows cost more than the ~0.15 ms they can hide.  Off by default; the kernels and their tests stay.
-BWD_WINDOWS = int(os.environ.get('LAS_BWD_WINDOWS', '1'))
-BWD_WINDOWS_ALL = os.environ.get('LAS_BWD_WINDOWS_ALL', '0') != '0'
-BWD_WINDOW_MIN_STEPS = 64
 
 
 def bilstm_backward(rec, dy, d_state, grads, need_dx=True, overlap=None, defer_weight_grads=False, exposed=False):
@@ -457,11 +557,9 @@ def bilstm_backward(rec, dy, d_state, grads, need_dx=True, overlap=None, defer_w
         split = max(1, min(32, BT // 512, round((TN_WORKGROUPS_EXPOSED if exposed else TN_WORKGROUPS) / tiles)))
     keepalive = [dz, x, y] + [a for a, _ in (dropped or [])]
 
-    def weight_grads(win=None, beside=False):
-        """win = (s_lo, s_hi): the products over the rows of that window of recurrence steps only (positions [s_lo, s_hi) of the
-        left-to-right direction, [len - s_hi, len - s_lo) of the right-to-left one); beside: a chain launch follows on the main stream."""
+    def weight_grads():
         for i, (kn, bn) in enumerate(w.names):
-            with (overlap or _NoOverlap()).fork(*keepalive, lane=(i % 2 if exposed else 0), beside_chain=((i == 0 and not exposed) or beside)):
+            with (overlap or _NoOverlap()).fork(*keepalive, lane=(i % 2 if exposed else 0), beside_chain=(i == 0 and not exposed)):
                 gk, gb = grads[kn], grads[bn]
                 dzi = dz.view(BT, nd * 4 * H)[:, i * 4 * H:]
                 xa, lda = (dropped[i] if dropped is not None else (x, Dp))
@@ -482,19 +580,10 @@ def bilstm_backward(rec, dy, d_state, grads, need_dx=True, overlap=None, defer_w
                         if gdst is None:
                             gdst = pads[i] = torch.empty(Df + H, 4 * H, dtype=torch.float32, device=dev)
                         gdst.zero_()
-                    if win is None:
-                        tok = hip.prof_begin('gemm_tn_lstm', 2.0 * (Df + H + 1) * 4 * H * BT)
-                        hip.check(hip.lib().las_gemm_tn_lstm(hip.p(xa) if Df > 0 else None, lda, Df, hip.p(yi), nd * H, H,
-                                                             (-1 if i == 0 else 1), T, hip.p(dzi), nd * 4 * H, hip.p(gdst), hip.p(gb),
-                                                             BT, split, hip.p(ws), hip.stream()))
-                    else:
-                        s_lo, s_hi = win
-                        wsplit = max(2, min(split, B * (s_hi - s_lo) // 512))
-                        tok = hip.prof_begin('gemm_tn_lstm', 2.0 * (Df + H + 1) * 4 * H * B * (s_hi - s_lo))
-                        hip.check(hip.lib().las_gemm_tn_lstm_window(
-                            hip.p(xa) if Df > 0 else None, lda, Df, hip.p(yi), nd * H, H, (-1 if i == 0 else 1), B, T, s_hi - s_lo,
-                            (s_lo if i == 0 else s_hi), (None if i == 0 else hip.p(rec['length'])), hip.p(dzi), nd * 4 * H,
-                            hip.p(gdst), hip.p(gb), wsplit, hip.p(ws), hip.stream()))
+                    tok = hip.prof_begin('gemm_tn_lstm', 2.0 * (Df + H + 1) * 4 * H * BT)
+                    hip.check(hip.lib().las_gemm_tn_lstm(hip.p(xa) if Df > 0 else None, lda, Df, hip.p(yi), nd * H, H,
+                                                         (-1 if i == 0 else 1), T, hip.p(dzi), nd * 4 * H, hip.p(gdst), hip.p(gb),
+                                                         BT, split, hip.p(ws), hip.stream()))
                     hip.prof_end(tok)
                     if Df != D:
                         gk[:D].add_(gdst[:D])
@@ -506,43 +595,26 @@ def bilstm_backward(rec, dy, d_state, grads, need_dx=True, overlap=None, defer_w
                             a_shift=(-1 if i == 0 else 1), period=T, split_k=split, c_perm_h=H)
                 hip.colsum_bf16(dzi, BT, 4 * H, gb, ldx=nd * 4 * H, perm_h=H)
 
-    nwin = 1
-    if (overlap is not None and not defer_weight_grads and (exposed or BWD_WINDOWS_ALL) and Df_w >= 0 and nd == 2
-            and T >= 2 * BWD_WINDOW_MIN_STEPS and BT >= 8192):
-        nwin = max(1, min(BWD_WINDOWS, T // BWD_WINDOW_MIN_STEPS))
-    bounds = [round(k * T / nwin) for k in range(nwin + 1)]
-    window_grads = []                       # (s_lo, s_hi) of the windows whose weight gradients are still to be launched
-    if nwin == 1:
-        tok = hip.prof_begin('lstm_bwd', 2.0 * B * T * nd * H * 4 * H)       # dh_{t-1} = dz_t K_h^T of every step
-        hip.check(hip.lib().las_lstm_recurrent_bwd(hip.p(rec['gates']), hip.p(rec['cbuf']), hip.p(dy), hip.p(dc_last),
-                                                   hip.p(dh_last), hip.p(w.kh), hip.p(rec['length']), hip.p(dz),
-                                                   hip.p(lstm_workspace(B, H, nd)), B, T, H, nd, hip.stream()))
-        hip.prof_end(tok)
-    else:
-        # time windows, last steps first: each launch hands d(h), d(c) to the next; the weight gradients of a window's rows are
-        # forked as soon as its launch is enqueued, i.e. they run beside the next window's chain
-        lib = hip.lib()
-        carry = [(torch.empty(nd, B, H, dtype=torch.float32, device=dev), torch.empty(nd, B, H, dtype=torch.float32, device=dev))
-                 for _ in range(2)]
-        keepalive.extend(t for pair in carry for t in pair)
-        dc_in, dh_in = dc_last, dh_last
-        for k in range(nwin - 1, -1, -1):
-            s_lo, s_hi = bounds[k], bounds[k + 1]
-            dc_out, dh_out = carry[k % 2] if s_lo > 0 else (None, None)
-            tok = hip.prof_begin('lstm_bwd', 2.0 * B * (s_hi - s_lo) * nd * H * 4 * H)
-            hip.check(lib.las_lstm_recurrent_bwd_window(hip.p(rec['gates']), hip.p(rec['cbuf']), hip.p(dy), hip.p(dc_in), hip.p(dh_in),
-                                                        hip.p(w.kh), hip.p(rec['length']), hip.p(dz), hip.p(lstm_workspace(B, H, nd)),
-                                                        B, T, H, nd, s_lo, s_hi, hip.p(dc_out), hip.p(dh_out), hip.stream()))
-            hip.prof_end(tok)
-            dc_in, dh_in = dc_out, dh_out
-            if k > 0 or not need_dx:
-                weight_grads((s_lo, s_hi), beside=(k > 0))
-            else:
-                window_grads.append((s_lo, s_hi))       # behind dX (critical path first), as without windows
-    # critical path first: dX feeds the next (lower) layer's recurrence
-    if need_dx:
+    # dX = dz K_x^T feeds the next (lower) layer's recurrence, which starts on the rows this layer's chains reach LAST: the product
+    # follows the chains (a follower product, one half per direction) instead of waiting for them
+    follower = None
+    if need_dx and dropped is None:
+        plan = _follow_plan(B, T, D, 4 * H, H, nd, True) if D % 8 == 0 else None
+        dx = torch.empty(B, T, D, dtype=torch.float32, device=dev)
+        if plan is not None:
+            follower = _Follower(w, ('bwd', B, T), dict(
+                A=dz, Bw=w.kx, C=dx, bias=None, lda=nd * 4 * H, ldb=nd * 4 * H, ldc=D, a_dir=4 * H, a_seg=0, b_dir=4 * H, b_seg=0,
+                nseg=1, seg_len=4 * H, N=D, B=B, T_out=T, stack=1, ndir=nd, kind=1, length=rec['length']), plan, keep=[])
+    tok = hip.prof_begin('lstm_bwd', 2.0 * B * T * nd * H * 4 * H)       # dh_{t-1} = dz_t K_h^T of every step
+    hip.check(hip.lib().las_lstm_recurrent_bwd(hip.p(rec['gates']), hip.p(rec['cbuf']), hip.p(dy), hip.p(dc_last),
+                                               hip.p(dh_last), hip.p(w.kh), hip.p(rec['length']), hip.p(dz),
+                                               hip.p(lstm_workspace(B, H, nd)), B, T, H, nd,
+                                               hip.p(follower.words) if follower is not None else None, hip.stream()))
+    hip.prof_end(tok)
+    if follower is not None:
+        follower.launch()
+    if need_dx and follower is None:
         if dropped is None:
-            dx = torch.empty(B, T, D, dtype=torch.float32, device=dev)
             hip.gemm_nt(dz, w.kx, dx, BT, D, nd * 4 * H, lda=nd * 4 * H, ldb=nd * 4 * H, ldc=D)
         else:
             # per direction dX_i = dZ_i K_x,i^T, then through that direction's input dropout (masks regenerated from
@@ -576,10 +648,6 @@ def bilstm_backward(rec, dy, d_state, grads, need_dx=True, overlap=None, defer_w
                                                   stream0 + 1, hip.stream()))
             if dx is None:
                 dx = torch.cat(parts, -1) if split_in else (parts[0] if nd == 1 else parts[0] + parts[1])
-    if nwin > 1:
-        for wn in window_grads:
-            weight_grads(wn)
-        return dx
     if defer_weight_grads:
         return dx, weight_grads
     weight_grads()
@@ -631,13 +699,22 @@ def pyramidal_bilstm(inputs, sequence_length, mode, hparams, *, variables=None, 
         levels = torch.empty(hparams.num_layers - 1, sequence_length.shape[0], dtype=torch.int32, device=sequence_length.device)
         hip.check(hip.lib().las_pyramid_lengths_multi(hip.p(sequence_length), hip.p(levels), sequence_length.shape[0],
                                                       hparams.num_layers - 1, hip.stream()))
+    xproj_ready = None
+    no_drop = not (mode == TRAIN and hparams.dropout > 0.0)
     for layer in range(hparams.num_layers):
         w = weights[layer] if weights is not None else None
         hooks = after_first_layer if (layer == 0 and after_first_layer is not None) else (None, None)
-        out, state = bilstm(outputs, sequence_length, hparams.num_units, hparams.dropout, mode,
-                            hparams.unidirectional, variables=variables,
-                            scope='listener/bilstm_{}'.format(layer), weights=w, tape=tape, in_features=D,
-                            rng=(seed, 16 + 2 * layer), after_projection=hooks[0])
+        # the next layer's input projection as a follower product of this layer's recurrence (its input = this layer's outputs,
+        # stacked in pairs from layer 1 on: las/ops.py:75-87)
+        nxt = None
+        if weights is not None and layer + 1 < hparams.num_layers and no_drop:
+            nxt = (weights[layer + 1], 2 if layer >= 1 else 1)
+        res = bilstm(outputs, sequence_length, hparams.num_units, hparams.dropout, mode,
+                     hparams.unidirectional, variables=variables,
+                     scope='listener/bilstm_{}'.format(layer), weights=w, tape=tape, in_features=D,
+                     rng=(seed, 16 + 2 * layer), after_projection=hooks[0], xproj_ready=xproj_ready, follow_next=nxt)
+        out, state = res[0], res[1]
+        xproj_ready = res[2] if nxt is not None else None
         outputs = concat_outputs(out)
         if hooks[1] is not None:
             hooks[1]()

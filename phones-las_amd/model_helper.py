@@ -557,7 +557,7 @@ class LasModel:
                         self.ctc.refresh(self.vars.params)
                     done.append(self.overlap.mark())
 
-            hooks = (start, lambda: torch.cuda.current_stream().wait_event(done[0]))
+            hooks = (start, lambda: done[0].wait())
         else:
             self.listener.refresh(self.vars.params)
             for mod, _ in self.spellers:
@@ -733,7 +733,7 @@ class LasModel:
                     self.clip_adam_update()
                 return
             # the bottom layer's recurrence has been enqueued on this stream; the side streams hold its products
-            torch.cuda.current_stream().wait_event(ev)          # ... and, before them, every other weight gradient
+            ev.wait()                                           # ... and, before them, every other weight gradient
             self.collect_status(zero_norms=True)
             self.__dict__.pop('_norms_zeroed', None)
             self.gradient_norms(tb[0], acc=True)

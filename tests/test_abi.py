@@ -55,22 +55,22 @@ def test_slice_height_policy_and_workspace_sizes(monkeypatch):
     every layout."""
     from phones_las_amd import hip
     l = hip.lib()
-    monkeypatch.delenv('LAS_LSTM_ROWS', raising=False)
+    hip.set_knob('LAS_LSTM_ROWS', 0)
     assert l.las_lstm_slice_rows(64, 256, 2) == 4            # 32 chains x 4 workgroups + 32 companions = 160
     assert l.las_lstm_slice_rows(96, 256, 2) == 4            # 48 x 4 + 48 = 240
     assert l.las_lstm_slice_rows(128, 256, 2) == 8           # 4-row slices would need 320 workgroups
     assert l.las_lstm_slice_rows(512, 256, 2) == 16
-    monkeypatch.delenv('LAS_LSTM_G512', raising=False)
+    hip.set_knob('LAS_LSTM_G512', 8)
     assert l.las_lstm_slice_rows(64, 512, 2) == 8            # 512 units as 8 members (round 3): 16 chains x 8 + 32 companions = 160
     assert l.las_lstm_slice_rows(16, 512, 2) == 4            # 8 chains x 8 + 16 = 80
-    monkeypatch.setenv('LAS_LSTM_G512', '16')
+    hip.set_knob('LAS_LSTM_G512', 16)
     assert l.las_lstm_slice_rows(64, 512, 2) == 16           # the round-2 form (16 members, K / row split) runs on full tiles
-    monkeypatch.delenv('LAS_LSTM_G512')
+    hip.set_knob('LAS_LSTM_G512', 8)
     assert l.las_lstm_slice_rows(8, 128, 2) == 4
     assert l.las_lstm_slice_rows(0, 256, 2) == 0 and l.las_lstm_slice_rows(8, 100, 2) == 0
-    monkeypatch.setenv('LAS_LSTM_ROWS', '16')
+    hip.set_knob('LAS_LSTM_ROWS', 16)
     assert l.las_lstm_slice_rows(64, 256, 2) == 16
-    monkeypatch.delenv('LAS_LSTM_ROWS')
+    hip.set_knob('LAS_LSTM_ROWS', 0)
     # the workspace covers the forward and the backward exchange of every slice height
     w = l.las_lstm_workspace_bytes(64, 256, 2)
     assert w >= 64 + 2 * 32 * 4 * 4 * 4 * 256 * 8            # backward, 4-row slices: 32 groups x 4 x 4 pairs x NUB*256 granules x 2 slots
@@ -85,7 +85,7 @@ def test_ctypes_structures_have_the_layout_of_the_header(tmp_path):
     from phones_las_amd import hip
     pairs = {'las_lstm_fwd': hip.LstmFwd, 'las_dec_step': hip.DecStep, 'las_dec_persist': hip.DecPersist,
              'las_dec_step_bwd': hip.DecStepBwd, 'las_dec_persist_bwd': hip.DecPersistBwd, 'las_dec_seq_bwd': hip.DecSeqBwd,
-             'las_image_job': hip.ImageJob, 'las_fill_job': hip.FillJob}
+             'las_image_job': hip.ImageJob, 'las_fill_job': hip.FillJob, 'las_follow': hip.Follow}
     lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "las_hip.h"', 'int main(void) {']
     for cname, cls in pairs.items():
         lines.append('  printf("%s . %%zu\\n", sizeof(%s));' % (cname, cname))

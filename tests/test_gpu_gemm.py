@@ -217,43 +217,6 @@ def test_gemm_tn_lstm_fused_weight_gradients(D, H, B, T, shift, use_ws):
     _close(gb + 0.25, ref_b)
 
 
-@pytest.mark.parametrize('D,H,B,T,shift,from_end', [(40, 64, 5, 96, -1, False), (40, 256, 6, 100, 1, True), (128, 128, 3, 77, 1, True),
-                                                     (0, 128, 4, 64, -1, False)])
-def test_gemm_tn_lstm_row_windows_add_up_to_the_whole_product(D, H, B, T, shift, from_end):
-    """las_gemm_tn_lstm_window: the fused weight-gradient product over a time window of every utterance.  Windows counted from
-    the start (the left-to-right direction) or from the END of each utterance (the right-to-left one: rows len - s_hi .. len -
-    s_lo, ragged lengths, rows before the utterance read as zeros); three windows that cover the steps must add up to the
-    product over all rows (rows beyond an utterance's length are zero in dz, as the recurrence leaves them)."""
-    from phones_las_amd import hip
-    K = B * T
-    Dp = max(D, 8)
-    x, y, dz = _mk((K, Dp), 13), _mk((K, 2 * H), 14), _mk((K, 8 * H), 15)
-    lens = [T - (i * 29) % (T // 2) for i in range(B)]
-    dz3 = dz.view(B, T, 8 * H)
-    for b in range(B):
-        dz3[b, lens[b]:] = 0
-    xd, yd, dzd = x.cuda(), y.cuda(), dz.cuda()
-    ld = torch.tensor(lens, dtype=torch.int32, device='cuda')
-    split = 5
-    need = hip.lib().las_gemm_tn_lstm_workspace_bytes(D, H, split)
-    ws = torch.full((need // 4,), float('nan'), device='cuda')
-    whole_k = torch.zeros(D + H, 4 * H, device='cuda')
-    whole_b = torch.zeros(4 * H, device='cuda')
-    hip.check(hip.lib().las_gemm_tn_lstm(hip.p(xd) if D else None, Dp, D, hip.addr(yd, H), 2 * H, H, shift, T,
-                                         hip.addr(dzd, 4 * H), 8 * H, hip.p(whole_k), hip.p(whole_b), K, split, hip.p(ws), hip.stream()))
-    gk = torch.zeros(D + H, 4 * H, device='cuda')
-    gb = torch.zeros(4 * H, device='cuda')
-    bounds = [0, T // 3 + 1, 2 * T // 3, T]
-    for k in (2, 1, 0):
-        s_lo, s_hi = bounds[k], bounds[k + 1]
-        hip.check(hip.lib().las_gemm_tn_lstm_window(hip.p(xd) if D else None, Dp, D, hip.addr(yd, H), 2 * H, H, shift, B, T, s_hi - s_lo,
-                                                    (s_hi if from_end else s_lo), (hip.p(ld) if from_end else None),
-                                                    hip.addr(dzd, 4 * H), 8 * H, hip.p(gk), hip.p(gb), split, hip.p(ws), hip.stream()))
-    torch.cuda.synchronize()
-    assert float((gk - whole_k).abs().max()) <= 2e-5 * float(whole_k.abs().max())
-    assert float((gb - whole_b).abs().max()) <= 2e-5 * float(whole_b.abs().max())
-
-
 def test_gemm_nt_ring_asymmetric_identity_strides_and_batch():
     """The LDS-DMA ring kernel (gemm_nt_ring_kernel: 256 x 128 tiles of v_mfma_f32_32x32x16_bf16): A = I against an
     asymmetric B catches a transposed or permuted C write and a wrong source-chunk swizzle exactly (integer data);
