@@ -551,8 +551,12 @@ class Speller:
         # bias exist as variables but are not applied.  transform_binf_to_phones (:17-27); TRAIN concatenates the input.
         Mb = self.binf_map()
         nf = Mb.shape[0]
-        if out.shape[1] != 2 * nf:
-            raise ValueError('binf_projection needs the decoder output to be the 2*binf_count attention vector')
+        # The output is the 2*binf_count attention vector -- or, for a multi-layer --bottom_only decoder (AttentionMultiCell,
+        # las/model.py:36-69,188-200), the TOP CELL's h: transform_binf_to_phones then slices ITS first 2*binf_count columns
+        # (utils/training_helper.py:19-21; narrower outputs fail in its matmul when the graph is built).
+        if out.shape[1] < 2 * nf:
+            raise ValueError('binf_projection: the decoder output (%d wide) must hold [lp1 | lp0] = 2*binf_count = %d columns'
+                             % (out.shape[1], 2 * nf))
         logits = out[:, :nf] @ Mb + out[:, nf:2 * nf] @ (1 - Mb)
         return torch.cat([logits, out], 1) if self.train else logits
 

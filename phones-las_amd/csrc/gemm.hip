@@ -718,7 +718,7 @@ __global__ __launch_bounds__(256) void tn_reduce_kernel(const float* __restrict_
 // 128 B/clk LDS port against 1 024 cycles of MFMA per SIMD -- the LDS port is as busy as the matrix cores, and the kernel sat
 // at half the clock-derated roof.  NW = 4 gives every wave a 128 x 128 block (256 accumulator registers, one wave per SIMD):
 // 16 reads for 32 MFMAs, 64 + 32 KiB per stage = 768 LDS cycles against the same 1 024 MFMA cycles.
-template <int BM, int BN, int BK, int STAGES, int WGM, bool STREAM = false, int NW = 8>
+template <int BM, int BN, int BK, int STAGES, int WGM, bool STREAM = false, int NW = 8, bool PP = false>
 __global__ __launch_bounds__(NW * 64) void gemm_nt_ring_kernel(GemmArgs g) {
   constexpr int WGN = NW / WGM;
   constexpr int TM = BM / WGM / 32, TN = BN / WGN / 32;          // 32 x 32 tiles per wave
@@ -739,7 +739,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_nt_ring_kernel(GemmArgs g) {
   const int wm = wave / WGN, wn = wave % WGN;
   // ---- streamed form: this XCD's list of chain groups, then tiles from its queue until the list is done ----
   __shared__ int s_list[STREAM ? 256 : 1];
-  __shared__ int s_n, s_q, s_sp;
+  __shared__ int s_n, s_q;
   int my_xcd = 0;
   if constexpr (STREAM) {
     static_assert(BM == 256, "streamed tiles are one slice x 256 / R steps");
@@ -747,13 +747,26 @@ __global__ __launch_bounds__(NW * 64) void gemm_nt_ring_kernel(GemmArgs g) {
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
     my_xcd = (int)(xcc & 7);
     if (tid == 0) {
-      // This XCD's list of chain groups is STATIC -- group gi is expected on XCD gi % 8 (the recurrence's block layout under
-      // round-robin dispatch) -- so every workgroup of an XCD maps a queue slot to the same tile whatever it has seen of the
-      // recurrence so far (lists built from polls that could time out in one workgroup and not in another shared one
-      // queue index).  Where a group REALLY runs only decides, tile by tile, whether the hand-over needs the device-wide fence.
+      // This XCD's list of chain groups: the groups that PUBLISHED this XCD (workgroup i of a launch does not always land on XCD
+      // i % 8: the dispatcher carries on from where the previous launch stopped).  The list is built only once EVERY group has
+      // published -- the words never change afterwards, so every workgroup of an XCD derives the same list and maps a queue slot
+      // to the same tile (lists built while polls could time out in one workgroup and not in another shared one queue
+      // index).  A workgroup that does not see all groups in time leaves: the recurrence's bounded wait then flags the launch.
+      // Groups whose members are spread over XCDs go to XCD gi % 8 and take the device-wide fence.
       const int ngroups = g.s_nslices * g.s_ndir;
+      bool all = true;
+      unsigned spins = 0;
+      for (int gi = 0; gi < ngroups && all; ++gi)
+        while (__hip_atomic_load(g.ready + 16 + gi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
+          if (++spins > (1u << 15)) { all = false; break; }
+          __builtin_amdgcn_s_sleep(8);
+        }
       int n = 0;
-      for (int gi = my_xcd; gi < ngroups && n < 256; gi += 8) s_list[n++] = gi;
+      for (int gi = 0; gi < ngroups && gi < 256 && all; ++gi) {
+        const unsigned v = __hip_atomic_load(g.ready + 16 + gi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (v == (unsigned)my_xcd + 1u) s_list[n++] = gi;
+        else if (v == LAS_STREAM_SPREAD && (gi & 7) == my_xcd) s_list[n++] = gi | 0x10000;
+      }
       s_n = n;
     }
     __syncthreads();
@@ -771,22 +784,9 @@ __global__ __launch_bounds__(NW * 64) void gemm_nt_ring_kernel(GemmArgs g) {
     if (per_sb == 0 || q >= per_sb * g.s_nsb) break;
     // step block by step block; inside a block the column tiles of one group are neighbours (they share the A rows)
     s_sb = q / per_sb;
-    const int r = q % per_sb;
-    s_group = s_list[r / nc_tiles];
-    // the recurrence publishes where its groups run when it starts (it is launched first).  On this XCD: plain stores into
-    // the L2 the consumer reads.  Anywhere else, spread over XCDs, or not published in time: the write-back fence, which is
-    // correct for every placement.
-    if (tid == 0) {
-      unsigned v = 0, spins = 0;
-      do {
-        v = __hip_atomic_load(g.ready + 16 + s_group, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (v != 0) break;
-        __builtin_amdgcn_s_sleep(8);
-      } while (++spins < (1u << 14));
-      s_sp = (v == (unsigned)my_xcd + 1u) ? 0 : 1;
-    }
-    __syncthreads();
-    s_spread = s_sp != 0;
+    const int r = q % per_sb, e = s_list[r / nc_tiles];
+    s_group = e & 0xffff;
+    s_spread = (e >> 16) != 0;
     s_d = s_group / g.s_nslices;
     s_slice = s_group % g.s_nslices;
     bx = s_d * nc_tiles + r % nc_tiles;
@@ -856,6 +856,64 @@ __global__ __launch_bounds__(NW * 64) void gemm_nt_ring_kernel(GemmArgs g) {
 #pragma unroll
   for (int ks = 0; ks < KS; ++ks) koff[ks] = ((2 * ks + hk) ^ swz) << 4;
 
+  if constexpr (PP) {
+    // PING-PONG form (round 5; MI355X_MICROARCH.md "Two waves per SIMD", cdna_hip_programming.md "The 256^2 8-phase template").  The
+    // two waves of a SIMD are wave w and wave w + 4.  In the form below both run the same program between the same barriers: both
+    // want the LDS at the same time, then both want the matrix pipe at the same time, and each waits while the other's phase runs.
+    // Here a stage is TWO segments -- LOAD (all of the stage's fragments into registers, the LDS-DMA of a later stage issued, the
+    // waits) and MATH (the stage's 16 MFMAs, nothing else) -- with a barrier after each, and waves 4..7 run ONE BARRIER BEHIND waves
+    // 0..3: while one wave of a SIMD is in MATH its partner is in LOAD.  Hazards, with segments numbered s (group 0: LOAD(k) at 2k,
+    // MATH(k) at 2k + 1; group 1 one later): a wave waits for ITS pieces of stage k + 1 and for its own fragment reads at the end
+    // of LOAD(k), i.e. in front of a barrier that precedes every read of stage k + 1 by either group (RAW) and every LDS-DMA into
+    // the slot LOAD(k) has just read (issued in LOAD(k + 1) at the earliest: WAR).
+    static_assert(!STREAM && NW == 8, "ping-pong form: 8 waves, plain tiles");
+    const int grp = wave >> 2;
+    if (nk > 0) {
+#pragma unroll
+      for (int p = 0; p < STAGES - 1; ++p)
+        if (p < nk) issue(p);
+      if (STAGES - 2 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(NL * (STAGES - 2)) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();                        // stage 0 has landed
+      if (grp == 1) __builtin_amdgcn_s_barrier();          // the stagger
+      asm volatile("" ::: "memory");
+      int stage = 0;
+      for (int kt = 0; kt < nk; ++kt) {
+        // ---- LOAD(kt) ----
+        const lds_u8* st = lds + stage * STAGE_BYTES;
+        bf16x8 af[KS][TM], bfr[KS][TN];
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+#pragma unroll
+          for (int j = 0; j < TN; ++j) bfr[ks][j] = *(const __attribute__((address_space(3))) bf16x8*)(st + b_row + j * 32 * ROWB + koff[ks]);
+#pragma unroll
+          for (int i = 0; i < TM; ++i) af[ks][i] = *(const __attribute__((address_space(3))) bf16x8*)(st + a_row + i * 32 * ROWB + koff[ks]);
+        }
+        if (kt + STAGES - 1 < nk) issue(stage == 0 ? STAGES - 1 : stage - 1);        // = (kt + STAGES - 1) % STAGES: last read in LOAD(kt - 1)
+        if (kt + 1 + STAGES - 2 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(NL * (STAGES - 2)) : "memory");      // own pieces of stage kt + 1
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                           // own fragments are in registers
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- MATH(kt) ----
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+          for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks][i], bfr[ks][j], acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        stage = (stage + 1 == STAGES) ? 0 : stage + 1;
+      }
+      if (grp == 0) __builtin_amdgcn_s_barrier();          // the barrier the other half is one ahead by
+    }
+  } else
   if (nk > 0) {
 #pragma unroll
     for (int p = 0; p < STAGES - 1; ++p)
@@ -998,8 +1056,8 @@ __global__ __launch_bounds__(NW * 64) void gemm_nt_ring_kernel(GemmArgs g) {
 // tiles of its last block of steps are still to do; today's "product behind the recurrence" has become "product behind the
 // chain's last 64 steps".
 // The kernel is PERSISTENT and XCD-aware, like the streamed product above: a workgroup reads its XCC id and serves the slices
-// that run on its XCD (slice s -> XCD s % 8 for both directions: the chains' block layout; the launch requires nslices % 8 == 0
-// when there are two directions) from that XCD's queue, in the order the chains make the tiles ready.  It reads the chains'
+// whose chains run on its XCD (the chains publish where they run; with two directions the launch requires nslices % 8 == 0, which
+// puts both chains of a slice 8 k blocks apart: on one XCD) from that XCD's queue, in the order the chains make the tiles ready.  It reads the chains'
 // rows through the L2 their plain stores land in, and both halves of a tile meet in that L2 as well.  NOTHING is assumed: a
 // tile is taken only if the chain group has published that it runs on this XCD, that its rows beyond the lengths are zero
 // and that the steps the tile needs are stored; every wait is bounded, and whatever the follower leaves undone -- a group
@@ -1077,6 +1135,32 @@ __global__ __launch_bounds__(512) void gemm_nt_follow_kernel(FollowArgs g) {
   auto fswz = [](int r) { return (r >> 2) & 3; };
   auto load_word = [](const unsigned* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
 
+  // The slices this workgroup serves: those whose chain groups (both directions) PUBLISHED this XCD.  Read once every group of the
+  // launch has published (the words never change afterwards): every workgroup of an XCD derives the same list, so a queue slot
+  // means the same tile to all of them.  No chain beside this launch (nothing published in time): leave, the clean-up pass does it.
+  __shared__ int s_slices[128];
+  __shared__ int s_nmy;
+  if (!g.cleanup) {
+    if (tid == 0) {
+      const int ngroups = g.nslices * g.ndir;
+      bool all = true;
+      unsigned spins = 0;
+      for (int gi = 0; gi < ngroups && all; ++gi)
+        while (load_word(g.words + 16 + gi) == 0) {
+          if (++spins > FO_WAIT_PLACEMENT) { all = false; break; }
+          __builtin_amdgcn_s_sleep(16);
+        }
+      int n = 0;
+      for (int sl = 0; sl < g.nslices && n < 128 && all; ++sl) {
+        bool mine = true;
+        for (int d = 0; d < g.ndir; ++d) mine = mine && (load_word(g.words + 16 + d * g.nslices + sl) & 0xffu) == (unsigned)my_xcd + 1u;
+        if (mine) s_slices[n++] = sl;
+      }
+      s_nmy = n;
+    }
+    __syncthreads();
+    if (s_nmy == 0) return;
+  }
   for (;;) {
     __syncthreads();                                 // the previous tile has left the LDS; s_item may be rewritten
     if (tid == 0) s_item = (int)__hip_atomic_fetch_add(g.words + (g.cleanup ? 8 : my_xcd), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1084,13 +1168,12 @@ __global__ __launch_bounds__(512) void gemm_nt_follow_kernel(FollowArgs g) {
     const int q = s_item;
     int slice, tb, ct, d0, d1;
     if (!g.cleanup) {
-      const int n_my = my_xcd < g.nslices ? (g.nslices - my_xcd + 7) / 8 : 0;
-      const int per_blk = n_my * g.ndir * g.nct;
-      if (per_blk == 0 || q >= per_blk * g.ntb) break;
+      const int per_blk = s_nmy * g.ndir * g.nct;
+      if (q >= per_blk * g.ntb) break;
       // block of time by block of time in the order the chains pass them; inside one, the column tiles of a (slice, direction)
       // are neighbours (they share the A rows)
       const int k = q / per_blk, r = q % per_blk, r2 = r % (g.ndir * g.nct);
-      slice = my_xcd + 8 * (r / (g.ndir * g.nct));
+      slice = s_slices[r / (g.ndir * g.nct)];
       d0 = r2 / g.nct;
       d1 = d0 + 1;
       ct = r2 % g.nct;
@@ -1123,12 +1206,10 @@ __global__ __launch_bounds__(512) void gemm_nt_follow_kernel(FollowArgs g) {
         if (!g.cleanup) {
           // (a wait that runs out means the recurrence is not running beside this launch: the workgroup LEAVES -- go = 3 --
           // instead of spending the same wait on every tile that is left; a group that runs elsewhere only skips its tiles)
-          unsigned pl = 0, spins = 0;
-          while ((pl = load_word(g.words + 16 + group)) == 0 && ++spins < FO_WAIT_PLACEMENT) __builtin_amdgcn_s_sleep(16);
+          const unsigned pl = load_word(g.words + 16 + group);        // (published, and on this XCD: the list above)
           const unsigned waves = (pl >> 8) & 0xffu, cpg = (pl >> 16) & 0xffu;
-          if (pl == 0) go = 3;
-          else if ((pl & 0xffu) != (unsigned)my_xcd + 1u || waves == 0) go = 0;
-          spins = 0;
+          if (waves == 0) go = 0;
+          unsigned spins = 0;
           while (go == 1 && load_word(g.words + g.z0 + group) < cpg) {
             if (++spins > FO_WAIT_PLACEMENT) go = 3;
             __builtin_amdgcn_s_sleep(16);
@@ -1292,17 +1373,17 @@ __global__ __launch_bounds__(512) void gemm_nt_follow_kernel(FollowArgs g) {
   }
 }
 
-template <int BM, int BN, int BK, int STAGES, int WGM, int NW = 8>
+template <int BM, int BN, int BK, int STAGES, int WGM, int NW = 8, bool PP = false>
 int launch_ring(const GemmArgs& g, int batch, hipStream_t st) {
   dim3 grid((g.N + BN - 1) / BN, (g.M + BM - 1) / BM, batch);
   const size_t lds = (size_t)STAGES * (BM + BN) * BK * 2;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_ring_kernel<BM, BN, BK, STAGES, WGM, false, NW>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_ring_kernel<BM, BN, BK, STAGES, WGM, false, NW, PP>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
-  hipLaunchKernelGGL((gemm_nt_ring_kernel<BM, BN, BK, STAGES, WGM, false, NW>), grid, dim3(NW * 64), lds, st, g);
+  hipLaunchKernelGGL((gemm_nt_ring_kernel<BM, BN, BK, STAGES, WGM, false, NW, PP>), grid, dim3(NW * 64), lds, st, g);
   LAS_LAUNCH_CHECK("ring gemm launch");
   return LAS_OK;
 }
@@ -1427,8 +1508,12 @@ static int gemm_nt(const las_bf16* A, int64_t lda, const las_bf16* B, int64_t ld
     if (ring && split_k == 1 && K % 64 == 0 && K >= 128 && M >= 1024 && N >= 128 && (ldc % 4 == 0 || out_bf16)) {
       const bool wide = N >= 256 && N % 256 != 128;
       if (ring == 1) return launch_ring<256, 128, 64, 3, 4>(g, batch, st);
-      if (ring == 4 || (ring >= 5 && !(wide && K > 1024))) return launch_ring<256, 128, 32, 3, 4>(g, batch, st);
-      if (wide) return launch_ring<256, 256, 32, 4, 2>(g, batch, st);
+      if (ring == 4 || (ring >= 5 && !(wide && K > 1024)))
+        return las_knob("LAS_GEMM_PP", 1) == 2 ? launch_ring<256, 128, 32, 3, 4, 8, true>(g, batch, st) : launch_ring<256, 128, 32, 3, 4>(g, batch, st);
+      // LAS_GEMM_PP (round 5): the ping-pong schedule of the ring (the two waves of a SIMD alternate LOAD and MATH segments); 0: off,
+      // 1: the 256 x 256 form, 2: the two-per-CU 256 x 128 form too
+      const int pp = las_knob("LAS_GEMM_PP", 1);
+      if (wide) return pp ? launch_ring<256, 256, 32, 4, 2, 8, true>(g, batch, st) : launch_ring<256, 256, 32, 4, 2>(g, batch, st);
       return launch_ring<256, 128, 64, 3, 4>(g, batch, st);
     }
   }
@@ -1669,6 +1754,8 @@ extern "C" int las_gemm_tn_lstm(const las_bf16* x, int64_t ldx, int D, const las
                                 (int)((size_t)TR_STAGES * TR_STAGE_BYTES));
       attr_ring = true;
     }
+    // (round 5: the ping-pong schedule of gemm_nt_ring_kernel was tried here too and measured 20-25 % SLOWER -- 64 x 64 per wave
+    // gives a MATH segment of eight MFMAs, shorter than the LOAD segment beside it; not kept)
     hipLaunchKernelGGL(gemm_tn_ring_kernel, grid, dim3(512), lds, (hipStream_t)stream, g);
   } else {
   dim3 grid((g.N + 127) / 128, (g.M + 127) / 128, split_k);

@@ -39,6 +39,8 @@ _SIGS = {
     'las_lstm_recurrent_fwd': ([_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp], C.c_int),
     'las_lstm_recurrent_bwd': ([_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp], C.c_int),
     'las_set_knob': ([C.c_char_p, _i32], C.c_int),
+    'las_stream_create_masked': ([C.c_uint32, _vp], C.c_int),
+    'las_xcd_histogram': ([_vp, _i32, _i32, _vp], C.c_int),
     'las_gemm_nt_follow_supported': ([_i32, _i32, _i32, _i32, _i32], C.c_int),
     'las_gemm_nt_follow_words': ([_i32, _i32, _i32, _i32, _i32], C.c_size_t),
     'las_gemm_nt_follow': ([_vp, _i32, _vp], C.c_int),

@@ -303,7 +303,7 @@ def _stream_setup(a, lda, a_dir_stride, weights, xproj, sequence_length, B, T, H
 # LAS_FOLLOW=0: no follower products (round 5) -- the next layer's input projection / the gradient w.r.t. a layer's input are
 # formed behind the recurrence again (or streamed beside the consumer, STREAM_X) instead of behind the chains that produce
 # their operands.  LAS_FOLLOW_WGS: persistent workgroups of a follower (the recurrence keeps a CU per workgroup of its own).
-FOLLOW = os.environ.get('LAS_FOLLOW', '1') != '0'
+FOLLOW = os.environ.get('LAS_FOLLOW', '0') != '0'
 FOLLOW_BWD = os.environ.get('LAS_FOLLOW_BWD', '1') != '0'
 FOLLOW_WGS = int(os.environ.get('LAS_FOLLOW_WGS', '96'))
 FOLLOW_MIN_ROWS = 4096

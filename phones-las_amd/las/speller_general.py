@@ -84,9 +84,13 @@ class GeneralSpeller:
         self.sigmoid = bool(sigmoid)
         self.binf = binf2phone if not sigmoid else None      # the binf_projection machinery (fixed output map, A = 2 nf)
         self.feat = binf2phone                               # feature table of the token feed (both binary decoders)
-        if binf2phone is not None and d.bottom_only and d.num_layers > 1:
-            raise ValueError('binf_projection needs the decoder output to be the 2*binf_count attention vector: '
-                             'use decoder_layers 1 or drop --bottom_only')
+        if binf2phone is not None and not sigmoid and d.bottom_only and d.num_layers > 1 and d.num_units < 2 * int(binf2phone.shape[0]):
+            # a multi-layer --bottom_only decoder outputs the TOP CELL's h (AttentionMultiCell, las/model.py:36-69); the reference's
+            # transform_binf_to_phones slices its first 2*binf_count columns (utils/training_helper.py:19-21) and fails in the
+            # matmul, when the graph is built, if there are fewer
+            raise ValueError('binf_projection on a multi-layer --bottom_only decoder reads [lp1 | lp0] from the first 2*binf_count = %d '
+                             'columns of the top cell\'s output: decoder_units must be at least that (got %d)'
+                             % (2 * int(binf2phone.shape[0]), d.num_units))
         if binf2phone is not None and d.embedding_size:
             raise ValueError('binf_projection with embedding_size > 0: the reference embeds with target_embedding and '
                              'ignores the feature vectors; not implemented on the HIP path')
@@ -161,11 +165,11 @@ class GeneralSpeller:
             self.emb_bf[:, :self.nf].copy_(self.feat.to(device=dev, dtype=torch.float32).t())
         if self.binf is not None:
             Mb = self.binf.to(device=dev, dtype=torch.float32)
-            wb = torch.cat([Mb, 1.0 - Mb], 0)                         # [2nf, V]: logits = [lp1 | lp0] Wb
-            self.wproj.zero_()
-            self.wprojT.zero_()
-            self.wproj[:, :self.V].copy_(wb)
-            self.wprojT[:self.V].copy_(wb.t())
+            wb = torch.cat([Mb, 1.0 - Mb], 0)                         # [2nf, V]: logits = [lp1 | lp0] Wb, [lp1 | lp0] = the first
+            self.wproj.zero_()                                        # 2nf columns of the decoder output (all of them, unless the
+            self.wprojT.zero_()                                       # output is the top cell's h of a --bottom_only stack)
+            self.wproj[:2 * self.nf, :self.V].copy_(wb)
+            self.wprojT[:self.V, :2 * self.nf].copy_(wb.t())
         if self.uses_wq:
             self.wq = torch.empty(Hd, Hd, dtype=bf, device=dev)
             self.wq_t = torch.empty(Hd, Hd, dtype=bf, device=dev)
@@ -197,8 +201,8 @@ class GeneralSpeller:
             Mb = var[self.binf_var]
             self.emb_bf[:, :self.nf].copy_(Mb.t())
             wb = torch.cat([Mb, 1.0 - Mb], 0)
-            self.wproj[:, :V].copy_(wb)
-            self.wprojT[:V].copy_(wb.t())
+            self.wproj[:2 * self.nf, :V].copy_(wb)
+            self.wprojT[:V, :2 * self.nf].copy_(wb.t())
         hip.cast_bf16(var[self.K_MEM], M, Hd, self.wmemT, Hd, M, transpose=True)
         hip.cast_bf16(var[self.K_MEM], M, Hd, self.wmem, M, Hd)
         self.bias = []
@@ -665,10 +669,13 @@ class GeneralSpeller:
         """loss += weight * compute_log_probs_loss(raw outputs) (model_helper.py:132-146,327-331) on the attention vectors
         of the last forward_train; its gradient joins d(outputs) in backward()."""
         sv = self.saved
-        B, U, A = sv['B'], sv['U'], self.A
-        sv['dreg'] = torch.empty(B, U, A, dtype=torch.float32, device=loss.device)
-        hip.check(hip.lib().las_log_probs_loss(hip.p(sv['att']), A, B * U, self.nf, weight, grad_scale, hip.p(loss),
-                                               hip.p(sv['dreg']), A, hip.stream()))
+        B, U, P = sv['B'], sv['U'], self.P
+        # the raw outputs: the attention vectors (P = 2 nf), or the top cell's h of a --bottom_only stack (P = decoder_units) --
+        # compute_log_probs_loss halves WHATEVER width it is handed (model_helper.py:137-139: nfeatures = outputs.shape[-1] // 2)
+        raw = sv['out'] if (self.bottom and self.NL > 1) else sv['att']
+        sv['dreg'] = torch.zeros(B, U, P, dtype=torch.float32, device=loss.device)
+        hip.check(hip.lib().las_log_probs_loss(hip.p(raw), P, B * U, P // 2, weight, grad_scale, hip.p(loss),
+                                               hip.p(sv['dreg']), P, hip.stream()))
 
     # ------------------------------------------------------------------------------------------------------------------
     def _cell_bwd(self, l, t, sv, dc, sources, dz):

@@ -125,16 +125,28 @@ def test_follower_kernel_alone(B, T_out, stack, H, N, kind, ragged):
     if bool(claimed.all()):
         assert torch.equal(C1, C3b)
 
-    # (4) only ONE direction's chain has published: the follower stores that direction's halves, the clean-up adds the others
+    # (4) only ONE direction's chains make progress: the follower stores (some of) that direction's halves, gives the other
+    #     direction up after its bounded wait, and the clean-up pass adds what is missing: same bits
     def half_done(words):
         all_done(words)
         for g in range(nslices, 2 * nslices):
             words[p0 + g] = 0
-            words[16 + g] = 0x1ff | (16 << 8)                          # direction 1 "runs spread over XCDs": never taken
     C4, w4 = _run(c, dev, script=half_done)
     assert torch.equal(C1, C4)
     st4 = w4[s0:total]
-    assert bool(((st4 & 0x300) == 0x300).all()) and bool(((st4 & 2) == 0).all())
+    assert bool(((st4 & 0x300) == 0x300).all())
+    if not ragged:                       # (a tile beyond every length of its slice needs no step of the chain: taken at once)
+        assert bool(((st4 & 2) == 0).all())
+
+    # (5) a group that runs on ANOTHER XCD than its twin (or spread over several): its slice is left to the clean-up pass
+    def elsewhere(words):
+        all_done(words)
+        words[16 + nslices] = 0xff | (16 << 8) | (1 << 16)
+        words[16 + 1] = (((1 % 8) + 1) % 8 + 1) | (16 << 8) | (1 << 16)
+    C5, w5 = _run(c, dev, script=elsewhere)
+    assert torch.equal(C1, C5)
+    st5 = w5[s0:total].view(nslices, ntb * nct)
+    assert bool(((st5 & 0x300) == 0x300).all()) and bool((st5[0] == 0x300).all()) and bool((st5[1] == 0x300).all())
 
 
 def _listener_run(cfg, follow, monkeypatch, steps=2, cleanup_only=False):

@@ -467,7 +467,12 @@ def _toy_binf(nf, V, seed=5):
 @pytest.mark.parametrize('kw', [
     dict(att='luong', dec_layers=1, bottom_only=True, pass_hidden=True, nf=8),
     dict(att='bahdanau_monotonic', dec_layers=2, bottom_only=False, pass_hidden=False, nf=12),     # cfg5's attention type
-], ids=['binf_luong', 'binf_bahdanau_monotonic'])
+    # round 5: AttentionMultiCell (--bottom_only) under the projection: the decoder output is the TOP CELL's h, of which
+    # transform_binf_to_phones reads the first 2 nf columns and compute_log_probs_loss the two halves (las/model.py:178-200,
+    # utils/training_helper.py:17-27, model_helper.py:132-146)
+    dict(att='luong', dec_layers=2, bottom_only=True, pass_hidden=True, nf=8),
+    dict(att='bahdanau', dec_layers=3, bottom_only=True, pass_hidden=False, nf=12),
+], ids=['binf_luong', 'binf_bahdanau_monotonic', 'binf_multicell_luong', 'binf_multicell3_bahdanau'])
 def test_binf_projection_decoder_vs_oracle(kw):
     """SURVEY.md 8(a) rows a11 + a14 (cfg5: --binary_outputs --binf_projection): binary-feature token feed, attention
     layer of 2*binf_count outputs, DenseBinfDecoder's fixed map to phone logits, CE + compute_log_probs_loss."""
