@@ -120,8 +120,6 @@ KERNEL_NAMES = {        # family (phones_las_amd.hip.KernelTimer) -> kernel symb
     'dec_persist_bwd': 'dec_persist_bwd_kernel<wq, M/128>',
     'gemm_nt': 'gemm_nt_ring_kernel<256, 128|256, 32, ...> (+ gemm_kernel<..., false, ...> for the small shapes): x K_x, dX, keys, logits',
     'gemm_tn': 'gemm_tn_tr_kernel / gemm_kernel<..., true, ...> (speller weight gradients)',
-    'gemm_nt_follow': 'gemm_nt_follow_kernel, persistent beside a recurrence: the next layer\'s x K_x / this layer\'s dX behind the chains (its time is mostly waiting for them)',
-    'gemm_nt_follow_cleanup': 'gemm_nt_follow_kernel, clean-up pass behind the recurrence: the tiles of the chains\' last steps',
     'gemm_tn_lstm': 'gemm_tn_ring_kernel + tn_reduce_kernel (dK_x, dK_h, db of a direction)',
 }
 

@@ -79,7 +79,7 @@ int las_set_knob(const char* name, int value);
 int las_gemm_nt(const las_bf16* A, int64_t lda, const las_bf16* B, int64_t ldb, void* C, int64_t ldc,
                 const float* bias, int M, int N, int K, int out_bf16, int accumulate, int batch,
                 int64_t sa, int64_t sb, int64_t sc, int split_k, void* stream);
-/* The input product of a recurrent layer that runs BESIDE the product (round 4): C [B*T, N] fp32 = A [B*T, K] * Bm [N, K]^T + bias,
+/* The input product of a recurrent layer that runs BESIDE the product (round 4; las_gemm_nt_stream_dirs): C [B*T, N] fp32 = A [B*T, K] * Bm [N, K]^T + bias,
  * row b*T + t = utterance b at time t, the N columns in ndir halves (direction d reads columns [d*N/ndir, (d+1)*N/ndir)).  A
  * 256 x 128 output tile is the rows_per_slice (= las_lstm_slice_rows) utterances of ONE chain group x 256 / rows_per_slice
  * STEPS of its direction's time order (step tau = time tau forward, time length - 1 - tau in the reversed direction; steps
@@ -90,45 +90,13 @@ int las_gemm_nt(const las_bf16* A, int64_t lda, const las_bf16* B, int64_t ldb, 
  * las_gemm_nt_stream_flags(...) 32-bit words, zero before both launches.  N / ndir a multiple of 128, K of 64. */
 int las_gemm_nt_stream_supported(int N, int K, int ndir);
 size_t las_gemm_nt_stream_flags(int B, int T, int ndir, int rows_per_slice);
-int las_gemm_nt_stream(const las_bf16* A, int64_t lda, const las_bf16* Bm, int64_t ldb, float* C, int64_t ldc,
-                       const float* bias, const int32_t* length, int B, int T, int N, int K, int ndir,
-                       int rows_per_slice, uint32_t* ready, void* stream);
-/* ... with one A operand per direction: the columns of direction d are formed from A + d * a_dir_stride (elements).  Under
+/* One A operand per direction: the columns of direction d are formed from A + d * a_dir_stride (elements; 0: one operand).  Under
  * DropoutWrapper(input_keep_prob) the fw and bw cells of a layer read the same input through independent masks
  * (las/ops.py:14-18): the two masked copies lie a_dir_stride apart; a MultiRNNCell stack per direction (las/model.py:111-142)
  * reads its own column range of the layer below: a_dir_stride = that range's width. */
 int las_gemm_nt_stream_dirs(const las_bf16* A, int64_t lda, int64_t a_dir_stride, const las_bf16* Bm, int64_t ldb, float* C,
                             int64_t ldc, const float* bias, const int32_t* length, int B, int T, int N, int K, int ndir,
                             int rows_per_slice, uint32_t* ready, void* stream);
-
-/* FOLLOWER product (round 5): C [B*T_out, N] fp32 = A(view) B^T (+ bias) over the OUTPUT rows of a recurrent launch that runs beside
- * it -- the next layer's input projection behind a forward launch (kind 0: A = y, las/ops.py:75-87), dX = dz K_x^T behind a
- * backward launch (kind 1: A = dz) -- formed in two halves, one per direction of the recurrence: direction d contributes the K
- * columns [d * a_dir + i * a_seg, + seg_len), i < nseg, of A (the same with b_dir / b_seg of Bw [N, ldb]), and each half is
- * produced as soon as ITS chain has passed the tile's rows; the half that comes first stores, the second adds (and adds the
- * bias): (P + Q) + b in either order, so results do not depend on timing.  Row (b, t) of A = A + (b * T_out + t) * lda; one row
- * covers `stack` steps of the chain (2: pyramidal_stack's view of the layer below), T_chain = T_out * stack; `length` = the
- * chain's lengths.  rows_per_slice = las_lstm_slice_rows of the recurrence.
- * Protocol: zero `words` (las_gemm_nt_follow_words of them); launch the recurrence with follow = words; launch this with cleanup
- * = 0 and `workgroups` persistent workgroups on ANOTHER stream (one that runs beside the first: las_stream_concurrency_probe);
- * then, ordered behind BOTH, launch it again with cleanup = 1: that pass forms whatever the follower did not (the tiles of
- * the chain's last steps; every tile if the two did not overlap).  las_gemm_nt_follow_supported: rows_per_slice in {4, 8, 16},
- * two directions need ceil(B / rows_per_slice) % 8 == 0 (both chains of a slice on one XCD), seg_len a multiple of 32. */
-typedef struct las_follow {
-  const las_bf16* A;
-  const las_bf16* Bw;
-  float* C;
-  const float* bias;             /* [N] or NULL */
-  int64_t lda, ldb, ldc;
-  int32_t a_dir, a_seg, b_dir, b_seg, nseg, seg_len;
-  int32_t N, B, T_out, T_chain, stack, rows_per_slice, ndir, kind;
-  const int32_t* length;
-  uint32_t* words;
-  int32_t workgroups, reserved;
-} las_follow;
-int las_gemm_nt_follow_supported(int B, int N, int seg_len, int rows_per_slice, int ndir);
-size_t las_gemm_nt_follow_words(int B, int T_out, int N, int rows_per_slice, int ndir);
-int las_gemm_nt_follow(const las_follow* p, int cleanup, void* stream);
 
 /* C (=|+=) (A B^T) * mask / keep, mask[row, col] = [las_uniform(seed, stream_id, row * N + col) < keep]: the gradient through a
  * cell's input dropout (DropoutWrapper(input_keep_prob), las/ops.py:14-18; the mask las_dropout_bf16 drew for that cell in
@@ -222,9 +190,14 @@ int las_add_cast_bf16(const float* a, int64_t lda, const float* b, int64_t ldb, 
  * becomes runnable at the same moment as a persistent recurrent launch on the main stream and should not take CUs before
  * that launch's workgroups are resident (a chain that finds some of its CUs taken starts late as a whole). */
 int las_stream_delay(int microseconds, void* stream);
+/* Diagnostics / tests: `workgroups` one-wave workgroups that each add 1 to counts[XCD they run on] (8 device words) and then stay
+ * resident for spin_us microseconds holding lds_bytes of LDS: a census of the dispatcher's workgroup -> XCD placement, and a way to
+ * take CUs away from a launch that needs them (the persistent kernels' bounded waits under CU pressure: tests/test_gpu_step_forms.py). */
+int las_xcd_histogram(uint32_t* counts, int workgroups, int spin_us, int lds_bytes, void* stream);
+
 /* Can a kernel on `setter_stream` run while an EARLIER-enqueued kernel on `waiter_stream` is still running?  A process that
  * has created many streams gets them mapped onto a handful of hardware queues; two streams that share one run their kernels
- * in submission order.  The streamed input products (las_gemm_nt_stream beside las_lstm_recurrent_fwd_ex) need the answer to be
+ * in submission order.  The streamed input products (las_gemm_nt_stream_dirs beside las_lstm_recurrent_fwd_ex) need the answer to be
  * yes for their pair of streams.  Enqueues a one-thread kernel on waiter_stream that waits up to wait_us for a word that a
  * one-thread kernel enqueued AFTERWARDS on setter_stream writes; once both streams are synchronised, words[1] == 1: concurrent,
  * 2: the setter never ran beside the waiter.  words: two int32 in device memory. */
@@ -293,14 +266,11 @@ int las_lstm_fused_input_chunks(int H, int Dp);
 int las_lstm_pack_input(const float* kernel, int D, int H, int chunks, las_bf16* packed, void* stream);
 /* The forward recurrence with its options (las_lstm_recurrent_fwd = all of them off):
  *   x != NULL      fused input projection, as described above;
- *   ready != NULL  STREAMED input projection: xproj is being produced by a las_gemm_nt_stream launch that runs beside this
+ *   ready != NULL  STREAMED input projection: xproj is being produced by a las_gemm_nt_stream_dirs launch that runs beside this
  *                  one on another stream (launch this kernel first; hold the product back a few microseconds with
  *                  las_stream_delay so that the chain's workgroups are resident first).  ready = the buffer shared with the
  *                  product (las_gemm_nt_stream_flags words, zeroed by the caller before both launches: this launch writes its
- *                  groups' XCDs into it and waits on the product's counters); ready_count = column tiles per block = N / ndir / 128.
- *   follow != NULL a FOLLOWER product (las_gemm_nt_follow: the next layer's input projection) consumes y behind this launch: the
- *                  chains publish where they run and how far they are in these words (las_gemm_nt_follow_words of them, zeroed
- *                  by the caller before both launches). */
+ *                  groups' XCDs into it and waits on the product's counters); ready_count = column tiles per block = N / ndir / 128. */
 typedef struct las_lstm_fwd {
   float* xproj;                  /* [B,T,ndir*4H] fp32: x K_x + b on entry (unless x != NULL), the saved gates on exit */
   const las_bf16* wpacked;
@@ -316,9 +286,8 @@ typedef struct las_lstm_fwd {
   int32_t Dp, reserved0;
   const las_bf16* kx_packed;
   const float* bias;
-  uint32_t* ready;               /* streamed input projection (optional): shared with las_gemm_nt_stream, written by both */
+  uint32_t* ready;               /* streamed input projection (optional): shared with las_gemm_nt_stream_dirs, written by both */
   int32_t ready_count, reserved1;
-  uint32_t* follow;              /* a follower product consumes y behind this launch (optional): the words shared with las_gemm_nt_follow */
 } las_lstm_fwd;
 int las_lstm_recurrent_fwd_ex(const las_lstm_fwd* p, void* stream);
 
@@ -336,7 +305,7 @@ size_t las_lstm_workspace_bytes(int B, int H, int ndir);
  * per-step latency is mostly element-wise work per lane).  LAS_LSTM_ROWS=16|8 in the environment overrides (tests). */
 int las_lstm_slice_rows(int B, int H, int ndir);
 /* Workgroups (chain members + prefetch companions, one CU each) of a forward launch for this shape: a streamed input product
- * (las_gemm_nt_stream) beside it needs CUs of its own, so callers only stream when this leaves some (0 = unsupported). */
+ * (las_gemm_nt_stream_dirs) beside it needs CUs of its own, so callers only stream when this leaves some (0 = unsupported). */
 int las_lstm_fwd_workgroups(int B, int H, int ndir);
 
 /* Backward recurrence (reverse-mode AD of the loop above).
@@ -347,8 +316,7 @@ int las_lstm_fwd_workgroups(int B, int H, int ndir);
  * the caller derives dX, dK_x, dK_h, db from it with las_gemm_nt / las_gemm_tn / las_colsum. */
 int las_lstm_recurrent_bwd(const float* gates, const float* cbuf, const float* dy, const float* dc_last,
                            const float* dh_last, const las_bf16* kh_bf16, const int32_t* length,
-                           las_bf16* dz, void* workspace, int B, int T, int H, int ndir, uint32_t* follow, void* stream);
-/* follow: NULL, or the words shared with a follower product (las_gemm_nt_follow, kind 1: dX = dz K_x^T behind the chains). */
+                           las_bf16* dz, void* workspace, int B, int T, int H, int ndir, void* stream);
 
 /* len_out[b] = len[b]/2 + len[b]%2  (las/ops.py:65 pyramidal_stack). */
 int las_pyramid_lengths(const int32_t* len_in, int32_t* len_out, int B, void* stream);
@@ -837,9 +805,8 @@ int las_status_collect(const uint32_t* const* status_words, int n, float* flag, 
 int las_clip_adam_update(float* params, float* m, float* v, float* grads, const int64_t* seg_offsets, int nseg,
                          int64_t total, const float* sumsq, float clip, float lr, float beta1, float beta2, float eps,
                          int step, const int32_t* step_dev, const float* skip_flag, void* stream);
-/* *counter += delta on the stream (tf.train.get_global_step increment, model_helper.py:417). */
-int las_counter_add(int32_t* counter, int32_t delta, void* stream);
-/* The same, but nothing happens when *skip_flag != 0 (the flag las_adam_update / las_clip_adam_update honour): the Adam
+/* *counter += delta on the stream (tf.train.get_global_step increment, model_helper.py:417) -- unless *skip_flag != 0 (the flag
+ * las_adam_update / las_clip_adam_update honour): the Adam
  * step count t of a step whose update was withheld (a persistent kernel timed out on some replica) is not consumed, so
  * the bias corrections of the next applied step are those of an uninterrupted run.  skip_flag may be NULL. */
 int las_counter_add_unless(int32_t* counter, int32_t delta, const float* skip_flag, void* stream);
@@ -911,10 +878,6 @@ int las_tfrecord_parse_batch(const uint8_t* data, const int64_t* offsets, const 
                              float* frames, int64_t frame_rows_capacity, int64_t* frame_row_offsets, uint8_t* label_bytes,
                              int64_t label_bytes_capacity, int32_t* token_offsets, int64_t token_capacity,
                              int32_t* label_counts);
-/* The same for ONE serialized SequenceExample (token_offsets [n_labels + 1]). */
-int las_tfrecord_parse(const uint8_t* record, int64_t length, int num_channels, float* frames, int64_t frame_rows_capacity,
-                       int32_t* n_frames, uint8_t* label_bytes, int64_t label_bytes_capacity, int32_t* token_offsets,
-                       int64_t token_capacity, int32_t* n_labels);
 /* Vocabulary lookup of a batch's label tokens (utils/vocab_utils.py create_vocab_table: index_table_from_tensor with
  * default_value = <unk>): token k = label_bytes[token_offsets[k] .. token_offsets[k+1]) -> ids[k].  The table is open
  * addressing over the tokens' FNV-1a 64-bit hashes (keys[table_size], 0 = empty slot, a hash of 0 is stored as 1;

@@ -337,9 +337,7 @@ extern "C" int las_stream_delay(int microseconds, void* stream) {
   return LAS_OK;
 }
 
-// ---- streams confined to some of the chip's XCDs (hipExtStreamCreateWithCUMask) ----
-// Bit i of a CU mask selects a CU of XCD i % 8 on a device of 8 XCDs (the driver deals the mask's bits to the XCDs in turn), so
-// "XCD x" is every bit i with i % 8 == x.  xcd_mask: bit x set = the stream's kernels may run on XCD x.
+// ---- a census of the dispatcher's placement, and a way to take CUs away from a launch (tests) ----
 namespace {
 __global__ void xcd_histogram_kernel(unsigned* counts, int spin) {
   if (threadIdx.x == 0) {
@@ -352,27 +350,15 @@ __global__ void xcd_histogram_kernel(unsigned* counts, int spin) {
 }
 }  // namespace
 
-extern "C" int las_stream_create_masked(uint32_t xcd_mask, void** stream_out) {
-  LAS_REQUIRE(stream_out != nullptr && (xcd_mask & 0xffu) != 0, "las_stream_create_masked: a non-empty set of XCDs (bits 0..7)");
-  int dev = 0, cus = 0;
-  int rc = las_check_hip(hipGetDevice(&dev), "get device");
-  if (!rc) rc = las_check_hip(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev), "CU count");
-  if (rc) return rc;
-  LAS_REQUIRE(cus > 0 && cus % 8 == 0 && cus <= 1024, "las_stream_create_masked: %d CUs (expected 8 XCDs)", cus);
-  uint32_t mask[32] = {0};
-  for (int i = 0; i < cus; ++i)
-    if ((xcd_mask >> (i & 7)) & 1u) mask[i >> 5] |= 1u << (i & 31);
-  hipStream_t st = nullptr;
-  rc = las_check_hip(hipExtStreamCreateWithCUMask(&st, (uint32_t)((cus + 31) / 32), mask), "hipExtStreamCreateWithCUMask");
-  if (rc) return rc;
-  *stream_out = (void*)st;
-  return LAS_OK;
-}
-
-// diagnostics: how many of `workgroups` one-wave workgroups of a launch on `stream` ran on each XCD (counts: 8 device words, added to)
-extern "C" int las_xcd_histogram(uint32_t* counts, int workgroups, int spin_us, void* stream) {
-  LAS_REQUIRE(counts != nullptr && workgroups > 0 && spin_us >= 0 && spin_us <= 10000, "las_xcd_histogram: bad arguments");
-  hipLaunchKernelGGL(xcd_histogram_kernel, dim3(workgroups), dim3(64), 0, (hipStream_t)stream, counts, spin_us);
+// diagnostics / tests: `workgroups` one-wave workgroups that each note the XCD they run on (counts: 8 device words, added to) and
+// then stay resident for spin_us microseconds holding lds_bytes of LDS -- a census of the dispatcher's placement, and a way to
+// take CUs away from a launch that needs them (tests of the persistent kernels' bounded waits under CU pressure)
+extern "C" int las_xcd_histogram(uint32_t* counts, int workgroups, int spin_us, int lds_bytes, void* stream) {
+  LAS_REQUIRE(counts != nullptr && workgroups > 0 && spin_us >= 0 && spin_us <= 5000000 && lds_bytes >= 0 && lds_bytes <= 160 * 1024,
+              "las_xcd_histogram: bad arguments");
+  if (lds_bytes > 48 * 1024)
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&xcd_histogram_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+  hipLaunchKernelGGL(xcd_histogram_kernel, dim3(workgroups), dim3(64), (size_t)lds_bytes, (hipStream_t)stream, counts, spin_us);
   LAS_LAUNCH_CHECK("xcd histogram launch");
   return LAS_OK;
 }

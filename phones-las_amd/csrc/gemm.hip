@@ -1040,339 +1040,6 @@ __global__ __launch_bounds__(NW * 64) void gemm_nt_ring_kernel(GemmArgs g) {
 }
 
 
-// ------------------------------------------------------------------------------------------------
-// FOLLOWER product (round 5): an NT product over the OUTPUT rows of a recurrent launch that runs beside it.
-//   forward:   xproj_{l+1}[b, t', :] = y_l(view)[b, t', :] K_x^T + bias   -- the next layer's input projection (las/ops.py:75-87: the
-//              stacking that makes layer l+1 wait for layer l)
-//   backward:  dX_l[b, t, :]         = dz_l[b, t, :] K_x                  -- the gradient w.r.t. the layer's input (= d y_{l-1})
-// Both need BOTH directions of the layer: the left-to-right chain finishes time t after t steps, the right-to-left one after
-// len - t, so a row is complete only when the later of the two has passed it -- for the rows the next recurrence starts on,
-// at the very end.  But the product is a SUM over the directions' column ranges of the A operand:
-//   C = A[:, cols of direction 0] B[:, same]^T + A[:, cols of direction 1] B[:, same]^T,
-// and each half only needs ITS chain.  So every (slice of R utterances x 256 / R rows of time) tile is produced in two halves,
-// each as soon as its chain has passed the tile's rows (the chains publish their progress: lstm.hip, FollowPub): the half that
-// comes first stores its fp32 partial product, the one that comes second adds its own and the bias -- (P + Q) + b whichever of
-// the two was first, so the result does not depend on timing (fp32 addition commutes).  When the recurrence ends, only the
-// tiles of its last block of steps are still to do; today's "product behind the recurrence" has become "product behind the
-// chain's last 64 steps".
-// The kernel is PERSISTENT and XCD-aware, like the streamed product above: a workgroup reads its XCC id and serves the slices
-// whose chains run on its XCD (the chains publish where they run; with two directions the launch requires nslices % 8 == 0, which
-// puts both chains of a slice 8 k blocks apart: on one XCD) from that XCD's queue, in the order the chains make the tiles ready.  It reads the chains'
-// rows through the L2 their plain stores land in, and both halves of a tile meet in that L2 as well.  NOTHING is assumed: a
-// tile is taken only if the chain group has published that it runs on this XCD, that its rows beyond the lengths are zero
-// and that the steps the tile needs are stored; every wait is bounded, and whatever the follower leaves undone -- a group
-// that runs elsewhere, a wait that ran out, the tiles of the last steps, all of them when the two launches did not overlap
-// at all -- is done by the CLEAN-UP launch of the same kernel behind the recurrence (stream order): it walks every tile,
-// reads its state word and forms the missing halves in the same arithmetic.  The follower is an optimisation, never a
-// precondition.
-// 256 x 128 output tile, 8 waves as 4 x 2, 64 x 64 per wave = 2 x 2 tiles of v_mfma_f32_32x32x16_bf16, LDS-DMA ring of three
-// 32-deep stages (72 KiB): gemm_nt_ring_kernel<256, 128, 32, 3, 4> with gated, segmented operands.
-// ------------------------------------------------------------------------------------------------
-struct FollowArgs {
-  const unsigned short* A;
-  const unsigned short* Bw;
-  float* C;
-  const float* bias;
-  int64_t lda, ldb, ldc;
-  int a_dir, a_seg, b_dir, b_seg, nseg, seg_len;   // direction d's K columns: segments i = 0 .. nseg-1 of seg_len at d * dir + i * seg
-  int N, Bn, T_out, T_chain, stack, R, ndir, kind; // kind 0: behind a forward chain (y), 1: behind a backward chain (dz)
-  const int32_t* length;                           // the chain's sequence lengths
-  unsigned* words;                                 // las_follow_layout_of(nslices * ndir, nslices * ntb * nct)
-  int nslices, ntb, nct, p0, z0, s0;
-  int cleanup;
-};
-
-constexpr int FO_BM = 256, FO_BN = 128, FO_BK = 32, FO_STAGES = 3;
-constexpr unsigned FO_WAIT_PLACEMENT = 1u << 13, FO_WAIT_PROGRESS = 1u << 19, FO_WAIT_HALF = 1u << 18;
-
-// steps (iterations of the chain) after which every row of tile [a, b) x slice is stored, direction d; 0: the tile holds no
-// valid row (its operand rows are the zero-filled ones: the product is formed all the same, so that C is what the product behind
-// the recurrence would have left everywhere).  *smax_out = steps the chain runs.  (lstm.hip: the forward chain of direction 0 handles position s at step s, of
-// direction 1 position len - 1 - s; the backward chains walk the same positions in the opposite order, and rows shorter than
-// the slice's longest join late.)
-__device__ __forceinline__ int follow_need(const FollowArgs& g, int slice, int d, int a, int b, int* smax_out) {
-  int smax = 0;
-  for (int u = 0; u < g.R; ++u) {
-    const int bb = slice * g.R + u;
-    if (bb < g.Bn) smax = max(smax, min(g.length[bb], g.T_chain));
-  }
-  int need = 0;
-  for (int u = 0; u < g.R; ++u) {
-    const int bb = slice * g.R + u;
-    if (bb >= g.Bn) continue;
-    const int len = min(g.length[bb], g.T_chain);
-    if (len <= a) continue;
-    const int e = min(b, len);
-    const int t = g.kind == 0 ? (d == 0 ? e : len - a) : (d == 0 ? smax - a : smax - len + e);
-    need = max(need, t);
-  }
-  *smax_out = smax;
-  return need;
-}
-
-__global__ __launch_bounds__(512) void gemm_nt_follow_kernel(FollowArgs g) {
-  constexpr int BM = FO_BM, BN = FO_BN, BK = FO_BK, STAGES = FO_STAGES, NW = 8, WGM = 4, WGN = 2;
-  constexpr int TM = BM / WGM / 32, TN = BN / WGN / 32;
-  constexpr int ROWB = BK * 2, CPR = BK / 8, RPC = 1024 / ROWB;
-  constexpr int NA = BM / RPC / NW, NB = BN / RPC / NW, NL = NA + NB;
-  constexpr int STAGE_BYTES = (BM + BN) * ROWB;
-  constexpr int KS = BK / 16;
-  extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
-  typedef __attribute__((address_space(3))) unsigned char lds_u8;
-  lds_u8* lds = (lds_u8*)smem;
-  const unsigned lds_base = (unsigned)__builtin_amdgcn_readfirstlane((int)(size_t)lds);
-  __shared__ int s_item, s_flag;
-
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave / WGN, wn = wave % WGN;
-  unsigned xcc;
-  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-  const int my_xcd = (int)(xcc & 7);
-  const int SBO = BM / g.R;                          // output rows per utterance and tile
-  const int nk = g.nseg * g.seg_len / BK;
-  const int NBLK = (g.T_chain + LAS_FOLLOW_STEPS - 1) / LAS_FOLLOW_STEPS;
-  auto fswz = [](int r) { return (r >> 2) & 3; };
-  auto load_word = [](const unsigned* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
-
-  // The slices this workgroup serves: those whose chain groups (both directions) PUBLISHED this XCD.  Read once every group of the
-  // launch has published (the words never change afterwards): every workgroup of an XCD derives the same list, so a queue slot
-  // means the same tile to all of them.  No chain beside this launch (nothing published in time): leave, the clean-up pass does it.
-  __shared__ int s_slices[128];
-  __shared__ int s_nmy;
-  if (!g.cleanup) {
-    if (tid == 0) {
-      const int ngroups = g.nslices * g.ndir;
-      bool all = true;
-      unsigned spins = 0;
-      for (int gi = 0; gi < ngroups && all; ++gi)
-        while (load_word(g.words + 16 + gi) == 0) {
-          if (++spins > FO_WAIT_PLACEMENT) { all = false; break; }
-          __builtin_amdgcn_s_sleep(16);
-        }
-      int n = 0;
-      for (int sl = 0; sl < g.nslices && n < 128 && all; ++sl) {
-        bool mine = true;
-        for (int d = 0; d < g.ndir; ++d) mine = mine && (load_word(g.words + 16 + d * g.nslices + sl) & 0xffu) == (unsigned)my_xcd + 1u;
-        if (mine) s_slices[n++] = sl;
-      }
-      s_nmy = n;
-    }
-    __syncthreads();
-    if (s_nmy == 0) return;
-  }
-  for (;;) {
-    __syncthreads();                                 // the previous tile has left the LDS; s_item may be rewritten
-    if (tid == 0) s_item = (int)__hip_atomic_fetch_add(g.words + (g.cleanup ? 8 : my_xcd), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __syncthreads();
-    const int q = s_item;
-    int slice, tb, ct, d0, d1;
-    if (!g.cleanup) {
-      const int per_blk = s_nmy * g.ndir * g.nct;
-      if (q >= per_blk * g.ntb) break;
-      // block of time by block of time in the order the chains pass them; inside one, the column tiles of a (slice, direction)
-      // are neighbours (they share the A rows)
-      const int k = q / per_blk, r = q % per_blk, r2 = r % (g.ndir * g.nct);
-      slice = s_slices[r / (g.ndir * g.nct)];
-      d0 = r2 / g.nct;
-      d1 = d0 + 1;
-      ct = r2 % g.nct;
-      tb = ((g.kind == 0) == (d0 == 0)) ? k : g.ntb - 1 - k;
-    } else {
-      if (q >= g.nslices * g.ntb * g.nct) break;
-      slice = q / (g.ntb * g.nct);
-      tb = (q / g.nct) % g.ntb;
-      ct = q % g.nct;
-      d0 = 0;
-      d1 = g.ndir;
-    }
-    unsigned* state = g.words + g.s0 + (slice * g.ntb + tb) * g.nct + ct;
-    const int pa = tb * SBO * g.stack, pb = min((tb + 1) * SBO * g.stack, g.T_chain);     // the chain positions the tile's rows cover
-    unsigned done_bits = 0;
-    if (g.cleanup) {
-      if (tid == 0) s_flag = (int)load_word(state);
-      __syncthreads();
-      done_bits = ((unsigned)s_flag >> 8) & 3u;
-    }
-    for (int d = d0; d < d1; ++d) {
-      if ((done_bits >> d) & 1u) continue;
-      const int group = d * g.nslices + slice;
-      // ---- gate (thread 0): 1 = go, 0 = leave the half to the clean-up pass, 3 = leave the kernel ----
-      __syncthreads();
-      if (tid == 0) {
-        int smax = 0;
-        const int need = follow_need(g, slice, d, pa, pb, &smax);
-        int go = 1;
-        if (!g.cleanup) {
-          // (a wait that runs out means the recurrence is not running beside this launch: the workgroup LEAVES -- go = 3 --
-          // instead of spending the same wait on every tile that is left; a group that runs elsewhere only skips its tiles)
-          const unsigned pl = load_word(g.words + 16 + group);        // (published, and on this XCD: the list above)
-          const unsigned waves = (pl >> 8) & 0xffu, cpg = (pl >> 16) & 0xffu;
-          if (waves == 0) go = 0;
-          unsigned spins = 0;
-          while (go == 1 && load_word(g.words + g.z0 + group) < cpg) {
-            if (++spins > FO_WAIT_PLACEMENT) go = 3;
-            __builtin_amdgcn_s_sleep(16);
-          }
-          const unsigned want = (unsigned)(need >= smax ? NBLK : (need + LAS_FOLLOW_STEPS - 1) / LAS_FOLLOW_STEPS) * waves;
-          spins = 0;
-          while (go == 1 && load_word(g.words + g.p0 + group) < want) {
-            if (++spins > FO_WAIT_PROGRESS) go = 3;
-            __builtin_amdgcn_s_sleep(8);
-          }
-        }
-        s_flag = go;
-      }
-      __syncthreads();
-      const int go = s_flag;
-      if (go == 3) return;
-      if (go != 1) continue;
-      asm volatile("" ::: "memory");                 // the rows are read after the counters (first touch of these lines in this kernel)
-
-      // ---- operands: tile row i = utterance slice * R + i / SBO at output time tb * SBO + i % SBO; rows that do not exist
-      //      re-read the tile's first row (complete like every row of the tile; never stored) ----
-      const unsigned short* src[NL];
-#pragma unroll
-      for (int i = 0; i < NL; ++i) {
-        const bool isA = i < NA;
-        const int qq = wave + NW * (isA ? i : i - NA);
-        const int row = RPC * qq + lane / CPR;
-        const int ch = (lane % CPR) ^ fswz(row);
-        if (isA) {
-          int bb = slice * g.R + row / SBO, t = tb * SBO + row % SBO;
-          if (bb >= g.Bn || t >= g.T_out) { bb = slice * g.R; t = tb * SBO; }
-          src[i] = g.A + ((int64_t)bb * g.T_out + t) * g.lda + d * g.a_dir + 8 * ch;
-        } else {
-          src[i] = g.Bw + (int64_t)min(ct * BN + row, g.N - 1) * g.ldb + d * g.b_dir + 8 * ch;
-        }
-      }
-      int kpos = 0;
-      auto issue = [&](int stage) {
-        const unsigned base = lds_base + stage * STAGE_BYTES;
-#pragma unroll
-        for (int i = 0; i < NL; ++i) {
-          const int qq = wave + NW * (i < NA ? i : i - NA);
-          glds16(src[i], base + (i < NA ? 0 : BM * ROWB) + qq * 1024);
-          src[i] += BK;
-        }
-        kpos += BK;
-        if (kpos == g.seg_len) {                      // next segment of the direction's columns
-          kpos = 0;
-#pragma unroll
-          for (int i = 0; i < NL; ++i) src[i] += (i < NA ? g.a_seg : g.b_seg) - g.seg_len;
-        }
-      };
-
-      f32x16 acc[TM][TN];
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-      const int l31 = lane & 31, hk = lane >> 5, swz = fswz(l31);
-      const int a_row = (wm * (BM / WGM) + l31) * ROWB, b_row = BM * ROWB + (wn * (BN / WGN) + l31) * ROWB;
-      int koff[KS];
-#pragma unroll
-      for (int ks = 0; ks < KS; ++ks) koff[ks] = ((2 * ks + hk) ^ swz) << 4;
-
-#pragma unroll
-      for (int p = 0; p < STAGES - 1; ++p)
-        if (p < nk) issue(p);
-      int stage = 0;
-      for (int kt = 0; kt < nk; ++kt) {
-        if (kt + STAGES - 2 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(NL * (STAGES - 2)) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        if (kt + STAGES - 1 < nk) issue(stage == 0 ? STAGES - 1 : stage - 1);
-        const lds_u8* st = lds + stage * STAGE_BYTES;
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-          bf16x8 af[TM], bfr[TN];
-#pragma unroll
-          for (int i = 0; i < TM; ++i) af[i] = *(const __attribute__((address_space(3))) bf16x8*)(st + a_row + i * 32 * ROWB + koff[ks]);
-#pragma unroll
-          for (int j = 0; j < TN; ++j) bfr[j] = *(const __attribute__((address_space(3))) bf16x8*)(st + b_row + j * 32 * ROWB + koff[ks]);
-#pragma unroll
-          for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int j = 0; j < TN; ++j)
-              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
-        }
-        stage = (stage + 1 == STAGES) ? 0 : stage + 1;
-      }
-
-      // ---- which half is this?  0: the first (stores P), 1: the second (C = (C + P) + bias), 2: the only one (P + bias) ----
-      int mode;
-      __syncthreads();                               // every wave has finished reading the last stage; s_flag may be rewritten
-      if (g.ndir == 1) mode = 2;
-      else if (g.cleanup) mode = done_bits ? 1 : 0;
-      else {
-        if (tid == 0) {
-          const unsigned old = __hip_atomic_fetch_or(state, 1u << d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          int m = (old & 3u) ? 1 : 0;
-          if (m == 1) {                              // the other half was claimed first: its tile must be stored before it is read
-            unsigned spins = 0;
-            while (!(load_word(state) & (0x100u << (1 - d)))) {
-              if (++spins > FO_WAIT_HALF) { m = -1; break; }
-              __builtin_amdgcn_s_sleep(8);
-            }
-          }
-          s_flag = m;
-        }
-        __syncthreads();
-        mode = s_flag;
-        if (mode < 0) continue;                      // (left to the clean-up pass, which looks at the done bits only)
-      }
-      asm volatile("" ::: "memory");
-
-      // ---- epilogue through LDS (32 rows x 64 columns of the wave's tile at a time): row-contiguous 16-byte accesses ----
-      constexpr int WN_ = 32 * TN, LDC = WN_ + 4;
-      static_assert(NW * 32 * LDC * 4 <= STAGES * STAGE_BYTES, "epilogue staging must fit in the ring");
-      float* cs = reinterpret_cast<float*>(smem) + wave * 32 * LDC;
-      constexpr int LPR = WN_ / 4, RPI = 64 / LPR;
-      const int cl = (lane % LPR) * 4, rl = lane / LPR;
-      const int col = ct * BN + wn * WN_ + cl;
-      float bv[4] = {0.f, 0.f, 0.f, 0.f};
-      if (g.bias != nullptr && mode != 0)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) if (col + e < g.N) bv[e] = g.bias[col + e];
-#pragma unroll
-      for (int i = 0; i < TM; ++i) {
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-          for (int r = 0; r < 16; ++r)
-            cs[((r & 3) + 8 * (r >> 2) + 4 * hk) * LDC + j * 32 + l31] = acc[i][j][r];
-        __builtin_amdgcn_s_waitcnt(0xC07F);        // lgkmcnt(0): a wave reads back only what it wrote itself
-#pragma unroll 4
-        for (int r0 = 0; r0 < 32; r0 += RPI) {
-          const int rt = wm * (BM / WGM) + i * 32 + r0 + rl;
-          const int u = rt / SBO, t = tb * SBO + rt % SBO, bb = slice * g.R + u;
-          if (bb >= g.Bn || t >= g.T_out || col >= g.N) continue;
-          const float4 v4 = *reinterpret_cast<const float4*>(cs + (r0 + rl) * LDC + cl);
-          float* dst = g.C + ((int64_t)bb * g.T_out + t) * g.ldc + col;
-          float4 o = v4;
-          if (mode == 1) {
-            const float4 c = *reinterpret_cast<const float4*>(dst);
-            o.x += c.x; o.y += c.y; o.z += c.z; o.w += c.w;
-          }
-          if (mode != 0) { o.x += bv[0]; o.y += bv[1]; o.z += bv[2]; o.w += bv[3]; }
-          *reinterpret_cast<float4*>(dst) = o;
-        }
-        __builtin_amdgcn_s_waitcnt(0xC07F);        // the staging rows are rewritten by the next 32 rows
-      }
-      // every wave's stores have been acknowledged by this XCD's L2 (the clean-up pass: by the end of the kernel) before the
-      // half is marked done
-      __builtin_amdgcn_s_waitcnt(0x0F70);          // vmcnt(0)
-      __syncthreads();
-      if (tid == 0) __hip_atomic_fetch_or(state, 0x100u << d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      done_bits |= 1u << d;
-    }
-  }
-}
-
 template <int BM, int BN, int BK, int STAGES, int WGM, int NW = 8, bool PP = false>
 int launch_ring(const GemmArgs& g, int batch, hipStream_t st) {
   dim3 grid((g.N + BN - 1) / BN, (g.M + BM - 1) / BM, batch);
@@ -1566,16 +1233,6 @@ extern "C" size_t las_gemm_nt_stream_flags(int B, int T, int ndir, int rows_per_
 
 extern "C" int las_gemm_nt_stream_dirs(const las_bf16* A, int64_t lda, int64_t a_dir_stride, const las_bf16* Bm, int64_t ldb, float* C,
                                        int64_t ldc, const float* bias, const int32_t* length, int B, int T, int N, int K, int ndir,
-                                       int rows_per_slice, uint32_t* ready, void* stream);
-
-extern "C" int las_gemm_nt_stream(const las_bf16* A, int64_t lda, const las_bf16* Bm, int64_t ldb, float* C, int64_t ldc,
-                                  const float* bias, const int32_t* length, int B, int T, int N, int K, int ndir,
-                                  int rows_per_slice, uint32_t* ready, void* stream) {
-  return las_gemm_nt_stream_dirs(A, lda, 0, Bm, ldb, C, ldc, bias, length, B, T, N, K, ndir, rows_per_slice, ready, stream);
-}
-
-extern "C" int las_gemm_nt_stream_dirs(const las_bf16* A, int64_t lda, int64_t a_dir_stride, const las_bf16* Bm, int64_t ldb, float* C,
-                                       int64_t ldc, const float* bias, const int32_t* length, int B, int T, int N, int K, int ndir,
                                        int rows_per_slice, uint32_t* ready, void* stream) {
   LAS_REQUIRE(a_dir_stride % 8 == 0, "las_gemm_nt_stream_dirs: the directions' operands 16-byte aligned (a_dir_stride a multiple of 8)");
   LAS_REQUIRE(A && Bm && C && length && ready && B > 0 && T > 0, "las_gemm_nt_stream: null argument or empty batch");
@@ -1606,59 +1263,6 @@ extern "C" int las_gemm_nt_stream_dirs(const las_bf16* A, int64_t lda, int64_t a
   if (sgrid < 8 || sgrid > 1024) sgrid = 192;
   hipLaunchKernelGGL((gemm_nt_ring_kernel<BM, BN, BK, STAGES, WGM, true>), dim3(sgrid), dim3(512), lds, (hipStream_t)stream, g);
   LAS_LAUNCH_CHECK("streamed gemm launch");
-  return LAS_OK;
-}
-
-extern "C" int las_gemm_nt_follow_supported(int B, int N, int seg_len, int rows_per_slice, int ndir) {
-  if (rows_per_slice != 4 && rows_per_slice != 8 && rows_per_slice != 16) return 0;
-  const int nslices = (B + rows_per_slice - 1) / rows_per_slice;
-  // both directions of a slice on one XCD (slice s and group nslices + s are 8 k blocks apart): the halves of a tile meet in its L2
-  return B > 0 && (ndir == 1 || (ndir == 2 && nslices % 8 == 0)) && N > 0 && N % 4 == 0 && seg_len >= FO_BK && seg_len % FO_BK == 0 &&
-         nslices * ndir <= 240;
-}
-
-extern "C" size_t las_gemm_nt_follow_words(int B, int T_out, int N, int rows_per_slice, int ndir) {
-  if (rows_per_slice != 4 && rows_per_slice != 8 && rows_per_slice != 16) return 0;
-  const int nslices = (B + rows_per_slice - 1) / rows_per_slice, sbo = FO_BM / rows_per_slice;
-  return (size_t)las_follow_layout_of(nslices * ndir, nslices * ((T_out + sbo - 1) / sbo) * ((N + FO_BN - 1) / FO_BN)).words;
-}
-
-extern "C" int las_gemm_nt_follow(const las_follow* p, int cleanup, void* stream) {
-  LAS_REQUIRE(p && p->A && p->Bw && p->C && p->length && p->words, "las_gemm_nt_follow: null argument");
-  LAS_REQUIRE(las_gemm_nt_follow_supported(p->B, p->N, p->seg_len, p->rows_per_slice, p->ndir),
-              "las_gemm_nt_follow: unsupported shape B=%d N=%d seg_len=%d rows_per_slice=%d ndir=%d", p->B, p->N, p->seg_len, p->rows_per_slice, p->ndir);
-  LAS_REQUIRE(p->T_out > 0 && p->stack >= 1 && p->T_chain == p->T_out * p->stack && p->nseg >= 1 && (p->kind == 0 || p->kind == 1),
-              "las_gemm_nt_follow: T_chain = T_out * stack, nseg >= 1, kind 0 (forward chain) or 1 (backward chain)");
-  LAS_REQUIRE(p->lda % 8 == 0 && p->ldb % 8 == 0 && p->ldc % 4 == 0 && p->a_dir % 8 == 0 && p->a_seg % 8 == 0 && p->b_dir % 8 == 0 && p->b_seg % 8 == 0 &&
-                  ((uintptr_t)p->A % 16 == 0) && ((uintptr_t)p->Bw % 16 == 0) && ((uintptr_t)p->C % 16 == 0),
-              "las_gemm_nt_follow: operands 16-byte aligned, element strides multiples of 8 (ldc of 4)");
-  FollowArgs g{};
-  g.A = p->A; g.Bw = p->Bw; g.C = p->C; g.bias = p->bias;
-  g.lda = p->lda; g.ldb = p->ldb; g.ldc = p->ldc;
-  g.a_dir = p->a_dir; g.a_seg = p->a_seg; g.b_dir = p->b_dir; g.b_seg = p->b_seg; g.nseg = p->nseg; g.seg_len = p->seg_len;
-  g.N = p->N; g.Bn = p->B; g.T_out = p->T_out; g.T_chain = p->T_chain; g.stack = p->stack; g.R = p->rows_per_slice; g.ndir = p->ndir; g.kind = p->kind;
-  g.length = p->length;
-  g.words = p->words;
-  g.nslices = (p->B + g.R - 1) / g.R;
-  const int sbo = FO_BM / g.R;
-  g.ntb = (p->T_out + sbo - 1) / sbo;
-  g.nct = (p->N + FO_BN - 1) / FO_BN;
-  const las_follow_layout L = las_follow_layout_of(g.nslices * g.ndir, g.nslices * g.ntb * g.nct);
-  g.p0 = L.p0; g.z0 = L.z0; g.s0 = L.s0;
-  g.cleanup = cleanup ? 1 : 0;
-  const size_t lds = (size_t)FO_STAGES * (FO_BM + FO_BN) * FO_BK * 2;
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_follow_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_set = true;
-  }
-  // follower: persistent, `workgroups` of them (the caller leaves the recurrence its CUs); clean-up: one pass over the tiles by a
-  // grid that fills the chip
-  int grid = cleanup ? g.nslices * g.ntb * g.nct : p->workgroups;
-  if (cleanup && grid > 512) grid = 512;
-  LAS_REQUIRE(grid > 0 && grid <= 4096, "las_gemm_nt_follow: workgroups = %d", grid);
-  hipLaunchKernelGGL(gemm_nt_follow_kernel, dim3(grid), dim3(512), lds, (hipStream_t)stream, g);
-  LAS_LAUNCH_CHECK("follower gemm launch");
   return LAS_OK;
 }
 

@@ -2,7 +2,7 @@
 // -> (x - mean) / std -> padded batch), host side in C and one HIP kernel:
 //   las_tfrecord_index        TFRecord framing of a file image (length, masked crc32c, payload, masked crc32c) + the frame /
 //                             label counts of every SequenceExample, one pass, optional CRC check (hardware crc32c)
-//   las_tfrecord_parse[_batch] SequenceExample{feature_lists{'inputs': float_list per frame, 'labels': bytes_list per step}}
+//   las_tfrecord_parse_batch  SequenceExample{feature_lists{'inputs': float_list per frame, 'labels': bytes_list per step}}
 //                             -> packed [sum T, F] float frames + the label tokens as bytes with offsets
 //   las_normalize_pad_bf16    packed frames -> (x - mean) / std -> bf16 [B, T', F'] zero padded (the listener's input layout)
 // The Python host (utils/fast_input.py) keeps the reference's pipeline semantics (repeat, shuffle buffer, filters, padded
@@ -307,18 +307,6 @@ extern "C" int las_vocab_lookup(const uint8_t* label_bytes, const int32_t* token
     ids[k] = id;
   }
   return LAS_OK;
-}
-
-extern "C" int las_tfrecord_parse(const uint8_t* record, int64_t length, int num_channels, float* frames, int64_t frame_rows_capacity,
-                                  int32_t* n_frames, uint8_t* label_bytes, int64_t label_bytes_capacity, int32_t* token_offsets,
-                                  int64_t token_capacity, int32_t* n_labels) {
-  LAS_REQUIRE(record && n_frames && n_labels, "las_tfrecord_parse: null argument");
-  const int64_t off = 0;
-  int64_t rows[2];
-  const int rc = las_tfrecord_parse_batch(record, &off, &length, 1, num_channels, frames, frame_rows_capacity, rows, label_bytes,
-                                          label_bytes_capacity, token_offsets, token_capacity, n_labels);
-  if (rc == LAS_OK) *n_frames = (int32_t)rows[1];
-  return rc;
 }
 
 extern "C" int las_normalize_pad_bf16(const float* frames, const int64_t* frame_row_offsets, const double* mean, const double* stdv,

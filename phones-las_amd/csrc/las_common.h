@@ -29,23 +29,6 @@ int las_check_hip(hipError_t e, const char* what);
 // las_set_knob (the C-ABI's test hook) overrides a value afterwards -- the tests switch slice heights and member counts that way.
 int las_knob(const char* name, int default_value);
 
-// Follower products (round 5: lstm.hip publishes, gemm.hip consumes).  A chain publishes its progress in blocks of this many steps:
-#define LAS_FOLLOW_STEPS 64
-// 32-bit words shared by a chain launch and the follower product beside it, zero before both:
-//   [0, 8) per-XCD queue heads of the follower, [8] queue head of its clean-up pass, [16, 16 + ngroups) the chain groups' placement,
-//   [p0, p0 + ngroups) their progress counters, [z0, z0 + ngroups) their zero-fill counters, [s0, s0 + ntiles) the state of every
-//   output tile (bit d: direction d's half claimed, bit 8 + d: done).
-struct las_follow_layout { int p0, z0, s0, words; };
-static inline las_follow_layout las_follow_layout_of(int ngroups, int ntiles) {
-  const int g16 = (ngroups + 15) & ~15;
-  las_follow_layout L;
-  L.p0 = 16 + g16;
-  L.z0 = L.p0 + g16;
-  L.s0 = L.z0 + g16;
-  L.words = L.s0 + ntiles;
-  return L;
-}
-
 #define LAS_REQUIRE(cond, ...)            \
   do {                                    \
     if (!(cond)) {                        \

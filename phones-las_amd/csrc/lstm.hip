@@ -170,20 +170,6 @@ __global__ void pack_input_kernel(const float* kx, int D, int H, int chunks, uns
 // (loaded one step ahead; the companion keeps the rows L2-resident).  These products do not depend on h_{t-1}: they are issued
 // at the top of the step and run while the peers' granules are on their way, so the bottom listener layer needs no x K_x GEMM,
 // no 419 MB fp32 round trip of its result, and the chain no xproj load.  `xproj` is then only the saved-gates OUTPUT.
-// Progress of a chain for a FOLLOWER product (round 5; gemm.hip, las_gemm_nt_follow): a product over this launch's OUTPUT rows
-// (y: the next layer's input projection; dz: the gradient w.r.t. the layer's input) runs BESIDE the launch on the CUs the chain
-// leaves idle and consumes the rows behind the chain, direction by direction.  `words` is the buffer shared with it (layout:
-// las_follow_layout in las_common.h; zero before both launches).  The chain writes
-//   words[16 + group]   at its start: XCC id + 1 of the group (0xff: members spread over XCDs) | waves per group << 8 |
-//                       companions per group << 16 -- the follower's workgroups on that XCD read the rows through the L2 the
-//                       chain's plain stores land in;
-//   words[z0 + group]   += 1 per companion workgroup once the rows beyond every utterance's length are zero-filled;
-//   words[p0 + group]   += 1 per wave for every block of LAS_FOLLOW_STEPS steps whose stores have been acknowledged by the L2
-//                       (vmcnt(0) once per block, at a point of the step where the wave's memory queue is all but empty), and at
-//                       the end what is missing to ceil(T / LAS_FOLLOW_STEPS): waves * n says "all rows of the first n blocks
-//                       of steps are there".
-struct FollowPub { unsigned* words; int p0, z0; };
-
 struct FusedInput {
   const unsigned short* x;       // [B, T, ldx] bf16 (per direction: + dir * xdir elements)
   int64_t ldx, xdir;
@@ -198,19 +184,7 @@ struct FusedInput {
   unsigned* ready;
   int nsb, flags;
   unsigned want;
-  FollowPub pub;                 // a follower product consumes y behind this launch (words == nullptr: none)
 };
-
-__device__ __forceinline__ void follow_publish(const FollowPub& pub, int group, unsigned n) {
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's stores of every finished step are in the L2
-  if ((threadIdx.x & 63) == 0) atomicAdd(pub.words + pub.p0 + group, n);
-}
-__device__ __forceinline__ void follow_placement(const FollowPub& pub, int group, bool one_xcd, int waves, int companions) {
-  unsigned xcc;
-  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-  __hip_atomic_store(pub.words + 16 + group, (one_xcd ? (xcc & 7u) + 1u : 0xffu) | ((unsigned)waves << 8) | ((unsigned)companions << 16),
-                     __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
 
 // Wait until the streamed rows of step block sb of this group are there (wave-uniform; bounded).  Returns false on timeout.
 __device__ __forceinline__ bool stream_wait(const FusedInput& fi, int group, int sb) {
@@ -306,11 +280,6 @@ __device__ __forceinline__ void lstm_fwd_body(float* __restrict__ xproj, const u
         const int t = e / LPR, c = cm * LPR + e % LPR;
         *reinterpret_cast<uint4*>(y + ((int64_t)bb * T + t) * yrow + dir * H + c * 8) = make_uint4(0, 0, 0, 0);
       }
-    }
-    if (fi.pub.words != nullptr) {                                // a follower product reads those rows: they are in the L2 now
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();
-      if (tid == 0) atomicAdd(fi.pub.words + fi.pub.z0 + group, 1u);
     }
     const u64* tag0 = ex_group;                                   // member 0 publishes here every step
     int seen = -1;
@@ -425,9 +394,6 @@ __device__ __forceinline__ void lstm_fwd_body(float* __restrict__ xproj, const u
       __hip_atomic_store(fi.ready + 16 + group, (local || G == 1) ? (xcc & 7u) + 1u : 0x100u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
-
-  if (fi.pub.words != nullptr && member == 0 && tid == 0) follow_placement(fi.pub, group, local || G == 1, 4 * G, companions ? CPG : 0);
-  int pub_blocks = 0;                                         // blocks of LAS_FOLLOW_STEPS steps this wave has published
 
   const int unit0 = member * HS + wblk * 16 + l15;            // + ub*16
 
@@ -630,10 +596,6 @@ __device__ __forceinline__ void lstm_fwd_body(float* __restrict__ xproj, const u
     }
     LSTM_STAMP(0, s, 1);
     flush_pending();                          // the previous step's stores, now that this step's polls are served
-    if (fi.pub.words != nullptr && s > 0 && (s & (LAS_FOLLOW_STEPS - 1)) == 0) {      // (wave-uniform)
-      follow_publish(fi.pub, group, 1u);      // steps < s: what is still in flight here is this step's own operand load
-      ++pub_blocks;
-    }
     lds_barrier();
     LSTM_STAMP(0, s, 2);
     if (fail_flag) return false;
@@ -742,7 +704,6 @@ __device__ __forceinline__ void lstm_fwd_body(float* __restrict__ xproj, const u
   for (; s < smin && ok; ++s) ok = step(s, std::true_type{});
   for (; s < smax && ok; ++s) ok = step(s, std::false_type{});
   flush_pending();
-  if (fi.pub.words != nullptr) follow_publish(fi.pub, group, (unsigned)((T + LAS_FOLLOW_STEPS - 1) / LAS_FOLLOW_STEPS - pub_blocks));
 
   if (tid == 0) __hip_atomic_store(done_word, ((u64)(base + 1u) << 32) | 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // releases the companion
   if (!ok) {
@@ -783,14 +744,13 @@ __global__ __launch_bounds__(256) void lstm_fwd_kernel(float* __restrict__ xproj
 // is 4 x (G-1) granules each way, against 8 x 4 x (G-1) for an all-gather of dz_t.
 // kh is K_h [H, 4H] in bf16 with GATE-INTERLEAVED columns (u*4+g): a member's K range is contiguous.
 // ------------------------------------------------------------------------------------------------
-// `pub`: a follower product (dX = dz K_x^T, gemm.hip las_gemm_nt_follow) consumes dz behind this launch, see FollowPub.
 template <int H, int ROWS, int G>     // ROWS: utterances per slice, G: members, as in lstm_fwd_kernel
 __device__ __forceinline__ void lstm_bwd_body(const float* __restrict__ gates, const float* __restrict__ cbuf,
                                               const float* __restrict__ dy, const float* __restrict__ dc_last,
                                               const float* __restrict__ dh_last, const unsigned short* __restrict__ kh,
                                               const int32_t* __restrict__ length, unsigned short* __restrict__ dz,
                                               u64* __restrict__ exch, unsigned* __restrict__ status,
-                                              int B, int T, int ndir, int ngroups, const unsigned base, const FollowPub pub, const int companions) {
+                                              int B, int T, int ndir, int ngroups, const unsigned base) {
   constexpr int HS = H / G;
   constexpr int NUB = HS / 16;                    // 16-unit blocks of a member
   constexpr bool SPLIT = NUB < 4;                 // H = 512: two waves share a unit block, two rows of every quad each
@@ -861,11 +821,6 @@ __device__ __forceinline__ void lstm_bwd_body(const float* __restrict__ gates, c
         const int t = e / LPR, c = cm * LPR + e % LPR;
         *reinterpret_cast<uint4*>(dz + ((int64_t)bb * T + t) * grow + dir * 4 * H + c * 8) = make_uint4(0, 0, 0, 0);
       }
-    }
-    if (pub.words != nullptr) {                                   // a follower product reads those rows: they are in the L2 now
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();
-      if (tid == 0) atomicAdd(pub.words + pub.z0 + group, 1u);
     }
     const u64* tag0 = ex_group + (G > 1 ? (int64_t)(1 * G + 0) * PAIR : 0);   // (destination 1, sender 0): member 0 writes it every step (G = 1: a progress granule)
     int seen = -1;
@@ -949,8 +904,6 @@ __device__ __forceinline__ void lstm_bwd_body(const float* __restrict__ gates, c
   if (tid == 0) fail_flag = 0;
   __syncthreads();
   const bool local = xcd_colocated<G>(exch + 2 * par_stride + (int64_t)group * G, member, &colo_flag, status, base);
-  if (pub.words != nullptr && member == 0 && tid == 0) follow_placement(pub, group, local || G == 1, 4 * G, companions ? CPG : 0);
-  int pub_blocks = 0;
 
   // loop-invariant pieces of the exchange (byte offsets inside the group's parity slot)
   unsigned poll_off[PER], send_off[NT > OWN ? NT - OWN : 1];
@@ -1103,10 +1056,6 @@ __device__ __forceinline__ void lstm_bwd_body(const float* __restrict__ gates, c
     }
 
     LSTM_STAMP(2048, smax - 1 - s, 1);
-    if (pub.words != nullptr && epoch > 0 && (epoch & (LAS_FOLLOW_STEPS - 1)) == 0) {     // (wave-uniform)
-      follow_publish(pub, group, 1u);          // the dz rows of the first `epoch` iterations; in flight here: the last one's stores
-      ++pub_blocks;
-    }
     // next step's operands first: in flight during the gate math, the product and the exchange, and ahead of this
     // step's dz stores in the in-order vector-memory queue
     unsigned zoff[RPL];
@@ -1215,7 +1164,6 @@ __device__ __forceinline__ void lstm_bwd_body(const float* __restrict__ gates, c
     for (; s >= smin && go; --s) go = iter(s, std::false_type{});
     for (; s >= 0 && go; --s) go = iter(s, std::true_type{});
   }
-  if (pub.words != nullptr) follow_publish(pub, group, (unsigned)((T + LAS_FOLLOW_STEPS - 1) / LAS_FOLLOW_STEPS - pub_blocks));
   if (tid == 0) __hip_atomic_store(done_word, ((u64)(base + 1u) << 32) | 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   if (!ok && tid == 0) atomicOr(status, 2u);
 }
@@ -1226,9 +1174,9 @@ __global__ __launch_bounds__(256) void lstm_bwd_kernel(const float* __restrict__
                                                        const float* __restrict__ dh_last, const unsigned short* __restrict__ kh,
                                                        const int32_t* __restrict__ length, unsigned short* __restrict__ dz,
                                                        u64* __restrict__ exch, unsigned* __restrict__ status,
-                                                       int B, int T, int ndir, int ngroups, long long exch_words, const FollowPub pub, int companions) {
+                                                       int B, int T, int ndir, int ngroups, long long exch_words) {
   const unsigned base = launch_base(status);
-  lstm_bwd_body<H, ROWS, G>(gates, cbuf, dy, dc_last, dh_last, kh, length, dz, exch, status, B, T, ndir, ngroups, base, pub, companions);
+  lstm_bwd_body<H, ROWS, G>(gates, cbuf, dy, dc_last, dh_last, kh, length, dz, exch, status, B, T, ndir, ngroups, base);
   launch_arrive(status, base, T, exch, exch_words);
 }
 
@@ -1361,8 +1309,7 @@ int launch_fwd(float* xproj, const las_bf16* wp, const int32_t* length, las_bf16
 
 template <int H, int ROWS, int G>
 int launch_bwd_as(const float* gates, const float* cbuf, const float* dy, const float* dc_last, const float* dh_last,
-                  const las_bf16* kh, const int32_t* length, las_bf16* dz, void* ws, int B, int T, int ndir, hipStream_t st,
-                  const FollowPub pub) {
+                  const las_bf16* kh, const int32_t* length, las_bf16* dz, void* ws, int B, int T, int ndir, hipStream_t st) {
   const CoopGeom g = geom(B, H, ndir, true, ROWS, G);
   unsigned* status = reinterpret_cast<unsigned*>(ws);
   u64* exch = reinterpret_cast<u64*>(reinterpret_cast<char*>(ws) + 64);
@@ -1382,17 +1329,16 @@ int launch_bwd_as(const float* gates, const float* cbuf, const float* dy, const 
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&lstm_bwd_kernel<H, ROWS, G>), hipFuncAttributeMaxDynamicSharedMemorySize, hog_kb * 1024);
   }
   hipLaunchKernelGGL((lstm_bwd_kernel<H, ROWS, G>), dim3(pf ? g.blocks + g.companions : g.blocks), dim3(256), (size_t)(hog_kb > 0 ? hog_kb : 0) * 1024, st,
-                     gates, cbuf, dy, dc_last, dh_last, kh, length, dz, exch, status, B, T, ndir, g.ngroups, exch_words(B, H, ndir), pub, pf);
+                     gates, cbuf, dy, dc_last, dh_last, kh, length, dz, exch, status, B, T, ndir, g.ngroups, exch_words(B, H, ndir));
   LAS_LAUNCH_CHECK("lstm bwd launch");
   return LAS_OK;
 }
 
 template <int H>
 int launch_bwd(const float* gates, const float* cbuf, const float* dy, const float* dc_last, const float* dh_last,
-               const las_bf16* kh, const int32_t* length, las_bf16* dz, void* ws, int B, int T, int ndir, hipStream_t st,
-               const FollowPub pub) {
+               const las_bf16* kh, const int32_t* length, las_bf16* dz, void* ws, int B, int T, int ndir, hipStream_t st) {
   const int rows = slice_rows(B, H, ndir, true);
-#define LAS_BWD(R, GG) return launch_bwd_as<H, R, GG>(gates, cbuf, dy, dc_last, dh_last, kh, length, dz, ws, B, T, ndir, st, pub)
+#define LAS_BWD(R, GG) return launch_bwd_as<H, R, GG>(gates, cbuf, dy, dc_last, dh_last, kh, length, dz, ws, B, T, ndir, st)
   if constexpr (H == 512) {
     if (members(H) == 8) {
       if (rows == 4) LAS_BWD(4, 8);
@@ -1410,14 +1356,6 @@ int launch_bwd(const float* gates, const float* cbuf, const float* dy, const flo
 }
 
 bool supported_units(int H) { return H == 64 || H == 128 || H == 256 || H == 512; }
-
-// the follower's shared words as a chain launch sees them (las_follow_layout_of: the same arithmetic as in gemm.hip)
-FollowPub follow_pub(uint32_t* words, int B, int H, int ndir, bool bwd) {
-  if (words == nullptr) return FollowPub{nullptr, 0, 0};
-  const int rows = slice_rows(B, H, ndir, bwd);
-  const las_follow_layout L = las_follow_layout_of(((B + rows - 1) / rows) * ndir, 0);
-  return FollowPub{words, L.p0, L.z0};
-}
 
 }  // namespace
 
@@ -1509,14 +1447,13 @@ extern "C" int las_lstm_recurrent_fwd_ex(const las_lstm_fwd* p, void* stream) {
     fi.flags = 16 + ((((p->B + rows - 1) / rows) * p->ndir + 15) & ~15);
     fi.want = (unsigned)p->ready_count;
   }
-  fi.pub = follow_pub(p->follow, p->B, p->H, p->ndir, false);
   return recurrent_fwd(p->xproj, p->wpacked, p->length, p->y, p->cbuf, p->c_last, p->h_last, p->workspace, p->B, p->T, p->H, p->ndir, stream, fi);
 }
 
 namespace {
 int recurrent_bwd(const float* gates, const float* cbuf, const float* dy, const float* dc_last, const float* dh_last,
                   const las_bf16* kh_bf16, const int32_t* length, las_bf16* dz, void* workspace, int B, int T, int H, int ndir,
-                  void* stream, const FollowPub pub) {
+                  void* stream) {
   LAS_REQUIRE(B > 0 && T > 0 && (ndir == 1 || ndir == 2), "las_lstm_recurrent_bwd: bad shape");
   LAS_REQUIRE(supported_units(H), "las_lstm_recurrent_bwd: num_units %d not in {64,128,256,512}", H);
   LAS_REQUIRE(workspace != nullptr && ((uintptr_t)workspace % 16 == 0), "las_lstm_recurrent_bwd: workspace missing or misaligned");
@@ -1528,19 +1465,18 @@ int recurrent_bwd(const float* gates, const float* cbuf, const float* dy, const 
   }
   // (no memset of the exchange buffer: launch epochs, see las_lstm_recurrent_fwd)
   switch (H) {
-    case 64: return launch_bwd<64>(gates, cbuf, dy, dc_last, dh_last, kh_bf16, length, dz, workspace, B, T, ndir, st, pub);
-    case 128: return launch_bwd<128>(gates, cbuf, dy, dc_last, dh_last, kh_bf16, length, dz, workspace, B, T, ndir, st, pub);
-    case 512: return launch_bwd<512>(gates, cbuf, dy, dc_last, dh_last, kh_bf16, length, dz, workspace, B, T, ndir, st, pub);
-    default: return launch_bwd<256>(gates, cbuf, dy, dc_last, dh_last, kh_bf16, length, dz, workspace, B, T, ndir, st, pub);
+    case 64: return launch_bwd<64>(gates, cbuf, dy, dc_last, dh_last, kh_bf16, length, dz, workspace, B, T, ndir, st);
+    case 128: return launch_bwd<128>(gates, cbuf, dy, dc_last, dh_last, kh_bf16, length, dz, workspace, B, T, ndir, st);
+    case 512: return launch_bwd<512>(gates, cbuf, dy, dc_last, dh_last, kh_bf16, length, dz, workspace, B, T, ndir, st);
+    default: return launch_bwd<256>(gates, cbuf, dy, dc_last, dh_last, kh_bf16, length, dz, workspace, B, T, ndir, st);
   }
 }
 }  // namespace
 
 extern "C" int las_lstm_recurrent_bwd(const float* gates, const float* cbuf, const float* dy, const float* dc_last,
                                       const float* dh_last, const las_bf16* kh_bf16, const int32_t* length,
-                                      las_bf16* dz, void* workspace, int B, int T, int H, int ndir, uint32_t* follow, void* stream) {
-  return recurrent_bwd(gates, cbuf, dy, dc_last, dh_last, kh_bf16, length, dz, workspace, B, T, H, ndir, stream,
-                       follow_pub(follow, B, H, ndir, true));
+                                      las_bf16* dz, void* workspace, int B, int T, int H, int ndir, void* stream) {
+  return recurrent_bwd(gates, cbuf, dy, dc_last, dh_last, kh_bf16, length, dz, workspace, B, T, H, ndir, stream);
 }
 
 #ifdef LAS_STAMPS

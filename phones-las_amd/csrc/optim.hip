@@ -282,12 +282,6 @@ extern "C" int las_status_collect(const uint32_t* const* status_words, int n, fl
   return LAS_OK;
 }
 
-extern "C" int las_counter_add(int32_t* counter, int32_t delta, void* stream) {
-  hipLaunchKernelGGL(counter_add_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, counter, delta, (const float*)nullptr);
-  LAS_LAUNCH_CHECK("counter launch");
-  return LAS_OK;
-}
-
 extern "C" int las_counter_add_unless(int32_t* counter, int32_t delta, const float* skip_flag, void* stream) {
   LAS_REQUIRE(counter != nullptr, "las_counter_add_unless: null counter");
   hipLaunchKernelGGL(counter_add_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, counter, delta, skip_flag);

@@ -37,19 +37,14 @@ _SIGS = {
     'las_colsum_bf16_ws': ([_vp, _i64, _i32, _i32, _vp, _i32, _vp, C.c_size_t, _vp], C.c_int),
     'las_lstm_pack_recurrent': ([_vp, _i32, _vp, _vp], C.c_int),
     'las_lstm_recurrent_fwd': ([_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp], C.c_int),
-    'las_lstm_recurrent_bwd': ([_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp], C.c_int),
+    'las_lstm_recurrent_bwd': ([_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp], C.c_int),
     'las_set_knob': ([C.c_char_p, _i32], C.c_int),
-    'las_stream_create_masked': ([C.c_uint32, _vp], C.c_int),
-    'las_xcd_histogram': ([_vp, _i32, _i32, _vp], C.c_int),
-    'las_gemm_nt_follow_supported': ([_i32, _i32, _i32, _i32, _i32], C.c_int),
-    'las_gemm_nt_follow_words': ([_i32, _i32, _i32, _i32, _i32], C.c_size_t),
-    'las_gemm_nt_follow': ([_vp, _i32, _vp], C.c_int),
+    'las_xcd_histogram': ([_vp, _i32, _i32, _i32, _vp], C.c_int),
     'las_lstm_fused_input_chunks': ([_i32, _i32], C.c_int),
     'las_lstm_pack_input': ([_vp, _i32, _i32, _i32, _vp, _vp], C.c_int),
     'las_lstm_recurrent_fwd_ex': ([_vp, _vp], C.c_int),
     'las_gemm_nt_stream_supported': ([_i32, _i32, _i32], C.c_int),
     'las_gemm_nt_stream_flags': ([_i32, _i32, _i32, _i32], C.c_size_t),
-    'las_gemm_nt_stream': ([_vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp], C.c_int),
     'las_gemm_nt_stream_dirs': ([_vp, _i64, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp], C.c_int),
     'las_lstm_workspace_bytes': ([_i32, _i32, _i32], C.c_size_t),
     'las_lstm_slice_rows': ([_i32, _i32, _i32], C.c_int),
@@ -77,7 +72,6 @@ _SIGS = {
     'las_grad_l2_norms_acc': ([_vp, _vp, _vp, _i32, _i64, _f32, _vp, _vp, _vp, C.c_size_t, _vp], C.c_int),
     'las_train_op_begin': ([_vp, _i32, _vp, _vp, _i32, _vp, _i32, _vp], C.c_int),
     'las_total_loss': ([_vp, _vp, _i32, _f32, _vp, _vp], C.c_int),
-    'las_counter_add': ([_vp, _i32, _vp], C.c_int),
     'las_counter_add_unless': ([_vp, _i32, _vp, _vp], C.c_int),
     'las_sumsq': ([_vp, _i64, _vp, _vp], C.c_int),
     'las_crc32c': ([C.c_char_p, C.c_size_t], C.c_uint32),
@@ -89,7 +83,6 @@ _SIGS = {
     'las_tfrecord_index': ([_vp, C.c_size_t, _i32, _i64, _vp, _vp, _vp, _vp, _vp], C.c_int64),
     'las_tfrecord_parse_batch': ([_vp, _vp, _vp, _i32, _i32, _vp, _i64, _vp, _vp, _i64, _vp, _i64, _vp], C.c_int),
     'las_vocab_lookup': ([_vp, _vp, _i64, _vp, _vp, _i64, _i32, _vp], C.c_int),
-    'las_tfrecord_parse': ([_vp, _i64, _i32, _vp, _i64, _vp, _vp, _i64, _vp, _i64, _vp], C.c_int),
     'las_normalize_pad_bf16': ([_vp, _vp, _vp, _vp, _i32, _vp, _i32, _i32, _i32, _vp, _vp], C.c_int),
     'las_dropout_bf16': ([_vp, _i64, _vp, _i64, _i32, _i32, _f32, C.c_uint32, C.c_uint32, _vp], C.c_int),
     'las_dropout_bf16_pair': ([_vp, _i64, _vp, _vp, _i64, _i32, _i32, _f32, C.c_uint32, C.c_uint32, C.c_uint32, _vp], C.c_int),
@@ -138,15 +131,7 @@ class LstmFwd(C.Structure):
     _fields_ = [('xproj', _vp), ('wpacked', _vp), ('length', _vp), ('y', _vp), ('cbuf', _vp), ('c_last', _vp), ('h_last', _vp),
                 ('workspace', _vp), ('B', _i32), ('T', _i32), ('H', _i32), ('ndir', _i32),
                 ('x', _vp), ('ldx', _i64), ('x_dir_stride', _i64), ('Dp', _i32), ('reserved0', _i32), ('kx_packed', _vp), ('bias', _vp),
-                ('ready', _vp), ('ready_count', _i32), ('reserved1', _i32), ('follow', _vp)]
-
-
-class Follow(C.Structure):
-    """struct las_follow (include/las_hip.h)."""
-    _fields_ = [('A', _vp), ('Bw', _vp), ('C', _vp), ('bias', _vp), ('lda', _i64), ('ldb', _i64), ('ldc', _i64),
-                ('a_dir', _i32), ('a_seg', _i32), ('b_dir', _i32), ('b_seg', _i32), ('nseg', _i32), ('seg_len', _i32),
-                ('N', _i32), ('B', _i32), ('T_out', _i32), ('T_chain', _i32), ('stack', _i32), ('rows_per_slice', _i32), ('ndir', _i32),
-                ('kind', _i32), ('length', _vp), ('words', _vp), ('workgroups', _i32), ('reserved', _i32)]
+                ('ready', _vp), ('ready_count', _i32), ('reserved1', _i32)]
 
 
 class DecStep(C.Structure):

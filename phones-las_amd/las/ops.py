@@ -300,101 +300,14 @@ def _stream_setup(a, lda, a_dir_stride, weights, xproj, sequence_length, B, T, H
     return (ready, 4 * H // 128, launch_product)
 
 
-# LAS_FOLLOW=0: no follower products (round 5) -- the next layer's input projection / the gradient w.r.t. a layer's input are
-# formed behind the recurrence again (or streamed beside the consumer, STREAM_X) instead of behind the chains that produce
-# their operands.  LAS_FOLLOW_WGS: persistent workgroups of a follower (the recurrence keeps a CU per workgroup of its own).
-FOLLOW = os.environ.get('LAS_FOLLOW', '0') != '0'
-FOLLOW_BWD = os.environ.get('LAS_FOLLOW_BWD', '1') != '0'
-FOLLOW_WGS = int(os.environ.get('LAS_FOLLOW_WGS', '96'))
-FOLLOW_MIN_ROWS = 4096
-
-
-def _follow_words(owner, key, n, dev):
-    """The words a chain launch and its follower share (cached per layer and shape; zeroed before every use)."""
-    cache = owner.__dict__.setdefault('_follow', {})
-    words = cache.get(key)
-    if words is None or words.numel() < n:
-        if torch.cuda.is_current_stream_capturing():
-            raise hip.LasError('follower product: new shape during graph capture (run the step once eagerly first)')
-        words = cache[key] = torch.zeros(n, dtype=torch.int32, device=dev)
-    return words
-
-
-def _follow_plan(B, T_out, N, seg_len, H, nd, bwd):
-    """(rows per slice, persistent workgroups) of a follower product beside a recurrent launch of (B, H, nd), or None."""
-    lib = hip.lib()
-    if not FOLLOW or (bwd and not FOLLOW_BWD) or B * T_out < FOLLOW_MIN_ROWS:
-        return None
-    rows = lib.las_lstm_slice_rows(B, H, nd)
-    if lib.las_gemm_nt_follow_supported(B, N, seg_len, rows, nd) != 1:
-        return None
-    chain = lib.las_lstm_fwd_workgroups(B, H, nd)
-    wgs = min(FOLLOW_WGS, 256 - chain)
-    if chain <= 0 or (wgs < 16 and FOLLOW_WGS > 0):
-        return None
-    _product_stream()                 # (created -- and probed against the current stream -- before the first launch that needs it)
-    if not STREAM_X:                  # no stream of this process runs beside the current one
-        return None
-    return rows, wgs
-
-
-class _Follower:
-    """One follower product: zero the shared words, hand them to the recurrent launch (`.words`), then launch(): the persistent
-    follower on the product stream (held back a few microseconds so that the chain's workgroups are resident first), the
-    join, and the clean-up pass on the launching stream behind the recurrence."""
-
-    def __init__(self, owner, key, desc, plan, keep):
-        self.rows, self.wgs = plan
-        self.desc = desc
-        n = hip.lib().las_gemm_nt_follow_words(desc['B'], desc['T_out'], desc['N'], self.rows, desc['ndir'])
-        self.words = _follow_words(owner, key, n, desc['C'].device)
-        hip.fill_many(zero=[self.words])
-        self.cleared = torch.cuda.Event()
-        self.cleared.record()
-        self.keep = keep
-
-    def _struct(self, workgroups):
-        d = self.desc
-        f = hip.Follow()
-        f.A, f.Bw, f.C, f.bias = hip.addr(d['A']), hip.addr(d['Bw']), hip.addr(d['C']), hip.addr(d.get('bias'))
-        f.lda, f.ldb, f.ldc = d['lda'], d['ldb'], d['ldc']
-        f.a_dir, f.a_seg, f.b_dir, f.b_seg, f.nseg, f.seg_len = d['a_dir'], d['a_seg'], d['b_dir'], d['b_seg'], d['nseg'], d['seg_len']
-        f.N, f.B, f.T_out, f.T_chain, f.stack, f.rows_per_slice, f.ndir, f.kind = (d['N'], d['B'], d['T_out'], d['T_out'] * d['stack'],
-                                                                                   d['stack'], self.rows, d['ndir'], d['kind'])
-        f.length, f.words, f.workgroups = hip.addr(d['length']), hip.addr(self.words), workgroups
-        return f
-
-    def launch(self):
-        import ctypes
-        lib, d = hip.lib(), self.desc
-        flops = 2.0 * d['B'] * d['T_out'] * d['N'] * d['nseg'] * d['seg_len'] * d['ndir']
-        side = _product_stream()
-        side.wait_event(self.cleared)
-        if self.wgs > 0:              # (FOLLOW_WGS = 0: the clean-up pass does all of the work -- tests)
-            with torch.cuda.stream(side):
-                hip.check(lib.las_stream_delay(Overlap.BESIDE_US, hip.stream()))
-                tok = hip.prof_begin('gemm_nt_follow', flops)
-                hip.check(lib.las_gemm_nt_follow(ctypes.byref(self._struct(self.wgs)), 0, hip.stream()))
-                hip.prof_end(tok)
-            torch.cuda.current_stream().wait_stream(side)
-        tok = hip.prof_begin('gemm_nt_follow_cleanup', 0.0)
-        hip.check(lib.las_gemm_nt_follow(ctypes.byref(self._struct(0)), 1, hip.stream()))
-        hip.prof_end(tok)
-
-
 def bilstm(inputs, sequence_length, num_units, dropout, mode, unidirectional=False, *, variables=None,
-           scope='', weights=None, tape=None, in_features=None, rng=None, split_inputs=False, after_projection=None,
-           xproj_ready=None, follow_next=None):
+           scope='', weights=None, tape=None, in_features=None, rng=None, split_inputs=False, after_projection=None):
     """las/ops.py:23-46.  inputs [B,T,Dp] bf16; sequence_length int32 [B] (CUDA).
     Returns (outputs, state) with the reference's structure: bidirectional -> ((fw, bw), (state_fw,
     state_bw)); unidirectional -> (fw, state).  fw/bw are views of one [B,T,ndir*H] buffer
     (use ``concat_outputs`` for the tf.concat of las/ops.py:81).
     split_inputs: direction i reads only columns [i*D, (i+1)*D) of ``inputs`` (the per-direction MultiRNNCell
-    stacks of the non-pyramidal listener, las/model.py:111-133).
-    xproj_ready: this layer's x K_x + b [B,T,nd*4H] fp32, already formed (by the follower of the layer below).
-    follow_next = (weights of the layer above, stack): that layer's input projection over this layer's outputs (viewed
-    [B, T/stack, stack*nd*H]) is formed by a FOLLOWER product behind this layer's chains; the return value gets a third
-    element: the projection (or None when the shapes do not allow it)."""
+    stacks of the non-pyramidal listener, las/model.py:111-133)."""
     cell = lstm_cell(num_units, dropout, mode)
     keep = cell.input_keep_prob
     B, T, Dfull = inputs.shape
@@ -406,16 +319,14 @@ def bilstm(inputs, sequence_length, num_units, dropout, mode, unidirectional=Fal
         weights = LayerWeights(variables, scope, D, Dp, H, unidirectional)
     nd = len(weights.dirs)
     dev = inputs.device
-    xproj = xproj_ready if xproj_ready is not None else torch.empty(B, T, nd * 4 * H, dtype=torch.float32, device=dev)
+    xproj = torch.empty(B, T, nd * 4 * H, dtype=torch.float32, device=dev)
     dropped = None
     stream_ready = None
     # narrow inputs (the features): x_t K_x + b is formed inside the recurrent kernel -- no product, no fp32 round trip
-    fused = (weights.kx_chunks > 0 and not split_inputs and Dp == weights.Dp and xproj_ready is None and
+    fused = (weights.kx_chunks > 0 and not split_inputs and Dp == weights.Dp and
              (keep == 1.0 or nd == 1 or (nd == 2 and Dp % 8 == 0)))
     fused_x = None                    # (x, ldx, stride between the directions' copies)
-    if xproj_ready is not None:
-        assert keep == 1.0 and not split_inputs and tuple(xproj.shape) == (B, T, nd * 4 * H)
-    elif fused and keep == 1.0:
+    if fused and keep == 1.0:
         fused_x = (inputs, Dfull, 0)
     elif keep < 1.0 or split_inputs:
         # one A operand per direction: DropoutWrapper(input_keep_prob) draws independent masks for the fw and bw
@@ -462,20 +373,7 @@ def bilstm(inputs, sequence_length, num_units, dropout, mode, unidirectional=Fal
                         bias=weights.bias)
     if after_projection is not None:
         after_projection()          # (LasModel: side-stream work that should run beside this layer's recurrence starts here)
-    # the layer above's input projection behind THIS layer's chains (follower product)
-    follower, xproj_next = None, None
-    if follow_next is not None and nd == len(follow_next[0].dirs):
-        w2, stack = follow_next
-        H2, T2 = w2.H, T // stack
-        plan = _follow_plan(B, T2, nd * 4 * H2, H, H, nd, False) if (T % stack == 0 and w2.Dp == stack * nd * H) else None
-        if plan is not None:
-            xproj_next = torch.empty(B, T2, nd * 4 * H2, dtype=torch.float32, device=dev)
-            # A = y viewed [B, T/stack, stack * nd * H]: direction d's columns are [d * H + i * nd * H, + H), i < stack
-            follower = _Follower(weights, ('fwd', B, T, stack), dict(
-                A=torch.empty(B, T, nd * H, dtype=torch.bfloat16, device=dev), Bw=w2.kxT, C=xproj_next, bias=w2.bias, lda=stack * nd * H, ldb=w2.Dp, ldc=nd * 4 * H2,
-                a_dir=H, a_seg=nd * H, b_dir=H, b_seg=nd * H, nseg=stack, seg_len=H, N=nd * 4 * H2, B=B, T_out=T2, stack=stack,
-                ndir=nd, kind=0, length=sequence_length), plan, keep=[])
-    y = follower.desc['A'] if follower is not None else torch.empty(B, T, nd * H, dtype=torch.bfloat16, device=dev)
+    y = torch.empty(B, T, nd * H, dtype=torch.bfloat16, device=dev)
     cbuf = torch.empty(B, T, nd * H, dtype=torch.float32, device=dev)
     c_last = torch.empty(nd, B, H, dtype=torch.float32, device=dev)
     h_last = torch.empty(nd, B, H, dtype=torch.float32, device=dev)
@@ -491,8 +389,6 @@ def bilstm(inputs, sequence_length, num_units, dropout, mode, unidirectional=Fal
         flops += 2.0 * B * T * nd * Dp * 4 * H                            # x_t K_x of every step as well
     elif stream_ready is not None:
         a.ready, a.ready_count = hip.addr(stream_ready[0]), stream_ready[1]
-    if follower is not None:
-        a.follow = hip.addr(follower.words)
     tok = hip.prof_begin('lstm_fwd', flops)
     import ctypes
     hip.check(hip.lib().las_lstm_recurrent_fwd_ex(ctypes.byref(a), hip.stream()))
@@ -501,15 +397,14 @@ def bilstm(inputs, sequence_length, num_units, dropout, mode, unidirectional=Fal
         # (the product is done long before the recurrence is; everything later on this stream is ordered behind both,
         # so the operands need no record_stream)
         torch.cuda.current_stream().wait_stream(stream_ready[2]())
-    if follower is not None:
-        follower.launch()
     if tape is not None:
         tape.append(dict(kind='bilstm', inputs=inputs, length=sequence_length, gates=xproj, cbuf=cbuf, y=y,
                          weights=weights, B=B, T=T, H=H, D=D, Dp=Dp, nd=nd, dropped=dropped, keep=keep, rng=rng,
                          split=split_inputs, Dfull=Dfull))
     states = tuple(LSTMStateTuple(c_last[i], h_last[i]) for i in range(nd))
-    out = (y, states[0]) if unidirectional else ((y[..., :H], y[..., H:]), states)
-    return out + (xproj_next,) if follow_next is not None else out
+    if unidirectional:
+        return y, states[0]
+    return (y[..., :H], y[..., H:]), states
 
 
 def concat_outputs(outputs):
@@ -595,26 +490,15 @@ def bilstm_backward(rec, dy, d_state, grads, need_dx=True, overlap=None, defer_w
                             a_shift=(-1 if i == 0 else 1), period=T, split_k=split, c_perm_h=H)
                 hip.colsum_bf16(dzi, BT, 4 * H, gb, ldx=nd * 4 * H, perm_h=H)
 
-    # dX = dz K_x^T feeds the next (lower) layer's recurrence, which starts on the rows this layer's chains reach LAST: the product
-    # follows the chains (a follower product, one half per direction) instead of waiting for them
-    follower = None
-    if need_dx and dropped is None:
-        plan = _follow_plan(B, T, D, 4 * H, H, nd, True) if D % 8 == 0 else None
-        dx = torch.empty(B, T, D, dtype=torch.float32, device=dev)
-        if plan is not None:
-            follower = _Follower(w, ('bwd', B, T), dict(
-                A=dz, Bw=w.kx, C=dx, bias=None, lda=nd * 4 * H, ldb=nd * 4 * H, ldc=D, a_dir=4 * H, a_seg=0, b_dir=4 * H, b_seg=0,
-                nseg=1, seg_len=4 * H, N=D, B=B, T_out=T, stack=1, ndir=nd, kind=1, length=rec['length']), plan, keep=[])
     tok = hip.prof_begin('lstm_bwd', 2.0 * B * T * nd * H * 4 * H)       # dh_{t-1} = dz_t K_h^T of every step
     hip.check(hip.lib().las_lstm_recurrent_bwd(hip.p(rec['gates']), hip.p(rec['cbuf']), hip.p(dy), hip.p(dc_last),
                                                hip.p(dh_last), hip.p(w.kh), hip.p(rec['length']), hip.p(dz),
-                                               hip.p(lstm_workspace(B, H, nd)), B, T, H, nd,
-                                               hip.p(follower.words) if follower is not None else None, hip.stream()))
+                                               hip.p(lstm_workspace(B, H, nd)), B, T, H, nd, hip.stream()))
     hip.prof_end(tok)
-    if follower is not None:
-        follower.launch()
-    if need_dx and follower is None:
+    # critical path first: dX feeds the next (lower) layer's recurrence
+    if need_dx:
         if dropped is None:
+            dx = torch.empty(B, T, D, dtype=torch.float32, device=dev)
             hip.gemm_nt(dz, w.kx, dx, BT, D, nd * 4 * H, lda=nd * 4 * H, ldb=nd * 4 * H, ldc=D)
         else:
             # per direction dX_i = dZ_i K_x,i^T, then through that direction's input dropout (masks regenerated from
@@ -699,22 +583,13 @@ def pyramidal_bilstm(inputs, sequence_length, mode, hparams, *, variables=None, 
         levels = torch.empty(hparams.num_layers - 1, sequence_length.shape[0], dtype=torch.int32, device=sequence_length.device)
         hip.check(hip.lib().las_pyramid_lengths_multi(hip.p(sequence_length), hip.p(levels), sequence_length.shape[0],
                                                       hparams.num_layers - 1, hip.stream()))
-    xproj_ready = None
-    no_drop = not (mode == TRAIN and hparams.dropout > 0.0)
     for layer in range(hparams.num_layers):
         w = weights[layer] if weights is not None else None
         hooks = after_first_layer if (layer == 0 and after_first_layer is not None) else (None, None)
-        # the next layer's input projection as a follower product of this layer's recurrence (its input = this layer's outputs,
-        # stacked in pairs from layer 1 on: las/ops.py:75-87)
-        nxt = None
-        if weights is not None and layer + 1 < hparams.num_layers and no_drop:
-            nxt = (weights[layer + 1], 2 if layer >= 1 else 1)
-        res = bilstm(outputs, sequence_length, hparams.num_units, hparams.dropout, mode,
-                     hparams.unidirectional, variables=variables,
-                     scope='listener/bilstm_{}'.format(layer), weights=w, tape=tape, in_features=D,
-                     rng=(seed, 16 + 2 * layer), after_projection=hooks[0], xproj_ready=xproj_ready, follow_next=nxt)
-        out, state = res[0], res[1]
-        xproj_ready = res[2] if nxt is not None else None
+        out, state = bilstm(outputs, sequence_length, hparams.num_units, hparams.dropout, mode,
+                            hparams.unidirectional, variables=variables,
+                            scope='listener/bilstm_{}'.format(layer), weights=w, tape=tape, in_features=D,
+                            rng=(seed, 16 + 2 * layer), after_projection=hooks[0])
         outputs = concat_outputs(out)
         if hooks[1] is not None:
             hooks[1]()

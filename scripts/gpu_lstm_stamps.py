@@ -24,7 +24,7 @@ for it in range(2):
     hip.check(lib.las_lstm_recurrent_fwd(hip.p(xproj), hip.p(wp), hip.p(length), hip.p(y), hip.p(cbuf), hip.p(cl), hip.p(hl),
                                          hip.p(ws), B, T, H, nd, hip.stream()))
     hip.check(lib.las_lstm_recurrent_bwd(hip.p(xproj), hip.p(cbuf), hip.p(dy), None, None, hip.p(khb), hip.p(length), hip.p(dz),
-                                         hip.p(ws), B, T, H, nd, None, hip.stream()))
+                                         hip.p(ws), B, T, H, nd, hip.stream()))
 torch.cuda.synchronize()
 lib.las_debug_read_lstm_stamps.argtypes = [C.c_void_p, C.c_int]
 buf = np.zeros(2 * 256 * 8, np.uint64)

@@ -30,7 +30,7 @@ for T in (800, 400, 200):
                                              hip.p(ws), B, T, H, nd, hip.stream()))
         e[1].record()
         hip.check(lib.las_lstm_recurrent_bwd(hip.p(xproj), hip.p(cbuf), hip.p(dy), None, None, hip.p(khb), hip.p(length), hip.p(dz),
-                                             hip.p(ws), B, T, H, nd, None, hip.stream()))
+                                             hip.p(ws), B, T, H, nd, hip.stream()))
         e[2].record(); torch.cuda.synchronize()
         ops.check_lstm_status(B, H, nd)
         tf.append(e[0].elapsed_time(e[1])); tb.append(e[1].elapsed_time(e[2]))

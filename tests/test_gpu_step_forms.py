@@ -118,3 +118,97 @@ def test_bench_lists_no_form_without_a_test():
     import bench
     covered_here = {'plain_eager', 'plain_graph', 'overlap_eager', 'overlap_graph'}
     assert set(bench.COVERED_FORMS) == covered_here
+
+
+def test_cu_pressure_moderate_runs_heavy_times_out_withholds_the_update_and_the_probe_drops_the_form():
+    """VERDICT r4 #7b: what RCCL's kernels could do to the overlapped step at N > 1 -- hold CUs the persistent kernels need --
+    provoked on one GPU with a spinner kernel (one workgroup per CU it takes, 100 KiB of LDS each so that no chain workgroup fits
+    beside it) while an overlapped two-bucket step (1-rank RCCL group) is enqueued.
+    MODERATE pressure (176 of 256 CUs taken): the recurrent launches' 160 workgroups no longer fit at once, but their blocks are
+    laid out in chunks of whole groups and the dispatcher works in order, so the resident groups are complete and the others
+    take their turn: the step finishes, nothing times out, and the parameters are BIT-IDENTICAL to an undisturbed twin's
+    (results never depend on placement).
+    HEAVY pressure (248 CUs taken: fewer than one chunk's 32 workgroups fit): the members' bounded waits run out, the sticky
+    status word is set, Adam is WITHHELD (parameters and step counter unchanged), and bench.choose_step_form drops the form
+    and falls back to the plain eager one; the next step, on a free chip, trains normally."""
+    import socket
+    import time
+    import torch.distributed as dist
+    import bench
+    from phones_las_amd import hip, model_helper as mh
+    from phones_las_amd.las import ops
+    sock = socket.socket()
+    sock.bind(('127.0.0.1', 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    dist.init_process_group('nccl', init_method='tcp://127.0.0.1:%d' % port, rank=0, world_size=1, device_id=torch.device('cuda', 0))
+    try:
+        c = dict(F=40, L=2, H=256, Hd=256, V=64, att='luong', T=64, U=8, B=64)          # 32 chains x 4 workgroups + 32 companions
+        dev = torch.device('cuda', 0)
+
+        def make():
+            model = mh.LasModel(bench.build_params(c), process_group=dist.group.WORLD)
+            assert len(model.enable_exchange_overlap()) == 2
+            feats, labels = bench.synthetic_batch(c, 1234, dev)
+            feats['encoder_inputs'] = model.listener.pad_features(feats['encoder_inputs'])
+            forms = bench.StepForms(model, feats, labels, c['U'], multi=True)
+            forms.warm_up()
+            cands = forms.build(want_eager=True, want_graph=False, overlap_exchange=True, plain_too=True)
+            assert sorted(cands) == ['overlap_eager', 'plain_eager']
+            torch.cuda.synchronize()
+            assert not model.read_and_clear_status()
+            return model, cands
+        model, cands = make()
+        twin, twin_cands = make()
+        assert torch.equal(model.vars.flat, twin.vars.flat)
+        side = ops._concurrent_stream()
+        counts = torch.zeros(8, dtype=torch.int32, device=dev)
+        state = {'spinners': 0, 'us': 0}
+
+        def overlapped_under_pressure():
+            if state['spinners']:
+                with torch.cuda.stream(side):
+                    hip.check(hip.lib().las_xcd_histogram(hip.p(counts), state['spinners'], state['us'], 100 * 1024, hip.stream()))
+                time.sleep(0.05)                      # the spinners are resident before the step's first recurrence is enqueued
+            cands['overlap_eager'][0]()
+
+        # ---- moderate pressure ----
+        state.update(spinners=176, us=400000)
+        overlapped_under_pressure()
+        twin_cands['overlap_eager'][0]()
+        torch.cuda.synchronize()
+        assert int(counts.sum()) == 176
+        assert not model.read_and_clear_status() and not twin.read_and_clear_status()
+        assert torch.equal(model.vars.flat, twin.vars.flat) and torch.equal(model.vars.m, twin.vars.m)
+        time.sleep(0.5)
+        # ---- heavy pressure ----
+        before = model.vars.flat.clone()
+        step_before = int(model.step_dev.item())
+        state.update(spinners=248, us=2500000)
+        t0 = time.time()
+        overlapped_under_pressure()
+        torch.cuda.synchronize()
+        took = time.time() - t0
+        assert torch.equal(model.vars.flat, before), 'a step whose recurrences timed out must not touch the parameters'
+        assert int(model.step_dev.item()) == step_before
+        assert took < 120.0
+        time.sleep(3.0)
+        # the probe: the same candidate under pressure is dropped (status read AND cleared), the plain eager form is chosen
+        probe = lambda fn: (fn(), torch.cuda.synchronize(), 1.0)[2]
+        chosen, probed, dropped = bench.choose_step_form({'overlap_eager': (overlapped_under_pressure, False, True), 'plain_eager': cands['plain_eager']},
+                                                         probe, model.read_and_clear_status, lambda f: f)
+        assert chosen == 'plain_eager' and list(dropped) == ['overlap_eager'] and 'timeout' in dropped['overlap_eager']
+        torch.cuda.synchronize()
+        time.sleep(3.0)                               # (the last spinner launch has left the chip)
+        torch.cuda.synchronize()
+        model.read_and_clear_status()
+        # ---- recovery ----
+        state.update(spinners=0)
+        now = model.vars.flat.clone()
+        step_now = int(model.step_dev.item())
+        overlapped_under_pressure()
+        torch.cuda.synchronize()
+        assert not model.read_and_clear_status()
+        assert not torch.equal(model.vars.flat, now) and int(model.step_dev.item()) == step_now + 1
+    finally:
+        dist.destroy_process_group()
