@@ -398,9 +398,15 @@ class StepForms:
         self._overlapped(self.part_a1, self.part_a2, self.part_b_dp)()
 
     # -- construction --------------------------------------------------------------------------------------------------------
+    _warm_stream = {}       # device -> the side stream every StepForms of this process warms up on (streams share a handful of
+                            # hardware queues: a process should not create one per model)
+
     def _eagerly(self, fn, n=2):
         """n eager runs on a side stream (allocations, job tables, workspaces: what graph capture needs to find in place)."""
-        s = torch.cuda.Stream()
+        dev = torch.cuda.current_device()
+        s = StepForms._warm_stream.get(dev)
+        if s is None:
+            s = StepForms._warm_stream[dev] = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(s):
             for _ in range(n):        # (the second step starts from stale weight images, as every later one: its job tables)

@@ -4419,8 +4419,10 @@ extern "C" int las_decoder_persist_bwd(const las_dec_persist_bwd* p, void* strea
   } while (0)
   if (s->Hd == 512) {            // 5 column tiles per member, 6 of 16 K chunks per wave resident, 8 d(context) columns and 2 units per thread
     if (wq) {
-      if (npq == 16) LAS_BWD_LAUNCH(true, 16, 5, 5, 16, 8, 2);      // (one resident chunk fewer: the query-layer part's registers)
-      else LAS_BWD_LAUNCH(true, 0, 5, 5, 16, 8, 2);
+      // (two resident chunks fewer than without the query layer: that part's registers.  With 5 of them the kernel spilled 72-76
+      // bytes per lane; 4 = no scratch at the same time per step -- round 5, metric-L: 2.185 against 2.189 ms per launch)
+      if (npq == 16) LAS_BWD_LAUNCH(true, 16, 5, 4, 16, 8, 2);
+      else LAS_BWD_LAUNCH(true, 0, 5, 4, 16, 8, 2);
     } else {
       if (npq == 16) LAS_BWD_LAUNCH(false, 16, 5, 6, 16, 8, 2);
       else LAS_BWD_LAUNCH(false, 0, 5, 6, 16, 8, 2);

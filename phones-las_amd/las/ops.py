@@ -182,16 +182,39 @@ _ALIASED_STREAMS = []
 
 
 def _product_stream():
-    """The stream the streamed input products run on (one per device; its work is always joined by the launching stream).
-    The recurrence waits INSIDE its kernel for tiles this stream's kernel produces, so the two must never share a hardware queue
-    -- a process that has created many streams gets them mapped onto a handful of queues, and a product queued behind the
-    recurrence that waits for it is a (bounded) deadlock: every streamed launch timed out in a test session that had created
-    ~100 streams before this one.  (A high-priority stream has queues of its own but its workgroups are placed before the
-    recurrence's: measured, 41 ms per step.)  So the stream is PROBED when it is created (_concurrent_stream)."""
+    """The stream the streamed input products run on: one per (device, LAUNCHING stream); its work is always joined by the
+    launching stream.  The recurrence waits INSIDE its kernel for tiles this stream's kernel produces, so the two must never share
+    a hardware queue -- a process that has created many streams gets them mapped onto a handful of queues, and a product queued
+    behind the recurrence that waits for it is a (bounded) deadlock: every streamed launch timed out in a test session that had
+    created ~100 streams before this one.  (A high-priority stream has queues of its own but its workgroups are placed before the
+    recurrence's: measured, 41 ms per step.)  So the stream is PROBED when it is created (_concurrent_stream) -- against the
+    stream the recurrence will be launched on, which is why the cache is keyed by it (round 5: bench.StepForms of a second
+    model warmed up on another side stream than the first one's, the cached product stream shared THAT stream's queue, and its
+    streamed launches timed out: found by tests/test_gpu_step_forms.py).  During a graph capture nothing can be probed: the
+    capture takes the stream that an eager step on this device found (callers run the step eagerly first)."""
     dev = torch.cuda.current_device()
-    st = _PRODUCT_STREAMS.get(dev)
+    cur = torch.cuda.current_stream()
+    key = (dev, cur.cuda_stream)
+    st = _PRODUCT_STREAMS.get(key)
     if st is None:
-        st = _PRODUCT_STREAMS[dev] = _concurrent_stream()
+        if torch.cuda.is_current_stream_capturing():
+            st = next((v for (d, _), v in _PRODUCT_STREAMS.items() if d == dev), None)
+            if st is None:
+                st = torch.cuda.Stream()
+        else:
+            # a stream that already serves another launching stream of this device is tried first (fewer streams, fewer queues)
+            words = torch.zeros(2, dtype=torch.int32, device='cuda')
+            for (d, _), cand in list(_PRODUCT_STREAMS.items()):
+                if d != dev or cand.cuda_stream == cur.cuda_stream:
+                    continue
+                hip.check(hip.lib().las_stream_concurrency_probe(cur.cuda_stream, cand.cuda_stream, hip.p(words), 2000))
+                cur.wait_stream(cand)
+                if int(words[1].item()) == 1:
+                    st = cand
+                    break
+            if st is None:
+                st = _concurrent_stream()
+        _PRODUCT_STREAMS[key] = st
     return st
 
 
