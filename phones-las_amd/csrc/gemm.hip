@@ -524,17 +524,29 @@ __global__ __launch_bounds__(256) void gemm_tn_tr_kernel(GemmArgs g) {
 // from a 32-byte constant block instead.  Slices store their tiles into the caller's workspace (tn_reduce_kernel sums them).
 // ------------------------------------------------------------------------------------------------
 __device__ __attribute__((aligned(32))) unsigned short las_const_rows[16] = {0x3F80, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-constexpr int TR_STAGES = 4, TR_BK = 32, TR_STAGE_BYTES = TR_BK * 256 * 3;      // A 8 KiB + B 2 x 8 KiB
+constexpr int TR_BK = 32;
+// NBI = 128-column sub-images of B per stage: 2 = a 128 x 256 output tile, waves as 2 x 4 with 64 x 64 each (round 2); 4 = a
+// 128 x 512 tile, waves as 1 x 8 with 128 x 64 each (round 5): per MFMA a third fewer LDS-DMA pieces (5 per wave and stage for 16
+// MFMAs against 3 for 8) and a quarter fewer fragment reads -- the instruction stream of a wave, not the LDS or the matrix pipe,
+// is what the 64 x 64 form was paced by (an LDS-DMA piece costs its wave 60-180 issue cycles, MI355X_MICROARCH.md).
+template <int NBI> struct TnRing {
+  static constexpr int STAGES = NBI == 2 ? 4 : 3;
+  static constexpr int STAGE_BYTES = TR_BK * 256 * (1 + NBI);        // A 8 KiB + NBI x 8 KiB
+  static constexpr int BM = 128, BN = 128 * NBI;
+  static constexpr int TM = NBI == 2 ? 2 : 4, TN = 2;                 // 32 x 32 tiles per wave
+};
 
+template <int NBI>
 __global__ __launch_bounds__(512) void gemm_tn_ring_kernel(GemmArgs g) {
-  constexpr int BM = 128, BN = 256;
+  typedef TnRing<NBI> R;
+  constexpr int BM = R::BM, BN = R::BN, TR_STAGES = R::STAGES, TR_STAGE_BYTES = R::STAGE_BYTES, TM = R::TM, TN = R::TN;
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
   typedef __attribute__((address_space(3))) unsigned char lds_u8;
   lds_u8* lds = (lds_u8*)smem;
   const unsigned lds_base = (unsigned)__builtin_amdgcn_readfirstlane((int)(size_t)lds);
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 2, wn = wave & 3;
+  const int wm = NBI == 2 ? wave >> 2 : 0, wn = NBI == 2 ? wave & 3 : wave;       // this wave's 64-row (128-row) block and 64-column block
   // XCD-aware order as in gemm_tn_tr_kernel: the tiles of one K slice go to one XCD
   int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
   {
@@ -554,7 +566,7 @@ __global__ __launch_bounds__(512) void gemm_tn_ring_kernel(GemmArgs g) {
   const int kt_begin = slice * nk_per;
   const int nk = max(0, min(nk_total, kt_begin + nk_per) - kt_begin);
 
-  // this lane's three loads per stage: rows 4 wave + (lane >> 4) of the A image and of the two B sub-images; LDS slot
+  // this lane's 1 + NBI loads per stage: rows 4 wave + (lane >> 4) of the A image and of the B sub-images; LDS slot
   // (lane & 15) of a row holds source chunk slot ^ swz(row)
   const int srow = 4 * wave + (lane >> 4);
   const int chunk = (lane & 15) ^ (((srow & 3) << 2) | ((srow >> 2) & 3));
@@ -572,10 +584,10 @@ __global__ __launch_bounds__(512) void gemm_tn_ring_kernel(GemmArgs g) {
   int kcur = kt_begin * TR_BK + srow;
   int t0 = kcur % g.period;
   const unsigned short* paK = pa + ((int64_t)kcur + shift) * lda_e;
-  const unsigned short* pbK[2];
-  bool b_ok[2];
+  const unsigned short* pbK[NBI];
+  bool b_ok[NBI];
 #pragma unroll
-  for (int j = 0; j < 2; ++j) {
+  for (int j = 0; j < NBI; ++j) {
     const int n = n0 + j * 128 + chunk * 8;
     b_ok[j] = n < g.N;
     pbK[j] = g.B + (int64_t)kcur * g.ldb + (b_ok[j] ? n : 0);
@@ -591,20 +603,21 @@ __global__ __launch_bounds__(512) void gemm_tn_ring_kernel(GemmArgs g) {
     }
     glds16(sa, base);
 #pragma unroll
-    for (int j = 0; j < 2; ++j) glds16((k_ok && b_ok[j]) ? pbK[j] : zeros, base + (1 + j) * TR_BK * 256);
+    for (int j = 0; j < NBI; ++j) {
+      glds16((k_ok && b_ok[j]) ? pbK[j] : zeros, base + (1 + j) * TR_BK * 256);
+      pbK[j] += (int64_t)TR_BK * g.ldb;
+    }
     kcur += TR_BK;
     paK += (int64_t)TR_BK * lda_e;
-    pbK[0] += (int64_t)TR_BK * g.ldb;
-    pbK[1] += (int64_t)TR_BK * g.ldb;
     t0 += TR_BK;
     while (t0 >= g.period) t0 -= g.period;
   };
 
-  f32x16 acc[2][2];
+  f32x16 acc[TM][TN];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < TM; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < TN; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
@@ -625,7 +638,7 @@ __global__ __launch_bounds__(512) void gemm_tn_ring_kernel(GemmArgs g) {
       if (s0 < nk) issue(s0);
     int stage = 0;
     for (int kt = 0; kt < nk; ++kt) {
-      if (kt + TR_STAGES - 2 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(3 * (TR_STAGES - 2)) : "memory");
+      if (kt + TR_STAGES - 2 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"i"((1 + NBI) * (TR_STAGES - 2)) : "memory");
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
@@ -634,15 +647,15 @@ __global__ __launch_bounds__(512) void gemm_tn_ring_kernel(GemmArgs g) {
       const lds_u8* bs = as + TR_BK * 256 + (wn >> 1) * TR_BK * 256;       // the 128-column sub-image of this wave's columns
 #pragma unroll
       for (int kk = 0; kk < TR_BK; kk += 16) {
-        bf16x8 af[2], bfr[2];
+        bf16x8 af[TM], bfr[TN];
 #pragma unroll
-        for (int i = 0; i < 2; ++i) af[i] = frag(as, kk, wm * 2 + i);
+        for (int i = 0; i < TM; ++i) af[i] = frag(as, kk, wm * 2 + i);
 #pragma unroll
-        for (int j = 0; j < 2; ++j) bfr[j] = frag(bs, kk, (wn & 1) * 2 + j);
+        for (int j = 0; j < TN; ++j) bfr[j] = frag(bs, kk, (wn & 1) * 2 + j);
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < TM; ++i)
 #pragma unroll
-          for (int j = 0; j < 2; ++j)
+          for (int j = 0; j < TN; ++j)
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
       }
       stage = (stage + 1 == TR_STAGES) ? 0 : stage + 1;
@@ -652,9 +665,9 @@ __global__ __launch_bounds__(512) void gemm_tn_ring_kernel(GemmArgs g) {
   float* P = g.partial + (int64_t)bz * g.partial_stride;
   const int l31 = lane & 31;
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < TM; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
+    for (int j = 0; j < TN; ++j) {
       const int coln = n0 + wn * 64 + j * 32 + l31;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
@@ -1350,17 +1363,26 @@ extern "C" int las_gemm_tn_lstm(const las_bf16* x, int64_t ldx, int D, const las
   }
   const int ring = las_knob("LAS_TN_RING", 1);          // 0: the register-staged 128 x 128 kernel (diagnostics, A/B timing)
   if (ring && g.partial) {
-    dim3 grid((g.N + 255) / 256, (g.M + 127) / 128, split_k);
-    const size_t lds = (size_t)TR_STAGES * TR_STAGE_BYTES;
+    // LAS_TN_WIDE (round 5): 128 x 512 output tiles (128 x 64 per wave) where N is a multiple of 512; 0: 128 x 256 everywhere
+    const bool wide = las_knob("LAS_TN_WIDE", 1) != 0 && g.N % 512 == 0;
     static bool attr_ring = false;
     if (!attr_ring) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_ring_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)((size_t)TR_STAGES * TR_STAGE_BYTES));
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_ring_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                TnRing<2>::STAGES * TnRing<2>::STAGE_BYTES);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_ring_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                TnRing<4>::STAGES * TnRing<4>::STAGE_BYTES);
       attr_ring = true;
     }
-    // (round 5: the ping-pong schedule of gemm_nt_ring_kernel was tried here too and measured 20-25 % SLOWER -- 64 x 64 per wave
-    // gives a MATH segment of eight MFMAs, shorter than the LOAD segment beside it; not kept)
-    hipLaunchKernelGGL(gemm_tn_ring_kernel, grid, dim3(512), lds, (hipStream_t)stream, g);
+    // (round 5: the ping-pong schedule of gemm_nt_ring_kernel was tried on both forms and measured SLOWER -- 64 x 64 per wave: a MATH
+    // segment of eight MFMAs is shorter than the LOAD segment beside it, 179 -> 226 us alone; 128 x 64 per wave: 155 -> 168 us alone,
+    // 5.57 -> 6.10 ms in the metric-L step; not kept)
+    if (wide) {
+      dim3 grid((g.N + 511) / 512, (g.M + 127) / 128, split_k);
+      hipLaunchKernelGGL(gemm_tn_ring_kernel<4>, grid, dim3(512), (size_t)TnRing<4>::STAGES * TnRing<4>::STAGE_BYTES, (hipStream_t)stream, g);
+    } else {
+      dim3 grid((g.N + 255) / 256, (g.M + 127) / 128, split_k);
+      hipLaunchKernelGGL(gemm_tn_ring_kernel<2>, grid, dim3(512), (size_t)TnRing<2>::STAGES * TnRing<2>::STAGE_BYTES, (hipStream_t)stream, g);
+    }
   } else {
   dim3 grid((g.N + 127) / 128, (g.M + 127) / 128, split_k);
   const size_t lds = (size_t)4 * TBK * 256;

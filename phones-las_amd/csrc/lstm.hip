@@ -126,7 +126,9 @@ __device__ bool xcd_colocated(u64* table, int member, int* lds_flag, unsigned* s
 }
 
 // number of cooperating workgroups per chain
-// H <= 128: one workgroup; H = 256: 4 x 64 units; H = 512: 16 x 32 units with the K dimension split over wave pairs
+// H <= 128: one workgroup; H = 256: 4 x 64 units; H = 512: 16 x 32 units with the K dimension split over wave pairs; H = 1024 (round 5):
+// 32 x 32 units the same way -- a chain is then a whole XCD (32 CUs), B = 64 fills the chip with its 8 chains: built for completeness
+// (the reference takes any num_units, las/ops.py:10-12), not for speed
 // (a wave's register-resident weight block is 16 units x 4 gates x K/KS: 128 VGPRs in every case)
 __host__ __device__ constexpr int coop_members(int H) { return H <= 128 ? 1 : (H == 256 ? 4 : H / 32); }
 // The kernels take the member count as a template parameter (default: coop_members(H)); H = 512 also runs as 8 members of
@@ -1208,9 +1210,9 @@ CoopGeom geom(int B, int H, int ndir, bool bwd, int rows = 16, int G = 0) {
 // a CU each (256 on MI355X); LAS_LSTM_ROWS=16 / 8 / 4 forces one (tests, diagnostics).
 int slice_rows(int B, int H, int ndir, bool bwd) {
   const int forced = las_knob("LAS_LSTM_ROWS", 0);
-  if (H > 256 && members(H) == 16) {    // the 16-member 512-unit kernels (K split, row split): 16 or 8 rows
+  if (H > 256 && members(H) >= 16) {    // the 32-unit-member kernels (512 units as 16 members, 1024 as 32: K split, row split): 16 or 8 rows
     if (forced == 16 || forced == 8) return forced;
-    return 16;
+    return H > 512 ? 8 : 16;            // (1024 units on full tiles spill 200-500 bytes per lane: half tiles by default)
   }
   if (forced == 16 || forced == 8 || forced == 4) return forced;
   // every chain workgroup and every companion should find a CU of its own (256 on MI355X; fewer in a partitioned
@@ -1355,7 +1357,7 @@ int launch_bwd(const float* gates, const float* cbuf, const float* dy, const flo
 #undef LAS_BWD
 }
 
-bool supported_units(int H) { return H == 64 || H == 128 || H == 256 || H == 512; }
+bool supported_units(int H) { return H == 64 || H == 128 || H == 256 || H == 512 || H == 1024; }
 
 }  // namespace
 
@@ -1383,7 +1385,7 @@ extern "C" size_t las_lstm_workspace_bytes(int B, int H, int ndir) {
 }
 
 extern "C" int las_lstm_pack_recurrent(const float* kernel_h, int H, las_bf16* packed, void* stream) {
-  LAS_REQUIRE(supported_units(H), "las_lstm_pack_recurrent: num_units must be 64, 128, 256 or 512 (got %d)", H);
+  LAS_REQUIRE(supported_units(H), "las_lstm_pack_recurrent: num_units must be 64, 128, 256, 512 or 1024 (got %d)", H);
   hipLaunchKernelGGL(pack_recurrent_kernel, dim3(256), dim3(256), 0, (hipStream_t)stream, kernel_h, H, packed);
   LAS_LAUNCH_CHECK("pack launch");
   return LAS_OK;
@@ -1393,7 +1395,7 @@ namespace {
 int recurrent_fwd(float* xproj, const las_bf16* wpacked, const int32_t* length, las_bf16* y, float* cbuf, float* c_last,
                   float* h_last, void* workspace, int B, int T, int H, int ndir, void* stream, const FusedInput& fi) {
   LAS_REQUIRE(B > 0 && T > 0 && (ndir == 1 || ndir == 2), "las_lstm_recurrent_fwd: bad shape B=%d T=%d ndir=%d", B, T, ndir);
-  LAS_REQUIRE(supported_units(H), "las_lstm_recurrent_fwd: num_units %d not in {64,128,256,512}", H);
+  LAS_REQUIRE(supported_units(H), "las_lstm_recurrent_fwd: num_units %d not in {64,128,256,512,1024}", H);
   LAS_REQUIRE(workspace != nullptr && ((uintptr_t)workspace % 16 == 0), "las_lstm_recurrent_fwd: workspace missing or misaligned");
   hipStream_t st = (hipStream_t)stream;
   int rc = 0;
@@ -1408,6 +1410,7 @@ int recurrent_fwd(float* xproj, const las_bf16* wpacked, const int32_t* length, 
     case 64: return launch_fwd<64>(xproj, wpacked, length, y, cbuf, c_last, h_last, workspace, B, T, ndir, st, fi);
     case 128: return launch_fwd<128>(xproj, wpacked, length, y, cbuf, c_last, h_last, workspace, B, T, ndir, st, fi);
     case 512: return launch_fwd<512>(xproj, wpacked, length, y, cbuf, c_last, h_last, workspace, B, T, ndir, st, fi);
+    case 1024: return launch_fwd<1024>(xproj, wpacked, length, y, cbuf, c_last, h_last, workspace, B, T, ndir, st, fi);
     default: return launch_fwd<256>(xproj, wpacked, length, y, cbuf, c_last, h_last, workspace, B, T, ndir, st, fi);
   }
 }
@@ -1455,7 +1458,7 @@ int recurrent_bwd(const float* gates, const float* cbuf, const float* dy, const 
                   const las_bf16* kh_bf16, const int32_t* length, las_bf16* dz, void* workspace, int B, int T, int H, int ndir,
                   void* stream) {
   LAS_REQUIRE(B > 0 && T > 0 && (ndir == 1 || ndir == 2), "las_lstm_recurrent_bwd: bad shape");
-  LAS_REQUIRE(supported_units(H), "las_lstm_recurrent_bwd: num_units %d not in {64,128,256,512}", H);
+  LAS_REQUIRE(supported_units(H), "las_lstm_recurrent_bwd: num_units %d not in {64,128,256,512,1024}", H);
   LAS_REQUIRE(workspace != nullptr && ((uintptr_t)workspace % 16 == 0), "las_lstm_recurrent_bwd: workspace missing or misaligned");
   hipStream_t st = (hipStream_t)stream;
   int rc = 0;
@@ -1468,6 +1471,7 @@ int recurrent_bwd(const float* gates, const float* cbuf, const float* dy, const 
     case 64: return launch_bwd<64>(gates, cbuf, dy, dc_last, dh_last, kh_bf16, length, dz, workspace, B, T, ndir, st);
     case 128: return launch_bwd<128>(gates, cbuf, dy, dc_last, dh_last, kh_bf16, length, dz, workspace, B, T, ndir, st);
     case 512: return launch_bwd<512>(gates, cbuf, dy, dc_last, dh_last, kh_bf16, length, dz, workspace, B, T, ndir, st);
+    case 1024: return launch_bwd<1024>(gates, cbuf, dy, dc_last, dh_last, kh_bf16, length, dz, workspace, B, T, ndir, st);
     default: return launch_bwd<256>(gates, cbuf, dy, dc_last, dh_last, kh_bf16, length, dz, workspace, B, T, ndir, st);
   }
 }

@@ -29,8 +29,8 @@ def lstm_cell(num_units, dropout, mode):
     dropout = dropout if mode == TRAIN else 0.0
     if not 0.0 <= dropout < 1.0:
         raise ValueError('dropout must be in [0, 1)')
-    if num_units not in (64, 128, 256, 512):
-        raise ValueError('the recurrent kernels are built for 64, 128, 256 and 512 units (got %d): LasModel runs other '
+    if num_units not in (64, 128, 256, 512, 1024):
+        raise ValueError('the recurrent kernels are built for 64, 128, 256, 512 and 1024 units (got %d): LasModel runs other '
                          'widths zero-padded to the next of these (model_helper.physical_params)' % num_units)
     return LSTMCellSpec(num_units, 1.0 - dropout)
 
@@ -85,6 +85,7 @@ TN_WORKGROUPS = int(os.environ.get('LAS_TN_WGS', '704'))
 # ... of the bottom layer, whose two directions' products run ALONE on the chip (nothing hides them), at the same time on two
 # streams; a 512-thread workgroup with 96 KiB of LDS takes a CU
 TN_WORKGROUPS_EXPOSED = int(os.environ.get('LAS_TN_WGS_EXPOSED', '704'))
+TN_WIDE = os.environ.get('LAS_TN_WIDE', '1') != '0'         # (the library reads the same switch: 128 x 512 tiles of the fused product)
 
 
 class Overlap:
@@ -473,6 +474,8 @@ def bilstm_backward(rec, dy, d_state, grads, need_dx=True, overlap=None, defer_w
         # fused product: about 700 workgroups in flight measured best on MI355X (128 x 128 output tiles, K cut in slices)
         tiles = -(-(Df + H + 1) // 128) * -(-(4 * H) // 128)
         split = max(1, min(32, BT // 512, round((TN_WORKGROUPS_EXPOSED if exposed else TN_WORKGROUPS) / tiles)))
+        if TN_WIDE and (4 * H) % 512 == 0:       # 128 x 512 output tiles (round 5): half the workgroups per K slice, so twice the slices
+            split = max(1, min(32, BT // 512, 2 * split))
     keepalive = [dz, x, y] + [a for a, _ in (dropped or [])]
 
     def weight_grads():

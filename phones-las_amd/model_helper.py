@@ -33,7 +33,8 @@ def _enc_depth(e):
     return dirs * e.num_units
 
 
-SUPPORTED_UNITS = (64, 128, 256, 512)      # what the recurrent / decoder kernels are built for (las/ops.py lstm_cell)
+SUPPORTED_UNITS = (64, 128, 256, 512, 1024)      # what the recurrent / decoder kernels are built for (las/ops.py lstm_cell); 1024
+# (round 5): chains of 32 workgroups, the decoder on its step-by-step launches -- the reference takes any width (las/ops.py:10-12)
 
 
 def physical_units(n):

@@ -42,7 +42,7 @@ def test_index_maps_cover_the_logical_model(case):
     _, plain = make_hparams(att='luong', H=128, Hd=64, pass_hidden=False)
     assert mh.physical_params(plain) is plain
     with pytest.raises(ValueError):
-        mh.physical_units(520)
+        mh.physical_units(1030)
 
 
 def _padded_model(case):
