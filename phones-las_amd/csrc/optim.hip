@@ -307,12 +307,12 @@ static int grad_l2_norms(float* grads, const float* params, const int64_t* seg_o
   LAS_REQUIRE(((uintptr_t)grads % 16 == 0) && ((uintptr_t)params % 16 == 0), "las_grad_l2_norms: buffers must be 16-byte aligned");
   hipStream_t st = (hipStream_t)stream;
   if (zero_first) {
-    int rc = las_check_hip(hipMemsetAsync(sumsq, 0, sizeof(float) * nseg, st), "memset sumsq");
-    if (rc) return rc;
-    if (param_sumsq) {
-      rc = las_check_hip(hipMemsetAsync(param_sumsq, 0, sizeof(float), st), "memset param_sumsq");
-      if (rc) return rc;
-    }
+    // one small launch, not hipMemsetAsync: as MEMSET NODES of a captured graph the 16- and 4-byte clears this used to enqueue left
+    // garbage in the accumulators (round 5, tests/test_gpu_step_forms.py: six of six replays of the two-bucket exchange form
+    // had a bottom-layer ||g||^2 of -7.8e31 -- harmless while negative, a zeroed gradient when it came out positive; the same
+    // calls launched eagerly, and the large memsets of the recurrent / decoder workspaces inside graphs, were never seen wrong)
+    hipLaunchKernelGGL(train_op_begin_kernel, dim3(1), dim3(64), 0, st, nullptr, 0, nullptr, sumsq, nseg, param_sumsq, param_sumsq ? 1 : 0);
+    LAS_LAUNCH_CHECK("norm accumulators zeroing launch");
   }
   LAS_REQUIRE(workspace == nullptr || (workspace_bytes >= las_grad_l2_norms_ws_bytes(nseg, total) && (uintptr_t)workspace % 16 == 0),
               "las_grad_l2_norms: workspace of las_grad_l2_norms_ws_bytes(nseg, total) bytes needed");

@@ -492,7 +492,7 @@ class LasModel:
             # the raw outputs are then the top cell's h, and compute_log_probs_loss splits them at HALF their width
             # (model_helper.py:137-139): a zero-padded h would move that split
             raise ValueError('binf_projection on a multi-layer --bottom_only decoder: decoder_units must be one of the widths the '
-                             'kernels are built for (64, 128, 256, 512), not a zero-padded one (got %d)' % self.hparams.decoder.num_units)
+                             'kernels are built for (64, 128, 256, 512, 1024), not a zero-padded one (got %d)' % self.hparams.decoder.num_units)
         if self.padded:
             self.vars = Variables(param_table(params), logical_table=param_table(self.hparams),
                                   index_maps=pad_index_maps(self.hparams, params))

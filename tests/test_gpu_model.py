@@ -1085,3 +1085,31 @@ def test_two_cell_decoder_with_a_memory_longer_than_the_lds(bottom, monkeypatch)
     for name in res['1'][2]:
         assert relerr(res['1'][2][name], res['0'][2][name].cpu()) < 6e-3, name
 
+
+
+@pytest.mark.parametrize('kw', [
+    pytest.param(dict(att='luong', H=1024, Hd=256, pass_hidden=False), id='listener1024_speller256'),
+    pytest.param(dict(att='luong', H=1024, Hd=1024, pass_hidden=True), id='both1024_state_handed_over'),
+    pytest.param(dict(att='bahdanau', H=1024, Hd=1024, pass_hidden=True, dec_layers=2), id='both1024_bahdanau_two_cells'),
+])
+def test_1024_units_vs_oracle(kw):
+    """num_units 1024 (the widest the recurrent kernels are built for: 32 members x 32 units per chain group; 513..1023 run
+    padded to it, tests/test_units_padding.py) against the oracle with the device's bf16 storage points."""
+    O, ohp, op, model = _models(L=2, **kw)
+    tgt = [6, 4, 5, 2, 6]
+    batch = make_batch(B=5, T=14, src_len=[14, 7, 10, 3, 12], tgt_len=tgt)
+    feats, labels = to_device(batch)
+    out = O.train_step(ohp, op, None, None, 1, batch, mxu='bf16')
+    model.vars.grad.zero_()
+    loss, logits, dlogits = model.forward_train(feats, labels)
+    model.backward(dlogits)
+    torch.cuda.synchronize()
+    assert model.read_and_clear_status() == []
+    ce = float(out['aux']['ce'])
+    assert abs(float(loss) - ce) < 1e-3 * abs(ce)
+    V = ohp.decoder.target_vocab_size
+    for b, n in enumerate(tgt):
+        assert relerr(logits[b, :n, :V], out['aux']['logits'][b, :n]) < 2e-2
+    tol = 2 * GRAD_TOL if kw.get('dec_layers', 1) >= 2 else GRAD_TOL      # 2x for the general decoder, as above
+    for name, _, _ in model.vars.table:
+        assert relerr(model.vars.grads[name], out['grads'][name] - ohp.l2_reg_scale * op[name]) < tol, name

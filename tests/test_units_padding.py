@@ -16,6 +16,7 @@ CASES = {
     'general_72_104': dict(att='luong_monotonic', H=72, Hd=104, pass_hidden=False, dec_layers=2, als=24, emb=16,
                            ctc=0.3, L=3),                                              # general decoder, CTC head, 3 layers
     'stacked_40_40': dict(att='custom', H=40, Hd=40, pyramidal=False, pass_hidden=False),
+    'luong_600_520': dict(att='luong', H=600, Hd=520, pass_hidden=False),               # both -> 1024 (32-member chains)
 }
 
 
