@@ -160,7 +160,7 @@ class _NoOverlap:
         return contextlib.nullcontext()
 
     def mark(self):
-        return None
+        return _Marks([])
 
     def join(self):
         pass

@@ -520,7 +520,8 @@ class LasModel:
         self.world_size = world_size
         self.process_group = process_group
         self._images_stale = False
-        self.overlap = las_model.ops.Overlap()
+        # LAS_SERIAL=1 (diagnostics, A/B timing): no side streams -- every product runs where it is issued, on the one stream
+        self.overlap = las_model.ops.Overlap() if os.environ.get('LAS_SERIAL', '0') != '1' else las_model.ops._NoOverlap()
         self.tail_buckets = self._tail_buckets()
 
     def _tail_buckets(self):
