@@ -106,29 +106,33 @@ __global__ __launch_bounds__(256) void l2_norm_kernel(float* g, const float* p, 
   }
   __syncthreads();
   if (!last) return;
-  // 32 tensors at a time: thread (tensor sl, stripe pt) adds the rows pt, pt + 8, ... (L2-bypassing loads, eight in flight: one
-  // lane walking all rows with dependent loads made this tail 60 us of an 84-us kernel), the eight stripes meet in LDS
-  // in stripe order -- a fixed assignment, so the sums do not depend on scheduling
-  __shared__ float stripe[8][32];
-  const int sl = threadIdx.x & 31, pt = threadIdx.x >> 5;
-  for (int s0 = 0; s0 <= nseg; s0 += 32) {
-    const int seg = s0 + sl;
+  // One wave per tensor (waves take tensors w, w + 4, ...).  A workgroup covers SPAN contiguous elements, so the rows that can
+  // hold a partial sum of tensor `seg` are the workgroups off[seg] / SPAN ... (off[seg + 1] - 1) / SPAN and nothing else: the
+  // wave reads those (lane l the rows b0 + l, b0 + l + 64, ...: L2-bypassing loads, independent, many in flight) and adds its
+  // lanes in the butterfly's fixed order -- the sums depend on the layout only, not on scheduling.  (Until round 5 every one of
+  // the nseg + 1 columns was read over ALL rows, eight loads in flight per thread: 2 228 rows x 41 columns took 170 of the
+  // kernel's 281 us at metric-L, on the critical path behind the last recurrence; the column of sum theta^2 does need all rows
+  // and is read by the whole workgroup.)
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  for (int seg = wave; seg < nseg; seg += 4) {
+    const int64_t lo = off[seg], hi = (seg + 1 < nseg) ? off[seg + 1] : total;
     float t = 0.f;
-    if (seg <= nseg) {
+    if (hi > lo) {
+      const unsigned b0 = (unsigned)(lo / SPAN), b1 = (unsigned)((hi - 1) / SPAN);
       const float* src = rows + seg;
-#pragma unroll 8
-      for (unsigned b = pt; b < gridDim.x; b += 8) t += __hip_atomic_load(src + (int64_t)b * (nseg + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll 4
+      for (unsigned b = b0 + lane; b <= b1; b += 64) t += __hip_atomic_load(src + (int64_t)b * (nseg + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    stripe[pt][sl] = t;
-    __syncthreads();
-    if (pt == 0 && seg <= nseg && (seg < nseg || param_sumsq)) {
-      float tot = 0.f;
-#pragma unroll
-      for (int k = 0; k < 8; ++k) tot += stripe[k][sl];
-      if (seg < nseg) sumsq[seg] += tot;
-      else *param_sumsq += tot;
-    }
-    __syncthreads();
+    t = las_wave_sum(t);
+    if (lane == 0 && hi > lo) sumsq[seg] += t;
+  }
+  if (param_sumsq) {
+    float t = 0.f;
+    const float* src = rows + nseg;
+#pragma unroll 4
+    for (unsigned b = threadIdx.x; b < gridDim.x; b += 256) t += __hip_atomic_load(src + (int64_t)b * (nseg + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    t = block_sum(t, red);
+    if (threadIdx.x == 0) *param_sumsq += t;
   }
   if (threadIdx.x == 0) *ws = 0u;
 }

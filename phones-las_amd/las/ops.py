@@ -111,7 +111,11 @@ class Overlap:
         are resident first -- a chain that finds CUs taken by a GEMM workgroup starts late as a whole (measured: 1.03-1.07
         instead of 0.96-1.00 ms for an 800-step backward launch when the product beside it was dispatched first)."""
         if lane and self.side2 is None:
-            self.side2 = torch.cuda.Stream()
+            # the two directions' exposed products are meant to run AT THE SAME TIME: a third stream that landed on the first
+            # side stream's hardware queue (streams share a handful of them) ran them one after the other -- 77 + 62 us behind the
+            # last recurrence of a metric-M step (round 5, dispatch timeline) -- so the stream is probed, as the product stream is
+            self.side2 = (_stream_beside([self.side, torch.cuda.current_stream()]) if os.environ.get('LAS_SIDE2_PROBE', '1') != '0'
+                          else torch.cuda.Stream())
         side = self.side2 if lane else self.side
         if lane:
             self.side2_busy = True
@@ -217,6 +221,34 @@ def _product_stream():
                 st = _concurrent_stream()
         _PRODUCT_STREAMS[key] = st
     return st
+
+
+def _stream_beside(others, tries=6):
+    """A new stream whose kernels run beside kernels of every stream in `others` (las_stream_concurrency_probe); the last
+    candidate when none is found (correct all the same: work is only ordered more than it had to be)."""
+    if torch.cuda.is_current_stream_capturing():
+        return torch.cuda.Stream()               # (cannot probe inside a capture: an eager step creates the stream first)
+    words = torch.zeros(2, dtype=torch.int32, device='cuda')
+    cur = torch.cuda.current_stream()
+    cand = None
+    for _ in range(tries):
+        cand = torch.cuda.Stream()
+        good = True
+        for o in others:
+            if o.cuda_stream == cand.cuda_stream:
+                good = False
+                break
+            o.wait_stream(cur)                   # (`words` was cleared on the current stream)
+            hip.check(hip.lib().las_stream_concurrency_probe(o.cuda_stream, cand.cuda_stream, hip.p(words), 2000))
+            o.wait_stream(cand)
+            cur.wait_stream(o)
+            if int(words[1].item()) != 1:
+                good = False
+                break
+        if good:
+            return cand
+        _ALIASED_STREAMS.append(cand)
+    return cand
 
 
 def _concurrent_stream(tries=8):
