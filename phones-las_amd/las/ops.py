@@ -111,10 +111,13 @@ class Overlap:
         are resident first -- a chain that finds CUs taken by a GEMM workgroup starts late as a whole (measured: 1.03-1.07
         instead of 0.96-1.00 ms for an 800-step backward launch when the product beside it was dispatched first)."""
         if lane and self.side2 is None:
-            # the two directions' exposed products are meant to run AT THE SAME TIME: a third stream that landed on the first
-            # side stream's hardware queue (streams share a handful of them) ran them one after the other -- 77 + 62 us behind the
-            # last recurrence of a metric-M step (round 5, dispatch timeline) -- so the stream is probed, as the product stream is
-            self.side2 = (_stream_beside([self.side, torch.cuda.current_stream()]) if os.environ.get('LAS_SIDE2_PROBE', '1') != '0'
+            # LAS_SIDE2_PROBE=1: a third stream that is PROBED to run beside the first side stream and the current one (a stream
+            # that lands on the first side stream's hardware queue -- streams share four of them -- runs the two directions'
+            # exposed products one after the other: 77 + 62 us behind the last recurrence of a metric-M step in a dispatch
+            # timeline).  Measured in round 5: side by side the two products take as long as one after the other (they share the
+            # chip: 6.012 against 6.024 ms, within noise), and a process whose main, side, third and product streams hold all four
+            # queues leaves none for RCCL's stream -- so the default stays an unprobed stream.
+            self.side2 = (_stream_beside([self.side, torch.cuda.current_stream()]) if os.environ.get('LAS_SIDE2_PROBE', '0') == '1'
                           else torch.cuda.Stream())
         side = self.side2 if lane else self.side
         if lane:
@@ -223,7 +226,7 @@ def _product_stream():
     return st
 
 
-def _stream_beside(others, tries=6):
+def _stream_beside(others, tries=16):
     """A new stream whose kernels run beside kernels of every stream in `others` (las_stream_concurrency_probe); the last
     candidate when none is found (correct all the same: work is only ordered more than it had to be)."""
     if torch.cuda.is_current_stream_capturing():
