@@ -182,7 +182,7 @@ def test_cu_pressure_moderate_runs_heavy_times_out_withholds_the_update_and_the_
         def spinner_stream():
             # beside EVERY stream the step uses: spinners queued in front of one of the step's side streams would hold the step back
             # until they are gone (its joins wait for that stream) -- no pressure at all (streams share four hardware queues)
-            used = [torch.cuda.current_stream()] + [x for m in (model, twin) for x in (m.overlap.side, m.overlap.side2) if x is not None]
+            used = [torch.cuda.current_stream()] + [x for x in (model.overlap.side, model.overlap.side2) if x is not None]   # (three of the four queues at most)
             return ops._stream_beside(used)
         side = spinner_stream()
         counts = torch.zeros(8, dtype=torch.int32, device=dev)
@@ -228,9 +228,22 @@ def test_cu_pressure_moderate_runs_heavy_times_out_withholds_the_update_and_the_
         time.sleep(5.5)
         # the probe: the same candidate under pressure is dropped (status read AND cleared), the plain eager form is chosen
         probe = lambda fn: (fn(), torch.cuda.synchronize(), 1.0)[2]
-        chosen, probed, dropped = bench.choose_step_form({'overlap_eager': (overlapped_under_pressure, False, True), 'plain_eager': cands['plain_eager']},
-                                                         probe, model.read_and_clear_status, lambda f: f)
-        assert chosen == 'plain_eager' and list(dropped) == ['overlap_eager'] and 'timeout' in dropped['overlap_eager']
+        for attempt in range(3):
+            seen = []
+
+            def read_status():
+                seen.append(model.read_and_clear_status())
+                return seen[-1]
+            chosen, probed, dropped = bench.choose_step_form({'overlap_eager': (overlapped_under_pressure, False, True), 'plain_eager': cands['plain_eager']},
+                                                             probe, read_status, lambda f: f)
+            if seen and seen[0]:
+                break
+            # (the overlapped candidate saw no timeout: its step ran behind the spinners, not beside them -- see above)
+            torch.cuda.synchronize()
+            time.sleep(5.5)
+            side = spinner_stream()
+        assert seen and seen[0], 'the overlapped candidate never ran beside the spinners (three spinner streams tried)'
+        assert chosen == 'plain_eager' and list(dropped) == ['overlap_eager'] and 'timeout' in dropped['overlap_eager'], (chosen, probed, dropped, seen)
         torch.cuda.synchronize()
         time.sleep(5.5)                               # (the last spinner launch has left the chip)
         torch.cuda.synchronize()
