@@ -746,7 +746,10 @@ __global__ __launch_bounds__(256) void lstm_fwd_kernel(float* __restrict__ xproj
 // is 4 x (G-1) granules each way, against 8 x 4 x (G-1) for an all-gather of dz_t.
 // kh is K_h [H, 4H] in bf16 with GATE-INTERLEAVED columns (u*4+g): a member's K range is contiguous.
 // ------------------------------------------------------------------------------------------------
-template <int H, int ROWS, int G>     // ROWS: utterances per slice, G: members, as in lstm_fwd_kernel
+// PACK (round 5; 8-row slices without the row split, i.e. two rows per lane): the two rows' partial sums of a tile travel as ONE
+// granule {epoch, bf16 | bf16 << 16} instead of two fp32 granules -- half the exchange instructions on either side; the sums
+// are still formed in fp32 (own partial in fp32 + the peers' bf16-rounded ones).
+template <int H, int ROWS, int G, bool PACK = false>     // ROWS: utterances per slice, G: members, as in lstm_fwd_kernel
 __device__ __forceinline__ void lstm_bwd_body(const float* __restrict__ gates, const float* __restrict__ cbuf,
                                               const float* __restrict__ dy, const float* __restrict__ dc_last,
                                               const float* __restrict__ dh_last, const unsigned short* __restrict__ kh,
@@ -766,7 +769,9 @@ __device__ __forceinline__ void lstm_bwd_body(const float* __restrict__ gates, c
   constexpr int OWN = SPLIT ? 0 : UBW;            // ... of which stay in registers (own units)
   constexpr int ZS = 4 * HS + 8;                  // LDS row stride of the dz tile (elements)
   constexpr int PAIR = NUB * 256;                 // granules per (destination, sender) pair: [block][row][lane]
-  constexpr int PER = G > 1 ? (SPLIT ? G * RPL : (G - 1) * UBW * RPL) : 1;   // granules a lane polls per step
+  static_assert(!PACK || (!SPLIT && RPL == 2 && G > 1), "packed partial sums: two rows per lane, no row split");
+  constexpr int RPG = PACK ? 1 : RPL;             // granules per (tile, lane)
+  constexpr int PER = G > 1 ? (SPLIT ? G * RPL : (G - 1) * UBW * RPG) : 1;   // granules a lane polls per step
   __shared__ __attribute__((aligned(16))) unsigned short ztile[2][16][ZS];
   __shared__ int fail_flag;
   __shared__ int colo_flag;
@@ -914,7 +919,7 @@ __device__ __forceinline__ void lstm_bwd_body(const float* __restrict__ gates, c
     for (int e = 0; e < PER; ++e) {
       int sender, ub, r;
       if constexpr (SPLIT) { sender = e / RPL; ub = 0; r = hh * RPL + e % RPL; }
-      else { sender = (member + 1 + e / (UBW * RPL)) % G; ub = (e / RPL) % UBW; r = e % RPL; }
+      else { sender = (member + 1 + e / (UBW * RPG)) % G; ub = (e / RPG) % UBW; r = e % RPG; }
       poll_off[e] = (unsigned)((((member * G + sender) * NUB + blk + ub) * 4 + r) * 64 + lane) * 8u;
     }
 #pragma unroll
@@ -1045,8 +1050,14 @@ __device__ __forceinline__ void lstm_bwd_body(const float* __restrict__ gates, c
 #pragma unroll
           for (int i = 0; i < CH; ++i) {
             const int e = c0 + i;
-            const int ub = SPLIT ? 0 : (e / RPL) % UBW, r = e % RPL;
-            cand[ub][r] += __uint_as_float((unsigned)v[i]);
+            if constexpr (PACK) {
+              const int ub = e % UBW;
+              cand[ub][0] += __uint_as_float((unsigned)v[i] << 16);
+              cand[ub][1] += __uint_as_float((unsigned)v[i] & 0xffff0000u);
+            } else {
+              const int ub = SPLIT ? 0 : (e / RPL) % UBW, r = e % RPL;
+              cand[ub][r] += __uint_as_float((unsigned)v[i]);
+            }
           }
         }
       }
@@ -1134,9 +1145,14 @@ __device__ __forceinline__ void lstm_bwd_body(const float* __restrict__ gates, c
       for (int j = OWN; j < NT; ++j) {
 #pragma unroll
         for (int kc = 0; kc < KCW; ++kc) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afr[kc], wf[j][kc], acc[j], 0, 0, 0);
+        if constexpr (PACK) {
+          granule_store(reinterpret_cast<u64*>(dst + send_off[j - OWN]), base + epoch + 1,
+                        (unsigned)las_f2bf(acc[j][0]) | ((unsigned)las_f2bf(acc[j][1]) << 16), local);
+        } else {
 #pragma unroll
-        for (int r = 0; r < (SPLIT ? ROWS / 4 : RPL); ++r)       // 8-row slices: rows 2, 3 of every quad carry nothing
-          granule_store(reinterpret_cast<u64*>(dst + send_off[j - OWN] + r * 512), base + epoch + 1, __float_as_uint(acc[j][r]), local);
+          for (int r = 0; r < (SPLIT ? ROWS / 4 : RPL); ++r)       // 8-row slices: rows 2, 3 of every quad carry nothing
+            granule_store(reinterpret_cast<u64*>(dst + send_off[j - OWN] + r * 512), base + epoch + 1, __float_as_uint(acc[j][r]), local);
+        }
       }
     }
     // own tiles: nobody waits for one of them in particular, so they advance together -- K chunk by K chunk -- instead of one
@@ -1170,7 +1186,7 @@ __device__ __forceinline__ void lstm_bwd_body(const float* __restrict__ gates, c
   if (!ok && tid == 0) atomicOr(status, 2u);
 }
 
-template <int H, int ROWS, int G = coop_members(H)>
+template <int H, int ROWS, int G = coop_members(H), bool PACK = false>
 __global__ __launch_bounds__(256) void lstm_bwd_kernel(const float* __restrict__ gates, const float* __restrict__ cbuf,
                                                        const float* __restrict__ dy, const float* __restrict__ dc_last,
                                                        const float* __restrict__ dh_last, const unsigned short* __restrict__ kh,
@@ -1178,7 +1194,7 @@ __global__ __launch_bounds__(256) void lstm_bwd_kernel(const float* __restrict__
                                                        u64* __restrict__ exch, unsigned* __restrict__ status,
                                                        int B, int T, int ndir, int ngroups, long long exch_words) {
   const unsigned base = launch_base(status);
-  lstm_bwd_body<H, ROWS, G>(gates, cbuf, dy, dc_last, dh_last, kh, length, dz, exch, status, B, T, ndir, ngroups, base);
+  lstm_bwd_body<H, ROWS, G, PACK>(gates, cbuf, dy, dc_last, dh_last, kh, length, dz, exch, status, B, T, ndir, ngroups, base);
   launch_arrive(status, base, T, exch, exch_words);
 }
 
@@ -1309,7 +1325,7 @@ int launch_fwd(float* xproj, const las_bf16* wp, const int32_t* length, las_bf16
 #undef LAS_FWD0
 }
 
-template <int H, int ROWS, int G>
+template <int H, int ROWS, int G, bool PACK = false>
 int launch_bwd_as(const float* gates, const float* cbuf, const float* dy, const float* dc_last, const float* dh_last,
                   const las_bf16* kh, const int32_t* length, las_bf16* dz, void* ws, int B, int T, int ndir, hipStream_t st) {
   const CoopGeom g = geom(B, H, ndir, true, ROWS, G);
@@ -1328,9 +1344,9 @@ int launch_bwd_as(const float* gates, const float* cbuf, const float* dy, const 
     hog_kb = las_knob("LAS_LSTM_BWD_LDS_KB", 160 - static_kb - 6);
     if (hog_kb > 160 - static_kb - 2) hog_kb = 160 - static_kb - 2;
     if (hog_kb > 0)
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&lstm_bwd_kernel<H, ROWS, G>), hipFuncAttributeMaxDynamicSharedMemorySize, hog_kb * 1024);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&lstm_bwd_kernel<H, ROWS, G, PACK>), hipFuncAttributeMaxDynamicSharedMemorySize, hog_kb * 1024);
   }
-  hipLaunchKernelGGL((lstm_bwd_kernel<H, ROWS, G>), dim3(pf ? g.blocks + g.companions : g.blocks), dim3(256), (size_t)(hog_kb > 0 ? hog_kb : 0) * 1024, st,
+  hipLaunchKernelGGL((lstm_bwd_kernel<H, ROWS, G, PACK>), dim3(pf ? g.blocks + g.companions : g.blocks), dim3(256), (size_t)(hog_kb > 0 ? hog_kb : 0) * 1024, st,
                      gates, cbuf, dy, dc_last, dh_last, kh, length, dz, exch, status, B, T, ndir, g.ngroups, exch_words(B, H, ndir));
   LAS_LAUNCH_CHECK("lstm bwd launch");
   return LAS_OK;
@@ -1341,20 +1357,31 @@ int launch_bwd(const float* gates, const float* cbuf, const float* dy, const flo
                const las_bf16* kh, const int32_t* length, las_bf16* dz, void* ws, int B, int T, int ndir, hipStream_t st) {
   const int rows = slice_rows(B, H, ndir, true);
 #define LAS_BWD(R, GG) return launch_bwd_as<H, R, GG>(gates, cbuf, dy, dc_last, dh_last, kh, length, dz, ws, B, T, ndir, st)
+  // On 8-row slices the partial sums travel as bf16 pairs (lstm_bwd_body, PACK; LAS_LSTM_BWD_PACK=0: fp32 granules as before).
+  // Measured (round 5, scripts/gpu_r05_r.sh): 512 units 2.46 -> 2.06 us per step alone, metric-L 17.37 -> 16.67 ms, cfg4 18.69 ->
+  // 18.03; 256 units on 8-row slices (B > 64) 1.52 -> 1.42.  Parity (scripts/gpu_pack_parity.py, 512 units, against the oracle's
+  // bf16 storage model / its exact f64 model): worst listener gradient 1.85e-3 -> 1.92e-3 / 1.166e-2 -> 1.173e-2 of max-abs.
+  const bool pack = las_knob("LAS_LSTM_BWD_PACK", 1) != 0;
+#define LAS_BWD_PACKED(GG) return launch_bwd_as<H, 8, GG, true>(gates, cbuf, dy, dc_last, dh_last, kh, length, dz, ws, B, T, ndir, st)
   if constexpr (H == 512) {
     if (members(H) == 8) {
       if (rows == 4) LAS_BWD(4, 8);
+      if (rows == 8 && pack) LAS_BWD_PACKED(8);
       if (rows == 8) LAS_BWD(8, 8);
       LAS_BWD(16, 8);
     }
   }
   constexpr int G0 = coop_members(H);
+  if constexpr (H == 256) {
+    if (rows == 8 && pack) LAS_BWD_PACKED(G0);
+  }
   if (rows == 8) LAS_BWD(8, G0);
   if constexpr (H <= 256) {
     if (rows == 4) LAS_BWD(4, G0);
   }
   LAS_BWD(16, G0);
 #undef LAS_BWD
+#undef LAS_BWD_PACKED
 }
 
 bool supported_units(int H) { return H == 64 || H == 128 || H == 256 || H == 512 || H == 1024; }

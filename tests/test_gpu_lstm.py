@@ -118,6 +118,20 @@ def test_512_unit_chains_as_8_or_16_members(g512, rows, B, T, monkeypatch):
         hip.set_knob('LAS_LSTM_G512', 8)
 
 
+@pytest.mark.parametrize('H,B,T', [(512, 19, 14), (512, 70, 9), (256, 21, 40)])
+def test_backward_partial_sums_as_fp32_granules_or_bf16_pairs(H, B, T, monkeypatch):
+    """8-row slices send the two rows' partial dh sums of a tile as ONE granule of two bf16 values (default since round 5,
+    LAS_LSTM_BWD_PACK); the fp32-granule form stays selectable.  Both against the oracle, at the tolerance of the other tests."""
+    from phones_las_amd import hip
+    lengths = [T - (i * 5) % T for i in range(B)]
+    for pack in (0, 1):
+        hip.set_knob('LAS_LSTM_BWD_PACK', pack)
+        try:
+            test_bilstm_forward_backward_vs_oracle(B, T, 24, H, lengths, 8, monkeypatch)
+        finally:
+            hip.set_knob('LAS_LSTM_BWD_PACK', 1)
+
+
 def test_unidirectional_and_pyramid_view():
     from oracle import las_oracle as O
     from phones_las_amd.las import ops
