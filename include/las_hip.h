@@ -287,7 +287,10 @@ typedef struct las_lstm_fwd {
   const las_bf16* kx_packed;
   const float* bias;
   uint32_t* ready;               /* streamed input projection (optional): shared with las_gemm_nt_stream_dirs, written by both */
-  int32_t ready_count, reserved1;
+  int32_t ready_count;
+  int32_t rows_per_slice;        /* 0: the library's choice (las_lstm_slice_rows); 4 / 8 / 16: this launch's utterances per slice -- the caller of a
+                                  * streamed product passes the value it laid `ready` out for (round 5: 8-row slices under a product that the
+                                  * 4-row form, with twice the chain workgroups, leaves too few CUs) */
 } las_lstm_fwd;
 int las_lstm_recurrent_fwd_ex(const las_lstm_fwd* p, void* stream);
 

@@ -186,6 +186,7 @@ struct FusedInput {
   unsigned* ready;
   int nsb, flags;
   unsigned want;
+  int rows;                      // utterances per slice of this launch (0: slice_rows' choice)
 };
 
 // Wait until the streamed rows of step block sb of this group are there (wave-uniform; bounded).  Returns false on timeout.
@@ -1293,7 +1294,7 @@ int fused_input_chunks(int H, int Dp) {
 template <int H>
 int launch_fwd(float* xproj, const las_bf16* wp, const int32_t* length, las_bf16* y, float* cbuf, float* c_last,
                float* h_last, void* ws, int B, int T, int ndir, hipStream_t st, const FusedInput& fi) {
-  const int rows = slice_rows(B, H, ndir, false);
+  const int rows = fi.rows > 0 ? fi.rows : slice_rows(B, H, ndir, false);
   const int kx = fi.x ? fused_input_chunks(H, fi.Dp) : 0;
 #define LAS_FWD(R, GG) do {                                                                                                   \
     if constexpr (fused_input_units(H)) {                                                                                      \
@@ -1472,10 +1473,16 @@ extern "C" int las_lstm_recurrent_fwd_ex(const las_lstm_fwd* p, void* stream) {
   }
   if (p->ready != nullptr) {
     LAS_REQUIRE(p->ready_count > 0, "las_lstm_recurrent_fwd_ex: ready_count = column tiles per block of the streamed product");
-    const int rows = slice_rows(p->B, p->H, p->ndir, false), sbs = 256 / rows;
+    const int rows = p->rows_per_slice > 0 ? p->rows_per_slice : slice_rows(p->B, p->H, p->ndir, false), sbs = 256 / rows;
     fi.ready = p->ready; fi.nsb = (p->T + sbs - 1) / sbs;
     fi.flags = 16 + ((((p->B + rows - 1) / rows) * p->ndir + 15) & ~15);
     fi.want = (unsigned)p->ready_count;
+  }
+  if (p->rows_per_slice != 0) {
+    const int r = p->rows_per_slice;
+    LAS_REQUIRE(r == 16 || r == 8 || (r == 4 && members(p->H) < 16),
+                "las_lstm_recurrent_fwd_ex: rows_per_slice %d is not a slice height of the %d-unit kernels", r, p->H);
+    fi.rows = r;
   }
   return recurrent_fwd(p->xproj, p->wpacked, p->length, p->y, p->cbuf, p->c_last, p->h_last, p->workspace, p->B, p->T, p->H, p->ndir, stream, fi);
 }

@@ -131,7 +131,7 @@ class LstmFwd(C.Structure):
     _fields_ = [('xproj', _vp), ('wpacked', _vp), ('length', _vp), ('y', _vp), ('cbuf', _vp), ('c_last', _vp), ('h_last', _vp),
                 ('workspace', _vp), ('B', _i32), ('T', _i32), ('H', _i32), ('ndir', _i32),
                 ('x', _vp), ('ldx', _i64), ('x_dir_stride', _i64), ('Dp', _i32), ('reserved0', _i32), ('kx_packed', _vp), ('bias', _vp),
-                ('ready', _vp), ('ready_count', _i32), ('reserved1', _i32)]
+                ('ready', _vp), ('ready_count', _i32), ('rows_per_slice', _i32)]
 
 
 class DecStep(C.Structure):

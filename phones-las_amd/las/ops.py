@@ -184,6 +184,7 @@ FUSED_X = os.environ.get('LAS_LSTM_FUSED_X', '1') != '0'
 STREAM_X = os.environ.get('LAS_LSTM_STREAM', '1') != '0'
 STREAM_512 = os.environ.get('LAS_LSTM_STREAM_512', '0') != '0'      # (diagnostics: stream at 512 units too)
 STREAM_MIN_ROWS = int(os.environ.get('LAS_LSTM_STREAM_MIN_ROWS', '4096'))      # smaller products are not worth the hand-over
+STREAM_ROWS8_MIN_K = int(os.environ.get('LAS_STREAM_ROWS8_MIN_K', str(1 << 30)))      # (diagnostics, see _stream_setup)
 STREAM_MAX_WORKGROUPS = 192       # the recurrence (members + companions, a CU each) must leave CUs to the product beside it
 _PRODUCT_STREAMS = {}
 _ALIASED_STREAMS = []
@@ -335,6 +336,11 @@ def _stream_setup(a, lda, a_dir_stride, weights, xproj, sequence_length, B, T, H
     # counters zeroed here, the product on its own stream (held back a few microseconds so that the chain's workgroups are
     # resident first), the recurrence consumes the rows as they become visible
     rows = lib.las_lstm_slice_rows(B, H, nd)
+    # (LAS_STREAM_ROWS8_MIN_K=k: 8-row chain slices under products with K >= k -- half the chain workgroups, more CUs for the
+    # product.  Measured in round 5, metric-M's layer 2 (K = 1024): 0.523 ms against 0.501 on 4-row slices, the step 6.08 against
+    # 6.05: the product beside the chain is not short of CUs.  Off by default.)
+    if rows == 4 and Dp >= STREAM_ROWS8_MIN_K:
+        rows = 8
     n = lib.las_gemm_nt_stream_flags(B, T, nd, rows)
     ready = weights.__dict__.setdefault('_ready', {}).get((B, T, rows))
     if ready is None:
@@ -356,7 +362,7 @@ def _stream_setup(a, lda, a_dir_stride, weights, xproj, sequence_length, B, T, H
                                                   hip.p(ready), hip.stream()))
             hip.prof_end(tok)
         return side
-    return (ready, 4 * H // 128, launch_product)
+    return (ready, 4 * H // 128, launch_product, rows)
 
 
 def bilstm(inputs, sequence_length, num_units, dropout, mode, unidirectional=False, *, variables=None,
@@ -447,7 +453,7 @@ def bilstm(inputs, sequence_length, num_units, dropout, mode, unidirectional=Fal
         a.kx_packed, a.bias = hip.addr(weights.kxp), hip.addr(weights.bias)
         flops += 2.0 * B * T * nd * Dp * 4 * H                            # x_t K_x of every step as well
     elif stream_ready is not None:
-        a.ready, a.ready_count = hip.addr(stream_ready[0]), stream_ready[1]
+        a.ready, a.ready_count, a.rows_per_slice = hip.addr(stream_ready[0]), stream_ready[1], stream_ready[3]
     tok = hip.prof_begin('lstm_fwd', flops)
     import ctypes
     hip.check(hip.lib().las_lstm_recurrent_fwd_ex(ctypes.byref(a), hip.stream()))
