@@ -220,8 +220,21 @@ __device__ __forceinline__ void lstm_fwd_body(float* __restrict__ xproj, const u
   constexpr int GV = RL >= 2 ? 2 : 1;      // bf16 values per granule: a row pair of one unit, or a single value (4-row slices)
   constexpr int NGRAN = ROWS * HS / GV;    // granules a member publishes per step
   constexpr int NPOLL = (G - 1) * NGRAN;   // granules a member collects per step
-  constexpr int PER = G > 1 ? (NPOLL + 255) / 256 : 1;     // granules a thread polls per step (512 units, 8 rows: 7.5 ->
-                                                           // 8, the threads past the end poll a granule a second time)
+  // WIDE polls (round 5): a thread fetches two ADJACENT granules of a peer with one 16-byte load and checks both epochs -- each
+  // 8-byte half is a granule of its own, written by one 8-byte store, so nothing is assumed about the 16 bytes arriving together.
+  // The load is `global_load_dwordx4 ... sc1` in inline assembly, i.e. granule_load's instruction at twice the width (there is no
+  // 16-byte atomic load to ask the compiler for).  NOT a raw buffer load: `buffer_load_dwordx4 ... sc0 sc1` through a descriptor
+  // kept returning the previous step's granules from this CU's L1 while the 8-byte load of the same address saw the new ones
+  // (scripts/micro/wideload.hip passes -- a lone poller -- the chains timed out: measured, round 5).
+  // Half the polling instructions (256 units, 4 rows: 3 -> 2 per thread; 512 units, 8 rows: 7 -> 4); -DLAS_FWD_NARROW_POLL
+  // builds the one-granule form (A/B).
+#ifdef LAS_FWD_NARROW_POLL
+  constexpr bool WIDEP = false;
+#else
+  constexpr bool WIDEP = G > 1 && NGRAN % 2 == 0 && HS % 2 == 0 && KX == 0;   // (KX > 0 issues x_{s+1} loads between a round and its check)
+#endif
+  constexpr int NPW = WIDEP ? NPOLL / 2 : NPOLL;           // polling units of a member per step (pairs / granules)
+  constexpr int PER = G > 1 ? (NPW + 255) / 256 : 1;       // ... per thread (the threads past the end poll a unit a second time)
   __shared__ __attribute__((aligned(16))) unsigned short hlds[2][16][LS];
   __shared__ int fail_flag;
   __shared__ int colo_flag;
@@ -405,8 +418,8 @@ __device__ __forceinline__ void lstm_fwd_body(float* __restrict__ xproj, const u
   if constexpr (G > 1) {
 #pragma unroll
     for (int i = 0; i < PER; ++i) {
-      const int q = (tid + i * 256) % NPOLL;
-      const int pi = q / NGRAN, gi = q % NGRAN;
+      const int q = (tid + i * 256) % NPW;
+      const int pi = WIDEP ? q / (NGRAN / 2) : q / NGRAN, gi = WIDEP ? 2 * (q % (NGRAN / 2)) : q % NGRAN;   // (WIDEP: the first of the pair)
       const int peer = pi + (pi >= member ? 1 : 0);
       poll_off[i] = (unsigned)(peer * NGRAN + gi) * 8u;                              // bytes inside the group's parity slot
       scat_off[i] = (unsigned)((gi / HS) * (ROWS == 16 ? 2 : 4) * LS + peer * HS + gi % HS);   // (first) row of the granule in the tile
@@ -553,15 +566,49 @@ __device__ __forceinline__ void lstm_fwd_body(float* __restrict__ xproj, const u
       static_assert(PER % CH == 0, "sweep chunking");
 #pragma unroll
       for (int c0 = 0; c0 < PER; c0 += CH) {
-        u64 v[CH];
+        typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+        u64 v[WIDEP ? 1 : CH];
+        u32x4 w[WIDEP ? CH : 1];
+        // a round of wide polls: the loads, then ONE wait for all of them (inline assembly: the compiler does not know these loads
+        // are in flight; nothing else is issued in between -- WIDEP implies KX == 0 -- and older loads have returned by then)
+        // (the slot's address as a scalar pair: where the compiler took it for divergent, the "s" operand came out as a VGPR pair)
+        const u64 src_bits = reinterpret_cast<u64>(src);
+        const char* usrc = reinterpret_cast<const char*>(((u64)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)(src_bits >> 32)) << 32) |
+                                                         (u64)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)src_bits));   // (the builtin returns int)
+        auto wide_round = [&]() {
+#pragma unroll
+          for (int i = 0; i < CH; ++i)
+            asm volatile("global_load_dwordx4 %0, %1, %2 sc1" : "=&v"(w[i]) : "v"(poll_off[c0 + i]), "s"(usrc) : "memory");
+#pragma unroll
+          for (int i = 0; i < CH; ++i) asm volatile("s_waitcnt vmcnt(0)" : "+v"(w[i]) : : "memory");
+        };
         unsigned spins = 0;
         bool ok = true;
+        const unsigned want_tag = base + (unsigned)s;
         // the first polling round is issued, THEN the input products of this step (fused input projection) and the request
         // for x_{s+1}: the MFMAs run while the round is in flight.  One site, unconditional: with the products under the
         // "round came back empty" branch the compiler merged two copies of them through 16 accumulator moves and a
         // vmcnt(0) wait for x_{s+1} INSIDE the polling loop (0.80 against 0.70 ms per 800-step launch).
+        auto poll_round = [&]() {
+          bool all_in = true;
+          if constexpr (WIDEP) {
+            wide_round();
 #pragma unroll
-        for (int i = 0; i < CH; ++i) v[i] = granule_load(reinterpret_cast<const u64*>(src + poll_off[c0 + i]));
+            for (int i = 0; i < CH; ++i) all_in = all_in && (w[i].y == want_tag) && (w[i].w == want_tag);
+          } else {
+#pragma unroll
+            for (int i = 0; i < CH; ++i) v[i] = granule_load(reinterpret_cast<const u64*>(src + poll_off[c0 + i]));
+#pragma unroll
+            for (int i = 0; i < CH; ++i) all_in = all_in && ((unsigned)(v[i] >> 32) == want_tag);
+          }
+          return all_in;
+        };
+        if constexpr (WIDEP) {
+          wide_round();
+        } else {
+#pragma unroll
+          for (int i = 0; i < CH; ++i) v[i] = granule_load(reinterpret_cast<const u64*>(src + poll_off[c0 + i]));
+        }
         if constexpr (KX > 0) {
           if (c0 == 0) {
             __builtin_amdgcn_sched_barrier(0);
@@ -570,23 +617,32 @@ __device__ __forceinline__ void lstm_fwd_body(float* __restrict__ xproj, const u
             __builtin_amdgcn_sched_barrier(0);
           }
         }
+        if constexpr (WIDEP) {
 #pragma unroll
-        for (int i = 0; i < CH; ++i) ok = ok && ((unsigned)(v[i] >> 32) == base + (unsigned)s);
+          for (int i = 0; i < CH; ++i) ok = ok && (w[i].y == want_tag) && (w[i].w == want_tag);
+        } else {
+#pragma unroll
+          for (int i = 0; i < CH; ++i) ok = ok && ((unsigned)(v[i] >> 32) == want_tag);
+        }
         while (!__all(ok)) {                         // wave-uniform loop: every lane re-polls until the whole wave is served
           if (++spins > SPIN_LIMIT) { fail_flag = 1; break; }
           __builtin_amdgcn_s_sleep(1);
-          ok = true;
+          ok = poll_round();
+        }
+        if constexpr (WIDEP) {
 #pragma unroll
           for (int i = 0; i < CH; ++i) {
-            v[i] = granule_load(reinterpret_cast<const u64*>(src + poll_off[c0 + i]));
-            ok = ok && ((unsigned)(v[i] >> 32) == base + (unsigned)s);
+            // two adjacent units of the same row(s): one 32-bit LDS store per row
+            *reinterpret_cast<unsigned*>(&hl[scat_off[c0 + i]]) = (w[i].x & 0xffffu) | (w[i].z << 16);
+            if constexpr (GV == 2) *reinterpret_cast<unsigned*>(&hl[scat_off[c0 + i] + LS]) = (w[i].x >> 16) | (w[i].z & 0xffff0000u);
           }
-        }
+        } else {
 #pragma unroll
-        for (int i = 0; i < CH; ++i) {
-          const unsigned val = (unsigned)v[i];
-          hl[scat_off[c0 + i]] = (unsigned short)(val & 0xffffu);
-          if constexpr (GV == 2) hl[scat_off[c0 + i] + LS] = (unsigned short)(val >> 16);
+          for (int i = 0; i < CH; ++i) {
+            const unsigned val = (unsigned)v[i];
+            hl[scat_off[c0 + i]] = (unsigned short)(val & 0xffffu);
+            if constexpr (GV == 2) hl[scat_off[c0 + i] + LS] = (unsigned short)(val >> 16);
+          }
         }
       }
     }
