@@ -571,14 +571,13 @@ __device__ __forceinline__ void lstm_fwd_body(float* __restrict__ xproj, const u
         u32x4 w[WIDEP ? CH : 1];
         // a round of wide polls: the loads, then ONE wait for all of them (inline assembly: the compiler does not know these loads
         // are in flight; nothing else is issued in between -- WIDEP implies KX == 0 -- and older loads have returned by then)
-        // (the slot's address as a scalar pair: where the compiler took it for divergent, the "s" operand came out as a VGPR pair)
-        const u64 src_bits = reinterpret_cast<u64>(src);
-        const char* usrc = reinterpret_cast<const char*>(((u64)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)(src_bits >> 32)) << 32) |
-                                                         (u64)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)src_bits));   // (the builtin returns int)
         auto wide_round = [&]() {
+          // (a 64-bit VGPR address per load.  The scalar-base form -- voffset + an "s" operand made uniform with readfirstlane -- ran the
+          // dense steps 0.01 us faster and FAULTED on address 0 in the steps of ragged batches, whose loop the compiler treats as
+          // divergent; the same polls written as two 8-byte atomic loads ran there, so the defect is in how that operand is formed.)
 #pragma unroll
           for (int i = 0; i < CH; ++i)
-            asm volatile("global_load_dwordx4 %0, %1, %2 sc1" : "=&v"(w[i]) : "v"(poll_off[c0 + i]), "s"(usrc) : "memory");
+            asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=&v"(w[i]) : "v"(src + poll_off[c0 + i]) : "memory");
 #pragma unroll
           for (int i = 0; i < CH; ++i) asm volatile("s_waitcnt vmcnt(0)" : "+v"(w[i]) : : "memory");
         };
