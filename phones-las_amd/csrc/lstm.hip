@@ -572,6 +572,9 @@ __device__ __forceinline__ void lstm_fwd_body(float* __restrict__ xproj, const u
         // a round of wide polls: the loads, then ONE wait for all of them (inline assembly: the compiler does not know these loads
         // are in flight; nothing else is issued in between -- WIDEP implies KX == 0 -- and older loads have returned by then)
         auto wide_round = [&]() {
+          // The compiler does not know that the destination registers are written later, by the memory system: nothing it emits
+          // between a load and the wait may touch them -- tests/test_wide_poll_isa.py checks the generated assembly of every
+          // instantiation for that (scripts/check_wide_polls.py).
           // (a 64-bit VGPR address per load.  The scalar-base form -- voffset + an "s" operand made uniform with readfirstlane -- ran the
           // dense steps 0.01 us faster and FAULTED on address 0 in the steps of ragged batches, whose loop the compiler treats as
           // divergent; the same polls written as two 8-byte atomic loads ran there, so the defect is in how that operand is formed.)
