@@ -86,6 +86,9 @@ TN_WORKGROUPS = int(os.environ.get('LAS_TN_WGS', '704'))
 # streams; a 512-thread workgroup with 96 KiB of LDS takes a CU
 TN_WORKGROUPS_EXPOSED = int(os.environ.get('LAS_TN_WGS_EXPOSED', '704'))
 TN_WIDE = os.environ.get('LAS_TN_WIDE', '1') != '0'         # (the library reads the same switch: 128 x 512 tiles of the fused product)
+# LAS_TN_WIDE_BESIDE_256=1: the wide tiles also for the 256-unit layers' products that run BESIDE a backward recurrence (A/B; default:
+# square tiles there -- the wide ones cost the chain beside them what they gain themselves -- and wide where the product is exposed)
+TN_WIDE_BESIDE_256 = os.environ.get('LAS_TN_WIDE_BESIDE_256', '0') != '0'
 
 
 class Overlap:
@@ -515,7 +518,8 @@ def bilstm_backward(rec, dy, d_state, grads, need_dx=True, overlap=None, defer_w
         # fused product: about 700 workgroups in flight measured best on MI355X (128 x 128 output tiles, K cut in slices)
         tiles = -(-(Df + H + 1) // 128) * -(-(4 * H) // 128)
         split = max(1, min(32, BT // 512, round((TN_WORKGROUPS_EXPOSED if exposed else TN_WORKGROUPS) / tiles)))
-        if TN_WIDE and (4 * H) % 512 == 0:       # 128 x 512 output tiles (round 5): half the workgroups per K slice, so twice the slices
+        wide = TN_WIDE and (4 * H) % 512 == 0 and (exposed or H >= 512 or TN_WIDE_BESIDE_256)
+        if wide:                                 # 128 x 512 output tiles (round 5): half the workgroups per K slice, so twice the slices
             split = max(1, min(32, BT // 512, 2 * split))
     keepalive = [dz, x, y] + [a for a, _ in (dropped or [])]
 
@@ -542,6 +546,8 @@ def bilstm_backward(rec, dy, d_state, grads, need_dx=True, overlap=None, defer_w
                         if gdst is None:
                             gdst = pads[i] = torch.empty(Df + H, 4 * H, dtype=torch.float32, device=dev)
                         gdst.zero_()
+                    if TN_WIDE and (4 * H) % 512 == 0:
+                        hip.set_knob('LAS_TN_WIDE', 1 if wide else 0)      # (the library picks the tile from this switch at every launch)
                     tok = hip.prof_begin('gemm_tn_lstm', 2.0 * (Df + H + 1) * 4 * H * BT)
                     hip.check(hip.lib().las_gemm_tn_lstm(hip.p(xa) if Df > 0 else None, lda, Df, hip.p(yi), nd * H, H,
                                                          (-1 if i == 0 else 1), T, hip.p(dzi), nd * 4 * H, hip.p(gdst), hip.p(gb),
