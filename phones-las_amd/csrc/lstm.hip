@@ -53,6 +53,12 @@ __device__ __forceinline__ void lds_barrier() {
   __builtin_amdgcn_s_barrier();
 }
 
+// Re-read a flag word in LDS as a ds_read_b32 (a cast to a generic `volatile int*` is compiled into a FLAT load followed by
+// `s_waitcnt vmcnt(0)`; scripts/check_isa.py lists the kernels that have flat instructions).
+__device__ __forceinline__ int lds_flag(int* p) {
+  return *reinterpret_cast<volatile __attribute__((address_space(3))) int*>((__attribute__((address_space(3))) int*)p);
+}
+
 // `local`: every member of the group runs on the SAME XCD (established at kernel start, see xcd_colocated): the
 // XCD's L2 is then the coherence point, so a plain store (line stays in L2) plus the peers' L1-bypassing loads is
 // enough and a poll costs an L2 hit instead of a fabric round trip.  Otherwise the write-through agent-scope store.
@@ -808,7 +814,13 @@ __global__ __launch_bounds__(256) void lstm_fwd_kernel(float* __restrict__ xproj
 // PACK (round 5; 8-row slices without the row split, i.e. two rows per lane): the two rows' partial sums of a tile travel as ONE
 // granule {epoch, bf16 | bf16 << 16} instead of two fp32 granules -- half the exchange instructions on either side; the sums
 // are still formed in fp32 (own partial in fp32 + the peers' bf16-rounded ones).
-template <int H, int ROWS, int G, bool PACK = false>     // ROWS: utterances per slice, G: members, as in lstm_fwd_kernel
+// HW (round 6; "helper waves"): the workgroup has EIGHT waves.  Waves 0-3 walk the chain as before but issue no HBM access of their
+// own any more: waves 4-7 (one beside each chain wave on its SIMD, default priority) load the saved values of the step AFTER
+// next, fold them into the gate-derivative coefficients and leave those in LDS (two slots), and copy the dz rows the chain
+// waves put into the LDS tile out to HBM.  A chain wave's step is then: poll -> seven multiply-adds -> LDS store -> barrier ->
+// products + sends; its vector-memory queue holds granules only.  Same arithmetic in the same order: results are bit-identical
+// to the four-wave form.  The per-step barrier counts all eight waves; the helpers arrive a step's length early.
+template <int H, int ROWS, int G, bool PACK = false, bool HW = false>     // ROWS: utterances per slice, G: members, as in lstm_fwd_kernel
 __device__ __forceinline__ void lstm_bwd_body(const float* __restrict__ gates, const float* __restrict__ cbuf,
                                               const float* __restrict__ dy, const float* __restrict__ dc_last,
                                               const float* __restrict__ dh_last, const unsigned short* __restrict__ kh,
@@ -831,12 +843,16 @@ __device__ __forceinline__ void lstm_bwd_body(const float* __restrict__ gates, c
   static_assert(!PACK || (!SPLIT && RPL == 2 && G > 1), "packed partial sums: two rows per lane, no row split");
   constexpr int RPG = PACK ? 1 : RPL;             // granules per (tile, lane)
   constexpr int PER = G > 1 ? (SPLIT ? G * RPL : (G - 1) * UBW * RPG) : 1;   // granules a lane polls per step
+  static_assert(!HW || (G > 1 && !SPLIT && RPL <= 2), "helper waves: exchanging chains on 4- or 8-row slices");
   __shared__ __attribute__((aligned(16))) unsigned short ztile[2][16][ZS];
   __shared__ int fail_flag;
   __shared__ int colo_flag;
   __shared__ __attribute__((aligned(16))) float pf_scratch[256];
+  // HW: coefficients of a step, [slot][half][row of the lane][chain thread]: {ao, bc, ci, cj} and {cf, gf, dy, -}
+  __shared__ __attribute__((aligned(16))) float4 coef_lds[HW ? 2 : 1][2][HW ? UBW * RPL : 1][HW ? 256 : 1];
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = HW ? (threadIdx.x & 255) : threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const bool helper = HW && threadIdx.x >= 256;          // waves 4-7: wave w + 4 serves chain wave w (same lanes, same rows and units)
   const int gstride = (ngroups + 7) & ~7;
   const int nblk = gstride * G;
   constexpr int CPG = group_companions_g(G);
@@ -875,6 +891,7 @@ __device__ __forceinline__ void lstm_bwd_body(const float* __restrict__ gates, c
 
   if (companion) {
     // PREFETCH COMPANION (see lstm_fwd_kernel): gates, c and dy lines of the whole group, PF_AHEAD steps ahead.
+    if (HW && threadIdx.x >= 256) return;        // (the companion workgroup of the eight-wave form: four waves do the work)
     constexpr int PF_AHEAD = 6;
     const int mylen = (l15 < ROWS && slice * ROWS + l15 < B) ? min(length[slice * ROWS + l15], T) : 0;
     // dz rows t >= length are zero: cleared here (the direction's gate columns), so dense batches need no memset of dz
@@ -930,7 +947,8 @@ __device__ __forceinline__ void lstm_bwd_body(const float* __restrict__ gates, c
     return;
   }
 
-  __builtin_amdgcn_s_setprio(3);           // latency-bound chain: ahead of co-resident GEMM waves in the issue arbitration
+  // latency-bound chain: ahead of co-resident GEMM waves (and of its own helper wave) in the issue arbitration
+  if (!helper) __builtin_amdgcn_s_setprio(3);
 
   // register-resident B fragments: B[k][n] = K_h[n][member's gate columns k]: rows of K_h, contiguous 16-byte pieces
   const unsigned short* khd = kh + (int64_t)dir * H * 4 * H;
@@ -942,9 +960,11 @@ __device__ __forceinline__ void lstm_bwd_body(const float* __restrict__ gates, c
     const int ublk = SPLIT ? blk : blk + j % UBW;
     tile_dest[j] = dest;
     const int n = dest * HS + ublk * 16 + l15;
+    if (!helper) {
 #pragma unroll
-    for (int kc = 0; kc < KCW; ++kc)
-      wf[j][kc] = *reinterpret_cast<const bf16x8*>(khd + (int64_t)n * 4 * H + member * 4 * HS + kc * 32 + 8 * lq);
+      for (int kc = 0; kc < KCW; ++kc)
+        wf[j][kc] = *reinterpret_cast<const bf16x8*>(khd + (int64_t)n * 4 * H + member * 4 * HS + kc * 32 + 8 * lq);
+    }
   }
   constexpr bool W_AGPR = NT * KCW * 4 > 128;       // (see lstm_fwd_kernel: weights beyond 128 registers live in AccVGPRs)
 
@@ -1071,15 +1091,77 @@ __device__ __forceinline__ void lstm_bwd_body(const float* __restrict__ gates, c
   int cur = 0;
   unsigned epoch = 0;          // = iterations done; partial sums sent in iteration i carry tag i+1 in parity slot i&1
   bool ok = true;
-  set_goff(smin > 0 ? smin - 1 : 0);
-  load_general(s_start);
-  prepare();
+  if constexpr (HW) {
+    if (helper) {
+      // HELPER WAVE.  Iteration s runs between the chain's barriers of steps s + 1 and s: coefficients of step s - 1 into slot
+      // (s - 1) & 1 (the chain read that slot's previous content, step s + 1's, before the barrier of step s + 1), the dz rows of
+      // step s + 1 from the tile the chain filled before that barrier (it refills this buffer in step s - 1, behind the barrier
+      // of step s) out to HBM, then the request for step s - 2's saved values, which have the whole step to arrive.
+      auto put_coefs = [&](int slot) {
+#pragma unroll
+        for (int ub = 0; ub < UBW; ++ub)
+#pragma unroll
+          for (int r = 0; r < RPL; ++r) {
+            const Coef k = cf[ub][r];
+            coef_lds[slot][0][ub * RPL + r][tid] = make_float4(k.ao, k.bc, k.ci, k.cj);
+            coef_lds[slot][1][ub * RPL + r][tid] = make_float4(k.cf, k.gf, k.dyv, 0.f);
+          }
+      };
+      auto store_dz = [&](int x) {                   // time step x of this lane's rows: LDS tile -> HBM
+        const unsigned short* zt = &ztile[(s_start - x) & 1][0][0];
+#pragma unroll
+        for (int ub = 0; ub < UBW; ++ub) {
+          const int unit = unit0 + ub * 16;
+#pragma unroll
+          for (int r = 0; r < RPL; ++r)
+            if (x < len[r]) {
+              const uint2 zv = *reinterpret_cast<const uint2*>(zt + (lq * 4 + hh * RPL + r) * ZS + (unit - member * HS) * 4);
+              const int pos = dir == 0 ? x : len[r] - 1 - x;
+              *reinterpret_cast<uint2*>(dz + ((int64_t)bidx[r] * T + pos) * grow + dir * 4 * H + unit * 4) = zv;
+            }
+        }
+      };
+      load_general(s_start);
+      prepare();
+      put_coefs(s_start & 1);
+      load_general(s_start - 1);
+      __syncthreads();
+      for (int s = s_start; s >= 0; --s) {
+        if (s >= 1) {
+          prepare();                                 // from the values requested one iteration ago
+          put_coefs((s - 1) & 1);
+        }
+        if (s < s_start) store_dz(s + 1);
+        if (s >= 2) load_general(s - 2);
+        lds_barrier();
+        if (lds_flag(&fail_flag)) return;
+      }
+      store_dz(0);
+      return;
+    }
+    __syncthreads();                                 // the first step's coefficients are in their slot
+  } else {
+    set_goff(smin > 0 ? smin - 1 : 0);
+    load_general(s_start);
+    prepare();
+  }
   // one time step; LEAN (compile time): every row of the slice is running at step s (and at s - 1: the lean loader).
   // Two instantiations instead of a run-time flag: with both loaders in one body the values they load met in phi copies,
   // i.e. in waits for loads that are not needed before the end of the step.  Returns false when the chain is over.
   auto iter = [&](const int s, auto lean_tag) -> bool {
     constexpr bool lean = decltype(lean_tag)::value;
     LSTM_STAMP(2048, smax - 1 - s, 0);
+    if constexpr (HW) {
+      // this step's coefficients: requested from LDS now, in registers long before the peers' granules are
+#pragma unroll
+      for (int ub = 0; ub < UBW; ++ub)
+#pragma unroll
+        for (int r = 0; r < RPL; ++r) {
+          const float4 a = coef_lds[s & 1][0][ub * RPL + r][tid], b = coef_lds[s & 1][1][ub * RPL + r][tid];
+          cf[ub][r] = Coef{a.x, a.y, a.z, a.w, b.x, b.y, b.z};
+        }
+      __builtin_amdgcn_sched_barrier(0);
+    }
     // ---- dh_s: own partial + the peers' (sent in the previous iteration, i.e. for time step s) ----
     if (epoch > 0) {
       float cand[UBW][RPL];
@@ -1132,8 +1214,10 @@ __device__ __forceinline__ void lstm_bwd_body(const float* __restrict__ gates, c
     // step's dz stores in the in-order vector-memory queue
     unsigned zoff[RPL];
 #pragma unroll
-    for (int r = 0; r < RPL; ++r) zoff[r] = goff[r];
-    if constexpr (lean) {
+    for (int r = 0; r < RPL; ++r) zoff[r] = HW ? 0u : goff[r];
+    if constexpr (HW) {
+      // (the helper wave has them)
+    } else if constexpr (lean) {
       // unconditional (a block under `if (s > 0)` gave the loaded values a home register to be copied into, behind a wait for
       // the load: 0.2 us per step): the last step re-reads its own row, nobody uses what it gets
       const unsigned dec = s > 0 ? (unsigned)gstep : 0u;
@@ -1164,7 +1248,9 @@ __device__ __forceinline__ void lstm_bwd_body(const float* __restrict__ gates, c
           dc[ub][r] = dct * k.gf;
           zv.x = (unsigned)las_f2bf(di) | ((unsigned)las_f2bf(dj) << 16);
           zv.y = (unsigned)las_f2bf(df) | ((unsigned)las_f2bf(dov) << 16);
-          if (lean) *reinterpret_cast<uint2*>(zbase + (zoff[r] >> 1) + ub * 128) = zv;
+          if constexpr (HW) {
+            // (the helper wave copies the row out of the LDS tile)
+          } else if (lean) *reinterpret_cast<uint2*>(zbase + (zoff[r] >> 1) + ub * 128) = zv;
           else {
             const int pos = dir == 0 ? s : len[r] - 1 - s;
             *reinterpret_cast<uint2*>(dz + ((int64_t)bidx[r] * T + pos) * grow + dir * 4 * H + unit * 4) = zv;
@@ -1181,7 +1267,10 @@ __device__ __forceinline__ void lstm_bwd_body(const float* __restrict__ gates, c
     // per step, 512 units: 2.60 -> 2.50).  The single-workgroup chains keep the early test (there the late one costs: 128
     // units 1.26 -> 1.42 us; so does it in the forward kernel, 0.87 -> 0.95: measured, left alone).
     int failed = 0;
-    if constexpr (G > 1) failed = *reinterpret_cast<volatile int*>(&fail_flag);
+    // (HW: a ds_read_b32.  The four-wave form keeps the generic volatile read it has had since round 3 -- compiled into a FLAT load
+    // and a vmcnt(0) wait behind the barrier, which looks like a defect in the ISA and measures FASTER there: 1.02 us per step
+    // against 1.09 with the LDS read, round 6, gpurun_out/r06_lstm_ab.log -- the wait happens to drain the queue at a cheap moment.)
+    if constexpr (G > 1) failed = HW ? lds_flag(&fail_flag) : *reinterpret_cast<volatile int*>(&fail_flag);
     else if (fail_flag) { ok = false; return false; }
     if (s == 0) {                            // dh_{-1} is not needed
       if (failed) ok = false;
@@ -1226,7 +1315,7 @@ __device__ __forceinline__ void lstm_bwd_body(const float* __restrict__ gates, c
     for (int ub = 0; ub < OWN; ++ub)
 #pragma unroll
       for (int r = 0; r < RPL; ++r) part[ub][r] = acc[ub][r];
-    prepare(lean && s == 1);                 // coefficients of step s-1 (its operands were loaded above)
+    if constexpr (!HW) prepare(lean && s == 1);                 // coefficients of step s-1 (its operands were loaded above)
     LSTM_STAMP(2048, smax - 1 - s, 6);
     if constexpr (G == 1) {                  // (see lstm_fwd_kernel: the companion's pace)
       if (tid == 0 && (epoch & 3) == 3) granule_store(ex_group + (int64_t)(epoch & 1) * par_stride, base + epoch + 1, 0u, false);
@@ -1245,15 +1334,15 @@ __device__ __forceinline__ void lstm_bwd_body(const float* __restrict__ gates, c
   if (!ok && tid == 0) atomicOr(status, 2u);
 }
 
-template <int H, int ROWS, int G = coop_members(H), bool PACK = false>
-__global__ __launch_bounds__(256) void lstm_bwd_kernel(const float* __restrict__ gates, const float* __restrict__ cbuf,
+template <int H, int ROWS, int G = coop_members(H), bool PACK = false, bool HW = false>
+__global__ __launch_bounds__(HW ? 512 : 256) void lstm_bwd_kernel(const float* __restrict__ gates, const float* __restrict__ cbuf,
                                                        const float* __restrict__ dy, const float* __restrict__ dc_last,
                                                        const float* __restrict__ dh_last, const unsigned short* __restrict__ kh,
                                                        const int32_t* __restrict__ length, unsigned short* __restrict__ dz,
                                                        u64* __restrict__ exch, unsigned* __restrict__ status,
                                                        int B, int T, int ndir, int ngroups, long long exch_words) {
   const unsigned base = launch_base(status);
-  lstm_bwd_body<H, ROWS, G, PACK>(gates, cbuf, dy, dc_last, dh_last, kh, length, dz, exch, status, B, T, ndir, ngroups, base);
+  lstm_bwd_body<H, ROWS, G, PACK, HW>(gates, cbuf, dy, dc_last, dh_last, kh, length, dz, exch, status, B, T, ndir, ngroups, base);
   launch_arrive(status, base, T, exch, exch_words);
 }
 
@@ -1384,7 +1473,7 @@ int launch_fwd(float* xproj, const las_bf16* wp, const int32_t* length, las_bf16
 #undef LAS_FWD0
 }
 
-template <int H, int ROWS, int G, bool PACK = false>
+template <int H, int ROWS, int G, bool PACK = false, bool HW = false>
 int launch_bwd_as(const float* gates, const float* cbuf, const float* dy, const float* dc_last, const float* dh_last,
                   const las_bf16* kh, const int32_t* length, las_bf16* dz, void* ws, int B, int T, int ndir, hipStream_t st) {
   const CoopGeom g = geom(B, H, ndir, true, ROWS, G);
@@ -1399,13 +1488,14 @@ int launch_bwd_as(const float* gates, const float* cbuf, const float* dy, const 
   static int hog_kb = -1;
   if (hog_kb < 0) {
     constexpr int HS_ = H / G;
-    constexpr int static_kb = (2 * 16 * (4 * HS_ + 8) * 2 + 1024 + 1023) / 1024 + 1;
+    constexpr int coef_bytes = HW ? 2 * 2 * (ROWS / 4) * 256 * 16 : 16;      // the helper waves' coefficient slots
+    constexpr int static_kb = (2 * 16 * (4 * HS_ + 8) * 2 + 1024 + coef_bytes + 1023) / 1024 + 1;
     hog_kb = las_knob("LAS_LSTM_BWD_LDS_KB", 160 - static_kb - 6);
     if (hog_kb > 160 - static_kb - 2) hog_kb = 160 - static_kb - 2;
     if (hog_kb > 0)
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&lstm_bwd_kernel<H, ROWS, G, PACK>), hipFuncAttributeMaxDynamicSharedMemorySize, hog_kb * 1024);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&lstm_bwd_kernel<H, ROWS, G, PACK, HW>), hipFuncAttributeMaxDynamicSharedMemorySize, hog_kb * 1024);
   }
-  hipLaunchKernelGGL((lstm_bwd_kernel<H, ROWS, G, PACK>), dim3(pf ? g.blocks + g.companions : g.blocks), dim3(256), (size_t)(hog_kb > 0 ? hog_kb : 0) * 1024, st,
+  hipLaunchKernelGGL((lstm_bwd_kernel<H, ROWS, G, PACK, HW>), dim3(pf ? g.blocks + g.companions : g.blocks), dim3(HW ? 512 : 256), (size_t)(hog_kb > 0 ? hog_kb : 0) * 1024, st,
                      gates, cbuf, dy, dc_last, dh_last, kh, length, dz, exch, status, B, T, ndir, g.ngroups, exch_words(B, H, ndir));
   LAS_LAUNCH_CHECK("lstm bwd launch");
   return LAS_OK;
@@ -1432,6 +1522,11 @@ int launch_bwd(const float* gates, const float* cbuf, const float* dy, const flo
   }
   constexpr int G0 = coop_members(H);
   if constexpr (H == 256) {
+    // eight-wave form (lstm_bwd_body, HW): helper waves own the HBM side of a step; LAS_LSTM_BWD_HW=0 restores the four-wave form
+    if (las_knob("LAS_LSTM_BWD_HW", 1) != 0) {
+      if (rows == 4) return launch_bwd_as<H, 4, G0, false, true>(gates, cbuf, dy, dc_last, dh_last, kh, length, dz, ws, B, T, ndir, st);
+      if (rows == 8 && pack) return launch_bwd_as<H, 8, G0, true, true>(gates, cbuf, dy, dc_last, dh_last, kh, length, dz, ws, B, T, ndir, st);
+    }
     if (rows == 8 && pack) LAS_BWD_PACKED(G0);
   }
   if (rows == 8) LAS_BWD(8, G0);

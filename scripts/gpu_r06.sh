@@ -1,0 +1,33 @@
+#!/bin/bash
+# Round-6 GPU recipes, one per `gpurun` call:  bash scripts/gpu_r06.sh <recipe> [args]   (output: gpurun_out/r06_<recipe>.log)
+# ab_base/ = a built git worktree of the round-5 tree (git worktree add ab_base <commit>; python phones-las_amd/build.py).
+set -u
+R=${1:-help}; shift || true
+mkdir -p gpurun_out
+LOG=gpurun_out/r06_$R.log
+bench_line() {   # dir, env..., then bench args after --
+  local d=$1; shift
+  local envs=(); while [ "$1" != "--" ]; do envs+=("$1"); shift; done; shift
+  (cd $d && env "${envs[@]}" python bench.py --no-cpu-baseline --steps 30 --warmup 5 "$@" 2>/dev/null | tail -1 |
+     python -c "import sys,json; d=json.loads(sys.stdin.read()); print('$d', '${envs[*]}', d['config']['workload'], d['value'], d['ms_per_step'], d['config'].get('step_form'), d.get('final_loss'))")
+}
+case $R in
+  lstm_ab)      # recurrent kernels alone: round-5 tree, this tree with and without the helper waves; then parity
+    { for rep in 1 2; do
+        (cd ab_base && python scripts/gpu_lstm_time.py 2>&1 | sed 's/^/r05      /')
+        LAS_LSTM_BWD_HW=0 python scripts/gpu_lstm_time.py 2>&1 | sed 's/^/r06 hw=0 /'
+        LAS_LSTM_BWD_HW=1 python scripts/gpu_lstm_time.py 2>&1 | sed 's/^/r06 hw=1 /'
+      done
+      timeout 900 python -m pytest tests/test_gpu_lstm.py -q -x --timeout 300 2>&1 | tail -5
+    } > $LOG 2>&1 ;;
+  bench_ab)     # whole step, interleaved: round-5 tree / this tree (args: bench.py arguments, e.g. --config metric-L)
+    { for rep in 1 2 3; do
+        bench_line ab_base X=0 -- "$@"
+        bench_line . LAS_LSTM_BWD_HW=0 -- "$@"
+        bench_line . LAS_LSTM_BWD_HW=1 -- "$@"
+      done } > $LOG 2>&1 ;;
+  tests)        # the GPU suite
+    timeout 2400 python -m pytest tests -m gpu -q -x --timeout 600 > $LOG 2>&1 ;;
+  *) echo "recipes: lstm_ab bench_ab tests"; exit 2 ;;
+esac
+tail -40 $LOG
