@@ -17,7 +17,9 @@ OBJDIR = os.path.join(HERE, 'build' + ('_' + '_'.join(x.strip('-') for x in EXTR
 
 
 def sources():
-    return sorted(glob.glob(os.path.join(CSRC, '*.hip')))
+    """HIP translation units + the plain C++ host file (csrc/host.cpp: no HIP include, so that it also builds under the
+    sanitizers: tests/test_host_sanitized.py)."""
+    return sorted(glob.glob(os.path.join(CSRC, '*.hip'))) + sorted(glob.glob(os.path.join(CSRC, '*.cpp')))
 
 
 def needs_build():

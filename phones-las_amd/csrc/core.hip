@@ -2,15 +2,6 @@
 #include "las_common.h"
 #include <string.h>
 
-static thread_local char g_err[512] = "";
-
-void las_set_error(const char* fmt, ...) {
-  va_list ap;
-  va_start(ap, fmt);
-  vsnprintf(g_err, sizeof(g_err), fmt, ap);
-  va_end(ap);
-}
-
 int las_check_hip(hipError_t e, const char* what) {
   if (e == hipSuccess) return LAS_OK;
   las_set_error("%s: %s", what, hipGetErrorString(e));
@@ -44,7 +35,6 @@ extern "C" int las_set_knob(const char* name, int value) {
 }
 
 extern "C" int las_version(void) { return 100; }
-extern "C" const char* las_last_error(void) { return g_err; }
 
 namespace {
 
@@ -450,34 +440,3 @@ extern "C" int las_pyramid_lengths_multi(const int32_t* len_in, int32_t* len_out
   return LAS_OK;
 }
 
-// ------------------------------------------------------------------------------------------------
-// Host helper: CRC-32C (Castagnoli) as used by the TFRecord framing (masked crc of length and payload).
-// ------------------------------------------------------------------------------------------------
-extern "C" uint32_t las_crc32c(const void* data, size_t n) {
-  static uint32_t table[8][256];
-  static bool init = false;
-  if (!init) {
-    for (uint32_t i = 0; i < 256; ++i) {
-      uint32_t c = i;
-      for (int k = 0; k < 8; ++k) c = (c & 1) ? (c >> 1) ^ 0x82F63B78u : (c >> 1);
-      table[0][i] = c;
-    }
-    for (uint32_t i = 0; i < 256; ++i)
-      for (int t = 1; t < 8; ++t) table[t][i] = (table[t - 1][i] >> 8) ^ table[0][table[t - 1][i] & 0xff];
-    init = true;
-  }
-  const unsigned char* p = static_cast<const unsigned char*>(data);
-  uint32_t c = 0xffffffffu;
-  while (n >= 8) {
-    uint32_t lo, hi;
-    memcpy(&lo, p, 4);
-    memcpy(&hi, p + 4, 4);
-    lo ^= c;
-    c = table[7][lo & 0xff] ^ table[6][(lo >> 8) & 0xff] ^ table[5][(lo >> 16) & 0xff] ^ table[4][lo >> 24] ^
-        table[3][hi & 0xff] ^ table[2][(hi >> 8) & 0xff] ^ table[1][(hi >> 16) & 0xff] ^ table[0][hi >> 24];
-    p += 8;
-    n -= 8;
-  }
-  while (n--) c = table[0][(c ^ *p++) & 0xff] ^ (c >> 8);
-  return c ^ 0xffffffffu;
-}

@@ -1,10 +1,7 @@
 // Shared device/host helpers for liblas_hip (gfx950 only).
 #pragma once
 #include <hip/hip_runtime.h>
-#include <stdint.h>
-#include <stdio.h>
-#include <stdarg.h>
-#include "../../include/las_hip.h"
+#include "las_host.h"
 
 // One target, stated to the compiler: the fence-free "last workgroup adds up" reductions (optim.hip, decoder.hip)
 // order their relaxed stores with s_waitcnt vmcnt(0) because gfx950 acknowledges sc1 write-through stores at the coherence
@@ -23,19 +20,10 @@ typedef __attribute__((ext_vector_type(4))) unsigned short u16x4;
 
 #define LAS_WAVE 64
 
-void las_set_error(const char* fmt, ...);
 int las_check_hip(hipError_t e, const char* what);
 // Diagnostics / A-B knobs of the host code: integer environment variables READ ONCE, at their first use in the process (core.hip);
 // las_set_knob (the C-ABI's test hook) overrides a value afterwards -- the tests switch slice heights and member counts that way.
 int las_knob(const char* name, int default_value);
-
-#define LAS_REQUIRE(cond, ...)            \
-  do {                                    \
-    if (!(cond)) {                        \
-      las_set_error(__VA_ARGS__);         \
-      return LAS_ERR_ARG;                 \
-    }                                     \
-  } while (0)
 
 #define LAS_LAUNCH_CHECK(what)                                   \
   do {                                                           \

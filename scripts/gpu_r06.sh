@@ -26,8 +26,22 @@ case $R in
         bench_line . LAS_LSTM_BWD_HW=0 -- "$@"
         bench_line . LAS_LSTM_BWD_HW=1 -- "$@"
       done } > $LOG 2>&1 ;;
+  fwd_early)    # forward recurrence with the member's own K chunks multiplied in the shadow of the exchange (EARLY) against the build without
+    NOE=LAS_HIP_LIB=$PWD/phones-las_amd/liblas_hip_noearly.so
+    { for H in 256 512; do for rep in 1 2; do
+        (cd ab_base && H=$H python scripts/gpu_lstm_time.py 2>&1 | grep '^H' | sed 's/^/r05        /')
+        env $NOE H=$H python scripts/gpu_lstm_time.py 2>&1 | grep '^H' | sed 's/^/r06 noearly /'
+        H=$H python scripts/gpu_lstm_time.py 2>&1 | grep '^H' | sed 's/^/r06 early   /'
+      done; done
+      timeout 900 python -m pytest tests/test_gpu_lstm.py tests/test_gpu_golden_shapes.py -q -x --timeout 300 2>&1 | tail -5
+      for cfg in metric-M metric-L; do for rep in 1 2; do
+        bench_line ab_base X=0 -- --config $cfg
+        bench_line . $NOE -- --config $cfg
+        bench_line . X=0 -- --config $cfg
+      done; done
+    } > $LOG 2>&1 ;;
   tests)        # the GPU suite
     timeout 2400 python -m pytest tests -m gpu -q -x --timeout 600 > $LOG 2>&1 ;;
-  *) echo "recipes: lstm_ab bench_ab tests"; exit 2 ;;
+  *) echo "recipes: lstm_ab bench_ab fwd_early tests"; exit 2 ;;
 esac
 tail -40 $LOG
