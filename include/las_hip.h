@@ -10,8 +10,8 @@
  *
  * Conventions
  *   - every pointer is a DEVICE pointer owned by the caller (torch tensors); nothing is
- *     allocated or freed inside the library; scratch comes from a caller-provided workspace
- *     whose size las_workspace_bytes() reports;
+ *     allocated or freed inside the library; scratch comes from caller-provided workspaces
+ *     whose sizes the *_workspace_bytes() / *_ws_bytes() queries next to each entry point report;
  *   - `stream` is a hipStream_t passed as void* (NULL = default stream); calls only enqueue;
  *   - row-major, batch-major [B,T,C] tensors; weights in TF layout: LSTM kernel [D+H, 4H]
  *     with gate column order i, j, f, o and bias [4H] (tf.nn.rnn_cell.LSTMCell, forget_bias 1);

@@ -34,7 +34,9 @@ extern "C" int las_set_knob(const char* name, int value) {
   return LAS_OK;
 }
 
-extern "C" int las_version(void) { return 100; }
+// 101 (round 6): host.cpp split off, the recurrent backward launches eight-wave workgroups at 64 / 128 / 256 units (same entry points,
+// same results); 100 (round 5) removed five entry points and gave las_lstm_fwd::reserved1 a meaning (rows_per_slice).
+extern "C" int las_version(void) { return 101; }
 
 namespace {
 

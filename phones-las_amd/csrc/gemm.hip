@@ -1188,10 +1188,10 @@ static int gemm_nt(const las_bf16* A, int64_t lda, const las_bf16* B, int64_t ld
     if (ring && split_k == 1 && K % 64 == 0 && K >= 128 && M >= 1024 && N >= 128 && (ldc % 4 == 0 || out_bf16)) {
       const bool wide = N >= 256 && N % 256 != 128;
       if (ring == 1) return launch_ring<256, 128, 64, 3, 4>(g, batch, st);
-      if (ring == 4 || (ring >= 5 && !(wide && K > 1024)))
-        return las_knob("LAS_GEMM_PP", 1) == 2 ? launch_ring<256, 128, 32, 3, 4, 8, true>(g, batch, st) : launch_ring<256, 128, 32, 3, 4>(g, batch, st);
-      // LAS_GEMM_PP (round 5): the ping-pong schedule of the ring (the two waves of a SIMD alternate LOAD and MATH segments); 0: off,
-      // 1: the 256 x 256 form, 2: the two-per-CU 256 x 128 form too
+      if (ring == 4 || (ring >= 5 && !(wide && K > 1024))) return launch_ring<256, 128, 32, 3, 4>(g, batch, st);
+      // LAS_GEMM_PP (round 5): the ping-pong schedule of the 256 x 256 ring (the two waves of a SIMD alternate LOAD and MATH
+      // segments: +3-6 % on the K > 1024 shapes); 0: off.  (On the two-per-CU 256 x 128 form it changed nothing -- two workgroups
+      // de-phase each other already -- and that instantiation was removed in round 6.)
       const int pp = las_knob("LAS_GEMM_PP", 1);
       if (wide) return pp ? launch_ring<256, 256, 32, 4, 2, 8, true>(g, batch, st) : launch_ring<256, 256, 32, 4, 2>(g, batch, st);
       return launch_ring<256, 128, 64, 3, 4>(g, batch, st);

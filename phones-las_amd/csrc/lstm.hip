@@ -132,14 +132,14 @@ __device__ bool xcd_colocated(u64* table, int member, int* lds_flag, unsigned* s
 }
 
 // number of cooperating workgroups per chain
-// H <= 128: one workgroup; H = 256: 4 x 64 units; H = 512: 16 x 32 units with the K dimension split over wave pairs; H = 1024 (round 5):
-// 32 x 32 units the same way -- a chain is then a whole XCD (32 CUs), B = 64 fills the chip with its 8 chains: built for completeness
-// (the reference takes any num_units, las/ops.py:10-12), not for speed
-// (a wave's register-resident weight block is 16 units x 4 gates x K/KS: 128 VGPRs in every case)
-__host__ __device__ constexpr int coop_members(int H) { return H <= 128 ? 1 : (H == 256 ? 4 : H / 32); }
-// The kernels take the member count as a template parameter (default: coop_members(H)); H = 512 also runs as 8 members of
-// 64 units (round 3): one 16-unit block per wave over the WHOLE K (256 weight VGPRs of the wave's 512), no K split / row
-// split hand-over inside the workgroup, 7 peers instead of 15 -- the H = 256 code path at twice the K.
+// H <= 128: one workgroup; H = 256: 4 x 64 units; H = 512: 8 x 64 units (round 3: one 16-unit block per wave over the WHOLE K, 256
+// weight registers of the wave's 512, pinned in AccVGPRs -- the H = 256 code path at twice the K; the round-2 form, 16 x 32 units
+// with the K / row split, measured 2.46 against 2.06 us per backward step and was removed in round 6); H = 1024 (round 5): 32 x 32
+// units with the K dimension split over wave pairs (forward) and the rows of a quad split over wave pairs (backward) -- a chain is
+// then a whole XCD (32 CUs), B = 64 fills the chip with its 8 chains: built for completeness (the reference takes any num_units,
+// las/ops.py:10-12), not for speed
+__host__ __device__ constexpr int coop_members(int H) { return H <= 128 ? 1 : (H == 256 ? 4 : (H == 512 ? 8 : H / 32)); }
+// The kernels take the member count as a template parameter (default: coop_members(H)).
 __host__ __device__ constexpr int k_split_g(int H, int G) { return H / G < 64 ? 2 : 1; }
 // prefetch companions per group: one serves four members' columns
 __host__ __device__ constexpr int group_companions_g(int G) { return G >= 4 ? G / 4 : 1; }
@@ -575,20 +575,55 @@ __device__ __forceinline__ void lstm_fwd_body(float* __restrict__ xproj, const u
         typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
         u64 v[WIDEP ? 1 : CH];
         u32x4 w[WIDEP ? CH : 1];
-        // a round of wide polls: the loads, then ONE wait for all of them (inline assembly: the compiler does not know these loads
-        // are in flight; nothing else is issued in between -- WIDEP implies KX == 0 -- and older loads have returned by then)
         auto wide_round = [&]() {
-          // The compiler does not know that the destination registers are written later, by the memory system: nothing it emits
-          // between a load and the wait may touch them -- tests/test_wide_poll_isa.py checks the generated assembly of every
-          // instantiation for that (scripts/check_wide_polls.py).
+          // The loads of a round and the ONE wait behind them are a single asm statement (round 6, ADVICE r5: with a statement per
+          // load and a separate wait the compiler saw a window in which the destination registers looked defined although the
+          // memory system had not written them yet; only a scan of the generated assembly guarded that).
           // (a 64-bit VGPR address per load.  The scalar-base form -- voffset + an "s" operand made uniform with readfirstlane -- ran the
           // dense steps 0.01 us faster and FAULTED on address 0 in the steps of ragged batches, whose loop the compiler treats as
           // divergent; the same polls written as two 8-byte atomic loads ran there, so the defect is in how that operand is formed.)
+          if constexpr (WIDEP) {
+            const char* a[CH];
 #pragma unroll
-          for (int i = 0; i < CH; ++i)
-            asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=&v"(w[i]) : "v"(src + poll_off[c0 + i]) : "memory");
-#pragma unroll
-          for (int i = 0; i < CH; ++i) asm volatile("s_waitcnt vmcnt(0)" : "+v"(w[i]) : : "memory");
+            for (int i = 0; i < CH; ++i) a[i] = src + poll_off[c0 + i];
+#define WPL(o, a) "global_load_dwordx4 %" #o ", %" #a ", off sc1\n\t"
+            // (every load count a thread has per round in the exchanging instantiations: 256 units 2 / 3, 512 units 4 / 7, the
+            // 32-unit-member forms 4 / 8 / 16)
+            if constexpr (CH == 1) {
+              asm volatile(WPL(0, 1) "s_waitcnt vmcnt(0)"
+                           : "=&v"(w[0])
+                           : "v"(a[0]) : "memory");
+            } else if constexpr (CH == 2) {
+              asm volatile(WPL(0, 2) WPL(1, 3) "s_waitcnt vmcnt(0)"
+                           : "=&v"(w[0]), "=&v"(w[1])
+                           : "v"(a[0]), "v"(a[1]) : "memory");
+            } else if constexpr (CH == 3) {
+              asm volatile(WPL(0, 3) WPL(1, 4) WPL(2, 5) "s_waitcnt vmcnt(0)"
+                           : "=&v"(w[0]), "=&v"(w[1]), "=&v"(w[2])
+                           : "v"(a[0]), "v"(a[1]), "v"(a[2]) : "memory");
+            } else if constexpr (CH == 4) {
+              asm volatile(WPL(0, 4) WPL(1, 5) WPL(2, 6) WPL(3, 7) "s_waitcnt vmcnt(0)"
+                           : "=&v"(w[0]), "=&v"(w[1]), "=&v"(w[2]), "=&v"(w[3])
+                           : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]) : "memory");
+            } else if constexpr (CH == 7) {
+              asm volatile(WPL(0, 7) WPL(1, 8) WPL(2, 9) WPL(3, 10) WPL(4, 11) WPL(5, 12) WPL(6, 13) "s_waitcnt vmcnt(0)"
+                           : "=&v"(w[0]), "=&v"(w[1]), "=&v"(w[2]), "=&v"(w[3]), "=&v"(w[4]), "=&v"(w[5]), "=&v"(w[6])
+                           : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(a[4]), "v"(a[5]), "v"(a[6]) : "memory");
+            } else if constexpr (CH == 8) {
+              asm volatile(WPL(0, 8) WPL(1, 9) WPL(2, 10) WPL(3, 11) WPL(4, 12) WPL(5, 13) WPL(6, 14) WPL(7, 15) "s_waitcnt vmcnt(0)"
+                           : "=&v"(w[0]), "=&v"(w[1]), "=&v"(w[2]), "=&v"(w[3]), "=&v"(w[4]), "=&v"(w[5]), "=&v"(w[6]), "=&v"(w[7])
+                           : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(a[4]), "v"(a[5]), "v"(a[6]), "v"(a[7]) : "memory");
+            } else {
+              static_assert(CH == 16, "wide polls: add a statement for this load count");
+              asm volatile(WPL(0, 8) WPL(1, 9) WPL(2, 10) WPL(3, 11) WPL(4, 12) WPL(5, 13) WPL(6, 14) WPL(7, 15) "s_waitcnt vmcnt(0)"
+                           : "=&v"(w[0]), "=&v"(w[1]), "=&v"(w[2]), "=&v"(w[3]), "=&v"(w[4]), "=&v"(w[5]), "=&v"(w[6]), "=&v"(w[7])
+                           : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(a[4]), "v"(a[5]), "v"(a[6]), "v"(a[7]) : "memory");
+              asm volatile(WPL(0, 8) WPL(1, 9) WPL(2, 10) WPL(3, 11) WPL(4, 12) WPL(5, 13) WPL(6, 14) WPL(7, 15) "s_waitcnt vmcnt(0)"
+                           : "=&v"(w[8 + 0]), "=&v"(w[8 + 1]), "=&v"(w[8 + 2]), "=&v"(w[8 + 3]), "=&v"(w[8 + 4]), "=&v"(w[8 + 5]), "=&v"(w[8 + 6]), "=&v"(w[8 + 7])
+                           : "v"(a[8 + 0]), "v"(a[8 + 1]), "v"(a[8 + 2]), "v"(a[8 + 3]), "v"(a[8 + 4]), "v"(a[8 + 5]), "v"(a[8 + 6]), "v"(a[8 + 7]) : "memory");
+            }
+#undef WPL
+          }
         };
         unsigned spins = 0;
         bool ok = true;
@@ -843,7 +878,7 @@ __device__ __forceinline__ void lstm_bwd_body(const float* __restrict__ gates, c
   static_assert(!PACK || (!SPLIT && RPL == 2 && G > 1), "packed partial sums: two rows per lane, no row split");
   constexpr int RPG = PACK ? 1 : RPL;             // granules per (tile, lane)
   constexpr int PER = G > 1 ? (SPLIT ? G * RPL : (G - 1) * UBW * RPG) : 1;   // granules a lane polls per step
-  static_assert(!HW || (G > 1 && !SPLIT && RPL <= 2), "helper waves: exchanging chains on 4- or 8-row slices");
+  static_assert(!HW || (!SPLIT && UBW * RPL <= 4), "helper waves: chains without the row split, at most four (row, unit) pairs per lane");
   __shared__ __attribute__((aligned(16))) unsigned short ztile[2][16][ZS];
   __shared__ int fail_flag;
   __shared__ int colo_flag;
@@ -1348,12 +1383,7 @@ __global__ __launch_bounds__(HW ? 512 : 256) void lstm_bwd_kernel(const float* _
 
 struct CoopGeom { int nslices, ngroups, G, blocks, companions; size_t exch_bytes; };
 
-// members per chain at run time: 512 units run as 8 members of 64 units (default since round 3; LAS_LSTM_G512=16 selects the
-// round-2 form: 16 members of 32 units with the K split / row split inside the workgroup)
-int members(int H) {
-  if (H != 512) return coop_members(H);
-  return las_knob("LAS_LSTM_G512", 8) == 16 ? 16 : 8;
-}
+int members(int H) { return coop_members(H); }
 
 CoopGeom geom(int B, int H, int ndir, bool bwd, int rows = 16, int G = 0) {
   CoopGeom g;
@@ -1434,7 +1464,6 @@ int launch_fwd_as(float* xproj, const las_bf16* wp, const int32_t* length, las_b
 constexpr bool fused_input_units(int H) { return H == 128 || H == 256 || H == 512; }
 int fused_input_chunks(int H, int Dp) {
   if (!fused_input_units(H) || Dp < 8 || Dp % 8 || Dp > 96) return 0;
-  if (H == 512 && members(H) != 8) return 0;       // (the 16-member form splits K over wave pairs)
   return Dp <= 64 ? 2 : 3;
 }
 
@@ -1451,22 +1480,13 @@ int launch_fwd(float* xproj, const las_bf16* wp, const int32_t* length, las_bf16
     return launch_fwd_as<H, R, GG, 0>(xproj, wp, length, y, cbuf, c_last, h_last, ws, B, T, ndir, st, fi);                     \
   } while (0)
 #define LAS_FWD0(R, GG) return launch_fwd_as<H, R, GG, 0>(xproj, wp, length, y, cbuf, c_last, h_last, ws, B, T, ndir, st, fi)
-  if constexpr (H == 512) {
-    if (members(H) == 8) {
-      if (rows == 4) LAS_FWD(4, 8);
-      if (rows == 8) LAS_FWD(8, 8);
-      LAS_FWD(16, 8);
-    }
-  }
   constexpr int G0 = coop_members(H);
-  if constexpr (H == 512) {
+  if constexpr (H == 1024) {            // (32-unit members: K split over wave pairs, no fused input projection, 8- or 16-row slices)
     if (rows == 8) LAS_FWD0(8, G0);
     LAS_FWD0(16, G0);
   } else {
     if (rows == 8) LAS_FWD(8, G0);
-    if constexpr (H <= 256) {
-      if (rows == 4) LAS_FWD(4, G0);
-    }
+    if (rows == 4) LAS_FWD(4, G0);
     LAS_FWD(16, G0);
   }
 #undef LAS_FWD
@@ -1488,7 +1508,7 @@ int launch_bwd_as(const float* gates, const float* cbuf, const float* dy, const 
   static int hog_kb = -1;
   if (hog_kb < 0) {
     constexpr int HS_ = H / G;
-    constexpr int coef_bytes = HW ? 2 * 2 * (ROWS / 4) * 256 * 16 : 16;      // the helper waves' coefficient slots
+    constexpr int coef_bytes = HW ? 2 * 2 * ((HS_ >= 64 ? HS_ / 64 : 1) * (ROWS / 4)) * 256 * 16 : 16;      // the helper waves' coefficient slots
     constexpr int static_kb = (2 * 16 * (4 * HS_ + 8) * 2 + 1024 + coef_bytes + 1023) / 1024 + 1;
     hog_kb = las_knob("LAS_LSTM_BWD_LDS_KB", 160 - static_kb - 6);
     if (hog_kb > 160 - static_kb - 2) hog_kb = 160 - static_kb - 2;
@@ -1505,37 +1525,39 @@ template <int H>
 int launch_bwd(const float* gates, const float* cbuf, const float* dy, const float* dc_last, const float* dh_last,
                const las_bf16* kh, const int32_t* length, las_bf16* dz, void* ws, int B, int T, int ndir, hipStream_t st) {
   const int rows = slice_rows(B, H, ndir, true);
-#define LAS_BWD(R, GG) return launch_bwd_as<H, R, GG>(gates, cbuf, dy, dc_last, dh_last, kh, length, dz, ws, B, T, ndir, st)
-  // On 8-row slices the partial sums travel as bf16 pairs (lstm_bwd_body, PACK; LAS_LSTM_BWD_PACK=0: fp32 granules as before).
-  // Measured (round 5, scripts/gpu_r05_r.sh): 512 units 2.46 -> 2.06 us per step alone, metric-L 17.37 -> 16.67 ms, cfg4 18.69 ->
-  // 18.03; 256 units on 8-row slices (B > 64) 1.52 -> 1.42.  Parity (scripts/gpu_pack_parity.py, 512 units, against the oracle's
-  // bf16 storage model / its exact f64 model): worst listener gradient 1.85e-3 -> 1.92e-3 / 1.166e-2 -> 1.173e-2 of max-abs.
-  const bool pack = las_knob("LAS_LSTM_BWD_PACK", 1) != 0;
-#define LAS_BWD_PACKED(GG) return launch_bwd_as<H, 8, GG, true>(gates, cbuf, dy, dc_last, dh_last, kh, length, dz, ws, B, T, ndir, st)
-  if constexpr (H == 512) {
-    if (members(H) == 8) {
-      if (rows == 4) LAS_BWD(4, 8);
-      if (rows == 8 && pack) LAS_BWD_PACKED(8);
-      if (rows == 8) LAS_BWD(8, 8);
-      LAS_BWD(16, 8);
-    }
-  }
   constexpr int G0 = coop_members(H);
-  if constexpr (H == 256) {
-    // eight-wave form (lstm_bwd_body, HW): helper waves own the HBM side of a step; LAS_LSTM_BWD_HW=0 restores the four-wave form
-    if (las_knob("LAS_LSTM_BWD_HW", 1) != 0) {
-      if (rows == 4) return launch_bwd_as<H, 4, G0, false, true>(gates, cbuf, dy, dc_last, dh_last, kh, length, dz, ws, B, T, ndir, st);
-      if (rows == 8 && pack) return launch_bwd_as<H, 8, G0, true, true>(gates, cbuf, dy, dc_last, dh_last, kh, length, dz, ws, B, T, ndir, st);
+#define LAS_BWD(R, PACK, HW) return launch_bwd_as<H, R, G0, PACK, HW>(gates, cbuf, dy, dc_last, dh_last, kh, length, dz, ws, B, T, ndir, st)
+  // Eight-wave form (lstm_bwd_body, HW; round 6): helper waves own the HBM side of a step.  256 units 1.02 -> 0.88 us per step,
+  // 128 units 1.05 -> 0.96 (profiles/r06_lstm_helper_waves_ab.txt, r06_hw128_ab.txt); not at 64 units (0.60 -> 0.66: a step is
+  // too short for the eight-wave barrier), not at 512 / 1024 (a wave's 256 weight registers leave no room for a second wave on
+  // its SIMD), not on 16-row slices (four (row, unit) pairs per lane: registers).  LAS_LSTM_BWD_HW=0: the four-wave form (A/B).
+  const bool hw = (H == 256 || H == 128) && las_knob("LAS_LSTM_BWD_HW", 1) != 0;
+  if constexpr (H == 256 || H == 512) {
+    // exchanging chains without the row split.  On 8-row slices the partial sums travel as bf16 PAIRS (PACK, round 5: 512 units
+    // 2.46 -> 2.06 us per step, metric-L 17.37 -> 16.67 ms; worst listener gradient against the oracle's bf16 / f64 model
+    // 1.85e-3 -> 1.92e-3 / 1.166e-2 -> 1.173e-2 of max-abs; the fp32-granule form was removed in round 6).
+    if (rows == 4) {
+      if constexpr (H == 256) { if (hw) LAS_BWD(4, false, true); }
+      LAS_BWD(4, false, false);
     }
-    if (rows == 8 && pack) LAS_BWD_PACKED(G0);
+    if (rows == 8) {
+      if constexpr (H == 256) { if (hw) LAS_BWD(8, true, true); }
+      LAS_BWD(8, true, false);
+    }
+    LAS_BWD(16, false, false);
+  } else if constexpr (H == 128) {
+    if (rows == 4) { if (hw) LAS_BWD(4, false, true); LAS_BWD(4, false, false); }
+    if (rows == 8) { if (hw) LAS_BWD(8, false, true); LAS_BWD(8, false, false); }
+    LAS_BWD(16, false, false);
+  } else if constexpr (H == 64) {
+    if (rows == 4) LAS_BWD(4, false, false);
+    if (rows == 8) LAS_BWD(8, false, false);
+    LAS_BWD(16, false, false);
+  } else {                              // 1024 units: 32-unit members, rows of a quad split over wave pairs
+    if (rows == 8) LAS_BWD(8, false, false);
+    LAS_BWD(16, false, false);
   }
-  if (rows == 8) LAS_BWD(8, G0);
-  if constexpr (H <= 256) {
-    if (rows == 4) LAS_BWD(4, G0);
-  }
-  LAS_BWD(16, G0);
 #undef LAS_BWD
-#undef LAS_BWD_PACKED
 }
 
 bool supported_units(int H) { return H == 64 || H == 128 || H == 256 || H == 512 || H == 1024; }
@@ -1556,12 +1578,11 @@ extern "C" int las_lstm_fwd_workgroups(int B, int H, int ndir) {
 extern "C" size_t las_lstm_workspace_bytes(int B, int H, int ndir) {
   if (!supported_units(H) || B <= 0) return 0;
   size_t n = 0;
-  for (int G = (H == 512 ? 8 : coop_members(H)); G <= (H == 512 ? 16 : coop_members(H)); G *= 2)      // every member count the launches may take
-    for (int rows = 4; rows <= 16; rows *= 2)
-      for (int bwd = 0; bwd < 2; ++bwd) {
-        const size_t e = geom(B, H, ndir, bwd != 0, rows, G).exch_bytes;
-        if (e > n) n = e;
-      }
+  for (int rows = 4; rows <= 16; rows *= 2)             // every slice height the launches may take
+    for (int bwd = 0; bwd < 2; ++bwd) {
+      const size_t e = geom(B, H, ndir, bwd != 0, rows).exch_bytes;
+      if (e > n) n = e;
+    }
   return 64 + n;
 }
 

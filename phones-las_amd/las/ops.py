@@ -86,9 +86,6 @@ TN_WORKGROUPS = int(os.environ.get('LAS_TN_WGS', '704'))
 # streams; a 512-thread workgroup with 96 KiB of LDS takes a CU
 TN_WORKGROUPS_EXPOSED = int(os.environ.get('LAS_TN_WGS_EXPOSED', '704'))
 TN_WIDE = os.environ.get('LAS_TN_WIDE', '1') != '0'         # (the library reads the same switch: 128 x 512 tiles of the fused product)
-# LAS_TN_WIDE_BESIDE_256=1: the wide tiles also for the 256-unit layers' products that run BESIDE a backward recurrence (A/B; default:
-# square tiles there -- the wide ones cost the chain beside them what they gain themselves -- and wide where the product is exposed)
-TN_WIDE_BESIDE_256 = os.environ.get('LAS_TN_WIDE_BESIDE_256', '0') != '0'
 
 
 class Overlap:
@@ -114,14 +111,10 @@ class Overlap:
         are resident first -- a chain that finds CUs taken by a GEMM workgroup starts late as a whole (measured: 1.03-1.07
         instead of 0.96-1.00 ms for an 800-step backward launch when the product beside it was dispatched first)."""
         if lane and self.side2 is None:
-            # LAS_SIDE2_PROBE=1: a third stream that is PROBED to run beside the first side stream and the current one (a stream
-            # that lands on the first side stream's hardware queue -- streams share four of them -- runs the two directions'
-            # exposed products one after the other: 77 + 62 us behind the last recurrence of a metric-M step in a dispatch
-            # timeline).  Measured in round 5: side by side the two products take as long as one after the other (they share the
-            # chip: 6.012 against 6.024 ms, within noise), and a process whose main, side, third and product streams hold all four
-            # queues leaves none for RCCL's stream -- so the default stays an unprobed stream.
-            self.side2 = (_stream_beside([self.side, torch.cuda.current_stream()]) if os.environ.get('LAS_SIDE2_PROBE', '0') == '1'
-                          else torch.cuda.Stream())
+            # (an UNPROBED stream: one that is probed to run beside the first side stream -- streams share four hardware queues --
+            # measured the same in round 5, 6.012 against 6.024 ms: side by side the two exposed products take as long as one
+            # after the other, and a process whose streams hold all four queues leaves none for RCCL's)
+            self.side2 = torch.cuda.Stream()
         side = self.side2 if lane else self.side
         if lane:
             self.side2_busy = True
@@ -518,7 +511,7 @@ def bilstm_backward(rec, dy, d_state, grads, need_dx=True, overlap=None, defer_w
         # fused product: about 700 workgroups in flight measured best on MI355X (128 x 128 output tiles, K cut in slices)
         tiles = -(-(Df + H + 1) // 128) * -(-(4 * H) // 128)
         split = max(1, min(32, BT // 512, round((TN_WORKGROUPS_EXPOSED if exposed else TN_WORKGROUPS) / tiles)))
-        wide = TN_WIDE and (4 * H) % 512 == 0 and (exposed or H >= 512 or TN_WIDE_BESIDE_256)
+        wide = TN_WIDE and (4 * H) % 512 == 0 and (exposed or H >= 512)
         if wide:                                 # 128 x 512 output tiles (round 5): half the workgroups per K slice, so twice the slices
             split = max(1, min(32, BT // 512, 2 * split))
     keepalive = [dz, x, y] + [a for a, _ in (dropped or [])]

@@ -142,6 +142,67 @@ def speller_plan(d):
     return [('speller', kind)]
 
 
+def tf_variable_name_map(params):
+    """{product variable name: name of the same tensor in the reference's TF-1 graph}, for a checkpoint importer.  Layouts are
+    identical (kernel [D+H, 4H], gate order i, j, f, o, zero bias with the forget bias added in the cell); only names differ.
+
+    VERIFIED against SURVEY A.1 (the names the reference's graph gives the listener, `las/ops.py:23-46`, `las/model.py:113-141`):
+      pyramidal      listener/bilstm_{l}/{fw,bw}/lstm_cell/X   ->  listener/bilstm_{l}/bidirectional_rnn/{fw,bw}/lstm_cell/X
+      (unidirectional: tf.nn.dynamic_rnn's default scope)      ->  listener/bilstm_{l}/rnn/lstm_cell/X
+      stacked        listener/{fw,bw}/multi_rnn_cell/cell_{l}/lstm_cell/X
+                                                               ->  listener/bidirectional_rnn/{fw,bw}/multi_rnn_cell/cell_{l}/lstm_cell/X
+      (unidirectional)                                         ->  listener/rnn/multi_rnn_cell/cell_{l}/lstm_cell/X
+    The `fw_cell` / `bw_cell` scopes of `las/ops.py:30,33` leave no trace: cells create their variables at their first call, inside
+    the rnn scope.  `ctc_logits/*` is a tf.layers.dense under its own name (`model_helper.py:350`).
+    NOT VERIFIED (TensorFlow is not installed here and the reference ships no checkpoint): the speller.  Its variables are
+    created inside `dynamic_decode`'s `decoder` scope by AttentionWrapper; the values returned for them follow TF-1.15's scoping
+    rules as written in tf.contrib.seq2seq and are marked by UNVERIFIED_TF_NAMES -- an importer must check them against
+    `tf.train.list_variables(checkpoint)` before trusting them."""
+    e, d = params.encoder, params.decoder
+    rnn = 'rnn' if e.unidirectional else 'bidirectional_rnn'
+    out = {}
+    mech = {'luong': 'luong_attention', 'bahdanau': 'bahdanau_attention', 'luong_monotonic': 'luong_monotonic_attention',
+            'bahdanau_monotonic': 'bahdanau_monotonic_attention', 'custom': 'CustomAttention'}[d.attention_type]
+    for name, _, _ in param_layout(params):
+        parts = name.split('/')
+        if parts[0] == 'listener':
+            if e.use_pyramidal:                    # listener/bilstm_l/<dir>/lstm_cell/X
+                mid = [rnn] if e.unidirectional else [rnn, parts[2]]
+                out[name] = '/'.join(parts[:2] + mid + parts[3:])
+            else:                                  # listener/<dir>/multi_rnn_cell/cell_l/lstm_cell/X
+                mid = [rnn] if e.unidirectional else [rnn, parts[1]]
+                out[name] = '/'.join(parts[:1] + mid + parts[2:])
+        elif parts[0] in ('speller', 'speller_binf'):
+            scope, rest = parts[0], parts[1:]
+            if rest[0] == 'memory_layer':          # built with the mechanism, before the decoder scope exists
+                tf_name = [scope, 'memory_layer', rest[1]]
+            elif rest[0] in ('query_layer', 'attention_v', 'attention_score_bias'):
+                tf_name = [scope, 'decoder', 'attention_wrapper', mech] + rest
+            elif rest[0] == 'attention_layer':
+                tf_name = [scope, 'decoder', 'attention_wrapper', 'attention_layer', rest[1]]
+            elif rest[0].startswith('decoder_cell_'):
+                l = int(rest[0].rsplit('_', 1)[1])
+                if d.bottom_only:                  # AttentionMultiCell: cell 0 inside the wrapper, the others as cell_{l-1} of the multi cell
+                    cell = ['attention_multi_cell'] + (['attention_wrapper'] if l == 0 else ['cell_%d' % (l - 1)]) if d.num_layers > 1 \
+                        else ['attention_wrapper']
+                else:
+                    cell = ['attention_wrapper'] + (['multi_rnn_cell', 'cell_%d' % l] if d.num_layers > 1 else [])
+                tf_name = [scope, 'decoder'] + cell + rest[1:]
+            elif rest[0] == 'projection_layer':
+                tf_name = [scope, 'decoder', 'projection_layer'] + rest[1:]
+            else:                                  # target_embedding: tf.get_variable in the speller's own scope
+                tf_name = [scope] + rest
+            out[name] = '/'.join(tf_name)
+        else:                                      # binf2phone, ctc_logits/*
+            out[name] = name
+    return out
+
+
+def UNVERIFIED_TF_NAMES(params):
+    """The entries of tf_variable_name_map() that could not be checked against the reference (see there)."""
+    return sorted(n for n in tf_variable_name_map(params) if n.split('/')[0] in ('speller', 'speller_binf'))
+
+
 def _speller_layout(d, M, scope, kind):
     """param_layout's rows of one decoder; M: the memory depth as atoms (_mem_atoms)."""
     V = d.target_vocab_size

@@ -25,10 +25,22 @@ NAMES = {'forward': 'G:operands+MFMA,G:LDS reduce+z granules,S:wait for z+cell,S
 for which, off in (('forward', 0), ('backward', 256)):
     st = buf.reshape(512, 16)[off:off + U].astype(np.int64)
     names = NAMES[which].split(',')
-    d = np.diff(st[:, :len(names) + 1], axis=1) / 100.0          # 100 MHz ticks -> us
     print('%s: step time (stamp 0 to stamp 0): %.2f us' % (which, np.diff(st[:, 0]).mean() / 100.0))
-    for k, n in enumerate(names[:d.shape[1]]):
-        print('  %-44s %6.2f us  (min %5.2f max %5.2f)' % (n, d[5:-1, k].mean(), d[5:-1, k].min(), d[5:-1, k].max()))
+    # A stamp slot this launch form never writes stays zero, and a difference against it is garbage (round 5 kept a profile with a
+    # phase of -9.6e11 us).  Phases are the differences of consecutive WRITTEN slots; a slot written in some steps only, or
+    # stamps that are not in time order, end the script with an error instead of a number.
+    cols = st[5:-1, :len(names) + 1]
+    written = [k for k in range(cols.shape[1]) if (cols[:, k] != 0).all()]
+    partly = [k for k in range(cols.shape[1]) if k not in written and (cols[:, k] != 0).any()]
+    if partly or len(written) < 2:
+        sys.exit('%s: stamp slots %s were written in some steps only (or fewer than two slots at all)' % (which, partly))
+    d = np.diff(cols[:, written], axis=1) / 100.0            # 100 MHz ticks -> us
+    if (d < 0).any() or (d > 1e4).any():
+        sys.exit('%s: stamps out of time order or more than 10 ms apart' % which)
+    for i in range(d.shape[1]):
+        k = written[i]
+        label = names[k] if written[i + 1] == k + 1 else '%s .. %s' % (names[k], names[written[i + 1] - 1])
+        print('  %-44s %6.2f us  (min %5.2f max %5.2f)' % (label, d[:, i].mean(), d[:, i].min(), d[:, i].max()))
 st = buf.reshape(512, 16)[0:U].astype(np.int64)
 if st[5:, 11].any():
     print('forward G role: operands + resident products %.2f us, streamed chunks %.2f us, partial sums to LDS %.2f us' % (

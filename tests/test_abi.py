@@ -60,12 +60,9 @@ def test_slice_height_policy_and_workspace_sizes(monkeypatch):
     assert l.las_lstm_slice_rows(96, 256, 2) == 4            # 48 x 4 + 48 = 240
     assert l.las_lstm_slice_rows(128, 256, 2) == 8           # 4-row slices would need 320 workgroups
     assert l.las_lstm_slice_rows(512, 256, 2) == 16
-    hip.set_knob('LAS_LSTM_G512', 8)
     assert l.las_lstm_slice_rows(64, 512, 2) == 8            # 512 units as 8 members (round 3): 16 chains x 8 + 32 companions = 160
     assert l.las_lstm_slice_rows(16, 512, 2) == 4            # 8 chains x 8 + 16 = 80
-    hip.set_knob('LAS_LSTM_G512', 16)
-    assert l.las_lstm_slice_rows(64, 512, 2) == 16           # the round-2 form (16 members, K / row split) runs on full tiles
-    hip.set_knob('LAS_LSTM_G512', 8)
+    assert l.las_lstm_slice_rows(64, 1024, 2) == 8           # 32-unit members (K / row split): half or full tiles only
     assert l.las_lstm_slice_rows(8, 128, 2) == 4
     assert l.las_lstm_slice_rows(0, 256, 2) == 0 and l.las_lstm_slice_rows(8, 100, 2) == 0
     hip.set_knob('LAS_LSTM_ROWS', 16)

@@ -166,3 +166,33 @@ def test_exchange_buckets_partition_the_flat_buffer():
     # a split at either end keeps the single bucket
     w = mh.Variables(table, device='cpu')
     assert len(w.split_buckets(0)) == 1 and len(w.split_buckets(5)) == 1
+
+
+def test_tf_variable_name_map_listener_names_follow_survey_a1():
+    """`listener/bilstm_{l}/bidirectional_rnn/{fw,bw}/lstm_cell/{kernel,bias}` are the names the reference's graph gives
+    the pyramidal listener (`las/ops.py:23-46`); the stacked listener and the unidirectional forms by the same TF scoping rules."""
+    from phones_las_amd import model_helper as mh
+    from tests.helpers import make_hparams
+    _, p = make_hparams(L=3, H=16)
+    m = mh.tf_variable_name_map(p)
+    assert set(m) == {n for n, _, _ in mh.param_table(p)}                    # every variable, nothing else
+    assert len(set(m.values())) == len(m)                                     # one-to-one
+    for l in range(3):
+        for d in ('fw', 'bw'):
+            for x in ('kernel', 'bias'):
+                assert m['listener/bilstm_%d/%s/lstm_cell/%s' % (l, d, x)] == 'listener/bilstm_%d/bidirectional_rnn/%s/lstm_cell/%s' % (l, d, x)
+    _, p = make_hparams(L=2, H=16, unidirectional=True)
+    assert mh.tf_variable_name_map(p)['listener/bilstm_1/fw/lstm_cell/kernel'] == 'listener/bilstm_1/rnn/lstm_cell/kernel'
+    _, p = make_hparams(L=2, H=16, pyramidal=False)
+    m = mh.tf_variable_name_map(p)
+    assert m['listener/bw/multi_rnn_cell/cell_1/lstm_cell/bias'] == 'listener/bidirectional_rnn/bw/multi_rnn_cell/cell_1/lstm_cell/bias'
+    _, p = make_hparams(L=2, H=16, pyramidal=False, unidirectional=True)
+    assert mh.tf_variable_name_map(p)['listener/fw/multi_rnn_cell/cell_0/lstm_cell/kernel'] == 'listener/rnn/multi_rnn_cell/cell_0/lstm_cell/kernel'
+    # the speller's names are derived, not verified: they are listed as such, and the listener's are not
+    _, p = make_hparams(L=2, H=16, att='bahdanau', dec_layers=2, ctc=0.3)
+    unv = mh.UNVERIFIED_TF_NAMES(p)
+    assert unv and all(n.startswith('speller') for n in unv)
+    m = mh.tf_variable_name_map(p)
+    assert m['speller/memory_layer/kernel'] == 'speller/memory_layer/kernel'
+    assert m['speller/attention_v'] == 'speller/decoder/attention_wrapper/bahdanau_attention/attention_v'
+    assert m['ctc_logits/kernel'] == 'ctc_logits/kernel'
