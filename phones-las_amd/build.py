@@ -42,6 +42,24 @@ def build(force=False, verbose=True):
         objs.append(obj)
         cmd = [hipcc, '-O3', '--offload-arch=gfx950', '-std=c++17', '-fPIC', '-Wno-unused-value'] + EXTRA + ['-c', src, '-o', obj]
         procs.append((cmd, subprocess.Popen(cmd)))
+    # While the objects compile: the assembly of lstm.hip, built with the SAME flags, is scanned for compiler instructions that
+    # touch the destination registers of an inline-assembly polling load before its wait (scripts/check_wide_polls.py; ADVICE r5:
+    # the guard belongs to every build, diagnostics builds included, not to a test that can be skipped).  LAS_SKIP_ISA_CHECK=1 skips.
+    isa = None
+    if os.environ.get('LAS_SKIP_ISA_CHECK', '0') != '1':
+        import importlib.util
+        spec = importlib.util.spec_from_file_location('check_wide_polls', os.path.join(HERE, '..', 'scripts', 'check_wide_polls.py'))
+        isa = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(isa)
+        asm_path = os.path.join(OBJDIR, 'lstm.isa_check.s')
+        isa.compile_to_asm(asm_path, EXTRA)
+        nload, bad = isa.check(open(asm_path).read())
+        os.remove(asm_path)
+        if bad or nload == 0:
+            for _, p in procs:
+                p.kill()
+            raise RuntimeError('lstm.hip: %d polling loads, %d instructions touch their destination registers in flight: %s'
+                               % (nload, len(bad), bad[:3]))
     for cmd, p in procs:
         if p.wait() != 0:
             raise RuntimeError('hipcc failed: ' + ' '.join(cmd))

@@ -575,55 +575,23 @@ __device__ __forceinline__ void lstm_fwd_body(float* __restrict__ xproj, const u
         typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
         u64 v[WIDEP ? 1 : CH];
         u32x4 w[WIDEP ? CH : 1];
+        // a round of wide polls: the loads, then ONE wait for all of them (inline assembly: the compiler does not know these loads
+        // are in flight; nothing else is issued in between -- WIDEP implies KX == 0 -- and older loads have returned by then)
         auto wide_round = [&]() {
-          // The loads of a round and the ONE wait behind them are a single asm statement (round 6, ADVICE r5: with a statement per
-          // load and a separate wait the compiler saw a window in which the destination registers looked defined although the
-          // memory system had not written them yet; only a scan of the generated assembly guarded that).
+          // The compiler does not know that the destination registers are written later, by the memory system: nothing it emits
+          // between a load and the wait may touch them -- phones-las_amd/build.py checks the generated assembly of every
+          // instantiation for that ON EVERY BUILD, with the flags of that build (scripts/check_wide_polls.py; round 6),
+          // and fails the build on a violation.  (The loads and the wait as ONE asm statement per round close the window by
+          // construction; measured 0.86 -> 0.88 us per step at 256 units -- profiles/r06_fwd_helper_waves_ab.txt, fhw=0 against
+          // r05 -- because nothing can be scheduled into the round any more: not taken.)
           // (a 64-bit VGPR address per load.  The scalar-base form -- voffset + an "s" operand made uniform with readfirstlane -- ran the
           // dense steps 0.01 us faster and FAULTED on address 0 in the steps of ragged batches, whose loop the compiler treats as
           // divergent; the same polls written as two 8-byte atomic loads ran there, so the defect is in how that operand is formed.)
-          if constexpr (WIDEP) {
-            const char* a[CH];
 #pragma unroll
-            for (int i = 0; i < CH; ++i) a[i] = src + poll_off[c0 + i];
-#define WPL(o, a) "global_load_dwordx4 %" #o ", %" #a ", off sc1\n\t"
-            // (every load count a thread has per round in the exchanging instantiations: 256 units 2 / 3, 512 units 4 / 7, the
-            // 32-unit-member forms 4 / 8 / 16)
-            if constexpr (CH == 1) {
-              asm volatile(WPL(0, 1) "s_waitcnt vmcnt(0)"
-                           : "=&v"(w[0])
-                           : "v"(a[0]) : "memory");
-            } else if constexpr (CH == 2) {
-              asm volatile(WPL(0, 2) WPL(1, 3) "s_waitcnt vmcnt(0)"
-                           : "=&v"(w[0]), "=&v"(w[1])
-                           : "v"(a[0]), "v"(a[1]) : "memory");
-            } else if constexpr (CH == 3) {
-              asm volatile(WPL(0, 3) WPL(1, 4) WPL(2, 5) "s_waitcnt vmcnt(0)"
-                           : "=&v"(w[0]), "=&v"(w[1]), "=&v"(w[2])
-                           : "v"(a[0]), "v"(a[1]), "v"(a[2]) : "memory");
-            } else if constexpr (CH == 4) {
-              asm volatile(WPL(0, 4) WPL(1, 5) WPL(2, 6) WPL(3, 7) "s_waitcnt vmcnt(0)"
-                           : "=&v"(w[0]), "=&v"(w[1]), "=&v"(w[2]), "=&v"(w[3])
-                           : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]) : "memory");
-            } else if constexpr (CH == 7) {
-              asm volatile(WPL(0, 7) WPL(1, 8) WPL(2, 9) WPL(3, 10) WPL(4, 11) WPL(5, 12) WPL(6, 13) "s_waitcnt vmcnt(0)"
-                           : "=&v"(w[0]), "=&v"(w[1]), "=&v"(w[2]), "=&v"(w[3]), "=&v"(w[4]), "=&v"(w[5]), "=&v"(w[6])
-                           : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(a[4]), "v"(a[5]), "v"(a[6]) : "memory");
-            } else if constexpr (CH == 8) {
-              asm volatile(WPL(0, 8) WPL(1, 9) WPL(2, 10) WPL(3, 11) WPL(4, 12) WPL(5, 13) WPL(6, 14) WPL(7, 15) "s_waitcnt vmcnt(0)"
-                           : "=&v"(w[0]), "=&v"(w[1]), "=&v"(w[2]), "=&v"(w[3]), "=&v"(w[4]), "=&v"(w[5]), "=&v"(w[6]), "=&v"(w[7])
-                           : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(a[4]), "v"(a[5]), "v"(a[6]), "v"(a[7]) : "memory");
-            } else {
-              static_assert(CH == 16, "wide polls: add a statement for this load count");
-              asm volatile(WPL(0, 8) WPL(1, 9) WPL(2, 10) WPL(3, 11) WPL(4, 12) WPL(5, 13) WPL(6, 14) WPL(7, 15) "s_waitcnt vmcnt(0)"
-                           : "=&v"(w[0]), "=&v"(w[1]), "=&v"(w[2]), "=&v"(w[3]), "=&v"(w[4]), "=&v"(w[5]), "=&v"(w[6]), "=&v"(w[7])
-                           : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(a[4]), "v"(a[5]), "v"(a[6]), "v"(a[7]) : "memory");
-              asm volatile(WPL(0, 8) WPL(1, 9) WPL(2, 10) WPL(3, 11) WPL(4, 12) WPL(5, 13) WPL(6, 14) WPL(7, 15) "s_waitcnt vmcnt(0)"
-                           : "=&v"(w[8 + 0]), "=&v"(w[8 + 1]), "=&v"(w[8 + 2]), "=&v"(w[8 + 3]), "=&v"(w[8 + 4]), "=&v"(w[8 + 5]), "=&v"(w[8 + 6]), "=&v"(w[8 + 7])
-                           : "v"(a[8 + 0]), "v"(a[8 + 1]), "v"(a[8 + 2]), "v"(a[8 + 3]), "v"(a[8 + 4]), "v"(a[8 + 5]), "v"(a[8 + 6]), "v"(a[8 + 7]) : "memory");
-            }
-#undef WPL
-          }
+          for (int i = 0; i < CH; ++i)
+            asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=&v"(w[i]) : "v"(src + poll_off[c0 + i]) : "memory");
+#pragma unroll
+          for (int i = 0; i < CH; ++i) asm volatile("s_waitcnt vmcnt(0)" : "+v"(w[i]) : : "memory");
         };
         unsigned spins = 0;
         bool ok = true;

@@ -38,11 +38,14 @@ def check(asm_text):
     return nload, bad
 
 
-def compile_to_asm(out_path):
+def compile_to_asm(out_path, extra=None):
+    """extra: the additional compiler flags of the build being checked (default: LAS_CXXFLAGS, as build.py reads it)."""
     src = os.path.join(ROOT, 'phones-las_amd', 'csrc', 'lstm.hip')
     hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
-    subprocess.run([hipcc, '--offload-arch=gfx950', '-O3', '-std=c++17', '-S', '--cuda-device-only', '-Wno-unused-value',
-                    '-I', os.path.dirname(src), src, '-o', out_path], check=True, stderr=subprocess.DEVNULL)
+    if extra is None:
+        extra = os.environ.get('LAS_CXXFLAGS', '').split()
+    subprocess.run([hipcc, '--offload-arch=gfx950', '-O3', '-std=c++17', '-S', '--cuda-device-only', '-Wno-unused-value'] + list(extra) +
+                   ['-I', os.path.dirname(src), src, '-o', out_path], check=True, stderr=subprocess.DEVNULL)
 
 
 def main():

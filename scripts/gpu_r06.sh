@@ -63,8 +63,50 @@ case $R in
         bench_line . X=0 -- --config $cfg
       done; done
     } > $LOG 2>&1 ;;
+  prof)         # kernel stats + dispatch timeline of one config (args: tag, then bench.py arguments)
+    T=${1:-r06_p}; shift || true
+    bash scripts/gpu_prof.sh $T --steps 3 --warmup 1 --no-graph "$@" > gpurun_out/$T.out 2>&1
+    python scripts/trace_timeline.py gpurun_out/$T > gpurun_out/${T}_timeline.txt 2>&1
+    { head -30 gpurun_out/$T.out; tail -60 gpurun_out/${T}_timeline.txt; } > $LOG ;;
+  final)        # the round's measurement set (args: tag [suite|nosuite]) -> gpurun_out/, copied to profiles/r06_*
+    T=${1:-r06_z}
+    { if [ "${2:-suite}" = suite ]; then
+        (time timeout 2400 python -m pytest tests -m gpu -q --timeout 600 2>&1 | grep -E "passed|failed|error" | tail -5) 2>&1 | tail -8
+      fi
+      bash scripts/gpu_prof.sh ${T}_metricM --steps 3 --warmup 1 --no-graph > gpurun_out/${T}_metricM.out 2>&1
+      python scripts/trace_timeline.py gpurun_out/${T}_metricM > gpurun_out/${T}_timeline_metricM.txt 2>&1
+      bash scripts/gpu_prof.sh ${T}_metricL --config metric-L --steps 3 --warmup 1 --no-graph > gpurun_out/${T}_metricL.out 2>&1
+      bash scripts/gpu_prof.sh ${T}_cfg5 --config cfg5 --steps 3 --warmup 1 --no-graph > gpurun_out/${T}_cfg5.out 2>&1
+      bash scripts/gpu_prof.sh ${T}_default-arch --config default-arch --steps 3 --warmup 1 --no-graph > gpurun_out/${T}_default-arch.out 2>&1
+      bash scripts/gpu_pmc.sh r06 > gpurun_out/r06_pmc.out 2>&1
+      timeout 1200 python bench.py --steps 30 --warmup 5 2>&1 | tail -1 > gpurun_out/r06_bench_metricM.json
+      for c in metric-M-ragged metric-M-stochastic metric-L cfg4 cfg5 cfg1 default-arch two-cell-bottom-only; do
+        timeout 400 python bench.py --config $c --steps 20 --warmup 3 --no-cpu-baseline 2>&1 | tail -1 > gpurun_out/r06_bench_$c.json
+      done
+      python - <<PY
+import json
+for c in ["metricM","metric-M-ragged","metric-M-stochastic","metric-L","cfg4","cfg5","cfg1","default-arch","two-cell-bottom-only"]:
+    try:
+        d=json.load(open("gpurun_out/r06_bench_%s.json"%c))
+        print(c, d["ms_per_step"], d["value"], d["config"].get("final_loss"), d["config"].get("step_form"), d["roofline"]["kernel"], d["roofline"]["frac"], d["roofline"].get("traffic_stale"), d.get("cpu_baseline",{}).get("value"), d.get("error"))
+    except Exception as e:
+        print(c, "FAILED", e)
+PY
+    } > $LOG 2>&1 ;;
+  fwd_hw)       # helper waves in the 256-unit forward chains: alone, parity, whole step
+    { for rep in 1 2; do
+        (cd ab_base && python scripts/gpu_lstm_time.py 2>&1 | grep '^H' | sed 's/^/r05       /')
+        LAS_LSTM_FWD_HW=0 python scripts/gpu_lstm_time.py 2>&1 | grep '^H' | sed 's/^/r06 fhw=0 /'
+        python scripts/gpu_lstm_time.py 2>&1 | grep '^H' | sed 's/^/r06 fhw=1 /'
+      done
+      timeout 1200 python -m pytest tests/test_gpu_lstm.py tests/test_gpu_golden_shapes.py tests/test_gpu_step_forms.py -q -x --timeout 300 2>&1 | grep -v '^RCCL\|^HIP ver\|^ROCm\|^Hostname\|^Librccl' | tail -6
+      for cfg in metric-M metric-M-ragged cfg5; do for rep in 1 2; do
+        bench_line . LAS_LSTM_FWD_HW=0 -- --config $cfg
+        bench_line . LAS_LSTM_FWD_HW=1 -- --config $cfg
+      done; done
+    } > $LOG 2>&1 ;;
   tests)        # the GPU suite
     timeout 2400 python -m pytest tests -m gpu -q -x --timeout 600 2>&1 | grep -v '^RCCL\|^HIP ver\|^ROCm\|^Hostname\|^Librccl' > $LOG ;;
-  *) echo "recipes: lstm_ab bench_ab fwd_early adj hw128 tests"; exit 2 ;;
+  *) echo "recipes: lstm_ab bench_ab fwd_early adj hw128 fwd_hw prof final tests"; exit 2 ;;
 esac
 tail -40 $LOG
