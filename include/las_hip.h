@@ -142,7 +142,9 @@ int las_gemm_tn_store(const las_bf16* A, int64_t lda, const las_bf16* B, int64_t
  * fp32 in TF column order (g*H+u).  K is cut into split_k slices; with `workspace`
  * (las_gemm_tn_lstm_workspace_bytes, caller-owned, reusable once the stream has passed this call) every slice stores
  * its partial product and a second kernel sums them into the outputs; workspace NULL accumulates with fp32 atomics
- * instead (several times slower at training shapes). */
+ * instead (several times slower at training shapes).  split_k | LAS_TN_SPLIT_WIDE asks for 128 x 512 output tiles (4H a multiple
+ * of 512; half the workgroups per K slice, so callers double the slices) instead of 128 x 256. */
+#define LAS_TN_SPLIT_WIDE 0x10000
 size_t las_gemm_tn_lstm_workspace_bytes(int D, int H, int split_k);
 int las_gemm_tn_lstm(const las_bf16* x, int64_t ldx, int D, const las_bf16* y, int64_t ldy, int H, int a_shift,
                      int period, const las_bf16* dz, int64_t ldz, float* kernel_grad, float* bias_grad, int K,

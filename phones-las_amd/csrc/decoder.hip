@@ -3614,8 +3614,11 @@ __global__ __launch_bounds__(256) void dec_persist_bwd_kernel(las_dec_persist_bw
           for (int i = 0; i < FB; ++i) {
             const int tt = tb + i * P;
             if (tt >= flen) continue;
-            const uint4 v = resident ? *reinterpret_cast<const uint4*>(lkeys + (size_t)(tt - f0) * Hd + u)
-                                     : *reinterpret_cast<const uint4*>(keys + (int64_t)tt * Hd + u);
+            // (an if, and the LDS side through an address-space pointer: as `resident ? *lds : *global` the two met in a generic
+            // pointer and the load was a FLAT one, which waits on both the LDS and the vector-memory counters; round 6)
+            uint4 v;
+            if (resident) v = ld16((lds_cu16)lkeys + (size_t)(tt - f0) * Hd + u);
+            else v = ld16(keys + (int64_t)tt * Hd + u);
             const unsigned short* e = reinterpret_cast<const unsigned short*>(&v);
             const float d = dal[tt];
             float dkv[8] = {d0[i].x, d0[i].y, d0[i].z, d0[i].w, d1[i].x, d1[i].y, d1[i].z, d1[i].w};

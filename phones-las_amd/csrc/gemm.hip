@@ -765,13 +765,16 @@ __global__ __launch_bounds__(NW * 64) void gemm_nt_ring_kernel(GemmArgs g) {
       // published -- the words never change afterwards, so every workgroup of an XCD derives the same list and maps a queue slot
       // to the same tile (lists built while polls could time out in one workgroup and not in another shared one queue
       // index).  A workgroup that does not see all groups in time leaves: the recurrence's bounded wait then flags the launch.
+      // The budget is the recurrence's own (about 0.3 s: 2^18 polls of >= 1 us; round 6, ADVICE r5 -- it was 2^15, some 40 ms, and
+      // a recurrence that started later than that, queued behind other work or short of CUs, found every producer gone and
+      // burnt its whole bounded wait where it used to finish late).
       // Groups whose members are spread over XCDs go to XCD gi % 8 and take the device-wide fence.
       const int ngroups = g.s_nslices * g.s_ndir;
       bool all = true;
       unsigned spins = 0;
       for (int gi = 0; gi < ngroups && all; ++gi)
         while (__hip_atomic_load(g.ready + 16 + gi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
-          if (++spins > (1u << 15)) { all = false; break; }
+          if (++spins > (1u << 18)) { all = false; break; }
           __builtin_amdgcn_s_sleep(8);
         }
       int n = 0;
@@ -1350,6 +1353,10 @@ extern "C" int las_gemm_tn_lstm(const las_bf16* x, int64_t ldx, int D, const las
   LAS_REQUIRE((D == 0 || (x && ldx % 8 == 0 && ((uintptr_t)x % 16 == 0))) && y && dz && kernel_grad && bias_grad && ldy % 8 == 0 &&
                   ldz % 8 == 0 && ((uintptr_t)y % 16 == 0) && ((uintptr_t)dz % 16 == 0),
               "las_gemm_tn_lstm: operands must be 16-byte aligned with strides that are multiples of 8");
+  // the tile shape travels with the call (round 6, ADVICE r5: it used to be a process-global knob the Python layer rewrote before
+  // every launch): LAS_TN_SPLIT_WIDE in split_k asks for 128 x 512 output tiles
+  const bool want_wide = (split_k & LAS_TN_SPLIT_WIDE) != 0;
+  split_k &= LAS_TN_SPLIT_WIDE - 1;
   if (split_k < 1) split_k = 1;
   GemmArgs g{x, dz, kernel_grad, nullptr, ldx, ldz, 4 * (int64_t)H, 0, 0, 0, D + H + 1, 4 * H, K, 0, 1, 1, split_k, a_shift, period, H};
   g.A2 = y;
@@ -1363,8 +1370,9 @@ extern "C" int las_gemm_tn_lstm(const las_bf16* x, int64_t ldx, int D, const las
   }
   const int ring = las_knob("LAS_TN_RING", 1);          // 0: the register-staged 128 x 128 kernel (diagnostics, A/B timing)
   if (ring && g.partial) {
-    // LAS_TN_WIDE (round 5): 128 x 512 output tiles (128 x 64 per wave) where N is a multiple of 512; 0: 128 x 256 everywhere
-    const bool wide = las_knob("LAS_TN_WIDE", 1) != 0 && g.N % 512 == 0;
+    // 128 x 512 output tiles (round 5; 128 x 64 per wave) where the caller asks for them and N is a multiple of 512;
+    // LAS_TN_WIDE=0 (A/B override): 128 x 256 everywhere
+    const bool wide = want_wide && las_knob("LAS_TN_WIDE", 1) != 0 && g.N % 512 == 0;
     static bool attr_ring = false;
     if (!attr_ring) {
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_ring_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize,

@@ -86,6 +86,7 @@ TN_WORKGROUPS = int(os.environ.get('LAS_TN_WGS', '704'))
 # streams; a 512-thread workgroup with 96 KiB of LDS takes a CU
 TN_WORKGROUPS_EXPOSED = int(os.environ.get('LAS_TN_WGS_EXPOSED', '704'))
 TN_WIDE = os.environ.get('LAS_TN_WIDE', '1') != '0'         # (the library reads the same switch: 128 x 512 tiles of the fused product)
+TN_SPLIT_WIDE = 0x10000                                      # LAS_TN_SPLIT_WIDE of las_hip.h: the tile shape travels in split_k
 
 
 class Overlap:
@@ -539,12 +540,10 @@ def bilstm_backward(rec, dy, d_state, grads, need_dx=True, overlap=None, defer_w
                         if gdst is None:
                             gdst = pads[i] = torch.empty(Df + H, 4 * H, dtype=torch.float32, device=dev)
                         gdst.zero_()
-                    if TN_WIDE and (4 * H) % 512 == 0:
-                        hip.set_knob('LAS_TN_WIDE', 1 if wide else 0)      # (the library picks the tile from this switch at every launch)
                     tok = hip.prof_begin('gemm_tn_lstm', 2.0 * (Df + H + 1) * 4 * H * BT)
                     hip.check(hip.lib().las_gemm_tn_lstm(hip.p(xa) if Df > 0 else None, lda, Df, hip.p(yi), nd * H, H,
                                                          (-1 if i == 0 else 1), T, hip.p(dzi), nd * 4 * H, hip.p(gdst), hip.p(gb),
-                                                         BT, split, hip.p(ws), hip.stream()))
+                                                         BT, split | (TN_SPLIT_WIDE if wide else 0), hip.p(ws), hip.stream()))
                     hip.prof_end(tok)
                     if Df != D:
                         gk[:D].add_(gdst[:D])

@@ -105,8 +105,19 @@ PY
         bench_line . LAS_LSTM_FWD_HW=1 -- --config $cfg
       done; done
     } > $LOG 2>&1 ;;
+  dec512)       # the 512-unit Bahdanau decoder alone and metric-L / cfg4 / cfg5 against the round-5 tree (flat loads of the query path removed)
+    { for rep in 1 2; do
+        (cd ab_base && python scripts/gpu_dec512_time.py 2>&1 | tail -3 | sed 's/^/r05 /')
+        python scripts/gpu_dec512_time.py 2>&1 | tail -3 | sed 's/^/r06 /'
+      done
+      timeout 1500 python -m pytest tests/test_gpu_gemm.py tests/test_gpu_model.py tests/test_gpu_golden_shapes.py -q -x --timeout 300 2>&1 | grep -v '^RCCL\|^HIP ver\|^ROCm\|^Hostname\|^Librccl' | tail -6
+      for cfg in metric-L cfg5; do for rep in 1 2; do
+        bench_line ab_base X=0 -- --config $cfg
+        bench_line . X=0 -- --config $cfg
+      done; done
+    } > $LOG 2>&1 ;;
   tests)        # the GPU suite
     timeout 2400 python -m pytest tests -m gpu -q -x --timeout 600 2>&1 | grep -v '^RCCL\|^HIP ver\|^ROCm\|^Hostname\|^Librccl' > $LOG ;;
-  *) echo "recipes: lstm_ab bench_ab fwd_early adj hw128 fwd_hw prof final tests"; exit 2 ;;
+  *) echo "recipes: lstm_ab bench_ab fwd_early adj hw128 fwd_hw dec512 prof final tests"; exit 2 ;;
 esac
 tail -40 $LOG

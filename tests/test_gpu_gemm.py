@@ -181,11 +181,12 @@ def test_bad_arguments_raise():
         hip.gemm_nt(A.cpu(), A, C, 8, 8, 8)     # CPU tensor: no fallback
 
 
-@pytest.mark.parametrize('use_ws', [True, False])
+@pytest.mark.parametrize('use_ws,wide', [(True, False), (True, True), (False, False)])
 @pytest.mark.parametrize('D,H,B,T,shift', [(40, 64, 3, 20, -1), (128, 64, 2, 37, 1), (0, 128, 2, 16, -1), (40, 256, 8, 100, 1)])
-def test_gemm_tn_lstm_fused_weight_gradients(D, H, B, T, shift, use_ws):
+def test_gemm_tn_lstm_fused_weight_gradients(D, H, B, T, shift, use_ws, wide):
     """las_gemm_tn_lstm: dK_x, dK_h (row-shifted h) and db of one LSTM direction in one product, against float64.
-    dz arrives with gate-interleaved columns (u*4+g); outputs are in TF column order (g*H+u)."""
+    dz arrives with gate-interleaved columns (u*4+g); outputs are in TF column order (g*H+u).  wide: the 128 x 512 output tiles,
+    asked for per call through LAS_TN_SPLIT_WIDE in split_k (taken where 4H is a multiple of 512, ignored elsewhere)."""
     from phones_las_amd import hip
     K = B * T
     Dp = max(D, 8)
@@ -211,7 +212,8 @@ def test_gemm_tn_lstm_fused_weight_gradients(D, H, B, T, shift, use_ws):
         assert need == 4 * split * (D + H + 1) * 4 * H
         ws = torch.full((need // 4,), float('nan'), device='cuda')           # every word must be overwritten before use
     hip.check(hip.lib().las_gemm_tn_lstm(hip.p(xd) if D else None, Dp, D, hip.addr(yd, H), 2 * H, H, shift, T,
-                                         hip.addr(dzd, 4 * H), 8 * H, hip.p(gk), hip.p(gb), K, split, hip.p(ws), hip.stream()))
+                                         hip.addr(dzd, 4 * H), 8 * H, hip.p(gk), hip.p(gb), K, split | (0x10000 if wide else 0), hip.p(ws),
+                                         hip.stream()))
     torch.cuda.synchronize()
     _close(gk - 0.5, ref_k)
     _close(gb + 0.25, ref_b)
