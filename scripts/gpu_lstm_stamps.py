@@ -31,8 +31,8 @@ buf = np.zeros(2 * 256 * 8, np.uint64)
 hip.check(lib.las_debug_read_lstm_stamps(buf.ctypes.data, buf.size))
 NAMES = {'forward': ['request x.K_x; poll the peers\' h', 'previous stores + LDS barrier', 'MFMA issue (+ K-split hand-over)', 'wait for product + x; gates; h granules',
                      'HBM stores issued'],
-         'backward': ['poll the partial dh', 'request next step\'s saved values', 'gate derivatives -> dz (LDS + HBM)', 'LDS barrier',
-                      'product + partial-tile granules', 'coefficients of the next step']}
+         'backward': ['poll the partial dh', 'request next step\'s saved values (8-wave form: the helpers do)', 'gate derivatives -> dz (LDS [+ HBM])', 'LDS barrier',
+                      'product + partial-tile granules', 'coefficients of the next step (8-wave form: the helpers do)']}
 for which, off in (('forward', 0), ('backward', 256)):
     st = buf.reshape(512, 8)[off:off + 256].astype(np.int64)
     names = NAMES[which]

@@ -78,6 +78,13 @@ case $R in
       bash scripts/gpu_prof.sh ${T}_metricL --config metric-L --steps 3 --warmup 1 --no-graph > gpurun_out/${T}_metricL.out 2>&1
       bash scripts/gpu_prof.sh ${T}_cfg5 --config cfg5 --steps 3 --warmup 1 --no-graph > gpurun_out/${T}_cfg5.out 2>&1
       bash scripts/gpu_prof.sh ${T}_default-arch --config default-arch --steps 3 --warmup 1 --no-graph > gpurun_out/${T}_default-arch.out 2>&1
+      if [ -f phones-las_amd/liblas_hip_stamps.so ]; then     # diagnostics build: LAS_CXXFLAGS=-DLAS_STAMPS LAS_HIP_LIB=.../liblas_hip_stamps.so python phones-las_amd/build.py
+        { for H in 256 512; do LAS_HIP_LIB=$PWD/phones-las_amd/liblas_hip_stamps.so H=$H python scripts/gpu_lstm_stamps.py 2>&1 | grep -v amdgpu.ids; done
+          echo "--- 256 units, four-wave backward (LAS_LSTM_BWD_HW=0) for comparison"
+          LAS_LSTM_BWD_HW=0 LAS_HIP_LIB=$PWD/phones-las_amd/liblas_hip_stamps.so H=256 python scripts/gpu_lstm_stamps.py 2>&1 | grep -A8 '^backward'
+        } > gpurun_out/r06_lstm_stamps.txt 2>&1
+        LAS_HIP_LIB=$PWD/phones-las_amd/liblas_hip_stamps.so python scripts/gpu_dec_stamps.py > gpurun_out/r06_dec_stamps_metricM.txt 2>&1
+      fi
       bash scripts/gpu_pmc.sh r06 > gpurun_out/r06_pmc.out 2>&1
       timeout 1200 python bench.py --steps 30 --warmup 5 2>&1 | tail -1 > gpurun_out/r06_bench_metricM.json
       for c in metric-M-ragged metric-M-stochastic metric-L cfg4 cfg5 cfg1 default-arch two-cell-bottom-only; do
