@@ -48,6 +48,7 @@ struct GemmArgs {
 
 // Layout of the `ready` buffer shared by las_gemm_nt_stream and the recurrence it feeds (32-bit words, zero before both launches):
 //   [0, 8)                      per-XCD tile queues (next tile index of the XCD's list)
+//   [8]                         the launch's handshake decision (gemm_nt_ring_kernel, STREAM): 1 = XCD-local lists, 2 = spread form
 //   [16, 16 + ngroups)          written by the RECURRENCE at its start: group g = dir * nslices + slice runs on XCD x -> x + 1;
 //                               its members are spread over several XCDs -> LAS_STREAM_SPREAD
 //   [flags, flags + ngroups*nsb) column tiles finished of (group, step block): flags = 16 + ngroups rounded up to 16
@@ -642,21 +643,46 @@ __global__ __launch_bounds__(512) void gemm_tn_ring_kernel(GemmArgs g) {
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
-      if (kt + TR_STAGES - 1 < nk) issue(stage == 0 ? TR_STAGES - 1 : stage - 1);
+      // (TNR_NO_GLDS / TNR_NO_DSREAD / TNR_NO_MFMA: ablation builds for scripts/gpu_tn_ablate.py -- which of the three the loop waits for)
       const lds_u8* as = lds + stage * TR_STAGE_BYTES;
       const lds_u8* bs = as + TR_BK * 256 + (wn >> 1) * TR_BK * 256;       // the 128-column sub-image of this wave's columns
 #pragma unroll
       for (int kk = 0; kk < TR_BK; kk += 16) {
         bf16x8 af[TM], bfr[TN];
+#ifndef TNR_NO_DSREAD
 #pragma unroll
         for (int i = 0; i < TM; ++i) af[i] = frag(as, kk, wm * 2 + i);
 #pragma unroll
         for (int j = 0; j < TN; ++j) bfr[j] = frag(bs, kk, (wn & 1) * 2 + j);
+#else
+#pragma unroll
+        for (int i = 0; i < TM; ++i) { af[i] = __builtin_bit_cast(bf16x8, make_uint4(kt + i, lane, kk, 3)); asm volatile("" : "+v"(af[i])); }
+#pragma unroll
+        for (int j = 0; j < TN; ++j) { bfr[j] = __builtin_bit_cast(bf16x8, make_uint4(kt + j, lane, kk, 5)); asm volatile("" : "+v"(bfr[j])); }
+#endif
+#ifndef TNR_NO_MFMA
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
           for (int j = 0; j < TN; ++j)
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+#else
+#pragma unroll
+        for (int i = 0; i < TM; ++i) asm volatile("" :: "v"(af[i]));
+#pragma unroll
+        for (int j = 0; j < TN; ++j) asm volatile("" :: "v"(bfr[j]));
+#endif
+#if !defined(TNR_NO_GLDS)
+        // the LDS-DMA of stage kt + STAGES - 1 is issued BEHIND the first half's products, not in front of the stage's fragment
+        // reads (round 6): the pieces' issue time -- 60-180 cycles each -- then runs in the shadow of eight MFMAs.  Alone 538 -> 556
+        // TFLOP/s on the metric-L shapes, nothing in the step (profiles/r06_tn_ring_ablation.txt: the same file has what the loop
+        // waits for -- without the MFMAs it takes 64 % of its time, without the LDS-DMA 69 %, without the fragment reads 95 %).
+        if (kk == 0) {
+          __builtin_amdgcn_sched_barrier(0);
+          if (kt + TR_STAGES - 1 < nk) issue(stage == 0 ? TR_STAGES - 1 : stage - 1);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+#endif
       }
       stage = (stage + 1 == TR_STAGES) ? 0 : stage + 1;
     }
@@ -761,27 +787,40 @@ __global__ __launch_bounds__(NW * 64) void gemm_nt_ring_kernel(GemmArgs g) {
     my_xcd = (int)(xcc & 7);
     if (tid == 0) {
       // This XCD's list of chain groups: the groups that PUBLISHED this XCD (workgroup i of a launch does not always land on XCD
-      // i % 8: the dispatcher carries on from where the previous launch stopped).  The list is built only once EVERY group has
-      // published -- the words never change afterwards, so every workgroup of an XCD derives the same list and maps a queue slot
-      // to the same tile (lists built while polls could time out in one workgroup and not in another shared one queue
-      // index).  A workgroup that does not see all groups in time leaves: the recurrence's bounded wait then flags the launch.
-      // The budget is the recurrence's own (about 0.3 s: 2^18 polls of >= 1 us; round 6, ADVICE r5 -- it was 2^15, some 40 ms, and
-      // a recurrence that started later than that, queued behind other work or short of CUs, found every producer gone and
-      // burnt its whole bounded wait where it used to finish late).
-      // Groups whose members are spread over XCDs go to XCD gi % 8 and take the device-wide fence.
+      // i % 8: the dispatcher carries on from where the previous launch stopped).  Every workgroup of an XCD must derive the SAME
+      // list (they share one queue index: ADVICE r4), so the launch takes ONE decision, in word 8 of `ready`:
+      //   1 = every group has published (the words never change afterwards): the XCD-local lists;
+      //   2 = some workgroup waited STREAM_HANDSHAKE_POLLS (a few milliseconds) in vain: every workgroup deals the groups to the
+      //       XCDs round-robin and produces them in the SPREAD form (device-wide release per tile), whether or not the recurrence
+      //       has started.  Round 6: a recurrence that starts late -- queued behind other work, or short of CUs
+      //       BECAUSE the producers that wait for it hold them -- used to find the producers gone (they left after 2^15 polls),
+      //       burn its own bounded wait and have the optimiser step withheld; now the product is simply there when it arrives
+      //       (tests/test_gpu_lstm.py::test_streamed_input_product_whose_chain_starts_late).
+      // The first workgroup to know decides (compare-and-swap); the others follow it.
+      constexpr unsigned STREAM_HANDSHAKE_POLLS = 1u << 12;
+      unsigned* mode_w = g.ready + 8;
       const int ngroups = g.s_nslices * g.s_ndir;
-      bool all = true;
-      unsigned spins = 0;
-      for (int gi = 0; gi < ngroups && all; ++gi)
+      unsigned spins = 0, mode = 0;
+      for (int gi = 0; gi < ngroups && mode == 0; ++gi)
         while (__hip_atomic_load(g.ready + 16 + gi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
-          if (++spins > (1u << 18)) { all = false; break; }
+          mode = __hip_atomic_load(mode_w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (mode != 0) break;
+          if (++spins > STREAM_HANDSHAKE_POLLS) { atomicCAS(mode_w, 0u, 2u); break; }
           __builtin_amdgcn_s_sleep(8);
         }
+      if (mode == 0) {
+        if (spins <= STREAM_HANDSHAKE_POLLS) atomicCAS(mode_w, 0u, 1u);          // saw them all
+        mode = __hip_atomic_load(mode_w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
       int n = 0;
-      for (int gi = 0; gi < ngroups && gi < 256 && all; ++gi) {
-        const unsigned v = __hip_atomic_load(g.ready + 16 + gi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (v == (unsigned)my_xcd + 1u) s_list[n++] = gi;
-        else if (v == LAS_STREAM_SPREAD && (gi & 7) == my_xcd) s_list[n++] = gi | 0x10000;
+      for (int gi = 0; gi < ngroups && gi < 256; ++gi) {
+        if (mode == 1) {
+          const unsigned v = __hip_atomic_load(g.ready + 16 + gi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (v == (unsigned)my_xcd + 1u) s_list[n++] = gi;
+          else if (v == LAS_STREAM_SPREAD && (gi & 7) == my_xcd) s_list[n++] = gi | 0x10000;
+        } else if ((gi & 7) == my_xcd) {
+          s_list[n++] = gi | 0x10000;
+        }
       }
       s_n = n;
     }

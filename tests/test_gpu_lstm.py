@@ -260,6 +260,54 @@ def test_streamed_input_product_matches_the_product_before_the_recurrence(B, T, 
     assert float(((ca - cb) * mask).abs().max()) < 3e-2
 
 
+def test_streamed_input_product_whose_chain_starts_late(monkeypatch):
+    """the streamed producer's workgroups wait for the chain groups to publish their XCDs.  With a budget of 2^15 polls
+    (some 40 ms) a recurrence that started later -- queued behind other work, short of CUs -- found every producer gone, burnt
+    its whole bounded wait and had the optimiser step withheld.  Here the chain's stream is held back 120 ms (las_stream_delay)
+    AFTER the product has been handed to its stream: the producers must still be there (their budget is the chain's own now),
+    the launch must finish clean and give the bits of an undisturbed streamed launch."""
+    from phones_las_amd import hip
+    from phones_las_amd.las import ops
+    monkeypatch.setattr(ops, 'STREAM_MIN_ROWS', 0)
+    monkeypatch.setattr(ops, 'STREAM_X', True)
+    B, T, D, H = 64, 48, 512, 256
+    x, length, var = _setup(B, T, D, H, [T] * B)
+    dvar = {k: v.float().cuda() for k, v in var.items()}
+    xd = (x * 0.25).to(torch.bfloat16).cuda()
+    ld = length.to(torch.int32).cuda()
+
+    def run(delay_us):
+        real = hip.lib().las_lstm_recurrent_fwd_ex
+        calls = []
+
+        def late(p, stream):                       # the recurrence's launch, behind a delay kernel on ITS stream
+            for _ in range(delay_us // 1000):       # (las_stream_delay takes at most 1000 us per launch)
+                hip.check(hip.lib().las_stream_delay(1000, stream))
+            calls.append(1)
+            return real(p, stream)
+        monkeypatch.setattr(hip.lib(), 'las_lstm_recurrent_fwd_ex', late, raising=False)
+        try:
+            tape = []
+            (ofw, obw), _ = ops.bilstm(xd, ld, H, 0.0, ops.TRAIN, variables=dvar, scope='L', tape=tape, in_features=D)
+            torch.cuda.synchronize()
+        finally:
+            monkeypatch.setattr(hip.lib(), 'las_lstm_recurrent_fwd_ex', real, raising=False)
+        assert calls, 'the streamed path launches the recurrence through las_lstm_recurrent_fwd_ex'
+        ops.check_lstm_status(B, H, 2)             # raises on a timeout
+        return ops.concat_outputs((ofw, obw)).float().clone(), tape[0]['gates'].clone()
+
+    y0, g0 = run(0)
+    y1, g1 = run(120000)
+    assert ops.STREAM_X, 'the late start must not have switched streaming off'
+    assert torch.equal(y0, y1) and torch.equal(g0, g1)
+
+
+def test_1024_units_two_chunks_of_chain_groups(monkeypatch):
+    """B = 64 bidirectional at 1024 units is 8 slices x 2 directions x 32 members = 512 chain workgroups -- two
+    chunks of 8 groups, more than the device holds at once; forward and backward against the oracle."""
+    test_bilstm_forward_backward_vs_oracle(64, 5, 16, 1024, [5 - (i * 3) % 5 for i in range(64)], 0, monkeypatch)
+
+
 @pytest.mark.parametrize('mode', ['dropout', 'split'])
 def test_streamed_input_product_with_one_operand_per_direction(mode, monkeypatch):
     """las_gemm_nt_stream_dirs: the streamed product when the two directions read DIFFERENT operands -- the two masked copies of
