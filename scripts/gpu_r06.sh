@@ -130,32 +130,8 @@ PY
           TAG=$f LAS_HIP_LIB=$PWD/phones-las_amd/liblas_hip_tnr_$f.so python scripts/gpu_tn_ablate.py 2>&1 | grep TN
         done
       done } > $LOG 2>&1 ;;
-  lds_pad)      # LDS row padding of the chains' fragment tiles: 16 elements (conflict-free ds_read_b128 groups) against 8 (liblas_hip_pad8.so)
-    P8=LAS_HIP_LIB=$PWD/phones-las_amd/liblas_hip_pad8.so
-    { for H in 256 128 512; do for rep in 1 2; do
-        env $P8 H=$H python scripts/gpu_lstm_time.py 2>&1 | grep '^H' | sed 's/^/pad 8  /'
-        H=$H python scripts/gpu_lstm_time.py 2>&1 | grep '^H' | sed 's/^/pad 16 /'
-      done; done
-      timeout 900 python -m pytest tests/test_gpu_lstm.py -q -x --timeout 600 2>&1 | grep -v '^RCCL\|^HIP ver\|^ROCm\|^Hostname\|^Librccl' | tail -4
-      for cfg in metric-M metric-L default-arch; do for rep in 1 2; do
-        bench_line . $P8 -- --config $cfg
-        bench_line . X=0 -- --config $cfg
-      done; done
-    } > $LOG 2>&1 ;;
-  dec_pad)      # LDS strides of the one-launch decoders' fragment operands (values rows backward, transposed values forward): old library against this one
-    OLD=LAS_HIP_LIB=$PWD/phones-las_amd/liblas_hip_decold.so
-    { for cfg in metric-M metric-L; do for rep in 1 2; do
-        env $OLD CFG=$cfg ATT=$([ $cfg = metric-M ] && echo luong || echo bahdanau) python scripts/gpu_dec512_time.py 2>&1 | tail -2 | sed "s/^/old $cfg /"
-        CFG=$cfg ATT=$([ $cfg = metric-M ] && echo luong || echo bahdanau) python scripts/gpu_dec512_time.py 2>&1 | tail -2 | sed "s/^/new $cfg /"
-      done; done
-      timeout 1500 python -m pytest tests/test_gpu_model.py tests/test_gpu_golden_shapes.py tests/test_gpu_step_forms.py -q -x --timeout 600 2>&1 | grep -v '^RCCL\|^HIP ver\|^ROCm\|^Hostname\|^Librccl' | tail -4
-      for cfg in metric-M metric-L cfg5; do for rep in 1 2; do
-        bench_line . $OLD -- --config $cfg
-        bench_line . X=0 -- --config $cfg
-      done; done
-    } > $LOG 2>&1 ;;
   tests)        # the GPU suite
     timeout 2400 python -m pytest tests -m gpu -q -x --timeout 600 2>&1 | grep -v '^RCCL\|^HIP ver\|^ROCm\|^Hostname\|^Librccl' > $LOG ;;
-  *) echo "recipes: lstm_ab bench_ab fwd_early adj hw128 fwd_hw dec512 tn_ablate lds_pad dec_pad prof final tests"; exit 2 ;;
+  *) echo "recipes: lstm_ab bench_ab fwd_early adj hw128 fwd_hw dec512 tn_ablate prof final tests"; exit 2 ;;
 esac
 tail -40 $LOG
