@@ -679,7 +679,9 @@ def epilogue(rank, world, dt, final_loss, bad_status, eager_step, c, args, confi
     utt_s = c['B'] * world * args.steps / dt
     f_in, f_rec = lstm_gemm_flops_per_utt(c)
     dom = kernels[0]         # the dominant kernel = the family with the largest time per step
-    traffic, traffic_src, traffic_stale = pmc_traffic(dom['family'])
+    # the committed PMC passes are of the default configuration's step: another configuration's kernels (other unit
+    # counts, other shapes) have no counter evidence and say so
+    traffic, traffic_src, traffic_stale = pmc_traffic(dom['family']) if args.config == 'metric-M' else (None, None, None)
     step_tflops = 3 * (f_in + f_rec) * utt_s / world / 1e12
     config = dict(config, final_loss=round(final_loss, 4) if math.isfinite(final_loss) else repr(final_loss))
     out = {
