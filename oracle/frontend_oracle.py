@@ -10,7 +10,13 @@ Two pipelines of the reference:
     quirk) -> optional RMS energy column -> optional Savitzky-Golay deltas (width 9, orders 1 and 2, mode 'interp'),
     interleaved [c0, d c0, dd c0, c1, ...].
 
-PARITY UNPINNED against librosa / TensorFlow themselves (neither is installed).  The building blocks
+  * ``speechpy_features`` — preprocess_all.py:69-130 with ``--backend speechpy`` (round 6): ``speechpy.feature.mfe`` /
+    ``mfcc`` / ``extract_derivative_feature`` of speechpy==2.4 (requirements.txt:19), a third-party dependency that is not
+    under /root/reference and not installed: its published algorithm is restated below FROM KNOWLEDGE OF THAT RELEASE, quirks
+    included (each is named where it is restated).  Anchored on the reference's call sites (preprocess_all.py:73-79, 88-91,
+    122-123) -- the reference holds no test or golden vector for it.
+
+PARITY UNPINNED against librosa / TensorFlow / speechpy themselves (none is installed).  The building blocks
 are pinned in tests/test_oracle_frontend.py against scipy (get_window, fft.dct, savgol_filter, rfft) and torch.stft.
 """
 import numpy as np
@@ -196,4 +202,120 @@ def librosa_features(y, feature_type='mfcc', n_mfcc=13, n_mels=40, window_ms=20,
     if deltas:
         d1, d2 = delta(feats, order=1), delta(feats, order=2)
         feats = np.stack([feats, d1, d2], axis=-1).reshape(feats.shape[0], -1)  # interleaved [c0,dc0,ddc0,c1,...]
+    return feats
+
+
+# ---- speechpy==2.4 (third-party; restated from the published source of that release) ------------------------------
+SPEECHPY_EPS = np.finfo(float).eps
+
+
+def speechpy_zero_handling(x):
+    """speechpy.functions.zero_handling: exact zeros become machine epsilon (so that the log exists)."""
+    return np.where(x == 0, SPEECHPY_EPS, x)
+
+
+def speechpy_stack_frames(sig, sampling_frequency, frame_length, frame_stride):
+    """speechpy.processing.stack_frames(..., filter=ones, zero_padding=False) as speechpy.feature.mfe calls it: frames of
+    round(fs * frame_length) samples every round(fs * frame_stride), rectangular window.  QUIRK kept: numframes =
+    floor((N - L) / stride) -- one frame FEWER than fit (the frame that ends exactly at or before the last sample is dropped)."""
+    sig = np.asarray(sig, dtype=np.float64)
+    L = int(np.round(sampling_frequency * frame_length))
+    stride = float(np.round(sampling_frequency * frame_stride))
+    numframes = int(np.floor((sig.shape[0] - L) / stride))
+    if numframes <= 0:
+        return np.zeros((0, L))
+    idx = np.arange(L)[None, :] + (np.arange(numframes) * stride).astype(np.int32)[:, None]
+    return sig[idx]
+
+
+def speechpy_filterbanks(num_filter, coefficients, sampling_freq, low_freq=None, high_freq=None):
+    """speechpy.feature.filterbanks: [num_filter, coefficients] triangles between HTK-mel-spaced points.  QUIRKS kept:
+    `low_freq = low_freq or 300` -- the low_frequency=0 that mfe passes is falsy, so the bank starts at 300 Hz; the bin of a
+    frequency is floor((coefficients + 1) * f / fs) with coefficients = fft_length / 2 + 1 (the number of rfft bins, not the
+    FFT length), so the bank covers the lower half of the bins only."""
+    high_freq = high_freq or sampling_freq / 2
+    low_freq = low_freq or 300
+    mel = lambda f: 1127.0 * np.log(1.0 + f / 700.0)
+    mels = np.linspace(mel(low_freq), mel(high_freq), num_filter + 2)
+    hertz = 700.0 * (np.exp(mels / 1127.0) - 1.0)
+    freq_index = np.floor((coefficients + 1) * hertz / sampling_freq).astype(int)
+    bank = np.zeros((num_filter, coefficients))
+    for i in range(num_filter):
+        left, middle, right = int(freq_index[i]), int(freq_index[i + 1]), int(freq_index[i + 2])
+        z = np.linspace(left, right, num=right - left + 1)
+        tri = np.zeros(z.shape)                                   # speechpy.functions.triangle
+        up = np.logical_and(left < z, z <= middle)
+        tri[up] = (z[up] - left) / (middle - left) if middle > left else 0.0
+        down = np.logical_and(middle <= z, z < right)
+        tri[down] = (right - z[down]) / (right - middle) if right > middle else 0.0
+        bank[i, left:right + 1] = tri
+    return bank
+
+
+def speechpy_mfe(signal, sampling_frequency, frame_length, frame_stride, num_filters, fft_length):
+    """speechpy.feature.mfe: (filterbank energies [T, num_filters], frame energies [T]); power spectrum = |rfft(frame, n =
+    fft_length)|^2 / fft_length (a frame longer than fft_length is cropped by rfft, a shorter one zero-padded)."""
+    frames = speechpy_stack_frames(signal, sampling_frequency, frame_length, frame_stride)
+    power = np.abs(np.fft.rfft(frames, n=fft_length, axis=-1)) ** 2 / fft_length
+    energy = speechpy_zero_handling(power.sum(axis=1))
+    bank = speechpy_filterbanks(num_filters, power.shape[1], sampling_frequency, 0, sampling_frequency / 2)
+    return speechpy_zero_handling(power @ bank.T), energy
+
+
+def speechpy_mfcc(signal, sampling_frequency, frame_length, frame_stride, num_cepstral, num_filters, fft_length):
+    """speechpy.feature.mfcc (dc_elimination=True): ortho DCT-II of the log filterbank energies, first num_cepstral; the first
+    coefficient REPLACED by the log frame energy."""
+    feat, energy = speechpy_mfe(signal, sampling_frequency, frame_length, frame_stride, num_filters, fft_length)
+    if len(feat) == 0:
+        return np.empty((0, num_cepstral))
+    feat = np.log(feat) @ dct2_matrix(num_cepstral, num_filters, ortho=True).T
+    feat[:, 0] = np.log(energy)
+    return feat
+
+
+def speechpy_derivative(feat, delta_windows=2):
+    """speechpy.processing.derivative_extraction(feat, DeltaWindows=2).  QUIRKS kept: the differences run along the FEATURE axis
+    (axis 1, edge-padded), not along time; and the published loop body is the two lines
+        dif = Range * FEAT[:, offset + Range:offset + Range + cols]
+        - FEAT[:, offset - Range:offset - Range + cols]
+    of which the second is an expression statement of its own (a line break, no backslash): nothing is subtracted, so
+    DIF[c] = (1 * f[c + 1] + 2 * f[c + 2]) / 10.  SPEECHPY_DELTA_SUBTRACTS = True gives the reading the author meant
+    (Range * f[c + R] - f[c - R]); the product's table follows this function, whichever reading it is set to."""
+    rows, cols = feat.shape
+    dif = np.zeros(feat.shape)
+    scale = 0.0
+    pad = np.pad(feat, ((0, 0), (delta_windows, delta_windows)), 'edge')
+    for i in range(delta_windows):
+        r = i + 1
+        d = r * pad[:, delta_windows + r:delta_windows + r + cols]
+        if SPEECHPY_DELTA_SUBTRACTS:
+            d = d - pad[:, delta_windows - r:delta_windows - r + cols]
+        scale += 2 * r ** 2
+        dif += d
+    return dif / scale
+
+
+SPEECHPY_DELTA_SUBTRACTS = False
+
+
+def speechpy_features(y, feature_type='mfcc', n_mfcc=13, n_mels=40, window_ms=20, step_ms=10, energy=False, deltas=False,
+                      sr=SAMPLE_RATE):
+    """preprocess_all.py:69-130 with --backend speechpy.  mfe: log(hstack(filterbank energies, frame energy) + 1e-8) -- the
+    reference assigns `acoustic_features` only under --energy (:77-79), without it the function dies with UnboundLocalError, and so
+    does this one; mfcc: speechpy's mfcc, --energy ignored (:88-91); --deltas: extract_derivative_feature's [T, F, 3] cube
+    reshaped to [T, 3F], i.e. interleaved [c0, d c0, dd c0, c1, ...] (:122-128)."""
+    n_fft = int(window_ms * sr / 1000.0)
+    if feature_type == 'mfe':
+        spec, en = speechpy_mfe(y, sr, window_ms * 1e-3, step_ms * 1e-3, n_mels, n_fft)
+        if not energy:
+            raise UnboundLocalError("local variable 'acoustic_features' referenced before assignment")
+        feats = np.log(np.hstack((spec, en[:, None])) + 1e-8)
+    elif feature_type == 'mfcc':
+        feats = speechpy_mfcc(y, sr, window_ms * 1e-3, step_ms * 1e-3, n_mfcc, n_mels, n_fft)
+    else:
+        raise ValueError('Unexpected features type.')
+    if deltas:
+        d1 = speechpy_derivative(feats)
+        d2 = speechpy_derivative(d1)
+        feats = np.stack([feats, d1, d2], axis=-1).reshape(feats.shape[0], -1)
     return feats

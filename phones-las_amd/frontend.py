@@ -1,12 +1,15 @@
 """Acoustic front-end on the GPU, mirroring the reference's two entry points:
 
-  * ``calculate_acoustic_features(args, waveform)`` — preprocess_all.py:69-130 with ``--backend librosa``
+  * ``calculate_acoustic_features(args, waveform)`` — preprocess_all.py:69-130, ``--backend librosa`` and ``--backend speechpy``
     (feature_type mfcc | mfe, --n_mfcc, --n_mels, --window, --step, --energy, --deltas);
   * ``calculate_mfcc_op(sample_rate, coeffs, window, step, mels)`` — utils/features_utils.py:5-20.
 
 The signal-processing tables (periodic Hann window, DFT twiddles, Slaney / HTK mel bases, DCT-II basis,
 Savitzky-Golay taps) are built here in float64 and handed to the table-driven kernels of csrc/frontend.hip.
-The speechpy backend, the lyon cochlear model and audio decoding are out of scope."""
+The speechpy backend (round 6) runs on the same kernels with speechpy==2.4's tables -- rectangular frames without centering,
+its filterbank, its feature-axis differences -- restated from the published source of that release (requirements.txt:19; the
+package is not under /root/reference): see oracle/frontend_oracle.py for the quirks that are kept.  The lyon cochlear model and
+audio decoding are out of scope."""
 import functools
 
 import numpy as np
@@ -108,18 +111,126 @@ def _tables(kind, n_fft, n_mels, n_out, sr):
     return d
 
 
+# ---- speechpy==2.4 tables (preprocess_all.py:73-79, 88-91, 122-123) ---------------------------------------------------
+def _speechpy_filterbanks(num_filter, coefficients, sampling_freq):
+    """speechpy.feature.filterbanks as speechpy.feature.mfe calls it (low_frequency = 0, high_frequency = fs / 2), [num_filter,
+    coefficients].  Two properties of the published code are kept: `low_freq = low_freq or 300` turns the 0 into 300 Hz, and the
+    bin of a frequency is floor((coefficients + 1) * f / fs) with coefficients = the number of rfft bins."""
+    mel = lambda f: 1127.0 * np.log(1.0 + f / 700.0)
+    hertz = 700.0 * (np.exp(np.linspace(mel(300.0), mel(sampling_freq / 2.0), num_filter + 2) / 1127.0) - 1.0)
+    idx = np.floor((coefficients + 1) * hertz / sampling_freq).astype(int)
+    bank = np.zeros((num_filter, coefficients))
+    for i in range(num_filter):
+        left, middle, right = int(idx[i]), int(idx[i + 1]), int(idx[i + 2])
+        for z in range(left, right + 1):
+            if left < z <= middle:
+                bank[i, z] = (z - left) / (middle - left)
+            elif middle <= z < right:
+                bank[i, z] = (right - z) / (right - middle)
+    return bank
+
+
+# speechpy.processing.derivative_extraction as published: the loop body's second line (`- FEAT[...]`) is a statement of its own,
+# nothing is subtracted.  True: the reading its author meant (Range * f[c + R] - f[c - R]).
+SPEECHPY_DELTA_SUBTRACTS = False
+
+
+def _speechpy_delta_matrix(F):
+    """extract_derivative_feature as ONE matrix: [F, 3F], columns interleaved [c0, d c0, dd c0, c1, ...].  The differences run
+    along the FEATURE axis (edge-padded), DeltaWindows = 2: d f[c] = sum_R R f[c + R] (- f[c - R]) / 10."""
+    M = np.zeros((F, F))
+    for c in range(F):
+        for r in (1, 2):
+            M[min(c + r, F - 1), c] += r / 10.0
+            if SPEECHPY_DELTA_SUBTRACTS:
+                M[max(c - r, 0), c] -= 1.0 / 10.0
+    W = np.zeros((F, 3 * F))
+    W[:, 0::3] = np.eye(F)
+    W[:, 1::3] = M
+    W[:, 2::3] = M @ M
+    return W
+
+
+@functools.lru_cache(maxsize=16)
+def _tables_speechpy(n_fft, frame_len, n_mels, n_cep, sr, subtracts):
+    t = lambda a: torch.tensor(np.ascontiguousarray(a), dtype=torch.float32, device='cuda')
+    bins = n_fft // 2 + 1
+    cos, sin = _twiddles(n_fft)
+    window = np.zeros(n_fft)
+    window[:min(frame_len, n_fft)] = 1.0                         # rectangular; rfft(n = fft_length) crops or zero-pads the frame
+    # power spectrum = |X|^2 / fft_length; one more column sums it: the frame energy
+    mel = np.hstack([_speechpy_filterbanks(n_mels, bins, sr).T, np.ones((bins, 1))]) / n_fft
+    # ortho DCT-II of the log filterbank energies; its first coefficient replaced by the log frame energy (dc_elimination)
+    dct = np.zeros((n_mels + 1, n_cep))
+    dct[:n_mels] = _dct_basis(n_cep, n_mels, ortho=True)
+    dct[:, 0] = 0.0
+    dct[n_mels, 0] = 1.0
+    return {'window': t(window), 'cos': t(cos), 'sin': t(sin), 'mel': t(mel), 'dct': t(dct)}
+
+
+@functools.lru_cache(maxsize=16)
+def _speechpy_delta_table(F, subtracts):
+    return torch.tensor(_speechpy_delta_matrix(F), dtype=torch.float32, device='cuda')
+
+
+def _speechpy_features(args, waveform):
+    """preprocess_all.py:69-130 with --backend speechpy (speechpy.feature.mfe / mfcc / extract_derivative_feature)."""
+    lib, st = hip.lib(), hip.stream()
+    n_fft = int(args.window * SAMPLE_RATE / 1000.0)
+    frame_len = int(np.round(SAMPLE_RATE * (args.window * 1e-3)))
+    stride = int(np.round(SAMPLE_RATE * (args.step * 1e-3)))
+    if args.feature_type == 'mfe' and not args.energy:
+        # preprocess_all.py:77-79: `acoustic_features` is assigned under --energy only; the reference dies here with this error
+        raise UnboundLocalError("local variable 'acoustic_features' referenced before assignment (preprocess_all.py:79: --feature_type mfe "
+                                "--backend speechpy works with --energy only)")
+    wave = _as_wave(waveform)
+    N = wave.numel()
+    frames = int(np.floor((N - frame_len) / float(stride)))      # stack_frames(zero_padding=False): one frame fewer than fit
+    if frames <= 0 or stride <= 0:
+        raise ValueError('signal shorter than two frames')
+    bins = n_fft // 2 + 1
+    tb = _tables_speechpy(n_fft, frame_len, args.n_mels, args.n_mfcc, SAMPLE_RATE, SPEECHPY_DELTA_SUBTRACTS)
+    dev = wave.device
+    spec = torch.empty(frames, bins, device=dev)
+    hip.check(lib.las_fe_stft(hip.p(wave), N, n_fft, stride, 0, 2, hip.p(tb['window']), hip.p(tb['cos']), hip.p(tb['sin']), bins,
+                              hip.p(spec), bins, frames, st))
+    M1 = args.n_mels + 1
+    logmel = torch.empty(frames, M1, device=dev)
+    if args.feature_type == 'mfcc':
+        # log(zero_handling(.)): exact zeros become machine epsilon
+        hip.check(lib.las_fe_matmul(hip.p(spec), bins, hip.p(tb['mel']), M1, hip.p(logmel), M1, frames, M1, bins, 1,
+                                    float(np.finfo(float).eps), st))
+        feats = torch.empty(frames, args.n_mfcc, device=dev)
+        hip.check(lib.las_fe_matmul(hip.p(logmel), M1, hip.p(tb['dct']), args.n_mfcc, hip.p(feats), args.n_mfcc, frames,
+                                    args.n_mfcc, M1, 0, 0.0, st))
+    else:
+        # np.log(hstack(spec, energy) + 1e-8)
+        hip.check(lib.las_fe_matmul(hip.p(spec), bins, hip.p(tb['mel']), M1, hip.p(logmel), M1, frames, M1, bins, 1, 1e-8, st))
+        feats = logmel
+    if args.deltas:
+        F = feats.shape[1]
+        W = _speechpy_delta_table(F, SPEECHPY_DELTA_SUBTRACTS)
+        out = torch.empty(frames, 3 * F, device=dev)
+        hip.check(lib.las_fe_matmul(hip.p(feats), F, hip.p(W), 3 * F, hip.p(out), 3 * F, frames, 3 * F, F, 0, 0.0, st))
+        feats = out
+    return feats
+
+
 def _as_wave(waveform):
     w = torch.as_tensor(waveform, dtype=torch.float32)
     return w.cuda().contiguous() if not w.is_cuda else w.contiguous()
 
 
 def calculate_acoustic_features(args, waveform):
-    """preprocess_all.py:69-130 (librosa backend).  ``args`` needs feature_type, n_mfcc, n_mels, window, step, energy,
-    deltas (backend must be 'librosa').  Returns a CUDA fp32 tensor [T, F]."""
-    if getattr(args, 'backend', 'librosa') != 'librosa':
-        raise ValueError('only --backend librosa is implemented on the HIP path')
+    """preprocess_all.py:69-130.  ``args`` needs feature_type, n_mfcc, n_mels, window, step, energy, deltas and backend
+    ('librosa', the default, or 'speechpy').  Returns a CUDA fp32 tensor [T, F]."""
+    backend = getattr(args, 'backend', 'librosa')
+    if backend not in ('librosa', 'speechpy'):
+        raise ValueError('backend must be librosa or speechpy (got %r)' % (backend,))
     if args.feature_type not in ('mfcc', 'mfe'):
         raise ValueError('Unexpected features type.' if args.feature_type != 'lyon' else 'lyon features are out of scope')
+    if backend == 'speechpy':
+        return _speechpy_features(args, waveform)
     lib, st = hip.lib(), hip.stream()
     n_fft = int(args.window * SAMPLE_RATE / 1000.0)
     hop = int(args.step * SAMPLE_RATE / 1000.0)
@@ -175,8 +286,11 @@ def calculate_acoustic_features_batch(args, waveforms):
     calculate_acoustic_features on every waveform.  Returns a list of CUDA fp32 tensors [T_u, F] (views of one buffer).
     preprocess_all.py:69-130 of the reference runs this chain file by file on the host (librosa); here the utterances of
     a batch share every launch."""
+    if getattr(args, 'backend', 'librosa') == 'speechpy':
+        # (the reference forces n_jobs = 1 for this backend, preprocess_all.py:228-230: utterance by utterance here too)
+        return [calculate_acoustic_features(args, w) for w in waveforms]
     if getattr(args, 'backend', 'librosa') != 'librosa':
-        raise ValueError('only --backend librosa is implemented on the HIP path')
+        raise ValueError('backend must be librosa or speechpy')
     if args.feature_type not in ('mfcc', 'mfe'):
         raise ValueError('Unexpected features type.' if args.feature_type != 'lyon' else 'lyon features are out of scope')
     if not len(waveforms):

@@ -4,9 +4,12 @@
 SequenceExamples (+ vocab.txt, norm.dmp beside it).  Behaviour kept from the reference: per-line try/except skip, norm
 statistics = MEAN of the per-utterance mean / std (quirk B5), vocabulary = most common `top_k` tokens.
 
+--backend speechpy (round 6) runs speechpy==2.4's mfe / mfcc / extract_derivative_feature on the same kernels
+(phones-las_amd/frontend.py; utterance by utterance, as the reference's forced n_jobs = 1, preprocess_all.py:228-230).
+
 Not on this path: audio decoding other than 16 kHz PCM WAV (the reference calls librosa.load),
-the speechpy backend, lyon features, espeak-ng text->IPA: texts whose language column is not 'arpabet'/'ipa' are
-refused for --targets phones / binary_features."""
+lyon features, espeak-ng text->IPA: texts whose language column is not 'arpabet'/'ipa' are refused for --targets phones /
+binary_features."""
 import argparse
 import os
 import sys
@@ -70,6 +73,9 @@ def main(args):
     from phones_las_amd.utils import tfrecord
     from phones_las_amd.utils.features_utils import save_normalization
     out_dir = os.path.dirname(args.output_file)
+    if args.feature_type == 'lyon' or args.backend == 'speechpy':      # preprocess_all.py:228-230
+        print('Forcing n_jobs = 1 for selected configuration.')
+        args.n_jobs = 1
     lines = open(args.input_file, 'r').readlines()
     count = len(lines) - args.start
     if 0 < args.count < len(lines):
