@@ -79,6 +79,13 @@ int las_set_knob(const char* name, int value);
 int las_gemm_nt(const las_bf16* A, int64_t lda, const las_bf16* B, int64_t ldb, void* C, int64_t ldc,
                 const float* bias, int M, int N, int K, int out_bf16, int accumulate, int batch,
                 int64_t sa, int64_t sb, int64_t sc, int split_k, void* stream);
+/* C [M, N] fp32 (=|+=) A [M, K] * W [N, K]^T + bias with the WEIGHT operand handed in as its LAS_IMAGE_PACK_MFMA_B image (dst_rows =
+ * N, dst_cols = K: [N / 16][K / 32][64 lanes][8]): only the activation operand goes through the LDS, a wave fetches its weight
+ * fragments from the image straight into registers.  N a multiple of 256, K of 128.  las_pack_mfma_b_bf16: the image of a
+ * bf16 matrix [N, K] (the model's weights are packed from their fp32 masters by las_refresh_images). */
+int las_pack_mfma_b_bf16(const las_bf16* B, int64_t ldb, int N, int K, las_bf16* image, void* stream);
+int las_gemm_nt_bimg(const las_bf16* A, int64_t lda, const las_bf16* b_image, float* C, int64_t ldc, const float* bias, int M, int N,
+                     int K, int accumulate, void* stream);
 /* The input product of a recurrent layer that runs BESIDE the product (round 4; las_gemm_nt_stream_dirs): C [B*T, N] fp32 = A [B*T, K] * Bm [N, K]^T + bias,
  * row b*T + t = utterance b at time t, the N columns in ndir halves (direction d reads columns [d*N/ndir, (d+1)*N/ndir)).  A
  * 256 x 128 output tile is the rows_per_slice (= las_lstm_slice_rows) utterances of ONE chain group x 256 / rows_per_slice
@@ -170,7 +177,9 @@ int las_cast_bf16(const float* src, int64_t lds, int rows, int cols, las_bf16* d
  *                             dst_rows (multiple of 16) x dst_cols (multiple of 32): [dst_rows / 16][dst_cols / 32][64 lanes][8]
  *                             with lane l = row tile * 16 + (l & 15), columns chunk * 32 + (l >> 4) * 8 + 0..7 -- every
  *                             fragment one contiguous KB (rows 2^k bytes apart all land on one L2 channel otherwise);
- *                             transpose = 1: the image of src^T (src is [cols, rows], row stride lds). */
+ *                             transpose = 1: the image of src^T (src is [cols, rows], row stride lds); perm_h = H: the source's
+ *                             column axis is read through the gate interleaving (index u * 4 + g <- column g * H + u); ldd > 0: the
+ *                             window is the K range [reserved, reserved + dst_cols) of an image whose whole K is ldd. */
 enum las_image_kind { LAS_IMAGE_CAST = 0, LAS_IMAGE_PACK_RECURRENT = 1, LAS_IMAGE_BIAS_INTERLEAVE = 2, LAS_IMAGE_COPY_F32 = 3,
                       LAS_IMAGE_PACK_MFMA_B = 4, LAS_IMAGE_PACK_INPUT = 5 };
 typedef struct las_image_job {

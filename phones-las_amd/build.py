@@ -60,6 +60,16 @@ def build(force=False, verbose=True):
                 p.kill()
             raise RuntimeError('lstm.hip: %d polling loads, %d instructions touch their destination registers in flight: %s'
                                % (nload, len(bad), bad[:3]))
+        # ... and gemm.hip's las_gemm_nt_bimg kernels: hand-counted fragment loads (check_fragment_loads)
+        asm_path = os.path.join(OBJDIR, 'gemm.isa_check.s')
+        isa.compile_to_asm(asm_path, EXTRA, name='gemm.hip')
+        nk, nfrag, gbad = isa.check_fragment_loads(open(asm_path).read())
+        os.remove(asm_path)
+        if gbad or nk == 0:
+            for _, p in procs:
+                p.kill()
+            raise RuntimeError('gemm.hip: %d image-GEMM kernels, %d fragment loads, %d instructions touch a fragment in flight: %s'
+                               % (nk, nfrag, len(gbad), gbad[:3]))
     for cmd, p in procs:
         if p.wait() != 0:
             raise RuntimeError('hipcc failed: ' + ' '.join(cmd))

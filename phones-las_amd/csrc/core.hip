@@ -36,7 +36,7 @@ extern "C" int las_set_knob(const char* name, int value) {
 
 // 101 (round 6): host.cpp split off, the recurrent backward launches eight-wave workgroups at 64 / 128 / 256 units (same entry points,
 // same results); 100 (round 5) removed five entry points and gave las_lstm_fwd::reserved1 a meaning (rows_per_slice).
-extern "C" int las_version(void) { return 101; }
+extern "C" int las_version(void) { return 102; }
 
 namespace {
 
@@ -91,15 +91,22 @@ __global__ __launch_bounds__(256) void refresh_images_kernel(const las_image_job
   } else if (jb.kind == LAS_IMAGE_PACK_MFMA_B) {
     // [dst_rows / 16 column tiles][dst_cols / 32 K chunks][64 lanes][8]: lane l of a fragment holds row tile * 16 + (l & 15),
     // columns chunk * 32 + (l >> 4) * 8 + 0..7 of the source -- the B operand of v_mfma_f32_16x16x32_bf16 as one contiguous KB
+    // (round 6, the weight images of las_gemm_nt_bimg: this window may be a K RANGE of a wider image -- ldd = the image's whole K,
+    //  reserved = the window's first k --, and perm_h = H reads the source's COLUMN axis through the gate interleaving, logical
+    //  index u * 4 + g <- TF column g * H + u)
     unsigned short* dst = static_cast<unsigned short*>(jb.dst);
     const int KC = jb.dst_cols / 32;
+    const int KCT = jb.ldd > 0 ? (int)(jb.ldd / 32) : KC, kc0 = jb.reserved / 32;
     const int64_t total = (int64_t)jb.dst_rows * jb.dst_cols;
     for (int64_t i = first; i < total; i += stride) {
       const int e = (int)(i & 7), lane = (int)(i >> 3) & 63;
       const int64_t frag = i >> 9;
-      const int n = (int)(frag / KC) * 16 + (lane & 15), k = (int)(frag % KC) * 32 + (lane >> 4) * 8 + e;
+      const int nt = (int)(frag / KC), kc = (int)(frag % KC);
+      const int n = nt * 16 + (lane & 15), k = kc * 32 + (lane >> 4) * 8 + e;
       // (transpose: the image of the source's transpose -- row n of the product's B operand is COLUMN n of src [cols, rows])
-      dst[i] = las_f2bf(n < jb.rows && k < jb.cols ? (jb.transpose ? jb.src[(int64_t)k * jb.lds + n] : jb.src[(int64_t)n * jb.lds + k]) : 0.f);
+      int sr = jb.transpose ? k : n, sc = jb.transpose ? n : k;
+      if (jb.perm_h > 0) sc = (sc & 3) * jb.perm_h + (sc >> 2);
+      dst[(((int64_t)nt * KCT + kc0 + kc) << 9) + (lane << 3) + e] = las_f2bf(n < jb.rows && k < jb.cols ? jb.src[(int64_t)sr * jb.lds + sc] : 0.f);
     }
   } else if (jb.kind == LAS_IMAGE_PACK_INPUT) {
     unsigned short* dst = static_cast<unsigned short*>(jb.dst);

@@ -1270,6 +1270,219 @@ static int gemm_tn(const las_bf16* A, int64_t lda, const las_bf16* B, int64_t ld
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// NT product whose B operand is a WEIGHT matrix handed in as its LAS_IMAGE_PACK_MFMA_B image (round 6).  The ring
+// kernels above stage both operands through the LDS and sit where its port is as busy as the matrix cores (12 fragment reads for
+// 16 MFMAs of 32x32x16 per wave and stage).  Here only the ACTIVATION operand goes through the LDS ring (LDS-DMA, 16 KB per
+// 32-deep stage); a wave fetches its B fragments -- four contiguous KB per stage, the same for the waves above and below it -- from
+// the image straight into registers, two stages ahead.  256 x 256 tiles, 8 waves as 2 x 4, a wave owns 128 x 64 as 8 x 4 tiles
+// of v_mfma_f32_16x16x32_bf16: 8 LDS fragment reads + 4 global fragment loads for 32 MFMAs per stage.
+// Every load of the K loop is inline assembly (LDS-DMA and the fragment loads share the wave's in-order vmcnt queue and the
+// compiler knows of neither): every stage issues [B(kt + 3) x 4, A(kt + 3) x 2] and waits vmcnt(12) = everything up to A(kt).
+// K a multiple of 128, N of 256.
+// ------------------------------------------------------------------------------------------------
+namespace {
+// TI: 16-row tiles per wave; the workgroup's tile is 32 TI rows x 256 columns.  The host picks the height that fills the last round
+// of workgroups best (800 tiles of 256 rows on 256 CUs are four rounds, the last one an eighth full: 0.91 PFLOP/s for a kernel that
+// runs 1.17 while every CU has a tile; 1280 tiles of 160 rows are five full rounds of five eighths of the work each).
+template <int STAGES, int TI>
+__global__ __launch_bounds__(512) void gemm_nt_bimg_kernel(GemmArgs g) {
+  static_assert(STAGES == 4, "the LDS slot of a stage is its fragment slot");
+  static_assert(TI >= 6 && TI <= 8, "a wave's rows: 96 .. 128");
+  constexpr int BM = 32 * TI, BN = 256, BK = 32, ROWB = BK * 2, STAGE_BYTES = BM * ROWB;
+  extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+  typedef __attribute__((address_space(3))) unsigned char lds_u8;
+  lds_u8* lds = (lds_u8*)smem;
+  const unsigned lds_base = (unsigned)__builtin_amdgcn_readfirstlane((int)(size_t)lds);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+  int bx = blockIdx.x, by = blockIdx.y;
+  {
+    const int gx = gridDim.x, gy = gridDim.y;
+    const int id = bx + gx * by;
+    const int full = (gy / 8) * 8 * gx;
+    if (id < full) {
+      by = (id / (8 * gx)) * 8 + (id & 7);
+      bx = (id >> 3) % gx;
+    }
+  }
+  const int m0 = by * BM, n0 = bx * BN;
+  const int nk = g.K / BK, KC = nk;
+  // LDS slot s of row r holds source chunk s ^ f(r), f(r) = (-(r >> 2)) & 3: the sixteen 16-byte pieces one ds_read_b128 lane group
+  // touches for a 16x16x32 A fragment (rows {0-3, 12-15} of one k piece with rows {4-11} of the next) then fall on distinct banks
+  auto fswz = [](int r) { return (-(r >> 2)) & 3; };
+  // A: this lane's two source rows per stage (1-KB LDS-DMA loads: 16 rows x 4 chunks; 2 TI pieces; wave w loads pieces w and w + 8,
+  // past the last piece the last piece once more -- every wave has the same two loads per stage in its queue)
+  const unsigned short* asrc[2];
+  int apiece[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    apiece[i] = min(wave + 8 * i, 2 * TI - 1);
+    const int row = 16 * apiece[i] + (lane >> 2);
+    asrc[i] = g.A + (int64_t)min(m0 + row, g.M - 1) * g.lda + 8 * ((lane & 3) ^ fswz(row));
+  }
+  // B: fragment (column tile nt, k chunk kc) of the image = 512 elements at (nt * KC + kc) * 512; this lane's 8 at + lane * 8
+  const unsigned short* bsrc = g.B + ((int64_t)((n0 + wn * 64) / 16) * KC) * 512 + lane * 8;
+  typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));       // (a native vector: inline assembly ties it to registers)
+  u32x4 bq[4][4];
+  auto issue_b = [&](int slot, int kc) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(bq[slot][j]) : "v"(bsrc + ((int64_t)j * KC + kc) * 512) : "memory");
+  };
+  auto issue_a = [&](int stage, bool advance) {
+    const unsigned base = lds_base + stage * STAGE_BYTES;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      glds16(advance ? asrc[i] : asrc[i] - BK, base + apiece[i] * 1024);      // (past the end: the last stage again)
+      if (advance) asrc[i] += BK;
+    }
+  };
+  f32x4 acc[TI][4];
+#pragma unroll
+  for (int i = 0; i < TI; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int l15 = lane & 15, lq = lane >> 4;
+  const int a_off = (wm * 16 * TI + l15) * ROWB + ((lq ^ fswz(l15)) << 4);       // (+ i * 16 rows: f is the same for rows 16 apart)
+
+  // The K loop has NO branch but its back edge: every stage issues the loads of the stage three on -- past the end the LAST stage
+  // again, into a slot nobody reads any more -- so the queue always holds the same 12 loads behind the stage being waited for
+  // and no register of an in-flight fragment ever meets a control-flow merge (a first version guarded the issues: the compiler
+  // rotated the fragment slots through v_mov copies at the merges, of registers whose loads had not landed -- wrong sums).
+  // nk a multiple of 4 and >= 4 (the slots are compile-time registers: the loop is written out four stages at a time).
+#pragma unroll
+  for (int p = 0; p < 3; ++p) { issue_b(p, p); issue_a(p, true); }
+  auto stage_body = [&](int kt, auto slot_tag) {
+    constexpr int SLOT = decltype(slot_tag)::value;
+    // everything up to A(kt) has landed: behind it in the queue are the 6 loads each of stages kt + 1 and kt + 2
+    asm volatile("s_waitcnt vmcnt(12)" : "+v"(bq[SLOT][0]), "+v"(bq[SLOT][1]), "+v"(bq[SLOT][2]), "+v"(bq[SLOT][3]) : : "memory");
+    __builtin_amdgcn_s_barrier();                  // everybody's pieces of A(kt) have landed; everybody has left stage kt - 1
+    asm volatile("" ::: "memory");
+    const bool more = kt + 3 < nk;
+    issue_b((SLOT + 3) % 4, more ? kt + 3 : nk - 1);
+    issue_a((SLOT + 3) % 4, more);                 // (STAGES = 4: the LDS slot of a stage is its fragment slot)
+    const lds_u8* st = lds + SLOT * STAGE_BYTES;
+    bf16x8 af[TI];
+#pragma unroll
+    for (int i = 0; i < TI; ++i) af[i] = *(const __attribute__((address_space(3))) bf16x8*)(st + a_off + i * 16 * ROWB);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const bf16x8 bf = __builtin_bit_cast(bf16x8, bq[SLOT][j]);
+#pragma unroll
+      for (int i = 0; i < TI; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bf, acc[i][j], 0, 0, 0);
+    }
+  };
+  for (int kt = 0; kt < nk; kt += 4) {
+    stage_body(kt, std::integral_constant<int, 0>{});
+    stage_body(kt + 1, std::integral_constant<int, 1>{});
+    stage_body(kt + 2, std::integral_constant<int, 2>{});
+    stage_body(kt + 3, std::integral_constant<int, 3>{});
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // (the repeated loads of the last stage)
+
+  // epilogue: a wave parks 16 rows x 64 columns of its block at a time in LDS and writes them back 16 bytes per lane
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  constexpr int LDC = 64 + 4;
+  float* cs = reinterpret_cast<float*>(smem) + wave * 16 * LDC;
+  float* Cf = reinterpret_cast<float*>(g.C);
+  const int cl = (lane & 15) * 4, rl = lane >> 4;
+  const int col = n0 + wn * 64 + cl;
+  float bv[4] = {0.f, 0.f, 0.f, 0.f};
+  if (g.bias != nullptr)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) bv[e] = g.bias[col + e];
+#pragma unroll
+  for (int i = 0; i < TI; ++i) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) cs[(lq * 4 + r) * LDC + j * 16 + l15] = acc[i][j][r];
+    __builtin_amdgcn_s_waitcnt(0xC07F);        // lgkmcnt(0): a wave reads back only what it wrote itself
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const int row = m0 + wm * 16 * TI + i * 16 + p * 4 + rl;
+      if (row >= g.M) continue;
+      const float4 v4 = *reinterpret_cast<const float4*>(cs + (p * 4 + rl) * LDC + cl);
+      float4 o = make_float4(v4.x + bv[0], v4.y + bv[1], v4.z + bv[2], v4.w + bv[3]);
+      float* dst = Cf + (int64_t)row * g.ldc + col;
+      if (g.accumulate) {
+        const float4 c = *reinterpret_cast<const float4*>(dst);
+        o.x += c.x; o.y += c.y; o.z += c.z; o.w += c.w;
+      }
+      *reinterpret_cast<float4*>(dst) = o;
+    }
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+  }
+}
+
+// the LAS_IMAGE_PACK_MFMA_B image of a bf16 matrix [N, K] (row stride ldb): the micro-benchmark's way to the image (the model's
+// weights are packed from their fp32 masters by las_refresh_images)
+__global__ __launch_bounds__(256) void pack_b_bf16_kernel(const unsigned short* B, int64_t ldb, int N, int K, unsigned short* img) {
+  const int KC = K / 32;
+  const int64_t total = (int64_t)N * K;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int e = (int)(i & 7), lane = (int)(i >> 3) & 63;
+    const int64_t frag = i >> 9;
+    const int n = (int)(frag / KC) * 16 + (lane & 15), k = (int)(frag % KC) * 32 + (lane >> 4) * 8 + e;
+    img[i] = B[(int64_t)n * ldb + k];
+  }
+}
+}  // namespace
+
+extern "C" int las_pack_mfma_b_bf16(const las_bf16* B, int64_t ldb, int N, int K, las_bf16* image, void* stream) {
+  LAS_REQUIRE(B && image && N > 0 && K > 0 && N % 16 == 0 && K % 32 == 0, "las_pack_mfma_b_bf16: N a multiple of 16, K of 32");
+  hipLaunchKernelGGL(pack_b_bf16_kernel, dim3(1024), dim3(256), 0, (hipStream_t)stream, B, ldb, N, K, image);
+  LAS_LAUNCH_CHECK("pack image launch");
+  return LAS_OK;
+}
+
+extern "C" int las_gemm_nt_bimg(const las_bf16* A, int64_t lda, const las_bf16* b_image, float* C, int64_t ldc, const float* bias, int M,
+                                int N, int K, int accumulate, void* stream) {
+  LAS_REQUIRE(A && b_image && C && M > 0, "las_gemm_nt_bimg: null argument or empty problem");
+  LAS_REQUIRE(N > 0 && N % 256 == 0 && K >= 128 && K % 128 == 0 && lda % 8 == 0 && ldc % 4 == 0 && ((uintptr_t)A % 16 == 0) && ((uintptr_t)b_image % 16 == 0),
+              "las_gemm_nt_bimg: N a multiple of 256, K of 128 (N = %d, K = %d), lda of 8, ldc of 4, operands 16-byte aligned", N, K);
+  GemmArgs g{A, b_image, C, bias, lda, 0, ldc, 0, 0, 0, M, N, K, 0, accumulate, 0, 1, 0, 0, 0};
+  // tile height 32 TI, TI = 6 .. 8: the one whose rounds of workgroups (one per CU) cost least -- rounds x height x what a lower
+  // tile loses per flop (the weight fragments are amortised over fewer rows; measured: 160-row tiles give back all that five
+  // full rounds instead of four save, 224-row tiles run dZ K_x^T of metric-M's layer 2 at 1.0 PFLOP/s against 0.89)
+  static int cus = 0;
+  if (cus == 0) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
+  }
+  int ti = las_knob("LAS_BIMG_TI", 0);
+  if (ti < 6 || ti > 8) {
+    long best = -1;
+    for (int t = 8; t >= 6; --t) {
+      const long tiles = (long)((M + 32 * t - 1) / (32 * t)) * (N / 256);
+      const long cost = ((tiles + cus - 1) / cus) * t * (t == 8 ? 100 : t == 7 ? 105 : 112);
+      if (best < 0 || cost < best) { best = cost; ti = t; }
+    }
+  }
+  const dim3 grid(N / 256, (M + 32 * ti - 1) / (32 * ti), 1);
+  auto go = [&](auto ti_tag) {
+    constexpr int TI = decltype(ti_tag)::value;
+    const size_t lds = (size_t)4 * 32 * TI * 64;      // (the ring; the epilogue's staging, 34 KB, fits inside)
+    static bool attr_set = false;
+    if (!attr_set) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_bimg_kernel<4, TI>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      attr_set = true;
+    }
+    hipLaunchKernelGGL((gemm_nt_bimg_kernel<4, TI>), grid, dim3(512), lds, (hipStream_t)stream, g);
+  };
+  switch (ti) {
+    case 6: go(std::integral_constant<int, 6>{}); break;
+    case 7: go(std::integral_constant<int, 7>{}); break;
+    default: go(std::integral_constant<int, 8>{}); break;
+  }
+  LAS_LAUNCH_CHECK("image gemm launch");
+  return LAS_OK;
+}
+
 extern "C" int las_gemm_nt(const las_bf16* A, int64_t lda, const las_bf16* B, int64_t ldb, void* C, int64_t ldc,
                            const float* bias, int M, int N, int K, int out_bf16, int accumulate, int batch,
                            int64_t sa, int64_t sb, int64_t sc, int split_k, void* stream) {

@@ -45,6 +45,8 @@ _SIGS = {
     'las_lstm_recurrent_fwd_ex': ([_vp, _vp], C.c_int),
     'las_gemm_nt_stream_supported': ([_i32, _i32, _i32], C.c_int),
     'las_gemm_nt_stream_flags': ([_i32, _i32, _i32, _i32], C.c_size_t),
+    'las_pack_mfma_b_bf16': ([_vp, _i64, _i32, _i32, _vp, _vp], C.c_int),
+    'las_gemm_nt_bimg': ([_vp, _i64, _vp, _vp, _i64, _vp, _i32, _i32, _i32, _i32, _vp], C.c_int),
     'las_gemm_nt_stream_dirs': ([_vp, _i64, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp], C.c_int),
     'las_lstm_workspace_bytes': ([_i32, _i32, _i32], C.c_size_t),
     'las_lstm_slice_rows': ([_i32, _i32, _i32], C.c_int),
@@ -530,14 +532,38 @@ def pack_input(kernel, D, H, chunks, packed):
     check(lib().las_lstm_pack_input(p(kernel), D, H, chunks, p(packed), stream()))
 
 
-def pack_mfma_b(src, rows, cols, dst, lds=None, transpose=False):
+def pack_mfma_b(src, rows, cols, dst, lds=None, transpose=False, perm_h=0, image_k=0, k0=0, dst_rows=None, dst_cols=None):
     """dst = the LAS_IMAGE_PACK_MFMA_B image of fp32 src[rows, cols] (joins an open image_batch): dst holds
-    ceil(rows / 16) * 16 x ceil(cols / 32) * 32 bf16 elements in B-fragment order."""
-    dr, dc = -(-rows // 16) * 16, -(-cols // 32) * 32
-    if dst.numel() != dr * dc:
-        raise LasError('pack_mfma_b: destination of %d elements, expected %d' % (dst.numel(), dr * dc))
-    _image_job(IMAGE_PACK_MFMA_B, src, dst, lds=lds if lds is not None else src.stride(-2), rows=rows, cols=cols, dst_rows=dr, dst_cols=dc,
-               transpose=int(transpose))
+    ceil(rows / 16) * 16 x ceil(cols / 32) * 32 bf16 elements in B-fragment order.  perm_h = H: the source's column axis through the
+    gate interleaving; image_k / k0: the window is the K range [k0, k0 + dst_cols) of an image whose whole K is image_k (dst = the
+    whole image then)."""
+    dr = dst_rows if dst_rows is not None else -(-rows // 16) * 16
+    dc = dst_cols if dst_cols is not None else -(-cols // 32) * 32
+    if dst.numel() != dr * (image_k or dc):
+        raise LasError('pack_mfma_b: destination of %d elements, expected %d' % (dst.numel(), dr * (image_k or dc)))
+    job = ImageJob(src.data_ptr(), dst.data_ptr(), lds if lds is not None else src.stride(-2), image_k, rows, cols, dr, dc, int(transpose),
+                   perm_h, IMAGE_PACK_MFMA_B, k0)
+    if _image_batch is not None:
+        _image_batch.jobs.append(job)
+    else:
+        _run_image_jobs([job])
+
+
+def gemm_nt_bimg(A, image, C_, M, N, K, lda=None, ldc=None, bias=None, accumulate=False):
+    """C_ [M, N] fp32 (=|+=) A [M, K] W^T + bias, W as its LAS_IMAGE_PACK_MFMA_B image (las_gemm_nt_bimg)."""
+    lda = lda if lda is not None else A.stride(-2)
+    ldc = ldc if ldc is not None else C_.stride(-2)
+    tok = prof_begin('gemm_nt', 2.0 * M * N * K)
+    check(lib().las_gemm_nt_bimg(p(A), lda, p(image), p(C_), ldc, p(bias), M, N, K, int(accumulate), stream()))
+    prof_end(tok)
+
+
+def gemm_nt_bimg_wanted(M, N, K):
+    """Shapes on which the image form measured faster than the ring kernels (profiles/r06_gemm_vs_lib.txt): deep or wide products."""
+    return BIMG and M >= 1024 and N % 256 == 0 and K % 128 == 0 and (K >= 2048 or N >= 4096)
+
+
+BIMG = os.environ.get('LAS_GEMM_BIMG', '1') != '0'       # (0: the ring kernels everywhere -- A/B timing)
 
 
 def bias_interleave(bias, H, dst):

@@ -299,6 +299,13 @@ class LayerWeights:
         self.kx_chunks = hip.lib().las_lstm_fused_input_chunks(H, Dp) if (FUSED_X and D > 0) else 0
         self.kxp = (torch.empty(nd, (H // 16) * self.kx_chunks * 4 * 512, dtype=torch.bfloat16, device=dev)
                     if self.kx_chunks else None)
+        # las_gemm_nt_bimg (round 6): K_x as LAS_IMAGE_PACK_MFMA_B images -- [nd * 4H, Dp] for x K_x, [D, nd * 4H] for dZ K_x^T --
+        # where the shapes are ones that kernel takes and wins on (a wave fetches the weight fragments straight into registers)
+        N4 = nd * 4 * H
+        self.kxT_img = (torch.empty(N4 * Dp, dtype=torch.bfloat16, device=dev)
+                        if (not self.kx_chunks and D == Dp and hip.gemm_nt_bimg_wanted(1 << 20, N4, Dp)) else None)
+        self.kx_img = (torch.empty(D * N4, dtype=torch.bfloat16, device=dev)
+                       if (D > 0 and D == Dp and hip.gemm_nt_bimg_wanted(1 << 20, D, N4)) else None)
         self.refresh(variables)
 
     def refresh(self, variables):
@@ -314,6 +321,11 @@ class LayerWeights:
             hip.pack_recurrent(k[D:], H, self.khp[i])
             if self.kx_chunks:
                 hip.pack_input(k, D, H, self.kx_chunks, self.kxp[i])
+            if self.kxT_img is not None:        # rows [i * 4H, (i + 1) * 4H) of the image: row n = gate-interleaved column of K_x, k = input feature
+                hip.pack_mfma_b(k, 4 * H, D, self.kxT_img[i * 4 * H * Dp:(i + 1) * 4 * H * Dp], lds=4 * H, transpose=True, perm_h=H,
+                                dst_rows=4 * H, dst_cols=Dp)
+            if self.kx_img is not None:         # K range [i * 4H, (i + 1) * 4H) of the image: row n = input feature, k = gate-interleaved column
+                hip.pack_mfma_b(k, D, 4 * H, self.kx_img, lds=4 * H, perm_h=H, image_k=nd * 4 * H, k0=i * 4 * H, dst_rows=D, dst_cols=4 * H)
             hip.bias_interleave(b, H, self.bias[i * 4 * H:(i + 1) * 4 * H])
 
 
@@ -431,8 +443,11 @@ def bilstm(inputs, sequence_length, num_units, dropout, mode, unidirectional=Fal
     else:
         stream_ready = _stream_setup(inputs, Dp, 0, weights, xproj, sequence_length, B, T, H, Dp, nd, dev)
         if stream_ready is None:
-            hip.gemm_nt(inputs, weights.kxT, xproj, B * T, nd * 4 * H, Dp, lda=Dp, ldb=Dp, ldc=nd * 4 * H,
-                        bias=weights.bias)
+            if weights.kxT_img is not None and hip.gemm_nt_bimg_wanted(B * T, nd * 4 * H, Dp):
+                hip.gemm_nt_bimg(inputs, weights.kxT_img, xproj, B * T, nd * 4 * H, Dp, lda=Dp, ldc=nd * 4 * H, bias=weights.bias)
+            else:
+                hip.gemm_nt(inputs, weights.kxT, xproj, B * T, nd * 4 * H, Dp, lda=Dp, ldb=Dp, ldc=nd * 4 * H,
+                            bias=weights.bias)
     if after_projection is not None:
         after_projection()          # (LasModel: side-stream work that should run beside this layer's recurrence starts here)
     y = torch.empty(B, T, nd * H, dtype=torch.bfloat16, device=dev)
@@ -564,7 +579,10 @@ def bilstm_backward(rec, dy, d_state, grads, need_dx=True, overlap=None, defer_w
     if need_dx:
         if dropped is None:
             dx = torch.empty(B, T, D, dtype=torch.float32, device=dev)
-            hip.gemm_nt(dz, w.kx, dx, BT, D, nd * 4 * H, lda=nd * 4 * H, ldb=nd * 4 * H, ldc=D)
+            if w.kx_img is not None and hip.gemm_nt_bimg_wanted(BT, D, nd * 4 * H):
+                hip.gemm_nt_bimg(dz, w.kx_img, dx, BT, D, nd * 4 * H, lda=nd * 4 * H, ldc=D)
+            else:
+                hip.gemm_nt(dz, w.kx, dx, BT, D, nd * 4 * H, lda=nd * 4 * H, ldb=nd * 4 * H, ldc=D)
         else:
             # per direction dX_i = dZ_i K_x,i^T, then through that direction's input dropout (masks regenerated from
             # the counter-based generator); summed when both directions read the same input, side by side otherwise

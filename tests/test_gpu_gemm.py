@@ -243,3 +243,61 @@ def test_gemm_nt_ring_asymmetric_identity_strides_and_batch():
     Cb = torch.empty(nb, M, N, device='cuda')
     hip.gemm_nt(Ab.cuda(), Bb.cuda(), Cb, M, N, K, lda=K, ldb=K, ldc=N, batch=nb, sa=M * K, sb=N * K, sc=M * N)
     _close(Cb, torch.einsum('bmk,bnk->bmn', Ab.double(), Bb.double()))
+
+
+@pytest.mark.parametrize('M,N,K', [(1024, 256, 128), (1300, 512, 384), (2049, 256, 2048), (4096, 1024, 512), (5000, 256, 4096)])
+def test_gemm_nt_with_the_weight_operand_from_its_image(M, N, K):
+    """las_gemm_nt_bimg (round 6): the weight operand as its LAS_IMAGE_PACK_MFMA_B image, fetched into registers fragment by fragment
+    (every load of the K loop is hand-counted inline assembly -- several repetitions: a fragment consumed before it has landed shows
+    up as a wrong sum now and then).  One to 32 rounds of the four-stage loop, ragged M, bias, accumulate; image from a bf16 matrix
+    (las_pack_mfma_b_bf16) and from fp32 through the image job (the [N, K] window, and the two K halves of one image)."""
+    from phones_las_amd import hip
+    lib = hip.lib()
+    A, W = _mk((M, K), 3), _mk((N, K), 4) * 0.25
+    bias = torch.randn(N)
+    ref = A.double() @ W.double().t() + bias.double()
+    Ad, Wd = A.cuda(), W.cuda()
+    img = torch.empty(N * K, dtype=torch.bfloat16, device='cuda')
+    hip.check(lib.las_pack_mfma_b_bf16(hip.p(Wd), K, N, K, hip.p(img), hip.stream()))
+    img2 = torch.empty_like(img)
+    hip.pack_mfma_b(Wd.float(), N, K, img2, lds=K)
+    assert torch.equal(img, img2)
+    img3 = torch.zeros_like(img)                        # two windows of one image: the K halves
+    with hip.image_batch():
+        hip.pack_mfma_b(Wd.float(), N, K // 2, img3, lds=K, image_k=K, k0=0, dst_rows=N, dst_cols=K // 2)
+        hip.pack_mfma_b(Wd.float()[:, K // 2:], N, K // 2, img3, lds=K, image_k=K, k0=K // 2, dst_rows=N, dst_cols=K // 2)
+    assert torch.equal(img, img3)
+    for rep in range(6):
+        C = torch.full((M, N), float('nan'), device='cuda')
+        hip.gemm_nt_bimg(Ad, img, C, M, N, K, bias=bias.cuda())
+        _close(C, ref)
+    C2 = torch.ones(M, N, device='cuda')
+    hip.gemm_nt_bimg(Ad, img, C2, M, N, K, accumulate=True)
+    _close(C2, ref - bias.double() + 1.0)
+    with pytest.raises(hip.LasError):
+        hip.gemm_nt_bimg(Ad, img, C, M, N - 16, K)
+
+
+def test_weight_image_with_the_gate_interleaving():
+    """The image job's perm_h (the K_x images of las/ops.py LayerWeights): source column g * H + u read at logical index u * 4 + g, on
+    the image's row axis (transpose: x K_x) and on its K axis (a K window per direction: dZ K_x^T) -- against the images of the
+    bf16 operand copies the ring kernels read (LAS_IMAGE_CAST with the same permutation)."""
+    from phones_las_amd import hip
+    lib = hip.lib()
+    D, H, nd = 256, 64, 2
+    g = torch.Generator().manual_seed(5)
+    kernels = [torch.randn(D + H, 4 * H, generator=g).cuda() for _ in range(nd)]
+    kxT = torch.empty(nd * 4 * H, D, dtype=torch.bfloat16, device='cuda')
+    kx = torch.empty(D, nd * 4 * H, dtype=torch.bfloat16, device='cuda')
+    kxT_img = torch.empty(nd * 4 * H * D, dtype=torch.bfloat16, device='cuda')
+    kx_img = torch.empty(D * nd * 4 * H, dtype=torch.bfloat16, device='cuda')
+    with hip.image_batch():
+        for i, k in enumerate(kernels):
+            hip.cast_bf16(k, D, 4 * H, kxT[i * 4 * H:], 4 * H, D, ldd=D, transpose=True, lds=4 * H, perm_h=H)
+            hip.cast_bf16(k, D, 4 * H, kx[:, i * 4 * H:], D, 4 * H, ldd=nd * 4 * H, lds=4 * H, perm_h=H)
+            hip.pack_mfma_b(k, 4 * H, D, kxT_img[i * 4 * H * D:(i + 1) * 4 * H * D], lds=4 * H, transpose=True, perm_h=H, dst_rows=4 * H, dst_cols=D)
+            hip.pack_mfma_b(k, D, 4 * H, kx_img, lds=4 * H, perm_h=H, image_k=nd * 4 * H, k0=i * 4 * H, dst_rows=D, dst_cols=4 * H)
+    for mat, img in ((kxT, kxT_img), (kx, kx_img)):
+        ref = torch.empty_like(img)
+        hip.check(lib.las_pack_mfma_b_bf16(hip.p(mat), mat.shape[1], mat.shape[0], mat.shape[1], hip.p(ref), hip.stream()))
+        assert torch.equal(img, ref)
