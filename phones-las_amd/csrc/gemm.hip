@@ -1278,7 +1278,7 @@ static int gemm_tn(const las_bf16* A, int64_t lda, const las_bf16* B, int64_t ld
 // the image straight into registers, two stages ahead.  256 x 256 tiles, 8 waves as 2 x 4, a wave owns 128 x 64 as 8 x 4 tiles
 // of v_mfma_f32_16x16x32_bf16: 8 LDS fragment reads + 4 global fragment loads for 32 MFMAs per stage.
 // Every load of the K loop is inline assembly (LDS-DMA and the fragment loads share the wave's in-order vmcnt queue and the
-// compiler knows of neither): every stage issues [B(kt + 3) x 4, A(kt + 3) x 2] and waits vmcnt(12) = everything up to A(kt).
+// compiler knows of neither): every stage issues [B(kt + 3) x 4, A(kt + 3) x 2] and waits vmcnt(12) = everything up to A(kt + 1).
 // K a multiple of 128, N of 256.
 // ------------------------------------------------------------------------------------------------
 namespace {
@@ -1354,31 +1354,51 @@ __global__ __launch_bounds__(512) void gemm_nt_bimg_kernel(GemmArgs g) {
   // nk a multiple of 4 and >= 4 (the slots are compile-time registers: the loop is written out four stages at a time).
 #pragma unroll
   for (int p = 0; p < 3; ++p) { issue_b(p, p); issue_a(p, true); }
-  auto stage_body = [&](int kt, auto slot_tag) {
-    constexpr int SLOT = decltype(slot_tag)::value;
-    // everything up to A(kt) has landed: behind it in the queue are the 6 loads each of stages kt + 1 and kt + 2
-    asm volatile("s_waitcnt vmcnt(12)" : "+v"(bq[SLOT][0]), "+v"(bq[SLOT][1]), "+v"(bq[SLOT][2]), "+v"(bq[SLOT][3]) : : "memory");
-    __builtin_amdgcn_s_barrier();                  // everybody's pieces of A(kt) have landed; everybody has left stage kt - 1
+  {
+    // PING-PONG form (as gemm_nt_ring_kernel's): a stage is a LOAD segment -- the stage's A fragments out of the LDS, the loads of
+    // the stage three on issued, the wait for the NEXT stage's pieces (its weight fragments are then in their registers, its A
+    // pieces in the LDS) -- and a MATH segment of 4 TI MFMAs, a barrier behind each; waves 4..7 run one barrier behind waves 0..3,
+    // so that of the two waves of a SIMD one is in MATH while the other is in LOAD.
+    const int grp = wave >> 2;
+    asm volatile("s_waitcnt vmcnt(12)" : "+v"(bq[0][0]), "+v"(bq[0][1]), "+v"(bq[0][2]), "+v"(bq[0][3]) : : "memory");      // stage 0
+    __builtin_amdgcn_s_barrier();
+    if (grp == 1) __builtin_amdgcn_s_barrier();            // the stagger
     asm volatile("" ::: "memory");
-    const bool more = kt + 3 < nk;
-    issue_b((SLOT + 3) % 4, more ? kt + 3 : nk - 1);
-    issue_a((SLOT + 3) % 4, more);                 // (STAGES = 4: the LDS slot of a stage is its fragment slot)
-    const lds_u8* st = lds + SLOT * STAGE_BYTES;
-    bf16x8 af[TI];
+    auto pp_body = [&](int kt, auto slot_tag) {
+      constexpr int SLOT = decltype(slot_tag)::value, NEXT = (SLOT + 1) % 4;
+      // ---- LOAD(kt) ----
+      const lds_u8* st = lds + SLOT * STAGE_BYTES;
+      bf16x8 af[TI];
 #pragma unroll
-    for (int i = 0; i < TI; ++i) af[i] = *(const __attribute__((address_space(3))) bf16x8*)(st + a_off + i * 16 * ROWB);
+      for (int i = 0; i < TI; ++i) af[i] = *(const __attribute__((address_space(3))) bf16x8*)(st + a_off + i * 16 * ROWB);
+      const bool more = kt + 3 < nk;
+      issue_b((SLOT + 3) % 4, more ? kt + 3 : nk - 1);
+      issue_a((SLOT + 3) % 4, more);                       // (its slot was last read in LOAD(kt - 1), a barrier ago for either group)
+      asm volatile("s_waitcnt vmcnt(12)" : "+v"(bq[NEXT][0]), "+v"(bq[NEXT][1]), "+v"(bq[NEXT][2]), "+v"(bq[NEXT][3]) : : "memory");   // own pieces of stage kt + 1
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // own fragments are in registers
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      // ---- MATH(kt) ----
+      __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const bf16x8 bf = __builtin_bit_cast(bf16x8, bq[SLOT][j]);
+      for (int j = 0; j < 4; ++j) {
+        const bf16x8 bf = __builtin_bit_cast(bf16x8, bq[SLOT][j]);
 #pragma unroll
-      for (int i = 0; i < TI; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bf, acc[i][j], 0, 0, 0);
+        for (int i = 0; i < TI; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bf, acc[i][j], 0, 0, 0);
+      }
+      __builtin_amdgcn_s_setprio(0);
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+    };
+    for (int kt = 0; kt < nk; kt += 4) {
+      pp_body(kt, std::integral_constant<int, 0>{});
+      pp_body(kt + 1, std::integral_constant<int, 1>{});
+      pp_body(kt + 2, std::integral_constant<int, 2>{});
+      pp_body(kt + 3, std::integral_constant<int, 3>{});
     }
-  };
-  for (int kt = 0; kt < nk; kt += 4) {
-    stage_body(kt, std::integral_constant<int, 0>{});
-    stage_body(kt + 1, std::integral_constant<int, 1>{});
-    stage_body(kt + 2, std::integral_constant<int, 2>{});
-    stage_body(kt + 3, std::integral_constant<int, 3>{});
+    if (grp == 0) __builtin_amdgcn_s_barrier();            // the barrier the other half is one ahead by
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // (the repeated loads of the last stage)
 
@@ -1412,7 +1432,10 @@ __global__ __launch_bounds__(512) void gemm_nt_bimg_kernel(GemmArgs g) {
         const float4 c = *reinterpret_cast<const float4*>(dst);
         o.x += c.x; o.y += c.y; o.z += c.z; o.w += c.w;
       }
-      *reinterpret_cast<float4*>(dst) = o;
+      // non-temporal: 0.2-0.8 GB of fp32 that nobody on this XCD reads again (the next reader is a recurrence, rows at a time, through
+      // its own L2); x K_x of metric-L's layer 1 500 -> 477 us, metric-L 16.21 -> 16.12 ms
+      typedef float f4 __attribute__((ext_vector_type(4)));
+      __builtin_nontemporal_store(f4{o.x, o.y, o.z, o.w}, reinterpret_cast<f4*>(dst));
     }
     __builtin_amdgcn_s_waitcnt(0xC07F);
   }

@@ -559,8 +559,8 @@ def gemm_nt_bimg(A, image, C_, M, N, K, lda=None, ldc=None, bias=None, accumulat
 
 
 def gemm_nt_bimg_wanted(M, N, K):
-    """Shapes on which the image form measured faster than the ring kernels (profiles/r06_gemm_vs_lib.txt): deep or wide products."""
-    return BIMG and M >= 1024 and N % 256 == 0 and K % 128 == 0 and (K >= 2048 or N >= 4096)
+    """Shapes the image form takes; it measured faster than the ring kernels on every bulk shape of the steps (profiles/r06_gemm_vs_lib.txt)."""
+    return BIMG and M >= 1024 and N % 256 == 0 and K % 128 == 0 and K >= 512
 
 
 BIMG = os.environ.get('LAS_GEMM_BIMG', '1') != '0'       # (0: the ring kernels everywhere -- A/B timing)
