@@ -181,6 +181,7 @@ FUSED_X = os.environ.get('LAS_LSTM_FUSED_X', '1') != '0'
 STREAM_X = os.environ.get('LAS_LSTM_STREAM', '1') != '0'
 STREAM_512 = os.environ.get('LAS_LSTM_STREAM_512', '0') != '0'      # (diagnostics: stream at 512 units too)
 STREAM_MIN_ROWS = int(os.environ.get('LAS_LSTM_STREAM_MIN_ROWS', '4096'))      # smaller products are not worth the hand-over
+STREAM_ALWAYS = os.environ.get('LAS_LSTM_STREAM_ALWAYS', '0') != '0'           # (diagnostics / tests: stream whatever the recurrence's length)
 STREAM_ROWS8_MIN_K = int(os.environ.get('LAS_STREAM_ROWS8_MIN_K', str(1 << 30)))      # (diagnostics, see _stream_setup)
 STREAM_MAX_WORKGROUPS = 192       # the recurrence (members + companions, a CU each) must leave CUs to the product beside it
 _PRODUCT_STREAMS = {}
@@ -334,7 +335,11 @@ def _stream_setup(a, lda, a_dir_stride, weights, xproj, sequence_length, B, T, H
     direction, launch_product) or None.  a_dir_stride: 0 = both directions read `a`; else direction d reads a + d * stride."""
     lib = hip.lib()
     # the recurrence's slices must not straddle the product's 16-utterance blocks, and the chain must leave CUs to the product
-    streamed = (STREAM_X and (H == 256 or (H == 512 and STREAM_512)) and B * T >= STREAM_MIN_ROWS and lib.las_gemm_nt_stream_supported(nd * 4 * H, Dp, nd) == 1
+    # ... and the recurrence must be long enough for the product to finish beside it: the product gets the third of the chip the
+    # chains leave (~0.28 PFLOP/s); beside a recurrence shorter than ~1.6 x that it is the recurrence that waits (metric-M's layer 2,
+    # T = 400: 0.49 ms streamed against 0.33 + 0.14 one after the other since the image kernel; layer 1, T = 800: 0.79 against 0.84)
+    long_enough = STREAM_ALWAYS or T * 0.835e-6 > 1.6 * (2.0 * B * T * nd * 4 * H * Dp) / 0.28e15
+    streamed = (STREAM_X and long_enough and (H == 256 or (H == 512 and STREAM_512)) and B * T >= STREAM_MIN_ROWS and lib.las_gemm_nt_stream_supported(nd * 4 * H, Dp, nd) == 1
                 and 16 % max(lib.las_lstm_slice_rows(B, H, nd), 1) == 0
                 and 0 < lib.las_lstm_fwd_workgroups(B, H, nd) <= STREAM_MAX_WORKGROUPS)
     if not streamed:
@@ -435,8 +440,13 @@ def bilstm(inputs, sequence_length, num_units, dropout, mode, unidirectional=Fal
             else:
                 a, lda = src, Dfull
             if not fused and stream_ready is None:
-                hip.gemm_nt(a, weights.kxT[i * 4 * H:], xproj[..., i * 4 * H:], B * T, 4 * H, Dp, lda=lda, ldb=Dp,
-                            ldc=nd * 4 * H, bias=weights.bias[i * 4 * H:])
+                if weights.kxT_img is not None and hip.gemm_nt_bimg_wanted(B * T, 4 * H, Dp):
+                    # (direction i's rows of the image are one contiguous block: the image is row-tile major)
+                    hip.gemm_nt_bimg(a, weights.kxT_img[i * 4 * H * Dp:(i + 1) * 4 * H * Dp], xproj[..., i * 4 * H:], B * T, 4 * H, Dp,
+                                     lda=lda, ldc=nd * 4 * H, bias=weights.bias[i * 4 * H:])
+                else:
+                    hip.gemm_nt(a, weights.kxT[i * 4 * H:], xproj[..., i * 4 * H:], B * T, 4 * H, Dp, lda=lda, ldb=Dp,
+                                ldc=nd * 4 * H, bias=weights.bias[i * 4 * H:])
             dropped.append((a, lda))
         if fused:
             fused_x = (dropped[0][0], Dp, B * T * Dp if nd == 2 else 0)

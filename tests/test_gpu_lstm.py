@@ -234,6 +234,7 @@ def test_streamed_input_product_matches_the_product_before_the_recurrence(B, T, 
     gates, cell states and outputs must agree -- bit for bit where both products run on the same matrix-core instruction."""
     from phones_las_amd.las import ops
     monkeypatch.setattr(ops, 'STREAM_MIN_ROWS', 0)
+    monkeypatch.setattr(ops, 'STREAM_ALWAYS', True)
     lengths = [T - (i * 5) % T if ragged else T for i in range(B)]
     x, length, var = _setup(B, T, D, H, lengths)
     dvar = {k: v.float().cuda() for k, v in var.items()}
@@ -269,6 +270,7 @@ def test_streamed_input_product_whose_chain_starts_late(monkeypatch):
     from phones_las_amd import hip
     from phones_las_amd.las import ops
     monkeypatch.setattr(ops, 'STREAM_MIN_ROWS', 0)
+    monkeypatch.setattr(ops, 'STREAM_ALWAYS', True)
     monkeypatch.setattr(ops, 'STREAM_X', True)
     B, T, D, H = 64, 48, 512, 256
     x, length, var = _setup(B, T, D, H, [T] * B)
@@ -315,6 +317,7 @@ def test_streamed_input_product_with_one_operand_per_direction(mode, monkeypatch
     layer below (the stacked listener's split inputs).  Against the products before the recurrence, repeated (race check)."""
     from phones_las_amd.las import ops
     monkeypatch.setattr(ops, 'STREAM_MIN_ROWS', 0)
+    monkeypatch.setattr(ops, 'STREAM_ALWAYS', True)
     B, T, D, H = 19, 23, 128, 256
     lengths = [T - (i * 5) % T for i in range(B)]
     x, length, var = _setup(B, T, D, H, lengths)
