@@ -485,9 +485,12 @@ def _run_image_jobs(jobs):
     if table is None:
         if torch.cuda.is_current_stream_capturing():
             raise LasError('image_batch: new job table during graph capture (run the block once eagerly first)')
+        # (the tables are NEVER freed: a captured HIP graph replays its refresh launch with the table's address baked in.  Until round 6
+        #  the cache was emptied at 256 entries; in a process that had built that many different models -- the GPU test suite, once
+        #  the weight images of las_gemm_nt_bimg added tables -- a later table or tensor took a freed table's memory, and the next graph
+        #  replay walked garbage jobs: HSA_STATUS_ERROR_MEMORY_APERTURE_VIOLATION in tests/test_gpu_step_forms.py.  A table is 48 bytes
+        #  per image.)
         table = torch.frombuffer(bytearray(key), dtype=torch.uint8).cuda()
-        if len(_image_tables) > 256:
-            _image_tables.clear()
         _image_tables[key] = table
     check(lib().las_refresh_images(p(table), len(jobs), stream()))
 

@@ -106,8 +106,8 @@ def test_preprocess_all_cli_end_to_end(tmp_path):
     assert m.shape == (42,) and np.allclose(m, np.mean([x.mean(0) for x, _ in recs], 0), atol=1e-4)   # quirk B5
     # --backend speechpy through the same CLI (preprocess_all.py:88-91, 122-123, 228-230): 13 cepstra x 3, one frame fewer than fit
     n = preprocess_all.main(preprocess_all.parse_args(['--input_file', d + '/list.csv', '--output_file', d + '/sp.tfr', '--targets', 'phones',
-                                                       '--deltas', '--backend', 'speechpy', '--n_jobs', '4']))
-    assert n == 3
+                                                       '--deltas', '--backend', 'speechpy', '--n_jobs', '4', '--save_norm']))
+    assert n == 3                                                       # (the count of utterances in the norm statistics)
     recs = [tfrecord.parse_sequence_example(r, 39) for r in tfrecord.tf_record_iterator(d + '/sp.tfr', verify=True)]
     assert [x.shape for x, _ in recs] == [((8000 + 1600 * i - 320) // 160, 39) for i in range(3)]
     from oracle import frontend_oracle as FO

@@ -176,3 +176,26 @@ def test_stream_concurrency_probe_and_the_product_stream():
     torch.cuda.synchronize()
     assert int(words[1].item()) == 1
 
+
+
+def test_image_job_tables_outlive_any_number_of_other_tables():
+    """A captured HIP graph replays las_refresh_images with the ADDRESS of its job table baked in, so a table must never be freed.
+    Round 6: the cache used to be emptied at 256 tables; in a process that had built enough different models (the whole GPU
+    suite, once the image GEMM's weight images added tables) a later tensor took a freed table's memory and the next graph replay
+    walked garbage jobs (HSA_STATUS_ERROR_MEMORY_APERTURE_VIOLATION in tests/test_gpu_step_forms.py)."""
+    from phones_las_amd import hip
+    src = torch.randn(4, 8, device='cuda')
+    first = torch.empty(4, 8, dtype=torch.bfloat16, device='cuda')
+    with hip.image_batch():
+        hip.cast_bf16(src, 4, 8, first, 4, 8)
+    key0 = [k for k, t in hip._image_tables.items() if int.from_bytes(k[8:16], 'little') == first.data_ptr()]
+    assert len(key0) == 1
+    table0 = hip._image_tables[key0[0]]
+    ptr0 = table0.data_ptr()
+    outs = [torch.empty(4, 8, dtype=torch.bfloat16, device='cuda') for _ in range(400)]
+    for o in outs:                                   # 400 more tables (one per destination address)
+        with hip.image_batch():
+            hip.cast_bf16(src, 4, 8, o, 4, 8)
+    torch.cuda.synchronize()
+    assert hip._image_tables[key0[0]] is table0 and table0.data_ptr() == ptr0
+    assert bytes(table0.cpu().numpy().tobytes()) == key0[0]          # ... and still holds its jobs
