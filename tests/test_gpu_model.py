@@ -307,16 +307,20 @@ def test_weight_noise_hits_kernels_only():
             assert float(d.abs().max()) == 0.0, n
 
 
-def test_ctc_kernel_matches_torch_ctc_loss():
+@pytest.mark.parametrize('T,C,Cp,U', [(17, 9, 16, 6), (40, 150, 152, 12), (300, 30, 32, 140), (1, 9, 16, 6)])
+def test_ctc_kernel_matches_torch_ctc_loss(T, C, Cp, U):
+    """(round 6: the kernel's data movement was rewritten -- a row per wave with one or two classes per lane, or the loop form beyond
+    128 classes; one state per thread with the two recursions side by side, or the strided form beyond 256 states; state lists per
+    class, the long ones a frame per lane -- : the cases cover each form; profiles/r06_ctc_ab.txt has the bit-identity with round 5.)"""
     from phones_las_amd import hip
     import torch.nn.functional as F
     torch.manual_seed(0)
-    B, T, C, Cp, U = 5, 17, 9, 16, 6
+    B = 5
     logits = torch.randn(B, T, Cp) * 2
     labels = torch.randint(1, C, (B, U))
     labels[0, 2] = labels[0, 1]                       # a repeated label (needs the blank between)
-    ll = torch.tensor([6, 3, 1, 5, 2])
-    tl = torch.tensor([17, 9, 4, 16, 17])
+    tl = torch.tensor([T, max(1, T // 2), max(1, T // 4), max(1, T - 1), T])
+    ll = torch.tensor([min(max(1, u), U, max(1, (int(t) - 1) // 2)) for u, t in zip([U, 3, 1, U - 1, 2], tl)])   # (always feasible)
     lr = logits[..., :C].double().requires_grad_(True)
     ref = F.ctc_loss(torch.log_softmax(lr, -1).transpose(0, 1), labels, tl, ll, blank=0, reduction='none')
     ref.sum().backward()
